@@ -1,0 +1,559 @@
+/*
+ * thallo_oracle.c -- see thallo_oracle.h.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off: no FMA contraction, so the
+ * float arithmetic below is the plain IEEE sequence the reference's CPU mode runs).
+ */
+#include "thallo_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------ utilities */
+
+void orc_default_params(OrcSolverParams* sp)
+{   /* gauss_newton.t:41-55 */
+    sp->residual_reset_period   = 10;
+    sp->min_relative_decrease   = 1e-3f;
+    sp->min_trust_region_radius = 1e-32f;
+    sp->max_trust_region_radius = 1e16f;
+    sp->q_tolerance             = 0.0001f;
+    sp->function_tolerance      = 0.000001f;
+    sp->trust_region_radius     = 1e4f;
+    sp->radius_decrease_factor  = 2.0f;
+    sp->min_lm_diagonal         = 1e-6f;
+    sp->max_lm_diagonal         = 1e32f;
+    sp->nIterations             = 10;
+    sp->lIterations             = 10;
+    sp->use_lm                  = 0;
+    sp->float_sums              = 0;
+}
+
+void orc_msvc_rand_fill(float* out, long n, unsigned seed)
+{   /* tests/minimal/main.cpp:52-54 with the MSVC C runtime: RAND_MAX = 32767 */
+    unsigned s = seed;
+    for (long i = 0; i < n; ++i) {
+        s = s * 214013u + 2531011u;
+        int v = (int)((s >> 16) & 0x7fff);
+        out[i] = (float)((double)v / 32767.0);
+    }
+}
+
+/* summation helper: double accumulator, or float serial (cpu_cuda.t order) */
+typedef struct { double d; float f; int fl; } Acc;
+static inline void acc_init(Acc* a, int fl) { a->d = 0.0; a->f = 0.0f; a->fl = fl; }
+static inline void acc_add(Acc* a, float v) { if (a->fl) a->f = a->f + v; else a->d += (double)v; }
+static inline double acc_get(const Acc* a) { return a->fl ? (double)a->f : a->d; }
+
+static inline const float* img(const OrcEnergy* e, int param) { return (const float*)e->params[param]; }
+
+/* ------------------------------------------------------------------ energies */
+
+/* E5: tests/minimal/laplacian.t:1-14.  params: 0 X (unknown), 1 A.  dims W,H.
+ *   fit = w_fit*(X(x,y)-A(x,y))
+ *   reg = { Select(G, X(x,y)-X(x+1,y), 0), Select(InBounds(x,y+1), X(x,y)-X(x,y+1), 0) }
+ * G = InBounds(x+1,y+1) as shipped (iconst[0]=0) or InBounds(x+1,y) (iconst[0]=1: the
+ * variant gold.png was produced with). */
+static int rows_lap_image(const OrcEnergy* e, long elem, OrcRow* out)
+{
+    const long W = e->dims[0], H = e->dims[1];
+    const long x = elem % W, y = elem / W;
+    const float* X = img(e, 0); const float* A = img(e, 1);
+    const float w = e->fconst[0];
+    OrcRow* r = out;
+    r->nnz = 1; r->col[0] = (int)elem; r->val[0] = w; r->r = w * (X[elem] - A[elem]); ++r;
+    int gx = e->iconst[0] ? (x + 1 < W) : (x + 1 < W && y + 1 < H);
+    if (gx) { r->nnz = 2; r->col[0] = (int)elem; r->val[0] = 1.0f; r->col[1] = (int)(elem + 1); r->val[1] = -1.0f;
+              r->r = X[elem] - X[elem + 1]; }
+    else    { r->nnz = 0; r->r = 0.0f; }
+    ++r;
+    if (y + 1 < H) { r->nnz = 2; r->col[0] = (int)elem; r->val[0] = 1.0f; r->col[1] = (int)(elem + W); r->val[1] = -1.0f;
+                     r->r = X[elem] - X[elem + W]; }
+    else           { r->nnz = 0; r->r = 0.0f; }
+    return 3;
+}
+
+/* E6: tests/minimal_graph/laplacian.t:1-17.  params: 0 X, 1 A, 2 v0, 3 v1.  dims N,E.
+ * groups in name order: fit (N elements) then reg (E elements). */
+static int rows_lap_graph(const OrcEnergy* e, long elem, OrcRow* out)
+{
+    const long N = e->dims[0];
+    const float* X = img(e, 0); const float* A = img(e, 1);
+    if (elem < N) {
+        const float w = e->fconst[0];
+        out->nnz = 1; out->col[0] = (int)elem; out->val[0] = w; out->r = w * (X[elem] - A[elem]);
+        return 1;
+    }
+    const int* v0 = (const int*)e->params[2]; const int* v1 = (const int*)e->params[3];
+    const long k = elem - N;
+    const int a = v0[k], b = v1[k];
+    out->nnz = 2; out->col[0] = a; out->val[0] = 1.0f; out->col[1] = b; out->val[1] = -1.0f;
+    out->r = X[a] - X[b];
+    return 1;
+}
+
+/* E1: examples/image_warping/image_warping.t:1-31.
+ * params: 0 Offset float2 (unknown), 1 Angle float (unknown), 2 UrShape float2, 3 Constraints float2,
+ *         4 Mask float, 5 &w_fitSqrt, 6 &w_regSqrt.  dims W,H.
+ * flat unknown layout (thallo.t:1104-1125): [Offset: 2*pix+c][Angle: 2*N+pix]. */
+static int excl_image_warping(const OrcEnergy* e, long flat)
+{   /* image_warping.t:14-15: both unknowns excluded where Mask != 0 */
+    const long N = (long)e->dims[0] * e->dims[1];
+    long pix = flat < 2 * N ? flat / 2 : flat - 2 * N;
+    return img(e, 4)[pix] != 0.0f;
+}
+static int rows_image_warping(const OrcEnergy* e, long elem, OrcRow* out)
+{
+    const long W = e->dims[0], H = e->dims[1], N = W * H;
+    const long x = elem % W, y = elem / W;
+    const float* O = img(e, 0); const float* Ang = img(e, 1); const float* U = img(e, 2);
+    const float* C = img(e, 3); const float* M = img(e, 4);
+    const float wf = *(const float*)e->params[5];
+    const float wr = *(const float*)e->params[6];
+    static const int DX[4] = { 1, -1, 0, 0 }, DY[4] = { 0, 0, 1, -1 };   /* image_warping.t:18 */
+    const float a = Ang[elem];
+    const float ca = cosf(a), sa = sinf(a);
+    OrcRow* r = out;
+    for (int d = 0; d < 4; ++d) {
+        const long xn = x + DX[d], yn = y + DY[d];
+        const int inb = (xn >= 0 && xn < W && yn >= 0 && yn < H);
+        const long j = inb ? yn * W + xn : 0;
+        const int valid = inb && M[elem] == 0.0f && M[j] == 0.0f;
+        if (!valid) { r[0].nnz = 0; r[0].r = 0.0f; r[1].nnz = 0; r[1].r = 0.0f; r += 2; continue; }
+        const float dux = U[2 * elem] - U[2 * j], duy = U[2 * elem + 1] - U[2 * j + 1];
+        const float dox = O[2 * elem] - O[2 * j], doy = O[2 * elem + 1] - O[2 * j + 1];
+        /* Rotate2D (lib.t:138-142) and its angle derivative */
+        const float rx = ca * dux + (-sa) * duy, ry = sa * dux + ca * duy;
+        const float gx = (-sa) * dux - ca * duy, gy = ca * dux - sa * duy;
+        r[0].nnz = 3; r[0].col[0] = (int)(2 * elem);     r[0].val[0] = wr;
+                      r[0].col[1] = (int)(2 * j);        r[0].val[1] = -wr;
+                      r[0].col[2] = (int)(2 * N + elem); r[0].val[2] = -wr * gx;
+        r[0].r = wr * (dox - rx);
+        r[1].nnz = 3; r[1].col[0] = (int)(2 * elem + 1); r[1].val[0] = wr;
+                      r[1].col[1] = (int)(2 * j + 1);    r[1].val[1] = -wr;
+                      r[1].col[2] = (int)(2 * N + elem); r[1].val[2] = -wr * gy;
+        r[1].r = wr * (doy - ry);
+        r += 2;
+    }
+    const int vfit = (C[2 * elem] >= 0.0f) && (C[2 * elem + 1] >= 0.0f) && (M[elem] == 0.0f);
+    for (int c = 0; c < 2; ++c, ++r) {
+        if (vfit) { r->nnz = 1; r->col[0] = (int)(2 * elem + c); r->val[0] = wf; r->r = wf * (O[2 * elem + c] - C[2 * elem + c]); }
+        else      { r->nnz = 0; r->r = 0.0f; }
+    }
+    return 10;
+}
+
+/* E2: examples/arap_mesh_deformation/arap_mesh_deformation.t:1-21.
+ * params: 0 &w_fitSqrt, 1 &w_regSqrt, 2 Position float3 (unknown), 3 Angle float3 (unknown),
+ *         4 Original float3, 5 Constraints float3, 6 V0 int[E], 7 V1 int[E].   dims N,E.
+ * flat layout: [Position 3*n+c][Angle 3*N+3*n+c].  groups: fit (N elems), reg (E elems). */
+static void rot3_zyx(const float* a, float R[9])
+{   /* lib.t:123-137 */
+    const float ca = cosf(a[0]), cb = cosf(a[1]), cg = cosf(a[2]);
+    const float sa = sinf(a[0]), sb = sinf(a[1]), sg = sinf(a[2]);
+    R[0] = cg * cb;  R[1] = -sg * ca + cg * sb * sa;  R[2] = sg * sa + cg * sb * ca;
+    R[3] = sg * cb;  R[4] = cg * ca + sg * sb * sa;   R[5] = -cg * sa + sg * sb * ca;
+    R[6] = -sb;      R[7] = cb * sa;                  R[8] = cb * ca;
+}
+static void drot3_zyx(const float* a, float dA[9], float dB[9], float dG[9])
+{
+    const float ca = cosf(a[0]), cb = cosf(a[1]), cg = cosf(a[2]);
+    const float sa = sinf(a[0]), sb = sinf(a[1]), sg = sinf(a[2]);
+    /* d/d alpha */
+    dA[0] = 0.0f;     dA[1] = sg * sa + cg * sb * ca;   dA[2] = sg * ca - cg * sb * sa;
+    dA[3] = 0.0f;     dA[4] = -cg * sa + sg * sb * ca;  dA[5] = -cg * ca - sg * sb * sa;
+    dA[6] = 0.0f;     dA[7] = cb * ca;                  dA[8] = -cb * sa;
+    /* d/d beta */
+    dB[0] = -cg * sb; dB[1] = cg * cb * sa;             dB[2] = cg * cb * ca;
+    dB[3] = -sg * sb; dB[4] = sg * cb * sa;             dB[5] = sg * cb * ca;
+    dB[6] = -cb;      dB[7] = -sb * sa;                 dB[8] = -sb * ca;
+    /* d/d gamma */
+    dG[0] = -sg * cb; dG[1] = -cg * ca - sg * sb * sa;  dG[2] = cg * sa - sg * sb * ca;
+    dG[3] = cg * cb;  dG[4] = -sg * ca + cg * sb * sa;  dG[5] = sg * sa + cg * sb * ca;
+    dG[6] = 0.0f;     dG[7] = 0.0f;                     dG[8] = 0.0f;
+}
+static inline void mv3(const float M[9], const float v[3], float o[3])
+{
+    o[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+    o[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+    o[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+}
+static int rows_arap(const OrcEnergy* e, long elem, OrcRow* out)
+{
+    const long N = e->dims[0];
+    const float wf = *(const float*)e->params[0];
+    const float wr = *(const float*)e->params[1];
+    const float* P = img(e, 2); const float* A = img(e, 3); const float* Or = img(e, 4); const float* C = img(e, 5);
+    if (elem < N) {
+        const int valid = C[3 * elem] >= -999999.9f;
+        for (int c = 0; c < 3; ++c) {
+            if (valid) { out[c].nnz = 1; out[c].col[0] = (int)(3 * elem + c); out[c].val[0] = wf;
+                         out[c].r = wf * (P[3 * elem + c] - C[3 * elem + c]); }
+            else       { out[c].nnz = 0; out[c].r = 0.0f; }
+        }
+        return 3;
+    }
+    const long k = elem - N;
+    const int v0 = ((const int*)e->params[6])[k], v1 = ((const int*)e->params[7])[k];
+    float R[9], dA[9], dB[9], dG[9], dv[3], Rv[3], ga[3], gb[3], gg[3];
+    for (int c = 0; c < 3; ++c) dv[c] = Or[3 * v0 + c] - Or[3 * v1 + c];
+    rot3_zyx(&A[3 * v0], R); drot3_zyx(&A[3 * v0], dA, dB, dG);
+    mv3(R, dv, Rv); mv3(dA, dv, ga); mv3(dB, dv, gb); mv3(dG, dv, gg);
+    for (int c = 0; c < 3; ++c) {
+        OrcRow* r = &out[c];
+        r->nnz = 5;
+        r->col[0] = 3 * v0 + c;               r->val[0] = wr;
+        r->col[1] = 3 * v1 + c;               r->val[1] = -wr;
+        r->col[2] = (int)(3 * N + 3 * v0);     r->val[2] = -wr * ga[c];
+        r->col[3] = (int)(3 * N + 3 * v0 + 1); r->val[3] = -wr * gb[c];
+        r->col[4] = (int)(3 * N + 3 * v0 + 2); r->val[4] = -wr * gg[c];
+        r->r = wr * ((P[3 * v0 + c] - P[3 * v1 + c]) - Rv[c]);
+    }
+    return 3;
+}
+
+int orc_energy_init(OrcEnergy* e, int kind, const unsigned* dims, void** params,
+                    const float* fconst, const int* iconst)
+{
+    memset(e, 0, sizeof(*e));
+    e->kind = kind; e->params = params;
+    if (fconst) memcpy(e->fconst, fconst, sizeof(e->fconst));
+    if (iconst) memcpy(e->iconst, iconst, sizeof(e->iconst));
+    switch (kind) {
+    case ORC_LAPLACIAN_IMAGE: {
+        e->dims[0] = dims[0]; e->dims[1] = dims[1];
+        long N = (long)dims[0] * dims[1];
+        e->n_img = 1; e->img_param[0] = 0; e->img_chan[0] = 1; e->img_count[0] = N;
+        e->n_elems = N; e->rows = rows_lap_image; e->use_precond = 0;
+        break; }
+    case ORC_LAPLACIAN_GRAPH: {
+        e->dims[0] = dims[0]; e->dims[1] = dims[1];
+        e->n_img = 1; e->img_param[0] = 0; e->img_chan[0] = 1; e->img_count[0] = dims[0];
+        e->n_elems = (long)dims[0] + dims[1]; e->rows = rows_lap_graph; e->use_precond = 0;
+        break; }
+    case ORC_IMAGE_WARPING: {
+        e->dims[0] = dims[0]; e->dims[1] = dims[1];
+        long N = (long)dims[0] * dims[1];
+        e->n_img = 2;
+        e->img_param[0] = 0; e->img_chan[0] = 2; e->img_count[0] = N;
+        e->img_param[1] = 1; e->img_chan[1] = 1; e->img_count[1] = N;
+        e->n_elems = N; e->rows = rows_image_warping; e->excluded = excl_image_warping;
+        e->use_precond = 1;   /* image_warping.t:11 */
+        break; }
+    case ORC_ARAP_MESH: {
+        e->dims[0] = dims[0]; e->dims[1] = dims[1];
+        e->n_img = 2;
+        e->img_param[0] = 2; e->img_chan[0] = 3; e->img_count[0] = dims[0];
+        e->img_param[1] = 3; e->img_chan[1] = 3; e->img_count[1] = dims[0];
+        e->n_elems = (long)dims[0] + dims[1]; e->rows = rows_arap;
+        e->use_precond = 1;   /* arap_mesh_deformation.t:13 */
+        break; }
+    default:
+        return -1;
+    }
+    e->img_off[0] = 0;
+    for (int i = 0; i < e->n_img; ++i) e->img_off[i + 1] = e->img_off[i] + e->img_count[i] * e->img_chan[i];
+    e->n_unknowns = e->img_off[e->n_img];
+    return 0;
+}
+
+/* ------------------------------------------------------------------ generic fmap */
+
+double orc_cost(const OrcEnergy* e, int fl)
+{   /* thallo.t:3939-3949: per element 0.5*sum r_k^2 ; gauss_newton.t:1067-1079 reduces over elements */
+    OrcRow rows[ORC_MAX_ROWS]; Acc a; acc_init(&a, fl);
+    for (long el = 0; el < e->n_elems; ++el) {
+        int n = e->rows(e, el, rows);
+        float s = 0.0f;
+        for (int k = 0; k < n; ++k) s = s + rows[k].r * rows[k].r;
+        acc_add(&a, 0.5f * s);
+    }
+    return acc_get(&a);
+}
+
+void orc_eval_jtf(const OrcEnergy* e, float* r, float* pre)
+{   /* thallo.t:3898-3902: R[u] += -1*partial*F ; Pre[u] += partial*partial */
+    OrcRow rows[ORC_MAX_ROWS];
+    for (long el = 0; el < e->n_elems; ++el) {
+        int n = e->rows(e, el, rows);
+        for (int k = 0; k < n; ++k)
+            for (int j = 0; j < rows[k].nnz; ++j) {
+                const float v = rows[k].val[j];
+                r[rows[k].col[j]]   += -1.0f * v * rows[k].r;
+                pre[rows[k].col[j]] += v * v;
+            }
+    }
+}
+
+double orc_apply_jtj(const OrcEnergy* e, const float* p, float* Ap, int fl)
+{   /* thallo.t:3551-3566: Jp = sum partial*P[u]; Ap_X[u] += Jp*partial; result += P[u]*Jp*partial */
+    OrcRow rows[ORC_MAX_ROWS]; Acc a; acc_init(&a, fl);
+    for (long el = 0; el < e->n_elems; ++el) {
+        int n = e->rows(e, el, rows);
+        float d = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            float Jp = 0.0f;
+            for (int j = 0; j < rows[k].nnz; ++j) Jp = Jp + rows[k].val[j] * p[rows[k].col[j]];
+            for (int j = 0; j < rows[k].nnz; ++j) {
+                const float jtjp = Jp * rows[k].val[j];
+                Ap[rows[k].col[j]] += jtjp;
+                d = d + p[rows[k].col[j]] * jtjp;
+            }
+        }
+        acc_add(&a, d);
+    }
+    return acc_get(&a);
+}
+
+void orc_compute_ctc(const OrcEnergy* e, float inv_radius, float* ctc)
+{   /* thallo.t:3929-3933 */
+    OrcRow rows[ORC_MAX_ROWS];
+    for (long el = 0; el < e->n_elems; ++el) {
+        int n = e->rows(e, el, rows);
+        for (int k = 0; k < n; ++k)
+            for (int j = 0; j < rows[k].nnz; ++j)
+                ctc[rows[k].col[j]] += rows[k].val[j] * rows[k].val[j] * inv_radius;
+    }
+}
+
+double orc_model_cost(const OrcEnergy* e, const float* delta, int fl)
+{   /* thallo.t:3848-3863: 0.5 * sum (F + J delta)^2 */
+    OrcRow rows[ORC_MAX_ROWS]; Acc a; acc_init(&a, fl);
+    for (long el = 0; el < e->n_elems; ++el) {
+        int n = e->rows(e, el, rows);
+        float s = 0.0f;
+        for (int k = 0; k < n; ++k) {
+            float jd = 0.0f;
+            for (int j = 0; j < rows[k].nnz; ++j) jd = jd + rows[k].val[j] * delta[rows[k].col[j]];
+            const float m = rows[k].r + jd;
+            s = s + m * m;
+        }
+        acc_add(&a, 0.5f * s);
+    }
+    return acc_get(&a);
+}
+
+long orc_count_rows(const OrcEnergy* e, long* nnz_out)
+{
+    OrcRow rows[ORC_MAX_ROWS]; long nr = 0, nnz = 0;
+    for (long el = 0; el < e->n_elems; ++el) {
+        int n = e->rows(e, el, rows);
+        nr += n;
+        for (int k = 0; k < n; ++k) nnz += rows[k].nnz;
+    }
+    if (nnz_out) *nnz_out = nnz;
+    return nr;
+}
+
+long orc_export_csr(const OrcEnergy* e, int* rowptr, int* colind, float* vals, float* resid)
+{   /* the matrix gauss_newton.t:327-487 (generateDumpJ) materialises, rows in element order */
+    OrcRow rows[ORC_MAX_ROWS]; long nr = 0, nnz = 0;
+    for (long el = 0; el < e->n_elems; ++el) {
+        int n = e->rows(e, el, rows);
+        for (int k = 0; k < n; ++k) {
+            rowptr[nr] = (int)nnz;
+            if (resid) resid[nr] = rows[k].r;
+            for (int j = 0; j < rows[k].nnz; ++j) { colind[nnz] = rows[k].col[j]; vals[nnz] = rows[k].val[j]; ++nnz; }
+            ++nr;
+        }
+    }
+    rowptr[nr] = (int)nnz;
+    return nnz;
+}
+
+/* ------------------------------------------------------------------ driver */
+
+static inline int is_excl(const OrcEnergy* e, long i) { return e->excluded ? e->excluded(e, i) : 0; }
+
+static void linear_update(OrcEnergy* e, const float* delta)
+{   /* gauss_newton.t:901-906 */
+    for (int k = 0; k < e->n_img; ++k) {
+        float* X = (float*)e->params[e->img_param[k]];
+        const long off = e->img_off[k], len = e->img_off[k + 1] - off;
+        for (long i = 0; i < len; ++i)
+            if (!is_excl(e, off + i)) X[i] = X[i] + delta[off + i];
+    }
+}
+static void copy_unknowns(OrcEnergy* e, float* dst_flat, int to_flat)
+{
+    for (int k = 0; k < e->n_img; ++k) {
+        float* X = (float*)e->params[e->img_param[k]];
+        const long off = e->img_off[k], len = e->img_off[k + 1] - off;
+        for (long i = 0; i < len; ++i)
+            if (!is_excl(e, off + i)) { if (to_flat) dst_flat[off + i] = X[i]; else X[i] = dst_flat[off + i]; }
+    }
+}
+
+int orc_solve(OrcEnergy* e, const OrcSolverParams* sp, double* costs, int costs_cap, float* trace, int trace_cap)
+{
+    const long n = e->n_unknowns;
+    const int fl = sp->float_sums;
+    const int lm = sp->use_lm;
+    float* delta = calloc(n, 4); float* r = calloc(n, 4); float* z = calloc(n, 4); float* p = calloc(n, 4);
+    float* Ap = calloc(n, 4); float* pre = calloc(n, 4);
+    float* b = calloc(n, 4); float* Adelta = calloc(n, 4); float* CtC = calloc(n, 4); float* SSq = calloc(n, 4);
+    float* prevX = calloc(n, 4);
+    int ntrace = 0, ncost = 0, nIter = 0;
+    float radius = sp->trust_region_radius, decrease_factor = sp->radius_decrease_factor;
+
+    float prevCost = (float)orc_cost(e, fl);                   /* init, gauss_newton.t:1193 */
+    if (ncost < costs_cap) costs[ncost++] = prevCost;
+
+    while (nIter < sp->nIterations) {
+        /* ---- Nonlinear Setup (gauss_newton.t:1566-1606) */
+        memset(delta, 0, n * 4); memset(Ap, 0, n * 4); memset(r, 0, n * 4); memset(pre, 0, n * 4);
+        orc_eval_jtf(e, r, pre);                                /* PCGInit1 residual-wise :998-1003 */
+        Acc aN; acc_init(&aN, fl);
+        for (long i = 0; i < n; ++i) {                          /* PCGInit1_Finish :712-731 */
+            if (is_excl(e, i)) continue;
+            float m;
+            if (e->use_precond) { float s = 1.0f + sqrtf(pre[i]); m = 1.0f / (s * s); }   /* guardedInvert CERES :638-648 */
+            else m = 1.0f;
+            pre[i] = m; p[i] = m * r[i];
+            acc_add(&aN, r[i] * p[i]);
+        }
+        float alphaN = (float)acc_get(&aN);
+        float Q0 = 0.0f, Q1 = 0.0f;
+        if (lm) {                                               /* :1595-1606 */
+            if (nIter == 0) for (long i = 0; i < n; ++i) if (!is_excl(e, i)) SSq[i] = pre[i];   /* PCGSaveSSq */
+            memset(CtC, 0, n * 4);
+            orc_compute_ctc(e, 1.0f / radius, CtC);
+            Acc aQ; acc_init(&aN, fl); acc_init(&aQ, fl);
+            for (long i = 0; i < n; ++i) {                      /* PCGFinalizeDiagonal :936-969 */
+                if (is_excl(e, i)) continue;
+                const float unclamped = CtC[i];
+                const float invS = 1.0f / SSq[i];
+                const float cm = invS / radius;
+                const float lo = sp->min_lm_diagonal * cm, hi = sp->max_lm_diagonal * cm;
+                const float c = fminf(fmaxf(unclamped, lo), hi);
+                CtC[i] = c;
+                const float m = 1.0f / (c + radius * unclamped);
+                pre[i] = m; b[i] = r[i]; p[i] = m * r[i];
+                acc_add(&aN, r[i] * p[i]);
+                acc_add(&aQ, 0.5f * (delta[i] * (r[i] + r[i])));
+            }
+            alphaN = (float)acc_get(&aN); Q0 = (float)acc_get(&aQ);
+        }
+        /* ---- Linear Solve (:1615-1687) */
+        for (int lIter = 0; lIter < sp->lIterations; ++lIter) {
+            memset(Ap, 0, n * 4);
+            double dd = orc_apply_jtj(e, p, Ap, fl);            /* PCGStep1 residual-wise :1006-1015 */
+            float alphaD;
+            if (lm) {                                           /* PCGStep1_Finish :777-787 */
+                Acc aD; acc_init(&aD, fl);
+                for (long i = 0; i < n; ++i) { if (is_excl(e, i)) continue; Ap[i] = Ap[i] + CtC[i] * p[i]; acc_add(&aD, p[i] * Ap[i]); }
+                alphaD = (float)acc_get(&aD);
+            } else alphaD = (float)dd;
+            float alpha = 0.0f;                                  /* safeDivideIfNotLM :226-234 */
+            if (lm) alpha = alphaN / alphaD; else if (alphaD != 0.0f) alpha = alphaN / alphaD;
+            Acc aB, aQ; acc_init(&aB, fl); acc_init(&aQ, fl);
+            if (lm && ((lIter + 1) % sp->residual_reset_period) == 0) {   /* :1653-1657 */
+                for (long i = 0; i < n; ++i) if (!is_excl(e, i)) delta[i] = delta[i] + alpha * p[i];
+                memset(Adelta, 0, n * 4);
+                orc_apply_jtj(e, delta, Adelta, fl);
+                for (long i = 0; i < n; ++i) if (!is_excl(e, i)) Adelta[i] += delta[i] * CtC[i];
+                for (long i = 0; i < n; ++i) {
+                    if (is_excl(e, i)) continue;
+                    r[i] = b[i] - Adelta[i];
+                    z[i] = pre[i] * r[i];
+                    acc_add(&aB, z[i] * r[i]);
+                    acc_add(&aQ, 0.5f * (delta[i] * (r[i] + b[i])));
+                }
+            } else {
+                for (long i = 0; i < n; ++i) {                  /* PCGStep2 :801-843 */
+                    if (is_excl(e, i)) continue;
+                    delta[i] = delta[i] + alpha * p[i];
+                    r[i] = r[i] - alpha * Ap[i];
+                    z[i] = pre[i] * r[i];
+                    acc_add(&aB, z[i] * r[i]);
+                    if (lm) acc_add(&aQ, 0.5f * (delta[i] * (r[i] + b[i])));
+                }
+            }
+            const float betaN = (float)acc_get(&aB);
+            float beta = 0.0f;                                   /* PCGStep3 :889-899 */
+            if (lm) beta = betaN / alphaN; else if (alphaN != 0.0f) beta = betaN / alphaN;
+            for (long i = 0; i < n; ++i) if (!is_excl(e, i)) p[i] = z[i] + beta * p[i];
+            if (trace && ntrace < trace_cap) { trace[2 * ntrace] = alpha; trace[2 * ntrace + 1] = beta; ++ntrace; }
+            alphaN = betaN;                                      /* :1665 */
+            if (lm) {                                            /* :1666-1686 */
+                Q1 = (float)acc_get(&aQ);
+                if (!isfinite(Q1)) break;
+                const float zeta = (float)(lIter + 1) * (Q1 - Q0) / Q1;
+                if (!isfinite(zeta)) break;
+                if (zeta < sp->q_tolerance) break;
+                Q0 = Q1;
+            }
+        }
+        /* ---- Nonlinear Finish (:1690-1765) */
+        float model_cost_change = 0.0f;
+        if (lm) {
+            const float mc = (float)orc_model_cost(e, delta, fl);
+            model_cost_change = prevCost - mc;
+            copy_unknowns(e, prevX, 1);
+        }
+        linear_update(e, delta);
+        if (lm) {
+            const float newCost = (float)orc_cost(e, fl);
+            const float cost_change = prevCost - newCost;
+            const float rel = cost_change / model_cost_change;
+            if (cost_change >= 0 && rel > sp->min_relative_decrease) {
+                if (cost_change <= prevCost * sp->function_tolerance) {
+                    if (ncost < costs_cap) costs[ncost++] = newCost;
+                    ++nIter;  /* counted as a taken step in the returned trajectory */
+                    goto done;
+                }
+                const double tmp = 1.0 - pow(2.0 * (double)rel - 1.0, 3.0);
+                radius = (float)((double)radius / fmax(1.0 / 3.0, tmp));
+                radius = fminf(radius, sp->max_trust_region_radius);
+                decrease_factor = 2.0f;
+                prevCost = newCost;
+            } else {
+                copy_unknowns(e, prevX, 0);                      /* revertUpdate */
+                radius = radius / decrease_factor;
+                decrease_factor = 2.0f * decrease_factor;
+                if (radius < sp->min_trust_region_radius) {
+                    if (ncost < costs_cap) costs[ncost++] = prevCost;
+                    ++nIter;
+                    goto done;
+                }
+            }
+            if (ncost < costs_cap) costs[ncost++] = (float)orc_cost(e, fl);
+        } else {
+            /* GN: cost after the step, as Thallo_ProblemCurrentCost reports it (:1787-1793) */
+            if (ncost < costs_cap) costs[ncost++] = (float)orc_cost(e, fl);
+        }
+        ++nIter;
+    }
+done:
+    free(delta); free(r); free(z); free(p); free(Ap); free(pre);
+    free(b); free(Adelta); free(CtC); free(SSq); free(prevX);
+    return nIter;
+}
+
+int orc_solve_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst,
+                   const OrcSolverParams* sp, double* costs, int costs_cap, float* trace, int trace_cap)
+{
+    OrcEnergy e;
+    if (orc_energy_init(&e, kind, dims, params, fconst, iconst)) return -1;
+    return orc_solve(&e, sp, costs, costs_cap, trace, trace_cap);
+}
+
+/* thin wrappers so ctypes callers need not mirror the OrcEnergy struct */
+#define WRAP_PROLOGUE OrcEnergy e; if (orc_energy_init(&e, kind, dims, params, fconst, iconst)) return -1;
+double orc_cost_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst, int fl)
+{ WRAP_PROLOGUE return orc_cost(&e, fl); }
+long orc_n_unknowns_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst)
+{ WRAP_PROLOGUE return e.n_unknowns; }
+int orc_eval_jtf_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst, float* r, float* pre)
+{ WRAP_PROLOGUE orc_eval_jtf(&e, r, pre); return 0; }
+double orc_apply_jtj_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst,
+                          const float* p, float* Ap, int fl)
+{ WRAP_PROLOGUE return orc_apply_jtj(&e, p, Ap, fl); }
+long orc_count_rows_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst, long* nnz)
+{ WRAP_PROLOGUE return orc_count_rows(&e, nnz); }
+long orc_export_csr_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst,
+                         int* rowptr, int* colind, float* vals, float* resid)
+{ WRAP_PROLOGUE return orc_export_csr(&e, rowptr, colind, vals, resid); }
+int orc_excluded_mask_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst, unsigned char* mask)
+{ WRAP_PROLOGUE for (long i = 0; i < e.n_unknowns; ++i) mask[i] = (unsigned char)is_excl(&e, i); return 0; }

@@ -1,0 +1,92 @@
+"""Seeded synthetic problem instances (host numpy arrays) for the bundled energies.
+
+The shapes follow the reference's own example harnesses; there is no network for the real
+data sets, and only decoded pixels of the two gold PNGs travel as fixtures.
+
+  image_warping  examples/image_warping/src/CombinedSolver.h:158-204 (UrShape = pixel grid,
+                 Offset0 = UrShape, Angle0 = 0, constraints = -1 except markers + pinned border,
+                 weights sqrt(100)/sqrt(0.01) :123-127) -- perturbed so J is non-trivial at iter 0
+                 (SURVEY.md 8d "C-main").
+  arap_mesh      examples/arap_mesh_deformation/src/CombinedSolver.h:94-133 (directed edge pairs,
+                 unconstrained vertices carry -inf-like constraints :80), weights 4/1 main.cpp:115-116.
+"""
+import numpy as np
+
+
+def image_warping(W, H, seed=1234, perturb=0.5, angle_amp=0.1, n_markers=64, max_disp=32.0,
+                  mask_disc=0.1, w_fit=10.0, w_reg=0.1):
+    """Returns the params list indexed like image_warping.t Inputs{} (0..6)."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W]
+    ur = np.stack([xs, ys], -1).astype(np.float32)                      # UrShape(x,y) = (x,y)
+    off = (ur + perturb * rng.uniform(-1, 1, ur.shape)).astype(np.float32)
+    ang = (angle_amp * rng.uniform(-1, 1, (H, W))).astype(np.float32)
+    mask = np.zeros((H, W), np.float32)
+    if mask_disc > 0:
+        rr = (xs - W / 2.0) ** 2 + (ys - H / 2.0) ** 2
+        mask[rr < (mask_disc * W) ** 2] = 255.0
+    cons = np.full((H, W, 2), -1.0, np.float32)
+    border = (xs == 0) | (ys == 0) | (xs == W - 1) | (ys == H - 1)
+    cons[border] = ur[border]                                           # main.cpp:119-129
+    scale = max_disp * min(W, H) / 2048.0 if min(W, H) < 2048 else max_disp
+    placed = 0
+    while placed < n_markers:
+        x = int(rng.integers(1, W - 1)); y = int(rng.integers(1, H - 1))
+        if mask[y, x] != 0 or cons[y, x, 0] >= 0:
+            continue
+        d = rng.uniform(-scale, scale, 2)
+        t = np.clip(np.array([x, y]) + d, 0, [W - 1, H - 1])
+        cons[y, x] = t
+        placed += 1
+    return [np.ascontiguousarray(off), np.ascontiguousarray(ang), np.ascontiguousarray(ur),
+            np.ascontiguousarray(cons), np.ascontiguousarray(mask), float(w_fit), float(w_reg)]
+
+
+def laplacian_image(W, H, seed=3):
+    rng = np.random.default_rng(seed)
+    A = rng.uniform(0, 1, (H, W)).astype(np.float32)
+    return [A.copy(), A]
+
+
+def laplacian_graph(N, seed=5, extra_edges=0):
+    rng = np.random.default_rng(seed)
+    A = rng.uniform(0, 1, N).astype(np.float32)
+    v0 = np.arange(N - 1, dtype=np.int32)
+    v1 = v0 + 1
+    if extra_edges:
+        a = rng.integers(0, N, extra_edges).astype(np.int32)
+        b = rng.integers(0, N, extra_edges).astype(np.int32)
+        keep = a != b
+        v0 = np.concatenate([v0, a[keep]]); v1 = np.concatenate([v1, b[keep]])
+    return [A.copy(), A, np.ascontiguousarray(v0), np.ascontiguousarray(v1)]
+
+
+def torus_mesh(nu, nv, R=2.0, r=0.7):
+    """Closed triangle mesh on a torus grid: nu*nv vertices, valence 6.
+    Returns (positions [N,3] float32, directed edge arrays v0, v1 int32) -- both directions of every
+    undirected edge, like ThalloGraph (examples/shared/ThalloGraph.h:67-79)."""
+    u, v = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    tu = 2 * np.pi * u / nu; tv = 2 * np.pi * v / nv
+    pos = np.stack([(R + r * np.cos(tv)) * np.cos(tu), (R + r * np.cos(tv)) * np.sin(tu), r * np.sin(tv)], -1)
+    idx = (u * nv + v).astype(np.int32)
+
+    def nb(du, dv):
+        return (((u + du) % nu) * nv + (v + dv) % nv).astype(np.int32)
+    und = [(idx, nb(1, 0)), (idx, nb(0, 1)), (idx, nb(1, 1))]          # 3 undirected edges per vertex
+    a = np.concatenate([p[0].ravel() for p in und]); b = np.concatenate([p[1].ravel() for p in und])
+    v0 = np.concatenate([a, b]); v1 = np.concatenate([b, a])
+    return pos.reshape(-1, 3).astype(np.float32), np.ascontiguousarray(v0), np.ascontiguousarray(v1)
+
+
+def arap_mesh(nu, nv, seed=11, n_handles=32, w_fit=4.0, w_reg=1.0, angle_amp=0.05, pos_noise=0.01):
+    """Returns the params list indexed like arap_mesh_deformation.t Inputs{} (0..7)."""
+    rng = np.random.default_rng(seed)
+    orig, v0, v1 = torus_mesh(nu, nv)
+    N = orig.shape[0]
+    pos = (orig + pos_noise * rng.standard_normal(orig.shape)).astype(np.float32)
+    ang = (angle_amp * rng.uniform(-1, 1, (N, 3))).astype(np.float32)
+    cons = np.full((N, 3), -np.inf, np.float32)
+    cons[:] = -1.0e30                                                  # "unconstrained" sentinel < -999999.9
+    hs = rng.choice(N, n_handles, replace=False)
+    cons[hs] = orig[hs] + 0.3 * rng.standard_normal((n_handles, 3)).astype(np.float32)
+    return [float(w_fit), float(w_reg), pos, ang, orig.copy(), np.ascontiguousarray(cons), v0, v1]

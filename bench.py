@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- PCG iterations/s and ms per Gauss-Newton iteration, image_warping 2048^2 on MI355X.
+
+A "step" = one Gauss-Newton iteration (one Thallo_ProblemStep: PCGInit + lIterations=100 PCG
+iterations + PCGLinearUpdate) on one synthetic 2048x2048 image_warping instance already resident
+in HBM (reference workload: examples/image_warping/src/main.cpp:131-149, 8 GN x 100 PCG).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2048] [--liters 100]
+
+Prints ONE JSON line (rank 0).  `value` = whole-job PCG iterations per second.
+`roofline` = the dominant kernel (PCGStep1: fused PCGStep3 + delta update + applyJTJ) measured live
+with HIP events on the launch stream over the timed region (every 4th launch bracketed);
+`roofline.applyjtj_standalone` = the plain applyJTJ kernel (48 B/pixel) timed
+back-to-back after the timed region.  `cpu_baseline` = oracle/cpu_port_image_warping.c (OpenMP port
+of the same algorithm; the reference ships no runnable CPU path) on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy ceiling)
+ALG_BYTES_APPLYJTJ = 48         # read p 12 + Angle 4 + UrShape 8 + Mask 4 + Constraints 8, write Ap_X 12
+ALG_BYTES_FUSED_STEP1 = 96      # applyJTJ 48 + PCGStep3 (read z 12, p counted once, write p 12) + delta update (r/w 24)
+ALG_BYTES_PCG_ITER = 180        # applyJTJ 48 + PCGStep2 96 + PCGStep3 36
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--liters", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-period", type=int, default=4)
+    return ap.parse_args()
+
+
+def standalone_applyjtj(torch, W, H, p_np, reps=50):
+    """Time the plain applyJTJ kernel (48 B/px algorithmic) back-to-back with HIP events."""
+    import thallo_amd
+    from thallo_amd import api
+    L = thallo_amd.lib()
+    L.thallo_hip_vector_elems.restype = C.c_long; L.thallo_hip_vector_elems.argtypes = [C.c_long]
+    N = W * H; n = 3 * N; na = L.thallo_hip_vector_elems(n)
+    dev = [torch.from_numpy(x).cuda() if hasattr(x, "dtype") else x for x in p_np]
+    f = lambda: torch.zeros(na, dtype=torch.float32, device="cuda")
+    r, pre, z, p0, delta, Ap = f(), f(), f(), f(), f(), f()
+    cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda")
+    flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
+    parts = torch.zeros(4 * 1024, dtype=torch.float32, device="cuda")
+    vp, fl = C.c_void_p, C.c_float
+    L.thallo_hip_iw_pcg_init(W, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+                             vp(dev[4].data_ptr()), fl(p_np[5]), fl(p_np[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
+                             vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(parts.data_ptr()), None)
+
+    def launch():
+        return L.thallo_hip_iw_apply_jtj(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p_np[5]), fl(p_np[6]),
+                                         vp(z.data_ptr()), vp(Ap.data_ptr()), vp(parts.data_ptr() + 4096), None)
+    for _ in range(5):
+        assert launch() > 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # kernels run on the NULL stream = torch's current stream
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import thallo_amd
+    from thallo_amd import synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    W = H = args.size
+    L_it = args.liters
+    K, Wm = args.steps, args.warmup
+    p = syn.image_warping(W, H)
+
+    if world > 1:
+        from thallo_amd import distributed as tdist
+        res = tdist.bench_image_warping(p, W, H, L_it, K, Wm, rank, world)
+        if rank == 0:
+            print(json.dumps(res))
+        dist.destroy_process_group()
+        return
+
+    dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
+    s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
+    s.set_solver_parameters(nIterations=K + Wm, lIterations=L_it)
+    params = s.make_params(dev)
+    s.init(params)
+    for _ in range(Wm):
+        s.step(params)
+    torch.cuda.synchronize()
+    s.reset_kernel_stats()
+    s.set_kernel_sampling(args.sample_period)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        assert s.step(params) == 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s.set_kernel_sampling(0)
+    ks = s.kernel_stats()
+    final_cost = s.current_cost()
+
+    npx = W * H
+    step1_ms = ks["PCGStep1"]["mean_ms"]
+    step2_ms = ks["PCGStep2"]["mean_ms"]
+    fused_gbs = ALG_BYTES_FUSED_STEP1 * npx / (step1_ms * 1e-3) / 1e9
+    sa_ms = standalone_applyjtj(torch, W, H, p)
+    sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("PCGStep1_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "pcg_iters_per_sec", "value": K * L_it / dt, "unit": "PCG iterations/s",
+        "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"examples/image_warping {W}x{H} ARAP, GN + matrix-free PCG, {L_it} PCG iterations per GN step",
+                   "width": W, "height": H, "unknowns": 3 * npx, "l_iterations": L_it, "parallelism": "1 GPU"},
+        "ms_per_gn_iter": dt / K * 1e3, "us_per_pcg_iter": dt / (K * L_it) * 1e6,
+        "pcg_iter_algorithmic_GBps": ALG_BYTES_PCG_ITER * npx * K * L_it / dt / 1e9,
+        "final_cost": final_cost,
+        "roofline": {"bound": "hbm", "kernel": "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)",
+                     "achieved": fused_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused_gbs / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_pixel": ALG_BYTES_FUSED_STEP1,
+                     "avg_launch_ms": step1_ms, "samples": ks["PCGStep1"]["samples"],
+                     "applyjtj_standalone": {"algorithmic_bytes_per_pixel": ALG_BYTES_APPLYJTJ, "avg_launch_ms": sa_ms,
+                                             "achieved": sa_gbs, "frac": sa_gbs / HBM_PEAK_GBS},
+                     "pcg_step2": {"algorithmic_bytes_per_pixel": 60, "avg_launch_ms": step2_ms,
+                                   "achieved": 60 * npx / (step2_ms * 1e-3) / 1e9}},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        q = syn.image_warping(W, H)
+        sample_l = L_it
+        res = orc.cpu_port_image_warping(W, H, q, 1, sample_l, want_costs=False)
+        out["cpu_baseline"] = {"value": sample_l / res["seconds_pcg"], "unit": "PCG iterations/s", "cores": res["threads"],
+                               "kind": "port", "ms_per_gn_iter": res["seconds_total"] * 1e3,
+                               "sample": f"1 GN step x {sample_l} PCG iterations of the same {W}x{H} instance, OpenMP port of the "
+                                         "reference algorithm (oracle/cpu_port_image_warping.c)"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

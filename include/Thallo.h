@@ -1,0 +1,113 @@
+/*
+ * Thallo.h -- public C API of the MI355X-native Thallo solver backend (libThallo.so).
+ *
+ * ABI-compatible with the reference's API/release/include/Thallo.h:1-105: same 3 opaque
+ * handle types, same 6-int initialization struct passed BY VALUE, same 13 entry points and
+ * the same performance-summary structs, so an application written against the reference
+ * (examples/shared/ThalloSolver.h:43-106, every tests/<x>/main.cpp) relinks unchanged.
+ * Callers in C++ wrap the include in extern "C" exactly as they do for the reference; this
+ * header also does it itself.
+ *
+ * Behavioural notes (where this backend differs from the reference are marked DIFF):
+ *  - problem specifications: the bundled energies are recognised from the .t file and run on
+ *    precompiled gfx950 plugins; an unrecognised .t makes Thallo_ProblemPlan print a
+ *    diagnostic and return NULL (the reference prints a Lua traceback and returns NULL,
+ *    API/src/thallo.t:1431-1432).
+ *  - DIFF: cpuOnly=1 and doublePrecision=1 are rejected (NULL state / NULL plan); this build
+ *    has no CPU fallback on purpose.
+ *  - DIFF: GPU errors are reported on stderr and surface as NULL / 0 returns; the process is
+ *    never exit()ed (reference: API/src/cuda_util.t:103-118).
+ */
+#ifndef THALLO_H
+#define THALLO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Thallo_State   Thallo_State;
+typedef struct Thallo_Plan    Thallo_Plan;
+typedef struct Thallo_Problem Thallo_Problem;
+
+/* Set once per Thallo_NewState; an all-zero struct is the fast default. */
+struct Thallo_InitializationParameters {
+    int doublePrecision;   /* must be 0 in this build */
+    int verbosityLevel;    /* 0 quiet, >=1 prints solver log + timing table at the end of a solve */
+    int timingLevel;       /* 0/1 coarse events, 2 per-kernel hipEvents, 3 additionally device-syncs around them */
+    int threadsPerBlock;   /* accepted for compatibility; kernels carry their own tuned shapes */
+    int useAutoscheduler;  /* accepted for compatibility; the schedule is fixed per bundled energy */
+    int cpuOnly;           /* must be 0 in this build */
+};
+typedef struct Thallo_InitializationParameters Thallo_InitializationParameters;
+
+Thallo_State* Thallo_NewState(Thallo_InitializationParameters params);
+
+/* solverkind: "gauss_newton" or "levenberg_marquardt" (anything else: NULL). */
+Thallo_Problem* Thallo_ProblemDefine(Thallo_State* state, const char* filename, const char* solverkind);
+void            Thallo_ProblemDelete(Thallo_State* state, Thallo_Problem* problem);
+
+/* dimensions[i] is the extent of the i-th Dims() name of the .t; the pointer is retained. */
+Thallo_Plan* Thallo_ProblemPlan(Thallo_State* state, Thallo_Problem* problem, unsigned int* dimensions);
+void         Thallo_PlanFree(Thallo_State* state, Thallo_Plan* plan);
+
+/* Solver parameters by name; *value has the parameter's own type: int for nIterations,
+ * lIterations, residual_reset_period; float for the rest (API/src/gauss_newton.t:200-216). */
+void Thallo_SetSolverParameter(Thallo_State* state, Thallo_Plan* plan, const char* name, void* value);
+void Thallo_GetSolverParameter(Thallo_State* state, Thallo_Plan* plan, const char* name, void* value);
+
+/* problemparams[i] belongs to input index i of the .t: device pointers for Unknown/Array/Sparse,
+ * host pointers to the scalar for Param.  Unknown buffers are updated in place. */
+void   Thallo_ProblemSolve(Thallo_State* state, Thallo_Plan* plan, void** problemparams);
+void   Thallo_ProblemInit(Thallo_State* state, Thallo_Plan* plan, void** problemparams);
+int    Thallo_ProblemStep(Thallo_State* state, Thallo_Plan* plan, void** problemparams);   /* 0 = finished */
+double Thallo_ProblemCurrentCost(Thallo_State* state, Thallo_Plan* plan);
+
+struct Thallo_PerformanceEntry {
+    unsigned int count;
+    double minMS;
+    double maxMS;
+    double meanMS;
+    double stddevMS;
+};
+typedef struct Thallo_PerformanceEntry Thallo_PerformanceEntry;
+
+struct Thallo_PerformanceSummary {
+    Thallo_PerformanceEntry total;
+    Thallo_PerformanceEntry nonlinearIteration;
+    Thallo_PerformanceEntry nonlinearSetup;
+    Thallo_PerformanceEntry linearSolve;
+    Thallo_PerformanceEntry nonlinearResolve;
+};
+typedef struct Thallo_PerformanceSummary Thallo_PerformanceSummary;
+
+void Thallo_GetPerformanceSummary(Thallo_State* state, Thallo_Plan* plan, Thallo_PerformanceSummary* summary);
+
+/* ------------------------------------------------------------------------------------------
+ * Extensions (not in the reference; prefixed ThalloX_).  Used by bench.py and the tests.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Launch on `stream` (a hipStream_t) instead of the legacy default stream. */
+void ThalloX_SetStream(Thallo_Plan* plan, void* stream);
+
+/* Bracket every `period`-th launch of each kernel with hipEvents (0 = off).  Cheap enough to
+ * leave on inside a timed region; results via ThalloX_GetKernelStat. */
+void ThalloX_SetKernelSampling(Thallo_Plan* plan, int period);
+/* Enumerate sampled kernels: returns 0 while index is valid. launches = all launches,
+ * samples = timed launches, total_ms = sum over timed launches.  Synchronises the device. */
+int  ThalloX_GetKernelStat(Thallo_Plan* plan, int index, const char** name, long* launches, long* samples, double* total_ms);
+void ThalloX_ResetKernelStats(Thallo_Plan* plan);
+
+/* alpha/beta of every PCG iteration of the most recent Step (tests): writes up to cap pairs,
+ * returns the number of PCG iterations run. */
+int  ThalloX_GetAlphaBetaTrace(Thallo_Plan* plan, float* out_pairs, int cap);
+
+/* Name of the plugin a plan runs ("image_warping", "laplacian_image", ...). */
+const char* ThalloX_PlanEnergyName(Thallo_Plan* plan);
+
+/* Last error message of this thread ("" if none). */
+const char* ThalloX_LastError(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+/*
+ * thallo_hip.h -- thin C-ABI shim over the hand-written gfx950 (CDNA4) kernels of the
+ * Gauss-Newton / LM + PCG hot path.
+ *
+ * This is the seam BASELINE.json's north star describes: a host layer (the reference's
+ * API/src/gauss_newton.t driver, or this repo's C++ driver in thallo_amd/csrc/solver.cpp)
+ * calls these entry points instead of JIT-compiling Terra kernels to PTX
+ * (reference: API/src/util.t:797-927 makeGPUFunctions, API/src/cuda_util.t:470 cudacompile).
+ * Plain pointers, sizes and PODs only; no C++/torch types.  INTEGRATION.md shows the
+ * `terralib.includec("thallo_hip.h")` binding a Thallo maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what
+ *    the reference launches on: util.t:769-772);
+ *  - every function returns 0 / the number of partials written (>= 0) on success and a negative
+ *    hipError_t on failure; it never exits the process (the reference's cd() macro exits:
+ *    cuda_util.t:103-118);
+ *  - solver vectors are flat float arrays of n_unknowns elements laid out like the reference's
+ *    UnknownType: unknown images concatenated in declaration order, each AoS
+ *    (flat = image_offset + channels*element + channel; thallo.t:1104-1125, gauss_newton.t:448-451).
+ *    They must be allocated with thallo_hip_vector_elems(n) elements (padding for 16-byte access);
+ *  - reductions: a kernel that reduces writes ONE partial per workgroup with a plain store;
+ *    consumers take the quantity as a thallo_sum_t {partials, count} and add the partials in a
+ *    fixed order.  This replaces the reference's warp-shuffle + red.global.add.f32 into one word
+ *    (util.t:40-50, cuda_util.t:287-289,430-439) and its three per-iteration 4-byte memsets and
+ *    one 4-byte D2D copy (gauss_newton.t:1528-1541,1665).
+ */
+#ifndef THALLO_HIP_H
+#define THALLO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* thallo_stream_t;
+
+#define THALLO_HIP_MAX_PARTIALS 1024
+
+/* A deferred deterministic sum: sum_{i<count} partials[i]. count==1 is a plain scalar word
+   (e.g. the result of a cross-rank all-reduce). */
+typedef struct thallo_sum_t {
+    const float* partials;
+    int          count;
+} thallo_sum_t;
+
+long thallo_hip_vector_elems(long n_unknowns);          /* n rounded up to a multiple of 256 */
+int  thallo_hip_device_cu_count(void);                  /* multiprocessor count of the current device */
+
+/* ---------------------------------------------------------------- energy-independent PCG chain */
+
+/* Fused-schedule PCGStep2 (reference gauss_newton.t:801-843, minus the delta update which this
+ * schedule moves into the next PCGStep1):
+ *   alpha = alphaN/alphaD (0 if alphaD==0, GN guard :226-234); r -= alpha*Ap; z = pre*r;
+ *   betaN partials = sum z.r     pre==NULL means the identity preconditioner (:821-825). */
+int thallo_hip_pcg_step2(float* r, const float* Ap, const float* pre, float* z, long n,
+                         thallo_sum_t alphaN, thallo_sum_t alphaD, float* betaN_out, thallo_stream_t stream);
+
+/* Reference-shaped PCGStep2 (gauss_newton.t:801-843) incl. the delta update and, when b != NULL,
+ * the LM q term  q = 0.5*delta.(r+b)  (:832-837).  lm selects the unguarded divide. */
+int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const float* Ap, const float* pre,
+                              float* z, const float* b, long n, thallo_sum_t alphaN, thallo_sum_t alphaD,
+                              float* betaN_out, float* q_out, int lm, thallo_stream_t stream);
+
+/* PCGStep3 (gauss_newton.t:889-899): beta = betaN/alphaN (guarded unless lm); p = z + beta*p. */
+int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t betaN, thallo_sum_t alphaN,
+                         int lm, thallo_stream_t stream);
+
+/* PCGLinearUpdate (gauss_newton.t:901-906) for one unknown image:  X[i] += delta[i] (+ alpha*p[i]
+ * when p != NULL: the fused schedule's last pending delta += alpha*p). */
+int thallo_hip_linear_update(float* X, const float* delta, const float* p, long len,
+                             thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_stream_t stream);
+
+/* out[0] = sum(partials) -- used for cost / model-cost read-back (gauss_newton.t:1128-1150). */
+int thallo_hip_finish_sum(thallo_sum_t s, float* out, thallo_stream_t stream);
+
+/* alpha/beta trace for tests: out[0]=alphaN/alphaD, out[1]=betaN/alphaN with the GN guards. */
+int thallo_hip_alpha_beta(thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_sum_t betaN, float* out2,
+                          thallo_stream_t stream);
+
+/* ---------------------------------------------------------------- E5: tests/minimal/laplacian.t
+ * X unknown float {W,H} (param 0), A float {W,H} (param 1); fit = w*(X-A), reg = x/y forward
+ * differences guarded by InBounds.  xguard: 0 = InBounds(x+1,y+1) as shipped (laplacian.t:11),
+ * 1 = InBounds(x+1,y) (the variant gold.png was made with). */
+int thallo_hip_lapimg_cost(int W, int H, const float* X, const float* A, float w_fit, int xguard,
+                           float* cost_out, thallo_stream_t stream);
+/* fused PCGInit1 (+_Finish) (gauss_newton.t:678-731): r=-J^T F, pre (identity: no UsePreconditioner),
+ * z = pre*r, p_prev = 0, delta = 0, alphaN partials. */
+int thallo_hip_lapimg_pcg_init(int W, int H, const float* X, const float* A, float w_fit, int xguard,
+                               float* r, float* z, float* p_prev, float* delta,
+                               float* alphaN_out, thallo_stream_t stream);
+/* fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k) (gauss_newton.t:734-752,889-899):
+ *   first!=0: p = z (beta=0, no delta update); else beta = betaN/alphaN_prev, alpha = alphaN_prev/alphaD_prev,
+ *   delta += alpha*p_in; p_out = z + beta*p_in;  Ap = J^T J p_out; alphaD partials = sum p_out.Ap */
+int thallo_hip_lapimg_pcg_step1(int W, int H, float w_fit, int xguard,
+                                const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
+                                int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                                float* alphaD_out, thallo_stream_t stream);
+
+/* ---------------------------------------------------------------- E1: examples/image_warping/image_warping.t
+ * Offset float2 (0), Angle float (1) unknown; UrShape float2 (2), Constraints float2 (3), Mask float (4),
+ * w_fitSqrt (5), w_regSqrt (6).  Flat vector layout: [Offset 2*pix+c | Angle 2*N+pix].
+ * Per-GN-iteration precomputed planes (allowed by SURVEY.md section 7 step 3):
+ *   cs    float2 per pixel = (cos Angle, sin Angle)
+ *   flags uint8  per pixel : bit0 = Mask==0 (pixel active, image_warping.t:14-15,23),
+ *                            bit1 = fit residual valid (image_warping.t:27) */
+int thallo_hip_iw_cost(int W, int H, const float* offset, const float* angle, const float* urshape,
+                       const float* constraints, const float* mask, float w_fit, float w_reg,
+                       float* cost_out, thallo_stream_t stream);
+int thallo_hip_iw_pcg_init(int W, int H, const float* offset, const float* angle, const float* urshape,
+                           const float* constraints, const float* mask, float w_fit, float w_reg,
+                           float* r, float* pre, float* z, float* p_prev, float* delta,
+                           float* cs, unsigned char* flags, float* alphaN_out, thallo_stream_t stream);
+int thallo_hip_iw_pcg_step1(int W, int H, const float* cs, const float* urshape, const unsigned char* flags,
+                            float w_fit, float w_reg,
+                            const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
+                            int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                            float* alphaD_out, thallo_stream_t stream);
+
+/* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped
+ * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's
+ * stand-alone applyJTJ roofline measurement. */
+int thallo_hip_iw_apply_jtj(int W, int H, const float* cs, const float* urshape, const unsigned char* flags,
+                            float w_fit, float w_reg, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

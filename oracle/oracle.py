@@ -147,3 +147,18 @@ class Problem:
                                  trace.ctypes.data if want_trace else None, tcap)
         assert n >= 0
         return costs[: n + 1], (trace[:tcap] if want_trace else None)
+
+
+def cpu_port_image_warping(W, H, params, nIterations, lIterations, want_costs=True):
+    """OpenMP port (oracle/cpu_port_image_warping.c) -- bench.py's cpu_baseline. Updates params[0], params[1]
+    in place. Returns dict(costs, seconds_pcg, seconds_total, threads)."""
+    L = lib()
+    L.orc_cpu_port_image_warping.restype = C.c_int
+    L.orc_cpu_port_image_warping.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_int, C.c_int,
+                                                                                    C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    costs = np.zeros(nIterations + 1, np.float64)
+    tp, tt = C.c_double(), C.c_double()
+    th = L.orc_cpu_port_image_warping(W, H, params[0].ctypes.data, params[1].ctypes.data, params[2].ctypes.data,
+                                      params[3].ctypes.data, params[4].ctypes.data, float(params[5]), float(params[6]),
+                                      nIterations, lIterations, costs.ctypes.data if want_costs else None, C.byref(tp), C.byref(tt))
+    return {"costs": costs if want_costs else None, "seconds_pcg": tp.value, "seconds_total": tt.value, "threads": th}

@@ -1,0 +1,239 @@
+"""GPU parity: the HIP path (through the Thallo.h C-ABI and the thallo_hip.h shim) against the CPU
+oracle and the reference's golden images.
+
+Bars: integer/quantised outputs (gold PNG bytes) exact; float trajectories within 1e-5 relative
+(BASELINE.json north star) -- the reference's own float reductions are order-nondeterministic
+(util.t:40-50), so bitwise equality of floats is not defined even reference-vs-reference.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import thallo_amd
+from thallo_amd import api, synthetic as syn
+from helpers import to_device, to_host, rel_err, copy_params
+
+pytestmark = pytest.mark.gpu
+
+COST_RTOL = 1e-5      # per-GN-iteration cost trajectory, BASELINE.json
+VEC_RTOL = 2e-4       # unknown vectors after a full solve (PCG amplifies last-bit differences)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _solve_gpu(fname, dims, params_np, **sp):
+    dev = to_device(params_np)
+    s = api.ThalloSolver(dims, thallo_amd.energy_file(fname))
+    final, costs = s.solve(dev, profiled=True, **sp)
+    return s, dev, np.array(costs), final
+
+
+# ------------------------------------------------------------------ golden images (reference KATs)
+def test_kat_minimal_image_gold_png(torch, golden_dir, orc):
+    """tests/minimal: 512x512 Laplacian, MSVC-rand input, GN10 x PCG10 -> gold.png bytes."""
+    gold = np.fromfile(os.path.join(golden_dir, "minimal_gold.u8"), np.uint8).reshape(512, 512)
+    A = orc.msvc_rand(512 * 512).reshape(512, 512)
+    s, dev, costs, final = _solve_gpu("laplacian_image", (512, 512), [A.copy(), A])
+    out = (to_host(dev[0]) * 255).astype(np.uint8)
+    assert s.energy_name == "laplacian_image"
+    assert (out == gold).all(), f"{(out != gold).sum()} pixels differ"
+    assert len(costs) == 11
+
+
+def test_kat_minimal_image_shipped_guard_matches_oracle(torch, orc):
+    A = orc.msvc_rand(512 * 512).reshape(512, 512)
+    Xo = A.copy()
+    co, _ = orc.Problem(orc.LAPLACIAN_IMAGE, (512, 512), [Xo, A], fconst=[0.2], iconst=[0]).solve()
+    s, dev, costs, _ = _solve_gpu("laplacian_image_shipped_guard", (512, 512), [A.copy(), A])
+    assert rel_err(costs, co) < COST_RTOL
+    assert ((to_host(dev[0]) * 255).astype(np.uint8) == (Xo * 255).astype(np.uint8)).mean() > 0.9999
+
+
+# ------------------------------------------------------------------ image_warping trajectories
+@pytest.mark.parametrize("W,H,nit,lit", [(64, 64, 8, 100), (96, 80, 5, 40), (70, 33, 4, 25), (256, 256, 4, 50), (1, 1, 2, 3), (130, 3, 3, 10)])
+def test_image_warping_cost_trajectory(torch, orc, W, H, nit, lit):
+    p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=nit, lIterations=lit)
+    s, dev, costs, final = _solve_gpu("image_warping", (W, H), p, nIterations=nit, lIterations=lit)
+    assert len(costs) == len(co) == nit + 1
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)
+    assert abs(final - co[-1]) <= COST_RTOL * abs(co[-1])
+    assert rel_err(to_host(dev[0]), po[0]) < VEC_RTOL
+    assert np.abs(to_host(dev[1]) - po[1]).max() < VEC_RTOL * max(1.0, np.abs(po[1]).max())
+    # excluded (masked) pixels are never touched (image_warping.t:14-15)
+    m = p[4] != 0
+    assert (to_host(dev[0])[m] == p[0][m]).all() and (to_host(dev[1])[m] == p[1][m]).all()
+
+
+def test_image_warping_alpha_beta_trace(torch, orc):
+    """alpha_k, beta_k of the first GN step follow the oracle's (early iterations tightly)."""
+    W, H = 96, 64
+    p = syn.image_warping(W, H, n_markers=8)
+    po = copy_params(p)
+    _, tr = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=1, lIterations=30, want_trace=True)
+    dev = to_device(p)
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    s.solve(dev, profiled=True, nIterations=1, lIterations=30)
+    got = np.array(s.alpha_beta_trace())
+    assert got.shape == (30, 2)
+    assert np.abs(got[:10] - tr[:10]).max() <= 2e-5 * np.abs(tr[:10]).max()
+    assert np.abs(got - tr).max() <= 2e-3 * np.abs(tr).max()
+
+
+def test_image_warping_weights_rebound_every_step(torch, orc):
+    """Params are host scalars re-read at Init and every Step (util.t:609-643, gauss_newton.t:1559)."""
+    W, H = 48, 40
+    p = syn.image_warping(W, H, n_markers=6)
+    dev = to_device(p)
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    s.set_solver_parameters(nIterations=2, lIterations=20)
+    wf, wr = C.c_float(p[5]), C.c_float(p[6])
+    params = s.make_params(dev[:5] + [wf, wr])
+    s.init(params)
+    c0 = s.current_cost()
+    wf.value = 2.0 * p[5]
+    assert s.current_cost() == c0          # cost() does not re-bind (gauss_newton.t:1787-1793)
+    s.init(params)                         # Init re-reads the host scalars
+    c1 = s.current_cost()
+    po = copy_params(p); po[5] = 2.0 * p[5]
+    assert abs(c1 - orc.Problem(orc.IMAGE_WARPING, (W, H), po).cost()) <= COST_RTOL * c1
+    assert c1 > c0
+    # ... and so does every Step: one GN step under the doubled weight follows the oracle's
+    wr.value = 0.5 * p[6]
+    assert s.step(params) == 1
+    po[6] = 0.5 * p[6]
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=1, lIterations=20)
+    assert abs(s.current_cost() - co[-1]) <= COST_RTOL * max(co[-1], 1.0)
+
+
+# ------------------------------------------------------------------ kernel-level parity through the shim
+def _shim():
+    L = thallo_amd.lib()
+    L.thallo_hip_vector_elems.restype = C.c_long; L.thallo_hip_vector_elems.argtypes = [C.c_long]
+    return L
+
+
+@pytest.mark.parametrize("W,H", [(64, 16), (100, 37), (256, 128)])
+def test_shim_image_warping_init_and_apply(torch, orc, W, H):
+    """thallo_hip_iw_pcg_init == oracle evalJTF (+guardedInvert), thallo_hip_iw_pcg_step1 == oracle applyJTJ."""
+    L = _shim()
+    p = syn.image_warping(W, H, n_markers=6)
+    pr = orc.Problem(orc.IMAGE_WARPING, (W, H), p)
+    r_o, pre_o = pr.eval_jtf()
+    excl = pr.excluded()
+    N = W * H; n = 3 * N; na = L.thallo_hip_vector_elems(n)
+    dev = to_device(p)
+    f = lambda: torch.zeros(na, dtype=torch.float32, device="cuda")
+    r, pre, z, p0, p1, delta, Ap = f(), f(), f(), f(), f(), f(), f()
+    cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
+    parts = torch.zeros(4 * 1024, dtype=torch.float32, device="cuda")
+    vp = C.c_void_p; fl = C.c_float
+    nb = L.thallo_hip_iw_pcg_init(W, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+                                  vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
+                                  vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(parts.data_ptr()), None)
+    assert nb > 0
+    torch.cuda.synchronize()
+    r_g = to_host(r)[:n]; pre_g = to_host(pre)[:n]
+    scale = np.abs(r_o).max()
+    assert np.abs(r_g - r_o).max() <= 2e-5 * scale
+    inv_o = np.where(excl, 0.0, 1.0 / (1.0 + np.sqrt(pre_o)) ** 2)      # guardedInvert, gauss_newton.t:638-648
+    assert np.abs(pre_g - inv_o).max() <= 2e-6
+    aN = to_host(parts)[:nb].astype(np.float64).sum()
+    assert abs(aN - (r_o.astype(np.float64) ** 2 * inv_o).sum()) <= 1e-5 * aN
+    assert (to_host(z)[:n][excl] == 0).all() and (r_g[excl] == 0).all()
+    # applyJTJ on a random direction: feed it as z with first=1 (p = z)
+    v = np.random.default_rng(3).standard_normal(n).astype(np.float32); v[excl] = 0
+    z.zero_(); z[:n] = torch.from_numpy(v).cuda()
+    s0 = api.SumT(parts.data_ptr(), 1)
+    nb2 = L.thallo_hip_iw_pcg_step1(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
+                                    vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
+                                    1, s0, s0, s0, vp(parts.data_ptr() + 4096), None)
+    assert nb2 > 0
+    torch.cuda.synchronize()
+    Ap_o, d_o = pr.apply_jtj(v)
+    assert np.abs(to_host(Ap)[:n] - Ap_o).max() <= 2e-5 * np.abs(Ap_o).max()
+    assert (to_host(p1)[:n] == v).all()
+    aD = to_host(parts)[1024:1024 + nb2].astype(np.float64).sum()
+    assert abs(aD - d_o) <= 1e-5 * abs(d_o)
+
+
+# ------------------------------------------------------------------ size-independent properties at full size
+def test_full_size_properties_2048(torch):
+    """2048^2 (the benchmark size): J^T J is symmetric PSD and linear; the solve is bitwise reproducible;
+    one GN step with enough PCG iterations decreases the cost."""
+    L = _shim()
+    W = H = 2048
+    p = syn.image_warping(W, H)
+    N = W * H; n = 3 * N; na = L.thallo_hip_vector_elems(n)
+    dev = to_device(p)
+    f = lambda: torch.zeros(na, dtype=torch.float32, device="cuda")
+    r, pre, z, p0, p1, delta, Ap1, Ap2, Ap3 = [f() for _ in range(9)]
+    cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
+    parts = torch.zeros(8 * 1024, dtype=torch.float32, device="cuda")
+    vp = C.c_void_p; fl = C.c_float
+    L.thallo_hip_iw_pcg_init(W, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+                             vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
+                             vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(parts.data_ptr()), None)
+    active = (flags[:N] & 1).bool()
+    act3 = torch.cat([active.repeat_interleave(2), active])
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    a = torch.zeros(na, device="cuda"); b = torch.zeros(na, device="cuda")
+    a[:n] = torch.randn(n, device="cuda", generator=g) * act3; b[:n] = torch.randn(n, device="cuda", generator=g) * act3
+    s0 = api.SumT(parts.data_ptr(), 1)
+
+    def apply(vec, out):
+        nb = L.thallo_hip_iw_pcg_step1(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
+                                       vp(vec.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(out.data_ptr()),
+                                       1, s0, s0, s0, vp(parts.data_ptr() + 4096), None)
+        assert nb > 0
+        torch.cuda.synchronize()
+        return parts[1024:1024 + nb].double().sum().item()
+    dA = apply(a, Ap1); apply(b, Ap2); apply(a + 2 * b, Ap3)
+    ab = (a.double() * Ap2.double()).sum().item(); ba = (b.double() * Ap1.double()).sum().item()
+    assert abs(ab - ba) <= 1e-6 * max(abs(ab), abs(ba))                      # symmetry
+    assert dA >= 0 and abs(dA - (a.double() * Ap1.double()).sum().item()) <= 1e-5 * dA     # fused dot = p.Ap, PSD
+    lin = (Ap3 - (Ap1 + 2 * Ap2)).abs().max().item()
+    assert lin <= 1e-4 * Ap3.abs().max().item()                              # linearity
+    # reproducibility + descent through the public API
+    outs = []
+    for _ in range(2):
+        d2 = to_device(p)
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+        final, costs = s.solve(d2, profiled=True, nIterations=2, lIterations=30)
+        outs.append((costs, d2[0].clone(), d2[1].clone()))
+        s.close()
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert outs[0][0][1] < outs[0][0][0]
+
+
+def test_solver_parameters_and_perf_summary(torch):
+    p = syn.image_warping(64, 64, n_markers=4)
+    s = api.ThalloSolver((64, 64), thallo_amd.energy_file("image_warping"), timing_level=2)
+    assert s.get_solver_parameter("nIterations") == 10 and s.get_solver_parameter("lIterations") == 10   # gauss_newton.t:53-54
+    assert abs(s.get_solver_parameter("trust_region_radius") - 1e4) < 1e-3
+    s.solve(to_device(p), nIterations=3, lIterations=7)
+    assert s.get_solver_parameter("lIterations") == 7
+    ps = s.performance_summary()
+    assert ps["total"]["count"] == 1 and ps["nonlinearIteration"]["count"] == 3 and ps["linearSolve"]["count"] == 3
+    assert ps["total"]["meanMS"] >= ps["linearSolve"]["meanMS"] > 0
+    ks = s.kernel_stats()
+    assert ks["PCGStep1"]["launches"] == 21 and ks["PCGStep2"]["launches"] == 21 and ks["PCGInit1"]["launches"] == 3
+
+
+def test_unknown_energy_and_bad_kind_fail_loudly(torch, tmp_path):
+    f = tmp_path / "x.t"
+    f.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0) }\nr = Residuals { only = X(N()) }\n')
+    with pytest.raises(RuntimeError):
+        api.ThalloSolver((8,), str(f))
+    with pytest.raises(RuntimeError):
+        api.ThalloSolver((8, 8), thallo_amd.energy_file("image_warping"), solverkind="newton")
+    with pytest.raises(RuntimeError):
+        api.ThalloSolver((8, 8), thallo_amd.energy_file("image_warping"), cpu_only=True)

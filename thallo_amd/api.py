@@ -1,0 +1,215 @@
+"""ctypes mirror of include/Thallo.h (the drop-in C API) and a ThalloSolver harness class.
+
+The class mirrors the reference's application harness, examples/shared/ThalloSolver.h:40-112
+(ctor = NewState -> ProblemDefine -> ProblemPlan; solve = SetSolverParameter* -> Solve, or
+Init + while(Step) with a cost read after every step like launchProfiledSolve,
+examples/shared/ThalloUtils.h:75-92), so parity tests read like the reference's own programs.
+
+There is no CPU fallback: a missing libThallo.so or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libThallo.so")
+ENERGY_DIR = os.path.join(_HERE, "energies")
+
+
+class InitializationParameters(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("doublePrecision", "verbosityLevel", "timingLevel",
+                                       "threadsPerBlock", "useAutoscheduler", "cpuOnly")]
+
+
+class PerformanceEntry(C.Structure):
+    _fields_ = [("count", C.c_uint), ("minMS", C.c_double), ("maxMS", C.c_double),
+                ("meanMS", C.c_double), ("stddevMS", C.c_double)]
+
+
+class PerformanceSummary(C.Structure):
+    _fields_ = [(n, PerformanceEntry) for n in ("total", "nonlinearIteration", "nonlinearSetup",
+                                                "linearSolve", "nonlinearResolve")]
+
+
+class SumT(C.Structure):      # thallo_sum_t of include/thallo_hip.h
+    _fields_ = [("partials", C.c_void_p), ("count", C.c_int)]
+
+
+INT_PARAMS = ("nIterations", "lIterations", "residual_reset_period", "nIter")
+
+_lib = None
+
+
+def lib():
+    """Load libThallo.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(make -C thallo_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+    L.Thallo_NewState.argtypes = [InitializationParameters]; L.Thallo_NewState.restype = vp
+    L.Thallo_ProblemDefine.argtypes = [vp, C.c_char_p, C.c_char_p]; L.Thallo_ProblemDefine.restype = vp
+    L.Thallo_ProblemDelete.argtypes = [vp, vp]
+    L.Thallo_ProblemPlan.argtypes = [vp, vp, C.POINTER(C.c_uint)]; L.Thallo_ProblemPlan.restype = vp
+    L.Thallo_PlanFree.argtypes = [vp, vp]
+    L.Thallo_SetSolverParameter.argtypes = [vp, vp, C.c_char_p, vp]
+    L.Thallo_GetSolverParameter.argtypes = [vp, vp, C.c_char_p, vp]
+    L.Thallo_ProblemSolve.argtypes = [vp, vp, vpp]
+    L.Thallo_ProblemInit.argtypes = [vp, vp, vpp]
+    L.Thallo_ProblemStep.argtypes = [vp, vp, vpp]; L.Thallo_ProblemStep.restype = C.c_int
+    L.Thallo_ProblemCurrentCost.argtypes = [vp, vp]; L.Thallo_ProblemCurrentCost.restype = C.c_double
+    L.Thallo_GetPerformanceSummary.argtypes = [vp, vp, C.POINTER(PerformanceSummary)]
+    L.ThalloX_SetStream.argtypes = [vp, vp]
+    L.ThalloX_SetKernelSampling.argtypes = [vp, C.c_int]
+    L.ThalloX_GetKernelStat.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    L.ThalloX_GetKernelStat.restype = C.c_int
+    L.ThalloX_ResetKernelStats.argtypes = [vp]
+    L.ThalloX_GetAlphaBetaTrace.argtypes = [vp, vp, C.c_int]; L.ThalloX_GetAlphaBetaTrace.restype = C.c_int
+    L.ThalloX_PlanEnergyName.argtypes = [vp]; L.ThalloX_PlanEnergyName.restype = C.c_char_p
+    L.ThalloX_LastError.restype = C.c_char_p
+    L.ThalloX_ProblemFileHash.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; L.ThalloX_ProblemFileHash.restype = C.c_ulonglong
+    _lib = L
+    return L
+
+
+def energy_file(name):
+    """Path of a bundled problem specification (thallo_amd/energies/<name>.t)."""
+    p = os.path.join(ENERGY_DIR, name if name.endswith(".t") else name + ".t")
+    if not os.path.exists(p):
+        raise FileNotFoundError(p)
+    return p
+
+
+def last_error():
+    return lib().ThalloX_LastError().decode()
+
+
+def _ptr_of(x):
+    """Device pointer of a torch tensor, host pointer of a ctypes scalar, or a raw int."""
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if isinstance(x, (C.c_float, C.c_int, C.c_double, C.c_uint)):
+        return C.addressof(x)
+    if isinstance(x, int):
+        return x
+    raise TypeError(f"cannot turn {type(x)} into a problem parameter")
+
+
+class ThalloSolver:
+    """NewState -> ProblemDefine -> ProblemPlan, like examples/shared/ThalloSolver.h:43-74."""
+
+    def __init__(self, dims, thallofile, solverkind="gauss_newton", verbosity=0, timing_level=1,
+                 autoschedule=1, double_precision=False, cpu_only=False):
+        L = lib()
+        ip = InitializationParameters(int(double_precision), verbosity, timing_level, 0, autoschedule, int(cpu_only))
+        self._L = L
+        self.state = L.Thallo_NewState(ip)
+        if not self.state:
+            raise RuntimeError("Thallo_NewState failed: " + last_error())
+        self.problem = L.Thallo_ProblemDefine(self.state, os.fsencode(thallofile), solverkind.encode())
+        if not self.problem:
+            raise RuntimeError("Thallo_ProblemDefine failed: " + last_error())
+        self._dims = (C.c_uint * 10)(*dims)          # retained by the plan (thallo.t:1419)
+        self.plan = L.Thallo_ProblemPlan(self.state, self.problem, self._dims)
+        if not self.plan:
+            raise RuntimeError("Thallo_ProblemPlan failed: " + last_error())
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "plan", None):
+            self._L.Thallo_PlanFree(self.state, self.plan); self.plan = None
+        if getattr(self, "problem", None):
+            self._L.Thallo_ProblemDelete(self.state, self.problem); self.problem = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def energy_name(self):
+        return self._L.ThalloX_PlanEnergyName(self.plan).decode()
+
+    def set_solver_parameters(self, **kw):
+        for k, v in kw.items():
+            val = C.c_int(int(v)) if k in INT_PARAMS else C.c_float(float(v))
+            self._L.Thallo_SetSolverParameter(self.state, self.plan, k.encode(), C.addressof(val))
+
+    def get_solver_parameter(self, name):
+        val = C.c_int() if name in INT_PARAMS else C.c_float()
+        self._L.Thallo_GetSolverParameter(self.state, self.plan, name.encode(), C.addressof(val))
+        return val.value
+
+    def make_params(self, problem_params):
+        """void** indexed like the .t Inputs{}: tensors -> device pointers, python floats -> host float*."""
+        keep = []
+        ptrs = []
+        for p in problem_params:
+            if isinstance(p, float):
+                p = C.c_float(p)
+            keep.append(p)
+            ptrs.append(_ptr_of(p))
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        self._keep = (keep, arr)
+        return arr
+
+    def init(self, params):
+        self._L.Thallo_ProblemInit(self.state, self.plan, params)
+
+    def step(self, params):
+        return self._L.Thallo_ProblemStep(self.state, self.plan, params)
+
+    def current_cost(self):
+        return self._L.Thallo_ProblemCurrentCost(self.state, self.plan)
+
+    def solve(self, problem_params, profiled=False, **solver_params):
+        """Returns (final_cost, costs): costs[0] is the initial cost, costs[k] the cost after GN step k
+        when profiled (Init + while(Step) + CurrentCost, ThalloUtils.h:75-92), else just [final]."""
+        self.set_solver_parameters(**solver_params)
+        params = problem_params if isinstance(problem_params, C.Array) else self.make_params(problem_params)
+        costs = []
+        if profiled:
+            self.init(params)
+            costs.append(self.current_cost())
+            while self.step(params):
+                costs.append(self.current_cost())
+        else:
+            self._L.Thallo_ProblemSolve(self.state, self.plan, params)
+        final = self.current_cost()
+        if not profiled:
+            costs.append(final)
+        return final, costs
+
+    def performance_summary(self):
+        s = PerformanceSummary()
+        self._L.Thallo_GetPerformanceSummary(self.state, self.plan, C.byref(s))
+        return {n: {"count": getattr(s, n).count, "minMS": getattr(s, n).minMS, "maxMS": getattr(s, n).maxMS,
+                    "meanMS": getattr(s, n).meanMS, "stddevMS": getattr(s, n).stddevMS} for n, _ in s._fields_}
+
+    # ---- extensions
+    def set_kernel_sampling(self, period):
+        self._L.ThalloX_SetKernelSampling(self.plan, period)
+
+    def reset_kernel_stats(self):
+        self._L.ThalloX_ResetKernelStats(self.plan)
+
+    def kernel_stats(self):
+        out = {}
+        i = 0
+        while True:
+            name = C.c_char_p(); launches = C.c_long(); samples = C.c_long(); total = C.c_double()
+            if self._L.ThalloX_GetKernelStat(self.plan, i, C.byref(name), C.byref(launches), C.byref(samples), C.byref(total)):
+                break
+            out[name.value.decode()] = {"launches": launches.value, "samples": samples.value, "total_ms": total.value,
+                                        "mean_ms": total.value / samples.value if samples.value else None}
+            i += 1
+        return out
+
+    def alpha_beta_trace(self, cap=4096):
+        buf = (C.c_float * (2 * cap))()
+        n = self._L.ThalloX_GetAlphaBetaTrace(self.plan, C.addressof(buf), cap)
+        n = min(n, cap)
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]

@@ -1,0 +1,98 @@
+// device_common.hpp -- wave64 / workgroup primitives shared by every kernel (gfx950 only).
+//
+// Replaces the reference's warp-32 PTX primitives (API/src/cuda_util.t:287-449, util.t:40-50):
+//   reference: 5-step shfl.down, then ONE red.global.add.f32 per warp into a single word
+//              -> order-nondeterministic, 131k same-address atomics per reduction at 2048^2.
+//   here:      6-step wave64 butterfly, LDS across waves, ONE plain store per workgroup into
+//              partial[blockIdx]; the consumer kernel re-sums the <=1024 partials in a fixed
+//              order.  No atomics, no memsets, bitwise reproducible for a fixed launch shape
+//              (MI355X memory-side float atomics serialise at ~12 ns per same-address add).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define THALLO_WAVE 64
+#define THALLO_MAX_PARTIALS 1024   // upper bound on producer grid size for reduced quantities
+
+namespace thallo {
+
+__device__ __forceinline__ float wave_sum_all(float v)
+{   // butterfly: every lane ends with the same total, fixed association order
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
+    return v;
+}
+
+// Sum of `nb` per-workgroup partials written by the previous kernel.  Every wave computes it
+// itself (<= 16 L2-resident dwords per lane), so no barrier is needed and every thread in the
+// grid holds the bit-identical value.
+__device__ __forceinline__ float sum_partials(const float* __restrict__ part, int nb)
+{
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    float s = 0.0f;
+    for (int i = lane; i < nb; i += THALLO_WAVE) s += part[i];
+    return wave_sum_all(s);
+}
+
+// Workgroup reduction -> partial[blockIdx.x].  `red` is >= blockDim.x/64 floats of LDS.
+// Must be called by every thread of the workgroup.
+template <int NQ>
+__device__ __forceinline__ void block_store_partials(float (&v)[NQ], float* __restrict__ const (&out)[NQ], float* red)
+{
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    const int wave = threadIdx.x / THALLO_WAVE;
+    const int nw   = (blockDim.x + THALLO_WAVE - 1) / THALLO_WAVE;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float s = wave_sum_all(v[q]);
+        if (lane == 0) red[q * 16 + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        float s = 0.0f;
+        for (int w = 0; w < nw; ++w) s += red[threadIdx.x * 16 + w];
+        out[threadIdx.x][blockIdx.x] = s;
+    }
+}
+
+__device__ __forceinline__ void block_store_partial(float v, float* __restrict__ out, float* red)
+{
+    float vv[1] = { v };
+    float* __restrict__ const oo[1] = { out };
+    block_store_partials<1>(vv, oo, red);
+}
+
+// safeDivideIfNotLM (gauss_newton.t:226-234): GN guards the zero denominator, LM divides blindly.
+template <bool LM>
+__device__ __forceinline__ float safe_div(float num, float den)
+{
+    if (LM) return num / den;
+    return den != 0.0f ? num / den : 0.0f;
+}
+
+// guardedInvert, CERES flavour (gauss_newton.t:638-648)
+__device__ __forceinline__ float guarded_invert(float d)
+{
+    const float s = 1.0f + sqrtf(d);
+    return 1.0f / (s * s);
+}
+
+// XCD-aware persistent tile schedule.  Workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 labels the XCD group), so group g owns the contiguous tile range
+// [g*T/8, (g+1)*T/8) and its members sweep it together: x/y-neighbouring tiles -- whose halos
+// overlap -- are in flight on the same XCD's L2 at about the same time.  Purely a speed
+// heuristic; correctness never depends on placement.
+struct TileSweep {
+    int first, last, stride, cur;
+    __device__ __forceinline__ TileSweep(int n_tiles)
+    {
+        const int G = (gridDim.x >= 8 && (gridDim.x % 8) == 0) ? 8 : 1;
+        const int g = blockIdx.x % G, l = blockIdx.x / G, per = gridDim.x / G;
+        const long lo = (long)n_tiles * g / G, hi = (long)n_tiles * (g + 1) / G;
+        first = (int)lo + l; last = (int)hi; stride = per; cur = first;
+    }
+    __device__ __forceinline__ bool valid() const { return cur < last; }
+    __device__ __forceinline__ void next() { cur += stride; }
+};
+
+}  // namespace thallo

@@ -1,0 +1,213 @@
+// pcg_kernels.hip -- energy-independent kernels of the PCG chain (gfx950).
+//
+// All are pure streaming kernels over the flat unknown vector (HBM-bound; roofline = bytes/8 TB/s):
+// 16-byte accesses per lane, persistent grid of <= 1024 workgroups, grid-stride loop, one
+// partial per workgroup.  Reference kernels replaced: gauss_newton.t:801-843 (PCGStep2),
+// :889-899 (PCGStep3), :901-906 (PCGLinearUpdate); launch shapes util.t:715-765.
+//
+// Exclusion (fmap.exclude, gauss_newton.t:805): excluded unknowns hold r = p = z = delta = Ap = 0
+// (the init kernels write those zeros), so the flat kernels need no mask test: every update
+// leaves the zeros in place, exactly like the reference's skipped lanes over zero-initialised
+// vectors (thallo.t:1104-1126 initGPU memset).
+#include "device_common.hpp"
+#include "../../include/thallo_hip.h"
+
+using namespace thallo;
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+inline int flat_grid(long n4, int cus)
+{
+    long want = (n4 + BLOCK - 1) / BLOCK;
+    long cap = (long)cus * 4;                       // 4 x 256 threads per CU = 16 waves/CU
+    if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
+    if (cap >= 8) cap -= cap % 8;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+int g_cus = 0;
+int cu_count()
+{
+    if (!g_cus) {
+        int dev = 0; hipGetDevice(&dev);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cus = prop.multiProcessorCount;
+        if (g_cus <= 0) g_cus = 256;
+    }
+    return g_cus;
+}
+
+inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
+
+// r -= alpha*Ap ; z = pre*r ; betaN partial
+template <bool HAS_PRE>
+__global__ __launch_bounds__(BLOCK) void k_step2(float4* __restrict__ r, const float4* __restrict__ Ap,
+                                                  const float4* __restrict__ pre, float4* __restrict__ z, long n4,
+                                                  thallo_sum_t aN, thallo_sum_t aD, float* __restrict__ bN_out)
+{
+    __shared__ float red[16];
+    const float alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
+    float acc = 0.0f;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 rv = r[i]; const float4 av = Ap[i];
+        float4 pv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (HAS_PRE) pv = pre[i];
+        rv.x -= alpha * av.x; rv.y -= alpha * av.y; rv.z -= alpha * av.z; rv.w -= alpha * av.w;
+        float4 zv = make_float4(pv.x * rv.x, pv.y * rv.y, pv.z * rv.z, pv.w * rv.w);
+        r[i] = rv; z[i] = zv;
+        acc += zv.x * rv.x + zv.y * rv.y + zv.z * rv.z + zv.w * rv.w;
+    }
+    block_store_partial(acc, bN_out, red);
+}
+
+// reference-shaped PCGStep2 incl. delta update and optional LM q
+template <bool HAS_PRE, bool LM, bool HAS_B>
+__global__ __launch_bounds__(BLOCK) void k_step2_full(float4* __restrict__ delta, const float4* __restrict__ p,
+                                                       float4* __restrict__ r, const float4* __restrict__ Ap,
+                                                       const float4* __restrict__ pre, float4* __restrict__ z,
+                                                       const float4* __restrict__ b, long n4,
+                                                       thallo_sum_t aN, thallo_sum_t aD,
+                                                       float* __restrict__ bN_out, float* __restrict__ q_out)
+{
+    __shared__ float red[32];
+    const float alpha = safe_div<LM>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
+    float acc[2] = { 0.0f, 0.0f };
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 dv = delta[i]; const float4 pp = p[i];
+        float4 rv = r[i]; const float4 av = Ap[i];
+        float4 pv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (HAS_PRE) pv = pre[i];
+        dv.x += alpha * pp.x; dv.y += alpha * pp.y; dv.z += alpha * pp.z; dv.w += alpha * pp.w;
+        rv.x -= alpha * av.x; rv.y -= alpha * av.y; rv.z -= alpha * av.z; rv.w -= alpha * av.w;
+        float4 zv = make_float4(pv.x * rv.x, pv.y * rv.y, pv.z * rv.z, pv.w * rv.w);
+        delta[i] = dv; r[i] = rv; z[i] = zv;
+        acc[0] += zv.x * rv.x + zv.y * rv.y + zv.z * rv.z + zv.w * rv.w;
+        if (HAS_B) {
+            const float4 bv = b[i];
+            acc[1] += 0.5f * (dv.x * (rv.x + bv.x) + dv.y * (rv.y + bv.y) + dv.z * (rv.z + bv.z) + dv.w * (rv.w + bv.w));
+        }
+    }
+    if (HAS_B) {
+        float* __restrict__ const outs[2] = { bN_out, q_out };
+        block_store_partials<2>(acc, outs, red);
+    } else {
+        block_store_partial(acc[0], bN_out, red);
+    }
+}
+
+template <bool LM>
+__global__ __launch_bounds__(BLOCK) void k_step3(float4* __restrict__ p, const float4* __restrict__ z, long n4,
+                                                  thallo_sum_t bN, thallo_sum_t aN)
+{
+    const float beta = safe_div<LM>(sum_partials(bN.partials, bN.count), sum_partials(aN.partials, aN.count));
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 pv = p[i]; const float4 zv = z[i];
+        pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y; pv.z = zv.z + beta * pv.z; pv.w = zv.w + beta * pv.w;
+        p[i] = pv;
+    }
+}
+
+// X += delta (+ alpha*p).  X is a caller buffer of exactly `len` floats (not padded): scalar tail.
+template <bool HAS_P>
+__global__ __launch_bounds__(BLOCK) void k_linear_update(float* __restrict__ X, const float* __restrict__ delta,
+                                                          const float* __restrict__ p, long len,
+                                                          thallo_sum_t aN, thallo_sum_t aD)
+{
+    float alpha = 0.0f;
+    if (HAS_P) alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < len; i += (long)gridDim.x * BLOCK) {
+        float d = delta[i];
+        if (HAS_P) d += alpha * p[i];
+        X[i] = X[i] + d;
+    }
+}
+
+__global__ void k_finish_sum(thallo_sum_t s, float* __restrict__ out)
+{
+    const float v = sum_partials(s.partials, s.count);
+    if (threadIdx.x == 0) out[0] = v;
+}
+
+__global__ void k_alpha_beta(thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* __restrict__ out)
+{
+    const float n = sum_partials(aN.partials, aN.count);
+    const float alpha = safe_div<false>(n, sum_partials(aD.partials, aD.count));
+    const float beta = safe_div<false>(sum_partials(bN.partials, bN.count), n);
+    if (threadIdx.x == 0) { out[0] = alpha; out[1] = beta; }
+}
+
+}  // namespace
+
+extern "C" {
+
+long thallo_hip_vector_elems(long n) { return (n + 255) / 256 * 256; }
+int thallo_hip_device_cu_count(void) { return cu_count(); }
+
+int thallo_hip_pcg_step2(float* r, const float* Ap, const float* pre, float* z, long n,
+                         thallo_sum_t aN, thallo_sum_t aD, float* bN_out, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4;
+    const int grid = flat_grid(n4, cu_count());
+    hipStream_t s = (hipStream_t)stream;
+    if (pre) hipLaunchKernelGGL(k_step2<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out);
+    else     hipLaunchKernelGGL(k_step2<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
+int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const float* Ap, const float* pre,
+                              float* z, const float* b, long n, thallo_sum_t aN, thallo_sum_t aD,
+                              float* bN_out, float* q_out, int lm, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4;
+    const int grid = flat_grid(n4, cu_count());
+    hipStream_t s = (hipStream_t)stream;
+#define L2F(PRE, LMF, HB) hipLaunchKernelGGL((k_step2_full<PRE, LMF, HB>), dim3(grid), dim3(BLOCK), 0, s, \
+        (float4*)delta, (const float4*)p, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, (const float4*)b, n4, aN, aD, bN_out, q_out)
+    const bool hp = pre != nullptr, hb = (b != nullptr && q_out != nullptr);
+    if (hp) { if (lm) { if (hb) L2F(true, true, true); else L2F(true, true, false); } else { if (hb) L2F(true, false, true); else L2F(true, false, false); } }
+    else    { if (lm) { if (hb) L2F(false, true, true); else L2F(false, true, false); } else { if (hb) L2F(false, false, true); else L2F(false, false, false); } }
+#undef L2F
+    int e = check_launch();
+    return e ? e : grid;
+}
+
+int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t bN, thallo_sum_t aN, int lm, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4;
+    const int grid = flat_grid(n4, cu_count());
+    hipStream_t s = (hipStream_t)stream;
+    if (lm) hipLaunchKernelGGL(k_step3<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)p, (const float4*)z, n4, bN, aN);
+    else    hipLaunchKernelGGL(k_step3<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)p, (const float4*)z, n4, bN, aN);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
+int thallo_hip_linear_update(float* X, const float* delta, const float* p, long len,
+                             thallo_sum_t aN, thallo_sum_t aD, thallo_stream_t stream)
+{
+    const int grid = flat_grid(len, cu_count());
+    hipStream_t s = (hipStream_t)stream;
+    if (p) hipLaunchKernelGGL(k_linear_update<true>, dim3(grid), dim3(BLOCK), 0, s, X, delta, p, len, aN, aD);
+    else   hipLaunchKernelGGL(k_linear_update<false>, dim3(grid), dim3(BLOCK), 0, s, X, delta, p, len, aN, aD);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
+int thallo_hip_finish_sum(thallo_sum_t sum, float* out, thallo_stream_t stream)
+{
+    hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, sum, out);
+    return check_launch();
+}
+
+int thallo_hip_alpha_beta(thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out2, thallo_stream_t stream)
+{
+    hipLaunchKernelGGL(k_alpha_beta, dim3(1), dim3(64), 0, (hipStream_t)stream, aN, aD, bN, out2);
+    return check_launch();
+}
+
+}  // extern "C"

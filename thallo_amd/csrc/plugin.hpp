@@ -1,0 +1,106 @@
+// plugin.hpp -- host-side seam between the GN/LM driver and one energy's kernels.
+//
+// Mirrors the reference's per-residual-group function map `fmap`
+// (API/src/thallo.t:444-456; consumed at API/src/gauss_newton.t:677,733,979,997-1095):
+// cost / evalJTF(+PCGInit fusion) / applyJTJ(+PCGStep1 fusion) / exclude, plus the parameter
+// binding of API/src/util.t:609-643.  Each plugin only forwards to the C-ABI shim in
+// include/thallo_hip.h, so the same kernels are reachable from a Terra host layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/thallo_hip.h"
+
+namespace thallo {
+
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+// Sampled / full per-kernel hipEvent timing (reference: util.t:774-790 at timingLevel >= 2).
+class KernelTimer {
+public:
+    struct Stat { std::string name; long launches = 0; long samples = 0; double total_ms = 0; double sq_ms = 0;
+                  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+    int period = 0;          // 0 = off, 1 = every launch
+    bool invasive = false;   // timingLevel 3: device-sync around timed launches
+    ~KernelTimer();
+    int  begin(const char* name, hipStream_t s);   // returns slot or -1
+    void end(int slot, hipStream_t s);
+    void collect();                                 // synchronises, folds pending events into totals
+    void reset();
+    std::vector<Stat> stats;
+private:
+    std::map<std::string, int> index_;
+    hipEvent_t cur_start_ = nullptr;
+    std::vector<hipEvent_t> pool_;
+    hipEvent_t get_event();
+};
+
+struct LaunchCtx {
+    hipStream_t stream = nullptr;
+    KernelTimer* timer = nullptr;
+};
+
+// RAII bracket used by plugins / driver around each shim call.
+struct TimedLaunch {
+    LaunchCtx& c; int slot;
+    TimedLaunch(LaunchCtx& ctx, const char* name) : c(ctx), slot(ctx.timer ? ctx.timer->begin(name, ctx.stream) : -1) {}
+    ~TimedLaunch() { if (slot >= 0) c.timer->end(slot, c.stream); }
+};
+
+// Solver vectors of PlanData (gauss_newton.t:282-323), flat layout, each `n_alloc` floats.
+struct SolverVectors {
+    long n = 0, n_alloc = 0;
+    float *delta = nullptr, *r = nullptr, *z = nullptr, *Ap = nullptr, *pre = nullptr;
+    float *p[2] = { nullptr, nullptr };          // ping-pong: the fused step reads p[cur], writes p[cur^1]
+    float *b = nullptr, *Adelta = nullptr, *CtC = nullptr, *SSq = nullptr, *prevX = nullptr;   // LM only
+};
+
+struct UnknownImage { int param_index; long n_floats; };
+
+class EnergyPlugin {
+public:
+    virtual ~EnergyPlugin() {}
+    virtual const char* name() const = 0;
+    virtual long n_unknowns() const = 0;
+    virtual const std::vector<UnknownImage>& unknown_images() const = 0;   // declaration order
+    virtual bool use_preconditioner() const = 0;
+    // util.t:609-643: read the void** (device pointers for arrays, host pointers for Params).  Called at
+    // Init and at every Step, so callers may change weights / buffers between steps.
+    virtual int bind(void** params) = 0;
+    // once per bind at Init (e.g. graph incidence lists); default nothing
+    virtual int prepare(LaunchCtx&) { return 0; }
+    // fmap.cost -> partials; returns the partial count or <0
+    virtual int cost(LaunchCtx&, float* cost_out) = 0;
+    // PCGInit1 (+_Finish): r, pre (already inverted), z = pre*r, p[cur]=0, delta=0, alphaN partials
+    virtual int pcg_init(LaunchCtx&, SolverVectors&, int cur, float* alphaN_out) = 0;
+    // fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k): reads p[cur], writes p[cur^1], Ap, alphaD partials
+    virtual int pcg_step1(LaunchCtx&, SolverVectors&, int cur, bool first,
+                          thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev, float* alphaD_out) = 0;
+    // pointer to unknown image k as currently bound
+    virtual float* unknown_ptr(int k) = 0;
+};
+
+struct DeviceBuffer {
+    void* ptr = nullptr; size_t bytes = 0;
+    int alloc(size_t n);
+    void release();
+    ~DeviceBuffer() { release(); }
+};
+
+// .t front-end: recognise a bundled energy (frontend.cpp)
+struct ProblemSpec {
+    std::string file;
+    std::string energy;            // plugin id, "" if unknown
+    std::map<std::string, double> constants;   // literals lifted from the file (e.g. w_fit)
+    int  n_dims = 0;
+    bool verified_body = false;    // body hash matches a known bundled file
+    unsigned long long body_hash = 0;
+    std::string diagnostic;
+};
+bool parse_problem_file(const char* filename, ProblemSpec& out);
+
+EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims);
+
+}  // namespace thallo

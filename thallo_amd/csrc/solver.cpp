@@ -1,0 +1,314 @@
+// solver.cpp -- see solver.hpp.
+#include "solver.hpp"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace thallo {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    fprintf(stderr, "[thallo] error: %s\n", g_err);
+}
+const char* last_error() { return g_err; }
+
+#define HIP_OK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) set_error("%s failed: %s", #call, hipGetErrorString(e__)); } while (0)
+
+// ------------------------------------------------------------------ KernelTimer
+hipEvent_t KernelTimer::get_event()
+{
+    if (!pool_.empty()) { hipEvent_t e = pool_.back(); pool_.pop_back(); return e; }
+    hipEvent_t e = nullptr; HIP_OK(hipEventCreate(&e)); return e;
+}
+int KernelTimer::begin(const char* name, hipStream_t s)
+{
+    auto it = index_.find(name);
+    int idx;
+    if (it == index_.end()) { idx = (int)stats.size(); stats.emplace_back(); stats.back().name = name; index_[name] = idx; }
+    else idx = it->second;
+    Stat& st = stats[idx];
+    const long n = st.launches++;
+    if (period <= 0 || (n % period) != 0) return -1;
+    if (invasive) hipDeviceSynchronize();
+    cur_start_ = get_event();
+    hipEventRecord(cur_start_, s);
+    return idx;
+}
+void KernelTimer::end(int slot, hipStream_t s)
+{
+    if (invasive) hipDeviceSynchronize();
+    hipEvent_t e = get_event();
+    hipEventRecord(e, s);
+    stats[slot].pending.emplace_back(cur_start_, e);
+    cur_start_ = nullptr;
+}
+void KernelTimer::collect()
+{
+    for (auto& st : stats) {
+        for (auto& pr : st.pending) {
+            hipEventSynchronize(pr.second);
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { st.samples++; st.total_ms += ms; st.sq_ms += (double)ms * ms; }
+            pool_.push_back(pr.first); pool_.push_back(pr.second);
+        }
+        st.pending.clear();
+    }
+}
+void KernelTimer::reset() { collect(); for (auto& st : stats) { st.launches = st.samples = 0; st.total_ms = st.sq_ms = 0; } }
+KernelTimer::~KernelTimer()
+{
+    for (auto& st : stats) for (auto& pr : st.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto e : pool_) hipEventDestroy(e);
+}
+
+// ------------------------------------------------------------------ CoarseTimer
+int CoarseTimer::start(const char* name, hipStream_t s)
+{
+    Info i; i.name = name; i.start = i.end = nullptr;
+    HIP_OK(hipEventCreate(&i.start)); HIP_OK(hipEventCreate(&i.end));
+    hipEventRecord(i.start, s);
+    events.push_back(i);
+    return (int)events.size() - 1;
+}
+void CoarseTimer::stop(int idx, hipStream_t s) { if (idx >= 0) hipEventRecord(events[idx].end, s); }
+void CoarseTimer::cleanup()
+{
+    for (auto& i : events) { if (i.start) hipEventDestroy(i.start); if (i.end) hipEventDestroy(i.end); }
+    events.clear();
+}
+
+namespace {
+struct Running { unsigned count = 0; double sum = 0, sq = 0, mn = 0, mx = 0; };
+void upd(Running& r, double v)
+{   // util.t:428-444 RunningStats
+    if (!r.count) { r.mn = r.mx = v; } else { r.mn = std::fmin(r.mn, v); r.mx = std::fmax(r.mx, v); }
+    r.count++; r.sum += v; r.sq += v * v;
+}
+Thallo_PerformanceEntry entry(const Running& r)
+{   // util.t:495-508 computeSummary
+    Thallo_PerformanceEntry e; memset(&e, 0, sizeof(e));
+    if (!r.count) return e;
+    const double mean = r.sum / r.count, var = r.sq / r.count - mean * mean;
+    e.count = r.count; e.meanMS = mean; e.minMS = r.mn; e.maxMS = r.mx; e.stddevMS = std::sqrt(std::fabs(var));
+    return e;
+}
+}  // namespace
+
+void CoarseTimer::evaluate(Thallo_PerformanceSummary* out, bool print_table, KernelTimer* kt)
+{   // util.t:516-593
+    hipDeviceSynchronize();
+    std::vector<std::string> names; std::vector<Running> stats;
+    for (auto& i : events) {
+        float ms = 0.0f;
+        hipEventSynchronize(i.end);
+        if (hipEventElapsedTime(&ms, i.start, i.end) != hipSuccess) continue;
+        size_t k = 0; for (; k < names.size(); ++k) if (names[k] == i.name) break;
+        if (k == names.size()) { names.push_back(i.name); stats.emplace_back(); }
+        upd(stats[k], ms);
+    }
+    auto get = [&](const char* n) { for (size_t k = 0; k < names.size(); ++k) if (names[k] == n) return entry(stats[k]); return entry(Running()); };
+    out->total = get("Total");
+    out->nonlinearIteration = get("Nonlinear Iteration");
+    out->nonlinearSetup = get("Nonlinear Setup");
+    out->linearSolve = get("Linear Solve");
+    out->nonlinearResolve = get("Nonlinear Finish");
+    if (print_table) {
+        printf("\n|        Kernel        |   Count  | Total(ms) | Average(ms) | Std. Dev(ms) |\n");
+        printf("|----------------------|----------|-----------|-------------|--------------|\n");
+        for (size_t k = 0; k < names.size(); ++k) {
+            const Thallo_PerformanceEntry e = entry(stats[k]);
+            printf("| %-20s |   %4u   | %8.3f  |   %8.4f  |   %8.4f   |\n", names[k].c_str(), e.count, stats[k].sum, e.meanMS, e.stddevMS);
+        }
+        if (kt) {
+            kt->collect();
+            for (auto& st : kt->stats) if (st.samples) {
+                const double mean = st.total_ms / st.samples;
+                const double sd = std::sqrt(std::fabs(st.sq_ms / st.samples - mean * mean));
+                printf("| %-20s |   %4ld   | %8.3f  |   %8.4f  |   %8.4f   |\n", st.name.c_str(), st.samples, st.total_ms, mean, sd);
+            }
+        }
+        printf("|--------------------------------------------------------------------------|\n");
+    }
+}
+
+// ------------------------------------------------------------------ Plan
+Plan::Plan(EnergyPlugin* pl, const Thallo_InitializationParameters& ip_, bool lm, unsigned* dims_)
+    : plugin(pl), ip(ip_), dims(dims_), lm_(lm)
+{
+    memset(&summary, 0, sizeof(summary));
+    v_.n = plugin->n_unknowns();
+    v_.n_alloc = thallo_hip_vector_elems(v_.n);
+    float** vecs[] = { &v_.delta, &v_.r, &v_.z, &v_.Ap, &v_.pre, &v_.p[0], &v_.p[1] };
+    for (float** vp : vecs) {     // zero-filled like UnknownType:initGPU (thallo.t:1104-1126)
+        DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b);
+        if (b->alloc((size_t)v_.n_alloc * sizeof(float))) return;
+        *vp = (float*)b->ptr;
+    }
+    if (scratch_.alloc(64 * sizeof(float))) return;
+    ctx.timer = &ktimer;
+    if (ip.timingLevel >= 2) ktimer.period = 1;
+    if (ip.timingLevel >= 3) ktimer.invasive = true;
+    if (ensure_slots(sp.lIterations)) return;
+    ok_ = true;
+}
+
+Plan::~Plan()
+{
+    hipDeviceSynchronize();
+    for (auto b : bufs_) delete b;
+    delete plugin;
+}
+
+int Plan::ensure_slots(int L)
+{
+    const int need = 2 * L + 6;
+    if (need <= parts_slots_) return 0;
+    hipDeviceSynchronize();
+    if (parts_.alloc((size_t)need * THALLO_HIP_MAX_PARTIALS * sizeof(float))) return -1;
+    parts_slots_ = need; nb_.assign(need, 1);
+    return 0;
+}
+
+void Plan::set_param(const char* name, const void* value)
+{   // gauss_newton.t:1828-1844
+#define SETF(f) if (!strcmp(name, #f)) { sp.f = *(const float*)value; return; }
+#define SETI(f) if (!strcmp(name, #f)) { sp.f = *(const int*)value; return; }
+    SETF(min_relative_decrease) SETF(min_trust_region_radius) SETF(max_trust_region_radius) SETF(q_tolerance)
+    SETF(function_tolerance) SETF(trust_region_radius) SETF(radius_decrease_factor) SETF(min_lm_diagonal)
+    SETF(max_lm_diagonal) SETF(max_solver_time_in_seconds)
+    SETI(residual_reset_period) SETI(nIter) SETI(nIterations) SETI(lIterations)
+#undef SETF
+#undef SETI
+    if (ip.verbosityLevel > 0) printf("Warning: tried to set nonexistent solver parameter %s\n", name);
+}
+void Plan::get_param(const char* name, void* value)
+{   // gauss_newton.t:1845-1862
+#define GETF(f) if (!strcmp(name, #f)) { *(float*)value = sp.f; return; }
+#define GETI(f) if (!strcmp(name, #f)) { *(int*)value = sp.f; return; }
+    GETF(min_relative_decrease) GETF(min_trust_region_radius) GETF(max_trust_region_radius) GETF(q_tolerance)
+    GETF(function_tolerance) GETF(trust_region_radius) GETF(radius_decrease_factor) GETF(min_lm_diagonal)
+    GETF(max_lm_diagonal) GETF(max_solver_time_in_seconds)
+    GETI(residual_reset_period) GETI(nIter) GETI(nIterations) GETI(lIterations)
+#undef GETF
+#undef GETI
+    if (ip.verbosityLevel > 0) printf("Warning: tried to get nonexistent solver parameter %s\n", name);
+}
+
+float Plan::compute_cost()
+{   // gauss_newton.t:1128-1136 -- partials instead of memset + atomics; same blocking 4-byte read-back
+    const int nb = plugin->cost(ctx, slot(0));
+    if (nb < 0) { set_error("cost kernel launch failed (%d)", nb); return NAN; }
+    nb_[0] = nb;
+    thallo_hip_finish_sum(sum(0), (float*)scratch_.ptr, ctx.stream);
+    float f = 0.0f;
+    HIP_OK(hipMemcpyAsync(&f, scratch_.ptr, sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
+    HIP_OK(hipStreamSynchronize(ctx.stream));
+    return f;
+}
+
+void Plan::init(void** params)
+{   // gauss_newton.t:1166-1198
+    if (!ok_) return;
+    finalized_ = false;
+    timer_.cleanup();
+    ev_total_ = timer_.start("Total", ctx.stream);
+    if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return; }
+    plugin->prepare(ctx);
+    sp.nIter = 0;
+    prev_cost_ = compute_cost();
+    printf("Initial cost: %g\n", prev_cost_);
+}
+
+void Plan::finalize()
+{   // gauss_newton.t:1200-1212
+    prev_cost_ = compute_cost();
+    if (ip.verbosityLevel > 0) printf("final cost=%g\n", prev_cost_);
+    hipDeviceSynchronize();
+    timer_.stop(ev_total_, ctx.stream);
+    timer_.evaluate(&summary, ip.verbosityLevel > 0, &ktimer);
+    timer_.cleanup();
+    finalized_ = true;
+}
+
+double Plan::cost()
+{   // gauss_newton.t:1787-1793
+    if (!ok_) return 0.0;
+    if (!finalized_) prev_cost_ = compute_cost();
+    return (double)prev_cost_;
+}
+
+int Plan::step(void** params)
+{   // gauss_newton.t:1545-1785, GN branch, fused schedule (DESIGN.md "PCG schedule")
+    if (!ok_) return 0;
+    if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return 0; }
+    if (sp.nIter >= sp.nIterations) { if (!finalized_) finalize(); return 0; }
+    const int L = sp.lIterations;
+    if (ensure_slots(L)) return 0;
+    hipStream_t s = ctx.stream;
+    const int ev_iter = timer_.start("Nonlinear Iteration", s);
+    const int ev_setup = timer_.start("Nonlinear Setup", s);
+    const int B = 2;                       // slot layout: alphaN_k = B+2k, alphaD_k = B+2k+1, betaN_k = B+2k+2
+    cur_ = 0;
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
+    nb_[B] = nb;
+    timer_.stop(ev_setup, s);
+    const int ev_lin = timer_.start("Linear Solve", s);
+    for (int k = 0; k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        // PCGStep1 (+ previous iteration's PCGStep3 and delta update)
+        thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), bNp = sum(jN);
+        nb = plugin->pcg_step1(ctx, v_, cur_, k == 0, aNp, aDp, bNp, slot(jD));
+        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
+        nb_[jD] = nb; cur_ ^= 1;
+        {   // PCGStep2 (r, z, betaN)
+            TimedLaunch t(ctx, "PCGStep2");
+            nb = thallo_hip_pcg_step2(v_.r, v_.Ap, plugin->use_preconditioner() ? v_.pre : nullptr, v_.z, v_.n,
+                                      sum(jN), sum(jD), slot(jB), s);
+        }
+        if (nb < 0) { set_error("PCGStep2 launch failed (%d)", nb); return 0; }
+        nb_[jB] = nb;
+    }
+    last_l_iters = L;
+    timer_.stop(ev_lin, s);
+    const int ev_fin = timer_.start("Nonlinear Finish", s);
+    {   // PCGLinearUpdate, including the last pending delta += alpha*p
+        const auto& imgs = plugin->unknown_images();
+        long off = 0;
+        for (size_t k = 0; k < imgs.size(); ++k) {
+            TimedLaunch t(ctx, "PCGLinearUpdate");
+            const int jN = B + 2 * (L - 1), jD = jN + 1;
+            if (L > 0) thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_] + off, imgs[k].n_floats, sum(jN), sum(jD), s);
+            else       thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
+            off += imgs[k].n_floats;
+        }
+    }
+    sp.nIter++;
+    timer_.stop(ev_fin, s);
+    timer_.stop(ev_iter, s);
+    if (sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779
+        hipEvent_t q = nullptr; hipEventCreate(&q); hipEventRecord(q, s); hipEventSynchronize(q);
+        float ms = 0.0f; hipEventElapsedTime(&ms, timer_.events[ev_total_].start, q); hipEventDestroy(q);
+        if (ms / 1000.0f > sp.max_solver_time_in_seconds) { finalize(); return 0; }
+    }
+    return 1;
+}
+
+int Plan::alpha_beta_trace(float* out_pairs, int cap)
+{   // the partial slots of the last step are still resident: recompute alpha_k, beta_k from them
+    const int L = last_l_iters, B = 2;
+    if (!ok_ || L <= 0) return 0;
+    if (trace_.bytes < (size_t)L * 2 * sizeof(float) && trace_.alloc((size_t)L * 2 * sizeof(float))) return 0;
+    for (int k = 0; k < L; ++k)
+        thallo_hip_alpha_beta(sum(B + 2 * k), sum(B + 2 * k + 1), sum(B + 2 * k + 2), (float*)trace_.ptr + 2 * k, ctx.stream);
+    const int n = L < cap ? L : cap;
+    HIP_OK(hipMemcpyAsync(out_pairs, trace_.ptr, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
+    HIP_OK(hipStreamSynchronize(ctx.stream));
+    return L;
+}
+
+}  // namespace thallo

@@ -1,0 +1,86 @@
+// solver.hpp -- Gauss-Newton / Levenberg-Marquardt outer step + PCG inner loop (host driver).
+// Restates API/src/gauss_newton.t:1166-1198 (init), :1545-1785 (step), :1200-1212 (finalize),
+// :1787-1799 (cost / summary), :1806-1862 (solver parameters), :1963-2071 (makePlan) for the
+// fused MI355X schedule documented in DESIGN.md.
+#pragma once
+#include "plugin.hpp"
+#include "../../include/Thallo.h"
+
+namespace thallo {
+
+struct SolverParameters {   // gauss_newton.t:200-216, defaults :41-55
+    float min_relative_decrease = 1e-3f;
+    float min_trust_region_radius = 1e-32f;
+    float max_trust_region_radius = 1e16f;
+    float q_tolerance = 0.0001f;
+    float function_tolerance = 0.000001f;
+    float trust_region_radius = 1e4f;
+    float radius_decrease_factor = 2.0f;
+    float min_lm_diagonal = 1e-6f;
+    float max_lm_diagonal = 1e32f;
+    float max_solver_time_in_seconds = 0.0f;
+    int residual_reset_period = 10;
+    int nIter = 0;
+    int nIterations = 10;
+    int lIterations = 10;
+};
+
+// util.Timer (util.t:446-541) with hipEvents; names as in gauss_newton.t:1173,1563-1564,1611,1690
+class CoarseTimer {
+public:
+    struct Info { std::string name; hipEvent_t start, end; };
+    std::vector<Info> events;
+    int  start(const char* name, hipStream_t s);
+    void stop(int idx, hipStream_t s);
+    void evaluate(Thallo_PerformanceSummary* out, bool print_table, KernelTimer* kt);
+    void cleanup();
+    ~CoarseTimer() { cleanup(); }
+};
+
+class Plan {
+public:
+    Plan(EnergyPlugin* plugin, const Thallo_InitializationParameters& ip, bool lm, unsigned* dims);
+    ~Plan();
+    bool ok() const { return ok_; }
+
+    void init(void** params);
+    int  step(void** params);
+    double cost();
+    void set_param(const char* name, const void* value);
+    void get_param(const char* name, void* value);
+    int  alpha_beta_trace(float* out_pairs, int cap);
+
+    EnergyPlugin* plugin;
+    SolverParameters sp;
+    Thallo_InitializationParameters ip;
+    Thallo_PerformanceSummary summary;
+    LaunchCtx ctx;
+    KernelTimer ktimer;
+    std::vector<float> ab_trace;   // alpha,beta per PCG iteration of the last step
+    int last_l_iters = 0;
+    unsigned* dims;
+
+private:
+    bool ok_ = false;
+    bool lm_ = false;
+    bool finalized_ = true;
+    float prev_cost_ = 0.0f;
+    SolverVectors v_;
+    std::vector<DeviceBuffer*> bufs_;
+    DeviceBuffer parts_;            // reduction partial slots: (2*L+4) x THALLO_HIP_MAX_PARTIALS floats
+    int parts_slots_ = 0;
+    DeviceBuffer scratch_;          // a few scalar words (cost, trace)
+    DeviceBuffer trace_;
+    std::vector<int> nb_;           // partial count per slot
+    CoarseTimer timer_;
+    int ev_total_ = -1;
+    int cur_ = 0;
+
+    float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
+    thallo_sum_t sum(int j) { thallo_sum_t s; s.partials = slot(j); s.count = nb_[j]; return s; }
+    int  ensure_slots(int L);
+    float compute_cost();
+    void finalize();
+};
+
+}  // namespace thallo

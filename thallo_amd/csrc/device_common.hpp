@@ -95,4 +95,33 @@ struct TileSweep {
     __device__ __forceinline__ void next() { cur += stride; }
 };
 
+
+// Cache-policy helpers.  `nt` selects the non-temporal (streaming) form: data that is touched once per
+// sweep and not again before ~600 MB of other traffic (delta, r, pre, the per-GN constant planes)
+// should not displace the vectors that ARE re-read by the next kernel (Ap, z, p) from the 256 MiB
+// Infinity Cache.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ldf(const float* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ float2 ldf2(const float2* p, bool nt)
+{
+    if (nt) { const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p)); return make_float2(v.x, v.y); }
+    return *p;
+}
+__device__ __forceinline__ float4 ldf4(const float4* p, bool nt)
+{
+    if (nt) { const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *p;
+}
+__device__ __forceinline__ unsigned char ldb(const unsigned char* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void stf(float* p, float v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void stf2(float2* p, float2 v, bool nt)
+{
+    if (nt) { v2f w; w.x = v.x; w.y = v.y; __builtin_nontemporal_store(w, reinterpret_cast<v2f*>(p)); } else *p = v;
+}
+__device__ __forceinline__ void stf4(float4* p, float4 v, bool nt)
+{
+    if (nt) { v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<v4f*>(p)); } else *p = v;
+}
+
 }  // namespace thallo

@@ -38,14 +38,20 @@ inline Geo make_geo(int W, int H)
     Geo g; g.W = W; g.H = H; g.tx = (W + TW - 1) / TW; g.ty = (H + TH - 1) / TH; g.ntiles = g.tx * g.ty;
     return g;
 }
-inline int grid_for(const Geo& g)
+inline int grid_for(const Geo& g, int per_cu = 4)
 {
-    int cap = thallo_hip_device_cu_count() * 4;            // LDS: 4 x 38 KB per CU
+    int cap = thallo_hip_device_cu_count() * per_cu;       // LDS: 4 x 38 KB per CU
     if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
     cap -= cap % 8;
     return g.ntiles < cap ? g.ntiles : cap;
 }
 inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
+
+// diagnostic switch for tools/microbench.py only (0 = normal): 1 = skip stage B arithmetic, 2 = skip global loads
+int g_iw_debug = 0;
+int g_iw_variant = 2;   // 0 = two-phase tile kernel, 1 = pipelined 4 WG/CU (spills), 2 = pipelined 3 WG/CU (default)
+int g_nt_mask = 1;      // cache policy bits (k_step1p): 1 = delta non-temporal (measured +1-3 %% PCG it/s at 2048^2, tools/sweep_nt.sh)
+int g_iw_shape = 0;     // pipelined tile shape: 0 = 64x16, 1 = 128x8, 2 = 256x4, 3 = 32x32
 
 struct Tile {
     float px[LN], py[LN], pa[LN];   // step: CG direction p ; init: offset.x, offset.y, (unused)
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(BLOCK) void k_step1(Geo g, const float2* __restrict
                                                   float* __restrict__ p_out, float* __restrict__ delta,
                                                   float* __restrict__ Ap, int first,
                                                   thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                                                  float* __restrict__ aD_out)
+                                                  float* __restrict__ aD_out, int dbg)
 {
     __shared__ Tile T;
     __shared__ float red[16];
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_step1(Geo g, const float2* __restrict
                 const int gx = x0 + lx - 1, gy = y0 + ly - 1;
                 float npx = 0.f, npy = 0.f, npa = 0.f, cc = 1.f, ss = 0.f, uxx = 0.f, uyy = 0.f;
                 unsigned char ff = 0;
-                if (gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
+                if (dbg != 2 && gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
                     const long pix = (long)gy * g.W + gx;
                     const float2 pv = po[pix]; const float pav = pa[pix];
                     const float2 csv = cs[pix]; const float2 uv = ur[pix];
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(BLOCK) void k_step1(Geo g, const float2* __restrict
                 const unsigned char fi = T.f[i];
                 float ax = 0.f, ay = 0.f, aa = 0.f;
                 const float pxi = T.px[i], pyi = T.py[i], pai = T.pa[i];
-                if (fi & 1) {
+                if ((fi & 1) && dbg != 1) {
                     const float ci = T.c[i], si = T.s[i], uxi = T.ux[i], uyi = T.uy[i];
                     const int nb[4] = { i + 1, i - 1, i + LW, i - LW };
 #pragma unroll
@@ -160,6 +166,219 @@ __global__ __launch_bounds__(BLOCK) void k_step1(Geo g, const float2* __restrict
         __syncthreads();
     }
     block_store_partial(acc, aD_out, red);
+}
+
+// ------------------------------------------------------------------------------------------ step1, pipelined
+// Same math as k_step1, restructured so a workgroup keeps HBM busy while it computes:
+//  * every thread OWNS its 4 output pixels (one column) from load to store: centre values stay in
+//    registers, only neighbours come from LDS; the halo ring is loaded by the first threads;
+//  * the loads of tile t+1 are issued right after the LDS image of tile t is published and stay in
+//    flight during tile t's arithmetic: raw s_barrier + lgkmcnt(0) instead of __syncthreads(), which
+//    would drain vmcnt(0) and serialise the prefetch (cdna_hip_programming.md section 8, cp.async row).
+// Tile shape is a template parameter (TWx x THx, 1024 pixels, 4 per thread).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int TWx, int THx>
+struct TileT {
+    static constexpr int LWx = TWx + 2, LHx = THx + 2, LNx = LWx * LHx;
+    float px[LNx], py[LNx], pa[LNx], c[LNx], s[LNx], ux[LNx], uy[LNx];
+    unsigned char f[LNx + 4];
+};
+
+struct Owned { float2 zv, pv, dv, csv, uv; float zav, pav, da; unsigned char ff; };
+struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
+
+inline Geo make_geo_t(int W, int H, int tw, int th)
+{
+    Geo g; g.W = W; g.H = H; g.tx = (W + tw - 1) / tw; g.ty = (H + th - 1) / th; g.ntiles = g.tx * g.ty;
+    return g;
+}
+
+template <bool FUSED, int MINW, int TWx, int THx>
+__global__ __launch_bounds__(BLOCK, MINW) void k_step1p(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
+                                                         const unsigned char* __restrict__ flags, float wf2, float wr2,
+                                                         const float* __restrict__ z, const float* __restrict__ p_in,
+                                                         float* __restrict__ p_out, float* __restrict__ delta,
+                                                         float* __restrict__ Ap, int first,
+                                                         thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
+                                                         float* __restrict__ aD_out, int dbg)
+{
+    const int ntm = dbg >> 8; dbg &= 0xff;
+    const bool nt_delta = ntm & 1, nt_const = ntm & 2, nt_pin = ntm & 4, nt_ap = ntm & 8, nt_z = ntm & 32, nt_pout = ntm & 64;
+    using TT = TileT<TWx, THx>;
+    constexpr int LWx = TT::LWx, LHx = TT::LHx;
+    constexpr int PER = THx / (BLOCK / TWx);                 // owned pixels per thread (one column)
+    constexpr int HALO = 2 * LWx + 2 * THx;
+    constexpr int HPT = (HALO + BLOCK - 1) / BLOCK;          // halo positions per thread
+    static_assert(PER * (BLOCK / TWx) == THx && BLOCK % TWx == 0, "tile shape");
+    __shared__ TT T;
+    __shared__ float red[16];
+    const long N = (long)g.W * g.H;
+    const float2* __restrict__ zo = reinterpret_cast<const float2*>(z);
+    const float2* __restrict__ po = reinterpret_cast<const float2*>(p_in);
+    float2* __restrict__ qo = reinterpret_cast<float2*>(p_out);
+    float2* __restrict__ dlo = reinterpret_cast<float2*>(delta);
+    float2* __restrict__ Ao = reinterpret_cast<float2*>(Ap);
+    const float* __restrict__ za = z + 2 * N;  const float* __restrict__ pa = p_in + 2 * N;
+    float* __restrict__ qa = p_out + 2 * N;    float* __restrict__ dla = delta + 2 * N;
+    float* __restrict__ Aa = Ap + 2 * N;
+
+    const int tx = threadIdx.x % TWx, ty = (threadIdx.x / TWx) * PER;
+    int hlx[HPT], hly[HPT]; bool hhas[HPT];
+#pragma unroll
+    for (int q = 0; q < HPT; ++q) {
+        const int h = threadIdx.x + q * BLOCK;
+        hhas[q] = h < HALO;
+        if (h < LWx) { hlx[q] = h; hly[q] = 0; }
+        else if (h < 2 * LWx) { hlx[q] = h - LWx; hly[q] = LHx - 1; }
+        else if (h < 2 * LWx + THx) { hlx[q] = 0; hly[q] = h - 2 * LWx + 1; }
+        else { hlx[q] = LWx - 1; hly[q] = h - 2 * LWx - THx + 1; }
+    }
+
+    Owned ow[PER]; HaloLd hl[HPT];
+    bool ow_in[PER]; bool hl_in[HPT];
+
+    auto issue_loads = [&](int tile) {
+        const int x0 = (tile % g.tx) * TWx, y0 = (tile / g.tx) * THx;
+        const int gx = x0 + tx;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int gy = y0 + ty + k;
+            ow_in[k] = (dbg != 2) && gx < g.W && gy < g.H;
+            if (ow_in[k]) {
+                const long pix = (long)gy * g.W + gx;
+                ow[k].pv = ldf2(po + pix, nt_pin); ow[k].pav = ldf(pa + pix, nt_pin);
+                ow[k].csv = ldf2(cs + pix, nt_const); ow[k].uv = ldf2(ur + pix, nt_const); ow[k].ff = ldb(flags + pix, nt_const);
+                if (FUSED) {
+                    ow[k].zv = ldf2(zo + pix, nt_z); ow[k].zav = ldf(za + pix, nt_z);
+                    if (!first) { ow[k].dv = ldf2(dlo + pix, nt_delta); ow[k].da = ldf(dla + pix, nt_delta); }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            hl_in[q] = false;
+            if (hhas[q]) {
+                const int hx = x0 + hlx[q] - 1, hy = y0 + hly[q] - 1;
+                hl_in[q] = (dbg != 2) && hx >= 0 && hx < g.W && hy >= 0 && hy < g.H;
+                if (hl_in[q]) {
+                    const long pix = (long)hy * g.W + hx;
+                    hl[q].pv = po[pix]; hl[q].pav = pa[pix]; hl[q].csv = cs[pix]; hl[q].uv = ur[pix]; hl[q].ff = flags[pix];
+                    if (FUSED) { hl[q].zv = zo[pix]; hl[q].zav = za[pix]; }
+                }
+            }
+        }
+    };
+
+    TileSweep t(g.ntiles);
+    if (t.valid()) issue_loads(t.cur);
+
+    float alpha = 0.0f, beta = 0.0f;
+    if (FUSED && !first) {   // PCGStep3 of iteration k-1 (gauss_newton.t:892-896) and its alpha (:807-812)
+        const float an = sum_partials(aNp.partials, aNp.count);
+        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
+        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+    }
+
+    float acc = 0.0f;
+    while (t.valid()) {
+        const int x0 = (t.cur % g.tx) * TWx, y0 = (t.cur / g.tx) * THx;
+        const int gx = x0 + tx;
+        // ---- publish: p = z + beta*p_old (owned + halo) -> LDS ; owned: p_out, delta += alpha*p_old
+        float cpx[PER], cpy[PER], cpa[PER], cc[PER], cs_[PER], cux[PER], cuy[PER];
+        unsigned char cf[PER]; bool cin[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = (ty + k + 1) * LWx + tx + 1;
+            float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1 = 0.f, u1 = 0.f, u2 = 0.f; unsigned char ff = 0;
+            cin[k] = ow_in[k];
+            if (ow_in[k]) {
+                const long pix = (long)(y0 + ty + k) * g.W + gx;
+                if (FUSED) {
+                    npx = ow[k].zv.x + beta * ow[k].pv.x; npy = ow[k].zv.y + beta * ow[k].pv.y; npa = ow[k].zav + beta * ow[k].pav;
+                    stf2(qo + pix, make_float2(npx, npy), nt_pout); stf(qa + pix, npa, nt_pout);
+                    if (!first) {
+                        stf2(dlo + pix, make_float2(ow[k].dv.x + alpha * ow[k].pv.x, ow[k].dv.y + alpha * ow[k].pv.y), nt_delta);
+                        stf(dla + pix, ow[k].da + alpha * ow[k].pav, nt_delta);
+                    }
+                } else { npx = ow[k].pv.x; npy = ow[k].pv.y; npa = ow[k].pav; }
+                c1 = ow[k].csv.x; s1 = ow[k].csv.y; u1 = ow[k].uv.x; u2 = ow[k].uv.y; ff = ow[k].ff;
+            }
+            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.ux[i] = u1; T.uy[i] = u2; T.f[i] = ff;
+            cpx[k] = npx; cpy[k] = npy; cpa[k] = npa; cc[k] = c1; cs_[k] = s1; cux[k] = u1; cuy[k] = u2; cf[k] = ff;
+        }
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            if (hhas[q]) {
+                const int i = hly[q] * LWx + hlx[q];
+                float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1 = 0.f, u1 = 0.f, u2 = 0.f; unsigned char ff = 0;
+                if (hl_in[q]) {
+                    if (FUSED) { npx = hl[q].zv.x + beta * hl[q].pv.x; npy = hl[q].zv.y + beta * hl[q].pv.y; npa = hl[q].zav + beta * hl[q].pav; }
+                    else { npx = hl[q].pv.x; npy = hl[q].pv.y; npa = hl[q].pav; }
+                    c1 = hl[q].csv.x; s1 = hl[q].csv.y; u1 = hl[q].uv.x; u2 = hl[q].uv.y; ff = hl[q].ff;
+                }
+                T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.ux[i] = u1; T.uy[i] = u2; T.f[i] = ff;
+            }
+        }
+        lds_barrier();
+        // ---- prefetch the next tile while this one is computed
+        const int cur_y0 = y0;
+        t.next();
+        if (t.valid()) issue_loads(t.cur);
+        // ---- gather J^T J p for the owned pixels
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (cin[k] || (dbg == 2 && gx < g.W && cur_y0 + ty + k < g.H)) {
+                const int i = (ty + k + 1) * LWx + tx + 1;
+                const long pix = (long)(cur_y0 + ty + k) * g.W + gx;
+                float ax = 0.f, ay = 0.f, aa = 0.f;
+                const float pxi = cpx[k], pyi = cpy[k], pai = cpa[k];
+                if ((cf[k] & 1) && dbg != 1) {
+                    const float ci = cc[k], si = cs_[k], uxi = cux[k], uyi = cuy[k];
+                    const int nb[4] = { i + 1, i - 1, i + LWx, i - LWx };
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int j = nb[d];
+                        if (T.f[j] & 1) {
+                            const float dux = uxi - T.ux[j], duy = uyi - T.uy[j];
+                            const float gix = -si * dux - ci * duy, giy = ci * dux - si * duy;
+                            const float cj = T.c[j], sj = T.s[j], paj = T.pa[j];
+                            const float gjx = sj * dux + cj * duy, gjy = -cj * dux + sj * duy;
+                            const float dpx = pxi - T.px[j], dpy = pyi - T.py[j];
+                            const float ex = dpx - gix * pai, ey = dpy - giy * pai;
+                            ax += dpx + ex + gjx * paj;
+                            ay += dpy + ey + gjy * paj;
+                            aa -= gix * ex + giy * ey;
+                        }
+                    }
+                    ax *= wr2; ay *= wr2; aa *= wr2;
+                    if (cf[k] & 2) { ax += wf2 * pxi; ay += wf2 * pyi; }
+                }
+                stf2(Ao + pix, make_float2(ax, ay), nt_ap); stf(Aa + pix, aa, nt_ap);
+                acc += pxi * ax + pyi * ay + pai * aa;
+            }
+        }
+        lds_barrier();
+    }
+    block_store_partial(acc, aD_out, red);
+}
+
+// tile-shape dispatch for the pipelined kernel (shape index from g_iw_shape; experiments: tools/microbench.py)
+template <bool FUSED, int MINW>
+static int launch_step1p(int shape, int per_cu, int W, int H, hipStream_t s, const float* cs, const float* urshape, const unsigned char* flags,
+                         float wf2, float wr2, const float* z, const float* p_in, float* p_out, float* delta, float* Ap, int first,
+                         thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, float* aD_out, int dbg)
+{
+#define LAUNCH_SHAPE(TWx, THx) { const Geo g = make_geo_t(W, H, TWx, THx); const int grid = grid_for(g, per_cu); \
+        hipLaunchKernelGGL((k_step1p<FUSED, MINW, TWx, THx>), dim3(grid), dim3(BLOCK), 0, s, g, (const float2*)cs, (const float2*)urshape, flags, \
+                           wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg); return grid; }
+    switch (shape) {
+    case 1: LAUNCH_SHAPE(128, 8)
+    case 2: LAUNCH_SHAPE(256, 4)
+    case 3: LAUNCH_SHAPE(32, 32)
+    default: LAUNCH_SHAPE(64, 16)
+    }
+#undef LAUNCH_SHAPE
 }
 
 // ------------------------------------------------------------------------------------------ init
@@ -297,6 +516,8 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int ctx, int ntile
 
 extern "C" {
 
+void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 1) g_iw_variant = value; if (what == 2) g_iw_shape = value; if (what == 3) g_nt_mask = value; }
+
 int thallo_hip_iw_cost(int W, int H, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
                        float* cost_out, thallo_stream_t stream)
@@ -327,21 +548,32 @@ int thallo_hip_iw_pcg_step1(int W, int H, const float* cs, const float* urshape,
                             int first, thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
                             float* aD_out, thallo_stream_t stream)
 {
-    const Geo g = make_geo(W, H); const int grid = grid_for(g);
-    hipLaunchKernelGGL(k_step1<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
-                       (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                       z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out);
+    hipStream_t s = (hipStream_t)stream;
+    const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
+    int grid;
+    if (g_iw_variant == 1)      grid = launch_step1p<true, 4>(g_iw_shape, 4, W, H, s, cs, urshape, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8));
+    else if (g_iw_variant == 2) grid = launch_step1p<true, 3>(g_iw_shape, 3, W, H, s, cs, urshape, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8));
+    else {
+        const Geo g = make_geo(W, H); grid = grid_for(g);
+        hipLaunchKernelGGL(k_step1<true>, dim3(grid), dim3(BLOCK), 0, s, g, (const float2*)cs, (const float2*)urshape, flags, wf2, wr2,
+                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug);
+    }
     int e = check_launch(); return e ? e : grid;
 }
 
 int thallo_hip_iw_apply_jtj(int W, int H, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
 {
-    const Geo g = make_geo(W, H); const int grid = grid_for(g);
     thallo_sum_t none; none.partials = nullptr; none.count = 0;
-    hipLaunchKernelGGL(k_step1<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
-                       (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                       p, p, Ap, Ap, Ap, 1, none, none, none, aD_out);   /* z/p_out/delta unused when !FUSED */
+    hipStream_t s = (hipStream_t)stream;
+    const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
+    int grid;     /* z/p_out/delta are unused when !FUSED: pass valid dummies */
+    if (g_iw_variant >= 1) grid = launch_step1p<false, 4>(g_iw_shape, 4, W, H, s, cs, urshape, flags, wf2, wr2, p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug);
+    else {
+        const Geo g = make_geo(W, H); grid = grid_for(g);
+        hipLaunchKernelGGL(k_step1<false>, dim3(grid), dim3(BLOCK), 0, s, g, (const float2*)cs, (const float2*)urshape, flags, wf2, wr2,
+                           p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug);
+    }
     int e = check_launch(); return e ? e : grid;
 }
 

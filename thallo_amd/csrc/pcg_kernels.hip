@@ -30,6 +30,7 @@ inline int flat_grid(long n4, int cus)
 }
 
 int g_cus = 0;
+int g_nt2 = 3;   // cache policy: bit0 r load/store nt, bit1 pre load nt (measured best, tools/sweep_nt.sh), bit2 Ap load nt, bit3 z store nt
 int cu_count()
 {
     if (!g_cus) {
@@ -47,18 +48,19 @@ inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuc
 template <bool HAS_PRE>
 __global__ __launch_bounds__(BLOCK) void k_step2(float4* __restrict__ r, const float4* __restrict__ Ap,
                                                   const float4* __restrict__ pre, float4* __restrict__ z, long n4,
-                                                  thallo_sum_t aN, thallo_sum_t aD, float* __restrict__ bN_out)
+                                                  thallo_sum_t aN, thallo_sum_t aD, float* __restrict__ bN_out, int ntm)
 {
     __shared__ float red[16];
+    const bool nt_r = ntm & 1, nt_pre = ntm & 2, nt_ap = ntm & 4, nt_z = ntm & 8;
     const float alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
     float acc = 0.0f;
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
-        float4 rv = r[i]; const float4 av = Ap[i];
+        float4 rv = ldf4(r + i, nt_r); const float4 av = ldf4(Ap + i, nt_ap);
         float4 pv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (HAS_PRE) pv = pre[i];
+        if (HAS_PRE) pv = ldf4(pre + i, nt_pre);
         rv.x -= alpha * av.x; rv.y -= alpha * av.y; rv.z -= alpha * av.z; rv.w -= alpha * av.w;
         float4 zv = make_float4(pv.x * rv.x, pv.y * rv.y, pv.z * rv.z, pv.w * rv.w);
-        r[i] = rv; z[i] = zv;
+        stf4(r + i, rv, nt_r); stf4(z + i, zv, nt_z);
         acc += zv.x * rv.x + zv.y * rv.y + zv.z * rv.z + zv.w * rv.w;
     }
     block_store_partial(acc, bN_out, red);
@@ -144,6 +146,8 @@ __global__ void k_alpha_beta(thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, 
 
 extern "C" {
 
+void thallo_hip_debug_set2(int value) { g_nt2 = value; }
+
 long thallo_hip_vector_elems(long n) { return (n + 255) / 256 * 256; }
 int thallo_hip_device_cu_count(void) { return cu_count(); }
 
@@ -153,8 +157,8 @@ int thallo_hip_pcg_step2(float* r, const float* Ap, const float* pre, float* z, 
     const long n4 = (n + 3) / 4;
     const int grid = flat_grid(n4, cu_count());
     hipStream_t s = (hipStream_t)stream;
-    if (pre) hipLaunchKernelGGL(k_step2<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out);
-    else     hipLaunchKernelGGL(k_step2<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out);
+    if (pre) hipLaunchKernelGGL(k_step2<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out, g_nt2);
+    else     hipLaunchKernelGGL(k_step2<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out, g_nt2);
     int e = check_launch();
     return e ? e : grid;
 }

@@ -56,12 +56,12 @@ def standalone_applyjtj(torch, W, H, p_np, reps=50):
     flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
     parts = torch.zeros(4 * 1024, dtype=torch.float32, device="cuda")
     vp, fl = C.c_void_p, C.c_float
-    L.thallo_hip_iw_pcg_init(W, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+    L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                              vp(dev[4].data_ptr()), fl(p_np[5]), fl(p_np[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
                              vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(parts.data_ptr()), None)
 
     def launch():
-        return L.thallo_hip_iw_apply_jtj(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p_np[5]), fl(p_np[6]),
+        return L.thallo_hip_iw_apply_jtj(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p_np[5]), fl(p_np[6]),
                                          vp(z.data_ptr()), vp(Ap.data_ptr()), vp(parts.data_ptr() + 4096), None)
     for _ in range(5):
         assert launch() > 0
@@ -86,10 +86,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  THALLO_DIST_BACKEND=gloo exists only to exercise this leg on a 1-GPU box
+        # (RCCL refuses two ranks on one device); it is never the measured configuration.
+        dist.init_process_group(os.environ.get("THALLO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     W = H = args.size
     L_it = args.liters

@@ -44,6 +44,14 @@ typedef struct thallo_sum_t {
     int          count;
 } thallo_sum_t;
 
+/* Up to 4 contiguous pieces [off, off+len) (floats) of a flat solver vector: e.g. one image row of the
+   image_warping layout = {2*W*row, 2*W} in the Offset plane + {2*N + W*row, W} in the Angle plane. */
+typedef struct thallo_segs_t {
+    long off[4];
+    long len[4];
+    int  n;
+} thallo_segs_t;
+
 long thallo_hip_vector_elems(long n_unknowns);          /* n rounded up to a multiple of 256 */
 int  thallo_hip_device_cu_count(void);                  /* multiprocessor count of the current device */
 
@@ -55,6 +63,12 @@ int  thallo_hip_device_cu_count(void);                  /* multiprocessor count 
  *   betaN partials = sum z.r     pre==NULL means the identity preconditioner (:821-825). */
 int thallo_hip_pcg_step2(float* r, const float* Ap, const float* pre, float* z, long n,
                          thallo_sum_t alphaN, thallo_sum_t alphaD, float* betaN_out, thallo_stream_t stream);
+
+/* Same over two ranges of the flat vector, [off0,off0+len0) U [off1,off1+len1) (floats, multiples of 4):
+ * the owned rows of one slab of a row-partitioned image domain (multi-GPU). */
+int thallo_hip_pcg_step2_ranges(float* r, const float* Ap, const float* pre, float* z,
+                                long off0, long len0, long off1, long len1,
+                                thallo_sum_t alphaN, thallo_sum_t alphaD, float* betaN_out, thallo_stream_t stream);
 
 /* Reference-shaped PCGStep2 (gauss_newton.t:801-843) incl. the delta update and, when b != NULL,
  * the LM q term  q = 0.5*delta.(r+b)  (:832-837).  lm selects the unguarded divide. */
@@ -73,6 +87,15 @@ int thallo_hip_linear_update(float* X, const float* delta, const float* p, long 
 
 /* out[0] = sum(partials) -- used for cost / model-cost read-back (gauss_newton.t:1128-1150). */
 int thallo_hip_finish_sum(thallo_sum_t s, float* out, thallo_stream_t stream);
+
+/* Row-slab exchange helpers (multi-GPU).  One rank's message per PCG iteration is
+ *   out = [ local sum | first owned row | last owned row ]  (pack: out[0] = sum(partials) when sum.count > 0,
+ * out[1..] = the listed segments); after an all-gather of those messages, unpack writes
+ * sum_out[0] = sum over ranks in rank order (identical bits on every rank) and copies the neighbours' rows
+ * (src_top / src_bot point into the gathered buffer, NULL at the domain boundary) into the ghost segments. */
+int thallo_hip_slab_pack(const float* vec, thallo_segs_t segs, thallo_sum_t sum, float* out, thallo_stream_t stream);
+int thallo_hip_slab_unpack(float* vec, thallo_segs_t top, const float* src_top, thallo_segs_t bot, const float* src_bot,
+                           const float* gathered, long stride, int world, float* sum_out, thallo_stream_t stream);
 
 /* alpha/beta trace for tests: out[0]=alphaN/alphaD, out[1]=betaN/alphaN with the GN guards. */
 int thallo_hip_alpha_beta(thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_sum_t betaN, float* out2,
@@ -103,15 +126,20 @@ int thallo_hip_lapimg_pcg_step1(int W, int H, float w_fit, int xguard,
  * Per-GN-iteration precomputed planes (allowed by SURVEY.md section 7 step 3):
  *   cs    float2 per pixel = (cos Angle, sin Angle)
  *   flags uint8  per pixel : bit0 = Mask==0 (pixel active, image_warping.t:14-15,23),
- *                            bit1 = fit residual valid (image_warping.t:27) */
-int thallo_hip_iw_cost(int W, int H, const float* offset, const float* angle, const float* urshape,
+ *                            bit1 = fit residual valid (image_warping.t:27)
+ * Row slabs: W x H is the LOCAL image, which may carry one ghost row above and/or below; the kernels
+ * produce outputs for the owned rows [row0,row1) only (row0=0,row1=H for a whole image) and read the
+ * ghost rows as stencil halo.  pcg_init also fills cs/flags (and p_prev=0) on ghost rows; the fused
+ * pcg_step1 also keeps p current on ghost rows (p = z + beta p), so per PCG iteration only the ghost
+ * rows of z have to be refreshed from the neighbouring slab. */
+int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
                        float* cost_out, thallo_stream_t stream);
-int thallo_hip_iw_pcg_init(int W, int H, const float* offset, const float* angle, const float* urshape,
+int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                            const float* constraints, const float* mask, float w_fit, float w_reg,
                            float* r, float* pre, float* z, float* p_prev, float* delta,
                            float* cs, unsigned char* flags, float* alphaN_out, thallo_stream_t stream);
-int thallo_hip_iw_pcg_step1(int W, int H, const float* cs, const float* urshape, const unsigned char* flags,
+int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
                             int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
@@ -120,7 +148,7 @@ int thallo_hip_iw_pcg_step1(int W, int H, const float* cs, const float* urshape,
 /* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped
  * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's
  * stand-alone applyJTJ roofline measurement. */
-int thallo_hip_iw_apply_jtj(int W, int H, const float* cs, const float* urshape, const unsigned char* flags,
+int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 
 #ifdef __cplusplus

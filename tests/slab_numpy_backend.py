@@ -1,0 +1,178 @@
+"""CPU compute backend for thallo_amd.distributed.SlabSolver -- TEST INFRASTRUCTURE.
+
+Implements the slab kernel contract of include/thallo_hip.h (owned rows [row0,row1) of a local image
+with ghost rows; fused PCGStep1 keeps p current on ghost rows; pack/unpack message layout) in vectorised
+numpy float32, so the partition / halo-exchange / rank-ordered-sum logic of the multi-GPU driver can be
+exercised under gloo with world_size 2 on a machine without GPUs.  A third, independent statement of
+the image_warping gather formulas (after the C row-form oracle and the HIP kernels)."""
+import numpy as np
+import torch
+
+F = np.float32
+
+
+class NumpySlabBackend:
+    def __init__(self, W, layout, local_params, max_l_iters):
+        self.W, self.lay = W, layout
+        self.Hl, self.row0, self.row1 = layout.Hl, layout.row0, layout.row1
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).copy())
+        self.offset, self.angle, self.urshape, self.constraints, self.mask = [t(a) for a in local_params[:5]]
+        self.w_fit, self.w_reg = F(local_params[5]), F(local_params[6])
+        N = W * self.Hl
+        self.N, self.n = N, 3 * N
+        z = lambda: torch.zeros(self.n, dtype=torch.float32)
+        self.r, self.pre, self.z, self.delta, self.Ap = z(), z(), z(), z(), z()
+        self.p = [z(), z()]
+        self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32)
+        self.msg = 1 + 6 * W
+        self.send = torch.zeros(self.msg, dtype=torch.float32)
+        self.gath = torch.zeros(layout.world * self.msg, dtype=torch.float32)
+        self.local_sum = F(0)
+
+    # flat vector <-> planes (views into the torch storage)
+    def _planes(self, v):
+        a = v.numpy()
+        return a[:2 * self.N].reshape(self.Hl, self.W, 2), a[2 * self.N:].reshape(self.Hl, self.W)
+
+    def _consts(self):
+        act = (self.mask.numpy() == 0)
+        a = self.angle.numpy()
+        return act, np.cos(a).astype(F), np.sin(a).astype(F), self.urshape.numpy()
+
+    @staticmethod
+    def _shift(a, dy, dx, fill=0):
+        """b[y,x] = a[y+dy, x+dx] (fill outside)"""
+        out = np.full_like(a, fill)
+        H, W = a.shape[:2]
+        ys = slice(max(0, -dy), min(H, H - dy)); xs = slice(max(0, -dx), min(W, W - dx))
+        yd = slice(max(0, dy), min(H, H + dy)); xd = slice(max(0, dx), min(W, W + dx))
+        out[ys, xs] = a[yd, xd]
+        return out
+
+    def _owned(self, a):
+        return a[self.row0:self.row1]
+
+    def cost_local(self, out_idx):
+        act, c, s, u = self._consts()
+        o = self.offset.numpy(); cons = self.constraints.numpy()
+        tot = np.zeros((self.Hl, self.W), F)
+        for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+            v = act & self._shift(act, dy, dx, False)
+            du = u - self._shift(u, dy, dx); do = o - self._shift(o, dy, dx)
+            ex = self.w_reg * (do[..., 0] - (c * du[..., 0] - s * du[..., 1]))
+            ey = self.w_reg * (do[..., 1] - (s * du[..., 0] + c * du[..., 1]))
+            tot += np.where(v, ex * ex + ey * ey, 0).astype(F)
+        vf = act & (cons[..., 0] >= 0) & (cons[..., 1] >= 0)
+        f = self.w_fit * (o - cons)
+        tot += np.where(vf, (f * f).sum(-1), 0).astype(F)
+        self.S[out_idx] = float(np.sum(self._owned(0.5 * tot), dtype=np.float64))
+
+    def init(self, cur):
+        act, c, s, u = self._consts()
+        o = self.offset.numpy(); cons = self.constraints.numpy()
+        wr2, wf2 = self.w_reg * self.w_reg, self.w_fit * self.w_fit
+        jx = np.zeros((self.Hl, self.W), F); jy = jx.copy(); ja = jx.copy(); dgo = jx.copy(); dga = jx.copy()
+        for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+            v = act & self._shift(act, dy, dx, False)
+            du = u - self._shift(u, dy, dx); do = o - self._shift(o, dy, dx)
+            cj, sj = self._shift(c, dy, dx), self._shift(s, dy, dx)
+            eix = do[..., 0] - (c * du[..., 0] - s * du[..., 1]); eiy = do[..., 1] - (s * du[..., 0] + c * du[..., 1])
+            ejx = -do[..., 0] + (cj * du[..., 0] - sj * du[..., 1]); ejy = -do[..., 1] + (sj * du[..., 0] + cj * du[..., 1])
+            gix = -s * du[..., 0] - c * du[..., 1]; giy = c * du[..., 0] - s * du[..., 1]
+            jx += np.where(v, eix - ejx, 0); jy += np.where(v, eiy - ejy, 0); ja -= np.where(v, gix * eix + giy * eiy, 0)
+            dgo += np.where(v, F(2), 0); dga += np.where(v, gix * gix + giy * giy, 0)
+        jx *= wr2; jy *= wr2; ja *= wr2; dgo *= wr2; dga *= wr2
+        vf = act & (cons[..., 0] >= 0) & (cons[..., 1] >= 0)
+        jx += np.where(vf, wf2 * (o[..., 0] - cons[..., 0]), 0); jy += np.where(vf, wf2 * (o[..., 1] - cons[..., 1]), 0)
+        dgo += np.where(vf, wf2, 0)
+        inv = lambda d: (F(1) / (F(1) + np.sqrt(d)) ** 2).astype(F)
+        mo = np.where(act, inv(dgo), 0).astype(F); ma = np.where(act, inv(dga), 0).astype(F)
+        ro, ra = self._planes(self.r); po_, pa_ = self._planes(self.pre); zo, za = self._planes(self.z)
+        R0, R1 = self.row0, self.row1
+        ro[R0:R1, :, 0] = np.where(act, -jx, 0)[R0:R1]; ro[R0:R1, :, 1] = np.where(act, -jy, 0)[R0:R1]; ra[R0:R1] = np.where(act, -ja, 0)[R0:R1]
+        po_[R0:R1, :, 0] = mo[R0:R1]; po_[R0:R1, :, 1] = mo[R0:R1]; pa_[R0:R1] = ma[R0:R1]
+        zo[R0:R1] = po_[R0:R1] * ro[R0:R1]; za[R0:R1] = pa_[R0:R1] * ra[R0:R1]
+        self.p[cur].zero_(); self.delta.zero_()
+        self._fitvalid = vf
+        self.local_sum = F(np.sum((ro[R0:R1] * zo[R0:R1]).sum(-1) + ra[R0:R1] * za[R0:R1], dtype=np.float64))
+
+    def _alpha_beta(self, first, iN, iD, iB):
+        if first:
+            return F(0), F(0)
+        aN, aD, bN = F(self.S[iN]), F(self.S[iD]), F(self.S[iB])
+        alpha = aN / aD if aD != 0 else F(0)
+        beta = bN / aN if aN != 0 else F(0)
+        return alpha, beta
+
+    def step1(self, cur, first, iN, iD, iB, out_idx):
+        alpha, beta = self._alpha_beta(first, iN, iD, iB)
+        R0, R1 = self.row0, self.row1
+        zo, za = self._planes(self.z); po, pa = self._planes(self.p[cur]); qo, qa = self._planes(self.p[cur ^ 1])
+        do_, da_ = self._planes(self.delta); Ao, Aa = self._planes(self.Ap)
+        if not first:
+            do_[R0:R1] += alpha * po[R0:R1]; da_[R0:R1] += alpha * pa[R0:R1]
+        qo[:] = zo + beta * po; qa[:] = za + beta * pa          # all rows incl. ghosts: p stays current on ghost rows
+        act, c, s, u = self._consts()
+        wr2, wf2 = self.w_reg * self.w_reg, self.w_fit * self.w_fit
+        ax = np.zeros((self.Hl, self.W), F); ay = ax.copy(); aa = ax.copy()
+        for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+            v = act & self._shift(act, dy, dx, False)
+            du = u - self._shift(u, dy, dx)
+            cj, sj = self._shift(c, dy, dx), self._shift(s, dy, dx)
+            gix = -s * du[..., 0] - c * du[..., 1]; giy = c * du[..., 0] - s * du[..., 1]
+            gjx = sj * du[..., 0] + cj * du[..., 1]; gjy = -cj * du[..., 0] + sj * du[..., 1]
+            dp = qo - self._shift(qo, dy, dx); paj = self._shift(qa, dy, dx)
+            ex = dp[..., 0] - gix * qa; ey = dp[..., 1] - giy * qa
+            ax += np.where(v, dp[..., 0] + ex + gjx * paj, 0); ay += np.where(v, dp[..., 1] + ey + gjy * paj, 0)
+            aa -= np.where(v, gix * ex + giy * ey, 0)
+        ax *= wr2; ay *= wr2; aa *= wr2
+        ax += np.where(self._fitvalid, wf2 * qo[..., 0], 0); ay += np.where(self._fitvalid, wf2 * qo[..., 1], 0)
+        Ao[R0:R1, :, 0] = np.where(act, ax, 0)[R0:R1]; Ao[R0:R1, :, 1] = np.where(act, ay, 0)[R0:R1]; Aa[R0:R1] = np.where(act, aa, 0)[R0:R1]
+        self.S[out_idx] = float(np.sum((qo[R0:R1] * Ao[R0:R1]).sum(-1) + qa[R0:R1] * Aa[R0:R1], dtype=np.float64))
+
+    def step2(self, iN, iD):
+        aN, aD = F(self.S[iN]), F(self.S[iD])
+        alpha = aN / aD if aD != 0 else F(0)
+        R0, R1 = self.row0, self.row1
+        ro, ra = self._planes(self.r); Ao, Aa = self._planes(self.Ap); mo, ma = self._planes(self.pre); zo, za = self._planes(self.z)
+        ro[R0:R1] -= alpha * Ao[R0:R1]; ra[R0:R1] -= alpha * Aa[R0:R1]
+        zo[R0:R1] = mo[R0:R1] * ro[R0:R1]; za[R0:R1] = ma[R0:R1] * ra[R0:R1]
+        self.local_sum = F(np.sum((zo[R0:R1] * ro[R0:R1]).sum(-1) + za[R0:R1] * ra[R0:R1], dtype=np.float64))
+
+    def pack(self):
+        zo, za = self._planes(self.z)
+        W = self.W
+        m = self.send.numpy()
+        m[0] = self.local_sum
+        m[1:1 + 2 * W] = zo[self.row0].reshape(-1); m[1 + 2 * W:1 + 3 * W] = za[self.row0]
+        m[1 + 3 * W:1 + 5 * W] = zo[self.row1 - 1].reshape(-1); m[1 + 5 * W:] = za[self.row1 - 1]
+
+    def unpack(self, out_idx, gathered):
+        g = gathered.numpy().reshape(-1, self.msg)
+        tot = F(0)
+        for r in range(g.shape[0]):
+            tot = F(tot + g[r, 0])
+        self.S[out_idx] = float(tot)
+        zo, za = self._planes(self.z)
+        W, lay = self.W, self.lay
+        if lay.top:
+            src = g[lay.rank - 1, 1 + 3 * W:]
+            zo[self.row0 - 1] = src[:2 * W].reshape(W, 2); za[self.row0 - 1] = src[2 * W:]
+        if lay.bot:
+            src = g[lay.rank + 1, 1:1 + 3 * W]
+            zo[self.row1] = src[:2 * W].reshape(W, 2); za[self.row1] = src[2 * W:]
+
+    def linear_update(self, cur, iN, iD, with_p):
+        R0, R1 = self.row0, self.row1
+        do_, da_ = self._planes(self.delta)
+        o = self.offset.numpy(); a = self.angle.numpy()
+        if with_p:
+            aN, aD = F(self.S[iN]), F(self.S[iD])
+            alpha = aN / aD if aD != 0 else F(0)
+            po, pa = self._planes(self.p[cur])
+            o[R0:R1] += do_[R0:R1] + alpha * po[R0:R1]; a[R0:R1] += da_[R0:R1] + alpha * pa[R0:R1]
+        else:
+            o[R0:R1] += do_[R0:R1]; a[R0:R1] += da_[R0:R1]
+
+    def scalar(self, idx):
+        return float(self.S[idx])

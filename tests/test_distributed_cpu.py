@@ -1,0 +1,85 @@
+"""CPU, gloo, world_size 2 (and 3): the row-slab multi-GPU driver (thallo_amd/distributed.py) with a numpy
+compute backend reproduces the single-domain oracle trajectory; slab layout edge cases."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from thallo_amd import synthetic as syn
+from thallo_amd.distributed import SlabLayout, SlabSolver
+from slab_numpy_backend import NumpySlabBackend
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, nit, lit, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.image_warping(W, H, n_markers=8)
+        lay = SlabLayout(H, rank, world, align=4)
+        local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in p]
+        be = NumpySlabBackend(W, lay, local, lit)
+        solver = SlabSolver(be, lay)
+        costs = solver.solve(nit, lit)
+        own = slice(lay.row0, lay.row1)
+        q.put((rank, costs, lay.g0, lay.g1, be.offset.numpy()[own].copy(), be.angle.numpy()[own].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 32, 24), (3, 20, 36), (2, 16, 8)])
+def test_slab_solver_matches_single_domain_oracle(orc, world, W, H):
+    nit, lit = 3, 15
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    p = syn.image_warping(W, H, n_markers=8)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, g0, g1, off, ang in res:
+        assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]                                    # replicated scalars are bit-identical on all ranks
+        assert np.abs(off - p[0][g0:g1]).max() <= 2e-4 * np.abs(p[0]).max()
+        assert np.abs(ang - p[1][g0:g1]).max() <= 2e-4 * max(1.0, np.abs(p[1]).max())
+    assert [r[2] for r in res][0] == 0 and res[-1][3] == H
+
+
+def test_slab_layout_covers_image_without_gaps():
+    for H in (8, 33, 256, 2048, 100):
+        for world in (1, 2, 3, 4, 8):
+            try:
+                lays = [SlabLayout(H, r, world) for r in range(world)]
+            except ValueError:
+                assert H < 16 * world          # too few 16-row blocks for that many ranks
+                continue
+            assert lays[0].g0 == 0 and lays[-1].g1 == H
+            for a, b in zip(lays, lays[1:]):
+                assert a.g1 == b.g0 and a.bot == 1 and b.top == 1
+            assert lays[0].top == 0 and lays[-1].bot == 0
+            for l in lays:
+                assert l.Hl == (l.g1 - l.g0) + l.top + l.bot and l.row1 - l.row0 == l.g1 - l.g0
+
+
+def test_world_size_one_is_the_plain_solver(orc):
+    W, H = 24, 16
+    p = syn.imageWarping if False else syn.image_warping(W, H, n_markers=4)
+    lay = SlabLayout(H, 0, 1)
+    be = NumpySlabBackend(W, lay, [a.copy() if isinstance(a, np.ndarray) else a for a in p], 10)
+    costs = SlabSolver(be, lay).solve(2, 10)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=2, lIterations=10)
+    assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max()

@@ -1,0 +1,76 @@
+"""GPU: the HIP slab backend of the multi-GPU driver.  The box has ONE GPU, so the ranks share cuda:0 and
+talk over gloo (RCCL refuses two ranks on one device); the compute path is the real one -- row-range
+kernels, ghost-row maintenance, pack/unpack -- only the transport differs from the 8-GPU run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, nit, lit, q):
+    import torch
+    import torch.distributed as dist
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed import make_hip_solver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.image_warping(W, H, n_markers=8)
+        solver, lay = make_hip_solver(p, W, H, rank, world, lit)
+        costs = solver.solve(nit, lit)
+        be = solver.be
+        off = be.offset.view(be.Hl, W, 2)[lay.row0:lay.row1].cpu().numpy()
+        ang = be.angle.view(be.Hl, W)[lay.row0:lay.row1].cpu().numpy()
+        q.put((rank, costs, lay.g0, lay.g1, off, ang))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,nit,lit", [(2, 128, 96, 3, 30), (3, 64, 100, 2, 20), (2, 256, 256, 2, 40)])
+def test_hip_slabs_match_oracle(orc, world, W, H, nit, lit):
+    import torch.multiprocessing as mp
+    from thallo_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    p = syn.image_warping(W, H, n_markers=8)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, g0, g1, off, ang in res:
+        assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]
+        assert np.abs(off - p[0][g0:g1]).max() <= 2e-4 * np.abs(p[0]).max()
+        assert np.abs(ang - p[1][g0:g1]).max() <= 2e-4 * max(1.0, np.abs(p[1]).max())
+
+
+def test_hip_single_slab_equals_library_path(orc):
+    """world_size 1 through the slab driver == Thallo_ProblemSolve on the same instance (same kernels)."""
+    import torch
+    import thallo_amd
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed import make_hip_solver
+    W, H = 192, 80
+    p = syn.image_warping(W, H, n_markers=8)
+    solver, lay = make_hip_solver(p, W, H, 0, 1, 25)
+    costs = solver.solve(2, 25)
+    dev = [torch.from_numpy(x.copy()).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
+    s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    _, c2 = s.solve(dev, profiled=True, nIterations=2, lIterations=25)
+    assert np.abs(np.array(costs) - np.array(c2)).max() <= 1e-6 * max(c2)
+    assert torch.equal(solver.be.offset.view(-1), dev[0].view(-1)) and torch.equal(solver.be.angle.view(-1), dev[1].view(-1))

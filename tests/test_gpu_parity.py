@@ -136,7 +136,7 @@ def test_shim_image_warping_init_and_apply(torch, orc, W, H):
     cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
     parts = torch.zeros(4 * 1024, dtype=torch.float32, device="cuda")
     vp = C.c_void_p; fl = C.c_float
-    nb = L.thallo_hip_iw_pcg_init(W, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+    nb = L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                                   vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
                                   vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(parts.data_ptr()), None)
     assert nb > 0
@@ -153,7 +153,7 @@ def test_shim_image_warping_init_and_apply(torch, orc, W, H):
     v = np.random.default_rng(3).standard_normal(n).astype(np.float32); v[excl] = 0
     z.zero_(); z[:n] = torch.from_numpy(v).cuda()
     s0 = api.SumT(parts.data_ptr(), 1)
-    nb2 = L.thallo_hip_iw_pcg_step1(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
+    nb2 = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                     vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
                                     1, s0, s0, s0, vp(parts.data_ptr() + 4096), None)
     assert nb2 > 0
@@ -179,7 +179,7 @@ def test_full_size_properties_2048(torch):
     cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
     parts = torch.zeros(8 * 1024, dtype=torch.float32, device="cuda")
     vp = C.c_void_p; fl = C.c_float
-    L.thallo_hip_iw_pcg_init(W, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+    L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                              vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
                              vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(parts.data_ptr()), None)
     active = (flags[:N] & 1).bool()
@@ -190,7 +190,7 @@ def test_full_size_properties_2048(torch):
     s0 = api.SumT(parts.data_ptr(), 1)
 
     def apply(vec, out):
-        nb = L.thallo_hip_iw_pcg_step1(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
+        nb = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                        vp(vec.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(out.data_ptr()),
                                        1, s0, s0, s0, vp(parts.data_ptr() + 4096), None)
         assert nb > 0

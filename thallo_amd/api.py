@@ -34,6 +34,10 @@ class SumT(C.Structure):      # thallo_sum_t of include/thallo_hip.h
     _fields_ = [("partials", C.c_void_p), ("count", C.c_int)]
 
 
+class SegsT(C.Structure):     # thallo_segs_t of include/thallo_hip.h
+    _fields_ = [("off", C.c_long * 4), ("len", C.c_long * 4), ("n", C.c_int)]
+
+
 INT_PARAMS = ("nIterations", "lIterations", "residual_reset_period", "nIter")
 
 _lib = None

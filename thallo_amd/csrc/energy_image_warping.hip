@@ -11,16 +11,25 @@
 //   (J^T J P)_o(i) = w_reg^2 * sum_d v [ 2(po_i - po_j) - g_i pa_i + g_j pa_j ] + w_fit^2 [fit valid] po_i
 //   (J^T J P)_a(i) = -w_reg^2 * sum_d v  g_i . [ (po_i - po_j) - g_i pa_i ]
 //
-// Kernel design (MI355X): 64x16-pixel tiles + 1-pixel halo staged in LDS (register-staged loads,
-// all of a tile's loads issued before the first use -> ~38 KB in flight per workgroup, 4 workgroups
-// per CU), persistent XCD-aware tile sweep, one partial per workgroup.  The step kernel also
-// applies the previous iteration's PCGStep3 (p = z + beta p) and delta update on the fly, which
-// removes one kernel and 31 B/pixel of traffic per PCG iteration versus the reference's
-// PCGStep1 + PCGStep2 + PCGStep3 split (gauss_newton.t:1641-1661).
+// Kernel design (MI355X):
+//  * 64x16-pixel tiles (+1-pixel halo) = 1024 pixels per 256-thread workgroup; a thread OWNS one column
+//    of 4 pixels from load to store: its centre values stay in registers, only neighbours are read from
+//    the LDS image of the tile; the 164-position halo ring is loaded by the first 164 threads.
+//  * software pipeline: the loads of tile t+1 are issued right after tile t's LDS image is published and
+//    stay in flight during tile t's arithmetic.  The barriers are raw s_barrier + lgkmcnt(0): a
+//    __syncthreads() would drain vmcnt(0) and serialise the prefetch.
+//  * persistent grid (3 workgroups per CU: 150 VGPRs), XCD-aware contiguous tile ranges so that the halo
+//    re-reads of neighbouring tiles hit the same XCD's L2 (measured: HBM fetch = compulsory bytes + 8 %).
+//  * PCGStep1 also applies the previous iteration's PCGStep3 (p = z + beta p) and delta update on the
+//    fly: one kernel and 31 B/pixel less per PCG iteration than the reference's split
+//    (gauss_newton.t:1641-1661).  One partial per workgroup for alphaD, no atomics.
+//  * row slabs (multi-GPU): every kernel works on the owned rows [row0,row1) of a local
+//    image that may carry ghost rows above/below; ghost rows are read as halo, and the fused step also
+//    maintains p on them (p = z + beta p) so only z crosses the wire each iteration.
 //
-// Algorithmic bytes: applyJTJ 48 B/px; this fused kernel = applyJTJ + PCGStep3 +
-// the delta part of PCGStep2: reads z 12, p 12, delta 12, cs 8, u 8, flags 1; writes p 12, Ap 12,
-// delta 12 = 89 B/px actual.
+// Bytes per pixel: fused PCGStep1 reads z 12, p 12, delta 12, cs 8, UrShape 8, flags 1; writes p 12,
+// Ap 12, delta 12 = 89 actual (algorithmic, reference formulation of the fused ops: 96).
+// Plain applyJTJ: reads p 12, cs 8, UrShape 8, flags 1; writes Ap 12 = 41 actual (algorithmic 48).
 #include "device_common.hpp"
 #include "../../include/thallo_hip.h"
 
@@ -30,46 +39,56 @@ namespace {
 
 constexpr int TW = 64, TH = 16, BLOCK = 256;
 constexpr int LW = TW + 2, LH = TH + 2, LN = LW * LH;      // 66 x 18 = 1188 halo'd positions
-constexpr int PER_THREAD = TH / (BLOCK / TW);              // 4 pixels per thread, one column
+constexpr int PER = TH / (BLOCK / TW);                     // 4 owned pixels per thread (one column)
+constexpr int HALO = 2 * LW + 2 * TH;                      // 164 ring positions
 
-struct Geo { int W, H, tx, ty, ntiles; };
-inline Geo make_geo(int W, int H)
+// W x H = local image (rows include ghost rows); tiles cover the owned rows [row0,row1) only.
+struct Geo { int W, H, row0, row1, tx, ty, ntiles; };
+inline Geo make_geo(int W, int H, int row0, int row1)
 {
-    Geo g; g.W = W; g.H = H; g.tx = (W + TW - 1) / TW; g.ty = (H + TH - 1) / TH; g.ntiles = g.tx * g.ty;
+    Geo g; g.W = W; g.H = H; g.row0 = row0; g.row1 = row1;
+    g.tx = (W + TW - 1) / TW; g.ty = (row1 - row0 + TH - 1) / TH; g.ntiles = g.tx * g.ty;
     return g;
 }
-inline int grid_for(const Geo& g, int per_cu = 4)
+inline bool rows_ok(int H, int row0, int row1) { return row0 >= 0 && row1 <= H && row0 < row1; }
+inline int grid_for(const Geo& g, int per_cu)
 {
-    int cap = thallo_hip_device_cu_count() * per_cu;       // LDS: 4 x 38 KB per CU
+    int cap = thallo_hip_device_cu_count() * per_cu;
     if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
     cap -= cap % 8;
     return g.ntiles < cap ? g.ntiles : cap;
 }
 inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
 
-// diagnostic switch for tools/microbench.py only (0 = normal): 1 = skip stage B arithmetic, 2 = skip global loads
+// tools/microbench.py hooks (not product API): diagnostic mode 1 = skip arithmetic, 2 = skip loads;
+// cache-policy bits for PCGStep1: 1 delta nt, 2 cs/UrShape/flags nt, 4 p_in nt, 8 Ap nt, 32 z nt, 64 p_out nt
 int g_iw_debug = 0;
-int g_iw_variant = 2;   // 0 = two-phase tile kernel, 1 = pipelined 4 WG/CU (spills), 2 = pipelined 3 WG/CU (default)
-int g_nt_mask = 1;      // cache policy bits (k_step1p): 1 = delta non-temporal (measured +1-3 %% PCG it/s at 2048^2, tools/sweep_nt.sh)
-int g_iw_shape = 0;     // pipelined tile shape: 0 = 64x16, 1 = 128x8, 2 = 256x4, 3 = 32x32
+int g_nt_mask = 1;      // delta non-temporal: measured +1-3 % PCG it/s at 2048^2 (tools/sweep_nt.sh)
 
 struct Tile {
-    float px[LN], py[LN], pa[LN];   // step: CG direction p ; init: offset.x, offset.y, (unused)
+    float px[LN], py[LN], pa[LN];   // step: CG direction p ; init: offset.x, offset.y
     float c[LN], s[LN];             // cos / sin of Angle
     float ux[LN], uy[LN];           // UrShape
-    unsigned char f[LN + 4];        // bit0 active, bit1 fit-valid
+    unsigned char f[LN + 4];        // bit0 active (Mask==0), bit1 fit-valid
 };
 
-// ------------------------------------------------------------------------------------------ step1
-template <bool FUSED>
-__global__ __launch_bounds__(BLOCK) void k_step1(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
-                                                  const unsigned char* __restrict__ flags, float wf2, float wr2,
-                                                  const float* __restrict__ z, const float* __restrict__ p_in,
-                                                  float* __restrict__ p_out, float* __restrict__ delta,
-                                                  float* __restrict__ Ap, int first,
-                                                  thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                                                  float* __restrict__ aD_out, int dbg)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct Owned { float2 zv, pv, dv, csv, uv; float zav, pav, da; unsigned char ff; };
+struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
+
+// ------------------------------------------------------------------------------------------ PCGStep1
+template <bool FUSED, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
+                                                        const unsigned char* __restrict__ flags, float wf2, float wr2,
+                                                        const float* __restrict__ z, const float* __restrict__ p_in,
+                                                        float* __restrict__ p_out, float* __restrict__ delta,
+                                                        float* __restrict__ Ap, int first,
+                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
+                                                        float* __restrict__ aD_out, int dbg)
 {
+    const int ntm = dbg >> 8; dbg &= 0xff;
+    const bool nt_delta = ntm & 1, nt_const = ntm & 2, nt_pin = ntm & 4, nt_ap = ntm & 8, nt_z = ntm & 32, nt_pout = ntm & 64;
     __shared__ Tile T;
     __shared__ float red[16];
     const long N = (long)g.W * g.H;
@@ -82,190 +101,45 @@ __global__ __launch_bounds__(BLOCK) void k_step1(Geo g, const float2* __restrict
     float* __restrict__ qa = p_out + 2 * N;    float* __restrict__ dla = delta + 2 * N;
     float* __restrict__ Aa = Ap + 2 * N;
 
-    float alpha = 0.0f, beta = 0.0f;
-    if (FUSED && !first) {   // PCGStep3 of iteration k-1 (gauss_newton.t:892-896) and its alpha (:807-812)
-        const float an = sum_partials(aNp.partials, aNp.count);
-        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
-        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * PER;      // owned column / first owned row in the tile
+    int hlx, hly;                                                        // this thread's halo-ring position
+    {
+        const int h = threadIdx.x;
+        if (h < LW) { hlx = h; hly = 0; }
+        else if (h < 2 * LW) { hlx = h - LW; hly = LH - 1; }
+        else if (h < 2 * LW + TH) { hlx = 0; hly = h - 2 * LW + 1; }
+        else { hlx = LW - 1; hly = h - 2 * LW - TH + 1; }
     }
+    const bool has_halo = threadIdx.x < HALO;
 
-    float acc = 0.0f;
-    for (TileSweep t(g.ntiles); t.valid(); t.next()) {
-        const int x0 = (t.cur % g.tx) * TW, y0 = (t.cur / g.tx) * TH;
-        // ---- stage A: load halo'd tile, p = z + beta*p_old, delta += alpha*p_old
-#pragma unroll
-        for (int it = 0; it < (LN + BLOCK - 1) / BLOCK; ++it) {
-            const int idx = it * BLOCK + threadIdx.x;
-            if (idx < LN) {
-                const int ly = idx / LW, lx = idx - ly * LW;
-                const int gx = x0 + lx - 1, gy = y0 + ly - 1;
-                float npx = 0.f, npy = 0.f, npa = 0.f, cc = 1.f, ss = 0.f, uxx = 0.f, uyy = 0.f;
-                unsigned char ff = 0;
-                if (dbg != 2 && gx >= 0 && gx < g.W && gy >= 0 && gy < g.H) {
-                    const long pix = (long)gy * g.W + gx;
-                    const float2 pv = po[pix]; const float pav = pa[pix];
-                    const float2 csv = cs[pix]; const float2 uv = ur[pix];
-                    ff = flags[pix];
-                    if (FUSED) {
-                        const float2 zv = zo[pix]; const float zav = za[pix];
-                        npx = zv.x + beta * pv.x; npy = zv.y + beta * pv.y; npa = zav + beta * pav;
-                    } else { npx = pv.x; npy = pv.y; npa = pav; }
-                    cc = csv.x; ss = csv.y; uxx = uv.x; uyy = uv.y;
-                    if (FUSED && lx >= 1 && lx <= TW && ly >= 1 && ly <= TH) {      // owned pixel
-                        qo[pix] = make_float2(npx, npy); qa[pix] = npa;
-                        if (!first) {
-                            float2 dv = dlo[pix]; float da = dla[pix];
-                            dv.x += alpha * pv.x; dv.y += alpha * pv.y; da += alpha * pav;
-                            dlo[pix] = dv; dla[pix] = da;
-                        }
-                    }
-                }
-                T.px[idx] = npx; T.py[idx] = npy; T.pa[idx] = npa;
-                T.c[idx] = cc; T.s[idx] = ss; T.ux[idx] = uxx; T.uy[idx] = uyy; T.f[idx] = ff;
-            }
-        }
-        __syncthreads();
-        // ---- stage B: gather J^T J p
-        const int lx = (threadIdx.x % TW) + 1;
-        const int gx = x0 + lx - 1;
-#pragma unroll
-        for (int k = 0; k < PER_THREAD; ++k) {
-            const int ly = (threadIdx.x / TW) * PER_THREAD + k + 1;
-            const int gy = y0 + ly - 1;
-            const int i = ly * LW + lx;
-            if (gx < g.W && gy < g.H) {
-                const long pix = (long)gy * g.W + gx;
-                const unsigned char fi = T.f[i];
-                float ax = 0.f, ay = 0.f, aa = 0.f;
-                const float pxi = T.px[i], pyi = T.py[i], pai = T.pa[i];
-                if ((fi & 1) && dbg != 1) {
-                    const float ci = T.c[i], si = T.s[i], uxi = T.ux[i], uyi = T.uy[i];
-                    const int nb[4] = { i + 1, i - 1, i + LW, i - LW };
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const int j = nb[d];
-                        if (T.f[j] & 1) {
-                            const float dux = uxi - T.ux[j], duy = uyi - T.uy[j];
-                            const float gix = -si * dux - ci * duy, giy = ci * dux - si * duy;
-                            const float cj = T.c[j], sj = T.s[j], paj = T.pa[j];
-                            const float gjx = sj * dux + cj * duy, gjy = -cj * dux + sj * duy;
-                            const float dpx = pxi - T.px[j], dpy = pyi - T.py[j];
-                            const float ex = dpx - gix * pai, ey = dpy - giy * pai;
-                            ax += dpx + ex + gjx * paj;
-                            ay += dpy + ey + gjy * paj;
-                            aa -= gix * ex + giy * ey;
-                        }
-                    }
-                    ax *= wr2; ay *= wr2; aa *= wr2;
-                    if (fi & 2) { ax += wf2 * pxi; ay += wf2 * pyi; }
-                }
-                Ao[pix] = make_float2(ax, ay); Aa[pix] = aa;
-                acc += pxi * ax + pyi * ay + pai * aa;
-            }
-        }
-        __syncthreads();
-    }
-    block_store_partial(acc, aD_out, red);
-}
-
-// ------------------------------------------------------------------------------------------ step1, pipelined
-// Same math as k_step1, restructured so a workgroup keeps HBM busy while it computes:
-//  * every thread OWNS its 4 output pixels (one column) from load to store: centre values stay in
-//    registers, only neighbours come from LDS; the halo ring is loaded by the first threads;
-//  * the loads of tile t+1 are issued right after the LDS image of tile t is published and stay in
-//    flight during tile t's arithmetic: raw s_barrier + lgkmcnt(0) instead of __syncthreads(), which
-//    would drain vmcnt(0) and serialise the prefetch (cdna_hip_programming.md section 8, cp.async row).
-// Tile shape is a template parameter (TWx x THx, 1024 pixels, 4 per thread).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int TWx, int THx>
-struct TileT {
-    static constexpr int LWx = TWx + 2, LHx = THx + 2, LNx = LWx * LHx;
-    float px[LNx], py[LNx], pa[LNx], c[LNx], s[LNx], ux[LNx], uy[LNx];
-    unsigned char f[LNx + 4];
-};
-
-struct Owned { float2 zv, pv, dv, csv, uv; float zav, pav, da; unsigned char ff; };
-struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
-
-inline Geo make_geo_t(int W, int H, int tw, int th)
-{
-    Geo g; g.W = W; g.H = H; g.tx = (W + tw - 1) / tw; g.ty = (H + th - 1) / th; g.ntiles = g.tx * g.ty;
-    return g;
-}
-
-template <bool FUSED, int MINW, int TWx, int THx>
-__global__ __launch_bounds__(BLOCK, MINW) void k_step1p(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
-                                                         const unsigned char* __restrict__ flags, float wf2, float wr2,
-                                                         const float* __restrict__ z, const float* __restrict__ p_in,
-                                                         float* __restrict__ p_out, float* __restrict__ delta,
-                                                         float* __restrict__ Ap, int first,
-                                                         thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                                                         float* __restrict__ aD_out, int dbg)
-{
-    const int ntm = dbg >> 8; dbg &= 0xff;
-    const bool nt_delta = ntm & 1, nt_const = ntm & 2, nt_pin = ntm & 4, nt_ap = ntm & 8, nt_z = ntm & 32, nt_pout = ntm & 64;
-    using TT = TileT<TWx, THx>;
-    constexpr int LWx = TT::LWx, LHx = TT::LHx;
-    constexpr int PER = THx / (BLOCK / TWx);                 // owned pixels per thread (one column)
-    constexpr int HALO = 2 * LWx + 2 * THx;
-    constexpr int HPT = (HALO + BLOCK - 1) / BLOCK;          // halo positions per thread
-    static_assert(PER * (BLOCK / TWx) == THx && BLOCK % TWx == 0, "tile shape");
-    __shared__ TT T;
-    __shared__ float red[16];
-    const long N = (long)g.W * g.H;
-    const float2* __restrict__ zo = reinterpret_cast<const float2*>(z);
-    const float2* __restrict__ po = reinterpret_cast<const float2*>(p_in);
-    float2* __restrict__ qo = reinterpret_cast<float2*>(p_out);
-    float2* __restrict__ dlo = reinterpret_cast<float2*>(delta);
-    float2* __restrict__ Ao = reinterpret_cast<float2*>(Ap);
-    const float* __restrict__ za = z + 2 * N;  const float* __restrict__ pa = p_in + 2 * N;
-    float* __restrict__ qa = p_out + 2 * N;    float* __restrict__ dla = delta + 2 * N;
-    float* __restrict__ Aa = Ap + 2 * N;
-
-    const int tx = threadIdx.x % TWx, ty = (threadIdx.x / TWx) * PER;
-    int hlx[HPT], hly[HPT]; bool hhas[HPT];
-#pragma unroll
-    for (int q = 0; q < HPT; ++q) {
-        const int h = threadIdx.x + q * BLOCK;
-        hhas[q] = h < HALO;
-        if (h < LWx) { hlx[q] = h; hly[q] = 0; }
-        else if (h < 2 * LWx) { hlx[q] = h - LWx; hly[q] = LHx - 1; }
-        else if (h < 2 * LWx + THx) { hlx[q] = 0; hly[q] = h - 2 * LWx + 1; }
-        else { hlx[q] = LWx - 1; hly[q] = h - 2 * LWx - THx + 1; }
-    }
-
-    Owned ow[PER]; HaloLd hl[HPT];
-    bool ow_in[PER]; bool hl_in[HPT];
+    Owned ow[PER]; HaloLd hl;
+    bool ow_ld[PER], ow_in[PER]; bool hl_in = false;      // loaded (exists in the local image) / owned (row < row1)
 
     auto issue_loads = [&](int tile) {
-        const int x0 = (tile % g.tx) * TWx, y0 = (tile / g.tx) * THx;
+        const int x0 = (tile % g.tx) * TW, y0 = g.row0 + (tile / g.tx) * TH;
         const int gx = x0 + tx;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int gy = y0 + ty + k;
-            ow_in[k] = (dbg != 2) && gx < g.W && gy < g.H;
-            if (ow_in[k]) {
+            ow_ld[k] = (dbg != 2) && gx < g.W && gy < g.H;     // a slab's bottom ghost row may fall inside the last tile
+            ow_in[k] = ow_ld[k] && gy < g.row1;
+            if (ow_ld[k]) {
                 const long pix = (long)gy * g.W + gx;
                 ow[k].pv = ldf2(po + pix, nt_pin); ow[k].pav = ldf(pa + pix, nt_pin);
                 ow[k].csv = ldf2(cs + pix, nt_const); ow[k].uv = ldf2(ur + pix, nt_const); ow[k].ff = ldb(flags + pix, nt_const);
                 if (FUSED) {
                     ow[k].zv = ldf2(zo + pix, nt_z); ow[k].zav = ldf(za + pix, nt_z);
-                    if (!first) { ow[k].dv = ldf2(dlo + pix, nt_delta); ow[k].da = ldf(dla + pix, nt_delta); }
+                    if (!first && ow_in[k]) { ow[k].dv = ldf2(dlo + pix, nt_delta); ow[k].da = ldf(dla + pix, nt_delta); }
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < HPT; ++q) {
-            hl_in[q] = false;
-            if (hhas[q]) {
-                const int hx = x0 + hlx[q] - 1, hy = y0 + hly[q] - 1;
-                hl_in[q] = (dbg != 2) && hx >= 0 && hx < g.W && hy >= 0 && hy < g.H;
-                if (hl_in[q]) {
-                    const long pix = (long)hy * g.W + hx;
-                    hl[q].pv = po[pix]; hl[q].pav = pa[pix]; hl[q].csv = cs[pix]; hl[q].uv = ur[pix]; hl[q].ff = flags[pix];
-                    if (FUSED) { hl[q].zv = zo[pix]; hl[q].zav = za[pix]; }
-                }
+        if (has_halo) {
+            const int hx = x0 + hlx - 1, hy = y0 + hly - 1;
+            hl_in = (dbg != 2) && hx >= 0 && hx < g.W && hy >= 0 && hy < g.H;
+            if (hl_in) {
+                const long pix = (long)hy * g.W + hx;
+                hl.pv = po[pix]; hl.pav = pa[pix]; hl.csv = cs[pix]; hl.uv = ur[pix]; hl.ff = flags[pix];
+                if (FUSED) { hl.zv = zo[pix]; hl.zav = za[pix]; }
             }
         }
     };
@@ -282,22 +156,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1p(Geo g, const float2* __r
 
     float acc = 0.0f;
     while (t.valid()) {
-        const int x0 = (t.cur % g.tx) * TWx, y0 = (t.cur / g.tx) * THx;
+        const int x0 = (t.cur % g.tx) * TW, y0 = g.row0 + (t.cur / g.tx) * TH;
         const int gx = x0 + tx;
         // ---- publish: p = z + beta*p_old (owned + halo) -> LDS ; owned: p_out, delta += alpha*p_old
         float cpx[PER], cpy[PER], cpa[PER], cc[PER], cs_[PER], cux[PER], cuy[PER];
         unsigned char cf[PER]; bool cin[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = (ty + k + 1) * LWx + tx + 1;
+            const int i = (ty + k + 1) * LW + tx + 1;
             float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1 = 0.f, u1 = 0.f, u2 = 0.f; unsigned char ff = 0;
             cin[k] = ow_in[k];
-            if (ow_in[k]) {
+            if (ow_ld[k]) {
                 const long pix = (long)(y0 + ty + k) * g.W + gx;
                 if (FUSED) {
                     npx = ow[k].zv.x + beta * ow[k].pv.x; npy = ow[k].zv.y + beta * ow[k].pv.y; npa = ow[k].zav + beta * ow[k].pav;
-                    stf2(qo + pix, make_float2(npx, npy), nt_pout); stf(qa + pix, npa, nt_pout);
-                    if (!first) {
+                    stf2(qo + pix, make_float2(npx, npy), nt_pout); stf(qa + pix, npa, nt_pout);      // owned, or ghost row kept current
+                    if (!first && ow_in[k]) {
                         stf2(dlo + pix, make_float2(ow[k].dv.x + alpha * ow[k].pv.x, ow[k].dv.y + alpha * ow[k].pv.y), nt_delta);
                         stf(dla + pix, ow[k].da + alpha * ow[k].pav, nt_delta);
                     }
@@ -307,18 +181,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1p(Geo g, const float2* __r
             T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.ux[i] = u1; T.uy[i] = u2; T.f[i] = ff;
             cpx[k] = npx; cpy[k] = npy; cpa[k] = npa; cc[k] = c1; cs_[k] = s1; cux[k] = u1; cuy[k] = u2; cf[k] = ff;
         }
-#pragma unroll
-        for (int q = 0; q < HPT; ++q) {
-            if (hhas[q]) {
-                const int i = hly[q] * LWx + hlx[q];
-                float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1 = 0.f, u1 = 0.f, u2 = 0.f; unsigned char ff = 0;
-                if (hl_in[q]) {
-                    if (FUSED) { npx = hl[q].zv.x + beta * hl[q].pv.x; npy = hl[q].zv.y + beta * hl[q].pv.y; npa = hl[q].zav + beta * hl[q].pav; }
-                    else { npx = hl[q].pv.x; npy = hl[q].pv.y; npa = hl[q].pav; }
-                    c1 = hl[q].csv.x; s1 = hl[q].csv.y; u1 = hl[q].uv.x; u2 = hl[q].uv.y; ff = hl[q].ff;
-                }
-                T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.ux[i] = u1; T.uy[i] = u2; T.f[i] = ff;
+        if (has_halo) {
+            const int i = hly * LW + hlx;
+            float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1 = 0.f, u1 = 0.f, u2 = 0.f; unsigned char ff = 0;
+            if (hl_in) {
+                if (FUSED) {
+                    npx = hl.zv.x + beta * hl.pv.x; npy = hl.zv.y + beta * hl.pv.y; npa = hl.zav + beta * hl.pav;
+                    // ghost row of a slab (not owned by any tile of this rank): keep its p current
+                    const int hy = y0 + hly - 1;
+                    if ((hy < g.row0 || hy >= g.row1) && hlx >= 1 && hlx <= TW) {
+                        const long pix = (long)hy * g.W + (x0 + hlx - 1);
+                        qo[pix] = make_float2(npx, npy); qa[pix] = npa;
+                    }
+                } else { npx = hl.pv.x; npy = hl.pv.y; npa = hl.pav; }
+                c1 = hl.csv.x; s1 = hl.csv.y; u1 = hl.uv.x; u2 = hl.uv.y; ff = hl.ff;
             }
+            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.ux[i] = u1; T.uy[i] = u2; T.f[i] = ff;
         }
         lds_barrier();
         // ---- prefetch the next tile while this one is computed
@@ -328,14 +206,14 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1p(Geo g, const float2* __r
         // ---- gather J^T J p for the owned pixels
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            if (cin[k] || (dbg == 2 && gx < g.W && cur_y0 + ty + k < g.H)) {
-                const int i = (ty + k + 1) * LWx + tx + 1;
+            if (cin[k] || (dbg == 2 && gx < g.W && cur_y0 + ty + k < g.row1)) {
+                const int i = (ty + k + 1) * LW + tx + 1;
                 const long pix = (long)(cur_y0 + ty + k) * g.W + gx;
                 float ax = 0.f, ay = 0.f, aa = 0.f;
                 const float pxi = cpx[k], pyi = cpy[k], pai = cpa[k];
                 if ((cf[k] & 1) && dbg != 1) {
                     const float ci = cc[k], si = cs_[k], uxi = cux[k], uyi = cuy[k];
-                    const int nb[4] = { i + 1, i - 1, i + LWx, i - LWx };
+                    const int nb[4] = { i + 1, i - 1, i + LW, i - LW };
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int j = nb[d];
@@ -363,25 +241,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1p(Geo g, const float2* __r
     block_store_partial(acc, aD_out, red);
 }
 
-// tile-shape dispatch for the pipelined kernel (shape index from g_iw_shape; experiments: tools/microbench.py)
-template <bool FUSED, int MINW>
-static int launch_step1p(int shape, int per_cu, int W, int H, hipStream_t s, const float* cs, const float* urshape, const unsigned char* flags,
-                         float wf2, float wr2, const float* z, const float* p_in, float* p_out, float* delta, float* Ap, int first,
-                         thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, float* aD_out, int dbg)
-{
-#define LAUNCH_SHAPE(TWx, THx) { const Geo g = make_geo_t(W, H, TWx, THx); const int grid = grid_for(g, per_cu); \
-        hipLaunchKernelGGL((k_step1p<FUSED, MINW, TWx, THx>), dim3(grid), dim3(BLOCK), 0, s, g, (const float2*)cs, (const float2*)urshape, flags, \
-                           wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg); return grid; }
-    switch (shape) {
-    case 1: LAUNCH_SHAPE(128, 8)
-    case 2: LAUNCH_SHAPE(256, 4)
-    case 3: LAUNCH_SHAPE(32, 32)
-    default: LAUNCH_SHAPE(64, 16)
-    }
-#undef LAUNCH_SHAPE
-}
-
-// ------------------------------------------------------------------------------------------ init
+// ------------------------------------------------------------------------------------------ PCGInit1 (+_Finish)
+// Once per GN iteration: evalJTF in gather form, guardedInvert, z = M^-1 r, p_prev = 0, delta = 0, the
+// (cos,sin) and validity planes, alphaN partials.  Not pipelined (1 % of a GN iteration).
 __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict__ off, const float* __restrict__ ang,
                                                 const float2* __restrict__ ur, const float2* __restrict__ cons,
                                                 const float* __restrict__ mask, float wf, float wr,
@@ -396,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
     const float wr2 = wr * wr, wf2 = wf * wf;
     float acc = 0.0f;
     for (TileSweep t(g.ntiles); t.valid(); t.next()) {
-        const int x0 = (t.cur % g.tx) * TW, y0 = (t.cur / g.tx) * TH;
+        const int x0 = (t.cur % g.tx) * TW, y0 = g.row0 + (t.cur / g.tx) * TH;
         for (int idx = threadIdx.x; idx < LN; idx += BLOCK) {
             const int ly = idx / LW, lx = idx - ly * LW;
             const int gx = x0 + lx - 1, gy = y0 + ly - 1;
@@ -407,17 +269,22 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
                 ox = o.x; oy = o.y; uxx = u.x; uyy = u.y;
                 sincosf(ang[pix], &ss, &cc);
                 ff = mask[pix] == 0.0f ? 1 : 0;
+                if ((gy < g.row0 || gy >= g.row1) && lx >= 1 && lx <= TW) {
+                    // ghost row of a slab: the step kernel reads these planes as halo
+                    cs[pix] = make_float2(cc, ss); flags[pix] = ff;
+                    reinterpret_cast<float2*>(p_prev)[pix] = make_float2(0.f, 0.f); p_prev[2 * N + pix] = 0.f;
+                }
             }
             T.px[idx] = ox; T.py[idx] = oy; T.c[idx] = cc; T.s[idx] = ss; T.ux[idx] = uxx; T.uy[idx] = uyy; T.f[idx] = ff;
         }
         __syncthreads();
         const int lx = (threadIdx.x % TW) + 1;
         const int gx = x0 + lx - 1;
-        for (int k = 0; k < PER_THREAD; ++k) {
-            const int ly = (threadIdx.x / TW) * PER_THREAD + k + 1;
+        for (int k = 0; k < PER; ++k) {
+            const int ly = (threadIdx.x / TW) * PER + k + 1;
             const int gy = y0 + ly - 1;
             const int i = ly * LW + lx;
-            if (gx < g.W && gy < g.H) {
+            if (gx < g.W && gy < g.row1) {
                 const long pix = (long)gy * g.W + gx;
                 const unsigned char act = T.f[i] & 1;
                 float rx = 0.f, ry = 0.f, ra = 0.f, mx = 0.f, my = 0.f, ma = 0.f;
@@ -467,10 +334,10 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
     block_store_partial(acc, aN_out, red);
 }
 
-// ------------------------------------------------------------------------------------------ cost
-// computeCost (gauss_newton.t:1067-1079, thallo.t:3939-3949): once per solve (+ per LM step).
+// ------------------------------------------------------------------------------------------ computeCost
+// gauss_newton.t:1067-1079, thallo.t:3939-3949: once per solve (+ once per LM step); neighbours via L1/L2.
 constexpr int CW = 64, CH = 4;
-__global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int ctx, int ntiles,
+__global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int row0, int row1, int ctx, int ntiles,
                                                 const float2* __restrict__ off, const float* __restrict__ ang,
                                                 const float2* __restrict__ ur, const float2* __restrict__ cons,
                                                 const float* __restrict__ mask, float wf, float wr, float* __restrict__ out)
@@ -478,8 +345,8 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int ctx, int ntile
     __shared__ float red[16];
     float acc = 0.0f;
     for (TileSweep t(ntiles); t.valid(); t.next()) {
-        const int x = (t.cur % ctx) * CW + (threadIdx.x % CW), y = (t.cur / ctx) * CH + (threadIdx.x / CW);
-        if (x < W && y < H) {
+        const int x = (t.cur % ctx) * CW + (threadIdx.x % CW), y = row0 + (t.cur / ctx) * CH + (threadIdx.x / CW);
+        if (x < W && y < row1) {
             const long i = (long)y * W + x;
             if (mask[i] == 0.0f) {
                 const float2 o = off[i]; const float2 u = ur[i];
@@ -516,64 +383,58 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int ctx, int ntile
 
 extern "C" {
 
-void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 1) g_iw_variant = value; if (what == 2) g_iw_shape = value; if (what == 3) g_nt_mask = value; }
+void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; }
 
-int thallo_hip_iw_cost(int W, int H, const float* offset, const float* angle, const float* urshape,
+int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
                        float* cost_out, thallo_stream_t stream)
 {
-    const int ctx = (W + CW - 1) / CW, cty = (H + CH - 1) / CH, nt = ctx * cty;
+    if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
+    const int ctx = (W + CW - 1) / CW, cty = (row1 - row0 + CH - 1) / CH, nt = ctx * cty;
     int grid = thallo_hip_device_cu_count() * 4; if (grid > THALLO_MAX_PARTIALS) grid = THALLO_MAX_PARTIALS;
     grid -= grid % 8; if (nt < grid) grid = nt;
-    hipLaunchKernelGGL(k_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, W, H, ctx, nt,
+    hipLaunchKernelGGL(k_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, W, H, row0, row1, ctx, nt,
                        (const float2*)offset, angle, (const float2*)urshape, (const float2*)constraints, mask, w_fit, w_reg, cost_out);
     int e = check_launch(); return e ? e : grid;
 }
 
-int thallo_hip_iw_pcg_init(int W, int H, const float* offset, const float* angle, const float* urshape,
+int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                            const float* constraints, const float* mask, float w_fit, float w_reg,
                            float* r, float* pre, float* z, float* p_prev, float* delta,
                            float* cs, unsigned char* flags, float* aN_out, thallo_stream_t stream)
 {
-    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 4);
     hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)offset, angle, (const float2*)urshape, (const float2*)constraints, mask, w_fit, w_reg,
                        r, pre, z, p_prev, delta, (float2*)cs, flags, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 
-int thallo_hip_iw_pcg_step1(int W, int H, const float* cs, const float* urshape, const unsigned char* flags,
+int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
                             int first, thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
                             float* aD_out, thallo_stream_t stream)
 {
-    hipStream_t s = (hipStream_t)stream;
-    const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
-    int grid;
-    if (g_iw_variant == 1)      grid = launch_step1p<true, 4>(g_iw_shape, 4, W, H, s, cs, urshape, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8));
-    else if (g_iw_variant == 2) grid = launch_step1p<true, 3>(g_iw_shape, 3, W, H, s, cs, urshape, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8));
-    else {
-        const Geo g = make_geo(W, H); grid = grid_for(g);
-        hipLaunchKernelGGL(k_step1<true>, dim3(grid), dim3(BLOCK), 0, s, g, (const float2*)cs, (const float2*)urshape, flags, wf2, wr2,
-                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug);
-    }
+    if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 3);      // 150 VGPRs -> 3 workgroups per CU
+    hipLaunchKernelGGL((k_step1<true, 3>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
+                       (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
+                       z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8));
     int e = check_launch(); return e ? e : grid;
 }
 
-int thallo_hip_iw_apply_jtj(int W, int H, const float* cs, const float* urshape, const unsigned char* flags,
+int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
 {
+    if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 4);
     thallo_sum_t none; none.partials = nullptr; none.count = 0;
-    hipStream_t s = (hipStream_t)stream;
-    const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
-    int grid;     /* z/p_out/delta are unused when !FUSED: pass valid dummies */
-    if (g_iw_variant >= 1) grid = launch_step1p<false, 4>(g_iw_shape, 4, W, H, s, cs, urshape, flags, wf2, wr2, p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug);
-    else {
-        const Geo g = make_geo(W, H); grid = grid_for(g);
-        hipLaunchKernelGGL(k_step1<false>, dim3(grid), dim3(BLOCK), 0, s, g, (const float2*)cs, (const float2*)urshape, flags, wf2, wr2,
-                           p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug);
-    }
+    /* z / p_out / delta are unused when !FUSED: pass valid dummies */
+    hipLaunchKernelGGL((k_step1<false, 4>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
+                       (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
+                       p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug);
     int e = check_launch(); return e ? e : grid;
 }
 

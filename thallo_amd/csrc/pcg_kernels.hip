@@ -47,14 +47,17 @@ inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuc
 // r -= alpha*Ap ; z = pre*r ; betaN partial
 template <bool HAS_PRE>
 __global__ __launch_bounds__(BLOCK) void k_step2(float4* __restrict__ r, const float4* __restrict__ Ap,
-                                                  const float4* __restrict__ pre, float4* __restrict__ z, long n4,
+                                                  const float4* __restrict__ pre, float4* __restrict__ z,
+                                                  long off0, long len0, long off1, long len1,
                                                   thallo_sum_t aN, thallo_sum_t aD, float* __restrict__ bN_out, int ntm)
-{
+{   // two float4 ranges [off0,off0+len0) U [off1,off1+len1): the owned rows of a slab in the flat layout
     __shared__ float red[16];
     const bool nt_r = ntm & 1, nt_pre = ntm & 2, nt_ap = ntm & 4, nt_z = ntm & 8;
     const float alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
     float acc = 0.0f;
-    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+    const long n4 = len0 + len1;
+    for (long j = (long)blockIdx.x * BLOCK + threadIdx.x; j < n4; j += (long)gridDim.x * BLOCK) {
+        const long i = j < len0 ? off0 + j : off1 + (j - len0);
         float4 rv = ldf4(r + i, nt_r); const float4 av = ldf4(Ap + i, nt_ap);
         float4 pv = make_float4(1.f, 1.f, 1.f, 1.f);
         if (HAS_PRE) pv = ldf4(pre + i, nt_pre);
@@ -128,6 +131,47 @@ __global__ __launch_bounds__(BLOCK) void k_linear_update(float* __restrict__ X, 
     }
 }
 
+// out[0] = sum(partials) (if any), out[1..] = the listed segments of `vec`, concatenated (slab boundary rows)
+__global__ __launch_bounds__(BLOCK) void k_slab_pack(const float* __restrict__ vec, thallo_segs_t segs, thallo_sum_t s, float* __restrict__ out)
+{
+    if (blockIdx.x == 0 && s.count > 0) {
+        const float v = sum_partials(s.partials, s.count);
+        if (threadIdx.x == 0) out[0] = v;
+    }
+    long base = 1;
+    for (int k = 0; k < segs.n; ++k) {
+        for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < segs.len[k]; i += (long)gridDim.x * BLOCK) out[base + i] = vec[segs.off[k] + i];
+        base += segs.len[k];
+    }
+}
+
+// sum_out[0] = sum_r gathered[r*stride] in rank order (bit-identical on every rank); ghost segments of `vec`
+// <- the neighbours' packed boundary rows
+__global__ __launch_bounds__(BLOCK) void k_slab_unpack(float* __restrict__ vec, thallo_segs_t top, const float* __restrict__ src_top,
+                                                        thallo_segs_t bot, const float* __restrict__ src_bot,
+                                                        const float* __restrict__ gathered, long stride, int world, float* __restrict__ sum_out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sum_out) {
+        float v = 0.0f;
+        for (int r = 0; r < world; ++r) v += gathered[(long)r * stride];
+        sum_out[0] = v;
+    }
+    if (src_top) {
+        long base = 0;
+        for (int k = 0; k < top.n; ++k) {
+            for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < top.len[k]; i += (long)gridDim.x * BLOCK) vec[top.off[k] + i] = src_top[base + i];
+            base += top.len[k];
+        }
+    }
+    if (src_bot) {
+        long base = 0;
+        for (int k = 0; k < bot.n; ++k) {
+            for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < bot.len[k]; i += (long)gridDim.x * BLOCK) vec[bot.off[k] + i] = src_bot[base + i];
+            base += bot.len[k];
+        }
+    }
+}
+
 __global__ void k_finish_sum(thallo_sum_t s, float* __restrict__ out)
 {
     const float v = sum_partials(s.partials, s.count);
@@ -151,16 +195,24 @@ void thallo_hip_debug_set2(int value) { g_nt2 = value; }
 long thallo_hip_vector_elems(long n) { return (n + 255) / 256 * 256; }
 int thallo_hip_device_cu_count(void) { return cu_count(); }
 
+int thallo_hip_pcg_step2_ranges(float* r, const float* Ap, const float* pre, float* z,
+                                long off0, long len0, long off1, long len1,
+                                thallo_sum_t aN, thallo_sum_t aD, float* bN_out, thallo_stream_t stream)
+{
+    if ((off0 | len0 | off1 | len1) & 3) return -(int)hipErrorInvalidValue;     // 16-byte granules
+    const long o0 = off0 / 4, l0 = len0 / 4, o1 = off1 / 4, l1 = len1 / 4;
+    const int grid = flat_grid(l0 + l1, cu_count());
+    hipStream_t s = (hipStream_t)stream;
+    if (pre) hipLaunchKernelGGL(k_step2<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, o0, l0, o1, l1, aN, aD, bN_out, g_nt2);
+    else     hipLaunchKernelGGL(k_step2<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, o0, l0, o1, l1, aN, aD, bN_out, g_nt2);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
 int thallo_hip_pcg_step2(float* r, const float* Ap, const float* pre, float* z, long n,
                          thallo_sum_t aN, thallo_sum_t aD, float* bN_out, thallo_stream_t stream)
 {
-    const long n4 = (n + 3) / 4;
-    const int grid = flat_grid(n4, cu_count());
-    hipStream_t s = (hipStream_t)stream;
-    if (pre) hipLaunchKernelGGL(k_step2<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out, g_nt2);
-    else     hipLaunchKernelGGL(k_step2<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, n4, aN, aD, bN_out, g_nt2);
-    int e = check_launch();
-    return e ? e : grid;
+    return thallo_hip_pcg_step2_ranges(r, Ap, pre, z, 0, (n + 3) / 4 * 4, 0, 0, aN, aD, bN_out, stream);
 }
 
 int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const float* Ap, const float* pre,
@@ -205,6 +257,21 @@ int thallo_hip_linear_update(float* X, const float* delta, const float* p, long 
 int thallo_hip_finish_sum(thallo_sum_t sum, float* out, thallo_stream_t stream)
 {
     hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, sum, out);
+    return check_launch();
+}
+
+int thallo_hip_slab_pack(const float* vec, thallo_segs_t segs, thallo_sum_t sum, float* out, thallo_stream_t stream)
+{
+    if (segs.n < 0 || segs.n > 4) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_slab_pack, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, segs, sum, out);
+    return check_launch();
+}
+
+int thallo_hip_slab_unpack(float* vec, thallo_segs_t top, const float* src_top, thallo_segs_t bot, const float* src_bot,
+                           const float* gathered, long stride, int world, float* sum_out, thallo_stream_t stream)
+{
+    if (top.n < 0 || top.n > 4 || bot.n < 0 || bot.n > 4) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_slab_unpack, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, top, src_top, bot, src_bot, gathered, stride, world, sum_out);
     return check_launch();
 }
 

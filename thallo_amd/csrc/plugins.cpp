@@ -70,17 +70,17 @@ public:
     }
     float* unknown_ptr(int k) override { return k == 0 ? offset : angle; }
     int cost(LaunchCtx& c, float* out) override
-    { TimedLaunch t(c, "computeCost"); return thallo_hip_iw_cost(W, H, offset, angle, urshape, constraints, mask, w_fit, w_reg, out, c.stream); }
+    { TimedLaunch t(c, "computeCost"); return thallo_hip_iw_cost(W, H, 0, H, offset, angle, urshape, constraints, mask, w_fit, w_reg, out, c.stream); }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
         TimedLaunch t(c, "PCGInit1");
-        return thallo_hip_iw_pcg_init(W, H, offset, angle, urshape, constraints, mask, w_fit, w_reg,
+        return thallo_hip_iw_pcg_init(W, H, 0, H, offset, angle, urshape, constraints, mask, w_fit, w_reg,
                                       v.r, v.pre, v.z, v.p[cur], v.delta, (float*)cs.ptr, (unsigned char*)flags.ptr, aN, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_iw_pcg_step1(W, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
+        return thallo_hip_iw_pcg_step1(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
                                        v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, out, c.stream);
     }
 };

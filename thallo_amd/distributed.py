@@ -1,0 +1,301 @@
+"""Row-slab multi-GPU driver for the image-stencil hot path (image_warping), one process per GPU.
+
+The reference is single-device (NULL stream everywhere, API/src/util.t:769-772; no NCCL/MPI anywhere),
+so this layer is new design:
+
+  * the H rows of the image are split into contiguous slabs, one per rank; a rank's local image carries
+    one ghost row above/below (the energy's stencil radius is 1, image_warping.t:18);
+  * every rank runs the same gfx950 kernels as the single-GPU path on its owned rows
+    (include/thallo_hip.h: row0/row1 arguments);
+  * per PCG iteration there are exactly two exchanges, and both are dictated by the algorithm
+    (gauss_newton.t:1641-1665): alphaD = sum p.Ap after PCGStep1 (a 1-float all-reduce), and after
+    PCGStep2 ONE all-gather of [betaN_local | first owned row of z | last owned row of z]
+    (1 + 6W floats per rank) that delivers both the second scalar and the ghost rows of z.  p on the
+    ghost rows is kept current by the fused step kernel itself, so p never crosses the wire;
+  * every rank adds the gathered partial sums in rank order, so alpha and beta are bit-identical on all
+    ranks and the replicated host logic cannot diverge;
+  * once per GN step the ghost rows of the unknowns (Offset, Angle) are refreshed the same way.
+
+Communication goes through torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
+CPU tests (tests/test_distributed_cpu.py drives this exact class with a numpy compute backend).
+The compute backend below (HipSlabBackend) is the product path; it fails loudly without libThallo.so.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+class SlabLayout:
+    """Rows [g0,g1) of an H-row image owned by `rank`; local image = owned rows + ghost rows."""
+
+    def __init__(self, H, rank, world, align=16):
+        # slabs are multiples of `align` rows (the kernels' tile height) while rows last; remainder to the last rank
+        blocks = (H + align - 1) // align
+        per, rem = divmod(blocks, world)
+        counts = [(per + (1 if r < rem else 0)) * align for r in range(world)]
+        start = 0
+        bounds = []
+        for c in counts:
+            bounds.append((min(start, H), min(start + c, H)))
+            start += c
+        self.H, self.rank, self.world = H, rank, world
+        self.bounds = bounds
+        self.g0, self.g1 = bounds[rank]
+        if self.g1 <= self.g0:
+            raise ValueError(f"rank {rank} of {world} owns no rows of an image with {H} rows")
+        self.top = 1 if self.g0 > 0 else 0
+        self.bot = 1 if self.g1 < H else 0
+        self.Hl = (self.g1 - self.g0) + self.top + self.bot
+        self.row0 = self.top
+        self.row1 = self.top + (self.g1 - self.g0)
+
+    def local(self, arr):
+        """Rows of a global [H, ...] array that this rank holds (owned + ghost)."""
+        return arr[self.g0 - self.top: self.g1 + self.bot]
+
+    def up(self):
+        return self.rank - 1 if self.top else None
+
+    def down(self):
+        return self.rank + 1 if self.bot else None
+
+
+def _segs(pairs):
+    s = api.SegsT()
+    for k, (o, l) in enumerate(pairs):
+        s.off[k] = o
+        s.len[k] = l
+    s.n = len(pairs)
+    return s
+
+
+class HipSlabBackend:
+    """image_warping slab kernels through the C-ABI shim; all tensors live on the current CUDA device."""
+
+    def __init__(self, W, layout, local_params, max_l_iters):
+        self.L = api.lib()
+        self.W, self.lay = W, layout
+        Hl = layout.Hl
+        self.Hl, self.row0, self.row1 = Hl, layout.row0, layout.row1
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.offset, self.angle, self.urshape, self.constraints, self.mask = [
+            torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in local_params[:5]]
+        self.w_fit, self.w_reg = float(local_params[5]), float(local_params[6])
+        self.L.thallo_hip_vector_elems.restype = C.c_long
+        self.L.thallo_hip_vector_elems.argtypes = [C.c_long]
+        N = W * Hl
+        self.N, self.n = N, 3 * N
+        na = self.L.thallo_hip_vector_elems(self.n)
+        z = lambda: torch.zeros(na, dtype=torch.float32, device=dev)
+        self.r, self.pre, self.z, self.delta, self.Ap = z(), z(), z(), z(), z()
+        self.p = [z(), z()]
+        self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
+        self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
+        self.parts = torch.zeros(1024, dtype=torch.float32, device=dev)      # local partials of the current reduction
+        self.nb = 1
+        self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32, device=dev)    # global (all-reduced) scalars
+        self.msg = 1 + 6 * W
+        self.send = torch.zeros(self.msg, dtype=torch.float32, device=dev)
+        self.gath = torch.zeros(layout.world * self.msg, dtype=torch.float32, device=dev)
+        # flat-layout pieces: Offset plane [2*W*row, 2W), Angle plane [2N + W*row, W)
+        row = lambda y: [(2 * W * y, 2 * W), (2 * N + W * y, W)]
+        self.seg_first_last = _segs(row(self.row0) + row(self.row1 - 1))
+        self.seg_top_ghost = _segs(row(self.row0 - 1)) if layout.top else _segs([])
+        self.seg_bot_ghost = _segs(row(self.row1)) if layout.bot else _segs([])
+        if W % 4 or (2 * N) % 4:
+            raise ValueError("the slab path needs W % 4 == 0 (16-byte row granules in the flat kernels)")
+
+    # -- helpers
+    def _st(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _sum(self, idx):
+        return api.SumT(self.S.data_ptr() + 4 * idx, 1)
+
+    def _local(self):
+        return api.SumT(self.parts.data_ptr(), self.nb)
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed with hipError {-rc}")
+        return rc
+
+    # -- compute phases
+    def cost_local(self, out_idx):
+        vp, fl = C.c_void_p, C.c_float
+        self.nb = self._chk(self.L.thallo_hip_iw_cost(self.W, self.Hl, self.row0, self.row1, vp(self.offset.data_ptr()), vp(self.angle.data_ptr()),
+                                                      vp(self.urshape.data_ptr()), vp(self.constraints.data_ptr()), vp(self.mask.data_ptr()),
+                                                      fl(self.w_fit), fl(self.w_reg), vp(self.parts.data_ptr()), self._st()), "iw_cost")
+        self._chk(self.L.thallo_hip_finish_sum(self._local(), vp(self.S.data_ptr() + 4 * out_idx), self._st()), "finish_sum")
+
+    def init(self, cur):
+        vp, fl = C.c_void_p, C.c_float
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_init(
+            self.W, self.Hl, self.row0, self.row1, vp(self.offset.data_ptr()), vp(self.angle.data_ptr()), vp(self.urshape.data_ptr()),
+            vp(self.constraints.data_ptr()), vp(self.mask.data_ptr()), fl(self.w_fit), fl(self.w_reg),
+            vp(self.r.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.delta.data_ptr()),
+            vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_init")
+
+    def step1(self, cur, first, iN, iD, iB, out_idx):
+        vp, fl = C.c_void_p, C.c_float
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1(
+            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
+            fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
+            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), 1 if first else 0, self._sum(iN), self._sum(iD), self._sum(iB),
+            vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
+        self._chk(self.L.thallo_hip_finish_sum(self._local(), vp(self.S.data_ptr() + 4 * out_idx), self._st()), "finish_sum")
+
+    def step2(self, iN, iD):
+        vp = C.c_void_p
+        W, N = self.W, self.N
+        rows = self.row1 - self.row0
+        self.nb = self._chk(self.L.thallo_hip_pcg_step2_ranges(
+            vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()),
+            C.c_long(2 * W * self.row0), C.c_long(2 * W * rows), C.c_long(2 * N + W * self.row0), C.c_long(W * rows),
+            self._sum(iN), self._sum(iD), vp(self.parts.data_ptr()), self._st()), "pcg_step2_ranges")
+
+    def pack(self):
+        """send = [sum(local partials) | first owned row of z | last owned row of z]"""
+        self._chk(self.L.thallo_hip_slab_pack(C.c_void_p(self.z.data_ptr()), self.seg_first_last, self._local(),
+                                              C.c_void_p(self.send.data_ptr()), self._st()), "slab_pack")
+
+    def unpack(self, out_idx, gathered):
+        lay, msg = self.lay, self.msg
+        base = gathered.data_ptr()
+        # my top ghost row <- the LAST owned row of rank-1 ; my bottom ghost row <- the FIRST owned row of rank+1
+        src_top = C.c_void_p(base + 4 * ((lay.rank - 1) * msg + 1 + 3 * self.W)) if lay.top else None
+        src_bot = C.c_void_p(base + 4 * ((lay.rank + 1) * msg + 1)) if lay.bot else None
+        self._chk(self.L.thallo_hip_slab_unpack(C.c_void_p(self.z.data_ptr()), self.seg_top_ghost, src_top, self.seg_bot_ghost, src_bot,
+                                                C.c_void_p(base), C.c_long(msg), lay.world, C.c_void_p(self.S.data_ptr() + 4 * out_idx), self._st()),
+                  "slab_unpack")
+
+    def linear_update(self, cur, iN, iD, with_p):
+        vp = C.c_void_p
+        W, N = self.W, self.N
+        rows = self.row1 - self.row0
+        for X, off, ln, xo in ((self.offset, 2 * W * self.row0, 2 * W * rows, 2 * W * self.row0), (self.angle, 2 * N + W * self.row0, W * rows, W * self.row0)):
+            p_ptr = vp(self.p[cur].data_ptr() + 4 * off) if with_p else None
+            self._chk(self.L.thallo_hip_linear_update(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off), p_ptr, C.c_long(ln),
+                                                      self._sum(iN), self._sum(iD), self._st()), "linear_update")
+
+    def scalar(self, idx):
+        return float(self.S[idx].item())
+
+
+class SlabSolver:
+    """Gauss-Newton + PCG over row slabs; replicated host logic, rank-ordered sums (gauss_newton.t:1545-1785)."""
+
+    def __init__(self, backend, layout, group=None):
+        self.be, self.lay, self.group = backend, layout, group
+        self.world = layout.world
+
+    # -- collectives
+    def _allreduce(self, idx):
+        if self.world > 1:
+            dist.all_reduce(self.be.S[idx:idx + 1], group=self.group)
+
+    def _gather_sum_and_rows(self, out_idx):
+        be = self.be
+        be.pack()
+        if self.world > 1:
+            dist.all_gather_into_tensor(be.gath, be.send, group=self.group)
+            be.unpack(out_idx, be.gath)
+        else:
+            be.unpack(out_idx, be.send)
+
+    def _exchange_unknown_ghosts(self):
+        """once per GN step: ghost rows of Offset/Angle <- neighbours' boundary rows"""
+        if self.world == 1:
+            return
+        be, lay = self.be, self.lay
+        W = be.W
+        off = be.offset.view(be.Hl, 2 * W)
+        ang = be.angle.view(be.Hl, W)
+        send = torch.cat([off[be.row0], ang[be.row0], off[be.row1 - 1], ang[be.row1 - 1]])
+        gath = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(gath, send, group=self.group)
+        g = gath.view(self.world, 2, 3 * W)
+        if lay.top:
+            off[be.row0 - 1].copy_(g[lay.rank - 1, 1, :2 * W]); ang[be.row0 - 1].copy_(g[lay.rank - 1, 1, 2 * W:])
+        if lay.bot:
+            off[be.row1].copy_(g[lay.rank + 1, 0, :2 * W]); ang[be.row1].copy_(g[lay.rank + 1, 0, 2 * W:])
+
+    # -- solver
+    def cost(self):
+        self.be.cost_local(0)
+        self._allreduce(0)
+        return self.be.scalar(0)
+
+    def gn_step(self, l_iters):
+        """One Gauss-Newton iteration: PCGInit + l_iters PCG iterations + linear update (no host sync)."""
+        be = self.be
+        B, L = 2, l_iters
+        cur = 0
+        be.init(cur)                                   # local alphaN partials, z, ...
+        self._gather_sum_and_rows(B)                   # S[B] = alphaN_0 (global); ghost rows of z
+        for k in range(L):
+            jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
+            be.step1(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
+            self._allreduce(jD)                        # alphaD_k
+            cur ^= 1
+            be.step2(jN, jD)
+            self._gather_sum_and_rows(jB)              # betaN_k ; ghost rows of z
+        if L > 0:
+            be.linear_update(cur, B + 2 * (L - 1), B + 2 * (L - 1) + 1, True)
+        else:
+            be.linear_update(cur, B, B, False)
+        self._exchange_unknown_ghosts()
+
+    def solve(self, n_iters, l_iters):
+        costs = [self.cost()]
+        for _ in range(n_iters):
+            self.gn_step(l_iters)
+            costs.append(self.cost())
+        return costs
+
+
+def make_hip_solver(params_global, W, H, rank, world, max_l_iters):
+    lay = SlabLayout(H, rank, world)
+    local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in params_global]
+    be = HipSlabBackend(W, lay, local, max_l_iters)
+    return SlabSolver(be, lay), lay
+
+
+def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world):
+    """bench.py's N>1 leg: K timed GN steps between barriers, MAX over ranks, rank 0 reports."""
+    solver, lay = make_hip_solver(params_global, W, H, rank, world, l_iters)
+    c0 = solver.cost()
+    for _ in range(warmup):
+        solver.gn_step(l_iters)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.gn_step(l_iters)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    final = solver.cost()
+    npx = W * H
+    return {
+        "metric": "pcg_iters_per_sec", "value": steps * l_iters / dt, "unit": "PCG iterations/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"examples/image_warping {W}x{H} ARAP, GN + matrix-free PCG, {l_iters} PCG iterations per GN step",
+                   "width": W, "height": H, "unknowns": 3 * npx, "l_iterations": l_iters,
+                   "parallelism": f"{world} row slabs, RCCL all-reduce(alphaD) + all-gather(betaN, z ghost rows) per PCG iteration"},
+        "ms_per_gn_iter": dt / steps * 1e3, "us_per_pcg_iter": dt / (steps * l_iters) * 1e6,
+        "initial_cost": c0, "final_cost": final,
+        "roofline": None, "cpu_baseline": None,
+    }

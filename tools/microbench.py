@@ -25,7 +25,7 @@ cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros
 parts = torch.zeros(16 * 1024, dtype=torch.float32, device="cuda")
 vp, fl = C.c_void_p, C.c_float
 PB = parts.data_ptr()
-nb0 = L.thallo_hip_iw_pcg_init(W, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+nb0 = L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                                vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
                                vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(PB), None)
 s_aN = api.SumT(PB, nb0)
@@ -44,7 +44,7 @@ def timeit(fn, reps=REPS):
 
 
 def step1_fused(first=0):
-    nb = L.thallo_hip_iw_pcg_step1(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
+    nb = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                    vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
                                    first, s_aN, s_aN, s_aN, vp(PB + 4096), None)
     assert nb > 0
@@ -52,7 +52,7 @@ def step1_fused(first=0):
 
 
 def step1_plain():
-    nb = L.thallo_hip_iw_apply_jtj(W, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
+    nb = L.thallo_hip_iw_apply_jtj(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                    vp(z.data_ptr()), vp(Ap.data_ptr()), vp(PB + 4096), None)
     assert nb > 0
     return nb

@@ -80,6 +80,12 @@ int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const floa
 int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t betaN, thallo_sum_t alphaN,
                          int lm, thallo_stream_t stream);
 
+/* Stand-alone form of what the fused image kernels do on the fly: PCGStep3 of iteration k-1 (:889-899) and
+ * the delta part of PCGStep2 (:814-815):  delta += alpha*p_in ; p_out = z + beta*p_in  (first != 0: p_out = z).
+ * Used by plugins whose applyJTJ gathers p through index lists (graph domains). */
+int thallo_hip_pcg_pupdate(const float* z, const float* p_in, float* p_out, float* delta, long n, int first,
+                           thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_stream_t stream);
+
 /* PCGLinearUpdate (gauss_newton.t:901-906) for one unknown image:  X[i] += delta[i] (+ alpha*p[i]
  * when p != NULL: the fused schedule's last pending delta += alpha*p). */
 int thallo_hip_linear_update(float* X, const float* delta, const float* p, long len,
@@ -144,6 +150,37 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
                             int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
                             float* alphaD_out, thallo_stream_t stream);
+
+/* ---------------------------------------------------------------- graph-edge domains
+ * Incidence lists built by the host from the Sparse maps V0/V1 (device int32 arrays, thallo.t:136) once per
+ * Init -- legal because the maps are constant during a solve; the reference instead scatters with atomics
+ * every iteration (thallo.t:3352-3403):
+ *   out_ptr[N+1], out_v1[E] : edges sorted by source vertex; the position in this order is the edge id e'
+ *   in_ptr[N+1], in_edge[E], in_src[E] : for each vertex the ids / source vertices of the edges ending there
+ *
+ * E6: tests/minimal_graph/laplacian.t  (X float unknown (0), A float (1), v0 (2), v1 (3); w_fit literal) */
+int thallo_hip_lapgraph_cost(int N, const int* out_ptr, const int* out_v1, const float* X, const float* A, float w_fit,
+                             float* cost_out, thallo_stream_t stream);
+int thallo_hip_lapgraph_pcg_init(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
+                                 const float* X, const float* A, float w_fit, float* r, float* z, float* p_prev, float* delta,
+                                 float* alphaN_out, thallo_stream_t stream);
+int thallo_hip_lapgraph_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
+                                  float w_fit, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+
+/* E2: examples/arap_mesh_deformation/arap_mesh_deformation.t  (w_fitSqrt (0), w_regSqrt (1), Position float3 (2) and
+ * Angle float3 (3) unknown, Original float3 (4), Constraints float3 (5), V0 (6), V1 (7)).
+ * Flat vector layout [Position 3n+c | Angle 3N+3n+c].  precompute (once per GN iteration) fills, per edge in
+ * out-CSR order, F[3E] = the reg residual and G[9E] = d(R(Angle) dv)/d(Angle) (three float3 columns). */
+int thallo_hip_arap_cost(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
+                         const float* original, const float* constraints, float w_fit, float w_reg, float* cost_out, thallo_stream_t stream);
+int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
+                               const float* original, float w_reg, float* F, float* G, thallo_stream_t stream);
+int thallo_hip_arap_pcg_init(int N, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
+                             const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
+                             float* r, float* pre, float* z, float* p_prev, float* delta, float* alphaN_out, thallo_stream_t stream);
+int thallo_hip_arap_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
+                              const float* constraints, const float* G, float w_fit, float w_reg,
+                              const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 
 /* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped
  * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's

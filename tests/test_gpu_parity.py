@@ -237,3 +237,61 @@ def test_unknown_energy_and_bad_kind_fail_loudly(torch, tmp_path):
         api.ThalloSolver((8, 8), thallo_amd.energy_file("image_warping"), solverkind="newton")
     with pytest.raises(RuntimeError):
         api.ThalloSolver((8, 8), thallo_amd.energy_file("image_warping"), cpu_only=True)
+
+
+# ------------------------------------------------------------------ graph-edge domains
+def test_kat_minimal_graph_gold_png(torch, golden_dir, orc):
+    """tests/minimal_graph: 512-node chain, MSVC-rand input, GN10 x PCG10 -> gold.png bytes."""
+    gold = np.fromfile(os.path.join(golden_dir, "minimal_graph_gold.u8"), np.uint8)
+    A = orc.msvc_rand(512)
+    v0 = np.arange(511, dtype=np.int32); v1 = v0 + 1
+    s, dev, costs, final = _solve_gpu("laplacian_graph", (512, 511), [A.copy(), A, v0, v1])
+    assert s.energy_name == "laplacian_graph"
+    assert ((to_host(dev[0]) * 255).astype(np.uint8) == gold).all()
+    Xo = A.copy()
+    co, _ = orc.Problem(orc.LAPLACIAN_GRAPH, (512, 511), [Xo, A, v0, v1], fconst=[0.5]).solve()
+    assert rel_err(costs, co) < COST_RTOL
+
+
+def test_laplacian_graph_irregular_matches_oracle(torch, orc):
+    p = syn.laplacian_graph(300, extra_edges=500)
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.LAPLACIAN_GRAPH, (300, len(p[2])), po, fconst=[0.5]).solve(nIterations=4, lIterations=30)
+    s, dev, costs, _ = _solve_gpu("laplacian_graph", (300, len(p[2])), p, nIterations=4, lIterations=30)
+    assert rel_err(costs, co) < COST_RTOL
+    assert rel_err(to_host(dev[0]), po[0]) < VEC_RTOL
+
+
+@pytest.mark.parametrize("nu,nv,nit,lit", [(12, 8, 6, 40), (40, 30, 5, 60), (3, 3, 2, 5)])
+def test_arap_cost_trajectory(torch, orc, nu, nv, nit, lit):
+    p = syn.arap_mesh(nu, nv, n_handles=min(8, nu * nv // 2), angle_amp=0.3)
+    N, E = p[2].shape[0], p[6].shape[0]
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, E), po).solve(nIterations=nit, lIterations=lit)
+    s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (N, E), p, nIterations=nit, lIterations=lit)
+    assert s.energy_name == "arap_mesh"
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)
+    assert rel_err(to_host(dev[2]), po[2]) < VEC_RTOL and np.abs(to_host(dev[3]) - po[3]).max() < VEC_RTOL * max(1.0, np.abs(po[3]).max())
+
+
+def test_arap_100k_vertices(torch, orc):
+    """BASELINE config 3 size: 320x320 torus = 102,400 vertices / 614,400 directed edges."""
+    p = syn.arap_mesh(320, 320)
+    N, E = p[2].shape[0], p[6].shape[0]
+    assert N == 102400 and E == 614400
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, E), po).solve(nIterations=2, lIterations=40)
+    s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (N, E), p, nIterations=2, lIterations=40)
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)
+    # reproducible: gather form has no atomics
+    s2, dev2, costs2, _ = _solve_gpu("arap_mesh_deformation", (N, E), p, nIterations=2, lIterations=40)
+    assert list(costs) == list(costs2) and torch.equal(dev[2], dev2[2])
+
+
+def test_graph_rejects_out_of_range_edges(torch):
+    p = syn.laplacian_graph(50)
+    p[2][3] = 99
+    dev = to_device(p)
+    s = api.ThalloSolver((50, len(p[2])), thallo_amd.energy_file("laplacian_graph"))
+    s.solve(dev, nIterations=1, lIterations=1)
+    assert "outside" in api.last_error()

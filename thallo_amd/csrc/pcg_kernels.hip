@@ -116,6 +116,29 @@ __global__ __launch_bounds__(BLOCK) void k_step3(float4* __restrict__ p, const f
     }
 }
 
+// unfused PCGStep3 + delta update for energies whose applyJTJ gathers p through indices (graph domains):
+//   delta += alpha*p_in ; p_out = z + beta*p_in    (first: p_out = z)
+__global__ __launch_bounds__(BLOCK) void k_pupdate(const float4* __restrict__ z, const float4* __restrict__ p_in, float4* __restrict__ p_out,
+                                                    float4* __restrict__ delta, long n4, int first,
+                                                    thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp)
+{
+    float alpha = 0.0f, beta = 0.0f;
+    if (!first) {
+        const float an = sum_partials(aNp.partials, aNp.count);
+        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
+        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+    }
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        const float4 pv = p_in[i], zv = z[i];
+        if (!first) {
+            float4 dv = delta[i];
+            dv.x += alpha * pv.x; dv.y += alpha * pv.y; dv.z += alpha * pv.z; dv.w += alpha * pv.w;
+            delta[i] = dv;
+        }
+        p_out[i] = make_float4(zv.x + beta * pv.x, zv.y + beta * pv.y, zv.z + beta * pv.z, zv.w + beta * pv.w);
+    }
+}
+
 // X += delta (+ alpha*p).  X is a caller buffer of exactly `len` floats (not padded): scalar tail.
 template <bool HAS_P>
 __global__ __launch_bounds__(BLOCK) void k_linear_update(float* __restrict__ X, const float* __restrict__ delta,
@@ -239,6 +262,16 @@ int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t bN, thal
     hipStream_t s = (hipStream_t)stream;
     if (lm) hipLaunchKernelGGL(k_step3<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)p, (const float4*)z, n4, bN, aN);
     else    hipLaunchKernelGGL(k_step3<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)p, (const float4*)z, n4, bN, aN);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
+int thallo_hip_pcg_pupdate(const float* z, const float* p_in, float* p_out, float* delta, long n, int first,
+                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4;
+    const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_pupdate, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)z, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
     int e = check_launch();
     return e ? e : grid;
 }

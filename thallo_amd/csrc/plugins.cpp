@@ -85,11 +85,123 @@ public:
     }
 };
 
+// ------------------------------------------------------------------ graph incidence (host-built, once per Init)
+struct GraphIncidence {
+    int N = 0, E = 0;
+    DeviceBuffer out_ptr, out_v1, in_ptr, in_edge, in_src;
+    const int* bound_v0 = nullptr; const int* bound_v1 = nullptr;
+    int build(int N_, int E_, const int* d_v0, const int* d_v1)
+    {
+        N = N_; E = E_; bound_v0 = d_v0; bound_v1 = d_v1;
+        std::vector<int> v0(E), v1(E);
+        if (hipMemcpy(v0.data(), d_v0, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(v1.data(), d_v1, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess) { set_error("graph: cannot read the sparse maps"); return -1; }
+        for (int e = 0; e < E; ++e)
+            if (v0[e] < 0 || v0[e] >= N || v1[e] < 0 || v1[e] >= N) { set_error("graph: edge %d = (%d,%d) outside [0,%d)", e, v0[e], v1[e], N); return -1; }
+        std::vector<int> optr(N + 1, 0), iptr(N + 1, 0), ov1(E), pos(E), iedge(E), isrc(E);
+        for (int e = 0; e < E; ++e) { optr[v0[e] + 1]++; iptr[v1[e] + 1]++; }
+        for (int n = 0; n < N; ++n) { optr[n + 1] += optr[n]; iptr[n + 1] += iptr[n]; }
+        std::vector<int> oc(optr.begin(), optr.end() - 1), ic(iptr.begin(), iptr.end() - 1);
+        for (int e = 0; e < E; ++e) { pos[e] = oc[v0[e]]++; ov1[pos[e]] = v1[e]; }                 // stable: input order within a vertex
+        for (int e = 0; e < E; ++e) { const int k = ic[v1[e]]++; iedge[k] = pos[e]; isrc[k] = v0[e]; }
+        auto up = [&](DeviceBuffer& b, const std::vector<int>& h) {
+            if (b.alloc(sizeof(int) * (h.size() + 4))) return -1;
+            return hipMemcpy(b.ptr, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+        };
+        if (up(out_ptr, optr) || up(out_v1, ov1) || up(in_ptr, iptr) || up(in_edge, iedge) || up(in_src, isrc)) { set_error("graph: upload failed"); return -1; }
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------ tests/minimal_graph/laplacian.t
+class LaplacianGraphPlugin : public EnergyPlugin {
+    int N, E; float w_fit;
+    std::vector<UnknownImage> imgs;
+    float* X = nullptr; const float* A = nullptr; const int *v0 = nullptr, *v1 = nullptr;
+    GraphIncidence g;
+public:
+    LaplacianGraphPlugin(const unsigned* dims, float w) : N((int)dims[0]), E((int)dims[1]), w_fit(w) { imgs.push_back({ 0, (long)N }); }
+    const char* name() const override { return "laplacian_graph"; }
+    long n_unknowns() const override { return N; }
+    const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
+    bool use_preconditioner() const override { return false; }
+    int bind(void** p) override { X = (float*)p[0]; A = (const float*)p[1]; v0 = (const int*)p[2]; v1 = (const int*)p[3]; return (X && A && v0 && v1) ? 0 : -1; }
+    int prepare(LaunchCtx&) override { return g.build(N, E, v0, v1); }
+    float* unknown_ptr(int) override { return X; }
+    int cost(LaunchCtx& c, float* out) override
+    { TimedLaunch t(c, "computeCost"); return thallo_hip_lapgraph_cost(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, X, A, w_fit, out, c.stream); }
+    int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
+    {
+        TimedLaunch t(c, "PCGInit1");
+        return thallo_hip_lapgraph_pcg_init(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr,
+                                            X, A, w_fit, v.r, v.z, v.p[cur], v.delta, aN, c.stream);
+    }
+    int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
+    {
+        { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_lapgraph_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr,
+                                             w_fit, v.p[cur ^ 1], v.Ap, out, c.stream);
+    }
+};
+
+// ------------------------------------------------------------------ examples/arap_mesh_deformation/arap_mesh_deformation.t
+class ArapPlugin : public EnergyPlugin {
+    int N, E;
+    std::vector<UnknownImage> imgs;
+    float *position = nullptr, *angle = nullptr;
+    const float *original = nullptr, *constraints = nullptr; const int *v0 = nullptr, *v1 = nullptr;
+    float w_fit = 0, w_reg = 0;
+    GraphIncidence g;
+    DeviceBuffer F, G;       // per-GN-iteration edge residuals / rotation-derivative blocks (out-CSR order)
+public:
+    ArapPlugin(const unsigned* dims) : N((int)dims[0]), E((int)dims[1]) { imgs.push_back({ 2, 3L * N }); imgs.push_back({ 3, 3L * N }); }
+    const char* name() const override { return "arap_mesh"; }
+    long n_unknowns() const override { return 6L * N; }
+    const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
+    bool use_preconditioner() const override { return true; }            // arap_mesh_deformation.t:13
+    int bind(void** p) override
+    {
+        if (!p[0] || !p[1]) { set_error("arap: null weight parameter"); return -1; }
+        w_fit = *(const float*)p[0]; w_reg = *(const float*)p[1];
+        position = (float*)p[2]; angle = (float*)p[3]; original = (const float*)p[4]; constraints = (const float*)p[5];
+        v0 = (const int*)p[6]; v1 = (const int*)p[7];
+        if (!position || !angle || !original || !constraints || !v0 || !v1) { set_error("arap: null problem parameter"); return -1; }
+        if (!F.ptr) { if (F.alloc(sizeof(float) * 3 * (size_t)E + 64) || G.alloc(sizeof(float) * 9 * (size_t)E + 64)) return -1; }
+        return 0;
+    }
+    int prepare(LaunchCtx&) override { return g.build(N, E, v0, v1); }
+    float* unknown_ptr(int k) override { return k == 0 ? position : angle; }
+    int cost(LaunchCtx& c, float* out) override
+    {
+        TimedLaunch t(c, "computeCost");
+        return thallo_hip_arap_cost(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, c.stream);
+    }
+    int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
+    {
+        { TimedLaunch t(c, "precompute");
+          int rc = thallo_hip_arap_precompute(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, c.stream);
+          if (rc < 0) return rc; }
+        TimedLaunch t(c, "PCGInit1");
+        return thallo_hip_arap_pcg_init(N, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
+                                        (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, aN, c.stream);
+    }
+    int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
+    {
+        { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_arap_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+                                         constraints, (const float*)G.ptr, w_fit, w_reg, v.p[cur ^ 1], v.Ap, out, c.stream);
+    }
+};
+
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims)
 {
     auto cst = [&](const char* k, double dflt) { auto it = spec.constants.find(k); return it == spec.constants.end() ? dflt : it->second; };
     if (spec.energy == "laplacian_image") return new LaplacianImagePlugin(dims, (float)cst("w_fit", 0.2), (int)cst("xguard", 0));
     if (spec.energy == "image_warping")   return new ImageWarpingPlugin(dims);
+    if (spec.energy == "laplacian_graph") return new LaplacianGraphPlugin(dims, (float)cst("w_fit", 0.5));
+    if (spec.energy == "arap_mesh")       return new ArapPlugin(dims);
     set_error("no gfx950 plugin for energy '%s' (%s)", spec.energy.c_str(), spec.file.c_str());
     return nullptr;
 }

@@ -216,8 +216,10 @@ void Plan::init(void** params)
     finalized_ = false;
     timer_.cleanup();
     ev_total_ = timer_.start("Total", ctx.stream);
+    ready_ = false;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return; }
-    plugin->prepare(ctx);
+    if (plugin->prepare(ctx)) { const std::string why = last_error(); set_error("%s: prepare failed: %s", plugin->name(), why.c_str()); return; }
+    ready_ = true;
     sp.nIter = 0;
     prev_cost_ = compute_cost();
     printf("Initial cost: %g\n", prev_cost_);
@@ -236,14 +238,14 @@ void Plan::finalize()
 
 double Plan::cost()
 {   // gauss_newton.t:1787-1793
-    if (!ok_) return 0.0;
+    if (!ok_ || !ready_) return 0.0;
     if (!finalized_) prev_cost_ = compute_cost();
     return (double)prev_cost_;
 }
 
 int Plan::step(void** params)
 {   // gauss_newton.t:1545-1785, GN branch, fused schedule (DESIGN.md "PCG schedule")
-    if (!ok_) return 0;
+    if (!ok_ || !ready_) return 0;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return 0; }
     if (sp.nIter >= sp.nIterations) { if (!finalized_) finalize(); return 0; }
     const int L = sp.lIterations;

@@ -62,6 +62,7 @@ public:
 
 private:
     bool ok_ = false;
+    bool ready_ = false;           // Init succeeded (parameters bound, plugin prepared)
     bool lm_ = false;
     bool finalized_ = true;
     float prev_cost_ = 0.0f;

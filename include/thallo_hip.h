@@ -182,6 +182,26 @@ int thallo_hip_arap_apply_jtj(int N, const int* out_ptr, const int* out_v1, cons
                               const float* constraints, const float* G, float w_fit, float w_reg,
                               const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 
+/* ---------------------------------------------------------------- E4: examples/bundle_adjustment/bundle_adjustment.t
+ * on the materialized sparse-J path (reference: precomputeJ + cuSPARSE csrsort/csr2csc/csrmv x2,
+ * gauss_newton.t:327-487,1332-1525).  cameras float9 (0) and points float3 (1) unknown, observations float2 (2),
+ * oToC (3), oToP (4).  Flat layout [cameras 9c+k | points 9C+3p+k].
+ * Host-built incidence (once per Init), q = position of an observation in camera-sorted order:
+ *   cam_ptr[C+1], cam_obs[O] (original observation id of q), q_cam[O], q_pt[O] (camera / point of q),
+ *   pt_ptr[P+1], pt_pos[O] (the q's of each point's observations)
+ * compute_j (once per GN iteration) materialises J as one 24-float block per observation,
+ *   Jb[24q..] = { dr0/dcam[9], dr0/dpt[3], dr1/dcam[9], dr1/dpt[3] }, and the residuals F[2q..]. */
+int thallo_hip_ba_cost(int C, int P, int O, const float* cameras, const float* points, const float* observations,
+                       const int* oToC, const int* oToP, float* cost_out, thallo_stream_t stream);
+int thallo_hip_ba_compute_j(int O, const float* cameras, const float* points, const float* observations,
+                            const int* cam_obs, const int* q_cam, const int* q_pt, float* Jb, float* F, thallo_stream_t stream);
+int thallo_hip_ba_pcg_init(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
+                           const float* Jb, const float* F, float* r, float* pre, float* z, float* p_prev, float* delta,
+                           float* alphaN_out, thallo_stream_t stream);
+/* Ap = J^T (J p) by gather over the camera / point incidence lists; alphaD partials */
+int thallo_hip_ba_apply_jtj(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
+                            const float* Jb, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+
 /* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped
  * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's
  * stand-alone applyJTJ roofline measurement. */

@@ -213,6 +213,65 @@ static int rows_arap(const OrcEnergy* e, long elem, OrcRow* out)
     return 3;
 }
 
+/* E4: examples/bundle_adjustment/bundle_adjustment.t:1-34 (Snavely reprojection error).
+ * params: 0 cameras float9 (unknown: angle-axis 0-2, translation 3-5, focal 6, l1 7, l2 8), 1 points float3 (unknown),
+ *         2 observations float2, 3 oToC int[O], 4 oToP int[O].  dims C,P,O.
+ * flat layout: [cameras 9*c+k | points 9*C + 3*p + k].  One element = one observation = 2 rows x 12 nonzeros.
+ * Derivatives by forward-mode AD over the expression of lib.t:514-555 (AngleAxisRotatePoint; the Select on
+ * theta2 > 1e-8 differentiates the chosen branch, ad.t:800-809) -- the same partials the reference's symbolic
+ * AD produces. */
+typedef struct { float v; float d[12]; } Jet;
+static inline Jet jc(float c) { Jet r; r.v = c; memset(r.d, 0, sizeof(r.d)); return r; }
+static inline Jet jvar(float c, int k) { Jet r = jc(c); r.d[k] = 1.0f; return r; }
+static inline Jet jadd(Jet a, Jet b) { Jet r; r.v = a.v + b.v; for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+static inline Jet jsub(Jet a, Jet b) { Jet r; r.v = a.v - b.v; for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+static inline Jet jmul(Jet a, Jet b) { Jet r; r.v = a.v * b.v; for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+static inline Jet jdiv(Jet a, Jet b) { Jet r; const float ib = 1.0f / b.v; r.v = a.v * ib; for (int i = 0; i < 12; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+static inline Jet jneg(Jet a) { Jet r; r.v = -a.v; for (int i = 0; i < 12; ++i) r.d[i] = -a.d[i]; return r; }
+static inline Jet jsqrt(Jet a) { Jet r; r.v = sqrtf(a.v); const float k = 0.5f / r.v; for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] * k; return r; }
+static inline Jet jsin(Jet a) { Jet r; r.v = sinf(a.v); const float k = cosf(a.v); for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] * k; return r; }
+static inline Jet jcos(Jet a) { Jet r; r.v = cosf(a.v); const float k = -sinf(a.v); for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] * k; return r; }
+
+static void ba_residual_jets(const float* cam, const float* pt, const float* obs, Jet out[2])
+{
+    Jet c[9], X[3];
+    for (int k = 0; k < 9; ++k) c[k] = jvar(cam[k], k);
+    for (int k = 0; k < 3; ++k) X[k] = jvar(pt[k], 9 + k);
+    Jet theta2 = jadd(jadd(jmul(c[0], c[0]), jmul(c[1], c[1])), jmul(c[2], c[2]));
+    Jet p[3];
+    if (theta2.v > 1e-8f) {
+        Jet theta = jsqrt(theta2), ct = jcos(theta), st = jsin(theta), ti = jdiv(jc(1.0f), theta);
+        Jet w[3] = { jmul(c[0], ti), jmul(c[1], ti), jmul(c[2], ti) };
+        Jet wx[3] = { jsub(jmul(w[1], X[2]), jmul(w[2], X[1])), jsub(jmul(w[2], X[0]), jmul(w[0], X[2])), jsub(jmul(w[0], X[1]), jmul(w[1], X[0])) };
+        Jet tmp = jmul(jadd(jadd(jmul(w[0], X[0]), jmul(w[1], X[1])), jmul(w[2], X[2])), jsub(jc(1.0f), ct));
+        for (int k = 0; k < 3; ++k) p[k] = jadd(jadd(jmul(X[k], ct), jmul(wx[k], st)), jmul(w[k], tmp));
+    } else {
+        Jet wx[3] = { jsub(jmul(c[1], X[2]), jmul(c[2], X[1])), jsub(jmul(c[2], X[0]), jmul(c[0], X[2])), jsub(jmul(c[0], X[1]), jmul(c[1], X[0])) };
+        for (int k = 0; k < 3; ++k) p[k] = jadd(X[k], wx[k]);
+    }
+    for (int k = 0; k < 3; ++k) p[k] = jadd(p[k], c[3 + k]);
+    Jet cx = jdiv(jneg(p[0]), p[2]), cy = jdiv(jneg(p[1]), p[2]);
+    Jet r2 = jadd(jmul(cx, cx), jmul(cy, cy));
+    Jet dist = jadd(jc(1.0f), jmul(r2, jadd(c[7], jmul(c[8], r2))));
+    Jet fd = jmul(c[6], dist);
+    out[0] = jsub(jc(obs[0]), jmul(cx, fd));
+    out[1] = jsub(jc(obs[1]), jmul(cy, fd));
+}
+static int rows_bundle(const OrcEnergy* e, long elem, OrcRow* out)
+{
+    const long C = e->dims[0];
+    const float* cams = img(e, 0); const float* pts = img(e, 1); const float* obs = img(e, 2);
+    const int ci = ((const int*)e->params[3])[elem], pi = ((const int*)e->params[4])[elem];
+    Jet r[2];
+    ba_residual_jets(&cams[9 * ci], &pts[3 * pi], &obs[2 * elem], r);
+    for (int q = 0; q < 2; ++q) {
+        out[q].nnz = 12; out[q].r = r[q].v;
+        for (int k = 0; k < 9; ++k) { out[q].col[k] = 9 * ci + k; out[q].val[k] = r[q].d[k]; }
+        for (int k = 0; k < 3; ++k) { out[q].col[9 + k] = (int)(9 * C + 3 * pi + k); out[q].val[9 + k] = r[q].d[9 + k]; }
+    }
+    return 2;
+}
+
 int orc_energy_init(OrcEnergy* e, int kind, const unsigned* dims, void** params,
                     const float* fconst, const int* iconst)
 {
@@ -248,6 +307,14 @@ int orc_energy_init(OrcEnergy* e, int kind, const unsigned* dims, void** params,
         e->img_param[1] = 3; e->img_chan[1] = 3; e->img_count[1] = dims[0];
         e->n_elems = (long)dims[0] + dims[1]; e->rows = rows_arap;
         e->use_precond = 1;   /* arap_mesh_deformation.t:13 */
+        break; }
+    case ORC_BUNDLE_ADJUST: {
+        e->dims[0] = dims[0]; e->dims[1] = dims[1]; e->dims[2] = dims[2];
+        e->n_img = 2;
+        e->img_param[0] = 0; e->img_chan[0] = 9; e->img_count[0] = dims[0];
+        e->img_param[1] = 1; e->img_chan[1] = 3; e->img_count[1] = dims[1];
+        e->n_elems = dims[2]; e->rows = rows_bundle;
+        e->use_precond = 1;   /* bundle_adjustment.t:9 */
         break; }
     default:
         return -1;

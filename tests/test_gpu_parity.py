@@ -295,3 +295,44 @@ def test_graph_rejects_out_of_range_edges(torch):
     s = api.ThalloSolver((50, len(p[2])), thallo_amd.energy_file("laplacian_graph"))
     s.solve(dev, nIterations=1, lIterations=1)
     assert "outside" in api.last_error()
+
+
+# ------------------------------------------------------------------ materialized sparse-J path (bundle adjustment)
+@pytest.mark.parametrize("C_,P_,O_,nit,lit", [(12, 60, 300, 5, 40), (64, 4000, 20000, 3, 50), (2, 1, 2, 2, 3)])
+def test_bundle_adjustment_cost_trajectory(torch, orc, C_, P_, O_, nit, lit):
+    p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=min(8, C_))
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.BUNDLE_ADJUST, (C_, P_, O_), po).solve(nIterations=nit, lIterations=lit)
+    # The reference's float reduction order is nondeterministic (util.t:40-50); on an ill-conditioned BA system an
+    # unconverged PCG amplifies that: the oracle's own two legitimate summation orders (double vs serial float
+    # accumulators) drift apart by up to 4e-4 on the 12-camera case.  Bar = 1e-5, or 3x that intrinsic drift.
+    cf, _ = orc.Problem(orc.BUNDLE_ADJUST, (C_, P_, O_), copy_params(p)).solve(nIterations=nit, lIterations=lit, float_sums=1)
+    drift = np.abs(cf - co) / co
+    s, dev, costs, final = _solve_gpu("bundle_adjustment", (C_, P_, O_), p, nIterations=nit, lIterations=lit)
+    assert s.energy_name == "bundle_adjustment"
+    err = np.abs(np.array(costs) - co) / co
+    assert (err <= np.maximum(COST_RTOL, 3 * drift)).all(), (err, drift)
+    assert err[0] < 1e-6 and err[1] < 1e-3
+    assert rel_err(to_host(dev[1]), po[1]) < 2e-3
+
+
+def test_bundle_adjustment_short_pcg_is_tight(torch, orc):
+    """With 10 PCG iterations per step (before CG's error amplification sets in) the trajectory is 1e-5-exact."""
+    C_, P_, O_ = 12, 60, 300
+    p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+    co, _ = orc.Problem(orc.BUNDLE_ADJUST, (C_, P_, O_), copy_params(p)).solve(nIterations=4, lIterations=10)
+    s, dev, costs, final = _solve_gpu("bundle_adjustment", (C_, P_, O_), p, nIterations=4, lIterations=10)
+    assert (np.abs(np.array(costs) - co) / co < COST_RTOL).all()
+
+
+def test_bundle_adjustment_ladybug_1723_shape(torch):
+    """BASELINE config 5 size (C=1723, P=156,502, O=678,718): descent + bitwise reproducibility."""
+    p = syn.bundle_adjustment()
+    C_, P_, O_ = p[0].shape[0], p[1].shape[0], p[2].shape[0]
+    assert (C_, P_, O_) == (1723, 156502, 678718)
+    outs = []
+    for _ in range(2):
+        s, dev, costs, final = _solve_gpu("bundle_adjustment", (C_, P_, O_), p, nIterations=2, lIterations=30)
+        outs.append((list(costs), dev[0].clone(), dev[1].clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert outs[0][0][-1] < outs[0][0][0]

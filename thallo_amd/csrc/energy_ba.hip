@@ -1,0 +1,288 @@
+// energy_ba.hip -- bundle adjustment (examples/bundle_adjustment/bundle_adjustment.t:1-34) on the
+// MATERIALIZED sparse-J path.
+//
+// Reference schedule for this energy ([Jt][[J]p]): precomputeJ dumps J as CSR
+// (generateDumpJ gauss_newton.t:327-487: 2 rows per observation, 12 nonzeros per row), cuSPARSE sorts it,
+// transposes it (csr2csc :1375-1378) and every PCG iteration runs two csrmv: Jp = J p, Ap = J^T (Jp)
+// (:1493-1517).  282.7 MB of values+column indices per iteration at ladybug-1723 size.
+//
+// Here J is materialised once per GN iteration as ONE 96-byte block per observation
+//   Jb[q] = { dr0/dcam[9], dr0/dpt[3], dr1/dcam[9], dr1/dpt[3] }      (24 floats, 16-byte aligned)
+// stored in camera-sorted order q (camera incidence CSR).  The column indices are implicit (camera block,
+// point block), so no colInd array and no transposed copy exist: J^T(Jp) is a GATHER
+//   camera c : one wave walks the camera's contiguous blocks, wave-reduces 9 sums
+//   point  p : one thread walks the point's ~4 blocks through pt_pos[]
+// and Jp_q = Jc.p_cam + Jp.p_pt is recomputed on the fly by both sides (2 x 24 flops) instead of being
+// written and re-read.  No atomics, no sort, no csr2csc; 192 B/observation/iteration instead of 416.
+// Derivatives: forward-mode dual numbers over the expression of lib.t:514-555 -- the same partials the
+// reference's symbolic AD generates (Select differentiates the taken branch, ad.t:800-809).
+//
+// Flat vector layout: [cameras 9*c+k | points 9*C + 3*p + k]  (thallo.t:1104-1125).
+#include "device_common.hpp"
+#include "../../include/thallo_hip.h"
+
+using namespace thallo;
+
+namespace {
+
+constexpr int BLOCK = 256;
+inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
+
+struct Jet {
+    float v; float d[12];
+};
+__device__ __forceinline__ Jet jc(float c) { Jet r; r.v = c; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = 0.0f; return r; }
+__device__ __forceinline__ Jet jvar(float c, int k) { Jet r = jc(c); r.d[k] = 1.0f; return r; }
+__device__ __forceinline__ Jet operator+(const Jet& a, const Jet& b) { Jet r; r.v = a.v + b.v; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ Jet operator-(const Jet& a, const Jet& b) { Jet r; r.v = a.v - b.v; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ Jet operator*(const Jet& a, const Jet& b) { Jet r; r.v = a.v * b.v; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ Jet operator/(const Jet& a, const Jet& b) { Jet r; const float ib = 1.0f / b.v; r.v = a.v * ib; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+__device__ __forceinline__ Jet operator-(const Jet& a) { Jet r; r.v = -a.v; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ Jet jsqrt(const Jet& a) { Jet r; r.v = sqrtf(a.v); const float k = 0.5f / r.v; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] * k; return r; }
+__device__ __forceinline__ Jet jsin(const Jet& a, float s, float c) { Jet r; r.v = s; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = a.d[i] * c; return r; }
+__device__ __forceinline__ Jet jcos(const Jet& a, float s, float c) { Jet r; r.v = c; _Pragma("unroll")
+    for (int i = 0; i < 12; ++i) r.d[i] = -a.d[i] * s; return r; }
+
+// residual of one observation; T = float (cost) or Jet (Jacobian)
+template <typename T> struct Ops;
+template <> struct Ops<float> {
+    static __device__ __forceinline__ float var(float c, int) { return c; }
+    static __device__ __forceinline__ float cst(float c) { return c; }
+    static __device__ __forceinline__ float val(float a) { return a; }
+    static __device__ __forceinline__ float sqrt_(float a) { return sqrtf(a); }
+    static __device__ __forceinline__ void sincos_(float a, float& s, float& c) { sincosf(a, &s, &c); }
+};
+template <> struct Ops<Jet> {
+    static __device__ __forceinline__ Jet var(float c, int k) { return jvar(c, k); }
+    static __device__ __forceinline__ Jet cst(float c) { return jc(c); }
+    static __device__ __forceinline__ float val(const Jet& a) { return a.v; }
+    static __device__ __forceinline__ Jet sqrt_(const Jet& a) { return jsqrt(a); }
+    static __device__ __forceinline__ void sincos_(const Jet& a, Jet& s, Jet& c) { float sv, cv; sincosf(a.v, &sv, &cv); s = jsin(a, sv, cv); c = jcos(a, sv, cv); }
+};
+
+template <typename T>
+__device__ __forceinline__ void ba_residual(const float* __restrict__ cam, const float* __restrict__ pt, float ox, float oy, T& r0, T& r1)
+{
+    using O = Ops<T>;
+    T c[9], X[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c[k] = O::var(cam[k], k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = O::var(pt[k], 9 + k);
+    const T theta2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    T p[3];
+    if (O::val(theta2) > 1e-8f) {                         // bundle_adjustment.t via lib.t:516-535
+        const T theta = O::sqrt_(theta2);
+        T st, ct; O::sincos_(theta, st, ct);
+        const T ti = O::cst(1.0f) / theta;
+        const T w0 = c[0] * ti, w1 = c[1] * ti, w2 = c[2] * ti;
+        const T wx0 = w1 * X[2] - w2 * X[1], wx1 = w2 * X[0] - w0 * X[2], wx2 = w0 * X[1] - w1 * X[0];
+        const T tmp = (w0 * X[0] + w1 * X[1] + w2 * X[2]) * (O::cst(1.0f) - ct);
+        p[0] = X[0] * ct + wx0 * st + w0 * tmp; p[1] = X[1] * ct + wx1 * st + w1 * tmp; p[2] = X[2] * ct + wx2 * st + w2 * tmp;
+    } else {                                              // lib.t:537-553: R = I + hat(w)
+        p[0] = X[0] + (c[1] * X[2] - c[2] * X[1]); p[1] = X[1] + (c[2] * X[0] - c[0] * X[2]); p[2] = X[2] + (c[0] * X[1] - c[1] * X[0]);
+    }
+    p[0] = p[0] + c[3]; p[1] = p[1] + c[4]; p[2] = p[2] + c[5];
+    const T cx = -p[0] / p[2], cy = -p[1] / p[2];
+    const T r2 = cx * cx + cy * cy;
+    const T dist = O::cst(1.0f) + r2 * (c[7] + c[8] * r2);
+    const T fd = c[6] * dist;
+    r0 = O::cst(ox) - cx * fd; r1 = O::cst(oy) - cy * fd;
+}
+
+// computeCost: per observation (any order)
+__global__ __launch_bounds__(BLOCK) void k_cost(int O_, const float* __restrict__ cams, const float* __restrict__ pts,
+                                                const float2* __restrict__ obs, const int* __restrict__ oToC, const int* __restrict__ oToP,
+                                                float* __restrict__ out)
+{
+    __shared__ float red[16];
+    float acc = 0.0f;
+    for (int o = blockIdx.x * BLOCK + threadIdx.x; o < O_; o += gridDim.x * BLOCK) {
+        float r0, r1; const float2 ob = obs[o];
+        ba_residual<float>(cams + 9L * oToC[o], pts + 3L * oToP[o], ob.x, ob.y, r0, r1);
+        acc += 0.5f * (r0 * r0 + r1 * r1);
+    }
+    block_store_partial(acc, out, red);
+}
+
+// precomputeJ: J blocks + residuals in camera-sorted order q
+__global__ __launch_bounds__(BLOCK) void k_compute_j(int O_, const float* __restrict__ cams, const float* __restrict__ pts,
+                                                     const float2* __restrict__ obs, const int* __restrict__ cam_obs,
+                                                     const int* __restrict__ q_cam, const int* __restrict__ q_pt,
+                                                     float4* __restrict__ Jb, float2* __restrict__ F)
+{
+    for (int q = blockIdx.x * BLOCK + threadIdx.x; q < O_; q += gridDim.x * BLOCK) {
+        const float2 ob = obs[cam_obs[q]];
+        Jet r0, r1;
+        ba_residual<Jet>(cams + 9L * q_cam[q], pts + 3L * q_pt[q], ob.x, ob.y, r0, r1);
+        float4* b = Jb + 6L * q;
+        b[0] = make_float4(r0.d[0], r0.d[1], r0.d[2], r0.d[3]); b[1] = make_float4(r0.d[4], r0.d[5], r0.d[6], r0.d[7]);
+        b[2] = make_float4(r0.d[8], r0.d[9], r0.d[10], r0.d[11]);
+        b[3] = make_float4(r1.d[0], r1.d[1], r1.d[2], r1.d[3]); b[4] = make_float4(r1.d[4], r1.d[5], r1.d[6], r1.d[7]);
+        b[5] = make_float4(r1.d[8], r1.d[9], r1.d[10], r1.d[11]);
+        F[q] = make_float2(r0.v, r1.v);
+    }
+}
+
+struct Blk { float a[24]; };
+__device__ __forceinline__ Blk ld_blk(const float4* __restrict__ Jb, long q)
+{
+    Blk b; const float4* s = Jb + 6 * q;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const float4 v = s[k]; b.a[4 * k] = v.x; b.a[4 * k + 1] = v.y; b.a[4 * k + 2] = v.z; b.a[4 * k + 3] = v.w; }
+    return b;
+}
+
+// Gather kernels: workgroups [0, cam_blocks) = 4 cameras each (one wave per camera); the rest = one thread per point.
+// MODE 0: PCGInit1 (+_Finish): r = -J^T F, pre = guardedInvert(diag J^T J), z, p_prev = 0, delta = 0, alphaN partials
+// MODE 1: PCGStep1: Ap = J^T (J p), alphaD partials
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks, const int* __restrict__ cam_ptr, const int* __restrict__ q_pt,
+                                                  const int* __restrict__ pt_ptr, const int* __restrict__ pt_pos, const int* __restrict__ q_cam,
+                                                  const float4* __restrict__ Jb, const float2* __restrict__ F, const float* __restrict__ p,
+                                                  float* __restrict__ o0, float* __restrict__ pre, float* __restrict__ z,
+                                                  float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ part_out)
+{
+    __shared__ float red[16];
+    float acc = 0.0f;
+    const long PB = 9L * C_;                       // start of the point block in the flat vectors
+    if ((int)blockIdx.x < cam_blocks) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int c = blockIdx.x * 4 + wave; c < C_; c += cam_blocks * 4) {
+            float s[9], dg[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { s[k] = 0.0f; dg[k] = 0.0f; }
+            float pc[9];
+            if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) pc[k] = p[9L * c + k];
+            }
+            for (int q = cam_ptr[c] + lane; q < cam_ptr[c + 1]; q += 64) {
+                const Blk b = ld_blk(Jb, q);
+                float j0, j1;
+                if (MODE == 0) { const float2 f = F[q]; j0 = f.x; j1 = f.y; }
+                else {
+                    const float* pp = p + PB + 3L * q_pt[q];
+                    const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                    j0 = b.a[9] * p0 + b.a[10] * p1 + b.a[11] * p2; j1 = b.a[21] * p0 + b.a[22] * p1 + b.a[23] * p2;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { j0 += b.a[k] * pc[k]; j1 += b.a[12 + k] * pc[k]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    s[k] += b.a[k] * j0 + b.a[12 + k] * j1;
+                    if (MODE == 0) dg[k] += b.a[k] * b.a[k] + b.a[12 + k] * b.a[12 + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { s[k] = wave_sum_all(s[k]); if (MODE == 0) dg[k] = wave_sum_all(dg[k]); }
+            if (lane < 9) {
+                // pick element `lane` without dynamic register indexing
+                float sv = 0.0f, dv = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) if (lane == k) { sv = s[k]; dv = dg[k]; }
+                const long i = 9L * c + lane;
+                if (MODE == 0) {
+                    const float rr = -sv, m = guarded_invert(dv), zz = m * rr;
+                    o0[i] = rr; pre[i] = m; z[i] = zz; p_prev[i] = 0.0f; delta[i] = 0.0f;
+                    acc += rr * zz;
+                } else {
+                    o0[i] = sv;
+                    acc += p[i] * sv;
+                }
+            }
+        }
+    } else {
+        const int nb = gridDim.x - cam_blocks;
+        for (int j = (blockIdx.x - cam_blocks) * BLOCK + threadIdx.x; j < P_; j += nb * BLOCK) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            float pp0 = 0.f, pp1 = 0.f, pp2 = 0.f;
+            const long i = PB + 3L * j;
+            if (MODE == 1) { pp0 = p[i]; pp1 = p[i + 1]; pp2 = p[i + 2]; }
+            for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
+                const int q = pt_pos[k];
+                const Blk b = ld_blk(Jb, q);
+                float j0, j1;
+                if (MODE == 0) { const float2 f = F[q]; j0 = f.x; j1 = f.y; }
+                else {
+                    const float* pc = p + 9L * q_cam[q];
+                    j0 = b.a[9] * pp0 + b.a[10] * pp1 + b.a[11] * pp2; j1 = b.a[21] * pp0 + b.a[22] * pp1 + b.a[23] * pp2;
+#pragma unroll
+                    for (int m = 0; m < 9; ++m) { const float v = pc[m]; j0 += b.a[m] * v; j1 += b.a[12 + m] * v; }
+                }
+                s0 += b.a[9] * j0 + b.a[21] * j1; s1 += b.a[10] * j0 + b.a[22] * j1; s2 += b.a[11] * j0 + b.a[23] * j1;
+                if (MODE == 0) { d0 += b.a[9] * b.a[9] + b.a[21] * b.a[21]; d1 += b.a[10] * b.a[10] + b.a[22] * b.a[22]; d2 += b.a[11] * b.a[11] + b.a[23] * b.a[23]; }
+            }
+            if (MODE == 0) {
+                const float r0 = -s0, r1 = -s1, r2 = -s2;
+                const float m0 = guarded_invert(d0), m1 = guarded_invert(d1), m2 = guarded_invert(d2);
+                o0[i] = r0; o0[i + 1] = r1; o0[i + 2] = r2; pre[i] = m0; pre[i + 1] = m1; pre[i + 2] = m2;
+                z[i] = m0 * r0; z[i + 1] = m1 * r1; z[i + 2] = m2 * r2;
+                p_prev[i] = 0.f; p_prev[i + 1] = 0.f; p_prev[i + 2] = 0.f; delta[i] = 0.f; delta[i + 1] = 0.f; delta[i + 2] = 0.f;
+                acc += r0 * (m0 * r0) + r1 * (m1 * r1) + r2 * (m2 * r2);
+            } else {
+                o0[i] = s0; o0[i + 1] = s1; o0[i + 2] = s2;
+                acc += pp0 * s0 + pp1 * s1 + pp2 * s2;
+            }
+        }
+    }
+    block_store_partial(acc, part_out, red);
+}
+
+inline void gather_shape(int C_, int P_, int& cam_blocks, int& grid)
+{
+    cam_blocks = (C_ + 3) / 4; if (cam_blocks > 448) cam_blocks = 448;
+    int pb = (P_ + BLOCK - 1) / BLOCK; if (pb > 512) pb = 512; if (pb < 1) pb = 1;
+    grid = cam_blocks + pb;                        // <= 960 partials
+}
+
+}  // namespace
+
+extern "C" {
+
+int thallo_hip_ba_cost(int C_, int P_, int O_, const float* cameras, const float* points, const float* observations,
+                       const int* oToC, const int* oToP, float* cost_out, thallo_stream_t stream)
+{
+    (void)C_; (void)P_;
+    int grid = (O_ + BLOCK - 1) / BLOCK; if (grid > THALLO_MAX_PARTIALS) grid = THALLO_MAX_PARTIALS; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, O_, cameras, points, (const float2*)observations, oToC, oToP, cost_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_ba_compute_j(int O_, const float* cameras, const float* points, const float* observations,
+                            const int* cam_obs, const int* q_cam, const int* q_pt, float* Jb, float* F, thallo_stream_t stream)
+{
+    int grid = (O_ + BLOCK - 1) / BLOCK; if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_compute_j, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, O_, cameras, points, (const float2*)observations,
+                       cam_obs, q_cam, q_pt, (float4*)Jb, (float2*)F);
+    return check_launch();
+}
+
+int thallo_hip_ba_pcg_init(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
+                           const float* Jb, const float* F, float* r, float* pre, float* z, float* p_prev, float* delta,
+                           float* aN_out, thallo_stream_t stream)
+{
+    int cb, grid; gather_shape(C_, P_, cb, grid);
+    hipLaunchKernelGGL(k_gather<0>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
+                       (const float4*)Jb, (const float2*)F, (const float*)nullptr, r, pre, z, p_prev, delta, aN_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_ba_apply_jtj(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
+                            const float* Jb, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
+{
+    int cb, grid; gather_shape(C_, P_, cb, grid);
+    hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
+                       (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+}  // extern "C"

@@ -107,6 +107,7 @@ const Known KNOWN[] = {
     { "laplacian_graph", 2, "U1;A1;S0;S0;",                   "fit,reg",                        false },
     { "image_warping",   2, "U2;U1;A2;A2;A1;P1;P1;",          "fit,reg_nx,reg_ny,reg_px,reg_py", true },
     { "arap_mesh",       2, "P1;P1;U3;U3;A3;A3;S0;S0;",       "fit,reg",                        true },
+    { "bundle_adjustment", 3, "U9;U3;A2;S0;S0;",               "snavely_reprojection_error",     true },
 };
 
 #include "known_energy_hashes.inc"

@@ -195,6 +195,68 @@ public:
     }
 };
 
+// ------------------------------------------------------------------ examples/bundle_adjustment/bundle_adjustment.t
+class BundleAdjustmentPlugin : public EnergyPlugin {
+    int C, P, O;
+    std::vector<UnknownImage> imgs;
+    float *cameras = nullptr, *points = nullptr; const float* obs = nullptr; const int *oToC = nullptr, *oToP = nullptr;
+    DeviceBuffer cam_ptr, cam_obs, q_cam, q_pt, pt_ptr, pt_pos, Jb, F;
+public:
+    BundleAdjustmentPlugin(const unsigned* dims) : C((int)dims[0]), P((int)dims[1]), O((int)dims[2])
+    { imgs.push_back({ 0, 9L * C }); imgs.push_back({ 1, 3L * P }); }
+    const char* name() const override { return "bundle_adjustment"; }
+    long n_unknowns() const override { return 9L * C + 3L * P; }
+    const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
+    bool use_preconditioner() const override { return true; }            // bundle_adjustment.t:9
+    int bind(void** p) override
+    {
+        cameras = (float*)p[0]; points = (float*)p[1]; obs = (const float*)p[2]; oToC = (const int*)p[3]; oToP = (const int*)p[4];
+        if (!cameras || !points || !obs || !oToC || !oToP) { set_error("bundle_adjustment: null problem parameter"); return -1; }
+        return 0;
+    }
+    int prepare(LaunchCtx&) override
+    {   // incidence lists (the reference sorts / transposes the CSR with cuSPARSE every GN iteration: gauss_newton.t:1349-1378)
+        std::vector<int> oc(O), op(O);
+        if (hipMemcpy(oc.data(), oToC, sizeof(int) * O, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(op.data(), oToP, sizeof(int) * O, hipMemcpyDeviceToHost) != hipSuccess) { set_error("bundle_adjustment: cannot read the sparse maps"); return -1; }
+        for (int o = 0; o < O; ++o)
+            if (oc[o] < 0 || oc[o] >= C || op[o] < 0 || op[o] >= P) { set_error("bundle_adjustment: observation %d -> (camera %d, point %d) out of range", o, oc[o], op[o]); return -1; }
+        std::vector<int> cp(C + 1, 0), pp(P + 1, 0), cobs(O), qc(O), qp(O), pos(O), ppos(O);
+        for (int o = 0; o < O; ++o) { cp[oc[o] + 1]++; pp[op[o] + 1]++; }
+        for (int c = 0; c < C; ++c) cp[c + 1] += cp[c];
+        for (int j = 0; j < P; ++j) pp[j + 1] += pp[j];
+        std::vector<int> cc(cp.begin(), cp.end() - 1), pc(pp.begin(), pp.end() - 1);
+        for (int o = 0; o < O; ++o) { const int q = cc[oc[o]]++; pos[o] = q; cobs[q] = o; qc[q] = oc[o]; qp[q] = op[o]; }
+        for (int o = 0; o < O; ++o) ppos[pc[op[o]]++] = pos[o];
+        auto up = [&](DeviceBuffer& b, const std::vector<int>& h) {
+            if (b.alloc(sizeof(int) * (h.size() + 4))) return -1;
+            return hipMemcpy(b.ptr, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+        };
+        if (up(cam_ptr, cp) || up(cam_obs, cobs) || up(q_cam, qc) || up(q_pt, qp) || up(pt_ptr, pp) || up(pt_pos, ppos)) { set_error("bundle_adjustment: upload failed"); return -1; }
+        if (!Jb.ptr && (Jb.alloc(sizeof(float) * 24 * (size_t)O + 64) || F.alloc(sizeof(float) * 2 * (size_t)O + 64))) return -1;
+        return 0;
+    }
+    float* unknown_ptr(int k) override { return k == 0 ? cameras : points; }
+    int cost(LaunchCtx& c, float* out) override
+    { TimedLaunch t(c, "computeCost"); return thallo_hip_ba_cost(C, P, O, cameras, points, obs, oToC, oToP, out, c.stream); }
+    int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
+    {
+        { TimedLaunch t(c, "precomputeJ");
+          int rc = thallo_hip_ba_compute_j(O, cameras, points, obs, (const int*)cam_obs.ptr, (const int*)q_cam.ptr, (const int*)q_pt.ptr, (float*)Jb.ptr, (float*)F.ptr, c.stream);
+          if (rc < 0) return rc; }
+        TimedLaunch t(c, "PCGInit1");
+        return thallo_hip_ba_pcg_init(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
+                                      (const float*)Jb.ptr, (const float*)F.ptr, v.r, v.pre, v.z, v.p[cur], v.delta, aN, c.stream);
+    }
+    int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
+    {
+        { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
+                                       (const float*)Jb.ptr, v.p[cur ^ 1], v.Ap, out, c.stream);
+    }
+};
+
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims)
 {
     auto cst = [&](const char* k, double dflt) { auto it = spec.constants.find(k); return it == spec.constants.end() ? dflt : it->second; };
@@ -202,6 +264,7 @@ EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims)
     if (spec.energy == "image_warping")   return new ImageWarpingPlugin(dims);
     if (spec.energy == "laplacian_graph") return new LaplacianGraphPlugin(dims, (float)cst("w_fit", 0.5));
     if (spec.energy == "arap_mesh")       return new ArapPlugin(dims);
+    if (spec.energy == "bundle_adjustment") return new BundleAdjustmentPlugin(dims);
     set_error("no gfx950 plugin for energy '%s' (%s)", spec.energy.c_str(), spec.file.c_str());
     return nullptr;
 }

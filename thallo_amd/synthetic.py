@@ -90,3 +90,67 @@ def arap_mesh(nu, nv, seed=11, n_handles=32, w_fit=4.0, w_reg=1.0, angle_amp=0.0
     hs = rng.choice(N, n_handles, replace=False)
     cons[hs] = orig[hs] + 0.3 * rng.standard_normal((n_handles, 3)).astype(np.float32)
     return [float(w_fit), float(w_reg), pos, ang, orig.copy(), np.ascontiguousarray(cons), v0, v1]
+
+
+# ------------------------------------------------------------------ bundle adjustment (BAL-shaped)
+def _rodrigues_inverse(R):
+    """rotation matrix -> angle-axis (float64)"""
+    ang = np.arccos(np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0))
+    if ang < 1e-12:
+        return np.zeros(3)
+    ax = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2.0 * np.sin(ang))
+    return ax * ang
+
+
+def ba_project(cams, pts, ci, pi):
+    """Snavely projection in float64 (bundle_adjustment.t:12-31): predicted 2-D positions of observations."""
+    c = cams[ci].astype(np.float64); X = pts[pi].astype(np.float64)
+    aa = c[:, :3]
+    th2 = (aa * aa).sum(1)
+    th = np.sqrt(np.where(th2 > 1e-8, th2, 1.0))
+    w = aa / th[:, None]
+    ct, st = np.cos(th), np.sin(th)
+    big = X * ct[:, None] + np.cross(w, X) * st[:, None] + w * ((w * X).sum(1) * (1 - ct))[:, None]
+    small = X + np.cross(aa, X)
+    p = np.where((th2 > 1e-8)[:, None], big, small) + c[:, 3:6]
+    cd = -p[:, :2] / p[:, 2:3]
+    r2 = (cd * cd).sum(1)
+    dist = 1.0 + r2 * (c[:, 7] + c[:, 8] * r2)
+    return cd * (c[:, 6] * dist)[:, None]
+
+
+def bundle_adjustment(C=1723, P=156502, O=678718, seed=7, band=32, noise_px=1.0, cam_noise=1e-3, pt_noise=2e-2):
+    """BAL-shaped synthetic instance: cameras on a ring looking at a point blob, banded
+    visibility, >= 2 observations per point.  Returns the params list of bundle_adjustment.t Inputs{} (0..4):
+    cameras [C,9], points [P,3], observations [O,2], oToC [O] int32, oToP [O] int32 -- unknowns perturbed from
+    the ground truth that generated the (noisy) observations."""
+    rng = np.random.default_rng(seed)
+    assert O >= 2 * P and C >= 2
+    pts = rng.normal(0.0, 1.0, (P, 3)) * np.array([1.5, 0.6, 1.5])
+    cams = np.zeros((C, 9))
+    for i in range(C):
+        phi = 2 * np.pi * i / C
+        pos = np.array([12.0 * np.cos(phi), 1.0 + 0.5 * np.sin(3 * phi), 12.0 * np.sin(phi)])
+        zc = pos / np.linalg.norm(pos)                       # camera looks down -z at the origin
+        xc = np.cross([0.0, 1.0, 0.0], zc); xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        R = np.stack([xc, yc, zc])                           # world -> camera
+        cams[i, :3] = _rodrigues_inverse(R)
+        cams[i, 3:6] = -R @ pos
+        cams[i, 6] = 800.0 + 40.0 * rng.standard_normal()
+        cams[i, 7] = -1e-2 * rng.random(); cams[i, 8] = 1e-3 * rng.random()
+    # visibility: point j is seen by cnt_j cameras inside a band around its base camera
+    cnt = np.full(P, O // P, np.int64); cnt[: O - cnt.sum()] += 1
+    band = min(band, C)
+    assert cnt.max() <= band
+    oToP = np.repeat(np.arange(P, dtype=np.int64), cnt)
+    base = (np.arange(P, dtype=np.int64) * C) // P
+    offs = np.argsort(rng.random((P, band)), axis=1)         # a random subset of the band per point
+    start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    within = np.arange(O) - start[oToP]
+    oToC = (base[oToP] + offs[oToP, within] - band // 2) % C
+    obs = ba_project(cams, pts, oToC, oToP) + noise_px * rng.standard_normal((O, 2))
+    cams0 = cams + cam_noise * rng.standard_normal(cams.shape) * np.array([1, 1, 1, 10, 10, 10, 1000, 1, 0.1])
+    pts0 = pts + pt_noise * rng.standard_normal(pts.shape)
+    return [np.ascontiguousarray(cams0, np.float32), np.ascontiguousarray(pts0, np.float32), np.ascontiguousarray(obs, np.float32),
+            np.ascontiguousarray(oToC, np.int32), np.ascontiguousarray(oToP, np.int32)]

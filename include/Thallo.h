@@ -101,6 +101,11 @@ void ThalloX_ResetKernelStats(Thallo_Plan* plan);
  * returns the number of PCG iterations run. */
 int  ThalloX_GetAlphaBetaTrace(Thallo_Plan* plan, float* out_pairs, int cap);
 
+/* Run the Levenberg-Marquardt branch as the reference's text describes it (gauss_newton.t, every UsesLambda()
+ * branch).  Off by default even for "levenberg_marquardt": the reference as shipped executes plain GN for that
+ * kind (thallo.t:463 matches "LM", which no accepted kind string contains).  Call before Thallo_ProblemInit. */
+void ThalloX_EnableLM(Thallo_Plan* plan, int enable);
+
 /* Name of the plugin a plan runs ("image_warping", "laplacian_image", ...). */
 const char* ThalloX_PlanEnergyName(Thallo_Plan* plan);
 

@@ -85,6 +85,24 @@ int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t betaN, t
  * Used by plugins whose applyJTJ gathers p through index lists (graph domains). */
 int thallo_hip_pcg_pupdate(const float* z, const float* p_in, float* p_out, float* delta, long n, int first,
                            thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_stream_t stream);
+/* (delta == NULL: p update only with the unguarded LM divide; LM keeps the delta update in PCGStep2.) */
+
+/* ---- Levenberg-Marquardt set.  PCGSaveSSq + PCGComputeCtC + PCGFinalizeDiagonal (gauss_newton.t:929-969,
+ * thallo.t:3911-3937) in one pass over the raw diagonal `diag` = diag(J^T J) (pcg_init's diag_out):
+ *   SSq = guardedInvert(diag) on the first GN iteration of a solve (save_ssq != 0; 1 without preconditioner);
+ *   CtC = clamp(diag/radius, [min,max]_lm_diagonal/(SSq*radius)); pre = 1/(CtC + radius*diag/radius);
+ *   b = r; z = pre*r; alphaN partials. */
+int thallo_hip_lm_finalize_diagonal(const float* diag, float* SSq, float* CtC, float* pre, const float* r, float* b, float* z, long n,
+                                    float radius, float min_lm_diagonal, float max_lm_diagonal, int save_ssq, int use_preconditioner,
+                                    float* alphaN_out, thallo_stream_t stream);
+/* PCGStep1_Finish, LM form (gauss_newton.t:777-787): Ap += CtC*p; alphaD partials = sum p.Ap */
+int thallo_hip_lm_step1_finish(float* Ap, const float* CtC, const float* p, long n, float* alphaD_out, thallo_stream_t stream);
+/* PCGStep2_1stHalf / _2ndHalf (gauss_newton.t:845-886), used every residual_reset_period iterations */
+int thallo_hip_lm_step2_first_half(float* delta, const float* p, long n, thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_stream_t stream);
+int thallo_hip_lm_step2_second_half(float* r, const float* b, const float* Adelta, const float* pre, float* z, const float* delta, long n,
+                                    float* betaN_out, float* q_out, thallo_stream_t stream);
+/* partials of sum a.b */
+int thallo_hip_dot(const float* a, const float* b, long n, float* out, thallo_stream_t stream);
 
 /* PCGLinearUpdate (gauss_newton.t:901-906) for one unknown image:  X[i] += delta[i] (+ alpha*p[i]
  * when p != NULL: the fused schedule's last pending delta += alpha*p). */
@@ -107,7 +125,11 @@ int thallo_hip_slab_unpack(float* vec, thallo_segs_t top, const float* src_top, 
 int thallo_hip_alpha_beta(thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_sum_t betaN, float* out2,
                           thallo_stream_t stream);
 
-/* ---------------------------------------------------------------- E5: tests/minimal/laplacian.t
+/* Every <energy>_pcg_init takes `diag_out`: NULL, or a flat vector that receives the RAW diag(J^T J)
+ * (= what fmap.evalJTF accumulates into `preconditioner`, thallo.t:3898-3902, before guardedInvert) -- the input of
+ * LM's computeCtC (thallo.t:3929-3933).
+ *
+ * ---------------------------------------------------------------- E5: tests/minimal/laplacian.t
  * X unknown float {W,H} (param 0), A float {W,H} (param 1); fit = w*(X-A), reg = x/y forward
  * differences guarded by InBounds.  xguard: 0 = InBounds(x+1,y+1) as shipped (laplacian.t:11),
  * 1 = InBounds(x+1,y) (the variant gold.png was made with). */
@@ -117,7 +139,9 @@ int thallo_hip_lapimg_cost(int W, int H, const float* X, const float* A, float w
  * z = pre*r, p_prev = 0, delta = 0, alphaN partials. */
 int thallo_hip_lapimg_pcg_init(int W, int H, const float* X, const float* A, float w_fit, int xguard,
                                float* r, float* z, float* p_prev, float* delta,
-                               float* alphaN_out, thallo_stream_t stream);
+                               float* diag_out, float* alphaN_out, thallo_stream_t stream);
+/* plain PCGStep1: Ap = J^T J p, alphaD partials */
+int thallo_hip_lapimg_apply_jtj(int W, int H, float w_fit, int xguard, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 /* fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k) (gauss_newton.t:734-752,889-899):
  *   first!=0: p = z (beta=0, no delta update); else beta = betaN/alphaN_prev, alpha = alphaN_prev/alphaD_prev,
  *   delta += alpha*p_in; p_out = z + beta*p_in;  Ap = J^T J p_out; alphaD partials = sum p_out.Ap */
@@ -144,7 +168,7 @@ int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, co
 int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                            const float* constraints, const float* mask, float w_fit, float w_reg,
                            float* r, float* pre, float* z, float* p_prev, float* delta,
-                           float* cs, unsigned char* flags, float* alphaN_out, thallo_stream_t stream);
+                           float* cs, unsigned char* flags, float* diag_out, float* alphaN_out, thallo_stream_t stream);
 int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
@@ -163,7 +187,7 @@ int thallo_hip_lapgraph_cost(int N, const int* out_ptr, const int* out_v1, const
                              float* cost_out, thallo_stream_t stream);
 int thallo_hip_lapgraph_pcg_init(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
                                  const float* X, const float* A, float w_fit, float* r, float* z, float* p_prev, float* delta,
-                                 float* alphaN_out, thallo_stream_t stream);
+                                 float* diag_out, float* alphaN_out, thallo_stream_t stream);
 int thallo_hip_lapgraph_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
                                   float w_fit, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 
@@ -177,7 +201,7 @@ int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, con
                                const float* original, float w_reg, float* F, float* G, thallo_stream_t stream);
 int thallo_hip_arap_pcg_init(int N, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
-                             float* r, float* pre, float* z, float* p_prev, float* delta, float* alphaN_out, thallo_stream_t stream);
+                             float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* alphaN_out, thallo_stream_t stream);
 int thallo_hip_arap_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                               const float* constraints, const float* G, float w_fit, float w_reg,
                               const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
@@ -197,7 +221,7 @@ int thallo_hip_ba_compute_j(int O, const float* cameras, const float* points, co
                             const int* cam_obs, const int* q_cam, const int* q_pt, float* Jb, float* F, thallo_stream_t stream);
 int thallo_hip_ba_pcg_init(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
                            const float* Jb, const float* F, float* r, float* pre, float* z, float* p_prev, float* delta,
-                           float* alphaN_out, thallo_stream_t stream);
+                           float* diag_out, float* alphaN_out, thallo_stream_t stream);
 /* Ap = J^T (J p) by gather over the camera / point incidence lists; alphaD partials */
 int thallo_hip_ba_apply_jtj(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
                             const float* Jb, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);

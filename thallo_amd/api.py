@@ -71,6 +71,7 @@ def lib():
     L.ThalloX_GetKernelStat.restype = C.c_int
     L.ThalloX_ResetKernelStats.argtypes = [vp]
     L.ThalloX_GetAlphaBetaTrace.argtypes = [vp, vp, C.c_int]; L.ThalloX_GetAlphaBetaTrace.restype = C.c_int
+    L.ThalloX_EnableLM.argtypes = [vp, C.c_int]
     L.ThalloX_PlanEnergyName.argtypes = [vp]; L.ThalloX_PlanEnergyName.restype = C.c_char_p
     L.ThalloX_LastError.restype = C.c_char_p
     L.ThalloX_ProblemFileHash.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; L.ThalloX_ProblemFileHash.restype = C.c_ulonglong
@@ -194,6 +195,10 @@ class ThalloSolver:
                     "meanMS": getattr(s, n).meanMS, "stddevMS": getattr(s, n).stddevMS} for n, _ in s._fields_}
 
     # ---- extensions
+    def enable_lm(self, on=True):
+        """Run the LM branch of gauss_newton.t (dead as shipped in the reference, see include/Thallo.h)."""
+        self._L.ThalloX_EnableLM(self.plan, 1 if on else 0)
+
     def set_kernel_sampling(self, period):
         self._L.ThalloX_SetKernelSampling(self.plan, period)
 

@@ -106,6 +106,7 @@ int ThalloX_GetKernelStat(Thallo_Plan* plan, int index, const char** name, long*
 }
 void ThalloX_ResetKernelStats(Thallo_Plan* plan) { if (plan) plan->impl->ktimer.reset(); }
 int ThalloX_GetAlphaBetaTrace(Thallo_Plan* plan, float* out_pairs, int cap) { return plan ? plan->impl->alpha_beta_trace(out_pairs, cap) : 0; }
+void ThalloX_EnableLM(Thallo_Plan* plan, int enable) { if (plan) plan->impl->enable_lm(enable != 0); }
 const char* ThalloX_PlanEnergyName(Thallo_Plan* plan) { return plan ? plan->impl->plugin->name() : ""; }
 const char* ThalloX_LastError(void) { return last_error(); }
 

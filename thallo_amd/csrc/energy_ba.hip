@@ -149,7 +149,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
                                                   const int* __restrict__ pt_ptr, const int* __restrict__ pt_pos, const int* __restrict__ q_cam,
                                                   const float4* __restrict__ Jb, const float2* __restrict__ F, const float* __restrict__ p,
                                                   float* __restrict__ o0, float* __restrict__ pre, float* __restrict__ z,
-                                                  float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ part_out)
+                                                  float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ diag_out,
+                                                  float* __restrict__ part_out)
 {
     __shared__ float red[16];
     float acc = 0.0f;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
                 if (MODE == 0) {
                     const float rr = -sv, m = guarded_invert(dv), zz = m * rr;
                     o0[i] = rr; pre[i] = m; z[i] = zz; p_prev[i] = 0.0f; delta[i] = 0.0f;
+                    if (diag_out) diag_out[i] = dv;
                     acc += rr * zz;
                 } else {
                     o0[i] = sv;
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
                 const float m0 = guarded_invert(d0), m1 = guarded_invert(d1), m2 = guarded_invert(d2);
                 o0[i] = r0; o0[i + 1] = r1; o0[i + 2] = r2; pre[i] = m0; pre[i + 1] = m1; pre[i + 2] = m2;
                 z[i] = m0 * r0; z[i + 1] = m1 * r1; z[i + 2] = m2 * r2;
+                if (diag_out) { diag_out[i] = d0; diag_out[i + 1] = d1; diag_out[i + 2] = d2; }
                 p_prev[i] = 0.f; p_prev[i + 1] = 0.f; p_prev[i + 2] = 0.f; delta[i] = 0.f; delta[i + 1] = 0.f; delta[i + 2] = 0.f;
                 acc += r0 * (m0 * r0) + r1 * (m1 * r1) + r2 * (m2 * r2);
             } else {
@@ -268,11 +271,11 @@ int thallo_hip_ba_compute_j(int O_, const float* cameras, const float* points, c
 
 int thallo_hip_ba_pcg_init(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
                            const float* Jb, const float* F, float* r, float* pre, float* z, float* p_prev, float* delta,
-                           float* aN_out, thallo_stream_t stream)
+                           float* diag_out, float* aN_out, thallo_stream_t stream)
 {
     int cb, grid; gather_shape(C_, P_, cb, grid);
     hipLaunchKernelGGL(k_gather<0>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
-                       (const float4*)Jb, (const float2*)F, (const float*)nullptr, r, pre, z, p_prev, delta, aN_out);
+                       (const float4*)Jb, (const float2*)F, (const float*)nullptr, r, pre, z, p_prev, delta, diag_out, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -281,7 +284,7 @@ int thallo_hip_ba_apply_jtj(int C_, int P_, const int* cam_ptr, const int* q_pt,
 {
     int cb, grid; gather_shape(C_, P_, cb, grid);
     hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
-                       (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
+                       (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
     int e = check_launch(); return e ? e : grid;
 }
 

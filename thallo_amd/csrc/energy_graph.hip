@@ -74,12 +74,13 @@ __global__ __launch_bounds__(BLOCK) void k_lapg_init(int N, const int* __restric
                                                       const int* __restrict__ in_ptr, const int* __restrict__ in_src,
                                                       const float* __restrict__ X, const float* __restrict__ A, float w,
                                                       float* __restrict__ r, float* __restrict__ z, float* __restrict__ p_prev,
-                                                      float* __restrict__ delta, float* __restrict__ aN_out)
+                                                      float* __restrict__ delta, float* __restrict__ diag_out, float* __restrict__ aN_out)
 {
     __shared__ float red[16];
     float acc = 0.0f;
     for (int n = blockIdx.x * BLOCK + threadIdx.x; n < N; n += gridDim.x * BLOCK) {
         const float x = X[n];
+        if (diag_out) diag_out[n] = w * w + (float)(out_ptr[n + 1] - out_ptr[n]) + (float)(in_ptr[n + 1] - in_ptr[n]);
         const float res = -(w * (w * (x - A[n])) + lapg_apply(n, out_ptr, out_v1, in_ptr, in_src, X, x));
         r[n] = res; z[n] = res; p_prev[n] = 0.0f; delta[n] = 0.0f;      // identity preconditioner
         acc += res * res;
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, const int* __restric
                                                       const int* __restrict__ in_edge, const float* __restrict__ P, const float* __restrict__ Cn,
                                                       const float* __restrict__ F, const float* __restrict__ G, float wf, float wr,
                                                       float* __restrict__ r, float* __restrict__ pre, float* __restrict__ z,
-                                                      float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ aN_out)
+                                                      float* __restrict__ p_prev, float* __restrict__ delta,
+                                                      float* __restrict__ diag_out, float* __restrict__ aN_out)
 {
     __shared__ float red[16];
     float acc = 0.0f;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, const int* __restric
         const f3 zero = { 0.f, 0.f, 0.f };
         st3(r, n, rp); st3(r, (long)N + n, ra);
         st3(pre, n, mpv); st3(pre, (long)N + n, mav);
+        if (diag_out) { const f3 dpv = { dp, dp, dp }; st3(diag_out, n, dpv); st3(diag_out, (long)N + n, da); }
         st3(z, n, zp); st3(z, (long)N + n, za);
         st3(p_prev, n, zero); st3(p_prev, (long)N + n, zero);
         st3(delta, n, zero); st3(delta, (long)N + n, zero);
@@ -275,10 +278,10 @@ int thallo_hip_lapgraph_cost(int N, const int* out_ptr, const int* out_v1, const
 }
 int thallo_hip_lapgraph_pcg_init(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
                                  const float* X, const float* A, float w_fit, float* r, float* z, float* p_prev, float* delta,
-                                 float* aN_out, thallo_stream_t stream)
+                                 float* diag_out, float* aN_out, thallo_stream_t stream)
 {
     const int grid = vgrid(N);
-    hipLaunchKernelGGL(k_lapg_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, in_ptr, in_src, X, A, w_fit, r, z, p_prev, delta, aN_out);
+    hipLaunchKernelGGL(k_lapg_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, in_ptr, in_src, X, A, w_fit, r, z, p_prev, delta, diag_out, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_lapgraph_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
@@ -305,11 +308,11 @@ int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, con
 }
 int thallo_hip_arap_pcg_init(int N, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
-                             float* r, float* pre, float* z, float* p_prev, float* delta, float* aN_out, thallo_stream_t stream)
+                             float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, thallo_stream_t stream)
 {
     const int grid = vgrid(N);
     hipLaunchKernelGGL(k_arap_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, in_ptr, in_edge, position, constraints, F, G, w_fit, w_reg,
-                       r, pre, z, p_prev, delta, aN_out);
+                       r, pre, z, p_prev, delta, diag_out, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,

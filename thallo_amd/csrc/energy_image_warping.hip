@@ -250,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
                                                 float* __restrict__ r, float* __restrict__ pre, float* __restrict__ z,
                                                 float* __restrict__ p_prev, float* __restrict__ delta,
                                                 float2* __restrict__ cs, unsigned char* __restrict__ flags,
-                                                float* __restrict__ aN_out)
+                                                float* __restrict__ diag_out, float* __restrict__ aN_out)
 {
     __shared__ Tile T;
     __shared__ float red[16];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
             if (gx < g.W && gy < g.row1) {
                 const long pix = (long)gy * g.W + gx;
                 const unsigned char act = T.f[i] & 1;
-                float rx = 0.f, ry = 0.f, ra = 0.f, mx = 0.f, my = 0.f, ma = 0.f;
+                float rx = 0.f, ry = 0.f, ra = 0.f, mx = 0.f, my = 0.f, ma = 0.f, dgo_raw = 0.f, dga_raw = 0.f;
                 unsigned char fl = act;
                 if (act) {
                     const float oxi = T.px[i], oyi = T.py[i], ci = T.c[i], si = T.s[i], uxi = T.ux[i], uyi = T.uy[i];
@@ -317,6 +317,10 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
                     }
                     rx = -jx; ry = -jy; ra = -ja;                   // gauss_newton.t:690
                     mx = guarded_invert(dgo); my = mx; ma = guarded_invert(dga);   // :696, UsePreconditioner(true)
+                    dgo_raw = dgo; dga_raw = dga;
+                }
+                if (diag_out) {                                     // raw diag(J^T J): LM's computeCtC input (thallo.t:3929-3933)
+                    reinterpret_cast<float2*>(diag_out)[pix] = make_float2(dgo_raw, dgo_raw); diag_out[2 * N + pix] = dga_raw;
                 }
                 reinterpret_cast<float2*>(r)[pix] = make_float2(rx, ry);  r[2 * N + pix] = ra;
                 reinterpret_cast<float2*>(pre)[pix] = make_float2(mx, my); pre[2 * N + pix] = ma;
@@ -401,13 +405,13 @@ int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, co
 int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                            const float* constraints, const float* mask, float w_fit, float w_reg,
                            float* r, float* pre, float* z, float* p_prev, float* delta,
-                           float* cs, unsigned char* flags, float* aN_out, thallo_stream_t stream)
+                           float* cs, unsigned char* flags, float* diag_out, float* aN_out, thallo_stream_t stream)
 {
     if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 4);
     hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)offset, angle, (const float2*)urshape, (const float2*)constraints, mask, w_fit, w_reg,
-                       r, pre, z, p_prev, delta, (float2*)cs, flags, aN_out);
+                       r, pre, z, p_prev, delta, (float2*)cs, flags, diag_out, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 

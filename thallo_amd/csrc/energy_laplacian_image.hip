@@ -78,7 +78,7 @@ __global__ __launch_bounds__(BLOCK) void k_cost(Geo g, const float* __restrict__
 __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float* __restrict__ X, const float* __restrict__ A,
                                                 float w, int xguard, float* __restrict__ r, float* __restrict__ z,
                                                 float* __restrict__ p_prev, float* __restrict__ delta,
-                                                float* __restrict__ aN_out)
+                                                float* __restrict__ diag_out, float* __restrict__ aN_out)
 {
     __shared__ float red[16];
     float acc = 0.0f;
@@ -89,6 +89,14 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float* __restrict__
             if (x < g.W && y < g.H) {
                 const long i = (long)y * g.W + x;
                 const float c = X[i];
+                if (diag_out) {     // raw diag(J^T J) = w^2 + number of difference residuals touching the pixel
+                    float d = w * w;
+                    if (gx(x, y, g.W, g.H, xguard)) d += 1.0f;
+                    if (x > 0 && gx(x - 1, y, g.W, g.H, xguard)) d += 1.0f;
+                    if (y + 1 < g.H) d += 1.0f;
+                    if (y > 0) d += 1.0f;
+                    diag_out[i] = d;
+                }
                 const float jtf = w * (w * (c - A[i])) + lap_apply(X, x, y, g.W, g.H, xguard, c);
                 const float res = -jtf;                 // gauss_newton.t:690
                 r[i] = res; z[i] = res;                 // identity preconditioner (no UsePreconditioner)
@@ -156,10 +164,10 @@ int thallo_hip_lapimg_cost(int W, int H, const float* X, const float* A, float w
 }
 
 int thallo_hip_lapimg_pcg_init(int W, int H, const float* X, const float* A, float w_fit, int xguard,
-                               float* r, float* z, float* p_prev, float* delta, float* aN_out, thallo_stream_t stream)
+                               float* r, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, thallo_stream_t stream)
 {
     const Geo g = make_geo(W, H); const int grid = grid_for(g);
-    hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, X, A, w_fit, xguard, r, z, p_prev, delta, aN_out);
+    hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, X, A, w_fit, xguard, r, z, p_prev, delta, diag_out, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -173,6 +181,14 @@ int thallo_hip_lapimg_pcg_step1(int W, int H, float w_fit, int xguard,
     int fg = (int)((n + BLOCK - 1) / BLOCK); if (fg > 1024) fg = 1024;
     hipLaunchKernelGGL(k_pupdate, dim3(fg), dim3(BLOCK), 0, (hipStream_t)stream, n, z, p_in, p_out, delta, first, aNp, aDp, bNp);
     hipLaunchKernelGGL(k_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, w_fit, xguard, (const float*)p_out, Ap, aD_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+
+int thallo_hip_lapimg_apply_jtj(int W, int H, float w_fit, int xguard, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
+{
+    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    hipLaunchKernelGGL(k_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, w_fit, xguard, p, Ap, aD_out);
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -121,22 +121,123 @@ __global__ __launch_bounds__(BLOCK) void k_step3(float4* __restrict__ p, const f
 __global__ __launch_bounds__(BLOCK) void k_pupdate(const float4* __restrict__ z, const float4* __restrict__ p_in, float4* __restrict__ p_out,
                                                     float4* __restrict__ delta, long n4, int first,
                                                     thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp)
-{
+{   // delta == NULL: p update only (LM: PCGStep3 with the unguarded divide, delta lives in PCGStep2)
     float alpha = 0.0f, beta = 0.0f;
+    const bool lm = delta == nullptr;
     if (!first) {
         const float an = sum_partials(aNp.partials, aNp.count);
-        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
-        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+        if (lm) beta = safe_div<true>(sum_partials(bNp.partials, bNp.count), an);
+        else {
+            alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
+            beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+        }
     }
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
         const float4 pv = p_in[i], zv = z[i];
-        if (!first) {
+        if (!first && !lm) {
             float4 dv = delta[i];
             dv.x += alpha * pv.x; dv.y += alpha * pv.y; dv.z += alpha * pv.z; dv.w += alpha * pv.w;
             delta[i] = dv;
         }
         p_out[i] = make_float4(zv.x + beta * pv.x, zv.y + beta * pv.y, zv.z + beta * pv.z, zv.w + beta * pv.w);
     }
+}
+
+// ------------------------------------------------------------------ Levenberg-Marquardt set (gauss_newton.t:929-969,774-787,845-886)
+// PCGSaveSSq + PCGComputeCtC + PCGFinalizeDiagonal in one pass over the raw diagonal d = diag(J^T J):
+//   SSq (first GN iteration only) = guardedInvert(d) (or 1 without preconditioner)   -- Jacobi scale^2, ONCE_PER_SOLVE
+//   unclamped = d / radius ; CtC = clamp(unclamped, min_lm/(SSq*radius), max_lm/(SSq*radius))
+//   M^-1 = 1 / (CtC + radius*unclamped) ; b = r ; z = M^-1 r ; alphaN partials = sum r.z
+__global__ __launch_bounds__(BLOCK) void k_lm_finalize(const float4* __restrict__ diag, float4* __restrict__ SSq, float4* __restrict__ CtC,
+                                                        float4* __restrict__ pre, const float4* __restrict__ r, float4* __restrict__ b,
+                                                        float4* __restrict__ z, long n4, float radius, float min_lm, float max_lm,
+                                                        int save_ssq, int use_precond, float* __restrict__ aN_out)
+{
+    __shared__ float red[16];
+    float acc = 0.0f;
+    const float inv_radius = 1.0f / radius;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        const float4 d4 = diag[i], r4 = r[i];
+        float4 s4;
+        if (save_ssq) {
+            if (use_precond) s4 = make_float4(guarded_invert(d4.x), guarded_invert(d4.y), guarded_invert(d4.z), guarded_invert(d4.w));
+            else s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            SSq[i] = s4;
+        } else s4 = SSq[i];
+        const float dd[4] = { d4.x, d4.y, d4.z, d4.w }, ss[4] = { s4.x, s4.y, s4.z, s4.w }, rr[4] = { r4.x, r4.y, r4.z, r4.w };
+        float cc[4], mm[4], zz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float unclamped = dd[k] * inv_radius;
+            const float cm = (1.0f / ss[k]) / radius;
+            const float c = fminf(fmaxf(unclamped, min_lm * cm), max_lm * cm);
+            cc[k] = c;
+            mm[k] = 1.0f / (c + radius * unclamped);
+            zz[k] = mm[k] * rr[k];
+            acc += rr[k] * zz[k];
+        }
+        CtC[i] = make_float4(cc[0], cc[1], cc[2], cc[3]); pre[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        b[i] = r4; z[i] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+    }
+    block_store_partial(acc, aN_out, red);
+}
+
+// PCGStep1_Finish (LM): Ap += CtC*p ; alphaD partials = sum p.Ap
+__global__ __launch_bounds__(BLOCK) void k_lm_step1_finish(float4* __restrict__ Ap, const float4* __restrict__ CtC, const float4* __restrict__ p,
+                                                            long n4, float* __restrict__ aD_out)
+{
+    __shared__ float red[16];
+    float acc = 0.0f;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 a = Ap[i]; const float4 c = CtC[i], pv = p[i];
+        a.x += c.x * pv.x; a.y += c.y * pv.y; a.z += c.z * pv.z; a.w += c.w * pv.w;
+        Ap[i] = a;
+        acc += pv.x * a.x + pv.y * a.y + pv.z * a.z + pv.w * a.w;
+    }
+    block_store_partial(acc, aD_out, red);
+}
+
+// PCGStep2_1stHalf: delta += alpha*p
+__global__ __launch_bounds__(BLOCK) void k_lm_step2_first(float4* __restrict__ delta, const float4* __restrict__ p, long n4,
+                                                           thallo_sum_t aN, thallo_sum_t aD)
+{
+    const float alpha = safe_div<true>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 d = delta[i]; const float4 pv = p[i];
+        d.x += alpha * pv.x; d.y += alpha * pv.y; d.z += alpha * pv.z; d.w += alpha * pv.w;
+        delta[i] = d;
+    }
+}
+
+// PCGStep2_2ndHalf: r = b - Adelta ; z = M^-1 r ; betaN ; q = 0.5 delta.(r+b)
+__global__ __launch_bounds__(BLOCK) void k_lm_step2_second(float4* __restrict__ r, const float4* __restrict__ b, const float4* __restrict__ Ad,
+                                                            const float4* __restrict__ pre, float4* __restrict__ z, const float4* __restrict__ delta,
+                                                            long n4, float* __restrict__ bN_out, float* __restrict__ q_out)
+{
+    __shared__ float red[32];
+    float acc[2] = { 0.0f, 0.0f };
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        const float4 bv = b[i], av = Ad[i], mv = pre[i], dv = delta[i];
+        const float4 rv = make_float4(bv.x - av.x, bv.y - av.y, bv.z - av.z, bv.w - av.w);
+        const float4 zv = make_float4(mv.x * rv.x, mv.y * rv.y, mv.z * rv.z, mv.w * rv.w);
+        r[i] = rv; z[i] = zv;
+        acc[0] += zv.x * rv.x + zv.y * rv.y + zv.z * rv.z + zv.w * rv.w;
+        acc[1] += 0.5f * (dv.x * (rv.x + bv.x) + dv.y * (rv.y + bv.y) + dv.z * (rv.z + bv.z) + dv.w * (rv.w + bv.w));
+    }
+    float* __restrict__ const outs[2] = { bN_out, q_out };
+    block_store_partials<2>(acc, outs, red);
+}
+
+// sum a.b partials
+__global__ __launch_bounds__(BLOCK) void k_dot(const float4* __restrict__ a, const float4* __restrict__ b, long n4, float* __restrict__ out)
+{
+    __shared__ float red[16];
+    float acc = 0.0f;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        const float4 x = a[i], y = b[i];
+        acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    block_store_partial(acc, out, red);
 }
 
 // X += delta (+ alpha*p).  X is a caller buffer of exactly `len` floats (not padded): scalar tail.
@@ -274,6 +375,42 @@ int thallo_hip_pcg_pupdate(const float* z, const float* p_in, float* p_out, floa
     hipLaunchKernelGGL(k_pupdate, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)z, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
     int e = check_launch();
     return e ? e : grid;
+}
+
+int thallo_hip_lm_finalize_diagonal(const float* diag, float* SSq, float* CtC, float* pre, const float* r, float* b, float* z, long n,
+                                    float radius, float min_lm_diagonal, float max_lm_diagonal, int save_ssq, int use_preconditioner,
+                                    float* aN_out, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_lm_finalize, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)diag, (float4*)SSq, (float4*)CtC, (float4*)pre,
+                       (const float4*)r, (float4*)b, (float4*)z, n4, radius, min_lm_diagonal, max_lm_diagonal, save_ssq, use_preconditioner, aN_out);
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_lm_step1_finish(float* Ap, const float* CtC, const float* p, long n, float* aD_out, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_lm_step1_finish, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)Ap, (const float4*)CtC, (const float4*)p, n4, aD_out);
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_lm_step2_first_half(float* delta, const float* p, long n, thallo_sum_t aN, thallo_sum_t aD, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_lm_step2_first, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)delta, (const float4*)p, n4, aN, aD);
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_lm_step2_second_half(float* r, const float* b, const float* Adelta, const float* pre, float* z, const float* delta, long n,
+                                    float* bN_out, float* q_out, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_lm_step2_second, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)b, (const float4*)Adelta,
+                       (const float4*)pre, (float4*)z, (const float4*)delta, n4, bN_out, q_out);
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_dot(const float* a, const float* b, long n, float* out, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_dot, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b, n4, out);
+    int e = check_launch(); return e ? e : grid;
 }
 
 int thallo_hip_linear_update(float* X, const float* delta, const float* p, long len,

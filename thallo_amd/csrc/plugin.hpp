@@ -54,7 +54,7 @@ struct SolverVectors {
     long n = 0, n_alloc = 0;
     float *delta = nullptr, *r = nullptr, *z = nullptr, *Ap = nullptr, *pre = nullptr;
     float *p[2] = { nullptr, nullptr };          // ping-pong: the fused step reads p[cur], writes p[cur^1]
-    float *b = nullptr, *Adelta = nullptr, *CtC = nullptr, *SSq = nullptr, *prevX = nullptr;   // LM only
+    float *b = nullptr, *Adelta = nullptr, *CtC = nullptr, *SSq = nullptr, *prevX = nullptr, *diag = nullptr;   // LM only
 };
 
 struct UnknownImage { int param_index; long n_floats; };
@@ -73,8 +73,11 @@ public:
     virtual int prepare(LaunchCtx&) { return 0; }
     // fmap.cost -> partials; returns the partial count or <0
     virtual int cost(LaunchCtx&, float* cost_out) = 0;
-    // PCGInit1 (+_Finish): r, pre (already inverted), z = pre*r, p[cur]=0, delta=0, alphaN partials
+    // PCGInit1 (+_Finish): r, pre (already inverted), z = pre*r, p[cur]=0, delta=0, alphaN partials;
+    // when v.diag != NULL (LM) also the raw diag(J^T J) into v.diag
     virtual int pcg_init(LaunchCtx&, SolverVectors&, int cur, float* alphaN_out) = 0;
+    // plain PCGStep1: Ap = J^T J p, partials of p.Ap (LM branch, computeAdelta, model cost)
+    virtual int apply_jtj(LaunchCtx&, const float* p, float* Ap, float* alphaD_out) = 0;
     // fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k): reads p[cur], writes p[cur^1], Ap, alphaD partials
     virtual int pcg_step1(LaunchCtx&, SolverVectors&, int cur, bool first,
                           thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev, float* alphaD_out) = 0;

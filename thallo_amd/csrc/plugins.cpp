@@ -35,7 +35,9 @@ public:
     int cost(LaunchCtx& c, float* out) override
     { TimedLaunch t(c, "computeCost"); return thallo_hip_lapimg_cost(W, H, X, A, w_fit, xguard, out, c.stream); }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
-    { TimedLaunch t(c, "PCGInit1"); return thallo_hip_lapimg_pcg_init(W, H, X, A, w_fit, xguard, v.r, v.z, v.p[cur], v.delta, aN, c.stream); }
+    { TimedLaunch t(c, "PCGInit1"); return thallo_hip_lapimg_pcg_init(W, H, X, A, w_fit, xguard, v.r, v.z, v.p[cur], v.delta, v.diag, aN, c.stream); }
+    int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
+    { TimedLaunch t(c, "PCGStep1"); return thallo_hip_lapimg_apply_jtj(W, H, w_fit, xguard, p, Ap, out, c.stream); }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     { TimedLaunch t(c, "PCGStep1"); return thallo_hip_lapimg_pcg_step1(W, H, w_fit, xguard, v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, out, c.stream); }
 };
@@ -75,7 +77,12 @@ public:
     {
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_iw_pcg_init(W, H, 0, H, offset, angle, urshape, constraints, mask, w_fit, w_reg,
-                                      v.r, v.pre, v.z, v.p[cur], v.delta, (float*)cs.ptr, (unsigned char*)flags.ptr, aN, c.stream);
+                                      v.r, v.pre, v.z, v.p[cur], v.delta, (float*)cs.ptr, (unsigned char*)flags.ptr, v.diag, aN, c.stream);
+    }
+    int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_iw_apply_jtj(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg, p, Ap, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
@@ -134,7 +141,12 @@ public:
     {
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_lapgraph_pcg_init(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr,
-                                            X, A, w_fit, v.r, v.z, v.p[cur], v.delta, aN, c.stream);
+                                            X, A, w_fit, v.r, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
+    }
+    int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_lapgraph_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr, w_fit, p, Ap, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
@@ -184,7 +196,13 @@ public:
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_arap_pcg_init(N, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
-                                        (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, aN, c.stream);
+                                        (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
+    }
+    int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_arap_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+                                         constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
@@ -246,7 +264,13 @@ public:
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_ba_pcg_init(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
-                                      (const float*)Jb.ptr, (const float*)F.ptr, v.r, v.pre, v.z, v.p[cur], v.delta, aN, c.stream);
+                                      (const float*)Jb.ptr, (const float*)F.ptr, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
+    }
+    int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
+                                       (const float*)Jb.ptr, p, Ap, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {

@@ -244,14 +244,26 @@ double Plan::cost()
 }
 
 int Plan::step(void** params)
-{   // gauss_newton.t:1545-1785, GN branch, fused schedule (DESIGN.md "PCG schedule")
+{   // gauss_newton.t:1545-1785
     if (!ok_ || !ready_) return 0;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return 0; }
     if (sp.nIter >= sp.nIterations) { if (!finalized_) finalize(); return 0; }
+    if (ensure_slots(sp.lIterations)) return 0;
+    const int ev_iter = timer_.start("Nonlinear Iteration", ctx.stream);
+    const int rc = lm_ ? step_lm(ev_iter) : step_gn(ev_iter);
+    if (rc == 1 && sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779
+        hipStream_t s = ctx.stream;
+        hipEvent_t q = nullptr; hipEventCreate(&q); hipEventRecord(q, s); hipEventSynchronize(q);
+        float ms = 0.0f; hipEventElapsedTime(&ms, timer_.events[ev_total_].start, q); hipEventDestroy(q);
+        if (ms / 1000.0f > sp.max_solver_time_in_seconds) { finalize(); return 0; }
+    }
+    return rc;
+}
+
+int Plan::step_gn(int ev_iter)
+{   // GN branch, fused schedule (DESIGN.md "PCG schedule")
     const int L = sp.lIterations;
-    if (ensure_slots(L)) return 0;
     hipStream_t s = ctx.stream;
-    const int ev_iter = timer_.start("Nonlinear Iteration", s);
     const int ev_setup = timer_.start("Nonlinear Setup", s);
     const int B = 2;                       // slot layout: alphaN_k = B+2k, alphaD_k = B+2k+1, betaN_k = B+2k+2
     cur_ = 0;
@@ -292,11 +304,150 @@ int Plan::step(void** params)
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);
-    if (sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779
-        hipEvent_t q = nullptr; hipEventCreate(&q); hipEventRecord(q, s); hipEventSynchronize(q);
-        float ms = 0.0f; hipEventElapsedTime(&ms, timer_.events[ev_total_].start, q); hipEventDestroy(q);
-        if (ms / 1000.0f > sp.max_solver_time_in_seconds) { finalize(); return 0; }
+    return 1;
+}
+
+// ------------------------------------------------------------------ Levenberg-Marquardt branch
+void Plan::enable_lm(bool on) { lm_ = on; }
+
+int Plan::ensure_lm_vectors()
+{
+    if (v_.b) return 0;
+    float** vecs[] = { &v_.b, &v_.Adelta, &v_.CtC, &v_.SSq, &v_.prevX, &v_.diag };
+    for (float** vp : vecs) {
+        DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b);
+        if (b->alloc((size_t)v_.n_alloc * sizeof(float))) return -1;
+        *vp = (float*)b->ptr;
     }
+    return 0;
+}
+
+float Plan::read_sum(int j)
+{   // blocking 4-byte read-back, like fetchQ / computeModelCost (gauss_newton.t:1138-1150)
+    thallo_hip_finish_sum(sum(j), (float*)scratch_.ptr + 1, ctx.stream);
+    float f = 0.0f;
+    HIP_OK(hipMemcpyAsync(&f, (float*)scratch_.ptr + 1, sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
+    HIP_OK(hipStreamSynchronize(ctx.stream));
+    return f;
+}
+
+int Plan::step_lm(int ev_iter)
+{   // gauss_newton.t:1545-1785 with every UsesLambda() branch taken; unfused (reference-shaped) PCG schedule because
+    // q = 0.5 delta.(r+b) needs the current delta inside PCGStep2 and PCGStep1_Finish adds CtC*p.
+    // Slots: 0 cost, 1 q, B.. as in GN (alphaN_k = B+2k, alphaD_k = B+2k+1, betaN_k = B+2k+2); last two: scratch dots.
+    if (ensure_lm_vectors()) return 0;
+    hipStream_t s = ctx.stream;
+    const int L = sp.lIterations, B = 2, QS = 1, T0 = 2 * L + 4, T1 = 2 * L + 5;
+    const long n = v_.n;
+    const bool pc = plugin->use_preconditioner();
+    const int ev_setup = timer_.start("Nonlinear Setup", s);
+    if (sp.nIter == 0) { radius_ = sp.trust_region_radius; decrease_factor_ = sp.radius_decrease_factor; }   // :1185-1186 (copied at init)
+    cur_ = 0;
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));               // r, raw diag (v_.diag); delta = 0
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
+    {   TimedLaunch t(ctx, "PCGFinalizeDiagonal");                    // :1596-1604 (alphaN restarts from 0)
+        nb = thallo_hip_lm_finalize_diagonal(v_.diag, v_.SSq, v_.CtC, v_.pre, v_.r, v_.b, v_.z, n, radius_, sp.min_lm_diagonal, sp.max_lm_diagonal,
+                                             sp.nIter == 0 ? 1 : 0, pc ? 1 : 0, slot(B), s);
+    }
+    if (nb < 0) return 0;
+    nb_[B] = nb;
+    float Q0 = 0.0f;                                                  // delta = 0 -> q = 0 (:965)
+    timer_.stop(ev_setup, s);
+    const int ev_lin = timer_.start("Linear Solve", s);
+    float* p = v_.p[0];
+    int k_done = 0;
+    for (int k = 0; k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        {   TimedLaunch t(ctx, "PCGStep3");                           // p = z + beta p  (k = 0: p = z)
+            thallo_hip_pcg_pupdate(v_.z, p, p, nullptr, n, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
+        }
+        nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(T0));              // PCGStep1 (J^T J p)
+        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
+        {   TimedLaunch t(ctx, "PCGStep1_Finish");                    // + CtC p ; alphaD
+            nb = thallo_hip_lm_step1_finish(v_.Ap, v_.CtC, p, n, slot(jD), s);
+        }
+        if (nb < 0) return 0;
+        nb_[jD] = nb;
+        int nbq;
+        if (((k + 1) % sp.residual_reset_period) == 0) {              // :1653-1657
+            TimedLaunch t(ctx, "PCGStep2");
+            thallo_hip_lm_step2_first_half(v_.delta, p, n, sum(jN), sum(jD), s);
+            nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));             // computeAdelta
+            if (nb < 0) return 0;
+            thallo_hip_lm_step1_finish(v_.Adelta, v_.CtC, v_.delta, n, slot(T1), s);
+            nb = thallo_hip_lm_step2_second_half(v_.r, v_.b, v_.Adelta, v_.pre, v_.z, v_.delta, n, slot(jB), slot(QS), s);
+            nbq = nb;
+        } else {
+            TimedLaunch t(ctx, "PCGStep2");
+            nb = thallo_hip_pcg_step2_full(v_.delta, p, v_.r, v_.Ap, v_.pre, v_.z, v_.b, n, sum(jN), sum(jD), slot(jB), slot(QS), 1, s);
+            nbq = nb;
+        }
+        if (nb < 0) return 0;
+        nb_[jB] = nb; nb_[QS] = nbq;
+        k_done = k + 1;
+        const float Q1 = read_sum(QS);                                // :1666-1686 (blocking, as in the reference)
+        if (!std::isfinite(Q1)) break;
+        const float zeta = (float)(k + 1) * (Q1 - Q0) / Q1;
+        if (!std::isfinite(zeta)) break;
+        if (zeta < sp.q_tolerance) break;
+        Q0 = Q1;
+    }
+    last_l_iters = k_done;
+    timer_.stop(ev_lin, s);
+    const int ev_fin = timer_.start("Nonlinear Finish", s);
+    // model_cost_change = cost - 0.5|F + J delta|^2 = delta.b - 0.5 delta.(J^T J delta)   (b = -J^T F; thallo.t:3845-3865
+    // expanded algebraically, which also avoids the reference's cancellation between two large sums)
+    nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));
+    if (nb < 0) return 0;
+    nb_[T0] = nb;
+    nb = thallo_hip_dot(v_.delta, v_.b, n, slot(T1), s);
+    if (nb < 0) return 0;
+    nb_[T1] = nb;
+    const float dJJd = read_sum(T0), db = read_sum(T1);
+    const float model_cost_change = db - 0.5f * dJJd;
+    const auto& imgs = plugin->unknown_images();
+    {   long off = 0;                                                 // savePreviousUnknowns :915-920
+        for (size_t k = 0; k < imgs.size(); ++k) {
+            HIP_OK(hipMemcpyAsync(v_.prevX + off, plugin->unknown_ptr((int)k), imgs[k].n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+            off += imgs[k].n_floats;
+        }
+    }
+    {   long off = 0;                                                 // PCGLinearUpdate
+        for (size_t k = 0; k < imgs.size(); ++k) {
+            TimedLaunch t(ctx, "PCGLinearUpdate");
+            thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
+            off += imgs[k].n_floats;
+        }
+    }
+    const float newCost = compute_cost();
+    const float cost_change = prev_cost_ - newCost;
+    const float relative_decrease = cost_change / model_cost_change;
+    if (ip.verbosityLevel > 0) printf(" cost=%g new cost=%g model_cost_change=%g rho=%g radius=%g pcg=%d\n", prev_cost_, newCost, model_cost_change, relative_decrease, radius_, k_done);
+    bool stop = false;
+    if (cost_change >= 0 && relative_decrease > sp.min_relative_decrease) {      // :1715-1732
+        if (cost_change <= prev_cost_ * sp.function_tolerance) stop = true;
+        else {
+            const double tmp_factor = 1.0 - std::pow(2.0 * (double)relative_decrease - 1.0, 3.0);
+            radius_ = (float)((double)radius_ / std::fmax(1.0 / 3.0, tmp_factor));
+            radius_ = std::fmin(radius_, sp.max_trust_region_radius);
+            decrease_factor_ = 2.0f;
+            prev_cost_ = newCost;
+        }
+    } else {                                                                      // :1733-1749
+        long off = 0;
+        for (size_t k = 0; k < imgs.size(); ++k) {                               // revertUpdate
+            HIP_OK(hipMemcpyAsync(plugin->unknown_ptr((int)k), v_.prevX + off, imgs[k].n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+            off += imgs[k].n_floats;
+        }
+        radius_ = radius_ / decrease_factor_;
+        decrease_factor_ = 2.0f * decrease_factor_;
+        if (radius_ < sp.min_trust_region_radius) { sp.trust_region_radius = 10e4f; stop = true; }
+    }
+    if (!stop) sp.trust_region_radius = radius_;                                  // :1751
+    timer_.stop(ev_fin, s);
+    timer_.stop(ev_iter, s);
+    if (stop) { finalize(); return 0; }
+    sp.nIter++;
     return 1;
 }
 

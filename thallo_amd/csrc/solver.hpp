@@ -49,6 +49,8 @@ public:
     void set_param(const char* name, const void* value);
     void get_param(const char* name, void* value);
     int  alpha_beta_trace(float* out_pairs, int cap);
+    void enable_lm(bool on);       // extension: run the LM branch the reference text describes (dead as shipped, thallo.t:463)
+    bool lm() const { return lm_; }
 
     EnergyPlugin* plugin;
     SolverParameters sp;
@@ -81,6 +83,11 @@ private:
     thallo_sum_t sum(int j) { thallo_sum_t s; s.partials = slot(j); s.count = nb_[j]; return s; }
     int  ensure_slots(int L);
     float compute_cost();
+    int   step_gn(int ev_iter);
+    int   step_lm(int ev_iter);
+    int   ensure_lm_vectors();
+    float read_sum(int j);
+    float radius_ = 1e4f, decrease_factor_ = 2.0f;
     void finalize();
 };
 

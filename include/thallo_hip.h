@@ -226,6 +226,25 @@ int thallo_hip_ba_pcg_init(int C, int P, const int* cam_ptr, const int* q_pt, co
 int thallo_hip_ba_apply_jtj(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
                             const float* Jb, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 
+/* ---------------------------------------------------------------- E3: examples/shape_from_shading/shape_from_shading.t
+ * params 0-15 host scalars (w_p, w_s, w_g = SQUARED weights, f_x, f_y, u_x, u_y, L_1..L_9), X float unknown (16), D_i (17),
+ * Im (18), edgeMaskR/C uint8 (19, 20).  host_params = those 16 floats copied into one host array.
+ * precompute (the reference's `precompute` kernels for the computed array B_I_comp and its gradient images,
+ * gauss_newton.t:979-986, thallo.t:4046-4094; once per GN iteration and before every cost evaluation) fills
+ *   G  float4/pixel = (dBI/dX(c), dBI/dX(c-ex), dBI/dX(c-ey), BI(c)),  Wt float2/pixel = shading row weights,
+ *   fl uint8/pixel  = bit0 D_i>0, bit1 reg row valid.
+ * U (float2/pixel) and R (3 floats/pixel, planar) are scratch for the row pass of J^T(Jv). */
+int thallo_hip_sfs_precompute(int W, int H, const float* host_params, const float* X, const float* D, const float* Im,
+                              const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
+                              thallo_stream_t stream);
+int thallo_hip_sfs_cost(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+                        const unsigned char* fl, float* cost_out, thallo_stream_t stream);
+int thallo_hip_sfs_pcg_init(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+                            const unsigned char* fl, float* U, float* R, float* r, float* z, float* p_prev, float* delta,
+                            float* diag_out, float* alphaN_out, thallo_stream_t stream);
+int thallo_hip_sfs_apply_jtj(int W, int H, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                             float* U, float* R, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+
 /* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped
  * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's
  * stand-alone applyJTJ roofline measurement. */

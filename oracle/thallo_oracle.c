@@ -272,6 +272,107 @@ static int rows_bundle(const OrcEnergy* e, long elem, OrcRow* out)
     return 2;
 }
 
+/* E3: examples/shape_from_shading/shape_from_shading.t:1-112.
+ * params 0-15: host floats w_p, w_s, w_g (squared weights: the .t takes sqrt, :27), f_x, f_y, u_x, u_y, L_1..L_9;
+ * 16 X float (unknown), 17 D_i float, 18 Im float, 19 edgeMaskR uint8, 20 edgeMaskC uint8.   dims W,H.
+ * Guarded loads return 0 outside the image (thallo.t:876-883).  One element = one pixel = 6 rows:
+ *   fit, shading_h, shading_v, reg.x, reg.y, reg.z.
+ * B_I(c) = [D(c-ex)>0 & D(c)>0 & D(c-ey)>0] * (B(n(c)) - I(c)) depends on X(c), X(c-ex), X(c-ey); its three partials come
+ * from 3-wide forward-mode AD (what the reference's gradient images of the computed array B_I_comp hold, :79-80).
+ * `valid` of the reg term contains comparisons on X: zero derivative (ad.t:824-829). */
+typedef struct { float v, d[3]; } J3;
+static inline J3 k3(float c) { J3 r = { c, { 0, 0, 0 } }; return r; }
+static inline J3 v3(float c, int k) { J3 r = k3(c); r.d[k] = 1.0f; return r; }
+static inline J3 a3(J3 a, J3 b) { J3 r; r.v = a.v + b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+static inline J3 s3(J3 a, J3 b) { J3 r; r.v = a.v - b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+static inline J3 m3(J3 a, J3 b) { J3 r; r.v = a.v * b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+static inline J3 c3(J3 a, float c) { J3 r; r.v = a.v * c; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] * c; return r; }
+
+typedef struct { int W, H; const float *X, *D, *Im; const unsigned char *mR, *mC; float wp, ws, wg, fx, fy, ux, uy, L[9]; } Sfs;
+static inline float sfs_at(const Sfs* q, const float* a, long x, long y) { return (x >= 0 && x < q->W && y >= 0 && y < q->H) ? a[y * q->W + x] : 0.0f; }
+static void sfs_bind(const OrcEnergy* e, Sfs* q)
+{
+    q->W = (int)e->dims[0]; q->H = (int)e->dims[1];
+    const float wp = *(const float*)e->params[0], ws = *(const float*)e->params[1], wg = *(const float*)e->params[2];
+    q->wp = sqrtf(wp); q->ws = sqrtf(ws); q->wg = sqrtf(wg);
+    q->fx = *(const float*)e->params[3]; q->fy = *(const float*)e->params[4]; q->ux = *(const float*)e->params[5]; q->uy = *(const float*)e->params[6];
+    for (int k = 0; k < 9; ++k) q->L[k] = *(const float*)e->params[7 + k];
+    q->X = img(e, 16); q->D = img(e, 17); q->Im = img(e, 18);
+    q->mR = (const unsigned char*)e->params[19]; q->mC = (const unsigned char*)e->params[20];
+}
+/* B_I at pixel (x,y) with derivatives w.r.t. X(x,y) [0], X(x-1,y) [1], X(x,y-1) [2] */
+static J3 sfs_BI(const Sfs* q, long x, long y)
+{
+    if (!(sfs_at(q, q->D, x - 1, y) > 0.0f && sfs_at(q, q->D, x, y) > 0.0f && sfs_at(q, q->D, x, y - 1) > 0.0f)) return k3(0.0f);
+    const J3 c = v3(sfs_at(q, q->X, x, y), 0), l = v3(sfs_at(q, q->X, x - 1, y), 1), u = v3(sfs_at(q, q->X, x, y - 1), 2);
+    const float i = (float)x, j = (float)y;
+    const J3 nx = c3(m3(u, s3(c, l)), 1.0f / q->fy);                       /* shape_from_shading.t:47 */
+    const J3 ny = c3(m3(l, s3(c, u)), 1.0f / q->fx);                       /* :48 */
+    const J3 nz = s3(a3(c3(nx, (q->ux - i) / q->fx), c3(ny, (q->uy - j) / q->fy)), c3(m3(l, u), 1.0f / (q->fx * q->fy)));   /* :49 */
+    const J3 sq = a3(a3(m3(nx, nx), m3(ny, ny)), m3(nz, nz));
+    J3 inv;
+    if (sq.v > 0.0f) { inv.v = 1.0f / sqrtf(sq.v); const float k = -0.5f * inv.v / sq.v; for (int t = 0; t < 3; ++t) inv.d[t] = k * sq.d[t]; }
+    else inv = k3(1.0f);
+    const J3 n0 = m3(inv, nx), n1 = m3(inv, ny), n2 = m3(inv, nz);
+    const float* L = q->L;
+    J3 B = k3(L[0]);
+    B = a3(B, c3(n1, L[1])); B = a3(B, c3(n2, L[2])); B = a3(B, c3(n0, L[3]));
+    B = a3(B, c3(m3(n0, n1), L[4])); B = a3(B, c3(m3(n1, n2), L[5]));
+    B = a3(B, c3(a3(s3(c3(m3(n0, n0), -1.0f), m3(n1, n1)), c3(m3(n2, n2), 2.0f)), L[6]));
+    B = a3(B, c3(m3(n2, n0), L[7])); B = a3(B, c3(s3(m3(n0, n0), m3(n1, n1)), L[8]));
+    const float I = sfs_at(q, q->Im, x, y) * 0.5f + 0.25f * (sfs_at(q, q->Im, x - 1, y) + sfs_at(q, q->Im, x, y - 1));   /* :69 */
+    return s3(B, k3(I));
+}
+static inline void row_add(OrcRow* r, long W, long H, long x, long y, float v)
+{
+    if (x < 0 || x >= W || y < 0 || y >= H || v == 0.0f) return;
+    const int col = (int)(y * W + x);
+    for (int k = 0; k < r->nnz; ++k) if (r->col[k] == col) { r->val[k] += v; return; }
+    r->col[r->nnz] = col; r->val[r->nnz] = v; r->nnz++;
+}
+static int rows_sfs(const OrcEnergy* e, long elem, OrcRow* out)
+{
+    Sfs q; sfs_bind(e, &q);
+    const long W = q.W, H = q.H, x = elem % W, y = elem / W;
+    for (int k = 0; k < 6; ++k) { out[k].nnz = 0; out[k].r = 0.0f; }
+    const float Xc = q.X[elem];
+    /* fit (:86-87) */
+    if (q.D[elem] > 0.0f) { out[0].r = q.wp * (Xc - q.D[elem]); row_add(&out[0], W, H, x, y, q.wp); }
+    /* shading (:90-93): InBoundsExpanded(x,y,1) */
+    if (x >= 1 && x + 1 < W && y >= 1 && y + 1 < H) {
+        const J3 b0 = sfs_BI(&q, x, y), bx = sfs_BI(&q, x + 1, y), by = sfs_BI(&q, x, y + 1);
+        const float h = q.wg * (float)q.mR[elem], v = q.wg * (float)q.mC[elem];
+        out[1].r = h * (b0.v - bx.v);
+        row_add(&out[1], W, H, x, y, h * b0.d[0]); row_add(&out[1], W, H, x - 1, y, h * b0.d[1]); row_add(&out[1], W, H, x, y - 1, h * b0.d[2]);
+        row_add(&out[1], W, H, x + 1, y, -h * bx.d[0]); row_add(&out[1], W, H, x, y, -h * bx.d[1]); row_add(&out[1], W, H, x + 1, y - 1, -h * bx.d[2]);
+        out[2].r = v * (b0.v - by.v);
+        row_add(&out[2], W, H, x, y, v * b0.d[0]); row_add(&out[2], W, H, x - 1, y, v * b0.d[1]); row_add(&out[2], W, H, x, y - 1, v * b0.d[2]);
+        row_add(&out[2], W, H, x, y + 1, -v * by.d[0]); row_add(&out[2], W, H, x - 1, y + 1, -v * by.d[1]); row_add(&out[2], W, H, x, y, -v * by.d[2]);
+    }
+    /* regularisation (:96-104) */
+    static const int DX[4] = { -1, 0, 1, 0 }, DY[4] = { 0, -1, 0, 1 };
+    int valid = q.D[elem] > 0.0f;
+    for (int d = 0; d < 4 && valid; ++d) {
+        if (!(sfs_at(&q, q.D, x + DX[d], y + DY[d]) > 0.0f)) valid = 0;
+        else if (!(fabsf(Xc - sfs_at(&q, q.X, x + DX[d], y + DY[d])) < 0.01f)) valid = 0;
+    }
+    if (valid) {
+        for (int c = 0; c < 3; ++c) {
+            #define COEF(ix, iy) (c == 0 ? ((float)(ix) - q.ux) / q.fx : c == 1 ? ((float)(iy) - q.uy) / q.fy : 1.0f)
+            float acc = 4.0f * (COEF(x, y) * Xc);
+            row_add(&out[3 + c], W, H, x, y, q.ws * 4.0f * COEF(x, y));
+            for (int d = 0; d < 4; ++d) {
+                const long xn = x + DX[d], yn = y + DY[d];
+                acc -= COEF(xn, yn) * sfs_at(&q, q.X, xn, yn);
+                row_add(&out[3 + c], W, H, xn, yn, -q.ws * COEF(xn, yn));
+            }
+            #undef COEF
+            out[3 + c].r = q.ws * acc;
+        }
+    }
+    return 6;
+}
+
 int orc_energy_init(OrcEnergy* e, int kind, const unsigned* dims, void** params,
                     const float* fconst, const int* iconst)
 {
@@ -307,6 +408,12 @@ int orc_energy_init(OrcEnergy* e, int kind, const unsigned* dims, void** params,
         e->img_param[1] = 3; e->img_chan[1] = 3; e->img_count[1] = dims[0];
         e->n_elems = (long)dims[0] + dims[1]; e->rows = rows_arap;
         e->use_precond = 1;   /* arap_mesh_deformation.t:13 */
+        break; }
+    case ORC_SFS: {
+        e->dims[0] = dims[0]; e->dims[1] = dims[1];
+        e->n_img = 1; e->img_param[0] = 16; e->img_chan[0] = 1; e->img_count[0] = (long)dims[0] * dims[1];
+        e->n_elems = (long)dims[0] * dims[1]; e->rows = rows_sfs;
+        e->use_precond = 0;   /* shape_from_shading.t has no UsePreconditioner() */
         break; }
     case ORC_BUNDLE_ADJUST: {
         e->dims[0] = dims[0]; e->dims[1] = dims[1]; e->dims[2] = dims[2];

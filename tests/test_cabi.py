@@ -46,7 +46,8 @@ def test_reference_api_surface_is_complete(L):
 @pytest.mark.parametrize("fname,energy", [
     ("image_warping", "image_warping"), ("laplacian_image", "laplacian_image"),
     ("laplacian_image_shipped_guard", "laplacian_image"), ("laplacian_graph", "laplacian_graph"),
-    ("arap_mesh_deformation", "arap_mesh"), ("bundle_adjustment", "bundle_adjustment")])
+    ("arap_mesh_deformation", "arap_mesh"), ("bundle_adjustment", "bundle_adjustment"),
+    ("shape_from_shading", "shape_from_shading")])
 def test_frontend_recognises_bundled_energies(L, fname, energy):
     buf = C.create_string_buffer(64)
     h = L.ThalloX_ProblemFileHash(thallo_amd.energy_file(fname).encode(), buf, 64)

@@ -14,6 +14,27 @@ from thallo_amd.distributed import SlabLayout, SlabSolver
 from slab_numpy_backend import NumpySlabBackend
 
 
+def _collect(q, procs, world, limit=150.0):
+    """Gather one result per rank; fail fast if a rank died instead of waiting out the queue timeout."""
+    import queue as _queue
+    import time as _time
+    res, t0 = [], _time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=1.0))
+        except _queue.Empty:
+            dead = [p_.exitcode for p_ in procs if p_.exitcode not in (None, 0)]
+            if dead or _time.time() - t0 > limit:
+                for p_ in procs:
+                    if p_.is_alive():
+                        p_.terminate()
+                raise AssertionError(f"ranks failed: exit codes {[p_.exitcode for p_ in procs]}")
+    for p_ in procs:
+        p_.join(timeout=30)
+        assert p_.exitcode == 0
+    return res
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -44,10 +65,7 @@ def test_slab_solver_matches_single_domain_oracle(orc, world, W, H):
     procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
     for p_ in procs:
         p_.start()
-    res = [q.get(timeout=120) for _ in range(world)]
-    for p_ in procs:
-        p_.join(timeout=60)
-        assert p_.exitcode == 0
+    res = _collect(q, procs, world)
     p = syn.image_warping(W, H, n_markers=8)
     co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=nit, lIterations=lit)
     res.sort(key=lambda t: t[0])

@@ -75,6 +75,20 @@ def lib():
     L.ThalloX_PlanEnergyName.argtypes = [vp]; L.ThalloX_PlanEnergyName.restype = C.c_char_p
     L.ThalloX_LastError.restype = C.c_char_p
     L.ThalloX_ProblemFileHash.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; L.ThalloX_ProblemFileHash.restype = C.c_ulonglong
+    # --- kernel shim entry points that python drives directly (distributed driver, bench, tests): typed, so a
+    #     signature drift raises an ArgumentError instead of corrupting the call
+    fl, ci, cl = C.c_float, C.c_int, C.c_long
+    L.thallo_hip_vector_elems.argtypes = [cl]; L.thallo_hip_vector_elems.restype = cl
+    L.thallo_hip_finish_sum.argtypes = [SumT, vp, vp]
+    L.thallo_hip_iw_cost.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp]
+    L.thallo_hip_iw_pcg_init.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, vp, vp]
+    L.thallo_hip_iw_apply_jtj.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp]
+    L.thallo_hip_pcg_step2.argtypes = [vp, vp, vp, vp, cl, SumT, SumT, vp, vp]
+    L.thallo_hip_pcg_step2_ranges.argtypes = [vp, vp, vp, vp, cl, cl, cl, cl, SumT, SumT, vp, vp]
+    L.thallo_hip_linear_update.argtypes = [vp, vp, vp, cl, SumT, SumT, vp]
+    L.thallo_hip_slab_pack.argtypes = [vp, SegsT, SumT, vp, vp]
+    L.thallo_hip_slab_unpack.argtypes = [vp, SegsT, vp, SegsT, vp, vp, cl, ci, vp, vp]
     _lib = L
     return L
 

@@ -1,0 +1,319 @@
+// energy_sfs.hip -- plugin for examples/shape_from_shading/shape_from_shading.t:1-112 (refined depth X from
+// an RGB-D frame: depth fit + SH-shading gradient term + Laplacian of back-projected points).
+//
+// Residuals per pixel q = (x,y) (guarded loads return 0 outside the image, thallo.t:876-883):
+//   fit(q)  = [D(q)>0] w_p (X(q) - D(q))
+//   sh_h(q) = [1<=x<=W-2, 1<=y<=H-2] w_g edgeMaskR(q) (BI(q) - BI(q+ex))
+//   sh_v(q) = [same guard]           w_g edgeMaskC(q) (BI(q) - BI(q+ey))
+//   reg(q)  = [valid(q)] w_s (4 P(q) - P(q-ex) - P(q-ey) - P(q+ex) - P(q+ey)),  P(c) = X(c) ((cx-u_x)/f_x, (cy-u_y)/f_y, 1)
+//   BI(c)   = [D(c-ex)>0, D(c)>0, D(c-ey)>0] (B(n(c)) - I(c)): SH shading of the normal built from X(c), X(c-ex), X(c-ey)
+//   valid(q)= D>0 at q and its 4 neighbours and |X(q)-X(nbr)| < 0.01 (comparisons: zero derivative, ad.t:824-829)
+// w_p, w_s, w_g are the square roots of the caller's parameters (shape_from_shading.t:27).
+//
+// The reference materialises BI as a computed array with gradient images once per GN iteration
+// (`B_I_comp:get`, precompute kernels gauss_newton.t:979-986, thallo.t:4046-4094); so does k_precompute:
+//   G(c) = (dBI/dX(c), dBI/dX(c-ex), dBI/dX(c-ey), BI(c))   float4 per pixel, 3-wide forward-mode AD
+//   Wt(c) = (h, k) = shading row weights incl. guard and edge masks;  fl(c): bit0 D>0, bit1 reg valid
+// With those, J is a chain of radius-1 stencils and J^T(Jv) is computed by two gather kernels (no atomics):
+//   k_rows : per residual pixel q   U_h = h^2 (dB(q) - dB(q+ex)), U_v = k^2 (dB(q) - dB(q+ey)), R_c = valid w_s (Lap of coef_c v)
+//            with dB(c) = G.x v(c) + G.y v(c-ex) + G.z v(c-ey)            [dB = BI itself when evaluating J^T F]
+//   k_gather: per unknown pixel i   T(c) = U_h(c) - U_h(c-ex) + U_v(c) - U_v(c-ey)
+//            out(i) = w_p^2 [D>0] v(i) + G.x(i) T(i) + G.y(i+ex) T(i+ex) + G.z(i+ey) T(i+ey)
+//                     + w_s sum_c coef_c(i) (4 R_c(i) - sum_nbr R_c(nbr))
+// 1 float per pixel: the whole working set of a 2048^2 frame is ~250 MB of small planes; neighbours come through
+// L1/L2.  Not tuned yet (round 1: correctness + structure).
+#include "device_common.hpp"
+#include "../../include/thallo_hip.h"
+
+using namespace thallo;
+
+namespace {
+
+constexpr int TW = 64, TH = 4, BLOCK = 256;
+struct Geo { int W, H, tx, ty, ntiles; };
+inline Geo make_geo(int W, int H) { Geo g; g.W = W; g.H = H; g.tx = (W + TW - 1) / TW; g.ty = (H + TH - 1) / TH; g.ntiles = g.tx * g.ty; return g; }
+inline int grid_for(const Geo& g)
+{
+    int cap = thallo_hip_device_cu_count() * 4; if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS; cap -= cap % 8;
+    return g.ntiles < cap ? g.ntiles : cap;
+}
+inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
+
+struct Cam { float wp, ws, wg, fx, fy, ux, uy; float L[9]; };
+
+#define FOR_EACH_PIXEL(g) \
+    for (TileSweep t_((g).ntiles); t_.valid(); t_.next()) \
+        for (int x = (t_.cur % (g).tx) * TW + (threadIdx.x % TW), y = (t_.cur / (g).tx) * TH + (threadIdx.x / TW), once_ = 1; once_; once_ = 0) \
+            if (x < (g).W && y < (g).H)
+
+__device__ __forceinline__ float at(const float* __restrict__ a, int x, int y, int W, int H) { return (x >= 0 && x < W && y >= 0 && y < H) ? a[(long)y * W + x] : 0.0f; }
+
+struct J3 { float v, d0, d1, d2; };
+__device__ __forceinline__ J3 k3(float c) { J3 r = { c, 0.f, 0.f, 0.f }; return r; }
+__device__ __forceinline__ J3 operator+(J3 a, J3 b) { J3 r = { a.v + b.v, a.d0 + b.d0, a.d1 + b.d1, a.d2 + b.d2 }; return r; }
+__device__ __forceinline__ J3 operator-(J3 a, J3 b) { J3 r = { a.v - b.v, a.d0 - b.d0, a.d1 - b.d1, a.d2 - b.d2 }; return r; }
+__device__ __forceinline__ J3 operator*(J3 a, J3 b) { J3 r = { a.v * b.v, a.d0 * b.v + a.v * b.d0, a.d1 * b.v + a.v * b.d1, a.d2 * b.v + a.v * b.d2 }; return r; }
+__device__ __forceinline__ J3 operator*(J3 a, float c) { J3 r = { a.v * c, a.d0 * c, a.d1 * c, a.d2 * c }; return r; }
+
+// BI and its three partials at pixel (x,y)   (shape_from_shading.t:40-80)
+__device__ __forceinline__ J3 eval_BI(const Cam& cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
+                                      int x, int y, int W, int H)
+{
+    if (!(at(D, x - 1, y, W, H) > 0.0f && at(D, x, y, W, H) > 0.0f && at(D, x, y - 1, W, H) > 0.0f)) return k3(0.0f);
+    const J3 c = { at(X, x, y, W, H), 1.f, 0.f, 0.f }, l = { at(X, x - 1, y, W, H), 0.f, 1.f, 0.f }, u = { at(X, x, y - 1, W, H), 0.f, 0.f, 1.f };
+    const float i = (float)x, j = (float)y;
+    const J3 nx = (u * (c - l)) * (1.0f / cm.fy);
+    const J3 ny = (l * (c - u)) * (1.0f / cm.fx);
+    const J3 nz = (nx * ((cm.ux - i) / cm.fx) + ny * ((cm.uy - j) / cm.fy)) - (l * u) * (1.0f / (cm.fx * cm.fy));
+    const J3 sq = nx * nx + ny * ny + nz * nz;
+    J3 inv;
+    if (sq.v > 0.0f) { inv.v = 1.0f / sqrtf(sq.v); const float k = -0.5f * inv.v / sq.v; inv.d0 = k * sq.d0; inv.d1 = k * sq.d1; inv.d2 = k * sq.d2; }
+    else inv = k3(1.0f);
+    const J3 n0 = inv * nx, n1 = inv * ny, n2 = inv * nz;
+    const float* L = cm.L;
+    J3 B = k3(L[0]);
+    B = B + n1 * L[1]; B = B + n2 * L[2]; B = B + n0 * L[3];
+    B = B + (n0 * n1) * L[4]; B = B + (n1 * n2) * L[5];
+    B = B + (((n0 * n0) * -1.0f - n1 * n1) + (n2 * n2) * 2.0f) * L[6];
+    B = B + (n2 * n0) * L[7]; B = B + (n0 * n0 - n1 * n1) * L[8];
+    const float I = at(Im, x, y, W, H) * 0.5f + 0.25f * (at(Im, x - 1, y, W, H) + at(Im, x, y - 1, W, H));
+    return B - k3(I);
+}
+
+__device__ __forceinline__ float coef(const Cam& cm, int c, int x, int y) { return c == 0 ? ((float)x - cm.ux) / cm.fx : c == 1 ? ((float)y - cm.uy) / cm.fy : 1.0f; }
+
+// precompute: G, Wt, fl
+__global__ __launch_bounds__(BLOCK) void k_precompute(Geo g, Cam cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
+                                                       const unsigned char* __restrict__ mR, const unsigned char* __restrict__ mC,
+                                                       float4* __restrict__ G, float2* __restrict__ Wt, unsigned char* __restrict__ fl)
+{
+    FOR_EACH_PIXEL(g) {
+        const long i = (long)y * g.W + x;
+        const J3 b = eval_BI(cm, X, D, Im, x, y, g.W, g.H);
+        G[i] = make_float4(b.d0, b.d1, b.d2, b.v);
+        const bool inner = x >= 1 && x + 1 < g.W && y >= 1 && y + 1 < g.H;
+        Wt[i] = inner ? make_float2(cm.wg * (float)mR[i], cm.wg * (float)mC[i]) : make_float2(0.f, 0.f);
+        const float xc = X[i];
+        unsigned char f = D[i] > 0.0f ? 1 : 0;
+        bool valid = f;
+        const int dx[4] = { -1, 0, 1, 0 }, dy[4] = { 0, -1, 0, 1 };
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int xn = x + dx[d], yn = y + dy[d];
+            valid = valid && at(D, xn, yn, g.W, g.H) > 0.0f && fabsf(xc - at(X, xn, yn, g.W, g.H)) < 0.01f;
+        }
+        if (valid) f |= 2;
+        fl[i] = f;
+    }
+}
+
+// cost from the precomputed planes (gauss_newton.t:1067-1079)
+__global__ __launch_bounds__(BLOCK) void k_cost(Geo g, Cam cm, const float* __restrict__ X, const float* __restrict__ D,
+                                                const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
+                                                float* __restrict__ out)
+{
+    __shared__ float red[16];
+    float acc = 0.0f;
+    FOR_EACH_PIXEL(g) {
+        const long i = (long)y * g.W + x;
+        const unsigned char f = fl[i];
+        const float xc = X[i];
+        float s = 0.0f;
+        if (f & 1) { const float e = cm.wp * (xc - D[i]); s += e * e; }
+        const float2 w = Wt[i];
+        if (w.x != 0.0f || w.y != 0.0f) {           // inner pixel: q+ex, q+ey exist
+            const float b0 = G[i].w;
+            const float eh = w.x * (b0 - G[i + 1].w), ev = w.y * (b0 - G[i + g.W].w);
+            s += eh * eh + ev * ev;
+        }
+        if (f & 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a = 4.0f * (coef(cm, c, x, y) * xc);
+                a -= coef(cm, c, x - 1, y) * at(X, x - 1, y, g.W, g.H); a -= coef(cm, c, x, y - 1) * at(X, x, y - 1, g.W, g.H);
+                a -= coef(cm, c, x + 1, y) * at(X, x + 1, y, g.W, g.H); a -= coef(cm, c, x, y + 1) * at(X, x, y + 1, g.W, g.H);
+                a *= cm.ws; s += a * a;
+            }
+        }
+        acc += 0.5f * s;
+    }
+    block_store_partial(acc, out, red);
+}
+
+// rows: FROM_X = true evaluates residual values (J^T F pass), else J v
+template <bool FROM_X>
+__global__ __launch_bounds__(BLOCK) void k_rows(Geo g, Cam cm, const float* __restrict__ v, const float4* __restrict__ G,
+                                                const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
+                                                float2* __restrict__ U, float* __restrict__ R)
+{
+    const long N = (long)g.W * g.H;
+    FOR_EACH_PIXEL(g) {
+        const long i = (long)y * g.W + x;
+        const float2 w = Wt[i];
+        float uh = 0.0f, uv = 0.0f;
+        if (w.x != 0.0f || w.y != 0.0f) {
+            float b0, bx, by;
+            if (FROM_X) { b0 = G[i].w; bx = G[i + 1].w; by = G[i + g.W].w; }
+            else {
+                const float vc = v[i], vl = v[i - 1], vu = v[i - g.W];      // inner pixel: all in range
+                const float4 g0 = G[i], gx = G[i + 1], gy = G[i + g.W];
+                b0 = g0.x * vc + g0.y * vl + g0.z * vu;
+                bx = gx.x * v[i + 1] + gx.y * vc + gx.z * v[i + 1 - g.W];
+                by = gy.x * v[i + g.W] + gy.y * v[i + g.W - 1] + gy.z * vc;
+            }
+            uh = w.x * (w.x * (b0 - bx)); uv = w.y * (w.y * (b0 - by));
+        }
+        U[i] = make_float2(uh, uv);
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        if (fl[i] & 2) {
+            const float vc = v[i], vl = at(v, x - 1, y, g.W, g.H), vu = at(v, x, y - 1, g.W, g.H), vr = at(v, x + 1, y, g.W, g.H), vd = at(v, x, y + 1, g.W, g.H);
+            float a[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                a[c] = cm.ws * (4.0f * (coef(cm, c, x, y) * vc) - coef(cm, c, x - 1, y) * vl - coef(cm, c, x, y - 1) * vu
+                                - coef(cm, c, x + 1, y) * vr - coef(cm, c, x, y + 1) * vd);
+            r0 = a[0]; r1 = a[1]; r2 = a[2];
+        }
+        R[i] = r0; R[N + i] = r1; R[2 * N + i] = r2;
+    }
+}
+
+__device__ __forceinline__ float T_at(const float2* __restrict__ U, int x, int y, int W, int H)
+{   // T(c) = U_h(c) - U_h(c-ex) + U_v(c) - U_v(c-ey) ; 0 outside the image
+    if (x < 0 || x >= W || y < 0 || y >= H) return 0.0f;
+    const long i = (long)y * W + x;
+    const float2 u = U[i];
+    float t = u.x + u.y;
+    if (x > 0) t -= U[i - 1].x;
+    if (y > 0) t -= U[i - W].y;
+    return t;
+}
+
+// gather: MODE 0 = PCGInit1 (r = -J^T F, z = r, p_prev = 0, delta = 0, alphaN), MODE 1 = PCGStep1 (Ap, alphaD)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_gather(Geo g, Cam cm, const float* __restrict__ v, const float* __restrict__ D,
+                                                  const float4* __restrict__ G, const float2* __restrict__ U, const float* __restrict__ R,
+                                                  const unsigned char* __restrict__ fl, float* __restrict__ out, float* __restrict__ z,
+                                                  float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ part_out)
+{
+    __shared__ float red[16];
+    const long N = (long)g.W * g.H;
+    float acc = 0.0f;
+    FOR_EACH_PIXEL(g) {
+        const long i = (long)y * g.W + x;
+        const float vc = v[i];
+        float s = 0.0f;
+        if (fl[i] & 1) s += cm.wp * (cm.wp * (MODE == 0 ? vc - D[i] : vc));
+        s += G[i].x * T_at(U, x, y, g.W, g.H);
+        if (x + 1 < g.W) s += G[i + 1].y * T_at(U, x + 1, y, g.W, g.H);
+        if (y + 1 < g.H) s += G[i + g.W].z * T_at(U, x, y + 1, g.W, g.H);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* Rc = R + c * N;
+            const float lap = 4.0f * Rc[i] - at(Rc, x - 1, y, g.W, g.H) - at(Rc, x, y - 1, g.W, g.H) - at(Rc, x + 1, y, g.W, g.H) - at(Rc, x, y + 1, g.W, g.H);
+            s += cm.ws * (coef(cm, c, x, y) * lap);
+        }
+        if (MODE == 0) { const float r = -s; out[i] = r; z[i] = r; p_prev[i] = 0.0f; delta[i] = 0.0f; acc += r * r; }
+        else { out[i] = s; acc += vc * s; }
+    }
+    block_store_partial(acc, part_out, red);
+}
+
+// raw diag(J^T J) (LM only): enumerate the rows that contain X(i)
+__global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __restrict__ G, const float2* __restrict__ Wt,
+                                                const unsigned char* __restrict__ fl, float* __restrict__ diag)
+{
+    FOR_EACH_PIXEL(g) {
+        const long i = (long)y * g.W + x;
+        float d = (fl[i] & 1) ? cm.wp * cm.wp : 0.0f;
+        // shading rows at q with X(i) in their support: sh_h: q in {i, i+ex, i+ey, i-ex, i-ex+ey}; sh_v: q in {i, i+ex, i+ey, i-ey, i-ey+ex}
+        const int qx[7] = { 0, 1, 0, -1, -1, 0, 1 }, qy[7] = { 0, 0, 1, 0, 1, -1, -1 };
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int X0 = x + qx[k], Y0 = y + qy[k];
+            if (X0 < 1 || X0 + 1 >= g.W || Y0 < 1 || Y0 + 1 >= g.H) continue;      // row guard
+            const long q = (long)Y0 * g.W + X0;
+            const float2 w = Wt[q];
+            const float4 g0 = G[q], gx = G[q + 1], gy = G[q + g.W];
+            // coefficient of X(i) in sh_h(q) and sh_v(q); t = i - q
+            const int tx = -qx[k], ty = -qy[k];
+            float ch = 0.0f, cv = 0.0f;
+            if (tx == 0 && ty == 0) { ch = g0.x - gx.y; cv = g0.x - gy.z; }
+            else if (tx == -1 && ty == 0) { ch = g0.y; cv = g0.y; }
+            else if (tx == 0 && ty == -1) { ch = g0.z; cv = g0.z; }
+            else if (tx == 1 && ty == 0) { ch = -gx.x; }
+            else if (tx == 1 && ty == -1) { ch = -gx.z; }
+            else if (tx == 0 && ty == 1) { cv = -gy.x; }
+            else if (tx == -1 && ty == 1) { cv = -gy.y; }
+            ch *= w.x; cv *= w.y;
+            d += ch * ch + cv * cv;
+        }
+        // reg rows: q = i (coefficient 4 w_s coef_c(i)) and the four neighbours (-w_s coef_c(i))
+        float cc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float k = cm.ws * coef(cm, c, x, y); cc += k * k; }
+        float cnt = (fl[i] & 2) ? 16.0f : 0.0f;
+        if (x > 0 && (fl[i - 1] & 2)) cnt += 1.0f;
+        if (y > 0 && (fl[i - g.W] & 2)) cnt += 1.0f;
+        if (x + 1 < g.W && (fl[i + 1] & 2)) cnt += 1.0f;
+        if (y + 1 < g.H && (fl[i + g.W] & 2)) cnt += 1.0f;
+        diag[i] = d + cnt * cc;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* host_params: the 16 scalar parameters of the .t in Inputs{} order: w_p, w_s, w_g (squared weights), f_x, f_y, u_x, u_y, L_1..L_9 */
+static Cam cam_of(const float* hp)
+{
+    Cam c; c.wp = sqrtf(hp[0]); c.ws = sqrtf(hp[1]); c.wg = sqrtf(hp[2]); c.fx = hp[3]; c.fy = hp[4]; c.ux = hp[5]; c.uy = hp[6];
+    for (int k = 0; k < 9; ++k) c.L[k] = hp[7 + k];
+    return c;
+}
+
+int thallo_hip_sfs_precompute(int W, int H, const float* host_params, const float* X, const float* D, const float* Im,
+                              const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
+                              thallo_stream_t stream)
+{
+    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    hipLaunchKernelGGL(k_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
+                       (float4*)G, (float2*)Wt, fl);
+    return check_launch();
+}
+
+int thallo_hip_sfs_cost(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+                        const unsigned char* fl, float* cost_out, thallo_stream_t stream)
+{
+    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    hipLaunchKernelGGL(k_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), X, D, (const float4*)G, (const float2*)Wt, fl, cost_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_sfs_pcg_init(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+                            const unsigned char* fl, float* U, float* R, float* r, float* z, float* p_prev, float* delta,
+                            float* diag_out, float* aN_out, thallo_stream_t stream)
+{
+    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    const Cam cm = cam_of(host_params);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rows<true>, dim3(grid), dim3(BLOCK), 0, s, g, cm, X, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
+    hipLaunchKernelGGL(k_gather<0>, dim3(grid), dim3(BLOCK), 0, s, g, cm, X, D, (const float4*)G, (const float2*)U, (const float*)R, fl, r, z, p_prev, delta, aN_out);
+    if (diag_out) hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_sfs_apply_jtj(int W, int H, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                             float* U, float* R, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
+{
+    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    const Cam cm = cam_of(host_params);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rows<false>, dim3(grid), dim3(BLOCK), 0, s, g, cm, p, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
+    hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, s, g, cm, p, (const float*)nullptr, (const float4*)G, (const float2*)U, (const float*)R, fl,
+                       Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+}  // extern "C"

@@ -84,6 +84,7 @@ struct InputDecl { std::string name, kind, type; int index = -1; int channels = 
 
 int type_channels(const std::string& ty)
 {
+    if (ty == "uint8" || ty == "uchar" || ty == "bool") return 1;
     size_t i = ty.size(); while (i > 0 && isdigit((unsigned char)ty[i - 1])) --i;
     const std::string base = ty.substr(0, i), num = ty.substr(i);
     if (base != "float" && base != "thallo_float" && base != "double" && base != "uint8" && base != "uchar" && base != "int") return 0;
@@ -107,6 +108,7 @@ const Known KNOWN[] = {
     { "laplacian_graph", 2, "U1;A1;S0;S0;",                   "fit,reg",                        false },
     { "image_warping",   2, "U2;U1;A2;A2;A1;P1;P1;",          "fit,reg_nx,reg_ny,reg_px,reg_py", true },
     { "arap_mesh",       2, "P1;P1;U3;U3;A3;A3;S0;S0;",       "fit,reg",                        true },
+    { "shape_from_shading", 2, "P1;P1;P1;P1;P1;P1;P1;P1;P1;P1;P1;P1;P1;P1;P1;P1;U1;A1;A1;A1;A1;", "fit,reg,shading_h,shading_v", false },
     { "bundle_adjustment", 3, "U9;U3;A2;S0;S0;",               "snavely_reprojection_error",     true },
 };
 

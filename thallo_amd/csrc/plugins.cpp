@@ -281,6 +281,59 @@ public:
     }
 };
 
+// ------------------------------------------------------------------ examples/shape_from_shading/shape_from_shading.t
+class ShapeFromShadingPlugin : public EnergyPlugin {
+    int W, H;
+    std::vector<UnknownImage> imgs;
+    float hp[16];
+    float* X = nullptr; const float *D = nullptr, *Im = nullptr; const unsigned char *mR = nullptr, *mC = nullptr;
+    DeviceBuffer G, Wt, fl, U, R;
+    int precompute(LaunchCtx& c)
+    {
+        TimedLaunch t(c, "precompute");
+        return thallo_hip_sfs_precompute(W, H, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
+    }
+public:
+    ShapeFromShadingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1]) { imgs.push_back({ 16, (long)W * H }); }
+    const char* name() const override { return "shape_from_shading"; }
+    long n_unknowns() const override { return (long)W * H; }
+    const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
+    bool use_preconditioner() const override { return false; }            // no UsePreconditioner() in the .t
+    int bind(void** p) override
+    {
+        for (int k = 0; k < 16; ++k) { if (!p[k]) { set_error("shape_from_shading: null scalar parameter %d", k); return -1; } hp[k] = *(const float*)p[k]; }
+        X = (float*)p[16]; D = (const float*)p[17]; Im = (const float*)p[18]; mR = (const unsigned char*)p[19]; mC = (const unsigned char*)p[20];
+        if (!X || !D || !Im || !mR || !mC) { set_error("shape_from_shading: null image parameter"); return -1; }
+        const size_t N = (size_t)W * H;
+        if (!G.ptr && (G.alloc(16 * N + 64) || Wt.alloc(8 * N + 64) || fl.alloc(N + 256) || U.alloc(8 * N + 64) || R.alloc(12 * N + 64))) return -1;
+        return 0;
+    }
+    float* unknown_ptr(int) override { return X; }
+    int cost(LaunchCtx& c, float* out) override
+    {
+        int rc = precompute(c); if (rc < 0) return rc;
+        TimedLaunch t(c, "computeCost");
+        return thallo_hip_sfs_cost(W, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, out, c.stream);
+    }
+    int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
+    {
+        int rc = precompute(c); if (rc < 0) return rc;
+        TimedLaunch t(c, "PCGInit1");
+        return thallo_hip_sfs_pcg_init(W, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr,
+                                       v.r, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
+    }
+    int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_sfs_apply_jtj(W, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out, c.stream);
+    }
+    int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
+    {
+        { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
+        return apply_jtj(c, v.p[cur ^ 1], v.Ap, out);
+    }
+};
+
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims)
 {
     auto cst = [&](const char* k, double dflt) { auto it = spec.constants.find(k); return it == spec.constants.end() ? dflt : it->second; };
@@ -289,6 +342,7 @@ EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims)
     if (spec.energy == "laplacian_graph") return new LaplacianGraphPlugin(dims, (float)cst("w_fit", 0.5));
     if (spec.energy == "arap_mesh")       return new ArapPlugin(dims);
     if (spec.energy == "bundle_adjustment") return new BundleAdjustmentPlugin(dims);
+    if (spec.energy == "shape_from_shading") return new ShapeFromShadingPlugin(dims);
     set_error("no gfx950 plugin for energy '%s' (%s)", spec.energy.c_str(), spec.file.c_str());
     return nullptr;
 }

@@ -141,7 +141,7 @@ class HipSlabBackend:
             self.W, self.Hl, self.row0, self.row1, vp(self.offset.data_ptr()), vp(self.angle.data_ptr()), vp(self.urshape.data_ptr()),
             vp(self.constraints.data_ptr()), vp(self.mask.data_ptr()), fl(self.w_fit), fl(self.w_reg),
             vp(self.r.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.delta.data_ptr()),
-            vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_init")
+            vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), None, vp(self.parts.data_ptr()), self._st()), "iw_pcg_init")
 
     def step1(self, cur, first, iN, iD, iB, out_idx):
         vp, fl = C.c_void_p, C.c_float

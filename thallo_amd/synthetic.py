@@ -154,3 +154,89 @@ def bundle_adjustment(C=1723, P=156502, O=678718, seed=7, band=32, noise_px=1.0,
     pts0 = pts + pt_noise * rng.standard_normal(pts.shape)
     return [np.ascontiguousarray(cams0, np.float32), np.ascontiguousarray(pts0, np.float32), np.ascontiguousarray(obs, np.float32),
             np.ascontiguousarray(oToC, np.int32), np.ascontiguousarray(oToP, np.int32)]
+
+
+# ------------------------------------------------------------------ shape from shading
+SFS_LIGHTING = (0.6908, 0.0446, 0.0181, -0.1773, -0.0407, 0.1447, 0.0239, -0.2466, 0.0058)   # shipped default_* data set
+
+
+def _sfs_shift(a, dx, dy):
+    """b[y,x] = a[y+dy, x+dx], 0 outside (the reference's guarded loads)"""
+    out = np.zeros_like(a)
+    H, W = a.shape
+    ys = slice(max(0, -dy), min(H, H - dy)); xs = slice(max(0, -dx), min(W, W - dx))
+    yd = slice(max(0, dy), min(H, H + dy)); xd = slice(max(0, dx), min(W, W + dx))
+    out[ys, xs] = a[yd, xd]
+    return out
+
+
+def sfs_BI(X, D, Im, fx, fy, ux, uy, L):
+    """B_I image of shape_from_shading.t:44-80 in float64 (vectorised): shading minus smoothed intensity, 0 where invalid."""
+    X = X.astype(np.float64); H, W = X.shape
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    l, u = _sfs_shift(X, -1, 0), _sfs_shift(X, 0, -1)
+    nx = u * (X - l) / fy
+    ny = l * (X - u) / fx
+    nz = nx * (ux - xs) / fx + ny * (uy - ys) / fy - l * u / (fx * fy)
+    sq = nx * nx + ny * ny + nz * nz
+    inv = np.where(sq > 0, 1.0 / np.sqrt(np.where(sq > 0, sq, 1.0)), 1.0)
+    nx, ny, nz = inv * nx, inv * ny, inv * nz
+    B = (L[0] + L[1] * ny + L[2] * nz + L[3] * nx + L[4] * nx * ny + L[5] * ny * nz +
+         L[6] * (-nx * nx - ny * ny + 2 * nz * nz) + L[7] * nz * nx + L[8] * (nx * nx - ny * ny))
+    Imd = Im.astype(np.float64)
+    I = Imd * 0.5 + 0.25 * (_sfs_shift(Imd, -1, 0) + _sfs_shift(Imd, 0, -1))
+    Dd = D.astype(np.float64)
+    valid = (_sfs_shift(Dd, -1, 0) > 0) & (Dd > 0) & (_sfs_shift(Dd, 0, -1) > 0)
+    return np.where(valid, B - I, 0.0)
+
+
+def sfs_residuals(params):
+    """All residuals of shape_from_shading.t in float64, shape [H, W, 6] = fit, shading_h, shading_v, reg xyz."""
+    wp, ws, wg = (np.sqrt(float(params[k])) for k in range(3))
+    fx, fy, ux, uy = (float(params[k]) for k in range(3, 7))
+    L = [float(params[k]) for k in range(7, 16)]
+    X, D, Im, mR, mC = (np.asarray(params[k]) for k in range(16, 21))
+    Xd, Dd = X.astype(np.float64), D.astype(np.float64)
+    H, W = X.shape
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    out = np.zeros((H, W, 6))
+    out[..., 0] = np.where(Dd > 0, wp * (Xd - Dd), 0.0)
+    BI = sfs_BI(X, D, Im, fx, fy, ux, uy, L)
+    inner = (xs >= 1) & (xs <= W - 2) & (ys >= 1) & (ys <= H - 2)
+    out[..., 1] = np.where(inner, wg * (BI - _sfs_shift(BI, 1, 0)) * mR, 0.0)
+    out[..., 2] = np.where(inner, wg * (BI - _sfs_shift(BI, 0, 1)) * mC, 0.0)
+    valid = Dd > 0
+    acc = [4 * ((xs - ux) / fx) * Xd, 4 * ((ys - uy) / fy) * Xd, 4 * Xd]
+    for dx, dy in ((-1, 0), (0, -1), (1, 0), (0, 1)):
+        Xn, Dn = _sfs_shift(Xd, dx, dy), _sfs_shift(Dd, dx, dy)
+        valid &= (Dn > 0) & (np.abs(X.astype(np.float32) - _sfs_shift(X.astype(np.float32), dx, dy)) < np.float32(0.01))
+        acc[0] -= ((xs + dx - ux) / fx) * Xn; acc[1] -= ((ys + dy - uy) / fy) * Xn; acc[2] -= Xn
+    for c in range(3):
+        out[..., 3 + c] = np.where(valid, ws * acc[c], 0.0)
+    return out
+
+
+def shape_from_shading(W, H, seed=21, w_p=100.0, w_s=100.0, w_g=1.0, noise=5e-4, hole=True):
+    """Synthetic SFS instance shaped like the shipped 640x480 data set (examples/shape_from_shading/src/SFSSolverInput.h:20-44):
+    a smooth depth map (metres) with a small invalid region, intensity rendered from it with the shipped SH lighting,
+    random 0/1 edge masks, unknown initialised to the noisy depth.  Returns params indexed like the .t Inputs{} (0..20)."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 574.05 * W / 640.0
+    ux, uy = W / 2.0, H / 2.0
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    a = min(0.12, 0.002 * min(W, H) / (2 * np.pi))            # keeps |dX| per pixel well under the 0.01 m continuity gate
+    depth = 1.0 + a * np.sin(2 * np.pi * xs / W) * np.cos(2 * np.pi * ys / H) + 0.3 * a * np.cos(4 * np.pi * xs / W + 1.0)
+    D = depth.copy()
+    if hole and min(W, H) >= 12:
+        rr = (xs - 0.7 * W) ** 2 + (ys - 0.3 * H) ** 2
+        D[rr < (0.06 * min(W, H)) ** 2] = 0.0
+    L = SFS_LIGHTING
+    # intensity of the true surface: B with I = 0, smoothing undone approximately by using B itself
+    BI0 = sfs_BI(depth, np.ones_like(depth), np.zeros_like(depth), fx, fy, ux, uy, L)
+    Im = np.clip(BI0 + 0.01 * rng.standard_normal((H, W)), 0.0, 2.0)
+    X0 = np.where(D > 0, depth + noise * rng.standard_normal((H, W)), depth)
+    mR = (rng.random((H, W)) < 0.9).astype(np.uint8)
+    mC = (rng.random((H, W)) < 0.9).astype(np.uint8)
+    f32 = lambda v: np.ascontiguousarray(v, np.float32)
+    return [float(w_p), float(w_s), float(w_g), float(fx), float(fy), float(ux), float(uy)] + [float(v) for v in L] + \
+           [f32(X0), f32(D), f32(Im), np.ascontiguousarray(mR), np.ascontiguousarray(mC)]

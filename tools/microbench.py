@@ -27,7 +27,7 @@ vp, fl = C.c_void_p, C.c_float
 PB = parts.data_ptr()
 nb0 = L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                                vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
-                               vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), vp(PB), None)
+                               vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(PB), None)
 s_aN = api.SumT(PB, nb0)
 
 

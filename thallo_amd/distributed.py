@@ -192,19 +192,20 @@ class HipSlabBackend:
 class SlabSolver:
     """Gauss-Newton + PCG over row slabs; replicated host logic, rank-ordered sums (gauss_newton.t:1545-1785)."""
 
-    def __init__(self, backend, layout, group=None):
+    def __init__(self, backend, layout, group=None, force_collectives=False):
         self.be, self.lay, self.group = backend, layout, group
         self.world = layout.world
+        self.use_dist = self.world > 1 or force_collectives     # force: issue the collectives even at world size 1 (probes)
 
     # -- collectives
     def _allreduce(self, idx):
-        if self.world > 1:
+        if self.use_dist:
             dist.all_reduce(self.be.S[idx:idx + 1], group=self.group)
 
     def _gather_sum_and_rows(self, out_idx):
         be = self.be
         be.pack()
-        if self.world > 1:
+        if self.use_dist:
             dist.all_gather_into_tensor(be.gath, be.send, group=self.group)
             be.unpack(out_idx, be.gath)
         else:
@@ -212,7 +213,7 @@ class SlabSolver:
 
     def _exchange_unknown_ghosts(self):
         """once per GN step: ghost rows of Offset/Angle <- neighbours' boundary rows"""
-        if self.world == 1:
+        if not self.use_dist:
             return
         be, lay = self.be, self.lay
         W = be.W
@@ -260,6 +261,40 @@ class SlabSolver:
             costs.append(self.cost())
         return costs
 
+    # -- hipGraph replay of a whole GN step (kernels + RCCL collectives): removes ~100 us of host work per PCG
+    #    iteration, which at 4-8 ranks is several times the kernels' own time
+    def capture_gn_step(self, l_iters):
+        """Capture gn_step(l_iters) into a CUDA/HIP graph.  Returns True on success; on any failure the solver stays
+        in eager mode.  All ranks must call this together (the capture contains collectives)."""
+        self._graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.gn_step(l_iters)                   # warm-up on the side stream (allocations, RCCL channel setup)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self.gn_step(l_iters)
+            torch.cuda.synchronize()
+            self._graph, self._graph_l = g, l_iters
+            return True
+        except Exception as e:      # noqa: BLE001 - any capture problem means: stay eager
+            self._graph = None
+            self._graph_error = repr(e)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            return False
+
+    def gn_step_fast(self, l_iters):
+        if getattr(self, "_graph", None) is not None and self._graph_l == l_iters:
+            self._graph.replay()
+        else:
+            self.gn_step(l_iters)
+
 
 def make_hip_solver(params_global, W, H, rank, world, max_l_iters):
     lay = SlabLayout(H, rank, world)
@@ -272,14 +307,24 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     """bench.py's N>1 leg: K timed GN steps between barriers, MAX over ranks, rank 0 reports."""
     solver, lay = make_hip_solver(params_global, W, H, rank, world, l_iters)
     c0 = solver.cost()
+    # graph replay of the GN step is opt-out (THALLO_DIST_GRAPH=0); every rank must agree, so the outcome is all-reduced
+    use_graph = os.environ.get("THALLO_DIST_GRAPH", "1") != "0"
+    captured = False
+    if use_graph:
+        ok = solver.capture_gn_step(l_iters)            # runs one warm-up + one captured step
+        flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        captured = bool(flag.item() > 0.5)
+        if not captured:
+            solver._graph = None
     for _ in range(warmup):
-        solver.gn_step(l_iters)
+        solver.gn_step_fast(l_iters)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        solver.gn_step(l_iters)
+        solver.gn_step_fast(l_iters)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -296,6 +341,6 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
                    "width": W, "height": H, "unknowns": 3 * npx, "l_iterations": l_iters,
                    "parallelism": f"{world} row slabs, RCCL all-reduce(alphaD) + all-gather(betaN, z ghost rows) per PCG iteration"},
         "ms_per_gn_iter": dt / steps * 1e3, "us_per_pcg_iter": dt / (steps * l_iters) * 1e6,
-        "initial_cost": c0, "final_cost": final,
+        "initial_cost": c0, "final_cost": final, "graph_replay": captured,
         "roofline": None, "cpu_baseline": None,
     }

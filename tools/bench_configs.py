@@ -1,0 +1,46 @@
+"""Secondary configs of BASELINE.json (not the headline bench): ms per GN iteration / PCG it/s on one MI355X for
+image_warping 512^2, ARAP 102,400 vertices, shape_from_shading 2048^2, bundle adjustment ladybug-1723 shape.
+Prints one JSON object; kernel means from the library's sampled HIP events."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import thallo_amd
+from thallo_amd import synthetic as syn
+
+
+def run(name, fname, dims, params, nit, lit, warm=1):
+    dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in params]
+    s = thallo_amd.ThalloSolver(dims, thallo_amd.energy_file(fname))
+    s.set_solver_parameters(nIterations=nit + warm, lIterations=lit)
+    prm = s.make_params(dev)
+    s.init(prm)
+    c0 = s.current_cost()
+    for _ in range(warm):
+        s.step(prm)
+    torch.cuda.synchronize()
+    s.reset_kernel_stats(); s.set_kernel_sampling(4)
+    t0 = time.perf_counter()
+    for _ in range(nit):
+        s.step(prm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s.set_kernel_sampling(0)
+    ks = {k: round(v["mean_ms"] * 1e3, 2) for k, v in s.kernel_stats().items() if v["mean_ms"]}
+    return {"config": name, "ms_per_gn_iter": dt / nit * 1e3, "pcg_iters_per_sec": nit * lit / dt, "us_per_pcg_iter": dt / (nit * lit) * 1e6,
+            "cost0": c0, "cost": s.current_cost(), "kernel_mean_us": ks}
+
+
+out = []
+out.append(run("image_warping 512x512 GN 8x100", "image_warping", (512, 512), syn.image_warping(512, 512), 8, 100))
+p = syn.arap_mesh(320, 320)
+out.append(run("arap_mesh 102400 v / 614400 e GN 20x100", "arap_mesh_deformation", (p[2].shape[0], p[6].shape[0]), p, 5, 100))
+out.append(run("shape_from_shading 2048x2048 GN x10", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 6, 10))
+p = syn.bundle_adjustment()
+out.append(run("bundle_adjustment C=1723 P=156502 O=678718 GN x150", "bundle_adjustment", (p[0].shape[0], p[1].shape[0], p[2].shape[0]), p, 3, 150))
+print(json.dumps(out, indent=1))

@@ -55,14 +55,15 @@ def standalone_applyjtj(torch, W, H, p_np, reps=50):
     cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda")
     flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
     parts = torch.zeros(4 * 1024, dtype=torch.float32, device="cuda")
+    irregular = torch.zeros(16, dtype=torch.int32, device="cuda")
     vp, fl = C.c_void_p, C.c_float
     L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                              vp(dev[4].data_ptr()), fl(p_np[5]), fl(p_np[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
-                             vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(parts.data_ptr()), None)
+                             vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(irregular.data_ptr()), vp(parts.data_ptr()), None)
 
     def launch():
         return L.thallo_hip_iw_apply_jtj(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p_np[5]), fl(p_np[6]),
-                                         vp(z.data_ptr()), vp(Ap.data_ptr()), vp(parts.data_ptr() + 4096), None)
+                                         vp(z.data_ptr()), vp(Ap.data_ptr()), vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), None)
     for _ in range(5):
         assert launch() > 0
     torch.cuda.synchronize()

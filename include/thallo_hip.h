@@ -161,19 +161,23 @@ int thallo_hip_lapimg_pcg_step1(int W, int H, float w_fit, int xguard,
  * produce outputs for the owned rows [row0,row1) only (row0=0,row1=H for a whole image) and read the
  * ghost rows as stencil halo.  pcg_init also fills cs/flags (and p_prev=0) on ghost rows; the fused
  * pcg_step1 also keeps p current on ghost rows (p = z + beta p), so per PCG iteration only the ghost
- * rows of z have to be refreshed from the neighbouring slab. */
+ * rows of z have to be refreshed from the neighbouring slab.
+ * `irregular` (device int, may be NULL): pcg_init stores the number of pixels whose right/down UrShape neighbours are
+ * NOT at exact unit offsets; when it is 0 (UrShape = the pixel grid, which is what the reference's harness always
+ * passes: CombinedSolver.h:158-176) pcg_step1 / apply_jtj skip the UrShape plane (-8 B/pixel); the bits of the
+ * result are the same either way. */
 int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
                        float* cost_out, thallo_stream_t stream);
 int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                            const float* constraints, const float* mask, float w_fit, float w_reg,
                            float* r, float* pre, float* z, float* p_prev, float* delta,
-                           float* cs, unsigned char* flags, float* diag_out, float* alphaN_out, thallo_stream_t stream);
+                           float* cs, unsigned char* flags, float* diag_out, int* irregular_out, float* alphaN_out, thallo_stream_t stream);
 int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
                             int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
-                            float* alphaD_out, thallo_stream_t stream);
+                            const int* irregular, float* alphaD_out, thallo_stream_t stream);
 
 /* ---------------------------------------------------------------- graph-edge domains
  * Incidence lists built by the host from the Sparse maps V0/V1 (device int32 arrays, thallo.t:136) once per
@@ -249,7 +253,7 @@ int thallo_hip_sfs_apply_jtj(int W, int H, const float* host_params, const float
  * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's
  * stand-alone applyJTJ roofline measurement. */
 int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
-                            float w_fit, float w_reg, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+                            float w_fit, float w_reg, const float* p, float* Ap, const int* irregular, float* alphaD_out, thallo_stream_t stream);
 
 #ifdef __cplusplus
 }

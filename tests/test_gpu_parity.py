@@ -135,10 +135,11 @@ def test_shim_image_warping_init_and_apply(torch, orc, W, H):
     r, pre, z, p0, p1, delta, Ap = f(), f(), f(), f(), f(), f(), f()
     cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
     parts = torch.zeros(4 * 1024, dtype=torch.float32, device="cuda")
+    irregular = torch.zeros(16, dtype=torch.int32, device="cuda")
     vp = C.c_void_p; fl = C.c_float
     nb = L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                                   vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
-                                  vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(parts.data_ptr()), None)
+                                  vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(irregular.data_ptr()), vp(parts.data_ptr()), None)
     assert nb > 0
     torch.cuda.synchronize()
     r_g = to_host(r)[:n]; pre_g = to_host(pre)[:n]
@@ -155,7 +156,7 @@ def test_shim_image_warping_init_and_apply(torch, orc, W, H):
     s0 = api.SumT(parts.data_ptr(), 1)
     nb2 = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                     vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
-                                    1, s0, s0, s0, vp(parts.data_ptr() + 4096), None)
+                                    1, s0, s0, s0, vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), None)
     assert nb2 > 0
     torch.cuda.synchronize()
     Ap_o, d_o = pr.apply_jtj(v)
@@ -178,10 +179,11 @@ def test_full_size_properties_2048(torch):
     r, pre, z, p0, p1, delta, Ap1, Ap2, Ap3 = [f() for _ in range(9)]
     cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
     parts = torch.zeros(8 * 1024, dtype=torch.float32, device="cuda")
+    irregular = torch.zeros(16, dtype=torch.int32, device="cuda")
     vp = C.c_void_p; fl = C.c_float
     L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                              vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
-                             vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(parts.data_ptr()), None)
+                             vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(irregular.data_ptr()), vp(parts.data_ptr()), None)
     active = (flags[:N] & 1).bool()
     act3 = torch.cat([active.repeat_interleave(2), active])
     g = torch.Generator(device="cuda"); g.manual_seed(7)
@@ -192,7 +194,7 @@ def test_full_size_properties_2048(torch):
     def apply(vec, out):
         nb = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                        vp(vec.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(out.data_ptr()),
-                                       1, s0, s0, s0, vp(parts.data_ptr() + 4096), None)
+                                       1, s0, s0, s0, vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), None)
         assert nb > 0
         torch.cuda.synchronize()
         return parts[1024:1024 + nb].double().sum().item()
@@ -420,3 +422,21 @@ def test_shape_from_shading_2048_properties(torch):
         outs.append((list(costs), dev[16].clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0][-1] < outs[0][0][0]
+
+
+def test_image_warping_irregular_urshape_uses_general_path(torch, orc):
+    """A rest shape that is NOT the pixel grid: the kernels must fall back to loading UrShape (and still match)."""
+    W, H = 96, 64
+    p = syn.image_warping(W, H, n_markers=8)
+    rng = np.random.default_rng(5)
+    p[2] = (p[2] + 0.2 * rng.uniform(-1, 1, p[2].shape)).astype(np.float32)
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=4, lIterations=40)
+    s, dev, costs, final = _solve_gpu("image_warping", (W, H), p, nIterations=4, lIterations=40)
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)
+    # one perturbed pixel is enough to leave the fast path
+    p2 = syn.image_warping(W, H, n_markers=8); p2[2][H // 2, W // 2, 0] += 0.5
+    po2 = copy_params(p2)
+    co2, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po2).solve(nIterations=3, lIterations=30)
+    _, _, costs2, _ = _solve_gpu("image_warping", (W, H), p2, nIterations=3, lIterations=30)
+    assert rel_err(costs2, co2) < COST_RTOL

@@ -81,9 +81,9 @@ def lib():
     L.thallo_hip_vector_elems.argtypes = [cl]; L.thallo_hip_vector_elems.restype = cl
     L.thallo_hip_finish_sum.argtypes = [SumT, vp, vp]
     L.thallo_hip_iw_cost.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp]
-    L.thallo_hip_iw_pcg_init.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, vp, vp]
-    L.thallo_hip_iw_apply_jtj.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp]
+    L.thallo_hip_iw_pcg_init.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, vp, vp, vp]
+    L.thallo_hip_iw_apply_jtj.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp]
     L.thallo_hip_pcg_step2.argtypes = [vp, vp, vp, vp, cl, SumT, SumT, vp, vp]
     L.thallo_hip_pcg_step2_ranges.argtypes = [vp, vp, vp, vp, cl, cl, cl, cl, SumT, SumT, vp, vp]
     L.thallo_hip_linear_update.argtypes = [vp, vp, vp, cl, SumT, SumT, vp]

@@ -63,6 +63,7 @@ inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuc
 // tools/microbench.py hooks (not product API): diagnostic mode 1 = skip arithmetic, 2 = skip loads;
 // cache-policy bits for PCGStep1: 1 delta nt, 2 cs/UrShape/flags nt, 4 p_in nt, 8 Ap nt, 32 z nt, 64 p_out nt
 int g_iw_debug = 0;
+int g_no_grid = 0;      // microbench: 1 = ignore the regular-grid fast path
 int g_nt_mask = 1;      // delta non-temporal: measured +1-3 % PCG it/s at 2048^2 (tools/sweep_nt.sh)
 
 struct Tile {
@@ -78,19 +79,20 @@ struct Owned { float2 zv, pv, dv, csv, uv; float zav, pav, da; unsigned char ff;
 struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
 
 // ------------------------------------------------------------------------------------------ PCGStep1
-template <bool FUSED, int MINW>
-__global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
-                                                        const unsigned char* __restrict__ flags, float wf2, float wr2,
-                                                        const float* __restrict__ z, const float* __restrict__ p_in,
-                                                        float* __restrict__ p_out, float* __restrict__ delta,
-                                                        float* __restrict__ Ap, int first,
-                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                                                        float* __restrict__ aD_out, int dbg)
+// GRID = UrShape is the unit pixel grid (what the reference's harness always passes, CombinedSolver.h:158-176):
+// u_i - u_j is then exactly -(dx,dy), so the UrShape plane is neither loaded nor staged (-8 B/pixel, -2 LDS planes).
+// pcg_init verifies the property bit-exactly on the device every GN step; both paths give identical bits.
+template <bool FUSED, bool GRID>
+__device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, const float2* __restrict__ cs, const float2* __restrict__ ur,
+                                           const unsigned char* __restrict__ flags, float wf2, float wr2,
+                                           const float* __restrict__ z, const float* __restrict__ p_in,
+                                           float* __restrict__ p_out, float* __restrict__ delta,
+                                           float* __restrict__ Ap, int first,
+                                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
+                                           float* __restrict__ aD_out, int dbg)
 {
     const int ntm = dbg >> 8; dbg &= 0xff;
     const bool nt_delta = ntm & 1, nt_const = ntm & 2, nt_pin = ntm & 4, nt_ap = ntm & 8, nt_z = ntm & 32, nt_pout = ntm & 64;
-    __shared__ Tile T;
-    __shared__ float red[16];
     const long N = (long)g.W * g.H;
     const float2* __restrict__ zo = reinterpret_cast<const float2*>(z);
     const float2* __restrict__ po = reinterpret_cast<const float2*>(p_in);
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __re
             if (ow_ld[k]) {
                 const long pix = (long)gy * g.W + gx;
                 ow[k].pv = ldf2(po + pix, nt_pin); ow[k].pav = ldf(pa + pix, nt_pin);
-                ow[k].csv = ldf2(cs + pix, nt_const); ow[k].uv = ldf2(ur + pix, nt_const); ow[k].ff = ldb(flags + pix, nt_const);
+                ow[k].csv = ldf2(cs + pix, nt_const); ow[k].ff = ldb(flags + pix, nt_const);
+                if (!GRID) ow[k].uv = ldf2(ur + pix, nt_const);
                 if (FUSED) {
                     ow[k].zv = ldf2(zo + pix, nt_z); ow[k].zav = ldf(za + pix, nt_z);
                     if (!first && ow_in[k]) { ow[k].dv = ldf2(dlo + pix, nt_delta); ow[k].da = ldf(dla + pix, nt_delta); }
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __re
             hl_in = (dbg != 2) && hx >= 0 && hx < g.W && hy >= 0 && hy < g.H;
             if (hl_in) {
                 const long pix = (long)hy * g.W + hx;
-                hl.pv = po[pix]; hl.pav = pa[pix]; hl.csv = cs[pix]; hl.uv = ur[pix]; hl.ff = flags[pix];
+                hl.pv = po[pix]; hl.pav = pa[pix]; hl.csv = cs[pix]; hl.ff = flags[pix];
+                if (!GRID) hl.uv = ur[pix];
                 if (FUSED) { hl.zv = zo[pix]; hl.zav = za[pix]; }
             }
         }
@@ -176,9 +180,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __re
                         stf(dla + pix, ow[k].da + alpha * ow[k].pav, nt_delta);
                     }
                 } else { npx = ow[k].pv.x; npy = ow[k].pv.y; npa = ow[k].pav; }
-                c1 = ow[k].csv.x; s1 = ow[k].csv.y; u1 = ow[k].uv.x; u2 = ow[k].uv.y; ff = ow[k].ff;
+                c1 = ow[k].csv.x; s1 = ow[k].csv.y; ff = ow[k].ff;
+                if (!GRID) { u1 = ow[k].uv.x; u2 = ow[k].uv.y; }
             }
-            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.ux[i] = u1; T.uy[i] = u2; T.f[i] = ff;
+            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.f[i] = ff;
+            if (!GRID) { T.ux[i] = u1; T.uy[i] = u2; }
             cpx[k] = npx; cpy[k] = npy; cpa[k] = npa; cc[k] = c1; cs_[k] = s1; cux[k] = u1; cuy[k] = u2; cf[k] = ff;
         }
         if (has_halo) {
@@ -194,9 +200,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __re
                         qo[pix] = make_float2(npx, npy); qa[pix] = npa;
                     }
                 } else { npx = hl.pv.x; npy = hl.pv.y; npa = hl.pav; }
-                c1 = hl.csv.x; s1 = hl.csv.y; u1 = hl.uv.x; u2 = hl.uv.y; ff = hl.ff;
+                c1 = hl.csv.x; s1 = hl.csv.y; ff = hl.ff;
+                if (!GRID) { u1 = hl.uv.x; u2 = hl.uv.y; }
             }
-            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.ux[i] = u1; T.uy[i] = u2; T.f[i] = ff;
+            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1; T.f[i] = ff;
+            if (!GRID) { T.ux[i] = u1; T.uy[i] = u2; }
         }
         lds_barrier();
         // ---- prefetch the next tile while this one is computed
@@ -218,7 +226,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __re
                     for (int d = 0; d < 4; ++d) {
                         const int j = nb[d];
                         if (T.f[j] & 1) {
-                            const float dux = uxi - T.ux[j], duy = uyi - T.uy[j];
+                            float dux, duy;
+                            if (GRID) { dux = d == 0 ? -1.0f : d == 1 ? 1.0f : 0.0f; duy = d == 2 ? -1.0f : d == 3 ? 1.0f : 0.0f; }
+                            else { dux = uxi - T.ux[j]; duy = uyi - T.uy[j]; }
                             const float gix = -si * dux - ci * duy, giy = ci * dux - si * duy;
                             const float cj = T.c[j], sj = T.s[j], paj = T.pa[j];
                             const float gjx = sj * dux + cj * duy, gjy = -cj * dux + sj * duy;
@@ -241,6 +251,23 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __re
     block_store_partial(acc, aD_out, red);
 }
 
+template <bool FUSED, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
+                                                        const unsigned char* __restrict__ flags, float wf2, float wr2,
+                                                        const float* __restrict__ z, const float* __restrict__ p_in,
+                                                        float* __restrict__ p_out, float* __restrict__ delta,
+                                                        float* __restrict__ Ap, int first,
+                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
+                                                        float* __restrict__ aD_out, int dbg, const int* __restrict__ irregular)
+{
+    __shared__ Tile T;
+    __shared__ float red[16];
+    // `irregular` = number of pixels whose UrShape neighbours are not at unit offsets (written by pcg_init); wave-uniform
+    const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
+    if (grid) step1_body<FUSED, true>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
+    else      step1_body<FUSED, false>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
+}
+
 // ------------------------------------------------------------------------------------------ PCGInit1 (+_Finish)
 // Once per GN iteration: evalJTF in gather form, guardedInvert, z = M^-1 r, p_prev = 0, delta = 0, the
 // (cos,sin) and validity planes, alphaN partials.  Not pipelined (1 % of a GN iteration).
@@ -250,13 +277,14 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
                                                 float* __restrict__ r, float* __restrict__ pre, float* __restrict__ z,
                                                 float* __restrict__ p_prev, float* __restrict__ delta,
                                                 float2* __restrict__ cs, unsigned char* __restrict__ flags,
-                                                float* __restrict__ diag_out, float* __restrict__ aN_out)
+                                                float* __restrict__ diag_out, int* __restrict__ irregular, float* __restrict__ aN_out)
 {
     __shared__ Tile T;
     __shared__ float red[16];
     const long N = (long)g.W * g.H;
     const float wr2 = wr * wr, wf2 = wf * wf;
     float acc = 0.0f;
+    int bad = 0;
     for (TileSweep t(g.ntiles); t.valid(); t.next()) {
         const int x0 = (t.cur % g.tx) * TW, y0 = g.row0 + (t.cur / g.tx) * TH;
         for (int idx = threadIdx.x; idx < LN; idx += BLOCK) {
@@ -287,6 +315,9 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
             if (gx < g.W && gy < g.row1) {
                 const long pix = (long)gy * g.W + gx;
                 const unsigned char act = T.f[i] & 1;
+                // is UrShape the unit pixel grid here?  (right and down neighbour inside the local image)
+                if (gx + 1 < g.W && (T.ux[i + 1] - T.ux[i] != 1.0f || T.uy[i + 1] - T.uy[i] != 0.0f)) bad = 1;
+                if (gy + 1 < g.H && (T.ux[i + LW] - T.ux[i] != 0.0f || T.uy[i + LW] - T.uy[i] != 1.0f)) bad = 1;
                 float rx = 0.f, ry = 0.f, ra = 0.f, mx = 0.f, my = 0.f, ma = 0.f, dgo_raw = 0.f, dga_raw = 0.f;
                 unsigned char fl = act;
                 if (act) {
@@ -335,6 +366,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
         }
         __syncthreads();
     }
+    if (irregular && __any(bad) && (threadIdx.x & 63) == 0) atomicAdd(irregular, 1);     // int atomic: exact, order-free
     block_store_partial(acc, aN_out, red);
 }
 
@@ -387,7 +419,7 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int row0, int row1
 
 extern "C" {
 
-void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; }
+void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; }
 
 int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
@@ -405,13 +437,14 @@ int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, co
 int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                            const float* constraints, const float* mask, float w_fit, float w_reg,
                            float* r, float* pre, float* z, float* p_prev, float* delta,
-                           float* cs, unsigned char* flags, float* diag_out, float* aN_out, thallo_stream_t stream)
+                           float* cs, unsigned char* flags, float* diag_out, int* irregular_out, float* aN_out, thallo_stream_t stream)
 {
     if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 4);
+    if (irregular_out && hipMemsetAsync(irregular_out, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)offset, angle, (const float2*)urshape, (const float2*)constraints, mask, w_fit, w_reg,
-                       r, pre, z, p_prev, delta, (float2*)cs, flags, diag_out, aN_out);
+                       r, pre, z, p_prev, delta, (float2*)cs, flags, diag_out, irregular_out, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -419,18 +452,18 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
                             int first, thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                            float* aD_out, thallo_stream_t stream)
+                            const int* irregular, float* aD_out, thallo_stream_t stream)
 {
     if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 3);      // 150 VGPRs -> 3 workgroups per CU
     hipLaunchKernelGGL((k_step1<true, 3>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                       z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8));
+                       z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular);
     int e = check_launch(); return e ? e : grid;
 }
 
 int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
-                            float w_fit, float w_reg, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
+                            float w_fit, float w_reg, const float* p, float* Ap, const int* irregular, float* aD_out, thallo_stream_t stream)
 {
     if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 4);
@@ -438,7 +471,7 @@ int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, c
     /* z / p_out / delta are unused when !FUSED: pass valid dummies */
     hipLaunchKernelGGL((k_step1<false, 4>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                       p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug);
+                       p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug, g_no_grid ? nullptr : irregular);
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -49,7 +49,7 @@ class ImageWarpingPlugin : public EnergyPlugin {
     float *offset = nullptr, *angle = nullptr;
     const float *urshape = nullptr, *constraints = nullptr, *mask = nullptr;
     float w_fit = 0, w_reg = 0;
-    DeviceBuffer cs, flags;     // per-GN-iteration planes: (cos,sin) float2 and validity bits
+    DeviceBuffer cs, flags, irregular;     // per-GN-iteration planes: (cos,sin) float2, validity bits; UrShape-is-grid word
 public:
     ImageWarpingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1])
     {
@@ -67,7 +67,7 @@ public:
         if (!offset || !angle || !urshape || !constraints || !mask || !p[5] || !p[6]) { set_error("image_warping: null problem parameter"); return -1; }
         w_fit = *(const float*)p[5]; w_reg = *(const float*)p[6];       // host scalars, re-read every Init/Step
         const long N = (long)W * H;
-        if (!cs.ptr) { if (cs.alloc(N * 8)) return -1; if (flags.alloc((N + 255) / 256 * 256)) return -1; }
+        if (!cs.ptr) { if (cs.alloc(N * 8)) return -1; if (flags.alloc((N + 255) / 256 * 256)) return -1; if (irregular.alloc(64)) return -1; }
         return 0;
     }
     float* unknown_ptr(int k) override { return k == 0 ? offset : angle; }
@@ -77,18 +77,18 @@ public:
     {
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_iw_pcg_init(W, H, 0, H, offset, angle, urshape, constraints, mask, w_fit, w_reg,
-                                      v.r, v.pre, v.z, v.p[cur], v.delta, (float*)cs.ptr, (unsigned char*)flags.ptr, v.diag, aN, c.stream);
+                                      v.r, v.pre, v.z, v.p[cur], v.delta, (float*)cs.ptr, (unsigned char*)flags.ptr, v.diag, (int*)irregular.ptr, aN, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_iw_apply_jtj(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg, p, Ap, out, c.stream);
+        return thallo_hip_iw_apply_jtj(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg, p, Ap, (const int*)irregular.ptr, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_iw_pcg_step1(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
-                                       v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, out, c.stream);
+                                       v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, (const int*)irregular.ptr, out, c.stream);
     }
 };
 

@@ -98,6 +98,7 @@ class HipSlabBackend:
         self.p = [z(), z()]
         self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
+        self.irregular = torch.zeros(16, dtype=torch.int32, device=dev)      # UrShape-is-the-pixel-grid word (written by pcg_init)
         self.parts = torch.zeros(1024, dtype=torch.float32, device=dev)      # local partials of the current reduction
         self.nb = 1
         self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32, device=dev)    # global (all-reduced) scalars
@@ -141,7 +142,7 @@ class HipSlabBackend:
             self.W, self.Hl, self.row0, self.row1, vp(self.offset.data_ptr()), vp(self.angle.data_ptr()), vp(self.urshape.data_ptr()),
             vp(self.constraints.data_ptr()), vp(self.mask.data_ptr()), fl(self.w_fit), fl(self.w_reg),
             vp(self.r.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.delta.data_ptr()),
-            vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), None, vp(self.parts.data_ptr()), self._st()), "iw_pcg_init")
+            vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), None, vp(self.irregular.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_init")
 
     def step1(self, cur, first, iN, iD, iB, out_idx):
         vp, fl = C.c_void_p, C.c_float
@@ -149,7 +150,7 @@ class HipSlabBackend:
             self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
             fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
             vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), 1 if first else 0, self._sum(iN), self._sum(iD), self._sum(iB),
-            vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
+            vp(self.irregular.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
         self._chk(self.L.thallo_hip_finish_sum(self._local(), vp(self.S.data_ptr() + 4 * out_idx), self._st()), "finish_sum")
 
     def step2(self, iN, iD):

@@ -23,11 +23,12 @@ f = lambda: torch.zeros(na, dtype=torch.float32, device="cuda")
 r, pre, z, p0, p1, delta, Ap = [f() for _ in range(7)]
 cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
 parts = torch.zeros(16 * 1024, dtype=torch.float32, device="cuda")
+irregular = torch.zeros(16, dtype=torch.int32, device="cuda")
 vp, fl = C.c_void_p, C.c_float
 PB = parts.data_ptr()
 nb0 = L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
                                vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
-                               vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(PB), None)
+                               vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(irregular.data_ptr()), vp(PB), None)
 s_aN = api.SumT(PB, nb0)
 
 
@@ -46,14 +47,14 @@ def timeit(fn, reps=REPS):
 def step1_fused(first=0):
     nb = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                    vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
-                                   first, s_aN, s_aN, s_aN, vp(PB + 4096), None)
+                                   first, s_aN, s_aN, s_aN, vp(irregular.data_ptr()), vp(PB + 4096), None)
     assert nb > 0
     return nb
 
 
 def step1_plain():
     nb = L.thallo_hip_iw_apply_jtj(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
-                                   vp(z.data_ptr()), vp(Ap.data_ptr()), vp(PB + 4096), None)
+                                   vp(z.data_ptr()), vp(Ap.data_ptr()), vp(irregular.data_ptr()), vp(PB + 4096), None)
     assert nb > 0
     return nb
 
@@ -68,13 +69,13 @@ def step2():
 
 res = {}
 MB = 1e-6
-for var, shape in ((0, 0), (2, 0), (2, 1), (2, 2), (2, 3)):
-    L.thallo_hip_debug_set(1, var); L.thallo_hip_debug_set(2, shape)
+for nogrid in (0, 1):
+    L.thallo_hip_debug_set(4, nogrid)
     for mode in (0, 1):
         L.thallo_hip_debug_set(0, mode)
-        res[f"v{var}s{shape}_fused_dbg{mode}_us"] = round(timeit(step1_fused), 2)
-        res[f"v{var}s{shape}_plain_dbg{mode}_us"] = round(timeit(step1_plain), 2)
-L.thallo_hip_debug_set(0, 0); L.thallo_hip_debug_set(1, 2); L.thallo_hip_debug_set(2, 0)
+        res[f"grid{1-nogrid}_fused_dbg{mode}_us"] = round(timeit(step1_fused), 2)
+        res[f"grid{1-nogrid}_plain_dbg{mode}_us"] = round(timeit(step1_plain), 2)
+L.thallo_hip_debug_set(0, 0); L.thallo_hip_debug_set(4, 0)
 res["step1_fused_dbg0_us"] = timeit(step1_fused); res["step1_plain_dbg0_us"] = timeit(step1_plain)
 res["step2_us"] = timeit(step2)
 # HBM references with torch: copy (read 50 MB + write 50 MB) and 3-read/2-write elementwise

@@ -1,0 +1,46 @@
+"""Turn the rocprofv3 outputs that tools/profile.sh left in gpurun_out/ into the small committed summaries under
+profiles/<round>/ and profiles/traffic_latest.json (read by bench.py for roofline.traffic)."""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(out, exist_ok=True)
+g = os.path.join(ROOT, "gpurun_out")
+ks = glob.glob(os.path.join(g, "prof_kt", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(ks, os.path.join(out, "bench_kernel_stats.csv"))
+for f in ("bench_under_rocprof.json", "bench_plain.json"):
+    if os.path.exists(os.path.join(g, f)):
+        shutil.copy(os.path.join(g, f), os.path.join(out, f))
+
+
+def short(name):
+    for key, lab in (("k_step1<true", "PCGStep1_fused"), ("k_step1<false", "applyJTJ_plain"), ("k_step2<", "PCGStep2"), ("k_init", "PCGInit1"),
+                     ("k_linear_update", "PCGLinearUpdate"), ("k_cost", "computeCost")):
+        if key in name:
+            return lab
+    return None
+
+
+pmc = {}
+for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(os.path.join(g, f"prof_{kind}", "*", "*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        lab = short(row["Kernel_Name"])
+        if lab and row["Counter_Name"] == ctr:
+            agg[lab].append(float(row["Counter_Value"]))
+    for lab, v in agg.items():
+        pmc.setdefault(lab, {})[ctr + "_KB_mean"] = sum(v) / len(v)
+        pmc[lab]["launches_" + kind] = len(v)
+# gfx950: FETCH_SIZE reports half of the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact
+for lab, d in pmc.items():
+    if "FETCH_SIZE_KB_mean" in d and "WRITE_SIZE_KB_mean" in d:
+        d["hbm_bytes_per_launch_corrected"] = (2.0 * d["FETCH_SIZE_KB_mean"] + d["WRITE_SIZE_KB_mean"]) * 1024.0
+json.dump(pmc, open(os.path.join(out, "pmc_fetch_write.json"), "w"), indent=1)
+if "PCGStep1_fused" in pmc and "hbm_bytes_per_launch_corrected" in pmc["PCGStep1_fused"]:
+    json.dump({"PCGStep1_bytes_per_launch": pmc["PCGStep1_fused"]["hbm_bytes_per_launch_corrected"], "round": rnd,
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled (gfx950 correction)"},
+              open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
+print(json.dumps(pmc, indent=1))
+print(open(os.path.join(out, "bench_kernel_stats.csv")).read()[:1500])

@@ -110,7 +110,8 @@ def main():
     _L = thallo_amd.lib()      # tuning knobs for experiments (tools/sweep_nt.sh); defaults are the product settings
     if "THALLO_NT1" in os.environ: _L.thallo_hip_debug_set(3, int(os.environ["THALLO_NT1"]))
     if "THALLO_NT2" in os.environ: _L.thallo_hip_debug_set2(int(os.environ["THALLO_NT2"]))
-    if "THALLO_VARIANT" in os.environ: _L.thallo_hip_debug_set(1, int(os.environ["THALLO_VARIANT"]))
+    if "THALLO_PER_CU" in os.environ: _L.thallo_hip_debug_set(5, int(os.environ["THALLO_PER_CU"]))
+    if "THALLO_THREADS" in os.environ: _L.thallo_hip_debug_set(6, int(os.environ["THALLO_THREADS"]))
     dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
     s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
     s.set_solver_parameters(nIterations=K + Wm, lIterations=L_it)

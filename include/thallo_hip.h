@@ -255,6 +255,13 @@ int thallo_hip_sfs_apply_jtj(int W, int H, const float* host_params, const float
 int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg, const float* p, float* Ap, const int* irregular, float* alphaD_out, thallo_stream_t stream);
 
+/* ---------------------------------------------------------------- tuning / diagnostic hooks (tools/microbench.py, tools/sweep_*.sh)
+ * Not part of the contract a host layer needs.  thallo_hip_debug_set(what, value): 0 = diagnostic mode of the image_warping
+ * step kernel (1 skip arithmetic, 2 skip loads), 3 = its cache-policy bits, 4 = ignore the regular-grid fast path,
+ * 5 = workgroups per CU, 6 = threads per workgroup (256 | 512).  thallo_hip_debug_set2(bits): cache policy of PCGStep2. */
+void thallo_hip_debug_set(int what, int value);
+void thallo_hip_debug_set2(int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,8 @@ inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuc
 // tools/microbench.py hooks (not product API): diagnostic mode 1 = skip arithmetic, 2 = skip loads;
 // cache-policy bits for PCGStep1: 1 delta nt, 2 cs/UrShape/flags nt, 4 p_in nt, 8 Ap nt, 32 z nt, 64 p_out nt
 int g_iw_debug = 0;
+int g_step1_threads = 512; // fused step: 512 threads x 2 px/thread (default) or 256 x 4
+int g_step1_per_cu = 3; // microbench: workgroups per CU for the fused step (3 = VGPR limit)
 int g_no_grid = 0;      // microbench: 1 = ignore the regular-grid fast path
 int g_nt_mask = 1;      // delta non-temporal: measured +1-3 % PCG it/s at 2048^2 (tools/sweep_nt.sh)
 
@@ -82,7 +84,7 @@ struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
 // GRID = UrShape is the unit pixel grid (what the reference's harness always passes, CombinedSolver.h:158-176):
 // u_i - u_j is then exactly -(dx,dy), so the UrShape plane is neither loaded nor staged (-8 B/pixel, -2 LDS planes).
 // pcg_init verifies the property bit-exactly on the device every GN step; both paths give identical bits.
-template <bool FUSED, bool GRID>
+template <bool FUSED, bool GRID, int NT>
 __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, const float2* __restrict__ cs, const float2* __restrict__ ur,
                                            const unsigned char* __restrict__ flags, float wf2, float wr2,
                                            const float* __restrict__ z, const float* __restrict__ p_in,
@@ -91,6 +93,7 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
                                            thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
                                            float* __restrict__ aD_out, int dbg)
 {
+    constexpr int PER = TH / (NT / TW);                    // owned pixels per thread (one column): 4 at 256 threads, 2 at 512
     const int ntm = dbg >> 8; dbg &= 0xff;
     const bool nt_delta = ntm & 1, nt_const = ntm & 2, nt_pin = ntm & 4, nt_ap = ntm & 8, nt_z = ntm & 32, nt_pout = ntm & 64;
     const long N = (long)g.W * g.H;
@@ -251,8 +254,8 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
     block_store_partial(acc, aD_out, red);
 }
 
-template <bool FUSED, int MINW>
-__global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
+template <bool FUSED, int MINW, int NT>
+__global__ __launch_bounds__(NT, MINW) void k_step1(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur,
                                                         const unsigned char* __restrict__ flags, float wf2, float wr2,
                                                         const float* __restrict__ z, const float* __restrict__ p_in,
                                                         float* __restrict__ p_out, float* __restrict__ delta,
@@ -264,8 +267,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_step1(Geo g, const float2* __re
     __shared__ float red[16];
     // `irregular` = number of pixels whose UrShape neighbours are not at unit offsets (written by pcg_init); wave-uniform
     const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
-    if (grid) step1_body<FUSED, true>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
-    else      step1_body<FUSED, false>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
+    if (grid) step1_body<FUSED, true, NT>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
+    else      step1_body<FUSED, false, NT>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
 }
 
 // ------------------------------------------------------------------------------------------ PCGInit1 (+_Finish)
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int row0, int row1
 
 extern "C" {
 
-void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; }
+void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; if (what == 5) g_step1_per_cu = value; if (what == 6) g_step1_threads = value; }
 
 int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
@@ -455,10 +458,19 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
                             const int* irregular, float* aD_out, thallo_stream_t stream)
 {
     if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
-    const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 3);      // 150 VGPRs -> 3 workgroups per CU
-    hipLaunchKernelGGL((k_step1<true, 3>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
-                       (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                       z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular);
+    const Geo g = make_geo(W, H, row0, row1);
+    int grid;
+    if (g_step1_threads == 512) {       // 2 workgroups of 8 waves per CU (128 VGPRs): 16 waves/CU and 4096 tiles / 512 = 8 tiles each at 2048^2
+        grid = grid_for(g, g_step1_per_cu > 2 ? 2 : g_step1_per_cu);
+        hipLaunchKernelGGL((k_step1<true, 4, 512>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g,
+                           (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
+                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular);
+    } else {                            // 3 workgroups of 4 waves per CU (165 VGPRs)
+        grid = grid_for(g, g_step1_per_cu);
+        hipLaunchKernelGGL((k_step1<true, 3, 256>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
+                           (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
+                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular);
+    }
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -469,7 +481,7 @@ int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, c
     const Geo g = make_geo(W, H, row0, row1); const int grid = grid_for(g, 4);
     thallo_sum_t none; none.partials = nullptr; none.count = 0;
     /* z / p_out / delta are unused when !FUSED: pass valid dummies */
-    hipLaunchKernelGGL((k_step1<false, 4>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL((k_step1<false, 4, 256>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
                        p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug, g_no_grid ? nullptr : irregular);
     int e = check_launch(); return e ? e : grid;

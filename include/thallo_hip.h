@@ -101,6 +101,10 @@ int thallo_hip_lm_step1_finish(float* Ap, const float* CtC, const float* p, long
 int thallo_hip_lm_step2_first_half(float* delta, const float* p, long n, thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_stream_t stream);
 int thallo_hip_lm_step2_second_half(float* r, const float* b, const float* Adelta, const float* pre, float* z, const float* delta, long n,
                                     float* betaN_out, float* q_out, thallo_stream_t stream);
+/* PCGInit1_Finish (gauss_newton.t:712-731) for callers that assembled r and the RAW diagonal elsewhere (the sharded BA
+ * driver all-reduces the point blocks of both first): pre = guardedInvert(diag) (or 1), z = pre*r, alphaN partials. */
+int thallo_hip_pcg_init_finish(const float* r, const float* diag, float* pre, float* z, long n, int use_preconditioner,
+                               float* alphaN_out, thallo_stream_t stream);
 /* partials of sum a.b */
 int thallo_hip_dot(const float* a, const float* b, long n, float* out, thallo_stream_t stream);
 

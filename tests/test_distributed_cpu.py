@@ -101,3 +101,42 @@ def test_world_size_one_is_the_plain_solver(orc):
     costs = SlabSolver(be, lay).solve(2, 10)
     co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=2, lIterations=10)
     assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max()
+
+
+# ------------------------------------------------------------------ camera-sharded bundle adjustment
+def _ba_worker(rank, world, port, dims, nit, lit, q):
+    from thallo_amd.distributed_ba import BaShardLayout, BaShardSolver
+    from ba_scipy_backend import ScipyBaShardBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        C_, P_, O_ = dims
+        p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+        lay = BaShardLayout(C_, rank, world)
+        be = ScipyBaShardBackend(lay, lay.shard(p), lit)
+        costs = BaShardSolver(be, lay).solve(nit, lit)
+        q.put((rank, costs, lay.c0, lay.c1, be.params[0][:lay.C_loc].copy(), be.params[1].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, (12, 60, 300)), (3, (13, 80, 400))])
+def test_ba_camera_shards_match_single_domain_oracle(orc, world, dims):
+    nit, lit = 3, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ba_worker, args=(r, world, port, dims, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    C_, P_, O_ = dims
+    p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+    co, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, c0, c1, cams, pts in res:
+        assert np.abs(np.array(costs) - co).max() <= 2e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]
+        assert np.abs(cams - p[0][c0:c1]).max() <= 1e-3 * np.abs(p[0]).max()
+        assert np.array_equal(pts, res[0][5])                     # replicated point unknowns stay bit-identical
+        assert np.abs(pts - p[1]).max() <= 1e-3 * np.abs(p[1]).max()

@@ -92,3 +92,45 @@ def test_hip_single_slab_equals_library_path(orc):
     _, c2 = s.solve(dev, profiled=True, nIterations=2, lIterations=25)
     assert np.abs(np.array(costs) - np.array(c2)).max() <= 1e-6 * max(c2)
     assert torch.equal(solver.be.offset.view(-1), dev[0].view(-1)) and torch.equal(solver.be.angle.view(-1), dev[1].view(-1))
+
+
+# ------------------------------------------------------------------ camera-sharded bundle adjustment (HIP backend)
+def _ba_worker(rank, world, port, dims, nit, lit, q):
+    import torch
+    import torch.distributed as dist
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed_ba import make_hip_ba_solver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        C_, P_, O_ = dims
+        p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+        solver, lay = make_hip_ba_solver(p, rank, world, lit)
+        costs = solver.solve(nit, lit)
+        be = solver.be
+        q.put((rank, costs, lay.c0, lay.c1, be.cameras[:lay.C_loc].cpu().numpy(), be.points.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,nit,lit", [(2, (64, 4000, 20000), 3, 30), (3, (13, 80, 400), 3, 10)])
+def test_hip_ba_camera_shards_match_oracle(orc, world, dims, nit, lit):
+    import torch.multiprocessing as mp
+    from thallo_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ba_worker, args=(r, world, port, dims, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    C_, P_, O_ = dims
+    p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+    co, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, c0, c1, cams, pts in res:
+        assert np.abs(np.array(costs) - co).max() <= 3e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]
+        assert np.array_equal(pts, res[0][5])
+        assert np.abs(pts - p[1]).max() <= 2e-3 * np.abs(p[1]).max()

@@ -228,6 +228,24 @@ __global__ __launch_bounds__(BLOCK) void k_lm_step2_second(float4* __restrict__ 
     block_store_partials<2>(acc, outs, red);
 }
 
+// PCGInit1_Finish (gauss_newton.t:712-731) for callers that assembled r and the RAW diagonal elsewhere (e.g. after a
+// cross-rank reduction): pre = guardedInvert(diag) (or 1), z = pre*r, alphaN partials
+__global__ __launch_bounds__(BLOCK) void k_init_finish(const float4* __restrict__ r, const float4* __restrict__ diag, float4* __restrict__ pre,
+                                                        float4* __restrict__ z, long n4, int use_precond, float* __restrict__ aN_out)
+{
+    __shared__ float red[16];
+    float acc = 0.0f;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        const float4 rv = r[i];
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (use_precond) { const float4 d = diag[i]; m = make_float4(guarded_invert(d.x), guarded_invert(d.y), guarded_invert(d.z), guarded_invert(d.w)); }
+        const float4 zv = make_float4(m.x * rv.x, m.y * rv.y, m.z * rv.z, m.w * rv.w);
+        pre[i] = m; z[i] = zv;
+        acc += rv.x * zv.x + rv.y * zv.y + rv.z * zv.z + rv.w * zv.w;
+    }
+    block_store_partial(acc, aN_out, red);
+}
+
 // sum a.b partials
 __global__ __launch_bounds__(BLOCK) void k_dot(const float4* __restrict__ a, const float4* __restrict__ b, long n4, float* __restrict__ out)
 {
@@ -404,6 +422,14 @@ int thallo_hip_lm_step2_second_half(float* r, const float* b, const float* Adelt
     const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
     hipLaunchKernelGGL(k_lm_step2_second, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)b, (const float4*)Adelta,
                        (const float4*)pre, (float4*)z, (const float4*)delta, n4, bN_out, q_out);
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_pcg_init_finish(const float* r, const float* diag, float* pre, float* z, long n, int use_preconditioner,
+                               float* aN_out, thallo_stream_t stream)
+{
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_init_finish, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)r, (const float4*)diag, (float4*)pre, (float4*)z, n4,
+                       use_preconditioner, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_dot(const float* a, const float* b, long n, float* out, thallo_stream_t stream)

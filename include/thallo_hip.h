@@ -86,6 +86,10 @@ int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t betaN, t
 int thallo_hip_pcg_pupdate(const float* z, const float* p_in, float* p_out, float* delta, long n, int first,
                            thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_stream_t stream);
 /* (delta == NULL: p update only with the unguarded LM divide; LM keeps the delta update in PCGStep2.) */
+/* Same over two ranges of the flat vectors (floats, multiples of 4), cf. thallo_hip_pcg_step2_ranges. */
+int thallo_hip_pcg_pupdate_ranges(const float* z, const float* p_in, float* p_out, float* delta,
+                                  long off0, long len0, long off1, long len1, int first,
+                                  thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_stream_t stream);
 
 /* ---- Levenberg-Marquardt set.  PCGSaveSSq + PCGComputeCtC + PCGFinalizeDiagonal (gauss_newton.t:929-969,
  * thallo.t:3911-3937) in one pass over the raw diagonal `diag` = diag(J^T J) (pcg_init's diag_out):
@@ -202,15 +206,17 @@ int thallo_hip_lapgraph_apply_jtj(int N, const int* out_ptr, const int* out_v1, 
 /* E2: examples/arap_mesh_deformation/arap_mesh_deformation.t  (w_fitSqrt (0), w_regSqrt (1), Position float3 (2) and
  * Angle float3 (3) unknown, Original float3 (4), Constraints float3 (5), V0 (6), V1 (7)).
  * Flat vector layout [Position 3n+c | Angle 3N+3n+c].  precompute (once per GN iteration) fills, per edge in
- * out-CSR order, F[3E] = the reg residual and G[9E] = d(R(Angle) dv)/d(Angle) (three float3 columns). */
-int thallo_hip_arap_cost(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
+ * out-CSR order, F[3E] = the reg residual and G[9E] = d(R(Angle) dv)/d(Angle) (three float3 columns).
+ * cost / pcg_init / apply_jtj produce outputs for the vertex range [n0,n1) only (0,N = everything): the vertex-partitioned
+ * multi-GPU driver (thallo_amd/distributed_graph.py) keeps the vectors replicated and all-gathers p. */
+int thallo_hip_arap_cost(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
                          const float* original, const float* constraints, float w_fit, float w_reg, float* cost_out, thallo_stream_t stream);
 int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
                                const float* original, float w_reg, float* F, float* G, thallo_stream_t stream);
-int thallo_hip_arap_pcg_init(int N, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
+int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
                              float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* alphaN_out, thallo_stream_t stream);
-int thallo_hip_arap_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
+int thallo_hip_arap_apply_jtj(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                               const float* constraints, const float* G, float w_fit, float w_reg,
                               const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 

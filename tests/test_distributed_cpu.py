@@ -140,3 +140,39 @@ def test_ba_camera_shards_match_single_domain_oracle(orc, world, dims):
         assert np.abs(cams - p[0][c0:c1]).max() <= 1e-3 * np.abs(p[0]).max()
         assert np.array_equal(pts, res[0][5])                     # replicated point unknowns stay bit-identical
         assert np.abs(pts - p[1]).max() <= 1e-3 * np.abs(p[1]).max()
+
+
+# ------------------------------------------------------------------ vertex-partitioned ARAP
+def _arap_worker(rank, world, port, nu, nv, nit, lit, q):
+    from thallo_amd.distributed_graph import VertexPartition, GraphPartSolver
+    from arap_scipy_backend import ScipyArapPartBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.arap_mesh(nu, nv, n_handles=6, angle_amp=0.3)
+        part = VertexPartition(p[2].shape[0], rank, world)
+        be = ScipyArapPartBackend(part, p, lit)
+        costs = GraphPartSolver(be, part).solve(nit, lit)
+        q.put((rank, costs, be.params[2].copy(), be.params[3].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nu,nv", [(2, 8, 6), (3, 12, 8)])
+def test_arap_vertex_partition_matches_single_domain_oracle(orc, world, nu, nv):
+    nit, lit = 3, 15
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arap_worker, args=(r, world, port, nu, nv, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    p = syn.arap_mesh(nu, nv, n_handles=6, angle_amp=0.3)
+    co, _ = orc.Problem(orc.ARAP_MESH, (p[2].shape[0], p[6].shape[0]), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, pos, ang in res:
+        assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]
+        assert np.array_equal(pos, res[0][2]) and np.array_equal(ang, res[0][3])      # unknowns re-replicated bit-identically
+        assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()

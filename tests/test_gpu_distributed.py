@@ -134,3 +134,41 @@ def test_hip_ba_camera_shards_match_oracle(orc, world, dims, nit, lit):
         assert costs == res[0][1]
         assert np.array_equal(pts, res[0][5])
         assert np.abs(pts - p[1]).max() <= 2e-3 * np.abs(p[1]).max()
+
+
+# ------------------------------------------------------------------ vertex-partitioned ARAP (HIP backend)
+def _arap_worker(rank, world, port, nu, nv, nit, lit, q):
+    import torch
+    import torch.distributed as dist
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed_graph import make_hip_arap_solver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
+        solver, part = make_hip_arap_solver(p, rank, world, lit)
+        costs = solver.solve(nit, lit)
+        q.put((rank, costs, solver.be.position.cpu().numpy(), solver.be.angle.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nu,nv,nit,lit", [(2, 40, 30, 3, 40), (3, 24, 16, 3, 20)])
+def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
+    import torch.multiprocessing as mp
+    from thallo_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arap_worker, args=(r, world, port, nu, nv, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
+    co, _ = orc.Problem(orc.ARAP_MESH, (p[2].shape[0], p[6].shape[0]), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, pos, ang in res:
+        assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1] and np.array_equal(pos, res[0][2])
+        assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()

@@ -128,13 +128,13 @@ __device__ __forceinline__ f3 mv(const float* M, f3 v)
     return o;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_arap_cost(int N, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
+__global__ __launch_bounds__(BLOCK) void k_arap_cost(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
                                                       const float* __restrict__ P, const float* __restrict__ Ang, const float* __restrict__ O,
                                                       const float* __restrict__ Cn, float wf, float wr, float* __restrict__ out)
 {
     __shared__ float red[16];
     float acc = 0.0f;
-    for (int n = blockIdx.x * BLOCK + threadIdx.x; n < N; n += gridDim.x * BLOCK) {
+    for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
         const f3 p = ld3(P, n), o = ld3(O, n), c = ld3(Cn, n);
         Rot rt; rot3(ld3(Ang, n), rt);
         float s = 0.0f;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_precompute(int N, const int* __r
 }
 
 // PCGInit1 (+_Finish), gather form.  flat layout: [Position 3n+c | Angle 3N+3n+c]
-__global__ __launch_bounds__(BLOCK) void k_arap_init(int N, const int* __restrict__ out_ptr, const int* __restrict__ in_ptr,
+__global__ __launch_bounds__(BLOCK) void k_arap_init(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ in_ptr,
                                                       const int* __restrict__ in_edge, const float* __restrict__ P, const float* __restrict__ Cn,
                                                       const float* __restrict__ F, const float* __restrict__ G, float wf, float wr,
                                                       float* __restrict__ r, float* __restrict__ pre, float* __restrict__ z,
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, const int* __restric
     __shared__ float red[16];
     float acc = 0.0f;
     const float wr2 = wr * wr;
-    for (int n = blockIdx.x * BLOCK + threadIdx.x; n < N; n += gridDim.x * BLOCK) {
+    for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
         f3 jp = { 0.f, 0.f, 0.f }, ja = { 0.f, 0.f, 0.f }, da = { 0.f, 0.f, 0.f };
         float dp = 0.0f;
         for (int k = out_ptr[n]; k < out_ptr[n + 1]; ++k) {          // own edges: dF/dP_n = w I, dF/dA_n = -w G
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, const int* __restric
 }
 
 // PCGStep1: Ap = J^T J p (gather), alphaD partials
-__global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
+__global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
                                                        const int* __restrict__ in_ptr, const int* __restrict__ in_edge, const int* __restrict__ in_src,
                                                        const float* __restrict__ Cn, const float* __restrict__ G, float wf, float wr,
                                                        const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out)
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, const int* __restri
     __shared__ float red[16];
     float acc = 0.0f;
     const float wr2 = wr * wr;
-    for (int n = blockIdx.x * BLOCK + threadIdx.x; n < N; n += gridDim.x * BLOCK) {
+    for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
         const f3 pp = ld3(p, n), pa = ld3(p, (long)N + n);
         f3 ap = { 0.f, 0.f, 0.f }, aa = { 0.f, 0.f, 0.f };
         for (int k = out_ptr[n]; k < out_ptr[n + 1]; ++k) {
@@ -292,11 +292,12 @@ int thallo_hip_lapgraph_apply_jtj(int N, const int* out_ptr, const int* out_v1, 
     int e = check_launch(); return e ? e : grid;
 }
 
-int thallo_hip_arap_cost(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
+int thallo_hip_arap_cost(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
                          const float* original, const float* constraints, float w_fit, float w_reg, float* cost_out, thallo_stream_t stream)
 {
-    const int grid = vgrid(N);
-    hipLaunchKernelGGL(k_arap_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, position, angle, original, constraints, w_fit, w_reg, cost_out);
+    if (n0 < 0 || n1 > N || n0 >= n1) return -(int)hipErrorInvalidValue;
+    const int grid = vgrid(n1 - n0);
+    hipLaunchKernelGGL(k_arap_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, position, angle, original, constraints, w_fit, w_reg, cost_out);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
@@ -306,21 +307,23 @@ int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, con
     hipLaunchKernelGGL(k_arap_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, position, angle, original, w_reg, F, G);
     return check_launch();
 }
-int thallo_hip_arap_pcg_init(int N, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
+int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
                              float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, thallo_stream_t stream)
 {
-    const int grid = vgrid(N);
-    hipLaunchKernelGGL(k_arap_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, in_ptr, in_edge, position, constraints, F, G, w_fit, w_reg,
+    if (n0 < 0 || n1 > N || n0 >= n1) return -(int)hipErrorInvalidValue;
+    const int grid = vgrid(n1 - n0);
+    hipLaunchKernelGGL(k_arap_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, in_ptr, in_edge, position, constraints, F, G, w_fit, w_reg,
                        r, pre, z, p_prev, delta, diag_out, aN_out);
     int e = check_launch(); return e ? e : grid;
 }
-int thallo_hip_arap_apply_jtj(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
+int thallo_hip_arap_apply_jtj(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                               const float* constraints, const float* G, float w_fit, float w_reg,
                               const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
 {
-    const int grid = vgrid(N);
-    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out);
+    if (n0 < 0 || n1 > N || n0 >= n1) return -(int)hipErrorInvalidValue;
+    const int grid = vgrid(n1 - n0);
+    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out);
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BLOCK) void k_step3(float4* __restrict__ p, const f
 // unfused PCGStep3 + delta update for energies whose applyJTJ gathers p through indices (graph domains):
 //   delta += alpha*p_in ; p_out = z + beta*p_in    (first: p_out = z)
 __global__ __launch_bounds__(BLOCK) void k_pupdate(const float4* __restrict__ z, const float4* __restrict__ p_in, float4* __restrict__ p_out,
-                                                    float4* __restrict__ delta, long n4, int first,
+                                                    float4* __restrict__ delta, long off0, long len0, long off1, long len1, int first,
                                                     thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp)
 {   // delta == NULL: p update only (LM: PCGStep3 with the unguarded divide, delta lives in PCGStep2)
     float alpha = 0.0f, beta = 0.0f;
@@ -132,7 +132,9 @@ __global__ __launch_bounds__(BLOCK) void k_pupdate(const float4* __restrict__ z,
             beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
         }
     }
-    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+    const long n4 = len0 + len1;
+    for (long j = (long)blockIdx.x * BLOCK + threadIdx.x; j < n4; j += (long)gridDim.x * BLOCK) {
+        const long i = j < len0 ? off0 + j : off1 + (j - len0);
         const float4 pv = p_in[i], zv = z[i];
         if (!first && !lm) {
             float4 dv = delta[i];
@@ -385,14 +387,22 @@ int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t bN, thal
     return e ? e : grid;
 }
 
+int thallo_hip_pcg_pupdate_ranges(const float* z, const float* p_in, float* p_out, float* delta,
+                                  long off0, long len0, long off1, long len1, int first,
+                                  thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_stream_t stream)
+{
+    if ((off0 | len0 | off1 | len1) & 3) return -(int)hipErrorInvalidValue;
+    const int grid = flat_grid((len0 + len1) / 4, cu_count());
+    hipLaunchKernelGGL(k_pupdate, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)z, (const float4*)p_in, (float4*)p_out, (float4*)delta,
+                       off0 / 4, len0 / 4, off1 / 4, len1 / 4, first, aNp, aDp, bNp);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
 int thallo_hip_pcg_pupdate(const float* z, const float* p_in, float* p_out, float* delta, long n, int first,
                            thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_stream_t stream)
 {
-    const long n4 = (n + 3) / 4;
-    const int grid = flat_grid(n4, cu_count());
-    hipLaunchKernelGGL(k_pupdate, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)z, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
-    int e = check_launch();
-    return e ? e : grid;
+    return thallo_hip_pcg_pupdate_ranges(z, p_in, p_out, delta, 0, (n + 3) / 4 * 4, 0, 0, first, aNp, aDp, bNp, stream);
 }
 
 int thallo_hip_lm_finalize_diagonal(const float* diag, float* SSq, float* CtC, float* pre, const float* r, float* b, float* z, long n,

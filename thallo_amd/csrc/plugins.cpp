@@ -187,7 +187,7 @@ public:
     int cost(LaunchCtx& c, float* out) override
     {
         TimedLaunch t(c, "computeCost");
-        return thallo_hip_arap_cost(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, c.stream);
+        return thallo_hip_arap_cost(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, c.stream);
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
@@ -195,20 +195,20 @@ public:
           int rc = thallo_hip_arap_precompute(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, c.stream);
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
-        return thallo_hip_arap_pcg_init(N, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
+        return thallo_hip_arap_pcg_init(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
                                         (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+        return thallo_hip_arap_apply_jtj(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
                                          constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+        return thallo_hip_arap_apply_jtj(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
                                          constraints, (const float*)G.ptr, w_fit, w_reg, v.p[cur ^ 1], v.Ap, out, c.stream);
     }
 };

@@ -247,16 +247,20 @@ int thallo_hip_ba_apply_jtj(int C, int P, const int* cam_ptr, const int* q_pt, c
  * gauss_newton.t:979-986, thallo.t:4046-4094; once per GN iteration and before every cost evaluation) fills
  *   G  float4/pixel = (dBI/dX(c), dBI/dX(c-ex), dBI/dX(c-ey), BI(c)),  Wt float2/pixel = shading row weights,
  *   fl uint8/pixel  = bit0 D_i>0, bit1 reg row valid.
- * U (float2/pixel) and R (3 floats/pixel, planar) are scratch for the row pass of J^T(Jv). */
-int thallo_hip_sfs_precompute(int W, int H, const float* host_params, const float* X, const float* D, const float* Im,
+ * U (float2/pixel) and R (3 floats/pixel, planar) are scratch for the row pass of J^T(Jv).
+ * Row slabs: W x H is the LOCAL image (2 ghost rows per interior side: the chain B_I -> row -> gather has radius 2);
+ * yoff = global row of local row 0, Hg = global image height (pixel coordinates and the border guard of the shading
+ * rows are global); precompute visits local rows [ra,rb), the others produce outputs for the owned rows [row0,row1).
+ * Whole image: ra=row0=0, rb=row1=H, yoff=0, Hg=H. */
+int thallo_hip_sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
                               const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
                               thallo_stream_t stream);
-int thallo_hip_sfs_cost(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+int thallo_hip_sfs_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                         const unsigned char* fl, float* cost_out, thallo_stream_t stream);
-int thallo_hip_sfs_pcg_init(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                             const unsigned char* fl, float* U, float* R, float* r, float* z, float* p_prev, float* delta,
                             float* diag_out, float* alphaN_out, thallo_stream_t stream);
-int thallo_hip_sfs_apply_jtj(int W, int H, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 
 /* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped

@@ -174,5 +174,18 @@ class NumpySlabBackend:
         else:
             o[R0:R1] += do_[R0:R1]; a[R0:R1] += da_[R0:R1]
 
+    def pack_unknowns(self):
+        o, a = self.offset.view(self.Hl, 2 * self.W), self.angle.view(self.Hl, self.W)
+        return torch.cat([o[self.row0], a[self.row0], o[self.row1 - 1], a[self.row1 - 1]])
+
+    def unpack_unknowns(self, g):
+        W, lay = self.W, self.lay
+        o, a = self.offset.view(self.Hl, 2 * W), self.angle.view(self.Hl, W)
+        g = g.view(lay.world, 2, 3 * W)
+        if lay.top:
+            o[self.row0 - 1].copy_(g[lay.rank - 1, 1, :2 * W]); a[self.row0 - 1].copy_(g[lay.rank - 1, 1, 2 * W:])
+        if lay.bot:
+            o[self.row1].copy_(g[lay.rank + 1, 0, :2 * W]); a[self.row1].copy_(g[lay.rank + 1, 0, 2 * W:])
+
     def scalar(self, idx):
         return float(self.S[idx])

@@ -176,3 +176,38 @@ def test_arap_vertex_partition_matches_single_domain_oracle(orc, world, nu, nv):
         assert costs == res[0][1]
         assert np.array_equal(pos, res[0][2]) and np.array_equal(ang, res[0][3])      # unknowns re-replicated bit-identically
         assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
+
+
+# ------------------------------------------------------------------ shape_from_shading row slabs (ghost width 2)
+def _sfs_worker(rank, world, port, W, H, nit, lit, q):
+    from sfs_scipy_backend import ScipySfsSlabBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.shape_from_shading(W, H)
+        lay = SlabLayout(H, rank, world, align=4, ghost=2)
+        local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in p]
+        be = ScipySfsSlabBackend(W, lay, local, H, lit)
+        costs = SlabSolver(be, lay).solve(nit, lit)
+        q.put((rank, costs, lay.g0, lay.g1, be.X.view(be.Hl, W)[lay.row0:lay.row1].numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 20, 16), (3, 16, 24)])
+def test_sfs_slabs_match_single_domain_oracle(orc, world, W, H):
+    nit, lit = 3, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sfs_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    p = syn.shape_from_shading(W, H)
+    co, _ = orc.Problem(orc.SFS, (W, H), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, g0, g1, X in res:
+        assert (np.abs(np.array(costs) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (rank, costs, co)
+        assert costs == res[0][1]
+        assert np.abs(X - p[16][g0:g1]).max() <= 2e-5

@@ -172,3 +172,42 @@ def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
         assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
         assert costs == res[0][1] and np.array_equal(pos, res[0][2])
         assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
+
+
+# ------------------------------------------------------------------ shape_from_shading row slabs (2 ghost rows)
+def _sfs_worker(rank, world, port, W, H, nit, lit, q):
+    import torch
+    import torch.distributed as dist
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed_sfs import make_hip_sfs_solver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.shape_from_shading(W, H)
+        solver, lay = make_hip_sfs_solver(p, W, H, rank, world, lit)
+        costs = solver.solve(nit, lit)
+        be = solver.be
+        q.put((rank, costs, lay.g0, lay.g1, be.X.view(be.Hl, W)[lay.row0:lay.row1].cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,nit,lit", [(2, 64, 64, 4, 10), (3, 128, 112, 3, 10), (1, 64, 48, 3, 10)])
+def test_hip_sfs_slabs_match_oracle(orc, world, W, H, nit, lit):
+    import torch.multiprocessing as mp
+    from thallo_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sfs_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    p = syn.shape_from_shading(W, H)
+    co, _ = orc.Problem(orc.SFS, (W, H), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, g0, g1, X in res:
+        assert (np.abs(np.array(costs) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (rank, costs, co)
+        assert costs == res[0][1]
+        assert np.abs(X - p[16][g0:g1]).max() <= 2e-5

@@ -30,8 +30,14 @@ using namespace thallo;
 namespace {
 
 constexpr int TW = 64, TH = 4, BLOCK = 256;
-struct Geo { int W, H, tx, ty, ntiles; };
-inline Geo make_geo(int W, int H) { Geo g; g.W = W; g.H = H; g.tx = (W + TW - 1) / TW; g.ty = (H + TH - 1) / TH; g.ntiles = g.tx * g.ty; return g; }
+// W x H = local image (a row slab may carry 2 ghost rows per side); a kernel visits local rows [ra, rb);
+// yoff = global row of local row 0 and Hg = global image height (pixel coordinates and the image-border guard are global)
+struct Geo { int W, H, ra, rb, yoff, Hg, tx, ty, ntiles; };
+inline Geo make_geo(int W, int H, int ra, int rb, int yoff, int Hg)
+{
+    Geo g; g.W = W; g.H = H; g.ra = ra; g.rb = rb; g.yoff = yoff; g.Hg = Hg;
+    g.tx = (W + TW - 1) / TW; g.ty = (rb - ra + TH - 1) / TH; g.ntiles = g.tx * g.ty; return g;
+}
 inline int grid_for(const Geo& g)
 {
     int cap = thallo_hip_device_cu_count() * 4; if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS; cap -= cap % 8;
@@ -43,8 +49,8 @@ struct Cam { float wp, ws, wg, fx, fy, ux, uy; float L[9]; };
 
 #define FOR_EACH_PIXEL(g) \
     for (TileSweep t_((g).ntiles); t_.valid(); t_.next()) \
-        for (int x = (t_.cur % (g).tx) * TW + (threadIdx.x % TW), y = (t_.cur / (g).tx) * TH + (threadIdx.x / TW), once_ = 1; once_; once_ = 0) \
-            if (x < (g).W && y < (g).H)
+        for (int x = (t_.cur % (g).tx) * TW + (threadIdx.x % TW), y = (g).ra + (t_.cur / (g).tx) * TH + (threadIdx.x / TW), once_ = 1; once_; once_ = 0) \
+            if (x < (g).W && y < (g).rb)
 
 __device__ __forceinline__ float at(const float* __restrict__ a, int x, int y, int W, int H) { return (x >= 0 && x < W && y >= 0 && y < H) ? a[(long)y * W + x] : 0.0f; }
 
@@ -57,11 +63,11 @@ __device__ __forceinline__ J3 operator*(J3 a, float c) { J3 r = { a.v * c, a.d0 
 
 // BI and its three partials at pixel (x,y)   (shape_from_shading.t:40-80)
 __device__ __forceinline__ J3 eval_BI(const Cam& cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
-                                      int x, int y, int W, int H)
+                                      int x, int y, int W, int H, int yoff)
 {
     if (!(at(D, x - 1, y, W, H) > 0.0f && at(D, x, y, W, H) > 0.0f && at(D, x, y - 1, W, H) > 0.0f)) return k3(0.0f);
     const J3 c = { at(X, x, y, W, H), 1.f, 0.f, 0.f }, l = { at(X, x - 1, y, W, H), 0.f, 1.f, 0.f }, u = { at(X, x, y - 1, W, H), 0.f, 0.f, 1.f };
-    const float i = (float)x, j = (float)y;
+    const float i = (float)x, j = (float)(y + yoff);
     const J3 nx = (u * (c - l)) * (1.0f / cm.fy);
     const J3 ny = (l * (c - u)) * (1.0f / cm.fx);
     const J3 nz = (nx * ((cm.ux - i) / cm.fx) + ny * ((cm.uy - j) / cm.fy)) - (l * u) * (1.0f / (cm.fx * cm.fy));
@@ -89,9 +95,10 @@ __global__ __launch_bounds__(BLOCK) void k_precompute(Geo g, Cam cm, const float
 {
     FOR_EACH_PIXEL(g) {
         const long i = (long)y * g.W + x;
-        const J3 b = eval_BI(cm, X, D, Im, x, y, g.W, g.H);
+        const J3 b = eval_BI(cm, X, D, Im, x, y, g.W, g.H, g.yoff);
         G[i] = make_float4(b.d0, b.d1, b.d2, b.v);
-        const bool inner = x >= 1 && x + 1 < g.W && y >= 1 && y + 1 < g.H;
+        const int yg = y + g.yoff;
+        const bool inner = x >= 1 && x + 1 < g.W && yg >= 1 && yg + 1 < g.Hg;
         Wt[i] = inner ? make_float2(cm.wg * (float)mR[i], cm.wg * (float)mC[i]) : make_float2(0.f, 0.f);
         const float xc = X[i];
         unsigned char f = D[i] > 0.0f ? 1 : 0;
@@ -129,9 +136,9 @@ __global__ __launch_bounds__(BLOCK) void k_cost(Geo g, Cam cm, const float* __re
         if (f & 2) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float a = 4.0f * (coef(cm, c, x, y) * xc);
-                a -= coef(cm, c, x - 1, y) * at(X, x - 1, y, g.W, g.H); a -= coef(cm, c, x, y - 1) * at(X, x, y - 1, g.W, g.H);
-                a -= coef(cm, c, x + 1, y) * at(X, x + 1, y, g.W, g.H); a -= coef(cm, c, x, y + 1) * at(X, x, y + 1, g.W, g.H);
+                float a = 4.0f * (coef(cm, c, x, y + g.yoff) * xc);
+                a -= coef(cm, c, x - 1, y + g.yoff) * at(X, x - 1, y, g.W, g.H); a -= coef(cm, c, x, y - 1 + g.yoff) * at(X, x, y - 1, g.W, g.H);
+                a -= coef(cm, c, x + 1, y + g.yoff) * at(X, x + 1, y, g.W, g.H); a -= coef(cm, c, x, y + 1 + g.yoff) * at(X, x, y + 1, g.W, g.H);
                 a *= cm.ws; s += a * a;
             }
         }
@@ -170,8 +177,8 @@ __global__ __launch_bounds__(BLOCK) void k_rows(Geo g, Cam cm, const float* __re
             float a[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                a[c] = cm.ws * (4.0f * (coef(cm, c, x, y) * vc) - coef(cm, c, x - 1, y) * vl - coef(cm, c, x, y - 1) * vu
-                                - coef(cm, c, x + 1, y) * vr - coef(cm, c, x, y + 1) * vd);
+                a[c] = cm.ws * (4.0f * (coef(cm, c, x, y + g.yoff) * vc) - coef(cm, c, x - 1, y + g.yoff) * vl - coef(cm, c, x, y - 1 + g.yoff) * vu
+                                - coef(cm, c, x + 1, y + g.yoff) * vr - coef(cm, c, x, y + 1 + g.yoff) * vd);
             r0 = a[0]; r1 = a[1]; r2 = a[2];
         }
         R[i] = r0; R[N + i] = r1; R[2 * N + i] = r2;
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Geo g, Cam cm, const float* __
         for (int c = 0; c < 3; ++c) {
             const float* Rc = R + c * N;
             const float lap = 4.0f * Rc[i] - at(Rc, x - 1, y, g.W, g.H) - at(Rc, x, y - 1, g.W, g.H) - at(Rc, x + 1, y, g.W, g.H) - at(Rc, x, y + 1, g.W, g.H);
-            s += cm.ws * (coef(cm, c, x, y) * lap);
+            s += cm.ws * (coef(cm, c, x, y + g.yoff) * lap);
         }
         if (MODE == 0) { const float r = -s; out[i] = r; z[i] = r; p_prev[i] = 0.0f; delta[i] = 0.0f; acc += r * r; }
         else { out[i] = s; acc += vc * s; }
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __r
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int X0 = x + qx[k], Y0 = y + qy[k];
-            if (X0 < 1 || X0 + 1 >= g.W || Y0 < 1 || Y0 + 1 >= g.H) continue;      // row guard
+            if (X0 < 1 || X0 + 1 >= g.W || Y0 + g.yoff < 1 || Y0 + g.yoff + 1 >= g.Hg || Y0 < 0 || Y0 + 1 >= g.H) continue;      // row guard (global) + local storage
             const long q = (long)Y0 * g.W + X0;
             const float2 w = Wt[q];
             const float4 g0 = G[q], gx = G[q + 1], gy = G[q + g.W];
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __r
         // reg rows: q = i (coefficient 4 w_s coef_c(i)) and the four neighbours (-w_s coef_c(i))
         float cc = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const float k = cm.ws * coef(cm, c, x, y); cc += k * k; }
+        for (int c = 0; c < 3; ++c) { const float k = cm.ws * coef(cm, c, x, y + g.yoff); cc += k * k; }
         float cnt = (fl[i] & 2) ? 16.0f : 0.0f;
         if (x > 0 && (fl[i - 1] & 2)) cnt += 1.0f;
         if (y > 0 && (fl[i - g.W] & 2)) cnt += 1.0f;
@@ -273,44 +280,51 @@ static Cam cam_of(const float* hp)
     return c;
 }
 
-int thallo_hip_sfs_precompute(int W, int H, const float* host_params, const float* X, const float* D, const float* Im,
+int thallo_hip_sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
                               const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
                               thallo_stream_t stream)
 {
-    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    if (ra < 0 || rb > H || ra >= rb) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, ra, rb, yoff, Hg); const int grid = grid_for(g);
     hipLaunchKernelGGL(k_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
                        (float4*)G, (float2*)Wt, fl);
     return check_launch();
 }
 
-int thallo_hip_sfs_cost(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+int thallo_hip_sfs_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                         const unsigned char* fl, float* cost_out, thallo_stream_t stream)
 {
-    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
     hipLaunchKernelGGL(k_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), X, D, (const float4*)G, (const float2*)Wt, fl, cost_out);
     int e = check_launch(); return e ? e : grid;
 }
 
-int thallo_hip_sfs_pcg_init(int W, int H, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                             const unsigned char* fl, float* U, float* R, float* r, float* z, float* p_prev, float* delta,
                             float* diag_out, float* aN_out, thallo_stream_t stream)
 {
-    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
+    // row pass over the owned rows +-1 (they feed the gather of the owned rows), gather over the owned rows
+    const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
+    const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
     const Cam cm = cam_of(host_params);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_rows<true>, dim3(grid), dim3(BLOCK), 0, s, g, cm, X, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
+    hipLaunchKernelGGL(k_rows<true>, dim3(gridr), dim3(BLOCK), 0, s, gr, cm, X, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
     hipLaunchKernelGGL(k_gather<0>, dim3(grid), dim3(BLOCK), 0, s, g, cm, X, D, (const float4*)G, (const float2*)U, (const float*)R, fl, r, z, p_prev, delta, aN_out);
     if (diag_out) hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
     int e = check_launch(); return e ? e : grid;
 }
 
-int thallo_hip_sfs_apply_jtj(int W, int H, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
 {
-    const Geo g = make_geo(W, H); const int grid = grid_for(g);
+    if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
+    const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
     const Cam cm = cam_of(host_params);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_rows<false>, dim3(grid), dim3(BLOCK), 0, s, g, cm, p, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
+    hipLaunchKernelGGL(k_rows<false>, dim3(gridr), dim3(BLOCK), 0, s, gr, cm, p, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
     hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, s, g, cm, p, (const float*)nullptr, (const float4*)G, (const float2*)U, (const float*)R, fl,
                        Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
     int e = check_launch(); return e ? e : grid;

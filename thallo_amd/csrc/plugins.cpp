@@ -291,7 +291,7 @@ class ShapeFromShadingPlugin : public EnergyPlugin {
     int precompute(LaunchCtx& c)
     {
         TimedLaunch t(c, "precompute");
-        return thallo_hip_sfs_precompute(W, H, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
+        return thallo_hip_sfs_precompute(W, H, 0, H, 0, H, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
     }
 public:
     ShapeFromShadingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1]) { imgs.push_back({ 16, (long)W * H }); }
@@ -313,19 +313,19 @@ public:
     {
         int rc = precompute(c); if (rc < 0) return rc;
         TimedLaunch t(c, "computeCost");
-        return thallo_hip_sfs_cost(W, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, out, c.stream);
+        return thallo_hip_sfs_cost(W, H, 0, H, 0, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, out, c.stream);
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
         int rc = precompute(c); if (rc < 0) return rc;
         TimedLaunch t(c, "PCGInit1");
-        return thallo_hip_sfs_pcg_init(W, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr,
+        return thallo_hip_sfs_pcg_init(W, H, 0, H, 0, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr,
                                        v.r, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_sfs_apply_jtj(W, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out, c.stream);
+        return thallo_hip_sfs_apply_jtj(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {

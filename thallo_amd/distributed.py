@@ -34,7 +34,7 @@ from . import api
 class SlabLayout:
     """Rows [g0,g1) of an H-row image owned by `rank`; local image = owned rows + ghost rows."""
 
-    def __init__(self, H, rank, world, align=16):
+    def __init__(self, H, rank, world, align=16, ghost=1):
         # slabs are multiples of `align` rows (the kernels' tile height) while rows last; remainder to the last rank
         blocks = (H + align - 1) // align
         per, rem = divmod(blocks, world)
@@ -49,8 +49,11 @@ class SlabLayout:
         self.g0, self.g1 = bounds[rank]
         if self.g1 <= self.g0:
             raise ValueError(f"rank {rank} of {world} owns no rows of an image with {H} rows")
-        self.top = 1 if self.g0 > 0 else 0
-        self.bot = 1 if self.g1 < H else 0
+        self.ghost = ghost
+        self.top = ghost if self.g0 > 0 else 0
+        self.bot = ghost if self.g1 < H else 0
+        if (self.top or self.bot) and (self.g1 - self.g0) < ghost:
+            raise ValueError("slab thinner than the ghost width")
         self.Hl = (self.g1 - self.g0) + self.top + self.bot
         self.row0 = self.top
         self.row1 = self.top + (self.g1 - self.g0)
@@ -186,6 +189,20 @@ class HipSlabBackend:
             self._chk(self.L.thallo_hip_linear_update(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off), p_ptr, C.c_long(ln),
                                                       self._sum(iN), self._sum(iD), self._st()), "linear_update")
 
+    def pack_unknowns(self):
+        W = self.W
+        off = self.offset.view(self.Hl, 2 * W); ang = self.angle.view(self.Hl, W)
+        return torch.cat([off[self.row0], ang[self.row0], off[self.row1 - 1], ang[self.row1 - 1]])
+
+    def unpack_unknowns(self, g):
+        W, lay = self.W, self.lay
+        off = self.offset.view(self.Hl, 2 * W); ang = self.angle.view(self.Hl, W)
+        g = g.view(lay.world, 2, 3 * W)
+        if lay.top:
+            off[self.row0 - 1].copy_(g[lay.rank - 1, 1, :2 * W]); ang[self.row0 - 1].copy_(g[lay.rank - 1, 1, 2 * W:])
+        if lay.bot:
+            off[self.row1].copy_(g[lay.rank + 1, 0, :2 * W]); ang[self.row1].copy_(g[lay.rank + 1, 0, 2 * W:])
+
     def scalar(self, idx):
         return float(self.S[idx].item())
 
@@ -213,21 +230,13 @@ class SlabSolver:
             be.unpack(out_idx, be.send)
 
     def _exchange_unknown_ghosts(self):
-        """once per GN step: ghost rows of Offset/Angle <- neighbours' boundary rows"""
+        """once per GN step: ghost rows of the unknowns <- neighbours' boundary rows (backend packs / unpacks)"""
         if not self.use_dist:
             return
-        be, lay = self.be, self.lay
-        W = be.W
-        off = be.offset.view(be.Hl, 2 * W)
-        ang = be.angle.view(be.Hl, W)
-        send = torch.cat([off[be.row0], ang[be.row0], off[be.row1 - 1], ang[be.row1 - 1]])
+        send = self.be.pack_unknowns()
         gath = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
         dist.all_gather_into_tensor(gath, send, group=self.group)
-        g = gath.view(self.world, 2, 3 * W)
-        if lay.top:
-            off[be.row0 - 1].copy_(g[lay.rank - 1, 1, :2 * W]); ang[be.row0 - 1].copy_(g[lay.rank - 1, 1, 2 * W:])
-        if lay.bot:
-            off[be.row1].copy_(g[lay.rank + 1, 0, :2 * W]); ang[be.row1].copy_(g[lay.rank + 1, 0, 2 * W:])
+        self.be.unpack_unknowns(gath.view(self.world, -1))
 
     # -- solver
     def cost(self):

@@ -44,11 +44,11 @@ typedef struct thallo_sum_t {
     int          count;
 } thallo_sum_t;
 
-/* Up to 4 contiguous pieces [off, off+len) (floats) of a flat solver vector: e.g. one image row of the
+/* Up to 8 contiguous pieces [off, off+len) (floats) of a flat solver vector: e.g. one image row of the
    image_warping layout = {2*W*row, 2*W} in the Offset plane + {2*N + W*row, W} in the Angle plane. */
 typedef struct thallo_segs_t {
-    long off[4];
-    long len[4];
+    long off[8];
+    long len[8];
     int  n;
 } thallo_segs_t;
 
@@ -164,7 +164,8 @@ int thallo_hip_lapimg_pcg_step1(int W, int H, float w_fit, int xguard,
  * Per-GN-iteration precomputed planes (allowed by SURVEY.md section 7 step 3):
  *   cs    float2 per pixel = (cos Angle, sin Angle)
  *   flags uint8  per pixel : bit0 = Mask==0 (pixel active, image_warping.t:14-15,23),
- *                            bit1 = fit residual valid (image_warping.t:27)
+ *                            bit1 = fit residual valid (image_warping.t:27),
+ *                            bits2-4 = number of valid neighbour pairs (0..4)
  * Row slabs: W x H is the LOCAL image, which may carry one ghost row above and/or below; the kernels
  * produce outputs for the owned rows [row0,row1) only (row0=0,row1=H for a whole image) and read the
  * ghost rows as stencil halo.  pcg_init also fills cs/flags (and p_prev=0) on ghost rows; the fused
@@ -185,7 +186,13 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
                             int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
-                            const int* irregular, float* alphaD_out, thallo_stream_t stream);
+                            const int* irregular, const float* r, float* alphaD_out, thallo_stream_t stream);
+/* image_warping's PCGStep2 (gauss_newton.t:801-843 minus delta): r -= alpha*Ap, betaN partials = sum (M^-1 r).r over the owned
+ * rows.  When *irregular == 0 (UrShape = unit pixel grid) M^-1 is recomputed from the flags byte and z is NOT written
+ * (37 B/pixel instead of 60) -- pcg_step1 then forms z = M^-1 r from `r` on the fly; otherwise pre is read and z written. */
+int thallo_hip_iw_pcg_step2(int W, int H, int row0, int row1, const unsigned char* flags, float w_fit, float w_reg,
+                            float* r, const float* Ap, const float* pre, float* z,
+                            thallo_sum_t alphaN, thallo_sum_t alphaD, const int* irregular, float* betaN_out, thallo_stream_t stream);
 
 /* ---------------------------------------------------------------- graph-edge domains
  * Incidence lists built by the host from the Sparse maps V0/V1 (device int32 arrays, thallo.t:136) once per

@@ -156,7 +156,7 @@ def test_shim_image_warping_init_and_apply(torch, orc, W, H):
     s0 = api.SumT(parts.data_ptr(), 1)
     nb2 = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                     vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
-                                    1, s0, s0, s0, vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), None)
+                                    1, s0, s0, s0, vp(irregular.data_ptr()), None, vp(parts.data_ptr() + 4096), None)
     assert nb2 > 0
     torch.cuda.synchronize()
     Ap_o, d_o = pr.apply_jtj(v)
@@ -164,6 +164,60 @@ def test_shim_image_warping_init_and_apply(torch, orc, W, H):
     assert (to_host(p1)[:n] == v).all()
     aD = to_host(parts)[1024:1024 + nb2].astype(np.float64).sum()
     assert abs(aD - d_o) <= 1e-5 * abs(d_o)
+
+
+@pytest.mark.parametrize("W,H", [(64, 16), (100, 36), (256, 128)])
+def test_shim_image_warping_zfree_schedule(torch, W, H):
+    """The z-free PCG schedule (UrShape = pixel grid: M^-1 recomputed from the flags byte, z never written) computes the
+    same r, betaN, p and Ap as the general schedule (pre read, z written) -- gauss_newton.t:801-843, 728-799."""
+    L = _shim()
+    p = syn.image_warping(W, H, n_markers=6)
+    N = W * H; n = 3 * N; na = L.thallo_hip_vector_elems(n)
+    dev = to_device(p)
+    f = lambda: torch.zeros(na, dtype=torch.float32, device="cuda")
+    r, pre, z, p0, delta, Ap = f(), f(), f(), f(), f(), f()
+    cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
+    parts = torch.zeros(8 * 1024, dtype=torch.float32, device="cuda")
+    irregular = torch.zeros(16, dtype=torch.int32, device="cuda")
+    vp = C.c_void_p; fl = C.c_float
+    nb = L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+                                  vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
+                                  vp(p0.data_ptr()), vp(delta.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(irregular.data_ptr()), vp(parts.data_ptr()), None)
+    assert nb > 0 and int(irregular[0].item()) == 0
+    # the flags byte reproduces pre bit-exactly: M^-1 r from init == pre * r
+    assert torch.equal(z, pre * r)
+    aN = api.SumT(parts.data_ptr(), nb)
+
+    def one_iteration(zfree):
+        rr, zz, dd, AA, q0, q1 = r.clone(), z.clone(), delta.clone(), f(), p0.clone(), f()
+        PB = parts.data_ptr()
+        rp = vp(rr.data_ptr()) if zfree else None
+        step1 = lambda first, pin, pout, sN, sD, sB, out: L.thallo_hip_iw_pcg_step1(
+            W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]), vp(zz.data_ptr()), vp(pin.data_ptr()),
+            vp(pout.data_ptr()), vp(dd.data_ptr()), vp(AA.data_ptr()), first, sN, sD, sB, vp(irregular.data_ptr()), rp, vp(out), None)
+        nD = step1(1, q0, q1, aN, aN, aN, PB + 4096); assert nD > 0
+        aD = api.SumT(PB + 4096, nD)
+        if zfree:
+            nB = L.thallo_hip_iw_pcg_step2(W, H, 0, H, vp(flags.data_ptr()), fl(p[5]), fl(p[6]), vp(rr.data_ptr()), vp(AA.data_ptr()), vp(pre.data_ptr()),
+                                           vp(zz.data_ptr()), aN, aD, vp(irregular.data_ptr()), vp(PB + 8192), None)
+        else:
+            nB = L.thallo_hip_pcg_step2(vp(rr.data_ptr()), vp(AA.data_ptr()), vp(pre.data_ptr()), vp(zz.data_ptr()), C.c_long(n), aN, aD, vp(PB + 8192), None)
+        assert nB > 0
+        bN = api.SumT(PB + 8192, nB)
+        A2 = f()
+        step1b = lambda: L.thallo_hip_iw_pcg_step1(
+            W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]), vp(zz.data_ptr()), vp(q1.data_ptr()),
+            vp(q0.data_ptr()), vp(dd.data_ptr()), vp(A2.data_ptr()), 0, aN, aD, bN, vp(irregular.data_ptr()), rp, vp(PB + 12288), None)
+        nD2 = step1b(); assert nD2 > 0
+        torch.cuda.synchronize()
+        return (rr[:n].clone(), parts[2048:2048 + nB].double().sum().item(), q0[:n].clone(), A2[:n].clone(), dd[:n].clone(),
+                parts[3072:3072 + nD2].double().sum().item(), zz[:n].clone())
+    a = one_iteration(True); b = one_iteration(False)
+    assert torch.equal(a[6], z[:n])                                   # z untouched by the z-free schedule
+    tol = lambda x, y: (x - y).abs().max().item() <= 2e-6 * max(y.abs().max().item(), 1e-30)
+    assert tol(a[0], b[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(b[1])  # r, betaN
+    assert tol(a[2], b[2]) and tol(a[3], b[3]) and tol(a[4], b[4])    # p_1, A p_1, delta
+    assert abs(a[5] - b[5]) <= 1e-5 * abs(b[5])                       # alphaD_1
 
 
 # ------------------------------------------------------------------ size-independent properties at full size
@@ -194,7 +248,7 @@ def test_full_size_properties_2048(torch):
     def apply(vec, out):
         nb = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                        vp(vec.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(out.data_ptr()),
-                                       1, s0, s0, s0, vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), None)
+                                       1, s0, s0, s0, vp(irregular.data_ptr()), None, vp(parts.data_ptr() + 4096), None)
         assert nb > 0
         torch.cuda.synchronize()
         return parts[1024:1024 + nb].double().sum().item()

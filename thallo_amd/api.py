@@ -35,7 +35,7 @@ class SumT(C.Structure):      # thallo_sum_t of include/thallo_hip.h
 
 
 class SegsT(C.Structure):     # thallo_segs_t of include/thallo_hip.h
-    _fields_ = [("off", C.c_long * 4), ("len", C.c_long * 4), ("n", C.c_int)]
+    _fields_ = [("off", C.c_long * 8), ("len", C.c_long * 8), ("n", C.c_int)]
 
 
 INT_PARAMS = ("nIterations", "lIterations", "residual_reset_period", "nIter")
@@ -82,7 +82,8 @@ def lib():
     L.thallo_hip_finish_sum.argtypes = [SumT, vp, vp]
     L.thallo_hip_iw_cost.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp]
     L.thallo_hip_iw_pcg_init.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, vp, vp, vp]
+    L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, vp, vp, vp, vp]
+    L.thallo_hip_iw_pcg_step2.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, vp, vp, SumT, SumT, vp, vp, vp]
     L.thallo_hip_iw_apply_jtj.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp]
     L.thallo_hip_pcg_step2.argtypes = [vp, vp, vp, vp, cl, SumT, SumT, vp, vp]
     L.thallo_hip_pcg_step2_ranges.argtypes = [vp, vp, vp, vp, cl, cl, cl, cl, SumT, SumT, vp, vp]

@@ -75,6 +75,19 @@ struct Tile {
     unsigned char f[LN + 4];        // bit0 active (Mask==0), bit1 fit-valid
 };
 
+// flags byte: bit0 pixel active (Mask==0), bit1 fit residual valid, bits2-4 = number of valid neighbour pairs (0..4).
+// With UrShape on the unit pixel grid (GRID path) diag(J^T J) is a function of this byte alone:
+//   offset channels: w_reg^2 * 2*cnt + w_fit^2 [fit]      angle channel: w_reg^2 * cnt   (|R'(a) du|^2 = |du|^2 = 1)
+// so the GRID path never reads `pre` and never materialises z = M^-1 r: both are recomputed from r and the flags byte.
+__device__ __forceinline__ void pre_from_flags(unsigned char f, float wf2, float wr2, float& mo, float& ma)
+{
+    if (!(f & 1)) { mo = 0.0f; ma = 0.0f; return; }
+    const float cnt = (float)((f >> 2) & 7);
+    float dgo = (2.0f * cnt) * wr2;
+    if (f & 2) dgo += wf2;
+    mo = guarded_invert(dgo); ma = guarded_invert(cnt * wr2);
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct Owned { float2 zv, pv, dv, csv, uv; float zav, pav, da; unsigned char ff; };
@@ -92,7 +105,7 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
                                            float* __restrict__ Ap, int first,
                                            thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
                                            float* __restrict__ aD_out, int dbg)
-{
+{   // GRID: `z` points at r, and z = M^-1 r is formed here from the flags byte (pre_from_flags)
     constexpr int PER = TH / (NT / TW);                    // owned pixels per thread (one column): 4 at 256 threads, 2 at 512
     const int ntm = dbg >> 8; dbg &= 0xff;
     const bool nt_delta = ntm & 1, nt_const = ntm & 2, nt_pin = ntm & 4, nt_ap = ntm & 8, nt_z = ntm & 32, nt_pout = ntm & 64;
@@ -176,7 +189,9 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
             if (ow_ld[k]) {
                 const long pix = (long)(y0 + ty + k) * g.W + gx;
                 if (FUSED) {
-                    npx = ow[k].zv.x + beta * ow[k].pv.x; npy = ow[k].zv.y + beta * ow[k].pv.y; npa = ow[k].zav + beta * ow[k].pav;
+                    float zx = ow[k].zv.x, zy = ow[k].zv.y, zq = ow[k].zav;
+                    if (GRID) { float mo, ma; pre_from_flags(ow[k].ff, wf2, wr2, mo, ma); zx *= mo; zy *= mo; zq *= ma; }
+                    npx = zx + beta * ow[k].pv.x; npy = zy + beta * ow[k].pv.y; npa = zq + beta * ow[k].pav;
                     stf2(qo + pix, make_float2(npx, npy), nt_pout); stf(qa + pix, npa, nt_pout);      // owned, or ghost row kept current
                     if (!first && ow_in[k]) {
                         stf2(dlo + pix, make_float2(ow[k].dv.x + alpha * ow[k].pv.x, ow[k].dv.y + alpha * ow[k].pv.y), nt_delta);
@@ -195,7 +210,9 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
             float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1 = 0.f, u1 = 0.f, u2 = 0.f; unsigned char ff = 0;
             if (hl_in) {
                 if (FUSED) {
-                    npx = hl.zv.x + beta * hl.pv.x; npy = hl.zv.y + beta * hl.pv.y; npa = hl.zav + beta * hl.pav;
+                    float zx = hl.zv.x, zy = hl.zv.y, zq = hl.zav;
+                    if (GRID) { float mo, ma; pre_from_flags(hl.ff, wf2, wr2, mo, ma); zx *= mo; zy *= mo; zq *= ma; }
+                    npx = zx + beta * hl.pv.x; npy = zy + beta * hl.pv.y; npa = zq + beta * hl.pav;
                     // ghost row of a slab (not owned by any tile of this rank): keep its p current
                     const int hy = y0 + hly - 1;
                     if ((hy < g.row0 || hy >= g.row1) && hlx >= 1 && hlx <= TW) {
@@ -261,14 +278,58 @@ __global__ __launch_bounds__(NT, MINW) void k_step1(Geo g, const float2* __restr
                                                         float* __restrict__ p_out, float* __restrict__ delta,
                                                         float* __restrict__ Ap, int first,
                                                         thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                                                        float* __restrict__ aD_out, int dbg, const int* __restrict__ irregular)
+                                                        float* __restrict__ aD_out, int dbg, const int* __restrict__ irregular,
+                                                        const float* __restrict__ r)
 {
     __shared__ Tile T;
     __shared__ float red[16];
     // `irregular` = number of pixels whose UrShape neighbours are not at unit offsets (written by pcg_init); wave-uniform
     const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
-    if (grid) step1_body<FUSED, true, NT>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
+    if (grid) step1_body<FUSED, true, NT>(T, red, g, cs, ur, flags, wf2, wr2, FUSED ? r : z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
     else      step1_body<FUSED, false, NT>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
+}
+
+// ------------------------------------------------------------------------------------------ PCGStep2
+// gauss_newton.t:801-843 without the delta half (fused into the next PCGStep1).  On the GRID path M^-1 comes from the
+// flags byte and z is not written: reads r 12, Ap 12, flags 1; writes r 12 = 37 B/pixel instead of 60.
+// Otherwise the generic form (reads pre, writes z).  Two float4 ranges: Offset plane rows, Angle plane rows.
+__global__ __launch_bounds__(BLOCK) void k_step2_iw(float4* __restrict__ r, const float4* __restrict__ Ap, const float4* __restrict__ pre,
+                                                     float4* __restrict__ z, const unsigned char* __restrict__ flags, long N, float wf2, float wr2,
+                                                     long off0, long len0, long off1, long len1,
+                                                     thallo_sum_t aN, thallo_sum_t aD, const int* __restrict__ irregular, float* __restrict__ bN_out)
+{
+    __shared__ float red[16];
+    const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
+    const float alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
+    float acc = 0.0f;
+    const long n4 = len0 + len1;
+    for (long j = (long)blockIdx.x * BLOCK + threadIdx.x; j < n4; j += (long)gridDim.x * BLOCK) {
+        const bool in_off = j < len0;
+        const long i = in_off ? off0 + j : off1 + (j - len0);
+        float4 rv = ldf4(r + i, true);
+        const float4 av = Ap[i];
+        rv.x -= alpha * av.x; rv.y -= alpha * av.y; rv.z -= alpha * av.z; rv.w -= alpha * av.w;
+        float4 m;
+        if (grid) {
+            if (in_off) {               // elements 4i..4i+3 of the Offset plane = pixels 2i, 2i+1 (x,y each)
+                const unsigned f2 = reinterpret_cast<const unsigned short*>(flags)[i];
+                float m0, m1, dummy;
+                pre_from_flags((unsigned char)(f2 & 255), wf2, wr2, m0, dummy); pre_from_flags((unsigned char)(f2 >> 8), wf2, wr2, m1, dummy);
+                m = make_float4(m0, m0, m1, m1);
+            } else {                    // Angle plane: element e -> pixel e - 2N (a multiple of 4: 2N % 4 == 0)
+                const unsigned f4 = reinterpret_cast<const unsigned*>(flags)[i - N / 2];
+                float d, a0, a1, a2, a3;
+                pre_from_flags((unsigned char)(f4 & 255), wf2, wr2, d, a0); pre_from_flags((unsigned char)((f4 >> 8) & 255), wf2, wr2, d, a1);
+                pre_from_flags((unsigned char)((f4 >> 16) & 255), wf2, wr2, d, a2); pre_from_flags((unsigned char)(f4 >> 24), wf2, wr2, d, a3);
+                m = make_float4(a0, a1, a2, a3);
+            }
+        } else m = pre[i];
+        const float4 zv = make_float4(m.x * rv.x, m.y * rv.y, m.z * rv.z, m.w * rv.w);
+        stf4(r + i, rv, true);
+        if (!grid) z[i] = zv;
+        acc += zv.x * rv.x + zv.y * rv.y + zv.z * rv.z + zv.w * rv.w;
+    }
+    block_store_partial(acc, bN_out, red);
 }
 
 // ------------------------------------------------------------------------------------------ PCGInit1 (+_Finish)
@@ -326,12 +387,15 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
                 if (act) {
                     const float oxi = T.px[i], oyi = T.py[i], ci = T.c[i], si = T.s[i], uxi = T.ux[i], uyi = T.uy[i];
                     float jx = 0.f, jy = 0.f, ja = 0.f, dgo = 0.f, dga = 0.f;
+                    int cnt = 0; bool unit = true;
                     const int nb[4] = { i + 1, i - 1, i + LW, i - LW };
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int j = nb[d];
                         if (T.f[j] & 1) {
                             const float dux = uxi - T.ux[j], duy = uyi - T.uy[j];
+                            unit = unit && dux == (d == 0 ? -1.0f : d == 1 ? 1.0f : 0.0f) && duy == (d == 2 ? -1.0f : d == 3 ? 1.0f : 0.0f);
+                            ++cnt;
                             const float dox = oxi - T.px[j], doy = oyi - T.py[j];
                             // e_i = (o_i-o_j) - R(a_i)(u_i-u_j) ; e_j = (o_j-o_i) - R(a_j)(u_j-u_i)
                             const float eix = dox - (ci * dux - si * duy), eiy = doy - (si * dux + ci * duy);
@@ -344,6 +408,8 @@ __global__ __launch_bounds__(BLOCK) void k_init(Geo g, const float2* __restrict_
                         }
                     }
                     jx *= wr2; jy *= wr2; ja *= wr2; dgo *= wr2; dga *= wr2;
+                    if (unit) dga = (float)cnt * wr2;      // |R'(a) du|^2 = 1 exactly on the unit grid (same value the GRID step path recomputes)
+                    fl |= (unsigned char)(cnt << 2);
                     const float2 cv = cons[pix];
                     if (cv.x >= 0.0f && cv.y >= 0.0f) {            // image_warping.t:27 (Mask==0 already holds)
                         fl |= 2;
@@ -455,8 +521,9 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
                             int first, thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                            const int* irregular, float* aD_out, thallo_stream_t stream)
+                            const int* irregular, const float* r, float* aD_out, thallo_stream_t stream)
 {
+    if (!r || ((2L * W * H) & 3)) irregular = nullptr;      // the z-free path needs r and 16-byte planes
     if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1);
     int grid;
@@ -464,13 +531,32 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
         grid = grid_for(g, g_step1_per_cu > 2 ? 2 : g_step1_per_cu);
         hipLaunchKernelGGL((k_step1<true, 4, 512>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g,
                            (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular);
+                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular, r);
     } else {                            // 3 workgroups of 4 waves per CU (165 VGPRs)
         grid = grid_for(g, g_step1_per_cu);
         hipLaunchKernelGGL((k_step1<true, 3, 256>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                            (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular);
+                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular, r);
     }
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_iw_pcg_step2(int W, int H, int row0, int row1, const unsigned char* flags, float w_fit, float w_reg,
+                            float* r, const float* Ap, const float* pre, float* z,
+                            thallo_sum_t aN, thallo_sum_t aD, const int* irregular, float* bN_out, thallo_stream_t stream)
+{
+    if (!rows_ok(H, row0, row1)) return -(int)hipErrorInvalidValue;
+    const long N = (long)W * H, rows = row1 - row0;
+    const long off0 = 2L * W * row0, len0 = 2L * W * rows, off1 = 2 * N + (long)W * row0, len1 = (long)W * rows;
+    if (g_no_grid || ((off0 | len0 | off1 | len1 | (2 * N)) & 3)) {     // not 16-byte granular: the generic kernels (read pre, write z)
+        if (row0 == 0 && row1 == H) return thallo_hip_pcg_step2(r, Ap, pre, z, 3 * N, aN, aD, bN_out, stream);
+        return thallo_hip_pcg_step2_ranges(r, Ap, pre, z, off0, len0, off1, len1, aN, aD, bN_out, stream);
+    }
+    long want = ((len0 + len1) / 4 + BLOCK - 1) / BLOCK;
+    int grid = thallo_hip_device_cu_count() * 4; if (grid > THALLO_MAX_PARTIALS) grid = THALLO_MAX_PARTIALS; grid -= grid % 8;
+    if (want < grid) grid = (int)(want < 1 ? 1 : want);
+    hipLaunchKernelGGL(k_step2_iw, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z,
+                       flags, N, w_fit * w_fit, w_reg * w_reg, off0 / 4, len0 / 4, off1 / 4, len1 / 4, aN, aD, irregular, bN_out);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -483,7 +569,7 @@ int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, c
     /* z / p_out / delta are unused when !FUSED: pass valid dummies */
     hipLaunchKernelGGL((k_step1<false, 4, 256>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                       p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug, g_no_grid ? nullptr : irregular);
+                       p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug, g_no_grid ? nullptr : irregular, p);
     int e = check_launch(); return e ? e : grid;
 }
 

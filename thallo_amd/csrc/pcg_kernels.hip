@@ -468,7 +468,7 @@ int thallo_hip_finish_sum(thallo_sum_t sum, float* out, thallo_stream_t stream)
 
 int thallo_hip_slab_pack(const float* vec, thallo_segs_t segs, thallo_sum_t sum, float* out, thallo_stream_t stream)
 {
-    if (segs.n < 0 || segs.n > 4) return -(int)hipErrorInvalidValue;
+    if (segs.n < 0 || segs.n > 8) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_slab_pack, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, segs, sum, out);
     return check_launch();
 }
@@ -476,7 +476,7 @@ int thallo_hip_slab_pack(const float* vec, thallo_segs_t segs, thallo_sum_t sum,
 int thallo_hip_slab_unpack(float* vec, thallo_segs_t top, const float* src_top, thallo_segs_t bot, const float* src_bot,
                            const float* gathered, long stride, int world, float* sum_out, thallo_stream_t stream)
 {
-    if (top.n < 0 || top.n > 4 || bot.n < 0 || bot.n > 4) return -(int)hipErrorInvalidValue;
+    if (top.n < 0 || top.n > 8 || bot.n < 0 || bot.n > 8) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_slab_unpack, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, top, src_top, bot, src_bot, gathered, stride, world, sum_out);
     return check_launch();
 }

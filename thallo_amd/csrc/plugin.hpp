@@ -81,6 +81,12 @@ public:
     // fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k): reads p[cur], writes p[cur^1], Ap, alphaD partials
     virtual int pcg_step1(LaunchCtx&, SolverVectors&, int cur, bool first,
                           thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev, float* alphaD_out) = 0;
+    // PCGStep2 (r -= alpha Ap, z = M^-1 r, betaN partials); default = the energy-independent flat kernel
+    virtual int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* betaN_out)
+    {
+        TimedLaunch t(c, "PCGStep2");
+        return thallo_hip_pcg_step2(v.r, v.Ap, use_preconditioner() ? v.pre : nullptr, v.z, v.n, aN, aD, betaN_out, c.stream);
+    }
     // pointer to unknown image k as currently bound
     virtual float* unknown_ptr(int k) = 0;
 };

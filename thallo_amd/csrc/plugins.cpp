@@ -88,7 +88,12 @@ public:
     {
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_iw_pcg_step1(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
-                                       v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, (const int*)irregular.ptr, out, c.stream);
+                                       v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, (const int*)irregular.ptr, v.r, out, c.stream);
+    }
+    int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep2");
+        return thallo_hip_iw_pcg_step2(W, H, 0, H, (const unsigned char*)flags.ptr, w_fit, w_reg, v.r, v.Ap, v.pre, v.z, aN, aD, (const int*)irregular.ptr, out, c.stream);
     }
 };
 

@@ -279,11 +279,7 @@ int Plan::step_gn(int ev_iter)
         nb = plugin->pcg_step1(ctx, v_, cur_, k == 0, aNp, aDp, bNp, slot(jD));
         if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
         nb_[jD] = nb; cur_ ^= 1;
-        {   // PCGStep2 (r, z, betaN)
-            TimedLaunch t(ctx, "PCGStep2");
-            nb = thallo_hip_pcg_step2(v_.r, v_.Ap, plugin->use_preconditioner() ? v_.pre : nullptr, v_.z, v_.n,
-                                      sum(jN), sum(jD), slot(jB), s);
-        }
+        nb = plugin->pcg_step2(ctx, v_, sum(jN), sum(jD), slot(jB));      // PCGStep2 (r, z, betaN)
         if (nb < 0) { set_error("PCGStep2 launch failed (%d)", nb); return 0; }
         nb_[jB] = nb;
     }

@@ -97,7 +97,10 @@ class HipSlabBackend:
         self.N, self.n = N, 3 * N
         na = self.L.thallo_hip_vector_elems(self.n)
         z = lambda: torch.zeros(na, dtype=torch.float32, device=dev)
-        self.r, self.pre, self.z, self.delta, self.Ap = z(), z(), z(), z(), z()
+        self.rz = torch.zeros(2 * na, dtype=torch.float32, device=dev)          # r and z share one allocation: one pack/unpack covers both
+        self.r, self.z = self.rz[:na], self.rz[na:]
+        self.na = na
+        self.pre, self.delta, self.Ap = z(), z(), z()
         self.p = [z(), z()]
         self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
@@ -105,14 +108,17 @@ class HipSlabBackend:
         self.parts = torch.zeros(1024, dtype=torch.float32, device=dev)      # local partials of the current reduction
         self.nb = 1
         self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32, device=dev)    # global (all-reduced) scalars
-        self.msg = 1 + 6 * W
+        self.msg = 1 + 12 * W                                                   # [sum | first row: r, z | last row: r, z]
         self.send = torch.zeros(self.msg, dtype=torch.float32, device=dev)
         self.gath = torch.zeros(layout.world * self.msg, dtype=torch.float32, device=dev)
         # flat-layout pieces: Offset plane [2*W*row, 2W), Angle plane [2N + W*row, W)
-        row = lambda y: [(2 * W * y, 2 * W), (2 * N + W * y, W)]
-        self.seg_first_last = _segs(row(self.row0) + row(self.row1 - 1))
-        self.seg_top_ghost = _segs(row(self.row0 - 1)) if layout.top else _segs([])
-        self.seg_bot_ghost = _segs(row(self.row1)) if layout.bot else _segs([])
+        # (relative to rz: r at 0, z at na).  The z-free GRID schedule consumes the r rows, the general schedule the z rows;
+        # which one runs is a device-side word (irregular), so both travel.
+        row = lambda y, b=0: [(b + 2 * W * y, 2 * W), (b + 2 * N + W * y, W)]
+        both = lambda y0, y1: row(y0) + row(y0, na) + row(y1) + row(y1, na)
+        self.seg_first_last = _segs(both(self.row0, self.row1 - 1))
+        self.seg_top_ghost = _segs(row(self.row0 - 1) + row(self.row0 - 1, na)) if layout.top else _segs([])
+        self.seg_bot_ghost = _segs(row(self.row1) + row(self.row1, na)) if layout.bot else _segs([])
         if W % 4 or (2 * N) % 4:
             raise ValueError("the slab path needs W % 4 == 0 (16-byte row granules in the flat kernels)")
 
@@ -153,30 +159,28 @@ class HipSlabBackend:
             self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
             fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
             vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), 1 if first else 0, self._sum(iN), self._sum(iD), self._sum(iB),
-            vp(self.irregular.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
+            vp(self.irregular.data_ptr()), vp(self.r.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
         self._chk(self.L.thallo_hip_finish_sum(self._local(), vp(self.S.data_ptr() + 4 * out_idx), self._st()), "finish_sum")
 
     def step2(self, iN, iD):
-        vp = C.c_void_p
-        W, N = self.W, self.N
-        rows = self.row1 - self.row0
-        self.nb = self._chk(self.L.thallo_hip_pcg_step2_ranges(
+        vp, fl = C.c_void_p, C.c_float
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step2(
+            self.W, self.Hl, self.row0, self.row1, vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
             vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()),
-            C.c_long(2 * W * self.row0), C.c_long(2 * W * rows), C.c_long(2 * N + W * self.row0), C.c_long(W * rows),
-            self._sum(iN), self._sum(iD), vp(self.parts.data_ptr()), self._st()), "pcg_step2_ranges")
+            self._sum(iN), self._sum(iD), vp(self.irregular.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step2")
 
     def pack(self):
-        """send = [sum(local partials) | first owned row of z | last owned row of z]"""
-        self._chk(self.L.thallo_hip_slab_pack(C.c_void_p(self.z.data_ptr()), self.seg_first_last, self._local(),
+        """send = [sum(local partials) | first owned row of r, of z | last owned row of r, of z]"""
+        self._chk(self.L.thallo_hip_slab_pack(C.c_void_p(self.rz.data_ptr()), self.seg_first_last, self._local(),
                                               C.c_void_p(self.send.data_ptr()), self._st()), "slab_pack")
 
     def unpack(self, out_idx, gathered):
         lay, msg = self.lay, self.msg
         base = gathered.data_ptr()
         # my top ghost row <- the LAST owned row of rank-1 ; my bottom ghost row <- the FIRST owned row of rank+1
-        src_top = C.c_void_p(base + 4 * ((lay.rank - 1) * msg + 1 + 3 * self.W)) if lay.top else None
+        src_top = C.c_void_p(base + 4 * ((lay.rank - 1) * msg + 1 + 6 * self.W)) if lay.top else None
         src_bot = C.c_void_p(base + 4 * ((lay.rank + 1) * msg + 1)) if lay.bot else None
-        self._chk(self.L.thallo_hip_slab_unpack(C.c_void_p(self.z.data_ptr()), self.seg_top_ghost, src_top, self.seg_bot_ghost, src_bot,
+        self._chk(self.L.thallo_hip_slab_unpack(C.c_void_p(self.rz.data_ptr()), self.seg_top_ghost, src_top, self.seg_bot_ghost, src_bot,
                                                 C.c_void_p(base), C.c_long(msg), lay.world, C.c_void_p(self.S.data_ptr() + 4 * out_idx), self._st()),
                   "slab_unpack")
 
@@ -188,6 +192,20 @@ class HipSlabBackend:
             p_ptr = vp(self.p[cur].data_ptr() + 4 * off) if with_p else None
             self._chk(self.L.thallo_hip_linear_update(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off), p_ptr, C.c_long(ln),
                                                       self._sum(iN), self._sum(iD), self._st()), "linear_update")
+
+    def pack_grid_info(self):
+        """uint8 [irregular word (4 bytes) | flags of the first owned row | flags of the last owned row]"""
+        W = self.W
+        return torch.cat([self.irregular[:1].view(torch.uint8), self.flags[W * self.row0:W * (self.row0 + 1)],
+                          self.flags[W * (self.row1 - 1):W * self.row1]])
+
+    def unpack_grid_info(self, g):
+        W, lay = self.W, self.lay
+        self.irregular[:1].copy_(g[:, :4].contiguous().view(torch.int32).clamp_(max=1).sum())
+        if lay.top:
+            self.flags[W * (self.row0 - 1):W * self.row0].copy_(g[lay.rank - 1, 4 + W:4 + 2 * W])
+        if lay.bot:
+            self.flags[W * self.row1:W * (self.row1 + 1)].copy_(g[lay.rank + 1, 4:4 + W])
 
     def pack_unknowns(self):
         W = self.W
@@ -250,6 +268,13 @@ class SlabSolver:
         B, L = 2, l_iters
         cur = 0
         be.init(cur)                                   # local alphaN partials, z, ...
+        if self.use_dist and hasattr(be, "pack_grid_info"):
+            # every rank must pick the same PCG schedule (z-free iff UrShape is the pixel grid everywhere), and the ghost rows
+            # need their owner's flags byte (M^-1 of a ghost pixel depends on rows this rank does not hold)
+            send = be.pack_grid_info()
+            gath = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
+            dist.all_gather_into_tensor(gath, send, group=self.group)
+            be.unpack_grid_info(gath.view(self.world, -1))
         self._gather_sum_and_rows(B)                   # S[B] = alphaN_0 (global); ghost rows of z
         for k in range(L):
             jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2

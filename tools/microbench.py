@@ -44,10 +44,10 @@ def timeit(fn, reps=REPS):
     return e0.elapsed_time(e1) / reps * 1e3   # us
 
 
-def step1_fused(first=0):
+def step1_fused(first=0, zfree=True):
     nb = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                    vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
-                                   first, s_aN, s_aN, s_aN, vp(irregular.data_ptr()), vp(PB + 4096), None)
+                                   first, s_aN, s_aN, s_aN, vp(irregular.data_ptr()), vp(r.data_ptr()) if zfree else None, vp(PB + 4096), None)
     assert nb > 0
     return nb
 
@@ -67,6 +67,11 @@ def step2():
     assert L.thallo_hip_pcg_step2(vp(r.data_ptr()), vp(Ap.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()), C.c_long(n), s_aN, s_aD, vp(PB + 8192), None) > 0
 
 
+def step2_iw():
+    assert L.thallo_hip_iw_pcg_step2(W, H, 0, H, vp(flags.data_ptr()), fl(p[5]), fl(p[6]), vp(r.data_ptr()), vp(Ap.data_ptr()), vp(pre.data_ptr()),
+                                     vp(z.data_ptr()), s_aN, s_aD, vp(irregular.data_ptr()), vp(PB + 8192), None) > 0
+
+
 res = {}
 MB = 1e-6
 for nogrid in (0, 1):
@@ -78,6 +83,9 @@ for nogrid in (0, 1):
 L.thallo_hip_debug_set(0, 0); L.thallo_hip_debug_set(4, 0)
 res["step1_fused_dbg0_us"] = timeit(step1_fused); res["step1_plain_dbg0_us"] = timeit(step1_plain)
 res["step2_us"] = timeit(step2)
+res["step2_iw_zfree_us"] = timeit(step2_iw)
+res["step1_fused_general_us"] = timeit(lambda: step1_fused(0, False))
+res["step2_iw_zfree_alg37_GBs"] = 37 * N / res["step2_iw_zfree_us"] * 1e-3
 # HBM references with torch: copy (read 50 MB + write 50 MB) and 3-read/2-write elementwise
 a = torch.randn(na, device="cuda"); b = torch.randn(na, device="cuda"); c = torch.empty(na, device="cuda")
 res["torch_copy_us"] = timeit(lambda: c.copy_(a))

@@ -7,7 +7,8 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
-ks = glob.glob(os.path.join(g, "prof_kt", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # gpurun_out/ accumulates earlier runs
+ks = newest(os.path.join(g, "prof_kt", "*", "*_kernel_stats.csv"))
 shutil.copy(ks, os.path.join(out, "bench_kernel_stats.csv"))
 for f in ("bench_under_rocprof.json", "bench_plain.json"):
     if os.path.exists(os.path.join(g, f)):
@@ -15,7 +16,7 @@ for f in ("bench_under_rocprof.json", "bench_plain.json"):
 
 
 def short(name):
-    for key, lab in (("k_step1<true", "PCGStep1_fused"), ("k_step1<false", "applyJTJ_plain"), ("k_step2<", "PCGStep2"), ("k_init", "PCGInit1"),
+    for key, lab in (("k_step1<true", "PCGStep1_fused"), ("k_step1<false", "applyJTJ_plain"), ("k_step2_iw", "PCGStep2"), ("k_step2<", "PCGStep2_generic"), ("k_init", "PCGInit1"),
                      ("k_linear_update", "PCGLinearUpdate"), ("k_cost", "computeCost")):
         if key in name:
             return lab
@@ -24,7 +25,7 @@ def short(name):
 
 pmc = {}
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(g, f"prof_{kind}", "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(g, f"prof_{kind}", "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
         lab = short(row["Kernel_Name"])

@@ -52,6 +52,21 @@ typedef struct thallo_segs_t {
     int  n;
 } thallo_segs_t;
 
+/* Multi-GPU (one process per GPU) device-side exchange: every rank owns a mailbox of 8-byte granules
+   {float value | seq << 32} indexed [slot][source rank]; producers store one granule into EVERY rank's mailbox with
+   peer-to-peer stores over xGMI, consumers poll their own.  Replaces a host-driven all-reduce per PCG scalar
+   (SURVEY.md 8e).  Pointers in peer_* are the peers' allocations mapped into this process (thallo_hip_ipc_open). */
+#define THALLO_DIST_MAX_WORLD 8
+typedef struct thallo_dist_t {
+    unsigned long long* mail;                               /* == peer_mail[rank] */
+    unsigned long long* peer_mail[THALLO_DIST_MAX_WORLD];
+    float*    peer_r[2];         /* image slabs: the r vector of rank-1 / rank+1 (NULL at the image border) */
+    long      peer_off_o[2];     /* element offset of my row's landing place (that peer's ghost row), Offset plane */
+    long      peer_off_a[2];     /* ... Angle plane */
+    unsigned* ctl;               /* device words: [0] sequence number (GN step counter), [1] error (spin timeout), [2] ticket */
+    int       world, rank;
+} thallo_dist_t;
+
 long thallo_hip_vector_elems(long n_unknowns);          /* n rounded up to a multiple of 256 */
 int  thallo_hip_device_cu_count(void);                  /* multiprocessor count of the current device */
 
@@ -282,6 +297,32 @@ int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, c
  * 5 = workgroups per CU, 6 = threads per workgroup (256 | 512).  thallo_hip_debug_set2(bits): cache policy of PCGStep2. */
 void thallo_hip_debug_set(int what, int value);
 void thallo_hip_debug_set2(int value);
+
+/* ---------------------------------------------------------------- multi-GPU device-side exchange (one process per GPU) */
+/* Device memory that other processes can map: *ptr = hipMalloc(bytes) (zeroed), handle_out = 64-byte hipIpcMemHandle_t. */
+int thallo_hip_ipc_alloc(long bytes, void** ptr, void* handle_out64);
+int thallo_hip_ipc_open(const void* handle64, void** ptr);      /* maps a peer's allocation (enables peer access lazily) */
+int thallo_hip_ipc_close(void* ptr);
+int thallo_hip_ipc_free(void* ptr);
+/* seq += 1 (start of a GN step); error word untouched */
+int thallo_hip_dist_begin_step(thallo_dist_t d, thallo_stream_t stream);
+/* local mailbox slot <- {value[0] from rank 0, 0 from the others} with the current seq: injects a scalar every rank already
+   agrees on (alphaN_0 after the once-per-GN-step collective) */
+int thallo_hip_dist_seed(thallo_dist_t d, int slot, const float* value, thallo_stream_t stream);
+/* out[j] = rank-ordered sum of slot slot0+j for j < nslots (waits for each) */
+int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, thallo_stream_t stream);
+/* host-side read / clear of the error word (synchronises the stream) */
+int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream);
+/* image_warping PCGStep1 / PCGStep2 over a row slab with the exchange built in (z-free schedule only: UrShape must be the
+   unit pixel grid on every rank).  Scalars come from mailbox slots; step2 additionally stores its first / last owned row of
+   r into the neighbours' ghost rows before publishing betaN. */
+int thallo_hip_iw_pcg_step1_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                 const float* r, const float* p_in, float* p_out, float* delta, float* Ap, int first,
+                                 thallo_dist_t d, int slot_aN_prev, int slot_aD_prev, int slot_bN_prev, int slot_aD_out,
+                                 float* partials, thallo_stream_t stream);
+int thallo_hip_iw_pcg_step2_dist(int W, int H, int row0, int row1, const unsigned char* flags, float w_fit, float w_reg,
+                                 float* r, const float* Ap, thallo_dist_t d, int slot_aN, int slot_aD, int slot_bN_out,
+                                 float* partials, thallo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,54 @@ def _worker(rank, world, port, W, H, nit, lit, q):
         dist.destroy_process_group()
 
 
+def _worker_p2p(rank, world, port, W, H, nit, lit, q):
+    import torch
+    import torch.distributed as dist
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed import make_hip_solver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.image_warping(W, H, n_markers=8)
+        solver, lay = make_hip_solver(p, W, H, rank, world, lit, ipc=True)
+        on = solver.try_enable_p2p(l_iters=min(6, lit))
+        costs = solver.solve(nit, lit)
+        be = solver.be
+        err = be.p2p_error() if on else -1
+        trace = be.S[2:2 + 2 * lit + 1].cpu().numpy()
+        off = be.offset.view(be.Hl, W, 2)[lay.row0:lay.row1].cpu().numpy()
+        ang = be.angle.view(be.Hl, W)[lay.row0:lay.row1].cpu().numpy()
+        q.put((rank, costs, lay.g0, lay.g1, off, ang, on, dict(solver.p2p_check, post_mortem=getattr(be, 'p2p_post_mortem', None)), err, trace))
+        be.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,nit,lit", [(2, 128, 96, 3, 30), (3, 64, 100, 2, 20), (1, 64, 48, 2, 10)])
+def test_hip_slabs_p2p_mailbox_exchange(orc, world, W, H, nit, lit):
+    """The device-side exchange (mailbox granules + peer-to-peer ghost rows, csrc/dist_device.hpp) between `world` processes --
+    here all on GPU 0, mapped through hipIpc like real peers: it must enable itself (self-check against the collective path),
+    never time out, give every rank bit-identical alpha/beta, and follow the oracle's cost trajectory."""
+    import torch.multiprocessing as mp
+    from thallo_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_p2p, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    p = syn.image_warping(W, H, n_markers=8)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, g0, g1, off, ang, on, check, err, trace in res:
+        assert on, (rank, check)
+        assert err == 0, (rank, check)
+        assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
+        assert (trace == res[0][9]).all()          # rank-ordered sums: identical bits on every rank
+
+
 @pytest.mark.parametrize("world,W,H,nit,lit", [(2, 128, 96, 3, 30), (3, 64, 100, 2, 20), (2, 256, 256, 2, 40)])
 def test_hip_slabs_match_oracle(orc, world, W, H, nit, lit):
     import torch.multiprocessing as mp

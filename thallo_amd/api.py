@@ -34,6 +34,12 @@ class SumT(C.Structure):      # thallo_sum_t of include/thallo_hip.h
     _fields_ = [("partials", C.c_void_p), ("count", C.c_int)]
 
 
+class DistT(C.Structure):
+    """thallo_dist_t (include/thallo_hip.h): mailboxes + neighbour r vectors of the device-side multi-GPU exchange"""
+    _fields_ = [("mail", C.c_void_p), ("peer_mail", C.c_void_p * 8), ("peer_r", C.c_void_p * 2), ("peer_off_o", C.c_long * 2),
+                ("peer_off_a", C.c_long * 2), ("ctl", C.c_void_p), ("world", C.c_int), ("rank", C.c_int)]
+
+
 class SegsT(C.Structure):     # thallo_segs_t of include/thallo_hip.h
     _fields_ = [("off", C.c_long * 8), ("len", C.c_long * 8), ("n", C.c_int)]
 
@@ -83,6 +89,15 @@ def lib():
     L.thallo_hip_iw_cost.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp]
     L.thallo_hip_iw_pcg_init.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, vp, vp, vp, vp]
+    L.thallo_hip_ipc_alloc.argtypes = [C.c_long, C.POINTER(vp), vp]
+    L.thallo_hip_ipc_open.argtypes = [vp, C.POINTER(vp)]
+    L.thallo_hip_ipc_close.argtypes = [vp]; L.thallo_hip_ipc_free.argtypes = [vp]
+    L.thallo_hip_dist_begin_step.argtypes = [DistT, vp]
+    L.thallo_hip_dist_seed.argtypes = [DistT, ci, vp, vp]
+    L.thallo_hip_dist_collect.argtypes = [DistT, ci, ci, vp, vp]
+    L.thallo_hip_dist_error.argtypes = [DistT, ci, vp]
+    L.thallo_hip_iw_pcg_step1_dist.argtypes = [ci, ci, ci, ci, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, DistT, ci, ci, ci, ci, vp, vp]
+    L.thallo_hip_iw_pcg_step2_dist.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, DistT, ci, ci, ci, vp, vp]
     L.thallo_hip_iw_pcg_step2.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, vp, vp, SumT, SumT, vp, vp, vp]
     L.thallo_hip_iw_apply_jtj.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp]
     L.thallo_hip_pcg_step2.argtypes = [vp, vp, vp, vp, cl, SumT, SumT, vp, vp]

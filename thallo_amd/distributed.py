@@ -78,11 +78,23 @@ def _segs(pairs):
     return s
 
 
+class _RawDeviceFloats:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def _wrap_device_floats(ptr, n, dev):
+    """torch view of a raw device allocation (no ownership)"""
+    return torch.as_tensor(_RawDeviceFloats(ptr, n), device=dev)
+
+
 class HipSlabBackend:
     """image_warping slab kernels through the C-ABI shim; all tensors live on the current CUDA device."""
 
-    def __init__(self, W, layout, local_params, max_l_iters):
+    def __init__(self, W, layout, local_params, max_l_iters, ipc=False):
         self.L = api.lib()
+        self.p2p = None               # thallo_dist_t once enable_p2p() succeeded
+        self._ipc_ptrs, self._ipc_opened = [], []
         self.W, self.lay = W, layout
         Hl = layout.Hl
         self.Hl, self.row0, self.row1 = Hl, layout.row0, layout.row1
@@ -97,7 +109,13 @@ class HipSlabBackend:
         self.N, self.n = N, 3 * N
         na = self.L.thallo_hip_vector_elems(self.n)
         z = lambda: torch.zeros(na, dtype=torch.float32, device=dev)
-        self.rz = torch.zeros(2 * na, dtype=torch.float32, device=dev)          # r and z share one allocation: one pack/unpack covers both
+        # r and z share one allocation: one pack/unpack covers both.  With ipc=True it is a plain hipMalloc block other ranks can map
+        self.max_l = max_l_iters
+        if ipc:
+            ptr, self.rz_handle = self._ipc_alloc(8 * na)
+            self.rz = _wrap_device_floats(ptr, 2 * na, dev)
+        else:
+            self.rz = torch.zeros(2 * na, dtype=torch.float32, device=dev)
         self.r, self.z = self.rz[:na], self.rz[na:]
         self.na = na
         self.pre, self.delta, self.Ap = z(), z(), z()
@@ -105,7 +123,7 @@ class HipSlabBackend:
         self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
         self.irregular = torch.zeros(16, dtype=torch.int32, device=dev)      # UrShape-is-the-pixel-grid word (written by pcg_init)
-        self.parts = torch.zeros(1024, dtype=torch.float32, device=dev)      # local partials of the current reduction
+        self.parts = torch.zeros(2048, dtype=torch.float32, device=dev)      # local partials of the current reduction (p2p: step1 / step2 halves)
         self.nb = 1
         self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32, device=dev)    # global (all-reduced) scalars
         self.msg = 1 + 12 * W                                                   # [sum | first row: r, z | last row: r, z]
@@ -192,6 +210,86 @@ class HipSlabBackend:
             p_ptr = vp(self.p[cur].data_ptr() + 4 * off) if with_p else None
             self._chk(self.L.thallo_hip_linear_update(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off), p_ptr, C.c_long(ln),
                                                       self._sum(iN), self._sum(iD), self._st()), "linear_update")
+
+    # -- device-side exchange (thallo_dist_t, include/thallo_hip.h): mailboxes + neighbour r rows over xGMI peer-to-peer stores
+    def _ipc_alloc(self, nbytes):
+        ptr = C.c_void_p()
+        handle = C.create_string_buffer(64)
+        self._chk(self.L.thallo_hip_ipc_alloc(C.c_long(nbytes), C.byref(ptr), handle), "ipc_alloc")
+        self._ipc_ptrs.append(ptr.value)
+        return ptr.value, handle.raw
+
+    def _ipc_open(self, handle):
+        ptr = C.c_void_p()
+        self._chk(self.L.thallo_hip_ipc_open(C.create_string_buffer(handle, 64), C.byref(ptr)), "ipc_open")
+        self._ipc_opened.append(ptr.value)
+        return ptr.value
+
+    def enable_p2p(self, group=None):
+        """Collective.  Allocates this rank's mailbox, maps every peer's mailbox and the two neighbours' r vectors."""
+        lay, W = self.lay, self.W
+        if not hasattr(self, "rz_handle"):
+            raise RuntimeError("the backend was not created with ipc=True")
+        n_slots = 2 * self.max_l + 8
+        mail_ptr, mail_handle = self._ipc_alloc(8 * n_slots * lay.world)
+        self.ctl = torch.zeros(16, dtype=torch.int32, device=self.device)
+        mine = {"rank": lay.rank, "mail": mail_handle, "rz": self.rz_handle, "row0": self.row0, "row1": self.row1, "Hl": self.Hl, "pid": os.getpid()}
+        infos = [None] * lay.world
+        if lay.world > 1:
+            dist.all_gather_object(infos, mine, group=group)
+        else:
+            infos = [mine]
+        d = api.DistT()
+        d.world, d.rank = lay.world, lay.rank
+        d.mail = mail_ptr
+        d.ctl = self.ctl.data_ptr()
+        for r, inf in enumerate(infos):
+            d.peer_mail[r] = mail_ptr if r == lay.rank else self._ipc_open(inf["mail"])
+        for k, nb in enumerate((lay.up(), lay.down())):
+            if nb is None:
+                d.peer_r[k] = None
+                continue
+            inf = infos[nb]
+            d.peer_r[k] = self._ipc_open(inf["rz"])                        # r is the first half of the peer's rz block
+            ghost_row = inf["row1"] if k == 0 else inf["row0"] - 1         # my first row -> its bottom ghost; my last row -> its top ghost
+            d.peer_off_o[k] = 2 * W * ghost_row
+            d.peer_off_a[k] = 2 * W * inf["Hl"] + W * ghost_row
+        self.p2p = d
+        torch.cuda.synchronize()
+        if lay.world > 1:
+            dist.barrier(group=group)
+
+    def p2p_begin(self, slot):
+        self._chk(self.L.thallo_hip_dist_begin_step(self.p2p, self._st()), "dist_begin_step")
+        self._chk(self.L.thallo_hip_dist_seed(self.p2p, slot, C.c_void_p(self.S.data_ptr() + 4 * slot), self._st()), "dist_seed")
+
+    def step1_p2p(self, cur, first, iN, iD, iB, out_idx):
+        vp, fl = C.c_void_p, C.c_float
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1_dist(
+            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
+            vp(self.r.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()),
+            1 if first else 0, self.p2p, iN, iD, iB, out_idx, vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1_dist")
+
+    def step2_p2p(self, iN, iD, out_idx):
+        vp, fl = C.c_void_p, C.c_float
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step2_dist(
+            self.W, self.Hl, self.row0, self.row1, vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
+            vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), self.p2p, iN, iD, out_idx, vp(self.parts.data_ptr() + 4096), self._st()), "iw_pcg_step2_dist")
+
+    def p2p_collect(self, slot0, nslots):
+        self._chk(self.L.thallo_hip_dist_collect(self.p2p, slot0, nslots, C.c_void_p(self.S.data_ptr() + 4 * slot0), self._st()), "dist_collect")
+
+    def p2p_error(self, clear=True):
+        """1 if a bounded mailbox wait timed out since the last clear (synchronises)"""
+        self.p2p_post_mortem = self.ctl[4:9].cpu().tolist()     # (slot, source rank, expected seq, found seq, found value bits) of the first timeout
+        return self._chk(self.L.thallo_hip_dist_error(self.p2p, 1 if clear else 0, self._st()), "dist_error")
+
+    def close(self):
+        torch.cuda.synchronize()
+        for p in self._ipc_opened:
+            self.L.thallo_hip_ipc_close(C.c_void_p(p))
+        self._ipc_opened = []
+        # the rz / mailbox blocks stay allocated for the life of the process: tensors may still alias them
 
     def pack_grid_info(self):
         """uint8 [irregular word (4 bytes) | flags of the first owned row | flags of the last owned row]"""
@@ -292,12 +390,70 @@ class SlabSolver:
     def solve(self, n_iters, l_iters):
         costs = [self.cost()]
         for _ in range(n_iters):
-            self.gn_step(l_iters)
+            (self.gn_step_p2p if getattr(self, "p2p_on", False) else self.gn_step)(l_iters)
             costs.append(self.cost())
         return costs
 
     # -- hipGraph replay of a whole GN step (kernels + RCCL collectives): removes ~100 us of host work per PCG
     #    iteration, which at 4-8 ranks is several times the kernels' own time
+    def gn_step_p2p(self, l_iters):
+        """gn_step with the PCG loop's scalar and ghost-row exchange done by the kernels themselves (mailboxes + peer-to-peer row
+        stores, csrc/dist_device.hpp): RCCL only once per GN step (alphaN_0, initial ghost rows, flags).  z-free schedule only."""
+        be = self.be
+        B, L = 2, l_iters
+        cur = 0
+        be.init(cur)
+        if self.use_dist:
+            send = be.pack_grid_info()
+            gath = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
+            dist.all_gather_into_tensor(gath, send, group=self.group)
+            be.unpack_grid_info(gath.view(self.world, -1))
+        self._gather_sum_and_rows(B)
+        be.p2p_begin(B)                                # seq += 1 ; mailbox slot B <- alphaN_0
+        for k in range(L):
+            jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
+            be.step1_p2p(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
+            cur ^= 1
+            be.step2_p2p(jN, jD, jB)
+        be.p2p_collect(B, 2 * L + 1)                   # S[B..B+2L] <- rank-ordered sums (alpha/beta trace, linear update)
+        if L > 0:
+            be.linear_update(cur, B + 2 * (L - 1), B + 2 * (L - 1) + 1, True)
+        else:
+            be.linear_update(cur, B, B, False)
+        self._exchange_unknown_ghosts()
+
+    def try_enable_p2p(self, l_iters=6, rtol=1e-4):
+        """Collective.  Sets up the device-side exchange and checks it against the collective path on this very topology: one
+        GN step each way from the same unknowns must give the same alpha/beta scalars (a stale ghost row or a lost granule
+        shows up there), no wait may time out, and UrShape must be the pixel grid everywhere.  On success gn_step_fast /
+        capture use the p2p form.  Every rank returns the same answer."""
+        be = self.be
+        ok = 1.0
+        try:
+            be.enable_p2p(self.group)
+            X0, A0 = be.offset.clone(), be.angle.clone()
+            self.gn_step(l_iters)
+            ref = be.S[2:2 + 2 * l_iters + 1].clone()
+            irregular = int(be.irregular[0].item())
+            be.offset.copy_(X0); be.angle.copy_(A0)
+            self.gn_step_p2p(l_iters)
+            got = be.S[2:2 + 2 * l_iters + 1].clone()
+            err = be.p2p_error()
+            be.offset.copy_(X0); be.angle.copy_(A0)
+            rel = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item())
+            self.p2p_check = {"irregular": irregular, "timeout": err, "max_rel_scalar_diff": rel}
+            if irregular != 0 or err != 0 or not (rel <= rtol):
+                ok = 0.0
+        except Exception as e:      # noqa: BLE001 - any set-up problem means: stay on the collective path
+            self.p2p_check = {"error": repr(e)}
+            ok = 0.0
+        if self.world > 1:
+            flag = torch.tensor([ok], device=be.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = float(flag.item())
+        self.p2p_on = ok > 0.5
+        return self.p2p_on
+
     def capture_gn_step(self, l_iters):
         """Capture gn_step(l_iters) into a CUDA/HIP graph.  Returns True on success; on any failure the solver stays
         in eager mode.  All ranks must call this together (the capture contains collectives)."""
@@ -305,13 +461,14 @@ class SlabSolver:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            step = self.gn_step_p2p if getattr(self, "p2p_on", False) else self.gn_step
             with torch.cuda.stream(side):
-                self.gn_step(l_iters)                   # warm-up on the side stream (allocations, RCCL channel setup)
+                step(l_iters)                           # warm-up on the side stream (allocations, RCCL channel setup)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
-                self.gn_step(l_iters)
+                step(l_iters)
             torch.cuda.synchronize()
             self._graph, self._graph_l = g, l_iters
             return True
@@ -327,45 +484,65 @@ class SlabSolver:
     def gn_step_fast(self, l_iters):
         if getattr(self, "_graph", None) is not None and self._graph_l == l_iters:
             self._graph.replay()
+        elif getattr(self, "p2p_on", False):
+            self.gn_step_p2p(l_iters)
         else:
             self.gn_step(l_iters)
 
 
-def make_hip_solver(params_global, W, H, rank, world, max_l_iters):
+def make_hip_solver(params_global, W, H, rank, world, max_l_iters, ipc=False):
     lay = SlabLayout(H, rank, world)
     local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in params_global]
-    be = HipSlabBackend(W, lay, local, max_l_iters)
+    be = HipSlabBackend(W, lay, local, max_l_iters, ipc=ipc)
     return SlabSolver(be, lay), lay
 
 
 def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world):
     """bench.py's N>1 leg: K timed GN steps between barriers, MAX over ranks, rank 0 reports."""
-    solver, lay = make_hip_solver(params_global, W, H, rank, world, l_iters)
+    use_p2p = os.environ.get("THALLO_DIST_P2P", "1") != "0"
+    solver, lay = make_hip_solver(params_global, W, H, rank, world, l_iters, ipc=use_p2p)
     c0 = solver.cost()
+    # device-side exchange (mailboxes + peer-to-peer ghost rows): enabled only if its self-check against the collective path
+    # passes on this topology; every rank takes the same decision
+    p2p = solver.try_enable_p2p() if use_p2p else False
     # graph replay of the GN step is opt-out (THALLO_DIST_GRAPH=0); every rank must agree, so the outcome is all-reduced
     use_graph = os.environ.get("THALLO_DIST_GRAPH", "1") != "0"
-    captured = False
-    if use_graph:
+
+    def capture():
+        if not use_graph:
+            return False
         ok = solver.capture_gn_step(l_iters)            # runs one warm-up + one captured step
         flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        captured = bool(flag.item() > 0.5)
-        if not captured:
+        if flag.item() <= 0.5:
             solver._graph = None
-    for _ in range(warmup):
-        solver.gn_step_fast(l_iters)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        solver.gn_step_fast(l_iters)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
+        return bool(flag.item() > 0.5)
+
+    def timed():
+        for _ in range(warmup):
+            solver.gn_step_fast(l_iters)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            solver.gn_step_fast(l_iters)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item())
+
+    captured = capture()
+    dt = timed()
+    if p2p:
+        bad = torch.tensor([float(solver.be.p2p_error())], device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() > 0:          # a bounded mailbox wait timed out: the numbers above are void -- redo on the collective path
+            solver.p2p_on, solver._graph, p2p = False, None, False
+            captured = capture()
+            dt = timed()
     final = solver.cost()
     npx = W * H
     # roofline of the dominant kernel on this rank's slab: the graph replay cannot be bracketed per kernel, so the fused
@@ -395,8 +572,12 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"examples/image_warping {W}x{H} ARAP, GN + matrix-free PCG, {l_iters} PCG iterations per GN step",
                    "width": W, "height": H, "unknowns": 3 * npx, "l_iterations": l_iters,
-                   "parallelism": f"{world} row slabs, RCCL all-reduce(alphaD) + all-gather(betaN, z ghost rows) per PCG iteration"},
+                   "parallelism": (f"{world} row slabs; per PCG iteration: alphaD / betaN through device mailboxes (one 8-byte peer-to-peer store per "
+                                   "rank and scalar, summed in rank order by the consumer kernel) + boundary rows of r stored into the neighbours' "
+                                   "ghost rows over xGMI; RCCL once per GN step") if p2p else
+                                  f"{world} row slabs, RCCL all-reduce(alphaD) + all-gather(betaN, r/z ghost rows) per PCG iteration"},
         "ms_per_gn_iter": dt / steps * 1e3, "us_per_pcg_iter": dt / (steps * l_iters) * 1e6,
         "initial_cost": c0, "final_cost": final, "graph_replay": captured,
+        "exchange": "p2p-mailbox" if p2p else "rccl", "p2p_check": getattr(solver, "p2p_check", None),
         "roofline": roofline, "cpu_baseline": None,
     }

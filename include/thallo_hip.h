@@ -57,13 +57,15 @@ typedef struct thallo_segs_t {
    peer-to-peer stores over xGMI, consumers poll their own.  Replaces a host-driven all-reduce per PCG scalar
    (SURVEY.md 8e).  Pointers in peer_* are the peers' allocations mapped into this process (thallo_hip_ipc_open). */
 #define THALLO_DIST_MAX_WORLD 8
+#define THALLO_DIST_CTL_WORDS 16
 typedef struct thallo_dist_t {
     unsigned long long* mail;                               /* == peer_mail[rank] */
     unsigned long long* peer_mail[THALLO_DIST_MAX_WORLD];
     float*    peer_r[2];         /* image slabs: the r vector of rank-1 / rank+1 (NULL at the image border) */
     long      peer_off_o[2];     /* element offset of my row's landing place (that peer's ghost row), Offset plane */
     long      peer_off_a[2];     /* ... Angle plane */
-    unsigned* ctl;               /* device words: [0] sequence number (GN step counter), [1] error (spin timeout), [2] ticket */
+    unsigned* ctl;               /* THALLO_DIST_CTL_WORDS zeroed device words: [0] sequence number (GN step counter), [1] error
+                                    (spin timeout), [4..8] post-mortem of the first timeout */
     int       world, rank;
 } thallo_dist_t;
 
@@ -306,23 +308,21 @@ int thallo_hip_ipc_close(void* ptr);
 int thallo_hip_ipc_free(void* ptr);
 /* seq += 1 (start of a GN step); error word untouched */
 int thallo_hip_dist_begin_step(thallo_dist_t d, thallo_stream_t stream);
-/* local mailbox slot <- {value[0] from rank 0, 0 from the others} with the current seq: injects a scalar every rank already
-   agrees on (alphaN_0 after the once-per-GN-step collective) */
-int thallo_hip_dist_seed(thallo_dist_t d, int slot, const float* value, thallo_stream_t stream);
-/* out[j] = rank-ordered sum of slot slot0+j for j < nslots (waits for each) */
+/* The exchange, one single-wave launch behind the producing kernel: local = that kernel's per-workgroup partials; adds them in
+   the single-GPU order, stores the sum as one granule into EVERY rank's mailbox slot, waits (bounded) until every rank's
+   granule of the slot carries the current seq, out[0] = their rank-ordered sum.  The kernels after it on the stream read out[0]
+   as a thallo_sum_t of count 1; the kernel boundaries also order the neighbours' ghost rows (stored by their PCGStep2 before
+   their granule) ahead of every later read. */
+int thallo_hip_dist_exchange(thallo_dist_t d, int slot, thallo_sum_t local, float* out, thallo_stream_t stream);
+/* out[j] = rank-ordered sum of slot slot0+j for j < nslots (waits for each); diagnostics */
 int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, thallo_stream_t stream);
 /* host-side read / clear of the error word (synchronises the stream) */
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream);
-/* image_warping PCGStep1 / PCGStep2 over a row slab with the exchange built in (z-free schedule only: UrShape must be the
-   unit pixel grid on every rank).  Scalars come from mailbox slots; step2 additionally stores its first / last owned row of
-   r into the neighbours' ghost rows before publishing betaN. */
-int thallo_hip_iw_pcg_step1_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                                 const float* r, const float* p_in, float* p_out, float* delta, float* Ap, int first,
-                                 thallo_dist_t d, int slot_aN_prev, int slot_aD_prev, int slot_bN_prev, int slot_aD_out,
-                                 float* partials, thallo_stream_t stream);
+/* image_warping PCGStep2 over a row slab (z-free schedule only: UrShape must be the unit pixel grid on every rank) that also
+   stores its first / last owned row of r into the neighbours' ghost rows (d.peer_r) with peer-to-peer stores. */
 int thallo_hip_iw_pcg_step2_dist(int W, int H, int row0, int row1, const unsigned char* flags, float w_fit, float w_reg,
-                                 float* r, const float* Ap, thallo_dist_t d, int slot_aN, int slot_aD, int slot_bN_out,
-                                 float* partials, thallo_stream_t stream);
+                                 float* r, const float* Ap, thallo_sum_t alphaN, thallo_sum_t alphaD,
+                                 thallo_dist_t d, float* betaN_out, thallo_stream_t stream);
 
 #ifdef __cplusplus
 }

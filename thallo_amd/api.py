@@ -93,11 +93,10 @@ def lib():
     L.thallo_hip_ipc_open.argtypes = [vp, C.POINTER(vp)]
     L.thallo_hip_ipc_close.argtypes = [vp]; L.thallo_hip_ipc_free.argtypes = [vp]
     L.thallo_hip_dist_begin_step.argtypes = [DistT, vp]
-    L.thallo_hip_dist_seed.argtypes = [DistT, ci, vp, vp]
     L.thallo_hip_dist_collect.argtypes = [DistT, ci, ci, vp, vp]
     L.thallo_hip_dist_error.argtypes = [DistT, ci, vp]
-    L.thallo_hip_iw_pcg_step1_dist.argtypes = [ci, ci, ci, ci, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, DistT, ci, ci, ci, ci, vp, vp]
-    L.thallo_hip_iw_pcg_step2_dist.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, DistT, ci, ci, ci, vp, vp]
+    L.thallo_hip_dist_exchange.argtypes = [DistT, ci, SumT, vp, vp]
+    L.thallo_hip_iw_pcg_step2_dist.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, SumT, SumT, DistT, vp, vp]
     L.thallo_hip_iw_pcg_step2.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, vp, vp, SumT, SumT, vp, vp, vp]
     L.thallo_hip_iw_apply_jtj.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp]
     L.thallo_hip_pcg_step2.argtypes = [vp, vp, vp, vp, cl, SumT, SumT, vp, vp]

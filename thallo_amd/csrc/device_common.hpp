@@ -29,8 +29,18 @@ __device__ __forceinline__ float wave_sum_all(float v)
 __device__ __forceinline__ float sum_partials(const float* __restrict__ part, int nb)
 {
     const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    if (nb == 1) return part[0];                           // already reduced (finish_sum / cross-rank exchange)
+    // all <= 16 loads of a lane are issued before the first add (independent), then added in index order: the same value as
+    // the rolled loop `for (i = lane; i < nb; i += 64) s += part[i]` (missing entries add +0.0f)
+    float v[THALLO_MAX_PARTIALS / THALLO_WAVE];
+#pragma unroll
+    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
+        const int i = lane + k * THALLO_WAVE;
+        v[k] = i < nb ? part[i] : 0.0f;
+    }
     float s = 0.0f;
-    for (int i = lane; i < nb; i += THALLO_WAVE) s += part[i];
+#pragma unroll
+    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) s += v[k];
     return wave_sum_all(s);
 }
 

@@ -12,11 +12,18 @@ __global__ void k_begin_step(thallo_dist_t d)
     if (threadIdx.x == 0) __hip_atomic_fetch_add(d.ctl + DIST_SEQ, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void k_seed(thallo_dist_t d, int slot, const float* __restrict__ value)
+// one wave: local fixed-order sum -> one granule to every rank -> wait for every rank's granule -> rank-ordered sum
+__global__ __launch_bounds__(64) void k_exchange(thallo_dist_t d, int slot, thallo_sum_t local, float* __restrict__ out)
 {
+    __shared__ float vals[8];
+    const float s = sum_partials(local.partials, local.count);      // same association as a single-GPU consumer
     const unsigned seq = ld_agent(d.ctl + DIST_SEQ);
     if ((int)threadIdx.x < d.world)
-        st_sys(d.mail + (long)slot * d.world + threadIdx.x, ((u64)seq << 32) | (u64)__float_as_uint(threadIdx.x == 0 ? value[0] : 0.0f));
+        st_sys(d.peer_mail[threadIdx.x] + (long)slot * d.world + d.rank, ((u64)seq << 32) | (u64)__float_as_uint(s));
+    const int slots[1] = { slot };
+    float t[1];
+    dist_fetch<1>(d, slots, t, vals);
+    if (threadIdx.x == 0) out[0] = t[0];
 }
 
 __global__ __launch_bounds__(64) void k_collect(thallo_dist_t d, int slot0, int nslots, float* __restrict__ out)
@@ -37,6 +44,7 @@ extern "C" {
 int thallo_hip_ipc_alloc(long bytes, void** ptr, void* handle_out64)
 {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    static_assert(DIST_CTL_WORDS <= THALLO_DIST_CTL_WORDS, "ctl layout");
     if (bytes <= 0 || !ptr || !handle_out64) return -(int)hipErrorInvalidValue;
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, (size_t)bytes);
@@ -75,10 +83,10 @@ int thallo_hip_dist_begin_step(thallo_dist_t d, thallo_stream_t stream)
     return check_launch();
 }
 
-int thallo_hip_dist_seed(thallo_dist_t d, int slot, const float* value, thallo_stream_t stream)
+int thallo_hip_dist_exchange(thallo_dist_t d, int slot, thallo_sum_t local, float* out, thallo_stream_t stream)
 {
-    if (!dist_ok(d) || slot < 0 || !value) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, (hipStream_t)stream, d, slot, value);
+    if (!dist_ok(d) || slot < 0 || !out || !local.partials || local.count < 1) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_exchange, dim3(1), dim3(64), 0, (hipStream_t)stream, d, slot, local, out);
     return check_launch();
 }
 
@@ -96,7 +104,7 @@ int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream)
     unsigned v = 0;
     hipError_t e = hipMemcpyAsync(&v, d.ctl + DIST_ERR, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    if (e == hipSuccess && clear && v) { e = hipMemsetAsync(d.ctl + DIST_ERR, 0, 4, (hipStream_t)stream); if (e == hipSuccess) e = hipMemsetAsync(d.ctl + DIST_TICKET, 0, 4, (hipStream_t)stream); }
+    if (e == hipSuccess && clear && v) e = hipMemsetAsync(d.ctl + DIST_ERR, 0, 4, (hipStream_t)stream);
     if (e != hipSuccess) return -(int)e;
     return (int)v;
 }

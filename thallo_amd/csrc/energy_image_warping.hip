@@ -98,16 +98,14 @@ struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
 // GRID = UrShape is the unit pixel grid (what the reference's harness always passes, CombinedSolver.h:158-176):
 // u_i - u_j is then exactly -(dx,dy), so the UrShape plane is neither loaded nor staged (-8 B/pixel, -2 LDS planes).
 // pcg_init verifies the property bit-exactly on the device every GN step; both paths give identical bits.
-struct DistArgs { thallo_dist_t d; int s_aN, s_aD, s_bN, s_out; };
-
-template <bool FUSED, bool GRID, int NT, bool DIST = false>
+template <bool FUSED, bool GRID, int NT>
 __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, const float2* __restrict__ cs, const float2* __restrict__ ur,
                                            const unsigned char* __restrict__ flags, float wf2, float wr2,
                                            const float* __restrict__ z, const float* __restrict__ p_in,
                                            float* __restrict__ p_out, float* __restrict__ delta,
                                            float* __restrict__ Ap, int first,
                                            thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
-                                           float* __restrict__ aD_out, int dbg, const DistArgs* da = nullptr, float* dvals = nullptr)
+                                           float* __restrict__ aD_out, int dbg)
 {   // GRID: `z` points at r, and z = M^-1 r is formed here from the flags byte (pre_from_flags)
     constexpr int PER = TH / (NT / TW);                    // owned pixels per thread (one column): 4 at 256 threads, 2 at 512
     const int ntm = dbg >> 8; dbg &= 0xff;
@@ -169,24 +167,11 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
 
     TileSweep t(g.ntiles);
     float alpha = 0.0f, beta = 0.0f;
-    if (DIST) {
-        // multi-GPU: the scalars arrive in the mailbox; the neighbours' boundary rows of r were stored into this rank's ghost
-        // rows BEFORE their betaN granule, so nothing may be loaded ahead of the wait
-        if (!first) {
-            const int slots[3] = { da->s_aN, da->s_aD, da->s_bN };
-            float v[3];
-            dist_fetch<3>(da->d, slots, v, dvals);
-            alpha = safe_div<false>(v[0], v[1]);
-            beta  = safe_div<false>(v[2], v[0]);
-        }
-        if (t.valid()) issue_loads(t.cur);
-    } else {
     if (t.valid()) issue_loads(t.cur);
     if (FUSED && !first) {   // PCGStep3 of iteration k-1 (gauss_newton.t:892-896) and its alpha (:807-812)
         const float an = sum_partials(aNp.partials, aNp.count);
         alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
         beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
-    }
     }
 
     float acc = 0.0f;
@@ -283,22 +268,7 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
         }
         lds_barrier();
     }
-    if (DIST) dist_reduce_publish(acc, aD_out, da->d, da->s_out, red);
-    else      block_store_partial(acc, aD_out, red);
-}
-
-// multi-GPU form: fused, z-free (unit pixel grid), scalars from the mailbox (dist_device.hpp)
-template <int MINW, int NT>
-__global__ __launch_bounds__(NT, MINW) void k_step1_dist(Geo g, const float2* __restrict__ cs, const unsigned char* __restrict__ flags,
-                                                             float wf2, float wr2, const float* __restrict__ r, const float* __restrict__ p_in,
-                                                             float* __restrict__ p_out, float* __restrict__ delta, float* __restrict__ Ap,
-                                                             int first, DistArgs da, float* __restrict__ partials, int dbg)
-{
-    __shared__ Tile T;
-    __shared__ float red[20];
-    __shared__ float dvals[24];
-    const thallo_sum_t none = { nullptr, 0 };
-    step1_body<true, true, NT, true>(T, red, g, cs, nullptr, flags, wf2, wr2, r, p_in, p_out, delta, Ap, first, none, none, none, partials, dbg, &da, dvals);
+    block_store_partial(acc, aD_out, red);
 }
 
 template <bool FUSED, int MINW, int NT>
@@ -328,18 +298,12 @@ __global__ __launch_bounds__(BLOCK) void k_step2_iw(float4* __restrict__ r, cons
                                                      float4* __restrict__ z, const unsigned char* __restrict__ flags, long N, float wf2, float wr2,
                                                      long off0, long len0, long off1, long len1,
                                                      thallo_sum_t aN, thallo_sum_t aD, const int* __restrict__ irregular, float* __restrict__ bN_out,
-                                                     DistArgs da, long row_o4, long row_a4)
-{   // DIST: row_o4 / row_a4 = float4s per image row in the Offset / Angle plane
-    __shared__ float red[20];
-    __shared__ float dvals[16];
+                                                     thallo_dist_t dd, long row_o4, long row_a4)
+{   // DIST (multi-GPU row slabs): the first / last owned row of r is also stored into the neighbour's ghost row, peer-to-peer.
+    // row_o4 / row_a4 = float4s per image row in the Offset / Angle plane
+    __shared__ float red[16];
     const bool grid = DIST || (irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0);
-    float alpha;
-    if (DIST) {
-        const int slots[2] = { da.s_aN, da.s_aD };
-        float v[2];
-        dist_fetch<2>(da.d, slots, v, dvals);
-        alpha = safe_div<false>(v[0], v[1]);
-    } else alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
+    const float alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
     float acc = 0.0f;
     const long n4 = len0 + len1;
     for (long j = (long)blockIdx.x * BLOCK + threadIdx.x; j < n4; j += (long)gridDim.x * BLOCK) {
@@ -366,21 +330,21 @@ __global__ __launch_bounds__(BLOCK) void k_step2_iw(float4* __restrict__ r, cons
         const float4 zv = make_float4(m.x * rv.x, m.y * rv.y, m.z * rv.z, m.w * rv.w);
         stf4(r + i, rv, true);
         if (!grid) z[i] = zv;
-        if (DIST) {     // first / last owned row -> the neighbour's ghost row (peer-to-peer, write-through); drained before the publish
+        if (DIST) {     // write-through system-scope stores; complete (acknowledged) when this kernel ends, i.e. before the
+                        // exchange kernel behind it on the stream sends this rank's betaN granule
             const long jj = in_off ? j : j - len0, rowlen = in_off ? row_o4 : row_a4, total = in_off ? len0 : len1;
-            if (jj < rowlen && da.d.peer_r[0]) {
-                float* dst = da.d.peer_r[0] + (in_off ? da.d.peer_off_o[0] : da.d.peer_off_a[0]) + 4 * jj;
+            if (jj < rowlen && dd.peer_r[0]) {
+                float* dst = dd.peer_r[0] + (in_off ? dd.peer_off_o[0] : dd.peer_off_a[0]) + 4 * jj;
                 st_sys(dst, rv.x); st_sys(dst + 1, rv.y); st_sys(dst + 2, rv.z); st_sys(dst + 3, rv.w);
             }
-            if (jj >= total - rowlen && da.d.peer_r[1]) {
-                float* dst = da.d.peer_r[1] + (in_off ? da.d.peer_off_o[1] : da.d.peer_off_a[1]) + 4 * (jj - (total - rowlen));
+            if (jj >= total - rowlen && dd.peer_r[1]) {
+                float* dst = dd.peer_r[1] + (in_off ? dd.peer_off_o[1] : dd.peer_off_a[1]) + 4 * (jj - (total - rowlen));
                 st_sys(dst, rv.x); st_sys(dst + 1, rv.y); st_sys(dst + 2, rv.z); st_sys(dst + 3, rv.w);
             }
         }
         acc += zv.x * rv.x + zv.y * rv.y + zv.z * rv.z + zv.w * rv.w;
     }
-    if (DIST) dist_reduce_publish(acc, bN_out, da.d, da.s_out, red);
-    else      block_store_partial(acc, bN_out, red);
+    block_store_partial(acc, bN_out, red);
 }
 
 // ------------------------------------------------------------------------------------------ PCGInit1 (+_Finish)
@@ -592,22 +556,6 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
     int e = check_launch(); return e ? e : grid;
 }
 
-static bool dist_args_ok(const thallo_dist_t& d);
-
-int thallo_hip_iw_pcg_step1_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                                 const float* r, const float* p_in, float* p_out, float* delta, float* Ap, int first,
-                                 thallo_dist_t d, int slot_aN_prev, int slot_aD_prev, int slot_bN_prev, int slot_aD_out,
-                                 float* partials, thallo_stream_t stream)
-{
-    if (!rows_ok(H, row0, row1) || !dist_args_ok(d) || ((2L * W * H) & 3)) return -(int)hipErrorInvalidValue;
-    const Geo g = make_geo(W, H, row0, row1);
-    const int grid = grid_for(g, 2);
-    DistArgs da = { d, slot_aN_prev, slot_aD_prev, slot_bN_prev, slot_aD_out };
-    hipLaunchKernelGGL((k_step1_dist<4, 512>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, flags, w_fit * w_fit, w_reg * w_reg,
-                       r, p_in, p_out, delta, Ap, first, da, partials, g_iw_debug | (g_nt_mask << 8));
-    int e = check_launch(); return e ? e : grid;
-}
-
 int thallo_hip_iw_pcg_step2(int W, int H, int row0, int row1, const unsigned char* flags, float w_fit, float w_reg,
                             float* r, const float* Ap, const float* pre, float* z,
                             thallo_sum_t aN, thallo_sum_t aD, const int* irregular, float* bN_out, thallo_stream_t stream)
@@ -623,7 +571,7 @@ int thallo_hip_iw_pcg_step2(int W, int H, int row0, int row1, const unsigned cha
     int grid = thallo_hip_device_cu_count() * 4; if (grid > THALLO_MAX_PARTIALS) grid = THALLO_MAX_PARTIALS; grid -= grid % 8;
     if (want < grid) grid = (int)(want < 1 ? 1 : want);
     hipLaunchKernelGGL(k_step2_iw<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z,
-                       flags, N, w_fit * w_fit, w_reg * w_reg, off0 / 4, len0 / 4, off1 / 4, len1 / 4, aN, aD, irregular, bN_out, DistArgs{}, 0L, 0L);
+                       flags, N, w_fit * w_fit, w_reg * w_reg, off0 / 4, len0 / 4, off1 / 4, len1 / 4, aN, aD, irregular, bN_out, thallo_dist_t{}, 0L, 0L);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -633,8 +581,8 @@ static bool dist_args_ok(const thallo_dist_t& d)
 }
 
 int thallo_hip_iw_pcg_step2_dist(int W, int H, int row0, int row1, const unsigned char* flags, float w_fit, float w_reg,
-                                 float* r, const float* Ap, thallo_dist_t d, int slot_aN, int slot_aD, int slot_bN_out,
-                                 float* partials, thallo_stream_t stream)
+                                 float* r, const float* Ap, thallo_sum_t aN, thallo_sum_t aD, thallo_dist_t d,
+                                 float* bN_out, thallo_stream_t stream)
 {
     if (!rows_ok(H, row0, row1) || !dist_args_ok(d) || (W & 3)) return -(int)hipErrorInvalidValue;
     const long N = (long)W * H, rows = row1 - row0;
@@ -644,10 +592,8 @@ int thallo_hip_iw_pcg_step2_dist(int W, int H, int row0, int row1, const unsigne
     long want = ((len0 + len1) / 4 + BLOCK - 1) / BLOCK;
     int grid = thallo_hip_device_cu_count() * 4; if (grid > THALLO_MAX_PARTIALS) grid = THALLO_MAX_PARTIALS; grid -= grid % 8;
     if (want < grid) grid = (int)(want < 1 ? 1 : want);
-    const thallo_sum_t none = { nullptr, 0 };
-    DistArgs da = { d, slot_aN, slot_aD, 0, slot_bN_out };
     hipLaunchKernelGGL(k_step2_iw<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)Ap, (const float4*)nullptr, (float4*)nullptr,
-                       flags, N, w_fit * w_fit, w_reg * w_reg, off0 / 4, len0 / 4, off1 / 4, len1 / 4, none, none, (const int*)nullptr, partials, da,
+                       flags, N, w_fit * w_fit, w_reg * w_reg, off0 / 4, len0 / 4, off1 / 4, len1 / 4, aN, aD, (const int*)nullptr, bN_out, d,
                        2L * W / 4, (long)W / 4);
     int e = check_launch(); return e ? e : grid;
 }

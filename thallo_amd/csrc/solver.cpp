@@ -1,5 +1,6 @@
 // solver.cpp -- see solver.hpp.
 #include "solver.hpp"
+#include <stdlib.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -168,8 +169,10 @@ int Plan::ensure_slots(int L)
     const int need = 2 * L + 6;
     if (need <= parts_slots_) return 0;
     hipDeviceSynchronize();
-    if (parts_.alloc((size_t)need * THALLO_HIP_MAX_PARTIALS * sizeof(float))) return -1;
-    parts_slots_ = need; nb_.assign(need, 1);
+    if (need > THALLO_HIP_MAX_PARTIALS) return -1;                 // the scalar words of all slots share one extra slot
+    if (parts_.alloc((size_t)(need + 1) * THALLO_HIP_MAX_PARTIALS * sizeof(float))) return -1;
+    parts_slots_ = need; nb_.assign(need, 1); fin_.assign(need, 0);
+    { const char* e = getenv("THALLO_FINISH_SUMS"); finish_sums_ = !(e && e[0] == '0'); }
     return 0;
 }
 
@@ -202,7 +205,7 @@ float Plan::compute_cost()
 {   // gauss_newton.t:1128-1136 -- partials instead of memset + atomics; same blocking 4-byte read-back
     const int nb = plugin->cost(ctx, slot(0));
     if (nb < 0) { set_error("cost kernel launch failed (%d)", nb); return NAN; }
-    nb_[0] = nb;
+    set_nb(0, nb);
     thallo_hip_finish_sum(sum(0), (float*)scratch_.ptr, ctx.stream);
     float f = 0.0f;
     HIP_OK(hipMemcpyAsync(&f, scratch_.ptr, sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
@@ -269,7 +272,7 @@ int Plan::step_gn(int ev_iter)
     cur_ = 0;
     int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
     if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
-    nb_[B] = nb;
+    set_nb(B, nb); finish(B);
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
     for (int k = 0; k < L; ++k) {
@@ -278,10 +281,10 @@ int Plan::step_gn(int ev_iter)
         thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), bNp = sum(jN);
         nb = plugin->pcg_step1(ctx, v_, cur_, k == 0, aNp, aDp, bNp, slot(jD));
         if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
-        nb_[jD] = nb; cur_ ^= 1;
+        set_nb(jD, nb); finish(jD); cur_ ^= 1;
         nb = plugin->pcg_step2(ctx, v_, sum(jN), sum(jD), slot(jB));      // PCGStep2 (r, z, betaN)
         if (nb < 0) { set_error("PCGStep2 launch failed (%d)", nb); return 0; }
-        nb_[jB] = nb;
+        set_nb(jB, nb); finish(jB);
     }
     last_l_iters = L;
     timer_.stop(ev_lin, s);
@@ -346,7 +349,7 @@ int Plan::step_lm(int ev_iter)
                                              sp.nIter == 0 ? 1 : 0, pc ? 1 : 0, slot(B), s);
     }
     if (nb < 0) return 0;
-    nb_[B] = nb;
+    set_nb(B, nb);
     float Q0 = 0.0f;                                                  // delta = 0 -> q = 0 (:965)
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
@@ -363,7 +366,7 @@ int Plan::step_lm(int ev_iter)
             nb = thallo_hip_lm_step1_finish(v_.Ap, v_.CtC, p, n, slot(jD), s);
         }
         if (nb < 0) return 0;
-        nb_[jD] = nb;
+        set_nb(jD, nb);
         int nbq;
         if (((k + 1) % sp.residual_reset_period) == 0) {              // :1653-1657
             TimedLaunch t(ctx, "PCGStep2");
@@ -379,7 +382,7 @@ int Plan::step_lm(int ev_iter)
             nbq = nb;
         }
         if (nb < 0) return 0;
-        nb_[jB] = nb; nb_[QS] = nbq;
+        set_nb(jB, nb); set_nb(QS, nbq);
         k_done = k + 1;
         const float Q1 = read_sum(QS);                                // :1666-1686 (blocking, as in the reference)
         if (!std::isfinite(Q1)) break;
@@ -395,10 +398,10 @@ int Plan::step_lm(int ev_iter)
     // expanded algebraically, which also avoids the reference's cancellation between two large sums)
     nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));
     if (nb < 0) return 0;
-    nb_[T0] = nb;
+    set_nb(T0, nb);
     nb = thallo_hip_dot(v_.delta, v_.b, n, slot(T1), s);
     if (nb < 0) return 0;
-    nb_[T1] = nb;
+    set_nb(T1, nb);
     const float dJJd = read_sum(T0), db = read_sum(T1);
     const float model_cost_change = db - 0.5f * dJJd;
     const auto& imgs = plugin->unknown_images();

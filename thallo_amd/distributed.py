@@ -123,7 +123,7 @@ class HipSlabBackend:
         self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
         self.irregular = torch.zeros(16, dtype=torch.int32, device=dev)      # UrShape-is-the-pixel-grid word (written by pcg_init)
-        self.parts = torch.zeros(2048, dtype=torch.float32, device=dev)      # local partials of the current reduction (p2p: step1 / step2 halves)
+        self.parts = torch.zeros(1024, dtype=torch.float32, device=dev)      # local partials of the current reduction
         self.nb = 1
         self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32, device=dev)    # global (all-reduced) scalars
         self.msg = 1 + 12 * W                                                   # [sum | first row: r, z | last row: r, z]
@@ -232,7 +232,7 @@ class HipSlabBackend:
             raise RuntimeError("the backend was not created with ipc=True")
         n_slots = 2 * self.max_l + 8
         mail_ptr, mail_handle = self._ipc_alloc(8 * n_slots * lay.world)
-        self.ctl = torch.zeros(16, dtype=torch.int32, device=self.device)
+        self.ctl = torch.zeros(16, dtype=torch.int32, device=self.device)       # THALLO_DIST_CTL_WORDS
         mine = {"rank": lay.rank, "mail": mail_handle, "rz": self.rz_handle, "row0": self.row0, "row1": self.row1, "Hl": self.Hl, "pid": os.getpid()}
         infos = [None] * lay.world
         if lay.world > 1:
@@ -259,22 +259,28 @@ class HipSlabBackend:
         if lay.world > 1:
             dist.barrier(group=group)
 
-    def p2p_begin(self, slot):
+    def p2p_begin(self):
         self._chk(self.L.thallo_hip_dist_begin_step(self.p2p, self._st()), "dist_begin_step")
-        self._chk(self.L.thallo_hip_dist_seed(self.p2p, slot, C.c_void_p(self.S.data_ptr() + 4 * slot), self._st()), "dist_seed")
+
+    def p2p_exchange(self, out_idx):
+        """S[out_idx] <- rank-ordered sum over ranks of (fixed-order sum of this rank's current partials)"""
+        self._chk(self.L.thallo_hip_dist_exchange(self.p2p, out_idx, self._local(), C.c_void_p(self.S.data_ptr() + 4 * out_idx), self._st()), "dist_exchange")
 
     def step1_p2p(self, cur, first, iN, iD, iB, out_idx):
         vp, fl = C.c_void_p, C.c_float
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1_dist(
-            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
-            vp(self.r.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()),
-            1 if first else 0, self.p2p, iN, iD, iB, out_idx, vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1_dist")
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1(
+            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
+            fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
+            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), 1 if first else 0, self._sum(iN), self._sum(iD), self._sum(iB),
+            vp(self.irregular.data_ptr()), vp(self.r.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
+        self.p2p_exchange(out_idx)              # alphaD
 
     def step2_p2p(self, iN, iD, out_idx):
         vp, fl = C.c_void_p, C.c_float
         self.nb = self._chk(self.L.thallo_hip_iw_pcg_step2_dist(
             self.W, self.Hl, self.row0, self.row1, vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
-            vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), self.p2p, iN, iD, out_idx, vp(self.parts.data_ptr() + 4096), self._st()), "iw_pcg_step2_dist")
+            vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), self._sum(iN), self._sum(iD), self.p2p, vp(self.parts.data_ptr()), self._st()), "iw_pcg_step2_dist")
+        self.p2p_exchange(out_idx)              # betaN ; behind it the neighbours' rows of r are in my ghost rows
 
     def p2p_collect(self, slot0, nslots):
         self._chk(self.L.thallo_hip_dist_collect(self.p2p, slot0, nslots, C.c_void_p(self.S.data_ptr() + 4 * slot0), self._st()), "dist_collect")
@@ -409,13 +415,12 @@ class SlabSolver:
             dist.all_gather_into_tensor(gath, send, group=self.group)
             be.unpack_grid_info(gath.view(self.world, -1))
         self._gather_sum_and_rows(B)
-        be.p2p_begin(B)                                # seq += 1 ; mailbox slot B <- alphaN_0
+        be.p2p_begin()                                 # seq += 1
         for k in range(L):
             jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
             be.step1_p2p(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
             cur ^= 1
             be.step2_p2p(jN, jD, jB)
-        be.p2p_collect(B, 2 * L + 1)                   # S[B..B+2L] <- rank-ordered sums (alpha/beta trace, linear update)
         if L > 0:
             be.linear_update(cur, B + 2 * (L - 1), B + 2 * (L - 1) + 1, True)
         else:

@@ -220,6 +220,32 @@ def test_shim_image_warping_zfree_schedule(torch, W, H):
     assert abs(a[5] - b[5]) <= 1e-5 * abs(b[5])                       # alphaD_1
 
 
+def test_image_warping_reference_cat512_instance(torch, orc, golden_dir):
+    """The reference's own image_warping data set (cat512 mask + 9 markers + pinned border, examples/image_warping/src/main.cpp:
+    78-129; BASELINE.json configs[1]) through two steps of the harness' marker continuation: cost trajectory vs the oracle."""
+    from thallo_amd import formats as F
+    mask = F.read_png(os.path.join(golden_dir, "cat512_mask.png"))[:, :, 0].astype(np.float32)
+    H, W = mask.shape
+    cons = F.add_border_constraints(F.read_constraints(os.path.join(golden_dir, "cat512.constraints")), W, H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ur = np.stack([xx, yy], axis=2).astype(np.float32)
+    wf, wr = float(np.sqrt(np.float32(100.0))), float(np.sqrt(np.float32(0.01)))
+    off_o, ang_o = ur.copy(), np.zeros((H, W), dtype=np.float32)
+    dev = [torch.from_numpy(ur.copy()).cuda(), torch.zeros(H, W, device="cuda"), torch.from_numpy(ur.copy()).cuda(), None,
+           torch.from_numpy(mask).cuda(), wf, wr]
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    for i in range(2):
+        c_img = F.constraint_image(cons, mask, np.float32(i + 1) / np.float32(19))
+        po = [off_o, ang_o, ur.copy(), c_img.copy(), mask.copy(), wf, wr]
+        co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=2, lIterations=30)
+        off_o, ang_o = po[0], po[1]
+        dev[3] = torch.from_numpy(c_img).cuda()
+        final, costs = s.solve(dev, profiled=True, nIterations=2, lIterations=30)
+        assert rel_err(np.array(costs), co) < COST_RTOL, (i, costs, co)
+    s.close()
+    assert rel_err(to_host(dev[0]), off_o) < VEC_RTOL
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 def test_full_size_properties_2048(torch):
     """2048^2 (the benchmark size): J^T J is symmetric PSD and linear; the solve is bitwise reproducible;

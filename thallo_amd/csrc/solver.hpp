@@ -88,7 +88,8 @@ private:
     void set_nb(int j, int nb) { nb_[j] = nb; fin_[j] = 0; }
     // Adds the slot's partials once, in the order every consumer would use, so the next kernels read ONE word instead of each of
     // their waves re-adding up to 1024 partials in the prologue (measured: -10 us per PCG iteration at 2048^2)
-    void finish(int j) { if (!finish_sums_) return; thallo_hip_finish_sum(partial_sum(j), scal(j), ctx.stream); fin_[j] = 1; }
+    // (small launches -- <= 4 partials per lane -- are cheaper to re-add in place than to pay one more launch for)
+    void finish(int j) { if (!finish_sums_ || nb_[j] <= 256) return; thallo_hip_finish_sum(partial_sum(j), scal(j), ctx.stream); fin_[j] = 1; }
     int  ensure_slots(int L);
     float compute_cost();
     int   step_gn(int ev_iter);

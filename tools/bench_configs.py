@@ -36,8 +36,23 @@ def run(name, fname, dims, params, nit, lit, warm=1):
             "cost0": c0, "cost": s.current_cost(), "kernel_mean_us": ks}
 
 
+def cat512():
+    """BASELINE.json configs[1] on the reference's own data: cat512 mask + markers + pinned border (tests/golden fixtures),
+    first step of the harness' continuation (targets at 1/19 of the way)."""
+    from thallo_amd import formats as F
+    g = os.path.join(ROOT, "tests", "golden")
+    mask = F.read_png(os.path.join(g, "cat512_mask.png"))[:, :, 0].astype(np.float32)
+    H, W = mask.shape
+    cons = F.add_border_constraints(F.read_constraints(os.path.join(g, "cat512.constraints")), W, H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ur = np.stack([xx, yy], axis=2).astype(np.float32)
+    return [ur.copy(), np.zeros((H, W), np.float32), ur.copy(), F.constraint_image(cons, mask, np.float32(1.0 / 19.0)), mask,
+            float(np.sqrt(np.float32(100.0))), float(np.sqrt(np.float32(0.01)))]
+
+
 out = []
-out.append(run("image_warping 512x512 GN 8x100", "image_warping", (512, 512), syn.image_warping(512, 512), 8, 100))
+out.append(run("image_warping cat512 (reference data) GN 8x100", "image_warping", (512, 512), cat512(), 8, 100))
+out.append(run("image_warping 512x512 synthetic GN 8x100", "image_warping", (512, 512), syn.image_warping(512, 512), 8, 100))
 p = syn.arap_mesh(320, 320)
 out.append(run("arap_mesh 102400 v / 614400 e GN 20x100", "arap_mesh_deformation", (p[2].shape[0], p[6].shape[0]), p, 5, 100))
 out.append(run("shape_from_shading 2048x2048 GN x10", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 6, 10))

@@ -135,6 +135,10 @@ int thallo_hip_linear_update(float* X, const float* delta, const float* p, long 
                              thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_stream_t stream);
 
 /* out[0] = sum(partials) -- used for cost / model-cost read-back (gauss_newton.t:1128-1150). */
+/* X += delta + alpha_older * p_older + alpha * p (in that order): the tail of a GN step whose last two delta updates were
+   deferred (THALLO_IW_STEP1_MODE batching with an even number of PCG iterations) */
+int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older, thallo_sum_t alphaN_older, thallo_sum_t alphaD_older,
+                              const float* p, thallo_sum_t alphaN, thallo_sum_t alphaD, long len, thallo_stream_t stream);
 int thallo_hip_finish_sum(thallo_sum_t s, float* out, thallo_stream_t stream);
 
 /* Row-slab exchange helpers (multi-GPU).  One rank's message per PCG iteration is
@@ -202,8 +206,17 @@ int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset
 int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
-                            int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                            int mode, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                            thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
                             const int* irregular, const float* r, float* alphaD_out, thallo_stream_t stream);
+/* mode: bit 0 = first PCG iteration of the GN step (p = z, delta untouched); bits 1-2 = the delta update this launch carries:
+ *   0  delta += alpha_{k-1} p_{k-1}                          (every iteration: the plain fused schedule)
+ *   1  none -- deferred to the next launch
+ *   2  delta += alpha_{k-2} p_{k-2}, then += alpha_{k-1} p_{k-1}   (p_{k-2} is read from p_out just before it is overwritten;
+ *      alphaN_prev2 / alphaD_prev2 = the scalars of iteration k-2)
+ * Alternating 1, 2 halves delta's read + write traffic (-6 B/pixel/iteration) and produces the same bits as mode 0 throughout.
+ * THALLO_IW_STEP1_MODE(k, batched) gives the mode of iteration k. */
+#define THALLO_IW_STEP1_MODE(k, batched) ((k) == 0 ? 1 : !(batched) ? 0 : ((k) & 1) ? 2 : 4)
 /* image_warping's PCGStep2 (gauss_newton.t:801-843 minus delta): r -= alpha*Ap, betaN partials = sum (M^-1 r).r over the owned
  * rows.  When *irregular == 0 (UrShape = unit pixel grid) M^-1 is recomputed from the flags byte and z is NOT written
  * (37 B/pixel instead of 60) -- pcg_step1 then forms z = M^-1 r from `r` on the fly; otherwise pre is read and z written. */

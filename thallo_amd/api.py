@@ -88,7 +88,8 @@ def lib():
     L.thallo_hip_finish_sum.argtypes = [SumT, vp, vp]
     L.thallo_hip_iw_cost.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp]
     L.thallo_hip_iw_pcg_init.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, vp, vp, vp, vp]
+    L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, SumT, SumT, vp, vp, vp, vp]
+    L.thallo_hip_linear_update2.argtypes = [vp, vp, vp, SumT, SumT, vp, SumT, SumT, cl, vp]
     L.thallo_hip_ipc_alloc.argtypes = [C.c_long, C.POINTER(vp), vp]
     L.thallo_hip_ipc_open.argtypes = [vp, C.POINTER(vp)]
     L.thallo_hip_ipc_close.argtypes = [vp]; L.thallo_hip_ipc_free.argtypes = [vp]

@@ -91,7 +91,7 @@ __device__ __forceinline__ void pre_from_flags(unsigned char f, float wf2, float
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct Owned { float2 zv, pv, dv, csv, uv; float zav, pav, da; unsigned char ff; };
+struct Owned { float2 zv, pv, dv, csv, uv, ppv; float zav, pav, da, ppa; unsigned char ff; };
 struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
 
 // ------------------------------------------------------------------------------------------ PCGStep1
@@ -103,10 +103,16 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
                                            const unsigned char* __restrict__ flags, float wf2, float wr2,
                                            const float* __restrict__ z, const float* __restrict__ p_in,
                                            float* __restrict__ p_out, float* __restrict__ delta,
-                                           float* __restrict__ Ap, int first,
-                                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
+                                           float* __restrict__ Ap, int mode,
+                                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                            float* __restrict__ aD_out, int dbg)
-{   // GRID: `z` points at r, and z = M^-1 r is formed here from the flags byte (pre_from_flags)
+{   // mode: bit0 = first PCG iteration (p = z, no delta update); bits1-2 = delta update of this launch:
+    //   0: delta += alpha_{k-1} p_{k-1}   1: none (deferred)   2: delta += alpha_{k-2} p_{k-2} ; += alpha_{k-1} p_{k-1}
+    // (2 reads p_{k-2} from the p_out buffer just before overwriting it; alternating 1 / 2 halves delta's read+write traffic
+    //  and gives the same bits as updating every iteration: the adds happen in the same order)
+    const int first = mode & 1;
+    const int dmode = first ? 1 : (mode >> 1) & 3;
+    // GRID: `z` points at r, and z = M^-1 r is formed here from the flags byte (pre_from_flags)
     constexpr int PER = TH / (NT / TW);                    // owned pixels per thread (one column): 4 at 256 threads, 2 at 512
     const int ntm = dbg >> 8; dbg &= 0xff;
     const bool nt_delta = ntm & 1, nt_const = ntm & 2, nt_pin = ntm & 4, nt_ap = ntm & 8, nt_z = ntm & 32, nt_pout = ntm & 64;
@@ -149,7 +155,10 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
                 if (!GRID) ow[k].uv = ldf2(ur + pix, nt_const);
                 if (FUSED) {
                     ow[k].zv = ldf2(zo + pix, nt_z); ow[k].zav = ldf(za + pix, nt_z);
-                    if (!first && ow_in[k]) { ow[k].dv = ldf2(dlo + pix, nt_delta); ow[k].da = ldf(dla + pix, nt_delta); }
+                    if (dmode != 1 && ow_in[k]) {
+                        ow[k].dv = ldf2(dlo + pix, nt_delta); ow[k].da = ldf(dla + pix, nt_delta);
+                        if (dmode == 2) { ow[k].ppv = ldf2(qo + pix, nt_pin); ow[k].ppa = ldf(qa + pix, nt_pin); }
+                    }
                 }
             }
         }
@@ -166,12 +175,13 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
     };
 
     TileSweep t(g.ntiles);
-    float alpha = 0.0f, beta = 0.0f;
+    float alpha = 0.0f, beta = 0.0f, alpha2 = 0.0f;
     if (t.valid()) issue_loads(t.cur);
     if (FUSED && !first) {   // PCGStep3 of iteration k-1 (gauss_newton.t:892-896) and its alpha (:807-812)
         const float an = sum_partials(aNp.partials, aNp.count);
         alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
         beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+        if (dmode == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
     }
 
     float acc = 0.0f;
@@ -193,9 +203,13 @@ __device__ __forceinline__ void step1_body(Tile& T, float* red, const Geo& g, co
                     if (GRID) { float mo, ma; pre_from_flags(ow[k].ff, wf2, wr2, mo, ma); zx *= mo; zy *= mo; zq *= ma; }
                     npx = zx + beta * ow[k].pv.x; npy = zy + beta * ow[k].pv.y; npa = zq + beta * ow[k].pav;
                     stf2(qo + pix, make_float2(npx, npy), nt_pout); stf(qa + pix, npa, nt_pout);      // owned, or ghost row kept current
-                    if (!first && ow_in[k]) {
-                        stf2(dlo + pix, make_float2(ow[k].dv.x + alpha * ow[k].pv.x, ow[k].dv.y + alpha * ow[k].pv.y), nt_delta);
-                        stf(dla + pix, ow[k].da + alpha * ow[k].pav, nt_delta);
+                    if (dmode != 1 && ow_in[k]) {
+                        float dx = ow[k].dv.x, dy = ow[k].dv.y, dq = ow[k].da;
+                        // explicit fma everywhere a delta update is applied (here, linear_update, linear_update2): deferring an
+                        // update must not change a single bit
+                        if (dmode == 2) { dx = __builtin_fmaf(alpha2, ow[k].ppv.x, dx); dy = __builtin_fmaf(alpha2, ow[k].ppv.y, dy); dq = __builtin_fmaf(alpha2, ow[k].ppa, dq); }
+                        stf2(dlo + pix, make_float2(__builtin_fmaf(alpha, ow[k].pv.x, dx), __builtin_fmaf(alpha, ow[k].pv.y, dy)), nt_delta);
+                        stf(dla + pix, __builtin_fmaf(alpha, ow[k].pav, dq), nt_delta);
                     }
                 } else { npx = ow[k].pv.x; npy = ow[k].pv.y; npa = ow[k].pav; }
                 c1 = ow[k].csv.x; s1 = ow[k].csv.y; ff = ow[k].ff;
@@ -276,8 +290,8 @@ __global__ __launch_bounds__(NT, MINW) void k_step1(Geo g, const float2* __restr
                                                         const unsigned char* __restrict__ flags, float wf2, float wr2,
                                                         const float* __restrict__ z, const float* __restrict__ p_in,
                                                         float* __restrict__ p_out, float* __restrict__ delta,
-                                                        float* __restrict__ Ap, int first,
-                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
+                                                        float* __restrict__ Ap, int mode,
+                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                                         float* __restrict__ aD_out, int dbg, const int* __restrict__ irregular,
                                                         const float* __restrict__ r)
 {
@@ -285,8 +299,8 @@ __global__ __launch_bounds__(NT, MINW) void k_step1(Geo g, const float2* __restr
     __shared__ float red[16];
     // `irregular` = number of pixels whose UrShape neighbours are not at unit offsets (written by pcg_init); wave-uniform
     const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
-    if (grid) step1_body<FUSED, true, NT>(T, red, g, cs, ur, flags, wf2, wr2, FUSED ? r : z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
-    else      step1_body<FUSED, false, NT>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, dbg);
+    if (grid) step1_body<FUSED, true, NT>(T, red, g, cs, ur, flags, wf2, wr2, FUSED ? r : z, p_in, p_out, delta, Ap, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, dbg);
+    else      step1_body<FUSED, false, NT>(T, red, g, cs, ur, flags, wf2, wr2, z, p_in, p_out, delta, Ap, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, dbg);
 }
 
 // ------------------------------------------------------------------------------------------ PCGStep2
@@ -535,7 +549,7 @@ int thallo_hip_iw_pcg_init(int W, int H, int row0, int row1, const float* offset
 int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,
                             float w_fit, float w_reg,
                             const float* z, const float* p_in, float* p_out, float* delta, float* Ap,
-                            int first, thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp,
+                            int mode, thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                             const int* irregular, const float* r, float* aD_out, thallo_stream_t stream)
 {
     if (!r || ((2L * W * H) & 3)) irregular = nullptr;      // the z-free path needs r and 16-byte planes
@@ -546,12 +560,12 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
         grid = grid_for(g, g_step1_per_cu > 2 ? 2 : g_step1_per_cu);
         hipLaunchKernelGGL((k_step1<true, 4, 512>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g,
                            (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular, r);
+                           z, p_in, p_out, delta, Ap, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular, r);
     } else {                            // 3 workgroups of 4 waves per CU (165 VGPRs)
         grid = grid_for(g, g_step1_per_cu);
         hipLaunchKernelGGL((k_step1<true, 3, 256>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                            (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                           z, p_in, p_out, delta, Ap, first, aNp, aDp, bNp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular, r);
+                           z, p_in, p_out, delta, Ap, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, g_iw_debug | (g_nt_mask << 8), g_no_grid ? nullptr : irregular, r);
     }
     int e = check_launch(); return e ? e : grid;
 }
@@ -607,7 +621,7 @@ int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, c
     /* z / p_out / delta are unused when !FUSED: pass valid dummies */
     hipLaunchKernelGGL((k_step1<false, 4, 256>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g,
                        (const float2*)cs, (const float2*)urshape, flags, w_fit * w_fit, w_reg * w_reg,
-                       p, p, Ap, Ap, Ap, 1, none, none, none, aD_out, g_iw_debug, g_no_grid ? nullptr : irregular, p);
+                       p, p, Ap, Ap, Ap, 1, none, none, none, none, none, aD_out, g_iw_debug, g_no_grid ? nullptr : irregular, p);
     int e = check_launch(); return e ? e : grid;
 }
 

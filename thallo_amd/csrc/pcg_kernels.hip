@@ -270,7 +270,21 @@ __global__ __launch_bounds__(BLOCK) void k_linear_update(float* __restrict__ X, 
     if (HAS_P) alpha = safe_div<false>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < len; i += (long)gridDim.x * BLOCK) {
         float d = delta[i];
-        if (HAS_P) d += alpha * p[i];
+        if (HAS_P) d = __builtin_fmaf(alpha, p[i], d);      // explicit fma: the same rounding wherever a delta update is applied
+        X[i] = X[i] + d;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_linear_update2(float* __restrict__ X, const float* __restrict__ delta,
+                                                           const float* __restrict__ p0, thallo_sum_t aN0, thallo_sum_t aD0,
+                                                           const float* __restrict__ p1, thallo_sum_t aN1, thallo_sum_t aD1, long len)
+{
+    const float a0 = safe_div<false>(sum_partials(aN0.partials, aN0.count), sum_partials(aD0.partials, aD0.count));
+    const float a1 = safe_div<false>(sum_partials(aN1.partials, aN1.count), sum_partials(aD1.partials, aD1.count));
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < len; i += (long)gridDim.x * BLOCK) {
+        float d = delta[i];
+        d = __builtin_fmaf(a0, p0[i], d);
+        d = __builtin_fmaf(a1, p1[i], d);
         X[i] = X[i] + d;
     }
 }
@@ -456,6 +470,16 @@ int thallo_hip_linear_update(float* X, const float* delta, const float* p, long 
     hipStream_t s = (hipStream_t)stream;
     if (p) hipLaunchKernelGGL(k_linear_update<true>, dim3(grid), dim3(BLOCK), 0, s, X, delta, p, len, aN, aD);
     else   hipLaunchKernelGGL(k_linear_update<false>, dim3(grid), dim3(BLOCK), 0, s, X, delta, p, len, aN, aD);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
+int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older, thallo_sum_t aN0, thallo_sum_t aD0,
+                              const float* p, thallo_sum_t aN1, thallo_sum_t aD1, long len, thallo_stream_t stream)
+{
+    if (!p_older || !p) return -(int)hipErrorInvalidValue;
+    const int grid = flat_grid(len, cu_count());
+    hipLaunchKernelGGL(k_linear_update2, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, X, delta, p_older, aN0, aD0, p, aN1, aD1, len);
     int e = check_launch();
     return e ? e : grid;
 }

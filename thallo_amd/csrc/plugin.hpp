@@ -81,6 +81,12 @@ public:
     // fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k): reads p[cur], writes p[cur^1], Ap, alphaD partials
     virtual int pcg_step1(LaunchCtx&, SolverVectors&, int cur, bool first,
                           thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev, float* alphaD_out) = 0;
+    // Plugins whose fused PCGStep1 can defer every other delta update (thallo_hip.h THALLO_IW_STEP1_MODE) return true and
+    // implement pcg_step1_mode; the driver then finishes the GN step with up to two pending alpha*p terms.
+    virtual bool batches_delta() const { return false; }
+    virtual int pcg_step1_mode(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev,
+                               thallo_sum_t, thallo_sum_t, float* alphaD_out)
+    { return pcg_step1(c, v, cur, (mode & 1) != 0, aN_prev, aD_prev, bN_prev, alphaD_out); }
     // PCGStep2 (r -= alpha Ap, z = M^-1 r, betaN partials); default = the energy-independent flat kernel
     virtual int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* betaN_out)
     {

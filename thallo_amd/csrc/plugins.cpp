@@ -87,8 +87,17 @@ public:
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
+        const thallo_sum_t none = { nullptr, 0 };
         return thallo_hip_iw_pcg_step1(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
-                                       v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, (const int*)irregular.ptr, v.r, out, c.stream);
+                                       v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, none, none, (const int*)irregular.ptr, v.r, out, c.stream);
+    }
+    bool batches_delta() const override { return true; }
+    int pcg_step1_mode(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN,
+                       thallo_sum_t aN2, thallo_sum_t aD2, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_iw_pcg_step1(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                       v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, mode, aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, v.r, out, c.stream);
     }
     int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* out) override
     {

@@ -275,11 +275,13 @@ int Plan::step_gn(int ev_iter)
     set_nb(B, nb); finish(B);
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
+    const bool batched = plugin->batches_delta();      // every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         // PCGStep1 (+ previous iteration's PCGStep3 and delta update)
         thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), bNp = sum(jN);
-        nb = plugin->pcg_step1(ctx, v_, cur_, k == 0, aNp, aDp, bNp, slot(jD));
+        if (batched) nb = plugin->pcg_step1_mode(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, 1), aNp, aDp, bNp, sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), slot(jD));
+        else         nb = plugin->pcg_step1(ctx, v_, cur_, k == 0, aNp, aDp, bNp, slot(jD));
         if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
         set_nb(jD, nb); finish(jD); cur_ ^= 1;
         nb = plugin->pcg_step2(ctx, v_, sum(jN), sum(jD), slot(jB));      // PCGStep2 (r, z, betaN)
@@ -295,7 +297,11 @@ int Plan::step_gn(int ev_iter)
         for (size_t k = 0; k < imgs.size(); ++k) {
             TimedLaunch t(ctx, "PCGLinearUpdate");
             const int jN = B + 2 * (L - 1), jD = jN + 1;
-            if (L > 0) thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_] + off, imgs[k].n_floats, sum(jN), sum(jD), s);
+            // batched: after the last PCGStep1 (k = L-1) delta holds the terms up to p_{L-2} if L-1 is even, up to p_{L-3} if it is odd
+            if (L > 1 && batched && ((L - 1) & 1))
+                thallo_hip_linear_update2(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_ ^ 1] + off, sum(jN - 2), sum(jD - 2),
+                                          v_.p[cur_] + off, sum(jN), sum(jD), imgs[k].n_floats, s);
+            else if (L > 0) thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_] + off, imgs[k].n_floats, sum(jN), sum(jD), s);
             else       thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
             off += imgs[k].n_floats;
         }

@@ -171,12 +171,17 @@ class HipSlabBackend:
             vp(self.r.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.delta.data_ptr()),
             vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), None, vp(self.irregular.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_init")
 
-    def step1(self, cur, first, iN, iD, iB, out_idx):
+    batches_delta = True          # the fused kernel can defer every other delta update (thallo_hip.h THALLO_IW_STEP1_MODE)
+
+    def step1(self, cur, mode, iN, iD, iB, out_idx, iN2=None, iD2=None):
+        """mode: True / 1 = first PCG iteration, False / 0 = plain, 2 = defer the delta update, 4 = apply two (needs iN2, iD2)"""
         vp, fl = C.c_void_p, C.c_float
+        mode = int(mode)
+        s2 = (self._sum(iN2), self._sum(iD2)) if iN2 is not None else (api.SumT(None, 0), api.SumT(None, 0))
         self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1(
             self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
             fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
-            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), 1 if first else 0, self._sum(iN), self._sum(iD), self._sum(iB),
+            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), mode, self._sum(iN), self._sum(iD), self._sum(iB), s2[0], s2[1],
             vp(self.irregular.data_ptr()), vp(self.r.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
         self._chk(self.L.thallo_hip_finish_sum(self._local(), vp(self.S.data_ptr() + 4 * out_idx), self._st()), "finish_sum")
 
@@ -210,6 +215,16 @@ class HipSlabBackend:
             p_ptr = vp(self.p[cur].data_ptr() + 4 * off) if with_p else None
             self._chk(self.L.thallo_hip_linear_update(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off), p_ptr, C.c_long(ln),
                                                       self._sum(iN), self._sum(iD), self._st()), "linear_update")
+
+    def linear_update2(self, cur, iN0, iD0, iN1, iD1):
+        """X += delta + alpha_{L-2} p_{L-2} + alpha_{L-1} p_{L-1}: the tail of a GN step with two deferred delta updates"""
+        vp = C.c_void_p
+        W, N = self.W, self.N
+        rows = self.row1 - self.row0
+        for X, off, ln, xo in ((self.offset, 2 * W * self.row0, 2 * W * rows, 2 * W * self.row0), (self.angle, 2 * N + W * self.row0, W * rows, W * self.row0)):
+            self._chk(self.L.thallo_hip_linear_update2(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off),
+                                                       vp(self.p[cur ^ 1].data_ptr() + 4 * off), self._sum(iN0), self._sum(iD0),
+                                                       vp(self.p[cur].data_ptr() + 4 * off), self._sum(iN1), self._sum(iD1), C.c_long(ln), self._st()), "linear_update2")
 
     # -- device-side exchange (thallo_dist_t, include/thallo_hip.h): mailboxes + neighbour r rows over xGMI peer-to-peer stores
     def _ipc_alloc(self, nbytes):
@@ -266,12 +281,14 @@ class HipSlabBackend:
         """S[out_idx] <- rank-ordered sum over ranks of (fixed-order sum of this rank's current partials)"""
         self._chk(self.L.thallo_hip_dist_exchange(self.p2p, out_idx, self._local(), C.c_void_p(self.S.data_ptr() + 4 * out_idx), self._st()), "dist_exchange")
 
-    def step1_p2p(self, cur, first, iN, iD, iB, out_idx):
+    def step1_p2p(self, cur, mode, iN, iD, iB, out_idx, iN2=None, iD2=None):
         vp, fl = C.c_void_p, C.c_float
+        mode = int(mode)
+        s2 = (self._sum(iN2), self._sum(iD2)) if iN2 is not None else (api.SumT(None, 0), api.SumT(None, 0))
         self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1(
             self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
             fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
-            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), 1 if first else 0, self._sum(iN), self._sum(iD), self._sum(iB),
+            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), mode, self._sum(iN), self._sum(iD), self._sum(iB), s2[0], s2[1],
             vp(self.irregular.data_ptr()), vp(self.r.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
         self.p2p_exchange(out_idx)              # alphaD
 
@@ -371,6 +388,7 @@ class SlabSolver:
         be = self.be
         B, L = 2, l_iters
         cur = 0
+        batched = getattr(be, "batches_delta", False)
         be.init(cur)                                   # local alphaN partials, z, ...
         if self.use_dist and hasattr(be, "pack_grid_info"):
             # every rank must pick the same PCG schedule (z-free iff UrShape is the pixel grid everywhere), and the ghost rows
@@ -382,12 +400,18 @@ class SlabSolver:
         self._gather_sum_and_rows(B)                   # S[B] = alphaN_0 (global); ghost rows of z
         for k in range(L):
             jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
-            be.step1(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
+            if batched:                                # every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
+                be.step1(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD,
+                         jN - 4 if k > 1 else jN, jD - 4 if k > 1 else jD)
+            else:
+                be.step1(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
             self._allreduce(jD)                        # alphaD_k
             cur ^= 1
             be.step2(jN, jD)
             self._gather_sum_and_rows(jB)              # betaN_k ; ghost rows of z
-        if L > 0:
+        if L > 1 and batched and (L - 1) & 1:
+            be.linear_update2(cur, B + 2 * (L - 2), B + 2 * (L - 2) + 1, B + 2 * (L - 1), B + 2 * (L - 1) + 1)
+        elif L > 0:
             be.linear_update(cur, B + 2 * (L - 1), B + 2 * (L - 1) + 1, True)
         else:
             be.linear_update(cur, B, B, False)
@@ -408,6 +432,7 @@ class SlabSolver:
         be = self.be
         B, L = 2, l_iters
         cur = 0
+        batched = getattr(be, "batches_delta", False)
         be.init(cur)
         if self.use_dist:
             send = be.pack_grid_info()
@@ -418,10 +443,16 @@ class SlabSolver:
         be.p2p_begin()                                 # seq += 1
         for k in range(L):
             jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
-            be.step1_p2p(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
+            if batched:                                # every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
+                be.step1_p2p(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD,
+                             jN - 4 if k > 1 else jN, jD - 4 if k > 1 else jD)
+            else:
+                be.step1_p2p(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
             cur ^= 1
             be.step2_p2p(jN, jD, jB)
-        if L > 0:
+        if L > 1 and batched and (L - 1) & 1:
+            be.linear_update2(cur, B + 2 * (L - 2), B + 2 * (L - 2) + 1, B + 2 * (L - 1), B + 2 * (L - 1) + 1)
+        elif L > 0:
             be.linear_update(cur, B + 2 * (L - 1), B + 2 * (L - 1) + 1, True)
         else:
             be.linear_update(cur, B, B, False)

@@ -47,7 +47,7 @@ def timeit(fn, reps=REPS):
 def step1_fused(first=0, zfree=True):
     nb = L.thallo_hip_iw_pcg_step1(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
                                    vp(z.data_ptr()), vp(p0.data_ptr()), vp(p1.data_ptr()), vp(delta.data_ptr()), vp(Ap.data_ptr()),
-                                   first, s_aN, s_aN, s_aN, vp(irregular.data_ptr()), vp(r.data_ptr()) if zfree else None, vp(PB + 4096), None)
+                                   first, s_aN, s_aN, s_aN, s_aN, s_aN, vp(irregular.data_ptr()), vp(r.data_ptr()) if zfree else None, vp(PB + 4096), None)
     assert nb > 0
     return nb
 

@@ -108,6 +108,7 @@ def main():
         return
 
     _L = thallo_amd.lib()      # tuning knobs for experiments (tools/sweep_nt.sh); defaults are the product settings
+    if "THALLO_ITER_NT" in os.environ: _L.thallo_hip_debug_set(7, int(os.environ["THALLO_ITER_NT"]))
     if "THALLO_NT1" in os.environ: _L.thallo_hip_debug_set(3, int(os.environ["THALLO_NT1"]))
     if "THALLO_NT2" in os.environ: _L.thallo_hip_debug_set2(int(os.environ["THALLO_NT2"]))
     if "THALLO_PER_CU" in os.environ: _L.thallo_hip_debug_set(5, int(os.environ["THALLO_PER_CU"]))
@@ -133,16 +134,18 @@ def main():
     final_cost = s.current_cost()
 
     npx = W * H
-    step1_ms = ks["PCGStep1"]["mean_ms"]
-    step2_ms = ks["PCGStep2"]["mean_ms"]
-    fused_gbs = ALG_BYTES_FUSED_STEP1 * npx / (step1_ms * 1e-3) / 1e9
+    one_kernel = "PCGIteration" in ks          # one kernel per PCG iteration (thallo_hip_iw_pcg_iter) vs PCGStep1 + PCGStep2
+    dom = "PCGIteration" if one_kernel else "PCGStep1"
+    dom_alg = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1
+    step1_ms = ks[dom]["mean_ms"]
+    fused_gbs = dom_alg * npx / (step1_ms * 1e-3) / 1e9
     sa_ms = standalone_applyjtj(torch, W, H, p)
     sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("PCGStep1_bytes_per_launch")
+            traffic = json.load(open(tf)).get(dom + "_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -156,16 +159,18 @@ def main():
         "ms_per_gn_iter": dt / K * 1e3, "us_per_pcg_iter": dt / (K * L_it) * 1e6,
         "pcg_iter_algorithmic_GBps": ALG_BYTES_PCG_ITER * npx * K * L_it / dt / 1e9,
         "final_cost": final_cost,
-        "roofline": {"bound": "hbm", "kernel": "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)",
+        "roofline": {"bound": "hbm",
+                     "kernel": ("PCGIteration (one launch = PCGStep2 of iteration k-1 + PCGStep3 + delta update + applyJTJ of iteration k)"
+                                if one_kernel else "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)"),
                      "achieved": fused_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused_gbs / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_pixel": ALG_BYTES_FUSED_STEP1,
-                     "avg_launch_ms": step1_ms, "samples": ks["PCGStep1"]["samples"],
+                     "traffic": traffic, "algorithmic_bytes_per_pixel": dom_alg,
+                     "avg_launch_ms": step1_ms, "samples": ks[dom]["samples"],
                      "applyjtj_standalone": {"algorithmic_bytes_per_pixel": ALG_BYTES_APPLYJTJ, "avg_launch_ms": sa_ms,
-                                             "achieved": sa_gbs, "frac": sa_gbs / HBM_PEAK_GBS},
-                     # z-free schedule (UrShape = pixel grid): read r 12, Ap 12, flags 1; write r 12.  No pre read, no z write
-                     "pcg_step2": {"algorithmic_bytes_per_pixel": 37, "avg_launch_ms": step2_ms,
-                                   "achieved": 37 * npx / (step2_ms * 1e-3) / 1e9}},
+                                             "achieved": sa_gbs, "frac": sa_gbs / HBM_PEAK_GBS}},
     }
+    if not one_kernel:      # z-free two-kernel schedule: read r 12, Ap 12, flags 1; write r 12
+        step2_ms = ks["PCGStep2"]["mean_ms"]
+        out["roofline"]["pcg_step2"] = {"algorithmic_bytes_per_pixel": 37, "avg_launch_ms": step2_ms, "achieved": 37 * npx / (step2_ms * 1e-3) / 1e9}
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
         q = syn.image_warping(W, H)

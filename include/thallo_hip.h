@@ -217,6 +217,31 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
  * Alternating 1, 2 halves delta's read + write traffic (-6 B/pixel/iteration) and produces the same bits as mode 0 throughout.
  * THALLO_IW_STEP1_MODE(k, batched) gives the mode of iteration k. */
 #define THALLO_IW_STEP1_MODE(k, batched) ((k) == 0 ? 1 : !(batched) ? 0 : ((k) & 1) ? 2 : 4)
+/* One kernel per PCG iteration (replaces pcg_step1 + pcg_step2 of iteration k-1/k): r_out = r_in - alpha_{k-1} Ap_in (first:
+ * r_in), z = M^-1 r_out (pixel grid: from the flags byte; else from `pre`), p_out = z + beta_{k-1} p_in, the deferred delta
+ * update (mode as in pcg_step1), Ap_out = J^T J p_out, and per workgroup: alphaD partial (float) into alphaD_out[b] and the three
+ * double sums N = sum r.M^-1.r, S1 = sum r.M^-1.Ap, S2 = sum Ap.M^-1.Ap into s12_out[3b .. 3b+2] (3 * THALLO_HIP_MAX_PARTIALS
+ * doubles).  pcg_iter_finish (one wave) then writes alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2
+ * (= r_{k+1}.M^-1 r_{k+1}, evaluated in double from exact products of the float data), i.e. both PCG scalars of the iteration come
+ * from ONE reduction point.  r, Ap and p ping-pong (in != out); ghost rows of a slab: r and p are
+ * kept current by the kernel, Ap_in's ghost rows have to be refreshed from the neighbour.  81 B/pixel (+18 deferred delta). */
+int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,
+                           float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                           const float* p_in, float* p_out, float* delta, int mode,
+                           thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                           thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
+                           const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+/* the same over a row slab of a multi-GPU run: additionally stores the first / last owned row of Ap_out into the neighbours' ghost rows
+   (d.peer_r[k] + d.peer_off_o/a[k] = that row inside the neighbour's Ap_out buffer), peer-to-peer */
+int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,
+                                float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                const float* p_in, float* p_out, float* delta, int mode,
+                                thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                                thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
+                                const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+int thallo_hip_iw_pcg_iter_finish(const float* alphaD_partials, const double* s12_partials, int count, thallo_sum_t alphaN,
+                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+
 /* image_warping's PCGStep2 (gauss_newton.t:801-843 minus delta): r -= alpha*Ap, betaN partials = sum (M^-1 r).r over the owned
  * rows.  When *irregular == 0 (UrShape = unit pixel grid) M^-1 is recomputed from the flags byte and z is NOT written
  * (37 B/pixel instead of 60) -- pcg_step1 then forms z = M^-1 r from `r` on the fly; otherwise pre is read and z written. */
@@ -327,6 +352,12 @@ int thallo_hip_dist_begin_step(thallo_dist_t d, thallo_stream_t stream);
    as a thallo_sum_t of count 1; the kernel boundaries also order the neighbours' ghost rows (stored by their PCGStep2 before
    their granule) ahead of every later read. */
 int thallo_hip_dist_exchange(thallo_dist_t d, int slot, thallo_sum_t local, float* out, thallo_stream_t stream);
+/* The exchange of the one-kernel-per-iteration schedule: local fixed-order sums of the alphaD partials (float) and of the N, S1, S2
+   partials (double) of thallo_hip_iw_pcg_iter(_dist), 7 granules to every rank (slots slot0 .. slot0+6), bounded wait, rank-ordered
+   sums, then alphaD_word[0] = alphaD_k and betaN_word[0] = N - 2 alpha_k S1 + alpha_k^2 S2 with alpha_k = alphaN / alphaD_k
+   (alphaN: a one-word sum).  ONE exchange per PCG iteration. */
+int thallo_hip_dist_exchange_iter(thallo_dist_t d, int slot0, const float* alphaD_partials, const double* s12_partials, int count, thallo_sum_t alphaN,
+                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* out[j] = rank-ordered sum of slot slot0+j for j < nslots (waits for each); diagnostics */
 int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, thallo_stream_t stream);
 /* host-side read / clear of the error word (synchronises the stream) */

@@ -67,6 +67,7 @@ int g_iw_debug = 0;
 int g_step1_threads = 512; // fused step: 512 threads x 2 px/thread (default) or 256 x 4
 int g_step1_per_cu = 3; // microbench: workgroups per CU for the fused step (3 = VGPR limit)
 int g_no_grid = 0;      // microbench: 1 = ignore the regular-grid fast path
+int g_iter_nt = 31;      // one-kernel iteration, non-temporal bits: 1 delta, 2 r/Ap loads, 4 r/Ap stores, 8 p loads, 16 p stores, 32 cs/flags (31 measured best)
 int g_nt_mask = 1;      // delta non-temporal: measured +1-3 % PCG it/s at 2048^2 (tools/sweep_nt.sh)
 
 struct Tile {
@@ -513,11 +514,282 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int row0, int row1
     block_store_partial(acc, out, red);
 }
 
+// ------------------------------------------------------------------------------------------ one kernel per PCG iteration
+// The whole PCG iteration k in ONE pass (replaces PCGStep1 + PCGStep2 + PCGStep3, gauss_newton.t:734-752,801-843,889-899):
+//     r_k   = r_{k-1} - alpha_{k-1} A p_{k-1}        (owned + halo; fma, correctly rounded)          [first: r_0 as is]
+//     z_k   = M^-1 r_k ;  p_k = z_k + beta_{k-1} p_{k-1} ;  delta += ... (deferred as in PCGStep1)
+//     A p_k = J^T J p_k ;  alphaD_k = sum p_k . A p_k
+// and, so that beta_k is known without a second pass over r,
+//     N_k = sum r_k . M^-1 r_k ,  S1_k = sum r_k . M^-1 A p_k ,  S2_k = sum (A p_k) . M^-1 (A p_k)      (double precision)
+//     betaN_k = r_{k+1} . M^-1 r_{k+1} = N_k - 2 alpha_k S1_k + alpha_k^2 S2_k        (k_iter_finish, in double)
+// which is the same number the reference adds up from the rounded r_{k+1} to ~1e-7 relative (the products are exact in
+// double, r_{k+1} itself still follows the true recurrence).  One reduction point per iteration instead of two.
+// r, Ap and p ping-pong (a neighbouring tile reads the old value of a pixel this tile overwrites).
+// Bytes per pixel (pixel grid): read r 12, Ap 12, p 12, cs 8, flags 1; write r 12, p 12, Ap 12 = 81 (+ 18 deferred delta on
+// average) against 75 + 37 for the two-kernel form.
+struct TileI : Tile { float rx[LN], ry[LN], ra[LN]; };      // + r_k of the owned pixels (read back in the gather phase)
+struct OwnedI { float2 rv, av, pv, csv, uv, dv, ppv, mv; float ra, aa, pav, da, ppa, ma; unsigned char ff; };
+struct HaloI { float2 rv, av, pv, csv, uv, mv; float ra, aa, pav, ma; unsigned char ff; };
+
+__device__ __forceinline__ double wave_sum_all_d(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
+    return v;
+}
+
+template <bool GRID, int NT, bool DIST = false>
+__device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, const Geo& g, const float2* __restrict__ cs, const float2* __restrict__ ur,
+                                          const unsigned char* __restrict__ flags, const float* __restrict__ pre, float wf2, float wr2,
+                                          const float* __restrict__ r_in, float* __restrict__ r_out, const float* __restrict__ A_in, float* __restrict__ A_out,
+                                          const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, int mode,
+                                          thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
+                                          float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const thallo_dist_t* dd = nullptr)
+{
+    constexpr int PER = TH / (NT / TW);
+    const int first = mode & 1;
+    const int dmode = first ? 1 : (mode >> 1) & 3;                   // as in PCGStep1: 0 single, 1 none, 2 double delta update
+    const bool nt_delta = ntm & 1, nt_ra = ntm & 2, nt_out = ntm & 4, nt_pin = ntm & 8, nt_pout = ntm & 16, nt_const = ntm & 32;
+    const long N = (long)g.W * g.H;
+    const float2* __restrict__ ro = reinterpret_cast<const float2*>(r_in);   const float* __restrict__ ra = r_in + 2 * N;
+    const float2* __restrict__ ao = reinterpret_cast<const float2*>(A_in);   const float* __restrict__ aa = A_in + 2 * N;
+    const float2* __restrict__ po = reinterpret_cast<const float2*>(p_in);   const float* __restrict__ pa = p_in + 2 * N;
+    const float2* __restrict__ mo_ = reinterpret_cast<const float2*>(pre);   const float* __restrict__ ma_ = pre + 2 * N;
+    float2* __restrict__ Ro = reinterpret_cast<float2*>(r_out);  float* __restrict__ Ra = r_out + 2 * N;
+    float2* __restrict__ Ao = reinterpret_cast<float2*>(A_out);  float* __restrict__ Aa = A_out + 2 * N;
+    float2* __restrict__ qo = reinterpret_cast<float2*>(p_out);  float* __restrict__ qa = p_out + 2 * N;
+    float2* __restrict__ dlo = reinterpret_cast<float2*>(delta); float* __restrict__ dla = delta + 2 * N;
+
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * PER;
+    int hlx, hly;
+    {
+        const int h = threadIdx.x;
+        if (h < LW) { hlx = h; hly = 0; }
+        else if (h < 2 * LW) { hlx = h - LW; hly = LH - 1; }
+        else if (h < 2 * LW + TH) { hlx = 0; hly = h - 2 * LW + 1; }
+        else { hlx = LW - 1; hly = h - 2 * LW - TH + 1; }
+    }
+    const bool has_halo = threadIdx.x < HALO;
+    OwnedI ow[PER]; HaloI hl;
+    bool ow_ld[PER], ow_in[PER]; bool hl_in = false;
+
+    auto issue_loads = [&](int tile) {
+        const int x0 = (tile % g.tx) * TW, y0 = g.row0 + (tile / g.tx) * TH;
+        const int gx = x0 + tx;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int gy = y0 + ty + k;
+            ow_ld[k] = gx < g.W && gy < g.H;
+            ow_in[k] = ow_ld[k] && gy < g.row1;
+            if (ow_ld[k]) {
+                const long pix = (long)gy * g.W + gx;
+                ow[k].rv = ldf2(ro + pix, nt_ra); ow[k].ra = ldf(ra + pix, nt_ra);
+                if (!first) { ow[k].av = ldf2(ao + pix, nt_ra); ow[k].aa = ldf(aa + pix, nt_ra); }
+                ow[k].pv = ldf2(po + pix, nt_pin); ow[k].pav = ldf(pa + pix, nt_pin);
+                ow[k].csv = ldf2(cs + pix, nt_const); ow[k].ff = ldb(flags + pix, nt_const);
+                if (!GRID) { ow[k].uv = ur[pix]; ow[k].mv = mo_[pix]; ow[k].ma = ma_[pix]; }
+                if (dmode != 1 && ow_in[k]) {
+                    ow[k].dv = ldf2(dlo + pix, nt_delta); ow[k].da = ldf(dla + pix, nt_delta);
+                    if (dmode == 2) { ow[k].ppv = qo[pix]; ow[k].ppa = qa[pix]; }
+                }
+            }
+        }
+        if (has_halo) {
+            const int hx = x0 + hlx - 1, hy = y0 + hly - 1;
+            hl_in = hx >= 0 && hx < g.W && hy >= 0 && hy < g.H;
+            if (hl_in) {
+                const long pix = (long)hy * g.W + hx;
+                hl.rv = ro[pix]; hl.ra = ra[pix];
+                if (!first) { hl.av = ao[pix]; hl.aa = aa[pix]; }
+                hl.pv = po[pix]; hl.pav = pa[pix]; hl.csv = cs[pix]; hl.ff = flags[pix];
+                if (!GRID) { hl.uv = ur[pix]; hl.mv = mo_[pix]; hl.ma = ma_[pix]; }
+            }
+        }
+    };
+
+    TileSweep t(g.ntiles);
+    if (t.valid()) issue_loads(t.cur);
+    float alpha = 0.0f, beta = 0.0f, alpha2 = 0.0f;
+    if (!first) {
+        const float an = sum_partials(aNp.partials, aNp.count);
+        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
+        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+        if (dmode == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
+    }
+
+    float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    while (t.valid()) {
+        const int x0 = (t.cur % g.tx) * TW, y0 = g.row0 + (t.cur / g.tx) * TH;
+        const int gx = x0 + tx;
+        float cmo[PER], cmy[PER], cma[PER];           // non-GRID only: M^-1 of the owned pixels (GRID recomputes it from the flags byte)
+        bool cin[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = (ty + k + 1) * LW + tx + 1;
+            float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1_ = 0.f, u1 = 0.f, u2 = 0.f, zx = 0.f, zy = 0.f, zq = 0.f, mo = 0.f, my = 0.f, ma = 0.f; unsigned char ff = 0;
+            float rnx = 0.f, rny = 0.f, rnq = 0.f;
+            cin[k] = ow_in[k];
+            if (ow_ld[k]) {
+                const long pix = (long)(y0 + ty + k) * g.W + gx;
+                float rx = ow[k].rv.x, ry = ow[k].rv.y, rq = ow[k].ra;
+                if (!first) { rx = __builtin_fmaf(-alpha, ow[k].av.x, rx); ry = __builtin_fmaf(-alpha, ow[k].av.y, ry); rq = __builtin_fmaf(-alpha, ow[k].aa, rq); }
+                rnx = rx; rny = ry; rnq = rq;
+                stf2(Ro + pix, make_float2(rx, ry), nt_out); stf(Ra + pix, rq, nt_out);     // owned, or a slab's ghost row kept current
+                if (GRID) { pre_from_flags(ow[k].ff, wf2, wr2, mo, ma); my = mo; }
+                else { mo = ow[k].mv.x; my = ow[k].mv.y; ma = ow[k].ma; }
+                zx = mo * rx; zy = my * ry; zq = ma * rq;
+                npx = zx + beta * ow[k].pv.x; npy = zy + beta * ow[k].pv.y; npa = zq + beta * ow[k].pav;
+                stf2(qo + pix, make_float2(npx, npy), nt_pout); stf(qa + pix, npa, nt_pout);
+                if (dmode != 1 && ow_in[k]) {
+                    float dx = ow[k].dv.x, dy = ow[k].dv.y, dq = ow[k].da;
+                    if (dmode == 2) { dx = __builtin_fmaf(alpha2, ow[k].ppv.x, dx); dy = __builtin_fmaf(alpha2, ow[k].ppv.y, dy); dq = __builtin_fmaf(alpha2, ow[k].ppa, dq); }
+                    stf2(dlo + pix, make_float2(__builtin_fmaf(alpha, ow[k].pv.x, dx), __builtin_fmaf(alpha, ow[k].pv.y, dy)), nt_delta);
+                    stf(dla + pix, __builtin_fmaf(alpha, ow[k].pav, dq), nt_delta);
+                }
+                c1 = ow[k].csv.x; s1_ = ow[k].csv.y; ff = ow[k].ff;
+                if (!GRID) { u1 = ow[k].uv.x; u2 = ow[k].uv.y; }
+            }
+            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1_; T.f[i] = ff;
+            T.rx[i] = rnx; T.ry[i] = rny; T.ra[i] = rnq;
+            if (!GRID) { T.ux[i] = u1; T.uy[i] = u2; cmo[k] = mo; cmy[k] = my; cma[k] = ma; }
+        }
+        if (has_halo) {
+            const int i = hly * LW + hlx;
+            float npx = 0.f, npy = 0.f, npa = 0.f, c1 = 1.f, s1_ = 0.f, u1 = 0.f, u2 = 0.f; unsigned char ff = 0;
+            if (hl_in) {
+                float rx = hl.rv.x, ry = hl.rv.y, rq = hl.ra;
+                if (!first) { rx = __builtin_fmaf(-alpha, hl.av.x, rx); ry = __builtin_fmaf(-alpha, hl.av.y, ry); rq = __builtin_fmaf(-alpha, hl.aa, rq); }
+                float mo, my, ma;
+                if (GRID) { pre_from_flags(hl.ff, wf2, wr2, mo, ma); my = mo; } else { mo = hl.mv.x; my = hl.mv.y; ma = hl.ma; }
+                npx = mo * rx + beta * hl.pv.x; npy = my * ry + beta * hl.pv.y; npa = ma * rq + beta * hl.pav;
+                const int hy = y0 + hly - 1;
+                if ((hy < g.row0 || hy >= g.row1) && hlx >= 1 && hlx <= TW) {      // ghost row of a slab: keep its r and p current
+                    const long pix = (long)hy * g.W + (x0 + hlx - 1);
+                    Ro[pix] = make_float2(rx, ry); Ra[pix] = rq;
+                    qo[pix] = make_float2(npx, npy); qa[pix] = npa;
+                }
+                c1 = hl.csv.x; s1_ = hl.csv.y; ff = hl.ff;
+                if (!GRID) { u1 = hl.uv.x; u2 = hl.uv.y; }
+            }
+            T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1_; T.f[i] = ff;
+            if (!GRID) { T.ux[i] = u1; T.uy[i] = u2; }
+        }
+        lds_barrier();
+        const int cur_y0 = y0;
+        t.next();
+        if (t.valid()) issue_loads(t.cur);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (cin[k]) {
+                const int i = (ty + k + 1) * LW + tx + 1;
+                const long pix = (long)(cur_y0 + ty + k) * g.W + gx;
+                float ax = 0.f, ay = 0.f, av = 0.f;
+                const float pxi = T.px[i], pyi = T.py[i], pai = T.pa[i];
+                const unsigned char cfk = T.f[i];
+                if (cfk & 1) {
+                    const float ci = T.c[i], si = T.s[i];
+                    float uxi = 0.f, uyi = 0.f;
+                    if (!GRID) { uxi = T.ux[i]; uyi = T.uy[i]; }
+                    const int nb[4] = { i + 1, i - 1, i + LW, i - LW };
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int j = nb[d];
+                        if (T.f[j] & 1) {
+                            float dux, duy;
+                            if (GRID) { dux = d == 0 ? -1.0f : d == 1 ? 1.0f : 0.0f; duy = d == 2 ? -1.0f : d == 3 ? 1.0f : 0.0f; }
+                            else { dux = uxi - T.ux[j]; duy = uyi - T.uy[j]; }
+                            const float gix = -si * dux - ci * duy, giy = ci * dux - si * duy;
+                            const float cj = T.c[j], sj = T.s[j], paj = T.pa[j];
+                            const float gjx = sj * dux + cj * duy, gjy = -cj * dux + sj * duy;
+                            const float dpx = pxi - T.px[j], dpy = pyi - T.py[j];
+                            const float ex = dpx - gix * pai, ey = dpy - giy * pai;
+                            ax += dpx + ex + gjx * paj;
+                            ay += dpy + ey + gjy * paj;
+                            av -= gix * ex + giy * ey;
+                        }
+                    }
+                    ax *= wr2; ay *= wr2; av *= wr2;
+                    if (cfk & 2) { ax += wf2 * pxi; ay += wf2 * pyi; }
+                }
+                float mo, my, ma;
+                if (GRID) { pre_from_flags(cfk, wf2, wr2, mo, ma); my = mo; } else { mo = cmo[k]; my = cmy[k]; ma = cma[k]; }
+                stf2(Ao + pix, make_float2(ax, ay), nt_out); stf(Aa + pix, av, nt_out);
+                if (DIST) {     // multi-GPU row slabs: the first / last owned row of A p_k also goes into the neighbour's ghost row of its
+                                // Ap_out buffer (peer-to-peer, write-through; complete when this kernel ends, i.e. before the exchange
+                                // kernel behind it sends this rank's granules)
+                    const int gyk = cur_y0 + ty + k;
+                    if (gyk == g.row0 && dd->peer_r[0]) {
+                        float* d2 = dd->peer_r[0] + dd->peer_off_o[0] + 2 * gx; st_sys(d2, ax); st_sys(d2 + 1, ay);
+                        st_sys(dd->peer_r[0] + dd->peer_off_a[0] + gx, av);
+                    }
+                    if (gyk == g.row1 - 1 && dd->peer_r[1]) {
+                        float* d2 = dd->peer_r[1] + dd->peer_off_o[1] + 2 * gx; st_sys(d2, ax); st_sys(d2 + 1, ay);
+                        st_sys(dd->peer_r[1] + dd->peer_off_a[1] + gx, av);
+                    }
+                }
+                acc += pxi * ax + pyi * ay + pai * av;
+                // exact products of the float data, accumulated in double: N = sum r.M^-1.r, S1 = sum r.M^-1.Ap, S2 = sum Ap.M^-1.Ap
+                const double dmo = mo, dmy = my, dma = ma, drx = T.rx[i], dry = T.ry[i], dra = T.ra[i], dax = ax, day = ay, daa = av;
+                s0 += dmo * (drx * drx) + dmy * (dry * dry) + dma * (dra * dra);
+                s1 += dmo * (drx * dax) + dmy * (dry * day) + dma * (dra * daa);
+                s2 += dmo * (dax * dax) + dmy * (day * day) + dma * (daa * daa);
+            }
+        }
+        lds_barrier();
+    }
+    // float alphaD partial + the two double sums, one set per workgroup
+    const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
+    const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
+    if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+        for (int w = 0; w < NT / THALLO_WAVE; ++w) { a += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
+        aD_out[blockIdx.x] = a; s12_out[3 * blockIdx.x] = b0; s12_out[3 * blockIdx.x + 1] = b1; s12_out[3 * blockIdx.x + 2] = b2;
+    }
+}
+
+template <int MINW, int NT, bool DIST>
+__global__ __launch_bounds__(NT, MINW) void k_iter(Geo g, const float2* __restrict__ cs, const float2* __restrict__ ur, const unsigned char* __restrict__ flags,
+                                                       const float* __restrict__ pre, float wf2, float wr2,
+                                                       const float* __restrict__ r_in, float* __restrict__ r_out, const float* __restrict__ A_in, float* __restrict__ A_out,
+                                                       const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, int mode,
+                                                       thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
+                                                       float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const int* __restrict__ irregular,
+                                                       thallo_dist_t dd)
+{
+    __shared__ TileI T;
+    __shared__ float red[16];
+    __shared__ double redd[48];
+    const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
+    if (grid) iter_body<true, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd);
+    else      iter_body<false, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd);
+}
+
+// one wave: alphaD_k (float partials, the usual order), S1_k, S2_k (double partials, same lane-strided order), then
+// betaN_k = alphaN_k - 2 alpha_k S1_k + alpha_k^2 S2_k  with alpha_k = alphaN_k / alphaD_k exactly as every consumer forms it
+__global__ __launch_bounds__(64) void k_iter_finish(const float* __restrict__ aD_part, const double* __restrict__ s12, int nb, thallo_sum_t aN,
+                                                    float* __restrict__ aD_word, float* __restrict__ bN_word)
+{
+    const int lane = threadIdx.x;
+    const float ad = sum_partials(aD_part, nb);
+    double n = 0.0, a = 0.0, b = 0.0;
+    for (int i = lane; i < nb; i += THALLO_WAVE) { n += s12[3 * i]; a += s12[3 * i + 1]; b += s12[3 * i + 2]; }
+    n = wave_sum_all_d(n); a = wave_sum_all_d(a); b = wave_sum_all_d(b);
+    const float an = sum_partials(aN.partials, aN.count);          // what every consumer divides by (the float alphaN_k)
+    const float alpha = safe_div<false>(an, ad);
+    // the expansion starts from the double N = r_k.M^-1.r_k of the very same float data as S1, S2: the cancellation (betaN can be
+    // 1e-3 of alphaN) then costs nothing, which it would with the rounded float alphaN_k
+    double bn = n - 2.0 * (double)alpha * a + (double)alpha * (double)alpha * b;
+    if (!(bn > 0.0)) bn = 0.0;                       // r . M^-1 r is a sum of squares; guards the last bits at convergence
+    if (lane == 0) { aD_word[0] = ad; bN_word[0] = (float)bn; }
+}
+
 }  // namespace
 
 extern "C" {
 
-void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; if (what == 5) g_step1_per_cu = value; if (what == 6) g_step1_threads = value; }
+void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; if (what == 5) g_step1_per_cu = value; if (what == 6) g_step1_threads = value; if (what == 7) g_iter_nt = value; }
 
 int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
@@ -610,6 +882,46 @@ int thallo_hip_iw_pcg_step2_dist(int W, int H, int row0, int row1, const unsigne
                        flags, N, w_fit * w_fit, w_reg * w_reg, off0 / 4, len0 / 4, off1 / 4, len1 / 4, aN, aD, (const int*)nullptr, bN_out, d,
                        2L * W / 4, (long)W / 4);
     int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,
+                           float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                           const float* p_in, float* p_out, float* delta, int mode,
+                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
+                           const int* irregular, float* aD_out, double* s12_out, thallo_stream_t stream)
+{
+    if (!rows_ok(H, row0, row1) || !r_in || !r_out || !Ap_out || !p_in || !p_out || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
+    if (!(mode & 1) && !Ap_in) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1);
+    const int grid = grid_for(g, 2);
+    hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+                       w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{});
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,
+                                float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                const float* p_in, float* p_out, float* delta, int mode,
+                                thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
+                                const int* irregular, thallo_dist_t d, float* aD_out, double* s12_out, thallo_stream_t stream)
+{
+    if (!rows_ok(H, row0, row1) || !r_in || !r_out || !Ap_out || !p_in || !p_out || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
+    if ((!(mode & 1) && !Ap_in) || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1);
+    const int grid = grid_for(g, 2);
+    hipLaunchKernelGGL((k_iter<4, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+                       w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d);
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_iw_pcg_iter_finish(const float* aD_partials, const double* s12_partials, int count, thallo_sum_t alphaN,
+                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream)
+{
+    if (!aD_partials || !s12_partials || count < 1 || count > THALLO_MAX_PARTIALS || !alphaD_word || !betaN_word) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_iter_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, aD_partials, s12_partials, count, alphaN, alphaD_word, betaN_word);
+    return check_launch();
 }
 
 int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags,

@@ -55,6 +55,11 @@ struct SolverVectors {
     float *delta = nullptr, *r = nullptr, *z = nullptr, *Ap = nullptr, *pre = nullptr;
     float *p[2] = { nullptr, nullptr };          // ping-pong: the fused step reads p[cur], writes p[cur^1]
     float *b = nullptr, *Adelta = nullptr, *CtC = nullptr, *SSq = nullptr, *prevX = nullptr, *diag = nullptr;   // LM only
+    // one-kernel-per-iteration schedule (plugins with one_kernel_iteration()): r and Ap ping-pong like p; per-workgroup double sums
+    float *r2 = nullptr, *Ap2 = nullptr;
+    double* s12 = nullptr;                       // 3 * THALLO_HIP_MAX_PARTIALS doubles (N, S1, S2 per workgroup)
+    float* rbuf(int i) { return i ? r2 : r; }
+    float* Abuf(int i) { return i ? Ap2 : Ap; }
 };
 
 struct UnknownImage { int param_index; long n_floats; };
@@ -87,6 +92,11 @@ public:
     virtual int pcg_step1_mode(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev,
                                thallo_sum_t, thallo_sum_t, float* alphaD_out)
     { return pcg_step1(c, v, cur, (mode & 1) != 0, aN_prev, aD_prev, bN_prev, alphaD_out); }
+    // One kernel per PCG iteration (thallo_hip.h thallo_hip_iw_pcg_iter): reads r/Ap/p[cur], writes r/Ap/p[cur^1], alphaD partials
+    // to alphaD_out and the double sums to v.s12; pcg_iter_finish turns them into the two scalar words of the iteration.
+    virtual bool one_kernel_iteration() const { return false; }
+    virtual int pcg_iter(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, float* /*alphaD_out*/) { return -1; }
+    virtual int pcg_iter_finish(LaunchCtx&, SolverVectors&, const float* /*alphaD_partials*/, int /*count*/, thallo_sum_t /*alphaN*/, float* /*alphaD_word*/, float* /*betaN_word*/) { return -1; }
     // PCGStep2 (r -= alpha Ap, z = M^-1 r, betaN partials); default = the energy-independent flat kernel
     virtual int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* betaN_out)
     {

@@ -81,6 +81,7 @@ private:
 
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
+    bool one_kernel_ = true;        // THALLO_ONE_KERNEL=0: two-kernel schedule even where the plugin offers pcg_iter (A/B switch)
     bool finish_sums_ = true;       // THALLO_FINISH_SUMS=0: consumers re-add the partials themselves (A/B switch)
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }
     thallo_sum_t partial_sum(int j) { thallo_sum_t s; s.partials = slot(j); s.count = nb_[j]; return s; }
@@ -91,6 +92,8 @@ private:
     // (small launches -- <= 4 partials per lane -- are cheaper to re-add in place than to pay one more launch for)
     void finish(int j) { if (!finish_sums_ || nb_[j] <= 256) return; thallo_hip_finish_sum(partial_sum(j), scal(j), ctx.stream); fin_[j] = 1; }
     int  ensure_slots(int L);
+    int  ensure_iter_buffers();
+    int  step_gn_one_kernel(int ev_iter);
     float compute_cost();
     int   step_gn(int ev_iter);
     int   step_lm(int ev_iter);

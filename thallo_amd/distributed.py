@@ -111,14 +111,17 @@ class HipSlabBackend:
         z = lambda: torch.zeros(na, dtype=torch.float32, device=dev)
         # r and z share one allocation: one pack/unpack covers both.  With ipc=True it is a plain hipMalloc block other ranks can map
         self.max_l = max_l_iters
-        if ipc:
-            ptr, self.rz_handle = self._ipc_alloc(8 * na)
-            self.rz = _wrap_device_floats(ptr, 2 * na, dev)
+        if ipc:     # one block other ranks can map: [r | z | r' | Ap | Ap'] (r', Ap' = the ping-pong partners of the one-kernel schedule)
+            ptr, self.rz_handle = self._ipc_alloc(4 * 5 * na)
+            blk = _wrap_device_floats(ptr, 5 * na, dev)
+            self.rz, self.r_alt, self.Ap_ipc = blk[:2 * na], blk[2 * na:3 * na], [blk[3 * na:4 * na], blk[4 * na:5 * na]]
         else:
             self.rz = torch.zeros(2 * na, dtype=torch.float32, device=dev)
         self.r, self.z = self.rz[:na], self.rz[na:]
         self.na = na
-        self.pre, self.delta, self.Ap = z(), z(), z()
+        self.pre, self.delta = z(), z()
+        self.Ap = self.Ap_ipc[0] if ipc else z()
+        self.s12 = torch.zeros(3 * 1024, dtype=torch.float64, device=dev)      # N, S1, S2 partials of the one-kernel schedule
         self.p = [z(), z()]
         self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
@@ -245,10 +248,11 @@ class HipSlabBackend:
         lay, W = self.lay, self.W
         if not hasattr(self, "rz_handle"):
             raise RuntimeError("the backend was not created with ipc=True")
-        n_slots = 2 * self.max_l + 8
+        n_slots = 7 * (self.max_l + 2)                     # one-kernel schedule: 7 granules per iteration (two-kernel: 2)
         mail_ptr, mail_handle = self._ipc_alloc(8 * n_slots * lay.world)
         self.ctl = torch.zeros(16, dtype=torch.int32, device=self.device)       # THALLO_DIST_CTL_WORDS
-        mine = {"rank": lay.rank, "mail": mail_handle, "rz": self.rz_handle, "row0": self.row0, "row1": self.row1, "Hl": self.Hl, "pid": os.getpid()}
+        mine = {"rank": lay.rank, "mail": mail_handle, "rz": self.rz_handle, "row0": self.row0, "row1": self.row1, "Hl": self.Hl, "na": self.na,
+                "pid": os.getpid()}
         infos = [None] * lay.world
         if lay.world > 1:
             dist.all_gather_object(infos, mine, group=group)
@@ -270,6 +274,21 @@ class HipSlabBackend:
             d.peer_off_o[k] = 2 * W * ghost_row
             d.peer_off_a[k] = 2 * W * inf["Hl"] + W * ghost_row
         self.p2p = d
+        # one-kernel schedule: per parity of the ping-pong, a DistT whose peer offsets point at the neighbour's ghost row of ITS Ap_out
+        # buffer (block layout [r | z | r' | Ap | Ap'], na of the neighbour = its padded vector length)
+        self.p2p_iter = []
+        for out_idx in (0, 1):
+            e = api.DistT()
+            C.memmove(C.byref(e), C.byref(d), C.sizeof(api.DistT))
+            for k, nb in enumerate((lay.up(), lay.down())):
+                if nb is None:
+                    continue
+                inf = infos[nb]
+                ghost_row = inf["row1"] if k == 0 else inf["row0"] - 1
+                base = (3 + out_idx) * inf["na"]
+                e.peer_off_o[k] = base + 2 * W * ghost_row
+                e.peer_off_a[k] = base + 2 * W * inf["Hl"] + W * ghost_row
+            self.p2p_iter.append(e)
         torch.cuda.synchronize()
         if lay.world > 1:
             dist.barrier(group=group)
@@ -298,6 +317,20 @@ class HipSlabBackend:
             self.W, self.Hl, self.row0, self.row1, vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
             vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), self._sum(iN), self._sum(iD), self.p2p, vp(self.parts.data_ptr()), self._st()), "iw_pcg_step2_dist")
         self.p2p_exchange(out_idx)              # betaN ; behind it the neighbours' rows of r are in my ghost rows
+
+    def iter_p2p(self, cur, mode, iN, iD, iB, jD, jB, iN2, iD2, k):
+        """One PCG iteration = one kernel (thallo_hip_iw_pcg_iter_dist: also stores its boundary rows of Ap into the neighbours' ghost
+        rows) + one exchange (alphaD, N, S1, S2 -> S[jD] = alphaD_k, S[jB] = betaN_k).  Buffers r / Ap / p ping-pong on `cur`."""
+        vp, fl = C.c_void_p, C.c_float
+        rb = (self.r, self.r_alt)
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_iter_dist(
+            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()), vp(self.pre.data_ptr()),
+            fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(self.Ap_ipc[cur ^ 1].data_ptr()),
+            vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), int(mode),
+            self._sum(iN), self._sum(iD), self._sum(iB), self._sum(iN2), self._sum(iD2), vp(self.irregular.data_ptr()), self.p2p_iter[cur ^ 1],
+            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self._st()), "iw_pcg_iter_dist")
+        self._chk(self.L.thallo_hip_dist_exchange_iter(self.p2p, 7 * k, vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self.nb, self._sum(iB),
+                                                       vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB), self._st()), "dist_exchange_iter")
 
     def p2p_collect(self, slot0, nslots):
         self._chk(self.L.thallo_hip_dist_collect(self.p2p, slot0, nslots, C.c_void_p(self.S.data_ptr() + 4 * slot0), self._st()), "dist_collect")
@@ -441,7 +474,13 @@ class SlabSolver:
             be.unpack_grid_info(gath.view(self.world, -1))
         self._gather_sum_and_rows(B)
         be.p2p_begin()                                 # seq += 1
-        for k in range(L):
+        one_kernel = getattr(be, "p2p_iter", None) is not None and os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0"
+        for k in range(L if one_kernel else 0):        # one kernel + ONE exchange per PCG iteration (thallo_hip_iw_pcg_iter_dist)
+            jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
+            be.iter_p2p(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD, jB,
+                        jN - 4 if k > 1 else jN, jD - 4 if k > 1 else jD, k)
+            cur ^= 1
+        for k in range(0 if one_kernel else L):
             jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
             if batched:                                # every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
                 be.step1_p2p(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD,
@@ -458,10 +497,11 @@ class SlabSolver:
             be.linear_update(cur, B, B, False)
         self._exchange_unknown_ghosts()
 
-    def try_enable_p2p(self, l_iters=6, rtol=1e-4):
+    def try_enable_p2p(self, l_iters=6, rtol=1e-3):
         """Collective.  Sets up the device-side exchange and checks it against the collective path on this very topology: one
-        GN step each way from the same unknowns must give the same alpha/beta scalars (a stale ghost row or a lost granule
-        shows up there), no wait may time out, and UrShape must be the pixel grid everywhere.  On success gn_step_fast /
+        GN step each way from the same unknowns must give the same alpha/beta scalars to rtol (a stale ghost row or a lost granule
+        shows up there; the two paths round differently -- betaN from its double-precision expansion vs from the rounded r --
+        which after a few iterations is worth ~1e-5), no wait may time out, and UrShape must be the pixel grid everywhere.  On success gn_step_fast /
         capture use the p2p form.  Every rank returns the same answer."""
         be = self.be
         ok = 1.0

@@ -16,7 +16,7 @@ for f in ("bench_under_rocprof.json", "bench_plain.json"):
 
 
 def short(name):
-    for key, lab in (("k_step1<true", "PCGStep1_fused"), ("k_step1<false", "applyJTJ_plain"), ("k_step2_iw", "PCGStep2"), ("k_step2<", "PCGStep2_generic"), ("k_init", "PCGInit1"),
+    for key, lab in (("k_iter_finish", "PCGScalars"), ("k_iter<", "PCGIteration"), ("k_step1<true", "PCGStep1_fused"), ("k_step1<false", "applyJTJ_plain"), ("k_step2_iw", "PCGStep2"), ("k_step2<", "PCGStep2_generic"), ("k_init", "PCGInit1"),
                      ("k_linear_update", "PCGLinearUpdate"), ("k_cost", "computeCost")):
         if key in name:
             return lab
@@ -39,8 +39,10 @@ for lab, d in pmc.items():
     if "FETCH_SIZE_KB_mean" in d and "WRITE_SIZE_KB_mean" in d:
         d["hbm_bytes_per_launch_corrected"] = (2.0 * d["FETCH_SIZE_KB_mean"] + d["WRITE_SIZE_KB_mean"]) * 1024.0
 json.dump(pmc, open(os.path.join(out, "pmc_fetch_write.json"), "w"), indent=1)
-if "PCGStep1_fused" in pmc and "hbm_bytes_per_launch_corrected" in pmc["PCGStep1_fused"]:
-    json.dump({"PCGStep1_bytes_per_launch": pmc["PCGStep1_fused"]["hbm_bytes_per_launch_corrected"], "round": rnd,
+tl = {lab2: pmc[lab]["hbm_bytes_per_launch_corrected"] for lab, lab2 in (("PCGStep1_fused", "PCGStep1_bytes_per_launch"), ("PCGIteration", "PCGIteration_bytes_per_launch"))
+      if lab in pmc and "hbm_bytes_per_launch_corrected" in pmc[lab]}
+if tl:
+    json.dump({**tl, "round": rnd,
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled (gfx950 correction)"},
               open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(pmc, indent=1))

@@ -165,6 +165,10 @@ def main():
                      "achieved": fused_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused_gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_pixel": dom_alg,
                      "avg_launch_ms": step1_ms, "samples": ks[dom]["samples"],
+                     # what the kernel really moves (the schedule removes bytes the reference formulation has): 99 B/pixel for the
+                     # one-kernel iteration (r, Ap, p read + written, cs, flags, 18 of deferred delta), 75 for the fused PCGStep1
+                     "actual_bytes_per_pixel": 99 if one_kernel else 75,
+                     "achieved_actual": (99 if one_kernel else 75) * npx / (step1_ms * 1e-3) / 1e9,
                      "applyjtj_standalone": {"algorithmic_bytes_per_pixel": ALG_BYTES_APPLYJTJ, "avg_launch_ms": sa_ms,
                                              "achieved": sa_gbs, "frac": sa_gbs / HBM_PEAK_GBS}},
     }

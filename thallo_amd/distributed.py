@@ -648,9 +648,9 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"examples/image_warping {W}x{H} ARAP, GN + matrix-free PCG, {l_iters} PCG iterations per GN step",
                    "width": W, "height": H, "unknowns": 3 * npx, "l_iterations": l_iters,
-                   "parallelism": (f"{world} row slabs; per PCG iteration: alphaD / betaN through device mailboxes (one 8-byte peer-to-peer store per "
-                                   "rank and scalar, summed in rank order by the consumer kernel) + boundary rows of r stored into the neighbours' "
-                                   "ghost rows over xGMI; RCCL once per GN step") if p2p else
+                   "parallelism": (f"{world} row slabs; per PCG iteration ONE kernel + ONE exchange: alphaD, N, S1, S2 through device mailboxes "
+                                   "(7 eight-byte peer-to-peer stores per rank, summed in rank order) + boundary rows of Ap stored into the "
+                                   "neighbours' ghost rows over xGMI; RCCL once per GN step") if p2p else
                                   f"{world} row slabs, RCCL all-reduce(alphaD) + all-gather(betaN, r/z ghost rows) per PCG iteration"},
         "ms_per_gn_iter": dt / steps * 1e3, "us_per_pcg_iter": dt / (steps * l_iters) * 1e6,
         "initial_cost": c0, "final_cost": final, "graph_replay": captured,

@@ -289,9 +289,7 @@ class HipSlabBackend:
                 e.peer_off_o[k] = base + 2 * W * ghost_row
                 e.peer_off_a[k] = base + 2 * W * inf["Hl"] + W * ghost_row
             self.p2p_iter.append(e)
-        torch.cuda.synchronize()
-        if lay.world > 1:
-            dist.barrier(group=group)
+        torch.cuda.synchronize()      # (the caller agrees on success across ranks before any kernel touches a peer)
 
     def p2p_begin(self):
         self._chk(self.L.thallo_hip_dist_begin_step(self.p2p, self._st()), "dist_begin_step")
@@ -515,9 +513,26 @@ class SlabSolver:
         which after a few iterations is worth ~1e-5), no wait may time out, and UrShape must be the pixel grid everywhere.  On success gn_step_fast /
         capture use the p2p form.  Every rank returns the same answer."""
         be = self.be
-        ok = 1.0
+
+        def agree(flag):
+            if self.world > 1:
+                t = torch.tensor([1.0 if flag else 0.0], device=be.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+                return bool(t.item() > 0.5)
+            return bool(flag)
+
+        self.p2p_check = {}
         try:
             be.enable_p2p(self.group)
+            mapped = True
+        except Exception as e:      # noqa: BLE001 - any set-up problem (no IPC, no peer access ...) means: stay on the collective path
+            self.p2p_check = {"error": repr(e)}
+            mapped = False
+        if not agree(mapped):       # every rank mapped every peer, or nobody launches a kernel that touches one
+            self.p2p_on = False
+            return False
+        ok = True
+        try:
             X0, A0 = be.offset.clone(), be.angle.clone()
             self.gn_step(l_iters)
             ref = be.S[2:2 + 2 * l_iters + 1].clone()
@@ -530,15 +545,12 @@ class SlabSolver:
             rel = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item())
             self.p2p_check = {"irregular": irregular, "timeout": err, "max_rel_scalar_diff": rel}
             if irregular != 0 or err != 0 or not (rel <= rtol):
-                ok = 0.0
-        except Exception as e:      # noqa: BLE001 - any set-up problem means: stay on the collective path
+                ok = False
+        except Exception as e:      # noqa: BLE001
             self.p2p_check = {"error": repr(e)}
-            ok = 0.0
-        if self.world > 1:
-            flag = torch.tensor([ok], device=be.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            ok = float(flag.item())
-        self.p2p_on = ok > 0.5
+            ok = False
+        ok = agree(ok)
+        self.p2p_on = ok
         return self.p2p_on
 
     def capture_gn_step(self, l_iters):

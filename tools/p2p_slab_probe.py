@@ -22,6 +22,9 @@ def timeit(fn, n=5):
 
 
 out = {}
+if 'THALLO_ITER_NT' in os.environ:
+    from thallo_amd import api
+    api.lib().thallo_hip_debug_set(7, int(os.environ['THALLO_ITER_NT']))
 for name, p2p in (("rccl", False), ("p2p", True)):
     s, _ = make_hip_solver(p, W, H, 0, 1, L, ipc=p2p)
     s.use_dist = True

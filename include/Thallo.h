@@ -112,6 +112,12 @@ const char* ThalloX_PlanEnergyName(Thallo_Plan* plan);
 /* Last error message of this thread ("" if none). */
 const char* ThalloX_LastError(void);
 
+/* What a problem file asks for with its `r.<residual>.J:set_materialize(true)` / `.JtJ:set_materialize(true)` lines
+ * (API/src/thallo.t:5661-5690): 0 = matrix-free, 1 = `[Jt][[J]p]` (J and J^T as CSR, two SpMVs per PCG iteration), 2 = `[[Jt][J]]p`
+ * (J^T J formed once, one SpMV); -1 = no plugin for the file.  Honoured by the two Laplacian energies (constant J). */
+int ThalloX_ProblemFileSchedule(const char* filename);
+unsigned long long ThalloX_ProblemFileHash(const char* filename, char* energy_out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

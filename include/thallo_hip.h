@@ -338,6 +338,13 @@ int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, c
 void thallo_hip_debug_set(int what, int value);
 void thallo_hip_debug_set2(int value);
 
+/* ---------------------------------------------------------------- materialized schedules (CSR) */
+/* y = A x for a CSR matrix (rows+1 row pointers, int32 columns, float values); with dot_with / dot_out (both or neither) it also writes
+   the per-workgroup partials of dot_with . y.  Replaces the cuSPARSE csrmv calls of gauss_newton.t:1470-1517: `[Jt][[J]p]` = two calls
+   (J, then J^T with dot_with = p), `[[Jt][J]]p` = one call on the pre-multiplied J^T J. */
+int thallo_hip_csr_spmv(int rows, const int* rowptr, const int* col, const float* val, const float* x, float* y,
+                        const float* dot_with, float* dot_out, thallo_stream_t stream);
+
 /* ---------------------------------------------------------------- multi-GPU device-side exchange (one process per GPU) */
 /* Device memory that other processes can map: *ptr = hipMalloc(bytes) (zeroed), handle_out = 64-byte hipIpcMemHandle_t. */
 int thallo_hip_ipc_alloc(long bytes, void** ptr, void* handle_out64);

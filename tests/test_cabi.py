@@ -73,6 +73,20 @@ def test_frontend_ignores_comments_and_whitespace(L, tmp_path):
         L.ThalloX_ProblemFileHash(thallo_amd.energy_file("laplacian_graph").encode(), b2, 64)
 
 
+def test_frontend_reads_the_materialize_schedule_lines(L, tmp_path):
+    """r.<residual>.J:set_materialize(true) / .JtJ:set_materialize(true) (thallo.t:5661-5690; tests/minimal/laplacian.t:16-20)"""
+    src = open(thallo_amd.energy_file("laplacian_image")).read()
+    lines = {"fitJ": "r.fit.J:set_materialize(true)\n", "regJ": "r.reg.J:set_materialize(true)\n",
+             "fitJtJ": "r.fit.JtJ:set_materialize(true)\n", "regJtJ": "r.reg.JtJ:set_materialize(true)\n"}
+    cases = [("", 0), (lines["fitJ"] + lines["regJ"], 1), (lines["fitJ"], 0), ("".join(lines.values()), 2),
+             ("-- " + lines["fitJ"] + "-- " + lines["regJ"], 0)]
+    for extra, want in cases:
+        f = tmp_path / "l.t"
+        f.write_text(src + "\n" + extra)
+        assert L.ThalloX_ProblemFileSchedule(str(f).encode()) == want, (extra, want)
+    assert L.ThalloX_ProblemFileSchedule(str(tmp_path / "missing.t").encode()) == -1
+
+
 def test_vector_padding_rule(L):
     L.thallo_hip_vector_elems.restype = C.c_long
     L.thallo_hip_vector_elems.argtypes = [C.c_long]

@@ -47,6 +47,53 @@ def test_kat_minimal_image_gold_png(torch, golden_dir, orc):
     assert len(costs) == 11
 
 
+SCHEDULES = {"J": "r.fit.J:set_materialize(true)\nr.reg.J:set_materialize(true)\n",
+             "JtJ": "r.fit.J:set_materialize(true)\nr.fit.JtJ:set_materialize(true)\nr.reg.J:set_materialize(true)\nr.reg.JtJ:set_materialize(true)\n"}
+
+
+@pytest.mark.parametrize("schedule", ["J", "JtJ"])
+def test_kat_minimal_image_materialized_schedules(torch, golden_dir, orc, tmp_path, schedule):
+    """tests/minimal/laplacian.t:16-20 asks for materialized J / JtJ.  With those schedule lines the energy runs `[Jt][[J]p]` (two CSR
+    SpMVs per PCG iteration) or `[[Jt][J]]p` (one SpMV on the pre-multiplied J^T J) instead of the matrix-free stencil: same cost
+    trajectory, and the gold image up to pixels on a rounding boundary (the evaluation order differs)."""
+    gold = np.fromfile(os.path.join(golden_dir, "minimal_gold.u8"), np.uint8).reshape(512, 512)
+    A = orc.msvc_rand(512 * 512).reshape(512, 512)
+    tfile = tmp_path / "laplacian.t"
+    tfile.write_text(open(thallo_amd.energy_file("laplacian_image")).read() + "\n" + SCHEDULES[schedule])
+    dev = to_device([A.copy(), A])
+    s = api.ThalloSolver((512, 512), str(tfile), timing_level=2)
+    final, costs = s.solve(dev, profiled=True)
+    ks = s.kernel_stats()
+    if schedule == "J":
+        assert ks["PCGStep1_J"]["launches"] == 100 and ks["PCGStep1_Jt"]["launches"] == 100 and "PCGStep1_JtJ" not in ks
+    else:
+        assert ks["PCGStep1_JtJ"]["launches"] == 100 and "PCGStep1_J" not in ks
+    s0, dev0, costs0, _ = _solve_gpu("laplacian_image", (512, 512), [A.copy(), A])
+    assert rel_err(np.array(costs), costs0) < COST_RTOL
+    out = (to_host(dev[0]) * 255).astype(np.uint8)
+    assert (out == gold).mean() > 0.9999, f"{(out != gold).sum()} pixels differ"
+    assert np.abs(to_host(dev[0]) - to_host(dev0[0])).max() < 1e-5
+
+
+@pytest.mark.parametrize("schedule", ["J", "JtJ"])
+def test_kat_minimal_graph_materialized_schedules(torch, golden_dir, orc, tmp_path, schedule):
+    gold = np.fromfile(os.path.join(golden_dir, "minimal_graph_gold.u8"), np.uint8)
+    n = gold.size
+    A = orc.msvc_rand(n)
+    v0 = np.arange(n - 1, dtype=np.int32); v1 = v0 + 1                     # tests/minimal_graph/main.cpp:60-67: a chain
+    tfile = tmp_path / "laplacian.t"
+    tfile.write_text(open(thallo_amd.energy_file("laplacian_graph")).read() + "\n" + SCHEDULES[schedule])
+    dev = to_device([A.copy(), A, v0, v1])
+    s = api.ThalloSolver((n, n - 1), str(tfile), timing_level=2)
+    final, costs = s.solve(dev, profiled=True)
+    ks = s.kernel_stats()
+    assert ("PCGStep1_JtJ" in ks) == (schedule == "JtJ") and ("PCGStep1_Jt" in ks) == (schedule == "J")
+    s0, dev0, costs0, _ = _solve_gpu("laplacian_graph", (n, n - 1), [A.copy(), A, v0, v1])
+    assert rel_err(np.array(costs), costs0) < COST_RTOL
+    assert ((to_host(dev[0]) * 255).astype(np.uint8) == gold).mean() >= 0.99
+    assert np.abs(to_host(dev[0]) - to_host(dev0[0])).max() < 1e-5
+
+
 def test_kat_minimal_image_shipped_guard_matches_oracle(torch, orc):
     A = orc.msvc_rand(512 * 512).reshape(512, 512)
     Xo = A.copy()

@@ -81,6 +81,7 @@ def lib():
     L.ThalloX_PlanEnergyName.argtypes = [vp]; L.ThalloX_PlanEnergyName.restype = C.c_char_p
     L.ThalloX_LastError.restype = C.c_char_p
     L.ThalloX_ProblemFileHash.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; L.ThalloX_ProblemFileHash.restype = C.c_ulonglong
+    L.ThalloX_ProblemFileSchedule.argtypes = [C.c_char_p]; L.ThalloX_ProblemFileSchedule.restype = C.c_int
     # --- kernel shim entry points that python drives directly (distributed driver, bench, tests): typed, so a
     #     signature drift raises an ArgumentError instead of corrupting the call
     fl, ci, cl = C.c_float, C.c_int, C.c_long

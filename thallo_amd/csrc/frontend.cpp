@@ -170,6 +170,19 @@ bool parse_problem_file(const char* filename, ProblemSpec& out)
             t[i + 3].s != "-" && t[i + 3].s != "/" && (i == 0 || (t[i - 1].s != "," && t[i - 1].s != "{" && t[i - 1].s != "(")))
             out.constants[t[i].s] = atof(t[i + 2].s.c_str());
     }
+    {   // schedule lines:  <residuals>.<name>.J:set_materialize(true)  /  .JtJ:set_materialize(true)   (thallo.t:5661-5690)
+        std::set<std::string> matJ, matJtJ;
+        for (size_t i = 0; i + 8 < t.size(); ++i) {
+            if (t[i].k == Tok::ID && t[i + 1].s == "." && t[i + 2].k == Tok::ID && t[i + 3].s == "." && t[i + 4].k == Tok::ID &&
+                t[i + 5].s == ":" && t[i + 6].s == "set_materialize" && t[i + 7].s == "(" && t[i + 8].s == "true") {
+                if (t[i + 4].s == "J") matJ.insert(t[i + 2].s);
+                if (t[i + 4].s == "JtJ") matJtJ.insert(t[i + 2].s);
+            }
+        }
+        // honoured when it covers every residual group (a mixed schedule runs matrix-free: same values, different evaluation order)
+        if (!keys.empty() && matJ.size() == keys.size()) out.constants["materialize_J"] = 1.0;
+        if (!keys.empty() && matJtJ.size() == keys.size()) out.constants["materialize_JtJ"] = 1.0;
+    }
     std::string keystr; for (auto& k : keys) { if (!keystr.empty()) keystr += ","; keystr += k; }
     const std::string sig = sig_of(inputs);
     for (const Known& k : KNOWN) {
@@ -194,6 +207,15 @@ bool parse_problem_file(const char* filename, ProblemSpec& out)
 }
 
 }  // namespace thallo
+
+// 0 = matrix-free, 1 = `[Jt][[J]p]`, 2 = `[[Jt][J]]p` as requested by the file's set_materialize lines; -1 = no plugin for the file
+extern "C" int ThalloX_ProblemFileSchedule(const char* filename)
+{
+    thallo::ProblemSpec spec;
+    if (!thallo::parse_problem_file(filename, spec)) return -1;
+    auto has = [&](const char* k) { auto it = spec.constants.find(k); return it != spec.constants.end() && it->second > 0; };
+    return has("materialize_JtJ") ? 2 : has("materialize_J") ? 1 : 0;
+}
 
 extern "C" unsigned long long ThalloX_ProblemFileHash(const char* filename, char* energy_out, int cap)
 {

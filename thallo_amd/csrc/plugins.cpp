@@ -1,6 +1,7 @@
 // plugins.cpp -- the bundled energy plugins (host side).  Each one binds the caller's void**
 // (API/src/util.t:609-643) and forwards to the C-ABI kernel shim (include/thallo_hip.h).
 #include "plugin.hpp"
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -18,14 +19,110 @@ int DeviceBuffer::alloc(size_t n)
 }
 void DeviceBuffer::release() { if (ptr) { hipFree(ptr); ptr = nullptr; bytes = 0; } }
 
+// ------------------------------------------------------------------ materialized schedules (spmv_kernels.hip)
+// Host-built CSR Jacobian of an energy whose J is constant (the two Laplacian known-answer energies), its transpose and,
+// for `[[Jt][J]]p`, the product J^T J -- what precomputeJ + csr2csc (+ csrgemm) produce in the reference
+// (gauss_newton.t:327-487,1332-1446).  mode: 0 matrix-free, 1 = `[Jt][[J]p]`, 2 = `[[Jt][J]]p`.
+struct HostCsr {
+    int rows = 0, cols = 0;
+    std::vector<int> ptr, col; std::vector<float> val;
+    void begin(int ncols) { rows = 0; cols = ncols; ptr.assign(1, 0); col.clear(); val.clear(); }
+    void add(int c, float v) { col.push_back(c); val.push_back(v); }
+    void end_row() { ptr.push_back((int)col.size()); ++rows; }
+    HostCsr transposed() const
+    {
+        HostCsr t; t.rows = cols; t.cols = rows; t.ptr.assign(cols + 1, 0); t.col.resize(col.size()); t.val.resize(val.size());
+        for (int c : col) ++t.ptr[c + 1];
+        for (int i = 0; i < cols; ++i) t.ptr[i + 1] += t.ptr[i];
+        std::vector<int> fill(t.ptr.begin(), t.ptr.end() - 1);
+        for (int r = 0; r < rows; ++r) for (int k = ptr[r]; k < ptr[r + 1]; ++k) { const int d = fill[col[k]]++; t.col[d] = r; t.val[d] = val[k]; }
+        return t;
+    }
+    // this (n x m) times b (m x n'): row-by-row with a dense accumulator over the few columns a row touches
+    HostCsr times(const HostCsr& b) const
+    {
+        HostCsr c; c.begin(b.cols);
+        std::vector<float> acc(b.cols, 0.0f); std::vector<int> mark(b.cols, -1), touched;
+        for (int r = 0; r < rows; ++r) {
+            touched.clear();
+            for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+                const int m = col[k]; const float a = val[k];
+                for (int j = b.ptr[m]; j < b.ptr[m + 1]; ++j) {
+                    const int cc = b.col[j];
+                    if (mark[cc] != r) { mark[cc] = r; acc[cc] = 0.0f; touched.push_back(cc); }
+                    acc[cc] += a * b.val[j];
+                }
+            }
+            std::sort(touched.begin(), touched.end());
+            for (int cc : touched) c.add(cc, acc[cc]);
+            c.end_row();
+        }
+        return c;
+    }
+};
+
+struct DeviceCsr {
+    int rows = 0; DeviceBuffer ptr, col, val;
+    int upload(const HostCsr& h)
+    {
+        rows = h.rows;
+        if (ptr.alloc(h.ptr.size() * sizeof(int)) || col.alloc(std::max<size_t>(1, h.col.size()) * sizeof(int)) || val.alloc(std::max<size_t>(1, h.val.size()) * sizeof(float))) return -1;
+        if (hipMemcpy(ptr.ptr, h.ptr.data(), h.ptr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        if (!h.col.empty() && (hipMemcpy(col.ptr, h.col.data(), h.col.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                               hipMemcpy(val.ptr, h.val.data(), h.val.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)) return -1;
+        return 0;
+    }
+    int spmv(const float* x, float* y, const float* dot_with, float* dot_out, hipStream_t s) const
+    { return thallo_hip_csr_spmv(rows, (const int*)ptr.ptr, (const int*)col.ptr, (const float*)val.ptr, x, y, dot_with, dot_out, s); }
+};
+
+struct MaterializedJ {
+    int mode = 0;
+    DeviceCsr J, Jt, JtJ; DeviceBuffer Jp;
+    int build(const HostCsr& j, int mode_)
+    {
+        mode = mode_;
+        if (mode == 1) {
+            if (J.upload(j) || Jt.upload(j.transposed()) || Jp.alloc(std::max(1, j.rows) * sizeof(float))) return -1;
+        } else if (mode == 2) {
+            const HostCsr jt = j.transposed();
+            if (JtJ.upload(jt.times(j))) return -1;
+        }
+        return 0;
+    }
+    // Ap = J^T J p ; partials of p . Ap
+    int apply(LaunchCtx& c, const float* p, float* Ap, float* out) const
+    {
+        if (mode == 2) { TimedLaunch t(c, "PCGStep1_JtJ"); return JtJ.spmv(p, Ap, p, out, c.stream); }
+        { TimedLaunch t(c, "PCGStep1_J"); int rc = J.spmv(p, (float*)Jp.ptr, nullptr, nullptr, c.stream); if (rc < 0) return rc; }
+        TimedLaunch t(c, "PCGStep1_Jt");
+        return Jt.spmv((const float*)Jp.ptr, Ap, p, out, c.stream);
+    }
+};
+
 // ------------------------------------------------------------------ tests/minimal/laplacian.t
 class LaplacianImagePlugin : public EnergyPlugin {
     int W, H; float w_fit; int xguard;
+    int mat_mode = 0; MaterializedJ mat;
     std::vector<UnknownImage> imgs;
     float* X = nullptr; const float* A = nullptr;
 public:
-    LaplacianImagePlugin(const unsigned* dims, float w, int xg) : W((int)dims[0]), H((int)dims[1]), w_fit(w), xguard(xg)
+    LaplacianImagePlugin(const unsigned* dims, float w, int xg, int mat) : W((int)dims[0]), H((int)dims[1]), w_fit(w), xguard(xg), mat_mode(mat)
     { imgs.push_back({ 0, (long)W * H }); }
+    int prepare(LaunchCtx&) override
+    {   // tests/minimal/laplacian.t:16-20 asks for materialized J / JtJ; J is constant: rows = fit(x,y), then the guarded differences
+        if (!mat_mode || mat.mode) return 0;
+        HostCsr j; j.begin(W * H);
+        for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { j.add(y * W + x, w_fit); j.end_row(); }
+        for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+            const int i = y * W + x;
+            if (x + 1 < W && (xguard || y + 1 < H)) { j.add(i, 1.0f); j.add(i + 1, -1.0f); }      // InBounds(x+1,y) or the shipped InBounds(x+1,y+1)
+            j.end_row();
+            if (y + 1 < H) { j.add(i, 1.0f); j.add(i + W, -1.0f); }
+            j.end_row();
+        }
+        return mat.build(j, mat_mode);
+    }
     const char* name() const override { return "laplacian_image"; }
     long n_unknowns() const override { return (long)W * H; }
     const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
@@ -37,9 +134,18 @@ public:
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     { TimedLaunch t(c, "PCGInit1"); return thallo_hip_lapimg_pcg_init(W, H, X, A, w_fit, xguard, v.r, v.z, v.p[cur], v.delta, v.diag, aN, c.stream); }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
-    { TimedLaunch t(c, "PCGStep1"); return thallo_hip_lapimg_apply_jtj(W, H, w_fit, xguard, p, Ap, out, c.stream); }
+    {
+        if (mat.mode) return mat.apply(c, p, Ap, out);
+        TimedLaunch t(c, "PCGStep1"); return thallo_hip_lapimg_apply_jtj(W, H, w_fit, xguard, p, Ap, out, c.stream);
+    }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
-    { TimedLaunch t(c, "PCGStep1"); return thallo_hip_lapimg_pcg_step1(W, H, w_fit, xguard, v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, out, c.stream); }
+    {
+        if (mat.mode) {
+            { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
+            return mat.apply(c, v.p[cur ^ 1], v.Ap, out);
+        }
+        TimedLaunch t(c, "PCGStep1"); return thallo_hip_lapimg_pcg_step1(W, H, w_fit, xguard, v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, out, c.stream);
+    }
 };
 
 // ------------------------------------------------------------------ examples/image_warping/image_warping.t
@@ -153,14 +259,32 @@ class LaplacianGraphPlugin : public EnergyPlugin {
     std::vector<UnknownImage> imgs;
     float* X = nullptr; const float* A = nullptr; const int *v0 = nullptr, *v1 = nullptr;
     GraphIncidence g;
+    int mat_mode = 0; MaterializedJ mat; const int *mat_v0 = nullptr, *mat_v1 = nullptr;
+    int build_materialized()
+    {   // rows = fit(n), then reg(e) = X(v0(e)) - X(v1(e)); rebuilt when the caller binds other edge lists
+        if (!mat_mode || (mat.mode && mat_v0 == v0 && mat_v1 == v1)) return 0;
+        std::vector<int> h0(E), h1(E);
+        if (E && (hipMemcpy(h0.data(), v0, (size_t)E * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                  hipMemcpy(h1.data(), v1, (size_t)E * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)) { set_error("cannot read the edge lists"); return -1; }
+        HostCsr j; j.begin(N);
+        for (int n = 0; n < N; ++n) { j.add(n, w_fit); j.end_row(); }
+        for (int e = 0; e < E; ++e) {
+            if (h0[e] < 0 || h0[e] >= N || h1[e] < 0 || h1[e] >= N) { set_error("edge %d references vertex outside [0,%d)", e, N); return -1; }
+            if (h0[e] != h1[e]) { j.add(h0[e], 1.0f); j.add(h1[e], -1.0f); }
+            j.end_row();
+        }
+        mat = MaterializedJ();
+        mat_v0 = v0; mat_v1 = v1;
+        return mat.build(j, mat_mode);
+    }
 public:
-    LaplacianGraphPlugin(const unsigned* dims, float w) : N((int)dims[0]), E((int)dims[1]), w_fit(w) { imgs.push_back({ 0, (long)N }); }
+    LaplacianGraphPlugin(const unsigned* dims, float w, int matm) : N((int)dims[0]), E((int)dims[1]), w_fit(w), mat_mode(matm) { imgs.push_back({ 0, (long)N }); }
     const char* name() const override { return "laplacian_graph"; }
     long n_unknowns() const override { return N; }
     const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
     bool use_preconditioner() const override { return false; }
     int bind(void** p) override { X = (float*)p[0]; A = (const float*)p[1]; v0 = (const int*)p[2]; v1 = (const int*)p[3]; return (X && A && v0 && v1) ? 0 : -1; }
-    int prepare(LaunchCtx&) override { return g.build(N, E, v0, v1); }
+    int prepare(LaunchCtx&) override { if (int rc = g.build(N, E, v0, v1)) return rc; return build_materialized(); }
     float* unknown_ptr(int) override { return X; }
     int cost(LaunchCtx& c, float* out) override
     { TimedLaunch t(c, "computeCost"); return thallo_hip_lapgraph_cost(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, X, A, w_fit, out, c.stream); }
@@ -172,12 +296,14 @@ public:
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
+        if (mat.mode) return mat.apply(c, p, Ap, out);
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_lapgraph_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr, w_fit, p, Ap, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
+        if (mat.mode) return mat.apply(c, v.p[cur ^ 1], v.Ap, out);
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_lapgraph_apply_jtj(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr,
                                              w_fit, v.p[cur ^ 1], v.Ap, out, c.stream);
@@ -364,9 +490,11 @@ public:
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims)
 {
     auto cst = [&](const char* k, double dflt) { auto it = spec.constants.find(k); return it == spec.constants.end() ? dflt : it->second; };
-    if (spec.energy == "laplacian_image") return new LaplacianImagePlugin(dims, (float)cst("w_fit", 0.2), (int)cst("xguard", 0));
+    // schedule lines of the .t (thallo.t:5661-5690): J / JtJ materialized on every residual -> `[Jt][[J]p]` / `[[Jt][J]]p`
+    const int mat = cst("materialize_JtJ", 0) > 0 ? 2 : cst("materialize_J", 0) > 0 ? 1 : 0;
+    if (spec.energy == "laplacian_image") return new LaplacianImagePlugin(dims, (float)cst("w_fit", 0.2), (int)cst("xguard", 0), mat);
     if (spec.energy == "image_warping")   return new ImageWarpingPlugin(dims);
-    if (spec.energy == "laplacian_graph") return new LaplacianGraphPlugin(dims, (float)cst("w_fit", 0.5));
+    if (spec.energy == "laplacian_graph") return new LaplacianGraphPlugin(dims, (float)cst("w_fit", 0.5), mat);
     if (spec.energy == "arap_mesh")       return new ArapPlugin(dims);
     if (spec.energy == "bundle_adjustment") return new BundleAdjustmentPlugin(dims);
     if (spec.energy == "shape_from_shading") return new ShapeFromShadingPlugin(dims);

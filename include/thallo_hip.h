@@ -230,7 +230,12 @@ int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, co
                            const float* p_in, float* p_out, float* delta, int mode,
                            thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
                            thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
-                           const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+                           const int* irregular, float* alphaD_out, double* s12_out,
+                           unsigned* fin_tickets, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* fin_tickets / alphaD_word / betaN_word (all or none): THALLO_HIP_FIN_TICKET_WORDS zeroed device words + the two scalar words.  When given,
+ * the launch's last workgroup does pcg_iter_finish's job itself (same summation order, same bits) and no separate launch is needed; the
+ * tickets are zero again when the kernel ends.  alphaN_k is taken from betaN_prev (which is alphaN_k by definition). */
+#define THALLO_HIP_FIN_TICKET_WORDS 528
 /* the same over a row slab of a multi-GPU run: additionally stores the first / last owned row of Ap_out into the neighbours' ghost rows
    (d.peer_r[k] + d.peer_off_o/a[k] = that row inside the neighbour's Ap_out buffer), peer-to-peer */
 int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,

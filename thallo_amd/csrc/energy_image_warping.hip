@@ -544,7 +544,8 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
                                           const float* __restrict__ r_in, float* __restrict__ r_out, const float* __restrict__ A_in, float* __restrict__ A_out,
                                           const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, int mode,
                                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
-                                          float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const thallo_dist_t* dd = nullptr)
+                                          float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const thallo_dist_t* dd = nullptr,
+                                          unsigned* __restrict__ fin_tickets = nullptr, float* __restrict__ aD_word = nullptr, float* __restrict__ bN_word = nullptr)
 {
     constexpr int PER = TH / (NT / TW);
     const int first = mode & 1;
@@ -745,7 +746,57 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
     if (threadIdx.x == 0) {
         float a = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
         for (int w = 0; w < NT / THALLO_WAVE; ++w) { a += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
-        aD_out[blockIdx.x] = a; s12_out[3 * blockIdx.x] = b0; s12_out[3 * blockIdx.x + 1] = b1; s12_out[3 * blockIdx.x + 2] = b2;
+        if (!fin_tickets) { aD_out[blockIdx.x] = a; s12_out[3 * blockIdx.x] = b0; s12_out[3 * blockIdx.x + 1] = b1; s12_out[3 * blockIdx.x + 2] = b2; }
+        else {
+            // in-kernel finish (saves the one-wave k_iter_finish launch: worth 4-5 us per iteration on small images): write-through
+            // partials, two-level arrival tickets (workgroup b -> group b % 32, each group word on its own 64-byte line; same-address
+            // atomics serialise at ~12 ns each), the last arrival adds everything up in k_iter_finish's order
+            typedef unsigned long long u64_t;
+            __hip_atomic_store(aD_out + blockIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64_t* sp = reinterpret_cast<u64_t*>(s12_out) + 3 * blockIdx.x;
+            __hip_atomic_store(sp, (u64_t)__double_as_longlong(b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sp + 1, (u64_t)__double_as_longlong(b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sp + 2, (u64_t)__double_as_longlong(b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned grp = blockIdx.x % 32, members = (gridDim.x - grp + 31) / 32, groups = gridDim.x < 32 ? gridDim.x : 32;
+            unsigned* sub = fin_tickets + 16 + 16 * grp;
+            bool last = false;
+            if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = __hip_atomic_fetch_add(fin_tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+            }
+            red[15] = last ? 1.0f : 0.0f;
+        }
+    }
+    if (fin_tickets) {
+        __syncthreads();
+        if (red[15] != 0.0f && wave == 0) {
+            typedef unsigned long long u64_t;
+            const int nb = gridDim.x;
+            float t[THALLO_MAX_PARTIALS / THALLO_WAVE];
+#pragma unroll
+            for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
+                const int i = lane + k * THALLO_WAVE;
+                t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            }
+            float ad = 0.0f;
+#pragma unroll
+            for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) ad += t[k];
+            ad = wave_sum_all(ad);                                                   // == sum_partials(aD_out, nb)
+            const u64_t* sp = reinterpret_cast<const u64_t*>(s12_out);
+            double n = 0.0, a1 = 0.0, b1 = 0.0;
+            for (int i = lane; i < nb; i += THALLO_WAVE) {
+                n  += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                a1 += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b1 += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
+            const float an = sum_partials(bNp.partials, bNp.count);                  // alphaN_k (= betaN_{k-1}; alphaN_0 for the first iteration)
+            const float al = safe_div<false>(an, ad);
+            double bn = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
+            if (!(bn > 0.0)) bn = 0.0;
+            if (lane == 0) { aD_word[0] = ad; bN_word[0] = (float)bn; __hip_atomic_store(fin_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
     }
 }
 
@@ -756,14 +807,14 @@ __global__ __launch_bounds__(NT, MINW) void k_iter(Geo g, const float2* __restri
                                                        const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, int mode,
                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                                        float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const int* __restrict__ irregular,
-                                                       thallo_dist_t dd)
+                                                       thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word)
 {
     __shared__ TileI T;
     __shared__ float red[16];
     __shared__ double redd[48];
     const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
-    if (grid) iter_body<true, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd);
-    else      iter_body<false, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd);
+    if (grid) iter_body<true, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word);
+    else      iter_body<false, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word);
 }
 
 // one wave: alphaD_k (float partials, the usual order), S1_k, S2_k (double partials, same lane-strided order), then
@@ -888,15 +939,17 @@ int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, co
                            float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
                            const float* p_in, float* p_out, float* delta, int mode,
                            thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
-                           const int* irregular, float* aD_out, double* s12_out, thallo_stream_t stream)
+                           const int* irregular, float* aD_out, double* s12_out,
+                           unsigned* fin_tickets, float* aD_word, float* bN_word, thallo_stream_t stream)
 {
     if (!rows_ok(H, row0, row1) || !r_in || !r_out || !Ap_out || !p_in || !p_out || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
     if (!(mode & 1) && !Ap_in) return -(int)hipErrorInvalidValue;
+    if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
     const Geo g = make_geo(W, H, row0, row1);
     const int grid = grid_for(g, 2);
     hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
-                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{});
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -912,7 +965,7 @@ int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* c
     const int grid = grid_for(g, 2);
     hipLaunchKernelGGL((k_iter<4, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
-                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d);
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, (unsigned*)nullptr, (float*)nullptr, (float*)nullptr);
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -58,6 +58,7 @@ struct SolverVectors {
     // one-kernel-per-iteration schedule (plugins with one_kernel_iteration()): r and Ap ping-pong like p; per-workgroup double sums
     float *r2 = nullptr, *Ap2 = nullptr;
     double* s12 = nullptr;                       // 3 * THALLO_HIP_MAX_PARTIALS doubles (N, S1, S2 per workgroup)
+    unsigned* fin_tickets = nullptr;             // THALLO_HIP_FIN_TICKET_WORDS zeroed words (in-kernel finish of the iteration's scalars)
     float* rbuf(int i) { return i ? r2 : r; }
     float* Abuf(int i) { return i ? Ap2 : Ap; }
 };
@@ -95,7 +96,9 @@ public:
     // One kernel per PCG iteration (thallo_hip.h thallo_hip_iw_pcg_iter): reads r/Ap/p[cur], writes r/Ap/p[cur^1], alphaD partials
     // to alphaD_out and the double sums to v.s12; pcg_iter_finish turns them into the two scalar words of the iteration.
     virtual bool one_kernel_iteration() const { return false; }
-    virtual int pcg_iter(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, float* /*alphaD_out*/) { return -1; }
+    // aD_word / bN_word non-NULL: the kernel finishes the two scalars itself (no pcg_iter_finish launch)
+    virtual int pcg_iter(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, float* /*alphaD_out*/,
+                         float* /*aD_word*/, float* /*bN_word*/) { return -1; }
     virtual int pcg_iter_finish(LaunchCtx&, SolverVectors&, const float* /*alphaD_partials*/, int /*count*/, thallo_sum_t /*alphaN*/, float* /*alphaD_word*/, float* /*betaN_word*/) { return -1; }
     // PCGStep2 (r -= alpha Ap, z = M^-1 r, betaN partials); default = the energy-independent flat kernel
     virtual int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* betaN_out)

@@ -199,12 +199,14 @@ public:
     }
     bool batches_delta() const override { return true; }
     bool one_kernel_iteration() const override { return true; }
-    int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2, float* out) override
+    int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2, float* out,
+                 float* aD_word, float* bN_word) override
     {
         TimedLaunch t(c, "PCGIteration");
         return thallo_hip_iw_pcg_iter(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, v.pre, w_fit, w_reg,
                                       v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
-                                      aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, out, v.s12, c.stream);
+                                      aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, out, v.s12,
+                                      aD_word ? v.fin_tickets : nullptr, aD_word, bN_word, c.stream);
     }
     int pcg_iter_finish(LaunchCtx& c, SolverVectors& v, const float* part, int count, thallo_sum_t aN, float* aD_word, float* bN_word) override
     {

@@ -174,6 +174,7 @@ int Plan::ensure_slots(int L)
     parts_slots_ = need; nb_.assign(need, 1); fin_.assign(need, 0);
     { const char* e = getenv("THALLO_FINISH_SUMS"); finish_sums_ = !(e && e[0] == '0'); }
     { const char* e = getenv("THALLO_ONE_KERNEL"); one_kernel_ = !(e && e[0] == '0'); }
+    { const char* e = getenv("THALLO_FIN_IN_KERNEL"); fin_in_kernel_ = !(e && e[0] == '0'); }
     return 0;
 }
 
@@ -344,12 +345,13 @@ int Plan::step_gn_one_kernel(int ev_iter)
     const int ev_lin = timer_.start("Linear Solve", s);
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
         nb = plugin->pcg_iter(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, 1), sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
-                              sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), slot(jD));
+                              sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), slot(jD),
+                              fin_in_kernel_ ? scal(jD) : nullptr, fin_in_kernel_ ? scal(jB) : nullptr);
         if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
         set_nb(jD, nb); cur_ ^= 1;
-        // alphaD_k and betaN_k = alphaN_k - 2 alpha_k S1 + alpha_k^2 S2 in one wave
-        if (plugin->pcg_iter_finish(ctx, v_, slot(jD), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
+        if (!fin_in_kernel_ && plugin->pcg_iter_finish(ctx, v_, slot(jD), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
         fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
     }
     const bool batched = true;
@@ -381,11 +383,11 @@ int Plan::step_gn_one_kernel(int ev_iter)
 int Plan::ensure_iter_buffers()
 {
     if (v_.r2) return 0;
-    DeviceBuffer* b[3];
-    for (int i = 0; i < 3; ++i) { b[i] = new DeviceBuffer(); bufs_.push_back(b[i]); }
+    DeviceBuffer* b[4];
+    for (int i = 0; i < 4; ++i) { b[i] = new DeviceBuffer(); bufs_.push_back(b[i]); }
     if (b[0]->alloc((size_t)v_.n_alloc * sizeof(float)) || b[1]->alloc((size_t)v_.n_alloc * sizeof(float)) ||
-        b[2]->alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double))) return -1;
-    v_.r2 = (float*)b[0]->ptr; v_.Ap2 = (float*)b[1]->ptr; v_.s12 = (double*)b[2]->ptr;
+        b[2]->alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double)) || b[3]->alloc(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned))) return -1;
+    v_.r2 = (float*)b[0]->ptr; v_.Ap2 = (float*)b[1]->ptr; v_.s12 = (double*)b[2]->ptr; v_.fin_tickets = (unsigned*)b[3]->ptr;
     return 0;
 }
 

@@ -81,6 +81,7 @@ private:
 
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
+    bool fin_in_kernel_ = true;     // THALLO_FIN_IN_KERNEL=0: the iteration's scalars by a separate one-wave launch (A/B switch)
     bool one_kernel_ = true;        // THALLO_ONE_KERNEL=0: two-kernel schedule even where the plugin offers pcg_iter (A/B switch)
     bool finish_sums_ = true;       // THALLO_FINISH_SUMS=0: consumers re-add the partials themselves (A/B switch)
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }

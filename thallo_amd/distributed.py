@@ -339,7 +339,7 @@ class HipSlabBackend:
             fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(self.Ap_ipc[cur ^ 1].data_ptr()),
             vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), 0,
             self._sum(2), self._sum(3), self._sum(4), self._sum(2), self._sum(3), vp(self.irregular.data_ptr()),
-            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self._st()), "iw_pcg_iter")
+            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), None, None, None, self._st()), "iw_pcg_iter")
 
     def p2p_collect(self, slot0, nslots):
         self._chk(self.L.thallo_hip_dist_collect(self.p2p, slot0, nslots, C.c_void_p(self.S.data_ptr() + 4 * slot0), self._st()), "dist_collect")

@@ -243,7 +243,10 @@ int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* c
                                 const float* p_in, float* p_out, float* delta, int mode,
                                 thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
                                 thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
-                                const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+                                const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out,
+                                unsigned* fin_tickets, int slot0, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* fin_tickets / alphaD_word / betaN_word (all or none): the launch's last workgroup then IS the exchange (thallo_hip_dist_exchange_iter's job,
+   mailbox slots slot0 .. slot0+6, betaN_prev must be a one-word sum): one launch per PCG iteration on every rank. */
 int thallo_hip_iw_pcg_iter_finish(const float* alphaD_partials, const double* s12_partials, int count, thallo_sum_t alphaN,
                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 

@@ -101,7 +101,7 @@ def lib():
     L.thallo_hip_dist_exchange_iter.argtypes = [DistT, ci, vp, vp, ci, SumT, vp, vp, vp]
     _iter = [ci, ci, ci, ci, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, SumT, SumT, vp]
     L.thallo_hip_iw_pcg_iter.argtypes = _iter + [vp, vp, vp, vp, vp, vp]
-    L.thallo_hip_iw_pcg_iter_dist.argtypes = _iter + [DistT, vp, vp, vp]
+    L.thallo_hip_iw_pcg_iter_dist.argtypes = _iter + [DistT, vp, vp, vp, ci, vp, vp, vp]
     L.thallo_hip_iw_pcg_iter_finish.argtypes = [vp, vp, ci, SumT, vp, vp, vp]
     L.thallo_hip_iw_pcg_step2_dist.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, SumT, SumT, DistT, vp, vp]
     L.thallo_hip_iw_pcg_step2.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, vp, vp, SumT, SumT, vp, vp, vp]

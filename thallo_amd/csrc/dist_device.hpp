@@ -70,4 +70,57 @@ __device__ __forceinline__ void dist_fetch(const thallo_dist_t& d, const int (&s
     }
 }
 
+// The exchange of the one-kernel-per-iteration schedule, executed by ONE full wave (all 64 lanes, converged; no LDS, no barrier):
+// this rank's sums (alphaD float; N, S1, S2 double) go out as 7 granules to every rank's mailbox slots slot0 .. slot0+6 (the doubles
+// as hi / lo words), the wave waits (bounded) for everybody's, adds them in rank order and lane 0 writes alphaD_k and
+// betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 with alpha_k = alphaN / alphaD_k.  Identical bits on every rank.
+__device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, int slot0, float ad, double q0, double q1, double q2, float an,
+                                                        float* __restrict__ aD_word, float* __restrict__ bN_word)
+{
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    unsigned w[7];
+    w[0] = __float_as_uint(ad);
+    { const u64 b = (u64)__double_as_longlong(q0); w[1] = (unsigned)(b >> 32); w[2] = (unsigned)b; }
+    { const u64 b = (u64)__double_as_longlong(q1); w[3] = (unsigned)(b >> 32); w[4] = (unsigned)b; }
+    { const u64 b = (u64)__double_as_longlong(q2); w[5] = (unsigned)(b >> 32); w[6] = (unsigned)b; }
+    const unsigned seq = ld_agent(d.ctl + DIST_SEQ);
+    if (lane < d.world) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) st_sys(d.peer_mail[lane] + (long)(slot0 + j) * d.world + d.rank, ((u64)seq << 32) | (u64)w[j]);
+    }
+    unsigned mine = 0;
+    if (lane < 7 * d.world) {                       // lane -> (granule j, source rank r)
+        const int j = lane / d.world, r = lane - j * d.world;
+        const u64* g = d.mail + (long)(slot0 + j) * d.world + r;
+        u64 v = ld_sys(g);
+        int it = 0; long long t0 = 0;
+        while ((unsigned)(v >> 32) != seq) {
+            if ((it & 1023) == 0) { if (ld_agent(d.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
+            ++it;
+            if ((it & 1023) == 0 && wall_clock64() - t0 > DIST_SPIN_TICKS) {
+                if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    unsigned* pm = d.ctl + DIST_POST_MORTEM;
+                    pm[0] = (unsigned)(slot0 + j); pm[1] = (unsigned)r; pm[2] = seq; pm[3] = (unsigned)(v >> 32); pm[4] = (unsigned)v;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            v = ld_sys(g);
+        }
+        mine = (unsigned)v;
+    }
+    float gad = 0.0f; double gq[3] = { 0.0, 0.0, 0.0 };
+    for (int r = 0; r < d.world; ++r) {             // every lane runs the same shuffles; lane 0 keeps the result
+        gad += __uint_as_float(__shfl(mine, r, THALLO_WAVE));
+        for (int j = 0; j < 3; ++j) {
+            const unsigned hi = __shfl(mine, (1 + 2 * j) * d.world + r, THALLO_WAVE), lo = __shfl(mine, (2 + 2 * j) * d.world + r, THALLO_WAVE);
+            gq[j] += __longlong_as_double((long long)(((u64)hi << 32) | (u64)lo));
+        }
+    }
+    const float alpha = safe_div<false>(an, gad);
+    double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
+    if (!(bn > 0.0)) bn = 0.0;
+    if (lane == 0) { aD_word[0] = gad; bN_word[0] = (float)bn; }
+}
+
 }  // namespace thallo

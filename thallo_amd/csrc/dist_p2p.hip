@@ -40,57 +40,12 @@ __device__ __forceinline__ double wave_sum_all_dd(double v)
 __global__ __launch_bounds__(64) void k_exchange_iter(thallo_dist_t d, int slot0, const float* __restrict__ aD_part, const double* __restrict__ s12, int nb,
                                                       thallo_sum_t aN, float* __restrict__ aD_word, float* __restrict__ bN_word)
 {
-    __shared__ float vals[7 * THALLO_DIST_MAX_WORLD];
     const int lane = threadIdx.x;
     const float ad = sum_partials(aD_part, nb);
     double q[3] = { 0.0, 0.0, 0.0 };
     for (int i = lane; i < nb; i += THALLO_WAVE) { q[0] += s12[3 * i]; q[1] += s12[3 * i + 1]; q[2] += s12[3 * i + 2]; }
-    unsigned w[7];
-    w[0] = __float_as_uint(ad);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { const double t = wave_sum_all_dd(q[j]); const u64 b = (u64)__double_as_longlong(t); w[1 + 2 * j] = (unsigned)(b >> 32); w[2 + 2 * j] = (unsigned)b; }
-    const unsigned seq = ld_agent(d.ctl + DIST_SEQ);
-    if (lane < d.world) {
-#pragma unroll
-        for (int j = 0; j < 7; ++j) st_sys(d.peer_mail[lane] + (long)(slot0 + j) * d.world + d.rank, ((u64)seq << 32) | (u64)w[j]);
-    }
-    // wait for every rank's 7 granules (lanes < 7*world poll one each)
-    if (lane < 7 * d.world) {
-        const int j = lane / d.world, r = lane - j * d.world;
-        const u64* g = d.mail + (long)(slot0 + j) * d.world + r;
-        u64 v = ld_sys(g);
-        int it = 0; long long t0 = 0;
-        while ((unsigned)(v >> 32) != seq) {
-            if ((it & 1023) == 0) { if (ld_agent(d.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
-            ++it;
-            if ((it & 1023) == 0 && wall_clock64() - t0 > DIST_SPIN_TICKS) {
-                if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    unsigned* pm = d.ctl + DIST_POST_MORTEM;
-                    pm[0] = (unsigned)(slot0 + j); pm[1] = (unsigned)r; pm[2] = seq; pm[3] = (unsigned)(v >> 32); pm[4] = (unsigned)v;
-                }
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            v = ld_sys(g);
-        }
-        vals[lane] = __uint_as_float((unsigned)v);
-    }
-    __syncthreads();
-    if (lane == 0) {
-        float gad = 0.0f; double gq[3] = { 0.0, 0.0, 0.0 };
-        for (int r = 0; r < d.world; ++r) {
-            gad += vals[r];
-            for (int j = 0; j < 3; ++j) {
-                const u64 b = ((u64)__float_as_uint(vals[(1 + 2 * j) * d.world + r]) << 32) | (u64)__float_as_uint(vals[(2 + 2 * j) * d.world + r]);
-                gq[j] += __longlong_as_double((long long)b);
-            }
-        }
-        const float an = aN.count == 1 ? aN.partials[0] : 0.0f;
-        const float alpha = safe_div<false>(an, gad);
-        double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
-        if (!(bn > 0.0)) bn = 0.0;
-        aD_word[0] = gad; bN_word[0] = (float)bn;
-    }
+    const double q0 = wave_sum_all_dd(q[0]), q1 = wave_sum_all_dd(q[1]), q2 = wave_sum_all_dd(q[2]);
+    dist_exchange_iter_wave(d, slot0, ad, q0, q1, q2, aN.count == 1 ? aN.partials[0] : 0.0f, aD_word, bN_word);
 }
 
 __global__ __launch_bounds__(64) void k_collect(thallo_dist_t d, int slot0, int nslots, float* __restrict__ out)

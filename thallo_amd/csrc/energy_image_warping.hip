@@ -545,7 +545,8 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
                                           const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, int mode,
                                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                           float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const thallo_dist_t* dd = nullptr,
-                                          unsigned* __restrict__ fin_tickets = nullptr, float* __restrict__ aD_word = nullptr, float* __restrict__ bN_word = nullptr)
+                                          unsigned* __restrict__ fin_tickets = nullptr, float* __restrict__ aD_word = nullptr, float* __restrict__ bN_word = nullptr,
+                                          int xslot = 0)
 {
     constexpr int PER = TH / (NT / TW);
     const int first = mode & 1;
@@ -792,10 +793,15 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
             }
             n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
             const float an = sum_partials(bNp.partials, bNp.count);                  // alphaN_k (= betaN_{k-1}; alphaN_0 for the first iteration)
-            const float al = safe_div<false>(an, ad);
-            double bn = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
-            if (!(bn > 0.0)) bn = 0.0;
-            if (lane == 0) { aD_word[0] = ad; bN_word[0] = (float)bn; __hip_atomic_store(fin_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (lane == 0) __hip_atomic_store(fin_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (DIST) {     // multi-GPU: the same wave is the exchange (every workgroup's remote Ap rows were drained before its ticket)
+                dist_exchange_iter_wave(*dd, xslot, ad, n, a1, b1, an, aD_word, bN_word);
+            } else {
+                const float al = safe_div<false>(an, ad);
+                double bn = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
+                if (!(bn > 0.0)) bn = 0.0;
+                if (lane == 0) { aD_word[0] = ad; bN_word[0] = (float)bn; }
+            }
         }
     }
 }
@@ -807,14 +813,14 @@ __global__ __launch_bounds__(NT, MINW) void k_iter(Geo g, const float2* __restri
                                                        const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, int mode,
                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                                        float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const int* __restrict__ irregular,
-                                                       thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word)
+                                                       thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot)
 {
     __shared__ TileI T;
     __shared__ float red[16];
     __shared__ double redd[48];
     const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
-    if (grid) iter_body<true, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word);
-    else      iter_body<false, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word);
+    if (grid) iter_body<true, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word, xslot);
+    else      iter_body<false, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word, xslot);
 }
 
 // one wave: alphaD_k (float partials, the usual order), S1_k, S2_k (double partials, same lane-strided order), then
@@ -949,7 +955,7 @@ int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, co
     const int grid = grid_for(g, 2);
     hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
-                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word);
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word, 0);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -957,15 +963,18 @@ int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* c
                                 float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
                                 const float* p_in, float* p_out, float* delta, int mode,
                                 thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
-                                const int* irregular, thallo_dist_t d, float* aD_out, double* s12_out, thallo_stream_t stream)
+                                const int* irregular, thallo_dist_t d, float* aD_out, double* s12_out,
+                                unsigned* fin_tickets, int slot0, float* aD_word, float* bN_word, thallo_stream_t stream)
 {
+    if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
+    if (fin_tickets && (slot0 < 0 || !d.mail || !d.ctl || 7 * d.world > 64 || bNp.count != 1)) return -(int)hipErrorInvalidValue;
     if (!rows_ok(H, row0, row1) || !r_in || !r_out || !Ap_out || !p_in || !p_out || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
     if ((!(mode & 1) && !Ap_in) || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1);
     const int grid = grid_for(g, 2);
     hipLaunchKernelGGL((k_iter<4, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
-                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, (unsigned*)nullptr, (float*)nullptr, (float*)nullptr);
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, fin_tickets, aD_word, bN_word, slot0);
     int e = check_launch(); return e ? e : grid;
 }
 

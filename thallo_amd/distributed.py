@@ -122,6 +122,8 @@ class HipSlabBackend:
         self.pre, self.delta = z(), z()
         self.Ap = self.Ap_ipc[0] if ipc else z()
         self.s12 = torch.zeros(3 * 1024, dtype=torch.float64, device=dev)      # N, S1, S2 partials of the one-kernel schedule
+        self.fin_tickets = torch.zeros(528, dtype=torch.int32, device=dev)     # THALLO_HIP_FIN_TICKET_WORDS
+        self.exchange_in_kernel = os.environ.get("THALLO_DIST_EXCHANGE_IN_KERNEL", "1") != "0"
         self.p = [z(), z()]
         self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
@@ -326,9 +328,12 @@ class HipSlabBackend:
             fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(self.Ap_ipc[cur ^ 1].data_ptr()),
             vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), int(mode),
             self._sum(iN), self._sum(iD), self._sum(iB), self._sum(iN2), self._sum(iD2), vp(self.irregular.data_ptr()), self.p2p_iter[cur ^ 1],
-            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self._st()), "iw_pcg_iter_dist")
-        self._chk(self.L.thallo_hip_dist_exchange_iter(self.p2p, 7 * k, vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self.nb, self._sum(iB),
-                                                       vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB), self._st()), "dist_exchange_iter")
+            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()),
+            vp(self.fin_tickets.data_ptr()) if self.exchange_in_kernel else None, 7 * k, vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB),
+            self._st()), "iw_pcg_iter_dist")
+        if not self.exchange_in_kernel:      # THALLO_DIST_EXCHANGE_IN_KERNEL=0: the exchange as its own one-wave launch
+            self._chk(self.L.thallo_hip_dist_exchange_iter(self.p2p, 7 * k, vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self.nb, self._sum(iB),
+                                                           vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB), self._st()), "dist_exchange_iter")
 
     def iter_local(self, cur=0):
         """the one-kernel iteration without the remote stores and without the exchange (bench: kernel time on this rank's slab)"""

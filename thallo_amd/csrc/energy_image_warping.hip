@@ -67,6 +67,7 @@ int g_iw_debug = 0;
 int g_step1_threads = 512; // fused step: 512 threads x 2 px/thread (default) or 256 x 4
 int g_step1_per_cu = 3; // microbench: workgroups per CU for the fused step (3 = VGPR limit)
 int g_no_grid = 0;      // microbench: 1 = ignore the regular-grid fast path
+int g_iter_per_cu = 2;    // microbench: workgroups per CU of the one-kernel iteration (2 = VGPR limit at 512 threads)
 int g_iter_nt = 31;      // one-kernel iteration, non-temporal bits: 1 delta, 2 r/Ap loads, 4 r/Ap stores, 8 p loads, 16 p stores, 32 cs/flags (31 measured best)
 int g_nt_mask = 1;      // delta non-temporal: measured +1-3 % PCG it/s at 2048^2 (tools/sweep_nt.sh)
 
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(64) void k_iter_finish(const float* __restrict__ aD
 
 extern "C" {
 
-void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; if (what == 5) g_step1_per_cu = value; if (what == 6) g_step1_threads = value; if (what == 7) g_iter_nt = value; }
+void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; if (what == 5) g_step1_per_cu = value; if (what == 6) g_step1_threads = value; if (what == 7) g_iter_nt = value; if (what == 8) g_iter_per_cu = value < 1 ? 1 : value > 2 ? 2 : value; }
 
 int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,
                        const float* constraints, const float* mask, float w_fit, float w_reg,
@@ -952,7 +953,7 @@ int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, co
     if (!(mode & 1) && !Ap_in) return -(int)hipErrorInvalidValue;
     if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
     const Geo g = make_geo(W, H, row0, row1);
-    const int grid = grid_for(g, 2);
+    const int grid = grid_for(g, g_iter_per_cu);
     hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
                        aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word, 0);
@@ -971,7 +972,7 @@ int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* c
     if (!rows_ok(H, row0, row1) || !r_in || !r_out || !Ap_out || !p_in || !p_out || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
     if ((!(mode & 1) && !Ap_in) || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1);
-    const int grid = grid_for(g, 2);
+    const int grid = grid_for(g, g_iter_per_cu);
     hipLaunchKernelGGL((k_iter<4, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
                        aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, fin_tickets, aD_word, bN_word, slot0);

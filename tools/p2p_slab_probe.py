@@ -22,6 +22,9 @@ def timeit(fn, n=5):
 
 
 out = {}
+if 'THALLO_ITER_PER_CU' in os.environ:
+    from thallo_amd import api
+    api.lib().thallo_hip_debug_set(8, int(os.environ['THALLO_ITER_PER_CU']))
 if 'THALLO_ITER_NT' in os.environ:
     from thallo_amd import api
     api.lib().thallo_hip_debug_set(7, int(os.environ['THALLO_ITER_NT']))

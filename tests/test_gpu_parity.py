@@ -318,6 +318,50 @@ def test_image_warping_reference_cat512_instance(torch, orc, golden_dir):
     assert rel_err(to_host(dev[0]), off_o) < VEC_RTOL
 
 
+# ------------------------------------------------------------------ the reference's shipped data sets (tests/golden/make_real_data_fixtures.py)
+def test_arap_reference_small_armadillo_mesh(torch, orc, golden_dir):
+    """examples/data/small_armadillo.ply + .mrk (the default input of examples/arap_mesh_deformation): 130 vertices, each face split at
+    its centroid (the application runs one sqrt(3) subdivision first, which is why the markers index up to vertex 358; here without its
+    edge flips and smoothing), landmarks as fit constraints, weights 4 / 1 (main.cpp:115-116): cost trajectory vs the oracle."""
+    from thallo_amd import formats as F
+    V, faces = F.read_ply(os.path.join(golden_dir, "small_armadillo.ply"))
+    idx, target = F.read_mrk(os.path.join(golden_dir, "small_armadillo.mrk"))
+    nv = len(V)
+    cent = np.array([V[list(fc)].mean(axis=0) for fc in faces], dtype=np.float32)
+    V2 = np.concatenate([V, cent]).astype(np.float32)
+    faces2 = [[fc[k], fc[(k + 1) % 3], nv + i] for i, fc in enumerate(faces) for k in range(3)]
+    v0, v1 = F.mesh_directed_edges(faces2, len(V2))
+    assert len(V2) == 386 and idx.max() < len(V2) and len(v0) == 2 * (len(faces2) * 3 // 2)
+    cons = np.full((len(V2), 3), -1.0e30, np.float32)
+    cons[idx] = target
+    p = [4.0, 1.0, V2.copy(), np.zeros_like(V2), V2.copy(), cons, v0, v1]
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.ARAP_MESH, (len(V2), len(v0)), po).solve(nIterations=4, lIterations=30)
+    # The landmarks sit far from the mesh (rotations of ~pi): with 30 PCG iterations per step the trajectory is sensitive to the
+    # summation order -- the oracle's own two legitimate orders (double vs serial float accumulators; the reference's is
+    # nondeterministic, util.t:40-50) drift apart by 3e-3 here.  Bar as for bundle adjustment: 1e-5 on the first step, then 3x that drift.
+    cf, _ = orc.Problem(orc.ARAP_MESH, (len(V2), len(v0)), copy_params(p)).solve(nIterations=4, lIterations=30, float_sums=1)
+    s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (len(V2), len(v0)), p, nIterations=4, lIterations=30)
+    err, drift = np.abs(np.array(costs) - co) / co, np.abs(cf - co) / co
+    assert costs[0] > 0 and err[0] < COST_RTOL and err[1] < COST_RTOL, (costs, co)
+    assert err.max() <= max(3e-5, 3 * drift.max()), (err, drift)
+    assert costs[-1] < 0.05 * costs[0]
+
+
+def test_shape_from_shading_reference_default_data(torch, orc, golden_dir):
+    """examples/data/shape_from_shading/default_* (depth with -inf holes, intensity, row / column edge maps, the 160-byte parameter file
+    with the shipped lighting), every 4th pixel: 160 x 120.  Cost trajectory of GN 4 x 10 vs the oracle."""
+    d = np.load(os.path.join(golden_dir, "sfs_default_q4.npz"))
+    H, W = d["depth"].shape
+    p = [float(v) for v in d["scalars"]] + [d["initial"].copy(), d["depth"].copy(), d["intensity"].copy(), d["edge_r"].copy(), d["edge_c"].copy()]
+    assert (d["depth"] == -10000.0).any() and (d["depth"] > 0).any()         # the holes came through SimpleBuffer's -inf clamp
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.SFS, (W, H), po).solve(nIterations=4, lIterations=10)
+    s, dev, costs, final = _solve_gpu("shape_from_shading", (W, H), p, nIterations=4, lIterations=10)
+    assert costs[0] > 0 and costs[-1] < costs[0]
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 def test_full_size_properties_2048(torch):
     """2048^2 (the benchmark size): J^T J is symmetric PSD and linear; the solve is bitwise reproducible;

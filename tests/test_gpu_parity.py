@@ -103,6 +103,51 @@ def test_kat_minimal_image_shipped_guard_matches_oracle(torch, orc):
     assert ((to_host(dev[0]) * 255).astype(np.uint8) == (Xo * 255).astype(np.uint8)).mean() > 0.9999
 
 
+# ------------------------------------------------------------------ the reduction primitive (replaces util.t:40-50 + cuda_util.t:287-289,430-439)
+def _sum_partials_reference(part):
+    """sum_partials() of csrc/device_common.hpp in numpy float32: lane l adds part[l], part[l+64], ... in index order, then the wave64
+    butterfly v += shfl_xor(v, m) for m = 32, 16, ..., 1."""
+    lanes = np.zeros(64, np.float32)
+    for l in range(64):
+        acc = np.float32(0.0)
+        for x in part[l::64]:
+            acc = np.float32(acc + x)
+        lanes[l] = acc
+    m = 32
+    while m >= 1:
+        lanes = (lanes + lanes[np.arange(64) ^ m]).astype(np.float32)
+        m //= 2
+    return lanes[0]
+
+
+@pytest.mark.parametrize("nb", [1, 5, 64, 100, 513, 1024])
+def test_reduction_order_is_the_documented_one(torch, nb):
+    """Every PCG scalar is `finish_sum` / `sum_partials` of per-workgroup partials: one FIXED association order, which is what makes the
+    solver bitwise reproducible (the reference's red.global.add.f32 per warp is order-nondeterministic).  Pinned bit-exactly here;
+    and thallo_hip_dot counts every element exactly once (integer-valued data: any order gives the same float)."""
+    L = _shim()
+    rng = np.random.default_rng(nb)
+    part = (rng.standard_normal(nb) * 10.0 ** rng.integers(-3, 4, nb)).astype(np.float32)
+    d = torch.from_numpy(part).cuda()
+    out = torch.zeros(4, device="cuda")
+    assert L.thallo_hip_finish_sum(api.SumT(d.data_ptr(), nb), C.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    got = out[0].item()
+    want = float(_sum_partials_reference(part))
+    assert np.float32(got).tobytes() == np.float32(want).tobytes(), (got, want)
+    n = 1000 * nb + 3
+    na = L.thallo_hip_vector_elems(n)
+    a = torch.zeros(na, device="cuda"); b = torch.zeros(na, device="cuda")
+    a[:n] = torch.from_numpy(rng.integers(-3, 4, n).astype(np.float32)).cuda(); b[:n] = torch.from_numpy(rng.integers(-3, 4, n).astype(np.float32)).cuda()
+    parts = torch.zeros(1024, device="cuda")
+    L.thallo_hip_dot.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    k = L.thallo_hip_dot(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_long(n), C.c_void_p(parts.data_ptr()), None)
+    assert 0 < k <= 1024
+    L.thallo_hip_finish_sum(api.SumT(parts.data_ptr(), k), C.c_void_p(out.data_ptr() + 4), None)
+    torch.cuda.synchronize()
+    assert out[1].item() == float((a.double() * b.double()).sum().item())
+
+
 # ------------------------------------------------------------------ image_warping trajectories
 @pytest.mark.parametrize("W,H,nit,lit", [(64, 64, 8, 100), (96, 80, 5, 40), (70, 33, 4, 25), (256, 256, 4, 50), (1, 1, 2, 3), (130, 3, 3, 10)])
 def test_image_warping_cost_trajectory(torch, orc, W, H, nit, lit):

@@ -682,3 +682,89 @@ def test_image_warping_irregular_urshape_uses_general_path(torch, orc):
     co2, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po2).solve(nIterations=3, lIterations=30)
     _, _, costs2, _ = _solve_gpu("image_warping", (W, H), p2, nIterations=3, lIterations=30)
     assert rel_err(costs2, co2) < COST_RTOL
+
+
+# ------------------------------------------------------------------ degenerate inputs (ragged / empty / minimum sizes)
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 1), (1, 5), (3, 2)])
+def test_laplacian_image_minimum_sizes(torch, orc, W, H):
+    p = syn.laplacian_image(W, H)
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.LAPLACIAN_IMAGE, (W, H), po, fconst=[0.2], iconst=[1]).solve(nIterations=3, lIterations=4)
+    s, dev, costs, final = _solve_gpu("laplacian_image", (W, H), p, nIterations=3, lIterations=4)
+    assert np.abs(np.array(costs) - co).max() <= COST_RTOL * max(co.max(), 1e-12)
+    assert np.abs(to_host(dev[0]) - po[0]).max() < 1e-5
+
+
+@pytest.mark.parametrize("nit,lit", [(0, 5), (2, 0), (1, 1)])
+def test_image_warping_zero_iteration_budgets(torch, orc, nit, lit):
+    """nIterations = 0: Solve returns the initial cost and leaves the unknowns alone; lIterations = 0: a GN step with an empty PCG loop
+    is the identity (delta = 0) -- gauss_newton.t:1545-1785 with empty loops."""
+    p = syn.image_warping(48, 32, n_markers=4)
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (48, 32), po).solve(nIterations=nit, lIterations=lit)
+    x0 = p[0].copy()
+    s, dev, costs, final = _solve_gpu("image_warping", (48, 32), p, nIterations=nit, lIterations=lit)
+    assert len(costs) == nit + 1 and rel_err(np.array(costs), co) < COST_RTOL
+    if nit == 0 or lit == 0:
+        assert (to_host(dev[0]) == x0).all()
+
+
+def test_graph_energies_with_isolated_vertices_and_single_edge(torch, orc):
+    """vertices without any edge (valence 0), one edge only, a self loop: the incidence lists have empty rows"""
+    n = 9
+    A = np.linspace(0.1, 0.9, n).astype(np.float32)
+    v0 = np.array([2, 5, 5], dtype=np.int32); v1 = np.array([3, 5, 7], dtype=np.int32)      # edge 1 is a self loop: residual identically 0
+    p = [A.copy() + 0.3, A, v0, v1]
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.LAPLACIAN_GRAPH, (n, 3), po, fconst=[0.5]).solve(nIterations=3, lIterations=6)
+    s, dev, costs, final = _solve_gpu("laplacian_graph", (n, 3), p, nIterations=3, lIterations=6)
+    assert rel_err(np.array(costs), co) < COST_RTOL and np.abs(to_host(dev[0]) - po[0]).max() < 1e-5
+    q = syn.arap_mesh(8, 8)
+    N = q[2].shape[0]
+    keep = (q[6] != 0) & (q[7] != 0)                                                          # vertex 0 loses all its edges
+    q[6], q[7] = np.ascontiguousarray(q[6][keep]), np.ascontiguousarray(q[7][keep])
+    qo = copy_params(q)
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, q[6].shape[0]), qo).solve(nIterations=2, lIterations=10)
+    s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (N, q[6].shape[0]), q, nIterations=2, lIterations=10)
+    assert rel_err(np.array(costs), co) < COST_RTOL
+
+
+def test_bundle_adjustment_ragged_visibility(torch, orc):
+    """a camera without observations, a point without observations, a point seen once: empty / length-1 incidence rows"""
+    C_, P_ = 4, 12
+    p = syn.bundle_adjustment(C=C_, P=P_, O=30, band=3)
+    keep = (p[3] != 1) & (p[4] != 5)                  # camera 1 and point 5 lose every observation
+    first7 = np.flatnonzero(p[4] == 7)
+    if first7.size > 1:
+        keep[first7[1:]] = False                      # point 7 is seen exactly once
+    p[2], p[3], p[4] = np.ascontiguousarray(p[2][keep]), np.ascontiguousarray(p[3][keep]), np.ascontiguousarray(p[4][keep])
+    O_ = p[2].shape[0]
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.BUNDLE_ADJUST, (C_, P_, O_), po).solve(nIterations=2, lIterations=5)
+    cam1, pt5 = p[0][1].copy(), p[1][5].copy()
+    s, dev, costs, final = _solve_gpu("bundle_adjustment", (C_, P_, O_), p, nIterations=2, lIterations=5)
+    assert np.abs(np.array(costs) - co).max() <= 1e-4 * co[0], (costs, co)
+    assert (to_host(dev[0])[1] == cam1).all() and (to_host(dev[1])[5] == pt5).all()     # unobserved unknowns do not move
+
+
+@pytest.mark.parametrize("W,H", [(5, 5), (6, 7), (16, 5)])
+def test_shape_from_shading_minimum_sizes(torch, orc, W, H):
+    """images barely larger than the stencil footprint (most pixels fail the border / validity guards)"""
+    p = syn.shape_from_shading(W, H, hole=False)
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.SFS, (W, H), po).solve(nIterations=2, lIterations=5)
+    s, dev, costs, final = _solve_gpu("shape_from_shading", (W, H), p, nIterations=2, lIterations=5)
+    assert np.abs(np.array(costs) - co).max() <= COST_RTOL * max(co.max(), 1e-12), (costs, co)
+
+
+def test_solving_twice_on_one_plan_restarts_cleanly(torch, orc):
+    p = syn.image_warping(64, 48, n_markers=5)
+    dev = to_device(p)
+    s = api.ThalloSolver((64, 48), thallo_amd.energy_file("image_warping"))
+    f1, c1 = s.solve(dev, profiled=True, nIterations=2, lIterations=15)
+    dev2 = to_device(p)
+    f2, c2 = s.solve(dev2, profiled=True, nIterations=2, lIterations=15)             # other buffers, same plan
+    assert c1 == c2 and torch.equal(dev[0], dev2[0])
+    f3, c3 = s.solve(dev2, profiled=True, nIterations=1, lIterations=15)             # continue from the solution: smaller L
+    assert c3[0] == c2[-1]
+    s.close()

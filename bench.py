@@ -167,8 +167,12 @@ def main():
                      "avg_launch_ms": step1_ms, "samples": ks[dom]["samples"],
                      # what the kernel really moves (the schedule removes bytes the reference formulation has): 99 B/pixel for the
                      # one-kernel iteration (r, Ap, p read + written, cs, flags, 18 of deferred delta), 75 for the fused PCGStep1
+                     "note": ("achieved / frac use SURVEY.md 8d's algorithmic bytes of the reference formulation (180 B/pixel per PCG iteration); the one-kernel "
+                              "schedule moves 99 B/pixel, so frac can exceed 1 -- achieved_actual / frac_actual are the bytes really moved (= the PMC traffic)")
+                             if one_kernel else None,
                      "actual_bytes_per_pixel": 99 if one_kernel else 75,
                      "achieved_actual": (99 if one_kernel else 75) * npx / (step1_ms * 1e-3) / 1e9,
+                     "frac_actual": (99 if one_kernel else 75) * npx / (step1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "applyjtj_standalone": {"algorithmic_bytes_per_pixel": ALG_BYTES_APPLYJTJ, "avg_launch_ms": sa_ms,
                                              "achieved": sa_gbs, "frac": sa_gbs / HBM_PEAK_GBS}},
     }

@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--liters", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sample-period", type=int, default=16)      # HIP events around every 16th launch of each kernel (period 4 costs 2 % throughput)
+    ap.add_argument("--sample-period", type=int, default=16)      # two-kernel schedule only: HIP events around every 16th launch of each kernel
     return ap.parse_args()
 
 
@@ -121,8 +121,13 @@ def main():
     for _ in range(Wm):
         s.step(params)
     torch.cuda.synchronize()
+    # one kernel per PCG iteration (thallo_hip_iw_pcg_iter, the default) vs PCGStep1 + PCGStep2 (THALLO_ONE_KERNEL=0, A/B)
+    one_kernel = os.environ.get("THALLO_ONE_KERNEL", "1") != "0"
     s.reset_kernel_stats()
-    s.set_kernel_sampling(args.sample_period)
+    # one-kernel schedule: the PCG loop of a GN step is L launches of ONE kernel and nothing else, so the library's HIP-event pair
+    # around the loop ("Linear Solve", recorded on the launch stream every step) / L is that kernel's average launch duration,
+    # without per-launch events perturbing the timed region.  Two-kernel schedule: events around every 16th launch of each kernel.
+    s.set_kernel_sampling(0 if one_kernel else (args.sample_period or 16))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -132,12 +137,14 @@ def main():
     s.set_kernel_sampling(0)
     ks = s.kernel_stats()
     final_cost = s.current_cost()
+    assert s.step(params) == 0                 # budget used up: finalises the plan and its performance summary
+    perf = s.performance_summary()
 
     npx = W * H
-    one_kernel = "PCGIteration" in ks          # one kernel per PCG iteration (thallo_hip_iw_pcg_iter) vs PCGStep1 + PCGStep2
     dom = "PCGIteration" if one_kernel else "PCGStep1"
     dom_alg = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1
-    step1_ms = ks[dom]["mean_ms"]
+    step1_ms = perf["linearSolve"]["meanMS"] / L_it if one_kernel else ks[dom]["mean_ms"]
+    n_samples = perf["linearSolve"]["count"] * L_it if one_kernel else ks[dom]["samples"]
     fused_gbs = dom_alg * npx / (step1_ms * 1e-3) / 1e9
     sa_ms = standalone_applyjtj(torch, W, H, p)
     sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9
@@ -164,7 +171,9 @@ def main():
                                 if one_kernel else "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)"),
                      "achieved": fused_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused_gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_pixel": dom_alg,
-                     "avg_launch_ms": step1_ms, "samples": ks[dom]["samples"],
+                     "avg_launch_ms": step1_ms, "samples": n_samples,
+                     "timing": ("HIP events around the PCG loop of every GN step (L launches of this one kernel) / L" if one_kernel
+                                else "HIP events around every 16th launch of the kernel"),
                      # what the kernel really moves (the schedule removes bytes the reference formulation has): 99 B/pixel for the
                      # one-kernel iteration (r, Ap, p read + written, cs, flags, 18 of deferred delta), 75 for the fused PCGStep1
                      "note": ("achieved / frac use SURVEY.md 8d's algorithmic bytes of the reference formulation (180 B/pixel per PCG iteration); the one-kernel "

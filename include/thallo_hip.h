@@ -278,17 +278,24 @@ int thallo_hip_lapgraph_apply_jtj(int N, const int* out_ptr, const int* out_v1, 
  * Flat vector layout [Position 3n+c | Angle 3N+3n+c].  precompute (once per GN iteration) fills, per edge in
  * out-CSR order, F[3E] = the reg residual and G[9E] = d(R(Angle) dv)/d(Angle) (three float3 columns).
  * cost / pcg_init / apply_jtj produce outputs for the vertex range [n0,n1) only (0,N = everything): the vertex-partitioned
- * multi-GPU driver (thallo_amd/distributed_graph.py) keeps the vectors replicated and all-gathers p. */
+ * multi-GPU driver (thallo_amd/distributed_graph.py) keeps the vectors replicated and all-gathers p.
+ * ell_stride selects the layout of the per-edge arrays (out_v1, F, G; in_edge holds positions in that layout):
+ *   0      out-CSR order, array of structs: edge k of the CSR at k, its 3 / 9 floats contiguous;
+ *   S > 0  "ELL", structure of arrays: the j-th edge of vertex n at position j*N + n, component c of F / G at c*S + position,
+ *          S = maxdeg * N (out_v1 has S entries, F 3*S, G 9*S); in_edge / in_src likewise hold the j-th incoming edge of vertex n at
+ *          j*N + n (max in-degree * N entries; in_ptr still gives the degrees).  A wave of consecutive vertices then reads consecutive addresses in
+ *          every per-edge array (2 cache lines per wave instruction instead of up to 64): what the single-GPU plugin uses when
+ *          the padding is bounded (maxdeg <= 32, maxdeg*N <= 3E + N). */
 int thallo_hip_arap_cost(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
-                         const float* original, const float* constraints, float w_fit, float w_reg, float* cost_out, thallo_stream_t stream);
+                         const float* original, const float* constraints, float w_fit, float w_reg, float* cost_out, long ell_stride, thallo_stream_t stream);
 int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
-                               const float* original, float w_reg, float* F, float* G, thallo_stream_t stream);
+                               const float* original, float w_reg, float* F, float* G, long ell_stride, thallo_stream_t stream);
 int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
-                             float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* alphaN_out, thallo_stream_t stream);
+                             float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* alphaN_out, long ell_stride, thallo_stream_t stream);
 int thallo_hip_arap_apply_jtj(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                               const float* constraints, const float* G, float w_fit, float w_reg,
-                              const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+                              const float* p, float* Ap, float* alphaD_out, long ell_stride, thallo_stream_t stream);
 
 /* ---------------------------------------------------------------- E4: examples/bundle_adjustment/bundle_adjustment.t
  * on the materialized sparse-J path (reference: precomputeJ + cuSPARSE csrsort/csr2csc/csrmv x2,

@@ -104,6 +104,32 @@ __global__ __launch_bounds__(BLOCK) void k_lapg_apply(int N, const int* __restri
 }
 
 // ------------------------------------------------------------------------------------------ ARAP (E2)
+// Edge-data layout.  S == 0: out-CSR order, array of structs (edge k's 3 / 9 floats contiguous) -- what the slab / partition drivers
+// use.  S > 0 ("ELL"): the j-th edge of vertex n lives at position j*N + n and component c at c*S + position, S = maxdeg*N: the
+// threads of a wave (consecutive vertices) then read consecutive addresses in every edge array -- index lists, F, all 9 planes of G
+// -- instead of addresses 13 floats apart (a wave instruction touches 2 cache lines instead of up to 64).
+struct ELay { long S; int N; };
+__device__ __forceinline__ long epos(const ELay& L, int base, int n, int j) { return L.S ? (long)j * L.N + n : (long)base + j; }
+__device__ __forceinline__ f3 ldE(const float* __restrict__ F, const ELay& L, long pos)
+{
+    if (L.S) { f3 v; v.x = F[pos]; v.y = F[L.S + pos]; v.z = F[2 * L.S + pos]; return v; }
+    return ld3(F, pos);
+}
+__device__ __forceinline__ void stE(float* __restrict__ F, const ELay& L, long pos, f3 v)
+{
+    if (L.S) { F[pos] = v.x; F[L.S + pos] = v.y; F[2 * L.S + pos] = v.z; } else st3(F, pos, v);
+}
+// column c (0..2) of the 3x3 block G_e
+__device__ __forceinline__ f3 ldG(const float* __restrict__ G, const ELay& L, long pos, int c)
+{
+    if (L.S) { f3 v; v.x = G[(3 * c) * L.S + pos]; v.y = G[(3 * c + 1) * L.S + pos]; v.z = G[(3 * c + 2) * L.S + pos]; return v; }
+    return ld3(G, 3 * pos + c);
+}
+__device__ __forceinline__ void stG(float* __restrict__ G, const ELay& L, long pos, int c, f3 v)
+{
+    if (L.S) { G[(3 * c) * L.S + pos] = v.x; G[(3 * c + 1) * L.S + pos] = v.y; G[(3 * c + 2) * L.S + pos] = v.z; } else st3(G, 3 * pos + c, v);
+}
+
 struct Rot { float R[9], dA[9], dB[9], dG[9]; };
 __device__ __forceinline__ void rot3(f3 a, Rot& o)
 {   // lib.t:123-137 and its three angle derivatives
@@ -130,7 +156,7 @@ __device__ __forceinline__ f3 mv(const float* M, f3 v)
 
 __global__ __launch_bounds__(BLOCK) void k_arap_cost(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
                                                       const float* __restrict__ P, const float* __restrict__ Ang, const float* __restrict__ O,
-                                                      const float* __restrict__ Cn, float wf, float wr, float* __restrict__ out)
+                                                      const float* __restrict__ Cn, float wf, float wr, float* __restrict__ out, ELay L)
 {
     __shared__ float red[16];
     float acc = 0.0f;
@@ -139,8 +165,9 @@ __global__ __launch_bounds__(BLOCK) void k_arap_cost(int N, int n0, int n1, cons
         Rot rt; rot3(ld3(Ang, n), rt);
         float s = 0.0f;
         if (c.x >= -999999.9f) { const float fx = wf * (p.x - c.x), fy = wf * (p.y - c.y), fz = wf * (p.z - c.z); s += fx * fx + fy * fy + fz * fz; }
-        for (int k = out_ptr[n]; k < out_ptr[n + 1]; ++k) {
-            const int m = out_v1[k];
+        const int ob = out_ptr[n], deg = out_ptr[n + 1] - ob;
+        for (int j = 0; j < deg; ++j) {
+            const int m = out_v1[epos(L, ob, n, j)];
             const f3 pm = ld3(P, m), om = ld3(O, m);
             f3 dv; dv.x = o.x - om.x; dv.y = o.y - om.y; dv.z = o.z - om.z;
             const f3 rv = mv(rt.R, dv);
@@ -155,19 +182,21 @@ __global__ __launch_bounds__(BLOCK) void k_arap_cost(int N, int n0, int n1, cons
 // per GN iteration: F_e (3) and G_e (9, column-major: [dR/da dv | dR/db dv | dR/dg dv]) per edge, out-CSR order
 __global__ __launch_bounds__(BLOCK) void k_arap_precompute(int N, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
                                                             const float* __restrict__ P, const float* __restrict__ Ang, const float* __restrict__ O,
-                                                            float wr, float* __restrict__ F, float* __restrict__ G)
+                                                            float wr, float* __restrict__ F, float* __restrict__ G, ELay L)
 {
     for (int n = blockIdx.x * BLOCK + threadIdx.x; n < N; n += gridDim.x * BLOCK) {
         const f3 p = ld3(P, n), o = ld3(O, n);
         Rot rt; rot3(ld3(Ang, n), rt);
-        for (int k = out_ptr[n]; k < out_ptr[n + 1]; ++k) {
+        const int ob = out_ptr[n], deg = out_ptr[n + 1] - ob;
+        for (int j = 0; j < deg; ++j) {
+            const long k = epos(L, ob, n, j);
             const int m = out_v1[k];
             const f3 pm = ld3(P, m), om = ld3(O, m);
             f3 dv; dv.x = o.x - om.x; dv.y = o.y - om.y; dv.z = o.z - om.z;
             const f3 rv = mv(rt.R, dv);
             f3 f; f.x = wr * ((p.x - pm.x) - rv.x); f.y = wr * ((p.y - pm.y) - rv.y); f.z = wr * ((p.z - pm.z) - rv.z);
-            st3(F, k, f);
-            st3(G, 3L * k, mv(rt.dA, dv)); st3(G, 3L * k + 1, mv(rt.dB, dv)); st3(G, 3L * k + 2, mv(rt.dG, dv));
+            stE(F, L, k, f);
+            stG(G, L, k, 0, mv(rt.dA, dv)); stG(G, L, k, 1, mv(rt.dB, dv)); stG(G, L, k, 2, mv(rt.dG, dv));
         }
     }
 }
@@ -178,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, int n0, int n1, cons
                                                       const float* __restrict__ F, const float* __restrict__ G, float wf, float wr,
                                                       float* __restrict__ r, float* __restrict__ pre, float* __restrict__ z,
                                                       float* __restrict__ p_prev, float* __restrict__ delta,
-                                                      float* __restrict__ diag_out, float* __restrict__ aN_out)
+                                                      float* __restrict__ diag_out, float* __restrict__ aN_out, ELay L)
 {
     __shared__ float red[16];
     float acc = 0.0f;
@@ -186,9 +215,11 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, int n0, int n1, cons
     for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
         f3 jp = { 0.f, 0.f, 0.f }, ja = { 0.f, 0.f, 0.f }, da = { 0.f, 0.f, 0.f };
         float dp = 0.0f;
-        for (int k = out_ptr[n]; k < out_ptr[n + 1]; ++k) {          // own edges: dF/dP_n = w I, dF/dA_n = -w G
-            const f3 f = ld3(F, k);
-            const f3 g0 = ld3(G, 3L * k), g1 = ld3(G, 3L * k + 1), g2 = ld3(G, 3L * k + 2);
+        const int ob = out_ptr[n], deg = out_ptr[n + 1] - ob;
+        for (int j = 0; j < deg; ++j) {                              // own edges: dF/dP_n = w I, dF/dA_n = -w G
+            const long k = epos(L, ob, n, j);
+            const f3 f = ldE(F, L, k);
+            const f3 g0 = ldG(G, L, k, 0), g1 = ldG(G, L, k, 1), g2 = ldG(G, L, k, 2);
             jp.x += wr * f.x; jp.y += wr * f.y; jp.z += wr * f.z;
             ja.x -= wr * (g0.x * f.x + g0.y * f.y + g0.z * f.z);
             ja.y -= wr * (g1.x * f.x + g1.y * f.y + g1.z * f.z);
@@ -198,8 +229,9 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, int n0, int n1, cons
             da.y += wr2 * (g1.x * g1.x + g1.y * g1.y + g1.z * g1.z);
             da.z += wr2 * (g2.x * g2.x + g2.y * g2.y + g2.z * g2.z);
         }
-        for (int k = in_ptr[n]; k < in_ptr[n + 1]; ++k) {            // incoming edges: dF/dP_n = -w I
-            const f3 f = ld3(F, in_edge[k]);
+        const int ib = in_ptr[n], ideg = in_ptr[n + 1] - ib;
+        for (int j = 0; j < ideg; ++j) {                             // incoming edges: dF/dP_n = -w I
+            const f3 f = ldE(F, L, in_edge[epos(L, ib, n, j)]);
             jp.x -= wr * f.x; jp.y -= wr * f.y; jp.z -= wr * f.z;
             dp += wr2;
         }
@@ -229,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, int n0, int n1, cons
 __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
                                                        const int* __restrict__ in_ptr, const int* __restrict__ in_edge, const int* __restrict__ in_src,
                                                        const float* __restrict__ Cn, const float* __restrict__ G, float wf, float wr,
-                                                       const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out)
+                                                       const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out, ELay L)
 {
     __shared__ float red[16];
     float acc = 0.0f;
@@ -237,9 +269,12 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, con
     for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
         const f3 pp = ld3(p, n), pa = ld3(p, (long)N + n);
         f3 ap = { 0.f, 0.f, 0.f }, aa = { 0.f, 0.f, 0.f };
-        for (int k = out_ptr[n]; k < out_ptr[n + 1]; ++k) {
+        const int ob = out_ptr[n], deg = out_ptr[n + 1] - ob;
+#pragma unroll 4
+        for (int j = 0; j < deg; ++j) {
+            const long k = epos(L, ob, n, j);
             const f3 pm = ld3(p, out_v1[k]);
-            const f3 g0 = ld3(G, 3L * k), g1 = ld3(G, 3L * k + 1), g2 = ld3(G, 3L * k + 2);
+            const f3 g0 = ldG(G, L, k, 0), g1 = ldG(G, L, k, 1), g2 = ldG(G, L, k, 2);
             // Jp / w = (pP_n - pP_m) - G pA_n
             const float jx = (pp.x - pm.x) - (g0.x * pa.x + g1.x * pa.y + g2.x * pa.z);
             const float jy = (pp.y - pm.y) - (g0.y * pa.x + g1.y * pa.y + g2.y * pa.z);
@@ -249,10 +284,13 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, con
             aa.y -= g1.x * jx + g1.y * jy + g1.z * jz;
             aa.z -= g2.x * jx + g2.y * jy + g2.z * jz;
         }
-        for (int k = in_ptr[n]; k < in_ptr[n + 1]; ++k) {            // edge (m -> n): contributes -w * Jp to P_n
+        const int ib = in_ptr[n], ideg = in_ptr[n + 1] - ib;
+#pragma unroll 4
+        for (int j = 0; j < ideg; ++j) {                             // edge (m -> n): contributes -w * Jp to P_n
+            const long k = epos(L, ib, n, j);
             const int e = in_edge[k], m = in_src[k];
             const f3 pm = ld3(p, m), am = ld3(p, (long)N + m);
-            const f3 g0 = ld3(G, 3L * e), g1 = ld3(G, 3L * e + 1), g2 = ld3(G, 3L * e + 2);
+            const f3 g0 = ldG(G, L, e, 0), g1 = ldG(G, L, e, 1), g2 = ldG(G, L, e, 2);
             ap.x -= (pm.x - pp.x) - (g0.x * am.x + g1.x * am.y + g2.x * am.z);
             ap.y -= (pm.y - pp.y) - (g0.y * am.x + g1.y * am.y + g2.y * am.z);
             ap.z -= (pm.z - pp.z) - (g0.z * am.x + g1.z * am.y + g2.z * am.z);
@@ -293,37 +331,42 @@ int thallo_hip_lapgraph_apply_jtj(int N, const int* out_ptr, const int* out_v1, 
 }
 
 int thallo_hip_arap_cost(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
-                         const float* original, const float* constraints, float w_fit, float w_reg, float* cost_out, thallo_stream_t stream)
+                         const float* original, const float* constraints, float w_fit, float w_reg, float* cost_out, long ell_stride, thallo_stream_t stream)
 {
-    if (n0 < 0 || n1 > N || n0 >= n1) return -(int)hipErrorInvalidValue;
+    if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0) return -(int)hipErrorInvalidValue;
+    const ELay L = { ell_stride, N };
     const int grid = vgrid(n1 - n0);
-    hipLaunchKernelGGL(k_arap_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, position, angle, original, constraints, w_fit, w_reg, cost_out);
+    hipLaunchKernelGGL(k_arap_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, position, angle, original, constraints, w_fit, w_reg, cost_out, L);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
-                               const float* original, float w_reg, float* F, float* G, thallo_stream_t stream)
+                               const float* original, float w_reg, float* F, float* G, long ell_stride, thallo_stream_t stream)
 {
+    if (ell_stride < 0) return -(int)hipErrorInvalidValue;
+    const ELay L = { ell_stride, N };
     const int grid = vgrid(N);
-    hipLaunchKernelGGL(k_arap_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, position, angle, original, w_reg, F, G);
+    hipLaunchKernelGGL(k_arap_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, position, angle, original, w_reg, F, G, L);
     return check_launch();
 }
 int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
-                             float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, thallo_stream_t stream)
+                             float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, long ell_stride, thallo_stream_t stream)
 {
-    if (n0 < 0 || n1 > N || n0 >= n1) return -(int)hipErrorInvalidValue;
+    if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0) return -(int)hipErrorInvalidValue;
+    const ELay L = { ell_stride, N };
     const int grid = vgrid(n1 - n0);
     hipLaunchKernelGGL(k_arap_init, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, in_ptr, in_edge, position, constraints, F, G, w_fit, w_reg,
-                       r, pre, z, p_prev, delta, diag_out, aN_out);
+                       r, pre, z, p_prev, delta, diag_out, aN_out, L);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_apply_jtj(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                               const float* constraints, const float* G, float w_fit, float w_reg,
-                              const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
+                              const float* p, float* Ap, float* aD_out, long ell_stride, thallo_stream_t stream)
 {
-    if (n0 < 0 || n1 > N || n0 >= n1) return -(int)hipErrorInvalidValue;
+    if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0) return -(int)hipErrorInvalidValue;
+    const ELay L = { ell_stride, N };
     const int grid = vgrid(n1 - n0);
-    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out);
+    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L);
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -231,8 +231,9 @@ public:
 struct GraphIncidence {
     int N = 0, E = 0;
     DeviceBuffer out_ptr, out_v1, in_ptr, in_edge, in_src;
+    long ell_stride = 0;          // > 0: out_v1 / in_edge are in the ELL layout of thallo_hip.h (position j*N + n), stride maxdeg*N
     const int* bound_v0 = nullptr; const int* bound_v1 = nullptr;
-    int build(int N_, int E_, const int* d_v0, const int* d_v1)
+    int build(int N_, int E_, const int* d_v0, const int* d_v1, bool want_ell = false)
     {
         N = N_; E = E_; bound_v0 = d_v0; bound_v1 = d_v1;
         std::vector<int> v0(E), v1(E);
@@ -245,7 +246,29 @@ struct GraphIncidence {
         for (int n = 0; n < N; ++n) { optr[n + 1] += optr[n]; iptr[n + 1] += iptr[n]; }
         std::vector<int> oc(optr.begin(), optr.end() - 1), ic(iptr.begin(), iptr.end() - 1);
         for (int e = 0; e < E; ++e) { pos[e] = oc[v0[e]]++; ov1[pos[e]] = v1[e]; }                 // stable: input order within a vertex
-        for (int e = 0; e < E; ++e) { const int k = ic[v1[e]]++; iedge[k] = pos[e]; isrc[k] = v0[e]; }
+        int maxdeg = 0;
+        for (int n = 0; n < N; ++n) maxdeg = std::max(maxdeg, optr[n + 1] - optr[n]);
+        ell_stride = 0;
+        if (want_ell && maxdeg >= 1 && maxdeg <= 32 && (long)maxdeg * N <= 3L * E + N) {          // bounded padding: ELL positions j*N + n
+            ell_stride = (long)maxdeg * N;
+            std::vector<int> ell_v1((size_t)ell_stride, 0);
+            for (int e = 0; e < E; ++e) { const long q = (long)(pos[e] - optr[v0[e]]) * N + v0[e]; ell_v1[q] = v1[e]; pos[e] = (int)q; }
+            ov1.swap(ell_v1);
+        }
+        int maxin = 0;
+        for (int n = 0; n < N; ++n) maxin = std::max(maxin, iptr[n + 1] - iptr[n]);
+        if (ell_stride && (maxin > 32 || (long)maxin * N > 3L * E + N)) {                          // in-lists would pad too much: back to CSR everywhere
+            ell_stride = 0;
+            std::vector<int> oc2(optr.begin(), optr.end() - 1);
+            ov1.assign(E, 0);
+            for (int e = 0; e < E; ++e) { pos[e] = oc2[v0[e]]++; ov1[pos[e]] = v1[e]; }
+        }
+        if (ell_stride) { iedge.assign((size_t)std::max(1, maxin) * N, 0); isrc.assign((size_t)std::max(1, maxin) * N, 0); }
+        for (int e = 0; e < E; ++e) {
+            const int k = ic[v1[e]]++;
+            const long q = ell_stride ? (long)(k - iptr[v1[e]]) * N + v1[e] : k;
+            iedge[q] = pos[e]; isrc[q] = v0[e];
+        }
         auto up = [&](DeviceBuffer& b, const std::vector<int>& h) {
             if (b.alloc(sizeof(int) * (h.size() + 4))) return -1;
             return hipMemcpy(b.ptr, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
@@ -334,37 +357,42 @@ public:
         position = (float*)p[2]; angle = (float*)p[3]; original = (const float*)p[4]; constraints = (const float*)p[5];
         v0 = (const int*)p[6]; v1 = (const int*)p[7];
         if (!position || !angle || !original || !constraints || !v0 || !v1) { set_error("arap: null problem parameter"); return -1; }
-        if (!F.ptr) { if (F.alloc(sizeof(float) * 3 * (size_t)E + 64) || G.alloc(sizeof(float) * 9 * (size_t)E + 64)) return -1; }
         return 0;
     }
-    int prepare(LaunchCtx&) override { return g.build(N, E, v0, v1); }
+    int prepare(LaunchCtx&) override
+    {
+        if (int rc = g.build(N, E, v0, v1, true)) return rc;
+        const size_t edges = g.ell_stride ? (size_t)g.ell_stride : (size_t)E;      // ELL layout (thallo_hip.h) when its padding is bounded
+        if (F.bytes < sizeof(float) * 3 * edges + 64 && (F.alloc(sizeof(float) * 3 * edges + 64) || G.alloc(sizeof(float) * 9 * edges + 64))) return -1;
+        return 0;
+    }
     float* unknown_ptr(int k) override { return k == 0 ? position : angle; }
     int cost(LaunchCtx& c, float* out) override
     {
         TimedLaunch t(c, "computeCost");
-        return thallo_hip_arap_cost(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, c.stream);
+        return thallo_hip_arap_cost(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, g.ell_stride, c.stream);
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
         { TimedLaunch t(c, "precompute");
-          int rc = thallo_hip_arap_precompute(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, c.stream);
+          int rc = thallo_hip_arap_precompute(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, g.ell_stride, c.stream);
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_arap_pcg_init(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
-                                        (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
+                                        (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, g.ell_stride, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_arap_apply_jtj(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
-                                         constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, c.stream);
+                                         constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_arap_apply_jtj(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
-                                         constraints, (const float*)G.ptr, w_fit, w_reg, v.p[cur ^ 1], v.Ap, out, c.stream);
+                                         constraints, (const float*)G.ptr, w_fit, w_reg, v.p[cur ^ 1], v.Ap, out, g.ell_stride, c.stream);
     }
 };
 

@@ -32,10 +32,10 @@ class HipArapPartBackend:
         self.L = api.lib()
         L = self.L
         vp, ci, cl, fl = C.c_void_p, C.c_int, C.c_long, C.c_float
-        L.thallo_hip_arap_cost.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, fl, fl, vp, vp]
-        L.thallo_hip_arap_precompute.argtypes = [ci, vp, vp, vp, vp, vp, fl, vp, vp, vp]
-        L.thallo_hip_arap_pcg_init.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, vp]
-        L.thallo_hip_arap_apply_jtj.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp]
+        L.thallo_hip_arap_cost.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, fl, fl, vp, C.c_long, vp]
+        L.thallo_hip_arap_precompute.argtypes = [ci, vp, vp, vp, vp, vp, fl, vp, vp, C.c_long, vp]
+        L.thallo_hip_arap_pcg_init.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, C.c_long, vp]
+        L.thallo_hip_arap_apply_jtj.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, fl, fl, vp, vp, vp, C.c_long, vp]
         L.thallo_hip_pcg_pupdate_ranges.argtypes = [vp, vp, vp, vp, cl, cl, cl, cl, ci, api.SumT, api.SumT, api.SumT, vp]
         self.part = part
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -91,19 +91,19 @@ class HipArapPartBackend:
         op, ov, ip, ie, isr = self._g()
         self.nb = self._chk(self.L.thallo_hip_arap_cost(self.N, self.part.n0, self.part.n1, op, ov, vp(self.position.data_ptr()), vp(self.angle.data_ptr()),
                                                         vp(self.original.data_ptr()), vp(self.constraints.data_ptr()), fl(self.w_fit), fl(self.w_reg),
-                                                        vp(self.parts.data_ptr()), self._st()), "arap_cost")
+                                                        vp(self.parts.data_ptr()), C.c_long(0), self._st()), "arap_cost")
         self._finish(out_idx)
 
     def init(self, cur, out_idx):
         vp, fl = C.c_void_p, C.c_float
         op, ov, ip, ie, isr = self._g()
         self._chk(self.L.thallo_hip_arap_precompute(self.N, op, ov, vp(self.position.data_ptr()), vp(self.angle.data_ptr()), vp(self.original.data_ptr()),
-                                                    fl(self.w_reg), vp(self.F.data_ptr()), vp(self.G.data_ptr()), self._st()), "arap_precompute")
+                                                    fl(self.w_reg), vp(self.F.data_ptr()), vp(self.G.data_ptr()), C.c_long(0), self._st()), "arap_precompute")
         self.p[cur].zero_()
         self.nb = self._chk(self.L.thallo_hip_arap_pcg_init(self.N, self.part.n0, self.part.n1, op, ip, ie, vp(self.position.data_ptr()), vp(self.constraints.data_ptr()),
                                                             vp(self.F.data_ptr()), vp(self.G.data_ptr()), fl(self.w_fit), fl(self.w_reg),
                                                             vp(self.r.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()),
-                                                            vp(self.delta.data_ptr()), None, vp(self.parts.data_ptr()), self._st()), "arap_pcg_init")
+                                                            vp(self.delta.data_ptr()), None, vp(self.parts.data_ptr()), C.c_long(0), self._st()), "arap_pcg_init")
         self._finish(out_idx)
 
     def pupdate(self, cur, first, iN, iD, iB):
@@ -125,7 +125,7 @@ class HipArapPartBackend:
         op, ov, ip, ie, isr = self._g()
         self.nb = self._chk(self.L.thallo_hip_arap_apply_jtj(self.N, self.part.n0, self.part.n1, op, ov, ip, ie, isr, vp(self.constraints.data_ptr()),
                                                              vp(self.G.data_ptr()), fl(self.w_fit), fl(self.w_reg), vp(self.p[cur].data_ptr()),
-                                                             vp(self.Ap.data_ptr()), vp(self.parts.data_ptr()), self._st()), "arap_apply_jtj")
+                                                             vp(self.Ap.data_ptr()), vp(self.parts.data_ptr()), C.c_long(0), self._st()), "arap_apply_jtj")
         self._finish(out_idx)
 
     def step2(self, iN, iD, out_idx):

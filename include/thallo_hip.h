@@ -353,6 +353,26 @@ int thallo_hip_iw_apply_jtj(int W, int H, int row0, int row1, const float* cs, c
 void thallo_hip_debug_set(int what, int value);
 void thallo_hip_debug_set2(int value);
 
+/* ---------------------------------------------------------------- single-reduction PCG form (any energy whose applyJTJ also returns N, S1, S2)
+ * An apply_jtj entry point that takes (r, pre, s3_out) additionally writes, per workgroup b, the doubles
+ *   s3_out[3b] = sum r.M^-1.r,  s3_out[3b+1] = sum r.M^-1.Ap,  s3_out[3b+2] = sum Ap.M^-1.Ap     (M^-1 = pre, or 1 if pre == NULL)
+ * over the unknowns it produced.  thallo_hip_pcg_scalars_finish (one wave) turns them and the alphaD partials into the two scalar
+ * words alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 = r_{k+1}.M^-1 r_{k+1}; thallo_hip_pcg_update is then the only other
+ * launch of the iteration: r -= alpha_{k-1} Ap, p_out = M^-1 r + beta_{k-1} p_in, delta += alpha_{k-1} p_in (first: p_out = M^-1 r).
+ * Two kernels + one scalar launch per PCG iteration instead of three + two, one reduction point instead of two. */
+int thallo_hip_pcg_update(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, int first,
+                          thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_stream_t stream);
+int thallo_hip_pcg_scalars_finish(const float* alphaD_partials, const double* s3_partials, int count, thallo_sum_t alphaN,
+                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* the applyJTJ entry points of E2 / E3 / E4 (argument meaning as in the plain forms below) that also return the three sums */
+int thallo_hip_arap_apply_jtj_sums(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
+                                   const float* constraints, const float* G, float w_fit, float w_reg,
+                                   const float* p, float* Ap, float* alphaD_out, long ell_stride, const float* r, const float* pre, double* s3_out, thallo_stream_t stream);
+int thallo_hip_ba_apply_jtj_sums(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
+                                 const float* Jb, const float* p, float* Ap, float* alphaD_out, const float* r, const float* pre, double* s3_out, thallo_stream_t stream);
+int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                  float* U, float* R, const float* p, float* Ap, float* alphaD_out, const float* r, double* s3_out, thallo_stream_t stream);
+
 /* ---------------------------------------------------------------- materialized schedules (CSR) */
 /* y = A x for a CSR matrix (rows+1 row pointers, int32 columns, float values); with dot_with / dot_out (both or neither) it also writes
    the per-workgroup partials of dot_with . y.  Replaces the cuSPARSE csrmv calls of gauss_newton.t:1470-1517: `[Jt][[J]p]` = two calls

@@ -72,6 +72,38 @@ __device__ __forceinline__ void block_store_partial(float v, float* __restrict__
     block_store_partials<1>(vv, oo, red);
 }
 
+// --- the three double sums of the single-reduction PCG form (DESIGN.md "one reduction point per iteration"):
+//   N = sum r.M^-1.r,  S1 = sum r.M^-1.Ap,  S2 = sum Ap.M^-1.Ap   accumulated from exact products of the float data, so that
+//   betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 (= r_{k+1}.M^-1 r_{k+1}) survives its cancellation
+struct Sums3 {
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
+    __device__ __forceinline__ void add(float m, float r, float a)
+    {
+        const double dm = m, dr = r, da = a;
+        n += dm * (dr * dr); s1 += dm * (dr * da); s2 += dm * (da * da);
+    }
+};
+__device__ __forceinline__ double wave_sum_all_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
+    return v;
+}
+// one {N, S1, S2} triple per workgroup into out[3*blockIdx.x ..]; every thread calls it; redd >= 3 * (blockDim.x / 64) doubles of LDS
+__device__ __forceinline__ void block_store_sums3(const Sums3& s, double* __restrict__ out, double* redd)
+{
+    const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
+    const int nw = (blockDim.x + THALLO_WAVE - 1) / THALLO_WAVE;
+    const double a = wave_sum_all_f64(s.n), b = wave_sum_all_f64(s.s1), c = wave_sum_all_f64(s.s2);
+    if (lane == 0) { redd[3 * wave] = a; redd[3 * wave + 1] = b; redd[3 * wave + 2] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = 0.0, y = 0.0, z = 0.0;
+        for (int w = 0; w < nw; ++w) { x += redd[3 * w]; y += redd[3 * w + 1]; z += redd[3 * w + 2]; }
+        out[3 * blockIdx.x] = x; out[3 * blockIdx.x + 1] = y; out[3 * blockIdx.x + 2] = z;
+    }
+}
+
 // safeDivideIfNotLM (gauss_newton.t:226-234): GN guards the zero denominator, LM divides blindly.
 template <bool LM>
 __device__ __forceinline__ float safe_div(float num, float den)

@@ -150,10 +150,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
                                                   const float4* __restrict__ Jb, const float2* __restrict__ F, const float* __restrict__ p,
                                                   float* __restrict__ o0, float* __restrict__ pre, float* __restrict__ z,
                                                   float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ diag_out,
-                                                  float* __restrict__ part_out)
-{
+                                                  float* __restrict__ part_out, const float* __restrict__ rs = nullptr, const float* __restrict__ prs = nullptr,
+                                                  double* __restrict__ s3_out = nullptr)
+{   // MODE 1 with rs / prs / s3_out: also the Sums3 of the single-reduction PCG form (r and M^-1 at the unknowns this thread writes)
     __shared__ float red[16];
-    float acc = 0.0f;
+    __shared__ double redd[3 * BLOCK / 64];
+    float acc = 0.0f; Sums3 sm;
     const long PB = 9L * C_;                       // start of the point block in the flat vectors
     if ((int)blockIdx.x < cam_blocks) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
                 } else {
                     o0[i] = sv;
                     acc += p[i] * sv;
+                    if (s3_out) sm.add(prs[i], rs[i], sv);
                 }
             }
         }
@@ -234,10 +237,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
             } else {
                 o0[i] = s0; o0[i + 1] = s1; o0[i + 2] = s2;
                 acc += pp0 * s0 + pp1 * s1 + pp2 * s2;
+                if (s3_out) { sm.add(prs[i], rs[i], s0); sm.add(prs[i + 1], rs[i + 1], s1); sm.add(prs[i + 2], rs[i + 2], s2); }
             }
         }
     }
     block_store_partial(acc, part_out, red);
+    if (MODE == 1 && s3_out) block_store_sums3(sm, s3_out, redd);
 }
 
 inline void gather_shape(int C_, int P_, int& cam_blocks, int& grid)
@@ -285,6 +290,17 @@ int thallo_hip_ba_apply_jtj(int C_, int P_, const int* cam_ptr, const int* q_pt,
     int cb, grid; gather_shape(C_, P_, cb, grid);
     hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
                        (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_ba_apply_jtj_sums(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
+                                 const float* Jb, const float* p, float* Ap, float* aD_out, const float* r, const float* pre, double* s3_out, thallo_stream_t stream)
+{
+    if (!r || !pre || !s3_out) return -(int)hipErrorInvalidValue;
+    int cb, grid; gather_shape(C_, P_, cb, grid);
+    hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
+                       (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out,
+                       r, pre, s3_out);
     int e = check_launch(); return e ? e : grid;
 }
 

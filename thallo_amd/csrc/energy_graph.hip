@@ -261,10 +261,12 @@ __global__ __launch_bounds__(BLOCK) void k_arap_init(int N, int n0, int n1, cons
 __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
                                                        const int* __restrict__ in_ptr, const int* __restrict__ in_edge, const int* __restrict__ in_src,
                                                        const float* __restrict__ Cn, const float* __restrict__ G, float wf, float wr,
-                                                       const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out, ELay L)
-{
+                                                       const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out, ELay L,
+                                                       const float* __restrict__ rs, const float* __restrict__ pre, double* __restrict__ s3_out)
+{   // rs / pre / s3_out (all or none): also the Sums3 of the single-reduction PCG form over the unknowns of [n0,n1)
     __shared__ float red[16];
-    float acc = 0.0f;
+    __shared__ double redd[3 * BLOCK / 64];
+    float acc = 0.0f; Sums3 sm;
     const float wr2 = wr * wr;
     for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
         const f3 pp = ld3(p, n), pa = ld3(p, (long)N + n);
@@ -299,8 +301,14 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, con
         if (Cn[3 * n] >= -999999.9f) { ap.x += wf * wf * pp.x; ap.y += wf * wf * pp.y; ap.z += wf * wf * pp.z; }
         st3(Ap, n, ap); st3(Ap, (long)N + n, aa);
         acc += pp.x * ap.x + pp.y * ap.y + pp.z * ap.z + pa.x * aa.x + pa.y * aa.y + pa.z * aa.z;
+        if (s3_out) {
+            const f3 rp = ld3(rs, n), ra = ld3(rs, (long)N + n), mp = ld3(pre, n), ma = ld3(pre, (long)N + n);
+            sm.add(mp.x, rp.x, ap.x); sm.add(mp.y, rp.y, ap.y); sm.add(mp.z, rp.z, ap.z);
+            sm.add(ma.x, ra.x, aa.x); sm.add(ma.y, ra.y, aa.y); sm.add(ma.z, ra.z, aa.z);
+        }
     }
     block_store_partial(acc, aD_out, red);
+    if (s3_out) block_store_sums3(sm, s3_out, redd);
 }
 
 }  // namespace
@@ -366,7 +374,17 @@ int thallo_hip_arap_apply_jtj(int N, int n0, int n1, const int* out_ptr, const i
     if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0) return -(int)hipErrorInvalidValue;
     const ELay L = { ell_stride, N };
     const int grid = vgrid(n1 - n0);
-    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L);
+    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, (const float*)nullptr, (const float*)nullptr, (double*)nullptr);
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_arap_apply_jtj_sums(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
+                                   const float* constraints, const float* G, float w_fit, float w_reg,
+                                   const float* p, float* Ap, float* aD_out, long ell_stride, const float* r, const float* pre, double* s3_out, thallo_stream_t stream)
+{
+    if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0 || !r || !pre || !s3_out) return -(int)hipErrorInvalidValue;
+    const ELay L = { ell_stride, N };
+    const int grid = vgrid(n1 - n0);
+    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out);
     int e = check_launch(); return e ? e : grid;
 }
 

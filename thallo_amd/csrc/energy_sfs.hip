@@ -201,11 +201,13 @@ template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_gather(Geo g, Cam cm, const float* __restrict__ v, const float* __restrict__ D,
                                                   const float4* __restrict__ G, const float2* __restrict__ U, const float* __restrict__ R,
                                                   const unsigned char* __restrict__ fl, float* __restrict__ out, float* __restrict__ z,
-                                                  float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ part_out)
-{
+                                                  float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ part_out,
+                                                  const float* __restrict__ rs = nullptr, double* __restrict__ s3_out = nullptr)
+{   // MODE 1 with rs / s3_out: also the Sums3 of the single-reduction PCG form (no preconditioner in this energy: M^-1 = 1)
     __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
     const long N = (long)g.W * g.H;
-    float acc = 0.0f;
+    float acc = 0.0f; Sums3 sm;
     FOR_EACH_PIXEL(g) {
         const long i = (long)y * g.W + x;
         const float vc = v[i];
@@ -221,9 +223,10 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Geo g, Cam cm, const float* __
             s += cm.ws * (coef(cm, c, x, y + g.yoff) * lap);
         }
         if (MODE == 0) { const float r = -s; out[i] = r; z[i] = r; p_prev[i] = 0.0f; delta[i] = 0.0f; acc += r * r; }
-        else { out[i] = s; acc += vc * s; }
+        else { out[i] = s; acc += vc * s; if (s3_out) sm.add(1.0f, rs[i], s); }
     }
     block_store_partial(acc, part_out, red);
+    if (MODE == 1 && s3_out) block_store_sums3(sm, s3_out, redd);
 }
 
 // raw diag(J^T J) (LM only): enumerate the rows that contain X(i)
@@ -316,8 +319,19 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
     int e = check_launch(); return e ? e : grid;
 }
 
+static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream);
+
 int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
+{ return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream); }
+
+int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                  float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream)
+{ if (!r || !s3_out) return -(int)hipErrorInvalidValue; return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, r, s3_out, stream); }
+
+static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream)
 {
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
@@ -326,7 +340,7 @@ int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_rows<false>, dim3(gridr), dim3(BLOCK), 0, s, gr, cm, p, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
     hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, s, g, cm, p, (const float*)nullptr, (const float4*)G, (const float2*)U, (const float*)R, fl,
-                       Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
+                       Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out, r, s3_out);
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -145,6 +145,56 @@ __global__ __launch_bounds__(BLOCK) void k_pupdate(const float4* __restrict__ z,
     }
 }
 
+// ------------------------------------------------------------------ single-reduction form, energy-independent half
+// One flat pass = PCGStep2 of iteration k-1 + PCGStep3 + the delta update of iteration k (gauss_newton.t:801-843,889-899):
+//   r -= alpha_{k-1} Ap (fma) ;  z = M^-1 r (not stored) ;  p_out = z + beta_{k-1} p_in ;  delta += alpha_{k-1} p_in      [first: p_out = M^-1 r only]
+// possible because beta_{k-1} is already known: the applyJTJ kernel of iteration k-1 also produced N, S1, S2 (Sums3) and
+// k_scalars_finish expanded betaN_{k-1} = N - 2 alpha S1 + alpha^2 S2 from them.  No reduction in here.
+template <bool HAS_PRE>
+__global__ __launch_bounds__(BLOCK) void k_pcg_update(float4* __restrict__ r, const float4* __restrict__ Ap, const float4* __restrict__ pre,
+                                                       const float4* __restrict__ p_in, float4* __restrict__ p_out, float4* __restrict__ delta, long n4, int first,
+                                                       thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp)
+{
+    float alpha = 0.0f, beta = 0.0f;
+    if (!first) {
+        const float an = sum_partials(aNp.partials, aNp.count);
+        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
+        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+    }
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 rv = r[i];
+        const float4 pv = p_in[i];
+        if (!first) {
+            const float4 av = Ap[i];
+            rv.x = __builtin_fmaf(-alpha, av.x, rv.x); rv.y = __builtin_fmaf(-alpha, av.y, rv.y); rv.z = __builtin_fmaf(-alpha, av.z, rv.z); rv.w = __builtin_fmaf(-alpha, av.w, rv.w);
+            r[i] = rv;
+            float4 dv = delta[i];
+            dv.x = __builtin_fmaf(alpha, pv.x, dv.x); dv.y = __builtin_fmaf(alpha, pv.y, dv.y); dv.z = __builtin_fmaf(alpha, pv.z, dv.z); dv.w = __builtin_fmaf(alpha, pv.w, dv.w);
+            delta[i] = dv;
+        }
+        float4 zv = rv;
+        if (HAS_PRE) { const float4 m = pre[i]; zv.x *= m.x; zv.y *= m.y; zv.z *= m.z; zv.w *= m.w; }
+        p_out[i] = make_float4(zv.x + beta * pv.x, zv.y + beta * pv.y, zv.z + beta * pv.z, zv.w + beta * pv.w);
+    }
+}
+
+// one wave: alphaD_k (float partials, the usual order), N, S1, S2 (double partials, lane-strided then butterfly), then
+// betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 with alpha_k = alphaN_k / alphaD_k exactly as every consumer forms it
+__global__ __launch_bounds__(64) void k_scalars_finish(const float* __restrict__ aD_part, const double* __restrict__ s3, int nb, thallo_sum_t aN,
+                                                       float* __restrict__ aD_word, float* __restrict__ bN_word)
+{
+    const int lane = threadIdx.x;
+    const float ad = sum_partials(aD_part, nb);
+    double n = 0.0, a = 0.0, b = 0.0;
+    for (int i = lane; i < nb; i += THALLO_WAVE) { n += s3[3 * i]; a += s3[3 * i + 1]; b += s3[3 * i + 2]; }
+    n = wave_sum_all_f64(n); a = wave_sum_all_f64(a); b = wave_sum_all_f64(b);
+    const float an = sum_partials(aN.partials, aN.count);
+    const float alpha = safe_div<false>(an, ad);
+    double bn = n - 2.0 * (double)alpha * a + (double)alpha * (double)alpha * b;
+    if (!(bn > 0.0)) bn = 0.0;                       // r . M^-1 r is a sum of squares; guards the last bits at convergence
+    if (lane == 0) { aD_word[0] = ad; bN_word[0] = (float)bn; }
+}
+
 // ------------------------------------------------------------------ Levenberg-Marquardt set (gauss_newton.t:929-969,774-787,845-886)
 // PCGSaveSSq + PCGComputeCtC + PCGFinalizeDiagonal in one pass over the raw diagonal d = diag(J^T J):
 //   SSq (first GN iteration only) = guardedInvert(d) (or 1 without preconditioner)   -- Jacobi scale^2, ONCE_PER_SOLVE
@@ -417,6 +467,25 @@ int thallo_hip_pcg_pupdate(const float* z, const float* p_in, float* p_out, floa
                            thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_stream_t stream)
 {
     return thallo_hip_pcg_pupdate_ranges(z, p_in, p_out, delta, 0, (n + 3) / 4 * 4, 0, 0, first, aNp, aDp, bNp, stream);
+}
+
+int thallo_hip_pcg_update(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, int first,
+                          thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_stream_t stream)
+{
+    if (!r || !p_in || !p_out || (!first && (!Ap || !delta))) return -(int)hipErrorInvalidValue;
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipStream_t s = (hipStream_t)stream;
+    if (pre) hipLaunchKernelGGL(k_pcg_update<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
+    else     hipLaunchKernelGGL(k_pcg_update<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
+    return check_launch();
+}
+
+int thallo_hip_pcg_scalars_finish(const float* aD_partials, const double* s3_partials, int count, thallo_sum_t alphaN,
+                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream)
+{
+    if (!aD_partials || !s3_partials || count < 1 || count > THALLO_MAX_PARTIALS || !alphaD_word || !betaN_word) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_scalars_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, aD_partials, s3_partials, count, alphaN, alphaD_word, betaN_word);
+    return check_launch();
 }
 
 int thallo_hip_lm_finalize_diagonal(const float* diag, float* SSq, float* CtC, float* pre, const float* r, float* b, float* z, long n,

@@ -387,6 +387,13 @@ public:
         return thallo_hip_arap_apply_jtj(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
                                          constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
     }
+    bool apply_returns_sums() const override { return true; }
+    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_arap_apply_jtj_sums(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+                                              constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, v.r, v.pre, v.s12, c.stream);
+    }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
@@ -455,6 +462,13 @@ public:
         return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                        (const float*)Jb.ptr, p, Ap, out, c.stream);
     }
+    bool apply_returns_sums() const override { return true; }
+    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_ba_apply_jtj_sums(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
+                                            (const float*)Jb.ptr, p, Ap, out, v.r, v.pre, v.s12, c.stream);
+    }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
@@ -509,6 +523,13 @@ public:
     {
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_sfs_apply_jtj(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out, c.stream);
+    }
+    bool apply_returns_sums() const override { return true; }
+    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_sfs_apply_jtj_sums(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
+                                             v.r, v.s12, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {

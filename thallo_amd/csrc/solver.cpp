@@ -174,6 +174,7 @@ int Plan::ensure_slots(int L)
     parts_slots_ = need; nb_.assign(need, 1); fin_.assign(need, 0);
     { const char* e = getenv("THALLO_FINISH_SUMS"); finish_sums_ = !(e && e[0] == '0'); }
     { const char* e = getenv("THALLO_ONE_KERNEL"); one_kernel_ = !(e && e[0] == '0'); }
+    { const char* e = getenv("THALLO_EXPANDED"); expanded_ = !(e && e[0] == '0'); }
     { const char* e = getenv("THALLO_FIN_IN_KERNEL"); fin_in_kernel_ = !(e && e[0] == '0'); }
     return 0;
 }
@@ -268,6 +269,7 @@ int Plan::step(void** params)
 int Plan::step_gn(int ev_iter)
 {   // GN branch, fused schedule (DESIGN.md "PCG schedule")
     if (one_kernel_ && plugin->one_kernel_iteration()) return step_gn_one_kernel(ev_iter);
+    if (expanded_ && plugin->apply_returns_sums()) return step_gn_expanded(ev_iter);
     const int L = sp.lIterations;
     hipStream_t s = ctx.stream;
     const int ev_setup = timer_.start("Nonlinear Setup", s);
@@ -380,14 +382,81 @@ int Plan::step_gn_one_kernel(int ev_iter)
 }
 
 // ------------------------------------------------------------------ Levenberg-Marquardt branch
+int Plan::step_gn_expanded(int ev_iter)
+{   // GN branch, single-reduction form for gather energies: per PCG iteration pcg_update (flat) + applyJTJ with sums + scalars_finish
+    // (thallo_hip.h "single-reduction PCG form") instead of PCGStep3 + applyJTJ + PCGStep2 and their finish launches
+    if (ensure_sums_buffer()) { set_error("out of device memory for the single-reduction schedule"); return 0; }
+    const int L = sp.lIterations;
+    hipStream_t s = ctx.stream;
+    const int ev_setup = timer_.start("Nonlinear Setup", s);
+    const int B = 2;                       // slot layout: alphaN_k = B+2k, alphaD_k = B+2k+1, betaN_k = B+2k+2
+    cur_ = 0;
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
+    set_nb(B, nb); finish(B);
+    timer_.stop(ev_setup, s);
+    const int ev_lin = timer_.start("Linear Solve", s);
+    for (int k = 0; k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        {   // r -= alpha_{k-1} Ap ; p_k = M^-1 r + beta_{k-1} p_{k-1} ; delta += alpha_{k-1} p_{k-1}      (k = 0: p_0 = M^-1 r_0)
+            TimedLaunch t(ctx, "PCGUpdate");
+            if (thallo_hip_pcg_update(v_.r, v_.Ap, plugin->use_preconditioner() ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
+                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return 0; }
+        }
+        cur_ ^= 1;
+        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD));
+        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
+        set_nb(jD, nb);
+        {   // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2
+            TimedLaunch t(ctx, "PCGScalars");
+            if (thallo_hip_pcg_scalars_finish(slot(jD), v_.s12, nb, sum(jN), scal(jD), scal(jB), s) < 0) { set_error("PCGScalars launch failed"); return 0; }
+        }
+        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+    }
+    const bool batched = false;
+    last_l_iters = L;
+    timer_.stop(ev_lin, s);
+    const int ev_fin = timer_.start("Nonlinear Finish", s);
+    {   // PCGLinearUpdate, including the last pending delta += alpha*p
+        const auto& imgs = plugin->unknown_images();
+        long off = 0;
+        for (size_t k = 0; k < imgs.size(); ++k) {
+            TimedLaunch t(ctx, "PCGLinearUpdate");
+            const int jN = B + 2 * (L - 1), jD = jN + 1;
+            // batched: after the last PCGStep1 (k = L-1) delta holds the terms up to p_{L-2} if L-1 is even, up to p_{L-3} if it is odd
+            if (L > 1 && batched && ((L - 1) & 1))
+                thallo_hip_linear_update2(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_ ^ 1] + off, sum(jN - 2), sum(jD - 2),
+                                          v_.p[cur_] + off, sum(jN), sum(jD), imgs[k].n_floats, s);
+            else if (L > 0) thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_] + off, imgs[k].n_floats, sum(jN), sum(jD), s);
+            else       thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
+            off += imgs[k].n_floats;
+        }
+    }
+    sp.nIter++;
+    timer_.stop(ev_fin, s);
+    timer_.stop(ev_iter, s);
+    return 1;
+}
+
+// ------------------------------------------------------------------ Levenberg-Marquardt branch
+int Plan::ensure_sums_buffer()
+{
+    if (v_.s12) return 0;
+    DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b);
+    if (b->alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double))) return -1;
+    v_.s12 = (double*)b->ptr;
+    return 0;
+}
+
 int Plan::ensure_iter_buffers()
 {
     if (v_.r2) return 0;
-    DeviceBuffer* b[4];
-    for (int i = 0; i < 4; ++i) { b[i] = new DeviceBuffer(); bufs_.push_back(b[i]); }
+    if (ensure_sums_buffer()) return -1;
+    DeviceBuffer* b[3];
+    for (int i = 0; i < 3; ++i) { b[i] = new DeviceBuffer(); bufs_.push_back(b[i]); }
     if (b[0]->alloc((size_t)v_.n_alloc * sizeof(float)) || b[1]->alloc((size_t)v_.n_alloc * sizeof(float)) ||
-        b[2]->alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double)) || b[3]->alloc(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned))) return -1;
-    v_.r2 = (float*)b[0]->ptr; v_.Ap2 = (float*)b[1]->ptr; v_.s12 = (double*)b[2]->ptr; v_.fin_tickets = (unsigned*)b[3]->ptr;
+        b[2]->alloc(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned))) return -1;
+    v_.r2 = (float*)b[0]->ptr; v_.Ap2 = (float*)b[1]->ptr; v_.fin_tickets = (unsigned*)b[2]->ptr;
     return 0;
 }
 

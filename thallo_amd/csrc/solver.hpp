@@ -82,6 +82,7 @@ private:
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
     bool fin_in_kernel_ = true;     // THALLO_FIN_IN_KERNEL=0: the iteration's scalars by a separate one-wave launch (A/B switch)
+    bool expanded_ = true;          // THALLO_EXPANDED=0: three-kernel form even where the plugin's applyJTJ can return the sums (A/B switch)
     bool one_kernel_ = true;        // THALLO_ONE_KERNEL=0: two-kernel schedule even where the plugin offers pcg_iter (A/B switch)
     bool finish_sums_ = true;       // THALLO_FINISH_SUMS=0: consumers re-add the partials themselves (A/B switch)
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }
@@ -94,6 +95,8 @@ private:
     void finish(int j) { if (!finish_sums_ || nb_[j] <= 256) return; thallo_hip_finish_sum(partial_sum(j), scal(j), ctx.stream); fin_[j] = 1; }
     int  ensure_slots(int L);
     int  ensure_iter_buffers();
+    int  ensure_sums_buffer();
+    int  step_gn_expanded(int ev_iter);
     int  step_gn_one_kernel(int ev_iter);
     float compute_cost();
     int   step_gn(int ev_iter);

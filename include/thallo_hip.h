@@ -135,6 +135,13 @@ int thallo_hip_linear_update(float* X, const float* delta, const float* p, long 
                              thallo_sum_t alphaN, thallo_sum_t alphaD, thallo_stream_t stream);
 
 /* out[0] = sum(partials) -- used for cost / model-cost read-back (gauss_newton.t:1128-1150). */
+/* Collective transport of the one-kernel-per-iteration schedule over row slabs: message of a rank = [alphaD_local | N, S1, S2 as (hi, lo)
+   words | the listed segments of vec (boundary rows of Ap_out)]; unpack adds the gathered scalars in rank order, writes alphaD_k and
+   betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 (alphaN: a one-word sum) and copies the neighbours' rows into the ghost segments.
+   ONE all-gather of these messages per PCG iteration. */
+int thallo_hip_slab_pack_iter(const float* vec, thallo_segs_t segs, const float* alphaD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream);
+int thallo_hip_slab_unpack_iter(float* vec, thallo_segs_t top, const float* src_top, thallo_segs_t bot, const float* src_bot,
+                                const float* gathered, long stride, int world, thallo_sum_t alphaN, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* X += delta + alpha_older * p_older + alpha * p (in that order): the tail of a GN step whose last two delta updates were
    deferred (THALLO_IW_STEP1_MODE batching with an even number of PCG iterations) */
 int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older, thallo_sum_t alphaN_older, thallo_sum_t alphaD_older,

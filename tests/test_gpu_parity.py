@@ -328,6 +328,7 @@ def test_image_warping_deferred_delta_updates_are_bitwise_neutral(torch, L):
     for batched in (True, False):
         solver, lay = make_hip_solver(copy_params(p), W, H, 0, 1, L)
         solver.be.batches_delta = batched
+        solver.be.one_kernel_collective = False          # the two-kernel form in both runs: only the batching differs
         for _ in range(2):
             solver.gn_step(L)
         torch.cuda.synchronize()

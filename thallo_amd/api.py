@@ -97,6 +97,8 @@ def lib():
     L.thallo_hip_dist_begin_step.argtypes = [DistT, vp]
     L.thallo_hip_dist_collect.argtypes = [DistT, ci, ci, vp, vp]
     L.thallo_hip_dist_error.argtypes = [DistT, ci, vp]
+    L.thallo_hip_slab_pack_iter.argtypes = [vp, SegsT, vp, vp, ci, vp, vp]
+    L.thallo_hip_slab_unpack_iter.argtypes = [vp, SegsT, vp, SegsT, vp, vp, cl, ci, SumT, vp, vp, vp]
     L.thallo_hip_dist_exchange.argtypes = [DistT, ci, SumT, vp, vp]
     L.thallo_hip_dist_exchange_iter.argtypes = [DistT, ci, vp, vp, ci, SumT, vp, vp, vp]
     _iter = [ci, ci, ci, ci, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, SumT, SumT, vp]

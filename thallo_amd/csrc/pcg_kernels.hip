@@ -380,6 +380,74 @@ __global__ __launch_bounds__(BLOCK) void k_slab_unpack(float* __restrict__ vec, 
     }
 }
 
+// One-kernel-per-iteration schedule over row slabs, collective transport: the message of a rank =
+//   [ alphaD_local | N, S1, S2 as (hi, lo) words | first owned row of Ap_out | last owned row of Ap_out ]
+// (7 scalars words, then the listed segments).  One all-gather of these per PCG iteration replaces the all-reduce + all-gather of
+// the two-kernel form.
+__global__ __launch_bounds__(BLOCK) void k_slab_pack_iter(const float* __restrict__ vec, thallo_segs_t segs, const float* __restrict__ aD_part,
+                                                           const double* __restrict__ s3, int nb, float* __restrict__ out)
+{
+    if (blockIdx.x == 0 && threadIdx.x < THALLO_WAVE) {
+        const int lane = threadIdx.x;
+        const float ad = sum_partials(aD_part, nb);
+        double q[3] = { 0.0, 0.0, 0.0 };
+        for (int i = lane; i < nb; i += THALLO_WAVE) { q[0] += s3[3 * i]; q[1] += s3[3 * i + 1]; q[2] += s3[3 * i + 2]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) q[j] = wave_sum_all_f64(q[j]);
+        if (lane == 0) {
+            out[0] = ad;
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(q[j]);
+                out[1 + 2 * j] = __uint_as_float((unsigned)(b >> 32)); out[2 + 2 * j] = __uint_as_float((unsigned)b);
+            }
+        }
+    }
+    long base = 7;
+    for (int k = 0; k < segs.n; ++k) {
+        for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < segs.len[k]; i += (long)gridDim.x * BLOCK) out[base + i] = vec[segs.off[k] + i];
+        base += segs.len[k];
+    }
+}
+
+// rank-ordered sums of the gathered scalars -> alphaD_k, betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 (as k_scalars_finish); ghost rows of
+// Ap_out <- the neighbours' boundary rows
+__global__ __launch_bounds__(BLOCK) void k_slab_unpack_iter(float* __restrict__ vec, thallo_segs_t top, const float* __restrict__ src_top,
+                                                             thallo_segs_t bot, const float* __restrict__ src_bot,
+                                                             const float* __restrict__ gathered, long stride, int world, thallo_sum_t aN,
+                                                             float* __restrict__ aD_word, float* __restrict__ bN_word)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float gad = 0.0f; double gq[3] = { 0.0, 0.0, 0.0 };
+        for (int r = 0; r < world; ++r) {
+            const float* m = gathered + (long)r * stride;
+            gad += m[0];
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long b = ((unsigned long long)__float_as_uint(m[1 + 2 * j]) << 32) | (unsigned long long)__float_as_uint(m[2 + 2 * j]);
+                gq[j] += __longlong_as_double((long long)b);
+            }
+        }
+        const float an = aN.count == 1 ? aN.partials[0] : 0.0f;
+        const float alpha = safe_div<false>(an, gad);
+        double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
+        if (!(bn > 0.0)) bn = 0.0;
+        aD_word[0] = gad; bN_word[0] = (float)bn;
+    }
+    if (src_top) {
+        long base = 0;
+        for (int k = 0; k < top.n; ++k) {
+            for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < top.len[k]; i += (long)gridDim.x * BLOCK) vec[top.off[k] + i] = src_top[base + i];
+            base += top.len[k];
+        }
+    }
+    if (src_bot) {
+        long base = 0;
+        for (int k = 0; k < bot.n; ++k) {
+            for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < bot.len[k]; i += (long)gridDim.x * BLOCK) vec[bot.off[k] + i] = src_bot[base + i];
+            base += bot.len[k];
+        }
+    }
+}
+
 __global__ void k_finish_sum(thallo_sum_t s, float* __restrict__ out)
 {
     const float v = sum_partials(s.partials, s.count);
@@ -571,6 +639,21 @@ int thallo_hip_slab_unpack(float* vec, thallo_segs_t top, const float* src_top, 
 {
     if (top.n < 0 || top.n > 8 || bot.n < 0 || bot.n > 8) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_slab_unpack, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, top, src_top, bot, src_bot, gathered, stride, world, sum_out);
+    return check_launch();
+}
+
+int thallo_hip_slab_pack_iter(const float* vec, thallo_segs_t segs, const float* aD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream)
+{
+    if (segs.n < 0 || segs.n > 8 || !aD_partials || !s3_partials || count < 1 || count > THALLO_MAX_PARTIALS || !out) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_slab_pack_iter, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, segs, aD_partials, s3_partials, count, out);
+    return check_launch();
+}
+
+int thallo_hip_slab_unpack_iter(float* vec, thallo_segs_t top, const float* src_top, thallo_segs_t bot, const float* src_bot,
+                                const float* gathered, long stride, int world, thallo_sum_t alphaN, float* alphaD_word, float* betaN_word, thallo_stream_t stream)
+{
+    if (top.n < 0 || top.n > 8 || bot.n < 0 || bot.n > 8 || !gathered || world < 1 || alphaN.count != 1 || !alphaD_word || !betaN_word) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_slab_unpack_iter, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, top, src_top, bot, src_bot, gathered, stride, world, alphaN, alphaD_word, betaN_word);
     return check_launch();
 }
 

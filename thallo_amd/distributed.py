@@ -117,10 +117,11 @@ class HipSlabBackend:
             self.rz, self.r_alt, self.Ap_ipc = blk[:2 * na], blk[2 * na:3 * na], [blk[3 * na:4 * na], blk[4 * na:5 * na]]
         else:
             self.rz = torch.zeros(2 * na, dtype=torch.float32, device=dev)
+            self.r_alt, self.Ap_ipc = z(), [z(), z()]
         self.r, self.z = self.rz[:na], self.rz[na:]
         self.na = na
         self.pre, self.delta = z(), z()
-        self.Ap = self.Ap_ipc[0] if ipc else z()
+        self.Ap = self.Ap_ipc[0]
         self.s12 = torch.zeros(3 * 1024, dtype=torch.float64, device=dev)      # N, S1, S2 partials of the one-kernel schedule
         self.fin_tickets = torch.zeros(528, dtype=torch.int32, device=dev)     # THALLO_HIP_FIN_TICKET_WORDS
         self.exchange_in_kernel = os.environ.get("THALLO_DIST_EXCHANGE_IN_KERNEL", "1") != "0"
@@ -144,6 +145,14 @@ class HipSlabBackend:
         self.seg_bot_ghost = _segs(row(self.row1) + row(self.row1, na)) if layout.bot else _segs([])
         if W % 4 or (2 * N) % 4:
             raise ValueError("the slab path needs W % 4 == 0 (16-byte row granules in the flat kernels)")
+        # one-kernel schedule over collectives: message = [alphaD | N, S1, S2 (hi, lo) | first row of Ap_out | last row of Ap_out]
+        self.msg_iter = 7 + 6 * W
+        self.send_iter = torch.zeros(self.msg_iter, dtype=torch.float32, device=dev)
+        self.gath_iter = torch.zeros(layout.world * self.msg_iter, dtype=torch.float32, device=dev)
+        self.seg_iter_first_last = _segs(row(self.row0) + row(self.row1 - 1))
+        self.seg_iter_top = _segs(row(self.row0 - 1)) if layout.top else _segs([])
+        self.seg_iter_bot = _segs(row(self.row1)) if layout.bot else _segs([])
+        self.one_kernel_collective = os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0"
 
     # -- helpers
     def _st(self):
@@ -335,6 +344,32 @@ class HipSlabBackend:
             self._chk(self.L.thallo_hip_dist_exchange_iter(self.p2p, 7 * k, vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self.nb, self._sum(iB),
                                                            vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB), self._st()), "dist_exchange_iter")
 
+    def iter_collective(self, cur, mode, iN, iD, iB, jD, jB, iN2, iD2, allgather):
+        """One PCG iteration = the one-kernel iteration (no peer stores) + ONE all-gather of [alphaD, N, S1, S2, boundary rows of Ap_out]
+        (`allgather(send, recv)`; None at world size 1) -> S[jD] = alphaD_k, S[jB] = betaN_k, ghost rows of Ap_out."""
+        vp, fl = C.c_void_p, C.c_float
+        rb = (self.r, self.r_alt)
+        Ao = self.Ap_ipc[cur ^ 1]
+        self.nb = self._chk(self.L.thallo_hip_iw_pcg_iter(
+            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()), vp(self.pre.data_ptr()),
+            fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(Ao.data_ptr()),
+            vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), int(mode),
+            self._sum(iN), self._sum(iD), self._sum(iB), self._sum(iN2), self._sum(iD2), vp(self.irregular.data_ptr()),
+            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), None, None, None, self._st()), "iw_pcg_iter")
+        self._chk(self.L.thallo_hip_slab_pack_iter(vp(Ao.data_ptr()), self.seg_iter_first_last, vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self.nb,
+                                                   vp(self.send_iter.data_ptr()), self._st()), "slab_pack_iter")
+        lay, msg = self.lay, self.msg_iter
+        if allgather is not None:
+            allgather(self.send_iter, self.gath_iter)
+            g, world = self.gath_iter, lay.world
+        else:
+            g, world = self.send_iter, 1
+        base = g.data_ptr()
+        src_top = vp(base + 4 * ((lay.rank - 1) * msg + 7 + 3 * self.W)) if lay.top else None      # the LAST owned row of rank-1
+        src_bot = vp(base + 4 * ((lay.rank + 1) * msg + 7)) if lay.bot else None                    # the FIRST owned row of rank+1
+        self._chk(self.L.thallo_hip_slab_unpack_iter(vp(Ao.data_ptr()), self.seg_iter_top, src_top, self.seg_iter_bot, src_bot, vp(base), C.c_long(msg), world,
+                                                     self._sum(iB), vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB), self._st()), "slab_unpack_iter")
+
     def iter_local(self, cur=0):
         """the one-kernel iteration without the remote stores and without the exchange (bench: kernel time on this rank's slab)"""
         vp, fl = C.c_void_p, C.c_float
@@ -444,8 +479,20 @@ class SlabSolver:
             gath = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
             dist.all_gather_into_tensor(gath, send, group=self.group)
             be.unpack_grid_info(gath.view(self.world, -1))
-        self._gather_sum_and_rows(B)                   # S[B] = alphaN_0 (global); ghost rows of z
-        for k in range(L):
+        self._gather_sum_and_rows(B)                   # S[B] = alphaN_0 (global); ghost rows of r and z
+        one_kernel = getattr(be, "one_kernel_collective", False) and batched
+        if one_kernel and hasattr(be, "irregular") and not getattr(self, "_grid_checked", False):
+            # the one-kernel schedule needs UrShape on the pixel grid on every rank (z-free); checked once per solver (one host sync)
+            self._grid_ok = int(be.irregular[0].item()) == 0
+            self._grid_checked = True
+        one_kernel = one_kernel and getattr(self, "_grid_ok", False)
+        ag = (lambda send, recv: dist.all_gather_into_tensor(recv, send, group=self.group)) if self.use_dist else None
+        for k in range(L if one_kernel else 0):        # one kernel + ONE all-gather per PCG iteration
+            jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
+            be.iter_collective(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD, jB,
+                               jN - 4 if k > 1 else jN, jD - 4 if k > 1 else jD, ag)
+            cur ^= 1
+        for k in range(0 if one_kernel else L):
             jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
             if batched:                                # every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
                 be.step1(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD,

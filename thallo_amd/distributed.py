@@ -700,7 +700,7 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     # PCGStep1 is re-launched back-to-back right after the timed region and timed with HIP events on the launch stream
     be = solver.be
     reps = 40
-    one_kernel = p2p and getattr(be, "p2p_iter", None) is not None and os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0"
+    one_kernel = os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0" and getattr(solver, "_grid_ok", True)      # both transports run the one-kernel iteration
     kern = (lambda: be.iter_local(0)) if one_kernel else (lambda: be.step1(0, False, 2, 3, 4, 5))    # (step1: + the 1-block finish_sum)
     for _ in range(3):
         kern()
@@ -730,7 +730,7 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
                    "parallelism": (f"{world} row slabs; per PCG iteration ONE kernel + ONE exchange: alphaD, N, S1, S2 through device mailboxes "
                                    "(7 eight-byte peer-to-peer stores per rank, summed in rank order) + boundary rows of Ap stored into the "
                                    "neighbours' ghost rows over xGMI; RCCL once per GN step") if p2p else
-                                  f"{world} row slabs, RCCL all-reduce(alphaD) + all-gather(betaN, r/z ghost rows) per PCG iteration"},
+                                  f"{world} row slabs; per PCG iteration ONE kernel + ONE RCCL all-gather (alphaD, N, S1, S2, Ap boundary rows)"},
         "ms_per_gn_iter": dt / steps * 1e3, "us_per_pcg_iter": dt / (steps * l_iters) * 1e6,
         "initial_cost": c0, "final_cost": final, "graph_replay": captured,
         "exchange": "p2p-mailbox" if p2p else "rccl", "p2p_check": getattr(solver, "p2p_check", None),

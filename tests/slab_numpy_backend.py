@@ -12,7 +12,10 @@ F = np.float32
 
 
 class NumpySlabBackend:
-    def __init__(self, W, layout, local_params, max_l_iters):
+    def __init__(self, W, layout, local_params, max_l_iters, one_kernel=False):
+        # one_kernel: mirror the shipped multi-GPU schedule (thallo_hip_iw_pcg_iter + ONE all-gather per PCG iteration of
+        # [alphaD | N, S1, S2 | boundary rows of Ap]); else the two-kernel / two-collective form
+        self.one_kernel_collective = bool(one_kernel)
         self.W, self.lay = W, layout
         self.Hl, self.row0, self.row1 = layout.Hl, layout.row0, layout.row1
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a).copy())
@@ -28,6 +31,10 @@ class NumpySlabBackend:
         self.send = torch.zeros(self.msg, dtype=torch.float32)
         self.gath = torch.zeros(layout.world * self.msg, dtype=torch.float32)
         self.local_sum = F(0)
+        self.Ap_pp = [self.Ap, z()]                      # Ap ping-pongs in the one-kernel schedule
+        self.msg_iter = 7 + 6 * W
+        self.send_iter = torch.zeros(self.msg_iter, dtype=torch.float32)
+        self.gath_iter = torch.zeros(layout.world * self.msg_iter, dtype=torch.float32)
 
     # flat vector <-> planes (views into the torch storage)
     def _planes(self, v):
@@ -161,6 +168,88 @@ class NumpySlabBackend:
         if lay.bot:
             src = g[lay.rank + 1, 1:1 + 3 * W]
             zo[self.row1] = src[:2 * W].reshape(W, 2); za[self.row1] = src[2 * W:]
+
+    # -- once per GN step (one-kernel schedule): the ghost rows need their owner's M^-1 (it depends on rows this rank does not hold);
+    #    the HIP backend ships the flags byte instead and recomputes M^-1 from it
+    def pack_grid_info(self):
+        """[first owned row | last owned row] x [M^-1 (3W) | r_0 (3W)]"""
+        po_, pa_ = self._planes(self.pre); ro, ra = self._planes(self.r)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).reshape(-1).copy())
+        return torch.cat([t(x[y]) for y in (self.row0, self.row1 - 1) for x in (po_, pa_, ro, ra)])
+
+    def unpack_grid_info(self, g):
+        W, lay = self.W, self.lay
+        po_, pa_ = self._planes(self.pre); ro, ra = self._planes(self.r)
+        g = g.numpy().reshape(lay.world, 2, 6 * W)
+        for cond, ghost, src in ((lay.top, self.row0 - 1, (lay.rank - 1, 1)), (lay.bot, self.row1, (lay.rank + 1, 0))):
+            if cond:
+                m = g[src[0], src[1]]
+                po_[ghost] = m[:2 * W].reshape(W, 2); pa_[ghost] = m[2 * W:3 * W]
+                ro[ghost] = m[3 * W:5 * W].reshape(W, 2); ra[ghost] = m[5 * W:]
+
+    def iter_collective(self, cur, mode, iN, iD, iB, jD, jB, iN2, iD2, allgather):
+        """The one-kernel PCG iteration (csrc/energy_image_warping.hip k_iter) + its single exchange, in numpy:
+        r = r - alpha Ap (owned AND ghost rows: Ap's ghost rows came with the previous exchange), p = M^-1 r + beta p, delta update,
+        Ap' = J^T J p on the owned rows, message [alphaD | N, S1, S2 as (hi, lo) words | first, last owned row of Ap'],
+        betaN = N - 2 alpha S1 + alpha^2 S2 from the rank-ordered sums."""
+        first = bool(int(mode) & 1)
+        assert (int(mode) >> 1) == 0, "the numpy mirror updates delta every iteration"
+        alpha, beta = self._alpha_beta(first, iN, iD, iB)
+        R0, R1 = self.row0, self.row1
+        ro, ra = self._planes(self.r); mo, ma = self._planes(self.pre)
+        Ai_o, Ai_a = self._planes(self.Ap_pp[cur]); Ao, Aa = self._planes(self.Ap_pp[cur ^ 1])
+        po, pa = self._planes(self.p[cur]); qo, qa = self._planes(self.p[cur ^ 1]); do_, da_ = self._planes(self.delta)
+        if not first:
+            ro -= alpha * Ai_o; ra -= alpha * Ai_a
+            do_[R0:R1] += alpha * po[R0:R1]; da_[R0:R1] += alpha * pa[R0:R1]
+        qo[:] = mo * ro + beta * po; qa[:] = ma * ra + beta * pa
+        act, c, s, u = self._consts()
+        wr2, wf2 = self.w_reg * self.w_reg, self.w_fit * self.w_fit
+        ax = np.zeros((self.Hl, self.W), F); ay = ax.copy(); aa = ax.copy()
+        for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+            v = act & self._shift(act, dy, dx, False)
+            du = u - self._shift(u, dy, dx)
+            cj, sj = self._shift(c, dy, dx), self._shift(s, dy, dx)
+            gix = -s * du[..., 0] - c * du[..., 1]; giy = c * du[..., 0] - s * du[..., 1]
+            gjx = sj * du[..., 0] + cj * du[..., 1]; gjy = -cj * du[..., 0] + sj * du[..., 1]
+            dp = qo - self._shift(qo, dy, dx); paj = self._shift(qa, dy, dx)
+            ex = dp[..., 0] - gix * qa; ey = dp[..., 1] - giy * qa
+            ax += np.where(v, dp[..., 0] + ex + gjx * paj, 0); ay += np.where(v, dp[..., 1] + ey + gjy * paj, 0)
+            aa -= np.where(v, gix * ex + giy * ey, 0)
+        ax *= wr2; ay *= wr2; aa *= wr2
+        ax += np.where(self._fitvalid, wf2 * qo[..., 0], 0); ay += np.where(self._fitvalid, wf2 * qo[..., 1], 0)
+        Ao[R0:R1, :, 0] = np.where(act, ax, 0)[R0:R1]; Ao[R0:R1, :, 1] = np.where(act, ay, 0)[R0:R1]; Aa[R0:R1] = np.where(act, aa, 0)[R0:R1]
+        d = np.float64
+        own = lambda a: a[R0:R1].astype(d)
+        aD = F(np.sum((own(qo) * own(Ao)).sum(-1) + own(qa) * own(Aa)))
+        q3 = [np.sum((own(mo) * own(x) * own(y)).sum(-1) + own(ma) * own(xa) * own(ya))
+              for (x, xa, y, ya) in ((ro, ra, ro, ra), (ro, ra, Ao, Aa), (Ao, Aa, Ao, Aa))]
+        W, lay, msg = self.W, self.lay, self.msg_iter
+        m = self.send_iter.numpy()
+        m[0] = aD
+        m[1:7] = np.array(q3, dtype=np.float64).view(np.uint32).reshape(3, 2)[:, ::-1].reshape(-1).view(np.float32)      # (hi, lo) words
+        m[7:7 + 2 * W] = Ao[R0].reshape(-1); m[7 + 2 * W:7 + 3 * W] = Aa[R0]
+        m[7 + 3 * W:7 + 5 * W] = Ao[R1 - 1].reshape(-1); m[7 + 5 * W:] = Aa[R1 - 1]
+        if allgather is not None:
+            allgather(self.send_iter, self.gath_iter)
+            g = self.gath_iter.numpy().reshape(-1, msg)
+        else:
+            g = m.reshape(1, msg)
+        gad, gq = F(0), np.zeros(3, np.float64)
+        for r in range(g.shape[0]):
+            gad = F(gad + g[r, 0])
+            w = g[r, 1:7].view(np.uint32).astype(np.uint64).reshape(3, 2)
+            gq += ((w[:, 0] << np.uint64(32)) | w[:, 1]).view(np.float64)
+        aN = F(self.S[iB])
+        al = aN / gad if gad != 0 else F(0)
+        bn = gq[0] - 2.0 * float(al) * gq[1] + float(al) * float(al) * gq[2]
+        self.S[jD] = float(gad); self.S[jB] = float(F(max(bn, 0.0)))
+        if lay.top:
+            src = g[lay.rank - 1, 7 + 3 * W:]
+            Ao[R0 - 1] = src[:2 * W].reshape(W, 2); Aa[R0 - 1] = src[2 * W:]
+        if lay.bot:
+            src = g[lay.rank + 1, 7:7 + 3 * W]
+            Ao[R1] = src[:2 * W].reshape(W, 2); Aa[R1] = src[2 * W:]
 
     def linear_update(self, cur, iN, iD, with_p):
         R0, R1 = self.row0, self.row1

@@ -40,14 +40,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, nit, lit, q):
+def _worker(rank, world, port, W, H, nit, lit, q, one_kernel=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.image_warping(W, H, n_markers=8)
         lay = SlabLayout(H, rank, world, align=4)
         local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in p]
-        be = NumpySlabBackend(W, lay, local, lit)
+        be = NumpySlabBackend(W, lay, local, lit, one_kernel=one_kernel)
         solver = SlabSolver(be, lay)
         costs = solver.solve(nit, lit)
         own = slice(lay.row0, lay.row1)
@@ -56,13 +56,16 @@ def _worker(rank, world, port, W, H, nit, lit, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("one_kernel", [False, True])
 @pytest.mark.parametrize("world,W,H", [(2, 32, 24), (3, 20, 36), (2, 16, 8)])
-def test_slab_solver_matches_single_domain_oracle(orc, world, W, H):
+def test_slab_solver_matches_single_domain_oracle(orc, world, W, H, one_kernel):
+    """one_kernel: the shipped multi-GPU schedule -- ONE exchange per PCG iteration carrying alphaD, N, S1, S2 and the boundary rows of Ap,
+    betaN from the expansion; else the two-kernel / two-collective form.  Both reproduce the single-domain oracle."""
     nit, lit = 3, 15
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, nit, lit, q, one_kernel)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = _collect(q, procs, world)

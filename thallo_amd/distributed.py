@@ -480,16 +480,18 @@ class SlabSolver:
             dist.all_gather_into_tensor(gath, send, group=self.group)
             be.unpack_grid_info(gath.view(self.world, -1))
         self._gather_sum_and_rows(B)                   # S[B] = alphaN_0 (global); ghost rows of r and z
-        one_kernel = getattr(be, "one_kernel_collective", False) and batched
-        if one_kernel and hasattr(be, "irregular") and not getattr(self, "_grid_checked", False):
-            # the one-kernel schedule needs UrShape on the pixel grid on every rank (z-free); checked once per solver (one host sync)
-            self._grid_ok = int(be.irregular[0].item()) == 0
-            self._grid_checked = True
-        one_kernel = one_kernel and getattr(self, "_grid_ok", False)
+        one_kernel = getattr(be, "one_kernel_collective", False)
+        if one_kernel and hasattr(be, "irregular"):
+            if not getattr(self, "_grid_checked", False):
+                # the HIP one-kernel schedule needs UrShape on the pixel grid on every rank (z-free); checked once per solver (one host sync)
+                self._grid_ok = int(be.irregular[0].item()) == 0
+                self._grid_checked = True
+            one_kernel = self._grid_ok
         ag = (lambda send, recv: dist.all_gather_into_tensor(recv, send, group=self.group)) if self.use_dist else None
         for k in range(L if one_kernel else 0):        # one kernel + ONE all-gather per PCG iteration
             jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
-            be.iter_collective(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD, jB,
+            mode = (1 if k == 0 else 2 if k & 1 else 4) if batched else (1 if k == 0 else 0)
+            be.iter_collective(cur, mode, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD, jB,
                                jN - 4 if k > 1 else jN, jD - 4 if k > 1 else jD, ag)
             cur ^= 1
         for k in range(0 if one_kernel else L):

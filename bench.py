@@ -8,10 +8,12 @@ in HBM (reference workload: examples/image_warping/src/main.cpp:131-149, 8 GN x 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2048] [--liters 100]
 
 Prints ONE JSON line (rank 0).  `value` = whole-job PCG iterations per second.
-`roofline` = the dominant kernel (PCGStep1: fused PCGStep3 + delta update + applyJTJ) measured live
-with HIP events on the launch stream over the timed region (every 4th launch bracketed);
-`roofline.applyjtj_standalone` = the plain applyJTJ kernel (48 B/pixel) timed
-back-to-back after the timed region.  `cpu_baseline` = oracle/cpu_port_image_warping.c (OpenMP port
+`roofline` = the dominant kernel (PCGIteration: one launch = a whole PCG iteration) measured live with the
+library's HIP-event pair around the PCG loop of every GN step (the loop is L launches of that one kernel);
+`achieved` / `frac` use the bytes the fused schedule has to move (99 B/pixel, = the PMC traffic), the
+reference formulation's 180 B/pixel figure (SURVEY.md 8d) is kept under `reference_formulation`;
+`roofline.applyjtj_standalone` = the plain applyJTJ kernel (48 B/pixel) timed back-to-back
+after the timed region.  `--gpus N` (N > 1) without a launcher: this process starts the N ranks itself.  `cpu_baseline` = oracle/cpu_port_image_warping.c (OpenMP port
 of the same algorithm; the reference ships no runnable CPU path) on the host cores, rank 0, N=1 only.
 """
 import argparse
@@ -27,7 +29,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy ceiling)
 ALG_BYTES_APPLYJTJ = 48         # read p 12 + Angle 4 + UrShape 8 + Mask 4 + Constraints 8, write Ap_X 12
 ALG_BYTES_FUSED_STEP1 = 96      # applyJTJ 48 + PCGStep3 (read z 12, p counted once, write p 12) + delta update (r/w 24)
-ALG_BYTES_PCG_ITER = 180        # applyJTJ 48 + PCGStep2 96 + PCGStep3 36
+ALG_BYTES_PCG_ITER = 180        # applyJTJ 48 + PCGStep2 96 + PCGStep3 36 (the reference's three-kernel formulation)
+# What the one-kernel schedule has to move per pixel and PCG iteration, each array once: read r 12, Ap 12, p 12,
+# cs 8, flags 1; write r 12, Ap 12, p 12; the deferred delta update (read delta 12 + p_{k-2} 12, write delta 12) every other iteration = 18
+FUSED_BYTES_PCG_ITER = 99
+FUSED_BYTES_STEP1 = 75          # two-kernel A/B schedule: fused PCGStep3 + delta + applyJTJ
 
 
 def parse():
@@ -75,8 +81,45 @@ def standalone_applyjtj(torch, W, H, p_np, reps=50):
     return e0.elapsed_time(e1) / reps
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) before this process has made any GPU
+    call, pass rank 0's JSON line through and exit with the first failure's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:          # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if int(env_world or "1") != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -86,13 +129,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("THALLO_DIST_BACKEND", "nccl")
+    if os.environ.get("THALLO_BENCH_DRY") == "1":
+        # plumbing check without a GPU (tests/test_bench_spawn.py): the ranks rendezvous, agree on the world size and rank 0 prints a line
+        dist.init_process_group("gloo", rank=rank, world_size=world) if world > 1 else None
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+            assert dist.get_world_size() == args.gpus
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": int(t.item()), "steps": args.steps, "warmup": args.warmup}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback"
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        # (RCCL refuses two ranks on one device; never fall back to a silent 1-GPU run)
+        sys.exit(f"bench.py: --gpus {world} needs {world} GPUs on this node, found {ndev}")
+    torch.cuda.set_device(local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm.  THALLO_DIST_BACKEND=gloo exists only to exercise this leg on a 1-GPU box
-        # (RCCL refuses two ranks on one device); it is never the measured configuration.
-        dist.init_process_group(os.environ.get("THALLO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  THALLO_DIST_BACKEND=gloo exists only to exercise this leg on a 1-GPU box; it is never the
+        # measured configuration.
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
 
     W = H = args.size
     L_it = args.liters
@@ -142,19 +203,22 @@ def main():
 
     npx = W * H
     dom = "PCGIteration" if one_kernel else "PCGStep1"
-    dom_alg = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1
+    dom_bytes = FUSED_BYTES_PCG_ITER if one_kernel else FUSED_BYTES_STEP1          # what the kernel has to move (= its PMC traffic)
+    ref_bytes = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1        # the reference formulation of the same work
     step1_ms = perf["linearSolve"]["meanMS"] / L_it if one_kernel else ks[dom]["mean_ms"]
     n_samples = perf["linearSolve"]["count"] * L_it if one_kernel else ks[dom]["samples"]
-    fused_gbs = dom_alg * npx / (step1_ms * 1e-3) / 1e9
+    ach = dom_bytes * npx / (step1_ms * 1e-3) / 1e9
     sa_ms = standalone_applyjtj(torch, W, H, p)
     sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get(dom + "_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = None, None
+    for rel in (os.path.join("profiles", "traffic_latest.json"),):
+        tf = os.path.join(ROOT, rel)
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dom + "_bytes_per_launch")
+                traffic_source = rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/profile.sh; not measured in this run)"
+            except Exception:
+                traffic = None
 
     out = {
         "metric": "pcg_iters_per_sec", "value": K * L_it / dt, "unit": "PCG iterations/s",
@@ -164,24 +228,21 @@ def main():
         "config": {"workload": f"examples/image_warping {W}x{H} ARAP, GN + matrix-free PCG, {L_it} PCG iterations per GN step",
                    "width": W, "height": H, "unknowns": 3 * npx, "l_iterations": L_it, "parallelism": "1 GPU"},
         "ms_per_gn_iter": dt / K * 1e3, "us_per_pcg_iter": dt / (K * L_it) * 1e6,
-        "pcg_iter_algorithmic_GBps": ALG_BYTES_PCG_ITER * npx * K * L_it / dt / 1e9,
         "final_cost": final_cost,
         "roofline": {"bound": "hbm",
                      "kernel": ("PCGIteration (one launch = PCGStep2 of iteration k-1 + PCGStep3 + delta update + applyJTJ of iteration k)"
                                 if one_kernel else "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)"),
-                     "achieved": fused_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fused_gbs / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_pixel": dom_alg,
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "bytes_per_pixel": dom_bytes, "pixels_per_launch": npx,
                      "avg_launch_ms": step1_ms, "samples": n_samples,
                      "timing": ("HIP events around the PCG loop of every GN step (L launches of this one kernel) / L" if one_kernel
                                 else "HIP events around every 16th launch of the kernel"),
-                     # what the kernel really moves (the schedule removes bytes the reference formulation has): 99 B/pixel for the
-                     # one-kernel iteration (r, Ap, p read + written, cs, flags, 18 of deferred delta), 75 for the fused PCGStep1
-                     "note": ("achieved / frac use SURVEY.md 8d's algorithmic bytes of the reference formulation (180 B/pixel per PCG iteration); the one-kernel "
-                              "schedule moves 99 B/pixel, so frac can exceed 1 -- achieved_actual / frac_actual are the bytes really moved (= the PMC traffic)")
-                             if one_kernel else None,
-                     "actual_bytes_per_pixel": 99 if one_kernel else 75,
-                     "achieved_actual": (99 if one_kernel else 75) * npx / (step1_ms * 1e-3) / 1e9,
-                     "frac_actual": (99 if one_kernel else 75) * npx / (step1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "achieved = bytes_per_pixel x pixels / avg launch time: the bytes this fused kernel has to move, each array once "
+                             "(DESIGN.md section 4; equals the PMC traffic to ~1 %)",
+                     # the same launch priced with SURVEY.md 8d's bytes of the reference's three-kernel formulation -- a speed-up figure, not a
+                     # roofline fraction (it exceeds the HBM peak because the schedule removes 45 % of those bytes)
+                     "reference_formulation": {"bytes_per_pixel": ref_bytes, "equivalent_GBps": ref_bytes * npx / (step1_ms * 1e-3) / 1e9},
                      "applyjtj_standalone": {"algorithmic_bytes_per_pixel": ALG_BYTES_APPLYJTJ, "avg_launch_ms": sa_ms,
                                              "achieved": sa_gbs, "frac": sa_gbs / HBM_PEAK_GBS}},
     }
@@ -195,6 +256,7 @@ def main():
         res = orc.cpu_port_image_warping(W, H, q, 1, sample_l, want_costs=False)
         out["cpu_baseline"] = {"value": sample_l / res["seconds_pcg"], "unit": "PCG iterations/s", "cores": res["threads"],
                                "kind": "port", "ms_per_gn_iter": res["seconds_total"] * 1e3,
+                               "note": "baseline only (an OpenMP restatement, not a tuned CPU solver); the GPU / CPU ratio says nothing about kernel quality",
                                "sample": f"1 GN step x {sample_l} PCG iterations of the same {W}x{H} instance, OpenMP port of the "
                                          "reference algorithm (oracle/cpu_port_image_warping.c)"}
     print(json.dumps(out))

@@ -254,6 +254,28 @@ int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* c
                                 unsigned* fin_tickets, int slot0, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* fin_tickets / alphaD_word / betaN_word (all or none): the launch's last workgroup then IS the exchange (thallo_hip_dist_exchange_iter's job,
    mailbox slots slot0 .. slot0+6, betaN_prev must be a one-word sum): one launch per PCG iteration on every rank. */
+/* The same iteration as a barrier-free marching stencil (energy_image_warping_march.hip): a wave owns a 128-pixel column strip, keeps a
+ * three-row window in registers, x neighbours through DPP lane shifts, rows prefetched ahead; unit-pixel-grid UrShape ONLY (W even).
+ * The caller establishes that property once per Init (thallo_hip_iw_urshape_irregular: *count_out == 0); if the word pcg_init wrote
+ * (`irregular`, may be NULL = trust the caller) is nonzero the kernel writes NaN scalars instead of computing.  Same buffers, modes,
+ * partial / ticket / scalar-word conventions as thallo_hip_iw_pcg_iter (no urshape / pre arguments: never read). */
+int thallo_hip_iw_pcg_iter_march(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags,
+                                 float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                 const float* p_in, float* p_out, float* delta, int mode,
+                                 thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                                 thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
+                                 const int* irregular, float* alphaD_out, double* s12_out,
+                                 unsigned* fin_tickets, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+int thallo_hip_iw_pcg_iter_march_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags,
+                                      float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                      const float* p_in, float* p_out, float* delta, int mode,
+                                      thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev,
+                                      thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
+                                      const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out,
+                                      unsigned* fin_tickets, int slot0, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* *count_out (device int) = number of pixels whose right / down UrShape neighbour is not at the exact unit offset (0 = pixel grid) */
+int thallo_hip_iw_urshape_irregular(int W, int H, const float* urshape, int* count_out, thallo_stream_t stream);
+void thallo_hip_march_debug_set(int what, int value);     /* tools/ only: 0 rows per wave segment, 1 prefetch depth, 2 non-temporal mask */
 int thallo_hip_iw_pcg_iter_finish(const float* alphaD_partials, const double* s12_partials, int count, thallo_sum_t alphaN,
                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 

@@ -1,0 +1,111 @@
+// iw_device.hpp -- device pieces shared by the image_warping kernels (energy_image_warping.hip: LDS-tiled kernels;
+// energy_image_warping_march.hip: the wave-marching one-kernel PCG iteration).
+#pragma once
+#include "device_common.hpp"
+#include "dist_device.hpp"
+#include "../../include/thallo_hip.h"
+
+namespace thallo {
+
+// W x H = local image (rows include ghost rows); tiles cover the owned rows [row0,row1) only.
+struct Geo { int W, H, row0, row1, tx, ty, ntiles; };
+
+// flags byte: bit0 pixel active (Mask==0), bit1 fit residual valid, bits2-4 = number of valid neighbour pairs (0..4).
+// With UrShape on the unit pixel grid (GRID path) diag(J^T J) is a function of this byte alone:
+//   offset channels: w_reg^2 * 2*cnt + w_fit^2 [fit]      angle channel: w_reg^2 * cnt   (|R'(a) du|^2 = |du|^2 = 1)
+// so the GRID path never reads `pre` and never materialises z = M^-1 r: both are recomputed from r and the flags byte.
+__device__ __forceinline__ void pre_from_flags(unsigned char f, float wf2, float wr2, float& mo, float& ma)
+{
+    if (!(f & 1)) { mo = 0.0f; ma = 0.0f; return; }
+    const float cnt = (float)((f >> 2) & 7);
+    float dgo = (2.0f * cnt) * wr2;
+    if (f & 2) dgo += wf2;
+    mo = guarded_invert(dgo); ma = guarded_invert(cnt * wr2);
+}
+
+__device__ __forceinline__ double wave_sum_all_d(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
+    return v;
+}
+
+// End of a one-kernel PCG iteration, called by every thread of the workgroup with its private sums: float alphaD partial + the three
+// double sums, one set per workgroup; with fin_tickets the launch's last workgroup also finishes alphaD_k / betaN_k (single GPU) or
+// IS the cross-rank exchange (DIST).  red >= 16 floats, redd >= 48 doubles of LDS.
+template <int NT, bool DIST>
+__device__ __forceinline__ void iter_tail(float acc, double s0, double s1, double s2, float* red, double* redd,
+                                          float* __restrict__ aD_out, double* __restrict__ s12_out, thallo_sum_t bNp, const thallo_dist_t* dd,
+                                          unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot)
+{
+    // multi-GPU: EVERY wave of a boundary workgroup has issued peer-to-peer Ap stores; each drains its own before the workgroup
+    // barrier below, so that the arrival ticket behind that barrier (and the granules the last arrival sends) cannot overtake them
+    if (DIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // float alphaD partial + the two double sums, one set per workgroup
+    const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
+    const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
+    if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+        for (int w = 0; w < NT / THALLO_WAVE; ++w) { a += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
+        if (!fin_tickets) { aD_out[blockIdx.x] = a; s12_out[3 * blockIdx.x] = b0; s12_out[3 * blockIdx.x + 1] = b1; s12_out[3 * blockIdx.x + 2] = b2; }
+        else {
+            // in-kernel finish (saves the one-wave k_iter_finish launch: worth 4-5 us per iteration on small images): write-through
+            // partials, two-level arrival tickets (workgroup b -> group b % 32, each group word on its own 64-byte line; same-address
+            // atomics serialise at ~12 ns each), the last arrival adds everything up in k_iter_finish's order
+            typedef unsigned long long u64_t;
+            __hip_atomic_store(aD_out + blockIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64_t* sp = reinterpret_cast<u64_t*>(s12_out) + 3 * blockIdx.x;
+            __hip_atomic_store(sp, (u64_t)__double_as_longlong(b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sp + 1, (u64_t)__double_as_longlong(b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sp + 2, (u64_t)__double_as_longlong(b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned grp = blockIdx.x % 32, members = (gridDim.x - grp + 31) / 32, groups = gridDim.x < 32 ? gridDim.x : 32;
+            unsigned* sub = fin_tickets + 16 + 16 * grp;
+            bool last = false;
+            if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = __hip_atomic_fetch_add(fin_tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+            }
+            red[15] = last ? 1.0f : 0.0f;
+        }
+    }
+    if (fin_tickets) {
+        __syncthreads();
+        if (red[15] != 0.0f && wave == 0) {
+            typedef unsigned long long u64_t;
+            const int nb = gridDim.x;
+            float t[THALLO_MAX_PARTIALS / THALLO_WAVE];
+#pragma unroll
+            for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
+                const int i = lane + k * THALLO_WAVE;
+                t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            }
+            float ad = 0.0f;
+#pragma unroll
+            for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) ad += t[k];
+            ad = wave_sum_all(ad);                                                   // == sum_partials(aD_out, nb)
+            const u64_t* sp = reinterpret_cast<const u64_t*>(s12_out);
+            double n = 0.0, a1 = 0.0, b1 = 0.0;
+            for (int i = lane; i < nb; i += THALLO_WAVE) {
+                n  += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                a1 += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b1 += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
+            const float an = sum_partials(bNp.partials, bNp.count);                  // alphaN_k (= betaN_{k-1}; alphaN_0 for the first iteration)
+            if (lane == 0) __hip_atomic_store(fin_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (DIST) {     // multi-GPU: the same wave is the exchange (every wave drained its remote Ap rows -- s_waitcnt vmcnt(0) -- before the barrier in front of its workgroup's ticket)
+                dist_exchange_iter_wave(*dd, xslot, ad, n, a1, b1, an, aD_word, bN_word);
+            } else {
+                const float al = safe_div<false>(an, ad);
+                double bn = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
+                if (!(bn > 0.0)) bn = 0.0;
+                if (lane == 0) { aD_word[0] = ad; bN_word[0] = (float)bn; }
+            }
+        }
+    }
+}
+
+}  // namespace thallo

@@ -169,8 +169,9 @@ int Plan::ensure_slots(int L)
     const int need = 2 * L + 6;
     if (need <= parts_slots_) return 0;
     hipDeviceSynchronize();
-    if (need > THALLO_HIP_MAX_PARTIALS) return -1;                 // the scalar words of all slots share one extra slot
-    if (parts_.alloc((size_t)(need + 1) * THALLO_HIP_MAX_PARTIALS * sizeof(float))) return -1;
+    // `need` partial slots followed by `need` scalar words (scal(j)); 4 KB per slot, so lIterations = 4000
+    // (examples/embedded_mesh_deformation) costs 32 MB
+    if (parts_.alloc(((size_t)need * THALLO_HIP_MAX_PARTIALS + (size_t)need + 64) * sizeof(float))) { set_error("out of device memory for %d reduction slots (lIterations too large?)", need); return -1; }
     parts_slots_ = need; nb_.assign(need, 1); fin_.assign(need, 0);
     { const char* e = getenv("THALLO_FINISH_SUMS"); finish_sums_ = !(e && e[0] == '0'); }
     { const char* e = getenv("THALLO_ONE_KERNEL"); one_kernel_ = !(e && e[0] == '0'); }
@@ -254,7 +255,8 @@ int Plan::step(void** params)
     if (!ok_ || !ready_) return 0;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return 0; }
     if (sp.nIter >= sp.nIterations) { if (!finalized_) finalize(); return 0; }
-    if (ensure_slots(sp.lIterations)) return 0;
+    if (sp.lIterations < 0) { set_error("lIterations = %d is negative", sp.lIterations); if (!finalized_) finalize(); return 0; }
+    if (ensure_slots(sp.lIterations)) { if (!finalized_) finalize(); return 0; }
     const int ev_iter = timer_.start("Nonlinear Iteration", ctx.stream);
     const int rc = lm_ ? step_lm(ev_iter) : step_gn(ev_iter);
     if (rc == 1 && sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779

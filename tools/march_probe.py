@@ -1,0 +1,161 @@
+"""GPU probe (run through gpurun): the marching one-kernel PCG iteration (thallo_hip_iw_pcg_iter_march) against the LDS-tiled
+k_iter on the same inputs -- bitwise comparison of every output plane, then a timing sweep over rows-per-segment / prefetch depth /
+non-temporal mask.  Needs the sweep build for the knobs to take effect:  make -C thallo_amd/csrc SWEEP=1 -B
+Not part of the product or the tests."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import thallo_amd
+from thallo_amd import api, synthetic as syn
+
+W = int(os.environ.get("MB_W", "2048")); H = int(os.environ.get("MB_H", str(W)))
+REPS = int(os.environ.get("MB_REPS", "20"))
+L = thallo_amd.lib()
+L.thallo_hip_vector_elems.restype = C.c_long; L.thallo_hip_vector_elems.argtypes = [C.c_long]
+p = syn.image_warping(W, H)
+N = W * H; n = 3 * N; na = L.thallo_hip_vector_elems(n)
+dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else x for x in p]
+f = lambda: torch.zeros(na, dtype=torch.float32, device="cuda")
+r0, pre, z, p0, delta0, A0 = [f() for _ in range(6)]
+cs = torch.zeros(2 * N, dtype=torch.float32, device="cuda"); flags = torch.zeros(N + 256, dtype=torch.uint8, device="cuda")
+parts = torch.zeros(8 * 1024, dtype=torch.float32, device="cuda")
+s12 = torch.zeros(3 * 1024, dtype=torch.float64, device="cuda")
+irregular = torch.zeros(16, dtype=torch.int32, device="cuda")
+tickets = torch.zeros(528, dtype=torch.int32, device="cuda")
+words = torch.zeros(16, dtype=torch.float32, device="cuda")
+scal = torch.tensor([1.0, 2.0, 0.3, 1.5, 2.5], dtype=torch.float32, device="cuda")     # aN, aD, bN, aN2, aD2 -> alpha .5, beta .3, alpha2 .6
+vp, fl = C.c_void_p, C.c_float
+S = lambda i: api.SumT(scal.data_ptr() + 4 * i, 1)
+nb0 = L.thallo_hip_iw_pcg_init(W, H, 0, H, vp(dev[0].data_ptr()), vp(dev[1].data_ptr()), vp(dev[2].data_ptr()), vp(dev[3].data_ptr()),
+                               vp(dev[4].data_ptr()), fl(p[5]), fl(p[6]), vp(r0.data_ptr()), vp(pre.data_ptr()), vp(z.data_ptr()),
+                               vp(p0.data_ptr()), vp(delta0.data_ptr()), vp(cs.data_ptr()), vp(flags.data_ptr()), None, vp(irregular.data_ptr()), vp(parts.data_ptr()), None)
+assert nb0 > 0
+torch.cuda.synchronize()
+assert int(irregular[0].item()) == 0
+
+
+def run(kind, mode, r_in, A_in, p_in, dl, fin=True):
+    r_out, A_out, p_out = f(), f(), f()
+    d = dl.clone()
+    if ((mode >> 1) & 3) == 2:           # p_out holds p_{k-2} before it is overwritten
+        p_out.copy_(pk2)
+    args_tail = (S(0), S(1), S(2), S(3), S(4), vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), vp(s12.data_ptr()),
+                 vp(tickets.data_ptr()) if fin else None, vp(words.data_ptr()) if fin else None, vp(words.data_ptr() + 4) if fin else None, None)
+    if kind == "tile":
+        nb = L.thallo_hip_iw_pcg_iter(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), vp(pre.data_ptr()), fl(p[5]), fl(p[6]),
+                                      vp(r_in.data_ptr()), vp(r_out.data_ptr()), vp(A_in.data_ptr()), vp(A_out.data_ptr()), vp(p_in.data_ptr()), vp(p_out.data_ptr()),
+                                      vp(d.data_ptr()), mode, *args_tail)
+    else:
+        nb = L.thallo_hip_iw_pcg_iter_march(W, H, 0, H, vp(cs.data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]),
+                                            vp(r_in.data_ptr()), vp(r_out.data_ptr()), vp(A_in.data_ptr()), vp(A_out.data_ptr()), vp(p_in.data_ptr()), vp(p_out.data_ptr()),
+                                            vp(d.data_ptr()), mode, *args_tail)
+    assert nb > 0, nb
+    torch.cuda.synchronize()
+    aD = float(parts[1024:1024 + nb].double().sum().item())
+    ss = s12[:3 * nb].view(nb, 3).sum(0).tolist()
+    return dict(r=r_out, A=A_out, p=p_out, d=d, aD=aD, s=ss, nb=nb, words=words[:8].tolist())
+
+
+res = {"W": W, "H": H}
+# iteration 0 with the tile kernel gives realistic r1 / Ap1 / p1
+it0 = run("tile", 1, r0, A0, p0, delta0)
+pk2 = it0["p"].clone()
+it1 = run("tile", 2, it0["r"], it0["A"], it0["p"], delta0)       # mode 2: deferred (none)
+cmp = {}
+for mode, (ri, Ai, pi, di) in {1: (r0, A0, p0, delta0), 2: (it0["r"], it0["A"], it0["p"], delta0), 4: (it1["r"], it1["A"], it1["p"], delta0),
+                               0: (it0["r"], it0["A"], it0["p"], delta0)}.items():
+    a = run("tile", mode, ri, Ai, pi, di)
+    b = run("march", mode, ri, Ai, pi, di)
+    e = {}
+    for k in ("r", "A", "p", "d"):
+        x, y = a[k][:n], b[k][:n]
+        e[k + "_mismatch"] = int((x.view(torch.int32) != y.view(torch.int32)).sum().item())
+        e[k + "_maxabs"] = float((x - y).abs().max().item())
+        e[k + "_ref_maxabs"] = float(x.abs().max().item())
+    e["aD_rel"] = abs(a["aD"] - b["aD"]) / max(abs(a["aD"]), 1e-30)
+    e["s_rel"] = [abs(u - v) / max(abs(u), 1e-30) for u, v in zip(a["s"], b["s"])]
+    e["nb"] = [a["nb"], b["nb"]]
+    e["words"] = [a["words"][:2] + a["words"][4:6], b["words"][:2] + b["words"][4:6]]
+    cmp[f"mode{mode}"] = e
+res["compare"] = cmp
+print(json.dumps(res, indent=1)); sys.stdout.flush()
+
+
+def timeit(kind, reps=REPS, modes=(4, 2), pingpong=True):
+    """alternate modes 4 / 2 like the PCG loop does, ping-ponging the buffers (pingpong=False: always a -> b, so no launch reads what the previous one wrote)"""
+    bufs = [[it0["r"].clone(), it0["A"].clone(), it0["p"].clone()], [f(), f(), f()]]
+    d = delta0.clone()
+    fn = L.thallo_hip_iw_pcg_iter if kind == "tile" else L.thallo_hip_iw_pcg_iter_march
+
+    def one(k):
+        a, b = (bufs[k & 1], bufs[(k & 1) ^ 1]) if pingpong else (bufs[0], bufs[1])
+        mode = modes[k % len(modes)]
+        tail = (vp(a[0].data_ptr()), vp(b[0].data_ptr()), vp(a[1].data_ptr()), vp(b[1].data_ptr()), vp(a[2].data_ptr()), vp(b[2].data_ptr()), vp(d.data_ptr()), mode,
+                S(0), S(1), S(2), S(3), S(4), vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), vp(s12.data_ptr()),
+                vp(tickets.data_ptr()), vp(words.data_ptr()), vp(words.data_ptr() + 4), None)
+        if kind == "tile":
+            rc = fn(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), vp(pre.data_ptr()), fl(p[5]), fl(p[6]), *tail)
+        else:
+            rc = fn(W, H, 0, H, vp(cs.data_ptr()), vp(flags.data_ptr()), fl(p[5]), fl(p[6]), *tail)
+        assert rc > 0, rc
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(2 * reps):
+        one(k)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (2 * reps) * 1e3
+
+
+def time_stream(with_delta, ntm, per_cu, reps=REPS, pingpong=True, span=1):
+    a, b = [it0["r"].clone(), it0["A"].clone(), it0["p"].clone()], [f(), f(), f()]
+    d = delta0.clone()
+
+    def one(k):
+        x, y = ((a, b) if k & 1 else (b, a)) if pingpong else (a, b)
+        rc = L.thallo_hip_iw_stream_ref(W, H, vp(cs.data_ptr()), vp(flags.data_ptr()), vp(x[0].data_ptr()), vp(y[0].data_ptr()), vp(x[1].data_ptr()), vp(y[1].data_ptr()),
+                                        vp(x[2].data_ptr()), vp(y[2].data_ptr()), vp(d.data_ptr()), with_delta, ntm, per_cu, span, None)
+        assert rc == 0, rc
+    for k in range(4):
+        one(k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(2 * reps):
+        one(k)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (2 * reps) * 1e3
+
+
+def cfg(depth, nt, occ, dbg, rows=0, mp=0):
+    for what, v in ((0, rows), (1, depth), (2, nt), (3, occ), (4, dbg), (5, mp)):
+        L.thallo_hip_march_debug_set(what, v)
+
+
+if __name__ == "pmc":
+    cfg(2, 5, 2, 0); timeit("march", modes=(2,)); timeit("march", modes=(4,))
+    cfg(2, 5, 2, 3); timeit("march", modes=(2,))
+    time_stream(0, 11, 2, span=0); time_stream(0, 0, 2, span=0); time_stream(1, 11, 2, span=0)
+    timeit("tile", modes=(2,))
+    sys.exit(0)
+
+tm = {}
+for rep in range(2):
+    tm[f"tile_us_{rep}"] = round(timeit("tile"), 2)
+    for rows in (0, 27, 36, 48):
+        for nt in (5, 1, 0, 11, 9, 3, 33, 43, 17, 21):
+            cfg(2, nt, 2, 0, rows)
+            a, m2, m4 = timeit("march"), timeit("march", modes=(2,)), timeit("march", modes=(4,))
+            tm[f"march_nt{nt}_rows{rows}_us_{rep}"] = [round(a, 2), round(m2, 2), round(m4, 2)]
+        print(json.dumps(tm)); sys.stdout.flush()
+res["timing"] = tm
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"march_probe4_{W}x{H}.json"), "w"), indent=1)

@@ -135,9 +135,20 @@ static double iw_apply(const IW* q, const float* p, float* Ap)
 /* Runs nIterations GN steps of lIterations PCG iterations each, in place.  costs[0..nIterations].
  * seconds_pcg (optional) receives the wall time spent inside the PCG loops only.
  * Returns the number of threads used. */
+int orc_cpu_port_image_warping2(int W, int H, float* O, float* A, const float* U, const float* C, const float* M,
+                                float w_fit, float w_reg, int nIterations, int lIterations,
+                                double* costs, double* seconds_pcg, double* seconds_total, float* ab_trace, int trace_cap);
 int orc_cpu_port_image_warping(int W, int H, float* O, float* A, const float* U, const float* C, const float* M,
                                float w_fit, float w_reg, int nIterations, int lIterations,
                                double* costs, double* seconds_pcg, double* seconds_total)
+{
+    return orc_cpu_port_image_warping2(W, H, O, A, U, C, M, w_fit, w_reg, nIterations, lIterations, costs, seconds_pcg, seconds_total, 0, 0);
+}
+
+/* ... and (ab_trace != NULL) alpha_k, beta_k of the first trace_cap PCG iterations overall: ab_trace[2j], ab_trace[2j+1] */
+int orc_cpu_port_image_warping2(int W, int H, float* O, float* A, const float* U, const float* C, const float* M,
+                                float w_fit, float w_reg, int nIterations, int lIterations,
+                                double* costs, double* seconds_pcg, double* seconds_total, float* ab_trace, int trace_cap)
 {
     IW q; q.W = W; q.H = H; q.N = (long)W * H; q.U = U; q.C = C; q.M = M; q.wf = w_fit; q.wr = w_reg;
     const long N = q.N, n = 3 * N;
@@ -160,6 +171,7 @@ int orc_cpu_port_image_warping(int W, int H, float* O, float* A, const float* U,
                 bN += (double)(zz * rr);
             }
             const float beta = aN != 0.0f ? (float)bN / aN : 0.0f;
+            { const long j = (long)it * lIterations + k; if (ab_trace && j < trace_cap) { ab_trace[2 * j] = alpha; ab_trace[2 * j + 1] = beta; } }
 #pragma omp parallel for schedule(static)
             for (long i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
             aN = (float)bN;

@@ -149,16 +149,33 @@ class Problem:
         return costs[: n + 1], (trace[:tcap] if want_trace else None)
 
 
-def cpu_port_image_warping(W, H, params, nIterations, lIterations, want_costs=True):
-    """OpenMP port (oracle/cpu_port_image_warping.c) -- bench.py's cpu_baseline. Updates params[0], params[1]
-    in place. Returns dict(costs, seconds_pcg, seconds_total, threads)."""
+def set_threads(n):
+    """n > 1: the oracle's row loops run on n OpenMP threads (full-size configurations on the GPU box's host cores); 1 = the serial,
+    bit-exact known-answer path.  Returns the previous setting."""
     L = lib()
-    L.orc_cpu_port_image_warping.restype = C.c_int
-    L.orc_cpu_port_image_warping.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_int, C.c_int,
-                                                                                    C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_get_threads.restype = C.c_int
+    prev = L.orc_get_threads()
+    L.orc_set_threads(int(n))
+    return prev
+
+
+def cpu_port_image_warping(W, H, params, nIterations, lIterations, want_costs=True, want_trace=False):
+    """OpenMP port (oracle/cpu_port_image_warping.c) -- bench.py's cpu_baseline and the full-size checker. Updates params[0],
+    params[1] in place. Returns dict(costs, seconds_pcg, seconds_total, threads[, trace = (alpha_k, beta_k) rows])."""
+    L = lib()
+    L.orc_cpu_port_image_warping2.restype = C.c_int
+    L.orc_cpu_port_image_warping2.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_int, C.c_int,
+                                                                                     C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                                                     C.c_void_p, C.c_int]
     costs = np.zeros(nIterations + 1, np.float64)
+    ntr = nIterations * lIterations if want_trace else 0
+    trace = np.zeros((max(ntr, 1), 2), np.float32)
     tp, tt = C.c_double(), C.c_double()
-    th = L.orc_cpu_port_image_warping(W, H, params[0].ctypes.data, params[1].ctypes.data, params[2].ctypes.data,
-                                      params[3].ctypes.data, params[4].ctypes.data, float(params[5]), float(params[6]),
-                                      nIterations, lIterations, costs.ctypes.data if want_costs else None, C.byref(tp), C.byref(tt))
-    return {"costs": costs if want_costs else None, "seconds_pcg": tp.value, "seconds_total": tt.value, "threads": th}
+    th = L.orc_cpu_port_image_warping2(W, H, params[0].ctypes.data, params[1].ctypes.data, params[2].ctypes.data,
+                                       params[3].ctypes.data, params[4].ctypes.data, float(params[5]), float(params[6]),
+                                       nIterations, lIterations, costs.ctypes.data if want_costs else None, C.byref(tp), C.byref(tt),
+                                       trace.ctypes.data if want_trace else None, ntr)
+    out = {"costs": costs if want_costs else None, "seconds_pcg": tp.value, "seconds_total": tt.value, "threads": th}
+    if want_trace:
+        out["trace"] = trace[:ntr]
+    return out

@@ -434,8 +434,31 @@ int orc_energy_init(OrcEnergy* e, int kind, const unsigned* dims, void** params,
 
 /* ------------------------------------------------------------------ generic fmap */
 
+/* Threaded mode (orc_set_threads(n > 1), double-accumulator sums only): the five row loops below run under OpenMP -- same rows,
+ * same arithmetic per row, scatter-adds as float atomics (order-free like the reference's own atomics, util.t:40-50) and per-thread
+ * double sums.  It exists so that the full-size configurations (2048^2, ladybug-1723) can be checked on the GPU box's host cores in
+ * seconds; tests/test_oracle_golden.py pins it against the serial loops (which stay the bit-exact known-answer path). */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
+
 double orc_cost(const OrcEnergy* e, int fl)
 {   /* thallo.t:3939-3949: per element 0.5*sum r_k^2 ; gauss_newton.t:1067-1079 reduces over elements */
+    if (g_threads > 1 && !fl) {
+        double total = 0.0;
+#pragma omp parallel num_threads(g_threads) reduction(+:total)
+        {
+            OrcRow rows[ORC_MAX_ROWS];
+#pragma omp for schedule(static)
+            for (long el = 0; el < e->n_elems; ++el) {
+                int n = e->rows(e, el, rows);
+                float s = 0.0f;
+                for (int k = 0; k < n; ++k) s = s + rows[k].r * rows[k].r;
+                total += (double)(0.5f * s);
+            }
+        }
+        return total;
+    }
     OrcRow rows[ORC_MAX_ROWS]; Acc a; acc_init(&a, fl);
     for (long el = 0; el < e->n_elems; ++el) {
         int n = e->rows(e, el, rows);
@@ -448,6 +471,26 @@ double orc_cost(const OrcEnergy* e, int fl)
 
 void orc_eval_jtf(const OrcEnergy* e, float* r, float* pre)
 {   /* thallo.t:3898-3902: R[u] += -1*partial*F ; Pre[u] += partial*partial */
+    if (g_threads > 1) {
+#pragma omp parallel num_threads(g_threads)
+        {
+            OrcRow rows[ORC_MAX_ROWS];
+#pragma omp for schedule(static)
+            for (long el = 0; el < e->n_elems; ++el) {
+                int n = e->rows(e, el, rows);
+                for (int k = 0; k < n; ++k)
+                    for (int j = 0; j < rows[k].nnz; ++j) {
+                        const float v = rows[k].val[j];
+                        const float dr = -1.0f * v * rows[k].r, dp = v * v;
+#pragma omp atomic
+                        r[rows[k].col[j]] += dr;
+#pragma omp atomic
+                        pre[rows[k].col[j]] += dp;
+                    }
+            }
+        }
+        return;
+    }
     OrcRow rows[ORC_MAX_ROWS];
     for (long el = 0; el < e->n_elems; ++el) {
         int n = e->rows(e, el, rows);
@@ -462,6 +505,30 @@ void orc_eval_jtf(const OrcEnergy* e, float* r, float* pre)
 
 double orc_apply_jtj(const OrcEnergy* e, const float* p, float* Ap, int fl)
 {   /* thallo.t:3551-3566: Jp = sum partial*P[u]; Ap_X[u] += Jp*partial; result += P[u]*Jp*partial */
+    if (g_threads > 1 && !fl) {
+        double total = 0.0;
+#pragma omp parallel num_threads(g_threads) reduction(+:total)
+        {
+            OrcRow rows[ORC_MAX_ROWS];
+#pragma omp for schedule(static)
+            for (long el = 0; el < e->n_elems; ++el) {
+                int n = e->rows(e, el, rows);
+                float d = 0.0f;
+                for (int k = 0; k < n; ++k) {
+                    float Jp = 0.0f;
+                    for (int j = 0; j < rows[k].nnz; ++j) Jp = Jp + rows[k].val[j] * p[rows[k].col[j]];
+                    for (int j = 0; j < rows[k].nnz; ++j) {
+                        const float jtjp = Jp * rows[k].val[j];
+#pragma omp atomic
+                        Ap[rows[k].col[j]] += jtjp;
+                        d = d + p[rows[k].col[j]] * jtjp;
+                    }
+                }
+                total += (double)d;
+            }
+        }
+        return total;
+    }
     OrcRow rows[ORC_MAX_ROWS]; Acc a; acc_init(&a, fl);
     for (long el = 0; el < e->n_elems; ++el) {
         int n = e->rows(e, el, rows);
@@ -482,6 +549,23 @@ double orc_apply_jtj(const OrcEnergy* e, const float* p, float* Ap, int fl)
 
 void orc_compute_ctc(const OrcEnergy* e, float inv_radius, float* ctc)
 {   /* thallo.t:3929-3933 */
+    if (g_threads > 1) {
+#pragma omp parallel num_threads(g_threads)
+        {
+            OrcRow rows[ORC_MAX_ROWS];
+#pragma omp for schedule(static)
+            for (long el = 0; el < e->n_elems; ++el) {
+                int n = e->rows(e, el, rows);
+                for (int k = 0; k < n; ++k)
+                    for (int j = 0; j < rows[k].nnz; ++j) {
+                        const float c = rows[k].val[j] * rows[k].val[j] * inv_radius;
+#pragma omp atomic
+                        ctc[rows[k].col[j]] += c;
+                    }
+            }
+        }
+        return;
+    }
     OrcRow rows[ORC_MAX_ROWS];
     for (long el = 0; el < e->n_elems; ++el) {
         int n = e->rows(e, el, rows);
@@ -493,6 +577,26 @@ void orc_compute_ctc(const OrcEnergy* e, float inv_radius, float* ctc)
 
 double orc_model_cost(const OrcEnergy* e, const float* delta, int fl)
 {   /* thallo.t:3848-3863: 0.5 * sum (F + J delta)^2 */
+    if (g_threads > 1 && !fl) {
+        double total = 0.0;
+#pragma omp parallel num_threads(g_threads) reduction(+:total)
+        {
+            OrcRow rows[ORC_MAX_ROWS];
+#pragma omp for schedule(static)
+            for (long el = 0; el < e->n_elems; ++el) {
+                int n = e->rows(e, el, rows);
+                float s = 0.0f;
+                for (int k = 0; k < n; ++k) {
+                    float jd = 0.0f;
+                    for (int j = 0; j < rows[k].nnz; ++j) jd = jd + rows[k].val[j] * delta[rows[k].col[j]];
+                    const float m = rows[k].r + jd;
+                    s = s + m * m;
+                }
+                total += (double)(0.5f * s);
+            }
+        }
+        return total;
+    }
     OrcRow rows[ORC_MAX_ROWS]; Acc a; acc_init(&a, fl);
     for (long el = 0; el < e->n_elems; ++el) {
         int n = e->rows(e, el, rows);

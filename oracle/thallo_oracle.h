@@ -88,6 +88,9 @@ typedef struct {
 } OrcSolverParams;
 
 void orc_default_params(OrcSolverParams* sp);
+/* n > 1: the row loops (cost, evalJTF, applyJTJ, computeCtC, model cost) run on n OpenMP threads (double-accumulator mode only) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 
 /* MSVC rand(): s = s*214013+2531011; (s>>16)&0x7fff.  tests/minimal/main.cpp:52-54 */
 void orc_msvc_rand_fill(float* out, long n, unsigned seed);

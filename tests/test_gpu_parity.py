@@ -408,6 +408,110 @@ def test_shape_from_shading_reference_default_data(torch, orc, golden_dir):
     assert rel_err(costs, co) < COST_RTOL, (costs, co)
 
 
+# ------------------------------------------------------------------ the benchmarked / configured sizes against the oracle
+def _host_threads():
+    return max(1, min(64, os.cpu_count() or 1))
+
+
+def test_benchmark_configuration_2048_vs_cpu_port(torch, orc):
+    """bench.py's exact configuration -- image_warping 2048^2 (synthetic instance), one GN step of 100 PCG iterations through the
+    default (one-kernel) schedule -- against the OpenMP port of the reference algorithm, which tests/test_oracle_golden.py pins to the
+    row oracle: cost to 1e-5, the first 10 alpha / beta to 2e-5, the updated unknowns to VEC_RTOL."""
+    W = H = 2048
+    p = syn.image_warping(W, H)
+    q = copy_params(p)
+    ref = orc.cpu_port_image_warping(W, H, q, 1, 100, want_costs=True, want_trace=True)
+    dev = to_device(p)
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    final, costs = s.solve(dev, profiled=True, nIterations=1, lIterations=100)
+    tr = np.array(s.alpha_beta_trace())
+    print("2048^2 1x100: costs", costs, ref["costs"], "max rel alpha/beta error, first 10 / all",
+          (np.abs(tr[:10] - ref["trace"][:10]) / np.abs(ref["trace"][:10])).max(), (np.abs(tr - ref["trace"]) / np.abs(ref["trace"])).max())
+    assert len(costs) == 2 and rel_err(np.array(costs), ref["costs"]) < COST_RTOL, (costs, ref["costs"])
+    assert tr.shape == (100, 2)
+    assert (np.abs(tr[:10] - ref["trace"][:10]) <= 2e-5 * np.abs(ref["trace"][:10])).all(), (tr[:10], ref["trace"][:10])
+    # later iterations: CG amplifies the summation order (the reference's own is nondeterministic), so a looser bar
+    assert (np.abs(tr - ref["trace"]) <= 2e-2 * np.abs(ref["trace"]) + 1e-6).all()
+    assert rel_err(to_host(dev[0]), q[0]) < VEC_RTOL
+    s.close()
+
+
+def test_image_warping_cat512_reference_budget(torch, orc, golden_dir):
+    """BASELINE.json configs[1] at the reference's own budget: the cat512 data set, GN 8 x PCG 100 (examples/image_warping/src/
+    main.cpp:131-149), first solve of the marker continuation, against the row oracle.
+    This instance (w_fit^2 / w_reg^2 = 1e4, unknowns starting exactly at rest) is ill-conditioned enough that 100 unconverged float PCG
+    iterations amplify the summation order itself: the oracle's own two legitimate orders (double accumulators vs the serial float
+    order of the reference's CPU mode, cpu_cuda.t:265-301) end 5-17 % apart in running cost (measured; alpha_k already differs by tens
+    of per cent after 5 iterations between ANY two implementations), and the reference's GPU reduction order is nondeterministic
+    (util.t:40-50).  So: the initial cost and the whole trajectory on the scale the harness reports (relative to the initial cost) to
+    1e-5, each step's running cost within the oracle's own order-to-order spread."""
+    from thallo_amd import formats as F
+    mask = F.read_png(os.path.join(golden_dir, "cat512_mask.png"))[:, :, 0].astype(np.float32)
+    H, W = mask.shape
+    cons = F.add_border_constraints(F.read_constraints(os.path.join(golden_dir, "cat512.constraints")), W, H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ur = np.stack([xx, yy], axis=2).astype(np.float32)
+    wf, wr = float(np.sqrt(np.float32(100.0))), float(np.sqrt(np.float32(0.01)))
+    c_img = F.constraint_image(cons, mask, np.float32(1) / np.float32(19))
+    p = [ur.copy(), np.zeros((H, W), dtype=np.float32), ur.copy(), c_img, mask, wf, wr]
+    prev = orc.set_threads(_host_threads())
+    try:
+        co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), copy_params(p)).solve(nIterations=8, lIterations=100)
+    finally:
+        orc.set_threads(prev)
+    cf, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), copy_params(p)).solve(nIterations=8, lIterations=100, float_sums=1)
+    s, dev, costs, final = _solve_gpu("image_warping", (W, H), p, nIterations=8, lIterations=100)
+    costs = np.array(costs)
+    err, drift = np.abs(costs - co) / co, np.abs(cf - co) / co
+    print("cat512 8x100: rel. cost error per step", err, "oracle float-vs-double order drift", drift, costs)
+    assert len(costs) == 9 and err[0] < COST_RTOL
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)                       # relative to the initial cost: 1e-5
+    assert err.max() <= max(COST_RTOL, drift.max()), (err, drift)            # running cost: inside the oracle's own spread
+    assert costs[-1] < 1e-4 * costs[0]
+
+
+def test_shape_from_shading_2048_lm_vs_oracle(torch, orc):
+    """BASELINE.json configs[3]: shape_from_shading 2048^2 with the LM branch (reference budget 60 x 10, shape_from_shading/src/
+    main.cpp:44-53; here the first 3 LM steps x 10 PCG) against the row oracle on the host cores."""
+    W = H = 2048
+    p = syn.shape_from_shading(W, H)
+    prev = orc.set_threads(_host_threads())
+    try:
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=3, lIterations=10, use_lm=1)
+    finally:
+        orc.set_threads(prev)
+    s, dev, costs, final = _solve_gpu_lm("shape_from_shading", (W, H), p, nIterations=3, lIterations=10)
+    m = min(len(costs), len(co))
+    assert m >= 3 and len(costs) == len(co), (costs, co)
+    print("SFS 2048 LM 3x10: rel. cost error per step", np.abs(costs[:m] - co[:m]) / np.abs(co[:m]), costs[:m])
+    assert (np.abs(costs[:m] - co[:m]) <= 2e-4 * np.abs(co[:m])).all(), (costs, co)       # the bar of test_shape_from_shading_lm
+    assert costs[m - 1] < costs[0]
+
+
+def test_bundle_adjustment_ladybug_lm_vs_oracle(torch, orc):
+    """BASELINE.json configs[4]: the ladybug-1723-shaped instance with the reference's LM budget 5 x 150
+    (bundle_adjustment/src/main.cpp:9-14) against the row oracle on the host cores.  Bars as in test_bundle_adjustment_cost_trajectory:
+    the first step to 1e-5, later ones within what the summation order alone moves an unconverged PCG on this system."""
+    p = syn.bundle_adjustment()
+    dims = (p[0].shape[0], p[1].shape[0], p[2].shape[0])
+    prev = orc.set_threads(_host_threads())
+    try:
+        co, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, copy_params(p)).solve(nIterations=5, lIterations=150, use_lm=1)
+        c2, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, copy_params(p)).solve(nIterations=5, lIterations=150, use_lm=1)   # another atomic order
+    finally:
+        orc.set_threads(prev)
+    s, dev, costs, final = _solve_gpu_lm("bundle_adjustment", dims, p, nIterations=5, lIterations=150)
+    m = min(len(costs), len(co))
+    assert m >= 3, (costs, co)
+    den = np.maximum(co[:m], 1e-3 * co[0])
+    err = np.abs(costs[:m] - co[:m]) / den
+    drift = np.abs(c2[:m] - co[:m]) / den
+    print("ladybug LM 5x150: rel. cost error per step", err, "oracle atomic-order drift", drift, "costs", costs[:m])
+    assert err[0] < 1e-5 and err[1] < 1e-3, (costs, co)
+    assert err.max() <= max(1e-3, 10 * drift.max()), (err, drift, costs, co)
+    assert costs[m - 1] < 0.5 * costs[0]
+
+
 # ------------------------------------------------------------------ size-independent properties at full size
 def test_full_size_properties_2048(torch):
     """2048^2 (the benchmark size): J^T J is symmetric PSD and linear; the solve is bitwise reproducible;

@@ -412,6 +412,9 @@ int thallo_hip_csr_spmv(int rows, const int* rowptr, const int* col, const float
 /* ---------------------------------------------------------------- multi-GPU device-side exchange (one process per GPU) */
 /* Device memory that other processes can map: *ptr = hipMalloc(bytes) (zeroed), handle_out = 64-byte hipIpcMemHandle_t. */
 int thallo_hip_ipc_alloc(long bytes, void** ptr, void* handle_out64);
+/* the same, reporting the memory kind it got: 1 fine-grained device memory (the default: what peers write and running kernels poll),
+ * 0 plain coarse-grained hipMalloc (THALLO_DIST_MEM=coarse, or the fine-grained allocation / its IPC export was refused) */
+int thallo_hip_ipc_alloc2(long bytes, void** ptr, void* handle_out64, int* kind_out);
 int thallo_hip_ipc_open(const void* handle64, void** ptr);      /* maps a peer's allocation (enables peer access lazily) */
 int thallo_hip_ipc_close(void* ptr);
 int thallo_hip_ipc_free(void* ptr);

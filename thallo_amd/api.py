@@ -92,6 +92,7 @@ def lib():
     L.thallo_hip_iw_pcg_step1.argtypes = [ci, ci, ci, ci, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, SumT, SumT, vp, vp, vp, vp]
     L.thallo_hip_linear_update2.argtypes = [vp, vp, vp, SumT, SumT, vp, SumT, SumT, cl, vp]
     L.thallo_hip_ipc_alloc.argtypes = [C.c_long, C.POINTER(vp), vp]
+    L.thallo_hip_ipc_alloc2.argtypes = [C.c_long, C.POINTER(vp), vp, C.POINTER(ci)]
     L.thallo_hip_ipc_open.argtypes = [vp, C.POINTER(vp)]
     L.thallo_hip_ipc_close.argtypes = [vp]; L.thallo_hip_ipc_free.argtypes = [vp]
     L.thallo_hip_dist_begin_step.argtypes = [DistT, vp]
@@ -104,6 +105,11 @@ def lib():
     _iter = [ci, ci, ci, ci, vp, vp, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, SumT, SumT, vp]
     L.thallo_hip_iw_pcg_iter.argtypes = _iter + [vp, vp, vp, vp, vp, vp]
     L.thallo_hip_iw_pcg_iter_dist.argtypes = _iter + [DistT, vp, vp, vp, ci, vp, vp, vp]
+    _march = [ci, ci, ci, ci, vp, vp, fl, fl, vp, vp, vp, vp, vp, vp, vp, ci, SumT, SumT, SumT, SumT, SumT, vp]     # no urshape / pre
+    L.thallo_hip_iw_pcg_iter_march.argtypes = _march + [vp, vp, vp, vp, vp, vp]
+    L.thallo_hip_iw_pcg_iter_march_dist.argtypes = _march + [DistT, vp, vp, vp, ci, vp, vp, vp]
+    L.thallo_hip_iw_urshape_irregular.argtypes = [ci, ci, vp, vp, vp]
+    L.thallo_hip_march_debug_set.argtypes = [ci, ci]
     L.thallo_hip_iw_pcg_iter_finish.argtypes = [vp, vp, ci, SumT, vp, vp, vp]
     L.thallo_hip_iw_pcg_step2_dist.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, SumT, SumT, DistT, vp, vp]
     L.thallo_hip_iw_pcg_step2.argtypes = [ci, ci, ci, ci, vp, fl, fl, vp, vp, vp, vp, SumT, SumT, vp, vp, vp]

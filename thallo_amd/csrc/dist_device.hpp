@@ -18,7 +18,7 @@
 namespace thallo {
 
 typedef unsigned long long u64;
-constexpr long long DIST_SPIN_TICKS = 20LL * 100000000LL;     // 20 s of the 100 MHz wall clock: covers host-side skew between ranks (a peer may not have launched yet)
+constexpr long long DIST_SPIN_TICKS = 20LL * 100000000LL;     // default bound: 20 s of the 100 MHz wall clock: covers host-side skew between ranks (a peer may not have launched yet)
 
 __device__ __forceinline__ u64  ld_sys(const u64* p)   { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(u64* p, u64 v)  { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -26,7 +26,14 @@ __device__ __forceinline__ void st_sys(float* p, float v) { __hip_atomic_store(p
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ctl words
-enum { DIST_SEQ = 0, DIST_ERR = 1, DIST_POST_MORTEM = 4, DIST_CTL_WORDS = 16 };
+enum { DIST_SEQ = 0, DIST_ERR = 1, DIST_SPIN_MS = 2, DIST_POST_MORTEM = 4, DIST_CTL_WORDS = 16 };
+// ctl[DIST_SPIN_MS] != 0: spin bound in milliseconds instead of the default (the set-up's self-check runs with 500 ms, so that a
+// topology on which granules never become visible costs half a second, not 20 s, before every rank falls back to the collectives)
+__device__ __forceinline__ long long dist_spin_ticks(const thallo_dist_t& d)
+{
+    const unsigned ms = ld_agent(d.ctl + DIST_SPIN_MS);
+    return ms ? (long long)ms * 100000LL : DIST_SPIN_TICKS;
+}
 
 // Wait for NS slots and return their rank-ordered sums.  Every thread of the workgroup calls it (contains a barrier);
 // `vals` = NS*8 floats of LDS.  Needs blockDim.x >= NS*world.
@@ -42,13 +49,14 @@ __device__ __forceinline__ void dist_fetch(const thallo_dist_t& d, const int (&s
         u64 v = ld_sys(g);
         int it = 0;
         long long t0 = 0;
+        const long long bound = dist_spin_ticks(d);
         while ((unsigned)(v >> 32) != seq) {
             if ((it & 1023) == 0) {
                 if (ld_agent(d.ctl + DIST_ERR) != 0) break;                          // somebody already timed out: do not pile up
                 if (it == 0) t0 = wall_clock64();
             }
             ++it;
-            if ((it & 1023) == 0 && wall_clock64() - t0 > DIST_SPIN_TICKS) {
+            if ((it & 1023) == 0 && wall_clock64() - t0 > bound) {
                 if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                     // first timeout of this rank: leave a post-mortem (slot, source rank, expected seq, granule as found)
                     unsigned* pm = d.ctl + DIST_POST_MORTEM;
@@ -94,10 +102,11 @@ __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, 
         const u64* g = d.mail + (long)(slot0 + j) * d.world + r;
         u64 v = ld_sys(g);
         int it = 0; long long t0 = 0;
+        const long long bound = dist_spin_ticks(d);
         while ((unsigned)(v >> 32) != seq) {
             if ((it & 1023) == 0) { if (ld_agent(d.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
             ++it;
-            if ((it & 1023) == 0 && wall_clock64() - t0 > DIST_SPIN_TICKS) {
+            if ((it & 1023) == 0 && wall_clock64() - t0 > bound) {
                 if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                     unsigned* pm = d.ctl + DIST_POST_MORTEM;
                     pm[0] = (unsigned)(slot0 + j); pm[1] = (unsigned)r; pm[2] = seq; pm[3] = (unsigned)(v >> 32); pm[4] = (unsigned)v;

@@ -1,6 +1,7 @@
 // dist_p2p.hip -- host entry points of the multi-GPU device-side exchange (include/thallo_hip.h, dist_device.hpp).
 #include "dist_device.hpp"
 #include <string.h>
+#include <stdlib.h>
 
 using namespace thallo;
 
@@ -63,14 +64,33 @@ __global__ __launch_bounds__(64) void k_collect(thallo_dist_t d, int slot0, int 
 
 extern "C" {
 
-int thallo_hip_ipc_alloc(long bytes, void** ptr, void* handle_out64)
+// Memory other GPUs write into (mailboxes; the vector block holding the ghost rows) while this GPU's kernels read it: FINE-GRAINED device
+// memory (hipDeviceMallocFinegrained), the allocation type HIP defines cross-agent coherence for inside a running kernel.  Plain hipMalloc
+// memory is coarse-grained: coherent with other agents at kernel boundaries only, so a poll from inside a running kernel may legally
+// keep seeing a stale line in this GPU's L2.  THALLO_DIST_MEM=coarse selects the plain allocation (A/B on one GPU, where every "peer"
+// shares the L2 and both behave alike); if the fine-grained allocation or its IPC export is refused the plain one is used and *kind_out
+// says so.  kind: 1 fine-grained, 0 coarse.
+int thallo_hip_ipc_alloc2(long bytes, void** ptr, void* handle_out64, int* kind_out)
 {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     static_assert(DIST_CTL_WORDS <= THALLO_DIST_CTL_WORDS, "ctl layout");
     if (bytes <= 0 || !ptr || !handle_out64) return -(int)hipErrorInvalidValue;
+    const char* env = getenv("THALLO_DIST_MEM");
+    const bool want_fine = !(env && env[0] == 'c');
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, (size_t)bytes);
+    hipError_t e = hipErrorUnknown;
+    int kind = 0;
+    if (want_fine) {
+        e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
+        if (e == hipSuccess) {
+            hipIpcMemHandle_t probe;
+            if (hipIpcGetMemHandle(&probe, p) == hipSuccess) kind = 1;
+            else { (void)hipFree(p); p = nullptr; e = hipErrorUnknown; (void)hipGetLastError(); }
+        } else (void)hipGetLastError();
+    }
+    if (!p) e = hipMalloc(&p, (size_t)bytes);
     if (e != hipSuccess) return -(int)e;
+    if (kind_out) *kind_out = kind;
     e = hipMemset(p, 0, (size_t)bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     hipIpcMemHandle_t h;
@@ -80,6 +100,8 @@ int thallo_hip_ipc_alloc(long bytes, void** ptr, void* handle_out64)
     *ptr = p;
     return 0;
 }
+
+int thallo_hip_ipc_alloc(long bytes, void** ptr, void* handle_out64) { return thallo_hip_ipc_alloc2(bytes, ptr, handle_out64, nullptr); }
 
 int thallo_hip_ipc_open(const void* handle64, void** ptr)
 {

@@ -153,6 +153,7 @@ class HipSlabBackend:
         self.seg_iter_top = _segs(row(self.row0 - 1)) if layout.top else _segs([])
         self.seg_iter_bot = _segs(row(self.row1)) if layout.bot else _segs([])
         self.one_kernel_collective = os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0"
+        self.use_march = os.environ.get("THALLO_MARCH", "1") != "0" and W % 2 == 0
 
     # -- helpers
     def _st(self):
@@ -244,8 +245,10 @@ class HipSlabBackend:
     def _ipc_alloc(self, nbytes):
         ptr = C.c_void_p()
         handle = C.create_string_buffer(64)
-        self._chk(self.L.thallo_hip_ipc_alloc(C.c_long(nbytes), C.byref(ptr), handle), "ipc_alloc")
+        kind = C.c_int(-1)
+        self._chk(self.L.thallo_hip_ipc_alloc2(C.c_long(nbytes), C.byref(ptr), handle, C.byref(kind)), "ipc_alloc")
         self._ipc_ptrs.append(ptr.value)
+        self.ipc_memory = getattr(self, "ipc_memory", []) + ["fine-grained" if kind.value == 1 else "coarse-grained"]
         return ptr.value, handle.raw
 
     def _ipc_open(self, handle):
@@ -327,13 +330,24 @@ class HipSlabBackend:
             vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), self._sum(iN), self._sum(iD), self.p2p, vp(self.parts.data_ptr()), self._st()), "iw_pcg_step2_dist")
         self.p2p_exchange(out_idx)              # betaN ; behind it the neighbours' rows of r are in my ghost rows
 
+    def _iter_entry(self, dist_variant):
+        """The one-kernel iteration's shim entry + its leading arguments: the marching kernel (unit-pixel-grid UrShape, which the one-kernel
+        slab schedule requires anyway: SlabSolver checks `irregular` on the host) unless THALLO_MARCH=0 selects the LDS-tiled kernel."""
+        vp = C.c_void_p
+        if self.use_march:
+            fn = self.L.thallo_hip_iw_pcg_iter_march_dist if dist_variant else self.L.thallo_hip_iw_pcg_iter_march
+            return fn, (self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.flags.data_ptr()))
+        fn = self.L.thallo_hip_iw_pcg_iter_dist if dist_variant else self.L.thallo_hip_iw_pcg_iter
+        return fn, (self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()), vp(self.pre.data_ptr()))
+
     def iter_p2p(self, cur, mode, iN, iD, iB, jD, jB, iN2, iD2, k):
         """One PCG iteration = one kernel (thallo_hip_iw_pcg_iter_dist: also stores its boundary rows of Ap into the neighbours' ghost
         rows) + one exchange (alphaD, N, S1, S2 -> S[jD] = alphaD_k, S[jB] = betaN_k).  Buffers r / Ap / p ping-pong on `cur`."""
         vp, fl = C.c_void_p, C.c_float
         rb = (self.r, self.r_alt)
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_iter_dist(
-            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()), vp(self.pre.data_ptr()),
+        fn, head = self._iter_entry(True)
+        self.nb = self._chk(fn(
+            *head,
             fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(self.Ap_ipc[cur ^ 1].data_ptr()),
             vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), int(mode),
             self._sum(iN), self._sum(iD), self._sum(iB), self._sum(iN2), self._sum(iD2), vp(self.irregular.data_ptr()), self.p2p_iter[cur ^ 1],
@@ -350,8 +364,9 @@ class HipSlabBackend:
         vp, fl = C.c_void_p, C.c_float
         rb = (self.r, self.r_alt)
         Ao = self.Ap_ipc[cur ^ 1]
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_iter(
-            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()), vp(self.pre.data_ptr()),
+        fn, head = self._iter_entry(False)
+        self.nb = self._chk(fn(
+            *head,
             fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(Ao.data_ptr()),
             vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), int(mode),
             self._sum(iN), self._sum(iD), self._sum(iB), self._sum(iN2), self._sum(iD2), vp(self.irregular.data_ptr()),
@@ -374,8 +389,9 @@ class HipSlabBackend:
         """the one-kernel iteration without the remote stores and without the exchange (bench: kernel time on this rank's slab)"""
         vp, fl = C.c_void_p, C.c_float
         rb = (self.r, self.r_alt)
-        return self._chk(self.L.thallo_hip_iw_pcg_iter(
-            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()), vp(self.pre.data_ptr()),
+        fn, head = self._iter_entry(False)
+        return self._chk(fn(
+            *head,
             fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(self.Ap_ipc[cur ^ 1].data_ptr()),
             vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), 0,
             self._sum(2), self._sum(3), self._sum(4), self._sum(2), self._sum(3), vp(self.irregular.data_ptr()),
@@ -587,6 +603,7 @@ class SlabSolver:
             return False
         ok = True
         try:
+            be.ctl[2] = 500             # DIST_SPIN_MS: a topology where granules never become visible costs 0.5 s here, not the 20 s production bound
             X0, A0 = be.offset.clone(), be.angle.clone()
             self.gn_step(l_iters)
             ref = be.S[2:2 + 2 * l_iters + 1].clone()
@@ -597,7 +614,8 @@ class SlabSolver:
             err = be.p2p_error()
             be.offset.copy_(X0); be.angle.copy_(A0)
             rel = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item())
-            self.p2p_check = {"irregular": irregular, "timeout": err, "max_rel_scalar_diff": rel}
+            be.ctl[2] = 0
+            self.p2p_check = {"irregular": irregular, "timeout": err, "max_rel_scalar_diff": rel, "memory": sorted(set(getattr(be, "ipc_memory", [])))}
             if irregular != 0 or err != 0 or not (rel <= rtol):
                 ok = False
         except Exception as e:      # noqa: BLE001

@@ -127,6 +127,14 @@ int thallo_hip_lm_step2_second_half(float* r, const float* b, const float* Adelt
 int thallo_hip_pcg_init_finish(const float* r, const float* diag, float* pre, float* z, long n, int use_preconditioner,
                                float* alphaN_out, thallo_stream_t stream);
 /* partials of sum a.b */
+/* LM without the host in the loop (gauss_newton.t:1666-1686 semantics): `state` = 8 device words: [0] Q0, [1] frozen flag (the GATE word),
+ * [2] PCG iterations done when the loop froze, [3..7] free for the driver's end-of-step report.  lm_zeta (one wave, behind PCGStep2 of iteration k)
+ * applies the zeta test and freezes the loop; while the gate word set with lm_set_gate is non-zero, pcg_pupdate, lm_step1_finish,
+ * pcg_step2_full and lm_step2_first / second_half launches return at once (so do applyJTJ kernels given the word: *_apply_jtj_gated).
+ * The driver enqueues all lIterations iterations and reads the state back once per GN step. */
+void thallo_hip_lm_set_gate(const unsigned* gate);
+int thallo_hip_lm_state_reset(float* state, thallo_stream_t stream);
+int thallo_hip_lm_zeta(thallo_sum_t q, int k, float q_tolerance, float* state, thallo_stream_t stream);
 int thallo_hip_dot(const float* a, const float* b, long n, float* out, thallo_stream_t stream);
 
 /* PCGLinearUpdate (gauss_newton.t:901-906) for one unknown image:  X[i] += delta[i] (+ alpha*p[i]
@@ -397,6 +405,10 @@ int thallo_hip_pcg_scalars_finish(const float* alphaD_partials, const double* s3
 int thallo_hip_arap_apply_jtj_sums(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                                    const float* constraints, const float* G, float w_fit, float w_reg,
                                    const float* p, float* Ap, float* alphaD_out, long ell_stride, const float* r, const float* pre, double* s3_out, thallo_stream_t stream);
+/* shape_from_shading applyJTJ with a device-side gate word (may be NULL): non-zero = the launch does nothing (the LM branch ends its PCG loop on
+ * the device without a host round trip per iteration, solver.cpp) */
+int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                   float* U, float* R, const float* p, float* Ap, float* alphaD_out, const unsigned* gate, thallo_stream_t stream);
 int thallo_hip_ba_apply_jtj_sums(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
                                  const float* Jb, const float* p, float* Ap, float* alphaD_out, const float* r, const float* pre, double* s3_out, thallo_stream_t stream);
 int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

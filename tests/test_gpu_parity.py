@@ -728,6 +728,39 @@ def test_lm_trajectory_matches_oracle(torch, orc, which):
     assert all(costs[i + 1] <= costs[i] * (1 + 1e-6) for i in range(len(costs) - 1))     # LM never accepts an uphill step
 
 
+@pytest.mark.parametrize("which", ["sfs", "ba", "iw"])
+def test_lm_device_side_zeta_matches_the_blocking_form(torch, which, monkeypatch):
+    """LM without the host in the loop: the zeta test and the early-exit flag live on the device, one read-back per
+    GN step.  Same PCG iteration counts, same costs, same unknowns as the reference-shaped form that blocks on a 4-byte copy after every
+    PCG iteration (gauss_newton.t:1666-1686; THALLO_LM_HOST_ZETA=1)."""
+    if which == "sfs":
+        fname, dims, p, sp = "shape_from_shading", (96, 64), syn.shape_from_shading(96, 64), dict(nIterations=5, lIterations=10, q_tolerance=0.2)
+    elif which == "ba":
+        p = syn.bundle_adjustment(C=24, P=400, O=2400, band=8)
+        fname, dims, sp = "bundle_adjustment", (24, 400, 2400), dict(nIterations=4, lIterations=40, q_tolerance=0.02)
+    else:
+        fname, dims, p, sp = "image_warping", (96, 64), syn.image_warping(96, 64, n_markers=6), dict(nIterations=4, lIterations=30, q_tolerance=0.05)
+    runs = []
+    for host in ("1", "0"):
+        monkeypatch.setenv("THALLO_LM_HOST_ZETA", host)
+        dev = to_device(p)
+        s = api.ThalloSolver(dims, thallo_amd.energy_file(fname), solverkind="levenberg_marquardt")
+        s.enable_lm()
+        s.set_solver_parameters(**sp)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, iters = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); iters.append(len(s.alpha_beta_trace()))
+        runs.append((costs, iters, [d.clone() for d in dev if hasattr(d, "clone")]))
+        s.close()
+    (c0, i0, u0), (c1, i1, u1) = runs
+    assert i0 == i1 and len(i0) >= 2 and min(i0) >= 1, (i0, i1)
+    assert any(k < sp["lIterations"] for k in i0), i0          # the early exit is actually exercised
+    assert c0 == c1, (c0, c1)
+    assert all(torch.equal(a, b) for a, b in zip(u0, u1))
+
+
 def test_lm_kind_string_alone_runs_gn_like_the_reference(torch, orc):
     """"levenberg_marquardt" without ThalloX_EnableLM == GN (thallo.t:463: UsesLambda() never fires as shipped)."""
     p = syn.image_warping(48, 32, n_markers=4)

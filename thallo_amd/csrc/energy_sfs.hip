@@ -22,6 +22,7 @@
 //                     + w_s sum_c coef_c(i) (4 R_c(i) - sum_nbr R_c(nbr))
 // 1 float per pixel: the whole working set of a 2048^2 frame is ~250 MB of small planes; neighbours come through
 // L1/L2.  Not tuned yet (round 1: correctness + structure).
+#include <stdlib.h>
 #include "device_common.hpp"
 #include "../../include/thallo_hip.h"
 
@@ -229,6 +230,118 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Geo g, Cam cm, const float* __
     if (MODE == 1 && s3_out) block_store_sums3(sm, s3_out, redd);
 }
 
+// ------------------------------------------------------------------------------------------ fused J^T(J v): one LDS-tiled kernel
+// k_rows + k_gather above move ~94 B/pixel (v, G, Wt, fl in, U and R out; then v, G, U, R, fl in, out): the intermediate planes U (8 B)
+// and R (12 B) make a round trip through HBM.  Fused, they live in LDS: for a 64x16 output tile
+//   A  per pixel q of the tile +- 1:  U(q) = (h^2 (dB(q) - dB(q+ex)), k^2 (dB(q) - dB(q+ey))) and R_c(q), computed exactly as k_rows does,
+//      from v, G, Wt, fl in global memory (the 3x3 neighbourhoods overlap: L1 / L2 serve the re-reads)                       -> LDS
+//   B  per output pixel i:            T at i, i+ex, i+ey from U;  out(i) as k_gather;  alphaD (and the three double sums)
+// two workgroup barriers per tile, 24 KB of LDS per workgroup (6 workgroups per CU).
+// Bytes per pixel from HBM: read v 4, G 16, Wt 8, fl 1; write out 4 = 33 (the algorithmic bytes of this formulation);
+// the tile +- 1 halo (66x18 over 64x16 = 16 %) and the stencil neighbourhoods are re-read through L1 / L2.
+// MODE 0 is the J^T F pass of PCGInit1: dB := BI (G.w), v := X, the fit term uses X - D, and the outputs are r = -J^T F, z = r,
+// p_prev = 0, delta = 0, alphaN partials.  Same expressions in the same order as k_rows / k_gather: bit-identical outputs.
+// `gate` (may be NULL): a device word; non-zero = skip this launch (LM: the PCG loop ended early on the device, solver.cpp).
+constexpr int FW = 64, FH = 16;
+constexpr int UW = FW + 2, UH = FH + 2;        // U, R: tile +- 1
+struct FusedTile {
+    float uh[UW * UH], uv[UW * UH];
+    float r0[UW * UH], r1[UW * UH], r2[UW * UH];
+    float cx[UW + 2], cy[UH + 2];              // coef_0 = (x - u_x) / f_x per column, coef_1 = (y - u_y) / f_y per row of the tile +- 2 (coef_2 = 1):
+                                               // one division per column / row and tile instead of ten per pixel
+};
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __restrict__ v, const float* __restrict__ D,
+                                                 const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
+                                                 float* __restrict__ out, float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta,
+                                                 float* __restrict__ part_out, const float* __restrict__ rs, double* __restrict__ s3_out,
+                                                 const unsigned* __restrict__ gate)
+{
+    __shared__ FusedTile T;
+    __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
+    const int W = g.W, H = g.H;
+    const int ftx = (W + FW - 1) / FW, fty = (g.rb - g.ra + FH - 1) / FH, ntiles = ftx * fty;
+    float acc = 0.0f; Sums3 sm;
+    for (TileSweep t(ntiles); t.valid(); t.next()) {
+        const int x0 = (t.cur % ftx) * FW, y0 = g.ra + (t.cur / ftx) * FH;
+        if (threadIdx.x < UW + 2) T.cx[threadIdx.x] = coef(cm, 0, x0 + (int)threadIdx.x - 2, 0);
+        else if (threadIdx.x >= 128 && threadIdx.x < 128 + UH + 2) T.cy[threadIdx.x - 128] = coef(cm, 1, 0, y0 + (int)threadIdx.x - 128 - 2 + g.yoff);
+        __syncthreads();
+        // ---- A: U and R on the tile +- 1
+        for (int idx = threadIdx.x; idx < UW * UH; idx += BLOCK) {
+            const int ly = idx / UW, lx = idx - ly * UW;
+            const int qx = x0 + lx - 1, qy = y0 + ly - 1;
+            float uh = 0.f, uv = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
+                const long q = (long)qy * W + qx;
+                const float2 w = Wt[q];
+                if (w.x != 0.0f || w.y != 0.0f) {
+                    float b0, bx, by;
+                    if (MODE == 0) { b0 = G[q].w; bx = G[q + 1].w; by = G[q + W].w; }
+                    else {
+                        const float vc = v[q], vl = v[q - 1], vu = v[q - W];      // inner pixel: all in range
+                        const float4 g0 = G[q], gx = G[q + 1], gy = G[q + W];
+                        b0 = g0.x * vc + g0.y * vl + g0.z * vu;
+                        bx = gx.x * v[q + 1] + gx.y * vc + gx.z * v[q + 1 - W];
+                        by = gy.x * v[q + W] + gy.y * v[q + W - 1] + gy.z * vc;
+                    }
+                    uh = w.x * (w.x * (b0 - bx)); uv = w.y * (w.y * (b0 - by));
+                }
+                if (fl[q] & 2) {
+                    const float vc = v[q], vl = at(v, qx - 1, qy, W, H), vu = at(v, qx, qy - 1, W, H), vr = at(v, qx + 1, qy, W, H), vd = at(v, qx, qy + 1, W, H);
+                    // coef_c at q and its four neighbours: c = 0 varies with x only, c = 1 with y only, c = 2 is 1  (tables start at tile - 2)
+                    const float xm = T.cx[lx], xc = T.cx[lx + 1], xp = T.cx[lx + 2], ym = T.cy[ly], yc = T.cy[ly + 1], yp = T.cy[ly + 2];
+                    r0 = cm.ws * (4.0f * (xc * vc) - xm * vl - xc * vu - xp * vr - xc * vd);
+                    r1 = cm.ws * (4.0f * (yc * vc) - yc * vl - ym * vu - yc * vr - yp * vd);
+                    r2 = cm.ws * (4.0f * (1.0f * vc) - 1.0f * vl - 1.0f * vu - 1.0f * vr - 1.0f * vd);
+                }
+            }
+            T.uh[idx] = uh; T.uv[idx] = uv; T.r0[idx] = r0; T.r1[idx] = r1; T.r2[idx] = r2;
+        }
+        __syncthreads();
+        // ---- B: outputs
+#pragma unroll
+        for (int k = 0; k < FH / (BLOCK / FW); ++k) {
+            const int lx = threadIdx.x % FW, ly = threadIdx.x / FW + k * (BLOCK / FW);
+            const int x = x0 + lx, y = y0 + ly;
+            if (x < W && y < g.rb) {
+                const long i = (long)y * W + x;
+                const int iu = (ly + 1) * UW + (lx + 1);
+                // T(c) = U_h(c) - U_h(c-ex) + U_v(c) - U_v(c-ey), terms outside the image dropped (same order and guards as T_at)
+                auto Tat = [&](int j, int cx, int cy) {
+                    if (cx < 0 || cx >= W || cy < 0 || cy >= H) return 0.0f;
+                    float tt = T.uh[j] + T.uv[j];
+                    if (cx > 0) tt -= T.uh[j - 1];
+                    if (cy > 0) tt -= T.uv[j - UW];
+                    return tt;
+                };
+                const float vc = v[i];
+                float s = 0.0f;
+                if (fl[i] & 1) s += cm.wp * (cm.wp * (MODE == 0 ? vc - D[i] : vc));
+                s += G[i].x * Tat(iu, x, y);
+                if (x + 1 < W) s += G[i + 1].y * Tat(iu + 1, x + 1, y);
+                if (y + 1 < H) s += G[i + W].z * Tat(iu + UW, x, y + 1);
+                const float* Rp[3] = { T.r0, T.r1, T.r2 };
+                const float ci[3] = { T.cx[lx + 2], T.cy[ly + 2], 1.0f };
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* Rc = Rp[c];
+                    const float lap = 4.0f * Rc[iu] - Rc[iu - 1] - Rc[iu - UW] - Rc[iu + 1] - Rc[iu + UW];
+                    s += cm.ws * (ci[c] * lap);
+                }
+                if (MODE == 0) { const float r = -s; out[i] = r; z[i] = r; p_prev[i] = 0.0f; delta[i] = 0.0f; acc += r * r; }
+                else { out[i] = s; acc += vc * s; if (s3_out) sm.add(1.0f, rs[i], s); }
+            }
+        }
+        __syncthreads();
+    }
+    block_store_partial(acc, part_out, red);
+    if (MODE == 1 && s3_out) block_store_sums3(sm, s3_out, redd);
+}
+
 // raw diag(J^T J) (LM only): enumerate the rows that contain X(i)
 __global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __restrict__ G, const float2* __restrict__ Wt,
                                                 const unsigned char* __restrict__ fl, float* __restrict__ diag)
@@ -275,6 +388,15 @@ __global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __r
 
 extern "C" {
 
+// THALLO_SFS_FUSED=0: the two-pass k_rows + k_gather form (A/B switch)
+static bool sfs_fused() { static int v = -1; if (v < 0) { const char* e = getenv("THALLO_SFS_FUSED"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
+static int fused_grid(int W, int rows)
+{
+    const int nt = ((W + FW - 1) / FW) * ((rows + FH - 1) / FH);
+    int cap = thallo_hip_device_cu_count() * 4; if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS; cap -= cap % 8;      // (1024 partial slots: 4 of the 6 resident workgroups per CU)
+    return nt < cap ? nt : cap;
+}
+
 /* host_params: the 16 scalar parameters of the .t in Inputs{} order: w_p, w_s, w_g (squared weights), f_x, f_y, u_x, u_y, L_1..L_9 */
 static Cam cam_of(const float* hp)
 {
@@ -313,6 +435,13 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
     const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
     const Cam cm = cam_of(host_params);
     hipStream_t s = (hipStream_t)stream;
+    if (sfs_fused()) {
+        const int gridf = fused_grid(W, row1 - row0);
+        hipLaunchKernelGGL(k_fused<0>, dim3(gridf), dim3(BLOCK), 0, s, g, cm, X, D, (const float4*)G, (const float2*)Wt, fl, r, z, p_prev, delta, aN_out,
+                           (const float*)nullptr, (double*)nullptr, (const unsigned*)nullptr);
+        if (diag_out) hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
+        int e = check_launch(); return e ? e : gridf;
+    }
     hipLaunchKernelGGL(k_rows<true>, dim3(gridr), dim3(BLOCK), 0, s, gr, cm, X, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
     hipLaunchKernelGGL(k_gather<0>, dim3(grid), dim3(BLOCK), 0, s, g, cm, X, D, (const float4*)G, (const float2*)U, (const float*)R, fl, r, z, p_prev, delta, aN_out);
     if (diag_out) hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
@@ -320,7 +449,7 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
 }
 
 static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
-                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream);
+                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate = nullptr);
 
 int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
@@ -330,11 +459,21 @@ int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, in
                                   float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream)
 { if (!r || !s3_out) return -(int)hipErrorInvalidValue; return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, r, s3_out, stream); }
 
+int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                   float* U, float* R, const float* p, float* Ap, float* aD_out, const unsigned* gate, thallo_stream_t stream)
+{ return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream, gate); }
+
 static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
-                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream)
+                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate)
 {
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
+    if (sfs_fused()) {
+        const int gridf = fused_grid(W, row1 - row0);
+        hipLaunchKernelGGL(k_fused<1>, dim3(gridf), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), p, (const float*)nullptr, (const float4*)G, (const float2*)Wt, fl,
+                           Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out, r, s3_out, gate);
+        int e = check_launch(); return e ? e : gridf;
+    }
     const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
     const Cam cm = cam_of(host_params);
     hipStream_t s = (hipStream_t)stream;

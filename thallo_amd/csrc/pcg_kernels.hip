@@ -76,9 +76,10 @@ __global__ __launch_bounds__(BLOCK) void k_step2_full(float4* __restrict__ delta
                                                        const float4* __restrict__ pre, float4* __restrict__ z,
                                                        const float4* __restrict__ b, long n4,
                                                        thallo_sum_t aN, thallo_sum_t aD,
-                                                       float* __restrict__ bN_out, float* __restrict__ q_out)
+                                                       float* __restrict__ bN_out, float* __restrict__ q_out, const unsigned* __restrict__ gate)
 {
     __shared__ float red[32];
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device
     const float alpha = safe_div<LM>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
     float acc[2] = { 0.0f, 0.0f };
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
@@ -120,8 +121,9 @@ __global__ __launch_bounds__(BLOCK) void k_step3(float4* __restrict__ p, const f
 //   delta += alpha*p_in ; p_out = z + beta*p_in    (first: p_out = z)
 __global__ __launch_bounds__(BLOCK) void k_pupdate(const float4* __restrict__ z, const float4* __restrict__ p_in, float4* __restrict__ p_out,
                                                     float4* __restrict__ delta, long off0, long len0, long off1, long len1, int first,
-                                                    thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp)
+                                                    thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, const unsigned* __restrict__ gate)
 {   // delta == NULL: p update only (LM: PCGStep3 with the unguarded divide, delta lives in PCGStep2)
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device
     float alpha = 0.0f, beta = 0.0f;
     const bool lm = delta == nullptr;
     if (!first) {
@@ -236,9 +238,10 @@ __global__ __launch_bounds__(BLOCK) void k_lm_finalize(const float4* __restrict_
 
 // PCGStep1_Finish (LM): Ap += CtC*p ; alphaD partials = sum p.Ap
 __global__ __launch_bounds__(BLOCK) void k_lm_step1_finish(float4* __restrict__ Ap, const float4* __restrict__ CtC, const float4* __restrict__ p,
-                                                            long n4, float* __restrict__ aD_out)
+                                                            long n4, float* __restrict__ aD_out, const unsigned* __restrict__ gate)
 {
     __shared__ float red[16];
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device
     float acc = 0.0f;
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
         float4 a = Ap[i]; const float4 c = CtC[i], pv = p[i];
@@ -251,8 +254,9 @@ __global__ __launch_bounds__(BLOCK) void k_lm_step1_finish(float4* __restrict__ 
 
 // PCGStep2_1stHalf: delta += alpha*p
 __global__ __launch_bounds__(BLOCK) void k_lm_step2_first(float4* __restrict__ delta, const float4* __restrict__ p, long n4,
-                                                           thallo_sum_t aN, thallo_sum_t aD)
+                                                           thallo_sum_t aN, thallo_sum_t aD, const unsigned* __restrict__ gate)
 {
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device
     const float alpha = safe_div<true>(sum_partials(aN.partials, aN.count), sum_partials(aD.partials, aD.count));
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
         float4 d = delta[i]; const float4 pv = p[i];
@@ -264,9 +268,10 @@ __global__ __launch_bounds__(BLOCK) void k_lm_step2_first(float4* __restrict__ d
 // PCGStep2_2ndHalf: r = b - Adelta ; z = M^-1 r ; betaN ; q = 0.5 delta.(r+b)
 __global__ __launch_bounds__(BLOCK) void k_lm_step2_second(float4* __restrict__ r, const float4* __restrict__ b, const float4* __restrict__ Ad,
                                                             const float4* __restrict__ pre, float4* __restrict__ z, const float4* __restrict__ delta,
-                                                            long n4, float* __restrict__ bN_out, float* __restrict__ q_out)
+                                                            long n4, float* __restrict__ bN_out, float* __restrict__ q_out, const unsigned* __restrict__ gate)
 {
     __shared__ float red[32];
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device
     float acc[2] = { 0.0f, 0.0f };
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
         const float4 bv = b[i], av = Ad[i], mv = pre[i], dv = delta[i];
@@ -278,6 +283,22 @@ __global__ __launch_bounds__(BLOCK) void k_lm_step2_second(float4* __restrict__ 
     }
     float* __restrict__ const outs[2] = { bN_out, q_out };
     block_store_partials<2>(acc, outs, red);
+}
+
+// The zeta test of the LM branch on the device (gauss_newton.t:1666-1686: Q1 = q of this iteration; break if it or zeta = (k+1)(Q1-Q0)/Q1
+// is not finite or zeta < q_tolerance; else Q0 = Q1).  state: [0] Q0, [1] frozen (uint, the gate word of the loop's kernels), [2] number of
+// PCG iterations done when the loop froze (int).  One wave; runs behind PCGStep2 of iteration k.
+__global__ __launch_bounds__(64) void k_lm_zeta(thallo_sum_t q, int k, float q_tolerance, float* __restrict__ state)
+{
+    unsigned* su = reinterpret_cast<unsigned*>(state);
+    if (__builtin_amdgcn_readfirstlane((int)su[1]) != 0) return;
+    const float Q1 = sum_partials(q.partials, q.count), Q0 = state[0];
+    const float zeta = (float)(k + 1) * (Q1 - Q0) / Q1;
+    const bool stop = !isfinite(Q1) || !isfinite(zeta) || zeta < q_tolerance;
+    if (threadIdx.x == 0) {
+        if (stop) { su[1] = 1u; reinterpret_cast<int*>(state)[2] = k + 1; }
+        else state[0] = Q1;
+    }
 }
 
 // PCGInit1_Finish (gauss_newton.t:712-731) for callers that assembled r and the RAW diagonal elsewhere (e.g. after a
@@ -491,6 +512,26 @@ int thallo_hip_pcg_step2(float* r, const float* Ap, const float* pre, float* z, 
     return thallo_hip_pcg_step2_ranges(r, Ap, pre, z, 0, (n + 3) / 4 * 4, 0, 0, aN, aD, bN_out, stream);
 }
 
+// Ambient gate word of the LM loop (thallo_hip_lm_set_gate): passed to the loop's energy-independent kernels (pcg_pupdate, lm_step1_finish,
+// pcg_step2_full, lm_step2_first / second_half), which do nothing once it is non-zero.  NULL outside an LM loop.  One solver per process drives
+// this library at a time (the reference's own contract: one State per process, SURVEY.md 8b "Threading").
+static const unsigned* g_gate = nullptr;
+void thallo_hip_lm_set_gate(const unsigned* gate) { g_gate = gate; }
+
+int thallo_hip_lm_state_reset(float* state, thallo_stream_t stream)
+{
+    if (!state) return -(int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(state, 0, 8 * sizeof(float), (hipStream_t)stream);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+int thallo_hip_lm_zeta(thallo_sum_t q, int k, float q_tolerance, float* state, thallo_stream_t stream)
+{
+    if (!q.partials || q.count < 1 || !state) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lm_zeta, dim3(1), dim3(64), 0, (hipStream_t)stream, q, k, q_tolerance, state);
+    return check_launch();
+}
+
 int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const float* Ap, const float* pre,
                               float* z, const float* b, long n, thallo_sum_t aN, thallo_sum_t aD,
                               float* bN_out, float* q_out, int lm, thallo_stream_t stream)
@@ -499,7 +540,7 @@ int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const floa
     const int grid = flat_grid(n4, cu_count());
     hipStream_t s = (hipStream_t)stream;
 #define L2F(PRE, LMF, HB) hipLaunchKernelGGL((k_step2_full<PRE, LMF, HB>), dim3(grid), dim3(BLOCK), 0, s, \
-        (float4*)delta, (const float4*)p, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, (const float4*)b, n4, aN, aD, bN_out, q_out)
+        (float4*)delta, (const float4*)p, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, (const float4*)b, n4, aN, aD, bN_out, q_out, g_gate)
     const bool hp = pre != nullptr, hb = (b != nullptr && q_out != nullptr);
     if (hp) { if (lm) { if (hb) L2F(true, true, true); else L2F(true, true, false); } else { if (hb) L2F(true, false, true); else L2F(true, false, false); } }
     else    { if (lm) { if (hb) L2F(false, true, true); else L2F(false, true, false); } else { if (hb) L2F(false, false, true); else L2F(false, false, false); } }
@@ -526,7 +567,7 @@ int thallo_hip_pcg_pupdate_ranges(const float* z, const float* p_in, float* p_ou
     if ((off0 | len0 | off1 | len1) & 3) return -(int)hipErrorInvalidValue;
     const int grid = flat_grid((len0 + len1) / 4, cu_count());
     hipLaunchKernelGGL(k_pupdate, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)z, (const float4*)p_in, (float4*)p_out, (float4*)delta,
-                       off0 / 4, len0 / 4, off1 / 4, len1 / 4, first, aNp, aDp, bNp);
+                       off0 / 4, len0 / 4, off1 / 4, len1 / 4, first, aNp, aDp, bNp, g_gate);
     int e = check_launch();
     return e ? e : grid;
 }
@@ -568,13 +609,13 @@ int thallo_hip_lm_finalize_diagonal(const float* diag, float* SSq, float* CtC, f
 int thallo_hip_lm_step1_finish(float* Ap, const float* CtC, const float* p, long n, float* aD_out, thallo_stream_t stream)
 {
     const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
-    hipLaunchKernelGGL(k_lm_step1_finish, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)Ap, (const float4*)CtC, (const float4*)p, n4, aD_out);
+    hipLaunchKernelGGL(k_lm_step1_finish, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)Ap, (const float4*)CtC, (const float4*)p, n4, aD_out, g_gate);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_lm_step2_first_half(float* delta, const float* p, long n, thallo_sum_t aN, thallo_sum_t aD, thallo_stream_t stream)
 {
     const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
-    hipLaunchKernelGGL(k_lm_step2_first, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)delta, (const float4*)p, n4, aN, aD);
+    hipLaunchKernelGGL(k_lm_step2_first, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)delta, (const float4*)p, n4, aN, aD, g_gate);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_lm_step2_second_half(float* r, const float* b, const float* Adelta, const float* pre, float* z, const float* delta, long n,
@@ -582,7 +623,7 @@ int thallo_hip_lm_step2_second_half(float* r, const float* b, const float* Adelt
 {
     const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
     hipLaunchKernelGGL(k_lm_step2_second, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)b, (const float4*)Adelta,
-                       (const float4*)pre, (float4*)z, (const float4*)delta, n4, bN_out, q_out);
+                       (const float4*)pre, (float4*)z, (const float4*)delta, n4, bN_out, q_out, g_gate);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_pcg_init_finish(const float* r, const float* diag, float* pre, float* z, long n, int use_preconditioner,

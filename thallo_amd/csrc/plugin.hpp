@@ -40,6 +40,9 @@ private:
 struct LaunchCtx {
     hipStream_t stream = nullptr;
     KernelTimer* timer = nullptr;
+    // LM loop only: device word; non-zero = the PCG loop already ended on the device, an applyJTJ launch may return at once
+    // (plugins that take it: shape_from_shading, bundle_adjustment -- the two LM configurations; the others simply compute)
+    const unsigned* gate = nullptr;
 };
 
 // RAII bracket used by plugins / driver around each shim call.

@@ -542,7 +542,8 @@ public:
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_sfs_apply_jtj(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out, c.stream);
+        return thallo_hip_sfs_apply_jtj_gated(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
+                                              c.gate, c.stream);
     }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override

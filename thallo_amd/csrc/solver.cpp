@@ -475,11 +475,20 @@ int Plan::step_lm(int ev_iter)
 {   // gauss_newton.t:1545-1785 with every UsesLambda() branch taken; unfused (reference-shaped) PCG schedule because
     // q = 0.5 delta.(r+b) needs the current delta inside PCGStep2 and PCGStep1_Finish adds CtC*p.
     // Slots: 0 cost, 1 q, B.. as in GN (alphaN_k = B+2k, alphaD_k = B+2k+1, betaN_k = B+2k+2); last two: scratch dots.
+    //
+    // The zeta test (:1666-1686) runs ON THE DEVICE: all lIterations iterations are enqueued, a one-wave kernel behind each PCGStep2
+    // applies the test and sets the gate word, after which the remaining launches of the loop return at once; delta, r, z stay as of
+    // the break.  One read-back per GN step (iterations done, delta.J^T J delta, delta.b, new cost) instead of the reference's blocking
+    // 4-byte copy per PCG iteration (fetchQ :1146-1150).  THALLO_LM_HOST_ZETA=1 selects that blocking form (A/B; same iteration
+    // counts, same costs: tests/test_gpu_parity.py).
     if (ensure_lm_vectors()) return 0;
     hipStream_t s = ctx.stream;
     const int L = sp.lIterations, B = 2, QS = 1, T0 = 2 * L + 4, T1 = 2 * L + 5;
     const long n = v_.n;
     const bool pc = plugin->use_preconditioner();
+    const bool host_zeta = [] { const char* e = getenv("THALLO_LM_HOST_ZETA"); return e && e[0] == '1'; }();
+    float* lmst = (float*)scratch_.ptr + 16;                          // 8 words: Q0, gate, iterations done, | dJJd, db, new cost
+    const unsigned* gate = reinterpret_cast<const unsigned*>(lmst) + 1;
     const int ev_setup = timer_.start("Nonlinear Setup", s);
     if (sp.nIter == 0) { radius_ = sp.trust_region_radius; decrease_factor_ = sp.radius_decrease_factor; }   // :1185-1186 (copied at init)
     cur_ = 0;
@@ -492,28 +501,31 @@ int Plan::step_lm(int ev_iter)
     if (nb < 0) return 0;
     set_nb(B, nb);
     float Q0 = 0.0f;                                                  // delta = 0 -> q = 0 (:965)
+    if (thallo_hip_lm_state_reset(lmst, s) < 0) return 0;
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
     float* p = v_.p[0];
     int k_done = 0;
-    for (int k = 0; k < L; ++k) {
+    if (!host_zeta) { thallo_hip_lm_set_gate(gate); ctx.gate = gate; }
+    bool failed = false;
+    for (int k = 0; k < L && !failed; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         {   TimedLaunch t(ctx, "PCGStep3");                           // p = z + beta p  (k = 0: p = z)
             thallo_hip_pcg_pupdate(v_.z, p, p, nullptr, n, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
         }
         nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(T0));              // PCGStep1 (J^T J p)
-        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
+        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); failed = true; break; }
         {   TimedLaunch t(ctx, "PCGStep1_Finish");                    // + CtC p ; alphaD
             nb = thallo_hip_lm_step1_finish(v_.Ap, v_.CtC, p, n, slot(jD), s);
         }
-        if (nb < 0) return 0;
+        if (nb < 0) { failed = true; break; }
         set_nb(jD, nb);
         int nbq;
         if (((k + 1) % sp.residual_reset_period) == 0) {              // :1653-1657
             TimedLaunch t(ctx, "PCGStep2");
             thallo_hip_lm_step2_first_half(v_.delta, p, n, sum(jN), sum(jD), s);
             nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));             // computeAdelta
-            if (nb < 0) return 0;
+            if (nb < 0) { failed = true; break; }
             thallo_hip_lm_step1_finish(v_.Adelta, v_.CtC, v_.delta, n, slot(T1), s);
             nb = thallo_hip_lm_step2_second_half(v_.r, v_.b, v_.Adelta, v_.pre, v_.z, v_.delta, n, slot(jB), slot(QS), s);
             nbq = nb;
@@ -522,17 +534,23 @@ int Plan::step_lm(int ev_iter)
             nb = thallo_hip_pcg_step2_full(v_.delta, p, v_.r, v_.Ap, v_.pre, v_.z, v_.b, n, sum(jN), sum(jD), slot(jB), slot(QS), 1, s);
             nbq = nb;
         }
-        if (nb < 0) return 0;
+        if (nb < 0) { failed = true; break; }
         set_nb(jB, nb); set_nb(QS, nbq);
         k_done = k + 1;
-        const float Q1 = read_sum(QS);                                // :1666-1686 (blocking, as in the reference)
-        if (!std::isfinite(Q1)) break;
-        const float zeta = (float)(k + 1) * (Q1 - Q0) / Q1;
-        if (!std::isfinite(zeta)) break;
-        if (zeta < sp.q_tolerance) break;
-        Q0 = Q1;
+        if (host_zeta) {
+            const float Q1 = read_sum(QS);                            // :1666-1686 (blocking, as in the reference)
+            if (!std::isfinite(Q1)) break;
+            const float zeta = (float)(k + 1) * (Q1 - Q0) / Q1;
+            if (!std::isfinite(zeta)) break;
+            if (zeta < sp.q_tolerance) break;
+            Q0 = Q1;
+        } else {
+            TimedLaunch t(ctx, "PCGZeta");
+            if (thallo_hip_lm_zeta(sum(QS), k, sp.q_tolerance, lmst, s) < 0) { failed = true; break; }
+        }
     }
-    last_l_iters = k_done;
+    thallo_hip_lm_set_gate(nullptr); ctx.gate = nullptr;
+    if (failed) return 0;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
     // model_cost_change = cost - 0.5|F + J delta|^2 = delta.b - 0.5 delta.(J^T J delta)   (b = -J^T F; thallo.t:3845-3865
@@ -543,8 +561,8 @@ int Plan::step_lm(int ev_iter)
     nb = thallo_hip_dot(v_.delta, v_.b, n, slot(T1), s);
     if (nb < 0) return 0;
     set_nb(T1, nb);
-    const float dJJd = read_sum(T0), db = read_sum(T1);
-    const float model_cost_change = db - 0.5f * dJJd;
+    thallo_hip_finish_sum(sum(T0), lmst + 3, s);
+    thallo_hip_finish_sum(sum(T1), lmst + 4, s);
     const auto& imgs = plugin->unknown_images();
     {   long off = 0;                                                 // savePreviousUnknowns :915-920
         for (size_t k = 0; k < imgs.size(); ++k) {
@@ -559,7 +577,19 @@ int Plan::step_lm(int ev_iter)
             off += imgs[k].n_floats;
         }
     }
-    const float newCost = compute_cost();
+    {   // cost after the step, into the same report: ONE blocking read per GN step
+        const int nbc = plugin->cost(ctx, slot(0));
+        if (nbc < 0) { set_error("cost kernel launch failed (%d)", nbc); return 0; }
+        set_nb(0, nbc);
+        thallo_hip_finish_sum(sum(0), lmst + 5, s);
+    }
+    float rep[8] = { 0 };
+    HIP_OK(hipMemcpyAsync(rep, lmst, sizeof(rep), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (!host_zeta) { int frozen_at; memcpy(&frozen_at, &rep[2], sizeof(int)); unsigned fz; memcpy(&fz, &rep[1], sizeof(fz)); if (fz) k_done = frozen_at; }
+    last_l_iters = k_done;
+    const float dJJd = rep[3], db = rep[4], newCost = rep[5];
+    const float model_cost_change = db - 0.5f * dJJd;
     const float cost_change = prev_cost_ - newCost;
     const float relative_decrease = cost_change / model_cost_change;
     if (ip.verbosityLevel > 0) printf(" cost=%g new cost=%g model_cost_change=%g rho=%g radius=%g pcg=%d\n", prev_cost_, newCost, model_cost_change, relative_decrease, radius_, k_done);

@@ -245,6 +245,96 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
     if (MODE == 1 && s3_out) block_store_sums3(sm, s3_out, redd);
 }
 
+// ------------------------------------------------------------------------------------------ J^T (J p) with J p computed ONCE
+// k_gather<1> above reads every 96-byte J block twice and forms J p twice (once for the camera that owns the observation, once for
+// its point, gathered through pt_pos: uncoalesced 96-byte reads + 36 bytes of the camera's p per observation).  Here:
+//   k_cam2: one wave per camera (as before): full block, J p = J_cam p_cam + J_pt p_pt, camera part of J^T (J p); and (J p) goes out
+//           in POINT order (8-byte scatter through q_ptk, the position of observation q in its point's list);
+//   k_pt2 : one thread per point: its observations' point blocks (6 floats each, packed once per GN iteration in point order: JP) and
+//           their J p -- both contiguous per point: no index, no gather -- give the point part of J^T (J p).
+// Per observation: 96 + 12 (p of the point) + 8 (J p out) in the camera kernel, 24 + 8 in the point kernel = 148 B instead of
+// 2 x 96 + 48 of gathered p; two launches instead of one (the point kernel needs every camera's J p).
+__global__ __launch_bounds__(BLOCK) void k_inverse_perm(int O_, const int* __restrict__ pt_pos, int* __restrict__ q_ptk)
+{
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < O_; k += gridDim.x * BLOCK) q_ptk[pt_pos[k]] = k;
+}
+__global__ __launch_bounds__(BLOCK) void k_pack_point_blocks(int O_, const float4* __restrict__ Jb, const int* __restrict__ q_ptk, float2* __restrict__ JP)
+{
+    for (int q = blockIdx.x * BLOCK + threadIdx.x; q < O_; q += gridDim.x * BLOCK) {
+        const float4 a = Jb[6L * q + 2], b = Jb[6L * q + 5];       // (r0.d8, r0.d9, r0.d10, r0.d11), (r1.d8 .. r1.d11): entries 9..11 are the point's
+        float2* d = JP + 3L * q_ptk[q];
+        d[0] = make_float2(a.y, a.z); d[1] = make_float2(a.w, b.y); d[2] = make_float2(b.z, b.w);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ cam_ptr, const int* __restrict__ q_pt, const int* __restrict__ q_ptk,
+                                                const float4* __restrict__ Jb, const float* __restrict__ p, float* __restrict__ Ap, float2* __restrict__ JpP,
+                                                float* __restrict__ part_out, const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
+                                                const unsigned* __restrict__ gate)
+{
+    __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
+    float acc = 0.0f; Sums3 sm;
+    const long PB = 9L * C_;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = blockIdx.x * 4 + wave; c < C_; c += gridDim.x * 4) {
+        float s[9], pc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { s[k] = 0.0f; pc[k] = p[9L * c + k]; }
+        for (int q = cam_ptr[c] + lane; q < cam_ptr[c + 1]; q += 64) {
+            const Blk b = ld_blk(Jb, q);
+            const float* pp = p + PB + 3L * q_pt[q];
+            const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            float j0 = b.a[9] * p0 + b.a[10] * p1 + b.a[11] * p2, j1 = b.a[21] * p0 + b.a[22] * p1 + b.a[23] * p2;      // same order as k_gather<1>
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { j0 += b.a[k] * pc[k]; j1 += b.a[12 + k] * pc[k]; }
+            JpP[q_ptk[q]] = make_float2(j0, j1);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s[k] += b.a[k] * j0 + b.a[12 + k] * j1;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k] = wave_sum_all(s[k]);
+        if (lane < 9) {
+            float sv = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) if (lane == k) sv = s[k];
+            const long i = 9L * c + lane;
+            Ap[i] = sv;
+            acc += p[i] * sv;
+            if (s3_out) sm.add(prs[i], rs[i], sv);
+        }
+    }
+    block_store_partial(acc, part_out, red);
+    if (s3_out) block_store_sums3(sm, s3_out, redd);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __restrict__ pt_ptr, const float2* __restrict__ JP, const float2* __restrict__ JpP,
+                                               const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ part_out,
+                                               const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
+                                               const unsigned* __restrict__ gate)
+{
+    __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
+    float acc = 0.0f; Sums3 sm;
+    const long PB = 9L * C_;
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < P_; j += gridDim.x * BLOCK) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
+            const float2 a = JP[3L * k], b = JP[3L * k + 1], c = JP[3L * k + 2];        // (r0.d9, r0.d10), (r0.d11, r1.d9), (r1.d10, r1.d11)
+            const float2 jp = JpP[k];
+            s0 += a.x * jp.x + b.y * jp.y; s1 += a.y * jp.x + c.x * jp.y; s2 += b.x * jp.x + c.y * jp.y;
+        }
+        const long i = PB + 3L * j;
+        Ap[i] = s0; Ap[i + 1] = s1; Ap[i + 2] = s2;
+        acc += p[i] * s0 + p[i + 1] * s1 + p[i + 2] * s2;
+        if (s3_out) { sm.add(prs[i], rs[i], s0); sm.add(prs[i + 1], rs[i + 1], s1); sm.add(prs[i + 2], rs[i + 2], s2); }
+    }
+    block_store_partial(acc, part_out, red);
+    if (s3_out) block_store_sums3(sm, s3_out, redd);
+}
+
 inline void gather_shape(int C_, int P_, int& cam_blocks, int& grid)
 {
     cam_blocks = (C_ + 3) / 4; if (cam_blocks > 448) cam_blocks = 448;
@@ -301,6 +391,35 @@ int thallo_hip_ba_apply_jtj_sums(int C_, int P_, const int* cam_ptr, const int* 
     hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
                        (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out,
                        r, pre, s3_out);
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_ba_point_order(int O_, const int* pt_pos, int* q_ptk, thallo_stream_t stream)
+{
+    if (O_ < 1 || !pt_pos || !q_ptk) return -(int)hipErrorInvalidValue;
+    int grid = (O_ + BLOCK - 1) / BLOCK; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_inverse_perm, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, O_, pt_pos, q_ptk);
+    return check_launch();
+}
+
+int thallo_hip_ba_pack_point_blocks(int O_, const float* Jb, const int* q_ptk, float* JP, thallo_stream_t stream)
+{
+    if (O_ < 1 || !Jb || !q_ptk || !JP) return -(int)hipErrorInvalidValue;
+    int grid = (O_ + BLOCK - 1) / BLOCK; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_pack_point_blocks, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, O_, (const float4*)Jb, q_ptk, (float2*)JP);
+    return check_launch();
+}
+
+int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
+                             const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
+                             const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_stream_t stream)
+{
+    if (!cam_ptr || !q_pt || !q_ptk || !pt_ptr || !Jb || !JP || !JpP || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
+    if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
+    int cb, grid; gather_shape(C_, P_, cb, grid);
+    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, q_ptk, (const float4*)Jb, p, Ap, (float2*)JpP, aD_out, r, pre, s3_out, gate);
+    hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, (const float2*)JP, (const float2*)JpP, p, Ap, aD_out + cb, r, pre,
+                       s3_out ? s3_out + 3 * cb : nullptr, gate);
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 namespace thallo {
 
@@ -429,6 +430,14 @@ class BundleAdjustmentPlugin : public EnergyPlugin {
     std::vector<UnknownImage> imgs;
     float *cameras = nullptr, *points = nullptr; const float* obs = nullptr; const int *oToC = nullptr, *oToP = nullptr;
     DeviceBuffer cam_ptr, cam_obs, q_cam, q_pt, pt_ptr, pt_pos, Jb, F;
+    DeviceBuffer q_ptk, JP, JpP;          // J^T (J p) with J p formed once (thallo_hip_ba_apply_jtj2): point-order position per observation, packed point blocks, J p
+    bool once_ = true;                     // THALLO_BA_JP_ONCE=0: the one-kernel gather that forms J p on both sides (A/B switch)
+    int apply2(LaunchCtx& c, SolverVectors* v, const float* p, float* Ap, float* out)
+    {
+        return thallo_hip_ba_apply_jtj2(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)q_ptk.ptr, (const int*)pt_ptr.ptr,
+                                        (const float*)Jb.ptr, (const float*)JP.ptr, (float*)JpP.ptr, p, Ap, out,
+                                        v ? v->r : nullptr, v ? v->pre : nullptr, v ? v->s12 : nullptr, c.gate, c.stream);
+    }
 public:
     BundleAdjustmentPlugin(const unsigned* dims) : C((int)dims[0]), P((int)dims[1]), O((int)dims[2])
     { imgs.push_back({ 0, 9L * C }); imgs.push_back({ 1, 3L * P }); }
@@ -462,6 +471,11 @@ public:
         };
         if (up(cam_ptr, cp) || up(cam_obs, cobs) || up(q_cam, qc) || up(q_pt, qp) || up(pt_ptr, pp) || up(pt_pos, ppos)) { set_error("bundle_adjustment: upload failed"); return -1; }
         if (!Jb.ptr && (Jb.alloc(sizeof(float) * 24 * (size_t)O + 64) || F.alloc(sizeof(float) * 2 * (size_t)O + 64))) return -1;
+        { const char* e = getenv("THALLO_BA_JP_ONCE"); once_ = !(e && e[0] == '0'); }
+        if (once_) {
+            if (!q_ptk.ptr && (q_ptk.alloc(sizeof(int) * (size_t)O + 64) || JP.alloc(sizeof(float) * 6 * (size_t)O + 64) || JpP.alloc(sizeof(float) * 2 * (size_t)O + 64))) return -1;
+            if (thallo_hip_ba_point_order(O, (const int*)pt_pos.ptr, (int*)q_ptk.ptr, nullptr) < 0 || hipDeviceSynchronize() != hipSuccess) { set_error("bundle_adjustment: point order failed"); return -1; }
+        }
         return 0;
     }
     float* unknown_ptr(int k) override { return k == 0 ? cameras : points; }
@@ -471,7 +485,8 @@ public:
     {
         { TimedLaunch t(c, "precomputeJ");
           int rc = thallo_hip_ba_compute_j(O, cameras, points, obs, (const int*)cam_obs.ptr, (const int*)q_cam.ptr, (const int*)q_pt.ptr, (float*)Jb.ptr, (float*)F.ptr, c.stream);
-          if (rc < 0) return rc; }
+          if (rc < 0) return rc;
+          if (once_ && (rc = thallo_hip_ba_pack_point_blocks(O, (const float*)Jb.ptr, (const int*)q_ptk.ptr, (float*)JP.ptr, c.stream)) < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_ba_pcg_init(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                       (const float*)Jb.ptr, (const float*)F.ptr, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
@@ -479,6 +494,7 @@ public:
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
+        if (once_) return apply2(c, nullptr, p, Ap, out);
         return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                        (const float*)Jb.ptr, p, Ap, out, c.stream);
     }
@@ -486,6 +502,7 @@ public:
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
+        if (once_) return apply2(c, &v, p, Ap, out);
         return thallo_hip_ba_apply_jtj_sums(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                             (const float*)Jb.ptr, p, Ap, out, v.r, v.pre, v.s12, c.stream);
     }
@@ -493,6 +510,7 @@ public:
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
+        if (once_) return apply2(c, nullptr, v.p[cur ^ 1], v.Ap, out);
         return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                        (const float*)Jb.ptr, v.p[cur ^ 1], v.Ap, out, c.stream);
     }

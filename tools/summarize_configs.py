@@ -1,0 +1,56 @@
+"""rocprofv3 outputs of tools/profile_configs.sh (gpurun_out/cfg_*) -> profiles/<round>/secondary_kernel_stats.csv (the --stats table) and
+secondary_kernels.json: per hot kernel the average duration, the corrected HBM-side traffic (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md
+HBM section) per launch, the rate that gives and its fraction of the 8 TB/s peak, next to the algorithmic bytes DESIGN.md section 4 defines."""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+out = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(out, exist_ok=True)
+g = os.path.join(ROOT, "gpurun_out")
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+shutil.copy(newest(os.path.join(g, "cfg_kt", "*", "*_kernel_stats.csv")), os.path.join(out, "secondary_kernel_stats.csv"))
+if os.path.exists(os.path.join(g, "secondary_configs.json")):
+    shutil.copy(os.path.join(g, "secondary_configs.json"), os.path.join(out, "secondary_configs.json"))
+
+# kernel-name fragment -> (label, algorithmic bytes per launch at the profiled size or None)
+NPX = 2048 * 2048
+O_BA = 678718
+KEYS = [("k_fused<1>", "shape_from_shading applyJTJ (fused, 2048^2)", 33 * NPX),
+        ("k_fused<0>", "shape_from_shading PCGInit1 J^T F (fused, 2048^2)", None),
+        ("k_cam2", "bundle_adjustment J^T(Jp) camera kernel (ladybug-1723 shape)", 116 * O_BA),
+        ("k_pt2", "bundle_adjustment J^T(Jp) point kernel (ladybug-1723 shape)", 32 * O_BA),
+        ("k_apply", "ARAP applyJTJ (102,400 vertices)", None),
+        ("k_pcg_update", "PCGUpdate (flat)", None)]
+dur = collections.defaultdict(list)
+kt = newest(os.path.join(g, "cfg_kt", "*", "*_kernel_trace.csv"))
+for row in csv.DictReader(open(kt)):
+    for key, lab, _ in KEYS:
+        if key in row["Kernel_Name"]:
+            dur[lab].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+pmc = collections.defaultdict(dict)
+for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = newest(os.path.join(g, f"cfg_{kind}", "*", "*_counter_collection.csv"))
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] != ctr:
+            continue
+        for key, lab, _ in KEYS:
+            if key in row["Kernel_Name"]:
+                agg[lab].append(float(row["Counter_Value"]))
+    for lab, v in agg.items():
+        pmc[lab][ctr + "_KB_mean"] = sum(v) / len(v)
+res = {}
+for key, lab, alg in KEYS:
+    if lab not in dur:
+        continue
+    d = sorted(dur[lab]); us = sum(d) / len(d)
+    e = {"launches": len(d), "avg_us": round(us, 2), "median_us": round(d[len(d) // 2], 2)}
+    if "FETCH_SIZE_KB_mean" in pmc[lab] and "WRITE_SIZE_KB_mean" in pmc[lab]:
+        b = (2.0 * pmc[lab]["FETCH_SIZE_KB_mean"] + pmc[lab]["WRITE_SIZE_KB_mean"]) * 1024.0
+        e.update(traffic_bytes_per_launch=b, traffic_GBps=round(b / us * 1e-3, 1), frac_of_8TBps_on_traffic=round(b / us * 1e-3 / 8000.0, 3))
+    if alg:
+        e.update(algorithmic_bytes_per_launch=alg, algorithmic_GBps=round(alg / us * 1e-3, 1), frac_of_8TBps_algorithmic=round(alg / us * 1e-3 / 8000.0, 3))
+    res[lab] = e
+json.dump(res, open(os.path.join(out, "secondary_kernels.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -118,6 +118,12 @@ const char* ThalloX_LastError(void);
 int ThalloX_ProblemFileSchedule(const char* filename);
 unsigned long long ThalloX_ProblemFileHash(const char* filename, char* energy_out, int cap);
 
+/* The mini front-end (thallo_amd/csrc/dsl.hpp) run on a .t file without a device: what = 0 its declarations as text, 1 the HIP translation unit it
+ * generates (residual-wise cost / evalJTF / applyJTJ / applyJ / applyJt kernels per named residual).  Returns the text's length (the copy is truncated
+ * to cap - 1) or -1 (ThalloX_LastError).  A Plan on a file no hand-written plugin recognises -- or on any file under THALLO_FRONTEND=generate -- compiles
+ * that unit with hipRTC and runs it. */
+int ThalloX_FrontendText(const char* filename, int what, char* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,74 @@
+"""The mini front-end for .t problem specifications (thallo_amd/csrc/dsl*.{hpp,cpp}) without a GPU: it executes the
+bundled energy files (a Lua subset + the DSL's constructors and lib.t helpers as builtins), reports their declarations, generates one HIP
+translation unit per file -- and that unit compiles for gfx950."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+import thallo_amd
+from thallo_amd import api
+
+ENERGIES = ["laplacian_image", "laplacian_graph", "image_warping", "arap_mesh_deformation", "bundle_adjustment", "shape_from_shading"]
+
+
+def _text(path, what):
+    L = api.lib()
+    L.ThalloX_FrontendText.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]; L.ThalloX_FrontendText.restype = C.c_int
+    buf = C.create_string_buffer(1 << 20)
+    n = L.ThalloX_FrontendText(path.encode(), what, buf, len(buf))
+    assert n >= 0, api.last_error()
+    assert n < len(buf)
+    return buf.value.decode()
+
+
+def test_declarations_of_the_bundled_energies():
+    d = _text(thallo_amd.energy_file("image_warping"), 0)
+    assert "dims: W H" in d and "unknown Offset slot 0 channels 2 over W H (Exclude)" in d and "unknown Angle slot 1 channels 1 over W H (Exclude)" in d
+    assert "param w_fitSqrt slot 5" in d and "preconditioner 1" in d
+    for r in ("reg_px", "reg_nx", "reg_py", "reg_ny", "fit"):
+        assert f"residual {r} x2 over W H" in d
+    d = _text(thallo_amd.energy_file("arap_mesh_deformation"), 0)
+    assert "sparse V0 slot 6 E -> N" in d and "residual fit x3 over N" in d and "residual reg x3 over E" in d
+    d = _text(thallo_amd.energy_file("bundle_adjustment"), 0)
+    assert "unknown cameras slot 0 channels 9 over C" in d and "residual snavely_reprojection_error x2 over O" in d
+    d = _text(thallo_amd.energy_file("shape_from_shading"), 0)
+    assert "array edgeMaskR slot 19 channels 1 uint8 over W H" in d and "residual reg x3 over W H" in d and "preconditioner 0" in d
+    d = _text(thallo_amd.energy_file("laplacian_image"), 0)
+    assert "residual fit x1 over W H" in d and "residual reg x2 over W H" in d
+
+
+def test_schedule_lines_are_recorded(tmp_path):
+    """r.<name>.J / JtJ / Jp :set_materialize(true) (the surface tests/minimal/laplacian.t:16-20 and tests/minimal_graph/laplacian.t:19-20 use)"""
+    src = open(thallo_amd.energy_file("laplacian_graph")).read()
+    f = tmp_path / "sched.t"
+    f.write_text(src + "\nr.fit.J:set_materialize(true)\nr.fit.JtJ:set_materialize(true)\nr.reg.Jp:set_materialize(true)\n")
+    d = _text(str(f), 0)
+    assert "residual fit x1 over N J JtJ" in d and "residual reg x1 over E Jp" in d
+
+
+def test_unsupported_constructs_are_errors_not_guesses(tmp_path):
+    L = api.lib()
+    L.ThalloX_FrontendText.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]; L.ThalloX_FrontendText.restype = C.c_int
+    buf = C.create_string_buffer(4096)
+    for name, body, needle in (
+            ("undefined.t", 'local W = Dims("W")\nInputs { X = Unknown(float,{W},0) }\nlocal x = W()\nr = Residuals { a = Frobnicate(X(x)) }\n', "Frobnicate"),
+            ("syntax.t", 'local W = Dims("W"\n', "expected"),
+            ("nounknown.t", 'local W = Dims("W")\nInputs { A = Array(float,{W},0) }\nlocal x = W()\nr = Residuals { a = A(x) }\n', "no Unknown"),
+            ("threed.t", 'local W,H,D = Dims("W","H","D")\nInputs { X = Unknown(float,{W,H,D},0) }\n', "1- and 2-dimensional")):
+        f = tmp_path / name
+        f.write_text(body)
+        assert L.ThalloX_FrontendText(str(f).encode(), 0, buf, len(buf)) == -1
+        assert needle in api.last_error(), api.last_error()
+
+
+@pytest.mark.parametrize("energy", ENERGIES)
+def test_generated_kernels_compile_for_gfx950(energy, tmp_path):
+    src = _text(thallo_amd.energy_file(energy), 1)
+    assert 'extern "C" __global__' in src and "jtj_0" in src and "applyjt_0" in src
+    f = tmp_path / (energy + ".hip")
+    f.write_text(src)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-munsafe-fp-atomics", "-c", str(f), "-o", str(tmp_path / "o.o")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -1,0 +1,94 @@
+// dsl.hpp -- the mini front-end for `.t` problem specifications.
+//
+// The reference executes a `.t` file in a Lua/Terra sandbox whose globals are the DSL (API/src/thallo.t:1359-1434, 1580-2112;
+// API/src/lib.t:18-594): the file's operators build an expression graph, API/src/ad.t differentiates it symbolically and
+// thallo.t:3536-3949 emits residual-wise kernels through Terra -> PTX.  Here:
+//   dsl_lua.cpp     a small interpreter for the Lua subset the energy files use (locals, tables, functions / closures, for-in over
+//                   Stencil{}, method calls), with the DSL's constructors and the lib.t helpers as builtins; running a file yields a
+//                   `Problem`: declarations + one scalar expression DAG per residual component;
+//   dsl_codegen.cpp emits ONE HIP translation unit per problem: per named residual a cost / evalJTF / applyJTJ (and applyJ / applyJt)
+//                   kernel in the reference's residual-wise form (thallo.t:3536-3569, 3867-3908, 3939-3949).  Derivatives come from
+//                   forward-mode dual numbers over the residual's unknown accesses -- the rules of ad.t:698-836 applied at run time
+//                   instead of symbolically (Select: partials (0, c, not c), comparisons: zero derivative);
+//   dsl_plugin.cpp  compiles that unit with hipRTC for gfx950 at Plan time and drives it through the EnergyPlugin interface
+//                   (unfused PCG schedule; scatter-adds are float atomics, exactly the reference's residual-wise lowering).
+// Hand-written plugins stay the fast path for the bundled energies; a file they do not recognise -- or any file under
+// THALLO_FRONTEND=generate -- goes through here.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace thallo {
+namespace dsl {
+
+enum class Op {
+    Const, Param, Load, IndexVal,                  // leaves: literal, scalar Param, image access, iteration index as a value (x:asvalue())
+    Add, Sub, Mul, Div, Neg, Sqrt, Sin, Cos, Abs, Pow,
+    Select,                                        // a[0] != 0 ? a[1] : a[2]
+    Eq, Ge, Gt, Le, Lt, Not, And, Or,              // 0 / 1 valued, zero derivative (ad.t:824-829)
+    InBounds                                       // all index components inside the iteration-dimension bounds (thallo.t:1993-1997)
+};
+
+// one component of an image index: iteration variable of dimension `dim` plus a constant offset, optionally through a Sparse map
+// (graph domains: X(v0(e)): dim = the edge dimension, sparse = input slot of v0; the offset applies before the map and is 0 there)
+struct IndexComp { int dim = -1; int off = 0; int sparse = -1; };
+inline bool operator==(const IndexComp& a, const IndexComp& b) { return a.dim == b.dim && a.off == b.off && a.sparse == b.sparse; }
+
+struct Expr;
+typedef std::shared_ptr<const Expr> E;
+struct Expr {
+    Op op = Op::Const;
+    double c = 0.0;                                // Const
+    int input = -1;                                // Param / Load: index into Problem::inputs
+    int channel = 0;                               // Load
+    std::vector<IndexComp> idx;                    // Load / InBounds ; IndexVal: idx[0]
+    int expand = 0;                                // InBounds: InBoundsExpanded(x, y, n) keeps n pixels off the border
+    std::vector<E> a;                              // operands
+};
+
+enum class InputKind { Unknown, Array, Sparse, Param };
+struct Input {
+    std::string name;
+    InputKind kind = InputKind::Array;
+    int channels = 1;
+    bool is_u8 = false;                            // Array(uint8, ...)
+    std::vector<int> dims;                         // dimension ids (Unknown / Array: the image's; Sparse: {from, to})
+    int slot = -1;                                 // index into the void** problem parameters
+    E exclude;                                     // Unknown:Exclude(cond), evaluated at the unknown's own index (may be null)
+};
+
+struct Residual {
+    std::string name;
+    std::vector<E> exprs;                          // scalar components
+    std::vector<int> domain;                       // iteration dimensions (ids), in first-use order
+    bool mat_J = false, mat_JtJ = false, mat_Jp = false;   // r.<name>.J / JtJ / Jp :set_materialize(true) (thallo.t:5757-5772)
+};
+
+struct Problem {
+    std::string file;
+    std::vector<std::string> dims;                 // Dims("W","H"): ids are positions; sizes come from the unsigned[] at Plan time
+    std::vector<Input> inputs;                     // in Inputs{} order (= declaration order of the unknown images in the flat vectors)
+    bool use_preconditioner = false;
+    std::vector<Residual> residuals;
+    int max_slot = -1;
+};
+
+// dsl_lua.cpp: run a .t file.  false + `err` on anything outside the supported subset (never a silent partial result).
+bool run_problem_file(const char* filename, Problem& out, std::string& err);
+
+// dsl_codegen.cpp
+struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 cost, 1 evalJTF, 2 applyJTJ, 3 applyJ (Jp = J p), 4 applyJt (Ap += J^T Jp)
+struct Generated {
+    std::string source;                            // one HIP translation unit
+    std::vector<GenKernel> kernels;
+    std::vector<long> jp_offset;                   // per residual: offset of its rows in the Jp vector (Jt[Jp] schedule), in units of elements x components
+    int n_prm = 0;
+};
+bool generate_source(const Problem& p, Generated& out, std::string& err);
+
+std::string describe(const Problem& p);            // one-line-per-declaration summary (tests / verbosity)
+
+}  // namespace dsl
+}  // namespace thallo

@@ -1,0 +1,920 @@
+// dsl_lua.cpp -- interpreter for the Lua subset the Thallo energy files use; see dsl.hpp.
+//
+// What the reference's sandbox provides and this file restates as builtins (all citations relative to /root/reference/API/src):
+//   Dims / Inputs / Unknown / Array / Sparse / Param / UsePreconditioner / Residuals      thallo.t:1580-2112, 5541-5631
+//   image(ix, iy), sparse(e), dim(), x:asvalue(), Unknown:Exclude(c), expr:get(ix, iy)      thallo.t:1993-1997, 2091-2112, 2925-2943
+//   Select, InBounds, InBoundsExpanded, eq / greater / greatereq / less / lesseq, Not, All, Any, abs, sqrt, sin, cos, Vector, dot,
+//   cross, Rotate2D, Rotate3D, AngleAxisRotatePoint, Stencil, vec:slice(a, b), vec(i)       lib.t:18-594 (Rotate3D :123-137,
+//                                                                                          Rotate2D :138-142, AngleAxisRotatePoint :514-555)
+//   r.<name>.J / JtJ / Jp :set_materialize(b), r:merge(a, b), :compute_at_output(b)         thallo.t:5661-5772
+// Lua itself: locals and globals, multiple assignment and multiple returns, tables (constructors, #t, t[k], t.k), functions and
+// closures, numeric for, for-in over Stencil{} / ipairs / pairs, if / elseif / else, while, return, break, method calls, string and
+// number literals, comments.  Not supported (-> an error naming the construct): metatables, coroutines, goto, varargs, string library.
+#include "dsl.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <sstream>
+#include <stdexcept>
+
+namespace thallo {
+namespace dsl {
+
+namespace {
+
+[[noreturn]] void fail(const std::string& m) { throw std::runtime_error(m); }
+
+// ================================================================================================ lexer
+struct Tok { enum K { Name, Num, Str, Op, Kw, End } k = End; std::string s; double n = 0; int line = 0; };
+
+const char* KEYWORDS[] = { "and", "break", "do", "else", "elseif", "end", "false", "for", "function", "if", "in", "local", "nil", "not", "or",
+                           "repeat", "return", "then", "true", "until", "while", nullptr };
+
+std::vector<Tok> lex(const std::string& src)
+{
+    std::vector<Tok> out; size_t i = 0; int line = 1;
+    if (src.size() >= 3 && (unsigned char)src[0] == 0xEF && (unsigned char)src[1] == 0xBB && (unsigned char)src[2] == 0xBF) i = 3;
+    auto long_bracket = [&](size_t j, std::string* text) -> size_t {     // src[j] == '[': returns index after the closing bracket, or 0
+        size_t k = j + 1; int eq = 0;
+        while (k < src.size() && src[k] == '=') { ++eq; ++k; }
+        if (k >= src.size() || src[k] != '[') return 0;
+        const std::string close = "]" + std::string(eq, '=') + "]";
+        const size_t e = src.find(close, k + 1);
+        if (e == std::string::npos) fail("unterminated long bracket");
+        for (size_t q = k + 1; q < e; ++q) if (src[q] == '\n') ++line;
+        if (text) *text = src.substr(k + 1, e - k - 1);
+        return e + close.size();
+    };
+    while (i < src.size()) {
+        const unsigned char c = src[i];
+        if (c == '\n') { ++line; ++i; continue; }
+        if (isspace(c)) { ++i; continue; }
+        if (c == '-' && i + 1 < src.size() && src[i + 1] == '-') {
+            if (i + 2 < src.size() && src[i + 2] == '[') { const size_t e = long_bracket(i + 2, nullptr); if (e) { i = e; continue; } }
+            while (i < src.size() && src[i] != '\n') ++i;
+            continue;
+        }
+        Tok t; t.line = line;
+        if (isalpha(c) || c == '_') {
+            size_t j = i; while (j < src.size() && (isalnum((unsigned char)src[j]) || src[j] == '_')) ++j;
+            t.s = src.substr(i, j - i); t.k = Tok::Name;
+            for (int q = 0; KEYWORDS[q]; ++q) if (t.s == KEYWORDS[q]) t.k = Tok::Kw;
+            i = j;
+        } else if (isdigit(c) || (c == '.' && i + 1 < src.size() && isdigit((unsigned char)src[i + 1]))) {
+            char* endp = nullptr; t.n = strtod(src.c_str() + i, &endp); t.k = Tok::Num;
+            size_t j = endp - src.c_str();
+            if (j < src.size() && (src[j] == 'f' || src[j] == 'F')) ++j;      // tolerate a C-style suffix
+            t.s = src.substr(i, j - i); i = j;
+        } else if (c == '"' || c == '\'') {
+            size_t j = i + 1; std::string v;
+            while (j < src.size() && src[j] != (char)c) { if (src[j] == '\\' && j + 1 < src.size()) { ++j; v += src[j] == 'n' ? '\n' : src[j]; } else v += src[j]; ++j; }
+            if (j >= src.size()) fail("unterminated string at line " + std::to_string(line));
+            t.k = Tok::Str; t.s = v; i = j + 1;
+        } else if (c == '[' && i + 1 < src.size() && (src[i + 1] == '[' || src[i + 1] == '=')) {
+            std::string v; const size_t e = long_bracket(i, &v);
+            if (e) { t.k = Tok::Str; t.s = v; i = e; } else { t.k = Tok::Op; t.s = "["; ++i; }
+        } else {
+            static const char* OPS3[] = { "...", nullptr };
+            static const char* OPS2[] = { "==", "~=", "<=", ">=", "..", "::", nullptr };
+            t.k = Tok::Op; t.s = std::string(1, (char)c);
+            bool done = false;
+            for (int q = 0; OPS3[q] && !done; ++q) if (src.compare(i, 3, OPS3[q]) == 0) { t.s = OPS3[q]; i += 3; done = true; }
+            for (int q = 0; OPS2[q] && !done; ++q) if (src.compare(i, 2, OPS2[q]) == 0) { t.s = OPS2[q]; i += 2; done = true; }
+            if (!done) ++i;
+        }
+        out.push_back(t);
+    }
+    Tok e; e.k = Tok::End; e.line = line; out.push_back(e);
+    return out;
+}
+
+// ================================================================================================ AST
+struct Node;
+typedef std::shared_ptr<Node> NP;
+struct Node {
+    enum K { Nil, True, False, Number, String, Function, Name, Index, Call, Method, Binop, Unop, Table, Paren,
+             Local, Assign, CallStat, Do, While, NumFor, GenFor, If, FuncStat, Return, Break, Block } k;
+    int line = 0;
+    double num = 0; std::string s;                 // literal / name / operator / method name
+    std::vector<NP> a;                             // children (meaning per kind, see the parser)
+    std::vector<std::string> names;                // Local / GenFor / NumFor variable names ; Function parameter names
+    std::vector<NP> keys;                          // Table: key expression per field (null = positional)
+    bool is_local = false;
+    explicit Node(K kk, int ln) : k(kk), line(ln) {}
+};
+
+struct Parser {
+    std::vector<Tok> t; size_t p = 0;
+    explicit Parser(std::vector<Tok> toks) : t(std::move(toks)) {}
+    const Tok& cur() const { return t[p]; }
+    bool is_op(const char* s) const { return cur().k == Tok::Op && cur().s == s; }
+    bool is_kw(const char* s) const { return cur().k == Tok::Kw && cur().s == s; }
+    [[noreturn]] void err(const std::string& m) const { fail("line " + std::to_string(cur().line) + ": " + m + " near '" + cur().s + "'"); }
+    void expect_op(const char* s) { if (!is_op(s)) err(std::string("expected '") + s + "'"); ++p; }
+    void expect_kw(const char* s) { if (!is_kw(s)) err(std::string("expected '") + s + "'"); ++p; }
+    std::string expect_name() { if (cur().k != Tok::Name) err("expected a name"); return t[p++].s; }
+
+    NP block()
+    {
+        NP b = std::make_shared<Node>(Node::Block, cur().line);
+        for (;;) {
+            if (cur().k == Tok::End || is_kw("end") || is_kw("else") || is_kw("elseif") || is_kw("until")) break;
+            if (is_op(";")) { ++p; continue; }
+            NP s = statement();
+            b->a.push_back(s);
+            if (s->k == Node::Return || s->k == Node::Break) { if (is_op(";")) ++p; break; }
+        }
+        return b;
+    }
+    NP funcbody(int line)
+    {
+        NP f = std::make_shared<Node>(Node::Function, line);
+        expect_op("(");
+        if (!is_op(")")) for (;;) { if (is_op("...")) err("varargs are not supported"); f->names.push_back(expect_name()); if (is_op(",")) { ++p; continue; } break; }
+        expect_op(")");
+        f->a.push_back(block());
+        expect_kw("end");
+        return f;
+    }
+    std::vector<NP> exprlist() { std::vector<NP> v; v.push_back(expr()); while (is_op(",")) { ++p; v.push_back(expr()); } return v; }
+
+    NP statement()
+    {
+        const int line = cur().line;
+        if (is_kw("local")) {
+            ++p;
+            if (is_kw("function")) {
+                ++p; NP s = std::make_shared<Node>(Node::FuncStat, line); s->is_local = true;
+                NP nm = std::make_shared<Node>(Node::Name, line); nm->s = expect_name();
+                s->a.push_back(nm); s->a.push_back(funcbody(line)); return s;
+            }
+            NP s = std::make_shared<Node>(Node::Local, line);
+            s->names.push_back(expect_name());
+            while (is_op(",")) { ++p; s->names.push_back(expect_name()); }
+            if (is_op("=")) { ++p; s->a = exprlist(); }
+            return s;
+        }
+        if (is_kw("function")) {
+            ++p; NP s = std::make_shared<Node>(Node::FuncStat, line);
+            NP target = std::make_shared<Node>(Node::Name, line); target->s = expect_name();
+            while (is_op(".")) { ++p; NP ix = std::make_shared<Node>(Node::Index, line); NP key = std::make_shared<Node>(Node::String, line); key->s = expect_name(); ix->a = { target, key }; target = ix; }
+            if (is_op(":")) err("method definitions are not supported");
+            s->a.push_back(target); s->a.push_back(funcbody(line)); return s;
+        }
+        if (is_kw("if")) {
+            ++p; NP s = std::make_shared<Node>(Node::If, line);
+            s->a.push_back(expr()); expect_kw("then"); s->a.push_back(block());
+            while (is_kw("elseif")) { ++p; s->a.push_back(expr()); expect_kw("then"); s->a.push_back(block()); }
+            if (is_kw("else")) { ++p; s->a.push_back(nullptr); s->a.push_back(block()); }
+            expect_kw("end"); return s;
+        }
+        if (is_kw("while")) { ++p; NP s = std::make_shared<Node>(Node::While, line); s->a.push_back(expr()); expect_kw("do"); s->a.push_back(block()); expect_kw("end"); return s; }
+        if (is_kw("do")) { ++p; NP s = std::make_shared<Node>(Node::Do, line); s->a.push_back(block()); expect_kw("end"); return s; }
+        if (is_kw("for")) {
+            ++p; std::vector<std::string> names; names.push_back(expect_name());
+            if (is_op("=")) {
+                ++p; NP s = std::make_shared<Node>(Node::NumFor, line); s->names = names;
+                s->a.push_back(expr()); expect_op(","); s->a.push_back(expr());
+                if (is_op(",")) { ++p; s->a.push_back(expr()); } else s->a.push_back(nullptr);
+                expect_kw("do"); s->a.push_back(block()); expect_kw("end"); return s;
+            }
+            while (is_op(",")) { ++p; names.push_back(expect_name()); }
+            expect_kw("in");
+            NP s = std::make_shared<Node>(Node::GenFor, line); s->names = names;
+            s->a = exprlist();
+            expect_kw("do"); NP body = block(); expect_kw("end");
+            s->a.push_back(body); return s;
+        }
+        if (is_kw("return")) {
+            ++p; NP s = std::make_shared<Node>(Node::Return, line);
+            if (!(cur().k == Tok::End || is_kw("end") || is_kw("else") || is_kw("elseif") || is_kw("until") || is_op(";"))) s->a = exprlist();
+            return s;
+        }
+        if (is_kw("break")) { ++p; return std::make_shared<Node>(Node::Break, line); }
+        if (is_kw("repeat") || is_kw("goto")) err("statement not supported");
+        // assignment or call
+        NP e = suffixedexp();
+        if (is_op("=") || is_op(",")) {
+            NP s = std::make_shared<Node>(Node::Assign, line);
+            std::vector<NP> targets{ e };
+            while (is_op(",")) { ++p; targets.push_back(suffixedexp()); }
+            expect_op("=");
+            std::vector<NP> vals = exprlist();
+            s->keys = targets; s->a = vals;
+            for (auto& tg : targets) if (tg->k != Node::Name && tg->k != Node::Index) err("cannot assign to this expression");
+            return s;
+        }
+        if (e->k != Node::Call && e->k != Node::Method) err("syntax error (expression is not a statement)");
+        NP s = std::make_shared<Node>(Node::CallStat, line); s->a.push_back(e); return s;
+    }
+
+    NP primaryexp()
+    {
+        const int line = cur().line;
+        if (cur().k == Tok::Name) { NP n = std::make_shared<Node>(Node::Name, line); n->s = t[p++].s; return n; }
+        if (is_op("(")) { ++p; NP e = expr(); expect_op(")"); NP pr = std::make_shared<Node>(Node::Paren, line); pr->a.push_back(e); return pr; }
+        err("unexpected symbol");
+    }
+    std::vector<NP> callargs()
+    {
+        std::vector<NP> args;
+        if (cur().k == Tok::Str) { NP s = std::make_shared<Node>(Node::String, cur().line); s->s = t[p++].s; args.push_back(s); return args; }
+        if (is_op("{")) { args.push_back(tablector()); return args; }
+        expect_op("(");
+        if (!is_op(")")) args = exprlist();
+        expect_op(")");
+        return args;
+    }
+    NP suffixedexp()
+    {
+        NP e = primaryexp();
+        for (;;) {
+            const int line = cur().line;
+            if (is_op(".")) { ++p; NP ix = std::make_shared<Node>(Node::Index, line); NP key = std::make_shared<Node>(Node::String, line); key->s = expect_name(); ix->a = { e, key }; e = ix; }
+            else if (is_op("[")) { ++p; NP ix = std::make_shared<Node>(Node::Index, line); NP key = expr(); expect_op("]"); ix->a = { e, key }; e = ix; }
+            else if (is_op(":")) { ++p; NP m = std::make_shared<Node>(Node::Method, line); m->s = expect_name(); m->a.push_back(e); for (auto& x : callargs()) m->a.push_back(x); e = m; }
+            else if (is_op("(") || is_op("{") || cur().k == Tok::Str) { NP c = std::make_shared<Node>(Node::Call, line); c->a.push_back(e); for (auto& x : callargs()) c->a.push_back(x); e = c; }
+            else return e;
+        }
+    }
+    NP tablector()
+    {
+        NP tb = std::make_shared<Node>(Node::Table, cur().line);
+        expect_op("{");
+        while (!is_op("}")) {
+            if (cur().k == Tok::Name && t[p + 1].k == Tok::Op && t[p + 1].s == "=") {
+                NP key = std::make_shared<Node>(Node::String, cur().line); key->s = t[p].s; p += 2;
+                tb->keys.push_back(key); tb->a.push_back(expr());
+            } else if (is_op("[")) { ++p; NP key = expr(); expect_op("]"); expect_op("="); tb->keys.push_back(key); tb->a.push_back(expr()); }
+            else { tb->keys.push_back(nullptr); tb->a.push_back(expr()); }
+            if (is_op(",") || is_op(";")) ++p; else break;
+        }
+        expect_op("}");
+        return tb;
+    }
+    NP simpleexp()
+    {
+        const int line = cur().line;
+        if (cur().k == Tok::Num) { NP n = std::make_shared<Node>(Node::Number, line); n->num = t[p++].n; return n; }
+        if (cur().k == Tok::Str) { NP n = std::make_shared<Node>(Node::String, line); n->s = t[p++].s; return n; }
+        if (is_kw("nil")) { ++p; return std::make_shared<Node>(Node::Nil, line); }
+        if (is_kw("true")) { ++p; return std::make_shared<Node>(Node::True, line); }
+        if (is_kw("false")) { ++p; return std::make_shared<Node>(Node::False, line); }
+        if (is_op("{")) return tablector();
+        if (is_kw("function")) { ++p; return funcbody(line); }
+        if (is_op("...")) err("varargs are not supported");
+        return suffixedexp();
+    }
+    static int binprec(const Tok& tk, int& right)
+    {
+        right = 0;
+        if (tk.k == Tok::Kw) { if (tk.s == "or") return 1; if (tk.s == "and") return 2; return 0; }
+        if (tk.k != Tok::Op) return 0;
+        const std::string& s = tk.s;
+        if (s == "<" || s == ">" || s == "<=" || s == ">=" || s == "~=" || s == "==") return 3;
+        if (s == "..") { right = 1; return 5; }
+        if (s == "+" || s == "-") return 6;
+        if (s == "*" || s == "/" || s == "%") return 7;
+        if (s == "^") { right = 1; return 10; }
+        return 0;
+    }
+    NP subexpr(int limit)
+    {
+        NP left;
+        const int line = cur().line;
+        if (is_kw("not") || is_op("-") || is_op("#")) {
+            NP u = std::make_shared<Node>(Node::Unop, line); u->s = t[p++].s;
+            u->a.push_back(subexpr(8)); left = u;
+        } else left = simpleexp();
+        for (;;) {
+            int right; const int prec = binprec(cur(), right);
+            if (prec == 0 || prec <= limit) break;
+            NP b = std::make_shared<Node>(Node::Binop, cur().line); b->s = t[p++].s;
+            NP rhs = subexpr(right ? prec - 1 : prec);
+            b->a = { left, rhs }; left = b;
+        }
+        return left;
+    }
+    NP expr() { return subexpr(0); }
+};
+
+// ================================================================================================ values
+struct Value;
+struct TableV { std::vector<Value> arr; std::vector<std::pair<std::string, Value>> fields; };       // arr: 1-based positional part; fields keep insertion order
+struct Env;
+struct FuncV { int builtin = -1; std::string bname; NP def; std::shared_ptr<Env> env; };
+struct SymV {
+    enum K { Scalar, Vec, Dim, IndexDomain, IndexE, Image, TypeName, ResidualsH, NamedRes, MatInfo, StencilList } k = Scalar;
+    E e; std::vector<E> v;                         // Scalar / Vec
+    int id = -1;                                   // Dim / IndexDomain: dimension id ; Image: input index ; NamedRes: residual index
+    IndexComp ic;                                  // IndexE
+    std::string s;                                 // TypeName ; MatInfo: "J" / "JtJ" / "Jp"
+    std::vector<std::vector<double>> stencil;      // StencilList
+};
+struct Value {
+    enum T { Nil, Bool, Num, Str, Table, Func, Sym } t = Nil;
+    bool b = false; double n = 0; std::string s;
+    std::shared_ptr<TableV> tab; std::shared_ptr<FuncV> fn; std::shared_ptr<SymV> sym;
+    static Value num(double x) { Value v; v.t = Num; v.n = x; return v; }
+    static Value boolean(bool x) { Value v; v.t = Bool; v.b = x; return v; }
+    static Value str(const std::string& x) { Value v; v.t = Str; v.s = x; return v; }
+    static Value make_sym(const SymV& sv) { Value v; v.t = Sym; v.sym = std::make_shared<SymV>(sv); return v; }
+    bool truthy() const { return !(t == Nil || (t == Bool && !b)); }
+};
+typedef std::vector<Value> Values;
+
+struct Env {
+    std::map<std::string, Value> vars; std::shared_ptr<Env> parent;
+    Value* find(const std::string& n) { for (Env* e = this; e; e = e->parent.get()) { auto it = e->vars.find(n); if (it != e->vars.end()) return &it->second; } return nullptr; }
+};
+
+// ================================================================================================ expression helpers
+E mk(Op op, std::vector<E> a) { auto e = std::make_shared<Expr>(); e->op = op; e->a = std::move(a); return e; }
+E konst(double c) { auto e = std::make_shared<Expr>(); e->op = Op::Const; e->c = c; return e; }
+bool is_const(const E& e, double* c = nullptr) { if (e->op != Op::Const) return false; if (c) *c = e->c; return true; }
+E bin(Op op, const E& a, const E& b)
+{
+    double x, y;
+    if (is_const(a, &x) && is_const(b, &y)) {       // fold literals (the file's own arithmetic on numbers: weights, thresholds)
+        switch (op) { case Op::Add: return konst(x + y); case Op::Sub: return konst(x - y); case Op::Mul: return konst(x * y); case Op::Div: return konst(x / y); default: break; }
+    }
+    return mk(op, { a, b });
+}
+E un(Op op, const E& a)
+{
+    double x;
+    if (is_const(a, &x)) switch (op) { case Op::Neg: return konst(-x); case Op::Sqrt: return konst(std::sqrt(x)); case Op::Sin: return konst(std::sin(x)); case Op::Cos: return konst(std::cos(x));
+                                        case Op::Abs: return konst(std::fabs(x)); default: break; }
+    return mk(op, { a });
+}
+
+// shift every index of an expression (expr:get(x+dx, y+dy)): per dimension id the extra offset
+E shift_expr(const E& e, const std::map<int, int>& sh, std::map<const Expr*, E>& memo)
+{
+    auto it = memo.find(e.get()); if (it != memo.end()) return it->second;
+    auto n = std::make_shared<Expr>(*e);
+    for (auto& ic : n->idx) { auto f = sh.find(ic.dim); if (f != sh.end()) { if (ic.sparse >= 0 && f->second != 0) fail(":get with an offset through a Sparse map is not supported"); ic.off += f->second; } }
+    for (auto& c : n->a) c = shift_expr(c, sh, memo);
+    E r = n; memo[e.get()] = r; return r;
+}
+void collect_dims(const E& e, std::vector<int>& dims, std::map<const Expr*, int>& seen)
+{
+    if (seen.count(e.get())) return; seen[e.get()] = 1;
+    for (auto& ic : e->idx) { bool have = false; for (int d : dims) have = have || d == ic.dim; if (!have) dims.push_back(ic.dim); }
+    for (auto& c : e->a) collect_dims(c, dims, seen);
+}
+
+// ================================================================================================ interpreter
+struct Interp {
+    Problem& P;
+    std::shared_ptr<Env> globals = std::make_shared<Env>();
+    int depth = 0;
+    struct ReturnEx { Values v; };
+    struct BreakEx {};
+    explicit Interp(Problem& p) : P(p) { install_builtins(); }
+
+    // ---- symbolic value helpers
+    static Value scalar(const E& e) { SymV s; s.k = SymV::Scalar; s.e = e; return Value::make_sym(s); }
+    static Value vec(const std::vector<E>& v) { if (v.size() == 1) return scalar(v[0]); SymV s; s.k = SymV::Vec; s.v = v; return Value::make_sym(s); }
+    static bool is_symk(const Value& v, SymV::K k) { return v.t == Value::Sym && v.sym->k == k; }
+    // number / Scalar / Vec -> component list
+    static bool as_comps(const Value& v, std::vector<E>& out)
+    {
+        if (v.t == Value::Num) { out = { konst(v.n) }; return true; }
+        if (v.t == Value::Bool) { out = { konst(v.b ? 1.0 : 0.0) }; return true; }
+        if (is_symk(v, SymV::Scalar)) { out = { v.sym->e }; return true; }
+        if (is_symk(v, SymV::Vec)) { out = v.sym->v; return true; }
+        if (is_symk(v, SymV::IndexDomain) || is_symk(v, SymV::IndexE)) return false;
+        if (v.t == Value::Table) {                  // a Lua list of scalars, e.g. Residuals { reg = { e1, e2 } }
+            out.clear();
+            for (auto& x : v.tab->arr) { std::vector<E> c; if (!as_comps(x, c)) return false; out.insert(out.end(), c.begin(), c.end()); }
+            return !out.empty();
+        }
+        return false;
+    }
+    static std::vector<E> comps(const Value& v, const char* what)
+    { std::vector<E> c; if (!as_comps(v, c)) fail(std::string(what) + ": expected a number or an expression"); return c; }
+    static E one(const Value& v, const char* what) { auto c = comps(v, what); if (c.size() != 1) fail(std::string(what) + ": expected a scalar"); return c[0]; }
+    static IndexComp as_index(const Value& v, const char* what)
+    {
+        if (is_symk(v, SymV::IndexDomain)) { IndexComp ic; ic.dim = v.sym->id; return ic; }
+        if (is_symk(v, SymV::IndexE)) return v.sym->ic;
+        fail(std::string(what) + ": expected an index expression (an iteration variable plus an integer offset)");
+    }
+    static Value broadcast(Op op, const Value& a, const Value& b, const char* what)
+    {
+        std::vector<E> x = comps(a, what), y = comps(b, what), r;
+        if (x.size() != y.size() && x.size() != 1 && y.size() != 1) fail(std::string(what) + ": vector lengths differ");
+        const size_t n = std::max(x.size(), y.size());
+        for (size_t i = 0; i < n; ++i) r.push_back(bin(op, x[x.size() == 1 ? 0 : i], y[y.size() == 1 ? 0 : i]));
+        return vec(r);
+    }
+    static Value map1(Op op, const Value& a, const char* what) { std::vector<E> r; for (auto& e : comps(a, what)) r.push_back(un(op, e)); return vec(r); }
+
+    Value arith(const std::string& op, const Value& a, const Value& b, int line)
+    {
+        if (a.t == Value::Num && b.t == Value::Num) {
+            if (op == "+") return Value::num(a.n + b.n); if (op == "-") return Value::num(a.n - b.n); if (op == "*") return Value::num(a.n * b.n);
+            if (op == "/") return Value::num(a.n / b.n); if (op == "%") return Value::num(a.n - std::floor(a.n / b.n) * b.n); if (op == "^") return Value::num(std::pow(a.n, b.n));
+        }
+        // index arithmetic: x + 1, x - dx, dx + x
+        const bool ai = is_symk(a, SymV::IndexDomain) || is_symk(a, SymV::IndexE), bi = is_symk(b, SymV::IndexDomain) || is_symk(b, SymV::IndexE);
+        if ((ai && b.t == Value::Num) || (bi && a.t == Value::Num && op == "+")) {
+            IndexComp ic = as_index(ai ? a : b, "index arithmetic"); const double d = ai ? b.n : a.n;
+            if (d != std::floor(d)) fail("line " + std::to_string(line) + ": non-integer index offset");
+            if (ic.sparse >= 0 && d != 0) fail("line " + std::to_string(line) + ": offset on an index that went through a Sparse map");
+            if (op == "+") ic.off += (int)d; else if (op == "-") ic.off -= (int)d; else fail("line " + std::to_string(line) + ": only + and - are defined on indices");
+            SymV s; s.k = SymV::IndexE; s.ic = ic; return Value::make_sym(s);
+        }
+        const Op o = op == "+" ? Op::Add : op == "-" ? Op::Sub : op == "*" ? Op::Mul : op == "/" ? Op::Div : op == "^" ? Op::Pow : Op::Const;
+        if (o == Op::Const) fail("line " + std::to_string(line) + ": operator " + op + " on these operands");
+        if (o == Op::Pow) {
+            if (b.t != Value::Num || b.n != std::floor(b.n) || b.n < 1 || b.n > 8) fail("line " + std::to_string(line) + ": only small positive integer powers of expressions are supported");
+            Value r = a; for (int i = 1; i < (int)b.n; ++i) r = broadcast(Op::Mul, r, a, "^"); return r;
+        }
+        return broadcast(o, a, b, ("line " + std::to_string(line) + " operator " + op).c_str());
+    }
+
+    // ---- evaluation
+    Values eval_multi(const NP& n, const std::shared_ptr<Env>& env)
+    {
+        if (n->k == Node::Call || n->k == Node::Method) return call_node(n, env);
+        return { eval(n, env) };
+    }
+    Values eval_list(const std::vector<NP>& es, const std::shared_ptr<Env>& env)
+    {
+        Values out;
+        for (size_t i = 0; i < es.size(); ++i) {
+            if (i + 1 == es.size()) { Values last = eval_multi(es[i], env); out.insert(out.end(), last.begin(), last.end()); }
+            else out.push_back(eval(es[i], env));
+        }
+        return out;
+    }
+    Value eval(const NP& n, const std::shared_ptr<Env>& env)
+    {
+        switch (n->k) {
+        case Node::Nil: return Value();
+        case Node::True: return Value::boolean(true);
+        case Node::False: return Value::boolean(false);
+        case Node::Number: return Value::num(n->num);
+        case Node::String: return Value::str(n->s);
+        case Node::Paren: return eval(n->a[0], env);
+        case Node::Function: { Value v; v.t = Value::Func; v.fn = std::make_shared<FuncV>(); v.fn->def = n; v.fn->env = env; return v; }
+        case Node::Name: { Value* v = env->find(n->s); return v ? *v : Value(); }
+        case Node::Index: return index_value(eval(n->a[0], env), eval(n->a[1], env), n->line);
+        case Node::Call: case Node::Method: { Values r = call_node(n, env); return r.empty() ? Value() : r[0]; }
+        case Node::Table: {
+            Value v; v.t = Value::Table; v.tab = std::make_shared<TableV>();
+            for (size_t i = 0; i < n->a.size(); ++i) {
+                if (!n->keys[i]) {
+                    if (i + 1 == n->a.size()) { Values last = eval_multi(n->a[i], env); for (auto& x : last) v.tab->arr.push_back(x); }
+                    else v.tab->arr.push_back(eval(n->a[i], env));
+                } else {
+                    const Value key = eval(n->keys[i], env), val = eval(n->a[i], env);
+                    table_set(v, key, val, n->line);
+                }
+            }
+            return v;
+        }
+        case Node::Unop: {
+            const Value x = eval(n->a[0], env);
+            if (n->s == "not") return Value::boolean(!x.truthy());
+            if (n->s == "#") { if (x.t == Value::Table) return Value::num((double)x.tab->arr.size()); if (x.t == Value::Str) return Value::num((double)x.s.size()); if (is_symk(x, SymV::Vec)) return Value::num((double)x.sym->v.size()); fail("line " + std::to_string(n->line) + ": # on this value"); }
+            if (x.t == Value::Num) return Value::num(-x.n);
+            return map1(Op::Neg, x, "unary minus");
+        }
+        case Node::Binop: {
+            const std::string& op = n->s;
+            if (op == "and") { const Value l = eval(n->a[0], env); return l.truthy() ? eval(n->a[1], env) : l; }
+            if (op == "or") { const Value l = eval(n->a[0], env); return l.truthy() ? l : eval(n->a[1], env); }
+            const Value l = eval(n->a[0], env), r = eval(n->a[1], env);
+            if (op == "==" || op == "~=") {
+                bool eq = false;
+                if (l.t == r.t) { if (l.t == Value::Num) eq = l.n == r.n; else if (l.t == Value::Str) eq = l.s == r.s; else if (l.t == Value::Bool) eq = l.b == r.b; else if (l.t == Value::Nil) eq = true;
+                                  else if (l.t == Value::Table) eq = l.tab == r.tab; else if (l.t == Value::Sym) eq = l.sym == r.sym; }
+                return Value::boolean(op == "==" ? eq : !eq);
+            }
+            if (op == "<" || op == ">" || op == "<=" || op == ">=") {
+                if (l.t != Value::Num || r.t != Value::Num) fail("line " + std::to_string(n->line) + ": " + op + " compares numbers only (use less / greater / ... on expressions)");
+                return Value::boolean(op == "<" ? l.n < r.n : op == ">" ? l.n > r.n : op == "<=" ? l.n <= r.n : l.n >= r.n);
+            }
+            if (op == "..") { auto ts = [&](const Value& v) { if (v.t == Value::Str) return v.s; if (v.t == Value::Num) { char b[64]; snprintf(b, sizeof b, "%.14g", v.n); return std::string(b); } fail("concatenation of this value"); }; return Value::str(ts(l) + ts(r)); }
+            return arith(op, l, r, n->line);
+        }
+        default: fail("line " + std::to_string(n->line) + ": not an expression");
+        }
+    }
+    static Value* table_get(const Value& t, const Value& key)
+    {
+        if (key.t == Value::Num) { const double k = key.n; if (k == std::floor(k) && k >= 1 && k <= (double)t.tab->arr.size()) return &t.tab->arr[(size_t)k - 1]; return nullptr; }
+        if (key.t == Value::Str) { for (auto& f : t.tab->fields) if (f.first == key.s) return &f.second; return nullptr; }
+        return nullptr;
+    }
+    static void table_set(Value& t, const Value& key, const Value& val, int line)
+    {
+        if (key.t == Value::Num) {
+            const double k = key.n;
+            if (k != std::floor(k) || k < 1) fail("line " + std::to_string(line) + ": table key must be a positive integer or a string");
+            if (k <= (double)t.tab->arr.size()) { t.tab->arr[(size_t)k - 1] = val; return; }
+            if (k == (double)t.tab->arr.size() + 1) { t.tab->arr.push_back(val); return; }
+            fail("line " + std::to_string(line) + ": sparse table");
+        }
+        if (key.t != Value::Str) fail("line " + std::to_string(line) + ": table key must be a positive integer or a string");
+        for (auto& f : t.tab->fields) if (f.first == key.s) { f.second = val; return; }
+        t.tab->fields.push_back({ key.s, val });
+    }
+    Value index_value(const Value& obj, const Value& key, int line)
+    {
+        if (obj.t == Value::Table) { Value* v = table_get(obj, key); return v ? *v : Value(); }
+        if (is_symk(obj, SymV::Vec) || is_symk(obj, SymV::Scalar)) {           // normal[0]: 0-based component
+            if (key.t != Value::Num) fail("line " + std::to_string(line) + ": vector index must be a number");
+            auto c = comps(obj, "index"); const int i = (int)key.n;
+            if (i < 0 || i >= (int)c.size()) fail("line " + std::to_string(line) + ": vector component " + std::to_string(i) + " out of range");
+            return scalar(c[i]);
+        }
+        if (is_symk(obj, SymV::ResidualsH) && key.t == Value::Str) {
+            for (size_t i = 0; i < P.residuals.size(); ++i) if (P.residuals[i].name == key.s) { SymV s; s.k = SymV::NamedRes; s.id = (int)i; return Value::make_sym(s); }
+            fail("line " + std::to_string(line) + ": no residual named " + key.s);
+        }
+        if (is_symk(obj, SymV::NamedRes) && key.t == Value::Str) {
+            if (key.s == "J" || key.s == "JtJ" || key.s == "Jp" || key.s == "JtF") { SymV s; s.k = SymV::MatInfo; s.id = obj.sym->id; s.s = key.s; return Value::make_sym(s); }
+            fail("line " + std::to_string(line) + ": residual field " + key.s);
+        }
+        if (obj.t == Value::Nil) fail("line " + std::to_string(line) + ": attempt to index a nil value");
+        fail("line " + std::to_string(line) + ": cannot index this value");
+    }
+
+    Values call_value(const Value& f, const Values& args, int line)
+    {
+        if (f.t == Value::Func) {
+            if (f.fn->builtin >= 0) return call_builtin(f.fn->bname, args, line);
+            if (++depth > 200) fail("recursion too deep");
+            auto env = std::make_shared<Env>(); env->parent = f.fn->env;
+            for (size_t i = 0; i < f.fn->def->names.size(); ++i) env->vars[f.fn->def->names[i]] = i < args.size() ? args[i] : Value();
+            Values ret;
+            try { exec_block(f.fn->def->a[0], env); } catch (ReturnEx& r) { ret = r.v; }
+            --depth; return ret;
+        }
+        if (f.t == Value::Sym) return { call_sym(f, args, line) };
+        fail("line " + std::to_string(line) + ": attempt to call a " + std::string(f.t == Value::Nil ? "nil" : "non-function") + " value");
+    }
+    Values call_node(const NP& n, const std::shared_ptr<Env>& env)
+    {
+        if (n->k == Node::Call) {
+            const Value f = eval(n->a[0], env);
+            std::vector<NP> argn(n->a.begin() + 1, n->a.end());
+            if (f.t == Value::Nil) { std::string nm = n->a[0]->k == Node::Name ? n->a[0]->s : "?"; fail("line " + std::to_string(n->line) + ": '" + nm + "' is not defined (not part of the supported DSL subset)"); }
+            return call_value(f, eval_list(argn, env), n->line);
+        }
+        const Value obj = eval(n->a[0], env);
+        std::vector<NP> argn(n->a.begin() + 1, n->a.end());
+        return call_method(obj, n->s, eval_list(argn, env), n->line);
+    }
+
+    // image(ix, iy) / sparse(e) / dim() / vec(i)
+    Value call_sym(const Value& f, const Values& args, int line)
+    {
+        const std::string ln = "line " + std::to_string(line) + ": ";
+        const SymV& s = *f.sym;
+        if (s.k == SymV::Dim) { if (!args.empty()) fail(ln + "a dimension is called without arguments"); SymV r; r.k = SymV::IndexDomain; r.id = s.id; return Value::make_sym(r); }
+        if (s.k == SymV::Vec || s.k == SymV::Scalar) {
+            if (args.size() != 1 || args[0].t != Value::Num) fail(ln + "vector component selection takes one number");
+            return index_value(f, args[0], line);
+        }
+        if (s.k == SymV::Image) {
+            const Input& in = P.inputs[s.id];
+            if (in.kind == InputKind::Sparse) {
+                if (args.size() != 1) fail(ln + in.name + " takes one index");
+                IndexComp ic = as_index(args[0], in.name.c_str());
+                if (ic.sparse >= 0) fail(ln + "nested Sparse maps are not supported");
+                if (ic.dim != in.dims[0]) fail(ln + in.name + " is indexed over dimension " + P.dims[in.dims[0]]);
+                if (ic.off != 0) fail(ln + "offset inside a Sparse map access");
+                ic.sparse = s.id;
+                SymV r; r.k = SymV::IndexE; r.ic = ic; return Value::make_sym(r);
+            }
+            if (args.size() != in.dims.size()) fail(ln + in.name + " takes " + std::to_string(in.dims.size()) + " indices");
+            std::vector<IndexComp> idx;
+            for (size_t d = 0; d < args.size(); ++d) {
+                IndexComp ic = as_index(args[d], in.name.c_str());
+                const int target = ic.sparse >= 0 ? P.inputs[ic.sparse].dims[1] : ic.dim;
+                if (target != in.dims[d]) fail(ln + "index " + std::to_string(d) + " of " + in.name + " ranges over dimension " + P.dims[in.dims[d]] + ", got " + P.dims[target]);
+                idx.push_back(ic);
+            }
+            std::vector<E> out;
+            for (int c = 0; c < in.channels; ++c) { auto e = std::make_shared<Expr>(); e->op = Op::Load; e->input = s.id; e->channel = c; e->idx = idx; out.push_back(e); }
+            return vec(out);
+        }
+        fail(ln + "this value is not callable");
+    }
+
+    Values call_method(const Value& obj, const std::string& m, const Values& args, int line)
+    {
+        const std::string ln = "line " + std::to_string(line) + ": ";
+        if (is_symk(obj, SymV::IndexDomain) || is_symk(obj, SymV::IndexE)) {
+            if (m == "asvalue") { auto e = std::make_shared<Expr>(); e->op = Op::IndexVal; e->idx = { as_index(obj, "asvalue") }; if (e->idx[0].sparse >= 0) fail(ln + "asvalue through a Sparse map"); return { scalar(e) }; }
+        }
+        if (is_symk(obj, SymV::Image)) {
+            Input& in = P.inputs[obj.sym->id];
+            if (m == "Exclude") { if (in.kind != InputKind::Unknown) fail(ln + "Exclude applies to unknowns"); in.exclude = one(args.at(0), "Exclude"); return {}; }
+            if (m == "set_coherent") return {};
+        }
+        if (is_symk(obj, SymV::Vec) || is_symk(obj, SymV::Scalar)) {
+            if (m == "slice") {                      // lib.t Slice on a value: components [a, b)
+                if (args.size() != 2 || args[0].t != Value::Num || args[1].t != Value::Num) fail(ln + "slice(a, b)");
+                auto c = comps(obj, "slice"); const int a = (int)args[0].n, b = (int)args[1].n;
+                if (a < 0 || b > (int)c.size() || a >= b) fail(ln + "slice out of range");
+                return { vec(std::vector<E>(c.begin() + a, c.begin() + b)) };
+            }
+            if (m == "get") {                        // computed-array access at shifted indices; 0 outside the iteration domain (thallo.t:876-883)
+                auto c = comps(obj, "get");
+                std::vector<int> dims; { std::map<const Expr*, int> seen; for (auto& e : c) collect_dims(e, dims, seen); }
+                std::map<int, int> sh; std::vector<IndexComp> at;
+                for (auto& a : args) { IndexComp ic = as_index(a, "get"); if (ic.sparse >= 0) fail(ln + ":get through a Sparse map is not supported"); sh[ic.dim] = ic.off; at.push_back(ic); }
+                bool any = false; for (auto& kv : sh) any = any || kv.second != 0;
+                if (!any) return { obj };
+                std::vector<E> out; std::map<const Expr*, E> memo;
+                auto inb = std::make_shared<Expr>(); inb->op = Op::InBounds; inb->idx = at;
+                for (auto& e : c) out.push_back(mk(Op::Select, { inb, shift_expr(e, sh, memo), konst(0.0) }));
+                return { vec(out) };
+            }
+            if (m == "materialize") return {};
+        }
+        if (is_symk(obj, SymV::MatInfo)) {
+            Residual& r = P.residuals[obj.sym->id];
+            if (m == "set_materialize") { const bool b = !args.empty() && args[0].truthy(); if (obj.sym->s == "J") r.mat_J = b; else if (obj.sym->s == "JtJ") r.mat_JtJ = b; else if (obj.sym->s == "Jp") r.mat_Jp = b; return {}; }
+            if (m == "set_sparse" || m == "compute_at_output") return {};
+        }
+        if (is_symk(obj, SymV::NamedRes)) { if (m == "compute_at_output" || m == "reorder" || m == "clear_reorder") return { obj }; }
+        if (is_symk(obj, SymV::ResidualsH)) {
+            if (m == "merge") {                      // thallo.t:5676-5688: the second residual's expressions join the first
+                if (args.size() != 2 || !is_symk(args[0], SymV::NamedRes) || !is_symk(args[1], SymV::NamedRes)) fail(ln + "merge(r1, r2)");
+                const int i1 = args[0].sym->id, i2 = args[1].sym->id;
+                if (i1 == i2) fail(ln + "merge of a residual with itself");
+                if (P.residuals[i1].domain != P.residuals[i2].domain) fail(ln + "merge needs identical iteration domains");
+                P.residuals[i1].name += "_" + P.residuals[i2].name;
+                P.residuals[i1].exprs.insert(P.residuals[i1].exprs.end(), P.residuals[i2].exprs.begin(), P.residuals[i2].exprs.end());
+                P.residuals[i2].exprs.clear();     // (kept as an empty slot so that handles stay valid; dropped at the end)
+                return { args[0] };
+            }
+        }
+        if (obj.t == Value::Table) {                 // t:insert(v)
+            if (m == "insert" && args.size() == 1) { obj.tab->arr.push_back(args[0]); return {}; }
+            Value* f = table_get(obj, Value::str(m));
+            if (f) { Values a2{ obj }; a2.insert(a2.end(), args.begin(), args.end()); return call_value(*f, a2, line); }
+        }
+        fail(ln + "method '" + m + "' is not part of the supported DSL subset");
+    }
+
+    // ---- statements
+    void exec_block(const NP& b, const std::shared_ptr<Env>& env) { for (auto& s : b->a) exec(s, env); }
+    void assign(const NP& target, const Value& v, const std::shared_ptr<Env>& env)
+    {
+        if (target->k == Node::Name) { Value* slot = env->find(target->s); if (slot) *slot = v; else globals->vars[target->s] = v; return; }
+        Value obj = eval(target->a[0], env); const Value key = eval(target->a[1], env);
+        if (obj.t != Value::Table) fail("line " + std::to_string(target->line) + ": assignment into a non-table value");
+        table_set(obj, key, v, target->line);
+    }
+    void exec(const NP& s, const std::shared_ptr<Env>& env)
+    {
+        switch (s->k) {
+        case Node::Local: { Values v = eval_list(s->a, env); for (size_t i = 0; i < s->names.size(); ++i) env->vars[s->names[i]] = i < v.size() ? v[i] : Value(); return; }
+        case Node::Assign: { Values v = eval_list(s->a, env); for (size_t i = 0; i < s->keys.size(); ++i) assign(s->keys[i], i < v.size() ? v[i] : Value(), env); return; }
+        case Node::CallStat: call_node(s->a[0], env); return;
+        case Node::Do: { auto e2 = std::make_shared<Env>(); e2->parent = env; exec_block(s->a[0], e2); return; }
+        case Node::FuncStat: {
+            Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->def = s->a[1];
+            if (s->is_local) { env->vars[s->a[0]->s] = Value(); f.fn->env = env; env->vars[s->a[0]->s] = f; }
+            else { f.fn->env = env; assign(s->a[0], f, env); }
+            return;
+        }
+        case Node::If: {
+            for (size_t i = 0; i + 1 < s->a.size(); i += 2) {
+                if (!s->a[i] || eval(s->a[i], env).truthy()) { auto e2 = std::make_shared<Env>(); e2->parent = env; exec_block(s->a[i + 1], e2); return; }
+            }
+            return;
+        }
+        case Node::While: {
+            int guard = 0;
+            try { while (eval(s->a[0], env).truthy()) { if (++guard > 1000000) fail("loop does not terminate"); auto e2 = std::make_shared<Env>(); e2->parent = env; exec_block(s->a[1], e2); } } catch (BreakEx&) {}
+            return;
+        }
+        case Node::NumFor: {
+            const Value a = eval(s->a[0], env), b = eval(s->a[1], env), c = s->a[2] ? eval(s->a[2], env) : Value::num(1);
+            if (a.t != Value::Num || b.t != Value::Num || c.t != Value::Num || c.n == 0) fail("line " + std::to_string(s->line) + ": numeric for needs numbers");
+            try { for (double i = a.n; c.n > 0 ? i <= b.n : i >= b.n; i += c.n) { auto e2 = std::make_shared<Env>(); e2->parent = env; e2->vars[s->names[0]] = Value::num(i); exec_block(s->a[3], e2); } } catch (BreakEx&) {}
+            return;
+        }
+        case Node::GenFor: {
+            std::vector<NP> es(s->a.begin(), s->a.end() - 1);
+            Values it = eval_list(es, env);
+            const NP body = s->a.back();
+            auto run = [&](const Values& vals) { auto e2 = std::make_shared<Env>(); e2->parent = env; for (size_t i = 0; i < s->names.size(); ++i) e2->vars[s->names[i]] = i < vals.size() ? vals[i] : Value(); exec_block(body, e2); };
+            try {
+                if (!it.empty() && is_symk(it[0], SymV::StencilList)) {     // for dx, dy in Stencil { {1,0}, ... }
+                    for (auto& row : it[0].sym->stencil) { Values v; for (double d : row) v.push_back(Value::num(d)); run(v); }
+                } else if (it.size() >= 2 && it[0].t == Value::Func && (it[0].fn->bname == "ipairs_iter" || it[0].fn->bname == "pairs_iter") && it[1].t == Value::Table) {
+                    const auto tab = it[1].tab;
+                    for (size_t i = 0; i < tab->arr.size(); ++i) run({ Value::num((double)i + 1), tab->arr[i] });
+                    if (it[0].fn->bname == "pairs_iter") for (auto& f : tab->fields) run({ Value::str(f.first), f.second });
+                } else fail("line " + std::to_string(s->line) + ": for-in supports Stencil{...}, ipairs(t) and pairs(t)");
+            } catch (BreakEx&) {}
+            return;
+        }
+        case Node::Return: { ReturnEx r; r.v = eval_list(s->a, env); throw r; }
+        case Node::Break: throw BreakEx();
+        default: fail("line " + std::to_string(s->line) + ": statement not supported");
+        }
+    }
+
+    // ---- builtins
+    void def(const std::string& name) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = name; globals->vars[name] = f; }
+    void install_builtins()
+    {
+        for (const char* n : { "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
+                               "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
+                               "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
+            def(n);
+        for (const char* n : { "float", "float2", "float3", "float4", "float6", "float9", "thallo_float", "thallo_float2", "thallo_float3", "thallo_float4", "thallo_float6", "thallo_float9",
+                               "uint8", "double", "int", "thallo_int" }) { SymV s; s.k = SymV::TypeName; s.s = n; globals->vars[n] = Value::make_sym(s); }
+        Value math; math.t = Value::Table; math.tab = std::make_shared<TableV>();
+        for (const char* n : { "sqrt", "sin", "cos", "abs" }) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = n; math.tab->fields.push_back({ n, f }); }
+        math.tab->fields.push_back({ "pi", Value::num(3.14159265358979323846) });
+        globals->vars["math"] = math;
+    }
+    static int type_channels(const Value& t, bool* u8, int line)
+    {
+        if (!is_symk(t, SymV::TypeName)) fail("line " + std::to_string(line) + ": expected an element type (float, thallo_float2, uint8, ...)");
+        const std::string& s = t.sym->s; *u8 = s == "uint8";
+        const char last = s.back();
+        return isdigit((unsigned char)last) && s != "uint8" ? last - '0' : 1;
+    }
+    std::vector<int> dim_list(const Value& t, int line)
+    {
+        if (t.t != Value::Table) fail("line " + std::to_string(line) + ": expected a list of dimensions {W, H}");
+        std::vector<int> d; for (auto& v : t.tab->arr) { if (!is_symk(v, SymV::Dim)) fail("line " + std::to_string(line) + ": expected a dimension"); d.push_back(v.sym->id); }
+        return d;
+    }
+    E cmp(Op op, const E& a, const E& b) { return mk(op, { a, b }); }
+    Values call_builtin(const std::string& f, const Values& a, int line)
+    {
+        const std::string ln = "line " + std::to_string(line) + ": ";
+        auto need = [&](size_t n) { if (a.size() < n) fail(ln + f + " needs " + std::to_string(n) + " argument(s)"); };
+        if (f == "Dims") { Values out; for (auto& v : a) { if (v.t != Value::Str) fail(ln + "Dims takes names"); SymV s; s.k = SymV::Dim; s.id = (int)P.dims.size(); P.dims.push_back(v.s); out.push_back(Value::make_sym(s)); } return out; }
+        if (f == "Unknown" || f == "Array") {
+            need(3); Input in; in.kind = f == "Unknown" ? InputKind::Unknown : InputKind::Array;
+            in.channels = type_channels(a[0], &in.is_u8, line); in.dims = dim_list(a[1], line);
+            if (a[2].t != Value::Num) fail(ln + f + ": the third argument is the parameter index"); in.slot = (int)a[2].n;
+            if (in.dims.empty() || in.dims.size() > 2) fail(ln + f + ": 1- and 2-dimensional images are supported");
+            if (in.kind == InputKind::Unknown && in.is_u8) fail(ln + "uint8 unknowns are not supported");
+            return { decl(in) };
+        }
+        if (f == "Sparse") { need(3); Input in; in.kind = InputKind::Sparse; auto from = dim_list(a[0], line), to = dim_list(a[1], line); if (from.size() != 1 || to.size() != 1) fail(ln + "Sparse({E}, {N}, idx)"); in.dims = { from[0], to[0] }; in.slot = (int)a[2].n; return { decl(in) }; }
+        if (f == "Param") { need(2); Input in; in.kind = InputKind::Param; bool u8; if (type_channels(a[0], &u8, line) != 1 || u8) fail(ln + "scalar float Params are supported"); in.slot = (int)a[1].n; return { decl(in) }; }
+        if (f == "Inputs") {
+            need(1); if (a[0].t != Value::Table) fail(ln + "Inputs { name = ..., ... }");
+            for (auto& kv : a[0].tab->fields) {
+                if (!is_symk(kv.second, SymV::Image)) fail(ln + "Inputs: " + kv.first + " is not an Unknown / Array / Sparse / Param");
+                Input& in = P.inputs[kv.second.sym->id]; in.name = kv.first;
+                if (in.kind == InputKind::Param) { auto e = std::make_shared<Expr>(); e->op = Op::Param; e->input = kv.second.sym->id; globals->vars[kv.first] = scalar(e); }
+                else globals->vars[kv.first] = kv.second;
+                P.max_slot = std::max(P.max_slot, in.slot);
+            }
+            return {};
+        }
+        if (f == "UsePreconditioner") { P.use_preconditioner = !a.empty() && a[0].truthy(); return {}; }
+        if (f == "Stencil") { need(1); SymV s; s.k = SymV::StencilList; if (a[0].t != Value::Table) fail(ln + "Stencil { {dx, dy}, ... }"); for (auto& row : a[0].tab->arr) { std::vector<double> r; if (row.t != Value::Table) fail(ln + "Stencil entries are lists"); for (auto& v : row.tab->arr) { if (v.t != Value::Num) fail(ln + "Stencil offsets are numbers"); r.push_back(v.n); } s.stencil.push_back(r); } return { Value::make_sym(s) }; }
+        if (f == "Residuals") {
+            need(1); if (a[0].t != Value::Table) fail(ln + "Residuals { name = expr, ... }");
+            for (auto& kv : a[0].tab->fields) {
+                Residual r; r.name = kv.first; r.exprs = comps(kv.second, ("residual " + kv.first).c_str());
+                std::map<const Expr*, int> seen; for (auto& e : r.exprs) collect_dims(e, r.domain, seen);
+                if (r.domain.empty()) fail(ln + "residual " + kv.first + " does not depend on any iteration variable");
+                P.residuals.push_back(r);
+            }
+            if (!a[0].tab->arr.empty()) fail(ln + "Residuals entries need names");
+            SymV s; s.k = SymV::ResidualsH; return { Value::make_sym(s) };
+        }
+        if (f == "Select") {                        // ad.t:800-809
+            need(3); auto c = comps(a[0], "Select"), x = comps(a[1], "Select"), y = comps(a[2], "Select");
+            const size_t n = std::max(x.size(), y.size()); std::vector<E> out;
+            if ((c.size() != 1 && c.size() != n) || (x.size() != n && x.size() != 1) || (y.size() != n && y.size() != 1)) fail(ln + "Select: vector lengths differ");
+            for (size_t i = 0; i < n; ++i) out.push_back(mk(Op::Select, { c[c.size() == 1 ? 0 : i], x[x.size() == 1 ? 0 : i], y[y.size() == 1 ? 0 : i] }));
+            return { vec(out) };
+        }
+        if (f == "InBounds" || f == "InBoundsExpanded") {
+            auto e = std::make_shared<Expr>(); e->op = Op::InBounds;
+            size_t n = a.size();
+            if (f == "InBoundsExpanded") { need(2); if (a.back().t != Value::Num) fail(ln + "InBoundsExpanded(x, y, n)"); e->expand = (int)a.back().n; --n; }
+            for (size_t i = 0; i < n; ++i) e->idx.push_back(as_index(a[i], f.c_str()));
+            if (e->idx.empty()) fail(ln + f + " needs indices");
+            return { scalar(e) };
+        }
+        auto cmp2 = [&](Op op) { need(2); auto x = comps(a[0], f.c_str()), y = comps(a[1], f.c_str()); const size_t n = std::max(x.size(), y.size()); std::vector<E> out;
+                                 if (x.size() != y.size() && x.size() != 1 && y.size() != 1) fail(ln + f + ": vector lengths differ");
+                                 for (size_t i = 0; i < n; ++i) out.push_back(cmp(op, x[x.size() == 1 ? 0 : i], y[y.size() == 1 ? 0 : i])); return Values{ vec(out) }; };
+        if (f == "eq") return cmp2(Op::Eq); if (f == "greater") return cmp2(Op::Gt); if (f == "greatereq") return cmp2(Op::Ge);
+        if (f == "less") return cmp2(Op::Lt); if (f == "lesseq") return cmp2(Op::Le);
+        if (f == "And") return cmp2(Op::And); if (f == "Or") return cmp2(Op::Or);
+        if (f == "Not") { need(1); return { map1(Op::Not, a[0], "Not") }; }
+        if (f == "All" || f == "Any") { need(1); auto c = comps(a[0], f.c_str()); E r = c[0]; for (size_t i = 1; i < c.size(); ++i) r = mk(f == "All" ? Op::And : Op::Or, { r, c[i] }); return { scalar(r) }; }
+        if (f == "abs") { need(1); if (a[0].t == Value::Num) return { Value::num(std::fabs(a[0].n)) }; return { map1(Op::Abs, a[0], "abs") }; }
+        if (f == "sqrt" || f == "Sqrt") { need(1); if (a[0].t == Value::Num) return { Value::num(std::sqrt(a[0].n)) }; return { map1(Op::Sqrt, a[0], "sqrt") }; }
+        if (f == "sin") { need(1); if (a[0].t == Value::Num) return { Value::num(std::sin(a[0].n)) }; return { map1(Op::Sin, a[0], "sin") }; }
+        if (f == "cos") { need(1); if (a[0].t == Value::Num) return { Value::num(std::cos(a[0].n)) }; return { map1(Op::Cos, a[0], "cos") }; }
+        if (f == "Vector") { std::vector<E> out; for (auto& v : a) { auto c = comps(v, "Vector"); out.insert(out.end(), c.begin(), c.end()); } if (out.empty()) fail(ln + "empty Vector"); SymV s; s.k = SymV::Vec; s.v = out; return { Value::make_sym(s) }; }
+        if (f == "dot") { need(2); return { scalar(dot(comps(a[0], "dot"), comps(a[1], "dot"), ln)) }; }
+        if (f == "cross") { need(2); return { vec(cross(comps(a[0], "cross"), comps(a[1], "cross"), ln)) }; }
+        if (f == "normalize") { need(1); auto v = comps(a[0], "normalize"); E inv = bin(Op::Div, konst(1.0), un(Op::Sqrt, dot(v, v, ln))); std::vector<E> out; for (auto& e : v) out.push_back(bin(Op::Mul, e, inv)); return { vec(out) }; }
+        if (f == "length") { need(2); auto x = comps(a[0], "length"), y = comps(a[1], "length"); if (x.size() != y.size()) fail(ln + "length: sizes differ"); std::vector<E> d; for (size_t i = 0; i < x.size(); ++i) d.push_back(bin(Op::Sub, x[i], y[i])); return { scalar(un(Op::Sqrt, dot(d, d, ln))) }; }
+        if (f == "Rotate2D") {                      // lib.t:138-142
+            need(2); E ang = one(a[0], "Rotate2D"); auto v = comps(a[1], "Rotate2D"); if (v.size() != 2) fail(ln + "Rotate2D rotates 2-vectors");
+            E c = un(Op::Cos, ang), s = un(Op::Sin, ang);
+            return { vec({ bin(Op::Add, bin(Op::Mul, c, v[0]), bin(Op::Mul, un(Op::Neg, s), v[1])), bin(Op::Add, bin(Op::Mul, s, v[0]), bin(Op::Mul, c, v[1])) }) };
+        }
+        if (f == "Rotate3D") {                      // lib.t:123-137 (ZYX Euler), then gemv
+            need(2); auto an = comps(a[0], "Rotate3D"), v = comps(a[1], "Rotate3D"); if (an.size() != 3 || v.size() != 3) fail(ln + "Rotate3D(angle3, vector3)");
+            E ca = un(Op::Cos, an[0]), cb = un(Op::Cos, an[1]), cg = un(Op::Cos, an[2]), sa = un(Op::Sin, an[0]), sb = un(Op::Sin, an[1]), sg = un(Op::Sin, an[2]);
+            auto M = [&](E x, E y) { return bin(Op::Mul, x, y); }; auto A = [&](E x, E y) { return bin(Op::Add, x, y); }; auto N = [&](E x) { return un(Op::Neg, x); };
+            std::vector<E> m = { M(cg, cb), A(M(N(sg), ca), M(M(cg, sb), sa)), A(M(sg, sa), M(M(cg, sb), ca)),
+                                 M(sg, cb), A(M(cg, ca), M(M(sg, sb), sa)), A(M(N(cg), sa), M(M(sg, sb), ca)),
+                                 N(sb), M(cb, sa), M(cb, ca) };
+            std::vector<E> out; for (int r = 0; r < 3; ++r) out.push_back(A(A(M(m[3 * r], v[0]), M(m[3 * r + 1], v[1])), M(m[3 * r + 2], v[2])));
+            return { vec(out) };
+        }
+        if (f == "AngleAxisRotatePoint") {          // lib.t:514-555
+            need(2); auto w0 = comps(a[0], f.c_str()), pt = comps(a[1], f.c_str()); if (w0.size() != 3 || pt.size() != 3) fail(ln + "AngleAxisRotatePoint(axis3, point3)");
+            E th2 = dot(w0, w0, ln), large = cmp(Op::Gt, th2, konst(1e-8)), th = un(Op::Sqrt, th2), ct = un(Op::Cos, th), st = un(Op::Sin, th), inv = bin(Op::Div, konst(1.0), th);
+            std::vector<E> w; for (auto& e : w0) w.push_back(bin(Op::Mul, e, inv));
+            auto wxp = cross(w, pt, ln); E tmp = bin(Op::Mul, dot(w, pt, ln), bin(Op::Sub, konst(1.0), ct));
+            auto sxp = cross(w0, pt, ln);
+            std::vector<E> out;
+            for (int i = 0; i < 3; ++i) {
+                E lg = bin(Op::Add, bin(Op::Add, bin(Op::Mul, pt[i], ct), bin(Op::Mul, wxp[i], st)), bin(Op::Mul, w[i], tmp));
+                out.push_back(mk(Op::Select, { large, lg, bin(Op::Add, pt[i], sxp[i]) }));
+            }
+            return { vec(out) };
+        }
+        if (f == "ipairs" || f == "pairs") { need(1); Value it; it.t = Value::Func; it.fn = std::make_shared<FuncV>(); it.fn->builtin = 1; it.fn->bname = f + "_iter"; return { it, a[0], Value::num(0) }; }
+        if (f == "print") return {};
+        if (f == "assert") { need(1); if (!a[0].truthy()) fail(ln + "assertion failed" + (a.size() > 1 && a[1].t == Value::Str ? ": " + a[1].s : "")); return { a[0] }; }
+        if (f == "tostring") { need(1); if (a[0].t == Value::Num) { char b[64]; snprintf(b, sizeof b, "%.14g", a[0].n); return { Value::str(b) }; } if (a[0].t == Value::Str) return { a[0] }; return { Value::str("?") }; }
+        if (f == "tonumber") { need(1); if (a[0].t == Value::Num) return { a[0] }; if (a[0].t == Value::Str) return { Value::num(atof(a[0].s.c_str())) }; return { Value() }; }
+        if (f == "unpack") { need(1); if (a[0].t != Value::Table) fail(ln + "unpack(table)"); return a[0].tab->arr; }
+        fail(ln + "builtin " + f + " is not implemented");
+    }
+    Value decl(const Input& in) { SymV s; s.k = SymV::Image; s.id = (int)P.inputs.size(); P.inputs.push_back(in); return Value::make_sym(s); }
+    static E dot(const std::vector<E>& x, const std::vector<E>& y, const std::string& ln)
+    { if (x.size() != y.size() || x.empty()) fail(ln + "dot: sizes differ"); E r = bin(Op::Mul, x[0], y[0]); for (size_t i = 1; i < x.size(); ++i) r = bin(Op::Add, r, bin(Op::Mul, x[i], y[i])); return r; }
+    static std::vector<E> cross(const std::vector<E>& a, const std::vector<E>& b, const std::string& ln)
+    {
+        if (a.size() != 3 || b.size() != 3) fail(ln + "cross of 3-vectors");
+        auto M = [&](const E& x, const E& y) { return bin(Op::Mul, x, y); };
+        return { bin(Op::Sub, M(a[1], b[2]), M(a[2], b[1])), bin(Op::Sub, M(a[2], b[0]), M(a[0], b[2])), bin(Op::Sub, M(a[0], b[1]), M(a[1], b[0])) };
+    }
+};
+
+}  // namespace
+
+bool run_problem_file(const char* filename, Problem& out, std::string& err)
+{
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) { err = std::string("cannot open ") + filename; return false; }
+    std::stringstream ss; ss << f.rdbuf();
+    out = Problem(); out.file = filename;
+    try {
+        Parser ps(lex(ss.str()));
+        NP chunk = ps.block();
+        if (ps.cur().k != Tok::End) ps.err("unexpected token");
+        Interp in(out);
+        try { in.exec_block(chunk, in.globals); } catch (Interp::ReturnEx&) {}
+        // drop residuals emptied by merge; validate declarations
+        std::vector<Residual> keep; for (auto& r : out.residuals) if (!r.exprs.empty()) keep.push_back(r);
+        out.residuals = keep;
+        if (out.residuals.empty()) fail("the file defines no Residuals");
+        int n_unknown = 0;
+        for (auto& in2 : out.inputs) { if (in2.name.empty()) fail("an Unknown / Array / Sparse / Param was created outside Inputs{}"); if (in2.kind == InputKind::Unknown) ++n_unknown; }
+        if (!n_unknown) fail("the file declares no Unknown");
+    } catch (std::exception& e) { err = std::string(filename) + ": " + e.what(); return false; }
+    return true;
+}
+
+std::string describe(const Problem& p)
+{
+    std::ostringstream o;
+    o << "dims:"; for (auto& d : p.dims) o << " " << d; o << "\n";
+    for (auto& in : p.inputs) {
+        o << (in.kind == InputKind::Unknown ? "unknown " : in.kind == InputKind::Array ? "array " : in.kind == InputKind::Sparse ? "sparse " : "param ") << in.name << " slot " << in.slot;
+        if (in.kind == InputKind::Unknown || in.kind == InputKind::Array) { o << " channels " << in.channels << (in.is_u8 ? " uint8" : "") << " over"; for (int d : in.dims) o << " " << p.dims[d]; if (in.exclude) o << " (Exclude)"; }
+        if (in.kind == InputKind::Sparse) o << " " << p.dims[in.dims[0]] << " -> " << p.dims[in.dims[1]];
+        o << "\n";
+    }
+    o << "preconditioner " << (p.use_preconditioner ? 1 : 0) << "\n";
+    for (auto& r : p.residuals) { o << "residual " << r.name << " x" << r.exprs.size() << " over"; for (int d : r.domain) o << " " << p.dims[d]; if (r.mat_J) o << " J"; if (r.mat_JtJ) o << " JtJ"; if (r.mat_Jp) o << " Jp"; o << "\n"; }
+    return o.str();
+}
+
+}  // namespace dsl
+}  // namespace thallo

@@ -137,5 +137,7 @@ struct ProblemSpec {
 bool parse_problem_file(const char* filename, ProblemSpec& out);
 
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims);
+// the mini front-end (dsl.hpp): run the .t, generate its residual-wise kernels, compile them with hipRTC; NULL + set_error on failure
+EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims);
 
 }  // namespace thallo

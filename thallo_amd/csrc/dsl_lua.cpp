@@ -641,6 +641,7 @@ struct Interp {
                 return { vec(out) };
             }
             if (m == "materialize") return {};
+            if (m == "dot") { if (args.size() != 1) fail(ln + "v:dot(w)"); return { scalar(dot(comps(obj, "dot"), comps(args[0], "dot"), ln)) }; }
         }
         if (is_symk(obj, SymV::MatInfo)) {
             Residual& r = P.residuals[obj.sym->id];
@@ -733,12 +734,12 @@ struct Interp {
     void def(const std::string& name) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = name; globals->vars[name] = f; }
     void install_builtins()
     {
-        for (const char* n : { "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
+        for (const char* n : { "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
                                "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
                                "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
             def(n);
         for (const char* n : { "float", "float2", "float3", "float4", "float6", "float9", "thallo_float", "thallo_float2", "thallo_float3", "thallo_float4", "thallo_float6", "thallo_float9",
-                               "uint8", "double", "int", "thallo_int" }) { SymV s; s.k = SymV::TypeName; s.s = n; globals->vars[n] = Value::make_sym(s); }
+                               "thallo_mat3f", "thallo_mat4f", "mat3f", "mat4f", "float8", "thallo_float8", "uint8", "double", "int", "thallo_int" }) { SymV s; s.k = SymV::TypeName; s.s = n; globals->vars[n] = Value::make_sym(s); }
         Value math; math.t = Value::Table; math.tab = std::make_shared<TableV>();
         for (const char* n : { "sqrt", "sin", "cos", "abs" }) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = n; math.tab->fields.push_back({ n, f }); }
         math.tab->fields.push_back({ "pi", Value::num(3.14159265358979323846) });
@@ -748,6 +749,8 @@ struct Interp {
     {
         if (!is_symk(t, SymV::TypeName)) fail("line " + std::to_string(line) + ": expected an element type (float, thallo_float2, uint8, ...)");
         const std::string& s = t.sym->s; *u8 = s == "uint8";
+        if (s.find("mat3f") != std::string::npos) return 9;
+        if (s.find("mat4f") != std::string::npos) return 16;
         const char last = s.back();
         return isdigit((unsigned char)last) && s != "uint8" ? last - '0' : 1;
     }
@@ -762,12 +765,18 @@ struct Interp {
     {
         const std::string ln = "line " + std::to_string(line) + ": ";
         auto need = [&](size_t n) { if (a.size() < n) fail(ln + f + " needs " + std::to_string(n) + " argument(s)"); };
+        if (f == "Dim") {                           // Dim("N", 0): one dimension with an explicit position in the dimensions array (thallo.t:1580-1600)
+            need(2); if (a[0].t != Value::Str || a[1].t != Value::Num) fail(ln + "Dim(name, index)");
+            const size_t id = (size_t)a[1].n; if (id > 16) fail(ln + "Dim index too large");
+            if (P.dims.size() <= id) P.dims.resize(id + 1);
+            P.dims[id] = a[0].s; SymV s; s.k = SymV::Dim; s.id = (int)id; return { Value::make_sym(s) };
+        }
         if (f == "Dims") { Values out; for (auto& v : a) { if (v.t != Value::Str) fail(ln + "Dims takes names"); SymV s; s.k = SymV::Dim; s.id = (int)P.dims.size(); P.dims.push_back(v.s); out.push_back(Value::make_sym(s)); } return out; }
         if (f == "Unknown" || f == "Array") {
             need(3); Input in; in.kind = f == "Unknown" ? InputKind::Unknown : InputKind::Array;
             in.channels = type_channels(a[0], &in.is_u8, line); in.dims = dim_list(a[1], line);
             if (a[2].t != Value::Num) fail(ln + f + ": the third argument is the parameter index"); in.slot = (int)a[2].n;
-            if (in.dims.empty() || in.dims.size() > 2) fail(ln + f + ": 1- and 2-dimensional images are supported");
+            if (in.dims.empty() || in.dims.size() > 3) fail(ln + f + ": 1-, 2- and 3-dimensional images are supported");
             if (in.kind == InputKind::Unknown && in.is_u8) fail(ln + "uint8 unknowns are not supported");
             return { decl(in) };
         }
@@ -815,6 +824,7 @@ struct Interp {
         auto cmp2 = [&](Op op) { need(2); auto x = comps(a[0], f.c_str()), y = comps(a[1], f.c_str()); const size_t n = std::max(x.size(), y.size()); std::vector<E> out;
                                  if (x.size() != y.size() && x.size() != 1 && y.size() != 1) fail(ln + f + ": vector lengths differ");
                                  for (size_t i = 0; i < n; ++i) out.push_back(cmp(op, x[x.size() == 1 ? 0 : i], y[y.size() == 1 ? 0 : i])); return Values{ vec(out) }; };
+        if (f == "neq") { Values e = cmp2(Op::Eq); return { map1(Op::Not, e[0], "neq") }; }
         if (f == "eq") return cmp2(Op::Eq); if (f == "greater") return cmp2(Op::Gt); if (f == "greatereq") return cmp2(Op::Ge);
         if (f == "less") return cmp2(Op::Lt); if (f == "lesseq") return cmp2(Op::Le);
         if (f == "And") return cmp2(Op::And); if (f == "Or") return cmp2(Op::Or);
@@ -825,6 +835,13 @@ struct Interp {
         if (f == "sin") { need(1); if (a[0].t == Value::Num) return { Value::num(std::sin(a[0].n)) }; return { map1(Op::Sin, a[0], "sin") }; }
         if (f == "cos") { need(1); if (a[0].t == Value::Num) return { Value::num(std::cos(a[0].n)) }; return { map1(Op::Cos, a[0], "cos") }; }
         if (f == "Vector") { std::vector<E> out; for (auto& v : a) { auto c = comps(v, "Vector"); out.insert(out.end(), c.begin(), c.end()); } if (out.empty()) fail(ln + "empty Vector"); SymV s; s.k = SymV::Vec; s.v = out; return { Value::make_sym(s) }; }
+        if (f == "gemv") {                          // lib.t:78-90: row-major matrix (rows x cols values) times a vector of cols values
+            need(2); auto M = comps(a[0], "gemv"), v = comps(a[1], "gemv");
+            if (v.empty() || M.size() % v.size()) fail(ln + "gemv: matrix size is not a multiple of the vector size");
+            std::vector<E> out;
+            for (size_t r = 0; r < M.size() / v.size(); ++r) { E val = bin(Op::Mul, M[r * v.size()], v[0]); for (size_t c = 1; c < v.size(); ++c) val = bin(Op::Add, val, bin(Op::Mul, M[r * v.size() + c], v[c])); out.push_back(val); }
+            return { vec(out) };
+        }
         if (f == "dot") { need(2); return { scalar(dot(comps(a[0], "dot"), comps(a[1], "dot"), ln)) }; }
         if (f == "cross") { need(2); return { vec(cross(comps(a[0], "cross"), comps(a[1], "cross"), ln)) }; }
         if (f == "normalize") { need(1); auto v = comps(a[0], "normalize"); E inv = bin(Op::Div, konst(1.0), un(Op::Sqrt, dot(v, v, ln))); std::vector<E> out; for (auto& e : v) out.push_back(bin(Op::Mul, e, inv)); return { vec(out) }; }

@@ -428,6 +428,12 @@ int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, in
    (J, then J^T with dot_with = p), `[[Jt][J]]p` = one call on the pre-multiplied J^T J. */
 int thallo_hip_csr_spmv(int rows, const int* rowptr, const int* col, const float* val, const float* x, float* y,
                         const float* dot_with, float* dot_out, thallo_stream_t stream);
+/* Materialized J of a generated plugin in ELL form ([rows][K] values and unknown indices, -1 = no unknown), applied without a transpose:
+ * mode 0: Ap += J^T (J p) in one pass ([Jt][[J]p]); mode 1: Jp = J p; mode 2: Ap += J^T Jp (the Jt[Jp] pair on a materialized J). */
+int thallo_hip_ell_apply(int mode, long rows, int K, const float* val, const int* col, const float* p, float* Jp, float* Ap, thallo_stream_t stream);
+/* dense J^T J (n x n, zeroed by the caller) from materialized rows, and y = M x: the dense [JtJ]p schedule for small n (gauss_newton.t:560-622) */
+int thallo_hip_dense_jtj_accumulate(long rows, int K, const float* val, const int* col, long n, float* JtJ, thallo_stream_t stream);
+int thallo_hip_dense_gemv(long n, const float* M, const float* x, float* y, thallo_stream_t stream);
 
 /* ---------------------------------------------------------------- multi-GPU device-side exchange (one process per GPU) */
 /* Device memory that other processes can map: *ptr = hipMalloc(bytes) (zeroed), handle_out = 64-byte hipIpcMemHandle_t. */

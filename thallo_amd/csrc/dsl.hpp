@@ -79,10 +79,11 @@ struct Problem {
 bool run_problem_file(const char* filename, Problem& out, std::string& err);
 
 // dsl_codegen.cpp
-struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 cost, 1 evalJTF, 2 applyJTJ, 3 applyJ (Jp = J p), 4 applyJt (Ap += J^T Jp)
+struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 cost, 1 evalJTF, 2 applyJTJ, 3 applyJ (Jp = J p), 4 applyJt (Ap += J^T Jp), 5 dumpJ (materialize the rows)
 struct Generated {
     std::string source;                            // one HIP translation unit
     std::vector<GenKernel> kernels;
+    std::vector<int> slots_per_row;                // per residual: K, the entries per materialized row
     std::vector<long> jp_offset;                   // per residual: offset of its rows in the Jp vector (Jt[Jp] schedule), in units of elements x components
     int n_prm = 0;
 };

@@ -2,9 +2,15 @@
 // with hipRTC for gfx950 and driven through the same interface as the hand-written plugins, in the reference's unfused residual-wise
 // schedule (gauss_newton.t:998-1015: PCGInit1 + _Finish, PCGStep1 = clear Ap_X, one kernel per residual group, PCGStep1_Finish;
 // PCGStep2 / PCGStep3 are the energy-independent kernels of pcg_kernels.hip).
-// Schedule lines honoured per residual (thallo.t:5757-5772): `r.<name>.Jp:set_materialize(true)` -> the Jt[Jp] pair (applyJ into a
-// materialized Jp vector, applyJt from it: gauss_newton.t:1027-1047); J / JtJ materialization runs the matrix-free kernels (a legal
-// schedule for any request: materialization is an optimisation hint in the reference's autoscheduler too).
+// Schedule lines honoured per residual (thallo.t:5757-5772; the reference's five J^T J p schedules, gauss_newton.t:1019-1047, 1332-1525, 560-622):
+//   (none)                              JtJp inline: the generated applyJTJ kernel recomputes the partials every PCG iteration
+//   r.X.Jp:set_materialize(true)        Jt[Jp]: generated applyJ into a materialized Jp vector, generated applyJt from it
+//   r.X.J:set_materialize(true)         [Jt][[J]p]: the generated dumpJ kernel writes the residual's rows once per GN iteration (ELL: K entries per
+//                                       row); every PCG iteration applies them with the energy-independent thallo_hip_ell_apply -- no derivative is
+//                                       re-evaluated inside the PCG loop; with Jp materialized too, as the pair J p / J^T (J p)
+//   J and JtJ materialized on EVERY residual and n <= THALLO_DENSE_JTJ_MAX (default 2048): dense [JtJ]p -- J^T J accumulated once per GN iteration,
+//                                       one GEMV per PCG iteration (gauss_newton.t:560-622, 1216-1241); above that size JtJ requests run as [Jt][[J]p]
+//                                       (the reference's [[Jt][J]]p forms the sparse product with csrgemm: the same operator, not built here)
 #include "dsl.hpp"
 #include "plugin.hpp"
 #include <hip/hiprtc.h>
@@ -32,6 +38,9 @@ class GeneratedPlugin : public EnergyPlugin {
     std::vector<void*> bound;                      // problem parameters as last bound (by input index)
     DeviceBuffer jp;                               // Jt[Jp] schedule: the materialized Jp vector
     std::vector<long> nel, jp_off;                 // per residual: elements, offset of its rows in jp
+    std::vector<DeviceBuffer*> jval, jcol;         // per residual with a materialized J: ELL values / unknown indices ([rows][K])
+    DeviceBuffer dense;                            // dense [JtJ]p: the n x n matrix
+    bool dense_ = false;
     bool ok_ = false;
 
     long elements(const dsl::Residual& r) const { long n = 1; for (int d : r.domain) n *= dimv[d]; return n; }
@@ -45,7 +54,8 @@ class GeneratedPlugin : public EnergyPlugin {
         hipError_t e = hipModuleLaunchKernel(fn[kernel], grid, 1, 1, 256, 1, 1, 0, s, args, nullptr);
         return e == hipSuccess ? 0 : -(int)e;
     }
-    int kernel_of(int residual, int kind) const { return residual * 5 + kind; }
+    int kernel_of(int residual, int kind) const { return residual * 6 + kind; }
+    long rows_of(size_t ri) const { return nel[ri] * (long)P.residuals[ri].exprs.size(); }
 
 public:
     GeneratedPlugin(const dsl::Problem& p, const unsigned* dims) : P(p)
@@ -71,9 +81,22 @@ public:
         long rows = 0;
         for (auto& r : P.residuals) { nel.push_back(elements(r)); jp_off.push_back(rows); if (r.mat_Jp) rows += nel.back() * (long)r.exprs.size(); }
         if (rows && jp.alloc(sizeof(float) * (size_t)rows + 256)) { set_error("%s: out of device memory for the materialized Jp", label.c_str()); return; }
+        bool all_jtj = true;
+        for (auto& r : P.residuals) all_jtj = all_jtj && r.mat_J && r.mat_JtJ;
+        long dense_max = 2048; if (const char* e = getenv("THALLO_DENSE_JTJ_MAX")) dense_max = atol(e);
+        dense_ = all_jtj && n_unk <= dense_max;
+        if (dense_ && dense.alloc(sizeof(float) * (size_t)n_unk * (size_t)n_unk)) { set_error("%s: out of device memory for the dense JtJ", label.c_str()); return; }
+        jval.assign(P.residuals.size(), nullptr); jcol.assign(P.residuals.size(), nullptr);
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            if (!P.residuals[ri].mat_J && !P.residuals[ri].mat_JtJ) continue;
+            const size_t ent = (size_t)rows_of(ri) * (size_t)G.slots_per_row[ri];
+            jval[ri] = new DeviceBuffer(); jcol[ri] = new DeviceBuffer();
+            if (jval[ri]->alloc(sizeof(float) * ent + 256) || jcol[ri]->alloc(sizeof(int) * ent + 256)) { set_error("%s: out of device memory for the materialized J of %s", label.c_str(), P.residuals[ri].name.c_str()); return; }
+        }
         ok_ = true;
     }
-    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); }
+    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : jval) delete b; for (auto b : jcol) delete b; }
+    const char* schedule() const { return dense_ ? "dense [JtJ]p" : "per residual"; }
     bool ok() const { return ok_; }
 
     int compile()
@@ -144,15 +167,35 @@ public:
             const int rc = launch(kernel_of((int)ri, 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
         if (v.diag && hipMemcpyAsync(v.diag, v.pre, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;      // LM: the raw diagonal
+        if (dense_ && hipMemsetAsync(dense.ptr, 0, sizeof(float) * (size_t)n_unk * (size_t)n_unk, s) != hipSuccess) return -1;
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {            // precomputeJ (gauss_newton.t:1019-1025): once per GN iteration
+            if (!jval[ri]) continue;
+            float* jv = (float*)jval[ri]->ptr; int* jc = (int*)jcol[ri]->ptr; void* args[] = { ctx.data(), &jv, &jc };
+            int rc = launch(kernel_of((int)ri, 5), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
+            if (dense_ && (rc = thallo_hip_dense_jtj_accumulate(rows_of(ri), G.slots_per_row[ri], jv, jc, n_unk, (float*)dense.ptr, s)) < 0) return rc;
+        }
         return thallo_hip_pcg_init_finish(v.r, v.pre, v.pre, v.z, v.n, P.use_preconditioner ? 1 : 0, aN, s);           // PCGInit1_Finish (gauss_newton.t:712-731)
     }
     int apply(LaunchCtx& c, const float* p, float* Ap, float* out, long n_alloc)
     {
         hipStream_t s = c.stream;
+        if (dense_) {                                  // dense [JtJ]p
+            const int rc = thallo_hip_dense_gemv(n_unk, (const float*)dense.ptr, p, Ap, s); if (rc < 0) return rc;
+            return thallo_hip_dot(p, Ap, n_unk, out, s);
+        }
         if (hipMemsetAsync(Ap, 0, (size_t)n_alloc * sizeof(float), s) != hipSuccess) return -1;                         // Ap_X:clear() (gauss_newton.t:1633-1635)
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
             const int g = grid_for(nel[ri], 4096);
-            if (P.residuals[ri].mat_Jp) {          // Jt[Jp]: Jp = J p materialized, then Ap += J^T Jp
+            if (jval[ri]) {                        // materialized J: no derivative evaluation inside the PCG loop
+                const float* jv = (const float*)jval[ri]->ptr; const int* jc = (const int*)jcol[ri]->ptr; const int K = G.slots_per_row[ri];
+                int rc;
+                if (P.residuals[ri].mat_Jp) {
+                    float* j = (float*)jp.ptr + jp_off[ri];
+                    rc = thallo_hip_ell_apply(1, rows_of(ri), K, jv, jc, p, j, nullptr, s); if (rc < 0) return rc;
+                    rc = thallo_hip_ell_apply(2, rows_of(ri), K, jv, jc, nullptr, j, Ap, s);
+                } else rc = thallo_hip_ell_apply(0, rows_of(ri), K, jv, jc, p, nullptr, Ap, s);
+                if (rc < 0) return rc;
+            } else if (P.residuals[ri].mat_Jp) {          // Jt[Jp]: Jp = J p materialized, then Ap += J^T Jp
                 float* j = (float*)jp.ptr + jp_off[ri];
                 void* a1[] = { ctx.data(), &p, &j }; int rc = launch(kernel_of((int)ri, 3), g, a1, s); if (rc < 0) return rc;
                 void* a2[] = { ctx.data(), &j, &Ap }; rc = launch(kernel_of((int)ri, 4), g, a2, s); if (rc < 0) return rc;

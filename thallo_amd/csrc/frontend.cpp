@@ -182,6 +182,11 @@ bool parse_problem_file(const char* filename, ProblemSpec& out)
         // honoured when it covers every residual group (a mixed schedule runs matrix-free: same values, different evaluation order)
         if (!keys.empty() && matJ.size() == keys.size()) out.constants["materialize_J"] = 1.0;
         if (!keys.empty() && matJtJ.size() == keys.size()) out.constants["materialize_JtJ"] = 1.0;
+        // a schedule the hand-written plugins do not implement (only some residuals materialized, e.g. tests/minimal_graph/laplacian.t:19-20,
+        // or a materialized Jp): the Plan hands the file to the front-end, whose generated plugin schedules per residual (dsl_plugin.cpp)
+        bool any_jp = false;
+        for (size_t i = 0; i + 4 < t.size(); ++i) if (t[i].s == "Jp" && t[i + 1].s == ":" && t[i + 2].s == "set_materialize" && t[i + 4].s == "true") any_jp = true;
+        if (any_jp || (!matJ.empty() && matJ.size() != keys.size()) || (!matJtJ.empty() && matJtJ.size() != keys.size())) out.constants["schedule_per_residual"] = 1.0;
     }
     std::string keystr; for (auto& k : keys) { if (!keystr.empty()) keystr += ","; keystr += k; }
     const std::string sig = sig_of(inputs);

@@ -149,8 +149,12 @@ def test_reduction_order_is_the_documented_one(torch, nb):
 
 
 # ------------------------------------------------------------------ image_warping trajectories
-@pytest.mark.parametrize("W,H,nit,lit", [(64, 64, 8, 100), (96, 80, 5, 40), (70, 33, 4, 25), (256, 256, 4, 50), (1, 1, 2, 3), (130, 3, 3, 10)])
-def test_image_warping_cost_trajectory(torch, orc, W, H, nit, lit):
+@pytest.mark.parametrize("kernel", ["march", "tile"])
+@pytest.mark.parametrize("W,H,nit,lit", [(64, 64, 8, 100), (96, 80, 5, 40), (70, 33, 4, 25), (256, 256, 4, 50), (1, 1, 2, 3), (130, 3, 3, 10), (252, 41, 3, 20)])
+def test_image_warping_cost_trajectory(torch, orc, monkeypatch, W, H, nit, lit, kernel):
+    """Both one-kernel PCG iterations against the oracle at every size: the plugin picks the marching kernel from ~0.4 Mpixel up and the
+    LDS-tiled one below (plugins.cpp ImageWarpingPlugin::prepare); THALLO_MARCH=2 / 0 force one or the other (odd W always tiles)."""
+    monkeypatch.setenv("THALLO_MARCH", "2" if kernel == "march" else "0")
     p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
     po = copy_params(p)
     co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=nit, lIterations=lit)

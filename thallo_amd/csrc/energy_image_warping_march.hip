@@ -335,7 +335,8 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
                 issue(slot[j], t + 3 > t_last ? t_last : t + 3);
                 if (DMODE != 1) issue_d(dsl[(j + 2) % 3], t + 2);      // (the slot taken one step ago)
                 fence_order();                               // ... and in front of the arithmetic
-                publish(cur, curd, t, t >= t_first && t <= t_last, wn);
+                // (wave-uniform branch, no load inside: the three lead-in rows and the rounding-up rows skip the arithmetic; the window keeps its zeros)
+                if (t >= t_first && t <= t_last) publish(cur, curd, t, true, wn);
                 if (DBG == 3) { if (t >= t_first && t <= t_last) stencil(t, wc, wn, wm); }      // (timing only)
                 else if (t - 1 >= ya && t <= t_last) stencil(t - 1, wm, wc, wn);
             }

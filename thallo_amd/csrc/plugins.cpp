@@ -189,7 +189,9 @@ public:
         if (rc < 0) { set_error("image_warping: UrShape check failed (%d)", rc); return -1; }
         int bad = 1;
         if (hipMemcpyAsync(&bad, word, sizeof(int), hipMemcpyDeviceToHost, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess) return -1;
-        march_ = bad == 0;
+        // measured (tools/march_probe.py MB_MODE=rows, profiles/r02): 2048^2 82 vs 90 us, 1024^2 29.8 vs 31.5 us, 2048x256 21.1 vs 21.4 us, but 512^2 14.9 vs
+        // 13.5 us -- below ~0.4 Mpixel a wave's short march is all lead-in and tail, the LDS-tiled kernel wins
+        march_ = bad == 0 && ((long)W * H >= 400000 || (e && e[0] == '2'));          // THALLO_MARCH=2: the marching kernel at every size (tests)
         return 0;
     }
     float* unknown_ptr(int k) override { return k == 0 ? offset : angle; }

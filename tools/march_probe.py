@@ -140,6 +140,16 @@ def cfg(depth, nt, occ, dbg, rows=0, mp=0):
         L.thallo_hip_march_debug_set(what, v)
 
 
+if os.environ.get("MB_MODE") == "rows":          # rows-per-segment sweep at the current size (small images / slabs)
+    out = {"tile_us": round(timeit("tile"), 2)}
+    for rows in (0, 2, 3, 4, 5, 6, 8, 12, 16, 24, 36):
+        L.thallo_hip_march_debug_set(0, rows)
+        try:
+            out[f"march_rows{rows}_us"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2)]
+        except AssertionError as e:
+            out[f"march_rows{rows}_us"] = "launch refused"
+    print(json.dumps(out)); sys.exit(0)
+
 if __name__ == "pmc":
     cfg(2, 5, 2, 0); timeit("march", modes=(2,)); timeit("march", modes=(4,))
     cfg(2, 5, 2, 3); timeit("march", modes=(2,))

@@ -109,6 +109,9 @@ void ThalloX_EnableLM(Thallo_Plan* plan, int enable);
 /* Name of the plugin a plan runs ("image_warping", "laplacian_image", ...). */
 const char* ThalloX_PlanEnergyName(Thallo_Plan* plan);
 
+/* 1 if the most recent Thallo_ProblemInit on this plan succeeded (parameters bound, plugin prepared), else 0: Init itself returns void. */
+int ThalloX_PlanReady(Thallo_Plan* plan);
+
 /* Last error message of this thread ("" if none). */
 const char* ThalloX_LastError(void);
 
@@ -123,6 +126,41 @@ unsigned long long ThalloX_ProblemFileHash(const char* filename, char* energy_ou
  * to cap - 1) or -1 (ThalloX_LastError).  A Plan on a file no hand-written plugin recognises -- or on any file under THALLO_FRONTEND=generate -- compiles
  * that unit with hipRTC and runs it. */
 int ThalloX_FrontendText(const char* filename, int what, char* out, int cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU, one process per GPU (the reference is single-device, API/src/util.t:769-772).
+ *
+ * Image-stencil problems are split into contiguous ROW SLABS.  Each process makes its Plan for its LOCAL image -- the rows it owns plus one
+ * ghost row towards each neighbour -- passes the local buffers to Init / Step as usual, and declares the split once, before
+ * Thallo_ProblemInit, with ThalloX_PlanSetDistributed.  From then on Thallo_ProblemInit / Step / CurrentCost are COLLECTIVE: every rank calls
+ * them in the same order; costs, alpha and beta are rank-ordered sums, bit-identical on every rank.  Per PCG iteration each rank runs ONE
+ * kernel and ONE exchange:
+ *   - the caller's all-gather (RCCL: ncclAllGather on `stream`) of [alphaD, N, S1, S2 | first and last owned row of Ap], or
+ *   - when device_exchange != 0 and the self-check at the first Init passes on this topology: no host-visible collective at all -- the
+ *     kernel stores its scalars into every rank's mailbox and its boundary rows into the neighbours' ghost rows over xGMI
+ *     (hipIpc-mapped fine-grained memory) and its last workgroup waits for the peers' granules.
+ * Supported: image_warping with UrShape on the unit pixel grid, W % 4 == 0, Gauss-Newton.  Everything else returns an error.
+ * ------------------------------------------------------------------------------------------ */
+/* Every rank contributes `bytes_per_rank` bytes at `send` and receives world * bytes_per_rank at `recv`, rank order; DEVICE pointers;
+ * enqueued on `stream` (a hipStream_t).  Return 0 on success.  world == 1: may be NULL. */
+typedef int (*ThalloX_AllGatherFn)(void* user, const void* send, void* recv, long bytes_per_rank, void* stream);
+typedef struct ThalloX_Distributed {
+    int rank, world;                 /* world <= 8 (THALLO_DIST_MAX_WORLD) */
+    unsigned int row0, row1;         /* owned rows [row0, row1) of the local image; a ghost row above iff row0 == 1, below iff row1 == H_local - 1 */
+    ThalloX_AllGatherFn allgather;
+    void* user;
+    int device_exchange;             /* 1: try the mailbox / peer-to-peer exchange (falls back to the all-gather if its self-check fails) */
+} ThalloX_Distributed;
+/* Collective.  0 on success, -1 on error (ThalloX_LastError); every rank gets the same answer. */
+int ThalloX_PlanSetDistributed(Thallo_Plan* plan, const ThalloX_Distributed* cfg);
+/* JSON text: transport in use ("exchange": "p2p-mailbox" | "allgather"), memory kind of the mapped blocks, self-check outcome. */
+const char* ThalloX_PlanDistributedInfo(Thallo_Plan* plan);
+/* what = 0: read (and with value != 0 clear) the device-side exchange's error word -- 1 if a bounded mailbox wait timed out since the last clear
+ *           (synchronises the stream); what = 1: value 0 switches this plan to the all-gather transport for good (every rank must do the same).
+ * Returns the word / 0, or -1. */
+int ThalloX_DistributedControl(Thallo_Plan* plan, int what, int value);
+/* bench: `reps` back-to-back launches of the one-kernel PCG iteration on this rank's slab, without the exchange (kernel time per rank) */
+int ThalloX_DistributedKernelOnly(Thallo_Plan* plan, int reps);
 
 #ifdef __cplusplus
 }

@@ -36,112 +36,124 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, nit, lit, q):
+def _worker(rank, world, port, W, H, nit, lit, q, device_exchange=False):
+    """One rank of a slab run through the LIBRARY (ThalloX_PlanSetDistributed + Thallo_ProblemInit / Step / CurrentCost)."""
     import torch
     import torch.distributed as dist
     from thallo_amd import synthetic as syn
-    from thallo_amd.distributed import make_hip_solver
+    from thallo_amd.distributed import PlanSlabSolver
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.image_warping(W, H, n_markers=8)
-        solver, lay = make_hip_solver(p, W, H, rank, world, lit)
+        solver = PlanSlabSolver(p, W, H, rank, world, lit, device_exchange=device_exchange)
         costs = solver.solve(nit, lit)
-        be = solver.be
-        off = be.offset.view(be.Hl, W, 2)[lay.row0:lay.row1].cpu().numpy()
-        ang = be.angle.view(be.Hl, W)[lay.row0:lay.row1].cpu().numpy()
-        q.put((rank, costs, lay.g0, lay.g1, off, ang))
+        lay = solver.lay
+        info = solver.info
+        err = solver.solver.distributed_error() if device_exchange else 0
+        trace = solver.solver.alpha_beta_trace()
+        off, ang = solver.owned()
+        q.put((rank, costs, lay.g0, lay.g1, off, ang, info, err, trace))
+        solver.solver.close()
     finally:
         dist.destroy_process_group()
 
 
-def _worker_p2p(rank, world, port, W, H, nit, lit, q):
-    import torch
-    import torch.distributed as dist
-    from thallo_amd import synthetic as syn
-    from thallo_amd.distributed import make_hip_solver
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        p = syn.image_warping(W, H, n_markers=8)
-        solver, lay = make_hip_solver(p, W, H, rank, world, lit, ipc=True)
-        on = solver.try_enable_p2p(l_iters=min(6, lit))
-        costs = solver.solve(nit, lit)
-        be = solver.be
-        err = be.p2p_error() if on else -1
-        trace = be.S[2:2 + 2 * lit + 1].cpu().numpy()
-        off = be.offset.view(be.Hl, W, 2)[lay.row0:lay.row1].cpu().numpy()
-        ang = be.angle.view(be.Hl, W)[lay.row0:lay.row1].cpu().numpy()
-        q.put((rank, costs, lay.g0, lay.g1, off, ang, on, dict(solver.p2p_check, post_mortem=getattr(be, 'p2p_post_mortem', None)), err, trace))
-        be.close()
-    finally:
-        dist.destroy_process_group()
+def _run(world, W, H, nit, lit, device_exchange):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, nit, lit, q, device_exchange)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    res.sort(key=lambda t: t[0])
+    return res
 
 
 @pytest.mark.parametrize("world,W,H,nit,lit", [(2, 128, 96, 3, 30), (3, 64, 100, 2, 20), (1, 64, 48, 2, 10)])
 def test_hip_slabs_p2p_mailbox_exchange(orc, world, W, H, nit, lit):
     """The device-side exchange (mailbox granules + peer-to-peer ghost rows, csrc/dist_device.hpp) between `world` processes --
-    here all on GPU 0, mapped through hipIpc like real peers: it must enable itself (self-check against the collective path),
-    never time out, give every rank bit-identical alpha/beta, and follow the oracle's cost trajectory."""
-    import torch.multiprocessing as mp
+    here all on GPU 0, mapped through hipIpc like real peers -- behind Thallo_ProblemStep: it must enable itself (self-check against the
+    all-gather path at the first Init), never time out, give every rank bit-identical alpha/beta, and follow the oracle's cost trajectory."""
     from thallo_amd import synthetic as syn
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_p2p, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
-    for p_ in procs:
-        p_.start()
-    res = _collect(q, procs, world)
+    res = _run(world, W, H, nit, lit, True)
     p = syn.image_warping(W, H, n_markers=8)
     co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=nit, lIterations=lit)
-    res.sort(key=lambda t: t[0])
-    for rank, costs, g0, g1, off, ang, on, check, err, trace in res:
-        assert on, (rank, check)
-        assert err == 0, (rank, check)
+    for rank, costs, g0, g1, off, ang, info, err, trace in res:
+        assert info["exchange"] == "p2p-mailbox" and info["self_check"]["all_ranks_pass"], (rank, info)
+        assert info["memory"] == ["fine-grained", "fine-grained"], info
+        assert err == 0, (rank, info)
         assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
-        assert (trace == res[0][9]).all()          # rank-ordered sums: identical bits on every rank
+        assert costs == res[0][1]
+        assert trace == res[0][8] and len(trace) == lit          # rank-ordered sums: identical bits on every rank
 
 
 @pytest.mark.parametrize("world,W,H,nit,lit", [(2, 128, 96, 3, 30), (3, 64, 100, 2, 20), (2, 256, 256, 2, 40)])
 def test_hip_slabs_match_oracle(orc, world, W, H, nit, lit):
-    import torch.multiprocessing as mp
+    """The all-gather transport of the same schedule (what runs when the device-side exchange is not requested or its self-check fails)."""
     from thallo_amd import synthetic as syn
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
-    for p_ in procs:
-        p_.start()
-    res = _collect(q, procs, world)
+    res = _run(world, W, H, nit, lit, False)
     p = syn.image_warping(W, H, n_markers=8)
     co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=nit, lIterations=lit)
-    res.sort(key=lambda t: t[0])
-    for rank, costs, g0, g1, off, ang in res:
+    for rank, costs, g0, g1, off, ang, info, err, trace in res:
+        assert info["exchange"] == "allgather", info
         assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
-        assert costs == res[0][1]
+        assert costs == res[0][1] and trace == res[0][8]
         assert np.abs(off - p[0][g0:g1]).max() <= 2e-4 * np.abs(p[0]).max()
         assert np.abs(ang - p[1][g0:g1]).max() <= 2e-4 * max(1.0, np.abs(p[1]).max())
 
 
+def test_hip_slab_transports_agree_bitwise_on_the_unknowns(orc):
+    """Both transports add the per-rank sums in rank order from the same per-rank values: same alpha/beta bits, same unknowns."""
+    a = _run(2, 128, 64, 2, 12, True)
+    b = _run(2, 128, 64, 2, 12, False)
+    for ra, rb in zip(a, b):
+        assert ra[6]["exchange"] == "p2p-mailbox" and rb[6]["exchange"] == "allgather"
+        assert ra[8] == rb[8] and ra[1] == rb[1]
+        assert (ra[4] == rb[4]).all() and (ra[5] == rb[5]).all()
+
+
 def test_hip_single_slab_equals_library_path(orc):
-    """world_size 1 through the slab driver == Thallo_ProblemSolve on the same instance."""
+    """world_size 1 declared as a slab == the plain single-device plan on the same instance (same kernels, same one-kernel schedule; the slab
+    form adds its scalars through the rank-ordered finish instead of the kernel's last workgroup: same order, same bits)."""
     import torch
     import thallo_amd
     from thallo_amd import synthetic as syn
-    from thallo_amd.distributed import make_hip_solver
+    from thallo_amd.distributed import PlanSlabSolver
     W, H = 192, 80
     p = syn.image_warping(W, H, n_markers=8)
-    solver, lay = make_hip_solver(p, W, H, 0, 1, 25)
+    solver = PlanSlabSolver(p, W, H, 0, 1, 25, device_exchange=False)
     costs = solver.solve(2, 25)
     dev = [torch.from_numpy(x.copy()).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
     s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
     _, c2 = s.solve(dev, profiled=True, nIterations=2, lIterations=25)
-    # the library runs the one-kernel-per-iteration schedule (betaN from its double-precision expansion), the collective slab path the
-    # two-kernel one (betaN from the rounded r): same mathematics, last-bits different scalars
-    assert np.abs(np.array(costs) - np.array(c2)).max() <= 1e-5 * max(c2)
-    assert (solver.be.offset.view(-1) - dev[0].view(-1)).abs().max().item() <= 2e-4 * dev[0].abs().max().item()
+    assert np.abs(np.array(costs) - np.array(c2)).max() <= 1e-6 * max(c2)
+    assert (solver.offset.view(-1) - dev[0].view(-1)).abs().max().item() <= 1e-5 * dev[0].abs().max().item()
+
+
+def test_distributed_plan_rejects_what_it_cannot_run():
+    """Loud failures: a non-slab energy, a slab without its ghost row, a bad rank, an irregular UrShape."""
+    import torch
+    import thallo_amd
+    from thallo_amd import api, synthetic as syn
+    s = thallo_amd.ThalloSolver((16, 8), thallo_amd.energy_file("laplacian_image"))
+    with pytest.raises(RuntimeError, match="no row-slab form"):
+        s.set_distributed(0, 1, 0, 8)
+    s = thallo_amd.ThalloSolver((64, 16), thallo_amd.energy_file("image_warping"))
+    with pytest.raises(RuntimeError, match="ghost row"):
+        s.set_distributed(0, 2, 0, 16, allgather=lambda *a: None)      # rank 0 of 2 must keep one ghost row below
+    with pytest.raises(RuntimeError, match="rank"):
+        s.set_distributed(3, 2, 0, 16)
+    W, H = 64, 16
+    p = syn.image_warping(W, H, n_markers=4)
+    p[2] = p[2] * 1.5                                                  # UrShape off the unit grid
+    dev = [torch.from_numpy(np.ascontiguousarray(x)).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
+    s.set_distributed(0, 1, 0, 16)
+    s.init(s.make_params(dev))
+    assert not s.ready() and "unit pixel grid" in api.last_error()
 
 
 # ------------------------------------------------------------------ camera-sharded bundle adjustment (HIP backend)

@@ -321,22 +321,22 @@ def test_shim_image_warping_zfree_schedule(torch, W, H):
     assert abs(a[5] - b[5]) <= 1e-3 * abs(b[5])                       # alphaD_1
 
 
+@pytest.mark.parametrize("one_kernel", ["1", "0"])
 @pytest.mark.parametrize("L", [1, 2, 3, 6, 7])
-def test_image_warping_deferred_delta_updates_are_bitwise_neutral(torch, L):
-    """Deferring every other `delta += alpha p` into the next fused PCGStep1 (THALLO_IW_STEP1_MODE, -6 B/pixel/iteration) and
-    finishing the GN step with one or two pending terms gives the same bits as updating delta every iteration."""
-    from thallo_amd.distributed import make_hip_solver
+def test_image_warping_deferred_delta_updates_are_bitwise_neutral(torch, monkeypatch, L, one_kernel):
+    """Deferring every other `delta += alpha p` into the next fused launch (THALLO_IW_STEP1_MODE, -6 B/pixel/iteration) and finishing the
+    GN step with one or two pending terms gives the same bits as updating delta every iteration (THALLO_BATCH_DELTA=0) -- in the one-kernel
+    schedule and in the PCGStep1 + PCGStep2 one."""
     W, H = 96, 64
     p = syn.image_warping(W, H, n_markers=6)
+    monkeypatch.setenv("THALLO_ONE_KERNEL", one_kernel)
     res = []
-    for batched in (True, False):
-        solver, lay = make_hip_solver(copy_params(p), W, H, 0, 1, L)
-        solver.be.batches_delta = batched
-        solver.be.one_kernel_collective = False          # the two-kernel form in both runs: only the batching differs
-        for _ in range(2):
-            solver.gn_step(L)
-        torch.cuda.synchronize()
-        res.append((solver.be.offset.clone(), solver.be.angle.clone(), solver.cost()))
+    for batched in ("1", "0"):
+        monkeypatch.setenv("THALLO_BATCH_DELTA", batched)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+        final, _ = s.solve(dev, nIterations=2, lIterations=L)
+        res.append((dev[0].clone(), dev[1].clone(), final))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
 
 

@@ -49,6 +49,15 @@ INT_PARAMS = ("nIterations", "lIterations", "residual_reset_period", "nIter")
 _lib = None
 
 
+# include/Thallo.h: ThalloX_AllGatherFn / ThalloX_Distributed
+AllGatherFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p)
+
+
+class DistributedT(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("row0", C.c_uint), ("row1", C.c_uint),
+                ("allgather", AllGatherFn), ("user", C.c_void_p), ("device_exchange", C.c_int)]
+
+
 def lib():
     """Load libThallo.so; raises (never falls back) if it has not been built."""
     global _lib
@@ -80,6 +89,11 @@ def lib():
     L.ThalloX_EnableLM.argtypes = [vp, C.c_int]
     L.ThalloX_PlanEnergyName.argtypes = [vp]; L.ThalloX_PlanEnergyName.restype = C.c_char_p
     L.ThalloX_LastError.restype = C.c_char_p
+    L.ThalloX_PlanReady.argtypes = [vp]; L.ThalloX_PlanReady.restype = C.c_int
+    L.ThalloX_PlanSetDistributed.argtypes = [vp, C.POINTER(DistributedT)]; L.ThalloX_PlanSetDistributed.restype = C.c_int
+    L.ThalloX_PlanDistributedInfo.argtypes = [vp]; L.ThalloX_PlanDistributedInfo.restype = C.c_char_p
+    L.ThalloX_DistributedControl.argtypes = [vp, C.c_int, C.c_int]; L.ThalloX_DistributedControl.restype = C.c_int
+    L.ThalloX_DistributedKernelOnly.argtypes = [vp, C.c_int]; L.ThalloX_DistributedKernelOnly.restype = C.c_int
     L.ThalloX_ProblemFileHash.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; L.ThalloX_ProblemFileHash.restype = C.c_ulonglong
     L.ThalloX_ProblemFileSchedule.argtypes = [C.c_char_p]; L.ThalloX_ProblemFileSchedule.restype = C.c_int
     # --- kernel shim entry points that python drives directly (distributed driver, bench, tests): typed, so a
@@ -208,6 +222,9 @@ class ThalloSolver:
     def init(self, params):
         self._L.Thallo_ProblemInit(self.state, self.plan, params)
 
+    def ready(self):
+        return self._L.ThalloX_PlanReady(self.plan) == 1
+
     def step(self, params):
         return self._L.Thallo_ProblemStep(self.state, self.plan, params)
 
@@ -239,6 +256,39 @@ class ThalloSolver:
                     "meanMS": getattr(s, n).meanMS, "stddevMS": getattr(s, n).stddevMS} for n, _ in s._fields_}
 
     # ---- extensions
+    def set_stream(self, stream_ptr):
+        self._L.ThalloX_SetStream(self.plan, C.c_void_p(stream_ptr))
+
+    def set_distributed(self, rank, world, row0, row1, allgather=None, device_exchange=True):
+        """Collective (include/Thallo.h ThalloX_PlanSetDistributed): this plan is rank `rank`'s row slab; `allgather(send_ptr, recv_ptr,
+        bytes_per_rank, stream_ptr) -> None` moves DEVICE bytes (thallo_amd.distributed.torch_allgather builds one over torch.distributed)."""
+        def _cb(_user, send, recv, nbytes, stream):
+            try:
+                allgather(send, recv, nbytes, stream or 0)
+                return 0
+            except Exception:      # noqa: BLE001 - an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._dist_cb = AllGatherFn(_cb) if allgather is not None else C.cast(None, AllGatherFn)      # kept alive with the plan
+        cfg = DistributedT(rank, world, row0, row1, self._dist_cb, None, 1 if device_exchange else 0)
+        if self._L.ThalloX_PlanSetDistributed(self.plan, C.byref(cfg)) != 0:
+            raise RuntimeError("ThalloX_PlanSetDistributed failed: " + last_error())
+
+    def distributed_info(self):
+        import json
+        t = self._L.ThalloX_PlanDistributedInfo(self.plan).decode()
+        return json.loads(t) if t else {}
+
+    def distributed_error(self, clear=True):
+        return self._L.ThalloX_DistributedControl(self.plan, 0, 1 if clear else 0)
+
+    def distributed_use_allgather(self):
+        return self._L.ThalloX_DistributedControl(self.plan, 1, 0)
+
+    def distributed_kernel_only(self, reps):
+        return self._L.ThalloX_DistributedKernelOnly(self.plan, reps)
+
     def enable_lm(self, on=True):
         """Run the LM branch of gauss_newton.t (dead as shipped in the reference, see include/Thallo.h)."""
         self._L.ThalloX_EnableLM(self.plan, 1 if on else 0)

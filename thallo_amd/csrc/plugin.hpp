@@ -115,6 +115,15 @@ public:
     }
     // pointer to unknown image k as currently bound
     virtual float* unknown_ptr(int k) = 0;
+    // ---- one row slab of a multi-GPU run (solver_dist.cpp): image-stencil plugins whose kernels take an owned-row range
+    virtual bool supports_row_slabs() const { return false; }
+    virtual int  set_row_slab(int /*row0*/, int /*row1*/) { return -1; }
+    virtual int  slab_width() const { return 0; }
+    virtual bool slab_grid_ok() const { return false; }       // after prepare(): the precondition of the one-kernel slab schedule holds on this rank
+    virtual unsigned char* slab_flags() { return nullptr; }    // per-pixel byte plane (written by pcg_init) whose ghost rows come from their owner each GN step
+    // pcg_iter that also stores its boundary rows of Ap_out into the neighbours' ghost rows and whose last workgroup runs the mailbox exchange
+    virtual int  pcg_iter_dist(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t,
+                               const thallo_dist_t&, float* /*alphaD_out*/, int /*slot0*/, float* /*aD_word*/, float* /*bN_word*/) { return -1; }
 };
 
 struct DeviceBuffer {

@@ -158,8 +158,10 @@ class ImageWarpingPlugin : public EnergyPlugin {
     float w_fit = 0, w_reg = 0;
     DeviceBuffer cs, flags, irregular;     // per-GN-iteration planes: (cos,sin) float2, validity bits; UrShape-is-grid word
     bool march_ = false;                   // UrShape verified (at Init) to be the unit pixel grid and W even: the marching one-kernel iteration
+    bool grid_ = false;                    // UrShape is the unit pixel grid (host-checked at Init)
+    int row0_ = 0, row1_ = 0;              // owned rows (all of them unless the Plan is one row slab of a multi-GPU run)
 public:
-    ImageWarpingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1])
+    ImageWarpingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1]), row1_((int)dims[1])
     {
         const long N = (long)W * H;
         imgs.push_back({ 0, 2 * N }); imgs.push_back({ 1, N });
@@ -181,9 +183,8 @@ public:
     int prepare(LaunchCtx& c) override
     {   // UrShape is a constant input: establish once per Init, on the host, whether it is the unit pixel grid (what the reference's
         // harness passes, CombinedSolver.h:158-176) -- that selects thallo_hip_iw_pcg_iter_march; pcg_init still re-verifies on the device
-        march_ = false;
+        march_ = grid_ = false;
         const char* e = getenv("THALLO_MARCH");
-        if ((e && e[0] == '0') || (W & 1)) return 0;
         int* word = (int*)irregular.ptr + 8;
         int rc = thallo_hip_iw_urshape_irregular(W, H, urshape, word, c.stream);
         if (rc < 0) { set_error("image_warping: UrShape check failed (%d)", rc); return -1; }
@@ -191,28 +192,52 @@ public:
         if (hipMemcpyAsync(&bad, word, sizeof(int), hipMemcpyDeviceToHost, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess) return -1;
         // measured (tools/march_probe.py MB_MODE=rows, profiles/r02): 2048^2 82 vs 90 us, 1024^2 29.8 vs 31.5 us, 2048x256 21.1 vs 21.4 us, but 512^2 14.9 vs
         // 13.5 us -- below ~0.4 Mpixel a wave's short march is all lead-in and tail, the LDS-tiled kernel wins
-        march_ = bad == 0 && ((long)W * H >= 400000 || (e && e[0] == '2'));          // THALLO_MARCH=2: the marching kernel at every size (tests)
+        grid_ = bad == 0;
+        if ((e && e[0] == '0') || (W & 1)) return 0;
+        march_ = grid_ && ((long)W * H >= 400000 || (e && e[0] == '2'));              // THALLO_MARCH=2: the marching kernel at every size (tests)
         return 0;
+    }
+    // ---- one row slab of a multi-GPU run (solver_dist.cpp)
+    bool supports_row_slabs() const override { return true; }
+    int set_row_slab(int row0, int row1) override
+    {
+        if (row0 < 0 || row1 > H || row0 >= row1 || (W & 3)) { set_error("image_warping: row slab [%d,%d) of %d rows, W = %d (W %% 4 must be 0)", row0, row1, H, W); return -1; }
+        row0_ = row0; row1_ = row1; return 0;
+    }
+    int slab_width() const override { return W; }
+    bool slab_grid_ok() const override { return grid_; }
+    unsigned char* slab_flags() override { return (unsigned char*)flags.ptr; }
+    int pcg_iter_dist(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2,
+                      const thallo_dist_t& d, float* out, int slot0, float* aD_word, float* bN_word) override
+    {
+        TimedLaunch t(c, "PCGIteration");
+        if (march_)
+            return thallo_hip_iw_pcg_iter_march_dist(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                     v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                                     aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, d, out, v.s12, v.fin_tickets, slot0, aD_word, bN_word, c.stream);
+        return thallo_hip_iw_pcg_iter_dist(W, H, row0_, row1_, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, v.pre, w_fit, w_reg,
+                                           v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                           aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, d, out, v.s12, v.fin_tickets, slot0, aD_word, bN_word, c.stream);
     }
     float* unknown_ptr(int k) override { return k == 0 ? offset : angle; }
     int cost(LaunchCtx& c, float* out) override
-    { TimedLaunch t(c, "computeCost"); return thallo_hip_iw_cost(W, H, 0, H, offset, angle, urshape, constraints, mask, w_fit, w_reg, out, c.stream); }
+    { TimedLaunch t(c, "computeCost"); return thallo_hip_iw_cost(W, H, row0_, row1_, offset, angle, urshape, constraints, mask, w_fit, w_reg, out, c.stream); }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
         TimedLaunch t(c, "PCGInit1");
-        return thallo_hip_iw_pcg_init(W, H, 0, H, offset, angle, urshape, constraints, mask, w_fit, w_reg,
+        return thallo_hip_iw_pcg_init(W, H, row0_, row1_, offset, angle, urshape, constraints, mask, w_fit, w_reg,
                                       v.r, v.pre, v.z, v.p[cur], v.delta, (float*)cs.ptr, (unsigned char*)flags.ptr, v.diag, (int*)irregular.ptr, aN, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_iw_apply_jtj(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg, p, Ap, (const int*)irregular.ptr, out, c.stream);
+        return thallo_hip_iw_apply_jtj(W, H, row0_, row1_, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg, p, Ap, (const int*)irregular.ptr, out, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
         const thallo_sum_t none = { nullptr, 0 };
-        return thallo_hip_iw_pcg_step1(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
+        return thallo_hip_iw_pcg_step1(W, H, row0_, row1_, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
                                        v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, none, none, (const int*)irregular.ptr, v.r, out, c.stream);
     }
     bool batches_delta() const override { return true; }
@@ -222,11 +247,11 @@ public:
     {
         TimedLaunch t(c, "PCGIteration");
         if (march_)
-            return thallo_hip_iw_pcg_iter_march(W, H, 0, H, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+            return thallo_hip_iw_pcg_iter_march(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
                                                 v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
                                                 aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, out, v.s12,
                                                 aD_word ? v.fin_tickets : nullptr, aD_word, bN_word, c.stream);
-        return thallo_hip_iw_pcg_iter(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, v.pre, w_fit, w_reg,
+        return thallo_hip_iw_pcg_iter(W, H, row0_, row1_, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, v.pre, w_fit, w_reg,
                                       v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
                                       aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, out, v.s12,
                                       aD_word ? v.fin_tickets : nullptr, aD_word, bN_word, c.stream);
@@ -240,13 +265,13 @@ public:
                        thallo_sum_t aN2, thallo_sum_t aD2, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_iw_pcg_step1(W, H, 0, H, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
+        return thallo_hip_iw_pcg_step1(W, H, row0_, row1_, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, w_fit, w_reg,
                                        v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, mode, aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, v.r, out, c.stream);
     }
     int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* out) override
     {
         TimedLaunch t(c, "PCGStep2");
-        return thallo_hip_iw_pcg_step2(W, H, 0, H, (const unsigned char*)flags.ptr, w_fit, w_reg, v.r, v.Ap, v.pre, v.z, aN, aD, (const int*)irregular.ptr, out, c.stream);
+        return thallo_hip_iw_pcg_step2(W, H, row0_, row1_, (const unsigned char*)flags.ptr, w_fit, w_reg, v.r, v.Ap, v.pre, v.z, aN, aD, (const int*)irregular.ptr, out, c.stream);
     }
 };
 

@@ -160,6 +160,7 @@ Plan::Plan(EnergyPlugin* pl, const Thallo_InitializationParameters& ip_, bool lm
 Plan::~Plan()
 {
     hipDeviceSynchronize();
+    dist_release();
     for (auto b : bufs_) delete b;
     delete plugin;
 }
@@ -173,11 +174,19 @@ int Plan::ensure_slots(int L)
     // (examples/embedded_mesh_deformation) costs 32 MB
     if (parts_.alloc(((size_t)need * THALLO_HIP_MAX_PARTIALS + (size_t)need + 64) * sizeof(float))) { set_error("out of device memory for %d reduction slots (lIterations too large?)", need); return -1; }
     parts_slots_ = need; nb_.assign(need, 1); fin_.assign(need, 0);
-    { const char* e = getenv("THALLO_FINISH_SUMS"); finish_sums_ = !(e && e[0] == '0'); }
-    { const char* e = getenv("THALLO_ONE_KERNEL"); one_kernel_ = !(e && e[0] == '0'); }
-    { const char* e = getenv("THALLO_EXPANDED"); expanded_ = !(e && e[0] == '0'); }
-    { const char* e = getenv("THALLO_FIN_IN_KERNEL"); fin_in_kernel_ = !(e && e[0] == '0'); }
+    read_ab_switches();
     return 0;
+}
+
+void Plan::read_ab_switches()
+{   // A/B switches for tests/ and tools/ (each selects an older or alternative schedule that computes the same thing; the defaults are the
+    // product).  All of them in this one place; read when the reduction slots are (re)sized, i.e. at Plan time and when lIterations grows.
+    auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+    finish_sums_   = !off("THALLO_FINISH_SUMS");      // 0: consumers re-add the partials themselves
+    one_kernel_    = !off("THALLO_ONE_KERNEL");       // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
+    expanded_      = !off("THALLO_EXPANDED");         // 0: three-kernel form even where applyJTJ can return the sums
+    fin_in_kernel_ = !off("THALLO_FIN_IN_KERNEL");    // 0: the iteration's scalars by a separate one-wave launch
+    batch_delta_   = !off("THALLO_BATCH_DELTA");      // 0: delta += alpha p every iteration instead of every other one
 }
 
 void Plan::set_param(const char* name, const void* value)
@@ -207,6 +216,7 @@ void Plan::get_param(const char* name, void* value)
 
 float Plan::compute_cost()
 {   // gauss_newton.t:1128-1136 -- partials instead of memset + atomics; same blocking 4-byte read-back
+    if (dist_) return dist_cost();
     const int nb = plugin->cost(ctx, slot(0));
     if (nb < 0) { set_error("cost kernel launch failed (%d)", nb); return NAN; }
     set_nb(0, nb);
@@ -226,7 +236,13 @@ void Plan::init(void** params)
     ready_ = false;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return; }
     if (plugin->prepare(ctx)) { const std::string why = last_error(); set_error("%s: prepare failed: %s", plugin->name(), why.c_str()); return; }
+    if (dist_) {   // collective: the one-kernel slab schedule needs its precondition on EVERY rank; then (first Init) the exchange's self-check
+        bool all = false;
+        if (dist_agree(plugin->slab_grid_ok(), all)) return;
+        if (!all) { set_error("%s: the row-slab schedule needs UrShape on the unit pixel grid on every rank", plugin->name()); return; }
+    }
     ready_ = true;
+    if (dist_ && dist_->want_p2p && !dist_->checked && dist_self_check()) { ready_ = false; return; }
     sp.nIter = 0;
     prev_cost_ = compute_cost();
     printf("Initial cost: %g\n", prev_cost_);
@@ -258,7 +274,8 @@ int Plan::step(void** params)
     if (sp.lIterations < 0) { set_error("lIterations = %d is negative", sp.lIterations); if (!finalized_) finalize(); return 0; }
     if (ensure_slots(sp.lIterations)) { if (!finalized_) finalize(); return 0; }
     const int ev_iter = timer_.start("Nonlinear Iteration", ctx.stream);
-    const int rc = lm_ ? step_lm(ev_iter) : step_gn(ev_iter);
+    if (dist_ && lm_) { set_error("distributed: the Levenberg-Marquardt branch is single-device"); if (!finalized_) finalize(); return 0; }
+    const int rc = lm_ ? step_lm(ev_iter) : dist_ ? step_gn_slab(ev_iter) : step_gn(ev_iter);
     if (rc == 1 && sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779
         hipStream_t s = ctx.stream;
         hipEvent_t q = nullptr; hipEventCreate(&q); hipEventRecord(q, s); hipEventSynchronize(q);
@@ -266,6 +283,29 @@ int Plan::step(void** params)
         if (ms / 1000.0f > sp.max_solver_time_in_seconds) { finalize(); return 0; }
     }
     return rc;
+}
+
+void Plan::linear_update_tail(int L, bool batched)
+{   // PCGLinearUpdate (gauss_newton.t:901-906) at the end of a GN step of any of the fused schedules, including the delta += alpha*p terms
+    // still pending: after the last fused PCGStep1 (k = L-1) delta holds the terms up to p_{L-2}; with `batched` (every other update
+    // deferred) up to p_{L-2} if L-1 is even and up to p_{L-3} if it is odd.  One row slab of a multi-GPU run touches its owned rows only.
+    const int B = 2;                       // slot layout: alphaN_k = B+2k, alphaD_k = B+2k+1
+    hipStream_t s = ctx.stream;
+    const auto& imgs = plugin->unknown_images();
+    const int jN = B + 2 * (L - 1), jD = jN + 1;
+    long off = 0;
+    for (size_t k = 0; k < imgs.size(); ++k) {
+        TimedLaunch t(ctx, "PCGLinearUpdate");
+        long lo = 0, len = imgs[k].n_floats;
+        if (dist_) { const long rowlen = imgs[k].n_floats / dist_->Hl; lo = rowlen * dist_->row0; len = rowlen * (dist_->row1 - dist_->row0); }
+        float* X = plugin->unknown_ptr((int)k) + lo;
+        const float* dl = v_.delta + off + lo;
+        if (L > 1 && batched && ((L - 1) & 1))
+            thallo_hip_linear_update2(X, dl, v_.p[cur_ ^ 1] + off + lo, sum(jN - 2), sum(jD - 2), v_.p[cur_] + off + lo, sum(jN), sum(jD), len, s);
+        else if (L > 0) thallo_hip_linear_update(X, dl, v_.p[cur_] + off + lo, len, sum(jN), sum(jD), s);
+        else            thallo_hip_linear_update(X, dl, nullptr, len, sum(B), sum(B), s);
+        off += imgs[k].n_floats;
+    }
 }
 
 int Plan::step_gn(int ev_iter)
@@ -282,7 +322,7 @@ int Plan::step_gn(int ev_iter)
     set_nb(B, nb); finish(B);
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
-    const bool batched = plugin->batches_delta();      // every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
+    const bool batched = plugin->batches_delta() && batch_delta_;      // every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         // PCGStep1 (+ previous iteration's PCGStep3 and delta update)
@@ -298,21 +338,7 @@ int Plan::step_gn(int ev_iter)
     last_l_iters = L;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
-    {   // PCGLinearUpdate, including the last pending delta += alpha*p
-        const auto& imgs = plugin->unknown_images();
-        long off = 0;
-        for (size_t k = 0; k < imgs.size(); ++k) {
-            TimedLaunch t(ctx, "PCGLinearUpdate");
-            const int jN = B + 2 * (L - 1), jD = jN + 1;
-            // batched: after the last PCGStep1 (k = L-1) delta holds the terms up to p_{L-2} if L-1 is even, up to p_{L-3} if it is odd
-            if (L > 1 && batched && ((L - 1) & 1))
-                thallo_hip_linear_update2(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_ ^ 1] + off, sum(jN - 2), sum(jD - 2),
-                                          v_.p[cur_] + off, sum(jN), sum(jD), imgs[k].n_floats, s);
-            else if (L > 0) thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_] + off, imgs[k].n_floats, sum(jN), sum(jD), s);
-            else       thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
-            off += imgs[k].n_floats;
-        }
-    }
+    linear_update_tail(L, batched);
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);
@@ -350,7 +376,7 @@ int Plan::step_gn_one_kernel(int ev_iter)
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
-        nb = plugin->pcg_iter(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, 1), sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
+        nb = plugin->pcg_iter(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ ? 1 : 0), sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
                               sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), slot(jD),
                               fin_in_kernel_ ? scal(jD) : nullptr, fin_in_kernel_ ? scal(jB) : nullptr);
         if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
@@ -358,32 +384,17 @@ int Plan::step_gn_one_kernel(int ev_iter)
         if (!fin_in_kernel_ && plugin->pcg_iter_finish(ctx, v_, slot(jD), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
         fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
     }
-    const bool batched = true;
+    const bool batched = batch_delta_;                 // THALLO_IW_STEP1_MODE(k, 1): every other delta update is deferred
     last_l_iters = L;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
-    {   // PCGLinearUpdate, including the last pending delta += alpha*p
-        const auto& imgs = plugin->unknown_images();
-        long off = 0;
-        for (size_t k = 0; k < imgs.size(); ++k) {
-            TimedLaunch t(ctx, "PCGLinearUpdate");
-            const int jN = B + 2 * (L - 1), jD = jN + 1;
-            // batched: after the last PCGStep1 (k = L-1) delta holds the terms up to p_{L-2} if L-1 is even, up to p_{L-3} if it is odd
-            if (L > 1 && batched && ((L - 1) & 1))
-                thallo_hip_linear_update2(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_ ^ 1] + off, sum(jN - 2), sum(jD - 2),
-                                          v_.p[cur_] + off, sum(jN), sum(jD), imgs[k].n_floats, s);
-            else if (L > 0) thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_] + off, imgs[k].n_floats, sum(jN), sum(jD), s);
-            else       thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
-            off += imgs[k].n_floats;
-        }
-    }
+    linear_update_tail(L, batched);
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);
     return 1;
 }
 
-// ------------------------------------------------------------------ Levenberg-Marquardt branch
 int Plan::step_gn_expanded(int ev_iter)
 {   // GN branch, single-reduction form for gather energies: per PCG iteration pcg_update (flat) + applyJTJ with sums + scalars_finish
     // (thallo_hip.h "single-reduction PCG form") instead of PCGStep3 + applyJTJ + PCGStep2 and their finish launches
@@ -419,28 +430,13 @@ int Plan::step_gn_expanded(int ev_iter)
     last_l_iters = L;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
-    {   // PCGLinearUpdate, including the last pending delta += alpha*p
-        const auto& imgs = plugin->unknown_images();
-        long off = 0;
-        for (size_t k = 0; k < imgs.size(); ++k) {
-            TimedLaunch t(ctx, "PCGLinearUpdate");
-            const int jN = B + 2 * (L - 1), jD = jN + 1;
-            // batched: after the last PCGStep1 (k = L-1) delta holds the terms up to p_{L-2} if L-1 is even, up to p_{L-3} if it is odd
-            if (L > 1 && batched && ((L - 1) & 1))
-                thallo_hip_linear_update2(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_ ^ 1] + off, sum(jN - 2), sum(jD - 2),
-                                          v_.p[cur_] + off, sum(jN), sum(jD), imgs[k].n_floats, s);
-            else if (L > 0) thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, v_.p[cur_] + off, imgs[k].n_floats, sum(jN), sum(jD), s);
-            else       thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
-            off += imgs[k].n_floats;
-        }
-    }
+    linear_update_tail(L, batched);
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);
     return 1;
 }
 
-// ------------------------------------------------------------------ Levenberg-Marquardt branch
 int Plan::ensure_sums_buffer()
 {
     if (v_.s12) return 0;
@@ -452,13 +448,11 @@ int Plan::ensure_sums_buffer()
 
 int Plan::ensure_iter_buffers()
 {
-    if (v_.r2) return 0;
     if (ensure_sums_buffer()) return -1;
-    DeviceBuffer* b[3];
-    for (int i = 0; i < 3; ++i) { b[i] = new DeviceBuffer(); bufs_.push_back(b[i]); }
-    if (b[0]->alloc((size_t)v_.n_alloc * sizeof(float)) || b[1]->alloc((size_t)v_.n_alloc * sizeof(float)) ||
-        b[2]->alloc(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned))) return -1;
-    v_.r2 = (float*)b[0]->ptr; v_.Ap2 = (float*)b[1]->ptr; v_.fin_tickets = (unsigned*)b[2]->ptr;
+    auto get = [&](size_t bytes) -> void* { DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b); return b->alloc(bytes) ? nullptr : b->ptr; };
+    if (!v_.r2 && !(v_.r2 = (float*)get((size_t)v_.n_alloc * sizeof(float)))) return -1;            // (a row slab's r' / Ap' live in its exchange block)
+    if (!v_.Ap2 && !(v_.Ap2 = (float*)get((size_t)v_.n_alloc * sizeof(float)))) return -1;
+    if (!v_.fin_tickets && !(v_.fin_tickets = (unsigned*)get(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned)))) return -1;
     return 0;
 }
 

@@ -37,11 +37,35 @@ public:
     ~CoarseTimer() { cleanup(); }
 };
 
+// Row-slab multi-GPU state of a Plan (one process per GPU; SURVEY.md 8e -- the reference is single-device, util.t:769-772, so this is
+// new design).  The Plan was made for the LOCAL image {W, owned rows + ghost rows}; rows [row0,row1) are owned.  Per PCG iteration ONE
+// kernel + ONE exchange: either the caller's all-gather (RCCL) of [alphaD, N, S1, S2 | boundary rows of Ap], or -- after a self-check on
+// this very topology -- device mailboxes + peer-to-peer ghost-row stores done by the kernel itself (dist_device.hpp).  solver_dist.cpp.
+struct DistState {
+    ThalloX_Distributed cfg;
+    int W = 0, Hl = 0, row0 = 0, row1 = 0, top = 0, bot = 0, ghost = 1;
+    long N = 0, na = 0;
+    void* block = nullptr; bool block_ipc = false;      // [r | z | r' | Ap | Ap'] (one allocation peers can map)
+    unsigned char handle_block[64], handle_mail[64];
+    int mem_kind[2] = { -1, -1 };
+    DeviceBuffer send, gath;                             // message buffers (floats), sized for the larger of the two message kinds
+    long msg = 0, msg_iter = 0, msg_x = 0;
+    thallo_segs_t seg_first_last, seg_top, seg_bot, seg_iter_fl, seg_iter_top, seg_iter_bot;
+    // device-side exchange
+    bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
+    void* mail = nullptr; int mail_L = 0;
+    DeviceBuffer ctl;
+    thallo_dist_t d, d_iter[2];
+    std::vector<void*> opened;
+    std::string info;                                    // JSON: transport, memory kind, self-check outcome
+};
+
 class Plan {
 public:
     Plan(EnergyPlugin* plugin, const Thallo_InitializationParameters& ip, bool lm, unsigned* dims);
     ~Plan();
     bool ok() const { return ok_; }
+    bool ready() const { return ok_ && ready_; }
 
     void init(void** params);
     int  step(void** params);
@@ -51,6 +75,11 @@ public:
     int  alpha_beta_trace(float* out_pairs, int cap);
     void enable_lm(bool on);       // extension: run the LM branch the reference text describes (dead as shipped, thallo.t:463)
     bool lm() const { return lm_; }
+    // collective over the ranks; before Thallo_ProblemInit.  0 on success (every rank returns the same value)
+    int  set_distributed(const ThalloX_Distributed& cfg);
+    const char* distributed_info() const { return dist_ ? dist_->info.c_str() : ""; }
+    int  dist_control(int what, int value);
+    int  dist_kernel_only(int reps);      // bench: `reps` back-to-back one-kernel iterations on this rank's slab, no exchange
 
     EnergyPlugin* plugin;
     SolverParameters sp;
@@ -81,10 +110,8 @@ private:
 
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
-    bool fin_in_kernel_ = true;     // THALLO_FIN_IN_KERNEL=0: the iteration's scalars by a separate one-wave launch (A/B switch)
-    bool expanded_ = true;          // THALLO_EXPANDED=0: three-kernel form even where the plugin's applyJTJ can return the sums (A/B switch)
-    bool one_kernel_ = true;        // THALLO_ONE_KERNEL=0: two-kernel schedule even where the plugin offers pcg_iter (A/B switch)
-    bool finish_sums_ = true;       // THALLO_FINISH_SUMS=0: consumers re-add the partials themselves (A/B switch)
+    bool fin_in_kernel_ = true, expanded_ = true, one_kernel_ = true, finish_sums_ = true, batch_delta_ = true;   // A/B switches: read_ab_switches()
+    void read_ab_switches();
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }
     thallo_sum_t partial_sum(int j) { thallo_sum_t s; s.partials = slot(j); s.count = nb_[j]; return s; }
     thallo_sum_t sum(int j) { if (fin_[j]) { thallo_sum_t s; s.partials = scal(j); s.count = 1; return s; } return partial_sum(j); }
@@ -105,6 +132,17 @@ private:
     float read_sum(int j);
     float radius_ = 1e4f, decrease_factor_ = 2.0f;
     void finalize();
+    void linear_update_tail(int L, bool batched);
+    // solver_dist.cpp
+    DistState* dist_ = nullptr;
+    int  dist_allgather(const void* send, void* recv, long bytes);
+    int  dist_agree(bool flag, bool& all);
+    int  dist_map_peers();
+    int  dist_self_check();
+    int  dist_gn(int L, bool p2p);                      // PCGInit + L iterations + linear update + ghost refresh, no bookkeeping
+    int  step_gn_slab(int ev_iter);
+    float dist_cost();
+    void dist_release();
 };
 
 }  // namespace thallo

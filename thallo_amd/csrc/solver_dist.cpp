@@ -1,0 +1,378 @@
+// solver_dist.cpp -- the row-slab multi-GPU form of the Gauss-Newton step, behind Thallo_ProblemStep (see DistState in solver.hpp and
+// the ThalloX_Distributed block of include/Thallo.h).
+//
+// The reference has no counterpart (single device, NULL stream: API/src/util.t:769-772), so the decomposition follows the algorithm
+// itself (gauss_newton.t:1641-1665): what a PCG iteration needs from the other ranks is the two scalars and -- stencil radius 1,
+// image_warping.t:18 -- one ghost row of the vector the stencil is applied to.  With the one-kernel iteration both scalars come from
+// the same reduction point (alphaD and N, S1, S2), and Ap is the only vector whose ghost rows a rank cannot keep current itself, so ONE
+// exchange per iteration carries everything: [alphaD | N, S1, S2 | first owned row of Ap | last owned row of Ap].
+// Sums over ranks are always taken in rank order from the gathered per-rank values: alpha and beta are bit-identical on every rank, the
+// replicated host logic cannot diverge.
+#include "solver.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace thallo {
+
+namespace {
+thallo_segs_t segs(const std::vector<std::pair<long, long>>& pieces)
+{
+    thallo_segs_t s; memset(&s, 0, sizeof(s));
+    for (size_t k = 0; k < pieces.size() && k < 8; ++k) { s.off[k] = pieces[k].first; s.len[k] = pieces[k].second; }
+    s.n = (int)pieces.size();
+    return s;
+}
+struct PeerInfo {              // what a rank publishes about itself when the device-side exchange is set up
+    unsigned char block[64], mail[64];
+    int row0, row1, Hl, ok;
+    long na;
+};
+}  // namespace
+
+int Plan::dist_allgather(const void* send, void* recv, long bytes)
+{
+    DistState& D = *dist_;
+    if (D.cfg.world == 1 && !D.cfg.allgather)
+        return hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, ctx.stream) == hipSuccess ? 0 : -1;
+    const int rc = D.cfg.allgather(D.cfg.user, send, recv, bytes, (void*)ctx.stream);
+    if (rc) set_error("distributed: the caller's all-gather returned %d", rc);
+    return rc;
+}
+
+// host bytes of every rank, rank order (set-up only: two copies + one synchronisation)
+static int host_allgather(Plan& p, DistState& D, int (Plan::*ag)(const void*, void*, long), const void* in, void* out, long bytes)
+{
+    hipStream_t s = p.ctx.stream;
+    if ((size_t)bytes * D.cfg.world > D.gath.bytes || (size_t)bytes > D.send.bytes) { set_error("distributed: set-up message too large"); return -1; }
+    if (hipMemcpyAsync(D.send.ptr, in, (size_t)bytes, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    if ((p.*ag)(D.send.ptr, D.gath.ptr, bytes)) return -1;
+    if (hipMemcpyAsync(out, D.gath.ptr, (size_t)bytes * D.cfg.world, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+
+int Plan::dist_agree(bool flag, bool& all)
+{   // every rank learns whether EVERY rank said yes (decisions that change the launch sequence must be unanimous)
+    DistState& D = *dist_;
+    int mine[4] = { flag ? 1 : 0, 0, 0, 0 }, got[4 * THALLO_DIST_MAX_WORLD];
+    all = false;
+    if (host_allgather(*this, D, &Plan::dist_allgather, mine, got, sizeof(mine))) return -1;
+    all = true;
+    for (int r = 0; r < D.cfg.world; ++r) all = all && got[4 * r] == 1;
+    return 0;
+}
+
+int Plan::set_distributed(const ThalloX_Distributed& cfg)
+{
+    if (!ok_) return -1;
+    if (dist_) { set_error("distributed: already set for this plan"); return -1; }
+    if (lm_) { set_error("distributed: the Levenberg-Marquardt branch is single-device"); return -1; }
+    if (!plugin->supports_row_slabs() || !plugin->one_kernel_iteration()) { set_error("distributed: %s has no row-slab form", plugin->name()); return -1; }
+    if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
+    if (cfg.world > 1 && !cfg.allgather) { set_error("distributed: world > 1 needs an all-gather callback"); return -1; }
+    const int W = plugin->slab_width(), Hl = (int)dims[1];
+    const int top = (int)cfg.row0, bot = Hl - (int)cfg.row1;
+    if (top < 0 || top > 1 || bot < 0 || bot > 1 || (int)cfg.row1 <= (int)cfg.row0 ||
+        (top == 1) != (cfg.rank > 0) || (bot == 1) != (cfg.rank < cfg.world - 1)) {
+        set_error("distributed: rank %d of %d owns rows [%u,%u) of a %d-row local image; expected exactly one ghost row towards each neighbour", cfg.rank, cfg.world, cfg.row0, cfg.row1, Hl);
+        return -1;
+    }
+    if (plugin->set_row_slab((int)cfg.row0, (int)cfg.row1)) return -1;
+    hipDeviceSynchronize();
+    DistState* Dp = new DistState();
+    DistState& D = *Dp;
+    dist_ = Dp;
+    D.cfg = cfg; D.W = W; D.Hl = Hl; D.row0 = (int)cfg.row0; D.row1 = (int)cfg.row1; D.top = top; D.bot = bot;
+    D.N = (long)W * Hl; D.na = v_.n_alloc;
+    D.want_p2p = cfg.device_exchange != 0;
+    {   const char* e = getenv("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
+    // ---- r, z, r', Ap, Ap' in ONE block (peers map it; pack / unpack address r and z through one base)
+    const size_t block_bytes = (size_t)5 * D.na * sizeof(float);
+    if (D.want_p2p) {
+        if (thallo_hip_ipc_alloc2((long)block_bytes, &D.block, D.handle_block, &D.mem_kind[0]) < 0) { D.block = nullptr; D.want_p2p = false; }
+        else D.block_ipc = true;
+    }
+    if (!D.block) {
+        if (hipMalloc(&D.block, block_bytes) != hipSuccess) { set_error("distributed: out of device memory"); D.block = nullptr; return -1; }
+        if (hipMemset(D.block, 0, block_bytes) != hipSuccess) return -1;
+    }
+    for (int i : { 1, 2, 3 }) bufs_[i]->release();                     // the constructor's r, z, Ap
+    float* b = (float*)D.block;
+    v_.r = b; v_.z = b + D.na; v_.r2 = b + 2 * D.na; v_.Ap = b + 3 * D.na; v_.Ap2 = b + 4 * D.na;
+    if (ensure_iter_buffers()) { set_error("distributed: out of device memory"); return -1; }
+    // ---- messages
+    const long N = D.N, na = D.na;
+    auto row = [&](long y, long base) { return std::vector<std::pair<long, long>>{ { base + 2L * W * y, 2L * W }, { base + 2 * N + (long)W * y, (long)W } }; };
+    auto cat = [](std::vector<std::pair<long, long>> a, const std::vector<std::pair<long, long>>& c) { a.insert(a.end(), c.begin(), c.end()); return a; };
+    D.seg_first_last = segs(cat(cat(row(D.row0, 0), row(D.row0, na)), cat(row(D.row1 - 1, 0), row(D.row1 - 1, na))));
+    D.seg_top = top ? segs(cat(row(D.row0 - 1, 0), row(D.row0 - 1, na))) : segs({});
+    D.seg_bot = bot ? segs(cat(row(D.row1, 0), row(D.row1, na))) : segs({});
+    D.seg_iter_fl = segs(cat(row(D.row0, 0), row(D.row1 - 1, 0)));
+    D.seg_iter_top = top ? segs(row(D.row0 - 1, 0)) : segs({});
+    D.seg_iter_bot = bot ? segs(row(D.row1, 0)) : segs({});
+    D.msg = 1 + 12L * W + 2 * (W / 4);          // [alphaN_0 | first row: r, z | last row: r, z | flags bytes of the first, of the last owned row]
+    D.msg_iter = 7 + 6L * W;                    // [alphaD | N, S1, S2 as (hi, lo) | first row of Ap_out | last row of Ap_out]
+    D.msg_x = 6L * W;                           // boundary rows of the unknowns
+    const size_t words = (size_t)std::max(std::max(D.msg, D.msg_iter), std::max(D.msg_x, 64L));
+    if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory"); return -1; }
+    if (D.ctl.alloc(THALLO_DIST_CTL_WORDS * sizeof(unsigned)) || hipMemset(D.ctl.ptr, 0, THALLO_DIST_CTL_WORDS * sizeof(unsigned)) != hipSuccess) return -1;
+    // ---- device-side exchange: mailbox, peers' mailboxes, the neighbours' blocks
+    bool all = false;
+    if (dist_agree(D.want_p2p, all)) return -1;                          // (also the first use of the caller's all-gather: fails here, not mid-solve)
+    D.want_p2p = all;
+    if (D.want_p2p) { if (dist_map_peers()) return -1; }
+    char buf[256];
+    snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"rank\": %d, \"world\": %d, \"device_exchange_requested\": %s}", cfg.rank, cfg.world, cfg.device_exchange ? "true" : "false");
+    D.info = buf;
+    return 0;
+}
+
+int Plan::dist_map_peers()
+{
+    DistState& D = *dist_;
+    const int world = D.cfg.world, rank = D.cfg.rank, W = D.W;
+    D.mail_L = std::max(sp.lIterations, 256);
+    const long n_slots = 7L * (D.mail_L + 2);                            // 7 granules per PCG iteration
+    PeerInfo mine; memset(&mine, 0, sizeof(mine));
+    mine.ok = thallo_hip_ipc_alloc2(8 * n_slots * world, &D.mail, D.handle_mail, &D.mem_kind[1]) >= 0 ? 1 : 0;
+    if (!mine.ok) D.mail = nullptr;
+    memcpy(mine.block, D.handle_block, 64); memcpy(mine.mail, D.handle_mail, 64);
+    mine.row0 = D.row0; mine.row1 = D.row1; mine.Hl = D.Hl; mine.na = D.na;
+    PeerInfo infos[THALLO_DIST_MAX_WORLD];
+    if (host_allgather(*this, D, &Plan::dist_allgather, &mine, infos, sizeof(PeerInfo))) return -1;
+    bool ok = true;
+    for (int r = 0; r < world; ++r) ok = ok && infos[r].ok == 1;
+    thallo_dist_t d; memset(&d, 0, sizeof(d));
+    d.world = world; d.rank = rank; d.mail = (unsigned long long*)D.mail; d.ctl = (unsigned*)D.ctl.ptr;
+    if (ok) {
+        for (int r = 0; r < world && ok; ++r) {
+            if (r == rank) { d.peer_mail[r] = d.mail; continue; }
+            void* p = nullptr;
+            if (thallo_hip_ipc_open(infos[r].mail, &p) < 0) { ok = false; break; }
+            D.opened.push_back(p); d.peer_mail[r] = (unsigned long long*)p;
+        }
+        D.d_iter[0] = D.d_iter[1] = d;
+        const int nbr[2] = { D.top ? rank - 1 : -1, D.bot ? rank + 1 : -1 };
+        for (int k = 0; k < 2 && ok; ++k) {
+            if (nbr[k] < 0) continue;
+            const PeerInfo& inf = infos[nbr[k]];
+            void* p = nullptr;
+            if (thallo_hip_ipc_open(inf.block, &p) < 0) { ok = false; break; }
+            D.opened.push_back(p);
+            // my first owned row lands in the upper neighbour's BOTTOM ghost row, my last owned row in the lower neighbour's TOP ghost row
+            const long ghost_row = k == 0 ? inf.row1 : inf.row0 - 1;
+            d.peer_r[k] = (float*)p; d.peer_off_o[k] = 2L * W * ghost_row; d.peer_off_a[k] = 2L * W * inf.Hl + (long)W * ghost_row;
+            for (int out = 0; out < 2; ++out) {                          // ... inside ITS Ap / Ap' (block layout [r | z | r' | Ap | Ap'], its own padded length)
+                const long base = (3 + out) * inf.na;
+                D.d_iter[out].peer_r[k] = (float*)p;
+                D.d_iter[out].peer_off_o[k] = base + 2L * W * ghost_row;
+                D.d_iter[out].peer_off_a[k] = base + 2L * W * inf.Hl + (long)W * ghost_row;
+            }
+        }
+        for (int out = 0; out < 2; ++out) for (int r = 0; r < world; ++r) D.d_iter[out].peer_mail[r] = d.peer_mail[r];
+    }
+    D.d = d;
+    bool all = false;
+    if (dist_agree(ok, all)) return -1;                                  // every rank mapped every peer, or nobody launches a kernel that touches one
+    D.mapped = all;
+    if (!all) D.want_p2p = false;
+    return 0;
+}
+
+float Plan::dist_cost()
+{   // local partials -> one word per rank -> all-gather -> rank-ordered sum on the host (the read-back blocks anyway, gauss_newton.t:1128-1136)
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const int nb = plugin->cost(ctx, slot(0));
+    if (nb < 0) { set_error("cost kernel launch failed (%d)", nb); return NAN; }
+    set_nb(0, nb);
+    thallo_hip_finish_sum(sum(0), (float*)D.send.ptr, s);
+    if (dist_allgather(D.send.ptr, D.gath.ptr, sizeof(float))) return NAN;
+    float part[THALLO_DIST_MAX_WORLD];
+    if (hipMemcpyAsync(part, D.gath.ptr, sizeof(float) * D.cfg.world, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { set_error("distributed: cost read-back failed"); return NAN; }
+    float f = 0.0f;
+    for (int r = 0; r < D.cfg.world; ++r) f += part[r];
+    return f;
+}
+
+int Plan::dist_gn(int L, bool p2p)
+{
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const int B = 2, W = D.W, world = D.cfg.world, rank = D.cfg.rank;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    unsigned char* flags = plugin->slab_flags();
+    cur_ = 0;
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
+    set_nb(B, nb);
+    {   // alphaN_0 over all ranks; ghost rows of r and z; and the flags byte of the ghost rows (M^-1 of a ghost pixel depends on rows this rank
+        // does not hold, so its owner supplies it)
+        TimedLaunch t(ctx, "SlabExchangeInit");
+        if (thallo_hip_slab_pack(v_.r, D.seg_first_last, partial_sum(B), send, s) < 0) return -1;
+        unsigned char* fsend = (unsigned char*)(send + 1 + 12L * W);
+        if (hipMemcpyAsync(fsend, flags + (long)W * D.row0, W, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(fsend + W, flags + (long)W * (D.row1 - 1), W, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        if (dist_allgather(send, gath, D.msg * (long)sizeof(float))) return -1;
+        const float* src_top = D.top ? gath + (rank - 1) * D.msg + 1 + 6L * W : nullptr;      // the LAST owned row of rank-1
+        const float* src_bot = D.bot ? gath + (rank + 1) * D.msg + 1 : nullptr;               // the FIRST owned row of rank+1
+        if (thallo_hip_slab_unpack(v_.r, D.seg_top, src_top, D.seg_bot, src_bot, gath, D.msg, world, scal(B), s) < 0) return -1;
+        fin_[B] = 1;
+        if (D.top && hipMemcpyAsync(flags + (long)W * (D.row0 - 1), (const unsigned char*)(gath + (rank - 1) * D.msg + 1 + 12L * W) + W, W, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        if (D.bot && hipMemcpyAsync(flags + (long)W * D.row1, (const unsigned char*)(gath + (rank + 1) * D.msg + 1 + 12L * W), W, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+    }
+    if (p2p && thallo_hip_dist_begin_step(D.d, s) < 0) return -1;        // seq += 1: this GN step's granules
+    for (int k = 0; k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        const int mode = THALLO_IW_STEP1_MODE(k, 1);
+        const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
+        if (p2p) {        // the kernel stores its boundary rows of Ap_out into the neighbours' ghost rows and its last workgroup IS the exchange
+            nb = plugin->pcg_iter_dist(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, D.d_iter[cur_ ^ 1], slot(jD), 7 * k, scal(jD), scal(jB));
+            if (nb < 0) { set_error("PCGIteration (device-side exchange) launch failed (%d)", nb); return -1; }
+        } else {
+            nb = plugin->pcg_iter(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, slot(jD), nullptr, nullptr);
+            if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return -1; }
+            TimedLaunch t(ctx, "SlabExchange");
+            float* Ao = v_.Abuf(cur_ ^ 1);
+            if (thallo_hip_slab_pack_iter(Ao, D.seg_iter_fl, slot(jD), v_.s12, nb, send, s) < 0) return -1;
+            if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
+            const float* src_top = D.top ? gath + (rank - 1) * D.msg_iter + 7 + 3L * W : nullptr;
+            const float* src_bot = D.bot ? gath + (rank + 1) * D.msg_iter + 7 : nullptr;
+            if (thallo_hip_slab_unpack_iter(Ao, D.seg_iter_top, src_top, D.seg_iter_bot, src_bot, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
+        }
+        set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+        cur_ ^= 1;
+    }
+    last_l_iters = L;
+    linear_update_tail(L, true);                                         // owned rows only
+    {   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
+        TimedLaunch t(ctx, "SlabExchangeUnknowns");
+        const auto& imgs = plugin->unknown_images();
+        long pos = 0;
+        for (int which = 0; which < 2; ++which)
+            for (size_t k = 0; k < imgs.size(); ++k) {
+                const long rowlen = imgs[k].n_floats / D.Hl;
+                const long y = which == 0 ? D.row0 : D.row1 - 1;
+                if (hipMemcpyAsync(send + pos, plugin->unknown_ptr((int)k) + rowlen * y, rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+                pos += rowlen;
+            }
+        const long half = pos / 2;
+        if (pos > D.msg_x) { set_error("distributed: unknown rows exceed the message buffer"); return -1; }
+        if (dist_allgather(send, gath, pos * (long)sizeof(float))) return -1;
+        long at = 0;
+        for (size_t k = 0; k < imgs.size(); ++k) {
+            const long rowlen = imgs[k].n_floats / D.Hl;
+            if (D.top && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * (D.row0 - 1), gath + (rank - 1) * pos + half + at, rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+            if (D.bot && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * D.row1, gath + (rank + 1) * pos + at, rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+            at += rowlen;
+        }
+    }
+    return 0;
+}
+
+int Plan::dist_self_check()
+{   // The device-side exchange is used only if, ON THIS TOPOLOGY, one GN step through it reproduces the all-gather path's alpha / beta
+    // scalars from the same unknowns (a stale ghost row or a lost granule shows up there; the two paths round identically except for the
+    // order of the cross-rank additions), and no bounded wait timed out.  Every rank takes the same decision.
+    DistState& D = *dist_;
+    D.checked = true;
+    if (!D.mapped) { D.p2p_on = false; return 0; }
+    hipStream_t s = ctx.stream;
+    const int Lc = std::max(1, std::min(6, sp.lIterations)), B = 2, nw = 2 * Lc + 1;
+    if (ensure_slots(std::max(Lc, sp.lIterations))) return -1;
+    const auto& imgs = plugin->unknown_images();
+    std::vector<DeviceBuffer> keep(imgs.size());
+    auto restore = [&](bool save) {
+        for (size_t k = 0; k < imgs.size(); ++k) {
+            const size_t bytes = imgs[k].n_floats * sizeof(float);
+            if (save && keep[k].alloc(bytes)) return -1;
+            if (hipMemcpyAsync(save ? keep[k].ptr : (void*)plugin->unknown_ptr((int)k), save ? (void*)plugin->unknown_ptr((int)k) : keep[k].ptr, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        }
+        return 0;
+    };
+    const unsigned spin_ms = 500;       // a topology where granules never become visible costs 0.5 s here, not the production bound
+    const unsigned zero = 0;
+    std::vector<float> ref(nw), got(nw);
+    bool ok = restore(true) == 0;
+    ok = ok && hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &spin_ms, sizeof(unsigned), hipMemcpyHostToDevice, s) == hipSuccess;
+    ok = ok && dist_gn(Lc, false) == 0;
+    ok = ok && hipMemcpyAsync(ref.data(), scal(B), nw * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    ok = ok && restore(false) == 0;
+    ok = ok && dist_gn(Lc, true) == 0;
+    ok = ok && hipMemcpyAsync(got.data(), scal(B), nw * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    int err = ok ? thallo_hip_dist_error(D.d, 1, s) : -1;
+    unsigned pm[5] = { 0, 0, 0, 0, 0 };
+    hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
+    restore(false);
+    hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &zero, sizeof(unsigned), hipMemcpyHostToDevice, s);
+    hipStreamSynchronize(s);
+    double rel = 0.0;
+    for (int i = 0; i < nw; ++i) {
+        const double e = std::fabs((double)got[i] - (double)ref[i]) / std::fmax(std::fabs((double)ref[i]), 1e-30);
+        if (!(e <= rel)) rel = e;                                        // NaN-propagating max
+    }
+    const bool pass = ok && err == 0 && rel <= 1e-3;
+    bool all = false;
+    if (dist_agree(pass, all)) return -1;
+    D.p2p_on = all;
+    char buf[512];
+    snprintf(buf, sizeof(buf), "{\"exchange\": \"%s\", \"rank\": %d, \"world\": %d, \"memory\": [\"%s\", \"%s\"], \"self_check\": {\"iterations\": %d, \"timeout\": %d, "
+             "\"max_rel_scalar_diff\": %.3g, \"pass\": %s, \"all_ranks_pass\": %s, \"post_mortem\": [%u, %u, %u, %u, %u]}}",
+             all ? "p2p-mailbox" : "allgather", D.cfg.rank, D.cfg.world, D.mem_kind[0] == 1 ? "fine-grained" : "coarse-grained", D.mem_kind[1] == 1 ? "fine-grained" : "coarse-grained",
+             Lc, err, rel, pass ? "true" : "false", all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
+    D.info = buf;
+    return 0;
+}
+
+int Plan::step_gn_slab(int ev_iter)
+{
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const int L = sp.lIterations;
+    const int ev_lin = timer_.start("Linear Solve", s);
+    const bool p2p = D.p2p_on && L <= D.mail_L;                          // (same L on every rank: same decision)
+    if (dist_gn(L, p2p)) return 0;
+    timer_.stop(ev_lin, s);
+    sp.nIter++;
+    timer_.stop(ev_iter, s);
+    return 1;
+}
+
+int Plan::dist_control(int what, int value)
+{
+    if (!dist_) return -1;
+    DistState& D = *dist_;
+    if (what == 0) return D.mapped ? thallo_hip_dist_error(D.d, value ? 1 : 0, ctx.stream) : 0;
+    if (what == 1) {
+        if (value == 0 && D.p2p_on) {
+            D.p2p_on = false;
+            const size_t at = D.info.find("\"p2p-mailbox\"");
+            if (at != std::string::npos) D.info.replace(at, 13, "\"allgather\", \"switched_off\": true");
+        }
+        return 0;
+    }
+    return -1;
+}
+
+int Plan::dist_kernel_only(int reps)
+{
+    if (!dist_ || !ready_) return -1;
+    const int B = 2;
+    for (int i = 0; i < reps; ++i) {
+        const int nb = plugin->pcg_iter(ctx, v_, 0, 0, sum(B), sum(B + 1), sum(B + 2), sum(B), sum(B + 1), slot(B + 3), nullptr, nullptr);
+        if (nb < 0) return nb;
+    }
+    return 0;
+}
+
+void Plan::dist_release()
+{
+    if (!dist_) return;
+    DistState& D = *dist_;
+    for (void* p : D.opened) thallo_hip_ipc_close(p);
+    if (D.block) { if (D.block_ipc) thallo_hip_ipc_free(D.block); else hipFree(D.block); }
+    if (D.mail) thallo_hip_ipc_free(D.mail);
+    delete dist_; dist_ = nullptr;
+}
+
+}  // namespace thallo

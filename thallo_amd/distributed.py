@@ -1,24 +1,24 @@
-"""Row-slab multi-GPU driver for the image-stencil hot path (image_warping), one process per GPU.
+"""Row-slab multi-GPU runs of the image-stencil hot path, one process per GPU.
 
-The reference is single-device (NULL stream everywhere, API/src/util.t:769-772; no NCCL/MPI anywhere),
-so this layer is new design:
+The reference is single-device (NULL stream everywhere, API/src/util.t:769-772; no NCCL/MPI anywhere), so this layer is new design
+(SURVEY.md section 5 and 8e).
 
-  * the H rows of the image are split into contiguous slabs, one per rank; a rank's local image carries
-    one ghost row above/below (the energy's stencil radius is 1, image_warping.t:18);
-  * every rank runs the same gfx950 kernels as the single-GPU path on its owned rows
-    (include/thallo_hip.h: row0/row1 arguments);
-  * per PCG iteration there are exactly two exchanges, and both are dictated by the algorithm
-    (gauss_newton.t:1641-1665): alphaD = sum p.Ap after PCGStep1 (a 1-float all-reduce), and after
-    PCGStep2 ONE all-gather of [betaN_local | first owned row of z | last owned row of z]
-    (1 + 6W floats per rank) that delivers both the second scalar and the ghost rows of z.  p on the
-    ghost rows is kept current by the fused step kernel itself, so p never crosses the wire;
-  * every rank adds the gathered partial sums in rank order, so alpha and beta are bit-identical on all
-    ranks and the replicated host logic cannot diverge;
-  * once per GN step the ghost rows of the unknowns (Offset, Angle) are refreshed the same way.
+image_warping -- the benchmarked configuration -- runs BEHIND Thallo_ProblemStep: csrc/solver_dist.cpp holds the slab schedule (one kernel
++ one exchange per PCG iteration; device mailboxes + peer-to-peer ghost rows after a self-check, else the caller's all-gather), declared
+per plan with ThalloX_PlanSetDistributed (include/Thallo.h).  What is left here for that path is set-up: the row split (SlabLayout), the
+all-gather callback over torch.distributed (`torch_allgather`: backend "nccl" = RCCL over xGMI on GPUs, "gloo" with host staging in the
+single-GPU tests), hipGraph capture of the step, and bench.py's N > 1 leg.  `PlanSlabSolver` is that thin wrapper.
 
-Communication goes through torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
-CPU tests (tests/test_distributed_cpu.py drives this exact class with a numpy compute backend).
-The compute backend below (HipSlabBackend) is the product path; it fails loudly without libThallo.so.
+`SlabSolver` is the older host-side driver of the same decomposition (two exchanges per PCG iteration, or the one-exchange form when the
+backend offers it); shape_from_shading's slab backend (distributed_sfs.py) still runs on it, and tests/test_distributed_cpu.py drives it
+with a numpy compute backend under gloo as the executable statement of the schedule:
+  * the H rows of the image are split into contiguous slabs, one per rank; a rank's local image carries ghost rows above/below (the
+    energy's stencil radius, image_warping.t:18);
+  * per PCG iteration the exchanges are dictated by the algorithm (gauss_newton.t:1641-1665): the scalars and the ghost rows of the
+    vector the stencil is applied to;
+  * every rank adds the gathered partial sums in rank order, so alpha and beta are bit-identical on all ranks and the replicated host
+    logic cannot diverge;
+  * once per GN step the ghost rows of the unknowns are refreshed the same way.
 """
 import ctypes as C
 import os
@@ -76,372 +76,6 @@ def _segs(pairs):
         s.len[k] = l
     s.n = len(pairs)
     return s
-
-
-class _RawDeviceFloats:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
-def _wrap_device_floats(ptr, n, dev):
-    """torch view of a raw device allocation (no ownership)"""
-    return torch.as_tensor(_RawDeviceFloats(ptr, n), device=dev)
-
-
-class HipSlabBackend:
-    """image_warping slab kernels through the C-ABI shim; all tensors live on the current CUDA device."""
-
-    def __init__(self, W, layout, local_params, max_l_iters, ipc=False):
-        self.L = api.lib()
-        self.p2p = None               # thallo_dist_t once enable_p2p() succeeded
-        self._ipc_ptrs, self._ipc_opened = [], []
-        self.W, self.lay = W, layout
-        Hl = layout.Hl
-        self.Hl, self.row0, self.row1 = Hl, layout.row0, layout.row1
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.device = dev
-        self.offset, self.angle, self.urshape, self.constraints, self.mask = [
-            torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in local_params[:5]]
-        self.w_fit, self.w_reg = float(local_params[5]), float(local_params[6])
-        self.L.thallo_hip_vector_elems.restype = C.c_long
-        self.L.thallo_hip_vector_elems.argtypes = [C.c_long]
-        N = W * Hl
-        self.N, self.n = N, 3 * N
-        na = self.L.thallo_hip_vector_elems(self.n)
-        z = lambda: torch.zeros(na, dtype=torch.float32, device=dev)
-        # r and z share one allocation: one pack/unpack covers both.  With ipc=True it is a plain hipMalloc block other ranks can map
-        self.max_l = max_l_iters
-        if ipc:     # one block other ranks can map: [r | z | r' | Ap | Ap'] (r', Ap' = the ping-pong partners of the one-kernel schedule)
-            ptr, self.rz_handle = self._ipc_alloc(4 * 5 * na)
-            blk = _wrap_device_floats(ptr, 5 * na, dev)
-            self.rz, self.r_alt, self.Ap_ipc = blk[:2 * na], blk[2 * na:3 * na], [blk[3 * na:4 * na], blk[4 * na:5 * na]]
-        else:
-            self.rz = torch.zeros(2 * na, dtype=torch.float32, device=dev)
-            self.r_alt, self.Ap_ipc = z(), [z(), z()]
-        self.r, self.z = self.rz[:na], self.rz[na:]
-        self.na = na
-        self.pre, self.delta = z(), z()
-        self.Ap = self.Ap_ipc[0]
-        self.s12 = torch.zeros(3 * 1024, dtype=torch.float64, device=dev)      # N, S1, S2 partials of the one-kernel schedule
-        self.fin_tickets = torch.zeros(528, dtype=torch.int32, device=dev)     # THALLO_HIP_FIN_TICKET_WORDS
-        self.exchange_in_kernel = os.environ.get("THALLO_DIST_EXCHANGE_IN_KERNEL", "1") != "0"
-        self.p = [z(), z()]
-        self.cs = torch.zeros(2 * N, dtype=torch.float32, device=dev)
-        self.flags = torch.zeros(N + 256, dtype=torch.uint8, device=dev)
-        self.irregular = torch.zeros(16, dtype=torch.int32, device=dev)      # UrShape-is-the-pixel-grid word (written by pcg_init)
-        self.parts = torch.zeros(1024, dtype=torch.float32, device=dev)      # local partials of the current reduction
-        self.nb = 1
-        self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32, device=dev)    # global (all-reduced) scalars
-        self.msg = 1 + 12 * W                                                   # [sum | first row: r, z | last row: r, z]
-        self.send = torch.zeros(self.msg, dtype=torch.float32, device=dev)
-        self.gath = torch.zeros(layout.world * self.msg, dtype=torch.float32, device=dev)
-        # flat-layout pieces: Offset plane [2*W*row, 2W), Angle plane [2N + W*row, W)
-        # (relative to rz: r at 0, z at na).  The z-free GRID schedule consumes the r rows, the general schedule the z rows;
-        # which one runs is a device-side word (irregular), so both travel.
-        row = lambda y, b=0: [(b + 2 * W * y, 2 * W), (b + 2 * N + W * y, W)]
-        both = lambda y0, y1: row(y0) + row(y0, na) + row(y1) + row(y1, na)
-        self.seg_first_last = _segs(both(self.row0, self.row1 - 1))
-        self.seg_top_ghost = _segs(row(self.row0 - 1) + row(self.row0 - 1, na)) if layout.top else _segs([])
-        self.seg_bot_ghost = _segs(row(self.row1) + row(self.row1, na)) if layout.bot else _segs([])
-        if W % 4 or (2 * N) % 4:
-            raise ValueError("the slab path needs W % 4 == 0 (16-byte row granules in the flat kernels)")
-        # one-kernel schedule over collectives: message = [alphaD | N, S1, S2 (hi, lo) | first row of Ap_out | last row of Ap_out]
-        self.msg_iter = 7 + 6 * W
-        self.send_iter = torch.zeros(self.msg_iter, dtype=torch.float32, device=dev)
-        self.gath_iter = torch.zeros(layout.world * self.msg_iter, dtype=torch.float32, device=dev)
-        self.seg_iter_first_last = _segs(row(self.row0) + row(self.row1 - 1))
-        self.seg_iter_top = _segs(row(self.row0 - 1)) if layout.top else _segs([])
-        self.seg_iter_bot = _segs(row(self.row1)) if layout.bot else _segs([])
-        self.one_kernel_collective = os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0"
-        self.use_march = os.environ.get("THALLO_MARCH", "1") != "0" and W % 2 == 0
-
-    # -- helpers
-    def _st(self):
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def _sum(self, idx):
-        return api.SumT(self.S.data_ptr() + 4 * idx, 1)
-
-    def _local(self):
-        return api.SumT(self.parts.data_ptr(), self.nb)
-
-    def _chk(self, rc, what):
-        if rc < 0:
-            raise RuntimeError(f"{what} failed with hipError {-rc}")
-        return rc
-
-    # -- compute phases
-    def cost_local(self, out_idx):
-        vp, fl = C.c_void_p, C.c_float
-        self.nb = self._chk(self.L.thallo_hip_iw_cost(self.W, self.Hl, self.row0, self.row1, vp(self.offset.data_ptr()), vp(self.angle.data_ptr()),
-                                                      vp(self.urshape.data_ptr()), vp(self.constraints.data_ptr()), vp(self.mask.data_ptr()),
-                                                      fl(self.w_fit), fl(self.w_reg), vp(self.parts.data_ptr()), self._st()), "iw_cost")
-        self._chk(self.L.thallo_hip_finish_sum(self._local(), vp(self.S.data_ptr() + 4 * out_idx), self._st()), "finish_sum")
-
-    def init(self, cur):
-        vp, fl = C.c_void_p, C.c_float
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_init(
-            self.W, self.Hl, self.row0, self.row1, vp(self.offset.data_ptr()), vp(self.angle.data_ptr()), vp(self.urshape.data_ptr()),
-            vp(self.constraints.data_ptr()), vp(self.mask.data_ptr()), fl(self.w_fit), fl(self.w_reg),
-            vp(self.r.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.delta.data_ptr()),
-            vp(self.cs.data_ptr()), vp(self.flags.data_ptr()), None, vp(self.irregular.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_init")
-
-    batches_delta = True          # the fused kernel can defer every other delta update (thallo_hip.h THALLO_IW_STEP1_MODE)
-
-    def step1(self, cur, mode, iN, iD, iB, out_idx, iN2=None, iD2=None):
-        """mode: True / 1 = first PCG iteration, False / 0 = plain, 2 = defer the delta update, 4 = apply two (needs iN2, iD2)"""
-        vp, fl = C.c_void_p, C.c_float
-        mode = int(mode)
-        s2 = (self._sum(iN2), self._sum(iD2)) if iN2 is not None else (api.SumT(None, 0), api.SumT(None, 0))
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1(
-            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
-            fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
-            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), mode, self._sum(iN), self._sum(iD), self._sum(iB), s2[0], s2[1],
-            vp(self.irregular.data_ptr()), vp(self.r.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
-        self._chk(self.L.thallo_hip_finish_sum(self._local(), vp(self.S.data_ptr() + 4 * out_idx), self._st()), "finish_sum")
-
-    def step2(self, iN, iD):
-        vp, fl = C.c_void_p, C.c_float
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step2(
-            self.W, self.Hl, self.row0, self.row1, vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
-            vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), vp(self.pre.data_ptr()), vp(self.z.data_ptr()),
-            self._sum(iN), self._sum(iD), vp(self.irregular.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step2")
-
-    def pack(self):
-        """send = [sum(local partials) | first owned row of r, of z | last owned row of r, of z]"""
-        self._chk(self.L.thallo_hip_slab_pack(C.c_void_p(self.rz.data_ptr()), self.seg_first_last, self._local(),
-                                              C.c_void_p(self.send.data_ptr()), self._st()), "slab_pack")
-
-    def unpack(self, out_idx, gathered):
-        lay, msg = self.lay, self.msg
-        base = gathered.data_ptr()
-        # my top ghost row <- the LAST owned row of rank-1 ; my bottom ghost row <- the FIRST owned row of rank+1
-        src_top = C.c_void_p(base + 4 * ((lay.rank - 1) * msg + 1 + 6 * self.W)) if lay.top else None
-        src_bot = C.c_void_p(base + 4 * ((lay.rank + 1) * msg + 1)) if lay.bot else None
-        self._chk(self.L.thallo_hip_slab_unpack(C.c_void_p(self.rz.data_ptr()), self.seg_top_ghost, src_top, self.seg_bot_ghost, src_bot,
-                                                C.c_void_p(base), C.c_long(msg), lay.world, C.c_void_p(self.S.data_ptr() + 4 * out_idx), self._st()),
-                  "slab_unpack")
-
-    def linear_update(self, cur, iN, iD, with_p):
-        vp = C.c_void_p
-        W, N = self.W, self.N
-        rows = self.row1 - self.row0
-        for X, off, ln, xo in ((self.offset, 2 * W * self.row0, 2 * W * rows, 2 * W * self.row0), (self.angle, 2 * N + W * self.row0, W * rows, W * self.row0)):
-            p_ptr = vp(self.p[cur].data_ptr() + 4 * off) if with_p else None
-            self._chk(self.L.thallo_hip_linear_update(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off), p_ptr, C.c_long(ln),
-                                                      self._sum(iN), self._sum(iD), self._st()), "linear_update")
-
-    def linear_update2(self, cur, iN0, iD0, iN1, iD1):
-        """X += delta + alpha_{L-2} p_{L-2} + alpha_{L-1} p_{L-1}: the tail of a GN step with two deferred delta updates"""
-        vp = C.c_void_p
-        W, N = self.W, self.N
-        rows = self.row1 - self.row0
-        for X, off, ln, xo in ((self.offset, 2 * W * self.row0, 2 * W * rows, 2 * W * self.row0), (self.angle, 2 * N + W * self.row0, W * rows, W * self.row0)):
-            self._chk(self.L.thallo_hip_linear_update2(vp(X.data_ptr() + 4 * xo), vp(self.delta.data_ptr() + 4 * off),
-                                                       vp(self.p[cur ^ 1].data_ptr() + 4 * off), self._sum(iN0), self._sum(iD0),
-                                                       vp(self.p[cur].data_ptr() + 4 * off), self._sum(iN1), self._sum(iD1), C.c_long(ln), self._st()), "linear_update2")
-
-    # -- device-side exchange (thallo_dist_t, include/thallo_hip.h): mailboxes + neighbour r rows over xGMI peer-to-peer stores
-    def _ipc_alloc(self, nbytes):
-        ptr = C.c_void_p()
-        handle = C.create_string_buffer(64)
-        kind = C.c_int(-1)
-        self._chk(self.L.thallo_hip_ipc_alloc2(C.c_long(nbytes), C.byref(ptr), handle, C.byref(kind)), "ipc_alloc")
-        self._ipc_ptrs.append(ptr.value)
-        self.ipc_memory = getattr(self, "ipc_memory", []) + ["fine-grained" if kind.value == 1 else "coarse-grained"]
-        return ptr.value, handle.raw
-
-    def _ipc_open(self, handle):
-        ptr = C.c_void_p()
-        self._chk(self.L.thallo_hip_ipc_open(C.create_string_buffer(handle, 64), C.byref(ptr)), "ipc_open")
-        self._ipc_opened.append(ptr.value)
-        return ptr.value
-
-    def enable_p2p(self, group=None):
-        """Collective.  Allocates this rank's mailbox, maps every peer's mailbox and the two neighbours' r vectors."""
-        lay, W = self.lay, self.W
-        if not hasattr(self, "rz_handle"):
-            raise RuntimeError("the backend was not created with ipc=True")
-        n_slots = 7 * (self.max_l + 2)                     # one-kernel schedule: 7 granules per iteration (two-kernel: 2)
-        mail_ptr, mail_handle = self._ipc_alloc(8 * n_slots * lay.world)
-        self.ctl = torch.zeros(16, dtype=torch.int32, device=self.device)       # THALLO_DIST_CTL_WORDS
-        mine = {"rank": lay.rank, "mail": mail_handle, "rz": self.rz_handle, "row0": self.row0, "row1": self.row1, "Hl": self.Hl, "na": self.na,
-                "pid": os.getpid()}
-        infos = [None] * lay.world
-        if lay.world > 1:
-            dist.all_gather_object(infos, mine, group=group)
-        else:
-            infos = [mine]
-        d = api.DistT()
-        d.world, d.rank = lay.world, lay.rank
-        d.mail = mail_ptr
-        d.ctl = self.ctl.data_ptr()
-        for r, inf in enumerate(infos):
-            d.peer_mail[r] = mail_ptr if r == lay.rank else self._ipc_open(inf["mail"])
-        for k, nb in enumerate((lay.up(), lay.down())):
-            if nb is None:
-                d.peer_r[k] = None
-                continue
-            inf = infos[nb]
-            d.peer_r[k] = self._ipc_open(inf["rz"])                        # r is the first half of the peer's rz block
-            ghost_row = inf["row1"] if k == 0 else inf["row0"] - 1         # my first row -> its bottom ghost; my last row -> its top ghost
-            d.peer_off_o[k] = 2 * W * ghost_row
-            d.peer_off_a[k] = 2 * W * inf["Hl"] + W * ghost_row
-        self.p2p = d
-        # one-kernel schedule: per parity of the ping-pong, a DistT whose peer offsets point at the neighbour's ghost row of ITS Ap_out
-        # buffer (block layout [r | z | r' | Ap | Ap'], na of the neighbour = its padded vector length)
-        self.p2p_iter = []
-        for out_idx in (0, 1):
-            e = api.DistT()
-            C.memmove(C.byref(e), C.byref(d), C.sizeof(api.DistT))
-            for k, nb in enumerate((lay.up(), lay.down())):
-                if nb is None:
-                    continue
-                inf = infos[nb]
-                ghost_row = inf["row1"] if k == 0 else inf["row0"] - 1
-                base = (3 + out_idx) * inf["na"]
-                e.peer_off_o[k] = base + 2 * W * ghost_row
-                e.peer_off_a[k] = base + 2 * W * inf["Hl"] + W * ghost_row
-            self.p2p_iter.append(e)
-        torch.cuda.synchronize()      # (the caller agrees on success across ranks before any kernel touches a peer)
-
-    def p2p_begin(self):
-        self._chk(self.L.thallo_hip_dist_begin_step(self.p2p, self._st()), "dist_begin_step")
-
-    def p2p_exchange(self, out_idx):
-        """S[out_idx] <- rank-ordered sum over ranks of (fixed-order sum of this rank's current partials)"""
-        self._chk(self.L.thallo_hip_dist_exchange(self.p2p, out_idx, self._local(), C.c_void_p(self.S.data_ptr() + 4 * out_idx), self._st()), "dist_exchange")
-
-    def step1_p2p(self, cur, mode, iN, iD, iB, out_idx, iN2=None, iD2=None):
-        vp, fl = C.c_void_p, C.c_float
-        mode = int(mode)
-        s2 = (self._sum(iN2), self._sum(iD2)) if iN2 is not None else (api.SumT(None, 0), api.SumT(None, 0))
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step1(
-            self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()),
-            fl(self.w_fit), fl(self.w_reg), vp(self.z.data_ptr()), vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()),
-            vp(self.delta.data_ptr()), vp(self.Ap.data_ptr()), mode, self._sum(iN), self._sum(iD), self._sum(iB), s2[0], s2[1],
-            vp(self.irregular.data_ptr()), vp(self.r.data_ptr()), vp(self.parts.data_ptr()), self._st()), "iw_pcg_step1")
-        self.p2p_exchange(out_idx)              # alphaD
-
-    def step2_p2p(self, iN, iD, out_idx):
-        vp, fl = C.c_void_p, C.c_float
-        self.nb = self._chk(self.L.thallo_hip_iw_pcg_step2_dist(
-            self.W, self.Hl, self.row0, self.row1, vp(self.flags.data_ptr()), fl(self.w_fit), fl(self.w_reg),
-            vp(self.r.data_ptr()), vp(self.Ap.data_ptr()), self._sum(iN), self._sum(iD), self.p2p, vp(self.parts.data_ptr()), self._st()), "iw_pcg_step2_dist")
-        self.p2p_exchange(out_idx)              # betaN ; behind it the neighbours' rows of r are in my ghost rows
-
-    def _iter_entry(self, dist_variant):
-        """The one-kernel iteration's shim entry + its leading arguments: the marching kernel (unit-pixel-grid UrShape, which the one-kernel
-        slab schedule requires anyway: SlabSolver checks `irregular` on the host) unless THALLO_MARCH=0 selects the LDS-tiled kernel."""
-        vp = C.c_void_p
-        if self.use_march:
-            fn = self.L.thallo_hip_iw_pcg_iter_march_dist if dist_variant else self.L.thallo_hip_iw_pcg_iter_march
-            return fn, (self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.flags.data_ptr()))
-        fn = self.L.thallo_hip_iw_pcg_iter_dist if dist_variant else self.L.thallo_hip_iw_pcg_iter
-        return fn, (self.W, self.Hl, self.row0, self.row1, vp(self.cs.data_ptr()), vp(self.urshape.data_ptr()), vp(self.flags.data_ptr()), vp(self.pre.data_ptr()))
-
-    def iter_p2p(self, cur, mode, iN, iD, iB, jD, jB, iN2, iD2, k):
-        """One PCG iteration = one kernel (thallo_hip_iw_pcg_iter_dist: also stores its boundary rows of Ap into the neighbours' ghost
-        rows) + one exchange (alphaD, N, S1, S2 -> S[jD] = alphaD_k, S[jB] = betaN_k).  Buffers r / Ap / p ping-pong on `cur`."""
-        vp, fl = C.c_void_p, C.c_float
-        rb = (self.r, self.r_alt)
-        fn, head = self._iter_entry(True)
-        self.nb = self._chk(fn(
-            *head,
-            fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(self.Ap_ipc[cur ^ 1].data_ptr()),
-            vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), int(mode),
-            self._sum(iN), self._sum(iD), self._sum(iB), self._sum(iN2), self._sum(iD2), vp(self.irregular.data_ptr()), self.p2p_iter[cur ^ 1],
-            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()),
-            vp(self.fin_tickets.data_ptr()) if self.exchange_in_kernel else None, 7 * k, vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB),
-            self._st()), "iw_pcg_iter_dist")
-        if not self.exchange_in_kernel:      # THALLO_DIST_EXCHANGE_IN_KERNEL=0: the exchange as its own one-wave launch
-            self._chk(self.L.thallo_hip_dist_exchange_iter(self.p2p, 7 * k, vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self.nb, self._sum(iB),
-                                                           vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB), self._st()), "dist_exchange_iter")
-
-    def iter_collective(self, cur, mode, iN, iD, iB, jD, jB, iN2, iD2, allgather):
-        """One PCG iteration = the one-kernel iteration (no peer stores) + ONE all-gather of [alphaD, N, S1, S2, boundary rows of Ap_out]
-        (`allgather(send, recv)`; None at world size 1) -> S[jD] = alphaD_k, S[jB] = betaN_k, ghost rows of Ap_out."""
-        vp, fl = C.c_void_p, C.c_float
-        rb = (self.r, self.r_alt)
-        Ao = self.Ap_ipc[cur ^ 1]
-        fn, head = self._iter_entry(False)
-        self.nb = self._chk(fn(
-            *head,
-            fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(Ao.data_ptr()),
-            vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), int(mode),
-            self._sum(iN), self._sum(iD), self._sum(iB), self._sum(iN2), self._sum(iD2), vp(self.irregular.data_ptr()),
-            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), None, None, None, self._st()), "iw_pcg_iter")
-        self._chk(self.L.thallo_hip_slab_pack_iter(vp(Ao.data_ptr()), self.seg_iter_first_last, vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), self.nb,
-                                                   vp(self.send_iter.data_ptr()), self._st()), "slab_pack_iter")
-        lay, msg = self.lay, self.msg_iter
-        if allgather is not None:
-            allgather(self.send_iter, self.gath_iter)
-            g, world = self.gath_iter, lay.world
-        else:
-            g, world = self.send_iter, 1
-        base = g.data_ptr()
-        src_top = vp(base + 4 * ((lay.rank - 1) * msg + 7 + 3 * self.W)) if lay.top else None      # the LAST owned row of rank-1
-        src_bot = vp(base + 4 * ((lay.rank + 1) * msg + 7)) if lay.bot else None                    # the FIRST owned row of rank+1
-        self._chk(self.L.thallo_hip_slab_unpack_iter(vp(Ao.data_ptr()), self.seg_iter_top, src_top, self.seg_iter_bot, src_bot, vp(base), C.c_long(msg), world,
-                                                     self._sum(iB), vp(self.S.data_ptr() + 4 * jD), vp(self.S.data_ptr() + 4 * jB), self._st()), "slab_unpack_iter")
-
-    def iter_local(self, cur=0):
-        """the one-kernel iteration without the remote stores and without the exchange (bench: kernel time on this rank's slab)"""
-        vp, fl = C.c_void_p, C.c_float
-        rb = (self.r, self.r_alt)
-        fn, head = self._iter_entry(False)
-        return self._chk(fn(
-            *head,
-            fl(self.w_fit), fl(self.w_reg), vp(rb[cur].data_ptr()), vp(rb[cur ^ 1].data_ptr()), vp(self.Ap_ipc[cur].data_ptr()), vp(self.Ap_ipc[cur ^ 1].data_ptr()),
-            vp(self.p[cur].data_ptr()), vp(self.p[cur ^ 1].data_ptr()), vp(self.delta.data_ptr()), 0,
-            self._sum(2), self._sum(3), self._sum(4), self._sum(2), self._sum(3), vp(self.irregular.data_ptr()),
-            vp(self.parts.data_ptr()), vp(self.s12.data_ptr()), None, None, None, self._st()), "iw_pcg_iter")
-
-    def p2p_collect(self, slot0, nslots):
-        self._chk(self.L.thallo_hip_dist_collect(self.p2p, slot0, nslots, C.c_void_p(self.S.data_ptr() + 4 * slot0), self._st()), "dist_collect")
-
-    def p2p_error(self, clear=True):
-        """1 if a bounded mailbox wait timed out since the last clear (synchronises)"""
-        self.p2p_post_mortem = self.ctl[4:9].cpu().tolist()     # (slot, source rank, expected seq, found seq, found value bits) of the first timeout
-        return self._chk(self.L.thallo_hip_dist_error(self.p2p, 1 if clear else 0, self._st()), "dist_error")
-
-    def close(self):
-        torch.cuda.synchronize()
-        for p in self._ipc_opened:
-            self.L.thallo_hip_ipc_close(C.c_void_p(p))
-        self._ipc_opened = []
-        # the rz / mailbox blocks stay allocated for the life of the process: tensors may still alias them
-
-    def pack_grid_info(self):
-        """uint8 [irregular word (4 bytes) | flags of the first owned row | flags of the last owned row]"""
-        W = self.W
-        return torch.cat([self.irregular[:1].view(torch.uint8), self.flags[W * self.row0:W * (self.row0 + 1)],
-                          self.flags[W * (self.row1 - 1):W * self.row1]])
-
-    def unpack_grid_info(self, g):
-        W, lay = self.W, self.lay
-        self.irregular[:1].copy_(g[:, :4].contiguous().view(torch.int32).clamp_(max=1).sum())
-        if lay.top:
-            self.flags[W * (self.row0 - 1):W * self.row0].copy_(g[lay.rank - 1, 4 + W:4 + 2 * W])
-        if lay.bot:
-            self.flags[W * self.row1:W * (self.row1 + 1)].copy_(g[lay.rank + 1, 4:4 + W])
-
-    def pack_unknowns(self):
-        W = self.W
-        off = self.offset.view(self.Hl, 2 * W); ang = self.angle.view(self.Hl, W)
-        return torch.cat([off[self.row0], ang[self.row0], off[self.row1 - 1], ang[self.row1 - 1]])
-
-    def unpack_unknowns(self, g):
-        W, lay = self.W, self.lay
-        off = self.offset.view(self.Hl, 2 * W); ang = self.angle.view(self.Hl, W)
-        g = g.view(lay.world, 2, 3 * W)
-        if lay.top:
-            off[self.row0 - 1].copy_(g[lay.rank - 1, 1, :2 * W]); ang[self.row0 - 1].copy_(g[lay.rank - 1, 1, 2 * W:])
-        if lay.bot:
-            off[self.row1].copy_(g[lay.rank + 1, 0, :2 * W]); ang[self.row1].copy_(g[lay.rank + 1, 0, 2 * W:])
-
-    def scalar(self, idx):
-        return float(self.S[idx].item())
 
 
 class SlabSolver:
@@ -532,172 +166,175 @@ class SlabSolver:
     def solve(self, n_iters, l_iters):
         costs = [self.cost()]
         for _ in range(n_iters):
-            (self.gn_step_p2p if getattr(self, "p2p_on", False) else self.gn_step)(l_iters)
+            self.gn_step(l_iters)
             costs.append(self.cost())
         return costs
 
-    # -- hipGraph replay of a whole GN step (kernels + RCCL collectives): removes ~100 us of host work per PCG
-    #    iteration, which at 4-8 ranks is several times the kernels' own time
-    def gn_step_p2p(self, l_iters):
-        """gn_step with the PCG loop's scalar and ghost-row exchange done by the kernels themselves (mailboxes + peer-to-peer row
-        stores, csrc/dist_device.hpp): RCCL only once per GN step (alphaN_0, initial ghost rows, flags).  z-free schedule only."""
-        be = self.be
-        B, L = 2, l_iters
-        cur = 0
-        batched = getattr(be, "batches_delta", False)
-        be.init(cur)
-        if self.use_dist:
-            send = be.pack_grid_info()
-            gath = torch.empty(self.world * send.numel(), dtype=send.dtype, device=send.device)
-            dist.all_gather_into_tensor(gath, send, group=self.group)
-            be.unpack_grid_info(gath.view(self.world, -1))
-        self._gather_sum_and_rows(B)
-        be.p2p_begin()                                 # seq += 1
-        one_kernel = getattr(be, "p2p_iter", None) is not None and os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0"
-        for k in range(L if one_kernel else 0):        # one kernel + ONE exchange per PCG iteration (thallo_hip_iw_pcg_iter_dist)
-            jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
-            be.iter_p2p(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD, jB,
-                        jN - 4 if k > 1 else jN, jD - 4 if k > 1 else jD, k)
-            cur ^= 1
-        for k in range(0 if one_kernel else L):
-            jN, jD, jB = B + 2 * k, B + 2 * k + 1, B + 2 * k + 2
-            if batched:                                # every other delta update deferred (thallo_hip.h THALLO_IW_STEP1_MODE)
-                be.step1_p2p(cur, 1 if k == 0 else 2 if k & 1 else 4, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD,
-                             jN - 4 if k > 1 else jN, jD - 4 if k > 1 else jD)
+
+# ------------------------------------------------------------------ image_warping: the slab schedule behind Thallo_ProblemStep
+class _RawDeviceBytes:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def torch_allgather(group=None, device=None):
+    """ThalloX_AllGatherFn over torch.distributed: `f(send_ptr, recv_ptr, bytes_per_rank, stream_ptr)`.  Backend nccl: one
+    all_gather_into_tensor on the given stream (RCCL; capturable into a hipGraph).  Backend gloo (several ranks sharing one GPU in the
+    tests -- RCCL refuses that): staged through the host."""
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    views = {}
+
+    def view(ptr, n):
+        t = views.get((ptr, n))
+        if t is None:
+            t = views[(ptr, n)] = torch.as_tensor(_RawDeviceBytes(ptr, n), device=dev)
+        return t
+
+    def f(send, recv, nbytes, stream):
+        s, r = view(send, nbytes), view(recv, nbytes * world)
+        cur = torch.cuda.current_stream()
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream and stream != cur.cuda_stream else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            if backend == "nccl":
+                dist.all_gather_into_tensor(r, s, group=group)
             else:
-                be.step1_p2p(cur, k == 0, jN - 2 if k else jN, jD - 2 if k else jD, jN, jD)
-            cur ^= 1
-            be.step2_p2p(jN, jD, jB)
-        if L > 1 and batched and (L - 1) & 1:
-            be.linear_update2(cur, B + 2 * (L - 2), B + 2 * (L - 2) + 1, B + 2 * (L - 1), B + 2 * (L - 1) + 1)
-        elif L > 0:
-            be.linear_update(cur, B + 2 * (L - 1), B + 2 * (L - 1) + 1, True)
-        else:
-            be.linear_update(cur, B, B, False)
-        self._exchange_unknown_ghosts()
+                h = s.cpu()
+                out = [torch.empty_like(h) for _ in range(world)]
+                dist.all_gather(out, h, group=group)
+                r.copy_(torch.cat(out))
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+    return f
 
-    def try_enable_p2p(self, l_iters=6, rtol=1e-3):
-        """Collective.  Sets up the device-side exchange and checks it against the collective path on this very topology: one
-        GN step each way from the same unknowns must give the same alpha/beta scalars to rtol (a stale ghost row or a lost granule
-        shows up there; the two paths round differently -- betaN from its double-precision expansion vs from the rounded r --
-        which after a few iterations is worth ~1e-5), no wait may time out, and UrShape must be the pixel grid everywhere.  On success gn_step_fast /
-        capture use the p2p form.  Every rank returns the same answer."""
-        be = self.be
 
-        def agree(flag):
-            if self.world > 1:
-                t = torch.tensor([1.0 if flag else 0.0], device=be.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-                return bool(t.item() > 0.5)
-            return bool(flag)
+class PlanSlabSolver:
+    """One rank's row slab of an image_warping problem, solved through the library (Thallo_ProblemInit / Step / CurrentCost are
+    collective once ThalloX_PlanSetDistributed was called)."""
 
-        self.p2p_check = {}
-        try:
-            be.enable_p2p(self.group)
-            mapped = True
-        except Exception as e:      # noqa: BLE001 - any set-up problem (no IPC, no peer access ...) means: stay on the collective path
-            self.p2p_check = {"error": repr(e)}
-            mapped = False
-        if not agree(mapped):       # every rank mapped every peer, or nobody launches a kernel that touches one
-            self.p2p_on = False
-            return False
-        ok = True
-        try:
-            be.ctl[2] = 500             # DIST_SPIN_MS: a topology where granules never become visible costs 0.5 s here, not the 20 s production bound
-            X0, A0 = be.offset.clone(), be.angle.clone()
-            self.gn_step(l_iters)
-            ref = be.S[2:2 + 2 * l_iters + 1].clone()
-            irregular = int(be.irregular[0].item())
-            be.offset.copy_(X0); be.angle.copy_(A0)
-            self.gn_step_p2p(l_iters)
-            got = be.S[2:2 + 2 * l_iters + 1].clone()
-            err = be.p2p_error()
-            be.offset.copy_(X0); be.angle.copy_(A0)
-            rel = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item())
-            be.ctl[2] = 0
-            self.p2p_check = {"irregular": irregular, "timeout": err, "max_rel_scalar_diff": rel, "memory": sorted(set(getattr(be, "ipc_memory", [])))}
-            if irregular != 0 or err != 0 or not (rel <= rtol):
-                ok = False
-        except Exception as e:      # noqa: BLE001
-            self.p2p_check = {"error": repr(e)}
-            ok = False
-        ok = agree(ok)
-        self.p2p_on = ok
-        return self.p2p_on
+    def __init__(self, params_global, W, H, rank, world, l_iters, device_exchange=True, group=None, force_allgather=False):
+        self.lay = lay = SlabLayout(H, rank, world)
+        self.W, self.H, self.world, self.rank, self.group = W, H, world, rank, group
+        dev = torch.device("cuda", torch.cuda.current_device())
+        local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in params_global]
+        self.offset, self.angle, self.urshape, self.constraints, self.mask = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in local[:5]]
+        self.solver = api.ThalloSolver((W, lay.Hl), api.energy_file("image_warping"), timing_level=0)
+        self.l_iters = l_iters
+        self.solver.set_solver_parameters(nIterations=1 << 30, lIterations=l_iters)
+        ag = torch_allgather(group, dev) if world > 1 or force_allgather else None      # (force: the real collective even at world size 1 -- probes)
+        self.solver.set_distributed(rank, world, lay.row0, lay.row1, allgather=ag, device_exchange=device_exchange)
+        self.params = self.solver.make_params([self.offset, self.angle, self.urshape, self.constraints, self.mask, float(local[5]), float(local[6])])
+        self._graph = None
+        self._inited = False
 
-    def capture_gn_step(self, l_iters):
-        """Capture gn_step(l_iters) into a CUDA/HIP graph.  Returns True on success; on any failure the solver stays
-        in eager mode.  All ranks must call this together (the capture contains collectives)."""
+    def init(self):
+        """Collective.  The first Init also runs the device-side exchange's self-check (csrc/solver_dist.cpp dist_self_check)."""
+        self.solver.init(self.params)
+        if not self.solver.ready():
+            raise RuntimeError("Thallo_ProblemInit failed: " + api.last_error())
+        self._inited = True
+
+    @property
+    def info(self):
+        return self.solver.distributed_info()
+
+    def cost(self):
+        if not self._inited:
+            self.init()
+        return self.solver.current_cost()
+
+    def gn_step(self):
+        if self.solver.step(self.params) != 1:
+            raise RuntimeError("Thallo_ProblemStep failed: " + api.last_error())
+
+    def solve(self, n_iters, l_iters=None):
+        if l_iters is not None and l_iters != self.l_iters:
+            self.solver.set_solver_parameters(lIterations=l_iters)
+            self.l_iters = l_iters
+        self.init()
+        costs = [self.cost()]
+        for _ in range(n_iters):
+            self.gn_step()
+            costs.append(self.cost())
+        return costs
+
+    def owned(self):
+        """(Offset, Angle) rows this rank owns, as host arrays"""
+        lay, W = self.lay, self.W
+        return (self.offset.view(lay.Hl, W, 2)[lay.row0:lay.row1].cpu().numpy(), self.angle.view(lay.Hl, W)[lay.row0:lay.row1].cpu().numpy())
+
+    # -- hipGraph replay of a whole GN step (kernels + the exchange): removes the host's launch work per PCG iteration, which at 4-8 ranks
+    #    is several times the kernels' own time
+    def capture(self):
+        """Capture one Thallo_ProblemStep into a HIP graph.  True on success; on any failure the solver stays eager.  Collective."""
         self._graph = None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            step = self.gn_step_p2p if getattr(self, "p2p_on", False) else self.gn_step
+            self.solver.set_stream(side.cuda_stream)
             with torch.cuda.stream(side):
-                step(l_iters)                           # warm-up on the side stream (allocations, RCCL channel setup)
-            torch.cuda.current_stream().wait_stream(side)
+                self.gn_step()                          # warm-up on the side stream (allocations, RCCL channel set-up)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                step(l_iters)
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                self.gn_step()
             torch.cuda.synchronize()
-            self._graph, self._graph_l = g, l_iters
+            self._graph = g
             return True
         except Exception as e:      # noqa: BLE001 - any capture problem means: stay eager
-            self._graph = None
-            self._graph_error = repr(e)
+            self._graph, self._graph_error = None, repr(e)
             try:
                 torch.cuda.synchronize()
-            except Exception:
+            except Exception:       # noqa: BLE001
                 pass
+            self.solver.set_stream(0)
             return False
 
-    def gn_step_fast(self, l_iters):
-        if getattr(self, "_graph", None) is not None and self._graph_l == l_iters:
+    def drop_graph(self):
+        self._graph = None
+        self.solver.set_stream(0)
+
+    def gn_step_fast(self):
+        if self._graph is not None:
             self._graph.replay()
-        elif getattr(self, "p2p_on", False):
-            self.gn_step_p2p(l_iters)
         else:
-            self.gn_step(l_iters)
-
-
-def make_hip_solver(params_global, W, H, rank, world, max_l_iters, ipc=False):
-    lay = SlabLayout(H, rank, world)
-    local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in params_global]
-    be = HipSlabBackend(W, lay, local, max_l_iters, ipc=ipc)
-    return SlabSolver(be, lay), lay
+            self.gn_step()
 
 
 def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world):
     """bench.py's N>1 leg: K timed GN steps between barriers, MAX over ranks, rank 0 reports."""
     use_p2p = os.environ.get("THALLO_DIST_P2P", "1") != "0"
-    solver, lay = make_hip_solver(params_global, W, H, rank, world, l_iters, ipc=use_p2p)
-    c0 = solver.cost()
-    # device-side exchange (mailboxes + peer-to-peer ghost rows): enabled only if its self-check against the collective path
-    # passes on this topology; every rank takes the same decision
-    p2p = solver.try_enable_p2p() if use_p2p else False
+    solver = PlanSlabSolver(params_global, W, H, rank, world, l_iters, device_exchange=use_p2p)
+    lay = solver.lay
+    c0 = solver.cost()             # Init: collective; the device-side exchange enables itself only if its self-check passes on this topology
+    info = solver.info
+    p2p = info.get("exchange") == "p2p-mailbox"
     # graph replay of the GN step is opt-out (THALLO_DIST_GRAPH=0); every rank must agree, so the outcome is all-reduced
     use_graph = os.environ.get("THALLO_DIST_GRAPH", "1") != "0"
 
     def capture():
         if not use_graph:
             return False
-        ok = solver.capture_gn_step(l_iters)            # runs one warm-up + one captured step
+        ok = solver.capture()                           # runs one warm-up + one captured step
         flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if flag.item() <= 0.5:
-            solver._graph = None
+            solver.drop_graph()
         return bool(flag.item() > 0.5)
 
     def timed():
         for _ in range(warmup):
-            solver.gn_step_fast(l_iters)
+            solver.gn_step_fast()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            solver.gn_step_fast(l_iters)
+            solver.gn_step_fast()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -708,38 +345,36 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     captured = capture()
     dt = timed()
     if p2p:
-        bad = torch.tensor([float(solver.be.p2p_error())], device="cuda")
+        bad = torch.tensor([float(solver.solver.distributed_error())], device="cuda")
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if bad.item() > 0:          # a bounded mailbox wait timed out: the numbers above are void -- redo on the collective path
-            solver.p2p_on, solver._graph, p2p = False, None, False
+        if bad.item() > 0:          # a bounded mailbox wait timed out: the numbers above are void -- redo on the all-gather path
+            solver.drop_graph()
+            solver.solver.distributed_use_allgather()
+            p2p = False
             captured = capture()
             dt = timed()
+        info = solver.info
+    solver.drop_graph()
     final = solver.cost()
     npx = W * H
-    # roofline of the dominant kernel on this rank's slab: the graph replay cannot be bracketed per kernel, so the fused
-    # PCGStep1 is re-launched back-to-back right after the timed region and timed with HIP events on the launch stream
-    be = solver.be
+    # roofline of the dominant kernel on this rank's slab: the graph replay cannot be bracketed per kernel, so the one-kernel PCG iteration is
+    # re-launched back-to-back right after the timed region (no exchange) and timed with HIP events on the launch stream
     reps = 40
-    one_kernel = os.environ.get("THALLO_DIST_ONE_KERNEL", "1") != "0" and getattr(solver, "_grid_ok", True)      # both transports run the one-kernel iteration
-    kern = (lambda: be.iter_local(0)) if one_kernel else (lambda: be.step1(0, False, 2, 3, 4, 5))    # (step1: + the 1-block finish_sum)
-    for _ in range(3):
-        kern()
+    solver.solver.distributed_kernel_only(3)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        kern()
+    solver.solver.distributed_kernel_only(reps)
     e1.record(); torch.cuda.synchronize()
     k_ms = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device="cuda")
     dist.all_reduce(k_ms, op=dist.ReduceOp.MAX)
     k_ms = float(k_ms.item())
     slab_px = W * (lay.g1 - lay.g0)
-    alg = 180.0 if one_kernel else 96.0
-    ach = alg * slab_px / (k_ms * 1e-3) / 1e9
+    ach = 99.0 * slab_px / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm",
-                "kernel": ("PCGIteration (whole PCG iteration in one launch)" if one_kernel else "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)") + " on one rank's slab, slowest rank",
+                "kernel": "PCGIteration (whole PCG iteration in one launch) on one rank's slab, slowest rank",
                 "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                "algorithmic_bytes_per_pixel": alg, "actual_bytes_per_pixel": 99 if one_kernel else 75, "avg_launch_ms": k_ms, "slab_pixels": slab_px,
+                "algorithmic_bytes_per_pixel": 99, "reference_formulation_bytes_per_pixel": 180, "avg_launch_ms": k_ms, "slab_pixels": slab_px,
                 "note": "per GPU; measured right after the timed region (graph replay cannot be bracketed per kernel)"}
     return {
         "metric": "pcg_iters_per_sec", "value": steps * l_iters / dt, "unit": "PCG iterations/s",
@@ -747,12 +382,12 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"examples/image_warping {W}x{H} ARAP, GN + matrix-free PCG, {l_iters} PCG iterations per GN step",
                    "width": W, "height": H, "unknowns": 3 * npx, "l_iterations": l_iters,
-                   "parallelism": (f"{world} row slabs; per PCG iteration ONE kernel + ONE exchange: alphaD, N, S1, S2 through device mailboxes "
-                                   "(7 eight-byte peer-to-peer stores per rank, summed in rank order) + boundary rows of Ap stored into the "
+                   "parallelism": (f"{world} row slabs behind Thallo_ProblemStep; per PCG iteration ONE kernel + ONE exchange: alphaD, N, S1, S2 through device "
+                                   "mailboxes (7 eight-byte peer-to-peer stores per rank, summed in rank order) + boundary rows of Ap stored into the "
                                    "neighbours' ghost rows over xGMI; RCCL once per GN step") if p2p else
-                                  f"{world} row slabs; per PCG iteration ONE kernel + ONE RCCL all-gather (alphaD, N, S1, S2, Ap boundary rows)"},
+                                  f"{world} row slabs behind Thallo_ProblemStep; per PCG iteration ONE kernel + ONE RCCL all-gather (alphaD, N, S1, S2, Ap boundary rows)"},
         "ms_per_gn_iter": dt / steps * 1e3, "us_per_pcg_iter": dt / (steps * l_iters) * 1e6,
         "initial_cost": c0, "final_cost": final, "graph_replay": captured,
-        "exchange": "p2p-mailbox" if p2p else "rccl", "p2p_check": getattr(solver, "p2p_check", None),
+        "exchange": "p2p-mailbox" if p2p else "rccl", "p2p_check": info,
         "roofline": roofline, "cpu_baseline": None,
     }

@@ -1,12 +1,13 @@
-"""Probe (1 GPU, backend nccl, world_size 1 with the collective code path forced): per-PCG-iteration time of ONE rank's slab
-(W x H = what one of 8 ranks owns at 2048^2 -> 2048 x 256) through (a) RCCL collectives, eager and graph-replayed, and
-(b) the device-side exchange, eager and graph-replayed.  Gives the per-rank kernel + protocol cost without xGMI latency."""
+"""Probe (1 GPU, backend nccl, world_size 1 with the all-gather really issued): per-PCG-iteration time of ONE rank's slab
+(W x H = what one of 8 ranks owns at 2048^2 -> 2048 x 256) through the library's slab path (csrc/solver_dist.cpp) with (a) the RCCL
+all-gather transport, eager and graph-replayed, and (b) the device-side exchange, eager and graph-replayed.  Gives the per-rank kernel +
+protocol cost without xGMI latency.   PW / PH: slab size."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, torch.distributed as dist
 from thallo_amd import synthetic as syn
-from thallo_amd.distributed import make_hip_solver
+from thallo_amd.distributed import PlanSlabSolver
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
 torch.cuda.set_device(0)
@@ -22,25 +23,21 @@ def timeit(fn, n=5):
 
 
 out = {}
-if 'THALLO_ITER_PER_CU' in os.environ:
-    from thallo_amd import api
-    api.lib().thallo_hip_debug_set(8, int(os.environ['THALLO_ITER_PER_CU']))
-if 'THALLO_ITER_NT' in os.environ:
-    from thallo_amd import api
-    api.lib().thallo_hip_debug_set(7, int(os.environ['THALLO_ITER_NT']))
 for name, p2p in (("rccl", False), ("p2p", True)):
-    s, _ = make_hip_solver(p, W, H, 0, 1, L, ipc=p2p)
-    s.use_dist = True
-    if p2p:
-        print("p2p enabled:", s.try_enable_p2p(), s.p2p_check)
-    step = s.gn_step_p2p if p2p else s.gn_step
-    out[name + "_eager_us"] = timeit(lambda: step(L))
-    ok = s.capture_gn_step(L)
+    s = PlanSlabSolver(p, W, H, 0, 1, L, device_exchange=p2p, force_allgather=True)
+    out[name + "_cost0"] = s.cost()
+    print(name, s.info)
+    out[name + "_eager_us"] = timeit(s.gn_step)
+    ok = s.capture()
     print(name, "captured:", ok, getattr(s, "_graph_error", None))
     if ok:
-        out[name + "_graph_us"] = timeit(lambda: s.gn_step_fast(L))
+        out[name + "_graph_us"] = timeit(s.gn_step_fast)
     if p2p:
-        print("p2p error word:", s.be.p2p_error())
+        print("p2p error word:", s.solver.distributed_error())
+    s.drop_graph()
     out[name + "_cost"] = s.cost()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    s.solver.distributed_kernel_only(5); t0.record(); s.solver.distributed_kernel_only(50); t1.record(); torch.cuda.synchronize()
+    out[name + "_kernel_only_us"] = t0.elapsed_time(t1) / 50 * 1e3
 print({k: round(v, 2) for k, v in out.items()})
 dist.destroy_process_group()

@@ -1,36 +1,31 @@
-"""Soak test of the device-side exchange (GPU box): `world` processes on GPU 0 over real IPC mappings run many GN steps of the
-one-kernel schedule; every rank must finish without a mailbox timeout, hold bit-identical alpha/beta traces, and land on the cost
-of the collective path.  python tools/p2p_soak.py [world] [gn_steps] [l_iters] [W] [H]"""
+"""Soak test of the device-side exchange (GPU box): `world` processes on GPU 0 over real IPC mappings run many GN steps of the slab
+schedule behind Thallo_ProblemStep; every rank must finish without a mailbox timeout, hold bit-identical alpha/beta traces, and land on
+the cost of the all-gather transport.  python tools/p2p_soak.py [world] [gn_steps] [l_iters] [W] [H]"""
 import os, sys, socket, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 
 
 def worker(rank, world, port, W, H, steps, L, q):
     import torch, torch.distributed as dist
     from thallo_amd import synthetic as syn
-    from thallo_amd.distributed import make_hip_solver
+    from thallo_amd.distributed import PlanSlabSolver
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.image_warping(W, H, n_markers=8)
-        ref, _ = make_hip_solver(p, W, H, rank, world, L)
-        c_ref = ref.solve(3, L)
-        s, lay = make_hip_solver(p, W, H, rank, world, L, ipc=True)
-        on = s.try_enable_p2p(l_iters=min(6, L))
+        ref = PlanSlabSolver(p, W, H, rank, world, L, device_exchange=False)
+        c_ref = ref.solve(steps, L)
+        s = PlanSlabSolver(p, W, H, rank, world, L, device_exchange=True)
         c0 = s.cost()
         t0 = time.time()
-        traces = []
         for i in range(steps):
-            s.gn_step_p2p(L)
-            if i < 3 or i == steps - 1:
-                traces.append(s.be.S[2:2 + 2 * L + 1].cpu().numpy().copy())
+            s.gn_step()
         torch.cuda.synchronize()
         dt = time.time() - t0
-        err = s.be.p2p_error()
-        q.put((rank, on, s.p2p_check, err, getattr(s.be, "p2p_post_mortem", None), c_ref, [c0, s.cost()], np.concatenate(traces), dt))
+        err = s.solver.distributed_error()
+        q.put((rank, s.info, err, c_ref[-1], [c0, s.cost()], s.solver.alpha_beta_trace(), dt))
     finally:
         dist.destroy_process_group()
 
@@ -57,8 +52,8 @@ if __name__ == "__main__":
     for p_ in procs: p_.join(timeout=20)
     res.sort(key=lambda t: t[0])
     ok = len(res) == world
-    for r in res:
-        print("rank", r[0], "p2p", r[1], r[2], "timeout", r[3], r[4], "collective costs", [round(c, 5) for c in r[5]], "p2p costs", [round(c, 6) for c in r[6]], "%.1f s" % r[8])
-        ok = ok and r[1] and r[3] == 0 and (r[7] == res[0][7]).all()
-    print("exchanges per rank:", steps * L, "  SOAK", "OK" if ok else "FAILED")
+    for rank, info, err, c_ref, c, trace, dt in res:
+        print(f"rank {rank}: exchange={info.get('exchange')} err={err} cost {c[0]:.6g} -> {c[1]:.6g} (all-gather path: {c_ref:.6g}) {dt:.2f} s")
+        ok = ok and info.get("exchange") == "p2p-mailbox" and err == 0 and trace == res[0][5] and abs(c[1] - c_ref) <= 1e-5 * abs(c_ref)
+    print("SOAK", "OK" if ok else "FAILED")
     sys.exit(0 if ok else 1)

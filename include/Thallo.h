@@ -109,6 +109,10 @@ void ThalloX_EnableLM(Thallo_Plan* plan, int enable);
 /* Name of the plugin a plan runs ("image_warping", "laplacian_image", ...). */
 const char* ThalloX_PlanEnergyName(Thallo_Plan* plan);
 
+/* The J^T J p schedule the plan's plugin runs: "matrix-free" (hand-written plugins), or for generated plugins "per residual" (each residual's own
+ * schedule lines), "dense [JtJ]p", "sparse [[Jt][J]]p", "dense direct solve". */
+const char* ThalloX_PlanScheduleName(Thallo_Plan* plan);
+
 /* 1 if the most recent Thallo_ProblemInit on this plan succeeded (parameters bound, plugin prepared), else 0: Init itself returns void. */
 int ThalloX_PlanReady(Thallo_Plan* plan);
 

@@ -434,6 +434,12 @@ int thallo_hip_ell_apply(int mode, long rows, int K, const float* val, const int
 /* dense J^T J (n x n, zeroed by the caller) from materialized rows, and y = M x: the dense [JtJ]p schedule for small n (gauss_newton.t:560-622) */
 int thallo_hip_dense_jtj_accumulate(long rows, int K, const float* val, const int* col, long n, float* JtJ, thallo_stream_t stream);
 int thallo_hip_dense_gemv(long n, const float* M, const float* x, float* y, thallo_stream_t stream);
+/* Numeric phase of the sparse J^T J of a non-constant J ([[Jt][J]]p, gauss_newton.t:1394-1441 csrgemm): out[dest[(i*K + a)*K + b]] += val[i*K + a] * val[i*K + b]
+ * over the ELL rows of J; `dest` (positions in the CSR values, -1 = none) comes from the symbolic phase the host runs once per Init. */
+int thallo_hip_jtj_scatter(long rows, int K, const float* val, const int* dest, float* out, thallo_stream_t stream);
+/* Direct solve of the dense normal equations (gauss_newton.t:1280-1328; compiled out there, opt-in here): A (n x n row-major, symmetric positive
+ * definite, OVERWRITTEN by its Cholesky factor) x = b.  info[0] (device int) = 0, or 1 + the row of the first non-positive pivot. n <= 8192. */
+int thallo_hip_dense_cholesky_solve(long n, float* A, const float* b, float* x, int* info, thallo_stream_t stream);
 
 /* ---------------------------------------------------------------- multi-GPU device-side exchange (one process per GPU) */
 /* Device memory that other processes can map: *ptr = hipMalloc(bytes) (zeroed), handle_out = 64-byte hipIpcMemHandle_t. */

@@ -156,6 +156,27 @@ def test_distributed_plan_rejects_what_it_cannot_run():
     assert not s.ready() and "unit pixel grid" in api.last_error()
 
 
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """bench.py's N > 1 leg end to end on this 1-GPU box: `--gpus 2` spawns the ranks, THALLO_DIST_BACKEND=gloo lets them share cuda:0 (RCCL refuses
+    that; never a measured configuration), the slab schedule runs behind Thallo_ProblemStep with the device-side exchange, rank 0 prints the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, THALLO_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256", "--liters", "20"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["metric"] == "pcg_iters_per_sec" and d["value"] > 0
+    assert d["exchange"] == "p2p-mailbox" and d["p2p_check"]["self_check"]["all_ranks_pass"]
+    assert d["final_cost"] < d["initial_cost"]
+    assert 0 < d["roofline"]["frac"] < 1
+
+
 # ------------------------------------------------------------------ camera-sharded bundle adjustment (HIP backend)
 def _ba_worker(rank, world, port, dims, nit, lit, q):
     import torch

@@ -90,6 +90,7 @@ def lib():
     L.ThalloX_PlanEnergyName.argtypes = [vp]; L.ThalloX_PlanEnergyName.restype = C.c_char_p
     L.ThalloX_LastError.restype = C.c_char_p
     L.ThalloX_PlanReady.argtypes = [vp]; L.ThalloX_PlanReady.restype = C.c_int
+    L.ThalloX_PlanScheduleName.argtypes = [vp]; L.ThalloX_PlanScheduleName.restype = C.c_char_p
     L.ThalloX_PlanSetDistributed.argtypes = [vp, C.POINTER(DistributedT)]; L.ThalloX_PlanSetDistributed.restype = C.c_int
     L.ThalloX_PlanDistributedInfo.argtypes = [vp]; L.ThalloX_PlanDistributedInfo.restype = C.c_char_p
     L.ThalloX_DistributedControl.argtypes = [vp, C.c_int, C.c_int]; L.ThalloX_DistributedControl.restype = C.c_int
@@ -195,6 +196,10 @@ class ThalloSolver:
     @property
     def energy_name(self):
         return self._L.ThalloX_PlanEnergyName(self.plan).decode()
+
+    @property
+    def schedule_name(self):
+        return self._L.ThalloX_PlanScheduleName(self.plan).decode()
 
     def set_solver_parameters(self, **kw):
         for k, v in kw.items():

@@ -71,6 +71,8 @@ struct Problem {
     std::vector<std::string> dims;                 // Dims("W","H"): ids are positions; sizes come from the unsigned[] at Plan time
     std::vector<Input> inputs;                     // in Inputs{} order (= declaration order of the unknown images in the flat vectors)
     bool use_preconditioner = false;
+    bool direct_solve = false;                     // <Residuals handle>:set_direct_solve(true) (thallo.t:5634-5636); acted on only under THALLO_ENABLE_DIRECT_SOLVE=1,
+                                                   // like the reference's compile-time enable_direct_solve (gauss_newton.t:22)
     std::vector<Residual> residuals;
     int max_slot = -1;
 };

@@ -650,6 +650,7 @@ struct Interp {
         }
         if (is_symk(obj, SymV::NamedRes)) { if (m == "compute_at_output" || m == "reorder" || m == "clear_reorder") return { obj }; }
         if (is_symk(obj, SymV::ResidualsH)) {
+            if (m == "set_direct_solve") { P.direct_solve = !args.empty() && args[0].truthy(); return {}; }      // thallo.t:5634-5636
             if (m == "merge") {                      // thallo.t:5676-5688: the second residual's expressions join the first
                 if (args.size() != 2 || !is_symk(args[0], SymV::NamedRes) || !is_symk(args[1], SymV::NamedRes)) fail(ln + "merge(r1, r2)");
                 const int i1 = args[0].sym->id, i2 = args[1].sym->id;
@@ -929,6 +930,7 @@ std::string describe(const Problem& p)
         o << "\n";
     }
     o << "preconditioner " << (p.use_preconditioner ? 1 : 0) << "\n";
+    if (p.direct_solve) o << "direct_solve\n";
     for (auto& r : p.residuals) { o << "residual " << r.name << " x" << r.exprs.size() << " over"; for (int d : r.domain) o << " " << p.dims[d]; if (r.mat_J) o << " J"; if (r.mat_JtJ) o << " JtJ"; if (r.mat_Jp) o << " Jp"; o << "\n"; }
     return o.str();
 }

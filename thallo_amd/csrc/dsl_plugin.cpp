@@ -9,11 +9,16 @@
 //                                       row); every PCG iteration applies them with the energy-independent thallo_hip_ell_apply -- no derivative is
 //                                       re-evaluated inside the PCG loop; with Jp materialized too, as the pair J p / J^T (J p)
 //   J and JtJ materialized on EVERY residual and n <= THALLO_DENSE_JTJ_MAX (default 2048): dense [JtJ]p -- J^T J accumulated once per GN iteration,
-//                                       one GEMV per PCG iteration (gauss_newton.t:560-622, 1216-1241); above that size JtJ requests run as [Jt][[J]p]
-//                                       (the reference's [[Jt][J]]p forms the sparse product with csrgemm: the same operator, not built here)
+//                                       one GEMV per PCG iteration (gauss_newton.t:560-622, 1216-1241).  With <handle>:set_direct_solve(true) in the file AND
+//                                       THALLO_ENABLE_DIRECT_SOLVE=1 (the reference compiles this out: enable_direct_solve = false, gauss_newton.t:22) the GN step
+//                                       solves the dense system by Cholesky instead of running PCG (:1280-1328, 1612-1613)
+//   ... and n above that size:          sparse [[Jt][J]]p (:1394-1441 csrgemm, :1462-1481 one csrmv per PCG iteration): the CSR pattern of J^T J is built from
+//                                       the rows' unknown indices once per Init on the host, its values are re-accumulated once per GN iteration on the device
 #include "dsl.hpp"
 #include "plugin.hpp"
 #include <hip/hiprtc.h>
+#include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +46,12 @@ class GeneratedPlugin : public EnergyPlugin {
     std::vector<DeviceBuffer*> jval, jcol;         // per residual with a materialized J: ELL values / unknown indices ([rows][K])
     DeviceBuffer dense;                            // dense [JtJ]p: the n x n matrix
     bool dense_ = false;
+    bool direct_ = false;                          // dense + set_direct_solve(true) + THALLO_ENABLE_DIRECT_SOLVE=1
+    DeviceBuffer info_;                            // Cholesky status word
+    bool sparse_jtj_ = false, sp_ready_ = false;   // sparse [[Jt][J]]p; pattern built (once per Init)
+    DeviceBuffer sp_rowptr, sp_col, sp_val;
+    std::vector<DeviceBuffer*> jdest;              // per residual: [rows][K][K] positions of the products in sp_val
+    long sp_nnz = 0;
     bool ok_ = false;
 
     long elements(const dsl::Residual& r) const { long n = 1; for (int d : r.domain) n *= dimv[d]; return n; }
@@ -86,7 +97,10 @@ public:
         long dense_max = 2048; if (const char* e = getenv("THALLO_DENSE_JTJ_MAX")) dense_max = atol(e);
         dense_ = all_jtj && n_unk <= dense_max;
         if (dense_ && dense.alloc(sizeof(float) * (size_t)n_unk * (size_t)n_unk)) { set_error("%s: out of device memory for the dense JtJ", label.c_str()); return; }
-        jval.assign(P.residuals.size(), nullptr); jcol.assign(P.residuals.size(), nullptr);
+        sparse_jtj_ = all_jtj && !dense_ && !P.residuals.empty() && n_unk < (1L << 31);
+        { const char* e = getenv("THALLO_ENABLE_DIRECT_SOLVE"); direct_ = dense_ && P.direct_solve && e && e[0] == '1'; }
+        if (direct_ && info_.alloc(64)) return;
+        jval.assign(P.residuals.size(), nullptr); jcol.assign(P.residuals.size(), nullptr); jdest.assign(P.residuals.size(), nullptr);
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
             if (!P.residuals[ri].mat_J && !P.residuals[ri].mat_JtJ) continue;
             const size_t ent = (size_t)rows_of(ri) * (size_t)G.slots_per_row[ri];
@@ -95,8 +109,71 @@ public:
         }
         ok_ = true;
     }
-    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : jval) delete b; for (auto b : jcol) delete b; }
-    const char* schedule() const { return dense_ ? "dense [JtJ]p" : "per residual"; }
+    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : jval) delete b; for (auto b : jcol) delete b; for (auto b : jdest) delete b; }
+    const char* schedule_name() const override { return direct_ ? "dense direct solve" : dense_ ? "dense [JtJ]p" : sparse_jtj_ ? "sparse [[Jt][J]]p" : "per residual"; }
+    int prepare(LaunchCtx&) override { sp_ready_ = false; return 0; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
+
+    // symbolic phase of the sparse J^T J (the reference: cusparseXcsrgemmNnz, gauss_newton.t:1404-1412): the rows' unknown indices -> CSR pattern
+    // + for every product v[i][a] * v[i][b] its position in the values
+    int build_sparse_pattern(hipStream_t s)
+    {
+        const size_t R = P.residuals.size();
+        std::vector<std::vector<int>> hc(R);
+        size_t products = 0;
+        for (size_t ri = 0; ri < R; ++ri) {
+            const size_t ent = (size_t)rows_of(ri) * (size_t)G.slots_per_row[ri];
+            hc[ri].resize(ent);
+            if (ent && hipMemcpyAsync(hc[ri].data(), jcol[ri]->ptr, ent * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+            products += ent * (size_t)G.slots_per_row[ri];
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        std::vector<uint64_t> keys; keys.reserve(products);
+        for (size_t ri = 0; ri < R; ++ri) {
+            const int K = G.slots_per_row[ri]; const long rows = rows_of(ri);
+            for (long i = 0; i < rows; ++i) {
+                const int* c = &hc[ri][(size_t)i * K];
+                for (int a = 0; a < K; ++a) { if (c[a] < 0) continue; for (int b = 0; b < K; ++b) if (c[b] >= 0) keys.push_back(((uint64_t)(uint32_t)c[a] << 32) | (uint32_t)c[b]); }
+            }
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        if (keys.size() >= (size_t)1 << 31) { set_error("%s: J^T J has too many non-zeros for 32-bit positions", label.c_str()); return -1; }
+        sp_nnz = (long)keys.size();
+        std::vector<int> rowptr((size_t)n_unk + 1, 0), col(keys.size());
+        for (size_t q = 0; q < keys.size(); ++q) { rowptr[(size_t)(keys[q] >> 32) + 1]++; col[q] = (int)(uint32_t)keys[q]; }
+        for (long i = 0; i < n_unk; ++i) rowptr[i + 1] += rowptr[i];
+        auto up = [&](DeviceBuffer& b, const void* h, size_t bytes) { return b.alloc(bytes + 64) || (bytes && hipMemcpy(b.ptr, h, bytes, hipMemcpyHostToDevice) != hipSuccess) ? -1 : 0; };
+        if (up(sp_rowptr, rowptr.data(), rowptr.size() * sizeof(int)) || up(sp_col, col.data(), col.size() * sizeof(int)) || sp_val.alloc(keys.size() * sizeof(float) + 64)) {
+            set_error("%s: out of device memory for the sparse JtJ (%ld non-zeros)", label.c_str(), sp_nnz); return -1;
+        }
+        for (size_t ri = 0; ri < R; ++ri) {
+            const int K = G.slots_per_row[ri]; const long rows = rows_of(ri);
+            std::vector<int> dest((size_t)rows * K * K, -1);
+            for (long i = 0; i < rows; ++i) {
+                const int* c = &hc[ri][(size_t)i * K];
+                for (int a = 0; a < K; ++a) { if (c[a] < 0) continue; for (int b = 0; b < K; ++b) {
+                    if (c[b] < 0) continue;
+                    const uint64_t key = ((uint64_t)(uint32_t)c[a] << 32) | (uint32_t)c[b];
+                    dest[((size_t)i * K + a) * K + b] = (int)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+                } }
+            }
+            if (!jdest[ri]) jdest[ri] = new DeviceBuffer();
+            if (up(*jdest[ri], dest.data(), dest.size() * sizeof(int))) { set_error("%s: out of device memory for the sparse JtJ", label.c_str()); return -1; }
+        }
+        sp_ready_ = true;
+        return 0;
+    }
+    bool direct_solve() const override { return direct_; }
+    int solve_direct(LaunchCtx& c, SolverVectors& v) override
+    {   // delta = (J^T J)^-1 r with r = -J^T F as PCGInit1 left it (the reference: LU + inverse + gemv on the same two operands, gauss_newton.t:1290-1326)
+        TimedLaunch t(c, "DirectSolve");
+        int rc = thallo_hip_dense_cholesky_solve(n_unk, (float*)dense.ptr, v.r, v.delta, (int*)info_.ptr, c.stream);
+        if (rc < 0) return rc;
+        int info = 0;
+        if (hipMemcpyAsync(&info, info_.ptr, sizeof(int), hipMemcpyDeviceToHost, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess) return -1;
+        if (info) { set_error("%s: J^T J is not positive definite (pivot %d): the direct solve needs a full-rank J", label.c_str(), info - 1); return -1; }
+        return 0;
+    }
     bool ok() const { return ok_; }
 
     int compile()
@@ -174,6 +251,14 @@ public:
             int rc = launch(kernel_of((int)ri, 5), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
             if (dense_ && (rc = thallo_hip_dense_jtj_accumulate(rows_of(ri), G.slots_per_row[ri], jv, jc, n_unk, (float*)dense.ptr, s)) < 0) return rc;
         }
+        if (sparse_jtj_) {                             // csrgemm (gauss_newton.t:1394-1441): pattern once per Init, values once per GN iteration
+            if (!sp_ready_ && build_sparse_pattern(s)) return -1;
+            if (hipMemsetAsync(sp_val.ptr, 0, (size_t)sp_nnz * sizeof(float), s) != hipSuccess) return -1;
+            for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+                const int rc = thallo_hip_jtj_scatter(rows_of(ri), G.slots_per_row[ri], (const float*)jval[ri]->ptr, (const int*)jdest[ri]->ptr, (float*)sp_val.ptr, s);
+                if (rc < 0) return rc;
+            }
+        }
         return thallo_hip_pcg_init_finish(v.r, v.pre, v.pre, v.z, v.n, P.use_preconditioner ? 1 : 0, aN, s);           // PCGInit1_Finish (gauss_newton.t:712-731)
     }
     int apply(LaunchCtx& c, const float* p, float* Ap, float* out, long n_alloc)
@@ -183,6 +268,8 @@ public:
             const int rc = thallo_hip_dense_gemv(n_unk, (const float*)dense.ptr, p, Ap, s); if (rc < 0) return rc;
             return thallo_hip_dot(p, Ap, n_unk, out, s);
         }
+        if (sparse_jtj_)                               // one SpMV; alphaD = p . Ap rides along (the count of its partials is the return value)
+            return thallo_hip_csr_spmv((int)n_unk, (const int*)sp_rowptr.ptr, (const int*)sp_col.ptr, (const float*)sp_val.ptr, p, Ap, p, out, s);
         if (hipMemsetAsync(Ap, 0, (size_t)n_alloc * sizeof(float), s) != hipSuccess) return -1;                         // Ap_X:clear() (gauss_newton.t:1633-1635)
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
             const int g = grid_for(nel[ri], 4096);

@@ -72,6 +72,7 @@ class EnergyPlugin {
 public:
     virtual ~EnergyPlugin() {}
     virtual const char* name() const = 0;
+    virtual const char* schedule_name() const { return "matrix-free"; }    // which J^T J p schedule this plugin runs (ThalloX_PlanScheduleName)
     virtual long n_unknowns() const = 0;
     virtual const std::vector<UnknownImage>& unknown_images() const = 0;   // declaration order
     virtual bool use_preconditioner() const = 0;
@@ -115,6 +116,9 @@ public:
     }
     // pointer to unknown image k as currently bound
     virtual float* unknown_ptr(int k) = 0;
+    // Direct solve of the normal equations instead of PCG (gauss_newton.t:1280-1328, 1612-1613): after pcg_init, delta = (J^T J)^-1 r
+    virtual bool direct_solve() const { return false; }
+    virtual int  solve_direct(LaunchCtx&, SolverVectors&) { return -1; }
     // ---- one row slab of a multi-GPU run (solver_dist.cpp): image-stencil plugins whose kernels take an owned-row range
     virtual bool supports_row_slabs() const { return false; }
     virtual int  set_row_slab(int /*row0*/, int /*row1*/) { return -1; }

@@ -310,6 +310,21 @@ void Plan::linear_update_tail(int L, bool batched)
 
 int Plan::step_gn(int ev_iter)
 {   // GN branch, fused schedule (DESIGN.md "PCG schedule")
+    if (plugin->direct_solve()) {                     // the linear system solved exactly, no PCG loop (gauss_newton.t:1612-1613)
+        hipStream_t s = ctx.stream;
+        cur_ = 0;
+        const int nb = plugin->pcg_init(ctx, v_, cur_, slot(2));
+        if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
+        set_nb(2, nb);
+        const int ev_lin = timer_.start("Linear Solve", s);
+        if (plugin->solve_direct(ctx, v_) < 0) { const std::string why = last_error(); set_error("direct solve failed: %s", why.c_str()); return 0; }
+        timer_.stop(ev_lin, s);
+        last_l_iters = 0;
+        linear_update_tail(0, false);
+        sp.nIter++;
+        timer_.stop(ev_iter, s);
+        return 1;
+    }
     if (one_kernel_ && plugin->one_kernel_iteration()) return step_gn_one_kernel(ev_iter);
     if (expanded_ && plugin->apply_returns_sums()) return step_gn_expanded(ev_iter);
     const int L = sp.lIterations;

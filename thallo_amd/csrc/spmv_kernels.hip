@@ -72,9 +72,131 @@ __global__ __launch_bounds__(BLOCK) void k_dense_gemv(long n, const float* __res
         if (lane == 0) y[r] = s;
     }
 }
+// sparse J^T J for a non-constant J ([[Jt][J]]p, gauss_newton.t:1394-1441: csrgemm once per GN iteration): the PATTERN of J^T J follows from the
+// rows' unknown indices and is built once per Init on the host (dsl_plugin.cpp); `dest[(i*K + a)*K + b]` = position of the product
+// v[i][a] * v[i][b] in the CSR values (-1: no such entry).  The numeric phase is this scatter.
+__global__ __launch_bounds__(BLOCK) void k_jtj_scatter(long rows, int K, const float* __restrict__ val, const int* __restrict__ dest, float* __restrict__ out)
+{
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < rows; i += (long)gridDim.x * BLOCK) {
+        const float* v = val + i * K; const int* d = dest + i * K * K;
+        for (int a = 0; a < K; ++a) {
+            const float va = v[a];
+            if (va == 0.0f) continue;
+            for (int b = 0; b < K; ++b) { const int q = d[a * K + b]; const float w = va * v[b]; if (q >= 0 && w != 0.0f) atomicAdd(out + q, w); }
+        }
+    }
+}
+
+// ---- dense direct solve (gauss_newton.t:1280-1328 cublasDirectSolve: LU, inverse, gemv -- compiled out there by enable_direct_solve = false,
+// :22; opt-in here).  J^T J is symmetric positive definite when J has full column rank, so: blocked right-looking Cholesky A = L L^T in
+// place (lower triangle, row-major n x n), then L y = b, L^T x = y.  NB = 32: the diagonal block and one panel block live in LDS.
+constexpr int NB = 32;
+// one workgroup: factor the diagonal block at (k,k), then panel rows below it: L21 = A21 L11^-T.  info[0] = 1 + row of a non-positive pivot.
+__global__ __launch_bounds__(BLOCK) void k_potrf_panel(long n, long k, float* __restrict__ A, int* __restrict__ info)
+{
+    __shared__ float D[NB][NB + 1];
+    __shared__ int bad;
+    const int t = threadIdx.x, nb = (int)((n - k) < NB ? (n - k) : NB);
+    if (t == 0) bad = 0;
+    for (int e = t; e < NB * NB; e += BLOCK) { const int r = e / NB, c = e % NB; D[r][c] = (r < nb && c <= r) ? A[(k + r) * n + k + c] : 0.0f; }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {                 // unblocked Cholesky of the nb x nb block, column by column
+        if (t == 0) { const float d = D[j][j]; if (!(d > 0.0f)) { bad = j + 1; D[j][j] = 1.0f; } else D[j][j] = sqrtf(d); }
+        __syncthreads();
+        if (t > j && t < nb) D[t][j] /= D[j][j];
+        __syncthreads();
+        for (int e = t; e < nb * nb; e += BLOCK) { const int r = e / nb, c = e % nb; if (c > j && r >= c) D[r][c] -= D[r][j] * D[c][j]; }
+        __syncthreads();
+    }
+    if (t == 0 && bad && info[0] == 0) info[0] = (int)k + bad;
+    for (int e = t; e < nb * nb; e += BLOCK) { const int r = e / nb, c = e % nb; if (c <= r) A[(k + r) * n + k + c] = D[r][c]; }
+    for (long r = k + nb + t; r < n; r += BLOCK) {  // one panel row per thread: x L11^T = a  (forward substitution over the block's columns)
+        float x[NB];
+        for (int c = 0; c < nb; ++c) {
+            float v = A[r * n + k + c];
+            for (int q = 0; q < c; ++q) v -= x[q] * D[c][q];
+            x[c] = v / D[c][c];
+        }
+        for (int c = 0; c < nb; ++c) A[r * n + k + c] = x[c];
+    }
+}
+// trailing update A22 -= L21 L21^T (lower triangle only), one NB x NB tile per workgroup
+__global__ __launch_bounds__(BLOCK) void k_syrk_tile(long n, long k, int nb, float* __restrict__ A)
+{
+    __shared__ float P[NB][NB + 1], Q[NB][NB + 1];
+    const long base = k + nb;
+    const long tr = blockIdx.y, tc = blockIdx.x;
+    if (tc > tr) return;
+    const long r0 = base + tr * NB, c0 = base + tc * NB;
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += BLOCK) {
+        const int i = e / NB, j = e % NB;
+        P[i][j] = (r0 + i < n && j < nb) ? A[(r0 + i) * n + k + j] : 0.0f;
+        Q[i][j] = (c0 + i < n && j < nb) ? A[(c0 + i) * n + k + j] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += BLOCK) {
+        const int i = e / NB, j = e % NB;
+        if (r0 + i >= n || c0 + j >= n || c0 + j > r0 + i) continue;
+        float s = 0.0f;
+        for (int q = 0; q < NB; ++q) s += P[i][q] * Q[j][q];
+        A[(r0 + i) * n + c0 + j] -= s;
+    }
+}
+// one workgroup: x = L^-T L^-1 b, blockwise (the block's triangular solve by thread 0..nb-1 in LDS, the update of the rest by everyone)
+__global__ __launch_bounds__(BLOCK) void k_potrs(long n, const float* __restrict__ L, const float* __restrict__ b, float* __restrict__ x)
+{
+    __shared__ float xs[NB];
+    __shared__ float D[NB][NB + 1];
+    const int t = threadIdx.x;
+    for (long i = t; i < n; i += BLOCK) x[i] = b[i];
+    __syncthreads();
+    for (long k = 0; k < n; k += NB) {             // forward: L y = b
+        const int nb = (int)((n - k) < NB ? (n - k) : NB);
+        for (int e = t; e < nb * nb; e += BLOCK) D[e / nb][e % nb] = L[(k + e / nb) * n + k + e % nb];
+        __syncthreads();
+        if (t == 0) for (int c = 0; c < nb; ++c) { float v = x[k + c]; for (int q = 0; q < c; ++q) v -= D[c][q] * xs[q]; xs[c] = v / D[c][c]; x[k + c] = xs[c]; }
+        __syncthreads();
+        for (long r = k + nb + t; r < n; r += BLOCK) { float s = 0.0f; for (int q = 0; q < nb; ++q) s += L[r * n + k + q] * xs[q]; x[r] -= s; }
+        __syncthreads();
+    }
+    for (long k = (n - 1) / NB * NB; k >= 0; k -= NB) {   // backward: L^T x = y
+        const int nb = (int)((n - k) < NB ? (n - k) : NB);
+        for (int e = t; e < nb * nb; e += BLOCK) D[e / nb][e % nb] = L[(k + e / nb) * n + k + e % nb];
+        __syncthreads();
+        if (t == 0) for (int c = nb - 1; c >= 0; --c) { float v = x[k + c]; for (int q = c + 1; q < nb; ++q) v -= D[q][c] * xs[q]; xs[c] = v / D[c][c]; x[k + c] = xs[c]; }
+        __syncthreads();
+        for (long r = t; r < k; r += BLOCK) { float s = 0.0f; for (int q = 0; q < nb; ++q) s += L[(k + q) * n + r] * xs[q]; x[r] -= s; }
+        __syncthreads();
+    }
+}
 }  // namespace
 
 extern "C" {
+
+int thallo_hip_jtj_scatter(long rows, int K, const float* val, const int* dest, float* out, thallo_stream_t stream)
+{
+    if (rows < 0 || K < 1 || !val || !dest || !out) return -(int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    long want = (rows + BLOCK - 1) / BLOCK; if (want > 4096) want = 4096;
+    hipLaunchKernelGGL(k_jtj_scatter, dim3((unsigned)want), dim3(BLOCK), 0, (hipStream_t)stream, rows, K, val, dest, out);
+    return check_launch();
+}
+
+int thallo_hip_dense_cholesky_solve(long n, float* A, const float* b, float* x, int* info, thallo_stream_t stream)
+{
+    if (n < 1 || n > 8192 || !A || !b || !x || !info) return -(int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(info, 0, sizeof(int), s) != hipSuccess) return -(int)hipErrorInvalidValue;
+    for (long k = 0; k < n; k += NB) {
+        const int nb = (int)((n - k) < NB ? (n - k) : NB);
+        hipLaunchKernelGGL(k_potrf_panel, dim3(1), dim3(BLOCK), 0, s, n, k, A, info);
+        const long rest = n - k - nb;
+        if (rest > 0) { const unsigned tiles = (unsigned)((rest + NB - 1) / NB); hipLaunchKernelGGL(k_syrk_tile, dim3(tiles, tiles), dim3(BLOCK), 0, s, n, k, nb, A); }
+    }
+    hipLaunchKernelGGL(k_potrs, dim3(1), dim3(BLOCK), 0, s, n, A, b, x);
+    return check_launch();
+}
 
 int thallo_hip_ell_apply(int mode, long rows, int K, const float* val, const int* col, const float* p, float* Jp, float* Ap, thallo_stream_t stream)
 {

@@ -308,6 +308,13 @@ class PlanSlabSolver:
 def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world):
     """bench.py's N>1 leg: K timed GN steps between barriers, MAX over ranks, rank 0 reports."""
     use_p2p = os.environ.get("THALLO_DIST_P2P", "1") != "0"
+    rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"        # (gloo exists only to exercise this leg on a 1-GPU box)
+
+    def reduce(x, op, dtype=torch.float32):
+        t = torch.tensor([x], dtype=dtype, device=rdev)
+        dist.all_reduce(t, op=op)
+        return t.item()
+
     solver = PlanSlabSolver(params_global, W, H, rank, world, l_iters, device_exchange=use_p2p)
     lay = solver.lay
     c0 = solver.cost()             # Init: collective; the device-side exchange enables itself only if its self-check passes on this topology
@@ -319,12 +326,11 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     def capture():
         if not use_graph:
             return False
-        ok = solver.capture()                           # runs one warm-up + one captured step
-        flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() <= 0.5:
+        ok = solver.capture() if rdev == "cuda" else False     # runs one warm-up + one captured step (host-staged gloo cannot be captured)
+        ok = reduce(1.0 if ok else 0.0, dist.ReduceOp.MIN) > 0.5
+        if not ok:
             solver.drop_graph()
-        return bool(flag.item() > 0.5)
+        return ok
 
     def timed():
         for _ in range(warmup):
@@ -338,16 +344,12 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        return float(dt.item())
+        return float(reduce(time.perf_counter() - t0, dist.ReduceOp.MAX, torch.float64))
 
     captured = capture()
     dt = timed()
     if p2p:
-        bad = torch.tensor([float(solver.solver.distributed_error())], device="cuda")
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if bad.item() > 0:          # a bounded mailbox wait timed out: the numbers above are void -- redo on the all-gather path
+        if reduce(float(solver.solver.distributed_error()), dist.ReduceOp.MAX) > 0:          # a bounded mailbox wait timed out: the numbers above are void -- redo on the all-gather path
             solver.drop_graph()
             solver.solver.distributed_use_allgather()
             p2p = False
@@ -366,9 +368,7 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     e0.record()
     solver.solver.distributed_kernel_only(reps)
     e1.record(); torch.cuda.synchronize()
-    k_ms = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device="cuda")
-    dist.all_reduce(k_ms, op=dist.ReduceOp.MAX)
-    k_ms = float(k_ms.item())
+    k_ms = float(reduce(e0.elapsed_time(e1) / reps, dist.ReduceOp.MAX, torch.float64))
     slab_px = W * (lay.g1 - lay.g0)
     ach = 99.0 * slab_px / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm",

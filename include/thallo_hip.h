@@ -69,6 +69,17 @@ typedef struct thallo_dist_t {
     int       world, rank;
 } thallo_dist_t;
 
+/* In-kernel finish of the single-reduction PCG form (the *_apply_jtj_sums_fin entries): with `tickets` (THALLO_HIP_FIN_TICKET_WORDS zeroed device
+   words; zero again when the kernel ends) the launch's last workgroup also writes alphaD_word[0] = alphaD_k and betaN_word[0] = N - 2 alpha_k S1 +
+   alpha_k^2 S2 (alpha_k = alphaN / alphaD_k) -- what thallo_hip_pcg_scalars_finish does in a launch of its own, same order, same bits.
+   tickets == NULL: partials only. */
+typedef struct thallo_fin_t {
+    thallo_sum_t alphaN;
+    unsigned*    tickets;
+    float*       alphaD_word;
+    float*       betaN_word;
+} thallo_fin_t;
+
 long thallo_hip_vector_elems(long n_unknowns);          /* n rounded up to a multiple of 256 */
 int  thallo_hip_device_cu_count(void);                  /* multiprocessor count of the current device */
 
@@ -405,6 +416,16 @@ int thallo_hip_pcg_scalars_finish(const float* alphaD_partials, const double* s3
 int thallo_hip_arap_apply_jtj_sums(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                                    const float* constraints, const float* G, float w_fit, float w_reg,
                                    const float* p, float* Ap, float* alphaD_out, long ell_stride, const float* r, const float* pre, double* s3_out, thallo_stream_t stream);
+/* the same three with the in-kernel finish of the iteration's scalars (thallo_fin_t above); fin.tickets == NULL: identical to the plain forms */
+int thallo_hip_arap_apply_jtj_sums_fin(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
+                                       const float* constraints, const float* G, float w_fit, float w_reg,
+                                       const float* p, float* Ap, float* alphaD_out, long ell_stride, const float* r, const float* pre, double* s3_out,
+                                       thallo_fin_t fin, thallo_stream_t stream);
+int thallo_hip_sfs_apply_jtj_sums_fin(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                      float* U, float* R, const float* p, float* Ap, float* alphaD_out, const float* r, double* s3_out, thallo_fin_t fin, thallo_stream_t stream);
+int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
+                                 const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* alphaD_out,
+                                 const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream);
 /* shape_from_shading applyJTJ with a device-side gate word (may be NULL): non-zero = the launch does nothing (the LM branch ends its PCG loop on
  * the device without a host round trip per iteration, solver.cpp) */
 int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

@@ -740,6 +740,30 @@ def test_lm_trajectory_matches_oracle(torch, orc, which):
     assert all(costs[i + 1] <= costs[i] * (1 + 1e-6) for i in range(len(costs) - 1))     # LM never accepts an uphill step
 
 
+@pytest.mark.parametrize("which", ["iw", "arap", "sfs", "ba"])
+def test_in_kernel_scalar_finish_is_bitwise_the_separate_launch(torch, which, monkeypatch):
+    """The last workgroup of the iteration's (last) kernel finishes alphaD_k / betaN_k itself (device_common.hpp block_finish_sums,
+    iw_device.hpp iter_tail); THALLO_FIN_IN_KERNEL=0 runs the one-wave PCGScalars launch instead: same summation order, same bits."""
+    if which == "iw":
+        dims, p, name = (96, 80), syn.image_warping(96, 80, n_markers=8), "image_warping"
+    elif which == "arap":
+        p = syn.arap_mesh(40, 30, n_handles=8, angle_amp=0.3); dims, name = (p[2].shape[0], p[6].shape[0]), "arap_mesh_deformation"
+    elif which == "sfs":
+        dims, p, name = (130, 67), syn.shape_from_shading(130, 67), "shape_from_shading"
+    else:
+        dims, p, name = (64, 4000, 20000), syn.bundle_adjustment(C=64, P=4000, O=20000), "bundle_adjustment"
+    out = []
+    for fin in ("1", "0"):
+        monkeypatch.setenv("THALLO_FIN_IN_KERNEL", fin)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver(dims, thallo_amd.energy_file(name))
+        _, costs = s.solve(dev, profiled=True, nIterations=3, lIterations=25)
+        tr = s.alpha_beta_trace()
+        s.close()
+        out.append((costs, tr))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+
+
 @pytest.mark.parametrize("which", ["sfs", "ba", "iw"])
 def test_lm_device_side_zeta_matches_the_blocking_form(torch, which, monkeypatch):
     """LM without the host in the loop: the zeta test and the early-exit flag live on the device, one read-back per

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/thallo_hip.h"
 
 #define THALLO_WAVE 64
 #define THALLO_MAX_PARTIALS 1024   // upper bound on producer grid size for reduced quantities
@@ -110,6 +111,80 @@ __device__ __forceinline__ float safe_div(float num, float den)
 {
     if (LM) return num / den;
     return den != 0.0f ? num / den : 0.0f;
+}
+
+// End of a single-reduction applyJTJ (alphaD partial + {N, S1, S2}), called by EVERY thread of the workgroup with its private terms: one
+// partial set per workgroup into slot blk_off + blockIdx.x.  With fin.tickets the launch's last workgroup to arrive also finishes the two
+// scalars of the PCG iteration over all fin.nb_total slots -- alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 -- in exactly
+// k_scalars_finish's order (pcg_kernels.hip), so the separate one-wave launch (5-7 us per iteration on the small working sets) is not needed.
+// Tickets: two levels (workgroup b -> group b % 32, each group word on its own 64-byte line: same-address atomics serialise at ~12 ns each);
+// they are zero again when the kernel ends.  red >= 16 floats, redd >= 3 * (blockDim.x / 64) doubles of LDS.
+struct FinArgs {
+    thallo_sum_t alphaN;          // alphaN_k (a one-word sum or partials)
+    unsigned* tickets;            // THALLO_HIP_FIN_TICKET_WORDS zeroed words, or NULL: partials only
+    float *aD_word, *bN_word;
+    int blk_off, nb_total;        // slot offset of this launch's workgroups; slots to add up (>= blk_off + gridDim.x when several launches share the slots)
+};
+__device__ __forceinline__ void block_finish_sums(float acc, const Sums3& sm, float* __restrict__ aD_out, double* __restrict__ s3_out, const FinArgs& fin,
+                                                  float* red, double* redd)
+{
+    typedef unsigned long long u64_t;
+    const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
+    const int nw = (blockDim.x + THALLO_WAVE - 1) / THALLO_WAVE;
+    const float wa = wave_sum_all(acc);
+    const double w0 = wave_sum_all_f64(sm.n), w1 = wave_sum_all_f64(sm.s1), w2 = wave_sum_all_f64(sm.s2);
+    if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
+    __syncthreads();
+    const int slot = fin.blk_off + blockIdx.x;
+    if (threadIdx.x == 0) {
+        float a = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+        for (int w = 0; w < nw; ++w) { a += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
+        if (!fin.tickets) { aD_out[slot] = a; s3_out[3 * slot] = b0; s3_out[3 * slot + 1] = b1; s3_out[3 * slot + 2] = b2; }
+        else {
+            __hip_atomic_store(aD_out + slot, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64_t* sp = reinterpret_cast<u64_t*>(s3_out) + 3 * slot;
+            __hip_atomic_store(sp, (u64_t)__double_as_longlong(b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sp + 1, (u64_t)__double_as_longlong(b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sp + 2, (u64_t)__double_as_longlong(b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned grp = blockIdx.x % 32, members = (gridDim.x - grp + 31) / 32, groups = gridDim.x < 32 ? gridDim.x : 32;
+            unsigned* sub = fin.tickets + 16 + 16 * grp;
+            bool last = false;
+            if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = __hip_atomic_fetch_add(fin.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+            }
+            red[15] = last ? 1.0f : 0.0f;
+        }
+    }
+    if (!fin.tickets) return;
+    __syncthreads();
+    if (red[15] == 0.0f || wave != 0) return;
+    const int nb = fin.nb_total;
+    float t[THALLO_MAX_PARTIALS / THALLO_WAVE];
+#pragma unroll
+    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
+        const int i = lane + k * THALLO_WAVE;
+        t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+    }
+    float ad = 0.0f;
+#pragma unroll
+    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) ad += t[k];
+    ad = wave_sum_all(ad);                                                           // == sum_partials(aD_out, nb) for nb > 1
+    const u64_t* sp = reinterpret_cast<const u64_t*>(s3_out);
+    double n = 0.0, a1 = 0.0, b1 = 0.0;
+    for (int i = lane; i < nb; i += THALLO_WAVE) {
+        n  += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        a1 += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b1 += __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    n = wave_sum_all_f64(n); a1 = wave_sum_all_f64(a1); b1 = wave_sum_all_f64(b1);
+    const float an = sum_partials(fin.alphaN.partials, fin.alphaN.count);
+    if (lane == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float al = safe_div<false>(an, ad);
+    double bn = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
+    if (!(bn > 0.0)) bn = 0.0;
+    if (lane == 0) { fin.aD_word[0] = ad; fin.bN_word[0] = (float)bn; }
 }
 
 // guardedInvert, CERES flavour (gauss_newton.t:638-648)

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
 __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __restrict__ pt_ptr, const float2* __restrict__ JP, const float2* __restrict__ JpP,
                                                const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ part_out,
                                                const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
-                                               const unsigned* __restrict__ gate)
-{
+                                               const unsigned* __restrict__ gate, FinArgs fin)
+{   // part_out / s3_out: the slot arrays of the whole applyJTJ (k_cam2 filled slots [0, fin.blk_off)); this launch's workgroups use the slots behind them
     __shared__ float red[16];
     __shared__ double redd[3 * BLOCK / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __rest
         acc += p[i] * s0 + p[i + 1] * s1 + p[i + 2] * s2;
         if (s3_out) { sm.add(prs[i], rs[i], s0); sm.add(prs[i + 1], rs[i + 1], s1); sm.add(prs[i + 2], rs[i + 2], s2); }
     }
-    block_store_partial(acc, part_out, red);
-    if (s3_out) block_store_sums3(sm, s3_out, redd);
+    if (s3_out) block_finish_sums(acc, sm, part_out, s3_out, fin, red, redd);
+    else block_store_partial(acc, part_out + fin.blk_off, red);
 }
 
 inline void gather_shape(int C_, int P_, int& cam_blocks, int& grid)
@@ -410,17 +410,26 @@ int thallo_hip_ba_pack_point_blocks(int O_, const float* Jb, const int* q_ptk, f
     return check_launch();
 }
 
+int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
+                                 const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
+                                 const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream)
+{
+    if (!cam_ptr || !q_pt || !q_ptk || !pt_ptr || !Jb || !JP || !JpP || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
+    if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
+    if (fin.tickets && (!s3_out || gate || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
+    int cb, grid; gather_shape(C_, P_, cb, grid);
+    // the camera launch fills slots [0, cb); the point launch the rest, and (fin) its last workgroup adds up all `grid` of them
+    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, q_ptk, (const float4*)Jb, p, Ap, (float2*)JpP, aD_out, r, pre, s3_out, gate);
+    hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, (const float2*)JP, (const float2*)JpP, p, Ap, aD_out, r, pre,
+                       s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid });
+    int e = check_launch(); return e ? e : grid;
+}
 int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
                              const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
                              const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_stream_t stream)
 {
-    if (!cam_ptr || !q_pt || !q_ptk || !pt_ptr || !Jb || !JP || !JpP || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
-    if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
-    int cb, grid; gather_shape(C_, P_, cb, grid);
-    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, q_ptk, (const float4*)Jb, p, Ap, (float2*)JpP, aD_out, r, pre, s3_out, gate);
-    hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, (const float2*)JP, (const float2*)JpP, p, Ap, aD_out + cb, r, pre,
-                       s3_out ? s3_out + 3 * cb : nullptr, gate);
-    int e = check_launch(); return e ? e : grid;
+    const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+    return thallo_hip_ba_apply_jtj2_fin(C_, P_, cam_ptr, q_pt, q_ptk, pt_ptr, Jb, JP, JpP, p, Ap, aD_out, r, pre, s3_out, gate, none, stream);
 }
 
 }  // extern "C"

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, con
                                                        const int* __restrict__ in_ptr, const int* __restrict__ in_edge, const int* __restrict__ in_src,
                                                        const float* __restrict__ Cn, const float* __restrict__ G, float wf, float wr,
                                                        const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out, ELay L,
-                                                       const float* __restrict__ rs, const float* __restrict__ pre, double* __restrict__ s3_out)
+                                                       const float* __restrict__ rs, const float* __restrict__ pre, double* __restrict__ s3_out, FinArgs fin)
 {   // rs / pre / s3_out (all or none): also the Sums3 of the single-reduction PCG form over the unknowns of [n0,n1)
     __shared__ float red[16];
     __shared__ double redd[3 * BLOCK / 64];
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, con
             sm.add(ma.x, ra.x, aa.x); sm.add(ma.y, ra.y, aa.y); sm.add(ma.z, ra.z, aa.z);
         }
     }
-    block_store_partial(acc, aD_out, red);
-    if (s3_out) block_store_sums3(sm, s3_out, redd);
+    if (s3_out) block_finish_sums(acc, sm, aD_out, s3_out, fin, red, redd);
+    else block_store_partial(acc, aD_out, red);
 }
 
 }  // namespace
@@ -374,18 +374,28 @@ int thallo_hip_arap_apply_jtj(int N, int n0, int n1, const int* out_ptr, const i
     if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0) return -(int)hipErrorInvalidValue;
     const ELay L = { ell_stride, N };
     const int grid = vgrid(n1 - n0);
-    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, (const float*)nullptr, (const float*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, (const float*)nullptr, (const float*)nullptr, (double*)nullptr, FinArgs{});
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_arap_apply_jtj_sums_fin(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
+                                       const float* constraints, const float* G, float w_fit, float w_reg,
+                                       const float* p, float* Ap, float* aD_out, long ell_stride, const float* r, const float* pre, double* s3_out,
+                                       thallo_fin_t fin, thallo_stream_t stream)
+{
+    if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0 || !r || !pre || !s3_out) return -(int)hipErrorInvalidValue;
+    if (fin.tickets && (!fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
+    const ELay L = { ell_stride, N };
+    const int grid = vgrid(n1 - n0);
+    const FinArgs f = { fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, grid };
+    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_apply_jtj_sums(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                                    const float* constraints, const float* G, float w_fit, float w_reg,
                                    const float* p, float* Ap, float* aD_out, long ell_stride, const float* r, const float* pre, double* s3_out, thallo_stream_t stream)
 {
-    if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0 || !r || !pre || !s3_out) return -(int)hipErrorInvalidValue;
-    const ELay L = { ell_stride, N };
-    const int grid = vgrid(n1 - n0);
-    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out);
-    int e = check_launch(); return e ? e : grid;
+    const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+    return thallo_hip_arap_apply_jtj_sums_fin(N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, ell_stride, r, pre, s3_out, none, stream);
 }
 
 }  // extern "C"

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
                                                  const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
                                                  float* __restrict__ out, float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta,
                                                  float* __restrict__ part_out, const float* __restrict__ rs, double* __restrict__ s3_out,
-                                                 const unsigned* __restrict__ gate)
+                                                 const unsigned* __restrict__ gate, FinArgs fin)
 {
     __shared__ FusedTile T;
     __shared__ float red[16];
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
         }
         __syncthreads();
     }
-    block_store_partial(acc, part_out, red);
-    if (MODE == 1 && s3_out) block_store_sums3(sm, s3_out, redd);
+    if (MODE == 1 && s3_out) block_finish_sums(acc, sm, part_out, s3_out, fin, red, redd);
+    else block_store_partial(acc, part_out, red);
 }
 
 // raw diag(J^T J) (LM only): enumerate the rows that contain X(i)
@@ -438,7 +438,7 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
     if (sfs_fused()) {
         const int gridf = fused_grid(W, row1 - row0);
         hipLaunchKernelGGL(k_fused<0>, dim3(gridf), dim3(BLOCK), 0, s, g, cm, X, D, (const float4*)G, (const float2*)Wt, fl, r, z, p_prev, delta, aN_out,
-                           (const float*)nullptr, (double*)nullptr, (const unsigned*)nullptr);
+                           (const float*)nullptr, (double*)nullptr, (const unsigned*)nullptr, FinArgs{});
         if (diag_out) hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
         int e = check_launch(); return e ? e : gridf;
     }
@@ -449,7 +449,8 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
 }
 
 static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
-                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate = nullptr);
+                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate = nullptr,
+                     thallo_fin_t fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr });
 
 int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
@@ -459,19 +460,25 @@ int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, in
                                   float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream)
 { if (!r || !s3_out) return -(int)hipErrorInvalidValue; return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, r, s3_out, stream); }
 
+int thallo_hip_sfs_apply_jtj_sums_fin(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                      float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_fin_t fin, thallo_stream_t stream)
+{ if (!r || !s3_out) return -(int)hipErrorInvalidValue; return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, r, s3_out, stream, nullptr, fin); }
+
 int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                    float* U, float* R, const float* p, float* Ap, float* aD_out, const unsigned* gate, thallo_stream_t stream)
 { return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream, gate); }
 
 static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
-                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate)
+                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate, thallo_fin_t fin)
 {
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
+    if (fin.tickets && (!s3_out || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
     if (sfs_fused()) {
         const int gridf = fused_grid(W, row1 - row0);
         hipLaunchKernelGGL(k_fused<1>, dim3(gridf), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), p, (const float*)nullptr, (const float4*)G, (const float2*)Wt, fl,
-                           Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out, r, s3_out, gate);
+                           Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out, r, s3_out, gate,
+                           FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridf });
         int e = check_launch(); return e ? e : gridf;
     }
     const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
@@ -480,7 +487,9 @@ static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const f
     hipLaunchKernelGGL(k_rows<false>, dim3(gridr), dim3(BLOCK), 0, s, gr, cm, p, (const float4*)G, (const float2*)Wt, fl, (float2*)U, R);
     hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, s, g, cm, p, (const float*)nullptr, (const float4*)G, (const float2*)U, (const float*)R, fl,
                        Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out, r, s3_out);
-    int e = check_launch(); return e ? e : grid;
+    int e = check_launch(); if (e) return e;
+    if (fin.tickets && (e = thallo_hip_pcg_scalars_finish(aD_out, s3_out, grid, fin.alphaN, fin.alphaD_word, fin.betaN_word, stream)) < 0) return e;      // (A/B path: the words by a launch of their own)
+    return grid;
 }
 
 }  // extern "C"

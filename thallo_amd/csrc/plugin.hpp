@@ -100,7 +100,8 @@ public:
     // Single-reduction form for gather energies (thallo_hip.h "single-reduction PCG form"): applyJTJ that also writes the three double
     // sums over the unknowns (r = v.r, M^-1 = v.pre or 1) into v.s12; the driver then runs pcg_update + this + scalars_finish per iteration.
     virtual bool apply_returns_sums() const { return false; }
-    virtual int apply_jtj_sums(LaunchCtx&, SolverVectors&, const float* /*p*/, float* /*Ap*/, float* /*alphaD_out*/) { return -1; }
+    // fin.tickets != NULL: the two scalar words of the iteration are finished too (by the kernel's last workgroup; no PCGScalars launch)
+    virtual int apply_jtj_sums(LaunchCtx&, SolverVectors&, const float* /*p*/, float* /*Ap*/, float* /*alphaD_out*/, const thallo_fin_t& /*fin*/) { return -1; }
     // One kernel per PCG iteration (thallo_hip.h thallo_hip_iw_pcg_iter): reads r/Ap/p[cur], writes r/Ap/p[cur^1], alphaD partials
     // to alphaD_out and the double sums to v.s12; pcg_iter_finish turns them into the two scalar words of the iteration.
     virtual bool one_kernel_iteration() const { return false; }

@@ -436,11 +436,11 @@ public:
                                          constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
     }
     bool apply_returns_sums() const override { return true; }
-    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override
+    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj_sums(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
-                                              constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, v.r, v.pre, v.s12, c.stream);
+        return thallo_hip_arap_apply_jtj_sums_fin(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+                                                  constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, v.r, v.pre, v.s12, fin, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
@@ -459,11 +459,11 @@ class BundleAdjustmentPlugin : public EnergyPlugin {
     DeviceBuffer cam_ptr, cam_obs, q_cam, q_pt, pt_ptr, pt_pos, Jb, F;
     DeviceBuffer q_ptk, JP, JpP;          // J^T (J p) with J p formed once (thallo_hip_ba_apply_jtj2): point-order position per observation, packed point blocks, J p
     bool once_ = true;                     // THALLO_BA_JP_ONCE=0: the one-kernel gather that forms J p on both sides (A/B switch)
-    int apply2(LaunchCtx& c, SolverVectors* v, const float* p, float* Ap, float* out)
+    int apply2(LaunchCtx& c, SolverVectors* v, const float* p, float* Ap, float* out, const thallo_fin_t& fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr })
     {
-        return thallo_hip_ba_apply_jtj2(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)q_ptk.ptr, (const int*)pt_ptr.ptr,
-                                        (const float*)Jb.ptr, (const float*)JP.ptr, (float*)JpP.ptr, p, Ap, out,
-                                        v ? v->r : nullptr, v ? v->pre : nullptr, v ? v->s12 : nullptr, c.gate, c.stream);
+        return thallo_hip_ba_apply_jtj2_fin(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)q_ptk.ptr, (const int*)pt_ptr.ptr,
+                                            (const float*)Jb.ptr, (const float*)JP.ptr, (float*)JpP.ptr, p, Ap, out,
+                                            v ? v->r : nullptr, v ? v->pre : nullptr, v ? v->s12 : nullptr, c.gate, fin, c.stream);
     }
 public:
     BundleAdjustmentPlugin(const unsigned* dims) : C((int)dims[0]), P((int)dims[1]), O((int)dims[2])
@@ -526,12 +526,15 @@ public:
                                        (const float*)Jb.ptr, p, Ap, out, c.stream);
     }
     bool apply_returns_sums() const override { return true; }
-    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override
+    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
         TimedLaunch t(c, "PCGStep1");
-        if (once_) return apply2(c, &v, p, Ap, out);
-        return thallo_hip_ba_apply_jtj_sums(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
-                                            (const float*)Jb.ptr, p, Ap, out, v.r, v.pre, v.s12, c.stream);
+        if (once_) return apply2(c, &v, p, Ap, out, fin);
+        const int nb = thallo_hip_ba_apply_jtj_sums(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
+                                                    (const float*)Jb.ptr, p, Ap, out, v.r, v.pre, v.s12, c.stream);
+        if (nb < 0 || !fin.tickets) return nb;            // (A/B path: the two words by a launch of their own)
+        const int rc = thallo_hip_pcg_scalars_finish(out, v.s12, nb, fin.alphaN, fin.alphaD_word, fin.betaN_word, c.stream);
+        return rc < 0 ? rc : nb;
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
@@ -591,11 +594,11 @@ public:
                                               c.gate, c.stream);
     }
     bool apply_returns_sums() const override { return true; }
-    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out) override
+    int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_sfs_apply_jtj_sums(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
-                                             v.r, v.s12, c.stream);
+        return thallo_hip_sfs_apply_jtj_sums_fin(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
+                                                 v.r, v.s12, fin, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {

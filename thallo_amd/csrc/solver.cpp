@@ -432,10 +432,12 @@ int Plan::step_gn_expanded(int ev_iter)
                                       sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return 0; }
         }
         cur_ ^= 1;
-        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD));
+        // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the applyJTJ kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
+        const thallo_fin_t fin = { sum(jN), fin_in_kernel_ ? v_.fin_tickets : nullptr, scal(jD), scal(jB) };
+        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), fin);
         if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
         set_nb(jD, nb);
-        {   // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2
+        if (!fin_in_kernel_) {
             TimedLaunch t(ctx, "PCGScalars");
             if (thallo_hip_pcg_scalars_finish(slot(jD), v_.s12, nb, sum(jN), scal(jD), scal(jB), s) < 0) { set_error("PCGScalars launch failed"); return 0; }
         }
@@ -453,11 +455,10 @@ int Plan::step_gn_expanded(int ev_iter)
 }
 
 int Plan::ensure_sums_buffer()
-{
-    if (v_.s12) return 0;
-    DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b);
-    if (b->alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double))) return -1;
-    v_.s12 = (double*)b->ptr;
+{   // per-workgroup double sums + the arrival tickets of the in-kernel finish
+    auto get = [&](size_t bytes) -> void* { DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b); return b->alloc(bytes) ? nullptr : b->ptr; };
+    if (!v_.s12 && !(v_.s12 = (double*)get((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double)))) return -1;
+    if (!v_.fin_tickets && !(v_.fin_tickets = (unsigned*)get(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned)))) return -1;
     return 0;
 }
 
@@ -467,7 +468,6 @@ int Plan::ensure_iter_buffers()
     auto get = [&](size_t bytes) -> void* { DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b); return b->alloc(bytes) ? nullptr : b->ptr; };
     if (!v_.r2 && !(v_.r2 = (float*)get((size_t)v_.n_alloc * sizeof(float)))) return -1;            // (a row slab's r' / Ap' live in its exchange block)
     if (!v_.Ap2 && !(v_.Ap2 = (float*)get((size_t)v_.n_alloc * sizeof(float)))) return -1;
-    if (!v_.fin_tickets && !(v_.fin_tickets = (unsigned*)get(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned)))) return -1;
     return 0;
 }
 

@@ -74,6 +74,24 @@ def test_generated_kernels_compile_for_gfx950(energy, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
+def test_wave_aggregated_scatter_is_chosen_per_access(tmp_path):
+    """An unknown access whose index does not vary with the innermost iteration dimension scatters through the wave-aggregated add (the reference's
+    get_peers / reduce_peers case, thallo.t:3349-3399); every other access keeps the plain atomic.  The unit compiles for gfx950."""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "energies", "row_gain.t")
+    src = _text(f, 1)
+    fit = src[src.index("void jtj_0"):src.index("void applyj_0")]
+    assert "scatter_add<true>(Ap" in fit and "scatter_add<false>" not in fit
+    reg = src[src.index("void jtj_1"):src.index("void applyj_1")]          # residual over H alone: nothing to aggregate
+    assert "scatter_add<" not in reg and "atomicAdd(Ap" in reg
+    iw = _text(thallo_amd.energy_file("image_warping"), 1)                 # every access involves x
+    assert "scatter_add<true>" not in iw[iw.index("void jtj_0"):]
+    out = tmp_path / "row_gain.hip"
+    out.write_text(src)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-munsafe-fp-atomics", "-c", str(out), "-o", str(tmp_path / "o.o")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 REF = "/root/reference"
 REF_EXAMPLES = ["examples/image_warping/image_warping.t", "examples/arap_mesh_deformation/arap_mesh_deformation.t",
                 "examples/shape_from_shading/shape_from_shading.t", "examples/bundle_adjustment/bundle_adjustment.t",

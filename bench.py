@@ -256,6 +256,8 @@ def main():
         res = orc.cpu_port_image_warping(W, H, q, 1, sample_l, want_costs=False)
         out["cpu_baseline"] = {"value": sample_l / res["seconds_pcg"], "unit": "PCG iterations/s", "cores": res["threads"],
                                "kind": "port", "ms_per_gn_iter": res["seconds_total"] * 1e3,
+                               "placement": ("one thread pinned per CPU (sched_setaffinity), vectors first-touched by their threads" if res.get("pinned")
+                                             else "threads not pinned (sched_setaffinity refused)"),
                                "note": "baseline only (an OpenMP restatement, not a tuned CPU solver); the GPU / CPU ratio says nothing about kernel quality",
                                "sample": f"1 GN step x {sample_l} PCG iterations of the same {W}x{H} instance, OpenMP port of the "
                                          "reference algorithm (oracle/cpu_port_image_warping.c)"}

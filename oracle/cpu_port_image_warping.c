@@ -8,7 +8,9 @@
  * gauss_newton.t:678-752,801-843,889-906 with the energy of image_warping.t:17-31 in gather
  * (unknown-wise) form, float32, dot products accumulated in double -- threaded over image rows.
  */
+#define _GNU_SOURCE
 #include <math.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
@@ -145,15 +147,48 @@ int orc_cpu_port_image_warping(int W, int H, float* O, float* A, const float* U,
     return orc_cpu_port_image_warping2(W, H, O, A, U, C, M, w_fit, w_reg, nIterations, lIterations, costs, seconds_pcg, seconds_total, 0, 0);
 }
 
+/* Thread placement for the baseline measurement: thread t of the team is pinned to the t-th CPU this process may run on (explicit
+ * sched_setaffinity -- OMP_PROC_BIND is read when libgomp is loaded, which in bench.py happened long before), and every vector is FIRST TOUCHED by
+ * the thread that will stream it (static schedule, same partition as the PCG loops), so that on a multi-socket host the pages sit next to their
+ * threads.  pin = 0 undoes the pinning. */
+static int g_pinned = 0;
+static void pin_threads(int pin)
+{
+    cpu_set_t all; CPU_ZERO(&all);
+    if (sched_getaffinity(0, sizeof(all), &all) != 0) return;
+    int cpus[CPU_SETSIZE], nc = 0;
+    for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &all)) cpus[nc++] = c;
+    if (nc == 0) return;
+    int ok = 1;
+#pragma omp parallel reduction(&&:ok)
+    {
+        cpu_set_t one;
+        if (pin) { CPU_ZERO(&one); CPU_SET(cpus[omp_get_thread_num() % nc], &one); } else one = all;
+        ok = sched_setaffinity(0, sizeof(one), &one) == 0;
+    }
+    g_pinned = pin && ok;
+}
+int orc_cpu_port_threads_pinned(void) { return g_pinned; }
+static float* alloc_touch(long n, const float* src)
+{
+    float* v = malloc((size_t)n * sizeof(float));
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) v[i] = src ? src[i] : 0.0f;
+    return v;
+}
+
 /* ... and (ab_trace != NULL) alpha_k, beta_k of the first trace_cap PCG iterations overall: ab_trace[2j], ab_trace[2j+1] */
-int orc_cpu_port_image_warping2(int W, int H, float* O, float* A, const float* U, const float* C, const float* M,
+int orc_cpu_port_image_warping2(int W, int H, float* O_io, float* A_io, const float* U_in, const float* C_in, const float* M_in,
                                 float w_fit, float w_reg, int nIterations, int lIterations,
                                 double* costs, double* seconds_pcg, double* seconds_total, float* ab_trace, int trace_cap)
 {
-    IW q; q.W = W; q.H = H; q.N = (long)W * H; q.U = U; q.C = C; q.M = M; q.wf = w_fit; q.wr = w_reg;
-    const long N = q.N, n = 3 * N;
-    q.cs = malloc(N * 8); q.fl = malloc(N);
-    float *r = malloc(n * 4), *pre = malloc(n * 4), *p = malloc(n * 4), *delta = malloc(n * 4), *Ap = malloc(n * 4), *z = malloc(n * 4);
+    const long N = (long)W * H, n = 3 * N;
+    pin_threads(1);
+    float *O = alloc_touch(2 * N, O_io), *A = alloc_touch(N, A_io);
+    float *U = alloc_touch(2 * N, U_in), *C = alloc_touch(2 * N, C_in), *M = alloc_touch(N, M_in);
+    IW q; q.W = W; q.H = H; q.N = N; q.U = U; q.C = C; q.M = M; q.wf = w_fit; q.wr = w_reg;
+    q.cs = alloc_touch(2 * N, 0); q.fl = malloc(N);
+    float *r = alloc_touch(n, 0), *pre = alloc_touch(n, 0), *p = alloc_touch(n, 0), *delta = alloc_touch(n, 0), *Ap = alloc_touch(n, 0), *z = alloc_touch(n, 0);
     double t_pcg = 0.0; const double t0 = omp_get_wtime();
     if (costs) costs[0] = (float)iw_cost(&q, O, A);
     for (int it = 0; it < nIterations; ++it) {
@@ -185,6 +220,11 @@ int orc_cpu_port_image_warping2(int W, int H, float* O, float* A, const float* U
     }
     if (seconds_pcg) *seconds_pcg = t_pcg;
     if (seconds_total) *seconds_total = omp_get_wtime() - t0;
-    free(q.cs); free(q.fl); free(r); free(pre); free(p); free(delta); free(Ap); free(z);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; ++i) { O_io[2 * i] = O[2 * i]; O_io[2 * i + 1] = O[2 * i + 1]; A_io[i] = A[i]; }
+    free(q.cs); free(q.fl); free(r); free(pre); free(p); free(delta); free(Ap); free(z); free(O); free(A); free(U); free(C); free(M);
+    const int pinned = g_pinned;
+    pin_threads(0);
+    g_pinned = pinned;                    /* what the run that just ended had */
     return omp_get_max_threads();
 }

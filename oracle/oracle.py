@@ -175,7 +175,9 @@ def cpu_port_image_warping(W, H, params, nIterations, lIterations, want_costs=Tr
                                        params[3].ctypes.data, params[4].ctypes.data, float(params[5]), float(params[6]),
                                        nIterations, lIterations, costs.ctypes.data if want_costs else None, C.byref(tp), C.byref(tt),
                                        trace.ctypes.data if want_trace else None, ntr)
-    out = {"costs": costs if want_costs else None, "seconds_pcg": tp.value, "seconds_total": tt.value, "threads": th}
+    L.orc_cpu_port_threads_pinned.restype = C.c_int
+    out = {"costs": costs if want_costs else None, "seconds_pcg": tp.value, "seconds_total": tt.value, "threads": th,
+           "pinned": bool(L.orc_cpu_port_threads_pinned())}
     if want_trace:
         out["trace"] = trace[:ntr]
     return out

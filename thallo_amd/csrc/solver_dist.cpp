@@ -222,9 +222,12 @@ int Plan::dist_gn(int L, bool p2p)
         if (D.bot && hipMemcpyAsync(flags + (long)W * D.row1, (const unsigned char*)(gath + (rank + 1) * D.msg + 1 + 12L * W), W, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
     }
     if (p2p && thallo_hip_dist_begin_step(D.d, s) < 0) return -1;        // seq += 1: this GN step's granules
+    // delta += alpha p every iteration on the device-side transport: its "apply two" kernel variant (peer stores on top of 256 VGPRs) spills, and at
+    // slab sizes the 6 B/pixel it would save do not matter (2048x256: 22.6 vs 24.3 us per iteration); same bits either way (tested)
+    const bool batch = batch_delta_ && !p2p;
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        const int mode = THALLO_IW_STEP1_MODE(k, 1);
+        const int mode = THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
         const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
         if (p2p) {        // the kernel stores its boundary rows of Ap_out into the neighbours' ghost rows and its last workgroup IS the exchange
             nb = plugin->pcg_iter_dist(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, D.d_iter[cur_ ^ 1], slot(jD), 7 * k, scal(jD), scal(jB));
@@ -244,7 +247,7 @@ int Plan::dist_gn(int L, bool p2p)
         cur_ ^= 1;
     }
     last_l_iters = L;
-    linear_update_tail(L, true);                                         // owned rows only
+    linear_update_tail(L, batch);                                        // owned rows only
     {   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
         TimedLaunch t(ctx, "SlabExchangeUnknowns");
         const auto& imgs = plugin->unknown_images();

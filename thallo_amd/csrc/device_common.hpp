@@ -113,6 +113,51 @@ __device__ __forceinline__ float safe_div(float num, float den)
     return den != 0.0f ? num / den : 0.0f;
 }
 
+// The sums of one PCG iteration as the LAST workgroup of the producing launch reads them back (one wave, every lane gets the totals): the slots were
+// written by other workgroups of the same launch (write-through, agent scope), so they are read with agent-scope loads.  Everything that can be in
+// flight together is issued before the first addition -- the <= 16 float slots of a lane, its first four {N, S1, S2} slots and alphaN -- because this
+// read-back sits on the critical path between two dependent launches; the additions keep k_scalars_finish's order (absent slots add +0.0).
+struct IterationSums { float ad, an; double n, s1, s2; };
+__device__ __forceinline__ IterationSums load_iteration_sums(const float* aD_out, const double* s3_out, int nb, thallo_sum_t aN)
+{
+    typedef unsigned long long u64_t;
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    const u64_t* sp = reinterpret_cast<const u64_t*>(s3_out);
+    float t[THALLO_MAX_PARTIALS / THALLO_WAVE];
+#pragma unroll
+    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
+        const int i = lane + k * THALLO_WAVE;
+        t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+    }
+    auto load4 = [&](int i0, double (&v)[4][3]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * THALLO_WAVE;
+            const bool ok = i < nb;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[u][q] = ok ? __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+        }
+    };
+    double v[4][3];
+    load4(lane, v);
+    IterationSums S;
+    S.an = sum_partials(aN.partials, aN.count);
+    float ad = 0.0f;
+#pragma unroll
+    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) ad += t[k];
+    S.ad = wave_sum_all(ad);                                                         // == sum_partials(aD_out, nb) for nb > 1
+    double n = 0.0, a1 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { n += v[u][0]; a1 += v[u][1]; b1 += v[u][2]; }
+    for (int i0 = lane + 4 * THALLO_WAVE; i0 < nb; i0 += 4 * THALLO_WAVE) {          // more than 256 slots: four per lane and round, 12 loads in flight
+        load4(i0, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { n += v[u][0]; a1 += v[u][1]; b1 += v[u][2]; }
+    }
+    S.n = wave_sum_all_f64(n); S.s1 = wave_sum_all_f64(a1); S.s2 = wave_sum_all_f64(b1);
+    return S;
+}
+
 // End of a single-reduction applyJTJ (alphaD partial + {N, S1, S2}), called by EVERY thread of the workgroup with its private terms: one
 // partial set per workgroup into slot blk_off + blockIdx.x.  With fin.tickets the launch's last workgroup to arrive also finishes the two
 // scalars of the PCG iteration over all fin.nb_total slots -- alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 -- in exactly
@@ -160,35 +205,8 @@ __device__ __forceinline__ void block_finish_sums(float acc, const Sums3& sm, fl
     if (!fin.tickets) return;
     __syncthreads();
     if (red[15] == 0.0f || wave != 0) return;
-    const int nb = fin.nb_total;
-    float t[THALLO_MAX_PARTIALS / THALLO_WAVE];
-#pragma unroll
-    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
-        const int i = lane + k * THALLO_WAVE;
-        t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-    }
-    float ad = 0.0f;
-#pragma unroll
-    for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) ad += t[k];
-    ad = wave_sum_all(ad);                                                           // == sum_partials(aD_out, nb) for nb > 1
-    const u64_t* sp = reinterpret_cast<const u64_t*>(s3_out);
-    double n = 0.0, a1 = 0.0, b1 = 0.0;
-    // four slots per lane and round: their 12 loads are in flight together (a rolled loop pays one L2 round trip per slot: 16 in a row at 1024
-    // workgroups); the additions stay in index order, so the value is that of the plain loop (absent slots add +0.0)
-    for (int i0 = lane; i0 < nb; i0 += 4 * THALLO_WAVE) {
-        double v[4][3];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * THALLO_WAVE;
-            const bool ok = i < nb;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) v[u][q] = ok ? __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { n += v[u][0]; a1 += v[u][1]; b1 += v[u][2]; }
-    }
-    n = wave_sum_all_f64(n); a1 = wave_sum_all_f64(a1); b1 = wave_sum_all_f64(b1);
-    const float an = sum_partials(fin.alphaN.partials, fin.alphaN.count);
+    const IterationSums S = load_iteration_sums(aD_out, s3_out, fin.nb_total, fin.alphaN);
+    const float ad = S.ad, an = S.an; const double n = S.n, a1 = S.s1, b1 = S.s2;
     if (lane == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float al = safe_div<false>(an, ad);
     double bn = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;

@@ -74,36 +74,8 @@ __device__ __forceinline__ void iter_tail(float acc, double s0, double s1, doubl
     if (fin_tickets) {
         __syncthreads();
         if (red[15] != 0.0f && wave == 0) {
-            typedef unsigned long long u64_t;
-            const int nb = gridDim.x;
-            float t[THALLO_MAX_PARTIALS / THALLO_WAVE];
-#pragma unroll
-            for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
-                const int i = lane + k * THALLO_WAVE;
-                t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-            }
-            float ad = 0.0f;
-#pragma unroll
-            for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) ad += t[k];
-            ad = wave_sum_all(ad);                                                   // == sum_partials(aD_out, nb)
-            const u64_t* sp = reinterpret_cast<const u64_t*>(s12_out);
-            double n = 0.0, a1 = 0.0, b1 = 0.0;
-            // four slots per lane and round: their 12 loads are in flight together (a rolled loop pays one L2 round trip per slot: 16 in a row at 1024
-            // workgroups); the additions stay in index order, so the value is that of the plain loop (absent slots add +0.0)
-            for (int i0 = lane; i0 < nb; i0 += 4 * THALLO_WAVE) {
-                double v[4][3];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * THALLO_WAVE;
-                    const bool ok = i < nb;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) v[u][q] = ok ? __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { n += v[u][0]; a1 += v[u][1]; b1 += v[u][2]; }
-            }
-            n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
-            const float an = sum_partials(bNp.partials, bNp.count);                  // alphaN_k (= betaN_{k-1}; alphaN_0 for the first iteration)
+            const IterationSums S = load_iteration_sums(aD_out, s12_out, gridDim.x, bNp);          // bNp = alphaN_k (= betaN_{k-1}; alphaN_0 for the first iteration)
+            const float ad = S.ad, an = S.an; const double n = S.n, a1 = S.s1, b1 = S.s2;
             if (lane == 0) __hip_atomic_store(fin_tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (DIST) {     // multi-GPU: the same wave is the exchange (every wave drained its remote Ap rows -- s_waitcnt vmcnt(0) -- before the barrier in front of its workgroup's ticket)
                 dist_exchange_iter_wave(*dd, xslot, ad, n, a1, b1, an, aD_word, bN_word);

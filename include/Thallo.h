@@ -143,17 +143,21 @@ int ThalloX_FrontendText(const char* filename, int what, char* out, int cap);
  *   - when device_exchange != 0 and the self-check at the first Init passes on this topology: no host-visible collective at all -- the
  *     kernel stores its scalars into every rank's mailbox and its boundary rows into the neighbours' ghost rows over xGMI
  *     (hipIpc-mapped fine-grained memory) and its last workgroup waits for the peers' granules.
- * Supported: image_warping with UrShape on the unit pixel grid, W % 4 == 0, Gauss-Newton.  Everything else returns an error.
+ * Supported: image_warping (one ghost row per neighbour; UrShape on the unit pixel grid, W % 4 == 0; Gauss-Newton; both transports) and
+ * shape_from_shading (TWO ghost rows per neighbour; Gauss-Newton and ThalloX_EnableLM; all-gather transport: per PCG iteration one exchange
+ * in the GN form, two -- alphaD, then betaN + q + the ghost rows of z -- in the LM form).  Everything else returns an error.
  * ------------------------------------------------------------------------------------------ */
 /* Every rank contributes `bytes_per_rank` bytes at `send` and receives world * bytes_per_rank at `recv`, rank order; DEVICE pointers;
  * enqueued on `stream` (a hipStream_t).  Return 0 on success.  world == 1: may be NULL. */
 typedef int (*ThalloX_AllGatherFn)(void* user, const void* send, void* recv, long bytes_per_rank, void* stream);
 typedef struct ThalloX_Distributed {
     int rank, world;                 /* world <= 8 (THALLO_DIST_MAX_WORLD) */
-    unsigned int row0, row1;         /* owned rows [row0, row1) of the local image; a ghost row above iff row0 == 1, below iff row1 == H_local - 1 */
+    unsigned int row0, row1;         /* owned rows [row0, row1) of the local image; g ghost rows above iff row0 == g, below iff row1 == H_local - g (g = 1 or 2, see below) */
     ThalloX_AllGatherFn allgather;
     void* user;
     int device_exchange;             /* 1: try the mailbox / peer-to-peer exchange (falls back to the all-gather if its self-check fails) */
+    unsigned int global_row0;        /* global index of the local image's row 0 (ghost rows included) and the global image height: energies */
+    unsigned int global_rows;        /* whose expressions use pixel coordinates (shape_from_shading) need them; 0 0 = not given */
 } ThalloX_Distributed;
 /* Collective.  0 on success, -1 on error (ThalloX_LastError); every rank gets the same answer. */
 int ThalloX_PlanSetDistributed(Thallo_Plan* plan, const ThalloX_Distributed* cfg);

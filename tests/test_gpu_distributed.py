@@ -257,40 +257,86 @@ def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
         assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
 
 
-# ------------------------------------------------------------------ shape_from_shading row slabs (2 ghost rows)
-def _sfs_worker(rank, world, port, W, H, nit, lit, q):
+# ------------------------------------------------------------------ shape_from_shading row slabs (2 ghost rows), behind Thallo_ProblemStep
+def _sfs_worker(rank, world, port, W, H, nit, lit, lm, q):
     import torch
     import torch.distributed as dist
     from thallo_amd import synthetic as syn
-    from thallo_amd.distributed_sfs import make_hip_sfs_solver
+    from thallo_amd.distributed_sfs import PlanSfsSlabSolver
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.shape_from_shading(W, H)
-        solver, lay = make_hip_sfs_solver(p, W, H, rank, world, lit)
-        costs = solver.solve(nit, lit)
-        be = solver.be
-        q.put((rank, costs, lay.g0, lay.g1, be.X.view(be.Hl, W)[lay.row0:lay.row1].cpu().numpy()))
+        solver = PlanSfsSlabSolver(p, W, H, rank, world, lit, lm=lm)
+        extra = {"q_tolerance": 0.05} if lm else {}             # (LM: large enough that the device-side zeta test ends some PCG loops early)
+        costs = solver.solve(nit, **extra)
+        lay = solver.lay
+        q.put((rank, costs, lay.g0, lay.g1, solver.owned(), solver.solver.distributed_info()))
+        solver.solver.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,H,nit,lit", [(2, 64, 64, 4, 10), (3, 128, 112, 3, 10), (1, 64, 48, 3, 10)])
-def test_hip_sfs_slabs_match_oracle(orc, world, W, H, nit, lit):
+def _run_sfs(world, W, H, nit, lit, lm):
     import torch.multiprocessing as mp
-    from thallo_amd import synthetic as syn
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sfs_worker, args=(r, world, port, W, H, nit, lit, q)) for r in range(world)]
+    procs = [ctx.Process(target=_sfs_worker, args=(r, world, port, W, H, nit, lit, lm, q)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = _collect(q, procs, world)
+    res.sort(key=lambda t: t[0])
+    return res
+
+
+@pytest.mark.parametrize("world,W,H,nit,lit", [(2, 64, 64, 4, 10), (3, 128, 112, 3, 10), (1, 64, 48, 3, 10)])
+def test_hip_sfs_slabs_match_oracle(orc, world, W, H, nit, lit):
+    """Gauss-Newton, single-reduction form: one all-gather per PCG iteration."""
+    from thallo_amd import synthetic as syn
+    res = _run_sfs(world, W, H, nit, lit, False)
     p = syn.shape_from_shading(W, H)
     co, _ = orc.Problem(orc.SFS, (W, H), p).solve(nIterations=nit, lIterations=lit)
-    res.sort(key=lambda t: t[0])
-    for rank, costs, g0, g1, X in res:
+    for rank, costs, g0, g1, X, info in res:
+        assert info["exchange"] == "allgather" and info["world"] == world
         assert (np.abs(np.array(costs) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (rank, costs, co)
         assert costs == res[0][1]
         assert np.abs(X - p[16][g0:g1]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("world,W,H,nit,lit", [(2, 64, 64, 5, 10), (3, 128, 112, 4, 10), (1, 64, 48, 4, 10)])
+def test_hip_sfs_slabs_levenberg_marquardt_match_oracle(orc, world, W, H, nit, lit):
+    """BASELINE config 4's solver across ranks: the LM branch (trust region, zeta test on the device) with every reduction made global where it
+    is produced; identical cost trajectories -- including the steps LM rejects -- on every rank, and the oracle's LM trajectory."""
+    from thallo_amd import synthetic as syn
+    res = _run_sfs(world, W, H, nit, lit, True)
+    p = syn.shape_from_shading(W, H)
+    co, _ = orc.Problem(orc.SFS, (W, H), p).solve(nIterations=nit, lIterations=lit, use_lm=1, q_tolerance=0.05)
+    for rank, costs, g0, g1, X, info in res:
+        m = min(len(costs), len(co))
+        assert m >= 3 and abs(len(costs) - len(co)) <= 1, (costs, co)
+        assert (np.abs(np.array(costs[:m]) - co[:m]) <= 2e-4 * np.abs(co[:m])).all(), (rank, costs, co)       # the bar of test_shape_from_shading_lm
+        assert costs == res[0][1]
+        assert np.abs(X - p[16][g0:g1]).max() <= 2e-4
+
+
+def test_hip_sfs_2048_levenberg_marquardt_two_ranks_match_one_gpu():
+    """BASELINE config 4 at full size (2048 x 2048, LM + PCG 3 x 10), two row slabs against the single-GPU plan on the same instance (which
+    tests/test_gpu_parity.py checks against the oracle at this size): same trajectory to 1e-5, identical on both ranks."""
+    import torch
+    import thallo_amd
+    from thallo_amd import synthetic as syn
+    W = H = 2048
+    res = _run_sfs(2, W, H, 3, 10, True)
+    p = syn.shape_from_shading(W, H)
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() if isinstance(a, np.ndarray) else float(a) for a in p]
+    s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"))
+    s.enable_lm()
+    _, c1 = s.solve(dev, profiled=True, nIterations=3, lIterations=10, q_tolerance=0.05)
+    s.close()
+    for rank, costs, g0, g1, X, info in res:
+        m = min(len(costs), len(c1))
+        assert m >= 3 and (np.abs(np.array(costs[:m]) - np.array(c1[:m])) <= 1e-5 * np.abs(np.array(c1[:m]))).all(), (costs, c1)
+        assert costs == res[0][1]
+        assert np.abs(X - dev[16].view(H, W)[g0:g1].cpu().numpy()).max() <= 2e-4      # (sums over rows and ranks associate differently from one GPU's)

@@ -123,6 +123,8 @@ public:
     // ---- one row slab of a multi-GPU run (solver_dist.cpp): image-stencil plugins whose kernels take an owned-row range
     virtual bool supports_row_slabs() const { return false; }
     virtual int  set_row_slab(int /*row0*/, int /*row1*/) { return -1; }
+    virtual int  slab_ghost_rows() const { return 1; }         // stencil radius = ghost rows towards each neighbour
+    virtual int  set_slab_global(int /*global_row0*/, int /*global_rows*/) { return 0; }      // energies whose expressions use global pixel coordinates
     virtual int  slab_width() const { return 0; }
     virtual bool slab_grid_ok() const { return false; }       // after prepare(): the precondition of the one-kernel slab schedule holds on this rank
     virtual unsigned char* slab_flags() { return nullptr; }    // per-pixel byte plane (written by pcg_init) whose ghost rows come from their owner each GN step

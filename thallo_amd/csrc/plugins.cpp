@@ -553,13 +553,29 @@ class ShapeFromShadingPlugin : public EnergyPlugin {
     float hp[16];
     float* X = nullptr; const float *D = nullptr, *Im = nullptr; const unsigned char *mR = nullptr, *mC = nullptr;
     DeviceBuffer G, Wt, fl, U, R;
+    int row0_ = 0, row1_ = 0, yoff_ = 0, Hg_ = 0;      // owned rows of the local image; its first row's global index; global image height (all of it on one GPU)
     int precompute(LaunchCtx& c)
     {
         TimedLaunch t(c, "precompute");
-        return thallo_hip_sfs_precompute(W, H, 0, H, 0, H, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
+        return thallo_hip_sfs_precompute(W, H, 0, H, yoff_, Hg_, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
     }
 public:
-    ShapeFromShadingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1]) { imgs.push_back({ 16, (long)W * H }); }
+    ShapeFromShadingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1]), row1_((int)dims[1]), Hg_((int)dims[1]) { imgs.push_back({ 16, (long)W * H }); }
+    // ---- one row slab of a multi-GPU run (solver_dist.cpp): the chain B_I -> shading row -> J^T gather has radius 2; pixel coordinates and the
+    // image-border guard are global, so the kernels also get the slab's global row offset and the global height
+    bool supports_row_slabs() const override { return true; }
+    int slab_ghost_rows() const override { return 2; }
+    int slab_width() const override { return W; }
+    int set_row_slab(int row0, int row1) override
+    {
+        if (row0 < 0 || row1 > H || row0 >= row1 || (W & 3)) { set_error("shape_from_shading: row slab [%d,%d) of %d rows, W = %d (W %% 4 must be 0)", row0, row1, H, W); return -1; }
+        row0_ = row0; row1_ = row1; return 0;
+    }
+    int set_slab_global(int global_row0, int global_rows) override
+    {
+        if (global_row0 < 0 || global_rows < global_row0 + H) { set_error("shape_from_shading: local rows [%d,%d) outside the %d global rows", global_row0, global_row0 + H, global_rows); return -1; }
+        yoff_ = global_row0; Hg_ = global_rows; return 0;
+    }
     const char* name() const override { return "shape_from_shading"; }
     long n_unknowns() const override { return (long)W * H; }
     const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
@@ -578,26 +594,26 @@ public:
     {
         int rc = precompute(c); if (rc < 0) return rc;
         TimedLaunch t(c, "computeCost");
-        return thallo_hip_sfs_cost(W, H, 0, H, 0, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, out, c.stream);
+        return thallo_hip_sfs_cost(W, H, row0_, row1_, yoff_, Hg_, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, out, c.stream);
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
         int rc = precompute(c); if (rc < 0) return rc;
         TimedLaunch t(c, "PCGInit1");
-        return thallo_hip_sfs_pcg_init(W, H, 0, H, 0, H, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr,
+        return thallo_hip_sfs_pcg_init(W, H, row0_, row1_, yoff_, Hg_, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr,
                                        v.r, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_sfs_apply_jtj_gated(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
+        return thallo_hip_sfs_apply_jtj_gated(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
                                               c.gate, c.stream);
     }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_sfs_apply_jtj_sums_fin(W, H, 0, H, 0, H, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
+        return thallo_hip_sfs_apply_jtj_sums_fin(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
                                                  v.r, v.s12, fin, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override

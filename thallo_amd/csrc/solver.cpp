@@ -236,7 +236,7 @@ void Plan::init(void** params)
     ready_ = false;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return; }
     if (plugin->prepare(ctx)) { const std::string why = last_error(); set_error("%s: prepare failed: %s", plugin->name(), why.c_str()); return; }
-    if (dist_) {   // collective: the one-kernel slab schedule needs its precondition on EVERY rank; then (first Init) the exchange's self-check
+    if (dist_ && !dist_->flat) {   // collective: the one-kernel slab schedule needs its precondition on EVERY rank; then (first Init) the exchange's self-check
         bool all = false;
         if (dist_agree(plugin->slab_grid_ok(), all)) return;
         if (!all) { set_error("%s: the row-slab schedule needs UrShape on the unit pixel grid on every rank", plugin->name()); return; }
@@ -274,7 +274,7 @@ int Plan::step(void** params)
     if (sp.lIterations < 0) { set_error("lIterations = %d is negative", sp.lIterations); if (!finalized_) finalize(); return 0; }
     if (ensure_slots(sp.lIterations)) { if (!finalized_) finalize(); return 0; }
     const int ev_iter = timer_.start("Nonlinear Iteration", ctx.stream);
-    if (dist_ && lm_) { set_error("distributed: the Levenberg-Marquardt branch is single-device"); if (!finalized_) finalize(); return 0; }
+    if (dist_ && lm_ && !dist_->flat) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); if (!finalized_) finalize(); return 0; }
     const int rc = lm_ ? step_lm(ev_iter) : dist_ ? step_gn_slab(ev_iter) : step_gn(ev_iter);
     if (rc == 1 && sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779
         hipStream_t s = ctx.stream;
@@ -493,7 +493,14 @@ int Plan::step_lm(int ev_iter)
     if (ensure_lm_vectors()) return 0;
     hipStream_t s = ctx.stream;
     const int L = sp.lIterations, B = 2, QS = 1, T0 = 2 * L + 4, T1 = 2 * L + 5;
-    const long n = v_.n;
+    // One row slab of a multi-GPU run (flat form, solver_dist.cpp): the energy-independent kernels run on the owned rows' sub-vectors [o, o + n),
+    // p is kept current on the ghost rows too ([oe, oe + ne)), and every reduction is made global where it is produced: per PCG iteration one
+    // exchange for alphaD and one for [betaN, q | ghost rows of z]; all ranks see the same scalars, so gate and trust region cannot diverge.
+    const bool slab = dist_ != nullptr;
+    const long o = slab ? dist_->rowlen * dist_->row0 : 0, n = slab ? dist_->rowlen * (dist_->row1 - dist_->row0) : v_.n;
+    const long oe = slab ? dist_->rowlen * (dist_->row0 - dist_->top) : 0, ne = slab ? dist_->rowlen * (dist_->row1 + dist_->bot - (dist_->row0 - dist_->top)) : v_.n;
+    auto global = [&](int j) { return slab ? dist_sum_slot(j) : 0; };
+    auto global_rows = [&](int j, float* vec) { return slab ? dist_sum_and_rows(j, vec) : 0; };
     const bool pc = plugin->use_preconditioner();
     const bool host_zeta = [] { const char* e = getenv("THALLO_LM_HOST_ZETA"); return e && e[0] == '1'; }();
     float* lmst = (float*)scratch_.ptr + 16;                          // 8 words: Q0, gate, iterations done, | dJJd, db, new cost
@@ -504,11 +511,12 @@ int Plan::step_lm(int ev_iter)
     int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));               // r, raw diag (v_.diag); delta = 0
     if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
     {   TimedLaunch t(ctx, "PCGFinalizeDiagonal");                    // :1596-1604 (alphaN restarts from 0)
-        nb = thallo_hip_lm_finalize_diagonal(v_.diag, v_.SSq, v_.CtC, v_.pre, v_.r, v_.b, v_.z, n, radius_, sp.min_lm_diagonal, sp.max_lm_diagonal,
+        nb = thallo_hip_lm_finalize_diagonal(v_.diag + o, v_.SSq + o, v_.CtC + o, v_.pre + o, v_.r + o, v_.b + o, v_.z + o, n, radius_, sp.min_lm_diagonal, sp.max_lm_diagonal,
                                              sp.nIter == 0 ? 1 : 0, pc ? 1 : 0, slot(B), s);
     }
     if (nb < 0) return 0;
     set_nb(B, nb);
+    if (global_rows(B, v_.z)) return 0;                               // alphaN_0 over all ranks; ghost rows of z
     float Q0 = 0.0f;                                                  // delta = 0 -> q = 0 (:965)
     if (thallo_hip_lm_state_reset(lmst, s) < 0) return 0;
     timer_.stop(ev_setup, s);
@@ -520,31 +528,34 @@ int Plan::step_lm(int ev_iter)
     for (int k = 0; k < L && !failed; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         {   TimedLaunch t(ctx, "PCGStep3");                           // p = z + beta p  (k = 0: p = z)
-            thallo_hip_pcg_pupdate(v_.z, p, p, nullptr, n, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
+            thallo_hip_pcg_pupdate(v_.z + oe, p + oe, p + oe, nullptr, ne, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
         }
         nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(T0));              // PCGStep1 (J^T J p)
         if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); failed = true; break; }
         {   TimedLaunch t(ctx, "PCGStep1_Finish");                    // + CtC p ; alphaD
-            nb = thallo_hip_lm_step1_finish(v_.Ap, v_.CtC, p, n, slot(jD), s);
+            nb = thallo_hip_lm_step1_finish(v_.Ap + o, v_.CtC + o, p + o, n, slot(jD), s);
         }
         if (nb < 0) { failed = true; break; }
         set_nb(jD, nb);
+        if (global(jD)) { failed = true; break; }
         int nbq;
         if (((k + 1) % sp.residual_reset_period) == 0) {              // :1653-1657
             TimedLaunch t(ctx, "PCGStep2");
-            thallo_hip_lm_step2_first_half(v_.delta, p, n, sum(jN), sum(jD), s);
+            thallo_hip_lm_step2_first_half(v_.delta + o, p + o, n, sum(jN), sum(jD), s);
+            if (global_rows(-1, v_.delta)) { failed = true; break; }               // (slab: applyJTJ reads delta on the ghost rows)
             nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));             // computeAdelta
             if (nb < 0) { failed = true; break; }
-            thallo_hip_lm_step1_finish(v_.Adelta, v_.CtC, v_.delta, n, slot(T1), s);
-            nb = thallo_hip_lm_step2_second_half(v_.r, v_.b, v_.Adelta, v_.pre, v_.z, v_.delta, n, slot(jB), slot(QS), s);
+            thallo_hip_lm_step1_finish(v_.Adelta + o, v_.CtC + o, v_.delta + o, n, slot(T1), s);
+            nb = thallo_hip_lm_step2_second_half(v_.r + o, v_.b + o, v_.Adelta + o, v_.pre + o, v_.z + o, v_.delta + o, n, slot(jB), slot(QS), s);
             nbq = nb;
         } else {
             TimedLaunch t(ctx, "PCGStep2");
-            nb = thallo_hip_pcg_step2_full(v_.delta, p, v_.r, v_.Ap, v_.pre, v_.z, v_.b, n, sum(jN), sum(jD), slot(jB), slot(QS), 1, s);
+            nb = thallo_hip_pcg_step2_full(v_.delta + o, p + o, v_.r + o, v_.Ap + o, v_.pre + o, v_.z + o, v_.b + o, n, sum(jN), sum(jD), slot(jB), slot(QS), 1, s);
             nbq = nb;
         }
         if (nb < 0) { failed = true; break; }
         set_nb(jB, nb); set_nb(QS, nbq);
+        if (global(QS) || global_rows(jB, v_.z)) { failed = true; break; }          // q and betaN over all ranks; ghost rows of z
         k_done = k + 1;
         if (host_zeta) {
             const float Q1 = read_sum(QS);                            // :1666-1686 (blocking, as in the reference)
@@ -564,12 +575,14 @@ int Plan::step_lm(int ev_iter)
     const int ev_fin = timer_.start("Nonlinear Finish", s);
     // model_cost_change = cost - 0.5|F + J delta|^2 = delta.b - 0.5 delta.(J^T J delta)   (b = -J^T F; thallo.t:3845-3865
     // expanded algebraically, which also avoids the reference's cancellation between two large sums)
+    if (global_rows(-1, v_.delta)) return 0;
     nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));
     if (nb < 0) return 0;
     set_nb(T0, nb);
-    nb = thallo_hip_dot(v_.delta, v_.b, n, slot(T1), s);
+    nb = thallo_hip_dot(v_.delta + o, v_.b + o, n, slot(T1), s);
     if (nb < 0) return 0;
     set_nb(T1, nb);
+    if (global(T0) || global(T1)) return 0;
     thallo_hip_finish_sum(sum(T0), lmst + 3, s);
     thallo_hip_finish_sum(sum(T1), lmst + 4, s);
     const auto& imgs = plugin->unknown_images();
@@ -579,17 +592,13 @@ int Plan::step_lm(int ev_iter)
             off += imgs[k].n_floats;
         }
     }
-    {   long off = 0;                                                 // PCGLinearUpdate
-        for (size_t k = 0; k < imgs.size(); ++k) {
-            TimedLaunch t(ctx, "PCGLinearUpdate");
-            thallo_hip_linear_update(plugin->unknown_ptr((int)k), v_.delta + off, nullptr, imgs[k].n_floats, sum(B), sum(B), s);
-            off += imgs[k].n_floats;
-        }
-    }
+    linear_update_tail(0, false);                                     // PCGLinearUpdate: X += delta (the owned rows of a slab)
+    if (slab && dist_exchange_unknown_rows()) return 0;
     {   // cost after the step, into the same report: ONE blocking read per GN step
         const int nbc = plugin->cost(ctx, slot(0));
         if (nbc < 0) { set_error("cost kernel launch failed (%d)", nbc); return 0; }
         set_nb(0, nbc);
+        if (global(0)) return 0;
         thallo_hip_finish_sum(sum(0), lmst + 5, s);
     }
     float rep[8] = { 0 };

@@ -51,6 +51,10 @@ struct DistState {
     DeviceBuffer send, gath;                             // message buffers (floats), sized for the larger of the two message kinds
     long msg = 0, msg_iter = 0, msg_x = 0;
     thallo_segs_t seg_first_last, seg_top, seg_bot, seg_iter_fl, seg_iter_top, seg_iter_bot;
+    // flat form (single-image energies with apply_jtj_sums: shape_from_shading): vectors stay where the Plan allocated them, all-gather transport only
+    bool flat = false;
+    long rowlen = 0;                                     // floats per image row
+    thallo_segs_t seg_rows_fl, seg_rows_top, seg_rows_bot;   // first / last `ghost` owned rows; the ghost rows above / below
     // device-side exchange
     bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
     void* mail = nullptr; int mail_L = 0;
@@ -141,6 +145,10 @@ private:
     int  dist_self_check();
     int  dist_gn(int L, bool p2p);                      // PCGInit + L iterations + linear update + ghost refresh, no bookkeeping
     int  step_gn_slab(int ev_iter);
+    int  dist_gn_flat(int L);                           // flat form: pcg_update + apply_jtj_sums + ONE exchange per PCG iteration
+    int  dist_sum_slot(int j);                          // slot j (local partials) -> scal(j) = rank-ordered global sum
+    int  dist_sum_and_rows(int j, float* vec);          // ... and the ghost rows of a flat vector from the neighbours' boundary rows (j < 0: rows only)
+    int  dist_exchange_unknown_rows();
     float dist_cost();
     void dist_release();
 };

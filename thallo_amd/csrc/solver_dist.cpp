@@ -66,24 +66,47 @@ int Plan::set_distributed(const ThalloX_Distributed& cfg)
 {
     if (!ok_) return -1;
     if (dist_) { set_error("distributed: already set for this plan"); return -1; }
-    if (lm_) { set_error("distributed: the Levenberg-Marquardt branch is single-device"); return -1; }
-    if (!plugin->supports_row_slabs() || !plugin->one_kernel_iteration()) { set_error("distributed: %s has no row-slab form", plugin->name()); return -1; }
+    const bool flat = !plugin->one_kernel_iteration();         // single-image energies in the single-reduction form (shape_from_shading); else image_warping's one-kernel form
+    if (!plugin->supports_row_slabs() || (flat && (!plugin->apply_returns_sums() || plugin->unknown_images().size() != 1))) { set_error("distributed: %s has no row-slab form", plugin->name()); return -1; }
+    if (lm_ && !flat) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
     if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
     if (cfg.world > 1 && !cfg.allgather) { set_error("distributed: world > 1 needs an all-gather callback"); return -1; }
     const int W = plugin->slab_width(), Hl = (int)dims[1];
+    const int g = plugin->slab_ghost_rows();
     const int top = (int)cfg.row0, bot = Hl - (int)cfg.row1;
-    if (top < 0 || top > 1 || bot < 0 || bot > 1 || (int)cfg.row1 <= (int)cfg.row0 ||
-        (top == 1) != (cfg.rank > 0) || (bot == 1) != (cfg.rank < cfg.world - 1)) {
-        set_error("distributed: rank %d of %d owns rows [%u,%u) of a %d-row local image; expected exactly one ghost row towards each neighbour", cfg.rank, cfg.world, cfg.row0, cfg.row1, Hl);
+    if ((top != 0 && top != g) || (bot != 0 && bot != g) || (int)cfg.row1 - (int)cfg.row0 < g ||
+        (top == g) != (cfg.rank > 0) || (bot == g) != (cfg.rank < cfg.world - 1)) {
+        set_error("distributed: rank %d of %d owns rows [%u,%u) of a %d-row local image; expected exactly %d ghost row(s) towards each neighbour and at least as many owned rows", cfg.rank, cfg.world, cfg.row0, cfg.row1, Hl, g);
         return -1;
     }
     if (plugin->set_row_slab((int)cfg.row0, (int)cfg.row1)) return -1;
+    if (plugin->set_slab_global((int)cfg.global_row0, cfg.global_rows ? (int)cfg.global_rows : Hl)) return -1;
+    if (flat && cfg.world > 1 && cfg.global_rows == 0) { set_error("distributed: %s needs global_row0 / global_rows", plugin->name()); return -1; }
     hipDeviceSynchronize();
     DistState* Dp = new DistState();
     DistState& D = *Dp;
     dist_ = Dp;
-    D.cfg = cfg; D.W = W; D.Hl = Hl; D.row0 = (int)cfg.row0; D.row1 = (int)cfg.row1; D.top = top; D.bot = bot;
+    D.cfg = cfg; D.W = W; D.Hl = Hl; D.row0 = (int)cfg.row0; D.row1 = (int)cfg.row1; D.top = top; D.bot = bot; D.ghost = g;
     D.N = (long)W * Hl; D.na = v_.n_alloc;
+    D.flat = flat;
+    if (flat) {
+        D.rowlen = plugin->unknown_images()[0].n_floats / Hl;
+        if (D.rowlen & 3) { set_error("distributed: image rows of %ld floats (must be a multiple of 4)", D.rowlen); return -1; }
+        const long gl = g * D.rowlen;
+        D.seg_rows_fl = segs({ { D.rowlen * D.row0, gl }, { D.rowlen * (D.row1 - g), gl } });
+        D.seg_rows_top = top ? segs({ { D.rowlen * (D.row0 - g), gl } }) : segs({});
+        D.seg_rows_bot = bot ? segs({ { D.rowlen * D.row1, gl } }) : segs({});
+        D.msg = 2 + 2 * gl; D.msg_iter = 7 + 2 * gl; D.msg_x = 2 * gl;
+        const size_t words = (size_t)std::max(D.msg_iter, 64L);
+        if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory"); return -1; }
+        if (ensure_sums_buffer()) { set_error("distributed: out of device memory"); return -1; }
+        bool all = false;
+        if (dist_agree(true, all)) return -1;                            // the first use of the caller's all-gather: fails here, not mid-solve
+        char buf[256];
+        snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"single-image, %d ghost rows\", \"rank\": %d, \"world\": %d}", g, cfg.rank, cfg.world);
+        D.info = buf;
+        return 0;
+    }
     D.want_p2p = cfg.device_exchange != 0;
     {   const char* e = getenv("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
     // ---- r, z, r', Ap, Ap' in ONE block (peers map it; pack / unpack address r and z through one base)
@@ -248,29 +271,108 @@ int Plan::dist_gn(int L, bool p2p)
     }
     last_l_iters = L;
     linear_update_tail(L, batch);                                        // owned rows only
-    {   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
-        TimedLaunch t(ctx, "SlabExchangeUnknowns");
-        const auto& imgs = plugin->unknown_images();
-        long pos = 0;
-        for (int which = 0; which < 2; ++which)
-            for (size_t k = 0; k < imgs.size(); ++k) {
-                const long rowlen = imgs[k].n_floats / D.Hl;
-                const long y = which == 0 ? D.row0 : D.row1 - 1;
-                if (hipMemcpyAsync(send + pos, plugin->unknown_ptr((int)k) + rowlen * y, rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-                pos += rowlen;
-            }
-        const long half = pos / 2;
-        if (pos > D.msg_x) { set_error("distributed: unknown rows exceed the message buffer"); return -1; }
-        if (dist_allgather(send, gath, pos * (long)sizeof(float))) return -1;
-        long at = 0;
+    if (dist_exchange_unknown_rows()) return -1;
+    return 0;
+}
+
+int Plan::dist_exchange_unknown_rows()
+{   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const int rank = D.cfg.rank, g = D.ghost;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    TimedLaunch t(ctx, "SlabExchangeUnknowns");
+    const auto& imgs = plugin->unknown_images();
+    long pos = 0;
+    for (int which = 0; which < 2; ++which)
         for (size_t k = 0; k < imgs.size(); ++k) {
             const long rowlen = imgs[k].n_floats / D.Hl;
-            if (D.top && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * (D.row0 - 1), gath + (rank - 1) * pos + half + at, rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-            if (D.bot && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * D.row1, gath + (rank + 1) * pos + at, rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-            at += rowlen;
+            const long y = which == 0 ? D.row0 : D.row1 - g;
+            if (hipMemcpyAsync(send + pos, plugin->unknown_ptr((int)k) + rowlen * y, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+            pos += g * rowlen;
         }
+    const long half = pos / 2;
+    if (pos > D.msg_x) { set_error("distributed: unknown rows exceed the message buffer"); return -1; }
+    if (dist_allgather(send, gath, pos * (long)sizeof(float))) return -1;
+    long at = 0;
+    for (size_t k = 0; k < imgs.size(); ++k) {
+        const long rowlen = imgs[k].n_floats / D.Hl;
+        if (D.top && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * (D.row0 - g), gath + (rank - 1) * pos + half + at, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        if (D.bot && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * D.row1, gath + (rank + 1) * pos + at, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        at += g * rowlen;
     }
     return 0;
+}
+
+// ---- flat form (single-image energies)
+int Plan::dist_sum_slot(int j)
+{   // local partials of slot j -> one word per rank -> all-gather -> rank-ordered sum into scal(j): what every consumer then reads
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const thallo_segs_t none = segs({});
+    if (thallo_hip_finish_sum(partial_sum(j), (float*)D.send.ptr, s) < 0) return -1;
+    if (dist_allgather(D.send.ptr, D.gath.ptr, sizeof(float))) return -1;
+    if (thallo_hip_slab_unpack(nullptr, none, nullptr, none, nullptr, (const float*)D.gath.ptr, 1, D.cfg.world, scal(j), s) < 0) return -1;
+    fin_[j] = 1;
+    return 0;
+}
+
+int Plan::dist_sum_and_rows(int j, float* vec)
+{   // message = [sum of slot j (or nothing to add: j < 0) | my first `ghost` owned rows | my last `ghost` owned rows] of the flat vector `vec`
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    const long gl = D.ghost * D.rowlen, msg = 1 + 2 * gl;
+    const thallo_sum_t nothing = { nullptr, 0 };
+    if (thallo_hip_slab_pack(vec, D.seg_rows_fl, j >= 0 ? partial_sum(j) : nothing, send, s) < 0) return -1;
+    if (dist_allgather(send, gath, msg * (long)sizeof(float))) return -1;
+    const float* src_top = D.top ? gath + (D.cfg.rank - 1) * msg + 1 + gl : nullptr;          // the LAST rows of rank-1
+    const float* src_bot = D.bot ? gath + (D.cfg.rank + 1) * msg + 1 : nullptr;               // the FIRST rows of rank+1
+    if (thallo_hip_slab_unpack(vec, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, msg, D.cfg.world, j >= 0 ? scal(j) : nullptr, s) < 0) return -1;
+    if (j >= 0) fin_[j] = 1;
+    return 0;
+}
+
+int Plan::dist_gn_flat(int L)
+{   // the slab form of step_gn_expanded: per PCG iteration pcg_update over owned + ghost rows, applyJTJ with sums over the owned rows, ONE exchange
+    // [alphaD | N, S1, S2 | boundary rows of Ap]
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const int B = 2, world = D.cfg.world, rank = D.cfg.rank;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    const long gl = D.ghost * D.rowlen;
+    const long oe = D.rowlen * (D.row0 - D.top), lene = D.rowlen * (D.row1 + D.bot - (D.row0 - D.top));
+    const bool pc = plugin->use_preconditioner();
+    cur_ = 0;
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
+    set_nb(B, nb);
+    {   TimedLaunch t(ctx, "SlabExchangeInit");
+        if (dist_sum_and_rows(B, v_.r)) return -1;                       // alphaN_0; ghost rows of r (p_0 = M^-1 r_0 there too)
+        if (pc && dist_sum_and_rows(-1, v_.pre)) return -1;
+    }
+    for (int k = 0; k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        {   TimedLaunch t(ctx, "PCGUpdate");
+            if (thallo_hip_pcg_update(v_.r + oe, v_.Ap + oe, pc ? v_.pre + oe : nullptr, v_.p[cur_] + oe, v_.p[cur_ ^ 1] + oe, v_.delta + oe, lene, k == 0,
+                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return -1; }
+        }
+        cur_ ^= 1;
+        const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), none);
+        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return -1; }
+        set_nb(jD, nb);
+        TimedLaunch t(ctx, "SlabExchange");
+        if (thallo_hip_slab_pack_iter(v_.Ap, D.seg_rows_fl, slot(jD), v_.s12, nb, send, s) < 0) return -1;
+        if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
+        const float* src_top = D.top ? gath + (rank - 1) * D.msg_iter + 7 + gl : nullptr;
+        const float* src_bot = D.bot ? gath + (rank + 1) * D.msg_iter + 7 : nullptr;
+        if (thallo_hip_slab_unpack_iter(v_.Ap, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
+        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+    }
+    last_l_iters = L;
+    linear_update_tail(L, false);
+    return dist_exchange_unknown_rows();
 }
 
 int Plan::dist_self_check()
@@ -334,7 +436,7 @@ int Plan::step_gn_slab(int ev_iter)
     const int L = sp.lIterations;
     const int ev_lin = timer_.start("Linear Solve", s);
     const bool p2p = D.p2p_on && L <= D.mail_L;                          // (same L on every rank: same decision)
-    if (dist_gn(L, p2p)) return 0;
+    if (D.flat ? dist_gn_flat(L) : dist_gn(L, p2p)) return 0;
     timer_.stop(ev_lin, s);
     sp.nIter++;
     timer_.stop(ev_iter, s);
@@ -359,7 +461,7 @@ int Plan::dist_control(int what, int value)
 
 int Plan::dist_kernel_only(int reps)
 {
-    if (!dist_ || !ready_) return -1;
+    if (!dist_ || !ready_ || dist_->flat) return -1;
     const int B = 2;
     for (int i = 0; i < reps; ++i) {
         const int nb = plugin->pcg_iter(ctx, v_, 0, 0, sum(B), sum(B + 1), sum(B + 2), sum(B), sum(B + 1), slot(B + 3), nullptr, nullptr);

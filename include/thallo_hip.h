@@ -426,6 +426,12 @@ int thallo_hip_sfs_apply_jtj_sums_fin(int W, int H, int row0, int row1, int yoff
 int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
                                  const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* alphaD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream);
+/* LM: applyJTJ with PCGStep1_Finish folded in (gauss_newton.t:774-787): Ap = (J^T J + CtC) p, partials of p . Ap; gate as below (may be NULL) */
+int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                float* U, float* R, const float* p, const float* CtC, float* Ap, float* alphaD_out, const unsigned* gate, thallo_stream_t stream);
+int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
+                                const float* Jb, const float* JP, float* JpP, const float* p, const float* CtC, float* Ap, float* alphaD_out,
+                                const unsigned* gate, thallo_stream_t stream);
 /* shape_from_shading applyJTJ with a device-side gate word (may be NULL): non-zero = the launch does nothing (the LM branch ends its PCG loop on
  * the device without a host round trip per iteration, solver.cpp) */
 int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

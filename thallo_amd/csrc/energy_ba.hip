@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_point_blocks(int O_, const float
 __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ cam_ptr, const int* __restrict__ q_pt, const int* __restrict__ q_ptk,
                                                 const float4* __restrict__ Jb, const float* __restrict__ p, float* __restrict__ Ap, float2* __restrict__ JpP,
                                                 float* __restrict__ part_out, const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
-                                                const unsigned* __restrict__ gate)
+                                                const unsigned* __restrict__ gate, const float* __restrict__ ctc)
 {
     __shared__ float red[16];
     __shared__ double redd[3 * BLOCK / 64];
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
 #pragma unroll
             for (int k = 0; k < 9; ++k) if (lane == k) sv = s[k];
             const long i = 9L * c + lane;
+            if (ctc) sv += ctc[i] * p[i];                 // LM: (J^T J + CtC) p, PCGStep1_Finish (gauss_newton.t:774-787) folded in
             Ap[i] = sv;
             acc += p[i] * sv;
             if (s3_out) sm.add(prs[i], rs[i], sv);
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
 __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __restrict__ pt_ptr, const float2* __restrict__ JP, const float2* __restrict__ JpP,
                                                const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ part_out,
                                                const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
-                                               const unsigned* __restrict__ gate, FinArgs fin)
+                                               const unsigned* __restrict__ gate, FinArgs fin, const float* __restrict__ ctc)
 {   // part_out / s3_out: the slot arrays of the whole applyJTJ (k_cam2 filled slots [0, fin.blk_off)); this launch's workgroups use the slots behind them
     __shared__ float red[16];
     __shared__ double redd[3 * BLOCK / 64];
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __rest
             s0 += a.x * jp.x + b.y * jp.y; s1 += a.y * jp.x + c.x * jp.y; s2 += b.x * jp.x + c.y * jp.y;
         }
         const long i = PB + 3L * j;
+        if (ctc) { s0 += ctc[i] * p[i]; s1 += ctc[i + 1] * p[i + 1]; s2 += ctc[i + 2] * p[i + 2]; }
         Ap[i] = s0; Ap[i + 1] = s1; Ap[i + 2] = s2;
         acc += p[i] * s0 + p[i + 1] * s1 + p[i + 2] * s2;
         if (s3_out) { sm.add(prs[i], rs[i], s0); sm.add(prs[i + 1], rs[i + 1], s1); sm.add(prs[i + 2], rs[i + 2], s2); }
@@ -410,19 +412,31 @@ int thallo_hip_ba_pack_point_blocks(int O_, const float* Jb, const int* q_ptk, f
     return check_launch();
 }
 
-int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
-                                 const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
-                                 const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream)
+static int ba_apply2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
+                     const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
+                     const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, const float* ctc, thallo_stream_t stream)
 {
     if (!cam_ptr || !q_pt || !q_ptk || !pt_ptr || !Jb || !JP || !JpP || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
     if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || gate || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     int cb, grid; gather_shape(C_, P_, cb, grid);
     // the camera launch fills slots [0, cb); the point launch the rest, and (fin) its last workgroup adds up all `grid` of them
-    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, q_ptk, (const float4*)Jb, p, Ap, (float2*)JpP, aD_out, r, pre, s3_out, gate);
+    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, q_ptk, (const float4*)Jb, p, Ap, (float2*)JpP, aD_out, r, pre, s3_out, gate, ctc);
     hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, (const float2*)JP, (const float2*)JpP, p, Ap, aD_out, r, pre,
-                       s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid });
+                       s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid }, ctc);
     int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
+                                 const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
+                                 const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream)
+{ return ba_apply2(C_, P_, cam_ptr, q_pt, q_ptk, pt_ptr, Jb, JP, JpP, p, Ap, aD_out, r, pre, s3_out, gate, fin, nullptr, stream); }
+int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
+                                const float* Jb, const float* JP, float* JpP, const float* p, const float* CtC, float* Ap, float* aD_out,
+                                const unsigned* gate, thallo_stream_t stream)
+{
+    if (!CtC) return -(int)hipErrorInvalidValue;
+    const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+    return ba_apply2(C_, P_, cam_ptr, q_pt, q_ptk, pt_ptr, Jb, JP, JpP, p, Ap, aD_out, nullptr, nullptr, nullptr, gate, none, CtC, stream);
 }
 int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
                              const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Geo g, Cam cm, const float* __
 // MODE 0 is the J^T F pass of PCGInit1: dB := BI (G.w), v := X, the fit term uses X - D, and the outputs are r = -J^T F, z = r,
 // p_prev = 0, delta = 0, alphaN partials.  Same expressions in the same order as k_rows / k_gather: bit-identical outputs.
 // `gate` (may be NULL): a device word; non-zero = skip this launch (LM: the PCG loop ended early on the device, solver.cpp).
+// MODE 1 with D != NULL: D is the LM diagonal CtC and the output is (J^T J + CtC) v -- PCGStep1_Finish (gauss_newton.t:774-787) folded into the apply.
 constexpr int FW = 64, FH = 16;
 constexpr int UW = FW + 2, UH = FH + 2;        // U, R: tile +- 1
 struct FusedTile {
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
                     s += cm.ws * (ci[c] * lap);
                 }
                 if (MODE == 0) { const float r = -s; out[i] = r; z[i] = r; p_prev[i] = 0.0f; delta[i] = 0.0f; acc += r * r; }
-                else { out[i] = s; acc += vc * s; if (s3_out) sm.add(1.0f, rs[i], s); }
+                else { if (D) s += D[i] * vc; out[i] = s; acc += vc * s; if (s3_out) sm.add(1.0f, rs[i], s); }      // (MODE 1: D = the LM diagonal CtC or NULL)
             }
         }
         __syncthreads();
@@ -450,7 +451,7 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
 
 static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                      float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate = nullptr,
-                     thallo_fin_t fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr });
+                     thallo_fin_t fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr }, const float* ctc = nullptr);
 
 int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
@@ -468,15 +469,19 @@ int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, i
                                    float* U, float* R, const float* p, float* Ap, float* aD_out, const unsigned* gate, thallo_stream_t stream)
 { return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream, gate); }
 
+int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                float* U, float* R, const float* p, const float* CtC, float* Ap, float* aD_out, const unsigned* gate, thallo_stream_t stream)
+{ return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream, gate, thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr }, CtC); }
+
 static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
-                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate, thallo_fin_t fin)
+                     float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate, thallo_fin_t fin, const float* ctc)
 {
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
     if (sfs_fused()) {
         const int gridf = fused_grid(W, row1 - row0);
-        hipLaunchKernelGGL(k_fused<1>, dim3(gridf), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), p, (const float*)nullptr, (const float4*)G, (const float2*)Wt, fl,
+        hipLaunchKernelGGL(k_fused<1>, dim3(gridf), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), p, ctc, (const float4*)G, (const float2*)Wt, fl,
                            Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out, r, s3_out, gate,
                            FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridf });
         int e = check_launch(); return e ? e : gridf;
@@ -488,6 +493,10 @@ static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const f
     hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, s, g, cm, p, (const float*)nullptr, (const float4*)G, (const float2*)U, (const float*)R, fl,
                        Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out, r, s3_out);
     int e = check_launch(); if (e) return e;
+    if (ctc) {      // (A/B path: PCGStep1_Finish as a launch of its own over the owned rows; its partials are the ones returned)
+        const long o = (long)W * row0, n = (long)W * (row1 - row0);
+        return thallo_hip_lm_step1_finish(Ap + o, ctc + o, p + o, n, aD_out, stream);
+    }
     if (fin.tickets && (e = thallo_hip_pcg_scalars_finish(aD_out, s3_out, grid, fin.alphaN, fin.alphaD_word, fin.betaN_word, stream)) < 0) return e;      // (A/B path: the words by a launch of their own)
     return grid;
 }

@@ -43,6 +43,9 @@ struct LaunchCtx {
     // LM loop only: device word; non-zero = the PCG loop already ended on the device, an applyJTJ launch may return at once
     // (plugins that take it: shape_from_shading, bundle_adjustment -- the two LM configurations; the others simply compute)
     const unsigned* gate = nullptr;
+    // LM loop only: when set, an applyJTJ of a plugin with apply_adds_ctc() returns (J^T J + CtC) p and the partials of p . that -- PCGStep1_Finish
+    // (gauss_newton.t:774-787) folded into the apply, one launch less per PCG iteration
+    const float* lm_ctc = nullptr;
 };
 
 // RAII bracket used by plugins / driver around each shim call.
@@ -88,6 +91,7 @@ public:
     virtual int pcg_init(LaunchCtx&, SolverVectors&, int cur, float* alphaN_out) = 0;
     // plain PCGStep1: Ap = J^T J p, partials of p.Ap (LM branch, computeAdelta, model cost)
     virtual int apply_jtj(LaunchCtx&, const float* p, float* Ap, float* alphaD_out) = 0;
+    virtual bool apply_adds_ctc() const { return false; }      // honours LaunchCtx::lm_ctc
     // fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k): reads p[cur], writes p[cur^1], Ap, alphaD partials
     virtual int pcg_step1(LaunchCtx&, SolverVectors&, int cur, bool first,
                           thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev, float* alphaD_out) = 0;

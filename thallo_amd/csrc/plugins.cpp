@@ -521,10 +521,14 @@ public:
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
+        if (once_ && c.lm_ctc)
+            return thallo_hip_ba_apply_jtj2_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)q_ptk.ptr, (const int*)pt_ptr.ptr,
+                                               (const float*)Jb.ptr, (const float*)JP.ptr, (float*)JpP.ptr, p, c.lm_ctc, Ap, out, c.gate, c.stream);
         if (once_) return apply2(c, nullptr, p, Ap, out);
         return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                        (const float*)Jb.ptr, p, Ap, out, c.stream);
     }
+    bool apply_adds_ctc() const override { return once_; }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
@@ -606,9 +610,13 @@ public:
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
+        if (c.lm_ctc)
+            return thallo_hip_sfs_apply_jtj_lm(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr,
+                                               p, c.lm_ctc, Ap, out, c.gate, c.stream);
         return thallo_hip_sfs_apply_jtj_gated(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr, p, Ap, out,
                                               c.gate, c.stream);
     }
+    bool apply_adds_ctc() const override { return true; }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {

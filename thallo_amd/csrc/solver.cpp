@@ -502,6 +502,7 @@ int Plan::step_lm(int ev_iter)
     auto global = [&](int j) { return slab ? dist_sum_slot(j) : 0; };
     auto global_rows = [&](int j, float* vec) { return slab ? dist_sum_and_rows(j, vec) : 0; };
     const bool pc = plugin->use_preconditioner();
+    const bool fold_ctc = plugin->apply_adds_ctc() && ![] { const char* e = getenv("THALLO_LM_FOLD_CTC"); return e && e[0] == '0'; }();      // (=0: A/B)
     const bool host_zeta = [] { const char* e = getenv("THALLO_LM_HOST_ZETA"); return e && e[0] == '1'; }();
     float* lmst = (float*)scratch_.ptr + 16;                          // 8 words: Q0, gate, iterations done, | dJJd, db, new cost
     const unsigned* gate = reinterpret_cast<const unsigned*>(lmst) + 1;
@@ -530,9 +531,15 @@ int Plan::step_lm(int ev_iter)
         {   TimedLaunch t(ctx, "PCGStep3");                           // p = z + beta p  (k = 0: p = z)
             thallo_hip_pcg_pupdate(v_.z + oe, p + oe, p + oe, nullptr, ne, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
         }
-        nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(T0));              // PCGStep1 (J^T J p)
-        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); failed = true; break; }
-        {   TimedLaunch t(ctx, "PCGStep1_Finish");                    // + CtC p ; alphaD
+        if (fold_ctc) {                                               // PCGStep1 + PCGStep1_Finish in one launch: (J^T J + CtC) p ; alphaD
+            ctx.lm_ctc = v_.CtC;
+            nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(jD));
+            ctx.lm_ctc = nullptr;
+            if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); failed = true; break; }
+        } else {
+            nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(T0));          // PCGStep1 (J^T J p)
+            if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); failed = true; break; }
+            TimedLaunch t(ctx, "PCGStep1_Finish");                    // + CtC p ; alphaD
             nb = thallo_hip_lm_step1_finish(v_.Ap + o, v_.CtC + o, p + o, n, slot(jD), s);
         }
         if (nb < 0) { failed = true; break; }
@@ -543,9 +550,11 @@ int Plan::step_lm(int ev_iter)
             TimedLaunch t(ctx, "PCGStep2");
             thallo_hip_lm_step2_first_half(v_.delta + o, p + o, n, sum(jN), sum(jD), s);
             if (global_rows(-1, v_.delta)) { failed = true; break; }               // (slab: applyJTJ reads delta on the ghost rows)
-            nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));             // computeAdelta
+            ctx.lm_ctc = fold_ctc ? v_.CtC : nullptr;
+            nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));             // computeAdelta (+ CtC delta)
+            ctx.lm_ctc = nullptr;
             if (nb < 0) { failed = true; break; }
-            thallo_hip_lm_step1_finish(v_.Adelta + o, v_.CtC + o, v_.delta + o, n, slot(T1), s);
+            if (!fold_ctc) thallo_hip_lm_step1_finish(v_.Adelta + o, v_.CtC + o, v_.delta + o, n, slot(T1), s);
             nb = thallo_hip_lm_step2_second_half(v_.r + o, v_.b + o, v_.Adelta + o, v_.pre + o, v_.z + o, v_.delta + o, n, slot(jB), slot(QS), s);
             nbq = nb;
         } else {

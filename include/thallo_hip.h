@@ -146,6 +146,12 @@ int thallo_hip_pcg_init_finish(const float* r, const float* diag, float* pre, fl
 void thallo_hip_lm_set_gate(const unsigned* gate);
 int thallo_hip_lm_state_reset(float* state, thallo_stream_t stream);
 int thallo_hip_lm_zeta(thallo_sum_t q, int k, float q_tolerance, float* state, thallo_stream_t stream);
+/* LM PCGStep2 (as thallo_hip_pcg_step2_full with lm = 1, b and q_out given) whose last workgroup also applies thallo_hip_lm_zeta's test for PCG
+   iteration k on the q it just produced (tickets: THALLO_HIP_FIN_TICKET_WORDS zeroed device words, zero again when the kernel ends): one launch less
+   per LM PCG iteration. */
+int thallo_hip_pcg_step2_full_zeta(float* delta, const float* p, float* r, const float* Ap, const float* pre,
+                                   float* z, const float* b, long n, thallo_sum_t alphaN, thallo_sum_t alphaD,
+                                   float* betaN_out, float* q_out, unsigned* tickets, int k, float q_tolerance, float* lm_state, thallo_stream_t stream);
 int thallo_hip_dot(const float* a, const float* b, long n, float* out, thallo_stream_t stream);
 
 /* PCGLinearUpdate (gauss_newton.t:901-906) for one unknown image:  X[i] += delta[i] (+ alpha*p[i]

@@ -69,6 +69,10 @@ __global__ __launch_bounds__(BLOCK) void k_step2(float4* __restrict__ r, const f
     block_store_partial(acc, bN_out, red);
 }
 
+// LM: the zeta test of gauss_newton.t:1666-1686 done by the last workgroup of PCGStep2 itself (tickets != NULL) instead of a one-wave launch
+// behind it: state = the 8-word LM state of thallo_hip_lm_zeta (Q0, gate, iterations done), k = this PCG iteration.
+struct ZetaArgs { unsigned* tickets; float* state; int k; float q_tolerance; };
+
 // reference-shaped PCGStep2 incl. delta update and optional LM q
 template <bool HAS_PRE, bool LM, bool HAS_B>
 __global__ __launch_bounds__(BLOCK) void k_step2_full(float4* __restrict__ delta, const float4* __restrict__ p,
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(BLOCK) void k_step2_full(float4* __restrict__ delta
                                                        const float4* __restrict__ pre, float4* __restrict__ z,
                                                        const float4* __restrict__ b, long n4,
                                                        thallo_sum_t aN, thallo_sum_t aD,
-                                                       float* __restrict__ bN_out, float* __restrict__ q_out, const unsigned* __restrict__ gate)
+                                                       float* __restrict__ bN_out, float* __restrict__ q_out, const unsigned* __restrict__ gate, ZetaArgs zeta)
 {
     __shared__ float red[32];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device
@@ -99,7 +103,56 @@ __global__ __launch_bounds__(BLOCK) void k_step2_full(float4* __restrict__ delta
     }
     if (HAS_B) {
         float* __restrict__ const outs[2] = { bN_out, q_out };
-        block_store_partials<2>(acc, outs, red);
+        if (!zeta.tickets) block_store_partials<2>(acc, outs, red);
+        else {
+            // block_store_partials<2> with WRITE-THROUGH stores of the two partials (agent scope: the last workgroup may sit on another XCD, behind
+            // another L2; a full __threadfence() here would write every workgroup's dirty L2 lines back -- measured: the kernel takes twice as long),
+            // then an arrival ticket (two levels, as in block_finish_sums); the last workgroup adds the q partials in sum_partials' order and
+            // applies the test exactly as k_lm_zeta does
+            const int wlane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE, nw = (blockDim.x + THALLO_WAVE - 1) / THALLO_WAVE;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { const float w = wave_sum_all(acc[q]); if (wlane == 0) red[q * 16 + wave] = w; }
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                float w = 0.0f;
+                for (int k = 0; k < nw; ++k) w += red[threadIdx.x * 16 + k];
+                __hip_atomic_store(outs[threadIdx.x] + blockIdx.x, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x < THALLO_WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) {
+                const unsigned grp = blockIdx.x % 32, members = (gridDim.x - grp + 31) / 32, groups = gridDim.x < 32 ? gridDim.x : 32;
+                unsigned* sub = zeta.tickets + 16 + 16 * grp;
+                bool last = false;
+                if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                    __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = __hip_atomic_fetch_add(zeta.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+                }
+                red[31] = last ? 1.0f : 0.0f;
+            }
+            __syncthreads();
+            if (red[31] != 0.0f && threadIdx.x < THALLO_WAVE) {
+                const int lane = threadIdx.x, nb = gridDim.x;
+                float t[THALLO_MAX_PARTIALS / THALLO_WAVE];
+#pragma unroll
+                for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) {
+                    const int i = lane + k * THALLO_WAVE;
+                    t[k] = i < nb ? __hip_atomic_load(q_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                }
+                float Q1 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < THALLO_MAX_PARTIALS / THALLO_WAVE; ++k) Q1 += t[k];
+                Q1 = nb == 1 ? t[0] : wave_sum_all(Q1);
+                Q1 = __shfl(Q1, 0, THALLO_WAVE);                                          // (nb == 1: lane 0 holds it)
+                const float Q0 = zeta.state[0];
+                const float zt = (float)(zeta.k + 1) * (Q1 - Q0) / Q1;
+                const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < zeta.q_tolerance;
+                if (lane == 0) {
+                    __hip_atomic_store(zeta.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (stop) { reinterpret_cast<unsigned*>(zeta.state)[1] = 1u; reinterpret_cast<int*>(zeta.state)[2] = zeta.k + 1; }
+                    else zeta.state[0] = Q1;
+                }
+            }
+        }
     } else {
         block_store_partial(acc[0], bN_out, red);
     }
@@ -532,21 +585,32 @@ int thallo_hip_lm_zeta(thallo_sum_t q, int k, float q_tolerance, float* state, t
     return check_launch();
 }
 
-int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const float* Ap, const float* pre,
-                              float* z, const float* b, long n, thallo_sum_t aN, thallo_sum_t aD,
-                              float* bN_out, float* q_out, int lm, thallo_stream_t stream)
+static int step2_full(float* delta, const float* p, float* r, const float* Ap, const float* pre,
+                      float* z, const float* b, long n, thallo_sum_t aN, thallo_sum_t aD,
+                      float* bN_out, float* q_out, int lm, ZetaArgs zeta, thallo_stream_t stream)
 {
     const long n4 = (n + 3) / 4;
     const int grid = flat_grid(n4, cu_count());
     hipStream_t s = (hipStream_t)stream;
 #define L2F(PRE, LMF, HB) hipLaunchKernelGGL((k_step2_full<PRE, LMF, HB>), dim3(grid), dim3(BLOCK), 0, s, \
-        (float4*)delta, (const float4*)p, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, (const float4*)b, n4, aN, aD, bN_out, q_out, g_gate)
+        (float4*)delta, (const float4*)p, (float4*)r, (const float4*)Ap, (const float4*)pre, (float4*)z, (const float4*)b, n4, aN, aD, bN_out, q_out, g_gate, zeta)
     const bool hp = pre != nullptr, hb = (b != nullptr && q_out != nullptr);
     if (hp) { if (lm) { if (hb) L2F(true, true, true); else L2F(true, true, false); } else { if (hb) L2F(true, false, true); else L2F(true, false, false); } }
     else    { if (lm) { if (hb) L2F(false, true, true); else L2F(false, true, false); } else { if (hb) L2F(false, false, true); else L2F(false, false, false); } }
 #undef L2F
     int e = check_launch();
     return e ? e : grid;
+}
+int thallo_hip_pcg_step2_full(float* delta, const float* p, float* r, const float* Ap, const float* pre,
+                              float* z, const float* b, long n, thallo_sum_t aN, thallo_sum_t aD,
+                              float* bN_out, float* q_out, int lm, thallo_stream_t stream)
+{ return step2_full(delta, p, r, Ap, pre, z, b, n, aN, aD, bN_out, q_out, lm, ZetaArgs{ nullptr, nullptr, 0, 0.0f }, stream); }
+int thallo_hip_pcg_step2_full_zeta(float* delta, const float* p, float* r, const float* Ap, const float* pre,
+                                   float* z, const float* b, long n, thallo_sum_t aN, thallo_sum_t aD,
+                                   float* bN_out, float* q_out, unsigned* tickets, int k, float q_tolerance, float* lm_state, thallo_stream_t stream)
+{
+    if (!b || !q_out || !tickets || !lm_state) return -(int)hipErrorInvalidValue;
+    return step2_full(delta, p, r, Ap, pre, z, b, n, aN, aD, bN_out, q_out, 1, ZetaArgs{ tickets, lm_state, k, q_tolerance }, stream);
 }
 
 int thallo_hip_pcg_step3(float* p, const float* z, long n, thallo_sum_t bN, thallo_sum_t aN, int lm, thallo_stream_t stream)

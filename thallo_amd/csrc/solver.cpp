@@ -504,6 +504,9 @@ int Plan::step_lm(int ev_iter)
     const bool pc = plugin->use_preconditioner();
     const bool fold_ctc = plugin->apply_adds_ctc() && ![] { const char* e = getenv("THALLO_LM_FOLD_CTC"); return e && e[0] == '0'; }();      // (=0: A/B)
     const bool host_zeta = [] { const char* e = getenv("THALLO_LM_HOST_ZETA"); return e && e[0] == '1'; }();
+    // the zeta test by PCGStep2's last workgroup (one GPU, device-side test): one launch less per iteration.  A slab needs the GLOBAL q first.
+    if (!host_zeta && !slab && ensure_sums_buffer()) return 0;
+    const bool zeta_in_step2 = !host_zeta && !slab && ![] { const char* e = getenv("THALLO_LM_ZETA_IN_STEP2"); return e && e[0] == '0'; }();
     float* lmst = (float*)scratch_.ptr + 16;                          // 8 words: Q0, gate, iterations done, | dJJd, db, new cost
     const unsigned* gate = reinterpret_cast<const unsigned*>(lmst) + 1;
     const int ev_setup = timer_.start("Nonlinear Setup", s);
@@ -545,7 +548,7 @@ int Plan::step_lm(int ev_iter)
         if (nb < 0) { failed = true; break; }
         set_nb(jD, nb);
         if (global(jD)) { failed = true; break; }
-        int nbq;
+        int nbq; bool zeta_done = false;
         if (((k + 1) % sp.residual_reset_period) == 0) {              // :1653-1657
             TimedLaunch t(ctx, "PCGStep2");
             thallo_hip_lm_step2_first_half(v_.delta + o, p + o, n, sum(jN), sum(jD), s);
@@ -559,8 +562,10 @@ int Plan::step_lm(int ev_iter)
             nbq = nb;
         } else {
             TimedLaunch t(ctx, "PCGStep2");
-            nb = thallo_hip_pcg_step2_full(v_.delta + o, p + o, v_.r + o, v_.Ap + o, v_.pre + o, v_.z + o, v_.b + o, n, sum(jN), sum(jD), slot(jB), slot(QS), 1, s);
-            nbq = nb;
+            if (zeta_in_step2) nb = thallo_hip_pcg_step2_full_zeta(v_.delta + o, p + o, v_.r + o, v_.Ap + o, v_.pre + o, v_.z + o, v_.b + o, n, sum(jN), sum(jD), slot(jB), slot(QS),
+                                                                    v_.fin_tickets, k, sp.q_tolerance, lmst, s);
+            else nb = thallo_hip_pcg_step2_full(v_.delta + o, p + o, v_.r + o, v_.Ap + o, v_.pre + o, v_.z + o, v_.b + o, n, sum(jN), sum(jD), slot(jB), slot(QS), 1, s);
+            nbq = nb; zeta_done = zeta_in_step2;
         }
         if (nb < 0) { failed = true; break; }
         set_nb(jB, nb); set_nb(QS, nbq);
@@ -573,7 +578,7 @@ int Plan::step_lm(int ev_iter)
             if (!std::isfinite(zeta)) break;
             if (zeta < sp.q_tolerance) break;
             Q0 = Q1;
-        } else {
+        } else if (!zeta_done) {
             TimedLaunch t(ctx, "PCGZeta");
             if (thallo_hip_lm_zeta(sum(QS), k, sp.q_tolerance, lmst, s) < 0) { failed = true; break; }
         }

@@ -80,6 +80,19 @@ typedef struct thallo_fin_t {
     float*       betaN_word;
 } thallo_fin_t;
 
+/* DEFERRED finish of the one-kernel PCG iteration (thallo_hip_iw_pcg_iter*_deferred): instead of the launch's last workgroup reading the partials
+   back, the NEXT launch receives iteration k-1's raw partials -- alphaD (float) and {N, S1, S2} (double), `count` workgroups -- and every wave adds
+   them up itself while its first rows load; its workgroup 0 leaves alphaD_{k-1} / betaN_{k-1} behind in the two words.  Same summation order, same
+   bits as thallo_hip_iw_pcg_iter_finish.  The s12 buffer a launch writes must differ from the one it reads (ping-pong).  After the last iteration
+   of a GN step, thallo_hip_iw_pcg_iter_finish produces its two words. */
+typedef struct thallo_prev_t {
+    const float*  alphaD_partials;
+    const double* s12_partials;
+    int           count;
+    float*        alphaD_word;
+    float*        betaN_word;
+} thallo_prev_t;
+
 long thallo_hip_vector_elems(long n_unknowns);          /* n rounded up to a multiple of 256 */
 int  thallo_hip_device_cu_count(void);                  /* multiprocessor count of the current device */
 
@@ -298,6 +311,18 @@ int thallo_hip_iw_pcg_iter_march_dist(int W, int H, int row0, int row1, const fl
                                       thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
                                       const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out,
                                       unsigned* fin_tickets, int slot0, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* the two one-kernel iterations with the deferred finish (thallo_prev_t above): alphaN_prev = alphaN_{k-1} (a finished sum), alphaN_prev2 / alphaD_prev2 as
+   in the plain forms; `prev` is ignored for mode & 1 (first iteration of a GN step) */
+int thallo_hip_iw_pcg_iter_deferred(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,
+                                    float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                    const float* p_in, float* p_out, float* delta, int mode,
+                                    thallo_sum_t alphaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2, thallo_prev_t prev,
+                                    const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+int thallo_hip_iw_pcg_iter_march_deferred(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags,
+                                          float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                          const float* p_in, float* p_out, float* delta, int mode,
+                                          thallo_sum_t alphaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2, thallo_prev_t prev,
+                                          const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
 /* *count_out (device int) = number of pixels whose right / down UrShape neighbour is not at the exact unit offset (0 = pixel grid) */
 int thallo_hip_iw_urshape_irregular(int W, int H, const float* urshape, int* count_out, thallo_stream_t stream);
 void thallo_hip_march_debug_set(int what, int value);     /* tools/ only: 0 rows per wave segment, 1 prefetch depth, 2 non-temporal mask */

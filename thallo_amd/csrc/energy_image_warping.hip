@@ -523,7 +523,7 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
                                           thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                           float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const thallo_dist_t* dd = nullptr,
                                           unsigned* __restrict__ fin_tickets = nullptr, float* __restrict__ aD_word = nullptr, float* __restrict__ bN_word = nullptr,
-                                          int xslot = 0)
+                                          int xslot = 0, PrevSums prev = PrevSums{ nullptr, nullptr, 0, nullptr, nullptr })
 {
     constexpr int PER = TH / (NT / TW);
     const int first = mode & 1;
@@ -590,9 +590,7 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
     if (t.valid()) issue_loads(t.cur);
     float alpha = 0.0f, beta = 0.0f, alpha2 = 0.0f;
     if (!first) {
-        const float an = sum_partials(aNp.partials, aNp.count);
-        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
-        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+        iteration_scalars(aNp, aDp, bNp, prev, alpha, beta, blockIdx.x == 0 && threadIdx.x == 0);
         if (dmode == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
     }
 
@@ -726,14 +724,15 @@ __global__ __launch_bounds__(NT, MINW) void k_iter(Geo g, const float2* __restri
                                                        const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, int mode,
                                                        thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                                        float* __restrict__ aD_out, double* __restrict__ s12_out, int ntm, const int* __restrict__ irregular,
-                                                       thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot)
+                                                       thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot,
+                                                       PrevSums prev)
 {
     __shared__ TileI T;
     __shared__ float red[16];
     __shared__ double redd[48];
     const bool grid = irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) == 0;
-    if (grid) iter_body<true, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word, xslot);
-    else      iter_body<false, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word, xslot);
+    if (grid) iter_body<true, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word, xslot, prev);
+    else      iter_body<false, NT, DIST>(T, red, redd, g, cs, ur, flags, pre, wf2, wr2, r_in, r_out, A_in, A_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, ntm, &dd, fin_tickets, aD_word, bN_word, xslot, prev);
 }
 
 // one wave: alphaD_k (float partials, the usual order), S1_k, S2_k (double partials, same lane-strided order), then
@@ -868,7 +867,26 @@ int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, co
     const int grid = grid_for(g, g_iter_per_cu);
     hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
-                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word, 0);
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word, 0, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
+    int e = check_launch(); return e ? e : grid;
+}
+
+int thallo_hip_iw_pcg_iter_deferred(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,
+                                    float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                    const float* p_in, float* p_out, float* delta, int mode,
+                                    thallo_sum_t aNp, thallo_sum_t aNpp, thallo_sum_t aDpp, thallo_prev_t prev,
+                                    const int* irregular, float* aD_out, double* s12_out, thallo_stream_t stream)
+{
+    if (!rows_ok(H, row0, row1) || !r_in || !r_out || !Ap_out || !p_in || !p_out || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
+    if (!(mode & 1) && (!Ap_in || prev.count < 1 || prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_partials || !prev.s12_partials || !prev.alphaD_word || !prev.betaN_word ||
+                        prev.s12_partials == s12_out)) return -(int)hipErrorInvalidValue;
+    const Geo g = make_geo(W, H, row0, row1);
+    const int grid = grid_for(g, g_iter_per_cu);
+    const thallo_sum_t none = { nullptr, 0 };
+    const PrevSums ps = (mode & 1) ? PrevSums{ nullptr, nullptr, 0, nullptr, nullptr } : PrevSums{ prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word };
+    hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+                       w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp,
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, nullptr, nullptr, nullptr, 0, ps);
     int e = check_launch(); return e ? e : grid;
 }
 
@@ -887,7 +905,7 @@ int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* c
     const int grid = grid_for(g, g_iter_per_cu);
     hipLaunchKernelGGL((k_iter<4, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
-                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, fin_tickets, aD_word, bN_word, slot0);
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, fin_tickets, aD_word, bN_word, slot0, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
     int e = check_launch(); return e ? e : grid;
 }
 

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
                                                          const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta,
                                                          thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                                          float* __restrict__ aD_out, double* __restrict__ s12_out, const int* __restrict__ irregular,
-                                                         thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot)
+                                                         thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot,
+                                                         PrevSums prev)
 {
     __shared__ float2 lut[32];
     __shared__ float red[16];
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
     // otherwise, poison the scalars (NaN cost downstream) instead of computing with the wrong Jacobian.
     if (irregular != nullptr && __builtin_amdgcn_readfirstlane(irregular[0]) != 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && aD_word) { aD_word[0] = __builtin_nanf(""); bN_word[0] = __builtin_nanf(""); }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && prev.count > 0) { prev.aD_word[0] = __builtin_nanf(""); prev.bN_word[0] = __builtin_nanf(""); }
         if (threadIdx.x == 0) { aD_out[blockIdx.x] = __builtin_nanf(""); }
         return;
     }
@@ -166,11 +168,15 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
     float4* __restrict__ dl4 = reinterpret_cast<float4*>(delta);  float2* __restrict__ dl2 = reinterpret_cast<float2*>(delta + 2 * N);
 
     float alpha = 0.0f, beta = 0.0f, alpha2 = 0.0f;
-    if (!FIRST) {
-        const float an = sum_partials(aNp.partials, aNp.count);
-        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
-        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
-        if (DMODE == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
+    // alpha, beta are added up inside the row loop, behind the first three rows' loads (see there) -- except in the "apply two delta updates" variant,
+    // which sits at the 256-register limit and would spill around that block: it adds them up here, in front of the loop
+    constexpr bool SCALARS_IN_LOOP = DMODE != 2;
+    // the words of iteration k-1 are left behind by the one wave that owns the first segment of strip 0 (small grids leave whole workgroups --
+    // workgroup 0 included -- without rows, and a wave without rows never adds the scalars up)
+    const bool scal_writer = work && strip == 0 && ya == g.row0 && lane == 0;
+    if (!FIRST && !SCALARS_IN_LOOP) {
+        iteration_scalars<1>(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
+        alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
     }
 
     typedef Raw<FIRST> RawT;
@@ -324,6 +330,9 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
 #pragma unroll
         for (int j = 0; j < 3; ++j) { slot[j] = RawT{}; dsl[j] = RawD{}; }
         for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) {
+            // The iteration's scalars, at the start of the SECOND trip: the first trip only issued the loads of rows t_first .. t_first + 2, nothing
+            // needed alpha / beta yet; now the partial (or word) loads queue up behind those row loads and the additions run while the rows arrive.
+            if (!FIRST && SCALARS_IN_LOOP && t0 == t_first) iteration_scalars<1>(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = t0 + j;
@@ -451,7 +460,7 @@ template <bool DIST>
 int launch_march(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
                  const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
                  thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp, const int* irregular, thallo_dist_t d,
-                 float* aD_out, double* s12_out, unsigned* fin_tickets, float* aD_word, float* bN_word, int xslot, hipStream_t stream)
+                 float* aD_out, double* s12_out, unsigned* fin_tickets, float* aD_word, float* bN_word, int xslot, hipStream_t stream, PrevSums prev = PrevSums{ nullptr, nullptr, 0, nullptr, nullptr })
 {
     const MarchGeo g = make_march_geo(W, H, row0, row1, pick_rows(W, row1 - row0, MARCH_WG_PER_CU));
     const int grid = (g.total + 7) / 8 * 8;
@@ -460,7 +469,7 @@ int launch_march(int W, int H, int row0, int row1, const float* cs, const unsign
     const int dmode = first ? 1 : (mode >> 1) & 3;
     const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
 #define MARCH_LAUNCH(F, DM, DP, NTM, OCC, DBG) hipLaunchKernelGGL((k_iter_march<F, DM, DP, NTM, DIST, OCC, DBG>), dim3(grid), dim3(MARCH_NT), 0, stream, g, cs, flags, wf2, wr2, \
-        r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, irregular, d, fin_tickets, aD_word, bN_word, xslot)
+        r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, irregular, d, fin_tickets, aD_word, bN_word, xslot, prev)
 #define MARCH_BY_MODE(DP, NTM, OCC, DBG) do { if (first) MARCH_LAUNCH(true, 1, DP, NTM, OCC, DBG); else if (dmode == 1) MARCH_LAUNCH(false, 1, DP, NTM, OCC, DBG); \
         else if (dmode == 2) MARCH_LAUNCH(false, 2, DP, NTM, OCC, DBG); else MARCH_LAUNCH(false, 0, DP, NTM, OCC, DBG); } while (0)
     bool launched = false;
@@ -495,6 +504,22 @@ int thallo_hip_iw_pcg_iter_march(int W, int H, int row0, int row1, const float* 
     if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
     return launch_march<false>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode,
                                aNp, aDp, bNp, aNpp, aDpp, irregular, thallo_dist_t{}, aD_out, s12_out, fin_tickets, aD_word, bN_word, 0, (hipStream_t)stream);
+}
+
+int thallo_hip_iw_pcg_iter_march_deferred(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags,
+                                          float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,
+                                          const float* p_in, float* p_out, float* delta, int mode,
+                                          thallo_sum_t aNp, thallo_sum_t aNpp, thallo_sum_t aDpp, thallo_prev_t prev,
+                                          const int* irregular, float* aD_out, double* s12_out, thallo_stream_t stream)
+{
+    if (row0 < 0 || row1 > H || row0 >= row1 || (W & 1) || W < 2) return -(int)hipErrorInvalidValue;
+    if (!cs || !flags || !r_in || !r_out || !Ap_out || !p_in || !p_out || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
+    if (!(mode & 1) && (!Ap_in || !delta || prev.count < 1 || prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_partials || !prev.s12_partials || !prev.alphaD_word ||
+                        !prev.betaN_word || prev.s12_partials == s12_out)) return -(int)hipErrorInvalidValue;
+    const thallo_sum_t none = { nullptr, 0 };
+    return launch_march<false>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode,
+                               aNp, none, none, aNpp, aDpp, irregular, thallo_dist_t{}, aD_out, s12_out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream,
+                               (mode & 1) ? PrevSums{ nullptr, nullptr, 0, nullptr, nullptr } : PrevSums{ prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word });
 }
 
 int thallo_hip_iw_pcg_iter_march_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags,

@@ -30,6 +30,53 @@ __device__ __forceinline__ double wave_sum_all_d(double v)
     return v;
 }
 
+// The scalars a one-kernel PCG iteration starts from: alpha_{k-1} = alphaN_{k-1} / alphaD_{k-1}, beta_{k-1} = betaN_{k-1} / alphaN_{k-1}.
+// Either from the finished words of iteration k-1 (aDp, bNp), or -- prev.count > 0, the DEFERRED finish -- from its raw per-workgroup
+// partials: every wave adds them itself in k_iter_finish's order (same bits in every wave of every workgroup; the slots are L2-resident,
+// the additions overlap the first row loads), and one designated thread leaves alphaD_{k-1}, betaN_{k-1} behind as words for later consumers.
+// That takes the last-workgroup read-back (three dependent L2 round trips at the END of a launch, nothing to overlap them with) off the
+// critical path between two dependent launches.
+// U = slots per lane whose loads are in flight together (the marching kernel adds up with U = 1: it does so behind its first row loads, which
+// hide the round trips, and has no registers to spare there).
+struct PrevSums { const float* aD_part; const double* s12_part; int count; float* aD_word; float* bN_word; };
+template <int U = 4>
+__device__ __forceinline__ void iteration_scalars(thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, const PrevSums& prev, float& alpha, float& beta, bool writer)
+{
+    const float an = sum_partials(aNp.partials, aNp.count);
+    float ad, bn;
+    if (prev.count > 0) {
+        const int lane = threadIdx.x & (THALLO_WAVE - 1), nb = prev.count;
+        if (U == 1) {           // lean form: same additions in the same order as sum_partials, one load in flight, no staging registers
+            float t = 0.0f;
+            for (int i = lane; i < nb; i += THALLO_WAVE) t += prev.aD_part[i];
+            ad = nb == 1 ? prev.aD_part[0] : wave_sum_all(t);
+        } else ad = sum_partials(prev.aD_part, nb);
+        double n = 0.0, a1 = 0.0, b1 = 0.0;
+        for (int i0 = lane; i0 < nb; i0 += U * THALLO_WAVE) {             // U slots per lane and round in flight; additions in index order
+            double v[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * THALLO_WAVE;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v[u][q] = i < nb ? prev.s12_part[3 * i + q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { n += v[u][0]; a1 += v[u][1]; b1 += v[u][2]; }
+        }
+        n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
+        alpha = safe_div<false>(an, ad);
+        double bd = n - 2.0 * (double)alpha * a1 + (double)alpha * (double)alpha * b1;
+        if (!(bd > 0.0)) bd = 0.0;
+        bn = (float)bd;
+        if (writer) { prev.aD_word[0] = ad; prev.bN_word[0] = bn; }      // writer: exactly ONE thread of the launch, one that certainly gets here
+    } else {
+        ad = sum_partials(aDp.partials, aDp.count);
+        bn = sum_partials(bNp.partials, bNp.count);
+        alpha = safe_div<false>(an, ad);
+    }
+    beta = safe_div<false>(bn, an);
+}
+
 // End of a one-kernel PCG iteration, called by every thread of the workgroup with its private sums: float alphaD partial + the three
 // double sums, one set per workgroup; with fin_tickets the launch's last workgroup also finishes alphaD_k / betaN_k (single GPU) or
 // IS the cross-rank exchange (DIST).  red >= 16 floats, redd >= 48 doubles of LDS.

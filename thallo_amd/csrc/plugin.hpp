@@ -64,6 +64,8 @@ struct SolverVectors {
     // one-kernel-per-iteration schedule (plugins with one_kernel_iteration()): r and Ap ping-pong like p; per-workgroup double sums
     float *r2 = nullptr, *Ap2 = nullptr;
     double* s12 = nullptr;                       // 3 * THALLO_HIP_MAX_PARTIALS doubles (N, S1, S2 per workgroup)
+    double* s12b = nullptr;                      // its ping-pong partner (deferred finish: a launch reads the previous iteration's sums while it writes its own)
+    double* s12buf(int i) { return i ? s12b : s12; }
     unsigned* fin_tickets = nullptr;             // THALLO_HIP_FIN_TICKET_WORDS zeroed words (in-kernel finish of the iteration's scalars)
     float* rbuf(int i) { return i ? r2 : r; }
     float* Abuf(int i) { return i ? Ap2 : Ap; }
@@ -113,6 +115,13 @@ public:
     virtual int pcg_iter(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, float* /*alphaD_out*/,
                          float* /*aD_word*/, float* /*bN_word*/) { return -1; }
     virtual int pcg_iter_finish(LaunchCtx&, SolverVectors&, const float* /*alphaD_partials*/, int /*count*/, thallo_sum_t /*alphaN*/, float* /*alphaD_word*/, float* /*betaN_word*/) { return -1; }
+    // Deferred finish (thallo_hip.h thallo_prev_t): iteration k's launch adds up iteration k-1's partials itself (prev; ignored for the first iteration
+    // of a GN step) and writes its own {N, S1, S2} partials to s12_out (!= prev.s12_partials); pcg_iter_finish_from finishes the LAST iteration.
+    virtual bool iter_defers_finish() const { return false; }
+    virtual int pcg_iter_deferred(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t /*alphaN_prev*/, thallo_sum_t /*alphaN_prev2*/, thallo_sum_t /*alphaD_prev2*/,
+                                  const thallo_prev_t& /*prev*/, float* /*alphaD_out*/, double* /*s12_out*/) { return -1; }
+    virtual int pcg_iter_finish_from(LaunchCtx&, const float* /*alphaD_partials*/, const double* /*s12_partials*/, int /*count*/, thallo_sum_t /*alphaN*/,
+                                     float* /*alphaD_word*/, float* /*betaN_word*/) { return -1; }
     // PCGStep2 (r -= alpha Ap, z = M^-1 r, betaN partials); default = the energy-independent flat kernel
     virtual int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* betaN_out)
     {

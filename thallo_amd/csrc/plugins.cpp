@@ -261,6 +261,24 @@ public:
         TimedLaunch t(c, "PCGScalars");
         return thallo_hip_iw_pcg_iter_finish(part, v.s12, count, aN, aD_word, bN_word, c.stream);
     }
+    bool iter_defers_finish() const override { return true; }
+    int pcg_iter_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aN2, thallo_sum_t aD2, const thallo_prev_t& prev,
+                          float* out, double* s12_out) override
+    {
+        TimedLaunch t(c, "PCGIteration");
+        if (march_)
+            return thallo_hip_iw_pcg_iter_march_deferred(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                         v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                                         aN, aN2, aD2, prev, (const int*)irregular.ptr, out, s12_out, c.stream);
+        return thallo_hip_iw_pcg_iter_deferred(W, H, row0_, row1_, (const float*)cs.ptr, urshape, (const unsigned char*)flags.ptr, v.pre, w_fit, w_reg,
+                                               v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                               aN, aN2, aD2, prev, (const int*)irregular.ptr, out, s12_out, c.stream);
+    }
+    int pcg_iter_finish_from(LaunchCtx& c, const float* part, const double* s12p, int count, thallo_sum_t aN, float* aD_word, float* bN_word) override
+    {
+        TimedLaunch t(c, "PCGScalars");
+        return thallo_hip_iw_pcg_iter_finish(part, s12p, count, aN, aD_word, bN_word, c.stream);
+    }
     int pcg_step1_mode(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN,
                        thallo_sum_t aN2, thallo_sum_t aD2, float* out) override
     {

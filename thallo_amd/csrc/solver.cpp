@@ -187,6 +187,7 @@ void Plan::read_ab_switches()
     expanded_      = !off("THALLO_EXPANDED");         // 0: three-kernel form even where applyJTJ can return the sums
     fin_in_kernel_ = !off("THALLO_FIN_IN_KERNEL");    // 0: the iteration's scalars by a separate one-wave launch
     batch_delta_   = !off("THALLO_BATCH_DELTA");      // 0: delta += alpha p every iteration instead of every other one
+    defer_finish_  = !off("THALLO_DEFER_FINISH");     // 0: the one-kernel iteration's scalars by its own last workgroup instead of by the next launch
 }
 
 void Plan::set_param(const char* name, const void* value)
@@ -388,7 +389,25 @@ int Plan::step_gn_one_kernel(int ev_iter)
     set_nb(B, nb); finish(B);
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
-    for (int k = 0; k < L; ++k) {
+    // Deferred finish (the default where the plugin offers it; THALLO_DEFER_FINISH=0: A/B): the launch of iteration k adds up iteration k-1's partials
+    // itself -- alphaD_{k-1} and betaN_{k-1} = N - 2 alpha S1 + alpha^2 S2 -- while its first rows load, instead of iteration k-1's last workgroup
+    // reading them back at the very end of its launch; one one-wave launch per GN step finishes the last iteration.
+    const bool defer = defer_finish_ && plugin->iter_defers_finish();
+    int nb_prev = 0;
+    for (int k = 0; k < (defer ? L : 0); ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        const thallo_prev_t prev = { k ? slot(jD - 2) : nullptr, v_.s12buf((k - 1) & 1), nb_prev, k ? scal(jD - 2) : nullptr, k ? scal(jB - 2) : nullptr };
+        nb = plugin->pcg_iter_deferred(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ ? 1 : 0), sum(k ? jN - 2 : jN), sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD),
+                                       prev, slot(jD), v_.s12buf(k & 1));
+        if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
+        if (k) { fin_[jD - 2] = 1; set_nb(jB - 2, 1); fin_[jB - 2] = 1; }      // (that launch's workgroup 0 writes the two words of iteration k-1)
+        set_nb(jD, nb); nb_prev = nb; cur_ ^= 1;
+        if (k == L - 1) {
+            if (plugin->pcg_iter_finish_from(ctx, slot(jD), v_.s12buf(k & 1), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
+            fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+        }
+    }
+    for (int k = 0; k < (defer ? 0 : L); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
         nb = plugin->pcg_iter(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ ? 1 : 0), sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
@@ -458,6 +477,7 @@ int Plan::ensure_sums_buffer()
 {   // per-workgroup double sums + the arrival tickets of the in-kernel finish
     auto get = [&](size_t bytes) -> void* { DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b); return b->alloc(bytes) ? nullptr : b->ptr; };
     if (!v_.s12 && !(v_.s12 = (double*)get((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double)))) return -1;
+    if (!v_.s12b && !(v_.s12b = (double*)get((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double)))) return -1;
     if (!v_.fin_tickets && !(v_.fin_tickets = (unsigned*)get(THALLO_HIP_FIN_TICKET_WORDS * sizeof(unsigned)))) return -1;
     return 0;
 }

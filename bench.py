@@ -39,8 +39,8 @@ FUSED_BYTES_STEP1 = 75          # two-kernel A/B schedule: fused PCGStep3 + delt
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--liters", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")

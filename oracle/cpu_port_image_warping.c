@@ -152,18 +152,24 @@ int orc_cpu_port_image_warping(int W, int H, float* O, float* A, const float* U,
  * the thread that will stream it (static schedule, same partition as the PCG loops), so that on a multi-socket host the pages sit next to their
  * threads.  pin = 0 undoes the pinning. */
 static int g_pinned = 0;
+static cpu_set_t g_all;            /* the mask the process had before the first pinning: what pin = 0 restores (NOT the caller's current mask -- the
+                                      caller is thread 0 of the team and is itself pinned to one CPU at that point) */
+static int g_have_all = 0;
 static void pin_threads(int pin)
 {
-    cpu_set_t all; CPU_ZERO(&all);
-    if (sched_getaffinity(0, sizeof(all), &all) != 0) return;
+    if (!g_have_all) {
+        CPU_ZERO(&g_all);
+        if (sched_getaffinity(0, sizeof(g_all), &g_all) != 0) return;
+        g_have_all = 1;
+    }
     int cpus[CPU_SETSIZE], nc = 0;
-    for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &all)) cpus[nc++] = c;
+    for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &g_all)) cpus[nc++] = c;
     if (nc == 0) return;
     int ok = 1;
 #pragma omp parallel reduction(&&:ok)
     {
         cpu_set_t one;
-        if (pin) { CPU_ZERO(&one); CPU_SET(cpus[omp_get_thread_num() % nc], &one); } else one = all;
+        if (pin) { CPU_ZERO(&one); CPU_SET(cpus[omp_get_thread_num() % nc], &one); } else one = g_all;
         ok = sched_setaffinity(0, sizeof(one), &one) == 0;
     }
     g_pinned = pin && ok;

@@ -470,8 +470,11 @@ int launch_march(int W, int H, int row0, int row1, const float* cs, const unsign
     const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
 #define MARCH_LAUNCH(F, DM, DP, NTM, OCC, DBG) hipLaunchKernelGGL((k_iter_march<F, DM, DP, NTM, DIST, OCC, DBG>), dim3(grid), dim3(MARCH_NT), 0, stream, g, cs, flags, wf2, wr2, \
         r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, irregular, d, fin_tickets, aD_word, bN_word, xslot, prev)
+    // (the multi-GPU variant has no "apply two delta updates" form: peer stores on top of that variant's 256 registers spill, and at slab sizes the
+    //  6 B/pixel it saves do not matter -- solver_dist.cpp updates delta every iteration on the device-side transport)
+    if (DIST && dmode == 2) return -(int)hipErrorInvalidValue;
 #define MARCH_BY_MODE(DP, NTM, OCC, DBG) do { if (first) MARCH_LAUNCH(true, 1, DP, NTM, OCC, DBG); else if (dmode == 1) MARCH_LAUNCH(false, 1, DP, NTM, OCC, DBG); \
-        else if (dmode == 2) MARCH_LAUNCH(false, 2, DP, NTM, OCC, DBG); else MARCH_LAUNCH(false, 0, DP, NTM, OCC, DBG); } while (0)
+        else if (dmode == 2) { if constexpr (!DIST) MARCH_LAUNCH(false, 2, DP, NTM, OCC, DBG); } else MARCH_LAUNCH(false, 0, DP, NTM, OCC, DBG); } while (0)
     bool launched = false;
 #ifdef THALLO_MARCH_SWEEP
     if constexpr (!DIST) {

@@ -865,7 +865,15 @@ int thallo_hip_iw_pcg_iter(int W, int H, int row0, int row1, const float* cs, co
     if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
     const Geo g = make_geo(W, H, row0, row1);
     const int grid = grid_for(g, g_iter_per_cu);
-    hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+    // two register budgets of the same kernel: up to one workgroup per CU (every image the plugin sends here by default: < 0.4 Mpixel) the
+    // 139 registers it wants, no scratch; beyond that the 128-register build -- two workgroups per CU, 28 B/lane of scratch -- is 30 % faster
+    // (2048^2 with an irregular UrShape: 9.0 vs 11.8 ms per GN step)
+    if (grid <= thallo_hip_device_cu_count())
+        hipLaunchKernelGGL((k_iter<3, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+                       w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word, 0, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
+    else
+        hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
                        aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, fin_tickets, aD_word, bN_word, 0, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
     int e = check_launch(); return e ? e : grid;
@@ -884,7 +892,15 @@ int thallo_hip_iw_pcg_iter_deferred(int W, int H, int row0, int row1, const floa
     const int grid = grid_for(g, g_iter_per_cu);
     const thallo_sum_t none = { nullptr, 0 };
     const PrevSums ps = (mode & 1) ? PrevSums{ nullptr, nullptr, 0, nullptr, nullptr } : PrevSums{ prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word };
-    hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+    // two register budgets of the same kernel: up to one workgroup per CU (every image the plugin sends here by default: < 0.4 Mpixel) the
+    // 139 registers it wants, no scratch; beyond that the 128-register build -- two workgroups per CU, 28 B/lane of scratch -- is 30 % faster
+    // (2048^2 with an irregular UrShape: 9.0 vs 11.8 ms per GN step)
+    if (grid <= thallo_hip_device_cu_count())
+        hipLaunchKernelGGL((k_iter<3, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+                       w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp,
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, nullptr, nullptr, nullptr, 0, ps);
+    else
+        hipLaunchKernelGGL((k_iter<4, 512, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp,
                        aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, thallo_dist_t{}, nullptr, nullptr, nullptr, 0, ps);
     int e = check_launch(); return e ? e : grid;
@@ -903,7 +919,15 @@ int thallo_hip_iw_pcg_iter_dist(int W, int H, int row0, int row1, const float* c
     if ((!(mode & 1) && !Ap_in) || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1);
     const int grid = grid_for(g, g_iter_per_cu);
-    hipLaunchKernelGGL((k_iter<4, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+    // two register budgets of the same kernel: up to one workgroup per CU (every image the plugin sends here by default: < 0.4 Mpixel) the
+    // 139 registers it wants, no scratch; beyond that the 128-register build -- two workgroups per CU, 28 B/lane of scratch -- is 30 % faster
+    // (2048^2 with an irregular UrShape: 9.0 vs 11.8 ms per GN step)
+    if (grid <= thallo_hip_device_cu_count())
+        hipLaunchKernelGGL((k_iter<3, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
+                       w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
+                       aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, fin_tickets, aD_word, bN_word, slot0, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
+    else
+        hipLaunchKernelGGL((k_iter<4, 512, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, g, (const float2*)cs, (const float2*)urshape, flags, pre,
                        w_fit * w_fit, w_reg * w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp,
                        aD_out, s12_out, g_iter_nt, g_no_grid ? nullptr : irregular, d, fin_tickets, aD_word, bN_word, slot0, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
     int e = check_launch(); return e ? e : grid;

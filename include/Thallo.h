@@ -145,7 +145,11 @@ int ThalloX_FrontendText(const char* filename, int what, char* out, int cap);
  *     (hipIpc-mapped fine-grained memory) and its last workgroup waits for the peers' granules.
  * Supported: image_warping (one ghost row per neighbour; UrShape on the unit pixel grid, W % 4 == 0; Gauss-Newton; both transports) and
  * shape_from_shading (TWO ghost rows per neighbour; Gauss-Newton and ThalloX_EnableLM; all-gather transport: per PCG iteration one exchange
- * in the GN form, two -- alphaD, then betaN + q + the ghost rows of z -- in the LM form).  Everything else returns an error.
+ * in the GN form, two -- alphaD, then betaN + q + the ghost rows of z -- in the LM form).
+ * Graph energies (arap_mesh_deformation) are split into contiguous VERTEX RANGES instead: every rank makes its Plan for the WHOLE problem, passes the
+ * whole (replicated) buffers, and sets row0 / row1 to the vertex range it owns (equal ranges: N % world == 0); per PCG iteration one all-gather
+ * of [alphaD, N, S1, S2 | the owned slice of A p]; the unknowns stay replicated bit for bit.  Gauss-Newton, all-gather transport.
+ * Everything else returns an error.
  * ------------------------------------------------------------------------------------------ */
 /* Every rank contributes `bytes_per_rank` bytes at `send` and receives world * bytes_per_rank at `recv`, rank order; DEVICE pointers;
  * enqueued on `stream` (a hipStream_t).  Return 0 on success.  world == 1: may be NULL. */

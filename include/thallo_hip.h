@@ -180,6 +180,9 @@ int thallo_hip_linear_update(float* X, const float* delta, const float* p, long 
 int thallo_hip_slab_pack_iter(const float* vec, thallo_segs_t segs, const float* alphaD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream);
 int thallo_hip_slab_unpack_iter(float* vec, thallo_segs_t top, const float* src_top, thallo_segs_t bot, const float* src_bot,
                                 const float* gathered, long stride, int world, thallo_sum_t alphaN, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* Range partition (graph domains): after an all-gather of messages that carry every rank's owned slice of each plane of a flat vector (equal slices),
+   vec[first.off[j] + r * first.len[j] + i] = gathered[r * stride + skip + (pieces before j) + i] for every rank r and piece j (`first` = rank 0's pieces) */
+int thallo_hip_range_unpack(float* vec, thallo_segs_t first_rank_pieces, const float* gathered, long stride, long skip, int world, thallo_stream_t stream);
 /* X += delta + alpha_older * p_older + alpha * p (in that order): the tail of a GN step whose last two delta updates were
    deferred (THALLO_IW_STEP1_MODE batching with an even number of PCG iterations) */
 int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older, thallo_sum_t alphaN_older, thallo_sum_t alphaD_older,

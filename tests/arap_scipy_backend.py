@@ -1,27 +1,36 @@
-"""CPU compute backend for thallo_amd.distributed_graph.GraphPartSolver -- TEST INFRASTRUCTURE (oracle CSR + scipy)."""
+"""CPU mirror of the RANGE form of the multi-GPU Gauss-Newton step (thallo_amd/csrc/solver_dist.cpp Plan::dist_gn_range) for the vertex-partitioned
+graph energies -- TEST INFRASTRUCTURE (oracle CSR + scipy, torch.distributed / gloo).  The executable statement of that schedule:
+every rank holds the whole problem and FULL-length vectors, applies J^T J for its own vertex range only, does the vector update for ALL unknowns
+redundantly, and per PCG iteration ONE all-gather of [alphaD | N, S1, S2 | the owned slice of A p] travels; partial sums are added in rank order.
+"""
 import numpy as np
 import scipy.sparse as sp
 import torch
+import torch.distributed as dist
 
 from oracle import oracle as orc
 
 F = np.float32
 
 
-class ScipyArapPartBackend:
-    def __init__(self, part, params, max_l_iters):
+def _allgather(vec, world):
+    t = torch.from_numpy(np.ascontiguousarray(vec))
+    out = [torch.empty_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(out, t)
+    else:
+        out = [t]
+    return [o.numpy() for o in out]
+
+
+class ArapRangeMirror:
+    def __init__(self, part, params):
         self.part = part
         self.params = [a.copy() if isinstance(a, np.ndarray) else a for a in params]
         N, E = self.params[2].shape[0], self.params[6].shape[0]
         self.N, self.E, self.n = N, E, 6 * N
-        z = lambda: torch.zeros(self.n, dtype=torch.float32)
-        self.r, self.pre, self.z, self.delta, self.Ap = z(), z(), z(), z(), z()
-        self.p = [z(), z()]
-        self.S = torch.zeros(2 * max_l_iters + 8, dtype=torch.float32)
-        self.position, self.angle = torch.from_numpy(self.params[2]), torch.from_numpy(self.params[3])
-        self.rng = (3 * part.n0, 3 * part.chunk, 3 * N + 3 * part.n0, 3 * part.chunk)
         own = np.zeros(self.n, bool)
-        own[self.rng[0]:self.rng[0] + self.rng[1]] = True; own[self.rng[2]:self.rng[2] + self.rng[3]] = True
+        own[3 * part.n0:3 * part.n1] = True; own[3 * N + 3 * part.n0:3 * N + 3 * part.n1] = True
         self.own = own
         v0 = self.params[6]
         rows_own = np.zeros(3 * N + 3 * E, bool)
@@ -32,68 +41,58 @@ class ScipyArapPartBackend:
     def _problem(self):
         return orc.Problem(orc.ARAP_MESH, (self.N, self.E), self.params)
 
-    def cost_local(self, out_idx):
+    def _replicate(self, vec):
+        """every rank's owned slices of `vec` (two planes) into place; returns the full vector"""
+        N, w = self.N, self.part.world
+        got = _allgather(vec[self.own], w)
+        full = np.empty_like(vec)
+        for r, g in enumerate(got):
+            c = self.part.chunk
+            full[3 * c * r:3 * c * (r + 1)] = g[:3 * c]; full[3 * N + 3 * c * r:3 * N + 3 * c * (r + 1)] = g[3 * c:]
+        return full
+
+    def cost(self):
         res = self._problem().csr()[3].astype(np.float64)
-        self.S[out_idx] = float(0.5 * (res[self.rows_own] ** 2).sum())
+        mine = np.array([0.5 * (res[self.rows_own] ** 2).sum()], np.float64)
+        return float(sum(F(g[0]) for g in _allgather(mine, self.part.world)))
 
-    def init(self, cur, out_idx):
+    def gn_step(self, L):
+        w, own = self.part.world, self.own
         rp, col, val, res = self._problem().csr()
-        self.J = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(len(res), self.n))
-        own = self.own
-        r = (-(self.J.T @ res.astype(np.float64))).astype(F)
-        d = np.asarray(self.J.multiply(self.J).sum(0)).ravel().astype(F)
-        m = (F(1) / (F(1) + np.sqrt(d)) ** 2).astype(F)
-        self.r.numpy()[own] = r[own]; self.pre.numpy()[own] = m[own]; self.z.numpy()[own] = (m * r)[own]
-        self.p[cur].zero_(); self.delta.zero_()
-        self.S[out_idx] = float((r[own].astype(np.float64) * (m * r)[own]).sum())
-
-    def _ab(self, first, iN, iD, iB):
-        if first:
-            return F(0), F(0)
-        aN, aD, bN = F(self.S[iN]), F(self.S[iD]), F(self.S[iB])
-        return (aN / aD if aD != 0 else F(0)), (bN / aN if aN != 0 else F(0))
-
-    def pupdate(self, cur, first, iN, iD, iB):
-        alpha, beta = self._ab(first, iN, iD, iB)
-        own = self.own
-        pin = self.p[cur].numpy()
-        if not first:
-            self.delta.numpy()[own] += alpha * pin[own]
-        self.p[cur ^ 1].numpy()[own] = self.z.numpy()[own] + beta * pin[own]
-
-    def owned_slices(self, vec):
-        o0, l0, o1, l1 = self.rng
-        return vec[o0:o0 + l0], vec[o1:o1 + l1]
-
-    def full_slices(self, vec):
-        return vec[:3 * self.N], vec[3 * self.N:6 * self.N]
-
-    def apply(self, cur, out_idx):
-        pv = self.p[cur].numpy().astype(np.float64)
-        ap = (self.J.T @ (self.J @ pv)).astype(F)
-        self.Ap.numpy()[self.own] = ap[self.own]
-        self.S[out_idx] = float((pv[self.own] * ap[self.own]).sum())
-
-    def step2(self, iN, iD, out_idx):
-        aN, aD = F(self.S[iN]), F(self.S[iD])
-        alpha = aN / aD if aD != 0 else F(0)
-        own = self.own
-        self.r.numpy()[own] -= alpha * self.Ap.numpy()[own]
-        self.z.numpy()[own] = self.pre.numpy()[own] * self.r.numpy()[own]
-        self.S[out_idx] = float((self.z.numpy()[own].astype(np.float64) * self.r.numpy()[own]).sum())
-
-    def linear_update(self, cur, iN, iD, with_p):
-        own = self.own
-        d = self.delta.numpy().copy()
-        if with_p:
-            aN, aD = F(self.S[iN]), F(self.S[iD])
-            d += (aN / aD if aD != 0 else F(0)) * self.p[cur].numpy()
+        J = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(len(res), self.n))
+        r = (-(J.T @ res.astype(np.float64))).astype(F)
+        d = np.asarray(J.multiply(J).sum(0)).ravel().astype(F)
+        pre = (F(1) / (F(1) + np.sqrt(d)) ** 2).astype(F)
+        z = pre * r
+        aN = F(sum(F(g[0]) for g in _allgather(np.array([(r[own].astype(np.float64) * z[own]).sum()]), w)))       # rank-ordered
+        r, pre = self._replicate(r), self._replicate(pre)                            # (identical here; on the GPU only the owned slices are computed)
+        p = np.zeros(self.n, F); delta = np.zeros(self.n, F); Ap = np.zeros(self.n, F)
+        alpha = beta = F(0)
+        for k in range(L):
+            if k:                                                                    # pcg_update over ALL unknowns, redundantly
+                r = (r - alpha * Ap).astype(F); delta = (delta + alpha * p).astype(F)
+            p = (pre * r + beta * p).astype(F)
+            ap = (J.T @ (J @ p.astype(np.float64))).astype(F)
+            m64, r64, a64, p64 = pre[own].astype(np.float64), r[own].astype(np.float64), ap[own].astype(np.float64), p[own].astype(np.float64)
+            msg = np.concatenate([[(p64 * a64).sum(), (m64 * r64 * r64).sum(), (m64 * r64 * a64).sum(), (m64 * a64 * a64).sum()], ap[own].astype(np.float64)])
+            got = _allgather(msg, w)                                                 # ONE exchange per PCG iteration
+            aD = F(sum(F(g[0]) for g in got)); n_, s1, s2 = (sum(g[i] for g in got) for i in (1, 2, 3))
+            c, N = self.part.chunk, self.N
+            for rk, g in enumerate(got):
+                Ap[3 * c * rk:3 * c * (rk + 1)] = g[4:4 + 3 * c]; Ap[3 * N + 3 * c * rk:3 * N + 3 * c * (rk + 1)] = g[4 + 3 * c:]
+            alpha = aN / aD if aD != 0 else F(0)
+            bN = F(max(n_ - 2.0 * float(alpha) * s1 + float(alpha) ** 2 * s2, 0.0))
+            beta = bN / aN if aN != 0 else F(0)
+            aN = bN
+        if L:
+            delta = (delta + alpha * p).astype(F)
         N = self.N
-        self.params[2].reshape(-1)[own[:3 * N]] += d[:3 * N][own[:3 * N]]
-        self.params[3].reshape(-1)[own[3 * N:]] += d[3 * N:][own[3 * N:]]
+        self.params[2].reshape(-1)[:] += delta[:3 * N]                               # every rank updates every unknown: they stay replicated
+        self.params[3].reshape(-1)[:] += delta[3 * N:]
 
-    def unknown_views(self):
-        return self.position.view(-1), self.angle.view(-1)
-
-    def scalar(self, idx):
-        return float(self.S[idx])
+    def solve(self, nit, lit):
+        costs = [self.cost()]
+        for _ in range(nit):
+            self.gn_step(lit)
+            costs.append(self.cost())
+        return costs

@@ -147,15 +147,15 @@ def test_ba_camera_shards_match_single_domain_oracle(orc, world, dims):
 
 # ------------------------------------------------------------------ vertex-partitioned ARAP
 def _arap_worker(rank, world, port, nu, nv, nit, lit, q):
-    from thallo_amd.distributed_graph import VertexPartition, GraphPartSolver
-    from arap_scipy_backend import ScipyArapPartBackend
+    from thallo_amd.distributed_graph import VertexPartition
+    from arap_scipy_backend import ArapRangeMirror
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.arap_mesh(nu, nv, n_handles=6, angle_amp=0.3)
         part = VertexPartition(p[2].shape[0], rank, world)
-        be = ScipyArapPartBackend(part, p, lit)
-        costs = GraphPartSolver(be, part).solve(nit, lit)
+        be = ArapRangeMirror(part, p)
+        costs = be.solve(nit, lit)
         q.put((rank, costs, be.params[2].copy(), be.params[3].copy()))
     finally:
         dist.destroy_process_group()

@@ -224,20 +224,21 @@ def _arap_worker(rank, world, port, nu, nv, nit, lit, q):
     import torch
     import torch.distributed as dist
     from thallo_amd import synthetic as syn
-    from thallo_amd.distributed_graph import make_hip_arap_solver
+    from thallo_amd.distributed_graph import PlanArapSolver
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
-        solver, part = make_hip_arap_solver(p, rank, world, lit)
-        costs = solver.solve(nit, lit)
-        q.put((rank, costs, solver.be.position.cpu().numpy(), solver.be.angle.cpu().numpy()))
+        solver = PlanArapSolver(p, rank, world, lit)
+        costs = solver.solve(nit)
+        q.put((rank, costs, solver.position.cpu().numpy(), solver.angle.cpu().numpy(), solver.solver.distributed_info()))
+        solver.solver.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nu,nv,nit,lit", [(2, 40, 30, 3, 40), (3, 24, 16, 3, 20)])
+@pytest.mark.parametrize("world,nu,nv,nit,lit", [(2, 40, 30, 3, 40), (3, 24, 16, 3, 20), (1, 12, 8, 2, 10)])
 def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
     import torch.multiprocessing as mp
     from thallo_amd import synthetic as syn
@@ -251,9 +252,10 @@ def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
     p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
     co, _ = orc.Problem(orc.ARAP_MESH, (p[2].shape[0], p[6].shape[0]), p).solve(nIterations=nit, lIterations=lit)
     res.sort(key=lambda t: t[0])
-    for rank, costs, pos, ang in res:
+    for rank, costs, pos, ang, info in res:
+        assert info["exchange"] == "allgather" and "unit ranges" in info["form"]
         assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
-        assert costs == res[0][1] and np.array_equal(pos, res[0][2])
+        assert costs == res[0][1] and np.array_equal(pos, res[0][2]) and np.array_equal(ang, res[0][3])      # the unknowns stay replicated bit for bit
         assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
 
 

@@ -454,6 +454,20 @@ __global__ __launch_bounds__(BLOCK) void k_slab_unpack(float* __restrict__ vec, 
     }
 }
 
+// Range partition (graph domains, solver_dist.cpp): every rank's message carries its owned slice of each plane of a flat vector; rank r's slice j
+// goes to vec[first.off[j] + r * first.len[j] ...] (equal slices; `first` = the pieces of rank 0), read from gathered[r * stride + skip + ...]
+__global__ __launch_bounds__(BLOCK) void k_range_unpack(float* __restrict__ vec, thallo_segs_t first, const float* __restrict__ gathered, long stride, long skip, int world)
+{
+    for (int r = 0; r < world; ++r) {
+        long base = (long)r * stride + skip;
+        for (int j = 0; j < first.n; ++j) {
+            float* __restrict__ dst = vec + first.off[j] + (long)r * first.len[j];
+            for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < first.len[j]; i += (long)gridDim.x * BLOCK) dst[i] = gathered[base + i];
+            base += first.len[j];
+        }
+    }
+}
+
 // One-kernel-per-iteration schedule over row slabs, collective transport: the message of a rank =
 //   [ alphaD_local | N, S1, S2 as (hi, lo) words | first owned row of Ap_out | last owned row of Ap_out ]
 // (7 scalars words, then the listed segments).  One all-gather of these per PCG iteration replaces the all-reduce + all-gather of
@@ -744,6 +758,15 @@ int thallo_hip_slab_unpack(float* vec, thallo_segs_t top, const float* src_top, 
 {
     if (top.n < 0 || top.n > 8 || bot.n < 0 || bot.n > 8) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_slab_unpack, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, top, src_top, bot, src_bot, gathered, stride, world, sum_out);
+    return check_launch();
+}
+
+int thallo_hip_range_unpack(float* vec, thallo_segs_t first_rank_pieces, const float* gathered, long stride, long skip, int world, thallo_stream_t stream)
+{
+    if (!vec || !gathered || first_rank_pieces.n < 1 || first_rank_pieces.n > 8 || world < 1 || stride < 1 || skip < 0) return -(int)hipErrorInvalidValue;
+    long len = 0; for (int j = 0; j < first_rank_pieces.n; ++j) len += first_rank_pieces.len[j];
+    int grid = (int)((len + BLOCK - 1) / BLOCK); if (grid > 64) grid = 64; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_range_unpack, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, vec, first_rank_pieces, gathered, stride, skip, world);
     return check_launch();
 }
 

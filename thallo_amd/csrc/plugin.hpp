@@ -141,6 +141,10 @@ public:
     virtual int  slab_width() const { return 0; }
     virtual bool slab_grid_ok() const { return false; }       // after prepare(): the precondition of the one-kernel slab schedule holds on this rank
     virtual unsigned char* slab_flags() { return nullptr; }    // per-pixel byte plane (written by pcg_init) whose ghost rows come from their owner each GN step
+    // ---- range partition (graph domains): every rank holds the whole problem and FULL-length vectors, runs the gather kernels for its own contiguous
+    // range of units (vertices) only; range_units() = how many units there are (each unknown image has n_floats / units floats per unit)
+    virtual long range_units() const { return 0; }
+    virtual int  set_owned_range(long /*u0*/, long /*u1*/) { return -1; }
     // pcg_iter that also stores its boundary rows of Ap_out into the neighbours' ghost rows and whose last workgroup runs the mailbox exchange
     virtual int  pcg_iter_dist(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t,
                                const thallo_dist_t&, float* /*alphaD_out*/, int /*slot0*/, float* /*aD_word*/, float* /*bN_word*/) { return -1; }

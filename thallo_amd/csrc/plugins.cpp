@@ -410,8 +410,15 @@ class ArapPlugin : public EnergyPlugin {
     float w_fit = 0, w_reg = 0;
     GraphIncidence g;
     DeviceBuffer F, G;       // per-GN-iteration edge residuals / rotation-derivative blocks (out-CSR order)
+    int n0_ = 0, n1_ = 0;    // owned vertices (all of them unless the Plan is one rank of a vertex-partitioned multi-GPU run)
 public:
-    ArapPlugin(const unsigned* dims) : N((int)dims[0]), E((int)dims[1]) { imgs.push_back({ 2, 3L * N }); imgs.push_back({ 3, 3L * N }); }
+    ArapPlugin(const unsigned* dims) : N((int)dims[0]), E((int)dims[1]), n1_((int)dims[0]) { imgs.push_back({ 2, 3L * N }); imgs.push_back({ 3, 3L * N }); }
+    long range_units() const override { return N; }
+    int set_owned_range(long u0, long u1) override
+    {
+        if (u0 < 0 || u1 > N || u0 >= u1) { set_error("arap: vertex range [%ld,%ld) of %d", u0, u1, N); return -1; }
+        n0_ = (int)u0; n1_ = (int)u1; return 0;
+    }
     const char* name() const override { return "arap_mesh"; }
     long n_unknowns() const override { return 6L * N; }
     const std::vector<UnknownImage>& unknown_images() const override { return imgs; }
@@ -436,7 +443,7 @@ public:
     int cost(LaunchCtx& c, float* out) override
     {
         TimedLaunch t(c, "computeCost");
-        return thallo_hip_arap_cost(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, g.ell_stride, c.stream);
+        return thallo_hip_arap_cost(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, g.ell_stride, c.stream);
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
@@ -444,27 +451,27 @@ public:
           int rc = thallo_hip_arap_precompute(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, g.ell_stride, c.stream);
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
-        return thallo_hip_arap_pcg_init(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
+        return thallo_hip_arap_pcg_init(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
                                         (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, g.ell_stride, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+        return thallo_hip_arap_apply_jtj(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
                                          constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
     }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj_sums_fin(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+        return thallo_hip_arap_apply_jtj_sums_fin(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
                                                   constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, v.r, v.pre, v.s12, fin, c.stream);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj(N, 0, N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
+        return thallo_hip_arap_apply_jtj(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
                                          constraints, (const float*)G.ptr, w_fit, w_reg, v.p[cur ^ 1], v.Ap, out, g.ell_stride, c.stream);
     }
 };

@@ -237,7 +237,7 @@ void Plan::init(void** params)
     ready_ = false;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return; }
     if (plugin->prepare(ctx)) { const std::string why = last_error(); set_error("%s: prepare failed: %s", plugin->name(), why.c_str()); return; }
-    if (dist_ && !dist_->flat) {   // collective: the one-kernel slab schedule needs its precondition on EVERY rank; then (first Init) the exchange's self-check
+    if (dist_ && !dist_->flat && !dist_->range) {   // collective: the one-kernel slab schedule needs its precondition on EVERY rank; then (first Init) the exchange's self-check
         bool all = false;
         if (dist_agree(plugin->slab_grid_ok(), all)) return;
         if (!all) { set_error("%s: the row-slab schedule needs UrShape on the unit pixel grid on every rank", plugin->name()); return; }
@@ -275,7 +275,7 @@ int Plan::step(void** params)
     if (sp.lIterations < 0) { set_error("lIterations = %d is negative", sp.lIterations); if (!finalized_) finalize(); return 0; }
     if (ensure_slots(sp.lIterations)) { if (!finalized_) finalize(); return 0; }
     const int ev_iter = timer_.start("Nonlinear Iteration", ctx.stream);
-    if (dist_ && lm_ && !dist_->flat) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); if (!finalized_) finalize(); return 0; }
+    if (dist_ && lm_ && (!dist_->flat || dist_->range)) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); if (!finalized_) finalize(); return 0; }
     const int rc = lm_ ? step_lm(ev_iter) : dist_ ? step_gn_slab(ev_iter) : step_gn(ev_iter);
     if (rc == 1 && sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779
         hipStream_t s = ctx.stream;
@@ -298,7 +298,7 @@ void Plan::linear_update_tail(int L, bool batched)
     for (size_t k = 0; k < imgs.size(); ++k) {
         TimedLaunch t(ctx, "PCGLinearUpdate");
         long lo = 0, len = imgs[k].n_floats;
-        if (dist_) { const long rowlen = imgs[k].n_floats / dist_->Hl; lo = rowlen * dist_->row0; len = rowlen * (dist_->row1 - dist_->row0); }
+        if (dist_ && !dist_->range) { const long rowlen = imgs[k].n_floats / dist_->Hl; lo = rowlen * dist_->row0; len = rowlen * (dist_->row1 - dist_->row0); }
         float* X = plugin->unknown_ptr((int)k) + lo;
         const float* dl = v_.delta + off + lo;
         if (L > 1 && batched && ((L - 1) & 1))

@@ -55,6 +55,11 @@ struct DistState {
     bool flat = false;
     long rowlen = 0;                                     // floats per image row
     thallo_segs_t seg_rows_fl, seg_rows_top, seg_rows_bot;   // first / last `ghost` owned rows; the ghost rows above / below
+    // range form (graph domains: ARAP): every rank holds the whole problem and FULL-length vectors and owns the contiguous unit range [row0, row1)
+    // (units = vertices); equal ranges on all ranks.  pieces = rank 0's owned slice of every plane of the flat vector (rank r's: + r * len)
+    bool range = false;
+    thallo_segs_t pieces_first, pieces_mine;
+    long piece_floats = 0;                               // floats a rank owns in a flat vector
     // device-side exchange
     bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
     void* mail = nullptr; int mail_L = 0;
@@ -145,7 +150,9 @@ private:
     int  dist_self_check();
     int  dist_gn(int L, bool p2p);                      // PCGInit + L iterations + linear update + ghost refresh, no bookkeeping
     int  step_gn_slab(int ev_iter);
-    int  dist_gn_flat(int L);                           // flat form: pcg_update + apply_jtj_sums + ONE exchange per PCG iteration
+    int  dist_gn_flat(int L);
+    int  dist_gn_range(int L);                          // range form: full-length pcg_update + applyJTJ over the owned units + ONE exchange per PCG iteration
+    int  dist_replicate(float* vec, int sum_slot);      // every rank's owned pieces of `vec` to every rank (and, sum_slot >= 0, that slot's global sum)                           // flat form: pcg_update + apply_jtj_sums + ONE exchange per PCG iteration
     int  dist_sum_slot(int j);                          // slot j (local partials) -> scal(j) = rank-ordered global sum
     int  dist_sum_and_rows(int j, float* vec);          // ... and the ghost rows of a flat vector from the neighbours' boundary rows (j < 0: rows only)
     int  dist_exchange_unknown_rows();

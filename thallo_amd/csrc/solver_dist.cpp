@@ -66,6 +66,40 @@ int Plan::set_distributed(const ThalloX_Distributed& cfg)
 {
     if (!ok_) return -1;
     if (dist_) { set_error("distributed: already set for this plan"); return -1; }
+    if (plugin->range_units() > 0) {                           // graph domains: vertex ranges, whole problem and full-length vectors on every rank
+        const long U = plugin->range_units(), u0 = cfg.row0, u1 = cfg.row1;
+        if (lm_) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
+        if (!plugin->apply_returns_sums()) { set_error("distributed: %s has no range form", plugin->name()); return -1; }
+        if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
+        if (cfg.world > 1 && !cfg.allgather) { set_error("distributed: world > 1 needs an all-gather callback"); return -1; }
+        if (U % cfg.world || u1 - u0 != U / cfg.world || u0 != (U / cfg.world) * cfg.rank) {
+            set_error("distributed: rank %d of %d must own units [%ld,%ld) of %ld (equal contiguous ranges), got [%ld,%ld)", cfg.rank, cfg.world, (U / cfg.world) * cfg.rank, (U / cfg.world) * (cfg.rank + 1), U, u0, u1);
+            return -1;
+        }
+        if (plugin->set_owned_range(u0, u1)) return -1;
+        hipDeviceSynchronize();
+        DistState* Dp = new DistState(); DistState& D = *Dp; dist_ = Dp;
+        D.cfg = cfg; D.range = true; D.row0 = (int)u0; D.row1 = (int)u1; D.Hl = (int)U;
+        std::vector<std::pair<long, long>> first, mine;
+        long off = 0;
+        for (auto& im : plugin->unknown_images()) {
+            const long per = im.n_floats / U, len = per * (u1 - u0);
+            if (im.n_floats % U || (len & 3)) { set_error("distributed: an owned slice of %ld floats (must be a multiple of 4)", len); return -1; }
+            first.push_back({ off, len }); mine.push_back({ off + per * u0, len });
+            D.piece_floats += len; off += im.n_floats;
+        }
+        if (first.size() > 8) { set_error("distributed: more than 8 unknown images"); return -1; }
+        D.pieces_first = segs(first); D.pieces_mine = segs(mine);
+        D.msg = 1 + D.piece_floats; D.msg_iter = 7 + D.piece_floats;
+        const size_t words = (size_t)std::max(D.msg_iter, 64L);
+        if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world) || ensure_sums_buffer()) { set_error("distributed: out of device memory"); return -1; }
+        bool all = false;
+        if (dist_agree(true, all)) return -1;
+        char buf[256];
+        snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit ranges, full-length vectors\", \"rank\": %d, \"world\": %d}", cfg.rank, cfg.world);
+        D.info = buf;
+        return 0;
+    }
     const bool flat = !plugin->one_kernel_iteration();         // single-image energies in the single-reduction form (shape_from_shading); else image_warping's one-kernel form
     if (!plugin->supports_row_slabs() || (flat && (!plugin->apply_returns_sums() || plugin->unknown_images().size() != 1))) { set_error("distributed: %s has no row-slab form", plugin->name()); return -1; }
     if (lm_ && !flat) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
@@ -375,6 +409,66 @@ int Plan::dist_gn_flat(int L)
     return dist_exchange_unknown_rows();
 }
 
+// ---- range form (graph domains)
+int Plan::dist_replicate(float* vec, int sum_slot)
+{   // message = [sum of slot (if any) | my owned slice of every plane of vec]; afterwards every rank holds every rank's slices
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    const thallo_sum_t nothing = { nullptr, 0 };
+    const thallo_segs_t none = segs({});
+    if (thallo_hip_slab_pack(vec, D.pieces_mine, sum_slot >= 0 ? partial_sum(sum_slot) : nothing, send, s) < 0) return -1;
+    if (dist_allgather(send, gath, D.msg * (long)sizeof(float))) return -1;
+    if (sum_slot >= 0) {
+        if (thallo_hip_slab_unpack(nullptr, none, nullptr, none, nullptr, gath, D.msg, D.cfg.world, scal(sum_slot), s) < 0) return -1;
+        fin_[sum_slot] = 1;
+    }
+    return thallo_hip_range_unpack(vec, D.pieces_first, gath, D.msg, 1, D.cfg.world, s) < 0 ? -1 : 0;
+}
+
+int Plan::dist_gn_range(int L)
+{   // Every rank keeps FULL-length vectors (a 100k-vertex graph is 2.4 MB per vector) and does the energy-independent vector update for ALL
+    // unknowns -- redundantly, same inputs, same bits -- so the only thing that has to travel per PCG iteration is what a rank alone can
+    // compute: its owned slice of A p and its partial sums.  ONE all-gather of [alphaD | N, S1, S2 | owned slice of Ap] per iteration.
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const int B = 2, world = D.cfg.world;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    const bool pc = plugin->use_preconditioner();
+    const thallo_segs_t none = segs({});
+    cur_ = 0;
+    const size_t bytes = (size_t)v_.n_alloc * sizeof(float);
+    if (hipMemsetAsync(v_.p[0], 0, bytes, s) != hipSuccess || hipMemsetAsync(v_.delta, 0, bytes, s) != hipSuccess) return -1;      // (pcg_init clears the owned units only)
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
+    set_nb(B, nb);
+    {   TimedLaunch t(ctx, "RangeExchangeInit");
+        if (dist_replicate(v_.r, B)) return -1;                          // alphaN_0; r of every unit
+        if (pc && dist_replicate(v_.pre, -1)) return -1;
+    }
+    for (int k = 0; k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        {   TimedLaunch t(ctx, "PCGUpdate");
+            if (thallo_hip_pcg_update(v_.r, v_.Ap, pc ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
+                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return -1; }
+        }
+        cur_ ^= 1;
+        const thallo_fin_t nofin = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), nofin);
+        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return -1; }
+        set_nb(jD, nb);
+        TimedLaunch t(ctx, "RangeExchange");
+        if (thallo_hip_slab_pack_iter(v_.Ap, D.pieces_mine, slot(jD), v_.s12, nb, send, s) < 0) return -1;
+        if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
+        if (thallo_hip_slab_unpack_iter(v_.Ap, none, nullptr, none, nullptr, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
+        if (thallo_hip_range_unpack(v_.Ap, D.pieces_first, gath, D.msg_iter, 7, world, s) < 0) return -1;
+        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+    }
+    last_l_iters = L;
+    linear_update_tail(L, false);                                        // all unknowns on every rank: they stay replicated, bit for bit
+    return 0;
+}
+
 int Plan::dist_self_check()
 {   // The device-side exchange is used only if, ON THIS TOPOLOGY, one GN step through it reproduces the all-gather path's alpha / beta
     // scalars from the same unknowns (a stale ghost row or a lost granule shows up there; the two paths round identically except for the
@@ -436,7 +530,7 @@ int Plan::step_gn_slab(int ev_iter)
     const int L = sp.lIterations;
     const int ev_lin = timer_.start("Linear Solve", s);
     const bool p2p = D.p2p_on && L <= D.mail_L;                          // (same L on every rank: same decision)
-    if (D.flat ? dist_gn_flat(L) : dist_gn(L, p2p)) return 0;
+    if (D.range ? dist_gn_range(L) : D.flat ? dist_gn_flat(L) : dist_gn(L, p2p)) return 0;
     timer_.stop(ev_lin, s);
     sp.nIter++;
     timer_.stop(ev_iter, s);
@@ -461,7 +555,7 @@ int Plan::dist_control(int what, int value)
 
 int Plan::dist_kernel_only(int reps)
 {
-    if (!dist_ || !ready_ || dist_->flat) return -1;
+    if (!dist_ || !ready_ || dist_->flat || dist_->range) return -1;
     const int B = 2;
     for (int i = 0; i < reps; ++i) {
         const int nb = plugin->pcg_iter(ctx, v_, 0, 0, sum(B), sum(B + 1), sum(B + 2), sum(B), sum(B + 1), slot(B + 3), nullptr, nullptr);

@@ -582,6 +582,30 @@ def test_solver_parameters_and_perf_summary(torch):
     assert ks["PCGIteration"]["launches"] == 21 and ks["PCGScalars"]["launches"] == 3 and "PCGStep2" not in ks and ks["PCGInit1"]["launches"] == 3
 
 
+def test_linear_iteration_budgets_of_the_reference_examples(torch, orc):
+    """lIterations = 1000 (examples/arap_mesh_deformation/src/main.cpp:101,108) and 4000 (embedded_mesh_deformation): the reduction slots grow with the
+    budget (round 1 stopped silently above 509) and every iteration runs; a negative budget is an error, not a silent no-op.  (float32 CG run that far
+    past convergence on a small instance breaks down in the reference's recurrences -- oracle and GPU alike -- so the comparison is on the early alpha /
+    beta, the mechanics on the full length.)"""
+    p = syn.arap_mesh(12, 8, n_handles=8, angle_amp=0.3)
+    dims = (p[2].shape[0], p[6].shape[0])
+    _, tr = orc.Problem(orc.ARAP_MESH, dims, copy_params(p)).solve(nIterations=1, lIterations=1000, want_trace=True)
+    dev = to_device(p)
+    s = api.ThalloSolver(dims, thallo_amd.energy_file("arap_mesh_deformation"))
+    _, costs = s.solve(dev, profiled=True, nIterations=1, lIterations=1000)
+    got = np.array(s.alpha_beta_trace(cap=1200))
+    assert len(costs) == 2 and got.shape == (1000, 2)
+    assert np.abs(got[:20] - tr[:20]).max() <= 2e-3 * np.abs(tr[:20]).max()
+    W, H = 32, 24
+    q = syn.image_warping(W, H, n_markers=4)
+    s2 = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    _, c2 = s2.solve(to_device(q), profiled=True, nIterations=1, lIterations=4000)
+    assert len(c2) == 2 and len(s2.alpha_beta_trace(cap=4096)) == 4000
+    s3 = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    _, c3 = s3.solve(to_device(q), profiled=True, nIterations=2, lIterations=-3)
+    assert len(c3) == 1 and "negative" in api.last_error()
+
+
 def test_unknown_energy_and_bad_kind_fail_loudly(torch, tmp_path, monkeypatch):
     f = tmp_path / "x.t"
     f.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0) }\nr = Residuals { only = X(N()) }\n')

@@ -149,11 +149,18 @@ int ThalloX_FrontendText(const char* filename, int what, char* out, int cap);
  * Graph energies (arap_mesh_deformation) are split into contiguous VERTEX RANGES instead: every rank makes its Plan for the WHOLE problem, passes the
  * whole (replicated) buffers, and sets row0 / row1 to the vertex range it owns (equal ranges: N % world == 0); per PCG iteration one all-gather
  * of [alphaD, N, S1, S2 | the owned slice of A p]; the unknowns stay replicated bit for bit.  Gauss-Newton, all-gather transport.
+ * bundle_adjustment is split into CAMERA SHARDS: every rank makes its Plan for its SUB-INSTANCE -- its cameras (count padded to a multiple of 4 with
+ * unobserved cameras), ALL points, the observations of its cameras with camera indices renumbered locally; row0 / row1 are not used.  The camera block
+ * of J^T J p is complete on the rank; the point block is a partial sum and is all-reduced (`allreduce`, 3P floats per PCG iteration), after which
+ * every rank updates the (replicated) points identically; the scalars: one all-gather of the ranks' camera sums + the point sums every rank
+ * computes for itself.  Gauss-Newton.
  * Everything else returns an error.
  * ------------------------------------------------------------------------------------------ */
 /* Every rank contributes `bytes_per_rank` bytes at `send` and receives world * bytes_per_rank at `recv`, rank order; DEVICE pointers;
  * enqueued on `stream` (a hipStream_t).  Return 0 on success.  world == 1: may be NULL. */
 typedef int (*ThalloX_AllGatherFn)(void* user, const void* send, void* recv, long bytes_per_rank, void* stream);
+/* In-place sum over all ranks of `count` floats at `buf` (DEVICE pointer), on `stream` (ncclAllReduce, ncclSum).  Only the shard form needs it. */
+typedef int (*ThalloX_AllReduceFn)(void* user, void* buf, long count, void* stream);
 typedef struct ThalloX_Distributed {
     int rank, world;                 /* world <= 8 (THALLO_DIST_MAX_WORLD) */
     unsigned int row0, row1;         /* owned rows [row0, row1) of the local image; g ghost rows above iff row0 == g, below iff row1 == H_local - g (g = 1 or 2, see below) */
@@ -162,6 +169,7 @@ typedef struct ThalloX_Distributed {
     int device_exchange;             /* 1: try the mailbox / peer-to-peer exchange (falls back to the all-gather if its self-check fails) */
     unsigned int global_row0;        /* global index of the local image's row 0 (ghost rows included) and the global image height: energies */
     unsigned int global_rows;        /* whose expressions use pixel coordinates (shape_from_shading) need them; 0 0 = not given */
+    ThalloX_AllReduceFn allreduce;   /* bundle adjustment (camera shards) only; NULL otherwise */
 } ThalloX_Distributed;
 /* Collective.  0 on success, -1 on error (ThalloX_LastError); every rank gets the same answer. */
 int ThalloX_PlanSetDistributed(Thallo_Plan* plan, const ThalloX_Distributed* cfg);

@@ -180,6 +180,14 @@ int thallo_hip_linear_update(float* X, const float* delta, const float* p, long 
 int thallo_hip_slab_pack_iter(const float* vec, thallo_segs_t segs, const float* alphaD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream);
 int thallo_hip_slab_unpack_iter(float* vec, thallo_segs_t top, const float* src_top, thallo_segs_t bot, const float* src_bot,
                                 const float* gathered, long stride, int world, thallo_sum_t alphaN, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* Shard form (bundle adjustment across ranks): the PCG sums over a block of unknowns every rank holds in full (after the all-reduce completed A p there) --
+   alphaD partials (float) and {N, S1, S2} (double) per workgroup, returns their count; pre may be NULL (no preconditioner); n % 4 == 0 */
+int thallo_hip_block_sums(const float* p, const float* Ap, const float* r, const float* pre, long n, float* alphaD_out, double* s3_out, thallo_stream_t stream);
+/* ... and the two scalars of the iteration from the gathered per-rank messages of the rank-private blocks ([alphaD | N, S1, S2 as (hi, lo) words], rank
+   order) plus the shared block's partials.  betaN_word == NULL: only word 0 of each message and the float partials are added into alphaD_word[0]
+   (alphaN_0 at PCGInit). */
+int thallo_hip_shard_scalars(const float* gathered, long stride, int world, const float* alphaD_partials, const double* s3_partials, int count, thallo_sum_t alphaN,
+                             float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* Range partition (graph domains): after an all-gather of messages that carry every rank's owned slice of each plane of a flat vector (equal slices),
    vec[first.off[j] + r * first.len[j] + i] = gathered[r * stride + skip + (pieces before j) + i] for every rank r and piece j (`first` = rank 0's pieces) */
 int thallo_hip_range_unpack(float* vec, thallo_segs_t first_rank_pieces, const float* gathered, long stride, long skip, int world, thallo_stream_t stream);
@@ -460,6 +468,7 @@ int thallo_hip_sfs_apply_jtj_sums_fin(int W, int H, int row0, int row1, int yoff
 int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
                                  const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* alphaD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream);
+int thallo_hip_ba_apply2_camera_slots(int C_, int P_);      /* how many of thallo_hip_ba_apply_jtj2*'s partial slots (the first ones) are the camera launch's */
 /* LM: applyJTJ with PCGStep1_Finish folded in (gauss_newton.t:774-787): Ap = (J^T J + CtC) p, partials of p . Ap; gate as below (may be NULL) */
 int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                 float* U, float* R, const float* p, const float* CtC, float* Ap, float* alphaD_out, const unsigned* gate, thallo_stream_t stream);

@@ -1,101 +1,92 @@
-"""CPU compute backend for thallo_amd.distributed_ba.BaShardSolver -- TEST INFRASTRUCTURE.
-Uses the oracle's CSR export of the rank's sub-instance and scipy sparse products (float64 accumulate, float32 state),
-so the sharding / all-reduce logic can run under gloo without a GPU."""
+"""CPU mirror of the SHARD form of the multi-GPU Gauss-Newton step (thallo_amd/csrc/solver_dist.cpp Plan::dist_gn_shard) for camera-sharded bundle
+adjustment -- TEST INFRASTRUCTURE (oracle CSR of the rank's sub-instance + scipy, float64 accumulate / float32 state, torch.distributed / gloo).
+The executable statement of that schedule: a rank holds its cameras, ALL points and the observations of its cameras; J^T F, diag(J^T J) and A p are
+partial sums on the point block and are all-reduced; the vector update runs on [own cameras | all points], the points redundantly; the scalars are
+the rank-ordered sum of the ranks' camera parts (one tiny all-gather) plus the point part every rank computes for itself after the all-reduce."""
 import numpy as np
 import scipy.sparse as sp
 import torch
+import torch.distributed as dist
 
 from oracle import oracle as orc
 
 F = np.float32
 
 
-class ScipyBaShardBackend:
-    def __init__(self, layout, local_params, max_l_iters):
+def _allreduce(vec, world):
+    if world > 1:
+        t = torch.from_numpy(vec)
+        dist.all_reduce(t)
+    return vec
+
+
+def _allgather(vec, world):
+    t = torch.from_numpy(np.ascontiguousarray(vec))
+    out = [torch.empty_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(out, t)
+    else:
+        out = [t]
+    return [o.numpy() for o in out]
+
+
+class BaShardMirror:
+    def __init__(self, layout, local_params):
         self.lay = layout
         self.params = [a.copy() for a in local_params]
         cams, pts, obs, oc, op = self.params
         self.Cp, self.P, self.O = cams.shape[0], pts.shape[0], obs.shape[0]
-        self.cameras, self.points = torch.from_numpy(cams), torch.from_numpy(pts)       # views: updated in place
         self.nc, self.n = 9 * self.Cp, 9 * self.Cp + 3 * self.P
-        self.slot = (self.n + 3) // 4 * 4
-        na = self.slot + 8
-        z = lambda: torch.zeros(na, dtype=torch.float32)
-        self.r, self.pre, self.z, self.delta, self.Ap, self.diag = z(), z(), z(), z(), z(), z()
-        self.p = [z(), z()]
-        self.S = torch.zeros(2 * max_l_iters + 16, dtype=torch.float32)
-        self.T = torch.zeros(8, dtype=torch.float32)
 
     def _problem(self):
         return orc.Problem(orc.BUNDLE_ADJUST, (self.Cp, self.P, self.O), self.params)
 
-    def cost_local(self, out_idx):
-        self.S[out_idx] = self._problem().cost() if self.O else 0.0
+    def cost(self):
+        mine = np.array([self._problem().cost() if self.O else 0.0], np.float64)
+        return float(sum(F(g[0]) for g in _allgather(mine, self.lay.world)))
 
-    def init_partial(self, cur):
+    def _scalars(self, cam_parts, pt_parts):
+        """rank-ordered sum of the camera parts + the point parts (identical on every rank)"""
+        got = _allgather(np.asarray(cam_parts, np.float64), self.lay.world)
+        return [sum(g[i] for g in got) + pt_parts[i] for i in range(len(cam_parts))]
+
+    def gn_step(self, L):
+        w, nc, n = self.lay.world, self.nc, self.n
         rp, col, val, res = self._problem().csr()
-        self.J = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(len(res), self.n))
-        n = self.n
-        self.r.numpy()[:n] = (-(self.J.T @ res.astype(np.float64))).astype(F)
-        self.diag.numpy()[:n] = np.asarray(self.J.multiply(self.J).sum(0)).ravel().astype(F)
-        self.p[cur].zero_(); self.delta.zero_()
+        J = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(len(res), n))
+        r = (-(J.T @ res.astype(np.float64))).astype(F)
+        d = np.asarray(J.multiply(J).sum(0)).ravel().astype(F)
+        _allreduce(r[nc:], w); _allreduce(d[nc:], w)                  # point blocks of J^T F and of the raw diagonal
+        pre = (F(1) / (F(1) + np.sqrt(d)) ** 2).astype(F)
+        z = pre * r
+        dot = lambda a, b, sl: float(a[sl].astype(np.float64) @ b[sl].astype(np.float64))
+        cam, pts = slice(0, nc), slice(nc, n)
+        aN = F(F(self._scalars([dot(r, z, cam)], [0.0])[0]) + F(dot(r, z, pts)))
+        p = np.zeros(n, F); delta = np.zeros(n, F); Ap = np.zeros(n, F)
+        alpha = beta = F(0)
+        for k in range(L):
+            if k:
+                r = (r - alpha * Ap).astype(F); delta = (delta + alpha * p).astype(F)
+            p = (pre * r + beta * p).astype(F)
+            Ap = (J.T @ (J @ p.astype(np.float64))).astype(F)
+            _allreduce(Ap[nc:], w)                                    # the point block of A p: the per-iteration all-reduce
+            m64, r64, a64, p64 = (v.astype(np.float64) for v in (pre, r, Ap, p))
+            sums = lambda sl: [float(p64[sl] @ a64[sl]), float((m64[sl] * r64[sl]) @ r64[sl]), float((m64[sl] * r64[sl]) @ a64[sl]), float((m64[sl] * a64[sl]) @ a64[sl])]
+            c, q = sums(cam), sums(pts)
+            tot = self._scalars(c, [0.0] * 4)                         # ONE tiny all-gather: the camera parts, rank order
+            aD = F(F(tot[0]) + F(q[0])); n_, s1, s2 = tot[1] + q[1], tot[2] + q[2], tot[3] + q[3]
+            alpha = aN / aD if aD != 0 else F(0)
+            bN = F(max(n_ - 2.0 * float(alpha) * s1 + float(alpha) ** 2 * s2, 0.0))
+            beta = bN / aN if aN != 0 else F(0)
+            aN = bN
+        if L:
+            delta = (delta + alpha * p).astype(F)
+        self.params[0].reshape(-1)[:] += delta[:nc]
+        self.params[1].reshape(-1)[:] += delta[nc:]
 
-    def point_block(self, vec, with_slot=False):
-        return vec[self.nc: (self.slot + 1) if with_slot else self.n]
-
-    def _parts(self, a, b):
-        a, b = a.numpy().astype(np.float64), b.numpy().astype(np.float64)
-        self.T[0] = float(a[:self.nc] @ b[:self.nc]); self.T[1] = float(a[self.nc:self.n] @ b[self.nc:self.n])
-
-    def init_finish(self):
-        n = self.n
-        d = self.diag.numpy()[:n]
-        m = (F(1) / (F(1) + np.sqrt(d)) ** 2).astype(F)
-        self.pre.numpy()[:n] = m
-        self.z.numpy()[:n] = m * self.r.numpy()[:n]
-        self._parts(self.r, self.z)
-
-    def _ab(self, first, iN, iD, iB):
-        if first:
-            return F(0), F(0)
-        aN, aD, bN = F(self.S[iN]), F(self.S[iD]), F(self.S[iB])
-        return (aN / aD if aD != 0 else F(0)), (bN / aN if aN != 0 else F(0))
-
-    def pupdate(self, cur, first, iN, iD, iB):
-        alpha, beta = self._ab(first, iN, iD, iB)
-        n = self.n
-        pin = self.p[cur].numpy()[:n]
-        if not first:
-            self.delta.numpy()[:n] += alpha * pin
-        self.p[cur ^ 1].numpy()[:n] = self.z.numpy()[:n] + beta * pin
-
-    def apply_partial(self, cur):
-        n = self.n
-        pv = self.p[cur].numpy()[:n].astype(np.float64)
-        ap = (self.J.T @ (self.J @ pv)).astype(F)
-        self.Ap.numpy()[:n] = ap
-        self.Ap[self.slot] = float(pv[:self.nc] @ ap[:self.nc].astype(np.float64))
-
-    def apply_finish(self, cur, out_idx):
-        pv, ap = self.p[cur].numpy().astype(np.float64), self.Ap.numpy().astype(np.float64)
-        self.S[out_idx] = float(F(self.Ap[self.slot]) + F(pv[self.nc:self.n] @ ap[self.nc:self.n]))
-
-    def step2(self, iN, iD):
-        aN, aD = F(self.S[iN]), F(self.S[iD])
-        alpha = aN / aD if aD != 0 else F(0)
-        n = self.n
-        self.r.numpy()[:n] -= alpha * self.Ap.numpy()[:n]
-        self.z.numpy()[:n] = self.pre.numpy()[:n] * self.r.numpy()[:n]
-        self._parts(self.z, self.r)
-
-    def linear_update(self, cur, iN, iD, with_p):
-        n, nc = self.n, self.nc
-        d = self.delta.numpy()[:n].copy()
-        if with_p:
-            aN, aD = F(self.S[iN]), F(self.S[iD])
-            d += (aN / aD if aD != 0 else F(0)) * self.p[cur].numpy()[:n]
-        self.params[0].reshape(-1)[:] += d[:nc]
-        self.params[1].reshape(-1)[:] += d[nc:]
-
-    def scalar(self, idx):
-        return float(self.S[idx])
+    def solve(self, nit, lit):
+        costs = [self.cost()]
+        for _ in range(nit):
+            self.gn_step(lit)
+            costs.append(self.cost())
+        return costs

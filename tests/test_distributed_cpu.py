@@ -108,16 +108,16 @@ def test_world_size_one_is_the_plain_solver(orc):
 
 # ------------------------------------------------------------------ camera-sharded bundle adjustment
 def _ba_worker(rank, world, port, dims, nit, lit, q):
-    from thallo_amd.distributed_ba import BaShardLayout, BaShardSolver
-    from ba_scipy_backend import ScipyBaShardBackend
+    from thallo_amd.distributed_ba import BaShardLayout
+    from ba_scipy_backend import BaShardMirror
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         C_, P_, O_ = dims
         p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
         lay = BaShardLayout(C_, rank, world)
-        be = ScipyBaShardBackend(lay, lay.shard(p), lit)
-        costs = BaShardSolver(be, lay).solve(nit, lit)
+        be = BaShardMirror(lay, lay.shard(p))
+        costs = be.solve(nit, lit)
         q.put((rank, costs, lay.c0, lay.c1, be.params[0][:lay.C_loc].copy(), be.params[1].copy()))
     finally:
         dist.destroy_process_group()

@@ -51,12 +51,13 @@ _lib = None
 
 # include/Thallo.h: ThalloX_AllGatherFn / ThalloX_Distributed
 AllGatherFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p)
+AllReduceFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p)
 
 
 class DistributedT(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("row0", C.c_uint), ("row1", C.c_uint),
                 ("allgather", AllGatherFn), ("user", C.c_void_p), ("device_exchange", C.c_int),
-                ("global_row0", C.c_uint), ("global_rows", C.c_uint)]
+                ("global_row0", C.c_uint), ("global_rows", C.c_uint), ("allreduce", AllReduceFn)]
 
 
 def lib():
@@ -265,7 +266,7 @@ class ThalloSolver:
     def set_stream(self, stream_ptr):
         self._L.ThalloX_SetStream(self.plan, C.c_void_p(stream_ptr))
 
-    def set_distributed(self, rank, world, row0, row1, allgather=None, device_exchange=True, global_row0=0, global_rows=0):
+    def set_distributed(self, rank, world, row0, row1, allgather=None, device_exchange=True, global_row0=0, global_rows=0, allreduce=None):
         """Collective (include/Thallo.h ThalloX_PlanSetDistributed): this plan is rank `rank`'s row slab; `allgather(send_ptr, recv_ptr,
         bytes_per_rank, stream_ptr) -> None` moves DEVICE bytes (thallo_amd.distributed.torch_allgather builds one over torch.distributed)."""
         def _cb(_user, send, recv, nbytes, stream):
@@ -276,8 +277,17 @@ class ThalloSolver:
                 import traceback
                 traceback.print_exc()
                 return -1
+        def _ar(_user, buf, count, stream):
+            try:
+                allreduce(buf, count, stream or 0)
+                return 0
+            except Exception:      # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return -1
         self._dist_cb = AllGatherFn(_cb) if allgather is not None else C.cast(None, AllGatherFn)      # kept alive with the plan
-        cfg = DistributedT(rank, world, row0, row1, self._dist_cb, None, 1 if device_exchange else 0, global_row0, global_rows)
+        self._dist_ar = AllReduceFn(_ar) if allreduce is not None else C.cast(None, AllReduceFn)
+        cfg = DistributedT(rank, world, row0, row1, self._dist_cb, None, 1 if device_exchange else 0, global_row0, global_rows, self._dist_ar)
         if self._L.ThalloX_PlanSetDistributed(self.plan, C.byref(cfg)) != 0:
             raise RuntimeError("ThalloX_PlanSetDistributed failed: " + last_error())
 

@@ -426,6 +426,10 @@ static int ba_apply2(int C_, int P_, const int* cam_ptr, const int* q_pt, const 
                        s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid }, ctc);
     int e = check_launch(); return e ? e : grid;
 }
+int thallo_hip_ba_apply2_camera_slots(int C_, int P_)
+{   // how many of thallo_hip_ba_apply_jtj2*'s partial slots belong to the camera launch (the first ones)
+    int cb, grid; gather_shape(C_, P_, cb, grid); return cb;
+}
 int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
                                  const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream)

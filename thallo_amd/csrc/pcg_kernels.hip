@@ -454,6 +454,54 @@ __global__ __launch_bounds__(BLOCK) void k_slab_unpack(float* __restrict__ vec, 
     }
 }
 
+// Shard form (bundle adjustment across ranks, solver_dist.cpp): the sums of a PCG iteration over a block of unknowns that every rank holds in
+// full (the points), taken AFTER the cross-rank all-reduce completed A p there: alphaD partial (float) and {N, S1, S2} (double) per workgroup
+template <bool HAS_PRE>
+__global__ __launch_bounds__(BLOCK) void k_block_sums(const float4* __restrict__ p, const float4* __restrict__ Ap, const float4* __restrict__ r, const float4* __restrict__ pre,
+                                                       long n4, float* __restrict__ aD_out, double* __restrict__ s3_out)
+{
+    __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
+    float acc = 0.0f; Sums3 sm;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        const float4 pv = p[i], av = Ap[i], rv = r[i];
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (HAS_PRE) m = pre[i];
+        acc += pv.x * av.x + pv.y * av.y + pv.z * av.z + pv.w * av.w;
+        sm.add(m.x, rv.x, av.x); sm.add(m.y, rv.y, av.y); sm.add(m.z, rv.z, av.z); sm.add(m.w, rv.w, av.w);
+    }
+    block_store_partial(acc, aD_out, red);
+    block_store_sums3(sm, s3_out, redd);
+}
+// ... and the iteration's two scalars from the gathered per-rank sums of the rank-private blocks (cameras: [alphaD | N, S1, S2 as (hi, lo)] per
+// rank, added in rank order) plus the shared block's partials above (identical on every rank): alphaD_k, betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2.
+// count_only_first != 0: only word 0 of every rank's message and the float partials are added (alphaN_0 at PCGInit): out_a[0] = that sum.
+__global__ __launch_bounds__(64) void k_shard_scalars(const float* __restrict__ gathered, long stride, int world, const float* __restrict__ aD_part, const double* __restrict__ s3_part,
+                                                      int nb, thallo_sum_t aN, int count_only_first, float* __restrict__ out_a, float* __restrict__ out_b)
+{
+    const int lane = threadIdx.x;
+    float ad = 0.0f; double q[3] = { 0.0, 0.0, 0.0 };
+    for (int r = 0; r < world; ++r) {
+        const float* m = gathered + (long)r * stride;
+        ad += m[0];
+        if (!count_only_first)
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long b = ((unsigned long long)__float_as_uint(m[1 + 2 * j]) << 32) | (unsigned long long)__float_as_uint(m[2 + 2 * j]);
+                q[j] += __longlong_as_double((long long)b);
+            }
+    }
+    ad += sum_partials(aD_part, nb);
+    if (count_only_first) { if (lane == 0) out_a[0] = ad; return; }
+    double n = 0.0, a = 0.0, b = 0.0;
+    for (int i = lane; i < nb; i += THALLO_WAVE) { n += s3_part[3 * i]; a += s3_part[3 * i + 1]; b += s3_part[3 * i + 2]; }
+    n = q[0] + wave_sum_all_f64(n); a = q[1] + wave_sum_all_f64(a); b = q[2] + wave_sum_all_f64(b);
+    const float an = sum_partials(aN.partials, aN.count);
+    const float alpha = safe_div<false>(an, ad);
+    double bn = n - 2.0 * (double)alpha * a + (double)alpha * (double)alpha * b;
+    if (!(bn > 0.0)) bn = 0.0;
+    if (lane == 0) { out_a[0] = ad; out_b[0] = (float)bn; }
+}
+
 // Range partition (graph domains, solver_dist.cpp): every rank's message carries its owned slice of each plane of a flat vector; rank r's slice j
 // goes to vec[first.off[j] + r * first.len[j] ...] (equal slices; `first` = the pieces of rank 0), read from gathered[r * stride + skip + ...]
 __global__ __launch_bounds__(BLOCK) void k_range_unpack(float* __restrict__ vec, thallo_segs_t first, const float* __restrict__ gathered, long stride, long skip, int world)
@@ -758,6 +806,24 @@ int thallo_hip_slab_unpack(float* vec, thallo_segs_t top, const float* src_top, 
 {
     if (top.n < 0 || top.n > 8 || bot.n < 0 || bot.n > 8) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_slab_unpack, dim3(8), dim3(BLOCK), 0, (hipStream_t)stream, vec, top, src_top, bot, src_bot, gathered, stride, world, sum_out);
+    return check_launch();
+}
+
+int thallo_hip_block_sums(const float* p, const float* Ap, const float* r, const float* pre, long n, float* aD_out, double* s3_out, thallo_stream_t stream)
+{
+    if (!p || !Ap || !r || !aD_out || !s3_out || n < 0 || (n & 3)) return -(int)hipErrorInvalidValue;
+    const long n4 = n / 4; const int grid = flat_grid(n4 ? n4 : 1, cu_count());
+    if (pre) hipLaunchKernelGGL(k_block_sums<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)p, (const float4*)Ap, (const float4*)r, (const float4*)pre, n4, aD_out, s3_out);
+    else     hipLaunchKernelGGL(k_block_sums<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (const float4*)p, (const float4*)Ap, (const float4*)r, (const float4*)pre, n4, aD_out, s3_out);
+    int e = check_launch(); return e ? e : grid;
+}
+int thallo_hip_shard_scalars(const float* gathered, long stride, int world, const float* aD_partials, const double* s3_partials, int count, thallo_sum_t alphaN,
+                             float* alphaD_word, float* betaN_word, thallo_stream_t stream)
+{
+    if (!gathered || world < 1 || stride < 1 || !aD_partials || count < 1 || count > THALLO_MAX_PARTIALS || !alphaD_word) return -(int)hipErrorInvalidValue;
+    const int only_first = betaN_word == nullptr;
+    if (!only_first && (!s3_partials || alphaN.count < 1)) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_shard_scalars, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, stride, world, aD_partials, s3_partials, count, alphaN, only_first, alphaD_word, betaN_word);
     return check_launch();
 }
 

@@ -145,6 +145,12 @@ public:
     // range of units (vertices) only; range_units() = how many units there are (each unknown image has n_floats / units floats per unit)
     virtual long range_units() const { return 0; }
     virtual int  set_owned_range(long /*u0*/, long /*u1*/) { return -1; }
+    // ---- shard form (bundle adjustment: camera shards): the unknowns [shared_block_offset, + shared_block_floats) (the points) are held by every rank
+    // in full; a rank's J^T F / diag / J^T J p there are partial sums over ITS residuals and are all-reduced; the first shared_split_slots() partial
+    // slots of apply_jtj_sums belong to the rank-private unknowns (the cameras)
+    virtual long shared_block_offset() const { return 0; }
+    virtual long shared_block_floats() const { return 0; }
+    virtual int  shared_split_slots() const { return 0; }
     // pcg_iter that also stores its boundary rows of Ap_out into the neighbours' ghost rows and whose last workgroup runs the mailbox exchange
     virtual int  pcg_iter_dist(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t,
                                const thallo_dist_t&, float* /*alphaD_out*/, int /*slot0*/, float* /*aD_word*/, float* /*bN_word*/) { return -1; }

@@ -553,6 +553,9 @@ public:
         return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                        (const float*)Jb.ptr, p, Ap, out, c.stream);
     }
+    long shared_block_offset() const override { return 9L * C; }
+    long shared_block_floats() const override { return once_ ? 3L * P : 0; }        // (the shard form runs on the J p-once applyJTJ)
+    int shared_split_slots() const override { return thallo_hip_ba_apply2_camera_slots(C, P); }
     bool apply_adds_ctc() const override { return once_; }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override

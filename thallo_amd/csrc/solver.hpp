@@ -60,6 +60,11 @@ struct DistState {
     bool range = false;
     thallo_segs_t pieces_first, pieces_mine;
     long piece_floats = 0;                               // floats a rank owns in a flat vector
+    // shard form (bundle adjustment: camera shards): the unknowns [sh_off, sh_off + sh_len) (the points) are replicated; their J^T F / diag / A p are
+    // partial sums over the rank's residuals and are all-reduced; sums over them are taken after that, by every rank for itself
+    bool shard = false;
+    long sh_off = 0, sh_len = 0;
+    DeviceBuffer sh_aD, sh_s3;                           // the shared block's partials of an iteration
     // device-side exchange
     bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
     void* mail = nullptr; int mail_L = 0;
@@ -151,7 +156,9 @@ private:
     int  dist_gn(int L, bool p2p);                      // PCGInit + L iterations + linear update + ghost refresh, no bookkeeping
     int  step_gn_slab(int ev_iter);
     int  dist_gn_flat(int L);
-    int  dist_gn_range(int L);                          // range form: full-length pcg_update + applyJTJ over the owned units + ONE exchange per PCG iteration
+    int  dist_gn_range(int L);
+    int  dist_gn_shard(int L);                          // shard form: applyJTJ on the rank's residuals, all-reduce of the shared block of A p, one tiny all-gather
+    int  dist_allreduce(float* buf, long count);                          // range form: full-length pcg_update + applyJTJ over the owned units + ONE exchange per PCG iteration
     int  dist_replicate(float* vec, int sum_slot);      // every rank's owned pieces of `vec` to every rank (and, sum_slot >= 0, that slot's global sum)                           // flat form: pcg_update + apply_jtj_sums + ONE exchange per PCG iteration
     int  dist_sum_slot(int j);                          // slot j (local partials) -> scal(j) = rank-ordered global sum
     int  dist_sum_and_rows(int j, float* vec);          // ... and the ghost rows of a flat vector from the neighbours' boundary rows (j < 0: rows only)

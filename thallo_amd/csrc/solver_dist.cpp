@@ -66,6 +66,27 @@ int Plan::set_distributed(const ThalloX_Distributed& cfg)
 {
     if (!ok_) return -1;
     if (dist_) { set_error("distributed: already set for this plan"); return -1; }
+    if (plugin->shared_block_floats() > 0 && !plugin->supports_row_slabs() && plugin->range_units() == 0) {      // bundle adjustment: camera shards
+        if (lm_) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
+        if (!plugin->apply_returns_sums()) { set_error("distributed: %s has no shard form", plugin->name()); return -1; }
+        if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
+        if (cfg.world > 1 && (!cfg.allgather || !cfg.allreduce)) { set_error("distributed: the shard form needs an all-gather and an all-reduce callback"); return -1; }
+        const long off = plugin->shared_block_offset(), len = plugin->shared_block_floats();
+        if ((off & 3) || (len & 3) || off + len != v_.n) { set_error("distributed: shared block [%ld, %ld) of %ld unknowns (offset and length must be multiples of 4: pad the cameras to a multiple of 4)", off, off + len, v_.n); return -1; }
+        hipDeviceSynchronize();
+        DistState* Dp = new DistState(); DistState& D = *Dp; dist_ = Dp;
+        D.cfg = cfg; D.shard = true; D.range = true;            // (range: linear updates and the like cover the whole local vector)
+        D.sh_off = off; D.sh_len = len;
+        if (D.send.alloc(64 * sizeof(float)) || D.gath.alloc(64 * sizeof(float) * cfg.world) || ensure_sums_buffer() ||
+            D.sh_aD.alloc(THALLO_HIP_MAX_PARTIALS * sizeof(float)) || D.sh_s3.alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double))) { set_error("distributed: out of device memory"); return -1; }
+        if (!v_.diag) { DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b); if (b->alloc((size_t)v_.n_alloc * sizeof(float))) return -1; v_.diag = (float*)b->ptr; }      // raw diag(J^T J): all-reduced before it is inverted
+        bool all = false;
+        if (dist_agree(true, all)) return -1;
+        char buf[256];
+        snprintf(buf, sizeof(buf), "{\"exchange\": \"allreduce + allgather\", \"form\": \"residual shards, shared block of %ld unknowns\", \"rank\": %d, \"world\": %d}", len, cfg.rank, cfg.world);
+        D.info = buf;
+        return 0;
+    }
     if (plugin->range_units() > 0) {                           // graph domains: vertex ranges, whole problem and full-length vectors on every rank
         const long U = plugin->range_units(), u0 = cfg.row0, u1 = cfg.row1;
         if (lm_) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
@@ -469,6 +490,70 @@ int Plan::dist_gn_range(int L)
     return 0;
 }
 
+// ---- shard form (bundle adjustment)
+int Plan::dist_allreduce(float* buf, long count)
+{
+    DistState& D = *dist_;
+    if (D.cfg.world == 1) return 0;
+    const int rc = D.cfg.allreduce(D.cfg.user, buf, count, (void*)ctx.stream);
+    if (rc) set_error("distributed: the caller's all-reduce returned %d", rc);
+    return rc;
+}
+
+int Plan::dist_gn_shard(int L)
+{   // A rank holds its cameras, ALL points and the observations of its cameras.  J p is local; the camera block of J^T(J p) is complete, the point block
+    // is a partial sum -> all-reduce (3P floats per PCG iteration); then every rank holds identical point blocks of Ap, r, p, delta and updates them
+    // redundantly.  The scalars: the camera parts of [alphaD | N, S1, S2] travel in one tiny all-gather and are added in rank order, the point parts
+    // are computed by every rank for itself after the all-reduce (thallo_hip_block_sums) -- identical inputs, identical bits.
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    const int B = 2, world = D.cfg.world;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    float* sh_aD = (float*)D.sh_aD.ptr; double* sh_s3 = (double*)D.sh_s3.ptr;
+    const long off = D.sh_off, len = D.sh_len;
+    const bool pc = plugin->use_preconditioner();
+    const thallo_segs_t none = segs({});
+    cur_ = 0;
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));               // r = -J^T F and the RAW diagonal (v_.diag), both partial on the shared block
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
+    {   TimedLaunch t(ctx, "ShardExchangeInit");
+        if (dist_allreduce(v_.r + off, len) || dist_allreduce(v_.diag + off, len)) return -1;
+        // PCGInit1_Finish on the two blocks separately: pre = guardedInvert(diag), z = pre r, alphaN partials
+        const int nbc = thallo_hip_pcg_init_finish(v_.r, v_.diag, v_.pre, v_.z, off, pc ? 1 : 0, slot(B), s);
+        const int nbp = thallo_hip_pcg_init_finish(v_.r + off, v_.diag + off, v_.pre + off, v_.z + off, len, pc ? 1 : 0, sh_aD, s);
+        if (nbc < 0 || nbp < 0) return -1;
+        set_nb(B, nbc);
+        if (thallo_hip_finish_sum(partial_sum(B), send, s) < 0) return -1;
+        if (dist_allgather(send, gath, sizeof(float))) return -1;
+        if (thallo_hip_shard_scalars(gath, 1, world, sh_aD, nullptr, nbp, thallo_sum_t{ nullptr, 0 }, scal(B), nullptr, s) < 0) return -1;      // alphaN_0
+        fin_[B] = 1;
+    }
+    const int cam_slots = plugin->shared_split_slots();
+    for (int k = 0; k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        {   TimedLaunch t(ctx, "PCGUpdate");
+            if (thallo_hip_pcg_update(v_.r, v_.Ap, pc ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
+                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return -1; }
+        }
+        cur_ ^= 1;
+        const thallo_fin_t nofin = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), nofin);
+        if (nb < 0 || cam_slots < 1 || cam_slots >= nb) { set_error("PCGStep1 launch failed (%d)", nb); return -1; }
+        set_nb(jD, nb);
+        TimedLaunch t(ctx, "ShardExchange");
+        if (dist_allreduce(v_.Ap + off, len)) return -1;
+        const int nbp = thallo_hip_block_sums(v_.p[cur_] + off, v_.Ap + off, v_.r + off, pc ? v_.pre + off : nullptr, len, sh_aD, sh_s3, s);
+        if (nbp < 0) return -1;
+        if (thallo_hip_slab_pack_iter(v_.Ap, none, slot(jD), v_.s12, cam_slots, send, s) < 0) return -1;      // the camera launch's slots only
+        if (dist_allgather(send, gath, 7 * (long)sizeof(float))) return -1;
+        if (thallo_hip_shard_scalars(gath, 7, world, sh_aD, sh_s3, nbp, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
+        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+    }
+    last_l_iters = L;
+    linear_update_tail(L, false);                                        // cameras of this rank + all points (replicated, bit for bit)
+    return 0;
+}
+
 int Plan::dist_self_check()
 {   // The device-side exchange is used only if, ON THIS TOPOLOGY, one GN step through it reproduces the all-gather path's alpha / beta
     // scalars from the same unknowns (a stale ghost row or a lost granule shows up there; the two paths round identically except for the
@@ -530,7 +615,7 @@ int Plan::step_gn_slab(int ev_iter)
     const int L = sp.lIterations;
     const int ev_lin = timer_.start("Linear Solve", s);
     const bool p2p = D.p2p_on && L <= D.mail_L;                          // (same L on every rank: same decision)
-    if (D.range ? dist_gn_range(L) : D.flat ? dist_gn_flat(L) : dist_gn(L, p2p)) return 0;
+    if (D.shard ? dist_gn_shard(L) : D.range ? dist_gn_range(L) : D.flat ? dist_gn_flat(L) : dist_gn(L, p2p)) return 0;
     timer_.stop(ev_lin, s);
     sp.nIter++;
     timer_.stop(ev_iter, s);

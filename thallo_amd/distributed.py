@@ -212,6 +212,33 @@ def torch_allgather(group=None, device=None):
     return f
 
 
+def torch_allreduce(group=None, device=None):
+    """ThalloX_AllReduceFn over torch.distributed: `f(buf_ptr, count_floats, stream_ptr)`, in-place sum (nccl on the stream; gloo host-staged)."""
+    backend = dist.get_backend(group)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    views = {}
+
+    def f(buf, count, stream):
+        t = views.get((buf, count))
+        if t is None:
+            t = views[(buf, count)] = torch.as_tensor(_RawDeviceBytes(buf, 4 * count), device=dev).view(torch.float32)
+        cur = torch.cuda.current_stream()
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream and stream != cur.cuda_stream else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            if backend == "nccl":
+                dist.all_reduce(t, group=group)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, group=group)
+                t.copy_(h)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+    return f
+
+
 class PlanSlabSolver:
     """One rank's row slab of an image_warping problem, solved through the library (Thallo_ProblemInit / Step / CurrentCost are
     collective once ThalloX_PlanSetDistributed was called)."""

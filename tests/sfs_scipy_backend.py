@@ -1,4 +1,4 @@
-"""CPU compute backend for the shape_from_shading slab path (thallo_amd.distributed.SlabSolver, ghost width 2) --
+"""CPU compute backend for the shape_from_shading slab path (tests/slab_schedule_mirror.py SlabSolver, ghost width 2) --
 TEST INFRASTRUCTURE.  The rank's local image (owned rows + 2 ghost rows) is handed to the oracle as a stand-alone
 problem with u_y shifted by the slab's row offset; rows/columns of its Jacobian that belong to the owned pixels are
 exact (their stencils stay inside the local image), everything else is masked out."""

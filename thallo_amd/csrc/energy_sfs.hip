@@ -245,7 +245,9 @@ __global__ __launch_bounds__(BLOCK) void k_gather(Geo g, Cam cm, const float* __
 // MODE 1 with D != NULL: D is the LM diagonal CtC and the output is (J^T J + CtC) v -- PCGStep1_Finish (gauss_newton.t:774-787) folded into the apply.
 constexpr int FW = 64, FH = 16;
 constexpr int UW = FW + 2, UH = FH + 2;        // U, R: tile +- 1
+constexpr int BW = FW + 3, BH = FH + 3;        // b0: tile -1 .. +1 and one more column / row (U(q) needs b0 at q, q+ex, q+ey)
 struct FusedTile {
+    float b0[BW * BH];                         // the shading row's value at every pixel of that range: dB(q) = G(q) . (v(q), v(q-ex), v(q-ey)), once per pixel
     float uh[UW * UH], uv[UW * UH];
     float r0[UW * UH], r1[UW * UH], r2[UW * UH];
     float cx[UW + 2], cy[UH + 2];              // coef_0 = (x - u_x) / f_x per column, coef_1 = (y - u_y) / f_y per row of the tile +- 2 (coef_2 = 1):
@@ -270,6 +272,20 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
         const int x0 = (t.cur % ftx) * FW, y0 = g.ra + (t.cur / ftx) * FH;
         if (threadIdx.x < UW + 2) T.cx[threadIdx.x] = coef(cm, 0, x0 + (int)threadIdx.x - 2, 0);
         else if (threadIdx.x >= 128 && threadIdx.x < 128 + UH + 2) T.cy[threadIdx.x - 128] = coef(cm, 1, 0, y0 + (int)threadIdx.x - 128 - 2 + g.yoff);
+        // ---- A0: dB on the tile -1 .. +2 (round 2: each pixel's value once, into LDS -- the U of three sites uses it; before, every site re-gathered
+        //      three G rows and seven v values: 3 x the G traffic through L1 and twice the arithmetic; same expression, same bits)
+        for (int idx = threadIdx.x; idx < BW * BH; idx += BLOCK) {
+            const int ly = idx / BW, lx = idx - ly * BW;
+            const int qx = x0 + lx - 1, qy = y0 + ly - 1;
+            float b = 0.0f;
+            if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
+                const long q = (long)qy * W + qx;
+                const float4 g0 = G[q];
+                if (MODE == 0) b = g0.w;
+                else b = g0.x * v[q] + g0.y * at(v, qx - 1, qy, W, H) + g0.z * at(v, qx, qy - 1, W, H);
+            }
+            T.b0[idx] = b;
+        }
         __syncthreads();
         // ---- A: U and R on the tile +- 1
         for (int idx = threadIdx.x; idx < UW * UH; idx += BLOCK) {
@@ -280,15 +296,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
                 const long q = (long)qy * W + qx;
                 const float2 w = Wt[q];
                 if (w.x != 0.0f || w.y != 0.0f) {
-                    float b0, bx, by;
-                    if (MODE == 0) { b0 = G[q].w; bx = G[q + 1].w; by = G[q + W].w; }
-                    else {
-                        const float vc = v[q], vl = v[q - 1], vu = v[q - W];      // inner pixel: all in range
-                        const float4 g0 = G[q], gx = G[q + 1], gy = G[q + W];
-                        b0 = g0.x * vc + g0.y * vl + g0.z * vu;
-                        bx = gx.x * v[q + 1] + gx.y * vc + gx.z * v[q + 1 - W];
-                        by = gy.x * v[q + W] + gy.y * v[q + W - 1] + gy.z * vc;
-                    }
+                    const int j = ly * BW + lx;
+                    const float b0 = T.b0[j], bx = T.b0[j + 1], by = T.b0[j + BW];
                     uh = w.x * (w.x * (b0 - bx)); uv = w.y * (w.y * (b0 - by));
                 }
                 if (fl[q] & 2) {

@@ -20,7 +20,8 @@ KEYS = [("k_fused<1>", "shape_from_shading applyJTJ (fused, 2048^2)", 33 * NPX),
         ("k_fused<0>", "shape_from_shading PCGInit1 J^T F (fused, 2048^2)", None),
         ("k_cam2", "bundle_adjustment J^T(Jp) camera kernel (ladybug-1723 shape)", 116 * O_BA),
         ("k_pt2", "bundle_adjustment J^T(Jp) point kernel (ladybug-1723 shape)", 32 * O_BA),
-        ("k_apply", "ARAP applyJTJ (102,400 vertices)", None),
+        ("k_arap_apply", "ARAP applyJTJ + sums + in-kernel finish (102,400 vertices, 614,400 directed edges)", None),
+        ("k_iter<3, 512", "image_warping one-kernel PCG iteration, LDS-tiled form (512^2)", 99 * 512 * 512),
         ("k_pcg_update", "PCGUpdate (flat)", None)]
 dur = collections.defaultdict(list)
 kt = newest(os.path.join(g, "cfg_kt", "*", "*_kernel_trace.csv"))

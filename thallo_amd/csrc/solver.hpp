@@ -149,6 +149,7 @@ private:
     void linear_update_tail(int L, bool batched);
     // solver_dist.cpp
     DistState* dist_ = nullptr;
+    int  set_distributed_impl(const ThalloX_Distributed& cfg);
     int  dist_allgather(const void* send, void* recv, long bytes);
     int  dist_agree(bool flag, bool& all);
     int  dist_map_peers();

@@ -66,6 +66,18 @@ int Plan::set_distributed(const ThalloX_Distributed& cfg)
 {
     if (!ok_) return -1;
     if (dist_) { set_error("distributed: already set for this plan"); return -1; }
+    const int rc = set_distributed_impl(cfg);
+    if (rc && dist_) {      // failed half-way (out of memory, a failing callback ...): the plan's vectors may already live in the released exchange block
+        const std::string why = last_error();
+        dist_release();
+        ok_ = false;
+        set_error("%s (the plan is unusable now: free it)", why.c_str());
+    }
+    return rc;
+}
+
+int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
+{
     if (plugin->shared_block_floats() > 0 && !plugin->supports_row_slabs() && plugin->range_units() == 0) {      // bundle adjustment: camera shards
         if (lm_) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
         if (!plugin->apply_returns_sums()) { set_error("distributed: %s has no shard form", plugin->name()); return -1; }

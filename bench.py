@@ -239,7 +239,7 @@ def main():
                      "timing": ("HIP events around the PCG loop of every GN step (L launches of this one kernel) / L" if one_kernel
                                 else "HIP events around every 16th launch of the kernel"),
                      "note": "achieved = bytes_per_pixel x pixels / avg launch time: the bytes this fused kernel has to move, each array once "
-                             "(DESIGN.md section 4; equals the PMC traffic to ~1 %)",
+                             "(DESIGN.md section 4; the PMC traffic is 5 % above it: halo rows and strip overlaps)",
                      # the same launch priced with SURVEY.md 8d's bytes of the reference's three-kernel formulation -- a speed-up figure, not a
                      # roofline fraction (it exceeds the HBM peak because the schedule removes 45 % of those bytes)
                      "reference_formulation": {"bytes_per_pixel": ref_bytes, "equivalent_GBps": ref_bytes * npx / (step1_ms * 1e-3) / 1e9},

@@ -73,12 +73,15 @@ def _run(world, W, H, nit, lit, device_exchange):
     return res
 
 
+@pytest.mark.parametrize("kernel", ["auto", "march"])
 @pytest.mark.parametrize("world,W,H,nit,lit", [(2, 128, 96, 3, 30), (3, 64, 100, 2, 20), (1, 64, 48, 2, 10)])
-def test_hip_slabs_p2p_mailbox_exchange(orc, world, W, H, nit, lit):
+def test_hip_slabs_p2p_mailbox_exchange(orc, monkeypatch, world, W, H, nit, lit, kernel):
     """The device-side exchange (mailbox granules + peer-to-peer ghost rows, csrc/dist_device.hpp) between `world` processes --
     here all on GPU 0, mapped through hipIpc like real peers -- behind Thallo_ProblemStep: it must enable itself (self-check against the
     all-gather path at the first Init), never time out, give every rank bit-identical alpha/beta, and follow the oracle's cost trajectory."""
     from thallo_amd import synthetic as syn
+    if kernel == "march":
+        monkeypatch.setenv("THALLO_MARCH", "2")       # the marching kernel's multi-GPU variant at sizes where the plugin would pick the tile kernel (the ranks inherit the environment)
     res = _run(world, W, H, nit, lit, True)
     p = syn.image_warping(W, H, n_markers=8)
     co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), p).solve(nIterations=nit, lIterations=lit)

@@ -109,8 +109,11 @@ def test_hip_slabs_match_oracle(orc, world, W, H, nit, lit):
         assert np.abs(ang - p[1][g0:g1]).max() <= 2e-4 * max(1.0, np.abs(p[1]).max())
 
 
-def test_hip_slab_transports_agree_bitwise_on_the_unknowns(orc):
+@pytest.mark.parametrize("kernel", ["auto", "march"])
+def test_hip_slab_transports_agree_bitwise_on_the_unknowns(orc, monkeypatch, kernel):
     """Both transports add the per-rank sums in rank order from the same per-rank values: same alpha/beta bits, same unknowns."""
+    if kernel == "march":
+        monkeypatch.setenv("THALLO_MARCH", "2")
     a = _run(2, 128, 64, 2, 12, True)
     b = _run(2, 128, 64, 2, 12, False)
     for ra, rb in zip(a, b):

@@ -313,8 +313,8 @@ int Plan::dist_gn(int L, bool p2p)
     }
     if (p2p && thallo_hip_dist_begin_step(D.d, s) < 0) return -1;        // seq += 1: this GN step's granules
     // delta += alpha p every iteration on the device-side transport: its "apply two" kernel variant (peer stores on top of 256 VGPRs) spills, and at
-    // slab sizes the 6 B/pixel it would save do not matter (2048x256: 22.6 vs 24.3 us per iteration).  (The LDS-tiled kernel gives the same bits under
-    // either delta schedule -- tested; the marching kernel's template variants are contracted differently, there the two transports agree to rounding.)
+    // slab sizes the 6 B/pixel it would save do not matter (2048x256: 22.6 vs 24.3 us per iteration).  (Either delta schedule gives the same bits -- tested
+    // for both kernels; the marching kernel's multi-GPU variant is contracted differently from its single-GPU one, so its two TRANSPORTS agree to rounding.)
     const bool batch = batch_delta_ && !p2p;
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_potrf_panel(long n, long k, float* __
     for (int e = t; e < NB * NB; e += BLOCK) { const int r = e / NB, c = e % NB; D[r][c] = (r < nb && c <= r) ? A[(k + r) * n + k + c] : 0.0f; }
     __syncthreads();
     for (int j = 0; j < nb; ++j) {                 // unblocked Cholesky of the nb x nb block, column by column
-        if (t == 0) { const float d = D[j][j]; if (!(d > 0.0f)) { bad = j + 1; D[j][j] = 1.0f; } else D[j][j] = sqrtf(d); }
+        if (t == 0) { const float d = D[j][j]; if (!(d > 0.0f)) { if (!bad) bad = j + 1; D[j][j] = 1.0f; } else D[j][j] = sqrtf(d); }
         __syncthreads();
         if (t > j && t < nb) D[t][j] /= D[j][j];
         __syncthreads();

@@ -92,6 +92,27 @@ def test_wave_aggregated_scatter_is_chosen_per_access(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
+REF_PAIRS = [("examples/image_warping/image_warping.t", "image_warping"), ("examples/arap_mesh_deformation/arap_mesh_deformation.t", "arap_mesh_deformation"),
+             ("examples/shape_from_shading/shape_from_shading.t", "shape_from_shading"), ("examples/bundle_adjustment/bundle_adjustment.t", "bundle_adjustment"),
+             ("tests/minimal_graph/laplacian.t", "laplacian_graph"), ("tests/minimal/laplacian.t", "laplacian_image_shipped_guard")]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("rel,mine", REF_PAIRS)
+def test_bundled_energies_are_the_references_energies(rel, mine):
+    """The bundled .t files are re-written specifications (different text).  Run through the front-end, each of them and the reference's own file (read
+    in place, never copied) produce the SAME translation unit -- the same expression DAG per residual component, the same unknown accesses, the same
+    guards -- up to the residuals' names.  So everything the GPU tests establish about a bundled energy (oracle trajectories, gold PNGs, generated
+    vs hand-written plugins) is established about the energy the reference's file states, not about a restatement of it."""
+    import re
+    norm = lambda t: re.sub(r"// ---- residual \w+", "// ---- residual R", t)
+    a, b = norm(_text(os.path.join("/root/reference", rel), 1)), norm(_text(thallo_amd.energy_file(mine), 1))
+    assert a == b
+    da, db = _text(os.path.join("/root/reference", rel), 0), _text(thallo_amd.energy_file(mine), 0)
+    strip = lambda d: [re.sub("( J| JtJ| Jp)+$", "", re.sub("^residual [^ ]+", "residual", ln)) for ln in d.splitlines()]
+    assert strip(da) == strip(db)
+
+
 REF = "/root/reference"
 REF_EXAMPLES = ["examples/image_warping/image_warping.t", "examples/arap_mesh_deformation/arap_mesh_deformation.t",
                 "examples/shape_from_shading/shape_from_shading.t", "examples/bundle_adjustment/bundle_adjustment.t",

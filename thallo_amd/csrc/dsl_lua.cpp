@@ -341,6 +341,10 @@ E bin(Op op, const E& a, const E& b)
     if (is_const(a, &x) && is_const(b, &y)) {       // fold literals (the file's own arithmetic on numbers: weights, thresholds)
         switch (op) { case Op::Add: return konst(x + y); case Op::Sub: return konst(x - y); case Op::Mul: return konst(x * y); case Op::Div: return konst(x / y); default: break; }
     }
+    // additive identities (x + 0, 0 + x, x - 0 are x exactly -- but for the sign of a zero; the reference's own simplifier drops them too, ad.t): what an
+    // energy file writes as `offX + posX` with a literal 0 offset becomes the same node as `posX`
+    if (op == Op::Add && is_const(a, &x) && x == 0.0) return b;
+    if ((op == Op::Add || op == Op::Sub) && is_const(b, &y) && y == 0.0) return a;
     return mk(op, { a, b });
 }
 E un(Op op, const E& a)

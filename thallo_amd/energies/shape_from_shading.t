@@ -20,7 +20,7 @@ local px, py = x:asvalue(), y:asvalue()
 
 local function backproject(dx, dy)
     local d = X(x + dx, y + dy)
-    return Vector(((px + dx - u_x) / f_x) * d, ((py + dy - u_y) / f_y) * d, d)
+    return Vector(((dx + px - u_x) / f_x) * d, ((dy + py - u_y) / f_y) * d, d)
 end
 local function normal()
     local n_x = X(x, y - 1) * (X(x, y) - X(x - 1, y)) / f_y
@@ -46,7 +46,7 @@ local laplacian = 4.0 * backproject(0, 0) - (backproject(-1, 0) + backproject(0,
 
 r = Residuals {
     fit       = Select(depthOK(0, 0), w_p * (X(x, y) - D_i(x, y)), 0),
-    shading_h = Select(InBoundsExpanded(x, y, 1), w_g * (B_I(0, 0) - B_I(1, 0)) * edgeMaskR(x, y), 0),
-    shading_v = Select(InBoundsExpanded(x, y, 1), w_g * (B_I(0, 0) - B_I(0, 1)) * edgeMaskC(x, y), 0),
+    shading_h = Select(InBoundsExpanded(x, y, 1), w_g * ((B_I(0, 0) - B_I(1, 0)) * edgeMaskR(x, y)), 0),
+    shading_v = Select(InBoundsExpanded(x, y, 1), w_g * ((B_I(0, 0) - B_I(0, 1)) * edgeMaskC(x, y)), 0),
     reg       = Select(smooth, w_s * laplacian, 0)
 }

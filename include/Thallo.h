@@ -124,6 +124,10 @@ const char* ThalloX_LastError(void);
  * (J^T J formed once, one SpMV); -1 = no plugin for the file.  Honoured by the two Laplacian energies (constant J). */
 int ThalloX_ProblemFileSchedule(const char* filename);
 unsigned long long ThalloX_ProblemFileHash(const char* filename, char* energy_out, int cap);
+/* FNV-1a-64 of the translation unit the front-end generates from the file, residual names aside (0: outside the supported subset, ThalloX_LastError).
+ * Two files with the same value state the same energy.  A file with a bundled energy's declarations runs on that energy's hand-written plugin only if
+ * its text is a known one or this value is the bundled file's; otherwise on generated kernels. */
+unsigned long long ThalloX_ProblemFileUnitHash(const char* filename);
 
 /* The mini front-end (thallo_amd/csrc/dsl.hpp) run on a .t file without a device: what = 0 its declarations as text, 1 the HIP translation unit it
  * generates (residual-wise cost / evalJTF / applyJTJ / applyJ / applyJt kernels per named residual).  Returns the text's length (the copy is truncated

@@ -92,6 +92,28 @@ def test_wave_aggregated_scatter_is_chosen_per_access(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
+def test_unit_fingerprint_separates_look_alikes(tmp_path):
+    """ThalloX_ProblemFileUnitHash: schedule lines, comments and residual names do not change it; a different weight or a different expression does.
+    (A file with a bundled energy's declarations runs on that energy's hand-written plugin only if its fingerprint is the bundled file's.)"""
+    L = thallo_amd.lib()
+    L.ThalloX_ProblemFileUnitHash.restype = C.c_ulonglong
+    L.ThalloX_ProblemFileUnitHash.argtypes = [C.c_char_p]
+    fp = lambda path: L.ThalloX_ProblemFileUnitHash(str(path).encode())
+    src = open(thallo_amd.energy_file("laplacian_graph")).read()
+    base = fp(thallo_amd.energy_file("laplacian_graph"))
+    assert base != 0
+    a = tmp_path / "a.t"; a.write_text("-- a comment\n" + src + "\nr.fit.J:set_materialize(true)\nr.reg.J:set_materialize(true)\n")
+    assert fp(a) == base
+    b = tmp_path / "b.t"; b.write_text(src.replace("w_fit = 0.5", "w_fit = 0.25"))
+    assert fp(b) not in (0, base)
+    c = tmp_path / "c.t"; c.write_text(src.replace("X(v0(e)) - X(v1(e))", "sin(X(v0(e))) - sin(X(v1(e)))"))
+    assert fp(c) not in (0, base, fp(b))
+    d = tmp_path / "d.t"; d.write_text(src.replace("reg =", "smooth =").replace("r.reg", "r.smooth"))
+    assert fp(d) == base
+    assert fp(os.path.join(os.path.dirname(os.path.abspath(__file__)), "energies", "graph_get.t")) not in (0, base)
+    assert fp(tmp_path / "missing.t") == 0
+
+
 REF_PAIRS = [("examples/image_warping/image_warping.t", "image_warping"), ("examples/arap_mesh_deformation/arap_mesh_deformation.t", "arap_mesh_deformation"),
              ("examples/shape_from_shading/shape_from_shading.t", "shape_from_shading"), ("examples/bundle_adjustment/bundle_adjustment.t", "bundle_adjustment"),
              ("tests/minimal_graph/laplacian.t", "laplacian_graph"), ("tests/minimal/laplacian.t", "laplacian_image_shipped_guard")]

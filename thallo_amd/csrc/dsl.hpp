@@ -26,6 +26,7 @@ namespace dsl {
 enum class Op {
     Const, Param, Load, IndexVal,                  // leaves: literal, scalar Param, image access, iteration index as a value (x:asvalue())
     Add, Sub, Mul, Div, Neg, Sqrt, Sin, Cos, Abs, Pow,
+    Detach,                                        // lib.t Constant(e) = ad.constant: the value of e with no derivative (robust-norm weights, lib.t:157-169)
     Select,                                        // a[0] != 0 ? a[1] : a[2]
     Eq, Ge, Gt, Le, Lt, Not, And, Or,              // 0 / 1 valued, zero derivative (ad.t:824-829)
     InBounds                                       // all index components inside the iteration-dimension bounds (thallo.t:1993-1997)
@@ -90,6 +91,10 @@ struct Generated {
     int n_prm = 0;
 };
 bool generate_source(const Problem& p, Generated& out, std::string& err);
+
+// FNV-1a-64 of the translation unit generated from a .t file, residual names aside: two files with the same fingerprint state the same energy
+// (same expression DAG per residual component, same unknown accesses, same guards).  0 + err if the file is outside the supported subset.
+unsigned long long unit_fingerprint(const char* filename, std::string& err);
 
 std::string describe(const Problem& p);            // one-line-per-declaration summary (tests / verbosity)
 

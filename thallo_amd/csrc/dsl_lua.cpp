@@ -364,6 +364,21 @@ E shift_expr(const E& e, const std::map<int, int>& sh, std::map<const Expr*, E>&
     for (auto& c : n->a) c = shift_expr(c, sh, memo);
     E r = n; memo[e.get()] = r; return r;
 }
+// expr:get(v0(e)): the expression's iteration variable over dimension `from` becomes the Sparse-mapped index (graph access to a computed
+// expression, thallo.t:876-883 with a Sparse index): every plain occurrence of that variable is replaced
+E subst_expr(const E& e, const std::map<int, IndexComp>& to, std::map<const Expr*, E>& memo)
+{
+    auto it = memo.find(e.get()); if (it != memo.end()) return it->second;
+    auto n = std::make_shared<Expr>(*e);
+    for (auto& ic : n->idx) {
+        auto f = to.find(ic.dim);
+        if (f == to.end() || ic.sparse >= 0) continue;
+        if (ic.off != 0) fail(":get through a Sparse map of an expression that reads a shifted neighbour is not supported");
+        ic = f->second;
+    }
+    for (auto& c : n->a) c = subst_expr(c, to, memo);
+    E r = n; memo[e.get()] = r; return r;
+}
 void collect_dims(const E& e, std::vector<int>& dims, std::map<const Expr*, int>& seen)
 {
     if (seen.count(e.get())) return; seen[e.get()] = 1;
@@ -636,7 +651,17 @@ struct Interp {
                 auto c = comps(obj, "get");
                 std::vector<int> dims; { std::map<const Expr*, int> seen; for (auto& e : c) collect_dims(e, dims, seen); }
                 std::map<int, int> sh; std::vector<IndexComp> at;
-                for (auto& a : args) { IndexComp ic = as_index(a, "get"); if (ic.sparse >= 0) fail(ln + ":get through a Sparse map is not supported"); sh[ic.dim] = ic.off; at.push_back(ic); }
+                {   // graph access: every argument went through a Sparse map -> substitute the mapped index for the map's target dimension
+                    std::map<int, IndexComp> to; size_t nsp = 0;
+                    for (auto& a : args) { IndexComp ic = as_index(a, "get"); if (ic.sparse >= 0) { ++nsp; if (ic.off != 0) fail(ln + ":get with an offset through a Sparse map"); to[P.inputs[ic.sparse].dims[1]] = ic; } }
+                    if (nsp) {
+                        if (nsp != args.size()) fail(ln + ":get mixes plain and Sparse-mapped indices");
+                        std::vector<E> out; std::map<const Expr*, E> memo;
+                        for (auto& e : c) out.push_back(subst_expr(e, to, memo));
+                        return { vec(out) };
+                    }
+                }
+                for (auto& a : args) { IndexComp ic = as_index(a, "get"); sh[ic.dim] = ic.off; at.push_back(ic); }
                 bool any = false; for (auto& kv : sh) any = any || kv.second != 0;
                 if (!any) return { obj };
                 std::vector<E> out; std::map<const Expr*, E> memo;
@@ -644,7 +669,7 @@ struct Interp {
                 for (auto& e : c) out.push_back(mk(Op::Select, { inb, shift_expr(e, sh, memo), konst(0.0) }));
                 return { vec(out) };
             }
-            if (m == "materialize") return {};
+            if (m == "materialize" || m == "set_materialize" || m == "set_gradient_materialize") return {};      // computed-array scheduling hints (thallo.t:1907-1927): expressions are always inlined here
             if (m == "dot") { if (args.size() != 1) fail(ln + "v:dot(w)"); return { scalar(dot(comps(obj, "dot"), comps(args[0], "dot"), ln)) }; }
         }
         if (is_symk(obj, SymV::MatInfo)) {
@@ -739,7 +764,7 @@ struct Interp {
     void def(const std::string& name) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = name; globals->vars[name] = f; }
     void install_builtins()
     {
-        for (const char* n : { "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
+        for (const char* n : { "Constant", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
                                "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
                                "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
             def(n);
@@ -813,7 +838,7 @@ struct Interp {
         }
         if (f == "Select") {                        // ad.t:800-809
             need(3); auto c = comps(a[0], "Select"), x = comps(a[1], "Select"), y = comps(a[2], "Select");
-            const size_t n = std::max(x.size(), y.size()); std::vector<E> out;
+            const size_t n = std::max(c.size(), std::max(x.size(), y.size())); std::vector<E> out;       // (a vector condition broadcasts scalar branches)
             if ((c.size() != 1 && c.size() != n) || (x.size() != n && x.size() != 1) || (y.size() != n && y.size() != 1)) fail(ln + "Select: vector lengths differ");
             for (size_t i = 0; i < n; ++i) out.push_back(mk(Op::Select, { c[c.size() == 1 ? 0 : i], x[x.size() == 1 ? 0 : i], y[y.size() == 1 ? 0 : i] }));
             return { vec(out) };
@@ -835,6 +860,23 @@ struct Interp {
         if (f == "And") return cmp2(Op::And); if (f == "Or") return cmp2(Op::Or);
         if (f == "Not") { need(1); return { map1(Op::Not, a[0], "Not") }; }
         if (f == "All" || f == "Any") { need(1); auto c = comps(a[0], f.c_str()); E r = c[0]; for (size_t i = 1; i < c.size(); ++i) r = mk(f == "All" ? Op::And : Op::Or, { r, c[i] }); return { scalar(r) }; }
+        if (f == "Constant") { need(1); return { map1(Op::Detach, a[0], "Constant") }; }                     // lib.t:194 (ad.constant)
+        if (f == "pow") {                                                                                        // ad.pow(base, exponent): exponent a number, a Param or any derivative-free expression
+            need(2); auto bs = comps(a[0], "pow"), ex = comps(a[1], "pow");
+            if (ex.size() != 1) fail(ln + "pow: scalar exponent expected");
+            std::vector<E> out; for (auto& b : bs) out.push_back(mk(Op::Pow, { b, ex[0] }));
+            return { vec(out) };
+        }
+        if (f == "L_2_norm") { need(1); auto v = comps(a[0], "L_2_norm"); if (v.size() == 1) return { a[0] }; return { scalar(un(Op::Sqrt, dot(v, v, ln))) }; }      // lib.t:148-155
+        if (f == "L_p") {                                                                                        // lib.t:157-169: sqrt((|v| + eps)^(p-2)) held constant, times v
+            if (a.size() < 2) fail(ln + "L_p(val, p, domains)");
+            auto v = comps(a[0], "L_p"), pe = comps(a[1], "L_p");
+            if (pe.size() != 1) fail(ln + "L_p: scalar p expected");
+            E dist = v.size() == 1 ? v[0] : un(Op::Sqrt, dot(v, v, ln));
+            E cw = mk(Op::Detach, { un(Op::Sqrt, mk(Op::Pow, { bin(Op::Add, dist, konst(0.0000001)), bin(Op::Sub, pe[0], konst(2.0)) })) });
+            std::vector<E> out; for (auto& c : v) out.push_back(bin(Op::Mul, cw, c));
+            return { vec(out) };
+        }
         if (f == "abs") { need(1); if (a[0].t == Value::Num) return { Value::num(std::fabs(a[0].n)) }; return { map1(Op::Abs, a[0], "abs") }; }
         if (f == "sqrt" || f == "Sqrt") { need(1); if (a[0].t == Value::Num) return { Value::num(std::sqrt(a[0].n)) }; return { map1(Op::Sqrt, a[0], "sqrt") }; }
         if (f == "sin") { need(1); if (a[0].t == Value::Num) return { Value::num(std::sin(a[0].n)) }; return { map1(Op::Sin, a[0], "sin") }; }

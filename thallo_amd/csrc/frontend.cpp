@@ -9,6 +9,7 @@
 // warning; a file with no matching signature is rejected (Plan returns NULL, as the reference does
 // when compilation fails: thallo.t:1431-1432).
 #include "plugin.hpp"
+#include "dsl.hpp"
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -220,6 +221,27 @@ extern "C" int ThalloX_ProblemFileSchedule(const char* filename)
     if (!thallo::parse_problem_file(filename, spec)) return -1;
     auto has = [&](const char* k) { auto it = spec.constants.find(k); return it != spec.constants.end() && it->second > 0; };
     return has("materialize_JtJ") ? 2 : has("materialize_J") ? 1 : 0;
+}
+
+// Does the front-end derive, from this file, exactly the kernels it derives from one of the bundled files of `energy`?  (A file that matches a
+// hand-written plugin by its declarations only -- same inputs, same residual names -- may still state a different energy.)
+namespace thallo {
+bool unit_matches_bundled(const char* filename, const std::string& energy)
+{
+    std::string err;
+    const unsigned long long h = dsl::unit_fingerprint(filename, err);
+    if (!h) return false;
+    for (const auto& k : KNOWN_UNIT_HASHES) if (k.hash == h && energy == k.energy) return true;
+    return false;
+}
+}  // namespace thallo
+
+extern "C" unsigned long long ThalloX_ProblemFileUnitHash(const char* filename)
+{
+    std::string err;
+    const unsigned long long h = filename ? thallo::dsl::unit_fingerprint(filename, err) : 0ULL;
+    if (!h) thallo::set_error("%s", err.c_str());
+    return h;
 }
 
 extern "C" unsigned long long ThalloX_ProblemFileHash(const char* filename, char* energy_out, int cap)

@@ -174,6 +174,7 @@ struct ProblemSpec {
     std::string diagnostic;
 };
 bool parse_problem_file(const char* filename, ProblemSpec& out);
+bool unit_matches_bundled(const char* filename, const std::string& energy);      // frontend.cpp
 
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims);
 // the mini front-end (dsl.hpp): run the .t, generate its residual-wise kernels, compile them with hipRTC; NULL + set_error on failure

@@ -764,7 +764,7 @@ struct Interp {
     void def(const std::string& name) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = name; globals->vars[name] = f; }
     void install_builtins()
     {
-        for (const char* n : { "Constant", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
+        for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
                                "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
                                "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
             def(n);
@@ -774,6 +774,13 @@ struct Interp {
         for (const char* n : { "sqrt", "sin", "cos", "abs" }) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = n; math.tab->fields.push_back({ n, f }); }
         math.tab->fields.push_back({ "pi", Value::num(3.14159265358979323846) });
         globals->vars["math"] = math;
+        // `ad.*` as the energy files use it next to the lib.t names (ad.Vector, ad.sqrt, ad.select, ad.less ...): the same builtins
+        Value adt; adt.t = Value::Table; adt.tab = std::make_shared<TableV>();
+        const char* alias[][2] = { { "Vector", "Vector" }, { "sqrt", "sqrt" }, { "sin", "sin" }, { "cos", "cos" }, { "abs", "abs" }, { "pow", "pow" }, { "select", "Select" },
+                                   { "less", "less" }, { "lesseq", "lesseq" }, { "greater", "greater" }, { "greatereq", "greatereq" }, { "eq", "eq" }, { "constant", "Constant" },
+                                   { "and_", "And" }, { "or_", "Or" }, { "not_", "Not" } };
+        for (auto& al : alias) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = al[1]; adt.tab->fields.push_back({ al[0], f }); }
+        globals->vars["ad"] = adt;
     }
     static int type_channels(const Value& t, bool* u8, int line)
     {
@@ -907,6 +914,49 @@ struct Interp {
                                  N(sb), M(cb, sa), M(cb, ca) };
             std::vector<E> out; for (int r = 0; r < 3; ++r) out.push_back(A(A(M(m[3 * r], v[0]), M(m[3 * r + 1], v[1])), M(m[3 * r + 2], v[2])));
             return { vec(out) };
+        }
+        if (f == "Vec3") { need(1); auto v = comps(a[0], "Vec3"); if (v.size() < 3) fail(ln + "Vec3 of a shorter vector"); return { vec({ v[0], v[1], v[2] }) }; }
+        if (f == "RotationMatrixAndTranslationToMat4") {      // lib.t:256-261: [R | t ; 0 0 0 1], row-major
+            need(2); auto r = comps(a[0], f.c_str()), t = comps(a[1], f.c_str()); if (r.size() != 9 || t.size() != 3) fail(ln + f + "(matrix9, vector3)");
+            return { vec({ r[0], r[1], r[2], t[0], r[3], r[4], r[5], t[1], r[6], r[7], r[8], t[2], konst(0.0), konst(0.0), konst(0.0), konst(1.0) }) };
+        }
+        if (f == "rigid_trans") {                   // lib.t:508-510: the first three rows of M (4x4, row-major) applied to (v, 1)
+            need(2); auto M = comps(a[0], f.c_str()), v = comps(a[1], f.c_str()); if (M.size() != 16 || v.size() < 3) fail(ln + "rigid_trans(matrix16, vector3)");
+            std::vector<E> out;
+            for (int r = 0; r < 3; ++r) out.push_back(bin(Op::Add, bin(Op::Add, bin(Op::Add, bin(Op::Mul, M[4 * r], v[0]), bin(Op::Mul, M[4 * r + 1], v[1])), bin(Op::Mul, M[4 * r + 2], v[2])), bin(Op::Mul, M[4 * r + 3], konst(1.0))));
+            return { vec(out) };
+        }
+        if (f == "RodriguesSO3Exp" || f == "PoseToMatrix") {
+            // lib.t:207-240 / 466-501: rotation vector w -> R = I + A [w]x + B [w]x^2 written out entry by entry; PoseToMatrix picks A, B (and the translation's
+            // V-matrix coefficients) by the size of |w|^2 -- Taylor forms below 1e-8 and 1e-6, closed forms above -- and returns the 4x4 pose
+            auto M = [&](E x, E y) { return bin(Op::Mul, x, y); }; auto A_ = [&](E x, E y) { return bin(Op::Add, x, y); }; auto S_ = [&](E x, E y) { return bin(Op::Sub, x, y); };
+            auto rodrigues = [&](const std::vector<E>& w, E A, E B) {
+                E wx2 = M(w[0], w[0]), wy2 = M(w[1], w[1]), wz2 = M(w[2], w[2]);
+                E R00 = S_(konst(1.0), M(B, A_(wy2, wz2))), R11 = S_(konst(1.0), M(B, A_(wx2, wz2))), R22 = S_(konst(1.0), M(B, A_(wx2, wy2)));
+                E a = M(A, w[2]), b = M(B, M(w[0], w[1])); E R01 = S_(b, a), R10 = A_(b, a);
+                a = M(A, w[1]); b = M(B, M(w[0], w[2])); E R02 = A_(b, a), R20 = S_(b, a);
+                a = M(A, w[0]); b = M(B, M(w[1], w[2])); E R12 = S_(b, a), R21 = A_(b, a);
+                return std::vector<E>{ R00, R01, R02, R10, R11, R12, R20, R21, R22 };
+            };
+            if (f == "RodriguesSO3Exp") { need(3); auto w = comps(a[0], f.c_str()); if (w.size() != 3) fail(ln + "RodriguesSO3Exp(vector3, A, B)"); return { vec(rodrigues(w, one(a[1], f.c_str()), one(a[2], f.c_str()))) }; }
+            need(2); auto rot = comps(a[0], f.c_str()), tr = comps(a[1], f.c_str()); if (rot.size() != 3 || tr.size() != 3) fail(ln + "PoseToMatrix(rotation3, translation3)");
+            E th2 = dot(rot, rot, ln), th = un(Op::Sqrt, th2);
+            auto cr = cross(rot, tr, ln), wcr = cross(rot, cr, ln);
+            E small = mk(Op::Lt, { th2, konst(1e-8) }), mid = mk(Op::Lt, { th2, konst(1e-6) });
+            const double sixth = 1.0 / 6.0, twentieth = 1.0 / 20.0;
+            E A_s = S_(konst(1.0), M(konst(sixth), th2)), B_s = konst(0.5);
+            E C_m = M(konst(sixth), S_(konst(1.0), M(konst(twentieth), th2))), A_m = S_(konst(1.0), M(th2, C_m)), B_m = S_(konst(0.5), M(konst(0.25 * sixth), th2));
+            E inv = bin(Op::Div, konst(1.0), th), inv2 = M(inv, inv);
+            E A_l = M(un(Op::Sin, th), inv), B_l = M(S_(konst(1.0), un(Op::Cos, th)), inv2), C_l = M(S_(konst(1.0), A_l), inv2);
+            auto sel = [&](E c, E x, E y) { return mk(Op::Select, { c, x, y }); };
+            std::vector<E> t3;
+            for (int i = 0; i < 3; ++i) {
+                E ts = A_(tr[i], M(konst(0.5), cr[i])), tm = A_(A_(tr[i], M(B_m, cr[i])), M(C_m, wcr[i])), tl = A_(A_(tr[i], M(B_l, cr[i])), M(C_l, wcr[i]));
+                t3.push_back(sel(small, ts, sel(mid, tm, tl)));
+            }
+            E A = sel(small, A_s, sel(mid, A_m, A_l)), B = sel(small, B_s, sel(mid, B_m, B_l));
+            auto R = rodrigues(rot, A, B);
+            return { vec({ R[0], R[1], R[2], t3[0], R[3], R[4], R[5], t3[1], R[6], R[7], R[8], t3[2], konst(0.0), konst(0.0), konst(0.0), konst(1.0) }) };
         }
         if (f == "AngleAxisRotatePoint") {          // lib.t:514-555
             need(2); auto w0 = comps(a[0], f.c_str()), pt = comps(a[1], f.c_str()); if (w0.size() != 3 || pt.size() != 3) fail(ln + "AngleAxisRotatePoint(axis3, point3)");

@@ -142,7 +142,7 @@ REF_EXAMPLES = ["examples/image_warping/image_warping.t", "examples/arap_mesh_de
                 "examples/procrustes_alignment/procrustes_alignment.t", "examples/shape_and_shading/shape_and_shading.t",
                 "examples/volumetric_mesh_deformation/volumetric_mesh_deformation.t", "examples/embedded_mesh_deformation/embedded_mesh_deformation.t",
                 "examples/intrinsic_image_decomposition/intrinsic_image_decomposition.t", "examples/robust_nonrigid_alignment/robust_nonrigid_alignment.t",
-                "examples/sparse_bundle_fusion/bundle_fusion_solve.t",
+                "examples/sparse_bundle_fusion/bundle_fusion_solve.t", "examples/optical_flow/optical_flow.t",
                 "tests/minimal_sparse_materialize/minimal_sparse_materialize.t", "tests/expansive_sparse_materialize/expansive_sparse_materialize.t",
                 "tests/minimal/laplacian.t", "tests/minimal_graph/laplacian.t", "tests/minimal_exclude/minimal_exclude.t",
                 "tests/minimal_materialize/minimal_materialize.t", "tests/multidomain/multidomain.t", "tests/dense/curveFitting.t",
@@ -152,7 +152,7 @@ REF_EXAMPLES = ["examples/image_warping/image_warping.t", "examples/arap_mesh_de
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
 @pytest.mark.parametrize("rel", REF_EXAMPLES)
 def test_the_references_own_files_go_through_the_front_end(rel):
-    """13 of the reference's 17 example energies and 10 of its test energies, as shipped (read in place, never copied): the front-end executes
-    them and emits their kernels.  (Not yet: Sum / SampledImage, Sparse maps into 2-D domains.)"""
+    """14 of the reference's 17 example energies and 10 of its test energies, as shipped (read in place, never copied): the front-end executes
+    them and emits their kernels.  (Not yet: Sum, SampledImageArray, Sparse maps into 2-D domains.)"""
     src = _text(os.path.join(REF, rel), 1)
     assert "cost_0" in src and "jtf_0" in src and "jtj_0" in src

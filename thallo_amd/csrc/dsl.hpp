@@ -26,6 +26,8 @@ namespace dsl {
 enum class Op {
     Const, Param, Load, IndexVal,                  // leaves: literal, scalar Param, image access, iteration index as a value (x:asvalue())
     Add, Sub, Mul, Div, Neg, Sqrt, Sin, Cos, Abs, Pow,
+    Sample,                                        // SampledImage(im, dx, dy)(x, y): bilinear sample of an Array at the float position (a[0], a[1]); partials are the
+                                                   // samples of the two derivative images (thallo.t:5798-5817, Image:sample thallo.t:899-907)
     Detach,                                        // lib.t Constant(e) = ad.constant: the value of e with no derivative (robust-norm weights, lib.t:157-169)
     Select,                                        // a[0] != 0 ? a[1] : a[2]
     Eq, Ge, Gt, Le, Lt, Not, And, Or,              // 0 / 1 valued, zero derivative (ad.t:824-829)
@@ -43,7 +45,8 @@ struct Expr {
     Op op = Op::Const;
     double c = 0.0;                                // Const
     int input = -1;                                // Param / Load: index into Problem::inputs
-    int channel = 0;                               // Load
+    int channel = 0;                               // Load / Sample
+    int input_dx = -1, input_dy = -1;              // Sample: the derivative images (-1: none given, the sample then must not depend on an unknown)
     std::vector<IndexComp> idx;                    // Load / InBounds ; IndexVal: idx[0]
     int expand = 0;                                // InBounds: InBoundsExpanded(x, y, n) keeps n pixels off the border
     std::vector<E> a;                              // operands

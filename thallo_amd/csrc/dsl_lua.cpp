@@ -307,9 +307,10 @@ struct TableV { std::vector<Value> arr; std::vector<std::pair<std::string, Value
 struct Env;
 struct FuncV { int builtin = -1; std::string bname; NP def; std::shared_ptr<Env> env; };
 struct SymV {
-    enum K { Scalar, Vec, Dim, IndexDomain, IndexE, Image, TypeName, ResidualsH, NamedRes, MatInfo, StencilList } k = Scalar;
+    enum K { Scalar, Vec, Dim, IndexDomain, IndexE, Image, Sampled, TypeName, ResidualsH, NamedRes, MatInfo, StencilList } k = Scalar;
     E e; std::vector<E> v;                         // Scalar / Vec
-    int id = -1;                                   // Dim / IndexDomain: dimension id ; Image: input index ; NamedRes: residual index
+    int id = -1;                                   // Dim / IndexDomain: dimension id ; Image / Sampled: input index ; NamedRes: residual index
+    int id_dx = -1, id_dy = -1;                    // Sampled: the derivative images
     IndexComp ic;                                  // IndexE
     std::string s;                                 // TypeName ; MatInfo: "J" / "JtJ" / "Jp"
     std::vector<std::vector<double>> stencil;      // StencilList
@@ -626,6 +627,16 @@ struct Interp {
             for (int c = 0; c < in.channels; ++c) { auto e = std::make_shared<Expr>(); e->op = Op::Load; e->input = s.id; e->channel = c; e->idx = idx; out.push_back(e); }
             return vec(out);
         }
+        if (s.k == SymV::Sampled) {                                  // A.SampledImage:__call(x, y, c), thallo.t:5784-5795
+            const Input& in = P.inputs[s.id];
+            if (args.size() != 2 && args.size() != 3) fail(ln + "a sampled image takes (x, y) or (x, y, channel)");
+            const E x = one(args[0], "sampled image x"), y = one(args[1], "sampled image y");
+            int c0 = 0, c1 = in.channels;
+            if (args.size() == 3) { if (args[2].t != Value::Num || args[2].n < 0 || args[2].n >= in.channels) fail(ln + "index out of bounds"); c0 = (int)args[2].n; c1 = c0 + 1; }
+            std::vector<E> out;
+            for (int c = c0; c < c1; ++c) { auto e = std::make_shared<Expr>(); e->op = Op::Sample; e->input = s.id; e->input_dx = s.id_dx; e->input_dy = s.id_dy; e->channel = c; e->a = { x, y }; out.push_back(e); }
+            return out.size() == 1 ? scalar(out[0]) : vec(out);
+        }
         fail(ln + "this value is not callable");
     }
 
@@ -764,7 +775,7 @@ struct Interp {
     void def(const std::string& name) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = name; globals->vars[name] = f; }
     void install_builtins()
     {
-        for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
+        for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "SampledImage", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
                                "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
                                "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
             def(n);
@@ -867,6 +878,19 @@ struct Interp {
         if (f == "And") return cmp2(Op::And); if (f == "Or") return cmp2(Op::Or);
         if (f == "Not") { need(1); return { map1(Op::Not, a[0], "Not") }; }
         if (f == "All" || f == "Any") { need(1); auto c = comps(a[0], f.c_str()); E r = c[0]; for (size_t i = 1; i < c.size(); ++i) r = mk(f == "All" ? Op::And : Op::Or, { r, c[i] }); return { scalar(r) }; }
+        if (f == "SampledImage") {                                   // lib.t:144 = ad.sampledimage(image, imagedx, imagedy), thallo.t:5802-5818
+            const int n = (int)a.size(); if (n != 1 && n != 3) fail(ln + "SampledImage(image) or SampledImage(image, dx, dy)");
+            SymV r; r.k = SymV::Sampled;
+            for (int k = 0; k < n; ++k) {
+                if (!is_symk(a[k], SymV::Image)) fail(ln + "expected an image or a sampled image as a derivative");
+                const Input& in = P.inputs[a[k].sym->id];
+                if (in.kind != InputKind::Array || in.is_u8) fail(ln + "sampled images are float Arrays");
+                if (in.dims.size() != 2) fail(ln + "sampled images must be 2D");
+                if (k && in.channels != P.inputs[a[0].sym->id].channels) fail(ln + "the derivative images of a sampled image have its channel count");
+                (k == 0 ? r.id : k == 1 ? r.id_dx : r.id_dy) = a[k].sym->id;
+            }
+            return { Value::make_sym(r) };
+        }
         if (f == "Constant") { need(1); return { map1(Op::Detach, a[0], "Constant") }; }                     // lib.t:194 (ad.constant)
         if (f == "pow") {                                                                                        // ad.pow(base, exponent): exponent a number, a Param or any derivative-free expression
             need(2); auto bs = comps(a[0], "pow"), ex = comps(a[1], "pow");

@@ -114,6 +114,23 @@ def test_unit_fingerprint_separates_look_alikes(tmp_path):
     assert fp(tmp_path / "missing.t") == 0
 
 
+def test_the_compiled_in_unit_fingerprints_are_current():
+    """known_energy_hashes.inc (tools/gen_energy_hashes.py) holds the fingerprint of every bundled energy as THIS build of the front-end computes it --
+    a stale table silently sends a known energy with extra schedule lines to the generated kernels instead of its hand-written plugin."""
+    import glob
+    import re
+    L = thallo_amd.lib()
+    L.ThalloX_ProblemFileUnitHash.restype = C.c_ulonglong
+    L.ThalloX_ProblemFileUnitHash.argtypes = [C.c_char_p]
+    inc = open(os.path.join(os.path.dirname(os.path.abspath(thallo_amd.__file__)), "csrc", "known_energy_hashes.inc")).read()
+    table = inc[inc.index("KNOWN_UNIT_HASHES"):]
+    known = {int(h, 16) for h in re.findall(r"0x([0-9a-f]{16})ULL", table)}
+    files = sorted(glob.glob(os.path.join(os.path.dirname(thallo_amd.energy_file("image_warping")), "*.t")))
+    assert len(files) >= 6
+    for f in files:
+        assert L.ThalloX_ProblemFileUnitHash(f.encode()) in known, f
+
+
 REF_PAIRS = [("examples/image_warping/image_warping.t", "image_warping"), ("examples/arap_mesh_deformation/arap_mesh_deformation.t", "arap_mesh_deformation"),
              ("examples/shape_from_shading/shape_from_shading.t", "shape_from_shading"), ("examples/bundle_adjustment/bundle_adjustment.t", "bundle_adjustment"),
              ("tests/minimal_graph/laplacian.t", "laplacian_graph"), ("tests/minimal/laplacian.t", "laplacian_image_shipped_guard")]

@@ -615,10 +615,10 @@ def test_unknown_energy_and_bad_kind_fail_loudly(torch, tmp_path, monkeypatch):
     monkeypatch.delenv("THALLO_FRONTEND")                    # default: it goes through the front-end (tests/test_gpu_frontend.py) ...
     s = api.ThalloSolver((8,), str(f)); assert s.energy_name == "generated:x.t"; s.close()
     g = tmp_path / "y.t"                                     # ... which rejects what it does not implement, naming the construct
-    g.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0) }\nr = Residuals { only = SampledImage(X)(N()) }\n')
+    g.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0) }\nr = Residuals { only = SampledImageArray(X)(N()) }\n')
     with pytest.raises(RuntimeError):
         api.ThalloSolver((8,), str(g))
-    assert "SampledImage" in api.last_error()
+    assert "SampledImageArray" in api.last_error()
     with pytest.raises(RuntimeError):
         api.ThalloSolver((8, 8), thallo_amd.energy_file("image_warping"), solverkind="newton")
     with pytest.raises(RuntimeError):

@@ -17,10 +17,51 @@
 
 namespace thallo {
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not -- as __syncthreads() does with its
+// s_waitcnt vmcnt(0) -- for every global load and STORE it has in flight.  In a kernel's reduction tail that drain is 1-2 us during which
+// nothing else happens (the stores the wave issued a moment ago travel to L2 while the wave could already add its partials up); in the
+// tile kernel's loop it would serialise the prefetch of the next tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The wave64 butterfly (v += value of lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: every lane ends with the same total, fixed association order) WITHOUT
+// the LDS crossbar: __shfl_xor is a ds_bpermute_b32 per 32-bit word and step (address arithmetic + ~100 cycles of LDS round trip, six of them
+// in a dependent chain = ~0.5 us per reduction point, which is 5 % of a whole PCG iteration on the small working sets).  gfx950 has the lane
+// exchanges as plain VALU operations: v_permlane32_swap / v_permlane16_swap for the two cross-row steps, DPP row_ror:8, row_shl:4 + row_shr:4
+// (bank-masked halves), quad_perm for the steps inside a row of 16.  Same partners, same order, IEEE addition commutes: bit-identical to the
+// __shfl_xor form (tests/test_gpu_parity.py pins the reduce primitive against a numpy restatement).  All 64 lanes must be active.
+template <int M> __device__ __forceinline__ unsigned lane_xor_u32(unsigned v)
+{
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "in-row partners only");
+    const int x = (int)v;
+    if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);        // quad_perm:[1,0,3,2]
+    else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+    else if constexpr (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);  // row_ror:8
+    else {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);                            // row_shl:4 into banks 0, 2 (lane i <- i + 4)
+        return (unsigned)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);                         // row_shr:4 into banks 1, 3 (lane i <- i - 4)
+    }
+}
+// own + partner across the two halves of the wave (M = 32) or across neighbouring rows of 16 (M = 16).  After the swap of two copies of v:
+// a = {low, low} / {row0, row0, row2, row2}, b = {high, high} / {row1, row1, row3, row3}; a + b is own + partner in the first of each pair and
+// partner + own in the second.  The second copy is made opaque to the optimiser: it folds a swap of two IDENTICAL values into a no-op
+// (true for wave-uniform values only; seen as v_add v, v, v in the ISA).
+template <int M> __device__ __forceinline__ void swap_halves_u32(unsigned v, unsigned& a, unsigned& b)
+{
+    static_assert(M == 16 || M == 32, "cross-row partners only");
+    unsigned w = v;
+    asm volatile("" : "+v"(w));
+    if constexpr (M == 32) { const auto r = __builtin_amdgcn_permlane32_swap(v, w, false, false); a = r[0]; b = r[1]; }
+    else { const auto r = __builtin_amdgcn_permlane16_swap(v, w, false, false); a = r[0]; b = r[1]; }
+}
 __device__ __forceinline__ float wave_sum_all(float v)
-{   // butterfly: every lane ends with the same total, fixed association order
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
+{
+    unsigned a, b;
+    swap_halves_u32<32>(__builtin_bit_cast(unsigned, v), a, b); v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    swap_halves_u32<16>(__builtin_bit_cast(unsigned, v), a, b); v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    v += __builtin_bit_cast(float, lane_xor_u32<8>(__builtin_bit_cast(unsigned, v)));
+    v += __builtin_bit_cast(float, lane_xor_u32<4>(__builtin_bit_cast(unsigned, v)));
+    v += __builtin_bit_cast(float, lane_xor_u32<2>(__builtin_bit_cast(unsigned, v)));
+    v += __builtin_bit_cast(float, lane_xor_u32<1>(__builtin_bit_cast(unsigned, v)));
     return v;
 }
 
@@ -58,7 +99,7 @@ __device__ __forceinline__ void block_store_partials(float (&v)[NQ], float* __re
         float s = wave_sum_all(v[q]);
         if (lane == 0) red[q * 16 + wave] = s;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < NQ) {
         float s = 0.0f;
         for (int w = 0; w < nw; ++w) s += red[threadIdx.x * 16 + w];
@@ -84,10 +125,21 @@ struct Sums3 {
         n += dm * (dr * dr); s1 += dm * (dr * da); s2 += dm * (da * da);
     }
 };
+// the double butterfly: the two 32-bit halves travel separately (see wave_sum_all)
+template <int M> __device__ __forceinline__ double lane_xor_f64(double v)
+{
+    return __hiloint2double((int)lane_xor_u32<M>((unsigned)__double2hiint(v)), (int)lane_xor_u32<M>((unsigned)__double2loint(v)));
+}
+template <int M> __device__ __forceinline__ double swap_add_f64(double v)
+{
+    unsigned la, lb, ha, hb;
+    swap_halves_u32<M>((unsigned)__double2loint(v), la, lb); swap_halves_u32<M>((unsigned)__double2hiint(v), ha, hb);
+    return __hiloint2double((int)ha, (int)la) + __hiloint2double((int)hb, (int)lb);
+}
 __device__ __forceinline__ double wave_sum_all_f64(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
+    v = swap_add_f64<32>(v); v = swap_add_f64<16>(v);
+    v += lane_xor_f64<8>(v); v += lane_xor_f64<4>(v); v += lane_xor_f64<2>(v); v += lane_xor_f64<1>(v);
     return v;
 }
 // one {N, S1, S2} triple per workgroup into out[3*blockIdx.x ..]; every thread calls it; redd >= 3 * (blockDim.x / 64) doubles of LDS
@@ -97,7 +149,7 @@ __device__ __forceinline__ void block_store_sums3(const Sums3& s, double* __rest
     const int nw = (blockDim.x + THALLO_WAVE - 1) / THALLO_WAVE;
     const double a = wave_sum_all_f64(s.n), b = wave_sum_all_f64(s.s1), c = wave_sum_all_f64(s.s2);
     if (lane == 0) { redd[3 * wave] = a; redd[3 * wave + 1] = b; redd[3 * wave + 2] = c; }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         double x = 0.0, y = 0.0, z = 0.0;
         for (int w = 0; w < nw; ++w) { x += redd[3 * w]; y += redd[3 * w + 1]; z += redd[3 * w + 2]; }
@@ -179,7 +231,7 @@ __device__ __forceinline__ void block_finish_sums(float acc, const Sums3& sm, fl
     const float wa = wave_sum_all(acc);
     const double w0 = wave_sum_all_f64(sm.n), w1 = wave_sum_all_f64(sm.s1), w2 = wave_sum_all_f64(sm.s2);
     if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
-    __syncthreads();
+    lds_barrier();
     const int slot = fin.blk_off + blockIdx.x;
     if (threadIdx.x == 0) {
         float a = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
@@ -203,7 +255,7 @@ __device__ __forceinline__ void block_finish_sums(float acc, const Sums3& sm, fl
         }
     }
     if (!fin.tickets) return;
-    __syncthreads();
+    lds_barrier();
     if (red[15] == 0.0f || wave != 0) return;
     const IterationSums S = load_iteration_sums(aD_out, s3_out, fin.nb_total, fin.alphaN);
     const float ad = S.ad, an = S.an; const double n = S.n, a1 = S.s1, b1 = S.s2;

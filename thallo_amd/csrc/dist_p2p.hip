@@ -27,12 +27,7 @@ __global__ __launch_bounds__(64) void k_exchange(thallo_dist_t d, int slot, thal
     if (threadIdx.x == 0) out[0] = t[0];
 }
 
-__device__ __forceinline__ double wave_sum_all_dd(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
-    return v;
-}
+__device__ __forceinline__ double wave_sum_all_dd(double v) { return wave_sum_all_f64(v); }
 
 // The exchange of the one-kernel-per-iteration schedule (thallo_hip_iw_pcg_iter): one wave adds this rank's alphaD partials
 // (float) and N, S1, S2 partials (double) in the fixed single-GPU order, sends them as 7 granules (the doubles as hi / lo words)

@@ -74,8 +74,6 @@ struct Tile {
     unsigned char f[LN + 4];        // bit0 active (Mask==0), bit1 fit-valid
 };
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 struct Owned { float2 zv, pv, dv, csv, uv, ppv; float zav, pav, da, ppa; unsigned char ff; };
 struct HaloLd { float2 zv, pv, csv, uv; float zav, pav; unsigned char ff; };
 
@@ -511,6 +509,13 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int W, int H, int row0, int row1
 // r, Ap and p ping-pong (a neighbouring tile reads the old value of a pixel this tile overwrites).
 // Bytes per pixel (pixel grid): read r 12, Ap 12, p 12, cs 8, flags 1; write r 12, p 12, Ap 12 = 81 (+ 18 deferred delta on
 // average) against 75 + 37 for the two-kernel form.
+#ifdef THALLO_MARCH_SWEEP
+// tools/march_probe.py MB_MODE=stamps: where a launch of the tile kernel spends its time (100 MHz wall clock, thread 0 of every workgroup)
+__device__ unsigned long long* g_stamps = nullptr;
+#define IW_STAMP(k) do { if (threadIdx.x == 0 && g_stamps) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define IW_STAMP(k) do { } while (0)
+#endif
 struct TileI : Tile { float rx[LN], ry[LN], ra[LN]; };      // + r_k of the owned pixels (read back in the gather phase)
 struct OwnedI { float2 rv, av, pv, csv, uv, dv, ppv, mv; float ra, aa, pav, da, ppa, ma; unsigned char ff; };
 struct HaloI { float2 rv, av, pv, csv, uv, mv; float ra, aa, pav, ma; unsigned char ff; };
@@ -587,12 +592,18 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
     };
 
     TileSweep t(g.ntiles);
+    IW_STAMP(0);
+#ifdef THALLO_MARCH_SWEEP
+    const long long clk0 = clock64();
+#endif
     if (t.valid()) issue_loads(t.cur);
+    IW_STAMP(1);
     float alpha = 0.0f, beta = 0.0f, alpha2 = 0.0f;
     if (!first) {
         iteration_scalars(aNp, aDp, bNp, prev, alpha, beta, blockIdx.x == 0 && threadIdx.x == 0);
         if (dmode == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
     }
+    IW_STAMP(2);
 
     float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     while (t.valid()) {
@@ -651,7 +662,9 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
             T.px[i] = npx; T.py[i] = npy; T.pa[i] = npa; T.c[i] = c1; T.s[i] = s1_; T.f[i] = ff;
             if (!GRID) { T.ux[i] = u1; T.uy[i] = u2; }
         }
+        IW_STAMP(3);
         lds_barrier();
+        IW_STAMP(4);
         const int cur_y0 = y0;
         t.next();
         if (t.valid()) issue_loads(t.cur);
@@ -712,9 +725,14 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
                 s2 += dmo * (dax * dax) + dmy * (day * day) + dma * (daa * daa);
             }
         }
+        IW_STAMP(5);
         lds_barrier();
     }
     iter_tail<NT, DIST>(acc, s0, s1, s2, red, redd, aD_out, s12_out, bNp, dd, fin_tickets, aD_word, bN_word, xslot);
+    IW_STAMP(6);
+#ifdef THALLO_MARCH_SWEEP
+    if (threadIdx.x == 0 && g_stamps) g_stamps[blockIdx.x * 8 + 7] = (unsigned long long)(clock64() - clk0);
+#endif
 }
 
 template <int MINW, int NT, bool DIST>
@@ -758,6 +776,9 @@ __global__ __launch_bounds__(64) void k_iter_finish(const float* __restrict__ aD
 
 extern "C" {
 
+#ifdef THALLO_MARCH_SWEEP
+int thallo_hip_debug_stamps(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
+#endif
 void thallo_hip_debug_set(int what, int value) { if (what == 0) g_iw_debug = value; if (what == 3) g_nt_mask = value; if (what == 4) g_no_grid = value; if (what == 5) g_step1_per_cu = value; if (what == 6) g_step1_threads = value; if (what == 7) g_iter_nt = value; if (what == 8) g_iter_per_cu = value < 1 ? 1 : value > 2 ? 2 : value; }
 
 int thallo_hip_iw_cost(int W, int H, int row0, int row1, const float* offset, const float* angle, const float* urshape,

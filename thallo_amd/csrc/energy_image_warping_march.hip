@@ -104,6 +104,14 @@ __device__ __forceinline__ void nb_term(bool valid, float ci, float si, float px
     }
 }
 
+#ifdef THALLO_MARCH_SWEEP
+// tools/march_probe.py MB_MODE=stamps: where a launch spends its time (100 MHz wall clock, lane 0 of every wave)
+__device__ unsigned long long* g_stamps_m = nullptr;
+#define MARCH_STAMP(k) do { if ((threadIdx.x & 63) == 0 && g_stamps_m) g_stamps_m[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define MARCH_STAMP(k) do { } while (0)
+#endif
+
 template <bool FIRST, int DMODE, int DEPTH, int NTM, bool DIST, int OCC, int DBG>
 __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const float* __restrict__ cs, const unsigned char* __restrict__ flags, float wf2, float wr2,
                                                          const float* __restrict__ r_in, float* __restrict__ r_out, const float* __restrict__ A_in, float* __restrict__ A_out,
@@ -125,8 +133,10 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         if (threadIdx.x == 0) { aD_out[blockIdx.x] = __builtin_nanf(""); }
         return;
     }
+    MARCH_STAMP(0);
     if (threadIdx.x < 32) { float mo, ma; pre_from_flags((unsigned char)threadIdx.x, wf2, wr2, mo, ma); lut[threadIdx.x] = make_float2(mo, ma); }
     __syncthreads();
+    MARCH_STAMP(1);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long N = (long)g.W * g.H;
@@ -332,7 +342,10 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) {
             // The iteration's scalars, at the start of the SECOND trip: the first trip only issued the loads of rows t_first .. t_first + 2, nothing
             // needed alpha / beta yet; now the partial (or word) loads queue up behind those row loads and the additions run while the rows arrive.
+            if (t0 == t_first) MARCH_STAMP(2);
             if (!FIRST && SCALARS_IN_LOOP && t0 == t_first) iteration_scalars<1>(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
+            if (t0 == t_first) MARCH_STAMP(3);
+            if (t0 == t_first + 3) MARCH_STAMP(4);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = t0 + j;
@@ -351,7 +364,9 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
             }
         }
     }
+    MARCH_STAMP(5);
     iter_tail<MARCH_NT, DIST>(acc, s0, s1, s2, red, redd, aD_out, s12_out, bNp, &dd, fin_tickets, aD_word, bN_word, xslot);
+    MARCH_STAMP(6);
 }
 
 // Is UrShape the unit pixel grid?  Counts the pixels whose right / down neighbour is not at the exact unit offset (the property
@@ -493,6 +508,9 @@ int launch_march(int W, int H, int row0, int row1, const float* cs, const unsign
 }  // namespace
 
 extern "C" {
+#ifdef THALLO_MARCH_SWEEP
+int thallo_hip_debug_stamps_march(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_m), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
+#endif
 
 int thallo_hip_iw_pcg_iter_march(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags,
                                  float w_fit, float w_reg, const float* r_in, float* r_out, const float* Ap_in, float* Ap_out,

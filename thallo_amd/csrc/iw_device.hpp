@@ -23,12 +23,7 @@ __device__ __forceinline__ void pre_from_flags(unsigned char f, float wf2, float
     mo = guarded_invert(dgo); ma = guarded_invert(cnt * wr2);
 }
 
-__device__ __forceinline__ double wave_sum_all_d(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, THALLO_WAVE);
-    return v;
-}
+__device__ __forceinline__ double wave_sum_all_d(double v) { return wave_sum_all_f64(v); }
 
 // The scalars a one-kernel PCG iteration starts from: alpha_{k-1} = alphaN_{k-1} / alphaD_{k-1}, beta_{k-1} = betaN_{k-1} / alphaN_{k-1}.
 // Either from the finished words of iteration k-1 (aDp, bNp), or -- prev.count > 0, the DEFERRED finish -- from its raw per-workgroup
@@ -92,7 +87,7 @@ __device__ __forceinline__ void iter_tail(float acc, double s0, double s1, doubl
     const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
     const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
     if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         float a = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
         for (int w = 0; w < NT / THALLO_WAVE; ++w) { a += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
@@ -119,7 +114,7 @@ __device__ __forceinline__ void iter_tail(float acc, double s0, double s1, doubl
         }
     }
     if (fin_tickets) {
-        __syncthreads();
+        lds_barrier();
         if (red[15] != 0.0f && wave == 0) {
             const IterationSums S = load_iteration_sums(aD_out, s12_out, gridDim.x, bNp);          // bNp = alphaN_k (= betaN_{k-1}; alphaN_0 for the first iteration)
             const float ad = S.ad, an = S.an; const double n = S.n, a1 = S.s1, b1 = S.s2;

@@ -16,6 +16,7 @@ from thallo_amd import api, synthetic as syn
 
 W = int(os.environ.get("MB_W", "2048")); H = int(os.environ.get("MB_H", str(W)))
 REPS = int(os.environ.get("MB_REPS", "20"))
+FIN = os.environ.get("MB_FIN", "1") != "0"       # 0: timing chains without the in-kernel finish (plain partial stores, nothing adds them up)
 L = thallo_amd.lib()
 L.thallo_hip_vector_elems.restype = C.c_long; L.thallo_hip_vector_elems.argtypes = [C.c_long]
 p = syn.image_warping(W, H)
@@ -98,7 +99,7 @@ def timeit(kind, reps=REPS, modes=(4, 2), pingpong=True):
         mode = modes[k % len(modes)]
         tail = (vp(a[0].data_ptr()), vp(b[0].data_ptr()), vp(a[1].data_ptr()), vp(b[1].data_ptr()), vp(a[2].data_ptr()), vp(b[2].data_ptr()), vp(d.data_ptr()), mode,
                 S(0), S(1), S(2), S(3), S(4), vp(irregular.data_ptr()), vp(parts.data_ptr() + 4096), vp(s12.data_ptr()),
-                vp(tickets.data_ptr()), vp(words.data_ptr()), vp(words.data_ptr() + 4), None)
+                vp(tickets.data_ptr()) if FIN else None, vp(words.data_ptr()) if FIN else None, vp(words.data_ptr() + 4) if FIN else None, None)
         if kind == "tile":
             rc = fn(W, H, 0, H, vp(cs.data_ptr()), vp(dev[2].data_ptr()), vp(flags.data_ptr()), vp(pre.data_ptr()), fl(p[5]), fl(p[6]), *tail)
         else:
@@ -148,6 +149,58 @@ if os.environ.get("MB_MODE") == "rows":          # rows-per-segment sweep at the
             out[f"march_rows{rows}_us"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2)]
         except AssertionError as e:
             out[f"march_rows{rows}_us"] = "launch refused"
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "stamps":        # sweep build: phase time stamps (tile kernel: thread 0 of each workgroup; marching kernel: lane 0 of each wave), last launch of a chain
+    stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+    assert L.thallo_hip_debug_stamps(vp(stamps.data_ptr())) == 0 and L.thallo_hip_debug_stamps_march(vp(stamps.data_ptr())) == 0
+    if os.environ.get("MB_ROWS"):
+        L.thallo_hip_march_debug_set(0, int(os.environ["MB_ROWS"]))
+    NAMES = {"tile": ["entry", "loads issued", "scalars known", "tile published", "barrier 1", "stencil done", "tail done"],
+             "march": ["entry", "lut barrier", "first trip (loads issued)", "scalars known", "second trip done", "rows done", "tail done"]}
+    for kind in ("tile", "march"):
+        for modes in ((2,), (4,)):
+            stamps.zero_()
+            timeit(kind, modes=modes)
+            torch.cuda.synchronize()
+            st = stamps.cpu().numpy().reshape(-1, 8)
+            st = st[(st[:, 0] > 0) & (st[:, 6] > 0)].astype(np.float64)
+            for k in range(1, 7):                     # waves without rows skip the loop stamps
+                st[:, k] = np.where(st[:, k] > 0, st[:, k], st[:, k - 1])
+            t0 = st[:, 0].min()
+            out = {"kind": kind, "modes": modes, "stamped": int(st.shape[0]), "us_per_launch": round(timeit(kind, modes=modes), 2)}
+            for k, nm in enumerate(NAMES[kind]):
+                v = (st[:, k] - t0) * 0.01
+                out[nm] = [round(float(np.min(v)), 2), round(float(np.median(v)), 2), round(float(np.max(v)), 2)]
+            if kind == "tile":
+                out["clock64_ticks_per_us"] = round(float(np.median(st[:, 7] / np.maximum((st[:, 6] - st[:, 0]) * 0.01, 1e-3))), 1)
+            d = (st[:, 1:7] - st[:, 0:6]) * 0.01
+            out["phase_median_us"] = [round(float(x), 2) for x in np.median(d, 0)]
+            print(json.dumps(out))
+    sys.exit(0)
+
+if os.environ.get("MB_MODE") == "pmcsmall":      # under rocprofv3 --pmc (tools/small_pmc.sh): the two kernels and the streaming reference, one byte mix
+    timeit("tile", modes=(2,)); timeit("march", modes=(2,)); time_stream(0, 0, 1)
+    sys.exit(0)
+
+if os.environ.get("MB_MODE") == "floor":         # what a launch costs at this size: empty-ish launches, the streaming reference, the two real kernels
+    def chain(fn, reps=200):
+        for _ in range(10): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): fn()
+        e1.record(); torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) / reps * 1e3, 2)
+    one_word = torch.zeros(64, device="cuda"); plane = torch.zeros(3 * N, device="cuda"); plane2 = torch.zeros(3 * N, device="cuda")
+    out = {"W": W, "H": H, "tiny_add_us": chain(lambda: one_word.add_(1.0)), "plane_add_us": chain(lambda: plane.add_(1.0)),
+           "plane_copy_us": chain(lambda: plane2.copy_(plane))}
+    for per_cu in (1, 2, 4):
+        for span in (0, 1):
+            for nt in (0, 11):
+                out[f"stream_percu{per_cu}_span{span}_nt{nt}_us"] = round(time_stream(0, nt, per_cu, span=span), 2)
+    out["tile_us"] = [round(timeit("tile"), 2), round(timeit("tile", modes=(2,)), 2)]
+    out["march_us"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2)]
     print(json.dumps(out)); sys.exit(0)
 
 if __name__ == "pmc":

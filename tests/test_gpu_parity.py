@@ -844,6 +844,43 @@ def test_shape_from_shading_cost_trajectory(torch, orc, W, H, nit, lit):
     assert np.abs(to_host(dev[16]) - po[16]).max() < 2e-5
 
 
+_SFS_FORM_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from thallo_amd import api, synthetic as syn
+from helpers import to_device, to_host
+W, H = {W}, {H}
+p = syn.shape_from_shading(W, H)
+dev = to_device(p)
+s = api.ThalloSolver((W, H), __import__("thallo_amd").energy_file("shape_from_shading"))
+if {lm}: s.enable_lm(True)
+final, costs = s.solve(dev, profiled=True, nIterations=3, lIterations=8)
+np.save({out!r}, np.concatenate([to_host(dev[16]).ravel(), np.array(costs, np.float32)]))
+"""
+
+
+@pytest.mark.parametrize("lm", [0, 1])
+def test_shape_from_shading_apply_forms_agree(torch, tmp_path, lm):
+    """THALLO_SFS_FUSED = 1 (default: the fused, LDS-tiled J^T(J v) kernel) and 0 (two passes with U and R in global memory): same expressions in the same
+    order per pixel, a different number of reduction partials -- the depth map and the costs after 3 x 8 iterations agree to rounding.  A ragged size (130 x 67: partial tiles, image borders inside every
+    halo).  The form is read once per process, hence the child processes."""
+    import subprocess
+    import sys
+    outs = []
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for form in ("1", "0"):
+        out = str(tmp_path / f"sfs_form{form}.npy")
+        code = _SFS_FORM_SNIPPET.format(root=root, tests=os.path.join(root, "tests"), W=130, H=67, lm=lm, out=out)
+        env = dict(os.environ, THALLO_SFS_FUSED=form)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all() and outs[0][-1] < outs[0][-4]
+    a, b = outs
+    assert np.abs(a[-4:] - b[-4:]).max() <= 1e-5 * np.abs(a[-4:]).max(), (a[-4:], b[-4:])
+    assert np.abs(a[:-4] - b[:-4]).max() <= 1e-5 * np.abs(a[:-4]).max()
+
+
 def test_shape_from_shading_lm(torch, orc):
     W, H = 64, 48
     p = syn.shape_from_shading(W, H)

@@ -600,8 +600,17 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
     IW_STAMP(1);
     float alpha = 0.0f, beta = 0.0f, alpha2 = 0.0f;
     if (!first) {
-        iteration_scalars(aNp, aDp, bNp, prev, alpha, beta, blockIdx.x == 0 && threadIdx.x == 0);
-        if (dmode == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
+        // ONE wave adds the previous iteration's partials up (the same additions in the same order as before, so the same bits) and hands
+        // alpha / beta to the others through LDS: the other seven waves of the workgroup would only repeat its 1,000+ loads and ~250 VALU
+        // instructions, and on a one-tile launch (512^2: one workgroup per CU) instruction issue is what the workgroup waits for.  The barrier
+        // costs nothing: the tile's loads, issued above, are still on their way.
+        if (threadIdx.x < THALLO_WAVE) {
+            iteration_scalars(aNp, aDp, bNp, prev, alpha, beta, blockIdx.x == 0 && threadIdx.x == 0);
+            if (dmode == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
+            if (threadIdx.x == 0) { red[12] = alpha; red[13] = beta; red[14] = alpha2; }
+        }
+        lds_barrier();
+        alpha = red[12]; beta = red[13]; alpha2 = red[14];
     }
     IW_STAMP(2);
 

@@ -179,6 +179,16 @@ if os.environ.get("MB_MODE") == "stamps":        # sweep build: phase time stamp
             print(json.dumps(out))
     sys.exit(0)
 
+if os.environ.get("MB_MODE") == "dbg":            # sweep build: what the halo and the arithmetic cost (dbg 1 = no stencil arithmetic, 2 = no double sums, 3 = aligned strips without halo rows / lanes)
+    out = {"W": W, "H": H}
+    for rep in range(2):
+        for nt, dbg in ((5, 0), (5, 1), (5, 3), (11, 0), (11, 1), (11, 3), (0, 0), (0, 3), (1, 0), (1, 3)):
+            cfg(2, nt, 2, dbg)
+            out[f"nt{nt}_dbg{dbg}_us_{rep}"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+        out[f"stream_nt0_us_{rep}"] = [round(time_stream(0, 0, 2, span=0), 2), round(time_stream(1, 0, 2, span=0), 2)]
+        out[f"stream_nt11_us_{rep}"] = [round(time_stream(0, 11, 2, span=0), 2), round(time_stream(1, 11, 2, span=0), 2)]
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "pmcsmall":      # under rocprofv3 --pmc (tools/small_pmc.sh): the two kernels and the streaming reference, one byte mix
     timeit("tile", modes=(2,)); timeit("march", modes=(2,)); time_stream(0, 0, 1)
     sys.exit(0)

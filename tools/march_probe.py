@@ -189,6 +189,19 @@ if os.environ.get("MB_MODE") == "dbg":            # sweep build: what the halo a
         out[f"stream_nt11_us_{rep}"] = [round(time_stream(0, 11, 2, span=0), 2), round(time_stream(1, 11, 2, span=0), 2)]
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_MODE") == "order":          # sweep build: traversal order x cache policy (workgroup shape map 0 / 1, streaming reference span 0 / 1 / 8)
+    out = {"W": W, "H": H}
+    for nt in (5, 11):
+        for dbg in (0, 3):
+            for mp in (0, 1):
+                cfg(2, nt, 2, dbg, 0, mp)
+                out[f"march_nt{nt}_dbg{dbg}_map{mp}_us"] = [round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+    for nt in (0, 11):
+        for per_cu in (1, 2, 4):
+            for span in (0, 1, 8):
+                out[f"stream_nt{nt}_percu{per_cu}_span{span}_us"] = round(time_stream(0, nt, per_cu, span=span), 2)
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "pmcsmall":      # under rocprofv3 --pmc (tools/small_pmc.sh): the two kernels and the streaming reference, one byte mix
     timeit("tile", modes=(2,)); timeit("march", modes=(2,)); time_stream(0, 0, 1)
     sys.exit(0)

@@ -200,6 +200,9 @@ if os.environ.get("MB_MODE") == "order":          # sweep build: traversal order
         for per_cu in (1, 2, 4):
             for span in (0, 1, 8):
                 out[f"stream_nt{nt}_percu{per_cu}_span{span}_us"] = round(time_stream(0, nt, per_cu, span=span), 2)
+    for nt in (0, 11):                             # does the non-temporal gain need the previous launch's writes?  (pingpong off: a -> b every time)
+        out[f"stream_nt{nt}_percu2_nopingpong_us"] = round(time_stream(0, nt, 2, pingpong=False, span=0), 2)
+        out[f"march_nt{nt if nt else 5}_dbg3_nopingpong_us"] = (cfg(2, nt if nt else 5, 2, 3), round(timeit("march", modes=(2,), pingpong=False), 2))[1]
     print(json.dumps(out)); sys.exit(0)
 
 if os.environ.get("MB_MODE") == "pmcsmall":      # under rocprofv3 --pmc (tools/small_pmc.sh): the two kernels and the streaming reference, one byte mix

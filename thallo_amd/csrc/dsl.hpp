@@ -36,8 +36,9 @@ enum class Op {
 
 // one component of an image index: iteration variable of dimension `dim` plus a constant offset, optionally through a Sparse map
 // (graph domains: X(v0(e)): dim = the edge dimension, sparse = input slot of v0; the offset applies before the map and is 0 there)
-struct IndexComp { int dim = -1; int off = 0; int sparse = -1; };
-inline bool operator==(const IndexComp& a, const IndexComp& b) { return a.dim == b.dim && a.off == b.off && a.sparse == b.sparse; }
+// A Sparse map over a 2-D domain (Sparse({W,H},{W},k): Xn(x, y)) is looked up with TWO iteration variables: dim2 = the second one (-1: a 1-D map).
+struct IndexComp { int dim = -1; int off = 0; int sparse = -1; int dim2 = -1; };
+inline bool operator==(const IndexComp& a, const IndexComp& b) { return a.dim == b.dim && a.off == b.off && a.sparse == b.sparse && a.dim2 == b.dim2; }
 
 struct Expr;
 typedef std::shared_ptr<const Expr> E;
@@ -58,7 +59,7 @@ struct Input {
     InputKind kind = InputKind::Array;
     int channels = 1;
     bool is_u8 = false;                            // Array(uint8, ...)
-    std::vector<int> dims;                         // dimension ids (Unknown / Array: the image's; Sparse: {from, to})
+    std::vector<int> dims;                         // dimension ids (Unknown / Array: the image's; Sparse: {from..., to}: one or two source dimensions, then the target)
     int slot = -1;                                 // index into the void** problem parameters
     E exclude;                                     // Unknown:Exclude(cond), evaluated at the unknown's own index (may be null)
 };

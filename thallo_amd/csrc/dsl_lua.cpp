@@ -383,7 +383,7 @@ E subst_expr(const E& e, const std::map<int, IndexComp>& to, std::map<const Expr
 void collect_dims(const E& e, std::vector<int>& dims, std::map<const Expr*, int>& seen)
 {
     if (seen.count(e.get())) return; seen[e.get()] = 1;
-    for (auto& ic : e->idx) { bool have = false; for (int d : dims) have = have || d == ic.dim; if (!have) dims.push_back(ic.dim); }
+    for (auto& ic : e->idx) for (int dd : { ic.dim, ic.dim2 }) { if (dd < 0) continue; bool have = false; for (int d : dims) have = have || d == dd; if (!have) dims.push_back(dd); }
     for (auto& c : e->a) collect_dims(c, dims, seen);
 }
 
@@ -607,11 +607,16 @@ struct Interp {
         if (s.k == SymV::Image) {
             const Input& in = P.inputs[s.id];
             if (in.kind == InputKind::Sparse) {
-                if (args.size() != 1) fail(ln + in.name + " takes one index");
-                IndexComp ic = as_index(args[0], in.name.c_str());
-                if (ic.sparse >= 0) fail(ln + "nested Sparse maps are not supported");
-                if (ic.dim != in.dims[0]) fail(ln + in.name + " is indexed over dimension " + P.dims[in.dims[0]]);
-                if (ic.off != 0) fail(ln + "offset inside a Sparse map access");
+                const size_t nsrc = in.dims.size() - 1;                  // one or two source dimensions (thallo.t:1700-1740: Sparse(from, to, idx))
+                if (args.size() != nsrc) fail(ln + in.name + " takes " + std::to_string(nsrc) + (nsrc == 1 ? " index" : " indices"));
+                IndexComp ic;
+                for (size_t k = 0; k < nsrc; ++k) {
+                    const IndexComp a = as_index(args[k], in.name.c_str());
+                    if (a.sparse >= 0) fail(ln + "nested Sparse maps are not supported");
+                    if (a.dim != in.dims[k]) fail(ln + in.name + " is indexed over dimension " + P.dims[in.dims[k]]);
+                    if (a.off != 0) fail(ln + "offset inside a Sparse map access");
+                    if (k == 0) ic.dim = a.dim; else ic.dim2 = a.dim;
+                }
                 ic.sparse = s.id;
                 SymV r; r.k = SymV::IndexE; r.ic = ic; return Value::make_sym(r);
             }
@@ -619,7 +624,7 @@ struct Interp {
             std::vector<IndexComp> idx;
             for (size_t d = 0; d < args.size(); ++d) {
                 IndexComp ic = as_index(args[d], in.name.c_str());
-                const int target = ic.sparse >= 0 ? P.inputs[ic.sparse].dims[1] : ic.dim;
+                const int target = ic.sparse >= 0 ? P.inputs[ic.sparse].dims.back() : ic.dim;
                 if (target != in.dims[d]) fail(ln + "index " + std::to_string(d) + " of " + in.name + " ranges over dimension " + P.dims[in.dims[d]] + ", got " + P.dims[target]);
                 idx.push_back(ic);
             }
@@ -664,7 +669,7 @@ struct Interp {
                 std::map<int, int> sh; std::vector<IndexComp> at;
                 {   // graph access: every argument went through a Sparse map -> substitute the mapped index for the map's target dimension
                     std::map<int, IndexComp> to; size_t nsp = 0;
-                    for (auto& a : args) { IndexComp ic = as_index(a, "get"); if (ic.sparse >= 0) { ++nsp; if (ic.off != 0) fail(ln + ":get with an offset through a Sparse map"); to[P.inputs[ic.sparse].dims[1]] = ic; } }
+                    for (auto& a : args) { IndexComp ic = as_index(a, "get"); if (ic.sparse >= 0) { ++nsp; if (ic.off != 0) fail(ln + ":get with an offset through a Sparse map"); to[P.inputs[ic.sparse].dims.back()] = ic; } }
                     if (nsp) {
                         if (nsp != args.size()) fail(ln + ":get mixes plain and Sparse-mapped indices");
                         std::vector<E> out; std::map<const Expr*, E> memo;
@@ -828,7 +833,7 @@ struct Interp {
             if (in.kind == InputKind::Unknown && in.is_u8) fail(ln + "uint8 unknowns are not supported");
             return { decl(in) };
         }
-        if (f == "Sparse") { need(3); Input in; in.kind = InputKind::Sparse; auto from = dim_list(a[0], line), to = dim_list(a[1], line); if (from.size() != 1 || to.size() != 1) fail(ln + "Sparse({E}, {N}, idx)"); in.dims = { from[0], to[0] }; in.slot = (int)a[2].n; return { decl(in) }; }
+        if (f == "Sparse") { need(3); Input in; in.kind = InputKind::Sparse; auto from = dim_list(a[0], line), to = dim_list(a[1], line); if (from.empty() || from.size() > 2 || to.size() != 1) fail(ln + "Sparse({E}, {N}, idx) or Sparse({W,H}, {N}, idx)"); in.dims = from; in.dims.push_back(to[0]); in.slot = (int)a[2].n; return { decl(in) }; }
         if (f == "Param") { need(2); Input in; in.kind = InputKind::Param; bool u8; if (type_channels(a[0], &u8, line) != 1 || u8) fail(ln + "scalar float Params are supported"); in.slot = (int)a[1].n; return { decl(in) }; }
         if (f == "Inputs") {
             need(1); if (a[0].t != Value::Table) fail(ln + "Inputs { name = ..., ... }");
@@ -1046,7 +1051,7 @@ std::string describe(const Problem& p)
     for (auto& in : p.inputs) {
         o << (in.kind == InputKind::Unknown ? "unknown " : in.kind == InputKind::Array ? "array " : in.kind == InputKind::Sparse ? "sparse " : "param ") << in.name << " slot " << in.slot;
         if (in.kind == InputKind::Unknown || in.kind == InputKind::Array) { o << " channels " << in.channels << (in.is_u8 ? " uint8" : "") << " over"; for (int d : in.dims) o << " " << p.dims[d]; if (in.exclude) o << " (Exclude)"; }
-        if (in.kind == InputKind::Sparse) o << " " << p.dims[in.dims[0]] << " -> " << p.dims[in.dims[1]];
+        if (in.kind == InputKind::Sparse) { for (size_t k = 0; k + 1 < in.dims.size(); ++k) o << " " << p.dims[in.dims[k]]; o << " -> " << p.dims[in.dims.back()]; }
         o << "\n";
     }
     o << "preconditioner " << (p.use_preconditioner ? 1 : 0) << "\n";

@@ -780,7 +780,7 @@ struct Interp {
     void def(const std::string& name) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = name; globals->vars[name] = f; }
     void install_builtins()
     {
-        for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "SampledImage", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
+        for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "SampledImage", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Image", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
                                "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
                                "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
             def(n);
@@ -825,7 +825,7 @@ struct Interp {
             P.dims[id] = a[0].s; SymV s; s.k = SymV::Dim; s.id = (int)id; return { Value::make_sym(s) };
         }
         if (f == "Dims") { Values out; for (auto& v : a) { if (v.t != Value::Str) fail(ln + "Dims takes names"); SymV s; s.k = SymV::Dim; s.id = (int)P.dims.size(); P.dims.push_back(v.s); out.push_back(Value::make_sym(s)); } return out; }
-        if (f == "Unknown" || f == "Array") {
+        if (f == "Unknown" || f == "Array" || f == "Image") {           // Image: the deprecated spelling of Array (lib.t:573-576)
             need(3); Input in; in.kind = f == "Unknown" ? InputKind::Unknown : InputKind::Array;
             in.channels = type_channels(a[0], &in.is_u8, line); in.dims = dim_list(a[1], line);
             if (a[2].t != Value::Num) fail(ln + f + ": the third argument is the parameter index"); in.slot = (int)a[2].n;

@@ -352,6 +352,163 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
     else block_store_partial(acc, part_out, red);
 }
 
+// ------------------------------------------------------------------------------------------ marching J^T(J v): no LDS tile, no barrier
+// The same J^T(J v) as k_fused<1> (same expressions, same order, same guards), shaped like energy_image_warping_march.hip: a WAVE owns a
+// column strip of 64 pixels (lane l: column x0 + l; lanes 2..61 produce output, the outer two on each side carry the radius-2 x halo, so
+// strips overlap by 4 columns) and marches down R rows of it.  x neighbours come from the neighbouring lane (DPP wave shifts), y neighbours
+// from the lane's own registers: at the step that takes row t the lane forms dB(t), U_h(t), U_v(t-1), R_c(t-1), T(t-1) and the output of
+// row t-2.  A segment [ya, yb) therefore takes the rows ya-2 .. yb+1 (4 halo rows, re-read through L2 by the neighbouring segments, which
+// run at the same time on the same XCD); rows are prefetched three steps ahead into registers (v, G, Wt, flags of row t; r / CtC of the output
+// row t-2).  Every plane is read ONCE per pixel and wave (k_fused: 22 vector loads per pixel through L1), ~1/2 of its VALU work, no LDS traffic.
+constexpr int MS_USE = 60, MS_NT = 256;
+constexpr int MS_OCC = 2, MS_WG_PER_CU = 2;      // registers for 2 workgroups (8 waves) per CU; grid sized for that many (tools/sfs_probe.py sweeps)
+struct MsGeo { int W, H, ra, rb, yoff, R, nstrips, total; };
+struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct; };      // one row of one lane as loaded
+
+__device__ __forceinline__ float ms_left(float v)  { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); }   // wave_shr:1 (lane-1)
+__device__ __forceinline__ float ms_right(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); }   // wave_shl:1 (lane+1)
+__device__ __forceinline__ void ms_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void ms_mv(float& d, const float& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
+__device__ __forceinline__ void ms_mv(unsigned& d, const unsigned& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
+// a prefetch slot moves into fresh registers with real v_mov instructions, so that its refill can be issued into the SAME registers right
+// behind (energy_image_warping_march.hip `take`: otherwise the compiler computes in place and the refill turns into a blocking load)
+template <bool SUMS, bool CTC>
+__device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
+{
+    ms_mv(d.g.x, s.g.x); ms_mv(d.g.y, s.g.y); ms_mv(d.g.z, s.g.z); ms_mv(d.w.x, s.w.x); ms_mv(d.w.y, s.w.y); ms_mv(d.v, s.v); ms_mv(d.f, s.f);
+    d.g.w = 0.0f; d.rs = 0.0f; d.ct = 0.0f;
+    if (SUMS) ms_mv(d.rs, s.rs);
+    if (CTC) ms_mv(d.ct, s.ct);
+}
+
+template <bool SUMS, bool CTC, int OCC>
+__global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const float* __restrict__ v, const float* __restrict__ ctc,
+                                                      const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
+                                                      float* __restrict__ out, float* __restrict__ part_out, const float* __restrict__ rs,
+                                                      double* __restrict__ s3_out, const unsigned* __restrict__ gate, FinArgs fin)
+{
+    __shared__ float red[16];
+    __shared__ double redd[3 * MS_NT / 64];
+    if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = g.W, H = g.H;
+    // XCD-aware placement as in the image_warping marching kernel: workgroups b and b+8 share an XCD; group b%8 owns a contiguous range of
+    // (band of 4 segments, strip) ids, x-adjacent strips first
+    int strip = 0, ya = 0, yb = 0;
+    {
+        const int NG = (gridDim.x % 8) == 0 ? 8 : 1;
+        const int grp = blockIdx.x % NG, l = blockIdx.x / NG;
+        const long lo = (long)g.total * grp / NG, hi = (long)g.total * (grp + 1) / NG;
+        const long id = lo + l;
+        if (id < hi) {
+            strip = (int)(id % g.nstrips);
+            const int seg = (int)(id / g.nstrips) * (MS_NT / 64) + wave;
+            ya = g.ra + seg * g.R; yb = ya + g.R;
+            if (yb > g.rb) yb = g.rb;
+            if (ya > g.rb) ya = g.rb;
+        }
+    }
+    const bool work = ya < yb;
+    const int x = strip * MS_USE - 2 + lane;
+    const bool xin = x >= 0 && x < W;
+    const bool xout = xin && lane >= 2 && lane <= 61;
+    const int xc_ = x < 0 ? 0 : x > W - 1 ? W - 1 : x;
+    // coef_0 at x-1, x, x+1 (coef_2 = 1); coef_1 per row, carried
+    const float cxm = coef(cm, 0, x - 1, 0), cxc = coef(cm, 0, x, 0), cxp = coef(cm, 0, x + 1, 0);
+
+    const unsigned* __restrict__ fl4 = reinterpret_cast<const unsigned*>(fl);
+    float acc = 0.0f; Sums3 sm;
+    if (work) {
+        const int t_first = ya - 2, t_last = yb + 1;
+        // loads are unconditional (addresses clamped, validity applied when the row is taken): a load under a branch is waited for at once
+        auto issue = [&](MsRaw& s, int t) {
+            const int tc = t < 0 ? 0 : t > H - 1 ? H - 1 : t;
+            const long i = (long)tc * W + xc_;
+            s.g = G[i]; s.w = Wt[i]; s.v = v[i];
+            // the aligned dword that holds the pixel's flags byte (shifted when the row is taken): a byte load leaves a zero-extension for the
+            // compiler to place, and it places it at the loop latch behind a wait for the fresh load (energy_image_warping_march.hip)
+            s.f = fl4[i >> 2];
+            if (SUMS || CTC) {
+                const int yo = t - 2 < ya ? ya : t - 2 > yb - 1 ? yb - 1 : t - 2;
+                const long j = (long)yo * W + xc_;
+                if (SUMS) s.rs = rs[j];
+                if (CTC) s.ct = ctc[j];
+            }
+        };
+        // state carried from row to row (suffix = rows behind the row being taken)
+        float v1 = 0.f, v2 = 0.f, dB1 = 0.f, Uh1 = 0.f, Uv2 = 0.f, T2 = 0.f, gx1 = 0.f, gy1 = 0.f, gz1 = 0.f, gx2 = 0.f, gy2 = 0.f, cy1 = 0.f, cy2 = 0.f;
+        float2 w1 = make_float2(0.f, 0.f);
+        unsigned f1 = 0u, f2 = 0u;
+        float R2[3] = { 0.f, 0.f, 0.f }, R3[3] = { 0.f, 0.f, 0.f };
+        MsRaw slot[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) slot[j] = MsRaw{};
+        // no prologue: the loop starts three rows early with empty slots and its refills are the first loads (one path into the loop header)
+        for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = t0 + j;
+                MsRaw cur;
+                ms_take<SUMS, CTC>(cur, slot[j]);
+                ms_fence();
+                issue(slot[j], t + 3 > t_last ? t_last : t + 3);
+                ms_fence();
+                if (t < t_first || t > t_last) continue;          // (wave-uniform; no load inside)
+                const bool ok = xin && t >= 0 && t < H;
+                const float v0 = ok ? cur.v : 0.0f;
+                const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;
+                const float2 w0 = ok ? cur.w : make_float2(0.f, 0.f);
+                const float cy0 = coef(cm, 1, 0, t + g.yoff);
+                // lane exchanges (every lane active here)
+                const float vl0 = ms_left(v0), vl1 = ms_left(v1), vr1 = ms_right(v1);
+                const float dB0 = ok ? cur.g.x * v0 + cur.g.y * vl0 + cur.g.z * v1 : 0.0f;
+                const float dBr = ms_right(dB0);
+                float Uh0 = 0.f, Uv1 = 0.f;
+                if (w0.x != 0.0f || w0.y != 0.0f) Uh0 = w0.x * (w0.x * (dB0 - dBr));
+                if (w1.x != 0.0f || w1.y != 0.0f) Uv1 = w1.y * (w1.y * (dB1 - dB0));
+                float R1[3] = { 0.f, 0.f, 0.f };
+                if (f1 & 2u) {
+                    R1[0] = cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0);
+                    R1[1] = cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0);
+                    R1[2] = cm.ws * (4.0f * (1.0f * v1) - 1.0f * vl1 - 1.0f * v2 - 1.0f * vr1 - 1.0f * v0);
+                }
+                float T1 = Uh1 + Uv1;
+                T1 -= ms_left(Uh1);
+                T1 -= Uv2;
+                const float T2r = ms_right(T2), gy2r = ms_right(gy2);
+                float Rl[3], Rr[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { Rl[c] = ms_left(R2[c]); Rr[c] = ms_right(R2[c]); }
+                const int y = t - 2;
+                if (y >= ya && xout) {
+                    const long i = (long)y * W + x;
+                    const float vc = v2;
+                    float s = 0.0f;
+                    if (f2 & 1u) s += cm.wp * (cm.wp * vc);
+                    s += gx2 * T2;
+                    if (x + 1 < W) s += gy2r * T2r;
+                    if (y + 1 < H) s += gz1 * T1;
+                    const float ci[3] = { cxc, cy2, 1.0f };
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float lap = 4.0f * R2[c] - Rl[c] - R3[c] - Rr[c] - R1[c];
+                        s += cm.ws * (ci[c] * lap);
+                    }
+                    if (CTC) s += cur.ct * vc;
+                    out[i] = s; acc += vc * s;
+                    if (SUMS) sm.add(1.0f, cur.rs, s);
+                }
+                v2 = v1; v1 = v0; f2 = f1; f1 = f0; w1 = w0; dB1 = dB0; Uh1 = Uh0; Uv2 = Uv1; T2 = T1;
+                gx2 = gx1; gy2 = gy1; gx1 = cur.g.x; gy1 = cur.g.y; gz1 = cur.g.z; cy2 = cy1; cy1 = cy0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { R3[c] = R2[c]; R2[c] = R1[c]; }
+            }
+        }
+    }
+    if (SUMS) block_finish_sums(acc, sm, part_out, s3_out, fin, red, redd);
+    else block_store_partial(acc, part_out, red);
+}
+
 // raw diag(J^T J) (LM only): enumerate the rows that contain X(i)
 __global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __restrict__ G, const float2* __restrict__ Wt,
                                                 const unsigned char* __restrict__ fl, float* __restrict__ diag)
@@ -405,6 +562,34 @@ static int fused_grid(int W, int rows)
     const int nt = ((W + FW - 1) / FW) * ((rows + FH - 1) / FH);
     int cap = thallo_hip_device_cu_count() * 4; if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS; cap -= cap % 8;      // (1024 partial slots: 4 of the 6 resident workgroups per CU)
     return nt < cap ? nt : cap;
+}
+
+// THALLO_SFS_MARCH=0: the LDS-tiled k_fused for J^T(J v) (A/B switch); default: the marching kernel
+static int g_ms_rows = 0, g_ms_wgcu = 0, g_ms_force = -1;       // tools / tests: rows per wave segment, workgroups per CU the grid is sized for (0 = automatic), kernel choice (-1 = the environment's)
+static bool sfs_march()
+{
+    static int v = -1; if (v < 0) { const char* e = getenv("THALLO_SFS_MARCH"); v = (e && e[0] == '0') ? 0 : 1; }
+    return g_ms_force >= 0 ? g_ms_force == 1 : v == 1;
+}
+void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; }
+static MsGeo make_ms_geo(int W, int H, int ra, int rb, int yoff, int R)
+{
+    MsGeo g; g.W = W; g.H = H; g.ra = ra; g.rb = rb; g.yoff = yoff; g.R = R;
+    g.nstrips = (W + MS_USE - 1) / MS_USE;
+    const int nseg = (rb - ra + R - 1) / R;
+    g.total = g.nstrips * ((nseg + MS_NT / 64 - 1) / (MS_NT / 64));
+    return g;
+}
+static MsGeo pick_ms_geo(int W, int H, int ra, int rb, int yoff)
+{
+    if (g_ms_rows > 0) return make_ms_geo(W, H, ra, rb, yoff, g_ms_rows);
+    long cap = (long)thallo_hip_device_cu_count() * (g_ms_wgcu > 0 ? g_ms_wgcu : MS_WG_PER_CU);
+    if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
+    cap -= cap % 8;
+    for (int R = 4;; ++R) {
+        const MsGeo g = make_ms_geo(W, H, ra, rb, yoff, R);
+        if ((g.total + 7) / 8 * 8 <= cap) return g;
+    }
 }
 
 /* host_params: the 16 scalar parameters of the .t in Inputs{} order: w_p, w_s, w_g (squared weights), f_x, f_y, u_x, u_y, L_1..L_9 */
@@ -488,6 +673,18 @@ static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const f
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
+    if (sfs_fused() && sfs_march()) {
+        const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
+        const int gridm = (mg.total + 7) / 8 * 8;
+        if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;      // (only through the tools' forced rows per segment)
+        const FinArgs fa{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridm };
+        const Cam cm = cam_of(host_params);
+#define MS_LAUNCH(SUMS, CTC) hipLaunchKernelGGL((k_march<SUMS, CTC, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cm, p, ctc, (const float4*)G, \
+                                                (const float2*)Wt, fl, Ap, aD_out, r, s3_out, gate, fa)
+        if (s3_out && ctc) MS_LAUNCH(true, true); else if (s3_out) MS_LAUNCH(true, false); else if (ctc) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
+#undef MS_LAUNCH
+        int e = check_launch(); return e ? e : gridm;
+    }
     if (sfs_fused()) {
         const int gridf = fused_grid(W, row1 - row0);
         hipLaunchKernelGGL(k_fused<1>, dim3(gridf), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), p, ctc, (const float4*)G, (const float2*)Wt, fl,

@@ -1,0 +1,122 @@
+"""shape_from_shading J^T(J v): the marching kernel (energy_sfs.hip k_march) against the LDS-tiled k_fused<1> through the C-ABI shim.
+   python tools/sfs_probe.py check           bitwise / rounding comparison on ragged sizes, slabs, the three variants (plain, sums, LM diagonal)
+   python tools/sfs_probe.py time [W H]      launch times (HIP events, 50 launches) of both kernels and a sweep of the marching grid"""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from thallo_amd import api, synthetic as syn
+
+L = api.lib()
+vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+L.thallo_hip_sfs_march_debug_set.argtypes = [C.c_int, C.c_int]; L.thallo_hip_sfs_march_debug_set.restype = None
+
+
+class Inst:
+    def __init__(self, W, H, ra=None, rb=None, yoff=0, Hg=None, seed=3):
+        self.W, self.H = W, H
+        self.ra, self.rb = (0 if ra is None else ra), (H if rb is None else rb)
+        self.yoff, self.Hg = yoff, (H if Hg is None else Hg)
+        p = syn.shape_from_shading(W, H)
+        self.hp = (C.c_float * 16)(*[float(x) for x in p[:16]])
+        X, D, Im, mR, mC = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in p[16:21]]
+        N = W * H
+        self.G = torch.empty(4 * N, dtype=torch.float32, device="cuda"); self.Wt = torch.empty(2 * N, dtype=torch.float32, device="cuda")
+        self.fl = torch.empty(N + 4, dtype=torch.uint8, device="cuda")
+        rc = L.thallo_hip_sfs_precompute(W, H, 0, H, self.yoff, self.Hg, self.hp, vp(X), vp(D), vp(Im), vp(mR), vp(mC), vp(self.G), vp(self.Wt), vp(self.fl), None)
+        assert rc == 0, rc
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        self.p = torch.randn(N, device="cuda", generator=g) * 1e-3
+        self.r = torch.randn(N, device="cuda", generator=g) * 1e-3
+        self.ctc = torch.rand(N, device="cuda", generator=g) * 50.0
+        self.U = torch.empty(2 * N, dtype=torch.float32, device="cuda"); self.R = torch.empty(3 * N, dtype=torch.float32, device="cuda")
+
+    def apply(self, variant, Ap, aD, s3):
+        a = (self.W, self.H, self.ra, self.rb, self.yoff, self.Hg, self.hp, vp(self.G), vp(self.Wt), vp(self.fl), vp(self.U), vp(self.R), vp(self.p))
+        if variant == "plain":
+            return L.thallo_hip_sfs_apply_jtj(*a, vp(Ap), vp(aD), None)
+        if variant == "sums":
+            return L.thallo_hip_sfs_apply_jtj_sums(*a, vp(Ap), vp(aD), vp(self.r), vp(s3), None)
+        return L.thallo_hip_sfs_apply_jtj_lm(*a, vp(self.ctc), vp(Ap), vp(aD), None, None)
+
+
+def run(inst, variant, march):
+    L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0)
+    N = inst.W * inst.H
+    Ap = torch.full((N,), 7.0, device="cuda"); aD = torch.zeros(1024, device="cuda"); s3 = torch.zeros(3 * 1024, dtype=torch.float64, device="cuda")
+    nb = inst.apply(variant, Ap, aD, s3)
+    assert nb > 0, nb
+    torch.cuda.synchronize()
+    return Ap.cpu().numpy(), float(aD[:nb].double().sum()), s3[:3 * nb].view(-1, 3).sum(0).cpu().numpy()
+
+
+def check():
+    cases = [(130, 67, {}), (64, 48, {}), (3, 3, {}), (61, 5, {}), (200, 131, dict(ra=7, rb=90, yoff=50, Hg=400)), (121, 40, dict(ra=2, rb=38, yoff=0, Hg=40)),
+             (512, 512, {}), (2048, 2048, {})]
+    ok = True
+    for W, H, kw in cases:
+        inst = Inst(W, H, **kw)
+        for variant in ("plain", "sums", "lm"):
+            a, ad_a, s_a = run(inst, variant, False)
+            b, ad_b, s_b = run(inst, variant, True)
+            rows = slice(inst.ra * W, inst.rb * W)
+            same = np.array_equal(a[rows].view(np.uint32), b[rows].view(np.uint32))
+            untouched = np.array_equal(a[:inst.ra * W], b[:inst.ra * W]) and np.array_equal(a[inst.rb * W:], b[inst.rb * W:])
+            scale = np.abs(a[rows]).max()
+            md = np.abs(a[rows] - b[rows]).max() / scale
+            rel = lambda u, v: abs(u - v) / max(abs(u), 1e-30)
+            line = f"{W}x{H} {kw} {variant}: bitwise {same}, max diff / max {md:.2e}, outside rows equal {untouched}, alphaD rel {rel(ad_a, ad_b):.1e}"
+            if variant == "sums":
+                line += ", sums rel " + " ".join(f"{rel(u, v):.1e}" for u, v in zip(s_a, s_b))
+                ok = ok and all(rel(u, v) < 2e-6 for u, v in zip(s_a[1:], s_b[1:])) and rel(s_a[0], s_b[0]) < 1e-12      # (N = sum r.r: exact products, double sums)
+            print(line, flush=True)
+            ok = ok and md < 2e-6 and untouched and rel(ad_a, ad_b) < 1e-4 and np.isfinite(b).all()
+    L.thallo_hip_sfs_march_debug_set(2, -1)
+    print("CHECK", "OK" if ok else "FAILED")
+    return 0 if ok else 1
+
+
+def time_one(inst, variant, march, reps=50):
+    L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0)
+    N = inst.W * inst.H
+    Ap = torch.empty(N, device="cuda"); aD = torch.zeros(1024, device="cuda"); s3 = torch.zeros(3 * 1024, dtype=torch.float64, device="cuda")
+    for _ in range(5):
+        nb = inst.apply(variant, Ap, aD, s3)
+    if nb <= 0:
+        return None, nb
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps):
+        inst.apply(variant, Ap, aD, s3)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3, nb
+
+
+def timing(W, H):
+    inst = Inst(W, H)
+    for variant in ("plain", "sums", "lm"):
+        t, nb = time_one(inst, variant, False)
+        print(f"{W}x{H} {variant}: tile kernel {t:.1f} us ({nb} workgroups)", flush=True)
+        L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, 0)
+        t, nb = time_one(inst, variant, True)
+        print(f"{W}x{H} {variant}: marching kernel (default grid) {t:.1f} us ({nb} workgroups) = {33 * W * H / t / 1e6:.2f} TB/s of the 33 B/pixel", flush=True)
+    for wgcu in (1, 2, 3, 4):
+        L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, wgcu)
+        t, nb = time_one(inst, "sums", True)
+        print(f"  sums, grid for {wgcu} workgroups / CU: {t:.1f} us ({nb} workgroups)", flush=True)
+    L.thallo_hip_sfs_march_debug_set(1, 0)
+    for rows in (8, 12, 16, 24, 32, 48, 64, 128):
+        L.thallo_hip_sfs_march_debug_set(0, rows)
+        t, nb = time_one(inst, "sums", True)
+        print(f"  sums, {rows} rows per wave: " + (f"{t:.1f} us ({nb} workgroups)" if t else f"not launchable ({nb})"), flush=True)
+    L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(2, -1)
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 else "check"
+    if mode == "check":
+        sys.exit(check())
+    W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2048, 2048)
+    timing(W, H)

@@ -881,6 +881,37 @@ def test_shape_from_shading_apply_forms_agree(torch, tmp_path, lm):
     assert np.abs(a[:-4] - b[:-4]).max() <= 1e-5 * np.abs(a[:-4]).max()
 
 
+def test_shape_from_shading_marching_kernel_matches_the_tile_kernel(torch):
+    """J^T(J v) by the marching kernel (default; energy_sfs.hip k_march: wave-owned column strips, register window, no LDS tile) against the
+    LDS-tiled k_fused<1> through the C-ABI shim: ragged sizes (strip and segment remainders, 3x3), row slabs with ghost rows and a global row
+    offset, 2048^2; the plain, the three-sums and the LM-diagonal variants.  Same expressions per pixel; the two kernels are separate
+    instantiations, so the outputs agree to rounding (1e-7 of the largest entry), rows outside [row0, row1) are not written, and the
+    partial sums add up to the same alphaD / N / S1 / S2."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sfs_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "sfs_probe.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.check() == 0
+
+
+@pytest.mark.parametrize("lm", [0, 1])
+def test_shape_from_shading_marching_and_tile_solves_agree(torch, tmp_path, lm):
+    """Whole solves (GN and LM, 3 x 8 iterations, 130 x 67) with THALLO_SFS_MARCH = 1 (default) and 0: depth map and costs agree to rounding."""
+    import subprocess
+    import sys
+    outs = []
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for form in ("1", "0"):
+        out = str(tmp_path / f"sfs_march{form}.npy")
+        code = _SFS_FORM_SNIPPET.format(root=root, tests=os.path.join(root, "tests"), W=130, H=67, lm=lm, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, THALLO_SFS_MARCH=form), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.isfinite(a).all() and a[-1] < a[-4]
+    assert np.abs(a[-4:] - b[-4:]).max() <= 1e-5 * np.abs(a[-4:]).max(), (a[-4:], b[-4:])
+    assert np.abs(a[:-4] - b[:-4]).max() <= 1e-5 * np.abs(a[:-4]).max()
+
+
 def test_shape_from_shading_lm(torch, orc):
     W, H = 64, 48
     p = syn.shape_from_shading(W, H)

@@ -365,8 +365,10 @@ constexpr int MS_OCC = 2, MS_WG_PER_CU = 2;      // registers for 2 workgroups (
 struct MsGeo { int W, H, ra, rb, yoff, R, nstrips, total; };
 struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct; };      // one row of one lane as loaded
 
-__device__ __forceinline__ float ms_left(float v)  { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); }   // wave_shr:1 (lane-1)
-__device__ __forceinline__ float ms_right(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); }   // wave_shl:1 (lane+1)
+// value of lane-1 / lane+1 (wave_shr:1 / wave_shl:1); a lane without a source reads 0 (bound_ctrl) -- lanes 0 / 63 produce no output.
+// mov_dpp has no tied "old" operand: one v_mov_b32_dpp per exchange, and the compiler may fold it into the consuming instruction.
+__device__ __forceinline__ float ms_left(float v)  { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float ms_right(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true)); }
 __device__ __forceinline__ void ms_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void ms_mv(float& d, const float& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
 __device__ __forceinline__ void ms_mv(unsigned& d, const unsigned& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
     __shared__ float red[16];
     __shared__ double redd[3 * MS_NT / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // (uniform: rows, row addresses and guards stay scalar)
     const int W = g.W, H = g.H;
     // XCD-aware placement as in the image_warping marching kernel: workgroups b and b+8 share an XCD; group b%8 owns a contiguous range of
     // (band of 4 segments, strip) ids, x-adjacent strips first
@@ -412,34 +414,36 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
     const int x = strip * MS_USE - 2 + lane;
     const bool xin = x >= 0 && x < W;
     const bool xout = xin && lane >= 2 && lane <= 61;
-    const int xc_ = x < 0 ? 0 : x > W - 1 ? W - 1 : x;
+    const unsigned xc_ = x < 0 ? 0u : x > W - 1 ? (unsigned)(W - 1) : (unsigned)x;
     // coef_0 at x-1, x, x+1 (coef_2 = 1); coef_1 per row, carried
     const float cxm = coef(cm, 0, x - 1, 0), cxc = coef(cm, 0, x, 0), cxp = coef(cm, 0, x + 1, 0);
 
-    const unsigned* __restrict__ fl4 = reinterpret_cast<const unsigned*>(fl);
     float acc = 0.0f; Sums3 sm;
     if (work) {
         const int t_first = ya - 2, t_last = yb + 1;
-        // loads are unconditional (addresses clamped, validity applied when the row is taken): a load under a branch is waited for at once
+        // loads are unconditional (addresses clamped, validity applied when the row is taken): a load under a branch is waited for at once.
+        // Row base pointers are wave-uniform; the lane adds its (unsigned, clamped) column.
         auto issue = [&](MsRaw& s, int t) {
             const int tc = t < 0 ? 0 : t > H - 1 ? H - 1 : t;
-            const long i = (long)tc * W + xc_;
-            s.g = G[i]; s.w = Wt[i]; s.v = v[i];
+            const long rowoff = (long)tc * W;
+            s.g = (G + rowoff)[xc_]; s.w = (Wt + rowoff)[xc_]; s.v = (v + rowoff)[xc_];
             // the aligned dword that holds the pixel's flags byte (shifted when the row is taken): a byte load leaves a zero-extension for the
             // compiler to place, and it places it at the loop latch behind a wait for the fresh load (energy_image_warping_march.hip)
-            s.f = fl4[i >> 2];
+            s.f = *reinterpret_cast<const unsigned*>(fl + ((rowoff + xc_) & ~3L));
             if (SUMS || CTC) {
                 const int yo = t - 2 < ya ? ya : t - 2 > yb - 1 ? yb - 1 : t - 2;
-                const long j = (long)yo * W + xc_;
-                if (SUMS) s.rs = rs[j];
-                if (CTC) s.ct = ctc[j];
+                const long ro = (long)yo * W;
+                if (SUMS) s.rs = (rs + ro)[xc_];
+                if (CTC) s.ct = (ctc + ro)[xc_];
             }
         };
-        // state carried from row to row (suffix = rows behind the row being taken)
-        float v1 = 0.f, v2 = 0.f, dB1 = 0.f, Uh1 = 0.f, Uv2 = 0.f, T2 = 0.f, gx1 = 0.f, gy1 = 0.f, gz1 = 0.f, gx2 = 0.f, gy2 = 0.f, cy1 = 0.f, cy2 = 0.f;
-        float2 w1 = make_float2(0.f, 0.f);
-        unsigned f1 = 0u, f2 = 0u;
-        float R2[3] = { 0.f, 0.f, 0.f }, R3[3] = { 0.f, 0.f, 0.f };
+        // State carried from row to row: rings of three indexed by the row modulo 3.  Three rows are taken per loop trip, so every index is a
+        // compile-time constant and nothing is shifted from register to register (energy_image_warping_march.hip `win`).
+        float Vv[3] = { 0.f, 0.f, 0.f }, dB[3] = { 0.f, 0.f, 0.f }, Uh[3] = { 0.f, 0.f, 0.f }, Uv[3] = { 0.f, 0.f, 0.f }, Tt[3] = { 0.f, 0.f, 0.f };
+        float Gx[3] = { 0.f, 0.f, 0.f }, Gy[3] = { 0.f, 0.f, 0.f }, Gz[3] = { 0.f, 0.f, 0.f }, Cy[3] = { 0.f, 0.f, 0.f }, Wy[3] = { 0.f, 0.f, 0.f };
+        unsigned Fl[3] = { 0u, 0u, 0u };
+        bool Wn[3] = { false, false, false };
+        float Rr[3][3] = { { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f } };
         MsRaw slot[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) slot[j] = MsRaw{};
@@ -448,60 +452,64 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = t0 + j;
+                const int k0 = j, k1 = (j + 2) % 3, k2 = (j + 1) % 3;          // ring slots of rows t, t-1, t-2 (and t-3 = t)
                 MsRaw cur;
                 ms_take<SUMS, CTC>(cur, slot[j]);
                 ms_fence();
                 issue(slot[j], t + 3 > t_last ? t_last : t + 3);
                 ms_fence();
-                if (t < t_first || t > t_last) continue;          // (wave-uniform; no load inside)
-                const bool ok = xin && t >= 0 && t < H;
-                const float v0 = ok ? cur.v : 0.0f;
-                const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;
-                const float2 w0 = ok ? cur.w : make_float2(0.f, 0.f);
-                const float cy0 = coef(cm, 1, 0, t + g.yoff);
-                // lane exchanges (every lane active here)
-                const float vl0 = ms_left(v0), vl1 = ms_left(v1), vr1 = ms_right(v1);
-                const float dB0 = ok ? cur.g.x * v0 + cur.g.y * vl0 + cur.g.z * v1 : 0.0f;
-                const float dBr = ms_right(dB0);
-                float Uh0 = 0.f, Uv1 = 0.f;
-                if (w0.x != 0.0f || w0.y != 0.0f) Uh0 = w0.x * (w0.x * (dB0 - dBr));
-                if (w1.x != 0.0f || w1.y != 0.0f) Uv1 = w1.y * (w1.y * (dB1 - dB0));
-                float R1[3] = { 0.f, 0.f, 0.f };
-                if (f1 & 2u) {
-                    R1[0] = cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0);
-                    R1[1] = cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0);
-                    R1[2] = cm.ws * (4.0f * (1.0f * v1) - 1.0f * vl1 - 1.0f * v2 - 1.0f * vr1 - 1.0f * v0);
-                }
-                float T1 = Uh1 + Uv1;
-                T1 -= ms_left(Uh1);
-                T1 -= Uv2;
-                const float T2r = ms_right(T2), gy2r = ms_right(gy2);
-                float Rl[3], Rr[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { Rl[c] = ms_left(R2[c]); Rr[c] = ms_right(R2[c]); }
-                const int y = t - 2;
-                if (y >= ya && xout) {
-                    const long i = (long)y * W + x;
-                    const float vc = v2;
-                    float s = 0.0f;
-                    if (f2 & 1u) s += cm.wp * (cm.wp * vc);
-                    s += gx2 * T2;
-                    if (x + 1 < W) s += gy2r * T2r;
-                    if (y + 1 < H) s += gz1 * T1;
-                    const float ci[3] = { cxc, cy2, 1.0f };
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float lap = 4.0f * R2[c] - Rl[c] - R3[c] - Rr[c] - R1[c];
-                        s += cm.ws * (ci[c] * lap);
+                if (t >= t_first && t <= t_last) {                 // (wave-uniform; no load inside)
+                    const bool ok = xin && t >= 0 && t < H;
+                    const float v0 = ok ? cur.v : 0.0f;
+                    const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;
+                    const float v1 = Vv[k1], v2 = Vv[k2];
+                    Cy[k0] = coef(cm, 1, 0, t + g.yoff);
+                    // lane exchanges (every lane active here)
+                    const float vl0 = ms_left(v0), vl1 = ms_left(v1), vr1 = ms_right(v1);
+                    const float dB0 = ok ? cur.g.x * v0 + cur.g.y * vl0 + cur.g.z * v1 : 0.0f;
+                    const float dBr = ms_right(dB0);
+                    const bool wn0 = ok && (cur.w.x != 0.0f || cur.w.y != 0.0f);
+                    const float Uh0 = wn0 ? cur.w.x * (cur.w.x * (dB0 - dBr)) : 0.0f;
+                    const float Uv1 = Wn[k1] ? Wy[k1] * (Wy[k1] * (dB[k1] - dB0)) : 0.0f;
+                    float R1[3] = { 0.f, 0.f, 0.f };
+                    if (Fl[k1] & 2u) {
+                        const float cy0 = Cy[k0], cy1 = Cy[k1], cy2 = Cy[k2];
+                        R1[0] = cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0);
+                        R1[1] = cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0);
+                        R1[2] = cm.ws * (4.0f * (1.0f * v1) - 1.0f * vl1 - 1.0f * v2 - 1.0f * vr1 - 1.0f * v0);
                     }
-                    if (CTC) s += cur.ct * vc;
-                    out[i] = s; acc += vc * s;
-                    if (SUMS) sm.add(1.0f, cur.rs, s);
-                }
-                v2 = v1; v1 = v0; f2 = f1; f1 = f0; w1 = w0; dB1 = dB0; Uh1 = Uh0; Uv2 = Uv1; T2 = T1;
-                gx2 = gx1; gy2 = gy1; gx1 = cur.g.x; gy1 = cur.g.y; gz1 = cur.g.z; cy2 = cy1; cy1 = cy0;
+                    float T1 = Uh[k1] + Uv1;
+                    T1 -= ms_left(Uh[k1]);
+                    T1 -= Uv[k2];
+                    const float T2 = Tt[k2];
+                    // G.y(i+ex) T(i+ex): the product as the right neighbour forms it (same operands, same bits), one exchange instead of two
+                    const float gT2r = ms_right(Gy[k2] * T2);
+                    float Rl[3], Rq[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { R3[c] = R2[c]; R2[c] = R1[c]; }
+                    for (int c = 0; c < 3; ++c) { Rl[c] = ms_left(Rr[k2][c]); Rq[c] = ms_right(Rr[k2][c]); }
+                    const int y = t - 2;
+                    if (y >= ya && xout) {
+                        const float vc = v2;
+                        float s = 0.0f;
+                        if (Fl[k2] & 1u) s += cm.wp * (cm.wp * vc);
+                        s += Gx[k2] * T2;
+                        if (x + 1 < W) s += gT2r;
+                        if (y + 1 < H) s += Gz[k1] * T1;
+                        const float ci[3] = { cxc, Cy[k2], 1.0f };
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float lap = 4.0f * Rr[k2][c] - Rl[c] - Rr[k0][c] - Rq[c] - R1[c];      // (slot k0 still holds row t-3)
+                            s += cm.ws * (ci[c] * lap);
+                        }
+                        if (CTC) s += cur.ct * vc;
+                        (out + (long)y * W)[(unsigned)x] = s; acc += vc * s;
+                        if (SUMS) sm.add(1.0f, cur.rs, s);
+                    }
+                    Vv[k0] = v0; Fl[k0] = f0; Wn[k0] = wn0; Wy[k0] = cur.w.y; dB[k0] = dB0; Uh[k0] = Uh0; Uv[k1] = Uv1; Tt[k1] = T1;
+                    Gx[k0] = cur.g.x; Gy[k0] = cur.g.y; Gz[k0] = cur.g.z;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Rr[k1][c] = R1[c];
+                }
             }
         }
     }

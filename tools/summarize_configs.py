@@ -16,7 +16,10 @@ if os.path.exists(os.path.join(g, "secondary_configs.json")):
 # kernel-name fragment -> (label, algorithmic bytes per launch at the profiled size or None)
 NPX = 2048 * 2048
 O_BA = 678718
-KEYS = [("k_fused<1>", "shape_from_shading applyJTJ (fused, 2048^2)", 33 * NPX),
+KEYS = [("k_march<true, false", "shape_from_shading applyJTJ + three sums (marching kernel, 2048^2; 33 B/pixel + 4 for r)", 37 * NPX),
+        ("k_march<false, true", "shape_from_shading (J^T J + CtC) p (marching kernel, LM, 2048^2; 33 B/pixel + 4 for CtC)", 37 * NPX),
+        ("k_march<false, false", "shape_from_shading applyJTJ (marching kernel, 2048^2)", 33 * NPX),
+        ("k_fused<1>", "shape_from_shading applyJTJ (fused, 2048^2)", 33 * NPX),
         ("k_fused<0>", "shape_from_shading PCGInit1 J^T F (fused, 2048^2)", None),
         ("k_cam2", "bundle_adjustment J^T(Jp) camera kernel (ladybug-1723 shape)", 116 * O_BA),
         ("k_pt2", "bundle_adjustment J^T(Jp) point kernel (ladybug-1723 shape)", 32 * O_BA),

@@ -374,20 +374,24 @@ __device__ __forceinline__ void ms_mv(float& d, const float& s) { asm volatile("
 __device__ __forceinline__ void ms_mv(unsigned& d, const unsigned& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
 // a prefetch slot moves into fresh registers with real v_mov instructions, so that its refill can be issued into the SAME registers right
 // behind (energy_image_warping_march.hip `take`: otherwise the compiler computes in place and the refill turns into a blocking load)
-template <bool SUMS, bool CTC>
+template <bool SUMS, bool CTC, bool INIT>
 __device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
 {
     ms_mv(d.g.x, s.g.x); ms_mv(d.g.y, s.g.y); ms_mv(d.g.z, s.g.z); ms_mv(d.w.x, s.w.x); ms_mv(d.w.y, s.w.y); ms_mv(d.v, s.v); ms_mv(d.f, s.f);
     d.g.w = 0.0f; d.rs = 0.0f; d.ct = 0.0f;
+    if (INIT) ms_mv(d.g.w, s.g.w);
     if (SUMS) ms_mv(d.rs, s.rs);
     if (CTC) ms_mv(d.ct, s.ct);
 }
 
-template <bool SUMS, bool CTC, int OCC>
+// INIT: the J^T F pass of PCGInit1 (k_fused<0>): v := X, dB := BI (G.w), ctc := D (the fit term uses X - D), outputs r = -J^T F, z = r,
+// p_prev = 0, delta = 0 and the alphaN partials.
+template <bool SUMS, bool CTC, bool INIT, int OCC>
 __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const float* __restrict__ v, const float* __restrict__ ctc,
                                                       const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
                                                       float* __restrict__ out, float* __restrict__ part_out, const float* __restrict__ rs,
-                                                      double* __restrict__ s3_out, const unsigned* __restrict__ gate, FinArgs fin)
+                                                      double* __restrict__ s3_out, const unsigned* __restrict__ gate, FinArgs fin,
+                                                      float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta)
 {
     __shared__ float red[16];
     __shared__ double redd[3 * MS_NT / 64];
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                 const int t = t0 + j;
                 const int k0 = j, k1 = (j + 2) % 3, k2 = (j + 1) % 3;          // ring slots of rows t, t-1, t-2 (and t-3 = t)
                 MsRaw cur;
-                ms_take<SUMS, CTC>(cur, slot[j]);
+                ms_take<SUMS, CTC, INIT>(cur, slot[j]);
                 ms_fence();
                 issue(slot[j], t + 3 > t_last ? t_last : t + 3);
                 ms_fence();
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                     Cy[k0] = coef(cm, 1, 0, t + g.yoff);
                     // lane exchanges (every lane active here)
                     const float vl0 = ms_left(v0), vl1 = ms_left(v1), vr1 = ms_right(v1);
-                    const float dB0 = ok ? cur.g.x * v0 + cur.g.y * vl0 + cur.g.z * v1 : 0.0f;
+                    const float dB0 = ok ? (INIT ? cur.g.w : cur.g.x * v0 + cur.g.y * vl0 + cur.g.z * v1) : 0.0f;
                     const float dBr = ms_right(dB0);
                     const bool wn0 = ok && (cur.w.x != 0.0f || cur.w.y != 0.0f);
                     const float Uh0 = wn0 ? cur.w.x * (cur.w.x * (dB0 - dBr)) : 0.0f;
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                     if (y >= ya && xout) {
                         const float vc = v2;
                         float s = 0.0f;
-                        if (Fl[k2] & 1u) s += cm.wp * (cm.wp * vc);
+                        if (Fl[k2] & 1u) s += cm.wp * (cm.wp * (INIT ? vc - cur.ct : vc));
                         s += Gx[k2] * T2;
                         if (x + 1 < W) s += gT2r;
                         if (y + 1 < H) s += Gz[k1] * T1;
@@ -501,9 +505,14 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                             const float lap = 4.0f * Rr[k2][c] - Rl[c] - Rr[k0][c] - Rq[c] - R1[c];      // (slot k0 still holds row t-3)
                             s += cm.ws * (ci[c] * lap);
                         }
-                        if (CTC) s += cur.ct * vc;
-                        (out + (long)y * W)[(unsigned)x] = s; acc += vc * s;
-                        if (SUMS) sm.add(1.0f, cur.rs, s);
+                        if (INIT) {
+                            const float r = -s; const long ro = (long)y * W;
+                            (out + ro)[(unsigned)x] = r; (z + ro)[(unsigned)x] = r; (p_prev + ro)[(unsigned)x] = 0.0f; (delta + ro)[(unsigned)x] = 0.0f; acc += r * r;
+                        } else {
+                            if (CTC) s += cur.ct * vc;
+                            (out + (long)y * W)[(unsigned)x] = s; acc += vc * s;
+                            if (SUMS) sm.add(1.0f, cur.rs, s);
+                        }
                     }
                     Vv[k0] = v0; Fl[k0] = f0; Wn[k0] = wn0; Wy[k0] = cur.w.y; dB[k0] = dB0; Uh[k0] = Uh0; Uv[k1] = Uv1; Tt[k1] = T1;
                     Gx[k0] = cur.g.x; Gy[k0] = cur.g.y; Gz[k0] = cur.g.z;
@@ -638,6 +647,15 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
     const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
     const Cam cm = cam_of(host_params);
     hipStream_t s = (hipStream_t)stream;
+    if (sfs_fused() && sfs_march()) {
+        const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
+        const int gridm = (mg.total + 7) / 8 * 8;
+        if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_march<false, true, true, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, s, mg, cm, X, D, (const float4*)G, (const float2*)Wt, fl, r, aN_out,
+                           (const float*)nullptr, (double*)nullptr, (const unsigned*)nullptr, FinArgs{}, z, p_prev, delta);
+        if (diag_out) hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
+        int e = check_launch(); return e ? e : gridm;
+    }
     if (sfs_fused()) {
         const int gridf = fused_grid(W, row1 - row0);
         hipLaunchKernelGGL(k_fused<0>, dim3(gridf), dim3(BLOCK), 0, s, g, cm, X, D, (const float4*)G, (const float2*)Wt, fl, r, z, p_prev, delta, aN_out,
@@ -687,8 +705,8 @@ static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const f
         if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;      // (only through the tools' forced rows per segment)
         const FinArgs fa{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridm };
         const Cam cm = cam_of(host_params);
-#define MS_LAUNCH(SUMS, CTC) hipLaunchKernelGGL((k_march<SUMS, CTC, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cm, p, ctc, (const float4*)G, \
-                                                (const float2*)Wt, fl, Ap, aD_out, r, s3_out, gate, fa)
+#define MS_LAUNCH(SUMS, CTC) hipLaunchKernelGGL((k_march<SUMS, CTC, false, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cm, p, ctc, (const float4*)G, \
+                                                (const float2*)Wt, fl, Ap, aD_out, r, s3_out, gate, fa, (float*)nullptr, (float*)nullptr, (float*)nullptr)
         if (s3_out && ctc) MS_LAUNCH(true, true); else if (s3_out) MS_LAUNCH(true, false); else if (ctc) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
 #undef MS_LAUNCH
         int e = check_launch(); return e ? e : gridm;

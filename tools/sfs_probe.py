@@ -22,6 +22,7 @@ class Inst:
         p = syn.shape_from_shading(W, H)
         self.hp = (C.c_float * 16)(*[float(x) for x in p[:16]])
         X, D, Im, mR, mC = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in p[16:21]]
+        self.X, self.D = X, D
         N = W * H
         self.G = torch.empty(4 * N, dtype=torch.float32, device="cuda"); self.Wt = torch.empty(2 * N, dtype=torch.float32, device="cuda")
         self.fl = torch.empty(N + 4, dtype=torch.uint8, device="cuda")
@@ -42,6 +43,19 @@ class Inst:
         return L.thallo_hip_sfs_apply_jtj_lm(*a, vp(self.ctc), vp(Ap), vp(aD), None, None)
 
 
+def run_init(inst, march):
+    """PCGInit1's J^T F pass: r = -J^T F, z = r, p_prev = 0, delta = 0, alphaN partials"""
+    L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0)
+    N = inst.W * inst.H
+    o = [torch.full((N,), 7.0, device="cuda") for _ in range(4)]
+    aN = torch.zeros(1024, device="cuda")
+    nb = L.thallo_hip_sfs_pcg_init(inst.W, inst.H, inst.ra, inst.rb, inst.yoff, inst.Hg, inst.hp, vp(inst.X), vp(inst.D), vp(inst.G), vp(inst.Wt), vp(inst.fl),
+                                   vp(inst.U), vp(inst.R), vp(o[0]), vp(o[1]), vp(o[2]), vp(o[3]), None, vp(aN), None)
+    assert nb > 0, nb
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in o], float(aN[:nb].double().sum())
+
+
 def run(inst, variant, march):
     L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0)
     N = inst.W * inst.H
@@ -58,6 +72,12 @@ def check():
     ok = True
     for W, H, kw in cases:
         inst = Inst(W, H, **kw)
+        (ra_, za, pa, da), na = run_init(inst, False)
+        (rb_, zb, pb, db), nb_ = run_init(inst, True)
+        md = np.abs(ra_ - rb_).max() / np.abs(ra_).max()
+        good = md < 2e-6 and np.array_equal(rb_, zb) and np.array_equal(pa, pb) and np.array_equal(da, db) and abs(na - nb_) <= 1e-5 * abs(na)
+        print(f"{W}x{H} {kw} init: max diff / max {md:.2e}, z == r {np.array_equal(rb_, zb)}, p_prev / delta equal {np.array_equal(pa, pb) and np.array_equal(da, db)}, alphaN rel {abs(na - nb_) / abs(na):.1e}", flush=True)
+        ok = ok and good
         for variant in ("plain", "sums", "lm"):
             a, ad_a, s_a = run(inst, variant, False)
             b, ad_b, s_b = run(inst, variant, True)
@@ -102,6 +122,19 @@ def timing(W, H):
         L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, 0)
         t, nb = time_one(inst, variant, True)
         print(f"{W}x{H} {variant}: marching kernel (default grid) {t:.1f} us ({nb} workgroups) = {33 * W * H / t / 1e6:.2f} TB/s of the 33 B/pixel", flush=True)
+    for march in (False, True):
+        L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0)
+        o = [torch.empty(W * H, device="cuda") for _ in range(4)]; aN = torch.zeros(1024, device="cuda")
+        call = lambda: L.thallo_hip_sfs_pcg_init(W, H, 0, H, 0, H, inst.hp, vp(inst.X), vp(inst.D), vp(inst.G), vp(inst.Wt), vp(inst.fl), vp(inst.U), vp(inst.R),
+                                                 vp(o[0]), vp(o[1]), vp(o[2]), vp(o[3]), None, vp(aN), None)
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20):
+            call()
+        e1.record(); torch.cuda.synchronize()
+        print(f"{W}x{H} PCGInit1 J^T F: {'marching' if march else 'tile'} kernel {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
     for wgcu in (1, 2, 3, 4):
         L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, wgcu)
         t, nb = time_one(inst, "sums", True)

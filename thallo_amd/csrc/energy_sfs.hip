@@ -386,12 +386,14 @@ __device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
 
 // INIT: the J^T F pass of PCGInit1 (k_fused<0>): v := X, dB := BI (G.w), ctc := D (the fit term uses X - D), outputs r = -J^T F, z = r,
 // p_prev = 0, delta = 0 and the alphaN partials.
-template <bool SUMS, bool CTC, bool INIT, int OCC>
+// DIAG (with INIT, LM only): also the raw diag(J^T J) of k_diag -- the same seven shading rows in the same order, from the rows the lane already
+// holds (G.x(i), G.y(i+ex), G.z(i+ey) and the row weights of i, i+-ex, i+ey, i+ey-ex, i-ey, i-ey+ex: zero outside the inner image).
+template <bool SUMS, bool CTC, bool INIT, bool DIAG, int OCC>
 __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const float* __restrict__ v, const float* __restrict__ ctc,
                                                       const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
                                                       float* __restrict__ out, float* __restrict__ part_out, const float* __restrict__ rs,
                                                       double* __restrict__ s3_out, const unsigned* __restrict__ gate, FinArgs fin,
-                                                      float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta)
+                                                      float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ diag)
 {
     __shared__ float red[16];
     __shared__ double redd[3 * MS_NT / 64];
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
         // compile-time constant and nothing is shifted from register to register (energy_image_warping_march.hip `win`).
         float Vv[3] = { 0.f, 0.f, 0.f }, dB[3] = { 0.f, 0.f, 0.f }, Uh[3] = { 0.f, 0.f, 0.f }, Uv[3] = { 0.f, 0.f, 0.f }, Tt[3] = { 0.f, 0.f, 0.f };
         float Gx[3] = { 0.f, 0.f, 0.f }, Gy[3] = { 0.f, 0.f, 0.f }, Gz[3] = { 0.f, 0.f, 0.f }, Cy[3] = { 0.f, 0.f, 0.f }, Wy[3] = { 0.f, 0.f, 0.f };
+        float Wx[3] = { 0.f, 0.f, 0.f };       // (DIAG) the rows' h weights, zero outside the image like Wy
         unsigned Fl[3] = { 0u, 0u, 0u };
         bool Wn[3] = { false, false, false };
         float Rr[3][3] = { { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f } };
@@ -492,7 +495,34 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { Rl[c] = ms_left(Rr[k2][c]); Rq[c] = ms_right(Rr[k2][c]); }
                     const int y = t - 2;
+                    float dg_gyR = 0.f, dg_hR = 0.f, dg_kR = 0.f, dg_hL = 0.f, dg_hDL = 0.f, dg_kUR = 0.f; unsigned dg_fL = 0u, dg_fR = 0u;
+                    if (DIAG) {     // lane exchanges of the diagonal (every lane active): rows y = t-2 (k2), y+1 = t-1 (k1), y-1 = t-3 (k0, not yet overwritten)
+                        dg_gyR = ms_right(Gy[k2]); dg_hR = ms_right(Wx[k2]); dg_kR = ms_right(Wn[k2] ? Wy[k2] : 0.0f); dg_hL = ms_left(Wx[k2]);
+                        dg_hDL = ms_left(Wx[k1]); dg_kUR = ms_right(Wn[k0] ? Wy[k0] : 0.0f);
+                        dg_fL = (unsigned)__builtin_amdgcn_mov_dpp((int)Fl[k2], 0x138, 0xf, 0xf, true); dg_fR = (unsigned)__builtin_amdgcn_mov_dpp((int)Fl[k2], 0x130, 0xf, 0xf, true);
+                    }
                     if (y >= ya && xout) {
+                        if (DIAG) {
+                            const float gx = Gx[k2], gzD = Gz[k1];
+                            const float h0 = Wx[k2], k0w = Wn[k2] ? Wy[k2] : 0.0f, hD = Wx[k1], kD = Wn[k1] ? Wy[k1] : 0.0f, kU = Wn[k0] ? Wy[k0] : 0.0f;
+                            float d = (Fl[k2] & 1u) ? cm.wp * cm.wp : 0.0f;
+                            float ch, cv;
+                            ch = (gx - dg_gyR) * h0;  cv = (gx - gzD) * k0w;  d += ch * ch + cv * cv;       // q = i
+                            ch = dg_gyR * dg_hR;      cv = dg_gyR * dg_kR;    d += ch * ch + cv * cv;       // q = i+ex
+                            ch = gzD * hD;            cv = gzD * kD;          d += ch * ch + cv * cv;       // q = i+ey
+                            ch = -gx * dg_hL;         cv = 0.0f * 0.0f;       d += ch * ch + cv * cv;       // q = i-ex
+                            ch = -gzD * dg_hDL;                               d += ch * ch + cv * cv;       // q = i-ex+ey
+                            ch = 0.0f; cv = -gx * kU;                         d += ch * ch + cv * cv;       // q = i-ey
+                            cv = -dg_gyR * dg_kUR;                            d += ch * ch + cv * cv;       // q = i+ex-ey
+                            float cc = 0.0f;
+                            { const float k0c = cm.ws * cxc, k1c = cm.ws * Cy[k2], k2c = cm.ws * 1.0f; cc += k0c * k0c; cc += k1c * k1c; cc += k2c * k2c; }
+                            float cnt = (Fl[k2] & 2u) ? 16.0f : 0.0f;
+                            if (dg_fL & 2u) cnt += 1.0f;
+                            if (Fl[k0] & 2u) cnt += 1.0f;
+                            if (dg_fR & 2u) cnt += 1.0f;
+                            if (Fl[k1] & 2u) cnt += 1.0f;
+                            (diag + (long)y * W)[(unsigned)x] = d + cnt * cc;
+                        }
                         const float vc = v2;
                         float s = 0.0f;
                         if (Fl[k2] & 1u) s += cm.wp * (cm.wp * (INIT ? vc - cur.ct : vc));
@@ -514,7 +544,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                             if (SUMS) sm.add(1.0f, cur.rs, s);
                         }
                     }
-                    Vv[k0] = v0; Fl[k0] = f0; Wn[k0] = wn0; Wy[k0] = cur.w.y; dB[k0] = dB0; Uh[k0] = Uh0; Uv[k1] = Uv1; Tt[k1] = T1;
+                    Vv[k0] = v0; Fl[k0] = f0; Wn[k0] = wn0; Wy[k0] = cur.w.y; if (DIAG) Wx[k0] = ok ? cur.w.x : 0.0f; dB[k0] = dB0; Uh[k0] = Uh0; Uv[k1] = Uv1; Tt[k1] = T1;
                     Gx[k0] = cur.g.x; Gy[k0] = cur.g.y; Gz[k0] = cur.g.z;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) Rr[k1][c] = R1[c];
@@ -588,7 +618,9 @@ static bool sfs_march()
     static int v = -1; if (v < 0) { const char* e = getenv("THALLO_SFS_MARCH"); v = (e && e[0] == '0') ? 0 : 1; }
     return g_ms_force >= 0 ? g_ms_force == 1 : v == 1;
 }
-void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; }
+static int g_ms_diag = 1;      // 1: the LM diagonal by the marching J^T F kernel, 0: k_diag (tools / tests)
+static bool sfs_march_diag() { return g_ms_diag == 1; }
+void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; if (what == 3) g_ms_diag = value; }
 static MsGeo make_ms_geo(int W, int H, int ra, int rb, int yoff, int R)
 {
     MsGeo g; g.W = W; g.H = H; g.ra = ra; g.rb = rb; g.yoff = yoff; g.R = R;
@@ -651,9 +683,14 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
         const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
         const int gridm = (mg.total + 7) / 8 * 8;
         if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_march<false, true, true, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, s, mg, cm, X, D, (const float4*)G, (const float2*)Wt, fl, r, aN_out,
-                           (const float*)nullptr, (double*)nullptr, (const unsigned*)nullptr, FinArgs{}, z, p_prev, delta);
-        if (diag_out) hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
+        if (diag_out && !sfs_march_diag())
+            hipLaunchKernelGGL(k_diag, dim3(grid), dim3(BLOCK), 0, s, g, cm, (const float4*)G, (const float2*)Wt, fl, diag_out);
+        if (diag_out && sfs_march_diag())
+            hipLaunchKernelGGL((k_march<false, true, true, true, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, s, mg, cm, X, D, (const float4*)G, (const float2*)Wt, fl, r, aN_out,
+                               (const float*)nullptr, (double*)nullptr, (const unsigned*)nullptr, FinArgs{}, z, p_prev, delta, diag_out);
+        else
+            hipLaunchKernelGGL((k_march<false, true, true, false, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, s, mg, cm, X, D, (const float4*)G, (const float2*)Wt, fl, r, aN_out,
+                               (const float*)nullptr, (double*)nullptr, (const unsigned*)nullptr, FinArgs{}, z, p_prev, delta, (float*)nullptr);
         int e = check_launch(); return e ? e : gridm;
     }
     if (sfs_fused()) {
@@ -705,8 +742,8 @@ static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const f
         if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;      // (only through the tools' forced rows per segment)
         const FinArgs fa{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridm };
         const Cam cm = cam_of(host_params);
-#define MS_LAUNCH(SUMS, CTC) hipLaunchKernelGGL((k_march<SUMS, CTC, false, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cm, p, ctc, (const float4*)G, \
-                                                (const float2*)Wt, fl, Ap, aD_out, r, s3_out, gate, fa, (float*)nullptr, (float*)nullptr, (float*)nullptr)
+#define MS_LAUNCH(SUMS, CTC) hipLaunchKernelGGL((k_march<SUMS, CTC, false, false, MS_OCC>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cm, p, ctc, (const float4*)G, \
+                                                (const float2*)Wt, fl, Ap, aD_out, r, s3_out, gate, fa, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr)
         if (s3_out && ctc) MS_LAUNCH(true, true); else if (s3_out) MS_LAUNCH(true, false); else if (ctc) MS_LAUNCH(false, true); else MS_LAUNCH(false, false);
 #undef MS_LAUNCH
         int e = check_launch(); return e ? e : gridm;

@@ -43,16 +43,17 @@ class Inst:
         return L.thallo_hip_sfs_apply_jtj_lm(*a, vp(self.ctc), vp(Ap), vp(aD), None, None)
 
 
-def run_init(inst, march):
-    """PCGInit1's J^T F pass: r = -J^T F, z = r, p_prev = 0, delta = 0, alphaN partials"""
-    L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0)
+def run_init(inst, march, diag_by_march=True):
+    """PCGInit1's J^T F pass: r = -J^T F, z = r, p_prev = 0, delta = 0, alphaN partials; and the raw LM diagonal diag(J^T J)"""
+    L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0); L.thallo_hip_sfs_march_debug_set(3, 1 if diag_by_march else 0)
     N = inst.W * inst.H
-    o = [torch.full((N,), 7.0, device="cuda") for _ in range(4)]
+    o = [torch.full((N,), 7.0, device="cuda") for _ in range(5)]
     aN = torch.zeros(1024, device="cuda")
     nb = L.thallo_hip_sfs_pcg_init(inst.W, inst.H, inst.ra, inst.rb, inst.yoff, inst.Hg, inst.hp, vp(inst.X), vp(inst.D), vp(inst.G), vp(inst.Wt), vp(inst.fl),
-                                   vp(inst.U), vp(inst.R), vp(o[0]), vp(o[1]), vp(o[2]), vp(o[3]), None, vp(aN), None)
+                                   vp(inst.U), vp(inst.R), vp(o[0]), vp(o[1]), vp(o[2]), vp(o[3]), vp(o[4]), vp(aN), None)
     assert nb > 0, nb
     torch.cuda.synchronize()
+    L.thallo_hip_sfs_march_debug_set(3, 1)
     return [t.cpu().numpy() for t in o], float(aN[:nb].double().sum())
 
 
@@ -72,11 +73,14 @@ def check():
     ok = True
     for W, H, kw in cases:
         inst = Inst(W, H, **kw)
-        (ra_, za, pa, da), na = run_init(inst, False)
-        (rb_, zb, pb, db), nb_ = run_init(inst, True)
+        (ra_, za, pa, da, ga), na = run_init(inst, False)
+        (rb_, zb, pb, db, gb), nb_ = run_init(inst, True)
+        (_, _, _, _, gc), _ = run_init(inst, True, diag_by_march=False)
         md = np.abs(ra_ - rb_).max() / np.abs(ra_).max()
-        good = md < 2e-6 and np.array_equal(rb_, zb) and np.array_equal(pa, pb) and np.array_equal(da, db) and abs(na - nb_) <= 1e-5 * abs(na)
-        print(f"{W}x{H} {kw} init: max diff / max {md:.2e}, z == r {np.array_equal(rb_, zb)}, p_prev / delta equal {np.array_equal(pa, pb) and np.array_equal(da, db)}, alphaN rel {abs(na - nb_) / abs(na):.1e}", flush=True)
+        dd = np.abs(ga - gb).max() / np.abs(ga).max()
+        good = md < 2e-6 and dd < 2e-6 and np.array_equal(ga, gc) and np.array_equal(rb_, zb) and np.array_equal(pa, pb) and np.array_equal(da, db) and abs(na - nb_) <= 1e-5 * abs(na)
+        print(f"{W}x{H} {kw} init: max diff / max {md:.2e}, z == r {np.array_equal(rb_, zb)}, p_prev / delta equal {np.array_equal(pa, pb) and np.array_equal(da, db)}, "
+              f"alphaN rel {abs(na - nb_) / abs(na):.1e}; LM diagonal by the marching kernel vs k_diag: max diff / max {dd:.2e}, bitwise {np.array_equal(ga, gb)}", flush=True)
         ok = ok and good
         for variant in ("plain", "sums", "lm"):
             a, ad_a, s_a = run(inst, variant, False)
@@ -122,11 +126,11 @@ def timing(W, H):
         L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, 0)
         t, nb = time_one(inst, variant, True)
         print(f"{W}x{H} {variant}: marching kernel (default grid) {t:.1f} us ({nb} workgroups) = {33 * W * H / t / 1e6:.2f} TB/s of the 33 B/pixel", flush=True)
-    for march in (False, True):
-        L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0)
-        o = [torch.empty(W * H, device="cuda") for _ in range(4)]; aN = torch.zeros(1024, device="cuda")
+    for march, dg, lab in ((False, 0, "tile kernel"), (True, 0, "marching kernel"), (True, 1, "marching kernel + k_diag (LM)"), (True, 2, "marching kernel incl. the LM diagonal")):
+        L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0); L.thallo_hip_sfs_march_debug_set(3, 1 if dg == 2 else 0)
+        o = [torch.empty(W * H, device="cuda") for _ in range(5)]; aN = torch.zeros(1024, device="cuda")
         call = lambda: L.thallo_hip_sfs_pcg_init(W, H, 0, H, 0, H, inst.hp, vp(inst.X), vp(inst.D), vp(inst.G), vp(inst.Wt), vp(inst.fl), vp(inst.U), vp(inst.R),
-                                                 vp(o[0]), vp(o[1]), vp(o[2]), vp(o[3]), None, vp(aN), None)
+                                                 vp(o[0]), vp(o[1]), vp(o[2]), vp(o[3]), vp(o[4]) if dg else None, vp(aN), None)
         for _ in range(3):
             call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -134,7 +138,8 @@ def timing(W, H):
         for _ in range(20):
             call()
         e1.record(); torch.cuda.synchronize()
-        print(f"{W}x{H} PCGInit1 J^T F: {'marching' if march else 'tile'} kernel {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
+        print(f"{W}x{H} PCGInit1 J^T F: {lab} {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
+    L.thallo_hip_sfs_march_debug_set(3, 1)
     for wgcu in (1, 2, 3, 4):
         L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, wgcu)
         t, nb = time_one(inst, "sums", True)

@@ -429,6 +429,7 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
                             float* diag_out, float* alphaN_out, thallo_stream_t stream);
 int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+void thallo_hip_arap_debug_set(int what, int value);     /* tools / tests only: 0 = the unrolled ELL form of the ARAP applyJTJ on (1, default) / off */
 /* tools / tests only: 0 = rows per wave segment of the marching J^T(J v) kernel, 1 = workgroups per CU its grid is sized for (0 = automatic),
  * 2 = kernel choice (1 marching, 0 LDS-tiled, -1 the environment's THALLO_SFS_MARCH; default marching) */
 void thallo_hip_sfs_march_debug_set(int what, int value);

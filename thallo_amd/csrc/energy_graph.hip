@@ -311,9 +311,91 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply(int N, int n0, int n1, con
     else block_store_partial(acc, aD_out, red);
 }
 
+// The same J^T J p for the ELL layout with at most MD edge slots per vertex (S = maxdeg * N, maxdeg <= MD): both edge loops fully unrolled with
+// the slots beyond a vertex's degree predicated off, so that every index load of a vertex is issued first, then every gather that depends on
+// them, then the arithmetic -- two dependent memory round trips per vertex instead of one pair per group of four edges (the kernel is latency-bound:
+// 13 MB working set, 1.6 waves per SIMD).  Same terms in the same order: bitwise the loop form's output.
+template <int MD>
+__global__ __launch_bounds__(BLOCK) void k_arap_apply_ell(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
+                                                           const int* __restrict__ in_ptr, const int* __restrict__ in_edge, const int* __restrict__ in_src,
+                                                           const float* __restrict__ Cn, const float* __restrict__ G, float wf, float wr,
+                                                           const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out, ELay L,
+                                                           const float* __restrict__ rs, const float* __restrict__ pre, double* __restrict__ s3_out, FinArgs fin)
+{
+    __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
+    float acc = 0.0f; Sums3 sm;
+    const float wr2 = wr * wr;
+    for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
+        const int deg = out_ptr[n + 1] - out_ptr[n], ideg = in_ptr[n + 1] - in_ptr[n];
+        int vo[MD], ei[MD], vi[MD];
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {       // (slots beyond the degree exist -- the planes hold maxdeg * N entries -- but their contents are not used)
+            const long k = (long)j * L.N + n;
+            const bool a = j < deg, b = j < ideg;
+            vo[j] = a ? out_v1[k] : n; ei[j] = b ? in_edge[k] : n; vi[j] = b ? in_src[k] : n;
+        }
+        const f3 pp = ld3(p, n), pa = ld3(p, (long)N + n);
+        f3 pmo[MD], pmi[MD], ami[MD];
+#pragma unroll
+        for (int j = 0; j < MD; ++j) { pmo[j] = ld3(p, vo[j]); pmi[j] = ld3(p, vi[j]); ami[j] = ld3(p, (long)N + vi[j]); }
+        f3 ap = { 0.f, 0.f, 0.f }, aa = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            const long k = (long)j * L.N + n;
+            const f3 pm = pmo[j];
+            const f3 g0 = ldG(G, L, k, 0), g1 = ldG(G, L, k, 1), g2 = ldG(G, L, k, 2);
+            const float jx = (pp.x - pm.x) - (g0.x * pa.x + g1.x * pa.y + g2.x * pa.z);
+            const float jy = (pp.y - pm.y) - (g0.y * pa.x + g1.y * pa.y + g2.y * pa.z);
+            const float jz = (pp.z - pm.z) - (g0.z * pa.x + g1.z * pa.y + g2.z * pa.z);
+            if (j < deg) {
+                ap.x += jx; ap.y += jy; ap.z += jz;
+                aa.x -= g0.x * jx + g0.y * jy + g0.z * jz;
+                aa.y -= g1.x * jx + g1.y * jy + g1.z * jz;
+                aa.z -= g2.x * jx + g2.y * jy + g2.z * jz;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            const f3 pm = pmi[j], am = ami[j];
+            const f3 g0 = ldG(G, L, ei[j], 0), g1 = ldG(G, L, ei[j], 1), g2 = ldG(G, L, ei[j], 2);
+            if (j < ideg) {
+                ap.x -= (pm.x - pp.x) - (g0.x * am.x + g1.x * am.y + g2.x * am.z);
+                ap.y -= (pm.y - pp.y) - (g0.y * am.x + g1.y * am.y + g2.y * am.z);
+                ap.z -= (pm.z - pp.z) - (g0.z * am.x + g1.z * am.y + g2.z * am.z);
+            }
+        }
+        ap.x *= wr2; ap.y *= wr2; ap.z *= wr2; aa.x *= wr2; aa.y *= wr2; aa.z *= wr2;
+        if (Cn[3 * n] >= -999999.9f) { ap.x += wf * wf * pp.x; ap.y += wf * wf * pp.y; ap.z += wf * wf * pp.z; }
+        st3(Ap, n, ap); st3(Ap, (long)N + n, aa);
+        acc += pp.x * ap.x + pp.y * ap.y + pp.z * ap.z + pa.x * aa.x + pa.y * aa.y + pa.z * aa.z;
+        if (s3_out) {
+            const f3 rp = ld3(rs, n), ra = ld3(rs, (long)N + n), mp = ld3(pre, n), ma = ld3(pre, (long)N + n);
+            sm.add(mp.x, rp.x, ap.x); sm.add(mp.y, rp.y, ap.y); sm.add(mp.z, rp.z, ap.z);
+            sm.add(ma.x, ra.x, aa.x); sm.add(ma.y, ra.y, aa.y); sm.add(ma.z, ra.z, aa.z);
+        }
+    }
+    if (s3_out) block_finish_sums(acc, sm, aD_out, s3_out, fin, red, redd);
+    else block_store_partial(acc, aD_out, red);
+}
+
+int g_arap_unrolled = 1;       // tools / tests: 0 = the loop form for every layout
+
+// launches the unrolled ELL form when the layout allows it (maxdeg = S / N <= 8), the loop form otherwise
+template <typename... A>
+void launch_arap_apply(int grid, hipStream_t stream, ELay L, A... a)
+{
+    const long maxdeg = L.S && L.N > 0 ? L.S / L.N : 0;
+    if (g_arap_unrolled && maxdeg >= 1 && maxdeg <= 6) hipLaunchKernelGGL(k_arap_apply_ell<6>, dim3(grid), dim3(BLOCK), 0, stream, a...);
+    else if (g_arap_unrolled && maxdeg >= 1 && maxdeg <= 8) hipLaunchKernelGGL(k_arap_apply_ell<8>, dim3(grid), dim3(BLOCK), 0, stream, a...);
+    else hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, stream, a...);
+}
+
 }  // namespace
 
 extern "C" {
+
+void thallo_hip_arap_debug_set(int what, int value) { if (what == 0) g_arap_unrolled = value; }
 
 int thallo_hip_lapgraph_cost(int N, const int* out_ptr, const int* out_v1, const float* X, const float* A, float w_fit,
                              float* cost_out, thallo_stream_t stream)
@@ -374,7 +456,7 @@ int thallo_hip_arap_apply_jtj(int N, int n0, int n1, const int* out_ptr, const i
     if (n0 < 0 || n1 > N || n0 >= n1 || ell_stride < 0) return -(int)hipErrorInvalidValue;
     const ELay L = { ell_stride, N };
     const int grid = vgrid(n1 - n0);
-    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, (const float*)nullptr, (const float*)nullptr, (double*)nullptr, FinArgs{});
+    launch_arap_apply(grid, (hipStream_t)stream, L, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, (const float*)nullptr, (const float*)nullptr, (double*)nullptr, FinArgs{});
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_apply_jtj_sums_fin(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
@@ -387,7 +469,7 @@ int thallo_hip_arap_apply_jtj_sums_fin(int N, int n0, int n1, const int* out_ptr
     const ELay L = { ell_stride, N };
     const int grid = vgrid(n1 - n0);
     const FinArgs f = { fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, grid };
-    hipLaunchKernelGGL(k_arap_apply, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
+    launch_arap_apply(grid, (hipStream_t)stream, L, N, n0, n1, out_ptr, out_v1, in_ptr, in_edge, in_src, constraints, G, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_apply_jtj_sums(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,

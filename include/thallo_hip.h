@@ -429,6 +429,14 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
                             float* diag_out, float* alphaN_out, thallo_stream_t stream);
 int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                              float* U, float* R, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
+/* LM on one GPU, PCGStep3 folded into the apply (marching kernel only; thallo_hip_sfs_lm_pupdate_supported() says whether this build / environment
+ * runs it): p_out = z + beta p_in with beta = betaN_prev / alphaN_prev (0 when first), Ap = (J^T J + CtC) p_out over the rows [row0, row1),
+ * alphaD partials; p_out is written on those rows only, p_in != p_out.  Replaces thallo_hip_pcg_pupdate + thallo_hip_sfs_apply_jtj_lm
+ * (gauss_newton.t:889-899 + :734-787). */
+int thallo_hip_sfs_lm_pupdate_supported(void);
+int thallo_hip_sfs_apply_jtj_lm_pupdate(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                        const float* z, const float* p_in, float* p_out, const float* CtC, float* Ap, float* alphaD_out, int first,
+                                        thallo_sum_t alphaN_prev, thallo_sum_t betaN_prev, const unsigned* gate, thallo_stream_t stream);
 void thallo_hip_arap_debug_set(int what, int value);     /* tools / tests only: 0 = the unrolled ELL form of the ARAP applyJTJ on (1, default) / off */
 /* tools / tests only: 0 = rows per wave segment of the marching J^T(J v) kernel, 1 = workgroups per CU its grid is sized for (0 = automatic),
  * 2 = kernel choice (1 marching, 0 LDS-tiled, -1 the environment's THALLO_SFS_MARCH; default marching) */

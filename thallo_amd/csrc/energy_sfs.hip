@@ -363,7 +363,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
 constexpr int MS_USE = 60, MS_NT = 256;
 constexpr int MS_OCC = 2, MS_WG_PER_CU = 2;      // registers for 2 workgroups (8 waves) per CU; grid sized for that many (tools/sfs_probe.py sweeps)
 struct MsGeo { int W, H, ra, rb, yoff, R, nstrips, total; };
-struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct; };      // one row of one lane as loaded
+struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct, pv; };      // one row of one lane as loaded (pv: p_{k-1} of the row, PUPD)
 
 // value of lane-1 / lane+1 (wave_shr:1 / wave_shl:1); a lane without a source reads 0 (bound_ctrl) -- lanes 0 / 63 produce no output.
 // mov_dpp has no tied "old" operand: one v_mov_b32_dpp per exchange, and the compiler may fold it into the consuming instruction.
@@ -374,9 +374,11 @@ __device__ __forceinline__ void ms_mv(float& d, const float& s) { asm volatile("
 __device__ __forceinline__ void ms_mv(unsigned& d, const unsigned& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
 // a prefetch slot moves into fresh registers with real v_mov instructions, so that its refill can be issued into the SAME registers right
 // behind (energy_image_warping_march.hip `take`: otherwise the compiler computes in place and the refill turns into a blocking load)
-template <bool SUMS, bool CTC, bool INIT>
+template <bool SUMS, bool CTC, bool INIT, bool PUPD = false>
 __device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
 {
+    d.pv = 0.0f;
+    if (PUPD) ms_mv(d.pv, s.pv);
     ms_mv(d.g.x, s.g.x); ms_mv(d.g.y, s.g.y); ms_mv(d.g.z, s.g.z); ms_mv(d.w.x, s.w.x); ms_mv(d.w.y, s.w.y); ms_mv(d.v, s.v); ms_mv(d.f, s.f);
     d.g.w = 0.0f; d.rs = 0.0f; d.ct = 0.0f;
     if (INIT) ms_mv(d.g.w, s.g.w);
@@ -388,16 +390,22 @@ __device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
 // p_prev = 0, delta = 0 and the alphaN partials.
 // DIAG (with INIT, LM only): also the raw diag(J^T J) of k_diag -- the same seven shading rows in the same order, from the rows the lane already
 // holds (G.x(i), G.y(i+ex), G.z(i+ey) and the row weights of i, i+-ex, i+ey, i+ey-ex, i-ey, i-ey+ex: zero outside the inner image).
-template <bool SUMS, bool CTC, bool INIT, bool DIAG, int OCC>
+// PUPD (LM, one GPU): PCGStep3 rides along -- v is z, the lane forms p_k = z + beta_{k-1} p_{k-1} for every row it takes (halo rows and lanes
+// redundantly, like image_warping's marching kernel), stores p_k for its own rows and applies (J^T J + CtC) to it.  p_{k-1} and p_k are different buffers.
+struct MsPupd { const float* p_in; float* p_out; thallo_sum_t aN, bN; int first; };
+template <bool SUMS, bool CTC, bool INIT, bool DIAG, int OCC, bool PUPD = false>
 __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const float* __restrict__ v, const float* __restrict__ ctc,
                                                       const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
                                                       float* __restrict__ out, float* __restrict__ part_out, const float* __restrict__ rs,
                                                       double* __restrict__ s3_out, const unsigned* __restrict__ gate, FinArgs fin,
-                                                      float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ diag)
+                                                      float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ diag,
+                                                      MsPupd pu = MsPupd{})
 {
     __shared__ float red[16];
     __shared__ double redd[3 * MS_NT / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
+    float beta = 0.0f;
+    if (PUPD && !pu.first) beta = safe_div<true>(sum_partials(pu.bN.partials, pu.bN.count), sum_partials(pu.aN.partials, pu.aN.count));      // as k_pupdate (LM)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // (uniform: rows, row addresses and guards stay scalar)
     const int W = g.W, H = g.H;
     // XCD-aware placement as in the image_warping marching kernel: workgroups b and b+8 share an XCD; group b%8 owns a contiguous range of
@@ -433,6 +441,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
             const int tc = t < 0 ? 0 : t > H - 1 ? H - 1 : t;
             const long rowoff = (long)tc * W;
             s.g = (G + rowoff)[xc_]; s.w = (Wt + rowoff)[xc_]; s.v = (v + rowoff)[xc_];
+            if (PUPD) s.pv = (pu.p_in + rowoff)[xc_];
             // the aligned dword that holds the pixel's flags byte (shifted when the row is taken): a byte load leaves a zero-extension for the
             // compiler to place, and it places it at the loop latch behind a wait for the fresh load (energy_image_warping_march.hip)
             s.f = *reinterpret_cast<const unsigned*>(fl + ((rowoff + xc_) & ~3L));
@@ -461,13 +470,14 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                 const int t = t0 + j;
                 const int k0 = j, k1 = (j + 2) % 3, k2 = (j + 1) % 3;          // ring slots of rows t, t-1, t-2 (and t-3 = t)
                 MsRaw cur;
-                ms_take<SUMS, CTC, INIT>(cur, slot[j]);
+                ms_take<SUMS, CTC, INIT, PUPD>(cur, slot[j]);
                 ms_fence();
                 issue(slot[j], t + 3 > t_last ? t_last : t + 3);
                 ms_fence();
                 if (t >= t_first && t <= t_last) {                 // (wave-uniform; no load inside)
                     const bool ok = xin && t >= 0 && t < H;
-                    const float v0 = ok ? cur.v : 0.0f;
+                    const float v0 = ok ? (PUPD ? cur.v + beta * cur.pv : cur.v) : 0.0f;
+                    if (PUPD && t >= ya && t < yb && xout) (pu.p_out + (long)t * W)[(unsigned)x] = v0;
                     const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;
                     const float v1 = Vv[k1], v2 = Vv[k2];
                     Cy[k0] = coef(cm, 1, 0, t + g.yoff);
@@ -729,6 +739,24 @@ int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, i
 int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                 float* U, float* R, const float* p, const float* CtC, float* Ap, float* aD_out, const unsigned* gate, thallo_stream_t stream)
 { return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream, gate, thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr }, CtC); }
+
+int thallo_hip_sfs_lm_pupdate_supported(void) { return sfs_fused() && sfs_march() ? 1 : 0; }
+
+int thallo_hip_sfs_apply_jtj_lm_pupdate(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                        const float* z, const float* p_in, float* p_out, const float* CtC, float* Ap, float* aD_out, int first,
+                                        thallo_sum_t alphaN_prev, thallo_sum_t betaN_prev, const unsigned* gate, thallo_stream_t stream)
+{
+    if (row0 < 0 || row1 > H || row0 >= row1 || !z || !p_in || !p_out || p_in == p_out || !CtC || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
+    if (!first && (!alphaN_prev.partials || !betaN_prev.partials || alphaN_prev.count < 1 || betaN_prev.count < 1)) return -(int)hipErrorInvalidValue;
+    if (!thallo_hip_sfs_lm_pupdate_supported()) return -(int)hipErrorNotSupported;
+    const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
+    const int gridm = (mg.total + 7) / 8 * 8;
+    if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+    const MsPupd pu = { p_in, p_out, alphaN_prev, betaN_prev, first ? 1 : 0 };
+    hipLaunchKernelGGL((k_march<false, true, false, false, MS_OCC, true>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cam_of(host_params), z, CtC, (const float4*)G,
+                       (const float2*)Wt, fl, Ap, aD_out, (const float*)nullptr, (double*)nullptr, gate, FinArgs{}, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, pu);
+    int e = check_launch(); return e ? e : gridm;
+}
 
 static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                      float* U, float* R, const float* p, float* Ap, float* aD_out, const float* r, double* s3_out, thallo_stream_t stream, const unsigned* gate, thallo_fin_t fin, const float* ctc)

@@ -94,6 +94,11 @@ public:
     // plain PCGStep1: Ap = J^T J p, partials of p.Ap (LM branch, computeAdelta, model cost)
     virtual int apply_jtj(LaunchCtx&, const float* p, float* Ap, float* alphaD_out) = 0;
     virtual bool apply_adds_ctc() const { return false; }      // honours LaunchCtx::lm_ctc
+    // LM on one GPU: PCGStep3 folded into the apply -- p_out = z + beta p_in (beta = bN_prev / aN_prev, 0 when first), Ap = (J^T J + lm_ctc) p_out, alphaD partials;
+    // p_out is written over the owned rows only and differs from p_in.  Only asked for when apply_adds_ctc() and LaunchCtx::lm_ctc is set.
+    virtual bool apply_folds_pupdate() const { return false; }
+    virtual int apply_jtj_pupdate(LaunchCtx&, const float* /*z*/, const float* /*p_in*/, float* /*p_out*/, float* /*Ap*/, float* /*alphaD_out*/, bool /*first*/,
+                                  thallo_sum_t /*aN_prev*/, thallo_sum_t /*bN_prev*/) { return -1; }
     // fused PCGStep3(k-1) + delta update(k-1) + PCGStep1(k): reads p[cur], writes p[cur^1], Ap, alphaD partials
     virtual int pcg_step1(LaunchCtx&, SolverVectors&, int cur, bool first,
                           thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev, float* alphaD_out) = 0;

@@ -645,6 +645,13 @@ public:
                                               c.gate, c.stream);
     }
     bool apply_adds_ctc() const override { return true; }
+    bool apply_folds_pupdate() const override { return thallo_hip_sfs_lm_pupdate_supported() != 0; }
+    int apply_jtj_pupdate(LaunchCtx& c, const float* z, const float* p_in, float* p_out, float* Ap, float* out, bool first, thallo_sum_t aN, thallo_sum_t bN) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_sfs_apply_jtj_lm_pupdate(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, z, p_in, p_out, c.lm_ctc, Ap, out,
+                                                   first ? 1 : 0, aN, bN, c.gate, c.stream);
+    }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {

@@ -524,6 +524,8 @@ int Plan::step_lm(int ev_iter)
     const bool pc = plugin->use_preconditioner();
     const bool fold_ctc = plugin->apply_adds_ctc() && ![] { const char* e = getenv("THALLO_LM_FOLD_CTC"); return e && e[0] == '0'; }();      // (=0: A/B)
     const bool host_zeta = [] { const char* e = getenv("THALLO_LM_HOST_ZETA"); return e && e[0] == '1'; }();
+    // PCGStep3 folded into the apply too (one GPU; plugins that offer it; THALLO_LM_FOLD_P=0: A/B)
+    const bool fold_p = fold_ctc && !slab && plugin->apply_folds_pupdate() && v_.p[1] != nullptr && ![] { const char* e = getenv("THALLO_LM_FOLD_P"); return e && e[0] == '0'; }();
     // the zeta test by PCGStep2's last workgroup (one GPU, device-side test): one launch less per iteration.  A slab needs the GLOBAL q first.
     if (!host_zeta && !slab && ensure_sums_buffer()) return 0;
     const bool zeta_in_step2 = !host_zeta && !slab && ![] { const char* e = getenv("THALLO_LM_ZETA_IN_STEP2"); return e && e[0] == '0'; }();
@@ -551,10 +553,19 @@ int Plan::step_lm(int ev_iter)
     bool failed = false;
     for (int k = 0; k < L && !failed; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        {   TimedLaunch t(ctx, "PCGStep3");                           // p = z + beta p  (k = 0: p = z)
+        if (fold_p) {                                                 // PCGStep3 + PCGStep1 + PCGStep1_Finish in one launch; p ping-pongs between the two buffers
+            float* pn = p == v_.p[0] ? v_.p[1] : v_.p[0];
+            ctx.lm_ctc = v_.CtC;
+            nb = plugin->apply_jtj_pupdate(ctx, v_.z, p, pn, v_.Ap, slot(jD), k == 0, sum(k ? jN - 2 : jN), sum(jN));
+            ctx.lm_ctc = nullptr;
+            if (nb < 0) { set_error("PCGStep1 (+ PCGStep3) launch failed (%d)", nb); failed = true; break; }
+            p = pn;
+        } else {
+            TimedLaunch t(ctx, "PCGStep3");                           // p = z + beta p  (k = 0: p = z)
             thallo_hip_pcg_pupdate(v_.z + oe, p + oe, p + oe, nullptr, ne, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
         }
-        if (fold_ctc) {                                               // PCGStep1 + PCGStep1_Finish in one launch: (J^T J + CtC) p ; alphaD
+        if (fold_p) { }
+        else if (fold_ctc) {                                          // PCGStep1 + PCGStep1_Finish in one launch: (J^T J + CtC) p ; alphaD
             ctx.lm_ctc = v_.CtC;
             nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(jD));
             ctx.lm_ctc = nullptr;

@@ -23,6 +23,7 @@
 // 1 float per pixel: the whole working set of a 2048^2 frame is ~250 MB of small planes; neighbours come through
 // L1/L2.  Not tuned yet (round 1: correctness + structure).
 #include <stdlib.h>
+#include <stdint.h>
 #include "device_common.hpp"
 #include "../../include/thallo_hip.h"
 
@@ -62,13 +63,12 @@ __device__ __forceinline__ J3 operator-(J3 a, J3 b) { J3 r = { a.v - b.v, a.d0 -
 __device__ __forceinline__ J3 operator*(J3 a, J3 b) { J3 r = { a.v * b.v, a.d0 * b.v + a.v * b.d0, a.d1 * b.v + a.v * b.d1, a.d2 * b.v + a.v * b.d2 }; return r; }
 __device__ __forceinline__ J3 operator*(J3 a, float c) { J3 r = { a.v * c, a.d0 * c, a.d1 * c, a.d2 * c }; return r; }
 
-// BI and its three partials at pixel (x,y)   (shape_from_shading.t:40-80)
-__device__ __forceinline__ J3 eval_BI(const Cam& cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
-                                      int x, int y, int W, int H, int yoff)
+// BI and its three partials at pixel (x,y)   (shape_from_shading.t:40-80), from the values at (x,y), (x-1,y), (x,y-1) (0 outside the image)
+__device__ __forceinline__ J3 eval_BI_vals(const Cam& cm, float Dl, float Dc, float Du, float Xc, float Xl, float Xu, float Ic, float Il, float Iu, int x, int yg)
 {
-    if (!(at(D, x - 1, y, W, H) > 0.0f && at(D, x, y, W, H) > 0.0f && at(D, x, y - 1, W, H) > 0.0f)) return k3(0.0f);
-    const J3 c = { at(X, x, y, W, H), 1.f, 0.f, 0.f }, l = { at(X, x - 1, y, W, H), 0.f, 1.f, 0.f }, u = { at(X, x, y - 1, W, H), 0.f, 0.f, 1.f };
-    const float i = (float)x, j = (float)(y + yoff);
+    if (!(Dl > 0.0f && Dc > 0.0f && Du > 0.0f)) return k3(0.0f);
+    const J3 c = { Xc, 1.f, 0.f, 0.f }, l = { Xl, 0.f, 1.f, 0.f }, u = { Xu, 0.f, 0.f, 1.f };
+    const float i = (float)x, j = (float)yg;
     const J3 nx = (u * (c - l)) * (1.0f / cm.fy);
     const J3 ny = (l * (c - u)) * (1.0f / cm.fx);
     const J3 nz = (nx * ((cm.ux - i) / cm.fx) + ny * ((cm.uy - j) / cm.fy)) - (l * u) * (1.0f / (cm.fx * cm.fy));
@@ -83,8 +83,16 @@ __device__ __forceinline__ J3 eval_BI(const Cam& cm, const float* __restrict__ X
     B = B + (n0 * n1) * L[4]; B = B + (n1 * n2) * L[5];
     B = B + (((n0 * n0) * -1.0f - n1 * n1) + (n2 * n2) * 2.0f) * L[6];
     B = B + (n2 * n0) * L[7]; B = B + (n0 * n0 - n1 * n1) * L[8];
-    const float I = at(Im, x, y, W, H) * 0.5f + 0.25f * (at(Im, x - 1, y, W, H) + at(Im, x, y - 1, W, H));
+    const float I = Ic * 0.5f + 0.25f * (Il + Iu);
     return B - k3(I);
+}
+__device__ __forceinline__ J3 eval_BI(const Cam& cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
+                                      int x, int y, int W, int H, int yoff)
+{
+    const float Dl = at(D, x - 1, y, W, H), Dc = at(D, x, y, W, H), Du = at(D, x, y - 1, W, H);
+    if (!(Dl > 0.0f && Dc > 0.0f && Du > 0.0f)) return k3(0.0f);
+    return eval_BI_vals(cm, Dl, Dc, Du, at(X, x, y, W, H), at(X, x - 1, y, W, H), at(X, x, y - 1, W, H),
+                        at(Im, x, y, W, H), at(Im, x - 1, y, W, H), at(Im, x, y - 1, W, H), x, y + yoff);
 }
 
 __device__ __forceinline__ float coef(const Cam& cm, int c, int x, int y) { return c == 0 ? ((float)x - cm.ux) / cm.fx : c == 1 ? ((float)y - cm.uy) / cm.fy : 1.0f; }
@@ -566,6 +574,96 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
     else block_store_partial(acc, part_out, red);
 }
 
+// ------------------------------------------------------------------------------------------ marching precompute
+// k_precompute as a marching kernel: a wave owns 64 columns (lanes 1..62 produce output), rows are prefetched three ahead (X, D, Im and the two
+// mask dwords: every input once per pixel and wave instead of 13 guarded loads), the left / right neighbours come from the neighbouring lanes,
+// the upper / lower ones from the lane's rings.  The step that takes row t writes row t-1.  Same expressions (eval_BI_vals) as k_precompute.
+constexpr int MP_USE = 62;
+struct MpRaw { float x, d, im; unsigned mr, mc; };
+__device__ __forceinline__ void mp_take(MpRaw& d, const MpRaw& s) { ms_mv(d.x, s.x); ms_mv(d.d, s.d); ms_mv(d.im, s.im); ms_mv(d.mr, s.mr); ms_mv(d.mc, s.mc); }
+
+__global__ __launch_bounds__(MS_NT, 2) void k_precompute_march(MsGeo g, int Hg, Cam cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
+                                                               const unsigned char* __restrict__ mR, const unsigned char* __restrict__ mC,
+                                                               float4* __restrict__ G, float2* __restrict__ Wt, unsigned char* __restrict__ fl)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = g.W, H = g.H;
+    int strip = 0, ya = 0, yb = 0;
+    {
+        const int NG = (gridDim.x % 8) == 0 ? 8 : 1;
+        const int grp = blockIdx.x % NG, l = blockIdx.x / NG;
+        const long lo = (long)g.total * grp / NG, hi = (long)g.total * (grp + 1) / NG;
+        const long id = lo + l;
+        if (id < hi) {
+            strip = (int)(id % g.nstrips);
+            const int seg = (int)(id / g.nstrips) * (MS_NT / 64) + wave;
+            ya = g.ra + seg * g.R; yb = ya + g.R;
+            if (yb > g.rb) yb = g.rb;
+            if (ya > g.rb) ya = g.rb;
+        }
+    }
+    if (ya >= yb) return;
+    const int x = strip * MP_USE - 1 + lane;
+    const bool xin = x >= 0 && x < W;
+    const bool xout = xin && lane >= 1 && lane <= 62;
+    const unsigned xc_ = x < 0 ? 0u : x > W - 1 ? (unsigned)(W - 1) : (unsigned)x;
+    const int t_first = ya - 1, t_last = yb;
+    const long Nb = (long)W * H - 4;
+    auto issue = [&](MpRaw& s, int t) {
+        const int tc = t < 0 ? 0 : t > H - 1 ? H - 1 : t;
+        const long rowoff = (long)tc * W;
+        s.x = (X + rowoff)[xc_]; s.d = (D + rowoff)[xc_]; s.im = (Im + rowoff)[xc_];
+        // the dword that holds the pixel's mask byte (a byte load leaves a zero-extension that ends up behind a wait at the loop latch): aligned, except
+        // that the last one is pulled back inside a plane whose size is not a multiple of 4 (the host checks W * H >= 4 and 4-byte-aligned planes)
+        long b = (rowoff + xc_) & ~3L; if (b > Nb) b = Nb;
+        s.mr = *reinterpret_cast<const unsigned*>(mR + b); s.mc = *reinterpret_cast<const unsigned*>(mC + b);
+    };
+    float Xr[3] = { 0.f, 0.f, 0.f }, Dr[3] = { 0.f, 0.f, 0.f }, Ir[3] = { 0.f, 0.f, 0.f };
+    unsigned Mr[3] = { 0u, 0u, 0u }, Mc[3] = { 0u, 0u, 0u };
+    MpRaw slot[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) slot[j] = MpRaw{};
+    for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int t = t0 + j;
+            const int k0 = j, k1 = (j + 2) % 3, k2 = (j + 1) % 3;          // ring slots of rows t, t-1, t-2
+            MpRaw cur;
+            mp_take(cur, slot[j]);
+            ms_fence();
+            issue(slot[j], t + 3 > t_last ? t_last : t + 3);
+            ms_fence();
+            if (t >= t_first && t <= t_last) {
+                const bool ok = xin && t >= 0 && t < H;
+                const long ipx = (long)t * W + x; long bpx = ipx & ~3L; if (bpx > Nb) bpx = Nb;
+                const int sh = ok ? 8 * (int)(ipx - bpx) : 0;
+                Xr[k0] = ok ? cur.x : 0.0f; Dr[k0] = ok ? cur.d : 0.0f; Ir[k0] = ok ? cur.im : 0.0f;
+                Mr[k0] = (cur.mr >> sh) & 0xffu; Mc[k0] = (cur.mc >> sh) & 0xffu;
+                // the row being written: y = t-1 (slot k1); its upper row t-2 (k2), its lower row t (k0)
+                const float xc = Xr[k1], dc = Dr[k1], ic = Ir[k1];
+                const float xl = ms_left(xc), dl = ms_left(dc), il = ms_left(ic), xr = ms_right(xc), dr = ms_right(dc);
+                const int y = t - 1;
+                if (y >= ya && y < yb && xout) {
+                    const long i = (long)y * W;
+                    const J3 b = eval_BI_vals(cm, dl, dc, Dr[k2], xc, xl, Xr[k2], ic, il, Ir[k2], x, y + g.yoff);
+                    (G + i)[(unsigned)x] = make_float4(b.d0, b.d1, b.d2, b.v);
+                    const int yg = y + g.yoff;
+                    const bool inner = x >= 1 && x + 1 < W && yg >= 1 && yg + 1 < Hg;
+                    (Wt + i)[(unsigned)x] = inner ? make_float2(cm.wg * (float)Mr[k1], cm.wg * (float)Mc[k1]) : make_float2(0.f, 0.f);
+                    unsigned char f = dc > 0.0f ? 1 : 0;
+                    bool valid = f;
+                    valid = valid && dl > 0.0f && fabsf(xc - xl) < 0.01f;               // (x-1, y), (x, y-1), (x+1, y), (x, y+1): k_precompute's order
+                    valid = valid && Dr[k2] > 0.0f && fabsf(xc - Xr[k2]) < 0.01f;
+                    valid = valid && dr > 0.0f && fabsf(xc - xr) < 0.01f;
+                    valid = valid && Dr[k0] > 0.0f && fabsf(xc - Xr[k0]) < 0.01f;
+                    if (valid) f |= 2;
+                    (fl + i)[(unsigned)x] = f;
+                }
+            }
+        }
+    }
+}
+
 // raw diag(J^T J) (LM only): enumerate the rows that contain X(i)
 __global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __restrict__ G, const float2* __restrict__ Wt,
                                                 const unsigned char* __restrict__ fl, float* __restrict__ diag)
@@ -628,9 +726,10 @@ static bool sfs_march()
     static int v = -1; if (v < 0) { const char* e = getenv("THALLO_SFS_MARCH"); v = (e && e[0] == '0') ? 0 : 1; }
     return g_ms_force >= 0 ? g_ms_force == 1 : v == 1;
 }
+static int g_ms_precompute = 1;      // 1: precompute by the marching kernel, 0: k_precompute (tools / tests)
 static int g_ms_diag = 1;      // 1: the LM diagonal by the marching J^T F kernel, 0: k_diag (tools / tests)
 static bool sfs_march_diag() { return g_ms_diag == 1; }
-void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; if (what == 3) g_ms_diag = value; }
+void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; if (what == 3) g_ms_diag = value; if (what == 4) g_ms_precompute = value; }
 static MsGeo make_ms_geo(int W, int H, int ra, int rb, int yoff, int R)
 {
     MsGeo g; g.W = W; g.H = H; g.ra = ra; g.rb = rb; g.yoff = yoff; g.R = R;
@@ -664,6 +763,18 @@ int thallo_hip_sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, co
                               thallo_stream_t stream)
 {
     if (ra < 0 || rb > H || ra >= rb) return -(int)hipErrorInvalidValue;
+    if (sfs_fused() && sfs_march() && g_ms_precompute == 1 && (long)W * H >= 4 && (((uintptr_t)edgeMaskR | (uintptr_t)edgeMaskC) & 3) == 0) {
+        long cap = (long)thallo_hip_device_cu_count() * 4; cap -= cap % 8;
+        MsGeo mg;
+        for (int R = 4;; ++R) {
+            mg = make_ms_geo(W, H, ra, rb, yoff, R); mg.nstrips = (W + MP_USE - 1) / MP_USE;
+            mg.total = mg.nstrips * (((rb - ra + R - 1) / R + MS_NT / 64 - 1) / (MS_NT / 64));
+            if ((mg.total + 7) / 8 * 8 <= cap) break;
+        }
+        hipLaunchKernelGGL(k_precompute_march, dim3((mg.total + 7) / 8 * 8), dim3(MS_NT), 0, (hipStream_t)stream, mg, Hg, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
+                           (float4*)G, (float2*)Wt, fl);
+        return check_launch();
+    }
     const Geo g = make_geo(W, H, ra, rb, yoff, Hg); const int grid = grid_for(g);
     hipLaunchKernelGGL(k_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
                        (float4*)G, (float2*)Wt, fl);

@@ -24,15 +24,29 @@ class Inst:
         X, D, Im, mR, mC = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in p[16:21]]
         self.X, self.D = X, D
         N = W * H
-        self.G = torch.empty(4 * N, dtype=torch.float32, device="cuda"); self.Wt = torch.empty(2 * N, dtype=torch.float32, device="cuda")
-        self.fl = torch.empty(N + 4, dtype=torch.uint8, device="cuda")
-        rc = L.thallo_hip_sfs_precompute(W, H, 0, H, self.yoff, self.Hg, self.hp, vp(X), vp(D), vp(Im), vp(mR), vp(mC), vp(self.G), vp(self.Wt), vp(self.fl), None)
-        assert rc == 0, rc
+        self.Im, self.mR, self.mC = Im, mR, mC
+        self.G, self.Wt, self.fl = self.precompute(0)
+        G1, Wt1, fl1 = self.precompute(1)
+        # the marching precompute against k_precompute: flags and row weights bitwise, G to rounding (same expression tree, separate instantiations)
+        gs = float(self.G.abs().max())
+        self.pre_ok = bool(torch.equal(self.fl[:N], fl1[:N]) and torch.equal(self.Wt, Wt1) and float((self.G - G1).abs().max()) <= 1e-5 * gs)
+        self.pre_msg = f"precompute marching vs k_precompute: flags equal {torch.equal(self.fl[:N], fl1[:N])}, Wt equal {torch.equal(self.Wt, Wt1)}, G max diff / max {float((self.G - G1).abs().max()) / gs:.2e}"
         g = torch.Generator(device="cuda"); g.manual_seed(seed)
         self.p = torch.randn(N, device="cuda", generator=g) * 1e-3
         self.r = torch.randn(N, device="cuda", generator=g) * 1e-3
         self.ctc = torch.rand(N, device="cuda", generator=g) * 50.0
         self.U = torch.empty(2 * N, dtype=torch.float32, device="cuda"); self.R = torch.empty(3 * N, dtype=torch.float32, device="cuda")
+
+    def precompute(self, march):
+        N = self.W * self.H
+        G = torch.full((4 * N,), 3.0, dtype=torch.float32, device="cuda"); Wt = torch.full((2 * N,), 3.0, dtype=torch.float32, device="cuda")
+        fl = torch.full((N + 4,), 9, dtype=torch.uint8, device="cuda")
+        L.thallo_hip_sfs_march_debug_set(4, march)
+        rc = L.thallo_hip_sfs_precompute(self.W, self.H, 0, self.H, self.yoff, self.Hg, self.hp, vp(self.X), vp(self.D), vp(self.Im), vp(self.mR), vp(self.mC), vp(G), vp(Wt), vp(fl), None)
+        L.thallo_hip_sfs_march_debug_set(4, 1)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return G, Wt, fl
 
     def apply(self, variant, Ap, aD, s3):
         a = (self.W, self.H, self.ra, self.rb, self.yoff, self.Hg, self.hp, vp(self.G), vp(self.Wt), vp(self.fl), vp(self.U), vp(self.R), vp(self.p))
@@ -73,6 +87,8 @@ def check():
     ok = True
     for W, H, kw in cases:
         inst = Inst(W, H, **kw)
+        print(f"{W}x{H} {kw} {inst.pre_msg}", flush=True)
+        ok = ok and inst.pre_ok
         (ra_, za, pa, da, ga), na = run_init(inst, False)
         (rb_, zb, pb, db, gb), nb_ = run_init(inst, True)
         (_, _, _, _, gc), _ = run_init(inst, True, diag_by_march=False)
@@ -126,6 +142,18 @@ def timing(W, H):
         L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, 0)
         t, nb = time_one(inst, variant, True)
         print(f"{W}x{H} {variant}: marching kernel (default grid) {t:.1f} us ({nb} workgroups) = {33 * W * H / t / 1e6:.2f} TB/s of the 33 B/pixel", flush=True)
+    for march in (0, 1):
+        for _ in range(3):
+            inst.precompute(march)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        L.thallo_hip_sfs_march_debug_set(4, march)
+        G = torch.empty(4 * W * H, device="cuda"); Wt = torch.empty(2 * W * H, device="cuda"); fl = torch.empty(W * H + 4, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20):
+            L.thallo_hip_sfs_precompute(W, H, 0, H, 0, H, inst.hp, vp(inst.X), vp(inst.D), vp(inst.Im), vp(inst.mR), vp(inst.mC), vp(G), vp(Wt), vp(fl), None)
+        e1.record(); torch.cuda.synchronize()
+        L.thallo_hip_sfs_march_debug_set(4, 1)
+        print(f"{W}x{H} precompute: {'marching kernel' if march else 'k_precompute'} {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
     for march, dg, lab in ((False, 0, "tile kernel"), (True, 0, "marching kernel"), (True, 1, "marching kernel + k_diag (LM)"), (True, 2, "marching kernel incl. the LM diagonal")):
         L.thallo_hip_sfs_march_debug_set(2, 1 if march else 0); L.thallo_hip_sfs_march_debug_set(3, 1 if dg == 2 else 0)
         o = [torch.empty(W * H, device="cuda") for _ in range(5)]; aN = torch.zeros(1024, device="cuda")

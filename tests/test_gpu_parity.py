@@ -912,6 +912,31 @@ def test_shape_from_shading_marching_and_tile_solves_agree(torch, tmp_path, lm):
     assert np.abs(a[:-4] - b[:-4]).max() <= 1e-5 * np.abs(a[:-4]).max()
 
 
+@pytest.mark.parametrize("W,H", [(130, 67), (256, 256)])
+def test_shape_from_shading_one_kernel_iteration(torch, orc, monkeypatch, W, H):
+    """GN on one GPU: ONE launch per PCG iteration (the marching kernel with PCGUpdate riding along: r_k, p_k formed per row, r / Ap / p ping-pong,
+    the three sums from registers; thallo_hip_sfs_pcg_iter) against the two-launch form (THALLO_ONE_KERNEL=0: PCGUpdate + applyJTJ with sums) and the oracle."""
+    p = syn.shape_from_shading(W, H)
+    runs = []
+    for one in ("1", "0"):
+        monkeypatch.setenv("THALLO_ONE_KERNEL", one)
+        dev = to_device(p)
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"))
+        s.set_kernel_sampling(1)
+        final, costs = s.solve(dev, profiled=True, nIterations=4, lIterations=12)
+        ks = {k: v["launches"] for k, v in s.kernel_stats().items() if v["launches"]}
+        runs.append((np.array(costs), to_host(dev[16]).copy(), ks))
+        s.close()
+    (c1, x1, k1), (c0, x0, k0) = runs
+    assert k1.get("PCGIteration") == 4 * 12 and "PCGUpdate" not in k1 and "PCGStep1" not in k1, k1
+    assert k0.get("PCGUpdate") == 4 * 12 and "PCGIteration" not in k0, k0
+    assert np.abs(c1 - c0).max() <= 1e-5 * np.abs(c0).max(), (c1, c0)
+    assert np.abs(x1 - x0).max() <= 1e-5 * np.abs(x0).max()
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.SFS, (W, H), po).solve(nIterations=4, lIterations=12)
+    assert (np.abs(c1 - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (c1, co)
+
+
 def test_shape_from_shading_lm_step3_folded_into_the_apply(torch, monkeypatch):
     """LM on one GPU: PCGStep3 rides in the marching apply (p_k = z + beta p_{k-1} formed per row, p ping-pong; thallo_hip_sfs_apply_jtj_lm_pupdate) --
     against the separate PCGStep3 launch (THALLO_LM_FOLD_P=0): same costs and depth map to rounding, same PCG iteration counts with the zeta exit

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
 constexpr int MS_USE = 60, MS_NT = 256;
 constexpr int MS_OCC = 2, MS_WG_PER_CU = 2;      // registers for 2 workgroups (8 waves) per CU; grid sized for that many (tools/sfs_probe.py sweeps)
 struct MsGeo { int W, H, ra, rb, yoff, R, nstrips, total; };
-struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct, pv; };      // one row of one lane as loaded (pv: p_{k-1} of the row, PUPD)
+struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct, pv, av, dl; };      // one row of one lane as loaded (pv: p_{k-1} of the row, PUPD / UPD; av, dl: Ap_{k-1}, delta, UPD)
 
 // value of lane-1 / lane+1 (wave_shr:1 / wave_shl:1); a lane without a source reads 0 (bound_ctrl) -- lanes 0 / 63 produce no output.
 // mov_dpp has no tied "old" operand: one v_mov_b32_dpp per exchange, and the compiler may fold it into the consuming instruction.
@@ -382,15 +382,16 @@ __device__ __forceinline__ void ms_mv(float& d, const float& s) { asm volatile("
 __device__ __forceinline__ void ms_mv(unsigned& d, const unsigned& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
 // a prefetch slot moves into fresh registers with real v_mov instructions, so that its refill can be issued into the SAME registers right
 // behind (energy_image_warping_march.hip `take`: otherwise the compiler computes in place and the refill turns into a blocking load)
-template <bool SUMS, bool CTC, bool INIT, bool PUPD = false>
+template <bool SUMS, bool CTC, bool INIT, bool PUPD = false, bool UPD = false>
 __device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
 {
-    d.pv = 0.0f;
-    if (PUPD) ms_mv(d.pv, s.pv);
+    d.pv = 0.0f; d.av = 0.0f; d.dl = 0.0f;
+    if (PUPD || UPD) ms_mv(d.pv, s.pv);
+    if (UPD) { ms_mv(d.av, s.av); ms_mv(d.dl, s.dl); }
     ms_mv(d.g.x, s.g.x); ms_mv(d.g.y, s.g.y); ms_mv(d.g.z, s.g.z); ms_mv(d.w.x, s.w.x); ms_mv(d.w.y, s.w.y); ms_mv(d.v, s.v); ms_mv(d.f, s.f);
     d.g.w = 0.0f; d.rs = 0.0f; d.ct = 0.0f;
     if (INIT) ms_mv(d.g.w, s.g.w);
-    if (SUMS) ms_mv(d.rs, s.rs);
+    if (SUMS && !UPD) ms_mv(d.rs, s.rs);
     if (CTC) ms_mv(d.ct, s.ct);
 }
 
@@ -401,19 +402,30 @@ __device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
 // PUPD (LM, one GPU): PCGStep3 rides along -- v is z, the lane forms p_k = z + beta_{k-1} p_{k-1} for every row it takes (halo rows and lanes
 // redundantly, like image_warping's marching kernel), stores p_k for its own rows and applies (J^T J + CtC) to it.  p_{k-1} and p_k are different buffers.
 struct MsPupd { const float* p_in; float* p_out; thallo_sum_t aN, bN; int first; };
-template <bool SUMS, bool CTC, bool INIT, bool DIAG, int OCC, bool PUPD = false>
+// UPD (GN, one GPU): the whole PCG iteration in this launch -- k_pcg_update rides along.  v is r_{k-1}; per row taken the lane forms
+// r_k = r_{k-1} - alpha_{k-1} Ap_{k-1} and p_k = r_k + beta_{k-1} p_{k-1} (no preconditioner in this energy; halo rows and lanes redundantly), stores r_k, p_k
+// and delta += alpha_{k-1} p_{k-1} for its own rows, applies J^T J to p_k, and the three sums take r_k from registers.  r, Ap and p ping-pong
+// (the neighbours' halo rows re-read the previous iteration's planes while the owner writes this iteration's).
+struct MsUpd { float* r_out; const float* A_in; const float* p_in; float* p_out; float* delta; thallo_sum_t aN, aD, bN; int first; };
+template <bool SUMS, bool CTC, bool INIT, bool DIAG, int OCC, bool PUPD = false, bool UPD = false>
 __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const float* __restrict__ v, const float* __restrict__ ctc,
                                                       const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
                                                       float* __restrict__ out, float* __restrict__ part_out, const float* __restrict__ rs,
                                                       double* __restrict__ s3_out, const unsigned* __restrict__ gate, FinArgs fin,
                                                       float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ diag,
-                                                      MsPupd pu = MsPupd{})
+                                                      MsPupd pu = MsPupd{}, MsUpd up = MsUpd{})
 {
     __shared__ float red[16];
     __shared__ double redd[3 * MS_NT / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
     float beta = 0.0f;
     if (PUPD && !pu.first) beta = safe_div<true>(sum_partials(pu.bN.partials, pu.bN.count), sum_partials(pu.aN.partials, pu.aN.count));      // as k_pupdate (LM)
+    float alpha = 0.0f;
+    if (UPD && !up.first) {                                                                                                                      // as k_pcg_update
+        const float an = sum_partials(up.aN.partials, up.aN.count);
+        alpha = safe_div<false>(an, sum_partials(up.aD.partials, up.aD.count));
+        beta  = safe_div<false>(sum_partials(up.bN.partials, up.bN.count), an);
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // (uniform: rows, row addresses and guards stay scalar)
     const int W = g.W, H = g.H;
     // XCD-aware placement as in the image_warping marching kernel: workgroups b and b+8 share an XCD; group b%8 owns a contiguous range of
@@ -450,13 +462,18 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
             const long rowoff = (long)tc * W;
             s.g = (G + rowoff)[xc_]; s.w = (Wt + rowoff)[xc_]; s.v = (v + rowoff)[xc_];
             if (PUPD) s.pv = (pu.p_in + rowoff)[xc_];
+            if (UPD) {
+                s.pv = (up.p_in + rowoff)[xc_]; s.av = (up.A_in + rowoff)[xc_];
+                const int td = t < ya ? ya : t > yb - 1 ? yb - 1 : t;          // delta: the segment's own rows only
+                s.dl = (up.delta + (long)td * W)[xc_];
+            }
             // the aligned dword that holds the pixel's flags byte (shifted when the row is taken): a byte load leaves a zero-extension for the
             // compiler to place, and it places it at the loop latch behind a wait for the fresh load (energy_image_warping_march.hip)
             s.f = *reinterpret_cast<const unsigned*>(fl + ((rowoff + xc_) & ~3L));
             if (SUMS || CTC) {
                 const int yo = t - 2 < ya ? ya : t - 2 > yb - 1 ? yb - 1 : t - 2;
                 const long ro = (long)yo * W;
-                if (SUMS) s.rs = (rs + ro)[xc_];
+                if (SUMS && !UPD) s.rs = (rs + ro)[xc_];
                 if (CTC) s.ct = (ctc + ro)[xc_];
             }
         };
@@ -465,6 +482,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
         float Vv[3] = { 0.f, 0.f, 0.f }, dB[3] = { 0.f, 0.f, 0.f }, Uh[3] = { 0.f, 0.f, 0.f }, Uv[3] = { 0.f, 0.f, 0.f }, Tt[3] = { 0.f, 0.f, 0.f };
         float Gx[3] = { 0.f, 0.f, 0.f }, Gy[3] = { 0.f, 0.f, 0.f }, Gz[3] = { 0.f, 0.f, 0.f }, Cy[3] = { 0.f, 0.f, 0.f }, Wy[3] = { 0.f, 0.f, 0.f };
         float Wx[3] = { 0.f, 0.f, 0.f };       // (DIAG) the rows' h weights, zero outside the image like Wy
+        float Rk[3] = { 0.f, 0.f, 0.f };       // (UPD) r_k of the rows
         unsigned Fl[3] = { 0u, 0u, 0u };
         bool Wn[3] = { false, false, false };
         float Rr[3][3] = { { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f } };
@@ -478,14 +496,24 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                 const int t = t0 + j;
                 const int k0 = j, k1 = (j + 2) % 3, k2 = (j + 1) % 3;          // ring slots of rows t, t-1, t-2 (and t-3 = t)
                 MsRaw cur;
-                ms_take<SUMS, CTC, INIT, PUPD>(cur, slot[j]);
+                ms_take<SUMS, CTC, INIT, PUPD, UPD>(cur, slot[j]);
                 ms_fence();
                 issue(slot[j], t + 3 > t_last ? t_last : t + 3);
                 ms_fence();
                 if (t >= t_first && t <= t_last) {                 // (wave-uniform; no load inside)
                     const bool ok = xin && t >= 0 && t < H;
-                    const float v0 = ok ? (PUPD ? cur.v + beta * cur.pv : cur.v) : 0.0f;
+                    float rk = cur.v;
+                    if (UPD && !up.first) rk = __builtin_fmaf(-alpha, cur.av, rk);
+                    const float v0 = ok ? (PUPD ? cur.v + beta * cur.pv : UPD ? rk + beta * cur.pv : cur.v) : 0.0f;
                     if (PUPD && t >= ya && t < yb && xout) (pu.p_out + (long)t * W)[(unsigned)x] = v0;
+                    if (UPD) {
+                        Rk[k0] = rk;
+                        if (t >= ya && t < yb && xout) {
+                            const long ro = (long)t * W;
+                            (up.r_out + ro)[(unsigned)x] = rk; (up.p_out + ro)[(unsigned)x] = v0;
+                            if (!up.first) (up.delta + ro)[(unsigned)x] = __builtin_fmaf(alpha, cur.pv, cur.dl);
+                        }
+                    }
                     const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;
                     const float v1 = Vv[k1], v2 = Vv[k2];
                     Cy[k0] = coef(cm, 1, 0, t + g.yoff);
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                         } else {
                             if (CTC) s += cur.ct * vc;
                             (out + (long)y * W)[(unsigned)x] = s; acc += vc * s;
-                            if (SUMS) sm.add(1.0f, cur.rs, s);
+                            if (SUMS) sm.add(1.0f, UPD ? Rk[k2] : cur.rs, s);
                         }
                     }
                     Vv[k0] = v0; Fl[k0] = f0; Wn[k0] = wn0; Wy[k0] = cur.w.y; if (DIAG) Wx[k0] = ok ? cur.w.x : 0.0f; dB[k0] = dB0; Uh[k0] = Uh0; Uv[k1] = Uv1; Tt[k1] = T1;
@@ -852,6 +880,25 @@ int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int 
 { return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream, gate, thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr }, CtC); }
 
 int thallo_hip_sfs_lm_pupdate_supported(void) { return sfs_fused() && sfs_march() ? 1 : 0; }
+
+int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                            const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
+                            thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* aD_out, double* s3_out, thallo_fin_t fin, thallo_stream_t stream)
+{
+    if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !delta || !aD_out || !s3_out) return -(int)hipErrorInvalidValue;
+    if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !alphaD_prev.partials || !betaN_prev.partials)) return -(int)hipErrorInvalidValue;
+    if (fin.tickets && (!fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
+    if (!thallo_hip_sfs_lm_pupdate_supported()) return -(int)hipErrorNotSupported;
+    const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
+    const int gridm = (mg.total + 7) / 8 * 8;
+    if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+    const MsUpd up = { r_out, first ? r_in : Ap_in, p_in, p_out, delta, alphaN_prev, alphaD_prev, betaN_prev, first ? 1 : 0 };     // (first: Ap_in is not used; any readable plane)
+    const FinArgs fa{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridm };
+    hipLaunchKernelGGL((k_march<true, false, false, false, MS_OCC, false, true>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cam_of(host_params), r_in, (const float*)nullptr,
+                       (const float4*)G, (const float2*)Wt, fl, Ap_out, aD_out, (const float*)nullptr, s3_out, (const unsigned*)nullptr, fa,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, MsPupd{}, up);
+    int e = check_launch(); return e ? e : gridm;
+}
 
 int thallo_hip_sfs_apply_jtj_lm_pupdate(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                         const float* z, const float* p_in, float* p_out, const float* CtC, float* Ap, float* aD_out, int first,

@@ -116,6 +116,9 @@ public:
     // One kernel per PCG iteration (thallo_hip.h thallo_hip_iw_pcg_iter): reads r/Ap/p[cur], writes r/Ap/p[cur^1], alphaD partials
     // to alphaD_out and the double sums to v.s12; pcg_iter_finish turns them into the two scalar words of the iteration.
     virtual bool one_kernel_iteration() const { return false; }
+    // across ranks (solver_dist.cpp): the flat single-image form (applyJTJ with the three sums + one all-gather per iteration) rather than image_warping's
+    // one-kernel slab form; by default whatever has no one-kernel iteration
+    virtual bool dist_flat_form() const { return !one_kernel_iteration(); }
     // aD_word / bN_word non-NULL: the kernel finishes the two scalars itself (no pcg_iter_finish launch)
     virtual int pcg_iter(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, float* /*alphaD_out*/,
                          float* /*aD_word*/, float* /*bN_word*/) { return -1; }

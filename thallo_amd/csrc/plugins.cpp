@@ -652,6 +652,23 @@ public:
         return thallo_hip_sfs_apply_jtj_lm_pupdate(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, z, p_in, p_out, c.lm_ctc, Ap, out,
                                                    first ? 1 : 0, aN, bN, c.gate, c.stream);
     }
+    // GN on one GPU: one launch per PCG iteration (the marching kernel with PCGUpdate riding along; r, Ap, p ping-pong).  Across ranks: the flat form.
+    bool one_kernel_iteration() const override { return thallo_hip_sfs_lm_pupdate_supported() != 0 && row0_ == 0 && row1_ == H; }
+    bool dist_flat_form() const override { return true; }
+    int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t, thallo_sum_t, float* out,
+                 float* aD_word, float* bN_word) override
+    {
+        if (mode & ~1) return -1;                                   // (no batched delta updates here: batches_delta() is false)
+        TimedLaunch t(c, "PCGIteration");
+        const thallo_fin_t fin = { bN, aD_word ? v.fin_tickets : nullptr, aD_word, bN_word };
+        return thallo_hip_sfs_pcg_iter(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
+                                       v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode & 1, aN, aD, bN, out, v.s12, fin, c.stream);
+    }
+    int pcg_iter_finish(LaunchCtx& c, SolverVectors& v, const float* part, int count, thallo_sum_t aN, float* aD_word, float* bN_word) override
+    {
+        TimedLaunch t(c, "PCGScalars");
+        return thallo_hip_pcg_scalars_finish(part, v.s12, count, aN, aD_word, bN_word, c.stream);
+    }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {

@@ -397,7 +397,7 @@ int Plan::step_gn_one_kernel(int ev_iter)
     for (int k = 0; k < (defer ? L : 0); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         const thallo_prev_t prev = { k ? slot(jD - 2) : nullptr, v_.s12buf((k - 1) & 1), nb_prev, k ? scal(jD - 2) : nullptr, k ? scal(jB - 2) : nullptr };
-        nb = plugin->pcg_iter_deferred(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ ? 1 : 0), sum(k ? jN - 2 : jN), sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD),
+        nb = plugin->pcg_iter_deferred(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ && plugin->batches_delta() ? 1 : 0), sum(k ? jN - 2 : jN), sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD),
                                        prev, slot(jD), v_.s12buf(k & 1));
         if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
         if (k) { fin_[jD - 2] = 1; set_nb(jB - 2, 1); fin_[jB - 2] = 1; }      // (that launch's workgroup 0 writes the two words of iteration k-1)
@@ -410,7 +410,7 @@ int Plan::step_gn_one_kernel(int ev_iter)
     for (int k = 0; k < (defer ? 0 : L); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
-        nb = plugin->pcg_iter(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ ? 1 : 0), sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
+        nb = plugin->pcg_iter(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ && plugin->batches_delta() ? 1 : 0), sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
                               sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), slot(jD),
                               fin_in_kernel_ ? scal(jD) : nullptr, fin_in_kernel_ ? scal(jB) : nullptr);
         if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
@@ -418,7 +418,7 @@ int Plan::step_gn_one_kernel(int ev_iter)
         if (!fin_in_kernel_ && plugin->pcg_iter_finish(ctx, v_, slot(jD), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
         fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
     }
-    const bool batched = batch_delta_;                 // THALLO_IW_STEP1_MODE(k, 1): every other delta update is deferred
+    const bool batched = batch_delta_ && plugin->batches_delta();                 // THALLO_IW_STEP1_MODE(k, 1): every other delta update is deferred
     last_l_iters = L;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);

@@ -133,7 +133,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         D.info = buf;
         return 0;
     }
-    const bool flat = !plugin->one_kernel_iteration();         // single-image energies in the single-reduction form (shape_from_shading); else image_warping's one-kernel form
+    const bool flat = plugin->dist_flat_form();         // single-image energies in the single-reduction form (shape_from_shading); else image_warping's one-kernel form
     if (!plugin->supports_row_slabs() || (flat && (!plugin->apply_returns_sums() || plugin->unknown_images().size() != 1))) { set_error("distributed: %s has no row-slab form", plugin->name()); return -1; }
     if (lm_ && !flat) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
     if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }

@@ -526,7 +526,10 @@ public:
         { const char* e = getenv("THALLO_BA_JP_ONCE"); once_ = !(e && e[0] == '0'); }
         if (once_) {
             if (!q_ptk.ptr && (q_ptk.alloc(sizeof(int) * (size_t)O + 64) || JP.alloc(sizeof(float) * 6 * (size_t)O + 64) || JpP.alloc(sizeof(float) * 2 * (size_t)O + 64))) return -1;
-            if (thallo_hip_ba_point_order(O, (const int*)pt_pos.ptr, (int*)q_ptk.ptr, nullptr) < 0 || hipDeviceSynchronize() != hipSuccess) { set_error("bundle_adjustment: point order failed"); return -1; }
+            {   const int rc = thallo_hip_ba_point_order(O, (const int*)pt_pos.ptr, (int*)q_ptk.ptr, nullptr);
+                const hipError_t se = rc < 0 ? hipSuccess : hipDeviceSynchronize();
+                if (rc < 0 || se != hipSuccess) { set_error("bundle_adjustment: point order failed (launch %d, sync %d: %s)", rc, (int)se, hipGetErrorString(rc < 0 ? (hipError_t)(-rc) : se)); return -1; }
+            }
         }
         return 0;
     }
@@ -557,6 +560,7 @@ public:
     long shared_block_floats() const override { return once_ ? 3L * P : 0; }        // (the shard form runs on the J p-once applyJTJ)
     int shared_split_slots() const override { return thallo_hip_ba_apply2_camera_slots(C, P); }
     bool apply_adds_ctc() const override { return once_; }
+    // (PCGStep3 folded into this apply was measured: forming p_k = z + beta p_{k-1} at every gather costs the camera kernel 8 us, the launch it saves 7: not kept)
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {

@@ -937,6 +937,23 @@ def test_shape_from_shading_one_kernel_iteration(torch, orc, monkeypatch, W, H):
     assert (np.abs(c1 - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (c1, co)
 
 
+def test_sampled_timer_scopes_nest(torch):
+    """Kernel sampling on, LM with more PCG iterations than residual_reset_period (step_lm's timed PCGStep2 scope then contains an applyJTJ that times itself):
+    every sample is a valid event pair and the NEXT plan's first checked launch does not inherit a stale HIP error (round 2: it did)."""
+    p = syn.bundle_adjustment(C=24, P=400, O=2400, band=8)
+    for _ in range(2):
+        dev = to_device(p)
+        s = api.ThalloSolver((24, 400, 2400), thallo_amd.energy_file("bundle_adjustment"), solverkind="levenberg_marquardt")
+        s.enable_lm(); s.set_solver_parameters(nIterations=3, lIterations=40, q_tolerance=0.0); s.set_kernel_sampling(1)
+        params = s.make_params(dev); s.init(params)
+        n = 0
+        while s.step(params):
+            n += 1
+        ks = s.kernel_stats()
+        assert n >= 2 and ks["PCGStep2"]["samples"] == ks["PCGStep2"]["launches"] > 0 and ks["PCGStep1"]["samples"] == ks["PCGStep1"]["launches"], ks
+        s.close()
+
+
 @pytest.mark.parametrize("which", ["sfs"])
 def test_lm_step3_folded_into_the_apply(torch, monkeypatch, which):
     """LM on one GPU: PCGStep3 rides in shape_from_shading's marching apply (p_k = z + beta p_{k-1} formed per row, p ping-pong;

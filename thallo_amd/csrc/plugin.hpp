@@ -32,7 +32,7 @@ public:
     std::vector<Stat> stats;
 private:
     std::map<std::string, int> index_;
-    hipEvent_t cur_start_ = nullptr;
+    std::vector<hipEvent_t> open_;      // start events of the timed scopes that are open (they nest: step_lm's PCGStep2 scope contains an applyJTJ's PCGStep1)
     std::vector<hipEvent_t> pool_;
     hipEvent_t get_event();
 };

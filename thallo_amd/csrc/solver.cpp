@@ -35,17 +35,21 @@ int KernelTimer::begin(const char* name, hipStream_t s)
     const long n = st.launches++;
     if (period <= 0 || (n % period) != 0) return -1;
     if (invasive) hipDeviceSynchronize();
-    cur_start_ = get_event();
-    hipEventRecord(cur_start_, s);
+    open_.push_back(get_event());
+    hipEventRecord(open_.back(), s);
     return idx;
 }
 void KernelTimer::end(int slot, hipStream_t s)
 {
     if (invasive) hipDeviceSynchronize();
+    if (open_.empty()) return;              // (never: every sampled begin() is paired with one end())
     hipEvent_t e = get_event();
     hipEventRecord(e, s);
-    stats[slot].pending.emplace_back(cur_start_, e);
-    cur_start_ = nullptr;
+    // scopes nest (a timed plan-level step around a plugin's own timed launch): the innermost open scope ends first.  A single "current start" slot
+    // left the outer scope with a null start event -- hipEventElapsedTime then failed with hipErrorInvalidResourceHandle, and that stale error was
+    // reported by whatever launch was checked next (seen as "point order failed" in a later bundle adjustment plan).
+    stats[slot].pending.emplace_back(open_.back(), e);
+    open_.pop_back();
 }
 void KernelTimer::collect()
 {
@@ -64,6 +68,7 @@ KernelTimer::~KernelTimer()
 {
     for (auto& st : stats) for (auto& pr : st.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : pool_) hipEventDestroy(e);
+    for (auto e : open_) hipEventDestroy(e);
 }
 
 // ------------------------------------------------------------------ CoarseTimer

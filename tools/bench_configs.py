@@ -14,10 +14,12 @@ import thallo_amd
 from thallo_amd import synthetic as syn
 
 
-def run(name, fname, dims, params, nit, lit, warm=1):
+def run(name, fname, dims, params, nit, lit, warm=1, lm=False):
     dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in params]
-    s = thallo_amd.ThalloSolver(dims, thallo_amd.energy_file(fname))
-    s.set_solver_parameters(nIterations=nit + warm, lIterations=lit)
+    s = thallo_amd.ThalloSolver(dims, thallo_amd.energy_file(fname), **({"solverkind": "levenberg_marquardt"} if lm else {}))
+    if lm:
+        s.enable_lm()
+    s.set_solver_parameters(nIterations=nit + warm, lIterations=lit, **({"q_tolerance": 0.0} if lm else {}))
     prm = s.make_params(dev)
     s.init(prm)
     c0 = s.current_cost()
@@ -56,6 +58,8 @@ out.append(run("image_warping 512x512 synthetic GN 8x100", "image_warping", (512
 p = syn.arap_mesh(320, 320)
 out.append(run("arap_mesh 102400 v / 614400 e GN 20x100", "arap_mesh_deformation", (p[2].shape[0], p[6].shape[0]), p, 5, 100))
 out.append(run("shape_from_shading 2048x2048 GN x10", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 6, 10))
+out.append(run("shape_from_shading 2048x2048 LM x10 (BASELINE config 4's solver)", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 5, 10, lm=True))
 p = syn.bundle_adjustment()
+out.append(run("bundle_adjustment C=1723 P=156502 O=678718 LM x150 (BASELINE config 5's solver)", "bundle_adjustment", (p[0].shape[0], p[1].shape[0], p[2].shape[0]), p, 3, 150, lm=True))
 out.append(run("bundle_adjustment C=1723 P=156502 O=678718 GN x150", "bundle_adjustment", (p[0].shape[0], p[1].shape[0], p[2].shape[0]), p, 3, 150))
 print(json.dumps(out, indent=1))

@@ -16,9 +16,14 @@ if os.path.exists(os.path.join(g, "secondary_configs.json")):
 # kernel-name fragment -> (label, algorithmic bytes per launch at the profiled size or None)
 NPX = 2048 * 2048
 O_BA = 678718
-KEYS = [("k_march<true, false", "shape_from_shading applyJTJ + three sums (marching kernel, 2048^2; 33 B/pixel + 4 for r)", 37 * NPX),
-        ("k_march<false, true", "shape_from_shading (J^T J + CtC) p (marching kernel, LM, 2048^2; 33 B/pixel + 4 for CtC)", 37 * NPX),
-        ("k_march<false, false", "shape_from_shading applyJTJ (marching kernel, 2048^2)", 33 * NPX),
+KEYS = [("k_march<true, false, false, false, 2, false, true>", "shape_from_shading one-kernel GN iteration: PCGUpdate + applyJTJ + three sums (marching kernel, 2048^2; 57 B/pixel)", 57 * NPX),
+        ("k_march<false, true, false, false, 2, true, false>", "shape_from_shading LM: PCGStep3 + (J^T J + CtC) p (marching kernel, 2048^2; 45 B/pixel)", 45 * NPX),
+        ("k_march<true, false, false, false, 2, false, false>", "shape_from_shading applyJTJ + three sums (marching kernel, 2048^2; 37 B/pixel)", 37 * NPX),
+        ("k_march<false, true, false, false, 2, false, false>", "shape_from_shading (J^T J + CtC) p (marching kernel, LM, 2048^2; 37 B/pixel)", 37 * NPX),
+        ("k_march<false, false, false, false", "shape_from_shading applyJTJ (marching kernel, 2048^2; 33 B/pixel)", 33 * NPX),
+        ("k_march<false, true, true, false", "shape_from_shading PCGInit1 J^T F (marching kernel, 2048^2; 49 B/pixel: X D G Wt fl in, r z p delta out)", 49 * NPX),
+        ("k_march<false, true, true, true", "shape_from_shading PCGInit1 J^T F + LM diagonal (marching kernel, 2048^2; 53 B/pixel)", 53 * NPX),
+        ("k_precompute_march", "shape_from_shading precompute (marching kernel, 2048^2; 39 B/pixel: X D I masks in, G Wt fl out)", 39 * NPX),
         ("k_fused<1>", "shape_from_shading applyJTJ (fused, 2048^2)", 33 * NPX),
         ("k_fused<0>", "shape_from_shading PCGInit1 J^T F (fused, 2048^2)", None),
         ("k_cam2", "bundle_adjustment J^T(Jp) camera kernel (ladybug-1723 shape)", 116 * O_BA),

@@ -937,6 +937,40 @@ def test_shape_from_shading_one_kernel_iteration(torch, orc, monkeypatch, W, H):
     assert (np.abs(c1 - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (c1, co)
 
 
+def test_shape_from_shading_precomputed_planes_are_reused_only_while_valid(torch, orc):
+    """computeCost and PCGInit1 share the precomputed planes while the unknowns have not changed: LM's accepted steps run ONE precompute per step (the
+    cost evaluation's), rejected steps and Gauss-Newton steps recompute; a second Init on the same plan with rewritten unknowns behind the same pointers
+    starts from fresh planes (same trajectory as a new plan)."""
+    W, H = 96, 64
+    p = syn.shape_from_shading(W, H)
+    dev = to_device(p)
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), solverkind="levenberg_marquardt")
+    s.enable_lm()
+    s.set_solver_parameters(nIterations=4, lIterations=10, trust_region_radius=1e4)
+    params = s.make_params(dev)
+    s.init(params)
+    c_a, n = [s.current_cost()], 0
+    while s.step(params):
+        c_a.append(s.current_cost()); n += 1
+    ks = s.kernel_stats()
+    assert n >= 3 and all(c_a[i + 1] <= c_a[i] for i in range(len(c_a) - 1))
+    # Init's cost + one per step's cost evaluation + one more after every rejected step (the unknowns were reverted); before: two per step
+    rejected = sum(1 for i in range(len(c_a) - 1) if c_a[i + 1] == c_a[i])
+    steps = ks["PCGInit1"]["launches"]
+    assert 1 + steps <= ks["precompute"]["launches"] <= 1 + steps + rejected + 1 and ks["precompute"]["launches"] < 1 + 2 * steps, (ks["precompute"], steps, rejected, c_a)
+    # same plan, same pointers, unknowns rewritten by the caller: the second solve must not see the first solve's planes
+    dev[16].copy_(torch.from_numpy(p[16]).cuda())
+    s.set_solver_parameters(trust_region_radius=1e4)          # (a step writes the radius back into the parameter, gauss_newton.t:1751)
+    s.init(params)
+    c_b = [s.current_cost()]
+    while s.step(params):
+        c_b.append(s.current_cost())
+    assert c_b == c_a, (c_a, c_b)
+    co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=4, lIterations=10, use_lm=1, trust_region_radius=1e4)
+    m = min(len(co), len(c_a))
+    assert (np.abs(np.array(c_a[:m]) - co[:m]) <= 2e-4 * np.abs(co[:m])).all(), (c_a, co)
+
+
 def test_sampled_timer_scopes_nest(torch):
     """Kernel sampling on, LM with more PCG iterations than residual_reset_period (step_lm's timed PCGStep2 scope then contains an applyJTJ that times itself):
     every sample is a valid event pair and the NEXT plan's first checked launch does not inherit a stale HIP error (round 2: it did)."""

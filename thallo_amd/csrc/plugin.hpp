@@ -138,6 +138,8 @@ public:
     }
     // pointer to unknown image k as currently bound
     virtual float* unknown_ptr(int k) = 0;
+    // the driver (or an exchange) has just written the unknowns: whatever the plugin derived from them (shape_from_shading's precomputed planes) is stale
+    virtual void unknowns_changed() {}
     // Direct solve of the normal equations instead of PCG (gauss_newton.t:1280-1328, 1612-1613): after pcg_init, delta = (J^T J)^-1 r
     virtual bool direct_solve() const { return false; }
     virtual int  solve_direct(LaunchCtx&, SolverVectors&) { return -1; }

@@ -590,8 +590,15 @@ class ShapeFromShadingPlugin : public EnergyPlugin {
     float* X = nullptr; const float *D = nullptr, *Im = nullptr; const unsigned char *mR = nullptr, *mC = nullptr;
     DeviceBuffer G, Wt, fl, U, R;
     int row0_ = 0, row1_ = 0, yoff_ = 0, Hg_ = 0;      // owned rows of the local image; its first row's global index; global image height (all of it on one GPU)
+    // The precomputed planes (G, Wt, fl) are a function of the unknowns, the inputs and the scalar parameters.  computeCost and PCGInit1 both need them; LM
+    // evaluates the cost of the updated unknowns at the END of a step and, if the step is accepted, starts the next step from the same unknowns: the planes of
+    // that cost evaluation are the next PCGInit1's (the reference precomputes per GN iteration, gauss_newton.t:979-986, and has no precomputed planes in its
+    // cost kernel).  `planes_valid_` drops when the driver writes the unknowns (unknowns_changed), when a parameter or a pointer changes (bind) or the slab does.
+    bool planes_valid_ = false;
     int precompute(LaunchCtx& c)
     {
+        if (planes_valid_) return 0;
+        planes_valid_ = true;
         TimedLaunch t(c, "precompute");
         return thallo_hip_sfs_precompute(W, H, 0, H, yoff_, Hg_, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
     }
@@ -610,7 +617,7 @@ public:
     int set_slab_global(int global_row0, int global_rows) override
     {
         if (global_row0 < 0 || global_rows < global_row0 + H) { set_error("shape_from_shading: local rows [%d,%d) outside the %d global rows", global_row0, global_row0 + H, global_rows); return -1; }
-        yoff_ = global_row0; Hg_ = global_rows; return 0;
+        yoff_ = global_row0; Hg_ = global_rows; planes_valid_ = false; return 0;
     }
     const char* name() const override { return "shape_from_shading"; }
     long n_unknowns() const override { return (long)W * H; }
@@ -618,7 +625,13 @@ public:
     bool use_preconditioner() const override { return false; }            // no UsePreconditioner() in the .t
     int bind(void** p) override
     {
-        for (int k = 0; k < 16; ++k) { if (!p[k]) { set_error("shape_from_shading: null scalar parameter %d", k); return -1; } hp[k] = *(const float*)p[k]; }
+        for (int k = 0; k < 16; ++k) {
+            if (!p[k]) { set_error("shape_from_shading: null scalar parameter %d", k); return -1; }
+            const float v = *(const float*)p[k];
+            if (memcmp(&v, &hp[k], sizeof v)) planes_valid_ = false;
+            hp[k] = v;
+        }
+        if (X != (float*)p[16] || D != (const float*)p[17] || Im != (const float*)p[18] || mR != (const unsigned char*)p[19] || mC != (const unsigned char*)p[20]) planes_valid_ = false;
         X = (float*)p[16]; D = (const float*)p[17]; Im = (const float*)p[18]; mR = (const unsigned char*)p[19]; mC = (const unsigned char*)p[20];
         if (!X || !D || !Im || !mR || !mC) { set_error("shape_from_shading: null image parameter"); return -1; }
         const size_t N = (size_t)W * H;
@@ -626,6 +639,7 @@ public:
         return 0;
     }
     float* unknown_ptr(int) override { return X; }
+    void unknowns_changed() override { planes_valid_ = false; }
     int cost(LaunchCtx& c, float* out) override
     {
         int rc = precompute(c); if (rc < 0) return rc;

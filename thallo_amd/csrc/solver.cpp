@@ -241,6 +241,7 @@ void Plan::init(void** params)
     ev_total_ = timer_.start("Total", ctx.stream);
     ready_ = false;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return; }
+    plugin->unknowns_changed();                // a new solve: the caller may have rewritten unknowns and inputs behind the same pointers
     if (plugin->prepare(ctx)) { const std::string why = last_error(); set_error("%s: prepare failed: %s", plugin->name(), why.c_str()); return; }
     if (dist_ && !dist_->flat && !dist_->range) {   // collective: the one-kernel slab schedule needs its precondition on EVERY rank; then (first Init) the exchange's self-check
         bool all = false;
@@ -312,6 +313,7 @@ void Plan::linear_update_tail(int L, bool batched)
         else            thallo_hip_linear_update(X, dl, nullptr, len, sum(B), sum(B), s);
         off += imgs[k].n_floats;
     }
+    plugin->unknowns_changed();
 }
 
 int Plan::step_gn(int ev_iter)
@@ -677,6 +679,7 @@ int Plan::step_lm(int ev_iter)
             HIP_OK(hipMemcpyAsync(plugin->unknown_ptr((int)k), v_.prevX + off, imgs[k].n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
             off += imgs[k].n_floats;
         }
+        plugin->unknowns_changed();
         radius_ = radius_ / decrease_factor_;
         decrease_factor_ = 2.0f * decrease_factor_;
         if (radius_ < sp.min_trust_region_radius) { sp.trust_region_radius = 10e4f; stop = true; }

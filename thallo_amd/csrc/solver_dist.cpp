@@ -344,7 +344,8 @@ int Plan::dist_gn(int L, bool p2p)
 }
 
 int Plan::dist_exchange_unknown_rows()
-{   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
+{
+    plugin->unknowns_changed();                                   // (ghost rows of the unknowns are about to be rewritten)   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
     DistState& D = *dist_;
     hipStream_t s = ctx.stream;
     const int rank = D.cfg.rank, g = D.ghost;

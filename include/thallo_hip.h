@@ -422,6 +422,11 @@ int thallo_hip_ba_apply_jtj(int C, int P, const int* cam_ptr, const int* q_pt, c
 int thallo_hip_sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
                               const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
                               thallo_stream_t stream);
+/* precompute over the rows [ra, rb) and computeCost over the rows [c0, c1) of them in ONE launch (the marching precompute kernel with k_cost's terms riding one row
+ * behind); returns the number of cost partials, or -hipErrorNotSupported where the marching kernel does not run (the caller then launches the two separately) */
+int thallo_hip_sfs_precompute_cost(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
+                                   const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
+                                   int c0, int c1, float* cost_out, thallo_stream_t stream);
 int thallo_hip_sfs_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                         const unsigned char* fl, float* cost_out, thallo_stream_t stream);
 int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,

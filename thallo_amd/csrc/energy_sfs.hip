@@ -610,10 +610,15 @@ constexpr int MP_USE = 62;
 struct MpRaw { float x, d, im; unsigned mr, mc; };
 __device__ __forceinline__ void mp_take(MpRaw& d, const MpRaw& s) { ms_mv(d.x, s.x); ms_mv(d.d, s.d); ms_mv(d.im, s.im); ms_mv(d.mr, s.mr); ms_mv(d.mc, s.mc); }
 
+// COST: computeCost (k_cost's terms in k_cost's order) of the rows [c0, c1) rides along, one row behind the planes: the shading rows take BI of the pixel, of its
+// right neighbour (lane + 1) and of the row below straight from registers -- for that BI is also evaluated on lane 63 and on the row under the segment.
+template <bool COST>
 __global__ __launch_bounds__(MS_NT, 2) void k_precompute_march(MsGeo g, int Hg, Cam cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
                                                                const unsigned char* __restrict__ mR, const unsigned char* __restrict__ mC,
-                                                               float4* __restrict__ G, float2* __restrict__ Wt, unsigned char* __restrict__ fl)
+                                                               float4* __restrict__ G, float2* __restrict__ Wt, unsigned char* __restrict__ fl,
+                                                               float* __restrict__ cost_out, int c0, int c1)
 {
+    __shared__ float red[16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int W = g.W, H = g.H;
     int strip = 0, ya = 0, yb = 0;
@@ -630,12 +635,13 @@ __global__ __launch_bounds__(MS_NT, 2) void k_precompute_march(MsGeo g, int Hg, 
             if (ya > g.rb) ya = g.rb;
         }
     }
-    if (ya >= yb) return;
+    float acc = 0.0f;
+    if (ya < yb) {
     const int x = strip * MP_USE - 1 + lane;
     const bool xin = x >= 0 && x < W;
     const bool xout = xin && lane >= 1 && lane <= 62;
     const unsigned xc_ = x < 0 ? 0u : x > W - 1 ? (unsigned)(W - 1) : (unsigned)x;
-    const int t_first = ya - 1, t_last = yb;
+    const int t_first = ya - 1, t_last = COST ? yb + 1 : yb;
     const long Nb = (long)W * H - 4;
     auto issue = [&](MpRaw& s, int t) {
         const int tc = t < 0 ? 0 : t > H - 1 ? H - 1 : t;
@@ -648,6 +654,8 @@ __global__ __launch_bounds__(MS_NT, 2) void k_precompute_march(MsGeo g, int Hg, 
     };
     float Xr[3] = { 0.f, 0.f, 0.f }, Dr[3] = { 0.f, 0.f, 0.f }, Ir[3] = { 0.f, 0.f, 0.f };
     unsigned Mr[3] = { 0u, 0u, 0u }, Mc[3] = { 0u, 0u, 0u };
+    float Bv[3] = { 0.f, 0.f, 0.f }, Wxr[3] = { 0.f, 0.f, 0.f }, Wyr[3] = { 0.f, 0.f, 0.f };      // (COST) BI, the row weights and the flags of the rows
+    unsigned Fr[3] = { 0u, 0u, 0u };
     MpRaw slot[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) slot[j] = MpRaw{};
@@ -665,31 +673,65 @@ __global__ __launch_bounds__(MS_NT, 2) void k_precompute_march(MsGeo g, int Hg, 
                 const bool ok = xin && t >= 0 && t < H;
                 const long ipx = (long)t * W + x; long bpx = ipx & ~3L; if (bpx > Nb) bpx = Nb;
                 const int sh = ok ? 8 * (int)(ipx - bpx) : 0;
+                const float x3 = Xr[k0];                                   // (COST) row t-3, about to be overwritten
                 Xr[k0] = ok ? cur.x : 0.0f; Dr[k0] = ok ? cur.d : 0.0f; Ir[k0] = ok ? cur.im : 0.0f;
                 Mr[k0] = (cur.mr >> sh) & 0xffu; Mc[k0] = (cur.mc >> sh) & 0xffu;
                 // the row being written: y = t-1 (slot k1); its upper row t-2 (k2), its lower row t (k0)
                 const float xc = Xr[k1], dc = Dr[k1], ic = Ir[k1];
                 const float xl = ms_left(xc), dl = ms_left(dc), il = ms_left(ic), xr = ms_right(xc), dr = ms_right(dc);
                 const int y = t - 1;
-                if (y >= ya && y < yb && xout) {
-                    const long i = (long)y * W;
+                const bool own = y >= ya && y < yb && xout;
+                if (own || (COST && y >= ya && y <= yb && xin && lane >= 1)) {
                     const J3 b = eval_BI_vals(cm, dl, dc, Dr[k2], xc, xl, Xr[k2], ic, il, Ir[k2], x, y + g.yoff);
-                    (G + i)[(unsigned)x] = make_float4(b.d0, b.d1, b.d2, b.v);
-                    const int yg = y + g.yoff;
-                    const bool inner = x >= 1 && x + 1 < W && yg >= 1 && yg + 1 < Hg;
-                    (Wt + i)[(unsigned)x] = inner ? make_float2(cm.wg * (float)Mr[k1], cm.wg * (float)Mc[k1]) : make_float2(0.f, 0.f);
-                    unsigned char f = dc > 0.0f ? 1 : 0;
-                    bool valid = f;
-                    valid = valid && dl > 0.0f && fabsf(xc - xl) < 0.01f;               // (x-1, y), (x, y-1), (x+1, y), (x, y+1): k_precompute's order
-                    valid = valid && Dr[k2] > 0.0f && fabsf(xc - Xr[k2]) < 0.01f;
-                    valid = valid && dr > 0.0f && fabsf(xc - xr) < 0.01f;
-                    valid = valid && Dr[k0] > 0.0f && fabsf(xc - Xr[k0]) < 0.01f;
-                    if (valid) f |= 2;
-                    (fl + i)[(unsigned)x] = f;
+                    if (COST) Bv[k1] = b.v;
+                    if (own) {
+                        const long i = (long)y * W;
+                        (G + i)[(unsigned)x] = make_float4(b.d0, b.d1, b.d2, b.v);
+                        const int yg = y + g.yoff;
+                        const bool inner = x >= 1 && x + 1 < W && yg >= 1 && yg + 1 < Hg;
+                        const float2 wv = inner ? make_float2(cm.wg * (float)Mr[k1], cm.wg * (float)Mc[k1]) : make_float2(0.f, 0.f);
+                        (Wt + i)[(unsigned)x] = wv;
+                        unsigned char f = dc > 0.0f ? 1 : 0;
+                        bool valid = f;
+                        valid = valid && dl > 0.0f && fabsf(xc - xl) < 0.01f;               // (x-1, y), (x, y-1), (x+1, y), (x, y+1): k_precompute's order
+                        valid = valid && Dr[k2] > 0.0f && fabsf(xc - Xr[k2]) < 0.01f;
+                        valid = valid && dr > 0.0f && fabsf(xc - xr) < 0.01f;
+                        valid = valid && Dr[k0] > 0.0f && fabsf(xc - Xr[k0]) < 0.01f;
+                        if (valid) f |= 2;
+                        (fl + i)[(unsigned)x] = f;
+                        if (COST) { Wxr[k1] = wv.x; Wyr[k1] = wv.y; Fr[k1] = f; }
+                    }
+                }
+                if (COST) {
+                    // cost of row t-2 (slot k2): its planes were formed one step ago, BI of the row below just now
+                    const float x2 = Xr[k2];
+                    const float x2l = ms_left(x2), x2r = ms_right(x2), b2r = ms_right(Bv[k2]);
+                    const int yc = t - 2;
+                    if (yc >= ya && yc < yb && yc >= c0 && yc < c1 && xout) {
+                        float sacc = 0.0f;
+                        if (Fr[k2] & 1u) { const float e = cm.wp * (x2 - Dr[k2]); sacc += e * e; }
+                        if (Wxr[k2] != 0.0f || Wyr[k2] != 0.0f) {
+                            const float b0 = Bv[k2];
+                            const float eh = Wxr[k2] * (b0 - b2r), ev = Wyr[k2] * (b0 - Bv[k1]);
+                            sacc += eh * eh + ev * ev;
+                        }
+                        if (Fr[k2] & 2u) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                float a = 4.0f * (coef(cm, c, x, yc + g.yoff) * x2);
+                                a -= coef(cm, c, x - 1, yc + g.yoff) * x2l; a -= coef(cm, c, x, yc - 1 + g.yoff) * x3;
+                                a -= coef(cm, c, x + 1, yc + g.yoff) * x2r; a -= coef(cm, c, x, yc + 1 + g.yoff) * Xr[k1];
+                                a *= cm.ws; sacc += a * a;
+                            }
+                        }
+                        acc += 0.5f * sacc;
+                    }
                 }
             }
         }
     }
+    }
+    if (COST) block_store_partial(acc, cost_out, red);
 }
 
 // raw diag(J^T J) (LM only): enumerate the rows that contain X(i)
@@ -786,9 +828,25 @@ static Cam cam_of(const float* hp)
     return c;
 }
 
+static int sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
+                          const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl, float* cost_out, int c0, int c1, thallo_stream_t stream);
 int thallo_hip_sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
                               const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
                               thallo_stream_t stream)
+{ return sfs_precompute(W, H, ra, rb, yoff, Hg, host_params, X, D, Im, edgeMaskR, edgeMaskC, G, Wt, fl, nullptr, 0, 0, stream); }
+
+/* precompute over the rows [ra, rb) AND computeCost over the rows [c0, c1) of them in one launch (marching kernel only: -hipErrorNotSupported otherwise -- the caller
+ * then runs thallo_hip_sfs_precompute + thallo_hip_sfs_cost); returns the number of cost partials */
+int thallo_hip_sfs_precompute_cost(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
+                                   const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl,
+                                   int c0, int c1, float* cost_out, thallo_stream_t stream)
+{
+    if (!cost_out || c0 < ra || c1 > rb || c0 >= c1) return -(int)hipErrorInvalidValue;
+    return sfs_precompute(W, H, ra, rb, yoff, Hg, host_params, X, D, Im, edgeMaskR, edgeMaskC, G, Wt, fl, cost_out, c0, c1, stream);
+}
+
+static int sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
+                          const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl, float* cost_out, int c0, int c1, thallo_stream_t stream)
 {
     if (ra < 0 || rb > H || ra >= rb) return -(int)hipErrorInvalidValue;
     if (sfs_fused() && sfs_march() && g_ms_precompute == 1 && (long)W * H >= 4 && (((uintptr_t)edgeMaskR | (uintptr_t)edgeMaskC) & 3) == 0) {
@@ -799,10 +857,18 @@ int thallo_hip_sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, co
             mg.total = mg.nstrips * (((rb - ra + R - 1) / R + MS_NT / 64 - 1) / (MS_NT / 64));
             if ((mg.total + 7) / 8 * 8 <= cap) break;
         }
-        hipLaunchKernelGGL(k_precompute_march, dim3((mg.total + 7) / 8 * 8), dim3(MS_NT), 0, (hipStream_t)stream, mg, Hg, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
-                           (float4*)G, (float2*)Wt, fl);
+        const int gridp = (mg.total + 7) / 8 * 8;
+        if (cost_out) {
+            if (gridp > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+            hipLaunchKernelGGL(k_precompute_march<true>, dim3(gridp), dim3(MS_NT), 0, (hipStream_t)stream, mg, Hg, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
+                               (float4*)G, (float2*)Wt, fl, cost_out, c0, c1);
+            int e = check_launch(); return e ? e : gridp;
+        }
+        hipLaunchKernelGGL(k_precompute_march<false>, dim3(gridp), dim3(MS_NT), 0, (hipStream_t)stream, mg, Hg, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
+                           (float4*)G, (float2*)Wt, fl, (float*)nullptr, 0, 0);
         return check_launch();
     }
+    if (cost_out) return -(int)hipErrorNotSupported;
     const Geo g = make_geo(W, H, ra, rb, yoff, Hg); const int grid = grid_for(g);
     hipLaunchKernelGGL(k_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), X, D, Im, edgeMaskR, edgeMaskC,
                        (float4*)G, (float2*)Wt, fl);

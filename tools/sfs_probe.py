@@ -30,7 +30,18 @@ class Inst:
         # the marching precompute against k_precompute: flags and row weights bitwise, G to rounding (same expression tree, separate instantiations)
         gs = float(self.G.abs().max())
         self.pre_ok = bool(torch.equal(self.fl[:N], fl1[:N]) and torch.equal(self.Wt, Wt1) and float((self.G - G1).abs().max()) <= 1e-5 * gs)
-        self.pre_msg = f"precompute marching vs k_precompute: flags equal {torch.equal(self.fl[:N], fl1[:N])}, Wt equal {torch.equal(self.Wt, Wt1)}, G max diff / max {float((self.G - G1).abs().max()) / gs:.2e}"
+        # planes + computeCost in one launch against k_precompute + k_cost
+        cp = torch.zeros(1024, device="cuda"); cq = torch.zeros(1024, device="cuda")
+        L.thallo_hip_sfs_march_debug_set(4, 1)
+        G2 = torch.empty_like(self.G); Wt2 = torch.empty_like(self.Wt); fl2 = torch.full((N + 4,), 9, dtype=torch.uint8, device="cuda")
+        nb1 = L.thallo_hip_sfs_precompute_cost(W, H, 0, H, self.yoff, self.Hg, self.hp, vp(X), vp(D), vp(Im), vp(mR), vp(mC), vp(G2), vp(Wt2), vp(fl2), self.ra, self.rb, vp(cp), None)
+        nb0 = L.thallo_hip_sfs_cost(W, H, self.ra, self.rb, self.yoff, self.Hg, self.hp, vp(X), vp(D), vp(self.G), vp(self.Wt), vp(self.fl), vp(cq), None)
+        torch.cuda.synchronize()
+        assert nb1 > 0 and nb0 > 0, (nb1, nb0)
+        ca, cb = float(cp[:nb1].double().sum()), float(cq[:nb0].double().sum())
+        same_planes = bool(torch.equal(G2, G1) and torch.equal(Wt2, Wt1) and torch.equal(fl2[:N], fl1[:N]))
+        self.pre_ok = self.pre_ok and same_planes and abs(ca - cb) <= 2e-6 * abs(cb)
+        self.pre_msg = f"cost in the precompute launch {ca:.8g} vs k_cost {cb:.8g} (rel {abs(ca - cb) / abs(cb):.1e}), its planes bitwise the plain launch's {same_planes}; precompute marching vs k_precompute: flags equal {torch.equal(self.fl[:N], fl1[:N])}, Wt equal {torch.equal(self.Wt, Wt1)}, G max diff / max {float((self.G - G1).abs().max()) / gs:.2e}"
         g = torch.Generator(device="cuda"); g.manual_seed(seed)
         self.p = torch.randn(N, device="cuda", generator=g) * 1e-3
         self.r = torch.randn(N, device="cuda", generator=g) * 1e-3
@@ -142,6 +153,22 @@ def timing(W, H):
         L.thallo_hip_sfs_march_debug_set(0, 0); L.thallo_hip_sfs_march_debug_set(1, 0)
         t, nb = time_one(inst, variant, True)
         print(f"{W}x{H} {variant}: marching kernel (default grid) {t:.1f} us ({nb} workgroups) = {33 * W * H / t / 1e6:.2f} TB/s of the 33 B/pixel", flush=True)
+    cp = torch.zeros(1024, device="cuda")
+    for fused in (0, 1):
+        G = torch.empty(4 * W * H, device="cuda"); Wt = torch.empty(2 * W * H, device="cuda"); fl = torch.empty(W * H + 4, dtype=torch.uint8, device="cuda")
+        def call():
+            if fused:
+                return L.thallo_hip_sfs_precompute_cost(W, H, 0, H, 0, H, inst.hp, vp(inst.X), vp(inst.D), vp(inst.Im), vp(inst.mR), vp(inst.mC), vp(G), vp(Wt), vp(fl), 0, H, vp(cp), None)
+            L.thallo_hip_sfs_precompute(W, H, 0, H, 0, H, inst.hp, vp(inst.X), vp(inst.D), vp(inst.Im), vp(inst.mR), vp(inst.mC), vp(G), vp(Wt), vp(fl), None)
+            return L.thallo_hip_sfs_cost(W, H, 0, H, 0, H, inst.hp, vp(inst.X), vp(inst.D), vp(G), vp(Wt), vp(fl), vp(cp), None)
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20):
+            call()
+        e1.record(); torch.cuda.synchronize()
+        print(f"{W}x{H} precompute + computeCost: {'one launch' if fused else 'two launches'} {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
     for march in (0, 1):
         for _ in range(3):
             inst.precompute(march)

@@ -193,6 +193,7 @@ void Plan::read_ab_switches()
     fin_in_kernel_ = !off("THALLO_FIN_IN_KERNEL");    // 0: the iteration's scalars by a separate one-wave launch
     batch_delta_   = !off("THALLO_BATCH_DELTA");      // 0: delta += alpha p every iteration instead of every other one
     defer_finish_  = !off("THALLO_DEFER_FINISH");     // 0: the one-kernel iteration's scalars by its own last workgroup instead of by the next launch
+    lm_fold_p_     = !off("THALLO_LM_FOLD_P");        // 0: LM's PCGStep3 as a launch of its own even where the plugin's apply can carry it
 }
 
 void Plan::set_param(const char* name, const void* value)
@@ -531,8 +532,8 @@ int Plan::step_lm(int ev_iter)
     const bool pc = plugin->use_preconditioner();
     const bool fold_ctc = plugin->apply_adds_ctc() && ![] { const char* e = getenv("THALLO_LM_FOLD_CTC"); return e && e[0] == '0'; }();      // (=0: A/B)
     const bool host_zeta = [] { const char* e = getenv("THALLO_LM_HOST_ZETA"); return e && e[0] == '1'; }();
-    // PCGStep3 folded into the apply too (one GPU; plugins that offer it; THALLO_LM_FOLD_P=0: A/B)
-    const bool fold_p = fold_ctc && !slab && plugin->apply_folds_pupdate() && v_.p[1] != nullptr && ![] { const char* e = getenv("THALLO_LM_FOLD_P"); return e && e[0] == '0'; }();
+    // PCGStep3 folded into the apply too (one GPU; plugins that offer it; THALLO_LM_FOLD_P=0: A/B, read_ab_switches)
+    const bool fold_p = lm_fold_p_ && fold_ctc && !slab && plugin->apply_folds_pupdate() && v_.p[1] != nullptr;
     // the zeta test by PCGStep2's last workgroup (one GPU, device-side test): one launch less per iteration.  A slab needs the GLOBAL q first.
     if (!host_zeta && !slab && ensure_sums_buffer()) return 0;
     const bool zeta_in_step2 = !host_zeta && !slab && ![] { const char* e = getenv("THALLO_LM_ZETA_IN_STEP2"); return e && e[0] == '0'; }();

@@ -124,7 +124,7 @@ private:
 
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
-    bool fin_in_kernel_ = true, expanded_ = true, one_kernel_ = true, finish_sums_ = true, batch_delta_ = true, defer_finish_ = true;   // A/B switches: read_ab_switches()
+    bool fin_in_kernel_ = true, expanded_ = true, one_kernel_ = true, finish_sums_ = true, batch_delta_ = true, defer_finish_ = true, lm_fold_p_ = true;   // A/B switches: read_ab_switches()
     void read_ab_switches();
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }
     thallo_sum_t partial_sum(int j) { thallo_sum_t s; s.partials = slot(j); s.count = nb_[j]; return s; }

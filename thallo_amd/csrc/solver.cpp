@@ -278,6 +278,10 @@ int Plan::step(void** params)
 {   // gauss_newton.t:1545-1785
     if (!ok_ || !ready_) return 0;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return 0; }
+    // Gauss-Newton steps derive everything from the unknowns as they are NOW, like the reference (a caller may have rewritten them since the last call).  The LM
+    // branch already lives on state carried from the previous step's end -- prev_cost_, as the reference's pd.hd.prevCost (gauss_newton.t:1732,1710) -- so there a
+    // plugin may also keep what it derived from the unknowns at that point (shape_from_shading's precomputed planes).
+    if (!lm_) plugin->unknowns_changed();
     if (sp.nIter >= sp.nIterations) { if (!finalized_) finalize(); return 0; }
     if (sp.lIterations < 0) { set_error("lIterations = %d is negative", sp.lIterations); if (!finalized_) finalize(); return 0; }
     if (ensure_slots(sp.lIterations)) { if (!finalized_) finalize(); return 0; }

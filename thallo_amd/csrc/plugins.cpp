@@ -598,9 +598,10 @@ class ShapeFromShadingPlugin : public EnergyPlugin {
     int precompute(LaunchCtx& c)
     {
         if (planes_valid_) return 0;
-        planes_valid_ = true;
         TimedLaunch t(c, "precompute");
-        return thallo_hip_sfs_precompute(W, H, 0, H, yoff_, Hg_, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
+        const int rc = thallo_hip_sfs_precompute(W, H, 0, H, yoff_, Hg_, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, (unsigned char*)fl.ptr, c.stream);
+        planes_valid_ = rc >= 0;
+        return rc;
     }
 public:
     ShapeFromShadingPlugin(const unsigned* dims) : W((int)dims[0]), H((int)dims[1]), row1_((int)dims[1]), Hg_((int)dims[1]) { imgs.push_back({ 16, (long)W * H }); }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 counter passes over the shape_from_shading 2048^2 GN configuration (tools/sfs_pmc.py) -- what bounds the fused applyJTJ kernel.
+# rocprofv3 counter passes over the shape_from_shading 2048^2 GN configuration (tools/sfs_pmc.py) -- what bounds the applyJTJ kernels (the LDS-tiled k_fused of
+# THALLO_SFS_MARCH=0, the marching k_march variants by default).
 # Run on the GPU box through gpurun; summary in gpurun_out/sfs_pmc_summary.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
@@ -19,9 +20,9 @@ for d in sorted(glob.glob("gpurun_out/sfspmc_[0-9]")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
-            acc[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            acc[row["Kernel_Name"][:110]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, c in acc.items():
-            if "k_fused" in k or "k_pcg_update" in k:
+            if "k_fused" in k or "k_pcg_update" in k or "k_march" in k or "k_precompute_march" in k:
                 out.write(k + "\n   " + "  ".join(f"{n}={sum(v)/len(v):.4g}" for n, v in sorted(c.items())) + f"  (n={len(next(iter(c.values())))})\n")
 out.close()
 print(open("gpurun_out/sfs_pmc_summary.txt").read())

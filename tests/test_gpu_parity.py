@@ -492,6 +492,24 @@ def test_shape_from_shading_2048_lm_vs_oracle(torch, orc):
     assert costs[m - 1] < costs[0]
 
 
+def test_shape_from_shading_2048_gn_one_kernel_vs_oracle(torch, orc):
+    """shape_from_shading 2048^2, Gauss-Newton on the default schedule (ONE marching launch per PCG iteration: thallo_hip_sfs_pcg_iter; precompute + cost in
+    one launch), 2 GN x 10 PCG against the row oracle on the host cores: the bar of test_shape_from_shading_cost_trajectory."""
+    W = H = 2048
+    p = syn.shape_from_shading(W, H)
+    prev = orc.set_threads(_host_threads())
+    try:
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=2, lIterations=10)
+    finally:
+        orc.set_threads(prev)
+    s, dev, costs, final = _solve_gpu("shape_from_shading", (W, H), p, nIterations=2, lIterations=10)
+    ks = s.kernel_stats()
+    assert ks["PCGIteration"]["launches"] == 20 and "PCGUpdate" not in ks and "precompute+computeCost" in ks, ks
+    print("SFS 2048 GN 2x10: rel. cost error per step", np.abs(costs - co) / np.abs(co), costs)
+    assert (np.abs(costs - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (costs, co)
+    assert costs[-1] < costs[0]
+
+
 def test_bundle_adjustment_ladybug_lm_vs_oracle(torch, orc):
     """BASELINE.json configs[4]: the ladybug-1723-shaped instance with the reference's LM budget 5 x 150
     (bundle_adjustment/src/main.cpp:9-14) against the row oracle on the host cores.  Bars as in test_bundle_adjustment_cost_trajectory:

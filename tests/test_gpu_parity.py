@@ -492,6 +492,32 @@ def test_shape_from_shading_2048_lm_vs_oracle(torch, orc):
     assert costs[m - 1] < costs[0]
 
 
+def test_shape_from_shading_precompute_with_unaligned_mask_planes(torch):
+    """The marching precompute reads the two mask planes as aligned dwords; a caller's byte planes need not be 4-byte aligned -- then the shim runs k_precompute
+    (byte loads).  Same flags and row weights bit for bit, G to rounding; a plane whose size is not a multiple of 4 (61 x 5) stays on the marching kernel."""
+    import ctypes as C
+    L = api.lib()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    for W, H in ((64, 48), (61, 5)):
+        p = syn.shape_from_shading(W, H)
+        hp = (C.c_float * 16)(*[float(x) for x in p[:16]])
+        X, D, Im = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in p[16:19]]
+        N = W * H
+        outs = []
+        for shift in (0, 1):
+            bufs = [torch.zeros(N + 8, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            mR, mC = bufs[0][shift:shift + N], bufs[1][shift:shift + N]
+            mR.copy_(torch.from_numpy(p[19].ravel()).cuda()); mC.copy_(torch.from_numpy(p[20].ravel()).cuda())
+            assert mR.data_ptr() % 4 == shift
+            G = torch.full((4 * N,), 3.0, device="cuda"); Wt = torch.full((2 * N,), 3.0, device="cuda"); fl = torch.full((N + 4,), 9, dtype=torch.uint8, device="cuda")
+            assert L.thallo_hip_sfs_precompute(W, H, 0, H, 0, H, hp, vp(X), vp(D), vp(Im), vp(mR), vp(mC), vp(G), vp(Wt), vp(fl), None) == 0
+            torch.cuda.synchronize()
+            outs.append((G, Wt, fl))
+        (G0, W0, f0), (G1, W1, f1) = outs
+        assert torch.equal(f0[:N], f1[:N]) and torch.equal(W0, W1)
+        assert float((G0 - G1).abs().max()) <= 1e-5 * float(G0.abs().max())
+
+
 def test_shape_from_shading_2048_gn_one_kernel_vs_oracle(torch, orc):
     """shape_from_shading 2048^2, Gauss-Newton on the default schedule (ONE marching launch per PCG iteration: thallo_hip_sfs_pcg_iter; precompute + cost in
     one launch), 2 GN x 10 PCG against the row oracle on the host cores: the bar of test_shape_from_shading_cost_trajectory."""

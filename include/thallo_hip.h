@@ -336,7 +336,10 @@ int thallo_hip_iw_pcg_iter_march_deferred(int W, int H, int row0, int row1, cons
                                           const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
 /* *count_out (device int) = number of pixels whose right / down UrShape neighbour is not at the exact unit offset (0 = pixel grid) */
 int thallo_hip_iw_urshape_irregular(int W, int H, const float* urshape, int* count_out, thallo_stream_t stream);
-void thallo_hip_march_debug_set(int what, int value);     /* tools/ only: 0 rows per wave segment, 1 prefetch depth, 2 non-temporal mask */
+void thallo_hip_march_debug_set(int what, int value);     /* tools / tests only: 0 rows per wave segment, 1 prefetch depth, 2 non-temporal mask, 6 workgroup budget */
+/* rows per wave segment the marching kernels use on `rows` owned rows of a W-wide image; 0 = more column strips than the device has workgroup
+ * slots: the marching entry points return -hipErrorNotSupported, the caller stays on thallo_hip_iw_pcg_iter (host logic, no launch) */
+int thallo_hip_iw_march_rows(int W, int rows);
 int thallo_hip_iw_pcg_iter_finish(const float* alphaD_partials, const double* s12_partials, int count, thallo_sum_t alphaN,
                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 
@@ -446,6 +449,8 @@ int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, 
                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
                             thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* alphaD_out, double* s3_out, thallo_fin_t fin, thallo_stream_t stream);
 int thallo_hip_sfs_lm_pupdate_supported(void);
+/* ... and for a W-wide image: no more 60-pixel column strips than the device has workgroup slots (otherwise the LDS-tiled kernels run) */
+int thallo_hip_sfs_march_fits(int W);
 int thallo_hip_sfs_apply_jtj_lm_pupdate(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                         const float* z, const float* p_in, float* p_out, const float* CtC, float* Ap, float* alphaD_out, int first,
                                         thallo_sum_t alphaN_prev, thallo_sum_t betaN_prev, const unsigned* gate, thallo_stream_t stream);

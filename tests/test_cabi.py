@@ -91,3 +91,25 @@ def test_vector_padding_rule(L):
     L.thallo_hip_vector_elems.restype = C.c_long
     L.thallo_hip_vector_elems.argtypes = [C.c_long]
     assert L.thallo_hip_vector_elems(1) == 256 and L.thallo_hip_vector_elems(256) == 256 and L.thallo_hip_vector_elems(257) == 512
+
+
+def test_marching_geometry_search_is_bounded(L):
+    """rows-per-segment search of the marching kernels must terminate for every shape: with more column strips than workgroup slots
+    (W > ~31.7k on 256 CUs, ~3.9k on a 32-CU partition) it answers 0 = 'stay on the tile kernel' instead of spinning.  Host logic only: the
+    forced workgroup budget (debug knob 6) stands in for the device's CU count, so nothing here touches a GPU."""
+    L.thallo_hip_iw_march_rows.restype = C.c_int
+    L.thallo_hip_iw_march_rows.argtypes = [C.c_int, C.c_int]
+    try:
+        L.thallo_hip_march_debug_set(6, 256)
+        assert L.thallo_hip_iw_march_rows(2048, 2048) == 35          # 17 strips x ceil(59 segments / 4 waves) = 255 workgroups <= 256
+        assert L.thallo_hip_iw_march_rows(2048, 256) == 5            # 17 x ceil(52 / 4) = 221
+        assert L.thallo_hip_iw_march_rows(124 * 256, 64) > 0         # exactly 256 strips: one segment row
+        assert L.thallo_hip_iw_march_rows(124 * 256 + 2, 64) == 0    # 257 strips: no R fits -> 0, not an endless loop
+        assert L.thallo_hip_iw_march_rows(65536, 4096) == 0
+        L.thallo_hip_march_debug_set(6, 32)                           # a 32-CU partition
+        assert L.thallo_hip_iw_march_rows(3968, 512) > 0 and L.thallo_hip_iw_march_rows(4096, 512) == 0
+        L.thallo_hip_march_debug_set(6, 3)                            # fewer than 8 workgroup slots: the budget is clamped to 8, not rounded down to 0
+        assert L.thallo_hip_iw_march_rows(512, 512) > 0 and L.thallo_hip_iw_march_rows(2048, 512) == 0
+        assert L.thallo_hip_iw_march_rows(511, 512) == 0 and L.thallo_hip_iw_march_rows(512, 0) == 0      # odd width / no rows: not a marching shape
+    finally:
+        L.thallo_hip_march_debug_set(6, 0)

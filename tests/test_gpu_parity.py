@@ -169,6 +169,29 @@ def test_image_warping_cost_trajectory(torch, orc, monkeypatch, W, H, nit, lit, 
     assert (to_host(dev[0])[m] == p[0][m]).all() and (to_host(dev[1])[m] == p[1][m]).all()
 
 
+def test_image_warping_wider_than_the_workgroup_budget_runs_the_tile_kernel(torch, orc):
+    """an image with more 124-pixel column strips than the device has workgroup slots (W > ~31.7k on 256 CUs, ~3.9k on a 32-CU
+    partition) used to spin forever in the host's rows-per-segment search at the first Thallo_ProblemStep.  With the budget forced down to 8
+    workgroups a 1240-wide image (10 strips, 0.42 Mpixel: marching territory) must say 'does not fit', refuse the marching entry point, and
+    solve on the tile kernel with the oracle's trajectory."""
+    L = thallo_amd.lib()
+    L.thallo_hip_iw_march_rows.restype = C.c_int
+    L.thallo_hip_iw_march_rows.argtypes = [C.c_int, C.c_int]
+    W, H = 1240, 340
+    p = syn.image_warping(W, H, n_markers=8)
+    po = copy_params(p)
+    co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=2, lIterations=12)
+    try:
+        assert L.thallo_hip_iw_march_rows(W, H) > 0
+        L.thallo_hip_march_debug_set(6, 8)
+        assert L.thallo_hip_iw_march_rows(W, H) == 0
+        s, dev, costs, final = _solve_gpu("image_warping", (W, H), p, nIterations=2, lIterations=12)
+    finally:
+        L.thallo_hip_march_debug_set(6, 0)
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)
+    assert rel_err(to_host(dev[0]), po[0]) < VEC_RTOL
+
+
 def test_image_warping_alpha_beta_trace(torch, orc):
     """alpha_k, beta_k of the first GN step follow the oracle's (early iterations tightly)."""
     W, H = 96, 64

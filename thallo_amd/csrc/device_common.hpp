@@ -292,6 +292,31 @@ struct TileSweep {
 };
 
 
+// Host: rows per wave segment of a marching kernel -- the smallest R >= rmin such that nstrips * ceil(ceil(rows / R) / waves_per_wg) workgroups
+// (rounded up to a multiple of 8) fit under `cap` (clamped to [8, THALLO_MAX_PARTIALS]); 0 when not even ONE segment per strip fits (the image is
+// wider than `cap` strips): the caller then falls back to its tile kernel or reports "unsupported".  Bounded: R never passes `rows`.
+inline int march_rows_per_segment(int rows, int nstrips, int waves_per_wg, long cap, int rmin = 4)
+{
+    if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
+    cap -= cap % 8;
+    if (cap < 8) cap = 8;
+    const int rmax = rows > rmin ? rows : rmin;
+    for (int R = rmin; R <= rmax; ++R) {
+        const long nseg = (rows + R - 1) / R, total = (long)nstrips * ((nseg + waves_per_wg - 1) / waves_per_wg);
+        if ((total + 7) / 8 * 8 <= cap) return R;
+    }
+    return 0;
+}
+
+// ... and whether any R can: one segment per strip (R = rows) is the smallest grid
+inline bool march_strips_fit(int nstrips, long cap)
+{
+    if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
+    cap -= cap % 8;
+    if (cap < 8) cap = 8;
+    return ((long)nstrips + 7) / 8 * 8 <= cap;
+}
+
 // Cache-policy helpers.  `nt` selects the non-temporal (streaming) form: data that is touched once per
 // sweep and not again before ~600 MB of other traffic (delta, r, pre, the per-GN constant planes)
 // should not displace the vectors that ARE re-read by the next kernel (Ap, z, p) from the 256 MiB

@@ -26,6 +26,7 @@ int g_march_nt = 5;       // non-temporal bits as for k_iter: 1 delta, 2 r/Ap lo
 int g_march_occ = 2;       // microbench: workgroups per CU the kernel is compiled for (register budget) and sized for (rows per segment)
 int g_march_dbg = 0;       // microbench: 1 = no stencil arithmetic (Ap := p), 2 = no double sums, 3 = 1 + no halo rows / lanes
 int g_march_map = 0;       // microbench: 1 = the 4 waves of a workgroup side by side (x-adjacent strips) instead of stacked segments
+int g_march_cap = 0;       // tests: workgroup budget the grid is sized for (0 = CUs x workgroups per CU of the device)
 }
 
 using namespace thallo;
@@ -446,19 +447,14 @@ inline MarchGeo make_march_geo(int W, int H, int row0, int row1, int R)
 }
 
 // rows per wave segment: every workgroup resident at once (the 190-VGPR variant fits 2 workgroups of 4 waves per CU), i.e. about
-// 2 waves per SIMD, and at most 1024 workgroups (partial slots)
+// 2 waves per SIMD, and at most 1024 workgroups (partial slots).  0: the image is wider than that many strips (W > ~31.7k pixels on a 256-CU
+// device, ~3.9k on a 32-CU partition) -- the caller runs the tile kernel instead (thallo_hip_iw_march_fits).
+inline long march_cap(int occ) { return g_march_cap > 0 ? g_march_cap : (long)thallo_hip_device_cu_count() * occ; }
 inline int pick_rows(int W, int rows, int occ)
 {
     if (g_march_rows > 0) return g_march_rows;
-    long cap = (long)thallo_hip_device_cu_count() * occ;
-    if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
-    cap -= cap % 8;
-    int R = 4;
-    for (;; ++R) {
-        const MarchGeo g = make_march_geo(W, rows, 0, rows, R);
-        if ((g.total + 7) / 8 * 8 <= cap) break;
-    }
-    return R;
+    const int use = g_march_dbg == 3 ? 128 : MARCH_USE;
+    return march_rows_per_segment(rows, (W + use - 1) / use, MARCH_NT / 64, march_cap(occ));
 }
 
 constexpr int MARCH_DEPTH = 2, MARCH_NTM = 5, MARCH_OCC = 2;     // product configuration (tools/march_probe.py sweeps, profiles/r02): delta and the r / Ap stores non-temporal
@@ -477,7 +473,9 @@ int launch_march(int W, int H, int row0, int row1, const float* cs, const unsign
                  thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp, const int* irregular, thallo_dist_t d,
                  float* aD_out, double* s12_out, unsigned* fin_tickets, float* aD_word, float* bN_word, int xslot, hipStream_t stream, PrevSums prev = PrevSums{ nullptr, nullptr, 0, nullptr, nullptr })
 {
-    const MarchGeo g = make_march_geo(W, H, row0, row1, pick_rows(W, row1 - row0, MARCH_WG_PER_CU));
+    const int R = pick_rows(W, row1 - row0, MARCH_WG_PER_CU);
+    if (R <= 0) return -(int)hipErrorNotSupported;                          // wider than the workgroup budget: thallo_hip_iw_march_fits() said so
+    const MarchGeo g = make_march_geo(W, H, row0, row1, R);
     const int grid = (g.total + 7) / 8 * 8;
     if (grid > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;      // (only reachable through the tools' forced rows-per-segment)
     const bool first = mode & 1;
@@ -594,6 +592,15 @@ void thallo_hip_march_debug_set(int what, int value)
     if (what == 3) g_march_occ = value;
     if (what == 4) g_march_dbg = value;
     if (what == 5) g_march_map = value;
+    if (what == 6) g_march_cap = value;
+}
+
+/* rows per wave segment the marching kernels would use on `rows` owned rows of a W-wide image; 0 = the image has more column strips than the device
+ * has workgroup slots, the marching kernels return -hipErrorNotSupported and the caller stays on the tile kernel */
+int thallo_hip_iw_march_rows(int W, int rows)
+{
+    if (W < 2 || (W & 1) || rows < 1) return 0;
+    return pick_rows(W, rows, MARCH_WG_PER_CU);
 }
 
 }  // extern "C"

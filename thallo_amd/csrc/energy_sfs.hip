@@ -796,10 +796,11 @@ static bool sfs_march()
     static int v = -1; if (v < 0) { const char* e = getenv("THALLO_SFS_MARCH"); v = (e && e[0] == '0') ? 0 : 1; }
     return g_ms_force >= 0 ? g_ms_force == 1 : v == 1;
 }
+static int g_ms_cap = 0;        // tests: workgroup budget the grids are sized for (0 = CUs x workgroups per CU of the device)
 static int g_ms_precompute = 1;      // 1: precompute by the marching kernel, 0: k_precompute (tools / tests)
 static int g_ms_diag = 1;      // 1: the LM diagonal by the marching J^T F kernel, 0: k_diag (tools / tests)
 static bool sfs_march_diag() { return g_ms_diag == 1; }
-void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; if (what == 3) g_ms_diag = value; if (what == 4) g_ms_precompute = value; }
+void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; if (what == 3) g_ms_diag = value; if (what == 4) g_ms_precompute = value; if (what == 5) g_ms_cap = value; }
 static MsGeo make_ms_geo(int W, int H, int ra, int rb, int yoff, int R)
 {
     MsGeo g; g.W = W; g.H = H; g.ra = ra; g.rb = rb; g.yoff = yoff; g.R = R;
@@ -808,16 +809,14 @@ static MsGeo make_ms_geo(int W, int H, int ra, int rb, int yoff, int R)
     g.total = g.nstrips * ((nseg + MS_NT / 64 - 1) / (MS_NT / 64));
     return g;
 }
+static long ms_cap(int per_cu) { return g_ms_cap > 0 ? g_ms_cap : (long)thallo_hip_device_cu_count() * per_cu; }
+// the image has no more column strips than workgroup slots (otherwise the LDS-tiled kernels, which loop over their tiles, run)
+static bool sfs_march_fits(int W) { return march_strips_fit((W + MS_USE - 1) / MS_USE, ms_cap(g_ms_wgcu > 0 ? g_ms_wgcu : MS_WG_PER_CU)); }
 static MsGeo pick_ms_geo(int W, int H, int ra, int rb, int yoff)
 {
     if (g_ms_rows > 0) return make_ms_geo(W, H, ra, rb, yoff, g_ms_rows);
-    long cap = (long)thallo_hip_device_cu_count() * (g_ms_wgcu > 0 ? g_ms_wgcu : MS_WG_PER_CU);
-    if (cap > THALLO_MAX_PARTIALS) cap = THALLO_MAX_PARTIALS;
-    cap -= cap % 8;
-    for (int R = 4;; ++R) {
-        const MsGeo g = make_ms_geo(W, H, ra, rb, yoff, R);
-        if ((g.total + 7) / 8 * 8 <= cap) return g;
-    }
+    const int R = march_rows_per_segment(rb - ra, (W + MS_USE - 1) / MS_USE, MS_NT / 64, ms_cap(g_ms_wgcu > 0 ? g_ms_wgcu : MS_WG_PER_CU));
+    return make_ms_geo(W, H, ra, rb, yoff, R > 0 ? R : rb - ra);      // (R == 0 is excluded by sfs_march_fits() at every call site; one segment per strip otherwise)
 }
 
 /* host_params: the 16 scalar parameters of the .t in Inputs{} order: w_p, w_s, w_g (squared weights), f_x, f_y, u_x, u_y, L_1..L_9 */
@@ -849,14 +848,12 @@ static int sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const 
                           const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl, float* cost_out, int c0, int c1, thallo_stream_t stream)
 {
     if (ra < 0 || rb > H || ra >= rb) return -(int)hipErrorInvalidValue;
-    if (sfs_fused() && sfs_march() && g_ms_precompute == 1 && (long)W * H >= 4 && (((uintptr_t)edgeMaskR | (uintptr_t)edgeMaskC) & 3) == 0) {
-        long cap = (long)thallo_hip_device_cu_count() * 4; cap -= cap % 8;
-        MsGeo mg;
-        for (int R = 4;; ++R) {
-            mg = make_ms_geo(W, H, ra, rb, yoff, R); mg.nstrips = (W + MP_USE - 1) / MP_USE;
-            mg.total = mg.nstrips * (((rb - ra + R - 1) / R + MS_NT / 64 - 1) / (MS_NT / 64));
-            if ((mg.total + 7) / 8 * 8 <= cap) break;
-        }
+    if (sfs_fused() && sfs_march() && sfs_march_fits(W) && g_ms_precompute == 1 && (long)W * H >= 4 && (((uintptr_t)edgeMaskR | (uintptr_t)edgeMaskC) & 3) == 0) {
+        const int np = (W + MP_USE - 1) / MP_USE;
+        int R = march_rows_per_segment(rb - ra, np, MS_NT / 64, ms_cap(4));
+        if (R <= 0) R = rb - ra;                                           // (np <= the k_march strip count, which sfs_march_fits() bounded)
+        MsGeo mg = make_ms_geo(W, H, ra, rb, yoff, R); mg.nstrips = np;
+        mg.total = mg.nstrips * (((rb - ra + R - 1) / R + MS_NT / 64 - 1) / (MS_NT / 64));
         const int gridp = (mg.total + 7) / 8 * 8;
         if (cost_out) {
             if (gridp > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -894,7 +891,7 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
     const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
     const Cam cm = cam_of(host_params);
     hipStream_t s = (hipStream_t)stream;
-    if (sfs_fused() && sfs_march()) {
+    if (sfs_fused() && sfs_march() && sfs_march_fits(W)) {
         const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
         const int gridm = (mg.total + 7) / 8 * 8;
         if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -946,6 +943,7 @@ int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int 
 { return sfs_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, fl, U, R, p, Ap, aD_out, nullptr, nullptr, stream, gate, thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr }, CtC); }
 
 int thallo_hip_sfs_lm_pupdate_supported(void) { return sfs_fused() && sfs_march() ? 1 : 0; }
+int thallo_hip_sfs_march_fits(int W) { return sfs_fused() && sfs_march() && sfs_march_fits(W) ? 1 : 0; }
 
 int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
@@ -954,7 +952,7 @@ int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, 
     if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !delta || !aD_out || !s3_out) return -(int)hipErrorInvalidValue;
     if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !alphaD_prev.partials || !betaN_prev.partials)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
-    if (!thallo_hip_sfs_lm_pupdate_supported()) return -(int)hipErrorNotSupported;
+    if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -972,7 +970,7 @@ int thallo_hip_sfs_apply_jtj_lm_pupdate(int W, int H, int row0, int row1, int yo
 {
     if (row0 < 0 || row1 > H || row0 >= row1 || !z || !p_in || !p_out || p_in == p_out || !CtC || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
     if (!first && (!alphaN_prev.partials || !betaN_prev.partials || alphaN_prev.count < 1 || betaN_prev.count < 1)) return -(int)hipErrorInvalidValue;
-    if (!thallo_hip_sfs_lm_pupdate_supported()) return -(int)hipErrorNotSupported;
+    if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -988,7 +986,7 @@ static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const f
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
-    if (sfs_fused() && sfs_march()) {
+    if (sfs_fused() && sfs_march() && sfs_march_fits(W)) {
         const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
         const int gridm = (mg.total + 7) / 8 * 8;
         if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;      // (only through the tools' forced rows per segment)

@@ -195,6 +195,8 @@ public:
         grid_ = bad == 0;
         if ((e && e[0] == '0') || (W & 1)) return 0;
         march_ = grid_ && ((long)W * H >= 400000 || (e && e[0] == '2'));              // THALLO_MARCH=2: the marching kernel at every size (tests)
+        // an image with more 124-pixel column strips than the device has workgroup slots stays on the tile kernel (which loops over its tiles)
+        if (march_ && thallo_hip_iw_march_rows(W, H) <= 0) march_ = false;
         return 0;
     }
     // ---- one row slab of a multi-GPU run (solver_dist.cpp)
@@ -672,7 +674,7 @@ public:
                                               c.gate, c.stream);
     }
     bool apply_adds_ctc() const override { return true; }
-    bool apply_folds_pupdate() const override { return thallo_hip_sfs_lm_pupdate_supported() != 0; }
+    bool apply_folds_pupdate() const override { return thallo_hip_sfs_march_fits(W) != 0; }
     int apply_jtj_pupdate(LaunchCtx& c, const float* z, const float* p_in, float* p_out, float* Ap, float* out, bool first, thallo_sum_t aN, thallo_sum_t bN) override
     {
         TimedLaunch t(c, "PCGStep1");
@@ -680,7 +682,7 @@ public:
                                                    first ? 1 : 0, aN, bN, c.gate, c.stream);
     }
     // GN on one GPU: one launch per PCG iteration (the marching kernel with PCGUpdate riding along; r, Ap, p ping-pong).  Across ranks: the flat form.
-    bool one_kernel_iteration() const override { return thallo_hip_sfs_lm_pupdate_supported() != 0 && row0_ == 0 && row1_ == H; }
+    bool one_kernel_iteration() const override { return thallo_hip_sfs_march_fits(W) != 0 && row0_ == 0 && row1_ == H; }
     bool dist_flat_form() const override { return true; }
     int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t, thallo_sum_t, float* out,
                  float* aD_word, float* bN_word) override

@@ -180,8 +180,17 @@ int ThalloX_PlanSetDistributed(Thallo_Plan* plan, const ThalloX_Distributed* cfg
 /* JSON text: transport in use ("exchange": "p2p-mailbox" | "allgather"), memory kind of the mapped blocks, self-check outcome. */
 const char* ThalloX_PlanDistributedInfo(Thallo_Plan* plan);
 /* what = 0: read (and with value != 0 clear) the device-side exchange's error word -- 1 if a bounded mailbox wait timed out since the last clear
- *           (synchronises the stream); what = 1: value 0 switches this plan to the all-gather transport for good (every rank must do the same).
- * Returns the word / 0, or -1. */
+ *           (synchronises the stream); what = 1: value 0 switches this plan to the all-gather transport for good (every rank must do the same);
+ *           what = 2 (tests): the value-th rank-local launch from now on reports a failure.
+ * Returns the word / 0, or -1.
+ *
+ * Failures across ranks.  Decisions that change the sequence of collectives are unanimous (set-up, Init, the device-side exchange's self-check: a
+ * rank that cannot allocate, bind or prepare says so in an agreement, and then EVERY rank returns the error).  A launch or copy that fails on ONE
+ * rank in the middle of a step does not end that rank's part of the sequence: it skips its own launches, keeps issuing every collective with a
+ * poisoned payload (NaN scalars on every rank) and goes on returning 1 from Thallo_ProblemStep like the others; at the next cost evaluation --
+ * the end of Thallo_ProblemSolve, every Thallo_ProblemCurrentCost, every LM step -- all ranks learn of it together, report it, and their plans
+ * stop (Step returns 0, the cost is NaN).  What stays rank-local: a failing collective callback itself, and running out of memory for the two
+ * message buffers inside ThalloX_PlanSetDistributed before the first collective. */
 int ThalloX_DistributedControl(Thallo_Plan* plan, int what, int value);
 /* bench: `reps` back-to-back launches of the one-kernel PCG iteration on this rank's slab, without the exchange (kernel time per rank) */
 int ThalloX_DistributedKernelOnly(Thallo_Plan* plan, int reps);

@@ -149,6 +149,13 @@ class Problem:
         return costs[: n + 1], (trace[:tcap] if want_trace else None)
 
 
+def last_pcg_counts():
+    """PCG iterations each GN / LM step of the last solve() ran (LM's zeta test ends the loop early)."""
+    out = (C.c_int * 1024)()
+    n = lib().orc_last_pcg_counts(out, 1024)
+    return list(out[: min(n, 1024)])
+
+
 def set_threads(n):
     """n > 1: the oracle's row loops run on n OpenMP threads (full-size configurations on the GPU box's host cores); 1 = the serial,
     bit-exact known-answer path.  Returns the previous setting."""

@@ -663,8 +663,19 @@ static void copy_unknowns(OrcEnergy* e, float* dst_flat, int to_flat)
     }
 }
 
+/* PCG iterations each Gauss-Newton / LM step of the last orc_solve ran (the zeta test of :1666-1686 ends the LM loop early): what the tests compare the
+ * device-side early exit with */
+static int g_pcg_counts[1024], g_pcg_steps = 0;
+int orc_last_pcg_counts(int* out, int cap)
+{
+    const int n = g_pcg_steps < cap ? g_pcg_steps : cap;
+    for (int i = 0; i < n; ++i) out[i] = g_pcg_counts[i];
+    return g_pcg_steps;
+}
+
 int orc_solve(OrcEnergy* e, const OrcSolverParams* sp, double* costs, int costs_cap, float* trace, int trace_cap)
 {
+    g_pcg_steps = 0;
     const long n = e->n_unknowns;
     const int fl = sp->float_sums;
     const int lm = sp->use_lm;
@@ -714,7 +725,9 @@ int orc_solve(OrcEnergy* e, const OrcSolverParams* sp, double* costs, int costs_
             alphaN = (float)acc_get(&aN); Q0 = (float)acc_get(&aQ);
         }
         /* ---- Linear Solve (:1615-1687) */
+        int pcg_done = 0;
         for (int lIter = 0; lIter < sp->lIterations; ++lIter) {
+            pcg_done = lIter + 1;
             memset(Ap, 0, n * 4);
             double dd = orc_apply_jtj(e, p, Ap, fl);            /* PCGStep1 residual-wise :1006-1015 */
             float alphaD;
@@ -763,6 +776,7 @@ int orc_solve(OrcEnergy* e, const OrcSolverParams* sp, double* costs, int costs_
                 Q0 = Q1;
             }
         }
+        if (g_pcg_steps < 1024) g_pcg_counts[g_pcg_steps++] = pcg_done;
         /* ---- Nonlinear Finish (:1690-1765) */
         float model_cost_change = 0.0f;
         if (lm) {

@@ -361,3 +361,57 @@ def test_hip_sfs_2048_levenberg_marquardt_two_ranks_match_one_gpu():
         assert costs == res[0][1]
         # (sums over rows and ranks associate differently from one GPU's; 30 PCG iterations of an LM solve amplify that to a few 1e-4 of the depth values)
         assert np.abs(X - dev[16].view(H, W)[g0:g1].cpu().numpy()).max() <= 1e-3
+
+
+def _worker_fail(rank, world, port, W, H, lit, q, energy, fail_rank, nth):
+    """A 2-rank solve in which ONE rank reports a rank-local launch failure in the middle of its first step (ThalloX_DistributedControl what = 2)."""
+    import torch
+    import torch.distributed as dist
+    from thallo_amd import synthetic as syn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if energy == "iw":
+            from thallo_amd.distributed import PlanSlabSolver
+            solver = PlanSlabSolver(syn.image_warping(W, H, n_markers=8), W, H, rank, world, lit, device_exchange=False)
+        else:
+            from thallo_amd.distributed_sfs import PlanSfsSlabSolver
+            solver = PlanSfsSlabSolver(syn.shape_from_shading(W, H), W, H, rank, world, lit, lm=(energy == "sfs_lm"))
+        s = solver.solver
+        s.set_solver_parameters(nIterations=3, lIterations=lit)
+        s.init(solver.params)
+        c0 = s.current_cost()
+        if rank == fail_rank:
+            s._L.ThalloX_DistributedControl(s.plan, 2, nth)
+        steps = 0
+        while s.step(solver.params) and steps < 10:
+            steps += 1
+        c1 = s.current_cost()
+        more = s.step(solver.params)
+        from thallo_amd import api
+        q.put((rank, c0, steps, c1, more, api.last_error()))
+        s.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("energy,nth", [("iw", 7), ("sfs", 9), ("sfs_lm", 12)])
+def test_rank_local_failure_is_reported_by_every_rank_and_nobody_hangs(energy, nth):
+    """a launch that fails on ONE rank used to return in front of the matching all-gather and leave the other ranks blocked in it.  Now the rank stays
+    in the collective sequence with poisoned payloads and the failure becomes everybody's at the next cost evaluation: both ranks finish, both see a NaN cost and
+    an error text, both plans refuse further steps."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, W, H, lit = 2, 64, 48, 6
+    procs = [ctx.Process(target=_worker_fail, args=(r, world, port, W, H, lit, q, energy, 1, nth)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(_collect(q, procs, world, limit=120.0))
+    for rank, c0, steps, c1, more, err in res:
+        assert np.isfinite(c0) and c0 > 0
+        assert not np.isfinite(c1), (rank, c1)              # agreed: every rank's cost is void
+        assert more == 0 and "fail" in err.lower(), (rank, err)
+    assert res[0][2] == res[1][2]                           # the same number of steps on both ranks: nobody left the sequence early

@@ -857,36 +857,37 @@ def test_in_kernel_scalar_finish_is_bitwise_the_separate_launch(torch, which, mo
 
 
 @pytest.mark.parametrize("which", ["sfs", "ba", "iw"])
-def test_lm_device_side_zeta_matches_the_blocking_form(torch, which, monkeypatch):
+def test_lm_device_side_zeta_matches_the_oracle(torch, orc, which):
     """LM without the host in the loop: the zeta test and the early-exit flag live on the device, one read-back per
-    GN step.  Same PCG iteration counts, same costs, same unknowns as the reference-shaped form that blocks on a 4-byte copy after every
-    PCG iteration (gauss_newton.t:1666-1686; THALLO_LM_HOST_ZETA=1)."""
+    GN step.  The oracle runs the reference-shaped form -- a host-side test on q after every PCG iteration (gauss_newton.t:1666-1686) -- and
+    reports how many PCG iterations each LM step ran: the device must stop in the same iterations (the test compares nearly equal floats, so
+    one step may differ by one iteration) and follow the same costs.  (Round 2 pinned this against a blocking A/B form of the driver,
+    THALLO_LM_HOST_ZETA; that switch is gone.)"""
     if which == "sfs":
-        fname, dims, p, sp = "shape_from_shading", (96, 64), syn.shape_from_shading(96, 64), dict(nIterations=5, lIterations=10, q_tolerance=0.2)
+        kind, fname, dims, p, sp = orc.SFS, "shape_from_shading", (96, 64), syn.shape_from_shading(96, 64), dict(nIterations=5, lIterations=10, q_tolerance=0.2)
     elif which == "ba":
         p = syn.bundle_adjustment(C=24, P=400, O=2400, band=8)
-        fname, dims, sp = "bundle_adjustment", (24, 400, 2400), dict(nIterations=4, lIterations=40, q_tolerance=0.02)
+        kind, fname, dims, sp = orc.BUNDLE_ADJUST, "bundle_adjustment", (24, 400, 2400), dict(nIterations=4, lIterations=40, q_tolerance=0.02)
     else:
-        fname, dims, p, sp = "image_warping", (96, 64), syn.image_warping(96, 64, n_markers=6), dict(nIterations=4, lIterations=30, q_tolerance=0.05)
-    runs = []
-    for host in ("1", "0"):
-        monkeypatch.setenv("THALLO_LM_HOST_ZETA", host)
-        dev = to_device(p)
-        s = api.ThalloSolver(dims, thallo_amd.energy_file(fname), solverkind="levenberg_marquardt")
-        s.enable_lm()
-        s.set_solver_parameters(**sp)
-        params = s.make_params(dev)
-        s.init(params)
-        costs, iters = [s.current_cost()], []
-        while s.step(params):
-            costs.append(s.current_cost()); iters.append(len(s.alpha_beta_trace()))
-        runs.append((costs, iters, [d.clone() for d in dev if hasattr(d, "clone")]))
-        s.close()
-    (c0, i0, u0), (c1, i1, u1) = runs
-    assert i0 == i1 and len(i0) >= 2 and min(i0) >= 1, (i0, i1)
-    assert any(k < sp["lIterations"] for k in i0), i0          # the early exit is actually exercised
-    assert c0 == c1, (c0, c1)
-    assert all(torch.equal(a, b) for a, b in zip(u0, u1))
+        kind, fname, dims, p, sp = orc.IMAGE_WARPING, "image_warping", (96, 64), syn.image_warping(96, 64, n_markers=6), dict(nIterations=4, lIterations=30, q_tolerance=0.05)
+    co, _ = orc.Problem(kind, dims, copy_params(p)).solve(use_lm=1, **sp)
+    want = orc.last_pcg_counts()
+    dev = to_device(p)
+    s = api.ThalloSolver(dims, thallo_amd.energy_file(fname), solverkind="levenberg_marquardt")
+    s.enable_lm()
+    s.set_solver_parameters(**sp)
+    params = s.make_params(dev)
+    s.init(params)
+    costs, iters = [s.current_cost()], []
+    while s.step(params):
+        costs.append(s.current_cost()); iters.append(len(s.alpha_beta_trace()))
+    s.close()
+    m = min(len(iters), len(want))
+    assert m >= 2 and min(iters) >= 1, (iters, want)
+    assert any(k < sp["lIterations"] for k in iters), iters          # the early exit is actually exercised
+    assert sum(abs(a - b) for a, b in zip(iters[:m], want[:m])) <= 1, (iters, want)
+    mc = min(len(costs), len(co))
+    assert (np.abs(np.array(costs[:mc]) - co[:mc]) <= 2e-4 * np.abs(co[:mc]) + 1e-7).all(), (costs, co)
 
 
 def test_lm_kind_string_alone_runs_gn_like_the_reference(torch, orc):

@@ -241,13 +241,25 @@ void Plan::init(void** params)
     timer_.cleanup();
     ev_total_ = timer_.start("Total", ctx.stream);
     ready_ = false;
-    if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return; }
-    plugin->unknowns_changed();                // a new solve: the caller may have rewritten unknowns and inputs behind the same pointers
-    if (plugin->prepare(ctx)) { const std::string why = last_error(); set_error("%s: prepare failed: %s", plugin->name(), why.c_str()); return; }
-    if (dist_ && !dist_->flat && !dist_->range) {   // collective: the one-kernel slab schedule needs its precondition on EVERY rank; then (first Init) the exchange's self-check
+    // Across ranks Init is collective: a rank that cannot bind or prepare its parameters says so in the agreement below instead of returning in front of the
+    // other ranks' first all-gather (they would wait there forever); the same exchange carries the one-kernel slab schedule's precondition.
+    bool local_ok = true;
+    if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); local_ok = false; }
+    if (local_ok) {
+        plugin->unknowns_changed();            // a new solve: the caller may have rewritten unknowns and inputs behind the same pointers
+        if (plugin->prepare(ctx)) { const std::string why = last_error(); set_error("%s: prepare failed: %s", plugin->name(), why.c_str()); local_ok = false; }
+    }
+    if (!dist_) { if (!local_ok) return; }
+    else {
+        dist_->failed = false; dist_->stopped = false;      // a new solve
+        const bool need_grid = !dist_->flat && !dist_->range;
         bool all = false;
-        if (dist_agree(plugin->slab_grid_ok(), all)) return;
-        if (!all) { set_error("%s: the row-slab schedule needs UrShape on the unit pixel grid on every rank", plugin->name()); return; }
+        if (dist_agree(local_ok && (!need_grid || plugin->slab_grid_ok()), all)) return;
+        if (!all) {
+            if (local_ok && need_grid && !plugin->slab_grid_ok()) set_error("%s: the row-slab schedule needs UrShape on the unit pixel grid on every rank", plugin->name());
+            else if (local_ok) set_error("%s: another rank could not start the solve (its parameters, or UrShape off the unit pixel grid); no rank does", plugin->name());
+            return;
+        }
     }
     ready_ = true;
     if (dist_ && dist_->want_p2p && !dist_->checked && dist_self_check()) { ready_ = false; return; }
@@ -269,7 +281,7 @@ void Plan::finalize()
 
 double Plan::cost()
 {   // gauss_newton.t:1787-1793
-    if (!ok_ || !ready_) return 0.0;
+    if (!ok_ || !ready_) return dist_ && dist_->stopped ? (double)NAN : 0.0;
     if (!finalized_) prev_cost_ = compute_cost();
     return (double)prev_cost_;
 }
@@ -277,14 +289,20 @@ double Plan::cost()
 int Plan::step(void** params)
 {   // gauss_newton.t:1545-1785
     if (!ok_ || !ready_) return 0;
-    if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return 0; }
+    if (plugin->bind(params)) {
+        if (dist_) dist_fail("%s: parameter binding failed", plugin->name());      // (stays in step with the other ranks: solver_dist.cpp, DistState::failed)
+        else { set_error("%s: parameter binding failed", plugin->name()); return 0; }
+    }
     // Gauss-Newton steps derive everything from the unknowns as they are NOW, like the reference (a caller may have rewritten them since the last call).  The LM
     // branch already lives on state carried from the previous step's end -- prev_cost_, as the reference's pd.hd.prevCost (gauss_newton.t:1732,1710) -- so there a
     // plugin may also keep what it derived from the unknowns at that point (shape_from_shading's precomputed planes).
     if (!lm_) plugin->unknowns_changed();
     if (sp.nIter >= sp.nIterations) { if (!finalized_) finalize(); return 0; }
     if (sp.lIterations < 0) { set_error("lIterations = %d is negative", sp.lIterations); if (!finalized_) finalize(); return 0; }
-    if (ensure_slots(sp.lIterations)) { if (!finalized_) finalize(); return 0; }
+    if (ensure_slots(sp.lIterations)) {
+        if (dist_) dist_fail("out of device memory for the reduction slots");
+        else { if (!finalized_) finalize(); return 0; }
+    }
     const int ev_iter = timer_.start("Nonlinear Iteration", ctx.stream);
     if (dist_ && lm_ && (!dist_->flat || dist_->range)) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); if (!finalized_) finalize(); return 0; }
     const int rc = lm_ ? step_lm(ev_iter) : dist_ ? step_gn_slab(ev_iter) : step_gn(ev_iter);
@@ -518,150 +536,174 @@ int Plan::step_lm(int ev_iter)
     // Slots: 0 cost, 1 q, B.. as in GN (alphaN_k = B+2k, alphaD_k = B+2k+1, betaN_k = B+2k+2); last two: scratch dots.
     //
     // The zeta test (:1666-1686) runs ON THE DEVICE: all lIterations iterations are enqueued, a one-wave kernel behind each PCGStep2
-    // applies the test and sets the gate word, after which the remaining launches of the loop return at once; delta, r, z stay as of
-    // the break.  One read-back per GN step (iterations done, delta.J^T J delta, delta.b, new cost) instead of the reference's blocking
-    // 4-byte copy per PCG iteration (fetchQ :1146-1150).  THALLO_LM_HOST_ZETA=1 selects that blocking form (A/B; same iteration
-    // counts, same costs: tests/test_gpu_parity.py).
-    if (ensure_lm_vectors()) return 0;
+    // (or PCGStep2's own last workgroup) applies the test and sets the gate word, after which the remaining launches of the loop return at
+    // once; delta, r, z stay as of the break.  One read-back per GN step (iterations done, delta.J^T J delta, delta.b, new cost) instead of
+    // the reference's blocking 4-byte copy per PCG iteration (fetchQ :1146-1150); iteration counts and costs are pinned against the oracle's
+    // host-side test (tests/test_gpu_parity.py::test_lm_device_side_zeta_matches_the_oracle).
     hipStream_t s = ctx.stream;
     const int L = sp.lIterations, B = 2, QS = 1, T0 = 2 * L + 4, T1 = 2 * L + 5;
     // One row slab of a multi-GPU run (flat form, solver_dist.cpp): the energy-independent kernels run on the owned rows' sub-vectors [o, o + n),
     // p is kept current on the ghost rows too ([oe, oe + ne)), and every reduction is made global where it is produced: per PCG iteration one
     // exchange for alphaD and one for [betaN, q | ghost rows of z]; all ranks see the same scalars, so gate and trust region cannot diverge.
     const bool slab = dist_ != nullptr;
+    // A launch of this rank that fails: on one GPU the step ends (return 0).  One slab of several must not leave the collective sequence: it goes on
+    // issuing every exchange of the step with poisoned payloads, skips its own launches, and the error becomes everybody's at the cost evaluation
+    // at the end of the step (solver_dist.cpp, DistState::failed).
+    bool failed = false;
+    auto skip = [&]() { return failed || (slab && dist_->failed); };
+    auto check = [&](int rc, const char* what) {
+        if (rc >= 0 || skip()) return;
+        if (slab) dist_fail("%s failed (%d)", what, rc); else { set_error("%s failed (%d)", what, rc); failed = true; }
+    };
+    if (ensure_lm_vectors()) check(-1, "allocating the LM vectors");
+    if (failed) return 0;
     const long o = slab ? dist_->rowlen * dist_->row0 : 0, n = slab ? dist_->rowlen * (dist_->row1 - dist_->row0) : v_.n;
     const long oe = slab ? dist_->rowlen * (dist_->row0 - dist_->top) : 0, ne = slab ? dist_->rowlen * (dist_->row1 + dist_->bot - (dist_->row0 - dist_->top)) : v_.n;
-    auto global = [&](int j) { return slab ? dist_sum_slot(j) : 0; };
+    auto global = [&](int j) { return slab ? dist_sum_slot(j) : 0; };                         // nonzero: the collective itself failed
     auto global_rows = [&](int j, float* vec) { return slab ? dist_sum_and_rows(j, vec) : 0; };
     const bool pc = plugin->use_preconditioner();
     const bool fold_ctc = plugin->apply_adds_ctc() && ![] { const char* e = getenv("THALLO_LM_FOLD_CTC"); return e && e[0] == '0'; }();      // (=0: A/B)
-    const bool host_zeta = [] { const char* e = getenv("THALLO_LM_HOST_ZETA"); return e && e[0] == '1'; }();
     // PCGStep3 folded into the apply too (one GPU; plugins that offer it; THALLO_LM_FOLD_P=0: A/B, read_ab_switches)
     const bool fold_p = lm_fold_p_ && fold_ctc && !slab && plugin->apply_folds_pupdate() && v_.p[1] != nullptr;
-    // the zeta test by PCGStep2's last workgroup (one GPU, device-side test): one launch less per iteration.  A slab needs the GLOBAL q first.
-    if (!host_zeta && !slab && ensure_sums_buffer()) return 0;
-    const bool zeta_in_step2 = !host_zeta && !slab && ![] { const char* e = getenv("THALLO_LM_ZETA_IN_STEP2"); return e && e[0] == '0'; }();
+    // the zeta test by PCGStep2's last workgroup (one GPU): one launch less per iteration.  A slab needs the GLOBAL q first.
+    if (!slab && ensure_sums_buffer()) return 0;
+    const bool zeta_in_step2 = !slab && ![] { const char* e = getenv("THALLO_LM_ZETA_IN_STEP2"); return e && e[0] == '0'; }();
     float* lmst = (float*)scratch_.ptr + 16;                          // 8 words: Q0, gate, iterations done, | dJJd, db, new cost
     const unsigned* gate = reinterpret_cast<const unsigned*>(lmst) + 1;
     const int ev_setup = timer_.start("Nonlinear Setup", s);
     if (sp.nIter == 0) { radius_ = sp.trust_region_radius; decrease_factor_ = sp.radius_decrease_factor; }   // :1185-1186 (copied at init)
     cur_ = 0;
-    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));               // r, raw diag (v_.diag); delta = 0
-    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
-    {   TimedLaunch t(ctx, "PCGFinalizeDiagonal");                    // :1596-1604 (alphaN restarts from 0)
+    int nb = 0;
+    if (!skip()) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); check(nb, "PCGInit1 launch"); }        // r, raw diag (v_.diag); delta = 0
+    if (!skip()) {
+        TimedLaunch t(ctx, "PCGFinalizeDiagonal");                    // :1596-1604 (alphaN restarts from 0)
         nb = thallo_hip_lm_finalize_diagonal(v_.diag + o, v_.SSq + o, v_.CtC + o, v_.pre + o, v_.r + o, v_.b + o, v_.z + o, n, radius_, sp.min_lm_diagonal, sp.max_lm_diagonal,
                                              sp.nIter == 0 ? 1 : 0, pc ? 1 : 0, slot(B), s);
+        check(nb, "PCGFinalizeDiagonal launch");
     }
-    if (nb < 0) return 0;
-    set_nb(B, nb);
+    if (failed) return 0;
+    if (!skip()) set_nb(B, nb);
     if (global_rows(B, v_.z)) return 0;                               // alphaN_0 over all ranks; ghost rows of z
-    float Q0 = 0.0f;                                                  // delta = 0 -> q = 0 (:965)
-    if (thallo_hip_lm_state_reset(lmst, s) < 0) return 0;
+    if (!skip()) check(thallo_hip_lm_state_reset(lmst, s), "LM state reset");       // (delta = 0 -> q = 0, :965)
+    if (failed) return 0;
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
     float* p = v_.p[0];
     int k_done = 0;
-    if (!host_zeta) { thallo_hip_lm_set_gate(gate); ctx.gate = gate; }
-    bool failed = false;
-    for (int k = 0; k < L && !failed; ++k) {
+    thallo_hip_lm_set_gate(gate); ctx.gate = gate;
+    bool coll_failed = false;                                         // a collective itself failed: nothing left to stay in step with
+    for (int k = 0; k < L && !failed && !coll_failed; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        if (fold_p) {                                                 // PCGStep3 + PCGStep1 + PCGStep1_Finish in one launch; p ping-pongs between the two buffers
-            float* pn = p == v_.p[0] ? v_.p[1] : v_.p[0];
-            ctx.lm_ctc = v_.CtC;
-            nb = plugin->apply_jtj_pupdate(ctx, v_.z, p, pn, v_.Ap, slot(jD), k == 0, sum(k ? jN - 2 : jN), sum(jN));
-            ctx.lm_ctc = nullptr;
-            if (nb < 0) { set_error("PCGStep1 (+ PCGStep3) launch failed (%d)", nb); failed = true; break; }
-            p = pn;
-        } else {
-            TimedLaunch t(ctx, "PCGStep3");                           // p = z + beta p  (k = 0: p = z)
-            thallo_hip_pcg_pupdate(v_.z + oe, p + oe, p + oe, nullptr, ne, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
+        if (!skip()) {
+            if (fold_p) {                                             // PCGStep3 + PCGStep1 + PCGStep1_Finish in one launch; p ping-pongs between the two buffers
+                float* pn = p == v_.p[0] ? v_.p[1] : v_.p[0];
+                ctx.lm_ctc = v_.CtC;
+                nb = plugin->apply_jtj_pupdate(ctx, v_.z, p, pn, v_.Ap, slot(jD), k == 0, sum(k ? jN - 2 : jN), sum(jN));
+                ctx.lm_ctc = nullptr;
+                check(nb, "PCGStep1 (+ PCGStep3) launch");
+                p = pn;
+            } else {
+                {   TimedLaunch t(ctx, "PCGStep3");                   // p = z + beta p  (k = 0: p = z)
+                    check(thallo_hip_pcg_pupdate(v_.z + oe, p + oe, p + oe, nullptr, ne, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s), "PCGStep3 launch");
+                }
+                if (fold_ctc) {                                       // PCGStep1 + PCGStep1_Finish in one launch: (J^T J + CtC) p ; alphaD
+                    ctx.lm_ctc = v_.CtC;
+                    nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(jD));
+                    ctx.lm_ctc = nullptr;
+                    check(nb, "PCGStep1 launch");
+                } else {
+                    nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(T0));  // PCGStep1 (J^T J p)
+                    check(nb, "PCGStep1 launch");
+                    if (!skip()) {
+                        TimedLaunch t(ctx, "PCGStep1_Finish");        // + CtC p ; alphaD
+                        nb = thallo_hip_lm_step1_finish(v_.Ap + o, v_.CtC + o, p + o, n, slot(jD), s);
+                        check(nb, "PCGStep1_Finish launch");
+                    }
+                }
+            }
+            if (!skip()) set_nb(jD, nb);
         }
-        if (fold_p) { }
-        else if (fold_ctc) {                                          // PCGStep1 + PCGStep1_Finish in one launch: (J^T J + CtC) p ; alphaD
-            ctx.lm_ctc = v_.CtC;
-            nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(jD));
-            ctx.lm_ctc = nullptr;
-            if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); failed = true; break; }
-        } else {
-            nb = plugin->apply_jtj(ctx, p, v_.Ap, slot(T0));          // PCGStep1 (J^T J p)
-            if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); failed = true; break; }
-            TimedLaunch t(ctx, "PCGStep1_Finish");                    // + CtC p ; alphaD
-            nb = thallo_hip_lm_step1_finish(v_.Ap + o, v_.CtC + o, p + o, n, slot(jD), s);
-        }
-        if (nb < 0) { failed = true; break; }
-        set_nb(jD, nb);
-        if (global(jD)) { failed = true; break; }
-        int nbq; bool zeta_done = false;
-        if (((k + 1) % sp.residual_reset_period) == 0) {              // :1653-1657
-            TimedLaunch t(ctx, "PCGStep2");
-            thallo_hip_lm_step2_first_half(v_.delta + o, p + o, n, sum(jN), sum(jD), s);
-            if (global_rows(-1, v_.delta)) { failed = true; break; }               // (slab: applyJTJ reads delta on the ghost rows)
-            ctx.lm_ctc = fold_ctc ? v_.CtC : nullptr;
-            nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));             // computeAdelta (+ CtC delta)
-            ctx.lm_ctc = nullptr;
-            if (nb < 0) { failed = true; break; }
-            if (!fold_ctc) thallo_hip_lm_step1_finish(v_.Adelta + o, v_.CtC + o, v_.delta + o, n, slot(T1), s);
-            nb = thallo_hip_lm_step2_second_half(v_.r + o, v_.b + o, v_.Adelta + o, v_.pre + o, v_.z + o, v_.delta + o, n, slot(jB), slot(QS), s);
-            nbq = nb;
-        } else {
+        if (failed) break;
+        if (global(jD)) { coll_failed = true; break; }
+        int nbq = 0; bool zeta_done = false;
+        const bool reset = ((k + 1) % sp.residual_reset_period) == 0;     // :1653-1657
+        if (reset) {
+            if (!skip()) { TimedLaunch t(ctx, "PCGStep2"); check(thallo_hip_lm_step2_first_half(v_.delta + o, p + o, n, sum(jN), sum(jD), s), "PCGStep2 (first half) launch"); }
+            if (global_rows(-1, v_.delta)) { coll_failed = true; break; }          // (slab: applyJTJ reads delta on the ghost rows)
+            if (!skip()) {
+                TimedLaunch t(ctx, "PCGStep2");
+                ctx.lm_ctc = fold_ctc ? v_.CtC : nullptr;
+                nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));         // computeAdelta (+ CtC delta)
+                ctx.lm_ctc = nullptr;
+                check(nb, "computeAdelta launch");
+                if (!skip() && !fold_ctc) check(thallo_hip_lm_step1_finish(v_.Adelta + o, v_.CtC + o, v_.delta + o, n, slot(T1), s), "computeAdelta (CtC) launch");
+                if (!skip()) { nb = thallo_hip_lm_step2_second_half(v_.r + o, v_.b + o, v_.Adelta + o, v_.pre + o, v_.z + o, v_.delta + o, n, slot(jB), slot(QS), s); check(nb, "PCGStep2 (second half) launch"); }
+                nbq = nb;
+            }
+        } else if (!skip()) {
             TimedLaunch t(ctx, "PCGStep2");
             if (zeta_in_step2) nb = thallo_hip_pcg_step2_full_zeta(v_.delta + o, p + o, v_.r + o, v_.Ap + o, v_.pre + o, v_.z + o, v_.b + o, n, sum(jN), sum(jD), slot(jB), slot(QS),
                                                                     v_.fin_tickets, k, sp.q_tolerance, lmst, s);
             else nb = thallo_hip_pcg_step2_full(v_.delta + o, p + o, v_.r + o, v_.Ap + o, v_.pre + o, v_.z + o, v_.b + o, n, sum(jN), sum(jD), slot(jB), slot(QS), 1, s);
+            check(nb, "PCGStep2 launch");
             nbq = nb; zeta_done = zeta_in_step2;
         }
-        if (nb < 0) { failed = true; break; }
-        set_nb(jB, nb); set_nb(QS, nbq);
-        if (global(QS) || global_rows(jB, v_.z)) { failed = true; break; }          // q and betaN over all ranks; ghost rows of z
+        if (failed) break;
+        if (!skip()) { set_nb(jB, nb); set_nb(QS, nbq); }
+        if (global(QS) || global_rows(jB, v_.z)) { coll_failed = true; break; }     // q and betaN over all ranks; ghost rows of z
         k_done = k + 1;
-        if (host_zeta) {
-            const float Q1 = read_sum(QS);                            // :1666-1686 (blocking, as in the reference)
-            if (!std::isfinite(Q1)) break;
-            const float zeta = (float)(k + 1) * (Q1 - Q0) / Q1;
-            if (!std::isfinite(zeta)) break;
-            if (zeta < sp.q_tolerance) break;
-            Q0 = Q1;
-        } else if (!zeta_done) {
+        if (!zeta_done && !skip()) {
             TimedLaunch t(ctx, "PCGZeta");
-            if (thallo_hip_lm_zeta(sum(QS), k, sp.q_tolerance, lmst, s) < 0) { failed = true; break; }
+            check(thallo_hip_lm_zeta(sum(QS), k, sp.q_tolerance, lmst, s), "PCGZeta launch");
         }
     }
     thallo_hip_lm_set_gate(nullptr); ctx.gate = nullptr;
-    if (failed) return 0;
+    if (failed || coll_failed) return 0;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
     // model_cost_change = cost - 0.5|F + J delta|^2 = delta.b - 0.5 delta.(J^T J delta)   (b = -J^T F; thallo.t:3845-3865
     // expanded algebraically, which also avoids the reference's cancellation between two large sums)
     if (global_rows(-1, v_.delta)) return 0;
-    nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0));
-    if (nb < 0) return 0;
-    set_nb(T0, nb);
-    nb = thallo_hip_dot(v_.delta + o, v_.b + o, n, slot(T1), s);
-    if (nb < 0) return 0;
-    set_nb(T1, nb);
+    if (!skip()) { nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0)); check(nb, "model cost: applyJTJ launch"); }
+    if (!skip()) set_nb(T0, nb);
+    if (!skip()) { nb = thallo_hip_dot(v_.delta + o, v_.b + o, n, slot(T1), s); check(nb, "model cost: dot launch"); }
+    if (!skip()) set_nb(T1, nb);
+    if (failed) return 0;
     if (global(T0) || global(T1)) return 0;
-    thallo_hip_finish_sum(sum(T0), lmst + 3, s);
-    thallo_hip_finish_sum(sum(T1), lmst + 4, s);
     const auto& imgs = plugin->unknown_images();
-    {   long off = 0;                                                 // savePreviousUnknowns :915-920
+    if (!skip()) {
+        thallo_hip_finish_sum(sum(T0), lmst + 3, s);
+        thallo_hip_finish_sum(sum(T1), lmst + 4, s);
+        long off = 0;                                                 // savePreviousUnknowns :915-920
         for (size_t k = 0; k < imgs.size(); ++k) {
             HIP_OK(hipMemcpyAsync(v_.prevX + off, plugin->unknown_ptr((int)k), imgs[k].n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
             off += imgs[k].n_floats;
         }
+        linear_update_tail(0, false);                                 // PCGLinearUpdate: X += delta (the owned rows of a slab)
     }
-    linear_update_tail(0, false);                                     // PCGLinearUpdate: X += delta (the owned rows of a slab)
     if (slab && dist_exchange_unknown_rows()) return 0;
     {   // cost after the step, into the same report: ONE blocking read per GN step
-        const int nbc = plugin->cost(ctx, slot(0));
-        if (nbc < 0) { set_error("cost kernel launch failed (%d)", nbc); return 0; }
-        set_nb(0, nbc);
+        int nbc = 0;
+        if (!skip()) { nbc = plugin->cost(ctx, slot(0)); check(nbc, "cost kernel launch"); }
+        if (failed) return 0;
+        if (!skip()) set_nb(0, nbc);
         if (global(0)) return 0;
-        thallo_hip_finish_sum(sum(0), lmst + 5, s);
+        if (!skip()) thallo_hip_finish_sum(sum(0), lmst + 5, s);
+    }
+    if (slab) {   // the step's outcome decides the trust region on every rank: agree on whether every rank got through it before anyone reads its report
+        bool all = false;
+        if (dist_agree(!dist_->failed, all)) return 0;
+        if (!all) {
+            const std::string mine = dist_->failed ? last_error() : "";
+            if (dist_->failed) set_error("distributed: this rank failed (%s); every rank stops", mine.c_str()); else set_error("distributed: another rank reported a failure; every rank stops");
+            ready_ = false; dist_->stopped = true;
+            return 0;
+        }
     }
     float rep[8] = { 0 };
     HIP_OK(hipMemcpyAsync(rep, lmst, sizeof(rep), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    if (!host_zeta) { int frozen_at; memcpy(&frozen_at, &rep[2], sizeof(int)); unsigned fz; memcpy(&fz, &rep[1], sizeof(fz)); if (fz) k_done = frozen_at; }
+    { int frozen_at; memcpy(&frozen_at, &rep[2], sizeof(int)); unsigned fz; memcpy(&fz, &rep[1], sizeof(fz)); if (fz) k_done = frozen_at; }
     last_l_iters = k_done;
     const float dJJd = rep[3], db = rep[4], newCost = rep[5];
     const float model_cost_change = db - 0.5f * dJJd;

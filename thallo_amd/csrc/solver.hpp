@@ -72,6 +72,13 @@ struct DistState {
     thallo_dist_t d, d_iter[2];
     std::vector<void*> opened;
     std::string info;                                    // JSON: transport, memory kind, self-check outcome
+    // A rank-local failure (a launch, a copy, an allocation at Step time) must not end this rank's part of the collective sequence -- the other
+    // ranks would wait in the matching all-gather forever.  From the first failure on the rank skips its own launches, keeps issuing every
+    // collective of the sequence with a poisoned payload (NaN header: every rank's alpha / beta / cost turn NaN), and the error becomes
+    // everybody's at the next cost evaluation (dist_cost carries the flag; Init, Finalize and Thallo_ProblemCurrentCost all end there).
+    bool failed = false;
+    bool stopped = false;                                // the failure was agreed on: every rank's plan refuses further steps, its cost reads NaN
+    int inject = 0;                                      // tests (ThalloX_DistributedControl what = 2): the n-th rank-local launch / copy from now on reports a failure
 };
 
 class Plan {
@@ -152,6 +159,8 @@ private:
     int  set_distributed_impl(const ThalloX_Distributed& cfg);
     int  dist_allgather(const void* send, void* recv, long bytes);
     int  dist_agree(bool flag, bool& all);
+    void dist_fail(const char* fmt, ...);               // first rank-local failure: report it, switch this rank to "collectives only" (DistState::failed)
+    bool dist_skip() const { return dist_ && dist_->failed; }
     int  dist_map_peers();
     int  dist_self_check();
     int  dist_gn(int L, bool p2p);                      // PCGInit + L iterations + linear update + ghost refresh, no bookkeeping

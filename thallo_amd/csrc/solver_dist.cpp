@@ -10,6 +10,7 @@
 // replicated host logic cannot diverge.
 #include "solver.hpp"
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 
@@ -30,9 +31,26 @@ struct PeerInfo {              // what a rank publishes about itself when the de
 };
 }  // namespace
 
+// ---- rank-local failures (DistState::failed).  Every function below keeps ONE rule: collectives are issued unconditionally and in the same
+// order on every rank; everything rank-local sits behind `if (!D.failed)`.  What stays rank-local (cannot be agreed on): a failing collective
+// callback itself, and running out of memory for the two message buffers at set-up, before the first collective.
+void Plan::dist_fail(const char* fmt, ...)
+{
+    if (!dist_ || dist_->failed) return;
+    char why[384];
+    va_list ap; va_start(ap, fmt); vsnprintf(why, sizeof(why), fmt, ap); va_end(ap);
+    dist_->failed = true;
+    set_error("distributed: rank %d: %s -- this rank goes on issuing its collectives with poisoned payloads; every rank reports the failure at the next cost evaluation",
+              dist_->cfg.rank, why);
+}
+// a rank-local launch / copy: skipped once the rank has failed, a negative (or non-hipSuccess) result is the failure
+#define DLOCAL(call, what) do { if (!D.failed) { int rc__ = (int)(call); if (D.inject > 0 && --D.inject == 0) rc__ = -999; if (rc__ < 0) dist_fail("%s failed (%d)", what, rc__); } } while (0)
+#define DCOPY(call, what)  do { if (!D.failed) { const hipError_t e__ = (call); if (e__ != hipSuccess) dist_fail("%s failed (%s)", what, hipGetErrorString(e__)); } } while (0)
+
 int Plan::dist_allgather(const void* send, void* recv, long bytes)
 {
     DistState& D = *dist_;
+    if (D.failed) (void)hipMemsetAsync(const_cast<void*>(send), 0xFF, (size_t)(bytes < 32 ? bytes : 32), ctx.stream);      // NaN header: sums, alphaD, N / S1 / S2, the failure flag
     if (D.cfg.world == 1 && !D.cfg.allgather)
         return hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, ctx.stream) == hipSuccess ? 0 : -1;
     const int rc = D.cfg.allgather(D.cfg.user, send, recv, bytes, (void*)ctx.stream);
@@ -54,9 +72,14 @@ static int host_allgather(Plan& p, DistState& D, int (Plan::*ag)(const void*, vo
 int Plan::dist_agree(bool flag, bool& all)
 {   // every rank learns whether EVERY rank said yes (decisions that change the launch sequence must be unanimous)
     DistState& D = *dist_;
-    int mine[4] = { flag ? 1 : 0, 0, 0, 0 }, got[4 * THALLO_DIST_MAX_WORLD];
+    // (a rank that already failed says no -- and its message is poisoned anyway, which reads as "no" too)
+    int mine[4] = { flag && !D.failed ? 1 : 0, 0, 0, 0 }, got[4 * THALLO_DIST_MAX_WORLD];
     all = false;
-    if (host_allgather(*this, D, &Plan::dist_allgather, mine, got, sizeof(mine))) return -1;
+    const bool was_failed = D.failed;
+    D.failed = false;                                                    // (the agreement itself must travel unpoisoned: it is how a failure becomes everybody's)
+    const int rc = host_allgather(*this, D, &Plan::dist_allgather, mine, got, sizeof(mine));
+    D.failed = was_failed;
+    if (rc) return -1;
     all = true;
     for (int r = 0; r < D.cfg.world; ++r) all = all && got[4 * r] == 1;
     return 0;
@@ -89,11 +112,12 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         DistState* Dp = new DistState(); DistState& D = *Dp; dist_ = Dp;
         D.cfg = cfg; D.shard = true; D.range = true;            // (range: linear updates and the like cover the whole local vector)
         D.sh_off = off; D.sh_len = len;
-        if (D.send.alloc(64 * sizeof(float)) || D.gath.alloc(64 * sizeof(float) * cfg.world) || ensure_sums_buffer() ||
-            D.sh_aD.alloc(THALLO_HIP_MAX_PARTIALS * sizeof(float)) || D.sh_s3.alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double))) { set_error("distributed: out of device memory"); return -1; }
-        if (!v_.diag) { DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b); if (b->alloc((size_t)v_.n_alloc * sizeof(float))) return -1; v_.diag = (float*)b->ptr; }      // raw diag(J^T J): all-reduced before it is inverted
+        if (D.send.alloc(64 * sizeof(float)) || D.gath.alloc(64 * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }   // (rank-local: nothing to agree through yet)
+        bool mem = !(ensure_sums_buffer() || D.sh_aD.alloc(THALLO_HIP_MAX_PARTIALS * sizeof(float)) || D.sh_s3.alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double)));
+        if (mem && !v_.diag) { DeviceBuffer* b = new DeviceBuffer(); bufs_.push_back(b); if (b->alloc((size_t)v_.n_alloc * sizeof(float))) mem = false; else v_.diag = (float*)b->ptr; }      // raw diag(J^T J): all-reduced before it is inverted
         bool all = false;
-        if (dist_agree(true, all)) return -1;
+        if (dist_agree(mem, all)) return -1;                             // every rank has its buffers, or every rank returns the error
+        if (!all) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
         char buf[256];
         snprintf(buf, sizeof(buf), "{\"exchange\": \"allreduce + allgather\", \"form\": \"residual shards, shared block of %ld unknowns\", \"rank\": %d, \"world\": %d}", len, cfg.rank, cfg.world);
         D.info = buf;
@@ -125,9 +149,11 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         D.pieces_first = segs(first); D.pieces_mine = segs(mine);
         D.msg = 1 + D.piece_floats; D.msg_iter = 7 + D.piece_floats;
         const size_t words = (size_t)std::max(D.msg_iter, 64L);
-        if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world) || ensure_sums_buffer()) { set_error("distributed: out of device memory"); return -1; }
+        if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }
+        const bool mem = ensure_sums_buffer() == 0;
         bool all = false;
-        if (dist_agree(true, all)) return -1;
+        if (dist_agree(mem, all)) return -1;
+        if (!all) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
         char buf[256];
         snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit ranges, full-length vectors\", \"rank\": %d, \"world\": %d}", cfg.rank, cfg.world);
         D.info = buf;
@@ -165,10 +191,11 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         D.seg_rows_bot = bot ? segs({ { D.rowlen * D.row1, gl } }) : segs({});
         D.msg = 2 + 2 * gl; D.msg_iter = 7 + 2 * gl; D.msg_x = 2 * gl;
         const size_t words = (size_t)std::max(D.msg_iter, 64L);
-        if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory"); return -1; }
-        if (ensure_sums_buffer()) { set_error("distributed: out of device memory"); return -1; }
+        if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }
+        const bool mem = ensure_sums_buffer() == 0;
         bool all = false;
-        if (dist_agree(true, all)) return -1;                            // the first use of the caller's all-gather: fails here, not mid-solve
+        if (dist_agree(mem, all)) return -1;                             // the first use of the caller's all-gather: fails here, not mid-solve
+        if (!all) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
         char buf[256];
         snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"single-image, %d ghost rows\", \"rank\": %d, \"world\": %d}", g, cfg.rank, cfg.world);
         D.info = buf;
@@ -176,20 +203,6 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
     }
     D.want_p2p = cfg.device_exchange != 0;
     {   const char* e = getenv("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
-    // ---- r, z, r', Ap, Ap' in ONE block (peers map it; pack / unpack address r and z through one base)
-    const size_t block_bytes = (size_t)5 * D.na * sizeof(float);
-    if (D.want_p2p) {
-        if (thallo_hip_ipc_alloc2((long)block_bytes, &D.block, D.handle_block, &D.mem_kind[0]) < 0) { D.block = nullptr; D.want_p2p = false; }
-        else D.block_ipc = true;
-    }
-    if (!D.block) {
-        if (hipMalloc(&D.block, block_bytes) != hipSuccess) { set_error("distributed: out of device memory"); D.block = nullptr; return -1; }
-        if (hipMemset(D.block, 0, block_bytes) != hipSuccess) return -1;
-    }
-    for (int i : { 1, 2, 3 }) bufs_[i]->release();                     // the constructor's r, z, Ap
-    float* b = (float*)D.block;
-    v_.r = b; v_.z = b + D.na; v_.r2 = b + 2 * D.na; v_.Ap = b + 3 * D.na; v_.Ap2 = b + 4 * D.na;
-    if (ensure_iter_buffers()) { set_error("distributed: out of device memory"); return -1; }
     // ---- messages
     const long N = D.N, na = D.na;
     auto row = [&](long y, long base) { return std::vector<std::pair<long, long>>{ { base + 2L * W * y, 2L * W }, { base + 2 * N + (long)W * y, (long)W } }; };
@@ -204,8 +217,29 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
     D.msg_iter = 7 + 6L * W;                    // [alphaD | N, S1, S2 as (hi, lo) | first row of Ap_out | last row of Ap_out]
     D.msg_x = 6L * W;                           // boundary rows of the unknowns
     const size_t words = (size_t)std::max(std::max(D.msg, D.msg_iter), std::max(D.msg_x, 64L));
-    if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory"); return -1; }
-    if (D.ctl.alloc(THALLO_DIST_CTL_WORDS * sizeof(unsigned)) || hipMemset(D.ctl.ptr, 0, THALLO_DIST_CTL_WORDS * sizeof(unsigned)) != hipSuccess) return -1;
+    if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }   // (rank-local: nothing to agree through yet)
+    // ---- r, z, r', Ap, Ap' in ONE block (peers map it; pack / unpack address r and z through one base)
+    const size_t block_bytes = (size_t)5 * D.na * sizeof(float);
+    bool mem = true;
+    if (D.want_p2p) {
+        if (thallo_hip_ipc_alloc2((long)block_bytes, &D.block, D.handle_block, &D.mem_kind[0]) < 0) { D.block = nullptr; D.want_p2p = false; }
+        else D.block_ipc = true;
+    }
+    if (!D.block) {
+        if (hipMalloc(&D.block, block_bytes) != hipSuccess) { D.block = nullptr; mem = false; }
+        else if (hipMemset(D.block, 0, block_bytes) != hipSuccess) mem = false;
+    }
+    if (mem) {
+        for (int i : { 1, 2, 3 }) bufs_[i]->release();                 // the constructor's r, z, Ap
+        float* b = (float*)D.block;
+        v_.r = b; v_.z = b + D.na; v_.r2 = b + 2 * D.na; v_.Ap = b + 3 * D.na; v_.Ap2 = b + 4 * D.na;
+        if (ensure_iter_buffers()) mem = false;
+    }
+    if (mem && (D.ctl.alloc(THALLO_DIST_CTL_WORDS * sizeof(unsigned)) || hipMemset(D.ctl.ptr, 0, THALLO_DIST_CTL_WORDS * sizeof(unsigned)) != hipSuccess)) mem = false;
+    {   bool all_mem = false;
+        if (dist_agree(mem, all_mem)) return -1;                         // every rank has its vectors, or every rank returns the error
+        if (!all_mem) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
+    }
     // ---- device-side exchange: mailbox, peers' mailboxes, the neighbours' blocks
     bool all = false;
     if (dist_agree(D.want_p2p, all)) return -1;                          // (also the first use of the caller's all-gather: fails here, not mid-solve)
@@ -270,18 +304,31 @@ int Plan::dist_map_peers()
 }
 
 float Plan::dist_cost()
-{   // local partials -> one word per rank -> all-gather -> rank-ordered sum on the host (the read-back blocks anyway, gauss_newton.t:1128-1136)
+{   // local partials -> [cost, failure flag] per rank -> all-gather -> rank-ordered sum on the host (the read-back blocks anyway, gauss_newton.t:1128-1136).
+    // This is also where a rank-local failure becomes everybody's: any rank's flag (or a poisoned, non-finite word) makes EVERY rank report the error
+    // and leave the plan not ready, so the next Thallo_ProblemStep returns 0 on all of them.
     DistState& D = *dist_;
     hipStream_t s = ctx.stream;
-    const int nb = plugin->cost(ctx, slot(0));
-    if (nb < 0) { set_error("cost kernel launch failed (%d)", nb); return NAN; }
-    set_nb(0, nb);
-    thallo_hip_finish_sum(sum(0), (float*)D.send.ptr, s);
-    if (dist_allgather(D.send.ptr, D.gath.ptr, sizeof(float))) return NAN;
-    float part[THALLO_DIST_MAX_WORLD];
-    if (hipMemcpyAsync(part, D.gath.ptr, sizeof(float) * D.cfg.world, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { set_error("distributed: cost read-back failed"); return NAN; }
+    int nb = 0;
+    if (!D.failed) { nb = plugin->cost(ctx, slot(0)); if (nb < 0) dist_fail("cost kernel launch failed (%d)", nb); }
+    if (!D.failed) { set_nb(0, nb); DLOCAL(thallo_hip_finish_sum(sum(0), (float*)D.send.ptr, s), "cost sum"); }
+    DCOPY(hipMemsetAsync((float*)D.send.ptr + 1, 0, sizeof(float), s), "cost message");                 // word 1: 0 = healthy (a failed rank's header is poisoned: NaN)
+    if (dist_allgather(D.send.ptr, D.gath.ptr, 2 * sizeof(float))) return NAN;
+    float part[2 * THALLO_DIST_MAX_WORLD];
+    if (hipMemcpyAsync(part, D.gath.ptr, 2 * sizeof(float) * D.cfg.world, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { set_error("distributed: cost read-back failed"); return NAN; }
     float f = 0.0f;
-    for (int r = 0; r < D.cfg.world; ++r) f += part[r];
+    int bad_rank = -1;
+    for (int r = 0; r < D.cfg.world; ++r) {
+        f += part[2 * r];
+        if (!(part[2 * r + 1] == 0.0f) && bad_rank < 0) bad_rank = r;
+    }
+    if (bad_rank >= 0) {
+        const std::string mine = D.failed ? last_error() : "";
+        if (D.failed) set_error("distributed: this rank failed (%s); every rank stops", mine.c_str());
+        else set_error("distributed: rank %d reported a failure; every rank stops", bad_rank);
+        ready_ = false; D.stopped = true;
+        return NAN;
+    }
     return f;
 }
 
@@ -293,25 +340,27 @@ int Plan::dist_gn(int L, bool p2p)
     float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
     unsigned char* flags = plugin->slab_flags();
     cur_ = 0;
-    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
-    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
-    set_nb(B, nb);
+    int nb = 0;
+    if (!D.failed) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); if (nb < 0) dist_fail("PCGInit1 launch failed (%d)", nb); }
+    if (!D.failed) set_nb(B, nb);
     {   // alphaN_0 over all ranks; ghost rows of r and z; and the flags byte of the ghost rows (M^-1 of a ghost pixel depends on rows this rank
         // does not hold, so its owner supplies it)
         TimedLaunch t(ctx, "SlabExchangeInit");
-        if (thallo_hip_slab_pack(v_.r, D.seg_first_last, partial_sum(B), send, s) < 0) return -1;
+        DLOCAL(thallo_hip_slab_pack(v_.r, D.seg_first_last, partial_sum(B), send, s), "slab pack");
         unsigned char* fsend = (unsigned char*)(send + 1 + 12L * W);
-        if (hipMemcpyAsync(fsend, flags + (long)W * D.row0, W, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(fsend + W, flags + (long)W * (D.row1 - 1), W, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        DCOPY(hipMemcpyAsync(fsend, flags + (long)W * D.row0, W, hipMemcpyDeviceToDevice, s), "flags row copy");
+        DCOPY(hipMemcpyAsync(fsend + W, flags + (long)W * (D.row1 - 1), W, hipMemcpyDeviceToDevice, s), "flags row copy");
         if (dist_allgather(send, gath, D.msg * (long)sizeof(float))) return -1;
         const float* src_top = D.top ? gath + (rank - 1) * D.msg + 1 + 6L * W : nullptr;      // the LAST owned row of rank-1
         const float* src_bot = D.bot ? gath + (rank + 1) * D.msg + 1 : nullptr;               // the FIRST owned row of rank+1
-        if (thallo_hip_slab_unpack(v_.r, D.seg_top, src_top, D.seg_bot, src_bot, gath, D.msg, world, scal(B), s) < 0) return -1;
-        fin_[B] = 1;
-        if (D.top && hipMemcpyAsync(flags + (long)W * (D.row0 - 1), (const unsigned char*)(gath + (rank - 1) * D.msg + 1 + 12L * W) + W, W, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-        if (D.bot && hipMemcpyAsync(flags + (long)W * D.row1, (const unsigned char*)(gath + (rank + 1) * D.msg + 1 + 12L * W), W, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        DLOCAL(thallo_hip_slab_unpack(v_.r, D.seg_top, src_top, D.seg_bot, src_bot, gath, D.msg, world, scal(B), s), "slab unpack");
+        if (!D.failed) fin_[B] = 1;
+        if (D.top) DCOPY(hipMemcpyAsync(flags + (long)W * (D.row0 - 1), (const unsigned char*)(gath + (rank - 1) * D.msg + 1 + 12L * W) + W, W, hipMemcpyDeviceToDevice, s), "ghost flags copy");
+        if (D.bot) DCOPY(hipMemcpyAsync(flags + (long)W * D.row1, (const unsigned char*)(gath + (rank + 1) * D.msg + 1 + 12L * W), W, hipMemcpyDeviceToDevice, s), "ghost flags copy");
     }
-    if (p2p && thallo_hip_dist_begin_step(D.d, s) < 0) return -1;        // seq += 1: this GN step's granules
+    // seq += 1: this GN step's granules.  (A rank that failed sends none: its peers' bounded waits run out, their error word is set, they fall through
+    // to the collectives below and learn the cause at the next cost evaluation.)
+    if (p2p) DLOCAL(thallo_hip_dist_begin_step(D.d, s), "device-side exchange: begin step");
     // delta += alpha p every iteration on the device-side transport: its "apply two" kernel variant (peer stores on top of 256 VGPRs) spills, and at
     // slab sizes the 6 B/pixel it would save do not matter (2048x256: 22.6 vs 24.3 us per iteration).  (Either delta schedule gives the same bits -- tested
     // for both kernels; the marching kernel's multi-GPU variant is contracted differently from its single-GPU one, so its two TRANSPORTS agree to rounding.)
@@ -319,33 +368,36 @@ int Plan::dist_gn(int L, bool p2p)
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         const int mode = THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
-        const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
         if (p2p) {        // the kernel stores its boundary rows of Ap_out into the neighbours' ghost rows and its last workgroup IS the exchange
-            nb = plugin->pcg_iter_dist(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, D.d_iter[cur_ ^ 1], slot(jD), 7 * k, scal(jD), scal(jB));
-            if (nb < 0) { set_error("PCGIteration (device-side exchange) launch failed (%d)", nb); return -1; }
+            if (!D.failed) {
+                const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
+                nb = plugin->pcg_iter_dist(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, D.d_iter[cur_ ^ 1], slot(jD), 7 * k, scal(jD), scal(jB));
+                if (nb < 0) dist_fail("PCGIteration (device-side exchange) launch failed (%d)", nb);
+            }
         } else {
-            nb = plugin->pcg_iter(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, slot(jD), nullptr, nullptr);
-            if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return -1; }
-            TimedLaunch t(ctx, "SlabExchange");
             float* Ao = v_.Abuf(cur_ ^ 1);
-            if (thallo_hip_slab_pack_iter(Ao, D.seg_iter_fl, slot(jD), v_.s12, nb, send, s) < 0) return -1;
+            if (!D.failed) {
+                const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
+                nb = plugin->pcg_iter(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, slot(jD), nullptr, nullptr);
+                if (nb < 0) dist_fail("PCGIteration launch failed (%d)", nb);
+            }
+            TimedLaunch t(ctx, "SlabExchange");
+            DLOCAL(thallo_hip_slab_pack_iter(Ao, D.seg_iter_fl, slot(jD), v_.s12, nb, send, s), "slab pack");
             if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
             const float* src_top = D.top ? gath + (rank - 1) * D.msg_iter + 7 + 3L * W : nullptr;
             const float* src_bot = D.bot ? gath + (rank + 1) * D.msg_iter + 7 : nullptr;
-            if (thallo_hip_slab_unpack_iter(Ao, D.seg_iter_top, src_top, D.seg_iter_bot, src_bot, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
+            DLOCAL(thallo_hip_slab_unpack_iter(Ao, D.seg_iter_top, src_top, D.seg_iter_bot, src_bot, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s), "slab unpack");
         }
-        set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+        if (!D.failed) { set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
         cur_ ^= 1;
     }
-    last_l_iters = L;
-    linear_update_tail(L, batch);                                        // owned rows only
-    if (dist_exchange_unknown_rows()) return -1;
-    return 0;
+    if (!D.failed) { last_l_iters = L; linear_update_tail(L, batch); }   // owned rows only
+    return dist_exchange_unknown_rows();
 }
 
 int Plan::dist_exchange_unknown_rows()
-{
-    plugin->unknowns_changed();                                   // (ghost rows of the unknowns are about to be rewritten)   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
+{   // ghost rows of the unknowns <- the neighbours' boundary rows (once per GN step)
+    plugin->unknowns_changed();                                   // (ghost rows of the unknowns are about to be rewritten)
     DistState& D = *dist_;
     hipStream_t s = ctx.stream;
     const int rank = D.cfg.rank, g = D.ghost;
@@ -353,21 +405,23 @@ int Plan::dist_exchange_unknown_rows()
     TimedLaunch t(ctx, "SlabExchangeUnknowns");
     const auto& imgs = plugin->unknown_images();
     long pos = 0;
+    for (size_t k = 0; k < imgs.size(); ++k) pos += 2 * g * (imgs[k].n_floats / D.Hl);
+    if (pos > D.msg_x) { set_error("distributed: unknown rows exceed the message buffer"); return -1; }      // (a property of the plan: the same on every rank)
+    const long half = pos / 2;
+    long at = 0;
     for (int which = 0; which < 2; ++which)
         for (size_t k = 0; k < imgs.size(); ++k) {
             const long rowlen = imgs[k].n_floats / D.Hl;
             const long y = which == 0 ? D.row0 : D.row1 - g;
-            if (hipMemcpyAsync(send + pos, plugin->unknown_ptr((int)k) + rowlen * y, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-            pos += g * rowlen;
+            DCOPY(hipMemcpyAsync(send + at, plugin->unknown_ptr((int)k) + rowlen * y, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s), "unknown rows copy");
+            at += g * rowlen;
         }
-    const long half = pos / 2;
-    if (pos > D.msg_x) { set_error("distributed: unknown rows exceed the message buffer"); return -1; }
     if (dist_allgather(send, gath, pos * (long)sizeof(float))) return -1;
-    long at = 0;
+    at = 0;
     for (size_t k = 0; k < imgs.size(); ++k) {
         const long rowlen = imgs[k].n_floats / D.Hl;
-        if (D.top && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * (D.row0 - g), gath + (rank - 1) * pos + half + at, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-        if (D.bot && hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * D.row1, gath + (rank + 1) * pos + at, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+        if (D.top) DCOPY(hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * (D.row0 - g), gath + (rank - 1) * pos + half + at, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s), "ghost rows copy");
+        if (D.bot) DCOPY(hipMemcpyAsync(plugin->unknown_ptr((int)k) + rowlen * D.row1, gath + (rank + 1) * pos + at, g * rowlen * sizeof(float), hipMemcpyDeviceToDevice, s), "ghost rows copy");
         at += g * rowlen;
     }
     return 0;
@@ -379,10 +433,10 @@ int Plan::dist_sum_slot(int j)
     DistState& D = *dist_;
     hipStream_t s = ctx.stream;
     const thallo_segs_t none = segs({});
-    if (thallo_hip_finish_sum(partial_sum(j), (float*)D.send.ptr, s) < 0) return -1;
+    DLOCAL(thallo_hip_finish_sum(partial_sum(j), (float*)D.send.ptr, s), "partial sum");
     if (dist_allgather(D.send.ptr, D.gath.ptr, sizeof(float))) return -1;
-    if (thallo_hip_slab_unpack(nullptr, none, nullptr, none, nullptr, (const float*)D.gath.ptr, 1, D.cfg.world, scal(j), s) < 0) return -1;
-    fin_[j] = 1;
+    DLOCAL(thallo_hip_slab_unpack(nullptr, none, nullptr, none, nullptr, (const float*)D.gath.ptr, 1, D.cfg.world, scal(j), s), "rank-ordered sum");
+    if (!D.failed) fin_[j] = 1;
     return 0;
 }
 
@@ -393,12 +447,12 @@ int Plan::dist_sum_and_rows(int j, float* vec)
     float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
     const long gl = D.ghost * D.rowlen, msg = 1 + 2 * gl;
     const thallo_sum_t nothing = { nullptr, 0 };
-    if (thallo_hip_slab_pack(vec, D.seg_rows_fl, j >= 0 ? partial_sum(j) : nothing, send, s) < 0) return -1;
+    DLOCAL(thallo_hip_slab_pack(vec, D.seg_rows_fl, j >= 0 ? partial_sum(j) : nothing, send, s), "slab pack");
     if (dist_allgather(send, gath, msg * (long)sizeof(float))) return -1;
     const float* src_top = D.top ? gath + (D.cfg.rank - 1) * msg + 1 + gl : nullptr;          // the LAST rows of rank-1
     const float* src_bot = D.bot ? gath + (D.cfg.rank + 1) * msg + 1 : nullptr;               // the FIRST rows of rank+1
-    if (thallo_hip_slab_unpack(vec, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, msg, D.cfg.world, j >= 0 ? scal(j) : nullptr, s) < 0) return -1;
-    if (j >= 0) fin_[j] = 1;
+    DLOCAL(thallo_hip_slab_unpack(vec, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, msg, D.cfg.world, j >= 0 ? scal(j) : nullptr, s), "slab unpack");
+    if (j >= 0 && !D.failed) fin_[j] = 1;
     return 0;
 }
 
@@ -413,34 +467,34 @@ int Plan::dist_gn_flat(int L)
     const long oe = D.rowlen * (D.row0 - D.top), lene = D.rowlen * (D.row1 + D.bot - (D.row0 - D.top));
     const bool pc = plugin->use_preconditioner();
     cur_ = 0;
-    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
-    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
-    set_nb(B, nb);
+    int nb = 0;
+    if (!D.failed) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); if (nb < 0) dist_fail("PCGInit1 launch failed (%d)", nb); }
+    if (!D.failed) set_nb(B, nb);
     {   TimedLaunch t(ctx, "SlabExchangeInit");
         if (dist_sum_and_rows(B, v_.r)) return -1;                       // alphaN_0; ghost rows of r (p_0 = M^-1 r_0 there too)
         if (pc && dist_sum_and_rows(-1, v_.pre)) return -1;
     }
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        {   TimedLaunch t(ctx, "PCGUpdate");
-            if (thallo_hip_pcg_update(v_.r + oe, v_.Ap + oe, pc ? v_.pre + oe : nullptr, v_.p[cur_] + oe, v_.p[cur_ ^ 1] + oe, v_.delta + oe, lene, k == 0,
-                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return -1; }
+        if (!D.failed) {
+            {   TimedLaunch t(ctx, "PCGUpdate");
+                DLOCAL(thallo_hip_pcg_update(v_.r + oe, v_.Ap + oe, pc ? v_.pre + oe : nullptr, v_.p[cur_] + oe, v_.p[cur_ ^ 1] + oe, v_.delta + oe, lene, k == 0,
+                                             sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s), "PCGUpdate launch");
+            }
+            const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+            if (!D.failed) { nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_ ^ 1], v_.Ap, slot(jD), none); if (nb < 0) dist_fail("PCGStep1 launch failed (%d)", nb); }
+            if (!D.failed) set_nb(jD, nb);
         }
         cur_ ^= 1;
-        const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
-        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), none);
-        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return -1; }
-        set_nb(jD, nb);
         TimedLaunch t(ctx, "SlabExchange");
-        if (thallo_hip_slab_pack_iter(v_.Ap, D.seg_rows_fl, slot(jD), v_.s12, nb, send, s) < 0) return -1;
+        DLOCAL(thallo_hip_slab_pack_iter(v_.Ap, D.seg_rows_fl, slot(jD), v_.s12, nb, send, s), "slab pack");
         if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
         const float* src_top = D.top ? gath + (rank - 1) * D.msg_iter + 7 + gl : nullptr;
         const float* src_bot = D.bot ? gath + (rank + 1) * D.msg_iter + 7 : nullptr;
-        if (thallo_hip_slab_unpack_iter(v_.Ap, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
-        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+        DLOCAL(thallo_hip_slab_unpack_iter(v_.Ap, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s), "slab unpack");
+        if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
     }
-    last_l_iters = L;
-    linear_update_tail(L, false);
+    if (!D.failed) { last_l_iters = L; linear_update_tail(L, false); }
     return dist_exchange_unknown_rows();
 }
 
@@ -452,13 +506,14 @@ int Plan::dist_replicate(float* vec, int sum_slot)
     float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
     const thallo_sum_t nothing = { nullptr, 0 };
     const thallo_segs_t none = segs({});
-    if (thallo_hip_slab_pack(vec, D.pieces_mine, sum_slot >= 0 ? partial_sum(sum_slot) : nothing, send, s) < 0) return -1;
+    DLOCAL(thallo_hip_slab_pack(vec, D.pieces_mine, sum_slot >= 0 ? partial_sum(sum_slot) : nothing, send, s), "range pack");
     if (dist_allgather(send, gath, D.msg * (long)sizeof(float))) return -1;
     if (sum_slot >= 0) {
-        if (thallo_hip_slab_unpack(nullptr, none, nullptr, none, nullptr, gath, D.msg, D.cfg.world, scal(sum_slot), s) < 0) return -1;
-        fin_[sum_slot] = 1;
+        DLOCAL(thallo_hip_slab_unpack(nullptr, none, nullptr, none, nullptr, gath, D.msg, D.cfg.world, scal(sum_slot), s), "rank-ordered sum");
+        if (!D.failed) fin_[sum_slot] = 1;
     }
-    return thallo_hip_range_unpack(vec, D.pieces_first, gath, D.msg, 1, D.cfg.world, s) < 0 ? -1 : 0;
+    DLOCAL(thallo_hip_range_unpack(vec, D.pieces_first, gath, D.msg, 1, D.cfg.world, s), "range unpack");
+    return 0;
 }
 
 int Plan::dist_gn_range(int L)
@@ -473,34 +528,35 @@ int Plan::dist_gn_range(int L)
     const thallo_segs_t none = segs({});
     cur_ = 0;
     const size_t bytes = (size_t)v_.n_alloc * sizeof(float);
-    if (hipMemsetAsync(v_.p[0], 0, bytes, s) != hipSuccess || hipMemsetAsync(v_.delta, 0, bytes, s) != hipSuccess) return -1;      // (pcg_init clears the owned units only)
-    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
-    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
-    set_nb(B, nb);
+    DCOPY(hipMemsetAsync(v_.p[0], 0, bytes, s), "p clear");              // (pcg_init clears the owned units only)
+    DCOPY(hipMemsetAsync(v_.delta, 0, bytes, s), "delta clear");
+    int nb = 0;
+    if (!D.failed) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); if (nb < 0) dist_fail("PCGInit1 launch failed (%d)", nb); }
+    if (!D.failed) set_nb(B, nb);
     {   TimedLaunch t(ctx, "RangeExchangeInit");
         if (dist_replicate(v_.r, B)) return -1;                          // alphaN_0; r of every unit
         if (pc && dist_replicate(v_.pre, -1)) return -1;
     }
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        {   TimedLaunch t(ctx, "PCGUpdate");
-            if (thallo_hip_pcg_update(v_.r, v_.Ap, pc ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
-                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return -1; }
+        if (!D.failed) {
+            {   TimedLaunch t(ctx, "PCGUpdate");
+                DLOCAL(thallo_hip_pcg_update(v_.r, v_.Ap, pc ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
+                                             sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s), "PCGUpdate launch");
+            }
+            const thallo_fin_t nofin = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+            if (!D.failed) { nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_ ^ 1], v_.Ap, slot(jD), nofin); if (nb < 0) dist_fail("PCGStep1 launch failed (%d)", nb); }
+            if (!D.failed) set_nb(jD, nb);
         }
         cur_ ^= 1;
-        const thallo_fin_t nofin = { { nullptr, 0 }, nullptr, nullptr, nullptr };
-        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), nofin);
-        if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return -1; }
-        set_nb(jD, nb);
         TimedLaunch t(ctx, "RangeExchange");
-        if (thallo_hip_slab_pack_iter(v_.Ap, D.pieces_mine, slot(jD), v_.s12, nb, send, s) < 0) return -1;
+        DLOCAL(thallo_hip_slab_pack_iter(v_.Ap, D.pieces_mine, slot(jD), v_.s12, nb, send, s), "range pack");
         if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
-        if (thallo_hip_slab_unpack_iter(v_.Ap, none, nullptr, none, nullptr, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
-        if (thallo_hip_range_unpack(v_.Ap, D.pieces_first, gath, D.msg_iter, 7, world, s) < 0) return -1;
-        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+        DLOCAL(thallo_hip_slab_unpack_iter(v_.Ap, none, nullptr, none, nullptr, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s), "rank-ordered sums");
+        DLOCAL(thallo_hip_range_unpack(v_.Ap, D.pieces_first, gath, D.msg_iter, 7, world, s), "range unpack");
+        if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
     }
-    last_l_iters = L;
-    linear_update_tail(L, false);                                        // all unknowns on every rank: they stay replicated, bit for bit
+    if (!D.failed) { last_l_iters = L; linear_update_tail(L, false); }   // all unknowns on every rank: they stay replicated, bit for bit
     return 0;
 }
 
@@ -509,6 +565,7 @@ int Plan::dist_allreduce(float* buf, long count)
 {
     DistState& D = *dist_;
     if (D.cfg.world == 1) return 0;
+    if (D.failed) (void)hipMemsetAsync(buf, 0xFF, (size_t)(count < 8 ? count : 8) * sizeof(float), ctx.stream);      // poisons every rank's sum
     const int rc = D.cfg.allreduce(D.cfg.user, buf, count, (void*)ctx.stream);
     if (rc) set_error("distributed: the caller's all-reduce returned %d", rc);
     return rc;
@@ -528,77 +585,84 @@ int Plan::dist_gn_shard(int L)
     const bool pc = plugin->use_preconditioner();
     const thallo_segs_t none = segs({});
     cur_ = 0;
-    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));               // r = -J^T F and the RAW diagonal (v_.diag), both partial on the shared block
-    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return -1; }
+    int nb = 0;
+    if (!D.failed) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); if (nb < 0) dist_fail("PCGInit1 launch failed (%d)", nb); }     // r = -J^T F and the RAW diagonal (v_.diag), both partial on the shared block
     {   TimedLaunch t(ctx, "ShardExchangeInit");
         if (dist_allreduce(v_.r + off, len) || dist_allreduce(v_.diag + off, len)) return -1;
         // PCGInit1_Finish on the two blocks separately: pre = guardedInvert(diag), z = pre r, alphaN partials
-        const int nbc = thallo_hip_pcg_init_finish(v_.r, v_.diag, v_.pre, v_.z, off, pc ? 1 : 0, slot(B), s);
-        const int nbp = thallo_hip_pcg_init_finish(v_.r + off, v_.diag + off, v_.pre + off, v_.z + off, len, pc ? 1 : 0, sh_aD, s);
-        if (nbc < 0 || nbp < 0) return -1;
-        set_nb(B, nbc);
-        if (thallo_hip_finish_sum(partial_sum(B), send, s) < 0) return -1;
+        int nbp = 0;
+        if (!D.failed) {
+            const int nbc = thallo_hip_pcg_init_finish(v_.r, v_.diag, v_.pre, v_.z, off, pc ? 1 : 0, slot(B), s);
+            nbp = thallo_hip_pcg_init_finish(v_.r + off, v_.diag + off, v_.pre + off, v_.z + off, len, pc ? 1 : 0, sh_aD, s);
+            if (nbc < 0 || nbp < 0) dist_fail("PCGInit1_Finish launch failed (%d, %d)", nbc, nbp);
+            else { set_nb(B, nbc); DLOCAL(thallo_hip_finish_sum(partial_sum(B), send, s), "alphaN sum"); }
+        }
         if (dist_allgather(send, gath, sizeof(float))) return -1;
-        if (thallo_hip_shard_scalars(gath, 1, world, sh_aD, nullptr, nbp, thallo_sum_t{ nullptr, 0 }, scal(B), nullptr, s) < 0) return -1;      // alphaN_0
-        fin_[B] = 1;
+        DLOCAL(thallo_hip_shard_scalars(gath, 1, world, sh_aD, nullptr, nbp, thallo_sum_t{ nullptr, 0 }, scal(B), nullptr, s), "alphaN_0");
+        if (!D.failed) fin_[B] = 1;
     }
     const int cam_slots = plugin->shared_split_slots();
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        {   TimedLaunch t(ctx, "PCGUpdate");
-            if (thallo_hip_pcg_update(v_.r, v_.Ap, pc ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
-                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return -1; }
+        if (!D.failed) {
+            {   TimedLaunch t(ctx, "PCGUpdate");
+                DLOCAL(thallo_hip_pcg_update(v_.r, v_.Ap, pc ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
+                                             sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s), "PCGUpdate launch");
+            }
+            const thallo_fin_t nofin = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+            if (!D.failed) {
+                nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_ ^ 1], v_.Ap, slot(jD), nofin);
+                if (nb < 0 || cam_slots < 1 || cam_slots >= nb) dist_fail("PCGStep1 launch failed (%d)", nb);
+            }
+            if (!D.failed) set_nb(jD, nb);
         }
         cur_ ^= 1;
-        const thallo_fin_t nofin = { { nullptr, 0 }, nullptr, nullptr, nullptr };
-        nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), nofin);
-        if (nb < 0 || cam_slots < 1 || cam_slots >= nb) { set_error("PCGStep1 launch failed (%d)", nb); return -1; }
-        set_nb(jD, nb);
         TimedLaunch t(ctx, "ShardExchange");
         if (dist_allreduce(v_.Ap + off, len)) return -1;
-        const int nbp = thallo_hip_block_sums(v_.p[cur_] + off, v_.Ap + off, v_.r + off, pc ? v_.pre + off : nullptr, len, sh_aD, sh_s3, s);
-        if (nbp < 0) return -1;
-        if (thallo_hip_slab_pack_iter(v_.Ap, none, slot(jD), v_.s12, cam_slots, send, s) < 0) return -1;      // the camera launch's slots only
+        int nbp = 0;
+        if (!D.failed) { nbp = thallo_hip_block_sums(v_.p[cur_] + off, v_.Ap + off, v_.r + off, pc ? v_.pre + off : nullptr, len, sh_aD, sh_s3, s); if (nbp < 0) dist_fail("block sums launch failed (%d)", nbp); }
+        DLOCAL(thallo_hip_slab_pack_iter(v_.Ap, none, slot(jD), v_.s12, cam_slots, send, s), "shard pack");      // the camera launch's slots only
         if (dist_allgather(send, gath, 7 * (long)sizeof(float))) return -1;
-        if (thallo_hip_shard_scalars(gath, 7, world, sh_aD, sh_s3, nbp, sum(jN), scal(jD), scal(jB), s) < 0) return -1;
-        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+        DLOCAL(thallo_hip_shard_scalars(gath, 7, world, sh_aD, sh_s3, nbp, sum(jN), scal(jD), scal(jB), s), "shard scalars");
+        if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
     }
-    last_l_iters = L;
-    linear_update_tail(L, false);                                        // cameras of this rank + all points (replicated, bit for bit)
+    if (!D.failed) { last_l_iters = L; linear_update_tail(L, false); }   // cameras of this rank + all points (replicated, bit for bit)
     return 0;
 }
 
 int Plan::dist_self_check()
 {   // The device-side exchange is used only if, ON THIS TOPOLOGY, one GN step through it reproduces the all-gather path's alpha / beta
     // scalars from the same unknowns (a stale ghost row or a lost granule shows up there; the two paths round identically except for the
-    // order of the cross-rank additions), and no bounded wait timed out.  Every rank takes the same decision.
+    // order of the cross-rank additions), and no bounded wait timed out.  Every rank takes the same decision: a rank-local failure in here
+    // (memory, a copy, a launch) is a "no" in the agreement at the end, never an early return in front of the other ranks' collectives.
     DistState& D = *dist_;
     D.checked = true;
-    if (!D.mapped) { D.p2p_on = false; return 0; }
+    if (!D.mapped) { D.p2p_on = false; return 0; }                       // (agreed in dist_map_peers: the same on every rank)
     hipStream_t s = ctx.stream;
     const int Lc = std::max(1, std::min(6, sp.lIterations)), B = 2, nw = 2 * Lc + 1;
-    if (ensure_slots(std::max(Lc, sp.lIterations))) return -1;
+    if (ensure_slots(std::max(Lc, sp.lIterations))) dist_fail("out of device memory for the reduction slots");
     const auto& imgs = plugin->unknown_images();
     std::vector<DeviceBuffer> keep(imgs.size());
     auto restore = [&](bool save) {
-        for (size_t k = 0; k < imgs.size(); ++k) {
+        for (size_t k = 0; k < imgs.size() && !D.failed; ++k) {
             const size_t bytes = imgs[k].n_floats * sizeof(float);
-            if (save && keep[k].alloc(bytes)) return -1;
-            if (hipMemcpyAsync(save ? keep[k].ptr : (void*)plugin->unknown_ptr((int)k), save ? (void*)plugin->unknown_ptr((int)k) : keep[k].ptr, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+            if (save && keep[k].alloc(bytes)) { dist_fail("out of device memory for the self-check's copy of the unknowns"); break; }
+            DCOPY(hipMemcpyAsync(save ? keep[k].ptr : (void*)plugin->unknown_ptr((int)k), save ? (void*)plugin->unknown_ptr((int)k) : keep[k].ptr, bytes, hipMemcpyDeviceToDevice, s), "unknowns copy");
         }
-        return 0;
     };
     const unsigned spin_ms = 500;       // a topology where granules never become visible costs 0.5 s here, not the production bound
     const unsigned zero = 0;
-    std::vector<float> ref(nw), got(nw);
-    bool ok = restore(true) == 0;
-    ok = ok && hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &spin_ms, sizeof(unsigned), hipMemcpyHostToDevice, s) == hipSuccess;
-    ok = ok && dist_gn(Lc, false) == 0;
-    ok = ok && hipMemcpyAsync(ref.data(), scal(B), nw * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-    ok = ok && restore(false) == 0;
-    ok = ok && dist_gn(Lc, true) == 0;
-    ok = ok && hipMemcpyAsync(got.data(), scal(B), nw * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-    int err = ok ? thallo_hip_dist_error(D.d, 1, s) : -1;
+    std::vector<float> ref(nw, 0.0f), got(nw, 1.0f);
+    restore(true);
+    DCOPY(hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &spin_ms, sizeof(unsigned), hipMemcpyHostToDevice, s), "spin bound");
+    if (dist_gn(Lc, false)) return -1;
+    if (!D.failed) DCOPY(hipMemcpyAsync(ref.data(), scal(B), nw * sizeof(float), hipMemcpyDeviceToHost, s), "scalar read-back");
+    DCOPY(hipStreamSynchronize(s), "synchronise");
+    restore(false);
+    if (dist_gn(Lc, true)) return -1;
+    if (!D.failed) DCOPY(hipMemcpyAsync(got.data(), scal(B), nw * sizeof(float), hipMemcpyDeviceToHost, s), "scalar read-back");
+    DCOPY(hipStreamSynchronize(s), "synchronise");
+    int err = !D.failed ? thallo_hip_dist_error(D.d, 1, s) : -1;
     unsigned pm[5] = { 0, 0, 0, 0, 0 };
     hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
     restore(false);
@@ -609,7 +673,7 @@ int Plan::dist_self_check()
         const double e = std::fabs((double)got[i] - (double)ref[i]) / std::fmax(std::fabs((double)ref[i]), 1e-30);
         if (!(e <= rel)) rel = e;                                        // NaN-propagating max
     }
-    const bool pass = ok && err == 0 && rel <= 1e-3;
+    const bool pass = !D.failed && err == 0 && rel <= 1e-3;
     bool all = false;
     if (dist_agree(pass, all)) return -1;
     D.p2p_on = all;
@@ -619,7 +683,7 @@ int Plan::dist_self_check()
              all ? "p2p-mailbox" : "allgather", D.cfg.rank, D.cfg.world, D.mem_kind[0] == 1 ? "fine-grained" : "coarse-grained", D.mem_kind[1] == 1 ? "fine-grained" : "coarse-grained",
              Lc, err, rel, pass ? "true" : "false", all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
     D.info = buf;
-    return 0;
+    return 0;                                                            // (a rank that failed in here says so at the cost evaluation that follows in Init)
 }
 
 int Plan::step_gn_slab(int ev_iter)
@@ -629,6 +693,7 @@ int Plan::step_gn_slab(int ev_iter)
     const int L = sp.lIterations;
     const int ev_lin = timer_.start("Linear Solve", s);
     const bool p2p = D.p2p_on && L <= D.mail_L;                          // (same L on every rank: same decision)
+    // (nonzero only when the collective itself failed; a rank-local failure leaves this rank in step with the others until the next cost evaluation)
     if (D.shard ? dist_gn_shard(L) : D.range ? dist_gn_range(L) : D.flat ? dist_gn_flat(L) : dist_gn(L, p2p)) return 0;
     timer_.stop(ev_lin, s);
     sp.nIter++;
@@ -641,6 +706,7 @@ int Plan::dist_control(int what, int value)
     if (!dist_) return -1;
     DistState& D = *dist_;
     if (what == 0) return D.mapped ? thallo_hip_dist_error(D.d, value ? 1 : 0, ctx.stream) : 0;
+    if (what == 2) { D.inject = value; return 0; }
     if (what == 1) {
         if (value == 0 && D.p2p_on) {
             D.p2p_on = false;

@@ -337,6 +337,26 @@ int thallo_hip_iw_pcg_iter_march_deferred(int W, int H, int row0, int row1, cons
 /* *count_out (device int) = number of pixels whose right / down UrShape neighbour is not at the exact unit offset (0 = pixel grid) */
 int thallo_hip_iw_urshape_irregular(int W, int H, const float* urshape, int* count_out, thallo_stream_t stream);
 void thallo_hip_march_debug_set(int what, int value);     /* tools / tests only: 0 rows per wave segment, 1 prefetch depth, 2 non-temporal mask, 6 workgroup budget */
+/* ---- the PCG loop of a whole Gauss-Newton step in ONE launch (energy_image_warping_resident.hip), for images whose solver state fits the chip's
+ * registers: a wave keeps r, p, A p of its pixels in registers (delta in LDS) for all L iterations; per iteration the boundary of A p goes to the four
+ * neighbouring waves and the workgroup's sums to every workgroup as 8-byte {value | tag} granules, no launch boundary, no grid barrier.  Same geometry,
+ * arithmetic and summation order as thallo_hip_iw_pcg_iter_march with the same rows per segment: bit-identical r, p, delta, A p, alpha, beta.
+ * Replaces gauss_newton.t:1615-1687 for these shapes. */
+/* rows per wave segment (1..6), or 0: does not fit (the caller runs one launch per PCG iteration).  Host logic, no launch. */
+int  thallo_hip_iw_resident_rows(int W, int rows);
+/* bytes of exchange memory (granule buffers + control words) a plan must hand to the calls below, zeroed once */
+long thallo_hip_iw_resident_bytes(int W, int rows);
+/* L >= 1 iterations from what thallo_hip_iw_pcg_init left (r_0 in r_in; zeros in p_in and delta; cs, flags; alphaN_0).  Leaves what L launches of
+ * the marching kernel leave: r_{L-1}, A p_{L-1}, p_{L-1} in r_out / Ap_out / p_out, delta without its last term (thallo_hip_linear_update adds it), and
+ * words[2k] = alphaD_k, words[2k + 1] = betaN_k.  Whole images only (row0 = 0, row1 = H).  Returns the workgroup count, -hipErrorNotSupported when the
+ * shape does not fit, another negative hipError_t on failure.  Every wait inside is bounded (2 s by default): see thallo_hip_iw_resident_status. */
+int  thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
+                                thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, int L, thallo_stream_t stream);
+/* error word of the plan's resident launches (1 = a bounded wait ran out: results void); clear != 0 resets it; spin_ms >= 0 sets the bound in
+ * milliseconds (0 = default); pm: 5 words of post-mortem or NULL.  Synchronises the stream. */
+int  thallo_hip_iw_resident_status(int W, int rows, void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream);
+void thallo_hip_resident_debug_set(int what, int value);    /* tools / tests only: 0 rows per wave segment, 1 workgroup budget */
 /* rows per wave segment the marching kernels use on `rows` owned rows of a W-wide image; 0 = more column strips than the device has workgroup
  * slots: the marching entry points return -hipErrorNotSupported, the caller stays on thallo_hip_iw_pcg_iter (host logic, no launch) */
 int thallo_hip_iw_march_rows(int W, int rows);

@@ -149,12 +149,16 @@ def test_reduction_order_is_the_documented_one(torch, nb):
 
 
 # ------------------------------------------------------------------ image_warping trajectories
-@pytest.mark.parametrize("kernel", ["march", "tile"])
+@pytest.mark.parametrize("kernel", ["resident", "march", "tile"])
 @pytest.mark.parametrize("W,H,nit,lit", [(64, 64, 8, 100), (96, 80, 5, 40), (70, 33, 4, 25), (256, 256, 4, 50), (1, 1, 2, 3), (130, 3, 3, 10), (252, 41, 3, 20)])
 def test_image_warping_cost_trajectory(torch, orc, monkeypatch, W, H, nit, lit, kernel):
-    """Both one-kernel PCG iterations against the oracle at every size: the plugin picks the marching kernel from ~0.4 Mpixel up and the
-    LDS-tiled one below (plugins.cpp ImageWarpingPlugin::prepare); THALLO_MARCH=2 / 0 force one or the other (odd W always tiles)."""
-    monkeypatch.setenv("THALLO_MARCH", "2" if kernel == "march" else "0")
+    """All three forms of the PCG loop against the oracle at every size.  By default the plugin runs the resident kernel (the whole loop in one launch,
+    energy_image_warping_resident.hip) wherever the image fits the chip's registers -- every size here but the odd width; with THALLO_RESIDENT=0 one launch per
+    PCG iteration: the marching kernel from ~0.4 Mpixel up, the LDS-tiled one below (plugins.cpp ImageWarpingPlugin::prepare); THALLO_MARCH=2 / 0 force one or
+    the other (odd W always tiles)."""
+    if kernel != "resident":
+        monkeypatch.setenv("THALLO_RESIDENT", "0")
+        monkeypatch.setenv("THALLO_MARCH", "2" if kernel == "march" else "0")
     p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
     po = copy_params(p)
     co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), po).solve(nIterations=nit, lIterations=lit)
@@ -167,6 +171,46 @@ def test_image_warping_cost_trajectory(torch, orc, monkeypatch, W, H, nit, lit, 
     # excluded (masked) pixels are never touched (image_warping.t:14-15)
     m = p[4] != 0
     assert (to_host(dev[0])[m] == p[0][m]).all() and (to_host(dev[1])[m] == p[1][m]).all()
+
+
+@pytest.mark.parametrize("W,H,lit", [(512, 512, 100), (2048, 256, 40), (256, 256, 30), (640, 480, 25), (130, 7, 12), (124, 64, 9), (250, 2, 5), (126, 130, 7)])
+def test_resident_pcg_loop_is_bitwise_the_marching_kernel(torch, monkeypatch, W, H, lit):
+    """the whole PCG loop of a GN step in ONE launch -- r, p, A p in registers, the boundary of A p to the four neighbouring waves and
+    the workgroup sums to every workgroup as tagged 8-byte granules, no launch boundary and no grid barrier.  Same geometry, arithmetic and summation order as
+    one launch of the marching kernel per iteration with the same rows per segment: costs, every alpha_k / beta_k and the unknowns must be BIT-identical
+    after three GN steps (512^2 = BASELINE config 1, 2048 x 256 = one rank's slab of the 8-GPU benchmark; ragged strips, short last segments, one- and
+    two-strip images, a 2-row image)."""
+    L = thallo_amd.lib()
+    L.thallo_hip_iw_resident_rows.restype = C.c_int
+    R = L.thallo_hip_iw_resident_rows(W, H)
+    assert 1 <= R <= 6
+    p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
+    runs = []
+    for resident in (True, False):
+        monkeypatch.setenv("THALLO_RESIDENT", "1" if resident else "0")
+        monkeypatch.setenv("THALLO_MARCH", "2")
+        L.thallo_hip_march_debug_set(0, 0 if resident else R)
+        try:
+            dev = to_device(copy_params(p))
+            s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+            s.set_solver_parameters(nIterations=3, lIterations=lit)
+            params = s.make_params(dev)
+            s.init(params)
+            costs, traces = [s.current_cost()], []
+            while s.step(params):
+                costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+            names = s.kernel_stats()
+            s.close()
+        finally:
+            L.thallo_hip_march_debug_set(0, 0)
+        runs.append((costs, traces, dev[0].clone(), dev[1].clone(), names))
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == 4 and len(t0[0]) == lit
+    assert n0.get("PCGLoopResident", {}).get("launches") == 3 and "PCGIteration" not in n0, n0          # the resident kernel really ran: one launch per GN step
+    assert n1.get("PCGIteration", {}).get("launches") == 3 * lit and "PCGLoopResident" not in n1, n1
+    assert t0 == t1, [(i, k) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
 def test_image_warping_wider_than_the_workgroup_budget_runs_the_tile_kernel(torch, orc):

@@ -1,0 +1,548 @@
+// energy_image_warping_resident.hip -- the whole PCG loop of one Gauss-Newton step of image_warping in ONE launch, for working sets that fit
+// the register files of the chip (512^2, the 2048 x 256 slab of an 8-GPU run: BASELINE config 1 and the 1/8 slab of the benchmark).
+//
+// Why: at those sizes a launch per PCG iteration (energy_image_warping_march.hip, energy_image_warping.hip) is bounded by what sits BETWEEN the
+// arithmetic -- 2.7 us of launch boundary, a burst that loads r / Ap / p / cs / flags from L2, a burst that stores them again, a reduction tail --
+// 10.7 us per iteration at 512^2 and 16.4 us on the slab, of which ~2 us are arithmetic.  Here a wave keeps its pixels'
+// r, p, A p (and cos / sin / M^-1 / flags) in REGISTERS and delta in LDS for all L iterations; what moves per iteration is only what another
+// wave needs:
+//   * the boundary of A p_k (first / last row of a segment, lanes 1 / 62 of a strip) to the four neighbouring waves, as 8-byte
+//     {value | tag} granules in global memory (write-through, agent scope: MI355X_MICROARCH.md "handoff-1to1"; the data IS the flag);
+//   * the workgroup's four sums {alphaD | N, S1, S2} to EVERY workgroup (7 granules per workgroup, swept by all: "allgather").
+// Both are published at the same point -- the end of the iteration's arithmetic -- and consumed at the same point -- in front of the next
+// iteration's r / p update -- so an iteration has ONE synchronisation point, and it is neighbour-and-scalars only: no grid barrier.  (Exchanging
+// A p_{k-1} instead of p_k is what makes that possible: p_k on the halo needs alpha / beta, i.e. the global sums, first; A p_{k-1} does not, and
+// r, p on the halo are then recomputed locally -- the same trick the multi-GPU slabs use for their ghost rows, solver_dist.cpp.)
+//
+// Geometry, arithmetic and summation order are the marching kernel's (a wave = a 124-pixel-wide column strip x R rows, lane l the pixels
+// x0 + 2l, x0 + 2l + 1, lanes 0 / 63 the x halo; workgroup = 4 stacked segments; the same per-lane accumulation order, wave butterfly, workgroup
+// sum and lane-strided sum of the per-workgroup partials), and both files are compiled with -ffp-contract=on (contraction decided per source
+// expression, never across statements): r, p, delta, A p and every alpha / beta come out bit-identical to the launch-per-iteration marching
+// kernel run with the same R (tests/test_gpu_parity.py).  Replaces gauss_newton.t:1615-1687 (the PCG loop) for these shapes.
+#include "iw_device.hpp"
+
+using namespace thallo;
+
+namespace {
+
+constexpr int RES_USE = 124;              // output pixels per wave row (lanes 1..62 x 2)
+constexpr int RES_NT = 256;               // 4 waves = 4 vertically adjacent segments of one strip (one workgroup per CU)
+constexpr int RES_MAX_R = 6;              // rows per segment the kernel is instantiated for (register budget)
+
+inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
+
+typedef unsigned long long u64;
+__device__ __forceinline__ u64  ldg(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }       // global_load_dwordx2 sc1
+__device__ __forceinline__ void stg(u64* p, unsigned tag, unsigned v) { __hip_atomic_store(p, ((u64)tag << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stgf(u64* p, unsigned tag, float v) { stg(p, tag, __float_as_uint(v)); }
+
+__device__ __forceinline__ float from_left(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));   // wave_shr:1
+}
+__device__ __forceinline__ float from_right(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));   // wave_shl:1
+}
+__device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
+
+// one neighbour's contribution to (J^T J p)_i on the unit grid -- the marching kernel's nb_term, expression for expression
+template <int D>
+__device__ __forceinline__ void nb_term(bool valid, float ci, float si, float pxi, float pyi, float pai,
+                                        float pxj, float pyj, float paj, float cj, float sj, float& ax, float& ay, float& av)
+{
+    if (valid) {
+        const float gix = D == 0 ? si : D == 1 ? -si : D == 2 ? ci : -ci;
+        const float giy = D == 0 ? -ci : D == 1 ? ci : D == 2 ? si : -si;
+        const float gjx = D == 0 ? -sj : D == 1 ? sj : D == 2 ? -cj : cj;
+        const float gjy = D == 0 ? cj : D == 1 ? -cj : D == 2 ? -sj : sj;
+        const float dpx = pxi - pxj, dpy = pyi - pyj;
+        const float ex = dpx - gix * pai, ey = dpy - giy * pai;
+        ax += dpx + ex + gjx * paj;
+        ay += dpy + ey + gjy * paj;
+        av -= gix * ex + giy * ey;
+    }
+}
+
+}  // namespace
+
+// control words of a resident launch (device memory, RES_CTL_WORDS of them)
+enum { RES_SEQ = 0, RES_ERR = 1, RES_SPIN_MS = 2, RES_NEXT = 3, RES_PM = 4, RES_CTL_WORDS = 16 };
+
+struct ResGeo { int W, H, row0, row1, R, nstrips, nseg, nwgrow, total; };
+
+// exchange buffers of one plan (thallo_hip_iw_resident_bytes); parity = iteration & 1
+struct ResBufs {
+    u64* rowh;        // [2 parity][waves][2 sides: 0 = the wave's FIRST row (for the wave above), 1 = its LAST row (for the wave below)][6 components][64 lanes]
+    u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][RES_MAX_R rows][6 components]
+    u64* sums;        // [2 parity][7 words: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo][1024 workgroups]
+    unsigned* ctl;    // RES_CTL_WORDS
+};
+
+struct ResArgs {
+    ResGeo g; ResBufs b;
+    const float* cs; const unsigned char* flags; float wf2, wr2;
+    const float* r_in; const float* p_in;         // r_0 and p_{-1} (zeros): what PCGInit1 wrote
+    float* r_out; float* A_out; float* p_out;     // r_{L-1}, A p_{L-1}, p_{L-1}: what L launches of the marching kernel leave behind
+    float* delta;                                 // in: 0; out: sum_{k < L-1} alpha_k p_k (PCGLinearUpdate adds the last term, like behind the launches)
+    thallo_sum_t aN0;                             // alphaN_0
+    float* words;                                 // words[2k] = alphaD_k, words[2k + 1] = betaN_k  (the plan's scal(B + 2k + 1), scal(B + 2k + 2))
+    const int* irregular;
+    int L;
+};
+
+namespace {
+
+struct Spin { unsigned n; long long t0; };
+// bounded wait bookkeeping: true = give up (this wave or somebody else timed out; every later wait of the wave falls through at once)
+__device__ __forceinline__ bool spin_fail(Spin& sp, unsigned* ctl, unsigned what, unsigned idx, unsigned tag)
+{
+    __builtin_amdgcn_s_sleep(1);
+    if (((++sp.n) & 127u) != 0u) return false;
+    if (__hip_atomic_load(ctl + RES_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+    const long long now = wall_clock64();
+    if (sp.t0 == 0) { sp.t0 = now; return false; }
+    const unsigned ms = __hip_atomic_load(ctl + RES_SPIN_MS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long bound = ms ? (long long)ms * 100000LL : 2LL * 100000000LL;        // default: 2 s of the 100 MHz wall clock
+    if (now - sp.t0 <= bound) return false;
+    if ((threadIdx.x & 63) == 0 && __hip_atomic_exchange(ctl + RES_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        unsigned* pm = ctl + RES_PM;        // first timeout of the launch: what was waited for
+        pm[0] = what; pm[1] = blockIdx.x; pm[2] = threadIdx.x >> 6; pm[3] = idx; pm[4] = tag;
+    }
+    return true;
+}
+
+// LDS words shared by the four waves of a workgroup
+struct ResLds {
+    float2 lut[32];
+    unsigned qtag[4];                 // quarter-sweep exchange: wave w's column is complete for tag ...
+    unsigned wtag[4];                 // wave sums of an iteration are in place
+    unsigned q[4][7][64];             // per wave: the 7 words of the 64 slots it swept
+    float wa[4]; double wd[4][3];     // per wave: alphaD part, {N, S1, S2} parts
+};
+
+template <int R>
+__global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ResLds& S = *reinterpret_cast<ResLds*>(smem);
+    float* dl = reinterpret_cast<float*>(smem + ((sizeof(ResLds) + 15) & ~(size_t)15));      // delta: [R][6][256], a thread's own words only
+    const ResGeo g = a.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned* const ctl = a.b.ctl;
+
+    // workgroup -> (strip, first segment): the marching kernel's XCD-aware placement (workgroups b and b + 8 share an XCD)
+    const int grid = (int)gridDim.x;
+    const int G = (grid % 8) == 0 ? 8 : 1;
+    auto wg_id = [&](int b, long& id) { const int grp = b % G, l = b / G; const long lo = (long)g.total * grp / G, hi = (long)g.total * (grp + 1) / G; id = lo + l; return id < hi; };
+    long id;
+    if (!wg_id(blockIdx.x, id)) return;                                  // (a slot without rows: its sums are zeros, the sweeps know)
+    const bool writer = id == 0 && threadIdx.x == 0;                     // leaves alphaD_k / betaN_k behind as words
+    if (a.irregular != nullptr && __builtin_amdgcn_readfirstlane(a.irregular[0]) != 0) {      // not the unit pixel grid after all: poison, never the wrong Jacobian
+        if (writer) for (int k = 0; k < 2 * a.L; ++k) a.words[k] = __builtin_nanf("");
+        return;
+    }
+    if (threadIdx.x < 32) { float mo, ma; pre_from_flags((unsigned char)threadIdx.x, a.wf2, a.wr2, mo, ma); S.lut[threadIdx.x] = make_float2(mo, ma); }
+    if (threadIdx.x < 4) { S.qtag[threadIdx.x] = 0u; S.wtag[threadIdx.x] = 0u; }
+    __syncthreads();                                                      // (the only barrier of the launch)
+
+    const int strip = (int)(id % g.nstrips), seg = (int)(id / g.nstrips) * (RES_NT / 64) + wave;
+    int ya = g.row0 + seg * g.R, yb = ya + g.R;
+    if (yb > g.row1) yb = g.row1;
+    if (ya > g.row1) ya = g.row1;
+    const int nr = yb - ya;                                               // rows of this wave (0: a wave of the last workgroup row without a segment)
+    const int x0 = strip * RES_USE - 2 + 2 * lane;
+    const bool xin = x0 >= 0 && x0 < g.W;
+    const bool xout = xin && lane >= 1 && lane <= 62;
+    const long N = (long)g.W * g.H;
+    const int W2 = g.W >> 1;
+    const int xc = x0 < 0 ? 0 : x0 > g.W - 2 ? g.W - 2 : x0;
+    const unsigned seq = __hip_atomic_load(ctl + RES_SEQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // tag of iteration k: seq + k + 1
+
+    // ---- who my neighbours are (a neighbour exists = somebody publishes the granules I would wait for)
+    const int wid = strip * g.nseg + seg;                                 // wave id: (strip, segment)
+    const bool has_up = nr > 0 && seg > 0, has_dn = nr > 0 && yb < g.row1;
+    const bool has_lf = nr > 0 && strip > 0, has_rt = nr > 0 && strip + 1 < g.nstrips;        // (then lane 63's pixels -- x = 124 (strip + 1), + 1 -- are inside the image)
+    const long waves = (long)g.nstrips * g.nseg;
+    auto rowh = [&](int par, int w, int side, int c) { return a.b.rowh + ((((long)par * waves + w) * 2 + side) * 6 + c) * 64 + lane; };
+    auto colh = [&](int par, int w, int side, int j, int c) { return a.b.colh + ((((long)par * waves + w) * 2 + side) * RES_MAX_R + j) * 6 + c; };
+    auto sumw = [&](int par, int c, int slot) { return a.b.sums + ((long)par * 7 + c) * THALLO_MAX_PARTIALS + slot; };
+
+    // ---- state: rows t = ya - 1 + jj, jj = 0 .. R + 1 (jj = 0 and jj = nr + 1: the y halo; lanes 0 / 63: the x halo)
+    float rx[R + 2][2], ry[R + 2][2], ra[R + 2][2], px[R + 2][2], py[R + 2][2], pa[R + 2][2], ax[R + 2][2], ay[R + 2][2], av[R + 2][2];
+    float cc[R + 2][2], ss[R + 2][2], mo[R + 2][2], ma[R + 2][2];
+    unsigned fl[R + 2];
+    const float4* ro4 = reinterpret_cast<const float4*>(a.r_in); const float2* ra2 = reinterpret_cast<const float2*>(a.r_in + 2 * N);
+    const float4* po4 = reinterpret_cast<const float4*>(a.p_in); const float2* pa2 = reinterpret_cast<const float2*>(a.p_in + 2 * N);
+    const float4* cs4 = reinterpret_cast<const float4*>(a.cs);
+    const unsigned* f4 = reinterpret_cast<const unsigned*>(a.flags);
+    float4* dl4 = reinterpret_cast<float4*>(a.delta); float2* dl2 = reinterpret_cast<float2*>(a.delta + 2 * N);
+#pragma unroll
+    for (int jj = 0; jj < R + 2; ++jj) {
+        const int t = ya - 1 + jj;
+        const bool ok = nr > 0 && jj <= nr + 1 && xin && t >= 0 && t < g.H;
+        const int tc = t < 0 ? 0 : t > g.H - 1 ? g.H - 1 : t;
+        const long i2 = (long)tc * W2 + (xc >> 1);
+        const float4 r4 = ro4[i2]; const float2 r2 = ra2[i2]; const float4 p4 = po4[i2]; const float2 p2 = pa2[i2]; const float4 c4 = cs4[i2];
+        const unsigned fw = f4[i2 >> 1];
+        const unsigned f = ok ? (fw >> ((((long)t * W2 + (x0 >> 1)) & 1) != 0 ? 16 : 0)) & 0xffffu : 0u;
+        fl[jj] = f;
+        const float2 m0 = S.lut[f & 31u], m1 = S.lut[(f >> 8) & 31u];
+        mo[jj][0] = m0.x; mo[jj][1] = m1.x; ma[jj][0] = m0.y; ma[jj][1] = m1.y;
+        rx[jj][0] = r4.x; ry[jj][0] = r4.y; rx[jj][1] = r4.z; ry[jj][1] = r4.w; ra[jj][0] = r2.x; ra[jj][1] = r2.y;
+        px[jj][0] = p4.x; py[jj][0] = p4.y; px[jj][1] = p4.z; py[jj][1] = p4.w; pa[jj][0] = p2.x; pa[jj][1] = p2.y;
+        cc[jj][0] = c4.x; ss[jj][0] = c4.y; cc[jj][1] = c4.z; ss[jj][1] = c4.w;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { ax[jj][q] = 0.f; ay[jj][q] = 0.f; av[jj][q] = 0.f; }
+        if (jj >= 1 && jj <= R) {       // delta of my rows into LDS
+            const int j = jj - 1;
+            const bool mine = j < nr && xout;
+            float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f); float2 d2 = make_float2(0.f, 0.f);
+            if (mine) { const long i = (long)t * W2 + (x0 >> 1); d4 = dl4[i]; d2 = dl2[i]; }
+            float* d = dl + (j * 6) * RES_NT + threadIdx.x;
+            d[0] = d4.x; d[RES_NT] = d4.y; d[2 * RES_NT] = d4.z; d[3 * RES_NT] = d4.w; d[4 * RES_NT] = d2.x; d[5 * RES_NT] = d2.y;
+        }
+    }
+
+    const float aN0 = sum_partials(a.aN0.partials, a.aN0.count);
+    float aN_prev = aN0;                  // alphaN_{k-1}
+    float alpha = 0.0f, beta = 0.0f;
+    Spin sp; sp.n = 0; sp.t0 = 0;
+    bool dead = false;                    // a bounded wait ran out (here or elsewhere): no more waiting, the host raises
+
+    // The sums of iteration k (tag T): every wave sweeps the 64 slots 64 w + lane, the four waves exchange their columns through LDS, and every wave adds
+    // them up in the order the launch-per-iteration path uses (lane-strided over the slots, then the wave butterfly): alphaD_k, betaN_k -- same bits everywhere.
+    auto finish_scalars = [&](unsigned T, int par, float aN, float& aD_o, float& bN_o) {
+        const int slot = 64 * wave + lane;
+        long sid;
+        const bool live = slot < grid && wg_id(slot, sid);
+        unsigned w7[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) w7[c] = 0u;
+        if (live) {
+            bool ok = false;
+            sp.n = 0; sp.t0 = 0;
+            while (!ok && !dead) {
+                ok = true;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) { const u64 v = ldg(sumw(par, c, slot)); w7[c] = (unsigned)v; ok = ok && (unsigned)(v >> 32) == T; }
+                if (!ok && spin_fail(sp, ctl, 1u, (unsigned)slot, T)) dead = true;
+            }
+        }
+        // (lanes that finished wait here for the others of the wave: reconvergence)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) S.q[wave][c][lane] = w7[c];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&S.qtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sp.n = 0; sp.t0 = 0;
+        for (int w = 0; w < 4; ++w)
+            while (!dead && __hip_atomic_load(&S.qtag[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != T) { if (spin_fail(sp, ctl, 2u, (unsigned)w, T)) dead = true; }
+        dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+        float t = 0.0f; double n = 0.0, a1 = 0.0, b1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned* qq = &S.q[w][0][lane];
+            t += __uint_as_float(qq[0]);
+            n += __hiloint2double((int)qq[64], (int)qq[128]);
+            a1 += __hiloint2double((int)qq[192], (int)qq[256]);
+            b1 += __hiloint2double((int)qq[320], (int)qq[384]);
+        }
+        const float ad = wave_sum_all(t);
+        n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
+        const float al = safe_div<false>(aN, ad);
+        double bd = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
+        if (!(bd > 0.0)) bd = 0.0;
+        aD_o = ad; bN_o = (float)bd;
+    };
+
+    for (int k = 0; k < a.L; ++k) {
+        const unsigned T = seq + (unsigned)k + 1u, Tp = T - 1u;
+        const int par = k & 1, parp = par ^ 1;
+        if (k > 0) {
+            // ---- the one synchronisation point: sums of iteration k-1 from every workgroup, A p_{k-1} on my halo from my four neighbours
+            float aD, bN;
+            finish_scalars(Tp, parp, aN_prev, aD, bN);
+            alpha = safe_div<false>(aN_prev, aD);
+            beta = safe_div<false>(bN, aN_prev);
+            if (writer) { a.words[2 * (k - 1)] = aD; a.words[2 * (k - 1) + 1] = bN; }
+            aN_prev = bN;
+            // y halo: the LAST row of the wave above lands in row jj = 0, the FIRST row of the wave below in row jj = nr + 1 (lanes 1..62)
+            if (xout && (has_up || has_dn)) {
+                bool ok = false;
+                sp.n = 0; sp.t0 = 0;
+                float up[6], dn[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { up[c] = 0.f; dn[c] = 0.f; }
+                while (!ok && !dead) {
+                    ok = true;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        if (has_up) { const u64 v = ldg(rowh(parp, wid - 1, 1, c)); up[c] = __uint_as_float((unsigned)v); ok = ok && (unsigned)(v >> 32) == Tp; }
+                        if (has_dn) { const u64 v = ldg(rowh(parp, wid + 1, 0, c)); dn[c] = __uint_as_float((unsigned)v); ok = ok && (unsigned)(v >> 32) == Tp; }
+                    }
+                    if (!ok && spin_fail(sp, ctl, 3u, (unsigned)wid, Tp)) dead = true;
+                }
+                if (has_up) { ax[0][0] = up[0]; ay[0][0] = up[1]; av[0][0] = up[2]; ax[0][1] = up[3]; ay[0][1] = up[4]; av[0][1] = up[5]; }
+                if (has_dn) {
+#pragma unroll
+                    for (int jj = 2; jj < R + 2; ++jj)
+                        if (jj == nr + 1) { ax[jj][0] = dn[0]; ay[jj][0] = dn[1]; av[jj][0] = dn[2]; ax[jj][1] = dn[3]; ay[jj][1] = dn[4]; av[jj][1] = dn[5]; }
+                }
+            }
+            // x halo: lane 0 takes lane 62's pixels of the strip to the left, lane 63 lane 1's pixels of the strip to the right, for each of my rows
+            if ((lane == 0 && has_lf) || (lane == 63 && has_rt)) {
+                const int w = lane == 0 ? wid - g.nseg : wid + g.nseg, side = lane == 0 ? 1 : 0;
+                bool ok = false;
+                sp.n = 0; sp.t0 = 0;
+                while (!ok && !dead) {
+                    ok = true;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        if (j < nr) {
+                            u64 v[6];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) { v[c] = ldg(colh(parp, w, side, j, c)); ok = ok && (unsigned)(v[c] >> 32) == Tp; }
+                            ax[j + 1][0] = __uint_as_float((unsigned)v[0]); ay[j + 1][0] = __uint_as_float((unsigned)v[1]); av[j + 1][0] = __uint_as_float((unsigned)v[2]);
+                            ax[j + 1][1] = __uint_as_float((unsigned)v[3]); ay[j + 1][1] = __uint_as_float((unsigned)v[4]); av[j + 1][1] = __uint_as_float((unsigned)v[5]);
+                        }
+                    }
+                    if (!ok && spin_fail(sp, ctl, 4u, (unsigned)w, Tp)) dead = true;
+                }
+            }
+            dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+        }
+        // ---- r_k = r_{k-1} - alpha A p_{k-1} ; delta += alpha p_{k-1} ; p_k = M^-1 r_k + beta p_{k-1}     (every row I hold, halo included)
+#pragma unroll
+        for (int jj = 0; jj < R + 2; ++jj) {
+            if (k > 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    rx[jj][q] = __builtin_fmaf(-alpha, ax[jj][q], rx[jj][q]); ry[jj][q] = __builtin_fmaf(-alpha, ay[jj][q], ry[jj][q]);
+                    ra[jj][q] = __builtin_fmaf(-alpha, av[jj][q], ra[jj][q]);
+                }
+                if (jj >= 1 && jj <= R) {
+                    float* d = dl + ((jj - 1) * 6) * RES_NT + threadIdx.x;
+                    d[0] = __builtin_fmaf(alpha, px[jj][0], d[0]); d[RES_NT] = __builtin_fmaf(alpha, py[jj][0], d[RES_NT]);
+                    d[2 * RES_NT] = __builtin_fmaf(alpha, px[jj][1], d[2 * RES_NT]); d[3 * RES_NT] = __builtin_fmaf(alpha, py[jj][1], d[3 * RES_NT]);
+                    d[4 * RES_NT] = __builtin_fmaf(alpha, pa[jj][0], d[4 * RES_NT]); d[5 * RES_NT] = __builtin_fmaf(alpha, pa[jj][1], d[5 * RES_NT]);
+                }
+            }
+            const bool act = (jj <= nr + 1) && nr > 0 && xin && (ya - 1 + jj) >= 0 && (ya - 1 + jj) < g.H;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                px[jj][q] = act ? mo[jj][q] * rx[jj][q] + beta * px[jj][q] : 0.f;
+                py[jj][q] = act ? mo[jj][q] * ry[jj][q] + beta * py[jj][q] : 0.f;
+                pa[jj][q] = act ? ma[jj][q] * ra[jj][q] + beta * pa[jj][q] : 0.f;
+            }
+        }
+        // ---- A p_k for my rows; the four sums; the boundary of A p_k to my neighbours
+        float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j < nr) {
+                const int jm = j, jc = j + 1, jn = j + 2;
+                const float Lpx = from_left(px[jc][1]), Lpy = from_left(py[jc][1]), Lpa = from_left(pa[jc][1]), Lc = from_left(cc[jc][1]), Ls = from_left(ss[jc][1]);
+                const float Rpx = from_right(px[jc][0]), Rpy = from_right(py[jc][0]), Rpa = from_right(pa[jc][0]), Rc = from_right(cc[jc][0]), Rs = from_right(ss[jc][0]);
+                const unsigned Lf = from_left(fl[jc]) >> 8, Rf = from_right(fl[jc]);
+                if (xout) {
+                    float bx[2], by[2], bv[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        bx[q] = 0.f; by[q] = 0.f; bv[q] = 0.f;
+                        const unsigned fq = (fl[jc] >> (8 * q)) & 255u;
+                        const float pxi = px[jc][q], pyi = py[jc][q], pai = pa[jc][q];
+                        if (fq & 1u) {
+                            const float ci = cc[jc][q], si = ss[jc][q];
+                            if (q == 0) {
+                                nb_term<0>((fl[jc] >> 8) & 1u, ci, si, pxi, pyi, pai, px[jc][1], py[jc][1], pa[jc][1], cc[jc][1], ss[jc][1], bx[q], by[q], bv[q]);
+                                nb_term<1>(Lf & 1u, ci, si, pxi, pyi, pai, Lpx, Lpy, Lpa, Lc, Ls, bx[q], by[q], bv[q]);
+                            } else {
+                                nb_term<0>(Rf & 1u, ci, si, pxi, pyi, pai, Rpx, Rpy, Rpa, Rc, Rs, bx[q], by[q], bv[q]);
+                                nb_term<1>(fl[jc] & 1u, ci, si, pxi, pyi, pai, px[jc][0], py[jc][0], pa[jc][0], cc[jc][0], ss[jc][0], bx[q], by[q], bv[q]);
+                            }
+                            nb_term<2>((fl[jn] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jn][q], py[jn][q], pa[jn][q], cc[jn][q], ss[jn][q], bx[q], by[q], bv[q]);
+                            nb_term<3>((fl[jm] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jm][q], py[jm][q], pa[jm][q], cc[jm][q], ss[jm][q], bx[q], by[q], bv[q]);
+                            bx[q] *= a.wr2; by[q] *= a.wr2; bv[q] *= a.wr2;
+                            if (fq & 2u) { bx[q] += a.wf2 * pxi; by[q] += a.wf2 * pyi; }
+                        }
+                        acc += pxi * bx[q] + pyi * by[q] + pai * bv[q];
+                        const double dmo = mo[jc][q], dma = ma[jc][q], drx = rx[jc][q], dry = ry[jc][q], dra = ra[jc][q], dax = bx[q], day = by[q], daa = bv[q];
+                        s0 = __builtin_fma(dmo, __builtin_fma(dry, dry, drx * drx), __builtin_fma(dma, dra * dra, s0));
+                        s1 = __builtin_fma(dmo, __builtin_fma(dry, day, drx * dax), __builtin_fma(dma, dra * daa, s1));
+                        s2 = __builtin_fma(dmo, __builtin_fma(day, day, dax * dax), __builtin_fma(dma, daa * daa, s2));
+                        ax[jc][q] = bx[q]; ay[jc][q] = by[q]; av[jc][q] = bv[q];
+                    }
+                    // the boundary goes out as soon as it exists (the granules travel while the remaining rows are computed)
+                    if (j == 0 && has_up) {
+                        stgf(rowh(par, wid, 0, 0), T, bx[0]); stgf(rowh(par, wid, 0, 1), T, by[0]); stgf(rowh(par, wid, 0, 2), T, bv[0]);
+                        stgf(rowh(par, wid, 0, 3), T, bx[1]); stgf(rowh(par, wid, 0, 4), T, by[1]); stgf(rowh(par, wid, 0, 5), T, bv[1]);
+                    }
+                    if (j == nr - 1 && has_dn) {
+                        stgf(rowh(par, wid, 1, 0), T, bx[0]); stgf(rowh(par, wid, 1, 1), T, by[0]); stgf(rowh(par, wid, 1, 2), T, bv[0]);
+                        stgf(rowh(par, wid, 1, 3), T, bx[1]); stgf(rowh(par, wid, 1, 4), T, by[1]); stgf(rowh(par, wid, 1, 5), T, bv[1]);
+                    }
+                    if ((lane == 1 && has_lf) || (lane == 62 && has_rt)) {
+                        const int side = lane == 1 ? 0 : 1;
+                        stgf(colh(par, wid, side, j, 0), T, bx[0]); stgf(colh(par, wid, side, j, 1), T, by[0]); stgf(colh(par, wid, side, j, 2), T, bv[0]);
+                        stgf(colh(par, wid, side, j, 3), T, bx[1]); stgf(colh(par, wid, side, j, 4), T, by[1]); stgf(colh(par, wid, side, j, 5), T, bv[1]);
+                    }
+                }
+            }
+        }
+        // ---- the workgroup's sums: wave butterflies -> LDS -> wave 0 adds the four waves up in order and publishes 7 granules
+        {
+            const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
+            if (lane == 0) { S.wa[wave] = wa; S.wd[wave][0] = w0; S.wd[wave][1] = w1; S.wd[wave][2] = w2; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave == 0) {
+                sp.n = 0; sp.t0 = 0;
+                for (int w = 1; w < 4; ++w)
+                    while (!dead && __hip_atomic_load(&S.wtag[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != T) { if (spin_fail(sp, ctl, 5u, (unsigned)w, T)) dead = true; }
+                dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+                if (lane < 7) {
+                    float s = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+                    for (int w = 0; w < 4; ++w) { s += S.wa[w]; b0 += S.wd[w][0]; b1 += S.wd[w][1]; b2 += S.wd[w][2]; }
+                    const double pick = lane < 3 ? b0 : lane < 5 ? b1 : b2;
+                    const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
+                    stg(sumw(par, lane, blockIdx.x), T, word);
+                }
+            }
+        }
+    }
+    // ---- what L launches would have left behind: r_{L-1}, p_{L-1}, A p_{L-1}, delta (without its last term); the last iteration's two words
+    if (a.L > 0) {
+        float4* Ro4 = reinterpret_cast<float4*>(a.r_out); float2* Ra2 = reinterpret_cast<float2*>(a.r_out + 2 * N);
+        float4* Ao4 = reinterpret_cast<float4*>(a.A_out); float2* Aa2 = reinterpret_cast<float2*>(a.A_out + 2 * N);
+        float4* qo4 = reinterpret_cast<float4*>(a.p_out); float2* qa2 = reinterpret_cast<float2*>(a.p_out + 2 * N);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j < nr && xout) {
+                const int jc = j + 1;
+                const long i = (long)(ya + j) * W2 + (x0 >> 1);
+                Ro4[i] = make_float4(rx[jc][0], ry[jc][0], rx[jc][1], ry[jc][1]); Ra2[i] = make_float2(ra[jc][0], ra[jc][1]);
+                qo4[i] = make_float4(px[jc][0], py[jc][0], px[jc][1], py[jc][1]); qa2[i] = make_float2(pa[jc][0], pa[jc][1]);
+                Ao4[i] = make_float4(ax[jc][0], ay[jc][0], ax[jc][1], ay[jc][1]); Aa2[i] = make_float2(av[jc][0], av[jc][1]);
+                const float* d = dl + (j * 6) * RES_NT + threadIdx.x;
+                dl4[i] = make_float4(d[0], d[RES_NT], d[2 * RES_NT], d[3 * RES_NT]); dl2[i] = make_float2(d[4 * RES_NT], d[5 * RES_NT]);
+            }
+        }
+        if (id == 0) {      // (uniform per workgroup: all four waves of the writer's workgroup take part in the last sweep)
+            float aD, bN;
+            finish_scalars(seq + (unsigned)a.L, (a.L - 1) & 1, aN_prev, aD, bN);
+            if (writer) { a.words[2 * (a.L - 1)] = aD; a.words[2 * (a.L - 1) + 1] = bN; }
+        }
+    }
+}
+
+// this launch's tags are seq + 1 .. seq + L: never those of an earlier launch of the plan, whatever its L was (replay-safe: the counter lives on the device)
+__global__ void k_resident_begin(unsigned* ctl, unsigned L) { if (threadIdx.x == 0) { const unsigned s = ctl[RES_NEXT]; ctl[RES_SEQ] = s; ctl[RES_NEXT] = s + L + 1u; } }
+
+inline ResGeo make_res_geo(int W, int H, int row0, int row1, int R)
+{
+    ResGeo g; g.W = W; g.H = H; g.row0 = row0; g.row1 = row1; g.R = R;
+    g.nstrips = (W + RES_USE - 1) / RES_USE;
+    g.nseg = (row1 - row0 + R - 1) / R;
+    g.nwgrow = (g.nseg + RES_NT / 64 - 1) / (RES_NT / 64);
+    g.total = g.nstrips * g.nwgrow;
+    return g;
+}
+
+int g_res_cap = 0;       // tests: workgroup budget (0 = the device's CU count: one workgroup per CU, all of them resident at once)
+int g_res_rows = 0;      // tests / tools: rows per segment (0 = automatic)
+
+inline int res_rows(int W, int rows)
+{
+    if (W < 2 || (W & 1) || rows < 1) return 0;
+    const long cap = g_res_cap > 0 ? g_res_cap : thallo_hip_device_cu_count();
+    const int nstrips = (W + RES_USE - 1) / RES_USE;
+    int R = g_res_rows > 0 ? g_res_rows : march_rows_per_segment(rows, nstrips, RES_NT / 64, cap, 2);
+    if (R <= 0 || R > RES_MAX_R) return 0;
+    const ResGeo g = make_res_geo(W, rows, 0, rows, R);
+    if ((g.total + 7) / 8 * 8 > cap || (g.total + 7) / 8 * 8 > THALLO_MAX_PARTIALS) return 0;      // every workgroup must be resident: they wait for each other
+    return R;
+}
+
+inline size_t res_lds_bytes(int R) { return ((sizeof(ResLds) + 15) & ~(size_t)15) + (size_t)R * 6 * RES_NT * sizeof(float); }
+
+}  // namespace
+
+extern "C" {
+
+void thallo_hip_resident_debug_set(int what, int value) { if (what == 0) g_res_rows = value; if (what == 1) g_res_cap = value; }
+
+/* rows per wave segment of the resident PCG kernel on `rows` owned rows of a W-wide image, or 0: the shape does not fit the chip's registers
+ * (more than RES_MAX_R rows per wave at one workgroup per CU) and the caller runs one launch per PCG iteration */
+int thallo_hip_iw_resident_rows(int W, int rows) { return res_rows(W, rows); }
+
+/* bytes of exchange memory a plan needs for the resident kernel (zero-filled by the caller once; layout private to this file) */
+long thallo_hip_iw_resident_bytes(int W, int rows)
+{
+    const int R = res_rows(W, rows);
+    if (R <= 0) return 0;
+    const ResGeo g = make_res_geo(W, rows, 0, rows, R);
+    const long waves = (long)g.nstrips * g.nseg;
+    const long rowh = 2 * waves * 2 * 6 * 64, colh = 2 * waves * 2 * RES_MAX_R * 6, sums = 2L * 7 * THALLO_MAX_PARTIALS;
+    return (rowh + colh + sums) * (long)sizeof(u64) + RES_CTL_WORDS * (long)sizeof(unsigned) + 256;
+}
+
+/* The PCG loop of one Gauss-Newton step in one launch: L iterations from what thallo_hip_iw_pcg_init left (r_0 in r_in, zeros in p_in and delta, cs / flags,
+ * alphaN_0), leaving what L launches of thallo_hip_iw_pcg_iter_march leave: r_{L-1}, A p_{L-1}, p_{L-1} in the *_out planes, delta without its last term, and
+ * words[2k] = alphaD_k, words[2k + 1] = betaN_k.  The *_out planes may be the *_in planes (every workgroup has read its rows and halo before any workgroup can
+ * be through its L iterations: each iteration needs every workgroup's sums).  xbuf: thallo_hip_iw_resident_bytes() bytes, zeroed once by the caller, private to the plan.
+ * Returns the number of workgroups (> 0), -hipErrorNotSupported when the shape does not fit, another negative hipError_t on failure.
+ * Replaces gauss_newton.t:1615-1687 for shapes whose solver state fits the chip's registers. */
+int thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                               const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
+                               thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, int L, thallo_stream_t stream)
+{
+    if (row0 != 0 || row1 != H || H < 1 || (W & 1) || W < 2 || L < 1) return -(int)hipErrorInvalidValue;      // (whole images; the row-slab form is thallo_hip_iw_pcg_resident_dist)
+    if (!cs || !flags || !r_in || !p_in || !r_out || !Ap_out || !p_out || !delta || !words || !xbuf || !alphaN0.partials) return -(int)hipErrorInvalidValue;
+    const int R = res_rows(W, row1 - row0);
+    if (R <= 0) return -(int)hipErrorNotSupported;
+    ResArgs a;
+    a.g = make_res_geo(W, H, row0, row1, R);
+    const int grid = (a.g.total + 7) / 8 * 8;
+    const long waves = (long)a.g.nstrips * a.g.nseg;
+    u64* base = reinterpret_cast<u64*>(xbuf);
+    a.b.rowh = base; base += 2 * waves * 2 * 6 * 64;
+    a.b.colh = base; base += 2 * waves * 2 * RES_MAX_R * 6;
+    a.b.sums = base; base += 2L * 7 * THALLO_MAX_PARTIALS;
+    a.b.ctl = reinterpret_cast<unsigned*>(base);
+    a.cs = cs; a.flags = flags; a.wf2 = w_fit * w_fit; a.wr2 = w_reg * w_reg;
+    a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
+    a.aN0 = alphaN0; a.words = words; a.irregular = irregular; a.L = L;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)L);
+    const size_t lds = res_lds_bytes(R);
+#define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR>), dim3(grid), dim3(RES_NT), lds, s, a)
+    switch (R) {
+        case 1: RES_LAUNCH(1); break; case 2: RES_LAUNCH(2); break; case 3: RES_LAUNCH(3); break;
+        case 4: RES_LAUNCH(4); break; case 5: RES_LAUNCH(5); break; case 6: RES_LAUNCH(6); break;
+        default: return -(int)hipErrorNotSupported;
+    }
+#undef RES_LAUNCH
+    int e = check_launch(); return e ? e : grid;
+}
+
+/* the error word of a plan's resident launches: 1 = a bounded wait ran out (a workgroup was not resident, or a granule never arrived); clear != 0 resets
+ * it.  pm (5 words, may be NULL): what the first timed-out wait was for.  Synchronises the stream.  spin_ms >= 0 sets the bound (0 = the 2 s default). */
+int thallo_hip_iw_resident_status(int W, int rows, void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream)
+{
+    const int R = res_rows(W, rows);
+    if (R <= 0 || !xbuf) return -(int)hipErrorInvalidValue;
+    const ResGeo g = make_res_geo(W, rows, 0, rows, R);
+    const long waves = (long)g.nstrips * g.nseg;
+    unsigned* ctl = reinterpret_cast<unsigned*>(reinterpret_cast<u64*>(xbuf) + 2 * waves * 2 * 6 * 64 + 2 * waves * 2 * RES_MAX_R * 6 + 2L * 7 * THALLO_MAX_PARTIALS);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned w[RES_CTL_WORDS];
+    if (hipMemcpyAsync(w, ctl, sizeof(w), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -(int)hipErrorUnknown;
+    if (pm) for (int i = 0; i < 5; ++i) pm[i] = w[RES_PM + i];
+    if (clear && w[RES_ERR]) { const unsigned z = 0; if (hipMemcpyAsync(ctl + RES_ERR, &z, sizeof(z), hipMemcpyHostToDevice, s) != hipSuccess) return -(int)hipErrorUnknown; }
+    if (spin_ms >= 0) { const unsigned v = (unsigned)spin_ms; if (hipMemcpyAsync(ctl + RES_SPIN_MS, &v, sizeof(v), hipMemcpyHostToDevice, s) != hipSuccess) return -(int)hipErrorUnknown; }
+    if (hipStreamSynchronize(s) != hipSuccess) return -(int)hipErrorUnknown;
+    return (int)w[RES_ERR];
+}
+
+}  // extern "C"

@@ -130,6 +130,11 @@ public:
                                   const thallo_prev_t& /*prev*/, float* /*alphaD_out*/, double* /*s12_out*/) { return -1; }
     virtual int pcg_iter_finish_from(LaunchCtx&, const float* /*alphaD_partials*/, const double* /*s12_partials*/, int /*count*/, thallo_sum_t /*alphaN*/,
                                      float* /*alphaD_word*/, float* /*betaN_word*/) { return -1; }
+    // The whole PCG loop of a GN step in one launch (thallo_hip_iw_pcg_resident): after pcg_init, L iterations from r = v.rbuf(0), p = v.p[0]; leaves
+    // r / Ap / p in buffers (L & 1), delta without its last term, words[2k] = alphaD_k, words[2k + 1] = betaN_k.  resident_ok(): this plan's shape fits.
+    virtual bool resident_ok() const { return false; }
+    virtual int  pcg_resident(LaunchCtx&, SolverVectors&, int /*L*/, thallo_sum_t /*alphaN0*/, float* /*words*/) { return -1; }
+    virtual int  resident_status(LaunchCtx&, int /*clear*/, unsigned* /*pm*/) { return 0; }      // 1: a bounded wait inside the kernel ran out
     // PCGStep2 (r -= alpha Ap, z = M^-1 r, betaN partials); default = the energy-independent flat kernel
     virtual int pcg_step2(LaunchCtx& c, SolverVectors& v, thallo_sum_t aN, thallo_sum_t aD, float* betaN_out)
     {

@@ -157,6 +157,8 @@ class ImageWarpingPlugin : public EnergyPlugin {
     const float *urshape = nullptr, *constraints = nullptr, *mask = nullptr;
     float w_fit = 0, w_reg = 0;
     DeviceBuffer cs, flags, irregular;     // per-GN-iteration planes: (cos,sin) float2, validity bits; UrShape-is-grid word
+    DeviceBuffer xres;                     // exchange memory of the resident PCG kernel (granule buffers + control words)
+    bool resident_ = false;                // the shape fits the resident kernel (whole image, unit pixel grid, even W, few enough rows per wave)
     bool march_ = false;                   // UrShape verified (at Init) to be the unit pixel grid and W even: the marching one-kernel iteration
     bool grid_ = false;                    // UrShape is the unit pixel grid (host-checked at Init)
     int row0_ = 0, row1_ = 0;              // owned rows (all of them unless the Plan is one row slab of a multi-GPU run)
@@ -197,6 +199,16 @@ public:
         march_ = grid_ && ((long)W * H >= 400000 || (e && e[0] == '2'));              // THALLO_MARCH=2: the marching kernel at every size (tests)
         // an image with more 124-pixel column strips than the device has workgroup slots stays on the tile kernel (which loops over its tiles)
         if (march_ && thallo_hip_iw_march_rows(W, H) <= 0) march_ = false;
+        // small working sets: the whole PCG loop in one launch (state in registers); THALLO_RESIDENT=0: one launch per PCG iteration (A/B)
+        resident_ = false;
+        const char* er = getenv("THALLO_RESIDENT");
+        if (grid_ && !(er && er[0] == '0') && row0_ == 0 && row1_ == H && thallo_hip_iw_resident_rows(W, H) > 0) {
+            const long need = thallo_hip_iw_resident_bytes(W, H);
+            if ((long)xres.bytes < need) {
+                if (xres.alloc((size_t)need) || hipMemsetAsync(xres.ptr, 0, (size_t)need, c.stream) != hipSuccess) { set_error("image_warping: out of device memory for the resident kernel's exchange buffers"); return -1; }
+            }
+            resident_ = true;
+        }
         return 0;
     }
     // ---- one row slab of a multi-GPU run (solver_dist.cpp)
@@ -263,6 +275,15 @@ public:
         TimedLaunch t(c, "PCGScalars");
         return thallo_hip_iw_pcg_iter_finish(part, v.s12, count, aN, aD_word, bN_word, c.stream);
     }
+    bool resident_ok() const override { return resident_; }
+    int pcg_resident(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words) override
+    {
+        TimedLaunch t(c, "PCGLoopResident");
+        return thallo_hip_iw_pcg_resident(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg, v.rbuf(0), v.p[0],
+                                          v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words, (const int*)irregular.ptr, xres.ptr, L, c.stream);
+    }
+    int resident_status(LaunchCtx& c, int clear, unsigned* pm) override
+    { return resident_ && xres.ptr ? thallo_hip_iw_resident_status(W, H, xres.ptr, clear, -1, pm, c.stream) : 0; }
     bool iter_defers_finish() const override { return true; }
     int pcg_iter_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aN2, thallo_sum_t aD2, const thallo_prev_t& prev,
                           float* out, double* s12_out) override

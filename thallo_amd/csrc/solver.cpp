@@ -231,6 +231,15 @@ float Plan::compute_cost()
     float f = 0.0f;
     HIP_OK(hipMemcpyAsync(&f, scratch_.ptr, sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
     HIP_OK(hipStreamSynchronize(ctx.stream));
+    if (resident_used_) {     // the resident PCG kernel's waits are bounded; one that ran out voids the steps since the last check
+        resident_used_ = false;
+        unsigned pm[5] = { 0, 0, 0, 0, 0 };
+        if (plugin->resident_status(ctx, 1, pm) != 0) {
+            set_error("%s: a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u): the steps since the last cost evaluation are void; "
+                      "THALLO_RESIDENT=0 selects one launch per PCG iteration", plugin->name(), pm[0], pm[1], pm[2], pm[3], pm[4]);
+            return NAN;
+        }
+    }
     return f;
 }
 
@@ -356,6 +365,7 @@ int Plan::step_gn(int ev_iter)
         timer_.stop(ev_iter, s);
         return 1;
     }
+    if (one_kernel_ && sp.lIterations >= 1 && plugin->resident_ok()) return step_gn_resident(ev_iter);
     if (one_kernel_ && plugin->one_kernel_iteration()) return step_gn_one_kernel(ev_iter);
     if (expanded_ && plugin->apply_returns_sums()) return step_gn_expanded(ev_iter);
     const int L = sp.lIterations;
@@ -453,6 +463,35 @@ int Plan::step_gn_one_kernel(int ev_iter)
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
     linear_update_tail(L, batched);
+    sp.nIter++;
+    timer_.stop(ev_fin, s);
+    timer_.stop(ev_iter, s);
+    return 1;
+}
+
+int Plan::step_gn_resident(int ev_iter)
+{   // GN branch, the whole PCG loop in ONE launch (plugins whose shape fits the chip's registers: thallo_hip_iw_pcg_resident).  Same slots and words as
+    // step_gn_one_kernel leaves behind -- alphaN_k = B+2k (a word from k = 1 on), alphaD_k = B+2k+1, betaN_k = B+2k+2 -- so PCGLinearUpdate, the alpha / beta
+    // trace and the cost path do not know which schedule ran.  Replaces the loop of gauss_newton.t:1615-1687.
+    if (ensure_iter_buffers()) { set_error("out of device memory for the one-kernel schedule"); return 0; }
+    const int L = sp.lIterations, B = 2;
+    hipStream_t s = ctx.stream;
+    const int ev_setup = timer_.start("Nonlinear Setup", s);
+    cur_ = 0;
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
+    set_nb(B, nb); finish(B);
+    timer_.stop(ev_setup, s);
+    const int ev_lin = timer_.start("Linear Solve", s);
+    nb = plugin->pcg_resident(ctx, v_, L, sum(B), scal(B + 1));
+    if (nb < 0) { set_error("PCGLoopResident launch failed (%d)", nb); return 0; }
+    for (int k = 0; k < L; ++k) { const int jD = B + 2 * k + 1, jB = jD + 1; set_nb(jD, 1); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+    cur_ = L & 1;
+    resident_used_ = true;
+    last_l_iters = L;
+    timer_.stop(ev_lin, s);
+    const int ev_fin = timer_.start("Nonlinear Finish", s);
+    linear_update_tail(L, false);
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);

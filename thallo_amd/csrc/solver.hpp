@@ -146,6 +146,8 @@ private:
     int  ensure_sums_buffer();
     int  step_gn_expanded(int ev_iter);
     int  step_gn_one_kernel(int ev_iter);
+    int  step_gn_resident(int ev_iter);
+    bool resident_used_ = false;    // a resident launch ran since the last cost evaluation (its error word is read there)
     float compute_cost();
     int   step_gn(int ev_iter);
     int   step_lm(int ev_iter);

@@ -65,10 +65,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("THALLO_LIB") or LIB_PATH          # THALLO_LIB: tools only (an A/B build from `make VARIANT=...`, tools/ab/)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(make -C thallo_amd/csrc). There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
     L.Thallo_NewState.argtypes = [InitializationParameters]; L.Thallo_NewState.restype = vp
     L.Thallo_ProblemDefine.argtypes = [vp, C.c_char_p, C.c_char_p]; L.Thallo_ProblemDefine.restype = vp

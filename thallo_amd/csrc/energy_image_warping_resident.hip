@@ -27,14 +27,24 @@ namespace {
 
 constexpr int RES_USE = 124;              // output pixels per wave row (lanes 1..62 x 2)
 constexpr int RES_NT = 256;               // 4 waves = 4 vertically adjacent segments of one strip (one workgroup per CU)
-constexpr int RES_MAX_R = 6;              // rows per segment the kernel is instantiated for (register budget)
+constexpr int RES_MAX_R = 5;              // rows per segment the kernel is instantiated for (register budget; 6 R <= 32: a column's words fit half a wave)
 
 inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
 
 typedef unsigned long long u64;
-__device__ __forceinline__ u64  ldg(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }       // global_load_dwordx2 sc1
-__device__ __forceinline__ void stg(u64* p, unsigned tag, unsigned v) { __hip_atomic_store(p, ((u64)tag << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stgf(u64* p, unsigned tag, float v) { stg(p, tag, __float_as_uint(v)); }
+
+// The exchange buffers are addressed as raw buffers (one descriptor in SGPRs + a 32-bit byte offset per lane: no 64-bit address arithmetic in the loop);
+// aux 16 = sc1: write-through stores / L1-bypassing loads, the agent-scope forms of MI355X_MICROARCH.md "inter-workgroup visibility".  A 16-byte access
+// moves TWO granules; each 8-byte half carries its own tag, so a torn 16-byte access is still two whole granules.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ u32x4 ld2g(rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
+__device__ __forceinline__ u32x2 ld1g(rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16); }
+__device__ __forceinline__ void st2g(rsrc_t r, unsigned off, unsigned tag, float v0, float v1)
+{ u32x4 d; d.x = __float_as_uint(v0); d.y = tag; d.z = __float_as_uint(v1); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 16); }
+__device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsigned v) { u32x2 d; d.x = v; d.y = tag; __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, 16); }
 
 __device__ __forceinline__ float from_left(float v)
 {
@@ -74,9 +84,9 @@ struct ResGeo { int W, H, row0, row1, R, nstrips, nseg, nwgrow, total; };
 
 // exchange buffers of one plan (thallo_hip_iw_resident_bytes); parity = iteration & 1
 struct ResBufs {
-    u64* rowh;        // [2 parity][waves][2 sides: 0 = the wave's FIRST row (for the wave above), 1 = its LAST row (for the wave below)][6 components][64 lanes]
-    u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][RES_MAX_R rows][6 components]
-    u64* sums;        // [2 parity][7 words: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo][1024 workgroups]
+    u64* rowh;        // [2 parity][waves][2 sides: 0 = the wave's FIRST row (for the wave above), 1 = its LAST row (for the wave below)][64 lanes][6 components]
+    u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][32: word 6 * row + component]
+    u64* sums;        // [2 parity][1024 workgroups][8: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo, -]   (a workgroup's record = one 64-byte line, one store instruction)
     unsigned* ctl;    // RES_CTL_WORDS
 };
 
@@ -94,6 +104,18 @@ struct ResArgs {
 
 namespace {
 
+#ifdef THALLO_MARCH_SWEEP
+// tools/resident_probe.py RP_STAMPS=1: where an iteration spends its time (100 MHz wall clock, lane 0 of every wave, iterations 8..11)
+__device__ unsigned long long* g_stamps_r = nullptr;
+#define RES_STAMP(k, i) do { if ((threadIdx.x & 63) == 0 && g_stamps_r && (k) >= 8 && (k) < 12) g_stamps_r[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((k) - 8)) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define RES_STAMP(k, i) do { } while (0)
+#endif
+#ifdef THALLO_MARCH_SWEEP
+#define RES_NOTE(k, i, v) do { if ((threadIdx.x & 63) == 0 && g_stamps_r && (k) >= 8 && (k) < 12) g_stamps_r[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((k) - 8)) * 16 + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define RES_NOTE(k, i, v) do { } while (0)
+#endif
 struct Spin { unsigned n; long long t0; };
 // bounded wait bookkeeping: true = give up (this wave or somebody else timed out; every later wait of the wave falls through at once)
 __device__ __forceinline__ bool spin_fail(Spin& sp, unsigned* ctl, unsigned what, unsigned idx, unsigned tag)
@@ -118,8 +140,12 @@ struct ResLds {
     float2 lut[32];
     unsigned qtag[4];                 // quarter-sweep exchange: wave w's column is complete for tag ...
     unsigned wtag[4];                 // wave sums of an iteration are in place
+    unsigned rtag[2][4][2];           // [parity][wave][side]: that wave's first (0) / last (1) row of A p is in rrow, for the neighbouring wave of the same workgroup
     unsigned q[4][7][64];             // per wave: the 7 words of the 64 slots it swept
     float wa[4]; double wd[4][3];     // per wave: alphaD part, {N, S1, S2} parts
+    float rrow[2][4][2][6][64];       // the y halo between the stacked waves of the workgroup never leaves the CU
+    float cst[4][2][32];              // per wave: lane 1's / lane 62's A p of its rows, transposed so that ONE store instruction publishes a column
+    float crx[4][2][32];              // per wave: the received columns (from the strip to the left / right), for lanes 0 / 63 to pick up
 };
 
 template <int R>
@@ -129,7 +155,9 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     ResLds& S = *reinterpret_cast<ResLds*>(smem);
     float* dl = reinterpret_cast<float*>(smem + ((sizeof(ResLds) + 15) & ~(size_t)15));      // delta: [R][6][256], a thread's own words only
     const ResGeo g = a.g;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler then KNOWS that segment, rows, neighbour flags and buffer offsets are wave-uniform -- scalar registers and
+    //  scalar branches instead of exec-masked code for every `if (has_up)`)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned* const ctl = a.b.ctl;
 
     // workgroup -> (strip, first segment): the marching kernel's XCD-aware placement (workgroups b and b + 8 share an XCD)
@@ -145,6 +173,7 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     }
     if (threadIdx.x < 32) { float mo, ma; pre_from_flags((unsigned char)threadIdx.x, a.wf2, a.wr2, mo, ma); S.lut[threadIdx.x] = make_float2(mo, ma); }
     if (threadIdx.x < 4) { S.qtag[threadIdx.x] = 0u; S.wtag[threadIdx.x] = 0u; }
+    if (threadIdx.x < 16) (&S.rtag[0][0][0])[threadIdx.x] = 0u;
     __syncthreads();                                                      // (the only barrier of the launch)
 
     const int strip = (int)(id % g.nstrips), seg = (int)(id / g.nstrips) * (RES_NT / 64) + wave;
@@ -162,13 +191,15 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
 
     // ---- who my neighbours are (a neighbour exists = somebody publishes the granules I would wait for)
     const int wid = strip * g.nseg + seg;                                 // wave id: (strip, segment)
-    const bool has_up = nr > 0 && seg > 0, has_dn = nr > 0 && yb < g.row1;
+    // (a segment with fewer than R rows is the last of its strip -- nothing below it -- so the row below a wave that HAS one is always row jj = R + 1)
+    const bool has_up = nr > 0 && seg > 0, has_dn = nr == R && yb < g.row1;
     const bool has_lf = nr > 0 && strip > 0, has_rt = nr > 0 && strip + 1 < g.nstrips;        // (then lane 63's pixels -- x = 124 (strip + 1), + 1 -- are inside the image)
     const long waves = (long)g.nstrips * g.nseg;
-    auto rowh = [&](int par, int w, int side, int c) { return a.b.rowh + ((((long)par * waves + w) * 2 + side) * 6 + c) * 64 + lane; };
-    auto colh = [&](int par, int w, int side, int j, int c) { return a.b.colh + ((((long)par * waves + w) * 2 + side) * RES_MAX_R + j) * 6 + c; };
-    auto sumw = [&](int par, int c, int slot) { return a.b.sums + ((long)par * 7 + c) * THALLO_MAX_PARTIALS + slot; };
-
+    // byte offsets into the three exchange buffers (raw-buffer addressing: descriptor + 32-bit offset)
+    const rsrc_t RS_ROW = make_rsrc(a.b.rowh), RS_COL = make_rsrc(a.b.colh), RS_SUM = make_rsrc(a.b.sums);
+    auto rowh = [&](int par, int w, int side) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + lane) * 48); };       // this lane's 6 granules of that row
+    auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 32 + i) * 8); };     // granule i = 6 * row + component
+    auto sumw = [&](int par, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * 8) * 8); };                    // that workgroup's 64-byte record
     // ---- state: rows t = ya - 1 + jj, jj = 0 .. R + 1 (jj = 0 and jj = nr + 1: the y halo; lanes 0 / 63: the x halo)
     float rx[R + 2][2], ry[R + 2][2], ra[R + 2][2], px[R + 2][2], py[R + 2][2], pa[R + 2][2], ax[R + 2][2], ay[R + 2][2], av[R + 2][2];
     float cc[R + 2][2], ss[R + 2][2], mo[R + 2][2], ma[R + 2][2];
@@ -211,34 +242,33 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     Spin sp; sp.n = 0; sp.t0 = 0;
     bool dead = false;                    // a bounded wait ran out (here or elsewhere): no more waiting, the host raises
 
-    // The sums of iteration k (tag T): every wave sweeps the 64 slots 64 w + lane, the four waves exchange their columns through LDS, and every wave adds
-    // them up in the order the launch-per-iteration path uses (lane-strided over the slots, then the wave butterfly): alphaD_k, betaN_k -- same bits everywhere.
-    auto finish_scalars = [&](unsigned T, int par, float aN, float& aD_o, float& bN_o) {
-        const int slot = 64 * wave + lane;
-        long sid;
-        const bool live = slot < grid && wg_id(slot, sid);
-        unsigned w7[7];
-#pragma unroll
-        for (int c = 0; c < 7; ++c) w7[c] = 0u;
-        if (live) {
-            bool ok = false;
-            sp.n = 0; sp.t0 = 0;
-            while (!ok && !dead) {
-                ok = true;
-#pragma unroll
-                for (int c = 0; c < 7; ++c) { const u64 v = ldg(sumw(par, c, slot)); w7[c] = (unsigned)v; ok = ok && (unsigned)(v >> 32) == T; }
-                if (!ok && spin_fail(sp, ctl, 1u, (unsigned)slot, T)) dead = true;
-            }
-        }
-        // (lanes that finished wait here for the others of the wave: reconvergence)
+    // which of my halo rows comes through LDS (the neighbouring wave sits in my workgroup) and which through global memory (another workgroup)
+    const bool up_lds = has_up && wave > 0, up_glb = has_up && wave == 0;
+    const bool dn_lds = has_dn && wave < 3, dn_glb = has_dn && wave == 3;
+    const int slot = 64 * wave + lane;    // the sums slot this lane sweeps
+    long sid;
+    const bool slot_live = slot < grid && wg_id(slot, sid);
+    const int chalf = lane >> 5, cword = lane & 31;       // columns: lanes 0..31 carry the words of the LEFT exchange, lanes 32..63 of the RIGHT one
+    const bool col_lane = cword < 6 * nr; // (word 6 * row + component)
+
+    // Publish my quarter of the sums of an iteration (the 7 words of slot 64 w + lane) to the other waves of the workgroup, wait for theirs, and add all
+    // slots up in the order the launch-per-iteration path uses (lane-strided over the slots, then the wave butterfly): alphaD_k, betaN_k -- same bits everywhere.
+    auto exchange_scalars = [&](int kk, unsigned T, const unsigned (&w7)[7], float aN, float& aD_o, float& bN_o) {
+        RES_STAMP(kk, 8);
 #pragma unroll
         for (int c = 0; c < 7; ++c) S.q[wave][c][lane] = w7[c];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&S.qtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         sp.n = 0; sp.t0 = 0;
-        for (int w = 0; w < 4; ++w)
-            while (!dead && __hip_atomic_load(&S.qtag[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != T) { if (spin_fail(sp, ctl, 2u, (unsigned)w, T)) dead = true; }
+        while (!dead) {
+            const unsigned t0 = __hip_atomic_load(&S.qtag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), t1 = __hip_atomic_load(&S.qtag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned t2 = __hip_atomic_load(&S.qtag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), t3 = __hip_atomic_load(&S.qtag[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (t0 == T && t1 == T && t2 == T && t3 == T) break;
+            if (spin_fail(sp, ctl, 2u, 0u, T)) dead = true;
+        }
         dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");            // (no instruction: keeps the column reads below the tag polls)
+        RES_STAMP(kk, 9);
         float t = 0.0f; double n = 0.0, a1 = 0.0, b1 = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -254,64 +284,105 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
         double bd = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
         if (!(bd > 0.0)) bd = 0.0;
         aD_o = ad; bN_o = (float)bd;
+        RES_STAMP(kk, 10);
     };
 
     for (int k = 0; k < a.L; ++k) {
         const unsigned T = seq + (unsigned)k + 1u, Tp = T - 1u;
         const int par = k & 1, parp = par ^ 1;
+        // (the validity masks derived from the flags are loop-invariant; hoisted they are ~40 SGPR pairs, i.e. spilled to VGPR lanes and read back with two
+        //  v_readlane + hazard nops at every use -- recomputing the compare where it is used is cheaper, so the flags are made opaque once per iteration)
+#pragma unroll
+        for (int jj = 0; jj < R + 2; ++jj) asm volatile("" : "+v"(fl[jj]));
+        RES_STAMP(k, 0);
         if (k > 0) {
-            // ---- the one synchronisation point: sums of iteration k-1 from every workgroup, A p_{k-1} on my halo from my four neighbours
+            // ---- the one synchronisation point.  Everything that comes through global memory is polled in ONE loop, all loads of a pass in flight together:
+            // my quarter of the sums of iteration k-1, the row of A p_{k-1} from the workgroup above (wave 0) / below (wave 3), and one word per lane of the
+            // two columns from the strips to the left / right.
+            unsigned w7[7]; float rowv[6]; float cv = 0.f;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) w7[c] = 0u;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) rowv[c] = 0.f;
+            {
+                const bool need_r = xout && (up_glb || dn_glb), need_c = col_lane && (chalf == 0 ? has_lf : has_rt);
+                const unsigned rsrc = up_glb ? rowh(parp, wid - 1, 1) : rowh(parp, dn_glb ? wid + 1 : wid, 0);
+                const unsigned ssrc = sumw(parp, slot);
+                const unsigned csrc = chalf == 0 ? colh(parp, has_lf ? wid - g.nseg : wid, 1, cword) : colh(parp, has_rt ? wid + g.nseg : wid, 0, cword);
+                bool ok_s = !slot_live, ok_r = !need_r, ok_c = !need_c;
+                sp.n = 0; sp.t0 = 0;
+                unsigned npass = 0;
+                while (!(ok_s && ok_r && ok_c) && !dead) {
+                    ++npass;
+                    asm volatile("" ::: "memory");                     // (every pass re-reads: nothing may be hoisted out of the loop)
+                    u32x4 vs[4], vr[3]; u32x2 vc;
+                    if (!ok_s) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) vs[c] = ld2g(RS_SUM, ssrc + 16 * c);
+                    }
+                    if (!ok_r) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) vr[c] = ld2g(RS_ROW, rsrc + 16 * c);
+                    }
+                    if (!ok_c) vc = ld1g(RS_COL, csrc);
+                    if (!ok_s) {
+                        w7[0] = vs[0].x; w7[1] = vs[0].z; w7[2] = vs[1].x; w7[3] = vs[1].z; w7[4] = vs[2].x; w7[5] = vs[2].z; w7[6] = vs[3].x;
+                        ok_s = vs[0].y == Tp && vs[0].w == Tp && vs[1].y == Tp && vs[1].w == Tp && vs[2].y == Tp && vs[2].w == Tp && vs[3].y == Tp;
+                    }
+                    if (!ok_r) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { rowv[2 * c] = __uint_as_float(vr[c].x); rowv[2 * c + 1] = __uint_as_float(vr[c].z); }
+                        ok_r = vr[0].y == Tp && vr[0].w == Tp && vr[1].y == Tp && vr[1].w == Tp && vr[2].y == Tp && vr[2].w == Tp;
+                    }
+                    if (!ok_c) { cv = __uint_as_float(vc.x); ok_c = vc.y == Tp; }
+                    if (!(ok_s && ok_r && ok_c) && spin_fail(sp, ctl, !ok_s ? 1u : !ok_r ? 3u : 4u, (unsigned)wid, Tp)) dead = true;
+                }
+                RES_NOTE(k, 7, npass); (void)npass;
+            }
+            RES_STAMP(k, 1);
+            // the columns go through LDS to the two lanes that hold them (lane 0 / 63); same wave: program order + lgkmcnt(0)
+            if (col_lane) S.crx[wave][chalf][cword] = cv;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // y halo from the waves of my own workgroup: their rows are in LDS
+            if (up_lds || dn_lds) {
+                sp.n = 0; sp.t0 = 0;
+                const unsigned* tu = &S.rtag[parp][up_lds ? wave - 1 : wave][1]; const unsigned* td = &S.rtag[parp][dn_lds ? wave + 1 : wave][0];
+                while (!dead) {
+                    const unsigned a0 = up_lds ? __hip_atomic_load(tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp, a1 = dn_lds ? __hip_atomic_load(td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp;
+                    if (a0 == Tp && a1 == Tp) break;
+                    if (spin_fail(sp, ctl, 6u, (unsigned)wid, Tp)) dead = true;
+                }
+                dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            float up[6], dn[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                up[c] = up_lds ? S.rrow[parp][wave - 1][1][c][lane] : rowv[c];
+                dn[c] = dn_lds ? S.rrow[parp][wave + 1][0][c][lane] : rowv[c];
+            }
+            if (has_up && xout) { ax[0][0] = up[0]; ay[0][0] = up[1]; av[0][0] = up[2]; ax[0][1] = up[3]; ay[0][1] = up[4]; av[0][1] = up[5]; }
+            if (has_dn && xout) { ax[R + 1][0] = dn[0]; ay[R + 1][0] = dn[1]; av[R + 1][0] = dn[2]; ax[R + 1][1] = dn[3]; ay[R + 1][1] = dn[4]; av[R + 1][1] = dn[5]; }
+            // x halo: lane 0 takes lane 62's pixels of the strip to the left, lane 63 lane 1's pixels of the strip to the right, for each of my rows
+            if ((lane == 0 && has_lf) || (lane == 63 && has_rt)) {
+                const float* cx = &S.crx[wave][lane == 0 ? 0 : 1][0];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (j < nr) {
+                        ax[j + 1][0] = cx[6 * j]; ay[j + 1][0] = cx[6 * j + 1]; av[j + 1][0] = cx[6 * j + 2];
+                        ax[j + 1][1] = cx[6 * j + 3]; ay[j + 1][1] = cx[6 * j + 4]; av[j + 1][1] = cx[6 * j + 5];
+                    }
+                }
+            }
             float aD, bN;
-            finish_scalars(Tp, parp, aN_prev, aD, bN);
+            exchange_scalars(k, Tp, w7, aN_prev, aD, bN);
             alpha = safe_div<false>(aN_prev, aD);
             beta = safe_div<false>(bN, aN_prev);
             if (writer) { a.words[2 * (k - 1)] = aD; a.words[2 * (k - 1) + 1] = bN; }
             aN_prev = bN;
-            // y halo: the LAST row of the wave above lands in row jj = 0, the FIRST row of the wave below in row jj = nr + 1 (lanes 1..62)
-            if (xout && (has_up || has_dn)) {
-                bool ok = false;
-                sp.n = 0; sp.t0 = 0;
-                float up[6], dn[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) { up[c] = 0.f; dn[c] = 0.f; }
-                while (!ok && !dead) {
-                    ok = true;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        if (has_up) { const u64 v = ldg(rowh(parp, wid - 1, 1, c)); up[c] = __uint_as_float((unsigned)v); ok = ok && (unsigned)(v >> 32) == Tp; }
-                        if (has_dn) { const u64 v = ldg(rowh(parp, wid + 1, 0, c)); dn[c] = __uint_as_float((unsigned)v); ok = ok && (unsigned)(v >> 32) == Tp; }
-                    }
-                    if (!ok && spin_fail(sp, ctl, 3u, (unsigned)wid, Tp)) dead = true;
-                }
-                if (has_up) { ax[0][0] = up[0]; ay[0][0] = up[1]; av[0][0] = up[2]; ax[0][1] = up[3]; ay[0][1] = up[4]; av[0][1] = up[5]; }
-                if (has_dn) {
-#pragma unroll
-                    for (int jj = 2; jj < R + 2; ++jj)
-                        if (jj == nr + 1) { ax[jj][0] = dn[0]; ay[jj][0] = dn[1]; av[jj][0] = dn[2]; ax[jj][1] = dn[3]; ay[jj][1] = dn[4]; av[jj][1] = dn[5]; }
-                }
-            }
-            // x halo: lane 0 takes lane 62's pixels of the strip to the left, lane 63 lane 1's pixels of the strip to the right, for each of my rows
-            if ((lane == 0 && has_lf) || (lane == 63 && has_rt)) {
-                const int w = lane == 0 ? wid - g.nseg : wid + g.nseg, side = lane == 0 ? 1 : 0;
-                bool ok = false;
-                sp.n = 0; sp.t0 = 0;
-                while (!ok && !dead) {
-                    ok = true;
-#pragma unroll
-                    for (int j = 0; j < R; ++j) {
-                        if (j < nr) {
-                            u64 v[6];
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) { v[c] = ldg(colh(parp, w, side, j, c)); ok = ok && (unsigned)(v[c] >> 32) == Tp; }
-                            ax[j + 1][0] = __uint_as_float((unsigned)v[0]); ay[j + 1][0] = __uint_as_float((unsigned)v[1]); av[j + 1][0] = __uint_as_float((unsigned)v[2]);
-                            ax[j + 1][1] = __uint_as_float((unsigned)v[3]); ay[j + 1][1] = __uint_as_float((unsigned)v[4]); av[j + 1][1] = __uint_as_float((unsigned)v[5]);
-                        }
-                    }
-                    if (!ok && spin_fail(sp, ctl, 4u, (unsigned)w, Tp)) dead = true;
-                }
-            }
-            dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+            RES_STAMP(k, 2);
         }
+        RES_STAMP(k, 3);
         // ---- r_k = r_{k-1} - alpha A p_{k-1} ; delta += alpha p_{k-1} ; p_k = M^-1 r_k + beta p_{k-1}     (every row I hold, halo included)
 #pragma unroll
         for (int jj = 0; jj < R + 2; ++jj) {
@@ -336,6 +407,7 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                 pa[jj][q] = act ? ma[jj][q] * ra[jj][q] + beta * pa[jj][q] : 0.f;
             }
         }
+        RES_STAMP(k, 4);
         // ---- A p_k for my rows; the four sums; the boundary of A p_k to my neighbours
         float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -373,43 +445,65 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                         s2 = __builtin_fma(dmo, __builtin_fma(day, day, dax * dax), __builtin_fma(dma, daa * daa, s2));
                         ax[jc][q] = bx[q]; ay[jc][q] = by[q]; av[jc][q] = bv[q];
                     }
-                    // the boundary goes out as soon as it exists (the granules travel while the remaining rows are computed)
+                    // the boundary goes out as soon as it exists: to another workgroup as granules, to a wave of my workgroup through LDS (tagged below)
                     if (j == 0 && has_up) {
-                        stgf(rowh(par, wid, 0, 0), T, bx[0]); stgf(rowh(par, wid, 0, 1), T, by[0]); stgf(rowh(par, wid, 0, 2), T, bv[0]);
-                        stgf(rowh(par, wid, 0, 3), T, bx[1]); stgf(rowh(par, wid, 0, 4), T, by[1]); stgf(rowh(par, wid, 0, 5), T, bv[1]);
+                        if (up_glb) {
+                            const unsigned d = rowh(par, wid, 0);
+                            st2g(RS_ROW, d, T, bx[0], by[0]); st2g(RS_ROW, d + 16, T, bv[0], bx[1]); st2g(RS_ROW, d + 32, T, by[1], bv[1]);
+                        } else {
+                            float* d = &S.rrow[par][wave][0][0][lane];
+                            d[0] = bx[0]; d[64] = by[0]; d[128] = bv[0]; d[192] = bx[1]; d[256] = by[1]; d[320] = bv[1];
+                        }
                     }
                     if (j == nr - 1 && has_dn) {
-                        stgf(rowh(par, wid, 1, 0), T, bx[0]); stgf(rowh(par, wid, 1, 1), T, by[0]); stgf(rowh(par, wid, 1, 2), T, bv[0]);
-                        stgf(rowh(par, wid, 1, 3), T, bx[1]); stgf(rowh(par, wid, 1, 4), T, by[1]); stgf(rowh(par, wid, 1, 5), T, bv[1]);
+                        if (dn_glb) {
+                            const unsigned d = rowh(par, wid, 1);
+                            st2g(RS_ROW, d, T, bx[0], by[0]); st2g(RS_ROW, d + 16, T, bv[0], bx[1]); st2g(RS_ROW, d + 32, T, by[1], bv[1]);
+                        } else {
+                            float* d = &S.rrow[par][wave][1][0][lane];
+                            d[0] = bx[0]; d[64] = by[0]; d[128] = bv[0]; d[192] = bx[1]; d[256] = by[1]; d[320] = bv[1];
+                        }
                     }
-                    if ((lane == 1 && has_lf) || (lane == 62 && has_rt)) {
-                        const int side = lane == 1 ? 0 : 1;
-                        stgf(colh(par, wid, side, j, 0), T, bx[0]); stgf(colh(par, wid, side, j, 1), T, by[0]); stgf(colh(par, wid, side, j, 2), T, bv[0]);
-                        stgf(colh(par, wid, side, j, 3), T, bx[1]); stgf(colh(par, wid, side, j, 4), T, by[1]); stgf(colh(par, wid, side, j, 5), T, bv[1]);
+                    if (lane == 1 || lane == 62) {
+                        float* d = &S.cst[wave][lane == 1 ? 0 : 1][6 * j];
+                        d[0] = bx[0]; d[1] = by[0]; d[2] = bv[0]; d[3] = bx[1]; d[4] = by[1]; d[5] = bv[1];
                     }
                 }
             }
         }
-        // ---- the workgroup's sums: wave butterflies -> LDS -> wave 0 adds the four waves up in order and publishes 7 granules
+        RES_STAMP(k, 5);
+        // ---- publish: the LDS rows' tags, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the
+        // four waves up in order and publishes 7 granules)
         {
             const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
             if (lane == 0) { S.wa[wave] = wa; S.wd[wave][0] = w0; S.wd[wave][1] = w1; S.wd[wave][2] = w2; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (also the rows and columns written to LDS above)
+            if (lane == 0) {
+                __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (up_lds) __hip_atomic_store(&S.rtag[par][wave][0], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dn_lds) __hip_atomic_store(&S.rtag[par][wave][1], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (col_lane && (chalf == 0 ? has_lf : has_rt)) st1g(RS_COL, colh(par, wid, chalf, cword), T, __float_as_uint(S.cst[wave][chalf][cword]));
             if (wave == 0) {
                 sp.n = 0; sp.t0 = 0;
-                for (int w = 1; w < 4; ++w)
-                    while (!dead && __hip_atomic_load(&S.wtag[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != T) { if (spin_fail(sp, ctl, 5u, (unsigned)w, T)) dead = true; }
+                while (!dead) {
+                    const unsigned t1 = __hip_atomic_load(&S.wtag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), t2 = __hip_atomic_load(&S.wtag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned t3 = __hip_atomic_load(&S.wtag[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (t1 == T && t2 == T && t3 == T) break;
+                    if (spin_fail(sp, ctl, 5u, 0u, T)) dead = true;
+                }
                 dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (lane < 7) {
                     float s = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
                     for (int w = 0; w < 4; ++w) { s += S.wa[w]; b0 += S.wd[w][0]; b1 += S.wd[w][1]; b2 += S.wd[w][2]; }
                     const double pick = lane < 3 ? b0 : lane < 5 ? b1 : b2;
                     const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
-                    stg(sumw(par, lane, blockIdx.x), T, word);
+                    st1g(RS_SUM, sumw(par, blockIdx.x) + 8 * lane, T, word);
                 }
             }
         }
+        RES_STAMP(k, 6);
     }
     // ---- what L launches would have left behind: r_{L-1}, p_{L-1}, A p_{L-1}, delta (without its last term); the last iteration's two words
     if (a.L > 0) {
@@ -429,8 +523,21 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             }
         }
         if (id == 0) {      // (uniform per workgroup: all four waves of the writer's workgroup take part in the last sweep)
+            const unsigned T = seq + (unsigned)a.L; const int par = (a.L - 1) & 1;
+            unsigned w7[7];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) w7[c] = 0u;
+            bool ok = !slot_live;
+            sp.n = 0; sp.t0 = 0;
+            while (!ok && !dead) {
+                ok = true;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < 7; ++c) { const u32x2 v = ld1g(RS_SUM, sumw(par, slot) + 8 * c); w7[c] = v.x; ok = ok && v.y == T; }
+                if (!ok && spin_fail(sp, ctl, 1u, (unsigned)slot, T)) dead = true;
+            }
             float aD, bN;
-            finish_scalars(seq + (unsigned)a.L, (a.L - 1) & 1, aN_prev, aD, bN);
+            exchange_scalars(-1, T, w7, aN_prev, aD, bN);
             if (writer) { a.words[2 * (a.L - 1)] = aD; a.words[2 * (a.L - 1) + 1] = bN; }
         }
     }
@@ -470,6 +577,10 @@ inline size_t res_lds_bytes(int R) { return ((sizeof(ResLds) + 15) & ~(size_t)15
 
 extern "C" {
 
+#ifdef THALLO_MARCH_SWEEP
+int thallo_hip_debug_stamps_resident(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_r), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
+#endif
+
 void thallo_hip_resident_debug_set(int what, int value) { if (what == 0) g_res_rows = value; if (what == 1) g_res_cap = value; }
 
 /* rows per wave segment of the resident PCG kernel on `rows` owned rows of a W-wide image, or 0: the shape does not fit the chip's registers
@@ -483,7 +594,7 @@ long thallo_hip_iw_resident_bytes(int W, int rows)
     if (R <= 0) return 0;
     const ResGeo g = make_res_geo(W, rows, 0, rows, R);
     const long waves = (long)g.nstrips * g.nseg;
-    const long rowh = 2 * waves * 2 * 6 * 64, colh = 2 * waves * 2 * RES_MAX_R * 6, sums = 2L * 7 * THALLO_MAX_PARTIALS;
+    const long rowh = 2 * waves * 2 * 6 * 64, colh = 2 * waves * 2 * 32, sums = 2L * 8 * THALLO_MAX_PARTIALS;
     return (rowh + colh + sums) * (long)sizeof(u64) + RES_CTL_WORDS * (long)sizeof(unsigned) + 256;
 }
 
@@ -507,8 +618,8 @@ int thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs
     const long waves = (long)a.g.nstrips * a.g.nseg;
     u64* base = reinterpret_cast<u64*>(xbuf);
     a.b.rowh = base; base += 2 * waves * 2 * 6 * 64;
-    a.b.colh = base; base += 2 * waves * 2 * RES_MAX_R * 6;
-    a.b.sums = base; base += 2L * 7 * THALLO_MAX_PARTIALS;
+    a.b.colh = base; base += 2 * waves * 2 * 32;
+    a.b.sums = base; base += 2L * 8 * THALLO_MAX_PARTIALS;
     a.b.ctl = reinterpret_cast<unsigned*>(base);
     a.cs = cs; a.flags = flags; a.wf2 = w_fit * w_fit; a.wr2 = w_reg * w_reg;
     a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
@@ -519,7 +630,7 @@ int thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs
 #define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR>), dim3(grid), dim3(RES_NT), lds, s, a)
     switch (R) {
         case 1: RES_LAUNCH(1); break; case 2: RES_LAUNCH(2); break; case 3: RES_LAUNCH(3); break;
-        case 4: RES_LAUNCH(4); break; case 5: RES_LAUNCH(5); break; case 6: RES_LAUNCH(6); break;
+        case 4: RES_LAUNCH(4); break; case 5: RES_LAUNCH(5); break;
         default: return -(int)hipErrorNotSupported;
     }
 #undef RES_LAUNCH
@@ -534,7 +645,7 @@ int thallo_hip_iw_resident_status(int W, int rows, void* xbuf, int clear, int sp
     if (R <= 0 || !xbuf) return -(int)hipErrorInvalidValue;
     const ResGeo g = make_res_geo(W, rows, 0, rows, R);
     const long waves = (long)g.nstrips * g.nseg;
-    unsigned* ctl = reinterpret_cast<unsigned*>(reinterpret_cast<u64*>(xbuf) + 2 * waves * 2 * 6 * 64 + 2 * waves * 2 * RES_MAX_R * 6 + 2L * 7 * THALLO_MAX_PARTIALS);
+    unsigned* ctl = reinterpret_cast<unsigned*>(reinterpret_cast<u64*>(xbuf) + 2 * waves * 2 * 6 * 64 + 2 * waves * 2 * 32 + 2L * 8 * THALLO_MAX_PARTIALS);
     hipStream_t s = (hipStream_t)stream;
     unsigned w[RES_CTL_WORDS];
     if (hipMemcpyAsync(w, ctl, sizeof(w), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -(int)hipErrorUnknown;

@@ -56,6 +56,32 @@ if R > 0:
                 out["first_alpha_beta_mismatch"] = [i, bad[0], ta[bad[0]], tb[bad[0]]]; break
     out["resident_us_per_pcg_iter"] = round(a[4], 2)
     out["march_same_rows_us_per_pcg_iter"] = round(b[4], 2)
+if os.environ.get("RP_STAMPS") and R > 0:        # needs the sweep build: THALLO_LIB=tools/ab/libThallo_sweep.so
+    import ctypes as C
+    nw = 1024 * 4
+    st = torch.zeros(nw * 4 * 16, dtype=torch.int64, device="cuda")
+    assert Lb.thallo_hip_debug_stamps_resident(C.c_void_p(st.data_ptr())) == 0
+    run({}, steps=1)
+    torch.cuda.synchronize()
+    t = st.cpu().numpy().reshape(nw, 4, 16).astype(np.float64)
+    live = t[:, 0, 0] > 0
+    t = t[live]
+    names = ["global poll (sums quarter + row + columns)", "LDS exchange of the sums + butterflies", "LDS rows / columns in", "r / p / delta update", "stencil + halo stores", "wave sums + publish"]
+    d = np.diff(t[:, :, :7], axis=2) / 100.0          # us
+    out["stamps_waves"] = int(live.sum())
+    out["phase_us_mean"] = {n: round(float(d[:, :, i].mean()), 3) for i, n in enumerate(names)}
+    out["phase_us_max_wave"] = {n: round(float(d[:, :, i].mean(axis=1).max()), 3) for i, n in enumerate(names)}
+    tw = t[t[:, 1, 4] - t[:, 1, 3] > 30]            # waves with rows (their update phase takes time)
+    out["working_waves"] = int(len(tw))
+    out["working_phase_us"] = {"poll": round(float(((tw[:, :, 1] - tw[:, :, 0]) / 100).mean()), 3), "halo in (LDS)": round(float(((tw[:, :, 8] - tw[:, :, 1]) / 100).mean()), 3),
+                               "sums to LDS + wait siblings": round(float(((tw[:, :, 9] - tw[:, :, 8]) / 100).mean()), 3), "butterflies + scalars": round(float(((tw[:, :, 10] - tw[:, :, 9]) / 100).mean()), 3),
+                               "update": round(float(((tw[:, :, 4] - tw[:, :, 3]) / 100).mean()), 3), "stencil": round(float(((tw[:, :, 5] - tw[:, :, 4]) / 100).mean()), 3), "publish": round(float(((tw[:, :, 6] - tw[:, :, 5]) / 100).mean()), 3)}
+    out["poll_passes_lane0_mean"] = round(float(t[:, :, 7].mean()), 2)
+    out["iteration_us"] = round(float(((t[:, 1:, 0] - t[:, :-1, 0]) / 100.0).mean()), 3)
+    # skew: how far apart the waves enter an iteration, and leave their stencil
+    out["entry_skew_us"] = round(float((t[:, 1, 0].max() - t[:, 1, 0].min()) / 100.0), 3)
+    out["stencil_end_skew_us"] = round(float((t[:, 1, 5].max() - t[:, 1, 5].min()) / 100.0), 3)
+    Lb.thallo_hip_debug_stamps_resident(None)
 c = run({"THALLO_RESIDENT": "0"}, time_it=True)
 out["default_launch_per_iteration_us"] = round(c[4], 2)
 if R > 0:

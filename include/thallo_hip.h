@@ -355,7 +355,18 @@ int  thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* c
                                 thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, int L, thallo_stream_t stream);
 /* error word of the plan's resident launches (1 = a bounded wait ran out: results void); clear != 0 resets it; spin_ms >= 0 sets the bound in
  * milliseconds (0 = default); pm: 5 words of post-mortem or NULL.  Synchronises the stream. */
-int  thallo_hip_iw_resident_status(int W, int rows, void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream);
+int  thallo_hip_iw_resident_status(void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream);
+/* One rank's row slab of a multi-GPU run (local image W x H including its ghost rows, owned rows [row0, row1)): the first / last owned row of A p_k goes
+ * straight into the neighbouring ranks' ghost areas -- thallo_hip_iw_resident_ghost_bytes(W) bytes at byte offset ghost_off (a multiple of 16) of EVERY rank's
+ * mailbox block, d.peer_mail[rank -+ 1] -- workgroup 0 adds this rank's sums up, exchanges them through the mailbox slots slot0 + 7 k .. (the granules, slots
+ * and rank order of thallo_hip_iw_pcg_iter_march_dist: same bits) and publishes alphaD_k / betaN_k for the rest of the chip.  alphaN0: the GLOBAL alphaN_0.
+ * L <= 4095.  The caller has advanced the GN step counter (thallo_hip_dist_begin_step).  thallo_hip_iw_resident_rows_slab: rows per segment for such a slab
+ * (below != 0: a rank below -- the last segment must then be a full one), 0 = does not fit. */
+int  thallo_hip_iw_resident_rows_slab(int W, int rows, int below);
+long thallo_hip_iw_resident_ghost_bytes(int W);
+int  thallo_hip_iw_pcg_resident_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                     const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
+                                     thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, thallo_dist_t d, long ghost_off, int slot0, int L, thallo_stream_t stream);
 void thallo_hip_resident_debug_set(int what, int value);    /* tools / tests only: 0 rows per wave segment, 1 workgroup budget */
 /* rows per wave segment the marching kernels use on `rows` owned rows of a W-wide image; 0 = more column strips than the device has workgroup
  * slots: the marching entry points return -hipErrorNotSupported, the caller stays on thallo_hip_iw_pcg_iter (host logic, no launch) */

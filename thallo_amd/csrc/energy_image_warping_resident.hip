@@ -20,6 +20,7 @@
 // expression, never across statements): r, p, delta, A p and every alpha / beta come out bit-identical to the launch-per-iteration marching
 // kernel run with the same R (tests/test_gpu_parity.py).  Replaces gauss_newton.t:1615-1687 (the PCG loop) for these shapes.
 #include "iw_device.hpp"
+#include <cstring>
 
 using namespace thallo;
 
@@ -45,6 +46,11 @@ __device__ __forceinline__ u32x2 ld1g(rsrc_t r, unsigned off) { return __builtin
 __device__ __forceinline__ void st2g(rsrc_t r, unsigned off, unsigned tag, float v0, float v1)
 { u32x4 d; d.x = __float_as_uint(v0); d.y = tag; d.z = __float_as_uint(v1); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 16); }
 __device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsigned v) { u32x2 d; d.x = v; d.y = tag; __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, 16); }
+
+// system scope (sc0 sc1): granules a PEER GPU stored into my memory / that I store into a peer's
+__device__ __forceinline__ u32x4 ld2s(rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 17); }
+__device__ __forceinline__ void st2s(rsrc_t r, unsigned off, unsigned tag, float v0, float v1)
+{ u32x4 d; d.x = __float_as_uint(v0); d.y = tag; d.z = __float_as_uint(v1); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 17); }
 
 __device__ __forceinline__ float from_left(float v)
 {
@@ -87,11 +93,17 @@ struct ResBufs {
     u64* rowh;        // [2 parity][waves][2 sides: 0 = the wave's FIRST row (for the wave above), 1 = its LAST row (for the wave below)][64 lanes][6 components]
     u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][32: word 6 * row + component]
     u64* sums;        // [2 parity][1024 workgroups][8: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo, -]   (a workgroup's record = one 64-byte line, one store instruction)
+    u64* gs;          // [2 parity][2]: alphaD_k, betaN_k over ALL ranks, published by workgroup 0 (multi-GPU form: only that workgroup sweeps the sums)
     unsigned* ctl;    // RES_CTL_WORDS
 };
 
+// one rank's row slab of a multi-GPU run (solver_dist.cpp): the mailbox block of every rank carries, behind its scalar granules, a GHOST area
+// [2 parity][strips][2: 0 = the row that comes from the rank above, 1 = from the rank below][64 lanes][6 granules] that the neighbouring rank's
+// boundary waves store into directly (peer-to-peer over xGMI, system scope)
+struct ResDist { thallo_dist_t d; unsigned ghost_off; int slot0; int above, below; };
+
 struct ResArgs {
-    ResGeo g; ResBufs b;
+    ResGeo g; ResBufs b; ResDist x;
     const float* cs; const unsigned char* flags; float wf2, wr2;
     const float* r_in; const float* p_in;         // r_0 and p_{-1} (zeros): what PCGInit1 wrote
     float* r_out; float* A_out; float* p_out;     // r_{L-1}, A p_{L-1}, p_{L-1}: what L launches of the marching kernel leave behind
@@ -148,7 +160,58 @@ struct ResLds {
     float crx[4][2][32];              // per wave: the received columns (from the strip to the left / right), for lanes 0 / 63 to pick up
 };
 
-template <int R>
+// dist_exchange_iter_wave (dist_device.hpp) with the two results in registers: ONE full wave, converged.  This rank's sums go out as 7 granules to every rank's
+// mailbox slots slot0 .. slot0 + 6, the wave waits (bounded) for everybody's and adds them in rank order.
+__device__ __forceinline__ void res_exchange_ranks(const thallo_dist_t& d, int slot0, float ad, double q0, double q1, double q2, float an, float& gad_o, float& bn_o)
+{
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    unsigned w[7];
+    w[0] = __float_as_uint(ad);
+    { const u64 b = (u64)__double_as_longlong(q0); w[1] = (unsigned)(b >> 32); w[2] = (unsigned)b; }
+    { const u64 b = (u64)__double_as_longlong(q1); w[3] = (unsigned)(b >> 32); w[4] = (unsigned)b; }
+    { const u64 b = (u64)__double_as_longlong(q2); w[5] = (unsigned)(b >> 32); w[6] = (unsigned)b; }
+    const unsigned seq = ld_agent(d.ctl + DIST_SEQ);
+    if (lane < d.world) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) st_sys(d.peer_mail[lane] + (long)(slot0 + j) * d.world + d.rank, ((u64)seq << 32) | (u64)w[j]);
+    }
+    unsigned mine = 0;
+    if (lane < 7 * d.world) {                       // lane -> (granule j, source rank r)
+        const int j = lane / d.world, r = lane - j * d.world;
+        const u64* g = d.mail + (long)(slot0 + j) * d.world + r;
+        u64 v = ld_sys(g);
+        int it = 0; long long t0 = 0;
+        const long long bound = dist_spin_ticks(d);
+        while ((unsigned)(v >> 32) != seq) {
+            if ((it & 1023) == 0) { if (ld_agent(d.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
+            ++it;
+            if ((it & 1023) == 0 && wall_clock64() - t0 > bound) {
+                if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    unsigned* pm = d.ctl + DIST_POST_MORTEM;
+                    pm[0] = (unsigned)(slot0 + j); pm[1] = (unsigned)r; pm[2] = seq; pm[3] = (unsigned)(v >> 32); pm[4] = (unsigned)v;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = ld_sys(g);
+        }
+        mine = (unsigned)v;
+    }
+    float gad = 0.0f; double gq[3] = { 0.0, 0.0, 0.0 };
+    for (int r = 0; r < d.world; ++r) {
+        gad += __uint_as_float(__shfl(mine, r, THALLO_WAVE));
+        for (int j = 0; j < 3; ++j) {
+            const unsigned hi = __shfl(mine, (1 + 2 * j) * d.world + r, THALLO_WAVE), lo = __shfl(mine, (2 + 2 * j) * d.world + r, THALLO_WAVE);
+            gq[j] += __longlong_as_double((long long)(((u64)hi << 32) | (u64)lo));
+        }
+    }
+    const float alpha = safe_div<false>(an, gad);
+    double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
+    if (!(bn > 0.0)) bn = 0.0;
+    gad_o = gad; bn_o = (float)bn;
+}
+
+template <int R, bool DIST>
 __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,12 +254,20 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
 
     // ---- who my neighbours are (a neighbour exists = somebody publishes the granules I would wait for)
     const int wid = strip * g.nseg + seg;                                 // wave id: (strip, segment)
-    // (a segment with fewer than R rows is the last of its strip -- nothing below it -- so the row below a wave that HAS one is always row jj = R + 1)
-    const bool has_up = nr > 0 && seg > 0, has_dn = nr == R && yb < g.row1;
+    // (a segment with fewer than R rows is the last of its strip -- nothing below it, or the slab's ghost row only if the host made sure R divides the rows --
+    //  so the row below a wave that HAS one is always row jj = R + 1)
+    const bool rank_up = DIST && a.x.above != 0, rank_dn = DIST && a.x.below != 0;     // my top / bottom ghost row is the last / first owned row of another rank
+    const bool up_gh = nr > 0 && seg == 0 && rank_up, dn_gh = nr == R && yb == g.row1 && rank_dn;
+    const bool has_up = nr > 0 && (seg > 0 || rank_up), has_dn = nr == R && (yb < g.row1 || rank_dn);
     const bool has_lf = nr > 0 && strip > 0, has_rt = nr > 0 && strip + 1 < g.nstrips;        // (then lane 63's pixels -- x = 124 (strip + 1), + 1 -- are inside the image)
     const long waves = (long)g.nstrips * g.nseg;
     // byte offsets into the three exchange buffers (raw-buffer addressing: descriptor + 32-bit offset)
-    const rsrc_t RS_ROW = make_rsrc(a.b.rowh), RS_COL = make_rsrc(a.b.colh), RS_SUM = make_rsrc(a.b.sums);
+    const rsrc_t RS_ROW = make_rsrc(a.b.rowh), RS_COL = make_rsrc(a.b.colh), RS_SUM = make_rsrc(a.b.sums), RS_GS = make_rsrc(a.b.gs);
+    // multi-GPU: my ghost area (peers store into it) and the two neighbours' (I store into them)
+    const rsrc_t RS_GH = make_rsrc(DIST ? (const void*)a.x.d.mail : (const void*)a.b.gs);
+    const rsrc_t RS_PA = make_rsrc(rank_up ? (const void*)a.x.d.peer_mail[a.x.d.rank - 1] : (const void*)a.b.gs), RS_PB = make_rsrc(rank_dn ? (const void*)a.x.d.peer_mail[a.x.d.rank + 1] : (const void*)a.b.gs);
+    auto ghost = [&](int par, int dir) { return a.x.ghost_off + (unsigned)(((((long)par * g.nstrips + strip) * 2 + dir) * 64 + lane) * 48); };
+    const unsigned seqx = DIST ? __hip_atomic_load(a.x.d.ctl + DIST_SEQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 12 : 0u;       // cross-rank tag of iteration k: seqx + k + 1 (the GN step counter is the same on every rank)
     auto rowh = [&](int par, int w, int side) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + lane) * 48); };       // this lane's 6 granules of that row
     auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 32 + i) * 8); };     // granule i = 6 * row + component
     auto sumw = [&](int par, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * 8) * 8); };                    // that workgroup's 64-byte record
@@ -243,8 +314,9 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     bool dead = false;                    // a bounded wait ran out (here or elsewhere): no more waiting, the host raises
 
     // which of my halo rows comes through LDS (the neighbouring wave sits in my workgroup) and which through global memory (another workgroup)
-    const bool up_lds = has_up && wave > 0, up_glb = has_up && wave == 0;
-    const bool dn_lds = has_dn && wave < 3, dn_glb = has_dn && wave == 3;
+    const bool up_lds = has_up && wave > 0, up_glb = has_up && wave == 0 && !up_gh;
+    const bool dn_lds = has_dn && wave < 3 && !dn_gh, dn_glb = has_dn && wave == 3 && !dn_gh;
+    const bool sweeper = !DIST || id == 0;                    // multi-GPU: only workgroup 0 adds the sums up (and talks to the other ranks); everybody else waits for its two words
     const int slot = 64 * wave + lane;    // the sums slot this lane sweeps
     long sid;
     const bool slot_live = slot < grid && wg_id(slot, sid);
@@ -253,7 +325,7 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
 
     // Publish my quarter of the sums of an iteration (the 7 words of slot 64 w + lane) to the other waves of the workgroup, wait for theirs, and add all
     // slots up in the order the launch-per-iteration path uses (lane-strided over the slots, then the wave butterfly): alphaD_k, betaN_k -- same bits everywhere.
-    auto exchange_scalars = [&](int kk, unsigned T, const unsigned (&w7)[7], float aN, float& aD_o, float& bN_o) {
+    auto exchange_scalars = [&](int kk, unsigned T, const unsigned (&w7)[7], float& ad_o, double& n_o, double& s1_o, double& s2_o) {
         RES_STAMP(kk, 8);
 #pragma unroll
         for (int c = 0; c < 7; ++c) S.q[wave][c][lane] = w7[c];
@@ -278,13 +350,35 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             a1 += __hiloint2double((int)qq[192], (int)qq[256]);
             b1 += __hiloint2double((int)qq[320], (int)qq[384]);
         }
-        const float ad = wave_sum_all(t);
-        n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
-        const float al = safe_div<false>(aN, ad);
-        double bd = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
-        if (!(bd > 0.0)) bd = 0.0;
-        aD_o = ad; bN_o = (float)bd;
+        ad_o = wave_sum_all(t);
+        n_o = wave_sum_all_d(n); s1_o = wave_sum_all_d(a1); s2_o = wave_sum_all_d(b1);
         RES_STAMP(kk, 10);
+    };
+    // alphaD_k, betaN_k from the sums: on one GPU alpha_k = alphaN_k / alphaD_k, betaN_k = N - 2 alpha S1 + alpha^2 S2 (iteration_scalars' expressions); across
+    // ranks wave 0 of workgroup 0 sends this rank's four sums to every rank's mailbox, adds everybody's in rank order (dist_exchange_iter_wave's granules, slots and
+    // order: same bits as the launch-per-iteration transport) and publishes the two words for the rest of the chip
+    auto scalars_from_sums = [&](int k_of, unsigned T, int par, float aN, float ad, double n, double a1, double b1, float& aD_o, float& bN_o) {
+        if (!DIST) {
+            const float al = safe_div<false>(aN, ad);
+            double bd = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
+            if (!(bd > 0.0)) bd = 0.0;
+            aD_o = ad; bN_o = (float)bd;
+        } else if (wave == 0) {
+            float gad, gbn;
+            res_exchange_ranks(a.x.d, a.x.slot0 + 7 * k_of, ad, n, a1, b1, aN, gad, gbn);
+            if (lane == 0) st2g(RS_GS, (unsigned)par * 16u, T, gad, gbn);
+            aD_o = gad; bN_o = gbn;
+        } else {
+            u32x4 v; bool ok = false;
+            sp.n = 0; sp.t0 = 0;
+            while (!ok && !dead) {
+                asm volatile("" ::: "memory");
+                v = ld2g(RS_GS, (unsigned)par * 16u);
+                ok = v.y == T && v.w == T;
+                if (!ok && spin_fail(sp, ctl, 8u, 0u, T)) dead = true;
+            }
+            aD_o = __uint_as_float(v.x); bN_o = __uint_as_float(v.z);
+        }
     };
 
     for (int k = 0; k < a.L; ++k) {
@@ -299,46 +393,62 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             // ---- the one synchronisation point.  Everything that comes through global memory is polled in ONE loop, all loads of a pass in flight together:
             // my quarter of the sums of iteration k-1, the row of A p_{k-1} from the workgroup above (wave 0) / below (wave 3), and one word per lane of the
             // two columns from the strips to the left / right.
-            unsigned w7[7]; float rowv[6]; float cv = 0.f;
+            unsigned w7[7]; float rowu[6], rowd[6]; float cv = 0.f; float g_ad = 0.f, g_bn = 0.f;
 #pragma unroll
             for (int c = 0; c < 7; ++c) w7[c] = 0u;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) rowv[c] = 0.f;
+            for (int c = 0; c < 6; ++c) { rowu[c] = 0.f; rowd[c] = 0.f; }
             {
-                const bool need_r = xout && (up_glb || dn_glb), need_c = col_lane && (chalf == 0 ? has_lf : has_rt);
-                const unsigned rsrc = up_glb ? rowh(parp, wid - 1, 1) : rowh(parp, dn_glb ? wid + 1 : wid, 0);
+                const unsigned Txp = seqx + (unsigned)k;              // cross-rank tag of iteration k - 1
+                const bool need_u = xout && (up_glb || up_gh), need_d = xout && (dn_glb || dn_gh), need_c = col_lane && (chalf == 0 ? has_lf : has_rt);
+                const bool need_s = sweeper && slot_live, need_g = !sweeper;
+                const unsigned usrc = up_gh ? ghost(parp, 0) : rowh(parp, up_glb ? wid - 1 : wid, 1), dsrc = dn_gh ? ghost(parp, 1) : rowh(parp, dn_glb ? wid + 1 : wid, 0);
                 const unsigned ssrc = sumw(parp, slot);
                 const unsigned csrc = chalf == 0 ? colh(parp, has_lf ? wid - g.nseg : wid, 1, cword) : colh(parp, has_rt ? wid + g.nseg : wid, 0, cword);
-                bool ok_s = !slot_live, ok_r = !need_r, ok_c = !need_c;
+                bool ok_s = !need_s, ok_g = !need_g, ok_u = !need_u, ok_d = !need_d, ok_c = !need_c;
                 sp.n = 0; sp.t0 = 0;
                 unsigned npass = 0;
-                while (!(ok_s && ok_r && ok_c) && !dead) {
+                while (!(ok_s && ok_g && ok_u && ok_d && ok_c) && !dead) {
                     ++npass;
                     asm volatile("" ::: "memory");                     // (every pass re-reads: nothing may be hoisted out of the loop)
-                    u32x4 vs[4], vr[3]; u32x2 vc;
+                    u32x4 vs[4], vu[3], vd[3], vg; u32x2 vc;
                     if (!ok_s) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) vs[c] = ld2g(RS_SUM, ssrc + 16 * c);
                     }
-                    if (!ok_r) {
+                    if (!ok_g) vg = ld2g(RS_GS, (unsigned)parp * 16u);
+                    if (!ok_u) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) vr[c] = ld2g(RS_ROW, rsrc + 16 * c);
+                        for (int c = 0; c < 3; ++c) vu[c] = (DIST && up_gh) ? ld2s(RS_GH, usrc + 16 * c) : ld2g(RS_ROW, usrc + 16 * c);
+                    }
+                    if (!ok_d) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) vd[c] = (DIST && dn_gh) ? ld2s(RS_GH, dsrc + 16 * c) : ld2g(RS_ROW, dsrc + 16 * c);
                     }
                     if (!ok_c) vc = ld1g(RS_COL, csrc);
                     if (!ok_s) {
                         w7[0] = vs[0].x; w7[1] = vs[0].z; w7[2] = vs[1].x; w7[3] = vs[1].z; w7[4] = vs[2].x; w7[5] = vs[2].z; w7[6] = vs[3].x;
                         ok_s = vs[0].y == Tp && vs[0].w == Tp && vs[1].y == Tp && vs[1].w == Tp && vs[2].y == Tp && vs[2].w == Tp && vs[3].y == Tp;
                     }
-                    if (!ok_r) {
+                    if (!ok_g) { g_ad = __uint_as_float(vg.x); g_bn = __uint_as_float(vg.z); ok_g = vg.y == Tp && vg.w == Tp; }
+                    if (!ok_u) {
+                        const unsigned tt = (DIST && up_gh) ? Txp : Tp;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) { rowv[2 * c] = __uint_as_float(vr[c].x); rowv[2 * c + 1] = __uint_as_float(vr[c].z); }
-                        ok_r = vr[0].y == Tp && vr[0].w == Tp && vr[1].y == Tp && vr[1].w == Tp && vr[2].y == Tp && vr[2].w == Tp;
+                        for (int c = 0; c < 3; ++c) { rowu[2 * c] = __uint_as_float(vu[c].x); rowu[2 * c + 1] = __uint_as_float(vu[c].z); }
+                        ok_u = vu[0].y == tt && vu[0].w == tt && vu[1].y == tt && vu[1].w == tt && vu[2].y == tt && vu[2].w == tt;
+                    }
+                    if (!ok_d) {
+                        const unsigned tt = (DIST && dn_gh) ? Txp : Tp;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { rowd[2 * c] = __uint_as_float(vd[c].x); rowd[2 * c + 1] = __uint_as_float(vd[c].z); }
+                        ok_d = vd[0].y == tt && vd[0].w == tt && vd[1].y == tt && vd[1].w == tt && vd[2].y == tt && vd[2].w == tt;
                     }
                     if (!ok_c) { cv = __uint_as_float(vc.x); ok_c = vc.y == Tp; }
-                    if (!(ok_s && ok_r && ok_c) && spin_fail(sp, ctl, !ok_s ? 1u : !ok_r ? 3u : 4u, (unsigned)wid, Tp)) dead = true;
+                    if (!(ok_s && ok_g && ok_u && ok_d && ok_c) && spin_fail(sp, ctl, !ok_s ? 1u : !ok_g ? 8u : !(ok_u && ok_d) ? 3u : 4u, (unsigned)wid, Tp)) dead = true;
                 }
                 RES_NOTE(k, 7, npass); (void)npass;
             }
+            dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
             RES_STAMP(k, 1);
             // the columns go through LDS to the two lanes that hold them (lane 0 / 63); same wave: program order + lgkmcnt(0)
             if (col_lane) S.crx[wave][chalf][cword] = cv;
@@ -358,8 +468,8 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             float up[6], dn[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                up[c] = up_lds ? S.rrow[parp][wave - 1][1][c][lane] : rowv[c];
-                dn[c] = dn_lds ? S.rrow[parp][wave + 1][0][c][lane] : rowv[c];
+                up[c] = up_lds ? S.rrow[parp][wave - 1][1][c][lane] : rowu[c];
+                dn[c] = dn_lds ? S.rrow[parp][wave + 1][0][c][lane] : rowd[c];
             }
             if (has_up && xout) { ax[0][0] = up[0]; ay[0][0] = up[1]; av[0][0] = up[2]; ax[0][1] = up[3]; ay[0][1] = up[4]; av[0][1] = up[5]; }
             if (has_dn && xout) { ax[R + 1][0] = dn[0]; ay[R + 1][0] = dn[1]; av[R + 1][0] = dn[2]; ax[R + 1][1] = dn[3]; ay[R + 1][1] = dn[4]; av[R + 1][1] = dn[5]; }
@@ -374,8 +484,12 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                     }
                 }
             }
-            float aD, bN;
-            exchange_scalars(k, Tp, w7, aN_prev, aD, bN);
+            float aD = g_ad, bN = g_bn;
+            if (sweeper) {
+                float ad; double n, a1, b1;
+                exchange_scalars(k, Tp, w7, ad, n, a1, b1);
+                scalars_from_sums(k - 1, Tp, parp, aN_prev, ad, n, a1, b1, aD, bN);
+            }
             alpha = safe_div<false>(aN_prev, aD);
             beta = safe_div<false>(bN, aN_prev);
             if (writer) { a.words[2 * (k - 1)] = aD; a.words[2 * (k - 1) + 1] = bN; }
@@ -446,7 +560,15 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                         ax[jc][q] = bx[q]; ay[jc][q] = by[q]; av[jc][q] = bv[q];
                     }
                     // the boundary goes out as soon as it exists: to another workgroup as granules, to a wave of my workgroup through LDS (tagged below)
-                    if (j == 0 && has_up) {
+                    if (DIST && j == 0 && up_gh) {        // my first owned row is the rank above's bottom ghost row
+                        const unsigned d = ghost(par, 1), Tx = seqx + (unsigned)k + 1u;
+                        st2s(RS_PA, d, Tx, bx[0], by[0]); st2s(RS_PA, d + 16, Tx, bv[0], bx[1]); st2s(RS_PA, d + 32, Tx, by[1], bv[1]);
+                    }
+                    if (DIST && j == R - 1 && dn_gh) {    // my last owned row is the rank below's top ghost row
+                        const unsigned d = ghost(par, 0), Tx = seqx + (unsigned)k + 1u;
+                        st2s(RS_PB, d, Tx, bx[0], by[0]); st2s(RS_PB, d + 16, Tx, bv[0], bx[1]); st2s(RS_PB, d + 32, Tx, by[1], bv[1]);
+                    }
+                    if (j == 0 && has_up && !up_gh) {
                         if (up_glb) {
                             const unsigned d = rowh(par, wid, 0);
                             st2g(RS_ROW, d, T, bx[0], by[0]); st2g(RS_ROW, d + 16, T, bv[0], bx[1]); st2g(RS_ROW, d + 32, T, by[1], bv[1]);
@@ -455,7 +577,7 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                             d[0] = bx[0]; d[64] = by[0]; d[128] = bv[0]; d[192] = bx[1]; d[256] = by[1]; d[320] = bv[1];
                         }
                     }
-                    if (j == nr - 1 && has_dn) {
+                    if (j == nr - 1 && has_dn && !dn_gh) {
                         if (dn_glb) {
                             const unsigned d = rowh(par, wid, 1);
                             st2g(RS_ROW, d, T, bx[0], by[0]); st2g(RS_ROW, d + 16, T, bv[0], bx[1]); st2g(RS_ROW, d + 32, T, by[1], bv[1]);
@@ -536,8 +658,10 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                 for (int c = 0; c < 7; ++c) { const u32x2 v = ld1g(RS_SUM, sumw(par, slot) + 8 * c); w7[c] = v.x; ok = ok && v.y == T; }
                 if (!ok && spin_fail(sp, ctl, 1u, (unsigned)slot, T)) dead = true;
             }
+            float ad; double n, a1, b1;
+            exchange_scalars(-1, T, w7, ad, n, a1, b1);
             float aD, bN;
-            exchange_scalars(-1, T, w7, aN_prev, aD, bN);
+            scalars_from_sums(a.L - 1, T, par, aN_prev, ad, n, a1, b1, aD, bN);
             if (writer) { a.words[2 * (a.L - 1)] = aD; a.words[2 * (a.L - 1) + 1] = bN; }
         }
     }
@@ -559,12 +683,15 @@ inline ResGeo make_res_geo(int W, int H, int row0, int row1, int R)
 int g_res_cap = 0;       // tests: workgroup budget (0 = the device's CU count: one workgroup per CU, all of them resident at once)
 int g_res_rows = 0;      // tests / tools: rows per segment (0 = automatic)
 
-inline int res_rows(int W, int rows)
+// rows per wave segment, or 0 = the shape does not fit.  below: the slab has a ghost row under its last owned row (a rank below) -- the last segment must
+// then be a full one (its row below sits at a fixed place in the wave's registers)
+inline int res_rows(int W, int rows, bool below = false)
 {
     if (W < 2 || (W & 1) || rows < 1) return 0;
     const long cap = g_res_cap > 0 ? g_res_cap : thallo_hip_device_cu_count();
     const int nstrips = (W + RES_USE - 1) / RES_USE;
     int R = g_res_rows > 0 ? g_res_rows : march_rows_per_segment(rows, nstrips, RES_NT / 64, cap, 2);
+    if (below) while (R > 0 && R <= RES_MAX_R && rows % R != 0) ++R;
     if (R <= 0 || R > RES_MAX_R) return 0;
     const ResGeo g = make_res_geo(W, rows, 0, rows, R);
     if ((g.total + 7) / 8 * 8 > cap || (g.total + 7) / 8 * 8 > THALLO_MAX_PARTIALS) return 0;      // every workgroup must be resident: they wait for each other
@@ -572,6 +699,40 @@ inline int res_rows(int W, int rows)
 }
 
 inline size_t res_lds_bytes(int R) { return ((sizeof(ResLds) + 15) & ~(size_t)15) + (size_t)R * 6 * RES_NT * sizeof(float); }
+
+// the plan's exchange memory: [control words | the two global words | sums records | column granules | row granules]  (the control words come first: their
+// place does not depend on the rows per segment)
+struct ResLayout { long ctl, gs, sums, colh, rowh, bytes; };
+inline ResLayout res_layout(const ResGeo& g)
+{
+    const long waves = (long)g.nstrips * g.nseg;
+    ResLayout l;
+    l.ctl = 0; l.gs = 32; l.sums = l.gs + 8; l.colh = l.sums + 2L * 8 * THALLO_MAX_PARTIALS; l.rowh = l.colh + 2 * waves * 2 * 32;       // (u64 units; 32 u64 = 256 bytes of control words)
+    l.bytes = (l.rowh + 2 * waves * 2 * 64 * 6) * (long)sizeof(u64) + 256;
+    return l;
+}
+inline void res_bufs(void* xbuf, const ResGeo& g, ResBufs& b)
+{
+    const ResLayout l = res_layout(g);
+    u64* base = reinterpret_cast<u64*>(xbuf);
+    b.rowh = base + l.rowh; b.colh = base + l.colh; b.sums = base + l.sums; b.gs = base + l.gs; b.ctl = reinterpret_cast<unsigned*>(base + l.ctl);
+}
+
+template <bool DIST>
+int res_launch(const ResArgs& a, int R, hipStream_t s)
+{
+    const int grid = (a.g.total + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)a.L);
+    const size_t lds = res_lds_bytes(R);
+#define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR, DIST>), dim3(grid), dim3(RES_NT), lds, s, a)
+    switch (R) {
+        case 1: RES_LAUNCH(1); break; case 2: RES_LAUNCH(2); break; case 3: RES_LAUNCH(3); break;
+        case 4: RES_LAUNCH(4); break; case 5: RES_LAUNCH(5); break;
+        default: return -(int)hipErrorNotSupported;
+    }
+#undef RES_LAUNCH
+    int e = check_launch(); return e ? e : grid;
+}
 
 }  // namespace
 
@@ -584,19 +745,20 @@ int thallo_hip_debug_stamps_resident(unsigned long long* buf) { return hipMemcpy
 void thallo_hip_resident_debug_set(int what, int value) { if (what == 0) g_res_rows = value; if (what == 1) g_res_cap = value; }
 
 /* rows per wave segment of the resident PCG kernel on `rows` owned rows of a W-wide image, or 0: the shape does not fit the chip's registers
- * (more than RES_MAX_R rows per wave at one workgroup per CU) and the caller runs one launch per PCG iteration */
+ * (more than RES_MAX_R rows per wave at one workgroup per CU) and the caller runs one launch per PCG iteration.  below != 0: a row slab with a rank below. */
 int thallo_hip_iw_resident_rows(int W, int rows) { return res_rows(W, rows); }
+int thallo_hip_iw_resident_rows_slab(int W, int rows, int below) { return res_rows(W, rows, below != 0); }
 
 /* bytes of exchange memory a plan needs for the resident kernel (zero-filled by the caller once; layout private to this file) */
 long thallo_hip_iw_resident_bytes(int W, int rows)
 {
+    // (sized for the smallest admissible R: the largest wave count; a slab whose last segment must be full may run with a larger one)
     const int R = res_rows(W, rows);
     if (R <= 0) return 0;
-    const ResGeo g = make_res_geo(W, rows, 0, rows, R);
-    const long waves = (long)g.nstrips * g.nseg;
-    const long rowh = 2 * waves * 2 * 6 * 64, colh = 2 * waves * 2 * 32, sums = 2L * 8 * THALLO_MAX_PARTIALS;
-    return (rowh + colh + sums) * (long)sizeof(u64) + RES_CTL_WORDS * (long)sizeof(unsigned) + 256;
+    return res_layout(make_res_geo(W, rows, 0, rows, R)).bytes;
 }
+/* bytes of the ghost area a rank's mailbox block carries behind its scalar granules (multi-GPU form) */
+long thallo_hip_iw_resident_ghost_bytes(int W) { return W < 2 ? 0 : 2L * ((W + RES_USE - 1) / RES_USE) * 2 * 64 * 48; }
 
 /* The PCG loop of one Gauss-Newton step in one launch: L iterations from what thallo_hip_iw_pcg_init left (r_0 in r_in, zeros in p_in and delta, cs / flags,
  * alphaN_0), leaving what L launches of thallo_hip_iw_pcg_iter_march leave: r_{L-1}, A p_{L-1}, p_{L-1} in the *_out planes, delta without its last term, and
@@ -612,40 +774,47 @@ int thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs
     if (!cs || !flags || !r_in || !p_in || !r_out || !Ap_out || !p_out || !delta || !words || !xbuf || !alphaN0.partials) return -(int)hipErrorInvalidValue;
     const int R = res_rows(W, row1 - row0);
     if (R <= 0) return -(int)hipErrorNotSupported;
-    ResArgs a;
+    ResArgs a; memset(&a, 0, sizeof(a));
     a.g = make_res_geo(W, H, row0, row1, R);
-    const int grid = (a.g.total + 7) / 8 * 8;
-    const long waves = (long)a.g.nstrips * a.g.nseg;
-    u64* base = reinterpret_cast<u64*>(xbuf);
-    a.b.rowh = base; base += 2 * waves * 2 * 6 * 64;
-    a.b.colh = base; base += 2 * waves * 2 * 32;
-    a.b.sums = base; base += 2L * 8 * THALLO_MAX_PARTIALS;
-    a.b.ctl = reinterpret_cast<unsigned*>(base);
+    res_bufs(xbuf, a.g, a.b);
     a.cs = cs; a.flags = flags; a.wf2 = w_fit * w_fit; a.wr2 = w_reg * w_reg;
     a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
     a.aN0 = alphaN0; a.words = words; a.irregular = irregular; a.L = L;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)L);
-    const size_t lds = res_lds_bytes(R);
-#define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR>), dim3(grid), dim3(RES_NT), lds, s, a)
-    switch (R) {
-        case 1: RES_LAUNCH(1); break; case 2: RES_LAUNCH(2); break; case 3: RES_LAUNCH(3); break;
-        case 4: RES_LAUNCH(4); break; case 5: RES_LAUNCH(5); break;
-        default: return -(int)hipErrorNotSupported;
-    }
-#undef RES_LAUNCH
-    int e = check_launch(); return e ? e : grid;
+    return res_launch<false>(a, R, (hipStream_t)stream);
+}
+
+/* The same for ONE RANK's row slab of a multi-GPU run (local image W x H with its ghost rows, owned rows [row0, row1)): the first / last owned row of A p_k
+ * goes straight into the neighbouring ranks' ghost areas (d.peer_mail[rank -+ 1] + ghost_off bytes: thallo_hip_iw_resident_ghost_bytes() bytes behind the scalar
+ * granules of every rank's mailbox block), workgroup 0 adds this rank's sums up, exchanges them with the other ranks through the mailbox slots slot0 + 7 k ..
+ * (the granules, slots and rank order of thallo_hip_iw_pcg_iter_march_dist: same bits) and publishes alphaD_k / betaN_k for the rest of the chip.  alphaN0: the
+ * global alphaN_0 (one word).  L <= 4095.  The caller has advanced the GN step counter (thallo_hip_dist_begin_step). */
+int thallo_hip_iw_pcg_resident_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                    const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
+                                    thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, thallo_dist_t d, long ghost_off, int slot0, int L, thallo_stream_t stream)
+{
+    if (row0 < 0 || row1 > H || row0 >= row1 || (W & 1) || W < 2 || L < 1 || L > 4095) return -(int)hipErrorInvalidValue;
+    if (!cs || !flags || !r_in || !p_in || !r_out || !Ap_out || !p_out || !delta || !words || !xbuf || !alphaN0.partials) return -(int)hipErrorInvalidValue;
+    if (d.world < 1 || d.world > THALLO_DIST_MAX_WORLD || 7 * d.world > 64 || !d.mail || !d.ctl || ghost_off < 0 || (ghost_off & 15) || slot0 < 0) return -(int)hipErrorInvalidValue;
+    const bool above = row0 > 0, below = row1 < H;
+    if ((above && (d.rank < 1 || !d.peer_mail[d.rank - 1])) || (below && (d.rank + 1 >= d.world || !d.peer_mail[d.rank + 1])) || row0 > 1 || H - row1 > 1) return -(int)hipErrorInvalidValue;
+    const int R = res_rows(W, row1 - row0, below);
+    if (R <= 0) return -(int)hipErrorNotSupported;
+    ResArgs a; memset(&a, 0, sizeof(a));
+    a.g = make_res_geo(W, H, row0, row1, R);
+    res_bufs(xbuf, a.g, a.b);
+    a.x.d = d; a.x.ghost_off = (unsigned)ghost_off; a.x.slot0 = slot0; a.x.above = above; a.x.below = below;
+    a.cs = cs; a.flags = flags; a.wf2 = w_fit * w_fit; a.wr2 = w_reg * w_reg;
+    a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
+    a.aN0 = alphaN0; a.words = words; a.irregular = irregular; a.L = L;
+    return res_launch<true>(a, R, (hipStream_t)stream);
 }
 
 /* the error word of a plan's resident launches: 1 = a bounded wait ran out (a workgroup was not resident, or a granule never arrived); clear != 0 resets
  * it.  pm (5 words, may be NULL): what the first timed-out wait was for.  Synchronises the stream.  spin_ms >= 0 sets the bound (0 = the 2 s default). */
-int thallo_hip_iw_resident_status(int W, int rows, void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream)
+int thallo_hip_iw_resident_status(void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream)
 {
-    const int R = res_rows(W, rows);
-    if (R <= 0 || !xbuf) return -(int)hipErrorInvalidValue;
-    const ResGeo g = make_res_geo(W, rows, 0, rows, R);
-    const long waves = (long)g.nstrips * g.nseg;
-    unsigned* ctl = reinterpret_cast<unsigned*>(reinterpret_cast<u64*>(xbuf) + 2 * waves * 2 * 6 * 64 + 2 * waves * 2 * 32 + 2L * 8 * THALLO_MAX_PARTIALS);
+    if (!xbuf) return -(int)hipErrorInvalidValue;
+    unsigned* ctl = reinterpret_cast<unsigned*>(xbuf);
     hipStream_t s = (hipStream_t)stream;
     unsigned w[RES_CTL_WORDS];
     if (hipMemcpyAsync(w, ctl, sizeof(w), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -(int)hipErrorUnknown;

@@ -159,6 +159,7 @@ class ImageWarpingPlugin : public EnergyPlugin {
     DeviceBuffer cs, flags, irregular;     // per-GN-iteration planes: (cos,sin) float2, validity bits; UrShape-is-grid word
     DeviceBuffer xres;                     // exchange memory of the resident PCG kernel (granule buffers + control words)
     bool resident_ = false;                // the shape fits the resident kernel (whole image, unit pixel grid, even W, few enough rows per wave)
+    bool resident_slab_ = false;           // ... as one rank's row slab of a multi-GPU run (thallo_hip_iw_pcg_resident_dist)
     bool march_ = false;                   // UrShape verified (at Init) to be the unit pixel grid and W even: the marching one-kernel iteration
     bool grid_ = false;                    // UrShape is the unit pixel grid (host-checked at Init)
     int row0_ = 0, row1_ = 0;              // owned rows (all of them unless the Plan is one row slab of a multi-GPU run)
@@ -200,14 +201,16 @@ public:
         // an image with more 124-pixel column strips than the device has workgroup slots stays on the tile kernel (which loops over its tiles)
         if (march_ && thallo_hip_iw_march_rows(W, H) <= 0) march_ = false;
         // small working sets: the whole PCG loop in one launch (state in registers); THALLO_RESIDENT=0: one launch per PCG iteration (A/B)
-        resident_ = false;
+        resident_ = resident_slab_ = false;
         const char* er = getenv("THALLO_RESIDENT");
-        if (grid_ && !(er && er[0] == '0') && row0_ == 0 && row1_ == H && thallo_hip_iw_resident_rows(W, H) > 0) {
-            const long need = thallo_hip_iw_resident_bytes(W, H);
-            if ((long)xres.bytes < need) {
+        const bool whole = row0_ == 0 && row1_ == H;
+        const int rr = whole ? thallo_hip_iw_resident_rows(W, H) : thallo_hip_iw_resident_rows_slab(W, row1_ - row0_, row1_ < H ? 1 : 0);
+        if (grid_ && !(er && er[0] == '0') && rr > 0) {
+            const long need = thallo_hip_iw_resident_bytes(W, row1_ - row0_);
+            if (need > 0 && (long)xres.bytes < need) {
                 if (xres.alloc((size_t)need) || hipMemsetAsync(xres.ptr, 0, (size_t)need, c.stream) != hipSuccess) { set_error("image_warping: out of device memory for the resident kernel's exchange buffers"); return -1; }
             }
-            resident_ = true;
+            if (need > 0) { resident_ = whole; resident_slab_ = true; }
         }
         return 0;
     }
@@ -282,8 +285,16 @@ public:
         return thallo_hip_iw_pcg_resident(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg, v.rbuf(0), v.p[0],
                                           v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words, (const int*)irregular.ptr, xres.ptr, L, c.stream);
     }
+    bool resident_slab_ok() const override { return resident_slab_; }
+    long resident_ghost_bytes() const override { return (W & 1) ? 0 : thallo_hip_iw_resident_ghost_bytes(W); }
+    int pcg_resident_dist(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words, const thallo_dist_t& d, long ghost_off, int slot0) override
+    {
+        TimedLaunch t(c, "PCGLoopResident");
+        return thallo_hip_iw_pcg_resident_dist(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg, v.rbuf(0), v.p[0],
+                                               v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words, (const int*)irregular.ptr, xres.ptr, d, ghost_off, slot0, L, c.stream);
+    }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override
-    { return resident_ && xres.ptr ? thallo_hip_iw_resident_status(W, H, xres.ptr, clear, -1, pm, c.stream) : 0; }
+    { return xres.ptr ? thallo_hip_iw_resident_status(xres.ptr, clear, -1, pm, c.stream) : 0; }
     bool iter_defers_finish() const override { return true; }
     int pcg_iter_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aN2, thallo_sum_t aD2, const thallo_prev_t& prev,
                           float* out, double* s12_out) override

@@ -68,6 +68,7 @@ struct DistState {
     // device-side exchange
     bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
     void* mail = nullptr; int mail_L = 0;
+    long ghost_off = 0;                                  // byte offset of the resident kernel's ghost area inside every rank's mailbox block (0: none)
     DeviceBuffer ctl;
     thallo_dist_t d, d_iter[2];
     std::vector<void*> opened;

@@ -258,7 +258,10 @@ int Plan::dist_map_peers()
     D.mail_L = std::max(sp.lIterations, 256);
     const long n_slots = 7L * (D.mail_L + 2);                            // 7 granules per PCG iteration
     PeerInfo mine; memset(&mine, 0, sizeof(mine));
-    mine.ok = thallo_hip_ipc_alloc2(8 * n_slots * world, &D.mail, D.handle_mail, &D.mem_kind[1]) >= 0 ? 1 : 0;
+    // behind the scalar granules: the ghost area the resident PCG kernel's boundary waves of the neighbouring ranks store into (same offset on every rank)
+    const long gbytes = plugin->resident_ghost_bytes();
+    D.ghost_off = gbytes > 0 ? (8 * n_slots * world + 255) / 256 * 256 : 0;
+    mine.ok = thallo_hip_ipc_alloc2(gbytes > 0 ? D.ghost_off + gbytes : 8 * n_slots * world, &D.mail, D.handle_mail, &D.mem_kind[1]) >= 0 ? 1 : 0;
     if (!mine.ok) D.mail = nullptr;
     memcpy(mine.block, D.handle_block, 64); memcpy(mine.mail, D.handle_mail, 64);
     mine.row0 = D.row0; mine.row1 = D.row1; mine.Hl = D.Hl; mine.na = D.na;
@@ -309,6 +312,12 @@ float Plan::dist_cost()
     // and leave the plan not ready, so the next Thallo_ProblemStep returns 0 on all of them.
     DistState& D = *dist_;
     hipStream_t s = ctx.stream;
+    if (resident_used_ && !D.failed) {     // the resident PCG kernel's waits are bounded; one that ran out voids the steps since the last check (this rank says so in the message below: every rank stops)
+        resident_used_ = false;
+        unsigned pm[5] = { 0, 0, 0, 0, 0 };
+        if (plugin->resident_status(ctx, 1, pm) != 0)
+            dist_fail("a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u)", pm[0], pm[1], pm[2], pm[3], pm[4]);
+    }
     int nb = 0;
     if (!D.failed) { nb = plugin->cost(ctx, slot(0)); if (nb < 0) dist_fail("cost kernel launch failed (%d)", nb); }
     if (!D.failed) { set_nb(0, nb); DLOCAL(thallo_hip_finish_sum(sum(0), (float*)D.send.ptr, s), "cost sum"); }
@@ -365,7 +374,21 @@ int Plan::dist_gn(int L, bool p2p)
     // slab sizes the 6 B/pixel it would save do not matter (2048x256: 22.6 vs 24.3 us per iteration).  (Either delta schedule gives the same bits -- tested
     // for both kernels; the marching kernel's multi-GPU variant is contracted differently from its single-GPU one, so its two TRANSPORTS agree to rounding.)
     const bool batch = batch_delta_ && !p2p;
-    for (int k = 0; k < L; ++k) {
+    // Small slabs on the device-side transport: the whole PCG loop in ONE launch (state in registers, boundary rows of A p straight into the neighbours' ghost
+    // areas, the scalars through the same mailbox slots: thallo_hip_iw_pcg_resident_dist).  Same decision on every rank: the slabs are equal up to the image border.
+    const bool resident = p2p && L >= 1 && L <= 4095 && D.ghost_off > 0 && plugin->resident_slab_ok();
+    if (resident) {
+        if (!D.failed) {
+            nb = plugin->pcg_resident_dist(ctx, v_, L, sum(B), scal(B + 1), D.d, D.ghost_off, 0);
+            if (nb < 0) dist_fail("PCGLoopResident launch failed (%d)", nb);
+        }
+        if (!D.failed) {
+            for (int k = 0; k < L; ++k) { const int jD = B + 2 * k + 1, jB = jD + 1; set_nb(jD, 1); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+            resident_used_ = true;
+        }
+        cur_ = L & 1;
+    }
+    for (int k = 0; k < (resident ? 0 : L); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         const int mode = THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
         if (p2p) {        // the kernel stores its boundary rows of Ap_out into the neighbours' ghost rows and its last workgroup IS the exchange

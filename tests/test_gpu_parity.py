@@ -487,7 +487,7 @@ def _host_threads():
 def test_benchmark_configuration_2048_vs_cpu_port(torch, orc):
     """bench.py's exact configuration -- image_warping 2048^2 (synthetic instance), one GN step of 100 PCG iterations through the
     default (one-kernel) schedule -- against the OpenMP port of the reference algorithm, which tests/test_oracle_golden.py pins to the
-    row oracle: cost to 1e-5, the first 10 alpha / beta to 2e-5, the updated unknowns to VEC_RTOL."""
+    row oracle: cost to 1e-5, the first 10 alpha / beta to 5e-5, all 100 to 2e-3, the updated unknowns to VEC_RTOL."""
     W = H = 2048
     p = syn.image_warping(W, H)
     q = copy_params(p)
@@ -500,9 +500,11 @@ def test_benchmark_configuration_2048_vs_cpu_port(torch, orc):
           (np.abs(tr[:10] - ref["trace"][:10]) / np.abs(ref["trace"][:10])).max(), (np.abs(tr - ref["trace"]) / np.abs(ref["trace"])).max())
     assert len(costs) == 2 and rel_err(np.array(costs), ref["costs"]) < COST_RTOL, (costs, ref["costs"])
     assert tr.shape == (100, 2)
-    assert (np.abs(tr[:10] - ref["trace"][:10]) <= 2e-5 * np.abs(ref["trace"][:10])).all(), (tr[:10], ref["trace"][:10])
-    # later iterations: CG amplifies the summation order (the reference's own is nondeterministic), so a looser bar
-    assert (np.abs(tr - ref["trace"]) <= 2e-2 * np.abs(ref["trace"]) + 1e-6).all()
+    # (round 3: 2.5e-5 measured -- the image_warping kernels are built with -ffp-contract=on now, which fuses other multiply-adds than -ffp-contract=fast did
+    #  (1.9e-5 then); the port is compiled without contraction at all, so neither is "the" rounding: two times the measured value)
+    assert (np.abs(tr[:10] - ref["trace"][:10]) <= 5e-5 * np.abs(ref["trace"][:10])).all(), (tr[:10], ref["trace"][:10])
+    # later iterations: CG amplifies the summation order (the reference's own is nondeterministic), so a looser bar -- ten times what is measured (1.3e-4)
+    assert (np.abs(tr - ref["trace"]) <= 2e-3 * np.abs(ref["trace"]) + 1e-6).all()
     assert rel_err(to_host(dev[0]), q[0]) < VEC_RTOL
     s.close()
 
@@ -543,19 +545,19 @@ def test_image_warping_cat512_reference_budget(torch, orc, golden_dir):
 
 def test_shape_from_shading_2048_lm_vs_oracle(torch, orc):
     """BASELINE.json configs[3]: shape_from_shading 2048^2 with the LM branch (reference budget 60 x 10, shape_from_shading/src/
-    main.cpp:44-53; here the first 3 LM steps x 10 PCG) against the row oracle on the host cores."""
+    main.cpp:44-53; here the first 10 LM steps x 10 PCG) against the row oracle on the host cores: every cost to 2e-5 (ten times what is measured)."""
     W = H = 2048
     p = syn.shape_from_shading(W, H)
     prev = orc.set_threads(_host_threads())
     try:
-        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=3, lIterations=10, use_lm=1)
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=10, lIterations=10, use_lm=1)
     finally:
         orc.set_threads(prev)
-    s, dev, costs, final = _solve_gpu_lm("shape_from_shading", (W, H), p, nIterations=3, lIterations=10)
+    s, dev, costs, final = _solve_gpu_lm("shape_from_shading", (W, H), p, nIterations=10, lIterations=10)
     m = min(len(costs), len(co))
-    assert m >= 3 and len(costs) == len(co), (costs, co)
-    print("SFS 2048 LM 3x10: rel. cost error per step", np.abs(costs[:m] - co[:m]) / np.abs(co[:m]), costs[:m])
-    assert (np.abs(costs[:m] - co[:m]) <= 2e-4 * np.abs(co[:m])).all(), (costs, co)       # the bar of test_shape_from_shading_lm
+    assert m >= 10 and len(costs) == len(co), (costs, co)
+    print("SFS 2048 LM 10x10: rel. cost error per step", np.abs(costs[:m] - co[:m]) / np.abs(co[:m]), costs[:m])
+    assert (np.abs(costs[:m] - co[:m]) <= 2e-5 * np.abs(co[:m])).all(), (costs, co)
     assert costs[m - 1] < costs[0]
 
 
@@ -622,8 +624,8 @@ def test_bundle_adjustment_ladybug_lm_vs_oracle(torch, orc):
     err = np.abs(costs[:m] - co[:m]) / den
     drift = np.abs(c2[:m] - co[:m]) / den
     print("ladybug LM 5x150: rel. cost error per step", err, "oracle atomic-order drift", drift, "costs", costs[:m])
-    assert err[0] < 1e-5 and err[1] < 1e-3, (costs, co)
-    assert err.max() <= max(1e-3, 10 * drift.max()), (err, drift, costs, co)
+    assert err[0] < 1e-5 and err[1] < 1e-5, (costs, co)
+    assert err.max() <= max(1e-5, 3 * drift.max()), (err, drift, costs, co)       # (measured: 4e-7, the oracle's own atomic-order drift 3e-7)
     assert costs[m - 1] < 0.5 * costs[0]
 
 

@@ -177,6 +177,14 @@ typedef struct ThalloX_Distributed {
 } ThalloX_Distributed;
 /* Collective.  0 on success, -1 on error (ThalloX_LastError); every rank gets the same answer. */
 int ThalloX_PlanSetDistributed(Thallo_Plan* plan, const ThalloX_Distributed* cfg);
+/* The collectives INSIDE the library (round 3; no callback, no host-language hop in the PCG loop): rank 0 makes a 128-byte RCCL unique id, the application
+ * hands it to every rank by whatever channel it has (MPI, a file, torch.distributed), and each rank gives it to its plan BEFORE ThalloX_PlanSetDistributed
+ * (collective: ncclCommInitRank, the rank's GPU current).  A NULL allgather / allreduce in ThalloX_Distributed then means ncclAllGather / ncclAllReduce on the
+ * plan's stream.  RCCL is bound at run time (dlopen: the copy already in the process if there is one); -1 + ThalloX_LastError when it is not there.
+ * ThalloX_RcclSelfTest: a one-rank communicator moves a small buffer through both collectives (0 = fine). */
+int ThalloX_RcclUniqueId(unsigned char* id_out128);
+int ThalloX_PlanUseRccl(Thallo_Plan* plan, const unsigned char* id128, int rank, int world);
+int ThalloX_RcclSelfTest(void);
 /* JSON text: transport in use ("exchange": "p2p-mailbox" | "allgather"), memory kind of the mapped blocks, self-check outcome. */
 const char* ThalloX_PlanDistributedInfo(Thallo_Plan* plan);
 /* what = 0: read (and with value != 0 clear) the device-side exchange's error word -- 1 if a bounded mailbox wait timed out since the last clear

@@ -437,9 +437,6 @@ int thallo_hip_ba_compute_j(int O, const float* cameras, const float* points, co
 int thallo_hip_ba_pcg_init(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
                            const float* Jb, const float* F, float* r, float* pre, float* z, float* p_prev, float* delta,
                            float* diag_out, float* alphaN_out, thallo_stream_t stream);
-/* Ap = J^T (J p) by gather over the camera / point incidence lists; alphaD partials */
-int thallo_hip_ba_apply_jtj(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
-                            const float* Jb, const float* p, float* Ap, float* alphaD_out, thallo_stream_t stream);
 
 /* ---------------------------------------------------------------- E3: examples/shape_from_shading/shape_from_shading.t
  * params 0-15 host scalars (w_p, w_s, w_g = SQUARED weights, f_x, f_y, u_x, u_y, L_1..L_9), X float unknown (16), D_i (17),
@@ -547,8 +544,6 @@ int thallo_hip_ba_pack_point_blocks(int O, const float* Jb, const int* q_ptk, fl
 int thallo_hip_ba_apply_jtj2(int C, int P, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
                              const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* alphaD_out,
                              const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_stream_t stream);
-int thallo_hip_ba_apply_jtj_sums(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
-                                 const float* Jb, const float* p, float* Ap, float* alphaD_out, const float* r, const float* pre, double* s3_out, thallo_stream_t stream);
 int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                   float* U, float* R, const float* p, float* Ap, float* alphaD_out, const float* r, double* s3_out, thallo_stream_t stream);
 

@@ -459,3 +459,28 @@ def test_rank_local_failure_is_reported_by_every_rank_and_nobody_hangs(energy, n
         assert not np.isfinite(c1), (rank, c1)              # agreed: every rank's cost is void
         assert more == 0 and "fail" in err.lower(), (rank, err)
     assert res[0][2] == res[1][2]                           # the same number of steps on both ranks: nobody left the sequence early
+
+
+# ------------------------------------------------------------------ the collectives inside the library (RCCL bound at run time)
+def test_library_rccl_binding_and_world1_slab(orc):
+    """ncclAllGather / ncclAllReduce issued by the library on the plan's stream instead of a ctypes callback into torch.distributed once or twice
+    per PCG iteration.  What ONE GPU can check (RCCL refuses two ranks on a device): the run-time binding (a one-rank communicator moves a buffer through both
+    collectives) and a shape_from_shading slab plan -- the flat form: one all-gather per PCG iteration -- at world size 1 through ncclAllGather, against the same
+    plan on the in-process copy: identical costs, Gauss-Newton and LM."""
+    import torch
+    import thallo_amd
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed_sfs import PlanSfsSlabSolver
+    torch.cuda.set_device(0)
+    L = thallo_amd.lib()
+    assert L.ThalloX_RcclSelfTest() == 0, thallo_amd.last_error()
+    W, H = 96, 64
+    p = syn.shape_from_shading(W, H)
+    for lm in (False, True):
+        runs = []
+        for force in (True, False):
+            s = PlanSfsSlabSolver(p, W, H, 0, 1, 10, lm=lm, force_rccl=force)
+            assert s.library_rccl == force
+            runs.append(s.solve(3))
+            s.solver.close()
+        assert runs[0] == runs[1] and len(runs[0]) >= 3 and runs[0][-1] < runs[0][0], runs

@@ -545,20 +545,27 @@ def test_image_warping_cat512_reference_budget(torch, orc, golden_dir):
 
 def test_shape_from_shading_2048_lm_vs_oracle(torch, orc):
     """BASELINE.json configs[3]: shape_from_shading 2048^2 with the LM branch (reference budget 60 x 10, shape_from_shading/src/
-    main.cpp:44-53; here the first 10 LM steps x 10 PCG) against the row oracle on the host cores: every cost to 2e-5 (ten times what is measured)."""
+    main.cpp:44-53; here the first 10 LM steps x 10 PCG) against the row oracle on the host cores.  The first four costs to 2e-6 (measured: 3e-7).  From
+    the fifth step on this instance amplifies whatever differs by about ten per LM step (measured round 3: 1e-5, 6e-5, 1e-4, 6e-4, 3e-3 ...; ten unconverged
+    PCG iterations per step on a system the trust region keeps loosening) -- and that includes the oracle's OWN summation order: its threaded row loops
+    scatter with float atomics, so two runs of the oracle drift apart the same way.  Later steps are therefore asserted against that oracle-to-oracle
+    drift, as for bundle adjustment, not against a fixed number."""
     W = H = 2048
     p = syn.shape_from_shading(W, H)
     prev = orc.set_threads(_host_threads())
     try:
         co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=10, lIterations=10, use_lm=1)
+        c2, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=10, lIterations=10, use_lm=1)      # another atomic order
     finally:
         orc.set_threads(prev)
     s, dev, costs, final = _solve_gpu_lm("shape_from_shading", (W, H), p, nIterations=10, lIterations=10)
-    m = min(len(costs), len(co))
+    m = min(len(costs), len(co), len(c2))
     assert m >= 10 and len(costs) == len(co), (costs, co)
-    print("SFS 2048 LM 10x10: rel. cost error per step", np.abs(costs[:m] - co[:m]) / np.abs(co[:m]), costs[:m])
-    assert (np.abs(costs[:m] - co[:m]) <= 2e-5 * np.abs(co[:m])).all(), (costs, co)
-    assert costs[m - 1] < costs[0]
+    err, drift = np.abs(costs[:m] - co[:m]) / np.abs(co[:m]), np.abs(c2[:m] - co[:m]) / np.abs(co[:m])
+    print("SFS 2048 LM 10x10: rel. cost error per step", err, "oracle atomic-order drift", drift, costs[:m])
+    assert (err[:4] <= 2e-6).all(), (err, costs, co)
+    assert (err <= np.maximum(2e-5, 10 * np.maximum.accumulate(drift))).all(), (err, drift)
+    assert costs[m - 1] < 0.1 * costs[0]
 
 
 def test_shape_from_shading_precompute_with_unaligned_mask_planes(torch):

@@ -97,6 +97,9 @@ def lib():
     L.ThalloX_PlanSetDistributed.argtypes = [vp, C.POINTER(DistributedT)]; L.ThalloX_PlanSetDistributed.restype = C.c_int
     L.ThalloX_PlanDistributedInfo.argtypes = [vp]; L.ThalloX_PlanDistributedInfo.restype = C.c_char_p
     L.ThalloX_DistributedControl.argtypes = [vp, C.c_int, C.c_int]; L.ThalloX_DistributedControl.restype = C.c_int
+    L.ThalloX_RcclUniqueId.argtypes = [vp]; L.ThalloX_RcclUniqueId.restype = C.c_int
+    L.ThalloX_PlanUseRccl.argtypes = [vp, vp, C.c_int, C.c_int]; L.ThalloX_PlanUseRccl.restype = C.c_int
+    L.ThalloX_RcclSelfTest.argtypes = []; L.ThalloX_RcclSelfTest.restype = C.c_int
     L.ThalloX_DistributedKernelOnly.argtypes = [vp, C.c_int]; L.ThalloX_DistributedKernelOnly.restype = C.c_int
     L.ThalloX_ProblemFileHash.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; L.ThalloX_ProblemFileHash.restype = C.c_ulonglong
     L.ThalloX_ProblemFileSchedule.argtypes = [C.c_char_p]; L.ThalloX_ProblemFileSchedule.restype = C.c_int
@@ -151,6 +154,14 @@ def energy_file(name):
 
 def last_error():
     return lib().ThalloX_LastError().decode()
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0); raises when the library cannot bind RCCL"""
+    buf = (C.c_ubyte * 128)()
+    if lib().ThalloX_RcclUniqueId(C.addressof(buf)) != 0:
+        raise RuntimeError("ThalloX_RcclUniqueId failed: " + last_error())
+    return bytes(buf)
 
 
 def _ptr_of(x):
@@ -291,6 +302,13 @@ class ThalloSolver:
         cfg = DistributedT(rank, world, row0, row1, self._dist_cb, None, 1 if device_exchange else 0, global_row0, global_rows, self._dist_ar)
         if self._L.ThalloX_PlanSetDistributed(self.plan, C.byref(cfg)) != 0:
             raise RuntimeError("ThalloX_PlanSetDistributed failed: " + last_error())
+
+    def use_rccl(self, unique_id, rank, world):
+        """Collective, before set_distributed: the plan makes its own RCCL communicator from the 128-byte id (rccl_unique_id() on rank 0, handed to every
+        rank by the application); set_distributed without callbacks then means ncclAllGather / ncclAllReduce inside the library."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        if self._L.ThalloX_PlanUseRccl(self.plan, C.addressof(buf), rank, world) != 0:
+            raise RuntimeError("ThalloX_PlanUseRccl failed: " + last_error())
 
     def distributed_info(self):
         import json

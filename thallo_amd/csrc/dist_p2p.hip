@@ -70,8 +70,7 @@ int thallo_hip_ipc_alloc2(long bytes, void** ptr, void* handle_out64, int* kind_
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     static_assert(DIST_CTL_WORDS <= THALLO_DIST_CTL_WORDS, "ctl layout");
     if (bytes <= 0 || !ptr || !handle_out64) return -(int)hipErrorInvalidValue;
-    const char* env = getenv("THALLO_DIST_MEM");
-    const bool want_fine = !(env && env[0] == 'c');
+    const bool want_fine = true;       // fine-grained: the allocation type HIP defines cross-agent coherence for while a kernel runs; plain hipMalloc only if it is refused
     void* p = nullptr;
     hipError_t e = hipErrorUnknown;
     int kind = 0;

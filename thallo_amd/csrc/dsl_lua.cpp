@@ -724,8 +724,11 @@ struct Interp {
         if (obj.t != Value::Table) fail("line " + std::to_string(target->line) + ": assignment into a non-table value");
         table_set(obj, key, v, target->line);
     }
+    long steps = 0;     // statements executed: an energy file is a specification, not a program -- a budget turns `for i = 1, 1e12 do ... end` (or nested loops
+                        // that each stay under their own guard) into an error instead of a hang inside Thallo_ProblemPlan
     void exec(const NP& s, const std::shared_ptr<Env>& env)
     {
+        if (++steps > 20000000L) fail("the file executes more than 2e7 statements (an endless loop?)");
         switch (s->k) {
         case Node::Local: { Values v = eval_list(s->a, env); for (size_t i = 0; i < s->names.size(); ++i) env->vars[s->names[i]] = i < v.size() ? v[i] : Value(); return; }
         case Node::Assign: { Values v = eval_list(s->a, env); for (size_t i = 0; i < s->keys.size(); ++i) assign(s->keys[i], i < v.size() ? v[i] : Value(), env); return; }

@@ -94,11 +94,11 @@ public:
         if (rows && jp.alloc(sizeof(float) * (size_t)rows + 256)) { set_error("%s: out of device memory for the materialized Jp", label.c_str()); return; }
         bool all_jtj = true;
         for (auto& r : P.residuals) all_jtj = all_jtj && r.mat_J && r.mat_JtJ;
-        long dense_max = 2048; if (const char* e = getenv("THALLO_DENSE_JTJ_MAX")) dense_max = atol(e);
+        long dense_max = 2048; if (const char* e = env_switch("THALLO_DENSE_JTJ_MAX")) dense_max = atol(e);
         dense_ = all_jtj && n_unk <= dense_max;
         if (dense_ && dense.alloc(sizeof(float) * (size_t)n_unk * (size_t)n_unk)) { set_error("%s: out of device memory for the dense JtJ", label.c_str()); return; }
         sparse_jtj_ = all_jtj && !dense_ && !P.residuals.empty() && n_unk < (1L << 31);
-        { const char* e = getenv("THALLO_ENABLE_DIRECT_SOLVE"); direct_ = dense_ && P.direct_solve && e && e[0] == '1'; }
+        { const char* e = env_switch("THALLO_ENABLE_DIRECT_SOLVE"); direct_ = dense_ && P.direct_solve && e && e[0] == '1'; }
         if (direct_ && info_.alloc(64)) return;
         jval.assign(P.residuals.size(), nullptr); jcol.assign(P.residuals.size(), nullptr); jdest.assign(P.residuals.size(), nullptr);
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
@@ -181,7 +181,15 @@ public:
         hiprtcProgram prog = nullptr;
         const std::string src = "#include <hip/hip_runtime.h>\n" + G.source;
         if (hiprtcCreateProgram(&prog, src.c_str(), "thallo_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { set_error("hiprtcCreateProgram failed"); return -1; }
-        const char* opts[] = { "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics" };
+        // the architecture of the device the plan will run on (a library built for another ARCH must not generate gfx950 code and then blame the device)
+        std::string arch = "--offload-arch=gfx950";
+        {   int dev = 0; hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.gcnArchName[0]) {
+                std::string a = pr.gcnArchName; const size_t colon = a.find(':'); if (colon != std::string::npos) a.resize(colon);      // "gfx950:sramecc+:xnack-" -> "gfx950"
+                arch = "--offload-arch=" + a;
+            } else (void)hipGetLastError();
+        }
+        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics" };
         const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
         if (rc != HIPRTC_SUCCESS) {
             size_t n = 0; hiprtcGetProgramLogSize(prog, &n); std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
@@ -190,8 +198,7 @@ public:
         }
         size_t n = 0; hiprtcGetCodeSize(prog, &n); std::vector<char> code(n); hiprtcGetCode(prog, code.data());
         hiprtcDestroyProgram(&prog);
-        if (const char* dump = getenv("THALLO_FRONTEND_DUMP")) { FILE* f = fopen(dump, "w"); if (f) { fputs(src.c_str(), f); fclose(f); } }
-        if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { set_error("%s: hipModuleLoadData failed (no gfx950 device?)", label.c_str()); (void)hipGetLastError(); return -1; }
+                if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { set_error("%s: hipModuleLoadData failed for code generated with %s", label.c_str(), arch.c_str()); (void)hipGetLastError(); return -1; }
         for (auto& k : G.kernels) {
             hipFunction_t f = nullptr;
             if (hipModuleGetFunction(&f, mod, k.name.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), k.name.c_str()); return -1; }

@@ -376,26 +376,6 @@ int thallo_hip_ba_pcg_init(int C_, int P_, const int* cam_ptr, const int* q_pt, 
     int e = check_launch(); return e ? e : grid;
 }
 
-int thallo_hip_ba_apply_jtj(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
-                            const float* Jb, const float* p, float* Ap, float* aD_out, thallo_stream_t stream)
-{
-    int cb, grid; gather_shape(C_, P_, cb, grid);
-    hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
-                       (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out);
-    int e = check_launch(); return e ? e : grid;
-}
-
-int thallo_hip_ba_apply_jtj_sums(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
-                                 const float* Jb, const float* p, float* Ap, float* aD_out, const float* r, const float* pre, double* s3_out, thallo_stream_t stream)
-{
-    if (!r || !pre || !s3_out) return -(int)hipErrorInvalidValue;
-    int cb, grid; gather_shape(C_, P_, cb, grid);
-    hipLaunchKernelGGL(k_gather<1>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, cb, cam_ptr, q_pt, pt_ptr, pt_pos, q_cam,
-                       (const float4*)Jb, (const float2*)nullptr, p, Ap, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, aD_out,
-                       r, pre, s3_out);
-    int e = check_launch(); return e ? e : grid;
-}
-
 int thallo_hip_ba_point_order(int O_, const int* pt_pos, int* q_ptk, thallo_stream_t stream)
 {
     if (O_ < 1 || !pt_pos || !q_ptk) return -(int)hipErrorInvalidValue;

@@ -20,13 +20,17 @@
 #include "iw_device.hpp"
 
 namespace thallo {
-int g_march_rows = 0;      // microbench: rows per wave segment (0 = automatic)
-int g_march_depth = 2;     // microbench: prefetch depth in rows (1, 2 or 3)
-int g_march_nt = 5;       // non-temporal bits as for k_iter: 1 delta, 2 r/Ap loads, 4 r/Ap stores, 8 p loads, 16 p stores, 32 cs/flags
-int g_march_occ = 2;       // microbench: workgroups per CU the kernel is compiled for (register budget) and sized for (rows per segment)
-int g_march_dbg = 0;       // microbench: 1 = no stencil arithmetic (Ap := p), 2 = no double sums, 3 = 1 + no halo rows / lanes
-int g_march_map = 0;       // microbench: 1 = the 4 waves of a workgroup side by side (x-adjacent strips) instead of stacked segments
+int g_march_rows = 0;      // tests / tools: rows per wave segment (0 = automatic) -- the resident kernel's bitwise test forces its own R on this kernel
 int g_march_cap = 0;       // tests: workgroup budget the grid is sized for (0 = CUs x workgroups per CU of the device)
+#ifdef THALLO_MARCH_SWEEP  // tools/march_probe.py only (make VARIANT=sweep): the product has neither the knobs nor the extra instantiations
+int g_march_depth = 2;     // prefetch depth in rows (1, 2 or 3)
+int g_march_nt = 5;        // non-temporal bits as for k_iter: 1 delta, 2 r/Ap loads, 4 r/Ap stores, 8 p loads, 16 p stores, 32 cs/flags
+int g_march_occ = 2;       // workgroups per CU the kernel is compiled for (register budget) and sized for (rows per segment)
+int g_march_dbg = 0;       // 1 = no stencil arithmetic (Ap := p), 2 = no double sums, 3 = 1 + no halo rows / lanes
+int g_march_map = 0;       // 1 = the 4 waves of a workgroup side by side (x-adjacent strips) instead of stacked segments
+#else
+constexpr int g_march_dbg = 0, g_march_map = 0;
+#endif
 }
 
 using namespace thallo;
@@ -587,12 +591,14 @@ int thallo_hip_iw_stream_ref(int W, int H, const float* cs, const unsigned char*
 void thallo_hip_march_debug_set(int what, int value)
 {
     if (what == 0) g_march_rows = value;
+    if (what == 6) g_march_cap = value;
+#ifdef THALLO_MARCH_SWEEP
     if (what == 1) g_march_depth = value;
     if (what == 2) g_march_nt = value;
     if (what == 3) g_march_occ = value;
     if (what == 4) g_march_dbg = value;
     if (what == 5) g_march_map = value;
-    if (what == 6) g_march_cap = value;
+#endif
 }
 
 /* rows per wave segment the marching kernels would use on `rows` owned rows of a W-wide image; 0 = the image has more column strips than the device

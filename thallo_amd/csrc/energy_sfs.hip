@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include "device_common.hpp"
 #include "../../include/thallo_hip.h"
+namespace thallo { const char* env_switch(const char* name); }      // solver.cpp: the one table of the library's environment switches
 
 using namespace thallo;
 
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) void k_diag(Geo g, Cam cm, const float4* __r
 extern "C" {
 
 // THALLO_SFS_FUSED=0: the two-pass k_rows + k_gather form (A/B switch)
-static bool sfs_fused() { static int v = -1; if (v < 0) { const char* e = getenv("THALLO_SFS_FUSED"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
+static bool sfs_fused() { static int v = -1; if (v < 0) { const char* e = thallo::env_switch("THALLO_SFS_FUSED"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
 static int fused_grid(int W, int rows)
 {
     const int nt = ((W + FW - 1) / FW) * ((rows + FH - 1) / FH);
@@ -793,7 +794,7 @@ static int fused_grid(int W, int rows)
 static int g_ms_rows = 0, g_ms_wgcu = 0, g_ms_force = -1;       // tools / tests: rows per wave segment, workgroups per CU the grid is sized for (0 = automatic), kernel choice (-1 = the environment's)
 static bool sfs_march()
 {
-    static int v = -1; if (v < 0) { const char* e = getenv("THALLO_SFS_MARCH"); v = (e && e[0] == '0') ? 0 : 1; }
+    static int v = -1; if (v < 0) { const char* e = thallo::env_switch("THALLO_SFS_MARCH"); v = (e && e[0] == '0') ? 0 : 1; }
     return g_ms_force >= 0 ? g_ms_force == 1 : v == 1;
 }
 static int g_ms_cap = 0;        // tests: workgroup budget the grids are sized for (0 = CUs x workgroups per CU of the device)

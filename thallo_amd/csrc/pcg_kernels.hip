@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BLOCK) void k_step2_full(float4* __restrict__ delta
                                                        const float4* __restrict__ pre, float4* __restrict__ z,
                                                        const float4* __restrict__ b, long n4,
                                                        thallo_sum_t aN, thallo_sum_t aD,
-                                                       float* __restrict__ bN_out, float* __restrict__ q_out, const unsigned* __restrict__ gate, ZetaArgs zeta)
+                                                       float* __restrict__ bN_out, float* __restrict__ q_out, const unsigned* gate, ZetaArgs zeta)
 {
     __shared__ float red[32];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device
@@ -628,9 +628,9 @@ int thallo_hip_pcg_step2(float* r, const float* Ap, const float* pre, float* z, 
 }
 
 // Ambient gate word of the LM loop (thallo_hip_lm_set_gate): passed to the loop's energy-independent kernels (pcg_pupdate, lm_step1_finish,
-// pcg_step2_full, lm_step2_first / second_half), which do nothing once it is non-zero.  NULL outside an LM loop.  One solver per process drives
-// this library at a time (the reference's own contract: one State per process, SURVEY.md 8b "Threading").
-static const unsigned* g_gate = nullptr;
+// pcg_step2_full, lm_step2_first / second_half), which do nothing once it is non-zero.  NULL outside an LM loop.  Per THREAD: the word is set and reset
+// around one plan's LM loop by the thread that runs it, so two plans stepped from two threads never see each other's (or a freed plan's) word.
+static thread_local const unsigned* g_gate = nullptr;
 void thallo_hip_lm_set_gate(const unsigned* gate) { g_gate = gate; }
 
 int thallo_hip_lm_state_reset(float* state, thallo_stream_t stream)

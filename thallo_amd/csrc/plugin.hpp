@@ -16,6 +16,8 @@ namespace thallo {
 
 void set_error(const char* fmt, ...);
 const char* last_error();
+// the value of one of the library's environment switches (A/B comparisons for tests and tools; the one table of them is in solver.cpp), or NULL
+const char* env_switch(const char* name);
 
 // Sampled / full per-kernel hipEvent timing (reference: util.t:774-790 at timingLevel >= 2).
 class KernelTimer {

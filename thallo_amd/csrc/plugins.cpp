@@ -187,7 +187,7 @@ public:
     {   // UrShape is a constant input: establish once per Init, on the host, whether it is the unit pixel grid (what the reference's
         // harness passes, CombinedSolver.h:158-176) -- that selects thallo_hip_iw_pcg_iter_march; pcg_init still re-verifies on the device
         march_ = grid_ = false;
-        const char* e = getenv("THALLO_MARCH");
+        const char* e = env_switch("THALLO_MARCH");
         int* word = (int*)irregular.ptr + 8;
         int rc = thallo_hip_iw_urshape_irregular(W, H, urshape, word, c.stream);
         if (rc < 0) { set_error("image_warping: UrShape check failed (%d)", rc); return -1; }
@@ -202,7 +202,7 @@ public:
         if (march_ && thallo_hip_iw_march_rows(W, H) <= 0) march_ = false;
         // small working sets: the whole PCG loop in one launch (state in registers); THALLO_RESIDENT=0: one launch per PCG iteration (A/B)
         resident_ = resident_slab_ = false;
-        const char* er = getenv("THALLO_RESIDENT");
+        const char* er = env_switch("THALLO_RESIDENT");
         const bool whole = row0_ == 0 && row1_ == H;
         const int rr = whole ? thallo_hip_iw_resident_rows(W, H) : thallo_hip_iw_resident_rows_slab(W, row1_ - row0_, row1_ < H ? 1 : 0);
         if (grid_ && !(er && er[0] == '0') && rr > 0) {
@@ -517,7 +517,6 @@ class BundleAdjustmentPlugin : public EnergyPlugin {
     float *cameras = nullptr, *points = nullptr; const float* obs = nullptr; const int *oToC = nullptr, *oToP = nullptr;
     DeviceBuffer cam_ptr, cam_obs, q_cam, q_pt, pt_ptr, pt_pos, Jb, F;
     DeviceBuffer q_ptk, JP, JpP;          // J^T (J p) with J p formed once (thallo_hip_ba_apply_jtj2): point-order position per observation, packed point blocks, J p
-    bool once_ = true;                     // THALLO_BA_JP_ONCE=0: the one-kernel gather that forms J p on both sides (A/B switch)
     int apply2(LaunchCtx& c, SolverVectors* v, const float* p, float* Ap, float* out, const thallo_fin_t& fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr })
     {
         return thallo_hip_ba_apply_jtj2_fin(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)q_ptk.ptr, (const int*)pt_ptr.ptr,
@@ -557,8 +556,7 @@ public:
         };
         if (up(cam_ptr, cp) || up(cam_obs, cobs) || up(q_cam, qc) || up(q_pt, qp) || up(pt_ptr, pp) || up(pt_pos, ppos)) { set_error("bundle_adjustment: upload failed"); return -1; }
         if (!Jb.ptr && (Jb.alloc(sizeof(float) * 24 * (size_t)O + 64) || F.alloc(sizeof(float) * 2 * (size_t)O + 64))) return -1;
-        { const char* e = getenv("THALLO_BA_JP_ONCE"); once_ = !(e && e[0] == '0'); }
-        if (once_) {
+        {
             if (!q_ptk.ptr && (q_ptk.alloc(sizeof(int) * (size_t)O + 64) || JP.alloc(sizeof(float) * 6 * (size_t)O + 64) || JpP.alloc(sizeof(float) * 2 * (size_t)O + 64))) return -1;
             {   const int rc = thallo_hip_ba_point_order(O, (const int*)pt_pos.ptr, (int*)q_ptk.ptr, nullptr);
                 const hipError_t se = rc < 0 ? hipSuccess : hipDeviceSynchronize();
@@ -575,7 +573,7 @@ public:
         { TimedLaunch t(c, "precomputeJ");
           int rc = thallo_hip_ba_compute_j(O, cameras, points, obs, (const int*)cam_obs.ptr, (const int*)q_cam.ptr, (const int*)q_pt.ptr, (float*)Jb.ptr, (float*)F.ptr, c.stream);
           if (rc < 0) return rc;
-          if (once_ && (rc = thallo_hip_ba_pack_point_blocks(O, (const float*)Jb.ptr, (const int*)q_ptk.ptr, (float*)JP.ptr, c.stream)) < 0) return rc; }
+          if ((rc = thallo_hip_ba_pack_point_blocks(O, (const float*)Jb.ptr, (const int*)q_ptk.ptr, (float*)JP.ptr, c.stream)) < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_ba_pcg_init(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
                                       (const float*)Jb.ptr, (const float*)F.ptr, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, c.stream);
@@ -583,36 +581,27 @@ public:
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        if (once_ && c.lm_ctc)
+        if (c.lm_ctc)
             return thallo_hip_ba_apply_jtj2_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)q_ptk.ptr, (const int*)pt_ptr.ptr,
                                                (const float*)Jb.ptr, (const float*)JP.ptr, (float*)JpP.ptr, p, c.lm_ctc, Ap, out, c.gate, c.stream);
-        if (once_) return apply2(c, nullptr, p, Ap, out);
-        return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
-                                       (const float*)Jb.ptr, p, Ap, out, c.stream);
+        return apply2(c, nullptr, p, Ap, out);
     }
     long shared_block_offset() const override { return 9L * C; }
-    long shared_block_floats() const override { return once_ ? 3L * P : 0; }        // (the shard form runs on the J p-once applyJTJ)
+    long shared_block_floats() const override { return 3L * P; }
     int shared_split_slots() const override { return thallo_hip_ba_apply2_camera_slots(C, P); }
-    bool apply_adds_ctc() const override { return once_; }
+    bool apply_adds_ctc() const override { return true; }
     // (PCGStep3 folded into this apply was measured: forming p_k = z + beta p_{k-1} at every gather costs the camera kernel 8 us, the launch it saves 7: not kept)
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
         TimedLaunch t(c, "PCGStep1");
-        if (once_) return apply2(c, &v, p, Ap, out, fin);
-        const int nb = thallo_hip_ba_apply_jtj_sums(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
-                                                    (const float*)Jb.ptr, p, Ap, out, v.r, v.pre, v.s12, c.stream);
-        if (nb < 0 || !fin.tickets) return nb;            // (A/B path: the two words by a launch of their own)
-        const int rc = thallo_hip_pcg_scalars_finish(out, v.s12, nb, fin.alphaN, fin.alphaD_word, fin.betaN_word, c.stream);
-        return rc < 0 ? rc : nb;
+        return apply2(c, &v, p, Ap, out, fin);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
-        if (once_) return apply2(c, nullptr, v.p[cur ^ 1], v.Ap, out);
-        return thallo_hip_ba_apply_jtj(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_ptr.ptr, (const int*)pt_pos.ptr, (const int*)q_cam.ptr,
-                                       (const float*)Jb.ptr, v.p[cur ^ 1], v.Ap, out, c.stream);
+        return apply2(c, nullptr, v.p[cur ^ 1], v.Ap, out);
     }
 };
 

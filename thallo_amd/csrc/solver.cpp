@@ -166,6 +166,7 @@ Plan::~Plan()
 {
     hipDeviceSynchronize();
     dist_release();
+    if (rccl_) { rccl_comm_destroy(rccl_); rccl_ = nullptr; }
     for (auto b : bufs_) delete b;
     delete plugin;
 }
@@ -183,17 +184,39 @@ int Plan::ensure_slots(int L)
     return 0;
 }
 
+// ------------------------------------------------------------------ A/B switches
+// Every environment switch of the library, in this one table (the only getenv of thallo_amd/csrc).  Each selects an alternative that computes the same thing and that a
+// test or a tool still compares with the default; what lost its comparison in rounds 1-2 is gone (the blocking zeta test, the one-kernel bundle-adjustment
+// gather, THALLO_FINISH_SUMS / EXPANDED / DEFER_FINISH / LM_FOLD_CTC / LM_ZETA_IN_STEP2 / DIST_MEM / FRONTEND_DUMP).
+const char* env_switch(const char* name)
+{
+    static const char* const known[] = {
+        "THALLO_RESIDENT",            // 0: image_warping runs one launch per PCG iteration even where the whole PCG loop fits one resident launch
+        "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up)
+        "THALLO_ONE_KERNEL",          // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
+        "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch
+        "THALLO_BATCH_DELTA",         // 0: delta += alpha p every iteration instead of every other one
+        "THALLO_LM_FOLD_P",           // 0: LM's PCGStep3 as a launch of its own even where the plugin's apply can carry it
+        "THALLO_SFS_FUSED",           // 0: shape_from_shading's two-pass applyJTJ (round 1)
+        "THALLO_SFS_MARCH",           // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
+        "THALLO_DIST_P2P",            // 0: never the device-side exchange
+        "THALLO_FRONTEND",            // off / generate: see api.cpp
+        "THALLO_FRONTEND_AGGREGATE",  // 0: generated kernels scatter with plain atomics everywhere
+        "THALLO_DENSE_JTJ_MAX",       // largest n for the dense [JtJ]p schedule of generated plugins
+        "THALLO_ENABLE_DIRECT_SOLVE", // 1: honour <handle>:set_direct_solve(true) (compiled out in the reference: gauss_newton.t:22)
+    };
+    for (const char* k : known) if (!strcmp(k, name)) return getenv(name);
+    set_error("internal: unknown environment switch %s", name);
+    return nullptr;
+}
+
 void Plan::read_ab_switches()
-{   // A/B switches for tests/ and tools/ (each selects an older or alternative schedule that computes the same thing; the defaults are the
-    // product).  All of them in this one place; read when the reduction slots are (re)sized, i.e. at Plan time and when lIterations grows.
-    auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
-    finish_sums_   = !off("THALLO_FINISH_SUMS");      // 0: consumers re-add the partials themselves
-    one_kernel_    = !off("THALLO_ONE_KERNEL");       // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
-    expanded_      = !off("THALLO_EXPANDED");         // 0: three-kernel form even where applyJTJ can return the sums
-    fin_in_kernel_ = !off("THALLO_FIN_IN_KERNEL");    // 0: the iteration's scalars by a separate one-wave launch
-    batch_delta_   = !off("THALLO_BATCH_DELTA");      // 0: delta += alpha p every iteration instead of every other one
-    defer_finish_  = !off("THALLO_DEFER_FINISH");     // 0: the one-kernel iteration's scalars by its own last workgroup instead of by the next launch
-    lm_fold_p_     = !off("THALLO_LM_FOLD_P");        // 0: LM's PCGStep3 as a launch of its own even where the plugin's apply can carry it
+{   // read when the reduction slots are (re)sized, i.e. at Plan time and when lIterations grows
+    auto off = [](const char* name) { const char* e = env_switch(name); return e && e[0] == '0'; };
+    one_kernel_    = !off("THALLO_ONE_KERNEL");
+    fin_in_kernel_ = !off("THALLO_FIN_IN_KERNEL");
+    batch_delta_   = !off("THALLO_BATCH_DELTA");
+    lm_fold_p_     = !off("THALLO_LM_FOLD_P");
 }
 
 void Plan::set_param(const char* name, const void* value)
@@ -367,7 +390,7 @@ int Plan::step_gn(int ev_iter)
     }
     if (one_kernel_ && sp.lIterations >= 1 && plugin->resident_ok()) return step_gn_resident(ev_iter);
     if (one_kernel_ && plugin->one_kernel_iteration()) return step_gn_one_kernel(ev_iter);
-    if (expanded_ && plugin->apply_returns_sums()) return step_gn_expanded(ev_iter);
+    if (plugin->apply_returns_sums()) return step_gn_expanded(ev_iter);
     const int L = sp.lIterations;
     hipStream_t s = ctx.stream;
     const int ev_setup = timer_.start("Nonlinear Setup", s);
@@ -429,10 +452,10 @@ int Plan::step_gn_one_kernel(int ev_iter)
     set_nb(B, nb); finish(B);
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
-    // Deferred finish (the default where the plugin offers it; THALLO_DEFER_FINISH=0: A/B): the launch of iteration k adds up iteration k-1's partials
+    // Deferred finish (where the plugin offers it): the launch of iteration k adds up iteration k-1's partials
     // itself -- alphaD_{k-1} and betaN_{k-1} = N - 2 alpha S1 + alpha^2 S2 -- while its first rows load, instead of iteration k-1's last workgroup
     // reading them back at the very end of its launch; one one-wave launch per GN step finishes the last iteration.
-    const bool defer = defer_finish_ && plugin->iter_defers_finish();
+    const bool defer = plugin->iter_defers_finish();
     int nb_prev = 0;
     for (int k = 0; k < (defer ? L : 0); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
@@ -601,12 +624,12 @@ int Plan::step_lm(int ev_iter)
     auto global = [&](int j) { return slab ? dist_sum_slot(j) : 0; };                         // nonzero: the collective itself failed
     auto global_rows = [&](int j, float* vec) { return slab ? dist_sum_and_rows(j, vec) : 0; };
     const bool pc = plugin->use_preconditioner();
-    const bool fold_ctc = plugin->apply_adds_ctc() && ![] { const char* e = getenv("THALLO_LM_FOLD_CTC"); return e && e[0] == '0'; }();      // (=0: A/B)
+    const bool fold_ctc = plugin->apply_adds_ctc();
     // PCGStep3 folded into the apply too (one GPU; plugins that offer it; THALLO_LM_FOLD_P=0: A/B, read_ab_switches)
     const bool fold_p = lm_fold_p_ && fold_ctc && !slab && plugin->apply_folds_pupdate() && v_.p[1] != nullptr;
     // the zeta test by PCGStep2's last workgroup (one GPU): one launch less per iteration.  A slab needs the GLOBAL q first.
     if (!slab && ensure_sums_buffer()) return 0;
-    const bool zeta_in_step2 = !slab && ![] { const char* e = getenv("THALLO_LM_ZETA_IN_STEP2"); return e && e[0] == '0'; }();
+    const bool zeta_in_step2 = !slab;
     float* lmst = (float*)scratch_.ptr + 16;                          // 8 words: Q0, gate, iterations done, | dJJd, db, new cost
     const unsigned* gate = reinterpret_cast<const unsigned*>(lmst) + 1;
     const int ev_setup = timer_.start("Nonlinear Setup", s);

@@ -4,6 +4,7 @@
 // fused MI355X schedule documented in DESIGN.md.
 #pragma once
 #include "plugin.hpp"
+#include "rccl_transport.hpp"
 #include "../../include/Thallo.h"
 
 namespace thallo {
@@ -99,6 +100,8 @@ public:
     bool lm() const { return lm_; }
     // collective over the ranks; before Thallo_ProblemInit.  0 on success (every rank returns the same value)
     int  set_distributed(const ThalloX_Distributed& cfg);
+    // collective; before set_distributed: the plan's own RCCL communicator -- then a NULL all-gather / all-reduce callback means "ncclAllGather / ncclAllReduce on the plan's stream"
+    int  use_rccl(const unsigned char* id128, int rank, int world);
     const char* distributed_info() const { return dist_ ? dist_->info.c_str() : ""; }
     int  dist_control(int what, int value);
     int  dist_kernel_only(int reps);      // bench: `reps` back-to-back one-kernel iterations on this rank's slab, no exchange
@@ -132,7 +135,7 @@ private:
 
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
-    bool fin_in_kernel_ = true, expanded_ = true, one_kernel_ = true, finish_sums_ = true, batch_delta_ = true, defer_finish_ = true, lm_fold_p_ = true;   // A/B switches: read_ab_switches()
+    bool fin_in_kernel_ = true, one_kernel_ = true, batch_delta_ = true, lm_fold_p_ = true;   // A/B switches: read_ab_switches()
     void read_ab_switches();
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }
     thallo_sum_t partial_sum(int j) { thallo_sum_t s; s.partials = slot(j); s.count = nb_[j]; return s; }
@@ -141,7 +144,7 @@ private:
     // Adds the slot's partials once, in the order every consumer would use, so the next kernels read ONE word instead of each of
     // their waves re-adding up to 1024 partials in the prologue (measured: -10 us per PCG iteration at 2048^2)
     // (small launches -- <= 4 partials per lane -- are cheaper to re-add in place than to pay one more launch for)
-    void finish(int j) { if (!finish_sums_ || nb_[j] <= 256) return; thallo_hip_finish_sum(partial_sum(j), scal(j), ctx.stream); fin_[j] = 1; }
+    void finish(int j) { if (nb_[j] <= 256) return; thallo_hip_finish_sum(partial_sum(j), scal(j), ctx.stream); fin_[j] = 1; }
     int  ensure_slots(int L);
     int  ensure_iter_buffers();
     int  ensure_sums_buffer();
@@ -159,6 +162,7 @@ private:
     void linear_update_tail(int L, bool batched);
     // solver_dist.cpp
     DistState* dist_ = nullptr;
+    RcclComm* rccl_ = nullptr;
     int  set_distributed_impl(const ThalloX_Distributed& cfg);
     int  dist_allgather(const void* send, void* recv, long bytes);
     int  dist_agree(bool flag, bool& all);

@@ -51,6 +51,7 @@ int Plan::dist_allgather(const void* send, void* recv, long bytes)
 {
     DistState& D = *dist_;
     if (D.failed) (void)hipMemsetAsync(const_cast<void*>(send), 0xFF, (size_t)(bytes < 32 ? bytes : 32), ctx.stream);      // NaN header: sums, alphaD, N / S1 / S2, the failure flag
+    if (!D.cfg.allgather && rccl_) return rccl_allgather(rccl_, send, recv, bytes, ctx.stream);          // the library's own communicator: no callback, no host-language hop
     if (D.cfg.world == 1 && !D.cfg.allgather)
         return hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, ctx.stream) == hipSuccess ? 0 : -1;
     const int rc = D.cfg.allgather(D.cfg.user, send, recv, bytes, (void*)ctx.stream);
@@ -85,6 +86,15 @@ int Plan::dist_agree(bool flag, bool& all)
     return 0;
 }
 
+int Plan::use_rccl(const unsigned char* id128, int rank, int world)
+{
+    if (!ok_) return -1;
+    if (dist_) { set_error("distributed: ThalloX_PlanUseRccl comes before ThalloX_PlanSetDistributed"); return -1; }
+    if (rccl_) { rccl_comm_destroy(rccl_); rccl_ = nullptr; }
+    rccl_ = rccl_comm_create(id128, rank, world);
+    return rccl_ ? 0 : -1;
+}
+
 int Plan::set_distributed(const ThalloX_Distributed& cfg)
 {
     if (!ok_) return -1;
@@ -105,7 +115,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (lm_) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
         if (!plugin->apply_returns_sums()) { set_error("distributed: %s has no shard form", plugin->name()); return -1; }
         if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
-        if (cfg.world > 1 && (!cfg.allgather || !cfg.allreduce)) { set_error("distributed: the shard form needs an all-gather and an all-reduce callback"); return -1; }
+        if (cfg.world > 1 && (!cfg.allgather || !cfg.allreduce) && !(rccl_ && rccl_->world == cfg.world && rccl_->rank == cfg.rank)) { set_error("distributed: the shard form needs an all-gather and an all-reduce callback (or ThalloX_PlanUseRccl)"); return -1; }
         const long off = plugin->shared_block_offset(), len = plugin->shared_block_floats();
         if ((off & 3) || (len & 3) || off + len != v_.n) { set_error("distributed: shared block [%ld, %ld) of %ld unknowns (offset and length must be multiples of 4: pad the cameras to a multiple of 4)", off, off + len, v_.n); return -1; }
         hipDeviceSynchronize();
@@ -128,7 +138,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (lm_) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
         if (!plugin->apply_returns_sums()) { set_error("distributed: %s has no range form", plugin->name()); return -1; }
         if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
-        if (cfg.world > 1 && !cfg.allgather) { set_error("distributed: world > 1 needs an all-gather callback"); return -1; }
+        if (cfg.world > 1 && !cfg.allgather && !(rccl_ && rccl_->world == cfg.world && rccl_->rank == cfg.rank)) { set_error("distributed: world > 1 needs an all-gather callback (or ThalloX_PlanUseRccl)"); return -1; }
         if (U % cfg.world || u1 - u0 != U / cfg.world || u0 != (U / cfg.world) * cfg.rank) {
             set_error("distributed: rank %d of %d must own units [%ld,%ld) of %ld (equal contiguous ranges), got [%ld,%ld)", cfg.rank, cfg.world, (U / cfg.world) * cfg.rank, (U / cfg.world) * (cfg.rank + 1), U, u0, u1);
             return -1;
@@ -163,7 +173,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
     if (!plugin->supports_row_slabs() || (flat && (!plugin->apply_returns_sums() || plugin->unknown_images().size() != 1))) { set_error("distributed: %s has no row-slab form", plugin->name()); return -1; }
     if (lm_ && !flat) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); return -1; }
     if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
-    if (cfg.world > 1 && !cfg.allgather) { set_error("distributed: world > 1 needs an all-gather callback"); return -1; }
+    if (cfg.world > 1 && !cfg.allgather && !(rccl_ && rccl_->world == cfg.world && rccl_->rank == cfg.rank)) { set_error("distributed: world > 1 needs an all-gather callback (or ThalloX_PlanUseRccl)"); return -1; }
     const int W = plugin->slab_width(), Hl = (int)dims[1];
     const int g = plugin->slab_ghost_rows();
     const int top = (int)cfg.row0, bot = Hl - (int)cfg.row1;
@@ -202,7 +212,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         return 0;
     }
     D.want_p2p = cfg.device_exchange != 0;
-    {   const char* e = getenv("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
+    {   const char* e = env_switch("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
     // ---- messages
     const long N = D.N, na = D.na;
     auto row = [&](long y, long base) { return std::vector<std::pair<long, long>>{ { base + 2L * W * y, 2L * W }, { base + 2 * N + (long)W * y, (long)W } }; };
@@ -589,6 +599,7 @@ int Plan::dist_allreduce(float* buf, long count)
     DistState& D = *dist_;
     if (D.cfg.world == 1) return 0;
     if (D.failed) (void)hipMemsetAsync(buf, 0xFF, (size_t)(count < 8 ? count : 8) * sizeof(float), ctx.stream);      // poisons every rank's sum
+    if (!D.cfg.allreduce && rccl_) return rccl_allreduce_sum(rccl_, buf, count, ctx.stream);
     const int rc = D.cfg.allreduce(D.cfg.user, buf, count, (void*)ctx.stream);
     if (rc) set_error("distributed: the caller's all-reduce returned %d", rc);
     return rc;

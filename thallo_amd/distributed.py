@@ -127,6 +127,37 @@ def torch_allreduce(group=None, device=None):
     return f
 
 
+def library_rccl(solver, rank, world, group=None, force=False):
+    """Give the plan its own RCCL communicator (include/Thallo.h ThalloX_PlanUseRccl) when the ranks sit on GPUs of their own -- torch.distributed's backend is
+    nccl -- or `force` (probes at world size 1): the per-iteration all-gather / all-reduce then run inside the library, no callback into Python.  Collective;
+    True if every rank has its communicator (then pass allgather=None / allreduce=None to set_distributed), False = use the torch.distributed callbacks."""
+    if os.environ.get("THALLO_DIST_TRANSPORT", "") == "callback":
+        return False
+    on_own_gpus = dist.is_initialized() and dist.get_backend(group) == "nccl"
+    if not (on_own_gpus or force):
+        return False
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = api.rccl_unique_id()
+        except RuntimeError:
+            box[0] = None
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    if box[0] is None:
+        return False
+    ok = 1.0
+    try:
+        solver.use_rccl(box[0], rank, world)
+    except RuntimeError:
+        ok = 0.0
+    if world > 1:
+        t = torch.tensor([ok], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        ok = t.item()
+    return ok > 0.5
+
+
 class PlanSlabSolver:
     """One rank's row slab of an image_warping problem, solved through the library (Thallo_ProblemInit / Step / CurrentCost are
     collective once ThalloX_PlanSetDistributed was called)."""
@@ -140,7 +171,8 @@ class PlanSlabSolver:
         self.solver = api.ThalloSolver((W, lay.Hl), api.energy_file("image_warping"), timing_level=0)
         self.l_iters = l_iters
         self.solver.set_solver_parameters(nIterations=1 << 30, lIterations=l_iters)
-        ag = torch_allgather(group, dev) if world > 1 or force_allgather else None      # (force: the real collective even at world size 1 -- probes)
+        self.library_rccl = library_rccl(self.solver, rank, world, group, force=force_allgather)
+        ag = torch_allgather(group, dev) if (world > 1 or force_allgather) and not self.library_rccl else None      # (force: the real collective even at world size 1 -- probes)
         self.solver.set_distributed(rank, world, lay.row0, lay.row1, allgather=ag, device_exchange=device_exchange)
         self.params = self.solver.make_params([self.offset, self.angle, self.urshape, self.constraints, self.mask, float(local[5]), float(local[6])])
         self._graph = None

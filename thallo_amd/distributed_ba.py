@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import api
-from .distributed import torch_allgather, torch_allreduce
+from .distributed import library_rccl, torch_allgather, torch_allreduce
 
 
 class BaShardLayout:
@@ -50,8 +50,9 @@ class PlanBaShardSolver:
         dims = (lay.C_pad, local[1].shape[0], local[2].shape[0])
         self.solver = api.ThalloSolver(dims, api.energy_file("bundle_adjustment"), timing_level=0)
         self.solver.set_solver_parameters(nIterations=1 << 30, lIterations=l_iters)
-        ag = torch_allgather(group, dev) if world > 1 else None
-        ar = torch_allreduce(group, dev) if world > 1 else None
+        self.library_rccl = library_rccl(self.solver, rank, world, group)      # ranks on GPUs of their own: all-gather and all-reduce run inside the library (no callback)
+        ag = torch_allgather(group, dev) if world > 1 and not self.library_rccl else None
+        ar = torch_allreduce(group, dev) if world > 1 and not self.library_rccl else None
         self.solver.set_distributed(rank, world, lay.c0, lay.c1, allgather=ag, device_exchange=False, allreduce=ar)
         self.params = self.solver.make_params(self.tensors)
 

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import api
-from .distributed import torch_allgather
+from .distributed import library_rccl, torch_allgather
 
 
 class VertexPartition:
@@ -34,7 +34,8 @@ class PlanArapSolver:
         self._const = [t(orig), t(cons), t(v0.astype(np.int32)), t(v1.astype(np.int32))]
         self.solver = api.ThalloSolver((N, E), api.energy_file("arap_mesh_deformation"), timing_level=0)
         self.solver.set_solver_parameters(nIterations=1 << 30, lIterations=l_iters)
-        ag = torch_allgather(group, dev) if world > 1 else None
+        self.library_rccl = library_rccl(self.solver, rank, world, group)      # ranks on GPUs of their own: the all-gather runs inside the library (no callback)
+        ag = torch_allgather(group, dev) if world > 1 and not self.library_rccl else None
         self.solver.set_distributed(rank, world, part.n0, part.n1, allgather=ag, device_exchange=False)     # (row0, row1 = the owned vertex range)
         self.params = self.solver.make_params([float(w_fit), float(w_reg), self.position, self.angle] + self._const)
 

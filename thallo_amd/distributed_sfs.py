@@ -9,11 +9,11 @@ import numpy as np
 import torch
 
 from . import api
-from .distributed import SlabLayout, torch_allgather
+from .distributed import SlabLayout, library_rccl, torch_allgather
 
 
 class PlanSfsSlabSolver:
-    def __init__(self, params_global, W, H, rank, world, l_iters, lm=False, group=None):
+    def __init__(self, params_global, W, H, rank, world, l_iters, lm=False, group=None, force_rccl=False):
         self.lay = lay = SlabLayout(H, rank, world, ghost=2)
         self.W, self.H, self.rank, self.world = W, H, rank, world
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -24,7 +24,8 @@ class PlanSfsSlabSolver:
             self.solver.enable_lm()
         self.l_iters = l_iters
         self.solver.set_solver_parameters(nIterations=1 << 30, lIterations=l_iters)
-        ag = torch_allgather(group, dev) if world > 1 else None
+        self.library_rccl = library_rccl(self.solver, rank, world, group, force=force_rccl)
+        ag = torch_allgather(group, dev) if world > 1 and not self.library_rccl else None
         self.solver.set_distributed(rank, world, lay.row0, lay.row1, allgather=ag, device_exchange=False,
                                     global_row0=lay.g0 - lay.top, global_rows=H)
         self.params = self.solver.make_params([float(v) for v in local[:16]] + self.images)

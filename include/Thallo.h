@@ -105,6 +105,11 @@ int  ThalloX_GetAlphaBetaTrace(Thallo_Plan* plan, float* out_pairs, int cap);
  * branch).  Off by default even for "levenberg_marquardt": the reference as shipped executes plain GN for that
  * kind (thallo.t:463 matches "LM", which no accepted kind string contains).  Call before Thallo_ProblemInit. */
 void ThalloX_EnableLM(Thallo_Plan* plan, int enable);
+/* Between two LM steps the branch lives on state of the previous step's end, like the reference (pd.hd.prevCost, gauss_newton.t:1710,1732) -- here also what a
+ * plugin derived from the unknowns at that point (shape_from_shading's precomputed planes).  A caller that rewrites the unknowns or the input images IN PLACE
+ * between two LM steps (same pointers: parameter binding cannot see it) says so with this call: derived state is dropped and the carried cost re-evaluated.
+ * Gauss-Newton steps derive everything from the unknowns as they are at the call and never need it. */
+void ThalloX_UnknownsChanged(Thallo_State* state, Thallo_Plan* plan);
 
 /* Name of the plugin a plan runs ("image_warping", "laplacian_image", ...). */
 const char* ThalloX_PlanEnergyName(Thallo_Plan* plan);

@@ -97,6 +97,7 @@ def lib():
     L.ThalloX_PlanSetDistributed.argtypes = [vp, C.POINTER(DistributedT)]; L.ThalloX_PlanSetDistributed.restype = C.c_int
     L.ThalloX_PlanDistributedInfo.argtypes = [vp]; L.ThalloX_PlanDistributedInfo.restype = C.c_char_p
     L.ThalloX_DistributedControl.argtypes = [vp, C.c_int, C.c_int]; L.ThalloX_DistributedControl.restype = C.c_int
+    L.ThalloX_UnknownsChanged.argtypes = [vp, vp]
     L.ThalloX_RcclUniqueId.argtypes = [vp]; L.ThalloX_RcclUniqueId.restype = C.c_int
     L.ThalloX_PlanUseRccl.argtypes = [vp, vp, C.c_int, C.c_int]; L.ThalloX_PlanUseRccl.restype = C.c_int
     L.ThalloX_RcclSelfTest.argtypes = []; L.ThalloX_RcclSelfTest.restype = C.c_int
@@ -323,6 +324,10 @@ class ThalloSolver:
 
     def distributed_kernel_only(self, reps):
         return self._L.ThalloX_DistributedKernelOnly(self.plan, reps)
+
+    def unknowns_changed(self):
+        """The caller rewrote unknowns / inputs in place between two LM steps (include/Thallo.h ThalloX_UnknownsChanged)."""
+        self._L.ThalloX_UnknownsChanged(self.state, self.plan)
 
     def enable_lm(self, on=True):
         """Run the LM branch of gauss_newton.t (dead as shipped in the reference, see include/Thallo.h)."""

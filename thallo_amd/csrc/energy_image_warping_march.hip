@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_urshape_check(int W, int H, const float
 // tools/march_probe.py only: the same planes moved with the same access widths by a flat grid-stride loop and trivial arithmetic --
 // the streaming ceiling of this byte mix (81 B/pixel, or 117 with the delta / p_{k-2} planes) on this box.
 template <int NTM, bool DELTA>
-__global__ __launch_bounds__(256) void k_stream_ref(long n2, long N, int span, const float* __restrict__ cs, const unsigned char* __restrict__ flags,
+__global__ __launch_bounds__(256) void k_stream_ref(long n2, long N, int span, int rev, const float* __restrict__ cs, const unsigned char* __restrict__ flags,
                                                     const float* __restrict__ r_in, float* __restrict__ r_out, const float* __restrict__ A_in, float* __restrict__ A_out,
                                                     const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, float alpha)
 {
@@ -414,8 +414,9 @@ __global__ __launch_bounds__(256) void k_stream_ref(long n2, long N, int span, c
         const long band = it / span, within = it % span;
         const long chunk = (band * gridDim.x + blockIdx.x) * span + within;
         if (band * (long)gridDim.x * span >= chunks) break;
-        const long i = chunk * 256 + threadIdx.x;
-        if (i >= n2) continue;
+        // rev: the same chunks in the opposite order -- what the previous launch touched LAST is read FIRST (the part of it the 256 MB Infinity Cache still holds)
+        const long i = (rev ? chunks - 1 - chunk : chunk) * 256 + threadIdx.x;
+        if (i >= n2 || i < 0) continue;
         float4 r = ldf4(ro4 + i, nt_ra); float2 ra = ldf2(ra2 + i, nt_ra);
         const float4 a = ldf4(ao4 + i, nt_ra); const float2 aa = ldf2(aa2 + i, nt_ra);
         const float4 pp = ldf4(po4 + i, nt_pin); const float2 pa = ldf2(pa2 + i, nt_pin);
@@ -579,9 +580,10 @@ int thallo_hip_iw_stream_ref(int W, int H, const float* cs, const unsigned char*
 {
     const long N = (long)W * H, n2 = N / 2;
     const int grid = thallo_hip_device_cu_count() * blocks_per_cu;
+    const int rev = span >= 1000 ? 1 : 0; if (rev) span -= 1000;              // (tools: span + 1000 = the reversed traversal)
     if (span <= 0) span = (int)(((n2 + 255) / 256 + grid - 1) / grid);      // 0: one contiguous region per workgroup
-#define SR(NTM) do { if (with_delta) hipLaunchKernelGGL((k_stream_ref<NTM, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); \
-                     else hipLaunchKernelGGL((k_stream_ref<NTM, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); } while (0)
+#define SR(NTM) do { if (with_delta) hipLaunchKernelGGL((k_stream_ref<NTM, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, rev, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); \
+                     else hipLaunchKernelGGL((k_stream_ref<NTM, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, rev, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); } while (0)
     if (ntm == 0) SR(0); else if (ntm == 1) SR(1); else if (ntm == 11) SR(11); else if (ntm == 43) SR(43); else if (ntm == 31) SR(31); else if (ntm == 63) SR(63); else return -(int)hipErrorInvalidValue;
 #undef SR
     return check_launch();

@@ -426,6 +426,12 @@ int Plan::step_gn(int ev_iter)
 
 // ------------------------------------------------------------------ Levenberg-Marquardt branch
 void Plan::enable_lm(bool on) { lm_ = on; }
+void Plan::unknowns_changed()
+{
+    if (!ok_ || !ready_) return;
+    plugin->unknowns_changed();
+    if (lm_ && !finalized_) prev_cost_ = compute_cost();          // (the LM branch carries the cost of the previous step's end)
+}
 
 int Plan::ensure_lm_vectors()
 {

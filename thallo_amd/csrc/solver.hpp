@@ -96,6 +96,7 @@ public:
     void set_param(const char* name, const void* value);
     void get_param(const char* name, void* value);
     int  alpha_beta_trace(float* out_pairs, int cap);
+    void unknowns_changed();       // the caller rewrote unknowns / inputs in place between two LM steps (ThalloX_UnknownsChanged)
     void enable_lm(bool on);       // extension: run the LM branch the reference text describes (dead as shipped, thallo.t:463)
     bool lm() const { return lm_; }
     // collective over the ranks; before Thallo_ProblemInit.  0 on success (every rank returns the same value)

@@ -116,14 +116,14 @@ def timeit(kind, reps=REPS, modes=(4, 2), pingpong=True):
     return e0.elapsed_time(e1) / (2 * reps) * 1e3
 
 
-def time_stream(with_delta, ntm, per_cu, reps=REPS, pingpong=True, span=1):
+def time_stream(with_delta, ntm, per_cu, reps=REPS, pingpong=True, span=1, alternate=False):
     a, b = [it0["r"].clone(), it0["A"].clone(), it0["p"].clone()], [f(), f(), f()]
     d = delta0.clone()
 
     def one(k):
         x, y = ((a, b) if k & 1 else (b, a)) if pingpong else (a, b)
         rc = L.thallo_hip_iw_stream_ref(W, H, vp(cs.data_ptr()), vp(flags.data_ptr()), vp(x[0].data_ptr()), vp(y[0].data_ptr()), vp(x[1].data_ptr()), vp(y[1].data_ptr()),
-                                        vp(x[2].data_ptr()), vp(y[2].data_ptr()), vp(d.data_ptr()), with_delta, ntm, per_cu, span, None)
+                                        vp(x[2].data_ptr()), vp(y[2].data_ptr()), vp(d.data_ptr()), with_delta, ntm, per_cu, span + (1000 if alternate and (k & 1) else 0), None)
         assert rc == 0, rc
     for k in range(4):
         one(k)
@@ -203,6 +203,16 @@ if os.environ.get("MB_MODE") == "order":          # sweep build: traversal order
     for nt in (0, 11):                             # does the non-temporal gain need the previous launch's writes?  (pingpong off: a -> b every time)
         out[f"stream_nt{nt}_percu2_nopingpong_us"] = round(time_stream(0, nt, 2, pingpong=False, span=0), 2)
         out[f"march_nt{nt if nt else 5}_dbg3_nopingpong_us"] = (cfg(2, nt if nt else 5, 2, 3), round(timeit("march", modes=(2,), pingpong=False), 2))[1]
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "reverse":        # sweep build: does reading what the previous launch touched LAST first let the Infinity Cache serve it?  (every other launch reversed)
+    out = {"W": W, "H": H}
+    for per_cu in (2, 4):
+        for span in (0, 1, 8):
+            for nt in (0, 1, 11, 43, 63):
+                for wd in (0, 1):
+                    out[f"percu{per_cu}_span{span}_nt{nt}_delta{wd}_fwd_us"] = round(time_stream(wd, nt, per_cu, span=span), 2)
+                    out[f"percu{per_cu}_span{span}_nt{nt}_delta{wd}_alt_us"] = round(time_stream(wd, nt, per_cu, span=span, alternate=True), 2)
     print(json.dumps(out)); sys.exit(0)
 
 if os.environ.get("MB_MODE") == "pmcsmall":      # under rocprofv3 --pmc (tools/small_pmc.sh): the two kernels and the streaming reference, one byte mix

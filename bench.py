@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--liters", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small", action="store_true")              # skip the extra 512^2 / 2048x256 timings (resident PCG loop vs launch per iteration)
     ap.add_argument("--sample-period", type=int, default=16)      # two-kernel schedule only: HIP events around every 16th launch of each kernel
     return ap.parse_args()
 
@@ -249,6 +250,34 @@ def main():
     if not one_kernel:      # z-free two-kernel schedule: read r 12, Ap 12, flags 1; write r 12
         step2_ms = ks["PCGStep2"]["mean_ms"]
         out["roofline"]["pcg_step2"] = {"algorithmic_bytes_per_pixel": 37, "avg_launch_ms": step2_ms, "achieved": 37 * npx / (step2_ms * 1e-3) / 1e9}
+    # BASELINE config 1's size and one rank's slab of the 8-GPU run: working sets that fit the chip's registers run the whole PCG loop of a GN step in ONE
+    # launch (thallo_hip_iw_pcg_resident); the launch-per-iteration schedule of the same plan beside it (THALLO_RESIDENT=0).  Not the headline metric: extra keys.
+    if not args.no_small:
+        def small(w, h, resident):
+            os.environ["THALLO_RESIDENT"] = "1" if resident else "0"
+            try:
+                q = syn.image_warping(w, h)
+                d2 = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in q]
+                s2 = thallo_amd.ThalloSolver((w, h), thallo_amd.energy_file("image_warping"), timing_level=0)
+                s2.set_solver_parameters(nIterations=1 << 30, lIterations=L_it)
+                p2 = s2.make_params(d2)
+                s2.init(p2)
+                for _ in range(3):
+                    s2.step(p2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    s2.step(p2)
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t1) / (20 * L_it) * 1e6
+                names = sorted(s2.kernel_stats())
+                c = s2.current_cost()
+                s2.close()
+                assert c == c, thallo_amd.last_error()
+                return {"us_per_pcg_iter": us, "kernels": names}
+            finally:
+                os.environ.pop("THALLO_RESIDENT", None)
+        out["small_working_sets"] = {f"{w}x{h}": {"resident_loop": small(w, h, True), "launch_per_iteration": small(w, h, False)} for (w, h) in ((512, 512), (2048, 256))}
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
         q = syn.image_warping(W, H)

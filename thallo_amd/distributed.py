@@ -272,6 +272,8 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     solver = PlanSlabSolver(params_global, W, H, rank, world, l_iters, device_exchange=use_p2p)
     lay = solver.lay
     c0 = solver.cost()             # Init: collective; the device-side exchange enables itself only if its self-check passes on this topology
+    solver.gn_step()               # (untimed) the cost after the FIRST GN step is the tight half of the parity sentinel below: 100 unconverged float PCG iterations per step
+    c1 = solver.cost()             # amplify the summation order from step to step (the one-GPU plan ends 0.8 % apart between two contraction modes of the same kernel)
     info = solver.info
     p2p = info.get("exchange") == "p2p-mailbox"
     # graph replay of the GN step is opt-out (THALLO_DIST_GRAPH=0); every rank must agree, so the outcome is all-reduced
@@ -312,9 +314,9 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         info = solver.info
     solver.drop_graph()
     final = solver.cost()
-    # Parity sentinel: the same number of GN steps from the same unknowns on ONE GPU (rank 0, the plain plan) must end at the same cost -- the slabs change
-    # the summation order of the scalars (per-rank sums added in rank order) and nothing else.  Asserted, not just printed: a stale ghost row or a lost
-    # granule would show up here as a different trajectory.
+    # Parity sentinel: the same GN steps from the same unknowns on ONE GPU (rank 0, the plain plan) -- the slabs change the summation order of the scalars
+    # (per-rank sums added in rank order) and nothing else.  Asserted, not just printed: the initial cost and the cost after the first GN step to 1e-5 (a stale
+    # ghost row or a lost granule shows up there), the final cost loosely (what the summation order alone does to an unconverged trajectory).
     n_done = int(reduce(float(getattr(solver, "executed", 0)), dist.ReduceOp.MAX))
     parity = None
     if rank == 0:
@@ -324,14 +326,19 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         p1 = s1.make_params(dev1)
         s1.init(p1)
         c0_single = s1.current_cost()
+        assert s1.step(p1) == 1
+        c1_single = s1.current_cost()
         while s1.step(p1):
             pass
         c_single = s1.current_cost()
         s1.close()
-        parity = {"gn_steps": n_done, "initial_cost_single_gpu": c0_single, "final_cost_single_gpu": c_single,
-                  "rel_diff_final_cost": abs(final - c_single) / max(abs(c_single), 1e-30), "tolerance": 1e-4}
+        parity = {"gn_steps": n_done, "initial_cost_single_gpu": c0_single, "first_step_cost": c1, "first_step_cost_single_gpu": c1_single,
+                  "rel_diff_first_step_cost": abs(c1 - c1_single) / max(abs(c1_single), 1e-30),
+                  "final_cost_single_gpu": c_single, "rel_diff_final_cost": abs(final - c_single) / max(abs(c_single), 1e-30),
+                  "tolerance_first_step": 1e-5, "tolerance_final": 5e-2}
         assert abs(c0 - c0_single) <= 1e-5 * abs(c0_single), (c0, c0_single)
-        assert parity["rel_diff_final_cost"] <= parity["tolerance"], parity
+        assert parity["rel_diff_first_step_cost"] <= parity["tolerance_first_step"], parity
+        assert parity["rel_diff_final_cost"] <= parity["tolerance_final"], parity
     dist.barrier()
     npx = W * H
     # roofline of the dominant kernel on this rank's slab: the graph replay cannot be bracketed per kernel, so the one-kernel PCG iteration is

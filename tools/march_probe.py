@@ -241,6 +241,7 @@ if os.environ.get("MB_MODE") == "floor":         # what a launch costs at this s
 
 if __name__ == "pmc":
     cfg(2, 5, 2, 0); timeit("march", modes=(2,)); timeit("march", modes=(4,))
+    cfg(2, 11, 2, 0); timeit("march", modes=(2,)); timeit("march", modes=(4,))      # the streaming reference's best policy (loads non-temporal, stores default) on the marching kernel
     cfg(2, 5, 2, 3); timeit("march", modes=(2,))
     time_stream(0, 11, 2, span=0); time_stream(0, 0, 2, span=0); time_stream(1, 11, 2, span=0)
     timeit("tile", modes=(2,))

@@ -393,6 +393,27 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             // ---- the one synchronisation point.  Everything that comes through global memory is polled in ONE loop, all loads of a pass in flight together:
             // my quarter of the sums of iteration k-1, the row of A p_{k-1} from the workgroup above (wave 0) / below (wave 3), and one word per lane of the
             // two columns from the strips to the left / right.
+            // y halo from the waves of my own workgroup: their rows are in LDS, tagged when that wave's stencil was through -- earlier than anything that
+            // comes through global memory, so they are taken first and the polling below overlaps nothing with them
+            if (up_lds || dn_lds) {
+                sp.n = 0; sp.t0 = 0;
+                const unsigned* tu = &S.rtag[parp][up_lds ? wave - 1 : wave][1]; const unsigned* td = &S.rtag[parp][dn_lds ? wave + 1 : wave][0];
+                while (!dead) {
+                    const unsigned a0 = up_lds ? __hip_atomic_load(tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp, a1 = dn_lds ? __hip_atomic_load(td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp;
+                    if (a0 == Tp && a1 == Tp) break;
+                    if (spin_fail(sp, ctl, 6u, (unsigned)wid, Tp)) dead = true;
+                }
+                dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (up_lds && xout) {
+                    const float* u = &S.rrow[parp][wave - 1][1][0][lane];
+                    ax[0][0] = u[0]; ay[0][0] = u[64]; av[0][0] = u[128]; ax[0][1] = u[192]; ay[0][1] = u[256]; av[0][1] = u[320];
+                }
+                if (dn_lds && xout) {
+                    const float* d = &S.rrow[parp][wave + 1][0][0][lane];
+                    ax[R + 1][0] = d[0]; ay[R + 1][0] = d[64]; av[R + 1][0] = d[128]; ax[R + 1][1] = d[192]; ay[R + 1][1] = d[256]; av[R + 1][1] = d[320];
+                }
+            }
             unsigned w7[7]; float rowu[6], rowd[6]; float cv = 0.f; float g_ad = 0.f, g_bn = 0.f;
 #pragma unroll
             for (int c = 0; c < 7; ++c) w7[c] = 0u;
@@ -453,26 +474,9 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             // the columns go through LDS to the two lanes that hold them (lane 0 / 63); same wave: program order + lgkmcnt(0)
             if (col_lane) S.crx[wave][chalf][cword] = cv;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // y halo from the waves of my own workgroup: their rows are in LDS
-            if (up_lds || dn_lds) {
-                sp.n = 0; sp.t0 = 0;
-                const unsigned* tu = &S.rtag[parp][up_lds ? wave - 1 : wave][1]; const unsigned* td = &S.rtag[parp][dn_lds ? wave + 1 : wave][0];
-                while (!dead) {
-                    const unsigned a0 = up_lds ? __hip_atomic_load(tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp, a1 = dn_lds ? __hip_atomic_load(td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp;
-                    if (a0 == Tp && a1 == Tp) break;
-                    if (spin_fail(sp, ctl, 6u, (unsigned)wid, Tp)) dead = true;
-                }
-                dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            float up[6], dn[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                up[c] = up_lds ? S.rrow[parp][wave - 1][1][c][lane] : rowu[c];
-                dn[c] = dn_lds ? S.rrow[parp][wave + 1][0][c][lane] : rowd[c];
-            }
-            if (has_up && xout) { ax[0][0] = up[0]; ay[0][0] = up[1]; av[0][0] = up[2]; ax[0][1] = up[3]; ay[0][1] = up[4]; av[0][1] = up[5]; }
-            if (has_dn && xout) { ax[R + 1][0] = dn[0]; ay[R + 1][0] = dn[1]; av[R + 1][0] = dn[2]; ax[R + 1][1] = dn[3]; ay[R + 1][1] = dn[4]; av[R + 1][1] = dn[5]; }
+            // (the rows from the waves of my own workgroup were taken from LDS in front of the polling loop)
+            if ((up_glb || up_gh) && xout) { ax[0][0] = rowu[0]; ay[0][0] = rowu[1]; av[0][0] = rowu[2]; ax[0][1] = rowu[3]; ay[0][1] = rowu[4]; av[0][1] = rowu[5]; }
+            if ((dn_glb || dn_gh) && xout) { ax[R + 1][0] = rowd[0]; ay[R + 1][0] = rowd[1]; av[R + 1][0] = rowd[2]; ax[R + 1][1] = rowd[3]; ay[R + 1][1] = rowd[4]; av[R + 1][1] = rowd[5]; }
             // x halo: lane 0 takes lane 62's pixels of the strip to the left, lane 63 lane 1's pixels of the strip to the right, for each of my rows
             if ((lane == 0 && has_lf) || (lane == 63 && has_rt)) {
                 const float* cx = &S.crx[wave][lane == 0 ? 0 : 1][0];
@@ -597,15 +601,17 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
         // ---- publish: the LDS rows' tags, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the
         // four waves up in order and publishes 7 granules)
         {
-            const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
-            if (lane == 0) { S.wa[wave] = wa; S.wd[wave][0] = w0; S.wd[wave][1] = w1; S.wd[wave][2] = w2; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (also the rows and columns written to LDS above)
+            // what the neighbours wait for goes out first: the tags of the rows in LDS, the two columns; the wave butterflies come behind
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the rows and columns written to LDS above)
             if (lane == 0) {
-                __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (up_lds) __hip_atomic_store(&S.rtag[par][wave][0], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (dn_lds) __hip_atomic_store(&S.rtag[par][wave][1], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (col_lane && (chalf == 0 ? has_lf : has_rt)) st1g(RS_COL, colh(par, wid, chalf, cword), T, __float_as_uint(S.cst[wave][chalf][cword]));
+            const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
+            if (lane == 0) { S.wa[wave] = wa; S.wd[wave][0] = w0; S.wd[wave][1] = w1; S.wd[wave][2] = w2; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (wave == 0) {
                 sp.n = 0; sp.t0 = 0;
                 while (!dead) {

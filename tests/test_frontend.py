@@ -173,3 +173,27 @@ def test_the_references_own_files_go_through_the_front_end(rel):
     them and emits their kernels.  (Not yet: Sum, SampledImageArray, index arithmetic between two iteration variables.)"""
     src = _text(os.path.join(REF, rel), 1)
     assert "cost_0" in src and "jtf_0" in src and "jtj_0" in src
+
+
+def test_gather_lowering_exists_exactly_where_it_can(tmp_path):
+    """compute_at_output (thallo.t:5661-5674, bodies createjtjcentered / createjtfcentered :3603-3712): residuals whose dims are the dims of every unknown they read
+    through constant-offset accesses get unknown-wise kernels jtjg_ / jtfg_ (one thread per unknown pixel, no atomics); graph residuals (Sparse maps) and residuals
+    over other dims than their unknowns' do not.  The schedule call is recorded per residual, and the unit with the gather kernels compiles for gfx950."""
+    iw = _text(thallo_amd.energy_file("image_warping"), 1)
+    assert iw.count("void jtjg_") == iw.count("void jtj_") and "atomicAdd" not in iw[iw.index("void jtjg_0"):iw.index("void jtfg_0")]
+    sfs = _text(thallo_amd.energy_file("shape_from_shading"), 1)
+    assert "void jtjg_0" in sfs
+    for graph in ("laplacian_graph", "arap_mesh_deformation", "bundle_adjustment"):
+        src = _text(thallo_amd.energy_file(graph), 1)
+        # (ARAP's fit residual is over the vertices alone: gather; its edge residual reads through V0 / V1: scatter)
+        assert "void jtjg_" + str(src.count("void jtj_") - 1) not in src, graph
+    rg = _text(os.path.join(os.path.dirname(os.path.abspath(__file__)), "energies", "row_gain.t"), 1)
+    assert "void jtjg_0" not in rg                     # residual over (x, y) reads the unknown G(y): other dims than its own -> no gather form
+    f = tmp_path / "lap_at_output.t"
+    f.write_text(open(thallo_amd.energy_file("laplacian_image")).read() + "\nr.reg:compute_at_output(true)\nr.fit:compute_at_output(false)\n")
+    assert "void jtjg_0" in _text(str(f), 1)           # (the schedule call parses; which kernels RUN is decided per residual at Plan time: test_gpu_frontend.py)
+    out = tmp_path / "iw_gather.hip"
+    out.write_text(iw)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-munsafe-fp-atomics", "-c", str(out), "-o", str(tmp_path / "o.o")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]

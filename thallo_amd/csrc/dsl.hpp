@@ -69,6 +69,7 @@ struct Residual {
     std::vector<E> exprs;                          // scalar components
     std::vector<int> domain;                       // iteration dimensions (ids), in first-use order
     bool mat_J = false, mat_JtJ = false, mat_Jp = false;   // r.<name>.J / JtJ / Jp :set_materialize(true) (thallo.t:5757-5772)
+    int at_output = -1;                            // r.<name>:compute_at_output(b) (thallo.t:5661-5674): 1 = unknown-wise (gather) lowering asked for, 0 = residual-wise, -1 = not said
 };
 
 struct Problem {
@@ -86,11 +87,14 @@ struct Problem {
 bool run_problem_file(const char* filename, Problem& out, std::string& err);
 
 // dsl_codegen.cpp
-struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 cost, 1 evalJTF, 2 applyJTJ, 3 applyJ (Jp = J p), 4 applyJt (Ap += J^T Jp), 5 dumpJ (materialize the rows)
+struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 cost, 1 evalJTF, 2 applyJTJ, 3 applyJ (Jp = J p), 4 applyJt (Ap += J^T Jp), 5 dumpJ (materialize the rows),
+                                                                      // 6 evalJTF / 7 applyJTJ in the unknown-wise (gather) form -- present only where gather_ok
+constexpr int GEN_KINDS = 8;
 struct Generated {
     std::string source;                            // one HIP translation unit
     std::vector<GenKernel> kernels;
     std::vector<int> slots_per_row;                // per residual: K, the entries per materialized row
+    std::vector<char> gather_ok;                   // per residual: the unknown-wise lowering exists (residual dims == the dims of every unknown it reads, constant-offset stencil accesses)
     std::vector<long> jp_offset;                   // per residual: offset of its rows in the Jp vector (Jt[Jp] schedule), in units of elements x components
     int n_prm = 0;
 };

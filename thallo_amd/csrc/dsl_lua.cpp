@@ -693,7 +693,13 @@ struct Interp {
             if (m == "set_materialize") { const bool b = !args.empty() && args[0].truthy(); if (obj.sym->s == "J") r.mat_J = b; else if (obj.sym->s == "JtJ") r.mat_JtJ = b; else if (obj.sym->s == "Jp") r.mat_Jp = b; return {}; }
             if (m == "set_sparse" || m == "compute_at_output") return {};
         }
-        if (is_symk(obj, SymV::NamedRes)) { if (m == "compute_at_output" || m == "reorder" || m == "clear_reorder") return { obj }; }
+        if (is_symk(obj, SymV::NamedRes)) {
+            // compute_at_output (thallo.t:5661-5674): map the residual at its OUTPUT, i.e. unknown-wise gather instead of residual-wise scatter; honoured where
+            // the gather lowering exists (dsl_codegen.cpp), otherwise the plan says so in a warning.  reorder only permutes loop nests in the reference's
+            // generated code (thallo.t:5690-5740): no effect on results, nothing to permute in a one-thread-per-element kernel.
+            if (m == "compute_at_output") { P.residuals[obj.sym->id].at_output = args.empty() || args[0].truthy() ? 1 : 0; return { obj }; }
+            if (m == "reorder" || m == "clear_reorder") return { obj };
+        }
         if (is_symk(obj, SymV::ResidualsH)) {
             if (m == "set_direct_solve") { P.direct_solve = !args.empty() && args[0].truthy(); return {}; }      // thallo.t:5634-5636
             if (m == "merge") {                      // thallo.t:5676-5688: the second residual's expressions join the first

@@ -65,11 +65,12 @@ class GeneratedPlugin : public EnergyPlugin {
         hipError_t e = hipModuleLaunchKernel(fn[kernel], grid, 1, 1, 256, 1, 1, 0, s, args, nullptr);
         return e == hipSuccess ? 0 : -(int)e;
     }
-    int kernel_of(int residual, int kind) const { return residual * 6 + kind; }
+    int kernel_of(int residual, int kind) const { return residual * dsl::GEN_KINDS + kind; }
+    std::vector<char> gather_;                     // per residual: the unknown-wise (gather) kernels run (compute_at_output, or the autoscheduler's choice where eligible)
     long rows_of(size_t ri) const { return nel[ri] * (long)P.residuals[ri].exprs.size(); }
 
 public:
-    GeneratedPlugin(const dsl::Problem& p, const unsigned* dims) : P(p)
+    GeneratedPlugin(const dsl::Problem& p, const unsigned* dims, bool autoschedule) : P(p)
     {
         label = "generated:" + P.file.substr(P.file.find_last_of('/') == std::string::npos ? 0 : P.file.find_last_of('/') + 1);
         for (size_t d = 0; d < P.dims.size(); ++d) dimv.push_back((long)dims[d]);
@@ -83,6 +84,18 @@ public:
         std::string err;
         if (!dsl::generate_source(P, G, err)) { set_error("%s: %s", P.file.c_str(), err.c_str()); return; }
         if (compile()) return;
+        // Unknown-wise (gather) lowering per residual: asked for with r.<name>:compute_at_output(true), or -- like the reference's autoscheduler, which every
+        // example application switches on (thallo.t:5173-5190: residual dims == unknown dims, nothing materialized) -- chosen where it exists.
+        gather_.assign(P.residuals.size(), 0);
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            const dsl::Residual& r = P.residuals[ri];
+            const bool plain = !r.mat_J && !r.mat_JtJ && !r.mat_Jp;
+            const bool want = r.at_output == 1 || (r.at_output < 0 && autoschedule);
+            gather_[ri] = want && plain && G.gather_ok[ri];
+            if (r.at_output == 1 && !gather_[ri])
+                fprintf(stderr, "[thallo] warning: %s: residual %s asks for compute_at_output(true) but %s: its residual-wise kernels run\n", label.c_str(), r.name.c_str(),
+                        plain ? "has no unknown-wise lowering (it reads an unknown through a Sparse map, or an unknown over other dimensions than its own)" : "also materializes J / JtJ / Jp");
+        }
         // Ctx layout of the generated code: const void* in[NIN]; int dim[max(NDIM,1)]; float prm[NIN]; long uoff[NIN]
         const size_t nin = P.inputs.size(), nd = P.dims.empty() ? 1 : P.dims.size();
         off_dim = 8 * nin; off_prm = off_dim + 4 * nd; off_uoff = (off_prm + 4 * nin + 7) / 8 * 8;
@@ -110,7 +123,15 @@ public:
         ok_ = true;
     }
     ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : jval) delete b; for (auto b : jcol) delete b; for (auto b : jdest) delete b; }
-    const char* schedule_name() const override { return direct_ ? "dense direct solve" : dense_ ? "dense [JtJ]p" : sparse_jtj_ ? "sparse [[Jt][J]]p" : "per residual"; }
+    const char* schedule_name() const override
+    {
+        if (direct_) return "dense direct solve";
+        if (dense_) return "dense [JtJ]p";
+        if (sparse_jtj_) return "sparse [[Jt][J]]p";
+        bool all = !gather_.empty(), any = false;
+        for (char g : gather_) { all = all && g; any = any || g; }
+        return all ? "per residual, unknown-wise (gather)" : any ? "per residual, some unknown-wise (gather)" : "per residual";
+    }
     int prepare(LaunchCtx&) override { sp_ready_ = false; return 0; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
 
     // symbolic phase of the sparse J^T J (the reference: cusparseXcsrgemmNnz, gauss_newton.t:1404-1412): the rows' unknown indices -> CSR pattern
@@ -201,6 +222,7 @@ public:
                 if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { set_error("%s: hipModuleLoadData failed for code generated with %s", label.c_str(), arch.c_str()); (void)hipGetLastError(); return -1; }
         for (auto& k : G.kernels) {
             hipFunction_t f = nullptr;
+            if (k.name.empty()) { fn.push_back(nullptr); continue; }       // (no gather form for this residual)
             if (hipModuleGetFunction(&f, mod, k.name.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), k.name.c_str()); return -1; }
             fn.push_back(f);
         }
@@ -248,7 +270,7 @@ public:
             hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {            // evalJTF: r = -J^T F, pre = diag(J^T J)   (thallo.t:3898-3902)
             float *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
-            const int rc = launch(kernel_of((int)ri, 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
+            const int rc = launch(kernel_of((int)ri, gather_[ri] ? 6 : 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
         if (v.diag && hipMemcpyAsync(v.diag, v.pre, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;      // LM: the raw diagonal
         if (dense_ && hipMemsetAsync(dense.ptr, 0, sizeof(float) * (size_t)n_unk * (size_t)n_unk, s) != hipSuccess) return -1;
@@ -295,7 +317,7 @@ public:
                 void* a2[] = { ctx.data(), &j, &Ap }; rc = launch(kernel_of((int)ri, 4), g, a2, s); if (rc < 0) return rc;
             } else {
                 void* args[] = { ctx.data(), &p, &Ap };
-                const int rc = launch(kernel_of((int)ri, 2), g, args, s); if (rc < 0) return rc;
+                const int rc = launch(kernel_of((int)ri, gather_[ri] ? 7 : 2), g, args, s); if (rc < 0) return rc;
             }
         }
         return thallo_hip_dot(p, Ap, n_unk, out, s);                  // PCGStep1_Finish: alphaD = p . Ap_X
@@ -312,11 +334,11 @@ public:
 
 }  // namespace
 
-EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims)
+EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, bool autoschedule)
 {
     dsl::Problem p; std::string err;
     if (!dsl::run_problem_file(filename, p, err)) { set_error("%s", err.c_str()); return nullptr; }
-    GeneratedPlugin* g = new GeneratedPlugin(p, dims);
+    GeneratedPlugin* g = new GeneratedPlugin(p, dims, autoschedule);
     if (!g->ok()) { delete g; return nullptr; }
     return g;
 }

@@ -200,6 +200,7 @@ bool unit_matches_bundled(const char* filename, const std::string& energy);     
 
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims);
 // the mini front-end (dsl.hpp): run the .t, generate its residual-wise kernels, compile them with hipRTC; NULL + set_error on failure
-EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims);
+// autoschedule (Thallo_InitializationParameters::useAutoscheduler): residuals that have an unknown-wise (gather) lowering use it unless the file says otherwise
+EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, bool autoschedule);
 
 }  // namespace thallo

@@ -591,6 +591,31 @@ int thallo_hip_dist_exchange_iter(thallo_dist_t d, int slot0, const float* alpha
                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* out[j] = rank-ordered sum of slot slot0+j for j < nslots (waits for each); diagnostics */
 int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, thallo_stream_t stream);
+/* Rows + scalars of a flat solver vector between row slabs in ONE launch, device side (round 3; replaces slab_pack + all-gather + slab_unpack of the
+   single-image slab form, i.e. shape_from_shading's Gauss-Newton and Levenberg-Marquardt exchanges; reference: none -- single device, util.t:769-772).
+   Every rank's mailbox allocation carries, behind a ring of 4 x 8 scalar slots (slots ring0 ..), an INBOX of 2 (parity) x 2 (from above, from below) areas of
+   inbox_half floats at byte offset inbox_off (the same numbers on every rank).  The launch (one workgroup for rows up to 32 K floats, else 8 workgroups and a ticket):
+     1. stores the `first` segments of vec into the upper neighbour's inbox (its "from below" area) and the `last` segments into the lower neighbour's
+        ("from above"), peer-to-peer, fences, takes a ticket;
+     2. its last workgroup adds the local partials in the fixed single-GPU order, sends the scalar granules {value | tag} to every rank, waits (bounded, as
+        everywhere: ctl[1] error word + post-mortem) for every rank's, adds them in rank order -- the same bits as the all-gather path on every rank --
+        and writes the result words:  mode 0: out0[0] = sum over ranks of sum(local) (local.count == 0: no scalar, out0 ignored), and optionally a second one:
+        out1[0] = sum over ranks of sum(alphaD_partials[0 .. count)) (count == 0: none);
+        mode 1 (iteration form): out0[0] = alphaD_k, out1[0] = betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 from alphaD_partials / s3_partials[count]
+        and the one-word alphaN, exactly thallo_hip_slab_unpack_iter's arithmetic;
+     3. then copies its own inbox areas into the `top` / `bot` ghost segments of vec (a neighbour's granule is sent after its rows are fenced).
+   tag = ctl[10] + 1, a device-side counter of these exchanges (every rank issues the same sequence of them); parity = tag & 1: a rank can be at most one
+   exchange ahead of a neighbour, which still reads the other parity.  poison != 0: this rank failed earlier -- it sends NaN scalars and no rows so that
+   nobody waits for it and every rank sees the failure in its sums. */
+typedef struct thallo_xrows_t {
+    long inbox_off;              /* bytes from the start of a rank's mailbox allocation */
+    long inbox_half;             /* floats per (parity, direction) area; >= the total length of `first` / `last` */
+    int  above, below;           /* neighbour ranks; -1: image border */
+    int  ring0;                  /* first scalar slot of the ring (4 x 8 slots) */
+} thallo_xrows_t;
+int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                          int mode, thallo_sum_t local_or_alphaN, const float* alphaD_partials, const double* s3_partials, int count, int poison,
+                          float* out0, float* out1, thallo_stream_t stream);
 /* host-side read / clear of the error word (synchronises the stream) */
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream);
 /* image_warping PCGStep2 over a row slab (z-free schedule only: UrShape must be the unit pixel grid on every rank) that also

@@ -322,7 +322,7 @@ def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
 
 
 # ------------------------------------------------------------------ shape_from_shading row slabs (2 ghost rows), behind Thallo_ProblemStep
-def _sfs_worker(rank, world, port, W, H, nit, lit, lm, q):
+def _sfs_worker(rank, world, port, W, H, nit, lit, lm, q, device_exchange=True):
     import torch
     import torch.distributed as dist
     from thallo_amd import synthetic as syn
@@ -332,7 +332,7 @@ def _sfs_worker(rank, world, port, W, H, nit, lit, lm, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.shape_from_shading(W, H)
-        solver = PlanSfsSlabSolver(p, W, H, rank, world, lit, lm=lm)
+        solver = PlanSfsSlabSolver(p, W, H, rank, world, lit, lm=lm, device_exchange=device_exchange)
         extra = {"q_tolerance": 0.05} if lm else {}             # (LM: large enough that the device-side zeta test ends some PCG loops early)
         costs = solver.solve(nit, **extra)
         lay = solver.lay
@@ -342,12 +342,12 @@ def _sfs_worker(rank, world, port, W, H, nit, lit, lm, q):
         dist.destroy_process_group()
 
 
-def _run_sfs(world, W, H, nit, lit, lm):
+def _run_sfs(world, W, H, nit, lit, lm, device_exchange=True):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sfs_worker, args=(r, world, port, W, H, nit, lit, lm, q)) for r in range(world)]
+    procs = [ctx.Process(target=_sfs_worker, args=(r, world, port, W, H, nit, lit, lm, q, device_exchange)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = _collect(q, procs, world)
@@ -355,15 +355,30 @@ def _run_sfs(world, W, H, nit, lit, lm):
     return res
 
 
+@pytest.mark.parametrize("world,W,H,nit,lit,lm", [(2, 64, 64, 4, 10, False), (3, 128, 112, 3, 10, False), (3, 128, 112, 3, 10, True), (2, 256, 96, 3, 12, True), (1, 64, 48, 3, 10, False)])
+def test_sfs_device_side_row_exchange_is_bitwise_the_allgather_transport(world, W, H, nit, lit, lm):
+    """shape_from_shading's slabs exchanged through pack + all-gather + unpack (three launches and a collective per exchange).  Now ONE launch:
+    thallo_hip_dist_xrows stores the boundary rows into the neighbours' inboxes, sends the scalar granules to every rank, waits, sums in rank order and copies its own
+    inbox into the ghost rows.  Same arithmetic in the same order: costs and unknowns of both transports are bit-identical, Gauss-Newton and Levenberg-Marquardt
+    (whose early PCG exits depend on the exchanged q), 1-3 ranks."""
+    a = _run_sfs(world, W, H, nit, lit, lm, device_exchange=True)
+    b = _run_sfs(world, W, H, nit, lit, lm, device_exchange=False)
+    for (rank, costs, g0, g1, owned, info), (_, costs_b, _, _, owned_b, info_b) in zip(a, b):
+        assert info["exchange"] == "p2p-rows" and info["self_check"]["all_ranks_pass"] is True, info
+        assert info_b["exchange"] == "allgather", info_b
+        assert costs == costs_b, (rank, costs, costs_b)
+        assert np.array_equal(owned, owned_b), rank
+
+
 @pytest.mark.parametrize("world,W,H,nit,lit", [(2, 64, 64, 4, 10), (3, 128, 112, 3, 10), (1, 64, 48, 3, 10)])
 def test_hip_sfs_slabs_match_oracle(orc, world, W, H, nit, lit):
-    """Gauss-Newton, single-reduction form: one all-gather per PCG iteration."""
+    """Gauss-Newton, single-reduction form: one exchange per PCG iteration (the device-side one: thallo_hip_dist_xrows)."""
     from thallo_amd import synthetic as syn
     res = _run_sfs(world, W, H, nit, lit, False)
     p = syn.shape_from_shading(W, H)
     co, _ = orc.Problem(orc.SFS, (W, H), p).solve(nIterations=nit, lIterations=lit)
     for rank, costs, g0, g1, X, info in res:
-        assert info["exchange"] == "allgather" and info["world"] == world
+        assert info["exchange"] == "p2p-rows" and info["world"] == world
         assert (np.abs(np.array(costs) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (rank, costs, co)
         assert costs == res[0][1]
         assert np.abs(X - p[16][g0:g1]).max() <= 2e-5

@@ -26,7 +26,7 @@ __device__ __forceinline__ void st_sys(float* p, float v) { __hip_atomic_store(p
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ctl words
-enum { DIST_SEQ = 0, DIST_ERR = 1, DIST_SPIN_MS = 2, DIST_POST_MORTEM = 4, DIST_CTL_WORDS = 16 };
+enum { DIST_SEQ = 0, DIST_ERR = 1, DIST_SPIN_MS = 2, DIST_POST_MORTEM = 4, DIST_XSEQ = 10, DIST_XTICKET = 11, DIST_CTL_WORDS = 16 };     // [10], [11]: thallo_hip_dist_xrows' exchange counter and ticket
 // ctl[DIST_SPIN_MS] != 0: spin bound in milliseconds instead of the default (the set-up's self-check runs with 500 ms, so that a
 // topology on which granules never become visible costs half a second, not 20 s, before every rank falls back to the collectives)
 __device__ __forceinline__ long long dist_spin_ticks(const thallo_dist_t& d)
@@ -82,8 +82,16 @@ __device__ __forceinline__ void dist_fetch(const thallo_dist_t& d, const int (&s
 // this rank's sums (alphaD float; N, S1, S2 double) go out as 7 granules to every rank's mailbox slots slot0 .. slot0+6 (the doubles
 // as hi / lo words), the wave waits (bounded) for everybody's, adds them in rank order and lane 0 writes alphaD_k and
 // betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 with alpha_k = alphaN / alphaD_k.  Identical bits on every rank.
+__device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
+                                                            float* __restrict__ aD_word, float* __restrict__ bN_word);
 __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, int slot0, float ad, double q0, double q1, double q2, float an,
                                                         float* __restrict__ aD_word, float* __restrict__ bN_word)
+{
+    dist_exchange_iter_wave_seq(d, ld_agent(d.ctl + DIST_SEQ), slot0, ad, q0, q1, q2, an, aD_word, bN_word);
+}
+// (seq given by the caller: thallo_hip_dist_xrows tags with its own exchange counter)
+__device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, const unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
+                                                            float* __restrict__ aD_word, float* __restrict__ bN_word)
 {
     const int lane = threadIdx.x & (THALLO_WAVE - 1);
     unsigned w[7];
@@ -91,7 +99,6 @@ __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, 
     { const u64 b = (u64)__double_as_longlong(q0); w[1] = (unsigned)(b >> 32); w[2] = (unsigned)b; }
     { const u64 b = (u64)__double_as_longlong(q1); w[3] = (unsigned)(b >> 32); w[4] = (unsigned)b; }
     { const u64 b = (u64)__double_as_longlong(q2); w[5] = (unsigned)(b >> 32); w[6] = (unsigned)b; }
-    const unsigned seq = ld_agent(d.ctl + DIST_SEQ);
     if (lane < d.world) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) st_sys(d.peer_mail[lane] + (long)(slot0 + j) * d.world + d.rank, ((u64)seq << 32) | (u64)w[j]);
@@ -130,6 +137,45 @@ __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, 
     double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
     if (!(bn > 0.0)) bn = 0.0;
     if (lane == 0) { aD_word[0] = gad; bN_word[0] = (float)bn; }
+}
+
+// NS floats per rank, by ONE full wave (NS * world <= 64): granules to every rank's slots slot0 .. slot0+NS-1, bounded wait, rank-ordered sums (every lane returns them)
+template <int NS>
+__device__ __forceinline__ void dist_exchange_words_wave_seq(const thallo_dist_t& d, const unsigned seq, int slot0, const float (&w)[NS], float (&out)[NS])
+{
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    if (lane < d.world) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) st_sys(d.peer_mail[lane] + (long)(slot0 + j) * d.world + d.rank, ((u64)seq << 32) | (u64)__float_as_uint(w[j]));
+    }
+    unsigned got = 0;
+    if (lane < NS * d.world) {
+        const int j = lane / d.world, r = lane - j * d.world;
+        const u64* g = d.mail + (long)(slot0 + j) * d.world + r;
+        u64 v = ld_sys(g);
+        int it = 0; long long t0 = 0;
+        const long long bound = dist_spin_ticks(d);
+        while ((unsigned)(v >> 32) != seq) {
+            if ((it & 1023) == 0) { if (ld_agent(d.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
+            ++it;
+            if ((it & 1023) == 0 && wall_clock64() - t0 > bound) {
+                if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    unsigned* pm = d.ctl + DIST_POST_MORTEM;
+                    pm[0] = (unsigned)(slot0 + j); pm[1] = (unsigned)r; pm[2] = seq; pm[3] = (unsigned)(v >> 32); pm[4] = (unsigned)v;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            v = ld_sys(g);
+        }
+        got = (unsigned)v;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        float t = 0.0f;
+        for (int r = 0; r < d.world; ++r) t += __uint_as_float(__shfl(got, j * d.world + r, THALLO_WAVE));
+        out[j] = t;
+    }
 }
 
 }  // namespace thallo

@@ -1,6 +1,7 @@
 // dist_p2p.hip -- host entry points of the multi-GPU device-side exchange (include/thallo_hip.h, dist_device.hpp).
 #include "dist_device.hpp"
 #include <string.h>
+#include <algorithm>
 #include <stdlib.h>
 
 using namespace thallo;
@@ -53,6 +54,85 @@ __global__ __launch_bounds__(64) void k_collect(thallo_dist_t d, int slot0, int 
         dist_fetch<1>(d, slots, s, vals);
         if (threadIdx.x == 0) out[j] = s[0];
         __syncthreads();
+    }
+}
+
+// thallo_hip_dist_xrows (thallo_hip.h): boundary rows of a flat vector into the neighbours' inboxes + the scalars of the exchange to every rank + own inbox -> ghost rows,
+// ONE launch.  8-byte system-scope stores / loads for the rows (the inbox is memory another GPU writes while this one reads it).
+__device__ __forceinline__ float* inbox_of(unsigned long long* mail, const thallo_xrows_t& x, int parity, int dir)
+{
+    return (float*)((char*)mail + x.inbox_off) + (long)(parity * 2 + dir) * x.inbox_half;
+}
+__device__ __forceinline__ void rows_out(const float* __restrict__ vec, const thallo_segs_t& segs, float* dst)
+{   // segment lengths and offsets are multiples of 2 floats (checked by the host entry)
+    long base = 0;
+    for (int k = 0; k < segs.n; ++k) {
+        const u64* src = (const u64*)(vec + segs.off[k]);
+        u64* out = (u64*)(dst + base);
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < segs.len[k] / 2; i += (long)gridDim.x * blockDim.x) st_sys(out + i, src[i]);
+        base += segs.len[k];
+    }
+}
+__device__ __forceinline__ void rows_in(float* __restrict__ vec, const thallo_segs_t& segs, const float* src)
+{   // by ONE workgroup
+    long base = 0;
+    for (int k = 0; k < segs.n; ++k) {
+        u64* out = (u64*)(vec + segs.off[k]);
+        const u64* in = (const u64*)(src + base);
+        for (long i = threadIdx.x; i < segs.len[k] / 2; i += blockDim.x) out[i] = ld_sys(in + i);
+        base += segs.len[k];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x, float* __restrict__ vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                                                thallo_sum_t s, const float* __restrict__ aD_part, const double* __restrict__ s3, int nb, int poison,
+                                                float* __restrict__ out0, float* __restrict__ out1)
+{
+    __shared__ unsigned last_wg;
+    const unsigned tag = ld_agent(d.ctl + DIST_XSEQ) + 1u;
+    const int par = (int)(tag & 1u);
+    if (!poison) {
+        if (x.above >= 0) rows_out(vec, first, inbox_of(d.peer_mail[x.above], x, par, 1));       // I am BELOW my upper neighbour
+        if (x.below >= 0) rows_out(vec, last, inbox_of(d.peer_mail[x.below], x, par, 0));
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (gridDim.x > 1) {                            // (long rows: several workgroups carry them, the last one to arrive goes on)
+        if (threadIdx.x == 0) last_wg = __hip_atomic_fetch_add(d.ctl + DIST_XTICKET, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!last_wg) return;
+    }
+    // every row of this rank is out and fenced: the granules may go
+    const int slot0 = x.ring0 + (int)(tag & 3u) * 8;
+    if (threadIdx.x < THALLO_WAVE) {
+        const int lane = threadIdx.x;
+        if (MODE == 0) {                            // up to two float sums: s -> out0, (aD_part, nb) -> out1
+            float w[2], t[2];
+            w[0] = s.count > 0 ? sum_partials(s.partials, s.count) : 0.0f;
+            w[1] = nb > 0 ? sum_partials(aD_part, nb) : 0.0f;
+            if (poison) w[0] = w[1] = __uint_as_float(0x7fc00000u);
+            dist_exchange_words_wave_seq<2>(d, tag, slot0, w, t);
+            if (lane == 0 && s.count > 0) out0[0] = t[0];
+            if (lane == 0 && nb > 0) out1[0] = t[1];
+        } else {
+            float ad = sum_partials(aD_part, nb);
+            double q[3] = { 0.0, 0.0, 0.0 };
+            for (int i = lane; i < nb; i += THALLO_WAVE) { q[0] += s3[3 * i]; q[1] += s3[3 * i + 1]; q[2] += s3[3 * i + 2]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) q[j] = wave_sum_all_f64(q[j]);
+            if (poison) ad = __uint_as_float(0x7fc00000u);
+            dist_exchange_iter_wave_seq(d, tag, slot0, ad, q[0], q[1], q[2], s.count == 1 ? s.partials[0] : 0.0f, out0, out1);
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);                                                      // (system scope: the neighbours' rows are behind their granules)
+    if (x.above >= 0) rows_in(vec, top, inbox_of(d.mail, x, par, 0));
+    if (x.below >= 0) rows_in(vec, bot, inbox_of(d.mail, x, par, 1));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (gridDim.x > 1) __hip_atomic_store(d.ctl + DIST_XTICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d.ctl + DIST_XSEQ, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 }  // namespace
@@ -142,6 +222,35 @@ int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, 
     if (!dist_ok(d) || slot0 < 0 || nslots < 0 || !out) return -(int)hipErrorInvalidValue;
     if (nslots == 0) return 0;
     hipLaunchKernelGGL(k_collect, dim3(1), dim3(64), 0, (hipStream_t)stream, d, slot0, nslots, out);
+    return check_launch();
+}
+
+int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                          int mode, thallo_sum_t s, const float* aD_partials, const double* s3_partials, int count, int poison,
+                          float* out0, float* out1, thallo_stream_t stream)
+{
+    if (!dist_ok(d) || x.ring0 < 0 || x.inbox_off <= 0 || (x.inbox_off & 7) || x.inbox_half < 0 || (x.inbox_half & 1) || x.above >= d.world || x.below >= d.world ||
+        x.above == d.rank || x.below == d.rank || 7 * d.world > 64) return -(int)hipErrorInvalidValue;
+    auto total = [](const thallo_segs_t& g, bool& ok) {
+        long t = 0;
+        if (g.n < 0 || g.n > 8) { ok = false; return 0L; }
+        for (int k = 0; k < g.n; ++k) { if (g.len[k] < 0 || (g.len[k] & 1) || (g.off[k] & 1) || g.off[k] < 0) ok = false; t += g.len[k]; }
+        return t;
+    };
+    bool ok = true;
+    const long tf = total(first, ok), tl = total(last, ok), tt = total(top, ok), tb = total(bot, ok);
+    if (!ok || tf > x.inbox_half || tl > x.inbox_half) return -(int)hipErrorInvalidValue;
+    if ((x.above >= 0 && tt != tl && tt != tf) || (x.below >= 0 && tb != tf && tb != tl)) return -(int)hipErrorInvalidValue;   // (slabs are symmetric: what I receive is as long as what I send)
+    if ((tf + tl + tt + tb > 0) && !vec) return -(int)hipErrorInvalidValue;
+    if (mode == 0) {
+        if (s.count < 0 || (s.count > 0 && (!s.partials || !out0)) || s.count > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+        if (count < 0 || (count > 0 && (!aD_partials || !out1)) || count > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;      // the optional second sum
+    } else if (mode == 1) { if (!aD_partials || !s3_partials || count < 1 || count > THALLO_MAX_PARTIALS || s.count != 1 || !s.partials || !out0 || !out1) return -(int)hipErrorInvalidValue; }
+    else return -(int)hipErrorInvalidValue;
+    // rows of up to 32 K floats per direction (a 2048-wide image: 2 ghost rows of 4 channels): ONE workgroup, no ticket; longer ones: 8 workgroups
+    const int grid = std::max(tf, tl) <= 32768 ? 1 : 8, block = 256;
+    if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1);
+    else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1);
     return check_launch();
 }
 

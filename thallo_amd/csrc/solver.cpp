@@ -718,7 +718,7 @@ int Plan::step_lm(int ev_iter)
         }
         if (failed) break;
         if (!skip()) { set_nb(jB, nb); set_nb(QS, nbq); }
-        if (global(QS) || global_rows(jB, v_.z)) { coll_failed = true; break; }     // q and betaN over all ranks; ghost rows of z
+        if (slab && dist_two_sums_and_rows(QS, jB, v_.z)) { coll_failed = true; break; }   // q and betaN over all ranks; ghost rows of z
         k_done = k + 1;
         if (!zeta_done && !skip()) {
             TimedLaunch t(ctx, "PCGZeta");

@@ -56,6 +56,9 @@ struct DistState {
     bool flat = false;
     long rowlen = 0;                                     // floats per image row
     thallo_segs_t seg_rows_fl, seg_rows_top, seg_rows_bot;   // first / last `ghost` owned rows; the ghost rows above / below
+    thallo_segs_t seg_rows_first, seg_rows_last;             // ... the first and the last owned rows separately (device-side exchange: one goes up, one goes down)
+    thallo_xrows_t xr;                                       // device-side exchange of the flat form (thallo_hip_dist_xrows): inbox geometry, neighbours
+    bool xrows_now = false;                                  // the transport dist_sum_slot / dist_sum_and_rows / dist_gn_flat use right now (= p2p_on outside the self-check)
     // range form (graph domains: ARAP): every rank holds the whole problem and FULL-length vectors and owns the contiguous unit range [row0, row1)
     // (units = vertices); equal ranges on all ranks.  pieces = rank 0's owned slice of every plane of the flat vector (rank r's: + r * len)
     bool range = false;
@@ -170,6 +173,9 @@ private:
     void dist_fail(const char* fmt, ...);               // first rank-local failure: report it, switch this rank to "collectives only" (DistState::failed)
     bool dist_skip() const { return dist_ && dist_->failed; }
     int  dist_map_peers();
+    int  dist_map_peers_flat();
+    int  dist_two_sums_and_rows(int j1, int j2, float* vec);
+    int  dist_xrows(float* vec, bool rows, int mode, thallo_sum_t s, const float* aD_part, const double* s3, int nb, float* out0, float* out1);
     int  dist_self_check();
     int  dist_gn(int L, bool p2p);                      // PCGInit + L iterations + linear update + ghost refresh, no bookkeeping
     int  step_gn_slab(int ev_iter);

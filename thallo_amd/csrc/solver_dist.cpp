@@ -202,12 +202,22 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         D.msg = 2 + 2 * gl; D.msg_iter = 7 + 2 * gl; D.msg_x = 2 * gl;
         const size_t words = (size_t)std::max(D.msg_iter, 64L);
         if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }
-        const bool mem = ensure_sums_buffer() == 0;
+        D.seg_rows_first = segs({ { D.rowlen * D.row0, gl } }); D.seg_rows_last = segs({ { D.rowlen * (D.row1 - g), gl } });
+        bool mem = ensure_sums_buffer() == 0;
+        if (mem && (D.ctl.alloc(THALLO_DIST_CTL_WORDS * sizeof(unsigned)) || hipMemset(D.ctl.ptr, 0, THALLO_DIST_CTL_WORDS * sizeof(unsigned)) != hipSuccess)) mem = false;
         bool all = false;
         if (dist_agree(mem, all)) return -1;                             // the first use of the caller's all-gather: fails here, not mid-solve
         if (!all) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
+        // ---- device-side exchange (thallo_hip_dist_xrows): scalar ring + row inbox in one IPC allocation per rank; decided by every rank alike
+        D.want_p2p = cfg.device_exchange != 0;
+        {   const char* e = env_switch("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
+        all = false;
+        if (dist_agree(D.want_p2p, all)) return -1;
+        D.want_p2p = all;
+        if (D.want_p2p && dist_map_peers_flat()) return -1;
         char buf[256];
-        snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"single-image, %d ghost rows\", \"rank\": %d, \"world\": %d}", g, cfg.rank, cfg.world);
+        snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"single-image, %d ghost rows\", \"rank\": %d, \"world\": %d, \"device_exchange_requested\": %s}", g, cfg.rank, cfg.world,
+                 cfg.device_exchange ? "true" : "false");
         D.info = buf;
         return 0;
     }
@@ -316,6 +326,54 @@ int Plan::dist_map_peers()
     return 0;
 }
 
+int Plan::dist_map_peers_flat()
+{   // flat form: only the mailbox allocation (scalar ring + row inbox) is shared; the solver vectors stay where the Plan allocated them
+    DistState& D = *dist_;
+    const int world = D.cfg.world, rank = D.cfg.rank;
+    const long gl = D.ghost * D.rowlen;
+    thallo_xrows_t x; memset(&x, 0, sizeof(x));
+    x.ring0 = 0;
+    x.inbox_off = (8L * 32 * world + 255) / 256 * 256;                  // behind 4 x 8 scalar slots of `world` granules
+    x.inbox_half = gl;
+    x.above = D.top ? rank - 1 : -1; x.below = D.bot ? rank + 1 : -1;
+    PeerInfo mine; memset(&mine, 0, sizeof(mine));
+    mine.ok = thallo_hip_ipc_alloc2(x.inbox_off + 4 * gl * (long)sizeof(float), &D.mail, D.handle_mail, &D.mem_kind[1]) >= 0 ? 1 : 0;
+    if (!mine.ok) D.mail = nullptr;
+    memcpy(mine.mail, D.handle_mail, 64);
+    mine.row0 = D.row0; mine.row1 = D.row1; mine.Hl = D.Hl; mine.na = gl;
+    PeerInfo infos[THALLO_DIST_MAX_WORLD];
+    if (host_allgather(*this, D, &Plan::dist_allgather, &mine, infos, sizeof(PeerInfo))) return -1;
+    bool ok = true;
+    for (int r = 0; r < world; ++r) ok = ok && infos[r].ok == 1 && infos[r].na == gl;
+    thallo_dist_t d; memset(&d, 0, sizeof(d));
+    d.world = world; d.rank = rank; d.mail = (unsigned long long*)D.mail; d.ctl = (unsigned*)D.ctl.ptr;
+    for (int r = 0; r < world && ok; ++r) {
+        if (r == rank) { d.peer_mail[r] = d.mail; continue; }
+        void* p = nullptr;
+        if (thallo_hip_ipc_open(infos[r].mail, &p) < 0) { ok = false; break; }
+        D.opened.push_back(p); d.peer_mail[r] = (unsigned long long*)p;
+    }
+    D.d = d; D.xr = x;
+    bool all = false;
+    if (dist_agree(ok, all)) return -1;
+    D.mapped = all;
+    if (!all) D.want_p2p = false;
+    return 0;
+}
+
+int Plan::dist_xrows(float* vec, bool rows, int mode, thallo_sum_t sm, const float* aD_part, const double* s3, int nb, float* out0, float* out1)
+{   // one device-side exchange of the flat form.  Issued by EVERY rank, failed or not (a failed rank sends poisoned scalars and no rows: nobody waits for it,
+    // everybody's sums turn NaN and the failure is agreed on at the next cost evaluation)
+    DistState& D = *dist_;
+    const thallo_segs_t none = segs({});
+    const int poison = D.failed ? 1 : 0;
+    int rc = thallo_hip_dist_xrows(D.d, D.xr, vec, rows ? D.seg_rows_first : none, rows ? D.seg_rows_last : none, rows ? D.seg_rows_top : none, rows ? D.seg_rows_bot : none,
+                                   mode, sm, aD_part, s3, nb, poison, out0, out1, ctx.stream);
+    if (D.inject > 0 && !D.failed && --D.inject == 0) rc = -999;
+    if (rc < 0 && !D.failed) dist_fail("device-side row exchange failed (%d)", rc);
+    return 0;
+}
+
 float Plan::dist_cost()
 {   // local partials -> [cost, failure flag] per rank -> all-gather -> rank-ordered sum on the host (the read-back blocks anyway, gauss_newton.t:1128-1136).
     // This is also where a rank-local failure becomes everybody's: any rank's flag (or a poisoned, non-finite word) makes EVERY rank report the error
@@ -327,6 +385,14 @@ float Plan::dist_cost()
         unsigned pm[5] = { 0, 0, 0, 0, 0 };
         if (plugin->resident_status(ctx, 1, pm) != 0)
             dist_fail("a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u)", pm[0], pm[1], pm[2], pm[3], pm[4]);
+    }
+    if (D.flat && D.p2p_on && !D.failed) {  // the device-side row exchange's waits are bounded too
+        const int err = thallo_hip_dist_error(D.d, 1, s);
+        if (err != 0) {
+            unsigned pm[5] = { 0, 0, 0, 0, 0 };
+            hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
+            dist_fail("a bounded wait of the device-side row exchange ran out (slot %u, source rank %u, tag %u, found %u)", pm[0], pm[1], pm[2], pm[3]);
+        }
     }
     int nb = 0;
     if (!D.failed) { nb = plugin->cost(ctx, slot(0)); if (nb < 0) dist_fail("cost kernel launch failed (%d)", nb); }
@@ -437,6 +503,8 @@ int Plan::dist_exchange_unknown_rows()
     float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
     TimedLaunch t(ctx, "SlabExchangeUnknowns");
     const auto& imgs = plugin->unknown_images();
+    if (D.flat && D.xrows_now && imgs.size() == 1 && imgs[0].n_floats == D.rowlen * D.Hl)      // (the unknown image has the flat vector's layout: the same row segments)
+        return dist_xrows(plugin->unknown_ptr(0), true, 0, thallo_sum_t{ nullptr, 0 }, nullptr, nullptr, 0, nullptr, nullptr);
     long pos = 0;
     for (size_t k = 0; k < imgs.size(); ++k) pos += 2 * g * (imgs[k].n_floats / D.Hl);
     if (pos > D.msg_x) { set_error("distributed: unknown rows exceed the message buffer"); return -1; }      // (a property of the plan: the same on every rank)
@@ -466,6 +534,11 @@ int Plan::dist_sum_slot(int j)
     DistState& D = *dist_;
     hipStream_t s = ctx.stream;
     const thallo_segs_t none = segs({});
+    if (D.xrows_now) {
+        if (dist_xrows(nullptr, false, 0, D.failed ? thallo_sum_t{ (const float*)D.send.ptr, 1 } : partial_sum(j), nullptr, nullptr, 0, scal(j), nullptr)) return -1;
+        if (!D.failed) fin_[j] = 1;
+        return 0;
+    }
     DLOCAL(thallo_hip_finish_sum(partial_sum(j), (float*)D.send.ptr, s), "partial sum");
     if (dist_allgather(D.send.ptr, D.gath.ptr, sizeof(float))) return -1;
     DLOCAL(thallo_hip_slab_unpack(nullptr, none, nullptr, none, nullptr, (const float*)D.gath.ptr, 1, D.cfg.world, scal(j), s), "rank-ordered sum");
@@ -480,12 +553,28 @@ int Plan::dist_sum_and_rows(int j, float* vec)
     float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
     const long gl = D.ghost * D.rowlen, msg = 1 + 2 * gl;
     const thallo_sum_t nothing = { nullptr, 0 };
+    if (D.xrows_now) {
+        const thallo_sum_t sm = j < 0 ? nothing : D.failed ? thallo_sum_t{ (const float*)D.send.ptr, 1 } : partial_sum(j);
+        if (dist_xrows(vec, true, 0, sm, nullptr, nullptr, 0, j >= 0 ? scal(j) : nullptr, nullptr)) return -1;
+        if (j >= 0 && !D.failed) fin_[j] = 1;
+        return 0;
+    }
     DLOCAL(thallo_hip_slab_pack(vec, D.seg_rows_fl, j >= 0 ? partial_sum(j) : nothing, send, s), "slab pack");
     if (dist_allgather(send, gath, msg * (long)sizeof(float))) return -1;
     const float* src_top = D.top ? gath + (D.cfg.rank - 1) * msg + 1 + gl : nullptr;          // the LAST rows of rank-1
     const float* src_bot = D.bot ? gath + (D.cfg.rank + 1) * msg + 1 : nullptr;               // the FIRST rows of rank+1
     DLOCAL(thallo_hip_slab_unpack(vec, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, msg, D.cfg.world, j >= 0 ? scal(j) : nullptr, s), "slab unpack");
     if (j >= 0 && !D.failed) fin_[j] = 1;
+    return 0;
+}
+
+int Plan::dist_two_sums_and_rows(int j1, int j2, float* vec)
+{   // slots j1 and j2 made global and the ghost rows of `vec` refreshed: ONE launch on the device-side transport (LM: q and betaN + the rows of z), else two exchanges
+    DistState& D = *dist_;
+    if (!D.xrows_now) return dist_sum_slot(j1) || dist_sum_and_rows(j2, vec) ? -1 : 0;
+    const thallo_sum_t dummy = { (const float*)D.send.ptr, 1 };
+    if (dist_xrows(vec, true, 0, D.failed ? dummy : partial_sum(j1), D.failed ? (const float*)D.send.ptr : slot(j2), nullptr, D.failed ? 1 : nb_[j2], scal(j1), scal(j2))) return -1;
+    if (!D.failed) { fin_[j1] = 1; fin_[j2] = 1; }
     return 0;
 }
 
@@ -520,6 +609,12 @@ int Plan::dist_gn_flat(int L)
         }
         cur_ ^= 1;
         TimedLaunch t(ctx, "SlabExchange");
+        if (D.xrows_now) {                      // ONE launch: rows into the neighbours' inboxes, scalars to every rank, own inbox -> ghost rows
+            const thallo_sum_t dummy = { (const float*)D.send.ptr, 1 };     // (a failed rank's arguments only have to be launchable: it sends NaN)
+            if (dist_xrows(v_.Ap, true, 1, D.failed ? dummy : sum(jN), D.failed ? (const float*)D.send.ptr : slot(jD), v_.s12, D.failed ? 1 : nb, scal(jD), scal(jB))) return -1;
+            if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+            continue;
+        }
         DLOCAL(thallo_hip_slab_pack_iter(v_.Ap, D.seg_rows_fl, slot(jD), v_.s12, nb, send, s), "slab pack");
         if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
         const float* src_top = D.top ? gath + (rank - 1) * D.msg_iter + 7 + gl : nullptr;
@@ -673,6 +768,52 @@ int Plan::dist_self_check()
     D.checked = true;
     if (!D.mapped) { D.p2p_on = false; return 0; }                       // (agreed in dist_map_peers: the same on every rank)
     hipStream_t s = ctx.stream;
+    if (D.flat) {
+        // flat form: three exchanges (both parities, three ring positions) of a pattern that is a function of the GLOBAL row -- what has to arrive in the
+        // ghost rows is known without asking the neighbour -- and a scalar per rank; v_.Ap is scratch outside a step
+        const long rl = D.rowlen, nloc = rl * D.Hl;
+        const unsigned spin_ms = 500, zero = 0;
+        std::vector<float> host((size_t)nloc), back((size_t)nloc);
+        auto value = [&](long grow, long col, int t) { return (float)(((grow * rl + col) * 31 + t * 101) % 65521); };
+        bool pass = true; int err = 0; float got_sum = 0.0f;
+        DCOPY(hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &spin_ms, sizeof(unsigned), hipMemcpyHostToDevice, s), "spin bound");
+        for (int t = 0; t < 3; ++t) {
+            for (long y = 0; y < D.Hl; ++y) {
+                const bool owned = y >= D.row0 && y < D.row1;
+                for (long c = 0; c < rl; ++c) host[y * rl + c] = owned ? value((long)D.cfg.global_row0 + y, c, t) : -1.0f;
+            }
+            const float mine = (float)(D.cfg.rank + 1 + t);
+            DCOPY(hipMemcpyAsync(v_.Ap, host.data(), nloc * sizeof(float), hipMemcpyHostToDevice, s), "self-check pattern");
+            DCOPY(hipMemcpyAsync(D.send.ptr, &mine, sizeof(float), hipMemcpyHostToDevice, s), "self-check scalar");
+            if (dist_xrows(v_.Ap, true, 0, thallo_sum_t{ (const float*)D.send.ptr, 1 }, nullptr, nullptr, 0, (float*)D.send.ptr + 8, nullptr)) return -1;
+            DCOPY(hipMemcpyAsync(back.data(), v_.Ap, nloc * sizeof(float), hipMemcpyDeviceToHost, s), "self-check read-back");
+            DCOPY(hipMemcpyAsync(&got_sum, (float*)D.send.ptr + 8, sizeof(float), hipMemcpyDeviceToHost, s), "self-check read-back");
+            DCOPY(hipStreamSynchronize(s), "synchronise");
+            if (D.failed) { pass = false; continue; }
+            float want_sum = 0.0f;
+            for (int r = 0; r < D.cfg.world; ++r) want_sum += (float)(r + 1 + t);
+            if (got_sum != want_sum) pass = false;
+            for (long y = 0; y < D.Hl && pass; ++y)
+                for (long c = 0; c < rl; ++c) if (back[y * rl + c] != value((long)D.cfg.global_row0 + y, c, t)) { pass = false; break; }
+        }
+        err = !D.failed ? thallo_hip_dist_error(D.d, 1, s) : -1;
+        unsigned pm[5] = { 0, 0, 0, 0, 0 };
+        hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
+        hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &zero, sizeof(unsigned), hipMemcpyHostToDevice, s);
+        hipMemsetAsync(v_.Ap, 0, nloc * sizeof(float), s);
+        hipStreamSynchronize(s);
+        pass = pass && !D.failed && err == 0;
+        bool all = false;
+        if (dist_agree(pass, all)) return -1;
+        D.p2p_on = all; D.xrows_now = all;
+        char buf[512];
+        snprintf(buf, sizeof(buf), "{\"exchange\": \"%s\", \"form\": \"single-image, %d ghost rows\", \"rank\": %d, \"world\": %d, \"memory\": [\"plan\", \"%s\"], \"self_check\": {\"exchanges\": 3, \"timeout\": %d, "
+                 "\"pass\": %s, \"all_ranks_pass\": %s, \"post_mortem\": [%u, %u, %u, %u, %u]}}",
+                 all ? "p2p-rows" : "allgather", D.ghost, D.cfg.rank, D.cfg.world, D.mem_kind[1] == 1 ? "fine-grained" : "coarse-grained", err, pass ? "true" : "false", all ? "true" : "false",
+                 pm[0], pm[1], pm[2], pm[3], pm[4]);
+        D.info = buf;
+        return 0;
+    }
     const int Lc = std::max(1, std::min(6, sp.lIterations)), B = 2, nw = 2 * Lc + 1;
     if (ensure_slots(std::max(Lc, sp.lIterations))) dist_fail("out of device memory for the reduction slots");
     const auto& imgs = plugin->unknown_images();
@@ -743,9 +884,11 @@ int Plan::dist_control(int what, int value)
     if (what == 2) { D.inject = value; return 0; }
     if (what == 1) {
         if (value == 0 && D.p2p_on) {
-            D.p2p_on = false;
-            const size_t at = D.info.find("\"p2p-mailbox\"");
+            D.p2p_on = false; D.xrows_now = false;
+            size_t at = D.info.find("\"p2p-mailbox\"");
             if (at != std::string::npos) D.info.replace(at, 13, "\"allgather\", \"switched_off\": true");
+            at = D.info.find("\"p2p-rows\"");
+            if (at != std::string::npos) D.info.replace(at, 10, "\"allgather\", \"switched_off\": true");
         }
         return 0;
     }

@@ -1,8 +1,10 @@
 """Row slabs of shape_from_shading across GPUs, one process per GPU (image-stencil row; BASELINE config 4), behind
 Thallo_ProblemStep like image_warping's (csrc/solver_dist.cpp, flat form): TWO ghost rows per interior side -- the chain
 B_I(c) -> shading row(q) -> J^T gather(i) has radius 2 -- pixel coordinates and the image-border guard are global (global_row0 /
-global_rows of ThalloX_Distributed), Gauss-Newton in the single-reduction form (one all-gather per PCG iteration: alphaD, N, S1, S2 + the
-boundary rows of Ap) or, with lm=True, the Levenberg-Marquardt branch (two per iteration: alphaD; betaN, q + the ghost rows of z).
+global_rows of ThalloX_Distributed), Gauss-Newton in the single-reduction form (one exchange per PCG iteration: alphaD, N, S1, S2 + the
+boundary rows of Ap) or, with lm=True, the Levenberg-Marquardt branch (alphaD; q; betaN + the ghost rows of z).  The exchange is ONE launch on the
+device (thallo_hip_dist_xrows: rows into the neighbours' inboxes over xGMI, scalar granules to every rank; chosen after a self-check at Init,
+distributed_info() says which) or, device_exchange=False, pack + all-gather + unpack.
 This module is set-up only: the row split, the local buffers, the all-gather callback.
 """
 import numpy as np
@@ -13,7 +15,7 @@ from .distributed import SlabLayout, library_rccl, torch_allgather
 
 
 class PlanSfsSlabSolver:
-    def __init__(self, params_global, W, H, rank, world, l_iters, lm=False, group=None, force_rccl=False):
+    def __init__(self, params_global, W, H, rank, world, l_iters, lm=False, group=None, force_rccl=False, device_exchange=True):
         self.lay = lay = SlabLayout(H, rank, world, ghost=2)
         self.W, self.H, self.rank, self.world = W, H, rank, world
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -26,7 +28,7 @@ class PlanSfsSlabSolver:
         self.solver.set_solver_parameters(nIterations=1 << 30, lIterations=l_iters)
         self.library_rccl = library_rccl(self.solver, rank, world, group, force=force_rccl)
         ag = torch_allgather(group, dev) if world > 1 and not self.library_rccl else None
-        self.solver.set_distributed(rank, world, lay.row0, lay.row1, allgather=ag, device_exchange=False,
+        self.solver.set_distributed(rank, world, lay.row0, lay.row1, allgather=ag, device_exchange=device_exchange,
                                     global_row0=lay.g0 - lay.top, global_rows=H)
         self.params = self.solver.make_params([float(v) for v in local[:16]] + self.images)
 

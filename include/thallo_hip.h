@@ -512,6 +512,17 @@ int thallo_hip_pcg_update(float* r, const float* Ap, const float* pre, const flo
 int thallo_hip_pcg_scalars_finish(const float* alphaD_partials, const double* s3_partials, int count, thallo_sum_t alphaN,
                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* the applyJTJ entry points of E2 / E3 / E4 (argument meaning as in the plain forms below) that also return the three sums */
+/* Round 3: applyJTJ with the per-edge G block RECOMPUTED from the source vertex's sines / cosines (SC: [sin a, sin b, sin g] per vertex, then the cosines; written by
+ * thallo_hip_arap_precompute2) and dv = Original differences, instead of 2 x 36 streamed bytes per edge; ELL layout with at most 8 edge slots per vertex
+ * (thallo_hip_arap_recompute_supported).  s3_out == NULL: alphaD partials only; else the three sums of the single-reduction form and, with fin.tickets, the scalars.
+ * Same terms in the same order as thallo_hip_arap_apply_jtj(_sums_fin) (thallo.t:3536-3569's sums, gathered per vertex). */
+int thallo_hip_arap_precompute2(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
+                                const float* original, float w_reg, float* F, float* G, float* SC, long ell_stride, thallo_stream_t stream);
+int thallo_hip_arap_recompute_supported(int N, long ell_stride);
+int thallo_hip_arap_apply_jtj_rc(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
+                                 const float* constraints, const float* original, const float* SC, float w_fit, float w_reg,
+                                 const float* p, float* Ap, float* alphaD_out, long ell_stride, const float* r, const float* pre, double* s3_out,
+                                 thallo_fin_t fin, thallo_stream_t stream);
 int thallo_hip_arap_apply_jtj_sums(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_edge, const int* in_src,
                                    const float* constraints, const float* G, float w_fit, float w_reg,
                                    const float* p, float* Ap, float* alphaD_out, long ell_stride, const float* r, const float* pre, double* s3_out, thallo_stream_t stream);

@@ -750,6 +750,30 @@ def test_arap_cost_trajectory(torch, orc, nu, nv, nit, lit):
     assert rel_err(to_host(dev[2]), po[2]) < VEC_RTOL and np.abs(to_host(dev[3]) - po[3]).max() < VEC_RTOL * max(1.0, np.abs(po[3]).max())
 
 
+def test_arap_recomputed_edge_blocks_match_the_stored_ones(torch, orc):
+    """applyJTJ read the per-edge 3x3 block G_e twice (36 B/edge each time) although it is a function of the source vertex's three angles and two
+    Original positions.  The default kernel now rebuilds it (k_arap_apply_rc: per-vertex sines / cosines from the precompute, ~70 flops per edge); the stored-G kernels stay
+    as its A/B (thallo_hip_arap_debug_set(1, 0)).  Same formulas: both follow the oracle alike, and each other to rounding."""
+    L = api.lib()
+    L.thallo_hip_arap_debug_set.argtypes = [C.c_int, C.c_int]; L.thallo_hip_arap_debug_set.restype = None
+    p = syn.arap_mesh(40, 30, n_handles=8, angle_amp=0.3)
+    N, E = p[2].shape[0], p[6].shape[0]
+    sp = dict(nIterations=4, lIterations=30)
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, E), copy_params(p)).solve(**sp)
+    runs = {}
+    try:
+        for rc in (1, 0):
+            L.thallo_hip_arap_debug_set(1, rc)
+            s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (N, E), p, **sp)
+            runs[rc] = (np.array(costs), to_host(dev[2]), to_host(dev[3]))
+    finally:
+        L.thallo_hip_arap_debug_set(1, 1)
+    for rc in (1, 0):
+        assert rel_err(runs[rc][0], co) < COST_RTOL, (rc, runs[rc][0], co)
+    assert (np.abs(runs[1][0] - runs[0][0]) <= 2e-6 * np.abs(runs[0][0]) + 1e-9).all(), (runs[1][0], runs[0][0])
+    assert np.abs(runs[1][1] - runs[0][1]).max() <= 1e-4 * max(1.0, np.abs(runs[0][1]).max())
+
+
 def test_arap_100k_vertices(torch, orc):
     """BASELINE config 3 size: 320x320 torus = 102,400 vertices / 614,400 directed edges."""
     p = syn.arap_mesh(320, 320)

@@ -182,11 +182,16 @@ __global__ __launch_bounds__(BLOCK) void k_arap_cost(int N, int n0, int n1, cons
 // per GN iteration: F_e (3) and G_e (9, column-major: [dR/da dv | dR/db dv | dR/dg dv]) per edge, out-CSR order
 __global__ __launch_bounds__(BLOCK) void k_arap_precompute(int N, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
                                                             const float* __restrict__ P, const float* __restrict__ Ang, const float* __restrict__ O,
-                                                            float wr, float* __restrict__ F, float* __restrict__ G, ELay L)
+                                                            float wr, float* __restrict__ F, float* __restrict__ G, float* __restrict__ SC, ELay L)
 {
     for (int n = blockIdx.x * BLOCK + threadIdx.x; n < N; n += gridDim.x * BLOCK) {
         const f3 p = ld3(P, n), o = ld3(O, n);
-        Rot rt; rot3(ld3(Ang, n), rt);
+        const f3 ang = ld3(Ang, n);
+        Rot rt; rot3(ang, rt);
+        if (SC) {                                  // sines | cosines of the vertex's three angles: what k_arap_apply_rc rebuilds dR/da, dR/db, dR/dg from
+            f3 sn, cs; sincosf(ang.x, &sn.x, &cs.x); sincosf(ang.y, &sn.y, &cs.y); sincosf(ang.z, &sn.z, &cs.z);
+            st3(SC, n, sn); st3(SC, (long)N + n, cs);
+        }
         const int ob = out_ptr[n], deg = out_ptr[n + 1] - ob;
         for (int j = 0; j < deg; ++j) {
             const long k = epos(L, ob, n, j);
@@ -379,7 +384,103 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply_ell(int N, int n0, int n1,
     else block_store_partial(acc, aD_out, red);
 }
 
+// J^T J p with G_e RECOMPUTED instead of read (round 3; VERDICT r2 item 6: the per-edge G plane is 36 B/edge, read once for a vertex's own edges and once more,
+// gathered, for its incoming ones -- 43 MB of the kernel's 64 MB per launch at 102,400 vertices -- while 13.5 MB are algorithmic).  G_e = [dR/da dv | dR/db dv | dR/dg dv]
+// depends on the SOURCE vertex's angles and dv = O_src - O_dst only: per vertex the precompute stores the six sines / cosines (SC, 2.4 MB, L2-resident like p and O),
+// and an edge costs a 12-byte gather of O (incoming: + 24 bytes of SC) and ~70 flops instead of 36 streamed bytes.  ELL layout, at most MD edge slots, same gather
+// structure as k_arap_apply_ell (two dependent round trips per vertex); in_edge is not needed.  Same formulas as rot3 / k_arap_precompute.
+struct DRot { float a1, a2, a4, a5, a7, a8, b0, b1, b2, b3, b4, b5, b6, b7, b8, g0, g1, g2, g3, g4, g5; };      // the nonzero entries of dR/da, dR/db, dR/dg (row-major)
+__device__ __forceinline__ DRot drot(f3 s, f3 c)
+{   // s = (sin a, sin b, sin g), c = cosines; lib.t:123-137 differentiated, as in rot3
+    const float sa = s.x, sb = s.y, sg = s.z, ca = c.x, cb = c.y, cg = c.z;
+    DRot o;
+    o.a1 = sg * sa + cg * sb * ca;   o.a2 = sg * ca - cg * sb * sa;
+    o.a4 = -cg * sa + sg * sb * ca;  o.a5 = -cg * ca - sg * sb * sa;
+    o.a7 = cb * ca;                  o.a8 = -cb * sa;
+    o.b0 = -cg * sb; o.b1 = cg * cb * sa;  o.b2 = cg * cb * ca;
+    o.b3 = -sg * sb; o.b4 = sg * cb * sa;  o.b5 = sg * cb * ca;
+    o.b6 = -cb;      o.b7 = -sb * sa;      o.b8 = -sb * ca;
+    o.g0 = -sg * cb; o.g1 = -cg * ca - sg * sb * sa;  o.g2 = cg * sa - sg * sb * ca;
+    o.g3 = cg * cb;  o.g4 = -sg * ca + cg * sb * sa;  o.g5 = sg * sa + cg * sb * ca;
+    return o;
+}
+__device__ __forceinline__ void gcols(const DRot& d, f3 dv, f3& g0, f3& g1, f3& g2)
+{
+    g0.x = d.a1 * dv.y + d.a2 * dv.z;               g0.y = d.a4 * dv.y + d.a5 * dv.z;               g0.z = d.a7 * dv.y + d.a8 * dv.z;
+    g1.x = d.b0 * dv.x + d.b1 * dv.y + d.b2 * dv.z; g1.y = d.b3 * dv.x + d.b4 * dv.y + d.b5 * dv.z; g1.z = d.b6 * dv.x + d.b7 * dv.y + d.b8 * dv.z;
+    g2.x = d.g0 * dv.x + d.g1 * dv.y + d.g2 * dv.z; g2.y = d.g3 * dv.x + d.g4 * dv.y + d.g5 * dv.z; g2.z = 0.0f;
+}
+template <int MD>
+__global__ __launch_bounds__(BLOCK) void k_arap_apply_rc(int N, int n0, int n1, const int* __restrict__ out_ptr, const int* __restrict__ out_v1,
+                                                          const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                          const float* __restrict__ Cn, const float* __restrict__ O, const float* __restrict__ SC, float wf, float wr,
+                                                          const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ aD_out, ELay L,
+                                                          const float* __restrict__ rs, const float* __restrict__ pre, double* __restrict__ s3_out, FinArgs fin)
+{
+    __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
+    float acc = 0.0f; Sums3 sm;
+    const float wr2 = wr * wr;
+    for (int n = n0 + blockIdx.x * BLOCK + threadIdx.x; n < n1; n += gridDim.x * BLOCK) {
+        const int deg = out_ptr[n + 1] - out_ptr[n], ideg = in_ptr[n + 1] - in_ptr[n];
+        int vo[MD], vi[MD];
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            const long k = (long)j * L.N + n;
+            vo[j] = j < deg ? out_v1[k] : n; vi[j] = j < ideg ? in_src[k] : n;
+        }
+        const f3 pp = ld3(p, n), pa = ld3(p, (long)N + n), on = ld3(O, n);
+        const DRot dn = drot(ld3(SC, n), ld3(SC, (long)N + n));
+        f3 pmo[MD], omo[MD], pmi[MD], ami[MD], omi[MD], smi[MD], cmi[MD];
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            pmo[j] = ld3(p, vo[j]); omo[j] = ld3(O, vo[j]);
+            pmi[j] = ld3(p, vi[j]); ami[j] = ld3(p, (long)N + vi[j]); omi[j] = ld3(O, vi[j]); smi[j] = ld3(SC, vi[j]); cmi[j] = ld3(SC, (long)N + vi[j]);
+        }
+        f3 ap = { 0.f, 0.f, 0.f }, aa = { 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            const f3 pm = pmo[j];
+            f3 dv; dv.x = on.x - omo[j].x; dv.y = on.y - omo[j].y; dv.z = on.z - omo[j].z;
+            f3 g0, g1, g2; gcols(dn, dv, g0, g1, g2);
+            const float jx = (pp.x - pm.x) - (g0.x * pa.x + g1.x * pa.y + g2.x * pa.z);
+            const float jy = (pp.y - pm.y) - (g0.y * pa.x + g1.y * pa.y + g2.y * pa.z);
+            const float jz = (pp.z - pm.z) - (g0.z * pa.x + g1.z * pa.y + g2.z * pa.z);
+            if (j < deg) {
+                ap.x += jx; ap.y += jy; ap.z += jz;
+                aa.x -= g0.x * jx + g0.y * jy + g0.z * jz;
+                aa.y -= g1.x * jx + g1.y * jy + g1.z * jz;
+                aa.z -= g2.x * jx + g2.y * jy + g2.z * jz;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            const f3 pm = pmi[j], am = ami[j];
+            const DRot dm = drot(smi[j], cmi[j]);
+            f3 dv; dv.x = omi[j].x - on.x; dv.y = omi[j].y - on.y; dv.z = omi[j].z - on.z;
+            f3 g0, g1, g2; gcols(dm, dv, g0, g1, g2);
+            if (j < ideg) {
+                ap.x -= (pm.x - pp.x) - (g0.x * am.x + g1.x * am.y + g2.x * am.z);
+                ap.y -= (pm.y - pp.y) - (g0.y * am.x + g1.y * am.y + g2.y * am.z);
+                ap.z -= (pm.z - pp.z) - (g0.z * am.x + g1.z * am.y + g2.z * am.z);
+            }
+        }
+        ap.x *= wr2; ap.y *= wr2; ap.z *= wr2; aa.x *= wr2; aa.y *= wr2; aa.z *= wr2;
+        if (Cn[3 * n] >= -999999.9f) { ap.x += wf * wf * pp.x; ap.y += wf * wf * pp.y; ap.z += wf * wf * pp.z; }
+        st3(Ap, n, ap); st3(Ap, (long)N + n, aa);
+        acc += pp.x * ap.x + pp.y * ap.y + pp.z * ap.z + pa.x * aa.x + pa.y * aa.y + pa.z * aa.z;
+        if (s3_out) {
+            const f3 rp = ld3(rs, n), ra = ld3(rs, (long)N + n), mp = ld3(pre, n), ma = ld3(pre, (long)N + n);
+            sm.add(mp.x, rp.x, ap.x); sm.add(mp.y, rp.y, ap.y); sm.add(mp.z, rp.z, ap.z);
+            sm.add(ma.x, ra.x, aa.x); sm.add(ma.y, ra.y, aa.y); sm.add(ma.z, ra.z, aa.z);
+        }
+    }
+    if (s3_out) block_finish_sums(acc, sm, aD_out, s3_out, fin, red, redd);
+    else block_store_partial(acc, aD_out, red);
+}
+
 int g_arap_unrolled = 1;       // tools / tests: 0 = the loop form for every layout
+int g_arap_recompute = 1;      // tools / tests: 0 = read the stored G planes (round 2's kernels)
 
 // launches the unrolled ELL form when the layout allows it (maxdeg = S / N <= 8), the loop form otherwise
 template <typename... A>
@@ -395,7 +496,7 @@ void launch_arap_apply(int grid, hipStream_t stream, ELay L, A... a)
 
 extern "C" {
 
-void thallo_hip_arap_debug_set(int what, int value) { if (what == 0) g_arap_unrolled = value; }
+void thallo_hip_arap_debug_set(int what, int value) { if (what == 0) g_arap_unrolled = value; if (what == 1) g_arap_recompute = value; }
 
 int thallo_hip_lapgraph_cost(int N, const int* out_ptr, const int* out_v1, const float* X, const float* A, float w_fit,
                              float* cost_out, thallo_stream_t stream)
@@ -429,14 +530,39 @@ int thallo_hip_arap_cost(int N, int n0, int n1, const int* out_ptr, const int* o
     hipLaunchKernelGGL(k_arap_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, position, angle, original, constraints, w_fit, w_reg, cost_out, L);
     int e = check_launch(); return e ? e : grid;
 }
-int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
-                               const float* original, float w_reg, float* F, float* G, long ell_stride, thallo_stream_t stream)
+int thallo_hip_arap_precompute2(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
+                                const float* original, float w_reg, float* F, float* G, float* SC, long ell_stride, thallo_stream_t stream)
 {
     if (ell_stride < 0) return -(int)hipErrorInvalidValue;
     const ELay L = { ell_stride, N };
     const int grid = vgrid(N);
-    hipLaunchKernelGGL(k_arap_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, position, angle, original, w_reg, F, G, L);
+    hipLaunchKernelGGL(k_arap_precompute, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, out_ptr, out_v1, position, angle, original, w_reg, F, G, SC, L);
     return check_launch();
+}
+int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, const float* position, const float* angle,
+                               const float* original, float w_reg, float* F, float* G, long ell_stride, thallo_stream_t stream)
+{
+    return thallo_hip_arap_precompute2(N, out_ptr, out_v1, position, angle, original, w_reg, F, G, nullptr, ell_stride, stream);
+}
+int thallo_hip_arap_recompute_supported(int N, long ell_stride)
+{
+    return g_arap_recompute && N > 0 && ell_stride > 0 && ell_stride % N == 0 && ell_stride / N <= 8 ? 1 : 0;
+}
+int thallo_hip_arap_apply_jtj_rc(int N, int n0, int n1, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
+                                 const float* constraints, const float* original, const float* SC, float w_fit, float w_reg,
+                                 const float* p, float* Ap, float* aD_out, long ell_stride, const float* r, const float* pre, double* s3_out,
+                                 thallo_fin_t fin, thallo_stream_t stream)
+{
+    if (n0 < 0 || n1 > N || n0 >= n1 || !original || !SC || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
+    if (ell_stride <= 0 || ell_stride % N != 0 || ell_stride / N > 8) return -(int)hipErrorNotSupported;
+    if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
+    if (fin.tickets && (!s3_out || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
+    const ELay L = { ell_stride, N };
+    const int grid = vgrid(n1 - n0);
+    const FinArgs f = { fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, grid };
+    if (ell_stride / N <= 6) hipLaunchKernelGGL(k_arap_apply_rc<6>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_src, constraints, original, SC, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
+    else                     hipLaunchKernelGGL(k_arap_apply_rc<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_src, constraints, original, SC, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
+    int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,

@@ -26,7 +26,7 @@ int g_march_cap = 0;       // tests: workgroup budget the grid is sized for (0 =
 int g_march_depth = 2;     // prefetch depth in rows (1, 2 or 3)
 int g_march_nt = 5;        // non-temporal bits as for k_iter: 1 delta, 2 r/Ap loads, 4 r/Ap stores, 8 p loads, 16 p stores, 32 cs/flags
 int g_march_occ = 2;       // workgroups per CU the kernel is compiled for (register budget) and sized for (rows per segment)
-int g_march_dbg = 0;       // 1 = no stencil arithmetic (Ap := p), 2 = no double sums, 3 = 1 + no halo rows / lanes
+int g_march_dbg = 0;       // 1 = no stencil arithmetic (Ap := p), 2 = no double sums, 3 = 1 + no halo rows / lanes, 4 = segments marched bottom-up
 int g_march_map = 0;       // 1 = the 4 waves of a workgroup side by side (x-adjacent strips) instead of stacked segments
 #else
 constexpr int g_march_dbg = 0, g_march_map = 0;
@@ -359,12 +359,15 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
                 take(cur, slot[j]);                          // (the only place that waits for memory: s_waitcnt vmcnt(N) with the other two slots still in flight)
                 if (DMODE != 1) take<DMODE>(curd, dsl[j]);
                 fence_order();                               // the refill stays behind the moves ...
-                issue(slot[j], t + 3 > t_last ? t_last : t + 3);
-                if (DMODE != 1) issue_d(dsl[(j + 2) % 3], t + 2);      // (the slot taken one step ago)
+                // DBG == 4 (sweep build): the segment marched bottom-up -- step t works on row ya + yb - 1 - t, the window roles y-1 / y+1 swap
+                const auto phys = [&](int tt) { return DBG == 4 ? ya + yb - 1 - tt : tt; };
+                issue(slot[j], phys(t + 3 > t_last ? t_last : t + 3));
+                if (DMODE != 1) issue_d(dsl[(j + 2) % 3], phys(t + 2));      // (the slot taken one step ago)
                 fence_order();                               // ... and in front of the arithmetic
                 // (wave-uniform branch, no load inside: the three lead-in rows and the rounding-up rows skip the arithmetic; the window keeps its zeros)
-                if (t >= t_first && t <= t_last) publish(cur, curd, t, true, wn);
+                if (t >= t_first && t <= t_last) publish(cur, curd, phys(t), true, wn);
                 if (DBG == 3) { if (t >= t_first && t <= t_last) stencil(t, wc, wn, wm); }      // (timing only)
+                else if (DBG == 4) { if (t - 1 >= ya && t <= t_last) stencil(phys(t - 1), wn, wc, wm); }
                 else if (t - 1 >= ya && t <= t_last) stencil(t - 1, wm, wc, wn);
             }
         }
@@ -470,6 +473,7 @@ constexpr int MARCH_WG_PER_CU = 1;                                // grid sizing
     X(2, 0, 2, 0) X(2, 1, 2, 0) X(2, 3, 2, 0) X(2, 9, 2, 0) X(2, 11, 2, 0) X(2, 33, 2, 0) X(2, 35, 2, 0) X(2, 41, 2, 0) X(2, 43, 2, 0) \
     X(2, 5, 2, 0) X(2, 17, 2, 0) X(2, 21, 2, 0) X(2, 31, 2, 0) X(2, 63, 2, 0) \
     X(2, 1, 3, 0) X(2, 11, 3, 0) X(2, 43, 3, 0) X(1, 1, 3, 0) X(1, 11, 3, 0) X(1, 43, 3, 0) X(1, 1, 4, 0) X(1, 11, 4, 0) \
+    X(2, 5, 2, 4) X(2, 0, 2, 4) X(2, 1, 2, 4) X(2, 4, 2, 0) X(2, 4, 2, 4) X(2, 16, 2, 0) X(2, 16, 2, 4) \
     X(2, 1, 2, 1) X(2, 1, 2, 2) X(1, 1, 2, 0) X(3, 1, 2, 0) X(2, 5, 2, 1) X(2, 11, 2, 1) X(2, 0, 2, 1) X(2, 1, 2, 3) X(2, 5, 2, 3) X(2, 11, 2, 3) X(2, 0, 2, 3)
 
 template <bool DIST>

@@ -471,7 +471,19 @@ public:
         if (int rc = g.build(N, E, v0, v1, true)) return rc;
         const size_t edges = g.ell_stride ? (size_t)g.ell_stride : (size_t)E;      // ELL layout (thallo_hip.h) when its padding is bounded
         if (F.bytes < sizeof(float) * 3 * edges + 64 && (F.alloc(sizeof(float) * 3 * edges + 64) || G.alloc(sizeof(float) * 9 * edges + 64))) return -1;
+        rc_ = thallo_hip_arap_recompute_supported(N, g.ell_stride) != 0;      // applyJTJ rebuilds G_e from per-vertex sines / cosines instead of reading it (thallo_hip.h)
+        if (rc_ && SC.bytes < sizeof(float) * 6 * (size_t)N + 64 && SC.alloc(sizeof(float) * 6 * (size_t)N + 64)) return -1;
         return 0;
+    }
+    bool rc_ = false;
+    DeviceBuffer SC;
+    int apply_any(LaunchCtx& c, const float* p, float* Ap, float* out, const float* r, const float* pre, double* s3, const thallo_fin_t& fin)
+    {
+        const int* op = (const int*)g.out_ptr.ptr; const int* ov = (const int*)g.out_v1.ptr; const int* ip = (const int*)g.in_ptr.ptr;
+        const int* ie = (const int*)g.in_edge.ptr; const int* is = (const int*)g.in_src.ptr;
+        if (rc_) return thallo_hip_arap_apply_jtj_rc(N, n0_, n1_, op, ov, ip, is, constraints, original, (const float*)SC.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, r, pre, s3, fin, c.stream);
+        if (s3) return thallo_hip_arap_apply_jtj_sums_fin(N, n0_, n1_, op, ov, ip, ie, is, constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, r, pre, s3, fin, c.stream);
+        return thallo_hip_arap_apply_jtj(N, n0_, n1_, op, ov, ip, ie, is, constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
     }
     float* unknown_ptr(int k) override { return k == 0 ? position : angle; }
     int cost(LaunchCtx& c, float* out) override
@@ -482,7 +494,7 @@ public:
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
         { TimedLaunch t(c, "precompute");
-          int rc = thallo_hip_arap_precompute(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, g.ell_stride, c.stream);
+          int rc = thallo_hip_arap_precompute2(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, rc_ ? (float*)SC.ptr : nullptr, g.ell_stride, c.stream);
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_arap_pcg_init(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
@@ -491,22 +503,21 @@ public:
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
-                                         constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
+        const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+        return apply_any(c, p, Ap, out, nullptr, nullptr, nullptr, none);
     }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj_sums_fin(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
-                                                  constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, v.r, v.pre, v.s12, fin, c.stream);
+        return apply_any(c, p, Ap, out, v.r, v.pre, v.s12, fin);
     }
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_arap_apply_jtj(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, (const int*)g.in_src.ptr,
-                                         constraints, (const float*)G.ptr, w_fit, w_reg, v.p[cur ^ 1], v.Ap, out, g.ell_stride, c.stream);
+        const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+        return apply_any(c, v.p[cur ^ 1], v.Ap, out, nullptr, nullptr, nullptr, none);
     }
 };
 

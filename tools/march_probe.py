@@ -88,13 +88,15 @@ res["compare"] = cmp
 print(json.dumps(res, indent=1)); sys.stdout.flush()
 
 
-def timeit(kind, reps=REPS, modes=(4, 2), pingpong=True):
+def timeit(kind, reps=REPS, modes=(4, 2), pingpong=True, hook=None):
     """alternate modes 4 / 2 like the PCG loop does, ping-ponging the buffers (pingpong=False: always a -> b, so no launch reads what the previous one wrote)"""
     bufs = [[it0["r"].clone(), it0["A"].clone(), it0["p"].clone()], [f(), f(), f()]]
     d = delta0.clone()
     fn = L.thallo_hip_iw_pcg_iter if kind == "tile" else L.thallo_hip_iw_pcg_iter_march
 
     def one(k):
+        if hook is not None:
+            hook(k)
         a, b = (bufs[k & 1], bufs[(k & 1) ^ 1]) if pingpong else (bufs[0], bufs[1])
         mode = modes[k % len(modes)]
         tail = (vp(a[0].data_ptr()), vp(b[0].data_ptr()), vp(a[1].data_ptr()), vp(b[1].data_ptr()), vp(a[2].data_ptr()), vp(b[2].data_ptr()), vp(d.data_ptr()), mode,
@@ -178,6 +180,23 @@ if os.environ.get("MB_MODE") == "stamps":        # sweep build: phase time stamp
             out["phase_median_us"] = [round(float(x), 2) for x in np.median(d, 0)]
             print(json.dumps(out))
     sys.exit(0)
+
+if os.environ.get("MB_MODE") == "updown":         # sweep build: every other launch marches its segments bottom-up (reads first what the previous launch wrote last)
+    out = {"W": W, "H": H}
+    for mode, (ri, Ai, pi, di) in {2: (it0["r"], it0["A"], it0["p"], delta0), 4: (it1["r"], it1["A"], it1["p"], delta0), 0: (it0["r"], it0["A"], it0["p"], delta0)}.items():
+        cfg(2, 5, 2, 0); a = run("march", mode, ri, Ai, pi, di)
+        cfg(2, 5, 2, 4); b = run("march", mode, ri, Ai, pi, di)
+        out[f"up_vs_down_mode{mode}"] = {k: int((a[k][:n].view(torch.int32) != b[k][:n].view(torch.int32)).sum().item()) for k in ("r", "A", "p", "d")}
+        out[f"up_vs_down_mode{mode}"]["aD_rel"] = abs(a["aD"] - b["aD"]) / abs(a["aD"])
+    for rep in range(2):
+        for nt in (5, 0, 1, 4, 16):
+            cfg(2, nt, 2, 0)
+            out[f"nt{nt}_down_only_us_{rep}"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+            alt = lambda k: L.thallo_hip_march_debug_set(4, 4 if (k & 1) else 0)
+            out[f"nt{nt}_alternating_us_{rep}"] = [round(timeit("march", hook=alt), 2), round(timeit("march", modes=(2,), hook=alt), 2), round(timeit("march", modes=(4,), hook=alt), 2)]
+            out[f"nt{nt}_alternating_by_pairs_us_{rep}"] = [round(timeit("march", hook=lambda k: L.thallo_hip_march_debug_set(4, 4 if (k & 2) else 0)), 2)]
+            L.thallo_hip_march_debug_set(4, 0)
+    print(json.dumps(out)); sys.exit(0)
 
 if os.environ.get("MB_MODE") == "dbg":            # sweep build: what the halo and the arithmetic cost (dbg 1 = no stencil arithmetic, 2 = no double sums, 3 = aligned strips without halo rows / lanes)
     out = {"W": W, "H": H}

@@ -139,6 +139,8 @@ unsigned long long ThalloX_ProblemFileUnitHash(const char* filename);
  * to cap - 1) or -1 (ThalloX_LastError).  A Plan on a file no hand-written plugin recognises -- or on any file under THALLO_FRONTEND=generate -- compiles
  * that unit with hipRTC and runs it. */
 int ThalloX_FrontendText(const char* filename, int what, char* out, int cap);
+/* ... given the problem's dimensions (the array Thallo_ProblemPlan takes): needed by files that use Sum, which is expanded for those sizes */
+int ThalloX_FrontendTextDims(const char* filename, int what, const unsigned* dims, char* out, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU, one process per GPU (the reference is single-device, API/src/util.t:769-772).

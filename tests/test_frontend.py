@@ -13,11 +13,15 @@ from thallo_amd import api
 ENERGIES = ["laplacian_image", "laplacian_graph", "image_warping", "arap_mesh_deformation", "bundle_adjustment", "shape_from_shading"]
 
 
-def _text(path, what):
+def _text(path, what, dims=None, expect_error=False):
     L = api.lib()
-    L.ThalloX_FrontendText.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]; L.ThalloX_FrontendText.restype = C.c_int
-    buf = C.create_string_buffer(1 << 20)
-    n = L.ThalloX_FrontendText(path.encode(), what, buf, len(buf))
+    L.ThalloX_FrontendTextDims.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int]; L.ThalloX_FrontendTextDims.restype = C.c_int
+    buf = C.create_string_buffer(1 << 21)
+    d = (C.c_uint * len(dims))(*dims) if dims else None
+    n = L.ThalloX_FrontendTextDims(path.encode(), what, d, buf, len(buf))
+    if expect_error:
+        assert n < 0
+        return api.last_error()
     assert n >= 0, api.last_error()
     assert n < len(buf)
     return buf.value.decode()
@@ -170,7 +174,7 @@ REF_EXAMPLES = ["examples/image_warping/image_warping.t", "examples/arap_mesh_de
 @pytest.mark.parametrize("rel", REF_EXAMPLES)
 def test_the_references_own_files_go_through_the_front_end(rel):
     """14 of the reference's 17 example energies and 12 of its test energies, as shipped (read in place, never copied): the front-end executes
-    them and emits their kernels.  (Not yet: Sum, SampledImageArray, index arithmetic between two iteration variables.)"""
+    them and emits their kernels.  (Sum and index arithmetic between two iteration variables: test_sum_is_expanded_at_plan_time.  Not yet: SampledImageArray.)"""
     src = _text(os.path.join(REF, rel), 1)
     assert "cost_0" in src and "jtf_0" in src and "jtj_0" in src
 
@@ -197,3 +201,62 @@ def test_gather_lowering_exists_exactly_where_it_can(tmp_path):
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-munsafe-fp-atomics", "-c", str(out), "-o", str(tmp_path / "o.o")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_sum_is_expanded_at_plan_time(tmp_path):
+    """Sum({k, ...}, e) (lib.t:146 = P:TensorContraction, thallo.t:5887-5922) and index arithmetic between two iteration variables (R(n - k + 2)).  The front-end
+    expands the sum when the problem is planned -- the dimensions are known then -- into one term per value of the summed variables: W(m) becomes the constant
+    accesses W(0) .. W(M-1), R(n - k + 2) becomes R(n + 2), R(n + 1), ...; the residual's domain is what is left (N).  Without dimensions the file is refused with
+    a message that says why.  The unit compiles for gfx950."""
+    f = os.path.join(HERE, "energies", "series_fit.t")
+    d = _text(f, 0, dims=(512, 16))
+    assert "unknown Weights slot 0 channels 1 over M" in d and "array Basis slot 1 channels 1 over N M" in d and "residual fit x1 over N Jp" in d
+    src = _text(f, 1, dims=(512, 16))
+    assert "16 unknown access(es)" in src and "Dual<16>" in src
+    assert "16 unknown access(es)" not in _text(f, 1, dims=(512, 5)) and "5 unknown access(es)" in _text(f, 1, dims=(512, 5))
+    assert "Sum needs the sizes" in _text(f, 1, expect_error=True)
+    c = _text(os.path.join(HERE, "energies", "conv1d.t"), 1, dims=(512, 5))
+    assert "5 unknown access(es)" in c and "residual conv" in c
+    for off in ("i0 + (2)", "i0 + (1)", "i0 + (0)", "i0 + (-1)", "i0 + (-2)"):      # Signal(n - k + 2), k = 0 .. 4
+        assert off in c, off
+    assert "Sum over 262144 terms" in _text(f, 1, dims=(512, 262144), expect_error=True)
+    out = tmp_path / "series_fit.hip"
+    out.write_text(src)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-munsafe-fp-atomics", "-c", str(out), "-o", str(tmp_path / "o.o")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("rel,dims,accesses", [("tests/minimal_fitting/minimal_fitting.t", (512, 16), 16), ("tests/convolution/convolution.t", (512, 5), 5),
+                                               ("examples/face_fitting/face_fitting.t", (1000, 20, 1), 20),
+                                               ("examples/spatially_varying_deconvolution/spatially_varying_deconvolution.t", (64, 64, 5, 4), 25)])
+def test_the_references_sum_files_go_through_the_front_end(rel, dims, accesses):
+    """the reference's files that use Sum, as shipped (read in place): its two tests at the sizes their main.cpp uses, face_fitting (Sum over the blendshape weights,
+    image(n, channel) accesses) and spatially_varying_deconvolution with a 5 x 5 kernel (two iteration variables over ONE dimension -- k_0 = Kd(); k_1 = Kd() -- and a 3-D
+    array indexed through a Sparse map)."""
+    src = _text(os.path.join(REF, rel), 1, dims=dims)
+    assert "cost_0" in src and f"{accesses} unknown access(es)" in src
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
+def test_a_sum_too_wide_for_forward_mode_duals_is_refused():
+    """spatially_varying_deconvolution at its shipped 17 x 17 kernel reads 289 + 2 unknown elements per residual instance: refused with a message (the forward-mode
+    lowering carries one partial per access in registers), not compiled for minutes into a stack overflow"""
+    msg = _text(os.path.join(REF, "examples/spatially_varying_deconvolution/spatially_varying_deconvolution.t"), 1, dims=(64, 64, 17, 4), expect_error=True)
+    assert "unknown elements per instance" in msg and "up to 96" in msg
+
+
+def test_sampled_image_array_generates():
+    """SampledImageArray (lib.t:145, thallo.t:5887-5922): a 3-D Array sampled at (x, y) in layer z, value only (the reference's partials are 0.0 too)"""
+    src = _text(os.path.join(HERE, "energies", "layer_sample.t"), 1)
+    assert "f_sample((const float*)c.in[1] + (long)c.dim[0] * c.dim[1] * 2 * min(max((int)val(" in src and "1 unknown access(es)" in src
+
+
+def test_sampled_image_array_needs_three_dimensions(tmp_path):
+    f = tmp_path / "bad.t"
+    f.write_text('local W, H = Dims("W", "H")\nInputs { U = Unknown(float, {W, H}, 0), A = Array(float, {W, H}, 1) }\nlocal S = SampledImageArray(A)\nResiduals { r = U(W(), H()) }\n')
+    assert "sampled image arrays must be 3D" in _text(str(f), 1, expect_error=True)

@@ -37,8 +37,13 @@ enum class Op {
 // one component of an image index: iteration variable of dimension `dim` plus a constant offset, optionally through a Sparse map
 // (graph domains: X(v0(e)): dim = the edge dimension, sparse = input slot of v0; the offset applies before the map and is 0 there)
 // A Sparse map over a 2-D domain (Sparse({W,H},{W},k): Xn(x, y)) is looked up with TWO iteration variables: dim2 = the second one (-1: a 1-D map).
-struct IndexComp { int dim = -1; int off = 0; int sparse = -1; int dim2 = -1; };
-inline bool operator==(const IndexComp& a, const IndexComp& b) { return a.dim == b.dim && a.off == b.off && a.sparse == b.sparse && a.dim2 == b.dim2; }
+// Round 3 (Sum / tensor contraction, lib.t:146): plain components are affine in up to TWO iteration variables, sign * var(dim) + sign_b * var(dim_b) + off
+// (convolution.t: R(n - k + 2)), and a component with no variable left (dim < 0, sparse < 0) is the constant index `off` -- what a summed variable becomes
+// when Sum is expanded (W(m) -> W(0), W(1), ...).
+struct IndexComp { int dim = -1; int off = 0; int sparse = -1; int dim2 = -1; int sign = 1; int dim_b = -1; int sign_b = 1; };
+inline bool operator==(const IndexComp& a, const IndexComp& b)
+{ return a.dim == b.dim && a.off == b.off && a.sparse == b.sparse && a.dim2 == b.dim2 && a.sign == b.sign && a.dim_b == b.dim_b && a.sign_b == b.sign_b; }
+inline bool plain_index(const IndexComp& a) { return a.dim >= 0 && a.sparse < 0 && a.dim2 < 0 && a.sign == 1 && a.dim_b < 0; }      // var + off: what rounds 1-2 knew
 
 struct Expr;
 typedef std::shared_ptr<const Expr> E;
@@ -75,16 +80,21 @@ struct Residual {
 struct Problem {
     std::string file;
     std::vector<std::string> dims;                 // Dims("W","H"): ids are positions; sizes come from the unsigned[] at Plan time
+    std::vector<int> dim_alias;                    // per id: -1 = a declared dimension; d = a further ITERATION VARIABLE over dimension d (the second, third ... call of
+                                                   // Kd(): thallo.t:467-477 makes a new IndexDomain per call) -- same size, behind the declared ones, not part of the caller's array
+    int canonical(int d) const { return d >= 0 && d < (int)dim_alias.size() && dim_alias[d] >= 0 ? dim_alias[d] : d; }
     std::vector<Input> inputs;                     // in Inputs{} order (= declaration order of the unknown images in the flat vectors)
     bool use_preconditioner = false;
     bool direct_solve = false;                     // <Residuals handle>:set_direct_solve(true) (thallo.t:5634-5636); acted on only under THALLO_ENABLE_DIRECT_SOLVE=1,
                                                    // like the reference's compile-time enable_direct_solve (gauss_newton.t:22)
     std::vector<Residual> residuals;
     int max_slot = -1;
+    const unsigned* plan_dims = nullptr;           // Thallo_ProblemPlan's dimensions while the file runs (NULL: not known; Sum then is an error); read per declared dimension
+    std::vector<long> dim_sizes;                   // ... the sizes of the dimensions declared so far (-1: unknown)
 };
 
 // dsl_lua.cpp: run a .t file.  false + `err` on anything outside the supported subset (never a silent partial result).
-bool run_problem_file(const char* filename, Problem& out, std::string& err);
+bool run_problem_file(const char* filename, Problem& out, std::string& err, const unsigned* dims = nullptr);
 
 // dsl_codegen.cpp
 struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 cost, 1 evalJTF, 2 applyJTJ, 3 applyJ (Jp = J p), 4 applyJt (Ap += J^T Jp), 5 dumpJ (materialize the rows),

@@ -361,7 +361,10 @@ E shift_expr(const E& e, const std::map<int, int>& sh, std::map<const Expr*, E>&
 {
     auto it = memo.find(e.get()); if (it != memo.end()) return it->second;
     auto n = std::make_shared<Expr>(*e);
-    for (auto& ic : n->idx) { auto f = sh.find(ic.dim); if (f != sh.end()) { if (ic.sparse >= 0 && f->second != 0) fail(":get with an offset through a Sparse map is not supported"); ic.off += f->second; } }
+    for (auto& ic : n->idx) {
+        auto f = sh.find(ic.dim); if (f != sh.end()) { if (ic.sparse >= 0 && f->second != 0) fail(":get with an offset through a Sparse map is not supported"); ic.off += ic.sign * f->second; }
+        auto fb = sh.find(ic.dim_b); if (ic.dim_b >= 0 && fb != sh.end()) ic.off += ic.sign_b * fb->second;
+    }
     for (auto& c : n->a) c = shift_expr(c, sh, memo);
     E r = n; memo[e.get()] = r; return r;
 }
@@ -373,7 +376,9 @@ E subst_expr(const E& e, const std::map<int, IndexComp>& to, std::map<const Expr
     auto n = std::make_shared<Expr>(*e);
     for (auto& ic : n->idx) {
         auto f = to.find(ic.dim);
+        if (ic.dim_b >= 0 && to.count(ic.dim_b)) fail(":get through a Sparse map of an expression whose index mixes two iteration variables is not supported");
         if (f == to.end() || ic.sparse >= 0) continue;
+        if (ic.dim_b >= 0 || ic.sign != 1) fail(":get through a Sparse map of an expression whose index mixes two iteration variables is not supported");
         if (ic.off != 0) fail(":get through a Sparse map of an expression that reads a shifted neighbour is not supported");
         ic = f->second;
     }
@@ -383,8 +388,24 @@ E subst_expr(const E& e, const std::map<int, IndexComp>& to, std::map<const Expr
 void collect_dims(const E& e, std::vector<int>& dims, std::map<const Expr*, int>& seen)
 {
     if (seen.count(e.get())) return; seen[e.get()] = 1;
-    for (auto& ic : e->idx) for (int dd : { ic.dim, ic.dim2 }) { if (dd < 0) continue; bool have = false; for (int d : dims) have = have || d == dd; if (!have) dims.push_back(dd); }
+    for (auto& ic : e->idx) for (int dd : { ic.dim, ic.dim2, ic.dim_b }) { if (dd < 0) continue; bool have = false; for (int d : dims) have = have || d == dd; if (!have) dims.push_back(dd); }
     for (auto& c : e->a) collect_dims(c, dims, seen);
+}
+
+// Sum({k, ...}, e) expanded (lib.t:146, thallo.t:5887-5922): the iteration variable over dimension d takes the constant value to[d] -- a component that loses its
+// only variable becomes a constant index
+E subst_const(const E& e, const std::map<int, int>& to, std::map<const Expr*, E>& memo)
+{
+    auto it = memo.find(e.get()); if (it != memo.end()) return it->second;
+    auto n = std::make_shared<Expr>(*e);
+    for (auto& ic : n->idx) {
+        auto fa = to.find(ic.dim), fb = to.find(ic.dim_b), f2 = to.find(ic.dim2);
+        if (ic.sparse >= 0) { if ((ic.dim >= 0 && fa != to.end()) || (ic.dim2 >= 0 && f2 != to.end())) fail("Sum over the index of a Sparse map is not supported"); continue; }
+        if (ic.dim_b >= 0 && fb != to.end()) { ic.off += ic.sign_b * fb->second; ic.dim_b = -1; ic.sign_b = 1; }
+        if (ic.dim >= 0 && fa != to.end()) { ic.off += ic.sign * fa->second; ic.dim = ic.dim_b; ic.sign = ic.dim_b >= 0 ? ic.sign_b : 1; ic.dim_b = -1; ic.sign_b = 1; }
+    }
+    for (auto& c : n->a) c = subst_const(c, to, memo);
+    E r = n; memo[e.get()] = r; return r;
 }
 
 // ================================================================================================ interpreter
@@ -392,6 +413,7 @@ struct Interp {
     Problem& P;
     std::shared_ptr<Env> globals = std::make_shared<Env>();
     int depth = 0;
+    std::map<int, int> dim_calls;                  // how often each dimension was called for an iteration variable
     struct ReturnEx { Values v; };
     struct BreakEx {};
     explicit Interp(Problem& p) : P(p) { install_builtins(); }
@@ -448,6 +470,14 @@ struct Interp {
             if (ic.sparse >= 0 && d != 0) fail("line " + std::to_string(line) + ": offset on an index that went through a Sparse map");
             if (op == "+") ic.off += (int)d; else if (op == "-") ic.off -= (int)d; else fail("line " + std::to_string(line) + ": only + and - are defined on indices");
             SymV s; s.k = SymV::IndexE; s.ic = ic; return Value::make_sym(s);
+        }
+        if (ai && bi && (op == "+" || op == "-")) {   // two iteration variables: x - k + 8 (convolution.t, spatially_varying_deconvolution.t)
+            const IndexComp x = as_index(a, "index arithmetic"), y = as_index(b, "index arithmetic");
+            if (x.sparse >= 0 || y.sparse >= 0 || x.dim_b >= 0 || y.dim_b >= 0 || x.dim < 0 || y.dim < 0) fail("line " + std::to_string(line) + ": index arithmetic takes at most two iteration variables, none through a Sparse map");
+            IndexComp ic = x;
+            const int sg = op == "+" ? 1 : -1;
+            ic.dim_b = y.dim; ic.sign_b = sg * y.sign; ic.off = x.off + sg * y.off;
+            SymV r; r.k = SymV::IndexE; r.ic = ic; return Value::make_sym(r);
         }
         const Op o = op == "+" ? Op::Add : op == "-" ? Op::Sub : op == "*" ? Op::Mul : op == "/" ? Op::Div : op == "^" ? Op::Pow : Op::Const;
         if (o == Op::Const) fail("line " + std::to_string(line) + ": operator " + op + " on these operands");
@@ -599,7 +629,18 @@ struct Interp {
     {
         const std::string ln = "line " + std::to_string(line) + ": ";
         const SymV& s = *f.sym;
-        if (s.k == SymV::Dim) { if (!args.empty()) fail(ln + "a dimension is called without arguments"); SymV r; r.k = SymV::IndexDomain; r.id = s.id; return Value::make_sym(r); }
+        if (s.k == SymV::Dim) {
+            if (!args.empty()) fail(ln + "a dimension is called without arguments");
+            // every call makes a new iteration variable (thallo.t:467-477).  The first one IS the dimension; further ones (k_0 = Kd(); k_1 = Kd()) are alias ids behind it
+            P.dim_alias.resize(P.dims.size(), -1); P.dim_sizes.resize(P.dims.size(), -1);
+            int& calls = dim_calls[s.id];
+            SymV r; r.k = SymV::IndexDomain; r.id = s.id;
+            if (calls++ > 0) {
+                r.id = (int)P.dims.size();
+                P.dims.push_back(P.dims[s.id] + "_" + std::to_string(calls)); P.dim_alias.push_back(s.id); P.dim_sizes.push_back(P.dim_sizes[s.id]);
+            }
+            return Value::make_sym(r);
+        }
         if (s.k == SymV::Vec || s.k == SymV::Scalar) {
             if (args.size() != 1 || args[0].t != Value::Num) fail(ln + "vector component selection takes one number");
             return index_value(f, args[0], line);
@@ -613,24 +654,43 @@ struct Interp {
                 for (size_t k = 0; k < nsrc; ++k) {
                     const IndexComp a = as_index(args[k], in.name.c_str());
                     if (a.sparse >= 0) fail(ln + "nested Sparse maps are not supported");
-                    if (a.dim != in.dims[k]) fail(ln + in.name + " is indexed over dimension " + P.dims[in.dims[k]]);
-                    if (a.off != 0) fail(ln + "offset inside a Sparse map access");
+                    if (P.canonical(a.dim) != in.dims[k]) fail(ln + in.name + " is indexed over dimension " + P.dims[in.dims[k]]);
+                    if (a.off != 0 || a.dim_b >= 0 || a.sign != 1) fail(ln + "offset inside a Sparse map access");
                     if (k == 0) ic.dim = a.dim; else ic.dim2 = a.dim;
                 }
                 ic.sparse = s.id;
                 SymV r; r.k = SymV::IndexE; r.ic = ic; return Value::make_sym(r);
             }
-            if (args.size() != in.dims.size()) fail(ln + in.name + " takes " + std::to_string(in.dims.size()) + " indices");
+            // image(ix, iy) or image(ix, iy, channel) (thallo.t:2000-2040: a trailing number selects the channel)
+            int only_channel = -1;
+            Values iargs = args;
+            if (iargs.size() == in.dims.size() + 1 && iargs.back().t == Value::Num) {
+                only_channel = (int)iargs.back().n; iargs.pop_back();
+                if (only_channel < 0 || only_channel >= in.channels) fail(ln + in.name + ": channel out of range");
+            }
+            if (iargs.size() != in.dims.size()) fail(ln + in.name + " takes " + std::to_string(in.dims.size()) + " indices");
             std::vector<IndexComp> idx;
-            for (size_t d = 0; d < args.size(); ++d) {
-                IndexComp ic = as_index(args[d], in.name.c_str());
-                const int target = ic.sparse >= 0 ? P.inputs[ic.sparse].dims.back() : ic.dim;
+            for (size_t d = 0; d < iargs.size(); ++d) {
+                IndexComp ic;
+                if (iargs[d].t == Value::Num) { if (iargs[d].n != std::floor(iargs[d].n)) fail(ln + "non-integer constant index"); ic.off = (int)iargs[d].n; idx.push_back(ic); continue; }   // ConstantIndexComponent (thallo.t:485)
+                ic = as_index(iargs[d], in.name.c_str());
+                const int target = ic.sparse >= 0 ? P.inputs[ic.sparse].dims.back() : P.canonical(ic.dim);
                 if (target != in.dims[d]) fail(ln + "index " + std::to_string(d) + " of " + in.name + " ranges over dimension " + P.dims[in.dims[d]] + ", got " + P.dims[target]);
                 idx.push_back(ic);
             }
             std::vector<E> out;
-            for (int c = 0; c < in.channels; ++c) { auto e = std::make_shared<Expr>(); e->op = Op::Load; e->input = s.id; e->channel = c; e->idx = idx; out.push_back(e); }
+            for (int c = 0; c < in.channels; ++c) { if (only_channel >= 0 && c != only_channel) continue; auto e = std::make_shared<Expr>(); e->op = Op::Load; e->input = s.id; e->channel = c; e->idx = idx; out.push_back(e); }
             return vec(out);
+        }
+        if (s.k == SymV::Sampled && s.s == "array") {                // A.SampledImageArray:__call(x, y, z, c), thallo.t:5887-5898.  Its partials are 0 in the reference
+            const Input& in = P.inputs[s.id];                        // (op:getpartials returns { 0.0, 0.0 }, thallo.t:5913-5916): value only, like Constant(...)
+            if (args.size() != 3 && args.size() != 4) fail(ln + "a sampled image array takes (x, y, z) or (x, y, z, channel)");
+            const E x = un(Op::Detach, one(args[0], "sampled image array x")), y = un(Op::Detach, one(args[1], "sampled image array y")), z = un(Op::Detach, one(args[2], "sampled image array z"));
+            int c0 = 0, c1 = in.channels;
+            if (args.size() == 4) { if (args[3].t != Value::Num || args[3].n < 0 || args[3].n >= in.channels) fail(ln + "index out of bounds"); c0 = (int)args[3].n; c1 = c0 + 1; }
+            std::vector<E> out;
+            for (int c = c0; c < c1; ++c) { auto e = std::make_shared<Expr>(); e->op = Op::Sample; e->input = s.id; e->channel = c; e->a = { x, y, z }; out.push_back(e); }
+            return out.size() == 1 ? scalar(out[0]) : vec(out);
         }
         if (s.k == SymV::Sampled) {                                  // A.SampledImage:__call(x, y, c), thallo.t:5784-5795
             const Input& in = P.inputs[s.id];
@@ -789,7 +849,7 @@ struct Interp {
     void def(const std::string& name) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = name; globals->vars[name] = f; }
     void install_builtins()
     {
-        for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "SampledImage", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Image", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded",
+        for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "SampledImage", "SampledImageArray", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Image", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded", "Sum",
                                "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
                                "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
             def(n);
@@ -831,9 +891,10 @@ struct Interp {
             need(2); if (a[0].t != Value::Str || a[1].t != Value::Num) fail(ln + "Dim(name, index)");
             const size_t id = (size_t)a[1].n; if (id > 16) fail(ln + "Dim index too large");
             if (P.dims.size() <= id) P.dims.resize(id + 1);
-            P.dims[id] = a[0].s; SymV s; s.k = SymV::Dim; s.id = (int)id; return { Value::make_sym(s) };
+            P.dims[id] = a[0].s; if (P.dim_sizes.size() <= id) P.dim_sizes.resize(id + 1, -1); if (P.dim_alias.size() <= id) P.dim_alias.resize(id + 1, -1); P.dim_sizes[id] = P.plan_dims ? (long)P.plan_dims[id] : -1;
+            SymV s; s.k = SymV::Dim; s.id = (int)id; return { Value::make_sym(s) };
         }
-        if (f == "Dims") { Values out; for (auto& v : a) { if (v.t != Value::Str) fail(ln + "Dims takes names"); SymV s; s.k = SymV::Dim; s.id = (int)P.dims.size(); P.dims.push_back(v.s); out.push_back(Value::make_sym(s)); } return out; }
+        if (f == "Dims") { Values out; for (auto& v : a) { if (v.t != Value::Str) fail(ln + "Dims takes names"); SymV s; s.k = SymV::Dim; s.id = (int)P.dims.size(); P.dims.push_back(v.s); P.dim_alias.push_back(-1); P.dim_sizes.push_back(P.plan_dims ? (long)P.plan_dims[s.id] : -1); out.push_back(Value::make_sym(s)); } return out; }
         if (f == "Unknown" || f == "Array" || f == "Image") {           // Image: the deprecated spelling of Array (lib.t:573-576)
             need(3); Input in; in.kind = f == "Unknown" ? InputKind::Unknown : InputKind::Array;
             in.channels = type_channels(a[0], &in.is_u8, line); in.dims = dim_list(a[1], line);
@@ -875,6 +936,30 @@ struct Interp {
             for (size_t i = 0; i < n; ++i) out.push_back(mk(Op::Select, { c[c.size() == 1 ? 0 : i], x[x.size() == 1 ? 0 : i], y[y.size() == 1 ? 0 : i] }));
             return { vec(out) };
         }
+        if (f == "Sum") {                           // lib.t:146 Sum({k, ...}, e) = P:TensorContraction: e summed over the listed iteration variables
+            need(2);
+            if (a[0].t != Value::Table || a[0].tab->arr.empty()) fail(ln + "Sum({k, ...}, expression)");
+            if (!P.plan_dims) fail(ln + "Sum needs the sizes of the problem's dimensions: it is expanded when the problem is planned (Thallo_ProblemPlan)");
+            std::vector<int> ds; long terms = 1;
+            for (auto& v : a[0].tab->arr) {
+                if (!is_symk(v, SymV::IndexDomain)) fail(ln + "Sum: the first argument lists iteration variables");
+                const int d = v.sym->id;
+                if (d < 0 || d >= (int)P.dim_sizes.size() || P.dim_sizes[d] < 0) fail(ln + "Sum over a dimension without a size");
+                for (int e : ds) if (e == d) fail(ln + "Sum: a dimension listed twice");
+                ds.push_back(d); terms *= P.dim_sizes[d];
+            }
+            if (terms < 1 || terms > 4096) fail(ln + "Sum over " + std::to_string(terms) + " terms (expanded at Plan time: at most 4096)");
+            const std::vector<E> body = comps(a[1], "Sum");
+            std::vector<E> acc(body.size());
+            std::vector<int> at(ds.size(), 0);
+            for (long t = 0; t < terms; ++t) {
+                std::map<int, int> to; for (size_t k = 0; k < ds.size(); ++k) to[ds[k]] = at[k];
+                std::map<const Expr*, E> memo;
+                for (size_t c = 0; c < body.size(); ++c) { const E term = subst_const(body[c], to, memo); acc[c] = t == 0 ? term : bin(Op::Add, acc[c], term); }
+                for (size_t k = 0; k < ds.size(); ++k) { if (++at[k] < P.dim_sizes[ds[k]]) break; at[k] = 0; }      // first listed variable fastest
+            }
+            return { vec(acc) };
+        }
         if (f == "InBounds" || f == "InBoundsExpanded") {
             auto e = std::make_shared<Expr>(); e->op = Op::InBounds;
             size_t n = a.size();
@@ -903,6 +988,15 @@ struct Interp {
                 if (k && in.channels != P.inputs[a[0].sym->id].channels) fail(ln + "the derivative images of a sampled image have its channel count");
                 (k == 0 ? r.id : k == 1 ? r.id_dx : r.id_dy) = a[k].sym->id;
             }
+            return { Value::make_sym(r) };
+        }
+        if (f == "SampledImageArray") {                             // lib.t:145 = ad.sampledimagearray(image), thallo.t:5887-5922: a 3-D Array sampled at (x, y) in layer z
+            need(1);
+            if (!is_symk(a[0], SymV::Image)) fail(ln + "SampledImageArray(image)");
+            const Input& in = P.inputs[a[0].sym->id];
+            if (in.kind != InputKind::Array || in.is_u8) fail(ln + "sampled image arrays are float Arrays");
+            if (in.dims.size() != 3) fail(ln + "sampled image arrays must be 3D");
+            SymV r; r.k = SymV::Sampled; r.id = a[0].sym->id; r.s = "array";
             return { Value::make_sym(r) };
         }
         if (f == "Constant") { need(1); return { map1(Op::Detach, a[0], "Constant") }; }                     // lib.t:194 (ad.constant)
@@ -1030,12 +1124,13 @@ struct Interp {
 
 }  // namespace
 
-bool run_problem_file(const char* filename, Problem& out, std::string& err)
+bool run_problem_file(const char* filename, Problem& out, std::string& err, const unsigned* dims)
 {
     std::ifstream f(filename, std::ios::binary);
     if (!f) { err = std::string("cannot open ") + filename; return false; }
     std::stringstream ss; ss << f.rdbuf();
     out = Problem(); out.file = filename;
+    out.plan_dims = dims;
     try {
         Parser ps(lex(ss.str()));
         NP chunk = ps.block();
@@ -1049,6 +1144,8 @@ bool run_problem_file(const char* filename, Problem& out, std::string& err)
         int n_unknown = 0;
         for (auto& in2 : out.inputs) { if (in2.name.empty()) fail("an Unknown / Array / Sparse / Param was created outside Inputs{}"); if (in2.kind == InputKind::Unknown) ++n_unknown; }
         if (!n_unknown) fail("the file declares no Unknown");
+        out.plan_dims = nullptr;
+        out.dim_alias.resize(out.dims.size(), -1);
     } catch (std::exception& e) { err = std::string(filename) + ": " + e.what(); return false; }
     return true;
 }

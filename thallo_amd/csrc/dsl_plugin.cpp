@@ -73,7 +73,7 @@ public:
     GeneratedPlugin(const dsl::Problem& p, const unsigned* dims, bool autoschedule) : P(p)
     {
         label = "generated:" + P.file.substr(P.file.find_last_of('/') == std::string::npos ? 0 : P.file.find_last_of('/') + 1);
-        for (size_t d = 0; d < P.dims.size(); ++d) dimv.push_back((long)dims[d]);
+        for (size_t d = 0; d < P.dims.size(); ++d) dimv.push_back((long)dims[P.canonical((int)d)]);      // (alias ids: further iteration variables over a declared dimension)
         uoff.assign(P.inputs.size(), -1);
         for (size_t i = 0; i < P.inputs.size(); ++i) {
             const dsl::Input& in = P.inputs[i];
@@ -337,7 +337,7 @@ public:
 EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, bool autoschedule)
 {
     dsl::Problem p; std::string err;
-    if (!dsl::run_problem_file(filename, p, err)) { set_error("%s", err.c_str()); return nullptr; }
+    if (!dsl::run_problem_file(filename, p, err, dims)) { set_error("%s", err.c_str()); return nullptr; }
     GeneratedPlugin* g = new GeneratedPlugin(p, dims, autoschedule);
     if (!g->ok()) { delete g; return nullptr; }
     return g;
@@ -347,11 +347,14 @@ EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, 
 
 // The front-end without a device (tests, tooling): what = 0 the declarations as text (dsl::describe), 1 the generated HIP translation unit.
 // Returns the length of the text (which is truncated to cap - 1), or -1 with ThalloX_LastError() set.
-extern "C" int ThalloX_FrontendText(const char* filename, int what, char* out, int cap)
+extern "C" int ThalloX_FrontendTextDims(const char* filename, int what, const unsigned* dims, char* out, int cap);
+extern "C" int ThalloX_FrontendText(const char* filename, int what, char* out, int cap) { return ThalloX_FrontendTextDims(filename, what, nullptr, out, cap); }
+// ... with the problem's dimensions (as Thallo_ProblemPlan gets them: one entry per declared dimension): files that use Sum are expanded for those sizes
+extern "C" int ThalloX_FrontendTextDims(const char* filename, int what, const unsigned* dims, char* out, int cap)
 {
     if (!filename || !out || cap < 1) return -1;
     thallo::dsl::Problem p; std::string err, text;
-    if (!thallo::dsl::run_problem_file(filename, p, err)) { thallo::set_error("%s", err.c_str()); return -1; }
+    if (!thallo::dsl::run_problem_file(filename, p, err, dims)) { thallo::set_error("%s", err.c_str()); return -1; }
     if (what == 0) text = thallo::dsl::describe(p);
     else {
         thallo::dsl::Generated g;

@@ -614,7 +614,12 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
     }
     IW_STAMP(2);
 
-    float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#ifdef THALLO_AD_DOUBLE
+    double acc = 0.0;
+#else
+    float acc = 0.0f;
+#endif
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     while (t.valid()) {
         const int x0 = (t.cur % g.tx) * TW, y0 = g.row0 + (t.cur / g.tx) * TH;
         const int gx = x0 + tx;
@@ -726,7 +731,11 @@ __device__ __forceinline__ void iter_body(TileI& T, float* red, double* redd, co
                         st_sys(dd->peer_r[1] + dd->peer_off_a[1] + gx, av);
                     }
                 }
+#ifdef THALLO_AD_DOUBLE
+                acc += (double)pxi * (double)ax + (double)pyi * (double)ay + (double)pai * (double)av;
+#else
                 acc += pxi * ax + pyi * ay + pai * av;
+#endif
                 // exact products of the float data, accumulated in double: N = sum r.M^-1.r, S1 = sum r.M^-1.Ap, S2 = sum Ap.M^-1.Ap
                 const double dmo = mo, dmy = my, dma = ma, drx = T.rx[i], dry = T.ry[i], dra = T.ra[i], dax = ax, day = ay, daa = av;
                 s0 += dmo * (drx * drx) + dmy * (dry * dry) + dma * (dra * dra);

@@ -76,7 +76,11 @@ __device__ __forceinline__ void iteration_scalars(thallo_sum_t aNp, thallo_sum_t
 // double sums, one set per workgroup; with fin_tickets the launch's last workgroup also finishes alphaD_k / betaN_k (single GPU) or
 // IS the cross-rank exchange (DIST).  red >= 16 floats, redd >= 48 doubles of LDS.
 template <int NT, bool DIST>
+#ifdef THALLO_AD_DOUBLE
+__device__ __forceinline__ void iter_tail(double acc_d, double s0, double s1, double s2, float* red, double* redd,
+#else
 __device__ __forceinline__ void iter_tail(float acc, double s0, double s1, double s2, float* red, double* redd,
+#endif
                                           float* __restrict__ aD_out, double* __restrict__ s12_out, thallo_sum_t bNp, const thallo_dist_t* dd,
                                           unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot)
 {
@@ -85,7 +89,18 @@ __device__ __forceinline__ void iter_tail(float acc, double s0, double s1, doubl
     if (DIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // float alphaD partial + the two double sums, one set per workgroup
     const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
+#ifdef THALLO_AD_DOUBLE
+    // (experiment, VERDICT r2 "what's weak" 3: alphaD accumulated in double per workgroup like N, S1, S2; the workgroup's total is rounded to float once)
+    const double wad = wave_sum_all_d(acc_d);
+    if (lane == 0) redd[32 + wave] = wad;
+    lds_barrier();
+    double tot = 0.0; for (int w = 0; w < NT / THALLO_WAVE; ++w) tot += redd[32 + w];
+    const float acc = wave == 0 ? (float)tot : 0.0f;             // the workgroup's alphaD, carried by wave 0 only (all its lanes: wave_sum_all below divides by 64 -> use lane 0)
+    const float wa = wave == 0 ? (float)tot : 0.0f; (void)acc;
+    const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
+#else
     const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
+#endif
     if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
     lds_barrier();
     if (threadIdx.x == 0) {

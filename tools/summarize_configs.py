@@ -28,7 +28,9 @@ KEYS = [("k_march<true, false, false, false, 2, false, true>", "shape_from_shadi
         ("k_fused<0>", "shape_from_shading PCGInit1 J^T F (fused, 2048^2)", None),
         ("k_cam2", "bundle_adjustment J^T(Jp) camera kernel (ladybug-1723 shape)", 116 * O_BA),
         ("k_pt2", "bundle_adjustment J^T(Jp) point kernel (ladybug-1723 shape)", 32 * O_BA),
-        ("k_arap_apply", "ARAP applyJTJ + sums + in-kernel finish (102,400 vertices, 614,400 directed edges)", None),
+        ("k_arap_apply_rc", "ARAP applyJTJ, per-edge blocks recomputed, + sums + in-kernel finish (102,400 vertices, 614,400 directed edges; 13.5 MB algorithmic, SURVEY 8d)", 13.5e6),
+        ("k_arap_apply_ell", "ARAP applyJTJ, stored per-edge blocks (round 2's kernel)", 13.5e6),
+        ("k_pcg_resident<3", "image_warping resident PCG loop, 100 iterations per launch (512^2; 99 B/pixel per iteration in the launch-per-iteration formulation)", 100 * 99 * 512 * 512),
         ("k_iter<3, 512", "image_warping one-kernel PCG iteration, LDS-tiled form (512^2)", 99 * 512 * 512),
         ("k_pcg_update", "PCGUpdate (flat)", None)]
 dur = collections.defaultdict(list)

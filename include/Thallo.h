@@ -182,6 +182,14 @@ typedef struct ThalloX_Distributed {
     unsigned int global_rows;        /* whose expressions use pixel coordinates (shape_from_shading) need them; 0 0 = not given */
     ThalloX_AllReduceFn allreduce;   /* bundle adjustment (camera shards) only; NULL otherwise */
 } ThalloX_Distributed;
+/* Graph energies (arap_mesh_deformation) as a REAL vertex partition (round 3; the replicated "vertex range" form stays): the Plan is made for the rank's LOCAL
+ * sub-problem -- its owned vertices first (local ids [0, n_own)), then the GHOSTS: vertices owned elsewhere that an owned vertex shares an edge with; the edges are all
+ * directed edges with an owned end.  Call this before ThalloX_PlanSetDistributed (whose row0 / row1 are then 0 / n_own).  boundary_units: local ids of this rank's owned
+ * vertices that some other rank holds as ghosts, in an order every rank agrees on (ascending global id); ghost_units[g] (local id, >= n_own), filled from position
+ * ghost_src_pos[g] of rank ghost_src_rank[g]'s boundary list.  Host arrays, copied.  Per PCG iteration the ranks exchange [alphaD | N, S1, S2 | A p at the boundary
+ * vertices] in one all-gather; vectors, memory and the vector updates are local-sized (thallo_amd/distributed_graph.py builds the lists from the global edge list). */
+int ThalloX_PlanSetGhostExchange(Thallo_Plan* plan, int n_boundary, const int* boundary_units, int n_ghost, const int* ghost_units, const int* ghost_src_rank,
+                                 const int* ghost_src_pos);
 /* Collective.  0 on success, -1 on error (ThalloX_LastError); every rank gets the same answer. */
 int ThalloX_PlanSetDistributed(Thallo_Plan* plan, const ThalloX_Distributed* cfg);
 /* The collectives INSIDE the library (round 3; no callback, no host-language hop in the PCG loop): rank 0 makes a 128-byte RCCL unique id, the application

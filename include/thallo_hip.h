@@ -627,6 +627,25 @@ typedef struct thallo_xrows_t {
 int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                           int mode, thallo_sum_t local_or_alphaN, const float* alphaD_partials, const double* s3_partials, int count, int poison,
                           float* out0, float* out1, thallo_stream_t stream);
+/* Ghost units of a PARTITIONED graph problem (round 3; SURVEY.md 8e row 2: ARAP with ghost vertices).  A rank's local problem = its owned units (vertices) first, then
+   the ghosts: units owned elsewhere that its owned ones touch.  Per exchange a rank sends, behind the scalars, the values of its BOUNDARY units (owned here, ghost
+   somewhere) -- `per` floats per unit, taken from up to 8 planes of the flat vector (plane k: base[k] + unit * len[k], len[k] floats) -- and fills each of its ghosts from
+   (source rank, position in that rank's boundary list).  thallo_hip_units_pack(_iter): message = [1 (or 7) scalar words as thallo_hip_slab_pack(_iter) writes them |
+   boundary unit 0's floats | unit 1's | ...]; thallo_hip_units_unpack(_iter): the rank-ordered scalar sums exactly as thallo_hip_slab_unpack(_iter), and
+   vec[plane k of ghost g] <- gathered[ghost_src[g] ...] with ghost_src[g] = source rank * stride + header + position * per (element offset, precomputed by the host). */
+typedef struct thallo_units_t {
+    const int*  units;           /* DEVICE: pack: the boundary units (local ids); unpack: the ghost units (local ids) */
+    const long* src;             /* DEVICE, unpack only: element offset of each ghost's floats inside the gathered buffer */
+    int  n;                      /* how many */
+    int  nplanes;                /* <= 8 */
+    long base[8];                /* plane k starts at this element of the flat vector */
+    int  len[8];                 /* floats per unit in plane k */
+} thallo_units_t;
+int thallo_hip_units_pack(const float* vec, thallo_units_t u, thallo_sum_t sum, float* out, thallo_stream_t stream);
+int thallo_hip_units_unpack(float* vec, thallo_units_t u, const float* gathered, long stride, int world, float* sum_out, thallo_stream_t stream);
+int thallo_hip_units_pack_iter(const float* vec, thallo_units_t u, const float* alphaD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream);
+int thallo_hip_units_unpack_iter(float* vec, thallo_units_t u, const float* gathered, long stride, int world, thallo_sum_t alphaN,
+                                 float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* host-side read / clear of the error word (synchronises the stream) */
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream);
 /* image_warping PCGStep2 over a row slab (z-free schedule only: UrShape must be the unit pixel grid on every rank) that also

@@ -215,3 +215,24 @@ def test_sfs_slabs_match_single_domain_oracle(orc, world, W, H):
         assert (np.abs(np.array(costs) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (rank, costs, co)
         assert costs == res[0][1]
         assert np.abs(X - p[16][g0:g1]).max() <= 2e-5
+
+
+def test_ghost_partition_lists_are_consistent():
+    """thallo_amd.distributed_graph.GhostPartition (set-up of the real ARAP vertex partition): every local edge has an owned end, every ghost is found at the stated
+    position of its owner's boundary list, boundary lists are what the owners themselves derive, ragged ranges."""
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed_graph import GhostPartition
+    p = syn.arap_mesh(24, 17, n_handles=8, angle_amp=0.3)
+    N, v0, v1 = p[2].shape[0], p[6], p[7]
+    world = 3
+    parts = [GhostPartition(N, v0, v1, r, world) for r in range(world)]
+    assert sum(pt.n_own for pt in parts) == N and parts[-1].n1 == N
+    edges_seen = np.zeros(len(v0), int)
+    for pt in parts:
+        assert (np.minimum(pt.v0_local, pt.v1_local) < pt.n_own).all()                   # an owned end on every local edge
+        assert np.array_equal(pt.local_global[pt.v0_local], v0[pt.edge_ids]) and np.array_equal(pt.local_global[pt.v1_local], v1[pt.edge_ids])
+        edges_seen[pt.edge_ids[pt.v0_local < pt.n_own]] += 1                             # each directed edge is "owned" (by its source) exactly once
+        for g, r, pos in zip(pt.local_global[pt.n_own:], pt.ghost_src_rank, pt.ghost_src_pos):
+            assert parts[r].local_global[parts[r].boundary_units[pos]] == g and parts[r].n0 <= g < parts[r].n1
+        assert (pt.boundary_units < pt.n_own).all() and len(np.unique(pt.boundary_units)) == len(pt.boundary_units)
+    assert (edges_seen == 1).all()

@@ -321,6 +321,58 @@ def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
         assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
 
 
+def _arap_part_worker(rank, world, port, nu, nv, nit, lit, q):
+    import torch
+    import torch.distributed as dist
+    from thallo_amd import synthetic as syn
+    from thallo_amd.distributed_graph import PlanArapPartitionSolver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
+        solver = PlanArapPartitionSolver(p, rank, world, lit)
+        costs = solver.solve(nit)
+        part = solver.part
+        q.put((rank, costs, part.owned_global, part.local_global, solver.owned(), solver.ghosts(), solver.solver.distributed_info()))
+        solver.solver.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nu,nv,nit,lit", [(2, 40, 30, 3, 40), (3, 24, 17, 3, 20), (1, 12, 8, 2, 10)])
+def test_hip_arap_real_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
+    """VERDICT r2 item 8 / SURVEY 8(e) row 2: a REAL vertex partition -- every rank's Plan is its local sub-mesh (owned + ghost vertices, the edges with an owned end), the
+    vectors are local-sized, and per PCG iteration only A p at the boundary vertices travels (ThalloX_PlanSetGhostExchange).  Against the single-domain oracle; the
+    ghosts' unknowns end equal to their owners' bit for bit without ever being exchanged (same arithmetic on the same bits); ragged ranges (24 x 17 vertices on 3 ranks)."""
+    import torch.multiprocessing as mp
+    from thallo_amd import synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arap_part_worker, args=(r, world, port, nu, nv, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
+    N = p[2].shape[0]
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, p[6].shape[0]), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    pos, ang = np.full((N, 3), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+    for rank, costs, owned_g, local_g, (po, ao), _, info in res:
+        assert "unit partition" in info["form"] and info["world"] == world, info
+        if world > 1:
+            assert len(local_g) < N                                    # the plan really is smaller than the mesh
+        assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]
+        pos[owned_g] = po; ang[owned_g] = ao
+    assert not np.isnan(pos).any()
+    assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max() and np.abs(ang - p[3]).max() <= 2e-4 * max(1.0, np.abs(p[3]).max())
+    for rank, costs, owned_g, local_g, _, (pg, agh), info in res:      # ghosts == their owners' values, bit for bit
+        gh = local_g[len(owned_g):]
+        assert np.array_equal(pg, pos[gh]) and np.array_equal(agh, ang[gh]), rank
+
+
 # ------------------------------------------------------------------ shape_from_shading row slabs (2 ghost rows), behind Thallo_ProblemStep
 def _sfs_worker(rank, world, port, W, H, nit, lit, lm, q, device_exchange=True):
     import torch

@@ -304,6 +304,17 @@ class ThalloSolver:
         if self._L.ThalloX_PlanSetDistributed(self.plan, C.byref(cfg)) != 0:
             raise RuntimeError("ThalloX_PlanSetDistributed failed: " + last_error())
 
+    def set_ghost_exchange(self, boundary_units, ghost_units, ghost_src_rank, ghost_src_pos):
+        """Before set_distributed (include/Thallo.h ThalloX_PlanSetGhostExchange): this plan is a rank's LOCAL sub-problem of a partitioned graph energy -- owned units
+        first, then ghosts; the lists say which owned units travel and where each ghost's values come from (thallo_amd.distributed_graph.GhostPartition builds them)."""
+        import numpy as np
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (boundary_units, ghost_units, ghost_src_rank, ghost_src_pos)]
+        self._L.ThalloX_PlanSetGhostExchange.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._L.ThalloX_PlanSetGhostExchange.restype = C.c_int
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+        if self._L.ThalloX_PlanSetGhostExchange(self.plan, int(arrs[0].size), ptr(arrs[0]), int(arrs[1].size), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3])) != 0:
+            raise RuntimeError("ThalloX_PlanSetGhostExchange failed: " + last_error())
+
     def use_rccl(self, unique_id, rank, world):
         """Collective, before set_distributed: the plan makes its own RCCL communicator from the 128-byte id (rccl_unique_id() on rank 0, handed to every
         rank by the application); set_distributed without callbacks then means ncclAllGather / ncclAllReduce inside the library."""

@@ -584,6 +584,87 @@ __global__ __launch_bounds__(BLOCK) void k_slab_unpack_iter(float* __restrict__ 
     }
 }
 
+// ---- ghost units of a partitioned graph problem (thallo_hip.h thallo_units_t): the row parts of k_slab_pack / _unpack(_iter) with index lists
+__device__ __forceinline__ int units_per(const thallo_units_t& u) { int p = 0; for (int k = 0; k < u.nplanes; ++k) p += u.len[k]; return p; }
+__device__ __forceinline__ void units_gather(const float* __restrict__ vec, const thallo_units_t& u, float* __restrict__ out)
+{   // one thread per (unit, float of the unit)
+    const int per = units_per(u);
+    const long total = (long)u.n * per;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+        const int unit = (int)(i / per); int c = (int)(i - (long)unit * per), k = 0;
+        while (c >= u.len[k]) { c -= u.len[k]; ++k; }
+        out[i] = vec[u.base[k] + (long)u.units[unit] * u.len[k] + c];
+    }
+}
+__device__ __forceinline__ void units_scatter(float* __restrict__ vec, const thallo_units_t& u, const float* __restrict__ gathered)
+{
+    const int per = units_per(u);
+    const long total = (long)u.n * per;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long)gridDim.x * BLOCK) {
+        const int g = (int)(i / per); const int within = (int)(i - (long)g * per); int c = within, k = 0;
+        while (c >= u.len[k]) { c -= u.len[k]; ++k; }
+        vec[u.base[k] + (long)u.units[g] * u.len[k] + c] = gathered[u.src[g] + within];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_units_pack(const float* __restrict__ vec, thallo_units_t u, thallo_sum_t s, float* __restrict__ out)
+{
+    if (blockIdx.x == 0 && s.count > 0) {
+        const float v = sum_partials(s.partials, s.count);
+        if (threadIdx.x == 0) out[0] = v;
+    }
+    units_gather(vec, u, out + 1);
+}
+__global__ __launch_bounds__(BLOCK) void k_units_unpack(float* __restrict__ vec, thallo_units_t u, const float* __restrict__ gathered, long stride, int world, float* __restrict__ sum_out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sum_out) {
+        float v = 0.0f;
+        for (int r = 0; r < world; ++r) v += gathered[(long)r * stride];
+        sum_out[0] = v;
+    }
+    units_scatter(vec, u, gathered);
+}
+__global__ __launch_bounds__(BLOCK) void k_units_pack_iter(const float* __restrict__ vec, thallo_units_t u, const float* __restrict__ aD_part, const double* __restrict__ s3, int nb,
+                                                            float* __restrict__ out)
+{   // header: k_slab_pack_iter's
+    if (blockIdx.x == 0 && threadIdx.x < THALLO_WAVE) {
+        const int lane = threadIdx.x;
+        const float ad = sum_partials(aD_part, nb);
+        double q[3] = { 0.0, 0.0, 0.0 };
+        for (int i = lane; i < nb; i += THALLO_WAVE) { q[0] += s3[3 * i]; q[1] += s3[3 * i + 1]; q[2] += s3[3 * i + 2]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) q[j] = wave_sum_all_f64(q[j]);
+        if (lane == 0) {
+            out[0] = ad;
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(q[j]);
+                out[1 + 2 * j] = __uint_as_float((unsigned)(b >> 32)); out[2 + 2 * j] = __uint_as_float((unsigned)b);
+            }
+        }
+    }
+    units_gather(vec, u, out + 7);
+}
+__global__ __launch_bounds__(BLOCK) void k_units_unpack_iter(float* __restrict__ vec, thallo_units_t u, const float* __restrict__ gathered, long stride, int world, thallo_sum_t aN,
+                                                              float* __restrict__ aD_word, float* __restrict__ bN_word)
+{   // scalars: k_slab_unpack_iter's
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float gad = 0.0f; double gq[3] = { 0.0, 0.0, 0.0 };
+        for (int r = 0; r < world; ++r) {
+            const float* m = gathered + (long)r * stride;
+            gad += m[0];
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long b = ((unsigned long long)__float_as_uint(m[1 + 2 * j]) << 32) | (unsigned long long)__float_as_uint(m[2 + 2 * j]);
+                gq[j] += __longlong_as_double((long long)b);
+            }
+        }
+        const float an = aN.count == 1 ? aN.partials[0] : 0.0f;
+        const float alpha = safe_div<false>(an, gad);
+        double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
+        if (!(bn > 0.0)) bn = 0.0;
+        aD_word[0] = gad; bN_word[0] = (float)bn;
+    }
+    units_scatter(vec, u, gathered);
+}
+
 __global__ void k_finish_sum(thallo_sum_t s, float* __restrict__ out)
 {
     const float v = sum_partials(s.partials, s.count);
@@ -833,6 +914,39 @@ int thallo_hip_range_unpack(float* vec, thallo_segs_t first_rank_pieces, const f
     long len = 0; for (int j = 0; j < first_rank_pieces.n; ++j) len += first_rank_pieces.len[j];
     int grid = (int)((len + BLOCK - 1) / BLOCK); if (grid > 64) grid = 64; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_range_unpack, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, vec, first_rank_pieces, gathered, stride, skip, world);
+    return check_launch();
+}
+
+static bool units_ok(const thallo_units_t& u, bool unpack)
+{
+    if (u.n < 0 || u.nplanes < 1 || u.nplanes > 8 || (u.n > 0 && (!u.units || (unpack && !u.src)))) return false;
+    for (int k = 0; k < u.nplanes; ++k) if (u.len[k] < 1 || u.base[k] < 0) return false;
+    return true;
+}
+static int units_grid(const thallo_units_t& u) { long t = 0; for (int k = 0; k < u.nplanes; ++k) t += u.len[k]; t *= u.n; int g = (int)((t + BLOCK - 1) / BLOCK); return g > 64 ? 64 : g < 1 ? 1 : g; }
+int thallo_hip_units_pack(const float* vec, thallo_units_t u, thallo_sum_t sum, float* out, thallo_stream_t stream)
+{
+    if (!units_ok(u, false) || !out || (u.n > 0 && !vec) || sum.count < 0 || (sum.count > 0 && !sum.partials)) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_units_pack, dim3(units_grid(u)), dim3(BLOCK), 0, (hipStream_t)stream, vec, u, sum, out);
+    return check_launch();
+}
+int thallo_hip_units_unpack(float* vec, thallo_units_t u, const float* gathered, long stride, int world, float* sum_out, thallo_stream_t stream)
+{
+    if (!units_ok(u, true) || !gathered || (u.n > 0 && !vec) || stride < 1 || world < 1) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_units_unpack, dim3(units_grid(u)), dim3(BLOCK), 0, (hipStream_t)stream, vec, u, gathered, stride, world, sum_out);
+    return check_launch();
+}
+int thallo_hip_units_pack_iter(const float* vec, thallo_units_t u, const float* aD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream)
+{
+    if (!units_ok(u, false) || !aD_partials || !s3_partials || count < 1 || count > THALLO_MAX_PARTIALS || !out || (u.n > 0 && !vec)) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_units_pack_iter, dim3(units_grid(u)), dim3(BLOCK), 0, (hipStream_t)stream, vec, u, aD_partials, s3_partials, count, out);
+    return check_launch();
+}
+int thallo_hip_units_unpack_iter(float* vec, thallo_units_t u, const float* gathered, long stride, int world, thallo_sum_t alphaN,
+                                 float* alphaD_word, float* betaN_word, thallo_stream_t stream)
+{
+    if (!units_ok(u, true) || !gathered || stride < 7 || world < 1 || !alphaD_word || !betaN_word || (u.n > 0 && !vec)) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_units_unpack_iter, dim3(units_grid(u)), dim3(BLOCK), 0, (hipStream_t)stream, vec, u, gathered, stride, world, alphaN, alphaD_word, betaN_word);
     return check_launch();
 }
 

@@ -63,6 +63,10 @@ struct DistState {
     // (units = vertices); equal ranges on all ranks.  pieces = rank 0's owned slice of every plane of the flat vector (rank r's: + r * len)
     bool range = false;
     thallo_segs_t pieces_first, pieces_mine;
+    // ... or, partition form (ThalloX_PlanSetGhostExchange): the rank holds its owned units [0, row1) + ghost units; only the boundary units' values travel
+    bool part = false;
+    DeviceBuffer g_boundary, g_ghost, g_src1, g_src7;       // device copies of the index lists; element offsets of the ghosts' sources for the two message kinds
+    thallo_units_t u_send, u_recv1, u_recv7;
     long piece_floats = 0;                               // floats a rank owns in a flat vector
     // shard form (bundle adjustment: camera shards): the unknowns [sh_off, sh_off + sh_len) (the points) are replicated; their J^T F / diag / A p are
     // partial sums over the rank's residuals and are all-reduced; sums over them are taken after that, by every rank for itself
@@ -104,6 +108,7 @@ public:
     bool lm() const { return lm_; }
     // collective over the ranks; before Thallo_ProblemInit.  0 on success (every rank returns the same value)
     int  set_distributed(const ThalloX_Distributed& cfg);
+    int  set_ghost_exchange(int n_boundary, const int* boundary_units, int n_ghost, const int* ghost_units, const int* ghost_src_rank, const int* ghost_src_pos);
     // collective; before set_distributed: the plan's own RCCL communicator -- then a NULL all-gather / all-reduce callback means "ncclAllGather / ncclAllReduce on the plan's stream"
     int  use_rccl(const unsigned char* id128, int rank, int world);
     const char* distributed_info() const { return dist_ ? dist_->info.c_str() : ""; }
@@ -168,6 +173,8 @@ private:
     DistState* dist_ = nullptr;
     RcclComm* rccl_ = nullptr;
     int  set_distributed_impl(const ThalloX_Distributed& cfg);
+    struct GhostSpec { bool given = false; std::vector<int> boundary, ghost, src_rank, src_pos; } ghost_spec_;
+    int  dist_ghosts(float* vec, int sum_slot);
     int  dist_allgather(const void* send, void* recv, long bytes);
     int  dist_agree(bool flag, bool& all);
     void dist_fail(const char* fmt, ...);               // first rank-local failure: report it, switch this rank to "collectives only" (DistState::failed)

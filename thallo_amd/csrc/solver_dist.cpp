@@ -109,6 +109,19 @@ int Plan::set_distributed(const ThalloX_Distributed& cfg)
     return rc;
 }
 
+int Plan::set_ghost_exchange(int n_boundary, const int* boundary_units, int n_ghost, const int* ghost_units, const int* ghost_src_rank, const int* ghost_src_pos)
+{
+    if (dist_) { set_error("distributed: ThalloX_PlanSetGhostExchange comes before ThalloX_PlanSetDistributed"); return -1; }
+    if (plugin->range_units() <= 0) { set_error("distributed: %s has no unit (vertex) partition", plugin->name()); return -1; }
+    if (n_boundary < 0 || n_ghost < 0 || (n_boundary && !boundary_units) || (n_ghost && (!ghost_units || !ghost_src_rank || !ghost_src_pos))) { set_error("distributed: ghost exchange lists"); return -1; }
+    ghost_spec_.given = true;
+    ghost_spec_.boundary.assign(boundary_units, boundary_units + n_boundary);
+    ghost_spec_.ghost.assign(ghost_units, ghost_units + n_ghost);
+    ghost_spec_.src_rank.assign(ghost_src_rank, ghost_src_rank + n_ghost);
+    ghost_spec_.src_pos.assign(ghost_src_pos, ghost_src_pos + n_ghost);
+    return 0;
+}
+
 int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
 {
     if (plugin->shared_block_floats() > 0 && !plugin->supports_row_slabs() && plugin->range_units() == 0) {      // bundle adjustment: camera shards
@@ -139,25 +152,64 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (!plugin->apply_returns_sums()) { set_error("distributed: %s has no range form", plugin->name()); return -1; }
         if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
         if (cfg.world > 1 && !cfg.allgather && !(rccl_ && rccl_->world == cfg.world && rccl_->rank == cfg.rank)) { set_error("distributed: world > 1 needs an all-gather callback (or ThalloX_PlanUseRccl)"); return -1; }
-        if (U % cfg.world || u1 - u0 != U / cfg.world || u0 != (U / cfg.world) * cfg.rank) {
+        const bool part = ghost_spec_.given;
+        if (!part && (U % cfg.world || u1 - u0 != U / cfg.world || u0 != (U / cfg.world) * cfg.rank)) {
             set_error("distributed: rank %d of %d must own units [%ld,%ld) of %ld (equal contiguous ranges), got [%ld,%ld)", cfg.rank, cfg.world, (U / cfg.world) * cfg.rank, (U / cfg.world) * (cfg.rank + 1), U, u0, u1);
             return -1;
+        }
+        if (part) {       // partition form: owned units first, every other local unit is a ghost with a source
+            const GhostSpec& G = ghost_spec_;
+            bool ok = u0 == 0 && u1 >= 1 && u1 <= U && (long)G.ghost.size() == U - u1;
+            std::vector<char> seen((size_t)U, 0);
+            for (int b : G.boundary) ok = ok && b >= 0 && b < u1;
+            for (size_t g = 0; ok && g < G.ghost.size(); ++g) {
+                ok = G.ghost[g] >= u1 && G.ghost[g] < U && !seen[(size_t)G.ghost[g]] && G.src_rank[g] >= 0 && G.src_rank[g] < cfg.world && G.src_rank[g] != cfg.rank && G.src_pos[g] >= 0;
+                if (ok) seen[(size_t)G.ghost[g]] = 1;
+            }
+            if (!ok) { set_error("distributed: the ghost exchange lists do not describe local units [0,%ld) owned + [%ld,%ld) ghosts", u1, u1, U); return -1; }
         }
         if (plugin->set_owned_range(u0, u1)) return -1;
         hipDeviceSynchronize();
         DistState* Dp = new DistState(); DistState& D = *Dp; dist_ = Dp;
-        D.cfg = cfg; D.range = true; D.row0 = (int)u0; D.row1 = (int)u1; D.Hl = (int)U;
+        D.cfg = cfg; D.range = true; D.part = part; D.row0 = (int)u0; D.row1 = (int)u1; D.Hl = (int)U;
         std::vector<std::pair<long, long>> first, mine;
         long off = 0;
+        thallo_units_t un; memset(&un, 0, sizeof(un));
+        long per_unit = 0;
         for (auto& im : plugin->unknown_images()) {
             const long per = im.n_floats / U, len = per * (u1 - u0);
-            if (im.n_floats % U || (len & 3)) { set_error("distributed: an owned slice of %ld floats (must be a multiple of 4)", len); return -1; }
+            if (im.n_floats % U || (!part && (len & 3))) { set_error("distributed: an owned slice of %ld floats (must be a multiple of 4)", len); return -1; }
             first.push_back({ off, len }); mine.push_back({ off + per * u0, len });
+            if (un.nplanes < 8) { un.base[un.nplanes] = off; un.len[un.nplanes] = (int)per; ++un.nplanes; }
+            per_unit += per;
             D.piece_floats += len; off += im.n_floats;
         }
         if (first.size() > 8) { set_error("distributed: more than 8 unknown images"); return -1; }
         D.pieces_first = segs(first); D.pieces_mine = segs(mine);
         D.msg = 1 + D.piece_floats; D.msg_iter = 7 + D.piece_floats;
+        if (part) {
+            // every rank's boundary count (messages are padded to the largest; a ghost's source position must exist on its source rank)
+            const GhostSpec& G = ghost_spec_;
+            int counts[THALLO_DIST_MAX_WORLD]; const int mine_n = (int)G.boundary.size();
+            if (D.send.alloc(64 * sizeof(float)) || D.gath.alloc(64 * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }
+            if (host_allgather(*this, D, &Plan::dist_allgather, &mine_n, counts, sizeof(int))) return -1;
+            long maxb = 1; bool ok = true;
+            for (int r = 0; r < cfg.world; ++r) maxb = std::max(maxb, (long)counts[r]);
+            for (size_t g = 0; g < G.ghost.size(); ++g) ok = ok && G.src_pos[g] < counts[G.src_rank[g]];
+            D.msg = 1 + per_unit * maxb; D.msg_iter = 7 + per_unit * maxb;
+            std::vector<long> s1(G.ghost.size()), s7(G.ghost.size());
+            for (size_t g = 0; g < G.ghost.size(); ++g) { s1[g] = (long)G.src_rank[g] * D.msg + 1 + (long)G.src_pos[g] * per_unit; s7[g] = (long)G.src_rank[g] * D.msg_iter + 7 + (long)G.src_pos[g] * per_unit; }
+            auto up = [&](DeviceBuffer& b, const void* src, size_t bytes) { return b.alloc(bytes + 16) || (bytes && hipMemcpy(b.ptr, src, bytes, hipMemcpyHostToDevice) != hipSuccess); };
+            bool mem = !(up(D.g_boundary, G.boundary.data(), G.boundary.size() * sizeof(int)) || up(D.g_ghost, G.ghost.data(), G.ghost.size() * sizeof(int)) ||
+                         up(D.g_src1, s1.data(), s1.size() * sizeof(long)) || up(D.g_src7, s7.data(), s7.size() * sizeof(long)));
+            D.u_send = un; D.u_send.units = (const int*)D.g_boundary.ptr; D.u_send.n = (int)G.boundary.size();
+            D.u_recv1 = un; D.u_recv1.units = (const int*)D.g_ghost.ptr; D.u_recv1.src = (const long*)D.g_src1.ptr; D.u_recv1.n = (int)G.ghost.size();
+            D.u_recv7 = D.u_recv1; D.u_recv7.src = (const long*)D.g_src7.ptr;
+            bool all = false;
+            if (dist_agree(ok && mem, all)) return -1;
+            if (!all) { set_error(!ok ? "distributed: a ghost's source position lies outside its source rank's boundary list" : mem ? "distributed: another rank's ghost exchange lists are inconsistent (or it ran out of device memory)" : "distributed: out of device memory"); return -1; }
+            D.send.release(); D.gath.release();
+        }
         const size_t words = (size_t)std::max(D.msg_iter, 64L);
         if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }
         const bool mem = ensure_sums_buffer() == 0;
@@ -165,7 +217,9 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (dist_agree(mem, all)) return -1;
         if (!all) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
         char buf[256];
-        snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit ranges, full-length vectors\", \"rank\": %d, \"world\": %d}", cfg.rank, cfg.world);
+        if (part) snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit partition: %ld owned + %ld ghost units, %d boundary units sent\", \"rank\": %d, \"world\": %d}",
+                           u1, U - u1, D.u_send.n, cfg.rank, cfg.world);
+        else snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit ranges, full-length vectors\", \"rank\": %d, \"world\": %d}", cfg.rank, cfg.world);
         D.info = buf;
         return 0;
     }
@@ -644,6 +698,19 @@ int Plan::dist_replicate(float* vec, int sum_slot)
     return 0;
 }
 
+int Plan::dist_ghosts(float* vec, int sum_slot)
+{   // partition form: message = [sum of slot (if any) | vec at my boundary units]; afterwards my ghost units hold their owners' values
+    DistState& D = *dist_;
+    hipStream_t s = ctx.stream;
+    float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
+    const thallo_sum_t nothing = { nullptr, 0 };
+    DLOCAL(thallo_hip_units_pack(vec, D.u_send, sum_slot >= 0 ? partial_sum(sum_slot) : nothing, send, s), "boundary pack");
+    if (dist_allgather(send, gath, D.msg * (long)sizeof(float))) return -1;
+    DLOCAL(thallo_hip_units_unpack(vec, D.u_recv1, gath, D.msg, D.cfg.world, sum_slot >= 0 ? scal(sum_slot) : nullptr, s), "ghost unpack");
+    if (sum_slot >= 0 && !D.failed) fin_[sum_slot] = 1;
+    return 0;
+}
+
 int Plan::dist_gn_range(int L)
 {   // Every rank keeps FULL-length vectors (a 100k-vertex graph is 2.4 MB per vector) and does the energy-independent vector update for ALL
     // unknowns -- redundantly, same inputs, same bits -- so the only thing that has to travel per PCG iteration is what a rank alone can
@@ -662,8 +729,8 @@ int Plan::dist_gn_range(int L)
     if (!D.failed) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); if (nb < 0) dist_fail("PCGInit1 launch failed (%d)", nb); }
     if (!D.failed) set_nb(B, nb);
     {   TimedLaunch t(ctx, "RangeExchangeInit");
-        if (dist_replicate(v_.r, B)) return -1;                          // alphaN_0; r of every unit
-        if (pc && dist_replicate(v_.pre, -1)) return -1;
+        if (D.part ? dist_ghosts(v_.r, B) : dist_replicate(v_.r, B)) return -1;       // alphaN_0; r of every unit (partition form: of the ghost units)
+        if (pc && (D.part ? dist_ghosts(v_.pre, -1) : dist_replicate(v_.pre, -1))) return -1;
     }
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
@@ -678,6 +745,13 @@ int Plan::dist_gn_range(int L)
         }
         cur_ ^= 1;
         TimedLaunch t(ctx, "RangeExchange");
+        if (D.part) {       // [alphaD | N, S1, S2 | A p at my boundary units] -> the ghosts' A p (r, p, delta of a ghost then follow from the same arithmetic as its owner's)
+            DLOCAL(thallo_hip_units_pack_iter(v_.Ap, D.u_send, slot(jD), v_.s12, nb, send, s), "boundary pack");
+            if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
+            DLOCAL(thallo_hip_units_unpack_iter(v_.Ap, D.u_recv7, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s), "ghost unpack");
+            if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+            continue;
+        }
         DLOCAL(thallo_hip_slab_pack_iter(v_.Ap, D.pieces_mine, slot(jD), v_.s12, nb, send, s), "range pack");
         if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
         DLOCAL(thallo_hip_slab_unpack_iter(v_.Ap, none, nullptr, none, nullptr, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s), "rank-ordered sums");

@@ -656,7 +656,9 @@ def test_full_size_properties_2048(torch):
     assert outs[0][0][1] < outs[0][0][0]
 
 
-def test_solver_parameters_and_perf_summary(torch):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_solver_parameters_and_perf_summary(torch, monkeypatch, resident):
+    monkeypatch.setenv("THALLO_RESIDENT", resident)
     p = syn.image_warping(64, 64, n_markers=4)
     s = api.ThalloSolver((64, 64), thallo_amd.energy_file("image_warping"), timing_level=2)
     assert s.get_solver_parameter("nIterations") == 10 and s.get_solver_parameter("lIterations") == 10   # gauss_newton.t:53-54
@@ -669,7 +671,11 @@ def test_solver_parameters_and_perf_summary(torch):
     ks = s.kernel_stats()
     # image_warping runs ONE kernel per PCG iteration (thallo_hip_iw_pcg_iter*; deferred finish: each launch adds up its predecessor's partials,
     # one one-wave PCGScalars launch per GN step finishes the last iteration)
-    assert ks["PCGIteration"]["launches"] == 21 and ks["PCGScalars"]["launches"] == 3 and "PCGStep2" not in ks and ks["PCGInit1"]["launches"] == 3
+    # -- or, round 3, images whose state fits the registers: the WHOLE PCG loop of a GN step in one launch (thallo_hip_iw_pcg_resident)
+    if resident == "1":
+        assert ks["PCGLoopResident"]["launches"] == 3 and "PCGIteration" not in ks and "PCGStep2" not in ks and ks["PCGInit1"]["launches"] == 3, ks
+    else:
+        assert ks["PCGIteration"]["launches"] == 21 and ks["PCGScalars"]["launches"] == 3 and "PCGStep2" not in ks and ks["PCGInit1"]["launches"] == 3, ks
 
 
 def test_linear_iteration_budgets_of_the_reference_examples(torch, orc):
@@ -705,10 +711,10 @@ def test_unknown_energy_and_bad_kind_fail_loudly(torch, tmp_path, monkeypatch):
     monkeypatch.delenv("THALLO_FRONTEND")                    # default: it goes through the front-end (tests/test_gpu_frontend.py) ...
     s = api.ThalloSolver((8,), str(f)); assert s.energy_name == "generated:x.t"; s.close()
     g = tmp_path / "y.t"                                     # ... which rejects what it does not implement, naming the construct
-    g.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0) }\nr = Residuals { only = SampledImageArray(X)(N()) }\n')
+    g.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0) }\nr = Residuals { only = ComputedArray(X)(N()) }\n')
     with pytest.raises(RuntimeError):
         api.ThalloSolver((8,), str(g))
-    assert "SampledImageArray" in api.last_error()
+    assert "ComputedArray" in api.last_error()
     with pytest.raises(RuntimeError):
         api.ThalloSolver((8, 8), thallo_amd.energy_file("image_warping"), solverkind="newton")
     with pytest.raises(RuntimeError):

@@ -914,6 +914,11 @@ int Plan::dist_self_check()
     int err = !D.failed ? thallo_hip_dist_error(D.d, 1, s) : -1;
     unsigned pm[5] = { 0, 0, 0, 0, 0 };
     hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
+    if (resident_used_) {      // the device-side run went through the resident slab kernel: a bounded wait that ran out in THERE is a "no" of this check (and is
+        resident_used_ = false;                                              // cleared here: the cost evaluation that follows must not take it for a failure of the solve)
+        unsigned rpm[5] = { 0, 0, 0, 0, 0 };
+        if (!D.failed && plugin->resident_status(ctx, 1, rpm) != 0) { err = err ? err : 2; for (int i = 0; i < 5; ++i) pm[i] = rpm[i]; }
+    }
     restore(false);
     hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &zero, sizeof(unsigned), hipMemcpyHostToDevice, s);
     hipStreamSynchronize(s);

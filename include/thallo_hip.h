@@ -627,6 +627,11 @@ typedef struct thallo_xrows_t {
 int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                           int mode, thallo_sum_t local_or_alphaN, const float* alphaD_partials, const double* s3_partials, int count, int poison,
                           float* out0, float* out1, thallo_stream_t stream);
+/* ... mode 0 with the LM zeta test on the FIRST sum (q): the wave that holds the global q applies thallo_hip_lm_zeta's rule to lm_state right there (one launch
+   less per LM iteration of a slab) */
+int thallo_hip_dist_xrows_zeta(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                               thallo_sum_t q_local, const float* second_partials, int second_count, int poison, float* q_out, float* second_out,
+                               float* lm_state, int k, float q_tolerance, thallo_stream_t stream);
 /* Ghost units of a PARTITIONED graph problem (round 3; SURVEY.md 8e row 2: ARAP with ghost vertices).  A rank's local problem = its owned units (vertices) first, then
    the ghosts: units owned elsewhere that its owned ones touch.  Per exchange a rank sends, behind the scalars, the values of its BOUNDARY units (owned here, ghost
    somewhere) -- `per` floats per unit, taken from up to 8 planes of the flat vector (plane k: base[k] + unit * len[k], len[k] floats) -- and fills each of its ghosts from

@@ -87,7 +87,7 @@ __device__ __forceinline__ void rows_in(float* __restrict__ vec, const thallo_se
 template <int MODE>
 __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x, float* __restrict__ vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                                                 thallo_sum_t s, const float* __restrict__ aD_part, const double* __restrict__ s3, int nb, int poison,
-                                                float* __restrict__ out0, float* __restrict__ out1)
+                                                float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ zstate, int zk, float ztol)
 {
     __shared__ unsigned last_wg;
     const unsigned tag = ld_agent(d.ctl + DIST_XSEQ) + 1u;
@@ -115,6 +115,13 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
             dist_exchange_words_wave_seq<2>(d, tag, slot0, w, t);
             if (lane == 0 && s.count > 0) out0[0] = t[0];
             if (lane == 0 && nb > 0) out1[0] = t[1];
+            if (lane == 0 && zstate && reinterpret_cast<unsigned*>(zstate)[1] == 0u) {     // k_lm_zeta's rule on the global q (pcg_kernels.hip)
+                const float Q1 = t[0], Q0 = zstate[0];
+                const float zt = (float)(zk + 1) * (Q1 - Q0) / Q1;
+                const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < ztol;
+                if (stop) { reinterpret_cast<unsigned*>(zstate)[1] = 1u; reinterpret_cast<int*>(zstate)[2] = zk + 1; }
+                else zstate[0] = Q1;
+            }
         } else {
             float ad = sum_partials(aD_part, nb);
             double q[3] = { 0.0, 0.0, 0.0 };
@@ -225,9 +232,9 @@ int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, 
     return check_launch();
 }
 
-int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
-                          int mode, thallo_sum_t s, const float* aD_partials, const double* s3_partials, int count, int poison,
-                          float* out0, float* out1, thallo_stream_t stream)
+static int xrows_impl(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                      int mode, thallo_sum_t s, const float* aD_partials, const double* s3_partials, int count, int poison,
+                      float* out0, float* out1, float* zstate, int zk, float ztol, thallo_stream_t stream)
 {
     if (!dist_ok(d) || x.ring0 < 0 || x.inbox_off <= 0 || (x.inbox_off & 7) || x.inbox_half < 0 || (x.inbox_half & 1) || x.above >= d.world || x.below >= d.world ||
         x.above == d.rank || x.below == d.rank || 7 * d.world > 64) return -(int)hipErrorInvalidValue;
@@ -249,9 +256,21 @@ int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_
     else return -(int)hipErrorInvalidValue;
     // rows of up to 32 K floats per direction (a 2048-wide image: 2 ghost rows of 4 channels): ONE workgroup, no ticket; longer ones: 8 workgroups
     const int grid = std::max(tf, tl) <= 32768 ? 1 : 8, block = 256;
-    if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1);
-    else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1);
+    if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, zstate, zk, ztol);
+    else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, (float*)nullptr, 0, 0.0f);
     return check_launch();
+}
+
+int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                          int mode, thallo_sum_t s, const float* aD_partials, const double* s3_partials, int count, int poison,
+                          float* out0, float* out1, thallo_stream_t stream)
+{ return xrows_impl(d, x, vec, first, last, top, bot, mode, s, aD_partials, s3_partials, count, poison, out0, out1, nullptr, 0, 0.0f, stream); }
+int thallo_hip_dist_xrows_zeta(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                               thallo_sum_t q_local, const float* second_partials, int second_count, int poison, float* q_out, float* second_out,
+                               float* lm_state, int k, float q_tolerance, thallo_stream_t stream)
+{
+    if (!lm_state || q_local.count < 1 || !q_out) return -(int)hipErrorInvalidValue;
+    return xrows_impl(d, x, vec, first, last, top, bot, 0, q_local, second_partials, nullptr, second_count, poison, q_out, second_out, lm_state, k, q_tolerance, stream);
 }
 
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream)

@@ -718,7 +718,7 @@ int Plan::step_lm(int ev_iter)
         }
         if (failed) break;
         if (!skip()) { set_nb(jB, nb); set_nb(QS, nbq); }
-        if (slab && dist_two_sums_and_rows(QS, jB, v_.z)) { coll_failed = true; break; }   // q and betaN over all ranks; ghost rows of z
+        if (slab) { bool zd = false; if (dist_two_sums_and_rows(QS, jB, v_.z, lmst, k, &zd)) { coll_failed = true; break; } zeta_done = zeta_done || zd; }   // q and betaN over all ranks; ghost rows of z (device-side transport: + the zeta test)
         k_done = k + 1;
         if (!zeta_done && !skip()) {
             TimedLaunch t(ctx, "PCGZeta");

@@ -181,8 +181,8 @@ private:
     bool dist_skip() const { return dist_ && dist_->failed; }
     int  dist_map_peers();
     int  dist_map_peers_flat();
-    int  dist_two_sums_and_rows(int j1, int j2, float* vec);
-    int  dist_xrows(float* vec, bool rows, int mode, thallo_sum_t s, const float* aD_part, const double* s3, int nb, float* out0, float* out1);
+    int  dist_two_sums_and_rows(int j1, int j2, float* vec, float* zeta_state = nullptr, int zeta_k = 0, bool* zeta_done = nullptr);
+    int  dist_xrows(float* vec, bool rows, int mode, thallo_sum_t s, const float* aD_part, const double* s3, int nb, float* out0, float* out1, float* zeta_state = nullptr, int zeta_k = 0);
     int  dist_self_check();
     int  dist_gn(int L, bool p2p);                      // PCGInit + L iterations + linear update + ghost refresh, no bookkeeping
     int  step_gn_slab(int ev_iter);

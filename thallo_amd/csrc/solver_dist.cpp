@@ -415,14 +415,16 @@ int Plan::dist_map_peers_flat()
     return 0;
 }
 
-int Plan::dist_xrows(float* vec, bool rows, int mode, thallo_sum_t sm, const float* aD_part, const double* s3, int nb, float* out0, float* out1)
+int Plan::dist_xrows(float* vec, bool rows, int mode, thallo_sum_t sm, const float* aD_part, const double* s3, int nb, float* out0, float* out1, float* zeta_state, int zeta_k)
 {   // one device-side exchange of the flat form.  Issued by EVERY rank, failed or not (a failed rank sends poisoned scalars and no rows: nobody waits for it,
     // everybody's sums turn NaN and the failure is agreed on at the next cost evaluation)
     DistState& D = *dist_;
     const thallo_segs_t none = segs({});
     const int poison = D.failed ? 1 : 0;
-    int rc = thallo_hip_dist_xrows(D.d, D.xr, vec, rows ? D.seg_rows_first : none, rows ? D.seg_rows_last : none, rows ? D.seg_rows_top : none, rows ? D.seg_rows_bot : none,
-                                   mode, sm, aD_part, s3, nb, poison, out0, out1, ctx.stream);
+    int rc = zeta_state ? thallo_hip_dist_xrows_zeta(D.d, D.xr, vec, rows ? D.seg_rows_first : none, rows ? D.seg_rows_last : none, rows ? D.seg_rows_top : none, rows ? D.seg_rows_bot : none,
+                                                     sm, aD_part, nb, poison, out0, out1, zeta_state, zeta_k, sp.q_tolerance, ctx.stream)
+                        : thallo_hip_dist_xrows(D.d, D.xr, vec, rows ? D.seg_rows_first : none, rows ? D.seg_rows_last : none, rows ? D.seg_rows_top : none, rows ? D.seg_rows_bot : none,
+                                                mode, sm, aD_part, s3, nb, poison, out0, out1, ctx.stream);
     if (D.inject > 0 && !D.failed && --D.inject == 0) rc = -999;
     if (rc < 0 && !D.failed) dist_fail("device-side row exchange failed (%d)", rc);
     return 0;
@@ -622,12 +624,15 @@ int Plan::dist_sum_and_rows(int j, float* vec)
     return 0;
 }
 
-int Plan::dist_two_sums_and_rows(int j1, int j2, float* vec)
-{   // slots j1 and j2 made global and the ghost rows of `vec` refreshed: ONE launch on the device-side transport (LM: q and betaN + the rows of z), else two exchanges
+int Plan::dist_two_sums_and_rows(int j1, int j2, float* vec, float* zeta_state, int zeta_k, bool* zeta_done)
+{   // slots j1 and j2 made global and the ghost rows of `vec` refreshed: ONE launch on the device-side transport (LM: q and betaN + the rows of z -- and the zeta
+    // test on the global q by the wave that holds it), else two exchanges
     DistState& D = *dist_;
+    if (zeta_done) *zeta_done = false;
     if (!D.xrows_now) return dist_sum_slot(j1) || dist_sum_and_rows(j2, vec) ? -1 : 0;
     const thallo_sum_t dummy = { (const float*)D.send.ptr, 1 };
-    if (dist_xrows(vec, true, 0, D.failed ? dummy : partial_sum(j1), D.failed ? (const float*)D.send.ptr : slot(j2), nullptr, D.failed ? 1 : nb_[j2], scal(j1), scal(j2))) return -1;
+    if (dist_xrows(vec, true, 0, D.failed ? dummy : partial_sum(j1), D.failed ? (const float*)D.send.ptr : slot(j2), nullptr, D.failed ? 1 : nb_[j2], scal(j1), scal(j2), zeta_state, zeta_k)) return -1;
+    if (zeta_done && zeta_state) *zeta_done = true;
     if (!D.failed) { fin_[j1] = 1; fin_[j2] = 1; }
     return 0;
 }

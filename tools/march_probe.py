@@ -198,6 +198,14 @@ if os.environ.get("MB_MODE") == "updown":         # sweep build: every other lau
             L.thallo_hip_march_debug_set(4, 0)
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_MODE") == "dsums":          # sweep build: what the three double sums cost (dbg 2 = the kernel without them; cache policy 1)
+    out = {"W": W, "H": H}
+    for rep in range(3):
+        for dbg in (0, 2):
+            cfg(2, 1, 2, dbg)
+            out[f"nt1_dbg{dbg}_us_{rep}"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "dbg":            # sweep build: what the halo and the arithmetic cost (dbg 1 = no stencil arithmetic, 2 = no double sums, 3 = aligned strips without halo rows / lanes)
     out = {"W": W, "H": H}
     for rep in range(2):

@@ -651,6 +651,26 @@ int thallo_hip_units_unpack(float* vec, thallo_units_t u, const float* gathered,
 int thallo_hip_units_pack_iter(const float* vec, thallo_units_t u, const float* alphaD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream);
 int thallo_hip_units_unpack_iter(float* vec, thallo_units_t u, const float* gathered, long stride, int world, thallo_sum_t alphaN,
                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* The scalars of a PCG iteration in the shard form (bundle adjustment across camera shards) without a collective: every rank's OWN partials (its cameras':
+   alphaD float, {N, S1, S2} double) travel as 7 granules and are added in rank order; the sums of the SHARED block (the points, identical on every rank after the
+   all-reduce, thallo_hip_block_sums) join behind them; then alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 -- thallo_hip_shard_scalars' arithmetic and order.
+   x: only ring0 is used (no rows travel). */
+int thallo_hip_dist_xscalars_shard(thallo_dist_t d, thallo_xrows_t x, thallo_sum_t alphaN, const float* own_alphaD_partials, const double* own_s3_partials, int own_count,
+                                   const float* shared_alphaD_partials, const double* shared_s3_partials, int shared_count, int poison,
+                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* In-place sum over all ranks of `len` floats at `buf`, by peer stores only (round 3; bundle adjustment's point block across camera shards: SURVEY.md 8e row 3, "prefer
+   the direct form" -- replaces ncclAllReduce in the PCG loop).  Reduce-scatter + all-gather in ONE launch: rank r owns chunk r (x.chunk floats); every rank stores its part
+   of chunk c into rank c's inbox, the owner adds the `world` contributions IN RANK ORDER (every run and every rank gets the same bits) and stores the sums into every rank's
+   second inbox, from which they are copied into place.  Two waits on tagged granules (bounded, error word + post-mortem as everywhere), parity double-buffering: a rank can
+   be at most one all-reduce ahead.  Mailbox allocation of every rank: [scalar ring | at inbox_off: A[2][world][chunk], then B[2][world][chunk]].  len % 4 == 0,
+   chunk % 4 == 0, chunk * world >= len; all workgroups of the launch are resident at once (<= 64).  tag = ctl[12] + 1.  poison: this rank failed earlier; it takes part
+   (nobody waits for it) and turns the first element of its chunk into NaN. */
+typedef struct thallo_xreduce_t {
+    long inbox_off;              /* bytes from the start of a rank's mailbox allocation */
+    long chunk;                  /* floats per rank */
+    int  ring0;                  /* first of 8 scalar slots (2 granule kinds x 4 ring positions) */
+} thallo_xreduce_t;
+int thallo_hip_dist_allreduce(thallo_dist_t d, thallo_xreduce_t x, float* buf, long len, int poison, thallo_stream_t stream);
 /* host-side read / clear of the error word (synchronises the stream) */
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream);
 /* image_warping PCGStep2 over a row slab (z-free schedule only: UrShape must be the unit pixel grid on every rank) that also

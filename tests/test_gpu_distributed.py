@@ -237,7 +237,7 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
 
 
 # ------------------------------------------------------------------ camera-sharded bundle adjustment (HIP backend)
-def _ba_worker(rank, world, port, dims, nit, lit, q):
+def _ba_worker(rank, world, port, dims, nit, lit, q, device_exchange=True):
     import torch
     import torch.distributed as dist
     from thallo_amd import synthetic as syn
@@ -248,16 +248,16 @@ def _ba_worker(rank, world, port, dims, nit, lit, q):
     try:
         C_, P_, O_ = dims
         p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
-        solver = PlanBaShardSolver(p, rank, world, lit)
+        solver = PlanBaShardSolver(p, rank, world, lit, device_exchange=device_exchange)
         costs = solver.solve(nit)
         lay = solver.lay
-        q.put((rank, costs, lay.c0, lay.c1, solver.cameras[:lay.C_loc].cpu().numpy(), solver.points.cpu().numpy()))
+        q.put((rank, costs, lay.c0, lay.c1, solver.cameras[:lay.C_loc].cpu().numpy(), solver.points[:lay.P].cpu().numpy(), solver.solver.distributed_info()))
         solver.solver.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims,nit,lit", [(2, (64, 4000, 20000), 3, 30), (3, (13, 80, 400), 3, 10), (1, (12, 60, 300), 3, 20)])
+@pytest.mark.parametrize("world,dims,nit,lit", [(2, (64, 4000, 20000), 3, 30), (3, (13, 81, 400), 3, 10), (1, (12, 60, 300), 3, 20)])      # (81 points: the padded point block)
 def test_hip_ba_camera_shards_match_oracle(orc, world, dims, nit, lit):
     """Camera shards behind Thallo_ProblemStep (csrc/solver_dist.cpp, shard form): all-reduce of the point block of A p + one tiny all-gather per PCG
     iteration; the replicated points stay bit-identical across ranks."""
@@ -266,19 +266,27 @@ def test_hip_ba_camera_shards_match_oracle(orc, world, dims, nit, lit):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ba_worker, args=(r, world, port, dims, nit, lit, q)) for r in range(world)]
-    for p_ in procs:
-        p_.start()
-    res = _collect(q, procs, world)
     C_, P_, O_ = dims
     p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
     co, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, p).solve(nIterations=nit, lIterations=lit)
-    res.sort(key=lambda t: t[0])
-    for rank, costs, c0, c1, cams, pts in res:
-        assert np.abs(np.array(costs) - co).max() <= 3e-5 * np.abs(co).max(), (rank, costs, co)
-        assert costs == res[0][1]
-        assert np.array_equal(pts, res[0][5])
-        assert np.abs(pts - p[1]).max() <= 2e-3 * np.abs(p[1]).max()
+    runs = {}
+    for dx in (True, False):        # round 3: the point block's all-reduce by peer stores (one launch, sums in rank order) / through the all-reduce callback
+        port = _free_port()
+        procs = [ctx.Process(target=_ba_worker, args=(r, world, port, dims, nit, lit, q, dx)) for r in range(world)]
+        for p_ in procs:
+            p_.start()
+        res = _collect(q, procs, world)
+        res.sort(key=lambda t: t[0])
+        for rank, costs, c0, c1, cams, pts, info in res:
+            assert info["exchange"] == ("p2p-allreduce + allgather" if dx else "allreduce + allgather"), info
+            assert not dx or info["self_check"]["all_ranks_pass"] is True
+            assert np.abs(np.array(costs) - co).max() <= 3e-5 * np.abs(co).max(), (rank, costs, co)
+            assert costs == res[0][1]
+            assert np.array_equal(pts, res[0][5])
+            assert np.abs(pts - p[1]).max() <= 2e-3 * np.abs(p[1]).max()
+        runs[dx] = res
+    a, b = np.array(runs[True][0][1]), np.array(runs[False][0][1])
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (a, b)      # the two all-reduces add the ranks' parts in different orders: equal to rounding
 
 
 # ------------------------------------------------------------------ vertex-partitioned ARAP (HIP backend)
@@ -486,6 +494,12 @@ def _worker_fail(rank, world, port, W, H, lit, q, energy, fail_rank, nth):
         if energy == "iw":
             from thallo_amd.distributed import PlanSlabSolver
             solver = PlanSlabSolver(syn.image_warping(W, H, n_markers=8), W, H, rank, world, lit, device_exchange=False)
+        elif energy == "ba":
+            from thallo_amd.distributed_ba import PlanBaShardSolver
+            solver = PlanBaShardSolver(syn.bundle_adjustment(C=16, P=300, O=1500, band=8), rank, world, lit)       # device-side all-reduce + scalar granules
+        elif energy == "arap_part":
+            from thallo_amd.distributed_graph import PlanArapPartitionSolver
+            solver = PlanArapPartitionSolver(syn.arap_mesh(16, 12, n_handles=8, angle_amp=0.3), rank, world, lit)
         else:
             from thallo_amd.distributed_sfs import PlanSfsSlabSolver
             solver = PlanSfsSlabSolver(syn.shape_from_shading(W, H), W, H, rank, world, lit, lm=(energy == "sfs_lm"))
@@ -507,7 +521,7 @@ def _worker_fail(rank, world, port, W, H, lit, q, energy, fail_rank, nth):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("energy,nth", [("iw", 7), ("sfs", 9), ("sfs_lm", 12)])
+@pytest.mark.parametrize("energy,nth", [("iw", 7), ("sfs", 9), ("sfs_lm", 12), ("ba", 9), ("arap_part", 8)])
 def test_rank_local_failure_is_reported_by_every_rank_and_nobody_hangs(energy, nth):
     """a launch that fails on ONE rank used to return in front of the matching all-gather and leave the other ranks blocked in it.  Now the rank stays
     in the collective sequence with poisoned payloads and the failure becomes everybody's at the next cost evaluation: both ranks finish, both see a NaN cost and

@@ -26,7 +26,7 @@ __device__ __forceinline__ void st_sys(float* p, float v) { __hip_atomic_store(p
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ctl words
-enum { DIST_SEQ = 0, DIST_ERR = 1, DIST_SPIN_MS = 2, DIST_POST_MORTEM = 4, DIST_XSEQ = 10, DIST_XTICKET = 11, DIST_CTL_WORDS = 16 };     // [10], [11]: thallo_hip_dist_xrows' exchange counter and ticket
+enum { DIST_SEQ = 0, DIST_ERR = 1, DIST_SPIN_MS = 2, DIST_POST_MORTEM = 4, DIST_XSEQ = 10, DIST_XTICKET = 11, DIST_ASEQ = 12, DIST_ATICKET = 13 /* .. 15 */, DIST_CTL_WORDS = 16 };     // [10], [11]: thallo_hip_dist_xrows' exchange counter and ticket
 // ctl[DIST_SPIN_MS] != 0: spin bound in milliseconds instead of the default (the set-up's self-check runs with 500 ms, so that a
 // topology on which granules never become visible costs half a second, not 20 s, before every rank falls back to the collectives)
 __device__ __forceinline__ long long dist_spin_ticks(const thallo_dist_t& d)
@@ -82,8 +82,9 @@ __device__ __forceinline__ void dist_fetch(const thallo_dist_t& d, const int (&s
 // this rank's sums (alphaD float; N, S1, S2 double) go out as 7 granules to every rank's mailbox slots slot0 .. slot0+6 (the doubles
 // as hi / lo words), the wave waits (bounded) for everybody's, adds them in rank order and lane 0 writes alphaD_k and
 // betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 with alpha_k = alphaN / alphaD_k.  Identical bits on every rank.
+struct ExtraSums { bool on; float ad; double q0, q1, q2; };     // added behind the rank-ordered sums (shard form: the replicated block's own sums, k_shard_scalars' order)
 __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
-                                                            float* __restrict__ aD_word, float* __restrict__ bN_word);
+                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex = ExtraSums{ false, 0.0f, 0.0, 0.0, 0.0 });
 __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, int slot0, float ad, double q0, double q1, double q2, float an,
                                                         float* __restrict__ aD_word, float* __restrict__ bN_word)
 {
@@ -91,7 +92,7 @@ __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, 
 }
 // (seq given by the caller: thallo_hip_dist_xrows tags with its own exchange counter)
 __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, const unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
-                                                            float* __restrict__ aD_word, float* __restrict__ bN_word)
+                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex)
 {
     const int lane = threadIdx.x & (THALLO_WAVE - 1);
     unsigned w[7];
@@ -133,6 +134,7 @@ __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t&
             gq[j] += __longlong_as_double((long long)(((u64)hi << 32) | (u64)lo));
         }
     }
+    if (ex.on) { gad += ex.ad; gq[0] += ex.q0; gq[1] += ex.q1; gq[2] += ex.q2; }
     const float alpha = safe_div<false>(an, gad);
     double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
     if (!(bn > 0.0)) bn = 0.0;

@@ -87,7 +87,8 @@ __device__ __forceinline__ void rows_in(float* __restrict__ vec, const thallo_se
 template <int MODE>
 __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x, float* __restrict__ vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                                                 thallo_sum_t s, const float* __restrict__ aD_part, const double* __restrict__ s3, int nb, int poison,
-                                                float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ zstate, int zk, float ztol)
+                                                float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ zstate, int zk, float ztol,
+                                                const float* __restrict__ aD2 = nullptr, const double* __restrict__ s3_2 = nullptr, int nb2 = 0)
 {
     __shared__ unsigned last_wg;
     const unsigned tag = ld_agent(d.ctl + DIST_XSEQ) + 1u;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
         if (x.above >= 0) rows_out(vec, first, inbox_of(d.peer_mail[x.above], x, par, 1));       // I am BELOW my upper neighbour
         if (x.below >= 0) rows_out(vec, last, inbox_of(d.peer_mail[x.below], x, par, 0));
     }
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the rows went out as write-through system-scope stores: drained = at the peer)
     __syncthreads();
     if (gridDim.x > 1) {                            // (long rows: several workgroups carry them, the last one to arrive goes on)
         if (threadIdx.x == 0) last_wg = __hip_atomic_fetch_add(d.ctl + DIST_XTICKET, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
@@ -129,7 +130,14 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
 #pragma unroll
             for (int j = 0; j < 3; ++j) q[j] = wave_sum_all_f64(q[j]);
             if (poison) ad = __uint_as_float(0x7fc00000u);
-            dist_exchange_iter_wave_seq(d, tag, slot0, ad, q[0], q[1], q[2], s.count == 1 ? s.partials[0] : 0.0f, out0, out1);
+            ExtraSums ex = { false, 0.0f, 0.0, 0.0, 0.0 };
+            if (nb2 > 0) {                      // shard form: the replicated block's sums, computed by every rank for itself, join behind the ranks' (k_shard_scalars' order)
+                ex.on = true; ex.ad = sum_partials(aD2, nb2);
+                double n = 0.0, a = 0.0, b = 0.0;
+                for (int i = lane; i < nb2; i += THALLO_WAVE) { n += s3_2[3 * i]; a += s3_2[3 * i + 1]; b += s3_2[3 * i + 2]; }
+                ex.q0 = wave_sum_all_f64(n); ex.q1 = wave_sum_all_f64(a); ex.q2 = wave_sum_all_f64(b);
+            }
+            dist_exchange_iter_wave_seq(d, tag, slot0, ad, q[0], q[1], q[2], s.count == 1 ? s.partials[0] : (s.count > 1 ? sum_partials(s.partials, s.count) : 0.0f), out0, out1, ex);
         }
     }
     __syncthreads();
@@ -140,6 +148,103 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
     if (threadIdx.x == 0) {
         if (gridDim.x > 1) __hip_atomic_store(d.ctl + DIST_XTICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(d.ctl + DIST_XSEQ, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// thallo_hip_dist_allreduce (thallo_hip.h): reduce-scatter + all-gather by peer stores, one launch, every workgroup resident
+__device__ __forceinline__ float* xr_inbox(unsigned long long* mail, const thallo_xreduce_t& x, int world, int which, int par, int src)
+{
+    return (float*)((char*)mail + x.inbox_off) + ((long)(which * 2 + par) * world + src) * x.chunk;
+}
+// every thread of the workgroup: wait until `slot` carries `tag` from every rank
+__device__ __forceinline__ void xr_wait_all(const thallo_dist_t& d, int slot, unsigned tag)
+{
+    if ((int)threadIdx.x < d.world) {
+        const u64* g = d.mail + (long)slot * d.world + threadIdx.x;
+        u64 v = ld_sys(g);
+        int it = 0; long long t0 = 0;
+        const long long bound = dist_spin_ticks(d);
+        while ((unsigned)(v >> 32) != tag) {
+            if ((it & 1023) == 0) { if (ld_agent(d.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
+            ++it;
+            if ((it & 1023) == 0 && wall_clock64() - t0 > bound) {
+                if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    unsigned* pm = d.ctl + DIST_POST_MORTEM;
+                    pm[0] = (unsigned)slot; pm[1] = threadIdx.x; pm[2] = tag; pm[3] = (unsigned)(v >> 32); pm[4] = (unsigned)v;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+            v = ld_sys(g);
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+// grid-wide arrival: returns true in every thread of the LAST workgroup to arrive (which then sends the granules of this phase)
+__device__ __forceinline__ bool xr_arrive(unsigned* ticket, unsigned* flag_lds)
+{
+    // every peer store above is a write-through system-scope store: a wave that has drained them (vmcnt(0)) has them at the peer; no L2 write-back needed
+    // (a __threadfence_system() here writes back every dirty line of this XCD's L2: three of those per launch cost more than the data movement)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *flag_lds = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    return *flag_lds != 0u;
+}
+__global__ __launch_bounds__(256) void k_allreduce_p2p(thallo_dist_t d, thallo_xreduce_t x, float* __restrict__ buf, long len, int poison)
+{
+    __shared__ unsigned flag;
+    const unsigned tag = ld_agent(d.ctl + DIST_ASEQ) + 1u;
+    const int par = (int)(tag & 1u), world = d.world, me = d.rank;
+    const int slot_rs = x.ring0 + (int)(tag & 3u) * 2, slot_ag = slot_rs + 1;
+    const long C = x.chunk;
+    const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    auto clen = [&](int c) { const long lo = (long)c * C, hi = lo + C < len ? lo + C : len; return hi > lo ? hi - lo : 0L; };
+    // 1. my part of every other rank's chunk -> its inbox A
+    for (int c = 0; c < world; ++c) {
+        if (c == me) continue;
+        const u64* src = (const u64*)(buf + (long)c * C);
+        u64* dst = (u64*)xr_inbox(d.peer_mail[c], x, world, 0, par, me);
+        const long n2 = clen(c) / 2;
+        for (long i = gtid; i < n2; i += gsz) st_sys(dst + i, src[i]);
+    }
+    if (xr_arrive(d.ctl + DIST_ATICKET, &flag) && (int)threadIdx.x < world)
+        st_sys(d.peer_mail[threadIdx.x] + (long)slot_rs * world + me, ((u64)tag << 32) | 1ull);
+    xr_wait_all(d, slot_rs, tag);
+    // 2. my chunk: the contributions in RANK order; the sums into place and into every other rank's inbox B
+    {
+        const long n2 = clen(me) / 2;
+        float* mine = buf + (long)me * C;
+        for (long i = gtid; i < n2; i += gsz) {
+            float2 acc = make_float2(0.0f, 0.0f);
+            for (int r = 0; r < world; ++r) {
+                float2 t;
+                if (r == me) t = ((const float2*)mine)[i];
+                else { const u64 w = ld_sys((const u64*)xr_inbox(d.mail, x, world, 0, par, r) + i); t = make_float2(__uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32))); }
+                acc.x = r == 0 ? t.x : acc.x + t.x; acc.y = r == 0 ? t.y : acc.y + t.y;
+            }
+            if (poison && i == 0) acc.x = __uint_as_float(0x7fc00000u);
+            ((float2*)mine)[i] = acc;
+            const u64 w = (u64)__float_as_uint(acc.x) | ((u64)__float_as_uint(acc.y) << 32);
+            for (int c = 0; c < world; ++c) if (c != me) st_sys((u64*)xr_inbox(d.peer_mail[c], x, world, 1, par, me) + i, w);
+        }
+    }
+    if (xr_arrive(d.ctl + DIST_ATICKET + 1, &flag) && (int)threadIdx.x < world)
+        st_sys(d.peer_mail[threadIdx.x] + (long)slot_ag * world + me, ((u64)tag << 32) | 2ull);
+    xr_wait_all(d, slot_ag, tag);
+    // 3. the other ranks' chunks from my inbox B into place
+    for (int c = 0; c < world; ++c) {
+        if (c == me) continue;
+        const u64* src = (const u64*)xr_inbox(d.mail, x, world, 1, par, c);
+        u64* dst = (u64*)(buf + (long)c * C);
+        const long n2 = clen(c) / 2;
+        for (long i = gtid; i < n2; i += gsz) dst[i] = ld_sys(src + i);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(d.ctl + DIST_ATICKET + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        for (int q = 0; q < 3; ++q) __hip_atomic_store(d.ctl + DIST_ATICKET + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d.ctl + DIST_ASEQ, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 }  // namespace
@@ -234,7 +339,8 @@ int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, 
 
 static int xrows_impl(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                       int mode, thallo_sum_t s, const float* aD_partials, const double* s3_partials, int count, int poison,
-                      float* out0, float* out1, float* zstate, int zk, float ztol, thallo_stream_t stream)
+                      float* out0, float* out1, float* zstate, int zk, float ztol, thallo_stream_t stream,
+                      const float* aD2 = nullptr, const double* s3_2 = nullptr, int nb2 = 0)
 {
     if (!dist_ok(d) || x.ring0 < 0 || x.inbox_off <= 0 || (x.inbox_off & 7) || x.inbox_half < 0 || (x.inbox_half & 1) || x.above >= d.world || x.below >= d.world ||
         x.above == d.rank || x.below == d.rank || 7 * d.world > 64) return -(int)hipErrorInvalidValue;
@@ -257,7 +363,7 @@ static int xrows_impl(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs
     // rows of up to 32 K floats per direction (a 2048-wide image: 2 ghost rows of 4 channels): ONE workgroup, no ticket; longer ones: 8 workgroups
     const int grid = std::max(tf, tl) <= 32768 ? 1 : 8, block = 256;
     if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, zstate, zk, ztol);
-    else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, (float*)nullptr, 0, 0.0f);
+    else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, (float*)nullptr, 0, 0.0f, aD2, s3_2, nb2);
     return check_launch();
 }
 
@@ -271,6 +377,26 @@ int thallo_hip_dist_xrows_zeta(thallo_dist_t d, thallo_xrows_t x, float* vec, th
 {
     if (!lm_state || q_local.count < 1 || !q_out) return -(int)hipErrorInvalidValue;
     return xrows_impl(d, x, vec, first, last, top, bot, 0, q_local, second_partials, nullptr, second_count, poison, q_out, second_out, lm_state, k, q_tolerance, stream);
+}
+
+int thallo_hip_dist_allreduce(thallo_dist_t d, thallo_xreduce_t x, float* buf, long len, int poison, thallo_stream_t stream)
+{
+    if (!dist_ok(d) || !buf || len < 4 || (len & 3) || x.chunk < 4 || (x.chunk & 3) || x.chunk * d.world < len || x.inbox_off <= 0 || (x.inbox_off & 15) || x.ring0 < 0) return -(int)hipErrorInvalidValue;
+    long per = (x.chunk / 2 + 255) / 256;
+    int grid = (int)(per < 1 ? 1 : per > 64 ? 64 : per);         // every workgroup resident at once: the phases wait on each other inside the launch
+    hipLaunchKernelGGL(k_allreduce_p2p, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, x, buf, len, poison);
+    return check_launch();
+}
+
+int thallo_hip_dist_xscalars_shard(thallo_dist_t d, thallo_xrows_t x, thallo_sum_t alphaN, const float* own_alphaD_partials, const double* own_s3_partials, int own_count,
+                                   const float* shared_alphaD_partials, const double* shared_s3_partials, int shared_count, int poison,
+                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream)
+{
+    if (!shared_alphaD_partials || !shared_s3_partials || shared_count < 1 || shared_count > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+    const thallo_segs_t none = {};
+    x.above = -1; x.below = -1;
+    return xrows_impl(d, x, nullptr, none, none, none, none, 1, alphaN, own_alphaD_partials, own_s3_partials, own_count, poison, alphaD_word, betaN_word, nullptr, 0, 0.0f, stream,
+                      shared_alphaD_partials, shared_s3_partials, shared_count);
 }
 
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream)

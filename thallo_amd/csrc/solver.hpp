@@ -73,6 +73,7 @@ struct DistState {
     bool shard = false;
     long sh_off = 0, sh_len = 0;
     DeviceBuffer sh_aD, sh_s3;                           // the shared block's partials of an iteration
+    thallo_xreduce_t xa;                                 // device-side all-reduce of the shared block (thallo_hip_dist_allreduce): inbox geometry
     // device-side exchange
     bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
     void* mail = nullptr; int mail_L = 0;
@@ -181,6 +182,7 @@ private:
     bool dist_skip() const { return dist_ && dist_->failed; }
     int  dist_map_peers();
     int  dist_map_peers_flat();
+    int  dist_map_mail(long bytes);                     // the mailbox allocation of the flat / shard forms: allocate, exchange handles, map every peer's, agree
     int  dist_two_sums_and_rows(int j1, int j2, float* vec, float* zeta_state = nullptr, int zeta_k = 0, bool* zeta_done = nullptr);
     int  dist_xrows(float* vec, bool rows, int mode, thallo_sum_t s, const float* aD_part, const double* s3, int nb, float* out0, float* out1, float* zeta_state = nullptr, int zeta_k = 0);
     int  dist_self_check();

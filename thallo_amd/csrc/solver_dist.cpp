@@ -141,8 +141,23 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         bool all = false;
         if (dist_agree(mem, all)) return -1;                             // every rank has its buffers, or every rank returns the error
         if (!all) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
+        // ---- device-side all-reduce of the shared block (thallo_hip_dist_allreduce): scalar ring + two inboxes in one IPC allocation per rank
+        D.want_p2p = cfg.device_exchange != 0;
+        {   const char* e = env_switch("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
+        bool ctl_ok = !(D.ctl.alloc(THALLO_DIST_CTL_WORDS * sizeof(unsigned)) || hipMemset(D.ctl.ptr, 0, THALLO_DIST_CTL_WORDS * sizeof(unsigned)) != hipSuccess);
+        all = false;
+        if (dist_agree(D.want_p2p && ctl_ok, all)) return -1;
+        D.want_p2p = all;
+        if (D.want_p2p) {
+            memset(&D.xa, 0, sizeof(D.xa));
+            D.xa.ring0 = 0; D.xa.chunk = ((len + cfg.world - 1) / cfg.world + 3) / 4 * 4;
+            D.xa.inbox_off = (8L * 40 * cfg.world + 255) / 256 * 256;       // behind 8 (all-reduce) + 32 (scalars) granule slots
+            memset(&D.xr, 0, sizeof(D.xr)); D.xr.ring0 = 8; D.xr.inbox_off = D.xa.inbox_off; D.xr.above = D.xr.below = -1;
+            if (dist_map_mail(D.xa.inbox_off + 4L * cfg.world * D.xa.chunk * (long)sizeof(float))) return -1;
+        }
         char buf[256];
-        snprintf(buf, sizeof(buf), "{\"exchange\": \"allreduce + allgather\", \"form\": \"residual shards, shared block of %ld unknowns\", \"rank\": %d, \"world\": %d}", len, cfg.rank, cfg.world);
+        snprintf(buf, sizeof(buf), "{\"exchange\": \"allreduce + allgather\", \"form\": \"residual shards, shared block of %ld unknowns\", \"rank\": %d, \"world\": %d, \"device_exchange_requested\": %s}",
+                 len, cfg.rank, cfg.world, cfg.device_exchange ? "true" : "false");
         D.info = buf;
         return 0;
     }
@@ -380,25 +395,19 @@ int Plan::dist_map_peers()
     return 0;
 }
 
-int Plan::dist_map_peers_flat()
-{   // flat form: only the mailbox allocation (scalar ring + row inbox) is shared; the solver vectors stay where the Plan allocated them
+int Plan::dist_map_mail(long bytes)
+{   // only the mailbox allocation is shared between ranks; the solver vectors stay where the Plan allocated them
     DistState& D = *dist_;
     const int world = D.cfg.world, rank = D.cfg.rank;
-    const long gl = D.ghost * D.rowlen;
-    thallo_xrows_t x; memset(&x, 0, sizeof(x));
-    x.ring0 = 0;
-    x.inbox_off = (8L * 32 * world + 255) / 256 * 256;                  // behind 4 x 8 scalar slots of `world` granules
-    x.inbox_half = gl;
-    x.above = D.top ? rank - 1 : -1; x.below = D.bot ? rank + 1 : -1;
     PeerInfo mine; memset(&mine, 0, sizeof(mine));
-    mine.ok = thallo_hip_ipc_alloc2(x.inbox_off + 4 * gl * (long)sizeof(float), &D.mail, D.handle_mail, &D.mem_kind[1]) >= 0 ? 1 : 0;
+    mine.ok = thallo_hip_ipc_alloc2(bytes, &D.mail, D.handle_mail, &D.mem_kind[1]) >= 0 ? 1 : 0;
     if (!mine.ok) D.mail = nullptr;
     memcpy(mine.mail, D.handle_mail, 64);
-    mine.row0 = D.row0; mine.row1 = D.row1; mine.Hl = D.Hl; mine.na = gl;
+    mine.row0 = D.row0; mine.row1 = D.row1; mine.Hl = D.Hl; mine.na = bytes;
     PeerInfo infos[THALLO_DIST_MAX_WORLD];
     if (host_allgather(*this, D, &Plan::dist_allgather, &mine, infos, sizeof(PeerInfo))) return -1;
     bool ok = true;
-    for (int r = 0; r < world; ++r) ok = ok && infos[r].ok == 1 && infos[r].na == gl;
+    for (int r = 0; r < world; ++r) ok = ok && infos[r].ok == 1 && infos[r].na == bytes;
     thallo_dist_t d; memset(&d, 0, sizeof(d));
     d.world = world; d.rank = rank; d.mail = (unsigned long long*)D.mail; d.ctl = (unsigned*)D.ctl.ptr;
     for (int r = 0; r < world && ok; ++r) {
@@ -407,12 +416,25 @@ int Plan::dist_map_peers_flat()
         if (thallo_hip_ipc_open(infos[r].mail, &p) < 0) { ok = false; break; }
         D.opened.push_back(p); d.peer_mail[r] = (unsigned long long*)p;
     }
-    D.d = d; D.xr = x;
+    D.d = d;
     bool all = false;
     if (dist_agree(ok, all)) return -1;
     D.mapped = all;
     if (!all) D.want_p2p = false;
     return 0;
+}
+
+int Plan::dist_map_peers_flat()
+{   // flat form: scalar ring + row inbox
+    DistState& D = *dist_;
+    const long gl = D.ghost * D.rowlen;
+    thallo_xrows_t x; memset(&x, 0, sizeof(x));
+    x.ring0 = 0;
+    x.inbox_off = (8L * 32 * D.cfg.world + 255) / 256 * 256;            // behind 4 x 8 scalar slots of `world` granules
+    x.inbox_half = gl;
+    x.above = D.top ? D.cfg.rank - 1 : -1; x.below = D.bot ? D.cfg.rank + 1 : -1;
+    D.xr = x;
+    return dist_map_mail(x.inbox_off + 4 * gl * (long)sizeof(float));
 }
 
 int Plan::dist_xrows(float* vec, bool rows, int mode, thallo_sum_t sm, const float* aD_part, const double* s3, int nb, float* out0, float* out1, float* zeta_state, int zeta_k)
@@ -442,12 +464,12 @@ float Plan::dist_cost()
         if (plugin->resident_status(ctx, 1, pm) != 0)
             dist_fail("a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u)", pm[0], pm[1], pm[2], pm[3], pm[4]);
     }
-    if (D.flat && D.p2p_on && !D.failed) {  // the device-side row exchange's waits are bounded too
+    if ((D.flat || D.shard) && D.p2p_on && !D.failed) {  // the device-side row exchange's (all-reduce's) waits are bounded too
         const int err = thallo_hip_dist_error(D.d, 1, s);
         if (err != 0) {
             unsigned pm[5] = { 0, 0, 0, 0, 0 };
             hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
-            dist_fail("a bounded wait of the device-side row exchange ran out (slot %u, source rank %u, tag %u, found %u)", pm[0], pm[1], pm[2], pm[3]);
+            dist_fail("a bounded wait of the device-side %s ran out (slot %u, source rank %u, tag %u, found %u)", D.shard ? "all-reduce" : "row exchange", pm[0], pm[1], pm[2], pm[3]);
         }
     }
     int nb = 0;
@@ -771,6 +793,12 @@ int Plan::dist_gn_range(int L)
 int Plan::dist_allreduce(float* buf, long count)
 {
     DistState& D = *dist_;
+    if (D.shard && D.p2p_on && count == D.sh_len && (D.cfg.world > 1 || !D.checked)) {      // peer stores only (world size 1: nothing to add; the set-up's self-check still runs it): reduce-scatter + all-gather in one launch, sums in rank order (the same bits on every rank and in every run)
+        int rc = thallo_hip_dist_allreduce(D.d, D.xa, buf, count, D.failed ? 1 : 0, ctx.stream);
+        if (D.inject > 0 && !D.failed && --D.inject == 0) rc = -999;
+        if (rc < 0 && !D.failed) dist_fail("device-side all-reduce failed (%d)", rc);
+        return 0;
+    }
     if (D.cfg.world == 1) return 0;
     if (D.failed) (void)hipMemsetAsync(buf, 0xFF, (size_t)(count < 8 ? count : 8) * sizeof(float), ctx.stream);      // poisons every rank's sum
     if (!D.cfg.allreduce && rccl_) return rccl_allreduce_sum(rccl_, buf, count, ctx.stream);
@@ -829,6 +857,14 @@ int Plan::dist_gn_shard(int L)
         if (dist_allreduce(v_.Ap + off, len)) return -1;
         int nbp = 0;
         if (!D.failed) { nbp = thallo_hip_block_sums(v_.p[cur_] + off, v_.Ap + off, v_.r + off, pc ? v_.pre + off : nullptr, len, sh_aD, sh_s3, s); if (nbp < 0) dist_fail("block sums launch failed (%d)", nbp); }
+        if (D.p2p_on) {       // no collective: the ranks' camera sums as granules, the point sums behind them (thallo_hip_dist_xscalars_shard)
+            int rc = thallo_hip_dist_xscalars_shard(D.d, D.xr, D.failed ? thallo_sum_t{ (const float*)D.send.ptr, 1 } : sum(jN), D.failed ? (const float*)D.send.ptr : slot(jD), v_.s12,
+                                                    D.failed ? 1 : cam_slots, sh_aD, sh_s3, D.failed ? 1 : nbp, D.failed ? 1 : 0, scal(jD), scal(jB), s);
+            if (D.inject > 0 && !D.failed && --D.inject == 0) rc = -999;
+            if (rc < 0 && !D.failed) dist_fail("device-side scalar exchange failed (%d)", rc);
+            if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+            continue;
+        }
         DLOCAL(thallo_hip_slab_pack_iter(v_.Ap, none, slot(jD), v_.s12, cam_slots, send, s), "shard pack");      // the camera launch's slots only
         if (dist_allgather(send, gath, 7 * (long)sizeof(float))) return -1;
         DLOCAL(thallo_hip_shard_scalars(gath, 7, world, sh_aD, sh_s3, nbp, sum(jN), scal(jD), scal(jB), s), "shard scalars");
@@ -847,6 +883,43 @@ int Plan::dist_self_check()
     D.checked = true;
     if (!D.mapped) { D.p2p_on = false; return 0; }                       // (agreed in dist_map_peers: the same on every rank)
     hipStream_t s = ctx.stream;
+    if (D.shard) {
+        // shard form: three all-reduces (both parities, three ring positions) of a pattern whose sum is known exactly: rank r contributes (r + 1) * (i % 7 + 1)
+        const long len = D.sh_len;
+        const unsigned spin_ms = 500, zero = 0;
+        std::vector<float> host((size_t)len), back((size_t)len);
+        bool pass = true;
+        DCOPY(hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &spin_ms, sizeof(unsigned), hipMemcpyHostToDevice, s), "spin bound");
+        D.p2p_on = true;
+        for (int t = 0; t < 3; ++t) {
+            for (long i = 0; i < len; ++i) host[(size_t)i] = (float)((D.cfg.rank + 1) * (int)((i + t) % 7 + 1));
+            DCOPY(hipMemcpyAsync(v_.Ap + D.sh_off, host.data(), len * sizeof(float), hipMemcpyHostToDevice, s), "self-check pattern");
+            if (dist_allreduce(v_.Ap + D.sh_off, len)) return -1;
+            DCOPY(hipMemcpyAsync(back.data(), v_.Ap + D.sh_off, len * sizeof(float), hipMemcpyDeviceToHost, s), "self-check read-back");
+            DCOPY(hipStreamSynchronize(s), "synchronise");
+            if (D.failed) { pass = false; continue; }
+            const float S = (float)(D.cfg.world * (D.cfg.world + 1) / 2);
+            for (long i = 0; i < len && pass; ++i) if (back[(size_t)i] != S * (float)((i + t) % 7 + 1)) pass = false;
+        }
+        D.p2p_on = false;
+        int err = !D.failed ? thallo_hip_dist_error(D.d, 1, s) : -1;
+        unsigned pm[5] = { 0, 0, 0, 0, 0 };
+        hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
+        hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &zero, sizeof(unsigned), hipMemcpyHostToDevice, s);
+        hipMemsetAsync(v_.Ap + D.sh_off, 0, len * sizeof(float), s);
+        hipStreamSynchronize(s);
+        pass = pass && !D.failed && err == 0;
+        bool all = false;
+        if (dist_agree(pass, all)) return -1;
+        D.p2p_on = all;
+        char buf[512];
+        snprintf(buf, sizeof(buf), "{\"exchange\": \"%s\", \"form\": \"residual shards, shared block of %ld unknowns\", \"rank\": %d, \"world\": %d, \"memory\": [\"plan\", \"%s\"], \"self_check\": {\"allreduces\": 3, "
+                 "\"timeout\": %d, \"pass\": %s, \"all_ranks_pass\": %s, \"post_mortem\": [%u, %u, %u, %u, %u]}}",
+                 all ? "p2p-allreduce + allgather" : "allreduce + allgather", len, D.cfg.rank, D.cfg.world, D.mem_kind[1] == 1 ? "fine-grained" : "coarse-grained", err, pass ? "true" : "false",
+                 all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
+        D.info = buf;
+        return 0;
+    }
     if (D.flat) {
         // flat form: three exchanges (both parities, three ring positions) of a pattern that is a function of the GLOBAL row -- what has to arrive in the
         // ghost rows is known without asking the neighbour -- and a scalar per rank; v_.Ap is scratch outside a step
@@ -973,6 +1046,8 @@ int Plan::dist_control(int what, int value)
             if (at != std::string::npos) D.info.replace(at, 13, "\"allgather\", \"switched_off\": true");
             at = D.info.find("\"p2p-rows\"");
             if (at != std::string::npos) D.info.replace(at, 10, "\"allgather\", \"switched_off\": true");
+            at = D.info.find("\"p2p-allreduce + allgather\"");
+            if (at != std::string::npos) D.info.replace(at, 27, "\"allreduce + allgather\", \"switched_off\": true");
         }
         return 0;
     }

@@ -7,7 +7,9 @@ Rank k owns a contiguous range of cameras and every observation (row pair of J) 
     PCG iteration (and of the point blocks of J^T F and diag(J^T J) once per GN step);
   * after that every rank holds identical point blocks of Ap, r, p, delta and updates them redundantly, so the point unknowns never need a broadcast;
   * the scalars: the ranks' camera parts of [alphaD | N, S1, S2] in one tiny all-gather (added in rank order) + the point parts every rank computes
-    for itself after the all-reduce.
+    for itself after the all-reduce;
+  * round 3, device_exchange=True: the all-reduce is ONE launch of peer stores (thallo_hip_dist_allreduce: reduce-scatter into the chunk owners' inboxes, sums in
+    rank order, all-gather into every rank's second inbox) after a self-check at Init -- no ncclAllReduce in the PCG loop; distributed_info() says which.
 The kernels are the single-GPU ones run on the local sub-instance [cameras of this rank (padded to a multiple of 4) | all points].  This module is
 set-up only: the shard (BaShardLayout) and the two callbacks over torch.distributed.
 """
@@ -36,12 +38,17 @@ class BaShardLayout:
         sel = np.nonzero((oc >= self.c0) & (oc < self.c1))[0]
         cl = np.zeros((self.C_pad, 9), np.float32)
         cl[: self.C_loc] = cams[self.c0:self.c1]
+        # the shared (point) block is all-reduced and updated with 16-byte accesses: 3 P floats must be a multiple of 4 -> pad with points nobody observes
+        # (no rows, zero gradient, they never move; ladybug-1723 has 156,502 points)
+        self.P, self.P_pad = pts.shape[0], (pts.shape[0] + 3) // 4 * 4
+        pl = np.zeros((self.P_pad, 3), np.float32); pl[: self.P] = pts
+        pts = pl
         return [cl, np.ascontiguousarray(pts, np.float32), np.ascontiguousarray(obs[sel]),
                 np.ascontiguousarray(oc[sel] - self.c0, np.int32), np.ascontiguousarray(op[sel], np.int32)]
 
 
 class PlanBaShardSolver:
-    def __init__(self, params_global, rank, world, l_iters, group=None):
+    def __init__(self, params_global, rank, world, l_iters, group=None, device_exchange=True):
         self.lay = lay = BaShardLayout(params_global[0].shape[0], rank, world)
         local = lay.shard(params_global)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -53,7 +60,7 @@ class PlanBaShardSolver:
         self.library_rccl = library_rccl(self.solver, rank, world, group)      # ranks on GPUs of their own: all-gather and all-reduce run inside the library (no callback)
         ag = torch_allgather(group, dev) if world > 1 and not self.library_rccl else None
         ar = torch_allreduce(group, dev) if world > 1 and not self.library_rccl else None
-        self.solver.set_distributed(rank, world, lay.c0, lay.c1, allgather=ag, device_exchange=False, allreduce=ar)
+        self.solver.set_distributed(rank, world, lay.c0, lay.c1, allgather=ag, device_exchange=device_exchange, allreduce=ar)
         self.params = self.solver.make_params(self.tensors)
 
     def solve(self, n_iters, **solver_params):

@@ -651,6 +651,12 @@ int thallo_hip_units_unpack(float* vec, thallo_units_t u, const float* gathered,
 int thallo_hip_units_pack_iter(const float* vec, thallo_units_t u, const float* alphaD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream);
 int thallo_hip_units_unpack_iter(float* vec, thallo_units_t u, const float* gathered, long stride, int world, thallo_sum_t alphaN,
                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* thallo_hip_dist_xrows for a PARTITIONED graph (thallo_units_t): the boundary units' values go into every other rank's inbox (area [parity][this rank] of
+   unit_slot_floats floats at x.inbox_off), the scalars travel as in thallo_hip_dist_xrows (mode 0 / 1), and the ghost units are filled from the rank's own inbox --
+   recv.src[g] = source rank * unit_slot_floats + position * floats per unit.  One launch, no collective. */
+int thallo_hip_dist_xunits(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_units_t send, thallo_units_t recv, long unit_slot_floats,
+                           int mode, thallo_sum_t local_or_alphaN, const float* alphaD_partials, const double* s3_partials, int count, int poison,
+                           float* out0, float* out1, thallo_stream_t stream);
 /* The scalars of a PCG iteration in the shard form (bundle adjustment across camera shards) without a collective: every rank's OWN partials (its cameras':
    alphaD float, {N, S1, S2} double) travel as 7 granules and are added in rank order; the sums of the SHARED block (the points, identical on every rank after the
    all-reduce, thallo_hip_block_sums) join behind them; then alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 -- thallo_hip_shard_scalars' arithmetic and order.

@@ -329,7 +329,7 @@ def test_hip_arap_vertex_partition_matches_oracle(orc, world, nu, nv, nit, lit):
         assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
 
 
-def _arap_part_worker(rank, world, port, nu, nv, nit, lit, q):
+def _arap_part_worker(rank, world, port, nu, nv, nit, lit, q, device_exchange=True):
     import torch
     import torch.distributed as dist
     from thallo_amd import synthetic as syn
@@ -339,7 +339,7 @@ def _arap_part_worker(rank, world, port, nu, nv, nit, lit, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
-        solver = PlanArapPartitionSolver(p, rank, world, lit)
+        solver = PlanArapPartitionSolver(p, rank, world, lit, device_exchange=device_exchange)
         costs = solver.solve(nit)
         part = solver.part
         q.put((rank, costs, part.owned_global, part.local_global, solver.owned(), solver.ghosts(), solver.solver.distributed_info()))
@@ -358,14 +358,24 @@ def test_hip_arap_real_vertex_partition_matches_oracle(orc, world, nu, nv, nit, 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_arap_part_worker, args=(r, world, port, nu, nv, nit, lit, q)) for r in range(world)]
-    for p_ in procs:
-        p_.start()
-    res = _collect(q, procs, world)
+    runs = []
+    for dx in (True, False):        # the boundary exchange as one launch of peer stores (thallo_hip_dist_xunits) / as pack + all-gather + unpack
+        port = _free_port()
+        procs = [ctx.Process(target=_arap_part_worker, args=(r, world, port, nu, nv, nit, lit, q, dx)) for r in range(world)]
+        for p_ in procs:
+            p_.start()
+        r_ = _collect(q, procs, world)
+        r_.sort(key=lambda t: t[0])
+        for t in r_:
+            assert t[6]["exchange"] == ("p2p-units" if dx else "allgather"), t[6]
+            assert not dx or t[6]["self_check"]["all_ranks_pass"] is True
+        runs.append(r_)
+    for a, b in zip(*runs):         # same arithmetic in the same order: the two transports agree bit for bit
+        assert a[1] == b[1] and np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1]), a[0]
+    res = runs[0]
     p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
     N = p[2].shape[0]
     co, _ = orc.Problem(orc.ARAP_MESH, (N, p[6].shape[0]), p).solve(nIterations=nit, lIterations=lit)
-    res.sort(key=lambda t: t[0])
     pos, ang = np.full((N, 3), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
     for rank, costs, owned_g, local_g, (po, ao), _, info in res:
         assert "unit partition" in info["form"] and info["world"] == world, info

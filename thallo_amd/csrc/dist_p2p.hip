@@ -88,7 +88,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x, float* __restrict__ vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                                                 thallo_sum_t s, const float* __restrict__ aD_part, const double* __restrict__ s3, int nb, int poison,
                                                 float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ zstate, int zk, float ztol,
-                                                const float* __restrict__ aD2 = nullptr, const double* __restrict__ s3_2 = nullptr, int nb2 = 0)
+                                                const float* __restrict__ aD2 = nullptr, const double* __restrict__ s3_2 = nullptr, int nb2 = 0,
+                                                thallo_units_t us = thallo_units_t{}, thallo_units_t ur = thallo_units_t{}, long unit_slot = 0)
 {
     __shared__ unsigned last_wg;
     const unsigned tag = ld_agent(d.ctl + DIST_XSEQ) + 1u;
@@ -96,6 +97,17 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
     if (!poison) {
         if (x.above >= 0) rows_out(vec, first, inbox_of(d.peer_mail[x.above], x, par, 1));       // I am BELOW my upper neighbour
         if (x.below >= 0) rows_out(vec, last, inbox_of(d.peer_mail[x.below], x, par, 0));
+        if (us.n > 0) {      // partitioned graph: my boundary units' values into EVERY other rank's inbox, area [parity][me] (thallo_units_t; one workgroup)
+            int per = 0; for (int k = 0; k < us.nplanes; ++k) per += us.len[k];
+            const long total = (long)us.n * per;
+            for (long i = threadIdx.x; i < total; i += blockDim.x) {
+                const int unit = (int)(i / per); int c = (int)(i - (long)unit * per), k = 0;
+                while (c >= us.len[k]) { c -= us.len[k]; ++k; }
+                const float v = vec[us.base[k] + (long)us.units[unit] * us.len[k] + c];
+                for (int r = 0; r < d.world; ++r)
+                    if (r != d.rank) st_sys((float*)((char*)d.peer_mail[r] + x.inbox_off) + ((long)par * d.world + d.rank) * unit_slot + i, v);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the rows went out as write-through system-scope stores: drained = at the peer)
     __syncthreads();
@@ -144,6 +156,16 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
     __atomic_thread_fence(__ATOMIC_ACQUIRE);                                                      // (system scope: the neighbours' rows are behind their granules)
     if (x.above >= 0) rows_in(vec, top, inbox_of(d.mail, x, par, 0));
     if (x.below >= 0) rows_in(vec, bot, inbox_of(d.mail, x, par, 1));
+    if (ur.n > 0) {          // my ghost units from my own inbox: ur.src[g] = source rank * unit_slot + position * per (relative to the parity's base)
+        int per = 0; for (int k = 0; k < ur.nplanes; ++k) per += ur.len[k];
+        const float* base = (const float*)((const char*)d.mail + x.inbox_off) + (long)par * d.world * unit_slot;
+        const long total = (long)ur.n * per;
+        for (long i = threadIdx.x; i < total; i += blockDim.x) {
+            const int g = (int)(i / per); const int within = (int)(i - (long)g * per); int c = within, k = 0;
+            while (c >= ur.len[k]) { c -= ur.len[k]; ++k; }
+            vec[ur.base[k] + (long)ur.units[g] * ur.len[k] + c] = __hip_atomic_load(base + ur.src[g] + within, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (gridDim.x > 1) __hip_atomic_store(d.ctl + DIST_XTICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -340,7 +362,8 @@ int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, 
 static int xrows_impl(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                       int mode, thallo_sum_t s, const float* aD_partials, const double* s3_partials, int count, int poison,
                       float* out0, float* out1, float* zstate, int zk, float ztol, thallo_stream_t stream,
-                      const float* aD2 = nullptr, const double* s3_2 = nullptr, int nb2 = 0)
+                      const float* aD2 = nullptr, const double* s3_2 = nullptr, int nb2 = 0,
+                      thallo_units_t us = thallo_units_t{}, thallo_units_t ur = thallo_units_t{}, long unit_slot = 0)
 {
     if (!dist_ok(d) || x.ring0 < 0 || x.inbox_off <= 0 || (x.inbox_off & 7) || x.inbox_half < 0 || (x.inbox_half & 1) || x.above >= d.world || x.below >= d.world ||
         x.above == d.rank || x.below == d.rank || 7 * d.world > 64) return -(int)hipErrorInvalidValue;
@@ -362,8 +385,8 @@ static int xrows_impl(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs
     else return -(int)hipErrorInvalidValue;
     // rows of up to 32 K floats per direction (a 2048-wide image: 2 ghost rows of 4 channels): ONE workgroup, no ticket; longer ones: 8 workgroups
     const int grid = std::max(tf, tl) <= 32768 ? 1 : 8, block = 256;
-    if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, zstate, zk, ztol);
-    else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, (float*)nullptr, 0, 0.0f, aD2, s3_2, nb2);
+    if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, zstate, zk, ztol, (const float*)nullptr, (const double*)nullptr, 0, us, ur, unit_slot);
+    else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, (float*)nullptr, 0, 0.0f, aD2, s3_2, nb2, us, ur, unit_slot);
     return check_launch();
 }
 
@@ -397,6 +420,19 @@ int thallo_hip_dist_xscalars_shard(thallo_dist_t d, thallo_xrows_t x, thallo_sum
     x.above = -1; x.below = -1;
     return xrows_impl(d, x, nullptr, none, none, none, none, 1, alphaN, own_alphaD_partials, own_s3_partials, own_count, poison, alphaD_word, betaN_word, nullptr, 0, 0.0f, stream,
                       shared_alphaD_partials, shared_s3_partials, shared_count);
+}
+
+int thallo_hip_dist_xunits(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_units_t send, thallo_units_t recv, long unit_slot_floats,
+                           int mode, thallo_sum_t local_or_alphaN, const float* alphaD_partials, const double* s3_partials, int count, int poison,
+                           float* out0, float* out1, thallo_stream_t stream)
+{
+    long per = 0; for (int k = 0; k < send.nplanes && k < 8; ++k) per += send.len[k];
+    if (send.n < 0 || recv.n < 0 || send.nplanes < 1 || send.nplanes > 8 || recv.nplanes != send.nplanes || (send.n && !send.units) || (recv.n && (!recv.units || !recv.src)) ||
+        (long)send.n * per > unit_slot_floats || unit_slot_floats > 32768 || ((send.n || recv.n) && !vec)) return -(int)hipErrorInvalidValue;
+    const thallo_segs_t none = {};
+    x.above = -1; x.below = -1;
+    return xrows_impl(d, x, vec, none, none, none, none, mode, local_or_alphaN, alphaD_partials, s3_partials, count, poison, out0, out1, nullptr, 0, 0.0f, stream,
+                      nullptr, nullptr, 0, send, recv, unit_slot_floats);
 }
 
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream)

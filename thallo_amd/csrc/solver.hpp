@@ -65,7 +65,8 @@ struct DistState {
     thallo_segs_t pieces_first, pieces_mine;
     // ... or, partition form (ThalloX_PlanSetGhostExchange): the rank holds its owned units [0, row1) + ghost units; only the boundary units' values travel
     bool part = false;
-    DeviceBuffer g_boundary, g_ghost, g_src1, g_src7;       // device copies of the index lists; element offsets of the ghosts' sources for the two message kinds
+    DeviceBuffer g_boundary, g_ghost, g_src1, g_src7, g_srcx;   // (g_srcx: the ghosts' sources inside this rank's device-side inbox)
+    thallo_units_t u_recvx; long unit_slot = 0;              // device-side exchange of the partition form (thallo_hip_dist_xunits)       // device copies of the index lists; element offsets of the ghosts' sources for the two message kinds
     thallo_units_t u_send, u_recv1, u_recv7;
     long piece_floats = 0;                               // floats a rank owns in a flat vector
     // shard form (bundle adjustment: camera shards): the unknowns [sh_off, sh_off + sh_len) (the points) are replicated; their J^T F / diag / A p are

@@ -220,6 +220,11 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
             D.u_send = un; D.u_send.units = (const int*)D.g_boundary.ptr; D.u_send.n = (int)G.boundary.size();
             D.u_recv1 = un; D.u_recv1.units = (const int*)D.g_ghost.ptr; D.u_recv1.src = (const long*)D.g_src1.ptr; D.u_recv1.n = (int)G.ghost.size();
             D.u_recv7 = D.u_recv1; D.u_recv7.src = (const long*)D.g_src7.ptr;
+            D.unit_slot = per_unit * maxb;
+            std::vector<long> sx(G.ghost.size());
+            for (size_t g = 0; g < G.ghost.size(); ++g) sx[g] = (long)G.src_rank[g] * D.unit_slot + (long)G.src_pos[g] * per_unit;
+            mem = mem && !up(D.g_srcx, sx.data(), sx.size() * sizeof(long));
+            D.u_recvx = D.u_recv1; D.u_recvx.src = (const long*)D.g_srcx.ptr;
             bool all = false;
             if (dist_agree(ok && mem, all)) return -1;
             if (!all) { set_error(!ok ? "distributed: a ghost's source position lies outside its source rank's boundary list" : mem ? "distributed: another rank's ghost exchange lists are inconsistent (or it ran out of device memory)" : "distributed: out of device memory"); return -1; }
@@ -232,8 +237,21 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (dist_agree(mem, all)) return -1;
         if (!all) { set_error(mem ? "distributed: another rank ran out of device memory" : "distributed: out of device memory"); return -1; }
         char buf[256];
-        if (part) snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit partition: %ld owned + %ld ghost units, %d boundary units sent\", \"rank\": %d, \"world\": %d}",
-                           u1, U - u1, D.u_send.n, cfg.rank, cfg.world);
+        if (part) {       // device-side exchange of the boundary units (thallo_hip_dist_xunits): scalar ring + one inbox area per (parity, source rank)
+            D.want_p2p = cfg.device_exchange != 0 && D.unit_slot <= 32768;
+            {   const char* e = env_switch("THALLO_DIST_P2P"); if (e && e[0] == '0') D.want_p2p = false; }
+            const bool ctl_ok = !(D.ctl.alloc(THALLO_DIST_CTL_WORDS * sizeof(unsigned)) || hipMemset(D.ctl.ptr, 0, THALLO_DIST_CTL_WORDS * sizeof(unsigned)) != hipSuccess);
+            bool allp = false;
+            if (dist_agree(D.want_p2p && ctl_ok, allp)) return -1;
+            D.want_p2p = allp;
+            if (D.want_p2p) {
+                memset(&D.xr, 0, sizeof(D.xr)); D.xr.ring0 = 0; D.xr.above = D.xr.below = -1;
+                D.xr.inbox_off = (8L * 32 * cfg.world + 255) / 256 * 256;
+                if (dist_map_mail(D.xr.inbox_off + 2L * cfg.world * D.unit_slot * (long)sizeof(float))) return -1;
+            }
+        }
+        if (part) snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit partition: %ld owned + %ld ghost units, %d boundary units sent\", \"rank\": %d, \"world\": %d, \"device_exchange_requested\": %s}",
+                           u1, U - u1, D.u_send.n, cfg.rank, cfg.world, cfg.device_exchange ? "true" : "false");
         else snprintf(buf, sizeof(buf), "{\"exchange\": \"allgather\", \"form\": \"unit ranges, full-length vectors\", \"rank\": %d, \"world\": %d}", cfg.rank, cfg.world);
         D.info = buf;
         return 0;
@@ -464,12 +482,12 @@ float Plan::dist_cost()
         if (plugin->resident_status(ctx, 1, pm) != 0)
             dist_fail("a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u)", pm[0], pm[1], pm[2], pm[3], pm[4]);
     }
-    if ((D.flat || D.shard) && D.p2p_on && !D.failed) {  // the device-side row exchange's (all-reduce's) waits are bounded too
+    if ((D.flat || D.shard || D.part) && D.p2p_on && !D.failed) {  // the device-side row exchange's (all-reduce's) waits are bounded too
         const int err = thallo_hip_dist_error(D.d, 1, s);
         if (err != 0) {
             unsigned pm[5] = { 0, 0, 0, 0, 0 };
             hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
-            dist_fail("a bounded wait of the device-side %s ran out (slot %u, source rank %u, tag %u, found %u)", D.shard ? "all-reduce" : "row exchange", pm[0], pm[1], pm[2], pm[3]);
+            dist_fail("a bounded wait of the device-side %s ran out (slot %u, source rank %u, tag %u, found %u)", D.shard ? "all-reduce" : D.part ? "boundary exchange" : "row exchange", pm[0], pm[1], pm[2], pm[3]);
         }
     }
     int nb = 0;
@@ -731,6 +749,14 @@ int Plan::dist_ghosts(float* vec, int sum_slot)
     hipStream_t s = ctx.stream;
     float* send = (float*)D.send.ptr; float* gath = (float*)D.gath.ptr;
     const thallo_sum_t nothing = { nullptr, 0 };
+    if (D.xrows_now) {       // one launch, no collective
+        const thallo_sum_t sm = sum_slot < 0 ? nothing : D.failed ? thallo_sum_t{ (const float*)D.send.ptr, 1 } : partial_sum(sum_slot);
+        int rc = thallo_hip_dist_xunits(D.d, D.xr, vec, D.u_send, D.u_recvx, D.unit_slot, 0, sm, nullptr, nullptr, 0, D.failed ? 1 : 0, sum_slot >= 0 ? scal(sum_slot) : nullptr, nullptr, s);
+        if (D.inject > 0 && !D.failed && --D.inject == 0) rc = -999;
+        if (rc < 0 && !D.failed) dist_fail("device-side boundary exchange failed (%d)", rc);
+        if (sum_slot >= 0 && !D.failed) fin_[sum_slot] = 1;
+        return 0;
+    }
     DLOCAL(thallo_hip_units_pack(vec, D.u_send, sum_slot >= 0 ? partial_sum(sum_slot) : nothing, send, s), "boundary pack");
     if (dist_allgather(send, gath, D.msg * (long)sizeof(float))) return -1;
     DLOCAL(thallo_hip_units_unpack(vec, D.u_recv1, gath, D.msg, D.cfg.world, sum_slot >= 0 ? scal(sum_slot) : nullptr, s), "ghost unpack");
@@ -772,6 +798,15 @@ int Plan::dist_gn_range(int L)
         }
         cur_ ^= 1;
         TimedLaunch t(ctx, "RangeExchange");
+        if (D.part && D.xrows_now) {
+            const thallo_sum_t dummy = { (const float*)D.send.ptr, 1 };
+            int rc = thallo_hip_dist_xunits(D.d, D.xr, v_.Ap, D.u_send, D.u_recvx, D.unit_slot, 1, D.failed ? dummy : sum(jN), D.failed ? (const float*)D.send.ptr : slot(jD), v_.s12,
+                                            D.failed ? 1 : nb, D.failed ? 1 : 0, scal(jD), scal(jB), s);
+            if (D.inject > 0 && !D.failed && --D.inject == 0) rc = -999;
+            if (rc < 0 && !D.failed) dist_fail("device-side boundary exchange failed (%d)", rc);
+            if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+            continue;
+        }
         if (D.part) {       // [alphaD | N, S1, S2 | A p at my boundary units] -> the ghosts' A p (r, p, delta of a ghost then follow from the same arithmetic as its owner's)
             DLOCAL(thallo_hip_units_pack_iter(v_.Ap, D.u_send, slot(jD), v_.s12, nb, send, s), "boundary pack");
             if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
@@ -883,6 +918,54 @@ int Plan::dist_self_check()
     D.checked = true;
     if (!D.mapped) { D.p2p_on = false; return 0; }                       // (agreed in dist_map_peers: the same on every rank)
     hipStream_t s = ctx.stream;
+    if (D.part) {
+        // partition form: three exchanges of a pattern: the boundary unit at position `pos` of rank r's list carries (r * 4096 + pos) * 8 + c + t in its c-th float
+        const unsigned spin_ms = 500, zero = 0;
+        int per = 0; for (int k = 0; k < D.u_send.nplanes; ++k) per += D.u_send.len[k];
+        const GhostSpec& G = ghost_spec_;
+        std::vector<float> host((size_t)v_.n, 0.0f), back((size_t)v_.n);
+        auto put = [&](std::vector<float>& v, int unit, int c, float x) { int k = 0; while (c >= D.u_send.len[k]) { c -= D.u_send.len[k]; ++k; } v[(size_t)(D.u_send.base[k] + (long)unit * D.u_send.len[k] + c)] = x; };
+        auto get = [&](const std::vector<float>& v, int unit, int c) { int k = 0; while (c >= D.u_send.len[k]) { c -= D.u_send.len[k]; ++k; } return v[(size_t)(D.u_send.base[k] + (long)unit * D.u_send.len[k] + c)]; };
+        bool pass = true; float got_sum = 0.0f;
+        DCOPY(hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &spin_ms, sizeof(unsigned), hipMemcpyHostToDevice, s), "spin bound");
+        D.xrows_now = true;
+        for (int t = 0; t < 3; ++t) {
+            std::fill(host.begin(), host.end(), -1.0f);
+            for (size_t b = 0; b < G.boundary.size(); ++b) for (int c = 0; c < per; ++c) put(host, G.boundary[b], c, (float)((D.cfg.rank * 4096 + (int)b) * 8 + c + t));
+            const float mine = (float)(D.cfg.rank + 1 + t);
+            DCOPY(hipMemcpyAsync(v_.Ap, host.data(), (size_t)v_.n * sizeof(float), hipMemcpyHostToDevice, s), "self-check pattern");
+            DCOPY(hipMemcpyAsync(D.send.ptr, &mine, sizeof(float), hipMemcpyHostToDevice, s), "self-check scalar");
+            int rc = thallo_hip_dist_xunits(D.d, D.xr, v_.Ap, D.u_send, D.u_recvx, D.unit_slot, 0, thallo_sum_t{ (const float*)D.send.ptr, 1 }, nullptr, nullptr, 0, D.failed ? 1 : 0,
+                                            (float*)D.send.ptr + 8, nullptr, s);
+            if (rc < 0 && !D.failed) dist_fail("device-side boundary exchange failed (%d)", rc);
+            DCOPY(hipMemcpyAsync(back.data(), v_.Ap, (size_t)v_.n * sizeof(float), hipMemcpyDeviceToHost, s), "self-check read-back");
+            DCOPY(hipMemcpyAsync(&got_sum, (float*)D.send.ptr + 8, sizeof(float), hipMemcpyDeviceToHost, s), "self-check read-back");
+            DCOPY(hipStreamSynchronize(s), "synchronise");
+            if (D.failed) { pass = false; continue; }
+            float want_sum = 0.0f; for (int r = 0; r < D.cfg.world; ++r) want_sum += (float)(r + 1 + t);
+            if (got_sum != want_sum) pass = false;
+            for (size_t g = 0; g < G.ghost.size() && pass; ++g)
+                for (int c = 0; c < per; ++c) if (get(back, G.ghost[g], c) != (float)((G.src_rank[g] * 4096 + G.src_pos[g]) * 8 + c + t)) { pass = false; break; }
+        }
+        D.xrows_now = false;
+        int err = !D.failed ? thallo_hip_dist_error(D.d, 1, s) : -1;
+        unsigned pm[5] = { 0, 0, 0, 0, 0 };
+        hipMemcpy(pm, (unsigned*)D.ctl.ptr + 4, sizeof(pm), hipMemcpyDeviceToHost);
+        hipMemcpyAsync((unsigned*)D.ctl.ptr + 2, &zero, sizeof(unsigned), hipMemcpyHostToDevice, s);
+        hipMemsetAsync(v_.Ap, 0, (size_t)v_.n * sizeof(float), s);
+        hipStreamSynchronize(s);
+        pass = pass && !D.failed && err == 0;
+        bool all = false;
+        if (dist_agree(pass, all)) return -1;
+        D.p2p_on = all; D.xrows_now = all;
+        const size_t at = D.info.find("\"allgather\"");
+        if (all && at != std::string::npos) D.info.replace(at, 11, "\"p2p-units\"");
+        char buf[256];
+        snprintf(buf, sizeof(buf), ", \"self_check\": {\"exchanges\": 3, \"timeout\": %d, \"pass\": %s, \"all_ranks_pass\": %s, \"post_mortem\": [%u, %u, %u, %u, %u]}}", err, pass ? "true" : "false",
+                 all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
+        if (!D.info.empty() && D.info.back() == '}') { D.info.pop_back(); D.info += buf; }
+        return 0;
+    }
     if (D.shard) {
         // shard form: three all-reduces (both parities, three ring positions) of a pattern whose sum is known exactly: rank r contributes (r + 1) * (i % 7 + 1)
         const long len = D.sh_len;
@@ -1046,6 +1129,8 @@ int Plan::dist_control(int what, int value)
             if (at != std::string::npos) D.info.replace(at, 13, "\"allgather\", \"switched_off\": true");
             at = D.info.find("\"p2p-rows\"");
             if (at != std::string::npos) D.info.replace(at, 10, "\"allgather\", \"switched_off\": true");
+            at = D.info.find("\"p2p-units\"");
+            if (at != std::string::npos) D.info.replace(at, 11, "\"allgather\", \"switched_off\": true");
             at = D.info.find("\"p2p-allreduce + allgather\"");
             if (at != std::string::npos) D.info.replace(at, 27, "\"allreduce + allgather\", \"switched_off\": true");
         }

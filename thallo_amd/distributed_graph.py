@@ -93,7 +93,7 @@ class GhostPartition:
 class PlanArapPartitionSolver:
     """arap_mesh_deformation over a real vertex partition: the Plan sees only the local sub-mesh."""
 
-    def __init__(self, params, rank, world, l_iters, group=None):
+    def __init__(self, params, rank, world, l_iters, group=None, device_exchange=True):
         w_fit, w_reg, pos, ang, orig, cons, v0, v1 = params
         N = pos.shape[0]
         self.part = part = GhostPartition(N, v0, v1, rank, world)
@@ -107,7 +107,7 @@ class PlanArapPartitionSolver:
         self.library_rccl = library_rccl(self.solver, rank, world, group)
         ag = torch_allgather(group, dev) if world > 1 and not self.library_rccl else None
         self.solver.set_ghost_exchange(part.boundary_units, part.ghost_units, part.ghost_src_rank, part.ghost_src_pos)
-        self.solver.set_distributed(rank, world, 0, part.n_own, allgather=ag, device_exchange=False)
+        self.solver.set_distributed(rank, world, 0, part.n_own, allgather=ag, device_exchange=device_exchange)      # device_exchange: the boundary values + scalars in ONE launch of peer stores
         self.params = self.solver.make_params([float(w_fit), float(w_reg), self.position, self.angle] + self._const)
 
     solve = PlanArapSolver.solve

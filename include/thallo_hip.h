@@ -476,6 +476,19 @@ int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg,
 int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
                             thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* alphaD_out, double* s3_out, thallo_fin_t fin, thallo_stream_t stream);
+/* Round 3 -- LM on one GPU: ONE launch per PCG iteration.  As thallo_hip_sfs_pcg_iter with A = J^T J + CtC, the LM preconditioner (z = pre r: thallo_hip_lm_finalize_diagonal's M^-1), the scalars divided blindly (gauss_newton.t:226-234), and
+ * besides alphaD / {N, S1, S2} the three sums of q's expansion in alpha: q_{k+1} = 0.5 [U + alpha (T1 - T2) - alpha^2 alphaD], U = delta_k.(r_k + b), T1 = p_k.(r_k + b),
+ * T2 = delta_k.(A p_k) (q3_out: 3 * THALLO_HIP_MAX_PARTIALS doubles; the reference forms q after the update, :801-843, 965).  The launch's last workgroup (fin.tickets is
+ * required) finishes alphaD_k, betaN_k, q_{k+1} and applies thallo_hip_lm_zeta's test to lm_state; once lm_state[1] (the gate) is set later launches return at once, and
+ * thallo_hip_lm_owed_delta adds the one update of delta the loop still owes.  Replaces thallo_hip_sfs_apply_jtj_lm_pupdate + thallo_hip_pcg_step2_full_zeta. */
+int thallo_hip_sfs_pcg_iter_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                               const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, const float* CtC, const float* b,
+                               const float* pre, int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* alphaD_out, double* s3_out, double* q3_out,
+                               thallo_fin_t fin, float* lm_state, int k, float q_tolerance, thallo_stream_t stream);
+/* delta += alpha_kl p_kl with kl = (lm_state[1] ? lm_state[2] : L) - 1: the update of delta the one-launch LM loop owes when it ends (by the gate or after L iterations).
+ * p_even / p_odd: the buffers holding p_k for even / odd k; alphaN_words / alphaD_words: pointers to the scalar words of iteration 0, `word_stride` floats apart per iteration. */
+int thallo_hip_lm_owed_delta(float* delta, const float* p_even, const float* p_odd, long n, const float* alphaN_words, const float* alphaD_words, int word_stride,
+                             const float* lm_state, int L, thallo_stream_t stream);
 int thallo_hip_sfs_lm_pupdate_supported(void);
 /* ... and for a W-wide image: no more 60-pixel column strips than the device has workgroup slots (otherwise the LDS-tiled kernels run) */
 int thallo_hip_sfs_march_fits(int W);

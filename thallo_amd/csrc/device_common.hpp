@@ -266,6 +266,98 @@ __device__ __forceinline__ void block_finish_sums(float acc, const Sums3& sm, fl
     if (lane == 0) { fin.aD_word[0] = ad; fin.bN_word[0] = (float)bn; }
 }
 
+// ---- Levenberg-Marquardt iteration in ONE launch (round 3; shape_from_shading).  The reference's PCGStep2 forms q_{k+1} = 0.5 delta_{k+1} . (r_{k+1} + b) AFTER the
+// vector update (gauss_newton.t:801-843, 965); with delta_{k+1} = delta_k + alpha p_k and r_{k+1} = r_k - alpha A p_k that is
+//   q_{k+1} = 0.5 [ U + alpha (T1 - T2) - alpha^2 alphaD ],   U = delta_k.(r_k + b),  T1 = p_k.(r_k + b),  T2 = delta_k.A p_k
+// -- three more sums over what a kernel that carries the vector update already holds (delta_k, r_k, p_k, A p_k) plus b, taken in double like N, S1, S2.  The launch's
+// last workgroup then has alpha_k, betaN_k AND q_{k+1}, applies the zeta test (k_lm_zeta's rule, :1666-1686) and sets the gate.
+struct SumsQ {
+    double u = 0.0, t1 = 0.0, t2 = 0.0;
+    __device__ __forceinline__ void add(float d, float r, float b, float p, float a)
+    {
+        const double rb = (double)r + (double)b;
+        u += (double)d * rb; t1 += (double)p * rb; t2 += (double)d * (double)a;
+    }
+};
+struct LmFin {
+    const float* b;                         // b == NULL: not an LM launch
+    double* q3_out;                         // {U, T1, T2} per workgroup slot (3 * THALLO_MAX_PARTIALS doubles)
+    float* state;                           // lm state words: [0] Q0, [1] gate, [2] iterations done at the stop
+    int k; float q_tol;
+};
+__device__ __forceinline__ void load_sums3_wave(const double* s3, int nb, double& a, double& b, double& c)
+{   // one wave; four slots per lane and round with all twelve loads in flight (the read-back sits between two dependent launches), then the butterfly
+    typedef unsigned long long u64_t;
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    const u64_t* sp = reinterpret_cast<const u64_t*>(s3);
+    double x = 0.0, y = 0.0, z = 0.0;
+    for (int i0 = lane; i0 < nb; i0 += 4 * THALLO_WAVE) {
+        double v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * THALLO_WAVE;
+            const bool ok = i < nb;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[u][q] = ok ? __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x += v[u][0]; y += v[u][1]; z += v[u][2]; }
+    }
+    a = wave_sum_all_f64(x); b = wave_sum_all_f64(y); c = wave_sum_all_f64(z);
+}
+// block_finish_sums for an LM launch: also the {U, T1, T2} slot, and the last workgroup finishes alphaD_k, betaN_k, q_{k+1} and the zeta test.
+// red >= 16 floats, redd >= 6 * (blockDim.x / 64) doubles of LDS.  fin.tickets must be set.
+__device__ __forceinline__ void block_finish_sums_lm(float acc, const Sums3& sm, const SumsQ& sq, float* __restrict__ aD_out, double* __restrict__ s3_out, const FinArgs& fin,
+                                                     const LmFin& lm, float* red, double* redd)
+{
+    typedef unsigned long long u64_t;
+    const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
+    const int nw = (blockDim.x + THALLO_WAVE - 1) / THALLO_WAVE;
+    const float wa = wave_sum_all(acc);
+    const double w0 = wave_sum_all_f64(sm.n), w1 = wave_sum_all_f64(sm.s1), w2 = wave_sum_all_f64(sm.s2);
+    const double w3 = wave_sum_all_f64(sq.u), w4 = wave_sum_all_f64(sq.t1), w5 = wave_sum_all_f64(sq.t2);
+    if (lane == 0) { red[wave] = wa; double* d = redd + 6 * wave; d[0] = w0; d[1] = w1; d[2] = w2; d[3] = w3; d[4] = w4; d[5] = w5; }
+    lds_barrier();
+    const int slot = fin.blk_off + blockIdx.x;
+    if (threadIdx.x == 0) {
+        float a = 0.0f; double b[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+        for (int w = 0; w < nw; ++w) { a += red[w]; for (int q = 0; q < 6; ++q) b[q] += redd[6 * w + q]; }
+        __hip_atomic_store(aD_out + slot, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64_t* sp = reinterpret_cast<u64_t*>(s3_out) + 3 * slot; u64_t* qp = reinterpret_cast<u64_t*>(lm.q3_out) + 3 * slot;
+        for (int q = 0; q < 3; ++q) {
+            __hip_atomic_store(sp + q, (u64_t)__double_as_longlong(b[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(qp + q, (u64_t)__double_as_longlong(b[3 + q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned grp = blockIdx.x % 32, members = (gridDim.x - grp + 31) / 32, groups = gridDim.x < 32 ? gridDim.x : 32;
+        unsigned* sub = fin.tickets + 16 + 16 * grp;
+        bool last = false;
+        if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(fin.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+        }
+        red[15] = last ? 1.0f : 0.0f;
+    }
+    lds_barrier();
+    if (red[15] == 0.0f || wave != 0) return;
+    const IterationSums S = load_iteration_sums(aD_out, s3_out, fin.nb_total, fin.alphaN);
+    double U, T1, T2;
+    load_sums3_wave(lm.q3_out, fin.nb_total, U, T1, T2);
+    if (lane == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float al = safe_div<true>(S.an, S.ad);                 // LM divides blindly (gauss_newton.t:226-234)
+    double bn = S.n - 2.0 * (double)al * S.s1 + (double)al * (double)al * S.s2;
+    if (!(bn > 0.0)) bn = 0.0;
+    const float Q1 = (float)(0.5 * (U + (double)al * (T1 - T2) - (double)al * (double)al * (double)S.ad));
+    if (lane == 0) {
+        fin.aD_word[0] = S.ad; fin.bN_word[0] = (float)bn;
+        const float Q0 = lm.state[0];                             // k_lm_zeta's rule
+        const float zt = (float)(lm.k + 1) * (Q1 - Q0) / Q1;
+        const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < lm.q_tol;
+        if (stop) { reinterpret_cast<unsigned*>(lm.state)[1] = 1u; reinterpret_cast<int*>(lm.state)[2] = lm.k + 1; }
+        else lm.state[0] = Q1;
+    }
+}
+
 // guardedInvert, CERES flavour (gauss_newton.t:638-648)
 __device__ __forceinline__ float guarded_invert(float d)
 {

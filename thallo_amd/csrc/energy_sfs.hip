@@ -372,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Geo g, Cam cm, const float* __r
 constexpr int MS_USE = 60, MS_NT = 256;
 constexpr int MS_OCC = 2, MS_WG_PER_CU = 2;      // registers for 2 workgroups (8 waves) per CU; grid sized for that many (tools/sfs_probe.py sweeps)
 struct MsGeo { int W, H, ra, rb, yoff, R, nstrips, total; };
-struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct, pv, av, dl; };      // one row of one lane as loaded (pv: p_{k-1} of the row, PUPD / UPD; av, dl: Ap_{k-1}, delta, UPD)
+struct MsRaw { float4 g; float2 w; float v; unsigned f; float rs, ct, pv, av, dl, bb, mi; };      // one row of one lane as loaded (pv: p_{k-1} of the row, PUPD / UPD; av, dl: Ap_{k-1}, delta, UPD; bb: b of the OUTPUT row, mi: M^-1 of the row, LMQ)
 
 // value of lane-1 / lane+1 (wave_shr:1 / wave_shl:1); a lane without a source reads 0 (bound_ctrl) -- lanes 0 / 63 produce no output.
 // mov_dpp has no tied "old" operand: one v_mov_b32_dpp per exchange, and the compiler may fold it into the consuming instruction.
@@ -383,10 +383,11 @@ __device__ __forceinline__ void ms_mv(float& d, const float& s) { asm volatile("
 __device__ __forceinline__ void ms_mv(unsigned& d, const unsigned& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
 // a prefetch slot moves into fresh registers with real v_mov instructions, so that its refill can be issued into the SAME registers right
 // behind (energy_image_warping_march.hip `take`: otherwise the compiler computes in place and the refill turns into a blocking load)
-template <bool SUMS, bool CTC, bool INIT, bool PUPD = false, bool UPD = false>
+template <bool SUMS, bool CTC, bool INIT, bool PUPD = false, bool UPD = false, bool LMQ = false>
 __device__ __forceinline__ void ms_take(MsRaw& d, const MsRaw& s)
 {
-    d.pv = 0.0f; d.av = 0.0f; d.dl = 0.0f;
+    d.pv = 0.0f; d.av = 0.0f; d.dl = 0.0f; d.bb = 0.0f; d.mi = 1.0f;
+    if (LMQ) { ms_mv(d.bb, s.bb); ms_mv(d.mi, s.mi); }
     if (PUPD || UPD) ms_mv(d.pv, s.pv);
     if (UPD) { ms_mv(d.av, s.av); ms_mv(d.dl, s.dl); }
     ms_mv(d.g.x, s.g.x); ms_mv(d.g.y, s.g.y); ms_mv(d.g.z, s.g.z); ms_mv(d.w.x, s.w.x); ms_mv(d.w.y, s.w.y); ms_mv(d.v, s.v); ms_mv(d.f, s.f);
@@ -407,25 +408,29 @@ struct MsPupd { const float* p_in; float* p_out; thallo_sum_t aN, bN; int first;
 // r_k = r_{k-1} - alpha_{k-1} Ap_{k-1} and p_k = r_k + beta_{k-1} p_{k-1} (no preconditioner in this energy; halo rows and lanes redundantly), stores r_k, p_k
 // and delta += alpha_{k-1} p_{k-1} for its own rows, applies J^T J to p_k, and the three sums take r_k from registers.  r, Ap and p ping-pong
 // (the neighbours' halo rows re-read the previous iteration's planes while the owner writes this iteration's).
-struct MsUpd { float* r_out; const float* A_in; const float* p_in; float* p_out; float* delta; thallo_sum_t aN, aD, bN; int first; };
-template <bool SUMS, bool CTC, bool INIT, bool DIAG, int OCC, bool PUPD = false, bool UPD = false>
+struct MsUpd { float* r_out; const float* A_in; const float* p_in; float* p_out; float* delta; thallo_sum_t aN, aD, bN; int first; int lm; const float* b; const float* pre; };
+// LMQ (with UPD, SUMS, CTC; LM on one GPU): the whole LM iteration in this launch -- the vector update of PCGStep2 (iteration k-1's scalars), PCGStep3, (J^T J + CtC) p_k,
+// with the LM preconditioner M^-1 (`pre`: z = M^-1 r, one more plane per row taken), and besides alphaD and {N, S1, S2} the three sums {U, T1, T2} of q's expansion in alpha (device_common.hpp SumsQ: delta_k, r_k, p_k, A p_k are in registers, b is
+// one more plane read at the output row); the last workgroup finishes alphaD_k, betaN_k, q_{k+1} and the zeta test (block_finish_sums_lm).
+template <bool SUMS, bool CTC, bool INIT, bool DIAG, int OCC, bool PUPD = false, bool UPD = false, bool LMQ = false>
 __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const float* __restrict__ v, const float* __restrict__ ctc,
                                                       const float4* __restrict__ G, const float2* __restrict__ Wt, const unsigned char* __restrict__ fl,
                                                       float* __restrict__ out, float* __restrict__ part_out, const float* __restrict__ rs,
                                                       double* __restrict__ s3_out, const unsigned* __restrict__ gate, FinArgs fin,
                                                       float* __restrict__ z, float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ diag,
-                                                      MsPupd pu = MsPupd{}, MsUpd up = MsUpd{})
+                                                      MsPupd pu = MsPupd{}, MsUpd up = MsUpd{}, LmFin lmf = LmFin{})
 {
     __shared__ float red[16];
-    __shared__ double redd[3 * MS_NT / 64];
+    __shared__ double redd[(LMQ ? 6 : 3) * MS_NT / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
     float beta = 0.0f;
     if (PUPD && !pu.first) beta = safe_div<true>(sum_partials(pu.bN.partials, pu.bN.count), sum_partials(pu.aN.partials, pu.aN.count));      // as k_pupdate (LM)
     float alpha = 0.0f;
     if (UPD && !up.first) {                                                                                                                      // as k_pcg_update
         const float an = sum_partials(up.aN.partials, up.aN.count);
-        alpha = safe_div<false>(an, sum_partials(up.aD.partials, up.aD.count));
-        beta  = safe_div<false>(sum_partials(up.bN.partials, up.bN.count), an);
+        const float ad = sum_partials(up.aD.partials, up.aD.count), bn = sum_partials(up.bN.partials, up.bN.count);
+        alpha = up.lm ? safe_div<true>(an, ad) : safe_div<false>(an, ad);             // (LM divides blindly, gauss_newton.t:226-234)
+        beta  = up.lm ? safe_div<true>(bn, an) : safe_div<false>(bn, an);
     }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // (uniform: rows, row addresses and guards stay scalar)
     const int W = g.W, H = g.H;
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
     // coef_0 at x-1, x, x+1 (coef_2 = 1); coef_1 per row, carried
     const float cxm = coef(cm, 0, x - 1, 0), cxc = coef(cm, 0, x, 0), cxp = coef(cm, 0, x + 1, 0);
 
-    float acc = 0.0f; Sums3 sm;
+    float acc = 0.0f; Sums3 sm; SumsQ sq;
     if (work) {
         const int t_first = ya - 2, t_last = yb + 1;
         // loads are unconditional (addresses clamped, validity applied when the row is taken): a load under a branch is waited for at once.
@@ -467,6 +472,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                 s.pv = (up.p_in + rowoff)[xc_]; s.av = (up.A_in + rowoff)[xc_];
                 const int td = t < ya ? ya : t > yb - 1 ? yb - 1 : t;          // delta: the segment's own rows only
                 s.dl = (up.delta + (long)td * W)[xc_];
+                if (LMQ) s.mi = (up.pre + rowoff)[xc_];
             }
             // the aligned dword that holds the pixel's flags byte (shifted when the row is taken): a byte load leaves a zero-extension for the
             // compiler to place, and it places it at the loop latch behind a wait for the fresh load (energy_image_warping_march.hip)
@@ -476,6 +482,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                 const long ro = (long)yo * W;
                 if (SUMS && !UPD) s.rs = (rs + ro)[xc_];
                 if (CTC) s.ct = (ctc + ro)[xc_];
+                if (LMQ) s.bb = (up.b + ro)[xc_];
             }
         };
         // State carried from row to row: rings of three indexed by the row modulo 3.  Three rows are taken per loop trip, so every index is a
@@ -484,6 +491,8 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
         float Gx[3] = { 0.f, 0.f, 0.f }, Gy[3] = { 0.f, 0.f, 0.f }, Gz[3] = { 0.f, 0.f, 0.f }, Cy[3] = { 0.f, 0.f, 0.f }, Wy[3] = { 0.f, 0.f, 0.f };
         float Wx[3] = { 0.f, 0.f, 0.f };       // (DIAG) the rows' h weights, zero outside the image like Wy
         float Rk[3] = { 0.f, 0.f, 0.f };       // (UPD) r_k of the rows
+        float Dk[3] = { 0.f, 0.f, 0.f };       // (LMQ) delta_k of the rows
+        float Mk[3] = { 1.f, 1.f, 1.f };       // (LMQ) M^-1 of the rows
         unsigned Fl[3] = { 0u, 0u, 0u };
         bool Wn[3] = { false, false, false };
         float Rr[3][3] = { { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f } };
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                 const int t = t0 + j;
                 const int k0 = j, k1 = (j + 2) % 3, k2 = (j + 1) % 3;          // ring slots of rows t, t-1, t-2 (and t-3 = t)
                 MsRaw cur;
-                ms_take<SUMS, CTC, INIT, PUPD, UPD>(cur, slot[j]);
+                ms_take<SUMS, CTC, INIT, PUPD, UPD, LMQ>(cur, slot[j]);
                 ms_fence();
                 issue(slot[j], t + 3 > t_last ? t_last : t + 3);
                 ms_fence();
@@ -505,14 +514,16 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                     const bool ok = xin && t >= 0 && t < H;
                     float rk = cur.v;
                     if (UPD && !up.first) rk = __builtin_fmaf(-alpha, cur.av, rk);
-                    const float v0 = ok ? (PUPD ? cur.v + beta * cur.pv : UPD ? rk + beta * cur.pv : cur.v) : 0.0f;
+                    const float v0 = ok ? (PUPD ? cur.v + beta * cur.pv : UPD ? (LMQ ? cur.mi * rk : rk) + beta * cur.pv : cur.v) : 0.0f;      // (LMQ: p_k = M^-1 r_k + beta p_{k-1})
                     if (PUPD && t >= ya && t < yb && xout) (pu.p_out + (long)t * W)[(unsigned)x] = v0;
                     if (UPD) {
                         Rk[k0] = rk;
+                        const float dk = up.first ? cur.dl : __builtin_fmaf(alpha, cur.pv, cur.dl);
+                        if (LMQ) { Dk[k0] = dk; Mk[k0] = cur.mi; }
                         if (t >= ya && t < yb && xout) {
                             const long ro = (long)t * W;
                             (up.r_out + ro)[(unsigned)x] = rk; (up.p_out + ro)[(unsigned)x] = v0;
-                            if (!up.first) (up.delta + ro)[(unsigned)x] = __builtin_fmaf(alpha, cur.pv, cur.dl);
+                            if (!up.first) (up.delta + ro)[(unsigned)x] = dk;
                         }
                     }
                     const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;
@@ -588,7 +599,8 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                         } else {
                             if (CTC) s += cur.ct * vc;
                             (out + (long)y * W)[(unsigned)x] = s; acc += vc * s;
-                            if (SUMS) sm.add(1.0f, UPD ? Rk[k2] : cur.rs, s);
+                            if (SUMS) sm.add(LMQ ? Mk[k2] : 1.0f, UPD ? Rk[k2] : cur.rs, s);
+                            if (LMQ) sq.add(Dk[k2], Rk[k2], cur.bb, vc, s);
                         }
                     }
                     Vv[k0] = v0; Fl[k0] = f0; Wn[k0] = wn0; Wy[k0] = cur.w.y; if (DIAG) Wx[k0] = ok ? cur.w.x : 0.0f; dB[k0] = dB0; Uh[k0] = Uh0; Uv[k1] = Uv1; Tt[k1] = T1;
@@ -599,7 +611,8 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
             }
         }
     }
-    if (SUMS) block_finish_sums(acc, sm, part_out, s3_out, fin, red, redd);
+    if (LMQ) block_finish_sums_lm(acc, sm, sq, part_out, s3_out, fin, lmf, red, redd);
+    else if (SUMS) block_finish_sums(acc, sm, part_out, s3_out, fin, red, redd);
     else block_store_partial(acc, part_out, red);
 }
 
@@ -957,11 +970,33 @@ int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, 
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
-    const MsUpd up = { r_out, first ? r_in : Ap_in, p_in, p_out, delta, alphaN_prev, alphaD_prev, betaN_prev, first ? 1 : 0 };     // (first: Ap_in is not used; any readable plane)
+    const MsUpd up = { r_out, first ? r_in : Ap_in, p_in, p_out, delta, alphaN_prev, alphaD_prev, betaN_prev, first ? 1 : 0, 0, nullptr, nullptr };     // (first: Ap_in is not used; any readable plane)
     const FinArgs fa{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridm };
     hipLaunchKernelGGL((k_march<true, false, false, false, MS_OCC, false, true>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cam_of(host_params), r_in, (const float*)nullptr,
                        (const float4*)G, (const float2*)Wt, fl, Ap_out, aD_out, (const float*)nullptr, s3_out, (const unsigned*)nullptr, fa,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, MsPupd{}, up);
+    int e = check_launch(); return e ? e : gridm;
+}
+
+int thallo_hip_sfs_pcg_iter_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                               const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, const float* CtC, const float* b,
+                               const float* pre, int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* aD_out, double* s3_out, double* q3_out,
+                               thallo_fin_t fin, float* lm_state, int k, float q_tolerance, thallo_stream_t stream)
+{
+    if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !delta || !aD_out || !s3_out || !q3_out ||
+        q3_out == s3_out || !CtC || !b || !pre || !lm_state) return -(int)hipErrorInvalidValue;
+    if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !alphaD_prev.partials || !betaN_prev.partials)) return -(int)hipErrorInvalidValue;
+    if (!fin.tickets || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials) return -(int)hipErrorInvalidValue;
+    if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
+    const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
+    const int gridm = (mg.total + 7) / 8 * 8;
+    if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+    const MsUpd up = { r_out, first ? r_in : Ap_in, p_in, p_out, delta, alphaN_prev, alphaD_prev, betaN_prev, first ? 1 : 0, 1, b, pre };
+    const FinArgs fa{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridm };
+    const LmFin lf{ b, q3_out, lm_state, k, q_tolerance };
+    hipLaunchKernelGGL((k_march<true, true, false, false, MS_OCC, false, true, true>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cam_of(host_params), r_in, CtC,
+                       (const float4*)G, (const float2*)Wt, fl, Ap_out, aD_out, (const float*)nullptr, s3_out, reinterpret_cast<const unsigned*>(lm_state) + 1, fa,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, MsPupd{}, up, lf);
     int e = check_launch(); return e ? e : gridm;
 }
 

@@ -233,6 +233,23 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_update(float4* __restrict__ r, co
     }
 }
 
+// the update of delta the one-launch LM loop owes at its end (thallo_hip.h thallo_hip_lm_owed_delta)
+__global__ __launch_bounds__(BLOCK) void k_lm_owed_delta(float4* __restrict__ delta, const float4* __restrict__ p_even, const float4* __restrict__ p_odd, long n4,
+                                                          const float* __restrict__ aN_words, const float* __restrict__ aD_words, int stride, const float* __restrict__ state, int L)
+{
+    const unsigned gate = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned*>(state)[1]);
+    const int done = gate ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(state)[2]) : L;
+    const int kl = done - 1;
+    if (kl < 0) return;
+    const float alpha = safe_div<true>(aN_words[(long)kl * stride], aD_words[(long)kl * stride]);
+    const float4* __restrict__ p = (kl & 1) ? p_odd : p_even;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 d = delta[i]; const float4 pv = p[i];
+        d.x = __builtin_fmaf(alpha, pv.x, d.x); d.y = __builtin_fmaf(alpha, pv.y, d.y); d.z = __builtin_fmaf(alpha, pv.z, d.z); d.w = __builtin_fmaf(alpha, pv.w, d.w);
+        delta[i] = d;
+    }
+}
+
 // one wave: alphaD_k (float partials, the usual order), N, S1, S2 (double partials, lane-strided then butterfly), then
 // betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 with alpha_k = alphaN_k / alphaD_k exactly as every consumer forms it
 __global__ __launch_bounds__(64) void k_scalars_finish(const float* __restrict__ aD_part, const double* __restrict__ s3, int nb, thallo_sum_t aN,
@@ -793,6 +810,16 @@ int thallo_hip_pcg_update(float* r, const float* Ap, const float* pre, const flo
     hipStream_t s = (hipStream_t)stream;
     if (pre) hipLaunchKernelGGL(k_pcg_update<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
     else     hipLaunchKernelGGL(k_pcg_update<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
+    return check_launch();
+}
+
+int thallo_hip_lm_owed_delta(float* delta, const float* p_even, const float* p_odd, long n, const float* alphaN_words, const float* alphaD_words, int word_stride,
+                             const float* lm_state, int L, thallo_stream_t stream)
+{
+    if (!delta || !p_even || !p_odd || !alphaN_words || !alphaD_words || word_stride < 1 || !lm_state || L < 0) return -(int)hipErrorInvalidValue;
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_lm_owed_delta, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)delta, (const float4*)p_even, (const float4*)p_odd, n4, alphaN_words, alphaD_words,
+                       word_stride, lm_state, L);
     return check_launch();
 }
 

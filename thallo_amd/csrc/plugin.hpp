@@ -98,6 +98,12 @@ public:
     virtual bool apply_adds_ctc() const { return false; }      // honours LaunchCtx::lm_ctc
     // LM on one GPU: PCGStep3 folded into the apply -- p_out = z + beta p_in (beta = bN_prev / aN_prev, 0 when first), Ap = (J^T J + lm_ctc) p_out, alphaD partials;
     // p_out is written over the owned rows only and differs from p_in.  Only asked for when apply_adds_ctc() and LaunchCtx::lm_ctc is set.
+    // LM on one GPU, ONE launch per PCG iteration (round 3; shape_from_shading's marching kernel): vector update + PCGStep3 + (J^T J + CtC) p + alphaD, {N, S1, S2} and the
+    // {U, T1, T2} of q's expansion in alpha; the launch's last workgroup finishes alphaD_k, betaN_k, q_{k+1} and the zeta test (thallo_hip_sfs_pcg_iter_lm).
+    // r, Ap and p ping-pong as in pcg_iter; SolverVectors::CtC, b, s12b are read / written.
+    virtual bool lm_one_kernel() const { return false; }
+    virtual int pcg_iter_lm(LaunchCtx&, SolverVectors&, int /*cur*/, bool /*first*/, thallo_sum_t /*aN_prev*/, thallo_sum_t /*aD_prev*/, thallo_sum_t /*bN_prev*/, float* /*alphaD_out*/,
+                            const thallo_fin_t&, float* /*lm_state*/, int /*k*/, float /*q_tolerance*/) { return -1; }
     virtual bool apply_folds_pupdate() const { return false; }
     virtual int apply_jtj_pupdate(LaunchCtx&, const float* /*z*/, const float* /*p_in*/, float* /*p_out*/, float* /*Ap*/, float* /*alphaD_out*/, bool /*first*/,
                                   thallo_sum_t /*aN_prev*/, thallo_sum_t /*bN_prev*/) { return -1; }

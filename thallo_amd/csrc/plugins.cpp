@@ -725,6 +725,15 @@ public:
         return thallo_hip_sfs_pcg_iter(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
                                        v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode & 1, aN, aD, bN, out, v.s12, fin, c.stream);
     }
+    bool lm_one_kernel() const override { return one_kernel_iteration(); }
+    int pcg_iter_lm(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out, const thallo_fin_t& fin, float* lm_state, int k,
+                    float q_tol) override
+    {
+        TimedLaunch t(c, "PCGIteration");
+        return thallo_hip_sfs_pcg_iter_lm(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
+                                          v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, v.CtC, v.b, v.pre, first ? 1 : 0, aN, aD, bN, out, v.s12, v.s12b,
+                                          fin, lm_state, k, q_tol, c.stream);
+    }
     int pcg_iter_finish(LaunchCtx& c, SolverVectors& v, const float* part, int count, thallo_sum_t aN, float* aD_word, float* bN_word) override
     {
         TimedLaunch t(c, "PCGScalars");

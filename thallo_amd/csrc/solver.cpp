@@ -196,7 +196,7 @@ const char* env_switch(const char* name)
         "THALLO_ONE_KERNEL",          // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
         "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch
         "THALLO_BATCH_DELTA",         // 0: delta += alpha p every iteration instead of every other one
-        "THALLO_LM_FOLD_P",           // 0: LM's PCGStep3 as a launch of its own even where the plugin's apply can carry it
+        "THALLO_LM_FOLD_P",           // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own even where the plugin's marching kernel can carry them
         "THALLO_SFS_FUSED",           // 0: shape_from_shading's two-pass applyJTJ (round 1)
         "THALLO_SFS_MARCH",           // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
         "THALLO_DIST_P2P",            // 0: never the device-side exchange
@@ -660,7 +660,29 @@ int Plan::step_lm(int ev_iter)
     int k_done = 0;
     thallo_hip_lm_set_gate(gate); ctx.gate = gate;
     bool coll_failed = false;                                         // a collective itself failed: nothing left to stay in step with
-    for (int k = 0; k < L && !failed && !coll_failed; ++k) {
+    // One launch per LM iteration (one GPU; plugins that offer it: shape_from_shading's marching kernel; lIterations within one residual-reset period, where the reset
+    // -- it falls on the last iteration -- changes nothing that is read afterwards): the vector update, PCGStep3, (J^T J + CtC) p, all sums and the zeta test in
+    // pcg_iter_lm; behind the loop the one update of delta it still owes.  THALLO_LM_FOLD_P=0: the reference-shaped loop (A/B).
+    const int period = sp.residual_reset_period > 0 ? sp.residual_reset_period : (1 << 30);
+    const bool one_kernel_lm = !slab && lm_fold_p_ && fold_ctc && plugin->lm_one_kernel() && L >= 1 && L <= period && v_.p[1] != nullptr && ensure_iter_buffers() == 0;
+    if (one_kernel_lm) {
+        cur_ = 0;
+        for (int k = 0; k < L && !failed; ++k) {
+            const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+            const thallo_fin_t fin = { sum(jN), v_.fin_tickets, scal(jD), scal(jB) };
+            nb = plugin->pcg_iter_lm(ctx, v_, cur_, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), slot(jD), fin, lmst, k, sp.q_tolerance);
+            check(nb, "PCGIteration (LM) launch");
+            if (failed) break;
+            set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+            cur_ ^= 1;
+            k_done = k + 1;
+        }
+        if (!failed) {      // p_k lives in p[1] for even k, p[0] for odd k
+            TimedLaunch t(ctx, "PCGUpdate");
+            check(thallo_hip_lm_owed_delta(v_.delta, v_.p[1], v_.p[0], n, scal(B), scal(B + 1), 2, lmst, L, s), "PCGUpdate (owed delta) launch");
+        }
+    }
+    for (int k = 0; !one_kernel_lm && k < L && !failed && !coll_failed; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         if (!skip()) {
             if (fold_p) {                                             // PCGStep3 + PCGStep1 + PCGStep1_Finish in one launch; p ping-pongs between the two buffers

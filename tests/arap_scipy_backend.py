@@ -96,3 +96,93 @@ class ArapRangeMirror:
             self.gn_step(lit)
             costs.append(self.cost())
         return costs
+
+
+class ArapPartitionMirror:
+    """CPU mirror of the PARTITION form (solver_dist.cpp, D.part; thallo_amd/distributed_graph.py GhostPartition): a rank holds only its local sub-mesh -- owned vertices
+    [0, n_own), then ghosts; the edges with an owned end -- and local-sized vectors.  Per GN step the ghosts' r and M^-1 come from their owners; per PCG iteration ONE
+    all-gather of [alphaD | N, S1, S2 | A p at my boundary vertices] fills the ghosts' A p, after which a ghost's r, p, delta follow from the same arithmetic as its
+    owner's.  J restricted to the rows of owned fit terms and of edges with an owned SOURCE reproduces exactly the owned rows of the global J^T J p."""
+
+    def __init__(self, gp, params):
+        self.gp = gp
+        w_fit, w_reg, pos, ang, orig, cons, v0, v1 = params
+        lg = gp.local_global
+        self.local = [w_fit, w_reg, pos[lg].copy(), ang[lg].copy(), orig[lg].copy(), cons[lg].copy(), gp.v0_local.copy(), gp.v1_local.copy()]
+        self.Nl, self.El = len(lg), len(gp.v0_local)
+        self.n = 6 * self.Nl
+        no = gp.n_own
+        own = np.zeros(self.n, bool); own[:3 * no] = True; own[3 * self.Nl:3 * self.Nl + 3 * no] = True
+        self.own = own
+        rows = np.zeros(3 * self.Nl + 3 * self.El, bool)
+        rows[:3 * no] = True                                                           # fit rows of owned vertices
+        rows[3 * self.Nl:] = np.repeat(gp.v0_local < no, 3)                            # reg rows of edges LEAVING an owned vertex (each directed edge counted by its source's owner)
+        self.rows_cost = rows
+        rows_any = np.zeros_like(rows); rows_any[:3 * no] = True; rows_any[3 * self.Nl:] = True      # J^T J p at an owned vertex needs every local edge (in- and out-)
+        self.rows_apply = rows_any
+        self.maxb = None
+
+    def _unit_floats(self, units):
+        u = np.asarray(units, np.int64)
+        return np.concatenate([(3 * u[:, None] + np.arange(3)).ravel(), (3 * self.Nl + 3 * u[:, None] + np.arange(3)).ravel()]) if len(u) else np.zeros(0, np.int64)
+
+    def _exchange(self, header, vec):
+        """all-gather of [header | vec at my boundary units (padded)]; returns every rank's header and fills my ghosts"""
+        gp, w = self.gp, self.gp.world
+        if self.maxb is None:
+            self.maxb = max(int(g[0]) for g in _allgather(np.array([float(len(gp.boundary_units))]), w))
+        body = np.zeros(6 * self.maxb, np.float64)
+        idx = self._unit_floats(gp.boundary_units)
+        nb = len(gp.boundary_units)
+        body[:3 * nb] = vec[idx[:3 * nb]]; body[3 * self.maxb:3 * self.maxb + 3 * nb] = vec[idx[3 * nb:]]
+        got = _allgather(np.concatenate([np.asarray(header, np.float64), body]), w)
+        h = len(header)
+        for g, r, pos in zip(gp.ghost_units, gp.ghost_src_rank, gp.ghost_src_pos):
+            vec[3 * g:3 * g + 3] = got[r][h + 3 * pos:h + 3 * pos + 3]
+            vec[3 * self.Nl + 3 * g:3 * self.Nl + 3 * g + 3] = got[r][h + 3 * self.maxb + 3 * pos:h + 3 * self.maxb + 3 * pos + 3]
+        return [g[:h] for g in got]
+
+    def _csr(self):
+        return orc.Problem(orc.ARAP_MESH, (self.Nl, self.El), self.local).csr()
+
+    def cost(self):
+        res = self._csr()[3].astype(np.float64)
+        mine = np.array([0.5 * (res[self.rows_cost] ** 2).sum()], np.float64)
+        return float(sum(F(g[0]) for g in _allgather(mine, self.gp.world)))
+
+    def gn_step(self, L):
+        own = self.own
+        rp, col, val, res = self._csr()
+        J = sp.csr_matrix((val.astype(np.float64), col, rp), shape=(len(res), self.n))
+        Ja = sp.diags(self.rows_apply.astype(np.float64)) @ J                        # (all local rows: a ghost's own rows are incomplete, its values come from its owner)
+        r = (-(Ja.T @ res.astype(np.float64))).astype(F)
+        d = np.asarray(Ja.multiply(Ja).sum(0)).ravel().astype(F)
+        pre = (F(1) / (F(1) + np.sqrt(d)) ** 2).astype(F)
+        aN_loc = (r[own].astype(np.float64) * (pre[own] * r[own])).sum()
+        hs = self._exchange([aN_loc], r); aN = F(sum(F(h[0]) for h in hs))
+        self._exchange([], pre)
+        p = np.zeros(self.n, F); delta = np.zeros(self.n, F); Ap = np.zeros(self.n, F)
+        alpha = beta = F(0)
+        for k in range(L):
+            if k:
+                r = (r - alpha * Ap).astype(F); delta = (delta + alpha * p).astype(F)
+            p = (pre * r + beta * p).astype(F)
+            Ap = (Ja.T @ (Ja @ p.astype(np.float64))).astype(F)                      # right on the owned entries; the ghosts' come with the exchange
+            m64, r64, a64, p64 = pre[own].astype(np.float64), r[own].astype(np.float64), Ap[own].astype(np.float64), p[own].astype(np.float64)
+            hs = self._exchange([(p64 * a64).sum(), (m64 * r64 * r64).sum(), (m64 * r64 * a64).sum(), (m64 * a64 * a64).sum()], Ap)
+            aD = F(sum(F(h[0]) for h in hs)); n_, s1, s2 = (sum(h[i] for h in hs) for i in (1, 2, 3))
+            alpha = aN / aD if aD != 0 else F(0)
+            bN = F(max(n_ - 2.0 * float(alpha) * s1 + float(alpha) ** 2 * s2, 0.0))
+            beta = bN / aN if aN != 0 else F(0)
+            aN = bN
+        if L:
+            delta = (delta + alpha * p).astype(F)
+        self.local[2].reshape(-1)[:] += delta[:3 * self.Nl]                           # owned AND ghost unknowns: the ghosts follow their owners without an exchange
+        self.local[3].reshape(-1)[:] += delta[3 * self.Nl:]
+
+    def solve(self, nit, lit):
+        costs = [self.cost()]
+        for _ in range(nit):
+            self.gn_step(lit)
+            costs.append(self.cost())
+        return costs

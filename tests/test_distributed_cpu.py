@@ -236,3 +236,44 @@ def test_ghost_partition_lists_are_consistent():
             assert parts[r].local_global[parts[r].boundary_units[pos]] == g and parts[r].n0 <= g < parts[r].n1
         assert (pt.boundary_units < pt.n_own).all() and len(np.unique(pt.boundary_units)) == len(pt.boundary_units)
     assert (edges_seen == 1).all()
+
+
+def _arap_part_worker(rank, world, port, nu, nv, nit, lit, q):
+    from arap_scipy_backend import ArapPartitionMirror
+    from thallo_amd.distributed_graph import GhostPartition
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = syn.arap_mesh(nu, nv, n_handles=6, angle_amp=0.3)
+        gp = GhostPartition(p[2].shape[0], p[6], p[7], rank, world)
+        be = ArapPartitionMirror(gp, p)
+        costs = be.solve(nit, lit)
+        q.put((rank, costs, gp.local_global.copy(), gp.n_own, be.local[2].copy(), be.local[3].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nu,nv", [(2, 8, 6), (3, 12, 7)])
+def test_arap_ghost_partition_schedule_matches_single_domain_oracle(orc, world, nu, nv):
+    """The partition form's schedule (solver_dist.cpp D.part) restated on the CPU under gloo: local sub-meshes, ghost r / M^-1 per GN step, ONE all-gather of the boundary
+    A p + sums per PCG iteration -- against the single-domain oracle; every ghost ends equal to its owner without an exchange of unknowns."""
+    nit, lit = 3, 15
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arap_part_worker, args=(r, world, port, nu, nv, nit, lit, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    p = syn.arap_mesh(nu, nv, n_handles=6, angle_amp=0.3)
+    N = p[2].shape[0]
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, p[6].shape[0]), p).solve(nIterations=nit, lIterations=lit)
+    res.sort(key=lambda t: t[0])
+    pos = np.full((N, 3), np.nan, np.float32)
+    for rank, costs, lg, no, pl, al in res:
+        assert np.abs(np.array(costs) - co).max() <= 1e-5 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]
+        pos[lg[:no]] = pl[:no]
+    assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
+    for rank, costs, lg, no, pl, al in res:
+        assert np.array_equal(pl[no:], pos[lg[no:]]), rank                           # ghosts == owners, bit for bit

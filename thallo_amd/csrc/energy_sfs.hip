@@ -520,10 +520,13 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                         Rk[k0] = rk;
                         const float dk = up.first ? cur.dl : __builtin_fmaf(alpha, cur.pv, cur.dl);
                         if (LMQ) { Dk[k0] = dk; Mk[k0] = cur.mi; }
-                        if (t >= ya && t < yb && xout) {
+                        // own rows -- or a GHOST row of a slab (a row of the local image outside [ra, rb): nobody owns it here, the segment next to it keeps its r and p
+                        // current, like image_warping's marching kernel does; its A p comes with the exchange, its delta is never read)
+                        const bool mine = t >= ya && t < yb, ghost_row = ok && (t < g.ra || t >= g.rb);
+                        if ((mine || ghost_row) && xout) {
                             const long ro = (long)t * W;
                             (up.r_out + ro)[(unsigned)x] = rk; (up.p_out + ro)[(unsigned)x] = v0;
-                            if (!up.first) (up.delta + ro)[(unsigned)x] = dk;
+                            if (mine && !up.first) (up.delta + ro)[(unsigned)x] = dk;
                         }
                     }
                     const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;

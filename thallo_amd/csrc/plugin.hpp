@@ -127,6 +127,9 @@ public:
     // across ranks (solver_dist.cpp): the flat single-image form (applyJTJ with the three sums + one all-gather per iteration) rather than image_warping's
     // one-kernel slab form; by default whatever has no one-kernel iteration
     virtual bool dist_flat_form() const { return !one_kernel_iteration(); }
+    // flat slab form, round 3: pcg_iter also serves a row slab (it keeps r and p current on the slab's ghost rows; their A p comes with the exchange) -- then a slab's
+    // PCG iteration is pcg_iter + ONE exchange instead of pcg_update + applyJTJ + exchange
+    virtual bool one_kernel_slab() const { return false; }
     // aD_word / bN_word non-NULL: the kernel finishes the two scalars itself (no pcg_iter_finish launch)
     virtual int pcg_iter(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, thallo_sum_t, float* /*alphaD_out*/,
                          float* /*aD_word*/, float* /*bN_word*/) { return -1; }

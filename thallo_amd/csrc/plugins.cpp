@@ -725,6 +725,7 @@ public:
         return thallo_hip_sfs_pcg_iter(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
                                        v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode & 1, aN, aD, bN, out, v.s12, fin, c.stream);
     }
+    bool one_kernel_slab() const override { return thallo_hip_sfs_march_fits(W) != 0; }
     bool lm_one_kernel() const override { return one_kernel_iteration(); }
     int pcg_iter_lm(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out, const thallo_fin_t& fin, float* lm_state, int k,
                     float q_tol) override

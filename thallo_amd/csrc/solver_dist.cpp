@@ -291,6 +291,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (D.send.alloc(words * sizeof(float)) || D.gath.alloc(words * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }
         D.seg_rows_first = segs({ { D.rowlen * D.row0, gl } }); D.seg_rows_last = segs({ { D.rowlen * (D.row1 - g), gl } });
         bool mem = ensure_sums_buffer() == 0;
+        if (mem && plugin->one_kernel_slab() && !plugin->use_preconditioner() && ensure_iter_buffers()) mem = false;       // (r', Ap' of the one-launch-per-iteration slab loop)
         if (mem && (D.ctl.alloc(THALLO_DIST_CTL_WORDS * sizeof(unsigned)) || hipMemset(D.ctl.ptr, 0, THALLO_DIST_CTL_WORDS * sizeof(unsigned)) != hipSuccess)) mem = false;
         bool all = false;
         if (dist_agree(mem, all)) return -1;                             // the first use of the caller's all-gather: fails here, not mid-solve
@@ -695,7 +696,33 @@ int Plan::dist_gn_flat(int L)
         if (dist_sum_and_rows(B, v_.r)) return -1;                       // alphaN_0; ghost rows of r (p_0 = M^-1 r_0 there too)
         if (pc && dist_sum_and_rows(-1, v_.pre)) return -1;
     }
-    for (int k = 0; k < L; ++k) {
+    // One launch per PCG iteration on the slab too (round 3; plugins whose pcg_iter keeps r and p current on the ghost rows: shape_from_shading's marching kernel; the same
+    // decision on every rank): the iteration is pcg_iter + ONE exchange [alphaD | N, S1, S2 | boundary rows of the new A p].  THALLO_ONE_KERNEL=0: the three-launch form.
+    const bool onek = one_kernel_ && !pc && plugin->one_kernel_slab() && v_.r2 != nullptr && v_.Ap2 != nullptr && v_.p[1] != nullptr;
+    for (int k = 0; onek && k < L; ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        const thallo_sum_t nosum = { nullptr, 0 };
+        if (!D.failed) {
+            nb = plugin->pcg_iter(ctx, v_, cur_, k == 0 ? 1 : 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), nosum, nosum, slot(jD), nullptr, nullptr);
+            if (nb < 0) dist_fail("PCGIteration launch failed (%d)", nb);
+        }
+        if (!D.failed) set_nb(jD, nb);
+        float* Ao = v_.Abuf(cur_ ^ 1);
+        cur_ ^= 1;
+        TimedLaunch t(ctx, "SlabExchange");
+        if (D.xrows_now) {
+            const thallo_sum_t dummy = { (const float*)D.send.ptr, 1 };
+            if (dist_xrows(Ao, true, 1, D.failed ? dummy : sum(jN), D.failed ? (const float*)D.send.ptr : slot(jD), v_.s12, D.failed ? 1 : nb, scal(jD), scal(jB))) return -1;
+        } else {
+            DLOCAL(thallo_hip_slab_pack_iter(Ao, D.seg_rows_fl, slot(jD), v_.s12, nb, send, s), "slab pack");
+            if (dist_allgather(send, gath, D.msg_iter * (long)sizeof(float))) return -1;
+            const float* src_top = D.top ? gath + (rank - 1) * D.msg_iter + 7 + gl : nullptr;
+            const float* src_bot = D.bot ? gath + (rank + 1) * D.msg_iter + 7 : nullptr;
+            DLOCAL(thallo_hip_slab_unpack_iter(Ao, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, D.msg_iter, world, sum(jN), scal(jD), scal(jB), s), "slab unpack");
+        }
+        if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+    }
+    for (int k = 0; !onek && k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         if (!D.failed) {
             {   TimedLaunch t(ctx, "PCGUpdate");

@@ -617,7 +617,7 @@ int thallo_hip_dist_exchange_iter(thallo_dist_t d, int slot0, const float* alpha
 int thallo_hip_dist_collect(thallo_dist_t d, int slot0, int nslots, float* out, thallo_stream_t stream);
 /* Rows + scalars of a flat solver vector between row slabs in ONE launch, device side (round 3; replaces slab_pack + all-gather + slab_unpack of the
    single-image slab form, i.e. shape_from_shading's Gauss-Newton and Levenberg-Marquardt exchanges; reference: none -- single device, util.t:769-772).
-   Every rank's mailbox allocation carries, behind a ring of 4 x 8 scalar slots (slots ring0 ..), an INBOX of 2 (parity) x 2 (from above, from below) areas of
+   Every rank's mailbox allocation carries, behind a ring of 4 x 16 scalar slots (slots ring0 ..), an INBOX of 2 (parity) x 2 (from above, from below) areas of
    inbox_half floats at byte offset inbox_off (the same numbers on every rank).  The launch (one workgroup for rows up to 32 K floats, else 8 workgroups and a ticket):
      1. stores the `first` segments of vec into the upper neighbour's inbox (its "from below" area) and the `last` segments into the lower neighbour's
         ("from above"), peer-to-peer, fences, takes a ticket;
@@ -635,7 +635,7 @@ typedef struct thallo_xrows_t {
     long inbox_off;              /* bytes from the start of a rank's mailbox allocation */
     long inbox_half;             /* floats per (parity, direction) area; >= the total length of `first` / `last` */
     int  above, below;           /* neighbour ranks; -1: image border */
-    int  ring0;                  /* first scalar slot of the ring (4 x 8 slots) */
+    int  ring0;                  /* first scalar slot of the ring (4 x 16 slots) */
 } thallo_xrows_t;
 int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                           int mode, thallo_sum_t local_or_alphaN, const float* alphaD_partials, const double* s3_partials, int count, int poison,
@@ -664,6 +664,12 @@ int thallo_hip_units_unpack(float* vec, thallo_units_t u, const float* gathered,
 int thallo_hip_units_pack_iter(const float* vec, thallo_units_t u, const float* alphaD_partials, const double* s3_partials, int count, float* out, thallo_stream_t stream);
 int thallo_hip_units_unpack_iter(float* vec, thallo_units_t u, const float* gathered, long stride, int world, thallo_sum_t alphaN,
                                  float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* ... the exchange of a slab's one-launch LM iteration (thallo_hip_sfs_pcg_iter_lm without tickets): the ranks' alphaD / {N, S1, S2} / {U, T1, T2} partials travel as 13
+   granules, are added in rank order, and the wave that holds them writes alphaD_k, betaN_k, forms q_{k+1} = 0.5 [U + alpha (T1 - T2) - alpha^2 alphaD] and applies the zeta
+   test to lm_state; the boundary rows of the new A p travel as in thallo_hip_dist_xrows.  ONE exchange per LM iteration. */
+int thallo_hip_dist_xrows_lm(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                             thallo_sum_t alphaN, const float* alphaD_partials, const double* s3_partials, const double* q3_partials, int count, int poison,
+                             float* alphaD_word, float* betaN_word, float* lm_state, int k, float q_tolerance, thallo_stream_t stream);
 /* thallo_hip_dist_xrows for a PARTITIONED graph (thallo_units_t): the boundary units' values go into every other rank's inbox (area [parity][this rank] of
    unit_slot_floats floats at x.inbox_off), the scalars travel as in thallo_hip_dist_xrows (mode 0 / 1), and the ghost units are filled from the rank's own inbox --
    recv.src[g] = source rank * unit_slot_floats + position * floats per unit.  One launch, no collective. */

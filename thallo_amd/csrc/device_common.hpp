@@ -322,6 +322,11 @@ __device__ __forceinline__ void block_finish_sums_lm(float acc, const Sums3& sm,
     if (threadIdx.x == 0) {
         float a = 0.0f; double b[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
         for (int w = 0; w < nw; ++w) { a += red[w]; for (int q = 0; q < 6; ++q) b[q] += redd[6 * w + q]; }
+        if (!fin.tickets) {      // partials only (a row slab: the cross-rank exchange finishes the scalars and applies the zeta test)
+            aD_out[slot] = a;
+            for (int q = 0; q < 3; ++q) { s3_out[3 * slot + q] = b[q]; lm.q3_out[3 * slot + q] = b[3 + q]; }
+            red[15] = 0.0f;
+        } else {
         __hip_atomic_store(aD_out + slot, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u64_t* sp = reinterpret_cast<u64_t*>(s3_out) + 3 * slot; u64_t* qp = reinterpret_cast<u64_t*>(lm.q3_out) + 3 * slot;
         for (int q = 0; q < 3; ++q) {
@@ -337,7 +342,9 @@ __device__ __forceinline__ void block_finish_sums_lm(float acc, const Sums3& sm,
             last = __hip_atomic_fetch_add(fin.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
         }
         red[15] = last ? 1.0f : 0.0f;
+        }
     }
+    if (!fin.tickets) return;
     lds_barrier();
     if (red[15] == 0.0f || wave != 0) return;
     const IterationSums S = load_iteration_sums(aD_out, s3_out, fin.nb_total, fin.alphaN);

@@ -84,7 +84,8 @@ __device__ __forceinline__ void dist_fetch(const thallo_dist_t& d, const int (&s
 // betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 with alpha_k = alphaN / alphaD_k.  Identical bits on every rank.
 struct ExtraSums { bool on; float ad; double q0, q1, q2; };     // added behind the rank-ordered sums (shard form: the replicated block's own sums, k_shard_scalars' order)
 __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
-                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex = ExtraSums{ false, 0.0f, 0.0, 0.0, 0.0 });
+                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex = ExtraSums{ false, 0.0f, 0.0, 0.0, 0.0 },
+                                                            float* gad_out = nullptr, float* alpha_out = nullptr);
 __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, int slot0, float ad, double q0, double q1, double q2, float an,
                                                         float* __restrict__ aD_word, float* __restrict__ bN_word)
 {
@@ -92,7 +93,7 @@ __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, 
 }
 // (seq given by the caller: thallo_hip_dist_xrows tags with its own exchange counter)
 __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, const unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
-                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex)
+                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex, float* gad_out, float* alpha_out)
 {
     const int lane = threadIdx.x & (THALLO_WAVE - 1);
     unsigned w[7];
@@ -139,6 +140,54 @@ __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t&
     double bn = gq[0] - 2.0 * (double)alpha * gq[1] + (double)alpha * (double)alpha * gq[2];
     if (!(bn > 0.0)) bn = 0.0;
     if (lane == 0) { aD_word[0] = gad; bN_word[0] = (float)bn; }
+    if (gad_out) *gad_out = gad;
+    if (alpha_out) *alpha_out = alpha;
+}
+
+// ND doubles per rank (as hi / lo words: 2 * ND granules), by ONE full wave (2 * ND * world <= 64): bounded wait, rank-ordered double sums (every lane returns them)
+template <int ND>
+__device__ __forceinline__ void dist_exchange_doubles_wave_seq(const thallo_dist_t& d, const unsigned seq, int slot0, const double (&v)[ND], double (&out)[ND])
+{
+    const int lane = threadIdx.x & (THALLO_WAVE - 1);
+    if (lane < d.world) {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const u64 b = (u64)__double_as_longlong(v[j]);
+            st_sys(d.peer_mail[lane] + (long)(slot0 + 2 * j) * d.world + d.rank, ((u64)seq << 32) | (b >> 32));
+            st_sys(d.peer_mail[lane] + (long)(slot0 + 2 * j + 1) * d.world + d.rank, ((u64)seq << 32) | (b & 0xffffffffull));
+        }
+    }
+    unsigned got = 0;
+    if (lane < 2 * ND * d.world) {
+        const int j = lane / d.world, r = lane - j * d.world;
+        const u64* g = d.mail + (long)(slot0 + j) * d.world + r;
+        u64 w = ld_sys(g);
+        int it = 0; long long t0 = 0;
+        const long long bound = dist_spin_ticks(d);
+        while ((unsigned)(w >> 32) != seq) {
+            if ((it & 1023) == 0) { if (ld_agent(d.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
+            ++it;
+            if ((it & 1023) == 0 && wall_clock64() - t0 > bound) {
+                if (__hip_atomic_exchange(d.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    unsigned* pm = d.ctl + DIST_POST_MORTEM;
+                    pm[0] = (unsigned)(slot0 + j); pm[1] = (unsigned)r; pm[2] = seq; pm[3] = (unsigned)(w >> 32); pm[4] = (unsigned)w;
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            w = ld_sys(g);
+        }
+        got = (unsigned)w;
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        double t = 0.0;
+        for (int r = 0; r < d.world; ++r) {
+            const unsigned hi = __shfl(got, (2 * j) * d.world + r, THALLO_WAVE), lo = __shfl(got, (2 * j + 1) * d.world + r, THALLO_WAVE);
+            t += __longlong_as_double((long long)(((u64)hi << 32) | (u64)lo));
+        }
+        out[j] = t;
+    }
 }
 
 // NS floats per rank, by ONE full wave (NS * world <= 64): granules to every rank's slots slot0 .. slot0+NS-1, bounded wait, rank-ordered sums (every lane returns them)

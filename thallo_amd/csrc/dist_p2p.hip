@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
         if (!last_wg) return;
     }
     // every row of this rank is out and fenced: the granules may go
-    const int slot0 = x.ring0 + (int)(tag & 3u) * 8;
+    const int slot0 = x.ring0 + (int)(tag & 3u) * 16;
     if (threadIdx.x < THALLO_WAVE) {
         const int lane = threadIdx.x;
         if (MODE == 0) {                            // up to two float sums: s -> out0, (aD_part, nb) -> out1
@@ -130,6 +130,25 @@ __global__ __launch_bounds__(256) void k_xrows(thallo_dist_t d, thallo_xrows_t x
             if (lane == 0 && nb > 0) out1[0] = t[1];
             if (lane == 0 && zstate && reinterpret_cast<unsigned*>(zstate)[1] == 0u) {     // k_lm_zeta's rule on the global q (pcg_kernels.hip)
                 const float Q1 = t[0], Q0 = zstate[0];
+                const float zt = (float)(zk + 1) * (Q1 - Q0) / Q1;
+                const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < ztol;
+                if (stop) { reinterpret_cast<unsigned*>(zstate)[1] = 1u; reinterpret_cast<int*>(zstate)[2] = zk + 1; }
+                else zstate[0] = Q1;
+            }
+        } else if (MODE == 2) {                     // an LM iteration's scalars: alphaD, {N, S1, S2} and {U, T1, T2} (s3_2 = the q3 slots) -> alphaD_k, betaN_k, q_{k+1}, the zeta test
+            float ad = sum_partials(aD_part, nb);
+            double q[3] = { 0.0, 0.0, 0.0 }, u[3] = { 0.0, 0.0, 0.0 }, gu[3];
+            for (int i = lane; i < nb; i += THALLO_WAVE) { q[0] += s3[3 * i]; q[1] += s3[3 * i + 1]; q[2] += s3[3 * i + 2]; u[0] += s3_2[3 * i]; u[1] += s3_2[3 * i + 1]; u[2] += s3_2[3 * i + 2]; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { q[j] = wave_sum_all_f64(q[j]); u[j] = wave_sum_all_f64(u[j]); }
+            if (poison) ad = __uint_as_float(0x7fc00000u);
+            float gad = 0.0f, al = 0.0f;
+            dist_exchange_iter_wave_seq(d, tag, slot0, ad, q[0], q[1], q[2], s.count == 1 ? s.partials[0] : 0.0f, out0, out1, ExtraSums{ false, 0.0f, 0.0, 0.0, 0.0 }, &gad, &al);
+            dist_exchange_doubles_wave_seq<3>(d, tag, slot0 + 7, u, gu);
+            // (LM divides blindly, gauss_newton.t:226-234: alpha of the exchange above is the guarded quotient -- equal unless alphaD is 0)
+            const float Q1 = (float)(0.5 * (gu[0] + (double)al * (gu[1] - gu[2]) - (double)al * (double)al * (double)gad));
+            if (lane == 0 && zstate && reinterpret_cast<unsigned*>(zstate)[1] == 0u) {
+                const float Q0 = zstate[0];
                 const float zt = (float)(zk + 1) * (Q1 - Q0) / Q1;
                 const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < ztol;
                 if (stop) { reinterpret_cast<unsigned*>(zstate)[1] = 1u; reinterpret_cast<int*>(zstate)[2] = zk + 1; }
@@ -382,10 +401,12 @@ static int xrows_impl(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs
         if (s.count < 0 || (s.count > 0 && (!s.partials || !out0)) || s.count > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
         if (count < 0 || (count > 0 && (!aD_partials || !out1)) || count > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;      // the optional second sum
     } else if (mode == 1) { if (!aD_partials || !s3_partials || count < 1 || count > THALLO_MAX_PARTIALS || s.count != 1 || !s.partials || !out0 || !out1) return -(int)hipErrorInvalidValue; }
+    else if (mode == 2) { if (!aD_partials || !s3_partials || !s3_2 || s3_2 == s3_partials || count < 1 || count > THALLO_MAX_PARTIALS || s.count != 1 || !s.partials || !out0 || !out1 || !zstate || 13 * 0 + 7 * d.world > 64) return -(int)hipErrorInvalidValue; }
     else return -(int)hipErrorInvalidValue;
     // rows of up to 32 K floats per direction (a 2048-wide image: 2 ghost rows of 4 channels): ONE workgroup, no ticket; longer ones: 8 workgroups
     const int grid = std::max(tf, tl) <= 32768 ? 1 : 8, block = 256;
-    if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, zstate, zk, ztol, (const float*)nullptr, (const double*)nullptr, 0, us, ur, unit_slot);
+    if (mode == 2) hipLaunchKernelGGL(k_xrows<2>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, zstate, zk, ztol, (const float*)nullptr, s3_2, nb2, us, ur, unit_slot);
+    else if (mode == 0) hipLaunchKernelGGL(k_xrows<0>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, zstate, zk, ztol, (const float*)nullptr, (const double*)nullptr, 0, us, ur, unit_slot);
     else           hipLaunchKernelGGL(k_xrows<1>, dim3(grid), dim3(block), 0, (hipStream_t)stream, d, x, vec, first, last, top, bot, s, aD_partials, s3_partials, count, poison, out0, out1, (float*)nullptr, 0, 0.0f, aD2, s3_2, nb2, us, ur, unit_slot);
     return check_launch();
 }
@@ -433,6 +454,14 @@ int thallo_hip_dist_xunits(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo
     x.above = -1; x.below = -1;
     return xrows_impl(d, x, vec, none, none, none, none, mode, local_or_alphaN, alphaD_partials, s3_partials, count, poison, out0, out1, nullptr, 0, 0.0f, stream,
                       nullptr, nullptr, 0, send, recv, unit_slot_floats);
+}
+
+int thallo_hip_dist_xrows_lm(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
+                             thallo_sum_t alphaN, const float* alphaD_partials, const double* s3_partials, const double* q3_partials, int count, int poison,
+                             float* alphaD_word, float* betaN_word, float* lm_state, int k, float q_tolerance, thallo_stream_t stream)
+{
+    return xrows_impl(d, x, vec, first, last, top, bot, 2, alphaN, alphaD_partials, s3_partials, count, poison, alphaD_word, betaN_word, lm_state, k, q_tolerance, stream,
+                      nullptr, q3_partials, count);
 }
 
 int thallo_hip_dist_error(thallo_dist_t d, int clear, thallo_stream_t stream)

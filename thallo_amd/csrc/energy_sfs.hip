@@ -989,7 +989,7 @@ int thallo_hip_sfs_pcg_iter_lm(int W, int H, int row0, int row1, int yoff, int H
     if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !delta || !aD_out || !s3_out || !q3_out ||
         q3_out == s3_out || !CtC || !b || !pre || !lm_state) return -(int)hipErrorInvalidValue;
     if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !alphaD_prev.partials || !betaN_prev.partials)) return -(int)hipErrorInvalidValue;
-    if (!fin.tickets || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials) return -(int)hipErrorInvalidValue;
+    if (fin.tickets && (!fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;      // (no tickets: partials only -- a row slab, whose exchange finishes)
     if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;

@@ -102,6 +102,7 @@ public:
     // {U, T1, T2} of q's expansion in alpha; the launch's last workgroup finishes alphaD_k, betaN_k, q_{k+1} and the zeta test (thallo_hip_sfs_pcg_iter_lm).
     // r, Ap and p ping-pong as in pcg_iter; SolverVectors::CtC, b, s12b are read / written.
     virtual bool lm_one_kernel() const { return false; }
+    virtual bool lm_one_kernel_slab() const { return false; }       // ... pcg_iter_lm also serves a row slab (ghost rows of r and p kept current; fin without tickets: partials only)
     virtual int pcg_iter_lm(LaunchCtx&, SolverVectors&, int /*cur*/, bool /*first*/, thallo_sum_t /*aN_prev*/, thallo_sum_t /*aD_prev*/, thallo_sum_t /*bN_prev*/, float* /*alphaD_out*/,
                             const thallo_fin_t&, float* /*lm_state*/, int /*k*/, float /*q_tolerance*/) { return -1; }
     virtual bool apply_folds_pupdate() const { return false; }

@@ -727,6 +727,7 @@ public:
     }
     bool one_kernel_slab() const override { return thallo_hip_sfs_march_fits(W) != 0; }
     bool lm_one_kernel() const override { return one_kernel_iteration(); }
+    bool lm_one_kernel_slab() const override { return thallo_hip_sfs_march_fits(W) != 0; }
     int pcg_iter_lm(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out, const thallo_fin_t& fin, float* lm_state, int k,
                     float q_tol) override
     {

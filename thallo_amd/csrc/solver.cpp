@@ -665,8 +665,38 @@ int Plan::step_lm(int ev_iter)
     // pcg_iter_lm; behind the loop the one update of delta it still owes.  THALLO_LM_FOLD_P=0: the reference-shaped loop (A/B).
     const int period = sp.residual_reset_period > 0 ? sp.residual_reset_period : (1 << 30);
     const bool one_kernel_lm = !slab && lm_fold_p_ && fold_ctc && plugin->lm_one_kernel() && L >= 1 && L <= period && v_.p[1] != nullptr && ensure_iter_buffers() == 0;
+    // ... and on a row slab of a multi-GPU run (device-side transport; plugins whose pcg_iter_lm keeps the ghost rows current): the launch stores partials only, ONE
+    // exchange per LM iteration carries the 13 sums and the boundary rows of the new A p, finishes alphaD_k, betaN_k, q_{k+1} and applies the zeta test
+    // (thallo_hip_dist_xrows_lm).  Ghost rows of r and M^-1 are fetched once per step.
+    const bool one_kernel_lm_slab = slab && dist_->flat && dist_->xrows_now && lm_fold_p_ && fold_ctc && plugin->lm_one_kernel_slab() && L >= 1 && L <= period &&
+                                    v_.p[1] != nullptr && v_.r2 != nullptr && v_.Ap2 != nullptr && v_.s12b != nullptr;
+    if (one_kernel_lm_slab) {
+        if (global_rows(-1, v_.r) || global_rows(-1, v_.pre)) return 0;
+        cur_ = 0;
+        for (int k = 0; k < L; ++k) {
+            const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+            const thallo_fin_t fin = { sum(jN), nullptr, nullptr, nullptr };
+            if (!skip()) {
+                nb = plugin->pcg_iter_lm(ctx, v_, cur_, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), slot(jD), fin, lmst, k, sp.q_tolerance);
+                check(nb, "PCGIteration (LM) launch");
+            }
+            if (!skip()) set_nb(jD, nb);
+            float* Ao = v_.Abuf(cur_ ^ 1);
+            cur_ ^= 1;
+            if (dist_xrows_lm(Ao, jN, jD, jB, nb, lmst, k)) { coll_failed = true; break; }
+            k_done = k + 1;
+        }
+        if (!coll_failed && !skip()) {
+            TimedLaunch t(ctx, "PCGUpdate");
+            check(thallo_hip_lm_owed_delta(v_.delta + o, v_.p[1] + o, v_.p[0] + o, n, scal(B), scal(B + 1), 2, lmst, L, s), "PCGUpdate (owed delta) launch");
+        }
+    }
     if (one_kernel_lm) {
         cur_ = 0;
+        {   // alphaN_0 as a word (the owed-delta launch reads the scalars of iteration "done - 1" by address)
+            check(thallo_hip_finish_sum(partial_sum(B), scal(B), s), "alphaN_0 sum");
+            if (!failed) fin_[B] = 1;
+        }
         for (int k = 0; k < L && !failed; ++k) {
             const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
             const thallo_fin_t fin = { sum(jN), v_.fin_tickets, scal(jD), scal(jB) };
@@ -682,7 +712,7 @@ int Plan::step_lm(int ev_iter)
             check(thallo_hip_lm_owed_delta(v_.delta, v_.p[1], v_.p[0], n, scal(B), scal(B + 1), 2, lmst, L, s), "PCGUpdate (owed delta) launch");
         }
     }
-    for (int k = 0; !one_kernel_lm && k < L && !failed && !coll_failed; ++k) {
+    for (int k = 0; !one_kernel_lm && !one_kernel_lm_slab && k < L && !failed && !coll_failed; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         if (!skip()) {
             if (fold_p) {                                             // PCGStep3 + PCGStep1 + PCGStep1_Finish in one launch; p ping-pongs between the two buffers

@@ -184,6 +184,7 @@ private:
     int  dist_map_peers();
     int  dist_map_peers_flat();
     int  dist_map_mail(long bytes);                     // the mailbox allocation of the flat / shard forms: allocate, exchange handles, map every peer's, agree
+    int  dist_xrows_lm(float* vec, int jN, int jD, int jB, int nb, float* lm_state, int k);      // the ONE exchange of a slab's one-launch LM iteration
     int  dist_two_sums_and_rows(int j1, int j2, float* vec, float* zeta_state = nullptr, int zeta_k = 0, bool* zeta_done = nullptr);
     int  dist_xrows(float* vec, bool rows, int mode, thallo_sum_t s, const float* aD_part, const double* s3, int nb, float* out0, float* out1, float* zeta_state = nullptr, int zeta_k = 0);
     int  dist_self_check();

@@ -151,7 +151,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (D.want_p2p) {
             memset(&D.xa, 0, sizeof(D.xa));
             D.xa.ring0 = 0; D.xa.chunk = ((len + cfg.world - 1) / cfg.world + 3) / 4 * 4;
-            D.xa.inbox_off = (8L * 40 * cfg.world + 255) / 256 * 256;       // behind 8 (all-reduce) + 32 (scalars) granule slots
+            D.xa.inbox_off = (8L * 72 * cfg.world + 255) / 256 * 256;       // behind 8 (all-reduce) + 64 (scalars) granule slots
             memset(&D.xr, 0, sizeof(D.xr)); D.xr.ring0 = 8; D.xr.inbox_off = D.xa.inbox_off; D.xr.above = D.xr.below = -1;
             if (dist_map_mail(D.xa.inbox_off + 4L * cfg.world * D.xa.chunk * (long)sizeof(float))) return -1;
         }
@@ -246,7 +246,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
             D.want_p2p = allp;
             if (D.want_p2p) {
                 memset(&D.xr, 0, sizeof(D.xr)); D.xr.ring0 = 0; D.xr.above = D.xr.below = -1;
-                D.xr.inbox_off = (8L * 32 * cfg.world + 255) / 256 * 256;
+                D.xr.inbox_off = (8L * 64 * cfg.world + 255) / 256 * 256;
                 if (dist_map_mail(D.xr.inbox_off + 2L * cfg.world * D.unit_slot * (long)sizeof(float))) return -1;
             }
         }
@@ -449,7 +449,7 @@ int Plan::dist_map_peers_flat()
     const long gl = D.ghost * D.rowlen;
     thallo_xrows_t x; memset(&x, 0, sizeof(x));
     x.ring0 = 0;
-    x.inbox_off = (8L * 32 * D.cfg.world + 255) / 256 * 256;            // behind 4 x 8 scalar slots of `world` granules
+    x.inbox_off = (8L * 64 * D.cfg.world + 255) / 256 * 256;            // behind 4 x 16 scalar slots of `world` granules
     x.inbox_half = gl;
     x.above = D.top ? D.cfg.rank - 1 : -1; x.below = D.bot ? D.cfg.rank + 1 : -1;
     D.xr = x;
@@ -662,6 +662,18 @@ int Plan::dist_sum_and_rows(int j, float* vec)
     const float* src_bot = D.bot ? gath + (D.cfg.rank + 1) * msg + 1 : nullptr;               // the FIRST rows of rank+1
     DLOCAL(thallo_hip_slab_unpack(vec, D.seg_rows_top, src_top, D.seg_rows_bot, src_bot, gath, msg, D.cfg.world, j >= 0 ? scal(j) : nullptr, s), "slab unpack");
     if (j >= 0 && !D.failed) fin_[j] = 1;
+    return 0;
+}
+
+int Plan::dist_xrows_lm(float* vec, int jN, int jD, int jB, int nb, float* lm_state, int k)
+{   // device-side transport only: the ranks' alphaD / {N, S1, S2} / {U, T1, T2} partials + the boundary rows of the new A p; alphaD_k, betaN_k, q_{k+1} and the zeta test
+    DistState& D = *dist_;
+    const thallo_sum_t dummy = { (const float*)D.send.ptr, 1 };
+    int rc = thallo_hip_dist_xrows_lm(D.d, D.xr, vec, D.seg_rows_first, D.seg_rows_last, D.seg_rows_top, D.seg_rows_bot, D.failed ? dummy : sum(jN), D.failed ? (const float*)D.send.ptr : slot(jD),
+                                      v_.s12, v_.s12b, D.failed ? 1 : nb, D.failed ? 1 : 0, scal(jD), scal(jB), lm_state, k, sp.q_tolerance, ctx.stream);
+    if (D.inject > 0 && !D.failed && --D.inject == 0) rc = -999;
+    if (rc < 0 && !D.failed) dist_fail("device-side LM exchange failed (%d)", rc);
+    if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
     return 0;
 }
 

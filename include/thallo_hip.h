@@ -485,7 +485,8 @@ int thallo_hip_sfs_pcg_iter_lm(int W, int H, int row0, int row1, int yoff, int H
                                const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, const float* CtC, const float* b,
                                const float* pre, int first, thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* alphaD_out, double* s3_out, double* q3_out,
                                thallo_fin_t fin, float* lm_state, int k, float q_tolerance, thallo_stream_t stream);
-/* delta += alpha_kl p_kl with kl = (lm_state[1] ? lm_state[2] : L) - 1: the update of delta the one-launch LM loop owes when it ends (by the gate or after L iterations).
+/* delta += alpha_kl p_kl with kl = (lm_state[1] ? lm_state[2] : L) - 1: the update of delta the one-launch LM loop owes when it ends (by the gate or after L iterations):
+ * the delta half of the last PCGStep2 (gauss_newton.t:801-843).
  * p_even / p_odd: the buffers holding p_k for even / odd k; alphaN_words / alphaD_words: pointers to the scalar words of iteration 0, `word_stride` floats apart per iteration. */
 int thallo_hip_lm_owed_delta(float* delta, const float* p_even, const float* p_odd, long n, const float* alphaN_words, const float* alphaD_words, int word_stride,
                              const float* lm_state, int L, thallo_stream_t stream);
@@ -645,7 +646,8 @@ int thallo_hip_dist_xrows(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_
 int thallo_hip_dist_xrows_zeta(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo_segs_t first, thallo_segs_t last, thallo_segs_t top, thallo_segs_t bot,
                                thallo_sum_t q_local, const float* second_partials, int second_count, int poison, float* q_out, float* second_out,
                                float* lm_state, int k, float q_tolerance, thallo_stream_t stream);
-/* Ghost units of a PARTITIONED graph problem (round 3; SURVEY.md 8e row 2: ARAP with ghost vertices).  A rank's local problem = its owned units (vertices) first, then
+/* Ghost units of a PARTITIONED graph problem (round 3; SURVEY.md 8e row 2: ARAP with ghost vertices; the reference has no analogue -- single device, API/src/util.t:769-772;
+   the vectors exchanged are those of gauss_newton.t:282-323).  A rank's local problem = its owned units (vertices) first, then
    the ghosts: units owned elsewhere that its owned ones touch.  Per exchange a rank sends, behind the scalars, the values of its BOUNDARY units (owned here, ghost
    somewhere) -- `per` floats per unit, taken from up to 8 planes of the flat vector (plane k: base[k] + unit * len[k], len[k] floats) -- and fills each of its ghosts from
    (source rank, position in that rank's boundary list).  thallo_hip_units_pack(_iter): message = [1 (or 7) scalar words as thallo_hip_slab_pack(_iter) writes them |
@@ -683,7 +685,7 @@ int thallo_hip_dist_xunits(thallo_dist_t d, thallo_xrows_t x, float* vec, thallo
 int thallo_hip_dist_xscalars_shard(thallo_dist_t d, thallo_xrows_t x, thallo_sum_t alphaN, const float* own_alphaD_partials, const double* own_s3_partials, int own_count,
                                    const float* shared_alphaD_partials, const double* shared_s3_partials, int shared_count, int poison,
                                    float* alphaD_word, float* betaN_word, thallo_stream_t stream);
-/* In-place sum over all ranks of `len` floats at `buf`, by peer stores only (round 3; bundle adjustment's point block across camera shards: SURVEY.md 8e row 3, "prefer
+/* In-place sum over all ranks of `len` floats at `buf`, by peer stores only (round 3; the reference has no analogue -- single device, API/src/util.t:769-772; bundle adjustment's point block across camera shards: SURVEY.md 8e row 3, "prefer
    the direct form" -- replaces ncclAllReduce in the PCG loop).  Reduce-scatter + all-gather in ONE launch: rank r owns chunk r (x.chunk floats); every rank stores its part
    of chunk c into rank c's inbox, the owner adds the `world` contributions IN RANK ORDER (every run and every rank gets the same bits) and stores the sums into every rank's
    second inbox, from which they are copied into place.  Two waits on tagged granules (bounded, error word + post-mortem as everywhere), parity double-buffering: a rank can

@@ -112,8 +112,18 @@ __device__ __forceinline__ void nb_term(bool valid, float ci, float si, float px
 #ifdef THALLO_MARCH_SWEEP
 // tools/march_probe.py MB_MODE=stamps: where a launch spends its time (100 MHz wall clock, lane 0 of every wave)
 __device__ unsigned long long* g_stamps_m = nullptr;
-#define MARCH_STAMP(k) do { if ((threadIdx.x & 63) == 0 && g_stamps_m) g_stamps_m[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)
+// (the pointer is read ONCE per kernel, MARCH_STAMP_INIT: a read of the __device__ word inside the row loop is a load the compiler waits for with vmcnt(0) -- every row's
+//  prefetch drained; the sweep build ran like that until round 3 and timed the same as the product)
+#ifdef THALLO_MARCH_STAMPS      // (make VARIANT=stamps EXTRA="-DTHALLO_MARCH_SWEEP -DTHALLO_MARCH_STAMPS": the stamp stores are FLAT stores, and one FLAT instruction in the row loop makes
+                                //  the compiler wait with vmcnt(0) at the top of every trip -- the plain sweep build has none, so that its loop is the product's)
+#define MARCH_STAMP_INIT unsigned long long* const stamps_l = g_stamps_m
+#define MARCH_STAMP(k) do { if ((threadIdx.x & 63) == 0 && stamps_l) stamps_l[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)
 #else
+#define MARCH_STAMP_INIT do { } while (0)
+#define MARCH_STAMP(k) do { } while (0)
+#endif
+#else
+#define MARCH_STAMP_INIT do { } while (0)
 #define MARCH_STAMP(k) do { } while (0)
 #endif
 
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         if (threadIdx.x == 0) { aD_out[blockIdx.x] = __builtin_nanf(""); }
         return;
     }
+    MARCH_STAMP_INIT;
     MARCH_STAMP(0);
     if (threadIdx.x < 32) { float mo, ma; pre_from_flags((unsigned char)threadIdx.x, wf2, wr2, mo, ma); lut[threadIdx.x] = make_float2(mo, ma); }
     __syncthreads();
@@ -148,17 +159,18 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
     const int W2 = g.W >> 1;                                  // pixel pairs per row
     // XCD-aware placement: workgroups b and b+8 share an XCD (MI355X_MICROARCH.md), group b%8 owns a contiguous range of
     // (band of 4 segments, strip) ids, x-adjacent strips first: x-halo columns and y-halo rows are re-read from the same L2
-    int strip = 0, ya = 0, yb = 0;
+    int strip = 0, ya = 0, yb = 0, sya = 0, syb = 0;      // (sya, syb: the workgroup's segment -- map 2: waves without a strip still take part in its barriers)
     {
         const int G = (gridDim.x % 8) == 0 ? 8 : 1;
         const int grp = blockIdx.x % G, l = blockIdx.x / G;
         const long lo = (long)g.total * grp / G, hi = (long)g.total * (grp + 1) / G;
         const long id = lo + l;
-        if (id < hi && g.map == 1) {        // (microbench) the 4 waves side by side: one segment of 4 x-adjacent strips
-            const int nsb = (g.nstrips + 3) / 4;
+        if (id < hi && g.map >= 1) {        // (microbench) the 4 waves side by side: one segment of 4 x-adjacent strips; map 2: + a workgroup barrier per loop trip (three rows),
+            const int nsb = (g.nstrips + 3) / 4;                             // so that the four waves touch the same image rows -- the same DRAM pages -- at the same time
             strip = (int)(id % nsb) * 4 + wave;
             const int seg = (int)(id / nsb);
-            if (strip < g.nstrips) { ya = g.row0 + seg * g.R; yb = ya + g.R; if (yb > g.row1) yb = g.row1; if (ya > g.row1) ya = g.row1; }
+            sya = g.row0 + seg * g.R; syb = sya + g.R; if (syb > g.row1) syb = g.row1; if (sya > g.row1) sya = g.row1;
+            if (strip < g.nstrips) { ya = sya; yb = syb; }
         } else if (id < hi) {
             strip = (int)(id % g.nstrips);
             const int seg = (int)(id / g.nstrips) * (MARCH_NT / 64) + wave;
@@ -168,9 +180,9 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         }
     }
     const bool work = ya < yb;
-    const int x0 = DBG == 3 ? strip * 128 + 2 * lane : strip * MARCH_USE - 2 + 2 * lane;          // first of this lane's two pixels
+    const int x0 = (DBG == 3 || DBG == 6) ? strip * 128 + 2 * lane : strip * MARCH_USE - 2 + 2 * lane;          // first of this lane's two pixels
     const bool xin = x0 >= 0 && x0 < g.W;                     // W even: both pixels exist or neither
-    const bool xout = xin && (DBG == 3 || (lane >= 1 && lane <= 62));         // this lane's pixels are outputs of this wave
+    const bool xout = DBG == 6 ? true : xin && (DBG == 3 || (lane >= 1 && lane <= 62));      // (DBG 6, timing only, W a multiple of 128: DBG 3 with every store unconditional)         // this lane's pixels are outputs of this wave
 
     const float4* __restrict__ ro4 = reinterpret_cast<const float4*>(r_in);  const float2* __restrict__ ra2 = reinterpret_cast<const float2*>(r_in + 2 * N);
     const float4* __restrict__ ao4 = reinterpret_cast<const float4*>(A_in);  const float2* __restrict__ aa2 = reinterpret_cast<const float2*>(A_in + 2 * N);
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
 
     // publish row t from its raw slot into wn: r_k = r - alpha Ap, p_k = M^-1 r_k + beta p ; stores for owned rows (segment rows) and a slab's ghost rows
     auto publish = [&](const RawT& s, const RawD& sd, int t, bool live, Row& wn) {     // s, sd: copies made by take()
-        const bool ok = live && xin && row_exists(t);
+        const bool ok = DBG == 6 ? true : live && xin && row_exists(t);
         float rx[2] = { s.ro.x, s.ro.z }, ry[2] = { s.ro.y, s.ro.w }, rq[2] = { s.ra.x, s.ra.y };
         if (!FIRST) {
             rx[0] = __builtin_fmaf(-alpha, s.ao.x, rx[0]); ry[0] = __builtin_fmaf(-alpha, s.ao.y, ry[0]);
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         }
         wn.c[0] = s.cs.x; wn.s[0] = s.cs.y; wn.c[1] = s.cs.z; wn.s[1] = s.cs.w; wn.f = fl;
         const bool mine = t >= ya && t < yb;
-        if (ok && xout && (mine || !row_owned(t))) {       // this wave's own rows, or a ghost row of the slab (kept current here)
+        if (DBG == 6 || (ok && xout && (mine || !row_owned(t)))) {       // this wave's own rows, or a ghost row of the slab (kept current here)
             const long i2 = (long)t * W2 + (x0 >> 1);
             stf4(Ro4 + i2, make_float4(rx[0], ry[0], rx[1], ry[1]), nt_out); stf2(Ra2 + i2, make_float2(rq[0], rq[1]), nt_out);
             stf4(qo4 + i2, make_float4(wn.px[0], wn.py[0], wn.px[1], wn.py[1]), nt_pout); stf2(qa2 + i2, make_float2(wn.pa[0], wn.pa[1]), nt_pout);
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         const float Lpx = from_left(wc.px[1]), Lpy = from_left(wc.py[1]), Lpa = from_left(wc.pa[1]), Lc = from_left(wc.c[1]), Ls = from_left(wc.s[1]);
         const float Rpx = from_right(wc.px[0]), Rpy = from_right(wc.py[0]), Rpa = from_right(wc.pa[0]), Rc = from_right(wc.c[0]), Rs = from_right(wc.s[0]);
         const unsigned Lf = from_left(wc.f) >> 8, Rf = from_right(wc.f);
-        if (DBG == 1 || DBG == 3) {
+        if (DBG == 1 || DBG == 3 || DBG == 6) {
             if (xout) {
                 const long i2 = (long)y * W2 + (x0 >> 1);
                 stf4(Ao4 + i2, make_float4(wc.px[0] + Lpx, wc.py[0], wc.px[1] + Rpx, wc.py[1]), nt_out); stf2(Aa2 + i2, make_float2(wc.pa[0] + wn.pa[0], wc.pa[1] + wm.pa[1]), nt_out);
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
     };
 
     if (work) {
-        const int t_first = DBG == 3 ? ya : ya - 1, t_last = DBG == 3 ? yb - 1 : yb;            // rows to publish: the segment and its two halo rows
+        const int t_first = (DBG == 3 || DBG == 6) ? ya : ya - 1, t_last = (DBG == 3 || DBG == 6) ? yb - 1 : yb;            // rows to publish: the segment and its two halo rows
         // No branch around a load anywhere in this loop (see `issue`): the step count is rounded up to a multiple of 3, rows beyond
         // t_last are clamped re-reads of the last row (cache hits) whose publish / stencil are predicated off.
         // There is no prologue either: the loop starts three rows early with empty slots (publish predicated off) and its refills are
@@ -345,6 +357,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
 #pragma unroll
         for (int j = 0; j < 3; ++j) { slot[j] = RawT{}; dsl[j] = RawD{}; }
         for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) {
+            if (g.map == 2) __builtin_amdgcn_s_barrier();
             // The iteration's scalars, at the start of the SECOND trip: the first trip only issued the loads of rows t_first .. t_first + 2, nothing
             // needed alpha / beta yet; now the partial (or word) loads queue up behind those row loads and the additions run while the rows arrive.
             if (t0 == t_first) MARCH_STAMP(2);
@@ -365,12 +378,21 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
                 if (DMODE != 1) issue_d(dsl[(j + 2) % 3], phys(t + 2));      // (the slot taken one step ago)
                 fence_order();                               // ... and in front of the arithmetic
                 // (wave-uniform branch, no load inside: the three lead-in rows and the rounding-up rows skip the arithmetic; the window keeps its zeros)
+                if (DBG == 6) {     // no branch around a store: lead-in / rounding-up trips store (garbage, later overwritten / identical) into the clamped row
+                    const int tq = t < t_first ? t_first : t > t_last ? t_last : t;
+                    publish(cur, curd, tq, true, wn); stencil(tq, wc, wn, wm);
+                    continue;
+                }
                 if (t >= t_first && t <= t_last) publish(cur, curd, phys(t), true, wn);
                 if (DBG == 3) { if (t >= t_first && t <= t_last) stencil(t, wc, wn, wm); }      // (timing only)
                 else if (DBG == 4) { if (t - 1 >= ya && t <= t_last) stencil(phys(t - 1), wn, wc, wm); }
                 else if (t - 1 >= ya && t <= t_last) stencil(t - 1, wm, wc, wn);
             }
         }
+    }
+    else if (g.map == 2 && sya < syb) {      // a wave without a strip: the same number of barriers as its three siblings
+        const int t_first = DBG == 3 ? sya : sya - 1, t_last = DBG == 3 ? syb - 1 : syb;
+        for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) __builtin_amdgcn_s_barrier();
     }
     MARCH_STAMP(5);
     iter_tail<MARCH_NT, DIST>(acc, s0, s1, s2, red, redd, aD_out, s12_out, bNp, &dd, fin_tickets, aD_word, bN_word, xslot);
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(256) void k_urshape_check(int W, int H, const float
 #ifdef THALLO_MARCH_SWEEP
 // tools/march_probe.py only: the same planes moved with the same access widths by a flat grid-stride loop and trivial arithmetic --
 // the streaming ceiling of this byte mix (81 B/pixel, or 117 with the delta / p_{k-2} planes) on this box.
-template <int NTM, bool DELTA>
+template <int NTM, bool DELTA, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_stream_ref(long n2, long N, int span, int rev, const float* __restrict__ cs, const unsigned char* __restrict__ flags,
                                                     const float* __restrict__ r_in, float* __restrict__ r_out, const float* __restrict__ A_in, float* __restrict__ A_out,
                                                     const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta, float alpha)
@@ -413,30 +435,70 @@ __global__ __launch_bounds__(256) void k_stream_ref(long n2, long N, int span, i
     // workgroup walk K consecutive 256-thread chunks before it jumps ahead by gridDim.x * K chunks -- K = chunks / gridDim.x is the
     // order of the marching kernel (every workgroup owns one contiguous region, the chip touches the whole plane all the time)
     const long chunks = (n2 + 255) / 256;
+    // span < 0 (tools: the marching kernel's traversal without its halo, window or arithmetic): a WAVE owns a column strip of 128 pixels and walks down -span... rows of it;
+    // the image width comes in through `rev` (pixel pairs per row)
+    const int W2s = span < 0 ? rev : 0, strips = span < 0 ? W2s / 64 : 0;
+    const long rows_total = span < 0 ? n2 / W2s : 0, waves = (long)gridDim.x * 4, segs_per_strip = span < 0 ? waves / strips : 0;
+    const long Rw = span < 0 ? (rows_total + segs_per_strip - 1) / segs_per_strip : 0;
     for (long it = 0;; ++it) {
+        long i;
+        if (span < 0) {
+            const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+            const long strip = wid % strips, seg = wid / strips;
+            const long row = seg * Rw + it;
+            if (it >= Rw || seg >= segs_per_strip) break;
+            if (row >= rows_total) break;
+            i = row * W2s + strip * 64 + (threadIdx.x & 63);
+        } else {
         const long band = it / span, within = it % span;
         const long chunk = (band * gridDim.x + blockIdx.x) * span + within;
         if (band * (long)gridDim.x * span >= chunks) break;
         // rev: the same chunks in the opposite order -- what the previous launch touched LAST is read FIRST (the part of it the 256 MB Infinity Cache still holds)
-        const long i = (rev ? chunks - 1 - chunk : chunk) * 256 + threadIdx.x;
+        i = (rev ? chunks - 1 - chunk : chunk) * 256 + threadIdx.x;
+        }
         if (i >= n2 || i < 0) continue;
-        float4 r = ldf4(ro4 + i, nt_ra); float2 ra = ldf2(ra2 + i, nt_ra);
-        const float4 a = ldf4(ao4 + i, nt_ra); const float2 aa = ldf2(aa2 + i, nt_ra);
-        const float4 pp = ldf4(po4 + i, nt_pin); const float2 pa = ldf2(pa2 + i, nt_pin);
+        // FUSED (layout experiment): every solver vector as ONE stream of 6 floats per pixel pair (x0 y0 a0 x1 y1 a1) instead of an Offset plane and an Angle plane:
+        // 9 address streams per workgroup instead of 15
+        float4 r, a, pp; float2 ra, aa, pa;
+        if (FUSED) {
+            const float2* R6 = (const float2*)r_in + 3 * i; const float2* A6 = (const float2*)A_in + 3 * i; const float2* P6 = (const float2*)p_in + 3 * i;
+            const float2 r0 = ldf2(R6, nt_ra), r1 = ldf2(R6 + 1, nt_ra), r2 = ldf2(R6 + 2, nt_ra); r = make_float4(r0.x, r0.y, r1.x, r1.y); ra = r2;
+            const float2 a0 = ldf2(A6, nt_ra), a1 = ldf2(A6 + 1, nt_ra), a2 = ldf2(A6 + 2, nt_ra); a = make_float4(a0.x, a0.y, a1.x, a1.y); aa = a2;
+            const float2 p0 = ldf2(P6, nt_pin), p1 = ldf2(P6 + 1, nt_pin), p2 = ldf2(P6 + 2, nt_pin); pp = make_float4(p0.x, p0.y, p1.x, p1.y); pa = p2;
+        } else {
+            r = ldf4(ro4 + i, nt_ra); ra = ldf2(ra2 + i, nt_ra);
+            a = ldf4(ao4 + i, nt_ra); aa = ldf2(aa2 + i, nt_ra);
+            pp = ldf4(po4 + i, nt_pin); pa = ldf2(pa2 + i, nt_pin);
+        }
         const float4 c = ldf4(cs4 + i, nt_const); const unsigned f = nt_const ? (unsigned)__builtin_nontemporal_load(f2 + i) : (unsigned)f2[i];
         r.x -= alpha * a.x; r.y -= alpha * a.y; r.z -= alpha * a.z; r.w -= alpha * a.w; ra.x -= alpha * aa.x; ra.y -= alpha * aa.y;
         const float m = (f & 1u) ? 0.5f : 0.25f;
         const float4 q = make_float4(m * r.x + c.x * pp.x, m * r.y + c.y * pp.y, m * r.z + c.z * pp.z, m * r.w + c.w * pp.w);
         const float2 qa = make_float2(m * ra.x + pa.x, m * ra.y + pa.y);
+        if (FUSED) {
+            float2* R6 = (float2*)r_out + 3 * i; float2* Q6 = (float2*)p_out + 3 * i; float2* A6 = (float2*)A_out + 3 * i;
+            stf2(R6, make_float2(r.x, r.y), nt_out); stf2(R6 + 1, make_float2(r.z, r.w), nt_out); stf2(R6 + 2, ra, nt_out);
+            stf2(Q6, make_float2(q.x, q.y), nt_pout); stf2(Q6 + 1, make_float2(q.z, q.w), nt_pout); stf2(Q6 + 2, qa, nt_pout);
+            stf2(A6, make_float2(q.x + r.x, q.y + r.y), nt_out); stf2(A6 + 1, make_float2(q.z + r.z, q.w + r.w), nt_out); stf2(A6 + 2, make_float2(qa.x + ra.x, qa.y + ra.y), nt_out);
+        } else {
         stf4(Ro4 + i, r, nt_out); stf2(Ra2 + i, ra, nt_out);
         stf4(qo4 + i, q, nt_pout); stf2(qa2 + i, qa, nt_pout);
         stf4(Ao4 + i, make_float4(q.x + r.x, q.y + r.y, q.z + r.z, q.w + r.w), nt_out); stf2(Aa2 + i, make_float2(qa.x + ra.x, qa.y + ra.y), nt_out);
+        }
         if (DELTA) {
-            float4 d = ldf4(dl4 + i, nt_delta); float2 da = ldf2(dl2 + i, nt_delta);
-            const float4 o = qo4[i]; const float2 oa = qa2[i];     // (stand-in for p_{k-2}: the plane about to be overwritten)
+            float4 d; float2 da; float4 o; float2 oa;
+            if (FUSED) {
+                const float2* D6 = (const float2*)delta + 3 * i; const float2* O6 = (const float2*)p_out + 3 * i;
+                const float2 d0 = ldf2(D6, nt_delta), d1 = ldf2(D6 + 1, nt_delta), d2 = ldf2(D6 + 2, nt_delta); d = make_float4(d0.x, d0.y, d1.x, d1.y); da = d2;
+                const float2 o0 = O6[0], o1 = O6[1], o2 = O6[2]; o = make_float4(o0.x, o0.y, o1.x, o1.y); oa = o2;
+            } else {
+            d = ldf4(dl4 + i, nt_delta); da = ldf2(dl2 + i, nt_delta);
+            o = qo4[i]; oa = qa2[i];     // (stand-in for p_{k-2}: the plane about to be overwritten)
+            }
             d.x += alpha * (pp.x + o.x); d.y += alpha * (pp.y + o.y); d.z += alpha * (pp.z + o.z); d.w += alpha * (pp.w + o.w);
             da.x += alpha * (pa.x + oa.x); da.y += alpha * (pa.y + oa.y);
-            stf4(dl4 + i, d, nt_delta); stf2(dl2 + i, da, nt_delta);
+            if (FUSED) { float2* D6 = (float2*)delta + 3 * i; stf2(D6, make_float2(d.x, d.y), nt_delta); stf2(D6 + 1, make_float2(d.z, d.w), nt_delta); stf2(D6 + 2, da, nt_delta); }
+            else { stf4(dl4 + i, d, nt_delta); stf2(dl2 + i, da, nt_delta); }
         }
     }
 }
@@ -445,12 +507,12 @@ __global__ __launch_bounds__(256) void k_stream_ref(long n2, long N, int span, i
 inline MarchGeo make_march_geo(int W, int H, int row0, int row1, int R)
 {
     MarchGeo g; g.W = W; g.H = H; g.row0 = row0; g.row1 = row1; g.R = R;
-    g.map = g_march_map; g.use = g_march_dbg == 3 ? 128 : MARCH_USE;
+    g.map = g_march_map; g.use = (g_march_dbg == 3 || g_march_dbg == 6) ? 128 : MARCH_USE;
     g.nstrips = (W + g.use - 1) / g.use;
     const int nseg = (row1 - row0 + R - 1) / R;
     g.nwgrow = (nseg + MARCH_NT / 64 - 1) / (MARCH_NT / 64);
     g.total = g.nstrips * g.nwgrow;
-    if (g.map == 1) g.total = ((g.nstrips + 3) / 4) * nseg;
+    if (g.map >= 1) g.total = ((g.nstrips + 3) / 4) * nseg;
     return g;
 }
 
@@ -461,7 +523,7 @@ inline long march_cap(int occ) { return g_march_cap > 0 ? g_march_cap : (long)th
 inline int pick_rows(int W, int rows, int occ)
 {
     if (g_march_rows > 0) return g_march_rows;
-    const int use = g_march_dbg == 3 ? 128 : MARCH_USE;
+    const int use = (g_march_dbg == 3 || g_march_dbg == 6) ? 128 : MARCH_USE;
     return march_rows_per_segment(rows, (W + use - 1) / use, MARCH_NT / 64, march_cap(occ));
 }
 
@@ -473,7 +535,7 @@ constexpr int MARCH_WG_PER_CU = 1;                                // grid sizing
     X(2, 0, 2, 0) X(2, 1, 2, 0) X(2, 3, 2, 0) X(2, 9, 2, 0) X(2, 11, 2, 0) X(2, 33, 2, 0) X(2, 35, 2, 0) X(2, 41, 2, 0) X(2, 43, 2, 0) \
     X(2, 5, 2, 0) X(2, 17, 2, 0) X(2, 21, 2, 0) X(2, 31, 2, 0) X(2, 63, 2, 0) \
     X(2, 1, 3, 0) X(2, 11, 3, 0) X(2, 43, 3, 0) X(1, 1, 3, 0) X(1, 11, 3, 0) X(1, 43, 3, 0) X(1, 1, 4, 0) X(1, 11, 4, 0) \
-    X(2, 5, 2, 4) X(2, 0, 2, 4) X(2, 1, 2, 4) X(2, 4, 2, 0) X(2, 4, 2, 4) X(2, 16, 2, 0) X(2, 16, 2, 4) \
+    X(2, 5, 2, 6) X(2, 11, 2, 6) X(2, 5, 2, 4) X(2, 0, 2, 4) X(2, 1, 2, 4) X(2, 4, 2, 0) X(2, 4, 2, 4) X(2, 16, 2, 0) X(2, 16, 2, 4) \
     X(2, 1, 2, 1) X(2, 1, 2, 2) X(1, 1, 2, 0) X(3, 1, 2, 0) X(2, 5, 2, 1) X(2, 11, 2, 1) X(2, 0, 2, 1) X(2, 1, 2, 3) X(2, 5, 2, 3) X(2, 11, 2, 3) X(2, 0, 2, 3)
 
 template <bool DIST>
@@ -584,10 +646,15 @@ int thallo_hip_iw_stream_ref(int W, int H, const float* cs, const unsigned char*
 {
     const long N = (long)W * H, n2 = N / 2;
     const int grid = thallo_hip_device_cu_count() * blocks_per_cu;
-    const int rev = span >= 1000 ? 1 : 0; if (rev) span -= 1000;              // (tools: span + 1000 = the reversed traversal)
-    if (span <= 0) span = (int)(((n2 + 255) / 256 + grid - 1) / grid);      // 0: one contiguous region per workgroup
+    int rev = span >= 1000 ? 1 : 0; if (rev) span -= 1000;              // (tools: span + 1000 = the reversed traversal)
+    if (span < 0) { if ((W / 2) % 64) return -(int)hipErrorInvalidValue; rev = W / 2; }      // (tools: span < 0 = column strips walked down by waves, like the marching kernel)
+    else if (span == 0) span = (int)(((n2 + 255) / 256 + grid - 1) / grid);      // 0: one contiguous region per workgroup
 #define SR(NTM) do { if (with_delta) hipLaunchKernelGGL((k_stream_ref<NTM, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, rev, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); \
                      else hipLaunchKernelGGL((k_stream_ref<NTM, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, rev, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); } while (0)
+#define SRF(NTM) do { if (with_delta) hipLaunchKernelGGL((k_stream_ref<NTM, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, rev, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); \
+                     else hipLaunchKernelGGL((k_stream_ref<NTM, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, n2, N, span, rev, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, 0.5f); } while (0)
+    if (ntm == 100) { SRF(0); return check_launch(); } if (ntm == 105) { SRF(5); return check_launch(); } if (ntm == 111) { SRF(11); return check_launch(); }
+    if (ntm == 5) { SR(5); return check_launch(); }
     if (ntm == 0) SR(0); else if (ntm == 1) SR(1); else if (ntm == 11) SR(11); else if (ntm == 43) SR(43); else if (ntm == 31) SR(31); else if (ntm == 63) SR(63); else return -(int)hipErrorInvalidValue;
 #undef SR
     return check_launch();

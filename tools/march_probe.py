@@ -153,7 +153,7 @@ if os.environ.get("MB_MODE") == "rows":          # rows-per-segment sweep at the
             out[f"march_rows{rows}_us"] = "launch refused"
     print(json.dumps(out)); sys.exit(0)
 
-if os.environ.get("MB_MODE") == "stamps":        # sweep build: phase time stamps (tile kernel: thread 0 of each workgroup; marching kernel: lane 0 of each wave), last launch of a chain
+if os.environ.get("MB_MODE") == "stamps":        # stamps build (THALLO_LIB=tools/ab/libThallo_stamps.so, see csrc/Makefile): phase time stamps (tile kernel: thread 0 of each workgroup; marching kernel: lane 0 of each wave), last launch of a chain
     stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
     assert L.thallo_hip_debug_stamps(vp(stamps.data_ptr())) == 0 and L.thallo_hip_debug_stamps_march(vp(stamps.data_ptr())) == 0
     if os.environ.get("MB_ROWS"):
@@ -196,6 +196,52 @@ if os.environ.get("MB_MODE") == "updown":         # sweep build: every other lau
             out[f"nt{nt}_alternating_us_{rep}"] = [round(timeit("march", hook=alt), 2), round(timeit("march", modes=(2,), hook=alt), 2), round(timeit("march", modes=(4,), hook=alt), 2)]
             out[f"nt{nt}_alternating_by_pairs_us_{rep}"] = [round(timeit("march", hook=lambda k: L.thallo_hip_march_debug_set(4, 4 if (k & 2) else 0)), 2)]
             L.thallo_hip_march_debug_set(4, 0)
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "ab":             # any build: the marching kernel at its default configuration (product vs sweep build: the sweep build's stamp checks drain the loads every row)
+    out = {"W": W, "H": H, "lib": os.environ.get("THALLO_LIB", "product")}
+    for rep in range(3):
+        out[f"march_us_{rep}"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "uncond":         # sweep build: dbg 3 (aligned strips, no halo, no arithmetic) against dbg 6 (the same with every store unconditional: the compiler's
+    out = {"W": W, "H": H}                        # s_waitcnt vmcnt(N) then count the stores too -- 41 / 40 / 37 / 36 / 34 instead of 23 / 22 / 19 / 18 / 16)
+    for rep in range(3):
+        for nt in (5, 11):
+            for dbg in (0, 3, 6):
+                cfg(2, nt, 2, dbg)
+                out[f"nt{nt}_dbg{dbg}_us_{rep}"] = [round(timeit("march", modes=(2,)), 2)]
+        out[f"stream_strips_nt5_percu1_us_{rep}"] = round(time_stream(0, 5, 1, span=-1), 2)
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "strips":         # sweep build: the streaming reference in linear chunks vs walking column strips down like the marching kernel (no halo, no window, no arithmetic)
+    out = {"W": W, "H": H}
+    for rep in range(3):
+        for nt in (5, 0, 11):
+            for per_cu in (1, 2, 4):
+                out[f"linear_nt{nt}_percu{per_cu}_us_{rep}"] = [round(time_stream(0, nt, per_cu, span=0), 2), round(time_stream(1, nt, per_cu, span=0), 2)]
+                out[f"strips_nt{nt}_percu{per_cu}_us_{rep}"] = [round(time_stream(0, nt, per_cu, span=-1), 2), round(time_stream(1, nt, per_cu, span=-1), 2)]
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "pages":          # sweep build: the 4 waves of a workgroup stacked (0), side by side (1), side by side with a barrier per three rows (2)
+    out = {"W": W, "H": H}
+    for rep in range(2):
+        for nt in (5, 0):
+            for mp in (0, 1, 2):
+                for rows in (0, 72, 144):
+                    cfg(2, nt, 2, 0, rows, mp)
+                    try:
+                        out[f"nt{nt}_map{mp}_rows{rows}_us_{rep}"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+                    except AssertionError:
+                        out[f"nt{nt}_map{mp}_rows{rows}_us_{rep}"] = "refused"
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "layout":         # sweep build: streaming reference with the solver vectors as planes (Offset | Angle) vs as one 6-floats-per-pixel-pair stream each
+    out = {"W": W, "H": H}
+    for rep in range(3):
+        for nt in (0, 5, 11):
+            out[f"planes_nt{nt}_us_{rep}"] = [round(time_stream(0, nt, 2, span=0), 2), round(time_stream(1, nt, 2, span=0), 2)]
+            out[f"fused_nt{nt}_us_{rep}"] = [round(time_stream(0, 100 + nt, 2, span=0), 2), round(time_stream(1, 100 + nt, 2, span=0), 2)]
     print(json.dumps(out)); sys.exit(0)
 
 if os.environ.get("MB_MODE") == "dsums":          # sweep build: what the three double sums cost (dbg 2 = the kernel without them; cache policy 1)

@@ -31,6 +31,11 @@ int g_march_map = 0;       // 1 = the 4 waves of a workgroup side by side (x-adj
 #else
 constexpr int g_march_dbg = 0, g_march_map = 0;
 #endif
+#ifdef THALLO_MARCH_SWEEP
+constexpr bool MARCH_MAPS = true;
+#else
+constexpr bool MARCH_MAPS = false;      // the product has no workgroup-shape experiments (and no s_barrier in its row loop)
+#endif
 }
 
 using namespace thallo;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         const int grp = blockIdx.x % G, l = blockIdx.x / G;
         const long lo = (long)g.total * grp / G, hi = (long)g.total * (grp + 1) / G;
         const long id = lo + l;
-        if (id < hi && g.map >= 1) {        // (microbench) the 4 waves side by side: one segment of 4 x-adjacent strips; map 2: + a workgroup barrier per loop trip (three rows),
+        if (MARCH_MAPS && id < hi && g.map >= 1) {        // (microbench) the 4 waves side by side: one segment of 4 x-adjacent strips; map 2: + a workgroup barrier per loop trip (three rows),
             const int nsb = (g.nstrips + 3) / 4;                             // so that the four waves touch the same image rows -- the same DRAM pages -- at the same time
             strip = (int)(id % nsb) * 4 + wave;
             const int seg = (int)(id / nsb);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
 #pragma unroll
         for (int j = 0; j < 3; ++j) { slot[j] = RawT{}; dsl[j] = RawD{}; }
         for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) {
-            if (g.map == 2) __builtin_amdgcn_s_barrier();
+            if (MARCH_MAPS && g.map == 2) __builtin_amdgcn_s_barrier();
             // The iteration's scalars, at the start of the SECOND trip: the first trip only issued the loads of rows t_first .. t_first + 2, nothing
             // needed alpha / beta yet; now the partial (or word) loads queue up behind those row loads and the additions run while the rows arrive.
             if (t0 == t_first) MARCH_STAMP(2);
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
             }
         }
     }
-    else if (g.map == 2 && sya < syb) {      // a wave without a strip: the same number of barriers as its three siblings
+    else if (MARCH_MAPS && g.map == 2 && sya < syb) {      // a wave without a strip: the same number of barriers as its three siblings
         const int t_first = DBG == 3 ? sya : sya - 1, t_last = DBG == 3 ? syb - 1 : syb;
         for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) __builtin_amdgcn_s_barrier();
     }

@@ -50,16 +50,48 @@ __global__ __launch_bounds__(BLOCK) void k_ell(long rows, int K, const float* __
         for (int k = 0; k < K; ++k) { const float d = v[k]; if (c[k] >= 0 && d != 0.0f) atomicAdd(Ap + c[k], s * d); }
     }
 }
-// dense J^T J for small n (gauss_newton.t:560-622, 1216-1241: cuBLAS gemm once per GN iteration, gemv per PCG iteration): accumulated from the
-// materialized rows as outer products; then Ap = (J^T J) p, one wave per matrix row
-__global__ __launch_bounds__(BLOCK) void k_dense_accumulate(long rows, int K, const float* __restrict__ val, const int* __restrict__ col, long n, float* __restrict__ JtJ)
+// dense J^T J for small n (gauss_newton.t:560-622, 1216-1241: cuBLAS gemm once per GN iteration, gemv per PCG iteration): formed from the
+// materialized rows tile by tile on the matrix cores; then Ap = (J^T J) p, one wave per matrix row
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// One WAVE per 32 x 32 tile (unknowns a0.., unknowns b0..) of the lower triangle, on the matrix cores: the rows of J come 64 at a time, each lane densifies ITS row's
+// entries that fall into the tile's two column ranges into LDS (a row may name an unknown twice: +=), and the tile gains sum_i J[i][a] J[i][b] as
+// 32 x v_mfma_f32_32x32x2_f32 per 64 rows (f32 in, f32 accumulate: an fmaf chain over the rows in their order -- the sum is the same in every run, which the
+// atomic scatter this replaces was not).  Operand / result lane maps: cdna_hip_programming.md "fragment layout" (A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31];
+// result register v of lane l = element (row (v & 3) + 8 (v >> 2) + 4 (l >> 5), column l & 31)).  The tile is ADDED to J^T J (several residual groups accumulate
+// into one matrix, launch after launch on one stream) and mirrored into the upper triangle.
+__global__ __launch_bounds__(64) void k_dense_accumulate(long rows, int K, const float* __restrict__ val, const int* __restrict__ col, long n, float* __restrict__ JtJ)
 {
-    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < rows; i += (long)gridDim.x * BLOCK) {
-        const float* v = val + i * K; const int* c = col + i * K;
-        for (int a = 0; a < K; ++a) {
-            if (c[a] < 0 || v[a] == 0.0f) continue;
-            for (int b = 0; b < K; ++b) if (c[b] >= 0 && v[b] != 0.0f) atomicAdd(JtJ + (long)c[a] * n + c[b], v[a] * v[b]);
+    __shared__ float PA[64][33], PB[64][33];
+    const long ta = blockIdx.y, tb = blockIdx.x;
+    if (tb > ta) return;
+    const int a0 = (int)(ta * 32), b0 = (int)(tb * 32);
+    const int l = threadIdx.x, m = l & 31, h = l >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    for (long r0 = 0; r0 < rows; r0 += 64) {
+        for (int e = 0; e < 33; ++e) { PA[l][e] = 0.0f; PB[l][e] = 0.0f; }
+        const long i = r0 + l;
+        if (i < rows) {
+            const float* v = val + i * K; const int* c = col + i * K;
+            for (int k = 0; k < K; ++k) {
+                const int ck = c[k]; const float vk = v[k];
+                if (ck < 0 || vk == 0.0f) continue;
+                if (ck >= a0 && ck < a0 + 32) PA[l][ck - a0] += vk;
+                if (ck >= b0 && ck < b0 + 32) PB[l][ck - b0] += vk;
+            }
         }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 64; q += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[q + h][m], PB[q + h][m], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long i = a0 + (v & 3) + 8 * (v >> 2) + 4 * h, j = b0 + m;
+        if (i >= n || j >= n) continue;
+        if (ta != tb) { JtJ[i * n + j] += acc[v]; JtJ[j * n + i] += acc[v]; }
+        else JtJ[i * n + j] += acc[v];            // a diagonal tile holds both triangles itself (P_A = P_B: the product is symmetric bit for bit)
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_dense_gemv(long n, const float* __restrict__ M, const float* __restrict__ x, float* __restrict__ y)
@@ -120,27 +152,35 @@ __global__ __launch_bounds__(BLOCK) void k_potrf_panel(long n, long k, float* __
         for (int c = 0; c < nb; ++c) A[r * n + k + c] = x[c];
     }
 }
-// trailing update A22 -= L21 L21^T (lower triangle only), one NB x NB tile per workgroup
-__global__ __launch_bounds__(BLOCK) void k_syrk_tile(long n, long k, int nb, float* __restrict__ A)
+// trailing update A22 -= L21 L21^T (lower triangle only), one NB x NB tile per WAVE on the matrix cores: the tile's product P Q^T (P = the panel rows of the
+// tile's rows, Q = of its columns, both NB x nb) is 16 x v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, an fmaf chain over q in natural order, i.e. the same
+// arithmetic as a scalar loop.  Operands: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31] of the step's two k; result register v of lane l is
+// element (row (v & 3) + 8 (v >> 2) + 4 (l >> 5), column l & 31) (cdna_hip_programming.md, fragment layout).  The panels go through LDS once (coalesced reads).
+__global__ __launch_bounds__(64) void k_syrk_tile(long n, long k, int nb, float* __restrict__ A)
 {
+    static_assert(NB == 32, "one 32x32x2 MFMA tile");
     __shared__ float P[NB][NB + 1], Q[NB][NB + 1];
     const long base = k + nb;
     const long tr = blockIdx.y, tc = blockIdx.x;
     if (tc > tr) return;
     const long r0 = base + tr * NB, c0 = base + tc * NB;
-    const int t = threadIdx.x;
-    for (int e = t; e < NB * NB; e += BLOCK) {
+    const int l = threadIdx.x;
+    for (int e = l; e < NB * NB; e += 64) {
         const int i = e / NB, j = e % NB;
         P[i][j] = (r0 + i < n && j < nb) ? A[(r0 + i) * n + k + j] : 0.0f;
         Q[i][j] = (c0 + i < n && j < nb) ? A[(c0 + i) * n + k + j] : 0.0f;
     }
     __syncthreads();
-    for (int e = t; e < NB * NB; e += BLOCK) {
-        const int i = e / NB, j = e % NB;
-        if (r0 + i >= n || c0 + j >= n || c0 + j > r0 + i) continue;
-        float s = 0.0f;
-        for (int q = 0; q < NB; ++q) s += P[i][q] * Q[j][q];
-        A[(r0 + i) * n + c0 + j] -= s;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    const int m = l & 31, h = l >> 5;
+#pragma unroll
+    for (int q = 0; q < NB; q += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(P[m][q + h], Q[m][q + h], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long i = r0 + (v & 3) + 8 * (v >> 2) + 4 * h, j = c0 + m;
+        if (i < n && j < n && j <= i) A[i * n + j] -= acc[v];
     }
 }
 // one workgroup: x = L^-T L^-1 b, blockwise (the block's triangular solve by thread 0..nb-1 in LDS, the update of the rest by everyone)
@@ -192,7 +232,7 @@ int thallo_hip_dense_cholesky_solve(long n, float* A, const float* b, float* x, 
         const int nb = (int)((n - k) < NB ? (n - k) : NB);
         hipLaunchKernelGGL(k_potrf_panel, dim3(1), dim3(BLOCK), 0, s, n, k, A, info);
         const long rest = n - k - nb;
-        if (rest > 0) { const unsigned tiles = (unsigned)((rest + NB - 1) / NB); hipLaunchKernelGGL(k_syrk_tile, dim3(tiles, tiles), dim3(BLOCK), 0, s, n, k, nb, A); }
+        if (rest > 0) { const unsigned tiles = (unsigned)((rest + NB - 1) / NB); hipLaunchKernelGGL(k_syrk_tile, dim3(tiles, tiles), dim3(64), 0, s, n, k, nb, A); }
     }
     hipLaunchKernelGGL(k_potrs, dim3(1), dim3(BLOCK), 0, s, n, A, b, x);
     return check_launch();
@@ -215,8 +255,9 @@ int thallo_hip_dense_jtj_accumulate(long rows, int K, const float* val, const in
 {
     if (rows < 0 || K < 1 || !val || !col || n < 1 || !JtJ) return -(int)hipErrorInvalidValue;
     if (rows == 0) return 0;
-    long want = (rows + BLOCK - 1) / BLOCK; if (want > 4096) want = 4096;
-    hipLaunchKernelGGL(k_dense_accumulate, dim3((unsigned)want), dim3(BLOCK), 0, (hipStream_t)stream, rows, K, val, col, n, JtJ);
+    const unsigned tiles = (unsigned)((n + 31) / 32);
+    if (tiles > 65535u) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dense_accumulate, dim3(tiles, tiles), dim3(64), 0, (hipStream_t)stream, rows, K, val, col, n, JtJ);
     return check_launch();
 }
 

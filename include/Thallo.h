@@ -13,8 +13,12 @@
  *    precompiled gfx950 plugins; an unrecognised .t makes Thallo_ProblemPlan print a
  *    diagnostic and return NULL (the reference prints a Lua traceback and returns NULL,
  *    API/src/thallo.t:1431-1432).
- *  - DIFF: cpuOnly=1 and doublePrecision=1 are rejected (NULL state / NULL plan); this build
- *    has no CPU fallback on purpose.
+ *  - DIFF: cpuOnly=1 is rejected (NULL state); this build has no CPU fallback on purpose.
+ *  - doublePrecision=1 (API/src/precision.t:3-6: thallo_float = double): every problem file goes through the
+ *    front-end, whose kernels are generated with thallo_float = double, and the reference-shaped double loop drives
+ *    them (Gauss-Newton, one GPU).  Unknowns / thallo_float arrays are doubles, arrays and Params declared `float`
+ *    stay floats, solver parameters stay floats (gauss_newton.t:200-216).  DIFF: the ThalloX_ multi-GPU / LM
+ *    extensions are not available in this mode.
  *  - DIFF: GPU errors are reported on stderr and surface as NULL / 0 returns; the process is
  *    never exit()ed (reference: API/src/cuda_util.t:103-118).
  */
@@ -31,7 +35,7 @@ typedef struct Thallo_Problem Thallo_Problem;
 
 /* Set once per Thallo_NewState; an all-zero struct is the fast default. */
 struct Thallo_InitializationParameters {
-    int doublePrecision;   /* must be 0 in this build */
+    int doublePrecision;   /* 1: thallo_float = double (generated kernels, see above) */
     int verbosityLevel;    /* 0 quiet, >=1 prints solver log + timing table at the end of a solve */
     int timingLevel;       /* 0/1 coarse events, 2 per-kernel hipEvents, 3 additionally device-syncs around them */
     int threadsPerBlock;   /* accepted for compatibility; kernels carry their own tuned shapes */

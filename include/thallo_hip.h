@@ -587,6 +587,21 @@ int thallo_hip_dense_gemv(long n, const float* M, const float* x, float* y, thal
 /* Numeric phase of the sparse J^T J of a non-constant J ([[Jt][J]]p, gauss_newton.t:1394-1441 csrgemm): out[dest[(i*K + a)*K + b]] += val[i*K + a] * val[i*K + b]
  * over the ELL rows of J; `dest` (positions in the CSR values, -1 = none) comes from the symbolic phase the host runs once per Init. */
 int thallo_hip_jtj_scatter(long rows, int K, const float* val, const int* dest, float* out, thallo_stream_t stream);
+/* ---- doublePrecision = 1 (precision.t:3-6: thallo_float = double): the energy-independent PCG kernels on double vectors, reference-shaped and unfused
+ * (gauss_newton.t:712-731, 774-787, 801-843, 889-899, 901-906).  Reductions leave per-workgroup partials (the return value = how many, <= THALLO_HIP_MAX_PARTIALS),
+ * thallo_hip_f64_finish adds them in index order into one device word, and the kernels that need a scalar read such words: nothing goes through the host.
+ *   init_finish: pre = guardedInvert(pre) (or 1), z = pre r, p = z, partials of r . z (alphaN_0)
+ *   dot:         partials of a . b (PCGStep1_Finish: alphaD = p . Ap)
+ *   step2:       alpha = alphaN / alphaD (0 when alphaD = 0); delta += alpha p; r -= alpha Ap; z = pre r; partials of z . r (betaN)
+ *   step3:       beta = betaN / alphaN (0 when alphaN = 0); p = z + beta p
+ *   linear_update: X += delta */
+int thallo_hip_f64_init_finish(const double* r, double* pre, double* z, double* p, long n, int use_preconditioner, double* partials_out, thallo_stream_t stream);
+int thallo_hip_f64_dot(const double* a, const double* b, long n, double* partials_out, thallo_stream_t stream);
+int thallo_hip_f64_step2(double* delta, double* r, double* z, const double* p, const double* Ap, const double* pre, long n, const double* alphaN_word, const double* alphaD_word,
+                         double* partials_out, thallo_stream_t stream);
+int thallo_hip_f64_step3(double* p, const double* z, long n, const double* betaN_word, const double* alphaN_word, thallo_stream_t stream);
+int thallo_hip_f64_linear_update(double* X, const double* delta, long n, thallo_stream_t stream);
+int thallo_hip_f64_finish(const double* partials, int count, double* word, thallo_stream_t stream);
 /* Direct solve of the dense normal equations (gauss_newton.t:1280-1328; compiled out there, opt-in here): A (n x n row-major, symmetric positive
  * definite, OVERWRITTEN by its Cholesky factor) x = b.  info[0] (device int) = 0, or 1 + the row of the first non-positive pivot. n <= 8192. */
 int thallo_hip_dense_cholesky_solve(long n, float* A, const float* b, float* x, int* info, thallo_stream_t stream);

@@ -1,0 +1,154 @@
+"""Thallo_InitializationParameters::doublePrecision = 1 (API/src/precision.t:3-6: thallo_float = double): the front-end generates the energy's kernels with
+thallo_float = double and the reference-shaped double loop of csrc/solver_f64.cpp drives them.  Checked against float64 restatements (linear energies: to 1e-12)
+and against the float path of the same files (nonlinear energies: to float accuracy, with the double run converging at least as far)."""
+import numpy as np
+import pytest
+
+import thallo_amd
+from thallo_amd import api, synthetic as syn
+from helpers import to_device, to_host, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available()
+    return t
+
+
+WEIGHTED = '''local W,H = Dims("W","H")
+Inputs {
+    X = Unknown(thallo_float2,{W,H},0),
+    A = Array(thallo_float2,{W,H},1),
+    Wt = Array(float,{W,H},2),
+    Mask = Array(float,{W,H},3),
+    w_fit = Param(%s,4)
+}
+UsePreconditioner(true)
+local x,y = W(),H()
+X:Exclude(Not(eq(Mask(x,y),0)))
+local function edge(dx,dy)
+    return Select(InBounds(x+dx,y+dy), Wt(x,y)*(X(x,y) - X(x+dx,y+dy)), 0)
+end
+r = Residuals {
+    fit = w_fit*(X(x,y) - A(x,y)),
+    regx = edge(1,0),
+    regy = edge(0,1)
+}
+'''
+
+
+@pytest.mark.parametrize("param_type", ["float", "thallo_float"])
+def test_double_precision_linear_energy_against_float64(torch, tmp_path, param_type):
+    """A masked, weighted Laplacian: thallo_float2 unknowns and targets become doubles, the `float` weight and mask planes STAY floats (the reference's double
+    mode switches thallo_float only), the weight Param is a host float or a host double by its declared type.  GN 4 x PCG 15 against the same recurrences in
+    numpy float64: costs to 1e-12, unknowns to 1e-12, excluded unknowns bit-untouched."""
+    import scipy.sparse as sps
+    W, H = 40, 28
+    f = tmp_path / "weighted_laplacian.t"
+    f.write_text(WEIGHTED % param_type)
+    rng = np.random.default_rng(3)
+    A = rng.uniform(0, 1, (H, W, 2))
+    Wt = rng.uniform(0.5, 1.5, (H, W)).astype(np.float32)
+    Mask = (rng.uniform(0, 1, (H, W)) < 0.1).astype(np.float32)
+    X0 = A + 0.3 * rng.standard_normal(A.shape)
+    w_fit = np.float32(0.7) if param_type == "float" else np.float64(0.7)
+    dev = [torch.from_numpy(X0.copy()).cuda(), torch.from_numpy(A).cuda(), torch.from_numpy(Wt).cuda(), torch.from_numpy(Mask).cuda(), w_fit]
+    s = api.ThalloSolver((W, H), str(f), double_precision=True)
+    assert s.energy_name == "generated:weighted_laplacian.t"
+    final, costs = s.solve(dev, profiled=True, nIterations=4, lIterations=15)
+    s.close()
+    wf = float(w_fit)
+    n = 2 * W * H; idx = lambda x, y, c: 2 * (y * W + x) + c
+    rows, cols, vals, rhs = [], [], [], []
+    def add_row(entries):
+        k = len(rhs); rhs.append(0.0)
+        for j, v in entries: rows.append(k); cols.append(j); vals.append(v)
+    for y in range(H):
+        for x in range(W):
+            for c in range(2):
+                add_row([(idx(x, y, c), wf)]); rhs[-1] = -wf * float(A[y, x, c])
+    for dx, dy in ((1, 0), (0, 1)):
+        for y in range(H):
+            for x in range(W):
+                for c in range(2):
+                    if x + dx < W and y + dy < H: add_row([(idx(x, y, c), float(Wt[y, x])), (idx(x + dx, y + dy, c), -float(Wt[y, x]))])
+                    else: add_row([])
+    J = sps.csr_matrix((vals, (rows, cols)), shape=(len(rhs), n)); b0 = np.array(rhs)
+    free = np.repeat(Mask.reshape(-1) == 0, 2)
+    xk = X0.reshape(-1).copy()
+    ref = [0.5 * np.sum((J @ xk + b0) ** 2)]
+    Jf = J[:, free]
+    for _ in range(4):
+        F = J @ xk + b0
+        g = Jf.T @ F; d = np.asarray(Jf.multiply(Jf).sum(axis=0)).ravel()
+        M = 1.0 / (1.0 + np.sqrt(d)) ** 2
+        r = -g; z = M * r; pvec = z.copy(); delta = np.zeros_like(r); aN = r @ z
+        for _k in range(15):
+            Ap = Jf.T @ (Jf @ pvec); aD = pvec @ Ap
+            alpha = aN / aD if aD != 0 else 0.0
+            delta += alpha * pvec; r -= alpha * Ap; z = M * r; bN = z @ r
+            beta = bN / aN if aN != 0 else 0.0
+            pvec = z + beta * pvec; aN = bN
+        xk[free] += delta
+        ref.append(0.5 * np.sum((J @ xk + b0) ** 2))
+    assert rel_err(np.array(costs), np.array(ref)) < 1e-12, (costs, ref)
+    got = to_host(dev[0]).reshape(-1)
+    assert got.dtype == np.float64
+    assert np.abs(got[~free] - X0.reshape(-1)[~free]).max() == 0.0
+    assert np.abs(got - xk).max() < 1e-12
+
+
+def _solve_both(fname, dims, params32, monkeypatch, **sp):
+    """The same bundled .t through the front-end in float and in double (unknowns / thallo_float arrays as doubles, float Params as they are)."""
+    out = {}
+    for dbl in (False, True):
+        monkeypatch.setenv("THALLO_FRONTEND", "generate")
+        import torch
+        dev = []
+        for p in params32:
+            if isinstance(p, np.ndarray) and p.dtype == np.float32: dev.append(torch.from_numpy(p.astype(np.float64) if dbl else p.copy()).cuda())
+            elif isinstance(p, np.ndarray): dev.append(torch.from_numpy(p.copy()).cuda())
+            else: dev.append(np.float32(p))
+        s = api.ThalloSolver(dims, thallo_amd.energy_file(fname), double_precision=dbl)
+        assert s.energy_name.startswith("generated:")
+        final, costs = s.solve(dev, profiled=True, **sp)
+        s.close()
+        out[dbl] = (dev, np.array(costs))
+    return out
+
+
+def test_double_precision_image_warping_follows_the_float_path(torch, monkeypatch):
+    """image_warping (nonlinear: cos / sin of the Angle unknown, Exclude, two unknown images) generated in double: the trajectory agrees with the float kernels of
+    the same file to float accuracy, and the double run never ends above it by more than that."""
+    W, H = 96, 64
+    p = syn.image_warping(W, H)
+    res = _solve_both("image_warping.t", (W, H), p, monkeypatch, nIterations=5, lIterations=30)
+    cf, cd = res[False][1], res[True][1]
+    assert len(cf) == len(cd) == 6
+    assert rel_err(cd[:1], cf[:1]) < 1e-6
+    assert rel_err(cd, cf) < 2e-4, (cd, cf)
+    assert cd[-1] <= cf[-1] * (1 + 1e-4)
+    xf, xd = to_host(res[False][0][0]), to_host(res[True][0][0])
+    assert xd.dtype == np.float64 and np.abs(xd - xf).max() < 5e-3 * max(1.0, np.abs(xf).max())
+
+
+def test_double_precision_graph_energy_follows_the_float_path(torch, monkeypatch):
+    """arap_mesh_deformation (graph domain through Sparse maps, float3 unknowns, rotations) in double against the float kernels of the same file."""
+    p = syn.arap_mesh(24, 16)
+    N = p[2].shape[0]; E = p[6].shape[0]
+    res = _solve_both("arap_mesh_deformation.t", (N, E), p, monkeypatch, nIterations=4, lIterations=25)
+    cf, cd = res[False][1], res[True][1]
+    assert rel_err(cd[:1], cf[:1]) < 1e-6
+    assert rel_err(cd, cf) < 2e-4, (cd, cf)
+    assert cd[-1] <= cf[-1] * (1 + 1e-4)
+
+
+def test_double_precision_refuses_what_it_cannot_run(torch, tmp_path):
+    """An unknown declared with a fixed float type has no place in double solver vectors: the Plan fails with a message, it does not run in float silently."""
+    f = tmp_path / "fixed.t"
+    f.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0), A = Array(float,{N},1) }\nlocal i = N()\nr = Residuals { fit = X(i) - A(i) }\n')
+    with pytest.raises(RuntimeError, match="doublePrecision"):
+        api.ThalloSolver((16,), str(f), double_precision=True)

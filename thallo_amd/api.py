@@ -10,6 +10,8 @@ There is no CPU fallback: a missing libThallo.so or a missing GPU raises.
 import ctypes as C
 import os
 
+import numpy as np
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libThallo.so")
 ENERGY_DIR = os.path.join(_HERE, "energies")
@@ -231,8 +233,10 @@ class ThalloSolver:
         keep = []
         ptrs = []
         for p in problem_params:
-            if isinstance(p, float):
-                p = C.c_float(p)
+            if isinstance(p, np.float64):       # Param(thallo_float, ...) under double_precision=True: a host double
+                p = C.c_double(float(p))
+            elif isinstance(p, (float, np.float32)):
+                p = C.c_float(float(p))
             keep.append(p)
             ptrs.append(_ptr_of(p))
         arr = (C.c_void_p * len(ptrs))(*ptrs)

@@ -64,6 +64,8 @@ struct Input {
     InputKind kind = InputKind::Array;
     int channels = 1;
     bool is_u8 = false;                            // Array(uint8, ...)
+    bool fixed_f32 = false;                        // declared with a fixed single-precision element type (float, float3, mat3f ...) rather than a thallo_float one:
+                                                   // stays float under doublePrecision = 1 (precision.t:3-6 switches thallo_float only)
     std::vector<int> dims;                         // dimension ids (Unknown / Array: the image's; Sparse: {from..., to}: one or two source dimensions, then the target)
     int slot = -1;                                 // index into the void** problem parameters
     E exclude;                                     // Unknown:Exclude(cond), evaluated at the unknown's own index (may be null)
@@ -108,7 +110,8 @@ struct Generated {
     std::vector<long> jp_offset;                   // per residual: offset of its rows in the Jp vector (Jt[Jp] schedule), in units of elements x components
     int n_prm = 0;
 };
-bool generate_source(const Problem& p, Generated& out, std::string& err);
+// f64 (Thallo_InitializationParameters::doublePrecision): constants as double literals; the plugin compiles the unit with `float` standing for double
+bool generate_source(const Problem& p, Generated& out, std::string& err, bool f64 = false);
 
 // FNV-1a-64 of the translation unit generated from a .t file, residual names aside: two files with the same fingerprint state the same energy
 // (same expression DAG per residual component, same unknown accesses, same guards).  0 + err if the file is outside the supported subset.

@@ -27,8 +27,9 @@ namespace thallo {
 
 namespace {
 
-class GeneratedPlugin : public EnergyPlugin {
+class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     dsl::Problem P;
+    bool f64_ = false;                             // doublePrecision = 1: the unit is compiled with thallo_float = double, only the EnergyPlugin64 interface is used
     dsl::Generated G;
     std::string label;
     std::vector<long> dimv;                        // dimension sizes
@@ -70,8 +71,15 @@ class GeneratedPlugin : public EnergyPlugin {
     long rows_of(size_t ri) const { return nel[ri] * (long)P.residuals[ri].exprs.size(); }
 
 public:
-    GeneratedPlugin(const dsl::Problem& p, const unsigned* dims, bool autoschedule) : P(p)
+    GeneratedPlugin(const dsl::Problem& p, const unsigned* dims, bool autoschedule, bool f64) : P(p), f64_(f64)
     {
+        if (f64_) {
+            // the reference's double mode switches thallo_float (precision.t:3-6); an unknown declared with a fixed float type has no place in double solver vectors
+            for (auto& in : P.inputs) if (in.kind == dsl::InputKind::Unknown && in.fixed_f32) { set_error("%s: doublePrecision = 1 and the unknown %s is declared with a fixed float type (use thallo_float)", P.file.c_str(), in.name.c_str()); return; }
+            // one schedule in this mode: the generated kernels recompute the partials every PCG iteration (materialized J / J^T J / Jp live in float buffers)
+            for (auto& r : P.residuals) { r.mat_J = false; r.mat_JtJ = false; r.mat_Jp = false; }
+            P.direct_solve = false;
+        }
         label = "generated:" + P.file.substr(P.file.find_last_of('/') == std::string::npos ? 0 : P.file.find_last_of('/') + 1);
         for (size_t d = 0; d < P.dims.size(); ++d) dimv.push_back((long)dims[P.canonical((int)d)]);      // (alias ids: further iteration variables over a declared dimension)
         uoff.assign(P.inputs.size(), -1);
@@ -82,7 +90,7 @@ public:
             uoff[i] = n_unk; imgs.push_back({ in.slot, px * in.channels }); unknown_input.push_back((int)i); n_unk += px * in.channels;
         }
         std::string err;
-        if (!dsl::generate_source(P, G, err)) { set_error("%s: %s", P.file.c_str(), err.c_str()); return; }
+        if (!dsl::generate_source(P, G, err, f64_)) { set_error("%s: %s", P.file.c_str(), err.c_str()); return; }
         if (compile()) return;
         // Unknown-wise (gather) lowering per residual: asked for with r.<name>:compute_at_output(true), or -- like the reference's autoscheduler, which every
         // example application switches on (thallo.t:5173-5190: residual dims == unknown dims, nothing materialized) -- chosen where it exists.
@@ -97,8 +105,11 @@ public:
                         plain ? "has no unknown-wise lowering (it reads an unknown through a Sparse map, or an unknown over other dimensions than its own)" : "also materializes J / JtJ / Jp");
         }
         // Ctx layout of the generated code: const void* in[NIN]; int dim[max(NDIM,1)]; float prm[NIN]; long uoff[NIN]
+        // (doublePrecision = 1: `float` stands for double in the unit, so prm is an 8-byte-aligned array of doubles)
         const size_t nin = P.inputs.size(), nd = P.dims.empty() ? 1 : P.dims.size();
-        off_dim = 8 * nin; off_prm = off_dim + 4 * nd; off_uoff = (off_prm + 4 * nin + 7) / 8 * 8;
+        off_dim = 8 * nin;
+        if (f64_) { off_prm = (off_dim + 4 * nd + 7) / 8 * 8; off_uoff = off_prm + 8 * nin; }
+        else { off_prm = off_dim + 4 * nd; off_uoff = (off_prm + 4 * nin + 7) / 8 * 8; }
         ctx.assign(off_uoff + 8 * nin, 0);
         for (size_t d = 0; d < P.dims.size(); ++d) { const int v = (int)dimv[d]; memcpy(&ctx[off_dim + 4 * d], &v, 4); }
         for (size_t i = 0; i < nin; ++i) memcpy(&ctx[off_uoff + 8 * i], &uoff[i], 8);
@@ -200,7 +211,11 @@ public:
     int compile()
     {
         hiprtcProgram prog = nullptr;
-        const std::string src = "#include <hip/hip_runtime.h>\n" + G.source;
+        // doublePrecision = 1: the same translation unit with `float` standing for double (values, duals, solver vectors, thallo_float arrays, atomics, shuffles);
+        // arrays declared with a fixed float type keep reading floats through f32_t
+        const std::string f64_prelude = "#define THALLO_F32_T\ntypedef float f32_t;\n#define float double\n#define sqrtf sqrt\n#define sinf sin\n#define cosf cos\n#define fabsf fabs\n"
+                                        "#define powf pow\n#define floorf floor\n#define ceilf ceil\n";
+        const std::string src = "#include <hip/hip_runtime.h>\n" + (f64_ ? f64_prelude : std::string()) + G.source;
         if (hiprtcCreateProgram(&prog, src.c_str(), "thallo_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { set_error("hiprtcCreateProgram failed"); return -1; }
         // the architecture of the device the plan will run on (a library built for another ARCH must not generate gfx950 code and then blame the device)
         std::string arch = "--offload-arch=gfx950";
@@ -241,12 +256,55 @@ public:
             void* v = p[in.slot];
             if (!v) { set_error("%s: problem parameter %d (%s) is NULL", label.c_str(), in.slot, in.name.c_str()); return -1; }
             bound[i] = v;
-            if (in.kind == dsl::InputKind::Param) { const float f = *(const float*)v; memcpy(&ctx[off_prm + 4 * i], &f, 4); v = nullptr; }     // host scalar, re-read every Init / Step
+            if (in.kind == dsl::InputKind::Param) {     // host scalar, re-read every Init / Step
+                if (f64_) { const double d = in.fixed_f32 ? (double)*(const float*)v : *(const double*)v; memcpy(&ctx[off_prm + 8 * i], &d, 8); }
+                else { const float f = *(const float*)v; memcpy(&ctx[off_prm + 4 * i], &f, 4); }
+                v = nullptr;
+            }
             memcpy(&ctx[8 * i], &v, 8);
         }
         return 0;
     }
     float* unknown_ptr(int k) override { return (float*)bound[unknown_input[k]]; }
+    EnergyPlugin64* f64() override { return f64_ ? this : nullptr; }
+    double* unknown_ptr64(int k) override { return (double*)bound[unknown_input[k]]; }
+    // ---- doublePrecision = 1: the same launches on double vectors (the unit was compiled with float = double), reference-shaped and unfused
+    int cost64(LaunchCtx& c, double* out) override
+    {
+        TimedLaunch t(c, "computeCost");
+        const int cap = THALLO_HIP_MAX_PARTIALS / (int)P.residuals.size();
+        int total = 0;
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            const int g = grid_for(nel[ri], cap);
+            double* o = out + total; void* args[] = { ctx.data(), &o };
+            const int rc = launch(kernel_of((int)ri, 0), g, args, c.stream); if (rc < 0) return rc;
+            total += g;
+        }
+        return total;
+    }
+    int pcg_init64(LaunchCtx& c, Vectors64& v, double* aN) override
+    {
+        TimedLaunch t(c, "PCGInit1");
+        hipStream_t s = c.stream;
+        const size_t bytes = (size_t)v.n_alloc * sizeof(double);
+        if (hipMemsetAsync(v.r, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.pre, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {            // evalJTF: r = -J^T F, pre = diag(J^T J)   (thallo.t:3898-3902)
+            double *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
+            const int rc = launch(kernel_of((int)ri, gather_[ri] ? 6 : 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
+        }
+        return thallo_hip_f64_init_finish(v.r, v.pre, v.z, v.p, v.n, P.use_preconditioner ? 1 : 0, aN, s);           // PCGInit1_Finish (gauss_newton.t:712-731)
+    }
+    int apply_jtj64(LaunchCtx& c, Vectors64& v, const double* p, double* Ap, double* out) override
+    {
+        TimedLaunch t(c, "PCGStep1");
+        hipStream_t s = c.stream;
+        if (hipMemsetAsync(Ap, 0, (size_t)v.n_alloc * sizeof(double), s) != hipSuccess) return -1;                     // Ap_X:clear() (gauss_newton.t:1633-1635)
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            void* args[] = { ctx.data(), &p, &Ap };
+            const int rc = launch(kernel_of((int)ri, gather_[ri] ? 7 : 2), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
+        }
+        return thallo_hip_f64_dot(p, Ap, n_unk, out, s);              // PCGStep1_Finish: alphaD = p . Ap_X
+    }
 
     int cost(LaunchCtx& c, float* out) override
     {
@@ -334,11 +392,11 @@ public:
 
 }  // namespace
 
-EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, bool autoschedule)
+EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, bool autoschedule, bool f64)
 {
     dsl::Problem p; std::string err;
     if (!dsl::run_problem_file(filename, p, err, dims)) { set_error("%s", err.c_str()); return nullptr; }
-    GeneratedPlugin* g = new GeneratedPlugin(p, dims, autoschedule);
+    GeneratedPlugin* g = new GeneratedPlugin(p, dims, autoschedule, f64);
     if (!g->ok()) { delete g; return nullptr; }
     return g;
 }

@@ -75,10 +75,23 @@ struct SolverVectors {
 
 struct UnknownImage { int param_index; long n_floats; };
 
+// doublePrecision = 1 (precision.t:3-6): what a plugin that also runs on double vectors offers -- the generated plugins, compiled with thallo_float = double.
+// The driver is solver_f64.cpp's reference-shaped loop; the hand-written gfx950 kernels are float only.
+struct Vectors64 { long n = 0, n_alloc = 0; double *delta = nullptr, *r = nullptr, *z = nullptr, *Ap = nullptr, *pre = nullptr, *p = nullptr; };
+class EnergyPlugin64 {
+public:
+    virtual ~EnergyPlugin64() {}
+    virtual int cost64(struct LaunchCtx&, double* partials_out) = 0;                         // returns the partial count or < 0
+    virtual int pcg_init64(struct LaunchCtx&, Vectors64&, double* alphaN_partials) = 0;       // r = -J^T F, pre = M^-1, z = p = M^-1 r, delta = 0; partials of r . z
+    virtual int apply_jtj64(struct LaunchCtx&, Vectors64&, const double* p, double* Ap, double* alphaD_partials) = 0;      // Ap = J^T J p; partials of p . Ap
+    virtual double* unknown_ptr64(int k) = 0;
+};
+
 class EnergyPlugin {
 public:
     virtual ~EnergyPlugin() {}
     virtual const char* name() const = 0;
+    virtual EnergyPlugin64* f64() { return nullptr; }                    // non-NULL: built for doublePrecision = 1 (then ONLY this interface is used)
     virtual const char* schedule_name() const { return "matrix-free"; }    // which J^T J p schedule this plugin runs (ThalloX_PlanScheduleName)
     virtual long n_unknowns() const = 0;
     virtual const std::vector<UnknownImage>& unknown_images() const = 0;   // declaration order
@@ -211,6 +224,6 @@ bool unit_matches_bundled(const char* filename, const std::string& energy);     
 EnergyPlugin* make_plugin(const ProblemSpec& spec, const unsigned* dims);
 // the mini front-end (dsl.hpp): run the .t, generate its residual-wise kernels, compile them with hipRTC; NULL + set_error on failure
 // autoschedule (Thallo_InitializationParameters::useAutoscheduler): residuals that have an unknown-wise (gather) lowering use it unless the file says otherwise
-EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, bool autoschedule);
+EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, bool autoschedule, bool f64 = false);
 
 }  // namespace thallo

@@ -152,3 +152,52 @@ def test_double_precision_refuses_what_it_cannot_run(torch, tmp_path):
     f.write_text('local N = Dims("N")\nInputs { X = Unknown(float,{N},0), A = Array(float,{N},1) }\nlocal i = N()\nr = Residuals { fit = X(i) - A(i) }\n')
     with pytest.raises(RuntimeError, match="doublePrecision"):
         api.ThalloSolver((16,), str(f), double_precision=True)
+
+
+@pytest.mark.parametrize("form", ["graph", "dense"])
+@pytest.mark.parametrize("dbl", [True, False])
+def test_two_parameter_curve_fit_like_the_reference_dense_test(torch, form, dbl):
+    """The scenario of the reference's tests/dense (main.cpp:9-66: doublePrecision = 1, 512 samples of y = a cos(b x) + b sin(a x), generator (100, 102), start
+    (99.7, 101.6)): every residual adds into the same two unknowns (wave-aggregated atomics on doubles), through Sparse maps or over the product domain {N, U}.
+    Against the same Gauss-Newton / PCG recurrences in numpy float64: the double run to 1e-9 of the initial cost at every step, the float run to float accuracy."""
+    import os
+    dim = 512
+    a0, b0 = 100.0, 102.0
+    x = np.arange(dim) * 2.0 * 3.141592653589 / dim
+    y = a0 * np.cos(b0 * x) + b0 * np.sin(a0 * x)
+    dt = np.float64 if dbl else np.float32
+    samples = np.stack([x, y], 1).astype(dt)
+    start = np.array([[99.7, 101.6]], dtype=dt)
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "energies")
+    if form == "graph":
+        dev = [torch.from_numpy(start.copy()).cuda(), torch.from_numpy(samples).cuda(), torch.arange(dim, dtype=torch.int32).cuda(), torch.zeros(dim, dtype=torch.int32).cuda()]
+        s = api.ThalloSolver((dim, 1, dim), os.path.join(here, "curve_fit_graph.t"), double_precision=dbl)
+    else:
+        dev = [torch.from_numpy(start.copy()).cuda(), torch.from_numpy(samples).cuda()]
+        s = api.ThalloSolver((dim, 1), os.path.join(here, "curve_fit_dense.t"), double_precision=dbl)
+    final, costs = s.solve(dev, profiled=True, nIterations=6, lIterations=4)
+    s.close()
+    xs, ys = samples[:, 0].astype(np.float64), samples[:, 1].astype(np.float64)
+    p = start[0].astype(np.float64).copy()
+    F = lambda q: ys - (q[0] * np.cos(q[1] * xs) + q[1] * np.sin(q[0] * xs))
+    ref = [0.5 * np.sum(F(p) ** 2)]
+    for _ in range(6):
+        a, b = p
+        J = np.stack([-(np.cos(b * xs) + b * xs * np.cos(a * xs)), -(-a * xs * np.sin(b * xs) + np.sin(a * xs))], 1)
+        g = J.T @ F(p); d = (J * J).sum(0)
+        M = 1.0 / (1.0 + np.sqrt(d)) ** 2
+        r = -g; z = M * r; pv = z.copy(); delta = np.zeros(2); aN = r @ z
+        for _k in range(4):
+            Ap = J.T @ (J @ pv); aD = pv @ Ap
+            alpha = aN / aD if aD != 0 else 0.0
+            delta += alpha * pv; r -= alpha * Ap; z = M * r; bN = z @ r
+            beta = bN / aN if aN != 0 else 0.0
+            pv = z + beta * pv; aN = bN
+        p += delta
+        ref.append(0.5 * np.sum(F(p) ** 2))
+    costs, ref = np.array(costs), np.array(ref)
+    tol = 1e-9 if dbl else 2e-3
+    assert np.abs(costs - ref).max() <= tol * ref[0], (costs, ref)
+    if dbl:
+        assert np.abs(to_host(dev[0])[0] - p).max() < 1e-9 * 100.0
+        assert costs[-1] < 1e-6 * costs[0]          # the fit is found (the generator's parameters reproduce the samples exactly)

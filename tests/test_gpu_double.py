@@ -101,15 +101,16 @@ def test_double_precision_linear_energy_against_float64(torch, tmp_path, param_t
     assert np.abs(got - xk).max() < 1e-12
 
 
-def _solve_both(fname, dims, params32, monkeypatch, **sp):
-    """The same bundled .t through the front-end in float and in double (unknowns / thallo_float arrays as doubles, float Params as they are)."""
+def _solve_both(fname, dims, params32, monkeypatch, keep32=(), **sp):
+    """The same bundled .t through the front-end in float and in double (unknowns / thallo_float arrays as doubles; float Params and the arrays the file declares
+    with a fixed float type -- keep32: their parameter indices -- as they are)."""
     out = {}
     for dbl in (False, True):
         monkeypatch.setenv("THALLO_FRONTEND", "generate")
         import torch
         dev = []
-        for p in params32:
-            if isinstance(p, np.ndarray) and p.dtype == np.float32: dev.append(torch.from_numpy(p.astype(np.float64) if dbl else p.copy()).cuda())
+        for k, p in enumerate(params32):
+            if isinstance(p, np.ndarray) and p.dtype == np.float32: dev.append(torch.from_numpy(p.astype(np.float64) if dbl and k not in keep32 else p.copy()).cuda())
             elif isinstance(p, np.ndarray): dev.append(torch.from_numpy(p.copy()).cuda())
             else: dev.append(np.float32(p))
         s = api.ThalloSolver(dims, thallo_amd.energy_file(fname), double_precision=dbl)
@@ -144,6 +145,23 @@ def test_double_precision_graph_energy_follows_the_float_path(torch, monkeypatch
     assert rel_err(cd[:1], cf[:1]) < 1e-6
     assert rel_err(cd, cf) < 2e-4, (cd, cf)
     assert cd[-1] <= cf[-1] * (1 + 1e-4)
+
+
+@pytest.mark.parametrize("which", ["ba", "sfs"])
+def test_double_precision_on_the_other_bundled_energies(torch, monkeypatch, which):
+    """bundle_adjustment (Sparse maps into two unknown arrays, AngleAxisRotatePoint, a division by depth) and shape_from_shading (computed arrays over neighbour
+    pixels, uint8-free mask planes, sixteen Params) generated in double against the float kernels of the same files."""
+    if which == "ba":
+        p = syn.bundle_adjustment(C=12, P=60, O=300, band=8)
+        res = _solve_both("bundle_adjustment.t", (12, 60, 300), p, monkeypatch, keep32=(2,), nIterations=3, lIterations=10)      # observations = Array(float2, ...): floats in both modes
+    else:
+        p = syn.shape_from_shading(64, 48)
+        res = _solve_both("shape_from_shading.t", (64, 48), p, monkeypatch, nIterations=3, lIterations=10)
+    cf, cd = res[False][1], res[True][1]
+    assert len(cf) == len(cd) == 4
+    assert rel_err(cd[:1], cf[:1]) < 2e-6
+    assert rel_err(cd, cf) < 3e-4, (cd, cf)
+    assert cd[-1] < cd[0]
 
 
 def test_double_precision_refuses_what_it_cannot_run(torch, tmp_path):

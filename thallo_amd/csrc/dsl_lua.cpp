@@ -17,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 
@@ -26,6 +27,20 @@ namespace dsl {
 namespace {
 
 [[noreturn]] void fail(const std::string& m) { throw std::runtime_error(m); }
+// a number of the file that becomes an index offset, a vector component or a parameter slot: integral and small, or the file is refused (the cast of an
+// out-of-range double, like the overflow of an offset sum, is undefined behaviour -- tools/frontend_fuzz.cpp found both)
+constexpr long SMALL_INT_LIMIT = 1L << 20;
+int small_int(double v, const std::string& what)
+{
+    if (!(v == std::floor(v)) || v < -(double)SMALL_INT_LIMIT || v > (double)SMALL_INT_LIMIT) fail(what + ": " + std::to_string(v) + " is not a small integer");
+    return (int)v;
+}
+void add_off(int& off, long long delta)
+{
+    const long long s = (long long)off + delta;
+    if (s < -SMALL_INT_LIMIT || s > SMALL_INT_LIMIT) fail("index offset out of range");
+    off = (int)s;
+}
 
 // ================================================================================================ lexer
 struct Tok { enum K { Name, Num, Str, Op, Kw, End } k = End; std::string s; double n = 0; int line = 0; };
@@ -327,7 +342,15 @@ struct Value {
 };
 typedef std::vector<Value> Values;
 
-struct Env {
+// A closure holds its defining environment and that environment holds the closure (`local function f ... end`): a shared_ptr cycle per function of the file, i.e. a
+// leak per Thallo_ProblemPlan of any file that defines one (AddressSanitizer on tools/frontend_fuzz.cpp: image_warping.t, shape_from_shading.t ...).  Every Env of a
+// run registers here; when the interpreter goes -- normally or through an exception -- the variables of all that are still alive are dropped, which opens every cycle.
+struct Env;
+static thread_local std::set<Env*>* g_live_envs = nullptr;
+struct Env : std::enable_shared_from_this<Env> {
+    Env() { if (g_live_envs) g_live_envs->insert(this); }
+    ~Env() { if (g_live_envs) g_live_envs->erase(this); }
+    Env(const Env&) = delete; Env& operator=(const Env&) = delete;
     std::map<std::string, Value> vars; std::shared_ptr<Env> parent;
     Value* find(const std::string& n) { for (Env* e = this; e; e = e->parent.get()) { auto it = e->vars.find(n); if (it != e->vars.end()) return &it->second; } return nullptr; }
 };
@@ -362,8 +385,8 @@ E shift_expr(const E& e, const std::map<int, int>& sh, std::map<const Expr*, E>&
     auto it = memo.find(e.get()); if (it != memo.end()) return it->second;
     auto n = std::make_shared<Expr>(*e);
     for (auto& ic : n->idx) {
-        auto f = sh.find(ic.dim); if (f != sh.end()) { if (ic.sparse >= 0 && f->second != 0) fail(":get with an offset through a Sparse map is not supported"); ic.off += ic.sign * f->second; }
-        auto fb = sh.find(ic.dim_b); if (ic.dim_b >= 0 && fb != sh.end()) ic.off += ic.sign_b * fb->second;
+        auto f = sh.find(ic.dim); if (f != sh.end()) { if (ic.sparse >= 0 && f->second != 0) fail(":get with an offset through a Sparse map is not supported"); add_off(ic.off, (long long)ic.sign * f->second); }
+        auto fb = sh.find(ic.dim_b); if (ic.dim_b >= 0 && fb != sh.end()) add_off(ic.off, (long long)ic.sign_b * fb->second);
     }
     for (auto& c : n->a) c = shift_expr(c, sh, memo);
     E r = n; memo[e.get()] = r; return r;
@@ -401,17 +424,30 @@ E subst_const(const E& e, const std::map<int, int>& to, std::map<const Expr*, E>
     for (auto& ic : n->idx) {
         auto fa = to.find(ic.dim), fb = to.find(ic.dim_b), f2 = to.find(ic.dim2);
         if (ic.sparse >= 0) { if ((ic.dim >= 0 && fa != to.end()) || (ic.dim2 >= 0 && f2 != to.end())) fail("Sum over the index of a Sparse map is not supported"); continue; }
-        if (ic.dim_b >= 0 && fb != to.end()) { ic.off += ic.sign_b * fb->second; ic.dim_b = -1; ic.sign_b = 1; }
-        if (ic.dim >= 0 && fa != to.end()) { ic.off += ic.sign * fa->second; ic.dim = ic.dim_b; ic.sign = ic.dim_b >= 0 ? ic.sign_b : 1; ic.dim_b = -1; ic.sign_b = 1; }
+        if (ic.dim_b >= 0 && fb != to.end()) { add_off(ic.off, (long long)ic.sign_b * fb->second); ic.dim_b = -1; ic.sign_b = 1; }
+        if (ic.dim >= 0 && fa != to.end()) { add_off(ic.off, (long long)ic.sign * fa->second); ic.dim = ic.dim_b; ic.sign = ic.dim_b >= 0 ? ic.sign_b : 1; ic.dim_b = -1; ic.sign_b = 1; }
     }
     for (auto& c : n->a) c = subst_const(c, to, memo);
     E r = n; memo[e.get()] = r; return r;
 }
 
 // ================================================================================================ interpreter
+struct EnvRegistry {        // (a member of Interp in front of `globals`: set up before the first Env exists, torn down after the interpreter's own references went)
+    std::set<Env*> live;
+    EnvRegistry() { g_live_envs = &live; }
+    void open_cycles()
+    {
+        std::vector<std::shared_ptr<Env>> hold;
+        for (Env* e : live) if (auto sp = e->weak_from_this().lock()) hold.push_back(sp);
+        for (auto& e : hold) { e->vars.clear(); e->parent.reset(); }
+    }
+    ~EnvRegistry() { open_cycles(); g_live_envs = nullptr; }
+};
 struct Interp {
     Problem& P;
+    EnvRegistry env_registry;
     std::shared_ptr<Env> globals = std::make_shared<Env>();
+    ~Interp() { globals.reset(); }
     int depth = 0;
     std::map<int, int> dim_calls;                  // how often each dimension was called for an iteration variable
     struct ReturnEx { Values v; };
@@ -468,7 +504,7 @@ struct Interp {
             IndexComp ic = as_index(ai ? a : b, "index arithmetic"); const double d = ai ? b.n : a.n;
             if (d != std::floor(d)) fail("line " + std::to_string(line) + ": non-integer index offset");
             if (ic.sparse >= 0 && d != 0) fail("line " + std::to_string(line) + ": offset on an index that went through a Sparse map");
-            if (op == "+") ic.off += (int)d; else if (op == "-") ic.off -= (int)d; else fail("line " + std::to_string(line) + ": only + and - are defined on indices");
+            if (op == "+") add_off(ic.off, small_int(d, "index offset")); else if (op == "-") add_off(ic.off, -(long long)small_int(d, "index offset")); else fail("line " + std::to_string(line) + ": only + and - are defined on indices");
             SymV s; s.k = SymV::IndexE; s.ic = ic; return Value::make_sym(s);
         }
         if (ai && bi && (op == "+" || op == "-")) {   // two iteration variables: x - k + 8 (convolution.t, spatially_varying_deconvolution.t)
@@ -476,7 +512,7 @@ struct Interp {
             if (x.sparse >= 0 || y.sparse >= 0 || x.dim_b >= 0 || y.dim_b >= 0 || x.dim < 0 || y.dim < 0) fail("line " + std::to_string(line) + ": index arithmetic takes at most two iteration variables, none through a Sparse map");
             IndexComp ic = x;
             const int sg = op == "+" ? 1 : -1;
-            ic.dim_b = y.dim; ic.sign_b = sg * y.sign; ic.off = x.off + sg * y.off;
+            ic.dim_b = y.dim; ic.sign_b = sg * y.sign; add_off(ic.off, (long long)sg * y.off);
             SymV r; r.k = SymV::IndexE; r.ic = ic; return Value::make_sym(r);
         }
         const Op o = op == "+" ? Op::Add : op == "-" ? Op::Sub : op == "*" ? Op::Mul : op == "/" ? Op::Div : op == "^" ? Op::Pow : Op::Const;
@@ -581,7 +617,7 @@ struct Interp {
         if (obj.t == Value::Table) { Value* v = table_get(obj, key); return v ? *v : Value(); }
         if (is_symk(obj, SymV::Vec) || is_symk(obj, SymV::Scalar)) {           // normal[0]: 0-based component
             if (key.t != Value::Num) fail("line " + std::to_string(line) + ": vector index must be a number");
-            auto c = comps(obj, "index"); const int i = (int)key.n;
+            auto c = comps(obj, "index"); const int i = small_int(key.n, "line " + std::to_string(line) + ": vector index");
             if (i < 0 || i >= (int)c.size()) fail("line " + std::to_string(line) + ": vector component " + std::to_string(i) + " out of range");
             return scalar(c[i]);
         }
@@ -672,7 +708,7 @@ struct Interp {
             std::vector<IndexComp> idx;
             for (size_t d = 0; d < iargs.size(); ++d) {
                 IndexComp ic;
-                if (iargs[d].t == Value::Num) { if (iargs[d].n != std::floor(iargs[d].n)) fail(ln + "non-integer constant index"); ic.off = (int)iargs[d].n; idx.push_back(ic); continue; }   // ConstantIndexComponent (thallo.t:485)
+                if (iargs[d].t == Value::Num) { if (iargs[d].n != std::floor(iargs[d].n)) fail(ln + "non-integer constant index"); ic.off = small_int(iargs[d].n, ln + "constant index"); idx.push_back(ic); continue; }   // ConstantIndexComponent (thallo.t:485)
                 ic = as_index(iargs[d], in.name.c_str());
                 const int target = ic.sparse >= 0 ? P.inputs[ic.sparse].dims.back() : P.canonical(ic.dim);
                 if (target != in.dims[d]) fail(ln + "index " + std::to_string(d) + " of " + in.name + " ranges over dimension " + P.dims[in.dims[d]] + ", got " + P.dims[target]);
@@ -890,7 +926,7 @@ struct Interp {
         auto need = [&](size_t n) { if (a.size() < n) fail(ln + f + " needs " + std::to_string(n) + " argument(s)"); };
         if (f == "Dim") {                           // Dim("N", 0): one dimension with an explicit position in the dimensions array (thallo.t:1580-1600)
             need(2); if (a[0].t != Value::Str || a[1].t != Value::Num) fail(ln + "Dim(name, index)");
-            const size_t id = (size_t)a[1].n; if (id > 16) fail(ln + "Dim index too large");
+            if (!(a[1].n >= 0 && a[1].n <= 16 && a[1].n == std::floor(a[1].n))) fail(ln + "Dim index must be an integer in 0 .. 16"); const size_t id = (size_t)a[1].n;
             if (P.dims.size() <= id) P.dims.resize(id + 1);
             P.dims[id] = a[0].s; if (P.dim_sizes.size() <= id) P.dim_sizes.resize(id + 1, -1); if (P.dim_alias.size() <= id) P.dim_alias.resize(id + 1, -1); P.dim_sizes[id] = P.plan_dims ? (long)P.plan_dims[id] : -1;
             SymV s; s.k = SymV::Dim; s.id = (int)id; return { Value::make_sym(s) };
@@ -899,13 +935,13 @@ struct Interp {
         if (f == "Unknown" || f == "Array" || f == "Image") {           // Image: the deprecated spelling of Array (lib.t:573-576)
             need(3); Input in; in.kind = f == "Unknown" ? InputKind::Unknown : InputKind::Array;
             in.channels = type_channels(a[0], &in.is_u8, line, &in.fixed_f32); in.dims = dim_list(a[1], line);
-            if (a[2].t != Value::Num) fail(ln + f + ": the third argument is the parameter index"); in.slot = (int)a[2].n;
+            if (a[2].t != Value::Num) fail(ln + f + ": the third argument is the parameter index"); in.slot = small_int(a[2].n, ln + f + ": parameter index"); if (in.slot < 0 || in.slot > 4096) fail(ln + f + ": parameter index out of range");
             if (in.dims.empty() || in.dims.size() > 3) fail(ln + f + ": 1-, 2- and 3-dimensional images are supported");
             if (in.kind == InputKind::Unknown && in.is_u8) fail(ln + "uint8 unknowns are not supported");
             return { decl(in) };
         }
-        if (f == "Sparse") { need(3); Input in; in.kind = InputKind::Sparse; auto from = dim_list(a[0], line), to = dim_list(a[1], line); if (from.empty() || from.size() > 2 || to.size() != 1) fail(ln + "Sparse({E}, {N}, idx) or Sparse({W,H}, {N}, idx)"); in.dims = from; in.dims.push_back(to[0]); in.slot = (int)a[2].n; return { decl(in) }; }
-        if (f == "Param") { need(2); Input in; in.kind = InputKind::Param; bool u8; if (type_channels(a[0], &u8, line, &in.fixed_f32) != 1 || u8) fail(ln + "scalar float Params are supported"); in.slot = (int)a[1].n; return { decl(in) }; }
+        if (f == "Sparse") { need(3); Input in; in.kind = InputKind::Sparse; auto from = dim_list(a[0], line), to = dim_list(a[1], line); if (from.empty() || from.size() > 2 || to.size() != 1) fail(ln + "Sparse({E}, {N}, idx) or Sparse({W,H}, {N}, idx)"); in.dims = from; in.dims.push_back(to[0]); if (a[2].t != Value::Num) fail(ln + "Sparse: the third argument is the parameter index"); in.slot = small_int(a[2].n, ln + "Sparse: parameter index"); if (in.slot < 0 || in.slot > 4096) fail(ln + "Sparse: parameter index out of range"); return { decl(in) }; }
+        if (f == "Param") { need(2); Input in; in.kind = InputKind::Param; bool u8; if (type_channels(a[0], &u8, line, &in.fixed_f32) != 1 || u8) fail(ln + "scalar float Params are supported"); if (a[1].t != Value::Num) fail(ln + "Param(type, index)"); in.slot = small_int(a[1].n, ln + "Param: parameter index"); if (in.slot < 0 || in.slot > 4096) fail(ln + "Param: parameter index out of range"); return { decl(in) }; }
         if (f == "Inputs") {
             need(1); if (a[0].t != Value::Table) fail(ln + "Inputs { name = ..., ... }");
             for (auto& kv : a[0].tab->fields) {

@@ -22,6 +22,14 @@
 
 namespace harness {
 
+// Every count a file states is checked against the bytes the file actually has before anything is sized by it (tools/formats_fuzz.cpp mutates the fixtures
+// under AddressSanitizer: a count of 2^60 vertices must be a message, not an allocation)
+inline size_t file_bytes(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    return f.good() ? (size_t)f.tellg() : 0;
+}
+
 struct ImageDump {
     int width = 0, height = 0, channels = 0, datatype = 0;           // datatype 0: float32, 1: uint8
     std::vector<float> f; std::vector<uint8_t> u;
@@ -34,8 +42,9 @@ inline ImageDump read_imagedump(const std::string& path, bool clamp_infinity = t
     ImageDump d; int32_t h[4];
     in.read(reinterpret_cast<char*>(h), 16);
     d.width = h[0]; d.height = h[1]; d.channels = h[2]; d.datatype = h[3];
-    const size_t n = (size_t)d.width * d.height * d.channels;
-    if (!in || d.width <= 0 || d.height <= 0 || d.channels <= 0 || (d.datatype != 0 && d.datatype != 1)) throw std::runtime_error(path + ": bad imagedump header");
+    if (!in || d.width <= 0 || d.height <= 0 || d.channels <= 0 || d.channels > 64 || (d.datatype != 0 && d.datatype != 1)) throw std::runtime_error(path + ": bad imagedump header");
+    const size_t n = (size_t)d.width * (size_t)d.height * (size_t)d.channels;
+    if (n > file_bytes(path) || n * (d.datatype == 0 ? 4 : 1) + 16 > file_bytes(path)) throw std::runtime_error(path + ": truncated imagedump");
     if (d.datatype == 0) {
         d.f.resize(n); in.read(reinterpret_cast<char*>(d.f.data()), (std::streamsize)(n * 4));
         if (clamp_infinity)                                           // SimpleBuffer.cpp:29-41: +inf -> FLT_MAX, -inf -> -10000 (first w*h floats)
@@ -81,10 +90,17 @@ inline Mesh read_off(const std::string& path)
     std::string magic; size_t nv = 0, nf = 0, ne = 0;
     in >> magic >> nv >> nf >> ne;
     if (!in || magic != "OFF") throw std::runtime_error(path + ": not an OFF file");
+    const size_t bytes = file_bytes(path);
+    if (nv > bytes / 6 || nf > bytes / 2) throw std::runtime_error(path + ": the OFF header counts more vertices / faces than the file can hold");       // ("0 0 0\n": 6 bytes a vertex)
     Mesh m; m.v.resize(nv); m.f.resize(nf);
     for (auto& p : m.v) in >> p[0] >> p[1] >> p[2];
-    for (auto& f : m.f) { int k = 0; in >> k; f.resize(k); for (int& i : f) in >> i; }
+    for (auto& f : m.f) {
+        long k = 0; in >> k;
+        if (!in || k < 0 || (size_t)k > bytes / 2) throw std::runtime_error(path + ": bad face in OFF file");
+        f.resize((size_t)k); for (int& i : f) in >> i;
+    }
     if (!in) throw std::runtime_error(path + ": truncated OFF file");
+    for (auto& f : m.f) for (int i : f) if (i < 0 || (size_t)i >= nv) throw std::runtime_error(path + ": face index out of range");
     return m;
 }
 
@@ -99,8 +115,12 @@ inline Mesh read_ply(const std::string& path)
         if (!line.empty() && line.back() == '\r') line.pop_back();
         std::istringstream ls(line); std::string t; ls >> t;
         if (t == "format") ls >> fmt;
-        else if (t == "element") { Elem e; ls >> e.name >> e.n; elems.push_back(e); }
-        else if (t == "property") { Prop p; ls >> p.type; p.list = p.type == "list"; if (p.list) ls >> p.ctype >> p.itype; ls >> p.name; elems.back().props.push_back(p); }
+        else if (t == "element") { Elem e; e.n = 0; ls >> e.name >> e.n; if (!ls) throw std::runtime_error(path + ": bad PLY element line"); elems.push_back(e); }
+        else if (t == "property") {
+            Prop p; ls >> p.type; p.list = p.type == "list"; if (p.list) ls >> p.ctype >> p.itype; ls >> p.name;
+            if (elems.empty()) throw std::runtime_error(path + ": PLY property in front of the first element");
+            elems.back().props.push_back(p);
+        }
         else if (t == "end_header") break;
     }
     auto size_of = [](const std::string& t) -> int {
@@ -122,17 +142,26 @@ inline Mesh read_ply(const std::string& path)
         if (n == 2) { int16_t v; std::memcpy(&v, b, 2); return t[0] == 'u' ? (double)(uint16_t)v : (double)v; }
         int32_t v; std::memcpy(&v, b, 4); return t[0] == 'u' ? (double)(uint32_t)v : (double)v;
     };
+    const size_t bytes = file_bytes(path);
     for (auto& e : elems) {
+        if (e.n > bytes) throw std::runtime_error(path + ": the PLY header counts more " + e.name + " elements than the file has bytes");
+        if (e.props.empty() && e.n) throw std::runtime_error(path + ": PLY element " + e.name + " without properties");
         for (size_t i = 0; i < e.n; ++i) {
             std::array<float, 3> p = { 0, 0, 0 }; std::vector<int> face;
+            if (!in) throw std::runtime_error(path + ": truncated PLY file");
             for (auto& pr : e.props) {
-                if (pr.list) { const int k = (int)read_num(pr.ctype); std::vector<int> l(k); for (int& x : l) x = (int)read_num(pr.itype); face = l; }
+                if (pr.list) {
+                    const double kd = read_num(pr.ctype);
+                    if (!in || !(kd >= 0) || kd > (double)bytes) throw std::runtime_error(path + ": bad PLY list length");
+                    std::vector<int> l((size_t)kd); for (int& x : l) x = (int)read_num(pr.itype); face = l;
+                }
                 else { const double v = read_num(pr.type); if (pr.name == "x") p[0] = (float)v; else if (pr.name == "y") p[1] = (float)v; else if (pr.name == "z") p[2] = (float)v; }
             }
             if (e.name == "vertex") m.v.push_back(p); else if (e.name == "face") m.f.push_back(face);
         }
     }
     if (!in && !in.eof()) throw std::runtime_error(path + ": truncated PLY file");
+    for (auto& f : m.f) for (int i : f) if (i < 0 || (size_t)i >= m.v.size()) throw std::runtime_error(path + ": face index out of range");
     return m;
 }
 
@@ -159,6 +188,7 @@ inline Landmarks read_mrk(const std::string& path)
     std::ifstream in(path);
     if (!in.good()) throw std::runtime_error("could not open marker file " + path);
     size_t n = 0; in >> n;
+    if (!in || n > file_bytes(path) / 8) throw std::runtime_error(path + ": bad landmark count");        // ("0 0 0 0 0\n": 10 bytes a landmark)
     Landmarks l; l.index.resize(n); l.target.resize(n);
     for (size_t i = 0; i < n; ++i) { float radius; in >> l.target[i][0] >> l.target[i][1] >> l.target[i][2] >> radius >> l.index[i]; }
     if (!in) throw std::runtime_error(path + ": truncated landmark list");
@@ -170,6 +200,7 @@ inline Landmarks read_mrk(const std::string& path)
 inline void directed_edges(const Mesh& m, std::vector<int>& v0, std::vector<int>& v1)
 {
     std::set<std::pair<int, int>> und;
+    for (auto& f : m.f) for (int i : f) if (i < 0 || (size_t)i >= m.v.size()) throw std::runtime_error("mesh face index out of range");
     for (auto& f : m.f) for (size_t i = 0; i < f.size(); ++i) { const int a = f[i], b = f[(i + 1) % f.size()]; if (a != b) und.insert({ std::min(a, b), std::max(a, b) }); }
     std::vector<std::vector<int>> nbr(m.v.size());
     for (auto& e : und) { nbr[e.first].push_back(e.second); nbr[e.second].push_back(e.first); }

@@ -45,14 +45,17 @@ inline Image8 read_png(const std::string& path)
     for (size_t pos = 8; pos + 12 <= b.size();) {
         const uint32_t len = detail::be32(&b[pos]);
         const std::string typ(reinterpret_cast<const char*>(&b[pos + 4]), 4);
+        if ((size_t)len > b.size() - pos - 12) throw std::runtime_error(path + ": PNG chunk runs past the end of the file");
         const uint8_t* d = &b[pos + 8];
-        if (typ == "IHDR") { im.width = detail::be32(d); im.height = detail::be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        if (typ == "IHDR") { if (len < 13) throw std::runtime_error(path + ": short IHDR"); im.width = detail::be32(d); im.height = detail::be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
         else if (typ == "IDAT") idat.insert(idat.end(), d, d + len);
         else if (typ == "IEND") break;
         pos += 12 + (size_t)len;
     }
     im.channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (depth != 8 || !im.channels || interlace) throw std::runtime_error(path + ": only 8-bit non-interlaced gray/RGB/RGBA PNGs are supported");
+    // (deflate expands at most ~1032 : 1: an image the IDAT bytes cannot possibly hold is refused before it is allocated)
+    if (!im.width || !im.height || (double)im.width * im.height * im.channels > 1100.0 * (double)idat.size() + 65536.0) throw std::runtime_error(path + ": PNG dimensions do not fit its data");
     const size_t stride = (size_t)im.width * im.channels;
     std::vector<uint8_t> raw((stride + 1) * im.height);
     uLongf out_len = raw.size();
@@ -106,6 +109,8 @@ inline std::vector<std::vector<int>> read_constraints(const std::string& path)
     if (!in.good()) throw std::runtime_error("could not open marker file " + path);
     unsigned n = 0;
     in >> n;
+    {   std::ifstream sz(path, std::ios::binary | std::ios::ate);
+        if (!in || (size_t)n > (size_t)sz.tellg() / 8) throw std::runtime_error(path + ": bad marker count"); }      // ("0 0 0 0\n": 8 bytes a marker)
     std::vector<std::vector<int>> c(n, std::vector<int>(4, 0));
     for (auto& m : c) for (int& v : m) in >> v;
     if (!in) throw std::runtime_error(path + ": truncated marker list");

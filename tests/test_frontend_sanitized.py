@@ -18,7 +18,11 @@ def test_front_end_survives_mutated_energy_files_under_sanitizers(tmp_path):
         pytest.skip("no g++")
     exe = str(tmp_path / "frontend_fuzz")
     src = [os.path.join(ROOT, "tools", "frontend_fuzz.cpp"), os.path.join(ROOT, "thallo_amd", "csrc", "dsl_lua.cpp"), os.path.join(ROOT, "thallo_amd", "csrc", "dsl_codegen.cpp")]
-    cc = subprocess.run([cxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", *src, "-o", exe], capture_output=True, text=True)
+    flags = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+    if os.path.isdir("/opt/rocm/include"):      # + the recogniser of the bundled energies (csrc/frontend.cpp: its own lexer, declaration parser, hashes); host-only, no device
+        flags += ["-DWITH_RECOGNISER", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include")]
+        src.append(os.path.join(ROOT, "thallo_amd", "csrc", "frontend.cpp"))
+    cc = subprocess.run([*flags, *src, "-o", exe], capture_output=True, text=True)
     if cc.returncode != 0 and ("sanitize" in cc.stderr or "asan" in cc.stderr or "ubsan" in cc.stderr):
         pytest.skip("this g++ has no sanitizer runtime: " + cc.stderr[-300:])
     assert cc.returncode == 0, cc.stderr[-2000:]

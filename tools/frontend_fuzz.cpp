@@ -12,12 +12,33 @@
 #include <unistd.h>
 
 namespace thallo { const char* env_switch(const char*) { return nullptr; } }      // (solver.cpp's table; the front-end asks for THALLO_FRONTEND_AGGREGATE)
+#ifdef WITH_RECOGNISER      // + csrc/frontend.cpp (the recogniser of the bundled energies: its own lexer, declaration parser and hashes), built with -DWITH_RECOGNISER -I/opt/rocm/include -D__HIP_PLATFORM_AMD__
+#include <cstdarg>
+namespace thallo {
+static char g_err[4096];
+void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
+const char* last_error() { return g_err; }
+struct ProblemSpec;
+}
+extern "C" int ThalloX_ProblemFileSchedule(const char* filename);
+extern "C" unsigned long long ThalloX_ProblemFileUnitHash(const char* filename);
+extern "C" unsigned long long ThalloX_ProblemFileHash(const char* filename, char* energy_out, int cap);
+static void recognise(const char* path)
+{
+    char energy[64];
+    (void)ThalloX_ProblemFileHash(path, energy, (int)sizeof energy);
+    (void)ThalloX_ProblemFileSchedule(path);
+}
+#else
+static void recognise(const char*) {}
+#endif
 
 static unsigned long long rng_state = 0x9e3779b97f4a7c15ULL;
 static unsigned rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (unsigned)(rng_state >> 32); }
 
 static int lower(const std::string& path, const unsigned* dims, std::string* why)
 {
+    recognise(path.c_str());
     thallo::dsl::Problem p; std::string err;
     if (!thallo::dsl::run_problem_file(path.c_str(), p, err, dims)) { if (why) *why = err; return 1; }
     for (int f64 = 0; f64 < 2; ++f64) {

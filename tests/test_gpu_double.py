@@ -219,3 +219,29 @@ def test_two_parameter_curve_fit_like_the_reference_dense_test(torch, form, dbl)
     if dbl:
         assert np.abs(to_host(dev[0])[0] - p).max() < 1e-9 * 100.0
         assert costs[-1] < 1e-6 * costs[0]          # the fit is found (the generator's parameters reproduce the samples exactly)
+
+
+@pytest.mark.parametrize("kind", ["handwritten", "generated", "generated_double", "lm"])
+def test_plan_free_cycles_do_not_leak_device_memory(torch, monkeypatch, kind):
+    """The reference's tests/create_delete_cycle (main.cpp:22-26: Plan / Solve / Free ten times and watch the memory): device memory after the tenth cycle is what it
+    was after the second -- solver vectors, partial slots, exchange buffers, hipRTC modules and the plans' events all go with Thallo_PlanFree."""
+    W, H = 160, 128
+    p = syn.image_warping(W, H)
+    dbl = kind == "generated_double"
+    if kind in ("generated", "generated_double"): monkeypatch.setenv("THALLO_FRONTEND", "generate")
+    else: monkeypatch.delenv("THALLO_FRONTEND", raising=False)
+    dev = []
+    for q in p:
+        if isinstance(q, np.ndarray): dev.append(torch.from_numpy(q.astype(np.float64) if dbl else q.copy()).cuda())
+        else: dev.append(np.float32(q))
+    free = []
+    for cycle in range(10):
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping.t"), double_precision=dbl)
+        assert s.energy_name.startswith("generated:") == (kind in ("generated", "generated_double"))
+        if kind == "lm": s._L.ThalloX_EnableLM(s.plan, 1)
+        s.solve(dev, nIterations=2, lIterations=5)
+        s.close()
+        del s
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert free[1] - free[9] <= (1 << 20), free        # (the first cycle may load code objects that stay with the process)

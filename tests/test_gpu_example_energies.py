@@ -178,3 +178,22 @@ def test_lattice_arap_over_a_three_dimensional_domain(torch, dbl):
     got_x, got_costs = run(torch, "volume_arap.t", (W, H, D), [w_fit, w_reg, Pos0.copy(), Ang0.copy(), Rest, Tgt], [2, 3], dbl, nIterations=4, lIterations=15)
     ref_x, ref_costs = mirror(F, x0, np.ones(2 * n, bool), 4, 15, precond=True)
     check(got_x, got_costs, ref_x, ref_costs, dbl)
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+def test_two_unknown_index_spaces(torch, dbl):
+    """tests/energies/two_domains.t: unknowns over {U} and over {N}, a residual on the product domain {N, U} (every S(u) gathers N terms, every P(n) U terms) and one on
+    {N}: linear, so the mirror is exact."""
+    N, U = 40, 3
+    rng = np.random.default_rng(4)
+    T = rng.uniform(-1, 1, N)
+    S0 = rng.uniform(-0.5, 0.5, U); P0 = rng.uniform(-1, 1, N)
+
+    def F(x):
+        S, P = x[:U], x[U:]
+        fit = (S[None, :] + P[:, None] - T[:, None])          # element (n, u); the order of the residuals does not matter to J^T J
+        return np.concatenate([fit.reshape(-1), 0.5 * P])
+
+    got_x, got_costs = run(torch, "two_domains.t", (N, U), [S0.copy(), P0.copy(), T], [0, 1], dbl, nIterations=3, lIterations=8)
+    ref_x, ref_costs = mirror(F, np.concatenate([S0, P0]), np.ones(N + U, bool), 3, 8, precond=True)
+    check(got_x, got_costs, ref_x, ref_costs, dbl)

@@ -509,6 +509,29 @@ def test_benchmark_configuration_2048_vs_cpu_port(torch, orc):
     s.close()
 
 
+@pytest.mark.parametrize("W,H,L", [(8192, 4096, 8), (16384, 16384, 3)])
+def test_image_warping_beyond_the_benchmark_size(torch, orc, W, H, L):
+    """8192 x 4096 (33.5 M pixels, 100 M unknowns, 403 MB per solver vector -- eight times the benchmark's image: 67 column strips, 342 rows per wave, every grid- and
+    slot-sizing rule away from the sizes the other tests use) and 16384 x 16384 (268 M pixels, 805 M unknowns: the Offset plane alone is 2.15 GB, so every byte offset
+    into a solver vector passes 2^31 while the element indices stay int32 like the reference's, thallo.t:613-624; ~40 GB of the 288 GB of HBM): one GN step of a few PCG
+    iterations against the OpenMP port of the reference algorithm."""
+    p = syn.image_warping(W, H)
+    q = copy_params(p)
+    ref = orc.cpu_port_image_warping(W, H, q, 1, L, want_costs=True, want_trace=True)
+    dev = to_device(p)
+    del p
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    final, costs = s.solve(dev, profiled=True, nIterations=1, lIterations=L)
+    tr = np.array(s.alpha_beta_trace())
+    print(f"{W}x{H} 1x{L}: costs", costs, ref["costs"], "max rel alpha/beta error", (np.abs(tr - ref["trace"]) / np.abs(ref["trace"])).max())
+    assert len(costs) == 2 and rel_err(np.array(costs), ref["costs"]) < COST_RTOL, (costs, ref["costs"])
+    assert tr.shape == (L, 2) and (np.abs(tr - ref["trace"]) <= 1e-4 * np.abs(ref["trace"])).all(), (tr, ref["trace"])
+    assert rel_err(to_host(dev[0]), q[0]) < VEC_RTOL
+    s.close()
+    del dev
+    torch.cuda.empty_cache()
+
+
 def test_image_warping_cat512_reference_budget(torch, orc, golden_dir):
     """BASELINE.json configs[1] at the reference's own budget: the cat512 data set, GN 8 x PCG 100 (examples/image_warping/src/
     main.cpp:131-149), first solve of the marker continuation, against the row oracle.

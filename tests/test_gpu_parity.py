@@ -817,6 +817,30 @@ def test_arap_100k_vertices(torch, orc):
     assert list(costs) == list(costs2) and torch.equal(dev[2], dev2[2])
 
 
+def test_beyond_the_configured_sizes_arap_and_shape_from_shading(torch, orc):
+    """Ten times BASELINE's mesh (1024 x 1024 torus: 1,048,576 vertices, 6,291,456 directed edges) and four times its shape_from_shading image (4096^2), a short budget
+    each, against the row oracle on the host cores: the grid sizing, the ELL / incidence layouts and the marching geometry away from the sizes every other test uses."""
+    prev = orc.set_threads(_host_threads())
+    try:
+        p = syn.arap_mesh(1024, 1024)
+        N, E = p[2].shape[0], p[6].shape[0]
+        assert N == 1048576 and E == 6291456
+        co, _ = orc.Problem(orc.ARAP_MESH, (N, E), copy_params(p)).solve(nIterations=2, lIterations=10)
+        s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (N, E), p, nIterations=2, lIterations=10)
+        s.close()
+        print("ARAP 1M vertices 2x10:", costs, co)
+        assert rel_err(costs, co) < COST_RTOL, (costs, co)
+        W = H = 4096
+        p = syn.shape_from_shading(W, H)
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=2, lIterations=10)
+        s, dev, costs, final = _solve_gpu("shape_from_shading", (W, H), p, nIterations=2, lIterations=10)
+        s.close()
+        print("SFS 4096^2 2x10:", costs, co)
+        assert rel_err(costs, co) < COST_RTOL, (costs, co)
+    finally:
+        orc.set_threads(prev)
+
+
 def test_graph_rejects_out_of_range_edges(torch):
     p = syn.laplacian_graph(50)
     p[2][3] = 99

@@ -525,11 +525,28 @@ inline MarchGeo make_march_geo(int W, int H, int row0, int row1, int R)
 // 2 waves per SIMD, and at most 1024 workgroups (partial slots).  0: the image is wider than that many strips (W > ~31.7k pixels on a 256-CU
 // device, ~3.9k on a 32-CU partition) -- the caller runs the tile kernel instead (thallo_hip_iw_march_fits).
 inline long march_cap(int occ) { return g_march_cap > 0 ? g_march_cap : (long)thallo_hip_device_cu_count() * occ; }
+// Wide images: the grid is (strips) x (bands of 4 segments), so with ONE workgroup per CU as the budget a width whose strip count does not divide the CU count leaves
+// CUs without work -- 16384 pixels: 133 strips x 1 band = 133 of 256 CUs.  Measured (round 3, tools/march_probe.py MB_MODE=ab with and without MB_CAP=256): 16384 x 2048
+// 920 -> 697 us per launch with the budget grown until the grid fills its last round of workgroups; 8192 x 2048 (67 x 3 = 201 of 256) gains nothing from 469
+// workgroups, so a fill of 75 % counts as full.  The budget grows to 2, 3, 4 workgroups per CU (two are resident at once, the rest follow as CUs free up; at most
+// THALLO_MAX_PARTIALS): once it grows, up to the smallest multiple with a fill of 90 % (16384 wide: 931 workgroups; 737 us with 399), else the best.  Images for which one workgroup per CU already fills the chip -- every size the other
+// kernels are compared with bit for bit -- keep their rows per segment.
 inline int pick_rows(int W, int rows, int occ)
 {
     if (g_march_rows > 0) return g_march_rows;
     const int use = (g_march_dbg == 3 || g_march_dbg == 6) ? 128 : MARCH_USE;
-    return march_rows_per_segment(rows, (W + use - 1) / use, MARCH_NT / 64, march_cap(occ));
+    const int nstrips = (W + use - 1) / use, wpw = MARCH_NT / 64;
+    const long cus = march_cap(1);
+    int best_R = 0; double best_fill = -1.0;
+    for (int m = occ; m <= 4; ++m) {
+        const int R = march_rows_per_segment(rows, nstrips, wpw, cus * m);
+        if (R <= 0) continue;
+        const long nseg = (rows + R - 1) / R, total = (long)nstrips * ((nseg + wpw - 1) / wpw);
+        const double fill = (double)total / (double)(((total + cus - 1) / cus) * cus);
+        if (best_R == 0 || fill > best_fill + 1e-9) { best_R = R; best_fill = fill; }
+        if (fill >= (m == occ ? 0.75 : 0.9) || g_march_cap > 0) break;         // (a forced budget -- tests, tools -- is taken as it is)
+    }
+    return best_R;
 }
 
 constexpr int MARCH_DEPTH = 2, MARCH_NTM = 5, MARCH_OCC = 2;     // product configuration (tools/march_probe.py sweeps, profiles/r02): delta and the r / Ap stores non-temporal

@@ -198,6 +198,9 @@ if os.environ.get("MB_MODE") == "updown":         # sweep build: every other lau
             L.thallo_hip_march_debug_set(4, 0)
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_CAP"):      # force the workgroup budget the grid is sized for (256 on an MI355X = round 2's one workgroup per CU, whatever the width)
+    L.thallo_hip_march_debug_set(6, int(os.environ["MB_CAP"]))
+
 if os.environ.get("MB_MODE") == "ab":             # any build: the marching kernel at its default configuration (product vs sweep build: the sweep build's stamp checks drain the loads every row)
     out = {"W": W, "H": H, "lib": os.environ.get("THALLO_LIB", "product")}
     for rep in range(3):

@@ -225,7 +225,7 @@ def test_two_parameter_curve_fit_like_the_reference_dense_test(torch, form, dbl)
 def test_plan_free_cycles_do_not_leak_device_memory(torch, monkeypatch, kind):
     """The reference's tests/create_delete_cycle (main.cpp:22-26: Plan / Solve / Free ten times and watch the memory): device memory after the tenth cycle is what it
     was after the second -- solver vectors, partial slots, exchange buffers, hipRTC modules and the plans' events all go with Thallo_PlanFree."""
-    W, H = 160, 128
+    W, H = 512, 384             # ~25 MB of solver vectors per plan: eight leaked plans would be 200 MB
     p = syn.image_warping(W, H)
     dbl = kind == "generated_double"
     if kind in ("generated", "generated_double"): monkeypatch.setenv("THALLO_FRONTEND", "generate")
@@ -244,4 +244,5 @@ def test_plan_free_cycles_do_not_leak_device_memory(torch, monkeypatch, kind):
         del s
         torch.cuda.synchronize()
         free.append(torch.cuda.mem_get_info()[0])
-    assert free[1] - free[9] <= (1 << 20), free        # (the first cycle may load code objects that stay with the process)
+    # (the first cycle may load code objects that stay with the process, and the runtime's own pools grow in 2-MB steps when the whole suite runs in one process)
+    assert free[1] - free[9] <= (8 << 20), free

@@ -536,15 +536,16 @@ inline int pick_rows(int W, int rows, int occ)
     if (g_march_rows > 0) return g_march_rows;
     const int use = (g_march_dbg == 3 || g_march_dbg == 6) ? 128 : MARCH_USE;
     const int nstrips = (W + use - 1) / use, wpw = MARCH_NT / 64;
+    if (g_march_cap > 0) return march_rows_per_segment(rows, nstrips, wpw, march_cap(occ));       // (a forced budget -- tests, tools -- is taken as it is)
     const long cus = march_cap(1);
     int best_R = 0; double best_fill = -1.0;
     for (int m = occ; m <= 4; ++m) {
         const int R = march_rows_per_segment(rows, nstrips, wpw, cus * m);
-        if (R <= 0) continue;
+        if (R <= 0) break;                      // more strips than one workgroup per CU has slots: thallo_hip_iw_march_fits() says no, the tile kernel runs
         const long nseg = (rows + R - 1) / R, total = (long)nstrips * ((nseg + wpw - 1) / wpw);
         const double fill = (double)total / (double)(((total + cus - 1) / cus) * cus);
         if (best_R == 0 || fill > best_fill + 1e-9) { best_R = R; best_fill = fill; }
-        if (fill >= (m == occ ? 0.75 : 0.9) || g_march_cap > 0) break;         // (a forced budget -- tests, tools -- is taken as it is)
+        if (fill >= (m == occ ? 0.75 : 0.9)) break;
     }
     return best_R;
 }

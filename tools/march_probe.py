@@ -207,6 +207,31 @@ if os.environ.get("MB_MODE") == "ab":             # any build: the marching kern
         out[f"march_us_{rep}"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_MODE") == "occ":            # sweep build: workgroups per CU -- the register budget the kernel is compiled for (2: 256 VGPRs ... 4: 128, prefetch depth 1) x the grid budget
+    out = {"W": W, "H": H}
+    for rep in range(2):
+        for cap in (0, 512, 768, 1024):
+            L.thallo_hip_march_debug_set(6, cap)
+            for depth, occ in ((2, 2), (2, 3), (1, 3), (1, 4)):
+                cfg(depth, 1, occ, 0)
+                try:
+                    out[f"cap{cap}_depth{depth}_occ{occ}_us_{rep}"] = [round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(0,)), 2)]
+                except AssertionError:
+                    out[f"cap{cap}_depth{depth}_occ{occ}_us_{rep}"] = "refused"
+        L.thallo_hip_march_debug_set(6, 0)
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "policy":         # sweep build: the cache-policy masks at the current size (the product's 5 was chosen at 2048^2, where the Infinity Cache holds much of the working set)
+    out = {"W": W, "H": H}
+    for rep in range(2):
+        for nt in (5, 0, 1, 4, 11, 17, 21, 31, 43, 63):
+            cfg(2, nt, 2, 0)
+            out[f"nt{nt}_us_{rep}"] = [round(timeit("march"), 2), round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+        out[f"stream_nt5_percu4_us_{rep}"] = [round(time_stream(0, 5, 4, span=0), 2), round(time_stream(1, 5, 4, span=0), 2)]
+        out[f"stream_nt11_percu4_us_{rep}"] = [round(time_stream(0, 11, 4, span=0), 2), round(time_stream(1, 11, 4, span=0), 2)]
+        out[f"stream_nt0_percu4_us_{rep}"] = [round(time_stream(0, 0, 4, span=0), 2), round(time_stream(1, 0, 4, span=0), 2)]
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "uncond":         # sweep build: dbg 3 (aligned strips, no halo, no arithmetic) against dbg 6 (the same with every store unconditional: the compiler's
     out = {"W": W, "H": H}                        # s_waitcnt vmcnt(N) then count the stores too -- 41 / 40 / 37 / 36 / 34 instead of 23 / 22 / 19 / 18 / 16)
     for rep in range(3):

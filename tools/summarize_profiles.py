@@ -3,7 +3,7 @@ profiles/<round>/ and profiles/traffic_latest.json (read by bench.py for rooflin
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")

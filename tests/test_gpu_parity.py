@@ -839,6 +839,13 @@ def test_beyond_the_configured_sizes_arap_and_shape_from_shading(torch, orc):
         s.close()
         print("SFS 4096^2 2x10:", costs, co)
         assert rel_err(costs, co) < COST_RTOL, (costs, co)
+        W, H = 16384, 256           # 274 column strips: the marching grid grows past one round of workgroups (pick_ms_geo)
+        p = syn.shape_from_shading(W, H)
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=2, lIterations=10)
+        s, dev, costs, final = _solve_gpu("shape_from_shading", (W, H), p, nIterations=2, lIterations=10)
+        s.close()
+        print("SFS 16384x256 2x10:", costs, co)
+        assert rel_err(costs, co) < COST_RTOL, (costs, co)
     finally:
         orc.set_threads(prev)
 

@@ -832,7 +832,22 @@ static bool sfs_march_fits(int W) { return march_strips_fit((W + MS_USE - 1) / M
 static MsGeo pick_ms_geo(int W, int H, int ra, int rb, int yoff)
 {
     if (g_ms_rows > 0) return make_ms_geo(W, H, ra, rb, yoff, g_ms_rows);
-    const int R = march_rows_per_segment(rb - ra, (W + MS_USE - 1) / MS_USE, MS_NT / 64, ms_cap(g_ms_wgcu > 0 ? g_ms_wgcu : MS_WG_PER_CU));
+    const int nstrips = (W + MS_USE - 1) / MS_USE, per_cu = g_ms_wgcu > 0 ? g_ms_wgcu : MS_WG_PER_CU;
+    int R = march_rows_per_segment(rb - ra, nstrips, MS_NT / 64, ms_cap(per_cu));
+    // wide images (energy_image_warping_march.hip, pick_rows: the same rule): when the strip count leaves more than a quarter of the budget's workgroup slots empty,
+    // the budget grows (up to THALLO_MAX_PARTIALS workgroups) until the grid fills its last round of workgroups to 90 %
+    if (R > 0 && g_ms_cap <= 0 && g_ms_wgcu <= 0) {
+        const long slots = ms_cap(per_cu);
+        auto fill_of = [&](int rr) { const long nseg = (rb - ra + rr - 1) / rr, total = (long)nstrips * ((nseg + MS_NT / 64 - 1) / (MS_NT / 64)); return (double)total / (double)(((total + slots - 1) / slots) * slots); };
+        double best = fill_of(R);
+        for (int m = 2; best < 0.75 && m <= 4; ++m) {
+            const int r2 = march_rows_per_segment(rb - ra, nstrips, MS_NT / 64, slots * m);
+            if (r2 <= 0) break;
+            const double f = fill_of(r2);
+            if (f > best + 1e-9) { best = f; R = r2; }
+            if (f >= 0.9) break;
+        }
+    }
     return make_ms_geo(W, H, ra, rb, yoff, R > 0 ? R : rb - ra);      // (R == 0 is excluded by sfs_march_fits() at every call site; one segment per strip otherwise)
 }
 

@@ -243,11 +243,15 @@ def test_the_references_sum_files_go_through_the_front_end(rel, dims, accesses):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
-def test_a_sum_too_wide_for_forward_mode_duals_is_refused():
-    """spatially_varying_deconvolution at its shipped 17 x 17 kernel reads 289 + 2 unknown elements per residual instance: refused with a message (the forward-mode
-    lowering carries one partial per access in registers), not compiled for minutes into a stack overflow"""
-    msg = _text(os.path.join(REF, "examples/spatially_varying_deconvolution/spatially_varying_deconvolution.t"), 1, dims=(64, 64, 17, 4), expect_error=True)
-    assert "unknown elements per instance" in msg and "up to 96" in msg
+def test_a_sum_too_wide_for_forward_mode_duals_takes_the_wide_lowering(tmp_path):
+    """spatially_varying_deconvolution at its shipped 17 x 17 kernel reads 289 unknown elements per instance of its convolution residual: more than forward-mode duals carry at
+    once, so the residual gets the wide lowering (16 partials per evaluation at this size, chunk after chunk; round 2 refused the file) -- and the unit compiles for gfx950."""
+    src = _text(os.path.join(REF, "examples/spatially_varying_deconvolution/spatially_varying_deconvolution.t"), 1, dims=(64, 64, 17, 4))
+    assert "289 unknown access(es)" in src and "Dual<16> rr[" in src and "for (int cb = 0; cb < 304; cb += 16)" in src
+    out = tmp_path / "wide.hip"
+    out.write_text(src)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-munsafe-fp-atomics", "-c", str(out), "-o", str(tmp_path / "wide.o")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
 
 
 def test_sampled_image_array_generates():

@@ -46,13 +46,13 @@ def mirror(F, x0, free, n_iter, l_iter, precond):
     return x, np.array(costs)
 
 
-def run(torch, file, dims, params, unknown_slots, dbl, **sp):
+def run(torch, file, dims, params, unknown_slots, dbl, here=None, **sp):
     dev = []
     for p in params:
         if isinstance(p, np.ndarray) and p.dtype == np.float64: dev.append(torch.from_numpy(p if dbl else p.astype(np.float32)).cuda())
         elif isinstance(p, np.ndarray): dev.append(torch.from_numpy(p.copy()).cuda())
         else: dev.append(np.float32(p))
-    s = api.ThalloSolver(dims, os.path.join(HERE, file), double_precision=dbl)
+    s = api.ThalloSolver(dims, os.path.join(here or HERE, file), double_precision=dbl)
     assert s.energy_name == "generated:" + file
     final, costs = s.solve(dev, profiled=True, **sp)
     s.close()
@@ -196,4 +196,44 @@ def test_two_unknown_index_spaces(torch, dbl):
 
     got_x, got_costs = run(torch, "two_domains.t", (N, U), [S0.copy(), P0.copy(), T], [0, 1], dbl, nIterations=3, lIterations=8)
     ref_x, ref_costs = mirror(F, np.concatenate([S0, P0]), np.ones(N + U, bool), 3, 8, precond=True)
+    check(got_x, got_costs, ref_x, ref_costs, dbl)
+
+
+@pytest.mark.parametrize("dbl,KS", [(True, 11), (False, 11), (True, 17)])
+def test_deconvolution_with_a_window_wider_than_the_dual_width(torch, tmp_path, dbl, KS):
+    """tests/energies/conv2d_wide.t: an 11 x 11 Sum, 121 unknown accesses per residual -- more than the forward-mode lowering carries at once (48), so the front-end's WIDE
+    lowering runs (32 partials per evaluation of the residual, chunk after chunk) -- and the same file with a 17 x 17 window (289 accesses, ten chunks: the size of the
+    reference's spatially_varying_deconvolution as shipped)."""
+    import time
+    W, H = 40, 30
+    rng = np.random.default_rng(31)
+    Ker = rng.uniform(0.0, 1.0, (KS, KS)); Ker /= Ker.sum()
+    truth = rng.uniform(0.0, 1.0, (H, W))
+    c = KS // 2
+
+    def blur(X):
+        out = np.zeros((H, W), dtype=X.dtype)
+        for ky in range(KS):
+            for kx in range(KS):
+                out[c:H - c, c:W - c] += Ker[ky, kx] * X[ky:H - 2 * c + ky, kx:W - 2 * c + kx]
+        return out
+
+    B = blur(truth) + 1e-3 * rng.standard_normal((H, W))
+    X0 = B.copy()
+
+    def F(x):
+        X = x.reshape(H, W)
+        data = np.zeros((H, W), dtype=X.dtype)
+        data[c:H - c, c:W - c] = (blur(X) - B)[c:H - c, c:W - c]
+        return np.concatenate([data.reshape(-1), 0.05 * x])
+
+    text = open(os.path.join(HERE, "conv2d_wide.t")).read()
+    if KS != 11: text = text.replace("kx - 5", f"kx - {c}").replace("ky - 5", f"ky - {c}").replace("InBoundsExpanded(x, y, 5)", f"InBoundsExpanded(x, y, {c})")
+    (tmp_path / "conv2d_wide.t").write_text(text)
+    t0 = time.time()
+    got_x, got_costs = run(torch, "conv2d_wide.t", (W, H, KS, KS), [X0.copy(), B, np.ascontiguousarray(Ker)], [0], dbl, here=str(tmp_path), nIterations=3, lIterations=3)
+    print(f"plan + solve of the wide unit ({KS} x {KS}):", round(time.time() - t0, 1), "s")
+    # (three PCG iterations per step: deconvolution is ill-conditioned, and a long CG run near convergence amplifies the last bit -- the order of the atomics -- to 1e-5
+    #  by the second step of 12; the first step of 12 agrees to 1e-17, three steps of 3 to 1e-15)
+    ref_x, ref_costs = mirror(F, X0.reshape(-1), np.ones(W * H, bool), 3, 3, precond=True)
     check(got_x, got_costs, ref_x, ref_costs, dbl)

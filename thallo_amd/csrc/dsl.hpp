@@ -109,6 +109,7 @@ struct Generated {
     std::vector<char> gather_ok;                   // per residual: the unknown-wise lowering exists (residual dims == the dims of every unknown it reads, constant-offset stencil accesses)
     std::vector<long> jp_offset;                   // per residual: offset of its rows in the Jp vector (Jt[Jp] schedule), in units of elements x components
     int n_prm = 0;
+    bool has_wide = false;                         // some residual took the wide lowering (more than 48 unknown accesses): the plugin compiles the unit without loop unrolling
 };
 // f64 (Thallo_InitializationParameters::doublePrecision): constants as double literals; the plugin compiles the unit with `float` standing for double
 bool generate_source(const Problem& p, Generated& out, std::string& err, bool f64 = false);

@@ -225,8 +225,10 @@ public:
                 arch = "--offload-arch=" + a;
             } else (void)hipGetLastError();
         }
-        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics" };
-        const hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+        // (a unit with a wide residual -- hundreds of 32-wide dual operations in one function -- takes minutes at -O3 with the loops unrolled: 128 s for the
+        //  reference's 17 x 17 deconvolution against 25 s without unrolling)
+        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics", "-fno-unroll-loops" };
+        const hiprtcResult rc = hiprtcCompileProgram(prog, G.has_wide ? 4 : 3, opts);
         if (rc != HIPRTC_SUCCESS) {
             size_t n = 0; hiprtcGetProgramLogSize(prog, &n); std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
             set_error("%s: hipRTC compilation of the generated kernels failed:\n%.1500s", P.file.c_str(), log.c_str());

@@ -244,5 +244,7 @@ def test_plan_free_cycles_do_not_leak_device_memory(torch, monkeypatch, kind):
         del s
         torch.cuda.synchronize()
         free.append(torch.cuda.mem_get_info()[0])
-    # (the first cycle may load code objects that stay with the process, and the runtime's own pools grow in 2-MB steps when the whole suite runs in one process)
-    assert free[1] - free[9] <= (8 << 20), free
+    # A leak per plan shows as a drop after EVERY cycle (25 MB here).  The runtime's own pools (code objects, signals, kernel arguments) also grow while the whole suite
+    # runs in one process -- in steps of 2 to 32 MB, at most once or twice over these ten cycles, and never per cycle: so the cycles whose free memory dropped are counted.
+    drops = sum(1 for a, b in zip(free[1:], free[2:]) if b < a - (1 << 20))
+    assert drops <= 2 and free[1] - free[9] <= (96 << 20), free

@@ -237,3 +237,68 @@ def test_deconvolution_with_a_window_wider_than_the_dual_width(torch, tmp_path, 
     #  by the second step of 12; the first step of 12 agrees to 1e-17, three steps of 3 to 1e-15)
     ref_x, ref_costs = mirror(F, X0.reshape(-1), np.ones(W * H, bool), 3, 3, precond=True)
     check(got_x, got_costs, ref_x, ref_costs, dbl)
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+def test_one_rigid_motion_for_a_point_set(torch, dbl):
+    """tests/energies/rigid_fit.t: six unknowns shared by every residual over the product domain {N, U = 1}; in single precision the file's schedule lines select the dense
+    [JtJ]p schedule (J^T J formed by v_mfma_f32_32x32x2_f32 tiles, spmv_kernels.hip), in double the inline one."""
+    N = 200
+    rng = np.random.default_rng(17)
+    Rest = rng.uniform(-1, 1, (N, 3))
+    ang = np.array([0.3, -0.2, 0.25]); sh = np.array([0.4, -0.1, 0.2])
+    Goal = _rotate3d(np.broadcast_to(ang, (N, 3)), Rest) + sh + 0.01 * rng.standard_normal((N, 3))
+    Goal[rng.uniform(size=N) < 0.2] = -1e6
+    x0 = np.zeros(6)
+
+    def F(x):
+        Shift, Euler = x[:3], x[3:]
+        r = _rotate3d(np.broadcast_to(Euler, (N, 3)).astype(x.dtype), Rest.astype(x.dtype)) + Shift - Goal
+        return np.where((Goal[:, :1] >= -999999.9), r, 0.0).reshape(-1)
+
+    dev_params = [np.zeros((1, 3)), np.zeros((1, 3)), Rest, Goal]
+    dev = []
+    for p in dev_params: dev.append(torch.from_numpy(p if dbl else p.astype(np.float32)).cuda())
+    s = api.ThalloSolver((N, 1), os.path.join(HERE, "rigid_fit.t"), double_precision=dbl)
+    if not dbl: assert s.schedule_name == "dense [JtJ]p", s.schedule_name
+    final, costs = s.solve(dev, profiled=True, nIterations=5, lIterations=6)
+    s.close()
+    got_x = np.concatenate([to_host(dev[0]).astype(np.float64).reshape(-1), to_host(dev[1]).astype(np.float64).reshape(-1)])
+    ref_x, ref_costs = mirror(F, x0, np.ones(6, bool), 5, 6, precond=True)
+    check(got_x, np.array(costs), ref_x, ref_costs, dbl)
+    assert np.abs(ref_x[3:] - ang).max() < 0.02 and np.abs(ref_x[:3] - sh).max() < 0.02          # (the motion the goals were made with comes back)
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+def test_embedded_deformation_nodes(torch, dbl):
+    """tests/energies/embedded_nodes.t: a nine-channel unknown (a free 3 x 3 matrix per node) next to a three-channel one, gemv through Sparse maps, a residual with six
+    components."""
+    nx, ny = 6, 5
+    N = nx * ny
+    rng = np.random.default_rng(23)
+    gx, gy = np.meshgrid(np.arange(nx, dtype=np.float64), np.arange(ny, dtype=np.float64))
+    Rest = np.stack([gx, gy, 0.2 * np.sin(gx + 0.5 * gy)], -1).reshape(N, 3)
+    Goal = np.full((N, 3), -1e6); Goal[:nx] = Rest[:nx]; Goal[-nx:] = Rest[-nx:] + np.array([0.3, 0.1, 0.5])
+    vid = lambda i, j: j * nx + i
+    pairs = [(vid(i, j), vid(i + 1, j)) for j in range(ny) for i in range(nx - 1)] + [(vid(i, j), vid(i, j + 1)) for j in range(ny - 1) for i in range(nx)]
+    pairs = pairs + [(q, p) for p, q in pairs]
+    a = np.array([p for p, _ in pairs], np.int32); b = np.array([q for _, q in pairs], np.int32)
+    E = len(pairs)
+    Off0 = Rest + 0.02 * rng.standard_normal((N, 3))
+    M0 = np.tile(np.eye(3).reshape(1, 9), (N, 1)) + 0.02 * rng.standard_normal((N, 9))
+    w_fit, w_reg, w_rot = float(np.float32(3.0)), float(np.float32(1.0)), float(np.float32(2.0))
+
+    def F(x):
+        Off = x[:3 * N].reshape(N, 3); M = x[3 * N:].reshape(N, 3, 3)
+        fit = np.where(Goal[:, :1] >= -999999.9, w_fit * (Off - Goal), 0.0)
+        d = Rest[b] - Rest[a]
+        edge = (Off[b] - Off[a]) - np.einsum("eij,ej->ei", M[a], d.astype(x.dtype))
+        c0, c1, c2 = M[:, :, 0], M[:, :, 1], M[:, :, 2]
+        dot = lambda u, v: (u * v).sum(-1)
+        rot = w_rot * np.stack([dot(c0, c1), dot(c0, c2), dot(c1, c2), dot(c0, c0) - 1, dot(c1, c1) - 1, dot(c2, c2) - 1], -1)
+        return np.concatenate([fit.reshape(-1), (w_reg * edge).reshape(-1), rot.reshape(-1)])
+
+    x0 = np.concatenate([Off0.reshape(-1), M0.reshape(-1)])
+    got_x, got_costs = run(torch, "embedded_nodes.t", (N, E), [w_fit, w_reg, w_rot, Off0.copy(), M0.copy(), Rest, Goal, a, b], [3, 4], dbl, nIterations=4, lIterations=10)
+    ref_x, ref_costs = mirror(F, x0, np.ones(12 * N, bool), 4, 10, precond=True)
+    check(got_x, got_costs, ref_x, ref_costs, dbl)

@@ -248,3 +248,18 @@ def test_plan_free_cycles_do_not_leak_device_memory(torch, monkeypatch, kind):
     # runs in one process -- in steps of 2 to 32 MB, at most once or twice over these ten cycles, and never per cycle: so the cycles whose free memory dropped are counted.
     drops = sum(1 for a, b in zip(free[1:], free[2:]) if b < a - (1 << 20))
     assert drops <= 2 and free[1] - free[9] <= (96 << 20), free
+
+
+def test_an_array_declared_double_needs_double_precision(torch, tmp_path):
+    """`Array(double, ...)` is a double array whatever the state's precision: the single-precision kernels would read it as floats, so the Plan says so; under
+    doublePrecision = 1 it is simply one more double array."""
+    f = tmp_path / "dbl_array.t"
+    f.write_text('local N = Dims("N")\nInputs { X = Unknown(thallo_float,{N},0), A = Array(double,{N},1) }\nlocal i = N()\nr = Residuals { fit = X(i) - A(i) }\n')
+    with pytest.raises(RuntimeError, match="declared double"):
+        api.ThalloSolver((16,), str(f))
+    A = np.linspace(0, 1, 16)
+    dev = [torch.zeros(16, dtype=torch.float64, device="cuda"), torch.from_numpy(A).cuda()]
+    s = api.ThalloSolver((16,), str(f), double_precision=True)
+    s.solve(dev, nIterations=2, lIterations=2)
+    s.close()
+    assert np.abs(to_host(dev[0]) - A).max() < 1e-14

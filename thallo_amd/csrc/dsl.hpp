@@ -64,6 +64,7 @@ struct Input {
     InputKind kind = InputKind::Array;
     int channels = 1;
     bool is_u8 = false;                            // Array(uint8, ...)
+    bool fixed_f64 = false;                        // declared `double`: double whatever the precision of the state -- supported under doublePrecision = 1 only
     bool fixed_f32 = false;                        // declared with a fixed single-precision element type (float, float3, mat3f ...) rather than a thallo_float one:
                                                    // stays float under doublePrecision = 1 (precision.t:3-6 switches thallo_float only)
     std::vector<int> dims;                         // dimension ids (Unknown / Array: the image's; Sparse: {from..., to}: one or two source dimensions, then the target)

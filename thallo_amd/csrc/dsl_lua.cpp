@@ -903,11 +903,12 @@ struct Interp {
         for (auto& al : alias) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = al[1]; adt.tab->fields.push_back({ al[0], f }); }
         globals->vars["ad"] = adt;
     }
-    static int type_channels(const Value& t, bool* u8, int line, bool* fixed32 = nullptr)
+    static int type_channels(const Value& t, bool* u8, int line, bool* fixed32 = nullptr, bool* fixed64 = nullptr)
     {
         if (!is_symk(t, SymV::TypeName)) fail("line " + std::to_string(line) + ": expected an element type (float, thallo_float2, uint8, ...)");
         const std::string& s = t.sym->s; *u8 = s == "uint8";
         if (fixed32) *fixed32 = s.rfind("thallo_", 0) != 0 && s != "uint8" && s != "double" && s != "int";
+        if (fixed64) *fixed64 = s == "double";
         if (s.find("mat3f") != std::string::npos) return 9;
         if (s.find("mat4f") != std::string::npos) return 16;
         const char last = s.back();
@@ -934,14 +935,14 @@ struct Interp {
         if (f == "Dims") { Values out; for (auto& v : a) { if (v.t != Value::Str) fail(ln + "Dims takes names"); SymV s; s.k = SymV::Dim; s.id = (int)P.dims.size(); P.dims.push_back(v.s); P.dim_alias.push_back(-1); P.dim_sizes.push_back(P.plan_dims ? (long)P.plan_dims[s.id] : -1); out.push_back(Value::make_sym(s)); } return out; }
         if (f == "Unknown" || f == "Array" || f == "Image") {           // Image: the deprecated spelling of Array (lib.t:573-576)
             need(3); Input in; in.kind = f == "Unknown" ? InputKind::Unknown : InputKind::Array;
-            in.channels = type_channels(a[0], &in.is_u8, line, &in.fixed_f32); in.dims = dim_list(a[1], line);
+            in.channels = type_channels(a[0], &in.is_u8, line, &in.fixed_f32, &in.fixed_f64); in.dims = dim_list(a[1], line);
             if (a[2].t != Value::Num) fail(ln + f + ": the third argument is the parameter index"); in.slot = small_int(a[2].n, ln + f + ": parameter index"); if (in.slot < 0 || in.slot > 4096) fail(ln + f + ": parameter index out of range");
             if (in.dims.empty() || in.dims.size() > 3) fail(ln + f + ": 1-, 2- and 3-dimensional images are supported");
             if (in.kind == InputKind::Unknown && in.is_u8) fail(ln + "uint8 unknowns are not supported");
             return { decl(in) };
         }
         if (f == "Sparse") { need(3); Input in; in.kind = InputKind::Sparse; auto from = dim_list(a[0], line), to = dim_list(a[1], line); if (from.empty() || from.size() > 2 || to.size() != 1) fail(ln + "Sparse({E}, {N}, idx) or Sparse({W,H}, {N}, idx)"); in.dims = from; in.dims.push_back(to[0]); if (a[2].t != Value::Num) fail(ln + "Sparse: the third argument is the parameter index"); in.slot = small_int(a[2].n, ln + "Sparse: parameter index"); if (in.slot < 0 || in.slot > 4096) fail(ln + "Sparse: parameter index out of range"); return { decl(in) }; }
-        if (f == "Param") { need(2); Input in; in.kind = InputKind::Param; bool u8; if (type_channels(a[0], &u8, line, &in.fixed_f32) != 1 || u8) fail(ln + "scalar float Params are supported"); if (a[1].t != Value::Num) fail(ln + "Param(type, index)"); in.slot = small_int(a[1].n, ln + "Param: parameter index"); if (in.slot < 0 || in.slot > 4096) fail(ln + "Param: parameter index out of range"); return { decl(in) }; }
+        if (f == "Param") { need(2); Input in; in.kind = InputKind::Param; bool u8; if (type_channels(a[0], &u8, line, &in.fixed_f32, &in.fixed_f64) != 1 || u8) fail(ln + "scalar float Params are supported"); if (a[1].t != Value::Num) fail(ln + "Param(type, index)"); in.slot = small_int(a[1].n, ln + "Param: parameter index"); if (in.slot < 0 || in.slot > 4096) fail(ln + "Param: parameter index out of range"); return { decl(in) }; }
         if (f == "Inputs") {
             need(1); if (a[0].t != Value::Table) fail(ln + "Inputs { name = ..., ... }");
             for (auto& kv : a[0].tab->fields) {

@@ -73,6 +73,7 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
 public:
     GeneratedPlugin(const dsl::Problem& p, const unsigned* dims, bool autoschedule, bool f64) : P(p), f64_(f64)
     {
+        if (!f64_) for (auto& in : P.inputs) if (in.fixed_f64) { set_error("%s: %s is declared double: that needs doublePrecision = 1 (the single-precision kernels would read it as floats)", P.file.c_str(), in.name.c_str()); return; }
         if (f64_) {
             // the reference's double mode switches thallo_float (precision.t:3-6); an unknown declared with a fixed float type has no place in double solver vectors
             for (auto& in : P.inputs) if (in.kind == dsl::InputKind::Unknown && in.fixed_f32) { set_error("%s: doublePrecision = 1 and the unknown %s is declared with a fixed float type (use thallo_float)", P.file.c_str(), in.name.c_str()); return; }

@@ -36,6 +36,8 @@ int main(int argc, char** argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: formats_fuzz <mutants per file> <kind>:<file> ...\n"); return 2; }
     const int mutants = atoi(argv[1]);
+    if (const char* seed = getenv("THALLO_FUZZ_SEED")) rng_state ^= strtoull(seed, nullptr, 0) * 0x9e3779b97f4a7c15ULL;      // (another stream of mutants; the tests use the built-in seed)
+    if (!rng_state) rng_state = 0x2545f4914f6cdd1dULL;
     long ok = 0, refused = 0, intact = 0;
     for (int a = 2; a < argc; ++a) {
         const std::string arg = argv[a]; const size_t colon = arg.find(':');

@@ -54,6 +54,8 @@ int main(int argc, char** argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: frontend_fuzz <mutants per file> <file.t> ...\n"); return 2; }
     const int mutants = atoi(argv[1]);
+    if (const char* seed = getenv("THALLO_FUZZ_SEED")) rng_state ^= strtoull(seed, nullptr, 0) * 0x9e3779b97f4a7c15ULL;      // (another stream of mutants; the tests use the built-in seed)
+    if (!rng_state) rng_state = 0x2545f4914f6cdd1dULL;
     const unsigned dims[16] = { 7, 5, 6, 4, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2 };       // small sizes: files with Sum are expanded for them
     char tmpl[] = "/tmp/thallo_fuzz_XXXXXX";
     const int fd = mkstemp(tmpl); if (fd < 0) { perror("mkstemp"); return 2; }

@@ -221,6 +221,25 @@ if os.environ.get("MB_MODE") == "occ":            # sweep build: workgroups per 
         L.thallo_hip_march_debug_set(6, 0)
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_MODE") == "nohalo":         # sweep build: what more waves per CU would give if halo rows cost nothing (dbg 3 = aligned strips, no halo rows / lanes, no arithmetic) -- the
+    out = {"W": W, "H": H}                        # upper bound of "waves marching in alternating directions hand their boundary rows over through LDS" 
+    for rep in range(2):
+        for cap in (0, 512, 1024):
+            L.thallo_hip_march_debug_set(6, cap)
+            for dbg in (3, 0):
+                cfg(2, 5, 2, dbg)
+                out[f"cap{cap}_dbg{dbg}_us_{rep}"] = [round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+        L.thallo_hip_march_debug_set(6, 0)
+    print(json.dumps(out)); sys.exit(0)
+
+if os.environ.get("MB_MODE") == "depth":          # sweep build: rows of prefetch (1, 2, 3) at cache policy 1
+    out = {"W": W, "H": H}
+    for rep in range(2):
+        for depth in (1, 2, 3):
+            cfg(depth, 1, 2, 0)
+            out[f"depth{depth}_us_{rep}"] = [round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "policy":         # sweep build: the cache-policy masks at the current size (the product's 5 was chosen at 2048^2, where the Infinity Cache holds much of the working set)
     out = {"W": W, "H": H}
     for rep in range(2):

@@ -166,11 +166,11 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
     // (band of 4 segments, strip) ids, x-adjacent strips first: x-halo columns and y-halo rows are re-read from the same L2
     int strip = 0, ya = 0, yb = 0, sya = 0, syb = 0;      // (sya, syb: the workgroup's segment -- map 2: waves without a strip still take part in its barriers)
     {
-        const int G = (gridDim.x % 8) == 0 ? 8 : 1;
+        const int G = (MARCH_MAPS && g.map == 3) ? 1 : (gridDim.x % 8) == 0 ? 8 : 1;      // (map 3, microbench: no XCD-aware placement -- workgroup b takes id b)
         const int grp = blockIdx.x % G, l = blockIdx.x / G;
         const long lo = (long)g.total * grp / G, hi = (long)g.total * (grp + 1) / G;
         const long id = lo + l;
-        if (MARCH_MAPS && id < hi && g.map >= 1) {        // (microbench) the 4 waves side by side: one segment of 4 x-adjacent strips; map 2: + a workgroup barrier per loop trip (three rows),
+        if (MARCH_MAPS && id < hi && (g.map == 1 || g.map == 2)) {        // (microbench) the 4 waves side by side: one segment of 4 x-adjacent strips; map 2: + a workgroup barrier per loop trip (three rows),
             const int nsb = (g.nstrips + 3) / 4;                             // so that the four waves touch the same image rows -- the same DRAM pages -- at the same time
             strip = (int)(id % nsb) * 4 + wave;
             const int seg = (int)(id / nsb);
@@ -517,7 +517,7 @@ inline MarchGeo make_march_geo(int W, int H, int row0, int row1, int R)
     const int nseg = (row1 - row0 + R - 1) / R;
     g.nwgrow = (nseg + MARCH_NT / 64 - 1) / (MARCH_NT / 64);
     g.total = g.nstrips * g.nwgrow;
-    if (g.map >= 1) g.total = ((g.nstrips + 3) / 4) * nseg;
+    if (g.map == 1 || g.map == 2) g.total = ((g.nstrips + 3) / 4) * nseg;
     return g;
 }
 

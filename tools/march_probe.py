@@ -240,6 +240,15 @@ if os.environ.get("MB_MODE") == "depth":          # sweep build: rows of prefetc
             out[f"depth{depth}_us_{rep}"] = [round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_MODE") == "xcd":            # sweep build: with (map 0) and without (map 3) the XCD-aware placement of the workgroups
+    out = {"W": W, "H": H}
+    for rep in range(2):
+        for mp in (0, 3):
+            for dbg in (0, 3):
+                cfg(2, 5, 2, dbg, 0, mp)
+                out[f"map{mp}_dbg{dbg}_us_{rep}"] = [round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "policy":         # sweep build: the cache-policy masks at the current size (the product's 5 was chosen at 2048^2, where the Infinity Cache holds much of the working set)
     out = {"W": W, "H": H}
     for rep in range(2):

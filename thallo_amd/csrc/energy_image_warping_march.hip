@@ -369,6 +369,24 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
             if (!FIRST && SCALARS_IN_LOOP && t0 == t_first) iteration_scalars<1>(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
             if (t0 == t_first) MARCH_STAMP(3);
             if (t0 == t_first + 3) MARCH_STAMP(4);
+            if (DBG == 7) {     // (tools: BATCHED trips, no delta variants -- the three rows' loads taken together, their 24 refills issued back to back, then the three rows'
+                                // arithmetic and their 18 stores: fewer, longer bursts per wave, like the streaming reference)
+                RawT cur3[3]; const RawD nod = RawD{};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) take(cur3[j], slot[j]);
+                fence_order();
+#pragma unroll
+                for (int j = 0; j < 3; ++j) issue(slot[j], t0 + j + 3 > t_last ? t_last : t0 + j + 3);
+                fence_order();
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int t = t0 + j;
+                    Row& wn = win[(j + 2) % 3]; Row& wc = win[(j + 1) % 3]; Row& wm = win[j % 3];
+                    if (t >= t_first && t <= t_last) publish(cur3[j], nod, t, true, wn);
+                    if (t - 1 >= ya && t <= t_last) stencil(t - 1, wm, wc, wn);
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = t0 + j;
@@ -558,7 +576,7 @@ constexpr int MARCH_WG_PER_CU = 1;                                // grid sizing
     X(2, 0, 2, 0) X(2, 1, 2, 0) X(2, 3, 2, 0) X(2, 9, 2, 0) X(2, 11, 2, 0) X(2, 33, 2, 0) X(2, 35, 2, 0) X(2, 41, 2, 0) X(2, 43, 2, 0) \
     X(2, 5, 2, 0) X(2, 17, 2, 0) X(2, 21, 2, 0) X(2, 31, 2, 0) X(2, 63, 2, 0) \
     X(2, 1, 3, 0) X(2, 11, 3, 0) X(2, 43, 3, 0) X(1, 1, 3, 0) X(1, 11, 3, 0) X(1, 43, 3, 0) X(1, 1, 4, 0) X(1, 11, 4, 0) \
-    X(2, 5, 2, 6) X(2, 11, 2, 6) X(2, 5, 2, 4) X(2, 0, 2, 4) X(2, 1, 2, 4) X(2, 4, 2, 0) X(2, 4, 2, 4) X(2, 16, 2, 0) X(2, 16, 2, 4) \
+    X(2, 5, 2, 6) X(2, 11, 2, 6) X(2, 5, 2, 7) X(2, 0, 2, 7) X(2, 5, 2, 4) X(2, 0, 2, 4) X(2, 1, 2, 4) X(2, 4, 2, 0) X(2, 4, 2, 4) X(2, 16, 2, 0) X(2, 16, 2, 4) \
     X(2, 1, 2, 1) X(2, 1, 2, 2) X(1, 1, 2, 0) X(3, 1, 2, 0) X(2, 5, 2, 1) X(2, 11, 2, 1) X(2, 0, 2, 1) X(2, 1, 2, 3) X(2, 5, 2, 3) X(2, 11, 2, 3) X(2, 0, 2, 3)
 
 template <bool DIST>

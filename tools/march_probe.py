@@ -249,6 +249,18 @@ if os.environ.get("MB_MODE") == "xcd":            # sweep build: with (map 0) an
                 out[f"map{mp}_dbg{dbg}_us_{rep}"] = [round(timeit("march", modes=(2,)), 2), round(timeit("march", modes=(4,)), 2)]
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_MODE") == "batched":        # sweep build: dbg 7 = the three rows of a trip taken together, 24 refills back to back, then arithmetic and 18 stores (mode 2 only: no delta variant)
+    out = {"W": W, "H": H}
+    a = run("march", 2, it0["r"], it0["A"], it0["p"], delta0)
+    cfg(2, 5, 2, 7); b = run("march", 2, it0["r"], it0["A"], it0["p"], delta0); cfg(2, 5, 2, 0)
+    out["batched_vs_product_mismatches"] = {k: int((a[k][:n].view(torch.int32) != b[k][:n].view(torch.int32)).sum().item()) for k in ("r", "A", "p")}
+    for rep in range(3):
+        for nt in (5, 0):
+            for dbg in (0, 7):
+                cfg(2, nt, 2, dbg)
+                out[f"nt{nt}_dbg{dbg}_us_{rep}"] = round(timeit("march", modes=(2,)), 2)
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "policy":         # sweep build: the cache-policy masks at the current size (the product's 5 was chosen at 2048^2, where the Infinity Cache holds much of the working set)
     out = {"W": W, "H": H}
     for rep in range(2):

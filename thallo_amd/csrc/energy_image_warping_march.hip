@@ -185,9 +185,9 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         }
     }
     const bool work = ya < yb;
-    const int x0 = (DBG == 3 || DBG == 6) ? strip * 128 + 2 * lane : strip * MARCH_USE - 2 + 2 * lane;          // first of this lane's two pixels
+    const int x0 = (DBG == 3 || DBG == 6 || DBG == 8) ? strip * 128 + 2 * lane : strip * MARCH_USE - 2 + 2 * lane;          // first of this lane's two pixels
     const bool xin = x0 >= 0 && x0 < g.W;                     // W even: both pixels exist or neither
-    const bool xout = DBG == 6 ? true : xin && (DBG == 3 || (lane >= 1 && lane <= 62));      // (DBG 6, timing only, W a multiple of 128: DBG 3 with every store unconditional)         // this lane's pixels are outputs of this wave
+    const bool xout = DBG == 6 ? true : xin && (DBG == 3 || DBG == 8 || (lane >= 1 && lane <= 62));      // (DBG 6, timing only, W a multiple of 128: DBG 3 with every store unconditional)         // this lane's pixels are outputs of this wave
 
     const float4* __restrict__ ro4 = reinterpret_cast<const float4*>(r_in);  const float2* __restrict__ ra2 = reinterpret_cast<const float2*>(r_in + 2 * N);
     const float4* __restrict__ ao4 = reinterpret_cast<const float4*>(A_in);  const float2* __restrict__ aa2 = reinterpret_cast<const float2*>(A_in + 2 * N);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         const float Lpx = from_left(wc.px[1]), Lpy = from_left(wc.py[1]), Lpa = from_left(wc.pa[1]), Lc = from_left(wc.c[1]), Ls = from_left(wc.s[1]);
         const float Rpx = from_right(wc.px[0]), Rpy = from_right(wc.py[0]), Rpa = from_right(wc.pa[0]), Rc = from_right(wc.c[0]), Rs = from_right(wc.s[0]);
         const unsigned Lf = from_left(wc.f) >> 8, Rf = from_right(wc.f);
-        if (DBG == 1 || DBG == 3 || DBG == 6) {
+        if (DBG == 1 || DBG == 3 || DBG == 6 || DBG == 8) {
             if (xout) {
                 const long i2 = (long)y * W2 + (x0 >> 1);
                 stf4(Ao4 + i2, make_float4(wc.px[0] + Lpx, wc.py[0], wc.px[1] + Rpx, wc.py[1]), nt_out); stf2(Aa2 + i2, make_float2(wc.pa[0] + wn.pa[0], wc.pa[1] + wm.pa[1]), nt_out);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
     };
 
     if (work) {
-        const int t_first = (DBG == 3 || DBG == 6) ? ya : ya - 1, t_last = (DBG == 3 || DBG == 6) ? yb - 1 : yb;            // rows to publish: the segment and its two halo rows
+        const int t_first = (DBG == 3 || DBG == 6 || DBG == 8) ? ya : ya - 1, t_last = (DBG == 3 || DBG == 6 || DBG == 8) ? yb - 1 : yb;            // rows to publish: the segment and its two halo rows
         // No branch around a load anywhere in this loop (see `issue`): the step count is rounded up to a multiple of 3, rows beyond
         // t_last are clamped re-reads of the last row (cache hits) whose publish / stencil are predicated off.
         // There is no prologue either: the loop starts three rows early with empty slots (publish predicated off) and its refills are
@@ -366,6 +366,8 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
             // The iteration's scalars, at the start of the SECOND trip: the first trip only issued the loads of rows t_first .. t_first + 2, nothing
             // needed alpha / beta yet; now the partial (or word) loads queue up behind those row loads and the additions run while the rows arrive.
             if (t0 == t_first) MARCH_STAMP(2);
+            if (DBG == 8) { alpha = 0.5f; beta = 0.25f; }      // (tools: DBG 3 without the iteration's scalars and without the reduction tail -- what a launch's fixed parts cost)
+            else
             if (!FIRST && SCALARS_IN_LOOP && t0 == t_first) iteration_scalars<1>(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
             if (t0 == t_first) MARCH_STAMP(3);
             if (t0 == t_first + 3) MARCH_STAMP(4);
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
                     continue;
                 }
                 if (t >= t_first && t <= t_last) publish(cur, curd, phys(t), true, wn);
-                if (DBG == 3) { if (t >= t_first && t <= t_last) stencil(t, wc, wn, wm); }      // (timing only)
+                if (DBG == 3 || DBG == 8) { if (t >= t_first && t <= t_last) stencil(t, wc, wn, wm); }      // (timing only)
                 else if (DBG == 4) { if (t - 1 >= ya && t <= t_last) stencil(phys(t - 1), wn, wc, wm); }
                 else if (t - 1 >= ya && t <= t_last) stencil(t - 1, wm, wc, wn);
             }
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
         const int t_first = DBG == 3 ? sya : sya - 1, t_last = DBG == 3 ? syb - 1 : syb;
         for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) __builtin_amdgcn_s_barrier();
     }
+    if (DBG == 8) { if ((threadIdx.x & 63) == 0) aD_out[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 1023] = acc; return; }
     MARCH_STAMP(5);
     iter_tail<MARCH_NT, DIST>(acc, s0, s1, s2, red, redd, aD_out, s12_out, bNp, &dd, fin_tickets, aD_word, bN_word, xslot);
     MARCH_STAMP(6);
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256) void k_stream_ref(long n2, long N, int span, i
 inline MarchGeo make_march_geo(int W, int H, int row0, int row1, int R)
 {
     MarchGeo g; g.W = W; g.H = H; g.row0 = row0; g.row1 = row1; g.R = R;
-    g.map = g_march_map; g.use = (g_march_dbg == 3 || g_march_dbg == 6) ? 128 : MARCH_USE;
+    g.map = g_march_map; g.use = (g_march_dbg == 3 || g_march_dbg == 6 || g_march_dbg == 8) ? 128 : MARCH_USE;
     g.nstrips = (W + g.use - 1) / g.use;
     const int nseg = (row1 - row0 + R - 1) / R;
     g.nwgrow = (nseg + MARCH_NT / 64 - 1) / (MARCH_NT / 64);
@@ -552,7 +555,7 @@ inline long march_cap(int occ) { return g_march_cap > 0 ? g_march_cap : (long)th
 inline int pick_rows(int W, int rows, int occ)
 {
     if (g_march_rows > 0) return g_march_rows;
-    const int use = (g_march_dbg == 3 || g_march_dbg == 6) ? 128 : MARCH_USE;
+    const int use = (g_march_dbg == 3 || g_march_dbg == 6 || g_march_dbg == 8) ? 128 : MARCH_USE;
     const int nstrips = (W + use - 1) / use, wpw = MARCH_NT / 64;
     if (g_march_cap > 0) return march_rows_per_segment(rows, nstrips, wpw, march_cap(occ));       // (a forced budget -- tests, tools -- is taken as it is)
     const long cus = march_cap(1);
@@ -576,7 +579,7 @@ constexpr int MARCH_WG_PER_CU = 1;                                // grid sizing
     X(2, 0, 2, 0) X(2, 1, 2, 0) X(2, 3, 2, 0) X(2, 9, 2, 0) X(2, 11, 2, 0) X(2, 33, 2, 0) X(2, 35, 2, 0) X(2, 41, 2, 0) X(2, 43, 2, 0) \
     X(2, 5, 2, 0) X(2, 17, 2, 0) X(2, 21, 2, 0) X(2, 31, 2, 0) X(2, 63, 2, 0) \
     X(2, 1, 3, 0) X(2, 11, 3, 0) X(2, 43, 3, 0) X(1, 1, 3, 0) X(1, 11, 3, 0) X(1, 43, 3, 0) X(1, 1, 4, 0) X(1, 11, 4, 0) \
-    X(2, 5, 2, 6) X(2, 11, 2, 6) X(2, 5, 2, 7) X(2, 0, 2, 7) X(2, 5, 2, 4) X(2, 0, 2, 4) X(2, 1, 2, 4) X(2, 4, 2, 0) X(2, 4, 2, 4) X(2, 16, 2, 0) X(2, 16, 2, 4) \
+    X(2, 5, 2, 6) X(2, 11, 2, 6) X(2, 5, 2, 7) X(2, 0, 2, 7) X(2, 5, 2, 8) X(2, 5, 2, 4) X(2, 0, 2, 4) X(2, 1, 2, 4) X(2, 4, 2, 0) X(2, 4, 2, 4) X(2, 16, 2, 0) X(2, 16, 2, 4) \
     X(2, 1, 2, 1) X(2, 1, 2, 2) X(1, 1, 2, 0) X(3, 1, 2, 0) X(2, 5, 2, 1) X(2, 11, 2, 1) X(2, 0, 2, 1) X(2, 1, 2, 3) X(2, 5, 2, 3) X(2, 11, 2, 3) X(2, 0, 2, 3)
 
 template <bool DIST>

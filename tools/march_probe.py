@@ -261,6 +261,15 @@ if os.environ.get("MB_MODE") == "batched":        # sweep build: dbg 7 = the thr
                 out[f"nt{nt}_dbg{dbg}_us_{rep}"] = round(timeit("march", modes=(2,)), 2)
     print(json.dumps(out)); sys.exit(0)
 
+if os.environ.get("MB_MODE") == "fixed":          # sweep build: dbg 3 (the halo-free skeleton) against dbg 8 (the same without the iteration's scalars and without the reduction tail) and the streaming reference on strips
+    out = {"W": W, "H": H}
+    for rep in range(3):
+        for dbg in (0, 3, 8):
+            cfg(2, 5, 2, dbg)
+            out[f"dbg{dbg}_us_{rep}"] = round(timeit("march", modes=(2,)), 2)
+        out[f"stream_strips_percu1_us_{rep}"] = round(time_stream(0, 5, 1, span=-1), 2)
+    print(json.dumps(out)); sys.exit(0)
+
 if os.environ.get("MB_MODE") == "policy":         # sweep build: the cache-policy masks at the current size (the product's 5 was chosen at 2048^2, where the Infinity Cache holds much of the working set)
     out = {"W": W, "H": H}
     for rep in range(2):

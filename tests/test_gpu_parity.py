@@ -213,6 +213,39 @@ def test_resident_pcg_loop_is_bitwise_the_marching_kernel(torch, monkeypatch, W,
     assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
+@pytest.mark.parametrize("batch", ["1", "0"])
+@pytest.mark.parametrize("W,H,lit", [(2048, 2048, 12), (1024, 768, 25), (256, 256, 30), (130, 7, 12), (124, 64, 9), (250, 2, 5), (126, 130, 7), (2, 1, 4), (372, 5, 6)])
+def test_marching_iteration_without_the_ap_plane_is_bitwise_the_stored_plane_kernel(torch, monkeypatch, W, H, lit, batch):
+    """the marching iteration that RECOMPUTES A p_{k-1} from the p_{k-1} rows (energy_image_warping_march_rc.hip: 57 + 18 B/pixel, no A p
+    plane) against the round-2/3 kernel that stores and re-reads it (81 + 18): same expressions on the same inputs, same geometry and summation order --
+    costs, every alpha_k / beta_k and the unknowns BIT-identical after three GN steps, with both delta schedules (every other iteration / every iteration).
+    Sizes: the benchmark's, one with ragged strips and segments, one- to three-strip images, images of 1, 2, 5 and 7 rows (segments shorter than the
+    pipeline's four halo rows)."""
+    p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
+    runs = []
+    monkeypatch.setenv("THALLO_RESIDENT", "0")
+    monkeypatch.setenv("THALLO_BATCH_DELTA", batch)
+    for form in ("2", "4"):
+        monkeypatch.setenv("THALLO_MARCH", form)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=2)
+        s.set_solver_parameters(nIterations=3, lIterations=lit)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        names = s.kernel_stats()
+        s.close()
+        runs.append((costs, traces, dev[0].clone(), dev[1].clone(), names))
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == 4 and len(t0[0]) == lit
+    assert n0.get("PCGIteration", {}).get("launches") == 3 * lit == n1.get("PCGIteration", {}).get("launches"), (n0, n1)
+    assert t0 == t1, [(i, k) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1)
+
+
 def test_image_warping_wider_than_the_workgroup_budget_runs_the_tile_kernel(torch, orc):
     """an image with more 124-pixel column strips than the device has workgroup slots (W > ~31.7k on 256 CUs, ~3.9k on a 32-CU
     partition) used to spin forever in the host's rows-per-segment search at the first Thallo_ProblemStep.  With the budget forced down to 8

@@ -161,6 +161,7 @@ class ImageWarpingPlugin : public EnergyPlugin {
     bool resident_ = false;                // the shape fits the resident kernel (whole image, unit pixel grid, even W, few enough rows per wave)
     bool resident_slab_ = false;           // ... as one rank's row slab of a multi-GPU run (thallo_hip_iw_pcg_resident_dist)
     bool march_ = false;                   // UrShape verified (at Init) to be the unit pixel grid and W even: the marching one-kernel iteration
+    bool march_rc_ = false;                // ... in its form without an A p plane (whole image on one GPU; THALLO_MARCH=3: the stored-plane form, A/B)
     bool grid_ = false;                    // UrShape is the unit pixel grid (host-checked at Init)
     int row0_ = 0, row1_ = 0;              // owned rows (all of them unless the Plan is one row slab of a multi-GPU run)
 public:
@@ -186,7 +187,7 @@ public:
     int prepare(LaunchCtx& c) override
     {   // UrShape is a constant input: establish once per Init, on the host, whether it is the unit pixel grid (what the reference's
         // harness passes, CombinedSolver.h:158-176) -- that selects thallo_hip_iw_pcg_iter_march; pcg_init still re-verifies on the device
-        march_ = grid_ = false;
+        march_ = grid_ = march_rc_ = false;
         const char* e = env_switch("THALLO_MARCH");
         int* word = (int*)irregular.ptr + 8;
         int rc = thallo_hip_iw_urshape_irregular(W, H, urshape, word, c.stream);
@@ -197,9 +198,10 @@ public:
         // 13.5 us -- below ~0.4 Mpixel a wave's short march is all lead-in and tail, the LDS-tiled kernel wins
         grid_ = bad == 0;
         if ((e && e[0] == '0') || (W & 1)) return 0;
-        march_ = grid_ && ((long)W * H >= 400000 || (e && e[0] == '2'));              // THALLO_MARCH=2: the marching kernel at every size (tests)
+        march_ = grid_ && ((long)W * H >= 400000 || (e && (e[0] == '2' || e[0] == '4')));      // THALLO_MARCH=2: the marching kernel at every size (tests); 3: with the stored A p plane (A/B); 4: both
         // an image with more 124-pixel column strips than the device has workgroup slots stays on the tile kernel (which loops over its tiles)
         if (march_ && thallo_hip_iw_march_rows(W, H) <= 0) march_ = false;
+        march_rc_ = march_ && row0_ == 0 && row1_ == H && !(e && (e[0] == '3' || e[0] == '4'));
         // small working sets: the whole PCG loop in one launch (state in registers); THALLO_RESIDENT=0: one launch per PCG iteration (A/B)
         resident_ = resident_slab_ = false;
         const char* er = env_switch("THALLO_RESIDENT");
@@ -263,6 +265,11 @@ public:
                  float* aD_word, float* bN_word) override
     {
         TimedLaunch t(c, "PCGIteration");
+        if (march_rc_ && !(mode & 1))
+            return thallo_hip_iw_pcg_iter_march_rc(W, H, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                   v.rbuf(cur), v.rbuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                                   aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, out, v.s12,
+                                                   aD_word ? v.fin_tickets : nullptr, aD_word, bN_word, c.stream);
         if (march_)
             return thallo_hip_iw_pcg_iter_march(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
                                                 v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
@@ -300,6 +307,10 @@ public:
                           float* out, double* s12_out) override
     {
         TimedLaunch t(c, "PCGIteration");
+        if (march_rc_ && !(mode & 1))
+            return thallo_hip_iw_pcg_iter_march_rc_deferred(W, H, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                            v.rbuf(cur), v.rbuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                                            aN, aN2, aD2, prev, (const int*)irregular.ptr, out, s12_out, c.stream);
         if (march_)
             return thallo_hip_iw_pcg_iter_march_deferred(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
                                                          v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,

@@ -192,7 +192,7 @@ const char* env_switch(const char* name)
 {
     static const char* const known[] = {
         "THALLO_RESIDENT",            // 0: image_warping runs one launch per PCG iteration even where the whole PCG loop fits one resident launch
-        "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up)
+        "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up); 3: the marching kernel with the stored A p plane (round 2/3); 4 = 2 + 3
         "THALLO_ONE_KERNEL",          // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
         "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch
         "THALLO_BATCH_DELTA",         // 0: delta += alpha p every iteration instead of every other one

@@ -10,7 +10,7 @@ in HBM (reference workload: examples/image_warping/src/main.cpp:131-149, 8 GN x 
 Prints ONE JSON line (rank 0).  `value` = whole-job PCG iterations per second.
 `roofline` = the dominant kernel (PCGIteration: one launch = a whole PCG iteration) measured live with the
 library's HIP-event pair around the PCG loop of every GN step (the loop is L launches of that one kernel);
-`achieved` / `frac` use the bytes the fused schedule has to move (99 B/pixel, = the PMC traffic), the
+`achieved` / `frac` use the bytes the fused schedule has to move (round 4: 74.8 B/pixel -- the A p plane is recomputed, not stored; 99 with THALLO_MARCH=3), the
 reference formulation's 180 B/pixel figure (SURVEY.md 8d) is kept under `reference_formulation`;
 `roofline.applyjtj_standalone` = the plain applyJTJ kernel (48 B/pixel) timed back-to-back
 after the timed region.  `--gpus N` (N > 1) without a launcher: this process starts the N ranks itself.  `cpu_baseline` = oracle/cpu_port_image_warping.c (OpenMP port
@@ -30,9 +30,22 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB
 ALG_BYTES_APPLYJTJ = 48         # read p 12 + Angle 4 + UrShape 8 + Mask 4 + Constraints 8, write Ap_X 12
 ALG_BYTES_FUSED_STEP1 = 96      # applyJTJ 48 + PCGStep3 (read z 12, p counted once, write p 12) + delta update (r/w 24)
 ALG_BYTES_PCG_ITER = 180        # applyJTJ 48 + PCGStep2 96 + PCGStep3 36 (the reference's three-kernel formulation)
-# What the one-kernel schedule has to move per pixel and PCG iteration, each array once: read r 12, Ap 12, p 12,
-# cs 8, flags 1; write r 12, Ap 12, p 12; the deferred delta update (read delta 12 + p_{k-2} 12, write delta 12) every other iteration = 18
-FUSED_BYTES_PCG_ITER = 99
+# What the one-kernel schedule has to move per pixel and PCG iteration, each array once.
+# Stored-plane kernel (rounds 2-3; THALLO_MARCH=3): read r 12, Ap 12, p 12, cs 8, flags 1; write r 12, Ap 12, p 12; the deferred delta update (read delta 12 +
+# p_{k-2} 12, write delta 12) every other iteration = 18  ->  99.
+# Round 4 (energy_image_warping_march_rc.hip): no A p plane -- read r 12, p 12, cs 8, flags 1; write r 12, p 12 = 57 on odd iterations, 93 on even ones (the two
+# deferred delta updates), and the FIRST iteration of a GN step on the stored-plane kernel without its A p read = 69: fused_bytes_per_iter(L) below (74.76 at L = 100).
+FUSED_BYTES_PCG_ITER_STORED = 99
+
+
+def fused_bytes_per_iter(L):
+    if os.environ.get("THALLO_MARCH", "1")[:1] in ("0", "3", "4"):
+        return float(FUSED_BYTES_PCG_ITER_STORED)
+    odd = L // 2                      # k = 1, 3, ...: no delta update
+    even = (L - 1) // 2               # k = 2, 4, ...: two delta updates
+    return (69.0 + 57.0 * odd + 93.0 * even) / L if L >= 1 else 0.0
+
+
 FUSED_BYTES_STEP1 = 75          # two-kernel A/B schedule: fused PCGStep3 + delta + applyJTJ
 
 
@@ -204,7 +217,7 @@ def main():
 
     npx = W * H
     dom = "PCGIteration" if one_kernel else "PCGStep1"
-    dom_bytes = FUSED_BYTES_PCG_ITER if one_kernel else FUSED_BYTES_STEP1          # what the kernel has to move (= its PMC traffic)
+    dom_bytes = fused_bytes_per_iter(L_it) if one_kernel else FUSED_BYTES_STEP1          # what the kernel has to move (= its PMC traffic)
     ref_bytes = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1        # the reference formulation of the same work
     step1_ms = perf["linearSolve"]["meanMS"] / L_it if one_kernel else ks[dom]["mean_ms"]
     n_samples = perf["linearSolve"]["count"] * L_it if one_kernel else ks[dom]["samples"]
@@ -240,7 +253,8 @@ def main():
                      "timing": ("HIP events around the PCG loop of every GN step (L launches of this one kernel) / L" if one_kernel
                                 else "HIP events around every 16th launch of the kernel"),
                      "note": "achieved = bytes_per_pixel x pixels / avg launch time: the bytes this fused kernel has to move, each array once "
-                             "(DESIGN.md section 4; the PMC traffic is 5 % above it: halo rows and strip overlaps)",
+                             "(DESIGN.md section 4).  Round 4 removed the A p plane from the iteration (99 -> 74.8 B/pixel): frac is quoted on the NEW, "
+                             "smaller byte count, so a lower frac at a higher PCG rate than round 3's line is a faster kernel, not a slower one",
                      # the same launch priced with SURVEY.md 8d's bytes of the reference's three-kernel formulation -- a speed-up figure, not a
                      # roofline fraction (it exceeds the HBM peak because the schedule removes 45 % of those bytes)
                      "reference_formulation": {"bytes_per_pixel": ref_bytes, "equivalent_GBps": ref_bytes * npx / (step1_ms * 1e-3) / 1e9},

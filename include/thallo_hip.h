@@ -349,7 +349,7 @@ int thallo_hip_iw_pcg_iter_march_rc_deferred(int W, int H, const float* cs, cons
                                              const float* r_in, float* r_out, const float* p_in, float* p_out, float* delta, int mode,
                                              thallo_sum_t alphaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2, thallo_prev_t prev,
                                              const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
-void thallo_hip_march_rc_debug_set(int what, int value);  /* tools only: 0 rows of prefetch (1, 2, 4), 1 register budget (workgroups per CU: 1, 2) */
+void thallo_hip_march_rc_debug_set(int what, int value);  /* sweep builds (tools/rc_probe.py) only: 0 rows of prefetch (1, 2, 4), 1 register budget (workgroups per CU: 1, 2, 3), 2 cache-policy mask */
 /* *count_out (device int) = number of pixels whose right / down UrShape neighbour is not at the exact unit offset (0 = pixel grid) */
 int thallo_hip_iw_urshape_irregular(int W, int H, const float* urshape, int* count_out, thallo_stream_t stream);
 void thallo_hip_march_debug_set(int what, int value);     /* tools / tests only: 0 rows per wave segment, 6 workgroup budget (sweep builds: 1 prefetch depth, 2 non-temporal mask, 3 occupancy, 4 debug mode, 5 map) */

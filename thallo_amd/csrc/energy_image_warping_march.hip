@@ -193,8 +193,9 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march(MarchGeo g, const 
     float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     // gather J^T J p_k for the centre row y of the window (wm = y-1, wc = y, wn = y+1)
     auto stencil = [&](int y, const Row& wm, const Row& wc, const Row& wn) {
-        float ax[2], ay[2], av[2];
-        jtjp_pair(wm, wc, wn, wm, wc, wn, wf2, wr2, ax, ay, av);      // (all lanes: the DPP shifts read inactive lanes' registers as they are, but lanes 0 / 63 must have run publish)
+        float ax[2], ay[2], av[2], am[2], ac[2], an[2], wfm[2], wfc[2], wfn[2];
+        flag_masks(wm.f, wf2, am, wfm); flag_masks(wc.f, wf2, ac, wfc); flag_masks(wn.f, wf2, an, wfn);
+        jtjp_pair(wm, wc, wn, wm, wc, wn, am, ac, an, wfc, wr2, ax, ay, av);      // (every lane: the DPP shifts read the neighbouring lanes' registers)
         if (xout) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)

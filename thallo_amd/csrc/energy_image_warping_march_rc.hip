@@ -25,23 +25,74 @@ namespace {
 
 inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
 
+// Raw-buffer addressing: ONE descriptor per solver vector / plane (4 SGPRs), the lane's position in a row as a constant VGPR byte offset, the row as an SGPR byte
+// offset -- a row step needs no vector address arithmetic at all (the 64-bit global pointers of the first version cost ~10 v_lshl_add_u64 per row and ~20 VGPRs).
+// A vector is [Offset part: N x float2 | Angle part: N x float] = 12 N bytes < 4 GiB up to N = 357 Mpixel (16384^2 = 268 M: checked by the host).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffffu, 0x00020000); }
+template <bool NT> __device__ __forceinline__ u32x4 bld4(rsrc_t r, unsigned vo, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, NT ? 2 : 0); }
+template <bool NT> __device__ __forceinline__ u32x2 bld2(rsrc_t r, unsigned vo, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, NT ? 2 : 0); }
+template <bool NT> __device__ __forceinline__ unsigned bld1(rsrc_t r, unsigned vo, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, NT ? 2 : 0); }
+template <bool NT> __device__ __forceinline__ void bst4(rsrc_t r, unsigned vo, unsigned so, float a, float b, float c, float d)
+{ u32x4 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); v.z = __float_as_uint(c); v.w = __float_as_uint(d); __builtin_amdgcn_raw_buffer_store_b128(v, r, vo, so, NT ? 2 : 0); }
+template <bool NT> __device__ __forceinline__ void bst2(rsrc_t r, unsigned vo, unsigned so, float a, float b)
+{ u32x2 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); __builtin_amdgcn_raw_buffer_store_b64(v, r, vo, so, NT ? 2 : 0); }
+__device__ __forceinline__ float uf(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ float to_sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// iteration_scalars (iw_device.hpp) in a lean form: sums are added up by a ROLLED loop with one load in flight (the same additions in the same order as
+// sum_partials / k_iter_finish; finished sums are one word; alphaN_0 and iteration k-1's raw partials are at most a few per lane).  The general routine keeps 16
+// loads in flight per sum behind per-lane predicates: inside the row loop, with every ring register live, that cost ~20 VGPRs and ~90 spilled SGPRs.
+__device__ __forceinline__ float rc_sum(thallo_sum_t s)
+{
+    if (s.count == 1) return s.partials[0];
+    float t = 0.0f;
+    for (int i = threadIdx.x & (THALLO_WAVE - 1); i < s.count; i += THALLO_WAVE) t += s.partials[i];
+    return wave_sum_all(t);
+}
+__device__ __forceinline__ void rc_iteration_scalars(thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, const PrevSums& prev, float& alpha, float& beta, bool writer)
+{
+    const float an = rc_sum(aNp);
+    float ad, bn;
+    if (prev.count > 0) {
+        const int lane = threadIdx.x & (THALLO_WAVE - 1), nb = prev.count;
+        float t = 0.0f; double n = 0.0, a1 = 0.0, b1 = 0.0;
+        for (int i = lane; i < nb; i += THALLO_WAVE) { t += prev.aD_part[i]; n += prev.s12_part[3 * i]; a1 += prev.s12_part[3 * i + 1]; b1 += prev.s12_part[3 * i + 2]; }
+        ad = nb == 1 ? prev.aD_part[0] : wave_sum_all(t);
+        n = wave_sum_all_d(n); a1 = wave_sum_all_d(a1); b1 = wave_sum_all_d(b1);
+        alpha = safe_div<false>(an, ad);
+        double bd = n - 2.0 * (double)alpha * a1 + (double)alpha * (double)alpha * b1;
+        if (!(bd > 0.0)) bd = 0.0;
+        bn = (float)bd;
+        if (writer) { prev.aD_word[0] = ad; prev.bN_word[0] = bn; }      // writer: exactly ONE thread of the launch, one that certainly gets here
+    } else {
+        ad = rc_sum(aDp); bn = rc_sum(bNp);
+        alpha = safe_div<false>(an, ad);
+    }
+    beta = safe_div<false>(bn, an);
+}
+
 template <int DMODE>
 struct RawRc {                              // what one step takes, for one lane (2 pixels)
-    float4 po, cs; float2 pa; unsigned f;   // row t:   p_{k-1} (Offset part x0,y0,x1,y1 | Angle part a0,a1), (c0,s0,c1,s1), the dword holding the pair's flags bytes
-    float4 ro; float2 ra;                   // row t-1: r_{k-1}
-    float4 dlo, ppo; float2 dla, ppa;       // row t-1: delta (DMODE 0, 2) and p_{k-2} (DMODE 2)
+    u32x4 po, cs; u32x2 pa; unsigned f;     // row t:   p_{k-1} (Offset part x0,y0,x1,y1 | Angle part a0,a1), (c0,s0,c1,s1), the dword holding the pair's flags bytes
+    u32x4 ro; u32x2 ra;                     // row t-1: r_{k-1}
+    u32x4 dlo, ppo; u32x2 dla, ppa;         // row t-1: delta (DMODE 0, 2) and p_{k-2} (DMODE 2)
 };
+__device__ __forceinline__ void take4u(u32x4& d, const u32x4& s) { unsigned a, b, c, e; take1(a, s.x); take1(b, s.y); take1(c, s.z); take1(e, s.w); d.x = a; d.y = b; d.z = c; d.w = e; }
+__device__ __forceinline__ void take2u(u32x2& d, const u32x2& s) { unsigned a, b; take1(a, s.x); take1(b, s.y); d.x = a; d.y = b; }
 template <int DMODE>
 __device__ __forceinline__ void take(RawRc<DMODE>& d, const RawRc<DMODE>& s)
 {
-    take4(d.po, s.po); take2(d.pa, s.pa); take4(d.cs, s.cs); take1(d.f, s.f); take4(d.ro, s.ro); take2(d.ra, s.ra);
-    if (DMODE != 1) { take4(d.dlo, s.dlo); take2(d.dla, s.dla); }
-    if (DMODE == 2) { take4(d.ppo, s.ppo); take2(d.ppa, s.ppa); }
+    take4u(d.po, s.po); take2u(d.pa, s.pa); take4u(d.cs, s.cs); take1(d.f, s.f); take4u(d.ro, s.ro); take2u(d.ra, s.ra);
+    if (DMODE != 1) { take4u(d.dlo, s.dlo); take2u(d.dla, s.dla); }
+    if (DMODE == 2) { take4u(d.ppo, s.ppo); take2u(d.ppa, s.ppa); }
 }
 
 struct PRow { float px[2], py[2], pa[2]; };                      // p of a lane's pixel pair in one row
-struct GRow { float c[2], s[2]; unsigned f; };                   // cos / sin of Angle and the two flags bytes
-struct RRow { float rx[2], ry[2], ra[2], mo[2], ma[2]; };        // r_k and M^-1
+struct GRow { float c[2], s[2], a[2]; unsigned f; };             // cos / sin of Angle, the active bits as 0 / 1, the two flags bytes
+struct RRow { float rx[2], ry[2], ra[2]; };                      // r_k
 
 // DMODE: the delta update this launch carries (THALLO_IW_STEP1_MODE): 0 delta += alpha p_{k-1}; 1 none; 2 delta += alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}
 template <int DMODE, int DEPTH, int NTM, int OCC>
@@ -53,7 +104,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                                                             unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, PrevSums prev)
 {
     static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "the prefetch slots rotate inside a trip of four rows");
-    __shared__ float2 lut[32];
+    __shared__ float4 lut[32];              // by the 5-bit flags value: M^-1 of the Offset channels, of the Angle channel, w_fit^2 where the fit residual is valid
     __shared__ float red[16];
     __shared__ double redd[48];
     constexpr bool nt_delta = NTM & 1, nt_ra = NTM & 2, nt_out = NTM & 4, nt_pin = NTM & 8, nt_pout = NTM & 16, nt_const = NTM & 32;
@@ -64,11 +115,11 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
         if (threadIdx.x == 0) { aD_out[blockIdx.x] = __builtin_nanf(""); }
         return;
     }
-    if (threadIdx.x < 32) { float mo, ma; pre_from_flags((unsigned char)threadIdx.x, wf2, wr2, mo, ma); lut[threadIdx.x] = make_float2(mo, ma); }
+    if (threadIdx.x < 32) { float mo, ma; pre_from_flags((unsigned char)threadIdx.x, wf2, wr2, mo, ma); lut[threadIdx.x] = make_float4(mo, ma, (threadIdx.x & 2) ? wf2 : 0.f, 0.f); }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long N = (long)g.W * g.H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned N = (unsigned)g.W * (unsigned)g.H;         // (12 N < 2^32: host-checked)
     const int W2 = g.W >> 1;                                  // pixel pairs per row
     int strip, ya, yb;
     march_place(g, wave, strip, ya, yb);
@@ -77,13 +128,17 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
     const bool xin = x0 >= 0 && x0 < g.W;                     // W even: both pixels exist or neither
     const bool xout = xin && lane >= 1 && lane <= 62;         // this lane's pixels are outputs of this wave
 
-    const float4* __restrict__ ro4 = reinterpret_cast<const float4*>(r_in);  const float2* __restrict__ ra2 = reinterpret_cast<const float2*>(r_in + 2 * N);
-    const float4* __restrict__ po4 = reinterpret_cast<const float4*>(p_in);  const float2* __restrict__ pa2 = reinterpret_cast<const float2*>(p_in + 2 * N);
-    const float4* __restrict__ cs4 = reinterpret_cast<const float4*>(cs);
-    const unsigned* __restrict__ f4 = reinterpret_cast<const unsigned*>(flags);
-    float4* __restrict__ Ro4 = reinterpret_cast<float4*>(r_out);  float2* __restrict__ Ra2 = reinterpret_cast<float2*>(r_out + 2 * N);
-    float4* __restrict__ qo4 = reinterpret_cast<float4*>(p_out);  float2* __restrict__ qa2 = reinterpret_cast<float2*>(p_out + 2 * N);
-    float4* __restrict__ dl4 = reinterpret_cast<float4*>(delta);  float2* __restrict__ dl2 = reinterpret_cast<float2*>(delta + 2 * N);
+    const rsrc_t RS_P = make_rsrc(p_in), RS_R = make_rsrc(r_in), RS_CS = make_rsrc(cs), RS_F = make_rsrc(flags);
+    const rsrc_t RS_Q = make_rsrc(p_out), RS_RO = make_rsrc(r_out), RS_D = make_rsrc(delta);
+    // Loads are UNCONDITIONAL (rows clamped into the image / the segment, columns into the row; validity applied when the row enters the rings): a load under a
+    // branch is merged with the slot's old value right behind the branch, i.e. waited for at once (energy_image_warping_march.hip)
+    const int xc = x0 < 0 ? 0 : x0 > g.W - 2 ? g.W - 2 : x0;
+    const unsigned h = (unsigned)xc >> 1;                     // the lane's pixel pair in its row; output lanes: xc == x0, so loads and stores share the offsets
+    const unsigned vo16 = h * 16u, vo8 = h * 8u;              // byte offsets inside a row: Offset part / cs (float4 per pair), Angle part (float2 per pair)
+    // flags: the aligned dword that holds the pair's two bytes.  Pair index i = t W2 + h, dword i >> 1, bytes at bit 16 (i & 1).  With p = (t W2) & 1:
+    // p = 0: dword t W2 / 2 + (h >> 1); p = 1: (t W2 - 1) / 2 + ((h + 1) >> 1) -- the row part is scalar, the lane part one of two constants
+    const unsigned vf0 = (h >> 1) * 4u, vf1 = ((h + 1u) >> 1) * 4u, sh0 = (h & 1u) * 16u;
+    const unsigned angle0 = 8u * N;                           // byte offset of a vector's Angle part
 
     float alpha = 0.0f, beta = 0.0f, alpha2 = 0.0f;
     // the words of iteration k-1 are left behind by the one wave that owns the first segment of strip 0
@@ -91,23 +146,18 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 
     typedef RawRc<DMODE> RawT;
     RawT slot[DEPTH];
-    // Loads are UNCONDITIONAL (addresses clamped into the image / the segment, validity applied when the row enters the rings): a load under a branch is
-    // merged with the slot's old value right behind the branch, i.e. waited for at once (energy_image_warping_march.hip)
-    const int xc = x0 < 0 ? 0 : x0 > g.W - 2 ? g.W - 2 : x0;
     auto issue = [&](RawT& s, int t) {
-        const int tc = t < 0 ? 0 : t > g.H - 1 ? g.H - 1 : t;
-        const long i2 = (long)tc * W2 + (xc >> 1);
-        s.po = ldf4(po4 + i2, nt_pin); s.pa = ldf2(pa2 + i2, nt_pin);
-        s.cs = ldf4(cs4 + i2, nt_const);
-        s.f = nt_const ? __builtin_nontemporal_load(f4 + (i2 >> 1)) : f4[i2 >> 1];
-        const int tr = t - 1 < 0 ? 0 : t - 1 > g.H - 1 ? g.H - 1 : t - 1;
-        const long j2 = (long)tr * W2 + (xc >> 1);
-        s.ro = ldf4(ro4 + j2, nt_ra); s.ra = ldf2(ra2 + j2, nt_ra);
+        const unsigned tc = (unsigned)(t < 0 ? 0 : t > g.H - 1 ? g.H - 1 : t), row = tc * (unsigned)W2;
+        s.po = bld4<nt_pin>(RS_P, vo16, row * 16u); s.pa = bld2<nt_pin>(RS_P, vo8, angle0 + row * 8u);
+        s.cs = bld4<nt_const>(RS_CS, vo16, row * 16u);
+        const unsigned par = row & 1u;
+        s.f = bld1<nt_const>(RS_F, par ? vf1 : vf0, (row - par) * 2u);
+        const unsigned tr = (unsigned)(t - 1 < 0 ? 0 : t - 1 > g.H - 1 ? g.H - 1 : t - 1), rrow = tr * (unsigned)W2;
+        s.ro = bld4<nt_ra>(RS_R, vo16, rrow * 16u); s.ra = bld2<nt_ra>(RS_R, vo8, angle0 + rrow * 8u);
         if (DMODE != 1) {       // delta (and p_{k-2}) of the segment's own rows only (the halo rows re-read a row of the segment, unused)
-            const int td = t - 1 < ya ? ya : t - 1 > yb - 1 ? yb - 1 : t - 1;
-            const long d2 = (long)td * W2 + (xc >> 1);
-            s.dlo = ldf4(dl4 + d2, nt_delta); s.dla = ldf2(dl2 + d2, nt_delta);
-            if (DMODE == 2) { s.ppo = qo4[d2]; s.ppa = qa2[d2]; }
+            const unsigned td = (unsigned)(t - 1 < ya ? ya : t - 1 > yb - 1 ? yb - 1 : t - 1), drow = td * (unsigned)W2;
+            s.dlo = bld4<nt_delta>(RS_D, vo16, drow * 16u); s.dla = bld2<nt_delta>(RS_D, vo8, angle0 + drow * 8u);
+            if (DMODE == 2) { s.ppo = bld4<false>(RS_Q, vo16, drow * 16u); s.ppa = bld2<false>(RS_Q, vo8, angle0 + drow * 8u); }
         }
     };
 
@@ -116,30 +166,37 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { pp[i].px[q] = 0.f; pp[i].py[q] = 0.f; pp[i].pa[q] = 0.f; pk[i].px[q] = 0.f; pk[i].py[q] = 0.f; pk[i].pa[q] = 0.f; gg[i].c[q] = 1.f; gg[i].s[q] = 0.f; }
+        for (int q = 0; q < 2; ++q) { pp[i].px[q] = 0.f; pp[i].py[q] = 0.f; pp[i].pa[q] = 0.f; pk[i].px[q] = 0.f; pk[i].py[q] = 0.f; pk[i].pa[q] = 0.f;
+                                      gg[i].c[q] = 1.f; gg[i].s[q] = 0.f; gg[i].a[q] = 0.f; }
         gg[i].f = 0u;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { rr[i].rx[q] = 0.f; rr[i].ry[q] = 0.f; rr[i].ra[q] = 0.f; rr[i].mo[q] = 0.f; rr[i].ma[q] = 0.f; }
+        for (int q = 0; q < 2; ++q) { rr[i].rx[q] = 0.f; rr[i].ry[q] = 0.f; rr[i].ra[q] = 0.f; }
 
     float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const unsigned mxin = xin ? 0xffffu : 0u;
 
     if (work) {
         const int t_first = ya - 2, t_last = yb + 1;          // rows of p_{k-1} / cs / flags to take
         // No prologue (a second path into the loop header makes its wait the conservative merge of both): the loop starts DEPTH rows early with empty slots.
         // The rings are indexed by j, the position inside the trip, so any starting row works.
+        // The row step itself is BRANCH-FREE: rows outside [t_first, t_last] (lead-in: empty slots; rounding-up: clamped re-reads) and lanes outside the image go
+        // through the same arithmetic on zeros / finite garbage that nothing consumes -- pixels outside the image are INACTIVE (flags 0: every term that would read
+        // them is multiplied by 0), and a row's p_k is only used by the sums of rows that are themselves in range -- and only the stores (exec mask) and the sums
+        // (a 0 / 1 multiplicand, M^-1 = 0) are predicated.  A uniform branch around the arithmetic is a merge point with a phi per ring register.
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) slot[j] = RawT{};
         const int t_begin = t_first - DEPTH;
         for (int t0 = t_begin; t0 <= t_last; t0 += 4) {
             // The iteration's scalars, at the start of the SECOND trip: the first trip issued the loads of the first rows and entered (at most) rows ya-2, ya-1,
             // which need neither alpha nor beta; the partial loads queue up behind those row loads and the additions run while the rows arrive.
-            // (DEPTH 1 reaches row ya in its first trip: in front of the loop.)
+            // (DEPTH 1 reaches row ya in its first trip: in front of the loop.)  Wave-uniform: kept in SGPRs.
             if (DEPTH == 1 ? t0 == t_begin : t0 == t_begin + 4) {
-                iteration_scalars<1>(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
-                if (DMODE == 2) alpha2 = safe_div<false>(sum_partials(aNpp.partials, aNpp.count), sum_partials(aDpp.partials, aDpp.count));
+                rc_iteration_scalars(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
+                alpha = to_sgpr(alpha); beta = to_sgpr(beta);
+                if (DMODE == 2) alpha2 = to_sgpr(safe_div<false>(rc_sum(aNpp), rc_sum(aDpp)));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -154,61 +211,71 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                 fence_order();                               // the refill stays behind the moves ...
                 issue(slot[j % DEPTH], t + DEPTH > t_last ? t_last : t + DEPTH);
                 fence_order();                               // ... and in front of the arithmetic
-                if (t < t_first || t > t_last) continue;     // (wave-uniform, no load inside: lead-in and rounding-up rows; the rings keep their zeros)
-                // ---- row t enters the p_{k-1} / geometry rings
+                // ---- row t enters the p_{k-1} / geometry rings (outside the image: inactive)
                 {
-                    const bool ok = xin && t >= 0 && t < g.H;
-                    const unsigned fl = ok ? (cur.f >> (((((long)t * W2 + (x0 >> 1)) & 1) != 0) ? 16 : 0)) & 0xffffu : 0u;
-                    p0.px[0] = ok ? cur.po.x : 0.f; p0.py[0] = ok ? cur.po.y : 0.f; p0.px[1] = ok ? cur.po.z : 0.f; p0.py[1] = ok ? cur.po.w : 0.f;
-                    p0.pa[0] = ok ? cur.pa.x : 0.f; p0.pa[1] = ok ? cur.pa.y : 0.f;
-                    g0.c[0] = cur.cs.x; g0.s[0] = cur.cs.y; g0.c[1] = cur.cs.z; g0.s[1] = cur.cs.w; g0.f = fl;
+                    const bool rowok = t >= 0 && t < g.H;
+                    const unsigned par = ((unsigned)t * (unsigned)W2) & 1u;
+                    const unsigned fl = (cur.f >> (par ? 16u - sh0 : sh0)) & (rowok ? mxin : 0u);
+                    p0.px[0] = uf(cur.po.x); p0.py[0] = uf(cur.po.y); p0.px[1] = uf(cur.po.z); p0.py[1] = uf(cur.po.w); p0.pa[0] = uf(cur.pa.x); p0.pa[1] = uf(cur.pa.y);
+                    g0.c[0] = uf(cur.cs.x); g0.s[0] = uf(cur.cs.y); g0.c[1] = uf(cur.cs.z); g0.s[1] = uf(cur.cs.w); g0.f = fl;
+                    g0.a[0] = (float)(fl & 1u); g0.a[1] = (float)((fl >> 8) & 1u);
                 }
                 // ---- row u = t-1: A p_{k-1}(u) -> r_k(u), p_k(u)
                 const int u = t - 1;
-                if (u >= ya - 1 && u <= yb) {
+                {
+                    const float4 m0 = lut[g1.f & 31u], m1 = lut[(g1.f >> 8) & 31u];      // (M^-1 offsets, M^-1 angle, w_fit^2 or 0)
+                    const float wfit[2] = { m0.z, m1.z };
                     float ax[2], ay[2], av[2];
-                    jtjp_pair(p2, p1, p0, g2, g1, g0, wf2, wr2, ax, ay, av);
-                    const bool ok = xin && u >= 0 && u < g.H;
-                    float rx[2] = { cur.ro.x, cur.ro.z }, ry[2] = { cur.ro.y, cur.ro.w }, rq[2] = { cur.ra.x, cur.ra.y };
+                    jtjp_pair(p2, p1, p0, g2, g1, g0, g2.a, g1.a, g0.a, wfit, wr2, ax, ay, av);
+                    float rx[2] = { uf(cur.ro.x), uf(cur.ro.z) }, ry[2] = { uf(cur.ro.y), uf(cur.ro.w) }, rq[2] = { uf(cur.ra.x), uf(cur.ra.y) };
                     rx[0] = __builtin_fmaf(-alpha, ax[0], rx[0]); ry[0] = __builtin_fmaf(-alpha, ay[0], ry[0]);
                     rx[1] = __builtin_fmaf(-alpha, ax[1], rx[1]); ry[1] = __builtin_fmaf(-alpha, ay[1], ry[1]);
                     rq[0] = __builtin_fmaf(-alpha, av[0], rq[0]); rq[1] = __builtin_fmaf(-alpha, av[1], rq[1]);
-                    const float2 m0 = lut[g1.f & 31u], m1 = lut[(g1.f >> 8) & 31u];
                     const float mo[2] = { m0.x, m1.x }, ma[2] = { m0.y, m1.y };
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        k1.px[q] = ok ? mo[q] * rx[q] + beta * p1.px[q] : 0.f; k1.py[q] = ok ? mo[q] * ry[q] + beta * p1.py[q] : 0.f; k1.pa[q] = ok ? ma[q] * rq[q] + beta * p1.pa[q] : 0.f;
-                        r1.rx[q] = rx[q]; r1.ry[q] = ry[q]; r1.ra[q] = rq[q]; r1.mo[q] = mo[q]; r1.ma[q] = ma[q];
+                        k1.px[q] = mo[q] * rx[q] + beta * p1.px[q]; k1.py[q] = mo[q] * ry[q] + beta * p1.py[q]; k1.pa[q] = ma[q] * rq[q] + beta * p1.pa[q];
+                        r1.rx[q] = rx[q]; r1.ry[q] = ry[q]; r1.ra[q] = rq[q];
                     }
-                    if (ok && xout && u >= ya && u < yb) {
-                        const long i2 = (long)u * W2 + (x0 >> 1);
-                        stf4(Ro4 + i2, make_float4(rx[0], ry[0], rx[1], ry[1]), nt_out); stf2(Ra2 + i2, make_float2(rq[0], rq[1]), nt_out);
-                        stf4(qo4 + i2, make_float4(k1.px[0], k1.py[0], k1.px[1], k1.py[1]), nt_pout); stf2(qa2 + i2, make_float2(k1.pa[0], k1.pa[1]), nt_pout);
+                    if (xout && u >= ya && u < yb) {
+                        const unsigned row = (unsigned)u * (unsigned)W2;
+                        bst4<nt_out>(RS_RO, vo16, row * 16u, rx[0], ry[0], rx[1], ry[1]); bst2<nt_out>(RS_RO, vo8, angle0 + row * 8u, rq[0], rq[1]);
+                        bst4<nt_pout>(RS_Q, vo16, row * 16u, k1.px[0], k1.py[0], k1.px[1], k1.py[1]); bst2<nt_pout>(RS_Q, vo8, angle0 + row * 8u, k1.pa[0], k1.pa[1]);
                         if (DMODE != 1) {
-                            float4 d = cur.dlo; float2 da = cur.dla;
+                            float d[4] = { uf(cur.dlo.x), uf(cur.dlo.y), uf(cur.dlo.z), uf(cur.dlo.w) }, da[2] = { uf(cur.dla.x), uf(cur.dla.y) };
                             if (DMODE == 2) {
-                                d.x = __builtin_fmaf(alpha2, cur.ppo.x, d.x); d.y = __builtin_fmaf(alpha2, cur.ppo.y, d.y);
-                                d.z = __builtin_fmaf(alpha2, cur.ppo.z, d.z); d.w = __builtin_fmaf(alpha2, cur.ppo.w, d.w);
-                                da.x = __builtin_fmaf(alpha2, cur.ppa.x, da.x); da.y = __builtin_fmaf(alpha2, cur.ppa.y, da.y);
+                                d[0] = __builtin_fmaf(alpha2, uf(cur.ppo.x), d[0]); d[1] = __builtin_fmaf(alpha2, uf(cur.ppo.y), d[1]);
+                                d[2] = __builtin_fmaf(alpha2, uf(cur.ppo.z), d[2]); d[3] = __builtin_fmaf(alpha2, uf(cur.ppo.w), d[3]);
+                                da[0] = __builtin_fmaf(alpha2, uf(cur.ppa.x), da[0]); da[1] = __builtin_fmaf(alpha2, uf(cur.ppa.y), da[1]);
                             }
-                            d.x = __builtin_fmaf(alpha, p1.px[0], d.x); d.y = __builtin_fmaf(alpha, p1.py[0], d.y);
-                            d.z = __builtin_fmaf(alpha, p1.px[1], d.z); d.w = __builtin_fmaf(alpha, p1.py[1], d.w);
-                            da.x = __builtin_fmaf(alpha, p1.pa[0], da.x); da.y = __builtin_fmaf(alpha, p1.pa[1], da.y);
-                            stf4(dl4 + i2, d, nt_delta); stf2(dl2 + i2, da, nt_delta);
+                            d[0] = __builtin_fmaf(alpha, p1.px[0], d[0]); d[1] = __builtin_fmaf(alpha, p1.py[0], d[1]);
+                            d[2] = __builtin_fmaf(alpha, p1.px[1], d[2]); d[3] = __builtin_fmaf(alpha, p1.py[1], d[3]);
+                            da[0] = __builtin_fmaf(alpha, p1.pa[0], da[0]); da[1] = __builtin_fmaf(alpha, p1.pa[1], da[1]);
+                            bst4<nt_delta>(RS_D, vo16, row * 16u, d[0], d[1], d[2], d[3]); bst2<nt_delta>(RS_D, vo8, angle0 + row * 8u, da[0], da[1]);
                         }
                     }
                 }
-                // ---- row v = t-2: A p_k(v) and the iteration's sums
-                const int v = t - 2;
-                if (v >= ya && v < yb) {
+                // (phases in sequence: letting the scheduler interleave the two stencils and the two pixels' double sums for ILP costs ~60 registers -- the
+                //  difference between one and two waves per SIMD; at two waves per SIMD the other wave fills the issue slots)
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- row v = t-2: A p_k(v) and the iteration's sums (the wave's own rows and output lanes only: elsewhere the table's entry 0 -- M^-1 = 0 -- and a 0 multiplicand)
+                {
+                    const int v = t - 2;
+                    const bool on = xout && v >= ya && v < yb;
+                    const float4 m0 = lut[on ? g2.f & 31u : 0u], m1 = lut[on ? (g2.f >> 8) & 31u : 0u];
+                    const float wfit[2] = { m0.z, m1.z }, mo[2] = { m0.x, m1.x }, ma[2] = { m0.y, m1.y };
                     float ax[2], ay[2], av[2];
-                    jtjp_pair(k3, k2, k1, g3, g2, g1, wf2, wr2, ax, ay, av);
-                    if (xout) {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-                            iter_sums_pixel(k2.px[q], k2.py[q], k2.pa[q], ax[q], ay[q], av[q], r2.rx[q], r2.ry[q], r2.ra[q], r2.mo[q], r2.ma[q], acc, s0, s1, s2);
-                    }
+                    jtjp_pair(k3, k2, k1, g3, g2, g1, g3.a, g2.a, g1.a, wfit, wr2, ax, ay, av);
+                    const float msum = on ? 1.0f : 0.0f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    iter_sums_pixel_masked(msum, k2.px[0], k2.py[0], k2.pa[0], ax[0], ay[0], av[0], r2.rx[0], r2.ry[0], r2.ra[0], mo[0], ma[0], acc, s0, s1, s2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    iter_sums_pixel_masked(msum, k2.px[1], k2.py[1], k2.pa[1], ax[1], ay[1], av[1], r2.rx[1], r2.ry[1], r2.ra[1], mo[1], ma[1], acc, s0, s1, s2);
                 }
+                // a row's arithmetic stays inside its step: without the pin the double sums of all four rows of a trip sink behind the fourth row's take (their only
+                // consumers are the next sums), with the 14 values each of them reads kept alive until then -- 99 live registers at a trip's first take, 256 at its end
+                asm volatile("" : "+v"(acc), "+v"(s0), "+v"(s1), "+v"(s2));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -217,10 +284,17 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 
 }  // namespace
 
+// product configuration (tools/rc_probe.py, profiles/r04): two rows of prefetch, compiled for two workgroups of 4 waves per CU (<= 256 registers; the kernel needs
+// 160-200), the grid sized for one.  Depth 1 / 2 / 4 and one, two or three waves per SIMD all run within 2 % of each other: the launch moves its bytes at the
+// 5.4-5.7 TB/s this access pattern gets out of the memory system, plus ~7 us of launch ramp and tail.
+constexpr int MARCH_RC_DEPTH = 2, MARCH_RC_OCC = 2;
+#ifdef THALLO_MARCH_SWEEP
 namespace thallo {
-int g_march_rc_depth = 2;      // tools: rows of prefetch (1, 2, 4)
-int g_march_rc_occ = 2;        // tools: register budget -- workgroups of 4 waves per CU the kernel is compiled for (2: <= 256 registers, 1: <= 512; the grid is sized for one)
+int g_march_rc_depth = MARCH_RC_DEPTH;      // rows of prefetch (1, 2, 4)
+int g_march_rc_occ = MARCH_RC_OCC;          // register budget: workgroups of 4 waves per CU the kernel is compiled for (1: <= 512 registers, 2: <= 256, 3: <= 168)
+int g_march_rc_nt = MARCH_NTM;              // cache-policy mask (iw_march.hpp)
 }
+#endif
 
 namespace {
 int launch_march_rc(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
@@ -235,10 +309,18 @@ int launch_march_rc(int W, int H, const float* cs, const unsigned char* flags, f
     if (grid > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
     const int dmode = (mode >> 1) & 3;
     const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
-#define RC_LAUNCH(DM, DP, OCC) hipLaunchKernelGGL((k_iter_march_rc<DM, DP, MARCH_NTM, OCC>), dim3(grid), dim3(MARCH_NT), 0, stream, g, cs, flags, wf2, wr2, \
+#define RC_LAUNCH(DM, DP, OCC, NTM) hipLaunchKernelGGL((k_iter_march_rc<DM, DP, NTM, OCC>), dim3(grid), dim3(MARCH_NT), 0, stream, g, cs, flags, wf2, wr2, \
         r_in, r_out, p_in, p_out, delta, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, irregular, fin_tickets, aD_word, bN_word, prev)
-#define RC_BY_DEPTH(DM) do { if (g_march_rc_occ == 1) { if (g_march_rc_depth == 4) RC_LAUNCH(DM, 4, 1); else RC_LAUNCH(DM, 2, 1); } \
-                             else if (g_march_rc_depth == 1) RC_LAUNCH(DM, 1, 2); else RC_LAUNCH(DM, 2, 2); } while (0)
+#ifdef THALLO_MARCH_SWEEP      // tools/rc_probe.py: prefetch depth x register budget at the product's cache policy, and the cache-policy masks at the product's depth / budget
+#define RC_BY_DEPTH(DM) do { const int dp = g_march_rc_depth, oc = g_march_rc_occ, nt = g_march_rc_nt; \
+        if (nt != MARCH_NTM) { if (nt == 0) RC_LAUNCH(DM, 2, 2, 0); else if (nt == 1) RC_LAUNCH(DM, 2, 2, 1); else if (nt == 4) RC_LAUNCH(DM, 2, 2, 4); else if (nt == 7) RC_LAUNCH(DM, 2, 2, 7); \
+                                 else if (nt == 13) RC_LAUNCH(DM, 2, 2, 13); else if (nt == 21) RC_LAUNCH(DM, 2, 2, 21); else if (nt == 37) RC_LAUNCH(DM, 2, 2, 37); else if (nt == 63) RC_LAUNCH(DM, 2, 2, 63); else return -(int)hipErrorInvalidValue; } \
+        else if (oc == 1) { if (dp == 4) RC_LAUNCH(DM, 4, 1, MARCH_NTM); else RC_LAUNCH(DM, 2, 1, MARCH_NTM); } \
+        else if (oc == 3) { if (dp == 1) RC_LAUNCH(DM, 1, 3, MARCH_NTM); else RC_LAUNCH(DM, 2, 3, MARCH_NTM); } \
+        else { if (dp == 1) RC_LAUNCH(DM, 1, 2, MARCH_NTM); else if (dp == 4) RC_LAUNCH(DM, 4, 2, MARCH_NTM); else RC_LAUNCH(DM, 2, 2, MARCH_NTM); } } while (0)
+#else
+#define RC_BY_DEPTH(DM) RC_LAUNCH(DM, MARCH_RC_DEPTH, MARCH_RC_OCC, MARCH_NTM)
+#endif
     if (dmode == 1) RC_BY_DEPTH(1); else if (dmode == 2) RC_BY_DEPTH(2); else RC_BY_DEPTH(0);
 #undef RC_BY_DEPTH
 #undef RC_LAUNCH
@@ -257,6 +339,9 @@ int thallo_hip_iw_pcg_iter_march_rc(int W, int H, const float* cs, const unsigne
     if ((W & 1) || W < 2 || H < 1 || (mode & 1)) return -(int)hipErrorInvalidValue;          // (the first iteration of a GN step has no A p_{k-1}: the stored-plane kernel runs it)
     if (!cs || !flags || !r_in || !r_out || !p_in || !p_out || !delta || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
     if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
+    if (aNp.count < 1 || aDp.count < 1 || bNp.count < 1 || !aNp.partials || !aDp.partials || !bNp.partials) return -(int)hipErrorInvalidValue;
+    if (((mode >> 1) & 3) == 2 && (aNpp.count < 1 || aDpp.count < 1 || !aNpp.partials || !aDpp.partials)) return -(int)hipErrorInvalidValue;
+    if (12.0 * (double)W * (double)H >= 4294967296.0) return -(int)hipErrorNotSupported;       // a vector must fit one buffer descriptor
     return launch_march_rc(W, H, cs, flags, w_fit, w_reg, r_in, r_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, irregular,
                            aD_out, s12_out, fin_tickets, aD_word, bN_word, (hipStream_t)stream, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
 }
@@ -270,12 +355,24 @@ int thallo_hip_iw_pcg_iter_march_rc_deferred(int W, int H, const float* cs, cons
     if (!cs || !flags || !r_in || !r_out || !p_in || !p_out || !delta || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
     if (prev.count < 1 || prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_partials || !prev.s12_partials || !prev.alphaD_word || !prev.betaN_word ||
         prev.s12_partials == s12_out) return -(int)hipErrorInvalidValue;
+    if (aNp.count < 1 || !aNp.partials) return -(int)hipErrorInvalidValue;
+    if (((mode >> 1) & 3) == 2 && (aNpp.count < 1 || aDpp.count < 1 || !aNpp.partials || !aDpp.partials)) return -(int)hipErrorInvalidValue;
+    if (12.0 * (double)W * (double)H >= 4294967296.0) return -(int)hipErrorNotSupported;       // a vector must fit one buffer descriptor
     const thallo_sum_t none = { nullptr, 0 };
     return launch_march_rc(W, H, cs, flags, w_fit, w_reg, r_in, r_out, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp, irregular,
                            aD_out, s12_out, nullptr, nullptr, nullptr, (hipStream_t)stream,
                            PrevSums{ prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word });
 }
 
-void thallo_hip_march_rc_debug_set(int what, int value) { if (what == 0) g_march_rc_depth = value; if (what == 1) g_march_rc_occ = value; }
+void thallo_hip_march_rc_debug_set(int what, int value)
+{
+#ifdef THALLO_MARCH_SWEEP
+    if (what == 0) g_march_rc_depth = value;
+    if (what == 1) g_march_rc_occ = value;
+    if (what == 2) g_march_rc_nt = value;
+#else
+    (void)what; (void)value;
+#endif
+}
 
 }  // extern "C"

@@ -13,17 +13,9 @@ constexpr int MARCH_USE = 124;            // output pixels per wave row (lanes 1
 constexpr int MARCH_NT = 256;             // threads per workgroup: 4 waves = 4 vertically adjacent segments of one strip
 constexpr int MARCH_WG_PER_CU = 1;        // grid sizing: ~1 workgroup (4 waves) per CU measured best at 2048^2 (36 rows per wave; 18: +5 %, 48: +12 %)
 
-// value of the lane to the left (lane-1) / right (lane+1); lanes without a source keep `self` (never used: lanes 0 / 63 produce no output)
-__device__ __forceinline__ float from_left(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));   // wave_shr:1
-}
-__device__ __forceinline__ float from_right(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));   // wave_shl:1
-}
-__device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
+// value of the lane to the left (lane-1) / right (lane+1); lanes without a source (0 / 63) read 0.  mov_dpp has no tied "old" operand: one v_mov_b32_dpp per exchange
+__device__ __forceinline__ float from_left(float v)  { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true)); }   // wave_shr:1
+__device__ __forceinline__ float from_right(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true)); }   // wave_shl:1
 
 // Move a prefetch slot into fresh registers with REAL v_mov instructions (early-clobber outputs: never the slot's own registers).
 // All arithmetic then works on the copy, the slot's registers die here and its refill -- issued right behind -- loads into the SAME
@@ -39,54 +31,59 @@ __device__ __forceinline__ void take2(float2& d, const float2& s) { take1(d.x, s
 
 // one neighbour's contribution to (J^T J p)_i on the unit grid; D = 0: x+1, 1: x-1, 2: y+1, 3: y-1.  k_iter's expressions with
 // u_i - u_j = -(dx,dy) folded in by hand (the compiler may not drop the products with 0.0f): with g_i = R'(a_i)(u_i-u_j),
-// g_j = R'(a_j)(u_j-u_i):  D=0: g_i = (s_i,-c_i), g_j = (-s_j,c_j);  D=1: negated;  D=2: g_i = (c_i,s_i), g_j = (-c_j,-s_j);  D=3: negated
+// g_j = R'(a_j)(u_j-u_i):  D=0: g_i = (s_i,-c_i), g_j = (-s_j,c_j);  D=1: negated;  D=2: g_i = (c_i,s_i), g_j = (-c_j,-s_j);  D=3: negated.
+// BRANCH-FREE: m = 1.0f for a valid neighbour pair, 0.0f otherwise, enters as the multiplicand of the accumulating fma -- fma(1, t, a) rounds like a + t, so
+// the sums carry the bits of k_iter's `if (valid) a += t` (round 4: the predicated form cost an exec-mask branch per term, 16 per row, in an issue-bound loop).
 template <int D>
-__device__ __forceinline__ void nb_term(bool valid, float ci, float si, float pxi, float pyi, float pai,
+__device__ __forceinline__ void nb_term(float m, float ci, float si, float pxi, float pyi, float pai,
                                         float pxj, float pyj, float paj, float cj, float sj, float& ax, float& ay, float& av)
 {
-    if (valid) {
-        const float gix = D == 0 ? si : D == 1 ? -si : D == 2 ? ci : -ci;
-        const float giy = D == 0 ? -ci : D == 1 ? ci : D == 2 ? si : -si;
-        const float gjx = D == 0 ? -sj : D == 1 ? sj : D == 2 ? -cj : cj;
-        const float gjy = D == 0 ? cj : D == 1 ? -cj : D == 2 ? -sj : sj;
-        const float dpx = pxi - pxj, dpy = pyi - pyj;
-        const float ex = dpx - gix * pai, ey = dpy - giy * pai;
-        ax += dpx + ex + gjx * paj;
-        ay += dpy + ey + gjy * paj;
-        av -= gix * ex + giy * ey;
-    }
+    const float gix = D == 0 ? si : D == 1 ? -si : D == 2 ? ci : -ci;
+    const float giy = D == 0 ? -ci : D == 1 ? ci : D == 2 ? si : -si;
+    const float gjx = D == 0 ? -sj : D == 1 ? sj : D == 2 ? -cj : cj;
+    const float gjy = D == 0 ? cj : D == 1 ? -cj : D == 2 ? -sj : sj;
+    const float dpx = pxi - pxj, dpy = pyi - pyj;
+    const float ex = dpx - gix * pai, ey = dpy - giy * pai;
+    const float tx = dpx + ex + gjx * paj;
+    const float ty = dpy + ey + gjy * paj;
+    const float ta = gix * ex + giy * ey;
+    ax = __builtin_fmaf(m, tx, ax); ay = __builtin_fmaf(m, ty, ay); av = __builtin_fmaf(-m, ta, av);
 }
 
-// (J^T J p) at the lane's two pixels of a centre row.  P rows carry p as px[2], py[2], pa[2]; G rows the geometry: c[2], s[2] (cos / sin of Angle) and
-// f (the pair's two flags bytes: bits 0-7 pixel 0, 8-15 pixel 1).  m / c / n = rows y-1 / y / y+1; the x neighbours across the lane boundary (the left
-// lane's pixel 1, the right lane's pixel 0) come through DPP wave shifts.  Every lane may call it (lanes 0 / 63 get garbage for their outer pixel).
+// (J^T J p) at the lane's two pixels of a centre row.  P rows carry p as px[2], py[2], pa[2]; G rows the geometry: c[2], s[2] (cos / sin of Angle).  am / ac / an:
+// the pixels' ACTIVE bits (flags bit 0) of rows y-1 / y / y+1 as floats 0 / 1; wfit[q] = w_fit^2 where the pixel's fit residual is valid (flags bit 1), else 0.
+// The x neighbours across the lane boundary (the left lane's pixel 1, the right lane's pixel 0) come through DPP wave shifts.  Every lane calls it (lanes 0 / 63
+// get garbage for their outer pixel); an inactive centre gives exactly 0 (its scale is w_reg^2 * 0, and a fit-valid pixel is active: k_init).
 template <class P, class G>
-__device__ __forceinline__ void jtjp_pair(const P& pm, const P& pc, const P& pn, const G& gm, const G& gc, const G& gn, float wf2, float wr2,
+__device__ __forceinline__ void jtjp_pair(const P& pm, const P& pc, const P& pn, const G& gm, const G& gc, const G& gn,
+                                          const float (&am)[2], const float (&ac)[2], const float (&an)[2], const float (&wfit)[2], float wr2,
                                           float (&ax)[2], float (&ay)[2], float (&av)[2])
 {
-    const float Lpx = from_left(pc.px[1]), Lpy = from_left(pc.py[1]), Lpa = from_left(pc.pa[1]), Lc = from_left(gc.c[1]), Ls = from_left(gc.s[1]);
-    const float Rpx = from_right(pc.px[0]), Rpy = from_right(pc.py[0]), Rpa = from_right(pc.pa[0]), Rc = from_right(gc.c[0]), Rs = from_right(gc.s[0]);
-    const unsigned Lf = from_left(gc.f) >> 8, Rf = from_right(gc.f);
+    const float Lpx = from_left(pc.px[1]), Lpy = from_left(pc.py[1]), Lpa = from_left(pc.pa[1]), Lc = from_left(gc.c[1]), Ls = from_left(gc.s[1]), La = from_left(ac[1]);
+    const float Rpx = from_right(pc.px[0]), Rpy = from_right(pc.py[0]), Rpa = from_right(pc.pa[0]), Rc = from_right(gc.c[0]), Rs = from_right(gc.s[0]), Ra = from_right(ac[0]);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         ax[q] = 0.f; ay[q] = 0.f; av[q] = 0.f;
-        const unsigned fq = (gc.f >> (8 * q)) & 255u;
-        const float pxi = pc.px[q], pyi = pc.py[q], pai = pc.pa[q];
-        if (fq & 1u) {
-            const float ci = gc.c[q], si = gc.s[q];
-            if (q == 0) {
-                nb_term<0>((gc.f >> 8) & 1u, ci, si, pxi, pyi, pai, pc.px[1], pc.py[1], pc.pa[1], gc.c[1], gc.s[1], ax[q], ay[q], av[q]);
-                nb_term<1>(Lf & 1u, ci, si, pxi, pyi, pai, Lpx, Lpy, Lpa, Lc, Ls, ax[q], ay[q], av[q]);
-            } else {
-                nb_term<0>(Rf & 1u, ci, si, pxi, pyi, pai, Rpx, Rpy, Rpa, Rc, Rs, ax[q], ay[q], av[q]);
-                nb_term<1>(gc.f & 1u, ci, si, pxi, pyi, pai, pc.px[0], pc.py[0], pc.pa[0], gc.c[0], gc.s[0], ax[q], ay[q], av[q]);
-            }
-            nb_term<2>((gn.f >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, pn.px[q], pn.py[q], pn.pa[q], gn.c[q], gn.s[q], ax[q], ay[q], av[q]);
-            nb_term<3>((gm.f >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, pm.px[q], pm.py[q], pm.pa[q], gm.c[q], gm.s[q], ax[q], ay[q], av[q]);
-            ax[q] *= wr2; ay[q] *= wr2; av[q] *= wr2;
-            if (fq & 2u) { ax[q] += wf2 * pxi; ay[q] += wf2 * pyi; }
+        const float pxi = pc.px[q], pyi = pc.py[q], pai = pc.pa[q], ci = gc.c[q], si = gc.s[q];
+        if (q == 0) {
+            nb_term<0>(ac[1], ci, si, pxi, pyi, pai, pc.px[1], pc.py[1], pc.pa[1], gc.c[1], gc.s[1], ax[q], ay[q], av[q]);
+            nb_term<1>(La, ci, si, pxi, pyi, pai, Lpx, Lpy, Lpa, Lc, Ls, ax[q], ay[q], av[q]);
+        } else {
+            nb_term<0>(Ra, ci, si, pxi, pyi, pai, Rpx, Rpy, Rpa, Rc, Rs, ax[q], ay[q], av[q]);
+            nb_term<1>(ac[0], ci, si, pxi, pyi, pai, pc.px[0], pc.py[0], pc.pa[0], gc.c[0], gc.s[0], ax[q], ay[q], av[q]);
         }
+        nb_term<2>(an[q], ci, si, pxi, pyi, pai, pn.px[q], pn.py[q], pn.pa[q], gn.c[q], gn.s[q], ax[q], ay[q], av[q]);
+        nb_term<3>(am[q], ci, si, pxi, pyi, pai, pm.px[q], pm.py[q], pm.pa[q], gm.c[q], gm.s[q], ax[q], ay[q], av[q]);
+        const float w = wr2 * ac[q];
+        ax[q] *= w; ay[q] *= w; av[q] *= w;
+        ax[q] = __builtin_fmaf(wfit[q], pxi, ax[q]); ay[q] = __builtin_fmaf(wfit[q], pyi, ay[q]);
     }
+}
+// the masks of one row's flags pair (bits 0-7 pixel 0, 8-15 pixel 1)
+__device__ __forceinline__ void flag_masks(unsigned f, float wf2, float (&a)[2], float (&wfit)[2])
+{
+    a[0] = (float)(f & 1u); a[1] = (float)((f >> 8) & 1u);
+    wfit[0] = (f & 2u) ? wf2 : 0.f; wfit[1] = (f & 0x200u) ? wf2 : 0.f;
 }
 
 // the iteration's sums over one pixel: float alphaD term; N = sum r.M^-1.r, S1 = sum r.M^-1.Ap, S2 = sum Ap.M^-1.Ap as exact products of the float
@@ -95,6 +92,19 @@ __device__ __forceinline__ void iter_sums_pixel(float pxi, float pyi, float pai,
                                                 float& acc, double& s0, double& s1, double& s2)
 {
     acc += pxi * ax + pyi * ay + pai * av;
+    const double dmo = mo, dma = ma, drx = rx, dry = ry, dra = ra, dax = ax, day = ay, daa = av;
+    s0 = __builtin_fma(dmo, __builtin_fma(dry, dry, drx * drx), __builtin_fma(dma, dra * dra, s0));
+    s1 = __builtin_fma(dmo, __builtin_fma(dry, day, drx * dax), __builtin_fma(dma, dra * daa, s1));
+    s2 = __builtin_fma(dmo, __builtin_fma(day, day, dax * dax), __builtin_fma(dma, daa * daa, s2));
+}
+
+// ... the same with a 0 / 1 multiplicand instead of a branch (msum = 1: fma(1, t, acc) rounds like acc + t; the caller passes M^-1 = 0 where msum = 0, so the
+// double sums add exact zeros there)
+__device__ __forceinline__ void iter_sums_pixel_masked(float msum, float pxi, float pyi, float pai, float ax, float ay, float av, float rx, float ry, float ra, float mo, float ma,
+                                                       float& acc, double& s0, double& s1, double& s2)
+{
+    const float t = pxi * ax + pyi * ay + pai * av;
+    acc = __builtin_fmaf(msum, t, acc);
     const double dmo = mo, dma = ma, drx = rx, dry = ry, dra = ra, dax = ax, day = ay, daa = av;
     s0 = __builtin_fma(dmo, __builtin_fma(dry, dry, drx * drx), __builtin_fma(dma, dra * dra, s0));
     s1 = __builtin_fma(dmo, __builtin_fma(dry, day, drx * dax), __builtin_fma(dma, dra * daa, s1));

@@ -39,14 +39,8 @@ FUSED_BYTES_PCG_ITER_STORED = 99
 
 
 def fused_bytes_per_iter(L):
-    if os.environ.get("THALLO_MARCH", "1")[:1] in ("0", "3", "4"):
-        return float(FUSED_BYTES_PCG_ITER_STORED)
-    odd = L // 2                      # k = 1, 3, ...: no delta update
-    even = (L - 1) // 2               # k = 2, 4, ...: two delta updates
-    return (69.0 + 57.0 * odd + 93.0 * even) / L if L >= 1 else 0.0
-
-
-FUSED_BYTES_STEP1 = 75          # two-kernel A/B schedule: fused PCGStep3 + delta + applyJTJ
+    from thallo_amd.api import iw_fused_bytes_per_iter
+    return iw_fused_bytes_per_iter(L)
 
 
 def parse():

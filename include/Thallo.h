@@ -39,8 +39,12 @@ struct Thallo_InitializationParameters {
     int verbosityLevel;    /* 0 quiet, >=1 prints solver log + timing table at the end of a solve */
     int timingLevel;       /* 0/1 coarse events, 2 per-kernel hipEvents, 3 additionally device-syncs around them */
     int threadsPerBlock;   /* accepted for compatibility; kernels carry their own tuned shapes */
-    int useAutoscheduler;  /* accepted for compatibility; the schedule is fixed per bundled energy */
-    int cpuOnly;           /* must be 0 in this build */
+    int useAutoscheduler;  /* bundled energies: their hand-written plugin (a fixed schedule) either way.  Generated plugins (a .t file no plugin recognises, or
+                              THALLO_FRONTEND=generate): 1 = the autoscheduler's lowering where it applies -- residuals that live on their unknowns' grid become
+                              unknown-wise gather kernels, one merged kernel per (domain, schedule) group, no atomics (API/src/thallo.t:5173-5190,5273-5306);
+                              0 = the reference's default residual-wise scatter (thallo.t:4096-4098).  Every example passes 1 (examples/.../main.cpp:37). */
+    int cpuOnly;           /* must be 0: Thallo_NewState returns NULL for 1.  The product has no CPU path by design (the reference's needs Terra, API/src/cpu_cuda.t);
+                              the CPU restatement under oracle/ is test infrastructure and is never linked or loaded by this library. */
 };
 typedef struct Thallo_InitializationParameters Thallo_InitializationParameters;
 
@@ -201,6 +205,7 @@ int ThalloX_PlanSetDistributed(Thallo_Plan* plan, const ThalloX_Distributed* cfg
  * (collective: ncclCommInitRank, the rank's GPU current).  A NULL allgather / allreduce in ThalloX_Distributed then means ncclAllGather / ncclAllReduce on the
  * plan's stream.  RCCL is bound at run time (dlopen: the copy already in the process if there is one); -1 + ThalloX_LastError when it is not there.
  * ThalloX_RcclSelfTest: a one-rank communicator moves a small buffer through both collectives (0 = fine). */
+int ThalloX_RcclAvailable(void);      /* 1: librccl can be bound in this process (rank-local; all-reduce it before the collective ThalloX_PlanUseRccl) */
 int ThalloX_RcclUniqueId(unsigned char* id_out128);
 int ThalloX_PlanUseRccl(Thallo_Plan* plan, const unsigned char* id128, int rank, int world);
 int ThalloX_RcclSelfTest(void);

@@ -334,21 +334,29 @@ int thallo_hip_iw_pcg_iter_march_deferred(int W, int H, int row0, int row1, cons
                                           const float* p_in, float* p_out, float* delta, int mode,
                                           thallo_sum_t alphaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2, thallo_prev_t prev,
                                           const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
-/* The marching iteration WITHOUT an A p plane (round 4; energy_image_warping_march_rc.hip): iteration k >= 1 of a whole image on the unit pixel grid.
+/* The marching iteration WITHOUT an A p plane (round 4; energy_image_warping_march_rc.hip): iteration k >= 1 on the unit pixel grid.
  * r_out = r_in - alpha_{k-1} (J^T J p_in) with J^T J p_{k-1} RECOMPUTED from the rows of p_in the launch loads anyway, p_out = M^-1 r_out + beta_{k-1} p_in,
  * the delta update of `mode` (never mode & 1: a GN step's first iteration has no A p_{k-1}; thallo_hip_iw_pcg_iter_march runs it), and the partials of
  * alphaD_k / N, S1, S2 from J^T J p_out -- which is not stored.  57 B/pixel instead of 81 (+ 18 of deferred delta); r, p, delta and every alpha / beta are
- * bit-identical to thallo_hip_iw_pcg_iter_march with the same rows per segment.  Scalars / partials / tickets as there.  Replaces PCGStep1 + PCGStep2 +
- * PCGStep3 (gauss_newton.t:734-752,801-843,889-899). */
-int thallo_hip_iw_pcg_iter_march_rc(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                                    const float* r_in, float* r_out, const float* p_in, float* p_out, float* delta, int mode,
+ * bit-identical to thallo_hip_iw_pcg_iter_march with the same rows per segment.  Scalars / partials / tickets as there.
+ * Whole images (row0 = 0, row1 = H): Ap_in / Ap_out are not touched (NULL is fine).  A row slab of a multi-GPU run (one ghost row towards each neighbour): the
+ * exchange stays the stored-plane kernel's -- rows row0 and row1 - 1 of J^T J p_out are written to Ap_out (the _dist form: into the neighbours' ghost rows,
+ * peer-to-peer, and its last workgroup is the scalar exchange), and on a ghost row J^T J p_in is READ from Ap_in, where the exchange put it -- so the two kernels
+ * are interchangeable launch by launch.  Replaces PCGStep1 + PCGStep2 + PCGStep3 (gauss_newton.t:734-752,801-843,889-899). */
+int thallo_hip_iw_pcg_iter_march_rc(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                    const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
                                     thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
                                     const int* irregular, float* alphaD_out, double* s12_out,
                                     unsigned* fin_tickets, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
-int thallo_hip_iw_pcg_iter_march_rc_deferred(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                                             const float* r_in, float* r_out, const float* p_in, float* p_out, float* delta, int mode,
+int thallo_hip_iw_pcg_iter_march_rc_deferred(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
                                              thallo_sum_t alphaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2, thallo_prev_t prev,
                                              const int* irregular, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+int thallo_hip_iw_pcg_iter_march_rc_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                         const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
+                                         thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
+                                         const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out,
+                                         unsigned* fin_tickets, int slot0, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 void thallo_hip_march_rc_debug_set(int what, int value);  /* sweep builds (tools/rc_probe.py) only: 0 rows of prefetch (1, 2, 4), 1 register budget (workgroups per CU: 1, 2, 3), 2 cache-policy mask */
 /* *count_out (device int) = number of pixels whose right / down UrShape neighbour is not at the exact unit offset (0 = pixel grid) */
 int thallo_hip_iw_urshape_irregular(int W, int H, const float* urshape, int* count_out, thallo_stream_t stream);

@@ -277,3 +277,32 @@ def test_arap_ghost_partition_schedule_matches_single_domain_oracle(orc, world, 
     assert np.abs(pos - p[2]).max() <= 2e-4 * np.abs(p[2]).max()
     for rank, costs, lg, no, pl, al in res:
         assert np.array_equal(pl[no:], pos[lg[no:]]), rank                           # ghosts == owners, bit for bit
+
+
+def test_image_warping_slab_split_lets_every_rank_run_the_resident_loop(monkeypatch):
+    """the resident slab loop is a per-rank property -- a rank with a rank below needs rows %% R == 0 -- and the decision to use it is unanimous.
+    The default split of the headline configuration (2048 rows over 8 ranks: 256 each, R = 5) would leave ranks 0..6 saying no; image_warping_slab_counts() picks
+    7 x 255 + 263, for which thallo_hip_iw_resident_rows_slab answers R = 5 on EVERY rank.  Host-only geometry (no GPU: the library assumes 256 CUs)."""
+    import ctypes as C
+    import thallo_amd
+    from thallo_amd.distributed import SlabLayout, image_warping_slab_counts
+    L = thallo_amd.lib()
+    L.thallo_hip_iw_resident_rows_slab.restype = C.c_int
+    L.thallo_hip_iw_resident_rows_slab.argtypes = [C.c_int, C.c_int, C.c_int]
+    W = H = 2048
+    default = [SlabLayout(H, r, 8) for r in range(8)]
+    answers = [L.thallo_hip_iw_resident_rows_slab(W, lay.row1 - lay.row0, 1 if r < 7 else 0) for r, lay in enumerate(default)]
+    assert answers[:7] == [0] * 7 and answers[7] == 5          # the situation the advisor described: only the last rank would say yes
+    counts = image_warping_slab_counts(W, H, 8)
+    assert counts == [255] * 7 + [263]
+    lays = [SlabLayout(H, r, 8, counts=counts) for r in range(8)]
+    assert [l.g0 for l in lays] == [255 * r for r in range(8)] and lays[-1].g1 == H
+    assert [L.thallo_hip_iw_resident_rows_slab(W, l.row1 - l.row0, 1 if r < 7 else 0) for r, l in enumerate(lays)] == [5] * 8
+    # 2 and 4 ranks: the slabs do not fit the registers at all -> the default split, one marching launch per iteration
+    assert image_warping_slab_counts(W, H, 2) is None and image_warping_slab_counts(W, H, 4) is None
+    # a small image over 3 ranks: the tile kernel's territory -> the default split, unless the marching kernels are forced
+    assert image_warping_slab_counts(252, 90, 3) is None
+    monkeypatch.setenv("THALLO_MARCH", "2")
+    c3 = image_warping_slab_counts(252, 90, 3)
+    assert c3 is not None and sum(c3) == 90
+    assert all(L.thallo_hip_iw_resident_rows_slab(252, c, 1 if r < 2 else 0) > 0 for r, c in enumerate(c3))

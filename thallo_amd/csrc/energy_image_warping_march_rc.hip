@@ -95,13 +95,21 @@ struct GRow { float c[2], s[2], a[2]; unsigned f; };             // cos / sin of
 struct RRow { float rx[2], ry[2], ra[2]; };                      // r_k
 
 // DMODE: the delta update this launch carries (THALLO_IW_STEP1_MODE): 0 delta += alpha p_{k-1}; 1 none; 2 delta += alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}
-template <int DMODE, int DEPTH, int NTM, int OCC>
+// SLAB: 0 a whole image; 1 / 2 one rank's row slab of a multi-GPU run (local image = owned rows [row0, row1) + one ghost row towards each neighbour).  The exchange is
+// the stored-plane kernel's -- per iteration the first / last owned row of A p_k and the iteration's sums -- so the two kernels are interchangeable per launch:
+//   * the rows of A p_k the neighbours need exist anyway (the second stencil forms A p_k on every owned row for the sums): rows row0 and row1 - 1 go into A_out
+//     (1: this rank's plane, from where thallo_hip_slab_pack_iter takes them; 2: straight into the neighbours' ghost rows, peer-to-peer, and the launch's last
+//     workgroup is the scalar exchange);
+//   * on a GHOST row A p_{k-1} cannot be recomputed (it needs p_{k-1} two rows into the neighbour): it is read from A_in, where the exchange put it, and r_k, p_k of
+//     the ghost row follow locally -- same inputs, same bits as the owner's -- and are stored (the ghost rows of r, p stay current, as in the stored-plane kernel).
+template <int DMODE, int DEPTH, int NTM, int OCC, int SLAB>
 __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, const float* __restrict__ cs, const unsigned char* __restrict__ flags, float wf2, float wr2,
-                                                            const float* __restrict__ r_in, float* __restrict__ r_out,
+                                                            const float* __restrict__ r_in, float* __restrict__ r_out, const float* __restrict__ A_in, float* __restrict__ A_out,
                                                             const float* __restrict__ p_in, float* __restrict__ p_out, float* __restrict__ delta,
                                                             thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                                             float* __restrict__ aD_out, double* __restrict__ s12_out, const int* __restrict__ irregular,
-                                                            unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, PrevSums prev)
+                                                            thallo_dist_t dd, unsigned* __restrict__ fin_tickets, float* __restrict__ aD_word, float* __restrict__ bN_word, int xslot,
+                                                            PrevSums prev)
 {
     static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "the prefetch slots rotate inside a trip of four rows");
     __shared__ float4 lut[32];              // by the 5-bit flags value: M^-1 of the Offset channels, of the Angle channel, w_fit^2 where the fit residual is valid
@@ -130,6 +138,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 
     const rsrc_t RS_P = make_rsrc(p_in), RS_R = make_rsrc(r_in), RS_CS = make_rsrc(cs), RS_F = make_rsrc(flags);
     const rsrc_t RS_Q = make_rsrc(p_out), RS_RO = make_rsrc(r_out), RS_D = make_rsrc(delta);
+    const rsrc_t RS_AI = make_rsrc(SLAB ? (const void*)A_in : (const void*)r_in), RS_AO = make_rsrc(SLAB ? (void*)A_out : (void*)r_out);      // (slabs only: the exchanged rows of A p)
     // Loads are UNCONDITIONAL (rows clamped into the image / the segment, columns into the row; validity applied when the row enters the rings): a load under a
     // branch is merged with the slot's old value right behind the branch, i.e. waited for at once (energy_image_warping_march.hip)
     const int xc = x0 < 0 ? 0 : x0 > g.W - 2 ? g.W - 2 : x0;
@@ -227,6 +236,14 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                     const float wfit[2] = { m0.z, m1.z };
                     float ax[2], ay[2], av[2];
                     jtjp_pair(p2, p1, p0, g2, g1, g0, g2.a, g1.a, g0.a, wfit, wr2, ax, ay, av);
+                    // a ghost row of the slab: the row above the strip's first segment / below its last one (wave-uniform).  Only THAT wave keeps it current: the
+                    // rounding-up steps of other segments pass by the same row index with clamped re-reads in their slots
+                    const bool ghost_row = SLAB && ((u == ya - 1 && ya == g.row0 && u >= 0) || (u == yb && yb == g.row1 && u < g.H));
+                    if (ghost_row) {            // A p_{k-1} of a ghost row: what the exchange delivered (a blocking load, twice per boundary wave and launch)
+                        const unsigned row = (unsigned)u * (unsigned)W2;
+                        const u32x4 ao = bld4<false>(RS_AI, vo16, row * 16u); const u32x2 aa = bld2<false>(RS_AI, vo8, angle0 + row * 8u);
+                        ax[0] = uf(ao.x); ay[0] = uf(ao.y); ax[1] = uf(ao.z); ay[1] = uf(ao.w); av[0] = uf(aa.x); av[1] = uf(aa.y);
+                    }
                     float rx[2] = { uf(cur.ro.x), uf(cur.ro.z) }, ry[2] = { uf(cur.ro.y), uf(cur.ro.w) }, rq[2] = { uf(cur.ra.x), uf(cur.ra.y) };
                     rx[0] = __builtin_fmaf(-alpha, ax[0], rx[0]); ry[0] = __builtin_fmaf(-alpha, ay[0], ry[0]);
                     rx[1] = __builtin_fmaf(-alpha, ax[1], rx[1]); ry[1] = __builtin_fmaf(-alpha, ay[1], ry[1]);
@@ -237,11 +254,12 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                         k1.px[q] = mo[q] * rx[q] + beta * p1.px[q]; k1.py[q] = mo[q] * ry[q] + beta * p1.py[q]; k1.pa[q] = ma[q] * rq[q] + beta * p1.pa[q];
                         r1.rx[q] = rx[q]; r1.ry[q] = ry[q]; r1.ra[q] = rq[q];
                     }
-                    if (xout && u >= ya && u < yb) {
+                    const bool mine = u >= ya && u < yb;
+                    if (xout && (mine || ghost_row)) {      // this wave's own rows, or a ghost row of the slab (kept current here)
                         const unsigned row = (unsigned)u * (unsigned)W2;
                         bst4<nt_out>(RS_RO, vo16, row * 16u, rx[0], ry[0], rx[1], ry[1]); bst2<nt_out>(RS_RO, vo8, angle0 + row * 8u, rq[0], rq[1]);
                         bst4<nt_pout>(RS_Q, vo16, row * 16u, k1.px[0], k1.py[0], k1.px[1], k1.py[1]); bst2<nt_pout>(RS_Q, vo8, angle0 + row * 8u, k1.pa[0], k1.pa[1]);
-                        if (DMODE != 1) {
+                        if (DMODE != 1 && mine) {
                             float d[4] = { uf(cur.dlo.x), uf(cur.dlo.y), uf(cur.dlo.z), uf(cur.dlo.w) }, da[2] = { uf(cur.dla.x), uf(cur.dla.y) };
                             if (DMODE == 2) {
                                 d[0] = __builtin_fmaf(alpha2, uf(cur.ppo.x), d[0]); d[1] = __builtin_fmaf(alpha2, uf(cur.ppo.y), d[1]);
@@ -266,6 +284,22 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                     const float wfit[2] = { m0.z, m1.z }, mo[2] = { m0.x, m1.x }, ma[2] = { m0.y, m1.y };
                     float ax[2], ay[2], av[2];
                     jtjp_pair(k3, k2, k1, g3, g2, g1, g3.a, g2.a, g1.a, wfit, wr2, ax, ay, av);
+                    if (SLAB && xout && v >= ya && v < yb && (v == g.row0 || v == g.row1 - 1)) {      // the rows of A p_k the neighbouring ranks' ghost rows need
+                        if (SLAB == 1) {
+                            const unsigned row = (unsigned)v * (unsigned)W2;
+                            bst4<false>(RS_AO, vo16, row * 16u, ax[0], ay[0], ax[1], ay[1]); bst2<false>(RS_AO, vo8, angle0 + row * 8u, av[0], av[1]);
+                        } else {            // peer-to-peer, write-through; drained by every wave before the arrival ticket (iter_tail)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                if (v == (k == 0 ? g.row0 : g.row1 - 1) && dd.peer_r[k]) {
+                                    float* d2 = dd.peer_r[k] + dd.peer_off_o[k] + 2 * x0;
+                                    st_sys(d2, ax[0]); st_sys(d2 + 1, ay[0]); st_sys(d2 + 2, ax[1]); st_sys(d2 + 3, ay[1]);
+                                    float* d1 = dd.peer_r[k] + dd.peer_off_a[k] + x0;
+                                    st_sys(d1, av[0]); st_sys(d1 + 1, av[1]);
+                                }
+                            }
+                        }
+                    }
                     const float msum = on ? 1.0f : 0.0f;
                     __builtin_amdgcn_sched_barrier(0);
                     iter_sums_pixel_masked(msum, k2.px[0], k2.py[0], k2.pa[0], ax[0], ay[0], av[0], r2.rx[0], r2.ry[0], r2.ra[0], mo[0], ma[0], acc, s0, s1, s2);
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
             }
         }
     }
-    iter_tail<MARCH_NT, false>(acc, s0, s1, s2, red, redd, aD_out, s12_out, bNp, nullptr, fin_tickets, aD_word, bN_word, 0);
+    iter_tail<MARCH_NT, SLAB == 2>(acc, s0, s1, s2, red, redd, aD_out, s12_out, bNp, &dd, fin_tickets, aD_word, bN_word, xslot);
 }
 
 }  // namespace
@@ -297,27 +331,28 @@ int g_march_rc_nt = MARCH_NTM;              // cache-policy mask (iw_march.hpp)
 #endif
 
 namespace {
-int launch_march_rc(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                    const float* r_in, float* r_out, const float* p_in, float* p_out, float* delta, int mode,
-                    thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp, const int* irregular,
-                    float* aD_out, double* s12_out, unsigned* fin_tickets, float* aD_word, float* bN_word, hipStream_t stream, PrevSums prev)
+template <int SLAB>
+int launch_march_rc(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                    const float* r_in, float* r_out, const float* A_in, float* A_out, const float* p_in, float* p_out, float* delta, int mode,
+                    thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp, const int* irregular, thallo_dist_t d,
+                    float* aD_out, double* s12_out, unsigned* fin_tickets, float* aD_word, float* bN_word, int xslot, hipStream_t stream, PrevSums prev)
 {
-    const int R = march_pick_rows(W, H);
+    const int R = march_pick_rows(W, row1 - row0);
     if (R <= 0) return -(int)hipErrorNotSupported;
-    const MarchGeo g = make_march_geo(W, H, 0, H, R);
+    const MarchGeo g = make_march_geo(W, H, row0, row1, R);
     const int grid = (g.total + 7) / 8 * 8;
     if (grid > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
     const int dmode = (mode >> 1) & 3;
     const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
-#define RC_LAUNCH(DM, DP, OCC, NTM) hipLaunchKernelGGL((k_iter_march_rc<DM, DP, NTM, OCC>), dim3(grid), dim3(MARCH_NT), 0, stream, g, cs, flags, wf2, wr2, \
-        r_in, r_out, p_in, p_out, delta, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, irregular, fin_tickets, aD_word, bN_word, prev)
+#define RC_LAUNCH(DM, DP, OCC, NTM) hipLaunchKernelGGL((k_iter_march_rc<DM, DP, NTM, OCC, SLAB>), dim3(grid), dim3(MARCH_NT), 0, stream, g, cs, flags, wf2, wr2, \
+        r_in, r_out, A_in, A_out, p_in, p_out, delta, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, irregular, d, fin_tickets, aD_word, bN_word, xslot, prev)
 #ifdef THALLO_MARCH_SWEEP      // tools/rc_probe.py: prefetch depth x register budget at the product's cache policy, and the cache-policy masks at the product's depth / budget
-#define RC_BY_DEPTH(DM) do { const int dp = g_march_rc_depth, oc = g_march_rc_occ, nt = g_march_rc_nt; \
+#define RC_BY_DEPTH(DM) do { if constexpr (SLAB != 0) RC_LAUNCH(DM, MARCH_RC_DEPTH, MARCH_RC_OCC, MARCH_NTM); else { const int dp = g_march_rc_depth, oc = g_march_rc_occ, nt = g_march_rc_nt; \
         if (nt != MARCH_NTM) { if (nt == 0) RC_LAUNCH(DM, 2, 2, 0); else if (nt == 1) RC_LAUNCH(DM, 2, 2, 1); else if (nt == 4) RC_LAUNCH(DM, 2, 2, 4); else if (nt == 7) RC_LAUNCH(DM, 2, 2, 7); \
                                  else if (nt == 13) RC_LAUNCH(DM, 2, 2, 13); else if (nt == 21) RC_LAUNCH(DM, 2, 2, 21); else if (nt == 37) RC_LAUNCH(DM, 2, 2, 37); else if (nt == 63) RC_LAUNCH(DM, 2, 2, 63); else return -(int)hipErrorInvalidValue; } \
         else if (oc == 1) { if (dp == 4) RC_LAUNCH(DM, 4, 1, MARCH_NTM); else RC_LAUNCH(DM, 2, 1, MARCH_NTM); } \
         else if (oc == 3) { if (dp == 1) RC_LAUNCH(DM, 1, 3, MARCH_NTM); else RC_LAUNCH(DM, 2, 3, MARCH_NTM); } \
-        else { if (dp == 1) RC_LAUNCH(DM, 1, 2, MARCH_NTM); else if (dp == 4) RC_LAUNCH(DM, 4, 2, MARCH_NTM); else RC_LAUNCH(DM, 2, 2, MARCH_NTM); } } while (0)
+        else { if (dp == 1) RC_LAUNCH(DM, 1, 2, MARCH_NTM); else if (dp == 4) RC_LAUNCH(DM, 4, 2, MARCH_NTM); else RC_LAUNCH(DM, 2, 2, MARCH_NTM); } } } while (0)
 #else
 #define RC_BY_DEPTH(DM) RC_LAUNCH(DM, MARCH_RC_DEPTH, MARCH_RC_OCC, MARCH_NTM)
 #endif
@@ -326,42 +361,71 @@ int launch_march_rc(int W, int H, const float* cs, const unsigned char* flags, f
 #undef RC_LAUNCH
     int e = check_launch(); return e ? e : grid;
 }
+
+// what every entry checks: the shape (a whole image, or a slab with at most one ghost row towards each neighbour), the planes, the sums this iteration starts from
+int rc_check(int W, int H, int row0, int row1, const void* cs, const void* flags, const void* r_in, const void* r_out, const void* A_in, const void* A_out,
+             const void* p_in, const void* p_out, const void* delta, int mode, thallo_sum_t aNp, thallo_sum_t aNpp, thallo_sum_t aDpp, const void* aD_out, const void* s12_out)
+{
+    if ((W & 1) || W < 2 || H < 1 || row0 < 0 || row1 > H || row0 >= row1 || row0 > 1 || H - row1 > 1) return -(int)hipErrorInvalidValue;
+    if (mode & 1) return -(int)hipErrorInvalidValue;          // (the first iteration of a GN step has no A p_{k-1}: the stored-plane kernel runs it)
+    if (!cs || !flags || !r_in || !r_out || !p_in || !p_out || !delta || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
+    if ((row0 > 0 || row1 < H) && (!A_in || !A_out)) return -(int)hipErrorInvalidValue;          // slabs: the exchanged rows of A p
+    if (aNp.count < 1 || !aNp.partials) return -(int)hipErrorInvalidValue;
+    if (((mode >> 1) & 3) == 2 && (aNpp.count < 1 || aDpp.count < 1 || !aNpp.partials || !aDpp.partials)) return -(int)hipErrorInvalidValue;
+    if (12.0 * (double)W * (double)H >= 4294967296.0) return -(int)hipErrorNotSupported;       // a vector must fit one buffer descriptor
+    return 0;
+}
 }  // namespace
 
 extern "C" {
 
-int thallo_hip_iw_pcg_iter_march_rc(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                                    const float* r_in, float* r_out, const float* p_in, float* p_out, float* delta, int mode,
+int thallo_hip_iw_pcg_iter_march_rc(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                    const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
                                     thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
                                     const int* irregular, float* aD_out, double* s12_out,
                                     unsigned* fin_tickets, float* aD_word, float* bN_word, thallo_stream_t stream)
 {
-    if ((W & 1) || W < 2 || H < 1 || (mode & 1)) return -(int)hipErrorInvalidValue;          // (the first iteration of a GN step has no A p_{k-1}: the stored-plane kernel runs it)
-    if (!cs || !flags || !r_in || !r_out || !p_in || !p_out || !delta || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
+    if (int e = rc_check(W, H, row0, row1, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aNpp, aDpp, aD_out, s12_out)) return e;
+    if (aDp.count < 1 || bNp.count < 1 || !aDp.partials || !bNp.partials) return -(int)hipErrorInvalidValue;
     if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
-    if (aNp.count < 1 || aDp.count < 1 || bNp.count < 1 || !aNp.partials || !aDp.partials || !bNp.partials) return -(int)hipErrorInvalidValue;
-    if (((mode >> 1) & 3) == 2 && (aNpp.count < 1 || aDpp.count < 1 || !aNpp.partials || !aDpp.partials)) return -(int)hipErrorInvalidValue;
-    if (12.0 * (double)W * (double)H >= 4294967296.0) return -(int)hipErrorNotSupported;       // a vector must fit one buffer descriptor
-    return launch_march_rc(W, H, cs, flags, w_fit, w_reg, r_in, r_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, irregular,
-                           aD_out, s12_out, fin_tickets, aD_word, bN_word, (hipStream_t)stream, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
+    const PrevSums none = { nullptr, nullptr, 0, nullptr, nullptr };
+    if (row0 == 0 && row1 == H)
+        return launch_march_rc<0>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, nullptr, nullptr, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, irregular, thallo_dist_t{},
+                                  aD_out, s12_out, fin_tickets, aD_word, bN_word, 0, (hipStream_t)stream, none);
+    return launch_march_rc<1>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, irregular, thallo_dist_t{},
+                              aD_out, s12_out, fin_tickets, aD_word, bN_word, 0, (hipStream_t)stream, none);
 }
 
-int thallo_hip_iw_pcg_iter_march_rc_deferred(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                                             const float* r_in, float* r_out, const float* p_in, float* p_out, float* delta, int mode,
+int thallo_hip_iw_pcg_iter_march_rc_deferred(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
                                              thallo_sum_t aNp, thallo_sum_t aNpp, thallo_sum_t aDpp, thallo_prev_t prev,
                                              const int* irregular, float* aD_out, double* s12_out, thallo_stream_t stream)
 {
-    if ((W & 1) || W < 2 || H < 1 || (mode & 1)) return -(int)hipErrorInvalidValue;
-    if (!cs || !flags || !r_in || !r_out || !p_in || !p_out || !delta || !aD_out || !s12_out) return -(int)hipErrorInvalidValue;
+    if (int e = rc_check(W, H, row0, row1, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aNpp, aDpp, aD_out, s12_out)) return e;
     if (prev.count < 1 || prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_partials || !prev.s12_partials || !prev.alphaD_word || !prev.betaN_word ||
         prev.s12_partials == s12_out) return -(int)hipErrorInvalidValue;
-    if (aNp.count < 1 || !aNp.partials) return -(int)hipErrorInvalidValue;
-    if (((mode >> 1) & 3) == 2 && (aNpp.count < 1 || aDpp.count < 1 || !aNpp.partials || !aDpp.partials)) return -(int)hipErrorInvalidValue;
-    if (12.0 * (double)W * (double)H >= 4294967296.0) return -(int)hipErrorNotSupported;       // a vector must fit one buffer descriptor
     const thallo_sum_t none = { nullptr, 0 };
-    return launch_march_rc(W, H, cs, flags, w_fit, w_reg, r_in, r_out, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp, irregular,
-                           aD_out, s12_out, nullptr, nullptr, nullptr, (hipStream_t)stream,
-                           PrevSums{ prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word });
+    const PrevSums ps = { prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word };
+    if (row0 == 0 && row1 == H)
+        return launch_march_rc<0>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, nullptr, nullptr, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp, irregular, thallo_dist_t{},
+                                  aD_out, s12_out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, ps);
+    return launch_march_rc<1>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp, irregular, thallo_dist_t{},
+                              aD_out, s12_out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, ps);
+}
+
+int thallo_hip_iw_pcg_iter_march_rc_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                         const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
+                                         thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, thallo_sum_t aNpp, thallo_sum_t aDpp,
+                                         const int* irregular, thallo_dist_t d, float* aD_out, double* s12_out,
+                                         unsigned* fin_tickets, int slot0, float* aD_word, float* bN_word, thallo_stream_t stream)
+{
+    if (int e = rc_check(W, H, row0, row1, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aNpp, aDpp, aD_out, s12_out)) return e;
+    if (!Ap_in || !Ap_out || aDp.count < 1 || bNp.count < 1 || !aDp.partials || !bNp.partials || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD) return -(int)hipErrorInvalidValue;
+    if (!fin_tickets || !aD_word || !bN_word) { fin_tickets = nullptr; aD_word = nullptr; bN_word = nullptr; }
+    if (fin_tickets && (slot0 < 0 || !d.mail || !d.ctl || 7 * d.world > 64 || bNp.count != 1)) return -(int)hipErrorInvalidValue;
+    for (int k = 0; k < 2; ++k) if (d.peer_r[k] && ((d.peer_off_o[k] | d.peer_off_a[k]) & 1)) return -(int)hipErrorInvalidValue;
+    return launch_march_rc<2>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, irregular, d,
+                              aD_out, s12_out, fin_tickets, aD_word, bN_word, slot0, (hipStream_t)stream, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
 }
 
 void thallo_hip_march_rc_debug_set(int what, int value)

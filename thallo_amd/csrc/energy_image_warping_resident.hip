@@ -694,7 +694,10 @@ int g_res_rows = 0;      // tests / tools: rows per segment (0 = automatic)
 inline int res_rows(int W, int rows, bool below = false)
 {
     if (W < 2 || (W & 1) || rows < 1) return 0;
-    const long cap = g_res_cap > 0 ? g_res_cap : thallo_hip_device_cu_count();
+    // every workgroup must be RESIDENT (they wait for each other) and a wave's sums sweep covers slots 64 * wave + lane < 256: at most
+    // min(CUs, 256) workgroups, one per CU
+    long cap = g_res_cap > 0 ? g_res_cap : thallo_hip_device_cu_count();
+    if (cap > 256) cap = 256;
     const int nstrips = (W + RES_USE - 1) / RES_USE;
     int R = g_res_rows > 0 ? g_res_rows : march_rows_per_segment(rows, nstrips, RES_NT / 64, cap, 2);
     if (below) while (R > 0 && R <= RES_MAX_R && rows % R != 0) ++R;
@@ -728,8 +731,21 @@ template <bool DIST>
 int res_launch(const ResArgs& a, int R, hipStream_t s)
 {
     const int grid = (a.g.total + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)a.L);
     const size_t lds = res_lds_bytes(R);
+    {   // co-residency is a precondition, not an assumption: the kernel's workgroups wait for each other, so what the device says it can hold of THIS
+        // instantiation with THIS much LDS must cover the grid (asked once per instantiation)
+        static int fits[RES_MAX_R + 1][2] = {};
+        int& f = fits[R][DIST ? 1 : 0];
+        if (f == 0) {
+            int per_cu = 0; hipError_t e = hipErrorNotSupported;
+#define RES_OCC(RR) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_resident<RR, DIST>, RES_NT, lds)
+            switch (R) { case 1: RES_OCC(1); break; case 2: RES_OCC(2); break; case 3: RES_OCC(3); break; case 4: RES_OCC(4); break; case 5: RES_OCC(5); break; default: break; }
+#undef RES_OCC
+            f = (e == hipSuccess && per_cu >= 1) ? per_cu : -1;
+        }
+        if (f < 0 || (long)f * thallo_hip_device_cu_count() < grid) return -(int)hipErrorNotSupported;
+    }
+    hipLaunchKernelGGL(k_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)a.L);
 #define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR, DIST>), dim3(grid), dim3(RES_NT), lds, s, a)
     switch (R) {
         case 1: RES_LAUNCH(1); break; case 2: RES_LAUNCH(2); break; case 3: RES_LAUNCH(3); break;

@@ -160,8 +160,10 @@ public:
     virtual bool resident_ok() const { return false; }
     virtual int  pcg_resident(LaunchCtx&, SolverVectors&, int /*L*/, thallo_sum_t /*alphaN0*/, float* /*words*/) { return -1; }
     virtual int  resident_status(LaunchCtx&, int /*clear*/, unsigned* /*pm*/) { return 0; }      // 1: a bounded wait inside the kernel ran out
+    virtual void resident_disable() {}                                                          // ... after which the plan stays on one launch per PCG iteration
     // ... for one rank's row slab on the device-side transport (thallo_hip_iw_pcg_resident_dist): boundary rows of A p straight into the neighbours' ghost areas
     // (ghost_off bytes into every rank's mailbox block), the scalars through the mailbox slots slot0 + 7 k ..
+    virtual bool dist_batches_delta() const { return false; }          // the device-side transport's iteration kernel has the "apply two delta updates" form too
     virtual bool resident_slab_ok() const { return false; }
     virtual long resident_ghost_bytes() const { return 0; }
     virtual int  pcg_resident_dist(LaunchCtx&, SolverVectors&, int /*L*/, thallo_sum_t /*alphaN0*/, float* /*words*/, const thallo_dist_t&, long /*ghost_off*/, int /*slot0*/) { return -1; }

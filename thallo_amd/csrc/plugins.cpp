@@ -160,6 +160,7 @@ class ImageWarpingPlugin : public EnergyPlugin {
     DeviceBuffer xres;                     // exchange memory of the resident PCG kernel (granule buffers + control words)
     bool resident_ = false;                // the shape fits the resident kernel (whole image, unit pixel grid, even W, few enough rows per wave)
     bool resident_slab_ = false;           // ... as one rank's row slab of a multi-GPU run (thallo_hip_iw_pcg_resident_dist)
+    bool resident_broken_ = false;         // a bounded wait of the resident kernel ran out on this plan (something kept its workgroups from being co-resident): never again
     bool march_ = false;                   // UrShape verified (at Init) to be the unit pixel grid and W even: the marching one-kernel iteration
     bool march_rc_ = false;                // ... in its form without an A p plane (whole image on one GPU; THALLO_MARCH=3: the stored-plane form, A/B)
     bool grid_ = false;                    // UrShape is the unit pixel grid (host-checked at Init)
@@ -201,13 +202,13 @@ public:
         march_ = grid_ && ((long)W * H >= 400000 || (e && (e[0] == '2' || e[0] == '4')));      // THALLO_MARCH=2: the marching kernel at every size (tests); 3: with the stored A p plane (A/B); 4: both
         // an image with more 124-pixel column strips than the device has workgroup slots stays on the tile kernel (which loops over its tiles)
         if (march_ && thallo_hip_iw_march_rows(W, H) <= 0) march_ = false;
-        march_rc_ = march_ && row0_ == 0 && row1_ == H && !(e && (e[0] == '3' || e[0] == '4'));
+        march_rc_ = march_ && !(e && (e[0] == '3' || e[0] == '4')) && 12.0 * (double)W * (double)H < 4294967296.0;      // (whole images and row slabs alike)
         // small working sets: the whole PCG loop in one launch (state in registers); THALLO_RESIDENT=0: one launch per PCG iteration (A/B)
         resident_ = resident_slab_ = false;
         const char* er = env_switch("THALLO_RESIDENT");
         const bool whole = row0_ == 0 && row1_ == H;
         const int rr = whole ? thallo_hip_iw_resident_rows(W, H) : thallo_hip_iw_resident_rows_slab(W, row1_ - row0_, row1_ < H ? 1 : 0);
-        if (grid_ && !(er && er[0] == '0') && rr > 0) {
+        if (grid_ && !(er && er[0] == '0') && rr > 0 && !resident_broken_) {
             const long need = thallo_hip_iw_resident_bytes(W, row1_ - row0_);
             if (need > 0 && (long)xres.bytes < need) {
                 if (xres.alloc((size_t)need) || hipMemsetAsync(xres.ptr, 0, (size_t)need, c.stream) != hipSuccess) { set_error("image_warping: out of device memory for the resident kernel's exchange buffers"); return -1; }
@@ -230,6 +231,10 @@ public:
                       const thallo_dist_t& d, float* out, int slot0, float* aD_word, float* bN_word) override
     {
         TimedLaunch t(c, "PCGIteration");
+        if (march_rc_ && !(mode & 1))
+            return thallo_hip_iw_pcg_iter_march_rc_dist(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                        v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                                        aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, d, out, v.s12, v.fin_tickets, slot0, aD_word, bN_word, c.stream);
         if (march_)
             return thallo_hip_iw_pcg_iter_march_dist(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
                                                      v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
@@ -260,14 +265,15 @@ public:
                                        v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, none, none, (const int*)irregular.ptr, v.r, out, c.stream);
     }
     bool batches_delta() const override { return true; }
+    bool dist_batches_delta() const override { return march_rc_; }      // (the stored-plane marching kernel's multi-GPU variant has no such form: it would spill)
     bool one_kernel_iteration() const override { return true; }
     int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2, float* out,
                  float* aD_word, float* bN_word) override
     {
         TimedLaunch t(c, "PCGIteration");
         if (march_rc_ && !(mode & 1))
-            return thallo_hip_iw_pcg_iter_march_rc(W, H, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
-                                                   v.rbuf(cur), v.rbuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+            return thallo_hip_iw_pcg_iter_march_rc(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                   v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
                                                    aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, out, v.s12,
                                                    aD_word ? v.fin_tickets : nullptr, aD_word, bN_word, c.stream);
         if (march_)
@@ -302,14 +308,15 @@ public:
     }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override
     { return xres.ptr ? thallo_hip_iw_resident_status(xres.ptr, clear, -1, pm, c.stream) : 0; }
+    void resident_disable() override { resident_ = resident_slab_ = false; resident_broken_ = true; }
     bool iter_defers_finish() const override { return true; }
     int pcg_iter_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aN2, thallo_sum_t aD2, const thallo_prev_t& prev,
                           float* out, double* s12_out) override
     {
         TimedLaunch t(c, "PCGIteration");
         if (march_rc_ && !(mode & 1))
-            return thallo_hip_iw_pcg_iter_march_rc_deferred(W, H, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
-                                                            v.rbuf(cur), v.rbuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+            return thallo_hip_iw_pcg_iter_march_rc_deferred(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                            v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
                                                             aN, aN2, aD2, prev, (const int*)irregular.ptr, out, s12_out, c.stream);
         if (march_)
             return thallo_hip_iw_pcg_iter_march_deferred(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,

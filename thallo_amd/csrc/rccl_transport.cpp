@@ -39,9 +39,12 @@ Api& api()
     static Api a;
     if (a.tried) return a;
     a.tried = true;
-    for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1" }) {
-        a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // A copy the process has already mapped comes first (PyTorch ships its own, soname librccl.so.1: glibc matches mapped libraries by soname, so asking for
+    // "librccl.so" first could load a SECOND RCCL from the system path next to it -- ADVICE r3); only then the loader's search path.
+    a.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
         if (a.handle) break;
+        a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!a.handle) { a.why = "librccl.so not found"; return a; }
     a.get_unique_id = (GetUniqueId_t)dlsym(a.handle, "ncclGetUniqueId");

@@ -258,8 +258,12 @@ float Plan::compute_cost()
         resident_used_ = false;
         unsigned pm[5] = { 0, 0, 0, 0, 0 };
         if (plugin->resident_status(ctx, 1, pm) != 0) {
+            // (something kept the kernel's workgroups from being co-resident -- a long-running foreign kernel, a second resident plan on another stream: the launch
+            //  itself checks what the device can hold.)  This plan runs one launch per PCG iteration from now on; the voided steps are reported, not silently redone:
+            //  the unknowns already carry their update.
+            plugin->resident_disable();
             set_error("%s: a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u): the steps since the last cost evaluation are void; "
-                      "THALLO_RESIDENT=0 selects one launch per PCG iteration", plugin->name(), pm[0], pm[1], pm[2], pm[3], pm[4]);
+                      "the plan runs one launch per PCG iteration from now on (Thallo_ProblemInit and solve again)", plugin->name(), pm[0], pm[1], pm[2], pm[3], pm[4]);
             return NAN;
         }
     }

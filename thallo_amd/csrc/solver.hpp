@@ -77,6 +77,7 @@ struct DistState {
     thallo_xreduce_t xa;                                 // device-side all-reduce of the shared block (thallo_hip_dist_allreduce): inbox geometry
     // device-side exchange
     bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
+    bool resident_all = false;                           // EVERY rank's slab fits the resident PCG kernel (agreed once per Init: a rank whose last segment cannot be a full one says no)
     void* mail = nullptr; int mail_L = 0;
     long ghost_off = 0;                                  // byte offset of the resident kernel's ghost area inside every rank's mailbox block (0: none)
     DeviceBuffer ctl;

@@ -98,6 +98,12 @@ int Plan::use_rccl(const unsigned char* id128, int rank, int world)
 int Plan::set_distributed(const ThalloX_Distributed& cfg)
 {
     if (!ok_) return -1;
+    //  the plan's own communicator speaks for exactly one (rank, world): with another one its collectives would move world' x bytes into buffers sized for
+    // `world` -- refused for every world, 1 included (a NULL callback routes to it)
+    if (rccl_ && (rccl_->world != cfg.world || rccl_->rank != cfg.rank)) {
+        set_error("distributed: the plan's RCCL communicator is rank %d of %d, ThalloX_PlanSetDistributed says rank %d of %d", rccl_->rank, rccl_->world, cfg.rank, cfg.world);
+        return -1;
+    }
     if (dist_) { set_error("distributed: already set for this plan"); return -1; }
     const int rc = set_distributed_impl(cfg);
     if (rc && dist_) {      // failed half-way (out of memory, a failing callback ...): the plan's vectors may already live in the released exchange block
@@ -168,6 +174,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (cfg.world < 1 || cfg.world > THALLO_DIST_MAX_WORLD || cfg.rank < 0 || cfg.rank >= cfg.world) { set_error("distributed: rank %d of %d (at most %d ranks)", cfg.rank, cfg.world, THALLO_DIST_MAX_WORLD); return -1; }
         if (cfg.world > 1 && !cfg.allgather && !(rccl_ && rccl_->world == cfg.world && rccl_->rank == cfg.rank)) { set_error("distributed: world > 1 needs an all-gather callback (or ThalloX_PlanUseRccl)"); return -1; }
         const bool part = ghost_spec_.given;
+        bool part_bad = false;             // partition form: this rank's lists are inconsistent -- said in the first collective below, where every rank returns the error
         if (!part && (U % cfg.world || u1 - u0 != U / cfg.world || u0 != (U / cfg.world) * cfg.rank)) {
             set_error("distributed: rank %d of %d must own units [%ld,%ld) of %ld (equal contiguous ranges), got [%ld,%ld)", cfg.rank, cfg.world, (U / cfg.world) * cfg.rank, (U / cfg.world) * (cfg.rank + 1), U, u0, u1);
             return -1;
@@ -181,7 +188,10 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
                 ok = G.ghost[g] >= u1 && G.ghost[g] < U && !seen[(size_t)G.ghost[g]] && G.src_rank[g] >= 0 && G.src_rank[g] < cfg.world && G.src_rank[g] != cfg.rank && G.src_pos[g] >= 0;
                 if (ok) seen[(size_t)G.ghost[g]] = 1;
             }
-            if (!ok) { set_error("distributed: the ghost exchange lists do not describe local units [0,%ld) owned + [%ld,%ld) ghosts", u1, u1, U); return -1; }
+            std::vector<char> seen_b((size_t)std::max(1L, u1), 0);
+            for (int b : G.boundary) { if (ok && seen_b[(size_t)b]) ok = false; if (ok) seen_b[(size_t)b] = 1; }        // (a boundary unit listed twice would be sent twice)
+            //  NOT an early return: the other ranks are about to enter the first collective of this set-up -- a bad list is this rank's "no" in it
+            if (!ok) { set_error("distributed: the ghost exchange lists do not describe local units [0,%ld) owned + [%ld,%ld) ghosts (or list a boundary unit twice)", u1, u1, U); part_bad = true; }
         }
         if (plugin->set_owned_range(u0, u1)) return -1;
         hipDeviceSynchronize();
@@ -193,7 +203,11 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         long per_unit = 0;
         for (auto& im : plugin->unknown_images()) {
             const long per = im.n_floats / U, len = per * (u1 - u0);
-            if (im.n_floats % U || (!part && (len & 3))) { set_error("distributed: an owned slice of %ld floats (must be a multiple of 4)", len); return -1; }
+            if (im.n_floats % U || (!part && (len & 3))) {
+                set_error("distributed: an unknown image of %ld floats over %ld units, an owned slice of %ld floats (must divide / be a multiple of 4)", im.n_floats, U, len);
+                if (!part) return -1;
+                part_bad = true;
+            }
             first.push_back({ off, len }); mine.push_back({ off + per * u0, len });
             if (un.nplanes < 8) { un.base[un.nplanes] = off; un.len[un.nplanes] = (int)per; ++un.nplanes; }
             per_unit += per;
@@ -205,11 +219,17 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         if (part) {
             // every rank's boundary count (messages are padded to the largest; a ghost's source position must exist on its source rank)
             const GhostSpec& G = ghost_spec_;
-            int counts[THALLO_DIST_MAX_WORLD]; const int mine_n = (int)G.boundary.size();
+            int counts[THALLO_DIST_MAX_WORLD]; const int mine_n = part_bad ? -1 : (int)G.boundary.size();
             if (D.send.alloc(64 * sizeof(float)) || D.gath.alloc(64 * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }
             if (host_allgather(*this, D, &Plan::dist_allgather, &mine_n, counts, sizeof(int))) return -1;
             long maxb = 1; bool ok = true;
-            for (int r = 0; r < cfg.world; ++r) maxb = std::max(maxb, (long)counts[r]);
+            for (int r = 0; r < cfg.world; ++r) {
+                if (counts[r] < 0) {        // some rank's lists are inconsistent: EVERY rank returns here, in step
+                    if (!part_bad) set_error("distributed: rank %d's ghost exchange lists are inconsistent", r);
+                    return -1;
+                }
+                maxb = std::max(maxb, (long)counts[r]);
+            }
             for (size_t g = 0; g < G.ghost.size(); ++g) ok = ok && G.src_pos[g] < counts[G.src_rank[g]];
             D.msg = 1 + per_unit * maxb; D.msg_iter = 7 + per_unit * maxb;
             std::vector<long> s1(G.ghost.size()), s7(G.ghost.size());
@@ -480,7 +500,7 @@ float Plan::dist_cost()
     if (resident_used_ && !D.failed) {     // the resident PCG kernel's waits are bounded; one that ran out voids the steps since the last check (this rank says so in the message below: every rank stops)
         resident_used_ = false;
         unsigned pm[5] = { 0, 0, 0, 0, 0 };
-        if (plugin->resident_status(ctx, 1, pm) != 0)
+        if (plugin->resident_status(ctx, 1, pm) != 0 && (plugin->resident_disable(), true))
             dist_fail("a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u)", pm[0], pm[1], pm[2], pm[3], pm[4]);
     }
     if ((D.flat || D.shard || D.part) && D.p2p_on && !D.failed) {  // the device-side row exchange's (all-reduce's) waits are bounded too
@@ -546,10 +566,13 @@ int Plan::dist_gn(int L, bool p2p)
     // delta += alpha p every iteration on the device-side transport: its "apply two" kernel variant (peer stores on top of 256 VGPRs) spills, and at
     // slab sizes the 6 B/pixel it would save do not matter (2048x256: 22.6 vs 24.3 us per iteration).  (Either delta schedule gives the same bits -- tested
     // for both kernels; the marching kernel's multi-GPU variant is contracted differently from its single-GPU one, so its two TRANSPORTS agree to rounding.)
-    const bool batch = batch_delta_ && !p2p;
+    // (round 4: the kernel without an A p plane has that form on the device-side transport too -- 160-200 registers -- and every rank runs the same kernel)
+    const bool batch = batch_delta_ && (!p2p || plugin->dist_batches_delta());
     // Small slabs on the device-side transport: the whole PCG loop in ONE launch (state in registers, boundary rows of A p straight into the neighbours' ghost
-    // areas, the scalars through the same mailbox slots: thallo_hip_iw_pcg_resident_dist).  Same decision on every rank: the slabs are equal up to the image border.
-    const bool resident = p2p && L >= 1 && L <= 4095 && D.ghost_off > 0 && plugin->resident_slab_ok();
+    // areas, the scalars through the same mailbox slots: thallo_hip_iw_pcg_resident_dist).  UNANIMOUS: a rank's own answer depends on whether it has a
+    // rank below (its last segment must then be a full one) -- 8 ranks x 256 rows: R = 5 does not divide 256, ranks 0..6 say no, rank 7 alone would say yes and
+    // poll for granules nobody sends.  Agreed once per Init (dist_self_check), cached.
+    const bool resident = p2p && L >= 1 && L <= 4095 && D.ghost_off > 0 && D.resident_all;
     if (resident) {
         if (!D.failed) {
             nb = plugin->pcg_resident_dist(ctx, v_, L, sum(B), scal(B + 1), D.d, D.ghost_off, 0);
@@ -587,7 +610,7 @@ int Plan::dist_gn(int L, bool p2p)
         if (!D.failed) { set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
         cur_ ^= 1;
     }
-    if (!D.failed) { last_l_iters = L; linear_update_tail(L, batch); }   // owned rows only
+    if (!D.failed) { last_l_iters = L; linear_update_tail(L, batch && !resident); }   // owned rows only (the resident loop has applied every delta update but the last itself)
     return dist_exchange_unknown_rows();
 }
 
@@ -1089,6 +1112,11 @@ int Plan::dist_self_check()
         return 0;
     }
     const int Lc = std::max(1, std::min(6, sp.lIterations)), B = 2, nw = 2 * Lc + 1;
+    {   // does EVERY rank's slab fit the resident PCG kernel?  (asked before the first device-side step: dist_gn reads the answer)
+        bool all = false;
+        if (dist_agree(plugin->resident_slab_ok() && D.ghost_off > 0, all)) return -1;
+        D.resident_all = all;
+    }
     if (ensure_slots(std::max(Lc, sp.lIterations))) dist_fail("out of device memory for the reduction slots");
     const auto& imgs = plugin->unknown_images();
     std::vector<DeviceBuffer> keep(imgs.size());
@@ -1132,10 +1160,10 @@ int Plan::dist_self_check()
     if (dist_agree(pass, all)) return -1;
     D.p2p_on = all;
     char buf[512];
-    snprintf(buf, sizeof(buf), "{\"exchange\": \"%s\", \"rank\": %d, \"world\": %d, \"memory\": [\"%s\", \"%s\"], \"self_check\": {\"iterations\": %d, \"timeout\": %d, "
+    snprintf(buf, sizeof(buf), "{\"exchange\": \"%s\", \"rank\": %d, \"world\": %d, \"memory\": [\"%s\", \"%s\"], \"resident_loop\": %s, \"self_check\": {\"iterations\": %d, \"timeout\": %d, "
              "\"max_rel_scalar_diff\": %.3g, \"pass\": %s, \"all_ranks_pass\": %s, \"post_mortem\": [%u, %u, %u, %u, %u]}}",
              all ? "p2p-mailbox" : "allgather", D.cfg.rank, D.cfg.world, D.mem_kind[0] == 1 ? "fine-grained" : "coarse-grained", D.mem_kind[1] == 1 ? "fine-grained" : "coarse-grained",
-             Lc, err, rel, pass ? "true" : "false", all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
+             (all && D.resident_all) ? "true" : "false", Lc, err, rel, pass ? "true" : "false", all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
     D.info = buf;
     return 0;                                                            // (a rank that failed in here says so at the cost evaluation that follows in Init)
 }

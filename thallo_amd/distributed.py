@@ -24,11 +24,14 @@ from . import api
 class SlabLayout:
     """Rows [g0,g1) of an H-row image owned by `rank`; local image = owned rows + ghost rows."""
 
-    def __init__(self, H, rank, world, align=16, ghost=1):
-        # slabs are multiples of `align` rows (the kernels' tile height) while rows last; remainder to the last rank
-        blocks = (H + align - 1) // align
-        per, rem = divmod(blocks, world)
-        counts = [(per + (1 if r < rem else 0)) * align for r in range(world)]
+    def __init__(self, H, rank, world, align=16, ghost=1, counts=None):
+        # slabs are multiples of `align` rows (the kernels' tile height) while rows last; remainder to the last rank.  counts: an explicit split (rows per rank)
+        if counts is None:
+            blocks = (H + align - 1) // align
+            per, rem = divmod(blocks, world)
+            counts = [(per + (1 if r < rem else 0)) * align for r in range(world)]
+        elif len(counts) != world or sum(counts) != H or min(counts) < 1:
+            raise ValueError(f"counts {counts} do not split {H} rows over {world} ranks")
         start = 0
         bounds = []
         for c in counts:
@@ -57,6 +60,34 @@ class SlabLayout:
 
     def down(self):
         return self.rank + 1 if self.bot else None
+
+
+def image_warping_slab_counts(W, H, world):
+    """Rows per rank such that EVERY rank's slab fits the resident PCG kernel (one launch per Gauss-Newton step), or None: the default split.  A rank with a rank
+    below needs its rows to be a multiple of its rows per wave segment R (the ghost row below sits at a fixed register row: energy_image_warping_resident.hip), and
+    the decision to run the resident loop is unanimous (solver_dist.cpp) -- the default split of 2048 rows over 8 ranks, 256 each, has R = 5 and 256 % 5 != 0, so no
+    rank would run it.  Here: ranks 0 .. world-2 get the largest multiple of m <= H / world rows, m = 5 .. 1, the last rank the rest (2048 / 8: 7 x 255 + 263).
+    Host-only (the library's geometry functions; the same answer on every rank)."""
+    if world < 2 or W < 2 or (W & 1):
+        return None
+    # only where the plugin runs its MARCHING kernels on the slabs (plugins.cpp ImageWarpingPlugin::prepare: local image >= 0.4 Mpixel, or THALLO_MARCH=2 / 4): the
+    # LDS-tiled kernel of smaller slabs wants them in multiples of its tile height -- the default split
+    if W * (H // world) < 400000 and os.environ.get("THALLO_MARCH", "")[:1] not in ("2", "4"):
+        return None
+    L = api.lib()
+    L.thallo_hip_iw_resident_rows_slab.restype = C.c_int
+    L.thallo_hip_iw_resident_rows_slab.argtypes = [C.c_int, C.c_int, C.c_int]
+    for m in (5, 4, 3, 2, 1):
+        per = (H // world) // m * m
+        if per < 1:
+            continue
+        counts = [per] * (world - 1) + [H - per * (world - 1)]
+        if counts[-1] > per + 2 * m + m * (world - 1):
+            continue
+        rr = [L.thallo_hip_iw_resident_rows_slab(W, c, 1 if r < world - 1 else 0) for r, c in enumerate(counts)]
+        if min(rr) > 0 and min(rr) == max(rr):          # every rank fits, with the SAME rows per segment (equal work per wave; one geometry to reason about)
+            return counts
+    return None
 
 
 # ------------------------------------------------------------------ image_warping: the slab schedule behind Thallo_ProblemStep
@@ -136,6 +167,14 @@ def library_rccl(solver, rank, world, group=None, force=False):
     on_own_gpus = dist.is_initialized() and dist.get_backend(group) == "nccl"
     if not (on_own_gpus or force):
         return False
+    # every rank must be able to bind RCCL BEFORE anybody enters the collective ncclCommInitRank (a rank that fails in front of it leaves the others blocked inside)
+    mine = 1.0 if api.lib().ThalloX_RcclAvailable() == 1 else 0.0
+    if world > 1:
+        t = torch.tensor([mine], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        mine = t.item()
+    if mine < 0.5:
+        return False
     box = [None]
     if rank == 0:
         try:
@@ -163,7 +202,8 @@ class PlanSlabSolver:
     collective once ThalloX_PlanSetDistributed was called)."""
 
     def __init__(self, params_global, W, H, rank, world, l_iters, device_exchange=True, group=None, force_allgather=False):
-        self.lay = lay = SlabLayout(H, rank, world)
+        # (the resident-friendly split on either transport, so that the two stay comparable bit for bit: it is a valid split for every marching kernel)
+        self.lay = lay = SlabLayout(H, rank, world, counts=image_warping_slab_counts(W, H, world))
         self.W, self.H, self.world, self.rank, self.group = W, H, world, rank, group
         dev = torch.device("cuda", torch.cuda.current_device())
         local = [lay.local(a) if isinstance(a, np.ndarray) else a for a in params_global]
@@ -336,9 +376,16 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
                   "rel_diff_first_step_cost": abs(c1 - c1_single) / max(abs(c1_single), 1e-30),
                   "final_cost_single_gpu": c_single, "rel_diff_final_cost": abs(final - c_single) / max(abs(c_single), 1e-30),
                   "tolerance_first_step": 1e-5, "tolerance_final": 5e-2}
-        assert abs(c0 - c0_single) <= 1e-5 * abs(c0_single), (c0, c0_single)
-        assert parity["rel_diff_first_step_cost"] <= parity["tolerance_first_step"], parity
-        assert parity["rel_diff_final_cost"] <= parity["tolerance_final"], parity
+        parity["rel_diff_initial_cost"] = abs(c0 - c0_single) / max(abs(c0_single), 1e-30)
+        parity["parity_ok"] = bool(parity["rel_diff_initial_cost"] <= 1e-5 and parity["rel_diff_first_step_cost"] <= parity["tolerance_first_step"]
+                                   and parity["rel_diff_final_cost"] <= parity["tolerance_final"])
+        if not parity["parity_ok"]:
+            # the record first, the non-zero exit second: a failing sentinel leaves a diagnosable line next to its exit code
+            import json as _json
+            import sys as _sys
+            print(_json.dumps({"parity_ok": False, "n_gpus": world, "parity_vs_one_gpu": parity, "exchange": "p2p-mailbox" if p2p else "rccl"}), flush=True)
+            _sys.stdout.flush()
+        assert parity["parity_ok"], parity
     dist.barrier()
     npx = W * H
     # roofline of the dominant kernel on this rank's slab: the graph replay cannot be bracketed per kernel, so the one-kernel PCG iteration is
@@ -351,7 +398,7 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         # its duration per PCG iteration is the timed region's (exchange included)
         k_ms = dt / (steps * l_iters) * 1e3
         kname = "PCGLoopResident (the whole PCG loop of a GN step in one launch: state in registers, no HBM traffic inside the loop), per PCG iteration, slowest rank"
-        note = "per GPU; priced with the fused formulation's 99 algorithmic bytes per pixel and iteration although the resident loop moves none of them through HBM"
+        note = "per GPU; priced with the fused formulation's algorithmic bytes per pixel and iteration although the resident loop moves none of them through HBM"
     else:
         solver.solver.distributed_kernel_only(3)
         torch.cuda.synchronize()
@@ -362,11 +409,12 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         k_ms = float(reduce(e0.elapsed_time(e1) / reps, dist.ReduceOp.MAX, torch.float64))
         kname = "PCGIteration (whole PCG iteration in one launch) on one rank's slab, slowest rank"
         note = "per GPU; measured right after the timed region (graph replay cannot be bracketed per kernel)"
-    ach = 99.0 * slab_px / (k_ms * 1e-3) / 1e9
+    bpp = api.iw_fused_bytes_per_iter(l_iters)
+    ach = bpp * slab_px / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm",
                 "kernel": kname,
                 "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                "algorithmic_bytes_per_pixel": 99, "reference_formulation_bytes_per_pixel": 180, "avg_launch_ms": k_ms, "slab_pixels": slab_px,
+                "algorithmic_bytes_per_pixel": bpp, "reference_formulation_bytes_per_pixel": 180, "avg_launch_ms": k_ms, "slab_pixels": slab_px,
                 "note": note}
     return {
         "metric": "pcg_iters_per_sec", "value": steps * l_iters / dt, "unit": "PCG iterations/s",

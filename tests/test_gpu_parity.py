@@ -13,7 +13,7 @@ import pytest
 
 import thallo_amd
 from thallo_amd import api, synthetic as syn
-from helpers import to_device, to_host, rel_err, copy_params
+from helpers import to_device, to_host, rel_err, copy_params, oracle_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -542,12 +542,13 @@ def test_benchmark_configuration_2048_vs_cpu_port(torch, orc):
     s.close()
 
 
-@pytest.mark.parametrize("W,H,L", [(8192, 4096, 8), (16384, 16384, 3)])
+@pytest.mark.parametrize("W,H,L", [(8192, 4096, 8), (16384, 11264, 3)])
 def test_image_warping_beyond_the_benchmark_size(torch, orc, W, H, L):
     """8192 x 4096 (33.5 M pixels, 100 M unknowns, 403 MB per solver vector -- eight times the benchmark's image: 67 column strips, 342 rows per wave, every grid- and
-    slot-sizing rule away from the sizes the other tests use) and 16384 x 16384 (268 M pixels, 805 M unknowns: the Offset plane alone is 2.15 GB, so every byte offset
-    into a solver vector passes 2^31 while the element indices stay int32 like the reference's, thallo.t:613-624; ~40 GB of the 288 GB of HBM): one GN step of a few PCG
-    iterations against the OpenMP port of the reference algorithm."""
+    slot-sizing rule away from the sizes the other tests use) and 16384 x 11264 (185 M pixels, 554 M unknowns: a solver vector is 2.2 GB, so the byte offsets into its
+    Angle part pass 2^31 -- as 64-bit pointers in the stored-plane kernels and as UNSIGNED 32-bit buffer offsets in the kernel without the A p plane, which runs here --
+    while the element indices stay int32 like the reference's, thallo.t:613-624; ~28 GB of the 288 GB of HBM; round 3 ran 16384^2 here, 21 s of host time for the
+    same code paths): one GN step of a few PCG iterations against the OpenMP port of the reference algorithm."""
     p = syn.image_warping(W, H)
     q = copy_params(p)
     ref = orc.cpu_port_image_warping(W, H, q, 1, L, want_costs=True, want_trace=True)
@@ -585,12 +586,16 @@ def test_image_warping_cat512_reference_budget(torch, orc, golden_dir):
     wf, wr = float(np.sqrt(np.float32(100.0))), float(np.sqrt(np.float32(0.01)))
     c_img = F.constraint_image(cons, mask, np.float32(1) / np.float32(19))
     p = [ur.copy(), np.zeros((H, W), dtype=np.float32), ur.copy(), c_img, mask, wf, wr]
-    prev = orc.set_threads(_host_threads())
-    try:
-        co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), copy_params(p)).solve(nIterations=8, lIterations=100)
-    finally:
-        orc.set_threads(prev)
-    cf, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), copy_params(p)).solve(nIterations=8, lIterations=100, float_sums=1)
+    fx = oracle_fixture("cat512_8x100", p)          # (the oracle's two trajectories of this instance as committed golden vectors; live only if the inputs do not reproduce)
+    if fx is not None:
+        co, cf = np.array(fx["double"]), np.array(fx["float_order"])
+    else:
+        prev = orc.set_threads(_host_threads())
+        try:
+            co, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), copy_params(p)).solve(nIterations=8, lIterations=100)
+        finally:
+            orc.set_threads(prev)
+        cf, _ = orc.Problem(orc.IMAGE_WARPING, (W, H), copy_params(p)).solve(nIterations=8, lIterations=100, float_sums=1)
     s, dev, costs, final = _solve_gpu("image_warping", (W, H), p, nIterations=8, lIterations=100)
     costs = np.array(costs)
     err, drift = np.abs(costs - co) / co, np.abs(cf - co) / co
@@ -602,36 +607,56 @@ def test_image_warping_cat512_reference_budget(torch, orc, golden_dir):
 
 
 def test_shape_from_shading_2048_lm_vs_oracle(torch, orc):
-    """BASELINE.json configs[3]: shape_from_shading 2048^2 with the LM branch (reference budget 60 x 10, shape_from_shading/src/
-    main.cpp:44-53; here the first 8 LM steps x 10 PCG) against the row oracle on the host cores.  The first four costs to 2e-6 (measured: 3e-7).  From
-    the fifth step on the error grows about five-fold per LM step (measured round 3: 1e-5, 6e-5, 1e-4, 6e-4, 3e-3; same PCG iteration counts on both sides,
-    the zeta test never fires: tools/sfs_lm_diag.py) -- every accepted step triples the trust region, the damping CtC = diag / radius fades, and ten
-    unconverged PCG iterations on an ever worse conditioned system amplify whatever differs, the order of the dot products first of all.  The yardstick for
-    that is the oracle itself: its two legitimate summation modes (double accumulators, and the serial float order of the reference's CPU mode,
-    cpu_cuda.t:265-301) drift apart the same way, and the device must stay within three times that spread."""
+    """BASELINE.json configs[3]: shape_from_shading 2048^2 with the LM branch at the REFERENCE BUDGET, 60 x 10 (shape_from_shading/src/main.cpp:44-53; round 3 ran 8
+    of the 60 steps), against the row oracle's whole trajectory -- a committed golden vector since round 4 (tests/golden/make_oracle_trajectories.py: 375 s of oracle on 8
+    cores for the 60 steps, 300 s for 12 steps in the serial float order; live they took 90 s of the GPU suite for 8 steps).
+    What holds, measured (tools/sfs_lm_budget.py): the first four costs to 2e-7; then the error grows about five-fold per LM step (1e-5, 5e-5, 2e-4, 8e-4, 3e-3) --
+    every accepted step triples the trust region, the damping CtC = diag / radius fades, and ten unconverged PCG iterations on an ever worse conditioned system
+    amplify whatever differs -- SATURATES below 1.1e-2 (steps 8-40), and falls again as both trajectories settle into the same minimum: below 1e-3 from step 41, the
+    final cost 480.159 against 480.381 (4.6e-4); the zeta test ends the PCG loops early from step 45 on in both.  The yardstick is the oracle itself: its two
+    legitimate summation modes (double accumulators, and the serial float order of the reference's CPU mode, cpu_cuda.t:265-301) are 0.4 % apart at the INITIAL cost
+    of this 4-Mpixel instance and 1-6 % over the first twelve steps -- the device stays 5-50 times closer to the double mode than the reference's own CPU order does.
+    Asserted: steps 0-3 to 2e-6 (the 1e-5 corridor holds there), every step inside the oracle's float-vs-double spread where that is known (12 steps) and below 2e-2
+    (twice the measured maximum) throughout, the last ten steps and the final cost to 2e-3, a monotone trajectory."""
     W = H = 2048
     p = syn.shape_from_shading(W, H)
-    prev = orc.set_threads(_host_threads())
-    try:
-        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=8, lIterations=10, use_lm=1)
-        cf, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=8, lIterations=10, use_lm=1, float_sums=1)
-    finally:
-        orc.set_threads(prev)
-    s, dev, costs, final = _solve_gpu_lm("shape_from_shading", (W, H), p, nIterations=8, lIterations=10)
-    m = min(len(costs), len(co), len(cf))
-    assert m >= 8 and len(costs) == len(co), (costs, co)
-    err, spread = np.abs(costs[:m] - co[:m]) / np.abs(co[:m]), np.abs(cf[:m] - co[:m]) / np.abs(co[:m])
-    print("SFS 2048 LM 8x10: rel. cost error per step", err, "oracle float-vs-double order spread", spread, costs[:m])
+    fx, fxf = oracle_fixture("sfs2048_lm_60x10", p), oracle_fixture("sfs2048_lm_float_order_12x10", p)
+    nsteps = 60 if fx is not None else 8
+    if fx is not None and fxf is not None:
+        co, cf = np.array(fx["double"]), np.array(fxf["float_order"])
+    else:           # (inputs do not reproduce the fixture's: the round-3 form of this test, 8 steps live)
+        prev = orc.set_threads(_host_threads())
+        try:
+            co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=8, lIterations=10, use_lm=1)
+            cf, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=8, lIterations=10, use_lm=1, float_sums=1)
+        finally:
+            orc.set_threads(prev)
+    s, dev, costs, final = _solve_gpu_lm("shape_from_shading", (W, H), p, nIterations=nsteps, lIterations=10)
+    assert len(costs) == len(co) == nsteps + 1, (len(costs), len(co))
+    err = np.abs(costs - co) / np.abs(co)
+    mf = min(len(cf), len(co))
+    spread = np.abs(cf[:mf] - co[:mf]) / np.abs(co[:mf])
+    print(f"SFS 2048 LM {nsteps}x10: rel. cost error per step", err, "oracle float-vs-double order spread", spread, "final", costs[-1], co[-1])
     assert (err[:4] <= 2e-6).all(), (err, costs, co)
-    assert (err <= np.maximum(2e-6, 3 * np.maximum.accumulate(spread))).all(), (err, spread)
-    assert costs[m - 1] < 0.2 * costs[0]
+    assert (err[:mf] <= np.maximum(2e-6, np.maximum.accumulate(spread))).all(), (err, spread)
+    assert err.max() <= 2e-2, err
+    assert (np.diff(costs) <= 0).all(), costs
+    if nsteps == 60:
+        assert (err[-10:] <= 2e-3).all() and abs(costs[-1] - co[-1]) <= 2e-3 * co[-1], (err[-10:], costs[-1], co[-1])
+        assert costs[-1] < 0.02 * costs[0]
+    else:
+        assert costs[-1] < 0.2 * costs[0]
 
     p = syn.shape_from_shading(W, H)
-    prev = orc.set_threads(_host_threads())
-    try:
-        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=2, lIterations=10)
-    finally:
-        orc.set_threads(prev)
+    fg = oracle_fixture("sfs2048_gn_2x10", p)
+    if fg is not None:
+        co = np.array(fg["double"])
+    else:
+        prev = orc.set_threads(_host_threads())
+        try:
+            co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=2, lIterations=10)
+        finally:
+            orc.set_threads(prev)
     s, dev, costs, final = _solve_gpu("shape_from_shading", (W, H), p, nIterations=2, lIterations=10)
     ks = s.kernel_stats()
     assert ks["PCGIteration"]["launches"] == 20 and "PCGUpdate" not in ks and "precompute+computeCost" in ks, ks
@@ -646,18 +671,22 @@ def test_bundle_adjustment_ladybug_lm_vs_oracle(torch, orc):
     the first step to 1e-5, later ones within what the summation order alone moves an unconverged PCG on this system."""
     p = syn.bundle_adjustment()
     dims = (p[0].shape[0], p[1].shape[0], p[2].shape[0])
-    prev = orc.set_threads(_host_threads())
-    try:
-        co, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, copy_params(p)).solve(nIterations=5, lIterations=150, use_lm=1)
-        c2, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, copy_params(p)).solve(nIterations=5, lIterations=150, use_lm=1)   # another atomic order
-    finally:
-        orc.set_threads(prev)
+    fx = oracle_fixture("ba_ladybug_lm_5x150", p)       # (round 4: a committed golden vector -- live, the two oracle solves took 96 s of the GPU suite)
+    if fx is not None:
+        co, drift_fx = np.array(fx["double"]), np.array(fx["rerun_spread"])
+    else:
+        prev = orc.set_threads(_host_threads())
+        try:
+            co, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, copy_params(p)).solve(nIterations=5, lIterations=150, use_lm=1)
+            c2, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, copy_params(p)).solve(nIterations=5, lIterations=150, use_lm=1)   # another atomic order
+        finally:
+            orc.set_threads(prev)
     s, dev, costs, final = _solve_gpu_lm("bundle_adjustment", dims, p, nIterations=5, lIterations=150)
     m = min(len(costs), len(co))
     assert m >= 3, (costs, co)
     den = np.maximum(co[:m], 1e-3 * co[0])
     err = np.abs(costs[:m] - co[:m]) / den
-    drift = np.abs(c2[:m] - co[:m]) / den
+    drift = drift_fx[:m] if fx is not None else np.abs(c2[:m] - co[:m]) / den
     print("ladybug LM 5x150: rel. cost error per step", err, "oracle atomic-order drift", drift, "costs", costs[:m])
     assert err[0] < 1e-5 and err[1] < 1e-5, (costs, co)
     assert err.max() <= max(1e-5, 3 * drift.max()), (err, drift, costs, co)       # (measured: 4e-7, the oracle's own atomic-order drift 3e-7)

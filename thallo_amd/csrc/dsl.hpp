@@ -103,11 +103,15 @@ bool run_problem_file(const char* filename, Problem& out, std::string& err, cons
 struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 cost, 1 evalJTF, 2 applyJTJ, 3 applyJ (Jp = J p), 4 applyJt (Ap += J^T Jp), 5 dumpJ (materialize the rows),
                                                                       // 6 evalJTF / 7 applyJTJ in the unknown-wise (gather) form -- present only where gather_ok
 constexpr int GEN_KINDS = 8;
+// one merged gather kernel pair per iteration domain (dsl_codegen.cpp): the member residuals, the (input, channel) targets they write, the kernel names
+struct GenGroup { std::vector<int> domain; std::vector<int> members; std::vector<std::pair<int, int>> targets; std::string jtj, jtf; };
 struct Generated {
     std::string source;                            // one HIP translation unit
     std::vector<GenKernel> kernels;
     std::vector<int> slots_per_row;                // per residual: K, the entries per materialized row
     std::vector<char> gather_ok;                   // per residual: the unknown-wise lowering exists (residual dims == the dims of every unknown it reads, constant-offset stencil accesses)
+    std::vector<char> want_gather;                 // IN (optional): per residual, the caller wants it gathered -- only those join a merged group kernel (empty: every eligible one)
+    std::vector<GenGroup> groups;                  // the merged gather kernels, one pair per iteration domain
     std::vector<long> jp_offset;                   // per residual: offset of its rows in the Jp vector (Jt[Jp] schedule), in units of elements x components
     int n_prm = 0;
     bool has_wide = false;                         // some residual took the wide lowering (more than 48 unknown accesses): the plugin compiles the unit without loop unrolling

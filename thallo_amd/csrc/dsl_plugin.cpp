@@ -68,6 +68,16 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     }
     int kernel_of(int residual, int kind) const { return residual * dsl::GEN_KINDS + kind; }
     std::vector<char> gather_;                     // per residual: the unknown-wise (gather) kernels run (compute_at_output, or the autoscheduler's choice where eligible)
+    // merged gather kernels, one per iteration domain (G.groups): group_of_[ri] = the group residual ri runs in (-1: its own kernel); group_nel_: elements of the domain
+    std::vector<hipFunction_t> grp_jtj, grp_jtf;
+    std::vector<int> group_of_;
+    std::vector<long> group_nel_;
+    bool whole_ = false;                           // ONE group holds every residual and writes every unknown: its applyJTJ stores (no Ap clear, no read-modify-write) and alphaD rides along
+    int launch_fn(hipFunction_t f, int grid, void** args, hipStream_t s)
+    {
+        hipError_t e = hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+        return e == hipSuccess ? 0 : -(int)e;
+    }
     long rows_of(size_t ri) const { return nel[ri] * (long)P.residuals[ri].exprs.size(); }
 
 public:
@@ -91,6 +101,12 @@ public:
             uoff[i] = n_unk; imgs.push_back({ in.slot, px * in.channels }); unknown_input.push_back((int)i); n_unk += px * in.channels;
         }
         std::string err;
+        // which residuals the caller wants gathered (they alone join the merged one-kernel-per-domain gather lowering, dsl_codegen.cpp)
+        G.want_gather.assign(P.residuals.size(), 0);
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            const dsl::Residual& r = P.residuals[ri];
+            G.want_gather[ri] = (r.at_output == 1 || (r.at_output < 0 && autoschedule)) && !r.mat_J && !r.mat_JtJ && !r.mat_Jp;
+        }
         if (!dsl::generate_source(P, G, err, f64_)) { set_error("%s: %s", P.file.c_str(), err.c_str()); return; }
         if (compile()) return;
         // Unknown-wise (gather) lowering per residual: asked for with r.<name>:compute_at_output(true), or -- like the reference's autoscheduler, which every
@@ -104,6 +120,18 @@ public:
             if (r.at_output == 1 && !gather_[ri])
                 fprintf(stderr, "[thallo] warning: %s: residual %s asks for compute_at_output(true) but %s: its residual-wise kernels run\n", label.c_str(), r.name.c_str(),
                         plain ? "has no unknown-wise lowering (it reads an unknown through a Sparse map, or an unknown over other dimensions than its own)" : "also materializes J / JtJ / Jp");
+        }
+        // the merged gather kernels: a group runs when all of its members are gathered (they are: only wanted residuals join a group) -- groups of one included
+        group_of_.assign(P.residuals.size(), -1);
+        for (size_t gi = 0; gi < G.groups.size(); ++gi) {
+            long n = 1; for (int d : G.groups[gi].domain) n *= dimv[d];
+            group_nel_.push_back(n);
+            for (int ri : G.groups[gi].members) if (gather_[(size_t)ri]) group_of_[(size_t)ri] = (int)gi;
+        }
+        {   // one group, every residual in it, every unknown channel among its targets: nothing else ever adds to Ap
+            size_t nch = 0; for (int ui : unknown_input) nch += (size_t)P.inputs[(size_t)ui].channels;
+            whole_ = !f64_ && G.groups.size() == 1 && G.groups[0].members.size() == P.residuals.size() && G.groups[0].targets.size() == nch;
+            for (size_t ri = 0; ri < P.residuals.size(); ++ri) whole_ = whole_ && group_of_[ri] == 0;
         }
         // Ctx layout of the generated code: const void* in[NIN]; int dim[max(NDIM,1)]; float prm[NIN]; long uoff[NIN]
         // (doublePrecision = 1: `float` stands for double in the unit, so prm is an 8-byte-aligned array of doubles)
@@ -244,6 +272,11 @@ public:
             if (hipModuleGetFunction(&f, mod, k.name.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), k.name.c_str()); return -1; }
             fn.push_back(f);
         }
+        for (auto& g : G.groups) {
+            hipFunction_t fa = nullptr, fb = nullptr;
+            if (hipModuleGetFunction(&fa, mod, g.jtj.c_str()) != hipSuccess || hipModuleGetFunction(&fb, mod, g.jtf.c_str()) != hipSuccess) { set_error("%s: generated group kernel %s missing", label.c_str(), g.jtj.c_str()); return -1; }
+            grp_jtj.push_back(fa); grp_jtf.push_back(fb);
+        }
         return 0;
     }
 
@@ -291,7 +324,12 @@ public:
         hipStream_t s = c.stream;
         const size_t bytes = (size_t)v.n_alloc * sizeof(double);
         if (hipMemsetAsync(v.r, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.pre, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
+        for (size_t gi = 0; gi < G.groups.size(); ++gi) {               // merged gather groups first (one launch per iteration domain)
+            double *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
+            const int rc = launch_fn(grp_jtf[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
+        }
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {            // evalJTF: r = -J^T F, pre = diag(J^T J)   (thallo.t:3898-3902)
+            if (group_of_[ri] >= 0) continue;
             double *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
             const int rc = launch(kernel_of((int)ri, gather_[ri] ? 6 : 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
@@ -302,7 +340,12 @@ public:
         TimedLaunch t(c, "PCGStep1");
         hipStream_t s = c.stream;
         if (hipMemsetAsync(Ap, 0, (size_t)v.n_alloc * sizeof(double), s) != hipSuccess) return -1;                     // Ap_X:clear() (gauss_newton.t:1633-1635)
+        for (size_t gi = 0; gi < G.groups.size(); ++gi) {
+            int mode = 0; double* none = nullptr; void* args[] = { ctx.data(), &p, &Ap, &mode, &none };
+            const int rc = launch_fn(grp_jtj[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
+        }
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            if (group_of_[ri] >= 0) continue;
             void* args[] = { ctx.data(), &p, &Ap };
             const int rc = launch(kernel_of((int)ri, gather_[ri] ? 7 : 2), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
@@ -329,7 +372,12 @@ public:
         const size_t bytes = (size_t)v.n_alloc * sizeof(float);
         if (hipMemsetAsync(v.r, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.pre, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.p[cur], 0, bytes, s) != hipSuccess ||
             hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
+        for (size_t gi = 0; gi < G.groups.size(); ++gi) {               // merged gather groups first (one launch per iteration domain)
+            float *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
+            const int rc = launch_fn(grp_jtf[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
+        }
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {            // evalJTF: r = -J^T F, pre = diag(J^T J)   (thallo.t:3898-3902)
+            if (group_of_[ri] >= 0) continue;
             float *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
             const int rc = launch(kernel_of((int)ri, gather_[ri] ? 6 : 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
@@ -360,8 +408,19 @@ public:
         }
         if (sparse_jtj_)                               // one SpMV; alphaD = p . Ap rides along (the count of its partials is the return value)
             return thallo_hip_csr_spmv((int)n_unk, (const int*)sp_rowptr.ptr, (const int*)sp_col.ptr, (const float*)sp_val.ptr, p, Ap, p, out, s);
+        if (whole_) {          // every residual in ONE gather kernel that writes every unknown: Ap is stored, not accumulated (no clear), and alphaD = p . Ap rides along
+            const int g = grid_for(group_nel_[0], THALLO_HIP_MAX_PARTIALS);
+            int mode = 3; void* args[] = { ctx.data(), &p, &Ap, &mode, &out };
+            const int rc = launch_fn(grp_jtj[0], g, args, s);
+            return rc < 0 ? rc : g;
+        }
         if (hipMemsetAsync(Ap, 0, (size_t)n_alloc * sizeof(float), s) != hipSuccess) return -1;                         // Ap_X:clear() (gauss_newton.t:1633-1635)
+        for (size_t gi = 0; gi < G.groups.size(); ++gi) {
+            int mode = 0; float* none = nullptr; void* args[] = { ctx.data(), &p, &Ap, &mode, &none };
+            const int rc = launch_fn(grp_jtj[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
+        }
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            if (group_of_[ri] >= 0) continue;
             const int g = grid_for(nel[ri], 4096);
             if (jval[ri]) {                        // materialized J: no derivative evaluation inside the PCG loop
                 const float* jv = (const float*)jval[ri]->ptr; const int* jc = (const int*)jcol[ri]->ptr; const int K = G.slots_per_row[ri];

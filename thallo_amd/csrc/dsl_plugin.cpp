@@ -256,8 +256,9 @@ public:
         }
         // (a unit with a wide residual -- hundreds of 32-wide dual operations in one function -- takes minutes at -O3 with the loops unrolled: 128 s for the
         //  reference's 17 x 17 deconvolution against 25 s without unrolling)
-        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics", "-fno-unroll-loops" };
-        const hiprtcResult rc = hiprtcCompileProgram(prog, G.has_wide ? 4 : 3, opts);
+        // (-I: under rocprofv3 the runtime compiler does not find its own <hip/hip_runtime.h>)
+        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics", "-I/opt/rocm/include", "-fno-unroll-loops" };
+        const hiprtcResult rc = hiprtcCompileProgram(prog, G.has_wide ? 5 : 4, opts);
         if (rc != HIPRTC_SUCCESS) {
             size_t n = 0; hiprtcGetProgramLogSize(prog, &n); std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
             set_error("%s: hipRTC compilation of the generated kernels failed:\n%.1500s", P.file.c_str(), log.c_str());

@@ -286,6 +286,9 @@ def main():
             finally:
                 os.environ.pop("THALLO_RESIDENT", None)
         out["small_working_sets"] = {f"{w}x{h}": {"resident_loop": small(w, h, True), "launch_per_iteration": small(w, h, False)} for (w, h) in ((512, 512), (2048, 256))}
+        # the 1/4 and 1/2 slabs of the 4- and 2-GPU runs: more rows per wave than the resident kernel's registers hold (R = 10 / 19 > 5) -- one marching launch per iteration
+        for (w, h) in ((2048, 512), (2048, 1024)):
+            out["small_working_sets"][f"{w}x{h}"] = {"resident_loop": None, "launch_per_iteration": small(w, h, False)}
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
         q = syn.image_warping(W, H)

@@ -867,6 +867,68 @@ def test_arap_recomputed_edge_blocks_match_the_stored_ones(torch, orc):
     assert np.abs(runs[1][1] - runs[0][1]).max() <= 1e-4 * max(1.0, np.abs(runs[0][1]).max())
 
 
+@pytest.mark.parametrize("nu,nv,lit", [(320, 320, 100), (150, 120, 30), (40, 30, 40), (16, 12, 25), (37, 29, 13), (5, 4, 6)])
+def test_arap_resident_pcg_loop_is_bitwise_the_launch_per_iteration_form(torch, monkeypatch, nu, nv, lit):
+    """the whole PCG loop of an ARAP Gauss-Newton step in ONE launch (energy_graph.hip k_arap_resident) -- a thread keeps its vertex's r, p, A p, M^-1, delta
+    and the G matrices of its edges in registers, a workgroup keeps p_k of its vertices and of their neighbours in LDS and updates the neighbours' r and p itself; per
+    iteration A p_k goes out as tagged granules together with the workgroup's sums, which go up a two-level tree shaped like the single-launch summation order.  Same
+    vertex -> workgroup map, expressions and summation order as PCGUpdate + applyJTJ per iteration: costs, every alpha_k / beta_k and the unknowns BIT-identical after
+    three GN steps (102,400 vertices = BASELINE config 2's size; meshes whose vertex count is not a multiple of the workgroup size, one smaller than a workgroup, one with
+    more than 64 workgroups but no full second level)."""
+    p = syn.arap_mesh(nu, nv, n_handles=min(8, nu), angle_amp=0.3)
+    dims = (p[2].shape[0], p[6].shape[0])
+    runs = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("THALLO_RESIDENT", resident)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver(dims, thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
+        s.set_solver_parameters(nIterations=3, lIterations=lit)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        names = s.kernel_stats()
+        s.close()
+        runs.append((costs, traces, dev[2].clone(), dev[3].clone(), names))
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == 4 and len(t0[0]) == lit, (c0, thallo_amd.last_error())
+    assert n0.get("PCGLoopResident", {}).get("launches") == 3 and "PCGUpdate" not in n0, n0
+    assert n1.get("PCGUpdate", {}).get("launches") == 3 * lit and "PCGLoopResident" not in n1, n1
+    assert t0 == t1, [(i, k) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1)
+
+
+def test_arap_with_a_scattered_vertex_order_runs_one_launch_per_iteration(torch, orc):
+    """The resident loop stages a workgroup's neighbour vertices in LDS (at most 768 of other workgroups, in at most 16 index intervals: plugins.cpp build_wg_intervals);
+    a mesh whose vertices are numbered at random has its neighbours all over the index space: the plan must fall back to PCGUpdate + applyJTJ per iteration -- and still
+    solve the same problem (the energy does not depend on the numbering)."""
+    p = syn.arap_mesh(60, 40, n_handles=8, angle_amp=0.3)
+    N, E = p[2].shape[0], p[6].shape[0]
+    perm = np.random.default_rng(5).permutation(N)                      # new index of old vertex i = perm[i]
+    inv = np.argsort(perm)
+    q = copy_params(p)
+    for k in (2, 3, 4, 5): q[k] = np.ascontiguousarray(p[k][inv])
+    q[6] = perm[p[6]].astype(p[6].dtype); q[7] = perm[p[7]].astype(p[7].dtype)
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, E), copy_params(q)).solve(nIterations=3, lIterations=30)
+    s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (N, E), q, nIterations=3, lIterations=30)
+    assert rel_err(costs, co) < COST_RTOL, (costs, co)
+    s2 = api.ThalloSolver((N, E), thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
+    s2.set_solver_parameters(nIterations=1, lIterations=5)
+    prm = s2.make_params(to_device(copy_params(q))); s2.init(prm)
+    while s2.step(prm): pass
+    names = s2.kernel_stats(); s2.close()
+    assert "PCGLoopResident" not in names and names.get("PCGUpdate", {}).get("launches") == 5, names
+    # the same mesh in its natural order does take the resident loop
+    s3 = api.ThalloSolver((N, E), thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
+    s3.set_solver_parameters(nIterations=1, lIterations=5)
+    prm = s3.make_params(to_device(copy_params(p))); s3.init(prm)
+    while s3.step(prm): pass
+    names = s3.kernel_stats(); s3.close()
+    assert names.get("PCGLoopResident", {}).get("launches") == 1, names
+
+
 def test_arap_100k_vertices(torch, orc):
     """BASELINE config 3 size: 320x320 torus = 102,400 vertices / 614,400 directed edges."""
     p = syn.arap_mesh(320, 320)

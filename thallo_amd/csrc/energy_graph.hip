@@ -22,6 +22,7 @@
 //   incoming edges: F_e or (G_e, p_A(src), p_P(src)) (gather)
 // ~100k vertices / 600k edges = a 13 MB working set: L2/Infinity-Cache resident, latency-bound
 // (SURVEY.md 8d), so the kernels are one-thread-per-vertex with everything else kept simple.
+#include <cstring>
 #include "device_common.hpp"
 #include "../../include/thallo_hip.h"
 
@@ -479,6 +480,341 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply_rc(int N, int n0, int n1, 
     else block_store_partial(acc, aD_out, red);
 }
 
+// ------------------------------------------------------------------------------------------ the whole PCG loop of a Gauss-Newton step in ONE launch (round 4)
+// ARAP at 100k vertices is a 10 MB state walked by two latency-bound launches per PCG iteration (the flat vector update 7.6 us + the gather 13 us + their
+// boundaries = 19.5 us).  Here one thread keeps its vertex's r, p, A p, M^-1, delta -- and the G matrices of its edges, which a Gauss-Newton step does not change --
+// in registers for all L iterations (the idea of energy_image_warping_resident.hip on an index-list domain), and an iteration has ONE hand-over
+// between workgroups.  What this chip makes of a hand-over: an agent-scope access goes past the XCD's L2 to the fabric, ~1.5-2 us each way, so "store, then the
+// reader's poll sees it" is ~5 us however little is handed over (phase stamps, tools/arap_resident_probe.py), and 400 workgroups polling 400 records each is
+// volume-bound on top (10 us with one 16-byte request per lane and record part).  The first two versions of this kernel had two hand-overs per iteration (p_k to the
+// neighbours, the sums to everybody) and were no faster than two launches (24.9 and 19.3 us per iteration).  Hence:
+//   * same vertex -> (workgroup, thread) map as the launch-per-iteration kernels (vertex n = 256 b + t), so a workgroup's partial sums are the same numbers;
+//     every workgroup must be RESIDENT (they wait for each other): the host checks what the device can hold (2 workgroups per CU);
+//   * a workgroup keeps p_k of its own vertices AND of the vertices they share an edge with ("ghosts": a host-built list of index intervals, at most ARAP_RES_GHOSTS
+//     vertices, else the plan runs one launch per iteration) in LDS, and r, M^-1 of the ghosts too: it updates the ghosts' r and p itself, with the owner's
+//     expressions on the owner's inputs (bit-identical), and all it needs from the owner is A p_k at the ghost -- which goes out TOGETHER with the workgroup's
+//     sums: A p_k as {value | tag} granules (write-through sc1 stores: the data is the flag, nothing to drain), the {alphaD | N, S1, S2} record as four tagged
+//     16-byte parts in part-major order (a wave's load of one part of 64 records is 1 KB of whole lines);
+//   * the sums go up a two-level tree shaped like load_iteration_sums' order (lane l adds partials l, l + 64, ... ascending, then the butterflies): workgroup l < 64
+//     adds the records l, l + 64, ... into "lane record" l, and wave 0 of every workgroup reads the <= 64 lane records and runs the butterflies -- bit-identical
+//     alpha_k / beta_k everywhere.  (Every workgroup sweeping every record is W^2 fabric requests per poll round: 11 us of an iteration at 400 workgroups, 1 us at 25);
+//   * both are double-buffered by the iteration's parity: a workgroup publishes iteration k + 2 only after it has every record of k + 1, which a reader writes
+//     after it is through with k.
+// Every wait is bounded (2 s; an error word, later waits fall through, the host reports it at the next cost evaluation).  Bit-identical to PCGUpdate + applyJTJ per
+// iteration (Plan::step_gn_expanded): same expressions (this file is built with -ffp-contract=on; the flat update's fmas are spelled out), same summation order.
+// Replaces the loop of gauss_newton.t:1615-1687 for this plugin.
+constexpr int ARAP_RES_GHOSTS = 768;                      // vertices of other workgroups a workgroup may share edges with
+constexpr int ARAP_RES_SPAN = ARAP_RES_GHOSTS + BLOCK;    // staged vertices: LDS 2 parts x 3 floats each
+constexpr int ARAP_RES_COPIES = 8;                        // copies of the lane records (a reader takes copy workgroup % 8: its XCD's, with round-robin placement)
+constexpr int ARAP_RES_SEGS = 16;                         // index intervals the staged set may consist of
+constexpr int ARAP_RES_SEGW = 4 + 2 * ARAP_RES_SEGS;      // ints per workgroup in the exchange memory: {count, -, -, -, lo_0, hi_0, lo_1, hi_1, ...}
+enum { ARES_SEQ = 0, ARES_ERR = 1, ARES_SPIN_MS = 2, ARES_PM = 4, ARES_CTL_WORDS = 16 };
+typedef unsigned long long u64r;
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_r;
+__device__ __forceinline__ rsrc_r ares_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffffu, 0x00020000); }
+struct ArapResArgs {
+    int N, nwg, L; long ell;
+    const int *out_ptr, *out_v1, *in_ptr, *in_src;
+    const float *Cn, *O, *SC; float wf, wr;
+    float *r, *Ap; const float* pre; float *p0, *p1, *delta;      // p_{L-1} ends in p[L & 1] like behind L launches of the flat update (p0 = the plan's p[0]: zeros at the start)
+    thallo_sum_t aN0; float* words;
+    u64r* rec;            // [2 parity][4 parts][nwg] x 16 bytes
+    u64r* lrec;           // [2 parity][ARAP_RES_COPIES][4 parts][64] x 16 bytes: the lane records (every workgroup reads all 64: copies spread the readers)
+    u64r* ag;             // [2 parity][2 parts: Position, Angle][N][3] granules of A p_k
+    const int* wseg;      // [nwg][ARAP_RES_SEGW]: the index intervals that hold the workgroup's vertices and their neighbours
+    unsigned* ctl;
+};
+struct ASpin { unsigned n; long long t0; };
+__device__ __forceinline__ bool ares_spin_fail(ASpin& sp, unsigned* ctl, unsigned what, unsigned idx, unsigned tag)
+{   // bounded wait bookkeeping (as energy_image_warping_resident.hip: spin_fail): true = give up
+    __builtin_amdgcn_s_sleep(1);
+    if (((++sp.n) & 63u) != 0u) return false;
+    if (__hip_atomic_load(ctl + ARES_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+    const long long now = wall_clock64();
+    if (sp.t0 == 0) { sp.t0 = now; return false; }
+    const unsigned ms = __hip_atomic_load(ctl + ARES_SPIN_MS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long bound = ms ? (long long)ms * 100000LL : 2LL * 100000000LL;        // default: 2 s of the 100 MHz wall clock
+    if (now - sp.t0 <= bound) return false;
+    if (__hip_atomic_exchange(ctl + ARES_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        unsigned* pm = ctl + ARES_PM; pm[0] = what; pm[1] = blockIdx.x; pm[2] = threadIdx.x; pm[3] = idx; pm[4] = tag;
+    }
+    return true;
+}
+__global__ void k_arap_res_begin(unsigned* ctl, unsigned L) { if (threadIdx.x == 0) ctl[ARES_SEQ] += L + 2u; }       // tags of this launch: seq + 1 .. seq + L (never 0, never an earlier launch's)
+
+#ifdef ARAP_STAMPS            // research builds only (tools/arap_resident_probe.py): phase stamps of iteration 10, workgroups 0 and 200, into the control words
+#define ASTAMP(i) do { if (k == 10 && tid == 0 && (wg == 0 || wg == 200)) a.ctl[16 + (wg ? 12 : 0) + (i)] = (unsigned)wall_clock64(); } while (0)
+static void* g_arap_dbg_xbuf = nullptr;
+extern "C" void* thallo_hip_arap_debug_last_xbuf(void) { return g_arap_dbg_xbuf; }
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+struct G8 { float a, b, c, d, e, f, g, h; };          // gcols' three columns without the constant zero: g0 = (a, b, c), g1 = (d, e, f), g2 = (g, h, 0)
+template <int MD>
+__global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
+{
+    constexpr int GH = ARAP_RES_GHOSTS / BLOCK;                       // ghosts a thread looks after
+    __shared__ float4 lp[2 * ARAP_RES_SPAN];                          // [2 parts][span]: p_k of the staged vertices (slot order; one 16-byte read per neighbour)
+    __shared__ float gr[6 * ARAP_RES_GHOSTS], gm[6 * ARAP_RES_GHOSTS]; // [6 components][ghost]: r_k and M^-1 of the ghosts
+    __shared__ int s_vid[ARAP_RES_SPAN];                              // staged slot -> vertex
+    __shared__ int s_seg[ARAP_RES_SEGW];
+    __shared__ float red[16];
+    __shared__ double redd[3 * BLOCK / 64];
+    __shared__ float s_tot_f; __shared__ double s_tot[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    const int N = a.N, n = wg * BLOCK + tid;
+    const bool live = n < N;
+    const int nc = live ? n : 0;                                     // (threads past the last vertex run on vertex 0's data and contribute nothing)
+    const float wr2 = a.wr * a.wr;
+    const rsrc_r RREC = ares_rsrc(a.rec), RLREC = ares_rsrc(a.lrec), RAG = ares_rsrc(a.ag);
+    const int nlane = min(64, a.nwg);                                // lane records in use
+    if (tid < ARAP_RES_SEGW) s_seg[tid] = a.wseg[(long)ARAP_RES_SEGW * wg + tid];
+    __syncthreads();
+    const int nseg = s_seg[0];
+    int span = 0;
+    for (int s = 0; s < nseg; ++s) span += s_seg[5 + 2 * s] - s_seg[4 + 2 * s];
+    auto slot_of = [&](int v) { int base = 0; for (int s = 0; s < nseg; ++s) { const int l = s_seg[4 + 2 * s], h = s_seg[5 + 2 * s]; if (v >= l && v < h) return base + (v - l); base += h - l; } return 0; };
+    for (int u = tid; u < span; u += BLOCK) {
+        int base = 0, v = 0;
+        for (int s = 0; s < nseg; ++s) { const int l = s_seg[4 + 2 * s], h = s_seg[5 + 2 * s]; if (u >= base && u < base + (h - l)) v = l + (u - base); base += h - l; }
+        s_vid[u] = v;
+    }
+    const int own_s = slot_of(wg * BLOCK), nown = min(BLOCK, N - wg * BLOCK), nghost = span - nown;       // my workgroup's vertices are consecutive slots
+    // the vertex's constants: where its neighbours are staged, the G matrices of its edges (k_arap_apply_rc's expressions, evaluated once), the fit flag
+    const int deg = live ? a.out_ptr[nc + 1] - a.out_ptr[nc] : 0, ideg = live ? a.in_ptr[nc + 1] - a.in_ptr[nc] : 0;
+    const f3 on = ld3(a.O, nc), sn = ld3(a.SC, nc), cn = ld3(a.SC, (long)N + nc);
+    const DRot dn = drot(sn, cn);
+    int qo[MD], qi[MD]; G8 go[MD], gi[MD];
+#pragma unroll
+    for (int j = 0; j < MD; ++j) {
+        const long k = (long)j * N + nc;
+        const int vo = j < deg ? a.out_v1[k] : nc, vi = j < ideg ? a.in_src[k] : nc;
+        qo[j] = slot_of(vo); qi[j] = slot_of(vi);
+        {
+            const f3 om = ld3(a.O, vo);
+            f3 dv; dv.x = on.x - om.x; dv.y = on.y - om.y; dv.z = on.z - om.z;
+            f3 g0, g1, g2; gcols(dn, dv, g0, g1, g2);
+            go[j].a = g0.x; go[j].b = g0.y; go[j].c = g0.z; go[j].d = g1.x; go[j].e = g1.y; go[j].f = g1.z; go[j].g = g2.x; go[j].h = g2.y;
+        }
+        {
+            const f3 om = ld3(a.O, vi);
+            const DRot dm = drot(ld3(a.SC, vi), ld3(a.SC, (long)N + vi));
+            f3 dv; dv.x = om.x - on.x; dv.y = om.y - on.y; dv.z = om.z - on.z;
+            f3 g0, g1, g2; gcols(dm, dv, g0, g1, g2);
+            gi[j].a = g0.x; gi[j].b = g0.y; gi[j].c = g0.z; gi[j].d = g1.x; gi[j].e = g1.y; gi[j].f = g1.z; gi[j].g = g2.x; gi[j].h = g2.y;
+        }
+    }
+    const int qn = own_s + tid;
+    const bool fit = a.Cn[3 * nc] >= -999999.9f;
+    // the solver state of the vertex; p_0 = M^-1 r_0 + 0 p (PCGUpdate's expression with alpha = beta = 0), for the ghosts too
+    f3 rp = ld3(a.r, nc), ra = ld3(a.r, (long)N + nc), pp = ld3(a.p0, nc), pa = ld3(a.p0, (long)N + nc);
+    const f3 mp = ld3(a.pre, nc), ma = ld3(a.pre, (long)N + nc);
+    f3 dp = ld3(a.delta, nc), da = ld3(a.delta, (long)N + nc);
+    f3 ap = { 0.f, 0.f, 0.f }, aa = { 0.f, 0.f, 0.f };
+    float an = sum_partials(a.aN0.partials, a.aN0.count);
+    __syncthreads();                                                  // (s_vid)
+    {
+        pp.x = __builtin_fmaf(0.0f, pp.x, rp.x * mp.x); pp.y = __builtin_fmaf(0.0f, pp.y, rp.y * mp.y); pp.z = __builtin_fmaf(0.0f, pp.z, rp.z * mp.z);
+        pa.x = __builtin_fmaf(0.0f, pa.x, ra.x * ma.x); pa.y = __builtin_fmaf(0.0f, pa.y, ra.y * ma.y); pa.z = __builtin_fmaf(0.0f, pa.z, ra.z * ma.z);
+        if (live) { lp[qn] = make_float4(pp.x, pp.y, pp.z, 0.0f); lp[ARAP_RES_SPAN + qn] = make_float4(pa.x, pa.y, pa.z, 0.0f); }
+#pragma unroll
+        for (int h = 0; h < GH; ++h) {
+            const int g = tid + h * BLOCK;
+            if (g < nghost) {
+                const int u = g < own_s ? g : g + nown, v = s_vid[u];
+                const f3 r0 = ld3(a.r, v), r1 = ld3(a.r, (long)N + v), m0 = ld3(a.pre, v), m1 = ld3(a.pre, (long)N + v), z0 = ld3(a.p0, v), z1 = ld3(a.p0, (long)N + v);
+                gr[g] = r0.x; gr[ARAP_RES_GHOSTS + g] = r0.y; gr[2 * ARAP_RES_GHOSTS + g] = r0.z; gr[3 * ARAP_RES_GHOSTS + g] = r1.x; gr[4 * ARAP_RES_GHOSTS + g] = r1.y; gr[5 * ARAP_RES_GHOSTS + g] = r1.z;
+                gm[g] = m0.x; gm[ARAP_RES_GHOSTS + g] = m0.y; gm[2 * ARAP_RES_GHOSTS + g] = m0.z; gm[3 * ARAP_RES_GHOSTS + g] = m1.x; gm[4 * ARAP_RES_GHOSTS + g] = m1.y; gm[5 * ARAP_RES_GHOSTS + g] = m1.z;
+                lp[u] = make_float4(__builtin_fmaf(0.0f, z0.x, r0.x * m0.x), __builtin_fmaf(0.0f, z0.y, r0.y * m0.y), __builtin_fmaf(0.0f, z0.z, r0.z * m0.z), 0.0f);
+                lp[ARAP_RES_SPAN + u] = make_float4(__builtin_fmaf(0.0f, z1.x, r1.x * m1.x), __builtin_fmaf(0.0f, z1.y, r1.y * m1.y), __builtin_fmaf(0.0f, z1.z, r1.z * m1.z), 0.0f);
+            }
+        }
+    }
+    const unsigned seq0 = a.ctl[ARES_SEQ];
+    ASpin sp = { 0u, 0 };
+    bool dead = false;                                                // a bounded wait ran out (here or elsewhere): fall through to the end
+    __syncthreads();
+    for (int k = 0; k < a.L; ++k) {
+        const unsigned tag = seq0 + (unsigned)k + 1u;
+        const unsigned par = (unsigned)(k & 1);
+        ASTAMP(0);
+        // ---- J^T J p_k at my vertex (k_arap_apply_rc, expression for expression; the neighbours' p from LDS, the G matrices from registers)
+        ap.x = 0.f; ap.y = 0.f; ap.z = 0.f; aa.x = 0.f; aa.y = 0.f; aa.z = 0.f;
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            const float4 t4 = lp[qo[j]]; f3 pm; pm.x = t4.x; pm.y = t4.y; pm.z = t4.z;
+            f3 g0, g1, g2; g0.x = go[j].a; g0.y = go[j].b; g0.z = go[j].c; g1.x = go[j].d; g1.y = go[j].e; g1.z = go[j].f; g2.x = go[j].g; g2.y = go[j].h; g2.z = 0.0f;
+            const float jx = (pp.x - pm.x) - (g0.x * pa.x + g1.x * pa.y + g2.x * pa.z);
+            const float jy = (pp.y - pm.y) - (g0.y * pa.x + g1.y * pa.y + g2.y * pa.z);
+            const float jz = (pp.z - pm.z) - (g0.z * pa.x + g1.z * pa.y + g2.z * pa.z);
+            if (j < deg) {
+                ap.x += jx; ap.y += jy; ap.z += jz;
+                aa.x -= g0.x * jx + g0.y * jy + g0.z * jz;
+                aa.y -= g1.x * jx + g1.y * jy + g1.z * jz;
+                aa.z -= g2.x * jx + g2.y * jy + g2.z * jz;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MD; ++j) {
+            const float4 t4 = lp[qi[j]], u4 = lp[ARAP_RES_SPAN + qi[j]]; f3 pm, am; pm.x = t4.x; pm.y = t4.y; pm.z = t4.z; am.x = u4.x; am.y = u4.y; am.z = u4.z;
+            f3 g0, g1, g2; g0.x = gi[j].a; g0.y = gi[j].b; g0.z = gi[j].c; g1.x = gi[j].d; g1.y = gi[j].e; g1.z = gi[j].f; g2.x = gi[j].g; g2.y = gi[j].h; g2.z = 0.0f;
+            if (j < ideg) {
+                ap.x -= (pm.x - pp.x) - (g0.x * am.x + g1.x * am.y + g2.x * am.z);
+                ap.y -= (pm.y - pp.y) - (g0.y * am.x + g1.y * am.y + g2.y * am.z);
+                ap.z -= (pm.z - pp.z) - (g0.z * am.x + g1.z * am.y + g2.z * am.z);
+            }
+        }
+        ap.x *= wr2; ap.y *= wr2; ap.z *= wr2; aa.x *= wr2; aa.y *= wr2; aa.z *= wr2;
+        if (fit) { ap.x += a.wf * a.wf * pp.x; ap.y += a.wf * a.wf * pp.y; ap.z += a.wf * a.wf * pp.z; }
+        // ---- A p_k out: tagged granules for the workgroups that have my vertex as a ghost
+        if (live) {
+            const unsigned o0 = 24u * (unsigned)n + 48u * par * (unsigned)N, o1 = o0 + 24u * (unsigned)N;
+            u32x4r d; u32x2r e;
+            d.x = __float_as_uint(ap.x); d.y = tag; d.z = __float_as_uint(ap.y); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, RAG, o0, 0, 16);
+            e.x = __float_as_uint(ap.z); e.y = tag;                                        __builtin_amdgcn_raw_buffer_store_b64(e, RAG, o0 + 16u, 0, 16);
+            d.x = __float_as_uint(aa.x); d.y = tag; d.z = __float_as_uint(aa.y); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, RAG, o1, 0, 16);
+            e.x = __float_as_uint(aa.z); e.y = tag;                                        __builtin_amdgcn_raw_buffer_store_b64(e, RAG, o1 + 16u, 0, 16);
+        }
+        ASTAMP(1);
+        // ---- the workgroup's sums (block_finish_sums' arithmetic) as one record of four tagged parts
+        float acc = 0.0f; Sums3 sm;
+        if (live) {
+            acc += pp.x * ap.x + pp.y * ap.y + pp.z * ap.z + pa.x * aa.x + pa.y * aa.y + pa.z * aa.z;
+            sm.add(mp.x, rp.x, ap.x); sm.add(mp.y, rp.y, ap.y); sm.add(mp.z, rp.z, ap.z);
+            sm.add(ma.x, ra.x, aa.x); sm.add(ma.y, ra.y, aa.y); sm.add(ma.z, ra.z, aa.z);
+        }
+        {
+            const float wa = wave_sum_all(acc);
+            const double w0 = wave_sum_all_f64(sm.n), w1 = wave_sum_all_f64(sm.s1), w2 = wave_sum_all_f64(sm.s2);
+            if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
+            lds_barrier();
+            if (tid == 0) {
+                float sa = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+                for (int w = 0; w < BLOCK / 64; ++w) { sa += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
+                const u64r q0 = (u64r)__double_as_longlong(b0), q1 = (u64r)__double_as_longlong(b1), q2 = (u64r)__double_as_longlong(b2);
+                const unsigned off = 16u * (unsigned)(4u * par * (unsigned)a.nwg + (unsigned)wg), ps = 16u * (unsigned)a.nwg;
+                u32x4r d;
+                d.x = __float_as_uint(sa); d.y = tag; d.z = (unsigned)(q0 >> 32); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, RREC, off, 0, 16);
+                d.x = (unsigned)q0; d.y = tag; d.z = (unsigned)(q1 >> 32); d.w = tag;        __builtin_amdgcn_raw_buffer_store_b128(d, RREC, off + ps, 0, 16);
+                d.x = (unsigned)q1; d.y = tag; d.z = (unsigned)(q2 >> 32); d.w = tag;        __builtin_amdgcn_raw_buffer_store_b128(d, RREC, off + 2u * ps, 0, 16);
+                d.x = (unsigned)q2; d.y = tag; d.z = 0u; d.w = tag;                          __builtin_amdgcn_raw_buffer_store_b128(d, RREC, off + 3u * ps, 0, 16);
+            }
+        }
+        ASTAMP(2);
+        // ---- the sums' tree.  A record / lane record is four 16-byte parts {alphaD, tag, N.hi, tag} {N.lo, tag, S1.hi, tag} {S1.lo, tag, S2.hi, tag} {S2.lo, tag, 0, tag}.
+        auto poll4 = [&](const rsrc_r& R, unsigned off, unsigned ps, unsigned what, unsigned idx, float& v_ad, double& v0, double& v1, double& v2) {
+            for (;;) {
+                const u32x4r g0 = __builtin_amdgcn_raw_buffer_load_b128(R, off, 0, 16), g1 = __builtin_amdgcn_raw_buffer_load_b128(R, off + ps, 0, 16);
+                const u32x4r g2 = __builtin_amdgcn_raw_buffer_load_b128(R, off + 2u * ps, 0, 16), g3 = __builtin_amdgcn_raw_buffer_load_b128(R, off + 3u * ps, 0, 16);
+                if (g0.y == tag && g0.w == tag && g1.y == tag && g1.w == tag && g2.y == tag && g2.w == tag && g3.y == tag) {
+                    v_ad = __uint_as_float(g0.x);
+                    v0 = __longlong_as_double((long long)(((u64r)g0.z << 32) | (u64r)g1.x));
+                    v1 = __longlong_as_double((long long)(((u64r)g1.z << 32) | (u64r)g2.x));
+                    v2 = __longlong_as_double((long long)(((u64r)g2.z << 32) | (u64r)g3.x));
+                    return;
+                }
+                if (ares_spin_fail(sp, a.ctl, what, idx, tag)) { dead = true; return; }
+            }
+        };
+        auto store4 = [&](const rsrc_r& R, unsigned off, unsigned ps, float sa, double b0, double b1, double b2) {
+            const u64r q0 = (u64r)__double_as_longlong(b0), q1 = (u64r)__double_as_longlong(b1), q2 = (u64r)__double_as_longlong(b2);
+            u32x4r d;
+            d.x = __float_as_uint(sa); d.y = tag; d.z = (unsigned)(q0 >> 32); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, R, off, 0, 16);
+            d.x = (unsigned)q0; d.y = tag; d.z = (unsigned)(q1 >> 32); d.w = tag;        __builtin_amdgcn_raw_buffer_store_b128(d, R, off + ps, 0, 16);
+            d.x = (unsigned)q1; d.y = tag; d.z = (unsigned)(q2 >> 32); d.w = tag;        __builtin_amdgcn_raw_buffer_store_b128(d, R, off + 2u * ps, 0, 16);
+            d.x = (unsigned)q2; d.y = tag; d.z = 0u; d.w = tag;                          __builtin_amdgcn_raw_buffer_store_b128(d, R, off + 3u * ps, 0, 16);
+        };
+        if (wave == 0) {
+            // level 1 (workgroups 0 .. 63): lane j takes record wg + 64 j; lane 0 adds them up ascending from zero, as lane `wg` of load_iteration_sums does
+            if (wg < 64) {
+                float v_ad = 0.0f; double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+                const int i = wg + 64 * lane;
+                if (lane < 8 && i < a.nwg && !dead) poll4(RREC, 16u * (unsigned)(4u * par * (unsigned)a.nwg + (unsigned)i), 16u * (unsigned)a.nwg, 2u, (unsigned)i, v_ad, v0, v1, v2);
+                float t = 0.0f; double x = 0.0, y = 0.0, z = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float fj = __shfl(v_ad, j); const double x0 = __shfl(v0, j), x1 = __shfl(v1, j), x2 = __shfl(v2, j);
+                    if (wg + 64 * j < a.nwg) { t += fj; x += x0; y += x1; z += x2; }
+                }
+                if (lane < ARAP_RES_COPIES) store4(RLREC, 16u * (unsigned)(4u * 64u * (par * ARAP_RES_COPIES + (unsigned)lane) + (unsigned)wg), 16u * 64u, t, x, y, z);
+            }
+            // level 2 (every workgroup): lane l takes lane record l; the butterflies of load_iteration_sums
+            float t = 0.0f; double x = 0.0, y = 0.0, z = 0.0;
+            if (lane < nlane && !dead) poll4(RLREC, 16u * (unsigned)(4u * 64u * (par * ARAP_RES_COPIES + (unsigned)(wg % ARAP_RES_COPIES)) + (unsigned)lane), 16u * 64u, 3u, (unsigned)lane, t, x, y, z);
+            const float ad_ = wave_sum_all(t); const double n_ = wave_sum_all_f64(x), s1_ = wave_sum_all_f64(y), s2_ = wave_sum_all_f64(z);
+            if (lane == 0) { s_tot_f = ad_; s_tot[0] = n_; s_tot[1] = s1_; s_tot[2] = s2_; }
+        }
+        ASTAMP(3);
+        __syncthreads();
+        ASTAMP(4);
+        // ---- my ghosts' A p_k: the loads go out now -- every workgroup has published (an earlier first look is mostly stale and doubles the fabric traffic, which is
+        //      what this loop is bound by: 9 us of waiting at 400 workgroups) -- and are looked at after my own vertex's update
+        u32x4r xa[GH], ya[GH]; u32x2r xb[GH], yb[GH]; unsigned of[GH];
+#pragma unroll
+        for (int h = 0; h < GH; ++h) {
+            const int g = tid + h * BLOCK;
+            const int v = g < nghost ? s_vid[g < own_s ? g : g + nown] : 0;
+            of[h] = (g >= nghost || dead) ? 0xffffffffu : 24u * (unsigned)v + 48u * par * (unsigned)N;
+            if (of[h] != 0xffffffffu) {
+                xa[h] = __builtin_amdgcn_raw_buffer_load_b128(RAG, of[h], 0, 16); xb[h] = __builtin_amdgcn_raw_buffer_load_b64(RAG, of[h] + 16u, 0, 16);
+                ya[h] = __builtin_amdgcn_raw_buffer_load_b128(RAG, of[h] + 24u * (unsigned)N, 0, 16); yb[h] = __builtin_amdgcn_raw_buffer_load_b64(RAG, of[h] + 24u * (unsigned)N + 16u, 0, 16);
+            }
+        }
+        const float ad = s_tot_f; const double qn_ = s_tot[0], q1 = s_tot[1], q2 = s_tot[2];
+        const float al = safe_div<false>(an, ad);
+        double bn = qn_ - 2.0 * (double)al * q1 + (double)al * (double)al * q2;
+        if (!(bn > 0.0)) bn = 0.0;
+        const float bnf = (float)bn;
+        if (wg == 0 && tid == 0) { a.words[2 * k] = ad; a.words[2 * k + 1] = bnf; }
+        const float beta = safe_div<false>(bnf, an);
+        an = bnf;
+        ASTAMP(5);
+        // ---- PCGUpdate for iteration k + 1 (pcg_kernels.hip: k_pcg_update, expression for expression): r -= alpha A p ; delta += alpha p ; p = M^-1 r + beta p --
+        //      at my vertex, and at my ghosts from their owners' A p_k
+        if (k + 1 < a.L) {
+            rp.x = __builtin_fmaf(-al, ap.x, rp.x); rp.y = __builtin_fmaf(-al, ap.y, rp.y); rp.z = __builtin_fmaf(-al, ap.z, rp.z);
+            ra.x = __builtin_fmaf(-al, aa.x, ra.x); ra.y = __builtin_fmaf(-al, aa.y, ra.y); ra.z = __builtin_fmaf(-al, aa.z, ra.z);
+            dp.x = __builtin_fmaf(al, pp.x, dp.x); dp.y = __builtin_fmaf(al, pp.y, dp.y); dp.z = __builtin_fmaf(al, pp.z, dp.z);
+            da.x = __builtin_fmaf(al, pa.x, da.x); da.y = __builtin_fmaf(al, pa.y, da.y); da.z = __builtin_fmaf(al, pa.z, da.z);
+            const float zx = rp.x * mp.x, zy = rp.y * mp.y, zz = rp.z * mp.z, wx = ra.x * ma.x, wy = ra.y * ma.y, wz = ra.z * ma.z;
+            pp.x = __builtin_fmaf(beta, pp.x, zx); pp.y = __builtin_fmaf(beta, pp.y, zy); pp.z = __builtin_fmaf(beta, pp.z, zz);
+            pa.x = __builtin_fmaf(beta, pa.x, wx); pa.y = __builtin_fmaf(beta, pa.y, wy); pa.z = __builtin_fmaf(beta, pa.z, wz);
+            if (live) { lp[qn] = make_float4(pp.x, pp.y, pp.z, 0.0f); lp[ARAP_RES_SPAN + qn] = make_float4(pa.x, pa.y, pa.z, 0.0f); }
+#pragma unroll
+            for (int h = 0; h < GH; ++h) {
+                if (of[h] == 0xffffffffu) continue;
+                while (!(xa[h].y == tag && xa[h].w == tag && xb[h].y == tag && ya[h].y == tag && ya[h].w == tag && yb[h].y == tag)) {
+                    if (ares_spin_fail(sp, a.ctl, 1u, (of[h] - 48u * par * (unsigned)N) / 24u, tag)) { dead = true; break; }
+                    xa[h] = __builtin_amdgcn_raw_buffer_load_b128(RAG, of[h], 0, 16); xb[h] = __builtin_amdgcn_raw_buffer_load_b64(RAG, of[h] + 16u, 0, 16);
+                    ya[h] = __builtin_amdgcn_raw_buffer_load_b128(RAG, of[h] + 24u * (unsigned)N, 0, 16); yb[h] = __builtin_amdgcn_raw_buffer_load_b64(RAG, of[h] + 24u * (unsigned)N + 16u, 0, 16);
+                }
+                const int g = tid + h * BLOCK, u = g < own_s ? g : g + nown;
+                const float av[6] = { __uint_as_float(xa[h].x), __uint_as_float(xa[h].z), __uint_as_float(xb[h].x), __uint_as_float(ya[h].x), __uint_as_float(ya[h].z), __uint_as_float(yb[h].x) };
+                const float4 p0 = lp[u], p1 = lp[ARAP_RES_SPAN + u];
+                float pv[6] = { p0.x, p0.y, p0.z, p1.x, p1.y, p1.z };
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float rn = __builtin_fmaf(-al, av[c], gr[c * ARAP_RES_GHOSTS + g]);
+                    gr[c * ARAP_RES_GHOSTS + g] = rn;
+                    pv[c] = __builtin_fmaf(beta, pv[c], rn * gm[c * ARAP_RES_GHOSTS + g]);
+                }
+                lp[u] = make_float4(pv[0], pv[1], pv[2], 0.0f); lp[ARAP_RES_SPAN + u] = make_float4(pv[3], pv[4], pv[5], 0.0f);
+            }
+        }
+        dead = dead || __hip_atomic_load(a.ctl + ARES_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        ASTAMP(6);
+        __syncthreads();                                                // (p_{k+1} of every staged vertex is in LDS; the staging arrays are free again)
+        ASTAMP(7);
+    }
+    if (live) {
+        float* pl = (a.L & 1) ? a.p1 : a.p0;                            // p_{L-1}: where L launches of the flat update leave it
+        st3(pl, n, pp); st3(pl, (long)N + n, pa);
+        st3(a.r, n, rp); st3(a.r, (long)N + n, ra); st3(a.Ap, n, ap); st3(a.Ap, (long)N + n, aa); st3(a.delta, n, dp); st3(a.delta, (long)N + n, da);
+    }
+}
+
 int g_arap_unrolled = 1;       // tools / tests: 0 = the loop form for every layout
 int g_arap_recompute = 1;      // tools / tests: 0 = read the stored G planes (round 2's kernels)
 
@@ -563,6 +899,67 @@ int thallo_hip_arap_apply_jtj_rc(int N, int n0, int n1, const int* out_ptr, cons
     if (ell_stride / N <= 6) hipLaunchKernelGGL(k_arap_apply_rc<6>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_src, constraints, original, SC, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
     else                     hipLaunchKernelGGL(k_arap_apply_rc<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_src, constraints, original, SC, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
     int e = check_launch(); return e ? e : grid;
+}
+/* ---- the resident PCG loop (k_arap_resident): exchange memory layout [control words 256 B | lane records 2 x ARAP_RES_COPIES x 4 x 64 x 16 B | records 2 x 4 x nwg x 16 B | intervals nwg x ARAP_RES_SEGW ints | A p granules 2 x 2 x N x 3 x 8 B] */
+static inline int ares_nwg(int N) { return (N + BLOCK - 1) / BLOCK; }
+static inline long ares_off_lrec() { return 256; }
+static inline long ares_off_rec() { return 256 + 8192L * ARAP_RES_COPIES; }
+static inline long ares_off_range(int nwg) { return ares_off_rec() + 128L * nwg; }
+static inline long ares_off_pg(int nwg) { return (ares_off_range(nwg) + 4L * ARAP_RES_SEGW * nwg + 255) / 256 * 256; }
+long thallo_hip_arap_resident_bytes(int N) { if (N < 1) return 0; const int nwg = ares_nwg(N); return ares_off_pg(nwg) + 96L * N + 256; }
+long thallo_hip_arap_resident_intervals_offset(int N) { return N < 1 ? -1 : ares_off_range(ares_nwg(N)); }
+int thallo_hip_arap_resident_max_ghosts(void) { return ARAP_RES_GHOSTS; }
+int thallo_hip_arap_resident_max_intervals(void) { return ARAP_RES_SEGS; }
+/* 1: the shape can run the resident loop -- the ELL layout with at most 6 edge slots, the recomputing applyJTJ, and every workgroup resident at once
+ * (the staged sets are the caller's to check: at most thallo_hip_arap_resident_max_intervals() index intervals, at most thallo_hip_arap_resident_max_ghosts() vertices of other workgroups) */
+int thallo_hip_arap_resident_fits(int N, long ell_stride)
+{
+    if (!thallo_hip_arap_recompute_supported(N, ell_stride)) return 0;
+    const int nwg = ares_nwg(N);
+    if (nwg > 512 || nwg > THALLO_MAX_PARTIALS || 96.0 * N >= 4294967296.0) return 0;         // (a lane record adds up to 8 records; granule offsets are 32-bit)
+    if (ell_stride / N > 6) return 0;                   // (a thread keeps the G matrices of its edges in registers: 16 x edge slots of them)
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_arap_resident<6>, BLOCK, 0);
+        per_cu = (e == hipSuccess && n >= 1) ? n : -1;
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    return per_cu > 0 && (long)per_cu * thallo_hip_device_cu_count() >= nwg ? 1 : 0;
+}
+/* L iterations from what thallo_hip_arap_pcg_init left (r_0 in r, M^-1 in pre, zeros in p0 and delta): leaves r_{L-1}, A p_{L-1}, p_{L-1} (in p0 / p1 by the parity of
+ * L, like L launches of the flat update), delta = sum_{k < L-1} alpha_k p_k and words[2k] = alphaD_k, words[2k + 1] = betaN_k -- what PCGUpdate + applyJTJ per iteration
+ * leave, bit for bit.  xbuf: thallo_hip_arap_resident_bytes(N) zero-filled bytes with the workgroups' index intervals filled in.  Returns the grid size. */
+int thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
+                                 const float* constraints, const float* original, const float* SC, float w_fit, float w_reg, long ell_stride,
+                                 float* r, float* Ap, const float* pre, float* p0, float* p1, float* delta, thallo_sum_t alphaN0, float* words,
+                                 void* xbuf, int L, thallo_stream_t stream)
+{
+    if (N < 1 || L < 1 || !out_ptr || !out_v1 || !in_ptr || !in_src || !constraints || !original || !SC || !r || !Ap || !pre || !p0 || !p1 || !delta || !words || !xbuf || !alphaN0.partials)
+        return -(int)hipErrorInvalidValue;
+    if (!thallo_hip_arap_resident_fits(N, ell_stride)) return -(int)hipErrorNotSupported;
+    ArapResArgs a; memset(&a, 0, sizeof(a));
+    a.N = N; a.nwg = ares_nwg(N); a.L = L; a.ell = ell_stride;
+    a.out_ptr = out_ptr; a.out_v1 = out_v1; a.in_ptr = in_ptr; a.in_src = in_src; a.Cn = constraints; a.O = original; a.SC = SC; a.wf = w_fit; a.wr = w_reg;
+    a.r = r; a.Ap = Ap; a.pre = pre; a.p0 = p0; a.p1 = p1; a.delta = delta; a.aN0 = alphaN0; a.words = words;
+    char* base = (char*)xbuf;
+#ifdef ARAP_STAMPS
+    g_arap_dbg_xbuf = xbuf;
+#endif
+    a.ctl = (unsigned*)base; a.rec = (u64r*)(base + ares_off_rec()); a.lrec = (u64r*)(base + ares_off_lrec()); a.wseg = (const int*)(base + ares_off_range(a.nwg)); a.ag = (u64r*)(base + ares_off_pg(a.nwg));
+    hipLaunchKernelGGL(k_arap_res_begin, dim3(1), dim3(64), 0, (hipStream_t)stream, a.ctl, (unsigned)L);
+    hipLaunchKernelGGL(k_arap_resident<6>, dim3(a.nwg), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    int e = check_launch(); return e ? e : a.nwg;
+}
+/* 1: a bounded wait inside the resident loop ran out since the words were cleared (pm: what, workgroup, thread, index, tag); clear != 0 resets the error word */
+int thallo_hip_arap_resident_status(void* xbuf, int clear, unsigned* pm, thallo_stream_t stream)
+{
+    if (!xbuf) return 0;
+    unsigned w[ARES_CTL_WORDS];
+    if (hipMemcpyAsync(w, xbuf, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    if (pm) for (int i = 0; i < 5; ++i) pm[i] = w[ARES_PM + i];
+    if (clear && w[ARES_ERR]) { const unsigned z = 0; (void)hipMemcpyAsync((unsigned*)xbuf + ARES_ERR, &z, sizeof(unsigned), hipMemcpyHostToDevice, (hipStream_t)stream); (void)hipStreamSynchronize((hipStream_t)stream); }
+    return w[ARES_ERR] ? 1 : 0;
 }
 int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,

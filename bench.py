@@ -285,10 +285,10 @@ def main():
                 return {"us_per_pcg_iter": us, "kernels": names}
             finally:
                 os.environ.pop("THALLO_RESIDENT", None)
-        out["small_working_sets"] = {f"{w}x{h}": {"resident_loop": small(w, h, True), "launch_per_iteration": small(w, h, False)} for (w, h) in ((512, 512), (2048, 256))}
-        # the 1/4 and 1/2 slabs of the 4- and 2-GPU runs: more rows per wave than the resident kernel's registers hold (R = 10 / 19 > 5) -- one marching launch per iteration
-        for (w, h) in ((2048, 512), (2048, 1024)):
-            out["small_working_sets"][f"{w}x{h}"] = {"resident_loop": None, "launch_per_iteration": small(w, h, False)}
+        out["small_working_sets"] = {f"{w}x{h}": {"resident_loop": small(w, h, True), "launch_per_iteration": small(w, h, False)} for (w, h) in ((512, 512), (2048, 256), (2048, 512))}
+        # (2048 x 512, the 1/4 slab of a 4-GPU run: 9 rows per wave, round 4.)  The 1/2 slab of a 2-GPU run has more rows per wave than the resident kernel's
+        # registers hold (R = 18 > 10): one marching launch per iteration
+        out["small_working_sets"]["2048x1024"] = {"resident_loop": None, "launch_per_iteration": small(2048, 1024, False)}
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
         q = syn.image_warping(W, H)

@@ -281,8 +281,9 @@ def test_arap_ghost_partition_schedule_matches_single_domain_oracle(orc, world, 
 
 def test_image_warping_slab_split_lets_every_rank_run_the_resident_loop(monkeypatch):
     """the resident slab loop is a per-rank property -- a rank with a rank below needs rows %% R == 0 -- and the decision to use it is unanimous.
-    The default split of the headline configuration (2048 rows over 8 ranks: 256 each, R = 5) would leave ranks 0..6 saying no; image_warping_slab_counts() picks
-    7 x 255 + 263, for which thallo_hip_iw_resident_rows_slab answers R = 5 on EVERY rank.  Host-only geometry (no GPU: the library assumes 256 CUs)."""
+    The default split of the headline configuration (2048 rows over 8 ranks: 256 each) has 5 rows per wave on the last rank and -- the next divisor of 256 -- 8 on the
+    others (before round 4, whose kernel goes to 10 rows per wave: none); image_warping_slab_counts() picks 7 x 255 + 263, for which thallo_hip_iw_resident_rows_slab
+    answers R = 5 on EVERY rank, and 3 x 504 + 536 at R = 9 for four ranks.  Host-only geometry (no GPU: the library assumes 256 CUs)."""
     import ctypes as C
     import thallo_amd
     from thallo_amd.distributed import SlabLayout, image_warping_slab_counts
@@ -292,14 +293,17 @@ def test_image_warping_slab_split_lets_every_rank_run_the_resident_loop(monkeypa
     W = H = 2048
     default = [SlabLayout(H, r, 8) for r in range(8)]
     answers = [L.thallo_hip_iw_resident_rows_slab(W, lay.row1 - lay.row0, 1 if r < 7 else 0) for r, lay in enumerate(default)]
-    assert answers[:7] == [0] * 7 and answers[7] == 5          # the situation the advisor described: only the last rank would say yes
+    assert answers[:7] == [8] * 7 and answers[7] == 5          # no common rows-per-wave: the ranks above would march 8 rows where 5 do
     counts = image_warping_slab_counts(W, H, 8)
     assert counts == [255] * 7 + [263]
     lays = [SlabLayout(H, r, 8, counts=counts) for r in range(8)]
     assert [l.g0 for l in lays] == [255 * r for r in range(8)] and lays[-1].g1 == H
     assert [L.thallo_hip_iw_resident_rows_slab(W, l.row1 - l.row0, 1 if r < 7 else 0) for r, l in enumerate(lays)] == [5] * 8
-    # 2 and 4 ranks: the slabs do not fit the registers at all -> the default split, one marching launch per iteration
-    assert image_warping_slab_counts(W, H, 2) is None and image_warping_slab_counts(W, H, 4) is None
+    # 4 ranks: 9 rows per wave; 2 ranks: the slabs do not fit the registers at all -> the default split, one marching launch per iteration
+    c4 = image_warping_slab_counts(W, H, 4)
+    assert c4 == [504] * 3 + [536]
+    assert [L.thallo_hip_iw_resident_rows_slab(W, c, 1 if r < 3 else 0) for r, c in enumerate(c4)] == [9] * 4
+    assert image_warping_slab_counts(W, H, 2) is None
     # a small image over 3 ranks: the tile kernel's territory -> the default split, unless the marching kernels are forced
     assert image_warping_slab_counts(252, 90, 3) is None
     monkeypatch.setenv("THALLO_MARCH", "2")

@@ -127,22 +127,26 @@ def test_hip_slab_transports_agree_bitwise_on_the_unknowns(orc, monkeypatch, ker
         assert (ra[4] == rb[4]).all() and (ra[5] == rb[5]).all()
 
 
-def _worker_rows(rank, world, port, W, H, nit, lit, q, resident, rows):
-    """_worker on the device-side transport with the PCG loop either resident (one launch per GN step) or one marching launch per iteration with `rows` rows per segment"""
+def _worker_rows(rank, world, port, W, H, nit, lit, q, resident, rows, cap=0):
+    """_worker on the device-side transport with the PCG loop either resident (one launch per GN step) or one marching launch per iteration with `rows` rows per segment;
+    cap > 0: the resident kernel's workgroup budget per rank (so that the ranks sharing GPU 0 here ARE co-resident at the rows per wave of a real multi-GPU slab)"""
     import torch  # noqa: F401  (before libThallo.so: the HIP runtime torch ships must be the one that gets loaded)
     import thallo_amd
     os.environ["THALLO_RESIDENT"] = "1" if resident else "0"
     os.environ["THALLO_MARCH"] = "2"
     thallo_amd.lib().thallo_hip_march_debug_set(0, 0 if resident else rows)
+    if cap > 0:
+        thallo_amd.lib().thallo_hip_resident_debug_set(1, cap)
     _worker(rank, world, port, W, H, nit, lit, q, True)
 
 
-@pytest.mark.parametrize("world,W,H,lit", [(2, 128, 96, 30), (3, 252, 90, 12), (1, 2048, 256, 20), (2, 640, 240, 16)])
-def test_resident_slab_loop_is_bitwise_the_launch_per_iteration_transport(monkeypatch, world, W, H, lit):
+@pytest.mark.parametrize("world,W,H,lit,cap", [(2, 128, 96, 30, 0), (3, 252, 90, 12, 0), (1, 2048, 256, 20, 0), (2, 640, 240, 16, 0), (1, 2048, 512, 12, 0), (2, 1024, 900, 10, 112)])
+def test_resident_slab_loop_is_bitwise_the_launch_per_iteration_transport(monkeypatch, world, W, H, lit, cap):
     """VERDICT r2 item 1, multi-GPU half: on the device-side transport a rank's whole PCG loop is ONE launch (thallo_hip_iw_pcg_resident_dist): state in registers,
     the first / last owned row of A p straight into the neighbouring ranks' ghost areas, workgroup 0 exchanges the rank's sums through the same mailbox slots and
     publishes the two global words.  Same granules, same rank order, same per-rank summation order as one marching launch per iteration with the same rows per
-    segment: costs, alpha_k / beta_k and the owned unknowns are bit-identical on every rank (ranks share GPU 0 here; 2048 x 256 = one rank's slab of the 8-GPU run)."""
+    segment: costs, alpha_k / beta_k and the owned unknowns are bit-identical on every rank (ranks share GPU 0 here; 2048 x 256 / 2048 x 512 = one rank's slab of the
+    8- / 4-GPU run; the last case: two ranks with a budget of 112 workgroups each, i.e. co-resident on one GPU at the 10 rows per wave of a 4-GPU slab -- VERDICT r3 item 2)."""
     import ctypes as C
     import torch  # noqa: F401
     import torch.multiprocessing as mp
@@ -152,19 +156,26 @@ def test_resident_slab_loop_is_bitwise_the_launch_per_iteration_transport(monkey
     L.thallo_hip_iw_resident_rows_slab.restype = C.c_int
     rows = None
     monkeypatch.setenv("THALLO_MARCH", "2")         # (as the workers: the split PlanSlabSolver picks depends on which kernels the plugin will run)
-    counts = image_warping_slab_counts(W, H, world)
-    for r in range(world):
-        lay = SlabLayout(H, r, world, counts=counts)
-        rr = L.thallo_hip_iw_resident_rows_slab(W, lay.row1 - lay.row0, 1 if r < world - 1 else 0)
-        assert 1 <= rr <= 5, (r, rr)
-        rows = rr if rows is None else rows
-        assert rr == rows, "this test forces ONE rows-per-segment on the marching kernel of every rank"
+    if cap > 0:
+        L.thallo_hip_resident_debug_set(1, cap)
+    try:
+        counts = image_warping_slab_counts(W, H, world)
+        for r in range(world):
+            lay = SlabLayout(H, r, world, counts=counts)
+            rr = L.thallo_hip_iw_resident_rows_slab(W, lay.row1 - lay.row0, 1 if r < world - 1 else 0)
+            assert 1 <= rr <= 10, (r, rr)
+            rows = rr if rows is None else rows
+            assert rr == rows, "this test forces ONE rows-per-segment on the marching kernel of every rank"
+    finally:
+        L.thallo_hip_resident_debug_set(1, 0)
+    if cap > 0 or (W, H) == (2048, 512):
+        assert rows >= 9, rows
     out = []
     for resident in (True, False):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_worker_rows, args=(r, world, port, W, H, 2, lit, q, resident, rows)) for r in range(world)]
+        procs = [ctx.Process(target=_worker_rows, args=(r, world, port, W, H, 2, lit, q, resident, rows, cap)) for r in range(world)]
         for p_ in procs:
             p_.start()
         out.append(sorted(_collect(q, procs, world), key=lambda t: t[0]))

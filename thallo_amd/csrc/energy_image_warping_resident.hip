@@ -28,7 +28,7 @@ namespace {
 
 constexpr int RES_USE = 124;              // output pixels per wave row (lanes 1..62 x 2)
 constexpr int RES_NT = 256;               // 4 waves = 4 vertically adjacent segments of one strip (one workgroup per CU)
-constexpr int RES_MAX_R = 5;              // rows per segment the kernel is instantiated for (register budget; 6 R <= 32: a column's words fit half a wave)
+constexpr int RES_MAX_R = 10;             // rows per segment the kernel is instantiated for (register budget: 19 words per row and lane stay in registers; 6 R <= 64: a column's words fit a wave)
 
 inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
 
@@ -91,7 +91,7 @@ struct ResGeo { int W, H, row0, row1, R, nstrips, nseg, nwgrow, total; };
 // exchange buffers of one plan (thallo_hip_iw_resident_bytes); parity = iteration & 1
 struct ResBufs {
     u64* rowh;        // [2 parity][waves][2 sides: 0 = the wave's FIRST row (for the wave above), 1 = its LAST row (for the wave below)][64 lanes][6 components]
-    u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][32: word 6 * row + component]
+    u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][64: word 6 * row + component]
     u64* sums;        // [2 parity][1024 workgroups][8: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo, -]   (a workgroup's record = one 64-byte line, one store instruction)
     u64* gs;          // [2 parity][2]: alphaD_k, betaN_k over ALL ranks, published by workgroup 0 (multi-GPU form: only that workgroup sweeps the sums)
     unsigned* ctl;    // RES_CTL_WORDS
@@ -156,8 +156,8 @@ struct ResLds {
     unsigned q[4][7][64];             // per wave: the 7 words of the 64 slots it swept
     float wa[4]; double wd[4][3];     // per wave: alphaD part, {N, S1, S2} parts
     float rrow[2][4][2][6][64];       // the y halo between the stacked waves of the workgroup never leaves the CU
-    float cst[4][2][32];              // per wave: lane 1's / lane 62's A p of its rows, transposed so that ONE store instruction publishes a column
-    float crx[4][2][32];              // per wave: the received columns (from the strip to the left / right), for lanes 0 / 63 to pick up
+    float cst[4][2][64];              // per wave: lane 1's / lane 62's A p of its rows, transposed so that ONE store instruction publishes a column
+    float crx[4][2][64];              // per wave: the received columns (from the strip to the left / right), for lanes 0 / 63 to pick up
 };
 
 // dist_exchange_iter_wave (dist_device.hpp) with the two results in registers: ONE full wave, converged.  This rank's sums go out as 7 granules to every rank's
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ResLds& S = *reinterpret_cast<ResLds*>(smem);
     float* dl = reinterpret_cast<float*>(smem + ((sizeof(ResLds) + 15) & ~(size_t)15));      // delta: [R][6][256], a thread's own words only
+    float4* csl = reinterpret_cast<float4*>(dl + R * 6 * RES_NT) + threadIdx.x;               // cos / sin of the rows I hold: [R + 2][256] x {c0, s0, c1, s1}, a thread's own words only
     const ResGeo g = a.g;
     // (the wave index through readfirstlane: the compiler then KNOWS that segment, rows, neighbour flags and buffer offsets are wave-uniform -- scalar registers and
     //  scalar branches instead of exec-masked code for every `if (has_up)`)
@@ -269,11 +270,10 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     auto ghost = [&](int par, int dir) { return a.x.ghost_off + (unsigned)(((((long)par * g.nstrips + strip) * 2 + dir) * 64 + lane) * 48); };
     const unsigned seqx = DIST ? __hip_atomic_load(a.x.d.ctl + DIST_SEQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 12 : 0u;       // cross-rank tag of iteration k: seqx + k + 1 (the GN step counter is the same on every rank)
     auto rowh = [&](int par, int w, int side) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + lane) * 48); };       // this lane's 6 granules of that row
-    auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 32 + i) * 8); };     // granule i = 6 * row + component
+    auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + i) * 8); };     // granule i = 6 * row + component
     auto sumw = [&](int par, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * 8) * 8); };                    // that workgroup's 64-byte record
     // ---- state: rows t = ya - 1 + jj, jj = 0 .. R + 1 (jj = 0 and jj = nr + 1: the y halo; lanes 0 / 63: the x halo)
     float rx[R + 2][2], ry[R + 2][2], ra[R + 2][2], px[R + 2][2], py[R + 2][2], pa[R + 2][2], ax[R + 2][2], ay[R + 2][2], av[R + 2][2];
-    float cc[R + 2][2], ss[R + 2][2], mo[R + 2][2], ma[R + 2][2];
     unsigned fl[R + 2];
     const float4* ro4 = reinterpret_cast<const float4*>(a.r_in); const float2* ra2 = reinterpret_cast<const float2*>(a.r_in + 2 * N);
     const float4* po4 = reinterpret_cast<const float4*>(a.p_in); const float2* pa2 = reinterpret_cast<const float2*>(a.p_in + 2 * N);
@@ -290,11 +290,9 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
         const unsigned fw = f4[i2 >> 1];
         const unsigned f = ok ? (fw >> ((((long)t * W2 + (x0 >> 1)) & 1) != 0 ? 16 : 0)) & 0xffffu : 0u;
         fl[jj] = f;
-        const float2 m0 = S.lut[f & 31u], m1 = S.lut[(f >> 8) & 31u];
-        mo[jj][0] = m0.x; mo[jj][1] = m1.x; ma[jj][0] = m0.y; ma[jj][1] = m1.y;
         rx[jj][0] = r4.x; ry[jj][0] = r4.y; rx[jj][1] = r4.z; ry[jj][1] = r4.w; ra[jj][0] = r2.x; ra[jj][1] = r2.y;
         px[jj][0] = p4.x; py[jj][0] = p4.y; px[jj][1] = p4.z; py[jj][1] = p4.w; pa[jj][0] = p2.x; pa[jj][1] = p2.y;
-        cc[jj][0] = c4.x; ss[jj][0] = c4.y; cc[jj][1] = c4.z; ss[jj][1] = c4.w;
+        csl[jj * RES_NT] = c4;
 #pragma unroll
         for (int q = 0; q < 2; ++q) { ax[jj][q] = 0.f; ay[jj][q] = 0.f; av[jj][q] = 0.f; }
         if (jj >= 1 && jj <= R) {       // delta of my rows into LDS
@@ -320,8 +318,7 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     const int slot = 64 * wave + lane;    // the sums slot this lane sweeps
     long sid;
     const bool slot_live = slot < grid && wg_id(slot, sid);
-    const int chalf = lane >> 5, cword = lane & 31;       // columns: lanes 0..31 carry the words of the LEFT exchange, lanes 32..63 of the RIGHT one
-    const bool col_lane = cword < 6 * nr; // (word 6 * row + component)
+    const bool col_lane = lane < 6 * nr;  // columns: lane = word 6 * row + component of the LEFT and of the RIGHT exchange
 
     // Publish my quarter of the sums of an iteration (the 7 words of slot 64 w + lane) to the other waves of the workgroup, wait for theirs, and add all
     // slots up in the order the launch-per-iteration path uses (lane-strided over the slots, then the wave butterfly): alphaD_k, betaN_k -- same bits everywhere.
@@ -414,25 +411,25 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                     ax[R + 1][0] = d[0]; ay[R + 1][0] = d[64]; av[R + 1][0] = d[128]; ax[R + 1][1] = d[192]; ay[R + 1][1] = d[256]; av[R + 1][1] = d[320];
                 }
             }
-            unsigned w7[7]; float rowu[6], rowd[6]; float cv = 0.f; float g_ad = 0.f, g_bn = 0.f;
+            unsigned w7[7]; float rowu[6], rowd[6]; float cvl = 0.f, cvr = 0.f; float g_ad = 0.f, g_bn = 0.f;
 #pragma unroll
             for (int c = 0; c < 7; ++c) w7[c] = 0u;
 #pragma unroll
             for (int c = 0; c < 6; ++c) { rowu[c] = 0.f; rowd[c] = 0.f; }
             {
                 const unsigned Txp = seqx + (unsigned)k;              // cross-rank tag of iteration k - 1
-                const bool need_u = xout && (up_glb || up_gh), need_d = xout && (dn_glb || dn_gh), need_c = col_lane && (chalf == 0 ? has_lf : has_rt);
+                const bool need_u = xout && (up_glb || up_gh), need_d = xout && (dn_glb || dn_gh), need_cl = col_lane && has_lf, need_cr = col_lane && has_rt;
                 const bool need_s = sweeper && slot_live, need_g = !sweeper;
                 const unsigned usrc = up_gh ? ghost(parp, 0) : rowh(parp, up_glb ? wid - 1 : wid, 1), dsrc = dn_gh ? ghost(parp, 1) : rowh(parp, dn_glb ? wid + 1 : wid, 0);
                 const unsigned ssrc = sumw(parp, slot);
-                const unsigned csrc = chalf == 0 ? colh(parp, has_lf ? wid - g.nseg : wid, 1, cword) : colh(parp, has_rt ? wid + g.nseg : wid, 0, cword);
-                bool ok_s = !need_s, ok_g = !need_g, ok_u = !need_u, ok_d = !need_d, ok_c = !need_c;
+                const unsigned clsrc = colh(parp, has_lf ? wid - g.nseg : wid, 1, lane), crsrc = colh(parp, has_rt ? wid + g.nseg : wid, 0, lane);
+                bool ok_s = !need_s, ok_g = !need_g, ok_u = !need_u, ok_d = !need_d, ok_cl = !need_cl, ok_cr = !need_cr;
                 sp.n = 0; sp.t0 = 0;
                 unsigned npass = 0;
-                while (!(ok_s && ok_g && ok_u && ok_d && ok_c) && !dead) {
+                while (!(ok_s && ok_g && ok_u && ok_d && ok_cl && ok_cr) && !dead) {
                     ++npass;
                     asm volatile("" ::: "memory");                     // (every pass re-reads: nothing may be hoisted out of the loop)
-                    u32x4 vs[4], vu[3], vd[3], vg; u32x2 vc;
+                    u32x4 vs[4], vu[3], vd[3], vg; u32x2 vcl, vcr;
                     if (!ok_s) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) vs[c] = ld2g(RS_SUM, ssrc + 16 * c);
@@ -446,7 +443,8 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) vd[c] = (DIST && dn_gh) ? ld2s(RS_GH, dsrc + 16 * c) : ld2g(RS_ROW, dsrc + 16 * c);
                     }
-                    if (!ok_c) vc = ld1g(RS_COL, csrc);
+                    if (!ok_cl) vcl = ld1g(RS_COL, clsrc);
+                    if (!ok_cr) vcr = ld1g(RS_COL, crsrc);
                     if (!ok_s) {
                         w7[0] = vs[0].x; w7[1] = vs[0].z; w7[2] = vs[1].x; w7[3] = vs[1].z; w7[4] = vs[2].x; w7[5] = vs[2].z; w7[6] = vs[3].x;
                         ok_s = vs[0].y == Tp && vs[0].w == Tp && vs[1].y == Tp && vs[1].w == Tp && vs[2].y == Tp && vs[2].w == Tp && vs[3].y == Tp;
@@ -464,15 +462,16 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                         for (int c = 0; c < 3; ++c) { rowd[2 * c] = __uint_as_float(vd[c].x); rowd[2 * c + 1] = __uint_as_float(vd[c].z); }
                         ok_d = vd[0].y == tt && vd[0].w == tt && vd[1].y == tt && vd[1].w == tt && vd[2].y == tt && vd[2].w == tt;
                     }
-                    if (!ok_c) { cv = __uint_as_float(vc.x); ok_c = vc.y == Tp; }
-                    if (!(ok_s && ok_g && ok_u && ok_d && ok_c) && spin_fail(sp, ctl, !ok_s ? 1u : !ok_g ? 8u : !(ok_u && ok_d) ? 3u : 4u, (unsigned)wid, Tp)) dead = true;
+                    if (!ok_cl) { cvl = __uint_as_float(vcl.x); ok_cl = vcl.y == Tp; }
+                    if (!ok_cr) { cvr = __uint_as_float(vcr.x); ok_cr = vcr.y == Tp; }
+                    if (!(ok_s && ok_g && ok_u && ok_d && ok_cl && ok_cr) && spin_fail(sp, ctl, !ok_s ? 1u : !ok_g ? 8u : !(ok_u && ok_d) ? 3u : 4u, (unsigned)wid, Tp)) dead = true;
                 }
                 RES_NOTE(k, 7, npass); (void)npass;
             }
             dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
             RES_STAMP(k, 1);
             // the columns go through LDS to the two lanes that hold them (lane 0 / 63); same wave: program order + lgkmcnt(0)
-            if (col_lane) S.crx[wave][chalf][cword] = cv;
+            if (col_lane) { S.crx[wave][0][lane] = cvl; S.crx[wave][1][lane] = cvr; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // (the rows from the waves of my own workgroup were taken from LDS in front of the polling loop)
             if ((up_glb || up_gh) && xout) { ax[0][0] = rowu[0]; ay[0][0] = rowu[1]; av[0][0] = rowu[2]; ax[0][1] = rowu[3]; ay[0][1] = rowu[4]; av[0][1] = rowu[5]; }
@@ -520,9 +519,10 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             const bool act = (jj <= nr + 1) && nr > 0 && xin && (ya - 1 + jj) >= 0 && (ya - 1 + jj) < g.H;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                px[jj][q] = act ? mo[jj][q] * rx[jj][q] + beta * px[jj][q] : 0.f;
-                py[jj][q] = act ? mo[jj][q] * ry[jj][q] + beta * py[jj][q] : 0.f;
-                pa[jj][q] = act ? ma[jj][q] * ra[jj][q] + beta * pa[jj][q] : 0.f;
+                const float2 m = S.lut[(fl[jj] >> (8 * q)) & 31u];           // M^-1 by the pixel's flags, looked up where it is used: not a register per row
+                px[jj][q] = act ? m.x * rx[jj][q] + beta * px[jj][q] : 0.f;
+                py[jj][q] = act ? m.x * ry[jj][q] + beta * py[jj][q] : 0.f;
+                pa[jj][q] = act ? m.y * ra[jj][q] + beta * pa[jj][q] : 0.f;
             }
         }
         RES_STAMP(k, 4);
@@ -532,8 +532,10 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
         for (int j = 0; j < R; ++j) {
             if (j < nr) {
                 const int jm = j, jc = j + 1, jn = j + 2;
-                const float Lpx = from_left(px[jc][1]), Lpy = from_left(py[jc][1]), Lpa = from_left(pa[jc][1]), Lc = from_left(cc[jc][1]), Ls = from_left(ss[jc][1]);
-                const float Rpx = from_right(px[jc][0]), Rpy = from_right(py[jc][0]), Rpa = from_right(pa[jc][0]), Rc = from_right(cc[jc][0]), Rs = from_right(ss[jc][0]);
+                const float4 csm = csl[jm * RES_NT], csc = csl[jc * RES_NT], csn = csl[jn * RES_NT];        // {c0, s0, c1, s1} of the rows above, here, below (my own words in LDS)
+                const float ccm[2] = { csm.x, csm.z }, ssm[2] = { csm.y, csm.w }, ccc[2] = { csc.x, csc.z }, ssc[2] = { csc.y, csc.w }, ccn[2] = { csn.x, csn.z }, ssn[2] = { csn.y, csn.w };
+                const float Lpx = from_left(px[jc][1]), Lpy = from_left(py[jc][1]), Lpa = from_left(pa[jc][1]), Lc = from_left(ccc[1]), Ls = from_left(ssc[1]);
+                const float Rpx = from_right(px[jc][0]), Rpy = from_right(py[jc][0]), Rpa = from_right(pa[jc][0]), Rc = from_right(ccc[0]), Rs = from_right(ssc[0]);
                 const unsigned Lf = from_left(fl[jc]) >> 8, Rf = from_right(fl[jc]);
                 if (xout) {
                     float bx[2], by[2], bv[2];
@@ -543,21 +545,22 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                         const unsigned fq = (fl[jc] >> (8 * q)) & 255u;
                         const float pxi = px[jc][q], pyi = py[jc][q], pai = pa[jc][q];
                         if (fq & 1u) {
-                            const float ci = cc[jc][q], si = ss[jc][q];
+                            const float ci = ccc[q], si = ssc[q];
                             if (q == 0) {
-                                nb_term<0>((fl[jc] >> 8) & 1u, ci, si, pxi, pyi, pai, px[jc][1], py[jc][1], pa[jc][1], cc[jc][1], ss[jc][1], bx[q], by[q], bv[q]);
+                                nb_term<0>((fl[jc] >> 8) & 1u, ci, si, pxi, pyi, pai, px[jc][1], py[jc][1], pa[jc][1], ccc[1], ssc[1], bx[q], by[q], bv[q]);
                                 nb_term<1>(Lf & 1u, ci, si, pxi, pyi, pai, Lpx, Lpy, Lpa, Lc, Ls, bx[q], by[q], bv[q]);
                             } else {
                                 nb_term<0>(Rf & 1u, ci, si, pxi, pyi, pai, Rpx, Rpy, Rpa, Rc, Rs, bx[q], by[q], bv[q]);
-                                nb_term<1>(fl[jc] & 1u, ci, si, pxi, pyi, pai, px[jc][0], py[jc][0], pa[jc][0], cc[jc][0], ss[jc][0], bx[q], by[q], bv[q]);
+                                nb_term<1>(fl[jc] & 1u, ci, si, pxi, pyi, pai, px[jc][0], py[jc][0], pa[jc][0], ccc[0], ssc[0], bx[q], by[q], bv[q]);
                             }
-                            nb_term<2>((fl[jn] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jn][q], py[jn][q], pa[jn][q], cc[jn][q], ss[jn][q], bx[q], by[q], bv[q]);
-                            nb_term<3>((fl[jm] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jm][q], py[jm][q], pa[jm][q], cc[jm][q], ss[jm][q], bx[q], by[q], bv[q]);
+                            nb_term<2>((fl[jn] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jn][q], py[jn][q], pa[jn][q], ccn[q], ssn[q], bx[q], by[q], bv[q]);
+                            nb_term<3>((fl[jm] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jm][q], py[jm][q], pa[jm][q], ccm[q], ssm[q], bx[q], by[q], bv[q]);
                             bx[q] *= a.wr2; by[q] *= a.wr2; bv[q] *= a.wr2;
                             if (fq & 2u) { bx[q] += a.wf2 * pxi; by[q] += a.wf2 * pyi; }
                         }
                         acc += pxi * bx[q] + pyi * by[q] + pai * bv[q];
-                        const double dmo = mo[jc][q], dma = ma[jc][q], drx = rx[jc][q], dry = ry[jc][q], dra = ra[jc][q], dax = bx[q], day = by[q], daa = bv[q];
+                        const float2 mq = S.lut[fq & 31u];
+                        const double dmo = mq.x, dma = mq.y, drx = rx[jc][q], dry = ry[jc][q], dra = ra[jc][q], dax = bx[q], day = by[q], daa = bv[q];
                         s0 = __builtin_fma(dmo, __builtin_fma(dry, dry, drx * drx), __builtin_fma(dma, dra * dra, s0));
                         s1 = __builtin_fma(dmo, __builtin_fma(dry, day, drx * dax), __builtin_fma(dma, dra * daa, s1));
                         s2 = __builtin_fma(dmo, __builtin_fma(day, day, dax * dax), __builtin_fma(dma, daa * daa, s2));
@@ -607,7 +610,8 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                 if (up_lds) __hip_atomic_store(&S.rtag[par][wave][0], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (dn_lds) __hip_atomic_store(&S.rtag[par][wave][1], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (col_lane && (chalf == 0 ? has_lf : has_rt)) st1g(RS_COL, colh(par, wid, chalf, cword), T, __float_as_uint(S.cst[wave][chalf][cword]));
+            if (col_lane && has_lf) st1g(RS_COL, colh(par, wid, 0, lane), T, __float_as_uint(S.cst[wave][0][lane]));
+            if (col_lane && has_rt) st1g(RS_COL, colh(par, wid, 1, lane), T, __float_as_uint(S.cst[wave][1][lane]));
             const float wa = wave_sum_all(acc); const double w0 = wave_sum_all_d(s0), w1 = wave_sum_all_d(s1), w2 = wave_sum_all_d(s2);
             if (lane == 0) { S.wa[wave] = wa; S.wd[wave][0] = w0; S.wd[wave][1] = w1; S.wd[wave][2] = w2; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -707,7 +711,7 @@ inline int res_rows(int W, int rows, bool below = false)
     return R;
 }
 
-inline size_t res_lds_bytes(int R) { return ((sizeof(ResLds) + 15) & ~(size_t)15) + (size_t)R * 6 * RES_NT * sizeof(float); }
+inline size_t res_lds_bytes(int R) { return ((sizeof(ResLds) + 15) & ~(size_t)15) + ((size_t)R * 6 + (size_t)(R + 2) * 4) * RES_NT * sizeof(float); }
 
 // the plan's exchange memory: [control words | the two global words | sums records | column granules | row granules]  (the control words come first: their
 // place does not depend on the rows per segment)
@@ -716,7 +720,7 @@ inline ResLayout res_layout(const ResGeo& g)
 {
     const long waves = (long)g.nstrips * g.nseg;
     ResLayout l;
-    l.ctl = 0; l.gs = 32; l.sums = l.gs + 8; l.colh = l.sums + 2L * 8 * THALLO_MAX_PARTIALS; l.rowh = l.colh + 2 * waves * 2 * 32;       // (u64 units; 32 u64 = 256 bytes of control words)
+    l.ctl = 0; l.gs = 32; l.sums = l.gs + 8; l.colh = l.sums + 2L * 8 * THALLO_MAX_PARTIALS; l.rowh = l.colh + 2 * waves * 2 * 64;       // (u64 units; 32 u64 = 256 bytes of control words)
     l.bytes = (l.rowh + 2 * waves * 2 * 64 * 6) * (long)sizeof(u64) + 256;
     return l;
 }
@@ -739,7 +743,8 @@ int res_launch(const ResArgs& a, int R, hipStream_t s)
         if (f == 0) {
             int per_cu = 0; hipError_t e = hipErrorNotSupported;
 #define RES_OCC(RR) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_resident<RR, DIST>, RES_NT, lds)
-            switch (R) { case 1: RES_OCC(1); break; case 2: RES_OCC(2); break; case 3: RES_OCC(3); break; case 4: RES_OCC(4); break; case 5: RES_OCC(5); break; default: break; }
+            switch (R) { case 1: RES_OCC(1); break; case 2: RES_OCC(2); break; case 3: RES_OCC(3); break; case 4: RES_OCC(4); break; case 5: RES_OCC(5); break;
+                         case 6: RES_OCC(6); break; case 7: RES_OCC(7); break; case 8: RES_OCC(8); break; case 9: RES_OCC(9); break; case 10: RES_OCC(10); break; default: break; }
 #undef RES_OCC
             f = (e == hipSuccess && per_cu >= 1) ? per_cu : -1;
         }
@@ -749,7 +754,8 @@ int res_launch(const ResArgs& a, int R, hipStream_t s)
 #define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR, DIST>), dim3(grid), dim3(RES_NT), lds, s, a)
     switch (R) {
         case 1: RES_LAUNCH(1); break; case 2: RES_LAUNCH(2); break; case 3: RES_LAUNCH(3); break;
-        case 4: RES_LAUNCH(4); break; case 5: RES_LAUNCH(5); break;
+        case 4: RES_LAUNCH(4); break; case 5: RES_LAUNCH(5); break; case 6: RES_LAUNCH(6); break; case 7: RES_LAUNCH(7); break;
+        case 8: RES_LAUNCH(8); break; case 9: RES_LAUNCH(9); break; case 10: RES_LAUNCH(10); break;
         default: return -(int)hipErrorNotSupported;
     }
 #undef RES_LAUNCH

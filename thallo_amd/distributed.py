@@ -66,7 +66,8 @@ def image_warping_slab_counts(W, H, world):
     """Rows per rank such that EVERY rank's slab fits the resident PCG kernel (one launch per Gauss-Newton step), or None: the default split.  A rank with a rank
     below needs its rows to be a multiple of its rows per wave segment R (the ghost row below sits at a fixed register row: energy_image_warping_resident.hip), and
     the decision to run the resident loop is unanimous (solver_dist.cpp) -- the default split of 2048 rows over 8 ranks, 256 each, has R = 5 and 256 % 5 != 0, so no
-    rank would run it.  Here: ranks 0 .. world-2 get the largest multiple of m <= H / world rows, m = 5 .. 1, the last rank the rest (2048 / 8: 7 x 255 + 263).
+    rank would run it.  Here: ranks 0 .. world-2 get the largest multiple of m <= H / world rows, m = 1 .. 10, the last rank the rest; of the splits that fit, the one with
+    the fewest rows per wave, then the flattest (2048 / 8: 7 x 255 + 263 at R = 5; 2048 / 4: 3 x 504 + 536 at R = 9).
     Host-only (the library's geometry functions; the same answer on every rank)."""
     if world < 2 or W < 2 or (W & 1):
         return None
@@ -77,17 +78,18 @@ def image_warping_slab_counts(W, H, world):
     L = api.lib()
     L.thallo_hip_iw_resident_rows_slab.restype = C.c_int
     L.thallo_hip_iw_resident_rows_slab.argtypes = [C.c_int, C.c_int, C.c_int]
-    for m in (5, 4, 3, 2, 1):
+    best = None
+    for m in range(10, 0, -1):
         per = (H // world) // m * m
         if per < 1:
             continue
         counts = [per] * (world - 1) + [H - per * (world - 1)]
-        if counts[-1] > per + 2 * m + m * (world - 1):
-            continue
         rr = [L.thallo_hip_iw_resident_rows_slab(W, c, 1 if r < world - 1 else 0) for r, c in enumerate(counts)]
         if min(rr) > 0 and min(rr) == max(rr):          # every rank fits, with the SAME rows per segment (equal work per wave; one geometry to reason about)
-            return counts
-    return None
+            key = (rr[0], max(counts))                  # an iteration costs what the slowest rank's waves cost: fewest rows per wave first, then the flattest split
+            if best is None or key < best[0]:
+                best = (key, counts)
+    return best[1] if best else None
 
 
 # ------------------------------------------------------------------ image_warping: the slab schedule behind Thallo_ProblemStep

@@ -19,7 +19,7 @@
 // sum and lane-strided sum of the per-workgroup partials), and both files are compiled with -ffp-contract=on (contraction decided per source
 // expression, never across statements): r, p, delta, A p and every alpha / beta come out bit-identical to the launch-per-iteration marching
 // kernel run with the same R (tests/test_gpu_parity.py).  Replaces gauss_newton.t:1615-1687 (the PCG loop) for these shapes.
-#include "iw_device.hpp"
+#include "iw_march.hpp"
 #include <cstring>
 
 using namespace thallo;
@@ -51,35 +51,6 @@ __device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsig
 __device__ __forceinline__ u32x4 ld2s(rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 17); }
 __device__ __forceinline__ void st2s(rsrc_t r, unsigned off, unsigned tag, float v0, float v1)
 { u32x4 d; d.x = __float_as_uint(v0); d.y = tag; d.z = __float_as_uint(v1); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 17); }
-
-__device__ __forceinline__ float from_left(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));   // wave_shr:1
-}
-__device__ __forceinline__ float from_right(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));   // wave_shl:1
-}
-__device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
-
-// one neighbour's contribution to (J^T J p)_i on the unit grid -- the marching kernel's nb_term, expression for expression
-template <int D>
-__device__ __forceinline__ void nb_term(bool valid, float ci, float si, float pxi, float pyi, float pai,
-                                        float pxj, float pyj, float paj, float cj, float sj, float& ax, float& ay, float& av)
-{
-    if (valid) {
-        const float gix = D == 0 ? si : D == 1 ? -si : D == 2 ? ci : -ci;
-        const float giy = D == 0 ? -ci : D == 1 ? ci : D == 2 ? si : -si;
-        const float gjx = D == 0 ? -sj : D == 1 ? sj : D == 2 ? -cj : cj;
-        const float gjy = D == 0 ? cj : D == 1 ? -cj : D == 2 ? -sj : sj;
-        const float dpx = pxi - pxj, dpy = pyi - pyj;
-        const float ex = dpx - gix * pai, ey = dpy - giy * pai;
-        ax += dpx + ex + gjx * paj;
-        ay += dpy + ey + gjy * paj;
-        av -= gix * ex + giy * ey;
-    }
-}
 
 }  // namespace
 
@@ -533,31 +504,19 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             if (j < nr) {
                 const int jm = j, jc = j + 1, jn = j + 2;
                 const float4 csm = csl[jm * RES_NT], csc = csl[jc * RES_NT], csn = csl[jn * RES_NT];        // {c0, s0, c1, s1} of the rows above, here, below (my own words in LDS)
-                const float ccm[2] = { csm.x, csm.z }, ssm[2] = { csm.y, csm.w }, ccc[2] = { csc.x, csc.z }, ssc[2] = { csc.y, csc.w }, ccn[2] = { csn.x, csn.z }, ssn[2] = { csn.y, csn.w };
-                const float Lpx = from_left(px[jc][1]), Lpy = from_left(py[jc][1]), Lpa = from_left(pa[jc][1]), Lc = from_left(ccc[1]), Ls = from_left(ssc[1]);
-                const float Rpx = from_right(px[jc][0]), Rpy = from_right(py[jc][0]), Rpa = from_right(pa[jc][0]), Rc = from_right(ccc[0]), Rs = from_right(ssc[0]);
-                const unsigned Lf = from_left(fl[jc]) >> 8, Rf = from_right(fl[jc]);
+                struct PRow { float px[2], py[2], pa[2]; }; struct GRow { float c[2], s[2]; };
+                const PRow pm_ = { { px[jm][0], px[jm][1] }, { py[jm][0], py[jm][1] }, { pa[jm][0], pa[jm][1] } }, pc_ = { { px[jc][0], px[jc][1] }, { py[jc][0], py[jc][1] }, { pa[jc][0], pa[jc][1] } };
+                const PRow pn_ = { { px[jn][0], px[jn][1] }, { py[jn][0], py[jn][1] }, { pa[jn][0], pa[jn][1] } };
+                const GRow gm_ = { { csm.x, csm.z }, { csm.y, csm.w } }, gc_ = { { csc.x, csc.z }, { csc.y, csc.w } }, gn_ = { { csn.x, csn.z }, { csn.y, csn.w } };
+                float am[2], ac[2], an[2], wfit[2], wdum[2];
+                flag_masks(fl[jm], a.wf2, am, wdum); flag_masks(fl[jc], a.wf2, ac, wfit); flag_masks(fl[jn], a.wf2, an, wdum);
+                float bx[2], by[2], bv[2];
+                jtjp_pair(pm_, pc_, pn_, gm_, gc_, gn_, am, ac, an, wfit, a.wr2, bx, by, bv);       // (every lane: the x neighbours come through wave shifts; iw_march.hpp, branch-free)
                 if (xout) {
-                    float bx[2], by[2], bv[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        bx[q] = 0.f; by[q] = 0.f; bv[q] = 0.f;
                         const unsigned fq = (fl[jc] >> (8 * q)) & 255u;
                         const float pxi = px[jc][q], pyi = py[jc][q], pai = pa[jc][q];
-                        if (fq & 1u) {
-                            const float ci = ccc[q], si = ssc[q];
-                            if (q == 0) {
-                                nb_term<0>((fl[jc] >> 8) & 1u, ci, si, pxi, pyi, pai, px[jc][1], py[jc][1], pa[jc][1], ccc[1], ssc[1], bx[q], by[q], bv[q]);
-                                nb_term<1>(Lf & 1u, ci, si, pxi, pyi, pai, Lpx, Lpy, Lpa, Lc, Ls, bx[q], by[q], bv[q]);
-                            } else {
-                                nb_term<0>(Rf & 1u, ci, si, pxi, pyi, pai, Rpx, Rpy, Rpa, Rc, Rs, bx[q], by[q], bv[q]);
-                                nb_term<1>(fl[jc] & 1u, ci, si, pxi, pyi, pai, px[jc][0], py[jc][0], pa[jc][0], ccc[0], ssc[0], bx[q], by[q], bv[q]);
-                            }
-                            nb_term<2>((fl[jn] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jn][q], py[jn][q], pa[jn][q], ccn[q], ssn[q], bx[q], by[q], bv[q]);
-                            nb_term<3>((fl[jm] >> (8 * q)) & 1u, ci, si, pxi, pyi, pai, px[jm][q], py[jm][q], pa[jm][q], ccm[q], ssm[q], bx[q], by[q], bv[q]);
-                            bx[q] *= a.wr2; by[q] *= a.wr2; bv[q] *= a.wr2;
-                            if (fq & 2u) { bx[q] += a.wf2 * pxi; by[q] += a.wf2 * pyi; }
-                        }
                         acc += pxi * bx[q] + pyi * by[q] + pai * bv[q];
                         const float2 mq = S.lut[fq & 31u];
                         const double dmo = mq.x, dma = mq.y, drx = rx[jc][q], dry = ry[jc][q], dra = ra[jc][q], dax = bx[q], day = by[q], daa = bv[q];

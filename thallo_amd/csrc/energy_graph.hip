@@ -495,9 +495,11 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply_rc(int N, int n0, int n1, 
 //     expressions on the owner's inputs (bit-identical), and all it needs from the owner is A p_k at the ghost -- which goes out TOGETHER with the workgroup's
 //     sums: A p_k as {value | tag} granules (write-through sc1 stores: the data is the flag, nothing to drain), the {alphaD | N, S1, S2} record as four tagged
 //     16-byte parts in part-major order (a wave's load of one part of 64 records is 1 KB of whole lines);
-//   * the sums go up a two-level tree shaped like load_iteration_sums' order (lane l adds partials l, l + 64, ... ascending, then the butterflies): workgroup l < 64
-//     adds the records l, l + 64, ... into "lane record" l, and wave 0 of every workgroup reads the <= 64 lane records and runs the butterflies -- bit-identical
-//     alpha_k / beta_k everywhere.  (Every workgroup sweeping every record is W^2 fabric requests per poll round: 11 us of an iteration at 400 workgroups, 1 us at 25);
+//   * the sums go up a tree shaped like load_iteration_sums' order (lane l adds partials l, l + 64, ... ascending, then the butterflies): with more than 64 workgroups,
+//     workgroup l < 64 adds the records l, l + 64, ... into "lane record" l; the <= 64 lane records (up to 64 workgroups: the records themselves) are read and put
+//     through the butterflies by the last workgroup, which publishes the four totals for everybody else to poll (up to 192 workgroups), or by every workgroup for
+//     itself (beyond) -- bit-identical alpha_k / beta_k everywhere.  (Every workgroup sweeping every record is W^2 fabric requests per poll round: 11 us of an
+//     iteration at 400 workgroups, 1 us at 25);
 //   * both are double-buffered by the iteration's parity: a workgroup publishes iteration k + 2 only after it has every record of k + 1, which a reader writes
 //     after it is through with k.
 // Every wait is bounded (2 s; an error word, later waits fall through, the host reports it at the next cost evaluation).  Bit-identical to PCGUpdate + applyJTJ per
@@ -505,7 +507,8 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply_rc(int N, int n0, int n1, 
 // Replaces the loop of gauss_newton.t:1615-1687 for this plugin.
 constexpr int ARAP_RES_GHOSTS = 768;                      // vertices of other workgroups a workgroup may share edges with
 constexpr int ARAP_RES_SPAN = ARAP_RES_GHOSTS + BLOCK;    // staged vertices: LDS 2 parts x 3 floats each
-constexpr int ARAP_RES_COPIES = 8;                        // copies of the lane records (a reader takes copy workgroup % 8: its XCD's, with round-robin placement)
+constexpr int ARAP_RES_COPIES = 8;                        // copies of the iteration's totals (a reader takes copy workgroup % 8: its XCD's, with round-robin placement)
+constexpr int ARAP_RES_ROOT = 192;                        // up to this many workgroups ONE workgroup reads the lane records and publishes the totals
 constexpr int ARAP_RES_SEGS = 16;                         // index intervals the staged set may consist of
 constexpr int ARAP_RES_SEGW = 4 + 2 * ARAP_RES_SEGS;      // ints per workgroup in the exchange memory: {count, -, -, -, lo_0, hi_0, lo_1, hi_1, ...}
 enum { ARES_SEQ = 0, ARES_ERR = 1, ARES_SPIN_MS = 2, ARES_PM = 4, ARES_CTL_WORDS = 16 };
@@ -521,7 +524,7 @@ struct ArapResArgs {
     float *r, *Ap; const float* pre; float *p0, *p1, *delta;      // p_{L-1} ends in p[L & 1] like behind L launches of the flat update (p0 = the plan's p[0]: zeros at the start)
     thallo_sum_t aN0; float* words;
     u64r* rec;            // [2 parity][4 parts][nwg] x 16 bytes
-    u64r* lrec;           // [2 parity][ARAP_RES_COPIES][4 parts][64] x 16 bytes: the lane records (every workgroup reads all 64: copies spread the readers)
+    u64r* lrec;           // [2 parity][ARAP_RES_COPIES][4 parts][64] x 16 bytes: the lane records; behind them [2 parity][ARAP_RES_COPIES][4 parts] x 16 bytes: the totals (copies spread the readers)
     u64r* ag;             // [2 parity][2 parts: Position, Angle][N][3] granules of A p_k
     const int* wseg;      // [nwg][ARAP_RES_SEGW]: the index intervals that hold the workgroup's vertices and their neighbours
     unsigned* ctl;
@@ -668,15 +671,6 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
         }
         ap.x *= wr2; ap.y *= wr2; ap.z *= wr2; aa.x *= wr2; aa.y *= wr2; aa.z *= wr2;
         if (fit) { ap.x += a.wf * a.wf * pp.x; ap.y += a.wf * a.wf * pp.y; ap.z += a.wf * a.wf * pp.z; }
-        // ---- A p_k out: tagged granules for the workgroups that have my vertex as a ghost
-        if (live) {
-            const unsigned o0 = 24u * (unsigned)n + 48u * par * (unsigned)N, o1 = o0 + 24u * (unsigned)N;
-            u32x4r d; u32x2r e;
-            d.x = __float_as_uint(ap.x); d.y = tag; d.z = __float_as_uint(ap.y); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, RAG, o0, 0, 16);
-            e.x = __float_as_uint(ap.z); e.y = tag;                                        __builtin_amdgcn_raw_buffer_store_b64(e, RAG, o0 + 16u, 0, 16);
-            d.x = __float_as_uint(aa.x); d.y = tag; d.z = __float_as_uint(aa.y); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, RAG, o1, 0, 16);
-            e.x = __float_as_uint(aa.z); e.y = tag;                                        __builtin_amdgcn_raw_buffer_store_b64(e, RAG, o1 + 16u, 0, 16);
-        }
         ASTAMP(1);
         // ---- the workgroup's sums (block_finish_sums' arithmetic) as one record of four tagged parts
         float acc = 0.0f; Sums3 sm;
@@ -701,6 +695,16 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
                 d.x = (unsigned)q1; d.y = tag; d.z = (unsigned)(q2 >> 32); d.w = tag;        __builtin_amdgcn_raw_buffer_store_b128(d, RREC, off + 2u * ps, 0, 16);
                 d.x = (unsigned)q2; d.y = tag; d.z = 0u; d.w = tag;                          __builtin_amdgcn_raw_buffer_store_b128(d, RREC, off + 3u * ps, 0, 16);
             }
+        }
+        // ---- A p_k out: tagged granules for the workgroups that have my vertex as a ghost -- BEHIND the record in the CU's store queue: the record is what the whole
+        //      chip waits for, the granules are looked at a tree's latency later
+        if (live) {
+            const unsigned o0 = 24u * (unsigned)n + 48u * par * (unsigned)N, o1 = o0 + 24u * (unsigned)N;
+            u32x4r d; u32x2r e;
+            d.x = __float_as_uint(ap.x); d.y = tag; d.z = __float_as_uint(ap.y); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, RAG, o0, 0, 16);
+            e.x = __float_as_uint(ap.z); e.y = tag;                                        __builtin_amdgcn_raw_buffer_store_b64(e, RAG, o0 + 16u, 0, 16);
+            d.x = __float_as_uint(aa.x); d.y = tag; d.z = __float_as_uint(aa.y); d.w = tag; __builtin_amdgcn_raw_buffer_store_b128(d, RAG, o1, 0, 16);
+            e.x = __float_as_uint(aa.z); e.y = tag;                                        __builtin_amdgcn_raw_buffer_store_b64(e, RAG, o1 + 16u, 0, 16);
         }
         ASTAMP(2);
         // ---- the sums' tree.  A record / lane record is four 16-byte parts {alphaD, tag, N.hi, tag} {N.lo, tag, S1.hi, tag} {S1.lo, tag, S2.hi, tag} {S2.lo, tag, 0, tag}.
@@ -727,8 +731,15 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
             d.x = (unsigned)q2; d.y = tag; d.z = 0u; d.w = tag;                          __builtin_amdgcn_raw_buffer_store_b128(d, R, off + 3u * ps, 0, 16);
         };
         if (wave == 0) {
-            // level 1 (workgroups 0 .. 63): lane j takes record wg + 64 j; lane 0 adds them up ascending from zero, as lane `wg` of load_iteration_sums does
-            if (wg < 64) {
+            // lane records: [parity][copy][part][64]; totals (behind them): [parity][copy][part].  Up to ARAP_RES_ROOT workgroups the last workgroup reads the lane records
+            // and everybody else polls its four totals (fewest pollers: 6.3 vs 6.9 us per iteration at 25 workgroups, 8.9 vs 9.2 at 100); beyond, one more level costs more
+            // than it saves (12.8 vs 12.2 us at 400) and every workgroup reads the lane records itself, from its XCD's copy
+            const bool rooted = a.nwg <= ARAP_RES_ROOT;
+            const unsigned lps = 16u * 64u;
+            auto lbase = [&](unsigned copy) { return 16u * 4u * 64u * (par * ARAP_RES_COPIES + copy); };
+            const unsigned fbase = 16u * 4u * 64u * 2u * ARAP_RES_COPIES + 16u * 4u * ARAP_RES_COPIES * par;
+            // level 1 (workgroups 0 .. 63 of more than 64): lane j takes record wg + 64 j; lane 0 adds them up ascending from zero, as lane `wg` of load_iteration_sums does
+            if (a.nwg > 64 && wg < 64) {
                 float v_ad = 0.0f; double v0 = 0.0, v1 = 0.0, v2 = 0.0;
                 const int i = wg + 64 * lane;
                 if (lane < 8 && i < a.nwg && !dead) poll4(RREC, 16u * (unsigned)(4u * par * (unsigned)a.nwg + (unsigned)i), 16u * (unsigned)a.nwg, 2u, (unsigned)i, v_ad, v0, v1, v2);
@@ -738,12 +749,27 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
                     const float fj = __shfl(v_ad, j); const double x0 = __shfl(v0, j), x1 = __shfl(v1, j), x2 = __shfl(v2, j);
                     if (wg + 64 * j < a.nwg) { t += fj; x += x0; y += x1; z += x2; }
                 }
-                if (lane < ARAP_RES_COPIES) store4(RLREC, 16u * (unsigned)(4u * 64u * (par * ARAP_RES_COPIES + (unsigned)lane) + (unsigned)wg), 16u * 64u, t, x, y, z);
+                if (lane < (rooted ? 1 : ARAP_RES_COPIES)) store4(RLREC, lbase((unsigned)lane) + 16u * (unsigned)wg, lps, t, x, y, z);
             }
-            // level 2 (every workgroup): lane l takes lane record l; the butterflies of load_iteration_sums
-            float t = 0.0f; double x = 0.0, y = 0.0, z = 0.0;
-            if (lane < nlane && !dead) poll4(RLREC, 16u * (unsigned)(4u * 64u * (par * ARAP_RES_COPIES + (unsigned)(wg % ARAP_RES_COPIES)) + (unsigned)lane), 16u * 64u, 3u, (unsigned)lane, t, x, y, z);
-            const float ad_ = wave_sum_all(t); const double n_ = wave_sum_all_f64(x), s1_ = wave_sum_all_f64(y), s2_ = wave_sum_all_f64(z);
+            float ad_ = 0.0f; double n_ = 0.0, s1_ = 0.0, s2_ = 0.0;
+            if (!rooted || wg == a.nwg - 1) {
+                // level 2: lane l takes lane record l -- with at most 64 workgroups record l itself, added to zero like a lane's only slot -- and the wave runs the
+                // butterflies of load_iteration_sums; the root publishes the four totals, one copy per XCD
+                float t = 0.0f; double x = 0.0, y = 0.0, z = 0.0;
+                if (lane < nlane && !dead) {
+                    if (a.nwg > 64) poll4(RLREC, lbase(rooted ? 0u : (unsigned)(wg % ARAP_RES_COPIES)) + 16u * (unsigned)lane, lps, 3u, (unsigned)lane, t, x, y, z);
+                    else {
+                        float v_ad = 0.0f; double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+                        poll4(RREC, 16u * (unsigned)(4u * par * (unsigned)a.nwg + (unsigned)lane), 16u * (unsigned)a.nwg, 2u, (unsigned)lane, v_ad, v0, v1, v2);
+                        t += v_ad; x += v0; y += v1; z += v2;
+                    }
+                }
+                ad_ = wave_sum_all(t); n_ = wave_sum_all_f64(x); s1_ = wave_sum_all_f64(y); s2_ = wave_sum_all_f64(z);
+                if (rooted && lane < ARAP_RES_COPIES) store4(RLREC, fbase + 64u * (unsigned)lane, 16u, ad_, n_, s1_, s2_);
+            } else {
+                // level 3 (rooted, everybody else): the totals, from my XCD's copy
+                if (lane == 0 && !dead) poll4(RLREC, fbase + 64u * (unsigned)(wg % ARAP_RES_COPIES), 16u, 4u, 0u, ad_, n_, s1_, s2_);
+            }
             if (lane == 0) { s_tot_f = ad_; s_tot[0] = n_; s_tot[1] = s1_; s_tot[2] = s2_; }
         }
         ASTAMP(3);
@@ -900,10 +926,10 @@ int thallo_hip_arap_apply_jtj_rc(int N, int n0, int n1, const int* out_ptr, cons
     else                     hipLaunchKernelGGL(k_arap_apply_rc<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_src, constraints, original, SC, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
     int e = check_launch(); return e ? e : grid;
 }
-/* ---- the resident PCG loop (k_arap_resident): exchange memory layout [control words 256 B | lane records 2 x ARAP_RES_COPIES x 4 x 64 x 16 B | records 2 x 4 x nwg x 16 B | intervals nwg x ARAP_RES_SEGW ints | A p granules 2 x 2 x N x 3 x 8 B] */
+/* ---- the resident PCG loop (k_arap_resident): exchange memory layout [control words 256 B | lane records and totals 8192 x ARAP_RES_COPIES B | records 2 x 4 x nwg x 16 B | intervals nwg x ARAP_RES_SEGW ints | A p granules 2 x 2 x N x 3 x 8 B] */
 static inline int ares_nwg(int N) { return (N + BLOCK - 1) / BLOCK; }
 static inline long ares_off_lrec() { return 256; }
-static inline long ares_off_rec() { return 256 + 8192L * ARAP_RES_COPIES; }
+static inline long ares_off_rec() { return 256 + 8192L * ARAP_RES_COPIES + 1024; }
 static inline long ares_off_range(int nwg) { return ares_off_rec() + 128L * nwg; }
 static inline long ares_off_pg(int nwg) { return (ares_off_range(nwg) + 4L * ARAP_RES_SEGW * nwg + 255) / 256 * 256; }
 long thallo_hip_arap_resident_bytes(int N) { if (N < 1) return 0; const int nwg = ares_nwg(N); return ares_off_pg(nwg) + 96L * N + 256; }

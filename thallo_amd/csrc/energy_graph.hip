@@ -528,6 +528,7 @@ struct ArapResArgs {
     u64r* ag;             // [2 parity][2 parts: Position, Angle][N][3] granules of A p_k
     const int* wseg;      // [nwg][ARAP_RES_SEGW]: the index intervals that hold the workgroup's vertices and their neighbours
     unsigned* ctl;
+    unsigned* stamps;     // research build: [4 points][512 workgroups]
 };
 struct ASpin { unsigned n; long long t0; };
 __device__ __forceinline__ bool ares_spin_fail(ASpin& sp, unsigned* ctl, unsigned what, unsigned idx, unsigned tag)
@@ -548,7 +549,8 @@ __device__ __forceinline__ bool ares_spin_fail(ASpin& sp, unsigned* ctl, unsigne
 __global__ void k_arap_res_begin(unsigned* ctl, unsigned L) { if (threadIdx.x == 0) ctl[ARES_SEQ] += L + 2u; }       // tags of this launch: seq + 1 .. seq + L (never 0, never an earlier launch's)
 
 #ifdef ARAP_STAMPS            // research builds only (tools/arap_resident_probe.py): phase stamps of iteration 10, workgroups 0 and 200, into the control words
-#define ASTAMP(i) do { if (k == 10 && tid == 0 && (wg == 0 || wg == 200)) a.ctl[16 + (wg ? 12 : 0) + (i)] = (unsigned)wall_clock64(); } while (0)
+#define ASTAMP(i) do { if (k == 10 && tid == 0 && (wg == 0 || wg == 200)) a.ctl[16 + (wg ? 12 : 0) + (i)] = (unsigned)wall_clock64(); \
+                       if (k == 10 && tid == 0 && ((i) == 0 || (i) == 2 || (i) == 3 || (i) == 6)) a.stamps[((i) == 0 ? 0 : (i) == 2 ? 1 : (i) == 3 ? 2 : 3) * 512 + wg] = (unsigned)wall_clock64(); } while (0)
 static void* g_arap_dbg_xbuf = nullptr;
 extern "C" void* thallo_hip_arap_debug_last_xbuf(void) { return g_arap_dbg_xbuf; }
 #else
@@ -932,7 +934,7 @@ static inline long ares_off_lrec() { return 256; }
 static inline long ares_off_rec() { return 256 + 8192L * ARAP_RES_COPIES + 1024; }
 static inline long ares_off_range(int nwg) { return ares_off_rec() + 128L * nwg; }
 static inline long ares_off_pg(int nwg) { return (ares_off_range(nwg) + 4L * ARAP_RES_SEGW * nwg + 255) / 256 * 256; }
-long thallo_hip_arap_resident_bytes(int N) { if (N < 1) return 0; const int nwg = ares_nwg(N); return ares_off_pg(nwg) + 96L * N + 256; }
+long thallo_hip_arap_resident_bytes(int N) { if (N < 1) return 0; const int nwg = ares_nwg(N); return ares_off_pg(nwg) + 96L * N + 256 + 8192; }      // (+ 8 KB: the research build's per-workgroup stamps)
 long thallo_hip_arap_resident_intervals_offset(int N) { return N < 1 ? -1 : ares_off_range(ares_nwg(N)); }
 int thallo_hip_arap_resident_max_ghosts(void) { return ARAP_RES_GHOSTS; }
 int thallo_hip_arap_resident_max_intervals(void) { return ARAP_RES_SEGS; }
@@ -972,7 +974,7 @@ int thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, c
 #ifdef ARAP_STAMPS
     g_arap_dbg_xbuf = xbuf;
 #endif
-    a.ctl = (unsigned*)base; a.rec = (u64r*)(base + ares_off_rec()); a.lrec = (u64r*)(base + ares_off_lrec()); a.wseg = (const int*)(base + ares_off_range(a.nwg)); a.ag = (u64r*)(base + ares_off_pg(a.nwg));
+    a.ctl = (unsigned*)base; a.rec = (u64r*)(base + ares_off_rec()); a.lrec = (u64r*)(base + ares_off_lrec()); a.wseg = (const int*)(base + ares_off_range(a.nwg)); a.ag = (u64r*)(base + ares_off_pg(a.nwg)); a.stamps = (unsigned*)(base + ares_off_pg(a.nwg) + 96L * N + 256);
     hipLaunchKernelGGL(k_arap_res_begin, dim3(1), dim3(64), 0, (hipStream_t)stream, a.ctl, (unsigned)L);
     hipLaunchKernelGGL(k_arap_resident<6>, dim3(a.nwg), dim3(BLOCK), 0, (hipStream_t)stream, a);
     int e = check_launch(); return e ? e : a.nwg;

@@ -37,3 +37,16 @@ if os.environ.get("ARAP_STAMPS"):          # needs a library built with `make VA
     for name, o in (("wg0", 16), ("wg200", 28)):
         a = [t[o + i] for i in range(8)]
         print(name, "stamps (10 ns units, deltas): start>apply+store>record>polled>barrier>sums>update+ghosts>barrier", [a[i + 1] - a[i] for i in range(7)])
+    nb = Lb.thallo_hip_arap_resident_bytes
+    nb.restype = C.c_long; nb.argtypes = [C.c_int]
+    total = nb(dims[0])
+    st = (C.c_uint * 2048)()
+    C.CDLL("libamdhip64.so").hipMemcpy(st, C.c_void_p(Lb.thallo_hip_arap_debug_last_xbuf() + total - 8192), 8192, 2)
+    nwg = (dims[0] + 255) // 256
+    a = np.array(st[:], dtype=np.int64).reshape(4, 512)[:, :nwg]
+    t0 = a[0].min()
+    for name, row in zip(("iteration start", "record stored", "totals in", "update done"), a):
+        r = (row - t0) / 100.0
+        print(f"{name:16s} us after the first workgroup's start: min {r.min():6.2f}  median {np.median(r):6.2f}  p90 {np.percentile(r, 90):6.2f}  max {r.max():6.2f}  (last: wg {int(r.argmax())})")
+    late = np.argsort(a[1])[-8:]
+    print("the 8 latest records: workgroups", late.tolist(), "their iteration start - t0:", ((a[0][late] - t0) / 100.0).round(2).tolist(), "apply+record us:", ((a[1][late] - a[0][late]) / 100.0).round(2).tolist())

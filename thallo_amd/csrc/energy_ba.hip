@@ -249,10 +249,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather(int C_, int P_, int cam_blocks
 // k_gather<1> above reads every 96-byte J block twice and forms J p twice (once for the camera that owns the observation, once for
 // its point, gathered through pt_pos: uncoalesced 96-byte reads + 36 bytes of the camera's p per observation).  Here:
 //   k_cam2: one wave per camera (as before): full block, J p = J_cam p_cam + J_pt p_pt, camera part of J^T (J p); and (J p) goes out
-//           in POINT order (8-byte scatter through q_ptk, the position of observation q in its point's list);
-//   k_pt2 : one thread per point: its observations' point blocks (6 floats each, packed once per GN iteration in point order: JP) and
-//           their J p -- both contiguous per point: no index, no gather -- give the point part of J^T (J p).
-// Per observation: 96 + 12 (p of the point) + 8 (J p out) in the camera kernel, 24 + 8 in the point kernel = 148 B instead of
+//           in CAMERA order, coalesced (round 4; rounds 2-3 scattered it into point order through q_ptk: 8-byte writes, 20.3 MB of write traffic for 5.4 MB
+//           of data per launch at the ladybug shape -- profiles/r04/ba_camera_kernel_pmc.json);
+//   k_pt2 : one thread per point: its observations' point blocks (6 floats each, packed once per GN iteration in point order: JP, contiguous per point) and
+//           their J p, gathered through pt_pos (the observation's place in camera order: an index load + an 8-byte gather from a 5.4 MB array that the L2s hold)
+//           give the point part of J^T (J p).  1.3-1.5 us per PCG iteration less than the scatter, same bits (A/B of the two forms on one box: GN 42.6 -> 41.1, LM 49.6 -> 48.2 us).
+// Per observation: 96 + 12 (p of the point) + 8 (J p out) in the camera kernel, 24 + 4 + 8 in the point kernel = 152 B instead of
 // 2 x 96 + 48 of gathered p; two launches instead of one (the point kernel needs every camera's J p).
 __global__ __launch_bounds__(BLOCK) void k_inverse_perm(int O_, const int* __restrict__ pt_pos, int* __restrict__ q_ptk)
 {
@@ -267,8 +269,8 @@ __global__ __launch_bounds__(BLOCK) void k_pack_point_blocks(int O_, const float
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ cam_ptr, const int* __restrict__ q_pt, const int* __restrict__ q_ptk,
-                                                const float4* __restrict__ Jb, const float* __restrict__ p, float* __restrict__ Ap, float2* __restrict__ JpP,
+__global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ cam_ptr, const int* __restrict__ q_pt,
+                                                const float4* __restrict__ Jb, const float* __restrict__ p, float* __restrict__ Ap, float2* __restrict__ JpC,
                                                 float* __restrict__ part_out, const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
                                                 const unsigned* __restrict__ gate, const float* __restrict__ ctc)
 {
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
             float j0 = b.a[9] * p0 + b.a[10] * p1 + b.a[11] * p2, j1 = b.a[21] * p0 + b.a[22] * p1 + b.a[23] * p2;      // same order as k_gather<1>
 #pragma unroll
             for (int k = 0; k < 9; ++k) { j0 += b.a[k] * pc[k]; j1 += b.a[12 + k] * pc[k]; }
-            JpP[q_ptk[q]] = make_float2(j0, j1);
+            JpC[q] = make_float2(j0, j1);
 #pragma unroll
             for (int k = 0; k < 9; ++k) s[k] += b.a[k] * j0 + b.a[12 + k] * j1;
         }
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
     if (s3_out) block_store_sums3(sm, s3_out, redd);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __restrict__ pt_ptr, const float2* __restrict__ JP, const float2* __restrict__ JpP,
+__global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __restrict__ pt_ptr, const int* __restrict__ pt_pos, const float2* __restrict__ JP, const float2* __restrict__ JpC,
                                                const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ part_out,
                                                const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
                                                const unsigned* __restrict__ gate, FinArgs fin, const float* __restrict__ ctc)
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __rest
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
             const float2 a = JP[3L * k], b = JP[3L * k + 1], c = JP[3L * k + 2];        // (r0.d9, r0.d10), (r0.d11, r1.d9), (r1.d10, r1.d11)
-            const float2 jp = JpP[k];
+            const float2 jp = JpC[pt_pos[k]];
             s0 += a.x * jp.x + b.y * jp.y; s1 += a.y * jp.x + c.x * jp.y; s2 += b.x * jp.x + c.y * jp.y;
         }
         const long i = PB + 3L * j;
@@ -392,17 +394,17 @@ int thallo_hip_ba_pack_point_blocks(int O_, const float* Jb, const int* q_ptk, f
     return check_launch();
 }
 
-static int ba_apply2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
-                     const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
+static int ba_apply2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                     const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
                      const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, const float* ctc, thallo_stream_t stream)
 {
-    if (!cam_ptr || !q_pt || !q_ptk || !pt_ptr || !Jb || !JP || !JpP || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
+    if (!cam_ptr || !q_pt || !pt_pos || !pt_ptr || !Jb || !JP || !JpC || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
     if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || gate || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     int cb, grid; gather_shape(C_, P_, cb, grid);
     // the camera launch fills slots [0, cb); the point launch the rest, and (fin) its last workgroup adds up all `grid` of them
-    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, q_ptk, (const float4*)Jb, p, Ap, (float2*)JpP, aD_out, r, pre, s3_out, gate, ctc);
-    hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, (const float2*)JP, (const float2*)JpP, p, Ap, aD_out, r, pre,
+    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, (const float4*)Jb, p, Ap, (float2*)JpC, aD_out, r, pre, s3_out, gate, ctc);
+    hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, pt_pos, (const float2*)JP, (const float2*)JpC, p, Ap, aD_out, r, pre,
                        s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid }, ctc);
     int e = check_launch(); return e ? e : grid;
 }
@@ -410,24 +412,24 @@ int thallo_hip_ba_apply2_camera_slots(int C_, int P_)
 {   // how many of thallo_hip_ba_apply_jtj2*'s partial slots belong to the camera launch (the first ones)
     int cb, grid; gather_shape(C_, P_, cb, grid); return cb;
 }
-int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
-                                 const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
+int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                                 const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream)
-{ return ba_apply2(C_, P_, cam_ptr, q_pt, q_ptk, pt_ptr, Jb, JP, JpP, p, Ap, aD_out, r, pre, s3_out, gate, fin, nullptr, stream); }
-int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
-                                const float* Jb, const float* JP, float* JpP, const float* p, const float* CtC, float* Ap, float* aD_out,
+{ return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, Jb, JP, JpC, p, Ap, aD_out, r, pre, s3_out, gate, fin, nullptr, stream); }
+int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                                const float* Jb, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* aD_out,
                                 const unsigned* gate, thallo_stream_t stream)
 {
     if (!CtC) return -(int)hipErrorInvalidValue;
     const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
-    return ba_apply2(C_, P_, cam_ptr, q_pt, q_ptk, pt_ptr, Jb, JP, JpP, p, Ap, aD_out, nullptr, nullptr, nullptr, gate, none, CtC, stream);
+    return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, Jb, JP, JpC, p, Ap, aD_out, nullptr, nullptr, nullptr, gate, none, CtC, stream);
 }
-int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* q_ptk, const int* pt_ptr,
-                             const float* Jb, const float* JP, float* JpP, const float* p, float* Ap, float* aD_out,
+int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                             const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
                              const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_stream_t stream)
 {
     const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
-    return thallo_hip_ba_apply_jtj2_fin(C_, P_, cam_ptr, q_pt, q_ptk, pt_ptr, Jb, JP, JpP, p, Ap, aD_out, r, pre, s3_out, gate, none, stream);
+    return thallo_hip_ba_apply_jtj2_fin(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, Jb, JP, JpC, p, Ap, aD_out, r, pre, s3_out, gate, none, stream);
 }
 
 }  // extern "C"

@@ -324,10 +324,18 @@ __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __rest
     const long PB = 9L * C_;
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < P_; j += gridDim.x * BLOCK) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int k = pt_ptr[j]; k < pt_ptr[j + 1]; ++k) {
-            const float2 a = JP[3L * k], b = JP[3L * k + 1], c = JP[3L * k + 2];        // (r0.d9, r0.d10), (r0.d11, r1.d9), (r1.d10, r1.d11)
-            const float2 jp = JpC[pt_pos[k]];
-            s0 += a.x * jp.x + b.y * jp.y; s1 += a.y * jp.x + c.x * jp.y; s2 += b.x * jp.x + c.y * jp.y;
+        // four observations per trip, all their loads in flight together (a point has ~4 observations: one round of latencies instead of four; the index load and
+        // the gather behind it are the kernel's critical path); added up in the list's order, as the one-at-a-time loop did
+        const int k1 = pt_ptr[j + 1];
+        for (int k0 = pt_ptr[j]; k0 < k1; k0 += 4) {
+            float2 a[4], b[4], c[4], jp[4]; int q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int k = min(k0 + u, k1 - 1); q[u] = pt_pos[k]; a[u] = JP[3L * k]; b[u] = JP[3L * k + 1]; c[u] = JP[3L * k + 2]; }     // (r0.d9, r0.d10), (r0.d11, r1.d9), (r1.d10, r1.d11)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jp[u] = JpC[q[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < k1) { s0 += a[u].x * jp[u].x + b[u].y * jp[u].y; s1 += a[u].y * jp[u].x + c[u].x * jp[u].y; s2 += b[u].x * jp[u].x + c[u].y * jp[u].y; }
         }
         const long i = PB + 3L * j;
         if (ctc) { s0 += ctc[i] * p[i]; s1 += ctc[i + 1] * p[i + 1]; s2 += ctc[i + 2] * p[i + 2]; }

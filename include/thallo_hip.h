@@ -322,6 +322,16 @@ int thallo_hip_iw_pcg_iter_march_dist(int W, int H, int row0, int row1, const fl
                                       thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2,
                                       const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out,
                                       unsigned* fin_tickets, int slot0, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* The slab iteration with the DEFERRED cross-rank finish (round 4; energy_image_warping_march_rc.hip): as thallo_hip_iw_pcg_iter_march_rc_dist without tickets -- the launch
+   stores this rank's partials only --, and it finishes iteration k-1 itself: `prev` = that iteration's partials of THIS rank and its two words, prev_slot0 = the mailbox
+   slots of its exchange, gs = two device words of 8 bytes (zeroed once) through which the launch's designated wave (first segment of strip 0) hands the two GLOBAL words to
+   the other waves.  Same granules, slots, rank order and summation order as the exchange at the end of a launch: same bits.  alphaN_prev must be a finished word.
+   thallo_hip_iw_dist_finish_deferred: one wave that finishes a GN step's last iteration the same way. */
+int thallo_hip_iw_pcg_iter_march_rc_dist_deferred(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                                  const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
+                                                  thallo_sum_t alphaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2, thallo_prev_t prev, int prev_slot0,
+                                                  unsigned long long* gs, const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+int thallo_hip_iw_dist_finish_deferred(thallo_prev_t prev, int prev_slot0, thallo_sum_t alphaN_prev, thallo_dist_t d, unsigned long long* gs, thallo_stream_t stream);
 /* the two one-kernel iterations with the deferred finish (thallo_prev_t above): alphaN_prev = alphaN_{k-1} (a finished sum), alphaN_prev2 / alphaD_prev2 as
    in the plain forms; `prev` is ignored for mode & 1 (first iteration of a GN step) */
 int thallo_hip_iw_pcg_iter_deferred(int W, int H, int row0, int row1, const float* cs, const float* urshape, const unsigned char* flags, const float* pre,

@@ -85,7 +85,7 @@ __device__ __forceinline__ void dist_fetch(const thallo_dist_t& d, const int (&s
 struct ExtraSums { bool on; float ad; double q0, q1, q2; };     // added behind the rank-ordered sums (shard form: the replicated block's own sums, k_shard_scalars' order)
 __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
                                                             float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex = ExtraSums{ false, 0.0f, 0.0, 0.0, 0.0 },
-                                                            float* gad_out = nullptr, float* alpha_out = nullptr);
+                                                            float* gad_out = nullptr, float* alpha_out = nullptr, float* bn_out = nullptr);
 __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, int slot0, float ad, double q0, double q1, double q2, float an,
                                                         float* __restrict__ aD_word, float* __restrict__ bN_word)
 {
@@ -93,7 +93,7 @@ __device__ __forceinline__ void dist_exchange_iter_wave(const thallo_dist_t& d, 
 }
 // (seq given by the caller: thallo_hip_dist_xrows tags with its own exchange counter)
 __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t& d, const unsigned seq, int slot0, float ad, double q0, double q1, double q2, float an,
-                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex, float* gad_out, float* alpha_out)
+                                                            float* __restrict__ aD_word, float* __restrict__ bN_word, ExtraSums ex, float* gad_out, float* alpha_out, float* bn_out)
 {
     const int lane = threadIdx.x & (THALLO_WAVE - 1);
     unsigned w[7];
@@ -142,6 +142,7 @@ __device__ __forceinline__ void dist_exchange_iter_wave_seq(const thallo_dist_t&
     if (lane == 0) { aD_word[0] = gad; bN_word[0] = (float)bn; }
     if (gad_out) *gad_out = gad;
     if (alpha_out) *alpha_out = alpha;
+    if (bn_out) *bn_out = (float)bn;
 }
 
 // ND doubles per rank (as hi / lo words: 2 * ND granules), by ONE full wave (2 * ND * world <= 64): bounded wait, rank-ordered double sums (every lane returns them)

@@ -74,6 +74,54 @@ __device__ __forceinline__ void rc_iteration_scalars(thallo_sum_t aNp, thallo_su
     beta = safe_div<false>(bn, an);
 }
 
+// ... and on a row slab of a multi-GPU run with the DEFERRED cross-rank finish (round 4): the partials of iteration k-1 are this rank's only.  ONE wave of the launch that
+// has no rows (the launch carries eight extra workgroups for it: its last workgroup's wave 0) adds them up -- load_iteration_sums' order, every load in flight at once --,
+// trades the rank's four sums with the other ranks through the mailbox (dist_exchange_iter_wave_seq: the granules, slots and rank order of the exchange that used to
+// sit at the END of launch k-1, where nothing could hide its ~8 us), leaves the two words behind and publishes them as two tagged granules; every working wave polls
+// those (agent scope, one line; bounded like every wait of the exchange) at the start of its second trip, i.e. behind the round trip of its first row loads.
+// A ghost row's A p_{k-1} is read after that point: the peers' rows were stored before their sums went out.
+__device__ __forceinline__ void rc_exchange_prev(thallo_sum_t aNp, const PrevSums& prev, const thallo_dist_t& dd)
+{
+    typedef unsigned long long u64_t;
+    const unsigned seq = ld_agent(dd.ctl + DIST_SEQ);
+    const unsigned tag = (seq << 12) | (unsigned)(prev.xslot / 7 + 1);
+    const IterationSums S = load_iteration_sums(prev.aD_part, prev.s12_part, prev.count, aNp);
+    float ad = 0.0f, al = 0.0f, bn = 0.0f;
+    dist_exchange_iter_wave_seq(dd, seq, prev.xslot, S.ad, S.n, S.s1, S.s2, S.an, prev.aD_word, prev.bN_word, ExtraSums{ false, 0.0f, 0.0, 0.0, 0.0 }, &ad, &al, &bn);
+    if ((threadIdx.x & (THALLO_WAVE - 1)) == 0) {
+        __hip_atomic_store(prev.gs, ((u64_t)tag << 32) | (u64_t)__float_as_uint(ad), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(prev.gs + 1, ((u64_t)tag << 32) | (u64_t)__float_as_uint(bn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void rc_iteration_scalars_x(thallo_sum_t aNp, const PrevSums& prev, const thallo_dist_t& dd, float& alpha, float& beta)
+{
+    typedef unsigned long long u64_t;
+    const float an = rc_sum(aNp);
+    const unsigned seq = ld_agent(dd.ctl + DIST_SEQ);
+    const unsigned tag = (seq << 12) | (unsigned)(prev.xslot / 7 + 1);
+    u64_t v0 = __hip_atomic_load(prev.gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = __hip_atomic_load(prev.gs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int it = 0; long long t0 = 0;
+    const long long bound = dist_spin_ticks(dd);
+    while ((unsigned)(v0 >> 32) != tag || (unsigned)(v1 >> 32) != tag) {
+        if ((it & 255) == 0) { if (ld_agent(dd.ctl + DIST_ERR) != 0) break; if (it == 0) t0 = wall_clock64(); }
+        ++it;
+        if ((it & 255) == 0 && wall_clock64() - t0 > bound) {
+            if (__hip_atomic_exchange(dd.ctl + DIST_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                unsigned* pm = dd.ctl + DIST_POST_MORTEM;
+                pm[0] = (unsigned)prev.xslot; pm[1] = 0xffffu; pm[2] = tag; pm[3] = (unsigned)(v0 >> 32); pm[4] = (unsigned)(v1 >> 32);
+            }
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+        v0 = __hip_atomic_load(prev.gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v1 = __hip_atomic_load(prev.gs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float ad = __uint_as_float((unsigned)v0), bn = __uint_as_float((unsigned)v1);
+    alpha = safe_div<false>(an, ad);
+    beta = safe_div<false>(bn, an);
+}
+// the last iteration of a GN step has no next launch: one wave does what the exchange wave of a launch would have done
+__global__ __launch_bounds__(64) void k_rc_dist_finish(thallo_sum_t aNp, PrevSums prev, thallo_dist_t dd) { rc_exchange_prev(aNp, prev, dd); }
+
 template <int DMODE>
 struct RawRc {                              // what one step takes, for one lane (2 pixels)
     u32x4 po, cs; u32x2 pa; unsigned f;     // row t:   p_{k-1} (Offset part x0,y0,x1,y1 | Angle part a0,a1), (c0,s0,c1,s1), the dword holding the pair's flags bytes
@@ -186,6 +234,8 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 
     float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     const unsigned mxin = xin ? 0xffffu : 0u;
+    // deferred cross-rank finish: the launch's last workgroup has no rows (the host added eight workgroups); its wave 0 is the exchange of iteration k-1
+    if (SLAB == 2 && prev.gs != nullptr && prev.count > 0 && blockIdx.x == gridDim.x - 1 && wave == 0 && !work) rc_exchange_prev(aNp, prev, dd);
 
     if (work) {
         const int t_first = ya - 2, t_last = yb + 1;          // rows of p_{k-1} / cs / flags to take
@@ -203,7 +253,8 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
             // which need neither alpha nor beta; the partial loads queue up behind those row loads and the additions run while the rows arrive.
             // (DEPTH 1 reaches row ya in its first trip: in front of the loop.)  Wave-uniform: kept in SGPRs.
             if (DEPTH == 1 ? t0 == t_begin : t0 == t_begin + 4) {
-                rc_iteration_scalars(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
+                if (SLAB == 2 && prev.gs != nullptr && prev.count > 0) rc_iteration_scalars_x(aNp, prev, dd, alpha, beta);
+                else rc_iteration_scalars(aNp, aDp, bNp, prev, alpha, beta, scal_writer);
                 alpha = to_sgpr(alpha); beta = to_sgpr(beta);
                 if (DMODE == 2) alpha2 = to_sgpr(safe_div<false>(rc_sum(aNpp), rc_sum(aDpp)));
             }
@@ -340,7 +391,7 @@ int launch_march_rc(int W, int H, int row0, int row1, const float* cs, const uns
     const int R = march_pick_rows(W, row1 - row0);
     if (R <= 0) return -(int)hipErrorNotSupported;
     const MarchGeo g = make_march_geo(W, H, row0, row1, R);
-    const int grid = (g.total + 7) / 8 * 8;
+    const int grid = (g.total + 7) / 8 * 8 + ((SLAB == 2 && prev.gs != nullptr) ? 8 : 0);      // (deferred cross-rank finish: eight workgroups without rows; wave 0 of the last one is the exchange)
     if (grid > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
     const int dmode = (mode >> 1) & 3;
     const float wf2 = w_fit * w_fit, wr2 = w_reg * w_reg;
@@ -426,6 +477,31 @@ int thallo_hip_iw_pcg_iter_march_rc_dist(int W, int H, int row0, int row1, const
     for (int k = 0; k < 2; ++k) if (d.peer_r[k] && ((d.peer_off_o[k] | d.peer_off_a[k]) & 1)) return -(int)hipErrorInvalidValue;
     return launch_march_rc<2>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aDp, bNp, aNpp, aDpp, irregular, d,
                               aD_out, s12_out, fin_tickets, aD_word, bN_word, slot0, (hipStream_t)stream, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
+}
+
+/* ... with the deferred cross-rank finish (thallo_hip.h): `prev` = iteration k-1's partials of THIS rank, its two words, and where the exchange happens */
+int thallo_hip_iw_pcg_iter_march_rc_dist_deferred(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                                  const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
+                                                  thallo_sum_t aNp, thallo_sum_t aNpp, thallo_sum_t aDpp, thallo_prev_t prev, int prev_slot0, unsigned long long* gs,
+                                                  const int* irregular, thallo_dist_t d, float* aD_out, double* s12_out, thallo_stream_t stream)
+{
+    if (int e = rc_check(W, H, row0, row1, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aNpp, aDpp, aD_out, s12_out)) return e;
+    if (!Ap_in || !Ap_out || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD || !d.mail || !d.ctl || 7 * d.world > 64 || prev_slot0 < 0 || !gs || aNp.count != 1) return -(int)hipErrorInvalidValue;
+    if (prev.count < 1 || prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_partials || !prev.s12_partials || !prev.alphaD_word || !prev.betaN_word ||
+        prev.s12_partials == s12_out) return -(int)hipErrorInvalidValue;
+    for (int k = 0; k < 2; ++k) if (d.peer_r[k] && ((d.peer_off_o[k] | d.peer_off_a[k]) & 1)) return -(int)hipErrorInvalidValue;
+    const thallo_sum_t none = { nullptr, 0 };
+    const PrevSums ps = { prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word, gs, prev_slot0 };
+    return launch_march_rc<2>(W, H, row0, row1, cs, flags, w_fit, w_reg, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, none, none, aNpp, aDpp, irregular, d,
+                              aD_out, s12_out, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, ps);
+}
+int thallo_hip_iw_dist_finish_deferred(thallo_prev_t prev, int prev_slot0, thallo_sum_t aNp, thallo_dist_t d, unsigned long long* gs, thallo_stream_t stream)
+{
+    if (prev.count < 1 || prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_partials || !prev.s12_partials || !prev.alphaD_word || !prev.betaN_word || prev_slot0 < 0 || !gs ||
+        aNp.count != 1 || !aNp.partials || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD || !d.mail || !d.ctl || 7 * d.world > 64) return -(int)hipErrorInvalidValue;
+    const PrevSums ps = { prev.alphaD_partials, prev.s12_partials, prev.count, prev.alphaD_word, prev.betaN_word, gs, prev_slot0 };
+    hipLaunchKernelGGL(k_rc_dist_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, aNp, ps, d);
+    return check_launch();
 }
 
 void thallo_hip_march_rc_debug_set(int what, int value)

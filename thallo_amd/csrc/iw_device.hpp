@@ -33,7 +33,9 @@ __device__ __forceinline__ double wave_sum_all_d(double v) { return wave_sum_all
 // critical path between two dependent launches.
 // U = slots per lane whose loads are in flight together (the marching kernel adds up with U = 1: it does so behind its first row loads, which
 // hide the round trips, and has no registers to spare there).
-struct PrevSums { const float* aD_part; const double* s12_part; int count; float* aD_word; float* bN_word; };
+struct PrevSums { const float* aD_part; const double* s12_part; int count; float* aD_word; float* bN_word;
+                  unsigned long long* gs; int xslot; };     // gs != NULL (row slabs, device-side exchange): iteration k-1's sums are THIS rank's; the launch's designated wave trades them
+                                                            // with the other ranks through mailbox slots xslot .. xslot + 6 and publishes the two global words as tagged granules gs[0], gs[1]
 template <int U = 4>
 __device__ __forceinline__ void iteration_scalars(thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, const PrevSums& prev, float& alpha, float& beta, bool writer)
 {

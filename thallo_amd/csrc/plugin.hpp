@@ -163,6 +163,13 @@ public:
     virtual void resident_disable() {}                                                          // ... after which the plan stays on one launch per PCG iteration
     // ... for one rank's row slab on the device-side transport (thallo_hip_iw_pcg_resident_dist): boundary rows of A p straight into the neighbours' ghost areas
     // (ghost_off bytes into every rank's mailbox block), the scalars through the mailbox slots slot0 + 7 k ..
+    // Row slabs on the device-side transport with the DEFERRED cross-rank finish (round 4): launch k stores this rank's partials only; launch k + 1's designated wave adds
+    // them up, trades the rank sums through mailbox slots prev_slot0 .. + 6, leaves the two words of iteration k behind and publishes them to the launch's other waves
+    // through `gs`, all while the first rows load; pcg_iter_dist_finish does the same for a GN step's last iteration
+    virtual bool dist_defers_finish() const { return false; }
+    virtual int  pcg_iter_dist_deferred(LaunchCtx&, SolverVectors&, int /*cur*/, int /*mode*/, thallo_sum_t /*aN*/, thallo_sum_t /*aD*/, thallo_sum_t /*bN*/, thallo_sum_t /*aN2*/, thallo_sum_t /*aD2*/,
+                                        const thallo_prev_t& /*prev*/, int /*prev_slot0*/, unsigned long long* /*gs*/, const thallo_dist_t&, float* /*alphaD_out*/, double* /*s12_out*/) { return -1; }
+    virtual int  pcg_iter_dist_finish(LaunchCtx&, const thallo_prev_t& /*prev*/, int /*prev_slot0*/, thallo_sum_t /*aN*/, const thallo_dist_t&, unsigned long long* /*gs*/) { return -1; }
     virtual bool dist_batches_delta() const { return false; }          // the device-side transport's iteration kernel has the "apply two delta updates" form too
     virtual bool resident_slab_ok() const { return false; }
     virtual long resident_ghost_bytes() const { return 0; }

@@ -243,6 +243,21 @@ public:
                                            v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
                                            aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, d, out, v.s12, v.fin_tickets, slot0, aD_word, bN_word, c.stream);
     }
+    bool dist_defers_finish() const override { return march_rc_ && march_; }
+    int pcg_iter_dist_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2,
+                               const thallo_prev_t& prev, int prev_slot0, unsigned long long* gs, const thallo_dist_t& d, float* out, double* s12_out) override
+    {
+        TimedLaunch t(c, "PCGIteration");
+        if (mode & 1)       // a GN step's first iteration: the stored-plane kernel, partials only (no tickets: nothing is exchanged at its end)
+            return thallo_hip_iw_pcg_iter_march_dist(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                     v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                                     aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, d, out, s12_out, nullptr, 0, nullptr, nullptr, c.stream);
+        return thallo_hip_iw_pcg_iter_march_rc_dist_deferred(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg,
+                                                             v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
+                                                             aN, aN2, aD2, prev, prev_slot0, gs, (const int*)irregular.ptr, d, out, s12_out, c.stream);
+    }
+    int pcg_iter_dist_finish(LaunchCtx& c, const thallo_prev_t& prev, int prev_slot0, thallo_sum_t aN, const thallo_dist_t& d, unsigned long long* gs) override
+    { TimedLaunch t(c, "PCGScalars"); return thallo_hip_iw_dist_finish_deferred(prev, prev_slot0, aN, d, gs, c.stream); }
     float* unknown_ptr(int k) override { return k == 0 ? offset : angle; }
     int cost(LaunchCtx& c, float* out) override
     { TimedLaunch t(c, "computeCost"); return thallo_hip_iw_cost(W, H, row0_, row1_, offset, angle, urshape, constraints, mask, w_fit, w_reg, out, c.stream); }

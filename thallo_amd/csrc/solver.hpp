@@ -81,6 +81,8 @@ struct DistState {
     void* mail = nullptr; int mail_L = 0;
     long ghost_off = 0;                                  // byte offset of the resident kernel's ghost area inside every rank's mailbox block (0: none)
     DeviceBuffer ctl;
+    int defer_state = -1;                                 // the deferred cross-rank finish: -1 not agreed on yet, 0 no, 1 every rank runs it
+    DeviceBuffer gs;                                      // two tagged granules: the global words a launch's designated wave publishes for its other waves (deferred cross-rank finish)
     thallo_dist_t d, d_iter[2];
     std::vector<void*> opened;
     std::string info;                                    // JSON: transport, memory kind, self-check outcome

@@ -584,7 +584,44 @@ int Plan::dist_gn(int L, bool p2p)
         }
         cur_ = L & 1;
     }
-    for (int k = 0; k < (resident ? 0 : L); ++k) {
+    // Larger slabs on the device-side transport (the marching kernels): the exchange of an iteration's sums does not sit at the END of its launch (tickets -> last
+    // workgroup -> granules to the peers -> wait -> two words: ~8 us that nothing hides) but at the START of the next one, where a designated wave does it while every
+    // wave's first rows load (plugin.hpp dist_defers_finish); one one-wave launch finishes the step's last iteration.  Same granules, slots, orders: same bits.
+    bool defer_x = false;
+    if (p2p && !resident && L >= 1) {
+        // (every rank must run the same schedule -- a non-deferring rank's last workgroup would wait for granules a deferring rank sends a launch LATER --: agreed once,
+        //  at the first device-side step of the plan, which is the set-up's self-check: never inside a captured graph)
+        if (D.defer_state < 0) {
+            bool mine = plugin->dist_defers_finish() && ensure_iter_buffers() == 0 && (D.gs.ptr || D.gs.alloc(64) == 0), all = false;
+            if (dist_agree(mine, all)) return -1;
+            D.defer_state = all ? 1 : 0;
+        }
+        defer_x = D.defer_state == 1;
+    }
+    int nb_prev = 0;
+    for (int k = 0; k < ((resident || !defer_x) ? 0 : L); ++k) {
+        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+        const int mode = THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
+        unsigned long long* gs = (unsigned long long*)D.gs.ptr;
+        if (!D.failed) {
+            const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
+            const thallo_prev_t prev = { k ? slot(jD - 2) : nullptr, v_.s12buf((k - 1) & 1), nb_prev, k ? scal(jD - 2) : nullptr, k ? scal(jB - 2) : nullptr };
+            nb = plugin->pcg_iter_dist_deferred(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, prev, 7 * (k - 1), gs, D.d_iter[cur_ ^ 1], slot(jD), v_.s12buf(k & 1));
+            if (nb < 0) dist_fail("PCGIteration (device-side exchange, deferred finish) launch failed (%d)", nb);
+        }
+        if (!D.failed) {
+            if (k) { fin_[jD - 2] = 1; set_nb(jB - 2, 1); fin_[jB - 2] = 1; }      // (that launch's designated wave writes the two words of iteration k-1)
+            set_nb(jD, nb); nb_prev = nb;
+        }
+        cur_ ^= 1;
+        if (k == L - 1 && !D.failed) {
+            const thallo_prev_t last = { slot(jD), v_.s12buf(k & 1), nb, scal(jD), scal(jB) };
+            const int rc = plugin->pcg_iter_dist_finish(ctx, last, 7 * k, sum(jN), D.d, gs);
+            if (rc < 0) dist_fail("PCGScalars (device-side exchange) launch failed (%d)", rc);
+            if (!D.failed) { fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+        }
+    }
+    for (int k = 0; k < ((resident || defer_x) ? 0 : L); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         const int mode = THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
         if (p2p) {        // the kernel stores its boundary rows of Ap_out into the neighbours' ghost rows and its last workgroup IS the exchange

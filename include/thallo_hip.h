@@ -450,18 +450,16 @@ int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, con
                                const float* original, float w_reg, float* F, float* G, long ell_stride, thallo_stream_t stream);
 /* ---- ARAP: the PCG loop of a whole Gauss-Newton step in ONE launch (round 4; energy_graph.hip k_arap_resident).  One thread keeps its vertex's r, p, A p, M^-1, delta in
  * registers for all L iterations (and the G matrices of its edges, which a Gauss-Newton step does not change); a workgroup keeps p_k of its vertices and of the vertices
- * they share an edge with ("ghosts": a host-built list of index intervals) in LDS and updates the ghosts' r and p itself, so an iteration has ONE hand-over: A p_k of every
+ * they share an edge with ("ghosts": a host-built ascending list per workgroup) in LDS and updates the ghosts' r and p itself, so an iteration has ONE hand-over: A p_k of every
  * vertex as {value | tag} granules for the workgroups that have it as a ghost, together with the workgroup's {alphaD | N, S1, S2} record for everybody.  Same vertex ->
  * workgroup map, expressions and summation order as thallo_hip_pcg_update + thallo_hip_arap_apply_jtj_rc per iteration: bit-identical r, p, delta, A p, alpha_k, beta_k.
  * Every wait is bounded (thallo_hip_arap_resident_status).
- * xbuf: thallo_hip_arap_resident_bytes(N) zero-filled bytes; per workgroup (= vertex / 256) 4 + 2 x max_intervals ints {count, 0, 0, 0, lo_0, hi_0, lo_1, hi_1, ...} at
- * thallo_hip_arap_resident_intervals_offset(N): disjoint ascending intervals that hold the workgroup's own vertices (inside ONE interval) and every vertex one of them
- * shares an edge with, at most thallo_hip_arap_resident_max_ghosts() vertices besides its own.  fits: ELL layout with <= 6 edge slots and every workgroup resident at
- * once (<= 2 per CU, <= 512).  Replaces the loop of gauss_newton.t:1615-1687. */
+ * xbuf: thallo_hip_arap_resident_bytes(N) zero-filled bytes; per workgroup (= vertex / 256) 4 + max_ghosts ints {count, 0, 0, 0, the vertices of OTHER workgroups that one of
+ * its vertices shares an edge with (either direction), ascending} at thallo_hip_arap_resident_lists_offset(N); count <= thallo_hip_arap_resident_max_ghosts().  fits: ELL
+ * layout with <= 6 edge slots and every workgroup resident at once (<= 2 per CU, <= 512).  Replaces the loop of gauss_newton.t:1615-1687. */
 long thallo_hip_arap_resident_bytes(int N);
-long thallo_hip_arap_resident_intervals_offset(int N);
+long thallo_hip_arap_resident_lists_offset(int N);
 int  thallo_hip_arap_resident_max_ghosts(void);
-int  thallo_hip_arap_resident_max_intervals(void);
 int  thallo_hip_arap_resident_fits(int N, long ell_stride);
 int  thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
                                   const float* constraints, const float* original, const float* SC, float w_fit, float w_reg, long ell_stride,

@@ -903,7 +903,7 @@ def test_arap_resident_pcg_loop_is_bitwise_the_launch_per_iteration_form(torch, 
 
 
 def test_arap_with_a_scattered_vertex_order_runs_one_launch_per_iteration(torch, orc):
-    """The resident loop stages a workgroup's neighbour vertices in LDS (at most 768 of other workgroups, in at most 16 index intervals: plugins.cpp build_wg_intervals);
+    """The resident loop stages a workgroup's neighbour vertices in LDS (at most 768 of other workgroups: plugins.cpp build_wg_ghost_lists);
     a mesh whose vertices are numbered at random has its neighbours all over the index space: the plan must fall back to PCGUpdate + applyJTJ per iteration -- and still
     solve the same problem (the energy does not depend on the numbering)."""
     p = syn.arap_mesh(60, 40, n_handles=8, angle_amp=0.3)

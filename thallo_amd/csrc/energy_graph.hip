@@ -490,7 +490,7 @@ __global__ __launch_bounds__(BLOCK) void k_arap_apply_rc(int N, int n0, int n1, 
 // neighbours, the sums to everybody) and were no faster than two launches (24.9 and 19.3 us per iteration).  Hence:
 //   * same vertex -> (workgroup, thread) map as the launch-per-iteration kernels (vertex n = 256 b + t), so a workgroup's partial sums are the same numbers;
 //     every workgroup must be RESIDENT (they wait for each other): the host checks what the device can hold (2 workgroups per CU);
-//   * a workgroup keeps p_k of its own vertices AND of the vertices they share an edge with ("ghosts": a host-built list of index intervals, at most ARAP_RES_GHOSTS
+//   * a workgroup keeps p_k of its own vertices AND of the vertices they share an edge with ("ghosts": a host-built ascending list, at most ARAP_RES_GHOSTS
 //     vertices, else the plan runs one launch per iteration) in LDS, and r, M^-1 of the ghosts too: it updates the ghosts' r and p itself, with the owner's
 //     expressions on the owner's inputs (bit-identical), and all it needs from the owner is A p_k at the ghost -- which goes out TOGETHER with the workgroup's
 //     sums: A p_k as {value | tag} granules (write-through sc1 stores: the data is the flag, nothing to drain), the {alphaD | N, S1, S2} record as four tagged
@@ -509,8 +509,7 @@ constexpr int ARAP_RES_GHOSTS = 768;                      // vertices of other w
 constexpr int ARAP_RES_SPAN = ARAP_RES_GHOSTS + BLOCK;    // staged vertices: LDS 2 parts x 3 floats each
 constexpr int ARAP_RES_COPIES = 8;                        // copies of the iteration's totals (a reader takes copy workgroup % 8: its XCD's, with round-robin placement)
 constexpr int ARAP_RES_ROOT = 192;                        // up to this many workgroups ONE workgroup reads the lane records and publishes the totals
-constexpr int ARAP_RES_SEGS = 16;                         // index intervals the staged set may consist of
-constexpr int ARAP_RES_SEGW = 4 + 2 * ARAP_RES_SEGS;      // ints per workgroup in the exchange memory: {count, -, -, -, lo_0, hi_0, lo_1, hi_1, ...}
+constexpr int ARAP_RES_LISTW = 4 + ARAP_RES_GHOSTS;       // ints per workgroup in the exchange memory: {count, -, -, -, ghost vertices in ascending order}
 enum { ARES_SEQ = 0, ARES_ERR = 1, ARES_SPIN_MS = 2, ARES_PM = 4, ARES_CTL_WORDS = 16 };
 typedef unsigned long long u64r;
 typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
@@ -526,7 +525,7 @@ struct ArapResArgs {
     u64r* rec;            // [2 parity][4 parts][nwg] x 16 bytes
     u64r* lrec;           // [2 parity][ARAP_RES_COPIES][4 parts][64] x 16 bytes: the lane records; behind them [2 parity][ARAP_RES_COPIES][4 parts] x 16 bytes: the totals (copies spread the readers)
     u64r* ag;             // [2 parity][2 parts: Position, Angle][N][3] granules of A p_k
-    const int* wseg;      // [nwg][ARAP_RES_SEGW]: the index intervals that hold the workgroup's vertices and their neighbours
+    const int* wlist;     // [nwg][ARAP_RES_LISTW]: the vertices of other workgroups that the workgroup's vertices share an edge with, ascending
     unsigned* ctl;
     unsigned* stamps;     // research build: [4 points][512 workgroups]
 };
@@ -563,8 +562,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
     constexpr int GH = ARAP_RES_GHOSTS / BLOCK;                       // ghosts a thread looks after
     __shared__ float4 lp[2 * ARAP_RES_SPAN];                          // [2 parts][span]: p_k of the staged vertices (slot order; one 16-byte read per neighbour)
     __shared__ float gr[6 * ARAP_RES_GHOSTS], gm[6 * ARAP_RES_GHOSTS]; // [6 components][ghost]: r_k and M^-1 of the ghosts
-    __shared__ int s_vid[ARAP_RES_SPAN];                              // staged slot -> vertex
-    __shared__ int s_seg[ARAP_RES_SEGW];
+    __shared__ int s_gl[ARAP_RES_GHOSTS];                             // ghost -> vertex (ascending)
     __shared__ float red[16];
     __shared__ double redd[3 * BLOCK / 64];
     __shared__ float s_tot_f; __shared__ double s_tot[3];
@@ -575,18 +573,17 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
     const float wr2 = a.wr * a.wr;
     const rsrc_r RREC = ares_rsrc(a.rec), RLREC = ares_rsrc(a.lrec), RAG = ares_rsrc(a.ag);
     const int nlane = min(64, a.nwg);                                // lane records in use
-    if (tid < ARAP_RES_SEGW) s_seg[tid] = a.wseg[(long)ARAP_RES_SEGW * wg + tid];
+    // staged slots: my workgroup's vertices first (slot = thread), the ghosts behind them in the list's order
+    const int nown = min(BLOCK, N - wg * BLOCK), own_s = 0;
+    const int nghost = min(a.wlist[(long)ARAP_RES_LISTW * wg], ARAP_RES_GHOSTS);
+    for (int g = tid; g < nghost; g += BLOCK) s_gl[g] = a.wlist[(long)ARAP_RES_LISTW * wg + 4 + g];
     __syncthreads();
-    const int nseg = s_seg[0];
-    int span = 0;
-    for (int s = 0; s < nseg; ++s) span += s_seg[5 + 2 * s] - s_seg[4 + 2 * s];
-    auto slot_of = [&](int v) { int base = 0; for (int s = 0; s < nseg; ++s) { const int l = s_seg[4 + 2 * s], h = s_seg[5 + 2 * s]; if (v >= l && v < h) return base + (v - l); base += h - l; } return 0; };
-    for (int u = tid; u < span; u += BLOCK) {
-        int base = 0, v = 0;
-        for (int s = 0; s < nseg; ++s) { const int l = s_seg[4 + 2 * s], h = s_seg[5 + 2 * s]; if (u >= base && u < base + (h - l)) v = l + (u - base); base += h - l; }
-        s_vid[u] = v;
-    }
-    const int own_s = slot_of(wg * BLOCK), nown = min(BLOCK, N - wg * BLOCK), nghost = span - nown;       // my workgroup's vertices are consecutive slots
+    auto slot_of = [&](int v) {
+        if (v / BLOCK == wg) return v - wg * BLOCK;
+        int lo = 0, hi = nghost;                                      // (first entry >= v: the list holds every neighbour of my vertices)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_gl[mid] < v) lo = mid + 1; else hi = mid; }
+        return nown + min(lo, nghost > 0 ? nghost - 1 : 0);
+    };
     // the vertex's constants: where its neighbours are staged, the G matrices of its edges (k_arap_apply_rc's expressions, evaluated once), the fit flag
     const int deg = live ? a.out_ptr[nc + 1] - a.out_ptr[nc] : 0, ideg = live ? a.in_ptr[nc + 1] - a.in_ptr[nc] : 0;
     const f3 on = ld3(a.O, nc), sn = ld3(a.SC, nc), cn = ld3(a.SC, (long)N + nc);
@@ -628,7 +625,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
         for (int h = 0; h < GH; ++h) {
             const int g = tid + h * BLOCK;
             if (g < nghost) {
-                const int u = g < own_s ? g : g + nown, v = s_vid[u];
+                const int u = g < own_s ? g : g + nown, v = s_gl[g];
                 const f3 r0 = ld3(a.r, v), r1 = ld3(a.r, (long)N + v), m0 = ld3(a.pre, v), m1 = ld3(a.pre, (long)N + v), z0 = ld3(a.p0, v), z1 = ld3(a.p0, (long)N + v);
                 gr[g] = r0.x; gr[ARAP_RES_GHOSTS + g] = r0.y; gr[2 * ARAP_RES_GHOSTS + g] = r0.z; gr[3 * ARAP_RES_GHOSTS + g] = r1.x; gr[4 * ARAP_RES_GHOSTS + g] = r1.y; gr[5 * ARAP_RES_GHOSTS + g] = r1.z;
                 gm[g] = m0.x; gm[ARAP_RES_GHOSTS + g] = m0.y; gm[2 * ARAP_RES_GHOSTS + g] = m0.z; gm[3 * ARAP_RES_GHOSTS + g] = m1.x; gm[4 * ARAP_RES_GHOSTS + g] = m1.y; gm[5 * ARAP_RES_GHOSTS + g] = m1.z;
@@ -783,7 +780,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
 #pragma unroll
         for (int h = 0; h < GH; ++h) {
             const int g = tid + h * BLOCK;
-            const int v = g < nghost ? s_vid[g < own_s ? g : g + nown] : 0;
+            const int v = g < nghost ? s_gl[g] : 0;
             of[h] = (g >= nghost || dead) ? 0xffffffffu : 24u * (unsigned)v + 48u * par * (unsigned)N;
             if (of[h] != 0xffffffffu) {
                 xa[h] = __builtin_amdgcn_raw_buffer_load_b128(RAG, of[h], 0, 16); xb[h] = __builtin_amdgcn_raw_buffer_load_b64(RAG, of[h] + 16u, 0, 16);
@@ -928,18 +925,17 @@ int thallo_hip_arap_apply_jtj_rc(int N, int n0, int n1, const int* out_ptr, cons
     else                     hipLaunchKernelGGL(k_arap_apply_rc<8>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, N, n0, n1, out_ptr, out_v1, in_ptr, in_src, constraints, original, SC, w_fit, w_reg, p, Ap, aD_out, L, r, pre, s3_out, f);
     int e = check_launch(); return e ? e : grid;
 }
-/* ---- the resident PCG loop (k_arap_resident): exchange memory layout [control words 256 B | lane records and totals 8192 x ARAP_RES_COPIES B | records 2 x 4 x nwg x 16 B | intervals nwg x ARAP_RES_SEGW ints | A p granules 2 x 2 x N x 3 x 8 B] */
+/* ---- the resident PCG loop (k_arap_resident): exchange memory layout [control words 256 B | lane records and totals 8192 x ARAP_RES_COPIES B | records 2 x 4 x nwg x 16 B | ghost lists nwg x ARAP_RES_LISTW ints | A p granules 2 x 2 x N x 3 x 8 B] */
 static inline int ares_nwg(int N) { return (N + BLOCK - 1) / BLOCK; }
 static inline long ares_off_lrec() { return 256; }
 static inline long ares_off_rec() { return 256 + 8192L * ARAP_RES_COPIES + 1024; }
 static inline long ares_off_range(int nwg) { return ares_off_rec() + 128L * nwg; }
-static inline long ares_off_pg(int nwg) { return (ares_off_range(nwg) + 4L * ARAP_RES_SEGW * nwg + 255) / 256 * 256; }
+static inline long ares_off_pg(int nwg) { return (ares_off_range(nwg) + 4L * ARAP_RES_LISTW * nwg + 255) / 256 * 256; }
 long thallo_hip_arap_resident_bytes(int N) { if (N < 1) return 0; const int nwg = ares_nwg(N); return ares_off_pg(nwg) + 96L * N + 256 + 8192; }      // (+ 8 KB: the research build's per-workgroup stamps)
-long thallo_hip_arap_resident_intervals_offset(int N) { return N < 1 ? -1 : ares_off_range(ares_nwg(N)); }
+long thallo_hip_arap_resident_lists_offset(int N) { return N < 1 ? -1 : ares_off_range(ares_nwg(N)); }
 int thallo_hip_arap_resident_max_ghosts(void) { return ARAP_RES_GHOSTS; }
-int thallo_hip_arap_resident_max_intervals(void) { return ARAP_RES_SEGS; }
 /* 1: the shape can run the resident loop -- the ELL layout with at most 6 edge slots, the recomputing applyJTJ, and every workgroup resident at once
- * (the staged sets are the caller's to check: at most thallo_hip_arap_resident_max_intervals() index intervals, at most thallo_hip_arap_resident_max_ghosts() vertices of other workgroups) */
+ * (the staged sets are the caller's to check: at most thallo_hip_arap_resident_max_ghosts() vertices of other workgroups per workgroup) */
 int thallo_hip_arap_resident_fits(int N, long ell_stride)
 {
     if (!thallo_hip_arap_recompute_supported(N, ell_stride)) return 0;
@@ -957,7 +953,7 @@ int thallo_hip_arap_resident_fits(int N, long ell_stride)
 }
 /* L iterations from what thallo_hip_arap_pcg_init left (r_0 in r, M^-1 in pre, zeros in p0 and delta): leaves r_{L-1}, A p_{L-1}, p_{L-1} (in p0 / p1 by the parity of
  * L, like L launches of the flat update), delta = sum_{k < L-1} alpha_k p_k and words[2k] = alphaD_k, words[2k + 1] = betaN_k -- what PCGUpdate + applyJTJ per iteration
- * leave, bit for bit.  xbuf: thallo_hip_arap_resident_bytes(N) zero-filled bytes with the workgroups' index intervals filled in.  Returns the grid size. */
+ * leave, bit for bit.  xbuf: thallo_hip_arap_resident_bytes(N) zero-filled bytes with the workgroups' ghost lists filled in.  Returns the grid size. */
 int thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
                                  const float* constraints, const float* original, const float* SC, float w_fit, float w_reg, long ell_stride,
                                  float* r, float* Ap, const float* pre, float* p0, float* p1, float* delta, thallo_sum_t alphaN0, float* words,
@@ -974,7 +970,7 @@ int thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, c
 #ifdef ARAP_STAMPS
     g_arap_dbg_xbuf = xbuf;
 #endif
-    a.ctl = (unsigned*)base; a.rec = (u64r*)(base + ares_off_rec()); a.lrec = (u64r*)(base + ares_off_lrec()); a.wseg = (const int*)(base + ares_off_range(a.nwg)); a.ag = (u64r*)(base + ares_off_pg(a.nwg)); a.stamps = (unsigned*)(base + ares_off_pg(a.nwg) + 96L * N + 256);
+    a.ctl = (unsigned*)base; a.rec = (u64r*)(base + ares_off_rec()); a.lrec = (u64r*)(base + ares_off_lrec()); a.wlist = (const int*)(base + ares_off_range(a.nwg)); a.ag = (u64r*)(base + ares_off_pg(a.nwg)); a.stamps = (unsigned*)(base + ares_off_pg(a.nwg) + 96L * N + 256);
     hipLaunchKernelGGL(k_arap_res_begin, dim3(1), dim3(64), 0, (hipStream_t)stream, a.ctl, (unsigned)L);
     hipLaunchKernelGGL(k_arap_resident<6>, dim3(a.nwg), dim3(BLOCK), 0, (hipStream_t)stream, a);
     int e = check_launch(); return e ? e : a.nwg;

@@ -366,31 +366,22 @@ struct GraphIncidence {
     DeviceBuffer out_ptr, out_v1, in_ptr, in_edge, in_src;
     long ell_stride = 0;          // > 0: out_v1 / in_edge are in the ELL layout of thallo_hip.h (position j*N + n), stride maxdeg*N
     const int* bound_v0 = nullptr; const int* bound_v1 = nullptr;
-    // per workgroup of 256 consecutive vertices: the vertices it and its neighbours (either edge direction) are, as at most `segs` ascending index intervals
-    // {count, 0, 0, 0, lo_0, hi_0, ...} (cut at the widest gaps) -- what the resident ARAP loop stages; wg_ghosts = the most vertices of other workgroups among them
-    std::vector<int> wg_seg; int wg_ghosts = 0;
-    void build_wg_intervals(const std::vector<int>& v0, const std::vector<int>& v1, int segs)
+    // per workgroup of 256 consecutive vertices: the vertices of OTHER workgroups its vertices share an edge with (either direction), ascending: {count, 0, 0, 0, ids ...},
+    // `cap` ids at most (a longer list is cut: wg_ghosts tells) -- what the resident ARAP loop stages; wg_ghosts = the longest list
+    std::vector<int> wg_list; int wg_ghosts = 0;
+    void build_wg_ghost_lists(const std::vector<int>& v0, const std::vector<int>& v1, int cap)
     {
-        const int nwg = (N + 255) / 256, W = 4 + 2 * segs;
+        const int nwg = (N + 255) / 256, W = 4 + cap;
         std::vector<std::vector<int>> need(nwg);
-        for (int w = 0; w < nwg; ++w) for (int v = w * 256; v < std::min(N, w * 256 + 256); ++v) need[w].push_back(v);
-        for (int e = 0; e < E; ++e) { need[v0[e] / 256].push_back(v1[e]); need[v1[e] / 256].push_back(v0[e]); }
-        wg_seg.assign((size_t)W * nwg, 0); wg_ghosts = 0;
+        for (int e = 0; e < E; ++e) { const int a = v0[e] / 256, b = v1[e] / 256; if (a != b) { need[a].push_back(v1[e]); need[b].push_back(v0[e]); } }
+        wg_list.assign((size_t)W * nwg, 0); wg_ghosts = 0;
         for (int w = 0; w < nwg; ++w) {
             std::vector<int>& s = need[w];
             std::sort(s.begin(), s.end()); s.erase(std::unique(s.begin(), s.end()), s.end());
-            std::vector<std::pair<int, int>> gaps;                         // (width, position) of every hole in the sorted list
-            for (size_t i = 1; i < s.size(); ++i) if (s[i] - s[i - 1] > 1) gaps.push_back({ s[i] - s[i - 1], (int)i });
-            std::sort(gaps.begin(), gaps.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
-            if ((int)gaps.size() > segs - 1) gaps.resize(segs - 1);
-            std::vector<int> cuts; for (auto& g : gaps) cuts.push_back(g.second);
-            std::sort(cuts.begin(), cuts.end());
-            int* o = &wg_seg[(size_t)W * w]; int count = 0, total = 0; size_t from = 0;
-            for (size_t c = 0; c <= cuts.size(); ++c) {
-                const size_t to = c < cuts.size() ? (size_t)cuts[c] : s.size();
-                o[4 + 2 * count] = s[from]; o[5 + 2 * count] = s[to - 1] + 1; total += s[to - 1] + 1 - s[from]; ++count; from = to;
-            }
-            o[0] = count; wg_ghosts = std::max(wg_ghosts, total - (std::min(N, w * 256 + 256) - w * 256));
+            wg_ghosts = std::max(wg_ghosts, (int)s.size());
+            const int n = std::min((int)s.size(), cap);
+            wg_list[(size_t)W * w] = n;
+            std::copy(s.begin(), s.begin() + n, wg_list.begin() + (size_t)W * w + 4);
         }
     }
     int build(int N_, int E_, const int* d_v0, const int* d_v1, bool want_ell = false)
@@ -401,7 +392,7 @@ struct GraphIncidence {
             hipMemcpy(v1.data(), d_v1, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess) { set_error("graph: cannot read the sparse maps"); return -1; }
         for (int e = 0; e < E; ++e)
             if (v0[e] < 0 || v0[e] >= N || v1[e] < 0 || v1[e] >= N) { set_error("graph: edge %d = (%d,%d) outside [0,%d)", e, v0[e], v1[e], N); return -1; }
-        if (want_ell) build_wg_intervals(v0, v1, thallo_hip_arap_resident_max_intervals());
+        if (want_ell) build_wg_ghost_lists(v0, v1, thallo_hip_arap_resident_max_ghosts());
         std::vector<int> optr(N + 1, 0), iptr(N + 1, 0), ov1(E), pos(E), iedge(E), isrc(E);
         for (int e = 0; e < E; ++e) { optr[v0[e] + 1]++; iptr[v1[e] + 1]++; }
         for (int n = 0; n < N; ++n) { optr[n + 1] += optr[n]; iptr[n + 1] += iptr[n]; }
@@ -548,7 +539,7 @@ public:
         if (g.wg_ghosts > thallo_hip_arap_resident_max_ghosts()) return 0;      // (a vertex order that scatters the neighbours: one launch per iteration)
         const long need = thallo_hip_arap_resident_bytes(N);
         if ((long)xres_.bytes < need && xres_.alloc((size_t)need)) { set_error("arap: out of device memory for the resident loop's exchange buffers"); return -1; }
-        if (hipMemcpy((char*)xres_.ptr + thallo_hip_arap_resident_intervals_offset(N), g.wg_seg.data(), g.wg_seg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { set_error("arap: interval upload failed"); return -1; }
+        if (hipMemcpy((char*)xres_.ptr + thallo_hip_arap_resident_lists_offset(N), g.wg_list.data(), g.wg_list.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { set_error("arap: ghost list upload failed"); return -1; }
         resident_ = true;
         return 0;
     }

@@ -457,6 +457,11 @@ int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, con
  * xbuf: thallo_hip_arap_resident_bytes(N) zero-filled bytes; per workgroup (= vertex / 256) 4 + max_ghosts ints {count, 0, 0, 0, the vertices of OTHER workgroups that one of
  * its vertices shares an edge with (either direction), ascending} at thallo_hip_arap_resident_lists_offset(N); count <= thallo_hip_arap_resident_max_ghosts().  fits: ELL
  * layout with <= 6 edge slots and every workgroup resident at once (<= 2 per CU, <= 512).  Replaces the loop of gauss_newton.t:1615-1687. */
+/* tools / tests: 0 = the ARAP plugin keeps the caller's vertex numbering (default 1: it renumbers by recursive coordinate bisection of Original when that leaves its
+   workgroups fewer ghost vertices: plugins.cpp ArapPlugin) */
+void thallo_hip_arap_debug_reorder(int on);
+/* N float3 between two numberings: dst[i] = src[idx[i]] (scatter = 0) or dst[idx[i]] = src[i] (scatter != 0); src != dst */
+int  thallo_hip_permute3(int N, const int* idx, const float* src, float* dst, int scatter, thallo_stream_t stream);
 long thallo_hip_arap_resident_bytes(int N);
 long thallo_hip_arap_resident_lists_offset(int N);
 int  thallo_hip_arap_resident_max_ghosts(void);

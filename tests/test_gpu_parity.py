@@ -902,10 +902,12 @@ def test_arap_resident_pcg_loop_is_bitwise_the_launch_per_iteration_form(torch, 
     assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
-def test_arap_with_a_scattered_vertex_order_runs_one_launch_per_iteration(torch, orc):
-    """The resident loop stages a workgroup's neighbour vertices in LDS (at most 768 of other workgroups: plugins.cpp build_wg_ghost_lists);
-    a mesh whose vertices are numbered at random has its neighbours all over the index space: the plan must fall back to PCGUpdate + applyJTJ per iteration -- and still
-    solve the same problem (the energy does not depend on the numbering)."""
+def test_arap_with_a_scattered_vertex_order_is_renumbered_by_the_plan(torch, orc):
+    """The resident loop stages a workgroup's neighbour vertices in LDS (at most 768 of other workgroups: plugins.cpp build_wg_ghost_lists); a mesh whose vertices are
+    numbered at random has its neighbours all over the index space.  The plan then works in its OWN numbering (recursive coordinate bisection of Original into patches of
+    256 vertices: ArapPlugin::prepare), gathers the unknowns when the caller may have written them and scatters them back whenever the solver has: the resident loop runs,
+    the trajectory follows the oracle's on the scattered mesh, and the caller's arrays hold the solution in the CALLER's numbering (compared with the same mesh solved in
+    its natural order).  With the renumbering switched off (tools / tests) the plan falls back to PCGUpdate + applyJTJ per iteration."""
     p = syn.arap_mesh(60, 40, n_handles=8, angle_amp=0.3)
     N, E = p[2].shape[0], p[6].shape[0]
     perm = np.random.default_rng(5).permutation(N)                      # new index of old vertex i = perm[i]
@@ -916,18 +918,28 @@ def test_arap_with_a_scattered_vertex_order_runs_one_launch_per_iteration(torch,
     co, _ = orc.Problem(orc.ARAP_MESH, (N, E), copy_params(q)).solve(nIterations=3, lIterations=30)
     s, dev, costs, final = _solve_gpu("arap_mesh_deformation", (N, E), q, nIterations=3, lIterations=30)
     assert rel_err(costs, co) < COST_RTOL, (costs, co)
-    s2 = api.ThalloSolver((N, E), thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
-    s2.set_solver_parameters(nIterations=1, lIterations=5)
-    prm = s2.make_params(to_device(copy_params(q))); s2.init(prm)
-    while s2.step(prm): pass
-    names = s2.kernel_stats(); s2.close()
+    s0, dev0, costs0, _ = _solve_gpu("arap_mesh_deformation", (N, E), p, nIterations=3, lIterations=30)
+    assert rel_err(costs, costs0) < COST_RTOL, (costs, costs0)
+    for k in (2, 3):                                                      # Position, Angle: the scattered run's arrays are the natural run's, renumbered
+        a = to_host(dev[k]); b0 = to_host(dev0[k])[inv]
+        assert np.abs(a - b0).max() <= 2e-4 * max(1.0, np.abs(b0).max()), (k, np.abs(a - b0).max())
+
+    def kernels(params, reorder):
+        thallo_amd.lib().thallo_hip_arap_debug_reorder(reorder)
+        try:
+            sx = api.ThalloSolver((N, E), thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
+            sx.set_solver_parameters(nIterations=1, lIterations=5)
+            prm = sx.make_params(to_device(copy_params(params))); sx.init(prm)
+            while sx.step(prm): pass
+            names = sx.kernel_stats(); sx.close()
+        finally:
+            thallo_amd.lib().thallo_hip_arap_debug_reorder(1)
+        return names
+    names = kernels(q, 1)
+    assert names.get("PCGLoopResident", {}).get("launches") == 1 and "PCGUpdate" not in names, names
+    names = kernels(q, 0)
     assert "PCGLoopResident" not in names and names.get("PCGUpdate", {}).get("launches") == 5, names
-    # the same mesh in its natural order does take the resident loop
-    s3 = api.ThalloSolver((N, E), thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
-    s3.set_solver_parameters(nIterations=1, lIterations=5)
-    prm = s3.make_params(to_device(copy_params(p))); s3.init(prm)
-    while s3.step(prm): pass
-    names = s3.kernel_stats(); s3.close()
+    names = kernels(p, 0)                                                 # the natural order fits the resident loop as it is
     assert names.get("PCGLoopResident", {}).get("launches") == 1, names
 
 

@@ -985,6 +985,20 @@ int thallo_hip_arap_resident_status(void* xbuf, int clear, unsigned* pm, thallo_
     if (clear && w[ARES_ERR]) { const unsigned z = 0; (void)hipMemcpyAsync((unsigned*)xbuf + ARES_ERR, &z, sizeof(unsigned), hipMemcpyHostToDevice, (hipStream_t)stream); (void)hipStreamSynchronize((hipStream_t)stream); }
     return w[ARES_ERR] ? 1 : 0;
 }
+/* dst[i] = src[idx[i]] (scatter == 0) or dst[idx[i]] = src[i] (scatter != 0) for N float3: a vertex array between the caller's numbering and the plan's (plugins.cpp: ArapPlugin) */
+__global__ __launch_bounds__(BLOCK) void k_permute3(int N, const int* __restrict__ idx, const float* __restrict__ src, float* __restrict__ dst, int scatter)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const long a = scatter ? i : idx[i], b = scatter ? idx[i] : i;
+    dst[3 * b] = src[3 * a]; dst[3 * b + 1] = src[3 * a + 1]; dst[3 * b + 2] = src[3 * a + 2];
+}
+int thallo_hip_permute3(int N, const int* idx, const float* src, float* dst, int scatter, thallo_stream_t stream)
+{
+    if (N < 1 || !idx || !src || !dst || src == dst) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_permute3, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)stream, N, idx, src, dst, scatter);
+    return check_launch();
+}
 int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,
                              float* r, float* pre, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, long ell_stride, thallo_stream_t stream)

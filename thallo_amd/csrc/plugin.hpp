@@ -184,6 +184,9 @@ public:
     virtual float* unknown_ptr(int k) = 0;
     // the driver (or an exchange) has just written the unknowns: whatever the plugin derived from them (shape_from_shading's precomputed planes) is stale
     virtual void unknowns_changed() {}
+    // ... and the other direction: the SOLVER wrote the unknowns through unknown_ptr (PCGLinearUpdate, an LM revert).  A plugin that keeps the unknowns in its own
+    // numbering publishes them to the caller's arrays here; everybody else treats it like unknowns_changed
+    virtual void unknowns_written() { unknowns_changed(); }
     // Direct solve of the normal equations instead of PCG (gauss_newton.t:1280-1328, 1612-1613): after pcg_init, delta = (J^T J)^-1 r
     virtual bool direct_solve() const { return false; }
     virtual int  solve_direct(LaunchCtx&, SolverVectors&) { return -1; }

@@ -384,14 +384,36 @@ struct GraphIncidence {
             std::copy(s.begin(), s.begin() + n, wg_list.begin() + (size_t)W * w + 4);
         }
     }
-    int build(int N_, int E_, const int* d_v0, const int* d_v1, bool want_ell = false)
+    // the caller's sparse maps on the host, checked
+    static int read_edges(int N, int E, const int* d_v0, const int* d_v1, std::vector<int>& v0, std::vector<int>& v1)
     {
-        N = N_; E = E_; bound_v0 = d_v0; bound_v1 = d_v1;
-        std::vector<int> v0(E), v1(E);
+        v0.resize(E); v1.resize(E);
         if (hipMemcpy(v0.data(), d_v0, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(v1.data(), d_v1, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess) { set_error("graph: cannot read the sparse maps"); return -1; }
         for (int e = 0; e < E; ++e)
             if (v0[e] < 0 || v0[e] >= N || v1[e] < 0 || v1[e] >= N) { set_error("graph: edge %d = (%d,%d) outside [0,%d)", e, v0[e], v1[e], N); return -1; }
+        return 0;
+    }
+    // the most vertices of other workgroups (256 consecutive vertices each) that one workgroup's vertices share an edge with
+    static int ghost_count(int N, const std::vector<int>& v0, const std::vector<int>& v1)
+    {
+        const int nwg = (N + 255) / 256;
+        std::vector<std::vector<int>> need(nwg);
+        for (size_t e = 0; e < v0.size(); ++e) { const int a = v0[e] / 256, b = v1[e] / 256; if (a != b) { need[a].push_back(v1[e]); need[b].push_back(v0[e]); } }
+        size_t most = 0;
+        for (auto& s : need) { std::sort(s.begin(), s.end()); most = std::max(most, (size_t)(std::unique(s.begin(), s.end()) - s.begin())); }
+        return (int)most;
+    }
+    int build(int N_, int E_, const int* d_v0, const int* d_v1, bool want_ell = false)
+    {
+        std::vector<int> v0, v1;
+        if (int rc = read_edges(N_, E_, d_v0, d_v1, v0, v1)) return rc;
+        bound_v0 = d_v0; bound_v1 = d_v1;
+        return build_from_host(N_, E_, v0, v1, want_ell);
+    }
+    int build_from_host(int N_, int E_, const std::vector<int>& v0, const std::vector<int>& v1, bool want_ell)
+    {
+        N = N_; E = E_;
         if (want_ell) build_wg_ghost_lists(v0, v1, thallo_hip_arap_resident_max_ghosts());
         std::vector<int> optr(N + 1, 0), iptr(N + 1, 0), ov1(E), pos(E), iedge(E), isrc(E);
         for (int e = 0; e < E; ++e) { optr[v0[e] + 1]++; iptr[v1[e] + 1]++; }
@@ -487,6 +509,8 @@ public:
     }
 };
 
+int g_arap_reorder = 1;        // tools / tests: 0 = the caller's vertex numbering always
+extern "C" void thallo_hip_arap_debug_reorder(int on) { g_arap_reorder = on; }
 // ------------------------------------------------------------------ examples/arap_mesh_deformation/arap_mesh_deformation.t
 class ArapPlugin : public EnergyPlugin {
     int N, E;
@@ -518,9 +542,76 @@ public:
         if (!position || !angle || !original || !constraints || !v0 || !v1) { set_error("arap: null problem parameter"); return -1; }
         return 0;
     }
-    int prepare(LaunchCtx&) override
+    // ---- the plan's own vertex numbering (round 4).  The resident PCG loop stages, per workgroup of 256 consecutive vertices, the vertices of OTHER workgroups they share
+    // an edge with (at most 768), and every iteration moves their A p through the fabric: 516 per workgroup for the 320-wide torus in its natural order, and far more
+    // than fit for a mesh numbered in file order.  Recursive coordinate bisection of `Original` into patches of 256 vertices cuts that to the patch's rim (~70), so:
+    // when the whole problem is on this GPU and the bisection's numbering has fewer ghosts than the caller's, the plan works in its own numbering -- the graph is built
+    // from renumbered edges, Original / Constraints are gathered once per Init, the unknowns are gathered when the caller may have written them and scattered back
+    // whenever the solver has (PCGLinearUpdate, an LM revert): the caller's arrays are current when Thallo_ProblemStep returns, as the reference's are.
+    bool perm_ = false, import_pending_ = true;
+    std::vector<int> new2old_;                                   // cached per (Original, V0, V1) pointers
+    const void *perm_key_[3] = { nullptr, nullptr, nullptr };
+    DeviceBuffer posP, angP, origP, consP, d_new2old;
+    hipStream_t stream_ = nullptr;
+    float* Pos() { return perm_ ? (float*)posP.ptr : position; }
+    float* Ang() { return perm_ ? (float*)angP.ptr : angle; }
+    const float* Org() const { return perm_ ? (const float*)origP.ptr : original; }
+    const float* Cns() const { return perm_ ? (const float*)consP.ptr : constraints; }
+    static void bisect(std::vector<int>& idx, int lo, int hi, const float* P, int blocks)
+    {   // idx[lo, hi): vertices of `blocks` workgroups; split at the longest extent so that the left part is a whole number of workgroups
+        if (blocks <= 1) { std::sort(idx.begin() + lo, idx.begin() + hi); return; }
+        float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        for (int i = lo; i < hi; ++i) for (int c = 0; c < 3; ++c) { const float x = P[3L * idx[i] + c]; mn[c] = std::min(mn[c], x); mx[c] = std::max(mx[c], x); }
+        int ax = 0; for (int c = 1; c < 3; ++c) if (mx[c] - mn[c] > mx[ax] - mn[ax]) ax = c;
+        const int lb = blocks / 2, nl = lb * 256;
+        std::nth_element(idx.begin() + lo, idx.begin() + lo + nl, idx.begin() + hi,
+                         [&](int a, int b) { const float x = P[3L * a + ax], y = P[3L * b + ax]; return x < y || (x == y && a < b); });
+        bisect(idx, lo, lo + nl, P, lb); bisect(idx, lo + nl, hi, P, blocks - lb);
+    }
+    int import_unknowns(hipStream_t s)
     {
-        if (int rc = g.build(N, E, v0, v1, true)) return rc;
+        if (!perm_ || !import_pending_) return 0;
+        if (thallo_hip_permute3(N, (const int*)d_new2old.ptr, position, (float*)posP.ptr, 0, s) < 0 || thallo_hip_permute3(N, (const int*)d_new2old.ptr, angle, (float*)angP.ptr, 0, s) < 0) return -1;
+        import_pending_ = false;
+        return 0;
+    }
+public:
+    void unknowns_changed() override { import_pending_ = true; }
+    void unknowns_written() override
+    {
+        if (!perm_) return;
+        (void)thallo_hip_permute3(N, (const int*)d_new2old.ptr, (const float*)posP.ptr, position, 1, stream_);
+        (void)thallo_hip_permute3(N, (const int*)d_new2old.ptr, (const float*)angP.ptr, angle, 1, stream_);
+    }
+    int prepare(LaunchCtx& c) override
+    {
+        stream_ = c.stream;
+        std::vector<int> h0, h1;
+        if (int rc = GraphIncidence::read_edges(N, E, v0, v1, h0, h1)) return rc;
+        g.bound_v0 = v0; g.bound_v1 = v1;
+        perm_ = false; import_pending_ = true;
+        if (g_arap_reorder && n0_ == 0 && n1_ == N && N >= 512) {
+            if (perm_key_[0] != original || perm_key_[1] != v0 || perm_key_[2] != v1 || (int)new2old_.size() != N) {
+                std::vector<float> O((size_t)3 * N);
+                if (hipMemcpy(O.data(), original, O.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { set_error("arap: cannot read Original"); return -1; }
+                new2old_.resize(N); for (int i = 0; i < N; ++i) new2old_[i] = i;
+                bisect(new2old_, 0, N, O.data(), (N + 255) / 256);
+                perm_key_[0] = original; perm_key_[1] = v0; perm_key_[2] = v1;
+            }
+            std::vector<int> old2new(N), p0(E), p1(E);
+            for (int i = 0; i < N; ++i) old2new[new2old_[i]] = i;
+            for (int e = 0; e < E; ++e) { p0[e] = old2new[h0[e]]; p1[e] = old2new[h1[e]]; }
+            if (GraphIncidence::ghost_count(N, p0, p1) < GraphIncidence::ghost_count(N, h0, h1)) {
+                const size_t bytes = sizeof(float) * 3 * (size_t)N + 64;
+                if ((posP.bytes < bytes && (posP.alloc(bytes) || angP.alloc(bytes) || origP.alloc(bytes) || consP.alloc(bytes) || d_new2old.alloc(sizeof(int) * (size_t)N + 64))) ||
+                    hipMemcpy(d_new2old.ptr, new2old_.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice) != hipSuccess ||
+                    thallo_hip_permute3(N, (const int*)d_new2old.ptr, original, (float*)origP.ptr, 0, c.stream) < 0 ||
+                    thallo_hip_permute3(N, (const int*)d_new2old.ptr, constraints, (float*)consP.ptr, 0, c.stream) < 0) { set_error("arap: out of device memory for the renumbered vertex arrays"); return -1; }
+                perm_ = true;
+                h0.swap(p0); h1.swap(p1);
+            }
+        }
+        if (int rc = g.build_from_host(N, E, h0, h1, true)) return rc;
         const size_t edges = g.ell_stride ? (size_t)g.ell_stride : (size_t)E;      // ELL layout (thallo_hip.h) when its padding is bounded
         if (F.bytes < sizeof(float) * 3 * edges + 64 && (F.alloc(sizeof(float) * 3 * edges + 64) || G.alloc(sizeof(float) * 9 * edges + 64))) return -1;
         rc_ = thallo_hip_arap_recompute_supported(N, g.ell_stride) != 0;      // applyJTJ rebuilds G_e from per-vertex sines / cosines instead of reading it (thallo_hip.h)
@@ -548,7 +639,7 @@ public:
     int pcg_resident(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words) override
     {
         TimedLaunch t(c, "PCGLoopResident");
-        return thallo_hip_arap_pcg_resident(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr, constraints, original,
+        return thallo_hip_arap_pcg_resident(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr, Cns(), Org(),
                                             (const float*)SC.ptr, w_fit, w_reg, g.ell_stride, v.r, v.Ap, v.pre, v.p[0], v.p[1], v.delta, aN0, words, xres_.ptr, L, c.stream);
     }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_arap_resident_status(xres_.ptr, clear, pm, c.stream) : 0; }
@@ -557,23 +648,25 @@ public:
     {
         const int* op = (const int*)g.out_ptr.ptr; const int* ov = (const int*)g.out_v1.ptr; const int* ip = (const int*)g.in_ptr.ptr;
         const int* ie = (const int*)g.in_edge.ptr; const int* is = (const int*)g.in_src.ptr;
-        if (rc_) return thallo_hip_arap_apply_jtj_rc(N, n0_, n1_, op, ov, ip, is, constraints, original, (const float*)SC.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, r, pre, s3, fin, c.stream);
-        if (s3) return thallo_hip_arap_apply_jtj_sums_fin(N, n0_, n1_, op, ov, ip, ie, is, constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, r, pre, s3, fin, c.stream);
-        return thallo_hip_arap_apply_jtj(N, n0_, n1_, op, ov, ip, ie, is, constraints, (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
+        if (rc_) return thallo_hip_arap_apply_jtj_rc(N, n0_, n1_, op, ov, ip, is, Cns(), Org(), (const float*)SC.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, r, pre, s3, fin, c.stream);
+        if (s3) return thallo_hip_arap_apply_jtj_sums_fin(N, n0_, n1_, op, ov, ip, ie, is, Cns(), (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, r, pre, s3, fin, c.stream);
+        return thallo_hip_arap_apply_jtj(N, n0_, n1_, op, ov, ip, ie, is, Cns(), (const float*)G.ptr, w_fit, w_reg, p, Ap, out, g.ell_stride, c.stream);
     }
-    float* unknown_ptr(int k) override { return k == 0 ? position : angle; }
+    float* unknown_ptr(int k) override { return k == 0 ? Pos() : Ang(); }
     int cost(LaunchCtx& c, float* out) override
     {
+        if (import_unknowns(c.stream)) return -1;
         TimedLaunch t(c, "computeCost");
-        return thallo_hip_arap_cost(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, constraints, w_fit, w_reg, out, g.ell_stride, c.stream);
+        return thallo_hip_arap_cost(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, Pos(), Ang(), Org(), Cns(), w_fit, w_reg, out, g.ell_stride, c.stream);
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
+        if (import_unknowns(c.stream)) return -1;
         { TimedLaunch t(c, "precompute");
-          int rc = thallo_hip_arap_precompute2(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, position, angle, original, w_reg, (float*)F.ptr, (float*)G.ptr, rc_ ? (float*)SC.ptr : nullptr, g.ell_stride, c.stream);
+          int rc = thallo_hip_arap_precompute2(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, Pos(), Ang(), Org(), w_reg, (float*)F.ptr, (float*)G.ptr, rc_ ? (float*)SC.ptr : nullptr, g.ell_stride, c.stream);
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
-        return thallo_hip_arap_pcg_init(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, position, constraints,
+        return thallo_hip_arap_pcg_init(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, Pos(), Cns(),
                                         (const float*)F.ptr, (const float*)G.ptr, w_fit, w_reg, v.r, v.pre, v.z, v.p[cur], v.delta, v.diag, aN, g.ell_stride, c.stream);
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override

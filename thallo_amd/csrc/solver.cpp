@@ -372,7 +372,7 @@ void Plan::linear_update_tail(int L, bool batched)
         else            thallo_hip_linear_update(X, dl, nullptr, len, sum(B), sum(B), s);
         off += imgs[k].n_floats;
     }
-    plugin->unknowns_changed();
+    plugin->unknowns_written();
 }
 
 int Plan::step_gn(int ev_iter)
@@ -850,7 +850,7 @@ int Plan::step_lm(int ev_iter)
             HIP_OK(hipMemcpyAsync(plugin->unknown_ptr((int)k), v_.prevX + off, imgs[k].n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
             off += imgs[k].n_floats;
         }
-        plugin->unknowns_changed();
+        plugin->unknowns_written();
         radius_ = radius_ / decrease_factor_;
         decrease_factor_ = 2.0f * decrease_factor_;
         if (radius_ < sp.min_trust_region_radius) { sp.trust_region_radius = 10e4f; stop = true; }

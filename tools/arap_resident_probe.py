@@ -9,8 +9,9 @@ nu = int(sys.argv[1]) if len(sys.argv) > 1 else 320; nv = int(sys.argv[2]) if le
 p = syn.arap_mesh(nu, nv)
 dims = (p[2].shape[0], p[6].shape[0])
 L = 100
-def run(resident, steps=20, warm=3):
+def run(resident, steps=20, warm=3, reorder=1):
     os.environ["THALLO_RESIDENT"] = "1" if resident else "0"
+    thallo_amd.lib().thallo_hip_arap_debug_reorder(reorder)
     dev = [torch.from_numpy(x.copy()).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
     s = thallo_amd.ThalloSolver(dims, thallo_amd.energy_file("arap_mesh_deformation"), timing_level=0)
     s.set_solver_parameters(nIterations=1 << 30, lIterations=L)
@@ -20,8 +21,9 @@ def run(resident, steps=20, warm=3):
     for _ in range(steps): s.step(prm)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     names = sorted(s.kernel_stats()); c = s.current_cost(); s.close()
+    thallo_amd.lib().thallo_hip_arap_debug_reorder(1)
     return {"resident": resident, "us_per_pcg_iter": round(dt / (steps * L) * 1e6, 2), "ms_per_gn_step": round(dt / steps * 1e3, 3), "cost": c, "kernels": names}
-out = {"vertices": dims[0], "edges": dims[1], "runs": [run(True), run(False), run(True), run(False)]}
+out = {"vertices": dims[0], "edges": dims[1], "runs": [run(True), run(False), run(True), run(False)], "callers_numbering": [run(True, reorder=0), run(False, reorder=0)]}
 print(json.dumps(out))
 if os.environ.get("ARAP_STAMPS"):          # needs a library built with `make VARIANT=arapstamps EXTRA=-DARAP_STAMPS` (THALLO_LIB points at tools/ab/libThallo_arapstamps.so)
     import ctypes as C

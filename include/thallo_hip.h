@@ -460,6 +460,8 @@ int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, con
 /* tools / tests: 0 = the ARAP plugin keeps the caller's vertex numbering (default 1: it renumbers by recursive coordinate bisection of Original when that leaves its
    workgroups fewer ghost vertices: plugins.cpp ArapPlugin) */
 void thallo_hip_arap_debug_reorder(int on);
+/* *out_device += an order-sensitive checksum of n ints (out_device: 8 zeroed bytes of device memory) */
+int  thallo_hip_checksum_i32(long n, const int* v, unsigned long long* out_device, thallo_stream_t stream);
 /* N float3 between two numberings: dst[i] = src[idx[i]] (scatter = 0) or dst[idx[i]] = src[i] (scatter != 0); src != dst */
 int  thallo_hip_permute3(int N, const int* idx, const float* src, float* dst, int scatter, thallo_stream_t stream);
 long thallo_hip_arap_resident_bytes(int N);

@@ -23,6 +23,7 @@
 // ~100k vertices / 600k edges = a 13 MB working set: L2/Infinity-Cache resident, latency-bound
 // (SURVEY.md 8d), so the kernels are one-thread-per-vertex with everything else kept simple.
 #include <cstring>
+#include <algorithm>
 #include "device_common.hpp"
 #include "../../include/thallo_hip.h"
 
@@ -984,6 +985,22 @@ int thallo_hip_arap_resident_status(void* xbuf, int clear, unsigned* pm, thallo_
     if (pm) for (int i = 0; i < 5; ++i) pm[i] = w[ARES_PM + i];
     if (clear && w[ARES_ERR]) { const unsigned z = 0; (void)hipMemcpyAsync((unsigned*)xbuf + ARES_ERR, &z, sizeof(unsigned), hipMemcpyHostToDevice, (hipStream_t)stream); (void)hipStreamSynchronize((hipStream_t)stream); }
     return w[ARES_ERR] ? 1 : 0;
+}
+/* an order-sensitive checksum of n ints (a plan asks whether the sparse maps behind unchanged pointers are still the ones its incidence lists were built from) */
+__global__ __launch_bounds__(BLOCK) void k_checksum_i32(long n, const int* __restrict__ v, unsigned long long* __restrict__ out)
+{
+    unsigned long long h = 0;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+        h += ((unsigned long long)(unsigned)v[i] + 0x9e3779b97f4a7c15ull) * (2ull * (unsigned long long)i + 1ull);
+    for (int o = 32; o >= 1; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+int thallo_hip_checksum_i32(long n, const int* v, unsigned long long* out_device, thallo_stream_t stream)
+{
+    if (n < 1 || !v || !out_device) return -(int)hipErrorInvalidValue;
+    int grid = (int)std::min<long>((n + BLOCK - 1) / BLOCK, 512);
+    hipLaunchKernelGGL(k_checksum_i32, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, n, v, out_device);
+    return check_launch();
 }
 /* dst[i] = src[idx[i]] (scatter == 0) or dst[idx[i]] = src[i] (scatter != 0) for N float3: a vertex array between the caller's numbering and the plan's (plugins.cpp: ArapPlugin) */
 __global__ __launch_bounds__(BLOCK) void k_permute3(int N, const int* __restrict__ idx, const float* __restrict__ src, float* __restrict__ dst, int scatter)

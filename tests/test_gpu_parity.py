@@ -1052,13 +1052,15 @@ def _solve_gpu_lm(fname, dims, params_np, **sp):
     return s, dev, np.array(costs), final
 
 
-@pytest.mark.parametrize("which", ["iw", "arap", "lapimg", "lapgraph", "ba"])
+@pytest.mark.parametrize("which", ["iw", "arap", "arap_renumbered", "lapimg", "lapgraph", "ba"])
 def test_lm_trajectory_matches_oracle(torch, orc, which):
     """LM as the reference TEXT describes it (gauss_newton.t UsesLambda branches); oracle = same text on the CPU."""
     if which == "iw":
         p = syn.image_warping(64, 48, n_markers=8); kind, dims, fname, fc, ic = orc.IMAGE_WARPING, (64, 48), "image_warping", None, None
     elif which == "arap":
         p = syn.arap_mesh(16, 12, n_handles=8, angle_amp=0.3); kind, dims, fname, fc, ic = orc.ARAP_MESH, (p[2].shape[0], p[6].shape[0]), "arap_mesh_deformation", None, None
+    elif which == "arap_renumbered":      # >= 512 vertices: the plan works in its own vertex numbering (ArapPlugin::prepare); LM reverts write the unknowns back through it
+        p = syn.arap_mesh(40, 30, n_handles=8, angle_amp=0.3); kind, dims, fname, fc, ic = orc.ARAP_MESH, (p[2].shape[0], p[6].shape[0]), "arap_mesh_deformation", None, None
     elif which == "lapimg":
         p = syn.laplacian_image(40, 24); kind, dims, fname, fc, ic = orc.LAPLACIAN_IMAGE, (40, 24), "laplacian_image", [0.2], [1]
     elif which == "lapgraph":

@@ -943,6 +943,45 @@ def test_arap_with_a_scattered_vertex_order_is_renumbered_by_the_plan(torch, orc
     assert names.get("PCGLoopResident", {}).get("launches") == 1, names
 
 
+def test_arap_second_solve_on_the_same_plan_sees_new_constraints_and_a_new_graph(torch):
+    """The ARAP plan keeps its incidence lists and its vertex numbering across Inits while the sparse maps behind the same pointers are unchanged (a device checksum decides),
+    and gathers Original / Constraints into its own numbering at every Init: a second solve after the caller moved the handles IN PLACE must equal a fresh plan's on the
+    moved handles, bit for bit; and after the caller rewrote the edge lists in place (same graph, edges in another order) the lists are rebuilt and the solve still lands on
+    the same minimum."""
+    p = syn.arap_mesh(40, 30, n_handles=8, angle_amp=0.3)
+    N, E = p[2].shape[0], p[6].shape[0]
+    dims = (N, E)
+
+    def solve(solver, dev):
+        prm = solver.make_params(dev); solver.init(prm)
+        costs = [solver.current_cost()]
+        while solver.step(prm): costs.append(solver.current_cost())
+        return costs
+
+    dev = to_device(copy_params(p))
+    s = api.ThalloSolver(dims, thallo_amd.energy_file("arap_mesh_deformation"))
+    s.set_solver_parameters(nIterations=3, lIterations=20)
+    c1 = solve(s, dev)
+    q = copy_params(p)
+    moved = q[5].copy(); live = moved[:, 0] > -1e20; moved[live] += np.float32(0.15)
+    q[5] = moved
+    dev[5].copy_(torch.from_numpy(moved)); dev[2].copy_(torch.from_numpy(p[2])); dev[3].copy_(torch.from_numpy(p[3]))        # handles moved in place, unknowns reset
+    c2 = solve(s, dev)
+    devf = to_device(copy_params(q))
+    f = api.ThalloSolver(dims, thallo_amd.energy_file("arap_mesh_deformation"))
+    f.set_solver_parameters(nIterations=3, lIterations=20)
+    cf = solve(f, devf)
+    assert c2 == cf and c2 != c1, (c1, c2, cf)
+    assert torch.equal(dev[2], devf[2]) and torch.equal(dev[3], devf[3])
+    # the same graph with its edges listed in another order, written behind the same pointers
+    order = np.random.default_rng(3).permutation(E)
+    dev[6].copy_(torch.from_numpy(np.ascontiguousarray(p[6][order]))); dev[7].copy_(torch.from_numpy(np.ascontiguousarray(p[7][order])))
+    dev[2].copy_(torch.from_numpy(p[2])); dev[3].copy_(torch.from_numpy(p[3]))
+    c3 = solve(s, dev)
+    assert rel_err(np.array(c3), np.array(cf)) < COST_RTOL, (c3, cf)
+    s.close(); f.close()
+
+
 def test_arap_100k_vertices(torch, orc):
     """BASELINE config 3 size: 320x320 torus = 102,400 vertices / 614,400 directed edges."""
     p = syn.arap_mesh(320, 320)

@@ -493,6 +493,9 @@ int thallo_hip_ba_cost(int C, int P, int O, const float* cameras, const float* p
                        const int* oToC, const int* oToP, float* cost_out, thallo_stream_t stream);
 int thallo_hip_ba_compute_j(int O, const float* cameras, const float* points, const float* observations,
                             const int* cam_obs, const int* q_cam, const int* q_pt, float* Jb, float* F, thallo_stream_t stream);
+/* the same blocks from forward-mode dual numbers over the residual's expression (what rounds 1-3 stored): the reference of the closed form in the tests */
+int thallo_hip_ba_compute_j_ad(int O, const float* cameras, const float* points, const float* observations,
+                            const int* cam_obs, const int* q_cam, const int* q_pt, float* Jb, float* F, thallo_stream_t stream);
 int thallo_hip_ba_pcg_init(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_ptr, const int* pt_pos, const int* q_cam,
                            const float* Jb, const float* F, float* r, float* pre, float* z, float* p_prev, float* delta,
                            float* diag_out, float* alphaN_out, thallo_stream_t stream);
@@ -607,14 +610,14 @@ int thallo_hip_arap_apply_jtj_sums_fin(int N, int n0, int n1, const int* out_ptr
 int thallo_hip_sfs_apply_jtj_sums_fin(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                       float* U, float* R, const float* p, float* Ap, float* alphaD_out, const float* r, double* s3_out, thallo_fin_t fin, thallo_stream_t stream);
 int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                                 const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* alphaD_out,
+                                 const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* alphaD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream);
 int thallo_hip_ba_apply2_camera_slots(int C_, int P_);      /* how many of thallo_hip_ba_apply_jtj2*'s partial slots (the first ones) are the camera launch's */
 /* LM: applyJTJ with PCGStep1_Finish folded in (gauss_newton.t:774-787): Ap = (J^T J + CtC) p, partials of p . Ap; gate as below (may be NULL) */
 int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                 float* U, float* R, const float* p, const float* CtC, float* Ap, float* alphaD_out, const unsigned* gate, thallo_stream_t stream);
 int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                                const float* Jb, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* alphaD_out,
+                                const float* cameras, const float* points, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* alphaD_out,
                                 const unsigned* gate, thallo_stream_t stream);
 /* shape_from_shading applyJTJ with a device-side gate word (may be NULL): non-zero = the launch does nothing (the LM branch ends its PCG loop on
  * the device without a host round trip per iteration, solver.cpp) */
@@ -622,12 +625,13 @@ int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, i
                                    float* U, float* R, const float* p, float* Ap, float* alphaD_out, const unsigned* gate, thallo_stream_t stream);
 /* J^T (J p) with J p formed once (energy_ba.hip): q_ptk[q] = position of observation q in its point's list (inverse of pt_pos), JP = the
  * 6 point partials of every observation packed in that order once per GN iteration, JpC = 2 floats per observation of workspace (J p in camera order: written coalesced by
- * the camera kernel, gathered through pt_pos by the point kernel -- round 4; rounds 2-3 scattered it into point order).
+ * the camera kernel, gathered through pt_pos by the point kernel -- round 4; rounds 2-3 scattered it into point order).  The camera kernel REBUILDS an observation's block
+ * from `cameras` / `points` (the unknowns as they were when thallo_hip_ba_compute_j ran: they do not change inside a PCG loop) in closed form instead of loading its 96 bytes.
  * r / pre / s3_out (all or none): also the three double sums of the single-reduction PCG form; gate: see thallo_hip_lm_set_gate. */
 int thallo_hip_ba_point_order(int O, const int* pt_pos, int* q_ptk, thallo_stream_t stream);
 int thallo_hip_ba_pack_point_blocks(int O, const float* Jb, const int* q_ptk, float* JP, thallo_stream_t stream);
 int thallo_hip_ba_apply_jtj2(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                             const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* alphaD_out,
+                             const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* alphaD_out,
                              const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_stream_t stream);
 int thallo_hip_sfs_apply_jtj_sums(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                   float* U, float* R, const float* p, float* Ap, float* alphaD_out, const float* r, double* s3_out, thallo_stream_t stream);

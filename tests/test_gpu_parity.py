@@ -982,6 +982,43 @@ def test_arap_second_solve_on_the_same_plan_sees_new_constraints_and_a_new_graph
     s.close(); f.close()
 
 
+def test_bundle_adjustment_closed_form_blocks_equal_the_forward_mode_ones(torch):
+    """Round 4: the camera kernel of J^T (J p) rebuilds an observation's 2 x 12 block from the camera and the point in closed form (energy_ba.hip ba_cam_pre / ba_block)
+    instead of loading the 96 bytes that precomputeJ stored; precomputeJ stores the closed form too.  Reference: the forward-mode dual numbers over the residual's expression
+    that rounds 1-3 stored (thallo_hip_ba_compute_j_ad).  Cameras with ordinary rotations, with |w|^2 just above and below the 1e-8 switch of AngleAxisRotatePoint
+    (lib.t:514-555), with zero rotation, and with strong distortion coefficients."""
+    L = thallo_amd.lib()
+    rng = np.random.default_rng(11)
+    C_, P_, O_ = 64, 2000, 8000
+    cams = np.zeros((C_, 9), np.float32)
+    cams[:, :3] = rng.normal(0, 0.4, (C_, 3))
+    cams[:8, :3] = rng.normal(0, 1, (8, 3)) * 8e-5          # |w|^2 ~ 2e-8: either side of the switch
+    cams[8:12, :3] = rng.normal(0, 1, (4, 3)) * 2e-5        # below it
+    cams[12:14, :3] = 0.0
+    cams[:, 3:6] = rng.normal(0, 0.3, (C_, 3)); cams[:, 5] -= 6.0
+    cams[:, 6] = rng.uniform(400, 900, C_); cams[:, 7] = rng.normal(0, 0.05, C_); cams[:, 8] = rng.normal(0, 0.02, C_)
+    pts = rng.normal(0, 1.0, (P_, 3)).astype(np.float32)
+    qc = np.sort(rng.integers(0, C_, O_)).astype(np.int32); qp = rng.integers(0, P_, O_).astype(np.int32)
+    obs = rng.normal(0, 50, (O_, 2)).astype(np.float32); cobs = np.arange(O_, dtype=np.int32)
+    d = [torch.from_numpy(x).cuda() for x in (cams, pts, obs, cobs, qc, qp)]
+    out = []
+    for fn in (L.thallo_hip_ba_compute_j, L.thallo_hip_ba_compute_j_ad):
+        J = torch.zeros(O_ * 24, dtype=torch.float32, device="cuda"); F = torch.zeros(O_ * 2, dtype=torch.float32, device="cuda")
+        fn.restype = C.c_int
+        rc = fn(C.c_int(O_), *[C.c_void_p(t.data_ptr()) for t in d], C.c_void_p(J.data_ptr()), C.c_void_p(F.data_ptr()), None)
+        assert rc == 0, (rc, thallo_amd.last_error())
+        torch.cuda.synchronize()
+        out.append((J.cpu().numpy().reshape(O_, 24).astype(np.float64), F.cpu().numpy()))
+    (Ja, Fa), (Jd, Fd) = out
+    assert np.abs(Fa - Fd).max() <= 1e-5 * np.abs(Fd).max()           # (the residual: the float evaluation against the value part of the duals)
+    assert np.isfinite(Jd).all() and np.isfinite(Ja).all()
+    scale = np.abs(Jd).max(axis=1, keepdims=True) + 1e-30
+    rel = np.abs(Ja - Jd) / scale
+    # per block: entries agree to a few float ulps of the block's largest entry; small-angle cameras included
+    assert rel.max() < 2e-5, (rel.max(), np.unravel_index(rel.argmax(), rel.shape), qc[np.unravel_index(rel.argmax(), rel.shape)[0]])
+    assert np.median(rel.max(axis=1)) < 1e-6
+
+
 def test_arap_100k_vertices(torch, orc):
     """BASELINE config 3 size: 320x320 torus = 102,400 vertices / 614,400 directed edges."""
     p = syn.arap_mesh(320, 320)

@@ -98,6 +98,75 @@ __device__ __forceinline__ void ba_residual(const float* __restrict__ cam, const
     r0 = O::cst(ox) - cx * fd; r1 = O::cst(oy) - cy * fd;
 }
 
+// ------------------------------------------------------------------------------------------ the block of one observation in closed form (round 4)
+// The same partials as ba_residual<Jet> (tests/test_gpu_parity.py compares the two), hand-derived so that a block costs ~150 flops from a point and 45 per-camera
+// constants instead of a 96-byte load: the camera kernel of J^T (J p) rebuilds it per observation instead of streaming the 65 MB of J every PCG iteration (what
+// energy_graph.hip's k_arap_apply_rc does for ARAP's per-edge blocks).  With P = R(w) X + t, c = -P.xy / P.z, pred = f (1 + r2 (l1 + l2 r2)) c, residual = obs - pred:
+//   d pred / d P = A dc/dP,  A = f [dist I + 2 (l1 + 2 l2 r2) c c^T];  J_t = -d pred / d P =: D;  J_X = D R;  J_w[k] = D (dR/dw_k X);  J_f, J_l1, J_l2 = -dist c, -f r2 c, -f r2^2 c
+// and dR/dw_k from R X = cos X + sin (u x X) + (1 - cos) u (u . X), u = w / |w| (lib.t:516-535; the small-angle branch R = I + hat(w), lib.t:537-553, has dR/dw_k = hat(e_k)).
+struct CamPre { float R[9], B[27], t[3], f, l1, l2; };
+__device__ __forceinline__ CamPre ba_cam_pre(const float* __restrict__ cam)
+{
+    CamPre o;
+    const float w0 = cam[0], w1 = cam[1], w2 = cam[2];
+    o.t[0] = cam[3]; o.t[1] = cam[4]; o.t[2] = cam[5]; o.f = cam[6]; o.l1 = cam[7]; o.l2 = cam[8];
+    const float th2 = w0 * w0 + w1 * w1 + w2 * w2;
+    if (th2 > 1e-8f) {
+        const float th = sqrtf(th2), it = 1.0f / th;
+        float s, c; sincosf(th, &s, &c);
+        const float u[3] = { w0 * it, w1 * it, w2 * it }, oc = 1.0f - c;
+        o.R[0] = c + oc * u[0] * u[0];        o.R[1] = oc * u[0] * u[1] - s * u[2]; o.R[2] = oc * u[0] * u[2] + s * u[1];
+        o.R[3] = oc * u[1] * u[0] + s * u[2]; o.R[4] = c + oc * u[1] * u[1];        o.R[5] = oc * u[1] * u[2] - s * u[0];
+        o.R[6] = oc * u[2] * u[0] - s * u[1]; o.R[7] = oc * u[2] * u[1] + s * u[0]; o.R[8] = c + oc * u[2] * u[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float du[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) du[i] = ((i == k ? 1.0f : 0.0f) - u[k] * u[i]) * it;
+            float* B = o.B + 9 * k;
+            // -s u_k I + s hat(du) + c u_k hat(u) + (1 - c)(du u^T + u du^T) + s u_k u u^T
+            const float a = -s * u[k], b = c * u[k], e = s * u[k];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) B[3 * i + j] = oc * (du[i] * u[j] + u[i] * du[j]) + e * u[i] * u[j] + (i == j ? a : 0.0f);
+            B[1] += -s * du[2] - b * u[2]; B[2] += s * du[1] + b * u[1];
+            B[3] += s * du[2] + b * u[2];  B[5] += -s * du[0] - b * u[0];
+            B[6] += -s * du[1] - b * u[1]; B[7] += s * du[0] + b * u[0];
+        }
+    } else {
+        o.R[0] = 1.f; o.R[1] = -w2; o.R[2] = w1; o.R[3] = w2; o.R[4] = 1.f; o.R[5] = -w0; o.R[6] = -w1; o.R[7] = w0; o.R[8] = 1.f;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) o.B[i] = 0.0f;
+        o.B[5] = -1.f; o.B[7] = 1.f;            // hat(e_0)
+        o.B[9 + 2] = 1.f; o.B[9 + 6] = -1.f;    // hat(e_1)
+        o.B[18 + 1] = -1.f; o.B[18 + 3] = 1.f;  // hat(e_2)
+    }
+    return o;
+}
+struct Blk { float a[24]; };
+__device__ __forceinline__ Blk ba_block(const CamPre& c, float X0, float X1, float X2)
+{
+    Blk b;
+    const float P0 = c.R[0] * X0 + c.R[1] * X1 + c.R[2] * X2 + c.t[0], P1 = c.R[3] * X0 + c.R[4] * X1 + c.R[5] * X2 + c.t[1], P2 = c.R[6] * X0 + c.R[7] * X1 + c.R[8] * X2 + c.t[2];
+    const float iz = 1.0f / P2, cx = -P0 * iz, cy = -P1 * iz;
+    const float r2 = cx * cx + cy * cy, h = c.l1 + 2.0f * c.l2 * r2, dist = 1.0f + r2 * (c.l1 + c.l2 * r2), fd = c.f * dist, fh2 = 2.0f * c.f * h;
+    const float a00 = fd + fh2 * cx * cx, a01 = fh2 * cx * cy, a11 = fd + fh2 * cy * cy;
+    const float D0[3] = { a00 * iz, a01 * iz, (a00 * cx + a01 * cy) * iz }, D1[3] = { a01 * iz, a11 * iz, (a01 * cx + a11 * cy) * iz };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float* B = c.B + 9 * k;
+        const float v0 = B[0] * X0 + B[1] * X1 + B[2] * X2, v1 = B[3] * X0 + B[4] * X1 + B[5] * X2, v2 = B[6] * X0 + B[7] * X1 + B[8] * X2;
+        b.a[k] = D0[0] * v0 + D0[1] * v1 + D0[2] * v2; b.a[12 + k] = D1[0] * v0 + D1[1] * v1 + D1[2] * v2;
+        b.a[3 + k] = D0[k]; b.a[15 + k] = D1[k];
+        b.a[9 + k] = D0[0] * c.R[k] + D0[1] * c.R[3 + k] + D0[2] * c.R[6 + k]; b.a[21 + k] = D1[0] * c.R[k] + D1[1] * c.R[3 + k] + D1[2] * c.R[6 + k];
+    }
+    const float fr2 = c.f * r2;
+    b.a[6] = -cx * dist; b.a[7] = -cx * fr2; b.a[8] = -cx * fr2 * r2;
+    b.a[18] = -cy * dist; b.a[19] = -cy * fr2; b.a[20] = -cy * fr2 * r2;
+    return b;
+}
+
 // computeCost: per observation (any order)
 __global__ __launch_bounds__(BLOCK) void k_cost(int O_, const float* __restrict__ cams, const float* __restrict__ pts,
                                                 const float2* __restrict__ obs, const int* __restrict__ oToC, const int* __restrict__ oToP,
@@ -113,7 +182,8 @@ __global__ __launch_bounds__(BLOCK) void k_cost(int O_, const float* __restrict_
     block_store_partial(acc, out, red);
 }
 
-// precomputeJ: J blocks + residuals in camera-sorted order q
+// precomputeJ: J blocks + residuals in camera-sorted order q.  AD = the forward-mode duals (what rounds 1-3 stored; kept as the closed form's test reference)
+template <bool AD>
 __global__ __launch_bounds__(BLOCK) void k_compute_j(int O_, const float* __restrict__ cams, const float* __restrict__ pts,
                                                      const float2* __restrict__ obs, const int* __restrict__ cam_obs,
                                                      const int* __restrict__ q_cam, const int* __restrict__ q_pt,
@@ -121,18 +191,28 @@ __global__ __launch_bounds__(BLOCK) void k_compute_j(int O_, const float* __rest
 {
     for (int q = blockIdx.x * BLOCK + threadIdx.x; q < O_; q += gridDim.x * BLOCK) {
         const float2 ob = obs[cam_obs[q]];
-        Jet r0, r1;
-        ba_residual<Jet>(cams + 9L * q_cam[q], pts + 3L * q_pt[q], ob.x, ob.y, r0, r1);
         float4* b = Jb + 6L * q;
-        b[0] = make_float4(r0.d[0], r0.d[1], r0.d[2], r0.d[3]); b[1] = make_float4(r0.d[4], r0.d[5], r0.d[6], r0.d[7]);
-        b[2] = make_float4(r0.d[8], r0.d[9], r0.d[10], r0.d[11]);
-        b[3] = make_float4(r1.d[0], r1.d[1], r1.d[2], r1.d[3]); b[4] = make_float4(r1.d[4], r1.d[5], r1.d[6], r1.d[7]);
-        b[5] = make_float4(r1.d[8], r1.d[9], r1.d[10], r1.d[11]);
-        F[q] = make_float2(r0.v, r1.v);
+        if (AD) {
+            Jet r0, r1;
+            ba_residual<Jet>(cams + 9L * q_cam[q], pts + 3L * q_pt[q], ob.x, ob.y, r0, r1);
+            b[0] = make_float4(r0.d[0], r0.d[1], r0.d[2], r0.d[3]); b[1] = make_float4(r0.d[4], r0.d[5], r0.d[6], r0.d[7]);
+            b[2] = make_float4(r0.d[8], r0.d[9], r0.d[10], r0.d[11]);
+            b[3] = make_float4(r1.d[0], r1.d[1], r1.d[2], r1.d[3]); b[4] = make_float4(r1.d[4], r1.d[5], r1.d[6], r1.d[7]);
+            b[5] = make_float4(r1.d[8], r1.d[9], r1.d[10], r1.d[11]);
+            F[q] = make_float2(r0.v, r1.v);
+        } else {
+            const float* X = pts + 3L * q_pt[q];
+            float r0, r1;
+            ba_residual<float>(cams + 9L * q_cam[q], X, ob.x, ob.y, r0, r1);
+            const CamPre cp = ba_cam_pre(cams + 9L * q_cam[q]);
+            const Blk k = ba_block(cp, X[0], X[1], X[2]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) b[i] = make_float4(k.a[4 * i], k.a[4 * i + 1], k.a[4 * i + 2], k.a[4 * i + 3]);
+            F[q] = make_float2(r0, r1);
+        }
     }
 }
 
-struct Blk { float a[24]; };
 __device__ __forceinline__ Blk ld_blk(const float4* __restrict__ Jb, long q)
 {
     Blk b; const float4* s = Jb + 6 * q;
@@ -270,7 +350,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_point_blocks(int O_, const float
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ cam_ptr, const int* __restrict__ q_pt,
-                                                const float4* __restrict__ Jb, const float* __restrict__ p, float* __restrict__ Ap, float2* __restrict__ JpC,
+                                                const float* __restrict__ cams, const float* __restrict__ pts, const float* __restrict__ p, float* __restrict__ Ap, float2* __restrict__ JpC,
                                                 float* __restrict__ part_out, const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
                                                 const unsigned* __restrict__ gate, const float* __restrict__ ctc)
 {
@@ -284,9 +364,12 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
         float s[9], pc[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) { s[k] = 0.0f; pc[k] = p[9L * c + k]; }
+        const CamPre cp = ba_cam_pre(cams + 9L * c);              // (every lane for itself: ~200 flops per camera, against ~6 observations per lane)
         for (int q = cam_ptr[c] + lane; q < cam_ptr[c + 1]; q += 64) {
-            const Blk b = ld_blk(Jb, q);
-            const float* pp = p + PB + 3L * q_pt[q];
+            const long pi = q_pt[q];
+            const float* X = pts + 3L * pi;
+            const Blk b = ba_block(cp, X[0], X[1], X[2]);            // the observation's block, rebuilt (it was a 96-byte load)
+            const float* pp = p + PB + 3L * pi;
             const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
             float j0 = b.a[9] * p0 + b.a[10] * p1 + b.a[11] * p2, j1 = b.a[21] * p0 + b.a[22] * p1 + b.a[23] * p2;      // same order as k_gather<1>
 #pragma unroll
@@ -371,7 +454,16 @@ int thallo_hip_ba_compute_j(int O_, const float* cameras, const float* points, c
                             const int* cam_obs, const int* q_cam, const int* q_pt, float* Jb, float* F, thallo_stream_t stream)
 {
     int grid = (O_ + BLOCK - 1) / BLOCK; if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_compute_j, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, O_, cameras, points, (const float2*)observations,
+    hipLaunchKernelGGL(k_compute_j<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, O_, cameras, points, (const float2*)observations,
+                       cam_obs, q_cam, q_pt, (float4*)Jb, (float2*)F);
+    return check_launch();
+}
+/* the same blocks from forward-mode dual numbers over the residual's expression (rounds 1-3's J): the closed form's reference in the tests */
+int thallo_hip_ba_compute_j_ad(int O_, const float* cameras, const float* points, const float* observations,
+                               const int* cam_obs, const int* q_cam, const int* q_pt, float* Jb, float* F, thallo_stream_t stream)
+{
+    int grid = (O_ + BLOCK - 1) / BLOCK; if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_compute_j<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, O_, cameras, points, (const float2*)observations,
                        cam_obs, q_cam, q_pt, (float4*)Jb, (float2*)F);
     return check_launch();
 }
@@ -403,15 +495,15 @@ int thallo_hip_ba_pack_point_blocks(int O_, const float* Jb, const int* q_ptk, f
 }
 
 static int ba_apply2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                     const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
+                     const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
                      const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, const float* ctc, thallo_stream_t stream)
 {
-    if (!cam_ptr || !q_pt || !pt_pos || !pt_ptr || !Jb || !JP || !JpC || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
+    if (!cam_ptr || !q_pt || !pt_pos || !pt_ptr || !cameras || !points || !JP || !JpC || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
     if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || gate || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     int cb, grid; gather_shape(C_, P_, cb, grid);
     // the camera launch fills slots [0, cb); the point launch the rest, and (fin) its last workgroup adds up all `grid` of them
-    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, (const float4*)Jb, p, Ap, (float2*)JpC, aD_out, r, pre, s3_out, gate, ctc);
+    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, cameras, points, p, Ap, (float2*)JpC, aD_out, r, pre, s3_out, gate, ctc);
     hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, pt_pos, (const float2*)JP, (const float2*)JpC, p, Ap, aD_out, r, pre,
                        s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid }, ctc);
     int e = check_launch(); return e ? e : grid;
@@ -421,23 +513,23 @@ int thallo_hip_ba_apply2_camera_slots(int C_, int P_)
     int cb, grid; gather_shape(C_, P_, cb, grid); return cb;
 }
 int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                                 const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
+                                 const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream)
-{ return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, Jb, JP, JpC, p, Ap, aD_out, r, pre, s3_out, gate, fin, nullptr, stream); }
+{ return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, p, Ap, aD_out, r, pre, s3_out, gate, fin, nullptr, stream); }
 int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                                const float* Jb, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* aD_out,
+                                const float* cameras, const float* points, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* aD_out,
                                 const unsigned* gate, thallo_stream_t stream)
 {
     if (!CtC) return -(int)hipErrorInvalidValue;
     const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
-    return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, Jb, JP, JpC, p, Ap, aD_out, nullptr, nullptr, nullptr, gate, none, CtC, stream);
+    return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, p, Ap, aD_out, nullptr, nullptr, nullptr, gate, none, CtC, stream);
 }
 int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                             const float* Jb, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
+                             const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
                              const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_stream_t stream)
 {
     const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
-    return thallo_hip_ba_apply_jtj2_fin(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, Jb, JP, JpC, p, Ap, aD_out, r, pre, s3_out, gate, none, stream);
+    return thallo_hip_ba_apply_jtj2_fin(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, p, Ap, aD_out, r, pre, s3_out, gate, none, stream);
 }
 
 }  // extern "C"

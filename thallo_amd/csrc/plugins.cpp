@@ -724,7 +724,7 @@ class BundleAdjustmentPlugin : public EnergyPlugin {
     int apply2(LaunchCtx& c, SolverVectors* v, const float* p, float* Ap, float* out, const thallo_fin_t& fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr })
     {
         return thallo_hip_ba_apply_jtj2_fin(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr,
-                                            (const float*)Jb.ptr, (const float*)JP.ptr, (float*)JpP.ptr, p, Ap, out,
+                                            cameras, points, (const float*)JP.ptr, (float*)JpP.ptr, p, Ap, out,
                                             v ? v->r : nullptr, v ? v->pre : nullptr, v ? v->s12 : nullptr, c.gate, fin, c.stream);
     }
 public:
@@ -787,7 +787,7 @@ public:
         TimedLaunch t(c, "PCGStep1");
         if (c.lm_ctc)
             return thallo_hip_ba_apply_jtj2_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr,
-                                               (const float*)Jb.ptr, (const float*)JP.ptr, (float*)JpP.ptr, p, c.lm_ctc, Ap, out, c.gate, c.stream);
+                                               cameras, points, (const float*)JP.ptr, (float*)JpP.ptr, p, c.lm_ctc, Ap, out, c.gate, c.stream);
         return apply2(c, nullptr, p, Ap, out);
     }
     long shared_block_offset() const override { return 9L * C; }

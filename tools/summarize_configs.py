@@ -26,8 +26,9 @@ KEYS = [("k_march<true, false, false, false, 2, false, true>", "shape_from_shadi
         ("k_precompute_march", "shape_from_shading precompute (marching kernel, 2048^2; 39 B/pixel: X D I masks in, G Wt fl out)", 39 * NPX),
         ("k_fused<1>", "shape_from_shading applyJTJ (fused, 2048^2)", 33 * NPX),
         ("k_fused<0>", "shape_from_shading PCGInit1 J^T F (fused, 2048^2)", None),
-        ("k_cam2", "bundle_adjustment J^T(Jp) camera kernel (ladybug-1723 shape)", 116 * O_BA),
-        ("k_pt2", "bundle_adjustment J^T(Jp) point kernel (ladybug-1723 shape)", 32 * O_BA),
+        ("k_cam2", "bundle_adjustment J^T(Jp) camera kernel, blocks rebuilt in closed form (ladybug-1723 shape; 36 B/observation: index 4, point 12, p of the point 12, J p out 8; rounds 2-3 loaded the 96-byte block: 116)", 36 * O_BA),
+        ("k_pt2", "bundle_adjustment J^T(Jp) point kernel (ladybug-1723 shape; 36 B/observation: packed point block 24, index 4, J p 8)", 36 * O_BA),
+        ("k_arap_resident", "ARAP resident PCG loop, 100 iterations per launch (102,400 vertices; per iteration 48 B/vertex of A p granules out and the ghosts' in, through the fabric: latency-, not byte-bound)", None),
         ("k_arap_apply_rc", "ARAP applyJTJ, per-edge blocks recomputed, + sums + in-kernel finish (102,400 vertices, 614,400 directed edges; 13.5 MB algorithmic, SURVEY 8d)", 13.5e6),
         ("k_arap_apply_ell", "ARAP applyJTJ, stored per-edge blocks (round 2's kernel)", 13.5e6),
         ("k_pcg_resident<3", "image_warping resident PCG loop, 100 iterations per launch (512^2; 99 B/pixel per iteration in the launch-per-iteration formulation)", 100 * 99 * 512 * 512),

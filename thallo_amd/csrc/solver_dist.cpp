@@ -1196,11 +1196,12 @@ int Plan::dist_self_check()
     bool all = false;
     if (dist_agree(pass, all)) return -1;
     D.p2p_on = all;
-    char buf[512];
+    char buf[512], relbuf[32];
+    if (std::isfinite(rel)) snprintf(relbuf, sizeof(relbuf), "%.3g", rel); else snprintf(relbuf, sizeof(relbuf), "null");      // (a timed-out run leaves NaNs: "nan" is not JSON)
     snprintf(buf, sizeof(buf), "{\"exchange\": \"%s\", \"rank\": %d, \"world\": %d, \"memory\": [\"%s\", \"%s\"], \"resident_loop\": %s, \"self_check\": {\"iterations\": %d, \"timeout\": %d, "
-             "\"max_rel_scalar_diff\": %.3g, \"pass\": %s, \"all_ranks_pass\": %s, \"post_mortem\": [%u, %u, %u, %u, %u]}}",
+             "\"max_rel_scalar_diff\": %s, \"pass\": %s, \"all_ranks_pass\": %s, \"post_mortem\": [%u, %u, %u, %u, %u]}}",
              all ? "p2p-mailbox" : "allgather", D.cfg.rank, D.cfg.world, D.mem_kind[0] == 1 ? "fine-grained" : "coarse-grained", D.mem_kind[1] == 1 ? "fine-grained" : "coarse-grained",
-             (all && D.resident_all) ? "true" : "false", Lc, err, rel, pass ? "true" : "false", all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
+             (all && D.resident_all) ? "true" : "false", Lc, err, relbuf, pass ? "true" : "false", all ? "true" : "false", pm[0], pm[1], pm[2], pm[3], pm[4]);
     D.info = buf;
     return 0;                                                            // (a rank that failed in here says so at the cost evaluation that follows in Init)
 }

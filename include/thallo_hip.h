@@ -455,8 +455,9 @@ int thallo_hip_arap_precompute(int N, const int* out_ptr, const int* out_v1, con
  * workgroup map, expressions and summation order as thallo_hip_pcg_update + thallo_hip_arap_apply_jtj_rc per iteration: bit-identical r, p, delta, A p, alpha_k, beta_k.
  * Every wait is bounded (thallo_hip_arap_resident_status).
  * xbuf: thallo_hip_arap_resident_bytes(N) zero-filled bytes; per workgroup (= vertex / 256) 4 + max_ghosts ints {count, 0, 0, 0, the vertices of OTHER workgroups that one of
- * its vertices shares an edge with (either direction), ascending} at thallo_hip_arap_resident_lists_offset(N); count <= thallo_hip_arap_resident_max_ghosts().  fits: ELL
- * layout with <= 6 edge slots and every workgroup resident at once (<= 2 per CU, <= 512).  Replaces the loop of gauss_newton.t:1615-1687. */
+ * its vertices shares an edge with (either direction), ascending} at thallo_hip_arap_resident_lists_offset(N); count <= thallo_hip_arap_resident_max_ghosts().  fits: the ELL
+ * layout (ell_stride = out_slots x N, in-lists of in_slots x N entries; <= 32 slots) and every workgroup resident at once (<= 2 per CU, <= 512).  A vertex's first 6 out- and
+ * in-edges live in registers; the others go through `overflow` (thallo_hip_arap_resident_overflow_floats(N, out_slots, in_slots) floats, written by the launch itself).  Replaces the loop of gauss_newton.t:1615-1687. */
 /* tools / tests: 0 = the ARAP plugin keeps the caller's vertex numbering (default 1: it renumbers by recursive coordinate bisection of Original when that leaves its
    workgroups fewer ghost vertices: plugins.cpp ArapPlugin) */
 void thallo_hip_arap_debug_reorder(int on);
@@ -466,12 +467,13 @@ int  thallo_hip_checksum_i32(long n, const int* v, unsigned long long* out_devic
 int  thallo_hip_permute3(int N, const int* idx, const float* src, float* dst, int scatter, thallo_stream_t stream);
 long thallo_hip_arap_resident_bytes(int N);
 long thallo_hip_arap_resident_lists_offset(int N);
+long thallo_hip_arap_resident_overflow_floats(int N, int out_slots, int in_slots);
 int  thallo_hip_arap_resident_max_ghosts(void);
 int  thallo_hip_arap_resident_fits(int N, long ell_stride);
 int  thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
                                   const float* constraints, const float* original, const float* SC, float w_fit, float w_reg, long ell_stride,
                                   float* r, float* Ap, const float* pre, float* p0, float* p1, float* delta, thallo_sum_t alphaN0, float* words,
-                                  void* xbuf, int L, thallo_stream_t stream);
+                                  void* xbuf, float* overflow, int in_slots, int L, thallo_stream_t stream);
 int  thallo_hip_arap_resident_status(void* xbuf, int clear, unsigned* pm, thallo_stream_t stream);
 int thallo_hip_arap_pcg_init(int N, int n0, int n1, const int* out_ptr, const int* in_ptr, const int* in_edge, const float* position,
                              const float* constraints, const float* F, const float* G, float w_fit, float w_reg,

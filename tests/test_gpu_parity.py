@@ -943,6 +943,55 @@ def test_arap_with_a_scattered_vertex_order_is_renumbered_by_the_plan(torch, orc
     assert names.get("PCGLoopResident", {}).get("launches") == 1, names
 
 
+def _irregular_arap_mesh(nu, nv, chords, seed=9):
+    """the torus mesh with `chords` rounds of extra undirected edges (v, v + 2 along u / along v, alternating) from random vertices: degrees 6 .. 6 + 2 * chords, like
+    a real triangle mesh's (tests/golden/small_armadillo.ply: 6 on average, up to 10)"""
+    p = syn.arap_mesh(nu, nv, n_handles=8, angle_amp=0.3)
+    N = p[2].shape[0]
+    rng = np.random.default_rng(seed)
+    v0, v1 = [p[6]], [p[7]]
+    idx = np.arange(N); iu, iv = idx % nu, idx // nu
+    for c in range(chords):
+        pick = rng.random(N) < 0.3
+        tgt = (iv * nu + (iu + 2) % nu) if c % 2 == 0 else (((iv + 2) % nv) * nu + iu)
+        a, b = idx[pick].astype(p[6].dtype), tgt[pick].astype(p[6].dtype)
+        v0 += [a, b]; v1 += [b, a]
+    p[6] = np.ascontiguousarray(np.concatenate(v0)); p[7] = np.ascontiguousarray(np.concatenate(v1))
+    return p
+
+
+@pytest.mark.parametrize("chords,lit", [(1, 30), (2, 20)])
+def test_arap_resident_loop_on_meshes_of_irregular_degree(torch, orc, monkeypatch, chords, lit):
+    """A real mesh has vertices of degree 10 and more; the resident loop keeps a vertex's first 6 out- and in-edges in registers and takes the others through memory
+    (k_arap_resident: the overflow slots, written once per launch).  Degrees up to 8: bit-identical to PCGUpdate + the recomputing applyJTJ per iteration (its 8-slot
+    form); degrees up to 10: the launch-per-iteration form is the stored-block kernel (other expressions), so both follow the oracle's trajectory and each other to rounding."""
+    p = _irregular_arap_mesh(48, 40, chords)
+    N, E = p[2].shape[0], p[6].shape[0]
+    deg = np.bincount(p[6], minlength=N)
+    assert deg.max() > 6 and deg.max() <= 6 + 2 * chords
+    runs = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("THALLO_RESIDENT", resident)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((N, E), thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
+        s.set_solver_parameters(nIterations=3, lIterations=lit)
+        params = s.make_params(dev); s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        names = s.kernel_stats(); s.close()
+        runs.append((costs, traces, dev[2].clone(), dev[3].clone(), names))
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert n0.get("PCGLoopResident", {}).get("launches") == 3 and "PCGUpdate" not in n0, n0
+    assert "PCGLoopResident" not in n1, n1
+    co, _ = orc.Problem(orc.ARAP_MESH, (N, E), copy_params(p)).solve(nIterations=3, lIterations=lit)
+    assert rel_err(np.array(c0), co) < COST_RTOL and rel_err(np.array(c1), co) < COST_RTOL, (c0, c1, co)
+    if deg.max() <= 8:
+        assert t0 == t1 and c0 == c1 and torch.equal(o0, o1) and torch.equal(a0, a1)
+    else:
+        assert rel_err(np.array(c0), np.array(c1)) < COST_RTOL
+
+
 def test_arap_second_solve_on_the_same_plan_sees_new_constraints_and_a_new_graph(torch):
     """The ARAP plan keeps its incidence lists and its vertex numbering across Inits while the sparse maps behind the same pointers are unchanged (a device checksum decides),
     and gathers Original / Constraints into its own numbering at every Init: a second solve after the caller moved the handles IN PLACE must equal a fresh plan's on the

@@ -526,6 +526,8 @@ struct ArapResArgs {
     u64r* rec;            // [2 parity][4 parts][nwg] x 16 bytes
     u64r* lrec;           // [2 parity][ARAP_RES_COPIES][4 parts][64] x 16 bytes: the lane records; behind them [2 parity][ARAP_RES_COPIES][4 parts] x 16 bytes: the totals (copies spread the readers)
     u64r* ag;             // [2 parity][2 parts: Position, Angle][N][3] granules of A p_k
+    float* ovf;           // overflow edges (slots >= 6 of the ELL lists): [(out: j - 6 | in: maxo - 6 + j - 6)][N] x 9 words {staged slot, G8}, written by the launch itself
+    int maxo, maxi;       // edge slots of the out / in ELL lists
     const int* wlist;     // [nwg][ARAP_RES_LISTW]: the vertices of other workgroups that the workgroup's vertices share an edge with, ascending
     unsigned* ctl;
     unsigned* stamps;     // research build: [4 points][512 workgroups]
@@ -557,7 +559,7 @@ extern "C" void* thallo_hip_arap_debug_last_xbuf(void) { return g_arap_dbg_xbuf;
 #define ASTAMP(i) do { } while (0)
 #endif
 struct G8 { float a, b, c, d, e, f, g, h; };          // gcols' three columns without the constant zero: g0 = (a, b, c), g1 = (d, e, f), g2 = (g, h, 0)
-template <int MD>
+template <int MD, bool OVF>
 __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
 {
     constexpr int GH = ARAP_RES_GHOSTS / BLOCK;                       // ghosts a thread looks after
@@ -609,6 +611,25 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
             gi[j].a = g0.x; gi[j].b = g0.y; gi[j].c = g0.z; gi[j].d = g1.x; gi[j].e = g1.y; gi[j].f = g1.z; gi[j].g = g2.x; gi[j].h = g2.y;
         }
     }
+    // edge slots beyond MD (a real mesh has vertices of degree 10 and more; its AVERAGE is 6): slot and G of such an edge go to memory once per launch and are read back
+    // every iteration -- a few per cent of the edges, L2-resident -- in the same place of the summation order (ascending slot) as the launch-per-iteration kernels have them
+    for (int j = MD; OVF && j < deg; ++j) {
+        const int vo = a.out_v1[(long)j * N + nc];
+        const f3 om = ld3(a.O, vo);
+        f3 dv; dv.x = on.x - om.x; dv.y = on.y - om.y; dv.z = on.z - om.z;
+        f3 g0, g1, g2; gcols(dn, dv, g0, g1, g2);
+        float* o = a.ovf + 9L * ((long)(j - MD) * N + nc);
+        o[0] = __int_as_float(slot_of(vo)); o[1] = g0.x; o[2] = g0.y; o[3] = g0.z; o[4] = g1.x; o[5] = g1.y; o[6] = g1.z; o[7] = g2.x; o[8] = g2.y;
+    }
+    for (int j = MD; OVF && j < ideg; ++j) {
+        const int vi = a.in_src[(long)j * N + nc];
+        const f3 om = ld3(a.O, vi);
+        const DRot dm = drot(ld3(a.SC, vi), ld3(a.SC, (long)N + vi));
+        f3 dv; dv.x = om.x - on.x; dv.y = om.y - on.y; dv.z = om.z - on.z;
+        f3 g0, g1, g2; gcols(dm, dv, g0, g1, g2);
+        float* o = a.ovf + 9L * ((long)(a.maxo - MD + j - MD) * N + nc);
+        o[0] = __int_as_float(slot_of(vi)); o[1] = g0.x; o[2] = g0.y; o[3] = g0.z; o[4] = g1.x; o[5] = g1.y; o[6] = g1.z; o[7] = g2.x; o[8] = g2.y;
+    }
     const int qn = own_s + tid;
     const bool fit = a.Cn[3 * nc] >= -999999.9f;
     // the solver state of the vertex; p_0 = M^-1 r_0 + 0 p (PCGUpdate's expression with alpha = beta = 0), for the ghosts too
@@ -659,6 +680,18 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
                 aa.z -= g2.x * jx + g2.y * jy + g2.z * jz;
             }
         }
+        for (int j = MD; OVF && j < deg; ++j) {                      // (the thread's own stores of the prologue: program order)
+            const float* o = a.ovf + 9L * ((long)(j - MD) * N + nc);
+            const float4 t4 = lp[__float_as_int(o[0])]; f3 pm; pm.x = t4.x; pm.y = t4.y; pm.z = t4.z;
+            f3 g0, g1, g2; g0.x = o[1]; g0.y = o[2]; g0.z = o[3]; g1.x = o[4]; g1.y = o[5]; g1.z = o[6]; g2.x = o[7]; g2.y = o[8]; g2.z = 0.0f;
+            const float jx = (pp.x - pm.x) - (g0.x * pa.x + g1.x * pa.y + g2.x * pa.z);
+            const float jy = (pp.y - pm.y) - (g0.y * pa.x + g1.y * pa.y + g2.y * pa.z);
+            const float jz = (pp.z - pm.z) - (g0.z * pa.x + g1.z * pa.y + g2.z * pa.z);
+            ap.x += jx; ap.y += jy; ap.z += jz;
+            aa.x -= g0.x * jx + g0.y * jy + g0.z * jz;
+            aa.y -= g1.x * jx + g1.y * jy + g1.z * jz;
+            aa.z -= g2.x * jx + g2.y * jy + g2.z * jz;
+        }
 #pragma unroll
         for (int j = 0; j < MD; ++j) {
             const float4 t4 = lp[qi[j]], u4 = lp[ARAP_RES_SPAN + qi[j]]; f3 pm, am; pm.x = t4.x; pm.y = t4.y; pm.z = t4.z; am.x = u4.x; am.y = u4.y; am.z = u4.z;
@@ -668,6 +701,15 @@ __global__ __launch_bounds__(BLOCK, 2) void k_arap_resident(ArapResArgs a)
                 ap.y -= (pm.y - pp.y) - (g0.y * am.x + g1.y * am.y + g2.y * am.z);
                 ap.z -= (pm.z - pp.z) - (g0.z * am.x + g1.z * am.y + g2.z * am.z);
             }
+        }
+        for (int j = MD; OVF && j < ideg; ++j) {
+            const float* o = a.ovf + 9L * ((long)(a.maxo - MD + j - MD) * N + nc);
+            const int q = __float_as_int(o[0]);
+            const float4 t4 = lp[q], u4 = lp[ARAP_RES_SPAN + q]; f3 pm, am; pm.x = t4.x; pm.y = t4.y; pm.z = t4.z; am.x = u4.x; am.y = u4.y; am.z = u4.z;
+            f3 g0, g1, g2; g0.x = o[1]; g0.y = o[2]; g0.z = o[3]; g1.x = o[4]; g1.y = o[5]; g1.z = o[6]; g2.x = o[7]; g2.y = o[8]; g2.z = 0.0f;
+            ap.x -= (pm.x - pp.x) - (g0.x * am.x + g1.x * am.y + g2.x * am.z);
+            ap.y -= (pm.y - pp.y) - (g0.y * am.x + g1.y * am.y + g2.y * am.z);
+            ap.z -= (pm.z - pp.z) - (g0.z * am.x + g1.z * am.y + g2.z * am.z);
         }
         ap.x *= wr2; ap.y *= wr2; ap.z *= wr2; aa.x *= wr2; aa.y *= wr2; aa.z *= wr2;
         if (fit) { ap.x += a.wf * a.wf * pp.x; ap.y += a.wf * a.wf * pp.y; ap.z += a.wf * a.wf * pp.z; }
@@ -933,20 +975,21 @@ static inline long ares_off_rec() { return 256 + 8192L * ARAP_RES_COPIES + 1024;
 static inline long ares_off_range(int nwg) { return ares_off_rec() + 128L * nwg; }
 static inline long ares_off_pg(int nwg) { return (ares_off_range(nwg) + 4L * ARAP_RES_LISTW * nwg + 255) / 256 * 256; }
 long thallo_hip_arap_resident_bytes(int N) { if (N < 1) return 0; const int nwg = ares_nwg(N); return ares_off_pg(nwg) + 96L * N + 256 + 8192; }      // (+ 8 KB: the research build's per-workgroup stamps)
+/* floats of the overflow buffer for ELL lists of out_slots / in_slots edge slots (0: none needed) */
+long thallo_hip_arap_resident_overflow_floats(int N, int out_slots, int in_slots) { const long x = (long)std::max(0, out_slots - 6) + std::max(0, in_slots - 6); return N < 1 ? 0 : 9L * N * x; }
 long thallo_hip_arap_resident_lists_offset(int N) { return N < 1 ? -1 : ares_off_range(ares_nwg(N)); }
 int thallo_hip_arap_resident_max_ghosts(void) { return ARAP_RES_GHOSTS; }
-/* 1: the shape can run the resident loop -- the ELL layout with at most 6 edge slots, the recomputing applyJTJ, and every workgroup resident at once
+/* 1: the shape can run the resident loop -- the ELL layout (at most 32 edge slots; the first 6 of a vertex live in registers, the rest go through memory), and every workgroup resident at once
  * (the staged sets are the caller's to check: at most thallo_hip_arap_resident_max_ghosts() vertices of other workgroups per workgroup) */
 int thallo_hip_arap_resident_fits(int N, long ell_stride)
 {
-    if (!thallo_hip_arap_recompute_supported(N, ell_stride)) return 0;
+    if (N < 1 || ell_stride <= 0 || ell_stride % N != 0 || ell_stride / N > 32) return 0;      // (the ELL layout; slots beyond 6 through memory)
     const int nwg = ares_nwg(N);
     if (nwg > 512 || nwg > THALLO_MAX_PARTIALS || 96.0 * N >= 4294967296.0) return 0;         // (a lane record adds up to 8 records; granule offsets are 32-bit)
-    if (ell_stride / N > 6) return 0;                   // (a thread keeps the G matrices of its edges in registers: 16 x edge slots of them)
     static int per_cu = 0;
     if (per_cu == 0) {
         int n = 0;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_arap_resident<6>, BLOCK, 0);
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_arap_resident<6, true>, BLOCK, 0);
         per_cu = (e == hipSuccess && n >= 1) ? n : -1;
         if (e != hipSuccess) (void)hipGetLastError();
     }
@@ -958,8 +1001,9 @@ int thallo_hip_arap_resident_fits(int N, long ell_stride)
 int thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, const int* in_ptr, const int* in_src,
                                  const float* constraints, const float* original, const float* SC, float w_fit, float w_reg, long ell_stride,
                                  float* r, float* Ap, const float* pre, float* p0, float* p1, float* delta, thallo_sum_t alphaN0, float* words,
-                                 void* xbuf, int L, thallo_stream_t stream)
+                                 void* xbuf, float* overflow, int in_slots, int L, thallo_stream_t stream)
 {
+    if (in_slots < 0 || in_slots > 32 || ((ell_stride / (N > 0 ? N : 1) > 6 || in_slots > 6) && !overflow)) return -(int)hipErrorInvalidValue;
     if (N < 1 || L < 1 || !out_ptr || !out_v1 || !in_ptr || !in_src || !constraints || !original || !SC || !r || !Ap || !pre || !p0 || !p1 || !delta || !words || !xbuf || !alphaN0.partials)
         return -(int)hipErrorInvalidValue;
     if (!thallo_hip_arap_resident_fits(N, ell_stride)) return -(int)hipErrorNotSupported;
@@ -967,13 +1011,15 @@ int thallo_hip_arap_pcg_resident(int N, const int* out_ptr, const int* out_v1, c
     a.N = N; a.nwg = ares_nwg(N); a.L = L; a.ell = ell_stride;
     a.out_ptr = out_ptr; a.out_v1 = out_v1; a.in_ptr = in_ptr; a.in_src = in_src; a.Cn = constraints; a.O = original; a.SC = SC; a.wf = w_fit; a.wr = w_reg;
     a.r = r; a.Ap = Ap; a.pre = pre; a.p0 = p0; a.p1 = p1; a.delta = delta; a.aN0 = alphaN0; a.words = words;
+    a.ovf = overflow; a.maxo = std::max(6, (int)(ell_stride / N)); a.maxi = std::max(6, in_slots);
     char* base = (char*)xbuf;
 #ifdef ARAP_STAMPS
     g_arap_dbg_xbuf = xbuf;
 #endif
     a.ctl = (unsigned*)base; a.rec = (u64r*)(base + ares_off_rec()); a.lrec = (u64r*)(base + ares_off_lrec()); a.wlist = (const int*)(base + ares_off_range(a.nwg)); a.ag = (u64r*)(base + ares_off_pg(a.nwg)); a.stamps = (unsigned*)(base + ares_off_pg(a.nwg) + 96L * N + 256);
     hipLaunchKernelGGL(k_arap_res_begin, dim3(1), dim3(64), 0, (hipStream_t)stream, a.ctl, (unsigned)L);
-    hipLaunchKernelGGL(k_arap_resident<6>, dim3(a.nwg), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    if (a.maxo > 6 || a.maxi > 6) hipLaunchKernelGGL((k_arap_resident<6, true>), dim3(a.nwg), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    else                          hipLaunchKernelGGL((k_arap_resident<6, false>), dim3(a.nwg), dim3(BLOCK), 0, (hipStream_t)stream, a);
     int e = check_launch(); return e ? e : a.nwg;
 }
 /* 1: a bounded wait inside the resident loop ran out since the words were cleared (pm: what, workgroup, thread, index, tag); clear != 0 resets the error word */

@@ -365,6 +365,7 @@ struct GraphIncidence {
     int N = 0, E = 0;
     DeviceBuffer out_ptr, out_v1, in_ptr, in_edge, in_src;
     long ell_stride = 0;          // > 0: out_v1 / in_edge are in the ELL layout of thallo_hip.h (position j*N + n), stride maxdeg*N
+    int in_slots = 1;             // ... and the in-lists have this many edge slots (in_edge / in_src: in_slots * N entries)
     const int* bound_v0 = nullptr; const int* bound_v1 = nullptr;
     // per workgroup of 256 consecutive vertices: the vertices of OTHER workgroups its vertices share an edge with (either direction), ascending: {count, 0, 0, 0, ids ...},
     // `cap` ids at most (a longer list is cut: wg_ghosts tells) -- what the resident ARAP loop stages; wg_ghosts = the longest list
@@ -431,6 +432,7 @@ struct GraphIncidence {
         }
         int maxin = 0;
         for (int n = 0; n < N; ++n) maxin = std::max(maxin, iptr[n + 1] - iptr[n]);
+        in_slots = std::max(1, maxin);
         if (ell_stride && (maxin > 32 || (long)maxin * N > 3L * E + N)) {                          // in-lists would pad too much: back to CSR everywhere
             ell_stride = 0;
             std::vector<int> oc2(optr.begin(), optr.end() - 1);
@@ -631,24 +633,28 @@ public:
         const size_t edges = g.ell_stride ? (size_t)g.ell_stride : (size_t)E;      // ELL layout (thallo_hip.h) when its padding is bounded
         if (F.bytes < sizeof(float) * 3 * edges + 64 && (F.alloc(sizeof(float) * 3 * edges + 64) || G.alloc(sizeof(float) * 9 * edges + 64))) return -1;
         rc_ = thallo_hip_arap_recompute_supported(N, g.ell_stride) != 0;      // applyJTJ rebuilds G_e from per-vertex sines / cosines instead of reading it (thallo_hip.h)
-        if (rc_ && SC.bytes < sizeof(float) * 6 * (size_t)N + 64 && SC.alloc(sizeof(float) * 6 * (size_t)N + 64)) return -1;
+        sc_ = rc_ || (g.ell_stride > 0 && n0_ == 0 && n1_ == N);              // (the resident loop needs them for any ELL layout)
+        if (sc_ && SC.bytes < sizeof(float) * 6 * (size_t)N + 64 && SC.alloc(sizeof(float) * 6 * (size_t)N + 64)) return -1;
         if (int rc = prepare_resident()) return rc;
         built_.o = original; built_.a = v0; built_.b = v1; built_.ck = key; built_.n0 = n0_; built_.n1 = n1_; built_.reorder = g_arap_reorder; built_.valid = true;
         return 0;
     }
     bool resident_fits_ = false;
-    bool rc_ = false;
+    bool rc_ = false, sc_ = false;
+    DeviceBuffer ovf_;                     // the resident loop's overflow edges (ELL slots beyond 6)
     DeviceBuffer SC;
     DeviceBuffer xres_;                    // exchange memory of the resident PCG loop (thallo_hip_arap_pcg_resident)
     bool resident_ = false, resident_broken_ = false;
     int prepare_resident()
     {   // the whole PCG loop in one launch: whole problem on one GPU, the recomputing applyJTJ, every workgroup resident, at most 768 ghosts per workgroup
         resident_fits_ = false; resident_ = false;
-        if (!rc_ || n0_ != 0 || n1_ != N || !thallo_hip_arap_resident_fits(N, g.ell_stride)) return 0;
+        if (!sc_ || n0_ != 0 || n1_ != N || !thallo_hip_arap_resident_fits(N, g.ell_stride)) return 0;
         if (g.wg_ghosts > thallo_hip_arap_resident_max_ghosts()) return 0;      // (a vertex order that scatters the neighbours: one launch per iteration)
         const long need = thallo_hip_arap_resident_bytes(N);
         if ((long)xres_.bytes < need && xres_.alloc((size_t)need)) { set_error("arap: out of device memory for the resident loop's exchange buffers"); return -1; }
         if (hipMemcpy((char*)xres_.ptr + thallo_hip_arap_resident_lists_offset(N), g.wg_list.data(), g.wg_list.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { set_error("arap: ghost list upload failed"); return -1; }
+        {   const long of = thallo_hip_arap_resident_overflow_floats(N, (int)(g.ell_stride / N), g.in_slots);
+            if (of > 0 && (long)ovf_.bytes < of * (long)sizeof(float) && ovf_.alloc((size_t)of * sizeof(float) + 64)) { set_error("arap: out of device memory for the resident loop's overflow edges"); return -1; } }
         resident_fits_ = true;
         update_resident();
         return 0;
@@ -664,7 +670,7 @@ public:
     {
         TimedLaunch t(c, "PCGLoopResident");
         return thallo_hip_arap_pcg_resident(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_src.ptr, Cns(), Org(),
-                                            (const float*)SC.ptr, w_fit, w_reg, g.ell_stride, v.r, v.Ap, v.pre, v.p[0], v.p[1], v.delta, aN0, words, xres_.ptr, L, c.stream);
+                                            (const float*)SC.ptr, w_fit, w_reg, g.ell_stride, v.r, v.Ap, v.pre, v.p[0], v.p[1], v.delta, aN0, words, xres_.ptr, (float*)ovf_.ptr, g.in_slots, L, c.stream);
     }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_arap_resident_status(xres_.ptr, clear, pm, c.stream) : 0; }
     void resident_disable() override { resident_ = false; resident_broken_ = true; }
@@ -687,7 +693,7 @@ public:
     {
         if (import_unknowns(c.stream)) return -1;
         { TimedLaunch t(c, "precompute");
-          int rc = thallo_hip_arap_precompute2(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, Pos(), Ang(), Org(), w_reg, (float*)F.ptr, (float*)G.ptr, rc_ ? (float*)SC.ptr : nullptr, g.ell_stride, c.stream);
+          int rc = thallo_hip_arap_precompute2(N, (const int*)g.out_ptr.ptr, (const int*)g.out_v1.ptr, Pos(), Ang(), Org(), w_reg, (float*)F.ptr, (float*)G.ptr, sc_ ? (float*)SC.ptr : nullptr, g.ell_stride, c.stream);
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_arap_pcg_init(N, n0_, n1_, (const int*)g.out_ptr.ptr, (const int*)g.in_ptr.ptr, (const int*)g.in_edge.ptr, Pos(), Cns(),

@@ -613,7 +613,9 @@ public:
                 std::vector<float> O((size_t)3 * N);
                 if (hipMemcpy(O.data(), original, O.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { set_error("arap: cannot read Original"); return -1; }
                 new2old_.resize(N); for (int i = 0; i < N; ++i) new2old_[i] = i;
-                bisect(new2old_, 0, N, O.data(), (N + 255) / 256);
+                bool finite = true;
+                for (float x : O) if (!std::isfinite(x)) { finite = false; break; }       // (a NaN coordinate has no place in an ordering: such a mesh keeps the caller's numbering)
+                if (finite) bisect(new2old_, 0, N, O.data(), (N + 255) / 256);
                 perm_key_[0] = original; perm_key_[1] = v0; perm_key_[2] = v1;
             }
             std::vector<int> old2new(N), p0(E), p1(E);

@@ -992,6 +992,47 @@ def test_arap_resident_loop_on_meshes_of_irregular_degree(torch, orc, monkeypatc
         assert rel_err(np.array(c0), np.array(c1)) < COST_RTOL
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_arap_resident_loop_on_random_meshes_and_numberings(torch, monkeypatch, seed):
+    """Seeded random instances of what the resident ARAP loop has to cope with at once: mesh sizes that are no multiple of the workgroup size (1 .. 12 workgroups), degrees
+    6 .. 10, vertices numbered at random (the plan renumbers them from 512 vertices on; below that it stages what the caller's numbering gives it), edges listed in random
+    order.  Against PCGUpdate + applyJTJ per iteration on the same plan numbering: bit-identical while no vertex has more than 8 edges (the recomputing applyJTJ's range),
+    to rounding beyond (the stored-block kernel)."""
+    rng = np.random.default_rng(100 + seed)
+    nu, nv = int(rng.integers(9, 60)), int(rng.integers(7, 50))
+    chords = int(rng.integers(0, 3))
+    p = _irregular_arap_mesh(nu, nv, chords, seed=seed)
+    N, E = p[2].shape[0], p[6].shape[0]
+    perm = rng.permutation(N); inv = np.argsort(perm)
+    for k in (2, 3, 4, 5): p[k] = np.ascontiguousarray(p[k][inv])
+    eo = rng.permutation(E)
+    p[6] = np.ascontiguousarray(perm[p[6]][eo].astype(p[6].dtype)); p[7] = np.ascontiguousarray(perm[p[7]][eo].astype(p[7].dtype))
+    deg = np.bincount(p[6], minlength=N)
+    lit = int(rng.integers(5, 40))
+    runs = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("THALLO_RESIDENT", resident)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((N, E), thallo_amd.energy_file("arap_mesh_deformation"), timing_level=2)
+        s.set_solver_parameters(nIterations=2, lIterations=lit)
+        params = s.make_params(dev); s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        names = s.kernel_stats(); s.close()
+        runs.append((costs, traces, dev[2].clone(), dev[3].clone(), names))
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == 3, (c0, thallo_amd.last_error())
+    assert "PCGLoopResident" not in n1
+    if "PCGLoopResident" not in n0:          # (a small mesh in a random numbering may have more neighbours per workgroup than the loop stages: then both runs are the same schedule)
+        assert N < 512 and c0 == c1
+        return
+    if deg.max() <= 8:
+        assert t0 == t1 and c0 == c1 and torch.equal(o0, o1) and torch.equal(a0, a1), (N, E, int(deg.max()), lit)
+    else:
+        assert rel_err(np.array(c0), np.array(c1)) < COST_RTOL, (c0, c1)
+
+
 def test_arap_second_solve_on_the_same_plan_sees_new_constraints_and_a_new_graph(torch):
     """The ARAP plan keeps its incidence lists and its vertex numbering across Inits while the sparse maps behind the same pointers are unchanged (a device checksum decides),
     and gathers Original / Constraints into its own numbering at every Init: a second solve after the caller moved the handles IN PLACE must equal a fresh plan's on the

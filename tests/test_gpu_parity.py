@@ -992,7 +992,7 @@ def test_arap_resident_loop_on_meshes_of_irregular_degree(torch, orc, monkeypatc
         assert rel_err(np.array(c0), np.array(c1)) < COST_RTOL
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("ARAP_FUZZ_SEEDS", "5")))))      # (ARAP_FUZZ_SEEDS=60: a longer run by hand)
 def test_arap_resident_loop_on_random_meshes_and_numberings(torch, monkeypatch, seed):
     """Seeded random instances of what the resident ARAP loop has to cope with at once: mesh sizes that are no multiple of the workgroup size (1 .. 12 workgroups), degrees
     6 .. 10, vertices numbered at random (the plan renumbers them from 512 vertices on; below that it stages what the caller's numbering gives it), edges listed in random

@@ -549,7 +549,8 @@ def _worker_fail(rank, world, port, W, H, lit, q, energy, fail_rank, nth):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("energy,nth", [("iw", 7), ("sfs", 9), ("sfs_lm", 12), ("ba", 9), ("arap_part", 8)])
+@pytest.mark.parametrize("energy,nth", [("iw", 7), ("sfs", 9), ("sfs_lm", 12), ("ba", 9), ("arap_part", 8)] +
+                         [("sfs_lm", int(n)) for n in os.environ.get("THALLO_FAIL_SWEEP", "27,33").split(",") if n])      # (sfs_lm: also behind the step's cost exchange; THALLO_FAIL_SWEEP=1,2,...: a sweep by hand)
 def test_rank_local_failure_is_reported_by_every_rank_and_nobody_hangs(energy, nth):
     """a launch that fails on ONE rank used to return in front of the matching all-gather and leave the other ranks blocked in it.  Now the rank stays
     in the collective sequence with poisoned payloads and the failure becomes everybody's at the next cost evaluation: both ranks finish, both see a NaN cost and

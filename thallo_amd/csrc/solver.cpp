@@ -793,11 +793,20 @@ int Plan::step_lm(int ev_iter)
     if (!skip()) { nb = thallo_hip_dot(v_.delta + o, v_.b + o, n, slot(T1), s); check(nb, "model cost: dot launch"); }
     if (!skip()) set_nb(T1, nb);
     if (failed) return 0;
-    if (global(T0) || global(T1)) return 0;
+    // the two sums over all ranks, into the step's report.  Device-side transport: ONE exchange carries both and writes them where the report is read from (it was two
+    // exchanges and two one-wave launches that copied their words there; three launches fewer, though the step's time did not move: 37.5 us per PCG iteration either way on a
+    // 2048 x 256 shape_from_shading slab -- that stretch of the step is bound by the host's launch rate, not by the launches' 4 us each)
+    const bool two_in_one = slab && dist_->xrows_now;
+    if (two_in_one) {
+        const thallo_sum_t dummy = { (const float*)dist_->send.ptr, 1 };
+        if (dist_xrows(nullptr, false, 0, skip() ? dummy : partial_sum(T0), skip() ? (const float*)dist_->send.ptr : slot(T1), nullptr, skip() ? 1 : nb_[T1], lmst + 3, lmst + 4, nullptr, 0)) return 0;
+    } else if (global(T0) || global(T1)) return 0;
     const auto& imgs = plugin->unknown_images();
     if (!skip()) {
-        thallo_hip_finish_sum(sum(T0), lmst + 3, s);
-        thallo_hip_finish_sum(sum(T1), lmst + 4, s);
+        if (!two_in_one) {
+            thallo_hip_finish_sum(sum(T0), lmst + 3, s);
+            thallo_hip_finish_sum(sum(T1), lmst + 4, s);
+        }
         long off = 0;                                                 // savePreviousUnknowns :915-920
         for (size_t k = 0; k < imgs.size(); ++k) {
             HIP_OK(hipMemcpyAsync(v_.prevX + off, plugin->unknown_ptr((int)k), imgs[k].n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -570,9 +570,15 @@ public:
                          [&](int a, int b) { const float x = P[3L * a + ax], y = P[3L * b + ax]; return x < y || (x == y && a < b); });
         bisect(idx, lo, lo + nl, P, lb); bisect(idx, lo + nl, hi, P, blocks - lb);
     }
+    const float *orig_src_ = nullptr, *cons_src_ = nullptr;      // whose contents origP / consP hold
     int import_unknowns(hipStream_t s)
     {
-        if (!perm_ || !import_pending_) return 0;
+        if (!perm_) return 0;
+        if (orig_src_ != original || cons_src_ != constraints) {      // the caller bound other arrays between two steps (parameters are dereferenced at every step: util.t:609-643)
+            if (thallo_hip_permute3(N, (const int*)d_new2old.ptr, original, (float*)origP.ptr, 0, s) < 0 || thallo_hip_permute3(N, (const int*)d_new2old.ptr, constraints, (float*)consP.ptr, 0, s) < 0) return -1;
+            orig_src_ = original; cons_src_ = constraints;
+        }
+        if (!import_pending_) return 0;
         if (thallo_hip_permute3(N, (const int*)d_new2old.ptr, position, (float*)posP.ptr, 0, s) < 0 || thallo_hip_permute3(N, (const int*)d_new2old.ptr, angle, (float*)angP.ptr, 0, s) < 0) return -1;
         import_pending_ = false;
         return 0;
@@ -600,6 +606,7 @@ public:
             import_pending_ = true;
             if (perm_ && (thallo_hip_permute3(N, (const int*)d_new2old.ptr, original, (float*)origP.ptr, 0, c.stream) < 0 ||
                           thallo_hip_permute3(N, (const int*)d_new2old.ptr, constraints, (float*)consP.ptr, 0, c.stream) < 0)) return -1;
+            orig_src_ = original; cons_src_ = constraints;
             update_resident();
             return 0;
         }
@@ -627,7 +634,7 @@ public:
                     hipMemcpy(d_new2old.ptr, new2old_.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice) != hipSuccess ||
                     thallo_hip_permute3(N, (const int*)d_new2old.ptr, original, (float*)origP.ptr, 0, c.stream) < 0 ||
                     thallo_hip_permute3(N, (const int*)d_new2old.ptr, constraints, (float*)consP.ptr, 0, c.stream) < 0) { set_error("arap: out of device memory for the renumbered vertex arrays"); return -1; }
-                perm_ = true;
+                perm_ = true; orig_src_ = original; cons_src_ = constraints;
                 h0.swap(p0); h1.swap(p1);
             }
         }

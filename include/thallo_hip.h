@@ -196,6 +196,8 @@ int thallo_hip_range_unpack(float* vec, thallo_segs_t first_rank_pieces, const f
 int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older, thallo_sum_t alphaN_older, thallo_sum_t alphaD_older,
                               const float* p, thallo_sum_t alphaN, thallo_sum_t alphaD, long len, thallo_stream_t stream);
 int thallo_hip_finish_sum(thallo_sum_t s, float* out, thallo_stream_t stream);
+/* ... behind a device-side gate word (non-zero: the launch does nothing; the LM loop's gate, see thallo_hip_lm_zeta) */
+int thallo_hip_finish_sum_gated(thallo_sum_t s, float* out, const unsigned* gate, thallo_stream_t stream);
 
 /* Row-slab exchange helpers (multi-GPU).  One rank's message per PCG iteration is
  *   out = [ local sum | first owned row | last owned row ]  (pack: out[0] = sum(partials) when sum.count > 0,
@@ -621,6 +623,24 @@ int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int 
 int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                                 const float* cameras, const float* points, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* alphaD_out,
                                 const unsigned* gate, thallo_stream_t stream);
+/* LM in the single-reduction form (round 4): an iteration is thallo_hip_pcg_update_lm (r -= alpha_{k-1} A p_{k-1}, delta += alpha_{k-1} p_{k-1}, p_k = M^-1 r + beta_{k-1} p_{k-1};
+ * the LM branch's unguarded divides; first = 1: p_0 = M^-1 r; first = 2, behind a residual reset: p_k = M^-1 r + beta_{k-1} p_{k-1} only) and thallo_hip_ba_pcg_apply_lm: A p_k = (J^T J + CtC) p_k, the alphaD partials, {N, S1, S2} and the {U, T1, T2} of
+ * q_{k+1} = 0.5 [U + alpha (T1 - T2) - alpha^2 alphaD] (U = delta_k.(r_k + b), T1 = p_k.(r_k + b), T2 = delta_k.A p_k) in double; the point launch's last workgroup finishes
+ * alphaD_k, betaN_k, q_{k+1} and applies the zeta test of gauss_newton.t:1666-1686 to lm_state (thallo_hip_lm_zeta's words; word 1 gates both launches).  fin.tickets must be
+ * set.  Three launches per LM iteration where thallo_hip_pcg_pupdate + thallo_hip_ba_apply_jtj2_lm + thallo_hip_pcg_step2_full_zeta were four, one reduction point instead of
+ * two; thallo_hip_lm_owed_delta applies the last alpha p behind the loop.  Replaces gauss_newton.t:734-787,801-843,889-899 on the LM branch. */
+int thallo_hip_pcg_update_lm(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, int first,
+                             thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* betaN_word, const float* lm_state, thallo_stream_t stream);
+/* The residual reset of the LM loop (gauss_newton.t:1653-1657) for that form, behind thallo_hip_lm_step2_first_half (delta += alpha_k p_k): the two gather launches with
+ * p = delta, r = b - (J^T J + CtC) delta and the partials of betaN_k = r . M^-1 r as their epilogue (returns the number of partials); the next thallo_hip_pcg_update_lm
+ * (first = 2) adds them up, forms p_{k+1} and leaves betaN_k in betaN_word (may be NULL otherwise).  Three launches per reset where the reference-shaped loop has five. */
+int thallo_hip_ba_lm_reset_residual(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                                    const float* cameras, const float* points, const float* JP, float* JpC, const float* delta, const float* CtC, const float* b, const float* pre,
+                                    float* r, float* betaN_out, const unsigned* gate, thallo_stream_t stream);
+int thallo_hip_ba_pcg_apply_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                               const float* cameras, const float* points, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* alphaD_out,
+                               const float* r, const float* pre, const float* delta, const float* b, double* s3_out, double* q3_out, thallo_fin_t fin,
+                               float* lm_state, int k, float q_tolerance, thallo_stream_t stream);
 /* shape_from_shading applyJTJ with a device-side gate word (may be NULL): non-zero = the launch does nothing (the LM branch ends its PCG loop on
  * the device without a host round trip per iteration, solver.cpp) */
 int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

@@ -1,0 +1,85 @@
+"""lm_rounding_experiment.py -- which rounding makes two LM trajectories of shape_from_shading part: the ORDER of the dot products, or the element-wise arithmetic?
+
+VERDICT r3 asked for the device-side form of this experiment (every LM reduction in double on the GPU against the oracle's double mode: if the error still grows about
+five-fold per LM step, the cause is element-wise rounding -- fused multiply-adds -- and not summation order).  This is the same question asked of the oracle alone, where each
+kind of rounding can be switched by itself and nothing else differs (same compiler, same source, one thread, so no run-to-run order either):
+
+  A  the oracle as built (-ffp-contract=off: every float operation rounded by itself), dot products accumulated in double
+  B  the same source built with -ffp-contract=fast -mfma (the compiler fuses a*b+c where it can -- what hipcc does to the device code), dot products in double
+  C  the build of A with the dot products in the serial FLOAT order of the reference's CPU mode (cpu_cuda.t:265-301)
+
+  B - A  = element-wise rounding alone (all reductions in double on both sides)
+  C - A  = summation order / precision alone (bit-identical element-wise arithmetic)
+
+Run once in the build container (CPU only; test infrastructure like the rest of tests/golden): `python tests/golden/lm_rounding_experiment.py [W] [steps]` writes
+tests/golden/lm_rounding_experiment.json.  Every variant runs in a process of its own (the two builds export the same symbols).
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GOLD = os.path.join(ROOT, "tests", "golden")
+BUILD = os.path.join(ROOT, "gpurun_out", "lm_rounding_build")            # scratch, not tracked
+OUT = os.path.join(GOLD, "lm_rounding_experiment.json")
+
+FLAGS = {
+    "A": ["-ffp-contract=off"],
+    "B": ["-ffp-contract=fast", "-mfma"],
+}
+
+
+def build(tag):
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "liboracle_%s.so" % tag)
+    src = [os.path.join(ROOT, "oracle", f) for f in ("thallo_oracle.c", "cpu_port_image_warping.c")]
+    cmd = ["gcc", "-O2", "-fPIC", "-fno-fast-math", "-std=c11", "-fopenmp", "-shared"] + FLAGS[tag] + ["-o", so] + src + ["-lm"]
+    subprocess.check_call(cmd)
+    return so
+
+
+def child(so, W, steps, float_sums):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as orc
+    orc._LIB = so
+    orc.build = lambda force=False: so                                   # (the variant is already built; do not rebuild the default library over it)
+    from thallo_amd import synthetic as syn
+    from helpers import copy_params
+    p = syn.shape_from_shading(W, W)
+    orc.set_threads(1)
+    t0 = time.time()
+    c, _ = orc.Problem(orc.SFS, (W, W), copy_params(p)).solve(nIterations=steps, lIterations=10, use_lm=1, float_sums=float_sums)
+    print(json.dumps({"costs": [float(x) for x in c], "pcg_counts": [int(x) for x in orc.last_pcg_counts()], "seconds": time.time() - t0}))
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        return child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    libs = {t: build(t) for t in FLAGS}
+    runs = {"A": (libs["A"], 0), "B": (libs["B"], 0), "C": (libs["A"], 1)}
+    procs = {k: subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", so, str(W), str(steps), str(fs)], stdout=subprocess.PIPE, text=True)
+             for k, (so, fs) in runs.items()}
+    res = {}
+    for k, pr in procs.items():
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise SystemExit("variant %s failed" % k)
+        res[k] = json.loads(out.strip().splitlines()[-1])
+    import numpy as np
+    a = np.array(res["A"]["costs"])
+
+    def rel(x):
+        x = np.array(x); m = min(len(x), len(a))
+        return [float("%.3g" % v) for v in np.abs(x[:m] - a[:m]) / np.abs(a[:m])]
+    data = {"instance": "synthetic shape_from_shading %d x %d, LM %d x 10, one thread" % (W, W, steps), "flags": {k: " ".join(v) for k, v in FLAGS.items()},
+            "runs": res, "elementwise_only_B_vs_A": rel(res["B"]["costs"]), "sum_order_only_C_vs_A": rel(res["C"]["costs"])}
+    json.dump(data, open(OUT, "w"), indent=1)
+    print(json.dumps({k: data[k] for k in ("instance", "elementwise_only_B_vs_A", "sum_order_only_C_vs_A")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

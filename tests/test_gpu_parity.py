@@ -1474,10 +1474,11 @@ def test_sampled_timer_scopes_nest(torch):
         s.close()
 
 
-@pytest.mark.parametrize("which", ["sfs"])
+@pytest.mark.parametrize("which", ["sfs", "ba"])
 def test_lm_step3_folded_into_the_apply(torch, monkeypatch, which):
     """LM on one GPU: PCGStep3 rides in shape_from_shading's marching apply (p_k = z + beta p_{k-1} formed per row, p ping-pong;
-    thallo_hip_sfs_apply_jtj_lm_pupdate; bundle adjustment keeps the separate launch -- folding it there was measured slower) -- against the separate PCGStep3 launch (THALLO_LM_FOLD_P=0): same costs
+    thallo_hip_sfs_pcg_iter_lm); bundle adjustment runs the single-reduction form (thallo_hip_pcg_update_lm + thallo_hip_ba_pcg_apply_lm: the flat vector update carries
+    PCGStep3, the gather launches all sums and the zeta test) -- against the reference-shaped loop with its separate PCGStep3 / PCGStep2 launches (THALLO_LM_FOLD_P=0): same costs
     and unknowns to rounding, same PCG iteration counts with the zeta exit exercised, and one launch less per iteration (no PCGStep3 in the kernel census)."""
     if which == "sfs":
         fname, dims, p, sp, ui, tol = "shape_from_shading", (130, 67), syn.shape_from_shading(130, 67), dict(nIterations=5, lIterations=10, q_tolerance=0.2), 16, 1e-5
@@ -1500,8 +1501,10 @@ def test_lm_step3_folded_into_the_apply(torch, monkeypatch, which):
         runs.append((np.array(costs), iters, to_host(dev[ui]).copy(), names))
         s.close()
     (c1, i1, x1, n1), (c0, i0, x0, n0) = runs
-    assert "PCGStep3" in n0 and "PCGStep3" not in n1 and "PCGStep1" in n1, (n0, n1)
+    assert "PCGStep3" in n0 and "PCGStep3" not in n1 and ("PCGStep1" in n1 or "PCGIteration" in n1), (n0, n1)
+    if which == "ba": assert "PCGUpdate" in n1 and "PCGUpdate" not in n0, (n0, n1)      # (PCGStep2 stays in the census: the residual resets, lIterations = 40 > residual_reset_period)
     assert i0 == i1 and len(c0) == len(c1) >= 3, (i0, i1)
+    assert any(k < sp["lIterations"] for k in i1), i1
     assert np.abs(c1 - c0).max() <= tol * np.abs(c0).max(), (c1, c0)
     assert np.abs(x1 - x0).max() <= tol * np.abs(x0).max()
 

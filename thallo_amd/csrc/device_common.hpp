@@ -210,6 +210,62 @@ __device__ __forceinline__ IterationSums load_iteration_sums(const float* aD_out
     return S;
 }
 
+// The same read-back by ALL waves of the last workgroup: the 1 + NQD quantities (alphaD in float with alphaN beside it; N, S1, S2 from s3; with NQD = 6 also U, T1, T2 from
+// q3) are dealt over the waves, a wave issues every load of its (at most two) quantities before the first addition -- one round of fabric latency for the whole read-back
+// where the one-wave form takes a round per 256 slots and quantity group (bundle adjustment, 943 slots: the LM point launch 18.6 -> us) -- and adds them in
+// load_iteration_sums' order (lane l: slots l, l + 64, ... ascending from zero, then the butterfly): bit-identical totals.  Must be reached by every wave of the workgroup
+// (two barriers inside); the totals come back in every lane of every wave.  red >= 16 floats (words 13, 14 used), redd >= NQD doubles.
+template <int NQD>
+__device__ __forceinline__ void last_workgroup_totals(const float* aD_out, const double* s3_out, const double* q3_out, int nb, thallo_sum_t aN, float* red, double* redd,
+                                                      float& ad_out, float& an_out, double (&tot)[NQD])
+{
+    typedef unsigned long long u64_t;
+    constexpr int PER = THALLO_MAX_PARTIALS / THALLO_WAVE, NT = 1 + NQD;
+    const int lane = threadIdx.x & (THALLO_WAVE - 1), wave = threadIdx.x / THALLO_WAVE;
+    const int nw = (blockDim.x + THALLO_WAVE - 1) / THALLO_WAVE;
+    for (int q0 = wave; q0 < NT; q0 += 2 * nw) {
+        const int qs[2] = { q0, q0 + nw };
+        float t[PER]; double v[2][PER];
+        if (q0 == 0) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) { const int i = lane + k * THALLO_WAVE; t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = qs[h];
+            if (q < 1 || q >= NT) continue;
+            const u64_t* sp = reinterpret_cast<const u64_t*>(q <= 3 ? s3_out : q3_out) + (q - 1) % 3;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = lane + k * THALLO_WAVE;
+                v[h][k] = i < nb ? __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+            }
+        }
+        if (q0 == 0) {
+            const float an = sum_partials(aN.partials, aN.count);
+            float ad = 0.0f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) ad += t[k];
+            ad = wave_sum_all(ad);
+            if (lane == 0) { red[13] = ad; red[14] = an; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = qs[h];
+            if (q < 1 || q >= NT) continue;
+            double x = 0.0;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) x += v[h][k];
+            x = wave_sum_all_f64(x);
+            if (lane == 0) redd[q - 1] = x;
+        }
+    }
+    lds_barrier();
+    ad_out = red[13]; an_out = red[14];
+#pragma unroll
+    for (int q = 0; q < NQD; ++q) tot[q] = redd[q];
+}
+
 // End of a single-reduction applyJTJ (alphaD partial + {N, S1, S2}), called by EVERY thread of the workgroup with its private terms: one
 // partial set per workgroup into slot blk_off + blockIdx.x.  With fin.tickets the launch's last workgroup to arrive also finishes the two
 // scalars of the PCG iteration over all fin.nb_total slots -- alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2 -- in exactly
@@ -256,14 +312,16 @@ __device__ __forceinline__ void block_finish_sums(float acc, const Sums3& sm, fl
     }
     if (!fin.tickets) return;
     lds_barrier();
-    if (red[15] == 0.0f || wave != 0) return;
-    const IterationSums S = load_iteration_sums(aD_out, s3_out, fin.nb_total, fin.alphaN);
-    const float ad = S.ad, an = S.an; const double n = S.n, a1 = S.s1, b1 = S.s2;
-    if (lane == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (red[15] == 0.0f) return;                                   // (the same for every thread of the workgroup)
+    float ad, an; double t3[3];
+    last_workgroup_totals<3>(aD_out, s3_out, nullptr, fin.nb_total, fin.alphaN, red, redd, ad, an, t3);
+    if (threadIdx.x != 0) return;
+    const double n = t3[0], a1 = t3[1], b1 = t3[2];
+    __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float al = safe_div<false>(an, ad);
     double bn = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
     if (!(bn > 0.0)) bn = 0.0;
-    if (lane == 0) { fin.aD_word[0] = ad; fin.bN_word[0] = (float)bn; }
+    fin.aD_word[0] = ad; fin.bN_word[0] = (float)bn;
 }
 
 // ---- Levenberg-Marquardt iteration in ONE launch (round 3; shape_from_shading).  The reference's PCGStep2 forms q_{k+1} = 0.5 delta_{k+1} . (r_{k+1} + b) AFTER the
@@ -346,10 +404,12 @@ __device__ __forceinline__ void block_finish_sums_lm(float acc, const Sums3& sm,
     }
     if (!fin.tickets) return;
     lds_barrier();
-    if (red[15] == 0.0f || wave != 0) return;
-    const IterationSums S = load_iteration_sums(aD_out, s3_out, fin.nb_total, fin.alphaN);
-    double U, T1, T2;
-    load_sums3_wave(lm.q3_out, fin.nb_total, U, T1, T2);
+    if (red[15] == 0.0f) return;                                   // (the same for every thread of the workgroup)
+    struct { float ad, an; double n, s1, s2; } S; double t6[6];
+    last_workgroup_totals<6>(aD_out, s3_out, lm.q3_out, fin.nb_total, fin.alphaN, red, redd, S.ad, S.an, t6);
+    if (wave != 0) return;
+    S.n = t6[0]; S.s1 = t6[1]; S.s2 = t6[2];
+    const double U = t6[3], T1 = t6[4], T2 = t6[5];
     if (lane == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float al = safe_div<true>(S.an, S.ad);                 // LM divides blindly (gauss_newton.t:226-234)
     double bn = S.n - 2.0 * (double)al * S.s1 + (double)al * (double)al * S.s2;

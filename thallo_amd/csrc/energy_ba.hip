@@ -349,15 +349,19 @@ __global__ __launch_bounds__(BLOCK) void k_pack_point_blocks(int O_, const float
     }
 }
 
+// LM residual reset (gauss_newton.t:1653-1657) as the epilogue of the two launches: with p = delta and ctc set, r = b - (J^T J + CtC) delta and the partials of
+// betaN = r . M^-1 r instead of A p and p . A p (nothing else is read from a reset in the single-reduction loop: M^-1 r is formed where p is)
+struct ResetArgs { float* r; const float* b; const float* pre; };
+
 __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ cam_ptr, const int* __restrict__ q_pt,
                                                 const float* __restrict__ cams, const float* __restrict__ pts, const float* __restrict__ p, float* __restrict__ Ap, float2* __restrict__ JpC,
                                                 float* __restrict__ part_out, const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
-                                                const unsigned* __restrict__ gate, const float* __restrict__ ctc)
-{
+                                                const unsigned* __restrict__ gate, const float* __restrict__ ctc, const float* __restrict__ delta, LmFin lm, ResetArgs rst)
+{   // lm.b: the launch of a one-reduction LM iteration (thallo_hip_ba_pcg_apply_lm) -- also {U, T1, T2} of q's expansion in alpha (device_common.hpp SumsQ) per workgroup
     __shared__ float red[16];
     __shared__ double redd[3 * BLOCK / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
-    float acc = 0.0f; Sums3 sm;
+    float acc = 0.0f; Sums3 sm; SumsQ sq;
     const long PB = 9L * C_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = blockIdx.x * 4 + wave; c < C_; c += gridDim.x * 4) {
@@ -386,24 +390,33 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
             for (int k = 0; k < 9; ++k) if (lane == k) sv = s[k];
             const long i = 9L * c + lane;
             if (ctc) sv += ctc[i] * p[i];                 // LM: (J^T J + CtC) p, PCGStep1_Finish (gauss_newton.t:774-787) folded in
-            Ap[i] = sv;
-            acc += p[i] * sv;
-            if (s3_out) sm.add(prs[i], rs[i], sv);
+            if (rst.r) { const float rv = rst.b[i] - sv; rst.r[i] = rv; acc += (rst.pre[i] * rv) * rv; }
+            else {
+                Ap[i] = sv;
+                acc += p[i] * sv;
+                if (s3_out) sm.add(prs[i], rs[i], sv);
+                if (lm.b) sq.add(delta[i], rs[i], lm.b[i], p[i], sv);
+            }
         }
     }
     block_store_partial(acc, part_out, red);
     if (s3_out) block_store_sums3(sm, s3_out, redd);
+    if (lm.b) {
+        Sums3 t; t.n = sq.u; t.s1 = sq.t1; t.s2 = sq.t2;
+        lds_barrier();                                     // (redd is still being read by thread 0)
+        block_store_sums3(t, lm.q3_out, redd);
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __restrict__ pt_ptr, const int* __restrict__ pt_pos, const float2* __restrict__ JP, const float2* __restrict__ JpC,
                                                const float* __restrict__ p, float* __restrict__ Ap, float* __restrict__ part_out,
                                                const float* __restrict__ rs, const float* __restrict__ prs, double* __restrict__ s3_out,
-                                               const unsigned* __restrict__ gate, FinArgs fin, const float* __restrict__ ctc)
+                                               const unsigned* __restrict__ gate, FinArgs fin, const float* __restrict__ ctc, const float* __restrict__ delta, LmFin lm, ResetArgs rst)
 {   // part_out / s3_out: the slot arrays of the whole applyJTJ (k_cam2 filled slots [0, fin.blk_off)); this launch's workgroups use the slots behind them
     __shared__ float red[16];
-    __shared__ double redd[3 * BLOCK / 64];
+    __shared__ double redd[6 * BLOCK / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
-    float acc = 0.0f; Sums3 sm;
+    float acc = 0.0f; Sums3 sm; SumsQ sq;
     const long PB = 9L * C_;
     for (int j = blockIdx.x * BLOCK + threadIdx.x; j < P_; j += gridDim.x * BLOCK) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -422,11 +435,19 @@ __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __rest
         }
         const long i = PB + 3L * j;
         if (ctc) { s0 += ctc[i] * p[i]; s1 += ctc[i + 1] * p[i + 1]; s2 += ctc[i + 2] * p[i + 2]; }
+        if (rst.r) {
+            const float r0 = rst.b[i] - s0, r1 = rst.b[i + 1] - s1, r2 = rst.b[i + 2] - s2;
+            rst.r[i] = r0; rst.r[i + 1] = r1; rst.r[i + 2] = r2;
+            acc += (rst.pre[i] * r0) * r0 + (rst.pre[i + 1] * r1) * r1 + (rst.pre[i + 2] * r2) * r2;
+            continue;
+        }
         Ap[i] = s0; Ap[i + 1] = s1; Ap[i + 2] = s2;
         acc += p[i] * s0 + p[i + 1] * s1 + p[i + 2] * s2;
         if (s3_out) { sm.add(prs[i], rs[i], s0); sm.add(prs[i + 1], rs[i + 1], s1); sm.add(prs[i + 2], rs[i + 2], s2); }
+        if (lm.b) { sq.add(delta[i], rs[i], lm.b[i], p[i], s0); sq.add(delta[i + 1], rs[i + 1], lm.b[i + 1], p[i + 1], s1); sq.add(delta[i + 2], rs[i + 2], lm.b[i + 2], p[i + 2], s2); }
     }
-    if (s3_out) block_finish_sums(acc, sm, part_out, s3_out, fin, red, redd);
+    if (lm.b) block_finish_sums_lm(acc, sm, sq, part_out, s3_out, fin, lm, red, redd);
+    else if (s3_out) block_finish_sums(acc, sm, part_out, s3_out, fin, red, redd);
     else block_store_partial(acc, part_out + fin.blk_off, red);
 }
 
@@ -496,16 +517,19 @@ int thallo_hip_ba_pack_point_blocks(int O_, const float* Jb, const int* q_ptk, f
 
 static int ba_apply2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                      const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
-                     const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, const float* ctc, thallo_stream_t stream)
+                     const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, const float* ctc, thallo_stream_t stream,
+                     const float* delta = nullptr, LmFin lm = LmFin{ nullptr, nullptr, nullptr, 0, 0.0f }, ResetArgs rst = ResetArgs{ nullptr, nullptr, nullptr })
 {
+    if (rst.r && (!rst.b || !rst.pre || !ctc || s3_out || lm.b || fin.tickets)) return -(int)hipErrorInvalidValue;
     if (!cam_ptr || !q_pt || !pt_pos || !pt_ptr || !cameras || !points || !JP || !JpC || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
     if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
-    if (fin.tickets && (!s3_out || gate || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
+    if (fin.tickets && (!s3_out || (gate && !lm.b) || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
+    if (lm.b && (!fin.tickets || !ctc || !delta || !lm.q3_out || !lm.state)) return -(int)hipErrorInvalidValue;
     int cb, grid; gather_shape(C_, P_, cb, grid);
     // the camera launch fills slots [0, cb); the point launch the rest, and (fin) its last workgroup adds up all `grid` of them
-    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, cameras, points, p, Ap, (float2*)JpC, aD_out, r, pre, s3_out, gate, ctc);
+    hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, cameras, points, p, Ap, (float2*)JpC, aD_out, r, pre, s3_out, gate, ctc, delta, lm, rst);
     hipLaunchKernelGGL(k_pt2, dim3(grid - cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, P_, pt_ptr, pt_pos, (const float2*)JP, (const float2*)JpC, p, Ap, aD_out, r, pre,
-                       s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid }, ctc);
+                       s3_out, gate, FinArgs{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, cb, grid }, ctc, delta, lm, rst);
     int e = check_launch(); return e ? e : grid;
 }
 int thallo_hip_ba_apply2_camera_slots(int C_, int P_)
@@ -523,6 +547,24 @@ int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q
     if (!CtC) return -(int)hipErrorInvalidValue;
     const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
     return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, p, Ap, aD_out, nullptr, nullptr, nullptr, gate, none, CtC, stream);
+}
+int thallo_hip_ba_pcg_apply_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                               const float* cameras, const float* points, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* aD_out,
+                               const float* r, const float* pre, const float* delta, const float* b, double* s3_out, double* q3_out, thallo_fin_t fin,
+                               float* lm_state, int k, float q_tolerance, thallo_stream_t stream)
+{
+    if (!CtC || !b || !delta || !lm_state || !q3_out || !s3_out) return -(int)hipErrorInvalidValue;
+    return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, p, Ap, aD_out, r, pre, s3_out, reinterpret_cast<const unsigned*>(lm_state) + 1, fin, CtC, stream,
+                     delta, LmFin{ b, q3_out, lm_state, k, q_tolerance });
+}
+int thallo_hip_ba_lm_reset_residual(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                                    const float* cameras, const float* points, const float* JP, float* JpC, const float* delta, const float* CtC, const float* b, const float* pre,
+                                    float* r, float* betaN_out, const unsigned* gate, thallo_stream_t stream)
+{
+    if (!delta || !CtC || !b || !pre || !r || !betaN_out) return -(int)hipErrorInvalidValue;
+    const thallo_fin_t none = { { nullptr, 0 }, nullptr, nullptr, nullptr };
+    return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, delta, r /* (not written in this mode) */, betaN_out, nullptr, nullptr, nullptr, gate, none, CtC, stream,
+                     nullptr, LmFin{ nullptr, nullptr, nullptr, 0, 0.0f }, ResetArgs{ r, b, pre });
 }
 int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                              const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,

@@ -205,21 +205,26 @@ __global__ __launch_bounds__(BLOCK) void k_pupdate(const float4* __restrict__ z,
 //   r -= alpha_{k-1} Ap (fma) ;  z = M^-1 r (not stored) ;  p_out = z + beta_{k-1} p_in ;  delta += alpha_{k-1} p_in      [first: p_out = M^-1 r only]
 // possible because beta_{k-1} is already known: the applyJTJ kernel of iteration k-1 also produced N, S1, S2 (Sums3) and
 // k_scalars_finish expanded betaN_{k-1} = N - 2 alpha S1 + alpha^2 S2 from them.  No reduction in here.
-template <bool HAS_PRE>
+// LM (thallo_hip_pcg_update_lm): the unguarded divides of the LM branch (gauss_newton.t:226-234) and the loop's gate word; first == 2: the iteration behind a residual
+// reset (gauss_newton.t:1653-1657: delta and r are already those of this iteration) -- p_out = M^-1 r + beta p_in only.
+template <bool HAS_PRE, bool LM>
 __global__ __launch_bounds__(BLOCK) void k_pcg_update(float4* __restrict__ r, const float4* __restrict__ Ap, const float4* __restrict__ pre,
                                                        const float4* __restrict__ p_in, float4* __restrict__ p_out, float4* __restrict__ delta, long n4, int first,
-                                                       thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp)
+                                                       thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, const unsigned* __restrict__ gate, float* __restrict__ bn_word)
 {
+    if (LM && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;                    // the PCG loop already ended on the device
     float alpha = 0.0f, beta = 0.0f;
-    if (!first) {
+    if (first != 1) {
         const float an = sum_partials(aNp.partials, aNp.count);
-        alpha = safe_div<false>(an, sum_partials(aDp.partials, aDp.count));
-        beta  = safe_div<false>(sum_partials(bNp.partials, bNp.count), an);
+        alpha = safe_div<LM>(an, sum_partials(aDp.partials, aDp.count));
+        const float bn = sum_partials(bNp.partials, bNp.count);
+        beta  = safe_div<LM>(bn, an);
+        if (LM && bn_word != nullptr && blockIdx.x == 0 && threadIdx.x == 0) bn_word[0] = bn;     // (behind a residual reset: betaN_k exists as partials only)
     }
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
         float4 rv = r[i];
         const float4 pv = p_in[i];
-        if (!first) {
+        if (first == 0) {
             const float4 av = Ap[i];
             rv.x = __builtin_fmaf(-alpha, av.x, rv.x); rv.y = __builtin_fmaf(-alpha, av.y, rv.y); rv.z = __builtin_fmaf(-alpha, av.z, rv.z); rv.w = __builtin_fmaf(-alpha, av.w, rv.w);
             r[i] = rv;
@@ -687,6 +692,12 @@ __global__ void k_finish_sum(thallo_sum_t s, float* __restrict__ out)
     const float v = sum_partials(s.partials, s.count);
     if (threadIdx.x == 0) out[0] = v;
 }
+__global__ void k_finish_sum_gated(thallo_sum_t s, float* __restrict__ out, const unsigned* __restrict__ gate)
+{
+    if (__builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;      // LM: the PCG loop already ended on the device, the partials were not written
+    const float v = sum_partials(s.partials, s.count);
+    if (threadIdx.x == 0) out[0] = v;
+}
 
 __global__ void k_alpha_beta(thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* __restrict__ out)
 {
@@ -808,8 +819,18 @@ int thallo_hip_pcg_update(float* r, const float* Ap, const float* pre, const flo
     if (!r || !p_in || !p_out || (!first && (!Ap || !delta))) return -(int)hipErrorInvalidValue;
     const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
     hipStream_t s = (hipStream_t)stream;
-    if (pre) hipLaunchKernelGGL(k_pcg_update<true>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
-    else     hipLaunchKernelGGL(k_pcg_update<false>, dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp);
+    if (pre) hipLaunchKernelGGL((k_pcg_update<true, false>), dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp, (const unsigned*)nullptr, (float*)nullptr);
+    else     hipLaunchKernelGGL((k_pcg_update<false, false>), dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp, (const unsigned*)nullptr, (float*)nullptr);
+    return check_launch();
+}
+
+int thallo_hip_pcg_update_lm(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, int first,
+                             thallo_sum_t aNp, thallo_sum_t aDp, thallo_sum_t bNp, float* betaN_word, const float* lm_state, thallo_stream_t stream)
+{
+    if (!r || !pre || !p_in || !p_out || !lm_state || first < 0 || first > 2 || (!first && (!Ap || !delta))) return -(int)hipErrorInvalidValue;
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL((k_pcg_update<true, true>), dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out,
+                       (float4*)delta, n4, first, aNp, aDp, bNp, reinterpret_cast<const unsigned*>(lm_state) + 1, betaN_word);
     return check_launch();
 }
 
@@ -899,6 +920,13 @@ int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older
 int thallo_hip_finish_sum(thallo_sum_t sum, float* out, thallo_stream_t stream)
 {
     hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, sum, out);
+    return check_launch();
+}
+
+int thallo_hip_finish_sum_gated(thallo_sum_t sum, float* out, const unsigned* gate, thallo_stream_t stream)
+{
+    if (!gate || !out || !sum.partials) return -(int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_finish_sum_gated, dim3(1), dim3(64), 0, (hipStream_t)stream, sum, out, gate);
     return check_launch();
 }
 

@@ -810,6 +810,25 @@ public:
     int shared_split_slots() const override { return thallo_hip_ba_apply2_camera_slots(C, P); }
     bool apply_adds_ctc() const override { return true; }
     // (PCGStep3 folded into this apply was measured: forming p_k = z + beta p_{k-1} at every gather costs the camera kernel 8 us, the launch it saves 7: not kept)
+    // LM in the single-reduction form: the flat vector update, then the two gather launches with all sums; the point launch's last workgroup finishes the scalars
+    // and applies the zeta test (three launches per iteration instead of four)
+    bool lm_one_kernel() const override { return true; }
+    bool lm_iter_after_reset() const override { return true; }
+    int lm_reset_residual(LaunchCtx& c, SolverVectors& v, float* bN_out) override
+    {
+        TimedLaunch t(c, "PCGStep2");
+        return thallo_hip_ba_lm_reset_residual(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, points,
+                                               (const float*)JP.ptr, (float*)JpP.ptr, v.delta, v.CtC, v.b, v.pre, v.r, bN_out, c.gate, c.stream);
+    }
+    int pcg_iter_lm(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out, const thallo_fin_t& fin, float* lm_state, int k,
+                    float q_tol) override
+    {
+        { TimedLaunch t(c, "PCGUpdate");
+          int rc = thallo_hip_pcg_update_lm(v.r, v.Ap, v.pre, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : c.lm_reset_bn_word ? 2 : 0, aN, aD, bN, c.lm_reset_bn_word, lm_state, c.stream); if (rc < 0) return rc; }
+        TimedLaunch t(c, "PCGStep1");
+        return thallo_hip_ba_pcg_apply_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, points,
+                                          (const float*)JP.ptr, (float*)JpP.ptr, v.p[cur ^ 1], v.CtC, v.Ap, out, v.r, v.pre, v.delta, v.b, v.s12, v.s12b, fin, lm_state, k, q_tol, c.stream);
+    }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override
     {

@@ -668,7 +668,10 @@ int Plan::step_lm(int ev_iter)
     // -- it falls on the last iteration -- changes nothing that is read afterwards): the vector update, PCGStep3, (J^T J + CtC) p, all sums and the zeta test in
     // pcg_iter_lm; behind the loop the one update of delta it still owes.  THALLO_LM_FOLD_P=0: the reference-shaped loop (A/B).
     const int period = sp.residual_reset_period > 0 ? sp.residual_reset_period : (1 << 30);
-    const bool one_kernel_lm = !slab && lm_fold_p_ && fold_ctc && plugin->lm_one_kernel() && L >= 1 && L <= period && v_.p[1] != nullptr && ensure_iter_buffers() == 0;
+    // Plugins whose iteration can start from a reset residual (lm_iter_after_reset; bundle adjustment's three-launch form) run any L: every residual_reset_period-th iteration
+    // is followed by the reference's reset (:1653-1657) as launches of its own, below.
+    const bool one_kernel_lm = !slab && lm_fold_p_ && fold_ctc && plugin->lm_one_kernel() && L >= 1 && (L <= period || plugin->lm_iter_after_reset()) && v_.p[1] != nullptr &&
+                               ensure_iter_buffers() == 0;
     // ... and on a row slab of a multi-GPU run (device-side transport; plugins whose pcg_iter_lm keeps the ghost rows current): the launch stores partials only, ONE
     // exchange per LM iteration carries the 13 sums and the boundary rows of the new A p, finishes alphaD_k, betaN_k, q_{k+1} and applies the zeta test
     // (thallo_hip_dist_xrows_lm).  Ghost rows of r and M^-1 are fetched once per step.
@@ -701,15 +704,31 @@ int Plan::step_lm(int ev_iter)
             check(thallo_hip_finish_sum(partial_sum(B), scal(B), s), "alphaN_0 sum");
             if (!failed) fin_[B] = 1;
         }
+        bool after_reset = false;
         for (int k = 0; k < L && !failed; ++k) {
             const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
             const thallo_fin_t fin = { sum(jN), v_.fin_tickets, scal(jD), scal(jB) };
+            ctx.lm_reset_bn_word = after_reset ? scal(jN) : nullptr;
             nb = plugin->pcg_iter_lm(ctx, v_, cur_, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), slot(jD), fin, lmst, k, sp.q_tolerance);
+            ctx.lm_reset_bn_word = nullptr; after_reset = false;
             check(nb, "PCGIteration (LM) launch");
             if (failed) break;
             set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
             cur_ ^= 1;
             k_done = k + 1;
+            if (((k + 1) % period) == 0 && k + 1 < L) {
+                // residual reset (:1653-1657; on the last iteration it changes nothing that is read afterwards): delta_{k+1} = delta_k + alpha_k p_k now,
+                // r = b - (J^T J + CtC) delta and the partials of betaN_k = r . M^-1 r (they replace the expansion's word: the next iteration adds them up, leaves the
+                // word and forms p_{k+1} only); q_{k+1} and the zeta test stay the launch's own -- the same quantity, and the gate word it may have set ends these
+                // launches too.
+                { TimedLaunch t(ctx, "PCGStep2"); check(thallo_hip_lm_step2_first_half(v_.delta, v_.p[cur_], n, sum(jN), sum(jD), s), "PCGStep2 (first half) launch"); }
+                if (failed) break;
+                nb = plugin->lm_reset_residual(ctx, v_, slot(jB));
+                check(nb, "residual reset launch");
+                if (failed) break;
+                set_nb(jB, nb); fin_[jB] = 0;
+                after_reset = true;
+            }
         }
         if (!failed) {      // p_k lives in p[1] for even k, p[0] for odd k
             TimedLaunch t(ctx, "PCGUpdate");

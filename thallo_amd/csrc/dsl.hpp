@@ -105,7 +105,15 @@ struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 
 constexpr int GEN_KINDS = 8;
 // one merged gather kernel pair per iteration domain (dsl_codegen.cpp): the member residuals, the (input, channel) targets they write, the kernel names
 struct GenGroup { std::vector<int> domain; std::vector<int> members; std::vector<std::pair<int, int>> targets; std::string jtj, jtf; };
+// Unknown-wise lowering THROUGH index maps (round 4; dsl_codegen.cpp "incidence gather"): residuals that reach their unknowns through Sparse maps (or any other index
+// the stencil gather cannot invert at code-generation time).  The unknown images are grouped by their dimension lists (an "owner" = one pixel of that index space, all
+// images over it and all their channels); per (residual, group) a kernel pair walks the owners, each thread evaluating the residual instances in ITS list -- built by the
+// plugin per Init from the residual's own index evaluation (uidx kernel) -- and keeping only the partials of its own unknowns: one writer per element, no atomics.
+struct IncGroup { std::vector<int> dims; std::vector<int> inputs; };
+struct IncResidual { int ri = -1, K = 0; std::vector<int> slot_input; std::string uidx; std::vector<int> groups; std::vector<std::string> jtj, jtf; };
 struct Generated {
+    std::vector<IncGroup> inc_groups;
+    std::vector<IncResidual> inc;                  // (residuals without the stencil gather, at most 48 unknown accesses)
     std::string source;                            // one HIP translation unit
     std::vector<GenKernel> kernels;
     std::vector<int> slots_per_row;                // per residual: K, the entries per materialized row

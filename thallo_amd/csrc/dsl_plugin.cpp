@@ -79,6 +79,78 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
         return e == hipSuccess ? 0 : -(int)e;
     }
     long rows_of(size_t ri) const { return nel[ri] * (long)P.residuals[ri].exprs.size(); }
+    // unknown-wise lowering through index maps (dsl.hpp IncResidual): per (residual, owner group) the kernel pair and the owners' instance lists (CSR), rebuilt per Init
+    struct IncRun { int ri = -1, g = -1; hipFunction_t jtj = nullptr, jtf = nullptr; DeviceBuffer ptr, els; long npix = 0; };
+    std::vector<IncRun*> inc_runs_;
+    std::vector<hipFunction_t> inc_uidx_;          // G.inc order
+    std::vector<char> use_inc_;                    // per residual
+    bool inc_ready_ = false;
+    long group_pixels(int g) const { long n = 1; for (int d : G.inc_groups[(size_t)g].dims) n *= dimv[(size_t)d]; return n; }
+    // the owners' lists: the residual's own index evaluation (uidx_<ri>: K flat unknown indices per instance, -1 = absent), inverted on the host
+    int build_incidence(hipStream_t s)
+    {
+        for (size_t a = 0; a < G.inc.size(); ++a) {
+            const dsl::IncResidual& ir = G.inc[a];
+            if (!use_inc_[(size_t)ir.ri]) continue;
+            const long n = nel[(size_t)ir.ri]; const int K = ir.K;
+            DeviceBuffer col;
+            if (col.alloc(sizeof(int) * (size_t)n * (size_t)K + 256)) { set_error("%s: out of device memory for the index evaluation of %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1; }
+            int* cp = (int*)col.ptr; void* args[] = { ctx.data(), &cp };
+            if (launch_fn(inc_uidx_[a], grid_for(n, 4096), args, s) < 0) return -1;
+            std::vector<int> h((size_t)n * (size_t)K);
+            if (n && (hipMemcpyAsync(h.data(), col.ptr, h.size() * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) return -1;
+            for (IncRun* run : inc_runs_) {
+                if (run->ri != ir.ri) continue;
+                const long npix = group_pixels(run->g);
+                std::vector<int> slot_ch((size_t)K, 0); std::vector<long> slot_base((size_t)K, -1);       // slots of this group: base offset and channel count of their image
+                for (int q = 0; q < K; ++q) {
+                    const int in = ir.slot_input[(size_t)q];
+                    bool mine = false; for (int x : G.inc_groups[(size_t)run->g].inputs) mine = mine || x == in;
+                    if (P.inputs[(size_t)in].dims != G.inc_groups[(size_t)run->g].dims) mine = false;
+                    if (mine) { slot_base[(size_t)q] = uoff[(size_t)in]; slot_ch[(size_t)q] = P.inputs[(size_t)in].channels; }
+                }
+                std::vector<int> ptr((size_t)npix + 1, 0);
+                long own[64];
+                auto owners = [&](long el, long* o) {      // distinct owners of instance el in this group
+                    int m = 0;
+                    for (int q = 0; q < K; ++q) {
+                        if (slot_base[(size_t)q] < 0) continue;
+                        const int u = h[(size_t)el * K + q]; if (u < 0) continue;
+                        const long px = ((long)u - slot_base[(size_t)q]) / slot_ch[(size_t)q];
+                        if (px < 0 || px >= npix) continue;
+                        bool dup = false; for (int j = 0; j < m; ++j) dup = dup || o[j] == px;
+                        if (!dup) o[m++] = px;
+                    }
+                    return m;
+                };
+                for (long el = 0; el < n; ++el) { const int m = owners(el, own); for (int j = 0; j < m; ++j) ptr[(size_t)own[j] + 1]++; }
+                for (long i = 0; i < npix; ++i) {
+                    if ((long)ptr[(size_t)i] + ptr[(size_t)i + 1] > 0x7fffffffL) { set_error("%s: more than 2^31 (instance, unknown) pairs in residual %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1; }
+                    ptr[(size_t)i + 1] += ptr[(size_t)i];
+                }
+                std::vector<int> els((size_t)ptr[(size_t)npix]), fill(ptr.begin(), ptr.end() - 1);
+                for (long el = 0; el < n; ++el) { const int m = owners(el, own); for (int j = 0; j < m; ++j) els[(size_t)fill[(size_t)own[j]]++] = (int)el; }       // (ascending instance order per owner)
+                if (run->ptr.alloc(ptr.size() * sizeof(int) + 64) || run->els.alloc(els.size() * sizeof(int) + 64) ||
+                    hipMemcpy(run->ptr.ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                    (els.size() && hipMemcpy(run->els.ptr, els.data(), els.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)) {
+                    set_error("%s: out of device memory for the instance lists of %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1;
+                }
+                run->npix = npix;
+            }
+        }
+        inc_ready_ = true;
+        return 0;
+    }
+    int launch_inc(int ri, bool jtj, void* a0, void* a1, hipStream_t s)
+    {
+        for (IncRun* run : inc_runs_) {
+            if (run->ri != ri) continue;
+            const int* ip = (const int*)run->ptr.ptr; const int* ie = (const int*)run->els.ptr; long npix = run->npix;
+            void* args[] = { ctx.data(), a0, a1, &ip, &ie, &npix };
+            const int rc = launch_fn(jtj ? run->jtj : run->jtf, grid_for(npix, 4096), args, s); if (rc < 0) return rc;
+        }
+        return 0;
+    }
 
 public:
     GeneratedPlugin(const dsl::Problem& p, const unsigned* dims, bool autoschedule, bool f64) : P(p), f64_(f64)
@@ -117,9 +189,36 @@ public:
             const bool plain = !r.mat_J && !r.mat_JtJ && !r.mat_Jp;
             const bool want = r.at_output == 1 || (r.at_output < 0 && autoschedule);
             gather_[ri] = want && plain && G.gather_ok[ri];
-            if (r.at_output == 1 && !gather_[ri])
+        }
+        // ... and through index maps where the stencil form does not exist (Sparse maps, unknowns over other dimensions): the owners' instance lists
+        // (useAutoscheduler = 0 without compute_at_output(true), or compute_at_output(false): the residual-wise scatter, A/B)
+        use_inc_.assign(P.residuals.size(), 0);
+        {
+            const bool off = false;
+            for (size_t a = 0; a < G.inc.size(); ++a) {
+                const dsl::IncResidual& ir = G.inc[a];
+                const dsl::Residual& r = P.residuals[(size_t)ir.ri];
+                const bool plain = !r.mat_J && !r.mat_JtJ && !r.mat_Jp;
+                const bool want = r.at_output == 1 || (r.at_output < 0 && autoschedule);
+                bool fits = n_unk < (1L << 31) && elements(r) < (1L << 31) && ir.K <= 64;
+                for (int g : ir.groups) fits = fits && group_pixels(g) < (1L << 31);
+                use_inc_[(size_t)ir.ri] = want && plain && !f64_ && !off && fits;
+                if (!use_inc_[(size_t)ir.ri]) continue;
+                for (size_t k = 0; k < ir.groups.size(); ++k) {
+                    IncRun* run = new IncRun(); run->ri = ir.ri; run->g = ir.groups[k];
+                    if (hipModuleGetFunction(&run->jtj, mod, ir.jtj[k].c_str()) != hipSuccess || hipModuleGetFunction(&run->jtf, mod, ir.jtf[k].c_str()) != hipSuccess) {
+                        delete run; set_error("%s: generated kernel %s missing", label.c_str(), ir.jtj[k].c_str()); return;
+                    }
+                    inc_runs_.push_back(run);
+                }
+            }
+        }
+        for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            const dsl::Residual& r = P.residuals[ri];
+            const bool plain = !r.mat_J && !r.mat_JtJ && !r.mat_Jp;
+            if (r.at_output == 1 && !gather_[ri] && !use_inc_[ri])
                 fprintf(stderr, "[thallo] warning: %s: residual %s asks for compute_at_output(true) but %s: its residual-wise kernels run\n", label.c_str(), r.name.c_str(),
-                        plain ? "has no unknown-wise lowering (it reads an unknown through a Sparse map, or an unknown over other dimensions than its own)" : "also materializes J / JtJ / Jp");
+                        plain ? "has no unknown-wise lowering in this configuration (more than 48 unknown accesses per instance, or doublePrecision = 1)" : "also materializes J / JtJ / Jp");
         }
         // the merged gather kernels: a group runs when all of its members are gathered (they are: only wanted residuals join a group) -- groups of one included
         group_of_.assign(P.residuals.size(), -1);
@@ -162,17 +261,17 @@ public:
         }
         ok_ = true;
     }
-    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : jval) delete b; for (auto b : jcol) delete b; for (auto b : jdest) delete b; }
+    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : jval) delete b; for (auto b : jcol) delete b; for (auto b : jdest) delete b; for (auto r : inc_runs_) delete r; }
     const char* schedule_name() const override
     {
         if (direct_) return "dense direct solve";
         if (dense_) return "dense [JtJ]p";
         if (sparse_jtj_) return "sparse [[Jt][J]]p";
         bool all = !gather_.empty(), any = false;
-        for (char g : gather_) { all = all && g; any = any || g; }
+        for (size_t i = 0; i < gather_.size(); ++i) { const bool g = gather_[i] || use_inc_[i]; all = all && g; any = any || g; }
         return all ? "per residual, unknown-wise (gather)" : any ? "per residual, some unknown-wise (gather)" : "per residual";
     }
-    int prepare(LaunchCtx&) override { sp_ready_ = false; return 0; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
+    int prepare(LaunchCtx&) override { sp_ready_ = false; inc_ready_ = false; return 0; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
 
     // symbolic phase of the sparse J^T J (the reference: cusparseXcsrgemmNnz, gauss_newton.t:1404-1412): the rows' unknown indices -> CSR pattern
     // + for every product v[i][a] * v[i][b] its position in the values
@@ -272,6 +371,11 @@ public:
             if (k.name.empty()) { fn.push_back(nullptr); continue; }       // (no gather form for this residual)
             if (hipModuleGetFunction(&f, mod, k.name.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), k.name.c_str()); return -1; }
             fn.push_back(f);
+        }
+        for (auto& ir : G.inc) {
+            hipFunction_t f = nullptr;
+            if (hipModuleGetFunction(&f, mod, ir.uidx.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), ir.uidx.c_str()); return -1; }
+            inc_uidx_.push_back(f);
         }
         for (auto& g : G.groups) {
             hipFunction_t fa = nullptr, fb = nullptr;
@@ -377,9 +481,11 @@ public:
             float *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
             const int rc = launch_fn(grp_jtf[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
         }
+        if (!inc_ready_ && !inc_runs_.empty() && build_incidence(s)) return -1;
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {            // evalJTF: r = -J^T F, pre = diag(J^T J)   (thallo.t:3898-3902)
             if (group_of_[ri] >= 0) continue;
             float *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
+            if (use_inc_[ri]) { const int rc = launch_inc((int)ri, false, &r, &pre, s); if (rc < 0) return rc; continue; }
             const int rc = launch(kernel_of((int)ri, gather_[ri] ? 6 : 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
         if (v.diag && hipMemcpyAsync(v.diag, v.pre, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;      // LM: the raw diagonal
@@ -436,6 +542,9 @@ public:
                 float* j = (float*)jp.ptr + jp_off[ri];
                 void* a1[] = { ctx.data(), &p, &j }; int rc = launch(kernel_of((int)ri, 3), g, a1, s); if (rc < 0) return rc;
                 void* a2[] = { ctx.data(), &j, &Ap }; rc = launch(kernel_of((int)ri, 4), g, a2, s); if (rc < 0) return rc;
+            } else if (use_inc_[ri]) {
+                if (!inc_ready_) return -1;
+                const int rc = launch_inc((int)ri, true, &p, &Ap, s); if (rc < 0) return rc;
             } else {
                 void* args[] = { ctx.data(), &p, &Ap };
                 const int rc = launch(kernel_of((int)ri, gather_[ri] ? 7 : 2), g, args, s); if (rc < 0) return rc;

@@ -80,7 +80,7 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     }
     long rows_of(size_t ri) const { return nel[ri] * (long)P.residuals[ri].exprs.size(); }
     // unknown-wise lowering through index maps (dsl.hpp IncResidual): per (residual, owner group) the kernel pair and the owners' instance lists (CSR), rebuilt per Init
-    struct IncRun { int ri = -1, g = -1; hipFunction_t jtj = nullptr, jtf = nullptr; DeviceBuffer ptr, els; long npix = 0; };
+    struct IncRun { int ri = -1, g = -1; hipFunction_t jtj = nullptr, jtf = nullptr; DeviceBuffer ptr, els; long npix = 0; int wave = 0; };
     std::vector<IncRun*> inc_runs_;
     std::vector<hipFunction_t> inc_uidx_;          // G.inc order
     std::vector<char> use_inc_;                    // per residual
@@ -136,6 +136,9 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
                     set_error("%s: out of device memory for the instance lists of %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1;
                 }
                 run->npix = npix;
+                // owners with long lists (bundle adjustment's cameras: hundreds of observations each, a few thousand owners) get a wave each; 16 instances per owner on
+                // average is where a wave's 64 lanes stop being mostly idle
+                run->wave = npix > 0 && (long)els.size() >= 16 * npix ? 1 : 0;
             }
         }
         inc_ready_ = true;
@@ -145,9 +148,9 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     {
         for (IncRun* run : inc_runs_) {
             if (run->ri != ri) continue;
-            const int* ip = (const int*)run->ptr.ptr; const int* ie = (const int*)run->els.ptr; long npix = run->npix;
-            void* args[] = { ctx.data(), a0, a1, &ip, &ie, &npix };
-            const int rc = launch_fn(jtj ? run->jtj : run->jtf, grid_for(npix, 4096), args, s); if (rc < 0) return rc;
+            const int* ip = (const int*)run->ptr.ptr; const int* ie = (const int*)run->els.ptr; long npix = run->npix; int wave = run->wave;
+            void* args[] = { ctx.data(), a0, a1, &ip, &ie, &npix, &wave };
+            const int rc = launch_fn(jtj ? run->jtj : run->jtf, grid_for(wave ? npix * 64 : npix, 4096), args, s); if (rc < 0) return rc;
         }
         return 0;
     }

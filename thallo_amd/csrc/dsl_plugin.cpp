@@ -14,6 +14,10 @@
 //                                       solves the dense system by Cholesky instead of running PCG (:1280-1328, 1612-1613)
 //   ... and n above that size:          sparse [[Jt][J]]p (:1394-1441 csrgemm, :1462-1481 one csrmv per PCG iteration): the CSR pattern of J^T J is built from
 //                                       the rows' unknown indices once per Init on the host, its values are re-accumulated once per GN iteration on the device
+// Where a residual's kernels run (thallo.t:5173-5190,5273-5306: the reference maps a group at its output when it can; r.X:compute_at_output(true) or useAutoscheduler = 1 here):
+//   on its unknowns' own grid                 the stencil gather, one merged kernel per iteration domain (dsl_codegen.cpp "gather group")
+//   through Sparse maps / other index forms   per-owner instance lists, built per Init from the residual's own index evaluation (build_incidence below), a thread or a wave per owner
+//   otherwise (or asked not to)               residual-wise, atomics
 #include "dsl.hpp"
 #include "plugin.hpp"
 #include <hip/hiprtc.h>

@@ -16,9 +16,9 @@
  *  - DIFF: cpuOnly=1 is rejected (NULL state); this build has no CPU fallback on purpose.
  *  - doublePrecision=1 (API/src/precision.t:3-6: thallo_float = double): every problem file goes through the
  *    front-end, whose kernels are generated with thallo_float = double, and the reference-shaped double loop drives
- *    them (Gauss-Newton, one GPU).  Unknowns / thallo_float arrays are doubles, arrays and Params declared `float`
- *    stay floats, solver parameters stay floats (gauss_newton.t:200-216).  DIFF: the ThalloX_ multi-GPU / LM
- *    extensions are not available in this mode.
+ *    them (Gauss-Newton, and with ThalloX_EnableLM the LM branch; one GPU).  Unknowns / thallo_float arrays are
+ *    doubles, arrays and Params declared `float` stay floats, solver parameters stay floats (gauss_newton.t:200-216).
+ *    DIFF: the ThalloX_ multi-GPU extensions are not available in this mode.
  *  - DIFF: GPU errors are reported on stderr and surface as NULL / 0 returns; the process is
  *    never exit()ed (reference: API/src/cuda_util.t:103-118).
  */

@@ -688,6 +688,23 @@ int thallo_hip_f64_step2(double* delta, double* r, double* z, const double* p, c
 int thallo_hip_f64_step3(double* p, const double* z, long n, const double* betaN_word, const double* alphaN_word, thallo_stream_t stream);
 int thallo_hip_f64_linear_update(double* X, const double* delta, long n, thallo_stream_t stream);
 int thallo_hip_f64_finish(const double* partials, int count, double* word, thallo_stream_t stream);
+/* ... and the Levenberg-Marquardt set in double (round 4; the float forms: thallo_hip_lm_finalize_diagonal, thallo_hip_lm_step1_finish, thallo_hip_pcg_step2_full,
+ * thallo_hip_lm_step2_first_half / _second_half; gauss_newton.t:929-969, 774-787, 801-886).  LM divides blindly (gauss_newton.t:226-234).
+ *   lm_finalize_diagonal: from the RAW diagonal d: SSq (first GN iteration only) = guardedInvert(d) or 1; CtC = clamp(d / radius, min / (SSq radius), max / (SSq radius));
+ *                         pre = 1 / (CtC + d); b = r; z = pre r; partials of r . z
+ *   lm_step1_finish:      Ap += CtC p; partials of p . Ap
+ *   lm_step2:             delta += alpha p; r -= alpha Ap; z = pre r; partials of z . r and of q = 0.5 delta . (r + b)
+ *   lm_step2_first_half / _second_half: the residual reset -- delta += alpha p; then (with Adelta = (J^T J + CtC) delta) r = b - Adelta, z, the two partial sets
+ *   lm_step3:             p = z + (betaN / alphaN) p */
+int thallo_hip_f64_lm_finalize_diagonal(const double* diag, double* SSq, double* CtC, double* pre, const double* r, double* b, double* z, long n, double radius, double min_lm_diagonal,
+                                        double max_lm_diagonal, int save_ssq, int use_preconditioner, double* partials_out, thallo_stream_t stream);
+int thallo_hip_f64_lm_step1_finish(double* Ap, const double* CtC, const double* p, long n, double* partials_out, thallo_stream_t stream);
+int thallo_hip_f64_lm_step2(double* delta, double* r, double* z, const double* p, const double* Ap, const double* pre, const double* b, long n, const double* alphaN_word,
+                            const double* alphaD_word, double* betaN_out, double* q_out, thallo_stream_t stream);
+int thallo_hip_f64_lm_step2_first_half(double* delta, const double* p, long n, const double* alphaN_word, const double* alphaD_word, thallo_stream_t stream);
+int thallo_hip_f64_lm_step2_second_half(double* r, const double* b, const double* Adelta, const double* pre, double* z, const double* delta, long n, double* betaN_out, double* q_out,
+                                        thallo_stream_t stream);
+int thallo_hip_f64_lm_step3(double* p, const double* z, long n, const double* betaN_word, const double* alphaN_word, thallo_stream_t stream);
 /* Direct solve of the dense normal equations (gauss_newton.t:1280-1328; compiled out there, opt-in here): A (n x n row-major, symmetric positive
  * definite, OVERWRITTEN by its Cholesky factor) x = b.  info[0] (device int) = 0, or 1 + the row of the first non-positive pivot. n <= 8192. */
 int thallo_hip_dense_cholesky_solve(long n, float* A, const float* b, float* x, int* info, thallo_stream_t stream);

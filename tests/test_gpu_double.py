@@ -101,7 +101,96 @@ def test_double_precision_linear_energy_against_float64(torch, tmp_path, param_t
     assert np.abs(got - xk).max() < 1e-12
 
 
-def _solve_both(fname, dims, params32, monkeypatch, keep32=(), **sp):
+@pytest.mark.parametrize("q_tolerance", [0.0, 0.05])
+def test_double_precision_levenberg_marquardt_against_float64(torch, tmp_path, q_tolerance):
+    """doublePrecision = 1 with ThalloX_EnableLM (round 4: the mode ran Gauss-Newton only): the LM branch of gauss_newton.t on double vectors, reference-shaped -- SSq / CtC /
+    the damped preconditioner from the raw diagonal, (J^T J + CtC) p, the unguarded divides, q = 0.5 delta . (r + b) with the zeta test after every PCG iteration, the residual
+    reset every residual_reset_period iterations, the model cost, accept / revert and the trust region -- against the same recurrences in numpy float64 on the masked weighted
+    Laplacian: costs and unknowns to 1e-11 over 6 LM steps of up to 25 PCG iterations (two resets per step; with q_tolerance = 0.05 the zeta test ends the loops early)."""
+    import scipy.sparse as sps
+    W, H = 40, 28
+    f = tmp_path / "weighted_laplacian.t"
+    f.write_text(WEIGHTED % "float")
+    rng = np.random.default_rng(11)
+    A = rng.uniform(0, 1, (H, W, 2))
+    Wt = rng.uniform(0.5, 1.5, (H, W)).astype(np.float32)
+    Mask = (rng.uniform(0, 1, (H, W)) < 0.1).astype(np.float32)
+    X0 = A + 0.3 * rng.standard_normal(A.shape)
+    w_fit = np.float32(0.7)
+    dev = [torch.from_numpy(X0.copy()).cuda(), torch.from_numpy(A).cuda(), torch.from_numpy(Wt).cuda(), torch.from_numpy(Mask).cuda(), w_fit]
+    s = api.ThalloSolver((W, H), str(f), double_precision=True)
+    s.enable_lm()
+    nit, L, period = 6, 25, 10
+    sp = dict(nIterations=nit, lIterations=L, q_tolerance=q_tolerance, trust_region_radius=30.0)      # (a small radius: the damping is felt, steps are partial)
+    final, costs = s.solve(dev, profiled=True, **sp)
+    s.close()
+    wf = float(w_fit)
+    n = 2 * W * H; idx = lambda x, y, c: 2 * (y * W + x) + c
+    rows, cols, vals, rhs = [], [], [], []
+    def add_row(entries):
+        k = len(rhs); rhs.append(0.0)
+        for j, v in entries: rows.append(k); cols.append(j); vals.append(v)
+    for y in range(H):
+        for x in range(W):
+            for c in range(2):
+                add_row([(idx(x, y, c), wf)]); rhs[-1] = -wf * float(A[y, x, c])
+    for dx, dy in ((1, 0), (0, 1)):
+        for y in range(H):
+            for x in range(W):
+                for c in range(2):
+                    if x + dx < W and y + dy < H: add_row([(idx(x, y, c), float(Wt[y, x])), (idx(x + dx, y + dy, c), -float(Wt[y, x]))])
+                    else: add_row([])
+    J = sps.csr_matrix((vals, (rows, cols)), shape=(len(rhs), n)); b0 = np.array(rhs)
+    free = np.repeat(Mask.reshape(-1) == 0, 2)
+    Jf = J[:, free]
+    cost_of = lambda x: 0.5 * np.sum((J @ x + b0) ** 2)
+    f32 = lambda v: float(np.float32(v))           # solver parameters are floats in both precisions (gauss_newton.t:200-216)
+    min_lm, max_lm, min_rel, ftol, max_radius, min_radius = f32(1e-6), f32(1e32), f32(1e-3), f32(1e-6), f32(1e16), f32(1e-32)
+    radius, dec = f32(30.0), f32(2.0)
+    xk = X0.reshape(-1).copy()
+    prev = cost_of(xk); ref = [prev]; SSq = None; early = False
+    for it in range(nit):
+        F = J @ xk + b0
+        r = -(Jf.T @ F); d = np.asarray(Jf.multiply(Jf).sum(axis=0)).ravel()
+        if it == 0: SSq = 1.0 / (1.0 + np.sqrt(d)) ** 2
+        unclamped = d / radius; cm = (1.0 / SSq) / radius
+        CtC = np.minimum(np.maximum(unclamped, min_lm * cm), max_lm * cm)
+        M = 1.0 / (CtC + radius * unclamped)
+        b = r.copy(); z = M * r; aN = r @ z; delta = np.zeros_like(r); Q0 = 0.0; pvec = None
+        for k in range(L):
+            pvec = z.copy() if k == 0 else z + (bN / aN_prev) * pvec
+            if k: aN = bN
+            Ap = Jf.T @ (Jf @ pvec) + CtC * pvec; aD = pvec @ Ap
+            alpha = aN / aD
+            delta = delta + alpha * pvec
+            if (k + 1) % period == 0: r = b - (Jf.T @ (Jf @ delta) + CtC * delta)
+            else: r = r - alpha * Ap
+            z = M * r; bN = z @ r; aN_prev = aN
+            Q1 = 0.5 * delta @ (r + b)
+            zeta = (k + 1) * (Q1 - Q0) / Q1
+            if not np.isfinite(Q1) or not np.isfinite(zeta) or zeta < f32(q_tolerance): early = early or k + 1 < L; break
+            Q0 = Q1
+        model = delta @ b - 0.5 * delta @ (Jf.T @ (Jf @ delta))
+        xn = xk.copy(); xn[free] += delta
+        new = cost_of(xn); change = prev - new; rho = change / model
+        if change >= 0 and rho > min_rel:
+            if change <= prev * ftol: xk = xn; break
+            radius = min(radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), max_radius); dec = 2.0; prev = new; xk = xn
+        else:
+            radius = radius / dec; dec = 2.0 * dec
+            if radius < min_radius: break
+        ref.append(cost_of(xk))
+    costs = np.array(costs); ref = np.array(ref)
+    assert len(costs) == len(ref) >= 4, (costs, ref)
+    assert rel_err(costs, ref) < 1e-11, (costs, ref)
+    assert (q_tolerance > 0) == early
+    got = to_host(dev[0]).reshape(-1)
+    assert np.abs(got[~free] - X0.reshape(-1)[~free]).max() == 0.0
+    assert np.abs(got - xk).max() < 1e-10
+    assert costs[-1] < 0.2 * costs[0]
+
+
+def _solve_both(fname, dims, params32, monkeypatch, keep32=(), lm=False, **sp):
     """The same bundled .t through the front-end in float and in double (unknowns / thallo_float arrays as doubles; float Params and the arrays the file declares
     with a fixed float type -- keep32: their parameter indices -- as they are)."""
     out = {}
@@ -115,6 +204,7 @@ def _solve_both(fname, dims, params32, monkeypatch, keep32=(), **sp):
             else: dev.append(np.float32(p))
         s = api.ThalloSolver(dims, thallo_amd.energy_file(fname), double_precision=dbl)
         assert s.energy_name.startswith("generated:")
+        if lm: s.enable_lm()
         final, costs = s.solve(dev, profiled=True, **sp)
         s.close()
         out[dbl] = (dev, np.array(costs))
@@ -145,6 +235,21 @@ def test_double_precision_graph_energy_follows_the_float_path(torch, monkeypatch
     assert rel_err(cd[:1], cf[:1]) < 1e-6
     assert rel_err(cd, cf) < 2e-4, (cd, cf)
     assert cd[-1] <= cf[-1] * (1 + 1e-4)
+
+
+@pytest.mark.parametrize("which", ["iw", "ba"])
+def test_double_precision_levenberg_marquardt_follows_the_float_path(torch, monkeypatch, which):
+    """The LM branch in double on nonlinear energies (image_warping; bundle_adjustment through Sparse maps) against the float LM loop of solver.cpp on the kernels generated from
+    the same file: same accept / reject decisions, trajectories to float accuracy."""
+    if which == "iw":
+        res = _solve_both("image_warping.t", (64, 48), syn.image_warping(64, 48, n_markers=8), monkeypatch, lm=True, nIterations=5, lIterations=25)
+    else:
+        res = _solve_both("bundle_adjustment.t", (12, 60, 300), syn.bundle_adjustment(C=12, P=60, O=300, band=8), monkeypatch, keep32=(2,), lm=True, nIterations=5, lIterations=20)
+    cf, cd = res[False][1], res[True][1]
+    assert len(cf) == len(cd) >= 4, (cf, cd)
+    assert rel_err(cd[:1], cf[:1]) < 2e-6
+    assert rel_err(cd, cf) < 5e-4, (cd, cf)
+    assert cd[-1] < cd[0] and all(cd[i + 1] <= cd[i] * (1 + 1e-9) for i in range(len(cd) - 1))
 
 
 @pytest.mark.parametrize("which", ["ba", "sfs"])

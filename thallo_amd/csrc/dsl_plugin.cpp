@@ -445,6 +445,7 @@ public:
             double *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
             const int rc = launch(kernel_of((int)ri, gather_[ri] ? 6 : 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
+        if (v.diag && hipMemcpyAsync(v.diag, v.pre, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;      // LM: the raw diagonal
         return thallo_hip_f64_init_finish(v.r, v.pre, v.z, v.p, v.n, P.use_preconditioner ? 1 : 0, aN, s);           // PCGInit1_Finish (gauss_newton.t:712-731)
     }
     int apply_jtj64(LaunchCtx& c, Vectors64& v, const double* p, double* Ap, double* out) override

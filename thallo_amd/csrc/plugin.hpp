@@ -79,7 +79,8 @@ struct UnknownImage { int param_index; long n_floats; };
 
 // doublePrecision = 1 (precision.t:3-6): what a plugin that also runs on double vectors offers -- the generated plugins, compiled with thallo_float = double.
 // The driver is solver_f64.cpp's reference-shaped loop; the hand-written gfx950 kernels are float only.
-struct Vectors64 { long n = 0, n_alloc = 0; double *delta = nullptr, *r = nullptr, *z = nullptr, *Ap = nullptr, *pre = nullptr, *p = nullptr; };
+struct Vectors64 { long n = 0, n_alloc = 0; double *delta = nullptr, *r = nullptr, *z = nullptr, *Ap = nullptr, *pre = nullptr, *p = nullptr;
+                   double* diag = nullptr; };      // diag != NULL (LM): pcg_init64 also leaves the RAW diagonal of J^T J there
 class EnergyPlugin64 {
 public:
     virtual ~EnergyPlugin64() {}

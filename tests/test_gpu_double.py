@@ -339,21 +339,28 @@ def test_plan_free_cycles_do_not_leak_device_memory(torch, monkeypatch, kind):
     for q in p:
         if isinstance(q, np.ndarray): dev.append(torch.from_numpy(q.astype(np.float64) if dbl else q.copy()).cuda())
         else: dev.append(np.float32(q))
-    free = []
     ncyc = 6 if kind in ("generated", "generated_double") else 10       # (a generated plan compiles its kernels with hipRTC at every Plan: 1.5 s per cycle; a leak per plan shows after every cycle)
-    for cycle in range(ncyc):
-        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping.t"), double_precision=dbl)
-        assert s.energy_name.startswith("generated:") == (kind in ("generated", "generated_double"))
-        if kind == "lm": s._L.ThalloX_EnableLM(s.plan, 1)
-        s.solve(dev, nIterations=2, lIterations=5)
-        s.close()
-        del s
-        torch.cuda.synchronize()
-        free.append(torch.cuda.mem_get_info()[0])
-    # A leak per plan shows as a drop after EVERY cycle (25 MB here).  The runtime's own pools (code objects, signals, kernel arguments) also grow while the whole suite
-    # runs in one process -- in steps of 2 to 32 MB, at most once or twice over these ten cycles, and never per cycle: so the cycles whose free memory dropped are counted.
-    drops = sum(1 for a, b in zip(free[1:], free[2:]) if b < a - (1 << 20))
-    assert drops <= 2 and free[1] - free[-1] <= (96 << 20), free
+
+    def cycles():
+        free = []
+        for cycle in range(ncyc):
+            s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping.t"), double_precision=dbl)
+            assert s.energy_name.startswith("generated:") == (kind in ("generated", "generated_double"))
+            if kind == "lm": s._L.ThalloX_EnableLM(s.plan, 1)
+            s.solve(dev, nIterations=2, lIterations=5)
+            s.close()
+            del s
+            torch.cuda.synchronize()
+            free.append(torch.cuda.mem_get_info()[0])
+        # A leak per plan shows as a drop after EVERY cycle (25 MB here).  The runtime's own pools (code objects, signals, kernel arguments) also grow while the whole suite
+        # runs in one process -- in steps of 2 to 32 MB, at most once or twice over these ten cycles, and never per cycle: so the cycles whose free memory dropped are counted.
+        drops = sum(1 for a, b in zip(free[1:], free[2:]) if b < a - (1 << 20))
+        return drops <= 2 and free[1] - free[-1] <= (96 << 20), free
+    # mem_get_info is the DEVICE's free memory: anything else that allocates on the card while the cycles run (seen once in round 4: five equal 52-MB drops in a run whose
+    # neighbours -- the same tests in the same order on another box -- were flat) reads as a leak.  A leak of this library repeats; so a failed measurement is taken again.
+    ok, free = cycles()
+    if not ok: ok, free2 = cycles(); free = free + free2
+    assert ok, free
 
 
 def test_an_array_declared_double_needs_double_precision(torch, tmp_path):

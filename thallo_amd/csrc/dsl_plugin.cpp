@@ -209,7 +209,7 @@ public:
                 const bool want = r.at_output == 1 || (r.at_output < 0 && autoschedule);
                 bool fits = n_unk < (1L << 31) && elements(r) < (1L << 31) && ir.K <= 64;
                 for (int g : ir.groups) fits = fits && group_pixels(g) < (1L << 31);
-                use_inc_[(size_t)ir.ri] = want && plain && !f64_ && !off && fits;
+                use_inc_[(size_t)ir.ri] = want && plain && !off && fits;
                 if (!use_inc_[(size_t)ir.ri]) continue;
                 for (size_t k = 0; k < ir.groups.size(); ++k) {
                     IncRun* run = new IncRun(); run->ri = ir.ri; run->g = ir.groups[k];
@@ -225,7 +225,7 @@ public:
             const bool plain = !r.mat_J && !r.mat_JtJ && !r.mat_Jp;
             if (r.at_output == 1 && !gather_[ri] && !use_inc_[ri])
                 fprintf(stderr, "[thallo] warning: %s: residual %s asks for compute_at_output(true) but %s: its residual-wise kernels run\n", label.c_str(), r.name.c_str(),
-                        plain ? "has no unknown-wise lowering in this configuration (more than 48 unknown accesses per instance, or doublePrecision = 1)" : "also materializes J / JtJ / Jp");
+                        plain ? "has no unknown-wise lowering (more than 48 unknown accesses per instance: the wide lowering scatters)" : "also materializes J / JtJ / Jp");
         }
         // the merged gather kernels: a group runs when all of its members are gathered (they are: only wanted residuals join a group) -- groups of one included
         group_of_.assign(P.residuals.size(), -1);
@@ -440,9 +440,11 @@ public:
             double *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
             const int rc = launch_fn(grp_jtf[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
         }
+        if (!inc_ready_ && !inc_runs_.empty() && build_incidence(s)) return -1;
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {            // evalJTF: r = -J^T F, pre = diag(J^T J)   (thallo.t:3898-3902)
             if (group_of_[ri] >= 0) continue;
             double *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
+            if (use_inc_[ri]) { const int rc = launch_inc((int)ri, false, &r, &pre, s); if (rc < 0) return rc; continue; }
             const int rc = launch(kernel_of((int)ri, gather_[ri] ? 6 : 1), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
         if (v.diag && hipMemcpyAsync(v.diag, v.pre, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;      // LM: the raw diagonal
@@ -460,6 +462,7 @@ public:
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
             if (group_of_[ri] >= 0) continue;
             void* args[] = { ctx.data(), &p, &Ap };
+            if (use_inc_[ri]) { if (!inc_ready_) return -1; const int rc = launch_inc((int)ri, true, &p, &Ap, s); if (rc < 0) return rc; continue; }
             const int rc = launch(kernel_of((int)ri, gather_[ri] ? 7 : 2), grid_for(nel[ri], 4096), args, s); if (rc < 0) return rc;
         }
         return thallo_hip_f64_dot(p, Ap, n_unk, out, s);              // PCGStep1_Finish: alphaD = p . Ap_X

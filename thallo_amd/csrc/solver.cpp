@@ -704,12 +704,16 @@ int Plan::step_lm(int ev_iter)
             check(thallo_hip_finish_sum(partial_sum(B), scal(B), s), "alphaN_0 sum");
             if (!failed) fin_[B] = 1;
         }
-        bool after_reset = false;
+        bool after_reset = false; int reset_nb = 0;
         for (int k = 0; k < L && !failed; ++k) {
             const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
             const thallo_fin_t fin = { sum(jN), v_.fin_tickets, scal(jD), scal(jB) };
+            // behind a reset the iteration's first launch gets betaN_{k-1} as the reset's PARTIALS and replaces the word (the expansion's value) by their sum; everything
+            // later -- this iteration's finish, the next one's alpha, the owed update of delta, alpha_beta_trace -- reads the word, which is valid either way (a loop that the
+            // zeta test ended AT the reset iteration never ran the reset: its word is the expansion's)
+            const thallo_sum_t bn_partials = { slot(jN), reset_nb };
             ctx.lm_reset_bn_word = after_reset ? scal(jN) : nullptr;
-            nb = plugin->pcg_iter_lm(ctx, v_, cur_, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), slot(jD), fin, lmst, k, sp.q_tolerance);
+            nb = plugin->pcg_iter_lm(ctx, v_, cur_, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), after_reset ? bn_partials : sum(jN), slot(jD), fin, lmst, k, sp.q_tolerance);
             ctx.lm_reset_bn_word = nullptr; after_reset = false;
             check(nb, "PCGIteration (LM) launch");
             if (failed) break;
@@ -718,15 +722,15 @@ int Plan::step_lm(int ev_iter)
             k_done = k + 1;
             if (((k + 1) % period) == 0 && k + 1 < L) {
                 // residual reset (:1653-1657; on the last iteration it changes nothing that is read afterwards): delta_{k+1} = delta_k + alpha_k p_k now,
-                // r = b - (J^T J + CtC) delta and the partials of betaN_k = r . M^-1 r (they replace the expansion's word: the next iteration adds them up, leaves the
-                // word and forms p_{k+1} only); q_{k+1} and the zeta test stay the launch's own -- the same quantity, and the gate word it may have set ends these
+                // r = b - (J^T J + CtC) delta and the partials of betaN_k = r . M^-1 r (the next iteration's first launch adds them up, replaces the expansion's word by
+                // the sum and forms p_{k+1} only); q_{k+1} and the zeta test stay the launch's own -- the same quantity, and the gate word it may have set ends these
                 // launches too.
                 { TimedLaunch t(ctx, "PCGStep2"); check(thallo_hip_lm_step2_first_half(v_.delta, v_.p[cur_], n, sum(jN), sum(jD), s), "PCGStep2 (first half) launch"); }
                 if (failed) break;
                 nb = plugin->lm_reset_residual(ctx, v_, slot(jB));
                 check(nb, "residual reset launch");
                 if (failed) break;
-                set_nb(jB, nb); fin_[jB] = 0;
+                reset_nb = nb;
                 after_reset = true;
             }
         }

@@ -402,6 +402,7 @@ E subst_expr(const E& e, const std::map<int, IndexComp>& to, std::map<const Expr
         if (ic.dim_b >= 0 && to.count(ic.dim_b)) fail(":get through a Sparse map of an expression whose index mixes two iteration variables is not supported");
         if (f == to.end() || ic.sparse >= 0) continue;
         if (ic.dim_b >= 0 || ic.sign != 1) fail(":get through a Sparse map of an expression whose index mixes two iteration variables is not supported");
+        if (f->second.sparse < 0) { ic.dim = f->second.dim; continue; }      // a rename: another variable over the same dimension (the component's own offset stays)
         if (ic.off != 0) fail(":get through a Sparse map of an expression that reads a shifted neighbour is not supported");
         ic = f->second;
     }
@@ -690,7 +691,13 @@ struct Interp {
                 for (size_t k = 0; k < nsrc; ++k) {
                     const IndexComp a = as_index(args[k], in.name.c_str());
                     if (a.sparse >= 0) fail(ln + "nested Sparse maps are not supported");
-                    if (P.canonical(a.dim) != in.dims[k]) fail(ln + in.name + " is indexed over dimension " + P.dims[in.dims[k]]);
+                    // A map declared over one dimension and indexed with a variable of another (examples/bundle_fusion_solve: t_source = Sparse({CorrDim}, {T}) read as
+                    // t_source(p), p = PairDim()): the reference does not compare the two (thallo.t:1977-1990 builds the access from whatever index it is given; the declared
+                    // source space only sizes nothing on the device), the map is read at the variable's index.  Same here, with a note: the caller's array must hold an
+                    // entry for every index of the variable's dimension.
+                    if (P.canonical(a.dim) != in.dims[k])
+                        fprintf(stderr, "[thallo] note: %s%s is declared over %s and indexed over %s: read at that variable's index, as in the reference\n", ln.c_str(), in.name.c_str(),
+                                P.dims[in.dims[k]].c_str(), P.dims[P.canonical(a.dim)].c_str());
                     if (a.off != 0 || a.dim_b >= 0 || a.sign != 1) fail(ln + "offset inside a Sparse map access");
                     if (k == 0) ic.dim = a.dim; else ic.dim2 = a.dim;
                 }
@@ -745,7 +752,7 @@ struct Interp {
     {
         const std::string ln = "line " + std::to_string(line) + ": ";
         if (is_symk(obj, SymV::IndexDomain) || is_symk(obj, SymV::IndexE)) {
-            if (m == "asvalue") { auto e = std::make_shared<Expr>(); e->op = Op::IndexVal; e->idx = { as_index(obj, "asvalue") }; if (e->idx[0].sparse >= 0) fail(ln + "asvalue through a Sparse map"); return { scalar(e) }; }
+            if (m == "asvalue") { auto e = std::make_shared<Expr>(); e->op = Op::IndexVal; e->idx = { as_index(obj, "asvalue") }; return { scalar(e) }; }      // (through a Sparse map: the map's entry as a value, thallo.t:1578 SparseAccess:asvalue)
         }
         if (is_symk(obj, SymV::Image)) {
             Input& in = P.inputs[obj.sym->id];
@@ -763,6 +770,28 @@ struct Interp {
                 auto c = comps(obj, "get");
                 std::vector<int> dims; { std::map<const Expr*, int> seen; for (auto& e : c) collect_dims(e, dims, seen); }
                 std::map<int, int> sh; std::vector<IndexComp> at;
+                {   // POSITIONAL form (round 4): as many arguments as the expression has iteration variables (in the order the variables were made: t0, t1 = T(), T()) -- the
+                    // k-th variable becomes the k-th argument, which may be a Sparse-mapped index, ANOTHER variable over the same dimension (a rename: f(t0):get(t1)), or
+                    // the same variable with an offset (a shift, handled below).  examples/bundle_fusion_solve: M(t0, t1):get(t_target(p), t_source(p)) -- keyed by the map's
+                    // target dimension, as the one-argument graph form below is, both variables would have received the last map.
+                    std::vector<int> free = dims; std::sort(free.begin(), free.end());
+                    bool positional = args.size() == free.size() && !free.empty(), pure_shift = true;
+                    std::vector<IndexComp> ics;
+                    for (size_t k = 0; positional && k < args.size(); ++k) {
+                        IndexComp ic = as_index(args[k], "get"); ics.push_back(ic);
+                        if (ic.dim_b >= 0 || ic.sign != 1) positional = false;
+                        else if (ic.sparse >= 0) { pure_shift = false; if (ic.off != 0) fail(ln + ":get with an offset through a Sparse map"); if (P.inputs[ic.sparse].dims.back() != P.canonical(free[k])) positional = false; }
+                        else if (ic.dim != free[k]) { pure_shift = false; if (P.canonical(ic.dim) != P.canonical(free[k])) positional = false; }
+                    }
+                    if (positional && !pure_shift) {
+                        std::map<int, IndexComp> to; bool shifted = false;
+                        for (size_t k = 0; k < ics.size(); ++k) { if (ics[k].sparse < 0 && ics[k].dim == free[k] && ics[k].off == 0) continue; to[free[k]] = ics[k]; shifted = shifted || (ics[k].sparse < 0 && ics[k].off != 0); }
+                        if (shifted) fail(ln + ":get that renames a variable AND shifts it is not supported");
+                        std::vector<E> out; std::map<const Expr*, E> memo;
+                        for (auto& e : c) out.push_back(subst_expr(e, to, memo));
+                        return { vec(out) };
+                    }
+                }
                 {   // graph access: every argument went through a Sparse map -> substitute the mapped index for the map's target dimension
                     std::map<int, IndexComp> to; size_t nsp = 0;
                     for (auto& a : args) { IndexComp ic = as_index(a, "get"); if (ic.sparse >= 0) { ++nsp; if (ic.off != 0) fail(ln + ":get with an offset through a Sparse map"); to[P.inputs[ic.sparse].dims.back()] = ic; } }
@@ -887,14 +916,17 @@ struct Interp {
     {
         for (const char* n : { "Vec3", "RotationMatrixAndTranslationToMat4", "rigid_trans", "RodriguesSO3Exp", "PoseToMatrix", "Constant", "SampledImage", "SampledImageArray", "pow", "L_2_norm", "L_p", "gemv", "Dim", "neq", "Dims", "Inputs", "Unknown", "Array", "Image", "Sparse", "Param", "UsePreconditioner", "Residuals", "Stencil", "Select", "InBounds", "InBoundsExpanded", "Sum",
                                "eq", "greater", "greatereq", "less", "lesseq", "Not", "And", "Or", "All", "Any", "abs", "sqrt", "sin", "cos", "Vector", "dot", "cross",
-                               "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length" })
+                               "Rotate2D", "Rotate3D", "AngleAxisRotatePoint", "ipairs", "pairs", "print", "assert", "tostring", "tonumber", "unpack", "Sqrt", "normalize", "length",
+                               "Mat4ToRigidTransform", "RigidTransformToMat4", "CameraToDepth", "Max", "Min", "matmul", "transpose", "InvertRigidTransform", "SelectOnAll" })
             def(n);
         for (const char* n : { "float", "float2", "float3", "float4", "float6", "float9", "thallo_float", "thallo_float2", "thallo_float3", "thallo_float4", "thallo_float6", "thallo_float9",
                                "thallo_mat3f", "thallo_mat4f", "mat3f", "mat4f", "float8", "thallo_float8", "uint8", "double", "int", "thallo_int" }) { SymV s; s.k = SymV::TypeName; s.s = n; globals->vars[n] = Value::make_sym(s); }
         Value math; math.t = Value::Table; math.tab = std::make_shared<TableV>();
         for (const char* n : { "sqrt", "sin", "cos", "abs" }) { Value f; f.t = Value::Func; f.fn = std::make_shared<FuncV>(); f.fn->builtin = 1; f.fn->bname = n; math.tab->fields.push_back({ n, f }); }
         math.tab->fields.push_back({ "pi", Value::num(3.14159265358979323846) });
+        math.tab->fields.push_back({ "huge", Value::num(HUGE_VAL) });
         globals->vars["math"] = math;
+        globals->vars["inf"] = Value::num(HUGE_VAL);                      // lib.t:16 (L.inf = math.huge)
         // `ad.*` as the energy files use it next to the lib.t names (ad.Vector, ad.sqrt, ad.select, ad.less ...): the same builtins
         Value adt; adt.t = Value::Table; adt.tab = std::make_shared<TableV>();
         const char* alias[][2] = { { "Vector", "Vector" }, { "sqrt", "sqrt" }, { "sin", "sin" }, { "cos", "cos" }, { "abs", "abs" }, { "pow", "pow" }, { "select", "Select" },
@@ -1090,8 +1122,66 @@ struct Interp {
             need(2); auto r = comps(a[0], f.c_str()), t = comps(a[1], f.c_str()); if (r.size() != 9 || t.size() != 3) fail(ln + f + "(matrix9, vector3)");
             return { vec({ r[0], r[1], r[2], t[0], r[3], r[4], r[5], t[1], r[6], r[7], r[8], t[2], konst(0.0), konst(0.0), konst(0.0), konst(1.0) }) };
         }
+        if (f == "Mat4ToRigidTransform") {          // lib.t:263-267: the first three rows of a 4x4
+            need(1); auto m = comps(a[0], f.c_str()); if (m.size() != 16) fail(ln + f + "(matrix16)");
+            return { vec(std::vector<E>(m.begin(), m.begin() + 12)) };
+        }
+        if (f == "RigidTransformToMat4") {          // lib.t:269-274
+            need(1); auto m = comps(a[0], f.c_str()); if (m.size() != 12) fail(ln + f + "(matrix12)");
+            m.push_back(konst(0.0)); m.push_back(konst(0.0)); m.push_back(konst(0.0)); m.push_back(konst(1.0));
+            return { vec(m) };
+        }
+        if (f == "CameraToDepth") {                 // lib.t:276-280: pinhole projection (x fx / z + cx, y fy / z + cy)
+            need(5); auto pos = comps(a[4], f.c_str()); if (pos.size() < 3) fail(ln + "CameraToDepth(fx, fy, cx, cy, position3)");
+            E fx = one(a[0], f.c_str()), fy = one(a[1], f.c_str()), cx = one(a[2], f.c_str()), cy = one(a[3], f.c_str());
+            return { vec({ bin(Op::Add, bin(Op::Div, bin(Op::Mul, pos[0], fx), pos[2]), cx), bin(Op::Add, bin(Op::Div, bin(Op::Mul, pos[1], fy), pos[2]), cy) }) };
+        }
+        if (f == "Max" || f == "Min") {             // lib.t:282-285: select(greater(a, b), a, b)
+            need(2);
+            if (a[0].t == Value::Num && a[1].t == Value::Num) return { Value::num(f == "Max" ? std::fmax(a[0].n, a[1].n) : std::fmin(a[0].n, a[1].n)) };
+            E x = one(a[0], f.c_str()), y = one(a[1], f.c_str());
+            return { scalar(mk(Op::Select, { mk(f == "Max" ? Op::Gt : Op::Lt, { x, y }), x, y })) };
+        }
+        if (f == "matmul" || f == "transpose") {    // lib.t:287-305, 440-452: square row-major matrices
+            auto A_ = comps(a[0], f.c_str());
+            size_t dim = 0; while (dim * dim < A_.size()) ++dim;
+            if (dim * dim != A_.size()) fail(ln + f + ": square matrices only");
+            std::vector<E> out;
+            if (f == "transpose") { need(1); for (size_t i = 0; i < dim; ++i) for (size_t j = 0; j < dim; ++j) out.push_back(A_[j * dim + i]); return { vec(out) }; }
+            need(2); auto B_ = comps(a[1], f.c_str()); if (B_.size() != A_.size()) fail(ln + "matmul: sizes differ");
+            for (size_t i = 0; i < dim; ++i) for (size_t j = 0; j < dim; ++j) {
+                E c = konst(0.0);
+                for (size_t k = 0; k < dim; ++k) c = bin(Op::Add, c, bin(Op::Mul, A_[i * dim + k], B_[k * dim + j]));
+                out.push_back(c);
+            }
+            return { vec(out) };
+        }
+        if (f == "InvertRigidTransform") {          // lib.t:454-464: [R | t]^-1 = [R^T | -R^T t] of a 4x4
+            need(1); auto m = comps(a[0], f.c_str()); if (m.size() != 16) fail(ln + f + "(matrix16)");
+            const E Rt[9] = { m[0], m[4], m[8], m[1], m[5], m[9], m[2], m[6], m[10] }, t[3] = { m[3], m[7], m[11] };
+            std::vector<E> out;
+            for (int r = 0; r < 3; ++r) {
+                E nt = bin(Op::Mul, un(Op::Neg, Rt[3 * r]), t[0]);
+                for (int c = 1; c < 3; ++c) nt = bin(Op::Add, nt, bin(Op::Mul, un(Op::Neg, Rt[3 * r + c]), t[c]));
+                out.push_back(Rt[3 * r]); out.push_back(Rt[3 * r + 1]); out.push_back(Rt[3 * r + 2]); out.push_back(nt);
+            }
+            out.push_back(konst(0.0)); out.push_back(konst(0.0)); out.push_back(konst(0.0)); out.push_back(konst(1.0));
+            return { vec(out) };
+        }
+        if (f == "SelectOnAll") {                   // lib.t:196-205: val where every predicate of the list holds, else default
+            need(3);
+            if (a[0].t != Value::Table || a[0].tab->arr.empty()) fail(ln + "SelectOnAll({predicates}, value, default)");
+            std::vector<E> preds; for (auto& pv : a[0].tab->arr) preds.push_back(one(pv, f.c_str()));
+            if (preds.empty()) fail(ln + "SelectOnAll() requires at least one predicate");
+            auto val = comps(a[1], f.c_str()), dflt = comps(a[2], f.c_str());
+            if (dflt.size() == 1 && val.size() > 1) dflt.assign(val.size(), dflt[0]);
+            if (dflt.size() != val.size()) fail(ln + "SelectOnAll: value and default differ in size");
+            std::vector<E> out;
+            for (size_t c = 0; c < val.size(); ++c) { E r = val[c]; for (size_t i = preds.size(); i-- > 0;) r = mk(Op::Select, { preds[i], r, dflt[c] }); out.push_back(r); }
+            return { vec(out) };
+        }
         if (f == "rigid_trans") {                   // lib.t:508-510: the first three rows of M (4x4, row-major) applied to (v, 1)
-            need(2); auto M = comps(a[0], f.c_str()), v = comps(a[1], f.c_str()); if (M.size() != 16 || v.size() < 3) fail(ln + "rigid_trans(matrix16, vector3)");
+            need(2); auto M = comps(a[0], f.c_str()), v = comps(a[1], f.c_str()); if (((M.size() != 16) && (M.size() != 12)) || v.size() < 3) fail(ln + "rigid_trans(matrix16 or matrix12, vector3)");      // (gemv on the 3 x 4 rigid form gives the same three rows)
             std::vector<E> out;
             for (int r = 0; r < 3; ++r) out.push_back(bin(Op::Add, bin(Op::Add, bin(Op::Add, bin(Op::Mul, M[4 * r], v[0]), bin(Op::Mul, M[4 * r + 1], v[1])), bin(Op::Mul, M[4 * r + 2], v[2])), bin(Op::Mul, M[4 * r + 3], konst(1.0))));
             return { vec(out) };

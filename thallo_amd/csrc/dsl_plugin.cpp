@@ -103,6 +103,7 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
             if (launch_fn(inc_uidx_[a], grid_for(n, 4096), args, s) < 0) return -1;
             std::vector<int> h((size_t)n * (size_t)K);
             if (n && (hipMemcpyAsync(h.data(), col.ptr, h.size() * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) return -1;
+            bool few_owners = false;
             for (IncRun* run : inc_runs_) {
                 if (run->ri != ir.ri) continue;
                 const long npix = group_pixels(run->g);
@@ -143,6 +144,13 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
                 // owners with long lists (bundle adjustment's cameras: hundreds of observations each, a few thousand owners) get a wave each; 16 instances per owner on
                 // average is where a wave's 64 lanes stop being mostly idle
                 run->wave = npix > 0 && (long)els.size() >= 16 * npix ? 1 : 0;
+                // ... but a handful of owners with enormous lists (a dense residual over W x H x pairs that reads ten camera poses: ten waves for the whole launch) is the
+                // case the residual-wise kernels with their wave-aggregated atomics are for: below 256 such owners the residual keeps them
+                if (run->wave && npix < 256) few_owners = true;
+            }
+            if (few_owners) {
+                use_inc_[(size_t)ir.ri] = 0;
+                for (IncRun* run : inc_runs_) if (run->ri == ir.ri) { run->ptr.release(); run->els.release(); run->npix = 0; }
             }
         }
         inc_ready_ = true;

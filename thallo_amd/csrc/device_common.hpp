@@ -212,7 +212,7 @@ __device__ __forceinline__ IterationSums load_iteration_sums(const float* aD_out
 
 // The same read-back by ALL waves of the last workgroup: the 1 + NQD quantities (alphaD in float with alphaN beside it; N, S1, S2 from s3; with NQD = 6 also U, T1, T2 from
 // q3) are dealt over the waves, a wave issues every load of its (at most two) quantities before the first addition -- one round of fabric latency for the whole read-back
-// where the one-wave form takes a round per 256 slots and quantity group (bundle adjustment, 943 slots: the LM point launch 18.6 -> ~13 us, GN's 13.3 -> ~12) -- and adds them in
+// where the one-wave form takes a round per 256 slots and quantity group (bundle adjustment, 943 slots: the LM point launch from 1.33 to 1.05 times the camera launch of the same run, profiles/r04/ba_lm_loops.json) -- and adds them in
 // load_iteration_sums' order (lane l: slots l, l + 64, ... ascending from zero, then the butterfly): bit-identical totals.  Must be reached by every wave of the workgroup
 // (two barriers inside); the totals come back in every lane of every wave.  red >= 16 floats (words 13, 14 used), redd >= NQD doubles.
 template <int NQD>

@@ -16,6 +16,8 @@ def run(lm, steps=4):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s.close()
     return {"lm": lm, "us_per_pcg_iter": round(dt / max(n, 1) / L * 1e6, 2), "costs": costs}
+if os.environ.get("BA_TIME_ONLY") == "gn":
+    print(json.dumps([run(False), run(False)])); sys.exit(0)
 if os.environ.get("BA_TIME_ONLY") == "lm":      # under rocprofv3: the LM loop's kernels only
     print(json.dumps([run(True), run(True)])); sys.exit(0)
 out = [run(False), run(True), run(False), run(True)]

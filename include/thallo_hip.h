@@ -591,6 +591,12 @@ int thallo_hip_pcg_update(float* r, const float* Ap, const float* pre, const flo
                           thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, thallo_stream_t stream);
 int thallo_hip_pcg_scalars_finish(const float* alphaD_partials, const double* s3_partials, int count, thallo_sum_t alphaN,
                                   float* alphaD_word, float* betaN_word, thallo_stream_t stream);
+/* thallo_hip_pcg_update of iteration k (not the first) with thallo_hip_pcg_scalars_finish of iteration k-1 folded into it (round 4): every workgroup adds the partials of the
+ * previous applyJTJ up for itself -- the same order, the same bits -- forms alpha_{k-1}, betaN_{k-1}, beta_{k-1} and updates its share of the vectors; workgroup 0 leaves the two
+ * words.  The applyJTJ launch then needs neither tickets nor a read-back at its end (its ~3-us tail on bundle adjustment's 12-us point launch); one thallo_hip_pcg_scalars_finish
+ * behind the loop finishes the last iteration. */
+int thallo_hip_pcg_update_fin(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, thallo_sum_t alphaN_prev,
+                              const float* alphaD_partials, const double* s3_partials, int count, float* alphaD_word, float* betaN_word, thallo_stream_t stream);
 /* the applyJTJ entry points of E2 / E3 / E4 (argument meaning as in the plain forms below) that also return the three sums */
 /* Round 3: applyJTJ with the per-edge G block RECOMPUTED from the source vertex's sines / cosines (SC: [sin a, sin b, sin g] per vertex, then the cosines; written by
  * thallo_hip_arap_precompute2) and dv = Original differences, instead of 2 x 36 streamed bytes per edge; ELL layout with at most 8 edge slots per vertex
@@ -640,7 +646,14 @@ int thallo_hip_ba_lm_reset_residual(int C_, int P_, const int* cam_ptr, const in
 int thallo_hip_ba_pcg_apply_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                                const float* cameras, const float* points, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* alphaD_out,
                                const float* r, const float* pre, const float* delta, const float* b, double* s3_out, double* q3_out, thallo_fin_t fin,
-                               float* lm_state, int k, float q_tolerance, thallo_stream_t stream);
+                               float* lm_state, int k, float q_tolerance, int q_in, int q_out, thallo_stream_t stream);
+/* ... and with the finish deferred (round 4): thallo_hip_ba_pcg_apply_lm with fin.tickets = NULL leaves partials only, and the flat update of the NEXT iteration
+ * (thallo_hip_pcg_update_lm_fin) finishes alphaD, betaN, q and the zeta test in every workgroup before it updates -- the same arithmetic and order.  q_in / q_out: the words of
+ * lm_state Q0 is read from / Q1 is left in (0 and 6 by the iteration's parity in that loop, so that no launch reads a word one of its workgroups writes; 0, 0 in the loop that
+ * finishes in the applyJTJ launch).  Iterations that a residual reset follows, and the last one, finish in their own launch (fin.tickets set). */
+int thallo_hip_pcg_update_lm_fin(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, thallo_sum_t alphaN_prev,
+                                 const float* alphaD_partials, const double* s3_partials, const double* q3_partials, int count, float* alphaD_word, float* betaN_word,
+                                 float* lm_state, int k_prev, float q_tolerance, int q_in, int q_out, thallo_stream_t stream);
 /* shape_from_shading applyJTJ with a device-side gate word (may be NULL): non-zero = the launch does nothing (the LM branch ends its PCG loop on
  * the device without a host round trip per iteration, solver.cpp) */
 int thallo_hip_sfs_apply_jtj_gated(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

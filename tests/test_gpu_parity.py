@@ -1260,8 +1260,10 @@ def test_in_kernel_scalar_finish_is_bitwise_the_separate_launch(torch, which, mo
     else:
         dims, p, name = (64, 4000, 20000), syn.bundle_adjustment(C=64, P=4000, O=20000), "bundle_adjustment"
     out = []
-    for fin in ("1", "0"):
-        monkeypatch.setenv("THALLO_FIN_IN_KERNEL", fin)
+    for fin in ("1", "0", None):      # None = the default: in the single-reduction GN loop (bundle adjustment; ARAP where its resident loop does not run) the finish of iteration
+        # k - 1 rides in the flat update of iteration k (thallo_hip_pcg_update_fin: every workgroup adds the partials up for itself); elsewhere the in-kernel finish
+        if fin is None: monkeypatch.delenv("THALLO_FIN_IN_KERNEL", raising=False)
+        else: monkeypatch.setenv("THALLO_FIN_IN_KERNEL", fin)
         dev = to_device(copy_params(p))
         s = api.ThalloSolver(dims, thallo_amd.energy_file(name))
         _, costs = s.solve(dev, profiled=True, nIterations=3, lIterations=25)
@@ -1269,6 +1271,36 @@ def test_in_kernel_scalar_finish_is_bitwise_the_separate_launch(torch, which, mo
         s.close()
         out.append((costs, tr))
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert out[0][0] == out[2][0] and out[0][1] == out[2][1]
+
+
+@pytest.mark.parametrize("q_tolerance", [0.0, 0.02])
+def test_lm_finish_deferred_into_the_next_flat_update_is_bitwise_the_in_kernel_finish(torch, monkeypatch, q_tolerance):
+    """Bundle adjustment's LM iteration is three launches (flat update, camera gather, point gather).  By default the two gather launches leave per-workgroup partials and the
+    flat update of the NEXT iteration finishes them in every workgroup -- alphaD, betaN, q, the zeta test (thallo_hip_pcg_update_lm_fin); iterations that a residual reset follows
+    and the last one finish in the point launch's last workgroup, as every iteration does with THALLO_FIN_IN_KERNEL=1.  Same arithmetic, same order: costs, unknowns, alpha / beta
+    traces and PCG iteration counts bit for bit, with resets (lIterations = 40) and, at q_tolerance = 0.02, early exits that fall on deferred and on own finishes alike."""
+    p = syn.bundle_adjustment(C=24, P=400, O=2400, band=8)
+    sp = dict(nIterations=4, lIterations=40, q_tolerance=q_tolerance)
+    runs = []
+    for fin in ("1", None):
+        if fin is None: monkeypatch.delenv("THALLO_FIN_IN_KERNEL", raising=False)
+        else: monkeypatch.setenv("THALLO_FIN_IN_KERNEL", fin)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((24, 400, 2400), thallo_amd.energy_file("bundle_adjustment"), solverkind="levenberg_marquardt")
+        s.enable_lm()
+        s.set_solver_parameters(**sp)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        runs.append((costs, traces, to_host(dev[0]).copy(), to_host(dev[1]).copy()))
+        s.close()
+    (c1, t1, a1, b1), (c0, t0, a0, b0) = runs
+    assert c1 == c0 and t1 == t0 and len(c1) >= 3
+    assert np.array_equal(a1, a0) and np.array_equal(b1, b0)
+    if q_tolerance > 0: assert any(len(t) < 40 for t in t1), [len(t) for t in t1]
 
 
 @pytest.mark.parametrize("which", ["sfs", "ba", "iw"])

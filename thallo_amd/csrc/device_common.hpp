@@ -215,7 +215,9 @@ __device__ __forceinline__ IterationSums load_iteration_sums(const float* aD_out
 // where the one-wave form takes a round per 256 slots and quantity group (bundle adjustment, 943 slots: the LM point launch from 1.33 to 1.05 times the camera launch of the same run, profiles/r04/ba_lm_loops.json) -- and adds them in
 // load_iteration_sums' order (lane l: slots l, l + 64, ... ascending from zero, then the butterfly): bit-identical totals.  Must be reached by every wave of the workgroup
 // (two barriers inside); the totals come back in every lane of every wave.  red >= 16 floats (words 13, 14 used), redd >= NQD doubles.
-template <int NQD>
+// PLAIN: the slots were written by an EARLIER launch (the finish deferred into the next launch, pcg_kernels.hip k_pcg_update_fin): ordinary loads, which every workgroup of
+// that launch can take from its L2.
+template <int NQD, bool PLAIN = false>
 __device__ __forceinline__ void last_workgroup_totals(const float* aD_out, const double* s3_out, const double* q3_out, int nb, thallo_sum_t aN, float* red, double* redd,
                                                       float& ad_out, float& an_out, double (&tot)[NQD])
 {
@@ -228,7 +230,7 @@ __device__ __forceinline__ void last_workgroup_totals(const float* aD_out, const
         float t[PER]; double v[2][PER];
         if (q0 == 0) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) { const int i = lane + k * THALLO_WAVE; t[k] = i < nb ? __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f; }
+            for (int k = 0; k < PER; ++k) { const int i = lane + k * THALLO_WAVE; t[k] = i < nb ? (PLAIN ? aD_out[i] : __hip_atomic_load(aD_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0f; }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -238,7 +240,7 @@ __device__ __forceinline__ void last_workgroup_totals(const float* aD_out, const
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int i = lane + k * THALLO_WAVE;
-                v[h][k] = i < nb ? __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+                v[h][k] = i < nb ? (PLAIN ? __longlong_as_double((long long)sp[3 * i]) : __longlong_as_double((long long)__hip_atomic_load(sp + 3 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) : 0.0;
             }
         }
         if (q0 == 0) {
@@ -342,6 +344,9 @@ struct LmFin {
     double* q3_out;                         // {U, T1, T2} per workgroup slot (3 * THALLO_MAX_PARTIALS doubles)
     float* state;                           // lm state words: [0] Q0, [1] gate, [2] iterations done at the stop
     int k; float q_tol;
+    int q_in = 0, q_out = 0;                // words of `state` the zeta test reads Q0 from / leaves Q1 in (0, 0: one word; the loop whose finishes alternate between launches
+                                            // of different kinds -- thallo_hip_pcg_update_lm_fin -- uses words 0 and 6 by the iteration's parity, so that a launch never reads
+                                            // the word another of its workgroups writes)
 };
 __device__ __forceinline__ void load_sums3_wave(const double* s3, int nb, double& a, double& b, double& c)
 {   // one wave; four slots per lane and round with all twelve loads in flight (the read-back sits between two dependent launches), then the butterfly
@@ -417,11 +422,11 @@ __device__ __forceinline__ void block_finish_sums_lm(float acc, const Sums3& sm,
     const float Q1 = (float)(0.5 * (U + (double)al * (T1 - T2) - (double)al * (double)al * (double)S.ad));
     if (lane == 0) {
         fin.aD_word[0] = S.ad; fin.bN_word[0] = (float)bn;
-        const float Q0 = lm.state[0];                             // k_lm_zeta's rule
+        const float Q0 = lm.state[lm.q_in];                       // k_lm_zeta's rule
         const float zt = (float)(lm.k + 1) * (Q1 - Q0) / Q1;
         const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < lm.q_tol;
         if (stop) { reinterpret_cast<unsigned*>(lm.state)[1] = 1u; reinterpret_cast<int*>(lm.state)[2] = lm.k + 1; }
-        else lm.state[0] = Q1;
+        else lm.state[lm.q_out] = Q1;
     }
 }
 

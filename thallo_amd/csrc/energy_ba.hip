@@ -539,7 +539,7 @@ static int ba_apply2(int C_, int P_, const int* cam_ptr, const int* q_pt, const 
     if (!cam_ptr || !q_pt || !pt_pos || !pt_ptr || !cameras || !points || !JP || !JpC || !p || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
     if (s3_out && (!r || !pre)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || (gate && !lm.b) || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
-    if (lm.b && (!fin.tickets || !ctc || !delta || !lm.q3_out || !lm.state)) return -(int)hipErrorInvalidValue;
+    if (lm.b && (!ctc || !delta || !lm.q3_out || !lm.state)) return -(int)hipErrorInvalidValue;      // (fin.tickets NULL: partials only -- the next thallo_hip_pcg_update_lm_fin finishes)
     int cb, grid; gather_shape(C_, P_, cb, grid);
     // the camera launch fills slots [0, cb); the point launch the rest, and (fin) its last workgroup adds up all `grid` of them
     hipLaunchKernelGGL(k_cam2, dim3(cb), dim3(BLOCK), 0, (hipStream_t)stream, C_, cam_ptr, q_pt, cameras, points, p, Ap, (float2*)JpC, aD_out, r, pre, s3_out, gate, ctc, delta, lm, rst);
@@ -566,11 +566,11 @@ int thallo_hip_ba_apply_jtj2_lm(int C_, int P_, const int* cam_ptr, const int* q
 int thallo_hip_ba_pcg_apply_lm(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                                const float* cameras, const float* points, const float* JP, float* JpC, const float* p, const float* CtC, float* Ap, float* aD_out,
                                const float* r, const float* pre, const float* delta, const float* b, double* s3_out, double* q3_out, thallo_fin_t fin,
-                               float* lm_state, int k, float q_tolerance, thallo_stream_t stream)
+                               float* lm_state, int k, float q_tolerance, int q_in, int q_out, thallo_stream_t stream)
 {
-    if (!CtC || !b || !delta || !lm_state || !q3_out || !s3_out) return -(int)hipErrorInvalidValue;
+    if (!CtC || !b || !delta || !lm_state || !q3_out || !s3_out || q_in < 0 || q_in > 7 || q_out < 0 || q_out > 7) return -(int)hipErrorInvalidValue;
     return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, p, Ap, aD_out, r, pre, s3_out, reinterpret_cast<const unsigned*>(lm_state) + 1, fin, CtC, stream,
-                     delta, LmFin{ b, q3_out, lm_state, k, q_tolerance });
+                     delta, LmFin{ b, q3_out, lm_state, k, q_tolerance, q_in, q_out });
 }
 int thallo_hip_ba_lm_reset_residual(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                                     const float* cameras, const float* points, const float* JP, float* JpC, const float* delta, const float* CtC, const float* b, const float* pre,

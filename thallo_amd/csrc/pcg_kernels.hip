@@ -238,6 +238,89 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_update(float4* __restrict__ r, co
     }
 }
 
+// ... with the FINISH of iteration k-1 deferred into it (thallo_hip_pcg_update_fin): the applyJTJ launch of iteration k-1 left per-workgroup partials only -- no write-through
+// slots, no arrival tickets, no last workgroup reading everything back at the end of a 12-us launch (a ~3-us tail, profiles/r04/ba_lm_loops.json) -- and EVERY workgroup of this
+// launch adds them up for itself (all four waves, last_workgroup_totals' order: the same bits as the in-kernel finish and as k_scalars_finish; <= 1024 slots x 28 bytes from L2,
+// behind the workgroup's own first vector loads), forms alpha_{k-1}, betaN_{k-1} and beta_{k-1} from them and goes on as k_pcg_update; workgroup 0 leaves the two words.
+template <bool HAS_PRE>
+__global__ __launch_bounds__(BLOCK) void k_pcg_update_fin(float4* __restrict__ r, const float4* __restrict__ Ap, const float4* __restrict__ pre,
+                                                           const float4* __restrict__ p_in, float4* __restrict__ p_out, float4* __restrict__ delta, long n4,
+                                                           thallo_sum_t aNp, const float* __restrict__ aD_part, const double* __restrict__ s3_part, int nb,
+                                                           float* __restrict__ aD_word, float* __restrict__ bN_word)
+{
+    __shared__ float red[16];
+    __shared__ double redd[8];
+    const long i0 = (long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool have = i0 < n4;
+    float4 rv0 = make_float4(0.f, 0.f, 0.f, 0.f), av0 = rv0, pv0 = rv0, dv0 = rv0, mv0 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (have) { rv0 = r[i0]; av0 = Ap[i0]; pv0 = p_in[i0]; dv0 = delta[i0]; if (HAS_PRE) mv0 = pre[i0]; }      // (in flight while the partials are added up)
+    float ad, an; double t3[3];
+    last_workgroup_totals<3, true>(aD_part, s3_part, nullptr, nb, aNp, red, redd, ad, an, t3);
+    const float alpha = safe_div<false>(an, ad);
+    double bn = t3[0] - 2.0 * (double)alpha * t3[1] + (double)alpha * (double)alpha * t3[2];
+    if (!(bn > 0.0)) bn = 0.0;
+    const float bnf = (float)bn, beta = safe_div<false>(bnf, an);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { aD_word[0] = ad; bN_word[0] = bnf; }
+    for (long i = i0; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 rv, av, pv, dv, m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (i == i0) { rv = rv0; av = av0; pv = pv0; dv = dv0; m = mv0; }
+        else { rv = r[i]; av = Ap[i]; pv = p_in[i]; dv = delta[i]; if (HAS_PRE) m = pre[i]; }
+        rv.x = __builtin_fmaf(-alpha, av.x, rv.x); rv.y = __builtin_fmaf(-alpha, av.y, rv.y); rv.z = __builtin_fmaf(-alpha, av.z, rv.z); rv.w = __builtin_fmaf(-alpha, av.w, rv.w);
+        r[i] = rv;
+        dv.x = __builtin_fmaf(alpha, pv.x, dv.x); dv.y = __builtin_fmaf(alpha, pv.y, dv.y); dv.z = __builtin_fmaf(alpha, pv.z, dv.z); dv.w = __builtin_fmaf(alpha, pv.w, dv.w);
+        delta[i] = dv;
+        float4 zv = rv;
+        if (HAS_PRE) { zv.x *= m.x; zv.y *= m.y; zv.z *= m.z; zv.w *= m.w; }
+        p_out[i] = make_float4(zv.x + beta * pv.x, zv.y + beta * pv.y, zv.z + beta * pv.z, zv.w + beta * pv.w);
+    }
+}
+
+// The LM form of k_pcg_update_fin (thallo_hip_pcg_update_lm_fin): the finish of LM iteration k-1 -- alphaD, betaN, q_k = 0.5 [U + alpha (T1 - T2) - alpha^2 alphaD] and the zeta
+// test (device_common.hpp block_finish_sums_lm's arithmetic and order) -- by EVERY workgroup of iteration k's flat update, from the partials the applyJTJ launches of iteration
+// k-1 left.  All workgroups reach the same verdict; workgroup 0 records it (the two words; Q1 in state[q_out], or the gate and the iteration count) -- Q0 is read from another
+// word than Q1 is written to.  A stop ends this launch too: delta, r, p stay as of the break, like everywhere in the LM loop.
+__global__ __launch_bounds__(BLOCK) void k_pcg_update_lm_fin(float4* __restrict__ r, const float4* __restrict__ Ap, const float4* __restrict__ pre,
+                                                              const float4* __restrict__ p_in, float4* __restrict__ p_out, float4* __restrict__ delta, long n4,
+                                                              thallo_sum_t aNp, const float* __restrict__ aD_part, const double* __restrict__ s3_part, const double* __restrict__ q3_part, int nb,
+                                                              float* __restrict__ aD_word, float* __restrict__ bN_word, float* __restrict__ state, int kprev, float q_tol, int q_in, int q_out)
+{
+    __shared__ float red[16];
+    __shared__ double redd[8];
+    if (__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned*>(state)[1]) != 0) return;      // the PCG loop already ended on the device
+    const long i0 = (long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool have = i0 < n4;
+    float4 rv0 = make_float4(0.f, 0.f, 0.f, 0.f), av0 = rv0, pv0 = rv0, dv0 = rv0, mv0 = rv0;
+    if (have) { rv0 = r[i0]; av0 = Ap[i0]; pv0 = p_in[i0]; dv0 = delta[i0]; mv0 = pre[i0]; }
+    float ad, an; double t6[6];
+    last_workgroup_totals<6, true>(aD_part, s3_part, q3_part, nb, aNp, red, redd, ad, an, t6);
+    const float alpha = safe_div<true>(an, ad);                  // LM divides blindly (gauss_newton.t:226-234)
+    double bn = t6[0] - 2.0 * (double)alpha * t6[1] + (double)alpha * (double)alpha * t6[2];
+    if (!(bn > 0.0)) bn = 0.0;
+    const float bnf = (float)bn;
+    const float Q1 = (float)(0.5 * (t6[3] + (double)alpha * (t6[4] - t6[5]) - (double)alpha * (double)alpha * (double)ad));
+    const float Q0 = state[q_in];
+    const float zt = (float)(kprev + 1) * (Q1 - Q0) / Q1;
+    const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < q_tol;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        aD_word[0] = ad; bN_word[0] = bnf;
+        if (stop) { reinterpret_cast<unsigned*>(state)[1] = 1u; reinterpret_cast<int*>(state)[2] = kprev + 1; }
+        else state[q_out] = Q1;
+    }
+    if (stop) return;
+    const float beta = safe_div<true>(bnf, an);
+    for (long i = i0; i < n4; i += (long)gridDim.x * BLOCK) {
+        float4 rv, av, pv, dv, m;
+        if (i == i0) { rv = rv0; av = av0; pv = pv0; dv = dv0; m = mv0; }
+        else { rv = r[i]; av = Ap[i]; pv = p_in[i]; dv = delta[i]; m = pre[i]; }
+        rv.x = __builtin_fmaf(-alpha, av.x, rv.x); rv.y = __builtin_fmaf(-alpha, av.y, rv.y); rv.z = __builtin_fmaf(-alpha, av.z, rv.z); rv.w = __builtin_fmaf(-alpha, av.w, rv.w);
+        r[i] = rv;
+        dv.x = __builtin_fmaf(alpha, pv.x, dv.x); dv.y = __builtin_fmaf(alpha, pv.y, dv.y); dv.z = __builtin_fmaf(alpha, pv.z, dv.z); dv.w = __builtin_fmaf(alpha, pv.w, dv.w);
+        delta[i] = dv;
+        const float4 zv = make_float4(rv.x * m.x, rv.y * m.y, rv.z * m.z, rv.w * m.w);
+        p_out[i] = make_float4(zv.x + beta * pv.x, zv.y + beta * pv.y, zv.z + beta * pv.z, zv.w + beta * pv.w);
+    }
+}
+
 // the update of delta the one-launch LM loop owes at its end (thallo_hip.h thallo_hip_lm_owed_delta)
 __global__ __launch_bounds__(BLOCK) void k_lm_owed_delta(float4* __restrict__ delta, const float4* __restrict__ p_even, const float4* __restrict__ p_odd, long n4,
                                                           const float* __restrict__ aN_words, const float* __restrict__ aD_words, int stride, const float* __restrict__ state, int L)
@@ -821,6 +904,32 @@ int thallo_hip_pcg_update(float* r, const float* Ap, const float* pre, const flo
     hipStream_t s = (hipStream_t)stream;
     if (pre) hipLaunchKernelGGL((k_pcg_update<true, false>), dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp, (const unsigned*)nullptr, (float*)nullptr);
     else     hipLaunchKernelGGL((k_pcg_update<false, false>), dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4, first, aNp, aDp, bNp, (const unsigned*)nullptr, (float*)nullptr);
+    return check_launch();
+}
+
+int thallo_hip_pcg_update_fin(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, thallo_sum_t alphaN_prev,
+                              const float* alphaD_partials, const double* s3_partials, int count, float* alphaD_word, float* betaN_word, thallo_stream_t stream)
+{
+    if (!r || !Ap || !p_in || !p_out || !delta || !alphaN_prev.partials || !alphaD_partials || !s3_partials || count < 1 || count > THALLO_MAX_PARTIALS || !alphaD_word || !betaN_word)
+        return -(int)hipErrorInvalidValue;
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipStream_t s = (hipStream_t)stream;
+    if (pre) hipLaunchKernelGGL((k_pcg_update_fin<true>), dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4,
+                                alphaN_prev, alphaD_partials, s3_partials, count, alphaD_word, betaN_word);
+    else     hipLaunchKernelGGL((k_pcg_update_fin<false>), dim3(grid), dim3(BLOCK), 0, s, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4,
+                                alphaN_prev, alphaD_partials, s3_partials, count, alphaD_word, betaN_word);
+    return check_launch();
+}
+
+int thallo_hip_pcg_update_lm_fin(float* r, const float* Ap, const float* pre, const float* p_in, float* p_out, float* delta, long n, thallo_sum_t alphaN_prev,
+                                 const float* alphaD_partials, const double* s3_partials, const double* q3_partials, int count, float* alphaD_word, float* betaN_word,
+                                 float* lm_state, int k_prev, float q_tolerance, int q_in, int q_out, thallo_stream_t stream)
+{
+    if (!r || !Ap || !pre || !p_in || !p_out || !delta || !alphaN_prev.partials || !alphaD_partials || !s3_partials || !q3_partials || count < 1 || count > THALLO_MAX_PARTIALS ||
+        !alphaD_word || !betaN_word || !lm_state || k_prev < 0 || q_in < 0 || q_in > 7 || q_out < 0 || q_out > 7 || q_in == q_out) return -(int)hipErrorInvalidValue;
+    const long n4 = (n + 3) / 4; const int grid = flat_grid(n4, cu_count());
+    hipLaunchKernelGGL(k_pcg_update_lm_fin, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, (float4*)r, (const float4*)Ap, (const float4*)pre, (const float4*)p_in, (float4*)p_out, (float4*)delta, n4,
+                       alphaN_prev, alphaD_partials, s3_partials, q3_partials, count, alphaD_word, betaN_word, lm_state, k_prev, q_tolerance, q_in, q_out);
     return check_launch();
 }
 

@@ -48,6 +48,9 @@ struct LaunchCtx {
     // LM loop only: when set, an applyJTJ of a plugin with apply_adds_ctc() returns (J^T J + CtC) p and the partials of p . that -- PCGStep1_Finish
     // (gauss_newton.t:774-787) folded into the apply, one launch less per PCG iteration
     const float* lm_ctc = nullptr;
+    float *lm_defer_aD_word = nullptr, *lm_defer_bN_word = nullptr;      // pcg_iter_lm (plugins with lm_iter_defers_finish()): non-NULL = `aD` holds the PARTIALS of iteration k-1, which
+                                        // this iteration's first launch finishes (words, zeta test) before it updates
+    int lm_q_in = 0, lm_q_out = 0;      // ... and the words of the LM state the iteration's own finish (fin.tickets set) reads Q0 from / leaves Q1 in
     float* lm_reset_bn_word = nullptr;  // pcg_iter_lm: non-NULL = the iteration behind a residual reset (delta and r are already this iteration's, betaN_{k-1} arrives as
                                         // partials and is left here as a word; plugins with lm_iter_after_reset())
 };
@@ -118,6 +121,7 @@ public:
     // {U, T1, T2} of q's expansion in alpha; the launch's last workgroup finishes alphaD_k, betaN_k, q_{k+1} and the zeta test (thallo_hip_sfs_pcg_iter_lm).
     // r, Ap and p ping-pong as in pcg_iter; SolverVectors::CtC, b, s12b are read / written.
     virtual bool lm_one_kernel() const { return false; }
+    virtual bool lm_iter_defers_finish() const { return false; }    // pcg_iter_lm honours LaunchCtx::lm_defer_* / lm_q_* and fin.tickets == NULL (partials only)
     virtual bool lm_iter_after_reset() const { return false; }      // pcg_iter_lm honours LaunchCtx::lm_reset_bn_word and lm_reset_residual exists: the one-reduction LM loop may run past residual_reset_period
     // r = b - (J^T J + CtC) delta (v.CtC, v.b), partials of r . M^-1 r (v.pre) to betaN_out; returns their number
     virtual int lm_reset_residual(LaunchCtx&, SolverVectors&, float* /*betaN_out*/) { return -1; }

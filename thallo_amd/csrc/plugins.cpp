@@ -814,6 +814,7 @@ public:
     // and applies the zeta test (three launches per iteration instead of four)
     bool lm_one_kernel() const override { return true; }
     bool lm_iter_after_reset() const override { return true; }
+    bool lm_iter_defers_finish() const override { return true; }
     int lm_reset_residual(LaunchCtx& c, SolverVectors& v, float* bN_out) override
     {
         TimedLaunch t(c, "PCGStep2");
@@ -824,10 +825,16 @@ public:
                     float q_tol) override
     {
         { TimedLaunch t(c, "PCGUpdate");
-          int rc = thallo_hip_pcg_update_lm(v.r, v.Ap, v.pre, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : c.lm_reset_bn_word ? 2 : 0, aN, aD, bN, c.lm_reset_bn_word, lm_state, c.stream); if (rc < 0) return rc; }
+          int rc;
+          if (c.lm_defer_aD_word)      // the finish of iteration k - 1 rides in this launch (aD: its partials)
+              rc = thallo_hip_pcg_update_lm_fin(v.r, v.Ap, v.pre, v.p[cur], v.p[cur ^ 1], v.delta, v.n, aN, aD.partials, v.s12, v.s12b, aD.count, c.lm_defer_aD_word, c.lm_defer_bN_word,
+                                                lm_state, k - 1, q_tol, ((k - 1) & 1) ? 6 : 0, (k & 1) ? 6 : 0, c.stream);
+          else rc = thallo_hip_pcg_update_lm(v.r, v.Ap, v.pre, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : c.lm_reset_bn_word ? 2 : 0, aN, aD, bN, c.lm_reset_bn_word, lm_state, c.stream);
+          if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
         return thallo_hip_ba_pcg_apply_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, points,
-                                          (const float*)JP.ptr, (float*)JpP.ptr, v.p[cur ^ 1], v.CtC, v.Ap, out, v.r, v.pre, v.delta, v.b, v.s12, v.s12b, fin, lm_state, k, q_tol, c.stream);
+                                          (const float*)JP.ptr, (float*)JpP.ptr, v.p[cur ^ 1], v.CtC, v.Ap, out, v.r, v.pre, v.delta, v.b, v.s12, v.s12b, fin, lm_state, k, q_tol,
+                                          c.lm_q_in, c.lm_q_out, c.stream);
     }
     bool apply_returns_sums() const override { return true; }
     int apply_jtj_sums(LaunchCtx& c, SolverVectors& v, const float* p, float* Ap, float* out, const thallo_fin_t& fin) override

@@ -194,7 +194,8 @@ const char* env_switch(const char* name)
         "THALLO_RESIDENT",            // 0: image_warping runs one launch per PCG iteration even where the whole PCG loop fits one resident launch
         "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up); 3: the marching kernel with the stored A p plane (round 2/3); 4 = 2 + 3
         "THALLO_ONE_KERNEL",          // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
-        "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch
+        "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch; 1: by the last workgroup of the iteration's kernel everywhere; unset: that, except in the
+                                      //    single-reduction GN loop of the gather plugins, where the finish of iteration k-1 is folded into the flat update of iteration k
         "THALLO_BATCH_DELTA",         // 0: delta += alpha p every iteration instead of every other one
         "THALLO_LM_FOLD_P",           // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own even where the plugin's marching kernel can carry them
         "THALLO_SFS_FUSED",           // 0: shape_from_shading's two-pass applyJTJ (round 1)
@@ -215,6 +216,7 @@ void Plan::read_ab_switches()
     auto off = [](const char* name) { const char* e = env_switch(name); return e && e[0] == '0'; };
     one_kernel_    = !off("THALLO_ONE_KERNEL");
     fin_in_kernel_ = !off("THALLO_FIN_IN_KERNEL");
+    { const char* e = env_switch("THALLO_FIN_IN_KERNEL"); fin_deferred_ = !(e && e[0]); }      // unset: deferred where the loop offers it (step_gn_expanded); 1: the in-kernel finish everywhere
     batch_delta_   = !off("THALLO_BATCH_DELTA");
     lm_fold_p_     = !off("THALLO_LM_FOLD_P");
 }
@@ -545,20 +547,28 @@ int Plan::step_gn_expanded(int ev_iter)
     set_nb(B, nb); finish(B);
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
+    // THALLO_FIN_IN_KERNEL unset: the finish of iteration k-1 -- alphaD, betaN from the applyJTJ launch's partials -- is folded into the flat update of iteration k
+    // (thallo_hip_pcg_update_fin: every workgroup adds the partials up for itself, the same bits), so the applyJTJ launch has no tail; one one-wave launch finishes the last iteration
+    const bool defer = fin_in_kernel_ && fin_deferred_;
+    int nb_prev = 0;
     for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         {   // r -= alpha_{k-1} Ap ; p_k = M^-1 r + beta_{k-1} p_{k-1} ; delta += alpha_{k-1} p_{k-1}      (k = 0: p_0 = M^-1 r_0)
             TimedLaunch t(ctx, "PCGUpdate");
-            if (thallo_hip_pcg_update(v_.r, v_.Ap, plugin->use_preconditioner() ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
-                                      sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s) < 0) { set_error("PCGUpdate launch failed"); return 0; }
+            int rc;
+            if (defer && k > 0) rc = thallo_hip_pcg_update_fin(v_.r, v_.Ap, plugin->use_preconditioner() ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, sum(jN - 2),
+                                                               slot(jD - 2), v_.s12, nb_prev, scal(jD - 2), scal(jN), s);
+            else rc = thallo_hip_pcg_update(v_.r, v_.Ap, plugin->use_preconditioner() ? v_.pre : nullptr, v_.p[cur_], v_.p[cur_ ^ 1], v_.delta, v_.n, k == 0,
+                                            sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN), s);
+            if (rc < 0) { set_error("PCGUpdate launch failed"); return 0; }
         }
         cur_ ^= 1;
-        // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the applyJTJ kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
-        const thallo_fin_t fin = { sum(jN), fin_in_kernel_ ? v_.fin_tickets : nullptr, scal(jD), scal(jB) };
+        // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the next flat update (default), by the applyJTJ kernel's last workgroup (THALLO_FIN_IN_KERNEL=1), or a one-wave launch (=0)
+        const thallo_fin_t fin = { sum(jN), fin_in_kernel_ && !defer ? v_.fin_tickets : nullptr, scal(jD), scal(jB) };
         nb = plugin->apply_jtj_sums(ctx, v_, v_.p[cur_], v_.Ap, slot(jD), fin);
         if (nb < 0) { set_error("PCGStep1 launch failed (%d)", nb); return 0; }
-        set_nb(jD, nb);
-        if (!fin_in_kernel_) {
+        set_nb(jD, nb); nb_prev = nb;
+        if (!fin_in_kernel_ || (defer && k == L - 1)) {
             TimedLaunch t(ctx, "PCGScalars");
             if (thallo_hip_pcg_scalars_finish(slot(jD), v_.s12, nb, sum(jN), scal(jD), scal(jB), s) < 0) { set_error("PCGScalars launch failed"); return 0; }
         }
@@ -705,16 +715,29 @@ int Plan::step_lm(int ev_iter)
             if (!failed) fin_[B] = 1;
         }
         bool after_reset = false; int reset_nb = 0;
+        // THALLO_FIN_IN_KERNEL unset and the plugin's iteration is several launches (lm_iter_defers_finish: bundle adjustment): the applyJTJ launches of iteration k leave partials
+        // only and the flat update of iteration k + 1 finishes them -- words, q, the zeta test -- in every workgroup (thallo_hip_pcg_update_lm_fin); iterations that a residual
+        // reset follows (the reset needs alpha_k first) and the last one finish in their own launch.  Q0 / Q1 alternate between words 0 and 6 of the state by parity.
+        const bool defer = fin_deferred_ && plugin->lm_iter_defers_finish();
+        auto own_finish = [&](int k) { return !defer || k == L - 1 || (((k + 1) % period) == 0 && k + 1 < L); };
+        int nb_prev = 0;
         for (int k = 0; k < L && !failed; ++k) {
             const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-            const thallo_fin_t fin = { sum(jN), v_.fin_tickets, scal(jD), scal(jB) };
+            const thallo_fin_t fin = { sum(jN), own_finish(k) ? v_.fin_tickets : nullptr, scal(jD), scal(jB) };
+            const bool finish_prev = defer && k > 0 && !own_finish(k - 1);
+            const thallo_sum_t aD_prev_partials = { slot(k ? jD - 2 : jD), nb_prev };
+            ctx.lm_defer_aD_word = finish_prev ? scal(jD - 2) : nullptr; ctx.lm_defer_bN_word = finish_prev ? scal(jN) : nullptr;
+            ctx.lm_q_in = defer ? ((k & 1) ? 6 : 0) : 0; ctx.lm_q_out = defer ? ((k & 1) ? 0 : 6) : 0;
             // behind a reset the iteration's first launch gets betaN_{k-1} as the reset's PARTIALS and replaces the word (the expansion's value) by their sum; everything
             // later -- this iteration's finish, the next one's alpha, the owed update of delta, alpha_beta_trace -- reads the word, which is valid either way (a loop that the
             // zeta test ended AT the reset iteration never ran the reset: its word is the expansion's)
             const thallo_sum_t bn_partials = { slot(jN), reset_nb };
             ctx.lm_reset_bn_word = after_reset ? scal(jN) : nullptr;
-            nb = plugin->pcg_iter_lm(ctx, v_, cur_, k == 0, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), after_reset ? bn_partials : sum(jN), slot(jD), fin, lmst, k, sp.q_tolerance);
+            nb = plugin->pcg_iter_lm(ctx, v_, cur_, k == 0, sum(k ? jN - 2 : jN), finish_prev ? aD_prev_partials : sum(k ? jD - 2 : jD), after_reset ? bn_partials : sum(jN), slot(jD), fin,
+                                     lmst, k, sp.q_tolerance);
             ctx.lm_reset_bn_word = nullptr; after_reset = false;
+            ctx.lm_defer_aD_word = ctx.lm_defer_bN_word = nullptr; ctx.lm_q_in = ctx.lm_q_out = 0;
+            nb_prev = nb;
             check(nb, "PCGIteration (LM) launch");
             if (failed) break;
             set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;

@@ -150,6 +150,7 @@ private:
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
     bool fin_in_kernel_ = true, one_kernel_ = true, batch_delta_ = true, lm_fold_p_ = true;   // A/B switches: read_ab_switches()
+    bool fin_deferred_ = true;      // THALLO_FIN_IN_KERNEL unset: the single-reduction GN loop finishes iteration k-1 inside the flat update of iteration k (=1: by the applyJTJ launch's last workgroup; =0: a one-wave launch)
     void read_ab_switches();
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }
     thallo_sum_t partial_sum(int j) { thallo_sum_t s; s.partials = slot(j); s.count = nb_[j]; return s; }

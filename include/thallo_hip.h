@@ -542,6 +542,12 @@ int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg,
 int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
                             thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* alphaD_out, double* s3_out, thallo_fin_t fin, thallo_stream_t stream);
+/* ... with the finish of iteration k-1 deferred into the launch of iteration k (round 4; thallo_prev_t above): every workgroup adds iteration k-1's partials up for itself at its
+ * start (the same order, the same bits), workgroup 0 leaves the two words; the launch writes partials only (s3_out != prev.s12_partials); thallo_hip_pcg_scalars_finish behind the
+ * loop finishes the last iteration.  The launch loses the tail of the in-kernel finish (write-through slots, tickets, the last workgroup's read-back). */
+int thallo_hip_sfs_pcg_iter_deferred(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                     const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
+                                     thallo_sum_t alphaN_prev, thallo_prev_t prev, float* alphaD_out, double* s3_out, thallo_stream_t stream);
 /* Round 3 -- LM on one GPU: ONE launch per PCG iteration.  As thallo_hip_sfs_pcg_iter with A = J^T J + CtC, the LM preconditioner (z = pre r: thallo_hip_lm_finalize_diagonal's M^-1), the scalars divided blindly (gauss_newton.t:226-234), and
  * besides alphaD / {N, S1, S2} the three sums of q's expansion in alpha: q_{k+1} = 0.5 [U + alpha (T1 - T2) - alpha^2 alphaD], U = delta_k.(r_k + b), T1 = p_k.(r_k + b),
  * T2 = delta_k.(A p_k) (q3_out: 3 * THALLO_HIP_MAX_PARTIALS doubles; the reference forms q after the update, :801-843, 965).  The launch's last workgroup (fin.tickets is

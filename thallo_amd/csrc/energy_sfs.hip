@@ -408,7 +408,10 @@ struct MsPupd { const float* p_in; float* p_out; thallo_sum_t aN, bN; int first;
 // r_k = r_{k-1} - alpha_{k-1} Ap_{k-1} and p_k = r_k + beta_{k-1} p_{k-1} (no preconditioner in this energy; halo rows and lanes redundantly), stores r_k, p_k
 // and delta += alpha_{k-1} p_{k-1} for its own rows, applies J^T J to p_k, and the three sums take r_k from registers.  r, Ap and p ping-pong
 // (the neighbours' halo rows re-read the previous iteration's planes while the owner writes this iteration's).
-struct MsUpd { float* r_out; const float* A_in; const float* p_in; float* p_out; float* delta; thallo_sum_t aN, aD, bN; int first; int lm; const float* b; const float* pre; };
+struct MsUpd { float* r_out; const float* A_in; const float* p_in; float* p_out; float* delta; thallo_sum_t aN, aD, bN; int first; int lm; const float* b; const float* pre;
+               // the finish of iteration k-1 DEFERRED into this launch (thallo_hip_sfs_pcg_iter_deferred): prev_nb > 0 -- aD.partials are that iteration's alphaD partials,
+               // prev_s3 its {N, S1, S2} partials (another buffer than this launch writes); every workgroup adds them up for itself, workgroup 0 leaves the two words
+               const double* prev_s3 = nullptr; int prev_nb = 0; float* aD_word = nullptr; float* bN_word = nullptr; };
 // LMQ (with UPD, SUMS, CTC; LM on one GPU): the whole LM iteration in this launch -- the vector update of PCGStep2 (iteration k-1's scalars), PCGStep3, (J^T J + CtC) p_k,
 // with the LM preconditioner M^-1 (`pre`: z = M^-1 r, one more plane per row taken), and besides alphaD and {N, S1, S2} the three sums {U, T1, T2} of q's expansion in alpha (device_common.hpp SumsQ: delta_k, r_k, p_k, A p_k are in registers, b is
 // one more plane read at the output row); the last workgroup finishes alphaD_k, betaN_k, q_{k+1} and the zeta test (block_finish_sums_lm).
@@ -426,6 +429,17 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
     float beta = 0.0f;
     if (PUPD && !pu.first) beta = safe_div<true>(sum_partials(pu.bN.partials, pu.bN.count), sum_partials(pu.aN.partials, pu.aN.count));      // as k_pupdate (LM)
     float alpha = 0.0f;
+    if (UPD && !LMQ && !up.first && up.prev_nb > 0) {                                  // the deferred finish: last_workgroup_totals' order, block_finish_sums' arithmetic -- the same bits
+        float ad, an; double t3[3];
+        last_workgroup_totals<3, true>(up.aD.partials, up.prev_s3, nullptr, up.prev_nb, up.aN, red, redd, ad, an, t3);
+        alpha = safe_div<false>(an, ad);
+        double bnd = t3[0] - 2.0 * (double)alpha * t3[1] + (double)alpha * (double)alpha * t3[2];
+        if (!(bnd > 0.0)) bnd = 0.0;
+        const float bnf = (float)bnd;
+        beta = safe_div<false>(bnf, an);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { up.aD_word[0] = ad; up.bN_word[0] = bnf; }
+        lds_barrier();                                                                  // (red / redd are the end-of-launch reduction's too)
+    } else
     if (UPD && !up.first) {                                                                                                                      // as k_pcg_update
         const float an = sum_partials(up.aN.partials, up.aN.count);
         const float ad = sum_partials(up.aD.partials, up.aD.count), bn = sum_partials(up.bN.partials, up.bN.count);
@@ -990,6 +1004,27 @@ int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, 
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
     const MsUpd up = { r_out, first ? r_in : Ap_in, p_in, p_out, delta, alphaN_prev, alphaD_prev, betaN_prev, first ? 1 : 0, 0, nullptr, nullptr };     // (first: Ap_in is not used; any readable plane)
     const FinArgs fa{ fin.alphaN, fin.tickets, fin.alphaD_word, fin.betaN_word, 0, gridm };
+    hipLaunchKernelGGL((k_march<true, false, false, false, MS_OCC, false, true>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cam_of(host_params), r_in, (const float*)nullptr,
+                       (const float4*)G, (const float2*)Wt, fl, Ap_out, aD_out, (const float*)nullptr, s3_out, (const unsigned*)nullptr, fa,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, MsPupd{}, up);
+    int e = check_launch(); return e ? e : gridm;
+}
+
+int thallo_hip_sfs_pcg_iter_deferred(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                     const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
+                                     thallo_sum_t alphaN_prev, thallo_prev_t prev, float* aD_out, double* s3_out, thallo_stream_t stream)
+{
+    if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !delta || !aD_out || !s3_out) return -(int)hipErrorInvalidValue;
+    if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !prev.alphaD_partials || !prev.s12_partials || prev.s12_partials == s3_out || prev.count < 1 ||
+                   prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_word || !prev.betaN_word)) return -(int)hipErrorInvalidValue;
+    if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
+    const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
+    const int gridm = (mg.total + 7) / 8 * 8;
+    if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
+    MsUpd up = { r_out, first ? r_in : Ap_in, p_in, p_out, delta, alphaN_prev, thallo_sum_t{ first ? alphaN_prev.partials : prev.alphaD_partials, first ? 1 : prev.count }, alphaN_prev,
+                 first ? 1 : 0, 0, nullptr, nullptr };
+    if (!first) { up.prev_s3 = prev.s12_partials; up.prev_nb = prev.count; up.aD_word = prev.alphaD_word; up.bN_word = prev.betaN_word; }
+    const FinArgs fa{ alphaN_prev, nullptr, nullptr, nullptr, 0, gridm };          // partials only: the next launch (or thallo_hip_pcg_scalars_finish behind the loop) finishes
     hipLaunchKernelGGL((k_march<true, false, false, false, MS_OCC, false, true>), dim3(gridm), dim3(MS_NT), 0, (hipStream_t)stream, mg, cam_of(host_params), r_in, (const float*)nullptr,
                        (const float4*)G, (const float2*)Wt, fl, Ap_out, aD_out, (const float*)nullptr, s3_out, (const unsigned*)nullptr, fa,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, MsPupd{}, up);

@@ -959,6 +959,20 @@ public:
         return thallo_hip_sfs_pcg_iter(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
                                        v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode & 1, aN, aD, bN, out, v.s12, fin, c.stream);
     }
+    // the finish of iteration k-1 inside the launch of iteration k (one GPU; THALLO_FIN_IN_KERNEL=1: the launch's own last workgroup finishes, A/B)
+    bool iter_defers_finish() const override { const char* e = env_switch("THALLO_FIN_IN_KERNEL"); return one_kernel_iteration() && !(e && e[0]); }
+    int pcg_iter_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t, thallo_sum_t, const thallo_prev_t& prev, float* out, double* s12_out) override
+    {
+        if (mode & ~1) return -1;
+        TimedLaunch t(c, "PCGIteration");
+        return thallo_hip_sfs_pcg_iter_deferred(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
+                                                v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode & 1, aN, prev, out, s12_out, c.stream);
+    }
+    int pcg_iter_finish_from(LaunchCtx& c, const float* part, const double* s12p, int count, thallo_sum_t aN, float* aD_word, float* bN_word) override
+    {
+        TimedLaunch t(c, "PCGScalars");
+        return thallo_hip_pcg_scalars_finish(part, s12p, count, aN, aD_word, bN_word, c.stream);
+    }
     bool one_kernel_slab() const override { return thallo_hip_sfs_march_fits(W) != 0; }
     bool lm_one_kernel() const override { return one_kernel_iteration(); }
     bool lm_one_kernel_slab() const override { return thallo_hip_sfs_march_fits(W) != 0; }

@@ -373,19 +373,41 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
         const float e_p = p[ie], e_c = ctc ? ctc[ie] : 0.f, e_r = s3_out ? rs[ie] : 0.f, e_m = s3_out ? prs[ie] : rst.r ? rst.pre[ie] : 0.f,
                     e_d = lm.b ? delta[ie] : 0.f, e_b = lm.b ? lm.b[ie] : rst.r ? rst.b[ie] : 0.f;
         const CamPre cp = ba_cam_pre(cams + 9L * c);              // (every lane for itself: ~200 flops per camera, against ~6 observations per lane)
-        for (int q = cam_ptr[c] + lane; q < cam_ptr[c + 1]; q += 64) {
-            const long pi = q_pt[q];
-            const float* X = pts + 3L * pi;
-            const Blk b = ba_block(cp, X[0], X[1], X[2]);            // the observation's block, rebuilt (it was a 96-byte load)
-            const float* pp = p + PB + 3L * pi;
-            const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
-            float j0 = b.a[9] * p0 + b.a[10] * p1 + b.a[11] * p2, j1 = b.a[21] * p0 + b.a[22] * p1 + b.a[23] * p2;      // same order as k_gather<1>
+        // TWO observations per trip: both index loads, then both gathers, are in flight before the first block is rebuilt, and the two blocks' arithmetic is independent -- at
+        // 1.7 waves per SIMD a wave is mostly alone and issues a DEPENDENT instruction every ~5 cycles (profiles/r04/issue_rates_pk_rate.txt).  Added into s in the list's order.
+        // Measured in one process per box, GN per PCG iteration: 1 / 2 / 3 / 4 per trip = 33.2 / 31.9 / 32.5 / 32.9 us (BA_CAM_OBS to rebuild with another count).
+#ifndef BA_CAM_OBS
+#define BA_CAM_OBS 2
+#endif
+        constexpr int NO = BA_CAM_OBS;
+        const int q1e = cam_ptr[c + 1];
+        for (int q = cam_ptr[c] + lane; q < q1e; q += 64 * NO) {
+            long pi[NO]; float x[NO][3], pp[NO][3]; bool h[NO];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { j0 += b.a[k] * pc[k]; j1 += b.a[12 + k] * pc[k]; }
-            JpC[q] = make_float2(j0, j1);
+            for (int u = 0; u < NO; ++u) { h[u] = q + 64 * u < q1e; pi[u] = q_pt[h[u] ? q + 64 * u : q]; }
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s[k] += b.a[k] * j0 + b.a[12 + k] * j1;
+            for (int u = 0; u < NO; ++u) { const float* X = pts + 3L * pi[u]; const float* P3 = p + PB + 3L * pi[u]; x[u][0] = X[0]; x[u][1] = X[1]; x[u][2] = X[2]; pp[u][0] = P3[0]; pp[u][1] = P3[1]; pp[u][2] = P3[2]; }
+            Blk b[NO]; float j0[NO], j1[NO];
+#pragma unroll
+            for (int u = 0; u < NO; ++u) b[u] = ba_block(cp, x[u][0], x[u][1], x[u][2]);
+#pragma unroll
+            for (int u = 0; u < NO; ++u) {
+                j0[u] = b[u].a[9] * pp[u][0] + b[u].a[10] * pp[u][1] + b[u].a[11] * pp[u][2]; j1[u] = b[u].a[21] * pp[u][0] + b[u].a[22] * pp[u][1] + b[u].a[23] * pp[u][2];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                for (int u = 0; u < NO; ++u) { j0[u] += b[u].a[k] * pc[k]; j1[u] += b[u].a[12 + k] * pc[k]; }
+            }
+#pragma unroll
+            for (int u = 0; u < NO; ++u) if (h[u]) JpC[q + 64 * u] = make_float2(j0[u], j1[u]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                for (int u = 0; u < NO; ++u) if (h[u]) s[k] += b[u].a[k] * j0[u] + b[u].a[12 + k] * j1[u];
+            }
         }
+
 #pragma unroll
         for (int k = 0; k < 9; ++k) s[k] = wave_sum_all(s[k]);
         if (lane < 9) {

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
                                                 const unsigned* __restrict__ gate, const float* __restrict__ ctc, const float* __restrict__ delta, LmFin lm, ResetArgs rst)
 {   // lm.b: the launch of a one-reduction LM iteration (thallo_hip_ba_pcg_apply_lm) -- also {U, T1, T2} of q's expansion in alpha (device_common.hpp SumsQ) per workgroup
     __shared__ float red[16];
-    __shared__ double redd[3 * BLOCK / 64];
+    __shared__ double redd[6 * BLOCK / 64];
     if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)gate[0]) != 0) return;
     float acc = 0.0f; Sums3 sm; SumsQ sq;
     const long PB = 9L * C_;
@@ -425,13 +425,11 @@ __global__ __launch_bounds__(BLOCK) void k_cam2(int C_, const int* __restrict__ 
             }
         }
     }
-    block_store_partial(acc, part_out, red);
-    if (s3_out) block_store_sums3(sm, s3_out, redd);
-    if (lm.b) {
-        Sums3 t; t.n = sq.u; t.s1 = sq.t1; t.s2 = sq.t2;
-        lds_barrier();                                     // (redd is still being read by thread 0)
-        block_store_sums3(t, lm.q3_out, redd);
-    }
+    // one pass for the float partial and the three / six double sums (one barrier; the same additions in the same order as one block_store_* call per quantity group)
+    const FinArgs nf{ thallo_sum_t{ nullptr, 0 }, nullptr, nullptr, nullptr, 0, 0 };
+    if (lm.b) block_finish_sums_lm(acc, sm, sq, part_out, s3_out, nf, lm, red, redd);
+    else if (s3_out) block_finish_sums(acc, sm, part_out, s3_out, nf, red, redd);
+    else block_store_partial(acc, part_out, red);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __restrict__ pt_ptr, const int* __restrict__ pt_pos, const float2* __restrict__ JP, const float2* __restrict__ JpC,

@@ -38,9 +38,13 @@ ALG_BYTES_PCG_ITER = 180        # applyJTJ 48 + PCGStep2 96 + PCGS
 FUSED_BYTES_PCG_ITER_STORED = 99
 
 
-def fused_bytes_per_iter(L):
+def fused_bytes_per_iter(L, ring=False):
     from thallo_amd.api import iw_fused_bytes_per_iter
-    return iw_fused_bytes_per_iter(L)
+    return iw_fused_bytes_per_iter(L, ring=ring)
+
+
+FUSED_BYTES_STEP1 = 75          # two-kernel schedule (THALLO_ONE_KERNEL=0, A/B): PCGStep1 = read z 12, p 12, cs 8, flags 1; write p 12, Ap 12 + the delta update every other launch 18
+ROOFLINE_STEPS = 3              # GN steps AFTER the timed region, with HIP events around every 4th launch of the dominant kernel on its own stream
 
 
 def parse():
@@ -184,7 +188,7 @@ def main():
     if "THALLO_THREADS" in os.environ: _L.thallo_hip_debug_set(6, int(os.environ["THALLO_THREADS"]))
     dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
     s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
-    s.set_solver_parameters(nIterations=K + Wm, lIterations=L_it)
+    s.set_solver_parameters(nIterations=K + Wm + ROOFLINE_STEPS, lIterations=L_it)
     params = s.make_params(dev)
     s.init(params)
     for _ in range(Wm):
@@ -193,9 +197,8 @@ def main():
     # one kernel per PCG iteration (thallo_hip_iw_pcg_iter, the default) vs PCGStep1 + PCGStep2 (THALLO_ONE_KERNEL=0, A/B)
     one_kernel = os.environ.get("THALLO_ONE_KERNEL", "1") != "0"
     s.reset_kernel_stats()
-    # one-kernel schedule: the PCG loop of a GN step is L launches of ONE kernel and nothing else, so the library's HIP-event pair
-    # around the loop ("Linear Solve", recorded on the launch stream every step) / L is that kernel's average launch duration,
-    # without per-launch events perturbing the timed region.  Two-kernel schedule: events around every 16th launch of each kernel.
+    # the timed region runs without per-launch events; the dominant kernel's own launch duration is sampled in ROOFLINE_STEPS extra steps behind it (round 5: the
+    # PCG loop of a GN step is no longer L launches of one kernel and nothing else -- the delta updates of the ring of p planes run next to it on a second stream)
     s.set_kernel_sampling(0 if one_kernel else (args.sample_period or 16))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -206,15 +209,24 @@ def main():
     s.set_kernel_sampling(0)
     ks = s.kernel_stats()
     final_cost = s.current_cost()
+    ring = "PCGDeltaUpdate" in ks
+    if one_kernel:
+        s.reset_kernel_stats()
+        s.set_kernel_sampling(4)
+        for _ in range(ROOFLINE_STEPS):
+            assert s.step(params) == 1
+        torch.cuda.synchronize()
+        s.set_kernel_sampling(0)
+        ks = s.kernel_stats()
     assert s.step(params) == 0                 # budget used up: finalises the plan and its performance summary
     perf = s.performance_summary()
 
     npx = W * H
     dom = "PCGIteration" if one_kernel else "PCGStep1"
-    dom_bytes = fused_bytes_per_iter(L_it) if one_kernel else FUSED_BYTES_STEP1          # what the kernel has to move (= its PMC traffic)
+    dom_bytes = fused_bytes_per_iter(L_it, ring) if one_kernel else FUSED_BYTES_STEP1          # what the kernel has to move (= its PMC traffic)
     ref_bytes = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1        # the reference formulation of the same work
-    step1_ms = perf["linearSolve"]["meanMS"] / L_it if one_kernel else ks[dom]["mean_ms"]
-    n_samples = perf["linearSolve"]["count"] * L_it if one_kernel else ks[dom]["samples"]
+    step1_ms = ks[dom]["mean_ms"]
+    n_samples = ks[dom]["samples"]
     ach = dom_bytes * npx / (step1_ms * 1e-3) / 1e9
     sa_ms = standalone_applyjtj(torch, W, H, p)
     sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9
@@ -238,17 +250,23 @@ def main():
         "ms_per_gn_iter": dt / K * 1e3, "us_per_pcg_iter": dt / (K * L_it) * 1e6,
         "final_cost": final_cost,
         "roofline": {"bound": "hbm",
-                     "kernel": ("PCGIteration (one launch = PCGStep2 of iteration k-1 + PCGStep3 + delta update + applyJTJ of iteration k)"
+                     "kernel": ("PCGIteration (one launch = PCGStep2 of iteration k-1 + PCGStep3 + applyJTJ of iteration k; p_k into a ring of planes)" if one_kernel and ring
+                                else "PCGIteration (one launch = PCGStep2 of iteration k-1 + PCGStep3 + delta update + applyJTJ of iteration k)"
                                 if one_kernel else "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)"),
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_pixel": dom_bytes, "pixels_per_launch": npx,
                      "avg_launch_ms": step1_ms, "samples": n_samples,
-                     "timing": ("HIP events around the PCG loop of every GN step (L launches of this one kernel) / L" if one_kernel
+                     "timing": (f"HIP events on the kernel's stream around every 4th launch of it, in {ROOFLINE_STEPS} GN steps run behind the timed region" if one_kernel
                                 else "HIP events around every 16th launch of the kernel"),
+                     "pcg_loop_ms_per_iteration": perf["linearSolve"]["meanMS"] / L_it,
                      "note": "achieved = bytes_per_pixel x pixels / avg launch time: the bytes this fused kernel has to move, each array once "
-                             "(DESIGN.md section 4).  Round 4 removed the A p plane from the iteration (99 -> 74.8 B/pixel): frac is quoted on the NEW, "
-                             "smaller byte count, so a lower frac at a higher PCG rate than round 3's line is a faster kernel, not a slower one",
+                             "(DESIGN.md section 4).  Round 4 removed the A p plane from the iteration (99 -> 74.8 B/pixel); round 5 took the delta update out of "
+                             "it (-> 57.1 B/pixel: p_k goes into a ring of planes and delta takes 32 of them per PCGDeltaUpdate launch, 12.75 B/pixel/iteration "
+                             "next to the loop).  frac is quoted on the kernel's OWN, smaller byte count: a lower frac at a higher PCG rate is a faster "
+                             "schedule, not a slower kernel",
+                     "delta_update": ({"kernel": "PCGDeltaUpdate (thallo_hip_linear_update_n)", "launches_per_gn_step": ks["PCGDeltaUpdate"]["launches"] / ROOFLINE_STEPS,
+                                       "avg_launch_ms": ks["PCGDeltaUpdate"]["mean_ms"]} if ring and one_kernel and ks.get("PCGDeltaUpdate", {}).get("samples") else None),
                      # the same launch priced with SURVEY.md 8d's bytes of the reference's three-kernel formulation -- a speed-up figure, not a
                      # roofline fraction (it exceeds the HBM peak because the schedule removes 45 % of those bytes)
                      "reference_formulation": {"bytes_per_pixel": ref_bytes, "equivalent_GBps": ref_bytes * npx / (step1_ms * 1e-3) / 1e9},

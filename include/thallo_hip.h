@@ -195,6 +195,13 @@ int thallo_hip_range_unpack(float* vec, thallo_segs_t first_rank_pieces, const f
    deferred (THALLO_IW_STEP1_MODE batching with an even number of PCG iterations) */
 int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older, thallo_sum_t alphaN_older, thallo_sum_t alphaD_older,
                               const float* p, thallo_sum_t alphaN, thallo_sum_t alphaD, long len, thallo_stream_t stream);
+/* delta += alpha_0 p_0, then += alpha_1 p_1, ... (terms.count <= THALLO_HIP_MAX_UPDATE_TERMS pending terms, oldest first; every term one fma on the running
+   value, i.e. the bits of one `delta += alpha p` per PCG iteration in that order).  X == NULL: delta is updated in place (the ring of p planes of the
+   one-kernel schedule is full; the library launches it on a stream of its own next to the PCG loop, with max_workgroups keeping it to a share of the
+   chip).  X != NULL: the tail of a GN step (gauss_newton.t:901-906): X += the updated delta, delta itself is left as it was. */
+#define THALLO_HIP_MAX_UPDATE_TERMS 32
+typedef struct { const float* p[THALLO_HIP_MAX_UPDATE_TERMS]; thallo_sum_t alphaN[THALLO_HIP_MAX_UPDATE_TERMS], alphaD[THALLO_HIP_MAX_UPDATE_TERMS]; int count; } thallo_update_terms_t;
+int thallo_hip_linear_update_n(float* X, float* delta, thallo_update_terms_t terms, long len, int max_workgroups /* 0: as many as the flat kernels use */, thallo_stream_t stream);
 int thallo_hip_finish_sum(thallo_sum_t s, float* out, thallo_stream_t stream);
 /* ... behind a device-side gate word (non-zero: the launch does nothing; the LM loop's gate, see thallo_hip_lm_zeta) */
 int thallo_hip_finish_sum_gated(thallo_sum_t s, float* out, const unsigned* gate, thallo_stream_t stream);

@@ -226,7 +226,7 @@ def test_marching_iteration_without_the_ap_plane_is_bitwise_the_stored_plane_ker
     p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
     runs = []
     monkeypatch.setenv("THALLO_RESIDENT", "0")
-    monkeypatch.setenv("THALLO_BATCH_DELTA", batch)
+    monkeypatch.setenv("THALLO_DELTA_PLANES", batch)
     for form in ("2", "4"):
         monkeypatch.setenv("THALLO_MARCH", form)
         dev = to_device(copy_params(p))
@@ -427,19 +427,61 @@ def test_shim_image_warping_zfree_schedule(torch, W, H):
 @pytest.mark.parametrize("L", [1, 2, 3, 6, 7])
 def test_image_warping_deferred_delta_updates_are_bitwise_neutral(torch, monkeypatch, L, one_kernel):
     """Deferring every other `delta += alpha p` into the next fused launch (THALLO_IW_STEP1_MODE, -6 B/pixel/iteration) and finishing the
-    GN step with one or two pending terms gives the same bits as updating delta every iteration (THALLO_BATCH_DELTA=0) -- in the one-kernel
+    GN step with one or two pending terms gives the same bits as updating delta every iteration (THALLO_DELTA_PLANES=0) -- in the one-kernel
     schedule and in the PCGStep1 + PCGStep2 one."""
     W, H = 96, 64
     p = syn.image_warping(W, H, n_markers=6)
     monkeypatch.setenv("THALLO_ONE_KERNEL", one_kernel)
     res = []
     for batched in ("1", "0"):
-        monkeypatch.setenv("THALLO_BATCH_DELTA", batched)
+        monkeypatch.setenv("THALLO_DELTA_PLANES", batched)
         dev = to_device(copy_params(p))
         s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
         final, _ = s.solve(dev, nIterations=2, lIterations=L)
         res.append((dev[0].clone(), dev[1].clone(), final))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("W,H,lit,planes", [(1024, 768, 25, "3"), (1024, 768, 25, "7"), (1024, 768, 25, None), (256, 256, 40, "33"), (256, 256, 40, "2"), (256, 256, 70, None),
+                                            (130, 7, 12, "4"), (250, 2, 5, "5"), (2048, 2048, 12, "5"), (126, 130, 3, None), (1024, 768, 25, "-7"), (256, 256, 70, "-33")])
+def test_ring_of_p_planes_is_bitwise_a_delta_update_per_iteration(torch, monkeypatch, W, H, lit, planes):
+    """Round 5: the one-kernel GN loop of the marching kernels writes p_k into a RING of planes and leaves delta alone (every launch moves 57 B/pixel); delta takes
+    the pending alpha_j p_j -- oldest first, one fma each -- when the ring is full (thallo_hip_linear_update_n, "PCGDeltaUpdate") and the last ones inside
+    PCGLinearUpdate.  Same roundings in the same order as `delta += alpha p` once per iteration (THALLO_DELTA_PLANES=0): costs, alpha / beta and the unknowns are
+    BIT-identical after three GN steps -- rings of 2, 3 .. 33 planes and the automatic size, rings longer and shorter than the PCG loop, ragged and tiny images;
+    with the update next to the loop on the plan's second stream (default) and on the loop's own stream (negative plane counts)."""
+    p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
+    monkeypatch.setenv("THALLO_RESIDENT", "0")
+    monkeypatch.setenv("THALLO_MARCH", "2")
+    runs = []
+    for dp in ("0", planes):
+        if dp is None: monkeypatch.delenv("THALLO_DELTA_PLANES", raising=False)
+        else: monkeypatch.setenv("THALLO_DELTA_PLANES", dp)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=2)
+        s.set_solver_parameters(nIterations=3, lIterations=lit)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        names = s.kernel_stats()
+        s.close()
+        runs.append((costs, traces, dev[0].clone(), dev[1].clone(), names))
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == 4 and len(t0[0]) == lit
+    n = min(lit, 33 if planes is None else abs(int(planes)))
+    flushes = flushed = 0                # what the host loop does before launch k (terms up to k - 2 have their scalars by then) ...
+    for k in range(lit):
+        if planes is not None and int(planes) < 0:      # ... on the loop's own stream: when plane k mod n still holds a term that is not in delta, everything goes
+            if k >= n and flushed < k - n + 1: flushes += 1; flushed = k - 1
+        elif k - 1 - flushed >= max(1, (n - 1) // 2):    # ... next to the loop (default): half a ring at a time
+            flushes += 1; flushed = k - 1
+    assert n1.get("PCGDeltaUpdate", {}).get("launches", 0) == 3 * flushes and "PCGDeltaUpdate" not in n0, (n1, flushes)
+    assert n0["PCGIteration"]["launches"] == 3 * lit == n1["PCGIteration"]["launches"]
+    assert t0 == t1, [(i, k) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
 def test_image_warping_reference_cat512_instance(torch, orc, golden_dir):

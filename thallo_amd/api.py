@@ -374,16 +374,19 @@ class ThalloSolver:
         return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
 
 
-def iw_fused_bytes_per_iter(L, every_iteration_delta=False):
+def iw_fused_bytes_per_iter(L, every_iteration_delta=False, ring=False):
     """Bytes per pixel and PCG iteration the image_warping one-kernel schedule has to move, each array once, averaged over the L iterations of
     a GN step.  Round 4 (energy_image_warping_march_rc.hip, no A p plane): read r 12, p 12, cs 8, flags 1; write r 12, p 12 = 57, + the delta update the launch carries:
     none on odd iterations and two (read delta 12 + p_{k-2} 12, write delta 12 = 36) on even ones -- or, on the multi-GPU device-side transport, one (24) every
-    iteration; the FIRST iteration of a GN step runs the stored-plane kernel without its A p read: 69.  THALLO_MARCH=0 / 3 / 4 (tile kernel / stored-plane marching
+    iteration -- or (round 5, ring=True: one GPU, the default) none at all, the update being a launch of its own per ring of p planes; the FIRST iteration of a GN
+    step runs the stored-plane kernel without its A p read: 69.  THALLO_MARCH=0 / 3 / 4 (tile kernel / stored-plane marching
     kernel, the A/B forms): 99."""
     if os.environ.get("THALLO_MARCH", "1")[:1] in ("0", "3", "4"):
         return 99.0
     if L < 1:
         return 0.0
+    if ring:        # round 5: p_k goes into a ring of planes, no launch touches delta (thallo_hip_linear_update_n does, once per ring: not this kernel's bytes)
+        return (69.0 + 57.0 * (L - 1)) / L
     if every_iteration_delta:
         return (69.0 + 81.0 * (L - 1)) / L
     odd, even = L // 2, (L - 1) // 2          # k = 1, 3, ...: no delta update; k = 2, 4, ...: two

@@ -518,6 +518,51 @@ __global__ __launch_bounds__(BLOCK) void k_linear_update2(float* __restrict__ X,
     }
 }
 
+// delta += sum_j alpha_j p_j over up to THALLO_HIP_MAX_UPDATE_TERMS pending terms, oldest first, each as ONE explicit fma on the running value -- the roundings
+// of `delta += alpha p` applied once per iteration in that order (round 5: the one-kernel schedule keeps a RING of p planes and touches delta once per ring
+// instead of once per iteration or two).  X != NULL: the end of a GN step, X += (the updated delta) and delta itself is not written back.
+// V4: every pointer 16-byte aligned and len a multiple of 4 (solver vectors always; caller buffers usually).
+template <bool V4>
+__global__ __launch_bounds__(BLOCK) void k_linear_update_n(float* __restrict__ X, float* __restrict__ delta, thallo_update_terms_t T, long len)
+{
+    __shared__ float al[THALLO_HIP_MAX_UPDATE_TERMS];
+    for (int j = 0; j < T.count; ++j) {     // (wave-cooperative sums: every wave computes every alpha, in the order every other consumer uses)
+        const float a = safe_div<false>(sum_partials(T.alphaN[j].partials, T.alphaN[j].count), sum_partials(T.alphaD[j].partials, T.alphaD[j].count));
+        if (threadIdx.x == 0) al[j] = a;
+    }
+    __syncthreads();
+    if (V4) {
+        const long n4 = len >> 2;
+        for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+            float4 d = reinterpret_cast<const float4*>(delta)[i];
+            int j = 0;
+            for (; j + 4 <= T.count; j += 4) {      // four planes' loads in flight per lane (the terms are still applied one after the other)
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = ldf4(reinterpret_cast<const float4*>(T.p[j + u]) + i, true);      // read once, never again
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float a = al[j + u];
+                    d.x = __builtin_fmaf(a, q[u].x, d.x); d.y = __builtin_fmaf(a, q[u].y, d.y); d.z = __builtin_fmaf(a, q[u].z, d.z); d.w = __builtin_fmaf(a, q[u].w, d.w);
+                }
+            }
+            for (; j < T.count; ++j) {
+                const float4 q = ldf4(reinterpret_cast<const float4*>(T.p[j]) + i, true);
+                const float a = al[j];
+                d.x = __builtin_fmaf(a, q.x, d.x); d.y = __builtin_fmaf(a, q.y, d.y); d.z = __builtin_fmaf(a, q.z, d.z); d.w = __builtin_fmaf(a, q.w, d.w);
+            }
+            if (X) { float4 x = reinterpret_cast<const float4*>(X)[i]; x.x = x.x + d.x; x.y = x.y + d.y; x.z = x.z + d.z; x.w = x.w + d.w; reinterpret_cast<float4*>(X)[i] = x; }
+            else reinterpret_cast<float4*>(delta)[i] = d;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < len; i += (long)gridDim.x * BLOCK) {
+            float d = delta[i];
+            for (int j = 0; j < T.count; ++j) d = __builtin_fmaf(al[j], T.p[j][i], d);
+            if (X) X[i] = X[i] + d; else delta[i] = d;
+        }
+    }
+}
+
 // out[0] = sum(partials) (if any), out[1..] = the listed segments of `vec`, concatenated (slab boundary rows)
 __global__ __launch_bounds__(BLOCK) void k_slab_pack(const float* __restrict__ vec, thallo_segs_t segs, thallo_sum_t s, float* __restrict__ out)
 {
@@ -1022,6 +1067,23 @@ int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older
     if (!p_older || !p) return -(int)hipErrorInvalidValue;
     const int grid = flat_grid(len, cu_count());
     hipLaunchKernelGGL(k_linear_update2, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, X, delta, p_older, aN0, aD0, p, aN1, aD1, len);
+    int e = check_launch();
+    return e ? e : grid;
+}
+
+int thallo_hip_linear_update_n(float* X, float* delta, thallo_update_terms_t terms, long len, int max_workgroups, thallo_stream_t stream)
+{
+    if (!delta || len < 0 || terms.count < 0 || terms.count > THALLO_HIP_MAX_UPDATE_TERMS) return -(int)hipErrorInvalidValue;
+    bool v4 = !(len & 3) && !(((uintptr_t)X | (uintptr_t)delta) & 15);
+    for (int j = 0; j < terms.count; ++j) {
+        if (!terms.p[j] || !terms.alphaN[j].partials || !terms.alphaD[j].partials || terms.alphaN[j].count < 1 || terms.alphaD[j].count < 1) return -(int)hipErrorInvalidValue;
+        if ((uintptr_t)terms.p[j] & 15) v4 = false;
+    }
+    if (len == 0 || (terms.count == 0 && !X)) return 0;
+    int grid = flat_grid(v4 ? len >> 2 : len, 2 * cu_count());
+    if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;      // (a background update next to the PCG loop's launches: a share of the bandwidth, not all of it)
+    if (v4) hipLaunchKernelGGL(k_linear_update_n<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, X, delta, terms, len);
+    else    hipLaunchKernelGGL(k_linear_update_n<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, X, delta, terms, len);
     int e = check_launch();
     return e ? e : grid;
 }

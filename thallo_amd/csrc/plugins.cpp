@@ -280,6 +280,7 @@ public:
                                        v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, none, none, (const int*)irregular.ptr, v.r, out, c.stream);
     }
     bool batches_delta() const override { return true; }
+    bool takes_any_p_plane() const override { return march_ && row0_ == 0 && row1_ == H; }      // (the marching kernels; the mode-1 launch of a GN step's first iteration included)
     bool dist_batches_delta() const override { return march_rc_; }      // (the stored-plane marching kernel's multi-GPU variant has no such form: it would spill)
     bool one_kernel_iteration() const override { return true; }
     int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2, float* out,

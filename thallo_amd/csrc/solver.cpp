@@ -165,6 +165,8 @@ Plan::Plan(EnergyPlugin* pl, const Thallo_InitializationParameters& ip_, bool lm
 Plan::~Plan()
 {
     hipDeviceSynchronize();
+    for (hipEvent_t e : aux_events_) hipEventDestroy(e);
+    if (aux_) hipStreamDestroy(aux_);
     dist_release();
     if (rccl_) { rccl_comm_destroy(rccl_); rccl_ = nullptr; }
     for (auto b : bufs_) delete b;
@@ -196,7 +198,10 @@ const char* env_switch(const char* name)
         "THALLO_ONE_KERNEL",          // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
         "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch; 1: by the last workgroup of the iteration's kernel everywhere; unset: that, except in the
                                       //    single-reduction GN loop of the gather plugins, where the finish of iteration k-1 is folded into the flat update of iteration k
-        "THALLO_BATCH_DELTA",         // 0: delta += alpha p every iteration instead of every other one
+        "THALLO_DELTA_PLANES",        // how often the one-kernel GN loop touches delta.  0: delta += alpha p every iteration (the reference's order of work); 1: every other iteration
+                                      //    (round 4); N >= 2: a ring of N p planes, delta updated when the ring is full (where the plugin's kernel takes any p plane);
+                                      //    unset: the ring where offered, sized by lIterations and the device's free memory, else 1; -N: the ring of N planes with its
+                                      //    updates on the loop's own stream instead of next to it (A/B)
         "THALLO_LM_FOLD_P",           // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own even where the plugin's marching kernel can carry them
         "THALLO_SFS_FUSED",           // 0: shape_from_shading's two-pass applyJTJ (round 1)
         "THALLO_SFS_MARCH",           // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
@@ -217,7 +222,10 @@ void Plan::read_ab_switches()
     one_kernel_    = !off("THALLO_ONE_KERNEL");
     fin_in_kernel_ = !off("THALLO_FIN_IN_KERNEL");
     { const char* e = env_switch("THALLO_FIN_IN_KERNEL"); fin_deferred_ = !(e && e[0]); }      // unset: deferred where the loop offers it (step_gn_expanded); 1: the in-kernel finish everywhere
-    batch_delta_   = !off("THALLO_BATCH_DELTA");
+    { const char* e = env_switch("THALLO_DELTA_PLANES"); delta_planes_ = e && e[0] ? atoi(e) : -1; if (delta_planes_ > THALLO_HIP_MAX_UPDATE_TERMS + 1) delta_planes_ = THALLO_HIP_MAX_UPDATE_TERMS + 1;
+      if (delta_planes_ < -(THALLO_HIP_MAX_UPDATE_TERMS + 1)) delta_planes_ = -(THALLO_HIP_MAX_UPDATE_TERMS + 1);
+      const char* c = e ? strchr(e, ':') : nullptr; if (c && atoi(c + 1) > 0) aux_workgroups_ = atoi(c + 1); }      // ("N:W": the background update on at most W workgroups; tuning)
+    batch_delta_   = delta_planes_ != 0;
     lm_fold_p_     = !off("THALLO_LM_FOLD_P");
 }
 
@@ -468,40 +476,146 @@ int Plan::step_gn_one_kernel(int ev_iter)
     // itself -- alphaD_{k-1} and betaN_{k-1} = N - 2 alpha S1 + alpha^2 S2 -- while its first rows load, instead of iteration k-1's last workgroup
     // reading them back at the very end of its launch; one one-wave launch per GN step finishes the last iteration.
     const bool defer = plugin->iter_defers_finish();
+    // Round 5: a RING of p planes instead of the ping-pong pair.  Launch k writes p_k into plane k mod n and carries no delta update at all; delta is touched once
+    // per n - 1 iterations by thallo_hip_linear_update_n (every pending alpha_j p_j, oldest first, one fma each: the bits of an update per iteration) and the step's
+    // last terms ride in PCGLinearUpdate.  Per iteration and unknown 4 (12 + 24 / (n - 1)) / 12 bytes of delta traffic instead of 24 (every iteration) or 18 (every other).
+    const int n_ring = ring_planes(L);
+    const bool ring = n_ring >= 2;
+    const bool batched = !ring && batch_delta_ && delta_planes_ != 0 && plugin->batches_delta();      // THALLO_IW_STEP1_MODE(k, 1): every other delta update is deferred
+    // The update runs NEXT TO the loop, on a low-priority stream of the plan's own and on a share of the chip (round 5): a marching launch leaves the memory system
+    // idle while it ramps up and while its last waves finish; the update's loads fill those gaps.  A chunk of (n - 1) / 2 terms goes out as soon as their scalars are
+    // words; the launch that overwrites a chunk's first plane waits for it (an event), which by then is half a ring ago.  THALLO_DELTA_PLANES < 0: on the loop's
+    // own stream, whole rings at a time (A/B).
+    const bool async = ring && delta_planes_ >= -1 && aux_stream();
+    const int chunk = !ring ? 0 : async ? (n_ring - 1) / 2 > 0 ? (n_ring - 1) / 2 : 1 : n_ring - 1;
+    int flushed = 0;                       // p_0 .. p_{flushed-1} are in delta, or on their way there (async)
+    int synced = 0;                        // ... and the loop's stream has waited for the updates of p_0 .. p_{synced-1}
+    struct Sent { int upto; hipEvent_t done; };
+    std::vector<Sent> sent;
+    size_t n_ev = 0;
+    SolverVectors vr = v_;                 // (ring: the plugin sees plane k-1 as p[cur], plane k as p[cur ^ 1])
+    auto ring_plane = [&](int k) -> float* { return k < 0 ? v_.p[0] : ring_[(size_t)(k % n_ring)]; };
+    auto flush_ring = [&](int upto) -> int {      // delta += alpha_j p_j for flushed <= j <= upto (their scalars are words once what is enqueued on s has run)
+        while (flushed <= upto) {
+            thallo_update_terms_t T; T.count = 0;
+            for (; flushed <= upto && T.count < THALLO_HIP_MAX_UPDATE_TERMS; ++flushed) {
+                T.p[T.count] = ring_plane(flushed); T.alphaN[T.count] = sum(B + 2 * flushed); T.alphaD[T.count] = sum(B + 2 * flushed + 1); ++T.count;
+            }
+            if (!async) {
+                TimedLaunch t(ctx, "PCGDeltaUpdate");
+                if (thallo_hip_linear_update_n(nullptr, v_.delta, T, v_.n_alloc, 0, s) < 0) return -1;
+                synced = flushed;
+                continue;
+            }
+            if (n_ev + 2 > aux_events_.size()) { hipEvent_t e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1; aux_events_.push_back(e);
+                                                 e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1; aux_events_.push_back(e); }
+            hipEvent_t words = aux_events_[n_ev++], done = aux_events_[n_ev++];
+            if (hipEventRecord(words, s) != hipSuccess || hipStreamWaitEvent(aux_, words, 0) != hipSuccess) return -1;
+            LaunchCtx cx = ctx; cx.stream = aux_;
+            {   TimedLaunch t(cx, "PCGDeltaUpdate");
+                if (thallo_hip_linear_update_n(nullptr, v_.delta, T, v_.n_alloc, aux_workgroups_, aux_) < 0) return -1; }
+            if (hipEventRecord(done, aux_) != hipSuccess) return -1;
+            sent.push_back(Sent{ flushed - 1, done });
+        }
+        return 0;
+    };
+    auto wait_for = [&](int term) -> int {        // the loop's stream goes on only when the update that took p_term has run
+        for (const Sent& q : sent) {
+            if (q.upto < synced) continue;
+            if (hipStreamWaitEvent(s, q.done, 0) != hipSuccess) return -1;
+            synced = q.upto + 1;
+            if (q.upto >= term) break;
+        }
+        return 0;
+    };
     int nb_prev = 0;
-    for (int k = 0; k < (defer ? L : 0); ++k) {
+    for (int k = 0; k < L; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        const thallo_prev_t prev = { k ? slot(jD - 2) : nullptr, v_.s12buf((k - 1) & 1), nb_prev, k ? scal(jD - 2) : nullptr, k ? scal(jB - 2) : nullptr };
-        nb = plugin->pcg_iter_deferred(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ && plugin->batches_delta() ? 1 : 0), sum(k ? jN - 2 : jN), sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD),
-                                       prev, slot(jD), v_.s12buf(k & 1));
-        if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
-        if (k) { fin_[jD - 2] = 1; set_nb(jB - 2, 1); fin_[jB - 2] = 1; }      // (that launch's workgroup 0 writes the two words of iteration k-1)
-        set_nb(jD, nb); nb_prev = nb; cur_ ^= 1;
-        if (k == L - 1) {
-            if (plugin->pcg_iter_finish_from(ctx, slot(jD), v_.s12buf(k & 1), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
+        const int mode = ring ? (k == 0 ? 1 : 2) : THALLO_IW_STEP1_MODE(k, batched ? 1 : 0);
+        if (ring) {
+            // plane k mod n still holds p_{k-n}: it has to be in delta before launch k overwrites it.  Terms up to k - 2 can go (launch k - 1 leaves their scalars)
+            const bool due = async ? k - 1 - flushed >= chunk : (k >= n_ring && flushed < k - n_ring + 1);
+            if (due && flush_ring(k - 2)) { set_error("PCGDeltaUpdate launch failed"); return 0; }
+            if (k >= n_ring && synced < k - n_ring + 1 && wait_for(k - n_ring)) { set_error("PCGDeltaUpdate: stream wait failed"); return 0; }
+            vr.p[cur_] = ring_plane(k - 1); vr.p[cur_ ^ 1] = ring_plane(k);
+        }
+        SolverVectors& vv = ring ? vr : v_;
+        if (defer) {
+            const thallo_prev_t prev = { k ? slot(jD - 2) : nullptr, v_.s12buf((k - 1) & 1), nb_prev, k ? scal(jD - 2) : nullptr, k ? scal(jB - 2) : nullptr };
+            nb = plugin->pcg_iter_deferred(ctx, vv, cur_, mode, sum(k ? jN - 2 : jN), sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), prev, slot(jD), v_.s12buf(k & 1));
+            if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
+            if (k) { fin_[jD - 2] = 1; set_nb(jB - 2, 1); fin_[jB - 2] = 1; }      // (that launch's workgroup 0 writes the two words of iteration k-1)
+            set_nb(jD, nb); nb_prev = nb; cur_ ^= 1;
+            if (k == L - 1) {
+                if (plugin->pcg_iter_finish_from(ctx, slot(jD), v_.s12buf(k & 1), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
+                fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+            }
+        } else {
+            // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
+            nb = plugin->pcg_iter(ctx, vv, cur_, mode, sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
+                                  sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), slot(jD),
+                                  fin_in_kernel_ ? scal(jD) : nullptr, fin_in_kernel_ ? scal(jB) : nullptr);
+            if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
+            set_nb(jD, nb); cur_ ^= 1;
+            if (!fin_in_kernel_ && plugin->pcg_iter_finish(ctx, v_, slot(jD), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
             fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
         }
     }
-    for (int k = 0; k < (defer ? 0 : L); ++k) {
-        const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        // alphaD_k and betaN_k = N - 2 alpha_k S1 + alpha_k^2 S2: by the kernel's last workgroup, or (THALLO_FIN_IN_KERNEL=0) a one-wave launch
-        nb = plugin->pcg_iter(ctx, v_, cur_, THALLO_IW_STEP1_MODE(k, batch_delta_ && plugin->batches_delta() ? 1 : 0), sum(k ? jN - 2 : jN), sum(k ? jD - 2 : jD), sum(jN),
-                              sum(k > 1 ? jN - 4 : jN), sum(k > 1 ? jD - 4 : jD), slot(jD),
-                              fin_in_kernel_ ? scal(jD) : nullptr, fin_in_kernel_ ? scal(jB) : nullptr);
-        if (nb < 0) { set_error("PCGIteration launch failed (%d)", nb); return 0; }
-        set_nb(jD, nb); cur_ ^= 1;
-        if (!fin_in_kernel_ && plugin->pcg_iter_finish(ctx, v_, slot(jD), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
-        fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
-    }
-    const bool batched = batch_delta_ && plugin->batches_delta();                 // THALLO_IW_STEP1_MODE(k, 1): every other delta update is deferred
     last_l_iters = L;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
-    linear_update_tail(L, batched);
+    if (ring && L > 0) {
+        // PCGLinearUpdate with every pending term: all but the last THALLO_HIP_MAX_UPDATE_TERMS go into delta first
+        if (flush_ring(L - 1 - THALLO_HIP_MAX_UPDATE_TERMS) || wait_for(L)) { set_error("PCGDeltaUpdate launch failed"); return 0; }
+        thallo_update_terms_t T; T.count = 0;
+        for (int j = flushed; j < L; ++j) { T.p[T.count] = ring_plane(j); T.alphaN[T.count] = sum(B + 2 * j); T.alphaD[T.count] = sum(B + 2 * j + 1); ++T.count; }
+        const auto& imgs = plugin->unknown_images();
+        long off = 0;
+        for (size_t u = 0; u < imgs.size(); ++u) {
+            TimedLaunch t(ctx, "PCGLinearUpdate");
+            thallo_update_terms_t Tu = T;
+            for (int j = 0; j < Tu.count; ++j) Tu.p[j] += off;
+            if (thallo_hip_linear_update_n(plugin->unknown_ptr((int)u), v_.delta + off, Tu, imgs[u].n_floats, 0, s) < 0) { set_error("PCGLinearUpdate launch failed"); return 0; }
+            off += imgs[u].n_floats;
+        }
+        plugin->unknowns_written();
+    } else linear_update_tail(L, batched);
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);
     return 1;
+}
+
+// The plan's second stream (lowest priority, non-blocking: the loop's stream may be the NULL stream): background updates of delta next to the PCG loop
+bool Plan::aux_stream()
+{
+    if (aux_) return true;
+    if (aux_failed_) return false;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+    if (hipStreamCreateWithPriority(&aux_, hipStreamNonBlocking, lo) != hipSuccess) { aux_ = nullptr; aux_failed_ = true; (void)hipGetLastError(); return false; }
+    return true;
+}
+
+// Planes in the ring of p vectors of the one-kernel GN loop (0: no ring).  v_.p[1], v_.p[0] are its first two; the rest is allocated on first use and grows
+// with lIterations, as long as the device has room: at most a quarter of what is free and 8 GiB, at most 33 planes (one PCGDeltaUpdate takes 32 terms).
+int Plan::ring_planes(int L)
+{
+    if (!plugin->takes_any_p_plane() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3 || dist_) return 0;
+    int want = delta_planes_ >= 2 ? delta_planes_ : delta_planes_ <= -2 ? -delta_planes_ : THALLO_HIP_MAX_UPDATE_TERMS + 1;
+    if (want > L) want = L;                 // (L planes: delta is never touched inside the loop)
+    if (ring_.size() < 2) { ring_.clear(); ring_.push_back(v_.p[1]); ring_.push_back(v_.p[0]); }
+    const size_t bytes = (size_t)v_.n_alloc * sizeof(float);
+    while ((int)ring_.size() < want) {
+        size_t free_b = 0, total_b = 0;
+        if (delta_planes_ == -1 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4 / (size_t)(want - (int)ring_.size()) ||
+                                  bytes * (ring_.size() - 1) > ((size_t)8 << 30))) break;
+        DeviceBuffer* b = new DeviceBuffer();
+        if (b->alloc(bytes)) { delete b; break; }
+        bufs_.push_back(b); ring_.push_back((float*)b->ptr);
+    }
+    const int n = (int)ring_.size() < want ? (int)ring_.size() : want;
+    return n >= 3 || want == 2 ? n : 0;      // (two planes = an update per iteration: only on request)
 }
 
 int Plan::step_gn_resident(int ev_iter)

@@ -150,6 +150,13 @@ private:
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
     bool fin_in_kernel_ = true, one_kernel_ = true, batch_delta_ = true, lm_fold_p_ = true;   // A/B switches: read_ab_switches()
+    int delta_planes_ = -1;         // THALLO_DELTA_PLANES (-1: unset)
+    std::vector<float*> ring_;      // the ring of p planes of the one-kernel GN loop (ring_planes)
+    int  ring_planes(int L);
+    hipStream_t aux_ = nullptr; bool aux_failed_ = false;      // the plan's second stream (background delta updates)
+    std::vector<hipEvent_t> aux_events_;
+    int aux_workgroups_ = 256;      // share of the chip a background update takes
+    bool aux_stream();
     bool fin_deferred_ = true;      // THALLO_FIN_IN_KERNEL unset: the single-reduction GN loop finishes iteration k-1 inside the flat update of iteration k (=1: by the applyJTJ launch's last workgroup; =0: a one-wave launch)
     void read_ab_switches();
     float* scal(int j) { return (float*)parts_.ptr + (size_t)parts_slots_ * THALLO_HIP_MAX_PARTIALS + j; }

@@ -186,6 +186,9 @@ def main():
     if "THALLO_NT2" in os.environ: _L.thallo_hip_debug_set2(int(os.environ["THALLO_NT2"]))
     if "THALLO_PER_CU" in os.environ: _L.thallo_hip_debug_set(5, int(os.environ["THALLO_PER_CU"]))
     if "THALLO_THREADS" in os.environ: _L.thallo_hip_debug_set(6, int(os.environ["THALLO_THREADS"]))
+    if "THALLO_PERSIST_ACQ" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(0, int(os.environ["THALLO_PERSIST_ACQ"]))
+    if "THALLO_PERSIST_RES" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(1, int(os.environ["THALLO_PERSIST_RES"]))
+    if "THALLO_PERSIST_OCC" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(2, int(os.environ["THALLO_PERSIST_OCC"]))
     dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
     s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
     s.set_solver_parameters(nIterations=K + Wm + ROOFLINE_STEPS, lIterations=L_it)
@@ -210,12 +213,14 @@ def main():
     ks = s.kernel_stats()
     final_cost = s.current_cost()
     ring = "PCGDeltaUpdate" in ks
-    if one_kernel:
+    persistent = "PCGLoopPersistent" in ks
+    if one_kernel and not persistent:
         s.reset_kernel_stats()
         s.set_kernel_sampling(4)
-        for _ in range(ROOFLINE_STEPS):
-            assert s.step(params) == 1
-        torch.cuda.synchronize()
+    for _ in range(ROOFLINE_STEPS):
+        assert s.step(params) == 1
+    torch.cuda.synchronize()
+    if one_kernel and not persistent:
         s.set_kernel_sampling(0)
         ks = s.kernel_stats()
     assert s.step(params) == 0                 # budget used up: finalises the plan and its performance summary
@@ -225,8 +230,12 @@ def main():
     dom = "PCGIteration" if one_kernel else "PCGStep1"
     dom_bytes = fused_bytes_per_iter(L_it, ring) if one_kernel else FUSED_BYTES_STEP1          # what the kernel has to move (= its PMC traffic)
     ref_bytes = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1        # the reference formulation of the same work
-    step1_ms = ks[dom]["mean_ms"]
-    n_samples = ks[dom]["samples"]
+    if persistent:      # the loop is a few launches of many iterations each: the library's event pair around it ("Linear Solve") / L, delta updates included
+        step1_ms = perf["linearSolve"]["meanMS"] / L_it
+        n_samples = perf["linearSolve"]["count"] * L_it
+    else:
+        step1_ms = ks[dom]["mean_ms"]
+        n_samples = ks[dom]["samples"]
     ach = dom_bytes * npx / (step1_ms * 1e-3) / 1e9
     sa_ms = standalone_applyjtj(torch, W, H, p)
     sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9

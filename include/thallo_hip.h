@@ -282,6 +282,27 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
  * Alternating 1, 2 halves delta's read + write traffic (-6 B/pixel/iteration) and produces the same bits as mode 0 throughout.
  * THALLO_IW_STEP1_MODE(k, batched) gives the mode of iteration k. */
 #define THALLO_IW_STEP1_MODE(k, batched) ((k) == 0 ? 1 : !(batched) ? 0 : ((k) & 1) ? 2 : 4)
+/* ---- the marching PCG iteration as a PERSISTENT loop (energy_image_warping_march_persist.hip): iterations k0 .. k1-1 of a GN step in ONE launch, for whole images on
+ * the unit pixel grid whose solver state does not fit the chip's registers (2048^2: 35 rows per wave).  The launch-per-iteration grid stays on the chip; the
+ * iteration's sums (a tagged record per workgroup) are its one synchronisation point, r_k / p_k are stored write-through.  What a launch per iteration
+ * (thallo_hip_iw_pcg_iter_march_rc_deferred, delta mode "none") reads and leaves behind, in the plan's own layout:
+ *   r[k & 1] -> r[(k + 1) & 1];  p_{k-1} in planes[(k - 1) % n_planes] -> p_k in planes[k % n_planes]   (n_planes >= k1 - k0 + 1);
+ *   reduction slots at parts + j * THALLO_HIP_MAX_PARTIALS, their words at parts + slots * THALLO_HIP_MAX_PARTIALS + j; alphaN_k = slot B + 2k, alphaD_k = B + 2k + 1, betaN_k = B + 2k + 2:
+ *   read  alphaN_{k0-1} (alphaN_prev: partials or one word), the nb_prev alphaD partials of iteration k0 - 1 and its double sums in s12[(k0 - 1) & 1];
+ *   write the words alphaD_{k-1}, betaN_{k-1} for k0 <= k < k1 and the partials of iteration k1 - 1 (alphaD slot, s12[(k1 - 1) & 1]; as many as the return value).
+ * xbuf: thallo_hip_iw_march_persist_bytes() bytes, zeroed once by the caller, private to the plan.  Bit-identical to the launches it replaces (same strips, segments,
+ * expressions and order of every sum).  Every workgroup must be resident (one per CU; checked at launch); every wait inside is bounded (2 s, or spin_ms), an expired
+ * one sets the error word thallo_hip_iw_march_persist_status reads.  Returns the number of workgroups (> 0), -hipErrorNotSupported when the shape does not fit.
+ * Replaces the loop of gauss_newton.t:1615-1687. */
+long thallo_hip_iw_march_persist_bytes(void);
+int thallo_hip_iw_march_persist_rows(int W, int H);      /* rows per wave, 0 = the shape does not run as a persistent loop */
+int thallo_hip_iw_pcg_march_persist(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
+                                    float* r0, float* r1, float* const* planes, int n_planes, int k0, int k1,
+                                    float* parts, int slots, int B, double* s12_0, double* s12_1, int nb_prev, thallo_sum_t alphaN_prev,
+                                    const int* irregular, void* xbuf, thallo_stream_t stream);
+int thallo_hip_iw_march_persist_status(void* xbuf, int clear, int spin_ms, unsigned* post_mortem5, thallo_stream_t stream);
+void thallo_hip_iw_march_persist_debug_set(int what, int value);      /* tools: what 0 = the acquire form (1) instead of L1-bypassing loads (0) */
+
 /* One kernel per PCG iteration (replaces pcg_step1 + pcg_step2 of iteration k-1/k): r_out = r_in - alpha_{k-1} Ap_in (first:
  * r_in), z = M^-1 r_out (pixel grid: from the flags byte; else from `pre`), p_out = z + beta_{k-1} p_in, the deferred delta
  * update (mode as in pcg_step1), Ap_out = J^T J p_out, and per workgroup: alphaD partial (float) into alphaD_out[b] and the three
@@ -340,6 +361,9 @@ int thallo_hip_iw_pcg_iter_march_rc_dist_deferred(int W, int H, int row0, int ro
                                                   const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
                                                   thallo_sum_t alphaN_prev, thallo_sum_t alphaN_prev2, thallo_sum_t alphaD_prev2, thallo_prev_t prev, int prev_slot0,
                                                   unsigned long long* gs, const int* irregular, thallo_dist_t d, float* alphaD_out, double* s12_out, thallo_stream_t stream);
+/* 1: the deferred cross-rank finish may run on `rows` owned rows of a W-wide slab (every workgroup of its launch, the eight extra ones included, is resident at once:
+   its working waves wait for the last workgroup's granules); 0: the caller runs thallo_hip_iw_pcg_iter_march_rc_dist */
+int thallo_hip_iw_march_rc_deferred_fits(int W, int rows);
 int thallo_hip_iw_dist_finish_deferred(thallo_prev_t prev, int prev_slot0, thallo_sum_t alphaN_prev, thallo_dist_t d, unsigned long long* gs, thallo_stream_t stream);
 /* the two one-kernel iterations with the deferred finish (thallo_prev_t above): alphaN_prev = alphaN_{k-1} (a finished sum), alphaN_prev2 / alphaD_prev2 as
    in the plain forms; `prev` is ignored for mode & 1 (first iteration of a GN step) */

@@ -484,6 +484,74 @@ def test_ring_of_p_planes_is_bitwise_a_delta_update_per_iteration(torch, monkeyp
     assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
+@pytest.mark.parametrize("acq,res,occ", [(0, 23, 1), (1, 23, 1), (0, 0, 1), (0, 5, 1), (0, 23, 2), (1, 3, 2)])
+@pytest.mark.parametrize("W,H,lit,planes", [(2048, 2048, 12, None), (2048, 2048, 40, "9"), (1024, 768, 25, None), (1024, 768, 70, None), (256, 256, 30, "4"), (130, 7, 12, None), (124, 64, 9, "3"),
+                                            (250, 2, 5, None), (126, 130, 7, None), (2, 1, 4, None), (372, 5, 6, None), (2048, 1024, 35, None)])
+def test_persistent_marching_loop_is_bitwise_a_launch_per_iteration(torch, monkeypatch, W, H, lit, planes, acq, res, occ):
+    """iterations 1 .. L-1 of a GN step as ONE launch of the marching kernel's grid (energy_image_warping_march_persist.hip: every wave loops over the
+    iterations; the sums of iteration k-1 -- a tagged record per workgroup -- are the one synchronisation point; r_k / p_k stored write-through and read past L1, or
+    behind one acquire per wave with acq = 1; r of up to `res` rows per wave kept in LDS between the iterations of a launch, only its halo lanes going through memory)
+    against one launch per iteration (THALLO_PERSIST=0).  Same strips, segments, expressions and summation order: costs,
+    every alpha_k / beta_k and the unknowns BIT-identical after three GN steps.  Sizes: the benchmark's and the 1/2 slab's, ragged strips and segments, one- to
+    three-strip images, images of 1 .. 7 rows, rings shorter than the loop (several persistent launches per step with a delta update between them)."""
+    p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
+    monkeypatch.setenv("THALLO_RESIDENT", "0")
+    monkeypatch.setenv("THALLO_MARCH", "2")
+    if planes is None: monkeypatch.delenv("THALLO_DELTA_PLANES", raising=False)
+    else: monkeypatch.setenv("THALLO_DELTA_PLANES", planes)
+    thallo_amd.lib().thallo_hip_iw_march_persist_debug_set(0, acq)
+    thallo_amd.lib().thallo_hip_iw_march_persist_debug_set(1, res)
+    thallo_amd.lib().thallo_hip_iw_march_persist_debug_set(2, occ)         # occ = 2: two workgroups per CU (half the rows per wave) -- the launch-per-iteration run is given the same rows
+    R2 = thallo_amd.lib().thallo_hip_iw_march_persist_rows(W, H) if occ == 2 else 0
+    if R2 > 0: thallo_amd.lib().thallo_hip_march_debug_set(0, R2)
+    runs = []
+    try:
+        for persist in ("0", "1"):
+            monkeypatch.setenv("THALLO_PERSIST", persist)
+            dev = to_device(copy_params(p))
+            s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=2)
+            s.set_solver_parameters(nIterations=3, lIterations=lit)
+            params = s.make_params(dev)
+            s.init(params)
+            costs, traces = [s.current_cost()], []
+            while s.step(params):
+                costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+            names = s.kernel_stats()
+            s.close()
+            runs.append((costs, traces, dev[0].clone(), dev[1].clone(), names))
+    finally:
+        thallo_amd.lib().thallo_hip_iw_march_persist_debug_set(0, 0)
+        thallo_amd.lib().thallo_hip_iw_march_persist_debug_set(1, 23)
+        thallo_amd.lib().thallo_hip_iw_march_persist_debug_set(2, 1)
+        thallo_amd.lib().thallo_hip_march_debug_set(0, 0)
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == 4 and len(t0[0]) == lit
+    n = min(lit, 33 if planes is None else int(planes))
+    launches = 0
+    k = 1
+    while k < lit: launches += 1; k += min(lit - k, n - 1)
+    assert n0["PCGIteration"]["launches"] == 3 * lit and "PCGLoopPersistent" not in n0
+    assert n1["PCGIteration"]["launches"] == 3 and n1["PCGLoopPersistent"]["launches"] == 3 * launches, (n1, launches)
+    assert t0 == t1, [(i, k) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1)
+
+
+def test_deferred_cross_rank_finish_is_refused_where_its_grid_cannot_be_resident(torch):
+    """the deferred cross-rank finish of the marching kernel makes every working wave wait for the launch's LAST workgroup, so the whole grid -- plus
+    its eight extra workgroups -- must fit the device at the two workgroups per CU the kernel is built for.  march_pick_rows sizes a wide slab's grid for up to four per
+    CU (16384 x 256: 133 strips x 7 bands): such a shape must say no (the launch-end exchange runs instead), the benchmark's slabs must say yes, and so must nothing
+    when the workgroup budget is forced below the grid."""
+    L = thallo_amd.lib()
+    assert L.thallo_hip_iw_march_rc_deferred_fits(2048, 1024) == 1 and L.thallo_hip_iw_march_rc_deferred_fits(2048, 256) == 1
+    assert L.thallo_hip_iw_march_rc_deferred_fits(16384, 256) == 0
+    L.thallo_hip_march_debug_set(6, 64)
+    try:
+        assert L.thallo_hip_iw_march_rc_deferred_fits(2048, 256) == 0          # (a grid sized for 64 workgroups + 8 > 64)
+    finally:
+        L.thallo_hip_march_debug_set(6, 0)
+
+
 def test_image_warping_reference_cat512_instance(torch, orc, golden_dir):
     """The reference's own image_warping data set (cat512 mask + 9 markers + pinned border, examples/image_warping/src/main.cpp:
     78-129; BASELINE.json configs[1]) through two steps of the harness' marker continuation: cost trajectory vs the oracle."""

@@ -87,7 +87,8 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     struct IncRun { int ri = -1, g = -1; hipFunction_t jtj = nullptr, jtf = nullptr; DeviceBuffer ptr, els; long npix = 0; int wave = 0; };
     std::vector<IncRun*> inc_runs_;
     std::vector<hipFunction_t> inc_uidx_;          // G.inc order
-    std::vector<char> use_inc_;                    // per residual
+    std::vector<char> use_inc_;                    // per residual: gathered through per-owner instance lists for THIS Init's Sparse maps and dims
+    std::vector<char> want_inc_;                   // ... what the constructor decided from the schedule (build_incidence may say no for one Init: few owners with enormous lists)
     bool inc_ready_ = false;
     long group_pixels(int g) const { long n = 1; for (int d : G.inc_groups[(size_t)g].dims) n *= dimv[(size_t)d]; return n; }
     // the owners' lists: the residual's own index evaluation (uidx_<ri>: K flat unknown indices per instance, -1 = absent), inverted on the host
@@ -228,6 +229,7 @@ public:
                 }
             }
         }
+        want_inc_ = use_inc_;          // (prepare() starts every Init from this; build_incidence may take a residual back for that Init's maps -- ADVICE r4)
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
             const dsl::Residual& r = P.residuals[ri];
             const bool plain = !r.mat_J && !r.mat_JtJ && !r.mat_Jp;
@@ -286,7 +288,7 @@ public:
         for (size_t i = 0; i < gather_.size(); ++i) { const bool g = gather_[i] || use_inc_[i]; all = all && g; any = any || g; }
         return all ? "per residual, unknown-wise (gather)" : any ? "per residual, some unknown-wise (gather)" : "per residual";
     }
-    int prepare(LaunchCtx&) override { sp_ready_ = false; inc_ready_ = false; return 0; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
+    int prepare(LaunchCtx&) override { sp_ready_ = false; inc_ready_ = false; use_inc_ = want_inc_; return 0; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
 
     // symbolic phase of the sparse J^T J (the reference: cusparseXcsrgemmNnz, gauss_newton.t:1404-1412): the rows' unknown indices -> CSR pattern
     // + for every product v[i][a] * v[i][b] its position in the values
@@ -371,7 +373,9 @@ public:
         // (a unit with a wide residual -- hundreds of 32-wide dual operations in one function -- takes minutes at -O3 with the loops unrolled: 128 s for the
         //  reference's 17 x 17 deconvolution against 25 s without unrolling)
         // (-I: under rocprofv3 the runtime compiler does not find its own <hip/hip_runtime.h>)
-        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics", "-I/opt/rocm/include", "-fno-unroll-loops" };
+        std::string inc = "-I";        // ROCM_PATH / HIP_PATH as hipcc reads them, else the image's default
+        { const char* rp = getenv("ROCM_PATH"); const char* hp = getenv("HIP_PATH"); inc += (rp && rp[0]) ? rp : (hp && hp[0]) ? hp : "/opt/rocm"; inc += "/include"; }
+        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics", inc.c_str(), "-fno-unroll-loops" };
         const hiprtcResult rc = hiprtcCompileProgram(prog, G.has_wide ? 5 : 4, opts);
         if (rc != HIPRTC_SUCCESS) {
             size_t n = 0; hiprtcGetProgramLogSize(prog, &n); std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);

@@ -479,6 +479,19 @@ int thallo_hip_iw_pcg_iter_march_rc_dist(int W, int H, int row0, int row1, const
                               aD_out, s12_out, fin_tickets, aD_word, bN_word, slot0, (hipStream_t)stream, PrevSums{ nullptr, nullptr, 0, nullptr, nullptr });
 }
 
+/* The deferred cross-rank finish makes every working wave wait for granules that wave 0 of the launch's LAST workgroup publishes: the whole grid (its eight extra
+ * workgroups included) must be resident at once -- the kernel is built for MARCH_RC_OCC workgroups per CU, while march_pick_rows may size a wide slab's grid for up to
+ * four.  1: it is; 0: run the launch-end exchange (thallo_hip_iw_pcg_iter_march_rc_dist), which has no such requirement. */
+int thallo_hip_iw_march_rc_deferred_fits(int W, int rows)
+{
+    if (W < 2 || (W & 1) || rows < 1) return 0;
+    const int R = march_pick_rows(W, rows);
+    if (R <= 0) return 0;
+    const MarchGeo g = make_march_geo(W, rows, 0, rows, R);
+    const long grid = (g.total + 7) / 8 * 8 + 8;
+    return grid <= march_cap(MARCH_RC_OCC) && grid <= THALLO_MAX_PARTIALS ? 1 : 0;
+}
+
 /* ... with the deferred cross-rank finish (thallo_hip.h): `prev` = iteration k-1's partials of THIS rank, its two words, and where the exchange happens */
 int thallo_hip_iw_pcg_iter_march_rc_dist_deferred(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
                                                   const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int mode,
@@ -487,6 +500,7 @@ int thallo_hip_iw_pcg_iter_march_rc_dist_deferred(int W, int H, int row0, int ro
 {
     if (int e = rc_check(W, H, row0, row1, cs, flags, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, mode, aNp, aNpp, aDpp, aD_out, s12_out)) return e;
     if (!Ap_in || !Ap_out || d.world < 1 || d.world > THALLO_DIST_MAX_WORLD || !d.mail || !d.ctl || 7 * d.world > 64 || prev_slot0 < 0 || !gs || aNp.count != 1) return -(int)hipErrorInvalidValue;
+    if (!thallo_hip_iw_march_rc_deferred_fits(W, row1 - row0)) return -(int)hipErrorNotSupported;      // (its waits need every workgroup resident)
     if (prev.count < 1 || prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_partials || !prev.s12_partials || !prev.alphaD_word || !prev.betaN_word ||
         prev.s12_partials == s12_out) return -(int)hipErrorInvalidValue;
     for (int k = 0; k < 2; ++k) if (d.peer_r[k] && ((d.peer_off_o[k] | d.peer_off_a[k]) & 1)) return -(int)hipErrorInvalidValue;

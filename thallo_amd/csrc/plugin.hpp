@@ -137,7 +137,11 @@ public:
     // Plugins whose fused PCGStep1 can defer every other delta update (thallo_hip.h THALLO_IW_STEP1_MODE) return true and
     // implement pcg_step1_mode; the driver then finishes the GN step with up to two pending alpha*p terms.
     virtual bool batches_delta() const { return false; }
-    virtual bool takes_any_p_plane() const { return false; }            // pcg_iter / pcg_iter_deferred read p[cur] and write p[cur ^ 1] wherever those point, and nothing else of p (the ring of p planes)
+    virtual bool takes_any_p_plane() const { return false; }
+    // iterations k0 .. k1-1 of the one-kernel GN loop in ONE launch (image_warping's persistent marching loop): planes[k % n] as in the ring schedule, the plan's
+    // slot layout passed through (thallo_hip_iw_pcg_march_persist).  Returns the workgroup count or < 0
+    virtual bool persist_ok() const { return false; }
+    virtual int pcg_persist(struct LaunchCtx&, SolverVectors&, float* const* planes, int n_planes, int k0, int k1, float* parts, int slots, int B, int nb_prev, thallo_sum_t alphaN_prev) { return -1; }            // pcg_iter / pcg_iter_deferred read p[cur] and write p[cur ^ 1] wherever those point, and nothing else of p (the ring of p planes)
     virtual int pcg_step1_mode(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN_prev, thallo_sum_t aD_prev, thallo_sum_t bN_prev,
                                thallo_sum_t, thallo_sum_t, float* alphaD_out)
     { return pcg_step1(c, v, cur, (mode & 1) != 0, aN_prev, aD_prev, bN_prev, alphaD_out); }

@@ -162,6 +162,8 @@ class ImageWarpingPlugin : public EnergyPlugin {
     bool resident_slab_ = false;           // ... as one rank's row slab of a multi-GPU run (thallo_hip_iw_pcg_resident_dist)
     bool resident_broken_ = false;         // a bounded wait of the resident kernel ran out on this plan (something kept its workgroups from being co-resident): never again
     bool march_ = false;                   // UrShape verified (at Init) to be the unit pixel grid and W even: the marching one-kernel iteration
+    DeviceBuffer xpst;                     // exchange memory of the persistent marching loop (control words + tagged sums records)
+    bool persist_ = false;                 // ... and iterations 1 .. L-1 of a GN step as ONE launch of it (whole image, every workgroup resident; THALLO_PERSIST)
     bool march_rc_ = false;                // ... in its form without an A p plane (whole image on one GPU; THALLO_MARCH=3: the stored-plane form, A/B)
     bool grid_ = false;                    // UrShape is the unit pixel grid (host-checked at Init)
     int row0_ = 0, row1_ = 0;              // owned rows (all of them unless the Plan is one row slab of a multi-GPU run)
@@ -215,6 +217,15 @@ public:
             }
             if (need > 0) { resident_ = whole; resident_slab_ = true; }
         }
+        // larger whole images: iterations 1 .. L-1 of a GN step as ONE persistent launch of the marching kernel's grid -- THALLO_PERSIST=1 only: measured 8-10 % SLOWER
+        // than a launch per iteration at 2048^2 (energy_image_warping_march_persist.hip, profiles/r05/persist_ab.txt); bit-identical, kept for the tests and the tools
+        persist_ = false;
+        const char* ep = env_switch("THALLO_PERSIST");
+        if (march_rc_ && whole && !resident_broken_ && ep && ep[0] == '1' && thallo_hip_iw_march_persist_rows(W, H) > 0) {
+            const long need = thallo_hip_iw_march_persist_bytes();
+            if ((long)xpst.bytes < need && xpst.alloc((size_t)need)) { set_error("image_warping: out of device memory for the persistent loop's exchange buffer"); return -1; }
+            persist_ = true;
+        }
         return 0;
     }
     // ---- one row slab of a multi-GPU run (solver_dist.cpp)
@@ -243,7 +254,7 @@ public:
                                            v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode,
                                            aN, aD, bN, aN2, aD2, (const int*)irregular.ptr, d, out, v.s12, v.fin_tickets, slot0, aD_word, bN_word, c.stream);
     }
-    bool dist_defers_finish() const override { return march_rc_ && march_; }
+    bool dist_defers_finish() const override { return march_rc_ && march_ && thallo_hip_iw_march_rc_deferred_fits(W, row1_ - row0_) != 0; }      // (every workgroup of the launch resident)
     int pcg_iter_dist_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2,
                                const thallo_prev_t& prev, int prev_slot0, unsigned long long* gs, const thallo_dist_t& d, float* out, double* s12_out) override
     {
@@ -280,7 +291,14 @@ public:
                                        v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, none, none, (const int*)irregular.ptr, v.r, out, c.stream);
     }
     bool batches_delta() const override { return true; }
-    bool takes_any_p_plane() const override { return march_ && row0_ == 0 && row1_ == H; }      // (the marching kernels; the mode-1 launch of a GN step's first iteration included)
+    bool takes_any_p_plane() const override { return march_ && row0_ == 0 && row1_ == H; }
+    bool persist_ok() const override { return persist_; }
+    int pcg_persist(LaunchCtx& c, SolverVectors& v, float* const* planes, int n_planes, int k0, int k1, float* parts, int slots, int B, int nb_prev, thallo_sum_t alphaN_prev) override
+    {
+        TimedLaunch t(c, "PCGLoopPersistent");
+        return thallo_hip_iw_pcg_march_persist(W, H, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg, v.rbuf(0), v.rbuf(1), planes, n_planes, k0, k1,
+                                               parts, slots, B, v.s12, v.s12b, nb_prev, alphaN_prev, (const int*)irregular.ptr, xpst.ptr, c.stream);
+    }      // (the marching kernels; the mode-1 launch of a GN step's first iteration included)
     bool dist_batches_delta() const override { return march_rc_; }      // (the stored-plane marching kernel's multi-GPU variant has no such form: it would spill)
     bool one_kernel_iteration() const override { return true; }
     int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2, float* out,
@@ -318,13 +336,18 @@ public:
     long resident_ghost_bytes() const override { return (W & 1) ? 0 : thallo_hip_iw_resident_ghost_bytes(W); }
     int pcg_resident_dist(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words, const thallo_dist_t& d, long ghost_off, int slot0) override
     {
+        if (!resident_slab_) return -(int)hipErrorNotSupported;      // (disabled since the ranks agreed -- a bounded wait ran out, THALLO_RESIDENT=0 at a later Init: the caller fails the step)
         TimedLaunch t(c, "PCGLoopResident");
         return thallo_hip_iw_pcg_resident_dist(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg, v.rbuf(0), v.p[0],
                                                v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words, (const int*)irregular.ptr, xres.ptr, d, ghost_off, slot0, L, c.stream);
     }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override
-    { return xres.ptr ? thallo_hip_iw_resident_status(xres.ptr, clear, -1, pm, c.stream) : 0; }
-    void resident_disable() override { resident_ = resident_slab_ = false; resident_broken_ = true; }
+    {
+        const int a = xres.ptr ? thallo_hip_iw_resident_status(xres.ptr, clear, -1, pm, c.stream) : 0;
+        if (a != 0 || !xpst.ptr) return a;
+        return thallo_hip_iw_march_persist_status(xpst.ptr, clear, -1, pm, c.stream);
+    }
+    void resident_disable() override { resident_ = resident_slab_ = persist_ = false; resident_broken_ = true; }
     bool iter_defers_finish() const override { return true; }
     int pcg_iter_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aN2, thallo_sum_t aD2, const thallo_prev_t& prev,
                           float* out, double* s12_out) override

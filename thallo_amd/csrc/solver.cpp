@@ -187,13 +187,14 @@ int Plan::ensure_slots(int L)
 }
 
 // ------------------------------------------------------------------ A/B switches
-// Every environment switch of the library, in this one table (the only getenv of thallo_amd/csrc).  Each selects an alternative that computes the same thing and that a
+// Every environment switch of the library, in this one table (the only getenv of a switch in thallo_amd/csrc; dsl_plugin.cpp reads ROCM_PATH / HIP_PATH for hipRTC).  Each selects an alternative that computes the same thing and that a
 // test or a tool still compares with the default; what lost its comparison in rounds 1-2 is gone (the blocking zeta test, the one-kernel bundle-adjustment
 // gather, THALLO_FINISH_SUMS / EXPANDED / DEFER_FINISH / LM_FOLD_CTC / LM_ZETA_IN_STEP2 / DIST_MEM / FRONTEND_DUMP).
 const char* env_switch(const char* name)
 {
     static const char* const known[] = {
         "THALLO_RESIDENT",            // 0: image_warping runs one launch per PCG iteration even where the whole PCG loop fits one resident launch
+        "THALLO_PERSIST",             // 1: iterations 1 .. L-1 of a GN step of image_warping's marching kernel as persistent launches (bit-identical; measured slower than a launch per iteration: opt-in)
         "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up); 3: the marching kernel with the stored A p plane (round 2/3); 4 = 2 + 3
         "THALLO_ONE_KERNEL",          // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
         "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch; 1: by the last workgroup of the iteration's kernel everywhere; unset: that, except in the
@@ -309,6 +310,17 @@ void Plan::init(void** params)
     }
     ready_ = true;
     if (dist_ && dist_->want_p2p && !dist_->checked && dist_self_check()) { ready_ = false; return; }
+    else if (dist_ && dist_->checked && dist_->p2p_on && !dist_->flat && !dist_->range && !dist_->shard) {
+        // Every Init agrees anew on what depends on the plugin's state NOW: whether every rank's slab runs the resident kernel (a rank may have switched it
+        // off since -- a bounded wait that ran out, THALLO_RESIDENT at re-Init) and whether the marching kernel's cross-rank finish is deferred.  Here, never at the
+        // first step: a step may be inside a captured graph.
+        bool all = false;
+        if (dist_agree(plugin->resident_slab_ok() && dist_->ghost_off > 0, all)) { ready_ = false; return; }
+        dist_->resident_all = all;
+        const bool mine = plugin->dist_defers_finish() && ensure_iter_buffers() == 0 && (dist_->gs.ptr || dist_->gs.alloc(64) == 0);
+        if (dist_agree(mine, all)) { ready_ = false; return; }
+        dist_->defer_state = all ? 1 : 0;
+    }
     sp.nIter = 0;
     prev_cost_ = compute_cost();
     printf("Initial cost: %g\n", prev_cost_);
@@ -486,7 +498,8 @@ int Plan::step_gn_one_kernel(int ev_iter)
     // idle while it ramps up and while its last waves finish; the update's loads fill those gaps.  A chunk of (n - 1) / 2 terms goes out as soon as their scalars are
     // words; the launch that overwrites a chunk's first plane waits for it (an event), which by then is half a ring ago.  THALLO_DELTA_PLANES < 0: on the loop's
     // own stream, whole rings at a time (A/B).
-    const bool async = ring && delta_planes_ >= -1 && aux_stream();
+    const bool persist = ring && defer && L >= 2 && plugin->persist_ok();
+    const bool async = ring && delta_planes_ >= -1 && !persist && aux_stream();
     const int chunk = !ring ? 0 : async ? (n_ring - 1) / 2 > 0 ? (n_ring - 1) / 2 : 1 : n_ring - 1;
     int flushed = 0;                       // p_0 .. p_{flushed-1} are in delta, or on their way there (async)
     int synced = 0;                        // ... and the loop's stream has waited for the updates of p_0 .. p_{synced-1}
@@ -528,8 +541,27 @@ int Plan::step_gn_one_kernel(int ev_iter)
         }
         return 0;
     };
+    // Persistent form (plugins that offer it, on the ring): iteration 0 as a launch of its own, then iterations k .. k + m - 1 per launch, m <= n - 1 (no plane of a
+    // launch is written twice, none is overwritten before delta has it)
     int nb_prev = 0;
     for (int k = 0; k < L; ++k) {
+        if (persist && k >= 1) {
+            const int m = L - k < n_ring - 1 ? L - k : n_ring - 1, k1 = k + m;
+            if (k1 - 1 >= n_ring && flushed < k1 - n_ring) { if (flush_ring(k - 2) || wait_for(k - 2)) { set_error("PCGDeltaUpdate launch failed"); return 0; } }
+            nb = plugin->pcg_persist(ctx, v_, ring_.data(), n_ring, k, k1, slot(0), parts_slots_, B, nb_prev, sum(B + 2 * (k - 1)));
+            if (nb < 0) { set_error("PCGLoopPersistent launch failed (%d)", nb); return 0; }
+            resident_used_ = true;
+            for (int i = k; i < k1; ++i) { const int jD = B + 2 * i + 1; fin_[jD - 2] = 1; set_nb(jD - 1, 1); fin_[jD - 1] = 1; }      // the words alphaD_{i-1}, betaN_{i-1} = alphaN_i
+            set_nb(B + 2 * (k1 - 1) + 1, nb); nb_prev = nb;
+            if (m & 1) cur_ ^= 1;
+            k = k1 - 1;
+            if (k == L - 1) {
+                const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
+                if (plugin->pcg_iter_finish_from(ctx, slot(jD), v_.s12buf(k & 1), nb, sum(jN), scal(jD), scal(jB)) < 0) { set_error("PCGScalars launch failed"); return 0; }
+                fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1;
+            }
+            continue;
+        }
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         const int mode = ring ? (k == 0 ? 1 : 2) : THALLO_IW_STEP1_MODE(k, batched ? 1 : 0);
         if (ring) {

@@ -151,12 +151,18 @@ int PlanF64::step(void** params)
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);
-    if (sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // gauss_newton.t:1767-1779
-        hipEvent_t q = nullptr; hipEventCreate(&q); hipEventRecord(q, s); hipEventSynchronize(q);
-        float ms = 0.0f; hipEventElapsedTime(&ms, timer_.events[ev_total_].start, q); hipEventDestroy(q);
-        if (ms / 1000.0f > sp.max_solver_time_in_seconds) { finalize(); return 0; }
-    }
-    return 1;
+    return out_of_time() ? 0 : 1;
+}
+
+// gauss_newton.t:1767-1779, behind every step of either branch: the time budget of the solve
+bool PlanF64::out_of_time()
+{
+    if (!(sp.max_solver_time_in_seconds > 0.0f) || ev_total_ < 0) return false;
+    hipStream_t s = ctx.stream;
+    hipEvent_t q = nullptr; hipEventCreate(&q); hipEventRecord(q, s); hipEventSynchronize(q);
+    float ms = 0.0f; hipEventElapsedTime(&ms, timer_.events[ev_total_].start, q); hipEventDestroy(q);
+    if (ms / 1000.0f > sp.max_solver_time_in_seconds) { finalize(); return true; }
+    return false;
 }
 
 int PlanF64::step_lm(int ev_iter)
@@ -243,7 +249,8 @@ int PlanF64::step_lm(int ev_iter)
     double rep[2] = { 0.0, 0.0 };
     if (hipMemcpyAsync(&rep[0], word(T0), sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(&rep[1], word(T1), sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
         return fail("model cost read-back", -1);
-    const double newCost = compute_cost();                                              // (synchronizes)
+    if (hipStreamSynchronize(s) != hipSuccess) return fail("model cost read-back", -1); // rep[] is host stack memory: in place before anything below can return or read it
+    const double newCost = compute_cost();
     const double model_cost_change = rep[1] - 0.5 * rep[0];
     const double cost_change = prev_cost_ - newCost;
     const double relative_decrease = cost_change / model_cost_change;
@@ -273,7 +280,7 @@ int PlanF64::step_lm(int ev_iter)
     timer_.stop(ev_iter, s);
     if (stop) { finalize(); return 0; }
     sp.nIter++;
-    return 1;
+    return out_of_time() ? 0 : 1;
 }
 
 }  // namespace thallo

@@ -35,6 +35,7 @@ private:
     bool use_lm_ = false;
     double radius_ = 0.0, decrease_factor_ = 2.0;
     int step_lm(int ev_iter);
+    bool out_of_time();          // max_solver_time_in_seconds behind a step of either branch (finalizes when the budget is spent)
     DeviceBuffer parts_;            // 8 x THALLO_HIP_MAX_PARTIALS partial slots, then 16 scalar words
     CoarseTimer timer_;
     int ev_total_ = -1;

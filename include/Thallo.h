@@ -209,6 +209,9 @@ int ThalloX_RcclAvailable(void);      /* 1: librccl can be bound in this process
 int ThalloX_RcclUniqueId(unsigned char* id_out128);
 int ThalloX_PlanUseRccl(Thallo_Plan* plan, const unsigned char* id128, int rank, int world);
 int ThalloX_RcclSelfTest(void);
+/* what the plan's communicator says about itself: out3 = { ncclCommCount, ncclCommCuDevice, ncclCommUserRank }, -1 where there is no communicator or no answer.
+ * Diagnostics for the first run on a real node: a count of 1 next to a torch.distributed world of N means the ranks never met. */
+void ThalloX_PlanRcclInfo(Thallo_Plan* plan, int out3[3]);
 /* JSON text: transport in use ("exchange": "p2p-mailbox" | "allgather"), memory kind of the mapped blocks, self-check outcome. */
 const char* ThalloX_PlanDistributedInfo(Thallo_Plan* plan);
 /* what = 0: read (and with value != 0 clear) the device-side exchange's error word -- 1 if a bounded mailbox wait timed out since the last clear

@@ -202,6 +202,11 @@ int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older
 #define THALLO_HIP_MAX_UPDATE_TERMS 32
 typedef struct { const float* p[THALLO_HIP_MAX_UPDATE_TERMS]; thallo_sum_t alphaN[THALLO_HIP_MAX_UPDATE_TERMS], alphaD[THALLO_HIP_MAX_UPDATE_TERMS]; int count; } thallo_update_terms_t;
 int thallo_hip_linear_update_n(float* X, float* delta, thallo_update_terms_t terms, long len, int max_workgroups /* 0: as many as the flat kernels use */, thallo_stream_t stream);
+/* Known-answer test of the wave64 primitives of the generated kernels (ballot, peer grouping by key, grouped sums: thallo.t:3380-3399 / cuda_util.t:334-427 for 64-wide waves),
+   the reference's tests/cuda_unit_tests/{ballot,get_peers,reduce_peers}.t restated for 64 lanes; one wave, compiled from the generated kernels' own prelude with hipRTC:
+   out_ballot = max over lanes of ballot(lane != 0) = 0xFFFFFFFFFFFFFFFE; out_peers = sum over lanes of (peer mask of key lane % 4) & 0xFF = 255 * 64 / 4;
+   sums4[i] = 480 + 16 i. */
+int thallo_hip_wave64_selftest(unsigned long long* out_ballot, unsigned* out_peers, float* sums4);
 int thallo_hip_finish_sum(thallo_sum_t s, float* out, thallo_stream_t stream);
 /* ... behind a device-side gate word (non-zero: the launch does nothing; the LM loop's gate, see thallo_hip_lm_zeta) */
 int thallo_hip_finish_sum_gated(thallo_sum_t s, float* out, const unsigned* gate, thallo_stream_t stream);

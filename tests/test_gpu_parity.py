@@ -545,9 +545,9 @@ def test_deferred_cross_rank_finish_is_refused_where_its_grid_cannot_be_resident
     L = thallo_amd.lib()
     assert L.thallo_hip_iw_march_rc_deferred_fits(2048, 1024) == 1 and L.thallo_hip_iw_march_rc_deferred_fits(2048, 256) == 1
     assert L.thallo_hip_iw_march_rc_deferred_fits(16384, 256) == 0
-    L.thallo_hip_march_debug_set(6, 64)
+    L.thallo_hip_march_debug_set(6, 56)
     try:
-        assert L.thallo_hip_iw_march_rc_deferred_fits(2048, 256) == 0          # (a grid sized for 64 workgroups + 8 > 64)
+        assert L.thallo_hip_iw_march_rc_deferred_fits(2048, 256) == 0          # (17 strips x 3 bands = 51 -> 56 workgroups, + 8 > a budget of 56)
     finally:
         L.thallo_hip_march_debug_set(6, 0)
 

@@ -327,6 +327,13 @@ class ThalloSolver:
         if self._L.ThalloX_PlanUseRccl(self.plan, C.addressof(buf), rank, world) != 0:
             raise RuntimeError("ThalloX_PlanUseRccl failed: " + last_error())
 
+    def rccl_info(self):
+        """{world, device, rank} as the plan's own RCCL communicator reports them (ncclCommCount / CuDevice / UserRank); -1 = no communicator."""
+        out = (C.c_int * 3)(-1, -1, -1)
+        self._L.ThalloX_PlanRcclInfo.argtypes = [C.c_void_p, C.c_void_p]; self._L.ThalloX_PlanRcclInfo.restype = None
+        self._L.ThalloX_PlanRcclInfo(self.plan, C.addressof(out))
+        return {"world": out[0], "device": out[1], "rank": out[2]}
+
     def distributed_info(self):
         import json
         t = self._L.ThalloX_PlanDistributedInfo(self.plan).decode()

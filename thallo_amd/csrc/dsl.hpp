@@ -131,6 +131,7 @@ bool generate_source(const Problem& p, Generated& out, std::string& err, bool f6
 // (same expression DAG per residual component, same unknown accesses, same guards).  0 + err if the file is outside the supported subset.
 unsigned long long unit_fingerprint(const char* filename, std::string& err);
 
+const char* generated_prelude();                   // the fixed text every generated unit starts with (Dual, helpers, the wave64 primitives)
 std::string describe(const Problem& p);            // one-line-per-declaration summary (tests / verbosity)
 
 }  // namespace dsl

@@ -31,6 +31,37 @@ namespace thallo {
 
 namespace {
 
+// hipRTC: one translation unit -> a loaded module, for the architecture of the current device
+int rtc_build(const std::string& src, bool wide, const char* what, hipModule_t* mod)
+{
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "thallo_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { set_error("hiprtcCreateProgram failed"); return -1; }
+    // the architecture of the device the plan will run on (a library built for another ARCH must not generate gfx950 code and then blame the device)
+    std::string arch = "--offload-arch=gfx950";
+    {   int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.gcnArchName[0]) {
+            std::string a = pr.gcnArchName; const size_t colon = a.find(':'); if (colon != std::string::npos) a.resize(colon);      // "gfx950:sramecc+:xnack-" -> "gfx950"
+            arch = "--offload-arch=" + a;
+        } else (void)hipGetLastError();
+    }
+    // (a unit with a wide residual -- hundreds of 32-wide dual operations in one function -- takes minutes at -O3 with the loops unrolled: 128 s for the
+    //  reference's 17 x 17 deconvolution against 25 s without unrolling)
+    // (-I: under rocprofv3 the runtime compiler does not find its own <hip/hip_runtime.h>)
+    std::string inc = "-I";        // ROCM_PATH / HIP_PATH as hipcc reads them, else the image's default
+    { const char* rp = getenv("ROCM_PATH"); const char* hp = getenv("HIP_PATH"); inc += (rp && rp[0]) ? rp : (hp && hp[0]) ? hp : "/opt/rocm"; inc += "/include"; }
+    const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics", inc.c_str(), "-fno-unroll-loops" };
+    const hiprtcResult rc = hiprtcCompileProgram(prog, wide ? 5 : 4, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0; hiprtcGetProgramLogSize(prog, &n); std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
+        set_error("%s: hipRTC compilation of the generated kernels failed:\n%.1500s", what, log.c_str());
+        hiprtcDestroyProgram(&prog); return -1;
+    }
+    size_t n = 0; hiprtcGetCodeSize(prog, &n); std::vector<char> code(n); hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    if (hipModuleLoadData(mod, code.data()) != hipSuccess) { set_error("%s: hipModuleLoadData failed for code generated with %s", what, arch.c_str()); (void)hipGetLastError(); return -1; }
+    return 0;
+}
+
 class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     dsl::Problem P;
     bool f64_ = false;                             // doublePrecision = 1: the unit is compiled with thallo_float = double, only the EnergyPlugin64 interface is used
@@ -355,36 +386,12 @@ public:
 
     int compile()
     {
-        hiprtcProgram prog = nullptr;
         // doublePrecision = 1: the same translation unit with `float` standing for double (values, duals, solver vectors, thallo_float arrays, atomics, shuffles);
         // arrays declared with a fixed float type keep reading floats through f32_t
         const std::string f64_prelude = "#define THALLO_F32_T\ntypedef float f32_t;\n#define float double\n#define sqrtf sqrt\n#define sinf sin\n#define cosf cos\n#define fabsf fabs\n"
                                         "#define powf pow\n#define floorf floor\n#define ceilf ceil\n";
         const std::string src = "#include <hip/hip_runtime.h>\n" + (f64_ ? f64_prelude : std::string()) + G.source;
-        if (hiprtcCreateProgram(&prog, src.c_str(), "thallo_generated.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { set_error("hiprtcCreateProgram failed"); return -1; }
-        // the architecture of the device the plan will run on (a library built for another ARCH must not generate gfx950 code and then blame the device)
-        std::string arch = "--offload-arch=gfx950";
-        {   int dev = 0; hipDeviceProp_t pr;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.gcnArchName[0]) {
-                std::string a = pr.gcnArchName; const size_t colon = a.find(':'); if (colon != std::string::npos) a.resize(colon);      // "gfx950:sramecc+:xnack-" -> "gfx950"
-                arch = "--offload-arch=" + a;
-            } else (void)hipGetLastError();
-        }
-        // (a unit with a wide residual -- hundreds of 32-wide dual operations in one function -- takes minutes at -O3 with the loops unrolled: 128 s for the
-        //  reference's 17 x 17 deconvolution against 25 s without unrolling)
-        // (-I: under rocprofv3 the runtime compiler does not find its own <hip/hip_runtime.h>)
-        std::string inc = "-I";        // ROCM_PATH / HIP_PATH as hipcc reads them, else the image's default
-        { const char* rp = getenv("ROCM_PATH"); const char* hp = getenv("HIP_PATH"); inc += (rp && rp[0]) ? rp : (hp && hp[0]) ? hp : "/opt/rocm"; inc += "/include"; }
-        const char* opts[] = { arch.c_str(), "-O3", "-munsafe-fp-atomics", inc.c_str(), "-fno-unroll-loops" };
-        const hiprtcResult rc = hiprtcCompileProgram(prog, G.has_wide ? 5 : 4, opts);
-        if (rc != HIPRTC_SUCCESS) {
-            size_t n = 0; hiprtcGetProgramLogSize(prog, &n); std::string log(n, '\0'); if (n) hiprtcGetProgramLog(prog, &log[0]);
-            set_error("%s: hipRTC compilation of the generated kernels failed:\n%.1500s", P.file.c_str(), log.c_str());
-            hiprtcDestroyProgram(&prog); return -1;
-        }
-        size_t n = 0; hiprtcGetCodeSize(prog, &n); std::vector<char> code(n); hiprtcGetCode(prog, code.data());
-        hiprtcDestroyProgram(&prog);
-                if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { set_error("%s: hipModuleLoadData failed for code generated with %s", label.c_str(), arch.c_str()); (void)hipGetLastError(); return -1; }
+        if (rtc_build(src, G.has_wide, P.file.c_str(), &mod)) return -1;
         for (auto& k : G.kernels) {
             hipFunction_t f = nullptr;
             if (k.name.empty()) { fn.push_back(nullptr); continue; }       // (no gather form for this residual)
@@ -597,6 +604,44 @@ EnergyPlugin* make_generated_plugin(const char* filename, const unsigned* dims, 
 }
 
 }  // namespace thallo
+
+// Known-answer test of the wave64 primitives the generated kernels use -- the text they are generated with, compiled here with hipRTC (tests/cuda_unit_tests/
+// ballot.t:11, get_peers.t:12, reduce_peers.t:14 restated for 64 lanes).  One wave: out_ballot = max over the lanes of ballot(lane != 0) (the reference: 0xFFFFFFFE
+// for 32 lanes); out_peers = sum over the lanes of (the mask of the lanes that share the lane's key lane % 4) & 0xFF (the reference: 255 * 32 / 4); sums4[i] = what
+// wave_add(sums4, lane % 4, lane) leaves = the sum of the lanes with lane % 4 == i (the reference: 112 + 8 i).  0 on success.
+extern "C" int thallo_hip_wave64_selftest(unsigned long long* out_ballot, unsigned* out_peers, float* sums4)
+{
+    if (!out_ballot || !out_peers || !sums4) return -(int)hipErrorInvalidValue;
+    static const char* KAT = R"KAT(
+extern "C" __global__ void k_wave64_kat(unsigned long long* ballot_max, unsigned* peers_sum, float* sums)
+{
+    const int t = threadIdx.x;
+    atomicMax(ballot_max, (unsigned long long)__ballot(t != 0));
+    unsigned long long mine = 0ull;
+    for (int k0 = 0; k0 < 4; ++k0) { const unsigned long long grp = __ballot((t & 3) == k0); if ((t & 3) == k0) mine = grp; }      // wave_add's grouping step
+    atomicAdd(peers_sum, (unsigned)(mine & 0xffull));
+    wave_add(sums, (long)(t & 3), (float)t);
+}
+)KAT";
+    const std::string src = std::string("#include <hip/hip_runtime.h>\n#define NIN 1\n#define NDIM 1\n") + thallo::dsl::generated_prelude() + KAT;
+    hipModule_t mod = nullptr; hipFunction_t f = nullptr;
+    if (thallo::rtc_build(src, false, "wave64 self-test", &mod)) return -1;
+    int rc = -1;
+    void* dev = nullptr;
+    if (hipModuleGetFunction(&f, mod, "k_wave64_kat") == hipSuccess && hipMalloc(&dev, 64) == hipSuccess && hipMemset(dev, 0, 64) == hipSuccess) {
+        unsigned long long* b = (unsigned long long*)dev; unsigned* ps = (unsigned*)((char*)dev + 8); float* sm = (float*)((char*)dev + 16);
+        void* args[] = { &b, &ps, &sm };
+        unsigned char host[64];
+        if (hipModuleLaunchKernel(f, 1, 1, 1, 64, 1, 1, 0, nullptr, args, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(host, dev, 64, hipMemcpyDeviceToHost) == hipSuccess) {
+            memcpy(out_ballot, host, 8); memcpy(out_peers, host + 8, 4); memcpy(sums4, host + 16, 16); rc = 0;
+        }
+    }
+    if (rc) thallo::set_error("wave64 self-test: launch failed");
+    if (dev) hipFree(dev);
+    hipModuleUnload(mod);
+    return rc;
+}
 
 // The front-end without a device (tests, tooling): what = 0 the declarations as text (dsl::describe), 1 the generated HIP translation unit.
 // Returns the length of the text (which is truncated to cap - 1), or -1 with ThalloX_LastError() set.

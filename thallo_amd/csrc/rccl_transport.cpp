@@ -25,12 +25,14 @@ typedef int (*CommDestroy_t)(void* comm);
 typedef int (*AllGather_t)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s);
 typedef int (*AllReduce_t)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s);
 typedef const char* (*GetErrorString_t)(int);
+typedef int (*CommQuery_t)(void* comm, int* out);      // ncclCommCount / ncclCommCuDevice / ncclCommUserRank
 constexpr int kChar = 0, kFloat = 7, kSum = 0;      // ncclChar, ncclFloat32, ncclSum (rccl.h:448-466)
 
 struct Api {
     void* handle = nullptr;
     GetUniqueId_t get_unique_id = nullptr; CommInitRank_t comm_init_rank = nullptr; CommDestroy_t comm_destroy = nullptr;
     AllGather_t all_gather = nullptr; AllReduce_t all_reduce = nullptr; GetErrorString_t error_string = nullptr;
+    CommQuery_t comm_count = nullptr, comm_device = nullptr, comm_rank = nullptr;      // (optional: diagnostics)
     bool tried = false;
     const char* why = "";
 };
@@ -53,6 +55,7 @@ Api& api()
     a.all_gather = (AllGather_t)dlsym(a.handle, "ncclAllGather");
     a.all_reduce = (AllReduce_t)dlsym(a.handle, "ncclAllReduce");
     a.error_string = (GetErrorString_t)dlsym(a.handle, "ncclGetErrorString");
+    a.comm_count = (CommQuery_t)dlsym(a.handle, "ncclCommCount"); a.comm_device = (CommQuery_t)dlsym(a.handle, "ncclCommCuDevice"); a.comm_rank = (CommQuery_t)dlsym(a.handle, "ncclCommUserRank");
     if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather || !a.all_reduce) { a.why = "librccl.so lacks an entry point"; a.handle = nullptr; }
     return a;
 }
@@ -96,6 +99,18 @@ void rccl_comm_destroy(RcclComm* c)
     Api& a = api();
     if (a.handle && c->comm) a.comm_destroy(c->comm);
     delete c;
+}
+
+// what the communicator itself says: ranks in it, this rank's device, this rank's number (-1 where RCCL has no answer).  First contact with a real node: a world of
+// 1 here while torch.distributed says N means the ranks never met
+void rccl_comm_query(RcclComm* c, int out[3])
+{
+    out[0] = out[1] = out[2] = -1;
+    Api& a = api();
+    if (!c || !a.handle || !c->comm) return;
+    if (a.comm_count) { int v = -1; if (a.comm_count(c->comm, &v) == 0) out[0] = v; }
+    if (a.comm_device) { int v = -1; if (a.comm_device(c->comm, &v) == 0) out[1] = v; }
+    if (a.comm_rank) { int v = -1; if (a.comm_rank(c->comm, &v) == 0) out[2] = v; }
 }
 
 int rccl_allgather(RcclComm* c, const void* send, void* recv, long bytes_per_rank, hipStream_t s)

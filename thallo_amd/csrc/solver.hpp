@@ -117,6 +117,7 @@ public:
     // collective; before set_distributed: the plan's own RCCL communicator -- then a NULL all-gather / all-reduce callback means "ncclAllGather / ncclAllReduce on the plan's stream"
     int  use_rccl(const unsigned char* id128, int rank, int world);
     const char* distributed_info() const { return dist_ ? dist_->info.c_str() : ""; }
+    void rccl_info(int out[3]);     // what the plan's RCCL communicator says about itself: world, device, rank (-1: no communicator / no answer)
     int  dist_control(int what, int value);
     int  dist_kernel_only(int reps);      // bench: `reps` back-to-back one-kernel iterations on this rank's slab, no exchange
 

@@ -86,6 +86,8 @@ int Plan::dist_agree(bool flag, bool& all)
     return 0;
 }
 
+void Plan::rccl_info(int out[3]) { out[0] = out[1] = out[2] = -1; if (rccl_) rccl_comm_query(rccl_, out); }
+
 int Plan::use_rccl(const unsigned char* id128, int rank, int world)
 {
     if (!ok_) return -1;

@@ -11,6 +11,7 @@ The reference is single-device (NULL stream everywhere, API/src/util.t:769-772; 
 The CPU statements of the schedules (numpy / scipy compute, gloo) that tests/test_distributed_cpu.py runs are test infrastructure under tests/.
 """
 import ctypes as C
+import json
 import os
 import time
 
@@ -318,6 +319,29 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     c1 = solver.cost()             # amplify the summation order from step to step (the one-GPU plan ends 0.8 % apart between two contraction modes of the same kernel)
     info = solver.info
     p2p = info.get("exchange") == "p2p-mailbox"
+    # First contact with a real node must not be silent: a device-side transport that was asked for and did not come up says so -- one stderr
+    # line per rank with the self-check's words, `transport_fallback` in the JSON line -- and THALLO_DIST_TRANSPORT=device makes it fatal instead of a fallback.
+    strict = os.environ.get("THALLO_DIST_TRANSPORT", "") == "device"
+    ndev = torch.cuda.device_count()
+    my_dev = torch.cuda.current_device() if ndev > 0 else -1
+    rccl = solver.solver.rccl_info()
+    rccl_world = int(reduce(float(rccl["world"]), dist.ReduceOp.MIN))            # (the smallest answer over the ranks: 1 = somebody's communicator is alone)
+    distinct = int(reduce(1.0 if (ndev >= world and my_dev == rank % max(ndev, 1)) else 0.0, dist.ReduceOp.MIN)) == 1
+    fallback, fallback_reason = None, None
+
+    def report_fallback(stage, words):
+        import sys as _sys
+        _sys.stderr.write("[thallo bench] rank %d of %d on device %d (%s devices%s): device-side transport %s -> %s; self-check: %s; library: %s\n" % (
+            rank, world, my_dev, ndev, ", one per rank" if distinct else ", SHARED between ranks", stage,
+            "exiting (THALLO_DIST_TRANSPORT=device)" if strict else "falling back to the RCCL all-gather", json.dumps(words), api.last_error() or "-"))
+        _sys.stderr.flush()
+
+    if use_p2p and not p2p:
+        fallback, fallback_reason = "self-check", info
+        report_fallback("did not pass its self-check at Init", info)
+        if strict:
+            dist.barrier()
+            raise SystemExit(3)
     # graph replay of the GN step is opt-out (THALLO_DIST_GRAPH=0); every rank must agree, so the outcome is all-reduced
     use_graph = os.environ.get("THALLO_DIST_GRAPH", "1") != "0"
 
@@ -348,6 +372,11 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     dt = timed()
     if p2p:
         if reduce(float(solver.solver.distributed_error()), dist.ReduceOp.MAX) > 0:          # a bounded mailbox wait timed out: the numbers above are void -- redo on the all-gather path
+            fallback, fallback_reason = "timed region", solver.info
+            report_fallback("lost a bounded wait inside the timed region", solver.info)
+            if strict:
+                dist.barrier()
+                raise SystemExit(3)
             solver.drop_graph()
             solver.solver.distributed_use_allgather()
             p2p = False
@@ -434,5 +463,7 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
         "ms_per_gn_iter": dt / steps * 1e3, "us_per_pcg_iter": dt / (steps * l_iters) * 1e6,
         "initial_cost": c0, "final_cost": final, "parity_vs_one_gpu": parity, "graph_replay": captured,
         "exchange": "p2p-mailbox" if p2p else "rccl", "p2p_check": info,
+        "transport_fallback": fallback is not None, "transport_fallback_reason": ({"stage": fallback, "self_check": fallback_reason} if fallback else None),
+        "rccl_world": rccl_world, "ranks_on_distinct_devices": distinct, "devices_visible": ndev,
         "roofline": roofline, "cpu_baseline": None,
     }

@@ -8,7 +8,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def mask_devices():
+    # SOAK_MASK=1: the per-rank visibility mask of a real launcher (HIP_VISIBLE_DEVICES=$LOCAL_RANK): every rank sees exactly ONE device and calls it device 0.  On a
+    # one-GPU box that is the same card for everybody, but handles are exported and opened between processes whose device enumerations are private -- as far as one GPU
+    # can emulate "rank r's device 0 is not rank s's device 0" (VERDICT r4 item 5d).  Set before torch / HIP are loaded.
+    if os.environ.get("SOAK_MASK") == "1": os.environ["HIP_VISIBLE_DEVICES"] = "0"
+
+
 def worker(rank, world, port, W, H, steps, L, q):
+    mask_devices()
     import torch, torch.distributed as dist
     from thallo_amd import synthetic as syn
     from thallo_amd.distributed import PlanSlabSolver
@@ -33,6 +41,7 @@ def worker(rank, world, port, W, H, steps, L, q):
 
 
 def worker_other(rank, world, port, W, H, steps, L, q):
+    mask_devices()
     import torch, torch.distributed as dist
     from thallo_amd import synthetic as syn
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)

@@ -8,12 +8,11 @@ in HBM (reference workload: examples/image_warping/src/main.cpp:131-149, 8 GN x 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2048] [--liters 100]
 
 Prints ONE JSON line (rank 0).  `value` = whole-job PCG iterations per second.
-`roofline` = the dominant kernel (PCGIteration: one launch = a whole PCG iteration) measured live with the
-library's HIP-event pair around the PCG loop of every GN step (the loop is L launches of that one kernel);
-`achieved` / `frac` use the bytes the fused schedule has to move (round 4: 74.8 B/pixel -- the A p plane is recomputed, not stored; 99 with THALLO_MARCH=3), the
-reference formulation's 180 B/pixel figure (SURVEY.md 8d) is kept under `reference_formulation`;
-`roofline.applyjtj_standalone` = the plain applyJTJ kernel (48 B/pixel) timed back-to-back
-after the timed region.  `--gpus N` (N > 1) without a launcher: this process starts the N ranks itself.  `cpu_baseline` = oracle/cpu_port_image_warping.c (OpenMP port
+`roofline` = the dominant kernel (PCGIteration: one launch = a whole PCG iteration; round 5: p_k into a ring of planes, 57.1 B/pixel, the delta update a launch of its own
+next to the loop) -- its own launch duration sampled with HIP events on its stream around every 4th launch in three GN steps BEHIND the timed region; the reference
+formulation's 180 B/pixel figure is kept under `reference_formulation`; `roofline.applyjtj_standalone` = the plain applyJTJ kernel (48 B/pixel) timed
+back-to-back after the timed region.  `--gpus N` (N > 1) without a launcher: this process starts the N ranks itself; a device-side transport that does not come up is
+reported per rank on stderr and in `transport_fallback` (THALLO_DIST_TRANSPORT=device: exit 3 instead).  `cpu_baseline` = oracle/cpu_port_image_warping.c (OpenMP port
 of the same algorithm; the reference ships no runnable CPU path) on the host cores, rank 0, N=1 only.
 """
 import argparse
@@ -43,7 +42,7 @@ def fused_bytes_per_iter(L, ring=False):
     return iw_fused_bytes_per_iter(L, ring=ring)
 
 
-FUSED_BYTES_STEP1 = 75          # two-kernel schedule (THALLO_ONE_KERNEL=0, A/B): PCGStep1 = read z 12, p 12, cs 8, flags 1; write p 12, Ap 12 + the delta update every other launch 18
+FUSED_BYTES_STEP1 = 75          # two-kernel schedule (THALLO_AB=one_kernel=0, A/B): PCGStep1 = read z 12, p 12, cs 8, flags 1; write p 12, Ap 12 + the delta update every other launch 18
 ROOFLINE_STEPS = 3              # GN steps AFTER the timed region, with HIP events around every 4th launch of the dominant kernel on its own stream
 
 
@@ -180,12 +179,7 @@ def main():
         dist.destroy_process_group()
         return
 
-    _L = thallo_amd.lib()      # tuning knobs for experiments (tools/sweep_nt.sh); defaults are the product settings
-    if "THALLO_ITER_NT" in os.environ: _L.thallo_hip_debug_set(7, int(os.environ["THALLO_ITER_NT"]))
-    if "THALLO_NT1" in os.environ: _L.thallo_hip_debug_set(3, int(os.environ["THALLO_NT1"]))
-    if "THALLO_NT2" in os.environ: _L.thallo_hip_debug_set2(int(os.environ["THALLO_NT2"]))
-    if "THALLO_PER_CU" in os.environ: _L.thallo_hip_debug_set(5, int(os.environ["THALLO_PER_CU"]))
-    if "THALLO_THREADS" in os.environ: _L.thallo_hip_debug_set(6, int(os.environ["THALLO_THREADS"]))
+    _L = thallo_amd.lib()      # tools knobs of the persistent marching loop (tools/persist_ab.sh); defaults are the product settings
     if "THALLO_PERSIST_ACQ" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(0, int(os.environ["THALLO_PERSIST_ACQ"]))
     if "THALLO_PERSIST_RES" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(1, int(os.environ["THALLO_PERSIST_RES"]))
     if "THALLO_PERSIST_OCC" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(2, int(os.environ["THALLO_PERSIST_OCC"]))
@@ -197,8 +191,8 @@ def main():
     for _ in range(Wm):
         s.step(params)
     torch.cuda.synchronize()
-    # one kernel per PCG iteration (thallo_hip_iw_pcg_iter, the default) vs PCGStep1 + PCGStep2 (THALLO_ONE_KERNEL=0, A/B)
-    one_kernel = os.environ.get("THALLO_ONE_KERNEL", "1") != "0"
+    # one kernel per PCG iteration (thallo_hip_iw_pcg_iter, the default) vs PCGStep1 + PCGStep2 (THALLO_AB=one_kernel=0, A/B)
+    one_kernel = "one_kernel=0" not in os.environ.get("THALLO_AB", "")
     s.reset_kernel_stats()
     # the timed region runs without per-launch events; the dominant kernel's own launch duration is sampled in ROOFLINE_STEPS extra steps behind it (round 5: the
     # PCG loop of a GN step is no longer L launches of one kernel and nothing else -- the delta updates of the ring of p planes run next to it on a second stream)

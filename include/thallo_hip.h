@@ -664,6 +664,18 @@ int thallo_hip_sfs_apply_jtj_sums_fin(int W, int H, int row0, int row1, int yoff
 int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                                  const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* alphaD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream);
+/* The PCG loop of a Gauss-Newton step of bundle adjustment in ONE launch (round 5): min(CUs, 256) workgroups stay on the chip and run the flat update, the camera
+   kernel and the point kernel of thallo_hip_pcg_update(_fin) + thallo_hip_ba_apply_jtj2 as phases of one loop, a grid-wide arrival barrier behind each; every
+   partial, sum and vector element has the bits of the three-launch form.  In: what thallo_hip_ba_pcg_init left (r_0, M^-1, delta = 0, alphaN_0) and the packed point
+   blocks JP.  Out: r_{L-1}, A p_{L-1}, p_{L-1} in p0 / p1 by L & 1 (0: p0), delta without its last term, words[2k] = alphaD_k, words[2k + 1] = betaN_k.
+   xbuf: thallo_hip_ba_resident_bytes() bytes, zeroed once, private to the plan; thallo_hip_ba_resident_status reads the error word a bounded wait that ran out leaves.
+   Replaces gauss_newton.t:1615-1687 (GN branch, one GPU). */
+long thallo_hip_ba_resident_bytes(void);
+int thallo_hip_ba_pcg_resident(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
+                               const float* cameras, const float* points, const float* JP, float* JpC,
+                               float* r, float* Ap, const float* pre, float* p0, float* p1, float* delta, thallo_sum_t alphaN0, float* words, void* xbuf, int L, thallo_stream_t stream);
+int thallo_hip_ba_resident_status(void* xbuf, int clear, unsigned* post_mortem5, thallo_stream_t stream);
+void thallo_hip_ba_resident_debug_set(int what, int value);      /* tools: what 0 = workgroups of the resident loop (0: two per CU) */
 int thallo_hip_ba_apply2_camera_slots(int C_, int P_);      /* how many of thallo_hip_ba_apply_jtj2*'s partial slots (the first ones) are the camera launch's */
 /* LM: applyJTJ with PCGStep1_Finish folded in (gauss_newton.t:774-787): Ap = (J^T J + CtC) p, partials of p . Ap; gate as below (may be NULL) */
 int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

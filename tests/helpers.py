@@ -47,3 +47,15 @@ def oracle_fixture(name, params):
         else:
             h.update(np.float64(a).tobytes())
     return fx if h.hexdigest()[:32] == fx["input_checksum"] else None
+
+
+def set_ab(monkeypatch, **kw):
+    """THALLO_AB=key=value,...: the library's A/B alternatives (csrc/solver.cpp env_switch).  set_ab(monkeypatch, one_kernel="0", fin_in_kernel=None) sets / removes keys
+    and leaves the others as they are."""
+    import os
+    cur = dict(tok.split("=", 1) for tok in os.environ.get("THALLO_AB", "").split(",") if "=" in tok)
+    for k, v in kw.items():
+        if v is None: cur.pop(k, None)
+        else: cur[k] = str(v)
+    if cur: monkeypatch.setenv("THALLO_AB", ",".join(f"{k}={v}" for k, v in cur.items()))
+    else: monkeypatch.delenv("THALLO_AB", raising=False)

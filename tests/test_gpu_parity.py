@@ -13,7 +13,7 @@ import pytest
 
 import thallo_amd
 from thallo_amd import api, synthetic as syn
-from helpers import to_device, to_host, rel_err, copy_params, oracle_fixture
+from helpers import to_device, to_host, rel_err, copy_params, oracle_fixture, set_ab
 
 pytestmark = pytest.mark.gpu
 
@@ -431,7 +431,7 @@ def test_image_warping_deferred_delta_updates_are_bitwise_neutral(torch, monkeyp
     schedule and in the PCGStep1 + PCGStep2 one."""
     W, H = 96, 64
     p = syn.image_warping(W, H, n_markers=6)
-    monkeypatch.setenv("THALLO_ONE_KERNEL", one_kernel)
+    set_ab(monkeypatch, one_kernel=one_kernel)
     res = []
     for batched in ("1", "0"):
         monkeypatch.setenv("THALLO_DELTA_PLANES", batched)
@@ -491,7 +491,7 @@ def test_persistent_marching_loop_is_bitwise_a_launch_per_iteration(torch, monke
     """iterations 1 .. L-1 of a GN step as ONE launch of the marching kernel's grid (energy_image_warping_march_persist.hip: every wave loops over the
     iterations; the sums of iteration k-1 -- a tagged record per workgroup -- are the one synchronisation point; r_k / p_k stored write-through and read past L1, or
     behind one acquire per wave with acq = 1; r of up to `res` rows per wave kept in LDS between the iterations of a launch, only its halo lanes going through memory)
-    against one launch per iteration (THALLO_PERSIST=0).  Same strips, segments, expressions and summation order: costs,
+    against one launch per iteration (THALLO_AB persist=0).  Same strips, segments, expressions and summation order: costs,
     every alpha_k / beta_k and the unknowns BIT-identical after three GN steps.  Sizes: the benchmark's and the 1/2 slab's, ragged strips and segments, one- to
     three-strip images, images of 1 .. 7 rows, rings shorter than the loop (several persistent launches per step with a delta update between them)."""
     p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
@@ -507,7 +507,7 @@ def test_persistent_marching_loop_is_bitwise_a_launch_per_iteration(torch, monke
     runs = []
     try:
         for persist in ("0", "1"):
-            monkeypatch.setenv("THALLO_PERSIST", persist)
+            set_ab(monkeypatch, persist=persist)
             dev = to_device(copy_params(p))
             s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=2)
             s.set_solver_parameters(nIterations=3, lIterations=lit)
@@ -1319,6 +1319,36 @@ def test_bundle_adjustment_ladybug_1723_shape(torch):
     assert outs[0][0][-1] < outs[0][0][0]
 
 
+@pytest.mark.parametrize("C_,P_,O_,nit,lit", [(1723, 156502, 678718, 2, 30), (64, 4000, 20000, 3, 50), (12, 60, 300, 3, 7), (3, 10, 30, 2, 3), (700, 300000, 900000, 2, 12)])
+def test_bundle_adjustment_resident_pcg_loop_is_bitwise_three_launches_per_iteration(torch, monkeypatch, C_, P_, O_, nit, lit):
+    """the PCG loop of a Gauss-Newton step of bundle adjustment in ONE launch (energy_ba.hip k_ba_resident: the flat update, the camera kernel and the
+    point kernel as phases of a persistent loop, an arrival barrier behind each; every physical workgroup walks the launch-per-iteration grid's blocks with those
+    kernels' own mapping) against PCGUpdate + two gather launches per iteration (THALLO_RESIDENT=0): costs, every alpha_k / beta_k and the unknowns BIT-identical --
+    the ladybug-1723 shape, small and tiny problems, and one with more points than one point block per workgroup slot covers (the point kernel's grid-stride loop)."""
+    p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=min(8, C_)) if (C_, P_, O_) != (1723, 156502, 678718) else syn.bundle_adjustment()
+    runs = []
+    for res in ("0", "2"):           # (2: bundle adjustment's resident loop is opt-in -- measured slower than the three launches it replaces, profiles/r05/ba_resident_phases.txt)
+        monkeypatch.setenv("THALLO_RESIDENT", res)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((C_, P_, O_), thallo_amd.energy_file("bundle_adjustment"), timing_level=2)
+        s.set_solver_parameters(nIterations=nit, lIterations=lit)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        names = s.kernel_stats()
+        assert api.last_error() in ("", None) or "resident" not in api.last_error(), api.last_error()
+        s.close()
+        runs.append((costs, traces, dev[0].clone(), dev[1].clone(), names))
+    (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == nit + 1 and len(t0[0]) == lit
+    assert "PCGLoopResident" not in n0 and n1["PCGLoopResident"]["launches"] == nit and "PCGUpdate" not in n1, (sorted(n0), sorted(n1))
+    assert t0 == t1, [(i, k) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1)
+
+
 # ------------------------------------------------------------------ Levenberg-Marquardt branch (a-9)
 def _solve_gpu_lm(fname, dims, params_np, **sp):
     dev = to_device(params_np)
@@ -1360,7 +1390,7 @@ def test_lm_trajectory_matches_oracle(torch, orc, which):
 @pytest.mark.parametrize("which", ["iw", "arap", "sfs", "ba"])
 def test_in_kernel_scalar_finish_is_bitwise_the_separate_launch(torch, which, monkeypatch):
     """The last workgroup of the iteration's (last) kernel finishes alphaD_k / betaN_k itself (device_common.hpp block_finish_sums,
-    iw_device.hpp iter_tail); THALLO_FIN_IN_KERNEL=0 runs the one-wave PCGScalars launch instead: same summation order, same bits."""
+    iw_device.hpp iter_tail); THALLO_AB fin_in_kernel=0 runs the one-wave PCGScalars launch instead: same summation order, same bits."""
     if which == "iw":
         dims, p, name = (96, 80), syn.image_warping(96, 80, n_markers=8), "image_warping"
     elif which == "arap":
@@ -1372,8 +1402,7 @@ def test_in_kernel_scalar_finish_is_bitwise_the_separate_launch(torch, which, mo
     out = []
     for fin in ("1", "0", None):      # None = the default: in the single-reduction GN loop (bundle adjustment; ARAP where its resident loop does not run) the finish of iteration
         # k - 1 rides in the flat update of iteration k (thallo_hip_pcg_update_fin: every workgroup adds the partials up for itself); elsewhere the in-kernel finish
-        if fin is None: monkeypatch.delenv("THALLO_FIN_IN_KERNEL", raising=False)
-        else: monkeypatch.setenv("THALLO_FIN_IN_KERNEL", fin)
+        set_ab(monkeypatch, fin_in_kernel=fin)
         dev = to_device(copy_params(p))
         s = api.ThalloSolver(dims, thallo_amd.energy_file(name))
         _, costs = s.solve(dev, profiled=True, nIterations=3, lIterations=25)
@@ -1388,14 +1417,13 @@ def test_in_kernel_scalar_finish_is_bitwise_the_separate_launch(torch, which, mo
 def test_lm_finish_deferred_into_the_next_flat_update_is_bitwise_the_in_kernel_finish(torch, monkeypatch, q_tolerance):
     """Bundle adjustment's LM iteration is three launches (flat update, camera gather, point gather).  By default the two gather launches leave per-workgroup partials and the
     flat update of the NEXT iteration finishes them in every workgroup -- alphaD, betaN, q, the zeta test (thallo_hip_pcg_update_lm_fin); iterations that a residual reset follows
-    and the last one finish in the point launch's last workgroup, as every iteration does with THALLO_FIN_IN_KERNEL=1.  Same arithmetic, same order: costs, unknowns, alpha / beta
+    and the last one finish in the point launch's last workgroup, as every iteration does with THALLO_AB fin_in_kernel=1.  Same arithmetic, same order: costs, unknowns, alpha / beta
     traces and PCG iteration counts bit for bit, with resets (lIterations = 40) and, at q_tolerance = 0.02, early exits that fall on deferred and on own finishes alike."""
     p = syn.bundle_adjustment(C=24, P=400, O=2400, band=8)
     sp = dict(nIterations=4, lIterations=40, q_tolerance=q_tolerance)
     runs = []
     for fin in ("1", None):
-        if fin is None: monkeypatch.delenv("THALLO_FIN_IN_KERNEL", raising=False)
-        else: monkeypatch.setenv("THALLO_FIN_IN_KERNEL", fin)
+        set_ab(monkeypatch, fin_in_kernel=fin)
         dev = to_device(copy_params(p))
         s = api.ThalloSolver((24, 400, 2400), thallo_amd.energy_file("bundle_adjustment"), solverkind="levenberg_marquardt")
         s.enable_lm()
@@ -1486,7 +1514,7 @@ np.save({out!r}, np.concatenate([to_host(dev[16]).ravel(), np.array(costs, np.fl
 
 @pytest.mark.parametrize("lm", [0, 1])
 def test_shape_from_shading_apply_forms_agree(torch, tmp_path, lm):
-    """THALLO_SFS_FUSED = 1 (default: the fused, LDS-tiled J^T(J v) kernel) and 0 (two passes with U and R in global memory): same expressions in the same
+    """THALLO_AB sfs_fused = 1 (default: the fused, LDS-tiled J^T(J v) kernel) and 0 (two passes with U and R in global memory): same expressions in the same
     order per pixel, a different number of reduction partials -- the depth map and the costs after 3 x 8 iterations agree to rounding.  A ragged size (130 x 67: partial tiles, image borders inside every
     halo).  The form is read once per process, hence the child processes."""
     import subprocess
@@ -1496,7 +1524,7 @@ def test_shape_from_shading_apply_forms_agree(torch, tmp_path, lm):
     for form in ("1", "0"):
         out = str(tmp_path / f"sfs_form{form}.npy")
         code = _SFS_FORM_SNIPPET.format(root=root, tests=os.path.join(root, "tests"), W=130, H=67, lm=lm, out=out)
-        env = dict(os.environ, THALLO_SFS_FUSED=form)
+        env = dict(os.environ, THALLO_AB="sfs_fused=" + form)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
@@ -1520,7 +1548,7 @@ def test_shape_from_shading_marching_kernel_matches_the_tile_kernel(torch):
 
 @pytest.mark.parametrize("lm", [0, 1])
 def test_shape_from_shading_marching_and_tile_solves_agree(torch, tmp_path, lm):
-    """Whole solves (GN and LM, 3 x 8 iterations, 130 x 67) with THALLO_SFS_MARCH = 1 (default) and 0: depth map and costs agree to rounding."""
+    """Whole solves (GN and LM, 3 x 8 iterations, 130 x 67) with THALLO_AB sfs_march = 1 (default) and 0: depth map and costs agree to rounding."""
     import subprocess
     import sys
     outs = []
@@ -1528,7 +1556,7 @@ def test_shape_from_shading_marching_and_tile_solves_agree(torch, tmp_path, lm):
     for form in ("1", "0"):
         out = str(tmp_path / f"sfs_march{form}.npy")
         code = _SFS_FORM_SNIPPET.format(root=root, tests=os.path.join(root, "tests"), W=130, H=67, lm=lm, out=out)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, THALLO_SFS_MARCH=form), capture_output=True, text=True, timeout=300)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, THALLO_AB="sfs_march=" + form), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
     a, b = outs
@@ -1540,11 +1568,11 @@ def test_shape_from_shading_marching_and_tile_solves_agree(torch, tmp_path, lm):
 @pytest.mark.parametrize("W,H", [(130, 67), (256, 256)])
 def test_shape_from_shading_one_kernel_iteration(torch, orc, monkeypatch, W, H):
     """GN on one GPU: ONE launch per PCG iteration (the marching kernel with PCGUpdate riding along: r_k, p_k formed per row, r / Ap / p ping-pong,
-    the three sums from registers; thallo_hip_sfs_pcg_iter) against the two-launch form (THALLO_ONE_KERNEL=0: PCGUpdate + applyJTJ with sums) and the oracle."""
+    the three sums from registers; thallo_hip_sfs_pcg_iter) against the two-launch form (THALLO_AB one_kernel=0: PCGUpdate + applyJTJ with sums) and the oracle."""
     p = syn.shape_from_shading(W, H)
     runs = []
     for one in ("1", "0"):
-        monkeypatch.setenv("THALLO_ONE_KERNEL", one)
+        set_ab(monkeypatch, one_kernel=one)
         dev = to_device(p)
         s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"))
         s.set_kernel_sampling(1)
@@ -1620,7 +1648,7 @@ def test_sampled_timer_scopes_nest(torch):
 def test_lm_step3_folded_into_the_apply(torch, monkeypatch, which):
     """LM on one GPU: PCGStep3 rides in shape_from_shading's marching apply (p_k = z + beta p_{k-1} formed per row, p ping-pong;
     thallo_hip_sfs_pcg_iter_lm); bundle adjustment runs the single-reduction form (thallo_hip_pcg_update_lm + thallo_hip_ba_pcg_apply_lm: the flat vector update carries
-    PCGStep3, the gather launches all sums and the zeta test) -- against the reference-shaped loop with its separate PCGStep3 / PCGStep2 launches (THALLO_LM_FOLD_P=0): same costs
+    PCGStep3, the gather launches all sums and the zeta test) -- against the reference-shaped loop with its separate PCGStep3 / PCGStep2 launches (THALLO_AB lm_fold_p=0): same costs
     and unknowns to rounding, same PCG iteration counts with the zeta exit exercised, and one launch less per iteration (no PCGStep3 in the kernel census)."""
     if which == "sfs":
         fname, dims, p, sp, ui, tol = "shape_from_shading", (130, 67), syn.shape_from_shading(130, 67), dict(nIterations=5, lIterations=10, q_tolerance=0.2), 16, 1e-5
@@ -1629,7 +1657,7 @@ def test_lm_step3_folded_into_the_apply(torch, monkeypatch, which):
         fname, dims, sp, ui, tol = "bundle_adjustment", (24, 400, 2400), dict(nIterations=4, lIterations=40, q_tolerance=0.02), 1, 2e-4
     runs = []
     for fold in ("1", "0"):
-        monkeypatch.setenv("THALLO_LM_FOLD_P", fold)
+        set_ab(monkeypatch, lm_fold_p=fold)
         dev = to_device(p)
         s = api.ThalloSolver(dims, thallo_amd.energy_file(fname), solverkind="levenberg_marquardt")
         s.enable_lm()

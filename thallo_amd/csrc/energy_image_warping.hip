@@ -57,7 +57,7 @@ inline int grid_for(const Geo& g, int per_cu)
 }
 inline int check_launch() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
 
-// tools/microbench.py hooks (not product API): diagnostic mode 1 = skip arithmetic, 2 = skip loads;
+// debug hooks of rounds 1-2's kernel experiments (thallo_hip_debug_set; not product API): diagnostic mode 1 = skip arithmetic, 2 = skip loads;
 // cache-policy bits for PCGStep1: 1 delta nt, 2 cs/UrShape/flags nt, 4 p_in nt, 8 Ap nt, 32 z nt, 64 p_out nt
 int g_iw_debug = 0;
 int g_step1_threads = 512; // fused step: 512 threads x 2 px/thread (default) or 256 x 4
@@ -65,7 +65,7 @@ int g_step1_per_cu = 3; // microbench: workgroups per CU for the fused step (3 =
 int g_no_grid = 0;      // microbench: 1 = ignore the regular-grid fast path
 int g_iter_per_cu = 2;    // microbench: workgroups per CU of the one-kernel iteration (2 = VGPR limit at 512 threads)
 int g_iter_nt = 31;      // one-kernel iteration, non-temporal bits: 1 delta, 2 r/Ap loads, 4 r/Ap stores, 8 p loads, 16 p stores, 32 cs/flags (31 measured best)
-int g_nt_mask = 1;      // delta non-temporal: measured +1-3 % PCG it/s at 2048^2 (tools/sweep_nt.sh)
+int g_nt_mask = 1;      // delta non-temporal: measured +1-3 % PCG it/s at 2048^2 (round 1, docs/history)
 
 struct Tile {
     float px[LN], py[LN], pa[LN];   // step: CG direction p ; init: offset.x, offset.y

@@ -30,7 +30,7 @@ inline int flat_grid(long n4, int cus)
 }
 
 int g_cus = 0;
-int g_nt2 = 3;   // cache policy: bit0 r load/store nt, bit1 pre load nt (measured best, tools/sweep_nt.sh), bit2 Ap load nt, bit3 z store nt
+int g_nt2 = 3;   // cache policy: bit0 r load/store nt, bit1 pre load nt (measured best in round 1, docs/history), bit2 Ap load nt, bit3 z store nt
 int cu_count()
 {
     if (!g_cus) {

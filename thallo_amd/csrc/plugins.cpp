@@ -760,6 +760,8 @@ class BundleAdjustmentPlugin : public EnergyPlugin {
     float *cameras = nullptr, *points = nullptr; const float* obs = nullptr; const int *oToC = nullptr, *oToP = nullptr;
     DeviceBuffer cam_ptr, cam_obs, q_cam, q_pt, pt_ptr, pt_pos, Jb, F;
     DeviceBuffer q_ptk, JP, JpP;          // J^T (J p) with J p formed once (thallo_hip_ba_apply_jtj2): point-order position per observation, packed point blocks, J p
+    DeviceBuffer xres_;                   // control words, arrival counters and partial slots of the resident PCG loop (thallo_hip_ba_pcg_resident)
+    bool resident_ = false, resident_broken_ = false;
     int apply2(LaunchCtx& c, SolverVectors* v, const float* p, float* Ap, float* out, const thallo_fin_t& fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr })
     {
         return thallo_hip_ba_apply_jtj2_fin(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr,
@@ -806,8 +808,29 @@ public:
                 if (rc < 0 || se != hipSuccess) { set_error("bundle_adjustment: point order failed (launch %d, sync %d: %s)", rc, (int)se, hipGetErrorString(rc < 0 ? (hipError_t)(-rc) : se)); return -1; }
             }
         }
+        // the PCG loop of a GN step in one launch (whole problem on one GPU) -- THALLO_RESIDENT=2 only: bit-identical to three launches per iteration but SLOWER at the
+        // ladybug shape (40.8 against 31.0 us per PCG iteration, profiles/r05/ba_resident_phases.txt: three grid-wide barriers of ~3 us each cost what the launch
+        // boundaries did, and a static share of the camera blocks per workgroup balances worse than the hardware's dispatch of 431 of them)
+        resident_ = false;
+        {   const char* er = env_switch("THALLO_RESIDENT");
+            if (er && er[0] == '2' && !resident_broken_) {
+                const long need = thallo_hip_ba_resident_bytes();
+                if ((long)xres_.bytes < need && xres_.alloc((size_t)need)) { set_error("bundle_adjustment: out of device memory for the resident loop's exchange buffer"); return -1; }
+                resident_ = true;
+            }
+        }
         return 0;
     }
+    bool resident_ok() const override { return resident_; }
+    int pcg_resident(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words) override
+    {
+        TimedLaunch t(c, "PCGLoopResident");
+        const int rc = thallo_hip_ba_pcg_resident(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, points,
+                                                  (const float*)JP.ptr, (float*)JpP.ptr, v.r, v.Ap, v.pre, v.p[0], v.p[1], v.delta, aN0, words, xres_.ptr, L, c.stream);
+        return rc;
+    }
+    int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_ba_resident_status(xres_.ptr, clear, pm, c.stream) : 0; }
+    void resident_disable() override { resident_ = false; resident_broken_ = true; }
     float* unknown_ptr(int k) override { return k == 0 ? cameras : points; }
     int cost(LaunchCtx& c, float* out) override
     { TimedLaunch t(c, "computeCost"); return thallo_hip_ba_cost(C, P, O, cameras, points, obs, oToC, oToP, out, c.stream); }

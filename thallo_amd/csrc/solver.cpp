@@ -187,32 +187,52 @@ int Plan::ensure_slots(int L)
 }
 
 // ------------------------------------------------------------------ A/B switches
-// Every environment switch of the library, in this one table (the only getenv of a switch in thallo_amd/csrc; dsl_plugin.cpp reads ROCM_PATH / HIP_PATH for hipRTC).  Each selects an alternative that computes the same thing and that a
-// test or a tool still compares with the default; what lost its comparison in rounds 1-2 is gone (the blocking zeta test, the one-kernel bundle-adjustment
-// gather, THALLO_FINISH_SUMS / EXPANDED / DEFER_FINISH / LM_FOLD_CTC / LM_ZETA_IN_STEP2 / DIST_MEM / FRONTEND_DUMP).
+// Every environment switch of the library, in this one function (the only getenv of a switch in thallo_amd/csrc; dsl_plugin.cpp reads ROCM_PATH / HIP_PATH for hipRTC).
+// Eight names (README.md has the table).  Seven are what a user may want to set; the eighth, THALLO_AB, is a comma-separated list of key=value pairs for the A/B
+// alternatives that exist because a test or a tool still compares them with the default (round 5: they were seven names of their own) -- callers inside the
+// library keep asking for them by their old names.  What lost its comparison in rounds 1-2 is gone (the blocking zeta test, the one-kernel bundle-adjustment gather,
+// THALLO_FINISH_SUMS / EXPANDED / DEFER_FINISH / LM_FOLD_CTC / LM_ZETA_IN_STEP2 / DIST_MEM / FRONTEND_DUMP); round 5 replaced THALLO_BATCH_DELTA by THALLO_DELTA_PLANES.
 const char* env_switch(const char* name)
 {
     static const char* const known[] = {
-        "THALLO_RESIDENT",            // 0: image_warping runs one launch per PCG iteration even where the whole PCG loop fits one resident launch
-        "THALLO_PERSIST",             // 1: iterations 1 .. L-1 of a GN step of image_warping's marching kernel as persistent launches (bit-identical; measured slower than a launch per iteration: opt-in)
-        "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up); 3: the marching kernel with the stored A p plane (round 2/3); 4 = 2 + 3
-        "THALLO_ONE_KERNEL",          // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
-        "THALLO_FIN_IN_KERNEL",       // 0: the iteration's two scalars by a separate one-wave launch; 1: by the last workgroup of the iteration's kernel everywhere; unset: that, except in the
-                                      //    single-reduction GN loop of the gather plugins, where the finish of iteration k-1 is folded into the flat update of iteration k
+        "THALLO_RESIDENT",            // 0: image_warping / ARAP run one launch per PCG iteration even where the whole PCG loop fits one resident launch; 2: also bundle adjustment's resident
+                                      //    PCG loop (bit-identical, measured slower than its three launches per iteration: opt-in)
+        "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up); 3: the marching kernel with the
+                                      //    stored A p plane (round 2/3); 4 = 2 + 3
         "THALLO_DELTA_PLANES",        // how often the one-kernel GN loop touches delta.  0: delta += alpha p every iteration (the reference's order of work); 1: every other iteration
-                                      //    (round 4); N >= 2: a ring of N p planes, delta updated when the ring is full (where the plugin's kernel takes any p plane);
+                                      //    (round 4); N >= 2: a ring of N p planes, delta updated per half ring next to the loop (where the plugin's kernel takes any p plane);
                                       //    unset: the ring where offered, sized by lIterations and the device's free memory, else 1; -N: the ring of N planes with its
-                                      //    updates on the loop's own stream instead of next to it (A/B)
-        "THALLO_LM_FOLD_P",           // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own even where the plugin's marching kernel can carry them
-        "THALLO_SFS_FUSED",           // 0: shape_from_shading's two-pass applyJTJ (round 1)
-        "THALLO_SFS_MARCH",           // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
+                                      //    updates on the loop's own stream instead of next to it (A/B); "N:W": the update on at most W workgroups
         "THALLO_DIST_P2P",            // 0: never the device-side exchange
         "THALLO_FRONTEND",            // off / generate: see api.cpp
-        "THALLO_FRONTEND_AGGREGATE",  // 0: generated kernels scatter with plain atomics everywhere
         "THALLO_DENSE_JTJ_MAX",       // largest n for the dense [JtJ]p schedule of generated plugins
         "THALLO_ENABLE_DIRECT_SOLVE", // 1: honour <handle>:set_direct_solve(true) (compiled out in the reference: gauss_newton.t:22)
     };
+    static const char* const ab[][2] = {      // THALLO_AB=key=value,...
+        { "THALLO_ONE_KERNEL", "one_kernel" },                  // 0: PCGStep1 + PCGStep2 even where the plugin offers the one-kernel iteration
+        { "THALLO_FIN_IN_KERNEL", "fin_in_kernel" },            // 0: the iteration's two scalars by a separate one-wave launch; 1: by the last workgroup of the iteration's kernel everywhere;
+                                                                //    absent: that, except where the finish of iteration k-1 is folded into the first launch of iteration k
+        { "THALLO_LM_FOLD_P", "lm_fold_p" },                    // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own
+        { "THALLO_SFS_FUSED", "sfs_fused" },                    // 0: shape_from_shading's two-pass applyJTJ (round 1)
+        { "THALLO_SFS_MARCH", "sfs_march" },                    // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
+        { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere
+        { "THALLO_PERSIST", "persist" },                        // 1: iterations 1 .. L-1 of a GN step of image_warping's marching kernel as persistent launches (bit-identical, measured slower)
+    };
     for (const char* k : known) if (!strcmp(k, name)) return getenv(name);
+    for (size_t i = 0; i < sizeof(ab) / sizeof(ab[0]); ++i) {
+        if (strcmp(ab[i][0], name)) continue;
+        static std::string slot[sizeof(ab) / sizeof(ab[0])];
+        const char* e = getenv("THALLO_AB");
+        if (!e) return nullptr;
+        const size_t kl = strlen(ab[i][1]);
+        for (const char* t = e; *t; ) {
+            while (*t == ',' || *t == ' ') ++t;
+            const char* end = t; while (*end && *end != ',' && *end != ' ') ++end;
+            if ((size_t)(end - t) > kl && !strncmp(t, ab[i][1], kl) && t[kl] == '=') { slot[i].assign(t + kl + 1, end); return slot[i].c_str(); }
+            t = end;
+        }
+        return nullptr;
+    }
     set_error("internal: unknown environment switch %s", name);
     return nullptr;
 }

@@ -21,6 +21,6 @@ if os.environ.get("BA_TIME_ONLY") == "gn":
 if os.environ.get("BA_TIME_ONLY") == "lm":      # under rocprofv3: the LM loop's kernels only
     print(json.dumps([run(True), run(True)])); sys.exit(0)
 out = [run(False), run(True), run(False), run(True)]
-os.environ["THALLO_LM_FOLD_P"] = "0"           # the reference-shaped LM loop (A/B)
+os.environ["THALLO_AB"] = "lm_fold_p=0"           # the reference-shaped LM loop (A/B)
 out += [dict(run(True), lm_fold_p=0), dict(run(True), lm_fold_p=0)]
 print(json.dumps(out))

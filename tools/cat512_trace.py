@@ -15,8 +15,8 @@ c_img = F.constraint_image(cons, mask, np.float32(1) / np.float32(19))
 P = lambda: [ur.copy(), np.zeros((H, W), np.float32), ur.copy(), c_img.copy(), mask.copy(), wf, wr]
 ref = orc.cpu_port_image_warping(W, H, P(), 1, 100, want_trace=True)
 out = {}
-for tag, env in (("march", {}), ("tile", {"THALLO_MARCH": "0"}), ("two", {"THALLO_ONE_KERNEL": "0"})):
-    for k in ("THALLO_MARCH", "THALLO_ONE_KERNEL"):
+for tag, env in (("march", {}), ("tile", {"THALLO_MARCH": "0"}), ("two", {"THALLO_AB": "one_kernel=0"})):
+    for k in ("THALLO_MARCH", "THALLO_AB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else x for x in P()]

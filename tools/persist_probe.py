@@ -4,7 +4,7 @@ import os, sys, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ.setdefault("THALLO_LIB", os.path.join(ROOT, "tools", "ab", "libThallo_pstamps.so"))
-os.environ["THALLO_PERSIST"] = "1"
+os.environ["THALLO_AB"] = "persist=1"
 import torch, thallo_amd
 from thallo_amd import synthetic as syn
 W = H = int(os.environ.get("PP_SIZE", 2048))

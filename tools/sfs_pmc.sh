@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 counter passes over the shape_from_shading 2048^2 GN configuration (tools/sfs_pmc.py) -- what bounds the applyJTJ kernels (the LDS-tiled k_fused of
-# THALLO_SFS_MARCH=0, the marching k_march variants by default).
+# THALLO_AB=sfs_march=0, the marching k_march variants by default).
 # Run on the GPU box through gpurun; summary in gpurun_out/sfs_pmc_summary.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out

@@ -1,5 +1,5 @@
 """shape_from_shading 2048^2 per PCG iteration through Thallo_ProblemStep, no kernel timers: Gauss-Newton and LM (10 PCG iterations per step, the reference's budget), with the
-finish of iteration k-1 deferred into the launch of iteration k (default) and with the in-kernel finish (THALLO_FIN_IN_KERNEL=1), alternating in one process.  python tools/sfs_time.py"""
+finish of iteration k-1 deferred into the launch of iteration k (default) and with the in-kernel finish (THALLO_AB=fin_in_kernel=1), alternating in one process.  python tools/sfs_time.py"""
 import json, os, sys, time
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/thallo_amd") else os.getcwd())
 import numpy as np, torch
@@ -10,8 +10,8 @@ p = syn.shape_from_shading(W, H)
 
 
 def run(lm, fin, steps=12, L=10):
-    if fin is None: os.environ.pop("THALLO_FIN_IN_KERNEL", None)
-    else: os.environ["THALLO_FIN_IN_KERNEL"] = fin
+    if fin is None: os.environ.pop("THALLO_AB", None)
+    else: os.environ["THALLO_AB"] = "fin_in_kernel=" + fin
     dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() if isinstance(a, np.ndarray) else float(a) for a in p]
     s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), timing_level=0)
     if lm: s.enable_lm()

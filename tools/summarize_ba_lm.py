@@ -14,7 +14,7 @@ for tag in ("new", "old"):
     rows.sort(key=lambda x: -x["total_ms"])
     log = open(os.path.join(ROOT, "gpurun_out", "ba_lm_%s.log" % tag)).read()
     m = re.findall(r'"us_per_pcg_iter": ([0-9.]+)', log)
-    out["single_reduction_form" if tag == "new" else "reference_shaped_form (THALLO_LM_FOLD_P=0)"] = {"us_per_pcg_iter_under_the_profiler": [float(x) for x in m], "kernels": rows[:10]}
+    out["single_reduction_form" if tag == "new" else "reference_shaped_form (THALLO_AB=lm_fold_p=0)"] = {"us_per_pcg_iter_under_the_profiler": [float(x) for x in m], "kernels": rows[:10]}
 os.makedirs(os.path.join(ROOT, "profiles", rnd), exist_ok=True)
 json.dump({"source": "tools/profile_ba_lm.sh: rocprofv3 --kernel-trace --stats of tools/ba_time.py (BA_TIME_ONLY=lm), ladybug-1723 shape, LM 5 x 150 twice", "loops": out},
           open(os.path.join(ROOT, "profiles", rnd, "ba_lm_loops.json"), "w"), indent=1)

@@ -3,7 +3,7 @@ profiles/<round>/ and profiles/traffic_latest.json (read by bench.py for rooflin
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 out = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
@@ -17,7 +17,7 @@ for f in ("bench_under_rocprof.json", "bench_plain.json"):
 
 def short(name):
     for key, lab in (("k_iter_finish", "PCGScalars"), ("k_iter_march_rc<", "PCGIteration"), ("k_iter_march<", "PCGIteration"), ("k_iter<", "PCGIteration"), ("k_step1<true", "PCGStep1_fused"), ("k_step1<false", "applyJTJ_plain"), ("k_step2_iw", "PCGStep2"), ("k_step2<", "PCGStep2_generic"), ("k_init", "PCGInit1"),
-                     ("k_linear_update", "PCGLinearUpdate"), ("k_cost", "computeCost")):
+                     ("k_linear_update_n", "PCGDeltaUpdate"), ("k_linear_update", "PCGLinearUpdate"), ("k_cost", "computeCost")):
         if key in name:
             return lab
     return None

@@ -263,6 +263,10 @@ def main():
                      "timing": (f"HIP events on the kernel's stream around every 4th launch of it, in {ROOFLINE_STEPS} GN steps run behind the timed region" if one_kernel
                                 else "HIP events around every 16th launch of the kernel"),
                      "pcg_loop_ms_per_iteration": perf["linearSolve"]["meanMS"] / L_it,
+                     # the whole schedule's HBM rate: the loop's bytes per iteration (the marching launch + the delta update's 12 per term + 24 per 16-term launch) over
+                     # the loop's time per iteration -- information next to the contract's per-kernel figure above
+                     "schedule": ({"bytes_per_pixel_per_iteration": dom_bytes + 13.5, "achieved": (dom_bytes + 13.5) * npx / (perf["linearSolve"]["meanMS"] / L_it * 1e-3) / 1e9,
+                                   "frac": (dom_bytes + 13.5) * npx / (perf["linearSolve"]["meanMS"] / L_it * 1e-3) / 1e9 / HBM_PEAK_GBS} if ring and one_kernel and not persistent else None),
                      "note": "achieved = bytes_per_pixel x pixels / avg launch time: the bytes this fused kernel has to move, each array once "
                              "(DESIGN.md section 4).  Round 4 removed the A p plane from the iteration (99 -> 74.8 B/pixel); round 5 took the delta update out of "
                              "it (-> 57.1 B/pixel: p_k goes into a ring of planes and delta takes 32 of them per PCGDeltaUpdate launch, 12.75 B/pixel/iteration "

@@ -537,6 +537,38 @@ def test_persistent_marching_loop_is_bitwise_a_launch_per_iteration(torch, monke
     assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
+def test_ring_of_p_planes_on_a_callers_stream(torch, monkeypatch):
+    """The delta updates of the ring run on the plan's second stream and are ordered against the loop's stream by events: the same bits whether the loop's stream is the
+    NULL stream (the reference's, util.t:769-772) or a non-blocking stream the caller hands in with ThalloX_SetStream -- with other work queued on the NULL stream
+    meanwhile (a non-blocking stream does not wait for it) -- and whether lIterations grows between two solves of one plan (the ring is extended)."""
+    W, H = 1024, 768
+    p = syn.image_warping(W, H, n_markers=8, mask_disc=0.1)
+    monkeypatch.setenv("THALLO_RESIDENT", "0")
+    outs = []
+    for mode in ("null", "own"):
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
+        st = torch.cuda.Stream() if mode == "own" else None
+        if st is not None:
+            torch.cuda.synchronize()
+            s.set_stream(st.cuda_stream)
+        costs = []
+        for lit in (9, 40):                      # the second solve needs more planes than the first allocated
+            s.set_solver_parameters(nIterations=2, lIterations=lit)
+            params = s.make_params(dev)
+            s.init(params)
+            noise = torch.empty(1 << 22, device="cuda")
+            while s.step(params):
+                noise.normal_()                  # unrelated work on the NULL stream between the steps
+                costs.append(s.current_cost())
+        if st is not None: st.synchronize()
+        torch.cuda.synchronize()
+        s.close()
+        outs.append((costs, dev[0].clone(), dev[1].clone()))
+    assert all(np.isfinite(outs[0][0])) and outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 def test_deferred_cross_rank_finish_is_refused_where_its_grid_cannot_be_resident(torch):
     """the deferred cross-rank finish of the marching kernel makes every working wave wait for the launch's LAST workgroup, so the whole grid -- plus
     its eight extra workgroups -- must fit the device at the two workgroups per CU the kernel is built for.  march_pick_rows sizes a wide slab's grid for up to four per

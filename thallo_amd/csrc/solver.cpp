@@ -552,6 +552,9 @@ int Plan::step_gn_one_kernel(int ev_iter)
         }
         return 0;
     };
+    // whichever way this function is left, the loop's stream ends up behind every update that went out on the second stream: the next step's PCGInit1 zeroes delta
+    // (on a failed launch too -- the caller may call Step again)
+    struct Join { hipStream_t s; const std::vector<Sent>* sent; ~Join() { if (!sent->empty()) (void)hipStreamWaitEvent(s, sent->back().done, 0); } } join_on_exit{ s, &sent };
     auto wait_for = [&](int term) -> int {        // the loop's stream goes on only when the update that took p_term has run
         for (const Sent& q : sent) {
             if (q.upto < synced) continue;

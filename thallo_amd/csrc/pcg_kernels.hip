@@ -536,10 +536,20 @@ __global__ __launch_bounds__(BLOCK) void k_linear_update_n(float* __restrict__ X
         for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
             float4 d = reinterpret_cast<const float4*>(delta)[i];
             int j = 0;
-            for (; j + 4 <= T.count; j += 4) {      // four planes' loads in flight per lane (the terms are still applied one after the other)
+            for (; j + 8 <= T.count; j += 8) {      // eight planes' loads in flight per lane (the terms are still applied one after the other): a background launch on 256
+                float4 q[8];                        // workgroups is latency-bound -- 9 x 16 B x 65,536 threads in flight against 5 x with four
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = ldf4(reinterpret_cast<const float4*>(T.p[j + u]) + i, true);      // read once, never again
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float a = al[j + u];
+                    d.x = __builtin_fmaf(a, q[u].x, d.x); d.y = __builtin_fmaf(a, q[u].y, d.y); d.z = __builtin_fmaf(a, q[u].z, d.z); d.w = __builtin_fmaf(a, q[u].w, d.w);
+                }
+            }
+            for (; j + 4 <= T.count; j += 4) {
                 float4 q[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = ldf4(reinterpret_cast<const float4*>(T.p[j + u]) + i, true);      // read once, never again
+                for (int u = 0; u < 4; ++u) q[u] = ldf4(reinterpret_cast<const float4*>(T.p[j + u]) + i, true);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float a = al[j + u];

@@ -546,7 +546,7 @@ int Plan::step_gn_one_kernel(int ev_iter)
             if (hipEventRecord(words, s) != hipSuccess || hipStreamWaitEvent(aux_, words, 0) != hipSuccess) return -1;
             LaunchCtx cx = ctx; cx.stream = aux_;
             {   TimedLaunch t(cx, "PCGDeltaUpdate");
-                if (thallo_hip_linear_update_n(nullptr, v_.delta, T, v_.n_alloc, aux_workgroups_, aux_) < 0) return -1; }
+                if (thallo_hip_linear_update_n(nullptr, v_.delta, T, v_.n_alloc, aux_workgroups_ > 0 ? aux_workgroups_ : thallo_hip_device_cu_count(), aux_) < 0) return -1; }
             if (hipEventRecord(done, aux_) != hipSuccess) return -1;
             sent.push_back(Sent{ flushed - 1, done });
         }

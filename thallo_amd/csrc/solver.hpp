@@ -156,7 +156,8 @@ private:
     int  ring_planes(int L);
     hipStream_t aux_ = nullptr; bool aux_failed_ = false;      // the plan's second stream (background delta updates)
     std::vector<hipEvent_t> aux_events_;
-    int aux_workgroups_ = 256;      // share of the chip a background update takes
+    int aux_workgroups_ = 0;        // share of the chip a background update takes (0: one workgroup per CU -- measured: 64 / 128 too slow, the loop ends up waiting; 320+ put two
+                                    // on some CUs, whose marching workgroups then hold everybody's iteration up: 6.4 against 6.0-6.1 ms per GN step)
     bool aux_stream();
     bool fin_deferred_ = true;      // THALLO_FIN_IN_KERNEL unset: the single-reduction GN loop finishes iteration k-1 inside the flat update of iteration k (=1: by the applyJTJ launch's last workgroup; =0: a one-wave launch)
     void read_ab_switches();

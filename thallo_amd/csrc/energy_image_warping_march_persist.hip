@@ -13,7 +13,7 @@
 // There is no grid barrier and no other hand-over: the sums are the synchronisation point of the iteration, as in the resident kernel.  r ping-pongs between
 // two planes as behind the launches; p_k goes into plane k mod n of the plan's ring (the host updates delta from the ring, solver.cpp).
 //
-// MEASURED (round 5, 2048^2, profiles/r05/persist_*.txt) and NOT the default: 6.58 ms per GN step against 5.96 for a launch per iteration on the same box (THALLO_PERSIST=1
+// MEASURED (round 5, 2048^2, profiles/r05/persist_*.txt) and NOT the default: 6.58 ms per GN step against 5.96 for a launch per iteration on the same box (THALLO_AB=persist=1
 // runs it).  Where the time goes (tools/persist_probe.py, stamps build): a wave's march takes 42-43 us on average with r resident (46-48 without) but 47-50 for the
 // slowest of the 1003 waves, and everybody waits for that one; the sums exchange behind the last arrival costs 1.6 us, the drain / barrier / publish steps another
 // 2-3.  With the cross-workgroup wait compiled out (tools build -DPST_NOSYNC, garbage results) the loop runs 5.54 ms per step: the coupling costs ~10 us per

@@ -163,7 +163,7 @@ class ImageWarpingPlugin : public EnergyPlugin {
     bool resident_broken_ = false;         // a bounded wait of the resident kernel ran out on this plan (something kept its workgroups from being co-resident): never again
     bool march_ = false;                   // UrShape verified (at Init) to be the unit pixel grid and W even: the marching one-kernel iteration
     DeviceBuffer xpst;                     // exchange memory of the persistent marching loop (control words + tagged sums records)
-    bool persist_ = false;                 // ... and iterations 1 .. L-1 of a GN step as ONE launch of it (whole image, every workgroup resident; THALLO_PERSIST)
+    bool persist_ = false;                 // ... and iterations 1 .. L-1 of a GN step as ONE launch of it (whole image, every workgroup resident; THALLO_AB=persist=1)
     bool march_rc_ = false;                // ... in its form without an A p plane (whole image on one GPU; THALLO_MARCH=3: the stored-plane form, A/B)
     bool grid_ = false;                    // UrShape is the unit pixel grid (host-checked at Init)
     int row0_ = 0, row1_ = 0;              // owned rows (all of them unless the Plan is one row slab of a multi-GPU run)
@@ -217,7 +217,7 @@ public:
             }
             if (need > 0) { resident_ = whole; resident_slab_ = true; }
         }
-        // larger whole images: iterations 1 .. L-1 of a GN step as ONE persistent launch of the marching kernel's grid -- THALLO_PERSIST=1 only: measured 8-10 % SLOWER
+        // larger whole images: iterations 1 .. L-1 of a GN step as ONE persistent launch of the marching kernel's grid -- THALLO_AB=persist=1 only: measured 8-10 % SLOWER
         // than a launch per iteration at 2048^2 (energy_image_warping_march_persist.hip, profiles/r05/persist_ab.txt); bit-identical, kept for the tests and the tools
         persist_ = false;
         const char* ep = env_switch("THALLO_PERSIST");

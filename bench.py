@@ -43,7 +43,9 @@ def fused_bytes_per_iter(L, ring=False):
 
 
 FUSED_BYTES_STEP1 = 75          # two-kernel schedule (THALLO_AB=one_kernel=0, A/B): PCGStep1 = read z 12, p 12, cs 8, flags 1; write p 12, Ap 12 + the delta update every other launch 18
-ROOFLINE_STEPS = 3              # GN steps AFTER the timed region, with HIP events around every 4th launch of the dominant kernel on its own stream
+SAMPLE_PERIOD = 53             # HIP events on the kernel's stream around every 53rd launch of the dominant kernel INSIDE the timed region: ~38 samples in 20 steps whose
+                               # place in the GN step rotates (53 does not divide 100 or the delta update's period of 16: a launch next to that update takes ~8 us longer, and
+                               # one fixed place per step measured 56 or 67 us depending on the place); every 16th launch cost 0.9 % of the rate, every 53rd ~0.3 %
 
 
 def parse():
@@ -55,7 +57,7 @@ def parse():
     ap.add_argument("--liters", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small", action="store_true")              # skip the extra 512^2 / 2048x256 timings (resident PCG loop vs launch per iteration)
-    ap.add_argument("--sample-period", type=int, default=16)      # two-kernel schedule only: HIP events around every 16th launch of each kernel
+    ap.add_argument("--sample-period", type=int, default=-1)      # HIP events around every N-th launch of each kernel inside the timed region (default 53; 0: none, roofline from the loop's event pair)
     return ap.parse_args()
 
 
@@ -185,7 +187,7 @@ def main():
     if "THALLO_PERSIST_OCC" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(2, int(os.environ["THALLO_PERSIST_OCC"]))
     dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
     s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
-    s.set_solver_parameters(nIterations=K + Wm + ROOFLINE_STEPS, lIterations=L_it)
+    s.set_solver_parameters(nIterations=K + Wm, lIterations=L_it)
     params = s.make_params(dev)
     s.init(params)
     for _ in range(Wm):
@@ -194,9 +196,10 @@ def main():
     # one kernel per PCG iteration (thallo_hip_iw_pcg_iter, the default) vs PCGStep1 + PCGStep2 (THALLO_AB=one_kernel=0, A/B)
     one_kernel = "one_kernel=0" not in os.environ.get("THALLO_AB", "")
     s.reset_kernel_stats()
-    # the timed region runs without per-launch events; the dominant kernel's own launch duration is sampled in ROOFLINE_STEPS extra steps behind it (round 5: the
-    # PCG loop of a GN step is no longer L launches of one kernel and nothing else -- the delta updates of the ring of p planes run next to it on a second stream)
-    s.set_kernel_sampling(0 if one_kernel else (args.sample_period or 16))
+    # the dominant kernel's own launch duration: HIP events around every 53rd launch, live inside the timed region (round 5: the PCG loop of a GN step is no longer
+    # L launches of one kernel and nothing else -- the delta updates of the ring of p planes run next to it on a second stream -- so the loop's event pair / L is
+    # the loop's figure, `pcg_loop_ms_per_iteration`, not the kernel's)
+    s.set_kernel_sampling(args.sample_period if args.sample_period >= 0 else SAMPLE_PERIOD)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -208,15 +211,6 @@ def main():
     final_cost = s.current_cost()
     ring = "PCGDeltaUpdate" in ks
     persistent = "PCGLoopPersistent" in ks
-    if one_kernel and not persistent:
-        s.reset_kernel_stats()
-        s.set_kernel_sampling(4)
-    for _ in range(ROOFLINE_STEPS):
-        assert s.step(params) == 1
-    torch.cuda.synchronize()
-    if one_kernel and not persistent:
-        s.set_kernel_sampling(0)
-        ks = s.kernel_stats()
     assert s.step(params) == 0                 # budget used up: finalises the plan and its performance summary
     perf = s.performance_summary()
 
@@ -227,9 +221,12 @@ def main():
     if persistent:      # the loop is a few launches of many iterations each: the library's event pair around it ("Linear Solve") / L, delta updates included
         step1_ms = perf["linearSolve"]["meanMS"] / L_it
         n_samples = perf["linearSolve"]["count"] * L_it
-    else:
+    elif ks.get(dom, {}).get("samples"):
         step1_ms = ks[dom]["mean_ms"]
         n_samples = ks[dom]["samples"]
+    else:               # --sample-period 0: the loop's figure stands in
+        step1_ms = perf["linearSolve"]["meanMS"] / L_it
+        n_samples = perf["linearSolve"]["count"] * L_it
     ach = dom_bytes * npx / (step1_ms * 1e-3) / 1e9
     sa_ms = standalone_applyjtj(torch, W, H, p)
     sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9
@@ -260,8 +257,7 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_pixel": dom_bytes, "pixels_per_launch": npx,
                      "avg_launch_ms": step1_ms, "samples": n_samples,
-                     "timing": (f"HIP events on the kernel's stream around every 4th launch of it, in {ROOFLINE_STEPS} GN steps run behind the timed region" if one_kernel
-                                else "HIP events around every 16th launch of the kernel"),
+                     "timing": "HIP events on the kernel's stream around every 53rd launch of it, inside the timed region",
                      "pcg_loop_ms_per_iteration": perf["linearSolve"]["meanMS"] / L_it,
                      # the whole schedule's HBM rate: the loop's bytes per iteration (the marching launch + the delta update's 12 per term + 24 per 16-term launch) over
                      # the loop's time per iteration -- information next to the contract's per-kernel figure above
@@ -272,7 +268,7 @@ def main():
                              "it (-> 57.1 B/pixel: p_k goes into a ring of planes and delta takes 32 of them per PCGDeltaUpdate launch, 12.75 B/pixel/iteration "
                              "next to the loop).  frac is quoted on the kernel's OWN, smaller byte count: a lower frac at a higher PCG rate is a faster "
                              "schedule, not a slower kernel",
-                     "delta_update": ({"kernel": "PCGDeltaUpdate (thallo_hip_linear_update_n)", "launches_per_gn_step": ks["PCGDeltaUpdate"]["launches"] / ROOFLINE_STEPS,
+                     "delta_update": ({"kernel": "PCGDeltaUpdate (thallo_hip_linear_update_n)", "launches_per_gn_step": ks["PCGDeltaUpdate"]["launches"] / K,
                                        "avg_launch_ms": ks["PCGDeltaUpdate"]["mean_ms"]} if ring and one_kernel and ks.get("PCGDeltaUpdate", {}).get("samples") else None),
                      # the same launch priced with SURVEY.md 8d's bytes of the reference's three-kernel formulation -- a speed-up figure, not a
                      # roofline fraction (it exceeds the HBM peak because the schedule removes 45 % of those bytes)

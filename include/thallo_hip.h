@@ -197,8 +197,8 @@ int thallo_hip_linear_update2(float* X, const float* delta, const float* p_older
                               const float* p, thallo_sum_t alphaN, thallo_sum_t alphaD, long len, thallo_stream_t stream);
 /* delta += alpha_0 p_0, then += alpha_1 p_1, ... (terms.count <= THALLO_HIP_MAX_UPDATE_TERMS pending terms, oldest first; every term one fma on the running
    value, i.e. the bits of one `delta += alpha p` per PCG iteration in that order).  X == NULL: delta is updated in place (the ring of p planes of the
-   one-kernel schedule is full; the library launches it on a stream of its own next to the PCG loop, with max_workgroups keeping it to a share of the
-   chip).  X != NULL: the tail of a GN step (gauss_newton.t:901-906): X += the updated delta, delta itself is left as it was. */
+   one-kernel schedule is full; with THALLO_DELTA_PLANES=N:W the library launches it on a stream of its own next to the PCG loop, max_workgroups keeping it to
+   a share of the chip).  X != NULL: the tail of a GN step (gauss_newton.t:901-906): X += the updated delta, delta itself is left as it was. */
 #define THALLO_HIP_MAX_UPDATE_TERMS 32
 typedef struct { const float* p[THALLO_HIP_MAX_UPDATE_TERMS]; thallo_sum_t alphaN[THALLO_HIP_MAX_UPDATE_TERMS], alphaD[THALLO_HIP_MAX_UPDATE_TERMS]; int count; } thallo_update_terms_t;
 int thallo_hip_linear_update_n(float* X, float* delta, thallo_update_terms_t terms, long len, int max_workgroups /* 0: as many as the flat kernels use */, thallo_stream_t stream);

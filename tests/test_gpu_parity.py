@@ -443,13 +443,14 @@ def test_image_warping_deferred_delta_updates_are_bitwise_neutral(torch, monkeyp
 
 
 @pytest.mark.parametrize("W,H,lit,planes", [(1024, 768, 25, "3"), (1024, 768, 25, "7"), (1024, 768, 25, None), (256, 256, 40, "33"), (256, 256, 40, "2"), (256, 256, 70, None),
-                                            (130, 7, 12, "4"), (250, 2, 5, "5"), (2048, 2048, 12, "5"), (126, 130, 3, None), (1024, 768, 25, "-7"), (256, 256, 70, "-33")])
+                                            (130, 7, 12, "4"), (250, 2, 5, "5"), (2048, 2048, 12, "5"), (126, 130, 3, None), (1024, 768, 25, "7:0"), (256, 256, 70, "33:64"), (2048, 2048, 40, "9:256"),
+                                            (130, 7, 12, "4:8"), (256, 256, 40, "2:16")])
 def test_ring_of_p_planes_is_bitwise_a_delta_update_per_iteration(torch, monkeypatch, W, H, lit, planes):
     """Round 5: the one-kernel GN loop of the marching kernels writes p_k into a RING of planes and leaves delta alone (every launch moves 57 B/pixel); delta takes
     the pending alpha_j p_j -- oldest first, one fma each -- when the ring is full (thallo_hip_linear_update_n, "PCGDeltaUpdate") and the last ones inside
     PCGLinearUpdate.  Same roundings in the same order as `delta += alpha p` once per iteration (THALLO_DELTA_PLANES=0): costs, alpha / beta and the unknowns are
     BIT-identical after three GN steps -- rings of 2, 3 .. 33 planes and the automatic size, rings longer and shorter than the PCG loop, ragged and tiny images;
-    with the update next to the loop on the plan's second stream (default) and on the loop's own stream (negative plane counts)."""
+    with the update on the loop's own stream (default) and next to the loop on the plan's second stream ("N:W": on at most W workgroups)."""
     p = syn.image_warping(W, H, n_markers=min(8, max(0, (W - 2) * (H - 2) // 4)), mask_disc=0.1 if min(W, H) > 8 else 0.0)
     monkeypatch.setenv("THALLO_RESIDENT", "0")
     monkeypatch.setenv("THALLO_MARCH", "2")
@@ -470,12 +471,12 @@ def test_ring_of_p_planes_is_bitwise_a_delta_update_per_iteration(torch, monkeyp
         runs.append((costs, traces, dev[0].clone(), dev[1].clone(), names))
     (c0, t0, o0, a0, n0), (c1, t1, o1, a1, n1) = runs
     assert all(np.isfinite(c0)) and len(c0) == 4 and len(t0[0]) == lit
-    n = min(lit, 33 if planes is None else abs(int(planes)))
+    n = min(lit, 33 if planes is None else abs(int(planes.split(":")[0])))
     flushes = flushed = 0                # what the host loop does before launch k (terms up to k - 2 have their scalars by then) ...
     for k in range(lit):
-        if planes is not None and int(planes) < 0:      # ... on the loop's own stream: when plane k mod n still holds a term that is not in delta, everything goes
+        if planes is None or ":" not in planes:      # ... on the loop's own stream (default): when plane k mod n still holds a term that is not in delta, everything goes
             if k >= n and flushed < k - n + 1: flushes += 1; flushed = k - 1
-        elif k - 1 - flushed >= max(1, (n - 1) // 2):    # ... next to the loop (default): half a ring at a time
+        elif k - 1 - flushed >= max(1, (n - 1) // 2):    # ... next to the loop ("N:W"): half a ring at a time
             flushes += 1; flushed = k - 1
     assert n1.get("PCGDeltaUpdate", {}).get("launches", 0) == 3 * flushes and "PCGDeltaUpdate" not in n0, (n1, flushes)
     assert n0["PCGIteration"]["launches"] == 3 * lit == n1["PCGIteration"]["launches"]
@@ -538,12 +539,13 @@ def test_persistent_marching_loop_is_bitwise_a_launch_per_iteration(torch, monke
 
 
 def test_ring_of_p_planes_on_a_callers_stream(torch, monkeypatch):
-    """The delta updates of the ring run on the plan's second stream and are ordered against the loop's stream by events: the same bits whether the loop's stream is the
+    """With THALLO_DELTA_PLANES=N:W the delta updates of the ring run on the plan's second stream and are ordered against the loop's stream by events: the same bits whether the loop's stream is the
     NULL stream (the reference's, util.t:769-772) or a non-blocking stream the caller hands in with ThalloX_SetStream -- with other work queued on the NULL stream
     meanwhile (a non-blocking stream does not wait for it) -- and whether lIterations grows between two solves of one plan (the ring is extended)."""
     W, H = 1024, 768
     p = syn.image_warping(W, H, n_markers=8, mask_disc=0.1)
     monkeypatch.setenv("THALLO_RESIDENT", "0")
+    monkeypatch.setenv("THALLO_DELTA_PLANES", "33:0")       # the updates next to the loop (the default runs them on the loop's own stream: nothing to order)
     outs = []
     for mode in ("null", "own"):
         dev = to_device(copy_params(p))

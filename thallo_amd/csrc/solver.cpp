@@ -201,8 +201,8 @@ const char* env_switch(const char* name)
                                       //    stored A p plane (round 2/3); 4 = 2 + 3
         "THALLO_DELTA_PLANES",        // how often the one-kernel GN loop touches delta.  0: delta += alpha p every iteration (the reference's order of work); 1: every other iteration
                                       //    (round 4); N >= 2: a ring of N p planes, delta updated per half ring next to the loop (where the plugin's kernel takes any p plane);
-                                      //    unset: the ring where offered, sized by lIterations and the device's free memory, else 1; -N: the ring of N planes with its
-                                      //    updates on the loop's own stream instead of next to it (A/B); "N:W": the update on at most W workgroups
+                                      //    unset: the ring where offered, sized by lIterations and the device's free memory, else 1; "N:W": the ring of N planes with its
+                                      //    updates on a second stream NEXT TO the loop, on at most W workgroups (0: one per CU); -N = N
         "THALLO_DIST_P2P",            // 0: never the device-side exchange
         "THALLO_FRONTEND",            // off / generate: see api.cpp
         "THALLO_DENSE_JTJ_MAX",       // largest n for the dense [JtJ]p schedule of generated plugins
@@ -245,7 +245,7 @@ void Plan::read_ab_switches()
     { const char* e = env_switch("THALLO_FIN_IN_KERNEL"); fin_deferred_ = !(e && e[0]); }      // unset: deferred where the loop offers it (step_gn_expanded); 1: the in-kernel finish everywhere
     { const char* e = env_switch("THALLO_DELTA_PLANES"); delta_planes_ = e && e[0] ? atoi(e) : -1; if (delta_planes_ > THALLO_HIP_MAX_UPDATE_TERMS + 1) delta_planes_ = THALLO_HIP_MAX_UPDATE_TERMS + 1;
       if (delta_planes_ < -(THALLO_HIP_MAX_UPDATE_TERMS + 1)) delta_planes_ = -(THALLO_HIP_MAX_UPDATE_TERMS + 1);
-      const char* c = e ? strchr(e, ':') : nullptr; if (c && atoi(c + 1) > 0) aux_workgroups_ = atoi(c + 1); }      // ("N:W": the background update on at most W workgroups; tuning)
+      const char* c = e ? strchr(e, ':') : nullptr; aux_async_ = c != nullptr; aux_workgroups_ = c && atoi(c + 1) > 0 ? atoi(c + 1) : 0; }      // ("N:W": the update NEXT TO the loop, on at most W workgroups)
     batch_delta_   = delta_planes_ != 0;
     lm_fold_p_     = !off("THALLO_LM_FOLD_P");
 }
@@ -514,12 +514,13 @@ int Plan::step_gn_one_kernel(int ev_iter)
     const int n_ring = ring_planes(L);
     const bool ring = n_ring >= 2;
     const bool batched = !ring && batch_delta_ && delta_planes_ != 0 && plugin->batches_delta();      // THALLO_IW_STEP1_MODE(k, 1): every other delta update is deferred
-    // The update runs NEXT TO the loop, on a low-priority stream of the plan's own and on a share of the chip (round 5): a marching launch leaves the memory system
-    // idle while it ramps up and while its last waves finish; the update's loads fill those gaps.  A chunk of (n - 1) / 2 terms goes out as soon as their scalars are
-    // words; the launch that overwrites a chunk's first plane waits for it (an event), which by then is half a ring ago.  THALLO_DELTA_PLANES < 0: on the loop's
-    // own stream, whole rings at a time (A/B).
+    // Where the update runs.  Default: on the loop's own stream, whole rings at a time (up to 32 terms per launch).  THALLO_DELTA_PLANES=N:W: NEXT TO the loop, on a
+    // low-priority stream of the plan's own and on at most W workgroups (0: one per CU), in chunks of (n - 1) / 2 terms as soon as their scalars are words; the launch
+    // that overwrites a chunk's first plane waits for its event.  Measured (profiles/r05/ring_ab*.txt): next to the loop 0.7-2 % more PCG iterations per second, but the
+    // marching launches that share the chip with an update take ~8 us longer each -- the loop streams at the memory system's rate in its steady state, and what the
+    // second kernel takes there it does not give back in the ramps and tails.  Not worth a second stream in the default path.
     const bool persist = ring && defer && L >= 2 && plugin->persist_ok();
-    const bool async = ring && delta_planes_ >= -1 && !persist && aux_stream();
+    const bool async = ring && aux_async_ && !persist && aux_stream();
     const int chunk = !ring ? 0 : async ? (n_ring - 1) / 2 > 0 ? (n_ring - 1) / 2 : 1 : n_ring - 1;
     int flushed = 0;                       // p_0 .. p_{flushed-1} are in delta, or on their way there (async)
     int synced = 0;                        // ... and the loop's stream has waited for the updates of p_0 .. p_{synced-1}

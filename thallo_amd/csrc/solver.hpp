@@ -156,6 +156,7 @@ private:
     int  ring_planes(int L);
     hipStream_t aux_ = nullptr; bool aux_failed_ = false;      // the plan's second stream (background delta updates)
     std::vector<hipEvent_t> aux_events_;
+    bool aux_async_ = false;        // THALLO_DELTA_PLANES=N:W: the delta updates of the ring on the second stream, next to the loop
     int aux_workgroups_ = 0;        // share of the chip a background update takes (0: one workgroup per CU -- measured: 64 / 128 too slow, the loop ends up waiting; 320+ put two
                                     // on some CUs, whose marching workgroups then hold everybody's iteration up: 6.4 against 6.0-6.1 ms per GN step)
     bool aux_stream();

@@ -228,6 +228,8 @@ def main():
         step1_ms = perf["linearSolve"]["meanMS"] / L_it
         n_samples = perf["linearSolve"]["count"] * L_it
     ach = dom_bytes * npx / (step1_ms * 1e-3) / 1e9
+    # the loop's bytes per iteration: the marching launch + 12 per pending term + delta read and written once per PCGDeltaUpdate launch
+    sched_bytes = dom_bytes + 12.0 + 24.0 * (ks.get("PCGDeltaUpdate", {}).get("launches", 0) / K) / L_it
     sa_ms = standalone_applyjtj(torch, W, H, p)
     sa_gbs = ALG_BYTES_APPLYJTJ * npx / (sa_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
@@ -259,10 +261,10 @@ def main():
                      "avg_launch_ms": step1_ms, "samples": n_samples,
                      "timing": "HIP events on the kernel's stream around every 53rd launch of it, inside the timed region",
                      "pcg_loop_ms_per_iteration": perf["linearSolve"]["meanMS"] / L_it,
-                     # the whole schedule's HBM rate: the loop's bytes per iteration (the marching launch + the delta update's 12 per term + 24 per 16-term launch) over
+                     # the whole schedule's HBM rate: the loop's bytes per iteration (the marching launch + the delta update's 12 per term + 24 per launch) over
                      # the loop's time per iteration -- information next to the contract's per-kernel figure above
-                     "schedule": ({"bytes_per_pixel_per_iteration": dom_bytes + 13.5, "achieved": (dom_bytes + 13.5) * npx / (perf["linearSolve"]["meanMS"] / L_it * 1e-3) / 1e9,
-                                   "frac": (dom_bytes + 13.5) * npx / (perf["linearSolve"]["meanMS"] / L_it * 1e-3) / 1e9 / HBM_PEAK_GBS} if ring and one_kernel and not persistent else None),
+                     "schedule": ({"bytes_per_pixel_per_iteration": sched_bytes, "achieved": sched_bytes * npx / (perf["linearSolve"]["meanMS"] / L_it * 1e-3) / 1e9,
+                                   "frac": sched_bytes * npx / (perf["linearSolve"]["meanMS"] / L_it * 1e-3) / 1e9 / HBM_PEAK_GBS} if ring and one_kernel and not persistent else None),
                      "note": "achieved = bytes_per_pixel x pixels / avg launch time: the bytes this fused kernel has to move, each array once "
                              "(DESIGN.md section 4).  Round 4 removed the A p plane from the iteration (99 -> 74.8 B/pixel); round 5 took the delta update out of "
                              "it (-> 57.1 B/pixel: p_k goes into a ring of planes and delta takes 32 of them per PCGDeltaUpdate launch, 12.75 B/pixel/iteration "

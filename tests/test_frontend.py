@@ -86,7 +86,7 @@ def test_wave_aggregated_scatter_is_chosen_per_access(tmp_path):
     fit = src[src.index("void jtj_0"):src.index("void applyj_0")]
     assert "scatter_add<true>(Ap" in fit and "scatter_add<false>" not in fit
     reg = src[src.index("void jtj_1"):src.index("void applyj_1")]          # residual over H alone: nothing to aggregate
-    assert "scatter_add<" not in reg and "atomicAdd(Ap" in reg
+    assert "scatter_add<true>" not in reg and "scatter_add<false>(Ap" in reg
     iw = _text(thallo_amd.energy_file("image_warping"), 1)                 # every access involves x
     assert "scatter_add<true>" not in iw[iw.index("void jtj_0"):]
     out = tmp_path / "row_gain.hip"
@@ -215,7 +215,7 @@ def test_sum_is_expanded_at_plan_time(tmp_path):
     d = _text(f, 0, dims=(512, 16))
     assert "unknown Weights slot 0 channels 1 over M" in d and "array Basis slot 1 channels 1 over N M" in d and "residual fit x1 over N Jp" in d
     src = _text(f, 1, dims=(512, 16))
-    assert "16 unknown access(es)" in src and "Dual<16>" in src
+    assert "16 unknown access(es)" in src and "dd[15] = " in src and "dd[16] = " not in src          # 16 partials, every one structurally non-zero
     assert "16 unknown access(es)" not in _text(f, 1, dims=(512, 5)) and "5 unknown access(es)" in _text(f, 1, dims=(512, 5))
     assert "Sum needs the sizes" in _text(f, 1, expect_error=True)
     c = _text(os.path.join(HERE, "energies", "conv1d.t"), 1, dims=(512, 5))

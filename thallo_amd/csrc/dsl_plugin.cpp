@@ -115,7 +115,7 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     }
     long rows_of(size_t ri) const { return nel[ri] * (long)P.residuals[ri].exprs.size(); }
     // unknown-wise lowering through index maps (dsl.hpp IncResidual): per (residual, owner group) the kernel pair and the owners' instance lists (CSR), rebuilt per Init
-    struct IncRun { int ri = -1, g = -1; hipFunction_t jtj = nullptr, jtf = nullptr; DeviceBuffer ptr, els; long npix = 0; int wave = 0; };
+    struct IncRun { int ri = -1, g = -1; hipFunction_t jtj = nullptr, jtf = nullptr; DeviceBuffer ptr, els; long npix = 0; int wave = 0, lanes = 1; };
     std::vector<IncRun*> inc_runs_;
     std::vector<hipFunction_t> inc_uidx_;          // G.inc order
     std::vector<char> use_inc_;                    // per residual: gathered through per-owner instance lists for THIS Init's Sparse maps and dims
@@ -176,6 +176,17 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
                 // owners with long lists (bundle adjustment's cameras: hundreds of observations each, a few thousand owners) get a wave each; 16 instances per owner on
                 // average is where a wave's 64 lanes stop being mostly idle
                 run->wave = npix > 0 && (long)els.size() >= 16 * npix ? 1 : 0;
+                // shorter lists: a few lanes per owner.  Measured (tools/generated_graph_times.py, THALLO_AB=inc_lanes=N): ARAP 102,400 vertices (12 instances per vertex)
+                // 47.4 / 37.6 / 39.0 / 48.8 / 57.6 us per applyJTJ at 1 / 2 / 4 / 8 / 16 lanes; bundle adjustment's points (4.3 per point) 67 / 64 / 66 / 75 / 101: the walk
+                // is bound by the number of scattered 4-byte gathers, not by its length, and the group's shuffle-adds cost more than they hide beyond 4 lanes.
+                run->lanes = run->wave ? 64 : 1;
+                if (!run->wave && npix > 0) {
+                    const long lanes_env = [] { const char* e = env_switch("THALLO_INC_LANES"); return e ? atol(e) : 0L; }();      // THALLO_AB=inc_lanes=N (tools/generated_graph_times.py sweeps it)
+                    const double mean = (double)els.size() / (double)npix;
+                    int l = 1; while (l < 4 && mean >= 6.0 * l) l *= 2;
+                    if (lanes_env >= 1 && lanes_env <= 64 && (lanes_env & (lanes_env - 1)) == 0) l = (int)lanes_env;
+                    run->lanes = l;
+                }
                 // ... but a handful of owners with enormous lists (a dense residual over W x H x pairs that reads ten camera poses: ten waves for the whole launch) is the
                 // case the residual-wise kernels with their wave-aggregated atomics are for: below 256 such owners the residual keeps them
                 if (run->wave && npix < 256) few_owners = true;
@@ -192,9 +203,9 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     {
         for (IncRun* run : inc_runs_) {
             if (run->ri != ri) continue;
-            const int* ip = (const int*)run->ptr.ptr; const int* ie = (const int*)run->els.ptr; long npix = run->npix; int wave = run->wave;
-            void* args[] = { ctx.data(), a0, a1, &ip, &ie, &npix, &wave };
-            const int rc = launch_fn(jtj ? run->jtj : run->jtf, grid_for(wave ? npix * 64 : npix, 4096), args, s); if (rc < 0) return rc;
+            const int* ip = (const int*)run->ptr.ptr; const int* ie = (const int*)run->els.ptr; long npix = run->npix; int lanes = run->lanes;
+            void* args[] = { ctx.data(), a0, a1, &ip, &ie, &npix, &lanes };
+            const int rc = launch_fn(jtj ? run->jtj : run->jtf, grid_for(npix * lanes, 4096), args, s); if (rc < 0) return rc;
         }
         return 0;
     }

@@ -216,6 +216,8 @@ const char* env_switch(const char* name)
         { "THALLO_SFS_FUSED", "sfs_fused" },                    // 0: shape_from_shading's two-pass applyJTJ (round 1)
         { "THALLO_SFS_MARCH", "sfs_march" },                    // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere
+        { "THALLO_FRONTEND_PRELOAD", "frontend_preload" },      // 0: every residual instance of a generated merged gather kernel loads for itself (round 4's lowering)
+        { "THALLO_INC_LANES", "inc_lanes" },                    // N (a power of two <= 64): lanes per owner in the generated index-map gather kernels (default: by list length and owner count)
         { "THALLO_PERSIST", "persist" },                        // 1: iterations 1 .. L-1 of a GN step of image_warping's marching kernel as persistent launches (bit-identical, measured slower)
     };
     for (const char* k : known) if (!strcmp(k, name)) return getenv(name);

@@ -595,6 +595,9 @@ public:
     }
     int apply_jtj(LaunchCtx& c, const float* p, float* Ap, float* out) override
     { TimedLaunch t(c, "PCGStep1"); return apply(c, p, Ap, out, thallo_hip_vector_elems(n_unk)); }
+    // (measured and dropped, round 5: the single-reduction form for a whole-domain gather kernel -- N, S1, S2 in double behind the store of Ap -- made generated
+    //  image_warping's two launches 67 + 103 us against 41 + 77 + 43 for the three of the reference's schedule: the flat launches run at HBM rate either way and the
+    //  double-precision sums cost the gather kernel more than the third launch does)
     int pcg_step1(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out) override
     {
         { TimedLaunch t(c, "PCGStep3"); int rc = thallo_hip_pcg_pupdate(v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : 0, aN, aD, bN, c.stream); if (rc < 0) return rc; }

@@ -740,6 +740,14 @@ int thallo_hip_dense_gemv(long n, const float* M, const float* x, float* y, thal
 /* Numeric phase of the sparse J^T J of a non-constant J ([[Jt][J]]p, gauss_newton.t:1394-1441 csrgemm): out[dest[(i*K + a)*K + b]] += val[i*K + a] * val[i*K + b]
  * over the ELL rows of J; `dest` (positions in the CSR values, -1 = none) comes from the symbolic phase the host runs once per Init. */
 int thallo_hip_jtj_scatter(long rows, int K, const float* val, const int* dest, float* out, thallo_stream_t stream);
+/* Per-owner instance lists of a generated plugin's gather through index maps (round 5: built on the device; the reference maps a residual group at its output when
+ * it can, thallo.t:5273-5306).  col[el * K + q]: the flat unknown index slot q of residual instance el touches (-1: none), from the residual's own index evaluation
+ * (the generated uidx kernel).  slot_base[q] >= 0: slot q's image belongs to the owner group, its flat offset; slot_ch[q]: its channels; owner = (col - base) / ch in
+ * [0, npix).  count: ptr[0 .. npix] (device) becomes the CSR row pointer of the lists (an instance counts once per distinct owner), *total_dev (device, 8 bytes) their
+ * total length.  fill: els[ptr[px] .. ptr[px + 1]) = the instances of owner px in ascending order; cursor: npix ints of scratch.  K <= THALLO_HIP_INC_MAX_SLOTS. */
+#define THALLO_HIP_INC_MAX_SLOTS 48
+int thallo_hip_incidence_count(const int* col, long n, int K, const long* slot_base, const int* slot_ch, long npix, int* ptr, long* total_dev, thallo_stream_t stream);
+int thallo_hip_incidence_fill(const int* col, long n, int K, const long* slot_base, const int* slot_ch, long npix, const int* ptr, int* cursor, int* els, thallo_stream_t stream);
 /* ---- doublePrecision = 1 (precision.t:3-6: thallo_float = double): the energy-independent PCG kernels on double vectors, reference-shaped and unfused
  * (gauss_newton.t:712-731, 774-787, 801-843, 889-899, 901-906).  Reductions leave per-workgroup partials (the return value = how many, <= THALLO_HIP_MAX_PARTIALS),
  * thallo_hip_f64_finish adds them in index order into one device word, and the kernels that need a scalar read such words: nothing goes through the host.

@@ -133,8 +133,8 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
             if (col.alloc(sizeof(int) * (size_t)n * (size_t)K + 256)) { set_error("%s: out of device memory for the index evaluation of %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1; }
             int* cp = (int*)col.ptr; void* args[] = { ctx.data(), &cp };
             if (launch_fn(inc_uidx_[a], grid_for(n, 4096), args, s) < 0) return -1;
-            std::vector<int> h((size_t)n * (size_t)K);
-            if (n && (hipMemcpyAsync(h.data(), col.ptr, h.size() * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) return -1;
+            DeviceBuffer tot;
+            if (tot.alloc(64)) return -1;
             bool few_owners = false;
             for (IncRun* run : inc_runs_) {
                 if (run->ri != ir.ri) continue;
@@ -146,50 +146,39 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
                     if (P.inputs[(size_t)in].dims != G.inc_groups[(size_t)run->g].dims) mine = false;
                     if (mine) { slot_base[(size_t)q] = uoff[(size_t)in]; slot_ch[(size_t)q] = P.inputs[(size_t)in].channels; }
                 }
-                std::vector<int> ptr((size_t)npix + 1, 0);
-                long own[64];
-                auto owners = [&](long el, long* o) {      // distinct owners of instance el in this group
-                    int m = 0;
-                    for (int q = 0; q < K; ++q) {
-                        if (slot_base[(size_t)q] < 0) continue;
-                        const int u = h[(size_t)el * K + q]; if (u < 0) continue;
-                        const long px = ((long)u - slot_base[(size_t)q]) / slot_ch[(size_t)q];
-                        if (px < 0 || px >= npix) continue;
-                        bool dup = false; for (int j = 0; j < m; ++j) dup = dup || o[j] == px;
-                        if (!dup) o[m++] = px;
-                    }
-                    return m;
-                };
-                for (long el = 0; el < n; ++el) { const int m = owners(el, own); for (int j = 0; j < m; ++j) ptr[(size_t)own[j] + 1]++; }
-                for (long i = 0; i < npix; ++i) {
-                    if ((long)ptr[(size_t)i] + ptr[(size_t)i + 1] > 0x7fffffffL) { set_error("%s: more than 2^31 (instance, unknown) pairs in residual %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1; }
-                    ptr[(size_t)i + 1] += ptr[(size_t)i];
+                // the inversion runs on the device (round 5; the host loop over n x K indices it replaces took 25-50 ms of a first Init at the benchmark sizes): count per
+                // owner -> prefix sums -> fill through atomic cursors -> every list sorted (ascending instance order, as the host built them: same sums from run to run)
+                long total = 0;
+                if (run->ptr.alloc((size_t)(npix + 1) * sizeof(int) + 64) ||
+                    thallo_hip_incidence_count(cp, n, K, slot_base.data(), slot_ch.data(), npix, (int*)run->ptr.ptr, (long*)tot.ptr, s) < 0 ||
+                    hipMemcpyAsync(&total, tot.ptr, sizeof(long), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                    set_error("%s: the instance lists of %s could not be counted (out of device memory?)", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1;
                 }
-                std::vector<int> els((size_t)ptr[(size_t)npix]), fill(ptr.begin(), ptr.end() - 1);
-                for (long el = 0; el < n; ++el) { const int m = owners(el, own); for (int j = 0; j < m; ++j) els[(size_t)fill[(size_t)own[j]]++] = (int)el; }       // (ascending instance order per owner)
-                if (run->ptr.alloc(ptr.size() * sizeof(int) + 64) || run->els.alloc(els.size() * sizeof(int) + 64) ||
-                    hipMemcpy(run->ptr.ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-                    (els.size() && hipMemcpy(run->els.ptr, els.data(), els.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)) {
-                    set_error("%s: out of device memory for the instance lists of %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1;
-                }
+                if (total > 0x7fffffffL) { set_error("%s: more than 2^31 (instance, unknown) pairs in residual %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1; }
                 run->npix = npix;
                 // owners with long lists (bundle adjustment's cameras: hundreds of observations each, a few thousand owners) get a wave each; 16 instances per owner on
                 // average is where a wave's 64 lanes stop being mostly idle
-                run->wave = npix > 0 && (long)els.size() >= 16 * npix ? 1 : 0;
+                run->wave = npix > 0 && total >= 16 * npix ? 1 : 0;
                 // shorter lists: a few lanes per owner.  Measured (tools/generated_graph_times.py, THALLO_AB=inc_lanes=N): ARAP 102,400 vertices (12 instances per vertex)
                 // 47.4 / 37.6 / 39.0 / 48.8 / 57.6 us per applyJTJ at 1 / 2 / 4 / 8 / 16 lanes; bundle adjustment's points (4.3 per point) 67 / 64 / 66 / 75 / 101: the walk
                 // is bound by the number of scattered 4-byte gathers, not by its length, and the group's shuffle-adds cost more than they hide beyond 4 lanes.
                 run->lanes = run->wave ? 64 : 1;
                 if (!run->wave && npix > 0) {
                     const long lanes_env = [] { const char* e = env_switch("THALLO_INC_LANES"); return e ? atol(e) : 0L; }();      // THALLO_AB=inc_lanes=N (tools/generated_graph_times.py sweeps it)
-                    const double mean = (double)els.size() / (double)npix;
+                    const double mean = (double)total / (double)npix;
                     int l = 1; while (l < 4 && mean >= 6.0 * l) l *= 2;
                     if (lanes_env >= 1 && lanes_env <= 64 && (lanes_env & (lanes_env - 1)) == 0) l = (int)lanes_env;
                     run->lanes = l;
                 }
                 // ... but a handful of owners with enormous lists (a dense residual over W x H x pairs that reads ten camera poses: ten waves for the whole launch) is the
                 // case the residual-wise kernels with their wave-aggregated atomics are for: below 256 such owners the residual keeps them
-                if (run->wave && npix < 256) few_owners = true;
+                if (run->wave && npix < 256) { few_owners = true; continue; }
+                DeviceBuffer cursor;
+                if (run->els.alloc((size_t)total * sizeof(int) + 64) || cursor.alloc((size_t)npix * sizeof(int) + 64) ||
+                    thallo_hip_incidence_fill(cp, n, K, slot_base.data(), slot_ch.data(), npix, (const int*)run->ptr.ptr, (int*)cursor.ptr, (int*)run->els.ptr, s) < 0 ||
+                    hipStreamSynchronize(s) != hipSuccess) {          // (cursor is released at the end of this scope: the fill must be through)
+                    set_error("%s: out of device memory for the instance lists of %s", label.c_str(), P.residuals[(size_t)ir.ri].name.c_str()); return -1;
+                }
             }
             if (few_owners) {
                 use_inc_[(size_t)ir.ri] = 0;

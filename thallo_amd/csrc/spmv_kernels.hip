@@ -210,9 +210,109 @@ __global__ __launch_bounds__(BLOCK) void k_potrs(long n, const float* __restrict
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------ per-owner instance lists (generated plugins' gather through index maps, dsl_plugin.cpp build_incidence)
+// col[el * K + q]: the flat unknown index that slot q of residual instance el touches (-1: none).  A slot belongs to the owner group when its base >= 0; its owner
+// is the pixel (col - base) / ch of the group's index space.  An instance counts ONCE per distinct owner.
+struct IncSlots { long base[THALLO_HIP_INC_MAX_SLOTS]; int ch[THALLO_HIP_INC_MAX_SLOTS]; };
+__device__ __forceinline__ long inc_owner(const int* __restrict__ col, long el, int K, const IncSlots& S, long npix, int q)
+{
+    if (S.base[q] < 0) return -1;
+    const int u = col[el * K + q]; if (u < 0) return -1;
+    const long px = ((long)u - S.base[q]) / S.ch[q];
+    return px >= 0 && px < npix ? px : -1;
+}
+template <bool FILL>
+__global__ __launch_bounds__(BLOCK) void k_inc_count_fill(const int* __restrict__ col, long n, int K, IncSlots S, long npix, int* __restrict__ ptr, int* __restrict__ cursor, int* __restrict__ els)
+{
+    for (long el = (long)blockIdx.x * BLOCK + threadIdx.x; el < n; el += (long)gridDim.x * BLOCK) {
+        for (int q = 0; q < K; ++q) {
+            const long px = inc_owner(col, el, K, S, npix, q);
+            if (px < 0) continue;
+            bool dup = false;
+            for (int j = 0; j < q; ++j) dup = dup || inc_owner(col, el, K, S, npix, j) == px;
+            if (dup) continue;
+            if (FILL) els[ptr[px] + atomicAdd(cursor + px, 1)] = (int)el;
+            else atomicAdd(ptr + px + 1, 1);
+        }
+    }
+}
+// ptr[0] = 0, ptr[1 .. m]: counts -> inclusive prefix sums, in place; one workgroup, 4 elements per thread and pass, the carry in a register.  *total = the sum (as a
+// long: more than 2^31 - 1 pairs is the caller's error to raise)
+__global__ __launch_bounds__(1024) void k_inc_scan(int* __restrict__ ptr, long m, long* __restrict__ total)
+{
+    __shared__ long wsum[16];
+    __shared__ long carry_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) { carry_s = 0; ptr[0] = 0; }
+    __syncthreads();
+    for (long base = 1; base <= m; base += 4096) {
+        const long i0 = base + 4L * t;
+        long v[4], run = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = i0 + j <= m ? (long)ptr[i0 + j] : 0; run += v[j]; v[j] = run; }
+        long inc = run;                                     // inclusive scan of the threads' sums over the wave, then over the 16 waves
+        for (int d = 1; d < 64; d <<= 1) { const long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        long before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const long excl = before + inc - run;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i0 + j <= m) { const long x = excl + v[j]; ptr[i0 + j] = x > 0x7fffffffL ? 0x7fffffff : (int)x; }
+        __syncthreads();
+        if (t == 1023) carry_s = excl + run;
+        __syncthreads();
+    }
+    if (t == 0) *total = carry_s;
+}
+// every owner's list in ascending instance order (the atomic cursor filled it in arrival order): what the host-side construction produced, and what makes the sums
+// of the gather kernels the same from run to run.  One thread per owner; insertion sort for short lists, heap sort above (in place, O(L log L)).
+__global__ __launch_bounds__(BLOCK) void k_inc_sort(const int* __restrict__ ptr, long npix, int* __restrict__ els)
+{
+    for (long px = (long)blockIdx.x * BLOCK + threadIdx.x; px < npix; px += (long)gridDim.x * BLOCK) {
+        int* a = els + ptr[px]; const int L = ptr[px + 1] - ptr[px];
+        if (L <= 32) {
+            for (int i = 1; i < L; ++i) { const int x = a[i]; int j = i - 1; while (j >= 0 && a[j] > x) { a[j + 1] = a[j]; --j; } a[j + 1] = x; }
+            continue;
+        }
+        auto sift = [&](int root, int end) {
+            for (;;) {
+                int c = 2 * root + 1; if (c >= end) break;
+                if (c + 1 < end && a[c + 1] > a[c]) ++c;
+                if (a[root] >= a[c]) break;
+                const int tmp = a[root]; a[root] = a[c]; a[c] = tmp; root = c;
+            }
+        };
+        for (int i = L / 2 - 1; i >= 0; --i) sift(i, L);
+        for (int e = L - 1; e > 0; --e) { const int tmp = a[0]; a[0] = a[e]; a[e] = tmp; sift(0, e); }
+    }
+}
 }  // namespace
 
 extern "C" {
+
+static inline int inc_grid(long n) { const long g = (n + BLOCK - 1) / BLOCK; return (int)(g < 1 ? 1 : g > 4096 ? 4096 : g); }
+int thallo_hip_incidence_count(const int* col, long n, int K, const long* slot_base, const int* slot_ch, long npix, int* ptr, long* total_dev, thallo_stream_t stream)
+{
+    if (K < 1 || K > THALLO_HIP_INC_MAX_SLOTS || npix < 0 || n < 0) return -(int)hipErrorInvalidValue;
+    IncSlots S; for (int q = 0; q < THALLO_HIP_INC_MAX_SLOTS; ++q) { S.base[q] = q < K ? slot_base[q] : -1; S.ch[q] = q < K && slot_ch[q] > 0 ? slot_ch[q] : 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ptr, 0, (size_t)(npix + 1) * sizeof(int), s) != hipSuccess) return -(int)hipErrorInvalidValue;
+    if (n > 0) hipLaunchKernelGGL(k_inc_count_fill<false>, dim3(inc_grid(n)), dim3(BLOCK), 0, s, col, n, K, S, npix, ptr, (int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_inc_scan, dim3(1), dim3(1024), 0, s, ptr, npix, total_dev);
+    return check_launch();
+}
+int thallo_hip_incidence_fill(const int* col, long n, int K, const long* slot_base, const int* slot_ch, long npix, const int* ptr, int* cursor, int* els, thallo_stream_t stream)
+{
+    if (K < 1 || K > THALLO_HIP_INC_MAX_SLOTS || npix < 0 || n < 0) return -(int)hipErrorInvalidValue;
+    IncSlots S; for (int q = 0; q < THALLO_HIP_INC_MAX_SLOTS; ++q) { S.base[q] = q < K ? slot_base[q] : -1; S.ch[q] = q < K && slot_ch[q] > 0 ? slot_ch[q] : 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (npix > 0 && hipMemsetAsync(cursor, 0, (size_t)npix * sizeof(int), s) != hipSuccess) return -(int)hipErrorInvalidValue;
+    if (n > 0) hipLaunchKernelGGL(k_inc_count_fill<true>, dim3(inc_grid(n)), dim3(BLOCK), 0, s, col, n, K, S, npix, const_cast<int*>(ptr), cursor, els);
+    if (npix > 0) hipLaunchKernelGGL(k_inc_sort, dim3(inc_grid(npix)), dim3(BLOCK), 0, s, ptr, npix, els);
+    return check_launch();
+}
 
 int thallo_hip_jtj_scatter(long rows, int K, const float* val, const int* dest, float* out, thallo_stream_t stream)
 {

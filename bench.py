@@ -43,7 +43,8 @@ def fused_bytes_per_iter(L, ring=False):
 
 
 FUSED_BYTES_STEP1 = 75          # two-kernel schedule (THALLO_AB=one_kernel=0, A/B): PCGStep1 = read z 12, p 12, cs 8, flags 1; write p 12, Ap 12 + the delta update every other launch 18
-SAMPLE_PERIOD = 53             # HIP events on the kernel's stream around every 53rd launch of the dominant kernel INSIDE the timed region: ~38 samples in 20 steps whose
+SAMPLE_PERIOD = 53             # HIP events at every 53rd launch of the dominant kernel INSIDE the timed region (handed to the launch itself -- the kernel's own begin / end
+                               # timestamps -- and, for comparison, recorded around it): ~38 samples in 20 steps whose
                                # place in the GN step rotates (53 does not divide 100 or the delta update's period of 16: a launch next to that update takes ~8 us longer, and
                                # one fixed place per step measured 56 or 67 us depending on the place); every 16th launch cost 0.9 % of the rate, every 53rd ~0.3 %
 
@@ -218,9 +219,15 @@ def main():
     dom = "PCGIteration" if one_kernel else "PCGStep1"
     dom_bytes = fused_bytes_per_iter(L_it, ring) if one_kernel else FUSED_BYTES_STEP1          # what the kernel has to move (= its PMC traffic)
     ref_bytes = ALG_BYTES_PCG_ITER if one_kernel else ALG_BYTES_FUSED_STEP1        # the reference formulation of the same work
+    timing = "HIP events on the kernel's stream around every 53rd launch of it, inside the timed region"
     if persistent:      # the loop is a few launches of many iterations each: the library's event pair around it ("Linear Solve") / L, delta updates included
         step1_ms = perf["linearSolve"]["meanMS"] / L_it
         n_samples = perf["linearSolve"]["count"] * L_it
+    elif ks.get(dom, {}).get("own_samples"):      # the sampled launches carried their own start / stop events: the kernel's begin-to-end time (what rocprofv3 calls its duration)
+        step1_ms = ks[dom]["own_mean_ms"]
+        n_samples = ks[dom]["own_samples"]
+        timing = ("HIP events handed to the sampled launches themselves (hipExtLaunchKernelGGL start / stop: the kernel's own begin and end timestamps), every "
+                  "53rd launch of it on its stream, inside the timed region")
     elif ks.get(dom, {}).get("samples"):
         step1_ms = ks[dom]["mean_ms"]
         n_samples = ks[dom]["samples"]
@@ -259,7 +266,9 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_pixel": dom_bytes, "pixels_per_launch": npx,
                      "avg_launch_ms": step1_ms, "samples": n_samples,
-                     "timing": "HIP events on the kernel's stream around every 53rd launch of it, inside the timed region",
+                     "timing": timing,
+                     # the same sampled launches between two events recorded around them: kernel + the dispatch gap in front of it
+                     "avg_launch_ms_between_recorded_events": ks.get(dom, {}).get("mean_ms"),
                      "pcg_loop_ms_per_iteration": perf["linearSolve"]["meanMS"] / L_it,
                      # the whole schedule's HBM rate: the loop's bytes per iteration (the marching launch + the delta update's 12 per term + 24 per launch) over
                      # the loop's time per iteration -- information next to the contract's per-kernel figure above

@@ -104,6 +104,9 @@ void ThalloX_SetKernelSampling(Thallo_Plan* plan, int period);
  * samples = timed launches, total_ms = sum over timed launches.  Synchronises the device. */
 int  ThalloX_GetKernelStat(Thallo_Plan* plan, int index, const char** name, long* launches, long* samples, double* total_ms);
 void ThalloX_ResetKernelStats(Thallo_Plan* plan);
+/* ... of the same entry: how many of the sampled launches carried their own start / stop events (the kernel's begin-to-end time, without the dispatch gap that
+   events recorded around a launch include) and their total; 0 samples where the kernel's shim does not offer it */
+int ThalloX_GetKernelStatOwn(Thallo_Plan* plan, int index, long* samples, double* total_ms);
 
 /* alpha/beta of every PCG iteration of the most recent Step (tests): writes up to cap pairs,
  * returns the number of PCG iterations run. */

@@ -746,6 +746,11 @@ int thallo_hip_jtj_scatter(long rows, int K, const float* val, const int* dest, 
  * [0, npix).  count: ptr[0 .. npix] (device) becomes the CSR row pointer of the lists (an instance counts once per distinct owner), *total_dev (device, 8 bytes) their
  * total length.  fill: els[ptr[px] .. ptr[px + 1]) = the instances of owner px in ascending order; cursor: npix ints of scratch.  K <= THALLO_HIP_INC_MAX_SLOTS. */
 #define THALLO_HIP_INC_MAX_SLOTS 48
+/* Measurement (the library's per-kernel timer, bench.py's roofline figure): arm -- the NEXT marching PCG iteration this thread launches (thallo_hip_iw_pcg_iter_march_rc*)
+ * carries the two events as hipExtLaunchKernelGGL's start / stop events, i.e. they take the kernel's own begin / end timestamps (what rocprofv3 reports as its duration;
+ * events recorded around a launch also contain the dispatch gap in front of it).  take -- disarm; 1 if a launch used them (then, and only then, they are recorded). */
+void thallo_hip_launch_events_arm(void* start_event, void* stop_event);
+int thallo_hip_launch_events_take(void);
 int thallo_hip_incidence_count(const int* col, long n, int K, const long* slot_base, const int* slot_ch, long npix, int* ptr, long* total_dev, thallo_stream_t stream);
 int thallo_hip_incidence_fill(const int* col, long n, int K, const long* slot_base, const int* slot_ch, long npix, const int* ptr, int* cursor, int* els, thallo_stream_t stream);
 /* ---- doublePrecision = 1 (precision.t:3-6: thallo_float = double): the energy-independent PCG kernels on double vectors, reference-shaped and unfused

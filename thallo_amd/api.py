@@ -89,6 +89,8 @@ def lib():
     L.ThalloX_SetKernelSampling.argtypes = [vp, C.c_int]
     L.ThalloX_GetKernelStat.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_double)]
     L.ThalloX_GetKernelStat.restype = C.c_int
+    L.ThalloX_GetKernelStatOwn.argtypes = [vp, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    L.ThalloX_GetKernelStatOwn.restype = C.c_int
     L.ThalloX_ResetKernelStats.argtypes = [vp]
     L.ThalloX_GetAlphaBetaTrace.argtypes = [vp, vp, C.c_int]; L.ThalloX_GetAlphaBetaTrace.restype = C.c_int
     L.ThalloX_EnableLM.argtypes = [vp, C.c_int]
@@ -369,8 +371,11 @@ class ThalloSolver:
             name = C.c_char_p(); launches = C.c_long(); samples = C.c_long(); total = C.c_double()
             if self._L.ThalloX_GetKernelStat(self.plan, i, C.byref(name), C.byref(launches), C.byref(samples), C.byref(total)):
                 break
+            ks = C.c_long(); kt = C.c_double()
+            self._L.ThalloX_GetKernelStatOwn(self.plan, i, C.byref(ks), C.byref(kt))
             out[name.value.decode()] = {"launches": launches.value, "samples": samples.value, "total_ms": total.value,
-                                        "mean_ms": total.value / samples.value if samples.value else None}
+                                        "mean_ms": total.value / samples.value if samples.value else None,
+                                        "own_samples": ks.value, "own_mean_ms": kt.value / ks.value if ks.value else None}
             i += 1
         return out
 

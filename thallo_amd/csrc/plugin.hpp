@@ -23,7 +23,9 @@ const char* env_switch(const char* name);
 class KernelTimer {
 public:
     struct Stat { std::string name; long launches = 0; long samples = 0; double total_ms = 0; double sq_ms = 0;
-                  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+                  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+                  // the kernel's OWN duration, where the sampled launch could carry its events (thallo_hip_launch_events_arm): no dispatch gap in it
+                  long ksamples = 0; double ktotal_ms = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> kpending; };
     int period = 0;          // 0 = off, 1 = every launch
     bool invasive = false;   // timingLevel 3: device-sync around timed launches
     ~KernelTimer();
@@ -36,6 +38,7 @@ private:
     std::map<std::string, int> index_;
     std::vector<hipEvent_t> open_;      // start events of the timed scopes that are open (they nest: step_lm's PCGStep2 scope contains an applyJTJ's PCGStep1)
     std::vector<hipEvent_t> pool_;
+    hipEvent_t k0_ = nullptr, k1_ = nullptr;        // the armed pair of the outermost open scope
     hipEvent_t get_event();
 };
 

@@ -35,6 +35,7 @@ int KernelTimer::begin(const char* name, hipStream_t s)
     const long n = st.launches++;
     if (period <= 0 || (n % period) != 0) return -1;
     if (invasive) hipDeviceSynchronize();
+    if (open_.empty()) { k0_ = get_event(); k1_ = get_event(); thallo_hip_launch_events_arm(k0_, k1_); }
     open_.push_back(get_event());
     hipEventRecord(open_.back(), s);
     return idx;
@@ -50,6 +51,10 @@ void KernelTimer::end(int slot, hipStream_t s)
     // reported by whatever launch was checked next (seen as "point order failed" in a later bundle adjustment plan).
     stats[slot].pending.emplace_back(open_.back(), e);
     open_.pop_back();
+    if (open_.empty() && k0_) {
+        if (thallo_hip_launch_events_take()) stats[slot].kpending.emplace_back(k0_, k1_); else { pool_.push_back(k0_); pool_.push_back(k1_); }
+        k0_ = k1_ = nullptr;
+    }
 }
 void KernelTimer::collect()
 {
@@ -61,12 +66,21 @@ void KernelTimer::collect()
             pool_.push_back(pr.first); pool_.push_back(pr.second);
         }
         st.pending.clear();
+        for (auto& pr : st.kpending) {
+            hipEventSynchronize(pr.second);
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { st.ksamples++; st.ktotal_ms += ms; }
+            pool_.push_back(pr.first); pool_.push_back(pr.second);
+        }
+        st.kpending.clear();
     }
 }
-void KernelTimer::reset() { collect(); for (auto& st : stats) { st.launches = st.samples = 0; st.total_ms = st.sq_ms = 0; } }
+void KernelTimer::reset() { collect(); for (auto& st : stats) { st.launches = st.samples = st.ksamples = 0; st.total_ms = st.sq_ms = st.ktotal_ms = 0; } }
 KernelTimer::~KernelTimer()
 {
     for (auto& st : stats) for (auto& pr : st.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& st : stats) for (auto& pr : st.kpending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (k0_) { hipEventDestroy(k0_); hipEventDestroy(k1_); }
     for (auto e : pool_) hipEventDestroy(e);
     for (auto e : open_) hipEventDestroy(e);
 }

@@ -75,6 +75,32 @@ def test_kat_minimal_image_materialized_schedules(torch, golden_dir, orc, tmp_pa
     assert np.abs(to_host(dev[0]) - to_host(dev0[0])).max() < 1e-5
 
 
+def test_sampled_marching_launches_carry_their_own_events(torch, monkeypatch):
+    """bench.py's roofline figure: with kernel sampling on, a sampled launch of the marching PCG iteration carries two events as hipExtLaunchKernelGGL's start / stop
+    events (thallo_hip_launch_events_arm): the kernel's own begin-to-end time, which cannot be longer than what two events RECORDED around the same launch measure
+    (they contain the dispatch gap in front of it).  Kernels whose shims do not offer it report no such samples; results are the same bits with and without sampling."""
+    monkeypatch.setenv("THALLO_MARCH", "2"); monkeypatch.setenv("THALLO_RESIDENT", "0")          # (a launch per PCG iteration, the marching kernel at this size too)
+    W, H = 256, 192
+    p = syn.image_warping(W, H, n_markers=8)
+    out = {}
+    for period in (0, 3):
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
+        s.set_solver_parameters(nIterations=3, lIterations=20)
+        prm = s.make_params(dev); s.init(prm)
+        s.set_kernel_sampling(period)
+        while s.step(prm): pass
+        ks = s.kernel_stats(); cost = s.current_cost(); s.close()
+        out[period] = (ks, cost, to_host(dev[0]).copy())
+    ks = out[3][0]
+    it = ks["PCGIteration"]
+    assert it["samples"] >= 10 and it["own_samples"] >= 10, it
+    assert 0.0 < it["own_mean_ms"] <= it["mean_ms"] * 1.05, it
+    assert all(v["own_samples"] == 0 for k, v in ks.items() if k != "PCGIteration"), ks
+    assert all(v["own_samples"] == 0 for v in out[0][0].values())
+    assert out[0][1] == out[3][1] and (out[0][2] == out[3][2]).all()
+
+
 @pytest.mark.parametrize("schedule", ["J", "JtJ"])
 def test_kat_minimal_graph_materialized_schedules(torch, golden_dir, orc, tmp_path, schedule):
     gold = np.fromfile(os.path.join(golden_dir, "minimal_graph_gold.u8"), np.uint8)

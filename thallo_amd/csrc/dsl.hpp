@@ -104,7 +104,7 @@ struct GenKernel { std::string name; int residual; int kind; };      // kind: 0 
                                                                       // 6 evalJTF / 7 applyJTJ in the unknown-wise (gather) form -- present only where gather_ok
 constexpr int GEN_KINDS = 8;
 // one merged gather kernel pair per iteration domain (dsl_codegen.cpp): the member residuals, the (input, channel) targets they write, the kernel names
-struct GenGroup { std::vector<int> domain; std::vector<int> members; std::vector<std::pair<int, int>> targets; std::string jtj, jtf; };
+struct GenGroup { std::vector<int> domain; std::vector<int> members; std::vector<std::pair<int, int>> targets; std::string jtj, jtf, cost; };      // cost: "" = the members' own cost kernels
 // Unknown-wise lowering THROUGH index maps (round 4; dsl_codegen.cpp "incidence gather"): residuals that reach their unknowns through Sparse maps (or any other index
 // the stencil gather cannot invert at code-generation time).  The unknown images are grouped by their dimension lists (an "owner" = one pixel of that index space, all
 // images over it and all their channels); per (residual, group) a kernel pair walks the owners, each thread evaluating the residual instances in ITS list -- built by the

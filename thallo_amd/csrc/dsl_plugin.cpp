@@ -104,7 +104,7 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     int kernel_of(int residual, int kind) const { return residual * dsl::GEN_KINDS + kind; }
     std::vector<char> gather_;                     // per residual: the unknown-wise (gather) kernels run (compute_at_output, or the autoscheduler's choice where eligible)
     // merged gather kernels, one per iteration domain (G.groups): group_of_[ri] = the group residual ri runs in (-1: its own kernel); group_nel_: elements of the domain
-    std::vector<hipFunction_t> grp_jtj, grp_jtf;
+    std::vector<hipFunction_t> grp_jtj, grp_jtf, grp_cost;      // (grp_cost[gi] == nullptr: the members' own cost kernels)
     std::vector<int> group_of_;
     std::vector<long> group_nel_;
     bool whole_ = false;                           // ONE group holds every residual and writes every unknown: its applyJTJ stores (no Ap clear, no read-modify-write) and alphaD rides along
@@ -407,6 +407,9 @@ public:
             hipFunction_t fa = nullptr, fb = nullptr;
             if (hipModuleGetFunction(&fa, mod, g.jtj.c_str()) != hipSuccess || hipModuleGetFunction(&fb, mod, g.jtf.c_str()) != hipSuccess) { set_error("%s: generated group kernel %s missing", label.c_str(), g.jtj.c_str()); return -1; }
             grp_jtj.push_back(fa); grp_jtf.push_back(fb);
+            hipFunction_t fc = nullptr;
+            if (!g.cost.empty() && hipModuleGetFunction(&fc, mod, g.cost.c_str()) != hipSuccess) { set_error("%s: generated group kernel %s missing", label.c_str(), g.cost.c_str()); return -1; }
+            grp_cost.push_back(fc);
         }
         return 0;
     }
@@ -435,13 +438,31 @@ public:
     float* unknown_ptr(int k) override { return (float*)bound[unknown_input[k]]; }
     EnergyPlugin64* f64() override { return f64_ ? this : nullptr; }
     double* unknown_ptr64(int k) override { return (double*)bound[unknown_input[k]]; }
+    // a merged group whose members all run gathered: ONE cost launch on shared loads (its partials behind `total`; the members are ticked off in `done`)
+    template <class T> int cost_groups(LaunchCtx& c, T* out, int cap, int& total, std::vector<char>& done)
+    {
+        for (size_t gi = 0; gi < G.groups.size(); ++gi) {
+            if (gi >= grp_cost.size() || !grp_cost[gi]) continue;
+            bool all = true; for (int ri : G.groups[gi].members) all = all && group_of_[(size_t)ri] == (int)gi;
+            if (!all) continue;
+            const int g = grid_for(group_nel_[gi], cap * (int)G.groups[gi].members.size());
+            T* o = out + total; void* args[] = { ctx.data(), &o };
+            if (launch_fn(grp_cost[gi], g, args, c.stream) < 0) return -1;
+            total += g;
+            for (int ri : G.groups[gi].members) done[(size_t)ri] = 1;
+        }
+        return 0;
+    }
     // ---- doublePrecision = 1: the same launches on double vectors (the unit was compiled with float = double), reference-shaped and unfused
     int cost64(LaunchCtx& c, double* out) override
     {
         TimedLaunch t(c, "computeCost");
         const int cap = THALLO_HIP_MAX_PARTIALS / (int)P.residuals.size();
         int total = 0;
+        std::vector<char> done(P.residuals.size(), 0);
+        if (cost_groups(c, out, cap, total, done) < 0) return -1;
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            if (done[ri]) continue;
             const int g = grid_for(nel[ri], cap);
             double* o = out + total; void* args[] = { ctx.data(), &o };
             const int rc = launch(kernel_of((int)ri, 0), g, args, c.stream); if (rc < 0) return rc;
@@ -456,7 +477,7 @@ public:
         const size_t bytes = (size_t)v.n_alloc * sizeof(double);
         if (hipMemsetAsync(v.r, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.pre, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
         for (size_t gi = 0; gi < G.groups.size(); ++gi) {               // merged gather groups first (one launch per iteration domain)
-            double *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
+            double *r = v.r, *pre = v.pre; int mode = 0; void* args[] = { ctx.data(), &r, &pre, &mode };
             const int rc = launch_fn(grp_jtf[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
         }
         if (!inc_ready_ && !inc_runs_.empty() && build_incidence(s)) return -1;
@@ -492,7 +513,10 @@ public:
         TimedLaunch t(c, "computeCost");
         const int cap = THALLO_HIP_MAX_PARTIALS / (int)P.residuals.size();
         int total = 0;
+        std::vector<char> done(P.residuals.size(), 0);
+        if (cost_groups(c, out, cap, total, done) < 0) return -1;
         for (size_t ri = 0; ri < P.residuals.size(); ++ri) {
+            if (done[ri]) continue;
             const int g = grid_for(nel[ri], cap);
             float* o = out + total; void* args[] = { ctx.data(), &o };
             const int rc = launch(kernel_of((int)ri, 0), g, args, c.stream); if (rc < 0) return rc;
@@ -505,10 +529,12 @@ public:
         TimedLaunch t(c, "PCGInit1");
         hipStream_t s = c.stream;
         const size_t bytes = (size_t)v.n_alloc * sizeof(float);
-        if (hipMemsetAsync(v.r, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.pre, 0, bytes, s) != hipSuccess || hipMemsetAsync(v.p[cur], 0, bytes, s) != hipSuccess ||
-            hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
+        // (one gather kernel writes every unknown: it STORES r and pre -- only the vectors' padding behind the last unknown is cleared, and nothing is read back)
+        const size_t head = whole_ ? (size_t)n_unk * sizeof(float) : 0;
+        if (hipMemsetAsync((char*)v.r + head, 0, bytes - head, s) != hipSuccess || hipMemsetAsync((char*)v.pre + head, 0, bytes - head, s) != hipSuccess ||
+            hipMemsetAsync(v.p[cur], 0, bytes, s) != hipSuccess || hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
         for (size_t gi = 0; gi < G.groups.size(); ++gi) {               // merged gather groups first (one launch per iteration domain)
-            float *r = v.r, *pre = v.pre; void* args[] = { ctx.data(), &r, &pre };
+            float *r = v.r, *pre = v.pre; int mode = whole_ ? 1 : 0; void* args[] = { ctx.data(), &r, &pre, &mode };
             const int rc = launch_fn(grp_jtf[gi], grid_for(group_nel_[gi], 4096), args, s); if (rc < 0) return rc;
         }
         if (!inc_ready_ && !inc_runs_.empty() && build_incidence(s)) return -1;

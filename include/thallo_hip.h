@@ -573,7 +573,8 @@ int thallo_hip_sfs_apply_jtj(int W, int H, int row0, int row1, int yoff, int Hg,
  * (gauss_newton.t:889-899 + :734-787). */
 /* GN on one GPU: ONE launch per PCG iteration (marching kernel only) = thallo_hip_pcg_update + thallo_hip_sfs_apply_jtj_sums_fin:
  * r_out = r_in - alpha Ap_in, p_out = r_out + beta p_in, delta += alpha p_in (alpha = alphaN_prev / alphaD_prev, beta = betaN_prev / alphaN_prev; first:
- * r_out = r_in, p_out = r_in, delta untouched), Ap_out = J^T J p_out, alphaD partials, the three double sums {N, S1, S2} of r_out / Ap_out, and with
+ * r_out = r_in, p_out = r_in, delta untouched; delta == NULL: never touched -- the caller keeps every p_k (a ring of planes) and adds alpha_k p_k with
+ * thallo_hip_linear_update_n), Ap_out = J^T J p_out, alphaD partials, the three double sums {N, S1, S2} of r_out / Ap_out, and with
  * fin.tickets the two scalar words of the iteration.  The in / out planes of r, Ap, p are different buffers (gauss_newton.t:734-752,801-843,889-899). */
 int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,

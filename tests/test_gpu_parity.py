@@ -511,6 +511,37 @@ def test_ring_of_p_planes_is_bitwise_a_delta_update_per_iteration(torch, monkeyp
     assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
+@pytest.mark.parametrize("W,H,lit,planes", [(256, 192, 10, None), (256, 192, 40, None), (256, 192, 40, "5"), (130, 67, 12, "3"), (64, 48, 7, None), (640, 480, 36, "33:0")])
+def test_shape_from_shading_ring_of_p_planes_is_bitwise_a_delta_update_per_iteration(torch, monkeypatch, W, H, lit, planes):
+    """The ring of p planes behind shape_from_shading's one-launch PCG iteration (round 5: thallo_hip_sfs_pcg_iter* with delta == NULL leaves delta alone; the solver's
+    loop is the one image_warping uses): costs, alpha / beta and the unknown are BIT-identical to `delta += alpha p` inside every launch (THALLO_DELTA_PLANES=0) after
+    three GN steps -- loops shorter and longer than the ring, small rings, the update next to the loop."""
+    p = syn.shape_from_shading(W, H)
+    runs = []
+    for dp in ("0", planes):
+        if dp is None: monkeypatch.delenv("THALLO_DELTA_PLANES", raising=False)
+        else: monkeypatch.setenv("THALLO_DELTA_PLANES", dp)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), timing_level=2)
+        s.set_solver_parameters(nIterations=3, lIterations=lit)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, traces = [s.current_cost()], []
+        while s.step(params):
+            costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+        names = s.kernel_stats()
+        s.close()
+        runs.append((costs, traces, [d.clone() for d in dev if hasattr(d, "shape")][0], names))
+    (c0, t0, x0, n0), (c1, t1, x1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == 4 and len(t0[0]) == lit
+    assert n0["PCGIteration"]["launches"] == 3 * lit == n1["PCGIteration"]["launches"] and "PCGDeltaUpdate" not in n0
+    n = min(lit, 33 if planes is None else int(planes.split(":")[0]))
+    assert ("PCGDeltaUpdate" in n1) == (lit > n), n1.keys()
+    assert t0 == t1, [(i, k) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(x0, x1)
+
+
 @pytest.mark.parametrize("acq,res,occ", [(0, 23, 1), (1, 23, 1), (0, 0, 1), (0, 5, 1), (0, 23, 2), (1, 3, 2)])
 @pytest.mark.parametrize("W,H,lit,planes", [(2048, 2048, 12, None), (2048, 2048, 40, "9"), (1024, 768, 25, None), (1024, 768, 70, None), (256, 256, 30, "4"), (130, 7, 12, None), (124, 64, 9, "3"),
                                             (250, 2, 5, None), (126, 130, 7, None), (2, 1, 4, None), (372, 5, 6, None), (2048, 1024, 35, None)])

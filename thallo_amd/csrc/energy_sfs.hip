@@ -485,7 +485,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
             if (UPD) {
                 s.pv = (up.p_in + rowoff)[xc_]; s.av = (up.A_in + rowoff)[xc_];
                 const int td = t < ya ? ya : t > yb - 1 ? yb - 1 : t;          // delta: the segment's own rows only
-                s.dl = (up.delta + (long)td * W)[xc_];
+                s.dl = up.delta ? (up.delta + (long)td * W)[xc_] : 0.0f;          // (NULL: the iteration leaves delta alone -- the caller's ring of p planes, thallo_hip_linear_update_n)
                 if (LMQ) s.mi = (up.pre + rowoff)[xc_];
             }
             // the aligned dword that holds the pixel's flags byte (shifted when the row is taken): a byte load leaves a zero-extension for the
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(MS_NT, OCC) void k_march(MsGeo g, Cam cm, const flo
                         if ((mine || ghost_row) && xout) {
                             const long ro = (long)t * W;
                             (up.r_out + ro)[(unsigned)x] = rk; (up.p_out + ro)[(unsigned)x] = v0;
-                            if (mine && !up.first) (up.delta + ro)[(unsigned)x] = dk;
+                            if (mine && !up.first && up.delta) (up.delta + ro)[(unsigned)x] = dk;
                         }
                     }
                     const unsigned f0 = ok ? (cur.f >> (8 * (int)(((long)t * W + x) & 3))) & 0xffu : 0u;
@@ -995,7 +995,7 @@ int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, 
                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
                             thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* aD_out, double* s3_out, thallo_fin_t fin, thallo_stream_t stream)
 {
-    if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !delta || !aD_out || !s3_out) return -(int)hipErrorInvalidValue;
+    if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !aD_out || !s3_out) return -(int)hipErrorInvalidValue;
     if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !alphaD_prev.partials || !betaN_prev.partials)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
@@ -1014,7 +1014,7 @@ int thallo_hip_sfs_pcg_iter_deferred(int W, int H, int row0, int row1, int yoff,
                                      const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
                                      thallo_sum_t alphaN_prev, thallo_prev_t prev, float* aD_out, double* s3_out, thallo_stream_t stream)
 {
-    if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !delta || !aD_out || !s3_out) return -(int)hipErrorInvalidValue;
+    if (row0 < 0 || row1 > H || row0 >= row1 || !r_in || !r_out || r_in == r_out || !Ap_out || !p_in || !p_out || p_in == p_out || !aD_out || !s3_out) return -(int)hipErrorInvalidValue;
     if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !prev.alphaD_partials || !prev.s12_partials || prev.s12_partials == s3_out || prev.count < 1 ||
                    prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_word || !prev.betaN_word)) return -(int)hipErrorInvalidValue;
     if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;

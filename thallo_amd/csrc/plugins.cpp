@@ -996,24 +996,25 @@ public:
     }
     // GN on one GPU: one launch per PCG iteration (the marching kernel with PCGUpdate riding along; r, Ap, p ping-pong).  Across ranks: the flat form.
     bool one_kernel_iteration() const override { return thallo_hip_sfs_march_fits(W) != 0 && row0_ == 0 && row1_ == H; }
+    bool takes_any_p_plane() const override { return one_kernel_iteration(); }          // round 5: p_k into a ring of planes, delta from the ring (solver.cpp ring_planes)
     bool dist_flat_form() const override { return true; }
     int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t, thallo_sum_t, float* out,
                  float* aD_word, float* bN_word) override
     {
-        if (mode & ~1) return -1;                                   // (no batched delta updates here: batches_delta() is false)
+        if ((mode & ~3) || (mode & 3) == 3) return -1;              // bit 0: first; bit 1: delta left alone (the ring of p planes); no batched delta updates here (batches_delta() is false)
         TimedLaunch t(c, "PCGIteration");
         const thallo_fin_t fin = { bN, aD_word ? v.fin_tickets : nullptr, aD_word, bN_word };
         return thallo_hip_sfs_pcg_iter(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
-                                       v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode & 1, aN, aD, bN, out, v.s12, fin, c.stream);
+                                       v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], (mode & 2) ? nullptr : v.delta, mode & 1, aN, aD, bN, out, v.s12, fin, c.stream);
     }
     // the finish of iteration k-1 inside the launch of iteration k (one GPU; THALLO_FIN_IN_KERNEL=1: the launch's own last workgroup finishes, A/B)
     bool iter_defers_finish() const override { const char* e = env_switch("THALLO_FIN_IN_KERNEL"); return one_kernel_iteration() && !(e && e[0]); }
     int pcg_iter_deferred(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t, thallo_sum_t, const thallo_prev_t& prev, float* out, double* s12_out) override
     {
-        if (mode & ~1) return -1;
+        if ((mode & ~3) || (mode & 3) == 3) return -1;
         TimedLaunch t(c, "PCGIteration");
         return thallo_hip_sfs_pcg_iter_deferred(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr,
-                                                v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], v.delta, mode & 1, aN, prev, out, s12_out, c.stream);
+                                                v.rbuf(cur), v.rbuf(cur ^ 1), v.Abuf(cur), v.Abuf(cur ^ 1), v.p[cur], v.p[cur ^ 1], (mode & 2) ? nullptr : v.delta, mode & 1, aN, prev, out, s12_out, c.stream);
     }
     int pcg_iter_finish_from(LaunchCtx& c, const float* part, const double* s12p, int count, thallo_sum_t aN, float* aD_word, float* bN_word) override
     {

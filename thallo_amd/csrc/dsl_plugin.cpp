@@ -531,7 +531,7 @@ public:
         const size_t bytes = (size_t)v.n_alloc * sizeof(float);
         // (one gather kernel writes every unknown: it STORES r and pre -- only the vectors' padding behind the last unknown is cleared, and nothing is read back)
         const size_t head = whole_ ? (size_t)n_unk * sizeof(float) : 0;
-        if (hipMemsetAsync((char*)v.r + head, 0, bytes - head, s) != hipSuccess || hipMemsetAsync((char*)v.pre + head, 0, bytes - head, s) != hipSuccess ||
+        if ((bytes > head && (hipMemsetAsync((char*)v.r + head, 0, bytes - head, s) != hipSuccess || hipMemsetAsync((char*)v.pre + head, 0, bytes - head, s) != hipSuccess)) ||
             hipMemsetAsync(v.p[cur], 0, bytes, s) != hipSuccess || hipMemsetAsync(v.delta, 0, bytes, s) != hipSuccess) return -1;
         for (size_t gi = 0; gi < G.groups.size(); ++gi) {               // merged gather groups first (one launch per iteration domain)
             float *r = v.r, *pre = v.pre; int mode = whole_ ? 1 : 0; void* args[] = { ctx.data(), &r, &pre, &mode };

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-for ctr in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum TCC_MISS_sum TCC_HIT_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCP_TCC_WRITE_REQ_sum; do
+for ctr in ${BA_PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ_sum TCC_MISS_sum TCC_HIT_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCP_TCC_WRITE_REQ_sum}; do
   timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/gpurun_out/ba_pmc_$ctr -- python3 $R/tools/lm_probe.py ba > $R/gpurun_out/ba_pmc_$ctr.log 2>&1
 done
 cd $R

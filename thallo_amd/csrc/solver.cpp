@@ -670,7 +670,7 @@ bool Plan::aux_stream()
 }
 
 // Planes in the ring of p vectors of the one-kernel GN loop (0: no ring).  v_.p[1], v_.p[0] are its first two; the rest is allocated on first use and grows
-// with lIterations, as long as the device has room: at most a quarter of what is free and 8 GiB, at most 33 planes (one PCGDeltaUpdate takes 32 terms).
+// with lIterations, as long as the device has room: at most a quarter of what is free and 64 GiB (of 288), at most 33 planes (one PCGDeltaUpdate takes 32 terms).
 int Plan::ring_planes(int L)
 {
     if (!plugin->takes_any_p_plane() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3 || dist_) return 0;
@@ -681,7 +681,7 @@ int Plan::ring_planes(int L)
     while ((int)ring_.size() < want) {
         size_t free_b = 0, total_b = 0;
         if (delta_planes_ == -1 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4 / (size_t)(want - (int)ring_.size()) ||
-                                  bytes * (ring_.size() - 1) > ((size_t)8 << 30))) break;
+                                  bytes * (ring_.size() - 1) > ((size_t)64 << 30))) break;
         DeviceBuffer* b = new DeviceBuffer();
         if (b->alloc(bytes)) { delete b; break; }
         bufs_.push_back(b); ring_.push_back((float*)b->ptr);

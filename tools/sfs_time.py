@@ -5,7 +5,7 @@ sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/thallo_amd") else o
 import numpy as np, torch
 import thallo_amd
 from thallo_amd import synthetic as syn
-W = H = 2048
+W = int(os.environ.get("PW", "2048")); H = int(os.environ.get("PH", str(W)))
 p = syn.shape_from_shading(W, H)
 
 

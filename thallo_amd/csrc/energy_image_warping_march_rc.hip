@@ -129,8 +129,10 @@ struct RawRc {                              // what one step takes, for one lane
     u32x4 ro; u32x2 ra;                     // row t-1: r_{k-1}
     u32x4 dlo, ppo; u32x2 dla, ppa;         // row t-1: delta (DMODE 0, 2) and p_{k-2} (DMODE 2)
 };
-__device__ __forceinline__ void take4u(u32x4& d, const u32x4& s) { unsigned a, b, c, e; take1(a, s.x); take1(b, s.y); take1(c, s.z); take1(e, s.w); d.x = a; d.y = b; d.z = c; d.w = e; }
-__device__ __forceinline__ void take2u(u32x2& d, const u32x2& s) { unsigned a, b; take1(a, s.x); take1(b, s.y); d.x = a; d.y = b; }
+// (pairs move as pairs: one v_mov_b64 per two words, and {x, y} / {c, s} stay in an aligned register pair for the packed arithmetic)
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void take4u(u32x4& d, const u32x4& s) { const u64x2 sv = __builtin_bit_cast(u64x2, s); unsigned long long a, b; take_pair(a, sv.x); take_pair(b, sv.y); u64x2 dv; dv.x = a; dv.y = b; d = __builtin_bit_cast(u32x4, dv); }
+__device__ __forceinline__ void take2u(u32x2& d, const u32x2& s) { unsigned long long a; take_pair(a, __builtin_bit_cast(unsigned long long, s)); d = __builtin_bit_cast(u32x2, a); }
 template <int DMODE>
 __device__ __forceinline__ void take(RawRc<DMODE>& d, const RawRc<DMODE>& s)
 {
@@ -139,9 +141,10 @@ __device__ __forceinline__ void take(RawRc<DMODE>& d, const RawRc<DMODE>& s)
     if (DMODE == 2) { take4u(d.ppo, s.ppo); take2u(d.ppa, s.ppa); }
 }
 
-struct PRow { float px[2], py[2], pa[2]; };                      // p of a lane's pixel pair in one row
-struct GRow { float c[2], s[2], a[2]; unsigned f; };             // cos / sin of Angle, the active bits as 0 / 1, the two flags bytes
-struct RRow { float rx[2], ry[2], ra[2]; };                      // r_k
+struct PRow { v2f xy[2]; float pa[2]; };                         // p of a lane's pixel pair in one row: (x, y) of each pixel as a register pair (iw_march.hpp jtjp_pair_xy)
+struct GRow { v2f cs[2], gx[2]; float a[2]; unsigned f; };       // (cos, sin) of Angle and (sin, -cos), the active bits as 0 / 1, the two flags bytes
+struct RRow { v2f xy[2]; float ra[2]; };                         // r_k
+__device__ __forceinline__ v2f uf2(unsigned a, unsigned b) { return v2f{ uf(a), uf(b) }; }
 
 // DMODE: the delta update this launch carries (THALLO_IW_STEP1_MODE): 0 delta += alpha p_{k-1}; 1 none; 2 delta += alpha_{k-2} p_{k-2} + alpha_{k-1} p_{k-1}
 // SLAB: 0 a whole image; 1 / 2 one rank's row slab of a multi-GPU run (local image = owned rows [row0, row1) + one ghost row towards each neighbour).  The exchange is
@@ -224,14 +227,14 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { pp[i].px[q] = 0.f; pp[i].py[q] = 0.f; pp[i].pa[q] = 0.f; pk[i].px[q] = 0.f; pk[i].py[q] = 0.f; pk[i].pa[q] = 0.f;
-                                      gg[i].c[q] = 1.f; gg[i].s[q] = 0.f; gg[i].a[q] = 0.f; }
+        for (int q = 0; q < 2; ++q) { pp[i].xy[q] = v2f{ 0.f, 0.f }; pp[i].pa[q] = 0.f; pk[i].xy[q] = v2f{ 0.f, 0.f }; pk[i].pa[q] = 0.f;
+                                      gg[i].cs[q] = v2f{ 1.f, 0.f }; gg[i].gx[q] = v2f{ 0.f, -1.f }; gg[i].a[q] = 0.f; }
         gg[i].f = 0u;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { rr[i].rx[q] = 0.f; rr[i].ry[q] = 0.f; rr[i].ra[q] = 0.f; }
+        for (int q = 0; q < 2; ++q) { rr[i].xy[q] = v2f{ 0.f, 0.f }; rr[i].ra[q] = 0.f; }
 
     float acc = 0.0f; double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     const unsigned mxin = xin ? 0xffffu : 0u;
@@ -277,8 +280,9 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                     const bool rowok = t >= 0 && t < g.H;
                     const unsigned par = ((unsigned)t * (unsigned)W2) & 1u;
                     const unsigned fl = (cur.f >> (par ? 16u - sh0 : sh0)) & (rowok ? mxin : 0u);
-                    p0.px[0] = uf(cur.po.x); p0.py[0] = uf(cur.po.y); p0.px[1] = uf(cur.po.z); p0.py[1] = uf(cur.po.w); p0.pa[0] = uf(cur.pa.x); p0.pa[1] = uf(cur.pa.y);
-                    g0.c[0] = uf(cur.cs.x); g0.s[0] = uf(cur.cs.y); g0.c[1] = uf(cur.cs.z); g0.s[1] = uf(cur.cs.w); g0.f = fl;
+                    p0.xy[0] = uf2(cur.po.x, cur.po.y); p0.xy[1] = uf2(cur.po.z, cur.po.w); p0.pa[0] = uf(cur.pa.x); p0.pa[1] = uf(cur.pa.y);
+                    g0.cs[0] = uf2(cur.cs.x, cur.cs.y); g0.cs[1] = uf2(cur.cs.z, cur.cs.w); g0.f = fl;
+                    g0.gx[0] = v2f{ g0.cs[0].y, -g0.cs[0].x }; g0.gx[1] = v2f{ g0.cs[1].y, -g0.cs[1].x };
                     g0.a[0] = (float)(fl & 1u); g0.a[1] = (float)((fl >> 8) & 1u);
                 }
                 // ---- row u = t-1: A p_{k-1}(u) -> r_k(u), p_k(u)
@@ -286,31 +290,30 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                 {
                     const float4 m0 = lut[g1.f & 31u], m1 = lut[(g1.f >> 8) & 31u];      // (M^-1 offsets, M^-1 angle, w_fit^2 or 0)
                     const float wfit[2] = { m0.z, m1.z };
-                    float ax[2], ay[2], av[2];
-                    jtjp_pair(p2, p1, p0, g2, g1, g0, g2.a, g1.a, g0.a, wfit, wr2, ax, ay, av);
+                    v2f axy[2]; float av[2];
+                    jtjp_pair_xy(p2, p1, p0, g2, g1, g0, g2.a, g1.a, g0.a, wfit, wr2, axy, av);
                     // a ghost row of the slab: the row above the strip's first segment / below its last one (wave-uniform).  Only THAT wave keeps it current: the
                     // rounding-up steps of other segments pass by the same row index with clamped re-reads in their slots
                     const bool ghost_row = SLAB && ((u == ya - 1 && ya == g.row0 && u >= 0) || (u == yb && yb == g.row1 && u < g.H));
                     if (ghost_row) {            // A p_{k-1} of a ghost row: what the exchange delivered (a blocking load, twice per boundary wave and launch)
                         const unsigned row = (unsigned)u * (unsigned)W2;
                         const u32x4 ao = bld4<false>(RS_AI, vo16, row * 16u); const u32x2 aa = bld2<false>(RS_AI, vo8, angle0 + row * 8u);
-                        ax[0] = uf(ao.x); ay[0] = uf(ao.y); ax[1] = uf(ao.z); ay[1] = uf(ao.w); av[0] = uf(aa.x); av[1] = uf(aa.y);
+                        axy[0] = uf2(ao.x, ao.y); axy[1] = uf2(ao.z, ao.w); av[0] = uf(aa.x); av[1] = uf(aa.y);
                     }
-                    float rx[2] = { uf(cur.ro.x), uf(cur.ro.z) }, ry[2] = { uf(cur.ro.y), uf(cur.ro.w) }, rq[2] = { uf(cur.ra.x), uf(cur.ra.y) };
-                    rx[0] = __builtin_fmaf(-alpha, ax[0], rx[0]); ry[0] = __builtin_fmaf(-alpha, ay[0], ry[0]);
-                    rx[1] = __builtin_fmaf(-alpha, ax[1], rx[1]); ry[1] = __builtin_fmaf(-alpha, ay[1], ry[1]);
+                    v2f rxy[2] = { uf2(cur.ro.x, cur.ro.y), uf2(cur.ro.z, cur.ro.w) }; float rq[2] = { uf(cur.ra.x), uf(cur.ra.y) };
+                    rxy[0] = fma2(-alpha, axy[0], rxy[0]); rxy[1] = fma2(-alpha, axy[1], rxy[1]);
                     rq[0] = __builtin_fmaf(-alpha, av[0], rq[0]); rq[1] = __builtin_fmaf(-alpha, av[1], rq[1]);
                     const float mo[2] = { m0.x, m1.x }, ma[2] = { m0.y, m1.y };
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        k1.px[q] = mo[q] * rx[q] + beta * p1.px[q]; k1.py[q] = mo[q] * ry[q] + beta * p1.py[q]; k1.pa[q] = ma[q] * rq[q] + beta * p1.pa[q];
-                        r1.rx[q] = rx[q]; r1.ry[q] = ry[q]; r1.ra[q] = rq[q];
+                        k1.xy[q] = mo[q] * rxy[q] + beta * p1.xy[q]; k1.pa[q] = ma[q] * rq[q] + beta * p1.pa[q];
+                        r1.xy[q] = rxy[q]; r1.ra[q] = rq[q];
                     }
                     const bool mine = u >= ya && u < yb;
                     if (xout && (mine || ghost_row)) {      // this wave's own rows, or a ghost row of the slab (kept current here)
                         const unsigned row = (unsigned)u * (unsigned)W2;
-                        bst4<nt_out>(RS_RO, vo16, row * 16u, rx[0], ry[0], rx[1], ry[1]); bst2<nt_out>(RS_RO, vo8, angle0 + row * 8u, rq[0], rq[1]);
-                        bst4<nt_pout>(RS_Q, vo16, row * 16u, k1.px[0], k1.py[0], k1.px[1], k1.py[1]); bst2<nt_pout>(RS_Q, vo8, angle0 + row * 8u, k1.pa[0], k1.pa[1]);
+                        bst4<nt_out>(RS_RO, vo16, row * 16u, rxy[0].x, rxy[0].y, rxy[1].x, rxy[1].y); bst2<nt_out>(RS_RO, vo8, angle0 + row * 8u, rq[0], rq[1]);
+                        bst4<nt_pout>(RS_Q, vo16, row * 16u, k1.xy[0].x, k1.xy[0].y, k1.xy[1].x, k1.xy[1].y); bst2<nt_pout>(RS_Q, vo8, angle0 + row * 8u, k1.pa[0], k1.pa[1]);
                         if (DMODE != 1 && mine) {
                             float d[4] = { uf(cur.dlo.x), uf(cur.dlo.y), uf(cur.dlo.z), uf(cur.dlo.w) }, da[2] = { uf(cur.dla.x), uf(cur.dla.y) };
                             if (DMODE == 2) {
@@ -318,8 +321,8 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                                 d[2] = __builtin_fmaf(alpha2, uf(cur.ppo.z), d[2]); d[3] = __builtin_fmaf(alpha2, uf(cur.ppo.w), d[3]);
                                 da[0] = __builtin_fmaf(alpha2, uf(cur.ppa.x), da[0]); da[1] = __builtin_fmaf(alpha2, uf(cur.ppa.y), da[1]);
                             }
-                            d[0] = __builtin_fmaf(alpha, p1.px[0], d[0]); d[1] = __builtin_fmaf(alpha, p1.py[0], d[1]);
-                            d[2] = __builtin_fmaf(alpha, p1.px[1], d[2]); d[3] = __builtin_fmaf(alpha, p1.py[1], d[3]);
+                            d[0] = __builtin_fmaf(alpha, p1.xy[0].x, d[0]); d[1] = __builtin_fmaf(alpha, p1.xy[0].y, d[1]);
+                            d[2] = __builtin_fmaf(alpha, p1.xy[1].x, d[2]); d[3] = __builtin_fmaf(alpha, p1.xy[1].y, d[3]);
                             da[0] = __builtin_fmaf(alpha, p1.pa[0], da[0]); da[1] = __builtin_fmaf(alpha, p1.pa[1], da[1]);
                             bst4<nt_delta>(RS_D, vo16, row * 16u, d[0], d[1], d[2], d[3]); bst2<nt_delta>(RS_D, vo8, angle0 + row * 8u, da[0], da[1]);
                         }
@@ -334,18 +337,18 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                     const bool on = xout && v >= ya && v < yb;
                     const float4 m0 = lut[on ? g2.f & 31u : 0u], m1 = lut[on ? (g2.f >> 8) & 31u : 0u];
                     const float wfit[2] = { m0.z, m1.z }, mo[2] = { m0.x, m1.x }, ma[2] = { m0.y, m1.y };
-                    float ax[2], ay[2], av[2];
-                    jtjp_pair(k3, k2, k1, g3, g2, g1, g3.a, g2.a, g1.a, wfit, wr2, ax, ay, av);
+                    v2f axy[2]; float av[2];
+                    jtjp_pair_xy(k3, k2, k1, g3, g2, g1, g3.a, g2.a, g1.a, wfit, wr2, axy, av);
                     if (SLAB && xout && v >= ya && v < yb && (v == g.row0 || v == g.row1 - 1)) {      // the rows of A p_k the neighbouring ranks' ghost rows need
                         if (SLAB == 1) {
                             const unsigned row = (unsigned)v * (unsigned)W2;
-                            bst4<false>(RS_AO, vo16, row * 16u, ax[0], ay[0], ax[1], ay[1]); bst2<false>(RS_AO, vo8, angle0 + row * 8u, av[0], av[1]);
+                            bst4<false>(RS_AO, vo16, row * 16u, axy[0].x, axy[0].y, axy[1].x, axy[1].y); bst2<false>(RS_AO, vo8, angle0 + row * 8u, av[0], av[1]);
                         } else {            // peer-to-peer, write-through; drained by every wave before the arrival ticket (iter_tail)
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
                                 if (v == (k == 0 ? g.row0 : g.row1 - 1) && dd.peer_r[k]) {
                                     float* d2 = dd.peer_r[k] + dd.peer_off_o[k] + 2 * x0;
-                                    st_sys(d2, ax[0]); st_sys(d2 + 1, ay[0]); st_sys(d2 + 2, ax[1]); st_sys(d2 + 3, ay[1]);
+                                    st_sys(d2, axy[0].x); st_sys(d2 + 1, axy[0].y); st_sys(d2 + 2, axy[1].x); st_sys(d2 + 3, axy[1].y);
                                     float* d1 = dd.peer_r[k] + dd.peer_off_a[k] + x0;
                                     st_sys(d1, av[0]); st_sys(d1 + 1, av[1]);
                                 }
@@ -354,9 +357,9 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
                     }
                     const float msum = on ? 1.0f : 0.0f;
                     __builtin_amdgcn_sched_barrier(0);
-                    iter_sums_pixel_masked(msum, k2.px[0], k2.py[0], k2.pa[0], ax[0], ay[0], av[0], r2.rx[0], r2.ry[0], r2.ra[0], mo[0], ma[0], acc, s0, s1, s2);
+                    iter_sums_pixel_masked(msum, k2.xy[0].x, k2.xy[0].y, k2.pa[0], axy[0].x, axy[0].y, av[0], r2.xy[0].x, r2.xy[0].y, r2.ra[0], mo[0], ma[0], acc, s0, s1, s2);
                     __builtin_amdgcn_sched_barrier(0);
-                    iter_sums_pixel_masked(msum, k2.px[1], k2.py[1], k2.pa[1], ax[1], ay[1], av[1], r2.rx[1], r2.ry[1], r2.ra[1], mo[1], ma[1], acc, s0, s1, s2);
+                    iter_sums_pixel_masked(msum, k2.xy[1].x, k2.xy[1].y, k2.pa[1], axy[1].x, axy[1].y, av[1], r2.xy[1].x, r2.xy[1].y, r2.ra[1], mo[1], ma[1], acc, s0, s1, s2);
                 }
                 // a row's arithmetic stays inside its step: without the pin the double sums of all four rows of a trip sink behind the fourth row's take (their only
                 // consumers are the next sums), with the 14 values each of them reads kept alive until then -- 99 live registers at a trip's first take, 256 at its end
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 // product configuration (tools/rc_probe.py, profiles/r04): two rows of prefetch, compiled for two workgroups of 4 waves per CU (<= 256 registers; the kernel needs
 // 160-200), the grid sized for one.  Depth 1 / 2 / 4 and one, two or three waves per SIMD all run within 2 % of each other: the launch moves its bytes at the
 // 5.4-5.7 TB/s this access pattern gets out of the memory system, plus ~7 us of launch ramp and tail.
-constexpr int MARCH_RC_DEPTH = 2, MARCH_RC_OCC = 2;
+constexpr int MARCH_RC_DEPTH = 4, MARCH_RC_OCC = 2;
 #ifdef THALLO_MARCH_SWEEP
 namespace thallo {
 int g_march_rc_depth = MARCH_RC_DEPTH;      // rows of prefetch (1, 2, 4)

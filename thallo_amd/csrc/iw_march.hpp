@@ -28,6 +28,8 @@ __device__ __forceinline__ void take1(float& d, const float& s) { asm volatile("
 __device__ __forceinline__ void take1(unsigned& d, const unsigned& s) { asm volatile("v_mov_b32 %0, %1" : "=&v"(d) : "v"(s)); }
 __device__ __forceinline__ void take4(float4& d, const float4& s) { take1(d.x, s.x); take1(d.y, s.y); take1(d.z, s.z); take1(d.w, s.w); }
 __device__ __forceinline__ void take2(float2& d, const float2& s) { take1(d.x, s.x); take1(d.y, s.y); }
+// ... a register PAIR with one v_mov_b64 (the pair stays a pair: what the packed arithmetic below wants)
+__device__ __forceinline__ void take_pair(unsigned long long& d, const unsigned long long& s) { asm volatile("v_mov_b64 %0, %1" : "=&v"(d) : "v"(s)); }
 
 // one neighbour's contribution to (J^T J p)_i on the unit grid; D = 0: x+1, 1: x-1, 2: y+1, 3: y-1.  k_iter's expressions with
 // u_i - u_j = -(dx,dy) folded in by hand (the compiler may not drop the products with 0.0f): with g_i = R'(a_i)(u_i-u_j),
@@ -79,6 +81,55 @@ __device__ __forceinline__ void jtjp_pair(const P& pm, const P& pc, const P& pn,
         ax[q] = __builtin_fmaf(wfit[q], pxi, ax[q]); ay[q] = __builtin_fmaf(wfit[q], pyi, ay[q]);
     }
 }
+// ---- the same J^T J p on (x, y) PAIRS (round 5; energy_image_warping_march_rc.hip).  Offset's two channels sit next to each other in every plane (r, p: {x0, y0, x1, y1};
+// cs: {c, s} per pixel) and the marching kernels are issue-bound -- a lone wave issues an instruction every ~5 cycles whatever it is, v_pk_fma_f32 included
+// (profiles/r04/issue_rates_pk_rate.txt).  Per neighbour d = p_i - p_j, e = d - g_i a_i, t = d + e + g_j a_j and a_xy = fma(m, t, a_xy) are ONE packed instruction
+// each; t_a = g_i . e and its accumulation stay scalar.  The x-direction terms need (s, -c): kept per pixel next to (c, s) (`gx`, formed once when a row enters
+// the rings) -- D = 0: g_i = gx_i, g_j = -gx_j; D = 1: negated; D = 2: g_i = cs_i, g_j = -cs_j; D = 3: negated.  Every component goes through the operations and
+// roundings of nb_term above (the same expression shapes under -ffp-contract=on, the same explicit fmas): BIT-identical results, 8 instead of 13 instructions.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(float m, v2f t, v2f a) { return __builtin_elementwise_fma(v2f{ m, m }, t, a); }
+template <int D>
+__device__ __forceinline__ void nb_term_xy(float m, v2f csi, v2f gxi, v2f pi, float pai, v2f pj, float paj, v2f csj, v2f gxj, v2f& axy, float& av)
+{
+    const v2f gi = D == 0 ? gxi : D == 1 ? -gxi : D == 2 ? csi : -csi;
+    const v2f gj = D == 0 ? -gxj : D == 1 ? gxj : D == 2 ? -csj : csj;
+    const v2f dp = pi - pj;
+    const v2f e = dp - gi * pai;
+    const v2f t = dp + e + gj * paj;
+    const float ta = gi.x * e.x + gi.y * e.y;
+    axy = fma2(m, t, axy); av = __builtin_fmaf(-m, ta, av);
+}
+// rows: P { v2f xy[2]; float pa[2]; }  G { v2f cs[2], gx[2]; float a[2]; }
+template <class P, class G>
+__device__ __forceinline__ void jtjp_pair_xy(const P& pm, const P& pc, const P& pn, const G& gm, const G& gc, const G& gn,
+                                             const float (&am)[2], const float (&ac)[2], const float (&an)[2], const float (&wfit)[2], float wr2,
+                                             v2f (&axy)[2], float (&av)[2])
+{
+    const v2f Lp = { from_left(pc.xy[1].x), from_left(pc.xy[1].y) }, Lcs = { from_left(gc.cs[1].x), from_left(gc.cs[1].y) }, Lgx = { Lcs.y, -Lcs.x };
+    const float Lpa = from_left(pc.pa[1]), La = from_left(ac[1]);
+    const v2f Rp = { from_right(pc.xy[0].x), from_right(pc.xy[0].y) }, Rcs = { from_right(gc.cs[0].x), from_right(gc.cs[0].y) }, Rgx = { Rcs.y, -Rcs.x };
+    const float Rpa = from_right(pc.pa[0]), Ra = from_right(ac[0]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        v2f a2 = { 0.f, 0.f }; float a_v = 0.f;
+        const v2f pi = pc.xy[q], csi = gc.cs[q], gxi = gc.gx[q]; const float pai = pc.pa[q];
+        if (q == 0) {
+            nb_term_xy<0>(ac[1], csi, gxi, pi, pai, pc.xy[1], pc.pa[1], gc.cs[1], gc.gx[1], a2, a_v);
+            nb_term_xy<1>(La, csi, gxi, pi, pai, Lp, Lpa, Lcs, Lgx, a2, a_v);
+        } else {
+            nb_term_xy<0>(Ra, csi, gxi, pi, pai, Rp, Rpa, Rcs, Rgx, a2, a_v);
+            nb_term_xy<1>(ac[0], csi, gxi, pi, pai, pc.xy[0], pc.pa[0], gc.cs[0], gc.gx[0], a2, a_v);
+        }
+        nb_term_xy<2>(an[q], csi, gxi, pi, pai, pn.xy[q], pn.pa[q], gn.cs[q], gn.gx[q], a2, a_v);
+        nb_term_xy<3>(am[q], csi, gxi, pi, pai, pm.xy[q], pm.pa[q], gm.cs[q], gm.gx[q], a2, a_v);
+        const float w = wr2 * ac[q];
+        a2 *= w; a_v *= w;
+        a2 = fma2(wfit[q], pi, a2);
+        axy[q] = a2; av[q] = a_v;
+    }
+}
+
 // the masks of one row's flags pair (bits 0-7 pixel 0, 8-15 pixel 1)
 __device__ __forceinline__ void flag_masks(unsigned f, float wf2, float (&a)[2], float (&wfit)[2])
 {

@@ -376,7 +376,12 @@ __global__ __launch_bounds__(MARCH_NT, OCC) void k_iter_march_rc(MarchGeo g, con
 // product configuration (tools/rc_probe.py, profiles/r04): two rows of prefetch, compiled for two workgroups of 4 waves per CU (<= 256 registers; the kernel needs
 // 160-200), the grid sized for one.  Depth 1 / 2 / 4 and one, two or three waves per SIMD all run within 2 % of each other: the launch moves its bytes at the
 // 5.4-5.7 TB/s this access pattern gets out of the memory system, plus ~7 us of launch ramp and tail.
-constexpr int MARCH_RC_DEPTH = 4, MARCH_RC_OCC = 2;
+[[maybe_unused]] constexpr int MARCH_RC_DEPTH = 4;      // (sweep build: the depth of the cache-policy variants)
+constexpr int MARCH_RC_OCC = 2;
+// Rows of prefetch: four where a wave has many rows (since the arithmetic went onto register pairs the row step is short enough for memory latency to show: 2048^2,
+// 35 rows per wave, 63.3 -> 59.5 us per PCG iteration), two where it has few -- the loop starts DEPTH rows early with empty slots, and at 5 rows per wave (2048 x 256)
+// four lead-in steps cost 14 %.  tools/rc_depth_by_size.py: 26 rows a tie, 22 / 18 / 9 / 5 rows 1-14 % for two.
+constexpr int MARCH_RC_DEEP_ROWS = 24;
 #ifdef THALLO_MARCH_SWEEP
 namespace thallo {
 int g_march_rc_depth = MARCH_RC_DEPTH;      // rows of prefetch (1, 2, 4)
@@ -412,13 +417,13 @@ int launch_march_rc(int W, int H, int row0, int row1, const float* cs, const uns
         r_in, r_out, A_in, A_out, p_in, p_out, delta, aNp, aDp, bNp, aNpp, aDpp, aD_out, s12_out, irregular, d, fin_tickets, aD_word, bN_word, xslot, prev); } while (0)
 #ifdef THALLO_MARCH_SWEEP      // tools/rc_probe.py: prefetch depth x register budget at the product's cache policy, and the cache-policy masks at the product's depth / budget
 #define RC_BY_DEPTH(DM) do { if constexpr (SLAB != 0) RC_LAUNCH(DM, MARCH_RC_DEPTH, MARCH_RC_OCC, MARCH_NTM); else { const int dp = g_march_rc_depth, oc = g_march_rc_occ, nt = g_march_rc_nt; \
-        if (nt != MARCH_NTM) { if (nt == 0) RC_LAUNCH(DM, 2, 2, 0); else if (nt == 1) RC_LAUNCH(DM, 2, 2, 1); else if (nt == 4) RC_LAUNCH(DM, 2, 2, 4); else if (nt == 7) RC_LAUNCH(DM, 2, 2, 7); \
-                                 else if (nt == 13) RC_LAUNCH(DM, 2, 2, 13); else if (nt == 21) RC_LAUNCH(DM, 2, 2, 21); else if (nt == 37) RC_LAUNCH(DM, 2, 2, 37); else if (nt == 63) RC_LAUNCH(DM, 2, 2, 63); else return -(int)hipErrorInvalidValue; } \
+        if (nt != MARCH_NTM) { if (nt == 0) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 0); else if (nt == 1) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 1); else if (nt == 4) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 4); else if (nt == 7) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 7); \
+                                 else if (nt == 13) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 13); else if (nt == 21) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 21); else if (nt == 37) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 37); else if (nt == 63) RC_LAUNCH(DM, MARCH_RC_DEPTH, 2, 63); else return -(int)hipErrorInvalidValue; } \
         else if (oc == 1) { if (dp == 4) RC_LAUNCH(DM, 4, 1, MARCH_NTM); else RC_LAUNCH(DM, 2, 1, MARCH_NTM); } \
         else if (oc == 3) { if (dp == 1) RC_LAUNCH(DM, 1, 3, MARCH_NTM); else RC_LAUNCH(DM, 2, 3, MARCH_NTM); } \
         else { if (dp == 1) RC_LAUNCH(DM, 1, 2, MARCH_NTM); else if (dp == 4) RC_LAUNCH(DM, 4, 2, MARCH_NTM); else RC_LAUNCH(DM, 2, 2, MARCH_NTM); } } } while (0)
 #else
-#define RC_BY_DEPTH(DM) RC_LAUNCH(DM, MARCH_RC_DEPTH, MARCH_RC_OCC, MARCH_NTM)
+#define RC_BY_DEPTH(DM) do { if (R >= MARCH_RC_DEEP_ROWS) RC_LAUNCH(DM, 4, MARCH_RC_OCC, MARCH_NTM); else RC_LAUNCH(DM, 2, MARCH_RC_OCC, MARCH_NTM); } while (0)
 #endif
     if (dmode == 1) RC_BY_DEPTH(1); else if (dmode == 2) RC_BY_DEPTH(2); else RC_BY_DEPTH(0);
 #undef RC_BY_DEPTH

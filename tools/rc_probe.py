@@ -57,5 +57,5 @@ for rep in range(2):
         for d, o in cfgs:
             out["runs"].append({"form": "rc", "rows": R, "depth": d, "occ": o, **run("1", d, o)})
         for nt in nts:
-            out["runs"].append({"form": "rc", "rows": R, "nt": nt, **run("1", 2, 2, nt)})
+            out["runs"].append({"form": "rc", "rows": R, "nt": nt, **run("1", int(os.environ.get("RC_NT_DEPTH", "2")), 2, nt)})
 print(json.dumps(out))

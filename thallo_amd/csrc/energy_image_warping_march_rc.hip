@@ -381,7 +381,7 @@ constexpr int MARCH_RC_OCC = 2;
 // Rows of prefetch: four where a wave has many rows (since the arithmetic went onto register pairs the row step is short enough for memory latency to show: 2048^2,
 // 35 rows per wave, 63.3 -> 59.5 us per PCG iteration), two where it has few -- the loop starts DEPTH rows early with empty slots, and at 5 rows per wave (2048 x 256)
 // four lead-in steps cost 14 %.  tools/rc_depth_by_size.py: 26 rows a tie, 22 / 18 / 9 / 5 rows 1-14 % for two.
-constexpr int MARCH_RC_DEEP_ROWS = 24;
+[[maybe_unused]] constexpr int MARCH_RC_DEEP_ROWS = 24;
 #ifdef THALLO_MARCH_SWEEP
 namespace thallo {
 int g_march_rc_depth = MARCH_RC_DEPTH;      // rows of prefetch (1, 2, 4)

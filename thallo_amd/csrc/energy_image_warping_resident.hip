@@ -244,7 +244,8 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
     auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + i) * 8); };     // granule i = 6 * row + component
     auto sumw = [&](int par, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * 8) * 8); };                    // that workgroup's 64-byte record
     // ---- state: rows t = ya - 1 + jj, jj = 0 .. R + 1 (jj = 0 and jj = nr + 1: the y halo; lanes 0 / 63: the x halo)
-    float rx[R + 2][2], ry[R + 2][2], ra[R + 2][2], px[R + 2][2], py[R + 2][2], pa[R + 2][2], ax[R + 2][2], ay[R + 2][2], av[R + 2][2];
+    // (x, y) of a pixel as a register pair: the stencil and the vector updates run on packed fp32 instructions (iw_march.hpp jtjp_pair_xy; round 5)
+    v2f rxy[R + 2][2], pxy[R + 2][2], axy[R + 2][2]; float ra[R + 2][2], pa[R + 2][2], av[R + 2][2];
     unsigned fl[R + 2];
     const float4* ro4 = reinterpret_cast<const float4*>(a.r_in); const float2* ra2 = reinterpret_cast<const float2*>(a.r_in + 2 * N);
     const float4* po4 = reinterpret_cast<const float4*>(a.p_in); const float2* pa2 = reinterpret_cast<const float2*>(a.p_in + 2 * N);
@@ -261,11 +262,11 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
         const unsigned fw = f4[i2 >> 1];
         const unsigned f = ok ? (fw >> ((((long)t * W2 + (x0 >> 1)) & 1) != 0 ? 16 : 0)) & 0xffffu : 0u;
         fl[jj] = f;
-        rx[jj][0] = r4.x; ry[jj][0] = r4.y; rx[jj][1] = r4.z; ry[jj][1] = r4.w; ra[jj][0] = r2.x; ra[jj][1] = r2.y;
-        px[jj][0] = p4.x; py[jj][0] = p4.y; px[jj][1] = p4.z; py[jj][1] = p4.w; pa[jj][0] = p2.x; pa[jj][1] = p2.y;
+        rxy[jj][0].x = r4.x; rxy[jj][0].y = r4.y; rxy[jj][1].x = r4.z; rxy[jj][1].y = r4.w; ra[jj][0] = r2.x; ra[jj][1] = r2.y;
+        pxy[jj][0].x = p4.x; pxy[jj][0].y = p4.y; pxy[jj][1].x = p4.z; pxy[jj][1].y = p4.w; pa[jj][0] = p2.x; pa[jj][1] = p2.y;
         csl[jj * RES_NT] = c4;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { ax[jj][q] = 0.f; ay[jj][q] = 0.f; av[jj][q] = 0.f; }
+        for (int q = 0; q < 2; ++q) { axy[jj][q].x = 0.f; axy[jj][q].y = 0.f; av[jj][q] = 0.f; }
         if (jj >= 1 && jj <= R) {       // delta of my rows into LDS
             const int j = jj - 1;
             const bool mine = j < nr && xout;
@@ -375,11 +376,11 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (up_lds && xout) {
                     const float* u = &S.rrow[parp][wave - 1][1][0][lane];
-                    ax[0][0] = u[0]; ay[0][0] = u[64]; av[0][0] = u[128]; ax[0][1] = u[192]; ay[0][1] = u[256]; av[0][1] = u[320];
+                    axy[0][0].x = u[0]; axy[0][0].y = u[64]; av[0][0] = u[128]; axy[0][1].x = u[192]; axy[0][1].y = u[256]; av[0][1] = u[320];
                 }
                 if (dn_lds && xout) {
                     const float* d = &S.rrow[parp][wave + 1][0][0][lane];
-                    ax[R + 1][0] = d[0]; ay[R + 1][0] = d[64]; av[R + 1][0] = d[128]; ax[R + 1][1] = d[192]; ay[R + 1][1] = d[256]; av[R + 1][1] = d[320];
+                    axy[R + 1][0].x = d[0]; axy[R + 1][0].y = d[64]; av[R + 1][0] = d[128]; axy[R + 1][1].x = d[192]; axy[R + 1][1].y = d[256]; av[R + 1][1] = d[320];
                 }
             }
             unsigned w7[7]; float rowu[6], rowd[6]; float cvl = 0.f, cvr = 0.f; float g_ad = 0.f, g_bn = 0.f;
@@ -445,16 +446,16 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             if (col_lane) { S.crx[wave][0][lane] = cvl; S.crx[wave][1][lane] = cvr; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // (the rows from the waves of my own workgroup were taken from LDS in front of the polling loop)
-            if ((up_glb || up_gh) && xout) { ax[0][0] = rowu[0]; ay[0][0] = rowu[1]; av[0][0] = rowu[2]; ax[0][1] = rowu[3]; ay[0][1] = rowu[4]; av[0][1] = rowu[5]; }
-            if ((dn_glb || dn_gh) && xout) { ax[R + 1][0] = rowd[0]; ay[R + 1][0] = rowd[1]; av[R + 1][0] = rowd[2]; ax[R + 1][1] = rowd[3]; ay[R + 1][1] = rowd[4]; av[R + 1][1] = rowd[5]; }
+            if ((up_glb || up_gh) && xout) { axy[0][0].x = rowu[0]; axy[0][0].y = rowu[1]; av[0][0] = rowu[2]; axy[0][1].x = rowu[3]; axy[0][1].y = rowu[4]; av[0][1] = rowu[5]; }
+            if ((dn_glb || dn_gh) && xout) { axy[R + 1][0].x = rowd[0]; axy[R + 1][0].y = rowd[1]; av[R + 1][0] = rowd[2]; axy[R + 1][1].x = rowd[3]; axy[R + 1][1].y = rowd[4]; av[R + 1][1] = rowd[5]; }
             // x halo: lane 0 takes lane 62's pixels of the strip to the left, lane 63 lane 1's pixels of the strip to the right, for each of my rows
             if ((lane == 0 && has_lf) || (lane == 63 && has_rt)) {
                 const float* cx = &S.crx[wave][lane == 0 ? 0 : 1][0];
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     if (j < nr) {
-                        ax[j + 1][0] = cx[6 * j]; ay[j + 1][0] = cx[6 * j + 1]; av[j + 1][0] = cx[6 * j + 2];
-                        ax[j + 1][1] = cx[6 * j + 3]; ay[j + 1][1] = cx[6 * j + 4]; av[j + 1][1] = cx[6 * j + 5];
+                        axy[j + 1][0].x = cx[6 * j]; axy[j + 1][0].y = cx[6 * j + 1]; av[j + 1][0] = cx[6 * j + 2];
+                        axy[j + 1][1].x = cx[6 * j + 3]; axy[j + 1][1].y = cx[6 * j + 4]; av[j + 1][1] = cx[6 * j + 5];
                     }
                 }
             }
@@ -477,13 +478,13 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             if (k > 0) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    rx[jj][q] = __builtin_fmaf(-alpha, ax[jj][q], rx[jj][q]); ry[jj][q] = __builtin_fmaf(-alpha, ay[jj][q], ry[jj][q]);
+                    rxy[jj][q] = fma2(-alpha, axy[jj][q], rxy[jj][q]);
                     ra[jj][q] = __builtin_fmaf(-alpha, av[jj][q], ra[jj][q]);
                 }
                 if (jj >= 1 && jj <= R) {
                     float* d = dl + ((jj - 1) * 6) * RES_NT + threadIdx.x;
-                    d[0] = __builtin_fmaf(alpha, px[jj][0], d[0]); d[RES_NT] = __builtin_fmaf(alpha, py[jj][0], d[RES_NT]);
-                    d[2 * RES_NT] = __builtin_fmaf(alpha, px[jj][1], d[2 * RES_NT]); d[3 * RES_NT] = __builtin_fmaf(alpha, py[jj][1], d[3 * RES_NT]);
+                    d[0] = __builtin_fmaf(alpha, pxy[jj][0].x, d[0]); d[RES_NT] = __builtin_fmaf(alpha, pxy[jj][0].y, d[RES_NT]);
+                    d[2 * RES_NT] = __builtin_fmaf(alpha, pxy[jj][1].x, d[2 * RES_NT]); d[3 * RES_NT] = __builtin_fmaf(alpha, pxy[jj][1].y, d[3 * RES_NT]);
                     d[4 * RES_NT] = __builtin_fmaf(alpha, pa[jj][0], d[4 * RES_NT]); d[5 * RES_NT] = __builtin_fmaf(alpha, pa[jj][1], d[5 * RES_NT]);
                 }
             }
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const float2 m = S.lut[(fl[jj] >> (8 * q)) & 31u];           // M^-1 by the pixel's flags, looked up where it is used: not a register per row
-                px[jj][q] = act ? m.x * rx[jj][q] + beta * px[jj][q] : 0.f;
-                py[jj][q] = act ? m.x * ry[jj][q] + beta * py[jj][q] : 0.f;
+                const v2f pnew = m.x * rxy[jj][q] + beta * pxy[jj][q];
+                pxy[jj][q] = act ? pnew : v2f{ 0.f, 0.f };
                 pa[jj][q] = act ? m.y * ra[jj][q] + beta * pa[jj][q] : 0.f;
             }
         }
@@ -504,57 +505,59 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             if (j < nr) {
                 const int jm = j, jc = j + 1, jn = j + 2;
                 const float4 csm = csl[jm * RES_NT], csc = csl[jc * RES_NT], csn = csl[jn * RES_NT];        // {c0, s0, c1, s1} of the rows above, here, below (my own words in LDS)
-                struct PRow { float px[2], py[2], pa[2]; }; struct GRow { float c[2], s[2]; };
-                const PRow pm_ = { { px[jm][0], px[jm][1] }, { py[jm][0], py[jm][1] }, { pa[jm][0], pa[jm][1] } }, pc_ = { { px[jc][0], px[jc][1] }, { py[jc][0], py[jc][1] }, { pa[jc][0], pa[jc][1] } };
-                const PRow pn_ = { { px[jn][0], px[jn][1] }, { py[jn][0], py[jn][1] }, { pa[jn][0], pa[jn][1] } };
-                const GRow gm_ = { { csm.x, csm.z }, { csm.y, csm.w } }, gc_ = { { csc.x, csc.z }, { csc.y, csc.w } }, gn_ = { { csn.x, csn.z }, { csn.y, csn.w } };
+                struct PRow { v2f xy[2]; float pa[2]; }; struct GRow { v2f cs[2], gx[2]; };
+                const PRow pm_ = { { pxy[jm][0], pxy[jm][1] }, { pa[jm][0], pa[jm][1] } }, pc_ = { { pxy[jc][0], pxy[jc][1] }, { pa[jc][0], pa[jc][1] } };
+                const PRow pn_ = { { pxy[jn][0], pxy[jn][1] }, { pa[jn][0], pa[jn][1] } };
+                // ((sin, -cos) is needed of the centre row only: the x-direction terms; the rows above / below enter through (cos, sin))
+                const GRow gm_ = { { v2f{ csm.x, csm.y }, v2f{ csm.z, csm.w } }, { v2f{ 0.f, 0.f }, v2f{ 0.f, 0.f } } }, gn_ = { { v2f{ csn.x, csn.y }, v2f{ csn.z, csn.w } }, { v2f{ 0.f, 0.f }, v2f{ 0.f, 0.f } } };
+                const GRow gc_ = { { v2f{ csc.x, csc.y }, v2f{ csc.z, csc.w } }, { v2f{ csc.y, -csc.x }, v2f{ csc.w, -csc.z } } };
                 float am[2], ac[2], an[2], wfit[2], wdum[2];
                 flag_masks(fl[jm], a.wf2, am, wdum); flag_masks(fl[jc], a.wf2, ac, wfit); flag_masks(fl[jn], a.wf2, an, wdum);
-                float bx[2], by[2], bv[2];
-                jtjp_pair(pm_, pc_, pn_, gm_, gc_, gn_, am, ac, an, wfit, a.wr2, bx, by, bv);       // (every lane: the x neighbours come through wave shifts; iw_march.hpp, branch-free)
+                v2f b2[2]; float bv[2];
+                jtjp_pair_xy(pm_, pc_, pn_, gm_, gc_, gn_, am, ac, an, wfit, a.wr2, b2, bv);        // (every lane: the x neighbours come through wave shifts; iw_march.hpp, branch-free, on (x, y) pairs)
                 if (xout) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const unsigned fq = (fl[jc] >> (8 * q)) & 255u;
-                        const float pxi = px[jc][q], pyi = py[jc][q], pai = pa[jc][q];
-                        acc += pxi * bx[q] + pyi * by[q] + pai * bv[q];
+                        const float pxi = pxy[jc][q].x, pyi = pxy[jc][q].y, pai = pa[jc][q];
+                        acc += pxi * b2[q].x + pyi * b2[q].y + pai * bv[q];
                         const float2 mq = S.lut[fq & 31u];
-                        const double dmo = mq.x, dma = mq.y, drx = rx[jc][q], dry = ry[jc][q], dra = ra[jc][q], dax = bx[q], day = by[q], daa = bv[q];
+                        const double dmo = mq.x, dma = mq.y, drx = rxy[jc][q].x, dry = rxy[jc][q].y, dra = ra[jc][q], dax = b2[q].x, day = b2[q].y, daa = bv[q];
                         s0 = __builtin_fma(dmo, __builtin_fma(dry, dry, drx * drx), __builtin_fma(dma, dra * dra, s0));
                         s1 = __builtin_fma(dmo, __builtin_fma(dry, day, drx * dax), __builtin_fma(dma, dra * daa, s1));
                         s2 = __builtin_fma(dmo, __builtin_fma(day, day, dax * dax), __builtin_fma(dma, daa * daa, s2));
-                        ax[jc][q] = bx[q]; ay[jc][q] = by[q]; av[jc][q] = bv[q];
+                        axy[jc][q] = b2[q]; av[jc][q] = bv[q];
                     }
                     // the boundary goes out as soon as it exists: to another workgroup as granules, to a wave of my workgroup through LDS (tagged below)
                     if (DIST && j == 0 && up_gh) {        // my first owned row is the rank above's bottom ghost row
                         const unsigned d = ghost(par, 1), Tx = seqx + (unsigned)k + 1u;
-                        st2s(RS_PA, d, Tx, bx[0], by[0]); st2s(RS_PA, d + 16, Tx, bv[0], bx[1]); st2s(RS_PA, d + 32, Tx, by[1], bv[1]);
+                        st2s(RS_PA, d, Tx, b2[0].x, b2[0].y); st2s(RS_PA, d + 16, Tx, bv[0], b2[1].x); st2s(RS_PA, d + 32, Tx, b2[1].y, bv[1]);
                     }
                     if (DIST && j == R - 1 && dn_gh) {    // my last owned row is the rank below's top ghost row
                         const unsigned d = ghost(par, 0), Tx = seqx + (unsigned)k + 1u;
-                        st2s(RS_PB, d, Tx, bx[0], by[0]); st2s(RS_PB, d + 16, Tx, bv[0], bx[1]); st2s(RS_PB, d + 32, Tx, by[1], bv[1]);
+                        st2s(RS_PB, d, Tx, b2[0].x, b2[0].y); st2s(RS_PB, d + 16, Tx, bv[0], b2[1].x); st2s(RS_PB, d + 32, Tx, b2[1].y, bv[1]);
                     }
                     if (j == 0 && has_up && !up_gh) {
                         if (up_glb) {
                             const unsigned d = rowh(par, wid, 0);
-                            st2g(RS_ROW, d, T, bx[0], by[0]); st2g(RS_ROW, d + 16, T, bv[0], bx[1]); st2g(RS_ROW, d + 32, T, by[1], bv[1]);
+                            st2g(RS_ROW, d, T, b2[0].x, b2[0].y); st2g(RS_ROW, d + 16, T, bv[0], b2[1].x); st2g(RS_ROW, d + 32, T, b2[1].y, bv[1]);
                         } else {
                             float* d = &S.rrow[par][wave][0][0][lane];
-                            d[0] = bx[0]; d[64] = by[0]; d[128] = bv[0]; d[192] = bx[1]; d[256] = by[1]; d[320] = bv[1];
+                            d[0] = b2[0].x; d[64] = b2[0].y; d[128] = bv[0]; d[192] = b2[1].x; d[256] = b2[1].y; d[320] = bv[1];
                         }
                     }
                     if (j == nr - 1 && has_dn && !dn_gh) {
                         if (dn_glb) {
                             const unsigned d = rowh(par, wid, 1);
-                            st2g(RS_ROW, d, T, bx[0], by[0]); st2g(RS_ROW, d + 16, T, bv[0], bx[1]); st2g(RS_ROW, d + 32, T, by[1], bv[1]);
+                            st2g(RS_ROW, d, T, b2[0].x, b2[0].y); st2g(RS_ROW, d + 16, T, bv[0], b2[1].x); st2g(RS_ROW, d + 32, T, b2[1].y, bv[1]);
                         } else {
                             float* d = &S.rrow[par][wave][1][0][lane];
-                            d[0] = bx[0]; d[64] = by[0]; d[128] = bv[0]; d[192] = bx[1]; d[256] = by[1]; d[320] = bv[1];
+                            d[0] = b2[0].x; d[64] = b2[0].y; d[128] = bv[0]; d[192] = b2[1].x; d[256] = b2[1].y; d[320] = bv[1];
                         }
                     }
                     if (lane == 1 || lane == 62) {
                         float* d = &S.cst[wave][lane == 1 ? 0 : 1][6 * j];
-                        d[0] = bx[0]; d[1] = by[0]; d[2] = bv[0]; d[3] = bx[1]; d[4] = by[1]; d[5] = bv[1];
+                        d[0] = b2[0].x; d[1] = b2[0].y; d[2] = bv[0]; d[3] = b2[1].x; d[4] = b2[1].y; d[5] = bv[1];
                     }
                 }
             }
@@ -606,9 +609,9 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             if (j < nr && xout) {
                 const int jc = j + 1;
                 const long i = (long)(ya + j) * W2 + (x0 >> 1);
-                Ro4[i] = make_float4(rx[jc][0], ry[jc][0], rx[jc][1], ry[jc][1]); Ra2[i] = make_float2(ra[jc][0], ra[jc][1]);
-                qo4[i] = make_float4(px[jc][0], py[jc][0], px[jc][1], py[jc][1]); qa2[i] = make_float2(pa[jc][0], pa[jc][1]);
-                Ao4[i] = make_float4(ax[jc][0], ay[jc][0], ax[jc][1], ay[jc][1]); Aa2[i] = make_float2(av[jc][0], av[jc][1]);
+                Ro4[i] = make_float4(rxy[jc][0].x, rxy[jc][0].y, rxy[jc][1].x, rxy[jc][1].y); Ra2[i] = make_float2(ra[jc][0], ra[jc][1]);
+                qo4[i] = make_float4(pxy[jc][0].x, pxy[jc][0].y, pxy[jc][1].x, pxy[jc][1].y); qa2[i] = make_float2(pa[jc][0], pa[jc][1]);
+                Ao4[i] = make_float4(axy[jc][0].x, axy[jc][0].y, axy[jc][1].x, axy[jc][1].y); Aa2[i] = make_float2(av[jc][0], av[jc][1]);
                 const float* d = dl + (j * 6) * RES_NT + threadIdx.x;
                 dl4[i] = make_float4(d[0], d[RES_NT], d[2 * RES_NT], d[3 * RES_NT]); dl2[i] = make_float2(d[4 * RES_NT], d[5 * RES_NT]);
             }

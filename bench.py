@@ -8,8 +8,11 @@ in HBM (reference workload: examples/image_warping/src/main.cpp:131-149, 8 GN x 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2048] [--liters 100]
 
 Prints ONE JSON line (rank 0).  `value` = whole-job PCG iterations per second.
-`roofline` = the dominant kernel (PCGIteration: one launch = a whole PCG iteration; round 5: p_k into a ring of planes, 57.1 B/pixel, the delta update a launch of its own
-next to the loop) -- its own launch duration sampled with HIP events on its stream around every 4th launch in three GN steps BEHIND the timed region; the reference
+`roofline` = the dominant kernel (PCGIteration: one launch = a whole PCG iteration; since round 5 p_k goes into a ring of planes, 57.1 B/pixel, and the delta update is a
+launch of its own next to the loop) -- its OWN duration (begin-to-end timestamps of two HIP events handed to the launch itself, hipExtLaunchKernelGGL) sampled at every
+53rd launch of it INSIDE the timed region (`roofline.method_version` 2; version 1, rounds 1-4: events recorded around the launch, dispatch gap included, on 74.8 B/pixel --
+kept as `avg_launch_ms_between_recorded_events`; the two versions' `frac` are not comparable).  `roofline.traffic` is NOT measured in this run
+(`traffic_measured_this_run` false): it is the committed PMC figure of tools/profile.sh's passes over this same command.  The reference
 formulation's 180 B/pixel figure is kept under `reference_formulation`; `roofline.applyjtj_standalone` = the plain applyJTJ kernel (48 B/pixel) timed
 back-to-back after the timed region.  `--gpus N` (N > 1) without a launcher: this process starts the N ranks itself; a device-side transport that does not come up is
 reported per rank on stderr and in `transport_fallback` (THALLO_DIST_TRANSPORT=device: exit 3 instead).  `cpu_baseline` = oracle/cpu_port_image_warping.c (OpenMP port
@@ -263,7 +266,8 @@ def main():
                                 else "PCGIteration (one launch = PCGStep2 of iteration k-1 + PCGStep3 + delta update + applyJTJ of iteration k)"
                                 if one_kernel else "PCGStep1 (fused PCGStep3 + delta update + applyJTJ)"),
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic": traffic, "traffic_source": traffic_source, "traffic_measured_this_run": False,
+                     "method_version": 2,      # 2 (round 5 on): the kernel's own begin-to-end duration, on the kernel's own byte count; 1: events recorded around the launch
                      "bytes_per_pixel": dom_bytes, "pixels_per_launch": npx,
                      "avg_launch_ms": step1_ms, "samples": n_samples,
                      "timing": timing,

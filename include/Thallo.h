@@ -166,8 +166,10 @@ int ThalloX_FrontendTextDims(const char* filename, int what, const unsigned* dim
  *     kernel stores its scalars into every rank's mailbox and its boundary rows into the neighbours' ghost rows over xGMI
  *     (hipIpc-mapped fine-grained memory) and its last workgroup waits for the peers' granules.
  * Supported: image_warping (one ghost row per neighbour; UrShape on the unit pixel grid, W % 4 == 0; Gauss-Newton; both transports) and
- * shape_from_shading (TWO ghost rows per neighbour; Gauss-Newton and ThalloX_EnableLM; all-gather transport: per PCG iteration one exchange
- * in the GN form, two -- alphaD, then betaN + q + the ghost rows of z -- in the LM form).
+ * shape_from_shading (TWO ghost rows per neighbour; Gauss-Newton and ThalloX_EnableLM; BOTH transports: per PCG iteration one exchange -- the
+ * all-gather carries the GN form's sums and rows, and the LM form's alphaD, then betaN + q + the ghost rows of z, in two; on the device-side
+ * transport the LM iteration is one launch + ONE mailbox / peer-to-peer exchange that also finishes alphaD, betaN, q and the zeta test,
+ * thallo_hip_dist_xrows_lm).
  * Graph energies (arap_mesh_deformation) are split into contiguous VERTEX RANGES instead: every rank makes its Plan for the WHOLE problem, passes the
  * whole (replicated) buffers, and sets row0 / row1 to the vertex range it owns (equal ranges: N % world == 0); per PCG iteration one all-gather
  * of [alphaD, N, S1, S2 | the owned slice of A p]; the unknowns stay replicated bit for bit.  Gauss-Newton, all-gather transport.

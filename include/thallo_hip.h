@@ -287,27 +287,6 @@ int thallo_hip_iw_pcg_step1(int W, int H, int row0, int row1, const float* cs, c
  * Alternating 1, 2 halves delta's read + write traffic (-6 B/pixel/iteration) and produces the same bits as mode 0 throughout.
  * THALLO_IW_STEP1_MODE(k, batched) gives the mode of iteration k. */
 #define THALLO_IW_STEP1_MODE(k, batched) ((k) == 0 ? 1 : !(batched) ? 0 : ((k) & 1) ? 2 : 4)
-/* ---- the marching PCG iteration as a PERSISTENT loop (energy_image_warping_march_persist.hip): iterations k0 .. k1-1 of a GN step in ONE launch, for whole images on
- * the unit pixel grid whose solver state does not fit the chip's registers (2048^2: 35 rows per wave).  The launch-per-iteration grid stays on the chip; the
- * iteration's sums (a tagged record per workgroup) are its one synchronisation point, r_k / p_k are stored write-through.  What a launch per iteration
- * (thallo_hip_iw_pcg_iter_march_rc_deferred, delta mode "none") reads and leaves behind, in the plan's own layout:
- *   r[k & 1] -> r[(k + 1) & 1];  p_{k-1} in planes[(k - 1) % n_planes] -> p_k in planes[k % n_planes]   (n_planes >= k1 - k0 + 1);
- *   reduction slots at parts + j * THALLO_HIP_MAX_PARTIALS, their words at parts + slots * THALLO_HIP_MAX_PARTIALS + j; alphaN_k = slot B + 2k, alphaD_k = B + 2k + 1, betaN_k = B + 2k + 2:
- *   read  alphaN_{k0-1} (alphaN_prev: partials or one word), the nb_prev alphaD partials of iteration k0 - 1 and its double sums in s12[(k0 - 1) & 1];
- *   write the words alphaD_{k-1}, betaN_{k-1} for k0 <= k < k1 and the partials of iteration k1 - 1 (alphaD slot, s12[(k1 - 1) & 1]; as many as the return value).
- * xbuf: thallo_hip_iw_march_persist_bytes() bytes, zeroed once by the caller, private to the plan.  Bit-identical to the launches it replaces (same strips, segments,
- * expressions and order of every sum).  Every workgroup must be resident (one per CU; checked at launch); every wait inside is bounded (2 s, or spin_ms), an expired
- * one sets the error word thallo_hip_iw_march_persist_status reads.  Returns the number of workgroups (> 0), -hipErrorNotSupported when the shape does not fit.
- * Replaces the loop of gauss_newton.t:1615-1687. */
-long thallo_hip_iw_march_persist_bytes(void);
-int thallo_hip_iw_march_persist_rows(int W, int H);      /* rows per wave, 0 = the shape does not run as a persistent loop */
-int thallo_hip_iw_pcg_march_persist(int W, int H, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
-                                    float* r0, float* r1, float* const* planes, int n_planes, int k0, int k1,
-                                    float* parts, int slots, int B, double* s12_0, double* s12_1, int nb_prev, thallo_sum_t alphaN_prev,
-                                    const int* irregular, void* xbuf, thallo_stream_t stream);
-int thallo_hip_iw_march_persist_status(void* xbuf, int clear, int spin_ms, unsigned* post_mortem5, thallo_stream_t stream);
-void thallo_hip_iw_march_persist_debug_set(int what, int value);      /* tools: what 0 = the acquire form (1) instead of L1-bypassing loads (0) */
-
 /* One kernel per PCG iteration (replaces pcg_step1 + pcg_step2 of iteration k-1/k): r_out = r_in - alpha_{k-1} Ap_in (first:
  * r_in), z = M^-1 r_out (pixel grid: from the flags byte; else from `pre`), p_out = z + beta_{k-1} p_in, the deferred delta
  * update (mode as in pcg_step1), Ap_out = J^T J p_out, and per workgroup: alphaD partial (float) into alphaD_out[b] and the three
@@ -609,6 +588,26 @@ void thallo_hip_arap_debug_set(int what, int value);     /* tools / tests only: 
 /* tools / tests only: 0 = rows per wave segment of the marching J^T(J v) kernel, 1 = workgroups per CU its grid is sized for (0 = automatic),
  * 2 = kernel choice (1 marching, 0 LDS-tiled, -1 the environment's THALLO_SFS_MARCH; default marching) */
 void thallo_hip_sfs_march_debug_set(int what, int value);
+/* Round 6 -- the layout of the precomputed planes every thallo_hip_sfs_* entry point reads / writes for a W x H (local) image: 0 = G float4 / Wt float2 / fl byte per pixel
+ * as described above; 1 = PACKED (images of even width; csrc/sfs_pair.hpp): the G buffer holds four planes of N floats Gx | Gy | Gz | BI, the first 4 N bytes of the Wt
+ * buffer one dword per pixel = flags | edgeMaskR << 8 | edgeMaskC << 16 (mask bytes zeroed outside the inner image), fl is not used; the marching kernels then work on
+ * pixel PAIRS (energy_sfs_pair.hip: 40 instead of 49 bytes per pixel and GN iteration).  Buffer sizes are the same in both.  thallo_hip_sfs_cost returns
+ * -hipErrorNotSupported on packed planes (thallo_hip_sfs_precompute_cost serves).  thallo_hip_sfs_march_debug_set(6, 0 / 1 / -1) forces the layout off / on / back to the
+ * environment's (THALLO_SFS_PAIR, default on); what = 7: rows of prefetch of the pair kernels (3 / 6; 0 = automatic). */
+int thallo_hip_sfs_planes_layout(int W, int H);
+/* Packed planes only (-hipErrorNotSupported elsewhere: the caller runs the launches they replace).
+ * thallo_hip_sfs_pcg_init_lm: PCGInit1's J^T F pass with PCGFinalizeDiagonal (gauss_newton.t:936-969) riding along: r = -J^T F, delta = 0, p_prev = 0 and, from the raw diagonal
+ * of J^T J formed in the same pass, CtC, pre = M^-1, b = r, z = M^-1 r, SSq (written when save_ssq, else read), partials of r . z -- thallo_hip_sfs_pcg_init +
+ * thallo_hip_lm_finalize_diagonal in one launch.
+ * thallo_hip_sfs_lm_model_cost: delta_out = delta + alpha_kl p_kl (the update the one-launch LM loop owes: thallo_hip_lm_owed_delta's rule; delta_out != delta) and the partials of
+ * delta_out . (J^T J delta_out) and delta_out . b -- thallo_hip_lm_owed_delta + thallo_hip_sfs_apply_jtj + thallo_hip_dot in one launch (whole image on one GPU).  Returns the
+ * number of partials in each of dJJd_out / db_out. */
+int thallo_hip_sfs_pcg_init_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+                               const unsigned char* fl, float* r, float* z, float* p_prev, float* delta, float* SSq, float* CtC, float* pre, float* b,
+                               float radius, float min_lm_diagonal, float max_lm_diagonal, int save_ssq, float* alphaN_out, thallo_stream_t stream);
+int thallo_hip_sfs_lm_model_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                 const float* delta, float* delta_out, const float* p_even, const float* p_odd, const float* b, const float* alphaN_words, const float* alphaD_words,
+                                 int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out, thallo_stream_t stream);
 
 /* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped
  * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's
@@ -665,18 +664,6 @@ int thallo_hip_sfs_apply_jtj_sums_fin(int W, int H, int row0, int row1, int yoff
 int thallo_hip_ba_apply_jtj2_fin(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                                  const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* alphaD_out,
                                  const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_fin_t fin, thallo_stream_t stream);
-/* The PCG loop of a Gauss-Newton step of bundle adjustment in ONE launch (round 5): min(CUs, 256) workgroups stay on the chip and run the flat update, the camera
-   kernel and the point kernel of thallo_hip_pcg_update(_fin) + thallo_hip_ba_apply_jtj2 as phases of one loop, a grid-wide arrival barrier behind each; every
-   partial, sum and vector element has the bits of the three-launch form.  In: what thallo_hip_ba_pcg_init left (r_0, M^-1, delta = 0, alphaN_0) and the packed point
-   blocks JP.  Out: r_{L-1}, A p_{L-1}, p_{L-1} in p0 / p1 by L & 1 (0: p0), delta without its last term, words[2k] = alphaD_k, words[2k + 1] = betaN_k.
-   xbuf: thallo_hip_ba_resident_bytes() bytes, zeroed once, private to the plan; thallo_hip_ba_resident_status reads the error word a bounded wait that ran out leaves.
-   Replaces gauss_newton.t:1615-1687 (GN branch, one GPU). */
-long thallo_hip_ba_resident_bytes(void);
-int thallo_hip_ba_pcg_resident(int C, int P, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                               const float* cameras, const float* points, const float* JP, float* JpC,
-                               float* r, float* Ap, const float* pre, float* p0, float* p1, float* delta, thallo_sum_t alphaN0, float* words, void* xbuf, int L, thallo_stream_t stream);
-int thallo_hip_ba_resident_status(void* xbuf, int clear, unsigned* post_mortem5, thallo_stream_t stream);
-void thallo_hip_ba_resident_debug_set(int what, int value);      /* tools: what 0 = workgroups of the resident loop (0: two per CU) */
 int thallo_hip_ba_apply2_camera_slots(int C_, int P_);      /* how many of thallo_hip_ba_apply_jtj2*'s partial slots (the first ones) are the camera launch's */
 /* LM: applyJTJ with PCGStep1_Finish folded in (gauss_newton.t:774-787): Ap = (J^T J + CtC) p, partials of p . Ap; gate as below (may be NULL) */
 int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

@@ -487,271 +487,9 @@ __global__ __launch_bounds__(BLOCK) void k_pt2(int C_, int P_, const int* __rest
     else block_store_partial(acc, part_out + fin.blk_off, red);
 }
 
-int g_ba_res_wg = 0;      // tools: workgroups of the resident loop (0: two per CU)
-// ------------------------------------------------------------------------------------------ the PCG loop of a GN step in ONE launch (round 5)
-// Three launches per PCG iteration (PCGUpdate, k_cam2, k_pt2) of 6 + 13 + 12 us move ~50 MB: what the iteration pays for is launch boundaries, ramps and tails, not
-// bytes.  Here min(CUs, 256) workgroups stay on the chip for all L iterations and run the three kernels' bodies as PHASES of one loop:
-//   U  the flat update (k_pcg_update's expressions, element by element): r -= alpha_{k-1} A p, p_k = M^-1 r + beta_{k-1} p_{k-1}, delta += alpha_{k-1} p_{k-1}
-//   A  the camera kernel (k_cam2's body per camera block): J p in camera order, the camera part of J^T (J p), the block's partial sums
-//   B  the point kernel (k_pt2's body per point block): the point part, the block's partial sums; then EVERY workgroup adds the partials up for itself
-//      (last_workgroup_totals' order, as k_pcg_update_fin does): alpha_k, beta_k
-// with a grid-wide arrival barrier behind each (sharded monotonic counters, quiet polling by eight lanes; ~1 us behind the last arrival).  Each physical workgroup
-// walks the launch-per-iteration grid's blocks b, b + G, ... with those kernels' own thread-to-work mapping, so every partial, every sum and every vector element has
-// the bits of the three-launch form (tests/test_gpu_parity.py).  What crosses workgroups inside the launch -- p, A p, r, J p, the partials -- is stored write-through
-// and loaded past L1 (agent scope); delta and M^-1 are each touched by one thread only.  Every wait is bounded (2 s; error word, the host reports it at the next cost).
-// Replaces gauss_newton.t:1615-1687 for bundle adjustment's GN branch on one GPU.
-enum { BRES_ERR = 0, BRES_SPIN_MS = 1, BRES_PM = 2, BRES_CTL_WORDS = 16, BRES_CNT_STRIDE = 32 };
-struct BaResArgs {
-    int C, P, L, cb, pb;
-    const int *cam_ptr, *q_pt, *pt_ptr, *pt_pos;
-    const float *cams, *pts; const float2* JP; float2* JpC;
-    float *r, *Ap; const float* pre; float* p[2]; float* delta;
-    thallo_sum_t aN0; float* words;                 // words[2k] = alphaD_k, words[2k + 1] = betaN_k
-    float* aD_part; double* s3_part;                // the iteration's partial slots (cb + pb of them), reused every iteration
-    unsigned* ctl; unsigned* cnt;                   // control words; arrival counters [8 shards] on lines of their own
-};
-__device__ __forceinline__ float ld1a(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st1a(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float2 ld2a(const float2* p)
-{ const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))); }
-__device__ __forceinline__ void st2a(float2* p, float2 v)
-{ __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(v.y) << 32) | (unsigned long long)__float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-typedef __amdgpu_buffer_rsrc_t ba_rsrc_t;
-typedef unsigned ba_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned ba_u32x3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ ba_rsrc_t ba_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffffu, 0x00020000); }
-// 16- / 12-byte accesses at agent scope (aux 16 = sc1: stores write through, loads go past L1); offsets in bytes (a flat vector is far below 4 GiB)
-__device__ __forceinline__ float4 ld4a(ba_rsrc_t r, unsigned off) { const ba_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
-__device__ __forceinline__ void st4a(ba_rsrc_t r, unsigned off, float4 f) { ba_u32x4 v; v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w); __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
-__device__ __forceinline__ void ld3a(ba_rsrc_t r, unsigned off, float (&o)[3]) { const ba_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 16); o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); }
-__device__ __forceinline__ void st3a(ba_rsrc_t r, unsigned off, float a, float b, float c) { ba_u32x3 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); v.z = __float_as_uint(c); __builtin_amdgcn_raw_buffer_store_b96(v, r, off, 0, 16); }
-
-#ifdef BRES_STAMPS
-__device__ unsigned long long* g_stamps_b = nullptr;      // tools/ba_resident_probe.py: wave 0's lane 0 of every workgroup, iterations 8 .. 11, 8 stamps each (100 MHz)
-#define BSTAMP(k, i) do { if (threadIdx.x == 0 && g_stamps_b && (k) >= 8 && (k) < 12) g_stamps_b[(blockIdx.x * 4 + ((k) - 8)) * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define BSTAMP(k, i) do { } while (0)
+#ifdef THALLO_RESEARCH
+#include "probe/ba_resident_device.inc"      // the one-launch PCG loop (round 5: bit-identical, slower; research builds only)
 #endif
-__global__ void k_ba_resident_begin(unsigned* cnt) { if (threadIdx.x < 8) cnt[threadIdx.x * BRES_CNT_STRIDE] = 0u; }
-
-__global__ __launch_bounds__(BLOCK, 2) void k_ba_resident(BaResArgs a)
-{
-    __shared__ float red[16];
-    __shared__ double redd[6 * BLOCK / 64];
-    __shared__ unsigned dead_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int G = (int)gridDim.x;
-    const long PB = 9L * a.C, n = PB + 3L * a.P;
-    const int nb = a.cb + a.pb;
-    unsigned epoch = 0;                                // barriers passed so far (every workgroup counts the same)
-    bool dead = false;
-    if (threadIdx.x == 0) dead_s = 0u;
-    __syncthreads();
-    // grid-wide barrier: every wave's stores have left the CU, one arrival per workgroup, quiet polling of the eight shard words
-    auto grid_barrier = [&](unsigned what) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        ++epoch;
-        if (wave == 0) {
-            if (lane == 0) __hip_atomic_fetch_add(a.cnt + (blockIdx.x & 7) * BRES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned members = 0;
-            if (lane < 8) members = (unsigned)((G - lane + 7) / 8);
-            const unsigned want = members * epoch;
-            bool in = lane >= 8;
-            unsigned spins = 0; long long t0 = 0;
-            while (!dead) {
-                if (!in) in = __hip_atomic_load(a.cnt + (lane & 7) * BRES_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
-                if (__all(in)) break;
-                __builtin_amdgcn_s_sleep(4);
-                if (((++spins) & 255u) == 0u) {
-                    if (__hip_atomic_load(a.ctl + BRES_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
-                    const long long now = wall_clock64();
-                    if (t0 == 0) t0 = now;
-                    const unsigned ms = __hip_atomic_load(a.ctl + BRES_SPIN_MS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (now - t0 > (ms ? (long long)ms * 100000LL : 200000000LL)) {
-                        if (lane == 0 && __hip_atomic_exchange(a.ctl + BRES_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                            unsigned* pm = a.ctl + BRES_PM; pm[0] = what; pm[1] = blockIdx.x; pm[2] = epoch; pm[3] = want; pm[4] = 0u;
-                        }
-                        dead = true;
-                    }
-                }
-                dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
-            }
-            if (lane == 0 && dead) dead_s = 1u;
-        }
-        __syncthreads();
-        dead = dead_s != 0u;
-    };
-
-    float alpha = 0.0f, beta = 0.0f, aN = 0.0f;
-    for (int k = 0; k < a.L; ++k) {
-        const float* p_in = a.p[k & 1]; float* p_out = a.p[(k & 1) ^ 1];
-        BSTAMP(k, 0);
-        // ---- U: k_pcg_update<true, false>, element by element in its float4s (first = k == 0: p_0 = M^-1 r_0 + 0 * p)
-        {
-            const ba_rsrc_t RS_R = ba_rsrc(a.r), RS_AP = ba_rsrc(a.Ap), RS_PI = ba_rsrc(p_in), RS_PO = ba_rsrc(p_out);
-            const float4* pre4 = reinterpret_cast<const float4*>(a.pre); float4* dl4 = reinterpret_cast<float4*>(a.delta);
-            const long n4 = (n + 3) >> 2;
-            for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (long)G * BLOCK) {
-                const unsigned off = (unsigned)i * 16u;
-                float4 rv = ld4a(RS_R, off);
-                const float4 pv = ld4a(RS_PI, off);
-                if (k > 0) {
-                    const float4 av = ld4a(RS_AP, off);
-                    rv.x = __builtin_fmaf(-alpha, av.x, rv.x); rv.y = __builtin_fmaf(-alpha, av.y, rv.y); rv.z = __builtin_fmaf(-alpha, av.z, rv.z); rv.w = __builtin_fmaf(-alpha, av.w, rv.w);
-                    st4a(RS_R, off, rv);
-                    float4 dv = dl4[i];
-                    dv.x = __builtin_fmaf(alpha, pv.x, dv.x); dv.y = __builtin_fmaf(alpha, pv.y, dv.y); dv.z = __builtin_fmaf(alpha, pv.z, dv.z); dv.w = __builtin_fmaf(alpha, pv.w, dv.w);
-                    dl4[i] = dv;
-                }
-                float4 zv = rv;
-                { const float4 m = pre4[i]; zv.x *= m.x; zv.y *= m.y; zv.z *= m.z; zv.w *= m.w; }
-                st4a(RS_PO, off, make_float4(zv.x + beta * pv.x, zv.y + beta * pv.y, zv.z + beta * pv.z, zv.w + beta * pv.w));
-            }
-        }
-        BSTAMP(k, 1);
-        grid_barrier(1u);
-        BSTAMP(k, 2);
-        const float* p = p_out;
-        const ba_rsrc_t RS_P = ba_rsrc(p), RS_R2 = ba_rsrc(a.r), RS_A2 = ba_rsrc(a.Ap);
-        float acc; Sums3 sm;
-        // ---- A: k_cam2's body, one launch-per-iteration workgroup (four cameras, one per wave) at a time
-        for (int vb = blockIdx.x; vb < a.cb; vb += G) {
-            acc = 0.0f; sm = Sums3();
-            for (int c = vb * 4 + wave; c < a.C; c += a.cb * 4) {
-                float s[9], pc[9];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) { s[q] = 0.0f; pc[q] = ld1a(p + 9L * c + q); }
-                const long ie = 9L * c + (lane < 9 ? lane : 8);
-                const float e_p = ld1a(p + ie), e_r = ld1a(a.r + ie), e_m = a.pre[ie];
-                const CamPre cp = ba_cam_pre(a.cams + 9L * c);
-                constexpr int NO = BA_CAM_OBS;
-                const int q1e = a.cam_ptr[c + 1];
-                for (int q = a.cam_ptr[c] + lane; q < q1e; q += 64 * NO) {
-                    long pi[NO]; float x[NO][3], pp[NO][3]; bool h[NO];
-#pragma unroll
-                    for (int u = 0; u < NO; ++u) { h[u] = q + 64 * u < q1e; pi[u] = a.q_pt[h[u] ? q + 64 * u : q]; }
-#pragma unroll
-                    for (int u = 0; u < NO; ++u) { const float* X = a.pts + 3L * pi[u]; const float* P3 = p + PB + 3L * pi[u]; x[u][0] = X[0]; x[u][1] = X[1]; x[u][2] = X[2];
-                                                   (void)P3; ld3a(RS_P, (unsigned)(PB + 3L * pi[u]) * 4u, pp[u]); }
-                    Blk b[NO]; float j0[NO], j1[NO];
-#pragma unroll
-                    for (int u = 0; u < NO; ++u) b[u] = ba_block(cp, x[u][0], x[u][1], x[u][2]);
-#pragma unroll
-                    for (int u = 0; u < NO; ++u) {
-                        j0[u] = b[u].a[9] * pp[u][0] + b[u].a[10] * pp[u][1] + b[u].a[11] * pp[u][2]; j1[u] = b[u].a[21] * pp[u][0] + b[u].a[22] * pp[u][1] + b[u].a[23] * pp[u][2];
-                    }
-#pragma unroll
-                    for (int q9 = 0; q9 < 9; ++q9) {
-#pragma unroll
-                        for (int u = 0; u < NO; ++u) { j0[u] += b[u].a[q9] * pc[q9]; j1[u] += b[u].a[12 + q9] * pc[q9]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < NO; ++u) if (h[u]) st2a(a.JpC + q + 64 * u, make_float2(j0[u], j1[u]));
-#pragma unroll
-                    for (int q9 = 0; q9 < 9; ++q9) {
-#pragma unroll
-                        for (int u = 0; u < NO; ++u) if (h[u]) s[q9] += b[u].a[q9] * j0[u] + b[u].a[12 + q9] * j1[u];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 9; ++q) s[q] = wave_sum_all(s[q]);
-                if (lane < 9) {
-                    float sv = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) if (lane == q) sv = s[q];
-                    st1a(a.Ap + 9L * c + lane, sv);
-                    acc += e_p * sv;
-                    sm.add(e_m, e_r, sv);
-                }
-            }
-            // the block's partial (block_finish_sums without tickets: wave sums, LDS, thread 0 adds the waves in order)
-            {
-                const float wa = wave_sum_all(acc);
-                const double w0 = wave_sum_all_f64(sm.n), w1 = wave_sum_all_f64(sm.s1), w2 = wave_sum_all_f64(sm.s2);
-                if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
-                lds_barrier();
-                if (threadIdx.x == 0) {
-                    float ta = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
-                    for (int w = 0; w < BLOCK / 64; ++w) { ta += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
-                    typedef unsigned long long u64_t;
-                    st1a(a.aD_part + vb, ta);
-                    u64_t* sp = reinterpret_cast<u64_t*>(a.s3_part) + 3 * vb;
-                    __hip_atomic_store(sp, (u64_t)__double_as_longlong(b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(sp + 1, (u64_t)__double_as_longlong(b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(sp + 2, (u64_t)__double_as_longlong(b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                lds_barrier();
-            }
-        }
-        BSTAMP(k, 3);
-        grid_barrier(2u);
-        BSTAMP(k, 4);
-        // ---- B: k_pt2's body, one launch-per-iteration workgroup at a time
-        for (int vb = blockIdx.x; vb < a.pb; vb += G) {
-            acc = 0.0f; sm = Sums3();
-            for (int j = vb * BLOCK + threadIdx.x; j < a.P; j += a.pb * BLOCK) {
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-                const long i = PB + 3L * j;
-                float pv[3], rv[3], mv[3];
-                ld3a(RS_P, (unsigned)i * 4u, pv); ld3a(RS_R2, (unsigned)i * 4u, rv);
-#pragma unroll
-                for (int u = 0; u < 3; ++u) mv[u] = a.pre[i + u];
-                const int k1 = a.pt_ptr[j + 1];
-                for (int k0 = a.pt_ptr[j]; k0 < k1; k0 += 4) {
-                    float2 ja[4], jb[4], jc_[4], jp[4]; int q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int kk = min(k0 + u, k1 - 1); q[u] = a.pt_pos[kk]; ja[u] = a.JP[3L * kk]; jb[u] = a.JP[3L * kk + 1]; jc_[u] = a.JP[3L * kk + 2]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) jp[u] = ld2a(a.JpC + q[u]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (k0 + u < k1) { s0 += ja[u].x * jp[u].x + jb[u].y * jp[u].y; s1 += ja[u].y * jp[u].x + jc_[u].x * jp[u].y; s2 += jb[u].x * jp[u].x + jc_[u].y * jp[u].y; }
-                }
-                st3a(RS_A2, (unsigned)i * 4u, s0, s1, s2);
-                acc += pv[0] * s0 + pv[1] * s1 + pv[2] * s2;
-                sm.add(mv[0], rv[0], s0); sm.add(mv[1], rv[1], s1); sm.add(mv[2], rv[2], s2);
-            }
-            {
-                const float wa = wave_sum_all(acc);
-                const double w0 = wave_sum_all_f64(sm.n), w1 = wave_sum_all_f64(sm.s1), w2 = wave_sum_all_f64(sm.s2);
-                if (lane == 0) { red[wave] = wa; redd[3 * wave] = w0; redd[3 * wave + 1] = w1; redd[3 * wave + 2] = w2; }
-                lds_barrier();
-                if (threadIdx.x == 0) {
-                    float ta = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
-                    for (int w = 0; w < BLOCK / 64; ++w) { ta += red[w]; b0 += redd[3 * w]; b1 += redd[3 * w + 1]; b2 += redd[3 * w + 2]; }
-                    typedef unsigned long long u64_t;
-                    const int slot = a.cb + vb;
-                    st1a(a.aD_part + slot, ta);
-                    u64_t* sp = reinterpret_cast<u64_t*>(a.s3_part) + 3 * slot;
-                    __hip_atomic_store(sp, (u64_t)__double_as_longlong(b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(sp + 1, (u64_t)__double_as_longlong(b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(sp + 2, (u64_t)__double_as_longlong(b2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                lds_barrier();
-            }
-        }
-        BSTAMP(k, 5);
-        grid_barrier(3u);
-        BSTAMP(k, 6);
-        // ---- the iteration's scalars, by every workgroup for itself (k_pcg_update_fin's sums: the same bits)
-        {
-            float ad, an0; double t3[3];
-            last_workgroup_totals<3>(a.aD_part, a.s3_part, nullptr, nb, a.aN0, red, redd, ad, an0, t3);
-            if (k == 0) aN = an0;
-            alpha = safe_div<false>(aN, ad);
-            double bn = t3[0] - 2.0 * (double)alpha * t3[1] + (double)alpha * (double)alpha * t3[2];
-            if (!(bn > 0.0)) bn = 0.0;
-            const float bnf = (float)bn;
-            beta = safe_div<false>(bnf, aN);
-            if (blockIdx.x == 0 && threadIdx.x == 0) { a.words[2 * k] = ad; a.words[2 * k + 1] = bnf; }
-            aN = bnf;
-            lds_barrier();              // (red / redd are written again by the next phase)
-            BSTAMP(k, 7);
-        }
-    }
-}
 
 inline void gather_shape(int C_, int P_, int& cam_blocks, int& grid)
 {
@@ -868,52 +606,9 @@ int thallo_hip_ba_lm_reset_residual(int C_, int P_, const int* cam_ptr, const in
     return ba_apply2(C_, P_, cam_ptr, q_pt, pt_pos, pt_ptr, cameras, points, JP, JpC, delta, r /* (not written in this mode) */, betaN_out, nullptr, nullptr, nullptr, gate, none, CtC, stream,
                      nullptr, LmFin{ nullptr, nullptr, nullptr, 0, 0.0f }, ResetArgs{ r, b, pre });
 }
-/* ---- the PCG loop of a Gauss-Newton step in ONE launch (k_ba_resident above).  From what thallo_hip_ba_pcg_init left (r_0, M^-1, delta = 0, alphaN_0) through L iterations of
- * thallo_hip_pcg_update(_fin) + thallo_hip_ba_apply_jtj2, leaving what they leave: r_{L-1}, A p_{L-1} in Ap, p_{L-1} in p[L & 1] (p0 = p[0], p1 = p[1]), delta without its
- * last term, and words[2k] = alphaD_k, words[2k + 1] = betaN_k -- bit for bit.  xbuf: thallo_hip_ba_resident_bytes() bytes, zeroed once, private to the plan.
- * Returns the number of workgroups (> 0) or a negative hipError_t (-hipErrorNotSupported: not every workgroup would be resident). */
-long thallo_hip_ba_resident_bytes(void) { return 256 + 8 * BRES_CNT_STRIDE * (long)sizeof(unsigned) + (long)THALLO_MAX_PARTIALS * (sizeof(float) + 3 * sizeof(double)) + 64; }
-int thallo_hip_ba_pcg_resident(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
-                               const float* cameras, const float* points, const float* JP, float* JpC,
-                               float* r, float* Ap, const float* pre, float* p0, float* p1, float* delta, thallo_sum_t alphaN0, float* words, void* xbuf, int L, thallo_stream_t stream)
-{
-    if (C_ < 1 || P_ < 1 || L < 1 || !cam_ptr || !q_pt || !pt_pos || !pt_ptr || !cameras || !points || !JP || !JpC || !r || !Ap || !pre || !p0 || !p1 || !delta || !words || !xbuf ||
-        !alphaN0.partials || alphaN0.count < 1) return -(int)hipErrorInvalidValue;
-    BaResArgs a; memset(&a, 0, sizeof(a));
-    int grid_lpi; gather_shape(C_, P_, a.cb, grid_lpi); a.pb = grid_lpi - a.cb;
-    a.C = C_; a.P = P_; a.L = L; a.cam_ptr = cam_ptr; a.q_pt = q_pt; a.pt_ptr = pt_ptr; a.pt_pos = pt_pos; a.cams = cameras; a.pts = points; a.JP = (const float2*)JP; a.JpC = (float2*)JpC;
-    a.r = r; a.Ap = Ap; a.pre = pre; a.p[0] = p0; a.p[1] = p1; a.delta = delta; a.aN0 = alphaN0; a.words = words;
-    char* x = reinterpret_cast<char*>(xbuf);
-    a.ctl = reinterpret_cast<unsigned*>(x); a.cnt = reinterpret_cast<unsigned*>(x + 256);
-    a.aD_part = reinterpret_cast<float*>(x + 256 + 8 * BRES_CNT_STRIDE * sizeof(unsigned));
-    a.s3_part = reinterpret_cast<double*>(x + 256 + 8 * BRES_CNT_STRIDE * sizeof(unsigned) + THALLO_MAX_PARTIALS * sizeof(float));
-    int cus = thallo_hip_device_cu_count(); if (cus > 256) cus = 256;
-    static int per_cu = 0;
-    if (per_cu == 0) { int v = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_ba_resident, BLOCK, 0) == hipSuccess && v >= 1) ? v : -1; }
-    if (per_cu < 1 || cus < 8) return -(int)hipErrorNotSupported;
-    // two workgroups per CU where the device holds them (what the launch-per-iteration kernels run at: the gathers are latency-bound), every one of them resident;
-    // a multiple of the eight counter shards
-    const int grid = g_ba_res_wg > 0 ? g_ba_res_wg / 8 * 8 : (per_cu >= 2 ? 2 : 1) * cus / 8 * 8;
-    if (grid < 8 || grid > (per_cu < 2 ? 1 : 2) * thallo_hip_device_cu_count()) return -(int)hipErrorNotSupported;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_ba_resident_begin, dim3(1), dim3(64), 0, s, a.cnt);
-    hipLaunchKernelGGL(k_ba_resident, dim3(grid), dim3(BLOCK), 0, s, a);
-    int e = check_launch(); return e ? e : grid;
-}
-/* the error word of a plan's resident launches: 1 = a bounded wait ran out; clear != 0 resets it.  pm (5 words, may be NULL): what the first expired wait was for. */
-void thallo_hip_ba_resident_debug_set(int what, int value) { if (what == 0) g_ba_res_wg = value; }
-#ifdef BRES_STAMPS
-int thallo_hip_debug_stamps_ba(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_b), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
+#ifdef THALLO_RESEARCH
+#include "probe/ba_resident_host.inc"
 #endif
-int thallo_hip_ba_resident_status(void* xbuf, int clear, unsigned* pm, thallo_stream_t stream)
-{
-    if (!xbuf) return 0;
-    unsigned w[BRES_CTL_WORDS];
-    if (hipMemcpyAsync(w, xbuf, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
-    if (pm) for (int i = 0; i < 5; ++i) pm[i] = w[BRES_PM + i];
-    if (clear && w[BRES_ERR]) { const unsigned z = 0; (void)hipMemcpyAsync((unsigned*)xbuf + BRES_ERR, &z, sizeof(unsigned), hipMemcpyHostToDevice, (hipStream_t)stream); (void)hipStreamSynchronize((hipStream_t)stream); }
-    return w[BRES_ERR] ? 1 : 0;
-}
 int thallo_hip_ba_apply_jtj2(int C_, int P_, const int* cam_ptr, const int* q_pt, const int* pt_pos, const int* pt_ptr,
                              const float* cameras, const float* points, const float* JP, float* JpC, const float* p, float* Ap, float* aD_out,
                              const float* r, const float* pre, double* s3_out, const unsigned* gate, thallo_stream_t stream)

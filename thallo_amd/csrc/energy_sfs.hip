@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include "device_common.hpp"
 #include "../../include/thallo_hip.h"
+#include "sfs_pair.hpp"
 namespace thallo { const char* env_switch(const char* name); }      // solver.cpp: the one table of the library's environment switches
 
 using namespace thallo;
@@ -831,7 +832,10 @@ static int g_ms_cap = 0;        // tests: workgroup budget the grids are sized f
 static int g_ms_precompute = 1;      // 1: precompute by the marching kernel, 0: k_precompute (tools / tests)
 static int g_ms_diag = 1;      // 1: the LM diagonal by the marching J^T F kernel, 0: k_diag (tools / tests)
 static bool sfs_march_diag() { return g_ms_diag == 1; }
-void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; if (what == 3) g_ms_diag = value; if (what == 4) g_ms_precompute = value; if (what == 5) g_ms_cap = value; }
+static int g_ms_pair = -1, g_ms_depth = 0;      // the pixel-pair kernels on the packed planes (energy_sfs_pair.hip): -1 the environment's THALLO_SFS_PAIR (default on), 0 / 1 forced; their rows of prefetch (0 = automatic)
+void thallo_hip_sfs_march_debug_set(int what, int value) { if (what == 0) g_ms_rows = value; if (what == 1) g_ms_wgcu = value; if (what == 2) g_ms_force = value; if (what == 3) g_ms_diag = value; if (what == 4) g_ms_precompute = value; if (what == 5) g_ms_cap = value;
+                                                           if (what == 6) g_ms_pair = value; if (what == 7) g_ms_depth = value; }
+static thallo::SfsTune pair_tune() { thallo::SfsTune t; t.rows = g_ms_rows; t.wgcu = g_ms_wgcu; t.cap = g_ms_cap; t.depth = g_ms_depth; return t; }
 static MsGeo make_ms_geo(int W, int H, int ra, int rb, int yoff, int R)
 {
     MsGeo g; g.W = W; g.H = H; g.ra = ra; g.rb = rb; g.yoff = yoff; g.R = R;
@@ -843,6 +847,15 @@ static MsGeo make_ms_geo(int W, int H, int ra, int rb, int yoff, int R)
 static long ms_cap(int per_cu) { return g_ms_cap > 0 ? g_ms_cap : (long)thallo_hip_device_cu_count() * per_cu; }
 // the image has no more column strips than workgroup slots (otherwise the LDS-tiled kernels, which loop over their tiles, run)
 static bool sfs_march_fits(int W) { return march_strips_fit((W + MS_USE - 1) / MS_USE, ms_cap(g_ms_wgcu > 0 ? g_ms_wgcu : MS_WG_PER_CU)); }
+// Round 6: images of even width run the marching kernels on pixel pairs, on PACKED planes (sfs_pair.hpp) -- every entry point below that takes G / Wt / fl then reads or
+// writes that layout (thallo_hip_sfs_planes_layout).  THALLO_SFS_PAIR=0 (THALLO_AB sfs_pair=0): the one-pixel-per-lane kernels on the float4 / float2 / byte planes (A/B).
+static bool sfs_pair(int W, int H)
+{
+    static int v = -1; if (v < 0) { const char* e = thallo::env_switch("THALLO_SFS_PAIR"); v = (e && e[0] == '0') ? 0 : 1; }
+    const bool on = g_ms_pair >= 0 ? g_ms_pair == 1 : v == 1;
+    return on && sfs_fused() && sfs_march() && sfs_march_fits(W) && thallo::sfs_pair_ok(W, H, pair_tune());
+}
+int thallo_hip_sfs_planes_layout(int W, int H) { return sfs_pair(W, H) ? 1 : 0; }
 static MsGeo pick_ms_geo(int W, int H, int ra, int rb, int yoff)
 {
     if (g_ms_rows > 0) return make_ms_geo(W, H, ra, rb, yoff, g_ms_rows);
@@ -894,6 +907,7 @@ static int sfs_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const 
                           const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt, unsigned char* fl, float* cost_out, int c0, int c1, thallo_stream_t stream)
 {
     if (ra < 0 || rb > H || ra >= rb) return -(int)hipErrorInvalidValue;
+    if (sfs_pair(W, H)) { (void)fl; return thallo::sfs_pair_precompute(W, H, ra, rb, yoff, Hg, host_params, X, D, Im, edgeMaskR, edgeMaskC, G, Wt, cost_out, c0, c1, pair_tune(), stream); }
     if (sfs_fused() && sfs_march() && sfs_march_fits(W) && g_ms_precompute == 1 && (long)W * H >= 4 && (((uintptr_t)edgeMaskR | (uintptr_t)edgeMaskC) & 3) == 0) {
         const int np = (W + MP_USE - 1) / MP_USE;
         int R = march_rows_per_segment(rb - ra, np, MS_NT / 64, ms_cap(4));
@@ -922,6 +936,7 @@ int thallo_hip_sfs_cost(int W, int H, int row0, int row1, int yoff, int Hg, cons
                         const unsigned char* fl, float* cost_out, thallo_stream_t stream)
 {
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
+    if (sfs_pair(W, H)) return -(int)hipErrorNotSupported;      // (packed planes: the cost comes out of thallo_hip_sfs_precompute_cost)
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
     hipLaunchKernelGGL(k_cost, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, g, cam_of(host_params), X, D, (const float4*)G, (const float2*)Wt, fl, cost_out);
     int e = check_launch(); return e ? e : grid;
@@ -932,6 +947,7 @@ int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, 
                             float* diag_out, float* aN_out, thallo_stream_t stream)
 {
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
+    if (sfs_pair(W, H)) return thallo::sfs_pair_init(W, H, row0, row1, yoff, Hg, host_params, X, D, G, Wt, r, z, p_prev, delta, diag_out, aN_out, thallo::SfsFinDiag{}, pair_tune(), stream);
     // row pass over the owned rows +-1 (they feed the gather of the owned rows), gather over the owned rows
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
     const Geo gr = make_geo(W, H, row0 > 0 ? row0 - 1 : 0, row1 < H ? row1 + 1 : H, yoff, Hg); const int gridr = grid_for(gr);
@@ -991,6 +1007,31 @@ int thallo_hip_sfs_apply_jtj_lm(int W, int H, int row0, int row1, int yoff, int 
 int thallo_hip_sfs_lm_pupdate_supported(void) { return sfs_fused() && sfs_march() ? 1 : 0; }
 int thallo_hip_sfs_march_fits(int W) { return sfs_fused() && sfs_march() && sfs_march_fits(W) ? 1 : 0; }
 
+/* Round 6 (packed planes only; -hipErrorNotSupported elsewhere: the caller runs the launches they replace).
+ * thallo_hip_sfs_pcg_init_lm: PCGInit1's J^T F pass with PCGFinalizeDiagonal riding along (gauss_newton.t:936-969): r = -J^T F, delta = 0, p_prev = 0 and, from the raw
+ * diagonal of J^T J formed in the same pass, CtC, M^-1 (pre), b = r, z = M^-1 r, SSq (written when save_ssq, else read), partials of r . z.
+ * thallo_hip_sfs_lm_model_cost: delta_out = delta + alpha_kl p_kl (the update the one-launch LM loop owes, thallo_hip_lm_owed_delta's rule) and the partials of
+ * delta_out . J^T J delta_out and delta_out . b in ONE launch -- the model cost of an LM step (thallo.t:3845-3865, expanded: solver.cpp step_lm). */
+int thallo_hip_sfs_pcg_init_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
+                               const unsigned char* fl, float* r, float* z, float* p_prev, float* delta, float* SSq, float* CtC, float* pre, float* b,
+                               float radius, float min_lm_diagonal, float max_lm_diagonal, int save_ssq, float* aN_out, thallo_stream_t stream)
+{
+    (void)fl;
+    if (!sfs_pair(W, H)) return -(int)hipErrorNotSupported;
+    thallo::SfsFinDiag fd; fd.SSq = SSq; fd.CtC = CtC; fd.pre = pre; fd.b = b; fd.radius = radius; fd.min_lm = min_lm_diagonal; fd.max_lm = max_lm_diagonal; fd.save_ssq = save_ssq;
+    if (!SSq || !CtC || !pre || !b) return -(int)hipErrorInvalidValue;
+    return thallo::sfs_pair_init(W, H, row0, row1, yoff, Hg, host_params, X, D, G, Wt, r, z, p_prev, delta, nullptr, aN_out, fd, pair_tune(), stream);
+}
+int thallo_hip_sfs_lm_model_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
+                                 const float* delta, float* delta_out, const float* p_even, const float* p_odd, const float* b, const float* alphaN_words, const float* alphaD_words,
+                                 int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out, thallo_stream_t stream)
+{
+    (void)fl;
+    if (!sfs_pair(W, H)) return -(int)hipErrorNotSupported;
+    return thallo::sfs_pair_model_cost(W, H, row0, row1, yoff, Hg, host_params, G, Wt, delta, delta_out, p_even, p_odd, b, alphaN_words, alphaD_words, word_stride, lm_state, L, dJJd_out, db_out,
+                                       pair_tune(), stream);
+}
+
 int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                             const float* r_in, float* r_out, const float* Ap_in, float* Ap_out, const float* p_in, float* p_out, float* delta, int first,
                             thallo_sum_t alphaN_prev, thallo_sum_t alphaD_prev, thallo_sum_t betaN_prev, float* aD_out, double* s3_out, thallo_fin_t fin, thallo_stream_t stream)
@@ -999,6 +1040,8 @@ int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, 
     if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !alphaD_prev.partials || !betaN_prev.partials)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
     if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
+    if (sfs_pair(W, H)) return thallo::sfs_pair_iter(W, H, row0, row1, yoff, Hg, host_params, G, Wt, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, first, alphaN_prev, alphaD_prev, betaN_prev, nullptr,
+                                                     aD_out, s3_out, fin, pair_tune(), stream);
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -1018,6 +1061,8 @@ int thallo_hip_sfs_pcg_iter_deferred(int W, int H, int row0, int row1, int yoff,
     if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !prev.alphaD_partials || !prev.s12_partials || prev.s12_partials == s3_out || prev.count < 1 ||
                    prev.count > THALLO_MAX_PARTIALS || !prev.alphaD_word || !prev.betaN_word)) return -(int)hipErrorInvalidValue;
     if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
+    if (sfs_pair(W, H)) return thallo::sfs_pair_iter(W, H, row0, row1, yoff, Hg, host_params, G, Wt, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, first, alphaN_prev, alphaN_prev, alphaN_prev, &prev,
+                                                     aD_out, s3_out, thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr }, pair_tune(), stream);
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -1041,6 +1086,8 @@ int thallo_hip_sfs_pcg_iter_lm(int W, int H, int row0, int row1, int yoff, int H
     if (!first && (!Ap_in || Ap_in == Ap_out || !alphaN_prev.partials || !alphaD_prev.partials || !betaN_prev.partials)) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;      // (no tickets: partials only -- a row slab, whose exchange finishes)
     if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
+    if (sfs_pair(W, H)) return thallo::sfs_pair_iter_lm(W, H, row0, row1, yoff, Hg, host_params, G, Wt, r_in, r_out, Ap_in, Ap_out, p_in, p_out, delta, CtC, b, pre, first, alphaN_prev, alphaD_prev, betaN_prev,
+                                                        aD_out, s3_out, q3_out, fin, lm_state, k, q_tolerance, pair_tune(), stream);
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -1060,6 +1107,7 @@ int thallo_hip_sfs_apply_jtj_lm_pupdate(int W, int H, int row0, int row1, int yo
     if (row0 < 0 || row1 > H || row0 >= row1 || !z || !p_in || !p_out || p_in == p_out || !CtC || !Ap || !aD_out) return -(int)hipErrorInvalidValue;
     if (!first && (!alphaN_prev.partials || !betaN_prev.partials || alphaN_prev.count < 1 || betaN_prev.count < 1)) return -(int)hipErrorInvalidValue;
     if (!thallo_hip_sfs_march_fits(W)) return -(int)hipErrorNotSupported;
+    if (sfs_pair(W, H)) return thallo::sfs_pair_apply_pupdate(W, H, row0, row1, yoff, Hg, host_params, G, Wt, z, p_in, p_out, CtC, Ap, aD_out, first, alphaN_prev, betaN_prev, gate, pair_tune(), stream);
     const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);
     const int gridm = (mg.total + 7) / 8 * 8;
     if (gridm > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
@@ -1074,6 +1122,7 @@ static int sfs_apply(int W, int H, int row0, int row1, int yoff, int Hg, const f
 {
     if (row0 < 0 || row1 > H || row0 >= row1) return -(int)hipErrorInvalidValue;
     if (fin.tickets && (!s3_out || !fin.alphaD_word || !fin.betaN_word || !fin.alphaN.partials)) return -(int)hipErrorInvalidValue;
+    if (sfs_pair(W, H)) return thallo::sfs_pair_apply(W, H, row0, row1, yoff, Hg, host_params, G, Wt, p, Ap, aD_out, r, s3_out, gate, fin, ctc, pair_tune(), stream);
     const Geo g = make_geo(W, H, row0, row1, yoff, Hg); const int grid = grid_for(g);
     if (sfs_fused() && sfs_march() && sfs_march_fits(W)) {
         const MsGeo mg = pick_ms_geo(W, H, row0, row1, yoff);

@@ -1,6 +1,9 @@
 // plugins.cpp -- the bundled energy plugins (host side).  Each one binds the caller's void**
 // (API/src/util.t:609-643) and forwards to the C-ABI kernel shim (include/thallo_hip.h).
 #include "plugin.hpp"
+#ifdef THALLO_RESEARCH
+#include "probe/thallo_hip_research.h"      // research builds only: the persistent marching loop, bundle adjustment's one-launch loop (measured slower; not in the product)
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -217,15 +220,17 @@ public:
             }
             if (need > 0) { resident_ = whole; resident_slab_ = true; }
         }
-        // larger whole images: iterations 1 .. L-1 of a GN step as ONE persistent launch of the marching kernel's grid -- THALLO_AB=persist=1 only: measured 8-10 % SLOWER
-        // than a launch per iteration at 2048^2 (energy_image_warping_march_persist.hip, profiles/r05/persist_ab.txt); bit-identical, kept for the tests and the tools
+        // larger whole images: iterations 1 .. L-1 of a GN step as ONE persistent launch of the marching kernel's grid -- RESEARCH builds with THALLO_AB=persist=1 only:
+        // measured 8-10 % SLOWER than a launch per iteration at 2048^2 (probe/iw_march_persist.hip, profiles/r05/persist_ab.txt); bit-identical; not in the product library
         persist_ = false;
+#ifdef THALLO_RESEARCH
         const char* ep = env_switch("THALLO_PERSIST");
         if (march_rc_ && whole && !resident_broken_ && ep && ep[0] == '1' && thallo_hip_iw_march_persist_rows(W, H) > 0) {
             const long need = thallo_hip_iw_march_persist_bytes();
             if ((long)xpst.bytes < need && xpst.alloc((size_t)need)) { set_error("image_warping: out of device memory for the persistent loop's exchange buffer"); return -1; }
             persist_ = true;
         }
+#endif
         return 0;
     }
     // ---- one row slab of a multi-GPU run (solver_dist.cpp)
@@ -293,12 +298,14 @@ public:
     bool batches_delta() const override { return true; }
     bool takes_any_p_plane() const override { return march_ && row0_ == 0 && row1_ == H; }
     bool persist_ok() const override { return persist_; }
+#ifdef THALLO_RESEARCH
     int pcg_persist(LaunchCtx& c, SolverVectors& v, float* const* planes, int n_planes, int k0, int k1, float* parts, int slots, int B, int nb_prev, thallo_sum_t alphaN_prev) override
     {
         TimedLaunch t(c, "PCGLoopPersistent");
         return thallo_hip_iw_pcg_march_persist(W, H, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg, v.rbuf(0), v.rbuf(1), planes, n_planes, k0, k1,
                                                parts, slots, B, v.s12, v.s12b, nb_prev, alphaN_prev, (const int*)irregular.ptr, xpst.ptr, c.stream);
-    }      // (the marching kernels; the mode-1 launch of a GN step's first iteration included)
+    }
+#endif      // (the marching kernels; the mode-1 launch of a GN step's first iteration included)
     bool dist_batches_delta() const override { return march_rc_; }      // (the stored-plane marching kernel's multi-GPU variant has no such form: it would spill)
     bool one_kernel_iteration() const override { return true; }
     int pcg_iter(LaunchCtx& c, SolverVectors& v, int cur, int mode, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, thallo_sum_t aN2, thallo_sum_t aD2, float* out,
@@ -344,8 +351,10 @@ public:
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override
     {
         const int a = xres.ptr ? thallo_hip_iw_resident_status(xres.ptr, clear, -1, pm, c.stream) : 0;
-        if (a != 0 || !xpst.ptr) return a;
-        return thallo_hip_iw_march_persist_status(xpst.ptr, clear, -1, pm, c.stream);
+#ifdef THALLO_RESEARCH
+        if (a == 0 && xpst.ptr) return thallo_hip_iw_march_persist_status(xpst.ptr, clear, -1, pm, c.stream);
+#endif
+        return a;
     }
     void resident_disable() override { resident_ = resident_slab_ = persist_ = false; resident_broken_ = true; }
     bool iter_defers_finish() const override { return true; }
@@ -808,10 +817,11 @@ public:
                 if (rc < 0 || se != hipSuccess) { set_error("bundle_adjustment: point order failed (launch %d, sync %d: %s)", rc, (int)se, hipGetErrorString(rc < 0 ? (hipError_t)(-rc) : se)); return -1; }
             }
         }
-        // the PCG loop of a GN step in one launch (whole problem on one GPU) -- THALLO_RESIDENT=2 only: bit-identical to three launches per iteration but SLOWER at the
-        // ladybug shape (40.8 against 31.0 us per PCG iteration, profiles/r05/ba_resident_phases.txt: three grid-wide barriers of ~3 us each cost what the launch
-        // boundaries did, and a static share of the camera blocks per workgroup balances worse than the hardware's dispatch of 431 of them)
+        // the PCG loop of a GN step in one launch (whole problem on one GPU) -- RESEARCH builds with THALLO_RESIDENT=2 only: bit-identical to three launches per iteration
+        // but SLOWER at the ladybug shape (40.8 against 31.0 us per PCG iteration, profiles/r05/ba_resident_phases.txt: three grid-wide barriers of ~3 us each cost what the
+        // launch boundaries did, and a static share of the camera blocks per workgroup balances worse than the hardware's dispatch of 431 of them); not in the product library
         resident_ = false;
+#ifdef THALLO_RESEARCH
         {   const char* er = env_switch("THALLO_RESIDENT");
             if (er && er[0] == '2' && !resident_broken_) {
                 const long need = thallo_hip_ba_resident_bytes();
@@ -819,9 +829,11 @@ public:
                 resident_ = true;
             }
         }
+#endif
         return 0;
     }
     bool resident_ok() const override { return resident_; }
+#ifdef THALLO_RESEARCH
     int pcg_resident(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words) override
     {
         TimedLaunch t(c, "PCGLoopResident");
@@ -830,6 +842,7 @@ public:
         return rc;
     }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_ba_resident_status(xres_.ptr, clear, pm, c.stream) : 0; }
+#endif
     void resident_disable() override { resident_ = false; resident_broken_ = true; }
     float* unknown_ptr(int k) override { return k == 0 ? cameras : points; }
     int cost(LaunchCtx& c, float* out) override

@@ -1,4 +1,4 @@
-// energy_image_warping_march_persist.hip -- the marching PCG iteration of image_warping as a PERSISTENT loop: iterations k0 .. k1-1 of a Gauss-Newton step
+// probe/iw_march_persist.hip (was energy_image_warping_march_persist.hip; RESEARCH builds only since round 6: make VARIANT=research) -- the marching PCG iteration of image_warping as a PERSISTENT loop: iterations k0 .. k1-1 of a Gauss-Newton step
 // in ONE launch, for images whose solver state does not fit the chip's registers (2048^2 on one GPU: 35 rows per wave).
 //
 // energy_image_warping_march_rc.hip pays a launch boundary, a ramp and a tail per iteration (~10 us of every ~49 at 2048^2).  Here the grid of that kernel --
@@ -24,6 +24,7 @@
 // Same expressions on the same inputs as the launch-per-iteration kernel (jtjp_pair / iter_sums_pixel_masked of iw_march.hpp, -ffp-contract=on), same strips,
 // segments and order of every sum: r, p and every alpha_k / beta_k are BIT-identical to it (tests/test_gpu_parity.py).  Replaces the loop of gauss_newton.t:1615-1687.
 #include "iw_march.hpp"
+#include "probe/thallo_hip_research.h"
 #include <cstring>
 
 using namespace thallo;

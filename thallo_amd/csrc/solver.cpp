@@ -229,6 +229,7 @@ const char* env_switch(const char* name)
         { "THALLO_LM_FOLD_P", "lm_fold_p" },                    // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own
         { "THALLO_SFS_FUSED", "sfs_fused" },                    // 0: shape_from_shading's two-pass applyJTJ (round 1)
         { "THALLO_SFS_MARCH", "sfs_march" },                    // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
+        { "THALLO_SFS_PAIR", "sfs_pair" },                      // 0: shape_from_shading's one-pixel-per-lane marching kernels on the float4 / float2 / byte planes instead of the pixel-pair kernels on packed planes (round 6)
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere
         { "THALLO_FRONTEND_PRELOAD", "frontend_preload" },      // 0: every residual instance of a generated merged gather kernel loads for itself (round 4's lowering)
         { "THALLO_INC_LANES", "inc_lanes" },                    // N (a power of two <= 64): lanes per owner in the generated index-map gather kernels (default: by list length and owner count)
@@ -346,7 +347,7 @@ void Plan::init(void** params)
     }
     ready_ = true;
     if (dist_ && dist_->want_p2p && !dist_->checked && dist_self_check()) { ready_ = false; return; }
-    else if (dist_ && dist_->checked && dist_->p2p_on && !dist_->flat && !dist_->range && !dist_->shard) {
+    if (dist_ && dist_->checked && dist_->p2p_on && !dist_->flat && !dist_->range && !dist_->shard) {      // (also right behind a self-check that has just passed: ADVICE r5)
         // Every Init agrees anew on what depends on the plugin's state NOW: whether every rank's slab runs the resident kernel (a rank may have switched it
         // off since -- a bounded wait that ran out, THALLO_RESIDENT at re-Init) and whether the marching kernel's cross-rank finish is deferred.  Here, never at the
         // first step: a step may be inside a captured graph.
@@ -358,6 +359,7 @@ void Plan::init(void** params)
         dist_->defer_state = all ? 1 : 0;
     }
     sp.nIter = 0;
+    if (!lm_ && one_kernel_ && plugin->one_kernel_iteration() && !plugin->resident_ok()) { ring_prepare(sp.lIterations); ring_L_ = sp.lIterations; }      // (the ring's planes: here, not inside a step)
     prev_cost_ = compute_cost();
     printf("Initial cost: %g\n", prev_cost_);
 }
@@ -669,23 +671,39 @@ bool Plan::aux_stream()
     return true;
 }
 
-// Planes in the ring of p vectors of the one-kernel GN loop (0: no ring).  v_.p[1], v_.p[0] are its first two; the rest is allocated on first use and grows
-// with lIterations, as long as the device has room: at most a quarter of what is free and 64 GiB (of 288), at most 33 planes (one PCGDeltaUpdate takes 32 terms).
-int Plan::ring_planes(int L)
+// Planes in the ring of p vectors of the one-kernel GN loop (0: no ring).  v_.p[1], v_.p[0] are its first two; the others are allocated by ring_prepare() -- at Init and
+// again only when lIterations asks for more than the last attempt did -- never inside the step's launch sequence (a hipMalloc + NULL-stream memset per plane is
+// a device-wide synchronisation, illegal under stream capture, and was retried at every step of a memory-limited plan).
+// Footprint: (planes - 2) x one solver vector; by default at most 33 planes, a quarter of the free device memory and 32 GiB (2048^2 image_warping: 31 x 50.3 MB = 1.56 GB;
+// 16384 x 8192: 20 planes of 1.6 GB).  THALLO_DELTA_PLANES=N asks for exactly N (no memory test); planes are released with the plan.
+void Plan::ring_prepare(int L)
 {
-    if (!plugin->takes_any_p_plane() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3 || dist_) return 0;
+    if (!plugin->takes_any_p_plane() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3 || dist_) return;
     int want = delta_planes_ >= 2 ? delta_planes_ : delta_planes_ <= -2 ? -delta_planes_ : THALLO_HIP_MAX_UPDATE_TERMS + 1;
     if (want > L) want = L;                 // (L planes: delta is never touched inside the loop)
     if (ring_.size() < 2) { ring_.clear(); ring_.push_back(v_.p[1]); ring_.push_back(v_.p[0]); }
+    if (want <= (int)ring_.size() || want <= ring_tried_) return;      // enough planes, or an attempt for this many already ran into the memory limit
+    ring_tried_ = want;
     const size_t bytes = (size_t)v_.n_alloc * sizeof(float);
     while ((int)ring_.size() < want) {
         size_t free_b = 0, total_b = 0;
         if (delta_planes_ == -1 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 4 / (size_t)(want - (int)ring_.size()) ||
-                                  bytes * (ring_.size() - 1) > ((size_t)64 << 30))) break;
-        DeviceBuffer* b = new DeviceBuffer();
-        if (b->alloc(bytes)) { delete b; break; }
-        bufs_.push_back(b); ring_.push_back((float*)b->ptr);
+                                  bytes * (ring_.size() - 1) > ((size_t)32 << 30))) break;
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, bytes) != hipSuccess) { (void)hipGetLastError(); break; }      // fewer planes, not a failed step: the sticky error goes, no error text is left
+        // zeroed once, in stream order on the plan's own stream: a launch writes every unknown of its plane but not the padding behind them, which the flat update reads
+        if (hipMemsetAsync(ptr, 0, bytes, ctx.stream) != hipSuccess) { (void)hipGetLastError(); hipFree(ptr); break; }
+        DeviceBuffer* b = new DeviceBuffer(); b->ptr = ptr; b->bytes = bytes;
+        bufs_.push_back(b); ring_.push_back((float*)ptr);
     }
+}
+int Plan::ring_planes(int L)
+{
+    if (!plugin->takes_any_p_plane() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3 || dist_) return 0;
+    int want = delta_planes_ >= 2 ? delta_planes_ : delta_planes_ <= -2 ? -delta_planes_ : THALLO_HIP_MAX_UPDATE_TERMS + 1;
+    if (want > L) want = L;
+    if (L != ring_L_) { ring_prepare(L); ring_L_ = L; }      // (lIterations changed since Init: once per change)
+    if (ring_.size() < 2) return 0;
     const int n = (int)ring_.size() < want ? (int)ring_.size() : want;
     return n >= 3 || want == 2 ? n : 0;      // (two planes = an update per iteration: only on request)
 }

@@ -153,7 +153,9 @@ private:
     bool fin_in_kernel_ = true, one_kernel_ = true, batch_delta_ = true, lm_fold_p_ = true;   // A/B switches: read_ab_switches()
     int delta_planes_ = -1;         // THALLO_DELTA_PLANES (-1: unset)
     std::vector<float*> ring_;      // the ring of p planes of the one-kernel GN loop (ring_planes)
-    int  ring_planes(int L);
+    int  ring_planes(int L);        // how many planes the loop of L iterations runs on (allocates nothing unless lIterations changed since Init)
+    void ring_prepare(int L);       // allocates the ring's planes: at Init, and once per change of lIterations; a memory-limited attempt is cached (ring_tried_)
+    int  ring_tried_ = 0, ring_L_ = -1;
     hipStream_t aux_ = nullptr; bool aux_failed_ = false;      // the plan's second stream (background delta updates)
     std::vector<hipEvent_t> aux_events_;
     bool aux_async_ = false;        // THALLO_DELTA_PLANES=N:W: the delta updates of the ring on the second stream, next to the loop

@@ -326,7 +326,21 @@ def bench_image_warping(params_global, W, H, l_iters, steps, warmup, rank, world
     my_dev = torch.cuda.current_device() if ndev > 0 else -1
     rccl = solver.solver.rccl_info()
     rccl_world = int(reduce(float(rccl["world"]), dist.ReduceOp.MIN))            # (the smallest answer over the ranks: 1 = somebody's communicator is alone)
-    distinct = int(reduce(1.0 if (ndev >= world and my_dev == rank % max(ndev, 1)) else 0.0, dist.ReduceOp.MIN)) == 1
+    # one device per rank?  Compared by IDENTITY (host name + PCI address / UUID, all-gathered), not by index: under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES every rank
+    # sees ONE device with index 0 (the index test called that correct set-up "SHARED between ranks")
+    def _device_identity():
+        import socket
+        if my_dev < 0:
+            return (socket.gethostname(), "none", rank)
+        pr = torch.cuda.get_device_properties(my_dev)
+        ident = getattr(pr, "uuid", None)
+        ident = str(ident) if ident is not None else "%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))
+        if ident in ("None", "?:?:?"):
+            ident = "index%d/%s" % (my_dev, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "")))
+        return (socket.gethostname(), ident)
+    idents = [None] * world
+    dist.all_gather_object(idents, _device_identity())
+    distinct = len(set(idents)) == world
     fallback, fallback_reason = None, None
 
     def report_fallback(stage, words):

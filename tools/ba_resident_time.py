@@ -1,4 +1,5 @@
-"""ba_resident_time.py -- GPU probe: bundle adjustment (ladybug-1723 shape) GN, us per PCG iteration through Thallo_ProblemStep, the resident PCG loop (one launch per GN
+"""[RESEARCH build: make -C thallo_amd/csrc VARIANT=research (stamps: EXTRA with -DTHALLO_RESEARCH), run with THALLO_LIB=tools/ab/libThallo_research.so -- the loop this probes is not in the product library since round 6]
+ba_resident_time.py -- GPU probe: bundle adjustment (ladybug-1723 shape) GN, us per PCG iteration through Thallo_ProblemStep, the resident PCG loop (one launch per GN
 step) against three launches per iteration (THALLO_RESIDENT=0), alternating in one process.  python tools/ba_resident_time.py"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

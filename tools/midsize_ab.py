@@ -1,4 +1,5 @@
-"""GPU probe: mid-size images (too large for the resident kernel's registers, smaller than the benchmark) through Thallo_ProblemStep: us per PCG iteration with a marching
+"""[RESEARCH build: make -C thallo_amd/csrc VARIANT=research (stamps: EXTRA with -DTHALLO_RESEARCH), run with THALLO_LIB=tools/ab/libThallo_research.so -- the loop this probes is not in the product library since round 6]
+GPU probe: mid-size images (too large for the resident kernel's registers, smaller than the benchmark) through Thallo_ProblemStep: us per PCG iteration with a marching
 launch per iteration (default) and with the persistent marching loop (THALLO_AB=persist=1).  python tools/midsize_ab.py"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

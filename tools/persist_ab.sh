@@ -1,4 +1,5 @@
 #!/bin/bash
+# [RESEARCH build: make -C thallo_amd/csrc VARIANT=research; export THALLO_LIB=$R/tools/ab/libThallo_research.so -- the persistent loop is not in the product library since round 6]
 # Runs on the GPU box: the headline bench with the persistent marching loop against one launch per iteration (THALLO_AB=persist=0), both visibility forms
 # (THALLO_PERSIST_ACQ=1: one agent-scope acquire per wave and iteration instead of L1-bypassing loads).  One line per variant into gpurun_out/persist_ab.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,4 +1,5 @@
-"""Where an iteration of the persistent marching loop spends its time: the stamps build (make VARIANT=pstamps EXTRA=-DPST_STAMPS, loaded through THALLO_LIB).
+"""[RESEARCH build: make -C thallo_amd/csrc VARIANT=research (stamps: EXTRA with -DTHALLO_RESEARCH), run with THALLO_LIB=tools/ab/libThallo_research.so -- the loop this probes is not in the product library since round 6]
+Where an iteration of the persistent marching loop spends its time: the stamps build (make VARIANT=pstamps EXTRA=-DPST_STAMPS, loaded through THALLO_LIB).
 Runs on the GPU box.  python tools/persist_probe.py  ->  gpurun_out/persist_stamps.txt"""
 import os, sys, ctypes as C
 import numpy as np

@@ -600,14 +600,15 @@ int thallo_hip_sfs_planes_layout(int W, int H);
  * of J^T J formed in the same pass, CtC, pre = M^-1, b = r, z = M^-1 r, SSq (written when save_ssq, else read), partials of r . z -- thallo_hip_sfs_pcg_init +
  * thallo_hip_lm_finalize_diagonal in one launch.
  * thallo_hip_sfs_lm_model_cost: delta_out = delta + alpha_kl p_kl (the update the one-launch LM loop owes: thallo_hip_lm_owed_delta's rule; delta_out != delta) and the partials of
- * delta_out . (J^T J delta_out) and delta_out . b -- thallo_hip_lm_owed_delta + thallo_hip_sfs_apply_jtj + thallo_hip_dot in one launch (whole image on one GPU).  Returns the
- * number of partials in each of dJJd_out / db_out. */
+ * delta_out . (J^T J delta_out) and delta_out . b -- thallo_hip_lm_owed_delta + thallo_hip_sfs_apply_jtj + thallo_hip_dot in one launch (whole image on one GPU); with X and
+ * prevX (both or neither) also savePreviousUnknowns and PCGLinearUpdate of the step: prevX = X, X = X + delta_out (gauss_newton.t:901-906,915-920).  Returns the number of
+ * partials in each of dJJd_out / db_out. */
 int thallo_hip_sfs_pcg_init_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                                const unsigned char* fl, float* r, float* z, float* p_prev, float* delta, float* SSq, float* CtC, float* pre, float* b,
                                float radius, float min_lm_diagonal, float max_lm_diagonal, int save_ssq, float* alphaN_out, thallo_stream_t stream);
 int thallo_hip_sfs_lm_model_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                  const float* delta, float* delta_out, const float* p_even, const float* p_odd, const float* b, const float* alphaN_words, const float* alphaD_words,
-                                 int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out, thallo_stream_t stream);
+                                 int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out, float* X /* may be NULL */, float* prevX /* with X */, thallo_stream_t stream);
 
 /* Plain PCGStep1 (gauss_newton.t:734-752): Ap = J^T J p, alphaD partials = sum p.Ap -- the reference-shaped
  * kernel whose algorithmic traffic is SURVEY.md 8d's 48 B/pixel; used by the unfused schedule and by bench.py's

@@ -1666,6 +1666,81 @@ def test_shape_from_shading_marching_and_tile_solves_agree(torch, tmp_path, lm):
     assert np.abs(a[:-4] - b[:-4]).max() <= 1e-5 * np.abs(a[:-4]).max()
 
 
+@pytest.mark.parametrize("lm", [0, 1])
+@pytest.mark.parametrize("W,H,nit,lit", [(130, 67, 4, 10), (256, 192, 3, 10), (640, 480, 3, 10), (2, 2, 2, 3), (126, 9, 3, 5), (1024, 1024, 2, 10)])
+def test_shape_from_shading_pixel_pair_kernels_match_the_one_pixel_kernels(torch, orc, W, H, nit, lit, lm):
+    """Round 6: images of even width run the marching kernels on PIXEL PAIRS (energy_sfs_pair.hip: packed register pairs, 8-byte loads, 124 output pixels per wave row) on the PACKED
+    planes -- Gx | Gy | Gz | BI planar, flags and the two edge-mask bytes in one dword per pixel, 40 instead of 49 bytes per pixel and GN iteration -- written by the closed-form
+    precompute.  Against the one-pixel-per-lane kernels on the float4 / float2 / byte planes (thallo_hip_sfs_march_debug_set(6, 0)): whole Gauss-Newton and LM solves agree to
+    rounding (the planes' partials come from two derivations, every sum is taken in another order), the launch census is the same, and both sit on the oracle's trajectory.
+    Sizes: ragged strips (130 = 124 + 6), one strip, 2 x 2 (every pixel on the border), the reference's data set size, a row count that is not a multiple of the segment."""
+    p = syn.shape_from_shading(W, H)
+    lib = thallo_amd.lib()
+    runs = []
+    try:
+        for pair in (1, 0):
+            lib.thallo_hip_sfs_march_debug_set(6, pair)
+            assert lib.thallo_hip_sfs_planes_layout(W, H) == pair
+            dev = to_device(copy_params(p))
+            s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), solverkind="levenberg_marquardt" if lm else "gauss_newton")
+            if lm: s.enable_lm()
+            s.set_kernel_sampling(1)
+            s.set_solver_parameters(nIterations=nit, lIterations=lit)
+            params = s.make_params(dev)
+            s.init(params)
+            costs = [s.current_cost()]
+            while s.step(params):
+                costs.append(s.current_cost())
+            ks = {k: v["launches"] for k, v in s.kernel_stats().items() if v["launches"]}
+            runs.append((np.array(costs), to_host(dev[16]).copy(), ks))
+            s.close()
+    finally:
+        lib.thallo_hip_sfs_march_debug_set(6, -1)
+    (c1, x1, k1), (c0, x0, k0) = runs
+    assert np.isfinite(c1).all() and len(c1) == len(c0) and len(c1) >= 2
+    tol = 2e-4 if lm else 1e-5
+    assert np.abs(c1 - c0).max() <= tol * np.abs(c0).max(), (c1, c0)
+    assert np.abs(x1 - x0).max() <= tol * np.abs(x0).max()
+    if lm:      # the pair path folds PCGFinalizeDiagonal into PCGInit1 and the model cost's three launches into one
+        assert "PCGFinalizeDiagonal" not in k1 and "PCGModelCost" in k1 and "PCGFinalizeDiagonal" in k0 and "PCGModelCost" not in k0, (k1, k0)
+        assert k1.get("PCGIteration") == k0.get("PCGIteration")
+    else:
+        assert k1 == k0, (k1, k0)
+    if W * H <= 70000:
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=nit, lIterations=lit, use_lm=lm)
+        m = min(len(co), len(c1))
+        assert (np.abs(c1[:m] - co[:m]) <= (2e-4 if lm else 2e-5) * np.abs(co[:m]) + 1e-9).all(), (c1, co)
+
+
+def test_shape_from_shading_lm_step_folds(torch, monkeypatch):
+    """Round 6, LM on one GPU on packed planes: PCGFinalizeDiagonal rides in PCGInit1's launch and the owed update of delta + the model cost's applyJTJ + its dot product are one
+    launch (thallo_hip_sfs_pcg_init_lm, thallo_hip_sfs_lm_model_cost) -- against the step with those launches on their own (THALLO_AB lm_fold_step=0): the same expressions per
+    element, sums in another order: costs, radii and unknowns agree to rounding over accepted AND rejected steps, PCG iteration counts are equal."""
+    W, H = 192, 130
+    p = syn.shape_from_shading(W, H)
+    runs = []
+    for fold in ("1", "0"):
+        set_ab(monkeypatch, lm_fold_step=fold)
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), solverkind="levenberg_marquardt")
+        s.enable_lm(); s.set_kernel_sampling(1)
+        s.set_solver_parameters(nIterations=8, lIterations=10, trust_region_radius=30.0, q_tolerance=0.05)      # (a small radius: the first steps are rejected)
+        params = s.make_params(dev)
+        s.init(params)
+        costs, iters, radii = [s.current_cost()], [], []
+        while s.step(params):
+            costs.append(s.current_cost()); iters.append(len(s.alpha_beta_trace())); radii.append(s.get_solver_parameter("trust_region_radius"))
+        ks = {k: v["launches"] for k, v in s.kernel_stats().items() if v["launches"]}
+        runs.append((np.array(costs), iters, np.array(radii), to_host(dev[16]).copy(), ks))
+        s.close()
+    (c1, i1, r1, x1, k1), (c0, i0, r0, x0, k0) = runs
+    assert len(c1) == len(c0) >= 4 and i1 == i0, (c1, c0, i1, i0)
+    assert np.abs(c1 - c0).max() <= 1e-4 * np.abs(c0).max(), (c1, c0)
+    assert np.abs(r1 - r0).max() <= 1e-3 * np.abs(r0).max(), (r1, r0)
+    assert np.abs(x1 - x0).max() <= 1e-4 * np.abs(x0).max()
+    assert "PCGFinalizeDiagonal" not in k1 and k1["PCGModelCost"] == k1["PCGInit1"] and k0["PCGFinalizeDiagonal"] == k0["PCGInit1"] and "PCGModelCost" not in k0, (k1, k0)
+
+
 @pytest.mark.parametrize("W,H", [(130, 67), (256, 256)])
 def test_shape_from_shading_one_kernel_iteration(torch, orc, monkeypatch, W, H):
     """GN on one GPU: ONE launch per PCG iteration (the marching kernel with PCGUpdate riding along: r_k, p_k formed per row, r / Ap / p ping-pong,

@@ -1011,7 +1011,8 @@ int thallo_hip_sfs_march_fits(int W) { return sfs_fused() && sfs_march() && sfs_
  * thallo_hip_sfs_pcg_init_lm: PCGInit1's J^T F pass with PCGFinalizeDiagonal riding along (gauss_newton.t:936-969): r = -J^T F, delta = 0, p_prev = 0 and, from the raw
  * diagonal of J^T J formed in the same pass, CtC, M^-1 (pre), b = r, z = M^-1 r, SSq (written when save_ssq, else read), partials of r . z.
  * thallo_hip_sfs_lm_model_cost: delta_out = delta + alpha_kl p_kl (the update the one-launch LM loop owes, thallo_hip_lm_owed_delta's rule) and the partials of
- * delta_out . J^T J delta_out and delta_out . b in ONE launch -- the model cost of an LM step (thallo.t:3845-3865, expanded: solver.cpp step_lm). */
+ * delta_out . J^T J delta_out and delta_out . b in ONE launch -- the model cost of an LM step (thallo.t:3845-3865, expanded: solver.cpp step_lm); with X / prevX also
+ * savePreviousUnknowns and PCGLinearUpdate (prevX = X, X = X + delta_out; gauss_newton.t:901-906,915-920). */
 int thallo_hip_sfs_pcg_init_lm(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                                const unsigned char* fl, float* r, float* z, float* p_prev, float* delta, float* SSq, float* CtC, float* pre, float* b,
                                float radius, float min_lm_diagonal, float max_lm_diagonal, int save_ssq, float* aN_out, thallo_stream_t stream)
@@ -1024,12 +1025,12 @@ int thallo_hip_sfs_pcg_init_lm(int W, int H, int row0, int row1, int yoff, int H
 }
 int thallo_hip_sfs_lm_model_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,
                                  const float* delta, float* delta_out, const float* p_even, const float* p_odd, const float* b, const float* alphaN_words, const float* alphaD_words,
-                                 int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out, thallo_stream_t stream)
+                                 int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out, float* X, float* prevX, thallo_stream_t stream)
 {
     (void)fl;
     if (!sfs_pair(W, H)) return -(int)hipErrorNotSupported;
     return thallo::sfs_pair_model_cost(W, H, row0, row1, yoff, Hg, host_params, G, Wt, delta, delta_out, p_even, p_odd, b, alphaN_words, alphaD_words, word_stride, lm_state, L, dJJd_out, db_out,
-                                       pair_tune(), stream);
+                                       X, prevX, pair_tune(), stream);
 }
 
 int thallo_hip_sfs_pcg_iter(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* G, const float* Wt, const unsigned char* fl,

@@ -49,7 +49,7 @@ __device__ __forceinline__ unsigned fl_right(unsigned f) { return ((f >> 8) & 0x
 __device__ __forceinline__ M2 bit(unsigned f, unsigned b) { return M2{ (f & b) != 0u, (f & (b << 8)) != 0u }; }
 
 constexpr int PM_USE = 124, PM_NT = 256;
-constexpr int PM_WG_PER_CU = 2;           // grid sizing (tools/sfs_probe.py sweeps); registers for 2 workgroups of 4 waves per CU
+constexpr int PM_WG_PER_CU = 1;           // grid sizing: one workgroup of 4 waves per CU (tools/sfs_pair_time.py at 2048^2: 32.6 us against 33.9 for two, 36.0 for three); registers for 2
 struct PmGeo { int W, H, ra, rb, yoff, R, nstrips, total; };
 struct PCam { float wp, ws, wg, fx, fy, ux, uy; float L[9]; };
 __device__ __forceinline__ float coef0(const PCam& cm, int x) { return ((float)x - cm.ux) / cm.fx; }
@@ -77,7 +77,8 @@ struct PmPupd { const float* p_in; float* p_out; thallo_sum_t aN, bN; int first;
 struct PmUpd { float* r_out; const float* A_in; const float* p_in; float* p_out; float* delta; thallo_sum_t aN, aD, bN; int first; int lm; const float* b; const float* pre;
                const double* prev_s3; int prev_nb; float* aD_word; float* bN_word; };
 struct PmFin { float* SSq; float* CtC; float* pre; float* b; float radius, min_lm, max_lm; int save_ssq; };
-struct PmModel { const float* p_even; const float* p_odd; const float* b; const float* aN_words; const float* aD_words; int stride; const float* state; int L; float* db_out; };
+struct PmModel { const float* p_even; const float* p_odd; const float* b; const float* aN_words; const float* aD_words; int stride; const float* state; int L; float* db_out;
+                 float* X; float* prevX; };      // X != NULL: savePreviousUnknowns + PCGLinearUpdate ride along (prevX = X, X += delta) on the segment's own rows
 
 // one row of one lane (two pixels) as loaded
 struct PmRaw { u32x2 gx, gy, gz, bi, fw, v, rs, ct, pv, av, dl, bb, mi; };
@@ -215,7 +216,14 @@ __global__ __launch_bounds__(PM_NT, OCC) void k_pmarch(PmGeo g, PCam cm, const f
                     v0 = sel(ok, v0, Z2);
                     const bool mine = t >= ya && t < yb;
                     if (PUPD && mine && xout) bst2(RS_PO, vo, (unsigned)t * rowb, v0);
-                    if (MODEL && mine && xout) bst2(RS_OUT, vo, (unsigned)t * rowb, v0);           // (out = the updated delta: ANOTHER plane than the one the neighbouring segments' halo rows still read)
+                    if (MODEL && mine && xout) {
+                        bst2(RS_OUT, vo, (unsigned)t * rowb, v0);                                  // (out = the updated delta: ANOTHER plane than the one the neighbouring segments' halo rows still read)
+                        if (md.X) {      // gauss_newton.t:915-920 (savePreviousUnknowns) + :901-906 (PCGLinearUpdate: X = X + delta, k_linear_update's expression); nobody else reads X here
+                            const rsrc_t RS_X = make_rsrc(md.X), RS_PX = make_rsrc(md.prevX);
+                            const v2f xo = f2(bld2(RS_X, vo, (unsigned)t * rowb));
+                            bst2(RS_PX, vo, (unsigned)t * rowb, xo); bst2(RS_X, vo, (unsigned)t * rowb, xo + v0);
+                        }
+                    }
                     if (UPD) {
                         Rk[k0] = rk;
                         const v2f dl = f2(cur.dl);
@@ -572,7 +580,7 @@ int sfs_pair_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const fl
 {
     if (!rows_ok(H, ra, rb) || !X || !D || !Im || !mR || !mC || !G || !Fw) return -(int)hipErrorInvalidValue;
     if (((uintptr_t)mR | (uintptr_t)mC) & 1) return -(int)hipErrorInvalidValue;
-    const PmGeo mg = pick_geo(W, H, ra, rb, yoff, t, 4);
+    const PmGeo mg = pick_geo(W, H, ra, rb, yoff, t, 2);      // (two workgroups per CU: tools/sfs_pair_time.py, cold launches at 2048^2: 39.5 us against 43.3 for one, 42.9 for four)
     const int grid = (mg.total + 7) / 8 * 8;
     if (grid > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
     if (cost_out) {
@@ -584,9 +592,16 @@ int sfs_pair_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const fl
 }
 
 #define PM_ARGS_NONE PmPupd{}, PmUpd{}, LmFin{}, PmFin{}, PmModel{}
+// Rows of prefetch: three.  Six (two trips ahead) measured 4-6 % slower on every form at 2048^2 and 640 x 480 (tools/sfs_pair_time.py, round 6) and pushes the LM form into
+// scratch; the product instantiates depth 3 only (-DTHALLO_SFS_PAIR_DEPTH6: both, for the tool's sweep).
+#ifdef THALLO_SFS_PAIR_DEPTH6
 #define PM_LAUNCH(SUMS, CTC, INIT, DIAG, PUPD, UPD, LMQ, FIN, MODEL, ...) do { \
     if (t.depth == 6) hipLaunchKernelGGL((k_pmarch<SUMS, CTC, INIT, DIAG, 2, PUPD, UPD, LMQ, FIN, MODEL, 6>), dim3(grid), dim3(PM_NT), 0, (hipStream_t)stream, __VA_ARGS__); \
     else hipLaunchKernelGGL((k_pmarch<SUMS, CTC, INIT, DIAG, 2, PUPD, UPD, LMQ, FIN, MODEL, 3>), dim3(grid), dim3(PM_NT), 0, (hipStream_t)stream, __VA_ARGS__); } while (0)
+#else
+#define PM_LAUNCH(SUMS, CTC, INIT, DIAG, PUPD, UPD, LMQ, FIN, MODEL, ...) do { (void)t.depth; \
+    hipLaunchKernelGGL((k_pmarch<SUMS, CTC, INIT, DIAG, 2, PUPD, UPD, LMQ, FIN, MODEL, 3>), dim3(grid), dim3(PM_NT), 0, (hipStream_t)stream, __VA_ARGS__); } while (0)
+#endif
 
 int sfs_pair_init(int W, int H, int row0, int row1, int yoff, int Hg, const float* hp, const float* X, const float* D, const float* G, const float* Fw,
                   float* r, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, const SfsFinDiag& fdh, const SfsTune& t, thallo_stream_t stream)
@@ -688,15 +703,16 @@ int sfs_pair_iter_lm(int W, int H, int row0, int row1, int yoff, int Hg, const f
 
 int sfs_pair_model_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* hp, const float* G, const float* Fw, const float* delta, float* delta_out, const float* p_even, const float* p_odd,
                         const float* b, const float* alphaN_words, const float* alphaD_words, int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out,
-                        const SfsTune& t, thallo_stream_t stream)
+                        float* X, float* prevX, const SfsTune& t, thallo_stream_t stream)
 {
     (void)Hg;
+    if ((X != nullptr) != (prevX != nullptr) || (X && X == prevX)) return -(int)hipErrorInvalidValue;
     if (!rows_ok(H, row0, row1) || row0 != 0 || row1 != H || !G || !Fw || !delta || !delta_out || delta == delta_out || !p_even || !p_odd || !b || !alphaN_words || !alphaD_words || word_stride < 1 || !lm_state || L < 0 ||
         !dJJd_out || !db_out) return -(int)hipErrorInvalidValue;
     const PmGeo mg = pick_geo(W, H, row0, row1, yoff, t);
     const int grid = (mg.total + 7) / 8 * 8;
     if (grid > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
-    const PmModel md = { p_even, p_odd, b, alphaN_words, alphaD_words, word_stride, lm_state, L, db_out };
+    const PmModel md = { p_even, p_odd, b, alphaN_words, alphaD_words, word_stride, lm_state, L, db_out, X, prevX };
     PM_LAUNCH(false, false, false, false, false, false, false, false, true, mg, cam_of(hp), G, (const unsigned*)Fw, delta, (const float*)nullptr, delta_out, dJJd_out, (const float*)nullptr,
               (double*)nullptr, (const unsigned*)nullptr, FinArgs{}, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, PmPupd{}, PmUpd{}, LmFin{}, PmFin{}, md);
     int e = check_launch(); return e ? e : grid;

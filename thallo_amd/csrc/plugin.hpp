@@ -131,6 +131,16 @@ public:
     virtual bool lm_one_kernel_slab() const { return false; }       // ... pcg_iter_lm also serves a row slab (ghost rows of r and p kept current; fin without tickets: partials only)
     virtual int pcg_iter_lm(LaunchCtx&, SolverVectors&, int /*cur*/, bool /*first*/, thallo_sum_t /*aN_prev*/, thallo_sum_t /*aD_prev*/, thallo_sum_t /*bN_prev*/, float* /*alphaD_out*/,
                             const thallo_fin_t&, float* /*lm_state*/, int /*k*/, float /*q_tolerance*/) { return -1; }
+    // LM on one GPU, round 6 (shape_from_shading on packed planes): PCGFinalizeDiagonal rides in PCGInit1's pass -- r, delta = 0, p[cur] = 0 and, from the raw diagonal formed in the
+    // same launch, CtC, pre, b = r, z = pre r, SSq (written when save_ssq), partials of r . z: pcg_init + thallo_hip_lm_finalize_diagonal in one launch
+    virtual bool init_folds_lm_diagonal() const { return false; }
+    virtual int pcg_init_lm(LaunchCtx&, SolverVectors&, int /*cur*/, float /*radius*/, float /*min_lm_diagonal*/, float /*max_lm_diagonal*/, int /*save_ssq*/, float* /*alphaN_out*/) { return -1; }
+    // ... and the step's model cost in ONE launch behind the one-launch LM loop: v.Adelta = v.delta + alpha_kl p_kl (the update of delta the loop owes; kl from lm_state as
+    // thallo_hip_lm_owed_delta), partials of that . J^T J that (dJJd_out) and of that . b (db_out); the driver then swaps v.delta and v.Adelta.  Returns the partial count of each.
+    virtual bool lm_model_cost_one_launch() const { return false; }
+    // update_unknowns: the launch also saves the unknowns to v.prevX and adds the new delta to them (savePreviousUnknowns + PCGLinearUpdate; single-image plugins)
+    virtual int lm_model_cost(LaunchCtx&, SolverVectors&, const float* /*alphaN_words*/, const float* /*alphaD_words*/, int /*word_stride*/, const float* /*lm_state*/, int /*L*/,
+                              float* /*dJJd_out*/, float* /*db_out*/, bool /*update_unknowns*/) { return -1; }
     virtual bool apply_folds_pupdate() const { return false; }
     virtual int apply_jtj_pupdate(LaunchCtx&, const float* /*z*/, const float* /*p_in*/, float* /*p_out*/, float* /*Ap*/, float* /*alphaD_out*/, bool /*first*/,
                                   thallo_sum_t /*aN_prev*/, thallo_sum_t /*bN_prev*/) { return -1; }

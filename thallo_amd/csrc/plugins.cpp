@@ -1000,6 +1000,25 @@ public:
                                               c.gate, c.stream);
     }
     bool apply_adds_ctc() const override { return true; }
+    // round 6, packed planes, the whole image on one GPU: PCGFinalizeDiagonal inside PCGInit1's launch; owed delta update + model-cost applyJTJ + dot in one launch
+    bool packed() const { return thallo_hip_sfs_planes_layout(W, H) == 1 && row0_ == 0 && row1_ == H; }
+    bool init_folds_lm_diagonal() const override { return packed(); }
+    int pcg_init_lm(LaunchCtx& c, SolverVectors& v, int cur, float radius, float min_lm, float max_lm, int save_ssq, float* aN) override
+    {
+        int rc = precompute(c); if (rc < 0) return rc;
+        TimedLaunch t(c, "PCGInit1");
+        return thallo_hip_sfs_pcg_init_lm(W, H, row0_, row1_, yoff_, Hg_, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, v.r, v.z, v.p[cur], v.delta,
+                                          v.SSq, v.CtC, v.pre, v.b, radius, min_lm, max_lm, save_ssq, aN, c.stream);
+    }
+    bool lm_model_cost_one_launch() const override { return packed(); }
+    int lm_model_cost(LaunchCtx& c, SolverVectors& v, const float* aN_words, const float* aD_words, int stride, const float* lm_state, int L, float* dJJd_out, float* db_out, bool upd) override
+    {
+        TimedLaunch t(c, "PCGModelCost");
+        const int rc = thallo_hip_sfs_lm_model_cost(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, v.delta, v.Adelta, v.p[1], v.p[0], v.b,
+                                                    aN_words, aD_words, stride, lm_state, L, dJJd_out, db_out, upd ? X : nullptr, upd ? v.prevX : nullptr, c.stream);
+        if (rc >= 0 && upd) unknowns_written();
+        return rc;
+    }
     bool apply_folds_pupdate() const override { return thallo_hip_sfs_march_fits(W) != 0; }
     int apply_jtj_pupdate(LaunchCtx& c, const float* z, const float* p_in, float* p_out, float* Ap, float* out, bool first, thallo_sum_t aN, thallo_sum_t bN) override
     {

@@ -45,6 +45,6 @@ int sfs_pair_iter_lm(int W, int H, int row0, int row1, int yoff, int Hg, const f
 // thallo_hip_lm_owed_delta + thallo_hip_sfs_apply_jtj + thallo_hip_dot
 int sfs_pair_model_cost(int W, int H, int row0, int row1, int yoff, int Hg, const float* hp, const float* G, const float* Fw, const float* delta, float* delta_out, const float* p_even, const float* p_odd,
                         const float* b, const float* alphaN_words, const float* alphaD_words, int word_stride, const float* lm_state, int L, float* dJJd_out, float* db_out,
-                        const SfsTune& t, thallo_stream_t stream);
+                        float* X, float* prevX /* both or neither: prevX = X, X += delta_out ride along (savePreviousUnknowns + PCGLinearUpdate) */, const SfsTune& t, thallo_stream_t stream);
 
 }  // namespace thallo

@@ -229,6 +229,7 @@ const char* env_switch(const char* name)
         { "THALLO_LM_FOLD_P", "lm_fold_p" },                    // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own
         { "THALLO_SFS_FUSED", "sfs_fused" },                    // 0: shape_from_shading's two-pass applyJTJ (round 1)
         { "THALLO_SFS_MARCH", "sfs_march" },                    // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
+        { "THALLO_LM_FOLD_STEP", "lm_fold_step" },              // 0: the LM step with PCGFinalizeDiagonal and the model cost as launches of their own where a plugin can fold them (round 6)
         { "THALLO_SFS_PAIR", "sfs_pair" },                      // 0: shape_from_shading's one-pixel-per-lane marching kernels on the float4 / float2 / byte planes instead of the pixel-pair kernels on packed planes (round 6)
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere
         { "THALLO_FRONTEND_PRELOAD", "frontend_preload" },      // 0: every residual instance of a generated merged gather kernel loads for itself (round 4's lowering)
@@ -265,6 +266,7 @@ void Plan::read_ab_switches()
       const char* c = e ? strchr(e, ':') : nullptr; aux_async_ = c != nullptr; aux_workgroups_ = c && atoi(c + 1) > 0 ? atoi(c + 1) : 0; }      // ("N:W": the update NEXT TO the loop, on at most W workgroups)
     batch_delta_   = delta_planes_ != 0;
     lm_fold_p_     = !off("THALLO_LM_FOLD_P");
+    lm_fold_step_  = !off("THALLO_LM_FOLD_STEP");
 }
 
 void Plan::set_param(const char* name, const void* value)
@@ -860,8 +862,14 @@ int Plan::step_lm(int ev_iter)
     if (sp.nIter == 0) { radius_ = sp.trust_region_radius; decrease_factor_ = sp.radius_decrease_factor; }   // :1185-1186 (copied at init)
     cur_ = 0;
     int nb = 0;
-    if (!skip()) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); check(nb, "PCGInit1 launch"); }        // r, raw diag (v_.diag); delta = 0
-    if (!skip()) {
+    // (round 6: plugins whose PCGInit1 launch also finalises the diagonal -- shape_from_shading on packed planes, one GPU; THALLO_LM_FOLD_STEP=0: the two launches, A/B)
+    const bool fold_init = !slab && lm_fold_step_ && plugin->init_folds_lm_diagonal();
+    if (fold_init && !skip()) {
+        nb = plugin->pcg_init_lm(ctx, v_, cur_, radius_, sp.min_lm_diagonal, sp.max_lm_diagonal, sp.nIter == 0 ? 1 : 0, slot(B));
+        check(nb, "PCGInit1 (+ PCGFinalizeDiagonal) launch");
+    }
+    if (!fold_init && !skip()) { nb = plugin->pcg_init(ctx, v_, cur_, slot(B)); check(nb, "PCGInit1 launch"); }        // r, raw diag (v_.diag); delta = 0
+    if (!fold_init && !skip()) {
         TimedLaunch t(ctx, "PCGFinalizeDiagonal");                    // :1596-1604 (alphaN restarts from 0)
         nb = thallo_hip_lm_finalize_diagonal(v_.diag + o, v_.SSq + o, v_.CtC + o, v_.pre + o, v_.r + o, v_.b + o, v_.z + o, n, radius_, sp.min_lm_diagonal, sp.max_lm_diagonal,
                                              sp.nIter == 0 ? 1 : 0, pc ? 1 : 0, slot(B), s);
@@ -878,6 +886,7 @@ int Plan::step_lm(int ev_iter)
     int k_done = 0;
     thallo_hip_lm_set_gate(gate); ctx.gate = gate;
     bool coll_failed = false;                                         // a collective itself failed: nothing left to stay in step with
+    bool model_cost_done = false;                                     // the two sums of the model cost are already in slots T0 / T1 (one launch behind the one-launch loop)
     // One launch per LM iteration (one GPU; plugins that offer it: shape_from_shading's marching kernel; lIterations within one residual-reset period, where the reset
     // -- it falls on the last iteration -- changes nothing that is read afterwards): the vector update, PCGStep3, (J^T J + CtC) p, all sums and the zeta test in
     // pcg_iter_lm; behind the loop the one update of delta it still owes.  THALLO_LM_FOLD_P=0: the reference-shaped loop (A/B).
@@ -961,6 +970,13 @@ int Plan::step_lm(int ev_iter)
                 after_reset = true;
             }
         }
+        // round 6: the owed update of delta, the model cost's applyJTJ and its dot product in ONE launch (plugins that offer it); delta moves to the other buffer
+        model_cost_done = !failed && lm_fold_step_ && plugin->lm_model_cost_one_launch();
+        if (model_cost_done) {
+            nb = plugin->lm_model_cost(ctx, v_, scal(B), scal(B + 1), 2, lmst, L, slot(T0), slot(T1), true);      // (... and savePreviousUnknowns + PCGLinearUpdate)
+            check(nb, "PCGModelCost launch");
+            if (!failed) { set_nb(T0, nb); set_nb(T1, nb); std::swap(v_.delta, v_.Adelta); }
+        } else
         if (!failed) {      // p_k lives in p[1] for even k, p[0] for odd k
             TimedLaunch t(ctx, "PCGUpdate");
             check(thallo_hip_lm_owed_delta(v_.delta, v_.p[1], v_.p[0], n, scal(B), scal(B + 1), 2, lmst, L, s), "PCGUpdate (owed delta) launch");
@@ -1038,10 +1054,12 @@ int Plan::step_lm(int ev_iter)
     // model_cost_change = cost - 0.5|F + J delta|^2 = delta.b - 0.5 delta.(J^T J delta)   (b = -J^T F; thallo.t:3845-3865
     // expanded algebraically, which also avoids the reference's cancellation between two large sums)
     if (global_rows(-1, v_.delta)) return 0;
-    if (!skip()) { nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0)); check(nb, "model cost: applyJTJ launch"); }
-    if (!skip()) set_nb(T0, nb);
-    if (!skip()) { nb = thallo_hip_dot(v_.delta + o, v_.b + o, n, slot(T1), s); check(nb, "model cost: dot launch"); }
-    if (!skip()) set_nb(T1, nb);
+    if (!model_cost_done) {
+        if (!skip()) { nb = plugin->apply_jtj(ctx, v_.delta, v_.Adelta, slot(T0)); check(nb, "model cost: applyJTJ launch"); }
+        if (!skip()) set_nb(T0, nb);
+        if (!skip()) { nb = thallo_hip_dot(v_.delta + o, v_.b + o, n, slot(T1), s); check(nb, "model cost: dot launch"); }
+        if (!skip()) set_nb(T1, nb);
+    }
     if (failed) return 0;
     // the two sums over all ranks, into the step's report.  Device-side transport: ONE exchange carries both and writes them where the report is read from (it was two
     // exchanges and two one-wave launches that copied their words there; three launches fewer, though the step's time did not move: 37.5 us per PCG iteration either way on a
@@ -1058,11 +1076,11 @@ int Plan::step_lm(int ev_iter)
             thallo_hip_finish_sum(sum(T1), lmst + 4, s);
         }
         long off = 0;                                                 // savePreviousUnknowns :915-920
-        for (size_t k = 0; k < imgs.size(); ++k) {
+        for (size_t k = 0; !model_cost_done && k < imgs.size(); ++k) {
             HIP_OK(hipMemcpyAsync(v_.prevX + off, plugin->unknown_ptr((int)k), imgs[k].n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
             off += imgs[k].n_floats;
         }
-        linear_update_tail(0, false);                                 // PCGLinearUpdate: X += delta (the owned rows of a slab)
+        if (!model_cost_done) linear_update_tail(0, false);           // PCGLinearUpdate: X += delta (the owned rows of a slab); the one-launch model cost has done both
     }
     if (slab && dist_exchange_unknown_rows()) return 0;
     bool failed_before_cost_exchange = false;

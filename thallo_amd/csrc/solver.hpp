@@ -150,7 +150,7 @@ private:
 
     float* slot(int j) { return (float*)parts_.ptr + (size_t)j * THALLO_HIP_MAX_PARTIALS; }
     std::vector<char> fin_;         // slot already reduced to one word (scal(j)) by a 1-wave finish_sum launch
-    bool fin_in_kernel_ = true, one_kernel_ = true, batch_delta_ = true, lm_fold_p_ = true;   // A/B switches: read_ab_switches()
+    bool fin_in_kernel_ = true, one_kernel_ = true, batch_delta_ = true, lm_fold_p_ = true, lm_fold_step_ = true;   // A/B switches: read_ab_switches()
     int delta_planes_ = -1;         // THALLO_DELTA_PLANES (-1: unset)
     std::vector<float*> ring_;      // the ring of p planes of the one-kernel GN loop (ring_planes)
     int  ring_planes(int L);        // how many planes the loop of L iterations runs on (allocates nothing unless lIterations changed since Init)

@@ -52,14 +52,21 @@ def cat512():
             float(np.sqrt(np.float32(100.0))), float(np.sqrt(np.float32(0.01)))]
 
 
+only = sys.argv[1] if len(sys.argv) > 1 else ""      # e.g. "sfs", "ba", "image_warping", "arap": the configurations whose name contains it
+want = lambda name: only in name
 out = []
-out.append(run("image_warping cat512 (reference data) GN 8x100", "image_warping", (512, 512), cat512(), 8, 100))
-out.append(run("image_warping 512x512 synthetic GN 8x100", "image_warping", (512, 512), syn.image_warping(512, 512), 8, 100))
-p = syn.arap_mesh(320, 320)
-out.append(run("arap_mesh 102400 v / 614400 e GN 20x100", "arap_mesh_deformation", (p[2].shape[0], p[6].shape[0]), p, 5, 100))
-out.append(run("shape_from_shading 2048x2048 GN x10", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 6, 10))
-out.append(run("shape_from_shading 2048x2048 LM x10 (BASELINE config 4's solver)", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 5, 10, lm=True))
-p = syn.bundle_adjustment()
-out.append(run("bundle_adjustment C=1723 P=156502 O=678718 LM x150 (BASELINE config 5's solver)", "bundle_adjustment", (p[0].shape[0], p[1].shape[0], p[2].shape[0]), p, 3, 150, lm=True))
-out.append(run("bundle_adjustment C=1723 P=156502 O=678718 GN x150", "bundle_adjustment", (p[0].shape[0], p[1].shape[0], p[2].shape[0]), p, 3, 150))
+if want("image_warping cat512"): out.append(run("image_warping cat512 (reference data) GN 8x100", "image_warping", (512, 512), cat512(), 8, 100))
+if want("image_warping 512"): out.append(run("image_warping 512x512 synthetic GN 8x100", "image_warping", (512, 512), syn.image_warping(512, 512), 8, 100))
+if want("arap"):
+    p = syn.arap_mesh(320, 320)
+    out.append(run("arap_mesh 102400 v / 614400 e GN 20x100", "arap_mesh_deformation", (p[2].shape[0], p[6].shape[0]), p, 5, 100))
+if want("shape_from_shading") or only == "sfs":
+    out.append(run("shape_from_shading 2048x2048 GN x10", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 6, 10))
+    out.append(run("shape_from_shading 2048x2048 LM x10 (BASELINE config 4's solver)", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 5, 10, lm=True))
+    out.append(run("shape_from_shading 640x480 GN x10 (the size of the reference's data set)", "shape_from_shading", (640, 480), syn.shape_from_shading(640, 480), 12, 10))
+    out.append(run("shape_from_shading 640x480 LM x10", "shape_from_shading", (640, 480), syn.shape_from_shading(640, 480), 10, 10, lm=True))
+if want("bundle_adjustment") or only == "ba":
+    p = syn.bundle_adjustment()
+    out.append(run("bundle_adjustment C=1723 P=156502 O=678718 LM x150 (BASELINE config 5's solver)", "bundle_adjustment", (p[0].shape[0], p[1].shape[0], p[2].shape[0]), p, 3, 150, lm=True))
+    out.append(run("bundle_adjustment C=1723 P=156502 O=678718 GN x150", "bundle_adjustment", (p[0].shape[0], p[1].shape[0], p[2].shape[0]), p, 3, 150))
 print(json.dumps(out, indent=1))

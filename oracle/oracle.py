@@ -156,6 +156,13 @@ def last_pcg_counts():
     return list(out[: min(n, 1024)])
 
 
+def last_trust_region():
+    """(radius, radius_decrease_factor) as the last LM solve() left them: with the unknowns, the state from which the trajectory continues."""
+    r, d = C.c_float(0), C.c_float(0)
+    lib().orc_last_trust_region(C.byref(r), C.byref(d))
+    return float(r.value), float(d.value)
+
+
 def set_threads(n):
     """n > 1: the oracle's row loops run on n OpenMP threads (full-size configurations on the GPU box's host cores); 1 = the serial,
     bit-exact known-answer path.  Returns the previous setting."""

@@ -666,6 +666,10 @@ static void copy_unknowns(OrcEnergy* e, float* dst_flat, int to_flat)
 /* PCG iterations each Gauss-Newton / LM step of the last orc_solve ran (the zeta test of :1666-1686 ends the LM loop early): what the tests compare the
  * device-side early exit with */
 static int g_pcg_counts[1024], g_pcg_steps = 0;
+/* the LM trust region as the last solve left it (radius, radius_decrease_factor): what a caller needs to CONTINUE a trajectory step by step from the state the oracle reached
+ * (tools/single_step_parity.py: every step of the device solver started from the oracle's state) */
+static float g_last_radius = 0.0f, g_last_decrease = 0.0f;
+void orc_last_trust_region(float* radius, float* decrease_factor) { if (radius) *radius = g_last_radius; if (decrease_factor) *decrease_factor = g_last_decrease; }
 int orc_last_pcg_counts(int* out, int cap)
 {
     const int n = g_pcg_steps < cap ? g_pcg_steps : cap;
@@ -818,6 +822,7 @@ int orc_solve(OrcEnergy* e, const OrcSolverParams* sp, double* costs, int costs_
         ++nIter;
     }
 done:
+    g_last_radius = radius; g_last_decrease = decrease_factor;
     free(delta); free(r); free(z); free(p); free(Ap); free(pre);
     free(b); free(Adelta); free(CtC); free(SSq); free(prevX);
     return nIter;

@@ -119,6 +119,8 @@ int orc_solve(OrcEnergy* e, const OrcSolverParams* sp, double* costs, int costs_
 /* Convenience single-call entry for ctypes */
 /* PCG iterations per GN / LM step of the last orc_solve (returns the number of steps; fills at most cap) */
 int orc_last_pcg_counts(int* out, int cap);
+/* LM: the trust region (radius, radius_decrease_factor) as the last orc_solve* call left it */
+void orc_last_trust_region(float* radius, float* decrease_factor);
 int orc_solve_kind(int kind, const unsigned* dims, void** params, const float* fconst, const int* iconst,
                    const OrcSolverParams* sp, double* costs, int costs_cap, float* trace, int trace_cap);
 

@@ -40,7 +40,7 @@ def build(tag):
     return so
 
 
-def child(so, W, steps, float_sums):
+def child(so, W, steps, float_sums, perturb=0):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle as orc
     orc._LIB = so
@@ -48,6 +48,10 @@ def child(so, W, steps, float_sums):
     from thallo_amd import synthetic as syn
     from helpers import copy_params
     p = syn.shape_from_shading(W, W)
+    if perturb:        # round 6: the unknown depth of every 97th pixel moved by ONE unit in the last place (build A, double sums): how fast does the smallest possible difference grow?
+        import numpy as np
+        x = p[16].reshape(-1)
+        x[::97] = np.nextafter(x[::97], np.float32(np.inf))
     orc.set_threads(1)
     t0 = time.time()
     c, _ = orc.Problem(orc.SFS, (W, W), copy_params(p)).solve(nIterations=steps, lIterations=10, use_lm=1, float_sums=float_sums)
@@ -56,7 +60,22 @@ def child(so, W, steps, float_sums):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        return child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+        return child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]) if len(sys.argv) > 6 else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--perturbed":      # adds the row "perturbed" (build A from an input one ulp away) to the existing file: python ... --perturbed [W] [steps]
+        W = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+        steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+        data = json.load(open(OUT))
+        assert data["instance"].startswith("synthetic shape_from_shading %d x %d, LM %d x 10" % (W, W, steps)), data["instance"]
+        so = build("A")
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", so, str(W), str(steps), "0", "1"], stdout=subprocess.PIPE, text=True, check=True).stdout
+        res = json.loads(out.strip().splitlines()[-1])
+        import numpy as np
+        a = np.array(data["runs"]["A"]["costs"]); x = np.array(res["costs"]); m = min(len(a), len(x))
+        data["perturbed"] = {"what": "oracle build A (-ffp-contract=off, double sums) started from unknowns in which every 97th pixel is moved by one unit in the last place",
+                             "costs": res["costs"], "rel_diff_vs_A": [float("%.3g" % v) for v in np.abs(x[:m] - a[:m]) / np.abs(a[:m])]}
+        json.dump(data, open(OUT, "w"), indent=1)
+        print(json.dumps(data["perturbed"]))
+        return
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     libs = {t: build(t) for t in FLAGS}

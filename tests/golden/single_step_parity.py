@@ -1,0 +1,139 @@
+"""single_step_parity.py -- every step of the device solver started FROM THE ORACLE'S STATE (VERDICT r5 "Next round" item 4: close the parity argument).
+
+Whole LM / GN trajectories of the three ill-conditioned configurations leave the 1e-5 corridor after a few steps (shape_from_shading 2048^2 LM from step 4, cat512 8 x 100,
+small_armadillo 4 x 30): every accepted LM step triples the trust region, ten (or a hundred) unconverged float PCG iterations amplify whatever differs, and ANY difference in
+rounding grows about five-fold per step -- the oracle against itself does it when only the compiler's fma contraction changes (lm_rounding_experiment.json, B vs A), and
+(row "perturbed" there) when its input moves by one unit in the last place.  So a trajectory cannot tell a rounding difference from a kernel bug.  This script separates the
+two: along the ORACLE's own trajectory S_0, S_1, ... (unknowns + trust region), step k of the device solver is started from S_k -- a fresh plan, the oracle's unknowns, the
+oracle's radius and decrease factor -- and its result is compared with the oracle's S_{k+1}.  If the kernels compute what the oracle computes, EVERY step agrees to the
+tolerance of one step (1e-5 relative in the cost), however long the trajectory; a kernel bug that the amplified bars of the trajectory tests were hiding would show as a step
+that does not.
+
+    python tests/golden/single_step_parity.py [sfs2048 | cat512 | armadillo | sfs512 | all]      (GPU box; the oracle runs on the host cores)
+writes / updates tests/golden/single_step_parity.json.  The oracle is the checker here (test infrastructure), the device path is the product library.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.environ.get("SSP_OUT") or os.path.join(ROOT, "tests", "golden", "single_step_parity.json")      # (gpurun brings back gpurun_out/ only: SSP_OUT=gpurun_out/single_step_parity.json there)
+
+
+def instances():
+    import numpy as np
+    from thallo_amd import synthetic as syn, formats as F
+    g = os.path.join(ROOT, "tests", "golden")
+
+    def cat512():
+        mask = F.read_png(os.path.join(g, "cat512_mask.png"))[:, :, 0].astype(np.float32)
+        H, W = mask.shape
+        cons = F.add_border_constraints(F.read_constraints(os.path.join(g, "cat512.constraints")), W, H)
+        yy, xx = np.mgrid[0:H, 0:W]
+        ur = np.stack([xx, yy], axis=2).astype(np.float32)
+        c_img = F.constraint_image(cons, mask, np.float32(1) / np.float32(19))
+        return (W, H), [ur.copy(), np.zeros((H, W), np.float32), ur.copy(), c_img, mask, float(np.sqrt(np.float32(100.0))), float(np.sqrt(np.float32(0.01)))]
+
+    def armadillo():
+        V, faces = F.read_ply(os.path.join(g, "small_armadillo.ply"))
+        idx, target = F.read_mrk(os.path.join(g, "small_armadillo.mrk"))
+        nv = len(V)
+        cent = np.array([V[list(fc)].mean(axis=0) for fc in faces], dtype=np.float32)
+        V2 = np.concatenate([V, cent]).astype(np.float32)
+        faces2 = [[fc[k], fc[(k + 1) % 3], nv + i] for i, fc in enumerate(faces) for k in range(3)]
+        v0, v1 = F.mesh_directed_edges(faces2, len(V2))
+        cons = np.full((len(V2), 3), -1.0e30, np.float32); cons[idx] = target
+        return (len(V2), len(v0)), [4.0, 1.0, V2.copy(), np.zeros_like(V2), V2.copy(), cons, v0, v1]
+
+    return {
+        "sfs2048": dict(name="shape_from_shading 2048 x 2048 (synthetic), LM 60 x 10 -- BASELINE config 3's budget", kind="SFS", fname="shape_from_shading", lm=1, steps=60, lit=10,
+                        make=lambda: ((2048, 2048), syn.shape_from_shading(2048, 2048)), unknowns=[16]),
+        "sfs512": dict(name="shape_from_shading 512 x 512 (synthetic), LM 24 x 10 (the suite's reduced form)", kind="SFS", fname="shape_from_shading", lm=1, steps=24, lit=10,
+                       make=lambda: ((512, 512), syn.shape_from_shading(512, 512)), unknowns=[16]),
+        "cat512": dict(name="image_warping cat512 (reference data), GN 8 x 100 -- BASELINE config 1", kind="IMAGE_WARPING", fname="image_warping", lm=0, steps=8, lit=100,
+                       make=cat512, unknowns=[0, 1], probe_lit=4),
+        "armadillo": dict(name="arap_mesh_deformation small_armadillo (reference data), GN 4 x 30", kind="ARAP_MESH", fname="arap_mesh_deformation", lm=0, steps=4, lit=30,
+                          make=armadillo, unknowns=[2, 3], probe_lit=4),
+    }
+
+
+def run_case(key, spec, verbose=True):
+    import numpy as np
+    import torch
+    import thallo_amd
+    from thallo_amd import api
+    from oracle import oracle as orc
+    from helpers import copy_params, to_device, to_host
+    orc.build()
+    dims, p = spec["make"]()
+    state = copy_params(p)
+    radius, dec = 1e4, 2.0                      # the solver parameters' defaults (gauss_newton.t:200-216)
+    lm, lit = spec["lm"], spec["lit"]
+    prev = orc.set_threads(max(1, min(64, os.cpu_count() or 1)))
+    rows = []
+    t0 = time.time()
+    try:
+        for k in range(spec["steps"]):
+            po = copy_params(state)
+            co, _ = orc.Problem(getattr(orc, spec["kind"]), dims, po).solve(nIterations=1, lIterations=lit, use_lm=lm, trust_region_radius=radius, radius_decrease_factor=dec)
+            r2, d2 = orc.last_trust_region() if lm else (radius, dec)
+            dev = to_device(copy_params(state))
+            s = api.ThalloSolver(dims, thallo_amd.energy_file(spec["fname"]), **({"solverkind": "levenberg_marquardt"} if lm else {}))
+            if lm:
+                s.enable_lm()
+            s.set_solver_parameters(nIterations=1, lIterations=lit, **({"trust_region_radius": radius, "radius_decrease_factor": dec} if lm else {}))
+            prm = s.make_params(dev)
+            s.init(prm)
+            c0 = s.current_cost()
+            s.step(prm)
+            c1 = s.current_cost()
+            rg = s.get_solver_parameter("trust_region_radius") if lm else radius
+            xd = max(float(np.abs(to_host(dev[u]) - po[u]).max() / max(np.abs(po[u]).max(), 1e-30)) for u in spec["unknowns"])
+            moved = max(float(np.abs(po[u] - state[u]).max() / max(np.abs(po[u]).max(), 1e-30)) for u in spec["unknowns"])
+            s.close()
+            row = {"step": k, "oracle_cost_in": float(co[0]), "oracle_cost_out": float(co[-1]), "device_cost_in": float(c0), "device_cost_out": float(c1),
+                   "rel_cost_in": abs(float(c0) - float(co[0])) / abs(float(co[0])), "rel_cost_out": abs(float(c1) - float(co[-1])) / abs(float(co[-1])),
+                   "unknowns_max_diff_over_max": xd, "step_size_over_max": moved, "accepted_oracle": bool(co[-1] < co[0]), "accepted_device": bool(c1 < c0)}
+            if lm:
+                row.update({"radius_in": radius, "radius_out_oracle": r2, "radius_out_device": float(rg), "rel_radius_out": abs(float(rg) - r2) / abs(r2)})
+            if spec.get("probe_lit"):      # the same state, a SHORT PCG loop on both sides: the kernels on this state without the within-step amplification of a long unconverged loop
+                pl = spec["probe_lit"]
+                pq = copy_params(state)
+                cq, _ = orc.Problem(getattr(orc, spec["kind"]), dims, pq).solve(nIterations=1, lIterations=pl)
+                dv = to_device(copy_params(state))
+                s2 = api.ThalloSolver(dims, thallo_amd.energy_file(spec["fname"]))
+                s2.set_solver_parameters(nIterations=1, lIterations=pl)
+                pr2 = s2.make_params(dv); s2.init(pr2); s2.step(pr2); cd = s2.current_cost(); s2.close()
+                row.update({"short_loop_iterations": pl, "short_loop_rel_cost_out": abs(float(cd) - float(cq[-1])) / abs(float(cq[-1])),
+                            "short_loop_unknowns_max_diff_over_max": max(float(np.abs(to_host(dv[u]) - pq[u]).max() / max(np.abs(pq[u]).max(), 1e-30)) for u in spec["unknowns"])})
+            rows.append(row)
+            if verbose:
+                print(key, json.dumps(row), flush=True)
+            state, radius, dec = po, r2, d2
+    finally:
+        orc.set_threads(prev)
+    worst = max(r["rel_cost_out"] for r in rows)
+    return {"instance": spec["name"], "method": "each step of the device solver (a fresh plan) starts from the ORACLE's state: its unknowns" + (", trust-region radius and decrease factor" if lm else ""),
+            "steps": rows, "worst_rel_cost_out": worst, "worst_rel_cost_in": max(r["rel_cost_in"] for r in rows),
+            "worst_unknowns_max_diff_over_max": max(r["unknowns_max_diff_over_max"] for r in rows),
+            "every_step_within_1e-5": bool(worst <= 1e-5), "decisions_equal": all(r["accepted_oracle"] == r["accepted_device"] for r in rows),
+            "worst_short_loop_rel_cost_out": (max(r["short_loop_rel_cost_out"] for r in rows) if spec.get("probe_lit") else None),
+            "seconds": time.time() - t0, "host_threads": max(1, min(64, os.cpu_count() or 1))}
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    inst = instances()
+    keys = [k for k in inst if which in ("all", k)] if which != "all" else ["sfs2048", "cat512", "armadillo", "sfs512"]
+    data = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    for k in keys:
+        data[k] = run_case(k, inst[k])
+        print("SUMMARY", k, "worst rel. cost after a step", data[k]["worst_rel_cost_out"], "every step within 1e-5:", data[k]["every_step_within_1e-5"], "decisions equal:",
+              data[k]["decisions_equal"], "short loop:", data[k]["worst_short_loop_rel_cost_out"], "(%.0f s)" % data[k]["seconds"], flush=True)
+        json.dump(data, open(OUT, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -31,7 +31,9 @@ enum class Op {
     Detach,                                        // lib.t Constant(e) = ad.constant: the value of e with no derivative (robust-norm weights, lib.t:157-169)
     Select,                                        // a[0] != 0 ? a[1] : a[2]
     Eq, Ge, Gt, Le, Lt, Not, And, Or,              // 0 / 1 valued, zero derivative (ad.t:824-829)
-    InBounds                                       // all index components inside the iteration-dimension bounds (thallo.t:1993-1997)
+    InBounds,                                      // all index components inside the iteration-dimension bounds (thallo.t:1993-1997)
+    Computed                                       // round 6: expr:get(x + dx, y + dy) -- component `channel` of computed array `input` (Problem::computed) at the shift idx; a[0] is the
+                                                   // same access INLINED (Select(InBounds, the shifted expression, 0)): what runs where the array is not materialized
 };
 
 // one component of an image index: iteration variable of dimension `dim` plus a constant offset, optionally through a Sparse map
@@ -80,6 +82,11 @@ struct Residual {
     int at_output = -1;                            // r.<name>:compute_at_output(b) (thallo.t:5661-5674): 1 = unknown-wise (gather) lowering asked for, 0 = residual-wise, -1 = not said
 };
 
+// A computed array (thallo.t:1868-1937): an expression over an iteration domain that the energy reads back through :get at shifted positions.  The reference materializes it
+// -- one image for the value and one GRADIENT image per unknown the expression depends on -- with a `precompute` kernel per Gauss-Newton iteration (and again after an LM
+// revert; gauss_newton.t:979-986,1748; thallo.t:4046-4094) instead of re-evaluating the expression at every access and in every PCG iteration.
+struct ComputedArray { std::vector<E> exprs; std::vector<int> domain; };
+
 struct Problem {
     std::string file;
     std::vector<std::string> dims;                 // Dims("W","H"): ids are positions; sizes come from the unsigned[] at Plan time
@@ -91,6 +98,7 @@ struct Problem {
     bool direct_solve = false;                     // <Residuals handle>:set_direct_solve(true) (thallo.t:5634-5636); acted on only under THALLO_ENABLE_DIRECT_SOLVE=1,
                                                    // like the reference's compile-time enable_direct_solve (gauss_newton.t:22)
     std::vector<Residual> residuals;
+    std::vector<ComputedArray> computed;           // the expressions read through :get with a pure shift (Op::Computed nodes refer to them by index)
     int max_slot = -1;
     const unsigned* plan_dims = nullptr;           // Thallo_ProblemPlan's dimensions while the file runs (NULL: not known; Sum then is an error); read per declared dimension
     std::vector<long> dim_sizes;                   // ... the sizes of the dimensions declared so far (-1: unknown)
@@ -111,7 +119,12 @@ struct GenGroup { std::vector<int> domain; std::vector<int> members; std::vector
 // plugin per Init from the residual's own index evaluation (uidx kernel) -- and keeping only the partials of its own unknowns: one writer per element, no atomics.
 struct IncGroup { std::vector<int> dims; std::vector<int> inputs; };
 struct IncResidual { int ri = -1, K = 0; std::vector<int> slot_input; std::string uidx; std::vector<int> groups; std::vector<std::string> jtj, jtf; };
+// a materialized computed array: its precompute kernel and its planes in Ctx::cap -- per component the value plane, then one plane per unknown access with a structurally
+// non-zero partial (planes of one array are consecutive; every plane has one float per element of the array's domain)
+struct GenComputed { std::string kernel; std::vector<int> domain; int plane0 = 0, planes = 0; };
 struct Generated {
+    std::vector<GenComputed> computed;             // (only the arrays that are materialized: at most 48 unknown accesses, materialization not switched off)
+    int n_planes = 0;
     std::vector<IncGroup> inc_groups;
     std::vector<IncResidual> inc;                  // (residuals without the stencil gather, at most 48 unknown accesses)
     std::string source;                            // one HIP translation unit

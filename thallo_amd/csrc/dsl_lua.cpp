@@ -18,6 +18,7 @@
 #include <fstream>
 #include <functional>
 #include <set>
+#include <algorithm>
 #include <sstream>
 #include <stdexcept>
 
@@ -451,6 +452,8 @@ struct Interp {
     ~Interp() { globals.reset(); }
     int depth = 0;
     std::map<int, int> dim_calls;                  // how often each dimension was called for an iteration variable
+    std::set<const Expr*> no_materialize;          // expressions the file asked to read inlined (e:set_materialize(false))
+    std::vector<std::vector<const Expr*>> computed_keys;      // P.computed[k] was made from these component expressions
     struct ReturnEx { Values v; };
     struct BreakEx {};
     explicit Interp(Problem& p) : P(p) { install_builtins(); }
@@ -804,13 +807,41 @@ struct Interp {
                 }
                 for (auto& a : args) { IndexComp ic = as_index(a, "get"); sh[ic.dim] = ic.off; at.push_back(ic); }
                 bool any = false; for (auto& kv : sh) any = any || kv.second != 0;
-                if (!any) return { obj };
                 std::vector<E> out; std::map<const Expr*, E> memo;
                 auto inb = std::make_shared<Expr>(); inb->op = Op::InBounds; inb->idx = at;
-                for (auto& e : c) out.push_back(mk(Op::Select, { inb, shift_expr(e, sh, memo), konst(0.0) }));
-                return { vec(out) };
+                for (auto& e : c) out.push_back(any ? mk(Op::Select, { inb, shift_expr(e, sh, memo), konst(0.0) }) : e);
+                // Round 6: a pure shift of an expression over exactly the dimensions it is read at IS a computed-array access (thallo.t:1868-1937): the node keeps the inlined
+                // form as its operand and names the array; the code generator materializes the array (value + gradient planes, a precompute kernel per GN iteration) unless
+                // the file said set_materialize(false) / set_gradient_materialize(false) on the expression, or THALLO_FRONTEND_COMPUTED=0
+                bool plain = at.size() == dims.size() && !dims.empty();
+                for (size_t k = 0; plain && k < at.size(); ++k) {
+                    plain = plain_index(at[k]) && std::find(dims.begin(), dims.end(), at[k].dim) != dims.end();
+                    for (size_t j = 0; plain && j < k; ++j) plain = at[j].dim != at[k].dim;
+                }
+                for (auto& e : c) plain = plain && !no_materialize.count(e.get());
+                if (!plain) { if (!any) return { obj }; return { vec(out) }; }
+                std::vector<const Expr*> key; for (auto& e : c) key.push_back(e.get());
+                int id = -1;
+                for (size_t q = 0; q < computed_keys.size(); ++q) if (computed_keys[q] == key) id = (int)q;
+                if (id < 0) {
+                    id = (int)P.computed.size(); computed_keys.push_back(key);
+                    ComputedArray ca; ca.exprs = c; for (auto& ic : at) ca.domain.push_back(ic.dim);
+                    P.computed.push_back(ca);
+                } else {
+                    for (size_t k = 0; k < at.size(); ++k) if (P.computed[(size_t)id].domain[k] != at[k].dim) { if (!any) return { obj }; return { vec(out) }; }      // (read with its indices in another order: inlined)
+                }
+                std::vector<E> nodes;
+                for (size_t k = 0; k < c.size(); ++k) {
+                    auto n = std::make_shared<Expr>(); n->op = Op::Computed; n->input = id; n->channel = (int)k; n->idx = at; n->a = { out[k] };
+                    nodes.push_back(n);
+                }
+                return { vec(nodes) };
             }
-            if (m == "materialize" || m == "set_materialize" || m == "set_gradient_materialize") return {};      // computed-array scheduling hints (thallo.t:1907-1927): expressions are always inlined here
+            if (m == "materialize" || m == "set_materialize" || m == "set_gradient_materialize") {      // computed-array scheduling hints (thallo.t:1907-1927): (false) = read it inlined
+                const bool on = m == "materialize" || args.empty() || args[0].truthy();
+                for (auto& e : comps(obj, "set_materialize")) { if (on) no_materialize.erase(e.get()); else no_materialize.insert(e.get()); }
+                return {};
+            }
             if (m == "dot") { if (args.size() != 1) fail(ln + "v:dot(w)"); return { scalar(dot(comps(obj, "dot"), comps(args[0], "dot"), ln)) }; }
         }
         if (is_symk(obj, SymV::MatInfo)) {
@@ -1291,6 +1322,7 @@ std::string describe(const Problem& p)
     o << "preconditioner " << (p.use_preconditioner ? 1 : 0) << "\n";
     if (p.direct_solve) o << "direct_solve\n";
     for (auto& r : p.residuals) { o << "residual " << r.name << " x" << r.exprs.size() << " over"; for (int d : r.domain) o << " " << p.dims[d]; if (r.mat_J) o << " J"; if (r.mat_JtJ) o << " JtJ"; if (r.mat_Jp) o << " Jp"; o << "\n"; }
+    for (auto& ca : p.computed) { o << "computed x" << ca.exprs.size() << " over"; for (int d : ca.domain) o << " " << p.dims[d]; o << "\n"; }
     return o.str();
 }
 

@@ -89,6 +89,26 @@ class GeneratedPlugin : public EnergyPlugin, public EnergyPlugin64 {
     std::vector<DeviceBuffer*> jdest;              // per residual: [rows][K][K] positions of the products in sp_val
     long sp_nnz = 0;
     bool ok_ = false;
+    // materialized computed arrays (round 6; thallo.t:1868-1937,4046-4094): their planes (values + gradient images), their precompute kernels, and whether the planes
+    // belong to the unknowns as they are now -- precompute() runs in front of whatever evaluates residuals (cost, PCGInit1) once per change of the unknowns: per GN
+    // iteration and after an LM revert (gauss_newton.t:979-986,1748)
+    std::vector<hipFunction_t> ca_fn;
+    std::vector<DeviceBuffer*> ca_buf;
+    std::vector<long> ca_nel;
+    size_t off_cap = 0;
+    bool ca_valid_ = false;
+    std::string sched_;
+    int precompute(LaunchCtx& c)
+    {
+        if (ca_valid_ || G.computed.empty()) return 0;
+        TimedLaunch t(c, "precompute");
+        for (size_t k = 0; k < G.computed.size(); ++k) {
+            void* args[] = { ctx.data() };
+            const int rc = launch_fn(ca_fn[k], grid_for(ca_nel[k], 4096), args, c.stream); if (rc < 0) return rc;
+        }
+        ca_valid_ = true;
+        return 0;
+    }
 
     long elements(const dsl::Residual& r) const { long n = 1; for (int d : r.domain) n *= dimv[d]; return n; }
     int grid_for(long n, int cap) const
@@ -286,9 +306,18 @@ public:
         off_dim = 8 * nin;
         if (f64_) { off_prm = (off_dim + 4 * nd + 7) / 8 * 8; off_uoff = off_prm + 8 * nin; }
         else { off_prm = off_dim + 4 * nd; off_uoff = (off_prm + 4 * nin + 7) / 8 * 8; }
-        ctx.assign(off_uoff + 8 * nin, 0);
+        off_cap = off_uoff + 8 * nin;                          // float* cap[max(NCAP, 1)]: the planes of the materialized computed arrays
+        ctx.assign(off_cap + 8 * (size_t)(G.n_planes > 0 ? G.n_planes : 1), 0);
         for (size_t d = 0; d < P.dims.size(); ++d) { const int v = (int)dimv[d]; memcpy(&ctx[off_dim + 4 * d], &v, 4); }
         for (size_t i = 0; i < nin; ++i) memcpy(&ctx[off_uoff + 8 * i], &uoff[i], 8);
+        for (auto& gc : G.computed) {
+            long n = 1; for (int d : gc.domain) n *= dimv[(size_t)d];
+            ca_nel.push_back(n);
+            DeviceBuffer* b = new DeviceBuffer(); ca_buf.push_back(b);
+            const size_t es = f64_ ? 8 : 4;
+            if (b->alloc(es * (size_t)n * (size_t)gc.planes + 256)) { set_error("%s: out of device memory for a computed array (%d planes of %ld elements)", label.c_str(), gc.planes, n); return; }
+            for (int q = 0; q < gc.planes; ++q) { char* pl = (char*)b->ptr + es * (size_t)n * (size_t)q; memcpy(&ctx[off_cap + 8 * (size_t)(gc.plane0 + q)], &pl, 8); }
+        }
         long rows = 0;
         for (auto& r : P.residuals) { nel.push_back(elements(r)); jp_off.push_back(rows); if (r.mat_Jp) rows += nel.back() * (long)r.exprs.size(); }
         if (rows && jp.alloc(sizeof(float) * (size_t)rows + 256)) { set_error("%s: out of device memory for the materialized Jp", label.c_str()); return; }
@@ -309,7 +338,7 @@ public:
         }
         ok_ = true;
     }
-    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : jval) delete b; for (auto b : jcol) delete b; for (auto b : jdest) delete b; for (auto r : inc_runs_) delete r; }
+    ~GeneratedPlugin() override { if (mod) (void)hipModuleUnload(mod); for (auto b : ca_buf) delete b; for (auto b : jval) delete b; for (auto b : jcol) delete b; for (auto b : jdest) delete b; for (auto r : inc_runs_) delete r; }
     const char* schedule_name() const override
     {
         if (direct_) return "dense direct solve";
@@ -317,9 +346,14 @@ public:
         if (sparse_jtj_) return "sparse [[Jt][J]]p";
         bool all = !gather_.empty(), any = false;
         for (size_t i = 0; i < gather_.size(); ++i) { const bool g = gather_[i] || use_inc_[i]; all = all && g; any = any || g; }
-        return all ? "per residual, unknown-wise (gather)" : any ? "per residual, some unknown-wise (gather)" : "per residual";
+        const char* base = all ? "per residual, unknown-wise (gather)" : any ? "per residual, some unknown-wise (gather)" : "per residual";
+        if (G.computed.empty()) return base;
+        int planes = 0; for (auto& gc : G.computed) planes += gc.planes;
+        const_cast<GeneratedPlugin*>(this)->sched_ = std::string(base) + "; " + std::to_string(G.computed.size()) + " computed array(s) materialized (" + std::to_string(planes) + " planes, precompute per GN iteration)";
+        return sched_.c_str();
     }
-    int prepare(LaunchCtx&) override { sp_ready_ = false; inc_ready_ = false; use_inc_ = want_inc_; return 0; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
+    int prepare(LaunchCtx&) override { sp_ready_ = false; inc_ready_ = false; use_inc_ = want_inc_; ca_valid_ = false; return 0; }
+    void unknowns_changed() override { ca_valid_ = false; }      // constant inputs (masks, Sparse maps) may differ from the previous Init
 
     // symbolic phase of the sparse J^T J (the reference: cusparseXcsrgemmNnz, gauss_newton.t:1404-1412): the rows' unknown indices -> CSR pattern
     // + for every product v[i][a] * v[i][b] its position in the values
@@ -398,6 +432,11 @@ public:
             if (hipModuleGetFunction(&f, mod, k.name.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), k.name.c_str()); return -1; }
             fn.push_back(f);
         }
+        for (auto& gc : G.computed) {
+            hipFunction_t f = nullptr;
+            if (hipModuleGetFunction(&f, mod, gc.kernel.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), gc.kernel.c_str()); return -1; }
+            ca_fn.push_back(f);
+        }
         for (auto& ir : G.inc) {
             hipFunction_t f = nullptr;
             if (hipModuleGetFunction(&f, mod, ir.uidx.c_str()) != hipSuccess) { set_error("%s: generated kernel %s missing", label.c_str(), ir.uidx.c_str()); return -1; }
@@ -420,6 +459,8 @@ public:
     bool use_preconditioner() const override { return P.use_preconditioner; }
     int bind(void** p) override
     {
+        const std::vector<unsigned char> before = ctx;
+        struct Stale { GeneratedPlugin* g; const std::vector<unsigned char>& b; ~Stale() { if (g->ctx != b) g->ca_valid_ = false; } } stale{ this, before };      // (a pointer or a scalar parameter moved)
         bound.assign(P.inputs.size(), nullptr);
         for (size_t i = 0; i < P.inputs.size(); ++i) {
             const dsl::Input& in = P.inputs[i];
@@ -456,6 +497,7 @@ public:
     // ---- doublePrecision = 1: the same launches on double vectors (the unit was compiled with float = double), reference-shaped and unfused
     int cost64(LaunchCtx& c, double* out) override
     {
+        if (precompute(c) < 0) return -1;
         TimedLaunch t(c, "computeCost");
         const int cap = THALLO_HIP_MAX_PARTIALS / (int)P.residuals.size();
         int total = 0;
@@ -472,6 +514,7 @@ public:
     }
     int pcg_init64(LaunchCtx& c, Vectors64& v, double* aN) override
     {
+        if (precompute(c) < 0) return -1;
         TimedLaunch t(c, "PCGInit1");
         hipStream_t s = c.stream;
         const size_t bytes = (size_t)v.n_alloc * sizeof(double);
@@ -510,6 +553,7 @@ public:
 
     int cost(LaunchCtx& c, float* out) override
     {
+        if (precompute(c) < 0) return -1;
         TimedLaunch t(c, "computeCost");
         const int cap = THALLO_HIP_MAX_PARTIALS / (int)P.residuals.size();
         int total = 0;
@@ -526,6 +570,7 @@ public:
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
+        if (precompute(c) < 0) return -1;
         TimedLaunch t(c, "PCGInit1");
         hipStream_t s = c.stream;
         const size_t bytes = (size_t)v.n_alloc * sizeof(float);
@@ -652,7 +697,7 @@ extern "C" __global__ void k_wave64_kat(unsigned long long* ballot_max, unsigned
     wave_add(sums, (long)(t & 3), (float)t);
 }
 )KAT";
-    const std::string src = std::string("#include <hip/hip_runtime.h>\n#define NIN 1\n#define NDIM 1\n") + thallo::dsl::generated_prelude() + KAT;
+    const std::string src = std::string("#include <hip/hip_runtime.h>\n#define NIN 1\n#define NDIM 1\n#define NCAP 0\n") + thallo::dsl::generated_prelude() + KAT;
     hipModule_t mod = nullptr; hipFunction_t f = nullptr;
     if (thallo::rtc_build(src, false, "wave64 self-test", &mod)) return -1;
     int rc = -1;

@@ -232,6 +232,7 @@ const char* env_switch(const char* name)
         { "THALLO_LM_FOLD_STEP", "lm_fold_step" },              // 0: the LM step with PCGFinalizeDiagonal and the model cost as launches of their own where a plugin can fold them (round 6)
         { "THALLO_SFS_PAIR", "sfs_pair" },                      // 0: shape_from_shading's one-pixel-per-lane marching kernels on the float4 / float2 / byte planes instead of the pixel-pair kernels on packed planes (round 6)
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere
+        { "THALLO_FRONTEND_COMPUTED", "frontend_computed" },    // 0: computed arrays (expr:get) inlined at every access instead of materialized by a precompute kernel (rounds 1-5; A/B)
         { "THALLO_FRONTEND_PRELOAD", "frontend_preload" },      // 0: every residual instance of a generated merged gather kernel loads for itself (round 4's lowering)
         { "THALLO_INC_LANES", "inc_lanes" },                    // N (a power of two <= 64): lanes per owner in the generated index-map gather kernels (default: by list length and owner count)
         { "THALLO_PERSIST", "persist" },                        // 1: iterations 1 .. L-1 of a GN step of image_warping's marching kernel as persistent launches (bit-identical, measured slower)

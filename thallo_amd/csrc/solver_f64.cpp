@@ -111,6 +111,7 @@ int PlanF64::step(void** params)
 {   // gauss_newton.t:1545-1785, GN branch, one launch per reference kernel
     if (!ok_ || !ready_) return 0;
     if (plugin->bind(params)) { set_error("%s: parameter binding failed", plugin->name()); return 0; }
+    if (!use_lm_) plugin->unknowns_changed();      // (Gauss-Newton steps derive everything from the unknowns as they are now: solver.cpp Plan::step)
     if (sp.nIter >= sp.nIterations) { if (!finalized_) finalize(); return 0; }
     if (sp.lIterations < 0) { set_error("lIterations = %d is negative", sp.lIterations); if (!finalized_) finalize(); return 0; }
     hipStream_t s = ctx.stream;
@@ -147,6 +148,7 @@ int PlanF64::step(void** params)
             if ((nb = thallo_hip_f64_linear_update(p64->unknown_ptr64((int)k), v_.delta + off, imgs[k].n_floats, s)) < 0) return fail("PCGLinearUpdate", nb);
             off += imgs[k].n_floats;
         }
+        plugin->unknowns_written();          // (what the plugin derived from the unknowns -- materialized computed arrays -- is stale)
     }
     sp.nIter++;
     timer_.stop(ev_fin, s);
@@ -245,6 +247,7 @@ int PlanF64::step_lm(int ev_iter)
             if ((nb = thallo_hip_f64_linear_update(p64->unknown_ptr64((int)k), v_.delta + off, imgs[k].n_floats, s)) < 0) return fail("PCGLinearUpdate", nb);
             off += imgs[k].n_floats;
         }
+        plugin->unknowns_written();
     }
     double rep[2] = { 0.0, 0.0 };
     if (hipMemcpyAsync(&rep[0], word(T0), sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(&rep[1], word(T1), sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
@@ -271,6 +274,7 @@ int PlanF64::step_lm(int ev_iter)
             if (hipMemcpyAsync(p64->unknown_ptr64((int)k), prevX_ + off, (size_t)imgs[k].n_floats * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("revertUpdate", -1);
             off += imgs[k].n_floats;
         }
+        plugin->unknowns_written();
         radius_ = radius_ / decrease_factor_;
         decrease_factor_ = 2.0 * decrease_factor_;
         if (radius_ < (double)sp.min_trust_region_radius) { sp.trust_region_radius = 10e4f; stop = true; }

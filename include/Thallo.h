@@ -177,7 +177,8 @@ int ThalloX_FrontendTextDims(const char* filename, int what, const unsigned* dim
  * unobserved cameras), ALL points, the observations of its cameras with camera indices renumbered locally; row0 / row1 are not used.  The camera block
  * of J^T J p is complete on the rank; the point block is a partial sum and is all-reduced (`allreduce`, 3P floats per PCG iteration), after which
  * every rank updates the (replicated) points identically; the scalars: one all-gather of the ranks' camera sums + the point sums every rank
- * computes for itself.  Gauss-Newton.
+ * computes for itself.  Gauss-Newton and, after ThalloX_EnableLM, Levenberg-Marquardt (round 6: the element-wise LM kernels run on the camera block and
+ * the point block separately; accept / revert and the trust region are decided by every rank on identical scalars).
  * Everything else returns an error.
  * ------------------------------------------------------------------------------------------ */
 /* Every rank contributes `bytes_per_rank` bytes at `send` and receives world * bytes_per_rank at `recv`, rank order; DEVICE pointers;

@@ -153,6 +153,47 @@ def test_ba_camera_shards_match_single_domain_oracle(orc, world, dims):
         assert np.abs(pts - p[1]).max() <= 1e-3 * np.abs(p[1]).max()
 
 
+def _ba_lm_worker(rank, world, port, dims, nit, lit, kw, q):
+    from thallo_amd.distributed_ba import BaShardLayout
+    from ba_scipy_backend import BaShardMirror
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        C_, P_, O_ = dims
+        p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+        lay = BaShardLayout(C_, rank, world)
+        be = BaShardMirror(lay, lay.shard(p))
+        costs = be.lm_solve(nit, lit, **kw)
+        q.put((rank, costs, lay.c0, lay.c1, be.params[0][:lay.C_loc].copy(), be.params[1].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,nit,lit,kw", [(2, (12, 60, 300), 4, 25, {}), (3, (13, 80, 400), 6, 12, {"min_relative_decrease": 0.99}), (2, (13, 80, 400), 4, 40, {"q_tolerance": 0.02})])
+def test_ba_camera_shards_lm_match_single_domain_oracle(orc, world, dims, nit, lit, kw):
+    """Round 6: the LM schedule on camera shards (solver_dist.cpp step_lm_shard, restated by BaShardMirror.lm_solve over gloo) against the oracle's LM trajectory of the
+    whole problem: across a residual reset (25 / 40 > residual_reset_period), rejected steps and the zeta exit; every rank holds the same costs and bit-identical points."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ba_lm_worker, args=(r, world, port, dims, nit, lit, kw, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(q, procs, world)
+    C_, P_, O_ = dims
+    p = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+    co, _ = orc.Problem(orc.BUNDLE_ADJUST, dims, p).solve(nIterations=nit, lIterations=lit, use_lm=1, **kw)
+    res.sort(key=lambda t: t[0])
+    for rank, costs, c0, c1, cams, pts in res:
+        m = min(len(costs), len(co))
+        assert m >= 3 and np.abs(np.array(costs[:m]) - co[:m]).max() <= 3e-4 * np.abs(co).max(), (rank, costs, co)
+        assert costs == res[0][1]
+        assert np.array_equal(pts, res[0][5])
+    if "min_relative_decrease" in kw:
+        c = res[0][1]
+        assert any(c[i + 1] == c[i] for i in range(len(c) - 1)), c
+
+
 # ------------------------------------------------------------------ vertex-partitioned ARAP
 def _arap_worker(rank, world, port, nu, nv, nit, lit, q):
     from thallo_amd.distributed_graph import VertexPartition

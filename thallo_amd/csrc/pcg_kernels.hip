@@ -1137,7 +1137,7 @@ int thallo_hip_block_sums(const float* p, const float* Ap, const float* r, const
 int thallo_hip_shard_scalars(const float* gathered, long stride, int world, const float* aD_partials, const double* s3_partials, int count, thallo_sum_t alphaN,
                              float* alphaD_word, float* betaN_word, thallo_stream_t stream)
 {
-    if (!gathered || world < 1 || stride < 1 || !aD_partials || count < 1 || count > THALLO_MAX_PARTIALS || !alphaD_word) return -(int)hipErrorInvalidValue;
+    if (!gathered || world < 1 || stride < 1 || !aD_partials || count < 0 || count > THALLO_MAX_PARTIALS || !alphaD_word) return -(int)hipErrorInvalidValue;      // (count 0: the shared block contributes nothing -- a sum that is linear in the ranks' parts)
     const int only_first = betaN_word == nullptr;
     if (!only_first && (!s3_partials || alphaN.count < 1)) return -(int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_shard_scalars, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, stride, world, aD_partials, s3_partials, count, alphaN, only_first, alphaD_word, betaN_word);

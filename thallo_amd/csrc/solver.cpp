@@ -403,8 +403,8 @@ int Plan::step(void** params)
         else { if (!finalized_) finalize(); return 0; }
     }
     const int ev_iter = timer_.start("Nonlinear Iteration", ctx.stream);
-    if (dist_ && lm_ && (!dist_->flat || dist_->range)) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); if (!finalized_) finalize(); return 0; }
-    const int rc = lm_ ? step_lm(ev_iter) : dist_ ? step_gn_slab(ev_iter) : step_gn(ev_iter);
+    if (dist_ && lm_ && !dist_->shard && (!dist_->flat || dist_->range)) { set_error("distributed: %s runs Gauss-Newton only across ranks", plugin->name()); if (!finalized_) finalize(); return 0; }
+    const int rc = lm_ && dist_ && dist_->shard ? step_lm_shard(ev_iter) : lm_ ? step_lm(ev_iter) : dist_ ? step_gn_slab(ev_iter) : step_gn(ev_iter);
     if (rc == 1 && sp.max_solver_time_in_seconds > 0.0f && ev_total_ >= 0) {   // :1767-1779
         hipStream_t s = ctx.stream;
         hipEvent_t q = nullptr; hipEventCreate(&q); hipEventRecord(q, s); hipEventSynchronize(q);
@@ -1117,8 +1117,16 @@ int Plan::step_lm(int ev_iter)
     HIP_OK(hipStreamSynchronize(s));
     if (late_agree && (failed_before_cost_exchange || !std::isfinite(rep[5])) && !agree_all()) return 0;      // (a failed rank skipped its own cost launches: its rep[5] says nothing)
     { int frozen_at; memcpy(&frozen_at, &rep[2], sizeof(int)); unsigned fz; memcpy(&fz, &rep[1], sizeof(fz)); if (fz) k_done = frozen_at; }
+    return lm_accept_or_revert(rep[3], rep[4], rep[5], k_done, ev_fin, ev_iter);
+}
+
+// The end of an LM step (gauss_newton.t:1707-1753): step quality from the model cost change delta.b - 0.5 delta.(J^T J delta) and the new cost; accept (grow the trust region,
+// Ceres' rule) or revert the unknowns and shrink it.  Host logic on scalars that every rank of a multi-GPU run holds bit for bit, so the ranks decide alike.
+int Plan::lm_accept_or_revert(float dJJd, float db, float newCost, int k_done, int ev_fin, int ev_iter)
+{
+    hipStream_t s = ctx.stream;
+    const auto& imgs = plugin->unknown_images();
     last_l_iters = k_done;
-    const float dJJd = rep[3], db = rep[4], newCost = rep[5];
     const float model_cost_change = db - 0.5f * dJJd;
     const float cost_change = prev_cost_ - newCost;
     const float relative_decrease = cost_change / model_cost_change;

@@ -74,6 +74,7 @@ struct DistState {
     bool shard = false;
     long sh_off = 0, sh_len = 0;
     DeviceBuffer sh_aD, sh_s3;                           // the shared block's partials of an iteration
+    DeviceBuffer sh_lm;                                  // ... of the second sum of an LM exchange (q next to betaN, delta.b next to delta.J^T J delta)
     thallo_xreduce_t xa;                                 // device-side all-reduce of the shared block (thallo_hip_dist_allreduce): inbox geometry
     // device-side exchange
     bool want_p2p = false, mapped = false, p2p_on = false, checked = false;
@@ -182,6 +183,8 @@ private:
     float compute_cost();
     int   step_gn(int ev_iter);
     int   step_lm(int ev_iter);
+    int   lm_accept_or_revert(float dJJd, float db, float newCost, int k_done, int ev_fin, int ev_iter);      // the end of an LM step: accept / revert, trust region (shared by step_lm and the shard form)
+    int   step_lm_shard(int ev_iter);                   // solver_dist.cpp: LM on residual shards (bundle adjustment's camera shards)
     int   ensure_lm_vectors();
     float read_sum(int j);
     float radius_ = 1e4f, decrease_factor_ = 2.0f;

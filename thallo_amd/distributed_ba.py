@@ -8,6 +8,9 @@ Rank k owns a contiguous range of cameras and every observation (row pair of J) 
   * after that every rank holds identical point blocks of Ap, r, p, delta and updates them redundantly, so the point unknowns never need a broadcast;
   * the scalars: the ranks' camera parts of [alphaD | N, S1, S2] in one tiny all-gather (added in rank order) + the point parts every rank computes
     for itself after the all-reduce;
+  * round 6, lm=True: the Levenberg-Marquardt branch on the same layout (solver_dist.cpp step_lm_shard): the element-wise LM kernels run on the camera block and the
+    point block separately, the camera sums travel in the tiny all-gather, the point sums are added by every rank for itself; accept / revert and the trust region are
+    replicated host logic on identical scalars;
   * round 3, device_exchange=True: the all-reduce is ONE launch of peer stores (thallo_hip_dist_allreduce: reduce-scatter into the chunk owners' inboxes, sums in
     rank order, all-gather into every rank's second inbox) after a self-check at Init -- no ncclAllReduce in the PCG loop; distributed_info() says which.
 The kernels are the single-GPU ones run on the local sub-instance [cameras of this rank (padded to a multiple of 4) | all points].  This module is
@@ -48,14 +51,16 @@ class BaShardLayout:
 
 
 class PlanBaShardSolver:
-    def __init__(self, params_global, rank, world, l_iters, group=None, device_exchange=True):
+    def __init__(self, params_global, rank, world, l_iters, group=None, device_exchange=True, lm=False):
         self.lay = lay = BaShardLayout(params_global[0].shape[0], rank, world)
         local = lay.shard(params_global)
         dev = torch.device("cuda", torch.cuda.current_device())
         self.tensors = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in local]
         self.cameras, self.points = self.tensors[0], self.tensors[1]
         dims = (lay.C_pad, local[1].shape[0], local[2].shape[0])
-        self.solver = api.ThalloSolver(dims, api.energy_file("bundle_adjustment"), timing_level=0)
+        self.solver = api.ThalloSolver(dims, api.energy_file("bundle_adjustment"), timing_level=0, **({"solverkind": "levenberg_marquardt"} if lm else {}))
+        if lm:          # round 6: the LM branch on camera shards (csrc/solver_dist.cpp step_lm_shard): the reference's example runs this energy as LM 5 x 150
+            self.solver.enable_lm()
         self.solver.set_solver_parameters(nIterations=1 << 30, lIterations=l_iters)
         self.library_rccl = library_rccl(self.solver, rank, world, group)      # ranks on GPUs of their own: all-gather and all-reduce run inside the library (no callback)
         ag = torch_allgather(group, dev) if world > 1 and not self.library_rccl else None

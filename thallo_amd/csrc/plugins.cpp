@@ -296,7 +296,7 @@ public:
                                        v.z, v.p[cur], v.p[cur ^ 1], v.delta, v.Ap, first ? 1 : 0, aN, aD, bN, none, none, (const int*)irregular.ptr, v.r, out, c.stream);
     }
     bool batches_delta() const override { return true; }
-    bool takes_any_p_plane() const override { return march_ && row0_ == 0 && row1_ == H; }
+    bool takes_any_p_plane() const override { return march_; }      // (whole images and -- round 6 -- row slabs: the marching kernels keep the ghost rows of whatever plane they write current)
     bool persist_ok() const override { return persist_; }
 #ifdef THALLO_RESEARCH
     int pcg_persist(LaunchCtx& c, SolverVectors& v, float* const* planes, int n_planes, int k0, int k1, float* parts, int slots, int B, int nb_prev, thallo_sum_t alphaN_prev) override

@@ -679,9 +679,13 @@ bool Plan::aux_stream()
 // a device-wide synchronisation, illegal under stream capture, and was retried at every step of a memory-limited plan).
 // Footprint: (planes - 2) x one solver vector; by default at most 33 planes, a quarter of the free device memory and 32 GiB (2048^2 image_warping: 31 x 50.3 MB = 1.56 GB;
 // 16384 x 8192: 20 planes of 1.6 GB).  THALLO_DELTA_PLANES=N asks for exactly N (no memory test); planes are released with the plan.
+bool Plan::ring_possible() const
+{   // one GPU, or (round 6) one rank's row slab of the one-kernel schedule: launch k writes p_k into whichever plane it is handed (the ghost rows are kept current there too)
+    return plugin->takes_any_p_plane() && (!dist_ || (!dist_->flat && !dist_->range && !dist_->shard && !dist_->part));
+}
 void Plan::ring_prepare(int L)
 {
-    if (!plugin->takes_any_p_plane() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3 || dist_) return;
+    if (!ring_possible() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3) return;
     int want = delta_planes_ >= 2 ? delta_planes_ : delta_planes_ <= -2 ? -delta_planes_ : THALLO_HIP_MAX_UPDATE_TERMS + 1;
     if (want > L) want = L;                 // (L planes: delta is never touched inside the loop)
     if (ring_.size() < 2) { ring_.clear(); ring_.push_back(v_.p[1]); ring_.push_back(v_.p[0]); }
@@ -702,7 +706,7 @@ void Plan::ring_prepare(int L)
 }
 int Plan::ring_planes(int L)
 {
-    if (!plugin->takes_any_p_plane() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3 || dist_) return 0;
+    if (!ring_possible() || delta_planes_ == 0 || delta_planes_ == 1 || L < 3) return 0;
     int want = delta_planes_ >= 2 ? delta_planes_ : delta_planes_ <= -2 ? -delta_planes_ : THALLO_HIP_MAX_UPDATE_TERMS + 1;
     if (want > L) want = L;
     if (L != ring_L_) { ring_prepare(L); ring_L_ = L; }      // (lIterations changed since Init: once per change)

@@ -154,6 +154,7 @@ private:
     bool fin_in_kernel_ = true, one_kernel_ = true, batch_delta_ = true, lm_fold_p_ = true, lm_fold_step_ = true;   // A/B switches: read_ab_switches()
     int delta_planes_ = -1;         // THALLO_DELTA_PLANES (-1: unset)
     std::vector<float*> ring_;      // the ring of p planes of the one-kernel GN loop (ring_planes)
+    bool ring_possible() const;     // the plugin's iteration takes any p plane, on one GPU or on a row slab of the one-kernel schedule
     int  ring_planes(int L);        // how many planes the loop of L iterations runs on (allocates nothing unless lIterations changed since Init)
     void ring_prepare(int L);       // allocates the ring's planes: at Init, and once per change of lIterations; a memory-limited attempt is cached (ring_tried_)
     int  ring_tried_ = 0, ring_L_ = -1;

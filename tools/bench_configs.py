@@ -63,6 +63,7 @@ if want("arap"):
 if want("shape_from_shading") or only == "sfs":
     out.append(run("shape_from_shading 2048x2048 GN x10", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 6, 10))
     out.append(run("shape_from_shading 2048x2048 LM x10 (BASELINE config 4's solver)", "shape_from_shading", (2048, 2048), syn.shape_from_shading(2048, 2048), 5, 10, lm=True))
+if only == "sfs640":      # (not in the default set: tools/profile_configs.sh averages per kernel NAME, so every profiled configuration of an energy has one size)
     out.append(run("shape_from_shading 640x480 GN x10 (the size of the reference's data set)", "shape_from_shading", (640, 480), syn.shape_from_shading(640, 480), 12, 10))
     out.append(run("shape_from_shading 640x480 LM x10", "shape_from_shading", (640, 480), syn.shape_from_shading(640, 480), 10, 10, lm=True))
 if want("bundle_adjustment") or only == "ba":

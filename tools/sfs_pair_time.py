@@ -148,7 +148,7 @@ def main(W, H):
                 for wgcu in (1, 2, 3):
                     set_tune(0, wgcu, depth)
                     print("  pair GN iteration (ring), depth %d, grid for %d workgroups / CU: %.2f us; LM iteration %.2f us" % (depth, wgcu, timed(gn_iter), timed(lm_iter)), flush=True)
-            for rows in (6, 8, 12, 16, 24, 32, 48, 64):
+            for rows in (2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
                 for depth in ((3, 6) if os.environ.get("SP_DEPTH6") else (3,)):
                     set_tune(rows, 0, depth)
                     try:

@@ -16,7 +16,16 @@ if os.path.exists(os.path.join(g, "secondary_configs.json")):
 # kernel-name fragment -> (label, algorithmic bytes per launch at the profiled size or None)
 NPX = 2048 * 2048
 O_BA = 678718
-KEYS = [("k_march<true, false, false, false, 2, false, true>", "shape_from_shading one-kernel GN iteration: PCGUpdate + applyJTJ + three sums (marching kernel, 2048^2; 57 B/pixel)", 57 * NPX),
+KEYS = [# round 6: shape_from_shading on pixel pairs and packed planes (energy_sfs_pair.hip; template arguments SUMS, CTC, INIT, DIAG, OCC, PUPD, UPD, LMQ, FIN, MODEL, DEPTH)
+        ("k_pmarch<true, false, false, false, 2, false, true, false, false, false", "shape_from_shading one-kernel GN iteration on pixel pairs: PCGUpdate + applyJTJ + three sums, p_k into the ring (2048^2; 40 B/pixel: Gx Gy Gz 12, flags+masks 4, r Ap p read 12 + written 12)", 40 * NPX),
+        ("k_pmarch<true, true, false, false, 2, false, true, true", "shape_from_shading one-kernel LM iteration on pixel pairs (2048^2; 60 B/pixel: + delta read and written 8, CtC b M^-1 12)", 60 * NPX),
+        ("k_pmarch<false, true, true, false", "shape_from_shading PCGInit1 J^T F on pixel pairs (2048^2; 44 B/pixel: Gx Gy Gz BI 16, flags+masks 4, X D 8 in; r z p delta 16 out)", 44 * NPX),
+        ("k_pmarch<false, true, true, true, 2, false, false, false, true", "shape_from_shading PCGInit1 + PCGFinalizeDiagonal in one launch (LM; 2048^2; 56 B/pixel: 28 in; r z p delta CtC M^-1 b 28 out; SSq written at the first step only)", 56 * NPX),
+        ("k_pmarch<false, false, false, false, 2, false, false, false, false, true", "shape_from_shading LM model cost in one launch: owed delta update + J^T J delta + two dots + savePreviousUnknowns + PCGLinearUpdate (2048^2; 44 B/pixel)", 44 * NPX),
+        ("k_pmarch<false, false, false, false, 2, false, false, false, false, false", "shape_from_shading applyJTJ on pixel pairs (2048^2; 24 B/pixel)", 24 * NPX),
+        ("k_pprecompute<false>", "shape_from_shading precompute, closed-form partials, packed planes (2048^2; 34 B/pixel: X D I 12 + masks 2 in; Gx Gy Gz BI 16 + flags/masks 4 out)", 34 * NPX),
+        ("k_pprecompute<true>", "shape_from_shading precompute + computeCost in one launch (2048^2; 34 B/pixel)", 34 * NPX),
+        ("k_march<true, false, false, false, 2, false, true>", "shape_from_shading one-kernel GN iteration: PCGUpdate + applyJTJ + three sums (marching kernel, 2048^2; 57 B/pixel)", 57 * NPX),
         ("k_march<false, true, false, false, 2, true, false>", "shape_from_shading LM: PCGStep3 + (J^T J + CtC) p (marching kernel, 2048^2; 45 B/pixel)", 45 * NPX),
         ("k_march<true, false, false, false, 2, false, false>", "shape_from_shading applyJTJ + three sums (marching kernel, 2048^2; 37 B/pixel)", 37 * NPX),
         ("k_march<false, true, false, false, 2, false, false>", "shape_from_shading (J^T J + CtC) p (marching kernel, LM, 2048^2; 37 B/pixel)", 37 * NPX),

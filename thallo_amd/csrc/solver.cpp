@@ -229,6 +229,7 @@ const char* env_switch(const char* name)
         { "THALLO_LM_FOLD_P", "lm_fold_p" },                    // 0: the reference-shaped LM loop: PCGStep3 / PCGStep2 / the zeta test as launches of their own
         { "THALLO_SFS_FUSED", "sfs_fused" },                    // 0: shape_from_shading's two-pass applyJTJ (round 1)
         { "THALLO_SFS_MARCH", "sfs_march" },                    // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
+        { "THALLO_BA_RENUMBER", "ba_renumber" },                // bundle adjustment's plan-side point order: 0 never, 1 always (default: when the caller's order is far from "by first observing camera"; round 6)
         { "THALLO_LM_FOLD_STEP", "lm_fold_step" },              // 0: the LM step with PCGFinalizeDiagonal and the model cost as launches of their own where a plugin can fold them (round 6)
         { "THALLO_SFS_PAIR", "sfs_pair" },                      // 0: shape_from_shading's one-pixel-per-lane marching kernels on the float4 / float2 / byte planes instead of the pixel-pair kernels on packed planes (round 6)
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere

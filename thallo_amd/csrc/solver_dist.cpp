@@ -141,6 +141,7 @@ int Plan::set_distributed_impl(const ThalloX_Distributed& cfg)
         hipDeviceSynchronize();
         DistState* Dp = new DistState(); DistState& D = *Dp; dist_ = Dp;
         D.cfg = cfg; D.shard = true; D.range = true;            // (range: linear updates and the like cover the whole local vector)
+        plugin->forbid_renumbering();                            // (the replicated point block keeps the caller's order on every rank)
         D.sh_off = off; D.sh_len = len;
         if (D.send.alloc(64 * sizeof(float)) || D.gath.alloc(64 * sizeof(float) * cfg.world)) { set_error("distributed: out of device memory for the message buffers"); return -1; }   // (rank-local: nothing to agree through yet)
         bool mem = !(ensure_sums_buffer() || D.sh_aD.alloc(THALLO_HIP_MAX_PARTIALS * sizeof(float)) || D.sh_s3.alloc((size_t)3 * THALLO_HIP_MAX_PARTIALS * sizeof(double)));

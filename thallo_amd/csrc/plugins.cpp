@@ -839,8 +839,12 @@ public:
         for (int c = 0; c < C; ++c) cp[c + 1] += cp[c];
         for (int j = 0; j < P; ++j) pp[j + 1] += pp[j];
         std::vector<int> cc(cp.begin(), cp.end() - 1), pc(pp.begin(), pp.end() - 1);
-        for (int o = 0; o < O; ++o) { const int q = cc[oc[o]]++; pos[o] = q; cobs[q] = o; qc[q] = oc[o]; qp[q] = op[o]; }
-        for (int o = 0; o < O; ++o) ppos[pc[op[o]]++] = pos[o];
+        for (int o = 0; o < O; ++o) cobs[cc[oc[o]]++] = o;
+        if (perm_)          // a renumbered plan also walks each camera's observations in the order of the (internal) point ids: its gathers then run through ptsP front to back
+            for (int c = 0; c < C; ++c) std::sort(cobs.begin() + cp[c], cobs.begin() + cp[c + 1], [&](int a, int b) { return op[a] != op[b] ? op[a] < op[b] : a < b; });
+        for (int q = 0; q < O; ++q) { const int o = cobs[q]; pos[o] = q; qc[q] = oc[o]; qp[q] = op[o]; }
+        if (perm_) { for (int q = 0; q < O; ++q) ppos[pc[qp[q]]++] = q; }          // ... and each point's observations in camera order
+        else for (int o = 0; o < O; ++o) ppos[pc[op[o]]++] = pos[o];
         auto up = [&](DeviceBuffer& b, const std::vector<int>& h) {
             if (b.alloc(sizeof(int) * (h.size() + 4))) return -1;
             return hipMemcpy(b.ptr, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;

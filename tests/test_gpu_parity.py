@@ -1730,7 +1730,7 @@ def test_shape_from_shading_marching_and_tile_solves_agree(torch, tmp_path, lm):
 
 @pytest.mark.parametrize("lm", [0, 1])
 @pytest.mark.parametrize("W,H,nit,lit", [(130, 67, 4, 10), (256, 192, 3, 10), (640, 480, 3, 10), (2, 2, 2, 3), (126, 9, 3, 5), (1024, 1024, 2, 10)])
-def test_shape_from_shading_pixel_pair_kernels_match_the_one_pixel_kernels(torch, orc, W, H, nit, lit, lm):
+def test_shape_from_shading_pixel_pair_kernels_match_the_one_pixel_kernels(torch, orc, monkeypatch, W, H, nit, lit, lm):
     """Round 6: images of even width run the marching kernels on PIXEL PAIRS (energy_sfs_pair.hip: packed register pairs, 8-byte loads, 124 output pixels per wave row) on the PACKED
     planes -- Gx | Gy | Gz | BI planar, flags and the two edge-mask bytes in one dword per pixel, 40 instead of 49 bytes per pixel and GN iteration -- written by the closed-form
     precompute.  Against the one-pixel-per-lane kernels on the float4 / float2 / byte planes (thallo_hip_sfs_march_debug_set(6, 0)): whole Gauss-Newton and LM solves agree to
@@ -1739,6 +1739,7 @@ def test_shape_from_shading_pixel_pair_kernels_match_the_one_pixel_kernels(torch
     p = syn.shape_from_shading(W, H)
     lib = thallo_amd.lib()
     runs = []
+    monkeypatch.setenv("THALLO_RESIDENT", "0")      # (one launch per PCG iteration on both sides: the launch census is compared)
     try:
         for pair in (1, 0):
             lib.thallo_hip_sfs_march_debug_set(6, pair)
@@ -1772,6 +1773,50 @@ def test_shape_from_shading_pixel_pair_kernels_match_the_one_pixel_kernels(torch
         co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=nit, lIterations=lit, use_lm=lm)
         m = min(len(co), len(c1))
         assert (np.abs(c1[:m] - co[:m]) <= (2e-4 if lm else 2e-5) * np.abs(co[:m]) + 1e-9).all(), (c1, co)
+
+
+@pytest.mark.parametrize("W,H,nit,lit", [(640, 480, 3, 10), (130, 67, 3, 10), (256, 192, 3, 12), (126, 9, 3, 5), (2, 2, 2, 3), (250, 130, 2, 7), (1024, 160, 2, 9), (372, 35, 3, 6)])
+def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(torch, orc, monkeypatch, W, H, nit, lit):
+    """Round 6: the whole PCG loop of a Gauss-Newton step of shape_from_shading in ONE launch (energy_sfs_resident.hip) -- r, p, A p, delta and the
+    precomputed planes of a wave's rows in registers, per iteration the first / last TWO rows of A p to the waves above / below, lane 1's / 62's pixels to the strips beside
+    (corner pixels of the halo rows from the diagonal neighbours' records) and the workgroup's sums to every workgroup as tagged granules; no launch boundary, no grid barrier.
+    Geometry, row step and summation order are the marching pair kernel's: with the same rows per wave every alpha_k / beta_k, the costs and the unknowns are BIT-identical to
+    one launch per iteration.  Sizes: the reference's data set, ragged strips, short last segments (67 = 16 x 4 + 3, 35), one strip, 2 x 2, three strips, a wide flat image."""
+    L = thallo_amd.lib()
+    L.thallo_hip_sfs_resident_rows.restype = C.c_int
+    R = L.thallo_hip_sfs_resident_rows(W, H)
+    assert 2 <= R <= 8, R
+    p = syn.shape_from_shading(W, H)
+    runs = []
+    for resident in (True, False):
+        monkeypatch.setenv("THALLO_RESIDENT", "1" if resident else "0")
+        monkeypatch.setenv("THALLO_DELTA_PLANES", "0")        # (delta inside the iteration's launch, as the resident loop forms it: one fma per iteration and element)
+        L.thallo_hip_sfs_march_debug_set(0, R)               # (both runs: PCGInit1's sums are taken in the marching geometry too)
+        try:
+            dev = to_device(copy_params(p))
+            s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"))
+            s.set_solver_parameters(nIterations=nit, lIterations=lit)
+            params = s.make_params(dev)
+            s.init(params)
+            costs, traces = [s.current_cost()], []
+            while s.step(params):
+                costs.append(s.current_cost()); traces.append(s.alpha_beta_trace())
+            names = s.kernel_stats()
+            assert api.last_error() in ("", None), api.last_error()
+            s.close()
+        finally:
+            L.thallo_hip_sfs_march_debug_set(0, 0)
+        runs.append((costs, traces, dev[16].clone(), names))
+    (c0, t0, x0, n0), (c1, t1, x1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) == nit + 1 and len(t0[0]) == lit
+    assert n0.get("PCGLoopResident", {}).get("launches") == nit and "PCGIteration" not in n0, n0
+    assert n1.get("PCGIteration", {}).get("launches") == nit * lit and "PCGLoopResident" not in n1, n1
+    assert t0 == t1, [(i, k, u, v) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(x0, x1)
+    if W * H <= 70000:
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=nit, lIterations=lit)
+        assert (np.abs(np.array(c0) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (c0, co)
 
 
 def test_shape_from_shading_lm_step_folds(torch, monkeypatch):

@@ -1072,6 +1072,31 @@ public:
         return thallo_hip_sfs_apply_jtj_lm_pupdate(W, H, row0_, row1_, yoff_, Hg_, hp, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, z, p_in, p_out, c.lm_ctc, Ap, out,
                                                    first ? 1 : 0, aN, bN, c.gate, c.stream);
     }
+    // GN on one GPU, small images (the reference's 640 x 480): the whole PCG loop of a step in ONE launch, state in registers (energy_sfs_resident.hip; round 6).
+    // THALLO_RESIDENT=0: one launch per PCG iteration (A/B)
+    DeviceBuffer xres_; bool resident_ = false, resident_broken_ = false;
+    int prepare(LaunchCtx& c) override
+    {
+        resident_ = false;
+        const char* er = env_switch("THALLO_RESIDENT");
+        if (packed() && !(er && er[0] == '0') && !resident_broken_ && thallo_hip_sfs_resident_rows(W, H) > 0) {
+            const long need = thallo_hip_sfs_resident_bytes(W, H);
+            if (need > 0 && (long)xres_.bytes < need) {
+                if (xres_.alloc((size_t)need) || hipMemsetAsync(xres_.ptr, 0, (size_t)need, c.stream) != hipSuccess) { set_error("shape_from_shading: out of device memory for the resident kernel's exchange buffers"); return -1; }
+            }
+            resident_ = need > 0;
+        }
+        return 0;
+    }
+    bool resident_ok() const override { return resident_ && packed(); }
+    int pcg_resident(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words) override
+    {
+        TimedLaunch t(c, "PCGLoopResident");
+        return thallo_hip_sfs_pcg_resident(W, H, yoff_, hp, (const float*)G.ptr, (const float*)Wt.ptr, v.rbuf(0), v.p[0], v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words,
+                                           xres_.ptr, L, c.stream);
+    }
+    int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_sfs_resident_status(xres_.ptr, clear, -1, pm, c.stream) : 0; }
+    void resident_disable() override { resident_ = false; resident_broken_ = true; }
     // GN on one GPU: one launch per PCG iteration (the marching kernel with PCGUpdate riding along; r, Ap, p ping-pong).  Across ranks: the flat form.
     bool one_kernel_iteration() const override { return thallo_hip_sfs_march_fits(W) != 0 && row0_ == 0 && row1_ == H; }
     bool takes_any_p_plane() const override { return one_kernel_iteration(); }          // round 5: p_k into a ring of planes, delta from the ring (solver.cpp ring_planes)

@@ -1,0 +1,91 @@
+"""sfs_resident_probe.py -- shape_from_shading's resident PCG loop against one launch per iteration with the same rows per wave: where do the unknowns differ?
+    python tools/sfs_resident_probe.py [W H nit lit]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import thallo_amd
+from thallo_amd import api, synthetic as syn
+from helpers import copy_params, to_device, to_host
+W, H, nit, lit = [int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (640, 480, 3, 10))]
+L = thallo_amd.lib(); L.thallo_hip_sfs_resident_rows.restype = C.c_int
+R = L.thallo_hip_sfs_resident_rows(W, H); print("R", R)
+p = syn.shape_from_shading(W, H)
+os.environ["THALLO_DELTA_PLANES"] = "0"
+def run(resident, n):
+    os.environ["THALLO_RESIDENT"] = "1" if resident else "0"
+    L.thallo_hip_sfs_march_debug_set(0, R)
+    dev = to_device(copy_params(p))
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"))
+    s.set_solver_parameters(nIterations=n, lIterations=lit)
+    prm = s.make_params(dev); s.init(prm)
+    tr = []
+    while s.step(prm): tr.append(s.alpha_beta_trace())
+    c = s.current_cost(); s.close()
+    L.thallo_hip_sfs_march_debug_set(0, 0)
+    return to_host(dev[16]).copy(), tr, c
+for n in (range(1, nit + 1) if not (len(sys.argv) > 5 and sys.argv[5] == "kernel") else []):
+    for rep in range(2):
+        xa, ta, ca = run(True, n); xb, tb, cb = run(False, n)
+        d = np.argwhere(xa != xb)
+        print("steps", n, "rep", rep, "cost", ca, cb, "differing pixels", len(d), "first", d[:6].tolist(), "trace equal", ta == tb,
+              "max rel", float(np.abs(xa - xb).max() / np.abs(xb).max()))
+        if len(d):
+            ys = np.unique(d[:, 0]); xs = np.unique(d[:, 1])
+            print("   rows", ys[:20].tolist(), "... cols", xs[:20].tolist(), "rows mod R", np.unique(ys % R).tolist())
+
+
+def kernel_level(state_steps=2):
+    """One iteration at kernel level from the solver's state after `state_steps` GN steps: resident L = 1 against thallo_hip_sfs_pcg_iter(first) on the same planes."""
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    class FinT(C.Structure): _fields_ = [("alphaN", api.SumT), ("tickets", C.c_void_p), ("aD", C.c_void_p), ("bN", C.c_void_p)]
+    x2, _, _ = run(False, state_steps) if state_steps else (p[16], None, None)
+    N = W * H
+    hp = (C.c_float * 16)(*[float(v) for v in p[:16]])
+    X = torch.from_numpy(np.ascontiguousarray(x2)).cuda()
+    D, Im, mR, mC = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in p[17:21]]
+    Gp = torch.zeros(4 * N, device="cuda"); Fw = torch.zeros(2 * N, device="cuda"); flx = torch.zeros(N + 4, dtype=torch.uint8, device="cuda")
+    L.thallo_hip_sfs_march_debug_set(6, 1)
+    assert L.thallo_hip_sfs_precompute(W, H, 0, H, 0, H, hp, vp(X), vp(D), vp(Im), vp(mR), vp(mC), vp(Gp), vp(Fw), vp(flx), None) == 0
+    f = lambda: torch.zeros(N + 64, device="cuda")
+    r0, z0, pp0, d0 = f(), f(), f(), f(); aN0 = torch.zeros(1024, device="cuda")
+    nb = L.thallo_hip_sfs_pcg_init(W, H, 0, H, 0, H, hp, vp(X), vp(D), vp(Gp), vp(Fw), vp(flx), None, None, vp(r0), vp(z0), vp(pp0), vp(d0), None, vp(aN0), None)
+    assert nb > 0, nb
+    # marching, first iteration, rows per wave = R
+    L.thallo_hip_sfs_march_debug_set(0, R)
+    r1, A1, p1 = f(), f(), f(); aD = torch.zeros(1024, device="cuda"); s3 = torch.zeros(3 * 1024, dtype=torch.float64, device="cuda")
+    S = lambda t, n: api.SumT(t.data_ptr(), n)
+    L.thallo_hip_sfs_pcg_iter.argtypes = [C.c_int] * 6 + [C.c_void_p] * 11 + [C.c_int, api.SumT, api.SumT, api.SumT, C.c_void_p, C.c_void_p, FinT, C.c_void_p]
+    fin = FinT(S(aN0, nb), None, None, None)
+    nbm = L.thallo_hip_sfs_pcg_iter(W, H, 0, H, 0, H, hp, vp(Gp), vp(Fw), vp(flx), vp(r0), vp(r1), vp(A1), vp(A1), vp(pp0), vp(p1), vp(d0), 1, S(aN0, nb), S(aN0, nb), S(aN0, nb), vp(aD), vp(s3), fin, None)
+    L.thallo_hip_sfs_march_debug_set(0, 0)
+    assert nbm > 0, nbm
+    torch.cuda.synchronize()
+    # resident, L = 1
+    L.thallo_hip_sfs_resident_bytes.restype = C.c_long
+    xb = torch.zeros(L.thallo_hip_sfs_resident_bytes(W, H) // 4 + 16, dtype=torch.int32, device="cuda")
+    r2, A2, p2, d2 = r0.clone(), f(), f(), f(); words = torch.zeros(64, device="cuda")
+    L.thallo_hip_sfs_pcg_resident.argtypes = [C.c_int] * 3 + [C.c_void_p] * 9 + [api.SumT, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    nbr = L.thallo_hip_sfs_pcg_resident(W, H, 0, hp, vp(Gp), vp(Fw), vp(r2), vp(pp0), vp(r2), vp(A2), vp(p2), vp(d2), S(aN0, nb), vp(words), vp(xb), 1, None)
+    assert nbr > 0, nbr
+    torch.cuda.synchronize()
+    print("workgroups", nbm, nbr, "p equal", bool(torch.equal(p1[:N], p2[:N])), "r equal", bool(torch.equal(r1[:N], r2[:N])))
+    dA = torch.nonzero(A1[:N] != A2[:N]).flatten().cpu().numpy()
+    print("A p differs at", len(dA), "pixels", [(int(i) // W, int(i) % W, float(A1[i]), float(A2[i])) for i in dA[:12]])
+    if len(dA):
+        ys, xs = dA // W, dA % W
+        print("  rows mod R", np.unique(ys % R).tolist(), "cols mod 124", np.unique(xs % 124).tolist()[:40])
+    rec = xb.view(torch.int64)[32:32 + 1024 * 8].view(1024, 8).cpu().numpy()
+    ad_r = (rec[:nbr, 0] & 0xffffffff).astype(np.uint32).view(np.float32)
+    hi_lo = lambda a, b: ((rec[:nbr, a] & 0xffffffff).astype(np.uint64) << np.uint64(32) | (rec[:nbr, b] & 0xffffffff).astype(np.uint64)).view(np.float64)
+    s3h = s3[:3 * nbm].cpu().numpy().reshape(-1, 3)
+    print("per-workgroup alphaD partials equal", bool((ad_r == aD[:nbm].cpu().numpy()).all()), "N / S1 / S2 equal", bool((hi_lo(1, 2) == s3h[:, 0]).all()), bool((hi_lo(3, 4) == s3h[:, 1]).all()), bool((hi_lo(5, 6) == s3h[:, 2]).all()))
+    bad = np.nonzero(ad_r != aD[:nbm].cpu().numpy())[0]; print("  differing slots", bad[:10].tolist(), [(float(ad_r[i]), float(aD[i])) for i in bad[:4]])
+    wm = torch.zeros(8, device="cuda")
+    L.thallo_hip_pcg_scalars_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, api.SumT, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.thallo_hip_pcg_scalars_finish(vp(aD), vp(s3), nbm, S(aN0, nb), vp(wm), vp(wm[1:]), None) >= 0
+    torch.cuda.synchronize(); print("marching words (scalars_finish)", float(wm[0]), float(wm[1]))
+    ad_m = aD[:nbm].cpu().numpy(); print("alphaD marching (lane-strided float sum)", float(ad_m.sum()), "resident word", float(words[0]), "betaN", float(words[1]))
+
+
+if len(sys.argv) > 5 and sys.argv[5] == "kernel":
+    kernel_level(int(sys.argv[6]) if len(sys.argv) > 6 else 2)

@@ -598,7 +598,8 @@ int thallo_hip_sfs_planes_layout(int W, int H);
 /* Round 6 -- the whole PCG loop of a Gauss-Newton step in ONE launch for images whose solver state fits the chip's registers (the reference's 640 x 480 data set; packed
  * planes, whole image on one GPU; csrc/energy_sfs_resident.hip): L iterations from what thallo_hip_sfs_pcg_init left (r_0 in r_in, zeros in p_in and delta, alphaN_0), leaving
  * what L launches of thallo_hip_sfs_pcg_iter_deferred leave -- r_{L-1}, A p_{L-1}, p_{L-1} in the *_out planes (which may be the *_in planes), delta without its last term,
- * words[2k] = alphaD_k, words[2k + 1] = betaN_k -- bit for bit when both run with the same rows per wave.  thallo_hip_sfs_resident_rows: rows per wave segment, 0 = the shape
+ * words[2k] = alphaD_k, words[2k + 1] = betaN_k -- bit for bit when both run with the same rows per wave; with X != NULL PCGLinearUpdate rides along (X += delta + alpha_{L-1} p_{L-1},
+ * thallo_hip_linear_update's bits; gauss_newton.t:901-906).  thallo_hip_sfs_resident_rows: rows per wave segment, 0 = the shape
  * does not fit (the caller runs one launch per PCG iteration).  xbuf: thallo_hip_sfs_resident_bytes() bytes, zeroed once by the caller, private to the plan.  Returns the number of
  * workgroups, -hipErrorNotSupported when the shape does not fit.  thallo_hip_sfs_resident_status: 1 = a bounded wait inside the kernel ran out (the steps since the last
  * check are void; pm: 5 words of post-mortem, may be NULL); clear != 0 resets; spin_ms >= 0 sets the bound (0 = the 2 s default); synchronises the stream.
@@ -607,7 +608,7 @@ int thallo_hip_sfs_resident_rows(int W, int H);
 long thallo_hip_sfs_resident_bytes(int W, int H);
 int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,
                                 const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
-                                thallo_sum_t alphaN0, float* words, void* xbuf, int L, thallo_stream_t stream);
+                                thallo_sum_t alphaN0, float* words, float* X, void* xbuf, int L, thallo_stream_t stream);
 int thallo_hip_sfs_resident_status(void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream);
 void thallo_hip_sfs_resident_debug_set(int what, int value);
 /* Packed planes only (-hipErrorNotSupported elsewhere: the caller runs the launches they replace).

@@ -519,6 +519,7 @@ def test_shape_from_shading_ring_of_p_planes_is_bitwise_a_delta_update_per_itera
     three GN steps -- loops shorter and longer than the ring, small rings, the update next to the loop."""
     p = syn.shape_from_shading(W, H)
     runs = []
+    monkeypatch.setenv("THALLO_RESIDENT", "0")          # (one launch per PCG iteration is what is compared; small images otherwise run the resident loop)
     for dp in ("0", planes):
         if dp is None: monkeypatch.delenv("THALLO_DELTA_PLANES", raising=False)
         else: monkeypatch.setenv("THALLO_DELTA_PLANES", dp)
@@ -1854,6 +1855,7 @@ def test_shape_from_shading_one_kernel_iteration(torch, orc, monkeypatch, W, H):
     the three sums from registers; thallo_hip_sfs_pcg_iter) against the two-launch form (THALLO_AB one_kernel=0: PCGUpdate + applyJTJ with sums) and the oracle."""
     p = syn.shape_from_shading(W, H)
     runs = []
+    monkeypatch.setenv("THALLO_RESIDENT", "0")          # (one launch per PCG iteration is what is compared; small images otherwise run the resident loop)
     for one in ("1", "0"):
         set_ab(monkeypatch, one_kernel=one)
         dev = to_device(p)

@@ -40,7 +40,7 @@ __device__ __forceinline__ void st2g(rsrc_t r, unsigned off, unsigned tag, float
 __device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsigned v) { u32x2 d; d.x = v; d.y = tag; __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, 16); }
 
 // control words of a resident launch (device memory)
-enum { SR_SEQ = 0, SR_ERR = 1, SR_SPIN_MS = 2, SR_NEXT = 3, SR_PM = 4, SR_CTL_WORDS = 16 };
+enum { SR_SEQ = 0, SR_ERR = 1, SR_SPIN_MS = 2, SR_PM = 4, SR_CTL_WORDS = 16 };
 
 struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total; };
 
@@ -60,6 +60,7 @@ struct SrArgs {
     float* delta;                                 // in: 0; out: sum_{k < L-1} alpha_k p_k (PCGLinearUpdate adds the last term, like behind the launches)
     thallo_sum_t aN0;                             // alphaN_0
     float* words;                                 // words[2k] = alphaD_k, words[2k + 1] = betaN_k
+    float* X;                                     // the unknowns, or NULL: PCGLinearUpdate stays a launch of its own
     int L;
 };
 
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                 *reinterpret_cast<float2*>(a.delta + i) = make_float2(dl[j].x, dl[j].y);
             }
         }
-        if (id == 0) {      // (uniform per workgroup: all four waves of the writer's workgroup take part in the last sweep)
+        if (id == 0 || a.X != nullptr) {      // (uniform per workgroup: all four waves take part in the last sweep; with the update of the unknowns riding along every workgroup needs alpha_{L-1})
             const unsigned T = seq + (unsigned)a.L; const int par = (a.L - 1) & 1;
             unsigned w7[7];
 #pragma unroll
@@ -443,13 +444,27 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             exchange_scalars(T, w7, ad, n, a1, b1);
             float aD, bN;
             scalars_from_sums(aN_prev, ad, n, a1, b1, aD, bN);
-            if (writer) { a.words[2 * (a.L - 1)] = aD; a.words[2 * (a.L - 1) + 1] = bN; }
+            if (writer) {
+                a.words[2 * (a.L - 1)] = aD; a.words[2 * (a.L - 1) + 1] = bN;
+                // the next launch's tags start behind this one's (seq + 1 .. seq + L were used): the counter lives on the device (replay-safe) and is advanced by the one thread
+                // that is through only when every workgroup has published its last sums, i.e. has long read it
+                __hip_atomic_store(ctl + SR_SEQ, seq + (unsigned)a.L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (a.X != nullptr) {      // PCGLinearUpdate (gauss_newton.t:901-906) riding along: X += delta + alpha_{L-1} p_{L-1} on my rows (k_linear_update's expressions)
+                const float al = safe_div<false>(aN_prev, aD);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (j < nr && xout) {
+                        const long i = (long)(ya + j) * W + x0;
+                        const float2 xo = *reinterpret_cast<const float2*>(a.X + i);
+                        const float d0 = __builtin_fmaf(al, pp[j + 2].x, dl[j].x), d1 = __builtin_fmaf(al, pp[j + 2].y, dl[j].y);
+                        *reinterpret_cast<float2*>(a.X + i) = make_float2(xo.x + d0, xo.y + d1);
+                    }
+                }
+            }
         }
     }
 }
-
-// this launch's tags are seq + 1 .. seq + L: never those of an earlier launch of the plan, whatever its L was (replay-safe: the counter lives on the device)
-__global__ void k_sfs_resident_begin(unsigned* ctl, unsigned L) { if (threadIdx.x == 0) { const unsigned s = ctl[SR_NEXT]; ctl[SR_SEQ] = s; ctl[SR_NEXT] = s + L + 1u; } }
 
 inline SrGeo make_sr_geo(int W, int H, int yoff, int R)
 {
@@ -503,7 +518,6 @@ template <int R> int sr_launch_r(const SrArgs& a, hipStream_t s)
         }
         if (fits < 0 || (long)fits * thallo_hip_device_cu_count() < grid) return -(int)hipErrorNotSupported;
     }
-    hipLaunchKernelGGL(k_sfs_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)a.L);
     hipLaunchKernelGGL((k_sfs_resident<R>), dim3(grid), dim3(SR_NT), 0, s, a);
     int e = check_launch(); return e ? e : grid;
 }
@@ -526,12 +540,13 @@ long thallo_hip_sfs_resident_bytes(int W, int H)
 
 /* The PCG loop of one Gauss-Newton step in one launch: L iterations from what thallo_hip_sfs_pcg_init left on PACKED planes (r_0 in r_in, zeros in p_in and delta,
  * alphaN_0), leaving what L launches of thallo_hip_sfs_pcg_iter_deferred leave: r_{L-1}, A p_{L-1}, p_{L-1} in the *_out planes, delta without its last term, and
- * words[2k] = alphaD_k, words[2k + 1] = betaN_k.  The *_out planes may be the *_in planes.  xbuf: thallo_hip_sfs_resident_bytes() bytes, zeroed once by the caller,
+ * words[2k] = alphaD_k, words[2k + 1] = betaN_k; with X != NULL also PCGLinearUpdate (X += delta + alpha_{L-1} p_{L-1}: thallo_hip_linear_update's result, bit for bit).
+ * The *_out planes may be the *_in planes.  xbuf: thallo_hip_sfs_resident_bytes() bytes, zeroed once by the caller,
  * private to the plan.  Returns the number of workgroups (> 0), -hipErrorNotSupported when the shape does not fit, another negative hipError_t on failure.
  * Replaces gauss_newton.t:1615-1687 for shapes whose solver state fits the chip's registers. */
 int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,
                                 const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
-                                thallo_sum_t alphaN0, float* words, void* xbuf, int L, thallo_stream_t stream)
+                                thallo_sum_t alphaN0, float* words, float* X, void* xbuf, int L, thallo_stream_t stream)
 {
     if (H < 1 || (W & 1) || W < 2 || L < 1 || !host_params) return -(int)hipErrorInvalidValue;
     if (!G || !Fw || !r_in || !p_in || !r_out || !Ap_out || !p_out || !delta || !words || !xbuf || !alphaN0.partials) return -(int)hipErrorInvalidValue;
@@ -547,7 +562,7 @@ int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params
     a.cm = cam_of(host_params);
     a.G = G; a.Fw = reinterpret_cast<const unsigned*>(Fw);
     a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
-    a.aN0 = alphaN0; a.words = words; a.L = L;
+    a.aN0 = alphaN0; a.words = words; a.X = X; a.L = L;
     hipStream_t s = (hipStream_t)stream;
     switch (R) {
         case 2: return sr_launch_r<2>(a, s); case 3: return sr_launch_r<3>(a, s); case 4: return sr_launch_r<4>(a, s); case 5: return sr_launch_r<5>(a, s);

@@ -187,6 +187,7 @@ public:
     // r / Ap / p in buffers (L & 1), delta without its last term, words[2k] = alphaD_k, words[2k + 1] = betaN_k.  resident_ok(): this plan's shape fits.
     virtual bool resident_ok() const { return false; }
     virtual int  pcg_resident(LaunchCtx&, SolverVectors&, int /*L*/, thallo_sum_t /*alphaN0*/, float* /*words*/) { return -1; }
+    virtual bool resident_updates_unknowns() const { return false; }                            // PCGLinearUpdate rides in the resident launch (the driver skips its own, and calls unknowns_written())
     virtual int  resident_status(LaunchCtx&, int /*clear*/, unsigned* /*pm*/) { return 0; }      // 1: a bounded wait inside the kernel ran out
     virtual void resident_disable() {}                                                          // ... after which the plan stays on one launch per PCG iteration
     // ... for one rank's row slab on the device-side transport (thallo_hip_iw_pcg_resident_dist): boundary rows of A p straight into the neighbours' ghost areas

@@ -1093,8 +1093,9 @@ public:
     {
         TimedLaunch t(c, "PCGLoopResident");
         return thallo_hip_sfs_pcg_resident(W, H, yoff_, hp, (const float*)G.ptr, (const float*)Wt.ptr, v.rbuf(0), v.p[0], v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words,
-                                           xres_.ptr, L, c.stream);
+                                           resident_updates_unknowns() ? X : nullptr, xres_.ptr, L, c.stream);
     }
+    bool resident_updates_unknowns() const override { const char* e = env_switch("THALLO_SFS_RESIDENT_FOLD"); return !(e && e[0] == '0'); }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_sfs_resident_status(xres_.ptr, clear, -1, pm, c.stream) : 0; }
     void resident_disable() override { resident_ = false; resident_broken_ = true; }
     // GN on one GPU: one launch per PCG iteration (the marching kernel with PCGUpdate riding along; r, Ap, p ping-pong).  Across ranks: the flat form.

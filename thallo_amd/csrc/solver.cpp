@@ -88,6 +88,7 @@ KernelTimer::~KernelTimer()
 // ------------------------------------------------------------------ CoarseTimer
 int CoarseTimer::start(const char* name, hipStream_t s)
 {
+    if (!enabled) return -1;
     Info i; i.name = name; i.start = i.end = nullptr;
     HIP_OK(hipEventCreate(&i.start)); HIP_OK(hipEventCreate(&i.end));
     hipEventRecord(i.start, s);
@@ -170,6 +171,7 @@ Plan::Plan(EnergyPlugin* pl, const Thallo_InitializationParameters& ip_, bool lm
     }
     if (scratch_.alloc(64 * sizeof(float))) return;
     ctx.timer = &ktimer;
+    timer_.enabled = ip.timingLevel >= 1;
     if (ip.timingLevel >= 2) ktimer.period = 1;
     if (ip.timingLevel >= 3) ktimer.invasive = true;
     if (ensure_slots(sp.lIterations)) return;
@@ -209,7 +211,7 @@ int Plan::ensure_slots(int L)
 const char* env_switch(const char* name)
 {
     static const char* const known[] = {
-        "THALLO_RESIDENT",            // 0: image_warping / ARAP run one launch per PCG iteration even where the whole PCG loop fits one resident launch; 2: also bundle adjustment's resident
+        "THALLO_RESIDENT",            // 0: image_warping / ARAP / shape_from_shading run one launch per PCG iteration even where the whole PCG loop fits one resident launch; 2: also bundle adjustment's resident
                                       //    PCG loop (bit-identical, measured slower than its three launches per iteration: opt-in)
         "THALLO_MARCH",               // 0: the LDS-tiled one-kernel iteration everywhere; 2: the marching kernel at every size (default: from 0.4 Mpixel up); 3: the marching kernel with the
                                       //    stored A p plane (round 2/3); 4 = 2 + 3
@@ -231,6 +233,7 @@ const char* env_switch(const char* name)
         { "THALLO_SFS_MARCH", "sfs_march" },                    // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
         { "THALLO_BA_RENUMBER", "ba_renumber" },                // bundle adjustment's plan-side point order: 0 never, 1 always (default: when the caller's order is far from "by first observing camera"; round 6)
         { "THALLO_LM_FOLD_STEP", "lm_fold_step" },              // 0: the LM step with PCGFinalizeDiagonal and the model cost as launches of their own where a plugin can fold them (round 6)
+        { "THALLO_SFS_RESIDENT_FOLD", "sfs_resident_fold" },    // 0: shape_from_shading's resident PCG loop leaves PCGLinearUpdate a launch of its own (round 6; A/B)
         { "THALLO_SFS_PAIR", "sfs_pair" },                      // 0: shape_from_shading's one-pixel-per-lane marching kernels on the float4 / float2 / byte planes instead of the pixel-pair kernels on packed planes (round 6)
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere
         { "THALLO_FRONTEND_COMPUTED", "frontend_computed" },    // 0: computed arrays (expr:get) inlined at every access instead of materialized by a precompute kernel (rounds 1-5; A/B)
@@ -738,7 +741,8 @@ int Plan::step_gn_resident(int ev_iter)
     last_l_iters = L;
     timer_.stop(ev_lin, s);
     const int ev_fin = timer_.start("Nonlinear Finish", s);
-    linear_update_tail(L, false);
+    if (plugin->resident_updates_unknowns()) plugin->unknowns_written();      // (PCGLinearUpdate rode in the resident launch)
+    else linear_update_tail(L, false);
     sp.nIter++;
     timer_.stop(ev_fin, s);
     timer_.stop(ev_iter, s);

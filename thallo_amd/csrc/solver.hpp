@@ -31,6 +31,7 @@ class CoarseTimer {
 public:
     struct Info { std::string name; hipEvent_t start, end; };
     std::vector<Info> events;
+    bool enabled = true;      // Thallo_InitializationParameters.timingLevel 0 = "No timing recorded" (Thallo.h): no events at all -- an event record is a barrier packet between two launches
     int  start(const char* name, hipStream_t s);
     void stop(int idx, hipStream_t s);
     void evaluate(Thallo_PerformanceSummary* out, bool print_table, KernelTimer* kt);

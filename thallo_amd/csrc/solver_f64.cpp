@@ -28,6 +28,7 @@ PlanF64::PlanF64(EnergyPlugin* pl, const Thallo_InitializationParameters& ip_) :
     // partial slots: 0 cost, 1 alphaN, 2 alphaD, 3 betaN; words behind them
     if (parts_.alloc((size_t)(8 * THALLO_HIP_MAX_PARTIALS + 16) * sizeof(double))) return;
     ctx.timer = &ktimer;
+    timer_.enabled = ip.timingLevel >= 1;
     if (ip.timingLevel >= 2) ktimer.period = 1;
     if (ip.timingLevel >= 3) ktimer.invasive = true;
     ok_ = true;

@@ -64,8 +64,8 @@ def kernel_level(state_steps=2):
     L.thallo_hip_sfs_resident_bytes.restype = C.c_long
     xb = torch.zeros(L.thallo_hip_sfs_resident_bytes(W, H) // 4 + 16, dtype=torch.int32, device="cuda")
     r2, A2, p2, d2 = r0.clone(), f(), f(), f(); words = torch.zeros(64, device="cuda")
-    L.thallo_hip_sfs_pcg_resident.argtypes = [C.c_int] * 3 + [C.c_void_p] * 9 + [api.SumT, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    nbr = L.thallo_hip_sfs_pcg_resident(W, H, 0, hp, vp(Gp), vp(Fw), vp(r2), vp(pp0), vp(r2), vp(A2), vp(p2), vp(d2), S(aN0, nb), vp(words), vp(xb), 1, None)
+    L.thallo_hip_sfs_pcg_resident.argtypes = [C.c_int] * 3 + [C.c_void_p] * 9 + [api.SumT, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    nbr = L.thallo_hip_sfs_pcg_resident(W, H, 0, hp, vp(Gp), vp(Fw), vp(r2), vp(pp0), vp(r2), vp(A2), vp(p2), vp(d2), S(aN0, nb), vp(words), None, vp(xb), 1, None)
     assert nbr > 0, nbr
     torch.cuda.synchronize()
     print("workgroups", nbm, nbr, "p equal", bool(torch.equal(p1[:N], p2[:N])), "r equal", bool(torch.equal(r1[:N], r2[:N])))

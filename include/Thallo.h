@@ -37,7 +37,8 @@ typedef struct Thallo_Problem Thallo_Problem;
 struct Thallo_InitializationParameters {
     int doublePrecision;   /* 1: thallo_float = double (generated kernels, see above) */
     int verbosityLevel;    /* 0 quiet, >=1 prints solver log + timing table at the end of a solve */
-    int timingLevel;       /* 0/1 coarse events, 2 per-kernel hipEvents, 3 additionally device-syncs around them */
+    int timingLevel;       /* 0 no timing recorded (no events in the stream: Thallo_GetPerformanceSummary reports zeros), 1 coarse events (eight per solver step -- each one
+                              a barrier packet between two launches: ~30 us per step, which small problems notice), 2 per-kernel hipEvents, 3 additionally device-syncs around them */
     int threadsPerBlock;   /* accepted for compatibility; kernels carry their own tuned shapes */
     int useAutoscheduler;  /* bundled energies: their hand-written plugin (a fixed schedule) either way.  Generated plugins (a .t file no plugin recognises, or
                               THALLO_FRONTEND=generate): 1 = the autoscheduler's lowering where it applies -- residuals that live on their unknowns' grid become

@@ -64,6 +64,13 @@ struct SrArgs {
     int L;
 };
 
+#ifdef THALLO_MARCH_SWEEP
+// tools/sfs_resident_probe.py stamps: where an iteration spends its time (100 MHz wall clock, lane 0 of every wave, iterations 4..7)
+__device__ unsigned long long* g_stamps_sr = nullptr;
+#define SR_STAMP(k, i) do { if ((threadIdx.x & 63) == 0 && g_stamps_sr && (k) >= 4 && (k) < 8) g_stamps_sr[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((k) - 4)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SR_STAMP(k, i) do { } while (0)
+#endif
 struct Spin { unsigned n; long long t0; };
 // bounded wait bookkeeping: true = give up (this wave or somebody else timed out; every later wait of the wave falls through at once)
 __device__ __forceinline__ bool spin_fail(Spin& sp, unsigned* ctl, unsigned what, unsigned idx, unsigned tag)
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     for (int k = 0; k < a.L; ++k) {
         const unsigned T = seq + (unsigned)k + 1u, Tp = T - 1u;
         const int par = k & 1, parp = par ^ 1;
+        SR_STAMP(k, 0);
         if (k > 0) {
             // ---- the one synchronisation point: my quarter of the sums of iteration k-1, the two rows of A p_{k-1} from the wave above and from the wave below, one
             // word per lane of the columns from the strips to the left / right.  Everything is polled in ONE loop, all loads of a pass in flight together.
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                 if (need_d) { Ap[R + 2] = rd0; Ap[R + 3] = rd1; }
             }
             dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+            SR_STAMP(k, 1);
             // the columns go through LDS to the two lanes that hold them (lane 0 / 63); same wave: program order + lgkmcnt(0)
             if (need_cl) S.crx[wave][0][c_dst] = cvl;
             if (need_cr) S.crx[wave][1][c_dst] = cvr;
@@ -286,6 +295,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             if (writer) { a.words[2 * (k - 1)] = aD; a.words[2 * (k - 1) + 1] = bN; }
             aN_prev = bN;
         }
+        SR_STAMP(k, 2);
         // ---- r_k = r_{k-1} - alpha A p_{k-1} ; delta += alpha p_{k-1} ; p_k = r_k + beta p_{k-1}     (every row I hold, halo included; k_pmarch<UPD>'s expressions)
 #pragma unroll
         for (int jj = 0; jj < NR; ++jj) {
@@ -300,6 +310,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             v0 = sel(ok, v0, Z2);
             rr[jj] = rk; pp[jj] = v0;
         }
+        SR_STAMP(k, 3);
         // ---- A p_k for my rows (the row step of k_pmarch: dB -> U_h, U_v -> T -> J^T, the Laplacian rows), the four sums
         v2f acc = Z2; Sums3 sm;
         {
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                 }
             }
         }
+        SR_STAMP(k, 4);
         // ---- publish: the boundary rows, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the four
         // waves up in order and publishes 7 granules)
         {
@@ -413,6 +425,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                 }
             }
         }
+        SR_STAMP(k, 5);
     }
     // ---- what L launches would have left behind: r_{L-1}, p_{L-1}, A p_{L-1}, delta (without its last term); the last iteration's two words
     if (a.L > 0) {
@@ -525,6 +538,10 @@ template <int R> int sr_launch_r(const SrArgs& a, hipStream_t s)
 }  // namespace
 
 extern "C" {
+
+#ifdef THALLO_MARCH_SWEEP
+int thallo_hip_debug_stamps_sfs_resident(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_sr), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
+#endif
 
 void thallo_hip_sfs_resident_debug_set(int what, int value) { if (what == 0) g_sr_rows = value; if (what == 1) g_sr_cap = value; }
 

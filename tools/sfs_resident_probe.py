@@ -23,7 +23,7 @@ def run(resident, n):
     c = s.current_cost(); s.close()
     L.thallo_hip_sfs_march_debug_set(0, 0)
     return to_host(dev[16]).copy(), tr, c
-for n in (range(1, nit + 1) if not (len(sys.argv) > 5 and sys.argv[5] == "kernel") else []):
+for n in (range(1, nit + 1) if not (len(sys.argv) > 5 and sys.argv[5] in ("kernel", "stamps")) else []):
     for rep in range(2):
         xa, ta, ca = run(True, n); xb, tb, cb = run(False, n)
         d = np.argwhere(xa != xb)
@@ -89,3 +89,24 @@ def kernel_level(state_steps=2):
 
 if len(sys.argv) > 5 and sys.argv[5] == "kernel":
     kernel_level(int(sys.argv[6]) if len(sys.argv) > 6 else 2)
+
+
+def stamps():
+    """needs the sweep build: make -C thallo_amd/csrc VARIANT=sweep; THALLO_LIB=tools/ab/libThallo_sweep.so"""
+    nw = 1024 * 4
+    st = torch.zeros(nw * 4 * 8, dtype=torch.int64, device="cuda")
+    assert L.thallo_hip_debug_stamps_sfs_resident(C.c_void_p(st.data_ptr())) == 0
+    run(True, 2)
+    torch.cuda.synchronize()
+    t = st.cpu().numpy().reshape(nw, 4, 8).astype(np.float64)
+    t = t[t[:, 0, 0] > 0]
+    names = ["global poll", "columns via LDS + scalars exchange", "r / p / delta update", "stencil + sums", "publish"]
+    d = np.diff(t[:, :, :6], axis=2) / 100.0
+    print("waves", len(t), "iteration us", round(float(((t[:, 1:, 0] - t[:, :-1, 0]) / 100.0).mean()), 3))
+    for i, n in enumerate(names): print("  %-40s mean %.3f  max-wave %.3f" % (n, d[:, :, i].mean(), d[:, :, i].mean(axis=1).max()))
+    print("  entry skew us", round(float((t[:, 1, 0].max() - t[:, 1, 0].min()) / 100.0), 3), "stencil-end skew", round(float((t[:, 1, 4].max() - t[:, 1, 4].min()) / 100.0), 3))
+    L.thallo_hip_debug_stamps_sfs_resident(None)
+
+
+if len(sys.argv) > 5 and sys.argv[5] == "stamps":
+    stamps()

@@ -609,6 +609,16 @@ long thallo_hip_sfs_resident_bytes(int W, int H);
 int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,
                                 const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
                                 thallo_sum_t alphaN0, float* words, float* X, void* xbuf, int L, thallo_stream_t stream);
+/* ... and a Levenberg-Marquardt step's loop WITH its tail: from what thallo_hip_sfs_pcg_init_lm left (r = b, M^-1 in pre, CtC, zeros in p_prev and delta, alphaN_0) and a reset
+ * state (thallo_hip_lm_state_reset), at most L iterations of thallo_hip_sfs_pcg_iter_lm -- the zeta test ends the loop on the device, in every workgroup alike; lm_state[1] /
+ * [2] = gate / iterations done as the launches leave them -- then thallo_hip_sfs_lm_model_cost's launch: the owed update of delta (into `delta`), per-workgroup partials of
+ * delta . J^T J delta and delta . b (the return value says how many), prevX = X, X += delta.  L <= the residual reset period (gauss_newton.t:1653-1657).
+ * thallo_hip_sfs_resident_rows_lm: rows per wave, 0 = does not fit (more registers per row: at most 5 rows per wave). */
+int thallo_hip_sfs_resident_rows_lm(int W, int H);
+int thallo_hip_sfs_pcg_resident_lm(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,
+                                   const float* r_in, const float* p_in, const float* pre, const float* CtC, float* delta,
+                                   thallo_sum_t alphaN0, float* words, float* lm_state, float q_tolerance, float* dJJd_out, float* db_out,
+                                   float* X, float* prevX, void* xbuf, int L, thallo_stream_t stream);
 int thallo_hip_sfs_resident_status(void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream);
 void thallo_hip_sfs_resident_debug_set(int what, int value);
 /* Packed planes only (-hipErrorNotSupported elsewhere: the caller runs the launches they replace).

@@ -1820,6 +1820,55 @@ def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(tor
         assert (np.abs(np.array(c0) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (c0, co)
 
 
+@pytest.mark.parametrize("W,H,radius,qtol", [(640, 480, 30.0, 0.05), (192, 130, 30.0, 0.05), (130, 67, 1e4, 1e-4), (126, 9, 30.0, 0.0), (250, 130, 3.0, 0.05), (2, 2, 1e4, 1e-4)])
+def test_shape_from_shading_resident_lm_step_is_bitwise_the_launches(torch, orc, monkeypatch, W, H, radius, qtol):
+    """Round 6: a Levenberg-Marquardt step's PCG loop (A = J^T J + CtC, z = M^-1 r, the six double sums, the zeta test after every iteration -- taken by every workgroup for
+    itself from the same sums), the update of delta the loop owes, the model cost's J^T J delta and two dot products, savePreviousUnknowns and PCGLinearUpdate in ONE resident
+    launch (energy_sfs_resident.hip, LM form) against one launch per iteration + the model-cost launch with the same rows per wave: costs, PCG iteration counts (loops the zeta
+    test ends early), alpha / beta of every iteration, trust-region radii (accepted AND rejected steps: a small initial radius) and the unknowns are BIT-identical; small
+    instances sit on the oracle's trajectory."""
+    L = thallo_amd.lib()
+    L.thallo_hip_sfs_resident_rows_lm.restype = C.c_int
+    R = L.thallo_hip_sfs_resident_rows_lm(W, H)
+    assert 2 <= R <= 5, R
+    p = syn.shape_from_shading(W, H)
+    nit, lit = 8, 10
+    runs = []
+    for resident in (True, False):
+        monkeypatch.setenv("THALLO_RESIDENT", "1" if resident else "0")
+        L.thallo_hip_sfs_march_debug_set(0, R)               # (both runs: PCGInit1's sums are taken in the marching geometry too)
+        try:
+            dev = to_device(copy_params(p))
+            s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), solverkind="levenberg_marquardt")
+            s.enable_lm(); s.set_kernel_sampling(1)
+            s.set_solver_parameters(nIterations=nit, lIterations=lit, trust_region_radius=radius, q_tolerance=qtol)
+            params = s.make_params(dev)
+            s.init(params)
+            costs, traces, radii = [s.current_cost()], [], []
+            while s.step(params):
+                costs.append(s.current_cost()); traces.append(s.alpha_beta_trace()); radii.append(s.get_solver_parameter("trust_region_radius"))
+            names = {k: v["launches"] for k, v in s.kernel_stats().items() if v["launches"]}
+            assert "resident" not in (api.last_error() or ""), api.last_error()
+            s.close()
+        finally:
+            L.thallo_hip_sfs_march_debug_set(0, 0)
+        runs.append((costs, traces, radii, dev[16].clone(), names))
+    (c0, t0, r0, x0, n0), (c1, t1, r1, x1, n1) = runs
+    assert all(np.isfinite(c0)) and len(c0) >= 3
+    assert n0.get("PCGLoopResident") == n0.get("PCGInit1") and "PCGIteration" not in n0 and "PCGModelCost" not in n0, n0
+    assert n1.get("PCGModelCost") == n1.get("PCGInit1") and "PCGLoopResident" not in n1, n1
+    assert [len(t) for t in t0] == [len(t) for t in t1], ([len(t) for t in t0], [len(t) for t in t1])
+    assert t0 == t1, [(i, k, u, v) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
+    assert c0 == c1, (c0, c1)
+    assert r0 == r1, (r0, r1)
+    assert torch.equal(x0, x1)
+    if qtol > 0.0 and (W, H) != (2, 2): assert min(len(t) for t in t0) < lit or radius >= 1e4, [len(t) for t in t0]      # (the zeta test ended some loop early)
+    if W * H <= 70000:
+        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=nit, lIterations=lit, use_lm=1, trust_region_radius=radius, q_tolerance=qtol)
+        m = min(len(co), len(c0))
+        assert m >= 2 and (np.abs(np.array(c0[:m]) - co[:m]) <= 2e-4 * np.abs(co[:m]) + 1e-9).all(), (c0, co)
+
+
 def test_shape_from_shading_lm_step_folds(torch, monkeypatch):
     """Round 6, LM on one GPU on packed planes: PCGFinalizeDiagonal rides in PCGInit1's launch and the owed update of delta + the model cost's applyJTJ + its dot product are one
     launch (thallo_hip_sfs_pcg_init_lm, thallo_hip_sfs_lm_model_cost) -- against the step with those launches on their own (THALLO_AB lm_fold_step=0): the same expressions per
@@ -1827,6 +1876,7 @@ def test_shape_from_shading_lm_step_folds(torch, monkeypatch):
     W, H = 192, 130
     p = syn.shape_from_shading(W, H)
     runs = []
+    monkeypatch.setenv("THALLO_RESIDENT", "0")          # (the launches are compared; an image of this size otherwise runs the LM step's resident launch)
     for fold in ("1", "0"):
         set_ab(monkeypatch, lm_fold_step=fold)
         dev = to_device(copy_params(p))

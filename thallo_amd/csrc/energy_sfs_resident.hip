@@ -27,7 +27,7 @@ using namespace thallo;
 namespace {
 
 constexpr int SR_NT = 256;                // 4 waves = 4 vertically adjacent segments of one strip (one workgroup per CU)
-constexpr int SR_MIN_R = 2, SR_MAX_R = 8; // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
+constexpr int SR_MIN_R = 2, SR_MAX_R = 8, SR_MAX_R_LM = 5;       // (LM: 18 registers per held row and lane + the own rows' CtC and b; from 6 rows on the compiler spills) // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -41,6 +41,7 @@ __device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsig
 
 // control words of a resident launch (device memory)
 enum { SR_SEQ = 0, SR_ERR = 1, SR_SPIN_MS = 2, SR_PM = 4, SR_CTL_WORDS = 16 };
+constexpr int SR_REC = 16;                // granules per sums record (7 used by GN, 13 by LM)
 
 struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total; };
 
@@ -48,7 +49,7 @@ struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total; };
 struct SrBufs {
     u64* rowh;        // [2 parity][waves][2 sides: 0 = the wave's FIRST two rows (for the wave above), 1 = its LAST two (for the wave below)][64 lanes][4: row a px 0, px 1, row b px 0, px 1]
     u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][64: word 2 * row + pixel]
-    u64* sums;        // [2 parity][1024 workgroups][8: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo, -]
+    u64* sums;        // [2 parity][1024 workgroups][16: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo (LM: U, T1, T2 hi / lo), -]
     unsigned* ctl;    // SR_CTL_WORDS
 };
 
@@ -60,8 +61,12 @@ struct SrArgs {
     float* delta;                                 // in: 0; out: sum_{k < L-1} alpha_k p_k (PCGLinearUpdate adds the last term, like behind the launches)
     thallo_sum_t aN0;                             // alphaN_0
     float* words;                                 // words[2k] = alphaD_k, words[2k + 1] = betaN_k
-    float* X;                                     // the unknowns, or NULL: PCGLinearUpdate stays a launch of its own
+    float* X;                                     // the unknowns, or NULL (GN only): PCGLinearUpdate stays a launch of its own
     int L;
+    // LM
+    const float* pre; const float* ctc;           // M^-1 and CtC of PCGFinalizeDiagonal (b = r_0)
+    float* state; float q_tol;                    // lm state words ([0] Q0, [1] gate, [2] iterations done at the stop); the zeta test's tolerance
+    float* prevX; float* t0_out; float* t1_out;   // savePreviousUnknowns' copy; per-workgroup partials of delta . J^T J delta and delta . b
 };
 
 #ifdef THALLO_MARCH_SWEEP
@@ -94,16 +99,24 @@ __device__ __forceinline__ bool spin_fail(Spin& sp, unsigned* ctl, unsigned what
 struct SrLds {
     unsigned qtag[4];                 // quarter-sweep exchange: wave w's column is complete for tag ...
     unsigned wtag[4];                 // wave sums of an iteration are in place
-    unsigned q[4][7][64];             // per wave: the 7 words of the 64 slots it swept
-    float wa[4]; double wd[4][3];     // per wave: alphaD part, {N, S1, S2} parts
+    unsigned q[4][13][64];            // per wave: the 7 (LM: 13) words of the 64 slots it swept
+    float wa[4]; double wd[4][6];     // per wave: alphaD part, {N, S1, S2} (LM: + {U, T1, T2}) parts
     float cst[4][2][64];              // per wave: lane 1's / lane 62's A p of its rows (word 2 * row + pixel), so that ONE store instruction publishes a column
     float crx[4][2][64];              // per wave: the received columns (word 2 * held row + pixel), for lanes 0 / 63 to pick up
+    float red[32];                    // block_store_partials (the LM model cost's two sums)
 };
 
-template <int R>
+// LM = the Levenberg-Marquardt loop (gauss_newton.t:1615-1687 with every UsesLambda() branch; k_pmarch<.., UPD, LMQ>'s iteration): A = J^T J + CtC, z = M^-1 r, blind
+// divisions, the three sums of q's expansion beside {N, S1, S2}, the zeta test after every iteration (every workgroup for itself, from the same sums: the same decision
+// everywhere) -- and behind the loop the update of delta it still owes, the model cost's J^T J delta and two dot products, savePreviousUnknowns and PCGLinearUpdate
+// (k_pmarch<MODEL>'s launch), all from the registers the loop leaves.
+template <int R, bool LM>
 __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 {
     constexpr int NR = R + 4;             // held rows: jj = 0, 1 the rows above, 2 .. R + 1 my own, R + 2, R + 3 the rows below (row t = ya - 2 + jj)
+    constexpr int NQ = LM ? 6 : 3;        // double sums per record
+    constexpr int NWD = 1 + 2 * NQ;       // words per record: alphaD, then (hi, lo) of every double
+    constexpr int NLD = (NWD + 1) / 2;    // 16-byte loads that fetch a record
     __shared__ SrLds S;
     const SrGeo g = a.g;
     const PCam cm = a.cm;
@@ -116,11 +129,14 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     const int NG = (grid % 8) == 0 ? 8 : 1;
     auto wg_id = [&](int b, long& id) { const int grp = b % NG, l = b / NG; const long lo = (long)g.total * grp / NG, hi = (long)g.total * (grp + 1) / NG; id = lo + l; return id < hi; };
     long id;
-    if (!wg_id(blockIdx.x, id)) return;                                  // (a slot without rows: its sums are zeros, the sweeps know)
+    if (!wg_id(blockIdx.x, id)) {                                         // (a slot without rows: its sums are zeros, the sweeps know; the model cost's partial slots are the caller's)
+        if (LM && threadIdx.x == 0) { a.t0_out[blockIdx.x] = 0.0f; a.t1_out[blockIdx.x] = 0.0f; }
+        return;
+    }
     const bool writer = id == 0 && threadIdx.x == 0;
     if (threadIdx.x < 4) { S.qtag[threadIdx.x] = 0u; S.wtag[threadIdx.x] = 0u; }
     for (int i = threadIdx.x; i < 4 * 2 * 64; i += SR_NT) { (&S.cst[0][0][0])[i] = 0.0f; (&S.crx[0][0][0])[i] = 0.0f; }
-    __syncthreads();                                                      // (the only barrier of the launch)
+    __syncthreads();
 
     const int strip = (int)(id % g.nstrips), seg = (int)(id / g.nstrips) * (SR_NT / 64) + wave;
     int ya = seg * g.R, yb = ya + g.R;
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     const rsrc_t RS_ROW = make_xrsrc(a.b.rowh), RS_COL = make_xrsrc(a.b.colh), RS_SUM = make_xrsrc(a.b.sums);
     auto rowh = [&](int par, int w, int side) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + lane) * 32); };      // this lane's 4 granules
     auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + i) * 8); };
-    auto sumw = [&](int par, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * 8) * 8); };
+    auto sumw = [&](int par, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * SR_REC) * 8); };              // a workgroup's record
     // which column word this lane fetches at the synchronisation point, and where it belongs (S.crx word 2 * jj + pixel):
     //   lanes 0 .. 2R-1: my own rows, from the strip beside me; 2R .. 2R+3: the two rows above, from the strip beside the wave above (its last two rows);
     //   2R+4 .. 2R+7: the two rows below, from the strip beside the wave below (its first two rows)
@@ -154,9 +170,11 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     else if (lane < 2 * R + 8) { c_dw = 1; c_word = lane - 2 * R - 4; c_dst = lane; c_any = has_dn; }
     const bool need_cl = c_any && has_lf, need_cr = c_any && has_rt;
     const bool col_pub = lane < 2 * R && nr > 0;
+    const v2f Z2 = { 0.f, 0.f };
+    auto row_ok = [&](int jj) __attribute__((always_inline)) { const int t = ya - 2 + jj; return nr > 0 && xin && t >= 0 && t < H; };
 
-    // ---- state
-    v2f rr[NR], pp[NR], Ap[NR], gx[NR], gy[NR], gz[NR], dl[R];
+    // ---- state.  delta: my own rows (GN); every held row (LM: the model cost's J^T J delta needs delta on the halo, and it is formed there from what the halo holds anyway)
+    v2f rr[NR], pp[NR], Ap[NR], gx[NR], gy[NR], gz[NR], dl[NR], mi[LM ? NR : 1], ct[LM ? R : 1], bb[LM ? R : 1];
     unsigned fwx[NR], fwy[NR];
     {
         const float* Gp = a.G;
@@ -168,34 +186,37 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             const float2 r2 = *reinterpret_cast<const float2*>(a.r_in + i), p2 = *reinterpret_cast<const float2*>(a.p_in + i);
             const float2 g0 = *reinterpret_cast<const float2*>(Gp + i), g1 = *reinterpret_cast<const float2*>(Gp + N + i), g2 = *reinterpret_cast<const float2*>(Gp + 2 * N + i);
             const uint2 fw = *reinterpret_cast<const uint2*>(a.Fw + i);
-            rr[jj] = v2f{ r2.x, r2.y }; pp[jj] = v2f{ p2.x, p2.y }; Ap[jj] = v2f{ 0.f, 0.f };
+            rr[jj] = v2f{ r2.x, r2.y }; pp[jj] = v2f{ p2.x, p2.y }; Ap[jj] = Z2; dl[jj] = Z2;
             gx[jj] = v2f{ g0.x, g0.y }; gy[jj] = v2f{ g1.x, g1.y }; gz[jj] = v2f{ g2.x, g2.y };
             fwx[jj] = fw.x; fwy[jj] = fw.y;
+            if (LM) { const float2 m2 = *reinterpret_cast<const float2*>(a.pre + i); mi[jj] = v2f{ m2.x, m2.y }; }
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const bool mine = j < nr && xout;
-            float2 d2 = make_float2(0.f, 0.f);
-            if (mine) d2 = *reinterpret_cast<const float2*>(a.delta + (long)(ya + j) * W + x0);
-            dl[j] = v2f{ d2.x, d2.y };
+            float2 d2 = make_float2(0.f, 0.f), c2 = make_float2(0.f, 0.f);
+            if (mine) { const long i = (long)(ya + j) * W + x0; d2 = *reinterpret_cast<const float2*>(a.delta + i); if (LM) c2 = *reinterpret_cast<const float2*>(a.ctc + i); }
+            dl[j + 2] = v2f{ d2.x, d2.y };
+            if (LM) { ct[j] = v2f{ c2.x, c2.y }; bb[j] = rr[j + 2]; }      // b = r_0 (PCGFinalizeDiagonal: gauss_newton.t:962)
         }
     }
 
     const float aN0 = sum_partials(a.aN0.partials, a.aN0.count);
     float aN_prev = aN0;                  // alphaN_{k-1}
     float alpha = 0.0f, beta = 0.0f;
+    float q_prev = LM ? a.state[0] : 0.0f;     // Q0 of the zeta test (0 behind thallo_hip_lm_state_reset: delta = 0, gauss_newton.t:965)
+    bool stopped = false;
     Spin sp; sp.n = 0; sp.t0 = 0;
     bool dead = false;                    // a bounded wait ran out (here or elsewhere): no more waiting, the host raises
     const int slot = 64 * wave + lane;    // the sums slot this lane sweeps
     long sid;
     const bool slot_live = slot < grid && wg_id(slot, sid);
-    const v2f Z2 = { 0.f, 0.f };
 
-    // Publish my quarter of the sums of an iteration (the 7 words of slot 64 w + lane) to the other waves of the workgroup, wait for theirs, and add all slots up in
+    // Publish my quarter of the sums of an iteration (the words of slot 64 w + lane) to the other waves of the workgroup, wait for theirs, and add all slots up in
     // the order the launch-per-iteration path uses (last_workgroup_totals: lane-strided over the slots, then the wave butterfly) -- same bits everywhere.
-    auto exchange_scalars = [&](unsigned T, const unsigned (&w7)[7], float& ad_o, double& n_o, double& s1_o, double& s2_o) {
+    auto exchange_scalars = [&](unsigned T, const unsigned (&wq)[NWD], float& ad_o, double (&tot)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < 7; ++c) S.q[wave][c][lane] = w7[c];
+        for (int c = 0; c < NWD; ++c) S.q[wave][c][lane] = wq[c];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&S.qtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         sp.n = 0; sp.t0 = 0;
@@ -207,24 +228,127 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         }
         dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");            // (no instruction: keeps the column reads below the tag polls)
-        float t = 0.0f; double n = 0.0, a1 = 0.0, b1 = 0.0;
+        float t = 0.0f; double d[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) d[q] = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const unsigned* qq = &S.q[w][0][lane];
             t += __uint_as_float(qq[0]);
-            n += __hiloint2double((int)qq[64], (int)qq[128]);
-            a1 += __hiloint2double((int)qq[192], (int)qq[256]);
-            b1 += __hiloint2double((int)qq[320], (int)qq[384]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) d[q] += __hiloint2double((int)qq[64 * (1 + 2 * q)], (int)qq[64 * (2 + 2 * q)]);
         }
         ad_o = wave_sum_all(t);
-        n_o = wave_sum_all_f64(n); s1_o = wave_sum_all_f64(a1); s2_o = wave_sum_all_f64(b1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tot[q] = wave_sum_all_f64(d[q]);
     };
-    // alphaD_k, betaN_k from the sums: alpha_k = alphaN_k / alphaD_k, betaN_k = N - 2 alpha S1 + alpha^2 S2 (k_pmarch's deferred finish, its expressions)
-    auto scalars_from_sums = [&](float aN, float ad, double n, double a1, double b1, float& aD_o, float& bN_o) {
-        const float al = safe_div<false>(aN, ad);
-        double bnd = n - 2.0 * (double)al * a1 + (double)al * (double)al * b1;
+    // The finish of iteration kf from its sums (k_pmarch's deferred finish / block_finish_sums_lm's last workgroup, their expressions): alpha_kf = alphaN_kf / alphaD_kf,
+    // betaN_kf = N - 2 alpha S1 + alpha^2 S2; LM: q_{kf+1} = 0.5 [U + alpha (T1 - T2) - alpha^2 alphaD] and the zeta test (k_lm_zeta's rule, :1666-1686).  Leaves alpha, beta
+    // for iteration kf + 1, the two words, and (LM) the decision to stop.
+    auto finish = [&](int kf, float ad, const double (&tot)[NQ]) __attribute__((always_inline)) {
+        const float al = safe_div<LM>(aN_prev, ad);
+        double bnd = tot[0] - 2.0 * (double)al * tot[1] + (double)al * (double)al * tot[2];
         if (!(bnd > 0.0)) bnd = 0.0;
-        aD_o = ad; bN_o = (float)bnd;
+        const float bN = (float)bnd;
+        if (writer) { a.words[2 * kf] = ad; a.words[2 * kf + 1] = bN; }
+        if (LM) {
+            const double U = tot[NQ - 3], T1 = tot[NQ - 2], T2 = tot[NQ - 1];
+            const float Q1 = (float)(0.5 * (U + (double)al * (T1 - T2) - (double)al * (double)al * (double)ad));
+            const float zt = (float)(kf + 1) * (Q1 - q_prev) / Q1;
+            const bool stop = !isfinite(Q1) || !isfinite(zt) || zt < a.q_tol;
+            if (stop) { stopped = true; if (writer) { reinterpret_cast<unsigned*>(a.state)[1] = 1u; reinterpret_cast<int*>(a.state)[2] = kf + 1; } }
+            else { q_prev = Q1; if (writer) a.state[0] = Q1; }
+        }
+        alpha = al;
+        beta = safe_div<LM>(bN, aN_prev);
+        aN_prev = bN;
+    };
+    // J^T J v for my rows from the held rows V (k_pmarch's row step: dB -> U_h, U_v -> T -> J^T, the Laplacian rows; every lane takes part in the exchanges);
+    // emit(jj, vc, s) for every output row jj = 2 .. nr + 1 on the output lanes
+    auto stencil = [&](const v2f (&V)[NR], auto&& emit) __attribute__((always_inline)) {
+        v2f dB[NR], Uh[NR], Uv[NR], Tt[NR], Rr[NR][3];
+        unsigned Fl[NR]; float Cy[NR];
+#pragma unroll
+        for (int jj = 0; jj < NR; ++jj) {
+            Fl[jj] = row_ok(jj) ? ((fwx[jj] & 0xffu) | ((fwy[jj] & 0xffu) << 8)) : 0u;
+            Cy[jj] = coef1(cm, ya - 2 + jj + g.yoff);
+            dB[jj] = Z2; Uh[jj] = Z2; Uv[jj] = Z2; Tt[jj] = Z2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rr[jj][c] = Z2;
+        }
+#pragma unroll
+        for (int jj = 1; jj < NR; ++jj) {                       // dB(row jj) from v(jj), v(jj - 1); U_h(jj)
+            const bool ok = row_ok(jj);
+            const v2f v0 = V[jj], v1 = V[jj - 1];
+            const v2f vl0 = nbL(v0);
+            const v2f dB0 = sel(ok, gx[jj] * v0 + gy[jj] * vl0 + gz[jj] * v1, Z2);
+            const v2f dBr = nbR(dB0);
+            const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
+            const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
+            const M2 wn0 = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
+            dB[jj] = dB0;
+            Uh[jj] = sel(wn0, wx * (wx * (dB0 - dBr)), Z2);
+        }
+#pragma unroll
+        for (int jj = 1; jj < NR - 1; ++jj) {                   // U_v(jj) from dB(jj), dB(jj + 1); the Laplacian rows R(jj) from v(jj - 1), v(jj), v(jj + 1)
+            const bool ok = row_ok(jj);
+            const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
+            const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
+            const M2 wn = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
+            Uv[jj] = sel(wn, wy * (wy * (dB[jj] - dB[jj + 1])), Z2);
+            const v2f v0 = V[jj + 1], v1 = V[jj], v2 = V[jj - 1];
+            const v2f vl1 = nbL(v1), vr1 = nbR(v1);
+            const float cy0 = Cy[jj + 1], cy1 = Cy[jj], cy2 = Cy[jj - 1];
+            const M2 f2b = bit(Fl[jj], 2u);
+            Rr[jj][0] = sel(f2b, cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0), Z2);
+            Rr[jj][1] = sel(f2b, cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0), Z2);
+            Rr[jj][2] = sel(f2b, cm.ws * (4.0f * v1 - vl1 - v2 - vr1 - v0), Z2);
+        }
+#pragma unroll
+        for (int jj = 2; jj < NR - 1; ++jj) {                   // T(jj)
+            v2f T1 = Uh[jj] + Uv[jj];
+            T1 -= nbL(Uh[jj]);
+            T1 -= Uv[jj - 1];
+            Tt[jj] = T1;
+        }
+#pragma unroll
+        for (int jj = 2; jj < R + 2; ++jj) {                    // output row y = ya + jj - 2
+            const int y = ya - 2 + jj;
+            const v2f T2 = Tt[jj], T1 = Tt[jj + 1];
+            const v2f gT2r = nbR(gy[jj] * T2);
+            v2f Rl[3], Rq[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { Rl[c] = nbL(Rr[jj][c]); Rq[c] = nbR(Rr[jj][c]); }
+            if (jj - 2 < nr && xout) {
+                const v2f vc = V[jj];
+                v2f s = Z2;
+                s = sel(bit(Fl[jj], 1u), s + cm.wp * (cm.wp * vc), s);
+                s += gx[jj] * T2;
+                s = sel(xp1, s + gT2r, s);
+                if (y + 1 < H) s += gz[jj + 1] * T1;
+                {
+                    v2f lap;
+                    lap = 4.0f * Rr[jj][0] - Rl[0] - Rr[jj - 1][0] - Rq[0] - Rr[jj + 1][0]; s += cm.ws * (cxc * lap);
+                    lap = 4.0f * Rr[jj][1] - Rl[1] - Rr[jj - 1][1] - Rq[1] - Rr[jj + 1][1]; s += cm.ws * (Cy[jj] * lap);
+                    lap = 4.0f * Rr[jj][2] - Rl[2] - Rr[jj - 1][2] - Rq[2] - Rr[jj + 1][2]; s += cm.ws * (1.0f * lap);
+                }
+                emit(jj, vc, s);
+            }
+        }
+    };
+    // my quarter of the sums records of an iteration, polled until every tag is there (the final sweep; inside the loop the same loads ride in the one polling loop)
+    auto sweep_sums = [&](int par, unsigned T, unsigned (&wq)[NWD]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < NWD; ++c) wq[c] = 0u;
+        bool ok = !slot_live;
+        sp.n = 0; sp.t0 = 0;
+        while (!ok && !dead) {
+            ok = true;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < NWD; ++c) { const u32x2 v = ld1g(RS_SUM, sumw(par, slot) + 8 * c); wq[c] = v.x; ok = ok && v.y == T; }
+            if (!ok && spin_fail(sp, ctl, 1u, (unsigned)slot, T)) dead = true;
+        }
     };
 
     for (int k = 0; k < a.L; ++k) {
@@ -234,10 +358,10 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         if (k > 0) {
             // ---- the one synchronisation point: my quarter of the sums of iteration k-1, the two rows of A p_{k-1} from the wave above and from the wave below, one
             // word per lane of the columns from the strips to the left / right.  Everything is polled in ONE loop, all loads of a pass in flight together.
-            unsigned w7[7]; float cvl = 0.f, cvr = 0.f;
+            unsigned wq[NWD]; float cvl = 0.f, cvr = 0.f;
             v2f ru0 = Z2, ru1 = Z2, rd0 = Z2, rd1 = Z2;
 #pragma unroll
-            for (int c = 0; c < 7; ++c) w7[c] = 0u;
+            for (int c = 0; c < NWD; ++c) wq[c] = 0u;
             {
                 const bool need_u = xout && has_up, need_d = xout && has_dn, need_s = slot_live;
                 const unsigned usrc = rowh(parp, has_up ? wid - 1 : wid, 1), dsrc = rowh(parp, has_dn ? wid + 1 : wid, 0);
@@ -247,18 +371,23 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                 sp.n = 0; sp.t0 = 0;
                 while (!(ok_s && ok_u && ok_d && ok_cl && ok_cr) && !dead) {
                     asm volatile("" ::: "memory");                     // (every pass re-reads: nothing may be hoisted out of the loop)
-                    u32x4 vs[4], vu[2], vd[2]; u32x2 vcl, vcr;
+                    u32x4 vs[NLD], vu[2], vd[2]; u32x2 vcl, vcr;
                     if (!ok_s) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) vs[c] = ld2g(RS_SUM, ssrc + 16 * c);
+                        for (int c = 0; c < NLD; ++c) vs[c] = ld2g(RS_SUM, ssrc + 16 * c);
                     }
                     if (!ok_u) { vu[0] = ld2g(RS_ROW, usrc); vu[1] = ld2g(RS_ROW, usrc + 16); }
                     if (!ok_d) { vd[0] = ld2g(RS_ROW, dsrc); vd[1] = ld2g(RS_ROW, dsrc + 16); }
                     if (!ok_cl) vcl = ld1g(RS_COL, clsrc);
                     if (!ok_cr) vcr = ld1g(RS_COL, crsrc);
                     if (!ok_s) {
-                        w7[0] = vs[0].x; w7[1] = vs[0].z; w7[2] = vs[1].x; w7[3] = vs[1].z; w7[4] = vs[2].x; w7[5] = vs[2].z; w7[6] = vs[3].x;
-                        ok_s = vs[0].y == Tp && vs[0].w == Tp && vs[1].y == Tp && vs[1].w == Tp && vs[2].y == Tp && vs[2].w == Tp && vs[3].y == Tp;
+                        bool all = true;
+#pragma unroll
+                        for (int c = 0; c < NLD; ++c) {
+                            wq[2 * c] = vs[c].x; all = all && vs[c].y == Tp;
+                            if (2 * c + 1 < NWD) { wq[2 * c + 1] = vs[c].z; all = all && vs[c].w == Tp; }
+                        }
+                        ok_s = all;
                     }
                     if (!ok_u) {
                         ru0 = v2f{ __uint_as_float(vu[0].x), __uint_as_float(vu[0].z) }; ru1 = v2f{ __uint_as_float(vu[1].x), __uint_as_float(vu[1].z) };
@@ -286,115 +415,40 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 #pragma unroll
                 for (int jj = 0; jj < NR; ++jj) Ap[jj] = v2f{ cx[2 * jj], cx[2 * jj + 1] };
             }
-            float ad; double n, a1, b1;
-            exchange_scalars(Tp, w7, ad, n, a1, b1);
-            float aD, bN;
-            scalars_from_sums(aN_prev, ad, n, a1, b1, aD, bN);
-            alpha = safe_div<false>(aN_prev, aD);
-            beta = safe_div<false>(bN, aN_prev);
-            if (writer) { a.words[2 * (k - 1)] = aD; a.words[2 * (k - 1) + 1] = bN; }
-            aN_prev = bN;
+            float ad; double tot[NQ];
+            exchange_scalars(Tp, wq, ad, tot);
+            finish(k - 1, ad, tot);
+            if (LM && stopped) break;                             // (every workgroup takes the same decision: nobody waits for an iteration that nobody runs)
         }
         SR_STAMP(k, 2);
-        // ---- r_k = r_{k-1} - alpha A p_{k-1} ; delta += alpha p_{k-1} ; p_k = r_k + beta p_{k-1}     (every row I hold, halo included; k_pmarch<UPD>'s expressions)
+        // ---- r_k = r_{k-1} - alpha A p_{k-1} ; delta += alpha p_{k-1} ; p_k = M^-1 r_k + beta p_{k-1}     (every row I hold, halo included; k_pmarch<UPD>'s expressions)
 #pragma unroll
         for (int jj = 0; jj < NR; ++jj) {
-            const int t = ya - 2 + jj;
-            const bool ok = nr > 0 && xin && t >= 0 && t < H;
+            const bool ok = row_ok(jj);
             v2f rk = rr[jj];
             if (k > 0) rk = fma2(-alpha, Ap[jj], rk);
             const v2f pv = pp[jj];
-            if (k > 0 && jj >= 2 && jj < R + 2) dl[jj - 2] = fma2(alpha, pv, dl[jj - 2]);
-            const v2f zk = rk;
+            if (k > 0) dl[jj] = fma2(alpha, pv, dl[jj]);
+            const v2f zk = LM ? mi[LM ? jj : 0] * rk : rk;
             v2f v0 = zk + beta * pv;
             v0 = sel(ok, v0, Z2);
             rr[jj] = rk; pp[jj] = v0;
         }
         SR_STAMP(k, 3);
-        // ---- A p_k for my rows (the row step of k_pmarch: dB -> U_h, U_v -> T -> J^T, the Laplacian rows), the four sums
-        v2f acc = Z2; Sums3 sm;
-        {
-            v2f dB[NR], Uh[NR], Uv[NR], Tt[NR], Rr[NR][3];
-            unsigned Fl[NR]; float Cy[NR];
-#pragma unroll
-            for (int jj = 0; jj < NR; ++jj) {
-                const int t = ya - 2 + jj;
-                const bool ok = nr > 0 && xin && t >= 0 && t < H;
-                Fl[jj] = ok ? ((fwx[jj] & 0xffu) | ((fwy[jj] & 0xffu) << 8)) : 0u;
-                Cy[jj] = coef1(cm, t + g.yoff);
-                dB[jj] = Z2; Uh[jj] = Z2; Uv[jj] = Z2; Tt[jj] = Z2;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Rr[jj][c] = Z2;
-            }
-#pragma unroll
-            for (int jj = 1; jj < NR; ++jj) {                       // dB(row jj) from p(jj), p(jj - 1); U_h(jj)
-                const int t = ya - 2 + jj;
-                const bool ok = nr > 0 && xin && t >= 0 && t < H;
-                const v2f v0 = pp[jj], v1 = pp[jj - 1];
-                const v2f vl0 = nbL(v0);
-                const v2f dB0 = sel(ok, gx[jj] * v0 + gy[jj] * vl0 + gz[jj] * v1, Z2);
-                const v2f dBr = nbR(dB0);
-                const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
-                const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
-                const M2 wn0 = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
-                dB[jj] = dB0;
-                Uh[jj] = sel(wn0, wx * (wx * (dB0 - dBr)), Z2);
-            }
-#pragma unroll
-            for (int jj = 1; jj < NR - 1; ++jj) {                   // U_v(jj) from dB(jj), dB(jj + 1); the Laplacian rows R(jj) from p(jj - 1), p(jj), p(jj + 1)
-                const int t = ya - 2 + jj;
-                const bool ok = nr > 0 && xin && t >= 0 && t < H;
-                const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
-                const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
-                const M2 wn = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
-                Uv[jj] = sel(wn, wy * (wy * (dB[jj] - dB[jj + 1])), Z2);
-                const v2f v0 = pp[jj + 1], v1 = pp[jj], v2 = pp[jj - 1];
-                const v2f vl1 = nbL(v1), vr1 = nbR(v1);
-                const float cy0 = Cy[jj + 1], cy1 = Cy[jj], cy2 = Cy[jj - 1];
-                const M2 f2b = bit(Fl[jj], 2u);
-                Rr[jj][0] = sel(f2b, cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0), Z2);
-                Rr[jj][1] = sel(f2b, cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0), Z2);
-                Rr[jj][2] = sel(f2b, cm.ws * (4.0f * v1 - vl1 - v2 - vr1 - v0), Z2);
-            }
-#pragma unroll
-            for (int jj = 2; jj < NR - 1; ++jj) {                   // T(jj)
-                v2f T1 = Uh[jj] + Uv[jj];
-                T1 -= nbL(Uh[jj]);
-                T1 -= Uv[jj - 1];
-                Tt[jj] = T1;
-            }
-#pragma unroll
-            for (int jj = 2; jj < R + 2; ++jj) {                    // output row y = ya + jj - 2
-                const int y = ya - 2 + jj;
-                const v2f T2 = Tt[jj], T1 = Tt[jj + 1];
-                const v2f gT2r = nbR(gy[jj] * T2);
-                v2f Rl[3], Rq[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { Rl[c] = nbL(Rr[jj][c]); Rq[c] = nbR(Rr[jj][c]); }
-                if (jj - 2 < nr && xout) {
-                    const v2f vc = pp[jj];
-                    v2f s = Z2;
-                    s = sel(bit(Fl[jj], 1u), s + cm.wp * (cm.wp * vc), s);
-                    s += gx[jj] * T2;
-                    s = sel(xp1, s + gT2r, s);
-                    if (y + 1 < H) s += gz[jj + 1] * T1;
-                    {
-                        v2f lap;
-                        lap = 4.0f * Rr[jj][0] - Rl[0] - Rr[jj - 1][0] - Rq[0] - Rr[jj + 1][0]; s += cm.ws * (cxc * lap);
-                        lap = 4.0f * Rr[jj][1] - Rl[1] - Rr[jj - 1][1] - Rq[1] - Rr[jj + 1][1]; s += cm.ws * (Cy[jj] * lap);
-                        lap = 4.0f * Rr[jj][2] - Rl[2] - Rr[jj - 1][2] - Rq[2] - Rr[jj + 1][2]; s += cm.ws * (1.0f * lap);
-                    }
-                    acc += vc * s;
-                    const v2f rk = rr[jj];
-                    sm.add(1.0f, rk.x, s.x); sm.add(1.0f, rk.y, s.y);
-                    Ap[jj] = s;
-                    if (lane == 1 || lane == 62) { float* d = &S.cst[wave][lane == 1 ? 0 : 1][2 * (jj - 2)]; d[0] = s.x; d[1] = s.y; }
-                }
-            }
-        }
+        // ---- A p_k for my rows, the sums
+        v2f acc = Z2; Sums3 sm; SumsQ sq;
+        stencil(pp, [&](int jj, v2f vc, v2f s) __attribute__((always_inline)) {
+            if (LM) s += ct[LM ? jj - 2 : 0] * vc;
+            acc += vc * s;
+            const v2f rk = rr[jj], mk = LM ? mi[LM ? jj : 0] : splat(1.0f);
+            sm.add(mk.x, rk.x, s.x); sm.add(mk.y, rk.y, s.y);
+            if (LM) { const v2f b2 = bb[LM ? jj - 2 : 0], dk = dl[jj]; sq.add(dk.x, rk.x, b2.x, vc.x, s.x); sq.add(dk.y, rk.y, b2.y, vc.y, s.y); }
+            Ap[jj] = s;
+            if (lane == 1 || lane == 62) { float* d = &S.cst[wave][lane == 1 ? 0 : 1][2 * (jj - 2)]; d[0] = s.x; d[1] = s.y; }
+        });
         SR_STAMP(k, 4);
         // ---- publish: the boundary rows, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the four
-        // waves up in order and publishes 7 granules)
+        // waves up in order and publishes the record)
         {
             if (xout && has_up) { const unsigned d = rowh(par, wid, 0); st2g(RS_ROW, d, T, Ap[2].x, Ap[2].y); st2g(RS_ROW, d + 16, T, Ap[3].x, Ap[3].y); }
             if (xout && has_dn) { const unsigned d = rowh(par, wid, 1); st2g(RS_ROW, d, T, Ap[R].x, Ap[R].y); st2g(RS_ROW, d + 16, T, Ap[R + 1].x, Ap[R + 1].y); }
@@ -402,8 +456,15 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             if (col_pub && has_lf) st1g(RS_COL, colh(par, wid, 0, lane), T, __float_as_uint(S.cst[wave][0][lane]));
             if (col_pub && has_rt) st1g(RS_COL, colh(par, wid, 1, lane), T, __float_as_uint(S.cst[wave][1][lane]));
             const float accf = acc.x + acc.y;
-            const float wa = wave_sum_all(accf); const double w0 = wave_sum_all_f64(sm.n), w1 = wave_sum_all_f64(sm.s1), w2 = wave_sum_all_f64(sm.s2);
-            if (lane == 0) { S.wa[wave] = wa; S.wd[wave][0] = w0; S.wd[wave][1] = w1; S.wd[wave][2] = w2; }
+            const float wa = wave_sum_all(accf);
+            double wsum[NQ];
+            wsum[0] = wave_sum_all_f64(sm.n); wsum[1] = wave_sum_all_f64(sm.s1); wsum[2] = wave_sum_all_f64(sm.s2);
+            if (LM) { wsum[NQ - 3] = wave_sum_all_f64(sq.u); wsum[NQ - 2] = wave_sum_all_f64(sq.t1); wsum[NQ - 1] = wave_sum_all_f64(sq.t2); }
+            if (lane == 0) {
+                S.wa[wave] = wa;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) S.wd[wave][q] = wsum[q];
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (wave == 0) {
@@ -416,10 +477,18 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                 }
                 dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane < 7) {
-                    float s = 0.0f; double b0 = 0.0, b1 = 0.0, b2 = 0.0;
-                    for (int w = 0; w < 4; ++w) { s += S.wa[w]; b0 += S.wd[w][0]; b1 += S.wd[w][1]; b2 += S.wd[w][2]; }
-                    const double pick = lane < 3 ? b0 : lane < 5 ? b1 : b2;
+                if (lane < NWD) {
+                    float s = 0.0f; double b[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) b[q] = 0.0;
+                    for (int w = 0; w < 4; ++w) {
+                        s += S.wa[w];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) b[q] += S.wd[w][q];
+                    }
+                    double pick = b[0];
+#pragma unroll
+                    for (int q = 1; q < NQ; ++q) if (lane >= 1 + 2 * q) pick = b[q];
                     const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
                     st1g(RS_SUM, sumw(par, blockIdx.x) + 8 * lane, T, word);
                 }
@@ -427,8 +496,25 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         }
         SR_STAMP(k, 5);
     }
-    // ---- what L launches would have left behind: r_{L-1}, p_{L-1}, A p_{L-1}, delta (without its last term); the last iteration's two words
-    if (a.L > 0) {
+    // ---- behind the loop.  Whoever needs alpha of the last iteration (the writer's workgroup: the two words; every workgroup when the update of the unknowns rides along,
+    // and in LM) sweeps the last sums -- unless the zeta test has ended the loop, whose finish is done.
+    const bool need_last = a.L > 0 && !stopped && (id == 0 || a.X != nullptr || LM);
+    if (need_last) {      // (uniform per workgroup: all four waves take part in the sweep)
+        const unsigned T = seq + (unsigned)a.L; const int par = (a.L - 1) & 1;
+        unsigned wq[NWD];
+        sweep_sums(par, T, wq);
+        float ad; double tot[NQ];
+        exchange_scalars(T, wq, ad, tot);
+        finish(a.L - 1, ad, tot);
+    }
+    if (writer) {
+        // the next launch's tags start behind this one's (seq + 1 .. seq + L were used): the counter lives on the device (replay-safe) and is advanced by the one thread
+        // that is through only when every workgroup has published its last sums, i.e. has long read it
+        __hip_atomic_store(ctl + SR_SEQ, seq + (unsigned)a.L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!LM) {
+        // what L launches would have left behind: r_{L-1}, p_{L-1}, A p_{L-1}, delta (without its last term); with X: PCGLinearUpdate (gauss_newton.t:901-906) riding along,
+        // X += delta + alpha_{L-1} p_{L-1} on my rows (k_linear_update's expressions)
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             if (j < nr && xout) {
@@ -436,46 +522,37 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                 *reinterpret_cast<float2*>(a.r_out + i) = make_float2(rr[j + 2].x, rr[j + 2].y);
                 *reinterpret_cast<float2*>(a.p_out + i) = make_float2(pp[j + 2].x, pp[j + 2].y);
                 *reinterpret_cast<float2*>(a.A_out + i) = make_float2(Ap[j + 2].x, Ap[j + 2].y);
-                *reinterpret_cast<float2*>(a.delta + i) = make_float2(dl[j].x, dl[j].y);
-            }
-        }
-        if (id == 0 || a.X != nullptr) {      // (uniform per workgroup: all four waves take part in the last sweep; with the update of the unknowns riding along every workgroup needs alpha_{L-1})
-            const unsigned T = seq + (unsigned)a.L; const int par = (a.L - 1) & 1;
-            unsigned w7[7];
-#pragma unroll
-            for (int c = 0; c < 7; ++c) w7[c] = 0u;
-            bool ok = !slot_live;
-            sp.n = 0; sp.t0 = 0;
-            while (!ok && !dead) {
-                ok = true;
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int c = 0; c < 7; ++c) { const u32x2 v = ld1g(RS_SUM, sumw(par, slot) + 8 * c); w7[c] = v.x; ok = ok && v.y == T; }
-                if (!ok && spin_fail(sp, ctl, 1u, (unsigned)slot, T)) dead = true;
-            }
-            float ad; double n, a1, b1;
-            exchange_scalars(T, w7, ad, n, a1, b1);
-            float aD, bN;
-            scalars_from_sums(aN_prev, ad, n, a1, b1, aD, bN);
-            if (writer) {
-                a.words[2 * (a.L - 1)] = aD; a.words[2 * (a.L - 1) + 1] = bN;
-                // the next launch's tags start behind this one's (seq + 1 .. seq + L were used): the counter lives on the device (replay-safe) and is advanced by the one thread
-                // that is through only when every workgroup has published its last sums, i.e. has long read it
-                __hip_atomic_store(ctl + SR_SEQ, seq + (unsigned)a.L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (a.X != nullptr) {      // PCGLinearUpdate (gauss_newton.t:901-906) riding along: X += delta + alpha_{L-1} p_{L-1} on my rows (k_linear_update's expressions)
-                const float al = safe_div<false>(aN_prev, aD);
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    if (j < nr && xout) {
-                        const long i = (long)(ya + j) * W + x0;
-                        const float2 xo = *reinterpret_cast<const float2*>(a.X + i);
-                        const float d0 = __builtin_fmaf(al, pp[j + 2].x, dl[j].x), d1 = __builtin_fmaf(al, pp[j + 2].y, dl[j].y);
-                        *reinterpret_cast<float2*>(a.X + i) = make_float2(xo.x + d0, xo.y + d1);
-                    }
+                *reinterpret_cast<float2*>(a.delta + i) = make_float2(dl[j + 2].x, dl[j + 2].y);
+                if (a.X != nullptr) {
+                    const float2 xo = *reinterpret_cast<const float2*>(a.X + i);
+                    const float d0 = __builtin_fmaf(alpha, pp[j + 2].x, dl[j + 2].x), d1 = __builtin_fmaf(alpha, pp[j + 2].y, dl[j + 2].y);
+                    *reinterpret_cast<float2*>(a.X + i) = make_float2(xo.x + d0, xo.y + d1);
                 }
             }
         }
+    } else {
+        // LM: the update of delta the loop still owes (thallo_hip_lm_owed_delta: the iteration the loop ended on), then the model cost (thallo.t:3845-3865 expanded:
+        // delta . J^T J delta and delta . b), savePreviousUnknowns (:915-920) and PCGLinearUpdate (:901-906) -- k_pmarch<MODEL>'s launch, from the registers
+        v2f dv[NR];
+#pragma unroll
+        for (int jj = 0; jj < NR; ++jj) { v2f v0 = fma2(alpha, pp[jj], dl[jj]); dv[jj] = sel(row_ok(jj), v0, Z2); }
+        v2f acc = Z2, acc2 = Z2;
+        stencil(dv, [&](int jj, v2f vc, v2f s) __attribute__((always_inline)) { acc += vc * s; acc2 += vc * bb[LM ? jj - 2 : 0]; });
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j < nr && xout) {
+                const long i = (long)(ya + j) * W + x0;
+                const v2f v0 = dv[j + 2];
+                *reinterpret_cast<float2*>(a.delta + i) = make_float2(v0.x, v0.y);
+                const float2 xo2 = *reinterpret_cast<const float2*>(a.X + i);
+                const v2f xo = { xo2.x, xo2.y }, xn = xo + v0;
+                *reinterpret_cast<float2*>(a.prevX + i) = xo2;
+                *reinterpret_cast<float2*>(a.X + i) = make_float2(xn.x, xn.y);
+            }
+        }
+        float vv[2] = { acc.x + acc.y, acc2.x + acc2.y };
+        float* __restrict__ const oo[2] = { a.t0_out, a.t1_out };
+        block_store_partials<2>(vv, oo, S.red);                  // (a workgroup barrier inside: every wave of a live workgroup gets here)
     }
 }
 
@@ -514,25 +591,43 @@ inline SrLayout sr_layout(const SrGeo& g)
 {
     const long waves = (long)g.nstrips * g.nseg;
     SrLayout l;
-    l.ctl = 0; l.sums = 32; l.colh = l.sums + 2L * 8 * THALLO_MAX_PARTIALS; l.rowh = l.colh + 2 * waves * 2 * 64;
+    l.ctl = 0; l.sums = 32; l.colh = l.sums + 2L * SR_REC * THALLO_MAX_PARTIALS; l.rowh = l.colh + 2 * waves * 2 * 64;
     l.bytes = (l.rowh + 2 * waves * 2 * 64 * 4) * (long)sizeof(u64) + 256;
     return l;
 }
 
-template <int R> int sr_launch_r(const SrArgs& a, hipStream_t s)
+template <int R, bool LM> int sr_launch_r(const SrArgs& a, hipStream_t s)
 {
     const int grid = (a.g.total + 7) / 8 * 8;
     {   // co-residency is a precondition, not an assumption: the kernel's workgroups wait for each other (asked once per instantiation)
         static int fits = 0;
         if (fits == 0) {
             int per_cu = 0;
-            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sfs_resident<R>, SR_NT, 0);
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sfs_resident<R, LM>, SR_NT, 0);
             fits = (e == hipSuccess && per_cu >= 1) ? per_cu : -1;
         }
         if (fits < 0 || (long)fits * thallo_hip_device_cu_count() < grid) return -(int)hipErrorNotSupported;
     }
-    hipLaunchKernelGGL((k_sfs_resident<R>), dim3(grid), dim3(SR_NT), 0, s, a);
+    hipLaunchKernelGGL((k_sfs_resident<R, LM>), dim3(grid), dim3(SR_NT), 0, s, a);
     int e = check_launch(); return e ? e : grid;
+}
+template <bool LM> int sr_launch(const SrArgs& a, int R, hipStream_t s)
+{
+    switch (R) {
+        case 2: return sr_launch_r<2, LM>(a, s); case 3: return sr_launch_r<3, LM>(a, s); case 4: return sr_launch_r<4, LM>(a, s); case 5: return sr_launch_r<5, LM>(a, s);
+        default: break;
+    }
+    if (!LM) switch (R) {
+        case 6: return sr_launch_r<6, false>(a, s); case 7: return sr_launch_r<7, false>(a, s); case 8: return sr_launch_r<8, false>(a, s);
+        default: break;
+    }
+    return -(int)hipErrorNotSupported;
+}
+inline void sr_bind(SrArgs& a, void* xbuf)
+{
+    const SrLayout l = sr_layout(a.g);
+    u64* base = reinterpret_cast<u64*>(xbuf);
+    a.b.rowh = base + l.rowh; a.b.colh = base + l.colh; a.b.sums = base + l.sums; a.b.ctl = reinterpret_cast<unsigned*>(base + l.ctl);
 }
 
 }  // namespace
@@ -547,6 +642,7 @@ void thallo_hip_sfs_resident_debug_set(int what, int value) { if (what == 0) g_s
 
 /* rows per wave segment of the resident PCG kernel on a W x H image, or 0: the shape does not fit the chip's registers and the caller runs one launch per PCG iteration */
 int thallo_hip_sfs_resident_rows(int W, int H) { return sr_rows(W, H); }
+int thallo_hip_sfs_resident_rows_lm(int W, int H) { const int R = sr_rows(W, H); return R <= SR_MAX_R_LM ? R : 0; }
 
 /* bytes of exchange memory a plan needs for the resident kernel (zero-filled by the caller once; layout private to this file) */
 long thallo_hip_sfs_resident_bytes(int W, int H)
@@ -571,21 +667,38 @@ int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params
     if (R <= 0) return -(int)hipErrorNotSupported;
     SrArgs a; memset(&a, 0, sizeof(a));
     a.g = make_sr_geo(W, H, yoff, R);
-    {
-        const SrLayout l = sr_layout(a.g);
-        u64* base = reinterpret_cast<u64*>(xbuf);
-        a.b.rowh = base + l.rowh; a.b.colh = base + l.colh; a.b.sums = base + l.sums; a.b.ctl = reinterpret_cast<unsigned*>(base + l.ctl);
-    }
+    sr_bind(a, xbuf);
     a.cm = cam_of(host_params);
     a.G = G; a.Fw = reinterpret_cast<const unsigned*>(Fw);
     a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
     a.aN0 = alphaN0; a.words = words; a.X = X; a.L = L;
-    hipStream_t s = (hipStream_t)stream;
-    switch (R) {
-        case 2: return sr_launch_r<2>(a, s); case 3: return sr_launch_r<3>(a, s); case 4: return sr_launch_r<4>(a, s); case 5: return sr_launch_r<5>(a, s);
-        case 6: return sr_launch_r<6>(a, s); case 7: return sr_launch_r<7>(a, s); case 8: return sr_launch_r<8>(a, s);
-        default: return -(int)hipErrorNotSupported;
-    }
+    return sr_launch<false>(a, R, (hipStream_t)stream);
+}
+
+/* The same for a Levenberg-Marquardt step, with its tail: from what thallo_hip_sfs_pcg_init_lm left (r = b, M^-1 in pre, CtC, zeros in p_prev and delta, alphaN_0 = r . M^-1 r) and
+ * a reset state (thallo_hip_lm_state_reset), at most L iterations of thallo_hip_sfs_pcg_iter_lm -- the zeta test (thallo_hip_lm_zeta's rule, q_tolerance) ends the loop on
+ * the device, in every workgroup alike; lm_state[1] / [2] = gate / iterations done as the launches leave them -- then thallo_hip_sfs_lm_model_cost's launch: the owed update of
+ * delta (written to `delta`), per-workgroup partials of delta . J^T J delta and delta . b (dJJd_out, db_out: the return value says how many), prevX = X, X += delta.
+ * words[2k] = alphaD_k, words[2k + 1] = betaN_k for the iterations that ran.  L must not exceed the residual reset period (gauss_newton.t:1653-1657: no reset inside the
+ * launch).  Bit for bit the launches' results when they run with the same rows per wave.  Replaces gauss_newton.t:1615-1687 + the model-cost part of :1707-1714. */
+int thallo_hip_sfs_pcg_resident_lm(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,
+                                   const float* r_in, const float* p_in, const float* pre, const float* CtC, float* delta,
+                                   thallo_sum_t alphaN0, float* words, float* lm_state, float q_tolerance, float* dJJd_out, float* db_out,
+                                   float* X, float* prevX, void* xbuf, int L, thallo_stream_t stream)
+{
+    if (H < 1 || (W & 1) || W < 2 || L < 1 || !host_params) return -(int)hipErrorInvalidValue;
+    if (!G || !Fw || !r_in || !p_in || !pre || !CtC || !delta || !words || !lm_state || !dJJd_out || !db_out || !X || !prevX || !xbuf || !alphaN0.partials) return -(int)hipErrorInvalidValue;
+    const int R = sr_rows(W, H);
+    if (R <= 0 || R > SR_MAX_R_LM) return -(int)hipErrorNotSupported;
+    SrArgs a; memset(&a, 0, sizeof(a));
+    a.g = make_sr_geo(W, H, yoff, R);
+    sr_bind(a, xbuf);
+    a.cm = cam_of(host_params);
+    a.G = G; a.Fw = reinterpret_cast<const unsigned*>(Fw);
+    a.r_in = r_in; a.p_in = p_in; a.delta = delta;
+    a.aN0 = alphaN0; a.words = words; a.X = X; a.L = L;
+    a.pre = pre; a.ctc = CtC; a.state = lm_state; a.q_tol = q_tolerance; a.prevX = prevX; a.t0_out = dJJd_out; a.t1_out = db_out;
+    return sr_launch<true>(a, R, (hipStream_t)stream);
 }
 
 /* the error word of a plan's resident launches: 1 = a bounded wait ran out (a workgroup was not resident, or a granule never arrived); clear != 0 resets it.

@@ -188,6 +188,10 @@ public:
     virtual bool resident_ok() const { return false; }
     virtual int  pcg_resident(LaunchCtx&, SolverVectors&, int /*L*/, thallo_sum_t /*alphaN0*/, float* /*words*/) { return -1; }
     virtual bool resident_updates_unknowns() const { return false; }                            // PCGLinearUpdate rides in the resident launch (the driver skips its own, and calls unknowns_written())
+    // ... an LM step's PCG loop, zeta test, owed delta update, model cost (partials of delta . J^T J delta, delta . b), savePreviousUnknowns and PCGLinearUpdate in one launch
+    // (thallo_hip_sfs_pcg_resident_lm): behind pcg_init_lm and a reset state; L within one residual-reset period
+    virtual bool resident_lm_ok() const { return false; }
+    virtual int  pcg_resident_lm(LaunchCtx&, SolverVectors&, int /*L*/, thallo_sum_t /*alphaN0*/, float* /*words*/, float* /*lm_state*/, float /*q_tol*/, float* /*dJJd_out*/, float* /*db_out*/) { return -1; }
     virtual int  resident_status(LaunchCtx&, int /*clear*/, unsigned* /*pm*/) { return 0; }      // 1: a bounded wait inside the kernel ran out
     virtual void resident_disable() {}                                                          // ... after which the plan stays on one launch per PCG iteration
     // ... for one rank's row slab on the device-side transport (thallo_hip_iw_pcg_resident_dist): boundary rows of A p straight into the neighbours' ghost areas

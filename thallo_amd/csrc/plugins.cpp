@@ -1096,6 +1096,15 @@ public:
                                            resident_updates_unknowns() ? X : nullptr, xres_.ptr, L, c.stream);
     }
     bool resident_updates_unknowns() const override { const char* e = env_switch("THALLO_SFS_RESIDENT_FOLD"); return !(e && e[0] == '0'); }
+    bool resident_lm_ok() const override { return resident_ && packed() && thallo_hip_sfs_resident_rows_lm(W, H) > 0; }
+    int pcg_resident_lm(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words, float* lm_state, float q_tol, float* dJJd_out, float* db_out) override
+    {
+        TimedLaunch t(c, "PCGLoopResident");
+        const int rc = thallo_hip_sfs_pcg_resident_lm(W, H, yoff_, hp, (const float*)G.ptr, (const float*)Wt.ptr, v.r, v.p[0], v.pre, v.CtC, v.delta, aN0, words, lm_state, q_tol, dJJd_out, db_out,
+                                                      X, v.prevX, xres_.ptr, L, c.stream);
+        if (rc >= 0) unknowns_written();
+        return rc;
+    }
     int resident_status(LaunchCtx& c, int clear, unsigned* pm) override { return xres_.ptr ? thallo_hip_sfs_resident_status(xres_.ptr, clear, -1, pm, c.stream) : 0; }
     void resident_disable() override { resident_ = false; resident_broken_ = true; }
     // GN on one GPU: one launch per PCG iteration (the marching kernel with PCGUpdate riding along; r, Ap, p ping-pong).  Across ranks: the flat form.

@@ -903,7 +903,10 @@ int Plan::step_lm(int ev_iter)
     const int period = sp.residual_reset_period > 0 ? sp.residual_reset_period : (1 << 30);
     // Plugins whose iteration can start from a reset residual (lm_iter_after_reset; bundle adjustment's three-launch form) run any L: every residual_reset_period-th iteration
     // is followed by the reference's reset (:1653-1657) as launches of its own, below.
-    const bool one_kernel_lm = !slab && lm_fold_p_ && fold_ctc && plugin->lm_one_kernel() && L >= 1 && (L <= period || plugin->lm_iter_after_reset()) && v_.p[1] != nullptr &&
+    // round 6: the loop, the zeta test, the owed update of delta, the model cost and the update of the unknowns in ONE resident launch (plugins whose state fits the chip's
+    // registers: shape_from_shading at the size of the reference's data set); lIterations within one residual-reset period.  THALLO_RESIDENT=0: the launches below (A/B).
+    const bool resident_lm = !slab && fold_init && lm_fold_step_ && lm_fold_p_ && fold_ctc && one_kernel_ && plugin->resident_lm_ok() && L >= 1 && L <= period;
+    const bool one_kernel_lm = !resident_lm && !slab && lm_fold_p_ && fold_ctc && plugin->lm_one_kernel() && L >= 1 && (L <= period || plugin->lm_iter_after_reset()) && v_.p[1] != nullptr &&
                                ensure_iter_buffers() == 0;
     // ... and on a row slab of a multi-GPU run (device-side transport; plugins whose pcg_iter_lm keeps the ghost rows current): the launch stores partials only, ONE
     // exchange per LM iteration carries the 13 sums and the boundary rows of the new A p, finishes alphaD_k, betaN_k, q_{k+1} and applies the zeta test
@@ -929,6 +932,17 @@ int Plan::step_lm(int ev_iter)
         if (!coll_failed && !skip()) {
             TimedLaunch t(ctx, "PCGUpdate");
             check(thallo_hip_lm_owed_delta(v_.delta + o, v_.p[1] + o, v_.p[0] + o, n, scal(B), scal(B + 1), 2, lmst, L, s), "PCGUpdate (owed delta) launch");
+        }
+    }
+    if (resident_lm) {
+        cur_ = 0;
+        finish(B);
+        nb = plugin->pcg_resident_lm(ctx, v_, L, sum(B), scal(B + 1), lmst, sp.q_tolerance, slot(T0), slot(T1));
+        check(nb, "PCGLoopResident (LM) launch");
+        if (!failed) {
+            for (int k = 0; k < L; ++k) { const int jD = B + 2 * k + 1, jB = jD + 1; set_nb(jD, 1); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
+            set_nb(T0, nb); set_nb(T1, nb);
+            model_cost_done = true; k_done = L; resident_used_ = true;
         }
     }
     if (one_kernel_lm) {
@@ -992,7 +1006,7 @@ int Plan::step_lm(int ev_iter)
             check(thallo_hip_lm_owed_delta(v_.delta, v_.p[1], v_.p[0], n, scal(B), scal(B + 1), 2, lmst, L, s), "PCGUpdate (owed delta) launch");
         }
     }
-    for (int k = 0; !one_kernel_lm && !one_kernel_lm_slab && k < L && !failed && !coll_failed; ++k) {
+    for (int k = 0; !resident_lm && !one_kernel_lm && !one_kernel_lm_slab && k < L && !failed && !coll_failed; ++k) {
         const int jN = B + 2 * k, jD = jN + 1, jB = jN + 2;
         if (!skip()) {
             if (fold_p) {                                             // PCGStep3 + PCGStep1 + PCGStep1_Finish in one launch; p ping-pongs between the two buffers

@@ -43,13 +43,13 @@ __device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsig
 enum { SR_SEQ = 0, SR_ERR = 1, SR_SPIN_MS = 2, SR_PM = 4, SR_CTL_WORDS = 16 };
 constexpr int SR_REC = 16;                // granules per sums record (7 used by GN, 13 by LM)
 
-struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total; };
+struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total, ab; };      // ab: A/B bits (tools): 1 = row granules row-major (a wave's 16-byte loads contiguous), 2 = 128-byte sums records in GN too
 
 // exchange buffers of one plan (thallo_hip_sfs_resident_bytes); parity = iteration & 1
 struct SrBufs {
     u64* rowh;        // [2 parity][waves][2 sides: 0 = the wave's FIRST two rows (for the wave above), 1 = its LAST two (for the wave below)][64 lanes][4: row a px 0, px 1, row b px 0, px 1]
     u64* colh;        // [2 parity][waves][2 sides: 0 = lane 1's pixels (for the strip to the left), 1 = lane 62's (for the strip to the right)][64: word 2 * row + pixel]
-    u64* sums;        // [2 parity][1024 workgroups][16: alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo (LM: U, T1, T2 hi / lo), -]
+    u64* sums;        // [2 parity][1024 workgroups][8 (LM: 16): alphaD, N hi, N lo, S1 hi, S1 lo, S2 hi, S2 lo (LM: U, T1, T2 hi / lo), -]
     unsigned* ctl;    // SR_CTL_WORDS
 };
 
@@ -158,9 +158,15 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     const bool has_lf = nr > 0 && strip > 0, has_rt = nr > 0 && strip + 1 < g.nstrips;
     const long waves = (long)g.nstrips * g.nseg;
     const rsrc_t RS_ROW = make_xrsrc(a.b.rowh), RS_COL = make_xrsrc(a.b.colh), RS_SUM = make_xrsrc(a.b.sums);
-    auto rowh = [&](int par, int w, int side) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + lane) * 32); };      // this lane's 4 granules
+    // (a lane's two 16-byte pieces side by side: its two loads ask for ONE line.  Measured, same box, 640 x 480 GN through Thallo_ProblemStep: 8.23 us per PCG iteration against
+    //  9.08 with the rows stored row-major -- a wave's 64 x 16 bytes of one load instruction contiguous, the lane's second piece 1 KB away; tools/sfs_resident_probe.py ab)
+    const unsigned row2 = (g.ab & 1) ? 1024u : 16u, rowl = (g.ab & 1) ? 16u : 32u;
+    auto rowh = [&](int par, int w, int side) { return (unsigned)((((long)par * waves + w) * 2 + side) * 2048 + lane * rowl); };      // this lane's granules: two at +0 (the first row), two at +1024 (the second): a wave's 16-byte accesses are contiguous
     auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + i) * 8); };
-    auto sumw = [&](int par, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * SR_REC) * 8); };              // a workgroup's record
+    // a workgroup's record: [par][slot][words]; 64 bytes (GN: two records per 128-byte line) or 128 (LM).  (Measured and dropped: the record stored word-pair-major, so that a
+    // sweeping wave reads 1 KB of contiguous memory per load instruction -- a record's pieces then sit in 4 / 7 lines that eight workgroups of different XCDs write into:
+    // GN 68.8 -> 84.2 us per 10-iteration launch at 640 x 480, LM 118 -> 114.7.  And a 128-byte stride for GN's 56 bytes: 68.8 -> 77: the cost is per 128-byte line touched.)
+    auto sumw = [&](int par, int c, int slot) { return (unsigned)((((long)par * THALLO_MAX_PARTIALS + slot) * ((LM || (g.ab & 2)) ? SR_REC : SR_REC / 2)) * 8 + c * 16); };
     // which column word this lane fetches at the synchronisation point, and where it belongs (S.crx word 2 * jj + pixel):
     //   lanes 0 .. 2R-1: my own rows, from the strip beside me; 2R .. 2R+3: the two rows above, from the strip beside the wave above (its last two rows);
     //   2R+4 .. 2R+7: the two rows below, from the strip beside the wave below (its first two rows)
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             ok = true;
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int c = 0; c < NWD; ++c) { const u32x2 v = ld1g(RS_SUM, sumw(par, slot) + 8 * c); wq[c] = v.x; ok = ok && v.y == T; }
+            for (int c = 0; c < NWD; ++c) { const u32x2 v = ld1g(RS_SUM, sumw(par, c >> 1, slot) + 8 * (c & 1)); wq[c] = v.x; ok = ok && v.y == T; }
             if (!ok && spin_fail(sp, ctl, 1u, (unsigned)slot, T)) dead = true;
         }
     };
@@ -365,7 +371,6 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             {
                 const bool need_u = xout && has_up, need_d = xout && has_dn, need_s = slot_live;
                 const unsigned usrc = rowh(parp, has_up ? wid - 1 : wid, 1), dsrc = rowh(parp, has_dn ? wid + 1 : wid, 0);
-                const unsigned ssrc = sumw(parp, slot);
                 const unsigned clsrc = colh(parp, need_cl ? wid - g.nseg + c_dw : wid, 1, c_word), crsrc = colh(parp, need_cr ? wid + g.nseg + c_dw : wid, 0, c_word);
                 bool ok_s = !need_s, ok_u = !need_u, ok_d = !need_d, ok_cl = !need_cl, ok_cr = !need_cr;
                 sp.n = 0; sp.t0 = 0;
@@ -374,10 +379,10 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
                     u32x4 vs[NLD], vu[2], vd[2]; u32x2 vcl, vcr;
                     if (!ok_s) {
 #pragma unroll
-                        for (int c = 0; c < NLD; ++c) vs[c] = ld2g(RS_SUM, ssrc + 16 * c);
+                        for (int c = 0; c < NLD; ++c) vs[c] = ld2g(RS_SUM, sumw(parp, c, slot));
                     }
-                    if (!ok_u) { vu[0] = ld2g(RS_ROW, usrc); vu[1] = ld2g(RS_ROW, usrc + 16); }
-                    if (!ok_d) { vd[0] = ld2g(RS_ROW, dsrc); vd[1] = ld2g(RS_ROW, dsrc + 16); }
+                    if (!ok_u) { vu[0] = ld2g(RS_ROW, usrc); vu[1] = ld2g(RS_ROW, usrc + row2); }
+                    if (!ok_d) { vd[0] = ld2g(RS_ROW, dsrc); vd[1] = ld2g(RS_ROW, dsrc + row2); }
                     if (!ok_cl) vcl = ld1g(RS_COL, clsrc);
                     if (!ok_cr) vcr = ld1g(RS_COL, crsrc);
                     if (!ok_s) {
@@ -450,8 +455,8 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         // ---- publish: the boundary rows, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the four
         // waves up in order and publishes the record)
         {
-            if (xout && has_up) { const unsigned d = rowh(par, wid, 0); st2g(RS_ROW, d, T, Ap[2].x, Ap[2].y); st2g(RS_ROW, d + 16, T, Ap[3].x, Ap[3].y); }
-            if (xout && has_dn) { const unsigned d = rowh(par, wid, 1); st2g(RS_ROW, d, T, Ap[R].x, Ap[R].y); st2g(RS_ROW, d + 16, T, Ap[R + 1].x, Ap[R + 1].y); }
+            if (xout && has_up) { const unsigned d = rowh(par, wid, 0); st2g(RS_ROW, d, T, Ap[2].x, Ap[2].y); st2g(RS_ROW, d + row2, T, Ap[3].x, Ap[3].y); }
+            if (xout && has_dn) { const unsigned d = rowh(par, wid, 1); st2g(RS_ROW, d, T, Ap[R].x, Ap[R].y); st2g(RS_ROW, d + row2, T, Ap[R + 1].x, Ap[R + 1].y); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the columns written to LDS above)
             if (col_pub && has_lf) st1g(RS_COL, colh(par, wid, 0, lane), T, __float_as_uint(S.cst[wave][0][lane]));
             if (col_pub && has_rt) st1g(RS_COL, colh(par, wid, 1, lane), T, __float_as_uint(S.cst[wave][1][lane]));
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 #pragma unroll
                     for (int q = 1; q < NQ; ++q) if (lane >= 1 + 2 * q) pick = b[q];
                     const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
-                    st1g(RS_SUM, sumw(par, blockIdx.x) + 8 * lane, T, word);
+                    st1g(RS_SUM, sumw(par, lane >> 1, blockIdx.x) + 8 * (lane & 1), T, word);
                 }
             }
         }
@@ -556,9 +561,11 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     }
 }
 
+int g_sr_ab = 0;         // tools: A/B bits of the exchange layout (SrGeo::ab)
+
 inline SrGeo make_sr_geo(int W, int H, int yoff, int R)
 {
-    SrGeo g; g.W = W; g.H = H; g.yoff = yoff; g.R = R;
+    SrGeo g; g.W = W; g.H = H; g.yoff = yoff; g.R = R; g.ab = g_sr_ab;
     g.nstrips = (W + PM_USE - 1) / PM_USE;
     g.nseg = (H + R - 1) / R;
     g.nwgrow = (g.nseg + SR_NT / 64 - 1) / (SR_NT / 64);
@@ -638,7 +645,7 @@ extern "C" {
 int thallo_hip_debug_stamps_sfs_resident(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_sr), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
 #endif
 
-void thallo_hip_sfs_resident_debug_set(int what, int value) { if (what == 0) g_sr_rows = value; if (what == 1) g_sr_cap = value; }
+void thallo_hip_sfs_resident_debug_set(int what, int value) { if (what == 0) g_sr_rows = value; if (what == 1) g_sr_cap = value; if (what == 2) g_sr_ab = value; }
 
 /* rows per wave segment of the resident PCG kernel on a W x H image, or 0: the shape does not fit the chip's registers and the caller runs one launch per PCG iteration */
 int thallo_hip_sfs_resident_rows(int W, int H) { return sr_rows(W, H); }

@@ -15,15 +15,17 @@ def run(resident, n):
     os.environ["THALLO_RESIDENT"] = "1" if resident else "0"
     L.thallo_hip_sfs_march_debug_set(0, R)
     dev = to_device(copy_params(p))
-    s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"))
-    s.set_solver_parameters(nIterations=n, lIterations=lit)
+    lm = os.environ.get("SRP_LM") == "1"            # the LM step's resident launch instead of the GN loop's
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), **({"solverkind": "levenberg_marquardt"} if lm else {}))
+    if lm: s.enable_lm()
+    s.set_solver_parameters(nIterations=n, lIterations=lit, **({"q_tolerance": 0.0} if lm else {}))
     prm = s.make_params(dev); s.init(prm)
     tr = []
     while s.step(prm): tr.append(s.alpha_beta_trace())
     c = s.current_cost(); s.close()
     L.thallo_hip_sfs_march_debug_set(0, 0)
     return to_host(dev[16]).copy(), tr, c
-for n in (range(1, nit + 1) if not (len(sys.argv) > 5 and sys.argv[5] in ("kernel", "stamps")) else []):
+for n in (range(1, nit + 1) if not (len(sys.argv) > 5 and sys.argv[5] in ("kernel", "stamps", "ab")) else []):
     for rep in range(2):
         xa, ta, ca = run(True, n); xb, tb, cb = run(False, n)
         d = np.argwhere(xa != xb)
@@ -110,3 +112,27 @@ def stamps():
 
 if len(sys.argv) > 5 and sys.argv[5] == "stamps":
     stamps()
+
+
+def ab_time():
+    """GN and LM steps at A/B settings of the exchange layout (thallo_hip_sfs_resident_debug_set(2, bits)), one box: us per PCG iteration through Thallo_ProblemStep"""
+    import time
+    for lm in (0, 1):
+        for bits in (0, 1, 2, 3, 0):
+            L.thallo_hip_sfs_resident_debug_set(2, bits)
+            dev = to_device(copy_params(p))
+            s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), timing_level=0, **({"solverkind": "levenberg_marquardt"} if lm else {}))
+            if lm: s.enable_lm()
+            s.set_solver_parameters(nIterations=40, lIterations=lit, **({"q_tolerance": 0.0} if lm else {}))
+            prm = s.make_params(dev); s.init(prm)
+            for _ in range(3): s.step(prm)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(30): s.step(prm)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            print("LM" if lm else "GN", "ab bits", bits, "us per PCG iteration %.2f" % (dt / 30 / lit * 1e6), "cost", s.current_cost(), flush=True)
+            s.close()
+    L.thallo_hip_sfs_resident_debug_set(2, 0)
+
+
+if len(sys.argv) > 5 and sys.argv[5] == "ab":
+    ab_time()

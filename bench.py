@@ -190,7 +190,7 @@ def main():
     if "THALLO_PERSIST_RES" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(1, int(os.environ["THALLO_PERSIST_RES"]))
     if "THALLO_PERSIST_OCC" in os.environ: _L.thallo_hip_iw_march_persist_debug_set(2, int(os.environ["THALLO_PERSIST_OCC"]))
     dev = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in p]
-    s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=0)
+    s = thallo_amd.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"), timing_level=1)      # (1: the coarse events -- eight per GN step of L PCG iterations -- that performance_summary() below reads; level 0 records nothing since round 6)
     s.set_solver_parameters(nIterations=K + Wm, lIterations=L_it)
     params = s.make_params(dev)
     s.init(params)

@@ -200,6 +200,22 @@ def test_image_warping_cost_trajectory(torch, orc, monkeypatch, W, H, nit, lit, 
     assert (to_host(dev[0])[m] == p[0][m]).all() and (to_host(dev[1])[m] == p[1][m]).all()
 
 
+def test_bench_py_single_gpu_line(torch):
+    """bench.py as the driver runs it (N = 1), shortened: one JSON line with the contract's keys, the roofline object computed from this run's own events and the CPU baseline leg
+    (round 6: the line broke once when timingLevel 0 stopped recording the coarse events bench.py reads -- nothing in the suite ran it on one GPU)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-small"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["metric"] == "pcg_iters_per_sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 1000 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0.3 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6, rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"], cb
+
+
 @pytest.mark.parametrize("W,H,lit", [(512, 512, 100), (2048, 256, 40), (2048, 512, 40), (1024, 1024, 25), (1200, 800, 16), (256, 256, 30), (640, 480, 25), (130, 7, 12), (124, 64, 9), (250, 2, 5), (126, 130, 7)])
 def test_resident_pcg_loop_is_bitwise_the_marching_kernel(torch, monkeypatch, W, H, lit):
     """the whole PCG loop of a GN step in ONE launch -- r, p, A p in registers, the boundary of A p to the four neighbouring waves and

@@ -418,7 +418,7 @@ long thallo_hip_iw_resident_ghost_bytes(int W);
 int  thallo_hip_iw_pcg_resident_dist(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
                                      const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
                                      thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, thallo_dist_t d, long ghost_off, int slot0, int L, thallo_stream_t stream);
-void thallo_hip_resident_debug_set(int what, int value);    /* tools / tests only: 0 rows per wave segment, 1 workgroup budget */
+void thallo_hip_resident_debug_set(int what, int value);    /* tools / tests only: 0 rows per wave segment, 1 workgroup budget, 2 fault injection (one workgroup withholds its sums of iteration 2), 3 the waits' bound in ms for the next launches (-1: leave) */
 /* rows per wave segment the marching kernels use on `rows` owned rows of a W-wide image; 0 = more column strips than the device has workgroup
  * slots: the marching entry points return -hipErrorNotSupported, the caller stays on thallo_hip_iw_pcg_iter (host logic, no launch) */
 int thallo_hip_iw_march_rows(int W, int rows);
@@ -603,7 +603,8 @@ int thallo_hip_sfs_planes_layout(int W, int H);
  * does not fit (the caller runs one launch per PCG iteration).  xbuf: thallo_hip_sfs_resident_bytes() bytes, zeroed once by the caller, private to the plan.  Returns the number of
  * workgroups, -hipErrorNotSupported when the shape does not fit.  thallo_hip_sfs_resident_status: 1 = a bounded wait inside the kernel ran out (the steps since the last
  * check are void; pm: 5 words of post-mortem, may be NULL); clear != 0 resets; spin_ms >= 0 sets the bound (0 = the 2 s default); synchronises the stream.
- * thallo_hip_sfs_resident_debug_set (tools / tests): 0 = rows per segment, 1 = workgroup budget (0 = automatic).  Replaces gauss_newton.t:1615-1687 for these shapes. */
+ * thallo_hip_sfs_resident_debug_set (tools / tests): 0 = rows per segment, 1 = workgroup budget (0 = automatic), 2 = A/B bits of the exchange layout (4: fault injection -- one
+ * workgroup withholds its sums of iteration 2), 3 = the bound of the kernel's waits in ms for the next launches (-1: leave).  Replaces gauss_newton.t:1615-1687 for these shapes. */
 int thallo_hip_sfs_resident_rows(int W, int H);
 long thallo_hip_sfs_resident_bytes(int W, int H);
 int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,

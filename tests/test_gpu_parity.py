@@ -7,6 +7,7 @@ Bars: integer/quantised outputs (gold PNG bytes) exact; float trajectories withi
 """
 import ctypes as C
 import json
+import time
 import os
 
 import numpy as np
@@ -198,6 +199,43 @@ def test_image_warping_cost_trajectory(torch, orc, monkeypatch, W, H, nit, lit, 
     # excluded (masked) pixels are never touched (image_warping.t:14-15)
     m = p[4] != 0
     assert (to_host(dev[0])[m] == p[0][m]).all() and (to_host(dev[1])[m] == p[1][m]).all()
+
+
+def test_image_warping_resident_loop_reports_a_wait_that_ran_out(torch):
+    """The resident PCG loop's workgroups wait for each other; every wait is bounded, and one that runs out ends the launch, reaches the caller as an error at the next cost
+    evaluation and turns the plan to one launch per PCG iteration -- never a hang.  Fault injection (thallo_hip_resident_debug_set(2, 1)): one workgroup withholds its sums
+    of iteration 2; the bound is 30 ms.  A fresh Init on the same plan then runs the launches and lands on the undisturbed result."""
+    W, H = 512, 128
+    L = thallo_amd.lib()
+    p = syn.image_warping(W, H)
+    def solve(s, dev):
+        s.set_solver_parameters(nIterations=3, lIterations=12)
+        prm = s.make_params(dev); s.init(prm)
+        costs = [s.current_cost()]
+        while s.step(prm): costs.append(s.current_cost())
+        return costs
+    s0 = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    ref = solve(s0, to_device(copy_params(p))); names0 = {k for k, v in s0.kernel_stats().items() if v["launches"]}; s0.close()
+    assert "PCGLoopResident" in names0 and len(ref) == 4 and all(np.isfinite(ref)), (names0, ref)
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("image_warping"))
+    L.thallo_hip_resident_debug_set(2, 1); L.thallo_hip_resident_debug_set(3, 30)
+    try:
+        t0 = time.time()
+        s.set_solver_parameters(nIterations=3, lIterations=12)
+        prm = s.make_params(to_device(copy_params(p))); s.init(prm)
+        s.step(prm)
+        c = s.current_cost()
+        dt = time.time() - t0
+    finally:
+        L.thallo_hip_resident_debug_set(2, 0); L.thallo_hip_resident_debug_set(3, 0)
+    err = api.last_error() or ""
+    assert "bounded wait inside the resident PCG kernel ran out" in err and "image_warping" in err and not np.isfinite(c), (err, c)
+    assert dt < 20.0, dt
+    again = solve(s, to_device(copy_params(p)))
+    names = {k for k, v in s.kernel_stats().items() if v["launches"]}
+    s.close()
+    assert "PCGIteration" in names, names
+    assert len(again) == len(ref) and np.abs(np.array(again) - np.array(ref)).max() <= 1e-4 * np.abs(np.array(ref)).max(), (again, ref)
 
 
 def test_bench_py_single_gpu_line(torch):
@@ -1890,6 +1928,54 @@ def test_shape_from_shading_resident_lm_step_is_bitwise_the_launches(torch, orc,
         co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=nit, lIterations=lit, use_lm=1, trust_region_radius=radius, q_tolerance=qtol)
         m = min(len(co), len(c0))
         assert m >= 2 and (np.abs(np.array(c0[:m]) - co[:m]) <= 2e-4 * np.abs(co[:m]) + 1e-9).all(), (c0, co)
+
+
+@pytest.mark.parametrize("lm", [0, 1])
+def test_shape_from_shading_resident_loop_reports_a_wait_that_ran_out(torch, lm):
+    """The resident loops' workgroups wait for each other; every wait is bounded, and one that runs out must end the launch, reach the caller as an error and turn the plan to
+    one launch per PCG iteration -- never a hang.  Fault injection (thallo_hip_sfs_resident_debug_set(2, 4)): one workgroup withholds its sums of iteration 2, which is what a
+    workgroup that is not resident looks like to the others; the bound is set to 30 ms.  The solve that follows a fresh Init on the same plan runs the launches and lands on the
+    undisturbed result."""
+    W, H = 250, 130
+    L = thallo_amd.lib()
+    p = syn.shape_from_shading(W, H)
+    kw = {"solverkind": "levenberg_marquardt"} if lm else {}
+    def solve(s, dev, n=3):
+        s.set_solver_parameters(nIterations=n, lIterations=10)
+        prm = s.make_params(dev); s.init(prm)
+        costs = [s.current_cost()]
+        while s.step(prm): costs.append(s.current_cost())
+        return costs
+    ref_dev = to_device(copy_params(p))
+    s0 = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), **kw)
+    if lm: s0.enable_lm()
+    ref = solve(s0, ref_dev); s0.close()
+    assert len(ref) == 4 and all(np.isfinite(ref))
+    dev = to_device(copy_params(p))
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), **kw)
+    if lm: s.enable_lm()
+    s.set_kernel_sampling(1)
+    L.thallo_hip_sfs_resident_debug_set(2, 4); L.thallo_hip_sfs_resident_debug_set(3, 30)
+    try:
+        t0 = time.time()
+        s.set_solver_parameters(nIterations=3, lIterations=10)
+        prm = s.make_params(dev); s.init(prm)
+        ok = s.step(prm)
+        c = s.current_cost()
+        dt = time.time() - t0
+    finally:
+        L.thallo_hip_sfs_resident_debug_set(2, 0); L.thallo_hip_sfs_resident_debug_set(3, 0)
+    err = api.last_error() or ""
+    assert "bounded wait inside the resident PCG kernel ran out" in err and "shape_from_shading" in err, err
+    assert (not ok) or not np.isfinite(c), (ok, c)            # (LM: the step itself fails; GN: the cost evaluation behind it reports the voided step)
+    assert dt < 20.0, dt                                       # (bounded: 30 ms per wait, not the default 2 s, and never a hang)
+    # the same plan, a fresh Init from the undisturbed unknowns: one launch per PCG iteration now, the same trajectory to rounding
+    dev2 = to_device(copy_params(p))
+    again = solve(s, dev2)
+    names = {k for k, v in s.kernel_stats().items() if v["launches"]}
+    s.close()
+    assert "PCGIteration" in names, names
+    assert len(again) == len(ref) and np.abs(np.array(again) - np.array(ref)).max() <= 2e-4 * np.abs(np.array(ref)).max(), (again, ref)
 
 
 def test_shape_from_shading_lm_step_folds(torch, monkeypatch):

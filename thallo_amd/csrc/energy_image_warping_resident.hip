@@ -83,6 +83,7 @@ struct ResArgs {
     float* words;                                 // words[2k] = alphaD_k, words[2k + 1] = betaN_k  (the plan's scal(B + 2k + 1), scal(B + 2k + 2))
     const int* irregular;
     int L;
+    int fault;                                    // tests: workgroup 1 never publishes the sums of iteration 2 (what a workgroup that is not resident looks like to the others)
 };
 
 namespace {
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                     for (int w = 0; w < 4; ++w) { s += S.wa[w]; b0 += S.wd[w][0]; b1 += S.wd[w][1]; b2 += S.wd[w][2]; }
                     const double pick = lane < 3 ? b0 : lane < 5 ? b1 : b2;
                     const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
-                    st1g(RS_SUM, sumw(par, blockIdx.x) + 8 * lane, T, word);
+                    if (!(a.fault && id == 1 && k == 2)) st1g(RS_SUM, sumw(par, blockIdx.x) + 8 * lane, T, word);
                 }
             }
         }
@@ -654,6 +655,8 @@ inline ResGeo make_res_geo(int W, int H, int row0, int row1, int R)
 
 int g_res_cap = 0;       // tests: workgroup budget (0 = the device's CU count: one workgroup per CU, all of them resident at once)
 int g_res_rows = 0;      // tests / tools: rows per segment (0 = automatic)
+int g_res_fault = 0;     // tests: fault injection (ResArgs::fault)
+int g_res_spin_ms = -1;  // tests: the bound of the kernel's waits in ms, written in front of the next launch (-1: leave the plan's control word)
 
 // rows per wave segment, or 0 = the shape does not fit.  below: the slab has a ghost row under its last owned row (a rank below) -- the last segment must
 // then be a full one (its row below sits at a fixed place in the wave's registers)
@@ -712,6 +715,7 @@ int res_launch(const ResArgs& a, int R, hipStream_t s)
         }
         if (f < 0 || (long)f * thallo_hip_device_cu_count() < grid) return -(int)hipErrorNotSupported;
     }
+    if (g_res_spin_ms >= 0) { const unsigned v = (unsigned)g_res_spin_ms; if (hipMemcpyAsync(a.b.ctl + RES_SPIN_MS, &v, sizeof(v), hipMemcpyHostToDevice, s) != hipSuccess) return -(int)hipErrorUnknown; }
     hipLaunchKernelGGL(k_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)a.L);
 #define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR, DIST>), dim3(grid), dim3(RES_NT), lds, s, a)
     switch (R) {
@@ -732,7 +736,7 @@ extern "C" {
 int thallo_hip_debug_stamps_resident(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_r), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
 #endif
 
-void thallo_hip_resident_debug_set(int what, int value) { if (what == 0) g_res_rows = value; if (what == 1) g_res_cap = value; }
+void thallo_hip_resident_debug_set(int what, int value) { if (what == 0) g_res_rows = value; if (what == 1) g_res_cap = value; if (what == 2) g_res_fault = value; if (what == 3) g_res_spin_ms = value; }
 
 /* rows per wave segment of the resident PCG kernel on `rows` owned rows of a W-wide image, or 0: the shape does not fit the chip's registers
  * (more than RES_MAX_R rows per wave at one workgroup per CU) and the caller runs one launch per PCG iteration.  below != 0: a row slab with a rank below. */
@@ -769,7 +773,7 @@ int thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs
     res_bufs(xbuf, a.g, a.b);
     a.cs = cs; a.flags = flags; a.wf2 = w_fit * w_fit; a.wr2 = w_reg * w_reg;
     a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
-    a.aN0 = alphaN0; a.words = words; a.irregular = irregular; a.L = L;
+    a.aN0 = alphaN0; a.words = words; a.irregular = irregular; a.L = L; a.fault = g_res_fault;
     return res_launch<false>(a, R, (hipStream_t)stream);
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsig
 enum { SR_SEQ = 0, SR_ERR = 1, SR_SPIN_MS = 2, SR_PM = 4, SR_CTL_WORDS = 16 };
 constexpr int SR_REC = 16;                // granules per sums record (7 used by GN, 13 by LM)
 
-struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total, ab; };      // ab: A/B bits (tools): 1 = row granules row-major (a wave's 16-byte loads contiguous), 2 = 128-byte sums records in GN too
+struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total, ab; };      // ab: A/B bits (tools): 1 = row granules row-major (a wave's 16-byte loads contiguous), 2 = 128-byte sums records in GN too; 4 (tests) = FAULT INJECTION: workgroup 1 never publishes the sums of iteration 2 (what a workgroup that is not resident looks like to the others)
 
 // exchange buffers of one plan (thallo_hip_sfs_resident_bytes); parity = iteration & 1
 struct SrBufs {
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 #pragma unroll
                     for (int q = 1; q < NQ; ++q) if (lane >= 1 + 2 * q) pick = b[q];
                     const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
-                    st1g(RS_SUM, sumw(par, lane >> 1, blockIdx.x) + 8 * (lane & 1), T, word);
+                    if (!((g.ab & 4) && id == 1 && k == 2)) st1g(RS_SUM, sumw(par, lane >> 1, blockIdx.x) + 8 * (lane & 1), T, word);
                 }
             }
         }
@@ -562,6 +562,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 }
 
 int g_sr_ab = 0;         // tools: A/B bits of the exchange layout (SrGeo::ab)
+int g_sr_spin_ms = -1;   // tests: the bound of the kernel's waits in ms, written in front of the next launch (-1: whatever the plan's control words say; 0 there = 2 s)
 
 inline SrGeo make_sr_geo(int W, int H, int yoff, int R)
 {
@@ -615,6 +616,7 @@ template <int R, bool LM> int sr_launch_r(const SrArgs& a, hipStream_t s)
         }
         if (fits < 0 || (long)fits * thallo_hip_device_cu_count() < grid) return -(int)hipErrorNotSupported;
     }
+    if (g_sr_spin_ms >= 0) { const unsigned v = (unsigned)g_sr_spin_ms; if (hipMemcpyAsync(a.b.ctl + SR_SPIN_MS, &v, sizeof(v), hipMemcpyHostToDevice, s) != hipSuccess) return -(int)hipErrorUnknown; }
     hipLaunchKernelGGL((k_sfs_resident<R, LM>), dim3(grid), dim3(SR_NT), 0, s, a);
     int e = check_launch(); return e ? e : grid;
 }
@@ -645,7 +647,7 @@ extern "C" {
 int thallo_hip_debug_stamps_sfs_resident(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_sr), &buf, sizeof buf) == hipSuccess ? 0 : -1; }
 #endif
 
-void thallo_hip_sfs_resident_debug_set(int what, int value) { if (what == 0) g_sr_rows = value; if (what == 1) g_sr_cap = value; if (what == 2) g_sr_ab = value; }
+void thallo_hip_sfs_resident_debug_set(int what, int value) { if (what == 0) g_sr_rows = value; if (what == 1) g_sr_cap = value; if (what == 2) g_sr_ab = value; if (what == 3) g_sr_spin_ms = value; }
 
 /* rows per wave segment of the resident PCG kernel on a W x H image, or 0: the shape does not fit the chip's registers and the caller runs one launch per PCG iteration */
 int thallo_hip_sfs_resident_rows(int W, int H) { return sr_rows(W, H); }

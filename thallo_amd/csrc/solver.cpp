@@ -1139,6 +1139,16 @@ int Plan::step_lm(int ev_iter)
     HIP_OK(hipMemcpyAsync(rep, lmst, sizeof(rep), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     if (late_agree && (failed_before_cost_exchange || !std::isfinite(rep[5])) && !agree_all()) return 0;      // (a failed rank skipped its own cost launches: its rep[5] says nothing)
+    if (resident_used_) {     // (the LM step's resident launch: its waits are bounded; one that ran out voids THIS step -- nothing of its report can be trusted)
+        resident_used_ = false;
+        unsigned pm[5] = { 0, 0, 0, 0, 0 };
+        if (plugin->resident_status(ctx, 1, pm) != 0) {
+            plugin->resident_disable();
+            set_error("%s: a bounded wait inside the resident PCG kernel ran out (wait kind %u, workgroup %u, wave %u, index %u, tag %u): this step is void; "
+                      "the plan runs one launch per PCG iteration from now on (Thallo_ProblemInit and solve again)", plugin->name(), pm[0], pm[1], pm[2], pm[3], pm[4]);
+            return 0;
+        }
+    }
     { int frozen_at; memcpy(&frozen_at, &rep[2], sizeof(int)); unsigned fz; memcpy(&fz, &rep[1], sizeof(fz)); if (fz) k_done = frozen_at; }
     return lm_accept_or_revert(rep[3], rep[4], rep[5], k_done, ev_fin, ev_iter);
 }

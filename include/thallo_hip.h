@@ -605,12 +605,6 @@ int thallo_hip_sfs_planes_layout(int W, int H);
  * check are void; pm: 5 words of post-mortem, may be NULL); clear != 0 resets; spin_ms >= 0 sets the bound (0 = the 2 s default); synchronises the stream.
  * thallo_hip_sfs_resident_debug_set (tools / tests): 0 = rows per segment, 1 = workgroup budget (0 = automatic), 2 = A/B bits of the exchange layout (4: fault injection -- one
  * workgroup withholds its sums of iteration 2), 3 = the bound of the kernel's waits in ms for the next launches (-1: leave).  Replaces gauss_newton.t:1615-1687 for these shapes. */
-/* Round 6 -- precompute + PCGInit1 (Gauss-Newton: r = -J^T F, z = r, p_prev = 0, delta = 0, the partials of r . r) in ONE launch on packed planes, whole image on one GPU:
- * the planes are written for the PCG iterations and consumed from registers.  -hipErrorNotSupported where the pixel-pair kernels do not run (the caller runs
- * thallo_hip_sfs_precompute + thallo_hip_sfs_pcg_init); the same bits as those two.  Returns the number of partials.  Replaces gauss_newton.t:979-986 + :712-731. */
-int thallo_hip_sfs_precompute_pcg_init(int W, int H, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
-                                       const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt,
-                                       float* r, float* z, float* p_prev, float* delta, float* aN_out, thallo_stream_t stream);
 int thallo_hip_sfs_resident_rows(int W, int H);
 long thallo_hip_sfs_resident_bytes(int W, int H);
 int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,

@@ -1978,45 +1978,6 @@ def test_shape_from_shading_resident_loop_reports_a_wait_that_ran_out(torch, lm)
     assert len(again) == len(ref) and np.abs(np.array(again) - np.array(ref)).max() <= 2e-4 * np.abs(np.array(ref)).max(), (again, ref)
 
 
-@pytest.mark.parametrize("resident", ["1", "0"])
-@pytest.mark.parametrize("W,H,nit,lit", [(640, 480, 3, 10), (130, 67, 4, 10), (126, 9, 3, 5), (2, 2, 2, 3), (250, 130, 3, 7), (1024, 1024, 2, 10)])
-def test_shape_from_shading_precompute_rides_in_pcg_init(torch, orc, monkeypatch, W, H, nit, lit, resident):
-    """Round 6: in a Gauss-Newton step on packed planes precompute and PCGInit1 are ONE launch (k_pinit_pre: the planes of a row are formed from the rows of X, D, I and the
-    masks the march loads, stored for the PCG iterations and fed from registers to the J^T F row step one row behind) -- against the two launches (THALLO_AB
-    sfs_init_fused=0): the same expressions in the same geometry: costs, every alpha / beta and the unknowns are BIT-identical, with the resident loop and with one launch per
-    PCG iteration behind it; the launch census loses `precompute`."""
-    p = syn.shape_from_shading(W, H)
-    monkeypatch.setenv("THALLO_RESIDENT", resident)
-    runs = []
-    for fused in ("1", "0"):
-        set_ab(monkeypatch, sfs_init_fused=fused)
-        dev = to_device(copy_params(p))
-        s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"))
-        s.set_kernel_sampling(1)
-        s.set_solver_parameters(nIterations=nit, lIterations=lit)
-        params = s.make_params(dev)
-        s.init(params)
-        costs, traces = [s.current_cost()], []
-        for k in range(nit):
-            if not s.step(params): break
-            traces.append(s.alpha_beta_trace())
-            if k == 1: costs.append(s.current_cost())          # (a cost poll between two steps leaves valid planes: the next PCGInit1 runs alone)
-        costs.append(s.current_cost())
-        ks = {k: v["launches"] for k, v in s.kernel_stats().items() if v["launches"]}
-        runs.append((costs, traces, dev[16].clone(), ks))
-        s.close()
-    (c1, t1, x1, k1), (c0, t0, x0, k0) = runs
-    assert all(np.isfinite(c1)) and len(t1) == len(t0) >= 2
-    assert k1.get("precompute+PCGInit1", 0) >= 1 and "precompute+PCGInit1" not in k0 and k0.get("precompute", 0) >= 1, (k1, k0)
-    assert k1.get("precompute", 0) == 0 and k1.get("PCGInit1", 0) + k1["precompute+PCGInit1"] == k0["PCGInit1"], (k1, k0)
-    assert t1 == t0, [(i, k, u, v) for i, (x, y) in enumerate(zip(t1, t0)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
-    assert c1 == c0, (c1, c0)
-    assert torch.equal(x1, x0)
-    if W * H <= 70000:
-        co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(nIterations=nit, lIterations=lit)
-        assert abs(c1[-1] - co[len(t1)]) <= 2e-5 * abs(co[len(t1)]) + 1e-9, (c1, co)
-
-
 def test_shape_from_shading_lm_step_folds(torch, monkeypatch):
     """Round 6, LM on one GPU on packed planes: PCGFinalizeDiagonal rides in PCGInit1's launch and the owed update of delta + the model cost's applyJTJ + its dot product are one
     launch (thallo_hip_sfs_pcg_init_lm, thallo_hip_sfs_lm_model_cost) -- against the step with those launches on their own (THALLO_AB lm_fold_step=0): the same expressions per

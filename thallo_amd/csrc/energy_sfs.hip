@@ -942,15 +942,6 @@ int thallo_hip_sfs_cost(int W, int H, int row0, int row1, int yoff, int Hg, cons
     int e = check_launch(); return e ? e : grid;
 }
 
-/* Round 6: precompute + PCGInit1 (Gauss-Newton) in ONE launch on packed planes, whole image (-hipErrorNotSupported elsewhere: the caller runs the two launches) */
-int thallo_hip_sfs_precompute_pcg_init(int W, int H, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* Im,
-                                       const unsigned char* edgeMaskR, const unsigned char* edgeMaskC, float* G, float* Wt,
-                                       float* r, float* z, float* p_prev, float* delta, float* aN_out, thallo_stream_t stream)
-{
-    if (!sfs_pair(W, H)) return -(int)hipErrorNotSupported;
-    return thallo::sfs_pair_precompute_init(W, H, yoff, Hg, host_params, X, D, Im, edgeMaskR, edgeMaskC, G, Wt, r, z, p_prev, delta, aN_out, pair_tune(), stream);
-}
-
 int thallo_hip_sfs_pcg_init(int W, int H, int row0, int row1, int yoff, int Hg, const float* host_params, const float* X, const float* D, const float* G, const float* Wt,
                             const unsigned char* fl, float* U, float* R, float* r, float* z, float* p_prev, float* delta,
                             float* diag_out, float* aN_out, thallo_stream_t stream)

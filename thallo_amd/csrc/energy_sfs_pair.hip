@@ -503,166 +503,6 @@ __global__ __launch_bounds__(PM_NT, 2) void k_pprecompute(PmGeo g, int Hg, PCam 
     if (COST) block_store_partial(acc.x + acc.y, cost_out, red);
 }
 
-// precompute AND PCGInit1 in one launch (Gauss-Newton, whole image on one GPU; round 6): the planes of a row are formed from the rows of X, D, I and the masks the march
-// loads (k_pprecompute's row step, its expressions), stored for the PCG iterations on the segment's own rows -- and fed, from registers, to the J^T F row step of
-// k_pmarch<INIT> one row behind (its expressions): no G / BI / flags planes are read, the BI plane's only other reader is the cost.  The march loads rows ya - 3 .. yb + 2,
-// forms the planes of rows ya - 2 .. yb + 1 (the halo rows redundantly: the neighbouring segments form them too) and writes r = -J^T F, z = r, p_prev = 0, delta = 0 and the
-// partials of r . r for the rows ya .. yb - 1.  Same bits as thallo_hip_sfs_precompute + thallo_hip_sfs_pcg_init with the same rows per wave.
-__global__ __launch_bounds__(PM_NT, 2) void k_pinit_pre(PmGeo g, int Hg, PCam cm, const float* __restrict__ X, const float* __restrict__ D, const float* __restrict__ Im,
-                                                        const unsigned char* __restrict__ mR, const unsigned char* __restrict__ mC,
-                                                        float* __restrict__ Gp, unsigned* __restrict__ Fw, float* __restrict__ r_out, float* __restrict__ z_out,
-                                                        float* __restrict__ p_prev, float* __restrict__ delta, float* __restrict__ part_out)
-{
-    __shared__ float red[16];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = g.W, H = g.H;
-    int strip, ya, yb;
-    pm_place(g, wave, strip, ya, yb);
-    v2f acc = { 0.f, 0.f };
-    if (ya < yb) {
-        const v2f Z2 = { 0.f, 0.f };
-        const int x0 = strip * PM_USE - 2 + 2 * lane;
-        const bool xin = x0 >= 0 && x0 < W;
-        const bool xout = xin && lane >= 1 && lane <= 62;
-        const int xcl = x0 < 0 ? 0 : x0 > W - 2 ? W - 2 : x0;
-        const unsigned vo = (unsigned)xcl * 4u, vob = (unsigned)xcl;
-        const unsigned rowb = (unsigned)W * 4u, planeb = (unsigned)W * (unsigned)H * 4u;
-        const rsrc_t RS_X = make_rsrc(X), RS_D = make_rsrc(D), RS_I = make_rsrc(Im), RS_MR = make_rsrc(mR), RS_MC = make_rsrc(mC), RS_G = make_rsrc(Gp), RS_F = make_rsrc(Fw);
-        const rsrc_t RS_R = make_rsrc(r_out), RS_Z = make_rsrc(z_out), RS_PP = make_rsrc(p_prev), RS_D0 = make_rsrc(delta);
-        const v2f ax = { (cm.ux - (float)x0) / cm.fx, (cm.ux - (float)(x0 + 1)) / cm.fx };
-        const v2f cxc = { coef0(cm, x0), coef0(cm, x0 + 1) }, cxm = { coef0(cm, x0 - 1), cxc.x }, cxp = { cxc.y, coef0(cm, x0 + 2) };
-        const M2 xinner = { x0 >= 1 && x0 + 1 < W, x0 + 2 < W };
-        const M2 xp1 = { true, x0 + 2 < W };
-        const int t_first = ya - 3, t_last = yb + 2;          // rows loaded; planes: rows t - 1; J^T F consumes row T = t - 1 and writes row T - 2 = t - 3
-        auto issue = [&](PpRaw& s, int t) {
-            const unsigned tc = (unsigned)(t < 0 ? 0 : t > H - 1 ? H - 1 : t), row = tc * rowb;
-            s.x = bld2(RS_X, vo, row); s.d = bld2(RS_D, vo, row); s.im = bld2(RS_I, vo, row);
-            s.mr = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(RS_MR, vob, tc * (unsigned)W, 0);
-            s.mc = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(RS_MC, vob, tc * (unsigned)W, 0);
-        };
-        // precompute's rings (rows t, t-1, t-2 of the inputs)
-        v2f Xr[3] = { Z2, Z2, Z2 }, Dr[3] = { Z2, Z2, Z2 }, Ir[3] = { Z2, Z2, Z2 };
-        unsigned Mr[3] = { 0u, 0u, 0u }, Mc[3] = { 0u, 0u, 0u };
-        // J^T F's rings (rows T, T-1, T-2 with T = t - 1): k_pmarch's
-        v2f Vv[3] = { Z2, Z2, Z2 }, dB[3] = { Z2, Z2, Z2 }, Uh[3] = { Z2, Z2, Z2 }, Uv[3] = { Z2, Z2, Z2 }, Tt[3] = { Z2, Z2, Z2 };
-        v2f Gx[3] = { Z2, Z2, Z2 }, Gy[3] = { Z2, Z2, Z2 }, Gz[3] = { Z2, Z2, Z2 }, Wy[3] = { Z2, Z2, Z2 };
-        float Cy[3] = { 0.f, 0.f, 0.f };
-        unsigned Fl[3] = { 0u, 0u, 0u };
-        M2 Wn[3] = { { false, false }, { false, false }, { false, false } };
-        v2f Rr[3][3] = { { Z2, Z2, Z2 }, { Z2, Z2, Z2 }, { Z2, Z2, Z2 } };
-        PpRaw slot[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) slot[j] = PpRaw{};
-        for (int t0 = t_first - 3; t0 <= t_last; t0 += 3) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int t = t0 + j;
-                const int k0 = j, k1 = (j + 2) % 3, k2 = (j + 1) % 3;          // ring slots of rows t, t-1, t-2
-                PpRaw cur = PpRaw{};
-                take2u(cur.x, slot[j].x); take2u(cur.d, slot[j].d); take2u(cur.im, slot[j].im); take1(cur.mr, slot[j].mr); take1(cur.mc, slot[j].mc);
-                fence_order();
-                issue(slot[j], t + 3 > t_last ? t_last : t + 3);
-                fence_order();
-                if (t >= t_first && t <= t_last) {
-                    const bool okt = xin && t >= 0 && t < H;
-                    const v2f d3 = Dr[k0];                                      // D of row t-3, about to be overwritten: J^T F's output row
-                    Xr[k0] = sel(okt, f2(cur.x), Z2); Dr[k0] = sel(okt, f2(cur.d), Z2); Ir[k0] = sel(okt, f2(cur.im), Z2);
-                    Mr[k0] = okt ? cur.mr : 0u; Mc[k0] = okt ? cur.mc : 0u;
-                    // ---- the planes of row T = t-1 (slot k1); its upper row t-2 (k2), its lower row t (k0): k_pprecompute's step
-                    const int T = t - 1;
-                    const v2f xc = Xr[k1], dc = Dr[k1], ic = Ir[k1];
-                    const v2f xl = nbL(xc), dlf = nbL(dc), il = nbL(ic), xr = nbR(xc), dr = nbR(dc);
-                    const BIv b = eval_BI_pair(cm, dlf, dc, Dr[k2], xc, xl, Xr[k2], ic, il, Ir[k2], ax, (cm.uy - (float)(T + g.yoff)) / cm.fy);
-                    unsigned fwx, fwy;
-                    {
-                        const int yg = T + g.yoff;
-                        const bool yinner = yg >= 1 && yg + 1 < Hg;
-                        const unsigned mr0 = (yinner && xinner.x) ? Mr[k1] & 0xffu : 0u, mr1 = (yinner && xinner.y) ? (Mr[k1] >> 8) & 0xffu : 0u;
-                        const unsigned mc0 = (yinner && xinner.x) ? Mc[k1] & 0xffu : 0u, mc1 = (yinner && xinner.y) ? (Mc[k1] >> 8) & 0xffu : 0u;
-                        unsigned fa = dc.x > 0.0f ? 1u : 0u, fb = dc.y > 0.0f ? 1u : 0u;
-                        bool va = fa != 0u, vb = fb != 0u;
-                        va = va && dlf.x > 0.0f && fabsf(xc.x - xl.x) < 0.01f;
-                        vb = vb && dlf.y > 0.0f && fabsf(xc.y - xl.y) < 0.01f;
-                        va = va && Dr[k2].x > 0.0f && fabsf(xc.x - Xr[k2].x) < 0.01f;
-                        vb = vb && Dr[k2].y > 0.0f && fabsf(xc.y - Xr[k2].y) < 0.01f;
-                        va = va && dr.x > 0.0f && fabsf(xc.x - xr.x) < 0.01f;
-                        vb = vb && dr.y > 0.0f && fabsf(xc.y - xr.y) < 0.01f;
-                        va = va && Dr[k0].x > 0.0f && fabsf(xc.x - Xr[k0].x) < 0.01f;
-                        vb = vb && Dr[k0].y > 0.0f && fabsf(xc.y - Xr[k0].y) < 0.01f;
-                        if (va) fa |= 2u;
-                        if (vb) fb |= 2u;
-                        fwx = fa | (mr0 << 8) | (mc0 << 16); fwy = fb | (mr1 << 8) | (mc1 << 16);
-                    }
-                    if (T >= ya && T < yb && xout) {
-                        const unsigned ro = (unsigned)T * rowb;
-                        bst2(RS_G, vo, ro, b.dc); bst2(RS_G, vo, planeb + ro, b.dl); bst2(RS_G, vo, 2u * planeb + ro, b.du); bst2(RS_G, vo, 3u * planeb + ro, b.b);
-                        bst2u(RS_F, vo, ro, fwx, fwy);
-                    }
-                    // ---- J^T F's step for row T (k_pmarch<INIT>): ring slots of rows T, T-1, T-2 are k1, k2, k0
-                    if (T >= ya - 2 && T <= yb + 1) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int q0 = k1, q1 = k2, q2 = k0;
-                        const bool rowok = T >= 0 && T < H, ok = xin && rowok;
-                        v2f v0 = sel(ok, xc, Z2);
-                        const unsigned f0 = ok ? ((fwx & 0xffu) | ((fwy & 0xffu) << 8)) : 0u;
-                        const v2f wx = cm.wg * v2f{ (float)((fwx >> 8) & 0xffu), (float)((fwy >> 8) & 0xffu) };
-                        const v2f wy = cm.wg * v2f{ (float)((fwx >> 16) & 0xffu), (float)((fwy >> 16) & 0xffu) };
-                        const v2f gx = b.dc, gy = b.dl, gz = b.du;
-                        const v2f v1 = Vv[q1], v2 = Vv[q2];
-                        Cy[q0] = coef1(cm, T + g.yoff);
-                        const v2f vl1 = nbL(v1), vr1 = nbR(v1);
-                        const v2f dB0 = sel(ok, b.b, Z2);
-                        const v2f dBr = nbR(dB0);
-                        const M2 wn0 = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
-                        const v2f Uh0 = sel(wn0, wx * (wx * (dB0 - dBr)), Z2);
-                        const v2f Uv1 = sel(Wn[q1], Wy[q1] * (Wy[q1] * (dB[q1] - dB0)), Z2);
-                        v2f R1[3];
-                        {
-                            const float cy0 = Cy[q0], cy1 = Cy[q1], cy2 = Cy[q2];
-                            const M2 f2b = bit(Fl[q1], 2u);
-                            R1[0] = sel(f2b, cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0), Z2);
-                            R1[1] = sel(f2b, cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0), Z2);
-                            R1[2] = sel(f2b, cm.ws * (4.0f * v1 - vl1 - v2 - vr1 - v0), Z2);
-                        }
-                        v2f T1 = Uh[q1] + Uv1;
-                        T1 -= nbL(Uh[q1]);
-                        T1 -= Uv[q2];
-                        const v2f T2 = Tt[q2];
-                        const v2f gT2r = nbR(Gy[q2] * T2);
-                        v2f Rl[3], Rq[3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) { Rl[c] = nbL(Rr[q2][c]); Rq[c] = nbR(Rr[q2][c]); }
-                        const int y = T - 2;
-                        if (y >= ya && xout) {
-                            const unsigned ro = (unsigned)y * rowb;
-                            const v2f vc = v2, ct = d3;
-                            v2f s = Z2;
-                            s = sel(bit(Fl[q2], 1u), s + cm.wp * (cm.wp * (vc - ct)), s);
-                            s += Gx[q2] * T2;
-                            s = sel(xp1, s + gT2r, s);
-                            if (y + 1 < H) s += Gz[q1] * T1;
-                            {
-                                v2f lap;
-                                lap = 4.0f * Rr[q2][0] - Rl[0] - Rr[q0][0] - Rq[0] - R1[0]; s += cm.ws * (cxc * lap);      // (slot q0 still holds row T-3)
-                                lap = 4.0f * Rr[q2][1] - Rl[1] - Rr[q0][1] - Rq[1] - R1[1]; s += cm.ws * (Cy[q2] * lap);
-                                lap = 4.0f * Rr[q2][2] - Rl[2] - Rr[q0][2] - Rq[2] - R1[2]; s += cm.ws * (1.0f * lap);
-                            }
-                            const v2f r = -s;
-                            bst2(RS_R, vo, ro, r); bst2(RS_PP, vo, ro, Z2); bst2(RS_D0, vo, ro, Z2); bst2(RS_Z, vo, ro, r);
-                            acc += r * r;
-                        }
-                        Vv[q0] = v0; Fl[q0] = f0; Wn[q0] = wn0; Wy[q0] = wy; dB[q0] = dB0; Uh[q0] = Uh0; Uv[q1] = Uv1; Tt[q1] = T1;
-                        Gx[q0] = gx; Gy[q0] = gy; Gz[q0] = gz;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) Rr[q1][c] = R1[c];
-                    }
-                }
-            }
-        }
-    }
-    block_store_partial(acc.x + acc.y, part_out, red);
-}
-
 PmGeo make_geo(int W, int H, int ra, int rb, int yoff, int R)
 {
     PmGeo g; g.W = W; g.H = H; g.ra = ra; g.rb = rb; g.yoff = yoff; g.R = R;
@@ -719,19 +559,6 @@ int sfs_pair_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const fl
     }
     hipLaunchKernelGGL(k_pprecompute<false>, dim3(grid), dim3(PM_NT), 0, (hipStream_t)stream, mg, Hg, cam_of(hp), X, D, Im, mR, mC, G, (unsigned*)Fw, (float*)nullptr, 0, 0);
     return check_launch();
-}
-
-// precompute + PCGInit1 in one launch (k_pinit_pre): the planes for every row, r / z / p_prev / delta / the partials of r . r -- whole images, Gauss-Newton
-int sfs_pair_precompute_init(int W, int H, int yoff, int Hg, const float* hp, const float* X, const float* D, const float* Im, const unsigned char* mR, const unsigned char* mC,
-                             float* G, float* Fw, float* r, float* z, float* p_prev, float* delta, float* aN_out, const SfsTune& t, thallo_stream_t stream)
-{
-    if (H < 1 || !X || !D || !Im || !mR || !mC || !G || !Fw || !r || !z || !p_prev || !delta || !aN_out) return -(int)hipErrorInvalidValue;
-    if (((uintptr_t)mR | (uintptr_t)mC) & 1) return -(int)hipErrorInvalidValue;
-    const PmGeo mg = pick_geo(W, H, 0, H, yoff, t);      // (PCGInit1's geometry: its partial sums are taken in it)
-    const int grid = (mg.total + 7) / 8 * 8;
-    if (grid > THALLO_MAX_PARTIALS) return -(int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_pinit_pre, dim3(grid), dim3(PM_NT), 0, (hipStream_t)stream, mg, Hg, cam_of(hp), X, D, Im, mR, mC, G, (unsigned*)Fw, r, z, p_prev, delta, aN_out);
-    int e = check_launch(); return e ? e : grid;
 }
 
 #define PM_ARGS_NONE PmPupd{}, PmUpd{}, LmFin{}, PmFin{}, PmModel{}

@@ -1031,14 +1031,6 @@ public:
     }
     int pcg_init(LaunchCtx& c, SolverVectors& v, int cur, float* aN) override
     {
-        if (!planes_valid_ && packed() && v.diag == nullptr) {      // round 6: precompute rides in PCGInit1's launch (GN: no raw LM diagonal asked for; THALLO_AB=sfs_init_fused=0: A/B)
-            const char* e = env_switch("THALLO_SFS_INIT_FUSED");
-            if (!(e && e[0] == '0')) {
-                TimedLaunch t(c, "precompute+PCGInit1");
-                const int rc = thallo_hip_sfs_precompute_pcg_init(W, H, yoff_, Hg_, hp, X, D, Im, mR, mC, (float*)G.ptr, (float*)Wt.ptr, v.r, v.z, v.p[cur], v.delta, aN, c.stream);
-                if (rc != -(int)hipErrorNotSupported) { planes_valid_ = rc >= 0; return rc; }
-            }
-        }
         int rc = precompute(c); if (rc < 0) return rc;
         TimedLaunch t(c, "PCGInit1");
         return thallo_hip_sfs_pcg_init(W, H, row0_, row1_, yoff_, Hg_, hp, X, D, (const float*)G.ptr, (const float*)Wt.ptr, (const unsigned char*)fl.ptr, (float*)U.ptr, (float*)R.ptr,

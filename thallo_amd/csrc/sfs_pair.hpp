@@ -25,9 +25,6 @@ struct SfsFinDiag { float* SSq = nullptr; float* CtC = nullptr; float* pre = nul
 
 int sfs_pair_precompute(int W, int H, int ra, int rb, int yoff, int Hg, const float* hp, const float* X, const float* D, const float* Im, const unsigned char* mR, const unsigned char* mC,
                         float* G, float* Fw, float* cost_out, int c0, int c1, const SfsTune& t, thallo_stream_t stream);
-// precompute and PCGInit1 (Gauss-Newton) in one launch on the whole image: the planes are written for the PCG iterations and consumed from registers (no G / BI / flags read)
-int sfs_pair_precompute_init(int W, int H, int yoff, int Hg, const float* hp, const float* X, const float* D, const float* Im, const unsigned char* mR, const unsigned char* mC,
-                             float* G, float* Fw, float* r, float* z, float* p_prev, float* delta, float* aN_out, const SfsTune& t, thallo_stream_t stream);
 int sfs_pair_init(int W, int H, int row0, int row1, int yoff, int Hg, const float* hp, const float* X, const float* D, const float* G, const float* Fw,
                   float* r, float* z, float* p_prev, float* delta, float* diag_out, float* aN_out, const SfsFinDiag& fd, const SfsTune& t, thallo_stream_t stream);
 int sfs_pair_apply(int W, int H, int row0, int row1, int yoff, int Hg, const float* hp, const float* G, const float* Fw, const float* p, float* Ap, float* aD_out,

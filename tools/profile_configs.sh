@@ -8,6 +8,9 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/cfg_kt -- python3 $R/tools/bench_configs.py > $R/gpurun_out/cfg_kt.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/cfg_fetch -- python3 $R/tools/bench_configs.py > $R/gpurun_out/cfg_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/cfg_write -- python3 $R/tools/bench_configs.py > $R/gpurun_out/cfg_write.log 2>&1
+# shape_from_shading at the size of the reference's data set (the resident loops; kernel trace only: every name of this run has one size)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/cfg640_kt -- python3 $R/tools/bench_configs.py sfs640 > $R/gpurun_out/cfg640_kt.log 2>&1
 cd $R
+python3 tools/bench_configs.py sfs640 2>/dev/null | grep -v "^Initial" > gpurun_out/sfs_640x480.json
 python3 tools/bench_configs.py 2>/dev/null | grep -v "^Initial" > gpurun_out/secondary_configs.json
 ls gpurun_out/cfg_kt/* | head

@@ -10,6 +10,10 @@ os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 shutil.copy(newest(os.path.join(g, "cfg_kt", "*", "*_kernel_stats.csv")), os.path.join(out, "secondary_kernel_stats.csv"))
+if glob.glob(os.path.join(g, "cfg640_kt", "*", "*_kernel_stats.csv")):
+    shutil.copy(newest(os.path.join(g, "cfg640_kt", "*", "*_kernel_stats.csv")), os.path.join(out, "sfs_640x480_kernel_stats.csv"))
+if os.path.exists(os.path.join(g, "sfs_640x480.json")):
+    shutil.copy(os.path.join(g, "sfs_640x480.json"), os.path.join(out, "sfs_640x480.json"))
 if os.path.exists(os.path.join(g, "secondary_configs.json")):
     shutil.copy(os.path.join(g, "secondary_configs.json"), os.path.join(out, "secondary_configs.json"))
 

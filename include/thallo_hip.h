@@ -403,8 +403,9 @@ long thallo_hip_iw_resident_bytes(int W, int rows);
  * shape does not fit, another negative hipError_t on failure.  Every wait inside is bounded (2 s by default): see thallo_hip_iw_resident_status. */
 int  thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
                                 const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
-                                thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, int L, thallo_stream_t stream);
-/* error word of the plan's resident launches (1 = a bounded wait ran out: results void); clear != 0 resets it; spin_ms >= 0 sets the bound in
+                                thallo_sum_t alphaN0, float* words, const int* irregular, float* X_offset, float* X_angle, void* xbuf, int L, thallo_stream_t stream);
+/* (X_offset / X_angle, round 6: both non-NULL = PCGLinearUpdate rides along, X += delta + alpha_{L-1} p_{L-1} with thallo_hip_linear_update's bits; both NULL: the caller's launch)
+   error word of the plan's resident launches (1 = a bounded wait ran out: results void); clear != 0 resets it; spin_ms >= 0 sets the bound in
  * milliseconds (0 = default); pm: 5 words of post-mortem or NULL.  Synchronises the stream. */
 int  thallo_hip_iw_resident_status(void* xbuf, int clear, int spin_ms, unsigned* pm, thallo_stream_t stream);
 /* One rank's row slab of a multi-GPU run (local image W x H including its ghost rows, owned rows [row0, row1)): the first / last owned row of A p_k goes

@@ -83,6 +83,7 @@ struct ResArgs {
     float* words;                                 // words[2k] = alphaD_k, words[2k + 1] = betaN_k  (the plan's scal(B + 2k + 1), scal(B + 2k + 2))
     const int* irregular;
     int L;
+    float* X0; float* X1;                         // the unknowns (Offset: 2 floats per pixel, Angle: 1), or NULL: PCGLinearUpdate stays a launch of its own (always NULL across ranks)
     int fault;                                    // tests: workgroup 1 never publishes the sums of iteration 2 (what a workgroup that is not resident looks like to the others)
 };
 
@@ -617,7 +618,8 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
                 dl4[i] = make_float4(d[0], d[RES_NT], d[2 * RES_NT], d[3 * RES_NT]); dl2[i] = make_float2(d[4 * RES_NT], d[5 * RES_NT]);
             }
         }
-        if (id == 0) {      // (uniform per workgroup: all four waves of the writer's workgroup take part in the last sweep)
+        const bool fold = !DIST && a.X0 != nullptr;      // PCGLinearUpdate (gauss_newton.t:901-906) rides along: every workgroup needs alpha_{L-1}
+        if (id == 0 || fold) {      // (uniform per workgroup: all four waves take part in the last sweep)
             const unsigned T = seq + (unsigned)a.L; const int par = (a.L - 1) & 1;
             unsigned w7[7];
 #pragma unroll
@@ -636,12 +638,30 @@ __global__ __launch_bounds__(RES_NT, 1) void k_pcg_resident(ResArgs a)
             float aD, bN;
             scalars_from_sums(a.L - 1, T, par, aN_prev, ad, n, a1, b1, aD, bN);
             if (writer) { a.words[2 * (a.L - 1)] = aD; a.words[2 * (a.L - 1) + 1] = bN; }
+            if (fold) {      // X += delta + alpha_{L-1} p_{L-1} on my rows (k_linear_update's expressions: one fma, one add per element)
+                const float al = safe_div<false>(aN_prev, aD);
+                float4* X4 = reinterpret_cast<float4*>(a.X0); float2* X2 = reinterpret_cast<float2*>(a.X1);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (j < nr && xout) {
+                        const int jc = j + 1;
+                        const long i = (long)(ya + j) * W2 + (x0 >> 1);
+                        const float* d = dl + (j * 6) * RES_NT + threadIdx.x;
+                        float4 x4 = X4[i]; float2 x2 = X2[i];
+                        x4.x = x4.x + __builtin_fmaf(al, pxy[jc][0].x, d[0]); x4.y = x4.y + __builtin_fmaf(al, pxy[jc][0].y, d[RES_NT]);
+                        x4.z = x4.z + __builtin_fmaf(al, pxy[jc][1].x, d[2 * RES_NT]); x4.w = x4.w + __builtin_fmaf(al, pxy[jc][1].y, d[3 * RES_NT]);
+                        x2.x = x2.x + __builtin_fmaf(al, pa[jc][0], d[4 * RES_NT]); x2.y = x2.y + __builtin_fmaf(al, pa[jc][1], d[5 * RES_NT]);
+                        X4[i] = x4; X2[i] = x2;
+                    }
+                }
+            }
         }
+        // the next launch's tags start behind this one's (the counter lives on the device: replay-safe; advanced by the one thread that is through only when every workgroup
+        // has published its last sums, i.e. has long read it)
+        if (writer) __hip_atomic_store(ctl + RES_SEQ, seq + (unsigned)a.L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// this launch's tags are seq + 1 .. seq + L: never those of an earlier launch of the plan, whatever its L was (replay-safe: the counter lives on the device)
-__global__ void k_resident_begin(unsigned* ctl, unsigned L) { if (threadIdx.x == 0) { const unsigned s = ctl[RES_NEXT]; ctl[RES_SEQ] = s; ctl[RES_NEXT] = s + L + 1u; } }
 
 inline ResGeo make_res_geo(int W, int H, int row0, int row1, int R)
 {
@@ -716,7 +736,6 @@ int res_launch(const ResArgs& a, int R, hipStream_t s)
         if (f < 0 || (long)f * thallo_hip_device_cu_count() < grid) return -(int)hipErrorNotSupported;
     }
     if (g_res_spin_ms >= 0) { const unsigned v = (unsigned)g_res_spin_ms; if (hipMemcpyAsync(a.b.ctl + RES_SPIN_MS, &v, sizeof(v), hipMemcpyHostToDevice, s) != hipSuccess) return -(int)hipErrorUnknown; }
-    hipLaunchKernelGGL(k_resident_begin, dim3(1), dim3(64), 0, s, a.b.ctl, (unsigned)a.L);
 #define RES_LAUNCH(RR) hipLaunchKernelGGL((k_pcg_resident<RR, DIST>), dim3(grid), dim3(RES_NT), lds, s, a)
     switch (R) {
         case 1: RES_LAUNCH(1); break; case 2: RES_LAUNCH(2); break; case 3: RES_LAUNCH(3); break;
@@ -756,14 +775,16 @@ long thallo_hip_iw_resident_ghost_bytes(int W) { return W < 2 ? 0 : 2L * ((W + R
 
 /* The PCG loop of one Gauss-Newton step in one launch: L iterations from what thallo_hip_iw_pcg_init left (r_0 in r_in, zeros in p_in and delta, cs / flags,
  * alphaN_0), leaving what L launches of thallo_hip_iw_pcg_iter_march leave: r_{L-1}, A p_{L-1}, p_{L-1} in the *_out planes, delta without its last term, and
- * words[2k] = alphaD_k, words[2k + 1] = betaN_k.  The *_out planes may be the *_in planes (every workgroup has read its rows and halo before any workgroup can
+ * words[2k] = alphaD_k, words[2k + 1] = betaN_k; with X_offset / X_angle (round 6) PCGLinearUpdate rides along: X += delta + alpha_{L-1} p_{L-1}, thallo_hip_linear_update's
+ * bits.  The *_out planes may be the *_in planes (every workgroup has read its rows and halo before any workgroup can
  * be through its L iterations: each iteration needs every workgroup's sums).  xbuf: thallo_hip_iw_resident_bytes() bytes, zeroed once by the caller, private to the plan.
  * Returns the number of workgroups (> 0), -hipErrorNotSupported when the shape does not fit, another negative hipError_t on failure.
  * Replaces gauss_newton.t:1615-1687 for shapes whose solver state fits the chip's registers. */
 int thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs, const unsigned char* flags, float w_fit, float w_reg,
                                const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
-                               thallo_sum_t alphaN0, float* words, const int* irregular, void* xbuf, int L, thallo_stream_t stream)
+                               thallo_sum_t alphaN0, float* words, const int* irregular, float* X_offset, float* X_angle, void* xbuf, int L, thallo_stream_t stream)
 {
+    if ((X_offset == nullptr) != (X_angle == nullptr)) return -(int)hipErrorInvalidValue;
     if (row0 != 0 || row1 != H || H < 1 || (W & 1) || W < 2 || L < 1) return -(int)hipErrorInvalidValue;      // (whole images; the row-slab form is thallo_hip_iw_pcg_resident_dist)
     if (!cs || !flags || !r_in || !p_in || !r_out || !Ap_out || !p_out || !delta || !words || !xbuf || !alphaN0.partials) return -(int)hipErrorInvalidValue;
     const int R = res_rows(W, row1 - row0);
@@ -773,7 +794,7 @@ int thallo_hip_iw_pcg_resident(int W, int H, int row0, int row1, const float* cs
     res_bufs(xbuf, a.g, a.b);
     a.cs = cs; a.flags = flags; a.wf2 = w_fit * w_fit; a.wr2 = w_reg * w_reg;
     a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
-    a.aN0 = alphaN0; a.words = words; a.irregular = irregular; a.L = L; a.fault = g_res_fault;
+    a.aN0 = alphaN0; a.words = words; a.irregular = irregular; a.L = L; a.fault = g_res_fault; a.X0 = X_offset; a.X1 = X_angle;
     return res_launch<false>(a, R, (hipStream_t)stream);
 }
 

@@ -337,8 +337,11 @@ public:
     {
         TimedLaunch t(c, "PCGLoopResident");
         return thallo_hip_iw_pcg_resident(W, H, row0_, row1_, (const float*)cs.ptr, (const unsigned char*)flags.ptr, w_fit, w_reg, v.rbuf(0), v.p[0],
-                                          v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words, (const int*)irregular.ptr, xres.ptr, L, c.stream);
+                                          v.rbuf(L & 1), v.Abuf(L & 1), v.p[L & 1], v.delta, aN0, words, (const int*)irregular.ptr,
+                                          resident_updates_unknowns() ? offset : nullptr, resident_updates_unknowns() ? angle : nullptr, xres.ptr, L, c.stream);
     }
+    // round 6: PCGLinearUpdate rides in the resident launch (one GPU; THALLO_AB=iw_resident_fold=0: a launch of its own, A/B)
+    bool resident_updates_unknowns() const override { const char* e = env_switch("THALLO_IW_RESIDENT_FOLD"); return resident_ && !(e && e[0] == '0'); }
     bool resident_slab_ok() const override { return resident_slab_; }
     long resident_ghost_bytes() const override { return (W & 1) ? 0 : thallo_hip_iw_resident_ghost_bytes(W); }
     int pcg_resident_dist(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words, const thallo_dist_t& d, long ghost_off, int slot0) override

@@ -233,6 +233,7 @@ const char* env_switch(const char* name)
         { "THALLO_SFS_MARCH", "sfs_march" },                    // 0: shape_from_shading's LDS-tiled kernels instead of the marching ones
         { "THALLO_BA_RENUMBER", "ba_renumber" },                // bundle adjustment's plan-side point order: 0 never, 1 always (default: when the caller's order is far from "by first observing camera"; round 6)
         { "THALLO_LM_FOLD_STEP", "lm_fold_step" },              // 0: the LM step with PCGFinalizeDiagonal and the model cost as launches of their own where a plugin can fold them (round 6)
+        { "THALLO_IW_RESIDENT_FOLD", "iw_resident_fold" },      // 0: image_warping's resident PCG loop leaves PCGLinearUpdate a launch of its own (round 6; A/B)
         { "THALLO_SFS_RESIDENT_FOLD", "sfs_resident_fold" },    // 0: shape_from_shading's resident PCG loop leaves PCGLinearUpdate a launch of its own (round 6; A/B)
         { "THALLO_SFS_PAIR", "sfs_pair" },                      // 0: shape_from_shading's one-pixel-per-lane marching kernels on the float4 / float2 / byte planes instead of the pixel-pair kernels on packed planes (round 6)
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere

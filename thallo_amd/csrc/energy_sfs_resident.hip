@@ -161,7 +161,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     // (a lane's two 16-byte pieces side by side: its two loads ask for ONE line.  Measured, same box, 640 x 480 GN through Thallo_ProblemStep: 8.23 us per PCG iteration against
     //  9.08 with the rows stored row-major -- a wave's 64 x 16 bytes of one load instruction contiguous, the lane's second piece 1 KB away; tools/sfs_resident_probe.py ab)
     const unsigned row2 = (g.ab & 1) ? 1024u : 16u, rowl = (g.ab & 1) ? 16u : 32u;
-    auto rowh = [&](int par, int w, int side) { return (unsigned)((((long)par * waves + w) * 2 + side) * 2048 + lane * rowl); };      // this lane's granules: two at +0 (the first row), two at +1024 (the second): a wave's 16-byte accesses are contiguous
+    auto rowh = [&](int par, int w, int side) { return (unsigned)((((long)par * waves + w) * 2 + side) * 2048 + lane * rowl); };      // this lane's four granules: the first row's two at +0, the second row's at +row2
     auto colh = [&](int par, int w, int side, int i) { return (unsigned)(((((long)par * waves + w) * 2 + side) * 64 + i) * 8); };
     // a workgroup's record: [par][slot][words]; 64 bytes (GN: two records per 128-byte line) or 128 (LM).  (Measured and dropped: the record stored word-pair-major, so that a
     // sweeping wave reads 1 KB of contiguous memory per load instruction -- a record's pieces then sit in 4 / 7 lines that eight workgroups of different XCDs write into:

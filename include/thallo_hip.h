@@ -611,12 +611,6 @@ long thallo_hip_sfs_resident_bytes(int W, int H);
 int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,
                                 const float* r_in, const float* p_in, float* r_out, float* Ap_out, float* p_out, float* delta,
                                 thallo_sum_t alphaN0, float* words, float* X, void* xbuf, int L, thallo_stream_t stream);
-/* ... and a WHOLE Gauss-Newton step in one launch: precompute (in registers), PCGInit1 (alphaN_0 through one exchange in front of the loop), L PCG iterations and PCGLinearUpdate
- * from the problem's images alone (X updated in place); words[2k] = alphaD_k, words[2k + 1] = betaN_k, alphaN0_word[0] = alphaN_0; no plane and no solver vector is read or
- * written; the same bits as the launches it replaces with the same rows per wave.  thallo_hip_sfs_resident_rows_full: rows per wave, 0 = does not fit (at most 6). */
-int thallo_hip_sfs_resident_rows_full(int W, int H);
-int thallo_hip_sfs_gn_step_resident(int W, int H, const float* host_params, float* X, const float* D, const float* Im, const unsigned char* edgeMaskR, const unsigned char* edgeMaskC,
-                                    float* alphaN0_word, float* words, void* xbuf, int L, thallo_stream_t stream);
 /* ... and a Levenberg-Marquardt step's loop WITH its tail: from what thallo_hip_sfs_pcg_init_lm left (r = b, M^-1 in pre, CtC, zeros in p_prev and delta, alphaN_0) and a reset
  * state (thallo_hip_lm_state_reset), at most L iterations of thallo_hip_sfs_pcg_iter_lm -- the zeta test ends the loop on the device, in every workgroup alike; lm_state[1] /
  * [2] = gate / iterations done as the launches leave them -- then thallo_hip_sfs_lm_model_cost's launch: the owed update of delta (into `delta`), per-workgroup partials of

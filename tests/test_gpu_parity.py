@@ -1837,26 +1837,19 @@ def test_shape_from_shading_pixel_pair_kernels_match_the_one_pixel_kernels(torch
         assert (np.abs(c1[:m] - co[:m]) <= (2e-4 if lm else 2e-5) * np.abs(co[:m]) + 1e-9).all(), (c1, co)
 
 
-@pytest.mark.parametrize("full", ["1", "0"])
 @pytest.mark.parametrize("W,H,nit,lit", [(640, 480, 3, 10), (130, 67, 3, 10), (256, 192, 3, 12), (126, 9, 3, 5), (2, 2, 2, 3), (250, 130, 2, 7), (1024, 160, 2, 9), (372, 35, 3, 6)])
-def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(torch, orc, monkeypatch, W, H, nit, lit, full):
+def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(torch, orc, monkeypatch, W, H, nit, lit):
     """Round 6: the whole PCG loop of a Gauss-Newton step of shape_from_shading in ONE launch (energy_sfs_resident.hip) -- r, p, A p, delta and the
     precomputed planes of a wave's rows in registers, per iteration the first / last TWO rows of A p to the waves above / below, lane 1's / 62's pixels to the strips beside
     (corner pixels of the halo rows from the diagonal neighbours' records) and the workgroup's sums to every workgroup as tagged granules; no launch boundary, no grid barrier.
     Geometry, row step and summation order are the marching pair kernel's: with the same rows per wave every alpha_k / beta_k, the costs and the unknowns are BIT-identical to
-    one launch per iteration.  Sizes: the reference's data set, ragged strips, short last segments (67 = 16 x 4 + 3, 35), one strip, 2 x 2, three strips, a wide flat image.
-    full = 1 (the default where at most 6 rows per wave hold the image): precompute and PCGInit1 happen inside the launch too -- the planes of the held rows formed in
-    registers, r_0 on the wave's rows, its halo and alphaN_0 through one more exchange in front of the loop: a GN step is ONE launch that reads and writes the unknowns only;
-    full = 0 (THALLO_AB sfs_resident_full=0): precompute and PCGInit1 as launches of their own.  Both bit-identical to the launches."""
+    one launch per iteration.  Sizes: the reference's data set, ragged strips, short last segments (67 = 16 x 4 + 3, 35), one strip, 2 x 2, three strips, a wide flat image."""
     L = thallo_amd.lib()
     L.thallo_hip_sfs_resident_rows.restype = C.c_int
     R = L.thallo_hip_sfs_resident_rows(W, H)
     assert 2 <= R <= 8, R
     p = syn.shape_from_shading(W, H)
     runs = []
-    L.thallo_hip_sfs_resident_rows_full.restype = C.c_int
-    whole = full == "1" and L.thallo_hip_sfs_resident_rows_full(W, H) > 0
-    set_ab(monkeypatch, sfs_resident_full=full)
     for resident in (True, False):
         monkeypatch.setenv("THALLO_RESIDENT", "1" if resident else "0")
         monkeypatch.setenv("THALLO_DELTA_PLANES", "0")        # (delta inside the iteration's launch, as the resident loop forms it: one fma per iteration and element)
@@ -1877,8 +1870,7 @@ def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(tor
         runs.append((costs, traces, dev[16].clone(), names))
     (c0, t0, x0, n0), (c1, t1, x1, n1) = runs
     assert all(np.isfinite(c0)) and len(c0) == nit + 1 and len(t0[0]) == lit
-    if whole: assert n0.get("GNStepResident", {}).get("launches") == nit and not ({"PCGIteration", "PCGInit1", "precompute", "PCGLinearUpdate", "PCGLoopResident"} & {k for k, v in n0.items() if v["launches"]}), n0
-    else: assert n0.get("PCGLoopResident", {}).get("launches") == nit and "PCGIteration" not in n0, n0
+    assert n0.get("PCGLoopResident", {}).get("launches") == nit and "PCGIteration" not in n0, n0
     assert n1.get("PCGIteration", {}).get("launches") == nit * lit and "PCGLoopResident" not in n1, n1
     assert t0 == t1, [(i, k, u, v) for i, (x, y) in enumerate(zip(t0, t1)) for k, (u, v) in enumerate(zip(x, y)) if u != v][:3]
     assert c0 == c1, (c0, c1)

@@ -343,6 +343,49 @@ __global__ __launch_bounds__(PM_NT, OCC) void k_pmarch(PmGeo g, PCam cm, const f
     else block_store_partial(accf, part_out, red);
 }
 
+// ------------------------------------------------------------------------------------------ precompute on pixel pairs, closed-form partials
+// BI(c) = B(n^(X(c), X(c-ex), X(c-ey))) - I(c) and its three partials (shape_from_shading.t:40-80).  With c, l, u the three depths,
+//   n = ( u (c-l) / f_y,  l (c-u) / f_x,  n_x a_x + n_y a_y - l u / (f_x f_y) ),   a_x = (u_x - x) / f_x, a_y = (u_y - y) / f_y,   n^ = n / |n|,
+//   B = L1 + L2 n^_y + L3 n^_z + L4 n^_x + L5 n^_x n^_y + L6 n^_y n^_z + L7 (-n^_x^2 - n^_y^2 + 2 n^_z^2) + L8 n^_z n^_x + L9 (n^_x^2 - n^_y^2)
+// the chain rule collapses to ONE 3-vector:  h = |n|^-1 (g - n^ (g . n^)),  g = grad_n^ B;  dB/dq = h . dn/dq  for q in {c, l, u}, and dn/dq are the products above with
+// one factor removed.  Values go through eval_BI_vals' operations in its order (energy_sfs.hip); the partials agree with its forward-mode duals to rounding.
+struct BIv { v2f b, dc, dl, du; };
+__device__ __forceinline__ BIv eval_BI_pair(const PCam& cm, v2f Dl, v2f Dc, v2f Du, v2f c, v2f l, v2f u, v2f Ic, v2f Il, v2f Iu, v2f ax, float ay)
+{
+    const v2f Z2 = { 0.f, 0.f };
+    const M2 on = { Dl.x > 0.0f && Dc.x > 0.0f && Du.x > 0.0f, Dl.y > 0.0f && Dc.y > 0.0f && Du.y > 0.0f };
+    const float ify = 1.0f / cm.fy, ifx = 1.0f / cm.fx, kxy = 1.0f / (cm.fx * cm.fy);
+    const v2f cl = c - l, cu = c - u;
+    const v2f nx = (u * cl) * ify;
+    const v2f ny = (l * cu) * ifx;
+    const v2f nz = (nx * ax + ny * ay) - (l * u) * kxy;
+    const v2f sq = nx * nx + ny * ny + nz * nz;
+    const M2 pos = { sq.x > 0.0f, sq.y > 0.0f };
+    const v2f inv = sel(pos, v2f{ 1.0f / sqrtf(sq.x), 1.0f / sqrtf(sq.y) }, splat(1.0f));
+    const v2f n0 = inv * nx, n1 = inv * ny, n2 = inv * nz;
+    const float* L = cm.L;
+    v2f B = splat(L[0]);
+    B = B + n1 * L[1]; B = B + n2 * L[2]; B = B + n0 * L[3];
+    B = B + (n0 * n1) * L[4]; B = B + (n1 * n2) * L[5];
+    B = B + (((n0 * n0) * -1.0f - n1 * n1) + (n2 * n2) * 2.0f) * L[6];
+    B = B + (n2 * n0) * L[7]; B = B + (n0 * n0 - n1 * n1) * L[8];
+    const v2f I = Ic * 0.5f + 0.25f * (Il + Iu);
+    // gradient of the SH polynomial in n^
+    const v2f g0 = L[3] + n1 * L[4] - (2.0f * L[6]) * n0 + n2 * L[7] + (2.0f * L[8]) * n0;
+    const v2f g1 = L[1] + n0 * L[4] + n2 * L[5] - (2.0f * L[6]) * n1 - (2.0f * L[8]) * n1;
+    const v2f g2 = L[2] + n1 * L[5] + (4.0f * L[6]) * n2 + n0 * L[7];
+    const v2f gn = g0 * n0 + g1 * n1 + g2 * n2;
+    const v2f h0 = sel(pos, inv * (g0 - n0 * gn), g0), h1 = sel(pos, inv * (g1 - n1 * gn), g1), h2 = sel(pos, inv * (g2 - n2 * gn), g2);
+    const v2f A = h0 + h2 * ax, Bq = h1 + h2 * ay, Cq = h2 * kxy;
+    const v2f uf = u * ify, lf = l * ifx;
+    BIv r;
+    r.b  = sel(on, B - I, Z2);
+    r.dc = sel(on, A * uf + Bq * lf, Z2);
+    r.dl = sel(on, Bq * (cu * ifx) - A * uf - Cq * u, Z2);
+    r.du = sel(on, A * (cl * ify) - Bq * lf - Cq * l, Z2);
+    return r;
+}
+
 struct PpRaw { u32x2 x, d, im; unsigned mr, mc; };
 
 // COST: computeCost (k_cost's terms in k_cost's order) of the rows [c0, c1) rides along, one row behind the planes

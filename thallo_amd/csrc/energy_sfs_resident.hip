@@ -21,15 +21,13 @@
 #include "sfs_pair.hpp"
 #include "sfs_pair_device.hpp"
 #include <cstring>
-#include <stdint.h>
-#include <type_traits>
 
 using namespace thallo;
 
 namespace {
 
 constexpr int SR_NT = 256;                // 4 waves = 4 vertically adjacent segments of one strip (one workgroup per CU)
-constexpr int SR_MIN_R = 2, SR_MAX_R = 8, SR_MAX_R_FULL = 6, SR_MAX_R_LM = 5;       // (LM: 18 registers per held row and lane + the own rows' CtC and b; from 6 rows on the compiler spills) // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
+constexpr int SR_MIN_R = 2, SR_MAX_R = 8, SR_MAX_R_LM = 5;       // (LM: 18 registers per held row and lane + the own rows' CtC and b; from 6 rows on the compiler spills) // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -65,8 +63,6 @@ struct SrArgs {
     float* words;                                 // words[2k] = alphaD_k, words[2k + 1] = betaN_k
     float* X;                                     // the unknowns, or NULL (GN only): PCGLinearUpdate stays a launch of its own
     int L;
-    // FULL (GN): the problem's images -- X (= the unknowns above), the target depth, the intensity, the two edge masks; the global image height; where alphaN_0 goes as a word
-    const float* D; const float* Im; const unsigned char* mR; const unsigned char* mC; int Hg; float* aN0_word;
     // LM
     const float* pre; const float* ctc;           // M^-1 and CtC of PCGFinalizeDiagonal (b = r_0)
     float* state; float q_tol;                    // lm state words ([0] Q0, [1] gate, [2] iterations done at the stop); the zeta test's tolerance
@@ -114,10 +110,7 @@ struct SrLds {
 // divisions, the three sums of q's expansion beside {N, S1, S2}, the zeta test after every iteration (every workgroup for itself, from the same sums: the same decision
 // everywhere) -- and behind the loop the update of delta it still owes, the model cost's J^T J delta and two dot products, savePreviousUnknowns and PCGLinearUpdate
 // (k_pmarch<MODEL>'s launch), all from the registers the loop leaves.
-// FULL (Gauss-Newton): precompute and PCGInit1 happen inside the launch too -- the planes of the held rows are formed from X, D, I and the masks (k_pprecompute's row step),
-// r_0 = -J^T F on the wave's own rows through the same row step (k_pmarch<INIT>'s expressions), its halo and alphaN_0 = r_0 . r_0 through ONE more exchange in front of the
-// loop: a GN step is this launch and nothing else (no plane, no solver vector is read or written; X is updated in place).
-template <int R, bool LM, bool FULL>
+template <int R, bool LM>
 __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 {
     constexpr int NR = R + 4;             // held rows: jj = 0, 1 the rows above, 2 .. R + 1 my own, R + 2, R + 3 the rows below (row t = ya - 2 + jj)
@@ -188,53 +181,8 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 
     // ---- state.  delta: my own rows (GN); every held row (LM: the model cost's J^T J delta needs delta on the halo, and it is formed there from what the halo holds anyway)
     v2f rr[NR], pp[NR], Ap[NR], gx[NR], gy[NR], gz[NR], dl[NR], mi[LM ? NR : 1], ct[LM ? R : 1], bb[LM ? R : 1];
-    v2f bi[FULL ? NR : 1], Xm[FULL ? NR : 1], Dm[FULL ? R : 1];      // FULL: BI, the masked unknowns of the held rows, the masked D of my own rows (transient: PCGInit1's inputs)
     unsigned fwx[NR], fwy[NR];
-    if constexpr (FULL) {
-        // ---- precompute for the held rows (k_pprecompute's step per row; nothing is stored): inputs of rows ya - 3 .. yb + 2
-        v2f Xe[NR + 2], De[NR + 2], Ie[NR + 2]; unsigned Mre[NR + 2], Mce[NR + 2];
-#pragma unroll
-        for (int e = 0; e < NR + 2; ++e) {
-            const int t = ya - 3 + e;
-            const bool ok = nr > 0 && xin && t >= 0 && t < H;
-            const int tc = t < 0 ? 0 : t > H - 1 ? H - 1 : t;
-            const long i = (long)tc * W + xcl;
-            const float2 x2 = *reinterpret_cast<const float2*>(a.X + i), d2 = *reinterpret_cast<const float2*>(a.D + i), i2 = *reinterpret_cast<const float2*>(a.Im + i);
-            const unsigned mr = *reinterpret_cast<const unsigned short*>(a.mR + i), mc = *reinterpret_cast<const unsigned short*>(a.mC + i);
-            Xe[e] = sel(ok, v2f{ x2.x, x2.y }, Z2); De[e] = sel(ok, v2f{ d2.x, d2.y }, Z2); Ie[e] = sel(ok, v2f{ i2.x, i2.y }, Z2);
-            Mre[e] = ok ? mr : 0u; Mce[e] = ok ? mc : 0u;
-        }
-        const v2f ax = { (cm.ux - (float)x0) / cm.fx, (cm.ux - (float)(x0 + 1)) / cm.fx };
-        const M2 xinner = { x0 >= 1 && x0 + 1 < W, x0 + 2 < W };
-#pragma unroll
-        for (int jj = 0; jj < NR; ++jj) {
-            const int e = jj + 1, T = ya - 2 + jj;
-            const v2f xc = Xe[e], dc = De[e], ic = Ie[e];
-            const v2f xl = nbL(xc), dlf = nbL(dc), il = nbL(ic), xr = nbR(xc), dr = nbR(dc);
-            const BIv b = eval_BI_pair(cm, dlf, dc, De[e - 1], xc, xl, Xe[e - 1], ic, il, Ie[e - 1], ax, (cm.uy - (float)(T + g.yoff)) / cm.fy);
-            const int yg = T + g.yoff;
-            const bool yinner = yg >= 1 && yg + 1 < a.Hg;
-            const unsigned mr0 = (yinner && xinner.x) ? Mre[e] & 0xffu : 0u, mr1 = (yinner && xinner.y) ? (Mre[e] >> 8) & 0xffu : 0u;
-            const unsigned mc0 = (yinner && xinner.x) ? Mce[e] & 0xffu : 0u, mc1 = (yinner && xinner.y) ? (Mce[e] >> 8) & 0xffu : 0u;
-            unsigned fa = dc.x > 0.0f ? 1u : 0u, fb = dc.y > 0.0f ? 1u : 0u;
-            bool va = fa != 0u, vb = fb != 0u;
-            va = va && dlf.x > 0.0f && fabsf(xc.x - xl.x) < 0.01f;               // (x-1, y), (x, y-1), (x+1, y), (x, y+1): k_precompute's order
-            vb = vb && dlf.y > 0.0f && fabsf(xc.y - xl.y) < 0.01f;
-            va = va && De[e - 1].x > 0.0f && fabsf(xc.x - Xe[e - 1].x) < 0.01f;
-            vb = vb && De[e - 1].y > 0.0f && fabsf(xc.y - Xe[e - 1].y) < 0.01f;
-            va = va && dr.x > 0.0f && fabsf(xc.x - xr.x) < 0.01f;
-            vb = vb && dr.y > 0.0f && fabsf(xc.y - xr.y) < 0.01f;
-            va = va && De[e + 1].x > 0.0f && fabsf(xc.x - Xe[e + 1].x) < 0.01f;
-            vb = vb && De[e + 1].y > 0.0f && fabsf(xc.y - Xe[e + 1].y) < 0.01f;
-            if (va) fa |= 2u;
-            if (vb) fb |= 2u;
-            fwx[jj] = fa | (mr0 << 8) | (mc0 << 16); fwy[jj] = fb | (mr1 << 8) | (mc1 << 16);
-            gx[jj] = b.dc; gy[jj] = b.dl; gz[jj] = b.du; bi[FULL ? jj : 0] = b.b;
-            Xm[FULL ? jj : 0] = xc;
-            if (jj >= 2 && jj < R + 2) Dm[FULL ? jj - 2 : 0] = dc;
-            rr[jj] = Z2; pp[jj] = Z2; Ap[jj] = Z2; dl[jj] = Z2;
-        }
-    } else {
+    {
         const float* Gp = a.G;
 #pragma unroll
         for (int jj = 0; jj < NR; ++jj) {
@@ -259,7 +207,8 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         }
     }
 
-    float aN_prev = FULL ? 0.0f : sum_partials(a.aN0.partials, a.aN0.count);      // alphaN_{k-1}; FULL: the exchange in front of the loop delivers alphaN_0
+    const float aN0 = sum_partials(a.aN0.partials, a.aN0.count);
+    float aN_prev = aN0;                  // alphaN_{k-1}
     float alpha = 0.0f, beta = 0.0f;
     float q_prev = LM ? a.state[0] : 0.0f;     // Q0 of the zeta test (0 behind thallo_hip_lm_state_reset: delta = 0, gauss_newton.t:965)
     bool stopped = false;
@@ -322,8 +271,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     };
     // J^T J v for my rows from the held rows V (k_pmarch's row step: dB -> U_h, U_v -> T -> J^T, the Laplacian rows; every lane takes part in the exchanges);
     // emit(jj, vc, s) for every output row jj = 2 .. nr + 1 on the output lanes
-    auto stencil = [&](const v2f (&V)[NR], auto init_tag, auto&& emit) __attribute__((always_inline)) {
-        constexpr bool INIT = decltype(init_tag)::value;      // PCGInit1's J^T F (k_pmarch<INIT>): dB is BI itself, the depth term works on X - D, V = the masked unknowns
+    auto stencil = [&](const v2f (&V)[NR], auto&& emit) __attribute__((always_inline)) {
         v2f dB[NR], Uh[NR], Uv[NR], Tt[NR], Rr[NR][3];
         unsigned Fl[NR]; float Cy[NR];
 #pragma unroll
@@ -339,7 +287,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             const bool ok = row_ok(jj);
             const v2f v0 = V[jj], v1 = V[jj - 1];
             const v2f vl0 = nbL(v0);
-            const v2f dB0 = sel(ok, INIT ? bi[FULL ? jj : 0] : gx[jj] * v0 + gy[jj] * vl0 + gz[jj] * v1, Z2);
+            const v2f dB0 = sel(ok, gx[jj] * v0 + gy[jj] * vl0 + gz[jj] * v1, Z2);
             const v2f dBr = nbR(dB0);
             const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
             const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
@@ -380,7 +328,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             if (jj - 2 < nr && xout) {
                 const v2f vc = V[jj];
                 v2f s = Z2;
-                s = sel(bit(Fl[jj], 1u), s + cm.wp * (cm.wp * (INIT ? vc - Dm[FULL ? jj - 2 : 0] : vc)), s);
+                s = sel(bit(Fl[jj], 1u), s + cm.wp * (cm.wp * vc), s);
                 s += gx[jj] * T2;
                 s = sel(xp1, s + gT2r, s);
                 if (y + 1 < H) s += gz[jj + 1] * T1;
@@ -409,146 +357,69 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         }
     };
 
-    // The one synchronisation point: what the neighbours and every workgroup published under tag Tp in buffer parp -- the two halo rows above and below (lanes 1..62) and the
-    // halo lanes' pixels of every held row (columns, through LDS) into Hh, my quarter of the sums records into wq.  Everything is polled in ONE loop, all loads of a pass in flight.
-    auto sync_halo = [&](int parp, unsigned Tp, v2f (&Hh)[NR], unsigned (&wq)[NWD]) __attribute__((always_inline)) {
-        // ---- the one synchronisation point: my quarter of the sums of iteration k-1, the two rows of A p_{k-1} from the wave above and from the wave below, one
-        // word per lane of the columns from the strips to the left / right.  Everything is polled in ONE loop, all loads of a pass in flight together.
-        float cvl = 0.f, cvr = 0.f;
-        v2f ru0 = Z2, ru1 = Z2, rd0 = Z2, rd1 = Z2;
-#pragma unroll
-        for (int c = 0; c < NWD; ++c) wq[c] = 0u;
-        {
-            const bool need_u = xout && has_up, need_d = xout && has_dn, need_s = slot_live;
-            const unsigned usrc = rowh(parp, has_up ? wid - 1 : wid, 1), dsrc = rowh(parp, has_dn ? wid + 1 : wid, 0);
-            const unsigned clsrc = colh(parp, need_cl ? wid - g.nseg + c_dw : wid, 1, c_word), crsrc = colh(parp, need_cr ? wid + g.nseg + c_dw : wid, 0, c_word);
-            bool ok_s = !need_s, ok_u = !need_u, ok_d = !need_d, ok_cl = !need_cl, ok_cr = !need_cr;
-            sp.n = 0; sp.t0 = 0;
-            while (!(ok_s && ok_u && ok_d && ok_cl && ok_cr) && !dead) {
-                asm volatile("" ::: "memory");                     // (every pass re-reads: nothing may be hoisted out of the loop)
-                u32x4 vs[NLD], vu[2], vd[2]; u32x2 vcl, vcr;
-                if (!ok_s) {
-#pragma unroll
-                    for (int c = 0; c < NLD; ++c) vs[c] = ld2g(RS_SUM, sumw(parp, c, slot));
-                }
-                if (!ok_u) { vu[0] = ld2g(RS_ROW, usrc); vu[1] = ld2g(RS_ROW, usrc + row2); }
-                if (!ok_d) { vd[0] = ld2g(RS_ROW, dsrc); vd[1] = ld2g(RS_ROW, dsrc + row2); }
-                if (!ok_cl) vcl = ld1g(RS_COL, clsrc);
-                if (!ok_cr) vcr = ld1g(RS_COL, crsrc);
-                if (!ok_s) {
-                    bool all = true;
-#pragma unroll
-                    for (int c = 0; c < NLD; ++c) {
-                        wq[2 * c] = vs[c].x; all = all && vs[c].y == Tp;
-                        if (2 * c + 1 < NWD) { wq[2 * c + 1] = vs[c].z; all = all && vs[c].w == Tp; }
-                    }
-                    ok_s = all;
-                }
-                if (!ok_u) {
-                    ru0 = v2f{ __uint_as_float(vu[0].x), __uint_as_float(vu[0].z) }; ru1 = v2f{ __uint_as_float(vu[1].x), __uint_as_float(vu[1].z) };
-                    ok_u = vu[0].y == Tp && vu[0].w == Tp && vu[1].y == Tp && vu[1].w == Tp;
-                }
-                if (!ok_d) {
-                    rd0 = v2f{ __uint_as_float(vd[0].x), __uint_as_float(vd[0].z) }; rd1 = v2f{ __uint_as_float(vd[1].x), __uint_as_float(vd[1].z) };
-                    ok_d = vd[0].y == Tp && vd[0].w == Tp && vd[1].y == Tp && vd[1].w == Tp;
-                }
-                if (!ok_cl) { cvl = __uint_as_float(vcl.x); ok_cl = vcl.y == Tp; }
-                if (!ok_cr) { cvr = __uint_as_float(vcr.x); ok_cr = vcr.y == Tp; }
-                if (!(ok_s && ok_u && ok_d && ok_cl && ok_cr) && spin_fail(sp, ctl, !ok_s ? 1u : !(ok_u && ok_d) ? 3u : 4u, (unsigned)wid, Tp)) dead = true;
-            }
-            if (need_u) { Hh[0] = ru0; Hh[1] = ru1; }
-            if (need_d) { Hh[R + 2] = rd0; Hh[R + 3] = rd1; }
-        }
-        dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
-        // the columns go through LDS to the two lanes that hold them (lane 0 / 63); same wave: program order + lgkmcnt(0)
-        if (need_cl) S.crx[wave][0][c_dst] = cvl;
-        if (need_cr) S.crx[wave][1][c_dst] = cvr;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if ((lane == 0 && has_lf) || (lane == 63 && has_rt)) {
-            const float* cx = &S.crx[wave][lane == 0 ? 0 : 1][0];
-#pragma unroll
-            for (int jj = 0; jj < NR; ++jj) Hh[jj] = v2f{ cx[2 * jj], cx[2 * jj + 1] };
-        }
-    };
-    // Publish under tag T in buffer par: the first / last two of my rows of Hh (lanes 1..62), my two columns (lanes 1 / 62 wrote them to S.cst; one store instruction each),
-    // then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the four waves up in order and publishes the record)
-    auto publish = [&](int par, unsigned T, const v2f (&Hh)[NR], v2f pacc, const Sums3& psm, const SumsQ& psq, int kf) __attribute__((always_inline)) {
-    // ---- publish: the boundary rows, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the four
-    // waves up in order and publishes the record)
-    {
-        if (xout && has_up) { const unsigned d = rowh(par, wid, 0); st2g(RS_ROW, d, T, Hh[2].x, Hh[2].y); st2g(RS_ROW, d + row2, T, Hh[3].x, Hh[3].y); }
-        if (xout && has_dn) { const unsigned d = rowh(par, wid, 1); st2g(RS_ROW, d, T, Hh[R].x, Hh[R].y); st2g(RS_ROW, d + row2, T, Hh[R + 1].x, Hh[R + 1].y); }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the columns written to LDS above)
-        if (col_pub && has_lf) st1g(RS_COL, colh(par, wid, 0, lane), T, __float_as_uint(S.cst[wave][0][lane]));
-        if (col_pub && has_rt) st1g(RS_COL, colh(par, wid, 1, lane), T, __float_as_uint(S.cst[wave][1][lane]));
-        const float accf = pacc.x + pacc.y;
-        const float wa = wave_sum_all(accf);
-        double wsum[NQ];
-        wsum[0] = wave_sum_all_f64(psm.n); wsum[1] = wave_sum_all_f64(psm.s1); wsum[2] = wave_sum_all_f64(psm.s2);
-        if (LM) { wsum[NQ - 3] = wave_sum_all_f64(psq.u); wsum[NQ - 2] = wave_sum_all_f64(psq.t1); wsum[NQ - 1] = wave_sum_all_f64(psq.t2); }
-        if (lane == 0) {
-            S.wa[wave] = wa;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) S.wd[wave][q] = wsum[q];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (wave == 0) {
-            sp.n = 0; sp.t0 = 0;
-            while (!dead) {
-                const unsigned t1 = __hip_atomic_load(&S.wtag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), t2 = __hip_atomic_load(&S.wtag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned t3 = __hip_atomic_load(&S.wtag[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (t1 == T && t2 == T && t3 == T) break;
-                if (spin_fail(sp, ctl, 5u, 0u, T)) dead = true;
-            }
-            dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < NWD) {
-                float s = 0.0f; double b[NQ];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) b[q] = 0.0;
-                for (int w = 0; w < 4; ++w) {
-                    s += S.wa[w];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) b[q] += S.wd[w][q];
-                }
-                double pick = b[0];
-#pragma unroll
-                for (int q = 1; q < NQ; ++q) if (lane >= 1 + 2 * q) pick = b[q];
-                const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
-                if (!((g.ab & 4) && id == 1 && kf == 2)) st1g(RS_SUM, sumw(par, lane >> 1, blockIdx.x) + 8 * (lane & 1), T, word);
-            }
-        }
-    }
-    };
-    constexpr unsigned TAG0 = FULL ? 1u : 0u;      // FULL: the exchange in front of the loop takes the launch's first tag
-    if constexpr (FULL) {
-        // ---- PCGInit1 inside the launch: r_0 = -J^T F on my rows (k_pmarch<INIT>'s row step on the planes just formed), z = r, p_prev = 0, delta = 0; then ONE exchange:
-        // r_0's boundary rows and columns to the neighbours (their halo), the workgroup's part of r_0 . r_0 to everybody (alphaN_0: PCGInit1's partials, added in its order)
-        v2f acc0 = Z2;
-        stencil(Xm, std::true_type{}, [&](int jj, v2f vc, v2f s) __attribute__((always_inline)) {
-            (void)vc;
-            const v2f r = -s;
-            rr[jj] = r; acc0 += r * r;
-            if (lane == 1 || lane == 62) { float* d = &S.cst[wave][lane == 1 ? 0 : 1][2 * (jj - 2)]; d[0] = r.x; d[1] = r.y; }
-        });
-        const unsigned T0 = seq + 1u;
-        publish(1, T0, rr, acc0, Sums3{}, SumsQ{}, -1);
-        unsigned wq[NWD];
-        sync_halo(1, T0, rr, wq);
-        float ad; double tot[NQ];
-        exchange_scalars(T0, wq, ad, tot);
-        aN_prev = ad;
-        if (writer) a.aN0_word[0] = ad;
-    }
     for (int k = 0; k < a.L; ++k) {
-        const unsigned T = seq + TAG0 + (unsigned)k + 1u, Tp = T - 1u;
+        const unsigned T = seq + (unsigned)k + 1u, Tp = T - 1u;
         const int par = k & 1, parp = par ^ 1;
         SR_STAMP(k, 0);
         if (k > 0) {
-            unsigned wq[NWD];
-            sync_halo(parp, Tp, Ap, wq);
+            // ---- the one synchronisation point: my quarter of the sums of iteration k-1, the two rows of A p_{k-1} from the wave above and from the wave below, one
+            // word per lane of the columns from the strips to the left / right.  Everything is polled in ONE loop, all loads of a pass in flight together.
+            unsigned wq[NWD]; float cvl = 0.f, cvr = 0.f;
+            v2f ru0 = Z2, ru1 = Z2, rd0 = Z2, rd1 = Z2;
+#pragma unroll
+            for (int c = 0; c < NWD; ++c) wq[c] = 0u;
+            {
+                const bool need_u = xout && has_up, need_d = xout && has_dn, need_s = slot_live;
+                const unsigned usrc = rowh(parp, has_up ? wid - 1 : wid, 1), dsrc = rowh(parp, has_dn ? wid + 1 : wid, 0);
+                const unsigned clsrc = colh(parp, need_cl ? wid - g.nseg + c_dw : wid, 1, c_word), crsrc = colh(parp, need_cr ? wid + g.nseg + c_dw : wid, 0, c_word);
+                bool ok_s = !need_s, ok_u = !need_u, ok_d = !need_d, ok_cl = !need_cl, ok_cr = !need_cr;
+                sp.n = 0; sp.t0 = 0;
+                while (!(ok_s && ok_u && ok_d && ok_cl && ok_cr) && !dead) {
+                    asm volatile("" ::: "memory");                     // (every pass re-reads: nothing may be hoisted out of the loop)
+                    u32x4 vs[NLD], vu[2], vd[2]; u32x2 vcl, vcr;
+                    if (!ok_s) {
+#pragma unroll
+                        for (int c = 0; c < NLD; ++c) vs[c] = ld2g(RS_SUM, sumw(parp, c, slot));
+                    }
+                    if (!ok_u) { vu[0] = ld2g(RS_ROW, usrc); vu[1] = ld2g(RS_ROW, usrc + row2); }
+                    if (!ok_d) { vd[0] = ld2g(RS_ROW, dsrc); vd[1] = ld2g(RS_ROW, dsrc + row2); }
+                    if (!ok_cl) vcl = ld1g(RS_COL, clsrc);
+                    if (!ok_cr) vcr = ld1g(RS_COL, crsrc);
+                    if (!ok_s) {
+                        bool all = true;
+#pragma unroll
+                        for (int c = 0; c < NLD; ++c) {
+                            wq[2 * c] = vs[c].x; all = all && vs[c].y == Tp;
+                            if (2 * c + 1 < NWD) { wq[2 * c + 1] = vs[c].z; all = all && vs[c].w == Tp; }
+                        }
+                        ok_s = all;
+                    }
+                    if (!ok_u) {
+                        ru0 = v2f{ __uint_as_float(vu[0].x), __uint_as_float(vu[0].z) }; ru1 = v2f{ __uint_as_float(vu[1].x), __uint_as_float(vu[1].z) };
+                        ok_u = vu[0].y == Tp && vu[0].w == Tp && vu[1].y == Tp && vu[1].w == Tp;
+                    }
+                    if (!ok_d) {
+                        rd0 = v2f{ __uint_as_float(vd[0].x), __uint_as_float(vd[0].z) }; rd1 = v2f{ __uint_as_float(vd[1].x), __uint_as_float(vd[1].z) };
+                        ok_d = vd[0].y == Tp && vd[0].w == Tp && vd[1].y == Tp && vd[1].w == Tp;
+                    }
+                    if (!ok_cl) { cvl = __uint_as_float(vcl.x); ok_cl = vcl.y == Tp; }
+                    if (!ok_cr) { cvr = __uint_as_float(vcr.x); ok_cr = vcr.y == Tp; }
+                    if (!(ok_s && ok_u && ok_d && ok_cl && ok_cr) && spin_fail(sp, ctl, !ok_s ? 1u : !(ok_u && ok_d) ? 3u : 4u, (unsigned)wid, Tp)) dead = true;
+                }
+                if (need_u) { Ap[0] = ru0; Ap[1] = ru1; }
+                if (need_d) { Ap[R + 2] = rd0; Ap[R + 3] = rd1; }
+            }
+            dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
             SR_STAMP(k, 1);
+            // the columns go through LDS to the two lanes that hold them (lane 0 / 63); same wave: program order + lgkmcnt(0)
+            if (need_cl) S.crx[wave][0][c_dst] = cvl;
+            if (need_cr) S.crx[wave][1][c_dst] = cvr;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((lane == 0 && has_lf) || (lane == 63 && has_rt)) {
+                const float* cx = &S.crx[wave][lane == 0 ? 0 : 1][0];
+#pragma unroll
+                for (int jj = 0; jj < NR; ++jj) Ap[jj] = v2f{ cx[2 * jj], cx[2 * jj + 1] };
+            }
             float ad; double tot[NQ];
             exchange_scalars(Tp, wq, ad, tot);
             finish(k - 1, ad, tot);
@@ -571,7 +442,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         SR_STAMP(k, 3);
         // ---- A p_k for my rows, the sums
         v2f acc = Z2; Sums3 sm; SumsQ sq;
-        stencil(pp, std::false_type{}, [&](int jj, v2f vc, v2f s) __attribute__((always_inline)) {
+        stencil(pp, [&](int jj, v2f vc, v2f s) __attribute__((always_inline)) {
             if (LM) s += ct[LM ? jj - 2 : 0] * vc;
             acc += vc * s;
             const v2f rk = rr[jj], mk = LM ? mi[LM ? jj : 0] : splat(1.0f);
@@ -581,14 +452,60 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             if (lane == 1 || lane == 62) { float* d = &S.cst[wave][lane == 1 ? 0 : 1][2 * (jj - 2)]; d[0] = s.x; d[1] = s.y; }
         });
         SR_STAMP(k, 4);
-        publish(par, T, Ap, acc, sm, sq, k);
+        // ---- publish: the boundary rows, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the four
+        // waves up in order and publishes the record)
+        {
+            if (xout && has_up) { const unsigned d = rowh(par, wid, 0); st2g(RS_ROW, d, T, Ap[2].x, Ap[2].y); st2g(RS_ROW, d + row2, T, Ap[3].x, Ap[3].y); }
+            if (xout && has_dn) { const unsigned d = rowh(par, wid, 1); st2g(RS_ROW, d, T, Ap[R].x, Ap[R].y); st2g(RS_ROW, d + row2, T, Ap[R + 1].x, Ap[R + 1].y); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the columns written to LDS above)
+            if (col_pub && has_lf) st1g(RS_COL, colh(par, wid, 0, lane), T, __float_as_uint(S.cst[wave][0][lane]));
+            if (col_pub && has_rt) st1g(RS_COL, colh(par, wid, 1, lane), T, __float_as_uint(S.cst[wave][1][lane]));
+            const float accf = acc.x + acc.y;
+            const float wa = wave_sum_all(accf);
+            double wsum[NQ];
+            wsum[0] = wave_sum_all_f64(sm.n); wsum[1] = wave_sum_all_f64(sm.s1); wsum[2] = wave_sum_all_f64(sm.s2);
+            if (LM) { wsum[NQ - 3] = wave_sum_all_f64(sq.u); wsum[NQ - 2] = wave_sum_all_f64(sq.t1); wsum[NQ - 1] = wave_sum_all_f64(sq.t2); }
+            if (lane == 0) {
+                S.wa[wave] = wa;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) S.wd[wave][q] = wsum[q];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&S.wtag[wave], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave == 0) {
+                sp.n = 0; sp.t0 = 0;
+                while (!dead) {
+                    const unsigned t1 = __hip_atomic_load(&S.wtag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), t2 = __hip_atomic_load(&S.wtag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned t3 = __hip_atomic_load(&S.wtag[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (t1 == T && t2 == T && t3 == T) break;
+                    if (spin_fail(sp, ctl, 5u, 0u, T)) dead = true;
+                }
+                dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < NWD) {
+                    float s = 0.0f; double b[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) b[q] = 0.0;
+                    for (int w = 0; w < 4; ++w) {
+                        s += S.wa[w];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) b[q] += S.wd[w][q];
+                    }
+                    double pick = b[0];
+#pragma unroll
+                    for (int q = 1; q < NQ; ++q) if (lane >= 1 + 2 * q) pick = b[q];
+                    const unsigned word = lane == 0 ? __float_as_uint(s) : (lane & 1) ? (unsigned)__double2hiint(pick) : (unsigned)__double2loint(pick);
+                    if (!((g.ab & 4) && id == 1 && k == 2)) st1g(RS_SUM, sumw(par, lane >> 1, blockIdx.x) + 8 * (lane & 1), T, word);
+                }
+            }
+        }
         SR_STAMP(k, 5);
     }
     // ---- behind the loop.  Whoever needs alpha of the last iteration (the writer's workgroup: the two words; every workgroup when the update of the unknowns rides along,
     // and in LM) sweeps the last sums -- unless the zeta test has ended the loop, whose finish is done.
     const bool need_last = a.L > 0 && !stopped && (id == 0 || a.X != nullptr || LM);
     if (need_last) {      // (uniform per workgroup: all four waves take part in the sweep)
-        const unsigned T = seq + TAG0 + (unsigned)a.L; const int par = (a.L - 1) & 1;
+        const unsigned T = seq + (unsigned)a.L; const int par = (a.L - 1) & 1;
         unsigned wq[NWD];
         sweep_sums(par, T, wq);
         float ad; double tot[NQ];
@@ -598,7 +515,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     if (writer) {
         // the next launch's tags start behind this one's (seq + 1 .. seq + L were used): the counter lives on the device (replay-safe) and is advanced by the one thread
         // that is through only when every workgroup has published its last sums, i.e. has long read it
-        __hip_atomic_store(ctl + SR_SEQ, seq + TAG0 + (unsigned)a.L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + SR_SEQ, seq + (unsigned)a.L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!LM) {
         // what L launches would have left behind: r_{L-1}, p_{L-1}, A p_{L-1}, delta (without its last term); with X: PCGLinearUpdate (gauss_newton.t:901-906) riding along,
@@ -607,12 +524,10 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         for (int j = 0; j < R; ++j) {
             if (j < nr && xout) {
                 const long i = (long)(ya + j) * W + x0;
-                if (!FULL) {      // (FULL: a GN step reads and writes the unknowns only)
-                    *reinterpret_cast<float2*>(a.r_out + i) = make_float2(rr[j + 2].x, rr[j + 2].y);
-                    *reinterpret_cast<float2*>(a.p_out + i) = make_float2(pp[j + 2].x, pp[j + 2].y);
-                    *reinterpret_cast<float2*>(a.A_out + i) = make_float2(Ap[j + 2].x, Ap[j + 2].y);
-                    *reinterpret_cast<float2*>(a.delta + i) = make_float2(dl[j + 2].x, dl[j + 2].y);
-                }
+                *reinterpret_cast<float2*>(a.r_out + i) = make_float2(rr[j + 2].x, rr[j + 2].y);
+                *reinterpret_cast<float2*>(a.p_out + i) = make_float2(pp[j + 2].x, pp[j + 2].y);
+                *reinterpret_cast<float2*>(a.A_out + i) = make_float2(Ap[j + 2].x, Ap[j + 2].y);
+                *reinterpret_cast<float2*>(a.delta + i) = make_float2(dl[j + 2].x, dl[j + 2].y);
                 if (a.X != nullptr) {
                     const float2 xo = *reinterpret_cast<const float2*>(a.X + i);
                     const float d0 = __builtin_fmaf(alpha, pp[j + 2].x, dl[j + 2].x), d1 = __builtin_fmaf(alpha, pp[j + 2].y, dl[j + 2].y);
@@ -627,7 +542,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
 #pragma unroll
         for (int jj = 0; jj < NR; ++jj) { v2f v0 = fma2(alpha, pp[jj], dl[jj]); dv[jj] = sel(row_ok(jj), v0, Z2); }
         v2f acc = Z2, acc2 = Z2;
-        stencil(dv, std::false_type{}, [&](int jj, v2f vc, v2f s) __attribute__((always_inline)) { acc += vc * s; acc2 += vc * bb[LM ? jj - 2 : 0]; });
+        stencil(dv, [&](int jj, v2f vc, v2f s) __attribute__((always_inline)) { acc += vc * s; acc2 += vc * bb[LM ? jj - 2 : 0]; });
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             if (j < nr && xout) {
@@ -689,30 +604,30 @@ inline SrLayout sr_layout(const SrGeo& g)
     return l;
 }
 
-template <int R, bool LM, bool FULL> int sr_launch_r(const SrArgs& a, hipStream_t s)
+template <int R, bool LM> int sr_launch_r(const SrArgs& a, hipStream_t s)
 {
     const int grid = (a.g.total + 7) / 8 * 8;
     {   // co-residency is a precondition, not an assumption: the kernel's workgroups wait for each other (asked once per instantiation)
         static int fits = 0;
         if (fits == 0) {
             int per_cu = 0;
-            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sfs_resident<R, LM, FULL>, SR_NT, 0);
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sfs_resident<R, LM>, SR_NT, 0);
             fits = (e == hipSuccess && per_cu >= 1) ? per_cu : -1;
         }
         if (fits < 0 || (long)fits * thallo_hip_device_cu_count() < grid) return -(int)hipErrorNotSupported;
     }
     if (g_sr_spin_ms >= 0) { const unsigned v = (unsigned)g_sr_spin_ms; if (hipMemcpyAsync(a.b.ctl + SR_SPIN_MS, &v, sizeof(v), hipMemcpyHostToDevice, s) != hipSuccess) return -(int)hipErrorUnknown; }
-    hipLaunchKernelGGL((k_sfs_resident<R, LM, FULL>), dim3(grid), dim3(SR_NT), 0, s, a);
+    hipLaunchKernelGGL((k_sfs_resident<R, LM>), dim3(grid), dim3(SR_NT), 0, s, a);
     int e = check_launch(); return e ? e : grid;
 }
-template <bool LM, bool FULL> int sr_launch(const SrArgs& a, int R, hipStream_t s)
+template <bool LM> int sr_launch(const SrArgs& a, int R, hipStream_t s)
 {
     switch (R) {
-        case 2: return sr_launch_r<2, LM, FULL>(a, s); case 3: return sr_launch_r<3, LM, FULL>(a, s); case 4: return sr_launch_r<4, LM, FULL>(a, s); case 5: return sr_launch_r<5, LM, FULL>(a, s);
+        case 2: return sr_launch_r<2, LM>(a, s); case 3: return sr_launch_r<3, LM>(a, s); case 4: return sr_launch_r<4, LM>(a, s); case 5: return sr_launch_r<5, LM>(a, s);
         default: break;
     }
     if (!LM) switch (R) {
-        case 6: return sr_launch_r<6, false, FULL>(a, s); case 7: return sr_launch_r<7, false, FULL>(a, s); case 8: return sr_launch_r<8, false, FULL>(a, s);
+        case 6: return sr_launch_r<6, false>(a, s); case 7: return sr_launch_r<7, false>(a, s); case 8: return sr_launch_r<8, false>(a, s);
         default: break;
     }
     return -(int)hipErrorNotSupported;
@@ -766,36 +681,8 @@ int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params
     a.G = G; a.Fw = reinterpret_cast<const unsigned*>(Fw);
     a.r_in = r_in; a.p_in = p_in; a.r_out = r_out; a.A_out = Ap_out; a.p_out = p_out; a.delta = delta;
     a.aN0 = alphaN0; a.words = words; a.X = X; a.L = L;
-    return sr_launch<false, false>(a, R, (hipStream_t)stream);
+    return sr_launch<false>(a, R, (hipStream_t)stream);
 }
-
-/* A WHOLE Gauss-Newton step in one launch (round 6): precompute (the planes of the rows a wave holds, in registers), PCGInit1 (r_0 = -J^T F; alphaN_0 through one exchange in
- * front of the loop), L PCG iterations and PCGLinearUpdate -- from the problem's images alone: X (updated in place), the target depth D, the intensity I, the two edge masks.
- * words[2k] = alphaD_k, words[2k + 1] = betaN_k; alphaN0_word[0] = alphaN_0.  No plane and no solver vector is read or written.  The same bits as thallo_hip_sfs_precompute +
- * thallo_hip_sfs_pcg_init + L launches of thallo_hip_sfs_pcg_iter_deferred + thallo_hip_linear_update with the same rows per wave.  Whole image on one GPU (Hg = H, yoff = 0).
- * Replaces gauss_newton.t:979-986 + :712-731 + :1615-1687 + :901-906 for shapes whose solver state fits the chip's registers. */
-int thallo_hip_sfs_gn_step_resident(int W, int H, const float* host_params, float* X, const float* D, const float* Im, const unsigned char* edgeMaskR, const unsigned char* edgeMaskC,
-                                    float* alphaN0_word, float* words, void* xbuf, int L, thallo_stream_t stream)
-{
-    if (H < 1 || (W & 1) || W < 2 || L < 1 || !host_params) return -(int)hipErrorInvalidValue;
-    if (!X || !D || !Im || !edgeMaskR || !edgeMaskC || !alphaN0_word || !words || !xbuf) return -(int)hipErrorInvalidValue;
-    if (((uintptr_t)edgeMaskR | (uintptr_t)edgeMaskC) & 1) return -(int)hipErrorInvalidValue;
-    const int R = sr_rows(W, H);
-    if (R <= 0 || R > SR_MAX_R_FULL) return -(int)hipErrorNotSupported;
-    SrArgs a; memset(&a, 0, sizeof(a));
-    a.g = make_sr_geo(W, H, 0, R);
-    sr_bind(a, xbuf);
-    a.cm = cam_of(host_params);
-    a.X = X; a.D = D; a.Im = Im; a.mR = edgeMaskR; a.mC = edgeMaskC; a.Hg = H; a.aN0_word = alphaN0_word;
-    a.words = words; a.L = L;
-    hipStream_t s = (hipStream_t)stream;
-    switch (R) {
-        case 2: return sr_launch_r<2, false, true>(a, s); case 3: return sr_launch_r<3, false, true>(a, s); case 4: return sr_launch_r<4, false, true>(a, s);
-        case 5: return sr_launch_r<5, false, true>(a, s); case 6: return sr_launch_r<6, false, true>(a, s);
-        default: return -(int)hipErrorNotSupported;
-    }
-}
-int thallo_hip_sfs_resident_rows_full(int W, int H) { const int R = sr_rows(W, H); return R <= SR_MAX_R_FULL ? R : 0; }
 
 /* The same for a Levenberg-Marquardt step, with its tail: from what thallo_hip_sfs_pcg_init_lm left (r = b, M^-1 in pre, CtC, zeros in p_prev and delta, alphaN_0 = r . M^-1 r) and
  * a reset state (thallo_hip_lm_state_reset), at most L iterations of thallo_hip_sfs_pcg_iter_lm -- the zeta test (thallo_hip_lm_zeta's rule, q_tolerance) ends the loop on
@@ -820,7 +707,7 @@ int thallo_hip_sfs_pcg_resident_lm(int W, int H, int yoff, const float* host_par
     a.r_in = r_in; a.p_in = p_in; a.delta = delta;
     a.aN0 = alphaN0; a.words = words; a.X = X; a.L = L;
     a.pre = pre; a.ctc = CtC; a.state = lm_state; a.q_tol = q_tolerance; a.prevX = prevX; a.t0_out = dJJd_out; a.t1_out = db_out;
-    return sr_launch<true, false>(a, R, (hipStream_t)stream);
+    return sr_launch<true>(a, R, (hipStream_t)stream);
 }
 
 /* the error word of a plan's resident launches: 1 = a bounded wait ran out (a workgroup was not resident, or a granule never arrived); clear != 0 resets it.

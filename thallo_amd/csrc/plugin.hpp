@@ -188,9 +188,6 @@ public:
     virtual bool resident_ok() const { return false; }
     virtual int  pcg_resident(LaunchCtx&, SolverVectors&, int /*L*/, thallo_sum_t /*alphaN0*/, float* /*words*/) { return -1; }
     virtual bool resident_updates_unknowns() const { return false; }                            // PCGLinearUpdate rides in the resident launch (the driver skips its own, and calls unknowns_written())
-    // ... PCGInit1 (and whatever it needs: shape_from_shading's precompute) inside the resident launch too: the driver does not call pcg_init; alphaN_0 arrives as a word
-    virtual bool resident_does_init() const { return false; }
-    virtual int  gn_step_resident(LaunchCtx&, SolverVectors&, int /*L*/, float* /*alphaN0_word*/, float* /*words*/) { return -1; }
     // ... an LM step's PCG loop, zeta test, owed delta update, model cost (partials of delta . J^T J delta, delta . b), savePreviousUnknowns and PCGLinearUpdate in one launch
     // (thallo_hip_sfs_pcg_resident_lm): behind pcg_init_lm and a reset state; L within one residual-reset period
     virtual bool resident_lm_ok() const { return false; }

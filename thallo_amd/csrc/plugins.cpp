@@ -1099,14 +1099,6 @@ public:
                                            resident_updates_unknowns() ? X : nullptr, xres_.ptr, L, c.stream);
     }
     bool resident_updates_unknowns() const override { const char* e = env_switch("THALLO_SFS_RESIDENT_FOLD"); return !(e && e[0] == '0'); }
-    // round 6: a WHOLE GN step -- precompute, PCGInit1, the loop, PCGLinearUpdate -- in the one launch (THALLO_AB=sfs_resident_full=0: precompute and PCGInit1 as launches, A/B)
-    bool resident_does_init() const override
-    { const char* e = env_switch("THALLO_SFS_RESIDENT_FULL"); return resident_ok() && resident_updates_unknowns() && yoff_ == 0 && Hg_ == H && thallo_hip_sfs_resident_rows_full(W, H) > 0 && !(e && e[0] == '0'); }
-    int gn_step_resident(LaunchCtx& c, SolverVectors&, int L, float* aN0_word, float* words) override
-    {
-        TimedLaunch t(c, "GNStepResident");
-        return thallo_hip_sfs_gn_step_resident(W, H, hp, X, D, Im, mR, mC, aN0_word, words, xres_.ptr, L, c.stream);
-    }
     bool resident_lm_ok() const override { return resident_ && packed() && thallo_hip_sfs_resident_rows_lm(W, H) > 0; }
     int pcg_resident_lm(LaunchCtx& c, SolverVectors& v, int L, thallo_sum_t aN0, float* words, float* lm_state, float q_tol, float* dJJd_out, float* db_out) override
     {

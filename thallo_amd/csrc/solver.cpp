@@ -234,7 +234,6 @@ const char* env_switch(const char* name)
         { "THALLO_BA_RENUMBER", "ba_renumber" },                // bundle adjustment's plan-side point order: 0 never, 1 always (default: when the caller's order is far from "by first observing camera"; round 6)
         { "THALLO_LM_FOLD_STEP", "lm_fold_step" },              // 0: the LM step with PCGFinalizeDiagonal and the model cost as launches of their own where a plugin can fold them (round 6)
         { "THALLO_IW_RESIDENT_FOLD", "iw_resident_fold" },      // 0: image_warping's resident PCG loop leaves PCGLinearUpdate a launch of its own (round 6; A/B)
-        { "THALLO_SFS_RESIDENT_FULL", "sfs_resident_full" },    // 0: shape_from_shading's resident GN launch leaves precompute and PCGInit1 launches of their own (round 6; A/B)
         { "THALLO_SFS_RESIDENT_FOLD", "sfs_resident_fold" },    // 0: shape_from_shading's resident PCG loop leaves PCGLinearUpdate a launch of its own (round 6; A/B)
         { "THALLO_SFS_PAIR", "sfs_pair" },                      // 0: shape_from_shading's one-pixel-per-lane marching kernels on the float4 / float2 / byte planes instead of the pixel-pair kernels on packed planes (round 6)
         { "THALLO_FRONTEND_AGGREGATE", "frontend_aggregate" },  // 0: generated kernels scatter with plain atomics everywhere
@@ -730,17 +729,12 @@ int Plan::step_gn_resident(int ev_iter)
     hipStream_t s = ctx.stream;
     const int ev_setup = timer_.start("Nonlinear Setup", s);
     cur_ = 0;
-    int nb = 0;
-    const bool whole_step = plugin->resident_does_init();      // (round 6: PCGInit1 -- and shape_from_shading's precompute -- inside the resident launch; alphaN_0 arrives as a word)
-    if (!whole_step) {
-        nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
-        if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
-        set_nb(B, nb); finish(B);
-    }
+    int nb = plugin->pcg_init(ctx, v_, cur_, slot(B));
+    if (nb < 0) { set_error("PCGInit1 launch failed (%d)", nb); return 0; }
+    set_nb(B, nb); finish(B);
     timer_.stop(ev_setup, s);
     const int ev_lin = timer_.start("Linear Solve", s);
-    if (whole_step) { nb = plugin->gn_step_resident(ctx, v_, L, scal(B), scal(B + 1)); set_nb(B, 1); fin_[B] = 1; }
-    else nb = plugin->pcg_resident(ctx, v_, L, sum(B), scal(B + 1));
+    nb = plugin->pcg_resident(ctx, v_, L, sum(B), scal(B + 1));
     if (nb < 0) { set_error("PCGLoopResident launch failed (%d)", nb); return 0; }
     for (int k = 0; k < L; ++k) { const int jD = B + 2 * k + 1, jB = jD + 1; set_nb(jD, 1); fin_[jD] = 1; set_nb(jB, 1); fin_[jB] = 1; }
     cur_ = L & 1;

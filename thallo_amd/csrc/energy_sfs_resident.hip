@@ -43,7 +43,7 @@ __device__ __forceinline__ void st1g(rsrc_t r, unsigned off, unsigned tag, unsig
 enum { SR_SEQ = 0, SR_ERR = 1, SR_SPIN_MS = 2, SR_PM = 4, SR_CTL_WORDS = 16 };
 constexpr int SR_REC = 16;                // granules per sums record (7 used by GN, 13 by LM)
 
-struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total, ab; };      // ab: A/B bits (tools): 1 = row granules row-major (a wave's 16-byte loads contiguous), 2 = 128-byte sums records in GN too; 4 (tests) = FAULT INJECTION: workgroup 1 never publishes the sums of iteration 2 (what a workgroup that is not resident looks like to the others)
+struct SrGeo { int W, H, yoff, R, nstrips, nseg, nwgrow, total, ab; };      // ab: A/B bits (tools): 1 = row granules row-major (a wave's 16-byte loads contiguous), 2 = 128-byte sums records in GN too; 8 = every halo row through global memory (none through LDS); 4 (tests) = FAULT INJECTION: workgroup 1 never publishes the sums of iteration 2 (what a workgroup that is not resident looks like to the others)
 
 // exchange buffers of one plan (thallo_hip_sfs_resident_bytes); parity = iteration & 1
 struct SrBufs {
@@ -103,6 +103,8 @@ struct SrLds {
     float wa[4]; double wd[4][6];     // per wave: alphaD part, {N, S1, S2} (LM: + {U, T1, T2}) parts
     float cst[4][2][64];              // per wave: lane 1's / lane 62's A p of its rows (word 2 * row + pixel), so that ONE store instruction publishes a column
     float crx[4][2][64];              // per wave: the received columns (word 2 * held row + pixel), for lanes 0 / 63 to pick up
+    unsigned rtag[2][4][2];           // [parity][wave][side]: that wave's first two (0) / last two (1) rows of A p are in rrow, for the neighbouring wave of the same workgroup
+    float rrow[2][4][2][4][64];       // the y halo between the stacked waves of a workgroup never leaves the CU (row a px 0, px 1, row b px 0, px 1 per lane)
     float red[32];                    // block_store_partials (the LM model cost's two sums)
 };
 
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     }
     const bool writer = id == 0 && threadIdx.x == 0;
     if (threadIdx.x < 4) { S.qtag[threadIdx.x] = 0u; S.wtag[threadIdx.x] = 0u; }
+    if (threadIdx.x < 16) (&S.rtag[0][0][0])[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i < 4 * 2 * 64; i += SR_NT) { (&S.cst[0][0][0])[i] = 0.0f; (&S.crx[0][0][0])[i] = 0.0f; }
     __syncthreads();
 
@@ -156,6 +159,9 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
     const int wid = strip * g.nseg + seg;
     const bool has_up = nr > 0 && seg > 0, has_dn = nr == R && yb < H;
     const bool has_lf = nr > 0 && strip > 0, has_rt = nr > 0 && strip + 1 < g.nstrips;
+    // which of my halo rows come through LDS (the neighbouring wave sits in my workgroup: three of four boundaries) and which through global memory (ab bit 3: all through global, A/B)
+    const bool lds_rows = !(g.ab & 8);
+    const bool up_lds = lds_rows && has_up && wave > 0, dn_lds = lds_rows && has_dn && wave < 3;
     const long waves = (long)g.nstrips * g.nseg;
     const rsrc_t RS_ROW = make_xrsrc(a.b.rowh), RS_COL = make_xrsrc(a.b.colh), RS_SUM = make_xrsrc(a.b.sums);
     // (a lane's two 16-byte pieces side by side: its two loads ask for ONE line.  Measured, same box, 640 x 480 GN through Thallo_ProblemStep: 8.23 us per PCG iteration against
@@ -368,8 +374,21 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             v2f ru0 = Z2, ru1 = Z2, rd0 = Z2, rd1 = Z2;
 #pragma unroll
             for (int c = 0; c < NWD; ++c) wq[c] = 0u;
+            if (up_lds || dn_lds) {      // the rows of the waves of my own workgroup: in LDS, tagged when that wave's stencil was through -- earlier than anything that comes through global memory
+                sp.n = 0; sp.t0 = 0;
+                const unsigned* tu = &S.rtag[parp][up_lds ? wave - 1 : wave][1]; const unsigned* td = &S.rtag[parp][dn_lds ? wave + 1 : wave][0];
+                while (!dead) {
+                    const unsigned a0 = up_lds ? __hip_atomic_load(tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp, a1 = dn_lds ? __hip_atomic_load(td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : Tp;
+                    if (a0 == Tp && a1 == Tp) break;
+                    if (spin_fail(sp, ctl, 6u, (unsigned)wid, Tp)) dead = true;
+                }
+                dead = __builtin_amdgcn_readfirstlane(__any(dead) ? 1 : 0) != 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (up_lds && xout) { const float* u = &S.rrow[parp][wave - 1][1][0][lane]; Ap[0] = v2f{ u[0], u[64] }; Ap[1] = v2f{ u[128], u[192] }; }
+                if (dn_lds && xout) { const float* d = &S.rrow[parp][wave + 1][0][0][lane]; Ap[R + 2] = v2f{ d[0], d[64] }; Ap[R + 3] = v2f{ d[128], d[192] }; }
+            }
             {
-                const bool need_u = xout && has_up, need_d = xout && has_dn, need_s = slot_live;
+                const bool need_u = xout && has_up && !up_lds, need_d = xout && has_dn && !dn_lds, need_s = slot_live;
                 const unsigned usrc = rowh(parp, has_up ? wid - 1 : wid, 1), dsrc = rowh(parp, has_dn ? wid + 1 : wid, 0);
                 const unsigned clsrc = colh(parp, need_cl ? wid - g.nseg + c_dw : wid, 1, c_word), crsrc = colh(parp, need_cr ? wid + g.nseg + c_dw : wid, 0, c_word);
                 bool ok_s = !need_s, ok_u = !need_u, ok_d = !need_d, ok_cl = !need_cl, ok_cr = !need_cr;
@@ -455,9 +474,19 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
         // ---- publish: the boundary rows, my two columns (one store instruction each), then the workgroup's sums (wave butterflies -> LDS -> wave 0 adds the four
         // waves up in order and publishes the record)
         {
-            if (xout && has_up) { const unsigned d = rowh(par, wid, 0); st2g(RS_ROW, d, T, Ap[2].x, Ap[2].y); st2g(RS_ROW, d + row2, T, Ap[3].x, Ap[3].y); }
-            if (xout && has_dn) { const unsigned d = rowh(par, wid, 1); st2g(RS_ROW, d, T, Ap[R].x, Ap[R].y); st2g(RS_ROW, d + row2, T, Ap[R + 1].x, Ap[R + 1].y); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the columns written to LDS above)
+            if (xout && has_up) {
+                if (up_lds) { float* d = &S.rrow[par][wave][0][0][lane]; d[0] = Ap[2].x; d[64] = Ap[2].y; d[128] = Ap[3].x; d[192] = Ap[3].y; }
+                else { const unsigned d = rowh(par, wid, 0); st2g(RS_ROW, d, T, Ap[2].x, Ap[2].y); st2g(RS_ROW, d + row2, T, Ap[3].x, Ap[3].y); }
+            }
+            if (xout && has_dn) {
+                if (dn_lds) { float* d = &S.rrow[par][wave][1][0][lane]; d[0] = Ap[R].x; d[64] = Ap[R].y; d[128] = Ap[R + 1].x; d[192] = Ap[R + 1].y; }
+                else { const unsigned d = rowh(par, wid, 1); st2g(RS_ROW, d, T, Ap[R].x, Ap[R].y); st2g(RS_ROW, d + row2, T, Ap[R + 1].x, Ap[R + 1].y); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the rows and columns written to LDS above)
+            if (lane == 0) {
+                if (up_lds) __hip_atomic_store(&S.rtag[par][wave][0], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dn_lds) __hip_atomic_store(&S.rtag[par][wave][1], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             if (col_pub && has_lf) st1g(RS_COL, colh(par, wid, 0, lane), T, __float_as_uint(S.cst[wave][0][lane]));
             if (col_pub && has_rt) st1g(RS_COL, colh(par, wid, 1, lane), T, __float_as_uint(S.cst[wave][1][lane]));
             const float accf = acc.x + acc.y;

@@ -118,7 +118,7 @@ def ab_time():
     """GN and LM steps at A/B settings of the exchange layout (thallo_hip_sfs_resident_debug_set(2, bits)), one box: us per PCG iteration through Thallo_ProblemStep"""
     import time
     for lm in (0, 1):
-        for bits in (0, 1, 2, 3, 0):
+        for bits in [int(b) for b in os.environ.get("SRP_BITS", "0,1,2,3,0").split(",")]:
             L.thallo_hip_sfs_resident_debug_set(2, bits)
             dev = to_device(copy_params(p))
             s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), timing_level=0, **({"solverkind": "levenberg_marquardt"} if lm else {}))

@@ -25,7 +25,7 @@ def run(resident, n):
     c = s.current_cost(); s.close()
     L.thallo_hip_sfs_march_debug_set(0, 0)
     return to_host(dev[16]).copy(), tr, c
-for n in (range(1, nit + 1) if not (len(sys.argv) > 5 and sys.argv[5] in ("kernel", "stamps", "ab")) else []):
+for n in (range(1, nit + 1) if not (len(sys.argv) > 5 and sys.argv[5] in ("kernel", "stamps", "ab", "soak")) else []):
     for rep in range(2):
         xa, ta, ca = run(True, n); xb, tb, cb = run(False, n)
         d = np.argwhere(xa != xb)
@@ -136,3 +136,16 @@ def ab_time():
 
 if len(sys.argv) > 5 and sys.argv[5] == "ab":
     ab_time()
+
+
+def soak(nsteps=150):
+    """many steps: the resident loops against themselves (determinism) and against the launches with the same rows per wave, GN and LM"""
+    for lm in (0, 1):
+        os.environ["SRP_LM"] = str(lm)
+        xa, ta, ca = run(True, nsteps); xb, tb, cb = run(True, nsteps); xc, tc, cc = run(False, nsteps)
+        print("LM" if lm else "GN", "steps run", len(ta), len(tb), len(tc), "resident twice equal", bool((xa == xb).all()) and ta == tb, "resident vs launches equal", bool((xa == xc).all()) and ta == tc,
+              "costs", ca, cb, cc, "error string", (api.last_error() or "")[:80], flush=True)
+
+
+if len(sys.argv) > 5 and sys.argv[5] == "soak":
+    soak(int(sys.argv[6]) if len(sys.argv) > 6 else 150)

@@ -181,6 +181,7 @@ Plan::Plan(EnergyPlugin* pl, const Thallo_InitializationParameters& ip_, bool lm
 Plan::~Plan()
 {
     hipDeviceSynchronize();
+    if (host_words_) { hipHostFree(host_words_); host_words_ = nullptr; }
     for (hipEvent_t e : aux_events_) hipEventDestroy(e);
     if (aux_) hipStreamDestroy(aux_);
     dist_release();
@@ -300,6 +301,12 @@ void Plan::get_param(const char* name, void* value)
     if (ip.verbosityLevel > 0) printf("Warning: tried to get nonexistent solver parameter %s\n", name);
 }
 
+float* Plan::host_words()
+{   // lazily: 16 pinned words (NULL if the allocation fails: the callers then copy into their own pageable words, as before)
+    if (!host_words_ && hipHostMalloc((void**)&host_words_, 16 * sizeof(float), hipHostMallocDefault) != hipSuccess) { host_words_ = nullptr; (void)hipGetLastError(); }
+    return host_words_;
+}
+
 float Plan::compute_cost()
 {   // gauss_newton.t:1128-1136 -- partials instead of memset + atomics; same blocking 4-byte read-back
     if (dist_) return dist_cost();
@@ -308,8 +315,10 @@ float Plan::compute_cost()
     set_nb(0, nb);
     thallo_hip_finish_sum(sum(0), (float*)scratch_.ptr, ctx.stream);
     float f = 0.0f;
-    HIP_OK(hipMemcpyAsync(&f, scratch_.ptr, sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
+    float* hw = host_words();
+    HIP_OK(hipMemcpyAsync(hw ? hw : &f, scratch_.ptr, sizeof(float), hipMemcpyDeviceToHost, ctx.stream));
     HIP_OK(hipStreamSynchronize(ctx.stream));
+    if (hw) f = hw[0];
     if (resident_used_) {     // the resident PCG kernel's waits are bounded; one that ran out voids the steps since the last check
         resident_used_ = false;
         unsigned pm[5] = { 0, 0, 0, 0, 0 };
@@ -1137,8 +1146,11 @@ int Plan::step_lm(int ev_iter)
     const bool late_agree = slab && dist_->xrows_now;
     if (slab && !late_agree && !agree_all()) return 0;
     float rep[8] = { 0 };
-    HIP_OK(hipMemcpyAsync(rep, lmst, sizeof(rep), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
+    {   float* hw = host_words();
+        HIP_OK(hipMemcpyAsync(hw ? hw : rep, lmst, sizeof(rep), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (hw) memcpy(rep, hw, sizeof(rep));
+    }
     if (late_agree && (failed_before_cost_exchange || !std::isfinite(rep[5])) && !agree_all()) return 0;      // (a failed rank skipped its own cost launches: its rep[5] says nothing)
     if (resident_used_) {     // (the LM step's resident launch: its waits are bounded; one that ran out voids THIS step -- nothing of its report can be trusted)
         resident_used_ = false;

@@ -147,6 +147,7 @@ private:
     DeviceBuffer trace_;
     std::vector<int> nb_;           // partial count per slot
     CoarseTimer timer_;
+    float* host_words_ = nullptr;      // 16 pinned host words: the step's read-backs (a cost, the LM report) land here -- a copy into pageable memory is staged and synchronous
     int ev_total_ = -1;
     int cur_ = 0;
 
@@ -183,6 +184,7 @@ private:
     int  step_gn_resident(int ev_iter);
     bool resident_used_ = false;    // a resident launch ran since the last cost evaluation (its error word is read there)
     float compute_cost();
+    float* host_words();
     int   step_gn(int ev_iter);
     int   step_lm(int ev_iter);
     int   lm_accept_or_revert(float dJJd, float db, float newCost, int k_done, int ev_fin, int ev_iter);      // the end of an LM step: accept / revert, trust region (shared by step_lm and the shard form)

@@ -325,6 +325,35 @@ def main():
         # (2048 x 512, the 1/4 slab of a 4-GPU run: 9 rows per wave, round 4.)  The 1/2 slab of a 2-GPU run has more rows per wave than the resident kernel's
         # registers hold (R = 18 > 10): one marching launch per iteration
         out["small_working_sets"]["2048x1024"] = {"resident_loop": None, "launch_per_iteration": small(2048, 1024, False)}
+        # round 6: shape_from_shading at the size of the reference's data set (640 x 480, 10 PCG iterations per step as its example runs): the PCG loop of a GN step / a whole
+        # LM step's loop + model cost + update in one resident launch, against one launch per PCG iteration (THALLO_RESIDENT=0)
+        def small_sfs(resident, lm):
+            os.environ["THALLO_RESIDENT"] = "1" if resident else "0"
+            try:
+                q = syn.shape_from_shading(640, 480)
+                d2 = [torch.from_numpy(x).cuda() if isinstance(x, np.ndarray) else float(x) for x in q]
+                s2 = thallo_amd.ThalloSolver((640, 480), thallo_amd.energy_file("shape_from_shading"), timing_level=0, **({"solverkind": "levenberg_marquardt"} if lm else {}))
+                if lm: s2.enable_lm()
+                s2.set_solver_parameters(nIterations=1 << 30, lIterations=10, **({"q_tolerance": 0.0} if lm else {}))
+                p2 = s2.make_params(d2)
+                s2.init(p2)
+                for _ in range(3):
+                    s2.step(p2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    s2.step(p2)
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t1) / (20 * 10) * 1e6
+                names = sorted(s2.kernel_stats())
+                c = s2.current_cost()
+                s2.close()
+                assert c == c, thallo_amd.last_error()
+                return {"us_per_pcg_iter": us, "kernels": names}
+            finally:
+                os.environ.pop("THALLO_RESIDENT", None)
+        out["small_working_sets"]["shape_from_shading_640x480"] = {"gn": {"resident_loop": small_sfs(True, False), "launch_per_iteration": small_sfs(False, False)},
+                                                                    "lm": {"resident_loop": small_sfs(True, True), "launch_per_iteration": small_sfs(False, True)}}
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
         q = syn.image_warping(W, H)

@@ -1837,17 +1837,18 @@ def test_shape_from_shading_pixel_pair_kernels_match_the_one_pixel_kernels(torch
         assert (np.abs(c1[:m] - co[:m]) <= (2e-4 if lm else 2e-5) * np.abs(co[:m]) + 1e-9).all(), (c1, co)
 
 
-@pytest.mark.parametrize("W,H,nit,lit", [(640, 480, 3, 10), (130, 67, 3, 10), (256, 192, 3, 12), (126, 9, 3, 5), (2, 2, 2, 3), (250, 130, 2, 7), (1024, 160, 2, 9), (372, 35, 3, 6)])
+@pytest.mark.parametrize("W,H,nit,lit", [(640, 480, 3, 10), (130, 67, 3, 10), (256, 192, 3, 12), (126, 9, 3, 5), (2, 2, 2, 3), (250, 130, 2, 7), (1024, 160, 2, 9), (372, 35, 3, 6), (1280, 960, 2, 10), (1024, 1024, 2, 8)])
 def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(torch, orc, monkeypatch, W, H, nit, lit):
     """Round 6: the whole PCG loop of a Gauss-Newton step of shape_from_shading in ONE launch (energy_sfs_resident.hip) -- r, p, A p, delta and the
     precomputed planes of a wave's rows in registers, per iteration the first / last TWO rows of A p to the waves above / below, lane 1's / 62's pixels to the strips beside
     (corner pixels of the halo rows from the diagonal neighbours' records) and the workgroup's sums to every workgroup as tagged granules; no launch boundary, no grid barrier.
     Geometry, row step and summation order are the marching pair kernel's: with the same rows per wave every alpha_k / beta_k, the costs and the unknowns are BIT-identical to
-    one launch per iteration.  Sizes: the reference's data set, ragged strips, short last segments (67 = 16 x 4 + 3, 35), one strip, 2 x 2, three strips, a wide flat image."""
+    one launch per iteration.  Sizes: the reference's data set, ragged strips, short last segments (67 = 16 x 4 + 3, 35), one strip, 2 x 2, three strips, a wide flat image, and 1.0 / 1.2 Mpixel
+    images at 10 / 11 rows per wave (the rolling row step keeps three rows of temporaries live: up to 12 rows per wave fit the registers)."""
     L = thallo_amd.lib()
     L.thallo_hip_sfs_resident_rows.restype = C.c_int
     R = L.thallo_hip_sfs_resident_rows(W, H)
-    assert 2 <= R <= 8, R
+    assert 2 <= R <= 12 and ((W, H) != (1280, 960) or R == 11), R
     p = syn.shape_from_shading(W, H)
     runs = []
     for resident in (True, False):
@@ -1880,7 +1881,7 @@ def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(tor
         assert (np.abs(np.array(c0) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (c0, co)
 
 
-@pytest.mark.parametrize("W,H,radius,qtol", [(640, 480, 30.0, 0.05), (192, 130, 30.0, 0.05), (130, 67, 1e4, 1e-4), (126, 9, 30.0, 0.0), (250, 130, 3.0, 0.05), (2, 2, 1e4, 1e-4)])
+@pytest.mark.parametrize("W,H,radius,qtol", [(640, 480, 30.0, 0.05), (192, 130, 30.0, 0.05), (130, 67, 1e4, 1e-4), (126, 9, 30.0, 0.0), (250, 130, 3.0, 0.05), (2, 2, 1e4, 1e-4), (1024, 576, 30.0, 0.05)])
 def test_shape_from_shading_resident_lm_step_is_bitwise_the_launches(torch, orc, monkeypatch, W, H, radius, qtol):
     """Round 6: a Levenberg-Marquardt step's PCG loop (A = J^T J + CtC, z = M^-1 r, the six double sums, the zeta test after every iteration -- taken by every workgroup for
     itself from the same sums), the update of delta the loop owes, the model cost's J^T J delta and two dot products, savePreviousUnknowns and PCGLinearUpdate in ONE resident
@@ -1890,7 +1891,7 @@ def test_shape_from_shading_resident_lm_step_is_bitwise_the_launches(torch, orc,
     L = thallo_amd.lib()
     L.thallo_hip_sfs_resident_rows_lm.restype = C.c_int
     R = L.thallo_hip_sfs_resident_rows_lm(W, H)
-    assert 2 <= R <= 5, R
+    assert 2 <= R <= 6 and ((W, H) != (1024, 576) or R == 6), R
     p = syn.shape_from_shading(W, H)
     nit, lit = 8, 10
     runs = []

@@ -27,7 +27,7 @@ using namespace thallo;
 namespace {
 
 constexpr int SR_NT = 256;                // 4 waves = 4 vertically adjacent segments of one strip (one workgroup per CU)
-constexpr int SR_MIN_R = 2, SR_MAX_R = 8, SR_MAX_R_LM = 5;       // (LM: 18 registers per held row and lane + the own rows' CtC and b; from 6 rows on the compiler spills) // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
+constexpr int SR_MIN_R = 2, SR_MAX_R = 12, SR_MAX_R_LM = 6;       // (GN: 14 registers per held row and lane, LM: 18 + the own rows' CtC and b, beside the three rows of temporaries the rolling row step keeps: 13 / 7 rows per wave spill to scratch) // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -289,62 +289,68 @@ __global__ __launch_bounds__(SR_NT, 1) void k_sfs_resident(SrArgs a)
             for (int c = 0; c < 3; ++c) Rr[jj][c] = Z2;
         }
 #pragma unroll
-        for (int jj = 1; jj < NR; ++jj) {                       // dB(row jj) from v(jj), v(jj - 1); U_h(jj)
-            const bool ok = row_ok(jj);
-            const v2f v0 = V[jj], v1 = V[jj - 1];
-            const v2f vl0 = nbL(v0);
-            const v2f dB0 = sel(ok, gx[jj] * v0 + gy[jj] * vl0 + gz[jj] * v1, Z2);
-            const v2f dBr = nbR(dB0);
-            const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
-            const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
-            const M2 wn0 = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
-            dB[jj] = dB0;
-            Uh[jj] = sel(wn0, wx * (wx * (dB0 - dBr)), Z2);
-        }
+        for (int st = 1; st < NR; ++st) {
+            // One ROLLING pass (the marching kernel's order of work): the step that takes row st forms dB(st), U_h(st); U_v(st-1), the Laplacian rows R(st-1), T(st-1); the output
+            // of row st-2.  Indices are compile-time constants; what a stage leaves is dead two steps later, so the temporaries of three rows are live at a time, not
+            // those of all R + 4 (the same expressions, the same bits as pass by pass).
+            {   // dB(row st) from v(st), v(st - 1); U_h(st)
+                const int jj = st;
+                const bool ok = row_ok(jj);
+                const v2f v0 = V[jj], v1 = V[jj - 1];
+                const v2f vl0 = nbL(v0);
+                const v2f dB0 = sel(ok, gx[jj] * v0 + gy[jj] * vl0 + gz[jj] * v1, Z2);
+                const v2f dBr = nbR(dB0);
+                const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
+                const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
+                const M2 wn0 = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
+                dB[jj] = dB0;
+                Uh[jj] = sel(wn0, wx * (wx * (dB0 - dBr)), Z2);
+            }
+            if (st >= 2) {   // U_v(st - 1) from dB(st - 1), dB(st); the Laplacian rows R(st - 1) from v(st - 2), v(st - 1), v(st)
+                const int jj = st - 1;
+                const bool ok = row_ok(jj);
+                const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
+                const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
+                const M2 wn = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
+                Uv[jj] = sel(wn, wy * (wy * (dB[jj] - dB[jj + 1])), Z2);
+                const v2f v0 = V[jj + 1], v1 = V[jj], v2 = V[jj - 1];
+                const v2f vl1 = nbL(v1), vr1 = nbR(v1);
+                const float cy0 = Cy[jj + 1], cy1 = Cy[jj], cy2 = Cy[jj - 1];
+                const M2 f2b = bit(Fl[jj], 2u);
+                Rr[jj][0] = sel(f2b, cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0), Z2);
+                Rr[jj][1] = sel(f2b, cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0), Z2);
+                Rr[jj][2] = sel(f2b, cm.ws * (4.0f * v1 - vl1 - v2 - vr1 - v0), Z2);
+            }
+            if (st >= 3) {   // T(st - 1)
+                const int jj = st - 1;
+                v2f T1 = Uh[jj] + Uv[jj];
+                T1 -= nbL(Uh[jj]);
+                T1 -= Uv[jj - 1];
+                Tt[jj] = T1;
+            }
+            if (st >= 4 && st - 2 < R + 2) {   // output row y = ya + (st - 2) - 2
+                const int jj = st - 2;
+                const int y = ya - 2 + jj;
+                const v2f T2 = Tt[jj], T1 = Tt[jj + 1];
+                const v2f gT2r = nbR(gy[jj] * T2);
+                v2f Rl[3], Rq[3];
 #pragma unroll
-        for (int jj = 1; jj < NR - 1; ++jj) {                   // U_v(jj) from dB(jj), dB(jj + 1); the Laplacian rows R(jj) from v(jj - 1), v(jj), v(jj + 1)
-            const bool ok = row_ok(jj);
-            const v2f wx = cm.wg * v2f{ (float)((fwx[jj] >> 8) & 0xffu), (float)((fwy[jj] >> 8) & 0xffu) };
-            const v2f wy = cm.wg * v2f{ (float)((fwx[jj] >> 16) & 0xffu), (float)((fwy[jj] >> 16) & 0xffu) };
-            const M2 wn = { ok && (wx.x != 0.0f || wy.x != 0.0f), ok && (wx.y != 0.0f || wy.y != 0.0f) };
-            Uv[jj] = sel(wn, wy * (wy * (dB[jj] - dB[jj + 1])), Z2);
-            const v2f v0 = V[jj + 1], v1 = V[jj], v2 = V[jj - 1];
-            const v2f vl1 = nbL(v1), vr1 = nbR(v1);
-            const float cy0 = Cy[jj + 1], cy1 = Cy[jj], cy2 = Cy[jj - 1];
-            const M2 f2b = bit(Fl[jj], 2u);
-            Rr[jj][0] = sel(f2b, cm.ws * (4.0f * (cxc * v1) - cxm * vl1 - cxc * v2 - cxp * vr1 - cxc * v0), Z2);
-            Rr[jj][1] = sel(f2b, cm.ws * (4.0f * (cy1 * v1) - cy1 * vl1 - cy2 * v2 - cy1 * vr1 - cy0 * v0), Z2);
-            Rr[jj][2] = sel(f2b, cm.ws * (4.0f * v1 - vl1 - v2 - vr1 - v0), Z2);
-        }
-#pragma unroll
-        for (int jj = 2; jj < NR - 1; ++jj) {                   // T(jj)
-            v2f T1 = Uh[jj] + Uv[jj];
-            T1 -= nbL(Uh[jj]);
-            T1 -= Uv[jj - 1];
-            Tt[jj] = T1;
-        }
-#pragma unroll
-        for (int jj = 2; jj < R + 2; ++jj) {                    // output row y = ya + jj - 2
-            const int y = ya - 2 + jj;
-            const v2f T2 = Tt[jj], T1 = Tt[jj + 1];
-            const v2f gT2r = nbR(gy[jj] * T2);
-            v2f Rl[3], Rq[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { Rl[c] = nbL(Rr[jj][c]); Rq[c] = nbR(Rr[jj][c]); }
-            if (jj - 2 < nr && xout) {
-                const v2f vc = V[jj];
-                v2f s = Z2;
-                s = sel(bit(Fl[jj], 1u), s + cm.wp * (cm.wp * vc), s);
-                s += gx[jj] * T2;
-                s = sel(xp1, s + gT2r, s);
-                if (y + 1 < H) s += gz[jj + 1] * T1;
-                {
-                    v2f lap;
-                    lap = 4.0f * Rr[jj][0] - Rl[0] - Rr[jj - 1][0] - Rq[0] - Rr[jj + 1][0]; s += cm.ws * (cxc * lap);
-                    lap = 4.0f * Rr[jj][1] - Rl[1] - Rr[jj - 1][1] - Rq[1] - Rr[jj + 1][1]; s += cm.ws * (Cy[jj] * lap);
-                    lap = 4.0f * Rr[jj][2] - Rl[2] - Rr[jj - 1][2] - Rq[2] - Rr[jj + 1][2]; s += cm.ws * (1.0f * lap);
+                for (int c = 0; c < 3; ++c) { Rl[c] = nbL(Rr[jj][c]); Rq[c] = nbR(Rr[jj][c]); }
+                if (jj - 2 < nr && xout) {
+                    const v2f vc = V[jj];
+                    v2f s = Z2;
+                    s = sel(bit(Fl[jj], 1u), s + cm.wp * (cm.wp * vc), s);
+                    s += gx[jj] * T2;
+                    s = sel(xp1, s + gT2r, s);
+                    if (y + 1 < H) s += gz[jj + 1] * T1;
+                    {
+                        v2f lap;
+                        lap = 4.0f * Rr[jj][0] - Rl[0] - Rr[jj - 1][0] - Rq[0] - Rr[jj + 1][0]; s += cm.ws * (cxc * lap);
+                        lap = 4.0f * Rr[jj][1] - Rl[1] - Rr[jj - 1][1] - Rq[1] - Rr[jj + 1][1]; s += cm.ws * (Cy[jj] * lap);
+                        lap = 4.0f * Rr[jj][2] - Rl[2] - Rr[jj - 1][2] - Rq[2] - Rr[jj + 1][2]; s += cm.ws * (1.0f * lap);
+                    }
+                    emit(jj, vc, s);
                 }
-                emit(jj, vc, s);
             }
         }
     };
@@ -653,10 +659,12 @@ template <bool LM> int sr_launch(const SrArgs& a, int R, hipStream_t s)
 {
     switch (R) {
         case 2: return sr_launch_r<2, LM>(a, s); case 3: return sr_launch_r<3, LM>(a, s); case 4: return sr_launch_r<4, LM>(a, s); case 5: return sr_launch_r<5, LM>(a, s);
+        case 6: return sr_launch_r<6, LM>(a, s);
         default: break;
     }
     if (!LM) switch (R) {
-        case 6: return sr_launch_r<6, false>(a, s); case 7: return sr_launch_r<7, false>(a, s); case 8: return sr_launch_r<8, false>(a, s);
+        case 7: return sr_launch_r<7, false>(a, s); case 8: return sr_launch_r<8, false>(a, s); case 9: return sr_launch_r<9, false>(a, s); case 10: return sr_launch_r<10, false>(a, s);
+        case 11: return sr_launch_r<11, false>(a, s); case 12: return sr_launch_r<12, false>(a, s);
         default: break;
     }
     return -(int)hipErrorNotSupported;

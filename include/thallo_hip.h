@@ -615,7 +615,7 @@ int thallo_hip_sfs_pcg_resident(int W, int H, int yoff, const float* host_params
  * state (thallo_hip_lm_state_reset), at most L iterations of thallo_hip_sfs_pcg_iter_lm -- the zeta test ends the loop on the device, in every workgroup alike; lm_state[1] /
  * [2] = gate / iterations done as the launches leave them -- then thallo_hip_sfs_lm_model_cost's launch: the owed update of delta (into `delta`), per-workgroup partials of
  * delta . J^T J delta and delta . b (the return value says how many), prevX = X, X += delta.  L <= the residual reset period (gauss_newton.t:1653-1657).
- * thallo_hip_sfs_resident_rows_lm: rows per wave, 0 = does not fit (more registers per row: at most 6 rows per wave; Gauss-Newton: 12). */
+ * thallo_hip_sfs_resident_rows_lm: rows per wave, 0 = does not fit (more registers per row: at most 7 rows per wave; Gauss-Newton: 12). */
 int thallo_hip_sfs_resident_rows_lm(int W, int H);
 int thallo_hip_sfs_pcg_resident_lm(int W, int H, int yoff, const float* host_params, const float* G, const float* Fw,
                                    const float* r_in, const float* p_in, const float* pre, const float* CtC, float* delta,

@@ -1881,7 +1881,7 @@ def test_shape_from_shading_resident_pcg_loop_is_bitwise_the_marching_kernel(tor
         assert (np.abs(np.array(c0) - co) <= 2e-5 * np.abs(co) + 1e-9).all(), (c0, co)
 
 
-@pytest.mark.parametrize("W,H,radius,qtol", [(640, 480, 30.0, 0.05), (192, 130, 30.0, 0.05), (130, 67, 1e4, 1e-4), (126, 9, 30.0, 0.0), (250, 130, 3.0, 0.05), (2, 2, 1e4, 1e-4), (1024, 576, 30.0, 0.05)])
+@pytest.mark.parametrize("W,H,radius,qtol", [(640, 480, 30.0, 0.05), (192, 130, 30.0, 0.05), (130, 67, 1e4, 1e-4), (126, 9, 30.0, 0.0), (250, 130, 3.0, 0.05), (2, 2, 1e4, 1e-4), (1024, 576, 30.0, 0.05), (1024, 768, 30.0, 0.05)])
 def test_shape_from_shading_resident_lm_step_is_bitwise_the_launches(torch, orc, monkeypatch, W, H, radius, qtol):
     """Round 6: a Levenberg-Marquardt step's PCG loop (A = J^T J + CtC, z = M^-1 r, the six double sums, the zeta test after every iteration -- taken by every workgroup for
     itself from the same sums), the update of delta the loop owes, the model cost's J^T J delta and two dot products, savePreviousUnknowns and PCGLinearUpdate in ONE resident
@@ -1891,7 +1891,7 @@ def test_shape_from_shading_resident_lm_step_is_bitwise_the_launches(torch, orc,
     L = thallo_amd.lib()
     L.thallo_hip_sfs_resident_rows_lm.restype = C.c_int
     R = L.thallo_hip_sfs_resident_rows_lm(W, H)
-    assert 2 <= R <= 6 and ((W, H) != (1024, 576) or R == 6), R
+    assert 2 <= R <= 7 and ((W, H) != (1024, 576) or R == 6) and ((W, H) != (1024, 768) or R == 7), R
     p = syn.shape_from_shading(W, H)
     nit, lit = 8, 10
     runs = []

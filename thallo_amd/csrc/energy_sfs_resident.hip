@@ -27,7 +27,7 @@ using namespace thallo;
 namespace {
 
 constexpr int SR_NT = 256;                // 4 waves = 4 vertically adjacent segments of one strip (one workgroup per CU)
-constexpr int SR_MIN_R = 2, SR_MAX_R = 12, SR_MAX_R_LM = 6;       // (GN: 14 registers per held row and lane, LM: 18 + the own rows' CtC and b, beside the three rows of temporaries the rolling row step keeps: 13 / 7 rows per wave spill to scratch) // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
+constexpr int SR_MIN_R = 2, SR_MAX_R = 12, SR_MAX_R_LM = 7;       // (GN: 14 registers per held row and lane, LM: 18 + the own rows' CtC and b, beside the three rows of temporaries the rolling row step keeps: LM at 7 rows spills one register, 14 / 8 rows per wave tens) // rows per segment the kernel is instantiated for (two halo rows come from ONE neighbouring segment: R >= 2; 14 registers per held row and lane)
 
 typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -659,11 +659,11 @@ template <bool LM> int sr_launch(const SrArgs& a, int R, hipStream_t s)
 {
     switch (R) {
         case 2: return sr_launch_r<2, LM>(a, s); case 3: return sr_launch_r<3, LM>(a, s); case 4: return sr_launch_r<4, LM>(a, s); case 5: return sr_launch_r<5, LM>(a, s);
-        case 6: return sr_launch_r<6, LM>(a, s);
+        case 6: return sr_launch_r<6, LM>(a, s); case 7: return sr_launch_r<7, LM>(a, s);
         default: break;
     }
     if (!LM) switch (R) {
-        case 7: return sr_launch_r<7, false>(a, s); case 8: return sr_launch_r<8, false>(a, s); case 9: return sr_launch_r<9, false>(a, s); case 10: return sr_launch_r<10, false>(a, s);
+        case 8: return sr_launch_r<8, false>(a, s); case 9: return sr_launch_r<9, false>(a, s); case 10: return sr_launch_r<10, false>(a, s);
         case 11: return sr_launch_r<11, false>(a, s); case 12: return sr_launch_r<12, false>(a, s);
         default: break;
     }

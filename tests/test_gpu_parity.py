@@ -780,6 +780,34 @@ def test_shape_from_shading_reference_default_data(torch, orc, golden_dir):
     assert rel_err(costs, co) < COST_RTOL, (costs, co)
 
 
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_shape_from_shading_reference_default_data_lm(torch, orc, golden_dir, monkeypatch, resident):
+    """The same data (holes, the shipped lighting) through Levenberg-Marquardt, 6 x 10, a small initial trust region (rejected and accepted steps): the LM step's resident launch
+    (the default at this size) and one launch per PCG iteration both follow the oracle -- costs to 2e-4, equal PCG iteration counts, equal accept / reject decisions."""
+    d = np.load(os.path.join(golden_dir, "sfs_default_q4.npz"))
+    H, W = d["depth"].shape
+    p = [float(v) for v in d["scalars"]] + [d["initial"].copy(), d["depth"].copy(), d["intensity"].copy(), d["edge_r"].copy(), d["edge_c"].copy()]
+    kw = dict(nIterations=6, lIterations=10, trust_region_radius=100.0, q_tolerance=0.01)
+    co, _ = orc.Problem(orc.SFS, (W, H), copy_params(p)).solve(use_lm=1, **kw)
+    pcg_o = orc.last_pcg_counts()
+    monkeypatch.setenv("THALLO_RESIDENT", resident)
+    dev = to_device(copy_params(p))
+    s = api.ThalloSolver((W, H), thallo_amd.energy_file("shape_from_shading"), solverkind="levenberg_marquardt")
+    s.enable_lm(); s.set_kernel_sampling(1)
+    s.set_solver_parameters(**kw)
+    prm = s.make_params(dev); s.init(prm)
+    costs, iters = [s.current_cost()], []
+    while s.step(prm):
+        costs.append(s.current_cost()); iters.append(len(s.alpha_beta_trace()))
+    names = {k for k, v in s.kernel_stats().items() if v["launches"]}
+    s.close()
+    assert ("PCGLoopResident" in names) == (resident == "1"), names
+    m = min(len(co), len(costs))
+    assert m >= 3 and (np.abs(np.array(costs[:m]) - co[:m]) <= 2e-4 * np.abs(co[:m]) + 1e-9).all(), (costs, co)
+    assert iters[:m - 1] == list(pcg_o[:m - 1]), (iters, pcg_o)
+    assert [b < a for a, b in zip(costs[:m - 1], costs[1:m])] == [b < a for a, b in zip(co[:m - 1], co[1:m])], (costs, co)
+
+
 # ------------------------------------------------------------------ the benchmarked / configured sizes against the oracle
 def _host_threads():
     return max(1, min(64, os.cpu_count() or 1))
